@@ -1,0 +1,71 @@
+/* oracle/cfhd_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Scalar C restatement of the CineForm encode/decode hot path (pixel unpack -> 3-level 2/6
+ * wavelet -> per-subband quantizer -> run-length/VLC, and the inverse), written from the
+ * behaviour of the reference (file:line cited on every function in cfhd_oracle*.c).
+ *
+ * Parity status: PINNED.  tests/test_oracle_vs_ref.py checks every function here against the
+ * unmodified reference compiled into oracle/_ref/libcfhd_ref.so (seeded random planes and Qbist
+ * frames), and tests/golden/ holds fixtures produced by that reference (generator committed).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use anything in
+ * oracle/.  The product (cineform-sdk_amd/) never links, loads or calls it.
+ */
+#ifndef CFHD_ORACLE_H
+#define CFHD_ORACLE_H
+#include <stdint.h>
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int16_t PIXEL16;
+
+/* ---- forward path ---- */
+void orc_unpack_yuyv_row(const uint8_t *in, PIXEL16 *out, int width, int channel, int shift, int uyvy);
+void orc_fwd_horizontal(const PIXEL16 *x, int width, int prescale, PIXEL16 *low, PIXEL16 *high);
+void orc_quantize_row(const PIXEL16 *in, PIXEL16 *out, int length, int divisor, int midpoint_prequant);
+/* One 2-D level: in (height x width, pitch in pixels) -> 4 bands of (height/2 x width/2).
+ * bands[0]=LL (never quantized), [1]=LH (horizontal high), [2]=HL (vertical high), [3]=HH. */
+void orc_fwd_spatial(const PIXEL16 *in, int in_pitch, int width, int height, int prescale,
+                     const int quant[4], int midpoint_prequant,
+                     PIXEL16 *bands[4], int band_pitch);
+/* Level 1 straight from packed 8-bit 4:2:2 (YUY2, or 2vuy when uyvy!=0) for one channel
+ * (0=Y, 1=V, 2=U: reference channel order). width = channel width in samples. */
+void orc_fwd_spatial_yuv422(const uint8_t *in, int in_pitch_bytes, int width, int height,
+                            int channel, int shift, int uyvy,
+                            const int quant[4], int midpoint_prequant,
+                            PIXEL16 *bands[4], int band_pitch);
+
+/* ---- inverse path ---- */
+/* One 2-D inverse level: 4 bands (h x w) -> out (2h x 2w). descale!=0 selects the
+ * "Descale" variant used when the encoder prescaled that level by 2 bits. */
+void orc_inv_spatial(PIXEL16 *const bands[4], int band_pitch, int w, int h, int descale,
+                     PIXEL16 *out, int out_pitch);
+/* Last level for YUV 4:2:2 8-bit output: three channels' level-1 bands -> packed YUYV/UYVY rows.
+ * dither: 0 = add 0 before the >>2, 1 = add 1 (the reference adds rand()&1 per SIMD lane). */
+void orc_inv_spatial_to_yuv422(PIXEL16 *const bands[3][4], const int band_pitch[3], int luma_w, int h,
+                               int precision, int uyvy, int dither, uint8_t *out, int out_pitch);
+
+/* ---- quantizer tables (host side of the path) ---- */
+typedef struct {
+	int num_channels;
+	int prescale[8];            /* per wavelet index */
+	int quant[4][3][4];         /* [channel][wavelet index 0..2][band] */
+	int scale[4][3][4];
+	int midpoint_prequant;
+} orc_quant_t;
+/* encoded_format: 1 = YUV422, 3 = RGB444, 4 = RGBA4444, 2 = BAYER (reference ENCODED_FORMAT_*) */
+void orc_quant_tables(int quality, int precision, int chroma_full_res, int num_channels, int progressive, orc_quant_t *q);
+
+/* ---- entropy (codeset 17, cubic companding) ---- */
+/* Returns number of bytes written (whole 32-bit big-endian words, band end code included,
+ * padded to a 32-bit boundary as PadBitsTag does). */
+size_t orc_vlc_encode_band(const PIXEL16 *band, int width, int height, int pitch, uint8_t *out, size_t cap);
+/* Decodes until the band end code; output pre-zeroed by the callee; values are multiplied by quant. */
+int orc_vlc_decode_band(const uint8_t *in, size_t nbytes, int width, int height, int pitch, int quant, PIXEL16 *band);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

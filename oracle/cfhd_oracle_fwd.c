@@ -1,0 +1,182 @@
+/* oracle/cfhd_oracle_fwd.c -- TEST INFRASTRUCTURE ONLY (see cfhd_oracle.h).
+ *
+ * Forward path: pixel unpack, 2/6 biorthogonal analysis (horizontal then vertical), quantizer.
+ *
+ * Arithmetic model.  The reference's SSE2 bodies use saturating 16-bit adds in a fixed association
+ * order; its scalar tails/borders use 32-bit sums followed by SATURATE.  The two only differ when
+ * an intermediate leaves the int16 range, which no pixel unpacker can produce (inputs are <= 12
+ * bits; see DESIGN.md "value ranges").  We restate the SIMD association order with saturation for
+ * interior taps and the scalar form for the border taps, exactly where the reference uses them.
+ */
+#include "cfhd_oracle.h"
+#include <stdlib.h>
+#include <string.h>
+
+static inline int sat16(int x) { return x < -32768 ? -32768 : (x > 32767 ? 32767 : x); }
+static inline int adds(int a, int b) { return sat16(a + b); }
+static inline int subs(int a, int b) { return sat16(a - b); }
+
+/* Codec/convert.c:4667 UnpackRowYUV16s (default branch: value << shift; ch0=Y, ch1=V, ch2=U;
+ * :4796-4800 luma, :4876-4878 / :5060-5066 chroma).  uyvy selects COLOR_FORMAT_UYVY byte order. */
+void orc_unpack_yuyv_row(const uint8_t *in, PIXEL16 *out, int width, int channel, int shift, int uyvy)
+{
+	int i;
+	if (channel == 0) {
+		int off = uyvy ? 1 : 0;
+		for (i = 0; i < width; i++) out[i] = (PIXEL16)(in[2 * i + off] << shift);
+	} else {
+		/* YUYV: Y0 U Y1 V ; UYVY: U Y0 V Y1 */
+		int off = (channel == 2) ? (uyvy ? 0 : 1) : (uyvy ? 2 : 3);
+		for (i = 0; i < width; i++) out[i] = (PIXEL16)(in[4 * i + off] << shift);
+	}
+}
+
+/* Codec/spatial.c:253 FilterHorizontalRow16s (prescale 0) and :3669 FilterHorizontalRow10bit16s
+ * (prescale 2: every tap sees (x+3)>>2, the lowpass is (x0+x1+3)>>2, :3774-3776,:3960).
+ * Left border :277-286, right border :559-569, interior SIMD order :326-397. */
+void orc_fwd_horizontal(const PIXEL16 *x, int width, int prescale, PIXEL16 *low, PIXEL16 *high)
+{
+	int half = width / 2;
+	int k;
+#define P(i) (prescale ? ((x[i] + 3) >> 2) : x[i])
+	for (k = 0; k < half; k++) {
+		if (prescale) low[k] = (PIXEL16)sat16((x[2 * k] + x[2 * k + 1] + 3) >> 2);
+		else          low[k] = (PIXEL16)adds(x[2 * k], x[2 * k + 1]);
+	}
+	{
+		int sum = 5 * P(0) - 11 * P(1) + 4 * P(2) + 4 * P(3) - P(4) - P(5) + 4;
+		high[0] = (PIXEL16)sat16(sum >> 3);
+	}
+	for (k = 1; k < half - 1; k++) {
+		int c = 2 * k;
+		int sum = subs(0, P(c - 2));
+		sum = subs(sum, P(c - 1));
+		sum = adds(sum, P(c + 2));
+		sum = adds(sum, P(c + 3));
+		sum = adds(sum, 4);
+		sum >>= 3;
+		high[k] = (PIXEL16)adds(sum, subs(P(c), P(c + 1)));
+	}
+	{
+		int c = width - 2;
+		int sum = 11 * P(c) - 5 * P(c + 1) - 4 * P(c - 1) - 4 * P(c - 2) + P(c - 3) + P(c - 4) + 4;
+		high[half - 1] = (PIXEL16)sat16(sum >> 3);
+	}
+#undef P
+}
+
+/* Codec/quantize.c:1395 QuantizeRow16sTo16s: sign * (((|x| + mid) * floor(65536/div)) >> 16)
+ * with 16-bit wrap of (|x|+mid) and of the multiplier (_mm_set1_epi16), mid per :1415-1427. */
+void orc_quantize_row(const PIXEL16 *in, PIXEL16 *out, int length, int divisor, int midpoint_prequant)
+{
+	int i, mid = 0;
+	unsigned mult;
+	if (midpoint_prequant >= 2 && midpoint_prequant < 9) {
+		mid = divisor / midpoint_prequant;
+		if (midpoint_prequant == 2 && mid) mid--;
+	}
+	if (divisor <= 1) { memmove(out, in, (size_t)length * sizeof(PIXEL16)); return; }
+	mult = ((1u << 16) / (unsigned)divisor) & 0xffffu;
+	for (i = 0; i < length; i++) {
+		int v = in[i];
+		int neg = v < 0;
+		unsigned a = (unsigned)(neg ? -v : v) & 0xffffu;
+		unsigned q;
+		a = (a + (unsigned)mid) & 0xffffu;
+		q = (a * mult) >> 16;
+		out[i] = (PIXEL16)(neg ? -(int)q : (int)q);
+	}
+}
+
+/* Vertical analysis of six consecutive rows of horizontal results producing one output row.
+ * Codec/spatial.c:10026 FilterSpatialQuant16s / :12942 FilterSpatialV210Quant16s / :14726
+ * FilterSpatialYUVQuant16s share it: top :10178-10185 (14880-14915), middle SIMD order
+ * :10301-10351 (15065-15180), bottom :10539-10546 (15290-15330). */
+static void vertical_row(PIXEL16 *const rows[6], int n, int position /*0 top,1 middle,2 bottom*/,
+                         PIXEL16 *lowout, PIXEL16 *highout)
+{
+	int c;
+	for (c = 0; c < n; c++) {
+		int a0 = rows[0][c], a1 = rows[1][c], a2 = rows[2][c], a3 = rows[3][c], a4 = rows[4][c], a5 = rows[5][c];
+		if (position == 0) {
+			lowout[c] = (PIXEL16)sat16(a0 + a1);
+			highout[c] = (PIXEL16)sat16((5 * a0 - 11 * a1 + 4 * a2 + 4 * a3 - a4 - a5 + 4) >> 3);
+		} else if (position == 2) {
+			lowout[c] = (PIXEL16)sat16(a4 + a5);
+			highout[c] = (PIXEL16)sat16((11 * a4 - 5 * a5 - 4 * a3 - 4 * a2 + a1 + a0 + 4) >> 3);
+		} else {
+			int sum = subs(0, a0);
+			sum = subs(sum, a1);
+			sum = adds(sum, a4);
+			sum = adds(sum, a5);
+			sum = adds(sum, 4);
+			sum >>= 3;
+			lowout[c] = (PIXEL16)adds(a2, a3);
+			highout[c] = (PIXEL16)adds(sum, subs(adds(0, a2), a3));
+		}
+	}
+}
+
+typedef void (*row_source_fn)(void *ctx, int row, PIXEL16 *dst);
+
+static void fwd_spatial_generic(row_source_fn src, void *ctx, int width, int height, int prescale,
+                                const int quant[4], int mpq, PIXEL16 *bands[4], int band_pitch)
+{
+	int half = width / 2, hh = height / 2;
+	PIXEL16 *L = (PIXEL16 *)malloc((size_t)height * half * sizeof(PIXEL16));
+	PIXEL16 *H = (PIXEL16 *)malloc((size_t)height * half * sizeof(PIXEL16));
+	PIXEL16 *rowbuf = (PIXEL16 *)malloc((size_t)width * sizeof(PIXEL16));
+	PIXEL16 *t1 = (PIXEL16 *)malloc((size_t)half * sizeof(PIXEL16));
+	PIXEL16 *t2 = (PIXEL16 *)malloc((size_t)half * sizeof(PIXEL16));
+	int r;
+	for (r = 0; r < height; r++) {
+		src(ctx, r, rowbuf);
+		orc_fwd_horizontal(rowbuf, width, prescale, L + (size_t)r * half, H + (size_t)r * half);
+	}
+	for (r = 0; r < hh; r++) {
+		int pos = (r == 0) ? 0 : (r == hh - 1 ? 2 : 1);
+		int first = (r == 0) ? 0 : (r == hh - 1 ? height - 6 : 2 * r - 2);
+		PIXEL16 *lr[6], *hr[6];
+		int k;
+		for (k = 0; k < 6; k++) { lr[k] = L + (size_t)(first + k) * half; hr[k] = H + (size_t)(first + k) * half; }
+		/* LL and HL (vertical high of horizontal low) */
+		vertical_row(lr, half, pos, bands[0] + (size_t)r * band_pitch, t1);
+		orc_quantize_row(t1, bands[2] + (size_t)r * band_pitch, half, quant[2], mpq);
+		/* LH (vertical low of horizontal high) and HH */
+		vertical_row(hr, half, pos, t2, t1);
+		orc_quantize_row(t2, bands[1] + (size_t)r * band_pitch, half, quant[1], mpq);
+		orc_quantize_row(t1, bands[3] + (size_t)r * band_pitch, half, quant[3], mpq);
+	}
+	free(L); free(H); free(rowbuf); free(t1); free(t2);
+}
+
+struct plane_src { const PIXEL16 *in; int pitch; int width; };
+static void plane_row(void *ctx, int row, PIXEL16 *dst)
+{
+	struct plane_src *s = (struct plane_src *)ctx;
+	memcpy(dst, s->in + (size_t)row * s->pitch, (size_t)s->width * sizeof(PIXEL16));
+}
+
+void orc_fwd_spatial(const PIXEL16 *in, int in_pitch, int width, int height, int prescale,
+                     const int quant[4], int midpoint_prequant, PIXEL16 *bands[4], int band_pitch)
+{
+	struct plane_src s = { in, in_pitch, width };
+	fwd_spatial_generic(plane_row, &s, width, height, prescale, quant, midpoint_prequant, bands, band_pitch);
+}
+
+struct yuv_src { const uint8_t *in; int pitch; int width; int channel; int shift; int uyvy; };
+static void yuv_row(void *ctx, int row, PIXEL16 *dst)
+{
+	struct yuv_src *s = (struct yuv_src *)ctx;
+	orc_unpack_yuyv_row(s->in + (size_t)row * s->pitch, dst, s->width, s->channel, s->shift, s->uyvy);
+}
+
+/* Codec/wavelet.c:2823 TransformForwardSpatialYUV -> spatial.c:14726 FilterSpatialYUVQuant16s
+ * (FilterHorizontalRowYUV16s :4005 = UnpackRowYUV16s + FilterHorizontalRow16s). */
+void orc_fwd_spatial_yuv422(const uint8_t *in, int in_pitch_bytes, int width, int height,
+                            int channel, int shift, int uyvy, const int quant[4], int midpoint_prequant,
+                            PIXEL16 *bands[4], int band_pitch)
+{
+	struct yuv_src s = { in, in_pitch_bytes, width, channel, shift, uyvy };
+	fwd_spatial_generic(yuv_row, &s, width, height, 0, quant, midpoint_prequant, bands, band_pitch);
+}

@@ -1,0 +1,157 @@
+/* oracle/cfhd_oracle_inv.c -- TEST INFRASTRUCTURE ONLY (see cfhd_oracle.h).
+ *
+ * Inverse path: 2/6 biorthogonal synthesis (vertical then horizontal), the "descale" variant that
+ * undoes the encoder's 2-bit prescale, and the last level fused with 8-bit 4:2:2 packing.
+ */
+#include "cfhd_oracle.h"
+#include <stdlib.h>
+#include <string.h>
+
+static inline int sat16(int x) { return x < -32768 ? -32768 : (x > 32767 ? 32767 : x); }
+static inline int adds(int a, int b) { return sat16(a + b); }
+static inline int subs(int a, int b) { return sat16(a - b); }
+
+/* Vertical synthesis of one coefficient row r into an even and an odd output row.
+ * Codec/spatial.c:21877 InvertSpatialQuant16s: top border :21975-22030 (11,-4,1)/(5,4,-1),
+ * middle SIMD order :22080-22150, bottom border :22330-22400 (5,4,-1)/(11,-4,1) mirrored.
+ * low = vertical-lowpass band (LL or LH), high = vertical-highpass band (HL or HH). */
+static void inv_vertical_row(const PIXEL16 *low, int low_pitch, const PIXEL16 *high_row, int r, int h, int w,
+                             PIXEL16 *even_out, PIXEL16 *odd_out)
+{
+	int c;
+	for (c = 0; c < w; c++) {
+		int hi = high_row[c];
+		int even, odd;
+		if (r == 0) {
+			int l0 = low[c], l1 = low[low_pitch + c], l2 = low[2 * low_pitch + c];
+			even = (((11 * l0 - 4 * l1 + l2 + 4) >> 3) + hi) >> 1;
+			odd  = (((5 * l0 + 4 * l1 - l2 + 4) >> 3) - hi) >> 1;
+			even = sat16(even); odd = sat16(odd);
+		} else if (r == h - 1) {
+			int l0 = low[(size_t)r * low_pitch + c], l1 = low[(size_t)(r - 1) * low_pitch + c], l2 = low[(size_t)(r - 2) * low_pitch + c];
+			even = (((5 * l0 + 4 * l1 - l2 + 4) >> 3) + hi) >> 1;
+			odd  = (((11 * l0 - 4 * l1 + l2 + 4) >> 3) - hi) >> 1;
+			even = sat16(even); odd = sat16(odd);
+		} else {
+			int a = low[(size_t)(r - 1) * low_pitch + c], b = low[(size_t)r * low_pitch + c], d = low[(size_t)(r + 1) * low_pitch + c];
+			even = subs(a, d); even = adds(even, 4); even >>= 3; even = adds(even, b); even = adds(even, hi); even >>= 1;
+			odd = subs(0, a); odd = adds(odd, d); odd = adds(odd, 4); odd >>= 3; odd = adds(odd, b); odd = subs(odd, hi); odd >>= 1;
+		}
+		even_out[c] = (PIXEL16)even;
+		odd_out[c] = (PIXEL16)odd;
+	}
+}
+
+/* Horizontal synthesis of one row: w lowpass + w highpass -> 2w outputs.
+ * Codec/InvertHorizontalStrip16s.c:459 InvertHorizontalStrip16s (borders :172-198, :409-438, interior
+ * :371-402) and :1700 InvertHorizontalStripDescale16s (no final >>1, result doubled with saturation:
+ * _mm_adds_epi16(out,out) :1934-1935, scalar "<<= descaleshift" :2067-2068). */
+static void inv_horizontal_row(const PIXEL16 *low, const PIXEL16 *high, int w, int descale, PIXEL16 *out)
+{
+	int c;
+	for (c = 0; c < w; c++) {
+		int even, odd, hi = high[c];
+		if (c == 0) {
+			even = ((11 * low[0] - 4 * low[1] + low[2] + 4) >> 3) + hi;
+			odd  = ((5 * low[0] + 4 * low[1] - low[2] + 4) >> 3) - hi;
+		} else if (c == w - 1) {
+			even = ((5 * low[c] + 4 * low[c - 1] - low[c - 2] + 4) >> 3) + hi;
+			odd  = ((11 * low[c] - 4 * low[c - 1] + low[c - 2] + 4) >> 3) - hi;
+		} else {
+			even = subs(low[c - 1], low[c + 1]); even = adds(even, 4); even >>= 3; even = adds(even, low[c]); even = adds(even, hi);
+			odd  = subs(low[c + 1], low[c - 1]); odd = adds(odd, 4); odd >>= 3; odd = adds(odd, low[c]); odd = subs(odd, hi);
+		}
+		if (descale) { even = sat16(even * 2); odd = sat16(odd * 2); }
+		else { even >>= 1; odd >>= 1; }
+		out[2 * c] = (PIXEL16)sat16(even);
+		out[2 * c + 1] = (PIXEL16)sat16(odd);
+	}
+}
+
+/* Codec/wavelet.c:5685 TransformInverseSpatialQuantLowpass -> spatial.c:21877 / :22414. */
+void orc_inv_spatial(PIXEL16 *const bands[4], int band_pitch, int w, int h, int descale, PIXEL16 *out, int out_pitch)
+{
+	PIXEL16 *el = (PIXEL16 *)malloc((size_t)w * 2), *ol = (PIXEL16 *)malloc((size_t)w * 2);
+	PIXEL16 *eh = (PIXEL16 *)malloc((size_t)w * 2), *oh = (PIXEL16 *)malloc((size_t)w * 2);
+	int r;
+	for (r = 0; r < h; r++) {
+		/* horizontal-lowpass rows from (LL, HL); horizontal-highpass rows from (LH, HH) */
+		inv_vertical_row(bands[0], band_pitch, bands[2] + (size_t)r * band_pitch, r, h, w, el, ol);
+		inv_vertical_row(bands[1], band_pitch, bands[3] + (size_t)r * band_pitch, r, h, w, eh, oh);
+		inv_horizontal_row(el, eh, w, descale, out + (size_t)(2 * r) * out_pitch);
+		inv_horizontal_row(ol, oh, w, descale, out + (size_t)(2 * r + 1) * out_pitch);
+	}
+	free(el); free(ol); free(eh); free(oh);
+}
+
+/* One reconstructed 4:2:2 sample before the 10->8 bit reduction:
+ * v = lowfilter +/- high (before the >>1), clamped at zero as the SIMD body does with the
+ * +2048 / subs_epu16 pair (InvertHorizontalStrip16s.c:4086-4089); then (v>>1 + dither) >> shift,
+ * clamped to 8 bits (packus :4620 / SATURATE_8U :4880).  dither is rand()&mask per SIMD lane in the
+ * reference (:3869-3893); the oracle takes it as an explicit 0/1 input so both extremes can be checked. */
+static inline int to8(int v, int shift, int dither)
+{
+	int x;
+	if (v < 0) v = 0;
+	x = ((v >> 1) + dither) >> shift;
+	return x < 0 ? 0 : (x > 255 ? 255 : x);
+}
+
+static void inv_horizontal_row_prepack(const PIXEL16 *low, const PIXEL16 *high, int w, int *out /* 2w values, before >>1 */)
+{
+	int c;
+	for (c = 0; c < w; c++) {
+		int even, odd, hi = high[c];
+		if (c == 0) {
+			even = ((11 * low[0] - 4 * low[1] + low[2] + 4) >> 3) + hi;
+			odd  = ((5 * low[0] + 4 * low[1] - low[2] + 4) >> 3) - hi;
+		} else if (c == w - 1) {
+			even = ((5 * low[c] + 4 * low[c - 1] - low[c - 2] + 4) >> 3) + hi;
+			odd  = ((11 * low[c] - 4 * low[c - 1] + low[c - 2] + 4) >> 3) - hi;
+		} else {
+			even = subs(low[c - 1], low[c + 1]); even = adds(even, 4); even >>= 3; even = adds(even, low[c]); even += hi;
+			odd  = subs(low[c + 1], low[c - 1]); odd = adds(odd, 4); odd >>= 3; odd = adds(odd, low[c]); odd -= hi;
+		}
+		out[2 * c] = even; out[2 * c + 1] = odd;
+	}
+}
+
+/* Codec/decoder.c:27323 TransformInverseSpatialSectionToOutput -> spatial.c:31341/31511/31975
+ * InvertSpatial{Top,Middle,Bottom}Row16sToOutput -> InvertHorizontalStrip16s.c:3770
+ * InvertHorizontalStrip16sToYUYV (:5025 ToUYVY).  Channel order Y,V,U (:3785-3791). */
+void orc_inv_spatial_to_yuv422(PIXEL16 *const bands[3][4], const int band_pitch[3], int luma_w, int h,
+                               int precision, int uyvy, int dither, uint8_t *out, int out_pitch)
+{
+	int shift = precision - 8;
+	int ch, r, k;
+	PIXEL16 *el[3], *ol[3], *eh[3], *oh[3];
+	int *even_px[3], *odd_px[3];
+	for (ch = 0; ch < 3; ch++) {
+		int w = ch ? luma_w / 2 : luma_w;
+		el[ch] = (PIXEL16 *)malloc((size_t)w * 2); ol[ch] = (PIXEL16 *)malloc((size_t)w * 2);
+		eh[ch] = (PIXEL16 *)malloc((size_t)w * 2); oh[ch] = (PIXEL16 *)malloc((size_t)w * 2);
+		even_px[ch] = (int *)malloc((size_t)w * 2 * sizeof(int)); odd_px[ch] = (int *)malloc((size_t)w * 2 * sizeof(int));
+	}
+	for (r = 0; r < h; r++) {
+		for (ch = 0; ch < 3; ch++) {
+			int w = ch ? luma_w / 2 : luma_w;
+			int bp = band_pitch[ch];
+			inv_vertical_row(bands[ch][0], bp, bands[ch][2] + (size_t)r * bp, r, h, w, el[ch], ol[ch]);
+			inv_vertical_row(bands[ch][1], bp, bands[ch][3] + (size_t)r * bp, r, h, w, eh[ch], oh[ch]);
+			inv_horizontal_row_prepack(el[ch], eh[ch], w, even_px[ch]);
+			inv_horizontal_row_prepack(ol[ch], oh[ch], w, odd_px[ch]);
+		}
+		for (k = 0; k < 2; k++) {
+			uint8_t *o = out + (size_t)(2 * r + k) * out_pitch;
+			int *const *px = k ? odd_px : even_px;
+			int x;
+			for (x = 0; x < luma_w; x++) {           /* luma_w = band width; 2*luma_w output luma samples */
+				int y0 = to8(px[0][2 * x], shift, dither), y1 = to8(px[0][2 * x + 1], shift, dither);
+				int u = to8(px[2][x], shift, dither), v = to8(px[1][x], shift, dither);
+				if (uyvy) { o[4 * x] = (uint8_t)u; o[4 * x + 1] = (uint8_t)y0; o[4 * x + 2] = (uint8_t)v; o[4 * x + 3] = (uint8_t)y1; }
+				else      { o[4 * x] = (uint8_t)y0; o[4 * x + 1] = (uint8_t)u; o[4 * x + 2] = (uint8_t)y1; o[4 * x + 3] = (uint8_t)v; }
+			}
+		}
+	}
+	for (ch = 0; ch < 3; ch++) { free(el[ch]); free(ol[ch]); free(eh[ch]); free(oh[ch]); free(even_px[ch]); free(odd_px[ch]); }
+}

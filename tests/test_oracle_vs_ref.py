@@ -1,0 +1,74 @@
+"""Pin the oracle (oracle/*.c, our scalar restatement) against the unmodified reference
+(oracle/_ref/libcfhd_ref.so, SSE2 build) on seeded random planes: bit-exact for every integer stage."""
+import ctypes
+import numpy as np
+import pytest
+from cfhd_testlib import *
+
+pytestmark = [pytest.mark.ref, pytest.mark.skipif(not have_ref(), reason="reference .so not built")]
+
+SIZES = [(64, 16), (128, 24), (240, 34), (248, 18), (480, 270), (1920, 64)]
+
+
+def rand_plane(rng, w, h, bits, signed=False):
+    lo = -(1 << (bits - 1)) if signed else 0
+    hi = (1 << (bits - 1)) - 1 if signed else (1 << bits) - 1
+    return rng.integers(lo, hi + 1, size=(h, w), dtype=np.int64).astype(np.int16)
+
+
+@pytest.mark.parametrize("divisor", [1, 2, 3, 6, 12, 24, 36, 48, 96, 144, 255])
+@pytest.mark.parametrize("mpq", [0, 2, 3, 5, 8])
+def test_quantize_row(divisor, mpq):
+    rng = np.random.default_rng(divisor * 31 + mpq)
+    x = rng.integers(-32767, 32768, size=1003).astype(np.int16)
+    x[:16] = [0, 1, -1, 2, -2, divisor, -divisor, divisor - 1, 1 - divisor, 32767, -32767, 1023, -1023, 4095, -4095, 7]
+    a = np.zeros_like(x); b = np.zeros_like(x)
+    oracle().orc_quantize_row(p16(x), p16(a), len(x), divisor, mpq)
+    ref().ref_quantize_row(p16(x), p16(b), len(x), divisor, mpq)
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("w,h", SIZES)
+@pytest.mark.parametrize("prescale,bits", [(0, 10), (0, 12), (2, 12), (2, 14)])
+def test_forward_level_16s(w, h, prescale, bits):
+    rng = np.random.default_rng(w * 7 + h + prescale)
+    x = rand_plane(rng, w, h, bits)
+    quant = [1, 24, 24, 36] if prescale == 0 else [1, 6, 6, 3]
+    outs_o = [np.zeros((h // 2, w // 2), np.int16) for _ in range(4)]
+    outs_r = [np.zeros((h // 2, w // 2), np.int16) for _ in range(4)]
+    bands = (c_i16p * 4)(*[p16(o) for o in outs_o])
+    oracle().orc_fwd_spatial(p16(x), w, w, h, prescale, iarr(quant), 2, bands, w // 2)
+    ref().ref_fwd_spatial(p16(x), w, h, prescale, iarr(quant), 2, *[p16(o) for o in outs_r])
+    for k in range(4):
+        assert np.array_equal(outs_o[k], outs_r[k]), "band %d" % k
+
+
+@pytest.mark.parametrize("w,h", [(64, 16), (128, 24), (720, 48), (1920, 32)])
+@pytest.mark.parametrize("uyvy", [0, 1])
+def test_forward_level1_yuv422(w, h, uyvy):
+    rng = np.random.default_rng(w + h + uyvy)
+    frame = rng.integers(0, 256, size=(h, w * 2), dtype=np.int64).astype(np.uint8)
+    quant = [1, 24, 24, 36]
+    for ch in range(3):
+        cw = w if ch == 0 else w // 2
+        outs_o = [np.zeros((h // 2, cw // 2), np.int16) for _ in range(4)]
+        outs_r = [np.zeros((h // 2, cw // 2), np.int16) for _ in range(4)]
+        bands = (c_i16p * 4)(*[p16(o) for o in outs_o])
+        oracle().orc_fwd_spatial_yuv422(p8(frame), w * 2, cw, h, ch, 2, uyvy, iarr(quant), 2, bands, cw // 2)
+        ref().ref_fwd_spatial_yuv(p8(frame), w * 2, cw, h, ch, COLOR_FORMAT_UYVY if uyvy else COLOR_FORMAT_YUYV, 10,
+                                  iarr(quant), 2, *[p16(o) for o in outs_r])
+        for k in range(4):
+            assert np.array_equal(outs_o[k], outs_r[k]), "channel %d band %d" % (ch, k)
+
+
+@pytest.mark.parametrize("w,h", [(32, 8), (120, 135), (240, 135), (480, 270), (960, 20)])
+@pytest.mark.parametrize("descale", [0, 2])
+def test_inverse_level_16s(w, h, descale):
+    rng = np.random.default_rng(w * 3 + h + descale)
+    ll = rand_plane(rng, w, h, 13)
+    hi = [rand_plane(rng, w, h, 11, signed=True) for _ in range(3)]
+    out_o = np.zeros((2 * h, 2 * w), np.int16); out_r = np.zeros_like(out_o)
+    bands = (c_i16p * 4)(p16(ll), p16(hi[0]), p16(hi[1]), p16(hi[2]))
+    oracle().orc_inv_spatial(bands, w, w, h, descale, p16(out_o), 2 * w)
+    ref().ref_inv_spatial(p16(ll), p16(hi[0]), p16(hi[1]), p16(hi[2]), w, h, descale, p16(out_r))
+    assert np.array_equal(out_o, out_r)
