@@ -1,0 +1,96 @@
+// cfhd_bitstream.h -- CineForm sample syntax: writer (encoder side) and parser (decoder side).
+#pragma once
+#include "cfhd_core.h"
+#include <vector>
+
+namespace cfhd {
+
+// Tags of the tag/value syntax (16-bit tag, 16-bit value, big endian; a negated tag is optional).
+// Numbering follows Codec/codec.h:201-416.
+enum Tag : int {
+	TAG_SAMPLE = 1, TAG_INDEX = 2, TAG_ENTRY = 3, TAG_MARKER = 4,
+	TAG_TRANSFORM_TYPE = 10, TAG_NUM_FRAMES = 11, TAG_NUM_CHANNELS = 12, TAG_NUM_WAVELETS = 13, TAG_NUM_SUBBANDS = 14,
+	TAG_NUM_SPATIAL = 15, TAG_FIRST_WAVELET = 16, TAG_GROUP_TRAILER = 18,
+	TAG_FRAME_TYPE = 19, TAG_FRAME_WIDTH = 20, TAG_FRAME_HEIGHT = 21, TAG_FRAME_FORMAT = 22, TAG_FRAME_INDEX = 23, TAG_FRAME_TRAILER = 24,
+	TAG_LOWPASS_SUBBAND = 25, TAG_NUM_LEVELS = 26, TAG_LOWPASS_WIDTH = 27, TAG_LOWPASS_HEIGHT = 28,
+	TAG_MARGIN_TOP = 29, TAG_MARGIN_BOTTOM = 30, TAG_MARGIN_LEFT = 31, TAG_MARGIN_RIGHT = 32,
+	TAG_PIXEL_OFFSET = 33, TAG_QUANTIZATION = 34, TAG_PIXEL_DEPTH = 35,
+	TAG_WAVELET_TYPE = 37, TAG_WAVELET_NUMBER = 38, TAG_WAVELET_LEVEL = 39, TAG_NUM_BANDS = 40,
+	TAG_HIGHPASS_WIDTH = 41, TAG_HIGHPASS_HEIGHT = 42, TAG_LOWPASS_BORDER = 43, TAG_HIGHPASS_BORDER = 44,
+	TAG_LOWPASS_SCALE = 45, TAG_LOWPASS_DIVISOR = 46,
+	TAG_BAND_NUMBER = 48, TAG_BAND_WIDTH = 49, TAG_BAND_HEIGHT = 50, TAG_BAND_SUBBAND = 51, TAG_BAND_ENCODING = 52,
+	TAG_BAND_QUANTIZATION = 53, TAG_BAND_SCALE = 54, TAG_BAND_HEADER = 55, TAG_BAND_TRAILER = 56,
+	TAG_CHANNEL = 62, TAG_INTERLACED_FLAGS = 63, TAG_PROTECTION_FLAGS = 64, TAG_PICTURE_ASPECT_X = 65, TAG_PICTURE_ASPECT_Y = 66,
+	TAG_SAMPLE_FLAGS = 68, TAG_FRAME_NUMBER = 69, TAG_PRECISION = 70, TAG_INPUT_FORMAT = 71, TAG_BAND_CODING_FLAGS = 72,
+	TAG_VERSION = 79, TAG_QUALITY_L = 80, TAG_QUALITY_H = 81, TAG_BAND_SECONDPASS = 82, TAG_PRESCALE_TABLE = 83,
+	TAG_ENCODED_FORMAT = 84, TAG_FRAME_DISPLAY_HEIGHT = 85, TAG_ENCODED_COLORSPACE = 91,
+	TAG_SUBBAND_SIZE = 0x2000, TAG_LEVEL_SIZE = 0x2100, TAG_SAMPLE_SIZE = 0x2200,
+	TAG_METADATA = 0x4002,
+};
+enum { SAMPLE_TYPE_CHANNEL = 3, SAMPLE_TYPE_IFRAME = 9 };
+enum { MARK_LOWPASS_START = 0x1A4A, MARK_LOWPASS_END = 0x1B4B, MARK_COEFF_START = 0x0F0F,
+       MARK_HIGHPASS_START = 0x0D0D, MARK_HIGHPASS_END = 0x0C0C, MARK_BAND_START = 0x0E0E };
+
+// MSB-first bit writer into 32-bit big-endian words (Codec/bitstream.c:819 PutBits semantics).
+class BitWriter {
+public:
+	BitWriter(uint8_t *buf, size_t cap) : p_(buf), cap_(cap) {}
+	size_t bytes() const { return n_; }                // whole words emitted so far
+	bool overflow() const { return overflow_; }
+	void put_bits(uint32_t bits, int nbits);
+	void pad32();                                       // PadBits32 + flush
+	void put_long(uint32_t w);                          // requires 32-bit alignment
+	void put_tag(int tag, int value) { put_long(((uint32_t)(uint16_t)tag << 16) | (uint32_t)(value & 0xffff)); }
+	void put_tag_opt(int tag, int value) { put_tag(-tag, value); }
+	void put_bytes(const void *src, size_t n);          // requires alignment; n multiple of 4
+	void size_push(int tag);                            // SizeTagPush (bitstream.c:2206)
+	void size_pop();                                    // SizeTagPop  (bitstream.c:2220)
+	uint8_t *cursor() { return p_ + n_; }
+	void patch32(size_t offset, uint32_t value_be);
+private:
+	void emit(uint32_t w);
+	uint8_t *p_; size_t cap_; size_t n_ = 0;
+	uint32_t acc_ = 0; int free_ = 32; bool overflow_ = false;
+	size_t stack_[8]; int depth_ = 0;
+};
+
+struct SampleHeaderInfo {
+	uint32_t frame_number;
+	int input_format;        // reference COLOR_FORMAT_* of the submitted frame
+	int color_space;         // reference COLOR_SPACE_* flags
+	int encoder_quality;     // 32-bit quality word as passed to the codec
+	bool progressive;
+	const uint8_t *meta_global; size_t meta_global_size;
+	const uint8_t *meta_local; size_t meta_local_size;
+};
+
+// Payload provider for one highpass band: either host-side VLC from coefficients, or bytes already
+// packed on the GPU.  Must append whole 32-bit words (band end code included, zero padded).
+struct BandSource {
+	const int16_t *coeffs = nullptr;     // frame coefficient buffer (FramePlan layout) for host VLC
+	const uint8_t *const *packed = nullptr;  // [channel*9 + k] -> GPU packed payload (k = coding order index 0..8)
+	const uint32_t *packed_bytes = nullptr;
+};
+
+// Writes a complete intra-frame sample.  Returns the sample size in bytes, or 0 on overflow.
+size_t write_sample(const FramePlan &plan, const SampleHeaderInfo &hdr, const BandSource &src, uint8_t *out, size_t cap);
+
+// Host VLC of one band (the reference's EncodeQuantLongRuns + band end code + pad), appended to w.
+void vlc_encode_band(BitWriter &w, const int16_t *band, int width, int height, int pitch, int codebook);
+
+// ---- parser ----
+struct ParsedBand { uint32_t offset, bytes; int width, height, quant, codebook, subband; bool present; };
+struct ParsedSample {
+	int width = 0, height = 0, display_height = 0, num_channels = 0, precision = 0, encoded_format = 0;
+	int input_format = 0, color_space = 0, quality = 0, prescale_table = 0, frame_number = 0, progressive = 1, version = 0;
+	int transform_type = 0, num_spatial = 0, num_wavelets = 0;
+	ParsedBand lowpass[kMaxChannels];                     // raw 16-bit big-endian pairs
+	ParsedBand high[kMaxChannels][kNumLevels][kNumBands]; // [ch][wavelet index][band 1..3]
+	uint32_t metadata_offset = 0, metadata_bytes = 0;     // first metadata chunk
+};
+// Returns 0 on success, <0 on malformed input.
+int parse_sample(const uint8_t *data, size_t size, ParsedSample *out);
+// Host VLC decode of one band into a zeroed band. Returns 0 on success.
+int vlc_decode_band(const uint8_t *data, size_t bytes, int width, int height, int pitch, int quant, int codebook, int16_t *band);
+
+} // namespace cfhd

@@ -1,0 +1,93 @@
+// cfhd_core.h -- shared host/device definitions of the MI355X CineForm core.
+//
+// Geometry ("FramePlan") of one frame's coefficient pyramid in HBM, the quantizer tables and the
+// entropy-code tables.  Everything here is plain data that host code computes once per
+// encoder/decoder and hands to the HIP kernels by value or through constant buffers.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#if defined(__HIPCC__) || defined(CFHD_HIPEMU)
+#define CFHD_HD __host__ __device__
+#else
+#define CFHD_HD
+#endif
+
+namespace cfhd {
+
+enum { kMaxChannels = 4, kNumLevels = 3, kNumBands = 4 };
+
+// Internal pixel formats handled by the unpack (encode) / pack (decode) kernels.
+enum PixelKind : int {
+	PIX_NONE = 0,
+	PIX_YUY2,      // 8-bit 4:2:2  Y0 U Y1 V   (reference COLOR_FORMAT_YUYV = 2)
+	PIX_2VUY,      // 8-bit 4:2:2  U Y0 V Y1   (reference COLOR_FORMAT_UYVY = 1)
+	PIX_RG48,      // 16-bit RGB 4:4:4          (COLOR_FORMAT_RGB48 = 120)
+	PIX_B64A,      // 16-bit ARGB 4:4:4:4       (COLOR_FORMAT_BGRA64 = 30)
+	PIX_BYR4,      // 16-bit Bayer              (COLOR_FORMAT_BYR4 = 104)
+};
+
+// ENCODED_FORMAT_* values as written into the bitstream (Codec/codec.h)
+enum EncodedFormat : int { ENC_YUV422 = 1, ENC_BAYER = 2, ENC_RGB444 = 3, ENC_RGBA4444 = 4 };
+
+struct BandDesc {
+	int width, height;     // coefficients
+	int pitch;             // row stride in int16 elements (width rounded up to 8: Codec/wavelet.c:439-442)
+	uint32_t offset;       // element offset inside the frame's coefficient buffer
+	int quant;             // divisor applied by the encoder (1 for every LL)
+	int scale;             // informational scale written into the band header
+};
+
+struct ChannelPlan {
+	int width, height;                       // channel plane at full resolution
+	BandDesc band[kNumLevels][kNumBands];    // [wavelet index 0..2 = level 1..3][LL,LH,HL,HH]
+};
+
+struct FramePlan {
+	int width, height;           // encoded dimensions (height rounded up to a multiple of 8)
+	int display_height;
+	int num_channels;
+	int precision;               // 10 or 12 bits
+	int encoded_format;          // EncodedFormat
+	int pixel_kind;              // PixelKind of the packed frame
+	int prescale[kNumLevels];    // per wavelet index (Codec/wavelet.c:1710)
+	int midpoint_prequant;       // Codec/quantize.c:183,211-213
+	ChannelPlan ch[kMaxChannels];
+	uint32_t coeff_elems;        // int16 elements of the whole pyramid (all channels)
+	uint32_t final_elems;        // leading part that holds the bands that get entropy coded
+};
+
+// ---- entropy tables (code set 17 = codebook 1, cubic companding; code set 18 = codebook 2, linear) ----
+struct RunCode { uint32_t bits; uint8_t size; uint16_t count; };
+struct EntropyTables {
+	uint32_t value_code[2048];     // size<<27 | codeword, indexed by 11-bit two's complement value (Codec/vlc.h:71-74)
+	uint32_t run_bits[3072];       // composite zero-run codewords (Codec/codebooks.c:499-582)
+	uint8_t  run_size[3072];
+	uint16_t run_count[3072];      // zeros actually covered by the composite code
+	uint32_t band_end_bits;
+	int      band_end_size;
+	// decoder: direct lookup on the next kDecBits bits of the stream
+	enum { kDecBits = 12 };
+	// entry: bits 0..4 = code length (0 => longer than kDecBits, take the slow path),
+	//        bits 5..15 = zero run (0 for a magnitude), bits 16..31 = expanded magnitude (0 for runs / zero)
+	uint32_t dec_lut[1 << kDecBits];
+	uint16_t mag_expand[256];      // magnitude after undoing the companding curve
+};
+
+const EntropyTables *entropy_tables(int codebook /*1 = cs17 cubic, 2 = cs18 linear*/);
+
+// ---- quantizer ----
+struct QuantState {            // mirrors the reference's cross-frame quantizer state (Codec/quantize.h QUANTIZER)
+	int overbitrate;
+	int FSratelimiter;
+	int64_t lastgopbitcount;
+};
+// Fills plan->prescale, midpoint_prequant and every band's quant/scale.
+void derive_quantization(FramePlan *plan, int quality, bool progressive, float framerate, QuantState *state);
+
+// Builds the pyramid geometry for the given encoded dimensions.
+bool build_frame_plan(FramePlan *plan, int width, int height, int pixel_kind, int encoded_format);
+
+static inline int align_up(int x, int a) { return (x + a - 1) / a * a; }
+
+} // namespace cfhd

@@ -1,0 +1,82 @@
+// cfhd_hooks.cpp -- host-only entry points (prefix cfhd_amd_) used by the CPU-side tests to exercise the
+// product's own syntax layer (plan geometry, quantizer derivation, sample writer/parser, host VLC)
+// without a GPU.  They are not part of the CFHD_* drop-in ABI and never touch the device.
+#include "cfhd_core.h"
+#include "cfhd_bitstream.h"
+#include <string.h>
+#include <vector>
+
+using namespace cfhd;
+
+extern "C" {
+
+// out[0]=coeff_elems, [1]=final_elems, [2]=num_channels, [3]=precision, [4]=midpoint_prequant, [5..7]=prescale,
+// then per channel, per level, per band: width,height,pitch,offset,quant,scale (6 ints).
+int cfhd_amd_plan_info(int width, int height, int pixel_kind, int encoded_format, int quality, int progressive, int *out)
+{
+	FramePlan plan;
+	if (!build_frame_plan(&plan, width, height, pixel_kind, encoded_format)) return -1;
+	QuantState st = {0, -1, 0};
+	derive_quantization(&plan, quality, progressive != 0, 0.0f, &st);
+	int n = 0;
+	out[n++] = (int)plan.coeff_elems; out[n++] = (int)plan.final_elems; out[n++] = plan.num_channels; out[n++] = plan.precision;
+	out[n++] = plan.midpoint_prequant; out[n++] = plan.prescale[0]; out[n++] = plan.prescale[1]; out[n++] = plan.prescale[2];
+	for (int c = 0; c < plan.num_channels; c++)
+		for (int lv = 0; lv < kNumLevels; lv++)
+			for (int b = 0; b < kNumBands; b++) {
+				const BandDesc &d = plan.ch[c].band[lv][b];
+				out[n++] = d.width; out[n++] = d.height; out[n++] = d.pitch; out[n++] = (int)d.offset; out[n++] = d.quant; out[n++] = d.scale;
+			}
+	return n;
+}
+
+// Assemble a sample on the host from a coefficient pyramid laid out per the plan (host VLC).
+size_t cfhd_amd_write_sample_host(int width, int height, int pixel_kind, int encoded_format, int quality, int progressive,
+                                  int input_format, int color_space, unsigned frame_number,
+                                  const int16_t *coeffs, const uint8_t *meta_global, size_t meta_global_size,
+                                  const uint8_t *meta_local, size_t meta_local_size, uint8_t *out, size_t cap)
+{
+	FramePlan plan;
+	if (!build_frame_plan(&plan, width, height, pixel_kind, encoded_format)) return 0;
+	QuantState st = {0, -1, 0};
+	derive_quantization(&plan, quality, progressive != 0, 0.0f, &st);
+	SampleHeaderInfo hdr = { frame_number, input_format, color_space, quality, progressive != 0, meta_global, meta_global_size, meta_local, meta_local_size };
+	BandSource src; src.coeffs = coeffs;
+	return write_sample(plan, hdr, src, out, cap);
+}
+
+// Parse a sample and entropy-decode every band on the host into a pyramid laid out per the plan
+// (highpass values already multiplied by their quant, as the reference's FSM decoder delivers them).
+int cfhd_amd_decode_bands_host(const uint8_t *sample, size_t size, int pixel_kind, int16_t *coeffs, size_t coeff_elems, int *info /*8 ints*/)
+{
+	ParsedSample ps;
+	int rc = parse_sample(sample, size, &ps);
+	if (rc) return rc;
+	FramePlan plan;
+	if (!build_frame_plan(&plan, ps.width, ps.display_height, pixel_kind, ps.encoded_format)) return -20;
+	if (coeff_elems < plan.coeff_elems) return -21;
+	info[0] = ps.width; info[1] = ps.height; info[2] = ps.display_height; info[3] = ps.num_channels; info[4] = ps.precision;
+	info[5] = ps.encoded_format; info[6] = ps.prescale_table; info[7] = ps.frame_number;
+	memset(coeffs, 0, (size_t)plan.coeff_elems * 2);
+	for (int c = 0; c < plan.num_channels; c++) {
+		const ParsedBand &lp = ps.lowpass[c];
+		const BandDesc &ll = plan.ch[c].band[2][0];
+		if (!lp.present || lp.width != ll.width || lp.height != ll.height) return -22;
+		for (int r = 0; r < ll.height; r++)
+			for (int x = 0; x < ll.width; x++) {
+				const uint8_t *p = sample + lp.offset + ((size_t)r * ll.width + x) * 2;
+				coeffs[ll.offset + (size_t)r * ll.pitch + x] = (int16_t)((p[0] << 8) | p[1]);
+			}
+		for (int lv = 0; lv < kNumLevels; lv++)
+			for (int b = 1; b < 4; b++) {
+				const ParsedBand &pb = ps.high[c][lv][b];
+				const BandDesc &bd = plan.ch[c].band[lv][b];
+				if (!pb.present || pb.width != bd.width || pb.height != bd.height) return -23;
+				rc = vlc_decode_band(sample + pb.offset, pb.bytes, bd.width, bd.height, bd.pitch, pb.quant, pb.codebook, coeffs + bd.offset);
+				if (rc) return rc * 100 - (c * 9 + lv * 3 + b);
+			}
+	}
+	return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,327 @@
+// cfhd_tables.cpp -- entropy-code tables, quantizer derivation and pyramid geometry (host side).
+//
+// Replaces, for the hot path: Codec/codebooks.c InitCodebooks (:202) / FillVleTable (:1032) /
+// ComputeRunLengthCodeTable (:401) / FillRunLengthCodeTable (:499), Codec/quantize.c
+// QuantizationSetQuality (:186) / SetTransformQuantization (:2865), Codec/wavelet.c
+// SetTransformScale (:7022) / SetTransformPrescale (:1710) / AllocWaveletStack (:427).
+#include "cfhd_core.h"
+#include "cfhd_codebook_data.h"
+#include <string.h>
+#include <stdlib.h>
+#include <mutex>
+#include <algorithm>
+
+namespace cfhd {
+
+// ------------------------------------------------------------------------------------------
+// Entropy tables
+// ------------------------------------------------------------------------------------------
+namespace {
+
+struct BaseCode { uint32_t bits; int size; int run; int mag; };
+
+void build_entropy_tables(EntropyTables *t, const uint8_t *mag_len, const uint32_t *mag_code, int num_mags,
+                          const uint32_t (*runs)[3], int num_runs, const uint32_t *band_end, bool cubic)
+{
+	// Companding: the encoder maps a quantized magnitude m (0..1023) to the largest code index i with
+	// expand(i) <= m, where expand(i) = i + floor(i^3 * 768 / 2^24)  (codebooks.c:1053-1078).
+	int inverse[1025];
+	for (int i = 0; i < 1025; i++) inverse[i] = 0;
+	for (int i = 0; i < 256; i++) {
+		int e = cubic ? i + (int)(((int64_t)i * i * i * 768) >> 24) : i;
+		t->mag_expand[i] = (uint16_t)e;
+		if (cubic && i > 0) inverse[e > 1023 ? 1023 : e] = i;
+	}
+	if (cubic) {
+		int last = 0;
+		for (int i = 0; i < 1025; i++) { if (inverse[i]) last = inverse[i]; else inverse[i] = last; }
+	}
+	for (int idx = 0; idx < 2048; idx++) {
+		int value = (idx & 1024) ? (idx & 1023) - 1024 : idx;
+		int mag = abs(value);
+		if (cubic) mag = inverse[mag];
+		if (mag > num_mags - 1) mag = num_mags - 1;
+		uint32_t code = mag_code[mag];
+		int size = mag_len[mag];
+		if (value > 0) { code = (code << 1); size++; }            // sign bit 0 = positive (vlc.h:81-84)
+		else if (value < 0) { code = (code << 1) | 1u; size++; }
+		t->value_code[idx] = ((uint32_t)size << 27) | code;
+	}
+
+	// Composite run-length table: greedy concatenation of the base run codes (longest first) while the
+	// composite stays within 31 bits; a single zero is the magnitude-0 code.
+	RunCode book[16]; int n = 0;
+	bool has_one = false;
+	for (int i = 0; i < num_runs; i++) {
+		book[n].bits = runs[i][0]; book[n].size = (uint8_t)runs[i][1]; book[n].count = (uint16_t)runs[i][2];
+		if (book[n].count == 1) has_one = true;
+		n++;
+	}
+	if (!has_one) { book[n].bits = mag_code[0]; book[n].size = mag_len[0]; book[n].count = 1; n++; }
+	std::sort(book, book + n, [](const RunCode &a, const RunCode &b) { return a.count > b.count; });
+	for (int len = 0; len < 3072; len++) {
+		uint32_t word = 0; int size = 0, remaining = len;
+		bool full = false;
+		for (int j = 0; j < n && remaining > 0 && !full; j++) {
+			int rep = remaining / book[j].count, k = 0;
+			for (; k < rep; k++) {
+				if (book[j].size > 31 - size) { if (size) full = true; break; }
+				word = (word << book[j].size) | book[j].bits;
+				size += book[j].size;
+			}
+			remaining -= k * book[j].count;
+		}
+		t->run_bits[len] = word; t->run_size[len] = (uint8_t)size; t->run_count[len] = (uint16_t)(len - remaining);
+	}
+	t->band_end_bits = band_end[0]; t->band_end_size = (int)band_end[1];
+
+	// Decoder LUT on the next kDecBits bits.
+	const int K = EntropyTables::kDecBits;
+	memset(t->dec_lut, 0, sizeof(t->dec_lut));
+	auto fill = [&](uint32_t code, int size, uint32_t payload) {
+		if (size > K) return;
+		uint32_t base = code << (K - size);
+		for (uint32_t s = 0; s < (1u << (K - size)); s++) t->dec_lut[base + s] = payload | (uint32_t)size;
+	};
+	for (int m = 0; m < num_mags; m++) {
+		if (m == 0) fill(mag_code[0], mag_len[0], (1u << 5));                       // one zero
+		else fill(mag_code[m], mag_len[m], ((uint32_t)t->mag_expand[m] << 16));    // magnitude, sign bit follows
+	}
+	for (int i = 0; i < num_runs; i++) fill(runs[i][0], (int)runs[i][1], (runs[i][2] << 5));
+}
+
+EntropyTables g_tables[3];
+std::once_flag g_tables_once;
+
+} // namespace
+
+const EntropyTables *entropy_tables(int codebook)
+{
+	std::call_once(g_tables_once, [] {
+		build_entropy_tables(&g_tables[1], cfhd_cs17_mag_len, cfhd_cs17_mag_code, CFHD_CS17_NUM_MAGS,
+		                     cfhd_cs17_run, CFHD_CS17_NUM_RUNS, cfhd_cs17_band_end, true);
+		build_entropy_tables(&g_tables[2], cfhd_cs18_mag_len, cfhd_cs18_mag_code, CFHD_CS18_NUM_MAGS,
+		                     cfhd_cs18_run, CFHD_CS18_NUM_RUNS, cfhd_cs18_band_end, false);
+	});
+	if (codebook != 1 && codebook != 2) return nullptr;
+	return &g_tables[codebook];
+}
+
+// Raw base codes for slow-path decoding of code words longer than kDecBits.
+int slow_decode_symbol(int codebook, uint32_t window /*next 32 bits, MSB first*/, int *size, int *run, int *mag, bool *band_end)
+{
+	const uint8_t *ml = codebook == 2 ? cfhd_cs18_mag_len : cfhd_cs17_mag_len;
+	const uint32_t *mc = codebook == 2 ? cfhd_cs18_mag_code : cfhd_cs17_mag_code;
+	const uint32_t (*rn)[3] = codebook == 2 ? cfhd_cs18_run : cfhd_cs17_run;
+	const uint32_t *be = codebook == 2 ? cfhd_cs18_band_end : cfhd_cs17_band_end;
+	const EntropyTables *t = entropy_tables(codebook);
+	*band_end = false; *run = 0; *mag = 0;
+	if ((window >> (32 - be[1])) == be[0]) { *size = (int)be[1]; *band_end = true; return 0; }
+	for (int i = 0; i < 7; i++) if ((window >> (32 - rn[i][1])) == rn[i][0]) { *size = (int)rn[i][1]; *run = (int)rn[i][2]; return 0; }
+	for (int m = 0; m < 256; m++) if ((window >> (32 - ml[m])) == mc[m]) {
+		*size = ml[m];
+		if (m == 0) *run = 1; else *mag = t->mag_expand[m];
+		return 0;
+	}
+	return -1;
+}
+
+// ------------------------------------------------------------------------------------------
+// Geometry
+// ------------------------------------------------------------------------------------------
+bool build_frame_plan(FramePlan *plan, int width, int height, int pixel_kind, int encoded_format)
+{
+	memset(plan, 0, sizeof(*plan));
+	if (width <= 0 || height <= 0) return false;
+	plan->display_height = height;
+	plan->encoded_format = encoded_format;
+	plan->pixel_kind = pixel_kind;
+	int chroma_width;
+	switch (encoded_format) {
+	case ENC_YUV422:   plan->num_channels = 3; plan->precision = 10; chroma_width = width / 2; break;
+	case ENC_RGB444:   plan->num_channels = 3; plan->precision = 12; chroma_width = width; break;
+	case ENC_RGBA4444: plan->num_channels = 4; plan->precision = 12; chroma_width = width; break;
+	case ENC_BAYER:    plan->num_channels = 4; plan->precision = 12; width /= 2; height /= 2; chroma_width = width;
+	                   plan->display_height = height; break;
+	default: return false;
+	}
+	// Height is rounded up to a multiple of 8 (Codec/encoder.c:1569-1571, :2236-2238).
+	int enc_height = (height + 7) / 8 * 8;
+	plan->width = width; plan->height = enc_height;
+	// Every level must halve evenly: widths divisible by 8 per channel (IsFrameTransformable).
+	if ((chroma_width % 8) != 0 || (width % 8) != 0) return false;
+
+	// Final (entropy coded) bands first, then the two intermediate LL planes of every channel.
+	uint32_t off = 0;
+	auto place = [&](BandDesc &b, int w, int h) {
+		b.width = w; b.height = h; b.pitch = align_up(w, 8); b.offset = off; b.quant = 1; b.scale = 1;
+		uint32_t elems = (uint32_t)b.pitch * (uint32_t)h;
+		off += (elems + 63u) & ~63u;      // 128-byte aligned bands
+	};
+	for (int c = 0; c < plan->num_channels; c++) {
+		ChannelPlan &cp = plan->ch[c];
+		cp.width = c == 0 ? width : chroma_width; cp.height = enc_height;
+		place(cp.band[2][0], cp.width >> 3, cp.height >> 3);                       // LL of level 3
+		for (int lv = 2; lv >= 0; lv--)
+			for (int b = 1; b < 4; b++) place(cp.band[lv][b], cp.width >> (lv + 1), cp.height >> (lv + 1));
+	}
+	plan->final_elems = off;
+	for (int c = 0; c < plan->num_channels; c++) {
+		ChannelPlan &cp = plan->ch[c];
+		place(cp.band[0][0], cp.width >> 1, cp.height >> 1);
+		place(cp.band[1][0], cp.width >> 2, cp.height >> 2);
+	}
+	plan->coeff_elems = off;
+	return true;
+}
+
+// ------------------------------------------------------------------------------------------
+// Quantizer
+// ------------------------------------------------------------------------------------------
+namespace {
+const int kLumaQ[4][17] = {
+	{4, 4,5,5, 4,5,5, 9,8,8,8, 4,4,4, 4,4,4},
+	{4, 8,8,12, 8,8,12, 9,12,12,16, 32,32,48, 32,32,48},
+	{4, 6,6,8, 6,6,8, 5,8,8,12, 16,16,24, 16,16,24},
+	{4, 4,4,6, 4,4,6, 5,8,8,8, 8,8,12, 8,8,12},
+};
+const int kChromaQ[4][17] = {
+	{4, 4,5,5, 4,5,5, 9,8,8,8, 8,8,8, 8,8,8},
+	{4, 8,8,12, 8,8,12, 9,12,12,16, 32,32,48, 32,32,48},
+	{4, 6,6,8, 6,6,8, 5,8,8,12, 16,16,32, 16,16,32},
+	{4, 6,6,8, 6,6,8, 5,8,8,8, 8,8,16, 8,8,16},
+};
+}
+
+void derive_quantization(FramePlan *plan, int quality, bool progressive, float framerate, QuantState *st)
+{
+	int qL[17], qC[17], qLmax[17], qCmax[17];
+	const bool chroma_full = plan->encoded_format != ENC_YUV422;
+	const int precision = plan->precision;
+	int factor = quality & 0xff;
+	const int detail = (quality & 0x0e0000) >> 17;
+	int rgb_quality = (quality & 0x06000000) >> 25;
+	if (rgb_quality > 2) rgb_quality = 2;
+	int mpq = detail + 2; if (mpq > 8) mpq = 0;
+	plan->midpoint_prequant = mpq;
+	if (quality & 0x1f00) factor = 5;
+	const int newQuality = factor;
+	// FSratelimiter is seeded once (frame == NULL in the reference's init call, quantize.c:228-238) and
+	// afterwards only moves for FILMSCAN2/3 rate feedback, which needs the previous sample size.
+	if (st->FSratelimiter < 0) st->FSratelimiter = (newQuality == 5) ? 8 : (newQuality == 6 ? 4 : 0);
+	if (newQuality >= 5 && st->lastgopbitcount && !(quality & 0x1f00)) {
+		float gop_size = (float)(int32_t)(st->lastgopbitcount >> 3);
+		float compression = (float)(plan->width * plan->height * plan->num_channels * precision / 8) / gop_size;
+		if (!chroma_full) compression /= 1.5f;
+		int &r = st->FSratelimiter;
+		if (newQuality == 5) {
+			if (compression > 5.5f) { r--; if (compression > 6.5f) r--; if (compression > 7.5f) r -= 2; }
+			else if (compression < 4.0f) { r++; if (compression < 3.5f) r++; if (compression < 3.0f) r++; if (compression < 2.5f) r++; if (compression < 2.0f) r++; if (compression < 1.5f) r += 2; }
+		} else if (newQuality == 10) {
+			if (compression > 2.5f) r--; else if (compression < 2.0f) { r++; if (compression < 1.5f) r += 2; }
+		} else {
+			if (compression > 4.5f) { r--; if (compression > 5.5f) r--; if (compression > 6.5f) r -= 2; }
+			else if (compression < 3.0f) { r++; if (compression < 2.5f) r++; if (compression < 2.0f) r++; if (compression < 1.5f) r += 2; }
+		}
+		if (r < 0) r = 0; if (r > 20) r = 20;
+	}
+	if (factor < 1 || factor > 10) factor = 0;
+	if (factor > 3) factor = 3;
+	int overrate = factor; if (overrate >= 2) overrate--;
+	for (int i = 0; i < 17; i++) {
+		qL[i] = kLumaQ[factor][i]; qLmax[i] = kLumaQ[overrate][i];
+		qC[i] = chroma_full ? kLumaQ[factor][i] : kChromaQ[factor][i];
+		qCmax[i] = chroma_full ? kLumaQ[overrate][i] : kChromaQ[overrate][i];
+	}
+	for (int i = 0; i < 17; i++) { qLmax[i] = qL[i] + (qLmax[i] - qL[i]) / 2; qCmax[i] = qC[i] + (qCmax[i] - qC[i]) / 2; }
+	int lowfreqquant = 4;
+	if (precision >= 10) {
+		int scale = 64, limiter = std::min(st->FSratelimiter, 16);
+		if (newQuality == 4) { lowfreqquant = 3; scale = 48; }
+		else if (newQuality >= 5 && newQuality <= 10) { lowfreqquant = 2; scale = 16 + limiter * 2; }
+		if (newQuality >= 5 && scale >= 4) scale >>= 1;
+		if (newQuality == 10 && scale >= 6) { scale *= 2; scale /= 3; }
+		if (newQuality >= 4) for (int i = 1; i < 7; i++) qL[i] = qC[i] = qLmax[i] = qCmax[i] = lowfreqquant;
+		for (int i = 8; i < 17; i++) {
+			qL[i] = std::max((qL[i] * scale) >> 4, 2); qC[i] = std::max((qC[i] * scale) >> 4, 2);
+			qLmax[i] = std::max((qLmax[i] * 64) >> 4, 2); qCmax[i] = std::max((qCmax[i] * 64) >> 4, 2);
+		}
+		qL[7] = qC[7] = qLmax[7] = qCmax[7] = 4;
+	}
+	if (precision == 12) {
+		int chromagain = rgb_quality == 0 ? 8 : (rgb_quality == 1 ? 6 : 4);
+		if (newQuality >= 4) for (int i = 1; i < 7; i++) qL[i] = qC[i] = qLmax[i] = qCmax[i] = lowfreqquant;
+		for (int i = 4; i < 7; i++) { qL[i] *= 4; qC[i] *= 4; qLmax[i] *= 4; qCmax[i] *= 4; }
+		if (st->FSratelimiter > 16) chromagain = std::min(chromagain + st->FSratelimiter - 16, 8);
+		for (int i = 11; i < 17; i++) { qL[i] *= 4; qC[i] *= chromagain; qLmax[i] *= 4; qCmax[i] *= chromagain; }
+	}
+	if (!progressive) {
+		if (factor == 2) for (int i : {12, 13, 15, 16}) { qLmax[i] = qL[i]; qCmax[i] = qC[i]; }
+		for (int *a : {qL, qC, qLmax, qCmax}) { a[11] = a[11] * 3 / 2; a[12] = a[12] * 2 / 3; a[14] = a[14] * 3 / 2; a[15] = a[15] * 2 / 3; }
+	}
+	for (int i = 0; i < 3; i++) { qL[7 + i] = qL[11 + i]; qC[7 + i] = qC[11 + i]; qLmax[7 + i] = qLmax[11 + i]; qCmax[7 + i] = qCmax[11 + i]; }
+	const int fixedQuality = factor;     // 0 => bitrate mode (not supported: treated as quality 3 tables w/o VBR)
+
+	plan->prescale[0] = 0; plan->prescale[1] = precision >= 10 ? 2 : 0; plan->prescale[2] = precision == 12 ? 2 : 0;
+
+	// Bit-rate limiter (quantize.c:2994-3100): active only for qualities <= HIGH on <= 1080p 3-channel YUV.
+	int64_t prevbits = st->lastgopbitcount;
+	float fr = (framerate > 10.0f && framerate < 120.0f) ? framerate : 30.0f;
+	int currentbitrate = (int)((float)(int32_t)prevbits * fr);
+	bool limiter_on = fixedQuality != 0 && !(plan->width > 1920 || plan->height > 1080 || plan->num_channels > 3 ||
+	                                          newQuality > 3 || plan->encoded_format == ENC_RGB444);
+	if (st->overbitrate < 0 || st->overbitrate > 16) st->overbitrate = 0;
+
+	for (int c = 0; c < plan->num_channels; c++) {
+		int quant[17], quantMAX[17];
+		memcpy(quant, c ? qC : qL, sizeof(quant)); memcpy(quantMAX, c ? qCmax : qLmax, sizeof(quantMAX));
+		if (limiter_on) {
+			const int BR_LIMIT = 130000000, BR_STEPS = 10000000;
+			int upper = fixedQuality == 1 ? BR_LIMIT - 2 * BR_STEPS : (fixedQuality == 3 ? BR_LIMIT + 2 * BR_STEPS : BR_LIMIT);
+			if (currentbitrate > upper) {
+				memcpy(quant, quantMAX, sizeof(quant));
+				if (c == 0) {
+					if (st->overbitrate == 0) st->overbitrate = 1;
+					if (currentbitrate > upper * 12 / 10) st->overbitrate++;
+					if (st->overbitrate > 16) st->overbitrate = 16;
+				}
+			} else if (st->overbitrate > 0) {
+				if (c == 0) {
+					if (st->overbitrate > 1 && currentbitrate < upper) st->overbitrate--;
+					else if (st->overbitrate == 1 && currentbitrate < upper * 8 / 10) st->overbitrate = 0;
+				}
+				if (st->overbitrate > 0) memcpy(quant, quantMAX, sizeof(quant));
+			}
+			if (st->overbitrate > 1) {
+				int rc = st->overbitrate - 1;
+				if (progressive) { for (int i = 11; i < 17; i++) quant[i] = (quant[i] * (rc + 4)) >> 2; }
+				else {
+					for (int i : {11, 14}) quant[i] = (quant[i] * (rc + 4)) >> 2;
+					for (int i : {12, 15, 13, 16}) quant[i] = (quant[i] * (rc / 8 + 4)) >> 2;
+				}
+			}
+		}
+		ChannelPlan &cp = plan->ch[c];
+		int scale[3][4] = {{4, 2, 2, 1}};
+		for (int k = 1; k < 3; k++) { int s = scale[k - 1][0]; scale[k][0] = 4 * s; scale[k][1] = 2 * s; scale[k][2] = 2 * s; scale[k][3] = s; }
+		for (int k = 0; k < 3; k++) for (int b = 0; b < 4; b++) { cp.band[k][b].scale = scale[k][b]; }
+		int subband = 1;
+		auto midpoint = [&](int q) { if (mpq) { q *= mpq; q /= (mpq - 1) * 2; } else q /= 2; return q; };
+		for (int index = 2; index >= 1; index--) {
+			cp.band[index][0].quant = 1;
+			for (int b = 1; b < 4; b++, subband++) {
+				int vscale = (quantMAX[subband] - quant[subband]) * 256 - 256 * quantMAX[subband] + 512 * quant[subband];
+				int q = ((vscale * scale[index][b]) >> 8) >> 2;
+				if (!(quality & 0x10000000)) q = midpoint(q);
+				cp.band[index][b].quant = q;
+			}
+		}
+		cp.band[0][0].quant = 1;
+		for (int b = 1; b < 4; b++, subband++) {
+			int vscale = (quantMAX[subband] - quant[subband]) * 256 - 256 * quantMAX[subband] + 512 * quant[subband];
+			cp.band[0][b].quant = midpoint(vscale >> 8);
+		}
+	}
+}
+
+} // namespace cfhd

@@ -154,3 +154,100 @@ def mask_volatile_metadata(sample):
             for k in range(n):
                 b[i + 8 + k] = 0
     return bytes(b)
+
+
+# ------------------------------------------------------------------------------------------
+# product library (cineform-sdk_amd/libcfhd_amd.so)
+# ------------------------------------------------------------------------------------------
+PRODUCT_DIR = os.path.join(ROOT, "cineform-sdk_amd")
+PRODUCT_SO = os.path.join(PRODUCT_DIR, "libcfhd_amd.so")
+PIXKIND = {"YUY2": 1, "2vuy": 2, "RG48": 3, "b64a": 4, "BYR4": 5}
+ENC = {"422": 1, "bayer": 2, "444": 3, "4444": 4}
+_product = None
+
+
+def product():
+    global _product
+    if _product is None:
+        if not os.path.exists(PRODUCT_SO):
+            subprocess.check_call(["make", "-C", PRODUCT_DIR])
+        L = ctypes.CDLL(PRODUCT_SO)
+        L.cfhd_amd_write_sample_host.restype = ctypes.c_size_t
+        L.cfhd_amd_write_sample_host.argtypes = [ctypes.c_int] * 8 + [ctypes.c_uint, c_i16p, c_u8p, ctypes.c_size_t, c_u8p, ctypes.c_size_t, c_u8p, ctypes.c_size_t]
+        L.cfhd_amd_decode_bands_host.argtypes = [c_u8p, ctypes.c_size_t, ctypes.c_int, c_i16p, ctypes.c_size_t, c_intp]
+        _product = L
+    return _product
+
+
+class Plan:
+    """Python view of cfhd::FramePlan (geometry + quantizer) as the product derives it."""
+
+    def __init__(self, width, height, pixkind=1, enc=1, quality=QUALITY_FILMSCAN1, progressive=1):
+        buf = (ctypes.c_int * 512)()
+        n = product().cfhd_amd_plan_info(width, height, pixkind, enc, quality, progressive, buf)
+        assert n > 0, "plan_info failed"
+        v = list(buf[:n])
+        self.coeff_elems, self.final_elems, self.num_channels, self.precision, self.mpq = v[0:5]
+        self.prescale = v[5:8]
+        self.band = {}
+        i = 8
+        for c in range(self.num_channels):
+            for lv in range(3):
+                for b in range(4):
+                    w, h, pitch, off, quant, scale = v[i:i + 6]; i += 6
+                    self.band[(c, lv, b)] = dict(width=w, height=h, pitch=pitch, offset=off, quant=quant, scale=scale)
+        self.width, self.height, self.pixkind, self.enc, self.quality = width, height, pixkind, enc, quality
+
+    def view(self, coeffs, c, lv, b):
+        d = self.band[(c, lv, b)]
+        return coeffs[d["offset"]: d["offset"] + d["pitch"] * d["height"]].reshape(d["height"], d["pitch"])
+
+
+def oracle_forward_yuv422(plan, frame, pitch, uyvy=0):
+    """Whole forward path of one 4:2:2 frame with the oracle, written into the product's pyramid layout."""
+    O = oracle()
+    coeffs = np.zeros(plan.coeff_elems, dtype=np.int16)
+    H = plan.height
+    for c in range(3):
+        cw = plan.width if c == 0 else plan.width // 2
+        # level 1 straight from the packed frame
+        q = [plan.band[(c, 0, b)]["quant"] for b in range(4)]
+        outs = [plan.view(coeffs, c, 0, b) for b in range(4)]
+        assert len({o.shape[1] for o in outs}) == 1
+        bands = (c_i16p * 4)(*[o.ctypes.data_as(c_i16p) for o in outs])
+        O.orc_fwd_spatial_yuv422(p8(frame), pitch, cw, H, c, plan.precision - 8, uyvy, iarr(q), plan.mpq, bands, outs[0].shape[1])
+        for lv in (1, 2):
+            src = plan.view(coeffs, c, lv - 1, 0)
+            d = plan.band[(c, lv - 1, 0)]
+            q = [plan.band[(c, lv, b)]["quant"] for b in range(4)]
+            outs = [plan.view(coeffs, c, lv, b) for b in range(4)]
+            bands = (c_i16p * 4)(*[o.ctypes.data_as(c_i16p) for o in outs])
+            O.orc_fwd_spatial(src.ctypes.data_as(c_i16p), d["pitch"], d["width"], d["height"], plan.prescale[lv], iarr(q), plan.mpq, bands, outs[0].shape[1])
+    return coeffs
+
+
+def product_write_sample_host(plan, coeffs, frame_number, meta_global=b"", meta_local=b"", input_format=COLOR_FORMAT_YUYV, color_space=2):
+    out = np.zeros(plan.width * plan.height * 4 + 65536, dtype=np.uint8)
+    mg = np.frombuffer(meta_global, dtype=np.uint8).copy() if meta_global else np.zeros(4, np.uint8)
+    ml = np.frombuffer(meta_local, dtype=np.uint8).copy() if meta_local else np.zeros(4, np.uint8)
+    n = product().cfhd_amd_write_sample_host(plan.width, plan.height, plan.pixkind, plan.enc, plan.quality, 1, input_format, color_space,
+                                             frame_number, p16(coeffs), p8(mg), len(meta_global), p8(ml), len(meta_local), p8(out), out.size)
+    assert n > 0
+    return bytes(out[:n])
+
+
+def first_metadata_chunk(sample):
+    """(offset, size) of the payload of the first CODEC_TAG_METADATA chunk in a sample."""
+    import struct
+    pos = 0
+    while pos + 4 <= len(sample):
+        tag, val = struct.unpack(">hH", sample[pos:pos + 4])
+        t = -tag if tag < 0 else tag
+        pos += 4
+        if t == 2:
+            pos += 4 * val
+        elif t == 0x4002:
+            return pos, val * 4
+        elif t & 0x4000:
+            pos += val * 4
+    return None

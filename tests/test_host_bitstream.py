@@ -1,0 +1,78 @@
+"""Product host layer (plan geometry, quantizer derivation, sample writer, host VLC, parser) checked on CPU:
+oracle forward transform -> product sample writer must reproduce the reference encoder's sample byte for byte."""
+import numpy as np
+import pytest
+from cfhd_testlib import *
+
+needs_ref = [pytest.mark.ref, pytest.mark.skipif(not have_ref(), reason="reference .so not built")]
+
+
+@pytest.mark.parametrize("w,h", [(320, 240), (640, 480), (1920, 1080)])
+def test_sample_bytes_equal_reference_synthetic(w, h):
+    for m in needs_ref: pass
+    if not have_ref(): pytest.skip("reference .so not built")
+    frame, pitch = synth_yuy2(w, h, 3)
+    refs = ref_encode_frames([frame, frame], pitch, w, h)
+    plan = Plan(w, h)
+    coeffs = oracle_forward_yuv422(plan, frame, pitch)
+    for i, rs in enumerate(refs):
+        off, n = first_metadata_chunk(rs)
+        mine = product_write_sample_host(plan, coeffs, i + 1, meta_global=rs[off:off + n])
+        assert len(mine) == len(rs)
+        assert mine == rs
+
+
+def test_sample_bytes_equal_reference_qbist_1080p():
+    if not have_ref(): pytest.skip("reference .so not built")
+    frames, pitch = qbist_frames(10, 2)
+    refs = ref_encode_frames(frames, pitch, 1920, 1080)
+    assert len(refs[0]) == 310392          # SURVEY.md section 6 [probe]
+    plan = Plan(1920, 1080)
+    for i, (f, rs) in enumerate(zip(frames, refs)):
+        coeffs = oracle_forward_yuv422(plan, f, pitch)
+        off, n = first_metadata_chunk(rs)
+        mine = product_write_sample_host(plan, coeffs, i + 1, meta_global=rs[off:off + n])
+        assert mine == rs
+
+
+def test_quant_tables_known_answers():
+    # SURVEY.md section 8 (a14) [probe]: 1080p YUY2 FILMSCAN1
+    plan = Plan(1920, 1080)
+    luma = [plan.band[(0, lv, b)]["quant"] for lv in (2, 1, 0) for b in (1, 2, 3)]
+    chroma = [plan.band[(1, lv, b)]["quant"] for lv in (2, 1, 0) for b in (1, 2, 3)]
+    scale = [plan.band[(0, lv, b)]["scale"] for lv in (2, 1, 0) for b in (1, 2, 3)]
+    assert luma == [24, 24, 12, 6, 6, 3, 24, 24, 36]
+    assert chroma == [24, 24, 12, 6, 6, 3, 24, 24, 48]
+    assert scale == [32, 32, 16, 8, 8, 4, 2, 2, 1]
+    assert plan.prescale == [0, 2, 0] and plan.mpq == 2
+    assert (plan.band[(0, 2, 0)]["width"], plan.band[(0, 2, 0)]["height"]) == (240, 135)
+    assert (plan.band[(1, 2, 0)]["width"], plan.band[(1, 2, 0)]["height"]) == (120, 135)
+
+
+@pytest.mark.parametrize("w,h", [(320, 240), (1920, 1080)])
+def test_parse_and_host_decode_roundtrip(w, h):
+    """write_sample -> parse_sample + host VLC decode gives back sign*expand(compand(|q|))*quant for every band."""
+    frame, pitch = synth_yuy2(w, h, 5)
+    plan = Plan(w, h)
+    coeffs = oracle_forward_yuv422(plan, frame, pitch)
+    sample = product_write_sample_host(plan, coeffs, 1)
+    out = np.zeros(plan.coeff_elems, dtype=np.int16)
+    info = (ctypes.c_int * 8)()
+    s = np.frombuffer(sample, dtype=np.uint8).copy()
+    rc = product().cfhd_amd_decode_bands_host(p8(s), len(sample), 1, p16(out), out.size, info)
+    assert rc == 0
+    assert list(info)[:5] == [w, plan.height, h, 3, 10]
+    # expected: companding curve applied by the encoder LUT, expanded and dequantized by the decoder
+    idx = np.arange(256)
+    expand = idx + ((idx.astype(np.int64) ** 3 * 768) >> 24)
+    inv = np.zeros(1025, dtype=np.int64)
+    inv[np.minimum(expand[1:], 1023)] = idx[1:]
+    inv = np.maximum.accumulate(inv)
+    for c in range(3):
+        assert np.array_equal(plan.view(out, c, 2, 0), plan.view(coeffs, c, 2, 0))
+        for lv in range(3):
+            for b in (1, 2, 3):
+                q = plan.view(coeffs, c, lv, b).astype(np.int64)
+                mag = np.minimum(np.abs(q), 1023)
+                want = np.sign(q) * expand[inv[mag]] * plan.band[(c, lv, b)]["quant"]
+                assert np.array_equal(plan.view(out, c, lv, b), want.astype(np.int16)), (c, lv, b)
