@@ -251,3 +251,24 @@ def first_metadata_chunk(sample):
         elif t & 0x4000:
             pos += val * 4
     return None
+
+
+# ------------------------------------------------------------------------------------------
+# CPU emulation of the HIP kernels (tests/hipemu): same kernel source, executed workgroup by workgroup
+# ------------------------------------------------------------------------------------------
+EMU_SO = os.path.join(ROOT, "tests", "_build", "libcfhd_emu.so")
+_emu = None
+
+
+def emu():
+    global _emu
+    if _emu is None:
+        src = os.path.join(ROOT, "tests", "hipemu", "emu_kernels.cpp")
+        deps = [src, os.path.join(ROOT, "tests", "hipemu", "hip_emu.h")] + [
+            os.path.join(PRODUCT_DIR, "csrc", f) for f in os.listdir(os.path.join(PRODUCT_DIR, "csrc")) if f.endswith(".h")]
+        if not os.path.exists(EMU_SO) or any(os.path.getmtime(d) > os.path.getmtime(EMU_SO) for d in deps):
+            os.makedirs(os.path.dirname(EMU_SO), exist_ok=True)
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + os.path.dirname(src),
+                                   "-I" + os.path.join(PRODUCT_DIR, "csrc"), src, "-o", EMU_SO])
+        _emu = ctypes.CDLL(EMU_SO)
+    return _emu

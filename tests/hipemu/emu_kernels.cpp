@@ -1,0 +1,65 @@
+// tests/hipemu/emu_kernels.cpp -- TEST INFRASTRUCTURE ONLY.
+// Runs the product's HIP kernels (cineform-sdk_amd/csrc/cfhd_kernels.h, unmodified source) on the CPU through
+// hip_emu.h so the `-m "not gpu"` suite can check their tiling / LDS / border logic against the oracle.
+#include "hip_emu.h"
+thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+#include "cfhd_kernels.h"
+
+using namespace cfhd::dev;
+
+static QuantParam make_q(int divisor, int mpq)
+{
+	QuantParam q; q.divisor = divisor; q.mid = 0; q.mult = 0;
+	if (divisor > 1) {
+		if (mpq >= 2 && mpq < 9) { q.mid = divisor / mpq; if (mpq == 2 && q.mid) q.mid--; }
+		q.mult = ((1u << 16) / (unsigned)divisor) & 0xffffu;
+	}
+	return q;
+}
+
+extern "C" {
+
+void emu_fwd_plane(const int16_t *in, int in_pitch, int width, int height, int prescale, const int *quant, int mpq,
+                   int16_t *ll, int16_t *lh, int16_t *hl, int16_t *hh, int out_pitch)
+{
+	FwdPlaneJob job;
+	job.in = in; job.in_pitch = in_pitch; job.width = width; job.height = height; job.prescale = prescale;
+	job.out[0] = ll; job.out[1] = lh; job.out[2] = hl; job.out[3] = hh; job.out_pitch = out_pitch;
+	for (int b = 0; b < 4; b++) job.q[b] = make_q(quant[b], mpq);
+	dim3 grid((width / 2 + TW - 1) / TW, (height / 2 + TH - 1) / TH, 1);
+	hipemu::launch(grid, dim3(NTHREADS), [&] { k_fwd_plane(&job); });
+}
+
+void emu_fwd_yuv422(const uint8_t *in, int in_pitch, int width, int height, int display_height, int uyvy, int shift,
+                    const int *quant /*[3][4]*/, int mpq, int16_t **out /*[3][4]*/, const int *out_pitch)
+{
+	FwdYuvJob job;
+	job.in = in; job.in_pitch = in_pitch; job.width = width; job.height = height; job.display_height = display_height;
+	job.uyvy = uyvy; job.shift = shift;
+	for (int c = 0; c < 3; c++) { job.out_pitch[c] = out_pitch[c]; for (int b = 0; b < 4; b++) { job.out[c][b] = out[c * 4 + b]; job.q[c][b] = make_q(quant[c * 4 + b], mpq); } }
+	dim3 grid((width / 2 + TW - 1) / TW, (height / 2 + TH - 1) / TH, 1);
+	hipemu::launch(grid, dim3(NTHREADS), [&] { k_fwd_yuv422(&job); });
+}
+
+void emu_inv_plane(const int16_t *ll, const int16_t *lh, const int16_t *hl, const int16_t *hh, int band_pitch, int w, int h, int descale,
+                   int16_t *out, int out_pitch)
+{
+	InvPlaneJob job;
+	job.band[0] = ll; job.band[1] = lh; job.band[2] = hl; job.band[3] = hh; job.band_pitch = band_pitch;
+	job.width = w; job.height = h; job.descale = descale; job.out = out; job.out_pitch = out_pitch;
+	dim3 grid((w + ITW - 1) / ITW, (h + ITH - 1) / ITH, 1);
+	hipemu::launch(grid, dim3(NTHREADS), [&] { k_inv_plane(&job); });
+}
+
+void emu_inv_yuv422(int16_t **bands /*[3][4]*/, const int *band_pitch, int w, int h, int display_height, int uyvy, int shift,
+                    unsigned dither_seed, uint8_t *out, int out_pitch)
+{
+	InvYuvJob job;
+	for (int c = 0; c < 3; c++) { job.band_pitch[c] = band_pitch[c]; for (int b = 0; b < 4; b++) job.band[c][b] = bands[c * 4 + b]; }
+	job.width = w; job.height = h; job.display_height = display_height; job.uyvy = uyvy; job.shift = shift;
+	job.dither_seed = dither_seed; job.out = out; job.out_pitch = out_pitch;
+	dim3 grid((w + ITW - 1) / ITW, (h + ITH - 1) / ITH, 1);
+	hipemu::launch(grid, dim3(NTHREADS), [&] { k_inv_yuv422(&job); });
+}
+
+} // extern "C"

@@ -1,0 +1,94 @@
+"""The product's HIP kernel source (cineform-sdk_amd/csrc/cfhd_kernels.h) executed on the CPU by tests/hipemu
+(one OS thread per GPU thread, real barriers) and compared bit for bit with the oracle.  This is the
+no-GPU half of the kernel parity tests; tests/test_gpu_parity.py repeats them on the MI355X."""
+import ctypes
+import numpy as np
+import pytest
+from cfhd_testlib import *
+
+
+def rand_plane(rng, w, h, bits, signed=False):
+    lo = -(1 << (bits - 1)) if signed else 0
+    hi = (1 << (bits - 1)) - 1 if signed else (1 << bits) - 1
+    return rng.integers(lo, hi + 1, size=(h, w), dtype=np.int64).astype(np.int16)
+
+
+@pytest.mark.parametrize("w,h", [(16, 8), (64, 16), (90, 34), (136, 70), (240, 134), (480, 66)])
+@pytest.mark.parametrize("prescale", [0, 2])
+def test_fwd_plane(w, h, prescale):
+    rng = np.random.default_rng(w * 11 + h + prescale)
+    x = rand_plane(rng, w, h, 12 if prescale == 0 else 14)
+    quant = [1, 24, 12, 36] if prescale == 0 else [1, 6, 6, 3]
+    hw, hh = w // 2, h // 2
+    pitch = (hw + 7) // 8 * 8
+    o = [np.zeros((hh, hw), np.int16) for _ in range(4)]
+    e = [np.full((hh, pitch), 77, np.int16) for _ in range(4)]
+    bands = (c_i16p * 4)(*[p16(a) for a in o])
+    oracle().orc_fwd_spatial(p16(x), w, w, h, prescale, iarr(quant), 2, bands, hw)
+    emu().emu_fwd_plane(p16(x), w, w, h, prescale, iarr(quant), 2, p16(e[0]), p16(e[1]), p16(e[2]), p16(e[3]), pitch)
+    for k in range(4):
+        assert np.array_equal(e[k][:, :hw], o[k]), "band %d" % k
+        if hw & 1:
+            assert np.all(e[k][:, hw] == 0)     # the pad column next to an odd width is written as zero
+
+
+@pytest.mark.parametrize("w,h,dh", [(64, 16, 16), (128, 48, 48), (192, 40, 34), (720, 64, 64)])
+@pytest.mark.parametrize("uyvy", [0, 1])
+def test_fwd_yuv422(w, h, dh, uyvy):
+    rng = np.random.default_rng(w + h + uyvy)
+    frame = rng.integers(0, 256, size=(dh, w * 2), dtype=np.int64).astype(np.uint8)
+    padded = np.full((h, w * 2), 128, np.uint8); padded[:dh] = frame
+    quant = [1, 24, 24, 36, 1, 24, 24, 48, 1, 24, 24, 48]
+    outs_e, outs_o, pitches = [], [], []
+    for ch in range(3):
+        cw = (w if ch == 0 else w // 2) // 2
+        pitches.append((cw + 7) // 8 * 8)
+        outs_e.append([np.zeros((h // 2, pitches[-1]), np.int16) for _ in range(4)])
+        outs_o.append([np.zeros((h // 2, cw), np.int16) for _ in range(4)])
+        bands = (c_i16p * 4)(*[p16(a) for a in outs_o[-1]])
+        oracle().orc_fwd_spatial_yuv422(p8(padded), w * 2, cw * 2, h, ch, 2, uyvy, iarr(quant[4 * ch:4 * ch + 4]), 2, bands, cw)
+    ptrs = (c_i16p * 12)(*[p16(a) for ch in range(3) for a in outs_e[ch]])
+    emu().emu_fwd_yuv422(p8(frame), w * 2, w, h, dh, uyvy, 2, iarr(quant), 2, ptrs, iarr(pitches))
+    for ch in range(3):
+        for k in range(4):
+            assert np.array_equal(outs_e[ch][k][:, :outs_o[ch][k].shape[1]], outs_o[ch][k]), (ch, k)
+
+
+@pytest.mark.parametrize("w,h", [(8, 4), (45, 17), (64, 8), (120, 135), (130, 20)])
+@pytest.mark.parametrize("descale", [0, 2])
+def test_inv_plane(w, h, descale):
+    rng = np.random.default_rng(w * 5 + h + descale)
+    pitch = (w + 7) // 8 * 8
+    b = [np.zeros((h, pitch), np.int16) for _ in range(4)]
+    b[0][:, :w] = rand_plane(rng, w, h, 13)
+    for k in range(1, 4): b[k][:, :w] = rand_plane(rng, w, h, 11, signed=True)
+    o = np.zeros((2 * h, 2 * w), np.int16); e = np.zeros((2 * h, 2 * pitch), np.int16)
+    bands = (c_i16p * 4)(*[p16(a) for a in b])
+    oracle().orc_inv_spatial(bands, pitch, w, h, descale, p16(o), 2 * w)
+    emu().emu_inv_plane(p16(b[0]), p16(b[1]), p16(b[2]), p16(b[3]), pitch, w, h, descale, p16(e), 2 * pitch)
+    assert np.array_equal(e[:, :2 * w], o)
+
+
+@pytest.mark.parametrize("w,h,dh", [(32, 8, 16), (96, 20, 40), (360, 30, 58)])
+@pytest.mark.parametrize("uyvy", [0, 1])
+def test_inv_yuv422(w, h, dh, uyvy):
+    """Emulated last-level kernel vs oracle: every output byte must equal the oracle with dither 0 or with dither 1."""
+    rng = np.random.default_rng(w + h + uyvy)
+    bands, pitches = [], []
+    for ch in range(3):
+        cw = w if ch == 0 else w // 2
+        pitch = (cw + 7) // 8 * 8; pitches.append(pitch)
+        bs = [np.zeros((h, pitch), np.int16) for _ in range(4)]
+        bs[0][:, :cw] = rand_plane(rng, cw, h, 11)              # LL1 of 10-bit video: <= 4*1020
+        for k in range(1, 4): bs[k][:, :cw] = rand_plane(rng, cw, h, 9, signed=True)
+        bands.append(bs)
+    ptrs = (c_i16p * 12)(*[p16(a) for ch in range(3) for a in bands[ch]])
+    outs = []
+    for dither in (0, 1):
+        o = np.zeros((2 * h, 4 * w), np.uint8)
+        oracle().orc_inv_spatial_to_yuv422(ptrs, iarr(pitches), w, h, 10, uyvy, dither, p8(o), 4 * w)
+        outs.append(o[:dh])
+    e = np.zeros((dh, 4 * w), np.uint8)
+    emu().emu_inv_yuv422(ptrs, iarr(pitches), w, h, dh, uyvy, 2, 1234, p8(e), 4 * w)
+    assert np.all((e == outs[0]) | (e == outs[1]))
+    assert np.any(e != outs[0]) and np.any(e != outs[1])        # the dither really toggles
