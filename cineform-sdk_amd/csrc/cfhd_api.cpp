@@ -1,0 +1,787 @@
+// cfhd_api.cpp -- the CFHD_* C ABI (include/cfhd_amd.h) on top of the GPU core.
+//
+// Mirrors the behaviour of the reference's SDK layer for the hot path:
+//   EncoderSDK/CFHDEncoder.cpp + SampleEncoder.cpp (sync encode, metadata handling :744-939),
+//   EncoderSDK/CFHDEncoderPool.cpp + EncoderPool.cpp + AsyncEncoder.cpp (async pool, FIFO completion),
+//   DecoderSDK/CFHDDecoder.cpp + SampleDecoder.cpp (decode), DecoderSDK/CFHDMetadata.cpp (sample metadata access).
+// The reference's CPU thread pool is replaced by HIP-stream frame slots; host threads only run the entropy stage.
+#include "../../include/cfhd_amd.h"
+#include "cfhd_core.h"
+#include "cfhd_bitstream.h"
+#include "cfhd_device.h"
+#include "cfhd_metadata.h"
+#include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <time.h>
+#include <vector>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <condition_variable>
+#include <thread>
+#include <atomic>
+#include <random>
+
+using namespace cfhd;
+
+enum {
+	ERR_OKAY = 0, ERR_INVALID_ARGUMENT = 1, ERR_OUTOFMEMORY = 2, ERR_BADFORMAT = 3, ERR_BADSCALING = 4, ERR_BADSAMPLE = 5, ERR_INTERNAL = 6,
+	ERR_METADATA_END = 9, ERR_UNEXPECTED = 10, ERR_BAD_RESOLUTION = 11, ERR_NOT_FINISHED = 13, ERR_ENCODING_NOT_STARTED = 14, ERR_CODEC_ERROR = 2048,
+};
+
+#define FOURCC_BE(a, b, c, d) (((uint32_t)(a) << 24) | ((uint32_t)(b) << 16) | ((uint32_t)(c) << 8) | (uint32_t)(d))
+static const uint32_t FMT_YUY2 = FOURCC_BE('Y', 'U', 'Y', '2'), FMT_2VUY = FOURCC_BE('2', 'v', 'u', 'y'), FMT_YUYV = FOURCC_BE('y', 'u', 'y', 'v');
+
+namespace {
+
+std::mutex g_guid_mutex;
+bool g_guid_fixed = false;
+unsigned char g_guid[16];
+
+void new_guid(unsigned char out[16])
+{
+	std::lock_guard<std::mutex> lk(g_guid_mutex);
+	if (g_guid_fixed) { memcpy(out, g_guid, 16); return; }
+	std::random_device rd;
+	for (int i = 0; i < 16; i += 4) { uint32_t r = rd(); memcpy(out + i, &r, 4); }
+	out[6] = (out[6] & 0x0f) | 0x40; out[8] = (out[8] & 0x3f) | 0x80;    // RFC 4122 version 4
+}
+
+int pixel_kind_of(uint32_t fmt)
+{
+	if (fmt == FMT_YUY2 || fmt == FMT_YUYV) return PIX_YUY2;
+	if (fmt == FMT_2VUY) return PIX_2VUY;
+	return PIX_NONE;
+}
+int color_format_of(int kind) { return kind == PIX_2VUY ? 1 : 2; }           // COLOR_FORMAT_UYVY / COLOR_FORMAT_YUYV (Codec/color.h:64-65)
+
+// ---- metadata handle shared by the encoder-side API (CSampleEncodeMetadata) ----
+struct EncMetadata {
+	std::mutex lock;
+	MetaBlock global, local;
+	bool changed = false;
+};
+
+// ---- the per-encoder metadata state machine (EncoderSDK/SampleEncoder.cpp:744-939 HandleMetadata) ----
+struct MetaState {
+	MetaBlock global, local;
+	int last_timecode_base = 0, last_timecode_frame = -1, last_unique_frame = -1;
+
+	void handle()
+	{
+		if (global.empty()) { unsigned char g[16]; new_guid(g); meta_add(global, MTAG_CLIP_GUID, 'G', 16, g); }
+		time_t clock = time(NULL);
+		struct tm tmv; localtime_r(&clock, &tmv);
+		char datestr[32], timestr[32], tmp[32];
+		snprintf(datestr, sizeof(datestr), "%04d-%02d-%02d", tmv.tm_year + 1900, tmv.tm_mon + 1, tmv.tm_mday);
+		snprintf(timestr, sizeof(timestr), "%02d:%02d:%02d", tmv.tm_hour, tmv.tm_min, tmv.tm_sec);
+		meta_add(global, MTAG_ENCODE_DATE, 'c', 10, datestr);
+		meta_add(global, MTAG_ENCODE_TIME, 'c', 8, timestr);
+
+		bool in_local = false;
+		uint32_t sz; unsigned char ty;
+		const uint8_t *data = meta_find(global.data(), global.size(), MTAG_TIMECODE, &sz, &ty);
+		if (!data) {
+			data = meta_find(local.data(), local.size(), MTAG_TIMECODE, &sz, &ty);
+			if (!data) {
+				last_timecode_base = 24;
+				last_timecode_frame = tmv.tm_hour * 3600 * 24 + tmv.tm_min * 60 * 24 + tmv.tm_sec * 24;
+				snprintf(tmp, sizeof(tmp), "%02d:%02d:%02d:00", tmv.tm_hour, tmv.tm_min, tmv.tm_sec);
+				meta_add(global, MTAG_TIMECODE, 'c', 11, tmp);
+			} else in_local = true;
+		}
+		if (data) {
+			const char *tc = (const char *)data;
+			int hours = (tc[0] - '0') * 10 + (tc[1] - '0'), mins = (tc[3] - '0') * 10 + (tc[4] - '0');
+			int secs = (tc[6] - '0') * 10 + (tc[7] - '0'), frms = (tc[9] - '0') * 10 + (tc[10] - '0');
+			if (last_timecode_base == 0) {
+				const uint8_t *b = meta_find(local.data(), local.size(), MTAG_TIMECODE_BASE, &sz, &ty);
+				if (!b) b = meta_find(global.data(), global.size(), MTAG_TIMECODE_BASE, &sz, &ty);
+				last_timecode_base = b ? *b : 24;
+				if (last_timecode_base == 0) last_timecode_base = 24;
+			}
+			int base = last_timecode_base;
+			int framenum = hours * 3600 * base + mins * 60 * base + secs * base + frms;
+			if (last_timecode_frame == -1) last_timecode_frame = framenum;
+			else if (framenum == last_timecode_frame && base <= 30) {
+				framenum = ++last_timecode_frame;
+				frms = framenum % base; framenum /= base;
+				secs = framenum % 60; framenum /= 60;
+				mins = framenum % 60; framenum /= 60;
+				hours = framenum % 60;
+				snprintf(tmp, sizeof(tmp), "%02d:%02d:%02d:%02d", hours, mins, secs, frms);
+				meta_add(in_local ? local : global, MTAG_TIMECODE, 'c', 11, tmp);
+			}
+		}
+		in_local = false;
+		data = meta_find(global.data(), global.size(), MTAG_UNIQUE_FRAMENUM, &sz, &ty);
+		if (!data) {
+			data = meta_find(local.data(), local.size(), MTAG_UNIQUE_FRAMENUM, &sz, &ty);
+			if (!data) { last_unique_frame = 0; uint32_t v = 0; meta_add(global, MTAG_UNIQUE_FRAMENUM, 'L', 4, &v); }
+			else in_local = true;
+		}
+		if (data) {
+			int32_t n; memcpy(&n, data, 4);
+			if (last_unique_frame == -1) last_unique_frame = n;
+			else if (n <= last_unique_frame) { uint32_t v = (uint32_t)++last_unique_frame; meta_add(in_local ? local : global, MTAG_UNIQUE_FRAMENUM, 'L', 4, &v); }
+		}
+	}
+};
+
+struct EncodeParams {
+	int width = 0, height = 0;
+	uint32_t pixel_format = 0;
+	int pixel_kind = 0, encoded_format = 0;
+	uint32_t flags = 0;
+	int quality = 0;
+	bool progressive = true;
+	int color_space = 2;
+	FramePlan plan;
+	QuantState qstate = {0, -1, 0};
+	bool valid = false;
+};
+
+int make_params(EncodeParams &p, int w, int h, uint32_t fmt, int encoded, uint32_t flags, int quality)
+{
+	p.valid = false;
+	int kind = pixel_kind_of(fmt);
+	if (kind == PIX_NONE) return ERR_BADFORMAT;
+	if (encoded != 0) return ERR_BADFORMAT;                               // CFHD_ENCODED_FORMAT_YUV_422 only (round 1 scope)
+	if (flags & (1u << 0)) return ERR_BADFORMAT;                          // interlaced: not built yet
+	if (flags & (1u << 1)) return ERR_BADFORMAT;                          // 2-frame GOP: out of scope
+	p.width = w; p.height = h; p.pixel_format = fmt; p.pixel_kind = kind; p.encoded_format = ENC_YUV422; p.flags = flags;
+	p.quality = quality; p.progressive = true;
+	const int yuv601 = (flags & (1u << 2)) ? 1 : 2, vsrgb = (flags & (1u << 8)) ? 2 : 1;   // SampleEncoder.cpp:210-212
+	p.color_space = (yuv601 == 1 ? 1 : 2) | (vsrgb == 2 ? 4 : 0);
+	if (!build_frame_plan(&p.plan, w, h, kind, ENC_YUV422)) return ERR_BADFORMAT;
+	p.qstate = {0, -1, 0};
+	derive_quantization(&p.plan, quality, true, 0.0f, &p.qstate);
+	p.valid = true;
+	return ERR_OKAY;
+}
+
+size_t sample_capacity(const EncodeParams &p) { return (size_t)p.width * p.height * 2 + 65536; }   // SampleEncoder.cpp:387
+
+// Encode one frame on one batch slot: upload, forward kernels, coefficients back, host entropy + syntax.
+int encode_one(EncodeBatch &batch, EncodeParams &p, const void *frame, int pitch, uint32_t frame_number,
+               MetaBlock global, MetaBlock local, uint8_t *out, size_t cap, size_t *size_out)
+{
+	int rc;
+	if ((rc = batch.upload_frame(0, frame, pitch))) return ERR_INTERNAL;
+	if ((rc = batch.launch_forward())) return ERR_INTERNAL;
+	if ((rc = batch.download_coeffs())) return ERR_INTERNAL;
+	if ((rc = batch.wait())) return ERR_INTERNAL;
+	meta_remove_hidden(global); meta_remove_hidden(local);
+	SampleHeaderInfo hdr = { frame_number, color_format_of(p.pixel_kind), p.color_space, p.quality, p.progressive,
+	                         global.data(), global.size(), local.data(), local.size() };
+	BandSource src; src.coeffs = batch.host_coeffs(0);
+	size_t n = write_sample(p.plan, hdr, src, out, cap);
+	if (!n) return ERR_CODEC_ERROR;
+	*size_out = n;
+	return ERR_OKAY;
+}
+
+struct Encoder {
+	EncodeParams params;
+	MetaState meta;
+	EncodeBatch batch;
+	bool batch_ready = false;
+	uint32_t frame_number = 0;
+	std::vector<uint8_t> sample; size_t sample_size = 0;
+};
+
+// ---- async pool ----
+struct SampleBuffer { std::vector<uint8_t> data; size_t size = 0; };
+
+struct PoolJob {
+	uint32_t frame_number = 0;
+	const void *frame = nullptr; intptr_t pitch = 0;
+	MetaBlock global, local;
+	std::unique_ptr<SampleBuffer> sample;
+	int error = 0;
+	bool finished = false;
+};
+
+struct PoolWorker {
+	EncodeBatch batch;
+	uint32_t encoded = 0;                     // per-"encoder" frame counter (the reference numbers frames per CAsyncEncoder)
+	std::thread thread;
+	std::deque<std::shared_ptr<PoolJob>> inbox;
+};
+
+struct EncoderPool {
+	int nworkers = 1, queue_len = 1;
+	EncodeParams params;
+	MetaState meta;                           // pool-wide metadata (attached with CFHD_AttachEncoderPoolMetadata)
+	std::vector<std::unique_ptr<PoolWorker>> workers;
+	std::mutex m; std::condition_variable cv_work, cv_done;
+	std::deque<std::shared_ptr<PoolJob>> fifo;               // submission order
+	bool started = false, stopping = false;
+	int next_worker = 0;
+
+	void worker_loop(PoolWorker *w)
+	{
+		device_init();
+		for (;;) {
+			std::shared_ptr<PoolJob> job;
+			{
+				std::unique_lock<std::mutex> lk(m);
+				cv_work.wait(lk, [&] { return stopping || !w->inbox.empty(); });
+				if (w->inbox.empty()) return;
+				job = w->inbox.front(); w->inbox.pop_front();
+			}
+			job->sample.reset(new SampleBuffer);
+			job->sample->data.resize(sample_capacity(params));
+			EncodeParams p = params;
+			job->error = encode_one(w->batch, p, job->frame, (int)job->pitch, ++w->encoded, job->global, job->local,
+			                        job->sample->data.data(), job->sample->data.size(), &job->sample->size);
+			{
+				std::lock_guard<std::mutex> lk(m);
+				job->finished = true;
+			}
+			cv_done.notify_all();
+		}
+	}
+	void stop()
+	{
+		{ std::lock_guard<std::mutex> lk(m); stopping = true; }
+		cv_work.notify_all();
+		for (auto &w : workers) if (w->thread.joinable()) w->thread.join();
+		started = false;
+	}
+};
+
+// ---- decoder ----
+struct Decoder {
+	ParsedSample header; bool prepared = false;
+	uint32_t out_format = 0; int out_kind = 0;
+	FramePlan plan;
+	DecodeBatch batch; bool batch_ready = false;
+	uint32_t frames_decoded = 0;
+};
+
+struct DecMetadata { std::vector<uint8_t> block; size_t cursor = 0; };
+
+void plan_from_sample(const ParsedSample &ps, int out_kind, FramePlan *plan, bool *ok)
+{
+	*ok = build_frame_plan(plan, ps.width, ps.display_height, out_kind, ps.encoded_format);
+	if (!*ok) return;
+	plan->precision = ps.precision;
+	if (ps.prescale_table) for (int i = 0; i < kNumLevels; i++) plan->prescale[i] = (ps.prescale_table >> (14 - 2 * i)) & 3;
+	else { plan->prescale[0] = 0; plan->prescale[1] = ps.precision >= 10 ? 2 : 0; plan->prescale[2] = ps.precision == 12 ? 2 : 0; }
+	if (plan->height != ps.height) *ok = false;
+}
+
+} // namespace
+
+extern "C" {
+
+int cfhd_amd_device_count(void) { return device_count(); }
+void cfhd_amd_set_clip_guid(const unsigned char guid[16])
+{
+	std::lock_guard<std::mutex> lk(g_guid_mutex);
+	if (guid) { memcpy(g_guid, guid, 16); g_guid_fixed = true; } else g_guid_fixed = false;
+}
+const char *cfhd_amd_last_error(void) { return device_last_error(); }
+
+// =============================================================================================
+// Synchronous encoder
+// =============================================================================================
+CFHD_Error CFHD_OpenEncoder(CFHD_EncoderRef *out, CFHD_ALLOCATOR *)
+{
+	if (!out) return ERR_INVALID_ARGUMENT;
+	Encoder *e = new (std::nothrow) Encoder;
+	if (!e) return ERR_OUTOFMEMORY;
+	*out = e;
+	return ERR_OKAY;
+}
+
+CFHD_Error CFHD_GetInputFormats(CFHD_EncoderRef ref, CFHD_PixelFormat *arr, int len, int *count)
+{
+	if (!ref || !arr) return ERR_INVALID_ARGUMENT;
+	const uint32_t fmts[] = { FMT_YUY2, FMT_2VUY };
+	int n = 0;
+	for (; n < 2 && n < len; n++) arr[n] = fmts[n];
+	if (count) *count = n;
+	return ERR_OKAY;
+}
+
+CFHD_Error CFHD_PrepareToEncode(CFHD_EncoderRef ref, int w, int h, CFHD_PixelFormat fmt, CFHD_EncodedFormat encoded,
+                                CFHD_EncodingFlags flags, CFHD_EncodingQuality quality)
+{
+	if (!ref) return ERR_INVALID_ARGUMENT;
+	Encoder *e = (Encoder *)ref;
+	if (e->params.valid && e->params.width == w && e->params.height == h && e->params.pixel_format == fmt) {
+		// "just changing quality" (SampleEncoder.cpp:322-327)
+		e->params.quality = (int)((0xffff0000u & (uint32_t)e->params.quality) | (0xffffu & (uint32_t)quality));
+		derive_quantization(&e->params.plan, e->params.quality, true, 0.0f, &e->params.qstate);
+		e->batch_ready = false;
+		return ERR_OKAY;
+	}
+	int rc = make_params(e->params, w, h, fmt, encoded, flags, quality);
+	if (rc) return rc;
+	e->batch_ready = false;
+	e->frame_number = 0;
+	e->sample.assign(sample_capacity(e->params), 0);
+	e->sample_size = 0;
+	return ERR_OKAY;
+}
+
+CFHD_Error CFHD_SetEncodeLicense(CFHD_EncoderRef ref, unsigned char *) { return ref ? ERR_OKAY : ERR_INVALID_ARGUMENT; }
+CFHD_Error CFHD_SetEncodeLicense2(CFHD_EncoderRef ref, unsigned char *, uint32_t *level) { if (level) *level = 31; return ref ? ERR_OKAY : ERR_INVALID_ARGUMENT; }
+
+CFHD_Error CFHD_EncodeSample(CFHD_EncoderRef ref, void *frame, int pitch)
+{
+	if (!ref || !frame) return ERR_INVALID_ARGUMENT;
+	Encoder *e = (Encoder *)ref;
+	if (!e->params.valid) return ERR_CODEC_ERROR;
+	e->meta.handle();
+	if (!e->batch_ready) {
+		if (e->batch.prepare(e->params.plan, 1, true)) return ERR_INTERNAL;
+		e->batch_ready = true;
+	}
+	int rc = encode_one(e->batch, e->params, frame, pitch, ++e->frame_number, e->meta.global, e->meta.local,
+	                    e->sample.data(), e->sample.size(), &e->sample_size);
+	e->meta.local.clear();                                                // FreeLocalMetadata (CFHDEncoder.cpp:351)
+	return rc;
+}
+
+CFHD_Error CFHD_GetSampleData(CFHD_EncoderRef ref, void **data, size_t *size)
+{
+	if (!ref || !data || !size) return ERR_INVALID_ARGUMENT;
+	Encoder *e = (Encoder *)ref;
+	*data = e->sample.data(); *size = e->sample_size;
+	return ERR_OKAY;
+}
+
+CFHD_Error CFHD_CloseEncoder(CFHD_EncoderRef ref)
+{
+	if (!ref) return ERR_INVALID_ARGUMENT;
+	delete (Encoder *)ref;
+	return ERR_OKAY;
+}
+
+// =============================================================================================
+// Encoder metadata
+// =============================================================================================
+CFHD_Error CFHD_MetadataOpen(CFHD_MetadataRef *out)
+{
+	if (!out) return ERR_INVALID_ARGUMENT;
+	*out = new (std::nothrow) EncMetadata;
+	return *out ? ERR_OKAY : ERR_OUTOFMEMORY;
+}
+
+CFHD_Error CFHD_MetadataAdd(CFHD_MetadataRef ref, uint32_t tag, CFHD_MetadataType type, size_t size, uint32_t *data, bool local)
+{
+	if (!ref || tag == 0 || size == 0 || !data) return ERR_INVALID_ARGUMENT;
+	EncMetadata *m = (EncMetadata *)ref;
+	static const char ctypes[] = { 0, 'c', 'L', 'S', 'B', 'f', 'd', 'G', 'x', 'H', 0, 'h', 0 };   // CFHDEncoderMetadata.cpp:196-236
+	unsigned char ctype = (type >= 0 && type < (int)sizeof(ctypes)) ? (unsigned char)ctypes[type] : 0;
+	if (!ctype) return ERR_INVALID_ARGUMENT;
+	std::lock_guard<std::mutex> lk(m->lock);
+	m->changed = true;
+	if (m->global.empty() && tag != MTAG_CLIP_GUID && !local) { unsigned char g[16]; new_guid(g); meta_add(m->global, MTAG_CLIP_GUID, 'G', 16, g); }
+	return meta_add(local ? m->local : m->global, tag, ctype, (uint32_t)size, data) ? ERR_OKAY : ERR_UNEXPECTED;
+}
+
+CFHD_Error CFHD_MetadataAttach(CFHD_EncoderRef eref, CFHD_MetadataRef mref)
+{
+	if (!eref || !mref) return ERR_INVALID_ARGUMENT;
+	Encoder *e = (Encoder *)eref; EncMetadata *m = (EncMetadata *)mref;
+	std::lock_guard<std::mutex> lk(m->lock);
+	if (m->changed) {
+		e->meta.global = m->global;                                       // MergeMetadata (SampleEncoder.cpp:962)
+		e->meta.local = m->local;
+		m->local.clear();
+		m->changed = false;
+	}
+	return ERR_OKAY;
+}
+
+CFHD_Error CFHD_MetadataClose(CFHD_MetadataRef ref)
+{
+	if (!ref) return ERR_INVALID_ARGUMENT;
+	delete (EncMetadata *)ref;
+	return ERR_OKAY;
+}
+
+// =============================================================================================
+// Asynchronous encoder pool
+// =============================================================================================
+CFHD_Error CFHD_CreateEncoderPool(CFHD_EncoderPoolRef *out, int threads, int queue_len, CFHD_ALLOCATOR *)
+{
+	if (!out) return ERR_INVALID_ARGUMENT;
+	EncoderPool *p = new (std::nothrow) EncoderPool;
+	if (!p) return ERR_OUTOFMEMORY;
+	p->nworkers = threads > 0 ? threads : 1;
+	p->queue_len = queue_len > 0 ? queue_len : p->nworkers;
+	*out = p;
+	return ERR_OKAY;
+}
+
+CFHD_Error CFHD_GetAsyncInputFormats(CFHD_EncoderPoolRef ref, CFHD_PixelFormat *arr, int len, int *count)
+{
+	if (!ref) return ERR_INVALID_ARGUMENT;
+	return CFHD_GetInputFormats((CFHD_EncoderRef)ref, arr, len, count);
+}
+
+CFHD_Error CFHD_PrepareEncoderPool(CFHD_EncoderPoolRef ref, uint_least16_t w, uint_least16_t h, CFHD_PixelFormat fmt,
+                                   CFHD_EncodedFormat encoded, CFHD_EncodingFlags flags, CFHD_EncodingQuality quality)
+{
+	if (!ref) return ERR_INVALID_ARGUMENT;
+	EncoderPool *p = (EncoderPool *)ref;
+	if (p->started) return ERR_UNEXPECTED;
+	return make_params(p->params, w, h, fmt, encoded, flags, quality);
+}
+
+CFHD_Error CFHD_SetEncoderPoolLicense(CFHD_EncoderPoolRef ref, unsigned char *) { return ref ? ERR_OKAY : ERR_INVALID_ARGUMENT; }
+CFHD_Error CFHD_SetEncoderPoolLicense2(CFHD_EncoderPoolRef ref, unsigned char *, uint32_t *level) { if (level) *level = 31; return ref ? ERR_OKAY : ERR_INVALID_ARGUMENT; }
+
+CFHD_Error CFHD_AttachEncoderPoolMetadata(CFHD_EncoderPoolRef ref, CFHD_MetadataRef mref)
+{
+	if (!ref || !mref) return ERR_INVALID_ARGUMENT;
+	EncoderPool *p = (EncoderPool *)ref; EncMetadata *m = (EncMetadata *)mref;
+	std::lock_guard<std::mutex> lk(m->lock);
+	std::lock_guard<std::mutex> lk2(p->m);
+	p->meta.global = m->global; p->meta.local = m->local;
+	return ERR_OKAY;
+}
+
+CFHD_Error CFHD_StartEncoderPool(CFHD_EncoderPoolRef ref)
+{
+	if (!ref) return ERR_INVALID_ARGUMENT;
+	EncoderPool *p = (EncoderPool *)ref;
+	if (!p->params.valid) return ERR_ENCODING_NOT_STARTED;
+	if (p->started) return ERR_OKAY;
+	p->stopping = false;
+	p->workers.clear();
+	for (int i = 0; i < p->nworkers; i++) {
+		std::unique_ptr<PoolWorker> w(new PoolWorker);
+		if (w->batch.prepare(p->params.plan, 1, true)) return ERR_INTERNAL;
+		p->workers.push_back(std::move(w));
+	}
+	for (auto &w : p->workers) { PoolWorker *pw = w.get(); pw->thread = std::thread([p, pw] { p->worker_loop(pw); }); }
+	p->started = true;
+	return ERR_OKAY;
+}
+
+CFHD_Error CFHD_StopEncoderPool(CFHD_EncoderPoolRef ref)
+{
+	if (!ref) return ERR_INVALID_ARGUMENT;
+	((EncoderPool *)ref)->stop();
+	return ERR_OKAY;
+}
+
+CFHD_Error CFHD_EncodeAsyncSample(CFHD_EncoderPoolRef ref, uint32_t frame_number, void *frame, intptr_t pitch, CFHD_MetadataRef mref)
+{
+	if (!ref || !frame) return ERR_INVALID_ARGUMENT;
+	EncoderPool *p = (EncoderPool *)ref;
+	if (!p->started) return ERR_ENCODING_NOT_STARTED;
+	std::shared_ptr<PoolJob> job(new PoolJob);
+	job->frame_number = frame_number; job->frame = frame; job->pitch = pitch;    // the frame is borrowed, not copied (EncoderPool.cpp:262)
+	{
+		std::unique_lock<std::mutex> lk(p->m);
+		// Bounded queue: block the submitter while jobQueueLength jobs are pending (MessageQueue semantics).
+		p->cv_done.wait(lk, [&] { size_t pending = 0; for (auto &j : p->fifo) if (!j->finished) pending++; return pending < (size_t)p->queue_len + p->nworkers; });
+		if (mref) {
+			EncMetadata *m = (EncMetadata *)mref;
+			std::lock_guard<std::mutex> lk2(m->lock);
+			p->meta.global = m->global; p->meta.local = m->local; m->local.clear();
+		}
+		p->meta.handle();
+		job->global = p->meta.global; job->local = p->meta.local;
+		p->meta.local.clear();
+		p->fifo.push_back(job);
+		PoolWorker *w = p->workers[p->next_worker].get();
+		p->next_worker = (p->next_worker + 1) % p->nworkers;                      // round robin on every (key) frame, EncoderPool.cpp:281-291
+		w->inbox.push_back(job);
+	}
+	p->cv_work.notify_all();
+	return ERR_OKAY;
+}
+
+static CFHD_Error pool_pop(EncoderPool *p, uint32_t *frame_number, CFHD_SampleBufferRef *out, bool wait)
+{
+	std::unique_lock<std::mutex> lk(p->m);
+	if (p->fifo.empty()) return ERR_UNEXPECTED;
+	if (!p->fifo.front()->finished) {
+		if (!wait) return ERR_NOT_FINISHED;
+		p->cv_done.wait(lk, [&] { return p->fifo.front()->finished; });
+	}
+	std::shared_ptr<PoolJob> job = p->fifo.front();
+	p->fifo.pop_front();
+	lk.unlock();
+	p->cv_done.notify_all();
+	if (frame_number) *frame_number = job->frame_number;
+	if (job->error) return job->error;
+	if (out) *out = job->sample.release();
+	return ERR_OKAY;
+}
+
+CFHD_Error CFHD_WaitForSample(CFHD_EncoderPoolRef ref, uint32_t *frame_number, CFHD_SampleBufferRef *out)
+{
+	if (!ref) return ERR_INVALID_ARGUMENT;
+	return pool_pop((EncoderPool *)ref, frame_number, out, true);
+}
+
+CFHD_Error CFHD_TestForSample(CFHD_EncoderPoolRef ref, uint32_t *frame_number, CFHD_SampleBufferRef *out)
+{
+	if (!ref) return ERR_INVALID_ARGUMENT;
+	return pool_pop((EncoderPool *)ref, frame_number, out, false);
+}
+
+CFHD_Error CFHD_GetEncodedSample(CFHD_SampleBufferRef ref, void **data, size_t *size)
+{
+	if (!ref || !data || !size) return ERR_INVALID_ARGUMENT;
+	SampleBuffer *s = (SampleBuffer *)ref;
+	*data = s->data.data(); *size = s->size;
+	return ERR_OKAY;
+}
+
+CFHD_Error CFHD_ReleaseSampleBuffer(CFHD_EncoderPoolRef, CFHD_SampleBufferRef ref)
+{
+	if (!ref) return ERR_INVALID_ARGUMENT;
+	delete (SampleBuffer *)ref;
+	return ERR_OKAY;
+}
+
+CFHD_Error CFHD_ReleaseEncoderPool(CFHD_EncoderPoolRef ref)
+{
+	if (!ref) return ERR_INVALID_ARGUMENT;
+	EncoderPool *p = (EncoderPool *)ref;
+	p->stop();
+	delete p;
+	return ERR_OKAY;
+}
+
+// =============================================================================================
+// Decoder
+// =============================================================================================
+CFHD_Error CFHD_OpenDecoder(CFHD_DecoderRef *out, CFHD_ALLOCATOR *)
+{
+	if (!out) return ERR_INVALID_ARGUMENT;
+	*out = new (std::nothrow) Decoder;
+	return *out ? ERR_OKAY : ERR_OUTOFMEMORY;
+}
+
+CFHD_Error CFHD_GetOutputFormats(CFHD_DecoderRef ref, void *, size_t, CFHD_PixelFormat *arr, int len, int *count)
+{
+	if (!ref || !arr) return ERR_INVALID_ARGUMENT;
+	const uint32_t fmts[] = { FMT_YUY2, FMT_2VUY };
+	int n = 0;
+	for (; n < 2 && n < len; n++) arr[n] = fmts[n];
+	if (count) *count = n;
+	return ERR_OKAY;
+}
+
+CFHD_Error CFHD_GetSampleInfo(CFHD_DecoderRef ref, void *sample, size_t size, CFHD_SampleInfoTag tag, void *value, size_t buffer_size)
+{
+	if (!ref || !sample || !value || buffer_size < 4) return ERR_INVALID_ARGUMENT;
+	ParsedSample ps;
+	if (parse_sample((const uint8_t *)sample, size, &ps) < 0) return ERR_BADSAMPLE;
+	int32_t v = 0;
+	switch (tag) {
+	case 0: v = 1; break;                                 // CFHD_SAMPLE_INFO_CHANNELS (video channels: 2D)
+	case 1: v = ps.width; break;                          // CFHD_SAMPLE_DISPLAY_WIDTH
+	case 2: v = ps.display_height; break;                 // CFHD_SAMPLE_DISPLAY_HEIGHT
+	case 3: v = 1; break;                                 // CFHD_SAMPLE_KEY_FRAME (intra only)
+	case 4: v = ps.progressive; break;                    // CFHD_SAMPLE_PROGRESSIVE
+	case 5: v = ps.encoded_format; break;                 // CFHD_SAMPLE_ENCODED_FORMAT
+	case 6: v = (10 << 16) | (1 << 8) | 0; break;         // CFHD_SAMPLE_SDK_VERSION
+	case 7: v = ((ps.version >> 12) << 16) | (((ps.version >> 8) & 0xf) << 8) | (ps.version & 0xff); break;   // CFHD_SAMPLE_ENCODE_VERSION
+	default: return ERR_INVALID_ARGUMENT;
+	}
+	memcpy(value, &v, 4);
+	return ERR_OKAY;
+}
+
+CFHD_Error CFHD_PrepareToDecode(CFHD_DecoderRef ref, int, int, CFHD_PixelFormat fmt, CFHD_DecodedResolution resolution, CFHD_DecodingFlags,
+                                void *sample, size_t size, int *aw, int *ah, CFHD_PixelFormat *af)
+{
+	if (!ref || !sample) return ERR_INVALID_ARGUMENT;
+	Decoder *d = (Decoder *)ref;
+	if (parse_sample((const uint8_t *)sample, size, &d->header) < 0) return ERR_BADSAMPLE;
+	if (resolution != 1 && resolution != 0) return ERR_BAD_RESOLUTION;                 // full resolution only (round 1 scope)
+	if (d->header.encoded_format != ENC_YUV422 || d->header.transform_type != 0) return ERR_BADFORMAT;
+	int kind = pixel_kind_of(fmt);
+	if (kind == PIX_NONE) return ERR_BADFORMAT;
+	bool ok;
+	plan_from_sample(d->header, kind, &d->plan, &ok);
+	if (!ok) return ERR_BADSAMPLE;
+	d->out_format = fmt; d->out_kind = kind; d->prepared = true; d->batch_ready = false;
+	if (aw) *aw = d->header.width;
+	if (ah) *ah = d->header.display_height;
+	if (af) *af = fmt;
+	return ERR_OKAY;
+}
+
+static int pixel_size_of(uint32_t fmt)
+{
+	switch (fmt) {
+	case FOURCC_BE('Y', 'U', 'Y', '2'): case FOURCC_BE('2', 'v', 'u', 'y'): case FOURCC_BE('y', 'u', 'y', 'v'):
+	case FOURCC_BE('B', 'Y', 'R', '2'): case FOURCC_BE('B', 'Y', 'R', '4'): return 2;
+	case FOURCC_BE('R', 'G', '2', '4'): return 3;
+	case FOURCC_BE('B', 'G', 'R', 'A'): case FOURCC_BE('B', 'G', 'R', 'a'): case FOURCC_BE('r', '2', '1', '0'): case FOURCC_BE('D', 'P', 'X', '0'):
+	case FOURCC_BE('R', 'G', '3', '0'): case FOURCC_BE('A', 'B', '1', '0'): case FOURCC_BE('A', 'R', '1', '0'): case FOURCC_BE('Y', 'U', '6', '4'): return 4;
+	case FOURCC_BE('R', 'G', '4', '8'): case FOURCC_BE('W', 'P', '1', '3'): return 6;
+	case FOURCC_BE('b', '6', '4', 'a'): case FOURCC_BE('R', 'G', '6', '4'): case FOURCC_BE('W', '1', '3', 'A'): return 8;
+	default: return 0;
+	}
+}
+
+CFHD_Error CFHD_GetPixelSize(CFHD_PixelFormat fmt, uint32_t *out)
+{
+	if (!out) return ERR_INVALID_ARGUMENT;
+	*out = (uint32_t)pixel_size_of(fmt);
+	return ERR_OKAY;
+}
+
+CFHD_Error CFHD_GetImagePitch(uint32_t width, CFHD_PixelFormat fmt, int32_t *out)
+{
+	if (!out) return ERR_INVALID_ARGUMENT;
+	*out = (int32_t)(((width * (uint32_t)pixel_size_of(fmt)) + 15u) & ~15u);              // SampleDecoder.cpp:290-305
+	return ERR_OKAY;
+}
+
+CFHD_Error CFHD_GetImageSize(uint32_t width, uint32_t height, CFHD_PixelFormat fmt, CFHD_VideoSelect videoselect, CFHD_Stereo3DType stereotype, uint32_t *out)
+{
+	if (!out) return ERR_INVALID_ARGUMENT;
+	int32_t pitch; CFHD_GetImagePitch(width, fmt, &pitch);
+	uint32_t size = (uint32_t)pitch * height;
+	if (stereotype == 0 && videoselect == 3) size *= 2;
+	*out = size;
+	return ERR_OKAY;
+}
+
+CFHD_Error CFHD_DecodeSample(CFHD_DecoderRef ref, void *sample, size_t size, void *out, int32_t pitch)
+{
+	if (!ref || !sample || !out) return ERR_INVALID_ARGUMENT;
+	Decoder *d = (Decoder *)ref;
+	if (!d->prepared) return ERR_UNEXPECTED;
+	const uint8_t *s = (const uint8_t *)sample;
+	ParsedSample ps;
+	auto fail_zero = [&](int err) {                                               // decode failure zero-fills the output (decoder.c:11850-11859)
+		int rowbytes = packed_frame_pitch(d->out_kind, d->plan.width);
+		for (int r = 0; r < d->plan.display_height; r++) memset((uint8_t *)out + (ptrdiff_t)r * pitch, 0, (size_t)rowbytes);
+		return err;
+	};
+	if (parse_sample(s, size, &ps) != 0) return fail_zero(ERR_BADSAMPLE);
+	if (ps.width != d->header.width || ps.display_height != d->header.display_height || ps.encoded_format != d->header.encoded_format ||
+	    ps.num_channels != d->plan.num_channels) return fail_zero(ERR_BADSAMPLE);
+	if (!d->batch_ready) {
+		if (d->batch.prepare(d->plan, 1, d->out_kind, true)) return ERR_INTERNAL;
+		d->batch_ready = true;
+	}
+	// Entropy decode on the host into the pinned coefficient staging (dequantized values, as the reference's FSM delivers them).
+	d->batch.clear_host_coeffs(0);
+	int16_t *coeffs = d->batch.host_coeffs(0);
+	const FramePlan &plan = d->plan;
+	// The reference biases the lowpass band while unpacking it (Codec/decoder.c:12240-12290 "channeloffset"):
+	// see lowpass_bias().
+	for (int c = 0; c < plan.num_channels; c++) {
+		const ParsedBand &lp = ps.lowpass[c];
+		const BandDesc &ll = plan.ch[c].band[2][0];
+		if (!lp.present || lp.width != ll.width || lp.height != ll.height) return fail_zero(ERR_BADSAMPLE);
+		const int lowpass_offset = lowpass_bias(plan.precision, ll.width, d->out_kind);
+		for (int r = 0; r < ll.height; r++) {
+			const uint8_t *p = s + lp.offset + (size_t)r * ll.width * 2;
+			int16_t *dst = coeffs + ll.offset + (size_t)r * ll.pitch;
+			for (int x = 0; x < ll.width; x++) {
+				int v = (int16_t)((p[2 * x] << 8) | p[2 * x + 1]);
+				v += lowpass_offset;
+				dst[x] = (int16_t)(v > 0x7fff ? 0x7fff : v);
+			}
+		}
+		for (int lv = 0; lv < kNumLevels; lv++)
+			for (int b = 1; b < 4; b++) {
+				const ParsedBand &pb = ps.high[c][lv][b];
+				const BandDesc &bd = plan.ch[c].band[lv][b];
+				if (!pb.present || pb.width != bd.width || pb.height != bd.height) return fail_zero(ERR_BADSAMPLE);
+				if (vlc_decode_band(s + pb.offset, pb.bytes, bd.width, bd.height, bd.pitch, pb.quant, pb.codebook, coeffs + bd.offset)) return fail_zero(ERR_BADSAMPLE);
+			}
+	}
+	if (d->batch.upload_coeffs()) return ERR_INTERNAL;
+	if (d->batch.launch_inverse(0x2545F491u * ++d->frames_decoded)) return ERR_INTERNAL;
+	if (d->batch.download_frame(0, out, pitch)) return ERR_INTERNAL;
+	if (d->batch.wait()) return ERR_INTERNAL;
+	d->batch.finish_frame(0, out, pitch);
+	return ERR_OKAY;
+}
+
+CFHD_Error CFHD_SetLicense(CFHD_DecoderRef ref, const unsigned char *) { return ref ? ERR_OKAY : ERR_INVALID_ARGUMENT; }
+CFHD_Error CFHD_SetActiveMetadata(CFHD_DecoderRef ref, CFHD_MetadataRef, unsigned int, CFHD_MetadataType, void *, unsigned int)
+{
+	// Active-metadata image development (colour, 3D, burn-ins) is outside the hot path; the tags are accepted and ignored.
+	return ref ? ERR_OKAY : ERR_INVALID_ARGUMENT;
+}
+CFHD_Error CFHD_ClearActiveMetadata(CFHD_DecoderRef ref, CFHD_MetadataRef) { return ref ? ERR_OKAY : ERR_INVALID_ARGUMENT; }
+CFHD_Error CFHD_GetThumbnail(CFHD_DecoderRef, void *, size_t, void *, size_t, uint32_t, size_t *, size_t *, size_t *) { return ERR_BAD_RESOLUTION; }
+
+CFHD_Error CFHD_CloseDecoder(CFHD_DecoderRef ref)
+{
+	if (!ref) return ERR_INVALID_ARGUMENT;
+	delete (Decoder *)ref;
+	return ERR_OKAY;
+}
+
+// =============================================================================================
+// Decoder-side metadata access
+// =============================================================================================
+CFHD_Error CFHD_OpenMetadata(CFHD_MetadataRef *out)
+{
+	if (!out) return ERR_INVALID_ARGUMENT;
+	*out = new (std::nothrow) DecMetadata;
+	return *out ? ERR_OKAY : ERR_OUTOFMEMORY;
+}
+
+CFHD_Error CFHD_InitSampleMetadata(CFHD_MetadataRef ref, CFHD_MetadataTrack, void *sample, size_t size)
+{
+	if (!ref || !sample) return ERR_INVALID_ARGUMENT;
+	DecMetadata *m = (DecMetadata *)ref;
+	ParsedSample ps;
+	m->block.clear(); m->cursor = 0;
+	if (parse_sample((const uint8_t *)sample, size, &ps) < 0) return ERR_BADSAMPLE;
+	if (ps.metadata_bytes && ps.metadata_offset + ps.metadata_bytes <= size)
+		m->block.assign((const uint8_t *)sample + ps.metadata_offset, (const uint8_t *)sample + ps.metadata_offset + ps.metadata_bytes);
+	return ERR_OKAY;
+}
+
+static int api_type_of(unsigned char c)
+{
+	switch (c) { case 'c': return 1; case 'L': return 2; case 'S': return 3; case 'B': return 4; case 'f': return 5; case 'd': return 6;
+	case 'G': return 7; case 'x': return 8; case 'H': return 9; case 'h': return 11; default: return 0; }
+}
+
+CFHD_Error CFHD_ReadMetadata(CFHD_MetadataRef ref, unsigned int *tag, CFHD_MetadataType *type, void **data, CFHD_MetadataSize *size)
+{
+	if (!ref || !tag || !type || !data || !size) return ERR_INVALID_ARGUMENT;
+	DecMetadata *m = (DecMetadata *)ref;
+	if (m->cursor + 8 > m->block.size()) return ERR_METADATA_END;
+	uint32_t t, ts; memcpy(&t, &m->block[m->cursor], 4); memcpy(&ts, &m->block[m->cursor + 4], 4);
+	uint32_t len = ts & 0xffffff;
+	if (t == 0 || m->cursor + 8 + len > m->block.size()) return ERR_METADATA_END;
+	*tag = t; *type = api_type_of((unsigned char)(ts >> 24)); *data = &m->block[m->cursor + 8]; *size = (CFHD_MetadataSize)len;
+	m->cursor += 8 + ((len + 3) & ~3u);
+	return ERR_OKAY;
+}
+
+CFHD_Error CFHD_FindMetadata(CFHD_MetadataRef ref, unsigned int tag, CFHD_MetadataType *type, void **data, CFHD_MetadataSize *size)
+{
+	if (!ref || !type || !data || !size) return ERR_INVALID_ARGUMENT;
+	DecMetadata *m = (DecMetadata *)ref;
+	uint32_t len; unsigned char ty;
+	const uint8_t *p = meta_find(m->block.data(), m->block.size(), tag, &len, &ty);
+	if (!p) return ERR_METADATA_END;
+	*type = api_type_of(ty); *data = (void *)p; *size = (CFHD_MetadataSize)len;
+	return ERR_OKAY;
+}
+
+CFHD_Error CFHD_CloseMetadata(CFHD_MetadataRef ref)
+{
+	if (!ref) return ERR_INVALID_ARGUMENT;
+	delete (DecMetadata *)ref;
+	return ERR_OKAY;
+}
+
+} // extern "C"

@@ -263,9 +263,10 @@ int parse_sample(const uint8_t *d, size_t size, ParsedSample *ps)
 	int channel = 0, lv = -1, band = 0, bw = 0, bh = 0, bq = 1, bflags = 0, bsub = 0;
 	int lw = 0, lh = 0;
 	uint32_t pending_chunk = 0;   // bytes of the SUBBAND_SIZE chunk that was just opened
+	bool truncated = false;       // ran off the end of the supplied bytes (callers that only need the header pass 512 bytes)
 	size_t pending_at = 0;
 	auto rd = [&](size_t o) { return ((uint32_t)d[o] << 24) | ((uint32_t)d[o + 1] << 16) | ((uint32_t)d[o + 2] << 8) | d[o + 3]; };
-	while (pos + 4 <= size) {
+	while (pos + 4 <= size && !truncated) {
 		uint32_t word = rd(pos);
 		int tag = (int16_t)(word >> 16);
 		int value = (int)(word & 0xffff);
@@ -275,7 +276,7 @@ int parse_sample(const uint8_t *d, size_t size, ParsedSample *ps)
 		if (tag & 0x4000) {                       // chunks with payload (metadata, peak tables): skip the payload
 			uint32_t bytes = (tag & 0x2000) ? ((((uint32_t)(tag & 0xff) << 16) | (uint32_t)value) * 4) : (uint32_t)value * 4;
 			if ((tag == TAG_METADATA || (tag & 0xff00) == 0x6000) && ps->metadata_bytes == 0) { ps->metadata_offset = (uint32_t)pos; ps->metadata_bytes = bytes; }
-			if (pos + bytes > size) return -2;
+			if (pos + bytes > size) { truncated = true; break; }
 			pos += bytes;
 			continue;
 		}
@@ -314,7 +315,8 @@ int parse_sample(const uint8_t *d, size_t size, ParsedSample *ps)
 				pb.bytes = (uint32_t)((size_t)lw * lh * 2);
 				if (pending_chunk == 0) return -4;
 				size_t end = pending_at + pending_chunk;
-				if (end > size || pos + pb.bytes > end) return -4;
+				if (pos + pb.bytes > end) return -4;
+				if (end > size) { pb.present = false; truncated = true; break; }
 				pos = end; pending_chunk = 0;
 			}
 			break;
@@ -329,7 +331,8 @@ int parse_sample(const uint8_t *d, size_t size, ParsedSample *ps)
 			if (lv < 0 || pending_chunk == 0) return -7;
 			ParsedBand &pb = ps->high[channel][lv][band];
 			size_t end = pending_at + pending_chunk;     // chunk covers BAND_HEADER .. BAND_TRAILER
-			if (end > size || end < pos + 4) return -7;
+			if (end < pos + 4) return -7;
+			if (end > size) { truncated = true; break; }
 			pb.offset = (uint32_t)pos; pb.bytes = (uint32_t)(end - 4 - pos);
 			pb.width = bw; pb.height = bh; pb.quant = bq; pb.codebook = bflags & 0xf; pb.subband = bsub; pb.present = true;
 			pos = end; pending_chunk = 0;
@@ -339,7 +342,19 @@ int parse_sample(const uint8_t *d, size_t size, ParsedSample *ps)
 	}
 	if (ps->display_height == 0) ps->display_height = ps->height;
 	if (ps->precision == 0) ps->precision = 8;
-	return (ps->width > 0 && ps->height > 0 && ps->num_channels > 0) ? 0 : -1;
+	if (!(ps->width > 0 && ps->height > 0 && ps->num_channels > 0)) return -1;
+	return truncated ? 1 : 0;
+}
+
+int lowpass_bias(int precision, int lowpass_width, int out_pixel_kind)
+{
+	const bool even = (lowpass_width & 1) == 0;
+	if (precision == 8) return 32;
+	if (precision == 10) {
+		(void)out_pixel_kind;              // YUY2 / 2vuy here; YU64, YR16 and V210 outputs would use 4 on the even-width path
+		return even ? 24 : 5;
+	}
+	return 0;                              // 12-bit: RG48 / b64a outputs carry no bias
 }
 
 // ------------------------------------------------------------------------------------------

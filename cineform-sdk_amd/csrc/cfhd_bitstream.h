@@ -82,14 +82,17 @@ void vlc_encode_band(BitWriter &w, const int16_t *band, int width, int height, i
 struct ParsedBand { uint32_t offset, bytes; int width, height, quant, codebook, subband; bool present; };
 struct ParsedSample {
 	int width = 0, height = 0, display_height = 0, num_channels = 0, precision = 0, encoded_format = 0;
-	int input_format = 0, color_space = 0, quality = 0, prescale_table = 0, frame_number = 0, progressive = 1, version = 0;
+	int input_format = 0, color_space = 0, quality = 0, prescale_table = 0, frame_number = 0, progressive = 0, version = 0;
 	int transform_type = 0, num_spatial = 0, num_wavelets = 0;
 	ParsedBand lowpass[kMaxChannels];                     // raw 16-bit big-endian pairs
 	ParsedBand high[kMaxChannels][kNumLevels][kNumBands]; // [ch][wavelet index][band 1..3]
 	uint32_t metadata_offset = 0, metadata_bytes = 0;     // first metadata chunk
 };
-// Returns 0 on success, <0 on malformed input.
+// Returns 0 on success, 1 when the header parsed but the data ends early (header sniffing), <0 on malformed input.
 int parse_sample(const uint8_t *data, size_t size, ParsedSample *out);
+// Bias the reference decoder adds to every lowpass coefficient while unpacking it (Codec/decoder.c:12240-12290 fast path for
+// even widths, :12468-12545 bit-serial path for odd widths): depends on the sample precision and the output pixel format.
+int lowpass_bias(int precision, int lowpass_width, int out_pixel_kind);
 // Host VLC decode of one band into a zeroed band. Returns 0 on success.
 int vlc_decode_band(const uint8_t *data, size_t bytes, int width, int height, int pitch, int quant, int codebook, int16_t *band);
 

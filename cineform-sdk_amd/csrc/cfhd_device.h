@@ -1,0 +1,82 @@
+// cfhd_device.h -- GPU side of the codec: batches of frames in flight (HIP stream + HBM buffers + job tables)
+// and the launch sequences for encode (forward transform) and decode (inverse transform).
+#pragma once
+#include "cfhd_core.h"
+#include "cfhd_bitstream.h"
+#include <stdint.h>
+#include <stddef.h>
+
+namespace cfhd {
+
+// 0 on success; otherwise a hipError_t value.  The product has no CPU fallback: callers turn a failure into
+// CFHD_ERROR_INTERNAL and the message is available from device_last_error().
+int device_init();                 // picks the device from CFHD_AMD_DEVICE, else LOCAL_RANK, else 0
+int device_count();
+const char *device_last_error();
+
+// N frames that travel through the forward path together: one launch per wavelet level covers every channel of
+// every frame (blockIdx.z walks the job table).  N = 1 is the synchronous CFHD_EncodeSample path.
+class EncodeBatch {
+public:
+	EncodeBatch();
+	~EncodeBatch();
+	// own_input: allocate HBM (and pinned host staging) for the packed frames; otherwise frames are supplied as device pointers.
+	int prepare(const FramePlan &plan, int nframes, bool own_input);
+	int nframes() const { return n_; }
+	const FramePlan &plan() const { return plan_; }
+	// Stage one host frame (any pitch, negative allowed as in Codec/encoder.c:1957) and start its H2D copy.
+	int upload_frame(int i, const void *frame, int pitch_bytes);
+	// Use frames that already live in HBM (bench / device-resident callers).
+	int set_device_frame(int i, const void *d_frame, int pitch_bytes);
+	int launch_forward();                              // async: all levels, all frames
+	int download_coeffs();                             // async: final (entropy coded) region of every frame -> pinned host
+	int wait();
+	const int16_t *host_coeffs(int i) const { return h_coeff_ + (size_t)i * plan_.final_elems; }
+	int16_t *device_coeffs(int i) { return d_coeff_ + (size_t)i * plan_.coeff_elems; }
+	void *stream() { return stream_; }
+	float last_kernel_ms() const { return kernel_ms_; }   // forward kernels of the last launch (HIP events on this stream)
+private:
+	void release();
+	int sync_jobs();
+	FramePlan plan_;
+	int n_ = 0; bool own_input_ = false, jobs_dirty_ = true;
+	void *stream_ = nullptr, *ev0_ = nullptr, *ev1_ = nullptr;
+	uint8_t *d_in_ = nullptr, *h_in_ = nullptr; size_t frame_bytes_ = 0; int in_pitch_ = 0;
+	int16_t *d_coeff_ = nullptr, *h_coeff_ = nullptr;
+	void *d_jobs_ = nullptr, *h_jobs_ = nullptr; size_t jobs_bytes_ = 0;
+	float kernel_ms_ = 0;
+};
+
+class DecodeBatch {
+public:
+	DecodeBatch();
+	~DecodeBatch();
+	int prepare(const FramePlan &plan, int nframes, int out_pixel_kind, bool own_output);
+	int nframes() const { return n_; }
+	const FramePlan &plan() const { return plan_; }
+	int16_t *host_coeffs(int i) { return h_coeff_ + (size_t)i * plan_.final_elems; }   // host entropy decoder writes here
+	int16_t *device_coeffs(int i) { return d_coeff_ + (size_t)i * plan_.coeff_elems; }
+	void clear_host_coeffs(int i);
+	int upload_coeffs();                               // async: pinned host -> HBM (final region of every frame)
+	int set_device_output(int i, void *d_out, int pitch_bytes);
+	int launch_inverse(uint32_t dither_seed);          // async
+	int download_frame(int i, void *out, int pitch_bytes);   // async D2H into pinned staging, then row copy after wait
+	int wait();
+	int finish_frame(int i, void *out, int pitch_bytes);      // after wait(): copy the staged frame to the caller's buffer
+	void *stream() { return stream_; }
+	float last_kernel_ms() const { return kernel_ms_; }
+private:
+	void release();
+	int sync_jobs();
+	FramePlan plan_;
+	int n_ = 0, out_kind_ = 0; bool own_output_ = false, jobs_dirty_ = true;
+	void *stream_ = nullptr, *ev0_ = nullptr, *ev1_ = nullptr;
+	int16_t *d_coeff_ = nullptr, *h_coeff_ = nullptr;
+	uint8_t *d_out_ = nullptr, *h_out_ = nullptr; size_t frame_bytes_ = 0; int out_pitch_ = 0;
+	void *d_jobs_ = nullptr, *h_jobs_ = nullptr; size_t jobs_bytes_ = 0;
+	float kernel_ms_ = 0;
+};
+
+int packed_frame_pitch(int pixel_kind, int width);     // bytes per row of a tightly packed frame
+
+} // namespace cfhd

@@ -1,0 +1,383 @@
+// cfhd_device.hip -- HIP runtime glue: device selection, HBM/pinned buffers, job tables and kernel launches.
+//
+// Replaces the reference's per-encoder scratch + thread pool (EncoderSDK/AsyncEncoder.cpp, Codec/thread.c) with
+// HIP streams: a batch owns one stream; H2D copy, the three forward (or inverse) launches and the D2H copy are
+// queued back to back on it, batches on different streams overlap.
+#include "cfhd_device.h"
+#include "cfhd_kernels.h"
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include <stdlib.h>
+#include <stdio.h>
+#include <mutex>
+#include <string>
+
+namespace cfhd {
+
+namespace {
+std::string g_err;
+std::once_flag g_init_once;
+int g_init_rc = -1;
+int g_device = 0;
+
+int fail(hipError_t e, const char *what)
+{
+	char buf[256];
+	snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
+	g_err = buf;
+	return (int)e ? (int)e : -1;
+}
+#define HIPCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return fail(_e, #expr); } while (0)
+
+dev::QuantParam make_q(int divisor, int mpq)
+{
+	dev::QuantParam q; q.divisor = divisor; q.mid = 0; q.mult = 0;
+	if (divisor > 1) {
+		if (mpq >= 2 && mpq < 9) { q.mid = divisor / mpq; if (mpq == 2 && q.mid) q.mid--; }   // quantize.c:1415-1427
+		q.mult = ((1u << 16) / (unsigned)divisor) & 0xffffu;
+	}
+	return q;
+}
+
+struct EncJobs {            // layout of the job table buffer of an EncodeBatch
+	dev::FwdYuvJob *yuv;    // [n]
+	dev::FwdPlaneJob *l2;   // [n * nch]
+	dev::FwdPlaneJob *l3;   // [n * nch]
+};
+EncJobs enc_jobs_at(void *base, int n, int nch)
+{
+	EncJobs j;
+	j.yuv = (dev::FwdYuvJob *)base;
+	j.l2 = (dev::FwdPlaneJob *)(j.yuv + n);
+	j.l3 = j.l2 + (size_t)n * nch;
+	return j;
+}
+size_t enc_jobs_bytes(int n, int nch) { return (size_t)n * sizeof(dev::FwdYuvJob) + 2 * (size_t)n * nch * sizeof(dev::FwdPlaneJob); }
+
+struct DecJobs { dev::InvPlaneJob *l3, *l2; dev::InvYuvJob *yuv; };
+DecJobs dec_jobs_at(void *base, int n, int nch)
+{
+	DecJobs j;
+	j.l3 = (dev::InvPlaneJob *)base;
+	j.l2 = j.l3 + (size_t)n * nch;
+	j.yuv = (dev::InvYuvJob *)(j.l2 + (size_t)n * nch);
+	return j;
+}
+size_t dec_jobs_bytes(int n, int nch) { return 2 * (size_t)n * nch * sizeof(dev::InvPlaneJob) + (size_t)n * sizeof(dev::InvYuvJob); }
+} // namespace
+
+const char *device_last_error() { return g_err.c_str(); }
+
+int device_count()
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+int device_init()
+{
+	std::call_once(g_init_once, [] {
+		int n = 0;
+		hipError_t e = hipGetDeviceCount(&n);
+		if (e != hipSuccess || n <= 0) { g_err = "no HIP device available (libcfhd_amd has no CPU fallback)"; g_init_rc = e ? (int)e : -1; return; }
+		const char *env = getenv("CFHD_AMD_DEVICE");
+		if (!env) env = getenv("LOCAL_RANK");
+		g_device = env ? atoi(env) % n : 0;
+		e = hipSetDevice(g_device);
+		if (e != hipSuccess) { fail(e, "hipSetDevice"); g_init_rc = (int)e; return; }
+		g_init_rc = 0;
+	});
+	if (g_init_rc == 0) hipSetDevice(g_device);      // per calling thread
+	return g_init_rc;
+}
+
+int packed_frame_pitch(int pixel_kind, int width)
+{
+	switch (pixel_kind) {
+	case PIX_YUY2: case PIX_2VUY: return width * 2;
+	case PIX_RG48: return width * 6;
+	case PIX_B64A: return width * 8;
+	case PIX_BYR4: return width * 2;
+	default: return 0;
+	}
+}
+
+// =============================================================================================
+// EncodeBatch
+// =============================================================================================
+EncodeBatch::EncodeBatch() {}
+EncodeBatch::~EncodeBatch() { release(); }
+
+void EncodeBatch::release()
+{
+	if (stream_) hipStreamSynchronize((hipStream_t)stream_);
+	if (d_in_) hipFree(d_in_);
+	if (h_in_) hipHostFree(h_in_);
+	if (d_coeff_) hipFree(d_coeff_);
+	if (h_coeff_) hipHostFree(h_coeff_);
+	if (d_jobs_) hipFree(d_jobs_);
+	if (h_jobs_) hipHostFree(h_jobs_);
+	if (ev0_) hipEventDestroy((hipEvent_t)ev0_);
+	if (ev1_) hipEventDestroy((hipEvent_t)ev1_);
+	if (stream_) hipStreamDestroy((hipStream_t)stream_);
+	d_in_ = h_in_ = nullptr; d_coeff_ = h_coeff_ = nullptr; d_jobs_ = h_jobs_ = nullptr; stream_ = ev0_ = ev1_ = nullptr; n_ = 0;
+}
+
+int EncodeBatch::prepare(const FramePlan &plan, int nframes, bool own_input)
+{
+	int rc = device_init();
+	if (rc) return rc;
+	release();
+	if (plan.pixel_kind != PIX_YUY2 && plan.pixel_kind != PIX_2VUY) { g_err = "pixel format not supported by the GPU path yet"; return -2; }
+	plan_ = plan; n_ = nframes; own_input_ = own_input;
+	HIPCHK(hipStreamCreateWithFlags((hipStream_t *)&stream_, hipStreamNonBlocking));
+	HIPCHK(hipEventCreate((hipEvent_t *)&ev0_));
+	HIPCHK(hipEventCreate((hipEvent_t *)&ev1_));
+	in_pitch_ = packed_frame_pitch(plan.pixel_kind, plan.width);
+	frame_bytes_ = (size_t)in_pitch_ * plan.display_height;
+	if (own_input) {
+		HIPCHK(hipMalloc((void **)&d_in_, frame_bytes_ * n_));
+		HIPCHK(hipHostMalloc((void **)&h_in_, frame_bytes_ * n_, hipHostMallocDefault));
+	}
+	HIPCHK(hipMalloc((void **)&d_coeff_, (size_t)plan.coeff_elems * 2 * n_));
+	HIPCHK(hipMemsetAsync(d_coeff_, 0, (size_t)plan.coeff_elems * 2 * n_, (hipStream_t)stream_));   // pad columns stay zero forever
+	HIPCHK(hipHostMalloc((void **)&h_coeff_, (size_t)plan.final_elems * 2 * n_, hipHostMallocDefault));
+	jobs_bytes_ = enc_jobs_bytes(n_, plan.num_channels);
+	HIPCHK(hipMalloc(&d_jobs_, jobs_bytes_));
+	HIPCHK(hipHostMalloc(&h_jobs_, jobs_bytes_, hipHostMallocDefault));
+	memset(h_jobs_, 0, jobs_bytes_);
+
+	const int nch = plan.num_channels, mpq = plan.midpoint_prequant;
+	EncJobs j = enc_jobs_at(h_jobs_, n_, nch);
+	for (int i = 0; i < n_; i++) {
+		int16_t *base = d_coeff_ + (size_t)i * plan.coeff_elems;
+		dev::FwdYuvJob &y = j.yuv[i];
+		y.in = own_input ? d_in_ + frame_bytes_ * i : nullptr; y.in_pitch = in_pitch_;
+		y.width = plan.width; y.height = plan.height; y.display_height = plan.display_height;
+		y.uyvy = plan.pixel_kind == PIX_2VUY; y.shift = plan.precision - 8;
+		for (int c = 0; c < 3; c++) {
+			y.out_pitch[c] = plan.ch[c].band[0][0].pitch;
+			for (int b = 0; b < 4; b++) { y.out[c][b] = base + plan.ch[c].band[0][b].offset; y.q[c][b] = make_q(plan.ch[c].band[0][b].quant, mpq); }
+		}
+		for (int lv = 1; lv < 3; lv++)
+			for (int c = 0; c < nch; c++) {
+				dev::FwdPlaneJob &p = (lv == 1 ? j.l2 : j.l3)[(size_t)i * nch + c];
+				const BandDesc &src = plan.ch[c].band[lv - 1][0];
+				p.in = base + src.offset; p.in_pitch = src.pitch; p.width = src.width; p.height = src.height; p.prescale = plan.prescale[lv];
+				p.out_pitch = plan.ch[c].band[lv][0].pitch;
+				for (int b = 0; b < 4; b++) { p.out[b] = base + plan.ch[c].band[lv][b].offset; p.q[b] = make_q(plan.ch[c].band[lv][b].quant, mpq); }
+			}
+	}
+	jobs_dirty_ = true;
+	return 0;
+}
+
+int EncodeBatch::sync_jobs()
+{
+	if (!jobs_dirty_) return 0;
+	HIPCHK(hipMemcpyAsync(d_jobs_, h_jobs_, jobs_bytes_, hipMemcpyHostToDevice, (hipStream_t)stream_));
+	jobs_dirty_ = false;
+	return 0;
+}
+
+int EncodeBatch::upload_frame(int i, const void *frame, int pitch)
+{
+	if (!own_input_ || i < 0 || i >= n_) return -1;
+	const uint8_t *src = (const uint8_t *)frame;
+	if (pitch < 0) { src += (ptrdiff_t)(plan_.display_height - 1) * pitch; pitch = -pitch; }     // encoder.c:1957
+	uint8_t *dst = h_in_ + frame_bytes_ * i;
+	if (pitch == in_pitch_) memcpy(dst, src, frame_bytes_);
+	else for (int r = 0; r < plan_.display_height; r++) memcpy(dst + (size_t)r * in_pitch_, src + (size_t)r * pitch, (size_t)in_pitch_);
+	HIPCHK(hipMemcpyAsync(d_in_ + frame_bytes_ * i, dst, frame_bytes_, hipMemcpyHostToDevice, (hipStream_t)stream_));
+	return 0;
+}
+
+int EncodeBatch::set_device_frame(int i, const void *d_frame, int pitch)
+{
+	if (i < 0 || i >= n_) return -1;
+	EncJobs j = enc_jobs_at(h_jobs_, n_, plan_.num_channels);
+	if (j.yuv[i].in != d_frame || j.yuv[i].in_pitch != pitch) { j.yuv[i].in = (const uint8_t *)d_frame; j.yuv[i].in_pitch = pitch; jobs_dirty_ = true; }
+	return 0;
+}
+
+int EncodeBatch::launch_forward()
+{
+	int rc = sync_jobs();
+	if (rc) return rc;
+	hipStream_t st = (hipStream_t)stream_;
+	const int nch = plan_.num_channels;
+	EncJobs j = enc_jobs_at(d_jobs_, n_, nch);
+	HIPCHK(hipEventRecord((hipEvent_t)ev0_, st));
+	{
+		dim3 grid((plan_.width / 2 + dev::TW - 1) / dev::TW, (plan_.height / 2 + dev::TH - 1) / dev::TH, n_);
+		dev::k_fwd_yuv422<<<grid, dev::NTHREADS, 0, st>>>(j.yuv);
+	}
+	for (int lv = 1; lv < 3; lv++) {
+		const BandDesc &src = plan_.ch[0].band[lv - 1][0];     // luma is the widest plane of the level
+		dim3 grid((src.width / 2 + dev::TW - 1) / dev::TW, (src.height / 2 + dev::TH - 1) / dev::TH, n_ * nch);
+		dev::k_fwd_plane<<<grid, dev::NTHREADS, 0, st>>>(lv == 1 ? j.l2 : j.l3);
+	}
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipEventRecord((hipEvent_t)ev1_, st));
+	return 0;
+}
+
+int EncodeBatch::download_coeffs()
+{
+	HIPCHK(hipMemcpy2DAsync(h_coeff_, (size_t)plan_.final_elems * 2, d_coeff_, (size_t)plan_.coeff_elems * 2,
+	                        (size_t)plan_.final_elems * 2, n_, hipMemcpyDeviceToHost, (hipStream_t)stream_));
+	return 0;
+}
+
+int EncodeBatch::wait()
+{
+	HIPCHK(hipStreamSynchronize((hipStream_t)stream_));
+	float ms = 0;
+	if (hipEventElapsedTime(&ms, (hipEvent_t)ev0_, (hipEvent_t)ev1_) == hipSuccess) kernel_ms_ = ms;
+	return 0;
+}
+
+// =============================================================================================
+// DecodeBatch
+// =============================================================================================
+DecodeBatch::DecodeBatch() {}
+DecodeBatch::~DecodeBatch() { release(); }
+
+void DecodeBatch::release()
+{
+	if (stream_) hipStreamSynchronize((hipStream_t)stream_);
+	if (d_out_) hipFree(d_out_);
+	if (h_out_) hipHostFree(h_out_);
+	if (d_coeff_) hipFree(d_coeff_);
+	if (h_coeff_) hipHostFree(h_coeff_);
+	if (d_jobs_) hipFree(d_jobs_);
+	if (h_jobs_) hipHostFree(h_jobs_);
+	if (ev0_) hipEventDestroy((hipEvent_t)ev0_);
+	if (ev1_) hipEventDestroy((hipEvent_t)ev1_);
+	if (stream_) hipStreamDestroy((hipStream_t)stream_);
+	d_out_ = h_out_ = nullptr; d_coeff_ = h_coeff_ = nullptr; d_jobs_ = h_jobs_ = nullptr; stream_ = ev0_ = ev1_ = nullptr; n_ = 0;
+}
+
+int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool own_output)
+{
+	int rc = device_init();
+	if (rc) return rc;
+	release();
+	if ((out_kind != PIX_YUY2 && out_kind != PIX_2VUY) || plan.encoded_format != ENC_YUV422) { g_err = "output format not supported by the GPU path yet"; return -2; }
+	plan_ = plan; n_ = nframes; out_kind_ = out_kind; own_output_ = own_output;
+	HIPCHK(hipStreamCreateWithFlags((hipStream_t *)&stream_, hipStreamNonBlocking));
+	HIPCHK(hipEventCreate((hipEvent_t *)&ev0_));
+	HIPCHK(hipEventCreate((hipEvent_t *)&ev1_));
+	out_pitch_ = packed_frame_pitch(out_kind, plan.width);
+	frame_bytes_ = (size_t)out_pitch_ * plan.display_height;
+	if (own_output) {
+		HIPCHK(hipMalloc((void **)&d_out_, frame_bytes_ * n_));
+		HIPCHK(hipHostMalloc((void **)&h_out_, frame_bytes_ * n_, hipHostMallocDefault));
+	}
+	HIPCHK(hipMalloc((void **)&d_coeff_, (size_t)plan.coeff_elems * 2 * n_));
+	HIPCHK(hipMemsetAsync(d_coeff_, 0, (size_t)plan.coeff_elems * 2 * n_, (hipStream_t)stream_));
+	HIPCHK(hipHostMalloc((void **)&h_coeff_, (size_t)plan.final_elems * 2 * n_, hipHostMallocDefault));
+	memset(h_coeff_, 0, (size_t)plan.final_elems * 2 * n_);
+	jobs_bytes_ = dec_jobs_bytes(n_, plan.num_channels);
+	HIPCHK(hipMalloc(&d_jobs_, jobs_bytes_));
+	HIPCHK(hipHostMalloc(&h_jobs_, jobs_bytes_, hipHostMallocDefault));
+	memset(h_jobs_, 0, jobs_bytes_);
+
+	const int nch = plan.num_channels;
+	DecJobs j = dec_jobs_at(h_jobs_, n_, nch);
+	for (int i = 0; i < n_; i++) {
+		int16_t *base = d_coeff_ + (size_t)i * plan.coeff_elems;
+		for (int lv = 2; lv >= 1; lv--)
+			for (int c = 0; c < nch; c++) {
+				dev::InvPlaneJob &p = (lv == 2 ? j.l3 : j.l2)[(size_t)i * nch + c];
+				for (int b = 0; b < 4; b++) p.band[b] = base + plan.ch[c].band[lv][b].offset;
+				p.band_pitch = plan.ch[c].band[lv][0].pitch;
+				p.width = plan.ch[c].band[lv][0].width; p.height = plan.ch[c].band[lv][0].height;
+				p.descale = plan.prescale[lv];                                  // wavelet.c:5685: prescaled levels use the Descale variant
+				p.out = base + plan.ch[c].band[lv - 1][0].offset; p.out_pitch = plan.ch[c].band[lv - 1][0].pitch;
+			}
+		dev::InvYuvJob &y = j.yuv[i];
+		for (int c = 0; c < 3; c++) { y.band_pitch[c] = plan.ch[c].band[0][0].pitch; for (int b = 0; b < 4; b++) y.band[c][b] = base + plan.ch[c].band[0][b].offset; }
+		y.width = plan.ch[0].band[0][0].width; y.height = plan.ch[0].band[0][0].height; y.display_height = plan.display_height;
+		y.uyvy = out_kind == PIX_2VUY; y.shift = plan.precision - 8; y.dither_seed = 0x9E3779B9u * (uint32_t)(i + 1);
+		y.out = own_output ? d_out_ + frame_bytes_ * i : nullptr; y.out_pitch = out_pitch_;
+	}
+	jobs_dirty_ = true;
+	return 0;
+}
+
+int DecodeBatch::sync_jobs()
+{
+	if (!jobs_dirty_) return 0;
+	HIPCHK(hipMemcpyAsync(d_jobs_, h_jobs_, jobs_bytes_, hipMemcpyHostToDevice, (hipStream_t)stream_));
+	jobs_dirty_ = false;
+	return 0;
+}
+
+void DecodeBatch::clear_host_coeffs(int i) { memset(h_coeff_ + (size_t)i * plan_.final_elems, 0, (size_t)plan_.final_elems * 2); }
+
+int DecodeBatch::upload_coeffs()
+{
+	HIPCHK(hipMemcpy2DAsync(d_coeff_, (size_t)plan_.coeff_elems * 2, h_coeff_, (size_t)plan_.final_elems * 2,
+	                        (size_t)plan_.final_elems * 2, n_, hipMemcpyHostToDevice, (hipStream_t)stream_));
+	return 0;
+}
+
+int DecodeBatch::set_device_output(int i, void *d_out, int pitch)
+{
+	if (i < 0 || i >= n_) return -1;
+	DecJobs j = dec_jobs_at(h_jobs_, n_, plan_.num_channels);
+	if (j.yuv[i].out != d_out || j.yuv[i].out_pitch != pitch) { j.yuv[i].out = (uint8_t *)d_out; j.yuv[i].out_pitch = pitch; jobs_dirty_ = true; }
+	return 0;
+}
+
+int DecodeBatch::launch_inverse(uint32_t dither_seed)
+{
+	int rc = sync_jobs();
+	if (rc) return rc;
+	hipStream_t st = (hipStream_t)stream_;
+	const int nch = plan_.num_channels;
+	DecJobs j = dec_jobs_at(d_jobs_, n_, nch);
+	HIPCHK(hipEventRecord((hipEvent_t)ev0_, st));
+	for (int lv = 2; lv >= 1; lv--) {
+		const BandDesc &b = plan_.ch[0].band[lv][0];
+		dim3 grid((b.width + dev::ITW - 1) / dev::ITW, (b.height + dev::ITH - 1) / dev::ITH, n_ * nch);
+		dev::k_inv_plane<<<grid, dev::NTHREADS, 0, st>>>(lv == 2 ? j.l3 : j.l2);
+	}
+	{
+		const BandDesc &b = plan_.ch[0].band[0][0];
+		dim3 grid((b.width + dev::ITW - 1) / dev::ITW, (b.height + dev::ITH - 1) / dev::ITH, n_);
+		dev::k_inv_yuv422<<<grid, dev::NTHREADS, 0, st>>>(j.yuv, dither_seed);
+	}
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipEventRecord((hipEvent_t)ev1_, st));
+	return 0;
+}
+
+int DecodeBatch::download_frame(int i, void *, int)
+{
+	if (!own_output_ || i < 0 || i >= n_) return -1;
+	HIPCHK(hipMemcpyAsync(h_out_ + frame_bytes_ * i, d_out_ + frame_bytes_ * i, frame_bytes_, hipMemcpyDeviceToHost, (hipStream_t)stream_));
+	return 0;
+}
+
+int DecodeBatch::wait()
+{
+	HIPCHK(hipStreamSynchronize((hipStream_t)stream_));
+	float ms = 0;
+	if (hipEventElapsedTime(&ms, (hipEvent_t)ev0_, (hipEvent_t)ev1_) == hipSuccess) kernel_ms_ = ms;
+	return 0;
+}
+
+int DecodeBatch::finish_frame(int i, void *out, int pitch)
+{
+	if (!own_output_ || i < 0 || i >= n_) return -1;
+	const uint8_t *src = h_out_ + frame_bytes_ * i;
+	uint8_t *dst = (uint8_t *)out;
+	if (pitch == out_pitch_) memcpy(dst, src, frame_bytes_);
+	else for (int r = 0; r < plan_.display_height; r++) memcpy(dst + (ptrdiff_t)r * pitch, src + (size_t)r * out_pitch_, (size_t)out_pitch_);
+	return 0;
+}
+
+} // namespace cfhd

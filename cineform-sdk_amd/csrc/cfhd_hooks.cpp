@@ -47,11 +47,11 @@ size_t cfhd_amd_write_sample_host(int width, int height, int pixel_kind, int enc
 
 // Parse a sample and entropy-decode every band on the host into a pyramid laid out per the plan
 // (highpass values already multiplied by their quant, as the reference's FSM decoder delivers them).
-int cfhd_amd_decode_bands_host(const uint8_t *sample, size_t size, int pixel_kind, int16_t *coeffs, size_t coeff_elems, int *info /*8 ints*/)
+int cfhd_amd_decode_bands_host(const uint8_t *sample, size_t size, int pixel_kind, int16_t *coeffs, size_t coeff_elems, int *info /*8 ints*/, int apply_lowpass_bias)
 {
 	ParsedSample ps;
 	int rc = parse_sample(sample, size, &ps);
-	if (rc) return rc;
+	if (rc) return rc < 0 ? rc : -30;
 	FramePlan plan;
 	if (!build_frame_plan(&plan, ps.width, ps.display_height, pixel_kind, ps.encoded_format)) return -20;
 	if (coeff_elems < plan.coeff_elems) return -21;
@@ -62,10 +62,13 @@ int cfhd_amd_decode_bands_host(const uint8_t *sample, size_t size, int pixel_kin
 		const ParsedBand &lp = ps.lowpass[c];
 		const BandDesc &ll = plan.ch[c].band[2][0];
 		if (!lp.present || lp.width != ll.width || lp.height != ll.height) return -22;
+		const int lowpass_offset = apply_lowpass_bias ? lowpass_bias(plan.precision, ll.width, pixel_kind) : 0;
 		for (int r = 0; r < ll.height; r++)
 			for (int x = 0; x < ll.width; x++) {
 				const uint8_t *p = sample + lp.offset + ((size_t)r * ll.width + x) * 2;
-				coeffs[ll.offset + (size_t)r * ll.pitch + x] = (int16_t)((p[0] << 8) | p[1]);
+				int v = (int16_t)((p[0] << 8) | p[1]);
+				v += lowpass_offset;                      // Codec/decoder.c:12240-12290 channeloffset
+				coeffs[ll.offset + (size_t)r * ll.pitch + x] = (int16_t)(v > 0x7fff ? 0x7fff : v);
 			}
 		for (int lv = 0; lv < kNumLevels; lv++)
 			for (int b = 1; b < 4; b++) {

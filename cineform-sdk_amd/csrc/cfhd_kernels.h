@@ -62,7 +62,7 @@ struct InvYuvJob {
 	int width, height;                      // luma band dimensions (chroma bands are width/2)
 	int display_height;                     // output rows
 	int uyvy, shift;
-	uint32_t dither_seed;
+	uint32_t dither_seed;                   // per frame; the kernel xors in its launch-wide seed
 	uint8_t *out; int out_pitch;            // bytes
 };
 
@@ -393,9 +393,10 @@ __device__ __forceinline__ int dither_bit(uint32_t seed, int row, int lane)
 	return (int)(x & 1u);
 }
 
-__global__ void __launch_bounds__(NTHREADS) k_inv_yuv422(const InvYuvJob *jobs)
+__global__ void __launch_bounds__(NTHREADS) k_inv_yuv422(const InvYuvJob *jobs, uint32_t launch_seed)
 {
 	const InvYuvJob &job = jobs[blockIdx.z];
+	const uint32_t seed = job.dither_seed ^ launch_seed;
 	const int w = job.width, h = job.height;          // luma band ; chroma bands are w/2 wide
 	const int c0 = blockIdx.x * ITW, r0 = blockIdx.y * ITH;
 	__shared__ int16_t s_y[2][2][ITH][ICOLS];
@@ -463,10 +464,10 @@ __global__ void __launch_bounds__(NTHREADS) k_inv_yuv422(const InvYuvJob *jobs)
 			for (int k = 0; k < 2; k++) {
 				// byte lanes within a 16-byte output group decide the dither lane (the reference uses one random bit per SIMD lane)
 				int lane = ((4 * cc + 2 * k) & 7) * 2;
-				uint32_t y0 = to8(yv[2 * k], sh, sh >= 2 ? dither_bit(job.dither_seed, orow, lane) : 0);
-				uint32_t y1 = to8(yv[2 * k + 1], sh, sh >= 2 ? dither_bit(job.dither_seed, orow, lane + 1) : 0);
-				uint32_t u = to8(uv[k], sh, sh >= 2 ? dither_bit(job.dither_seed, orow, 16 + ((2 * cc + k) & 7)) : 0);
-				uint32_t v = to8(vv[k], sh, sh >= 2 ? dither_bit(job.dither_seed, orow, 24 + ((2 * cc + k) & 7)) : 0);
+				uint32_t y0 = to8(yv[2 * k], sh, sh >= 2 ? dither_bit(seed, orow, lane) : 0);
+				uint32_t y1 = to8(yv[2 * k + 1], sh, sh >= 2 ? dither_bit(seed, orow, lane + 1) : 0);
+				uint32_t u = to8(uv[k], sh, sh >= 2 ? dither_bit(seed, orow, 16 + ((2 * cc + k) & 7)) : 0);
+				uint32_t v = to8(vv[k], sh, sh >= 2 ? dither_bit(seed, orow, 24 + ((2 * cc + k) & 7)) : 0);
 				px[k] = job.uyvy ? (u | (y0 << 8) | (v << 16) | (y1 << 24)) : (y0 | (u << 8) | (y1 << 16) | (v << 24));
 			}
 			uint2 o2; o2.x = px[0]; o2.y = px[1];

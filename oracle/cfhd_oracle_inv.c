@@ -89,9 +89,13 @@ void orc_inv_spatial(PIXEL16 *const bands[4], int band_pitch, int w, int h, int 
  * +2048 / subs_epu16 pair (InvertHorizontalStrip16s.c:4086-4089); then (v>>1 + dither) >> shift,
  * clamped to 8 bits (packus :4620 / SATURATE_8U :4880).  dither is rand()&mask per SIMD lane in the
  * reference (:3869-3893); the oracle takes it as an explicit 0/1 input so both extremes can be checked. */
+static int g_debug_raw = 0;            /* test hook: deliver ((v>>1) & 0xff) instead of the 8-bit pixel, see orc_debug_raw */
+void orc_debug_raw(int mode) { g_debug_raw = mode; }
 static inline int to8(int v, int shift, int dither)
 {
 	int x;
+	if (g_debug_raw == 1) return (v >> 1) & 0xff;          /* low byte of the 10-bit value */
+	if (g_debug_raw == 2) return ((v >> 1) >> 8) & 0xff;   /* high byte of the 10-bit value */
 	if (v < 0) v = 0;
 	x = ((v >> 1) + dither) >> shift;
 	return x < 0 ? 0 : (x > 255 ? 255 : x);

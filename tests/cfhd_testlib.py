@@ -174,7 +174,7 @@ def product():
         L = ctypes.CDLL(PRODUCT_SO)
         L.cfhd_amd_write_sample_host.restype = ctypes.c_size_t
         L.cfhd_amd_write_sample_host.argtypes = [ctypes.c_int] * 8 + [ctypes.c_uint, c_i16p, c_u8p, ctypes.c_size_t, c_u8p, ctypes.c_size_t, c_u8p, ctypes.c_size_t]
-        L.cfhd_amd_decode_bands_host.argtypes = [c_u8p, ctypes.c_size_t, ctypes.c_int, c_i16p, ctypes.c_size_t, c_intp]
+        L.cfhd_amd_decode_bands_host.argtypes = [c_u8p, ctypes.c_size_t, ctypes.c_int, c_i16p, ctypes.c_size_t, c_intp, ctypes.c_int]
         _product = L
     return _product
 
@@ -272,3 +272,85 @@ def emu():
                                    "-I" + os.path.join(PRODUCT_DIR, "csrc"), src, "-o", EMU_SO])
         _emu = ctypes.CDLL(EMU_SO)
     return _emu
+
+
+# ------------------------------------------------------------------------------------------
+# product C ABI (CFHD_* entry points of libcfhd_amd.so) -- needs a GPU
+# ------------------------------------------------------------------------------------------
+def amd_encode_frames(frames, pitch, width, height, pixfmt=PIX_YUY2, encoded=ENCODED_YUV422, quality=QUALITY_FILMSCAN1, flags=0):
+    L = product()
+    enc = ctypes.c_void_p()
+    assert L.CFHD_OpenEncoder(ctypes.byref(enc), None) == 0
+    rc = L.CFHD_PrepareToEncode(enc, width, height, pixfmt, encoded, flags, quality)
+    assert rc == 0, "CFHD_PrepareToEncode -> %d" % rc
+    out = []
+    for f in frames:
+        rc = L.CFHD_EncodeSample(enc, f.ctypes.data_as(ctypes.c_void_p), pitch)
+        assert rc == 0, "CFHD_EncodeSample -> %d (%s)" % (rc, amd_last_error())
+        p = ctypes.c_void_p(); n = ctypes.c_size_t()
+        assert L.CFHD_GetSampleData(enc, ctypes.byref(p), ctypes.byref(n)) == 0
+        out.append(ctypes.string_at(p, n.value))
+    L.CFHD_CloseEncoder(enc)
+    return out
+
+
+def amd_last_error():
+    L = product()
+    L.cfhd_amd_last_error.restype = ctypes.c_char_p
+    return (L.cfhd_amd_last_error() or b"").decode()
+
+
+def amd_decode_sample(sample, pixfmt=PIX_YUY2, pitch=None, decoder=None):
+    L = product()
+    dec = decoder or ctypes.c_void_p()
+    if decoder is None:
+        assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
+    aw = ctypes.c_int(); ah = ctypes.c_int(); af = ctypes.c_uint32()
+    sb = ctypes.create_string_buffer(sample, len(sample))
+    rc = L.CFHD_PrepareToDecode(dec, 0, 0, pixfmt, 1, 0, sb, 512, ctypes.byref(aw), ctypes.byref(ah), ctypes.byref(af))
+    assert rc == 0, "CFHD_PrepareToDecode -> %d" % rc
+    p = ctypes.c_int32()
+    assert L.CFHD_GetImagePitch(aw.value, af.value, ctypes.byref(p)) == 0
+    pitch = pitch or p.value
+    out = np.zeros(pitch * ah.value, dtype=np.uint8)
+    rc = L.CFHD_DecodeSample(dec, sb, len(sample), out.ctypes.data_as(ctypes.c_void_p), pitch)
+    assert rc == 0, "CFHD_DecodeSample -> %d (%s)" % (rc, amd_last_error())
+    if decoder is None:
+        L.CFHD_CloseDecoder(dec)
+    return out, pitch, aw.value, ah.value
+
+
+def host_decode_pyramid(sample, plan, lowpass_offset=1):
+    """Dequantized coefficient pyramid of a sample via the product's host parser + VLC decoder (CPU only).
+    lowpass_offset=1 applies the bias the reference decoder adds to the lowpass band (Codec/decoder.c:12240-12290,
+    :12468-12545: +24 / +5 for even / odd lowpass widths of 10-bit intra frames); pass 0 for the raw coefficients."""
+    out = np.zeros(plan.coeff_elems, dtype=np.int16)
+    info = (ctypes.c_int * 8)()
+    s = np.frombuffer(sample, dtype=np.uint8).copy()
+    rc = product().cfhd_amd_decode_bands_host(p8(s), len(sample), plan.pixkind, p16(out), out.size, info, lowpass_offset)
+    assert rc == 0, rc
+    return out
+
+
+def oracle_inverse_yuv422(plan, coeffs, dither, uyvy=0):
+    """Whole inverse path with the oracle from a dequantized pyramid (product layout) to packed 4:2:2."""
+    O = oracle()
+    work = coeffs.copy()
+    for c in range(3):
+        for lv in (2, 1):
+            d = plan.band[(c, lv, 0)]
+            bands = (c_i16p * 4)(*[plan.view(work, c, lv, b).ctypes.data_as(c_i16p) for b in range(4)])
+            dst = plan.view(work, c, lv - 1, 0)
+            O.orc_inv_spatial(bands, d["pitch"], d["width"], d["height"], plan.prescale[lv], dst.ctypes.data_as(c_i16p), plan.band[(c, lv - 1, 0)]["pitch"])
+    ptrs = (c_i16p * 12)(*[plan.view(work, c, 0, b).ctypes.data_as(c_i16p) for c in range(3) for b in range(4)])
+    pitches = [plan.band[(c, 0, 0)]["pitch"] for c in range(3)]
+    w = plan.band[(0, 0, 0)]["width"]; h = plan.band[(0, 0, 0)]["height"]
+    out = np.zeros((2 * h, 4 * w), np.uint8)
+    O.orc_inv_spatial_to_yuv422(ptrs, iarr(pitches), w, h, plan.precision, uyvy, dither, p8(out), 4 * w)
+    return out
+
+
+def psnr_yuy2(a, b):
+    d = a.astype(np.float64) - b.astype(np.float64)
+    mse = np.mean(d * d)
+    return 99.0 if mse == 0 else 10 * np.log10(255.0 * 255.0 / mse)

@@ -59,7 +59,7 @@ void emu_inv_yuv422(int16_t **bands /*[3][4]*/, const int *band_pitch, int w, in
 	job.width = w; job.height = h; job.display_height = display_height; job.uyvy = uyvy; job.shift = shift;
 	job.dither_seed = dither_seed; job.out = out; job.out_pitch = out_pitch;
 	dim3 grid((w + ITW - 1) / ITW, (h + ITH - 1) / ITH, 1);
-	hipemu::launch(grid, dim3(NTHREADS), [&] { k_inv_yuv422(&job); });
+	hipemu::launch(grid, dim3(NTHREADS), [&] { k_inv_yuv422(&job, 0u); });
 }
 
 } // extern "C"

@@ -59,7 +59,7 @@ def test_parse_and_host_decode_roundtrip(w, h):
     out = np.zeros(plan.coeff_elems, dtype=np.int16)
     info = (ctypes.c_int * 8)()
     s = np.frombuffer(sample, dtype=np.uint8).copy()
-    rc = product().cfhd_amd_decode_bands_host(p8(s), len(sample), 1, p16(out), out.size, info)
+    rc = product().cfhd_amd_decode_bands_host(p8(s), len(sample), 1, p16(out), out.size, info, 0)
     assert rc == 0
     assert list(info)[:5] == [w, plan.height, h, 3, 10]
     # expected: companding curve applied by the encoder LUT, expanded and dequantized by the decoder

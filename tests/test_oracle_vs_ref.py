@@ -72,3 +72,22 @@ def test_inverse_level_16s(w, h, descale):
     oracle().orc_inv_spatial(bands, w, w, h, descale, p16(out_o), 2 * w)
     ref().ref_inv_spatial(p16(ll), p16(hi[0]), p16(hi[1]), p16(hi[2]), w, h, descale, p16(out_r))
     assert np.array_equal(out_o, out_r)
+
+
+@pytest.mark.parametrize("w,h,fmt", [(320, 240, PIX_YUY2), (336, 252, PIX_YUY2), (720, 480, PIX_2VUY), (1920, 1080, PIX_YUY2)])
+def test_reference_decode_lies_in_oracle_dither_interval(w, h, fmt):
+    """Whole decode path: product host parser + VLC decoder -> oracle inverse transform (dither 0 and 1) brackets
+    every byte the reference decoder produces (it adds rand()&1 before the 10->8 bit shift)."""
+    f, p = synth_yuy2(w, h, 7)
+    sample = ref_encode_frames([f], p, w, h, fmt)[0]
+    rout, rpitch = ref_decode_sample(sample, w, h, fmt)
+    rimg = rout.reshape(h, rpitch)[:, : w * 2]
+    uyvy = int(fmt == PIX_2VUY)
+    plan = Plan(w, h, pixkind=2 if uyvy else 1)
+    coeffs = host_decode_pyramid(sample, plan)
+    lo = oracle_inverse_yuv422(plan, coeffs, 0, uyvy)[:h]
+    hi = oracle_inverse_yuv422(plan, coeffs, 1, uyvy)[:h]
+    ok = (rimg == lo) | (rimg == hi)
+    assert ok.all(), "%d bytes outside" % (~ok).sum()
+    differ = lo != hi
+    assert 0.3 < (rimg[differ] == hi[differ]).mean() < 0.7
