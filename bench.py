@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py -- 1080p YUY2 4:2:2 encode+decode round trip on MI355X (BASELINE.json metric).
+
+A step = one pass of the hot path over one batch of synthetic frames that are already resident in HBM:
+forward kernels -> entropy coding -> samples -> entropy decoding -> inverse kernels -> frames in HBM.
+`value` is whole-job frames per second (all ranks), `roofline` is the dominant kernel (level-1 forward) against the
+HBM peak, `cpu_baseline` is the unmodified reference (oracle/_ref) timed on this box's host cores on a bounded sample.
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse, ctypes, json, os, sys, time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+W, H = 1920, 1080
+
+
+def cpu_baseline(frames, pitch, seconds_budget=20.0):
+    """Reference SSE2 path on the host cores: async pool encode (POOL_THREADS = cores) + decode of the same samples."""
+    import cfhd_testlib as T
+    if not T.have_ref():
+        return None
+    L = T.ref()
+    cores = os.cpu_count() or 1
+    nfr = len(frames)
+    # encode: CFHD_CreateEncoderPool(threads = cores, queue = 1.5 * cores), as Example/TestCFHD.cpp:830-1026
+    pool = ctypes.c_void_p()
+    assert L.CFHD_CreateEncoderPool(ctypes.byref(pool), cores, max(2, cores * 3 // 2), None) == 0
+    assert L.CFHD_PrepareEncoderPool(pool, W, H, T.PIX_YUY2, T.ENCODED_YUV422, 0, T.QUALITY_FILMSCAN1) == 0
+    assert L.CFHD_StartEncoderPool(pool) == 0
+    samples = []
+    def collect(wait):
+        num = ctypes.c_uint32(); sb = ctypes.c_void_p()
+        rc = (L.CFHD_WaitForSample if wait else L.CFHD_TestForSample)(pool, ctypes.byref(num), ctypes.byref(sb))
+        if rc != 0:
+            return False
+        p = ctypes.c_void_p(); n = ctypes.c_size_t()
+        L.CFHD_GetEncodedSample(sb, ctypes.byref(p), ctypes.byref(n))
+        if len(samples) < nfr:
+            samples.append(ctypes.string_at(p, n.value))
+        else:
+            samples.append(None)
+        L.CFHD_ReleaseSampleBuffer(pool, sb)
+        return True
+    t0 = time.time(); sent = 0; target = 4 * nfr
+    while True:
+        L.CFHD_EncodeAsyncSample(pool, sent + 1, frames[sent % nfr].ctypes.data_as(ctypes.c_void_p), pitch, None)
+        sent += 1
+        while collect(False):
+            pass
+        if sent >= target and (time.time() - t0 > seconds_budget / 2 or sent >= 400):
+            break
+    while len(samples) < sent:
+        collect(True)
+    t_enc = time.time() - t0
+    L.CFHD_ReleaseEncoderPool(pool)
+    enc_fps = sent / t_enc
+    # decode: one decoder (it spawns its own worker threads, TAG_CPU_MAX unset = all cores)
+    dec = ctypes.c_void_p(); L.CFHD_OpenDecoder(ctypes.byref(dec), None)
+    aw = ctypes.c_int(); ah = ctypes.c_int(); af = ctypes.c_uint32()
+    sbuf = [ctypes.create_string_buffer(s, len(s)) for s in samples[:nfr]]
+    L.CFHD_PrepareToDecode(dec, 0, 0, T.PIX_YUY2, 1, 0, sbuf[0], 512, ctypes.byref(aw), ctypes.byref(ah), ctypes.byref(af))
+    import numpy as np
+    out = np.zeros(W * 2 * H, dtype=np.uint8)
+    t0 = time.time(); done = 0
+    while True:
+        s = sbuf[done % nfr]
+        L.CFHD_DecodeSample(dec, s, len(s) - 1 + 1 - 0, out.ctypes.data_as(ctypes.c_void_p), W * 2)
+        done += 1
+        if done >= 2 * nfr and (time.time() - t0 > seconds_budget / 2 or done >= 400):
+            break
+    t_dec = time.time() - t0
+    L.CFHD_CloseDecoder(dec)
+    dec_fps = done / t_dec
+    rt = 1.0 / (1.0 / enc_fps + 1.0 / dec_fps)
+    return {"value": round(rt, 1), "unit": "fps", "cores": cores, "kind": "reference",
+            "sample": "%d frames async-pool encode (%.1f fps, %d threads) + %d frames decode (%.1f fps) of 1920x1080 YUY2, reference SSE2 build"
+                      % (sent, enc_fps, cores, done, dec_fps)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="frames per step per GPU")
+    ap.add_argument("--threads", type=int, default=0, help="host entropy threads per rank (0 = cores / ranks)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("CFHD_AMD_DEVICE", str(local_rank))
+    import numpy as np
+    import torch
+    import cfhd_testlib as T
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: libcfhd_amd has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    L = T.product()
+    L.cfhd_amd_batch_create.restype = ctypes.c_void_p
+    L.cfhd_amd_batch_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    L.cfhd_amd_batch_upload.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    L.cfhd_amd_batch_roundtrip.restype = ctypes.c_longlong
+    L.cfhd_amd_batch_roundtrip.argtypes = [ctypes.c_void_p]
+    L.cfhd_amd_batch_kernel_ms.restype = ctypes.c_float
+    L.cfhd_amd_batch_kernel_ms.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.cfhd_amd_batch_stage_seconds.restype = ctypes.c_double
+    L.cfhd_amd_batch_stage_seconds.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.cfhd_amd_batch_destroy.argtypes = [ctypes.c_void_p]
+
+    cores = os.cpu_count() or 1
+    threads = args.threads or max(1, cores // world)
+    nuniq = 8
+    if T.have_ref():
+        frames, pitch = T.qbist_frames(10 + rank, nuniq)            # Qbist seed 10 (BASELINE configs), QBIST_UNIQUE frames
+        data = "synthetic Qbist 1920x1080 YUY2 (seed %d, %d unique frames per rank)" % (10, nuniq)
+    else:
+        frames = [T.synth_yuy2(W, H, 100 * rank + i)[0] for i in range(nuniq)]; pitch = W * 2
+        data = "synthetic gradients+noise 1920x1080 YUY2"
+    b = L.cfhd_amd_batch_create(W, H, T.PIX_YUY2, T.QUALITY_FILMSCAN1, args.batch, threads)
+    if not b:
+        raise SystemExit("cfhd_amd_batch_create failed: " + T.amd_last_error())
+    for i in range(args.batch):
+        assert L.cfhd_amd_batch_upload(b, i, frames[i % nuniq].ctypes.data_as(ctypes.c_void_p), pitch) == 0
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        assert L.cfhd_amd_batch_roundtrip(b) > 0, T.amd_last_error()
+    barrier()
+    t0 = time.perf_counter()
+    fwd_ms = []; stage = [0.0] * 4; total_bytes = 0
+    for _ in range(args.steps):
+        n = L.cfhd_amd_batch_roundtrip(b)
+        assert n > 0, T.amd_last_error()
+        total_bytes = n
+        fwd_ms.append(L.cfhd_amd_batch_kernel_ms(b, 0))
+        for k in range(4):
+            stage[k] += L.cfhd_amd_batch_stage_seconds(b, k)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    frames_total = args.batch * args.steps * world
+    fps = frames_total / elapsed
+
+    if rank == 0:
+        # dominant kernel: level-1 forward (k_fwd_yuv422): algorithmic bytes per launch = packed input + its four bands per channel
+        bytes_per_frame = W * H * 2 + 2 * (W * H * 2)      # 4 147 200 in + 8 294 400 out (12 441 600 B per 1080p frame)
+        ms = sum(fwd_ms) / len(fwd_ms)
+        achieved = bytes_per_frame * args.batch / (ms * 1e-3) / 1e9
+        line = {
+            "metric": "1080p YUY2 encode+decode fps", "value": round(fps, 1), "unit": "fps", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int16", "data": data,
+            "config": {"workload": "1920x1080 YUY2 4:2:2 FILMSCAN1 encode+decode round trip, frames resident in HBM", "frames_per_step_per_gpu": args.batch,
+                       "entropy_stage": "host threads (%d per rank)" % threads, "sample_bytes_per_frame": int(total_bytes / args.batch),
+                       "stage_ms_per_step": {"fwd_kernels+d2h": round(1000 * stage[0] / args.steps, 3), "host_entropy_encode": round(1000 * stage[1] / args.steps, 3),
+                                             "host_entropy_decode": round(1000 * stage[2] / args.steps, 3), "h2d+inv_kernels": round(1000 * stage[3] / args.steps, 3)}},
+            "roofline": {"bound": "hbm", "kernel": "k_fwd_yuv422", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "launch_ms": round(ms, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(frames, pitch)
+        print(json.dumps(line), flush=True)
+    L.cfhd_amd_batch_destroy(b)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,158 @@
+// cfhd_batch.cpp -- device-resident batched round trip (extension API, cfhd_amd_batch_*), used by bench.py and by
+// callers that keep frames in HBM: N frames -> forward kernels -> entropy coding -> N samples -> entropy decoding
+// -> inverse kernels -> N frames in HBM.  One launch per wavelet level covers the whole batch.
+//
+// Round-1 entropy stage: host threads (the reference's own arrangement, Codec/encoder.c:5386 / decoder.c:19534),
+// fed by one D2H copy of the quantized bands and followed by one H2D copy of the dequantized bands.
+#include "../../include/cfhd_amd.h"
+#include "cfhd_core.h"
+#include "cfhd_bitstream.h"
+#include "cfhd_device.h"
+#include "cfhd_metadata.h"
+#include <string.h>
+#include <vector>
+#include <thread>
+#include <atomic>
+#include <chrono>
+
+using namespace cfhd;
+
+struct cfhd_amd_batch {
+	FramePlan plan;
+	int n = 0, nthreads = 1, quality = 4, pixel_kind = PIX_YUY2;
+	EncodeBatch enc;
+	DecodeBatch dec;
+	std::vector<std::vector<uint8_t>> samples;
+	std::vector<size_t> sample_size;
+	MetaBlock meta;
+	uint32_t steps = 0;
+	double t_fwd = 0, t_entropy_enc = 0, t_entropy_dec = 0, t_inv = 0;   // wall seconds of the last round trip
+};
+
+namespace {
+template <typename F> void parallel_for(int n, int nthreads, F f)
+{
+	if (nthreads <= 1 || n <= 1) { for (int i = 0; i < n; i++) f(i); return; }
+	std::atomic<int> next(0);
+	std::vector<std::thread> pool;
+	int t = nthreads < n ? nthreads : n;
+	for (int k = 0; k < t; k++) pool.emplace_back([&] { for (int i; (i = next.fetch_add(1)) < n;) f(i); });
+	for (auto &th : pool) th.join();
+}
+double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}
+
+extern "C" {
+
+cfhd_amd_batch *cfhd_amd_batch_create(int width, int height, uint32_t pixel_format, int quality, int nframes, int nthreads)
+{
+	int kind = pixel_format == 0x32767579u /* '2vuy' */ ? PIX_2VUY : PIX_YUY2;
+	cfhd_amd_batch *b = new (std::nothrow) cfhd_amd_batch;
+	if (!b) return nullptr;
+	b->n = nframes; b->nthreads = nthreads > 0 ? nthreads : 1; b->quality = quality; b->pixel_kind = kind;
+	if (!build_frame_plan(&b->plan, width, height, kind, ENC_YUV422)) { delete b; return nullptr; }
+	QuantState st = {0, -1, 0};
+	derive_quantization(&b->plan, quality, true, 0.0f, &st);
+	if (b->enc.prepare(b->plan, nframes, true) || b->dec.prepare(b->plan, nframes, kind, true)) { delete b; return nullptr; }
+	b->samples.resize(nframes); b->sample_size.assign(nframes, 0);
+	for (auto &s : b->samples) s.resize((size_t)width * height * 2 + 65536);
+	unsigned char guid[16] = {0};
+	meta_add(b->meta, MTAG_CLIP_GUID, 'G', 16, guid);
+	return b;
+}
+
+void cfhd_amd_batch_destroy(cfhd_amd_batch *b) { delete b; }
+
+// Puts frame i into HBM (outside the timed region of the benchmark).
+int cfhd_amd_batch_upload(cfhd_amd_batch *b, int i, const void *frame, int pitch)
+{
+	if (!b) return -1;
+	int rc = b->enc.upload_frame(i, frame, pitch);
+	if (rc) return rc;
+	return b->enc.wait();
+}
+
+// One step of the hot path over the whole batch.  Returns the total number of sample bytes, or < 0.
+long long cfhd_amd_batch_roundtrip(cfhd_amd_batch *b)
+{
+	if (!b) return -1;
+	const FramePlan &plan = b->plan;
+	double t0 = now();
+	if (b->enc.launch_forward() || b->enc.download_coeffs() || b->enc.wait()) return -2;
+	double t1 = now();
+	std::atomic<int> bad(0);
+	const uint32_t base_number = b->steps * (uint32_t)b->n;
+	parallel_for(b->n, b->nthreads, [&](int i) {
+		SampleHeaderInfo hdr = { base_number + (uint32_t)i + 1, b->pixel_kind == PIX_2VUY ? 1 : 2, 2, b->quality, true, b->meta.data(), b->meta.size(), nullptr, 0 };
+		BandSource src; src.coeffs = b->enc.host_coeffs(i);
+		size_t n = write_sample(plan, hdr, src, b->samples[i].data(), b->samples[i].size());
+		if (!n) bad++;
+		b->sample_size[i] = n;
+	});
+	double t2 = now();
+	if (bad) return -3;
+	parallel_for(b->n, b->nthreads, [&](int i) {
+		const uint8_t *s = b->samples[i].data();
+		ParsedSample ps;
+		if (parse_sample(s, b->sample_size[i], &ps) != 0) { bad++; return; }
+		b->dec.clear_host_coeffs(i);
+		int16_t *coeffs = b->dec.host_coeffs(i);
+		for (int c = 0; c < plan.num_channels; c++) {
+			const ParsedBand &lp = ps.lowpass[c];
+			const BandDesc &ll = plan.ch[c].band[2][0];
+			const int bias = lowpass_bias(plan.precision, ll.width, b->pixel_kind);
+			for (int r = 0; r < ll.height; r++) {
+				const uint8_t *p = s + lp.offset + (size_t)r * ll.width * 2;
+				int16_t *dst = coeffs + ll.offset + (size_t)r * ll.pitch;
+				for (int x = 0; x < ll.width; x++) { int v = (int16_t)((p[2 * x] << 8) | p[2 * x + 1]); v += bias; dst[x] = (int16_t)(v > 0x7fff ? 0x7fff : v); }
+			}
+			for (int lv = 0; lv < kNumLevels; lv++)
+				for (int k = 1; k < 4; k++) {
+					const ParsedBand &pb = ps.high[c][lv][k];
+					const BandDesc &bd = plan.ch[c].band[lv][k];
+					if (!pb.present || vlc_decode_band(s + pb.offset, pb.bytes, bd.width, bd.height, bd.pitch, pb.quant, pb.codebook, coeffs + bd.offset)) { bad++; return; }
+				}
+		}
+	});
+	double t3 = now();
+	if (bad) return -4;
+	if (b->dec.upload_coeffs() || b->dec.launch_inverse(0xA511E9B3u * (b->steps + 1)) || b->dec.wait()) return -5;
+	double t4 = now();
+	b->t_fwd = t1 - t0; b->t_entropy_enc = t2 - t1; b->t_entropy_dec = t3 - t2; b->t_inv = t4 - t3;
+	b->steps++;
+	long long total = 0;
+	for (int i = 0; i < b->n; i++) total += (long long)b->sample_size[i];
+	return total;
+}
+
+// which: 0..2 forward level launches (0 = k_fwd_yuv422), 3..5 inverse level launches (3 = k_inv_yuv422), 6 forward total, 7 inverse total (ms, HIP events)
+float cfhd_amd_batch_kernel_ms(cfhd_amd_batch *b, int which)
+{
+	if (!b) return 0;
+	if (which < 3) return b->enc.last_level_ms(which);
+	if (which < 6) return b->dec.last_level_ms(which - 3);
+	return which == 6 ? b->enc.last_kernel_ms() : b->dec.last_kernel_ms();
+}
+
+// which: 0 forward (kernels + D2H), 1 host entropy encode + syntax, 2 host parse + entropy decode, 3 H2D + inverse kernels (wall seconds)
+double cfhd_amd_batch_stage_seconds(cfhd_amd_batch *b, int which)
+{
+	if (!b) return 0;
+	switch (which) { case 0: return b->t_fwd; case 1: return b->t_entropy_enc; case 2: return b->t_entropy_dec; default: return b->t_inv; }
+}
+
+int cfhd_amd_batch_get_sample(cfhd_amd_batch *b, int i, const void **data, size_t *size)
+{
+	if (!b || i < 0 || i >= b->n) return -1;
+	*data = b->samples[i].data(); *size = b->sample_size[i];
+	return 0;
+}
+
+int cfhd_amd_batch_download_output(cfhd_amd_batch *b, int i, void *out, int pitch)
+{
+	if (!b) return -1;
+	if (b->dec.download_frame(i, out, pitch) || b->dec.wait()) return -2;
+	return b->dec.finish_frame(i, out, pitch);
+}
+
+} // extern "C"

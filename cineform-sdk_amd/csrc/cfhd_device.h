@@ -35,12 +35,14 @@ public:
 	int16_t *device_coeffs(int i) { return d_coeff_ + (size_t)i * plan_.coeff_elems; }
 	void *stream() { return stream_; }
 	float last_kernel_ms() const { return kernel_ms_; }   // forward kernels of the last launch (HIP events on this stream)
+	float last_level_ms(int level) const { return level_ms_[level]; }   // level 0 = k_fwd_yuv422, 1/2 = k_fwd_plane launches
 private:
 	void release();
 	int sync_jobs();
 	FramePlan plan_;
 	int n_ = 0; bool own_input_ = false, jobs_dirty_ = true;
-	void *stream_ = nullptr, *ev0_ = nullptr, *ev1_ = nullptr;
+	void *stream_ = nullptr, *ev0_ = nullptr, *ev1_ = nullptr, *evl_[2] = {nullptr, nullptr};
+	float level_ms_[3] = {0, 0, 0};
 	uint8_t *d_in_ = nullptr, *h_in_ = nullptr; size_t frame_bytes_ = 0; int in_pitch_ = 0;
 	int16_t *d_coeff_ = nullptr, *h_coeff_ = nullptr;
 	void *d_jobs_ = nullptr, *h_jobs_ = nullptr; size_t jobs_bytes_ = 0;
@@ -65,12 +67,14 @@ public:
 	int finish_frame(int i, void *out, int pitch_bytes);      // after wait(): copy the staged frame to the caller's buffer
 	void *stream() { return stream_; }
 	float last_kernel_ms() const { return kernel_ms_; }
+	float last_level_ms(int level) const { return level_ms_[level]; }   // level 0 = k_inv_yuv422, 1/2 = k_inv_plane launches (level index)
 private:
 	void release();
 	int sync_jobs();
 	FramePlan plan_;
 	int n_ = 0, out_kind_ = 0; bool own_output_ = false, jobs_dirty_ = true;
-	void *stream_ = nullptr, *ev0_ = nullptr, *ev1_ = nullptr;
+	void *stream_ = nullptr, *ev0_ = nullptr, *ev1_ = nullptr, *evl_[2] = {nullptr, nullptr};
+	float level_ms_[3] = {0, 0, 0};
 	int16_t *d_coeff_ = nullptr, *h_coeff_ = nullptr;
 	uint8_t *d_out_ = nullptr, *h_out_ = nullptr; size_t frame_bytes_ = 0; int out_pitch_ = 0;
 	void *d_jobs_ = nullptr, *h_jobs_ = nullptr; size_t jobs_bytes_ = 0;

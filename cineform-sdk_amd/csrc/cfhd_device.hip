@@ -120,6 +120,7 @@ void EncodeBatch::release()
 	if (h_jobs_) hipHostFree(h_jobs_);
 	if (ev0_) hipEventDestroy((hipEvent_t)ev0_);
 	if (ev1_) hipEventDestroy((hipEvent_t)ev1_);
+	for (int k = 0; k < 2; k++) if (evl_[k]) { hipEventDestroy((hipEvent_t)evl_[k]); evl_[k] = nullptr; }
 	if (stream_) hipStreamDestroy((hipStream_t)stream_);
 	d_in_ = h_in_ = nullptr; d_coeff_ = h_coeff_ = nullptr; d_jobs_ = h_jobs_ = nullptr; stream_ = ev0_ = ev1_ = nullptr; n_ = 0;
 }
@@ -134,6 +135,7 @@ int EncodeBatch::prepare(const FramePlan &plan, int nframes, bool own_input)
 	HIPCHK(hipStreamCreateWithFlags((hipStream_t *)&stream_, hipStreamNonBlocking));
 	HIPCHK(hipEventCreate((hipEvent_t *)&ev0_));
 	HIPCHK(hipEventCreate((hipEvent_t *)&ev1_));
+	for (int k = 0; k < 2; k++) HIPCHK(hipEventCreate((hipEvent_t *)&evl_[k]));
 	in_pitch_ = packed_frame_pitch(plan.pixel_kind, plan.width);
 	frame_bytes_ = (size_t)in_pitch_ * plan.display_height;
 	if (own_input) {
@@ -214,6 +216,7 @@ int EncodeBatch::launch_forward()
 		dev::k_fwd_yuv422<<<grid, dev::NTHREADS, 0, st>>>(j.yuv);
 	}
 	for (int lv = 1; lv < 3; lv++) {
+		HIPCHK(hipEventRecord((hipEvent_t)evl_[lv - 1], st));
 		const BandDesc &src = plan_.ch[0].band[lv - 1][0];     // luma is the widest plane of the level
 		dim3 grid((src.width / 2 + dev::TW - 1) / dev::TW, (src.height / 2 + dev::TH - 1) / dev::TH, n_ * nch);
 		dev::k_fwd_plane<<<grid, dev::NTHREADS, 0, st>>>(lv == 1 ? j.l2 : j.l3);
@@ -235,6 +238,9 @@ int EncodeBatch::wait()
 	HIPCHK(hipStreamSynchronize((hipStream_t)stream_));
 	float ms = 0;
 	if (hipEventElapsedTime(&ms, (hipEvent_t)ev0_, (hipEvent_t)ev1_) == hipSuccess) kernel_ms_ = ms;
+	if (hipEventElapsedTime(&ms, (hipEvent_t)ev0_, (hipEvent_t)evl_[0]) == hipSuccess) level_ms_[0] = ms;
+	if (hipEventElapsedTime(&ms, (hipEvent_t)evl_[0], (hipEvent_t)evl_[1]) == hipSuccess) level_ms_[1] = ms;
+	if (hipEventElapsedTime(&ms, (hipEvent_t)evl_[1], (hipEvent_t)ev1_) == hipSuccess) level_ms_[2] = ms;
 	return 0;
 }
 
@@ -255,6 +261,7 @@ void DecodeBatch::release()
 	if (h_jobs_) hipHostFree(h_jobs_);
 	if (ev0_) hipEventDestroy((hipEvent_t)ev0_);
 	if (ev1_) hipEventDestroy((hipEvent_t)ev1_);
+	for (int k = 0; k < 2; k++) if (evl_[k]) { hipEventDestroy((hipEvent_t)evl_[k]); evl_[k] = nullptr; }
 	if (stream_) hipStreamDestroy((hipStream_t)stream_);
 	d_out_ = h_out_ = nullptr; d_coeff_ = h_coeff_ = nullptr; d_jobs_ = h_jobs_ = nullptr; stream_ = ev0_ = ev1_ = nullptr; n_ = 0;
 }
@@ -269,6 +276,7 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 	HIPCHK(hipStreamCreateWithFlags((hipStream_t *)&stream_, hipStreamNonBlocking));
 	HIPCHK(hipEventCreate((hipEvent_t *)&ev0_));
 	HIPCHK(hipEventCreate((hipEvent_t *)&ev1_));
+	for (int k = 0; k < 2; k++) HIPCHK(hipEventCreate((hipEvent_t *)&evl_[k]));
 	out_pitch_ = packed_frame_pitch(out_kind, plan.width);
 	frame_bytes_ = (size_t)out_pitch_ * plan.display_height;
 	if (own_output) {
@@ -344,6 +352,7 @@ int DecodeBatch::launch_inverse(uint32_t dither_seed)
 		const BandDesc &b = plan_.ch[0].band[lv][0];
 		dim3 grid((b.width + dev::ITW - 1) / dev::ITW, (b.height + dev::ITH - 1) / dev::ITH, n_ * nch);
 		dev::k_inv_plane<<<grid, dev::NTHREADS, 0, st>>>(lv == 2 ? j.l3 : j.l2);
+		HIPCHK(hipEventRecord((hipEvent_t)evl_[2 - lv], st));
 	}
 	{
 		const BandDesc &b = plan_.ch[0].band[0][0];
@@ -367,6 +376,9 @@ int DecodeBatch::wait()
 	HIPCHK(hipStreamSynchronize((hipStream_t)stream_));
 	float ms = 0;
 	if (hipEventElapsedTime(&ms, (hipEvent_t)ev0_, (hipEvent_t)ev1_) == hipSuccess) kernel_ms_ = ms;
+	if (hipEventElapsedTime(&ms, (hipEvent_t)ev0_, (hipEvent_t)evl_[0]) == hipSuccess) level_ms_[2] = ms;
+	if (hipEventElapsedTime(&ms, (hipEvent_t)evl_[0], (hipEvent_t)evl_[1]) == hipSuccess) level_ms_[1] = ms;
+	if (hipEventElapsedTime(&ms, (hipEvent_t)evl_[1], (hipEvent_t)ev1_) == hipSuccess) level_ms_[0] = ms;
 	return 0;
 }
 

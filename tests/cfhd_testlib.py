@@ -42,6 +42,31 @@ def iarr(vals):
     return (ctypes.c_int * len(vals))(*vals)
 
 
+def declare_cfhd_api(L):
+    """ctypes prototypes of the CFHD_* C ABI (identical for the reference build and for libcfhd_amd.so)."""
+    vp, vpp, i, u32, sz = ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_uint32, ctypes.c_size_t
+    protos = {
+        "CFHD_OpenEncoder": [vpp, vp], "CFHD_PrepareToEncode": [vp, i, i, u32, i, u32, i], "CFHD_EncodeSample": [vp, vp, i],
+        "CFHD_GetSampleData": [vp, vpp, ctypes.POINTER(sz)], "CFHD_CloseEncoder": [vp],
+        "CFHD_MetadataOpen": [vpp], "CFHD_MetadataAdd": [vp, u32, i, sz, vp, ctypes.c_bool], "CFHD_MetadataAttach": [vp, vp], "CFHD_MetadataClose": [vp],
+        "CFHD_CreateEncoderPool": [vpp, i, i, vp], "CFHD_PrepareEncoderPool": [vp, ctypes.c_uint16, ctypes.c_uint16, u32, i, u32, i],
+        "CFHD_AttachEncoderPoolMetadata": [vp, vp], "CFHD_StartEncoderPool": [vp], "CFHD_StopEncoderPool": [vp],
+        "CFHD_EncodeAsyncSample": [vp, u32, vp, ctypes.c_ssize_t, vp], "CFHD_WaitForSample": [vp, ctypes.POINTER(u32), vpp],
+        "CFHD_TestForSample": [vp, ctypes.POINTER(u32), vpp], "CFHD_GetEncodedSample": [vp, vpp, ctypes.POINTER(sz)],
+        "CFHD_ReleaseSampleBuffer": [vp, vp], "CFHD_ReleaseEncoderPool": [vp],
+        "CFHD_OpenDecoder": [vpp, vp], "CFHD_GetSampleInfo": [vp, vp, sz, i, vp, sz],
+        "CFHD_PrepareToDecode": [vp, i, i, u32, i, u32, vp, sz, ctypes.POINTER(i), ctypes.POINTER(i), ctypes.POINTER(u32)],
+        "CFHD_GetPixelSize": [u32, ctypes.POINTER(u32)], "CFHD_GetImagePitch": [u32, u32, ctypes.POINTER(ctypes.c_int32)],
+        "CFHD_GetImageSize": [u32, u32, u32, i, i, ctypes.POINTER(u32)], "CFHD_DecodeSample": [vp, vp, sz, vp, ctypes.c_int32],
+        "CFHD_SetActiveMetadata": [vp, vp, ctypes.c_uint, i, vp, ctypes.c_uint], "CFHD_CloseDecoder": [vp],
+        "CFHD_OpenMetadata": [vpp], "CFHD_InitSampleMetadata": [vp, i, vp, sz], "CFHD_CloseMetadata": [vp],
+    }
+    for name, args in protos.items():
+        fn = getattr(L, name)
+        fn.argtypes = args
+        fn.restype = ctypes.c_int
+
+
 _oracle = None
 
 
@@ -69,6 +94,7 @@ def ref():
     if _ref is None:
         _ref = ctypes.CDLL(REF_SO)
         _ref.ref_psnr.restype = ctypes.c_float
+        declare_cfhd_api(_ref)
     return _ref
 
 
@@ -132,10 +158,10 @@ def ref_decode_sample(sample, width, height, pixfmt=PIX_YUY2):
     L = ref()
     dec = ctypes.c_void_p()
     assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
-    aw = ctypes.c_int(); ah = ctypes.c_int(); af = ctypes.c_int()
+    aw = ctypes.c_int(); ah = ctypes.c_int(); af = ctypes.c_uint32()
     sb = ctypes.create_string_buffer(sample, len(sample))
     assert L.CFHD_PrepareToDecode(dec, 0, 0, pixfmt, 1, 0, sb, 512, ctypes.byref(aw), ctypes.byref(ah), ctypes.byref(af)) == 0
-    pitch = ctypes.c_int()
+    pitch = ctypes.c_int32()
     assert L.CFHD_GetImagePitch(aw.value, af.value, ctypes.byref(pitch)) == 0
     out = np.zeros(pitch.value * ah.value + 64, dtype=np.uint8)
     assert L.CFHD_DecodeSample(dec, sb, len(sample), out.ctypes.data_as(ctypes.c_void_p), pitch.value) == 0
@@ -175,6 +201,7 @@ def product():
         L.cfhd_amd_write_sample_host.restype = ctypes.c_size_t
         L.cfhd_amd_write_sample_host.argtypes = [ctypes.c_int] * 8 + [ctypes.c_uint, c_i16p, c_u8p, ctypes.c_size_t, c_u8p, ctypes.c_size_t, c_u8p, ctypes.c_size_t]
         L.cfhd_amd_decode_bands_host.argtypes = [c_u8p, ctypes.c_size_t, ctypes.c_int, c_i16p, ctypes.c_size_t, c_intp, ctypes.c_int]
+        declare_cfhd_api(L)
         _product = L
     return _product
 

@@ -168,5 +168,5 @@ def test_invalid_arguments_and_unsupported_formats():
     L.CFHD_CloseEncoder(enc)
     dec = ctypes.c_void_p(); L.CFHD_OpenDecoder(ctypes.byref(dec), None)
     junk = ctypes.create_string_buffer(b"\0" * 600, 600)
-    assert L.CFHD_PrepareToDecode(dec, 0, 0, PIX_YUY2, 1, 0, junk, 512, None, None, None) == 5   # CFHD_ERROR_BADSAMPLE
+    assert L.CFHD_PrepareToDecode(dec, 0, 0, PIX_YUY2, 1, 0, ctypes.cast(junk, ctypes.c_void_p), 512, None, None, None) == 5   # CFHD_ERROR_BADSAMPLE
     L.CFHD_CloseDecoder(dec)
