@@ -29,8 +29,15 @@ def cpu_baseline(frames, pitch, seconds_budget=20.0):
     # encode: CFHD_CreateEncoderPool(threads = cores, queue = 1.5 * cores), as Example/TestCFHD.cpp:830-1026
     pool = ctypes.c_void_p()
     assert L.CFHD_CreateEncoderPool(ctypes.byref(pool), cores, max(2, cores * 3 // 2), None) == 0
+    # TestCFHD attaches a metadata handle and refreshes timecode / unique frame number per frame (Example/TestCFHD.cpp:826-930);
+    # the reference's pool workers never complete a job that was submitted with a NULL metadata handle.
+    meta = ctypes.c_void_p()
+    assert L.CFHD_MetadataOpen(ctypes.byref(meta)) == 0
+    L.CFHD_AttachEncoderPoolMetadata(pool, meta)
     assert L.CFHD_PrepareEncoderPool(pool, W, H, T.PIX_YUY2, T.ENCODED_YUV422, 0, T.QUALITY_FILMSCAN1) == 0
+    L.CFHD_AttachEncoderPoolMetadata(pool, meta)
     assert L.CFHD_StartEncoderPool(pool) == 0
+    mtag = lambda t: ord(t[0]) | (ord(t[1]) << 8) | (ord(t[2]) << 16) | (ord(t[3]) << 24)
     samples = []
     def collect(wait):
         num = ctypes.c_uint32(); sb = ctypes.c_void_p()
@@ -46,17 +53,31 @@ def cpu_baseline(frames, pitch, seconds_budget=20.0):
         L.CFHD_ReleaseSampleBuffer(pool, sb)
         return True
     t0 = time.time(); sent = 0; target = 4 * nfr
+    qlen = max(2, cores * 3 // 2)
     while True:
-        L.CFHD_EncodeAsyncSample(pool, sent + 1, frames[sent % nfr].ctypes.data_as(ctypes.c_void_p), pitch, None)
+        # the job queue holds finished jobs until they are collected: never submit into a full queue (TestCFHD.cpp:903 does the same)
+        while sent - len(samples) >= qlen:
+            if not collect(True):
+                return {"value": None, "unit": "fps", "cores": cores, "kind": "reference", "sample": "reference pool failed"}
+        frms = 24 * 3600 + sent
+        tc = ctypes.create_string_buffer(("%02d:%02d:%02d:%02d" % ((frms // 86400) % 24, (frms // 1440) % 60, (frms // 24) % 60, frms % 24)).encode(), 12)
+        L.CFHD_MetadataAdd(meta, mtag("TIMC"), 1, 11, ctypes.cast(tc, ctypes.c_void_p), False)
+        uf = ctypes.c_uint32(sent)
+        L.CFHD_MetadataAdd(meta, mtag("UFRM"), 2, 4, ctypes.cast(ctypes.pointer(uf), ctypes.c_void_p), False)
+        rc = L.CFHD_EncodeAsyncSample(pool, sent + 1, frames[sent % nfr].ctypes.data_as(ctypes.c_void_p), pitch, meta)
+        if rc != 0:
+            return {"value": None, "unit": "fps", "cores": cores, "kind": "reference", "sample": "reference pool returned error %d" % rc}
         sent += 1
         while collect(False):
             pass
-        if sent >= target and (time.time() - t0 > seconds_budget / 2 or sent >= 400):
+        if sent >= target and time.time() - t0 > seconds_budget / 2:
             break
     while len(samples) < sent:
-        collect(True)
+        if not collect(True):
+            return {"value": None, "unit": "fps", "cores": cores, "kind": "reference", "sample": "reference pool failed while draining"}
     t_enc = time.time() - t0
     L.CFHD_ReleaseEncoderPool(pool)
+    L.CFHD_MetadataClose(meta)
     enc_fps = sent / t_enc
     # decode: one decoder (it spawns its own worker threads, TAG_CPU_MAX unset = all cores)
     dec = ctypes.c_void_p(); L.CFHD_OpenDecoder(ctypes.byref(dec), None)
@@ -68,9 +89,11 @@ def cpu_baseline(frames, pitch, seconds_budget=20.0):
     t0 = time.time(); done = 0
     while True:
         s = sbuf[done % nfr]
-        L.CFHD_DecodeSample(dec, s, len(s) - 1 + 1 - 0, out.ctypes.data_as(ctypes.c_void_p), W * 2)
+        rc = L.CFHD_DecodeSample(dec, s, len(s), out.ctypes.data_as(ctypes.c_void_p), W * 2)
+        if rc != 0:
+            return {"value": None, "unit": "fps", "cores": cores, "kind": "reference", "sample": "reference decoder returned error %d" % rc}
         done += 1
-        if done >= 2 * nfr and (time.time() - t0 > seconds_budget / 2 or done >= 400):
+        if done >= 2 * nfr and time.time() - t0 > seconds_budget / 2:
             break
     t_dec = time.time() - t0
     L.CFHD_CloseDecoder(dec)

@@ -47,6 +47,7 @@ private:
 	int16_t *d_coeff_ = nullptr, *h_coeff_ = nullptr;
 	void *d_jobs_ = nullptr, *h_jobs_ = nullptr; size_t jobs_bytes_ = 0;
 	float kernel_ms_ = 0;
+	bool timed_ = false;
 };
 
 class DecodeBatch {
@@ -79,6 +80,7 @@ private:
 	uint8_t *d_out_ = nullptr, *h_out_ = nullptr; size_t frame_bytes_ = 0; int out_pitch_ = 0;
 	void *d_jobs_ = nullptr, *h_jobs_ = nullptr; size_t jobs_bytes_ = 0;
 	float kernel_ms_ = 0;
+	bool timed_ = false;
 };
 
 int packed_frame_pitch(int pixel_kind, int width);     // bytes per row of a tightly packed frame

@@ -210,6 +210,8 @@ int EncodeBatch::launch_forward()
 	hipStream_t st = (hipStream_t)stream_;
 	const int nch = plan_.num_channels;
 	EncJobs j = enc_jobs_at(d_jobs_, n_, nch);
+	(void)hipGetLastError();                            // drop stale sticky errors: the check below is for these launches only
+	timed_ = true;
 	HIPCHK(hipEventRecord((hipEvent_t)ev0_, st));
 	{
 		dim3 grid((plan_.width / 2 + dev::TW - 1) / dev::TW, (plan_.height / 2 + dev::TH - 1) / dev::TH, n_);
@@ -237,6 +239,8 @@ int EncodeBatch::wait()
 {
 	HIPCHK(hipStreamSynchronize((hipStream_t)stream_));
 	float ms = 0;
+	if (!timed_) return 0;
+	timed_ = false;
 	if (hipEventElapsedTime(&ms, (hipEvent_t)ev0_, (hipEvent_t)ev1_) == hipSuccess) kernel_ms_ = ms;
 	if (hipEventElapsedTime(&ms, (hipEvent_t)ev0_, (hipEvent_t)evl_[0]) == hipSuccess) level_ms_[0] = ms;
 	if (hipEventElapsedTime(&ms, (hipEvent_t)evl_[0], (hipEvent_t)evl_[1]) == hipSuccess) level_ms_[1] = ms;
@@ -347,6 +351,8 @@ int DecodeBatch::launch_inverse(uint32_t dither_seed)
 	hipStream_t st = (hipStream_t)stream_;
 	const int nch = plan_.num_channels;
 	DecJobs j = dec_jobs_at(d_jobs_, n_, nch);
+	(void)hipGetLastError();
+	timed_ = true;
 	HIPCHK(hipEventRecord((hipEvent_t)ev0_, st));
 	for (int lv = 2; lv >= 1; lv--) {
 		const BandDesc &b = plan_.ch[0].band[lv][0];
@@ -375,6 +381,8 @@ int DecodeBatch::wait()
 {
 	HIPCHK(hipStreamSynchronize((hipStream_t)stream_));
 	float ms = 0;
+	if (!timed_) return 0;
+	timed_ = false;
 	if (hipEventElapsedTime(&ms, (hipEvent_t)ev0_, (hipEvent_t)ev1_) == hipSuccess) kernel_ms_ = ms;
 	if (hipEventElapsedTime(&ms, (hipEvent_t)ev0_, (hipEvent_t)evl_[0]) == hipSuccess) level_ms_[2] = ms;
 	if (hipEventElapsedTime(&ms, (hipEvent_t)evl_[0], (hipEvent_t)evl_[1]) == hipSuccess) level_ms_[1] = ms;

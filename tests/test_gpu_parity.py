@@ -170,3 +170,28 @@ def test_invalid_arguments_and_unsupported_formats():
     junk = ctypes.create_string_buffer(b"\0" * 600, 600)
     assert L.CFHD_PrepareToDecode(dec, 0, 0, PIX_YUY2, 1, 0, ctypes.cast(junk, ctypes.c_void_p), 512, None, None, None) == 5   # CFHD_ERROR_BADSAMPLE
     L.CFHD_CloseDecoder(dec)
+
+
+def test_reference_harness_links_unchanged_and_prints_same_numbers():
+    """Example/TestCFHD.cpp of the reference, compiled unmodified against the reference headers, linked once against the
+    reference library and once against libcfhd_amd.so (oracle/Makefile `testcfhd`): the `-D` quality test must print the
+    same compressed sizes (user metadata included) and the same PSNR to the printed 0.1 dB for the formats we support."""
+    import re, subprocess
+    ours = os.path.join(ORACLE_DIR, "_ref", "TestCFHD_amd"); theirs = os.path.join(ORACLE_DIR, "_ref", "TestCFHD_ref")
+    if not (os.path.exists(ours) and os.path.exists(theirs)):
+        pytest.skip("harness binaries not built (make -C oracle testcfhd needs /root/reference)")
+    def run(binary):
+        out = subprocess.run([binary, "-D"], capture_output=True, text=True, timeout=600, cwd="/tmp").stdout
+        res = {}; fmt = None
+        for line in out.splitlines():
+            m = re.match(r"Pixel format: (\S+)", line)
+            if m: fmt = m.group(1)
+            m = re.match(r"(\d+): source (\d+) compressed to (\d+) in .*PSNR ([0-9.]+)dB", line)
+            if m and fmt: res.setdefault(fmt, []).append((int(m.group(3)), float(m.group(4))))
+        return res
+    a, b = run(ours), run(theirs)
+    for fmt in ("YUY2", "2vuy"):
+        assert fmt in a and len(a[fmt]) == 10, "our library did not complete the %s run: %r" % (fmt, a.get(fmt))
+        for (sa, pa), (sb, pb) in zip(a[fmt], b[fmt][:10]):
+            assert sa == sb, "%s compressed size %d vs reference %d" % (fmt, sa, sb)
+            assert abs(pa - pb) <= 0.1 + 1e-6, "%s PSNR %.1f vs reference %.1f" % (fmt, pa, pb)
