@@ -163,18 +163,42 @@ int make_params(EncodeParams &p, int w, int h, uint32_t fmt, int encoded, uint32
 
 size_t sample_capacity(const EncodeParams &p) { return (size_t)p.width * p.height * 2 + 65536; }   // SampleEncoder.cpp:387
 
+// Where the run-length/VLC stage runs: on the GPU by default; CFHD_AMD_ENTROPY=host keeps the reference's arrangement
+// (host threads fed by one D2H copy of the quantized bands).  Both produce the same bytes.
+bool gpu_entropy_enabled() { const char *e = getenv("CFHD_AMD_ENTROPY"); return !(e && strcmp(e, "host") == 0); }
+
+int prepare_batch(EncodeBatch &batch, const EncodeParams &p)
+{
+	if (batch.prepare(p.plan, 1, true)) return ERR_INTERNAL;
+	if (gpu_entropy_enabled() && batch.prepare_entropy(sample_capacity(p))) return ERR_INTERNAL;
+	return ERR_OKAY;
+}
+
 // Encode one frame on one batch slot: upload, forward kernels, coefficients back, host entropy + syntax.
 int encode_one(EncodeBatch &batch, EncodeParams &p, const void *frame, int pitch, uint32_t frame_number,
                MetaBlock global, MetaBlock local, uint8_t *out, size_t cap, size_t *size_out)
 {
 	int rc;
-	if ((rc = batch.upload_frame(0, frame, pitch))) return ERR_INTERNAL;
-	if ((rc = batch.launch_forward())) return ERR_INTERNAL;
-	if ((rc = batch.download_coeffs())) return ERR_INTERNAL;
-	if ((rc = batch.wait())) return ERR_INTERNAL;
 	meta_remove_hidden(global); meta_remove_hidden(local);
 	SampleHeaderInfo hdr = { frame_number, color_format_of(p.pixel_kind), p.color_space, p.quality, p.progressive,
 	                         global.data(), global.size(), local.data(), local.size() };
+	if ((rc = batch.upload_frame(0, frame, pitch))) return ERR_INTERNAL;
+	if (batch.has_entropy()) {
+		// GPU entropy stage: the finished sample comes back, not the coefficients
+		if (batch.entropy().set_frame_header(0, hdr)) return ERR_CODEC_ERROR;
+		if ((rc = batch.launch_forward())) return ERR_INTERNAL;
+		if ((rc = batch.entropy().launch())) return ERR_INTERNAL;
+		if ((rc = batch.entropy().download())) return ERR_INTERNAL;
+		if ((rc = batch.wait())) return ERR_INTERNAL;
+		size_t n = batch.entropy().sample_bytes(0);
+		if (!n || n > cap) return ERR_CODEC_ERROR;
+		memcpy(out, batch.entropy().host_sample(0), n);
+		*size_out = n;
+		return ERR_OKAY;
+	}
+	if ((rc = batch.launch_forward())) return ERR_INTERNAL;
+	if ((rc = batch.download_coeffs())) return ERR_INTERNAL;
+	if ((rc = batch.wait())) return ERR_INTERNAL;
 	BandSource src; src.coeffs = batch.host_coeffs(0);
 	size_t n = write_sample(p.plan, hdr, src, out, cap);
 	if (!n) return ERR_CODEC_ERROR;
@@ -338,7 +362,7 @@ CFHD_Error CFHD_EncodeSample(CFHD_EncoderRef ref, void *frame, int pitch)
 	if (!e->params.valid) return ERR_CODEC_ERROR;
 	e->meta.handle();
 	if (!e->batch_ready) {
-		if (e->batch.prepare(e->params.plan, 1, true)) return ERR_INTERNAL;
+		if (prepare_batch(e->batch, e->params)) return ERR_INTERNAL;
 		e->batch_ready = true;
 	}
 	int rc = encode_one(e->batch, e->params, frame, pitch, ++e->frame_number, e->meta.global, e->meta.local,
@@ -458,7 +482,7 @@ CFHD_Error CFHD_StartEncoderPool(CFHD_EncoderPoolRef ref)
 	p->workers.clear();
 	for (int i = 0; i < p->nworkers; i++) {
 		std::unique_ptr<PoolWorker> w(new PoolWorker);
-		if (w->batch.prepare(p->params.plan, 1, true)) return ERR_INTERNAL;
+		if (prepare_batch(w->batch, p->params)) return ERR_INTERNAL;
 		p->workers.push_back(std::move(w));
 	}
 	for (auto &w : p->workers) { PoolWorker *pw = w.get(); pw->thread = std::thread([p, pw] { p->worker_loop(pw); }); }

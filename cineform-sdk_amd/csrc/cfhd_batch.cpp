@@ -10,6 +10,7 @@
 #include "cfhd_device.h"
 #include "cfhd_metadata.h"
 #include <string.h>
+#include <stdlib.h>
 #include <vector>
 #include <thread>
 #include <atomic>
@@ -26,6 +27,7 @@ struct cfhd_amd_batch {
 	std::vector<size_t> sample_size;
 	MetaBlock meta;
 	uint32_t steps = 0;
+	bool gpu_entropy = true;
 	double t_fwd = 0, t_entropy_enc = 0, t_entropy_dec = 0, t_inv = 0;   // wall seconds of the last round trip
 };
 
@@ -54,6 +56,11 @@ cfhd_amd_batch *cfhd_amd_batch_create(int width, int height, uint32_t pixel_form
 	QuantState st = {0, -1, 0};
 	derive_quantization(&b->plan, quality, true, 0.0f, &st);
 	if (b->enc.prepare(b->plan, nframes, true) || b->dec.prepare(b->plan, nframes, kind, true)) { delete b; return nullptr; }
+	{
+		const char *e = getenv("CFHD_AMD_ENTROPY");
+		b->gpu_entropy = !(e && strcmp(e, "host") == 0);
+		if (b->gpu_entropy && b->enc.prepare_entropy((size_t)width * height * 2 + 65536)) { delete b; return nullptr; }
+	}
 	b->samples.resize(nframes); b->sample_size.assign(nframes, 0);
 	for (auto &s : b->samples) s.resize((size_t)width * height * 2 + 65536);
 	unsigned char guid[16] = {0};
@@ -78,10 +85,27 @@ long long cfhd_amd_batch_roundtrip(cfhd_amd_batch *b)
 	if (!b) return -1;
 	const FramePlan &plan = b->plan;
 	double t0 = now();
-	if (b->enc.launch_forward() || b->enc.download_coeffs() || b->enc.wait()) return -2;
-	double t1 = now();
 	std::atomic<int> bad(0);
 	const uint32_t base_number = b->steps * (uint32_t)b->n;
+	double t1, t2;
+	if (b->gpu_entropy) {
+		for (int i = 0; i < b->n; i++) {
+			SampleHeaderInfo hdr = { base_number + (uint32_t)i + 1, b->pixel_kind == PIX_2VUY ? 1 : 2, 2, b->quality, true, b->meta.data(), b->meta.size(), nullptr, 0 };
+			if (b->enc.entropy().set_frame_header(i, hdr)) return -6;
+		}
+		if (b->enc.launch_forward() || b->enc.entropy().launch()) return -2;
+		t1 = now();
+		if (b->enc.entropy().download() || b->enc.wait()) return -2;
+		for (int i = 0; i < b->n; i++) {
+			size_t n = b->enc.entropy().sample_bytes(i);
+			if (!n) return -3;
+			memcpy(b->samples[i].data(), b->enc.entropy().host_sample(i), n);
+			b->sample_size[i] = n;
+		}
+		t2 = now();
+	} else {
+	if (b->enc.launch_forward() || b->enc.download_coeffs() || b->enc.wait()) return -2;
+	t1 = now();
 	parallel_for(b->n, b->nthreads, [&](int i) {
 		SampleHeaderInfo hdr = { base_number + (uint32_t)i + 1, b->pixel_kind == PIX_2VUY ? 1 : 2, 2, b->quality, true, b->meta.data(), b->meta.size(), nullptr, 0 };
 		BandSource src; src.coeffs = b->enc.host_coeffs(i);
@@ -89,8 +113,9 @@ long long cfhd_amd_batch_roundtrip(cfhd_amd_batch *b)
 		if (!n) bad++;
 		b->sample_size[i] = n;
 	});
-	double t2 = now();
+	t2 = now();
 	if (bad) return -3;
+	}
 	parallel_for(b->n, b->nthreads, [&](int i) {
 		const uint8_t *s = b->samples[i].data();
 		ParsedSample ps;

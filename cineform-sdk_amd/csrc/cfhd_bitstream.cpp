@@ -112,53 +112,116 @@ void vlc_encode_band(BitWriter &w, const int16_t *band, int width, int height, i
 // ------------------------------------------------------------------------------------------
 // Sample writer
 // ------------------------------------------------------------------------------------------
-size_t write_sample(const FramePlan &plan, const SampleHeaderInfo &hdr, const BandSource &src, uint8_t *out, size_t cap)
+// The syntax walk is written once against a "sink": BitWriter-backed (host entropy: the payloads are produced inline) or
+// the template recorder (GPU entropy: payloads become holes that the device fills, size fields become patches).
+namespace {
+
+struct HostSink {
+	BitWriter w; const FramePlan &plan; const BandSource &src;
+	size_t index_at = 0, channel_start = 0;
+	HostSink(uint8_t *out, size_t cap, const FramePlan &p, const BandSource &s) : w(out, cap), plan(p), src(s) {}
+	void tag(int t, int v) { w.put_tag(t, v); }
+	void tag_opt(int t, int v) { w.put_tag_opt(t, v); }
+	void bytes(const void *p, size_t n) { w.put_bytes(p, n); }
+	void push(int t) { w.size_push(t); }
+	void pop() { w.size_pop(); }
+	void index_entries(int n) { index_at = w.bytes(); for (int i = 0; i < n; i++) w.put_tag(TAG_ENTRY, i); }
+	void channel_begin(int) { channel_start = w.bytes(); }
+	void channel_end(int c) { w.patch32(index_at + 4 * (size_t)c, (uint32_t)(w.bytes() - channel_start)); }
+	void lowpass(int c)
+	{
+		const BandDesc &ll = plan.ch[c].band[2][0];
+		const int16_t *base = src.coeffs + ll.offset;
+		for (int r = 0; r < ll.height; r++) {
+			const int16_t *row = base + (size_t)r * ll.pitch;
+			if (ll.width & 1) { for (int x = 0; x < ll.width; x++) w.put_bits((uint16_t)row[x], 16); }
+			else for (int x = 0; x < ll.width; x += 2) w.put_long(((uint32_t)(uint16_t)row[x] << 16) | (uint16_t)row[x + 1]);
+		}
+		w.pad32();
+	}
+	void band(int c, int lv, int b, int k, int codebook)
+	{
+		const BandDesc &bd = plan.ch[c].band[lv][b];
+		if (src.packed) w.put_bytes(src.packed[c * 9 + k], src.packed_bytes[c * 9 + k]);
+		else vlc_encode_band(w, src.coeffs + bd.offset, bd.width, bd.height, bd.pitch, codebook);
+	}
+};
+
+struct TemplateSink {
+	SampleTemplate &t;
+	std::vector<uint8_t> &b;
+	int holes = 0; int stack[8]; int depth = 0; int index_at = 0; int ch_start_tmpl = 0, ch_start_holes = 0;
+	explicit TemplateSink(SampleTemplate &tt) : t(tt), b(tt.bytes) {}
+	void word(uint32_t w) { b.push_back((uint8_t)(w >> 24)); b.push_back((uint8_t)(w >> 16)); b.push_back((uint8_t)(w >> 8)); b.push_back((uint8_t)w); }
+	void tag(int tg, int v) { word(((uint32_t)(uint16_t)tg << 16) | (uint32_t)(v & 0xffff)); }
+	void tag_opt(int tg, int v) { tag(-tg, v); }
+	void bytes(const void *p, size_t n) { const uint8_t *q = (const uint8_t *)p; b.insert(b.end(), q, q + n); }
+	void push(int tg)
+	{
+		SampleTemplate::Patch p; p.kind = 0; p.at_tmpl = (int)b.size(); p.at_holes = holes; p.tag = tg; p.start_tmpl = p.start_holes = p.end_tmpl = p.end_holes = 0;
+		stack[depth++] = (int)t.patches.size(); t.patches.push_back(p);
+		tag(tg, 0);
+	}
+	void pop() { SampleTemplate::Patch &p = t.patches[stack[--depth]]; p.end_tmpl = (int)b.size(); p.end_holes = holes; }
+	void index_entries(int n) { index_at = (int)b.size(); for (int i = 0; i < n; i++) tag(TAG_ENTRY, i); }
+	void channel_begin(int) { ch_start_tmpl = (int)b.size(); ch_start_holes = holes; }
+	void channel_end(int c)
+	{
+		SampleTemplate::Patch p; p.kind = 1; p.at_tmpl = index_at + 4 * c; p.at_holes = 0; p.tag = 0;
+		p.start_tmpl = ch_start_tmpl; p.start_holes = ch_start_holes; p.end_tmpl = (int)b.size(); p.end_holes = holes;
+		t.patches.push_back(p);
+	}
+	void hole(int kind, int c, int lv, int bnd, int fixed) { SampleTemplate::Hole h = { (int)b.size(), kind, c, lv, bnd, fixed }; t.holes.push_back(h); holes++; }
+	void lowpass(int c) { const BandDesc &ll = t.plan.ch[c].band[2][0]; hole(0, c, 2, 0, (((ll.width * ll.height * 2) + 3) / 4) * 4); }
+	void band(int c, int lv, int bnd, int, int) { hole(1, c, lv, bnd, 0); }
+};
+
+template <typename Sink>
+void walk_sample(Sink &w, const FramePlan &plan, const SampleHeaderInfo &hdr)
 {
-	BitWriter w(out, cap);
 	const int nch = plan.num_channels;
 
 	// --- PutVideoIntraFrameHeader (codec.c:1364) ---
-	w.put_tag(TAG_SAMPLE, SAMPLE_TYPE_IFRAME);
-	w.put_tag(TAG_INDEX, nch);
-	size_t index_at = w.bytes();
-	for (int i = 0; i < nch; i++) w.put_tag(TAG_ENTRY, i);
-	w.put_tag(TAG_TRANSFORM_TYPE, 0);
-	w.put_tag(TAG_NUM_FRAMES, 1);
-	w.put_tag(TAG_NUM_CHANNELS, nch);
-	if (hdr.input_format >= 100) w.put_tag(TAG_INPUT_FORMAT, hdr.input_format);
-	else w.put_tag_opt(TAG_INPUT_FORMAT, hdr.input_format);
-	w.put_tag(TAG_ENCODED_FORMAT, plan.encoded_format);
+	w.tag(TAG_SAMPLE, SAMPLE_TYPE_IFRAME);
+	w.tag(TAG_INDEX, nch);
+	w.index_entries(nch);
+	w.tag(TAG_TRANSFORM_TYPE, 0);
+	w.tag(TAG_NUM_FRAMES, 1);
+	w.tag(TAG_NUM_CHANNELS, nch);
+	if (hdr.input_format >= 100) w.tag(TAG_INPUT_FORMAT, hdr.input_format);
+	else w.tag_opt(TAG_INPUT_FORMAT, hdr.input_format);
+	w.tag(TAG_ENCODED_FORMAT, plan.encoded_format);
 	{
 		int cs = hdr.color_space;
 		if (plan.encoded_format == ENC_YUV422) cs &= ~4;
 		else if (plan.encoded_format == ENC_BAYER) cs = 0;
 		else cs &= ~3;
-		if (cs) w.put_tag_opt(TAG_ENCODED_COLORSPACE, cs);
+		if (cs) w.tag_opt(TAG_ENCODED_COLORSPACE, cs);
 	}
-	w.put_tag(TAG_NUM_WAVELETS, kNumLevels);
-	w.put_tag(TAG_NUM_SUBBANDS, 10);
-	w.put_tag(TAG_NUM_SPATIAL, 2);
-	w.put_tag(TAG_FIRST_WAVELET, 3);
-	w.put_tag(TAG_FRAME_WIDTH, plan.width);
-	w.put_tag(TAG_FRAME_HEIGHT, plan.height);
-	w.put_tag_opt(TAG_FRAME_NUMBER, (int)(hdr.frame_number & 0xffff));
-	w.put_tag(TAG_PRECISION, plan.precision);
-	w.put_tag_opt(TAG_FRAME_DISPLAY_HEIGHT, plan.display_height);
-	w.put_tag_opt(TAG_VERSION, (10 << 12) | (1 << 8) | 0);
-	w.put_tag_opt(TAG_QUALITY_L, hdr.encoder_quality & 0xffff);
-	w.put_tag_opt(TAG_QUALITY_H, (hdr.encoder_quality >> 16) & 0xffff);
+	w.tag(TAG_NUM_WAVELETS, kNumLevels);
+	w.tag(TAG_NUM_SUBBANDS, 10);
+	w.tag(TAG_NUM_SPATIAL, 2);
+	w.tag(TAG_FIRST_WAVELET, 3);
+	w.tag(TAG_FRAME_WIDTH, plan.width);
+	w.tag(TAG_FRAME_HEIGHT, plan.height);
+	w.tag_opt(TAG_FRAME_NUMBER, (int)(hdr.frame_number & 0xffff));
+	w.tag(TAG_PRECISION, plan.precision);
+	w.tag_opt(TAG_FRAME_DISPLAY_HEIGHT, plan.display_height);
+	w.tag_opt(TAG_VERSION, (10 << 12) | (1 << 8) | 0);
+	w.tag_opt(TAG_QUALITY_L, hdr.encoder_quality & 0xffff);
+	w.tag_opt(TAG_QUALITY_H, (hdr.encoder_quality >> 16) & 0xffff);
 	{
 		unsigned table = 0;
 		for (int i = 0; i < kNumLevels; i++) table += (unsigned)plan.prescale[i] << (14 - i * 2);
-		w.put_tag_opt(TAG_PRESCALE_TABLE, (int)table);
+		w.tag_opt(TAG_PRESCALE_TABLE, (int)table);
 	}
 
 	// --- EncodeQuantizedGroup (encoder.c:7559-7620) ---
-	w.size_push(TAG_SAMPLE_SIZE);
+	w.push(TAG_SAMPLE_SIZE);
 	auto put_metadata = [&](const uint8_t *block, size_t size) {
 		if (!block || !size) return;
-		w.put_tag_opt(TAG_METADATA, (int)(size >> 2));
-		w.put_bytes(block, size);
+		w.tag_opt(TAG_METADATA, (int)(size >> 2));
+		w.bytes(block, size);
 	};
 	put_metadata(hdr.meta_global, hdr.meta_global_size);
 	put_metadata(hdr.meta_local, hdr.meta_local_size);
@@ -169,86 +232,92 @@ size_t write_sample(const FramePlan &plan, const SampleHeaderInfo &hdr, const Ba
 		freespace[4] = (uint8_t)(504 & 0xff); freespace[5] = (uint8_t)(504 >> 8);
 		put_metadata(freespace, sizeof(freespace));
 	}
-	w.put_tag_opt(TAG_INTERLACED_FLAGS, 0);
-	w.put_tag_opt(TAG_PROTECTION_FLAGS, 0);
-	w.put_tag_opt(TAG_PICTURE_ASPECT_X, 16);
-	w.put_tag_opt(TAG_PICTURE_ASPECT_Y, 9);
-	if (hdr.progressive) w.put_tag(TAG_SAMPLE_FLAGS, 1);
+	w.tag_opt(TAG_INTERLACED_FLAGS, 0);
+	w.tag_opt(TAG_PROTECTION_FLAGS, 0);
+	w.tag_opt(TAG_PICTURE_ASPECT_X, 16);
+	w.tag_opt(TAG_PICTURE_ASPECT_Y, 9);
+	if (hdr.progressive) w.tag(TAG_SAMPLE_FLAGS, 1);
 
 	for (int c = 0; c < nch; c++) {
 		const ChannelPlan &cp = plan.ch[c];
-		if (c > 0) { w.put_tag(TAG_SAMPLE, SAMPLE_TYPE_CHANNEL); w.put_tag(TAG_CHANNEL, c); }
-		size_t channel_start = w.bytes();
+		if (c > 0) { w.tag(TAG_SAMPLE, SAMPLE_TYPE_CHANNEL); w.tag(TAG_CHANNEL, c); }
+		w.channel_begin(c);
 
 		// --- EncodeLowPassBand (encoder.c:4251): raw 16-bit big-endian coefficients ---
 		const BandDesc &ll = cp.band[2][0];
-		w.put_tag(TAG_MARKER, MARK_LOWPASS_START);
-		w.put_tag(TAG_LOWPASS_SUBBAND, 0);
-		w.put_tag(TAG_NUM_LEVELS, 3);
-		w.put_tag(TAG_LOWPASS_WIDTH, ll.width);
-		w.put_tag(TAG_LOWPASS_HEIGHT, ll.height);
-		w.put_tag(TAG_MARGIN_LEFT, 0); w.put_tag(TAG_MARGIN_TOP, 0); w.put_tag(TAG_MARGIN_RIGHT, 0); w.put_tag(TAG_MARGIN_BOTTOM, 0);
-		w.put_tag(TAG_PIXEL_OFFSET, 0);
-		w.put_tag(TAG_QUANTIZATION, 1);
-		w.put_tag(TAG_PIXEL_DEPTH, 16);
-		w.size_push(TAG_SUBBAND_SIZE);
-		w.put_tag(TAG_MARKER, MARK_COEFF_START);
-		{
-			const int16_t *base = src.coeffs + ll.offset;
-			for (int r = 0; r < ll.height; r++) {
-				const int16_t *row = base + (size_t)r * ll.pitch;
-				if (ll.width & 1) { for (int x = 0; x < ll.width; x++) w.put_bits((uint16_t)row[x], 16); }
-				else for (int x = 0; x < ll.width; x += 2) w.put_long(((uint32_t)(uint16_t)row[x] << 16) | (uint16_t)row[x + 1]);
-			}
-		}
-		w.pad32();
-		w.put_tag(TAG_MARKER, MARK_LOWPASS_END);
-		w.size_pop();
+		w.tag(TAG_MARKER, MARK_LOWPASS_START);
+		w.tag(TAG_LOWPASS_SUBBAND, 0);
+		w.tag(TAG_NUM_LEVELS, 3);
+		w.tag(TAG_LOWPASS_WIDTH, ll.width);
+		w.tag(TAG_LOWPASS_HEIGHT, ll.height);
+		w.tag(TAG_MARGIN_LEFT, 0); w.tag(TAG_MARGIN_TOP, 0); w.tag(TAG_MARGIN_RIGHT, 0); w.tag(TAG_MARGIN_BOTTOM, 0);
+		w.tag(TAG_PIXEL_OFFSET, 0);
+		w.tag(TAG_QUANTIZATION, 1);
+		w.tag(TAG_PIXEL_DEPTH, 16);
+		w.push(TAG_SUBBAND_SIZE);
+		w.tag(TAG_MARKER, MARK_COEFF_START);
+		w.lowpass(c);
+		w.tag(TAG_MARKER, MARK_LOWPASS_END);
+		w.pop();
 
 		// --- EncodeQuantizedFrameTransform (encoder.c:7889) ---
 		int subband = 1, k = 0;
 		for (int lv = kNumLevels - 1; lv >= 0; lv--) {
 			const BandDesc &b1 = cp.band[lv][1];
-			w.put_tag(TAG_MARKER, MARK_HIGHPASS_START);
-			w.put_tag(TAG_WAVELET_TYPE, lv == 0 ? 5 : 3);       // level 1 is the "frame" wavelet (horizontal-temporal type)
-			w.put_tag(TAG_WAVELET_NUMBER, lv + 1);
-			w.put_tag(TAG_WAVELET_LEVEL, lv + 1);
-			w.put_tag(TAG_NUM_BANDS, 4);
-			w.put_tag(TAG_HIGHPASS_WIDTH, b1.width);
-			w.put_tag(TAG_HIGHPASS_HEIGHT, b1.height);
-			w.put_tag(TAG_LOWPASS_BORDER, 0);
-			w.put_tag(TAG_HIGHPASS_BORDER, 0);
-			w.put_tag(TAG_LOWPASS_SCALE, cp.band[lv][0].scale);
-			w.put_tag(TAG_LOWPASS_DIVISOR, 0);
-			w.size_push(TAG_LEVEL_SIZE);
+			w.tag(TAG_MARKER, MARK_HIGHPASS_START);
+			w.tag(TAG_WAVELET_TYPE, lv == 0 ? 5 : 3);       // level 1 is the "frame" wavelet (horizontal-temporal type)
+			w.tag(TAG_WAVELET_NUMBER, lv + 1);
+			w.tag(TAG_WAVELET_LEVEL, lv + 1);
+			w.tag(TAG_NUM_BANDS, 4);
+			w.tag(TAG_HIGHPASS_WIDTH, b1.width);
+			w.tag(TAG_HIGHPASS_HEIGHT, b1.height);
+			w.tag(TAG_LOWPASS_BORDER, 0);
+			w.tag(TAG_HIGHPASS_BORDER, 0);
+			w.tag(TAG_LOWPASS_SCALE, cp.band[lv][0].scale);
+			w.tag(TAG_LOWPASS_DIVISOR, 0);
+			w.push(TAG_LEVEL_SIZE);
 			for (int b = 1; b < 4; b++, subband++, k++) {
 				const BandDesc &bd = cp.band[lv][b];
-				const int codebook = 1;                          // SetCodingFlags (encoder.c:6120): progressive intra => code set 17
-				w.put_tag(TAG_MARKER, MARK_BAND_START);
-				w.put_tag(TAG_BAND_NUMBER, b);
-				w.put_tag(TAG_BAND_CODING_FLAGS, codebook);
-				w.put_tag(TAG_BAND_WIDTH, bd.width);
-				w.put_tag(TAG_BAND_HEIGHT, bd.height);
-				w.put_tag(TAG_BAND_SUBBAND, subband);
-				w.put_tag(TAG_BAND_ENCODING, 3);                 // BAND_ENCODING_RUNLENGTHS
-				w.put_tag(TAG_BAND_QUANTIZATION, bd.quant);
-				w.put_tag(TAG_BAND_SCALE, bd.scale);
-				w.size_push(TAG_SUBBAND_SIZE);
-				w.put_tag(TAG_BAND_HEADER, 0);
-				if (src.packed) w.put_bytes(src.packed[c * 9 + k], src.packed_bytes[c * 9 + k]);
-				else vlc_encode_band(w, src.coeffs + bd.offset, bd.width, bd.height, bd.pitch, codebook);
-				w.put_tag(TAG_BAND_TRAILER, 0);
-				w.size_pop();
+				const int codebook = 1;                      // SetCodingFlags (encoder.c:6120): progressive intra => code set 17
+				w.tag(TAG_MARKER, MARK_BAND_START);
+				w.tag(TAG_BAND_NUMBER, b);
+				w.tag(TAG_BAND_CODING_FLAGS, codebook);
+				w.tag(TAG_BAND_WIDTH, bd.width);
+				w.tag(TAG_BAND_HEIGHT, bd.height);
+				w.tag(TAG_BAND_SUBBAND, subband);
+				w.tag(TAG_BAND_ENCODING, 3);                 // BAND_ENCODING_RUNLENGTHS
+				w.tag(TAG_BAND_QUANTIZATION, bd.quant);
+				w.tag(TAG_BAND_SCALE, bd.scale);
+				w.push(TAG_SUBBAND_SIZE);
+				w.tag(TAG_BAND_HEADER, 0);
+				w.band(c, lv, b, k, codebook);
+				w.tag(TAG_BAND_TRAILER, 0);
+				w.pop();
 			}
-			w.put_tag(TAG_MARKER, MARK_HIGHPASS_END);
-			w.size_pop();
+			w.tag(TAG_MARKER, MARK_HIGHPASS_END);
+			w.pop();
 		}
-		uint32_t channel_bytes = (uint32_t)(w.bytes() - channel_start);
-		w.patch32(index_at + 4 * (size_t)c, channel_bytes);
+		w.channel_end(c);
 	}
-	w.put_tag(TAG_FRAME_TRAILER, 0);
-	w.size_pop();
-	return w.overflow() ? 0 : w.bytes();
+	w.tag(TAG_FRAME_TRAILER, 0);
+	w.pop();
+}
+
+} // namespace
+
+size_t write_sample(const FramePlan &plan, const SampleHeaderInfo &hdr, const BandSource &src, uint8_t *out, size_t cap)
+{
+	HostSink sink(out, cap, plan, src);
+	walk_sample(sink, plan, hdr);
+	return sink.w.overflow() ? 0 : sink.w.bytes();
+}
+
+void build_sample_template(const FramePlan &plan, const SampleHeaderInfo &hdr, SampleTemplate *t)
+{
+	t->plan = plan;
+	t->bytes.clear(); t->holes.clear(); t->patches.clear();
+	TemplateSink sink(*t);
+	walk_sample(sink, plan, hdr);
 }
 
 // ------------------------------------------------------------------------------------------

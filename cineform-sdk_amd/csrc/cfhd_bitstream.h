@@ -72,6 +72,22 @@ struct BandSource {
 	const uint32_t *packed_bytes = nullptr;
 };
 
+// Sample template for the GPU entropy stage: every fixed byte of the sample in order, with the positions where the device
+// inserts payloads (holes: raw lowpass words, entropy coded bands) and the size fields that depend on the payload sizes.
+// A template byte at offset x preceded by h holes ends up at x + (sum of the sizes of the first h holes) in the sample.
+struct SampleTemplate {
+	struct Hole { int tmpl_offset; int kind /*0 = lowpass raw, 1 = coded band*/; int channel, level, band; int fixed_bytes; };
+	struct Patch {          // kind 0: 24/16-bit chunk size at (at_tmpl, at_holes), chunk ends at (end_tmpl, end_holes)
+		int kind;           // kind 1: 32-bit big-endian byte count end - start written at at_tmpl (channel index entry)
+		int at_tmpl, at_holes, start_tmpl, start_holes, end_tmpl, end_holes, tag;
+	};
+	FramePlan plan;
+	std::vector<uint8_t> bytes;
+	std::vector<Hole> holes;
+	std::vector<Patch> patches;
+};
+void build_sample_template(const FramePlan &plan, const SampleHeaderInfo &hdr, SampleTemplate *t);
+
 // Writes a complete intra-frame sample.  Returns the sample size in bytes, or 0 on overflow.
 size_t write_sample(const FramePlan &plan, const SampleHeaderInfo &hdr, const BandSource &src, uint8_t *out, size_t cap);
 

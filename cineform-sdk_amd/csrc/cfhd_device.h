@@ -3,6 +3,7 @@
 #pragma once
 #include "cfhd_core.h"
 #include "cfhd_bitstream.h"
+#include "cfhd_entropy_gpu.h"
 #include <stdint.h>
 #include <stddef.h>
 
@@ -29,6 +30,10 @@ public:
 	// Use frames that already live in HBM (bench / device-resident callers).
 	int set_device_frame(int i, const void *d_frame, int pitch_bytes);
 	int launch_forward();                              // async: all levels, all frames
+	// GPU entropy stage (cfhd_entropy_kernels.h): complete samples are produced in HBM after launch_forward().
+	int prepare_entropy(size_t sample_cap);
+	GpuEntropyEncoder &entropy() { return ent_; }
+	bool has_entropy() const { return ent_ready_; }
 	int download_coeffs();                             // async: final (entropy coded) region of every frame -> pinned host
 	int wait();
 	const int16_t *host_coeffs(int i) const { return h_coeff_ + (size_t)i * plan_.final_elems; }
@@ -48,6 +53,7 @@ private:
 	void *d_jobs_ = nullptr, *h_jobs_ = nullptr; size_t jobs_bytes_ = 0;
 	float kernel_ms_ = 0;
 	bool timed_ = false;
+	GpuEntropyEncoder ent_; bool ent_ready_ = false;
 };
 
 class DecodeBatch {

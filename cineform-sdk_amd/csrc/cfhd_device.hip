@@ -112,6 +112,7 @@ EncodeBatch::~EncodeBatch() { release(); }
 void EncodeBatch::release()
 {
 	if (stream_) hipStreamSynchronize((hipStream_t)stream_);
+	ent_ready_ = false;
 	if (d_in_) hipFree(d_in_);
 	if (h_in_) hipHostFree(h_in_);
 	if (d_coeff_) hipFree(d_coeff_);
@@ -173,6 +174,13 @@ int EncodeBatch::prepare(const FramePlan &plan, int nframes, bool own_input)
 	}
 	jobs_dirty_ = true;
 	return 0;
+}
+
+int EncodeBatch::prepare_entropy(size_t sample_cap)
+{
+	int rc = ent_.prepare(plan_, n_, d_coeff_, plan_.coeff_elems, sample_cap, stream_);
+	ent_ready_ = rc == 0;
+	return rc;
 }
 
 int EncodeBatch::sync_jobs()

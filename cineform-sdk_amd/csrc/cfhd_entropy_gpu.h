@@ -1,0 +1,39 @@
+// cfhd_entropy_gpu.h -- host driver of the GPU entropy stage (cfhd_entropy_kernels.h): builds the per-frame sample
+// templates, the band/segment job tables and runs the four launches on the batch's stream.
+#pragma once
+#include "cfhd_core.h"
+#include "cfhd_bitstream.h"
+#include <vector>
+
+namespace cfhd {
+
+class GpuEntropyEncoder {
+public:
+	GpuEntropyEncoder();
+	~GpuEntropyEncoder();
+	// coeffs: device pyramid of frame 0; frames are coeff_stride elements apart.
+	int prepare(const FramePlan &plan, int nframes, int16_t *d_coeffs, size_t coeff_stride_elems, size_t sample_cap, void *stream);
+	int set_frame_header(int i, const SampleHeaderInfo &hdr);        // header fields / metadata of frame i's sample
+	int launch();                                                    // async: templates H2D + 4 kernels
+	int download();                                                  // async sizes -> sync -> async payloads (call wait on the stream afterwards)
+	int fetch_sizes();                                               // sizes only (device-resident consumers); synchronises the stream
+	const uint8_t *host_sample(int i) const { return h_samples_ + (size_t)i * cap_; }
+	uint8_t *device_sample(int i) { return d_samples_ + (size_t)i * cap_; }
+	uint32_t sample_bytes(int i) const { return h_sizes_[i]; }
+	size_t sample_cap() const { return cap_; }
+	int total_segments() const { return total_segs_; }
+private:
+	struct Host; Host *host_;           // host mirrors of the job tables (types live in the kernel headers)
+	void release();
+	FramePlan plan_; int n_ = 0; size_t cap_ = 0; void *stream_ = nullptr;
+	int nbands_ = 0, total_segs_ = 0;
+	std::vector<SampleTemplate> tmpl_;
+	uint8_t *d_samples_ = nullptr, *h_samples_ = nullptr;
+	uint32_t *d_sizes_ = nullptr, *h_sizes_ = nullptr;
+	void *d_tables_ = nullptr, *d_bands_ = nullptr, *d_segband_ = nullptr, *d_segs_ = nullptr, *d_bandstate_ = nullptr, *d_frames_ = nullptr;
+	uint8_t *d_tmpl_ = nullptr, *h_tmpl_ = nullptr;
+	bool dirty_ = true;
+	int16_t *d_coeffs_ = nullptr; size_t coeff_stride_ = 0;
+};
+
+} // namespace cfhd

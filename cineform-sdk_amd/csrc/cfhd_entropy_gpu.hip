@@ -1,0 +1,118 @@
+// cfhd_entropy_gpu.hip -- see cfhd_entropy_gpu.h
+#include "cfhd_entropy_gpu.h"
+#include "cfhd_entropy_jobs.h"
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include <stdio.h>
+
+namespace cfhd {
+
+int device_init();
+namespace { int g_fail(hipError_t e, const char *what) { fprintf(stderr, "[cfhd_amd] %s: %s\n", what, hipGetErrorString(e)); return (int)e ? (int)e : -1; } }
+#define HIPCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return g_fail(_e, #expr); } while (0)
+
+struct GpuEntropyEncoder::Host { EntHostJobs jobs; std::vector<dev::EntFrameJob> frames; };
+
+GpuEntropyEncoder::GpuEntropyEncoder() : host_(new Host) {}
+GpuEntropyEncoder::~GpuEntropyEncoder() { release(); delete host_; }
+
+void GpuEntropyEncoder::release()
+{
+	void *dev[] = { d_samples_, d_sizes_, d_tables_, d_bands_, d_segband_, d_segs_, d_bandstate_, d_frames_, d_tmpl_ };
+	for (void *p : dev) if (p) (void)hipFree(p);
+	if (h_samples_) (void)hipHostFree(h_samples_);
+	if (h_sizes_) (void)hipHostFree(h_sizes_);
+	if (h_tmpl_) (void)hipHostFree(h_tmpl_);
+	d_samples_ = h_samples_ = nullptr; d_sizes_ = h_sizes_ = nullptr; d_tables_ = d_bands_ = d_segband_ = d_segs_ = d_bandstate_ = d_frames_ = nullptr;
+	d_tmpl_ = h_tmpl_ = nullptr; n_ = 0;
+}
+
+int GpuEntropyEncoder::prepare(const FramePlan &plan, int nframes, int16_t *d_coeffs, size_t stride, size_t sample_cap, void *stream)
+{
+	int rc = device_init();
+	if (rc) return rc;
+	release();
+	plan_ = plan; n_ = nframes; cap_ = (sample_cap + 63) & ~(size_t)63; stream_ = stream; d_coeffs_ = d_coeffs; coeff_stride_ = stride;
+	{
+		dev::EntTables *h = new dev::EntTables;
+		ent_build_tables(h);
+		HIPCHK(hipMalloc(&d_tables_, sizeof(dev::EntTables)));
+		HIPCHK(hipMemcpy(d_tables_, h, sizeof(dev::EntTables), hipMemcpyHostToDevice));
+		delete h;
+	}
+	SampleHeaderInfo hdr0 = { 1, 2, 2, 4, true, nullptr, 0, nullptr, 0 };
+	tmpl_.assign(n_, SampleTemplate());
+	build_sample_template(plan, hdr0, &tmpl_[0]);
+	EntHostJobs &jobs = host_->jobs;
+	if (!ent_build_band_jobs(plan, tmpl_[0], n_, d_coeffs, stride, &jobs)) return -3;
+	nbands_ = jobs.nbands; total_segs_ = (int)jobs.segband.size();
+	HIPCHK(hipMalloc(&d_bands_, jobs.bands.size() * sizeof(dev::EntBandJob)));
+	HIPCHK(hipMemcpy(d_bands_, jobs.bands.data(), jobs.bands.size() * sizeof(dev::EntBandJob), hipMemcpyHostToDevice));
+	HIPCHK(hipMalloc(&d_segband_, jobs.segband.size() * sizeof(int)));
+	HIPCHK(hipMemcpy(d_segband_, jobs.segband.data(), jobs.segband.size() * sizeof(int), hipMemcpyHostToDevice));
+	HIPCHK(hipMalloc(&d_segs_, jobs.segband.size() * sizeof(dev::EntSegState)));
+	HIPCHK(hipMalloc(&d_bandstate_, jobs.bands.size() * sizeof(dev::EntBandState)));
+	HIPCHK(hipMalloc((void **)&d_samples_, cap_ * n_));
+	HIPCHK(hipHostMalloc((void **)&h_samples_, cap_ * n_, hipHostMallocDefault));
+	HIPCHK(hipMalloc((void **)&d_sizes_, sizeof(uint32_t) * n_));
+	HIPCHK(hipHostMalloc((void **)&h_sizes_, sizeof(uint32_t) * n_, hipHostMallocDefault));
+	memset(h_sizes_, 0, sizeof(uint32_t) * n_);
+	HIPCHK(hipMalloc((void **)&d_tmpl_, (size_t)kEntTmplStride * n_));
+	HIPCHK(hipHostMalloc((void **)&h_tmpl_, (size_t)kEntTmplStride * n_, hipHostMallocDefault));
+	memset(h_tmpl_, 0, (size_t)kEntTmplStride * n_);
+	HIPCHK(hipMalloc(&d_frames_, n_ * sizeof(dev::EntFrameJob)));
+	host_->frames.resize(n_);
+	for (int f = 0; f < n_; f++) { SampleHeaderInfo h = hdr0; h.frame_number = (uint32_t)f + 1; if ((rc = set_frame_header(f, h))) return rc; }
+	return 0;
+}
+
+int GpuEntropyEncoder::set_frame_header(int f, const SampleHeaderInfo &hdr)
+{
+	if (f < 0 || f >= n_) return -1;
+	SampleTemplate &t = tmpl_[f];
+	build_sample_template(plan_, hdr, &t);
+	if (!ent_fill_frame_block(plan_, t, f, host_->jobs, d_coeffs_ + (size_t)f * coeff_stride_, h_tmpl_ + (size_t)kEntTmplStride * f)) return -4;
+	host_->frames[f] = ent_frame_job(t, d_tmpl_ + (size_t)kEntTmplStride * f, d_samples_ + cap_ * f, (uint32_t)cap_, d_sizes_ + f);
+	dirty_ = true;
+	return 0;
+}
+
+int GpuEntropyEncoder::launch()
+{
+	hipStream_t st = (hipStream_t)stream_;
+	if (dirty_) {
+		HIPCHK(hipMemcpyAsync(d_tmpl_, h_tmpl_, (size_t)kEntTmplStride * n_, hipMemcpyHostToDevice, st));
+		HIPCHK(hipMemcpyAsync(d_frames_, host_->frames.data(), n_ * sizeof(dev::EntFrameJob), hipMemcpyHostToDevice, st));
+		dirty_ = false;
+	}
+	const dev::EntTables *T = (const dev::EntTables *)d_tables_;
+	(void)hipGetLastError();
+	dev::k_ent_count<<<total_segs_, dev::ENT_THREADS, 0, st>>>((const dev::EntBandJob *)d_bands_, (const int *)d_segband_, (dev::EntSegState *)d_segs_, T);
+	dev::k_ent_scan<<<nbands_ * n_, dev::ENT_THREADS, 0, st>>>((const dev::EntBandJob *)d_bands_, (dev::EntSegState *)d_segs_, (dev::EntBandState *)d_bandstate_, T);
+	dev::k_ent_layout<<<n_, dev::ENT_THREADS, 0, st>>>((const dev::EntFrameJob *)d_frames_, (const dev::EntBandJob *)d_bands_, (const dev::EntSegState *)d_segs_,
+	                                                  (dev::EntBandState *)d_bandstate_, T);
+	dev::k_ent_emit<<<total_segs_, dev::ENT_THREADS, 0, st>>>((const dev::EntBandJob *)d_bands_, (const int *)d_segband_, (const dev::EntSegState *)d_segs_,
+	                                                          (const dev::EntBandState *)d_bandstate_, (const dev::EntFrameJob *)d_frames_, T);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+
+int GpuEntropyEncoder::fetch_sizes()
+{
+	hipStream_t st = (hipStream_t)stream_;
+	HIPCHK(hipMemcpyAsync(h_sizes_, d_sizes_, sizeof(uint32_t) * n_, hipMemcpyDeviceToHost, st));
+	HIPCHK(hipStreamSynchronize(st));
+	return 0;
+}
+
+int GpuEntropyEncoder::download()
+{
+	int rc = fetch_sizes();
+	if (rc) return rc;
+	hipStream_t st = (hipStream_t)stream_;
+	for (int f = 0; f < n_; f++)
+		if (h_sizes_[f]) HIPCHK(hipMemcpyAsync(h_samples_ + cap_ * f, d_samples_ + cap_ * f, h_sizes_[f], hipMemcpyDeviceToHost, st));
+	return 0;
+}
+
+} // namespace cfhd

@@ -1,0 +1,101 @@
+// cfhd_entropy_jobs.h -- host-side construction of the tables the GPU entropy kernels consume (no HIP calls here, so the
+// CPU emulation harness in tests/hipemu builds exactly the same tables as the device driver).
+#pragma once
+#include "cfhd_core.h"
+#include "cfhd_bitstream.h"
+#include "cfhd_entropy_kernels.h"
+#include <vector>
+#include <string.h>
+
+namespace cfhd {
+
+enum { kEntTmplBytes = 6144, kEntWordHolesBytes = 1536, kEntHolesBytes = dev::ENT_MAX_HOLES * (int)sizeof(dev::EntHole), kEntMaxPatches = 64,
+       kEntPatchBytes = kEntMaxPatches * (int)sizeof(dev::EntPatch), kEntTmplStride = kEntTmplBytes + kEntWordHolesBytes + kEntHolesBytes + kEntPatchBytes };
+
+inline void ent_build_tables(dev::EntTables *h)
+{
+	const EntropyTables *t = entropy_tables(1);      // code set 17: progressive intra frames use codebook 1 for every band (encoder.c:6120)
+	memcpy(h->value_code, t->value_code, sizeof(h->value_code));
+	memcpy(h->run_bits, t->run_bits, sizeof(h->run_bits));
+	for (int c = 0; c < 3072; c++) { h->run_count[c] = t->run_count[c]; h->run_size[c] = t->run_size[c]; }
+	h->run_total[0] = 0;
+	for (int c = 1; c < 3072; c++) h->run_total[c] = (uint16_t)(t->run_size[c] + h->run_total[c - t->run_count[c]]);
+	h->band_end_bits = t->band_end_bits; h->band_end_size = t->band_end_size;
+}
+
+struct EntHostJobs {
+	std::vector<dev::EntBandJob> bands;
+	std::vector<int> segband;
+	std::vector<int> band_of_hole;      // template hole -> band job of frame 0 (-1 for lowpass holes)
+	int nbands = 0;                     // coded bands per frame
+};
+
+inline bool ent_build_band_jobs(const FramePlan &plan, const SampleTemplate &t0, int nframes, int16_t *coeffs, size_t stride, EntHostJobs *out)
+{
+	if ((int)t0.holes.size() > dev::ENT_MAX_HOLES || (int)t0.patches.size() > kEntMaxPatches) return false;
+	out->bands.clear(); out->segband.clear();
+	out->band_of_hole.assign(t0.holes.size(), -1);
+	for (int f = 0; f < nframes; f++) {
+		int16_t *base = coeffs + (size_t)f * stride;
+		for (size_t h = 0; h < t0.holes.size(); h++) {
+			const SampleTemplate::Hole &hole = t0.holes[h];
+			if (hole.kind != 1) continue;
+			const BandDesc &bd = plan.ch[hole.channel].band[hole.level][hole.band];
+			dev::EntBandJob j;
+			j.coeffs = base + bd.offset; j.n = bd.height * bd.pitch;
+			j.nseg = (j.n + dev::ENT_SEG - 1) / dev::ENT_SEG; j.seg_base = (int)out->segband.size();
+			j.frame = f; j.hole = (int)h;
+			if (f == 0) out->band_of_hole[h] = (int)out->bands.size();
+			for (int s = 0; s < j.nseg; s++) out->segband.push_back((int)out->bands.size());
+			out->bands.push_back(j);
+		}
+	}
+	out->nbands = (int)out->bands.size() / nframes;
+	return true;
+}
+
+// Serialises frame f's template into one kEntTmplStride block: bytes | holes-in-front-of-word | EntHole[] | EntPatch[].
+inline bool ent_fill_frame_block(const FramePlan &plan, const SampleTemplate &t, int f, const EntHostJobs &jobs, const int16_t *coeffs_f, uint8_t *block)
+{
+	if (t.bytes.size() > (size_t)kEntTmplBytes || t.bytes.size() / 4 > (size_t)kEntWordHolesBytes || t.holes.size() != jobs.band_of_hole.size() ||
+	    t.patches.size() > (size_t)kEntMaxPatches) return false;
+	memcpy(block, t.bytes.data(), t.bytes.size());
+	uint8_t *wh = block + kEntTmplBytes;
+	size_t hole = 0;
+	for (size_t w = 0; w < t.bytes.size() / 4; w++) {
+		while (hole < t.holes.size() && (size_t)t.holes[hole].tmpl_offset <= w * 4) hole++;
+		wh[w] = (uint8_t)hole;
+	}
+	dev::EntHole *eh = (dev::EntHole *)(block + kEntTmplBytes + kEntWordHolesBytes);
+	for (size_t i = 0; i < t.holes.size(); i++) {
+		const SampleTemplate::Hole &src = t.holes[i];
+		const BandDesc &bd = plan.ch[src.channel].band[src.level][src.band];
+		dev::EntHole &d = eh[i];
+		d.tmpl_offset = src.tmpl_offset; d.kind = src.kind; d.fixed_bytes = src.fixed_bytes;
+		d.band_job = src.kind == 1 ? jobs.band_of_hole[i] + f * jobs.nbands : -1;
+		d.lowpass = src.kind == 0 ? coeffs_f + bd.offset : nullptr;
+		d.lp_width = bd.width; d.lp_height = bd.height; d.lp_pitch = bd.pitch;
+	}
+	dev::EntPatch *ep = (dev::EntPatch *)(block + kEntTmplBytes + kEntWordHolesBytes + kEntHolesBytes);
+	for (size_t i = 0; i < t.patches.size(); i++) {
+		const SampleTemplate::Patch &p = t.patches[i];
+		ep[i].kind = p.kind; ep[i].at_tmpl = p.at_tmpl; ep[i].at_holes = p.at_holes; ep[i].start_tmpl = p.start_tmpl; ep[i].start_holes = p.start_holes;
+		ep[i].end_tmpl = p.end_tmpl; ep[i].end_holes = p.end_holes; ep[i].tag = p.tag;
+	}
+	return true;
+}
+
+// Frame job whose pointers refer to `block_addr` (the device -- or, under emulation, host -- address of the serialised block).
+inline dev::EntFrameJob ent_frame_job(const SampleTemplate &t, uint8_t *block_addr, uint8_t *out, uint32_t out_cap, uint32_t *size_out)
+{
+	dev::EntFrameJob fj;
+	fj.out = out; fj.out_cap = out_cap;
+	fj.tmpl = block_addr; fj.tmpl_bytes = (int)t.bytes.size();
+	fj.word_holes = block_addr + kEntTmplBytes;
+	fj.holes = (const dev::EntHole *)(block_addr + kEntTmplBytes + kEntWordHolesBytes); fj.nholes = (int)t.holes.size();
+	fj.patches = (const dev::EntPatch *)(block_addr + kEntTmplBytes + kEntWordHolesBytes + kEntHolesBytes); fj.npatches = (int)t.patches.size();
+	fj.sample_bytes = size_out;
+	return fj;
+}
+
+} // namespace cfhd

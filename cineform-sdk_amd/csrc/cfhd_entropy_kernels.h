@@ -1,0 +1,380 @@
+// cfhd_entropy_kernels.h -- GPU run-length / variable-length coding of the quantized bands, bit-exact with the reference's
+// host loop (Codec/encoder.c:5386 EncodeQuantLongRuns + band end code :6538 + PadBitsTag), and assembly of the complete
+// sample (headers, size chunks, raw lowpass words) in HBM.
+//
+//   k_ent_count   one workgroup per 2048-coefficient segment: zero-run structure + bits of the tokens that start in it
+//   k_ent_scan    one workgroup per band: previous-nonzero max-scan and bit-offset sum-scan over its segments, band size
+//   k_ent_layout  one workgroup per frame: payload offsets, header template copy, size-field patches, raw lowpass words,
+//                 payload zeroing, trailing zero run + band end marker
+//   k_ent_emit    one workgroup per segment: code words assembled in LDS (atomic OR), whole words stored big-endian
+//
+// A token = the zero run in front of a nonzero coefficient (greedy composite run codes, encoder.c:5488-5545) followed by
+// the coefficient's code word (value LUT with cubic companding and sign, :5556-5582).  Runs continue across rows through
+// the zeroed pad columns (the reference's `count += gap`, :5640) and across segments (resolved by k_ent_scan).
+#pragma once
+#include <stdint.h>
+#if defined(CFHD_HIPEMU)
+#include "hip_emu.h"
+#else
+#include <hip/hip_runtime.h>
+#endif
+
+namespace cfhd {
+namespace dev {
+
+enum { ENT_THREADS = 256, ENT_PER_THREAD = 8, ENT_SEG = ENT_THREADS * ENT_PER_THREAD, ENT_LDS_WORDS = 2048, ENT_MAX_HOLES = 40 };
+
+struct EntTables {
+	uint32_t value_code[2048];     // size << 27 | code word, index = value & 0x7ff
+	uint32_t run_bits[3072];       // composite run code for min(run, 3071)
+	uint16_t run_total[3072];      // bits the greedy loop spends on a run of this length (all iterations)
+	uint16_t run_count[3072];      // zeros covered by run_bits[]
+	uint8_t run_size[3072];
+	uint32_t band_end_bits; int band_end_size;
+};
+
+struct EntBandJob {
+	const int16_t *coeffs;         // band base, rows padded with zeros to `pitch`
+	int n;                         // raster length = height * pitch
+	int seg_base, nseg;            // its segments in the per-segment arrays
+	int frame, hole;               // frame of the batch, hole index in the frame's template
+};
+
+struct EntSegState {               // per segment, written by k_ent_count / k_ent_scan
+	int first_nz, last_nz;         // raster index within the band, -1 when the segment is all zero
+	uint32_t bits;                 // k_ent_count: bits of its tokens without the run in front of first_nz; k_ent_scan: with it
+	int prev_nz;                   // last nonzero before this segment (-1: none)
+	uint32_t bitoff;               // bit offset of its first token relative to the band payload
+};
+
+struct EntBandState { uint32_t seg_bits, tail_run, payload_bytes, base_byte; };
+
+struct EntHole { int tmpl_offset, kind, fixed_bytes, band_job; const int16_t *lowpass; int lp_width, lp_height, lp_pitch; };
+struct EntPatch { int kind, at_tmpl, at_holes, start_tmpl, start_holes, end_tmpl, end_holes, tag; };
+
+struct EntFrameJob {
+	uint8_t *out; uint32_t out_cap;            // sample buffer of this frame
+	const uint8_t *tmpl; int tmpl_bytes;       // this frame's header template (frame number / metadata differ per frame)
+	const uint8_t *word_holes;                 // [tmpl_bytes / 4] number of holes in front of each template word
+	const EntHole *holes; int nholes;          // holes[] is per frame (band_job / lowpass pointers)
+	const EntPatch *patches; int npatches;
+	uint32_t *sample_bytes;                    // out: size of the finished sample (0 on overflow)
+};
+
+__device__ __forceinline__ uint32_t bswap32(uint32_t v) { return (v >> 24) | ((v >> 8) & 0xff00u) | ((v << 8) & 0xff0000u) | (v << 24); }
+
+#if defined(CFHD_HIPEMU)
+__device__ __forceinline__ uint32_t atomic_or_u32(uint32_t *p, uint32_t v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+#else
+__device__ __forceinline__ uint32_t atomic_or_u32(uint32_t *p, uint32_t v) { return atomicOr(p, v); }
+#endif
+
+// Exclusive block scans over ENT_THREADS values (Hillis-Steele in LDS; the arrays are tiny, the barriers dominate).
+__device__ __forceinline__ int block_excl_sum(int v, int *buf, int *total)
+{
+	const int t = threadIdx.x;
+	buf[t] = v;
+	__syncthreads();
+	for (int d = 1; d < ENT_THREADS; d <<= 1) {
+		int x = t >= d ? buf[t - d] : 0;
+		__syncthreads();
+		buf[t] += x;
+		__syncthreads();
+	}
+	int incl = buf[t];
+	if (total) *total = buf[ENT_THREADS - 1];
+	__syncthreads();
+	return incl - v;
+}
+__device__ __forceinline__ int block_excl_max(int v, int *buf, int *total)
+{
+	const int t = threadIdx.x;
+	buf[t] = v;
+	__syncthreads();
+	for (int d = 1; d < ENT_THREADS; d <<= 1) {
+		int x = t >= d ? buf[t - d] : -1;
+		__syncthreads();
+		if (x > buf[t]) buf[t] = x;
+		__syncthreads();
+	}
+	int excl = t > 0 ? buf[t - 1] : -1;
+	if (total) *total = buf[ENT_THREADS - 1];
+	__syncthreads();
+	return excl;
+}
+
+__device__ __forceinline__ uint32_t run_bits_any(const EntTables *T, uint32_t run)
+{
+	uint32_t bits = 0;
+	while (run >= 3072) { bits += T->run_size[3071]; run -= T->run_count[3071]; }
+	return bits + T->run_total[run];
+}
+
+__device__ __forceinline__ uint32_t value_entry(const EntTables *T, int v)
+{
+	if (v < 0) { if (v <= -1024) v = -1023; v += 2048; } else if (v >= 1024) v = 1023;
+	return T->value_code[v];
+}
+
+// Loads the 8 coefficients of this thread (raster indices base .. base+7, zero beyond the band).
+__device__ __forceinline__ void ent_load8(const EntBandJob &job, int base, int *v)
+{
+	if (base + ENT_PER_THREAD <= job.n) {
+		const uint4 q = *(const uint4 *)(job.coeffs + base);
+		const uint32_t w[4] = { q.x, q.y, q.z, q.w };
+#pragma unroll
+		for (int k = 0; k < 4; k++) { v[2 * k] = (int)(int16_t)(w[k] & 0xffffu); v[2 * k + 1] = (int)(int16_t)(w[k] >> 16); }
+	} else {
+#pragma unroll
+		for (int k = 0; k < ENT_PER_THREAD; k++) v[k] = (base + k < job.n) ? (int)job.coeffs[base + k] : 0;
+	}
+}
+
+// =============================================================================================
+__global__ void __launch_bounds__(ENT_THREADS) k_ent_count(const EntBandJob *bands, const int *seg_band, EntSegState *segs, const EntTables *T)
+{
+	__shared__ int s_scan[ENT_THREADS];
+	const int seg = blockIdx.x;
+	const EntBandJob &job = bands[seg_band[seg]];
+	const int local = seg - job.seg_base;
+	const int base = local * ENT_SEG + threadIdx.x * ENT_PER_THREAD;
+	int v[ENT_PER_THREAD];
+	ent_load8(job, base, v);
+	int my_last = -1, my_first = 0x7fffffff;
+#pragma unroll
+	for (int k = 0; k < ENT_PER_THREAD; k++) if (v[k]) { my_last = base + k; if (my_first == 0x7fffffff) my_first = base + k; }
+	int seg_last;
+	int prev = block_excl_max(my_last, s_scan, &seg_last);      // last nonzero of the segment in front of this thread
+	uint32_t bits = 0;
+#pragma unroll
+	for (int k = 0; k < ENT_PER_THREAD; k++) {
+		if (!v[k]) continue;
+		if (prev >= 0) bits += T->run_total[base + k - prev - 1];  // run inside the segment: < 2048
+		bits += value_entry(T, v[k]) >> 27;
+		prev = base + k;
+	}
+	int total_bits;
+	block_excl_sum((int)bits, s_scan, &total_bits);
+	// first nonzero of the segment = the only one whose thread saw prev < 0 at a nonzero: min over threads
+	s_scan[threadIdx.x] = my_first;
+	__syncthreads();
+	for (int d = ENT_THREADS / 2; d > 0; d >>= 1) {
+		if ((int)threadIdx.x < d && s_scan[threadIdx.x + d] < s_scan[threadIdx.x]) s_scan[threadIdx.x] = s_scan[threadIdx.x + d];
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) {
+		EntSegState &s = segs[seg];
+		s.first_nz = s_scan[0] == 0x7fffffff ? -1 : s_scan[0];
+		s.last_nz = seg_last;
+		s.bits = (uint32_t)total_bits;
+	}
+}
+
+// =============================================================================================
+__global__ void __launch_bounds__(ENT_THREADS) k_ent_scan(const EntBandJob *bands, EntSegState *segs, EntBandState *band_state, const EntTables *T)
+{
+	__shared__ int s_scan[ENT_THREADS];
+	const EntBandJob &job = bands[blockIdx.x];
+	int carry_prev = -1; uint32_t carry_bits = 0;
+	for (int c0 = 0; c0 < job.nseg; c0 += ENT_THREADS) {
+		const int i = c0 + threadIdx.x;
+		const bool valid = i < job.nseg;
+		EntSegState s; s.first_nz = -1; s.last_nz = -1; s.bits = 0;
+		if (valid) s = segs[job.seg_base + i];
+		int chunk_last;
+		int prev = block_excl_max(s.last_nz, s_scan, &chunk_last);
+		if (prev < carry_prev) prev = carry_prev;
+		uint32_t bits = s.bits;
+		if (s.first_nz >= 0) bits += run_bits_any(T, (uint32_t)(s.first_nz - prev - 1));
+		int chunk_bits;
+		int off = block_excl_sum((int)bits, s_scan, &chunk_bits);
+		if (valid) {
+			EntSegState &o = segs[job.seg_base + i];
+			o.prev_nz = prev; o.bits = bits; o.bitoff = carry_bits + (uint32_t)off;
+		}
+		if (chunk_last > carry_prev) carry_prev = chunk_last;
+		carry_bits += (uint32_t)chunk_bits;
+	}
+	if (threadIdx.x == 0) {
+		EntBandState &b = band_state[blockIdx.x];
+		b.seg_bits = carry_bits;
+		b.tail_run = (uint32_t)(job.n - 1 - carry_prev);
+		uint32_t bits = carry_bits + run_bits_any(T, b.tail_run) + (uint32_t)T->band_end_size;
+		b.payload_bytes = ((bits + 31u) >> 5) << 2;
+		b.base_byte = 0;
+	}
+}
+
+// Appends one code word at bit position pos of a big-endian word stream held in (little-endian) memory words; single writer.
+__device__ __forceinline__ void put_code_plain(uint32_t *words, uint64_t pos, uint32_t code, int size)
+{
+	if (!size) return;
+	const uint64_t v = (uint64_t)code << (64 - size - (int)(pos & 31));
+	uint32_t *w = words + (pos >> 5);
+	w[0] |= bswap32((uint32_t)(v >> 32));
+	const uint32_t lo = (uint32_t)v;
+	if (lo) w[1] |= bswap32(lo);
+}
+
+// =============================================================================================
+__global__ void __launch_bounds__(ENT_THREADS) k_ent_layout(const EntFrameJob *frames, const EntBandJob *bands, const EntSegState *segs,
+                                                             EntBandState *band_state, const EntTables *T)
+{
+	const EntFrameJob &f = frames[blockIdx.x];
+	__shared__ uint32_t s_cum[ENT_MAX_HOLES + 1];       // bytes of the holes in front of hole h
+	__shared__ int s_ok;
+	const int tid = threadIdx.x;
+	if (tid == 0) {
+		uint32_t cum = 0;
+		for (int h = 0; h < f.nholes; h++) {
+			s_cum[h] = cum;
+			const EntHole &hole = f.holes[h];
+			cum += hole.kind == 0 ? (uint32_t)hole.fixed_bytes : band_state[hole.band_job].payload_bytes;
+		}
+		s_cum[f.nholes] = cum;
+		const uint32_t total = (uint32_t)f.tmpl_bytes + cum;
+		s_ok = total <= f.out_cap;
+		*f.sample_bytes = s_ok ? total : 0u;
+	}
+	__syncthreads();
+	if (!s_ok) return;                                   // uniform: the whole workgroup leaves
+	uint32_t *out = (uint32_t *)f.out;
+	// 1. fixed words of the template
+	const uint32_t *tw = (const uint32_t *)f.tmpl;
+	for (int i = tid; i < f.tmpl_bytes / 4; i += ENT_THREADS) out[i + (s_cum[f.word_holes[i]] >> 2)] = tw[i];
+	__syncthreads();
+	// 2. size fields
+	for (int i = tid; i < f.npatches; i += ENT_THREADS) {
+		const EntPatch &p = f.patches[i];
+		const uint32_t at = (uint32_t)p.at_tmpl + s_cum[p.at_holes], end = (uint32_t)p.end_tmpl + s_cum[p.end_holes];
+		if (p.kind == 0) {
+			uint32_t size = (end - at) >> 2; size = size ? size - 1 : 0;
+			int tag = p.tag;
+			if (tag & 0x2000) { tag |= (int)((size >> 16) & 0xff); size &= 0xffff; } else size &= 0xffff;
+			tag = -tag;
+			out[at >> 2] = bswap32(((uint32_t)(uint16_t)tag << 16) | size);
+		} else {
+			const uint32_t start = (uint32_t)p.start_tmpl + s_cum[p.start_holes];
+			out[at >> 2] = bswap32(end - start);
+		}
+	}
+	// 3. payload holes
+	for (int h = 0; h < f.nholes; h++) {
+		const EntHole &hole = f.holes[h];
+		const uint32_t base = (uint32_t)hole.tmpl_offset + s_cum[h];
+		if (hole.kind == 0) {
+			// raw lowpass: 16-bit big-endian, row after row without the pitch padding, zero padded to 32 bits (encoder.c:4423-4441)
+			const int count = hole.lp_width * hole.lp_height;
+			for (int i = tid; i < hole.fixed_bytes / 4; i += ENT_THREADS) {
+				uint32_t w = 0;
+#pragma unroll
+				for (int k = 0; k < 2; k++) {
+					const int e = 2 * i + k;
+					uint32_t v = 0;
+					if (e < count) { const int r = e / hole.lp_width, c = e - r * hole.lp_width; v = (uint16_t)hole.lowpass[(size_t)r * hole.lp_pitch + c]; }
+					w = (w << 16) | v;
+				}
+				out[(base >> 2) + i] = bswap32(w);
+			}
+		} else {
+			const uint32_t bytes = band_state[hole.band_job].payload_bytes;
+			for (uint32_t i = tid; i < bytes / 4; i += ENT_THREADS) out[(base >> 2) + i] = 0;
+			if (tid == 0) band_state[hole.band_job].base_byte = base;
+		}
+	}
+	__syncthreads();
+	// 4. trailing zero run + band end marker of every band (one thread per band; the payload words were zeroed above)
+	for (int h = tid; h < f.nholes; h += ENT_THREADS) {
+		const EntHole &hole = f.holes[h];
+		if (hole.kind != 1) continue;
+		const EntBandState &b = band_state[hole.band_job];
+		uint32_t *words = out + ((hole.tmpl_offset + s_cum[h]) >> 2);
+		uint64_t pos = b.seg_bits;
+		uint32_t run = b.tail_run;
+		while (run > 0) {
+			const uint32_t idx = run < 3072 ? run : 3071;
+			put_code_plain(words, pos, T->run_bits[idx], T->run_size[idx]);
+			pos += T->run_size[idx];
+			run -= T->run_count[idx];
+		}
+		put_code_plain(words, pos, T->band_end_bits, T->band_end_size);
+	}
+}
+
+// =============================================================================================
+__global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(const EntBandJob *bands, const int *seg_band, const EntSegState *segs,
+                                                           const EntBandState *band_state, const EntFrameJob *frames, const EntTables *T)
+{
+	__shared__ int s_scan[ENT_THREADS];
+	__shared__ uint32_t s_words[ENT_LDS_WORDS + 2];
+	const int seg = blockIdx.x;
+	const int bj = seg_band[seg];
+	const EntBandJob &job = bands[bj];
+	const EntSegState st = segs[seg];
+	if (st.bits == 0) return;                            // uniform: nothing starts in this segment
+	const EntFrameJob &f = frames[job.frame];
+	if (*f.sample_bytes == 0) return;                    // overflow detected by k_ent_layout
+	const int local = seg - job.seg_base;
+	const int base = local * ENT_SEG + threadIdx.x * ENT_PER_THREAD;
+	int v[ENT_PER_THREAD];
+	ent_load8(job, base, v);
+	int my_last = -1;
+#pragma unroll
+	for (int k = 0; k < ENT_PER_THREAD; k++) if (v[k]) my_last = base + k;
+	int prev = block_excl_max(my_last, s_scan, nullptr);
+	if (prev < 0) prev = st.prev_nz;                     // the run in front of the segment's first nonzero reaches back into earlier segments
+	const int prev0 = prev;
+	uint32_t bits = 0;
+#pragma unroll
+	for (int k = 0; k < ENT_PER_THREAD; k++) {
+		if (!v[k]) continue;
+		bits += run_bits_any(T, (uint32_t)(base + k - prev - 1)) + (value_entry(T, v[k]) >> 27);
+		prev = base + k;
+	}
+	const uint32_t my_off = (uint32_t)block_excl_sum((int)bits, s_scan, nullptr);
+
+	uint32_t *out = (uint32_t *)(f.out + band_state[bj].base_byte);
+	const uint64_t seg_pos = st.bitoff;                  // bit position of the segment inside the band payload
+	const uint32_t first_word = (uint32_t)(seg_pos >> 5), last_word = (uint32_t)((seg_pos + st.bits - 1) >> 5);
+	const uint32_t nwords = last_word - first_word + 1;
+	const bool use_lds = nwords <= ENT_LDS_WORDS;        // uniform
+	if (use_lds) for (int i = threadIdx.x; i < (int)nwords + 1; i += ENT_THREADS) s_words[i] = 0;
+	__syncthreads();
+	{
+		uint64_t pos = seg_pos + my_off;
+		prev = prev0;
+#pragma unroll
+		for (int k = 0; k < ENT_PER_THREAD; k++) {
+			if (!v[k]) continue;
+			uint32_t run = (uint32_t)(base + k - prev - 1);
+			const uint32_t e = value_entry(T, v[k]);
+			// run codes, then the value code
+			for (int part = 0; ; part++) {
+				uint32_t code; int size;
+				if (run > 0) { const uint32_t idx = run < 3072 ? run : 3071; code = T->run_bits[idx]; size = T->run_size[idx]; run -= T->run_count[idx]; }
+				else { code = e & 0x7FFFFFFu; size = (int)(e >> 27); part = -1; }
+				const uint64_t val = (uint64_t)code << (64 - size - (int)(pos & 31));
+				const uint32_t hi = (uint32_t)(val >> 32), lo = (uint32_t)val;
+				const uint32_t w = (uint32_t)(pos >> 5);
+				if (use_lds) { atomic_or_u32(&s_words[w - first_word], hi); if (lo) atomic_or_u32(&s_words[w - first_word + 1], lo); }
+				else { atomic_or_u32(&out[w], bswap32(hi)); if (lo) atomic_or_u32(&out[w + 1], bswap32(lo)); }
+				pos += size;
+				if (part < 0) break;
+			}
+			prev = base + k;
+		}
+	}
+	__syncthreads();
+	if (use_lds) {
+		// interior words belong to this segment alone: plain coalesced stores; the first and last word may be shared with
+		// the neighbouring segments (or the band's trailer): OR them into the zeroed payload
+		for (int i = threadIdx.x; i < (int)nwords; i += ENT_THREADS) {
+			const uint32_t w = bswap32(s_words[i]);
+			if (i == 0 || i == (int)nwords - 1) { if (w) atomic_or_u32(&out[first_word + i], w); }
+			else out[first_word + i] = w;
+		}
+	}
+}
+
+} // namespace dev
+} // namespace cfhd

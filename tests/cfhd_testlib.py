@@ -292,11 +292,13 @@ def emu():
     if _emu is None:
         src = os.path.join(ROOT, "tests", "hipemu", "emu_kernels.cpp")
         deps = [src, os.path.join(ROOT, "tests", "hipemu", "hip_emu.h")] + [
-            os.path.join(PRODUCT_DIR, "csrc", f) for f in os.listdir(os.path.join(PRODUCT_DIR, "csrc")) if f.endswith(".h")]
+            os.path.join(PRODUCT_DIR, "csrc", f) for f in os.listdir(os.path.join(PRODUCT_DIR, "csrc")) if f.endswith((".h", ".cpp"))]
         if not os.path.exists(EMU_SO) or any(os.path.getmtime(d) > os.path.getmtime(EMU_SO) for d in deps):
             os.makedirs(os.path.dirname(EMU_SO), exist_ok=True)
+            csrc = os.path.join(PRODUCT_DIR, "csrc")
+            host = [os.path.join(csrc, f) for f in ("cfhd_tables.cpp", "cfhd_bitstream.cpp")]      # host-only product sources the entropy emulation needs
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + os.path.dirname(src),
-                                   "-I" + os.path.join(PRODUCT_DIR, "csrc"), src, "-o", EMU_SO])
+                                   "-I" + csrc, src] + host + ["-o", EMU_SO])
         _emu = ctypes.CDLL(EMU_SO)
     return _emu
 

@@ -2,7 +2,7 @@
 // Runs the product's HIP kernels (cineform-sdk_amd/csrc/cfhd_kernels.h, unmodified source) on the CPU through
 // hip_emu.h so the `-m "not gpu"` suite can check their tiling / LDS / border logic against the oracle.
 #include "hip_emu.h"
-thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+dim3 threadIdx, blockIdx, blockDim, gridDim;
 #include "cfhd_kernels.h"
 
 using namespace cfhd::dev;
@@ -63,3 +63,38 @@ void emu_inv_yuv422(int16_t **bands /*[3][4]*/, const int *band_pitch, int w, in
 }
 
 } // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------
+// GPU entropy stage under emulation: same tables / job construction as the device driver (cfhd_entropy_jobs.h).
+// Needs the product's host objects for entropy_tables() / build_sample_template(): tests link them in.
+// ------------------------------------------------------------------------------------------------------------
+#include "cfhd_entropy_jobs.h"
+
+extern "C" long emu_entropy_encode(int width, int height, int pixel_kind, int quality, unsigned frame_number, int16_t *coeffs /* product pyramid layout */,
+                                   const uint8_t *meta, size_t meta_size, uint8_t *out, size_t cap)
+{
+	using namespace cfhd;
+	FramePlan plan;
+	if (!build_frame_plan(&plan, width, height, pixel_kind, ENC_YUV422)) return -1;
+	QuantState st = {0, -1, 0};
+	derive_quantization(&plan, quality, true, 0.0f, &st);
+	SampleHeaderInfo hdr = { frame_number, pixel_kind == PIX_2VUY ? 1 : 2, 2, quality, true, meta, meta_size, nullptr, 0 };
+	SampleTemplate t;
+	build_sample_template(plan, hdr, &t);
+	EntHostJobs jobs;
+	if (!ent_build_band_jobs(plan, t, 1, coeffs, plan.coeff_elems, &jobs)) return -2;
+	std::vector<uint8_t> block(kEntTmplStride, 0);
+	if (!ent_fill_frame_block(plan, t, 0, jobs, coeffs, block.data())) return -3;
+	uint32_t size = 0;
+	dev::EntFrameJob fj = ent_frame_job(t, block.data(), out, (uint32_t)cap, &size);
+	static dev::EntTables tables; static bool ready = false;
+	if (!ready) { ent_build_tables(&tables); ready = true; }
+	std::vector<dev::EntSegState> segs(jobs.segband.size());
+	std::vector<dev::EntBandState> bstate(jobs.bands.size());
+	const int nseg = (int)jobs.segband.size(), nb = (int)jobs.bands.size();
+	hipemu::launch(dim3(nseg), dim3(dev::ENT_THREADS), [&] { dev::k_ent_count(jobs.bands.data(), jobs.segband.data(), segs.data(), &tables); });
+	hipemu::launch(dim3(nb), dim3(dev::ENT_THREADS), [&] { dev::k_ent_scan(jobs.bands.data(), segs.data(), bstate.data(), &tables); });
+	hipemu::launch(dim3(1), dim3(dev::ENT_THREADS), [&] { dev::k_ent_layout(&fj, jobs.bands.data(), segs.data(), bstate.data(), &tables); });
+	hipemu::launch(dim3(nseg), dim3(dev::ENT_THREADS), [&] { dev::k_ent_emit(jobs.bands.data(), jobs.segband.data(), segs.data(), bstate.data(), &fj, &tables); });
+	return (long)size;
+}

@@ -2,18 +2,17 @@
 //
 // A tiny CPU stand-in for the subset of the HIP device model our kernels use, so that the *same kernel
 // source* (cineform-sdk_amd/csrc/cfhd_kernels.h) can be executed block by block on the host in the
-// `-m "not gpu"` test suite: one OS thread per GPU thread of a workgroup, a real barrier for
-// __syncthreads(), `__shared__` mapped to block-shared static storage (workgroups run one after another).
+// `-m "not gpu"` test suite: one fiber per GPU thread of a workgroup, __syncthreads() as a scheduling point,
+// `__shared__` mapped to block-shared static storage (workgroups run one after another).
 // It exists because this container has no GPU; it is never linked into the product library and is not a
 // fallback path -- the product fails loudly without a HIP device.
 #pragma once
 #include <stdint.h>
 #include <string.h>
+#include <stdlib.h>
+#include <ucontext.h>
 #include <algorithm>
-#include <thread>
 #include <vector>
-#include <mutex>
-#include <condition_variable>
 #include <functional>
 
 #define CFHD_HIPEMU 1
@@ -30,49 +29,69 @@ struct uint2 { unsigned x, y; };
 struct uint4 { unsigned x, y, z, w; };
 struct int2 { int x, y; };
 
+// One fiber (ucontext) per GPU thread of the workgroup, all on the calling OS thread: __syncthreads() yields to the
+// scheduler, which resumes the fibers round-robin, so every fiber reaches barrier k before any passes it -- the same
+// guarantee the hardware gives -- and `__shared__` (block-shared static storage) needs no locking.  Workgroups run one
+// after another.  Thread-uniform early returns are fine (a finished fiber is simply skipped).
+extern dim3 threadIdx, blockIdx, blockDim, gridDim;
+
 namespace hipemu {
-struct Barrier {
-	std::mutex m; std::condition_variable cv; unsigned count = 0, waiting = 0, generation = 0;
-	void reset(unsigned n) { count = n; waiting = 0; }
-	void wait() {
-		std::unique_lock<std::mutex> lk(m);
-		unsigned gen = generation;
-		if (++waiting == count) { waiting = 0; generation++; cv.notify_all(); }
-		else cv.wait(lk, [&] { return gen != generation; });
-	}
-};
-inline Barrier &barrier() { static Barrier b; return b; }
+struct Fiber { ucontext_t ctx; char *stack; bool done; dim3 tid; };
+struct Sched { ucontext_t main; Fiber *current; std::function<void()> *body; };
+inline Sched &sched() { static Sched s; return s; }
+inline void fiber_entry()
+{
+	Sched &s = sched();
+	(*s.body)();
+	s.current->done = true;
+	swapcontext(&s.current->ctx, &s.main);
+}
 }
 
-extern thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
-inline void __syncthreads() { hipemu::barrier().wait(); }
+inline void __syncthreads()
+{
+	hipemu::Sched &s = hipemu::sched();
+	hipemu::Fiber *me = s.current;
+	swapcontext(&me->ctx, &s.main);      // back to the scheduler; resumed after every other fiber reached this barrier
+	threadIdx = me->tid;
+}
 using std::min; using std::max;
 
 namespace hipemu {
-// Runs kernel(args...) for every workgroup of the grid; workgroups are executed sequentially, the threads
-// of one workgroup concurrently (so barriers and shared-memory hand-offs behave as on the device).
 template <typename F>
-void launch(dim3 grid, dim3 block, F body)
+void launch(dim3 grid, dim3 block, F body_fn)
 {
 	const unsigned nthreads = block.x * block.y * block.z;
-	Barrier &bar = barrier();
-	Barrier block_done;     // separates workgroups: static __shared__ storage is reused
-	bar.reset(nthreads);
-	block_done.reset(nthreads);
-	std::vector<std::thread> pool;
-	for (unsigned t = 0; t < nthreads; t++) {
-		pool.emplace_back([=, &block_done]() {
-			threadIdx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
-			blockDim = block; gridDim = grid;
-			for (unsigned bz = 0; bz < grid.z; bz++)
-				for (unsigned by = 0; by < grid.y; by++)
-					for (unsigned bx = 0; bx < grid.x; bx++) {
-						blockIdx = dim3(bx, by, bz);
-						body();
-						block_done.wait();
+	const size_t stack_bytes = 256 * 1024;
+	Sched &s = sched();
+	std::function<void()> body = body_fn;
+	s.body = &body;
+	std::vector<Fiber> fibers(nthreads);
+	for (auto &f : fibers) f.stack = (char *)malloc(stack_bytes);
+	blockDim = block; gridDim = grid;
+	for (unsigned bz = 0; bz < grid.z; bz++)
+		for (unsigned by = 0; by < grid.y; by++)
+			for (unsigned bx = 0; bx < grid.x; bx++) {
+				blockIdx = dim3(bx, by, bz);
+				for (unsigned t = 0; t < nthreads; t++) {
+					Fiber &f = fibers[t];
+					f.done = false;
+					f.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+					getcontext(&f.ctx);
+					f.ctx.uc_stack.ss_sp = f.stack; f.ctx.uc_stack.ss_size = stack_bytes; f.ctx.uc_link = &s.main;
+					makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+				}
+				for (bool any = true; any;) {
+					any = false;
+					for (unsigned t = 0; t < nthreads; t++) {
+						Fiber &f = fibers[t];
+						if (f.done) continue;
+						s.current = &f; threadIdx = f.tid;
+						swapcontext(&s.main, &f.ctx);
+						if (!f.done) any = true;
 					}
-		});
-	}
-	for (auto &th : pool) th.join();
+				}
+			}
+	for (auto &f : fibers) free(f.stack);
 }
 }

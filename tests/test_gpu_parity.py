@@ -208,3 +208,18 @@ def test_reference_harness_links_unchanged_and_prints_same_numbers():
         for (sa, pa), (sb, pb) in zip(a[fmt], b[fmt][:10]):
             assert sa == sb, "%s compressed size %d vs reference %d" % (fmt, sa, sb)
             assert abs(pa - pb) <= 0.1 + 1e-6, "%s PSNR %.1f vs reference %.1f" % (fmt, pa, pb)
+
+
+def test_gpu_entropy_and_host_entropy_paths_agree():
+    """CFHD_AMD_ENTROPY=host keeps the run-length/VLC stage on host threads (north_star arrangement); the default runs it on
+    the GPU (cfhd_entropy_kernels.h).  Both must give the same bytes (and both are compared with the reference above)."""
+    w, h = 1280, 720
+    frames = [synth_yuy2(w, h, s)[0] for s in (51, 52)]
+    a = amd_encode_frames(frames, w * 2, w, h)
+    os.environ["CFHD_AMD_ENTROPY"] = "host"
+    try:
+        b = amd_encode_frames(frames, w * 2, w, h)
+    finally:
+        del os.environ["CFHD_AMD_ENTROPY"]
+    for x, y in zip(a, b):
+        assert mask_volatile_metadata(x) == mask_volatile_metadata(y)

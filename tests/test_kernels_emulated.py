@@ -92,3 +92,52 @@ def test_inv_yuv422(w, h, dh, uyvy):
     emu().emu_inv_yuv422(ptrs, iarr(pitches), w, h, dh, uyvy, 2, 1234, p8(e), 4 * w)
     assert np.all((e == outs[0]) | (e == outs[1]))
     assert np.any(e != outs[0]) and np.any(e != outs[1])        # the dither really toggles
+
+
+def _emu_entropy(plan, coeffs, frame_number, meta):
+    out = np.zeros(plan.width * plan.height * 4 + 65536, dtype=np.uint8)
+    m = np.frombuffer(meta, dtype=np.uint8).copy()
+    E = emu()
+    E.emu_entropy_encode.restype = ctypes.c_long
+    E.emu_entropy_encode.argtypes = [ctypes.c_int] * 4 + [ctypes.c_uint, c_i16p, c_u8p, ctypes.c_size_t, c_u8p, ctypes.c_size_t]
+    n = E.emu_entropy_encode(plan.width, plan.height, plan.pixkind, plan.quality, frame_number, p16(coeffs), p8(m), len(meta), p8(out), out.size)
+    assert n > 0, n
+    return bytes(out[:n])
+
+
+@pytest.mark.parametrize("w,h,seed", [(192, 96, 1), (336, 252, 3), (720, 480, 4)])
+def test_gpu_entropy_stage_emulated_equals_host_writer(w, h, seed):
+    """The four entropy kernels (count / scan / layout / emit) under emulation produce the complete sample byte for byte
+    as the product's host writer does (which test_host_bitstream pins against the reference encoder)."""
+    frame, pitch = synth_yuy2(w, h, seed)
+    plan = Plan(w, h)
+    coeffs = oracle_forward_yuv422(plan, frame, pitch)
+    meta = b"GUID\x10\x00\x00G" + bytes(range(16)) + b"UFRM\x04\x00\x00L" + (7).to_bytes(4, "little")
+    want = product_write_sample_host(plan, coeffs, 5, meta_global=meta)
+    got = _emu_entropy(plan, coeffs, 5, meta)
+    assert len(got) == len(want)
+    if got != want:
+        first = next(k for k in range(len(got)) if got[k] != want[k])
+        raise AssertionError("first difference at byte %d of %d" % (first, len(got)))
+
+
+def test_gpu_entropy_stage_emulated_extreme_bands():
+    """All-zero frame (runs of hundreds of thousands of zeros spanning every segment), saturated values (clamp to +-1023),
+    dense noise (no zeros at all)."""
+    w, h = 208, 104
+    plan = Plan(w, h)
+    rng = np.random.default_rng(5)
+    meta = b"GUID\x10\x00\x00G" + bytes(16)
+    for mode in ("zero", "sparse", "dense", "huge"):
+        coeffs = np.zeros(plan.coeff_elems, dtype=np.int16)
+        for c in range(3):
+            plan.view(coeffs, c, 2, 0)[:, : plan.band[(c, 2, 0)]["width"]] = rng.integers(0, 16000, size=(plan.band[(c, 2, 0)]["height"], plan.band[(c, 2, 0)]["width"]))
+            for lv in range(3):
+                for b in (1, 2, 3):
+                    d = plan.band[(c, lv, b)]; v = plan.view(coeffs, c, lv, b)[:, : d["width"]]
+                    if mode == "sparse": v[rng.random(v.shape) < 0.0005] = 3
+                    elif mode == "dense": v[:] = rng.integers(1, 40, size=v.shape) * rng.choice([-1, 1], size=v.shape)
+                    elif mode == "huge": v[:] = rng.choice([0, 0, 0, 5000, -5000, 1023, -1024, 1], size=v.shape)
+        want = product_write_sample_host(plan, coeffs, 1, meta_global=meta)
+        got = _emu_entropy(plan, coeffs, 1, meta)
+        assert got == want, mode
