@@ -192,9 +192,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int16", "data": data,
             "config": {"workload": "1920x1080 YUY2 4:2:2 FILMSCAN1 encode+decode round trip, frames resident in HBM", "frames_per_step_per_gpu": args.batch,
-                       "entropy_stage": "host threads (%d per rank)" % threads, "sample_bytes_per_frame": int(total_bytes / args.batch),
-                       "stage_ms_per_step": {"fwd_kernels+d2h": round(1000 * stage[0] / args.steps, 3), "host_entropy_encode": round(1000 * stage[1] / args.steps, 3),
-                                             "host_entropy_decode": round(1000 * stage[2] / args.steps, 3), "h2d+inv_kernels": round(1000 * stage[3] / args.steps, 3)}},
+                       "entropy_stage": os.environ.get("CFHD_AMD_ENTROPY", "gpu") + (" (%d host threads)" % threads if os.environ.get("CFHD_AMD_ENTROPY") == "host" else " (k_ent_* / k_dec_* kernels; samples cross PCIe as bytes)"), "sample_bytes_per_frame": int(total_bytes / args.batch),
+                       "stage_ms_per_step": {"encode_submit": round(1000 * stage[0] / args.steps, 3), "encode_wait+sample_d2h": round(1000 * stage[1] / args.steps, 3),
+                                             "decode_parse+stage": round(1000 * stage[2] / args.steps, 3), "decode_h2d+kernels": round(1000 * stage[3] / args.steps, 3)}},
             "roofline": {"bound": "hbm", "kernel": "k_fwd_yuv422", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "launch_ms": round(ms, 4)},
         }

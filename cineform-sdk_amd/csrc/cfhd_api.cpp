@@ -182,6 +182,16 @@ int encode_one(EncodeBatch &batch, EncodeParams &p, const void *frame, int pitch
 	meta_remove_hidden(global); meta_remove_hidden(local);
 	SampleHeaderInfo hdr = { frame_number, color_format_of(p.pixel_kind), p.color_space, p.quality, p.progressive,
 	                         global.data(), global.size(), local.data(), local.size() };
+	{
+		// The one metadata override that changes the sample syntax for 2-D clips (Codec/encoder.c:9043-9046 UpdateEncoderOverrides):
+		// TAG_VIDEO_CHANNELS present => ignore_overrides => the channel number tag is written.  More than one video channel is 3-D
+		// (two stacked encodes per sample), which is outside the hot path.
+		uint32_t sz; unsigned char ty;
+		const uint32_t VCHN = CFHD_FOURCC('V', 'C', 'H', 'N');
+		const uint8_t *v = meta_find(global.data(), global.size(), VCHN, &sz, &ty);
+		if (!v) v = meta_find(local.data(), local.size(), VCHN, &sz, &ty);
+		if (v) { uint32_t n; memcpy(&n, v, 4); if (n > 1) return ERR_BADFORMAT; hdr.channel_number_tag = true; }
+	}
 	if ((rc = batch.upload_frame(0, frame, pitch))) return ERR_INTERNAL;
 	if (batch.has_entropy()) {
 		// GPU entropy stage: the finished sample comes back, not the coefficients
@@ -695,7 +705,19 @@ CFHD_Error CFHD_DecodeSample(CFHD_DecoderRef ref, void *sample, size_t size, voi
 	    ps.num_channels != d->plan.num_channels) return fail_zero(ERR_BADSAMPLE);
 	if (!d->batch_ready) {
 		if (d->batch.prepare(d->plan, 1, d->out_kind, true)) return ERR_INTERNAL;
+		if (gpu_entropy_enabled() && d->batch.prepare_entropy((size_t)d->plan.width * d->plan.height * 2 + 65536)) return ERR_INTERNAL;
 		d->batch_ready = true;
+	}
+	if (d->batch.has_entropy() && size <= (size_t)d->plan.width * d->plan.height * 2 + 65536) {
+		// GPU entropy decoder: ship the sample bytes, one lane per band rebuilds the pyramid in HBM
+		if (d->batch.entropy().set_sample_host(0, s, size)) return fail_zero(ERR_BADSAMPLE);
+		if (d->batch.entropy().launch()) return ERR_INTERNAL;
+		if (d->batch.launch_inverse(0x2545F491u * ++d->frames_decoded)) return ERR_INTERNAL;
+		if (d->batch.download_frame(0, out, pitch)) return ERR_INTERNAL;
+		if (d->batch.wait()) return ERR_INTERNAL;
+		if (d->batch.entropy().check()) return fail_zero(ERR_BADSAMPLE);
+		d->batch.finish_frame(0, out, pitch);
+		return ERR_OKAY;
 	}
 	// Entropy decode on the host into the pinned coefficient staging (dequantized values, as the reference's FSM delivers them).
 	d->batch.clear_host_coeffs(0);

@@ -59,7 +59,7 @@ cfhd_amd_batch *cfhd_amd_batch_create(int width, int height, uint32_t pixel_form
 	{
 		const char *e = getenv("CFHD_AMD_ENTROPY");
 		b->gpu_entropy = !(e && strcmp(e, "host") == 0);
-		if (b->gpu_entropy && b->enc.prepare_entropy((size_t)width * height * 2 + 65536)) { delete b; return nullptr; }
+		if (b->gpu_entropy && (b->enc.prepare_entropy((size_t)width * height * 2 + 65536) || b->dec.prepare_entropy((size_t)width * height * 2 + 65536))) { delete b; return nullptr; }
 	}
 	b->samples.resize(nframes); b->sample_size.assign(nframes, 0);
 	for (auto &s : b->samples) s.resize((size_t)width * height * 2 + 65536);
@@ -116,6 +116,14 @@ long long cfhd_amd_batch_roundtrip(cfhd_amd_batch *b)
 	t2 = now();
 	if (bad) return -3;
 	}
+	double t3;
+	if (b->gpu_entropy) {
+		// samples travel back to the GPU as bytes (H2D of the compressed size); one lane per band rebuilds the pyramid in HBM
+		for (int i = 0; i < b->n; i++) if (b->dec.entropy().set_sample_host(i, b->samples[i].data(), b->sample_size[i])) return -4;
+		t3 = now();
+		if (b->dec.entropy().launch() || b->dec.launch_inverse(0xA511E9B3u * (b->steps + 1)) || b->dec.wait()) return -5;
+		if (b->dec.entropy().check()) return -7;
+	} else {
 	parallel_for(b->n, b->nthreads, [&](int i) {
 		const uint8_t *s = b->samples[i].data();
 		ParsedSample ps;
@@ -139,9 +147,10 @@ long long cfhd_amd_batch_roundtrip(cfhd_amd_batch *b)
 				}
 		}
 	});
-	double t3 = now();
+	t3 = now();
 	if (bad) return -4;
 	if (b->dec.upload_coeffs() || b->dec.launch_inverse(0xA511E9B3u * (b->steps + 1)) || b->dec.wait()) return -5;
+	}
 	double t4 = now();
 	b->t_fwd = t1 - t0; b->t_entropy_enc = t2 - t1; b->t_entropy_dec = t3 - t2; b->t_inv = t4 - t3;
 	b->steps++;

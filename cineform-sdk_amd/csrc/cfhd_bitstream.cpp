@@ -216,6 +216,8 @@ void walk_sample(Sink &w, const FramePlan &plan, const SampleHeaderInfo &hdr)
 		w.tag_opt(TAG_PRESCALE_TABLE, (int)table);
 	}
 
+	if (hdr.channel_number_tag) w.tag_opt(TAG_ENCODED_CHANNEL_NUMBER, 0);
+
 	// --- EncodeQuantizedGroup (encoder.c:7559-7620) ---
 	w.push(TAG_SAMPLE_SIZE);
 	auto put_metadata = [&](const uint8_t *block, size_t size) {

@@ -23,7 +23,7 @@ enum Tag : int {
 	TAG_CHANNEL = 62, TAG_INTERLACED_FLAGS = 63, TAG_PROTECTION_FLAGS = 64, TAG_PICTURE_ASPECT_X = 65, TAG_PICTURE_ASPECT_Y = 66,
 	TAG_SAMPLE_FLAGS = 68, TAG_FRAME_NUMBER = 69, TAG_PRECISION = 70, TAG_INPUT_FORMAT = 71, TAG_BAND_CODING_FLAGS = 72,
 	TAG_VERSION = 79, TAG_QUALITY_L = 80, TAG_QUALITY_H = 81, TAG_BAND_SECONDPASS = 82, TAG_PRESCALE_TABLE = 83,
-	TAG_ENCODED_FORMAT = 84, TAG_FRAME_DISPLAY_HEIGHT = 85, TAG_ENCODED_COLORSPACE = 91,
+	TAG_ENCODED_FORMAT = 84, TAG_FRAME_DISPLAY_HEIGHT = 85, TAG_ENCODED_COLORSPACE = 91, TAG_ENCODED_CHANNEL_NUMBER = 93,
 	TAG_SUBBAND_SIZE = 0x2000, TAG_LEVEL_SIZE = 0x2100, TAG_SAMPLE_SIZE = 0x2200,
 	TAG_METADATA = 0x4002,
 };
@@ -62,6 +62,7 @@ struct SampleHeaderInfo {
 	bool progressive;
 	const uint8_t *meta_global; size_t meta_global_size;
 	const uint8_t *meta_local; size_t meta_local_size;
+	bool channel_number_tag = false;   // metadata carried TAG_VIDEO_CHANNELS: the reference then also writes -ENCODED_CHANNEL_NUMBER=0 (encoder.c:7553, :9043-9046)
 };
 
 // Payload provider for one highpass band: either host-side VLC from coefficients, or bytes already

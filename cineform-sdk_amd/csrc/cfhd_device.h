@@ -67,6 +67,10 @@ public:
 	int16_t *device_coeffs(int i) { return d_coeff_ + (size_t)i * plan_.coeff_elems; }
 	void clear_host_coeffs(int i);
 	int upload_coeffs();                               // async: pinned host -> HBM (final region of every frame)
+	// GPU entropy decoder (k_dec_bands): samples in, dequantized pyramid built in HBM (replaces host_coeffs()/upload_coeffs()).
+	int prepare_entropy(size_t sample_cap);
+	GpuEntropyDecoder &entropy() { return ent_; }
+	bool has_entropy() const { return ent_ready_; }
 	int set_device_output(int i, void *d_out, int pitch_bytes);
 	int launch_inverse(uint32_t dither_seed);          // async
 	int download_frame(int i, void *out, int pitch_bytes);   // async D2H into pinned staging, then row copy after wait
@@ -87,6 +91,7 @@ private:
 	void *d_jobs_ = nullptr, *h_jobs_ = nullptr; size_t jobs_bytes_ = 0;
 	float kernel_ms_ = 0;
 	bool timed_ = false;
+	GpuEntropyDecoder ent_; bool ent_ready_ = false;
 };
 
 int packed_frame_pitch(int pixel_kind, int width);     // bytes per row of a tightly packed frame

@@ -265,6 +265,7 @@ DecodeBatch::~DecodeBatch() { release(); }
 void DecodeBatch::release()
 {
 	if (stream_) hipStreamSynchronize((hipStream_t)stream_);
+	ent_ready_ = false;
 	if (d_out_) hipFree(d_out_);
 	if (h_out_) hipHostFree(h_out_);
 	if (d_coeff_) hipFree(d_coeff_);
@@ -325,6 +326,13 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 	}
 	jobs_dirty_ = true;
 	return 0;
+}
+
+int DecodeBatch::prepare_entropy(size_t sample_cap)
+{
+	int rc = ent_.prepare(plan_, n_, d_coeff_, plan_.coeff_elems, sample_cap, out_kind_, stream_);
+	ent_ready_ = rc == 0;
+	return rc;
 }
 
 int DecodeBatch::sync_jobs()

@@ -36,4 +36,28 @@ private:
 	int16_t *d_coeffs_ = nullptr; size_t coeff_stride_ = 0;
 };
 
+
+// Decoder counterpart: parses each sample on the host (tag walk only), ships the sample bytes to HBM (unless they already live
+// there) and lets one GPU lane per coded band rebuild the dequantized coefficient pyramid.
+class GpuEntropyDecoder {
+public:
+	GpuEntropyDecoder();
+	~GpuEntropyDecoder();
+	int prepare(const FramePlan &plan, int nframes, int16_t *d_coeffs, size_t coeff_stride_elems, size_t sample_cap, int out_pixel_kind, void *stream);
+	// Sample bytes on the host: staged through pinned memory and copied to HBM by launch().
+	int set_sample_host(int i, const uint8_t *sample, size_t size);
+	// Sample bytes already in HBM at d_sample; host_copy (same bytes) is only parsed for the band offsets.
+	int set_sample_device(int i, const uint8_t *d_sample, const uint8_t *host_copy, size_t size);
+	int launch();                        // async: clear pyramids, (H2D samples), job tables, k_dec_bands + k_dec_lowpass
+	int check();                         // after the stream was synchronised: 0 when every band decoded cleanly
+private:
+	struct Host; Host *host_;
+	void release();
+	FramePlan plan_; int n_ = 0, out_kind_ = 0; size_t cap_ = 0, coeff_stride_ = 0; void *stream_ = nullptr;
+	int16_t *d_coeffs_ = nullptr;
+	uint8_t *d_samples_ = nullptr, *h_samples_ = nullptr;
+	void *d_tables_ = nullptr, *d_bandjobs_ = nullptr, *d_lowjobs_ = nullptr;
+	int *d_errors_ = nullptr, *h_errors_ = nullptr;
+};
+
 } // namespace cfhd

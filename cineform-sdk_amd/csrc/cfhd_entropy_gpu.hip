@@ -115,4 +115,94 @@ int GpuEntropyEncoder::download()
 	return 0;
 }
 
+
+// =============================================================================================
+struct GpuEntropyDecoder::Host {
+	std::vector<std::vector<dev::DecBandJob>> bands;      // per frame
+	std::vector<std::vector<dev::DecLowpassJob>> lows;
+	std::vector<size_t> host_bytes;                       // bytes to copy H2D per frame (0: sample already in HBM)
+	std::vector<dev::DecBandJob> flat_bands; std::vector<dev::DecLowpassJob> flat_lows;
+};
+
+GpuEntropyDecoder::GpuEntropyDecoder() : host_(new Host) {}
+GpuEntropyDecoder::~GpuEntropyDecoder() { release(); delete host_; }
+
+void GpuEntropyDecoder::release()
+{
+	void *dev[] = { d_samples_, d_tables_, d_bandjobs_, d_lowjobs_, d_errors_ };
+	for (void *p : dev) if (p) (void)hipFree(p);
+	if (h_samples_) (void)hipHostFree(h_samples_);
+	if (h_errors_) (void)hipHostFree(h_errors_);
+	d_samples_ = h_samples_ = nullptr; d_tables_ = d_bandjobs_ = d_lowjobs_ = nullptr; d_errors_ = h_errors_ = nullptr; n_ = 0;
+}
+
+int GpuEntropyDecoder::prepare(const FramePlan &plan, int nframes, int16_t *d_coeffs, size_t stride, size_t sample_cap, int out_kind, void *stream)
+{
+	int rc = device_init();
+	if (rc) return rc;
+	release();
+	plan_ = plan; n_ = nframes; cap_ = (sample_cap + 63) & ~(size_t)63; stream_ = stream; d_coeffs_ = d_coeffs; coeff_stride_ = stride; out_kind_ = out_kind;
+	std::vector<uint32_t> t = build_dec_tables(1);
+	HIPCHK(hipMalloc(&d_tables_, t.size() * 4));
+	HIPCHK(hipMemcpy(d_tables_, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+	HIPCHK(hipMalloc((void **)&d_samples_, cap_ * n_));
+	HIPCHK(hipHostMalloc((void **)&h_samples_, cap_ * n_, hipHostMallocDefault));
+	const size_t max_bands = (size_t)n_ * kMaxChannels * 9, max_lows = (size_t)n_ * kMaxChannels;
+	HIPCHK(hipMalloc(&d_bandjobs_, max_bands * sizeof(dev::DecBandJob)));
+	HIPCHK(hipMalloc(&d_lowjobs_, max_lows * sizeof(dev::DecLowpassJob)));
+	HIPCHK(hipMalloc((void **)&d_errors_, sizeof(int)));
+	HIPCHK(hipHostMalloc((void **)&h_errors_, sizeof(int), hipHostMallocDefault));
+	*h_errors_ = 0;
+	host_->bands.assign(n_, {}); host_->lows.assign(n_, {}); host_->host_bytes.assign(n_, 0);
+	return 0;
+}
+
+int GpuEntropyDecoder::set_sample_host(int i, const uint8_t *sample, size_t size)
+{
+	if (i < 0 || i >= n_ || size > cap_) return -1;
+	memcpy(h_samples_ + cap_ * i, sample, size);
+	int rc = set_sample_device(i, d_samples_ + cap_ * i, sample, size);
+	if (rc == 0) host_->host_bytes[i] = (size + 3) & ~(size_t)3;
+	return rc;
+}
+
+int GpuEntropyDecoder::set_sample_device(int i, const uint8_t *d_sample, const uint8_t *host_copy, size_t size)
+{
+	if (i < 0 || i >= n_) return -1;
+	ParsedSample ps;
+	if (parse_sample(host_copy, size, &ps) != 0) return -2;
+	if (ps.width != plan_.width || ps.display_height != plan_.display_height || ps.encoded_format != plan_.encoded_format || ps.num_channels != plan_.num_channels) return -3;
+	host_->bands[i].clear(); host_->lows[i].clear(); host_->host_bytes[i] = 0;
+	if (!dec_build_jobs(ps, plan_, d_sample, d_coeffs_ + (size_t)i * coeff_stride_, out_kind_, &host_->bands[i], &host_->lows[i])) return -4;
+	return 0;
+}
+
+int GpuEntropyDecoder::launch()
+{
+	hipStream_t st = (hipStream_t)stream_;
+	// jobs ordered band-type major so that the 64 lanes of a wave decode bands of similar length
+	std::vector<dev::DecBandJob> &fb = host_->flat_bands; std::vector<dev::DecLowpassJob> &fl = host_->flat_lows;
+	fb.clear(); fl.clear();
+	size_t per_frame = 0;
+	for (int f = 0; f < n_; f++) per_frame = host_->bands[f].size() > per_frame ? host_->bands[f].size() : per_frame;
+	for (size_t k = 0; k < per_frame; k++) for (int f = 0; f < n_; f++) if (k < host_->bands[f].size()) fb.push_back(host_->bands[f][k]);
+	for (int f = 0; f < n_; f++) for (const dev::DecLowpassJob &j : host_->lows[f]) fl.push_back(j);
+	if (fb.empty()) return -1;
+	HIPCHK(hipMemset2DAsync(d_coeffs_, coeff_stride_ * 2, 0, (size_t)plan_.final_elems * 2, n_, st));
+	HIPCHK(hipMemsetAsync(d_errors_, 0, sizeof(int), st));
+	for (int f = 0; f < n_; f++)
+		if (host_->host_bytes[f]) HIPCHK(hipMemcpyAsync(d_samples_ + cap_ * f, h_samples_ + cap_ * f, host_->host_bytes[f], hipMemcpyHostToDevice, st));
+	HIPCHK(hipMemcpyAsync(d_bandjobs_, fb.data(), fb.size() * sizeof(dev::DecBandJob), hipMemcpyHostToDevice, st));
+	HIPCHK(hipMemcpyAsync(d_lowjobs_, fl.data(), fl.size() * sizeof(dev::DecLowpassJob), hipMemcpyHostToDevice, st));
+	(void)hipGetLastError();
+	const int nb = (int)fb.size();
+	dev::k_dec_bands<<<(nb + dev::DEC_THREADS - 1) / dev::DEC_THREADS, dev::DEC_THREADS, 0, st>>>((const dev::DecBandJob *)d_bandjobs_, nb, (const dev::DecTables *)d_tables_, d_errors_);
+	dev::k_dec_lowpass<<<dim3(8, (unsigned)fl.size()), 256, 0, st>>>((const dev::DecLowpassJob *)d_lowjobs_);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipMemcpyAsync(h_errors_, d_errors_, sizeof(int), hipMemcpyDeviceToHost, st));
+	return 0;
+}
+
+int GpuEntropyDecoder::check() { return *h_errors_ ? -1 : 0; }
+
 } // namespace cfhd

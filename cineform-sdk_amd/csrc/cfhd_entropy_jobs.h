@@ -23,6 +23,10 @@ inline void ent_build_tables(dev::EntTables *h)
 	h->band_end_bits = t->band_end_bits; h->band_end_size = t->band_end_size;
 }
 
+// Two-level decode tables from the base Huffman codes (cfhd_tables.cpp keeps them in EntropyTables::dec_lut for 12 bits;
+// here every code word up to 26 bits is resolved by table lookups only).  Returns the serialised dev::DecTables.
+std::vector<uint32_t> build_dec_tables(int codebook);
+
 struct EntHostJobs {
 	std::vector<dev::EntBandJob> bands;
 	std::vector<int> segband;
@@ -96,6 +100,30 @@ inline dev::EntFrameJob ent_frame_job(const SampleTemplate &t, uint8_t *block_ad
 	fj.patches = (const dev::EntPatch *)(block_addr + kEntTmplBytes + kEntWordHolesBytes + kEntHolesBytes); fj.npatches = (int)t.patches.size();
 	fj.sample_bytes = size_out;
 	return fj;
+}
+
+
+// Decode jobs of one parsed sample. `sample_addr` / `coeff_base` are the addresses the kernels will see (device, or host under
+// emulation).  Returns false when the sample does not match the plan.
+inline bool dec_build_jobs(const ParsedSample &ps, const FramePlan &plan, const uint8_t *sample_addr, int16_t *coeff_base, int out_pixel_kind,
+                           std::vector<dev::DecBandJob> *bands, std::vector<dev::DecLowpassJob> *lowpass)
+{
+	for (int c = 0; c < plan.num_channels; c++) {
+		const ParsedBand &lp = ps.lowpass[c];
+		const BandDesc &ll = plan.ch[c].band[2][0];
+		if (!lp.present || lp.width != ll.width || lp.height != ll.height) return false;
+		dev::DecLowpassJob lj = { sample_addr + lp.offset, coeff_base + ll.offset, ll.width, ll.height, ll.pitch, lowpass_bias(plan.precision, ll.width, out_pixel_kind) };
+		lowpass->push_back(lj);
+		for (int lv = 0; lv < kNumLevels; lv++)
+			for (int b = 1; b < 4; b++) {
+				const ParsedBand &pb = ps.high[c][lv][b];
+				const BandDesc &bd = plan.ch[c].band[lv][b];
+				if (!pb.present || pb.width != bd.width || pb.height != bd.height || (pb.offset & 3) || (pb.codebook != 1 && pb.codebook != 0)) return false;
+				dev::DecBandJob bj = { sample_addr + pb.offset, pb.bytes, coeff_base + bd.offset, bd.height * bd.pitch, pb.quant };
+				bands->push_back(bj);
+			}
+	}
+	return true;
 }
 
 } // namespace cfhd

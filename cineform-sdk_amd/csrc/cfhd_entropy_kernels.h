@@ -376,5 +376,85 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(const EntBandJob *band
 	}
 }
 
+
+// =============================================================================================
+// Decoder side: one lane per coded band (the code is sequential inside a band; bands are independent because each has its
+// own SUBBAND_SIZE chunk, codec.c:1778).  A wave decodes 64 bands of similar size in lock step; the first-level lookup table
+// (12 bits) lives in LDS, the second level (code words of 13..26 bits: magnitudes >= 24 and the band end marker) in HBM.
+// Equivalent to Codec/decoder.c:19534 DecodeBandFSM16sNoGap with the companding expansion of codebooks.c:1345-1378 and the
+// dequantization of decoder.c:20597-20608 folded into the table values (value * quant, 16-bit product).
+// =============================================================================================
+enum { DEC_K1 = 12, DEC_THREADS = 64 };
+
+struct DecTables {
+	uint32_t lut1[1 << DEC_K1];   // bits 0-4 code length (31: continue in lut2, base = e >> 10, extra index bits = (e >> 5) & 31)
+	uint32_t lut2_size;           // bits 5-15 zero run, bits 16-31 expanded magnitude (0xffff: band end)
+	uint32_t lut2[1];             // variable length
+};
+
+struct DecBandJob {
+	const uint8_t *bits; uint32_t bytes;      // coded payload (after BAND_HEADER, before BAND_TRAILER); 4-byte aligned
+	int16_t *dst; int n;                      // band raster (height * pitch), zeroed beforehand
+	int quant;
+};
+
+struct DecLowpassJob { const uint8_t *src; int16_t *dst; int width, height, pitch, bias; };
+
+__global__ void __launch_bounds__(DEC_THREADS) k_dec_bands(const DecBandJob *jobs, int njobs, const DecTables *T, int *errors)
+{
+	__shared__ uint32_t s_lut[1 << DEC_K1];
+	for (int i = threadIdx.x; i < (1 << DEC_K1); i += DEC_THREADS) s_lut[i] = T->lut1[i];
+	__syncthreads();
+	const int j = blockIdx.x * DEC_THREADS + threadIdx.x;
+	if (j >= njobs) return;
+	const DecBandJob job = jobs[j];
+	const uint32_t *words = (const uint32_t *)job.bits;
+	const uint32_t nwords = job.bytes >> 2;
+	uint32_t wpos = 0;
+	uint64_t acc = 0; int have = 0;
+	int idx = 0, err = 0;
+	for (;;) {
+		if (have <= 32) {
+			const uint32_t w = wpos < nwords ? bswap32(words[wpos]) : 0u;
+			wpos++;
+			acc |= (uint64_t)w << (32 - have);
+			have += 32;
+		}
+		uint32_t e = s_lut[(uint32_t)(acc >> (64 - DEC_K1))];
+		if ((e & 31u) == 31u) {
+			const int nb = (int)((e >> 5) & 31u);
+			e = T->lut2[(e >> 10) + (uint32_t)((acc << DEC_K1) >> (64 - nb))];
+		}
+		const int len = (int)(e & 31u);
+		if (len == 0) { err = 1; break; }
+		acc <<= len; have -= len;
+		const uint32_t mag = e >> 16;
+		if (mag == 0xffffu) break;                       // band end marker
+		if (mag) {
+			const int negative = (int)(acc >> 63);
+			acc <<= 1; have -= 1;
+			if (idx >= job.n) { err = 2; break; }
+			const int v = (int)mag * job.quant;
+			job.dst[idx++] = (int16_t)(negative ? -v : v);
+		} else idx += (int)((e >> 5) & 0x7ffu);
+		if (wpos > nwords + 2) { err = 3; break; }       // ran off the payload without meeting the end marker
+	}
+	if (err) atomic_or_u32((uint32_t *)errors, 1u);
+}
+
+// Raw 16-bit big-endian lowpass coefficients + the reference decoder's bias (decoder.c:12240-12290, :12468-12545).
+__global__ void __launch_bounds__(256) k_dec_lowpass(const DecLowpassJob *jobs)
+{
+	const DecLowpassJob job = jobs[blockIdx.y];
+	const int count = job.width * job.height;
+	for (int i = blockIdx.x * 256 + threadIdx.x; i < count; i += gridDim.x * 256) {
+		const int r = i / job.width, c = i - r * job.width;
+		int v = (int)(int16_t)(((uint32_t)job.src[2 * i] << 8) | job.src[2 * i + 1]);
+		if (job.width & 1) v = (int)(uint16_t)v;          // the odd-width path reads 16 unsigned bits (GetBits)
+		v += job.bias;
+		job.dst[(size_t)r * job.pitch + c] = (int16_t)(v > 0x7fff ? 0x7fff : v);
+	}
+}
+
 } // namespace dev
 } // namespace cfhd

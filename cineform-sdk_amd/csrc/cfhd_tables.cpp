@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <mutex>
 #include <algorithm>
+#include <vector>
 
 namespace cfhd {
 
@@ -105,6 +106,49 @@ const EntropyTables *entropy_tables(int codebook)
 	});
 	if (codebook != 1 && codebook != 2) return nullptr;
 	return &g_tables[codebook];
+}
+
+// Serialised dev::DecTables (cfhd_entropy_kernels.h): lut1[4096], lut2_size, lut2[].
+std::vector<uint32_t> build_dec_tables(int codebook)
+{
+	const uint8_t *ml = codebook == 2 ? cfhd_cs18_mag_len : cfhd_cs17_mag_len;
+	const uint32_t *mc = codebook == 2 ? cfhd_cs18_mag_code : cfhd_cs17_mag_code;
+	const uint32_t (*rn)[3] = codebook == 2 ? cfhd_cs18_run : cfhd_cs17_run;
+	const uint32_t *be = codebook == 2 ? cfhd_cs18_band_end : cfhd_cs17_band_end;
+	const EntropyTables *t = entropy_tables(codebook);
+	struct Code { uint32_t bits; int len; uint32_t payload; };
+	std::vector<Code> codes;
+	for (int m = 0; m < 256; m++) codes.push_back({ mc[m], ml[m], m == 0 ? (1u << 5) : ((uint32_t)t->mag_expand[m] << 16) });
+	for (int i = 0; i < 7; i++) codes.push_back({ rn[i][0], (int)rn[i][1], rn[i][2] << 5 });
+	codes.push_back({ be[0], (int)be[1], 0xffffu << 16 });
+	const int K = 12;
+	std::vector<uint32_t> lut1(1u << K, 0), lut2;
+	// long codes: group by their 12-bit prefix; each group gets a table indexed by the following (maxlen - 12) bits
+	std::vector<int> maxlen(1u << K, 0);
+	for (const Code &c : codes) if (c.len > K) { uint32_t p = c.bits >> (c.len - K); if (c.len > maxlen[p]) maxlen[p] = c.len; }
+	for (uint32_t p = 0; p < (1u << K); p++) if (maxlen[p]) {
+		const int nb = maxlen[p] - K;
+		lut1[p] = ((uint32_t)lut2.size() << 10) | ((uint32_t)nb << 5) | 31u;
+		lut2.resize(lut2.size() + ((size_t)1 << nb), 0);
+	}
+	for (const Code &c : codes) {
+		if (c.len <= K) {
+			const uint32_t base = c.bits << (K - c.len);
+			for (uint32_t s = 0; s < (1u << (K - c.len)); s++) lut1[base + s] = c.payload | (uint32_t)c.len;
+		} else {
+			const uint32_t p = c.bits >> (c.len - K);
+			const uint32_t e = lut1[p];
+			const int nb = (int)((e >> 5) & 31u);
+			const uint32_t rest = c.bits & ((1u << (c.len - K)) - 1);
+			const uint32_t base = (e >> 10) + (rest << (nb - (c.len - K)));
+			for (uint32_t s = 0; s < (1u << (nb - (c.len - K))); s++) lut2[base + s] = c.payload | (uint32_t)c.len;
+		}
+	}
+	std::vector<uint32_t> out;
+	out.insert(out.end(), lut1.begin(), lut1.end());
+	out.push_back((uint32_t)lut2.size());
+	out.insert(out.end(), lut2.begin(), lut2.end());
+	return out;
 }
 
 // Raw base codes for slow-path decoding of code words longer than kDecBits.

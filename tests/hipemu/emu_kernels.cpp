@@ -98,3 +98,26 @@ extern "C" long emu_entropy_encode(int width, int height, int pixel_kind, int qu
 	hipemu::launch(dim3(nseg), dim3(dev::ENT_THREADS), [&] { dev::k_ent_emit(jobs.bands.data(), jobs.segband.data(), segs.data(), bstate.data(), &fj, &tables); });
 	return (long)size;
 }
+
+// GPU entropy decoder under emulation: parse on the host (product parser), decode every band with k_dec_bands / k_dec_lowpass.
+extern "C" int emu_entropy_decode(const uint8_t *sample, size_t size, int pixel_kind, int16_t *coeffs, size_t coeff_elems)
+{
+	using namespace cfhd;
+	ParsedSample ps;
+	if (parse_sample(sample, size, &ps) != 0) return -1;
+	FramePlan plan;
+	if (!build_frame_plan(&plan, ps.width, ps.display_height, pixel_kind, ps.encoded_format)) return -2;
+	plan.precision = ps.precision;
+	if (coeff_elems < plan.coeff_elems) return -3;
+	memset(coeffs, 0, (size_t)plan.coeff_elems * 2);
+	std::vector<dev::DecBandJob> bands; std::vector<dev::DecLowpassJob> lows;
+	if (!dec_build_jobs(ps, plan, sample, coeffs, pixel_kind, &bands, &lows)) return -4;
+	static std::vector<uint32_t> tables;
+	if (tables.empty()) tables = build_dec_tables(1);
+	int errors = 0;
+	const int nb = (int)bands.size();
+	hipemu::launch(dim3((nb + dev::DEC_THREADS - 1) / dev::DEC_THREADS), dim3(dev::DEC_THREADS),
+	               [&] { dev::k_dec_bands(bands.data(), nb, (const dev::DecTables *)tables.data(), &errors); });
+	hipemu::launch(dim3(4, (unsigned)lows.size()), dim3(256), [&] { dev::k_dec_lowpass(lows.data()); });
+	return errors ? -10 : 0;
+}

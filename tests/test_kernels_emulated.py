@@ -141,3 +141,21 @@ def test_gpu_entropy_stage_emulated_extreme_bands():
         want = product_write_sample_host(plan, coeffs, 1, meta_global=meta)
         got = _emu_entropy(plan, coeffs, 1, meta)
         assert got == want, mode
+
+
+@pytest.mark.parametrize("w,h,seed", [(192, 96, 1), (336, 252, 3), (720, 480, 4)])
+def test_gpu_entropy_decoder_emulated_equals_host_decoder(w, h, seed):
+    """k_dec_bands / k_dec_lowpass under emulation reproduce the product's host VLC decoder (dequantized pyramid incl. lowpass bias)."""
+    frame, pitch = synth_yuy2(w, h, seed)
+    plan = Plan(w, h)
+    coeffs = oracle_forward_yuv422(plan, frame, pitch)
+    if seed == 3:                                   # long code words: values up to the +-1023 clamp
+        v = plan.view(coeffs, 0, 0, 1); v[::7, ::5] = 1023; v[1::9, 2::11] = -1023; v[3::5, 1::13] = 300
+    sample = product_write_sample_host(plan, coeffs, 1, meta_global=b"GUID\x10\x00\x00G" + bytes(16))
+    want = host_decode_pyramid(sample, plan)
+    got = np.full(plan.coeff_elems, 99, dtype=np.int16)
+    E = emu()
+    E.emu_entropy_decode.argtypes = [c_u8p, ctypes.c_size_t, ctypes.c_int, c_i16p, ctypes.c_size_t]
+    s = np.frombuffer(sample, dtype=np.uint8).copy()
+    assert E.emu_entropy_decode(p8(s), len(sample), 1, p16(got), got.size) == 0
+    assert np.array_equal(got[: plan.final_elems], want[: plan.final_elems])
