@@ -99,8 +99,7 @@ long long cfhd_amd_batch_roundtrip(cfhd_amd_batch *b)
 		for (int i = 0; i < b->n; i++) {
 			size_t n = b->enc.entropy().sample_bytes(i);
 			if (!n) return -3;
-			memcpy(b->samples[i].data(), b->enc.entropy().host_sample(i), n);
-			b->sample_size[i] = n;
+			b->sample_size[i] = n;                          // the sample stays in the encoder's pinned buffer (cfhd_amd_batch_get_sample)
 		}
 		t2 = now();
 	} else {
@@ -119,7 +118,8 @@ long long cfhd_amd_batch_roundtrip(cfhd_amd_batch *b)
 	double t3;
 	if (b->gpu_entropy) {
 		// samples travel back to the GPU as bytes (H2D of the compressed size); one lane per band rebuilds the pyramid in HBM
-		for (int i = 0; i < b->n; i++) if (b->dec.entropy().set_sample_host(i, b->samples[i].data(), b->sample_size[i])) return -4;
+		parallel_for(b->n, b->nthreads < 16 ? b->nthreads : 16, [&](int i) { if (b->dec.entropy().set_sample_host(i, b->enc.entropy().host_sample(i), b->sample_size[i])) bad++; });
+		if (bad) return -4;
 		t3 = now();
 		if (b->dec.entropy().launch() || b->dec.launch_inverse(0xA511E9B3u * (b->steps + 1)) || b->dec.wait()) return -5;
 		if (b->dec.entropy().check()) return -7;
@@ -178,7 +178,7 @@ double cfhd_amd_batch_stage_seconds(cfhd_amd_batch *b, int which)
 int cfhd_amd_batch_get_sample(cfhd_amd_batch *b, int i, const void **data, size_t *size)
 {
 	if (!b || i < 0 || i >= b->n) return -1;
-	*data = b->samples[i].data(); *size = b->sample_size[i];
+	*data = b->gpu_entropy ? (const void *)b->enc.entropy().host_sample(i) : (const void *)b->samples[i].data(); *size = b->sample_size[i];
 	return 0;
 }
 

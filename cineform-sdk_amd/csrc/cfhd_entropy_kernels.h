@@ -386,7 +386,18 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(const EntBandJob *band
 // =============================================================================================
 enum { DEC_K1 = 12, DEC_THREADS = 64 };
 
+// Multi-symbol first level: everything that fits completely (sign bits included) into the next 12 bits, up to two nonzero
+// values with the zero runs around them -- the same idea as the reference's nibble FSM (decoder.c:19597-19642: pre-skip, up to
+// two values, post-skip per step), sized for one LDS lookup per step instead of two table walks per byte.
+struct DecMulti {             // 8 bytes
+	uint16_t pre_bits;        // bits 0-3: bits consumed (0: no complete symbol in the window -> single-symbol path), bits 4-15: zeros before v1
+	int16_t v1;               // expanded signed magnitude (0: none)
+	uint16_t mid_post;        // bits 0-7: zeros between v1 and v2, bits 8-15: zeros after the last value
+	int16_t v2;
+};
+
 struct DecTables {
+	DecMulti multi[1 << DEC_K1];
 	uint32_t lut1[1 << DEC_K1];   // bits 0-4 code length (31: continue in lut2, base = e >> 10, extra index bits = (e >> 5) & 31)
 	uint32_t lut2_size;           // bits 5-15 zero run, bits 16-31 expanded magnitude (0xffff: band end)
 	uint32_t lut2[1];             // variable length
@@ -402,42 +413,61 @@ struct DecLowpassJob { const uint8_t *src; int16_t *dst; int width, height, pitc
 
 __global__ void __launch_bounds__(DEC_THREADS) k_dec_bands(const DecBandJob *jobs, int njobs, const DecTables *T, int *errors)
 {
-	__shared__ uint32_t s_lut[1 << DEC_K1];
-	for (int i = threadIdx.x; i < (1 << DEC_K1); i += DEC_THREADS) s_lut[i] = T->lut1[i];
+	__shared__ uint2 s_multi[1 << DEC_K1];               // 32 KB
+	for (int i = threadIdx.x; i < (1 << DEC_K1); i += DEC_THREADS) s_multi[i] = ((const uint2 *)T->multi)[i];
 	__syncthreads();
 	const int j = blockIdx.x * DEC_THREADS + threadIdx.x;
 	if (j >= njobs) return;
 	const DecBandJob job = jobs[j];
 	const uint32_t *words = (const uint32_t *)job.bits;
 	const uint32_t nwords = job.bytes >> 2;
+	// four words in flight ahead of the bit buffer: the refill below never waits for HBM
+	uint32_t w0 = nwords > 0 ? words[0] : 0u, w1 = nwords > 1 ? words[1] : 0u, w2 = nwords > 2 ? words[2] : 0u, w3 = nwords > 3 ? words[3] : 0u;
 	uint32_t wpos = 0;
 	uint64_t acc = 0; int have = 0;
 	int idx = 0, err = 0;
+	const int quant = job.quant, n = job.n;
 	for (;;) {
 		if (have <= 32) {
-			const uint32_t w = wpos < nwords ? bswap32(words[wpos]) : 0u;
+			const uint32_t w = bswap32(w0);
+			w0 = w1; w1 = w2; w2 = w3;
+			w3 = (wpos + 4 < nwords) ? words[wpos + 4] : 0u;
 			wpos++;
 			acc |= (uint64_t)w << (32 - have);
 			have += 32;
 		}
-		uint32_t e = s_lut[(uint32_t)(acc >> (64 - DEC_K1))];
-		if ((e & 31u) == 31u) {
-			const int nb = (int)((e >> 5) & 31u);
-			e = T->lut2[(e >> 10) + (uint32_t)((acc << DEC_K1) >> (64 - nb))];
+		const uint2 m = s_multi[(uint32_t)(acc >> (64 - DEC_K1))];
+		const int used = (int)(m.x & 15u);
+		if (used) {
+			const int pre = (int)((m.x >> 4) & 0xfffu), v1 = (int)(int16_t)(m.x >> 16);
+			const int mid = (int)(m.y & 0xffu), post = (int)((m.y >> 8) & 0xffu), v2 = (int)(int16_t)(m.y >> 16);
+			acc <<= used; have -= used;
+			idx += pre;
+			if (v1) { if (idx >= n) { err = 2; break; } job.dst[idx++] = (int16_t)(v1 * quant); }
+			idx += mid;
+			if (v2) { if (idx >= n) { err = 2; break; } job.dst[idx++] = (int16_t)(v2 * quant); }
+			idx += post;
+		} else {
+			// a code word longer than the window (or the band end marker): resolve it alone through lut1 / lut2
+			uint32_t e = T->lut1[(uint32_t)(acc >> (64 - DEC_K1))];
+			if ((e & 31u) == 31u) {
+				const int nb = (int)((e >> 5) & 31u);
+				e = T->lut2[(e >> 10) + (uint32_t)((acc << DEC_K1) >> (64 - nb))];
+			}
+			const int len = (int)(e & 31u);
+			if (len == 0) { err = 1; break; }
+			acc <<= len; have -= len;
+			const uint32_t mag = e >> 16;
+			if (mag == 0xffffu) break;                   // band end marker
+			if (mag) {
+				const int negative = (int)(acc >> 63);
+				acc <<= 1; have -= 1;
+				if (idx >= n) { err = 2; break; }
+				const int v = (int)mag * quant;
+				job.dst[idx++] = (int16_t)(negative ? -v : v);
+			} else idx += (int)((e >> 5) & 0x7ffu);
 		}
-		const int len = (int)(e & 31u);
-		if (len == 0) { err = 1; break; }
-		acc <<= len; have -= len;
-		const uint32_t mag = e >> 16;
-		if (mag == 0xffffu) break;                       // band end marker
-		if (mag) {
-			const int negative = (int)(acc >> 63);
-			acc <<= 1; have -= 1;
-			if (idx >= job.n) { err = 2; break; }
-			const int v = (int)mag * job.quant;
-			job.dst[idx++] = (int16_t)(negative ? -v : v);
-		} else idx += (int)((e >> 5) & 0x7ffu);
-		if (wpos > nwords + 2) { err = 3; break; }       // ran off the payload without meeting the end marker
+		if (wpos > nwords + 6) { err = 3; break; }       // ran off the payload without meeting the end marker
 	}
 	if (err) atomic_or_u32((uint32_t *)errors, 1u);
 }

@@ -108,7 +108,7 @@ const EntropyTables *entropy_tables(int codebook)
 	return &g_tables[codebook];
 }
 
-// Serialised dev::DecTables (cfhd_entropy_kernels.h): lut1[4096], lut2_size, lut2[].
+// Serialised dev::DecTables (cfhd_entropy_kernels.h): multi[4096] (8 bytes each), lut1[4096], lut2_size, lut2[].
 std::vector<uint32_t> build_dec_tables(int codebook)
 {
 	const uint8_t *ml = codebook == 2 ? cfhd_cs18_mag_len : cfhd_cs17_mag_len;
@@ -144,7 +144,38 @@ std::vector<uint32_t> build_dec_tables(int codebook)
 			for (uint32_t s = 0; s < (1u << (nb - (c.len - K))); s++) lut2[base + s] = c.payload | (uint32_t)c.len;
 		}
 	}
+	// Multi-symbol table: greedily take complete symbols (with their sign bits) from each 12-bit window, at most two values.
 	std::vector<uint32_t> out;
+	for (uint32_t win = 0; win < (1u << K); win++) {
+		int used = 0, pre = 0, mid = 0, post = 0, v1 = 0, v2 = 0;
+		for (;;) {
+			const uint32_t rest = (win << used) & ((1u << K) - 1);        // remaining bits, left aligned in K bits
+			const uint32_t e = lut1[rest];
+			const int len = (int)(e & 31u);
+			if (len == 0 || len == 31 || len > K - used) break;           // incomplete / long / does not fit
+			const uint32_t mag = e >> 16;
+			if (mag == 0xffffu) break;
+			if (mag) {
+				if (len + 1 > K - used) break;                            // the sign bit must be inside the window too
+				if (v2) break;
+				const int negative = (int)((rest >> (K - len - 1)) & 1u);
+				const int v = negative ? -(int)mag : (int)mag;
+				if (!v1) v1 = v; else v2 = v;
+				used += len + 1;
+			} else {
+				const int run = (int)((e >> 5) & 0x7ffu);
+				int *slot = v2 ? &post : (v1 ? &mid : &pre);
+				const int limit = slot == &pre ? 0xfff : 0xff;
+				if (*slot + run > limit) break;
+				*slot += run;
+				used += len;
+			}
+		}
+		// a trailing zero run after v1 (no v2) was accumulated in `mid`; keep the layout consistent: zeros after the last value = post
+		if (v1 && !v2) { post = mid; mid = 0; }
+		out.push_back((uint32_t)(used & 15) | ((uint32_t)pre << 4) | ((uint32_t)(uint16_t)(int16_t)v1 << 16));
+		out.push_back((uint32_t)(mid & 0xff) | ((uint32_t)(post & 0xff) << 8) | ((uint32_t)(uint16_t)(int16_t)v2 << 16));
+	}
 	out.insert(out.end(), lut1.begin(), lut1.end());
 	out.push_back((uint32_t)lut2.size());
 	out.insert(out.end(), lut2.begin(), lut2.end());
