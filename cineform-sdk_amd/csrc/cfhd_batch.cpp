@@ -15,14 +15,19 @@
 #include <thread>
 #include <atomic>
 #include <chrono>
+#include <memory>
 
 using namespace cfhd;
+
+struct cfhd_amd_chunk { EncodeBatch enc; DecodeBatch dec; int first = 0, n = 0; };
 
 struct cfhd_amd_batch {
 	FramePlan plan;
 	int n = 0, nthreads = 1, quality = 4, pixel_kind = PIX_YUY2;
-	EncodeBatch enc;
-	DecodeBatch dec;
+	// The batch is cut into chunks with their own HIP streams: while one chunk's entropy decode (latency bound: one lane per
+	// band) is in flight, the next chunk's bandwidth-bound kernels and PCIe copies run beside it.
+	std::vector<std::unique_ptr<cfhd_amd_chunk>> chunks;
+	cfhd_amd_chunk &chunk_of(int i, int *local) { for (auto &c : chunks) if (i < c->first + c->n) { *local = i - c->first; return *c; } *local = 0; return *chunks[0]; }
 	std::vector<std::vector<uint8_t>> samples;
 	std::vector<size_t> sample_size;
 	MetaBlock meta;
@@ -55,14 +60,21 @@ cfhd_amd_batch *cfhd_amd_batch_create(int width, int height, uint32_t pixel_form
 	if (!build_frame_plan(&b->plan, width, height, kind, ENC_YUV422)) { delete b; return nullptr; }
 	QuantState st = {0, -1, 0};
 	derive_quantization(&b->plan, quality, true, 0.0f, &st);
-	if (b->enc.prepare(b->plan, nframes, true) || b->dec.prepare(b->plan, nframes, kind, true)) { delete b; return nullptr; }
-	{
-		const char *e = getenv("CFHD_AMD_ENTROPY");
-		b->gpu_entropy = !(e && strcmp(e, "host") == 0);
-		if (b->gpu_entropy && (b->enc.prepare_entropy((size_t)width * height * 2 + 65536) || b->dec.prepare_entropy((size_t)width * height * 2 + 65536))) { delete b; return nullptr; }
+	const char *e = getenv("CFHD_AMD_ENTROPY");
+	b->gpu_entropy = !(e && strcmp(e, "host") == 0);
+	const char *cs = getenv("CFHD_AMD_CHUNK");
+	int chunk = cs ? atoi(cs) : 32;
+	if (chunk <= 0 || !b->gpu_entropy) chunk = nframes;
+	const size_t cap = (size_t)width * height * 2 + 65536;
+	for (int first = 0; first < nframes; first += chunk) {
+		std::unique_ptr<cfhd_amd_chunk> c(new cfhd_amd_chunk);
+		c->first = first; c->n = nframes - first < chunk ? nframes - first : chunk;
+		if (c->enc.prepare(b->plan, c->n, true) || c->dec.prepare(b->plan, c->n, kind, true)) { delete b; return nullptr; }
+		if (b->gpu_entropy && (c->enc.prepare_entropy(cap) || c->dec.prepare_entropy(cap))) { delete b; return nullptr; }
+		b->chunks.push_back(std::move(c));
 	}
 	b->samples.resize(nframes); b->sample_size.assign(nframes, 0);
-	for (auto &s : b->samples) s.resize((size_t)width * height * 2 + 65536);
+	if (!b->gpu_entropy) for (auto &s : b->samples) s.resize(cap);
 	unsigned char guid[16] = {0};
 	meta_add(b->meta, MTAG_CLIP_GUID, 'G', 16, guid);
 	return b;
@@ -73,10 +85,11 @@ void cfhd_amd_batch_destroy(cfhd_amd_batch *b) { delete b; }
 // Puts frame i into HBM (outside the timed region of the benchmark).
 int cfhd_amd_batch_upload(cfhd_amd_batch *b, int i, const void *frame, int pitch)
 {
-	if (!b) return -1;
-	int rc = b->enc.upload_frame(i, frame, pitch);
+	if (!b || i < 0 || i >= b->n) return -1;
+	int l; cfhd_amd_chunk &c = b->chunk_of(i, &l);
+	int rc = c.enc.upload_frame(l, frame, pitch);
 	if (rc) return rc;
-	return b->enc.wait();
+	return c.enc.wait();
 }
 
 // One step of the hot path over the whole batch.  Returns the total number of sample bytes, or < 0.
@@ -84,72 +97,74 @@ long long cfhd_amd_batch_roundtrip(cfhd_amd_batch *b)
 {
 	if (!b) return -1;
 	const FramePlan &plan = b->plan;
-	double t0 = now();
+	double t0 = now(), t1, t2, t3;
 	std::atomic<int> bad(0);
 	const uint32_t base_number = b->steps * (uint32_t)b->n;
-	double t1, t2;
+	auto header = [&](int i) { SampleHeaderInfo h = { base_number + (uint32_t)i + 1, b->pixel_kind == PIX_2VUY ? 1 : 2, 2, b->quality, true, b->meta.data(), b->meta.size(), nullptr, 0 }; return h; };
+	const uint32_t seed = 0xA511E9B3u * (b->steps + 1);
 	if (b->gpu_entropy) {
-		for (int i = 0; i < b->n; i++) {
-			SampleHeaderInfo hdr = { base_number + (uint32_t)i + 1, b->pixel_kind == PIX_2VUY ? 1 : 2, 2, b->quality, true, b->meta.data(), b->meta.size(), nullptr, 0 };
-			if (b->enc.entropy().set_frame_header(i, hdr)) return -6;
+		// 1. every chunk: forward transform + entropy coding, queued on the chunk's own stream
+		for (auto &c : b->chunks) {
+			for (int l = 0; l < c->n; l++) if (c->enc.entropy().set_frame_header(l, header(c->first + l))) return -6;
+			if (c->enc.launch_forward() || c->enc.entropy().launch()) return -2;
 		}
-		if (b->enc.launch_forward() || b->enc.entropy().launch()) return -2;
 		t1 = now();
-		if (b->enc.entropy().download() || b->enc.wait()) return -2;
-		for (int i = 0; i < b->n; i++) {
-			size_t n = b->enc.entropy().sample_bytes(i);
-			if (!n) return -3;
-			b->sample_size[i] = n;                          // the sample stays in the encoder's pinned buffer (cfhd_amd_batch_get_sample)
+		// 2. as each chunk's samples arrive on the host (the encoder's product), hand them to the decoder and queue its work
+		double wait_s = 0, stage_s = 0;
+		for (auto &c : b->chunks) {
+			double a = now();
+			if (c->enc.entropy().download() || c->enc.wait()) return -2;
+			for (int l = 0; l < c->n; l++) { size_t n = c->enc.entropy().sample_bytes(l); if (!n) return -3; b->sample_size[c->first + l] = n; }
+			double m = now();
+			cfhd_amd_chunk *cp = c.get();
+			parallel_for(c->n, b->nthreads < 16 ? b->nthreads : 16, [&, cp](int l) {
+				if (cp->dec.entropy().set_sample_host(l, cp->enc.entropy().host_sample(l), b->sample_size[cp->first + l])) bad++; });
+			if (bad) return -4;
+			if (c->dec.entropy().launch() || c->dec.launch_inverse(seed + (uint32_t)c->first)) return -5;
+			wait_s += m - a; stage_s += now() - m;
 		}
+		t2 = t1 + wait_s; t3 = t2 + stage_s;
+		// 3. drain
+		for (auto &c : b->chunks) { if (c->dec.wait()) return -5; if (c->dec.entropy().check()) return -7; }
+	} else {
+		cfhd_amd_chunk &c = *b->chunks[0];
+		if (c.enc.launch_forward() || c.enc.download_coeffs() || c.enc.wait()) return -2;
+		t1 = now();
+		parallel_for(b->n, b->nthreads, [&](int i) {
+			SampleHeaderInfo hdr = header(i);
+			BandSource src; src.coeffs = c.enc.host_coeffs(i);
+			size_t n = write_sample(plan, hdr, src, b->samples[i].data(), b->samples[i].size());
+			if (!n) bad++;
+			b->sample_size[i] = n;
+		});
 		t2 = now();
-	} else {
-	if (b->enc.launch_forward() || b->enc.download_coeffs() || b->enc.wait()) return -2;
-	t1 = now();
-	parallel_for(b->n, b->nthreads, [&](int i) {
-		SampleHeaderInfo hdr = { base_number + (uint32_t)i + 1, b->pixel_kind == PIX_2VUY ? 1 : 2, 2, b->quality, true, b->meta.data(), b->meta.size(), nullptr, 0 };
-		BandSource src; src.coeffs = b->enc.host_coeffs(i);
-		size_t n = write_sample(plan, hdr, src, b->samples[i].data(), b->samples[i].size());
-		if (!n) bad++;
-		b->sample_size[i] = n;
-	});
-	t2 = now();
-	if (bad) return -3;
-	}
-	double t3;
-	if (b->gpu_entropy) {
-		// samples travel back to the GPU as bytes (H2D of the compressed size); one lane per band rebuilds the pyramid in HBM
-		parallel_for(b->n, b->nthreads < 16 ? b->nthreads : 16, [&](int i) { if (b->dec.entropy().set_sample_host(i, b->enc.entropy().host_sample(i), b->sample_size[i])) bad++; });
-		if (bad) return -4;
-		t3 = now();
-		if (b->dec.entropy().launch() || b->dec.launch_inverse(0xA511E9B3u * (b->steps + 1)) || b->dec.wait()) return -5;
-		if (b->dec.entropy().check()) return -7;
-	} else {
-	parallel_for(b->n, b->nthreads, [&](int i) {
-		const uint8_t *s = b->samples[i].data();
-		ParsedSample ps;
-		if (parse_sample(s, b->sample_size[i], &ps) != 0) { bad++; return; }
-		b->dec.clear_host_coeffs(i);
-		int16_t *coeffs = b->dec.host_coeffs(i);
-		for (int c = 0; c < plan.num_channels; c++) {
-			const ParsedBand &lp = ps.lowpass[c];
-			const BandDesc &ll = plan.ch[c].band[2][0];
-			const int bias = lowpass_bias(plan.precision, ll.width, b->pixel_kind);
-			for (int r = 0; r < ll.height; r++) {
-				const uint8_t *p = s + lp.offset + (size_t)r * ll.width * 2;
-				int16_t *dst = coeffs + ll.offset + (size_t)r * ll.pitch;
-				for (int x = 0; x < ll.width; x++) { int v = (int16_t)((p[2 * x] << 8) | p[2 * x + 1]); v += bias; dst[x] = (int16_t)(v > 0x7fff ? 0x7fff : v); }
-			}
-			for (int lv = 0; lv < kNumLevels; lv++)
-				for (int k = 1; k < 4; k++) {
-					const ParsedBand &pb = ps.high[c][lv][k];
-					const BandDesc &bd = plan.ch[c].band[lv][k];
-					if (!pb.present || vlc_decode_band(s + pb.offset, pb.bytes, bd.width, bd.height, bd.pitch, pb.quant, pb.codebook, coeffs + bd.offset)) { bad++; return; }
+		if (bad) return -3;
+		parallel_for(b->n, b->nthreads, [&](int i) {
+			const uint8_t *s = b->samples[i].data();
+			ParsedSample ps;
+			if (parse_sample(s, b->sample_size[i], &ps) != 0) { bad++; return; }
+			c.dec.clear_host_coeffs(i);
+			int16_t *coeffs = c.dec.host_coeffs(i);
+			for (int ch = 0; ch < plan.num_channels; ch++) {
+				const ParsedBand &lp = ps.lowpass[ch];
+				const BandDesc &ll = plan.ch[ch].band[2][0];
+				const int bias = lowpass_bias(plan.precision, ll.width, b->pixel_kind);
+				for (int r = 0; r < ll.height; r++) {
+					const uint8_t *p = s + lp.offset + (size_t)r * ll.width * 2;
+					int16_t *dst = coeffs + ll.offset + (size_t)r * ll.pitch;
+					for (int x = 0; x < ll.width; x++) { int v = (int16_t)((p[2 * x] << 8) | p[2 * x + 1]); v += bias; dst[x] = (int16_t)(v > 0x7fff ? 0x7fff : v); }
 				}
-		}
-	});
-	t3 = now();
-	if (bad) return -4;
-	if (b->dec.upload_coeffs() || b->dec.launch_inverse(0xA511E9B3u * (b->steps + 1)) || b->dec.wait()) return -5;
+				for (int lv = 0; lv < kNumLevels; lv++)
+					for (int k = 1; k < 4; k++) {
+						const ParsedBand &pb = ps.high[ch][lv][k];
+						const BandDesc &bd = plan.ch[ch].band[lv][k];
+						if (!pb.present || vlc_decode_band(s + pb.offset, pb.bytes, bd.width, bd.height, bd.pitch, pb.quant, pb.codebook, coeffs + bd.offset)) { bad++; return; }
+					}
+			}
+		});
+		t3 = now();
+		if (bad) return -4;
+		if (c.dec.upload_coeffs() || c.dec.launch_inverse(seed) || c.dec.wait()) return -5;
 	}
 	double t4 = now();
 	b->t_fwd = t1 - t0; b->t_entropy_enc = t2 - t1; b->t_entropy_dec = t3 - t2; b->t_inv = t4 - t3;
@@ -163,9 +178,13 @@ long long cfhd_amd_batch_roundtrip(cfhd_amd_batch *b)
 float cfhd_amd_batch_kernel_ms(cfhd_amd_batch *b, int which)
 {
 	if (!b) return 0;
-	if (which < 3) return b->enc.last_level_ms(which);
-	if (which < 6) return b->dec.last_level_ms(which - 3);
-	return which == 6 ? b->enc.last_kernel_ms() : b->dec.last_kernel_ms();
+	float ms = 0;                                        // summed over the chunks (each chunk times its own launches with HIP events on its stream)
+	for (auto &c : b->chunks) {
+		if (which < 3) ms += c->enc.last_level_ms(which);
+		else if (which < 6) ms += c->dec.last_level_ms(which - 3);
+		else ms += which == 6 ? c->enc.last_kernel_ms() : c->dec.last_kernel_ms();
+	}
+	return ms;
 }
 
 // which: 0 forward (kernels + D2H), 1 host entropy encode + syntax, 2 host parse + entropy decode, 3 H2D + inverse kernels (wall seconds)
@@ -178,15 +197,17 @@ double cfhd_amd_batch_stage_seconds(cfhd_amd_batch *b, int which)
 int cfhd_amd_batch_get_sample(cfhd_amd_batch *b, int i, const void **data, size_t *size)
 {
 	if (!b || i < 0 || i >= b->n) return -1;
-	*data = b->gpu_entropy ? (const void *)b->enc.entropy().host_sample(i) : (const void *)b->samples[i].data(); *size = b->sample_size[i];
+	int l; cfhd_amd_chunk &c = b->chunk_of(i, &l);
+	*data = b->gpu_entropy ? (const void *)c.enc.entropy().host_sample(l) : (const void *)b->samples[i].data(); *size = b->sample_size[i];
 	return 0;
 }
 
 int cfhd_amd_batch_download_output(cfhd_amd_batch *b, int i, void *out, int pitch)
 {
-	if (!b) return -1;
-	if (b->dec.download_frame(i, out, pitch) || b->dec.wait()) return -2;
-	return b->dec.finish_frame(i, out, pitch);
+	if (!b || i < 0 || i >= b->n) return -1;
+	int l; cfhd_amd_chunk &c = b->chunk_of(i, &l);
+	if (c.dec.download_frame(l, out, pitch) || c.dec.wait()) return -2;
+	return c.dec.finish_frame(l, out, pitch);
 }
 
 } // extern "C"

@@ -223,3 +223,44 @@ def test_gpu_entropy_and_host_entropy_paths_agree():
         del os.environ["CFHD_AMD_ENTROPY"]
     for x, y in zip(a, b):
         assert mask_volatile_metadata(x) == mask_volatile_metadata(y)
+
+
+def test_batched_device_resident_round_trip():
+    """cfhd_amd_batch_* (what bench.py times): several chunks on their own streams; every sample must equal oracle transform +
+    product syntax, every decoded frame must lie in the oracle's dither interval of its own sample."""
+    L = product()
+    L.cfhd_amd_batch_create.restype = ctypes.c_void_p
+    L.cfhd_amd_batch_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    L.cfhd_amd_batch_upload.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    L.cfhd_amd_batch_roundtrip.restype = ctypes.c_longlong
+    L.cfhd_amd_batch_roundtrip.argtypes = [ctypes.c_void_p]
+    L.cfhd_amd_batch_get_sample.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
+    L.cfhd_amd_batch_download_output.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    L.cfhd_amd_batch_destroy.argtypes = [ctypes.c_void_p]
+    w, h, n = 640, 360, 5
+    frames = [synth_yuy2(w, h, 70 + i)[0] for i in range(n)]
+    os.environ["CFHD_AMD_CHUNK"] = "2"
+    try:
+        b = L.cfhd_amd_batch_create(w, h, PIX_YUY2, QUALITY_FILMSCAN1, n, 4)
+    finally:
+        del os.environ["CFHD_AMD_CHUNK"]
+    assert b
+    for i, f in enumerate(frames):
+        assert L.cfhd_amd_batch_upload(b, i, f.ctypes.data_as(ctypes.c_void_p), w * 2) == 0
+    plan = Plan(w, h)
+    for step in range(2):
+        assert L.cfhd_amd_batch_roundtrip(b) > 0, amd_last_error()
+        for i, f in enumerate(frames):
+            p = ctypes.c_void_p(); sz = ctypes.c_size_t()
+            assert L.cfhd_amd_batch_get_sample(b, i, ctypes.byref(p), ctypes.byref(sz)) == 0
+            sample = ctypes.string_at(p, sz.value)
+            off, m = first_metadata_chunk(sample)
+            want = product_write_sample_host(plan, oracle_forward_yuv422(plan, f, w * 2), step * n + i + 1, meta_global=sample[off:off + m])
+            assert sample == want, "step %d frame %d" % (step, i)
+            out = np.zeros(h * w * 2, dtype=np.uint8)
+            assert L.cfhd_amd_batch_download_output(b, i, out.ctypes.data_as(ctypes.c_void_p), w * 2) == 0
+            img = out.reshape(h, w * 2)
+            deq = host_decode_pyramid(sample, plan)
+            lo = oracle_inverse_yuv422(plan, deq, 0)[:h]; hi = oracle_inverse_yuv422(plan, deq, 1)[:h]
+            assert ((img == lo) | (img == hi)).all(), "step %d frame %d" % (step, i)
+    L.cfhd_amd_batch_destroy(b)
