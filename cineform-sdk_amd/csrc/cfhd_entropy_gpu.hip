@@ -11,7 +11,7 @@ int device_init();
 namespace { int g_fail(hipError_t e, const char *what) { fprintf(stderr, "[cfhd_amd] %s: %s\n", what, hipGetErrorString(e)); return (int)e ? (int)e : -1; } }
 #define HIPCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return g_fail(_e, #expr); } while (0)
 
-struct GpuEntropyEncoder::Host { EntHostJobs jobs; std::vector<dev::EntFrameJob> frames; };
+struct GpuEntropyEncoder::Host { EntHostJobs jobs; dev::EntFrameJob *frames = nullptr; /* pinned: async copies must not stall the host */ };
 
 GpuEntropyEncoder::GpuEntropyEncoder() : host_(new Host) {}
 GpuEntropyEncoder::~GpuEntropyEncoder() { release(); delete host_; }
@@ -23,6 +23,7 @@ void GpuEntropyEncoder::release()
 	if (h_samples_) (void)hipHostFree(h_samples_);
 	if (h_sizes_) (void)hipHostFree(h_sizes_);
 	if (h_tmpl_) (void)hipHostFree(h_tmpl_);
+	if (host_->frames) { (void)hipHostFree(host_->frames); host_->frames = nullptr; }
 	d_samples_ = h_samples_ = nullptr; d_sizes_ = h_sizes_ = nullptr; d_tables_ = d_bands_ = d_segband_ = d_segs_ = d_bandstate_ = d_frames_ = nullptr;
 	d_tmpl_ = h_tmpl_ = nullptr; n_ = 0;
 }
@@ -61,7 +62,7 @@ int GpuEntropyEncoder::prepare(const FramePlan &plan, int nframes, int16_t *d_co
 	HIPCHK(hipHostMalloc((void **)&h_tmpl_, (size_t)kEntTmplStride * n_, hipHostMallocDefault));
 	memset(h_tmpl_, 0, (size_t)kEntTmplStride * n_);
 	HIPCHK(hipMalloc(&d_frames_, n_ * sizeof(dev::EntFrameJob)));
-	host_->frames.resize(n_);
+	HIPCHK(hipHostMalloc((void **)&host_->frames, n_ * sizeof(dev::EntFrameJob), hipHostMallocDefault));
 	for (int f = 0; f < n_; f++) { SampleHeaderInfo h = hdr0; h.frame_number = (uint32_t)f + 1; if ((rc = set_frame_header(f, h))) return rc; }
 	return 0;
 }
@@ -82,7 +83,7 @@ int GpuEntropyEncoder::launch()
 	hipStream_t st = (hipStream_t)stream_;
 	if (dirty_) {
 		HIPCHK(hipMemcpyAsync(d_tmpl_, h_tmpl_, (size_t)kEntTmplStride * n_, hipMemcpyHostToDevice, st));
-		HIPCHK(hipMemcpyAsync(d_frames_, host_->frames.data(), n_ * sizeof(dev::EntFrameJob), hipMemcpyHostToDevice, st));
+		HIPCHK(hipMemcpyAsync(d_frames_, host_->frames, n_ * sizeof(dev::EntFrameJob), hipMemcpyHostToDevice, st));
 		dirty_ = false;
 	}
 	const dev::EntTables *T = (const dev::EntTables *)d_tables_;
@@ -121,7 +122,7 @@ struct GpuEntropyDecoder::Host {
 	std::vector<std::vector<dev::DecBandJob>> bands;      // per frame
 	std::vector<std::vector<dev::DecLowpassJob>> lows;
 	std::vector<size_t> host_bytes;                       // bytes to copy H2D per frame (0: sample already in HBM)
-	std::vector<dev::DecBandJob> flat_bands; std::vector<dev::DecLowpassJob> flat_lows;
+	dev::DecBandJob *flat_bands = nullptr; dev::DecLowpassJob *flat_lows = nullptr;   // pinned
 };
 
 GpuEntropyDecoder::GpuEntropyDecoder() : host_(new Host) {}
@@ -133,6 +134,8 @@ void GpuEntropyDecoder::release()
 	for (void *p : dev) if (p) (void)hipFree(p);
 	if (h_samples_) (void)hipHostFree(h_samples_);
 	if (h_errors_) (void)hipHostFree(h_errors_);
+	if (host_->flat_bands) { (void)hipHostFree(host_->flat_bands); host_->flat_bands = nullptr; }
+	if (host_->flat_lows) { (void)hipHostFree(host_->flat_lows); host_->flat_lows = nullptr; }
 	d_samples_ = h_samples_ = nullptr; d_tables_ = d_bandjobs_ = d_lowjobs_ = nullptr; d_errors_ = h_errors_ = nullptr; n_ = 0;
 }
 
@@ -150,6 +153,8 @@ int GpuEntropyDecoder::prepare(const FramePlan &plan, int nframes, int16_t *d_co
 	const size_t max_bands = (size_t)n_ * kMaxChannels * 9, max_lows = (size_t)n_ * kMaxChannels;
 	HIPCHK(hipMalloc(&d_bandjobs_, max_bands * sizeof(dev::DecBandJob)));
 	HIPCHK(hipMalloc(&d_lowjobs_, max_lows * sizeof(dev::DecLowpassJob)));
+	HIPCHK(hipHostMalloc((void **)&host_->flat_bands, max_bands * sizeof(dev::DecBandJob), hipHostMallocDefault));
+	HIPCHK(hipHostMalloc((void **)&host_->flat_lows, max_lows * sizeof(dev::DecLowpassJob), hipHostMallocDefault));
 	HIPCHK(hipMalloc((void **)&d_errors_, sizeof(int)));
 	HIPCHK(hipHostMalloc((void **)&h_errors_, sizeof(int), hipHostMallocDefault));
 	*h_errors_ = 0;
@@ -181,23 +186,22 @@ int GpuEntropyDecoder::launch()
 {
 	hipStream_t st = (hipStream_t)stream_;
 	// jobs ordered band-type major so that the 64 lanes of a wave decode bands of similar length
-	std::vector<dev::DecBandJob> &fb = host_->flat_bands; std::vector<dev::DecLowpassJob> &fl = host_->flat_lows;
-	fb.clear(); fl.clear();
-	size_t per_frame = 0;
+	dev::DecBandJob *fb = host_->flat_bands; dev::DecLowpassJob *fl = host_->flat_lows;
+	size_t nfb = 0, nfl = 0, per_frame = 0;
 	for (int f = 0; f < n_; f++) per_frame = host_->bands[f].size() > per_frame ? host_->bands[f].size() : per_frame;
-	for (size_t k = 0; k < per_frame; k++) for (int f = 0; f < n_; f++) if (k < host_->bands[f].size()) fb.push_back(host_->bands[f][k]);
-	for (int f = 0; f < n_; f++) for (const dev::DecLowpassJob &j : host_->lows[f]) fl.push_back(j);
-	if (fb.empty()) return -1;
+	for (size_t k = 0; k < per_frame; k++) for (int f = 0; f < n_; f++) if (k < host_->bands[f].size()) fb[nfb++] = host_->bands[f][k];
+	for (int f = 0; f < n_; f++) for (const dev::DecLowpassJob &j : host_->lows[f]) fl[nfl++] = j;
+	if (!nfb) return -1;
 	HIPCHK(hipMemset2DAsync(d_coeffs_, coeff_stride_ * 2, 0, (size_t)plan_.final_elems * 2, n_, st));
 	HIPCHK(hipMemsetAsync(d_errors_, 0, sizeof(int), st));
 	for (int f = 0; f < n_; f++)
 		if (host_->host_bytes[f]) HIPCHK(hipMemcpyAsync(d_samples_ + cap_ * f, h_samples_ + cap_ * f, host_->host_bytes[f], hipMemcpyHostToDevice, st));
-	HIPCHK(hipMemcpyAsync(d_bandjobs_, fb.data(), fb.size() * sizeof(dev::DecBandJob), hipMemcpyHostToDevice, st));
-	HIPCHK(hipMemcpyAsync(d_lowjobs_, fl.data(), fl.size() * sizeof(dev::DecLowpassJob), hipMemcpyHostToDevice, st));
+	HIPCHK(hipMemcpyAsync(d_bandjobs_, fb, nfb * sizeof(dev::DecBandJob), hipMemcpyHostToDevice, st));
+	HIPCHK(hipMemcpyAsync(d_lowjobs_, fl, nfl * sizeof(dev::DecLowpassJob), hipMemcpyHostToDevice, st));
 	(void)hipGetLastError();
-	const int nb = (int)fb.size();
+	const int nb = (int)nfb;
 	dev::k_dec_bands<<<(nb + dev::DEC_THREADS - 1) / dev::DEC_THREADS, dev::DEC_THREADS, 0, st>>>((const dev::DecBandJob *)d_bandjobs_, nb, (const dev::DecTables *)d_tables_, d_errors_);
-	dev::k_dec_lowpass<<<dim3(8, (unsigned)fl.size()), 256, 0, st>>>((const dev::DecLowpassJob *)d_lowjobs_);
+	dev::k_dec_lowpass<<<dim3(8, (unsigned)nfl), 256, 0, st>>>((const dev::DecLowpassJob *)d_lowjobs_);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipMemcpyAsync(h_errors_, d_errors_, sizeof(int), hipMemcpyDeviceToHost, st));
 	return 0;
