@@ -74,6 +74,37 @@ __device__ __forceinline__ int lo16(uint32_t v) { return (int)(int16_t)(v & 0xff
 __device__ __forceinline__ int hi16(uint32_t v) { return (int)(int16_t)(v >> 16); }
 __device__ __forceinline__ uint32_t pack16(int lo, int hi) { return ((uint32_t)(uint16_t)lo) | ((uint32_t)(uint16_t)hi << 16); }
 
+// ---- packed 2 x int16 arithmetic: v_pk_add_i16 / v_pk_sub_i16 with clamp are exactly SSE2's _mm_adds_epi16 / _mm_subs_epi16 on two
+// lanes, so the reference's saturating SIMD bodies map one to one onto CDNA4 packed math (half the VALU issue slots of the
+// scalar form, saturation for free).  Under tests/hipemu the same operations are spelled out in scalar C.
+#if defined(CFHD_HIPEMU)
+__device__ __forceinline__ uint32_t pk_adds(uint32_t a, uint32_t b) { return pack16(adds16(lo16(a), lo16(b)), adds16(hi16(a), hi16(b))); }
+__device__ __forceinline__ uint32_t pk_subs(uint32_t a, uint32_t b) { return pack16(subs16(lo16(a), lo16(b)), subs16(hi16(a), hi16(b))); }
+__device__ __forceinline__ uint32_t pk_sra(uint32_t a, int n) { return pack16(lo16(a) >> n, hi16(a) >> n); }
+__device__ __forceinline__ uint32_t pk_lolo(uint32_t a, uint32_t b) { return (a & 0xffffu) | (b << 16); }          // (a.lo, b.lo)
+__device__ __forceinline__ uint32_t pk_hihi(uint32_t a, uint32_t b) { return (a >> 16) | (b & 0xffff0000u); }       // (a.hi, b.hi)
+#else
+typedef short cfhd_s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_adds(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(cfhd_s2, a), __builtin_bit_cast(cfhd_s2, b))); }
+__device__ __forceinline__ uint32_t pk_subs(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(cfhd_s2, a), __builtin_bit_cast(cfhd_s2, b))); }
+__device__ __forceinline__ uint32_t pk_sra(uint32_t a, int n) { cfhd_s2 x = __builtin_bit_cast(cfhd_s2, a); x = x >> (short)n; return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ uint32_t pk_lolo(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }
+__device__ __forceinline__ uint32_t pk_hihi(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+#endif
+__device__ __forceinline__ uint32_t pk_set(int v) { return pack16(v, v); }
+
+// 2/6 analysis highpass on two lanes at once (SIMD association order, spatial.c:326-397 / :10301-10351)
+__device__ __forceinline__ uint32_t pk_hp_mid(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4, uint32_t a5)
+{
+	uint32_t s = pk_subs(0u, a0);
+	s = pk_subs(s, a1);
+	s = pk_adds(s, a4);
+	s = pk_adds(s, a5);
+	s = pk_adds(s, pk_set(4));
+	s = pk_sra(s, 3);
+	return pk_adds(s, pk_subs(a2, a3));
+}
+
 // quantize.c:1395: sign * (((|x| + mid) * mult) >> 16) with 16-bit wrap of |x|+mid
 __device__ __forceinline__ int quantize(int v, const QuantParam &q)
 {
@@ -98,21 +129,36 @@ __device__ __forceinline__ int hp_mid(int a0, int a1, int a2, int a3, int a4, in
 __device__ __forceinline__ int hp_first(int a0, int a1, int a2, int a3, int a4, int a5) { return sat16((5 * a0 - 11 * a1 + 4 * a2 + 4 * a3 - a4 - a5 + 4) >> 3); }
 __device__ __forceinline__ int hp_last(int a0, int a1, int a2, int a3, int a4, int a5) { return sat16((11 * a4 - 5 * a5 - 4 * a3 - 4 * a2 + a1 + a0 + 4) >> 3); }
 
-// Horizontal analysis of output columns c and c+1 from samples s[0..7] = x[2c-2 .. 2c+5] (e0,e1 = x[2c-4], x[2c-3]).
-// Border columns use the 6-tap border filters on x[0..5] (= s[2..7] when c == 0) and on x[W-6..W-1]
-// (= s[0..5] when c+1 is the last column, = e0,e1,s[0..3] when c itself is the last column).
-__device__ __forceinline__ void horiz_pair(const int *s, int e0, int e1, int prescale, bool first0, bool last0, bool last1,
-                                           int &l0, int &l1, int &h0, int &h1)
+// Horizontal analysis of output columns c and c+1.  d[0..3] are the packed sample pairs (x[2k], x[2k+1]) for k = c-1 .. c+2,
+// dm2 the pair k = c-2 (only read when column c is the last one).  Interior taps run on packed lanes; the border columns use
+// the 6-tap border filters in 32 bits on x[0..5] and x[W-6..W-1] exactly as the reference's scalar code does.
+__device__ __forceinline__ void horiz_pair(const uint32_t *d, uint32_t dm2, int prescale, bool first0, bool last0, bool last1, uint32_t &lpk, uint32_t &hpk)
 {
-	int p[8];
-#pragma unroll
-	for (int i = 0; i < 8; i++) p[i] = prescale ? ((s[i] + 3) >> 2) : s[i];
-	if (prescale) { e0 = (e0 + 3) >> 2; e1 = (e1 + 3) >> 2; }
-	if (prescale) { l0 = sat16((s[2] + s[3] + 3) >> 2); l1 = sat16((s[4] + s[5] + 3) >> 2); }
-	else { l0 = adds16(s[2], s[3]); l1 = adds16(s[4], s[5]); }
-	h0 = first0 ? hp_first(p[2], p[3], p[4], p[5], p[6], p[7])
-	   : (last0 ? hp_last(e0, e1, p[0], p[1], p[2], p[3]) : hp_mid(p[0], p[1], p[2], p[3], p[4], p[5]));
-	h1 = last1 ? hp_last(p[0], p[1], p[2], p[3], p[4], p[5]) : hp_mid(p[2], p[3], p[4], p[5], p[6], p[7]);
+	uint32_t p0 = d[0], p1 = d[1], p2 = d[2], p3 = d[3];
+	if (prescale) {
+		// FilterHorizontalRow10bit16s (spatial.c:3669): every tap sees (x + 3) >> 2, the lowpass is ((x0+3) + (x1+3) - 3) >> 2
+		const uint32_t three = pk_set(3);
+		p0 = pk_adds(p0, three); p1 = pk_adds(p1, three); p2 = pk_adds(p2, three); p3 = pk_adds(p3, three);
+		uint32_t low = pk_adds(pk_lolo(p1, p2), pk_hihi(p1, p2));
+		low = pk_subs(low, three);
+		lpk = pk_sra(low, 2);
+		p0 = pk_sra(p0, 2); p1 = pk_sra(p1, 2); p2 = pk_sra(p2, 2); p3 = pk_sra(p3, 2);
+	} else {
+		lpk = pk_adds(pk_lolo(p1, p2), pk_hihi(p1, p2));
+	}
+	const uint32_t em = pk_lolo(p0, p1), om = pk_hihi(p0, p1), e0 = pk_lolo(p1, p2), o0 = pk_hihi(p1, p2), ep = pk_lolo(p2, p3), op = pk_hihi(p2, p3);
+	hpk = pk_hp_mid(em, om, e0, o0, ep, op);
+	if (first0 || last0 || last1) {
+		int h0 = lo16(hpk), h1 = hi16(hpk);
+		if (first0) h0 = hp_first(lo16(p1), hi16(p1), lo16(p2), hi16(p2), lo16(p3), hi16(p3));
+		if (last0) {
+			uint32_t pm = dm2;
+			if (prescale) pm = pk_sra(pk_adds(pm, pk_set(3)), 2);
+			h0 = hp_last(lo16(pm), hi16(pm), lo16(p0), hi16(p0), lo16(p1), hi16(p1));
+		}
+		if (last1) h1 = hp_last(lo16(p0), hi16(p0), lo16(p1), hi16(p1), lo16(p2), hi16(p2));
+		hpk = pack16(h0, h1);
+	}
 }
 
 // Vertical analysis + quantizer for two adjacent columns held as packed pairs in LDS.
@@ -123,28 +169,33 @@ __device__ __forceinline__ void vert_pair_store(const uint32_t *sl, const uint32
 	uint32_t L[6], H[6];
 #pragma unroll
 	for (int k = 0; k < 6; k++) { L[k] = sl[k * stride]; H[k] = sh[k * stride]; }
-	int res[4][2];
+	uint32_t ll, hl, lh, hh;
+	if (pos == 1) {
+		ll = pk_adds(L[2], L[3]); hl = pk_hp_mid(L[0], L[1], L[2], L[3], L[4], L[5]);
+		lh = pk_adds(H[2], H[3]); hh = pk_hp_mid(H[0], H[1], H[2], H[3], H[4], H[5]);
+	} else {
+		int res[4][2];
 #pragma unroll
-	for (int e = 0; e < 2; e++) {
-		int a[6], b[6];
+		for (int e = 0; e < 2; e++) {
+			int a[6], b[6];
 #pragma unroll
-		for (int k = 0; k < 6; k++) { a[k] = e ? hi16(L[k]) : lo16(L[k]); b[k] = e ? hi16(H[k]) : lo16(H[k]); }
-		int ll, hl, lh, hh;
-		if (pos == 0) {
-			ll = sat16(a[0] + a[1]); hl = hp_first(a[0], a[1], a[2], a[3], a[4], a[5]);
-			lh = sat16(b[0] + b[1]); hh = hp_first(b[0], b[1], b[2], b[3], b[4], b[5]);
-		} else if (pos == 2) {
-			ll = sat16(a[4] + a[5]); hl = hp_last(a[0], a[1], a[2], a[3], a[4], a[5]);
-			lh = sat16(b[4] + b[5]); hh = hp_last(b[0], b[1], b[2], b[3], b[4], b[5]);
-		} else {
-			ll = adds16(a[2], a[3]); hl = hp_mid(a[0], a[1], a[2], a[3], a[4], a[5]);
-			lh = adds16(b[2], b[3]); hh = hp_mid(b[0], b[1], b[2], b[3], b[4], b[5]);
+			for (int k = 0; k < 6; k++) { a[k] = e ? hi16(L[k]) : lo16(L[k]); b[k] = e ? hi16(H[k]) : lo16(H[k]); }
+			if (pos == 0) {
+				res[0][e] = sat16(a[0] + a[1]); res[2][e] = hp_first(a[0], a[1], a[2], a[3], a[4], a[5]);
+				res[1][e] = sat16(b[0] + b[1]); res[3][e] = hp_first(b[0], b[1], b[2], b[3], b[4], b[5]);
+			} else {
+				res[0][e] = sat16(a[4] + a[5]); res[2][e] = hp_last(a[0], a[1], a[2], a[3], a[4], a[5]);
+				res[1][e] = sat16(b[4] + b[5]); res[3][e] = hp_last(b[0], b[1], b[2], b[3], b[4], b[5]);
+			}
 		}
-		res[0][e] = ll; res[1][e] = quantize(lh, q[1]); res[2][e] = quantize(hl, q[2]); res[3][e] = quantize(hh, q[3]);
+		ll = pack16(res[0][0], res[0][1]); lh = pack16(res[1][0], res[1][1]); hl = pack16(res[2][0], res[2][1]); hh = pack16(res[3][0], res[3][1]);
 	}
-	size_t o = (size_t)r * out_pitch + c;
-#pragma unroll
-	for (int b = 0; b < 4; b++) *(uint32_t *)(out[b] + o) = pack16(res[b][0], valid1 ? res[b][1] : 0);
+	lh = pack16(quantize(lo16(lh), q[1]), quantize(hi16(lh), q[1]));
+	hl = pack16(quantize(lo16(hl), q[2]), quantize(hi16(hl), q[2]));
+	hh = pack16(quantize(lo16(hh), q[3]), quantize(hi16(hh), q[3]));
+	if (!valid1) { ll &= 0xffffu; lh &= 0xffffu; hl &= 0xffffu; hh &= 0xffffu; }
+	const size_t o = (size_t)r * out_pitch + c;
+	*(uint32_t *)(out[0] + o) = ll; *(uint32_t *)(out[1] + o) = lh; *(uint32_t *)(out[2] + o) = hl; *(uint32_t *)(out[3] + o) = hh;
 }
 
 __device__ __forceinline__ int window_first_row(int r, int half_height, int height) { return r == 0 ? 0 : (r == half_height - 1 ? height - 6 : 2 * r - 2); }
@@ -181,14 +232,13 @@ __global__ void __launch_bounds__(NTHREADS) k_fwd_plane(const FwdPlaneJob *jobs)
 			int y = row_start + j;
 			if (c >= HW || y >= H) continue;
 			// samples x[2c-2 .. 2c+5] = dwords (c-1 .. c+2) -> local d = 2p+1 .. 2p+4
-			int s[8];
+			uint32_t d[4];
 #pragma unroll
-			for (int k = 0; k < 4; k++) { uint32_t v = s_in[j][2 * p + 1 + k]; s[2 * k] = lo16(v); s[2 * k + 1] = hi16(v); }
-			uint32_t ev = s_in[j][2 * p];                   // x[2c-4], x[2c-3]
-			int l0, l1, h0, h1;
-			horiz_pair(s, lo16(ev), hi16(ev), job.prescale, c == 0, c == HW - 1, c + 1 == HW - 1, l0, l1, h0, h1);
-			s_l[j][p] = pack16(l0, l1);
-			s_h[j][p] = pack16(h0, h1);
+			for (int k = 0; k < 4; k++) d[k] = s_in[j][2 * p + 1 + k];
+			uint32_t lpk, hpk;
+			horiz_pair(d, s_in[j][2 * p], job.prescale, c == 0, c == HW - 1, c + 1 == HW - 1, lpk, hpk);
+			s_l[j][p] = lpk;
+			s_h[j][p] = hpk;
 		}
 	}
 	__syncthreads();
@@ -240,13 +290,14 @@ __global__ void __launch_bounds__(NTHREADS) k_fwd_yuv422(const FwdYuvJob *jobs)
 			int j = i / (TW / 2), p = i - j * (TW / 2);
 			int c = c0 + 2 * p, y = row_start + j;
 			if (c >= DW || y >= H) continue;
-			int s[8];
+			// luma pair of dword v: (Y0, Y1) << shift, one AND + one shift per packed pair
+			uint32_t d[4];
 #pragma unroll
-			for (int k = 0; k < 4; k++) { uint32_t v = s_in[j][2 * p + 1 + k]; s[2 * k] = (int)((v >> ysh0) & 0xff) << shift; s[2 * k + 1] = (int)((v >> ysh1) & 0xff) << shift; }
-			int l0, l1, h0, h1;
-			horiz_pair(s, 0, 0, 0, c == 0, false, c + 1 == DW - 1, l0, l1, h0, h1);     // DW is even: c is never the last column
-			s_l[j][p] = pack16(l0, l1);
-			s_h[j][p] = pack16(h0, h1);
+			for (int k = 0; k < 4; k++) d[k] = ((s_in[j][2 * p + 1 + k] >> ysh0) & 0x00ff00ffu) << shift;
+			uint32_t lpk, hpk;
+			horiz_pair(d, 0u, 0, c == 0, false, c + 1 == DW - 1, lpk, hpk);     // DW is even: c is never the last column
+			s_l[j][p] = lpk;
+			s_h[j][p] = hpk;
 		}
 		// chroma: output column cc <-> chroma samples 2cc, 2cc+1 = dwords 2cc, 2cc+1 ; pair (cc, cc+1) needs dwords 2cc-2 .. 2cc+5
 		const int CW = DW >> 1;                       // chroma output columns
@@ -254,16 +305,20 @@ __global__ void __launch_bounds__(NTHREADS) k_fwd_yuv422(const FwdYuvJob *jobs)
 			int j = i / (TW / 4), p = i - j * (TW / 4);
 			int cc = (c0 >> 1) + 2 * p, y = row_start + j;
 			if (cc >= CW || y >= H) continue;
-			int su[8], sv[8];
-			// dword index 2cc-2 -> local d = 2cc - 2 - (c0 - 2) = 4p
+			// chroma samples k and k+1 sit in dwords 2cc-2+2k.. : pack (sample(2m), sample(2m+1)) from two dwords
+			uint32_t du[4], dv[4];
 #pragma unroll
-			for (int k = 0; k < 8; k++) { uint32_t v = s_in[j][4 * p + k]; su[k] = (int)((v >> ush) & 0xff) << shift; sv[k] = (int)((v >> vsh) & 0xff) << shift; }
+			for (int k = 0; k < 4; k++) {
+				const uint32_t a0 = s_in[j][4 * p + 2 * k], a1 = s_in[j][4 * p + 2 * k + 1];
+				du[k] = (((a0 >> ush) & 0xffu) | (((a1 >> ush) & 0xffu) << 16)) << shift;
+				dv[k] = (((a0 >> vsh) & 0xffu) | (((a1 >> vsh) & 0xffu) << 16)) << shift;
+			}
 			const bool first = (cc == 0), last = (cc + 1 == CW - 1);       // CW is even
-			int l0, l1, h0, h1;
-			horiz_pair(sv, 0, 0, 0, first, false, last, l0, l1, h0, h1);
-			s_l[j][TW / 2 + p] = pack16(l0, l1); s_h[j][TW / 2 + p] = pack16(h0, h1);
-			horiz_pair(su, 0, 0, 0, first, false, last, l0, l1, h0, h1);
-			s_l[j][TW / 2 + TW / 4 + p] = pack16(l0, l1); s_h[j][TW / 2 + TW / 4 + p] = pack16(h0, h1);
+			uint32_t lpk, hpk;
+			horiz_pair(dv, 0u, 0, first, false, last, lpk, hpk);
+			s_l[j][TW / 2 + p] = lpk; s_h[j][TW / 2 + p] = hpk;
+			horiz_pair(du, 0u, 0, first, false, last, lpk, hpk);
+			s_l[j][TW / 2 + TW / 4 + p] = lpk; s_h[j][TW / 2 + TW / 4 + p] = hpk;
 		}
 	}
 	__syncthreads();
