@@ -30,7 +30,7 @@
 namespace cfhd {
 namespace dev {
 
-enum { TW = 64, TH = 16, ROWS = 2 * TH + 4, NTHREADS = 256 };
+enum { TW = 64, TH = 16, ROWS = 2 * TH + 4, NTHREADS = 256, NSTAGE = (ROWS * (TW + 4) + NTHREADS - 1) / NTHREADS };
 
 struct QuantParam { int mid; unsigned mult; int divisor; };
 
@@ -198,6 +198,15 @@ __device__ __forceinline__ void vert_pair_store(const uint32_t *sl, const uint32
 	*(uint32_t *)(out[0] + o) = ll; *(uint32_t *)(out[1] + o) = lh; *(uint32_t *)(out[2] + o) = hl; *(uint32_t *)(out[3] + o) = hh;
 }
 
+// The job descriptor is copied into LDS once per workgroup: fields that are indexed with a per-lane channel number would
+// otherwise be fetched with dependent vector loads from HBM inside the item loops.
+template <typename J> __device__ __forceinline__ void stage_job(J *dst, const J *src)
+{
+	const uint32_t *s = (const uint32_t *)src; uint32_t *d = (uint32_t *)dst;
+	for (int i = threadIdx.x; i < (int)(sizeof(J) / 4); i += NTHREADS) d[i] = s[i];
+	__syncthreads();
+}
+
 __device__ __forceinline__ int window_first_row(int r, int half_height, int height) { return r == 0 ? 0 : (r == half_height - 1 ? height - 6 : 2 * r - 2); }
 __device__ __forceinline__ int tile_first_row(int r0, int height) { int s = 2 * r0 - 2; if (s > height - 6) s = height - 6; return s < 0 ? 0 : s; }
 
@@ -206,7 +215,9 @@ __device__ __forceinline__ int tile_first_row(int r0, int height) { int s = 2 * 
 // =============================================================================================
 __global__ void __launch_bounds__(NTHREADS) k_fwd_plane(const FwdPlaneJob *jobs)
 {
-	const FwdPlaneJob &job = jobs[blockIdx.z];
+	__shared__ FwdPlaneJob s_job;
+	stage_job(&s_job, &jobs[blockIdx.z]);
+	const FwdPlaneJob &job = s_job;
 	const int W = job.width, H = job.height, HW = W >> 1, HH = H >> 1;
 	const int c0 = blockIdx.x * TW, r0 = blockIdx.y * TH;
 	__shared__ uint32_t s_in[ROWS][TW + 4];     // dword d of a row holds samples 2(c0-2+d), 2(c0-2+d)+1
@@ -216,12 +227,20 @@ __global__ void __launch_bounds__(NTHREADS) k_fwd_plane(const FwdPlaneJob *jobs)
 	const int tid = threadIdx.x;
 	const int row_start = tile_first_row(r0, H);
 	if (active) {
-		for (int i = tid; i < ROWS * (TW + 4); i += NTHREADS) {
-			int j = i / (TW + 4), d = i - j * (TW + 4);
-			int y = row_start + j, dw = c0 - 2 + d;          // dword index within the plane row
-			uint32_t v = 0;
-			if (y < H && dw >= 0 && dw < HW) v = *(const uint32_t *)(job.in + (size_t)y * job.in_pitch + 2 * dw);
-			s_in[j][d] = v;
+		// all loads of the tile are issued before the first LDS store: one HBM round trip per workgroup instead of one per iteration
+		uint32_t va[NSTAGE];
+#pragma unroll
+		for (int k = 0; k < NSTAGE; k++) {
+			const int i = tid + k * NTHREADS;
+			const int j = i / (TW + 4), d = i - j * (TW + 4);
+			const int y = row_start + j, dw = c0 - 2 + d;    // dword index within the plane row
+			va[k] = 0;
+			if (i < ROWS * (TW + 4) && y < H && dw >= 0 && dw < HW) va[k] = *(const uint32_t *)(job.in + (size_t)y * job.in_pitch + 2 * dw);
+		}
+#pragma unroll
+		for (int k = 0; k < NSTAGE; k++) {
+			const int i = tid + k * NTHREADS;
+			if (i < ROWS * (TW + 4)) { const int j = i / (TW + 4); s_in[j][i - j * (TW + 4)] = va[k]; }
 		}
 	}
 	__syncthreads();
@@ -259,7 +278,9 @@ __global__ void __launch_bounds__(NTHREADS) k_fwd_plane(const FwdPlaneJob *jobs)
 // =============================================================================================
 __global__ void __launch_bounds__(NTHREADS) k_fwd_yuv422(const FwdYuvJob *jobs)
 {
-	const FwdYuvJob &job = jobs[blockIdx.z];
+	__shared__ FwdYuvJob s_job;
+	stage_job(&s_job, &jobs[blockIdx.z]);
+	const FwdYuvJob &job = s_job;
 	const int W = job.width, H = job.height;          // luma samples
 	const int DW = W >> 1;                            // dwords per row = luma output columns = chroma samples
 	const int HH = H >> 1;
@@ -272,13 +293,20 @@ __global__ void __launch_bounds__(NTHREADS) k_fwd_yuv422(const FwdYuvJob *jobs)
 	const int row_start = tile_first_row(r0, H);
 	const int shift = job.shift;
 	if (active) {
-		for (int i = tid; i < ROWS * (TW + 4); i += NTHREADS) {
-			int j = i / (TW + 4), d = i - j * (TW + 4);
-			int y = row_start + j, dw = c0 - 2 + d;
-			uint32_t v = 0;
-			if (y < H && dw >= 0 && dw < DW)
-				v = (y < job.display_height) ? *(const uint32_t *)(job.in + (size_t)y * job.in_pitch + 4 * (size_t)dw) : 0x80808080u;
-			s_in[j][d] = v;
+		uint32_t va[NSTAGE];
+#pragma unroll
+		for (int k = 0; k < NSTAGE; k++) {
+			const int i = tid + k * NTHREADS;
+			const int j = i / (TW + 4), d = i - j * (TW + 4);
+			const int y = row_start + j, dw = c0 - 2 + d;
+			va[k] = 0;
+			if (i < ROWS * (TW + 4) && y < H && dw >= 0 && dw < DW)
+				va[k] = (y < job.display_height) ? *(const uint32_t *)(job.in + (size_t)y * job.in_pitch + 4 * (size_t)dw) : 0x80808080u;
+		}
+#pragma unroll
+		for (int k = 0; k < NSTAGE; k++) {
+			const int i = tid + k * NTHREADS;
+			if (i < ROWS * (TW + 4)) { const int j = i / (TW + 4); s_in[j][i - j * (TW + 4)] = va[k]; }
 		}
 	}
 	__syncthreads();
@@ -374,24 +402,36 @@ __device__ __forceinline__ void inv_horiz(int lm1, int l0, int lp1, int lfar, in
 
 enum { ITW = 64, ITH = 8, ICOLS = ITW + 4 };    // inverse tile: 64 x 8 band coefficients -> 128 x 16 outputs
 
-// Loads the vertical synthesis of (vlow, vhigh) at (r, c) ; c may lie outside [0,w) (returns 0s, never used by valid taps)
-__device__ __forceinline__ void inv_vert_at(const int16_t *vlow, const int16_t *vhigh, int pitch, int w, int h, int r, int c, int &even, int &odd)
+// The four taps of one vertical synthesis: l[0..2] = lowpass rows (r-1, r, r+1), or for the border rows (r, r+1, r+2) resp.
+// (r-2, r-1, r); l[3] = the highpass value.  Zero outside [0,w) (never used by a valid tap).
+struct VTaps { int l0, l1, l2, hi; };
+__device__ __forceinline__ VTaps inv_vert_load(const int16_t *vlow, const int16_t *vhigh, int pitch, int w, int h, int r, int c)
 {
-	even = 0; odd = 0;
-	if (c < 0 || c >= w) return;
+	// branch-free: clamp the coordinates so that every lane issues its four loads back to back, then mask
+	const bool valid = c >= 0 && c < w && r < h;
+	const int cc = c < 0 ? 0 : (c >= w ? w - 1 : c), rr = r >= h ? h - 1 : r;
+	const int first = rr == 0 ? 0 : (rr == h - 1 ? h - 3 : rr - 1);
+	const int16_t *p = vlow + (size_t)first * pitch + cc;
+	VTaps t;
+	t.l0 = p[0]; t.l1 = p[pitch]; t.l2 = p[2 * (size_t)pitch];
+	t.hi = vhigh[(size_t)rr * pitch + cc];
+	const int mask = valid ? -1 : 0;                 // arithmetic select: no branch between the loads of consecutive items
+	t.l0 &= mask; t.l1 &= mask; t.l2 &= mask; t.hi &= mask;
+	return t;
+}
+__device__ __forceinline__ void inv_vert_apply(const VTaps &t, int r, int h, int &even, int &odd)
+{
 	const int pos = r == 0 ? 0 : (r == h - 1 ? 2 : 1);
-	int lm1 = 0, l0, lp1 = 0, lfar = 0;
-	l0 = vlow[(size_t)r * pitch + c];
-	if (pos == 0) { lp1 = vlow[(size_t)(r + 1) * pitch + c]; lfar = vlow[(size_t)(r + 2) * pitch + c]; }
-	else if (pos == 2) { lm1 = vlow[(size_t)(r - 1) * pitch + c]; lfar = vlow[(size_t)(r - 2) * pitch + c]; }
-	else { lm1 = vlow[(size_t)(r - 1) * pitch + c]; lp1 = vlow[(size_t)(r + 1) * pitch + c]; }
-	int hi = vhigh[(size_t)r * pitch + c];
-	inv_vert(lm1, l0, lp1, lfar, hi, pos, even, odd);
+	if (pos == 0) inv_vert(0, t.l0, t.l1, t.l2, t.hi, 0, even, odd);                 // rows 0,1,2
+	else if (pos == 2) inv_vert(t.l1, t.l2, 0, t.l0, t.hi, 2, even, odd);           // rows h-3 (far), h-2, h-1
+	else inv_vert(t.l0, t.l1, t.l2, 0, t.hi, 1, even, odd);
 }
 
 __global__ void __launch_bounds__(NTHREADS) k_inv_plane(const InvPlaneJob *jobs)
 {
-	const InvPlaneJob &job = jobs[blockIdx.z];
+	__shared__ InvPlaneJob s_job;
+	stage_job(&s_job, &jobs[blockIdx.z]);
+	const InvPlaneJob &job = s_job;
 	const int w = job.width, h = job.height;
 	const int c0 = blockIdx.x * ITW, r0 = blockIdx.y * ITH;
 	// vertical results for columns c0-2 .. c0+ITW+1 : [row parity][L/H][r][col]
@@ -399,14 +439,24 @@ __global__ void __launch_bounds__(NTHREADS) k_inv_plane(const InvPlaneJob *jobs)
 	const bool active = (c0 < w) && (r0 < h);
 	const int tid = threadIdx.x;
 	if (active) {
-		for (int i = tid; i < ITH * ICOLS; i += NTHREADS) {
-			int rl = i / ICOLS, cl = i - rl * ICOLS;
-			int r = r0 + rl, c = c0 - 2 + cl;
-			if (r >= h) continue;
+		enum { NIT = (ITH * ICOLS + NTHREADS - 1) / NTHREADS };
+		VTaps tl[NIT], th[NIT];
+#pragma unroll
+		for (int k = 0; k < NIT; k++) {                  // every load of the tile first ...
+			const int i = tid + k * NTHREADS, rl = i / ICOLS, cl = i - rl * ICOLS;
+			const int r = i < ITH * ICOLS ? r0 + rl : h, c = c0 - 2 + cl;
+			tl[k] = inv_vert_load(job.band[0], job.band[2], job.band_pitch, w, h, r, c);   // (LL, HL) -> horizontal-lowpass rows
+			th[k] = inv_vert_load(job.band[1], job.band[3], job.band_pitch, w, h, r, c);   // (LH, HH) -> horizontal-highpass rows
+		}
+#pragma unroll
+		for (int k = 0; k < NIT; k++) {                  // ... then the arithmetic and the LDS stores
+			const int i = tid + k * NTHREADS, rl = i / ICOLS, cl = i - rl * ICOLS;
+			const int r = r0 + rl;
+			if (i >= ITH * ICOLS || r >= h) continue;
 			int e, o;
-			inv_vert_at(job.band[0], job.band[2], job.band_pitch, w, h, r, c, e, o);   // (LL, HL) -> horizontal-lowpass rows
+			inv_vert_apply(tl[k], r, h, e, o);
 			s_v[0][0][rl][cl] = (int16_t)e; s_v[1][0][rl][cl] = (int16_t)o;
-			inv_vert_at(job.band[1], job.band[3], job.band_pitch, w, h, r, c, e, o);   // (LH, HH) -> horizontal-highpass rows
+			inv_vert_apply(th[k], r, h, e, o);
 			s_v[0][1][rl][cl] = (int16_t)e; s_v[1][1][rl][cl] = (int16_t)o;
 		}
 	}
@@ -450,7 +500,9 @@ __device__ __forceinline__ int dither_bit(uint32_t seed, int row, int lane)
 
 __global__ void __launch_bounds__(NTHREADS) k_inv_yuv422(const InvYuvJob *jobs, uint32_t launch_seed)
 {
-	const InvYuvJob &job = jobs[blockIdx.z];
+	__shared__ InvYuvJob s_job;
+	stage_job(&s_job, &jobs[blockIdx.z]);
+	const InvYuvJob &job = s_job;
 	const uint32_t seed = job.dither_seed ^ launch_seed;
 	const int w = job.width, h = job.height;          // luma band ; chroma bands are w/2 wide
 	const int c0 = blockIdx.x * ITW, r0 = blockIdx.y * ITH;
@@ -460,27 +512,41 @@ __global__ void __launch_bounds__(NTHREADS) k_inv_yuv422(const InvYuvJob *jobs, 
 	const int tid = threadIdx.x;
 	const int cw = w >> 1, cc0 = c0 >> 1;
 	if (active) {
-		for (int i = tid; i < ITH * ICOLS; i += NTHREADS) {
-			int rl = i / ICOLS, cl = i - rl * ICOLS;
-			int r = r0 + rl, c = c0 - 2 + cl;
-			if (r >= h) continue;
+		enum { NY = (ITH * ICOLS + NTHREADS - 1) / NTHREADS, CCOLS = ITW / 2 + 4, NC = (2 * ITH * CCOLS + NTHREADS - 1) / NTHREADS };
+		VTaps yl[NY], yh[NY], cl_[NC], ch_[NC];
+#pragma unroll
+		for (int k = 0; k < NY; k++) {
+			const int i = tid + k * NTHREADS, rl = i / ICOLS, cl = i - rl * ICOLS;
+			const int r = i < ITH * ICOLS ? r0 + rl : h, c = c0 - 2 + cl;
+			yl[k] = inv_vert_load(job.band[0][0], job.band[0][2], job.band_pitch[0], w, h, r, c);
+			yh[k] = inv_vert_load(job.band[0][1], job.band[0][3], job.band_pitch[0], w, h, r, c);
+		}
+#pragma unroll
+		for (int k = 0; k < NC; k++) {
+			const int i = tid + k * NTHREADS, q = i / (ITH * CCOLS), rem = i - q * (ITH * CCOLS), rl = rem / CCOLS, cl = rem - rl * CCOLS;
+			const int r = i < 2 * ITH * CCOLS ? r0 + rl : h, c = cc0 - 2 + cl, chn = (q & 1) + 1;
+			cl_[k] = inv_vert_load(job.band[chn][0], job.band[chn][2], job.band_pitch[chn], cw, h, r, c);
+			ch_[k] = inv_vert_load(job.band[chn][1], job.band[chn][3], job.band_pitch[chn], cw, h, r, c);
+		}
+#pragma unroll
+		for (int k = 0; k < NY; k++) {
+			const int i = tid + k * NTHREADS, rl = i / ICOLS, cl = i - rl * ICOLS, r = r0 + rl;
+			if (i >= ITH * ICOLS || r >= h) continue;
 			int e, o;
-			inv_vert_at(job.band[0][0], job.band[0][2], job.band_pitch[0], w, h, r, c, e, o);
+			inv_vert_apply(yl[k], r, h, e, o);
 			s_y[0][0][rl][cl] = (int16_t)e; s_y[1][0][rl][cl] = (int16_t)o;
-			inv_vert_at(job.band[0][1], job.band[0][3], job.band_pitch[0], w, h, r, c, e, o);
+			inv_vert_apply(yh[k], r, h, e, o);
 			s_y[0][1][rl][cl] = (int16_t)e; s_y[1][1][rl][cl] = (int16_t)o;
 		}
-		for (int i = tid; i < 2 * ITH * (ITW / 2 + 4); i += NTHREADS) {
-			int k = i / (ITH * (ITW / 2 + 4)), rem = i - k * (ITH * (ITW / 2 + 4));
-			int rl = rem / (ITW / 2 + 4), cl = rem - rl * (ITW / 2 + 4);
-			int r = r0 + rl, c = cc0 - 2 + cl;
-			if (r >= h) continue;
-			const int ch = k + 1;
+#pragma unroll
+		for (int k = 0; k < NC; k++) {
+			const int i = tid + k * NTHREADS, q = i / (ITH * CCOLS), rem = i - q * (ITH * CCOLS), rl = rem / CCOLS, cl = rem - rl * CCOLS, r = r0 + rl;
+			if (i >= 2 * ITH * CCOLS || r >= h) continue;
 			int e, o;
-			inv_vert_at(job.band[ch][0], job.band[ch][2], job.band_pitch[ch], cw, h, r, c, e, o);
-			s_c[k][0][0][rl][cl] = (int16_t)e; s_c[k][1][0][rl][cl] = (int16_t)o;
-			inv_vert_at(job.band[ch][1], job.band[ch][3], job.band_pitch[ch], cw, h, r, c, e, o);
-			s_c[k][0][1][rl][cl] = (int16_t)e; s_c[k][1][1][rl][cl] = (int16_t)o;
+			inv_vert_apply(cl_[k], r, h, e, o);
+			s_c[q][0][0][rl][cl] = (int16_t)e; s_c[q][1][0][rl][cl] = (int16_t)o;
+			inv_vert_apply(ch_[k], r, h, e, o);
+			s_c[q][0][1][rl][cl] = (int16_t)e; s_c[q][1][1][rl][cl] = (int16_t)o;
 		}
 	}
 	__syncthreads();
