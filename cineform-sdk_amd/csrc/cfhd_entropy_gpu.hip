@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <string.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <algorithm>
 
 namespace cfhd {
 
@@ -185,14 +187,17 @@ int GpuEntropyDecoder::set_sample_device(int i, const uint8_t *d_sample, const u
 int GpuEntropyDecoder::launch()
 {
 	hipStream_t st = (hipStream_t)stream_;
-	// jobs ordered band-type major so that the 64 lanes of a wave decode bands of similar length
+	static const bool lane_kernel = [] { const char *e = getenv("CFHD_AMD_DEC"); return e && strcmp(e, "lane") == 0; }();
 	dev::DecBandJob *fb = host_->flat_bands; dev::DecLowpassJob *fl = host_->flat_lows;
 	size_t nfb = 0, nfl = 0, per_frame = 0;
+	// band-type major: the 64 lanes of a wave (lane kernel) decode bands of similar length, and the workgroups of the parallel
+	// kernel start with the long bands (level-1 luma first) so that the short ones fill the tail of the launch
 	for (int f = 0; f < n_; f++) per_frame = host_->bands[f].size() > per_frame ? host_->bands[f].size() : per_frame;
 	for (size_t k = 0; k < per_frame; k++) for (int f = 0; f < n_; f++) if (k < host_->bands[f].size()) fb[nfb++] = host_->bands[f][k];
 	for (int f = 0; f < n_; f++) for (const dev::DecLowpassJob &j : host_->lows[f]) fl[nfl++] = j;
 	if (!nfb) return -1;
-	HIPCHK(hipMemset2DAsync(d_coeffs_, coeff_stride_ * 2, 0, (size_t)plan_.final_elems * 2, n_, st));
+	if (!lane_kernel) std::stable_sort(fb, fb + nfb, [](const dev::DecBandJob &a, const dev::DecBandJob &b) { return a.bytes > b.bytes; });
+	else HIPCHK(hipMemset2DAsync(d_coeffs_, coeff_stride_ * 2, 0, (size_t)plan_.final_elems * 2, n_, st));   // the parallel kernel clears its own bands
 	HIPCHK(hipMemsetAsync(d_errors_, 0, sizeof(int), st));
 	for (int f = 0; f < n_; f++)
 		if (host_->host_bytes[f]) HIPCHK(hipMemcpyAsync(d_samples_ + cap_ * f, h_samples_ + cap_ * f, host_->host_bytes[f], hipMemcpyHostToDevice, st));
@@ -200,7 +205,8 @@ int GpuEntropyDecoder::launch()
 	HIPCHK(hipMemcpyAsync(d_lowjobs_, fl, nfl * sizeof(dev::DecLowpassJob), hipMemcpyHostToDevice, st));
 	(void)hipGetLastError();
 	const int nb = (int)nfb;
-	dev::k_dec_bands<<<(nb + dev::DEC_THREADS - 1) / dev::DEC_THREADS, dev::DEC_THREADS, 0, st>>>((const dev::DecBandJob *)d_bandjobs_, nb, (const dev::DecTables *)d_tables_, d_errors_);
+	if (lane_kernel) dev::k_dec_bands<<<(nb + dev::DEC_THREADS - 1) / dev::DEC_THREADS, dev::DEC_THREADS, 0, st>>>((const dev::DecBandJob *)d_bandjobs_, nb, (const dev::DecTables *)d_tables_, d_errors_);
+	else dev::k_dec_bands_par<<<nb, dev::DECP_THREADS, 0, st>>>((const dev::DecBandJob *)d_bandjobs_, (const dev::DecTables *)d_tables_, d_errors_);
 	dev::k_dec_lowpass<<<dim3(8, (unsigned)nfl), 256, 0, st>>>((const dev::DecLowpassJob *)d_lowjobs_);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipMemcpyAsync(h_errors_, d_errors_, sizeof(int), hipMemcpyDeviceToHost, st));

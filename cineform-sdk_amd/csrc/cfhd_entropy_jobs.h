@@ -118,7 +118,7 @@ inline bool dec_build_jobs(const ParsedSample &ps, const FramePlan &plan, const 
 			for (int b = 1; b < 4; b++) {
 				const ParsedBand &pb = ps.high[c][lv][b];
 				const BandDesc &bd = plan.ch[c].band[lv][b];
-				if (!pb.present || pb.width != bd.width || pb.height != bd.height || (pb.offset & 3) || (pb.codebook != 1 && pb.codebook != 0)) return false;
+				if (!pb.present || pb.width != bd.width || pb.height != bd.height || (pb.offset & 3) || (pb.codebook != 1 && pb.codebook != 0) || (bd.offset & 7) || (bd.pitch & 7)) return false;   // k_dec_bands_par clears bands with 16-byte stores
 				dev::DecBandJob bj = { sample_addr + pb.offset, pb.bytes, coeff_base + bd.offset, bd.height * bd.pitch, pb.quant };
 				bands->push_back(bj);
 			}

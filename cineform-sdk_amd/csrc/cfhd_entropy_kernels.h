@@ -472,6 +472,115 @@ __global__ void __launch_bounds__(DEC_THREADS) k_dec_bands(const DecBandJob *job
 	if (err) atomic_or_u32((uint32_t *)errors, 1u);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Parallel decode of one band by one workgroup.  The code has no resynchronisation points, but a decoder's only state is its
+// bit position, so two decoders that ever meet on the same bit stay together: the payload is cut into 256-bit subsequences,
+// every lane decodes its subsequence from a guessed start (the subsequence boundary), hands the position where it crossed into
+// the next subsequence to its neighbour, and lanes whose start turned out different decode again until nothing changes (a
+// few rounds; lane 0 always starts from the exact position carried over from the previous 8 KB sequence, so round k makes at
+// least the first k subsequences exact).  A prefix sum over the per-lane coefficient counts gives every lane its raster
+// position and a last pass writes the dequantized values.  Same result as the one-lane kernel above and as
+// Codec/decoder.c:19534; the workgroup also zeroes its band first (the reference memset()s the band, decoder.c:19563).
+// ---------------------------------------------------------------------------------------------
+enum { DECP_THREADS = 256, DECP_SUB_BITS = 256, DECP_SEQ_BITS = DECP_THREADS * DECP_SUB_BITS, DECP_SEQ_WORDS = DECP_SEQ_BITS / 32 };
+enum : uint32_t { DECP_END = 0xFFFFFFFFu, DECP_BAD = 0xFFFFFFFEu };
+static_assert((int)DECP_THREADS == (int)ENT_THREADS, "block_excl_sum() is sized for ENT_THREADS");
+
+struct DecSub { uint32_t end, cnt; };
+
+// Decodes the code words that start in [p, limit) of the sequence held in s_words (big-endian bit order, already byte
+// swapped).  Returns where the next code word starts (DECP_END after the band end marker, DECP_BAD for an invalid code) and
+// how many coefficients (zero runs included) were produced; WRITE stores the nonzero ones at dst[idx...].
+template <bool WRITE>
+__device__ __forceinline__ DecSub dec_sub(const uint32_t *s_words, const uint32_t *s_lut1, const DecTables *T, uint32_t p, const uint32_t limit,
+                                          int16_t *dst, uint32_t idx, const uint32_t n, const int quant)
+{
+	uint32_t wi = p >> 5;
+	const int sh = (int)(p & 31u);
+	uint64_t acc = (((uint64_t)s_words[wi] << 32) | s_words[wi + 1]) << sh;
+	int have = 64 - sh;
+	wi += 2;
+	uint32_t cnt = 0;
+	while (p < limit) {
+		if (have < 32) { acc |= (uint64_t)s_words[wi++] << (32 - have); have += 32; }
+		uint32_t e = s_lut1[(uint32_t)(acc >> (64 - DEC_K1))];
+		if ((e & 31u) == 31u) {
+			const int nb = (int)((e >> 5) & 31u);
+			e = T->lut2[(e >> 10) + (uint32_t)((acc << DEC_K1) >> (64 - nb))];
+		}
+		int len = (int)(e & 31u);
+		if (len == 0) return DecSub{ DECP_BAD, cnt };
+		const uint32_t mag = e >> 16;
+		if (mag == 0xffffu) return DecSub{ DECP_END, cnt };
+		if (mag) {
+			if (WRITE) {
+				const int negative = (int)((acc << len) >> 63);
+				const int v = (int)mag * quant;
+				if (idx + cnt < n) dst[idx + cnt] = (int16_t)(negative ? -v : v);
+			}
+			len++; cnt++;
+		} else cnt += (e >> 5) & 0x7ffu;
+		acc <<= len; have -= len; p += (uint32_t)len;
+	}
+	return DecSub{ p, cnt };
+}
+
+__global__ void __launch_bounds__(DECP_THREADS) k_dec_bands_par(const DecBandJob *jobs, const DecTables *T, int *errors)
+{
+	__shared__ uint32_t s_lut1[1 << DEC_K1];             // 16 KB
+	__shared__ uint32_t s_words[DECP_SEQ_WORDS + 4];     // 8 KB: the current sequence of the payload
+	__shared__ uint32_t s_end[DECP_THREADS];
+	__shared__ int s_scan[DECP_THREADS];
+	__shared__ int s_flag[2];
+	const int t = threadIdx.x;
+	const DecBandJob job = jobs[blockIdx.x];
+	const uint32_t *words = (const uint32_t *)job.bits;
+	const uint32_t nwords = job.bytes >> 2, n = (uint32_t)job.n;
+	for (int i = t; i < (1 << DEC_K1); i += DECP_THREADS) s_lut1[i] = T->lut1[i];
+	if (t < 2) s_flag[t] = 0;
+	{	// the zero runs are never written: clear the band (16-byte stores; job.dst and job.n are multiples of 8 elements)
+		uint4 *z = (uint4 *)job.dst;
+		const uint4 zero = { 0u, 0u, 0u, 0u };
+		for (uint32_t i = t; i < n / 8; i += DECP_THREADS) z[i] = zero;
+	}
+	uint32_t carry = 0, base_idx = 0;
+	int err = 0;
+	for (uint32_t seq0 = 0; ; seq0 += DECP_SEQ_WORDS) {
+		if (seq0 >= nwords) { err = 3; break; }          // ran off the payload without meeting the end marker
+		__syncthreads();
+		for (int i = t; i < DECP_SEQ_WORDS + 4; i += DECP_THREADS) { const uint32_t w = seq0 + (uint32_t)i; s_words[i] = w < nwords ? bswap32(words[w]) : 0u; }
+		__syncthreads();
+		uint32_t start = t ? (uint32_t)t * DECP_SUB_BITS : carry;
+		const uint32_t limit = (uint32_t)(t + 1) * DECP_SUB_BITS;
+		DecSub r = dec_sub<false>(s_words, s_lut1, T, start, limit, nullptr, 0u, 0u, 0);
+		for (int round = 0; ; round++) {
+			s_end[t] = r.end;
+			__syncthreads();
+			if (t == 0) s_flag[(round + 1) & 1] = 0;
+			const uint32_t ns = t ? s_end[t - 1] : start;
+			const bool changed = ns != start;
+			if (changed) s_flag[round & 1] = 1;
+			__syncthreads();
+			if (!s_flag[round & 1]) break;
+			if (changed) {
+				start = ns;
+				if (ns >= DECP_BAD) { r.end = ns; r.cnt = 0; }
+				else r = dec_sub<false>(s_words, s_lut1, T, start, limit, nullptr, 0u, 0u, 0);
+			}
+		}
+		int total;
+		const uint32_t my_idx = base_idx + (uint32_t)block_excl_sum((int)r.cnt, s_scan, &total);
+		const uint32_t last = s_end[DECP_THREADS - 1];
+		if (last == DECP_BAD) { err = 1; break; }
+		if ((uint32_t)total > n - base_idx) { err = 2; break; }   // more coefficients than the band holds
+		if (start < DECP_BAD && r.cnt) (void)dec_sub<true>(s_words, s_lut1, T, start, r.end, job.dst, my_idx, n, job.quant);
+		if (last == DECP_END) break;
+		carry = last - DECP_SEQ_BITS;
+		base_idx += (uint32_t)total;
+	}
+	if (err && t == 0) atomic_or_u32((uint32_t *)errors, 1u << err);
+}
+
 // Raw 16-bit big-endian lowpass coefficients + the reference decoder's bias (decoder.c:12240-12290, :12468-12545).
 __global__ void __launch_bounds__(256) k_dec_lowpass(const DecLowpassJob *jobs)
 {

@@ -310,7 +310,7 @@ __global__ void __launch_bounds__(NTHREADS) k_fwd_yuv422(const FwdYuvJob *jobs)
 		}
 	}
 	__syncthreads();
-	const int ysh0 = job.uyvy ? 8 : 0, ysh1 = job.uyvy ? 24 : 16;     // byte lanes of Y0, Y1
+	const int ysh0 = job.uyvy ? 8 : 0;                                 // byte lane of Y0 (Y1 is 16 bits further)
 	const int ush = job.uyvy ? 0 : 8, vsh = job.uyvy ? 16 : 24;       // byte lanes of U, V
 	if (active) {
 		// luma: output column c <-> dword c ; needs dwords c-1 .. c+2 for the pair (c, c+1)

@@ -100,7 +100,7 @@ extern "C" long emu_entropy_encode(int width, int height, int pixel_kind, int qu
 }
 
 // GPU entropy decoder under emulation: parse on the host (product parser), decode every band with k_dec_bands / k_dec_lowpass.
-extern "C" int emu_entropy_decode(const uint8_t *sample, size_t size, int pixel_kind, int16_t *coeffs, size_t coeff_elems)
+extern "C" int emu_entropy_decode(const uint8_t *sample, size_t size, int pixel_kind, int16_t *coeffs, size_t coeff_elems, int parallel)
 {
 	using namespace cfhd;
 	ParsedSample ps;
@@ -109,15 +109,18 @@ extern "C" int emu_entropy_decode(const uint8_t *sample, size_t size, int pixel_
 	if (!build_frame_plan(&plan, ps.width, ps.display_height, pixel_kind, ps.encoded_format)) return -2;
 	plan.precision = ps.precision;
 	if (coeff_elems < plan.coeff_elems) return -3;
-	memset(coeffs, 0, (size_t)plan.coeff_elems * 2);
+	if (!parallel) memset(coeffs, 0, (size_t)plan.coeff_elems * 2);      // k_dec_bands_par clears its bands itself
 	std::vector<dev::DecBandJob> bands; std::vector<dev::DecLowpassJob> lows;
 	if (!dec_build_jobs(ps, plan, sample, coeffs, pixel_kind, &bands, &lows)) return -4;
 	static std::vector<uint32_t> tables;
 	if (tables.empty()) tables = build_dec_tables(1);
 	int errors = 0;
 	const int nb = (int)bands.size();
-	hipemu::launch(dim3((nb + dev::DEC_THREADS - 1) / dev::DEC_THREADS), dim3(dev::DEC_THREADS),
-	               [&] { dev::k_dec_bands(bands.data(), nb, (const dev::DecTables *)tables.data(), &errors); });
+	if (parallel)
+		hipemu::launch(dim3(nb), dim3(dev::DECP_THREADS), [&] { dev::k_dec_bands_par(bands.data(), (const dev::DecTables *)tables.data(), &errors); });
+	else
+		hipemu::launch(dim3((nb + dev::DEC_THREADS - 1) / dev::DEC_THREADS), dim3(dev::DEC_THREADS),
+		               [&] { dev::k_dec_bands(bands.data(), nb, (const dev::DecTables *)tables.data(), &errors); });
 	hipemu::launch(dim3(4, (unsigned)lows.size()), dim3(256), [&] { dev::k_dec_lowpass(lows.data()); });
-	return errors ? -10 : 0;
+	return errors ? -10 - errors : 0;
 }

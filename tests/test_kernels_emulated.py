@@ -143,9 +143,10 @@ def test_gpu_entropy_stage_emulated_extreme_bands():
         assert got == want, mode
 
 
+@pytest.mark.parametrize("parallel", [0, 1])
 @pytest.mark.parametrize("w,h,seed", [(192, 96, 1), (336, 252, 3), (720, 480, 4)])
-def test_gpu_entropy_decoder_emulated_equals_host_decoder(w, h, seed):
-    """k_dec_bands / k_dec_lowpass under emulation reproduce the product's host VLC decoder (dequantized pyramid incl. lowpass bias)."""
+def test_gpu_entropy_decoder_emulated_equals_host_decoder(w, h, seed, parallel):
+    """k_dec_bands (one lane per band) and k_dec_bands_par (one workgroup per band) + k_dec_lowpass under emulation reproduce the product's host VLC decoder (dequantized pyramid incl. lowpass bias)."""
     frame, pitch = synth_yuy2(w, h, seed)
     plan = Plan(w, h)
     coeffs = oracle_forward_yuv422(plan, frame, pitch)
@@ -155,7 +156,10 @@ def test_gpu_entropy_decoder_emulated_equals_host_decoder(w, h, seed):
     want = host_decode_pyramid(sample, plan)
     got = np.full(plan.coeff_elems, 99, dtype=np.int16)
     E = emu()
-    E.emu_entropy_decode.argtypes = [c_u8p, ctypes.c_size_t, ctypes.c_int, c_i16p, ctypes.c_size_t]
+    E.emu_entropy_decode.argtypes = [c_u8p, ctypes.c_size_t, ctypes.c_int, c_i16p, ctypes.c_size_t, ctypes.c_int]
     s = np.frombuffer(sample, dtype=np.uint8).copy()
-    assert E.emu_entropy_decode(p8(s), len(sample), 1, p16(got), got.size) == 0
-    assert np.array_equal(got[: plan.final_elems], want[: plan.final_elems])
+    assert E.emu_entropy_decode(p8(s), len(sample), 1, p16(got), got.size, parallel) == 0
+    for (c, lv, b) in plan.band:                    # every coded band incl. its pitch padding (the gaps between bands are nobody's)
+        if b == 0 and lv != 2: continue
+        cols = plan.band[(c, lv, b)]["width"] if b == 0 else None      # k_dec_lowpass writes the columns it has
+        assert np.array_equal(plan.view(got, c, lv, b)[:, :cols], plan.view(want, c, lv, b)[:, :cols]), (c, lv, b)
