@@ -33,6 +33,7 @@ struct cfhd_amd_batch {
 	MetaBlock meta;
 	uint32_t steps = 0;
 	bool gpu_entropy = true;
+	bool device_handoff = true;        // the decoder reads the samples where the encoder left them in HBM (k_dec_parse); the host copy arrives beside it
 	double t_fwd = 0, t_entropy_enc = 0, t_entropy_dec = 0, t_inv = 0;   // wall seconds of the last round trip
 };
 
@@ -62,6 +63,8 @@ cfhd_amd_batch *cfhd_amd_batch_create(int width, int height, uint32_t pixel_form
 	derive_quantization(&b->plan, quality, true, 0.0f, &st);
 	const char *e = getenv("CFHD_AMD_ENTROPY");
 	b->gpu_entropy = !(e && strcmp(e, "host") == 0);
+	const char *ho = getenv("CFHD_AMD_HANDOFF");
+	b->device_handoff = b->gpu_entropy && !(ho && strcmp(ho, "host") == 0);
 	const char *cs = getenv("CFHD_AMD_CHUNK");
 	int chunk = cs ? atoi(cs) : 0;                     // 0 = whole batch in one chunk (measured fastest: launches are already batch-wide)
 	if (chunk <= 0 || !b->gpu_entropy) chunk = nframes;
@@ -102,7 +105,25 @@ long long cfhd_amd_batch_roundtrip(cfhd_amd_batch *b)
 	const uint32_t base_number = b->steps * (uint32_t)b->n;
 	auto header = [&](int i) { SampleHeaderInfo h = { base_number + (uint32_t)i + 1, b->pixel_kind == PIX_2VUY ? 1 : 2, 2, b->quality, true, b->meta.data(), b->meta.size(), nullptr, 0 }; return h; };
 	const uint32_t seed = 0xA511E9B3u * (b->steps + 1);
-	if (b->gpu_entropy) {
+	if (b->gpu_entropy && b->device_handoff) {
+		// Samples stay in HBM between the encoder and the decoder: the decoder's stream waits for the encoder's kernels, parses
+		// the samples on the GPU and decodes, while the finished samples travel to the host (the encoder's product) on the
+		// encoder's stream beside it.
+		for (auto &c : b->chunks) {
+			for (int l = 0; l < c->n; l++) if (c->enc.entropy().set_frame_header(l, header(c->first + l))) return -6;
+			if (c->enc.launch_forward() || c->enc.entropy().launch()) return -2;
+			if (c->dec.after(c->enc.stream())) return -5;
+			if (c->dec.entropy().set_samples_device(c->enc.entropy().device_sample(0), c->enc.entropy().sample_cap(), c->enc.entropy().device_sizes())) return -4;
+			if (c->dec.entropy().launch() || c->dec.launch_inverse(seed + (uint32_t)c->first)) return -5;
+		}
+		t1 = now();
+		for (auto &c : b->chunks) {
+			if (c->enc.entropy().download() || c->enc.wait()) return -2;
+			for (int l = 0; l < c->n; l++) { size_t n = c->enc.entropy().sample_bytes(l); if (!n) return -3; b->sample_size[c->first + l] = n; }
+		}
+		t2 = t3 = now();
+		for (auto &c : b->chunks) { if (c->dec.wait()) return -5; if (c->dec.entropy().check()) return -7; }
+	} else if (b->gpu_entropy) {
 		// 1. every chunk: forward transform + entropy coding, queued on the chunk's own stream
 		for (auto &c : b->chunks) {
 			for (int l = 0; l < c->n; l++) if (c->enc.entropy().set_frame_header(l, header(c->first + l))) return -6;

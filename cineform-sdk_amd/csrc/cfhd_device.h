@@ -74,6 +74,7 @@ public:
 	int set_device_output(int i, void *d_out, int pitch_bytes);
 	int launch_inverse(uint32_t dither_seed);          // async
 	int download_frame(int i, void *out, int pitch_bytes);   // async D2H into pinned staging, then row copy after wait
+	int after(void *producer_stream);                  // async: later work on this batch's stream waits for what the producer stream holds now
 	int wait();
 	int finish_frame(int i, void *out, int pitch_bytes);      // after wait(): copy the staged frame to the caller's buffer
 	void *stream() { return stream_; }
@@ -91,6 +92,7 @@ private:
 	void *d_jobs_ = nullptr, *h_jobs_ = nullptr; size_t jobs_bytes_ = 0;
 	float kernel_ms_ = 0;
 	bool timed_ = false;
+	void *evdep_ = nullptr;
 	GpuEntropyDecoder ent_; bool ent_ready_ = false;
 };
 

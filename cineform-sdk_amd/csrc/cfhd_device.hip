@@ -275,6 +275,7 @@ void DecodeBatch::release()
 	if (ev0_) hipEventDestroy((hipEvent_t)ev0_);
 	if (ev1_) hipEventDestroy((hipEvent_t)ev1_);
 	for (int k = 0; k < 2; k++) if (evl_[k]) { hipEventDestroy((hipEvent_t)evl_[k]); evl_[k] = nullptr; }
+	if (evdep_) { hipEventDestroy((hipEvent_t)evdep_); evdep_ = nullptr; }
 	if (stream_) hipStreamDestroy((hipStream_t)stream_);
 	d_out_ = h_out_ = nullptr; d_coeff_ = h_coeff_ = nullptr; d_jobs_ = h_jobs_ = nullptr; stream_ = ev0_ = ev1_ = nullptr; n_ = 0;
 }
@@ -390,6 +391,15 @@ int DecodeBatch::download_frame(int i, void *, int)
 {
 	if (!own_output_ || i < 0 || i >= n_) return -1;
 	HIPCHK(hipMemcpyAsync(h_out_ + frame_bytes_ * i, d_out_ + frame_bytes_ * i, frame_bytes_, hipMemcpyDeviceToHost, (hipStream_t)stream_));
+	return 0;
+}
+
+// Orders everything queued on this batch's stream from now on behind what the producer stream holds at this moment.
+int DecodeBatch::after(void *producer_stream)
+{
+	if (!evdep_) { hipEvent_t e; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); evdep_ = e; }
+	HIPCHK(hipEventRecord((hipEvent_t)evdep_, (hipStream_t)producer_stream));
+	HIPCHK(hipStreamWaitEvent((hipStream_t)stream_, (hipEvent_t)evdep_, 0));
 	return 0;
 }
 

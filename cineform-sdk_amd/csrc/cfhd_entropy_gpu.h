@@ -17,6 +17,7 @@ public:
 	int launch();                                                    // async: templates H2D + 4 kernels
 	int download();                                                  // async sizes -> sync -> async payloads (call wait on the stream afterwards)
 	int fetch_sizes();                                               // sizes only (device-resident consumers); synchronises the stream
+	const uint32_t *device_sizes() const { return d_sizes_; }
 	const uint8_t *host_sample(int i) const { return h_samples_ + (size_t)i * cap_; }
 	uint8_t *device_sample(int i) { return d_samples_ + (size_t)i * cap_; }
 	uint32_t sample_bytes(int i) const { return h_sizes_[i]; }
@@ -48,7 +49,10 @@ public:
 	int set_sample_host(int i, const uint8_t *sample, size_t size);
 	// Sample bytes already in HBM at d_sample; host_copy (same bytes) is only parsed for the band offsets.
 	int set_sample_device(int i, const uint8_t *d_sample, const uint8_t *host_copy, size_t size);
-	int launch();                        // async: clear pyramids, (H2D samples), job tables, k_dec_bands + k_dec_lowpass
+	// All n samples already in HBM (sample i at d_samples + i * stride_bytes, its size in d_sizes[i]): nothing touches the host,
+	// k_dec_parse walks the tag streams on the GPU.  Stays in force until a set_sample_host()/set_sample_device() call.
+	int set_samples_device(const uint8_t *d_samples, size_t stride_bytes, const uint32_t *d_sizes);
+	int launch();                        // async: (H2D samples, job tables | k_dec_parse), k_dec_bands_par + k_dec_lowpass
 	int check();                         // after the stream was synchronised: 0 when every band decoded cleanly
 private:
 	struct Host; Host *host_;
@@ -56,8 +60,10 @@ private:
 	FramePlan plan_; int n_ = 0, out_kind_ = 0; size_t cap_ = 0, coeff_stride_ = 0; void *stream_ = nullptr;
 	int16_t *d_coeffs_ = nullptr;
 	uint8_t *d_samples_ = nullptr, *h_samples_ = nullptr;
-	void *d_tables_ = nullptr, *d_bandjobs_ = nullptr, *d_lowjobs_ = nullptr;
+	void *d_tables_ = nullptr, *d_bandjobs_ = nullptr, *d_lowjobs_ = nullptr, *d_plan_ = nullptr;
+	const uint8_t *ext_samples_ = nullptr; size_t ext_stride_ = 0; const uint32_t *ext_sizes_ = nullptr;   // set_samples_device()
 	int *d_errors_ = nullptr, *h_errors_ = nullptr;
+	bool lane_kernel_ = false;
 };
 
 } // namespace cfhd

@@ -132,13 +132,13 @@ GpuEntropyDecoder::~GpuEntropyDecoder() { release(); delete host_; }
 
 void GpuEntropyDecoder::release()
 {
-	void *dev[] = { d_samples_, d_tables_, d_bandjobs_, d_lowjobs_, d_errors_ };
+	void *dev[] = { d_samples_, d_tables_, d_bandjobs_, d_lowjobs_, d_errors_, d_plan_ };
 	for (void *p : dev) if (p) (void)hipFree(p);
 	if (h_samples_) (void)hipHostFree(h_samples_);
 	if (h_errors_) (void)hipHostFree(h_errors_);
 	if (host_->flat_bands) { (void)hipHostFree(host_->flat_bands); host_->flat_bands = nullptr; }
 	if (host_->flat_lows) { (void)hipHostFree(host_->flat_lows); host_->flat_lows = nullptr; }
-	d_samples_ = h_samples_ = nullptr; d_tables_ = d_bandjobs_ = d_lowjobs_ = nullptr; d_errors_ = h_errors_ = nullptr; n_ = 0;
+	d_samples_ = h_samples_ = nullptr; d_tables_ = d_bandjobs_ = d_lowjobs_ = d_plan_ = nullptr; d_errors_ = h_errors_ = nullptr; n_ = 0; ext_samples_ = nullptr;
 }
 
 int GpuEntropyDecoder::prepare(const FramePlan &plan, int nframes, int16_t *d_coeffs, size_t stride, size_t sample_cap, int out_kind, void *stream)
@@ -160,7 +160,21 @@ int GpuEntropyDecoder::prepare(const FramePlan &plan, int nframes, int16_t *d_co
 	HIPCHK(hipMalloc((void **)&d_errors_, sizeof(int)));
 	HIPCHK(hipHostMalloc((void **)&h_errors_, sizeof(int), hipHostMallocDefault));
 	*h_errors_ = 0;
+	{ const char *e = getenv("CFHD_AMD_DEC"); lane_kernel_ = e && strcmp(e, "lane") == 0; }   // A/B switch: the one-lane-per-band kernel
+	{
+		dev::DecPlan dp;
+		dec_build_plan(plan, out_kind, &dp);
+		HIPCHK(hipMalloc(&d_plan_, sizeof(dp)));
+		HIPCHK(hipMemcpy(d_plan_, &dp, sizeof(dp), hipMemcpyHostToDevice));
+	}
 	host_->bands.assign(n_, {}); host_->lows.assign(n_, {}); host_->host_bytes.assign(n_, 0);
+	return 0;
+}
+
+int GpuEntropyDecoder::set_samples_device(const uint8_t *d_samples, size_t stride_bytes, const uint32_t *d_sizes)
+{
+	if (!d_samples || !d_sizes || (stride_bytes & 15) || ((uintptr_t)d_samples & 15)) return -1;   // k_dec_parse reads 16 bytes at a time
+	ext_samples_ = d_samples; ext_stride_ = stride_bytes; ext_sizes_ = d_sizes;
 	return 0;
 }
 
@@ -176,6 +190,7 @@ int GpuEntropyDecoder::set_sample_host(int i, const uint8_t *sample, size_t size
 int GpuEntropyDecoder::set_sample_device(int i, const uint8_t *d_sample, const uint8_t *host_copy, size_t size)
 {
 	if (i < 0 || i >= n_) return -1;
+	ext_samples_ = nullptr;
 	ParsedSample ps;
 	if (parse_sample(host_copy, size, &ps) != 0) return -2;
 	if (ps.width != plan_.width || ps.display_height != plan_.display_height || ps.encoded_format != plan_.encoded_format || ps.num_channels != plan_.num_channels) return -3;
@@ -187,7 +202,20 @@ int GpuEntropyDecoder::set_sample_device(int i, const uint8_t *d_sample, const u
 int GpuEntropyDecoder::launch()
 {
 	hipStream_t st = (hipStream_t)stream_;
-	static const bool lane_kernel = [] { const char *e = getenv("CFHD_AMD_DEC"); return e && strcmp(e, "lane") == 0; }();
+	if (ext_samples_) {
+		// device-resident samples: parse on the GPU; the job tables have one row per band type (largest first), nframes wide
+		const int nch = plan_.num_channels, nb = n_ * nch * 9;
+		HIPCHK(hipMemsetAsync(d_errors_, 0, sizeof(int), st));
+		(void)hipGetLastError();
+		dev::k_dec_parse<<<(n_ + dev::DEC_PARSE_THREADS - 1) / dev::DEC_PARSE_THREADS, dev::DEC_PARSE_THREADS, 0, st>>>(ext_samples_, ext_stride_, ext_sizes_, n_,
+			(const dev::DecPlan *)d_plan_, d_coeffs_, coeff_stride_, (dev::DecBandJob *)d_bandjobs_, (dev::DecLowpassJob *)d_lowjobs_, d_errors_);
+		dev::k_dec_bands_par<<<nb, dev::DECP_THREADS, 0, st>>>((const dev::DecBandJob *)d_bandjobs_, (const dev::DecTables *)d_tables_, d_errors_);
+		dev::k_dec_lowpass<<<dim3(8, (unsigned)(n_ * nch)), 256, 0, st>>>((const dev::DecLowpassJob *)d_lowjobs_);
+		HIPCHK(hipGetLastError());
+		HIPCHK(hipMemcpyAsync(h_errors_, d_errors_, sizeof(int), hipMemcpyDeviceToHost, st));
+		return 0;
+	}
+	const bool lane_kernel = lane_kernel_;
 	dev::DecBandJob *fb = host_->flat_bands; dev::DecLowpassJob *fl = host_->flat_lows;
 	size_t nfb = 0, nfl = 0, per_frame = 0;
 	// band-type major: the 64 lanes of a wave (lane kernel) decode bands of similar length, and the workgroups of the parallel

@@ -5,6 +5,7 @@
 #include "cfhd_bitstream.h"
 #include "cfhd_entropy_kernels.h"
 #include <vector>
+#include <algorithm>
 #include <string.h>
 
 namespace cfhd {
@@ -124,6 +125,30 @@ inline bool dec_build_jobs(const ParsedSample &ps, const FramePlan &plan, const 
 			}
 	}
 	return true;
+}
+
+// Geometry the GPU sample parser (k_dec_parse) checks a sample against, and the launch order of the band jobs: by band area,
+// largest first, so that the long bands start early and the short ones fill the tail of the k_dec_bands_par launch.
+inline void dec_build_plan(const FramePlan &plan, int out_pixel_kind, dev::DecPlan *dp)
+{
+	memset(dp, 0, sizeof(*dp));
+	dp->width = plan.width; dp->display_height = plan.display_height; dp->encoded_format = plan.encoded_format; dp->num_channels = plan.num_channels;
+	struct Key { int area, c, lv, b; };
+	std::vector<Key> keys;
+	for (int c = 0; c < plan.num_channels; c++) {
+		const BandDesc &ll = plan.ch[c].band[2][0];
+		dp->low[c] = dev::DecPlanBand{ ll.width, ll.height, ll.pitch, (int)ll.offset };
+		dp->low_bias[c] = lowpass_bias(plan.precision, ll.width, out_pixel_kind);
+		for (int lv = 0; lv < kNumLevels; lv++)
+			for (int b = 1; b < 4; b++) {
+				const BandDesc &bd = plan.ch[c].band[lv][b];
+				dp->high[c][lv][b] = dev::DecPlanBand{ bd.width, bd.height, bd.pitch, (int)bd.offset };
+				keys.push_back(Key{ bd.width * bd.height, c, lv, b });
+			}
+	}
+	std::stable_sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) { return a.area > b.area; });
+	for (size_t k = 0; k < keys.size(); k++) dp->slot[keys[k].c][keys[k].lv][keys[k].b] = (int)k;
+	dp->bands_per_frame = (int)keys.size();
 }
 
 } // namespace cfhd

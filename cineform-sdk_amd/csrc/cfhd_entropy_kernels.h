@@ -581,6 +581,126 @@ __global__ void __launch_bounds__(DECP_THREADS) k_dec_bands_par(const DecBandJob
 	if (err && t == 0) atomic_or_u32((uint32_t *)errors, 1u << err);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Sample parser on the GPU, for samples that already live in HBM (the batched round trip hands the encoder's output straight
+// to the decoder; a device-resident reader would do the same): one lane per sample walks the tag/value stream exactly like
+// the host parser (cfhd_bitstream.cpp parse_sample, after Codec/decoder.c:8861-9420 UpdateCodecState/DecodeSampleIntraFrame:
+// optional tags are negated, 0x4000 chunks carry a payload to skip, 0x20xx chunks give the size of the band that follows) and
+// fills this frame's rows of the band / lowpass job tables.  Anything that does not match the prepared geometry leaves the
+// frame's jobs empty and raises the error flag.
+// ---------------------------------------------------------------------------------------------
+struct DecPlanBand { int width, height, pitch, offset; };
+struct DecPlan {
+	int width, display_height, encoded_format, num_channels, bands_per_frame;
+	DecPlanBand low[4]; int low_bias[4];
+	DecPlanBand high[4][3][4];
+	int slot[4][3][4];            // launch order of the band jobs: slot-major, the largest bands first
+};
+enum { DEC_PARSE_THREADS = 64, DEC_ERR_PARSE = 0x100 };
+
+struct DecTagReader {             // 16 bytes of the sample at a time (the tags of a band header sit next to each other)
+	const uint8_t *d; uint64_t base; uint4 c;
+	__device__ __forceinline__ uint32_t word(uint64_t pos)
+	{
+		const uint64_t b = pos & ~(uint64_t)15;
+		if (b != base) { c = *(const uint4 *)(d + b); base = b; }
+		const uint32_t k = (uint32_t)(pos >> 2) & 3u;
+		const uint32_t w = k == 0 ? c.x : k == 1 ? c.y : k == 2 ? c.z : c.w;
+		return bswap32(w);
+	}
+};
+
+__global__ void __launch_bounds__(DEC_PARSE_THREADS) k_dec_parse(const uint8_t *samples, size_t sample_stride, const uint32_t *sizes, int nframes, const DecPlan *P,
+                                                                 int16_t *coeffs, size_t coeff_stride, DecBandJob *bandjobs, DecLowpassJob *lowjobs, int *errors)
+{
+	const int f = blockIdx.x * DEC_PARSE_THREADS + threadIdx.x;
+	if (f >= nframes) return;
+	const uint8_t *d = samples + sample_stride * (size_t)f;
+	int16_t *cbase = coeffs + coeff_stride * (size_t)f;
+	const uint64_t size = sizes[f];
+	const int nch = P->num_channels;
+	for (int c = 0; c < nch; c++) {
+		lowjobs[f * nch + c] = DecLowpassJob{ d, cbase + P->low[c].offset, 0, 0, P->low[c].pitch, 0 };
+		for (int lv = 0; lv < 3; lv++)
+			for (int b = 1; b < 4; b++) {
+				const DecPlanBand pb = P->high[c][lv][b];
+				bandjobs[(size_t)P->slot[c][lv][b] * nframes + f] = DecBandJob{ d, 0u, cbase + pb.offset, pb.height * pb.pitch, 1 };
+			}
+	}
+	DecTagReader rd = { d, ~(uint64_t)0, { 0u, 0u, 0u, 0u } };
+	uint64_t pos = 0, pending_at = 0;
+	uint32_t pending = 0, seen = 0, seen_low = 0;
+	int channel = 0, lv = -1, band = 0, bw = 0, bh = 0, bq = 1, bflags = 0, lw = 0, lh = 0;
+	int width = 0, height = 0, display_height = 0, num_channels = 0, encoded_format = 0;
+	bool bad = size < 4;
+	while (!bad && pos + 4 <= size) {
+		const uint32_t word = rd.word(pos);
+		int tag = (int)(int16_t)(word >> 16);
+		const int value = (int)(word & 0xffffu);
+		if (tag < 0) tag = -tag;
+		pos += 4;
+		if (tag & 0x4000) {
+			const uint32_t bytes = (tag & 0x2000) ? ((((uint32_t)(tag & 0xff) << 16) | (uint32_t)value) * 4u) : (uint32_t)value * 4u;
+			if (pos + bytes > size) { bad = true; break; }
+			pos += bytes;
+			continue;
+		}
+		if (tag & 0x2000) {
+			if ((tag & 0xff00) == 0x2000) { pending = ((((uint32_t)(tag & 0xff)) << 16) | (uint32_t)value) * 4u; pending_at = pos; }
+			continue;
+		}
+		switch (tag) {
+		case 2: pos += 4u * (uint64_t)value; break;                                  // TAG_INDEX
+		case 62: channel = value; if (channel >= 4) bad = true; break;               // TAG_CHANNEL
+		case 12: num_channels = value; break;                                        // TAG_NUM_CHANNELS
+		case 84: encoded_format = value; break;                                      // TAG_ENCODED_FORMAT
+		case 20: width = value; break;                                               // TAG_FRAME_WIDTH
+		case 21: height = value; break;                                              // TAG_FRAME_HEIGHT
+		case 85: display_height = value; break;                                      // TAG_FRAME_DISPLAY_HEIGHT
+		case 27: lw = value; break;                                                  // TAG_LOWPASS_WIDTH
+		case 28: lh = value; break;                                                  // TAG_LOWPASS_HEIGHT
+		case 4:                                                                      // TAG_MARKER
+			if (value == 0x0f0f) {                                                   // MARK_COEFF_START: raw lowpass values inside the pending chunk
+				const uint64_t end = pending_at + pending;
+				const uint64_t bytes = (uint64_t)lw * (uint64_t)lh * 2u;
+				if (pending == 0 || pos + bytes > end || end > size || channel >= nch) { bad = true; break; }
+				const DecPlanBand ll = P->low[channel];
+				if (lw != ll.width || lh != ll.height) { bad = true; break; }
+				lowjobs[f * nch + channel] = DecLowpassJob{ d + pos, cbase + ll.offset, ll.width, ll.height, ll.pitch, P->low_bias[channel] };
+				seen_low |= 1u << channel;
+				pos = end; pending = 0;
+			}
+			break;
+		case 38: lv = value - 1; if (lv < 0 || lv >= 3) bad = true; break;          // TAG_WAVELET_NUMBER
+		case 48: band = value; if (band < 1 || band > 3) bad = true; bflags = 0; break;   // TAG_BAND_NUMBER
+		case 72: bflags = value; break;                                              // TAG_BAND_CODING_FLAGS
+		case 49: bw = value; break;                                                  // TAG_BAND_WIDTH
+		case 50: bh = value; break;                                                  // TAG_BAND_HEIGHT
+		case 53: bq = value; break;                                                  // TAG_BAND_QUANTIZATION
+		case 55: {                                                                   // TAG_BAND_HEADER: the code words follow, up to the band trailer
+			const uint64_t end = pending_at + pending;
+			if (lv < 0 || pending == 0 || end < pos + 4 || end > size || channel >= nch || band < 1) { bad = true; break; }
+			const DecPlanBand pb = P->high[channel][lv][band];
+			const int codebook = bflags & 0xf;
+			if (bw != pb.width || bh != pb.height || (pos & 3u) || (codebook != 0 && codebook != 1)) { bad = true; break; }
+			bandjobs[(size_t)P->slot[channel][lv][band] * nframes + f] = DecBandJob{ d + pos, (uint32_t)(end - 4 - pos), cbase + pb.offset, pb.height * pb.pitch, bq };
+			seen |= 1u << ((channel * 3 + lv) * 3 + band - 1);
+			pos = end; pending = 0;
+			break; }
+		default: break;
+		}
+	}
+	if (display_height == 0) display_height = height;
+	const uint32_t want = nch * 9 >= 32 ? 0xffffffffu : (1u << (nch * 9)) - 1u;
+	if (bad || width != P->width || display_height != P->display_height || encoded_format != P->encoded_format || num_channels != nch
+	    || seen != want || seen_low != (1u << nch) - 1u) {
+		for (int c = 0; c < nch; c++)
+			for (int l = 0; l < 3; l++)
+				for (int b = 1; b < 4; b++) bandjobs[(size_t)P->slot[c][l][b] * nframes + f].bytes = 0u;
+		atomic_or_u32((uint32_t *)errors, (uint32_t)DEC_ERR_PARSE);
+	}
+}
+
 // Raw 16-bit big-endian lowpass coefficients + the reference decoder's bias (decoder.c:12240-12290, :12468-12545).
 __global__ void __launch_bounds__(256) k_dec_lowpass(const DecLowpassJob *jobs)
 {

@@ -116,6 +116,28 @@ extern "C" int emu_entropy_decode(const uint8_t *sample, size_t size, int pixel_
 	if (tables.empty()) tables = build_dec_tables(1);
 	int errors = 0;
 	const int nb = (int)bands.size();
+	if (parallel == 2) {
+		// device-resident path: two copies of the sample, parsed by k_dec_parse (no host parser output reaches the kernels)
+		const size_t stride = (size + 64 + 63) & ~(size_t)63;
+		std::vector<uint8_t> raw(stride * 2 + 64, 0);
+		uint8_t *two = (uint8_t *)(((uintptr_t)raw.data() + 63) & ~(uintptr_t)63);
+		memcpy(two, sample, size); memcpy(two + stride, sample, size);
+		const uint32_t sizes[2] = { (uint32_t)size, (uint32_t)size };
+		std::vector<int16_t> pyr((size_t)plan.coeff_elems * 2, 77);
+		dev::DecPlan dp; dec_build_plan(plan, pixel_kind, &dp);
+		std::vector<dev::DecBandJob> bj((size_t)dp.bands_per_frame * 2); std::vector<dev::DecLowpassJob> lj((size_t)plan.num_channels * 2);
+		hipemu::launch(dim3(1), dim3(dev::DEC_PARSE_THREADS), [&] { dev::k_dec_parse(two, stride, sizes, 2, &dp, pyr.data(), plan.coeff_elems, bj.data(), lj.data(), &errors); });
+		if (errors) return -20 - errors;
+		hipemu::launch(dim3((unsigned)bj.size()), dim3(dev::DECP_THREADS), [&] { dev::k_dec_bands_par(bj.data(), (const dev::DecTables *)tables.data(), &errors); });
+		hipemu::launch(dim3(4, (unsigned)lj.size()), dim3(256), [&] { dev::k_dec_lowpass(lj.data()); });
+		if (errors) return -10 - errors;
+		memcpy(coeffs, pyr.data() + plan.coeff_elems, (size_t)plan.coeff_elems * 2);     // second frame out; both must agree where bands live
+		for (size_t k = 0; k < bands.size(); k++) {
+			const size_t off = (size_t)(bands[k].dst - coeffs);
+			if (memcmp(pyr.data() + off, pyr.data() + plan.coeff_elems + off, (size_t)bands[k].n * 2)) return -30;
+		}
+		return 0;
+	}
 	if (parallel)
 		hipemu::launch(dim3(nb), dim3(dev::DECP_THREADS), [&] { dev::k_dec_bands_par(bands.data(), (const dev::DecTables *)tables.data(), &errors); });
 	else

@@ -225,9 +225,12 @@ def test_gpu_entropy_and_host_entropy_paths_agree():
         assert mask_volatile_metadata(x) == mask_volatile_metadata(y)
 
 
-def test_batched_device_resident_round_trip():
+@pytest.mark.parametrize("handoff,decoder", [("device", "par"), ("host", "par"), ("host", "lane")])
+def test_batched_device_resident_round_trip(handoff, decoder):
     """cfhd_amd_batch_* (what bench.py times): several chunks on their own streams; every sample must equal oracle transform +
-    product syntax, every decoded frame must lie in the oracle's dither interval of its own sample."""
+    product syntax, every decoded frame must lie in the oracle's dither interval of its own sample.  handoff=device: the decoder
+    reads the samples in HBM and parses them with k_dec_parse; host: samples cross to the host parser and back.  decoder: the
+    workgroup-per-band kernel or the lane-per-band one."""
     L = product()
     L.cfhd_amd_batch_create.restype = ctypes.c_void_p
     L.cfhd_amd_batch_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_int]
@@ -240,10 +243,12 @@ def test_batched_device_resident_round_trip():
     w, h, n = 640, 360, 5
     frames = [synth_yuy2(w, h, 70 + i)[0] for i in range(n)]
     os.environ["CFHD_AMD_CHUNK"] = "2"
+    os.environ["CFHD_AMD_HANDOFF"] = handoff
+    os.environ["CFHD_AMD_DEC"] = decoder
     try:
         b = L.cfhd_amd_batch_create(w, h, PIX_YUY2, QUALITY_FILMSCAN1, n, 4)
     finally:
-        del os.environ["CFHD_AMD_CHUNK"]
+        del os.environ["CFHD_AMD_CHUNK"], os.environ["CFHD_AMD_HANDOFF"], os.environ["CFHD_AMD_DEC"]
     assert b
     for i, f in enumerate(frames):
         assert L.cfhd_amd_batch_upload(b, i, f.ctypes.data_as(ctypes.c_void_p), w * 2) == 0

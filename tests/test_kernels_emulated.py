@@ -143,10 +143,10 @@ def test_gpu_entropy_stage_emulated_extreme_bands():
         assert got == want, mode
 
 
-@pytest.mark.parametrize("parallel", [0, 1])
+@pytest.mark.parametrize("parallel", [0, 1, 2])
 @pytest.mark.parametrize("w,h,seed", [(192, 96, 1), (336, 252, 3), (720, 480, 4)])
 def test_gpu_entropy_decoder_emulated_equals_host_decoder(w, h, seed, parallel):
-    """k_dec_bands (one lane per band) and k_dec_bands_par (one workgroup per band) + k_dec_lowpass under emulation reproduce the product's host VLC decoder (dequantized pyramid incl. lowpass bias)."""
+    """k_dec_bands (one lane per band), k_dec_bands_par (one workgroup per band; 2: fed by the GPU parser k_dec_parse) + k_dec_lowpass under emulation reproduce the product's host VLC decoder (dequantized pyramid incl. lowpass bias)."""
     frame, pitch = synth_yuy2(w, h, seed)
     plan = Plan(w, h)
     coeffs = oracle_forward_yuv422(plan, frame, pitch)
@@ -163,3 +163,26 @@ def test_gpu_entropy_decoder_emulated_equals_host_decoder(w, h, seed, parallel):
         if b == 0 and lv != 2: continue
         cols = plan.band[(c, lv, b)]["width"] if b == 0 else None      # k_dec_lowpass writes the columns it has
         assert np.array_equal(plan.view(got, c, lv, b)[:, :cols], plan.view(want, c, lv, b)[:, :cols]), (c, lv, b)
+
+
+@pytest.mark.parametrize("parallel", [1, 2])
+def test_gpu_entropy_decoder_emulated_survives_damaged_samples(parallel):
+    """Truncated samples are refused; garbage inside the code words never writes outside the band nor hangs (error flag or wrong values, no crash)."""
+    w, h = 336, 252
+    frame, pitch = synth_yuy2(w, h, 5)
+    plan = Plan(w, h)
+    coeffs = oracle_forward_yuv422(plan, frame, pitch)
+    sample = product_write_sample_host(plan, coeffs, 1, meta_global=b"GUID\x10\x00\x00G" + bytes(16))
+    E = emu()
+    E.emu_entropy_decode.argtypes = [c_u8p, ctypes.c_size_t, ctypes.c_int, c_i16p, ctypes.c_size_t, ctypes.c_int]
+    guard = 4096
+    got = np.full(plan.coeff_elems + guard, 99, dtype=np.int16)
+    s = np.frombuffer(sample, dtype=np.uint8).copy()
+    assert E.emu_entropy_decode(p8(s), len(sample) // 2 & ~3, 1, p16(got), plan.coeff_elems, parallel) < 0
+    rng = np.random.default_rng(11)
+    for trial in range(4):
+        t = s.copy()
+        lo = len(t) // 3 + trial * 1000
+        t[lo: lo + 600] = rng.integers(0, 256, 600, dtype=np.uint8)
+        E.emu_entropy_decode(p8(t), len(t), 1, p16(got), plan.coeff_elems, parallel)
+        assert np.all(got[plan.coeff_elems:] == 99)
