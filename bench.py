@@ -3,8 +3,8 @@
 
 A step = one pass of the hot path over one batch of synthetic frames that are already resident in HBM:
 forward kernels -> entropy coding -> samples -> entropy decoding -> inverse kernels -> frames in HBM.
-`value` is whole-job frames per second (all ranks), `roofline` is the dominant kernel (level-1 forward) against the
-HBM peak, `cpu_baseline` is the unmodified reference (oracle/_ref) timed on this box's host cores on a bounded sample.
+`value` is whole-job frames per second (all ranks), `roofline` is the longest kernel of the step against the
+HBM peak (HIP events around every launch), `cpu_baseline` is the unmodified reference (oracle/_ref) timed on this box's host cores on a bounded sample.
 
   python bench.py --gpus 1 --steps 20 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -109,7 +109,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=128, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=256, help="frames per step per GPU")
     ap.add_argument("--threads", type=int, default=0, help="host entropy threads per rank (0 = cores / ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -165,12 +165,16 @@ def main():
         assert L.cfhd_amd_batch_roundtrip(b) > 0, T.amd_last_error()
     barrier()
     t0 = time.perf_counter()
-    fwd_ms = []; stage = [0.0] * 4; total_bytes = 0
+    KERNELS = [("k_fwd_yuv422", 0), ("k_fwd_plane[L2]", 1), ("k_fwd_plane[L3]", 2), ("k_ent_count", 8), ("k_ent_scan", 9), ("k_ent_layout", 10),
+               ("k_ent_emit", 11), ("k_dec_parse", 12), ("k_dec_bands_par", 13), ("k_dec_lowpass", 14), ("k_inv_plane[L3]", 5), ("k_inv_plane[L2]", 4),
+               ("k_inv_yuv422", 3)]
+    kms = {name: 0.0 for name, _ in KERNELS}; stage = [0.0] * 4; total_bytes = 0
     for _ in range(args.steps):
         n = L.cfhd_amd_batch_roundtrip(b)
         assert n > 0, T.amd_last_error()
         total_bytes = n
-        fwd_ms.append(L.cfhd_amd_batch_kernel_ms(b, 0))
+        for name, which in KERNELS:                    # HIP events recorded around each launch on the stream it runs on
+            kms[name] += L.cfhd_amd_batch_kernel_ms(b, which)
         for k in range(4):
             stage[k] += L.cfhd_amd_batch_stage_seconds(b, k)
     barrier()
@@ -183,20 +187,41 @@ def main():
     fps = frames_total / elapsed
 
     if rank == 0:
-        # dominant kernel: level-1 forward (k_fwd_yuv422): algorithmic bytes per launch = packed input + its four bands per channel
-        bytes_per_frame = W * H * 2 + 2 * (W * H * 2)      # 4 147 200 in + 8 294 400 out (12 441 600 B per 1080p frame)
-        ms = sum(fwd_ms) / len(fwd_ms)
-        achieved = bytes_per_frame * args.batch / (ms * 1e-3) / 1e9
+        kms = {k: v / args.steps for k, v in kms.items()}
+        sample_bytes = total_bytes / args.batch
+        # algorithmic bytes per frame of every kernel: samples are 8-bit in the packed frame, 16-bit in the pyramid
+        S = W * ((H + 7) // 8 * 8) * 2                   # samples per 4:2:2 frame (luma + both chroma) = packed bytes
+        coded = (S - S // 64) * 2                        # bytes of the 27 entropy-coded bands (everything but the three LL3 bands)
+        algo = {"k_fwd_yuv422": S + 2 * S, "k_fwd_plane[L2]": S, "k_fwd_plane[L3]": S // 4,        # 12 441 600 B per 1080p frame
+                "k_ent_count": coded, "k_ent_emit": coded + sample_bytes, "k_dec_bands_par": sample_bytes + coded,
+                "k_inv_plane[L3]": S // 4, "k_inv_plane[L2]": S, "k_inv_yuv422": 2 * S + S}
+        dom = max(algo, key=lambda k: kms[k])            # the dominant kernel = the longest launch of the step
+        ms = kms[dom]
+        achieved = algo[dom] * args.batch / (ms * 1e-3) / 1e9
+        traffic = None
+        try:                                             # HBM bytes per launch from the committed PMC passes (profiles/, same batch size), else null
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if pmc.get("frames_per_launch") == args.batch and dom in pmc["kernels"]:
+                traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
+        handoff = os.environ.get("CFHD_AMD_HANDOFF", "device")
+        ent = os.environ.get("CFHD_AMD_ENTROPY", "gpu")
         line = {
             "metric": "1080p YUY2 encode+decode fps", "value": round(fps, 1), "unit": "fps", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int16", "data": data,
             "config": {"workload": "1920x1080 YUY2 4:2:2 FILMSCAN1 encode+decode round trip, frames resident in HBM", "frames_per_step_per_gpu": args.batch,
-                       "entropy_stage": os.environ.get("CFHD_AMD_ENTROPY", "gpu") + (" (%d host threads)" % threads if os.environ.get("CFHD_AMD_ENTROPY") == "host" else " (k_ent_* / k_dec_* kernels; samples cross PCIe as bytes)"), "sample_bytes_per_frame": int(total_bytes / args.batch),
-                       "stage_ms_per_step": {"encode_submit": round(1000 * stage[0] / args.steps, 3), "encode_wait+sample_d2h": round(1000 * stage[1] / args.steps, 3),
-                                             "decode_parse+stage": round(1000 * stage[2] / args.steps, 3), "decode_h2d+kernels": round(1000 * stage[3] / args.steps, 3)}},
-            "roofline": {"bound": "hbm", "kernel": "k_fwd_yuv422", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "launch_ms": round(ms, 4)},
+                       "entropy_stage": ("host, %d threads" % threads) if ent == "host" else "gpu (k_ent_* / k_dec_* kernels)",
+                       "sample_handoff": "n/a" if ent == "host" else ("decoder reads the samples in HBM (k_dec_parse); host copy of every sample downloaded inside the step" if handoff != "host" else "samples cross PCIe to the host parser and back"),
+                       "sample_bytes_per_frame": int(sample_bytes),
+                       "stage_ms_per_step": {"submit": round(1000 * stage[0] / args.steps, 3), "encode_wait+sample_d2h": round(1000 * stage[1] / args.steps, 3),
+                                             "decode_parse+stage": round(1000 * stage[2] / args.steps, 3), "decode_wait": round(1000 * stage[3] / args.steps, 3)},
+                       "kernel_ms_per_step": {k: round(v, 4) for k, v in kms.items()}},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "launch_ms": round(ms, 4),
+                         "algorithmic_bytes_per_launch": int(algo[dom] * args.batch),
+                         "other_kernels_gbs": {k: round(algo[k] * args.batch / (kms[k] * 1e-3) / 1e9, 1) for k in algo if kms[k] > 0 and k != dom}},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(frames, pitch)

@@ -23,6 +23,8 @@ public:
 	uint32_t sample_bytes(int i) const { return h_sizes_[i]; }
 	size_t sample_cap() const { return cap_; }
 	int total_segments() const { return total_segs_; }
+	// HIP-event time of kernel k of the last launch() (0 k_ent_count, 1 k_ent_scan, 2 k_ent_layout, 3 k_ent_emit); valid once the stream was synchronised
+	float kernel_ms(int k);
 private:
 	struct Host; Host *host_;           // host mirrors of the job tables (types live in the kernel headers)
 	void release();
@@ -34,6 +36,7 @@ private:
 	void *d_tables_ = nullptr, *d_bands_ = nullptr, *d_segband_ = nullptr, *d_segs_ = nullptr, *d_bandstate_ = nullptr, *d_frames_ = nullptr;
 	uint8_t *d_tmpl_ = nullptr, *h_tmpl_ = nullptr;
 	bool dirty_ = true;
+	void *ev_[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; bool timed_ = false;
 	int16_t *d_coeffs_ = nullptr; size_t coeff_stride_ = 0;
 };
 
@@ -54,6 +57,7 @@ public:
 	int set_samples_device(const uint8_t *d_samples, size_t stride_bytes, const uint32_t *d_sizes);
 	int launch();                        // async: (H2D samples, job tables | k_dec_parse), k_dec_bands_par + k_dec_lowpass
 	int check();                         // after the stream was synchronised: 0 when every band decoded cleanly
+	float kernel_ms(int k);              // last launch(): 0 k_dec_parse (device-resident samples only), 1 k_dec_bands(_par), 2 k_dec_lowpass
 private:
 	struct Host; Host *host_;
 	void release();
@@ -64,6 +68,7 @@ private:
 	const uint8_t *ext_samples_ = nullptr; size_t ext_stride_ = 0; const uint32_t *ext_sizes_ = nullptr;   // set_samples_device()
 	int *d_errors_ = nullptr, *h_errors_ = nullptr;
 	bool lane_kernel_ = false;
+	void *ev_[4] = {nullptr, nullptr, nullptr, nullptr}; bool timed_ = false;
 };
 
 } // namespace cfhd

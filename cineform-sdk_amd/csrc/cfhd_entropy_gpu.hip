@@ -26,6 +26,8 @@ void GpuEntropyEncoder::release()
 	if (h_sizes_) (void)hipHostFree(h_sizes_);
 	if (h_tmpl_) (void)hipHostFree(h_tmpl_);
 	if (host_->frames) { (void)hipHostFree(host_->frames); host_->frames = nullptr; }
+	for (void *&e : ev_) if (e) { (void)hipEventDestroy((hipEvent_t)e); e = nullptr; }
+	timed_ = false;
 	d_samples_ = h_samples_ = nullptr; d_sizes_ = h_sizes_ = nullptr; d_tables_ = d_bands_ = d_segband_ = d_segs_ = d_bandstate_ = d_frames_ = nullptr;
 	d_tmpl_ = h_tmpl_ = nullptr; n_ = 0;
 }
@@ -66,6 +68,7 @@ int GpuEntropyEncoder::prepare(const FramePlan &plan, int nframes, int16_t *d_co
 	HIPCHK(hipMalloc(&d_frames_, n_ * sizeof(dev::EntFrameJob)));
 	HIPCHK(hipHostMalloc((void **)&host_->frames, n_ * sizeof(dev::EntFrameJob), hipHostMallocDefault));
 	for (int f = 0; f < n_; f++) { SampleHeaderInfo h = hdr0; h.frame_number = (uint32_t)f + 1; if ((rc = set_frame_header(f, h))) return rc; }
+	for (void *&e : ev_) HIPCHK(hipEventCreate((hipEvent_t *)&e));
 	return 0;
 }
 
@@ -90,14 +93,27 @@ int GpuEntropyEncoder::launch()
 	}
 	const dev::EntTables *T = (const dev::EntTables *)d_tables_;
 	(void)hipGetLastError();
+	HIPCHK(hipEventRecord((hipEvent_t)ev_[0], st));
 	dev::k_ent_count<<<total_segs_, dev::ENT_THREADS, 0, st>>>((const dev::EntBandJob *)d_bands_, (const int *)d_segband_, (dev::EntSegState *)d_segs_, T);
+	HIPCHK(hipEventRecord((hipEvent_t)ev_[1], st));
 	dev::k_ent_scan<<<nbands_ * n_, dev::ENT_THREADS, 0, st>>>((const dev::EntBandJob *)d_bands_, (dev::EntSegState *)d_segs_, (dev::EntBandState *)d_bandstate_, T);
+	HIPCHK(hipEventRecord((hipEvent_t)ev_[2], st));
 	dev::k_ent_layout<<<n_, dev::ENT_THREADS, 0, st>>>((const dev::EntFrameJob *)d_frames_, (const dev::EntBandJob *)d_bands_, (const dev::EntSegState *)d_segs_,
 	                                                  (dev::EntBandState *)d_bandstate_, T);
+	HIPCHK(hipEventRecord((hipEvent_t)ev_[3], st));
 	dev::k_ent_emit<<<total_segs_, dev::ENT_THREADS, 0, st>>>((const dev::EntBandJob *)d_bands_, (const int *)d_segband_, (const dev::EntSegState *)d_segs_,
 	                                                          (const dev::EntBandState *)d_bandstate_, (const dev::EntFrameJob *)d_frames_, T);
 	HIPCHK(hipGetLastError());
+	HIPCHK(hipEventRecord((hipEvent_t)ev_[4], st));
+	timed_ = true;
 	return 0;
+}
+
+float GpuEntropyEncoder::kernel_ms(int k)
+{
+	float ms = 0;
+	if (!timed_ || k < 0 || k > 3 || hipEventElapsedTime(&ms, (hipEvent_t)ev_[k], (hipEvent_t)ev_[k + 1]) != hipSuccess) { (void)hipGetLastError(); return 0; }
+	return ms;
 }
 
 int GpuEntropyEncoder::fetch_sizes()
@@ -138,6 +154,8 @@ void GpuEntropyDecoder::release()
 	if (h_errors_) (void)hipHostFree(h_errors_);
 	if (host_->flat_bands) { (void)hipHostFree(host_->flat_bands); host_->flat_bands = nullptr; }
 	if (host_->flat_lows) { (void)hipHostFree(host_->flat_lows); host_->flat_lows = nullptr; }
+	for (void *&e : ev_) if (e) { (void)hipEventDestroy((hipEvent_t)e); e = nullptr; }
+	timed_ = false;
 	d_samples_ = h_samples_ = nullptr; d_tables_ = d_bandjobs_ = d_lowjobs_ = d_plan_ = nullptr; d_errors_ = h_errors_ = nullptr; n_ = 0; ext_samples_ = nullptr;
 }
 
@@ -168,6 +186,7 @@ int GpuEntropyDecoder::prepare(const FramePlan &plan, int nframes, int16_t *d_co
 		HIPCHK(hipMemcpy(d_plan_, &dp, sizeof(dp), hipMemcpyHostToDevice));
 	}
 	host_->bands.assign(n_, {}); host_->lows.assign(n_, {}); host_->host_bytes.assign(n_, 0);
+	for (void *&e : ev_) HIPCHK(hipEventCreate((hipEvent_t *)&e));
 	return 0;
 }
 
@@ -207,11 +226,16 @@ int GpuEntropyDecoder::launch()
 		const int nch = plan_.num_channels, nb = n_ * nch * 9;
 		HIPCHK(hipMemsetAsync(d_errors_, 0, sizeof(int), st));
 		(void)hipGetLastError();
+		HIPCHK(hipEventRecord((hipEvent_t)ev_[0], st));
 		dev::k_dec_parse<<<(n_ + dev::DEC_PARSE_THREADS - 1) / dev::DEC_PARSE_THREADS, dev::DEC_PARSE_THREADS, 0, st>>>(ext_samples_, ext_stride_, ext_sizes_, n_,
 			(const dev::DecPlan *)d_plan_, d_coeffs_, coeff_stride_, (dev::DecBandJob *)d_bandjobs_, (dev::DecLowpassJob *)d_lowjobs_, d_errors_);
+		HIPCHK(hipEventRecord((hipEvent_t)ev_[1], st));
 		dev::k_dec_bands_par<<<nb, dev::DECP_THREADS, 0, st>>>((const dev::DecBandJob *)d_bandjobs_, (const dev::DecTables *)d_tables_, d_errors_);
+		HIPCHK(hipEventRecord((hipEvent_t)ev_[2], st));
 		dev::k_dec_lowpass<<<dim3(8, (unsigned)(n_ * nch)), 256, 0, st>>>((const dev::DecLowpassJob *)d_lowjobs_);
 		HIPCHK(hipGetLastError());
+		HIPCHK(hipEventRecord((hipEvent_t)ev_[3], st));
+		timed_ = true;
 		HIPCHK(hipMemcpyAsync(h_errors_, d_errors_, sizeof(int), hipMemcpyDeviceToHost, st));
 		return 0;
 	}
@@ -233,14 +257,26 @@ int GpuEntropyDecoder::launch()
 	HIPCHK(hipMemcpyAsync(d_lowjobs_, fl, nfl * sizeof(dev::DecLowpassJob), hipMemcpyHostToDevice, st));
 	(void)hipGetLastError();
 	const int nb = (int)nfb;
+	HIPCHK(hipEventRecord((hipEvent_t)ev_[0], st));
+	HIPCHK(hipEventRecord((hipEvent_t)ev_[1], st));
 	if (lane_kernel) dev::k_dec_bands<<<(nb + dev::DEC_THREADS - 1) / dev::DEC_THREADS, dev::DEC_THREADS, 0, st>>>((const dev::DecBandJob *)d_bandjobs_, nb, (const dev::DecTables *)d_tables_, d_errors_);
 	else dev::k_dec_bands_par<<<nb, dev::DECP_THREADS, 0, st>>>((const dev::DecBandJob *)d_bandjobs_, (const dev::DecTables *)d_tables_, d_errors_);
+	HIPCHK(hipEventRecord((hipEvent_t)ev_[2], st));
 	dev::k_dec_lowpass<<<dim3(8, (unsigned)nfl), 256, 0, st>>>((const dev::DecLowpassJob *)d_lowjobs_);
 	HIPCHK(hipGetLastError());
+	HIPCHK(hipEventRecord((hipEvent_t)ev_[3], st));
+	timed_ = true;
 	HIPCHK(hipMemcpyAsync(h_errors_, d_errors_, sizeof(int), hipMemcpyDeviceToHost, st));
 	return 0;
 }
 
 int GpuEntropyDecoder::check() { return *h_errors_ ? -1 : 0; }
+
+float GpuEntropyDecoder::kernel_ms(int k)
+{
+	float ms = 0;
+	if (!timed_ || k < 0 || k > 2 || hipEventElapsedTime(&ms, (hipEvent_t)ev_[k], (hipEvent_t)ev_[k + 1]) != hipSuccess) { (void)hipGetLastError(); return 0; }
+	return ms;
+}
 
 } // namespace cfhd

@@ -400,31 +400,73 @@ __device__ __forceinline__ void inv_horiz(int lm1, int l0, int lp1, int lfar, in
 	}
 }
 
-enum { ITW = 64, ITH = 8, ICOLS = ITW + 4 };    // inverse tile: 64 x 8 band coefficients -> 128 x 16 outputs
+// Inverse tile: 64 x 16 band coefficients -> 128 x 32 outputs.  The four bands of the tile are staged in LDS as dwords (two
+// adjacent columns each, columns c0-2 .. c0+ITW+1 = IDW dwords per row; the vertical-lowpass bands with one row above and one
+// below, ILROWS rows), the vertical pass runs on column pairs with packed saturating math and leaves its results in LDS, the
+// horizontal pass combines three neighbouring dwords per output pair.
+enum { ITW = 64, ITH = 16, IDW = ITW / 2 + 2, ILROWS = ITH + 2 };
 
-// The four taps of one vertical synthesis: l[0..2] = lowpass rows (r-1, r, r+1), or for the border rows (r, r+1, r+2) resp.
-// (r-2, r-1, r); l[3] = the highpass value.  Zero outside [0,w) (never used by a valid tap).
-struct VTaps { int l0, l1, l2, hi; };
-__device__ __forceinline__ VTaps inv_vert_load(const int16_t *vlow, const int16_t *vhigh, int pitch, int w, int h, int r, int c)
+__device__ __forceinline__ int inv_tile_first_row(int r0, int h) { int s = r0 - 1; if (s > h - 3) s = h - 3; return s < 0 ? 0 : s; }
+__device__ __forceinline__ int inv_window_first_row(int r, int h) { return r == 0 ? 0 : (r == h - 1 ? h - 3 : r - 1); }
+
+// Vertical synthesis of two adjacent columns: a, b, c = three consecutive rows of the vertical-lowpass band starting at
+// inv_window_first_row(r), hi = the vertical-highpass row r.  Interior rows in the reference's SIMD order (spatial.c:22080-22150),
+// the first and the last row of the band in 32-bit arithmetic (:21975-22030, :22330-22400).
+__device__ __forceinline__ void inv_vert_pk(uint32_t a, uint32_t b, uint32_t c, uint32_t hi, int pos, uint32_t &even, uint32_t &odd)
 {
-	// branch-free: clamp the coordinates so that every lane issues its four loads back to back, then mask
-	const bool valid = c >= 0 && c < w && r < h;
-	const int cc = c < 0 ? 0 : (c >= w ? w - 1 : c), rr = r >= h ? h - 1 : r;
-	const int first = rr == 0 ? 0 : (rr == h - 1 ? h - 3 : rr - 1);
-	const int16_t *p = vlow + (size_t)first * pitch + cc;
-	VTaps t;
-	t.l0 = p[0]; t.l1 = p[pitch]; t.l2 = p[2 * (size_t)pitch];
-	t.hi = vhigh[(size_t)rr * pitch + cc];
-	const int mask = valid ? -1 : 0;                 // arithmetic select: no branch between the loads of consecutive items
-	t.l0 &= mask; t.l1 &= mask; t.l2 &= mask; t.hi &= mask;
-	return t;
+	if (pos == 1) {
+		uint32_t e = pk_subs(a, c); e = pk_adds(e, pk_set(4)); e = pk_sra(e, 3); e = pk_adds(e, b); e = pk_adds(e, hi); even = pk_sra(e, 1);
+		uint32_t o = pk_subs(0u, a); o = pk_adds(o, c); o = pk_adds(o, pk_set(4)); o = pk_sra(o, 3); o = pk_adds(o, b); o = pk_subs(o, hi); odd = pk_sra(o, 1);
+	} else {
+		int e0, o0, e1, o1;
+		if (pos == 0) { inv_vert(0, lo16(a), lo16(b), lo16(c), lo16(hi), 0, e0, o0); inv_vert(0, hi16(a), hi16(b), hi16(c), hi16(hi), 0, e1, o1); }
+		else { inv_vert(lo16(b), lo16(c), 0, lo16(a), lo16(hi), 2, e0, o0); inv_vert(hi16(b), hi16(c), 0, hi16(a), hi16(hi), 2, e1, o1); }
+		even = pack16(e0, e1); odd = pack16(o0, o1);
+	}
 }
-__device__ __forceinline__ void inv_vert_apply(const VTaps &t, int r, int h, int &even, int &odd)
+
+// Horizontal synthesis of two lanes at once, interior columns, before the final >>1 / doubling (InvertHorizontalStrip16s.c:371-402).
+__device__ __forceinline__ void inv_horiz_pk(uint32_t lm1, uint32_t l0, uint32_t lp1, uint32_t hi, uint32_t &even, uint32_t &odd)
 {
-	const int pos = r == 0 ? 0 : (r == h - 1 ? 2 : 1);
-	if (pos == 0) inv_vert(0, t.l0, t.l1, t.l2, t.hi, 0, even, odd);                 // rows 0,1,2
-	else if (pos == 2) inv_vert(t.l1, t.l2, 0, t.l0, t.hi, 2, even, odd);           // rows h-3 (far), h-2, h-1
-	else inv_vert(t.l0, t.l1, t.l2, 0, t.hi, 1, even, odd);
+	uint32_t e = pk_subs(lm1, lp1); e = pk_adds(e, pk_set(4)); e = pk_sra(e, 3); e = pk_adds(e, l0); even = pk_adds(e, hi);
+	uint32_t o = pk_subs(lp1, lm1); o = pk_adds(o, pk_set(4)); o = pk_sra(o, 3); o = pk_adds(o, l0); odd = pk_subs(o, hi);
+}
+
+// First / last column of a row (32-bit arithmetic, InvertHorizontalStrip16s.c:172-198, :409-438): l[] = six consecutive columns,
+// l[idx] = the border column itself.
+__device__ __forceinline__ void inv_horiz_border(const int *l, int idx, int hi, int pos, int &even, int &odd)
+{
+	if (pos == 0) inv_horiz(0, l[idx], l[idx + 1], l[idx + 2], hi, 0, even, odd);
+	else inv_horiz(l[idx - 1], l[idx], 0, l[idx - 2], hi, 2, even, odd);
+}
+
+// Loads of one staged region (two bands b0, b1 of the same geometry), all issued before the first LDS store: item i ->
+// (band q, row j, dword d).  The band pointers are passed in registers and the loads go through the global address space
+// (global_load_dword): a flat load would tick lgkmcnt as well and every LDS access in between would drain the loads in flight.
+#if defined(CFHD_HIPEMU)
+#define CFHD_LDG32(p) (*(const uint32_t *)(p))
+#else
+#define CFHD_LDG32(p) (*(const __attribute__((address_space(1))) uint32_t *)(p))
+#endif
+template <int NROWS, int NDW, int N>
+__device__ __forceinline__ void inv_stage_load(uint32_t (&va)[N], const int16_t *b0, const int16_t *b1, int pitch, int row0, int h, int dw0, int wdw)
+{
+	// branch-free: every lane loads from clamped (always valid) coordinates, what lies outside the band is zeroed afterwards
+#pragma unroll
+	for (int k = 0; k < N; k++) {
+		const int i = (int)threadIdx.x + k * NTHREADS;
+		const int q = i / (NROWS * NDW), rem = i - q * (NROWS * NDW), j = rem / NDW, d = rem - j * NDW;
+		int row = row0 + j, dw = dw0 + d;
+		row = row < h ? row : h - 1; dw = dw < 0 ? 0 : (dw < wdw ? dw : wdw - 1);
+		va[k] = CFHD_LDG32((q == 1 ? b1 : b0) + (size_t)row * pitch + 2 * dw);
+	}
+#pragma unroll
+	for (int k = 0; k < N; k++) {
+		const int i = (int)threadIdx.x + k * NTHREADS;
+		const int q = i / (NROWS * NDW), rem = i - q * (NROWS * NDW), j = rem / NDW, d = rem - j * NDW;
+		const int row = row0 + j, dw = dw0 + d;
+		if (!(row < h && dw >= 0 && dw < wdw)) va[k] = 0;
+	}
 }
 
 __global__ void __launch_bounds__(NTHREADS) k_inv_plane(const InvPlaneJob *jobs)
@@ -434,48 +476,63 @@ __global__ void __launch_bounds__(NTHREADS) k_inv_plane(const InvPlaneJob *jobs)
 	const InvPlaneJob &job = s_job;
 	const int w = job.width, h = job.height;
 	const int c0 = blockIdx.x * ITW, r0 = blockIdx.y * ITH;
-	// vertical results for columns c0-2 .. c0+ITW+1 : [row parity][L/H][r][col]
-	__shared__ int16_t s_v[2][2][ITH][ICOLS];
+	__shared__ uint32_t s_low[2][ILROWS][IDW];          // LL, LH
+	__shared__ uint32_t s_high[2][ITH][IDW];            // HL, HH
+	__shared__ uint32_t s_v[2][2][ITH][IDW];            // [row parity][horizontal L/H]
 	const bool active = (c0 < w) && (r0 < h);
 	const int tid = threadIdx.x;
+	const int rs = inv_tile_first_row(r0, h);
 	if (active) {
-		enum { NIT = (ITH * ICOLS + NTHREADS - 1) / NTHREADS };
-		VTaps tl[NIT], th[NIT];
+		enum { NL = (2 * ILROWS * IDW + NTHREADS - 1) / NTHREADS, NH = (2 * ITH * IDW + NTHREADS - 1) / NTHREADS };
+		uint32_t vl[NL], vh[NH];
+		const int dw0 = (c0 >> 1) - 1, wdw = (w + 1) >> 1;
+		inv_stage_load<ILROWS, IDW>(vl, job.band[0], job.band[1], job.band_pitch, rs, h, dw0, wdw);
+		inv_stage_load<ITH, IDW>(vh, job.band[2], job.band[3], job.band_pitch, r0, h, dw0, wdw);
 #pragma unroll
-		for (int k = 0; k < NIT; k++) {                  // every load of the tile first ...
-			const int i = tid + k * NTHREADS, rl = i / ICOLS, cl = i - rl * ICOLS;
-			const int r = i < ITH * ICOLS ? r0 + rl : h, c = c0 - 2 + cl;
-			tl[k] = inv_vert_load(job.band[0], job.band[2], job.band_pitch, w, h, r, c);   // (LL, HL) -> horizontal-lowpass rows
-			th[k] = inv_vert_load(job.band[1], job.band[3], job.band_pitch, w, h, r, c);   // (LH, HH) -> horizontal-highpass rows
-		}
+		for (int k = 0; k < NL; k++) { const int i = tid + k * NTHREADS; if (i < 2 * ILROWS * IDW) (&s_low[0][0][0])[i] = vl[k]; }
 #pragma unroll
-		for (int k = 0; k < NIT; k++) {                  // ... then the arithmetic and the LDS stores
-			const int i = tid + k * NTHREADS, rl = i / ICOLS, cl = i - rl * ICOLS;
+		for (int k = 0; k < NH; k++) { const int i = tid + k * NTHREADS; if (i < 2 * ITH * IDW) (&s_high[0][0][0])[i] = vh[k]; }
+	}
+	__syncthreads();
+	if (active) {
+		for (int i = tid; i < 2 * ITH * IDW; i += NTHREADS) {
+			const int q = i / (ITH * IDW), rem = i - q * (ITH * IDW), rl = rem / IDW, d = rem - rl * IDW;
 			const int r = r0 + rl;
-			if (i >= ITH * ICOLS || r >= h) continue;
-			int e, o;
-			inv_vert_apply(tl[k], r, h, e, o);
-			s_v[0][0][rl][cl] = (int16_t)e; s_v[1][0][rl][cl] = (int16_t)o;
-			inv_vert_apply(th[k], r, h, e, o);
-			s_v[0][1][rl][cl] = (int16_t)e; s_v[1][1][rl][cl] = (int16_t)o;
+			if (r >= h) continue;
+			const int j = inv_window_first_row(r, h) - rs, pos = r == 0 ? 0 : (r == h - 1 ? 2 : 1);
+			uint32_t e, o;
+			inv_vert_pk(s_low[q][j][d], s_low[q][j + 1][d], s_low[q][j + 2][d], s_high[q][rl][d], pos, e, o);
+			s_v[0][q][rl][d] = e; s_v[1][q][rl][d] = o;
 		}
 	}
 	__syncthreads();
 	if (active) {
-		for (int i = tid; i < 2 * ITH * ITW; i += NTHREADS) {
-			int par = i / (ITH * ITW), rem = i - par * (ITH * ITW);
-			int rl = rem / ITW, cl = rem - rl * ITW;
-			int r = r0 + rl, c = c0 + cl;
+		for (int i = tid; i < 2 * ITH * (ITW / 2); i += NTHREADS) {
+			const int par = i / (ITH * (ITW / 2)), rem = i - par * (ITH * (ITW / 2)), rl = rem / (ITW / 2), p = rem - rl * (ITW / 2);
+			const int r = r0 + rl, c = c0 + 2 * p;
 			if (r >= h || c >= w) continue;
-			const int16_t *L = &s_v[par][0][rl][cl + 2], *Hh = &s_v[par][1][rl][cl + 2];
-			const int pos = c == 0 ? 0 : (c == w - 1 ? 2 : 1);
-			int even, odd;
-			if (pos == 0) inv_horiz(0, L[0], L[1], L[2], Hh[0], 0, even, odd);
-			else if (pos == 2) inv_horiz(L[-1], L[0], 0, L[-2], Hh[0], 2, even, odd);
-			else inv_horiz(L[-1], L[0], L[1], 0, Hh[0], 1, even, odd);
-			if (job.descale) { even = sat16(even * 2); odd = sat16(odd * 2); }
-			else { even = sat16(even >> 1); odd = sat16(odd >> 1); }
-			*(uint32_t *)(job.out + (size_t)(2 * r + par) * job.out_pitch + 2 * c) = pack16(even, odd);
+			const uint32_t *L = &s_v[par][0][rl][p + 1];
+			const uint32_t dm = L[-1], d0 = L[0], dp = L[1], hh = s_v[par][1][rl][p + 1];
+			uint32_t even, odd;
+			inv_horiz_pk((dm >> 16) | (d0 << 16), d0, (d0 >> 16) | (dp << 16), hh, even, odd);
+			if (job.descale) { even = pk_adds(even, even); odd = pk_adds(odd, odd); }
+			else { even = pk_sra(even, 1); odd = pk_sra(odd, 1); }
+			uint32_t o0 = pk_lolo(even, odd), o1 = pk_hihi(even, odd);      // (even, odd) of column c and of column c + 1
+			if (c == 0 || c >= w - 2) {
+				const int l[6] = { lo16(dm), hi16(dm), lo16(d0), hi16(d0), lo16(dp), hi16(dp) };
+#pragma unroll
+				for (int k = 0; k < 2; k++) {
+					const int col = c + k;
+					if (col != 0 && col != w - 1) continue;
+					int e, o;
+					inv_horiz_border(l, 2 + k, k ? hi16(hh) : lo16(hh), col == 0 ? 0 : 2, e, o);
+					if (job.descale) { e = sat16(e * 2); o = sat16(o * 2); } else { e = sat16(e >> 1); o = sat16(o >> 1); }
+					if (k) o1 = pack16(e, o); else o0 = pack16(e, o);
+				}
+			}
+			int16_t *dst = job.out + (size_t)(2 * r + par) * job.out_pitch + 2 * c;
+			if (c + 1 < w) { uint2 v2; v2.x = o0; v2.y = o1; *(uint2 *)dst = v2; }
+			else *(uint32_t *)dst = o0;
 		}
 	}
 }
@@ -489,13 +546,28 @@ __device__ __forceinline__ uint32_t to8(int v, int shift, int dither)
 	int x = ((v >> 1) + dither) >> shift;
 	return (uint32_t)(x > 255 ? 255 : x);
 }
-
-// Counter-based stand-in for the reference's libc rand() dither: one bit per (frame seed, output row, lane of 16).
-__device__ __forceinline__ int dither_bit(uint32_t seed, int row, int lane)
+// the same on two 16-bit lanes (v_pk_max_i16 / v_pk_ashrrev_i16 / v_pk_min_i16)
+#if defined(CFHD_HIPEMU)
+__device__ __forceinline__ uint32_t pk_to8(uint32_t v, int shift, uint32_t dither) { return to8(lo16(v), shift, (int)(dither & 1u)) | (to8(hi16(v), shift, (int)((dither >> 16) & 1u)) << 16); }
+#else
+__device__ __forceinline__ uint32_t pk_to8(uint32_t v, int shift, uint32_t dither)
 {
-	uint32_t x = seed ^ ((uint32_t)row * 0x9E3779B1u) ^ ((uint32_t)lane * 0x85EBCA77u);
+	cfhd_s2 x = __builtin_bit_cast(cfhd_s2, v);
+	const cfhd_s2 zero = { 0, 0 }, top = { 255, 255 };
+	x = __builtin_elementwise_max(x, zero);
+	x = (x >> (short)1) + __builtin_bit_cast(cfhd_s2, dither);
+	x = x >> (short)shift;
+	x = __builtin_elementwise_min(x, top);
+	return __builtin_bit_cast(uint32_t, x);
+}
+#endif
+
+// Counter-based stand-in for the reference's libc rand() dither: one word of random bits per (frame seed, output row, pixel group).
+__device__ __forceinline__ uint32_t dither_word(uint32_t seed, int row, int group)
+{
+	uint32_t x = seed ^ ((uint32_t)row * 0x9E3779B1u) ^ ((uint32_t)group * 0x85EBCA77u);
 	x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12; x *= 0x297A2D39u; x ^= x >> 15;
-	return (int)(x & 1u);
+	return x;
 }
 
 __global__ void __launch_bounds__(NTHREADS) k_inv_yuv422(const InvYuvJob *jobs, uint32_t launch_seed)
@@ -506,92 +578,114 @@ __global__ void __launch_bounds__(NTHREADS) k_inv_yuv422(const InvYuvJob *jobs, 
 	const uint32_t seed = job.dither_seed ^ launch_seed;
 	const int w = job.width, h = job.height;          // luma band ; chroma bands are w/2 wide
 	const int c0 = blockIdx.x * ITW, r0 = blockIdx.y * ITH;
-	__shared__ int16_t s_y[2][2][ITH][ICOLS];
-	__shared__ int16_t s_c[2][2][2][ITH][ITW / 2 + 4]; // [V,U][parity][L/H][r][col]
+	const int cw = w >> 1, cc0 = c0 >> 1;
+	enum { CDW = ITW / 2 + 4, CLD = CDW / 2 };          // chroma columns cc0-2 .. cc0+33, one (V, U) dword each; CLD dwords per band row to load
+	__shared__ uint32_t s_ylow[2][ILROWS][IDW], s_yhigh[2][ITH][IDW], s_vy[2][2][ITH][IDW];
+	__shared__ uint32_t s_clow[2][ILROWS][CDW], s_chigh[2][ITH][CDW], s_vc[2][2][ITH][CDW];
 	const bool active = (c0 < w) && (r0 < h);
 	const int tid = threadIdx.x;
-	const int cw = w >> 1, cc0 = c0 >> 1;
+	const int rs = inv_tile_first_row(r0, h);
 	if (active) {
-		enum { NY = (ITH * ICOLS + NTHREADS - 1) / NTHREADS, CCOLS = ITW / 2 + 4, NC = (2 * ITH * CCOLS + NTHREADS - 1) / NTHREADS };
-		VTaps yl[NY], yh[NY], cl_[NC], ch_[NC];
+		enum { NL = (2 * ILROWS * IDW + NTHREADS - 1) / NTHREADS, NH = (2 * ITH * IDW + NTHREADS - 1) / NTHREADS,
+		       NCL = (2 * ILROWS * CLD + NTHREADS - 1) / NTHREADS, NCH = (2 * ITH * CLD + NTHREADS - 1) / NTHREADS };
+		uint32_t yl[NL], yh[NH], cl[2][NCL], ch[2][NCH];
+		const int dw0 = (c0 >> 1) - 1, wdw = (w + 1) >> 1, cdw0 = (cc0 >> 1) - 1, cwdw = (cw + 1) >> 1;
+		inv_stage_load<ILROWS, IDW>(yl, job.band[0][0], job.band[0][1], job.band_pitch[0], rs, h, dw0, wdw);
+		inv_stage_load<ITH, IDW>(yh, job.band[0][2], job.band[0][3], job.band_pitch[0], r0, h, dw0, wdw);
 #pragma unroll
-		for (int k = 0; k < NY; k++) {
-			const int i = tid + k * NTHREADS, rl = i / ICOLS, cl = i - rl * ICOLS;
-			const int r = i < ITH * ICOLS ? r0 + rl : h, c = c0 - 2 + cl;
-			yl[k] = inv_vert_load(job.band[0][0], job.band[0][2], job.band_pitch[0], w, h, r, c);
-			yh[k] = inv_vert_load(job.band[0][1], job.band[0][3], job.band_pitch[0], w, h, r, c);
+		for (int x = 0; x < 2; x++) {                    // V, U
+			inv_stage_load<ILROWS, CLD>(cl[x], job.band[1 + x][0], job.band[1 + x][1], job.band_pitch[1 + x], rs, h, cdw0, cwdw);
+			inv_stage_load<ITH, CLD>(ch[x], job.band[1 + x][2], job.band[1 + x][3], job.band_pitch[1 + x], r0, h, cdw0, cwdw);
 		}
 #pragma unroll
-		for (int k = 0; k < NC; k++) {
-			const int i = tid + k * NTHREADS, q = i / (ITH * CCOLS), rem = i - q * (ITH * CCOLS), rl = rem / CCOLS, cl = rem - rl * CCOLS;
-			const int r = i < 2 * ITH * CCOLS ? r0 + rl : h, c = cc0 - 2 + cl, chn = (q & 1) + 1;
-			cl_[k] = inv_vert_load(job.band[chn][0], job.band[chn][2], job.band_pitch[chn], cw, h, r, c);
-			ch_[k] = inv_vert_load(job.band[chn][1], job.band[chn][3], job.band_pitch[chn], cw, h, r, c);
+		for (int k = 0; k < NL; k++) { const int i = tid + k * NTHREADS; if (i < 2 * ILROWS * IDW) (&s_ylow[0][0][0])[i] = yl[k]; }
+#pragma unroll
+		for (int k = 0; k < NH; k++) { const int i = tid + k * NTHREADS; if (i < 2 * ITH * IDW) (&s_yhigh[0][0][0])[i] = yh[k]; }
+		// chroma: the two columns of a loaded dword become the V (low) and U (high) halves of two (V, U) dwords
+#pragma unroll
+		for (int k = 0; k < NCL; k++) {
+			const int i = tid + k * NTHREADS;
+			if (i < 2 * ILROWS * CLD) {
+				uint32_t *dst = &s_clow[0][0][0] + 2 * i;     // item (q, j, m) -> columns 2m, 2m+1 of row (q, j): the row-major index doubles
+				dst[0] = pk_lolo(cl[0][k], cl[1][k]); dst[1] = pk_hihi(cl[0][k], cl[1][k]);
+			}
 		}
 #pragma unroll
-		for (int k = 0; k < NY; k++) {
-			const int i = tid + k * NTHREADS, rl = i / ICOLS, cl = i - rl * ICOLS, r = r0 + rl;
-			if (i >= ITH * ICOLS || r >= h) continue;
-			int e, o;
-			inv_vert_apply(yl[k], r, h, e, o);
-			s_y[0][0][rl][cl] = (int16_t)e; s_y[1][0][rl][cl] = (int16_t)o;
-			inv_vert_apply(yh[k], r, h, e, o);
-			s_y[0][1][rl][cl] = (int16_t)e; s_y[1][1][rl][cl] = (int16_t)o;
-		}
-#pragma unroll
-		for (int k = 0; k < NC; k++) {
-			const int i = tid + k * NTHREADS, q = i / (ITH * CCOLS), rem = i - q * (ITH * CCOLS), rl = rem / CCOLS, cl = rem - rl * CCOLS, r = r0 + rl;
-			if (i >= 2 * ITH * CCOLS || r >= h) continue;
-			int e, o;
-			inv_vert_apply(cl_[k], r, h, e, o);
-			s_c[q][0][0][rl][cl] = (int16_t)e; s_c[q][1][0][rl][cl] = (int16_t)o;
-			inv_vert_apply(ch_[k], r, h, e, o);
-			s_c[q][0][1][rl][cl] = (int16_t)e; s_c[q][1][1][rl][cl] = (int16_t)o;
+		for (int k = 0; k < NCH; k++) {
+			const int i = tid + k * NTHREADS;
+			if (i < 2 * ITH * CLD) {
+				uint32_t *dst = &s_chigh[0][0][0] + 2 * i;
+				dst[0] = pk_lolo(ch[0][k], ch[1][k]); dst[1] = pk_hihi(ch[0][k], ch[1][k]);
+			}
 		}
 	}
 	__syncthreads();
 	if (active) {
-		// one item = one chroma band column = 2 chroma samples, 2 luma band columns = 4 luma samples = 8 output bytes
-		for (int i = tid; i < 2 * ITH * (ITW / 2); i += NTHREADS) {
-			int par = i / (ITH * (ITW / 2)), rem = i - par * (ITH * (ITW / 2));
-			int rl = rem / (ITW / 2), cl = rem - rl * (ITW / 2);
-			int r = r0 + rl, cc = cc0 + cl;
-			int orow = 2 * r + par;
-			if (r >= h || cc >= cw || orow >= job.display_height) continue;
-			int yv[4], uv[2], vv[2];
-#pragma unroll
-			for (int k = 0; k < 2; k++) {
-				int c = 2 * cc + k;
-				const int16_t *L = &s_y[par][0][rl][2 * cl + k + 2], *Hh = &s_y[par][1][rl][2 * cl + k + 2];
-				const int pos = c == 0 ? 0 : (c == w - 1 ? 2 : 1);
-				if (pos == 0) inv_horiz(0, L[0], L[1], L[2], Hh[0], 0, yv[2 * k], yv[2 * k + 1]);
-				else if (pos == 2) inv_horiz(L[-1], L[0], 0, L[-2], Hh[0], 2, yv[2 * k], yv[2 * k + 1]);
-				else inv_horiz(L[-1], L[0], L[1], 0, Hh[0], 1, yv[2 * k], yv[2 * k + 1]);
+		for (int i = tid; i < 2 * ITH * (IDW + CDW); i += NTHREADS) {
+			const int q = i / (ITH * (IDW + CDW)), rem = i - q * (ITH * (IDW + CDW)), rl = rem / (IDW + CDW), d = rem - rl * (IDW + CDW);
+			const int r = r0 + rl;
+			if (r >= h) continue;
+			const int j = inv_window_first_row(r, h) - rs, pos = r == 0 ? 0 : (r == h - 1 ? 2 : 1);
+			uint32_t e, o;
+			if (d < IDW) {
+				inv_vert_pk(s_ylow[q][j][d], s_ylow[q][j + 1][d], s_ylow[q][j + 2][d], s_yhigh[q][rl][d], pos, e, o);
+				s_vy[0][q][rl][d] = e; s_vy[1][q][rl][d] = o;
+			} else {
+				const int dc = d - IDW;
+				inv_vert_pk(s_clow[q][j][dc], s_clow[q][j + 1][dc], s_clow[q][j + 2][dc], s_chigh[q][rl][dc], pos, e, o);
+				s_vc[0][q][rl][dc] = e; s_vc[1][q][rl][dc] = o;
 			}
-			{
-				const int pos = cc == 0 ? 0 : (cc == cw - 1 ? 2 : 1);
-#pragma unroll
-				for (int k = 0; k < 2; k++) {
-					const int16_t *L = &s_c[k][par][0][rl][cl + 2], *Hh = &s_c[k][par][1][rl][cl + 2];
-					int *dst = k == 0 ? vv : uv;
-					if (pos == 0) inv_horiz(0, L[0], L[1], L[2], Hh[0], 0, dst[0], dst[1]);
-					else if (pos == 2) inv_horiz(L[-1], L[0], 0, L[-2], Hh[0], 2, dst[0], dst[1]);
-					else inv_horiz(L[-1], L[0], L[1], 0, Hh[0], 1, dst[0], dst[1]);
+		}
+	}
+	__syncthreads();
+	if (active) {
+		const int sh = job.shift;
+		// one item = one chroma column (V and U side by side) + its two luma columns = 4 luma + 2 x 2 chroma samples = 8 output bytes
+		for (int i = tid; i < 2 * ITH * (ITW / 2); i += NTHREADS) {
+			const int par = i / (ITH * (ITW / 2)), rem = i - par * (ITH * (ITW / 2)), rl = rem / (ITW / 2), p = rem - rl * (ITW / 2);
+			const int r = r0 + rl, cc = cc0 + p, orow = 2 * r + par;
+			if (r >= h || cc >= cw || orow >= job.display_height) continue;
+			const uint32_t *L = &s_vy[par][0][rl][p + 1];
+			const uint32_t dm = L[-1], d0 = L[0], dp = L[1], yhh = s_vy[par][1][rl][p + 1];
+			uint32_t ye, yo;                              // (column 2cc, column 2cc+1): even outputs, odd outputs
+			inv_horiz_pk((dm >> 16) | (d0 << 16), d0, (d0 >> 16) | (dp << 16), yhh, ye, yo);
+			const uint32_t *C = &s_vc[par][0][rl][p + 2];
+			const uint32_t cm = C[-1], cz = C[0], cp = C[1], chh = s_vc[par][1][rl][p + 2];
+			uint32_t ce, co;                              // (V, U): even output, odd output
+			inv_horiz_pk(cm, cz, cp, chh, ce, co);
+			const uint32_t dz = sh >= 2 ? dither_word(seed, orow, cc) : 0u;
+			// 8-bit samples in 16-bit lanes: te = (y0, y2), to = (y1, y3), tce = (v0, u0), tco = (v1, u1)
+			uint32_t te = pk_to8(ye, sh, (dz & 1u) | ((dz << 14) & 0x10000u)), to = pk_to8(yo, sh, ((dz >> 1) & 1u) | ((dz << 13) & 0x10000u));
+			uint32_t tce = pk_to8(ce, sh, ((dz >> 4) & 1u) | ((dz << 11) & 0x10000u)), tco = pk_to8(co, sh, ((dz >> 6) & 1u) | ((dz << 9) & 0x10000u));
+			const int c = 2 * cc;
+			if (c == 0 || c + 1 == w - 1) {               // first / last luma column: 32-bit arithmetic
+				const int l[6] = { lo16(dm), hi16(dm), lo16(d0), hi16(d0), lo16(dp), hi16(dp) };
+				int e, o;
+				if (c == 0) {
+					inv_horiz_border(l, 2, lo16(yhh), 0, e, o);
+					te = (te & 0xffff0000u) | to8(e, sh, (int)(dz & 1u)); to = (to & 0xffff0000u) | to8(o, sh, (int)((dz >> 1) & 1u));
+				}
+				if (c + 1 == w - 1) {
+					inv_horiz_border(l, 3, hi16(yhh), 2, e, o);
+					te = (te & 0xffffu) | (to8(e, sh, (int)((dz >> 2) & 1u)) << 16); to = (to & 0xffffu) | (to8(o, sh, (int)((dz >> 3) & 1u)) << 16);
 				}
 			}
-			const int sh = job.shift;
-			uint32_t px[2];
-#pragma unroll
-			for (int k = 0; k < 2; k++) {
-				// byte lanes within a 16-byte output group decide the dither lane (the reference uses one random bit per SIMD lane)
-				int lane = ((4 * cc + 2 * k) & 7) * 2;
-				uint32_t y0 = to8(yv[2 * k], sh, sh >= 2 ? dither_bit(seed, orow, lane) : 0);
-				uint32_t y1 = to8(yv[2 * k + 1], sh, sh >= 2 ? dither_bit(seed, orow, lane + 1) : 0);
-				uint32_t u = to8(uv[k], sh, sh >= 2 ? dither_bit(seed, orow, 16 + ((2 * cc + k) & 7)) : 0);
-				uint32_t v = to8(vv[k], sh, sh >= 2 ? dither_bit(seed, orow, 24 + ((2 * cc + k) & 7)) : 0);
-				px[k] = job.uyvy ? (u | (y0 << 8) | (v << 16) | (y1 << 24)) : (y0 | (u << 8) | (y1 << 16) | (v << 24));
+			if (cc == 0 || cc == cw - 1) {                // first / last chroma column, V and U alike
+				// taps: first column -> columns cc, cc+1, cc+2; last column -> cc-2 (far), cc-1, cc
+				const int pos = cc == 0 ? 0 : 2;
+				const uint32_t far = pos == 0 ? C[2] : C[-2];
+				int e, o;
+				if (pos == 0) inv_horiz(0, lo16(cz), lo16(cp), lo16(far), lo16(chh), 0, e, o); else inv_horiz(lo16(cm), lo16(cz), 0, lo16(far), lo16(chh), 2, e, o);
+				const uint32_t v0 = to8(e, sh, (int)((dz >> 4) & 1u)), v1 = to8(o, sh, (int)((dz >> 6) & 1u));
+				if (pos == 0) inv_horiz(0, hi16(cz), hi16(cp), hi16(far), hi16(chh), 0, e, o); else inv_horiz(hi16(cm), hi16(cz), 0, hi16(far), hi16(chh), 2, e, o);
+				const uint32_t u0 = to8(e, sh, (int)((dz >> 5) & 1u)), u1 = to8(o, sh, (int)((dz >> 7) & 1u));
+				tce = v0 | (u0 << 16); tco = v1 | (u1 << 16);
 			}
-			uint2 o2; o2.x = px[0]; o2.y = px[1];
+			const uint32_t y0 = te & 0xffu, y2 = te >> 16, y1 = to & 0xffu, y3 = to >> 16;
+			const uint32_t v0 = tce & 0xffu, u0 = tce >> 16, v1 = tco & 0xffu, u1 = tco >> 16;
+			uint2 o2;
+			if (job.uyvy) { o2.x = u0 | (y0 << 8) | (v0 << 16) | (y1 << 24); o2.y = u1 | (y2 << 8) | (v1 << 16) | (y3 << 24); }
+			else { o2.x = y0 | (u0 << 8) | (y1 << 16) | (v0 << 24); o2.y = y2 | (u1 << 8) | (y3 << 16) | (v1 << 24); }
 			*(uint2 *)(job.out + (size_t)orow * job.out_pitch + 8 * (size_t)cc) = o2;
 		}
 	}

@@ -54,7 +54,7 @@ def test_fwd_yuv422(w, h, dh, uyvy):
             assert np.array_equal(outs_e[ch][k][:, :outs_o[ch][k].shape[1]], outs_o[ch][k]), (ch, k)
 
 
-@pytest.mark.parametrize("w,h", [(8, 4), (45, 17), (64, 8), (120, 135), (130, 20)])
+@pytest.mark.parametrize("w,h", [(8, 4), (45, 17), (64, 8), (120, 135), (130, 20), (66, 33), (129, 18), (64, 16), (200, 35), (3, 3)])
 @pytest.mark.parametrize("descale", [0, 2])
 def test_inv_plane(w, h, descale):
     rng = np.random.default_rng(w * 5 + h + descale)
@@ -69,7 +69,7 @@ def test_inv_plane(w, h, descale):
     assert np.array_equal(e[:, :2 * w], o)
 
 
-@pytest.mark.parametrize("w,h,dh", [(32, 8, 16), (96, 20, 40), (360, 30, 58)])
+@pytest.mark.parametrize("w,h,dh", [(32, 8, 16), (96, 20, 40), (360, 30, 58), (128, 17, 34), (132, 33, 66), (64, 16, 32), (260, 19, 37)])
 @pytest.mark.parametrize("uyvy", [0, 1])
 def test_inv_yuv422(w, h, dh, uyvy):
     """Emulated last-level kernel vs oracle: every output byte must equal the oracle with dither 0 or with dither 1."""
@@ -186,3 +186,20 @@ def test_gpu_entropy_decoder_emulated_survives_damaged_samples(parallel):
         t[lo: lo + 600] = rng.integers(0, 256, 600, dtype=np.uint8)
         E.emu_entropy_decode(p8(t), len(t), 1, p16(got), plan.coeff_elems, parallel)
         assert np.all(got[plan.coeff_elems:] == 99)
+
+
+@pytest.mark.parametrize("w,h", [(66, 33), (130, 20)])
+@pytest.mark.parametrize("descale", [0, 2])
+def test_inv_plane_full_range_saturation(w, h, descale):
+    """Full-range int16 bands: every saturating step of the packed kernel must clip exactly where the oracle (= the reference's
+    _mm_adds_epi16 / _mm_subs_epi16 chain, interior, and its 32-bit border arithmetic) clips."""
+    rng = np.random.default_rng(w + 3 * h + descale)
+    pitch = (w + 7) // 8 * 8
+    b = [np.zeros((h, pitch), np.int16) for _ in range(4)]
+    for k in range(4):
+        b[k][:, :w] = rng.choice(np.array([-32768, -32767, -20000, -1, 0, 1, 9000, 32767], dtype=np.int16), size=(h, w))
+    o = np.zeros((2 * h, 2 * w), np.int16); e = np.zeros((2 * h, 2 * pitch), np.int16)
+    bands = (c_i16p * 4)(*[p16(a) for a in b])
+    oracle().orc_inv_spatial(bands, pitch, w, h, descale, p16(o), 2 * w)
+    emu().emu_inv_plane(p16(b[0]), p16(b[1]), p16(b[2]), p16(b[3]), pitch, w, h, descale, p16(e), 2 * pitch)
+    assert np.array_equal(e[:, :2 * w], o)

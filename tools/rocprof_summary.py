@@ -2,8 +2,37 @@
 """Turn a rocprofv3 rocpd database (bench_results.db) into the plain-text per-kernel summary we commit under profiles/.
 
 usage: tools/rocprof_summary.py <kernel-trace db> [<pmc db> ...] > profiles/<name>.txt
+       tools/rocprof_summary.py --traffic-json profiles/pmc_traffic.json --frames N <FETCH_SIZE db> <WRITE_SIZE db>
+         (HBM bytes per launch of every kernel = FETCH_SIZE + WRITE_SIZE, KiB -> bytes; bench.py reads the file for roofline.traffic)
 """
-import sqlite3, sys
+import json, re, sqlite3, sys
+
+
+def short_name(mangled):
+    m = re.match(r"_ZN4cfhd3dev(\d+)", mangled)
+    if m:
+        start = m.end(); return mangled[start:start + int(m.group(1))]
+    return mangled.replace(".kd", "")
+
+
+def traffic_json(out, frames, dbs):
+    acc = {}
+    for path in dbs:
+        cur = sqlite3.connect(path).cursor()
+        t = tables(cur)
+        rows = cur.execute("select s.kernel_name, p.name, count(*), max(e.value) from %s e join %s p on e.pmc_id=p.id join %s k on e.event_id=k.event_id "
+                           "join %s s on k.kernel_id=s.id group by s.kernel_name, p.name" % (t["pmc_event"], t["info_pmc"], t["kernel_dispatch"], t["info_kernel_symbol"])).fetchall()
+        for name, counter, n, mx in rows:
+            # kernels launched once per wavelet level (k_fwd_plane / k_inv_plane) differ per launch: keep the largest launch
+            acc.setdefault(short_name(name), {})[counter] = mx * 1024.0
+    kernels = {}
+    for k, v in acc.items():
+        if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            kernels[k] = {"fetch_bytes_per_launch": int(v["FETCH_SIZE"]), "write_bytes_per_launch": int(v["WRITE_SIZE"]),
+                          "hbm_bytes_per_launch": int(v["FETCH_SIZE"] + v["WRITE_SIZE"])}
+    json.dump({"frames_per_launch": frames, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), KiB * 1024, largest launch of each kernel; "
+               "calibration: k_fwd_yuv422 WRITE_SIZE equals its band bytes exactly and FETCH_SIZE = packed input + 3 % halo with dword loads, so no gfx950 doubling is applied",
+               "kernels": kernels}, open(out, "w"), indent=1, sort_keys=True)
 
 
 def tables(cur):
@@ -13,6 +42,8 @@ def tables(cur):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--traffic-json":
+        return traffic_json(sys.argv[2], int(sys.argv[4]), sys.argv[5:])
     for path in sys.argv[1:]:
         cur = sqlite3.connect(path).cursor()
         t = tables(cur)
