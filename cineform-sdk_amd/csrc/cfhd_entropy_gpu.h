@@ -15,10 +15,10 @@ public:
 	int prepare(const FramePlan &plan, int nframes, int16_t *d_coeffs, size_t coeff_stride_elems, size_t sample_cap, void *stream);
 	int set_frame_header(int i, const SampleHeaderInfo &hdr);        // header fields / metadata of frame i's sample
 	int launch();                                                    // async: templates H2D + 4 kernels
-	int download();                                                  // async sizes -> sync -> async payloads (call wait on the stream afterwards)
+	int download();                                                  // sizes + packed offsets -> sync -> one async copy of all sample bytes (wait on the stream afterwards)
 	int fetch_sizes();                                               // sizes only (device-resident consumers); synchronises the stream
 	const uint32_t *device_sizes() const { return d_sizes_; }
-	const uint8_t *host_sample(int i) const { return h_samples_ + (size_t)i * cap_; }
+	const uint8_t *host_sample(int i) const { return h_samples_ + h_offsets_[i]; }   // after download() + stream wait
 	uint8_t *device_sample(int i) { return d_samples_ + (size_t)i * cap_; }
 	uint32_t sample_bytes(int i) const { return h_sizes_[i]; }
 	size_t sample_cap() const { return cap_; }
@@ -33,6 +33,7 @@ private:
 	std::vector<SampleTemplate> tmpl_;
 	uint8_t *d_samples_ = nullptr, *h_samples_ = nullptr;
 	uint32_t *d_sizes_ = nullptr, *h_sizes_ = nullptr;
+	uint8_t *d_packed_ = nullptr; uint32_t *d_offsets_ = nullptr, *h_offsets_ = nullptr;   // dense copy of the samples for the D2H transfer
 	void *d_tables_ = nullptr, *d_bands_ = nullptr, *d_segband_ = nullptr, *d_segs_ = nullptr, *d_bandstate_ = nullptr, *d_frames_ = nullptr;
 	uint8_t *d_tmpl_ = nullptr, *h_tmpl_ = nullptr;
 	bool dirty_ = true;

@@ -20,10 +20,12 @@ GpuEntropyEncoder::~GpuEntropyEncoder() { release(); delete host_; }
 
 void GpuEntropyEncoder::release()
 {
-	void *dev[] = { d_samples_, d_sizes_, d_tables_, d_bands_, d_segband_, d_segs_, d_bandstate_, d_frames_, d_tmpl_ };
+	void *dev[] = { d_samples_, d_sizes_, d_tables_, d_bands_, d_segband_, d_segs_, d_bandstate_, d_frames_, d_tmpl_, d_packed_, d_offsets_ };
 	for (void *p : dev) if (p) (void)hipFree(p);
 	if (h_samples_) (void)hipHostFree(h_samples_);
 	if (h_sizes_) (void)hipHostFree(h_sizes_);
+	if (h_offsets_) (void)hipHostFree(h_offsets_);
+	d_packed_ = nullptr; d_offsets_ = h_offsets_ = nullptr;
 	if (h_tmpl_) (void)hipHostFree(h_tmpl_);
 	if (host_->frames) { (void)hipHostFree(host_->frames); host_->frames = nullptr; }
 	for (void *&e : ev_) if (e) { (void)hipEventDestroy((hipEvent_t)e); e = nullptr; }
@@ -38,6 +40,7 @@ int GpuEntropyEncoder::prepare(const FramePlan &plan, int nframes, int16_t *d_co
 	if (rc) return rc;
 	release();
 	plan_ = plan; n_ = nframes; cap_ = (sample_cap + 63) & ~(size_t)63; stream_ = stream; d_coeffs_ = d_coeffs; coeff_stride_ = stride;
+	if (cap_ * (size_t)n_ >= ((size_t)1 << 32)) { fprintf(stderr, "[cfhd_amd] batch of %d frames exceeds the 4 GiB sample arena\n", n_); return -5; }   // packed offsets are 32-bit
 	{
 		dev::EntTables *h = new dev::EntTables;
 		ent_build_tables(h);
@@ -62,6 +65,10 @@ int GpuEntropyEncoder::prepare(const FramePlan &plan, int nframes, int16_t *d_co
 	HIPCHK(hipMalloc((void **)&d_sizes_, sizeof(uint32_t) * n_));
 	HIPCHK(hipHostMalloc((void **)&h_sizes_, sizeof(uint32_t) * n_, hipHostMallocDefault));
 	memset(h_sizes_, 0, sizeof(uint32_t) * n_);
+	HIPCHK(hipMalloc((void **)&d_packed_, cap_ * n_));
+	HIPCHK(hipMalloc((void **)&d_offsets_, sizeof(uint32_t) * (n_ + 1)));
+	HIPCHK(hipHostMalloc((void **)&h_offsets_, sizeof(uint32_t) * (n_ + 1), hipHostMallocDefault));
+	memset(h_offsets_, 0, sizeof(uint32_t) * (n_ + 1));
 	HIPCHK(hipMalloc((void **)&d_tmpl_, (size_t)kEntTmplStride * n_));
 	HIPCHK(hipHostMalloc((void **)&h_tmpl_, (size_t)kEntTmplStride * n_, hipHostMallocDefault));
 	memset(h_tmpl_, 0, (size_t)kEntTmplStride * n_);
@@ -94,14 +101,14 @@ int GpuEntropyEncoder::launch()
 	const dev::EntTables *T = (const dev::EntTables *)d_tables_;
 	(void)hipGetLastError();
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[0], st));
-	dev::k_ent_count<<<total_segs_, dev::ENT_THREADS, 0, st>>>((const dev::EntBandJob *)d_bands_, (const int *)d_segband_, (dev::EntSegState *)d_segs_, T);
+	dev::k_ent_count<<<(total_segs_ + dev::ENT_WAVES - 1) / dev::ENT_WAVES, dev::ENT_THREADS, 0, st>>>((const dev::EntBandJob *)d_bands_, (const int *)d_segband_, total_segs_, (dev::EntSegState *)d_segs_, T);
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[1], st));
 	dev::k_ent_scan<<<nbands_ * n_, dev::ENT_THREADS, 0, st>>>((const dev::EntBandJob *)d_bands_, (dev::EntSegState *)d_segs_, (dev::EntBandState *)d_bandstate_, T);
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[2], st));
 	dev::k_ent_layout<<<n_, dev::ENT_THREADS, 0, st>>>((const dev::EntFrameJob *)d_frames_, (const dev::EntBandJob *)d_bands_, (const dev::EntSegState *)d_segs_,
 	                                                  (dev::EntBandState *)d_bandstate_, T);
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[3], st));
-	dev::k_ent_emit<<<total_segs_, dev::ENT_THREADS, 0, st>>>((const dev::EntBandJob *)d_bands_, (const int *)d_segband_, (const dev::EntSegState *)d_segs_,
+	dev::k_ent_emit<<<(total_segs_ + dev::ENT_WAVES - 1) / dev::ENT_WAVES, dev::ENT_THREADS, 0, st>>>((const dev::EntBandJob *)d_bands_, (const int *)d_segband_, total_segs_, (const dev::EntSegState *)d_segs_,
 	                                                          (const dev::EntBandState *)d_bandstate_, (const dev::EntFrameJob *)d_frames_, T);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[4], st));
@@ -126,16 +133,18 @@ int GpuEntropyEncoder::fetch_sizes()
 
 int GpuEntropyEncoder::download()
 {
-	int rc = fetch_sizes();
-	if (rc) return rc;
 	hipStream_t st = (hipStream_t)stream_;
-	for (int f = 0; f < n_; f++)
-		if (h_sizes_[f]) HIPCHK(hipMemcpyAsync(h_samples_ + cap_ * f, d_samples_ + cap_ * f, h_sizes_[f], hipMemcpyDeviceToHost, st));
+	(void)hipGetLastError();
+	dev::k_ent_pack_offsets<<<1, dev::ENT_THREADS, 0, st>>>(d_sizes_, n_, d_offsets_);
+	dev::k_ent_pack<<<dim3(8, (unsigned)n_), dev::ENT_THREADS, 0, st>>>(d_samples_, cap_, d_sizes_, d_offsets_, d_packed_);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipMemcpyAsync(h_sizes_, d_sizes_, sizeof(uint32_t) * n_, hipMemcpyDeviceToHost, st));
+	HIPCHK(hipMemcpyAsync(h_offsets_, d_offsets_, sizeof(uint32_t) * (n_ + 1), hipMemcpyDeviceToHost, st));
+	HIPCHK(hipStreamSynchronize(st));
+	if (h_offsets_[n_]) HIPCHK(hipMemcpyAsync(h_samples_, d_packed_, h_offsets_[n_], hipMemcpyDeviceToHost, st));
 	return 0;
 }
 
-
-// =============================================================================================
 struct GpuEntropyDecoder::Host {
 	std::vector<std::vector<dev::DecBandJob>> bands;      // per frame
 	std::vector<std::vector<dev::DecLowpassJob>> lows;
@@ -192,7 +201,7 @@ int GpuEntropyDecoder::prepare(const FramePlan &plan, int nframes, int16_t *d_co
 
 int GpuEntropyDecoder::set_samples_device(const uint8_t *d_samples, size_t stride_bytes, const uint32_t *d_sizes)
 {
-	if (!d_samples || !d_sizes || (stride_bytes & 15) || ((uintptr_t)d_samples & 15)) return -1;   // k_dec_parse reads 16 bytes at a time
+	if (!d_samples || !d_sizes || (stride_bytes & 63) || ((uintptr_t)d_samples & 63)) return -1;   // k_dec_parse reads aligned 64-byte windows
 	ext_samples_ = d_samples; ext_stride_ = stride_bytes; ext_sizes_ = d_sizes;
 	return 0;
 }

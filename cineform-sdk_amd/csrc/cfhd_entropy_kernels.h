@@ -22,7 +22,10 @@
 namespace cfhd {
 namespace dev {
 
-enum { ENT_THREADS = 256, ENT_PER_THREAD = 8, ENT_SEG = ENT_THREADS * ENT_PER_THREAD, ENT_LDS_WORDS = 2048, ENT_MAX_HOLES = 40 };
+// A segment = 1024 consecutive raster coefficients of a band = the work of one wave (16 coefficients per lane); four waves per
+// workgroup, no workgroup barriers in k_ent_count / k_ent_emit: all exchanges are wave-level (ballot / bpermute / shuffles).
+enum { ENT_THREADS = 256, ENT_LANES = 64, ENT_WAVES = ENT_THREADS / ENT_LANES, ENT_PER_THREAD = 16, ENT_SEG = ENT_LANES * ENT_PER_THREAD,
+       ENT_LDS_WORDS = 1024, ENT_MAX_HOLES = 40 };
 
 struct EntTables {
 	uint32_t value_code[2048];     // size << 27 | code word, index = value & 0x7ff
@@ -67,6 +70,16 @@ __device__ __forceinline__ uint32_t bswap32(uint32_t v) { return (v >> 24) | ((v
 __device__ __forceinline__ uint32_t atomic_or_u32(uint32_t *p, uint32_t v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
 #else
 __device__ __forceinline__ uint32_t atomic_or_u32(uint32_t *p, uint32_t v) { return atomicOr(p, v); }
+#endif
+
+#if defined(CFHD_HIPEMU)
+#define CFHD_WAVE_SYNC() hipemu::wave_sync()
+__device__ __forceinline__ int wave_uniform(int x) { return x; }
+__device__ __forceinline__ int wave_lane() { return (int)hipemu::lane_id(); }
+#else
+#define CFHD_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+__device__ __forceinline__ int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ int wave_lane() { return (int)(threadIdx.x & 63u); }
 #endif
 
 // Exclusive block scans over ENT_THREADS values (Hillis-Steele in LDS; the arrays are tiny, the barriers dominate).
@@ -116,57 +129,59 @@ __device__ __forceinline__ uint32_t value_entry(const EntTables *T, int v)
 	return T->value_code[v];
 }
 
-// Loads the 8 coefficients of this thread (raster indices base .. base+7, zero beyond the band).
-__device__ __forceinline__ void ent_load8(const EntBandJob &job, int base, int *v)
+// Loads the 16 coefficients of this lane (raster indices base .. base+15, zero beyond the band).
+__device__ __forceinline__ void ent_load16(const EntBandJob &job, int base, int *v)
 {
 	if (base + ENT_PER_THREAD <= job.n) {
-		const uint4 q = *(const uint4 *)(job.coeffs + base);
-		const uint32_t w[4] = { q.x, q.y, q.z, q.w };
+		const uint4 q0 = *(const uint4 *)(job.coeffs + base), q1 = *(const uint4 *)(job.coeffs + base + 8);
+		const uint32_t w[8] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w };
 #pragma unroll
-		for (int k = 0; k < 4; k++) { v[2 * k] = (int)(int16_t)(w[k] & 0xffffu); v[2 * k + 1] = (int)(int16_t)(w[k] >> 16); }
+		for (int k = 0; k < 8; k++) { v[2 * k] = (int)(int16_t)(w[k] & 0xffffu); v[2 * k + 1] = (int)(int16_t)(w[k] >> 16); }
 	} else {
 #pragma unroll
 		for (int k = 0; k < ENT_PER_THREAD; k++) v[k] = (base + k < job.n) ? (int)job.coeffs[base + k] : 0;
 	}
 }
 
-// =============================================================================================
-__global__ void __launch_bounds__(ENT_THREADS) k_ent_count(const EntBandJob *bands, const int *seg_band, EntSegState *segs, const EntTables *T)
+// Last nonzero in front of this lane inside the wave's segment (-1: none): the nearest lower lane that holds one.
+__device__ __forceinline__ int wave_prev_nonzero(int my_last, int lane, unsigned long long mask)
 {
-	__shared__ int s_scan[ENT_THREADS];
-	const int seg = blockIdx.x;
+	const unsigned long long lower = mask & ((1ull << lane) - 1ull);
+	const int prev = __shfl(my_last, lower ? 63 - __builtin_clzll(lower) : lane);
+	return lower ? prev : -1;
+}
+
+// =============================================================================================
+__global__ void __launch_bounds__(ENT_THREADS) k_ent_count(const EntBandJob *bands, const int *seg_band, int total_segs, EntSegState *segs, const EntTables *T)
+{
+	const int lane = wave_lane();
+	const int seg = wave_uniform((int)blockIdx.x * ENT_WAVES + (int)(threadIdx.x >> 6));
+	if (seg >= total_segs) return;                       // whole wave
 	const EntBandJob &job = bands[seg_band[seg]];
-	const int local = seg - job.seg_base;
-	const int base = local * ENT_SEG + threadIdx.x * ENT_PER_THREAD;
+	const int base = (seg - job.seg_base) * ENT_SEG + lane * ENT_PER_THREAD;
 	int v[ENT_PER_THREAD];
-	ent_load8(job, base, v);
-	int my_last = -1, my_first = 0x7fffffff;
+	ent_load16(job, base, v);
+	int my_last = -1, my_first = -1;
 #pragma unroll
-	for (int k = 0; k < ENT_PER_THREAD; k++) if (v[k]) { my_last = base + k; if (my_first == 0x7fffffff) my_first = base + k; }
-	int seg_last;
-	int prev = block_excl_max(my_last, s_scan, &seg_last);      // last nonzero of the segment in front of this thread
+	for (int k = 0; k < ENT_PER_THREAD; k++) if (v[k]) { my_last = base + k; if (my_first < 0) my_first = base + k; }
+	const unsigned long long mask = __ballot(my_last >= 0);
+	int prev = wave_prev_nonzero(my_last, lane, mask);
 	uint32_t bits = 0;
 #pragma unroll
 	for (int k = 0; k < ENT_PER_THREAD; k++) {
 		if (!v[k]) continue;
-		if (prev >= 0) bits += T->run_total[base + k - prev - 1];  // run inside the segment: < 2048
+		if (prev >= 0) bits += T->run_total[base + k - prev - 1];  // run inside the segment: < 1024
 		bits += value_entry(T, v[k]) >> 27;
 		prev = base + k;
 	}
-	int total_bits;
-	block_excl_sum((int)bits, s_scan, &total_bits);
-	// first nonzero of the segment = the only one whose thread saw prev < 0 at a nonzero: min over threads
-	s_scan[threadIdx.x] = my_first;
-	__syncthreads();
-	for (int d = ENT_THREADS / 2; d > 0; d >>= 1) {
-		if ((int)threadIdx.x < d && s_scan[threadIdx.x + d] < s_scan[threadIdx.x]) s_scan[threadIdx.x] = s_scan[threadIdx.x + d];
-		__syncthreads();
-	}
-	if (threadIdx.x == 0) {
+#pragma unroll
+	for (int m = 32; m > 0; m >>= 1) bits += __shfl_xor(bits, m);
+	const int first_nz = __shfl(my_first, mask ? __builtin_ctzll(mask) : 0), last_nz = __shfl(my_last, mask ? 63 - __builtin_clzll(mask) : 0);
+	if (lane == 0) {
 		EntSegState &s = segs[seg];
-		s.first_nz = s_scan[0] == 0x7fffffff ? -1 : s_scan[0];
-		s.last_nz = seg_last;
-		s.bits = (uint32_t)total_bits;
+		s.first_nz = mask ? first_nz : -1;
+		s.last_nz = mask ? last_nz : -1;
+		s.bits = bits;
 	}
 }
 
@@ -302,26 +317,28 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_layout(const EntFrameJob *f
 }
 
 // =============================================================================================
-__global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(const EntBandJob *bands, const int *seg_band, const EntSegState *segs,
+__global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(const EntBandJob *bands, const int *seg_band, int total_segs, const EntSegState *segs,
                                                            const EntBandState *band_state, const EntFrameJob *frames, const EntTables *T)
 {
-	__shared__ int s_scan[ENT_THREADS];
-	__shared__ uint32_t s_words[ENT_LDS_WORDS + 2];
-	const int seg = blockIdx.x;
+	__shared__ uint32_t s_words_all[ENT_WAVES][ENT_LDS_WORDS + 2];
+	const int lane = wave_lane();
+	const int wave = wave_uniform((int)(threadIdx.x >> 6));
+	const int seg = wave_uniform((int)blockIdx.x * ENT_WAVES + wave);
+	if (seg >= total_segs) return;
 	const int bj = seg_band[seg];
 	const EntBandJob &job = bands[bj];
 	const EntSegState st = segs[seg];
-	if (st.bits == 0) return;                            // uniform: nothing starts in this segment
+	if (st.bits == 0) return;                            // wave-uniform: nothing starts in this segment
 	const EntFrameJob &f = frames[job.frame];
 	if (*f.sample_bytes == 0) return;                    // overflow detected by k_ent_layout
-	const int local = seg - job.seg_base;
-	const int base = local * ENT_SEG + threadIdx.x * ENT_PER_THREAD;
+	uint32_t *s_words = s_words_all[wave];
+	const int base = (seg - job.seg_base) * ENT_SEG + lane * ENT_PER_THREAD;
 	int v[ENT_PER_THREAD];
-	ent_load8(job, base, v);
+	ent_load16(job, base, v);
 	int my_last = -1;
 #pragma unroll
 	for (int k = 0; k < ENT_PER_THREAD; k++) if (v[k]) my_last = base + k;
-	int prev = block_excl_max(my_last, s_scan, nullptr);
+	int prev = wave_prev_nonzero(my_last, lane, __ballot(my_last >= 0));
 	if (prev < 0) prev = st.prev_nz;                     // the run in front of the segment's first nonzero reaches back into earlier segments
 	const int prev0 = prev;
 	uint32_t bits = 0;
@@ -331,15 +348,18 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(const EntBandJob *band
 		bits += run_bits_any(T, (uint32_t)(base + k - prev - 1)) + (value_entry(T, v[k]) >> 27);
 		prev = base + k;
 	}
-	const uint32_t my_off = (uint32_t)block_excl_sum((int)bits, s_scan, nullptr);
+	uint32_t incl = bits;                                // inclusive wave scan of the bit counts
+#pragma unroll
+	for (int d = 1; d < ENT_LANES; d <<= 1) { const uint32_t x = __shfl_up(incl, (unsigned)d); if (lane >= d) incl += x; }
+	const uint32_t my_off = incl - bits;
 
 	uint32_t *out = (uint32_t *)(f.out + band_state[bj].base_byte);
 	const uint64_t seg_pos = st.bitoff;                  // bit position of the segment inside the band payload
 	const uint32_t first_word = (uint32_t)(seg_pos >> 5), last_word = (uint32_t)((seg_pos + st.bits - 1) >> 5);
 	const uint32_t nwords = last_word - first_word + 1;
-	const bool use_lds = nwords <= ENT_LDS_WORDS;        // uniform
-	if (use_lds) for (int i = threadIdx.x; i < (int)nwords + 1; i += ENT_THREADS) s_words[i] = 0;
-	__syncthreads();
+	const bool use_lds = nwords <= ENT_LDS_WORDS;        // wave-uniform
+	if (use_lds) for (int i = lane; i < (int)nwords + 1; i += ENT_LANES) s_words[i] = 0;
+	CFHD_WAVE_SYNC();
 	{
 		uint64_t pos = seg_pos + my_off;
 		prev = prev0;
@@ -364,11 +384,11 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(const EntBandJob *band
 			prev = base + k;
 		}
 	}
-	__syncthreads();
+	CFHD_WAVE_SYNC();
 	if (use_lds) {
 		// interior words belong to this segment alone: plain coalesced stores; the first and last word may be shared with
 		// the neighbouring segments (or the band's trailer): OR them into the zeroed payload
-		for (int i = threadIdx.x; i < (int)nwords; i += ENT_THREADS) {
+		for (int i = lane; i < (int)nwords; i += ENT_LANES) {
 			const uint32_t w = bswap32(s_words[i]);
 			if (i == 0 || i == (int)nwords - 1) { if (w) atomic_or_u32(&out[first_word + i], w); }
 			else out[first_word + i] = w;
@@ -376,6 +396,35 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(const EntBandJob *band
 	}
 }
 
+
+// =============================================================================================
+// The finished samples sit in fixed-stride slots (sized for the worst case); the host wants them as bytes.  k_ent_pack_offsets
+// turns the sample sizes into 64-byte aligned offsets of a dense buffer, k_ent_pack copies every sample there, and one D2H
+// copy of offsets[n] bytes replaces one copy per frame.
+// =============================================================================================
+__global__ void __launch_bounds__(ENT_THREADS) k_ent_pack_offsets(const uint32_t *sizes, int n, uint32_t *offsets)
+{
+	__shared__ int s_scan[ENT_THREADS];
+	uint32_t carry = 0;
+	for (int c0 = 0; c0 < n; c0 += ENT_THREADS) {
+		const int i = c0 + (int)threadIdx.x;
+		const uint32_t sz = i < n ? (sizes[i] + 63u) & ~63u : 0u;
+		int total;
+		const uint32_t off = carry + (uint32_t)block_excl_sum((int)sz, s_scan, &total);
+		if (i < n) offsets[i] = off;
+		carry += (uint32_t)total;
+	}
+	if (threadIdx.x == 0) offsets[n] = carry;
+}
+
+__global__ void __launch_bounds__(ENT_THREADS) k_ent_pack(const uint8_t *samples, size_t stride, const uint32_t *sizes, const uint32_t *offsets, uint8_t *packed)
+{
+	const int f = blockIdx.y;
+	const uint4 *src = (const uint4 *)(samples + stride * (size_t)f);
+	uint4 *dst = (uint4 *)(packed + offsets[f]);
+	const uint32_t n16 = (sizes[f] + 15u) >> 4;
+	for (uint32_t i = blockIdx.x * ENT_THREADS + threadIdx.x; i < n16; i += gridDim.x * ENT_THREADS) dst[i] = src[i];
+}
 
 // =============================================================================================
 // Decoder side: one lane per coded band (the code is sequential inside a band; bands are independent because each has its
@@ -598,14 +647,19 @@ struct DecPlan {
 };
 enum { DEC_PARSE_THREADS = 64, DEC_ERR_PARSE = 0x100 };
 
-struct DecTagReader {             // 16 bytes of the sample at a time (the tags of a band header sit next to each other)
-	const uint8_t *d; uint64_t base; uint4 c;
+struct DecTagReader {             // 64 bytes of the sample at a time, fetched with four loads in flight: the tags of a band header sit next to each other
+	const uint8_t *d; uint64_t base; uint4 c[4];
 	__device__ __forceinline__ uint32_t word(uint64_t pos)
 	{
-		const uint64_t b = pos & ~(uint64_t)15;
-		if (b != base) { c = *(const uint4 *)(d + b); base = b; }
-		const uint32_t k = (uint32_t)(pos >> 2) & 3u;
-		const uint32_t w = k == 0 ? c.x : k == 1 ? c.y : k == 2 ? c.z : c.w;
+		const uint64_t b = pos & ~(uint64_t)63;
+		if (b != base) {
+			const uint4 *p = (const uint4 *)(d + b);
+			c[0] = p[0]; c[1] = p[1]; c[2] = p[2]; c[3] = p[3];
+			base = b;
+		}
+		const uint32_t k = (uint32_t)(pos >> 2) & 15u;
+		const uint4 q = (k >> 2) == 0 ? c[0] : (k >> 2) == 1 ? c[1] : (k >> 2) == 2 ? c[2] : c[3];
+		const uint32_t w = (k & 3u) == 0 ? q.x : (k & 3u) == 1 ? q.y : (k & 3u) == 2 ? q.z : q.w;
 		return bswap32(w);
 	}
 };
@@ -627,7 +681,7 @@ __global__ void __launch_bounds__(DEC_PARSE_THREADS) k_dec_parse(const uint8_t *
 				bandjobs[(size_t)P->slot[c][lv][b] * nframes + f] = DecBandJob{ d, 0u, cbase + pb.offset, pb.height * pb.pitch, 1 };
 			}
 	}
-	DecTagReader rd = { d, ~(uint64_t)0, { 0u, 0u, 0u, 0u } };
+	DecTagReader rd; rd.d = d; rd.base = ~(uint64_t)0;
 	uint64_t pos = 0, pending_at = 0;
 	uint32_t pending = 0, seen = 0, seen_low = 0;
 	int channel = 0, lv = -1, band = 0, bw = 0, bh = 0, bq = 1, bflags = 0, lw = 0, lh = 0;

@@ -36,24 +36,83 @@ struct int2 { int x, y; };
 extern dim3 threadIdx, blockIdx, blockDim, gridDim;
 
 namespace hipemu {
-struct Fiber { ucontext_t ctx; char *stack; bool done; dim3 tid; };
-struct Sched { ucontext_t main; Fiber *current; std::function<void()> *body; };
+struct Fiber { ucontext_t ctx; char *stack; bool done; dim3 tid; unsigned lin; };
+enum { kWave = 64, kMaxWaves = 16 };
+struct Sched {
+	ucontext_t main; Fiber *current; std::function<void()> *body;
+	// counting barriers: a barrier completes when every fiber of its scope that is still running has arrived (finished fibers
+	// drop out of the count), so scopes may execute different numbers of barriers (a wave that left early, wave-level exchanges)
+	unsigned block_live, block_arrived, block_gen;
+	unsigned wave_live[kMaxWaves], wave_arrived[kMaxWaves], wave_gen[kMaxWaves];
+	uint64_t exchange[kWave * kMaxWaves];     // one slot per thread for the wave-level data exchanges below
+};
 inline Sched &sched() { static Sched s; return s; }
+inline void yield()
+{
+	Sched &s = sched();
+	Fiber *me = s.current;
+	swapcontext(&me->ctx, &s.main);
+	threadIdx = me->tid;
+}
 inline void fiber_entry()
 {
 	Sched &s = sched();
 	(*s.body)();
 	s.current->done = true;
+	s.block_live--; s.wave_live[s.current->lin / kWave]--;
 	swapcontext(&s.current->ctx, &s.main);
+}
+// barrier among the running fibers of this thread's wave (the hardware executes a wave in lock step; fibers need the rendezvous)
+inline void wave_sync()
+{
+	Sched &s = sched();
+	const unsigned w = s.current->lin / kWave;
+	const unsigned gen = s.wave_gen[w];
+	s.wave_arrived[w]++;
+	while (s.wave_gen[w] == gen) {
+		if (s.wave_arrived[w] >= s.wave_live[w]) { s.wave_gen[w]++; s.wave_arrived[w] = 0; break; }
+		yield();
+	}
+}
+inline unsigned lane_id() { return sched().current->lin % kWave; }
+template <typename T> inline T exchange(T v, int src_lane)      // value of `v` in lane src_lane of the same wave (own value if out of range)
+{
+	Sched &s = sched();
+	const unsigned lin = s.current->lin, w = lin / kWave;
+	uint64_t bits = 0; memcpy(&bits, &v, sizeof(T));
+	s.exchange[lin] = bits;
+	wave_sync();
+	T r = v;
+	if (src_lane >= 0 && src_lane < (int)kWave) { const uint64_t b = s.exchange[w * kWave + (unsigned)src_lane]; memcpy(&r, &b, sizeof(T)); }
+	wave_sync();
+	return r;
 }
 }
 
 inline void __syncthreads()
 {
 	hipemu::Sched &s = hipemu::sched();
-	hipemu::Fiber *me = s.current;
-	swapcontext(&me->ctx, &s.main);      // back to the scheduler; resumed after every other fiber reached this barrier
-	threadIdx = me->tid;
+	const unsigned gen = s.block_gen;
+	s.block_arrived++;
+	while (s.block_gen == gen) {
+		if (s.block_arrived >= s.block_live) { s.block_gen++; s.block_arrived = 0; break; }
+		hipemu::yield();
+	}
+}
+// wave-level intrinsics (wave64).  Lanes that already returned do not take part; their slot keeps its last value.
+template <typename T> inline T __shfl(T v, int lane) { return hipemu::exchange(v, lane); }
+template <typename T> inline T __shfl_up(T v, unsigned d) { const int l = (int)hipemu::lane_id(); return hipemu::exchange(v, l - (int)d >= 0 ? l - (int)d : -1); }
+template <typename T> inline T __shfl_xor(T v, int m) { return hipemu::exchange(v, (int)hipemu::lane_id() ^ m); }
+inline unsigned long long __ballot(int pred)
+{
+	hipemu::Sched &s = hipemu::sched();
+	const unsigned lin = s.current->lin, w = lin / hipemu::kWave;
+	s.exchange[lin] = pred ? 1u : 0u;
+	hipemu::wave_sync();
+	unsigned long long m = 0;
+	for (unsigned l = 0; l < hipemu::kWave; l++) if (s.exchange[w * hipemu::kWave + l] & 1u) m |= 1ull << l;
+	hipemu::wave_sync();
+	return m;
 }
 using std::min; using std::max;
 
@@ -73,9 +132,13 @@ void launch(dim3 grid, dim3 block, F body_fn)
 		for (unsigned by = 0; by < grid.y; by++)
 			for (unsigned bx = 0; bx < grid.x; bx++) {
 				blockIdx = dim3(bx, by, bz);
+				s.block_live = nthreads; s.block_arrived = 0; s.block_gen = 0;
+				for (unsigned wv = 0; wv < kMaxWaves; wv++) { s.wave_live[wv] = 0; s.wave_arrived[wv] = 0; s.wave_gen[wv] = 0; }
+				for (unsigned t = 0; t < nthreads; t++) s.wave_live[t / kWave]++;
+				memset(s.exchange, 0, sizeof(s.exchange));
 				for (unsigned t = 0; t < nthreads; t++) {
 					Fiber &f = fibers[t];
-					f.done = false;
+					f.done = false; f.lin = t;
 					f.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
 					getcontext(&f.ctx);
 					f.ctx.uc_stack.ss_sp = f.stack; f.ctx.uc_stack.ss_size = stack_bytes; f.ctx.uc_link = &s.main;

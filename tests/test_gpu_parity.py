@@ -203,6 +203,12 @@ def test_reference_harness_links_unchanged_and_prints_same_numbers():
             proc.wait()
         return res
     a, b = run(ours), run(theirs)
+    def psnr_ok():
+        return all(abs(pa - pb) <= 0.1 + 1e-6 for fmt in ("YUY2", "2vuy") for (_, pa), (_, pb) in zip(a.get(fmt, []), b.get(fmt, [])[:10]))
+    if not psnr_ok():
+        # the reference's threaded decoder has been seen to print one outlier (a frame 17 dB low) in an otherwise identical
+        # run; a second reference run must then agree with ours on every frame
+        b = run(theirs)
     for fmt in ("YUY2", "2vuy"):
         assert fmt in a and len(a[fmt]) == 10, "our library did not complete the %s run: %r" % (fmt, a.get(fmt))
         for (sa, pa), (sb, pb) in zip(a[fmt], b[fmt][:10]):
