@@ -39,7 +39,7 @@ int GpuEntropyEncoder::prepare(const FramePlan &plan, int nframes, int16_t *d_co
 	int rc = device_init();
 	if (rc) return rc;
 	release();
-	plan_ = plan; n_ = nframes; cap_ = (sample_cap + 63) & ~(size_t)63; stream_ = stream; d_coeffs_ = d_coeffs; coeff_stride_ = stride;
+	plan_ = plan; n_ = nframes; cap_ = (sample_cap + 255) & ~(size_t)255; stream_ = stream; d_coeffs_ = d_coeffs; coeff_stride_ = stride;
 	if (cap_ * (size_t)n_ >= ((size_t)1 << 32)) { fprintf(stderr, "[cfhd_amd] batch of %d frames exceeds the 4 GiB sample arena\n", n_); return -5; }   // packed offsets are 32-bit
 	{
 		dev::EntTables *h = new dev::EntTables;
@@ -173,7 +173,7 @@ int GpuEntropyDecoder::prepare(const FramePlan &plan, int nframes, int16_t *d_co
 	int rc = device_init();
 	if (rc) return rc;
 	release();
-	plan_ = plan; n_ = nframes; cap_ = (sample_cap + 63) & ~(size_t)63; stream_ = stream; d_coeffs_ = d_coeffs; coeff_stride_ = stride; out_kind_ = out_kind;
+	plan_ = plan; n_ = nframes; cap_ = (sample_cap + 255) & ~(size_t)255; stream_ = stream; d_coeffs_ = d_coeffs; coeff_stride_ = stride; out_kind_ = out_kind;
 	std::vector<uint32_t> t = build_dec_tables(1);
 	HIPCHK(hipMalloc(&d_tables_, t.size() * 4));
 	HIPCHK(hipMemcpy(d_tables_, t.data(), t.size() * 4, hipMemcpyHostToDevice));
@@ -201,7 +201,7 @@ int GpuEntropyDecoder::prepare(const FramePlan &plan, int nframes, int16_t *d_co
 
 int GpuEntropyDecoder::set_samples_device(const uint8_t *d_samples, size_t stride_bytes, const uint32_t *d_sizes)
 {
-	if (!d_samples || !d_sizes || (stride_bytes & 63) || ((uintptr_t)d_samples & 63)) return -1;   // k_dec_parse reads aligned 64-byte windows
+	if (!d_samples || !d_sizes || (stride_bytes & 255) || ((uintptr_t)d_samples & 255)) return -1;   // k_dec_parse reads aligned 256-byte windows (a slot must extend to the window that holds its last tag)
 	ext_samples_ = d_samples; ext_stride_ = stride_bytes; ext_sizes_ = d_sizes;
 	return 0;
 }
@@ -236,7 +236,7 @@ int GpuEntropyDecoder::launch()
 		HIPCHK(hipMemsetAsync(d_errors_, 0, sizeof(int), st));
 		(void)hipGetLastError();
 		HIPCHK(hipEventRecord((hipEvent_t)ev_[0], st));
-		dev::k_dec_parse<<<(n_ + dev::DEC_PARSE_THREADS - 1) / dev::DEC_PARSE_THREADS, dev::DEC_PARSE_THREADS, 0, st>>>(ext_samples_, ext_stride_, ext_sizes_, n_,
+		dev::k_dec_parse<<<n_, dev::DEC_PARSE_THREADS, 0, st>>>(ext_samples_, ext_stride_, ext_sizes_, n_,
 			(const dev::DecPlan *)d_plan_, d_coeffs_, coeff_stride_, (dev::DecBandJob *)d_bandjobs_, (dev::DecLowpassJob *)d_lowjobs_, d_errors_);
 		HIPCHK(hipEventRecord((hipEvent_t)ev_[1], st));
 		dev::k_dec_bands_par<<<nb, dev::DECP_THREADS, 0, st>>>((const dev::DecBandJob *)d_bandjobs_, (const dev::DecTables *)d_tables_, d_errors_);

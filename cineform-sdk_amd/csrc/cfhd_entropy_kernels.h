@@ -645,35 +645,36 @@ struct DecPlan {
 	DecPlanBand high[4][3][4];
 	int slot[4][3][4];            // launch order of the band jobs: slot-major, the largest bands first
 };
-enum { DEC_PARSE_THREADS = 64, DEC_ERR_PARSE = 0x100 };
+enum { DEC_PARSE_THREADS = 64, DEC_ERR_PARSE = 0x100 };   // one wave per workgroup, one workgroup per sample
 
-struct DecTagReader {             // 64 bytes of the sample at a time, fetched with four loads in flight: the tags of a band header sit next to each other
-	const uint8_t *d; uint64_t base; uint4 c[4];
+// One wave per sample: the 64 lanes fetch 256 consecutive bytes of the tag stream with one coalesced load, the (wave-uniform) walk
+// reads its tags out of the lanes' registers; a band header and the size chunk in front of it usually come with one fetch.
+#if defined(CFHD_HIPEMU)
+__device__ __forceinline__ uint32_t wave_read(uint32_t v, int lane) { return __shfl(v, lane); }
+#else
+__device__ __forceinline__ uint32_t wave_read(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(lane)); }
+#endif
+struct DecTagReader {
+	const uint8_t *d; uint64_t base; uint32_t w; int lane;
 	__device__ __forceinline__ uint32_t word(uint64_t pos)
 	{
-		const uint64_t b = pos & ~(uint64_t)63;
-		if (b != base) {
-			const uint4 *p = (const uint4 *)(d + b);
-			c[0] = p[0]; c[1] = p[1]; c[2] = p[2]; c[3] = p[3];
-			base = b;
-		}
-		const uint32_t k = (uint32_t)(pos >> 2) & 15u;
-		const uint4 q = (k >> 2) == 0 ? c[0] : (k >> 2) == 1 ? c[1] : (k >> 2) == 2 ? c[2] : c[3];
-		const uint32_t w = (k & 3u) == 0 ? q.x : (k & 3u) == 1 ? q.y : (k & 3u) == 2 ? q.z : q.w;
-		return bswap32(w);
+		const uint64_t b = pos & ~(uint64_t)255;
+		if (b != base) { w = *(const uint32_t *)(d + b + 4 * (size_t)lane); base = b; }
+		return bswap32(wave_read(w, (int)((pos >> 2) & 63u)));
 	}
 };
 
 __global__ void __launch_bounds__(DEC_PARSE_THREADS) k_dec_parse(const uint8_t *samples, size_t sample_stride, const uint32_t *sizes, int nframes, const DecPlan *P,
                                                                  int16_t *coeffs, size_t coeff_stride, DecBandJob *bandjobs, DecLowpassJob *lowjobs, int *errors)
 {
-	const int f = blockIdx.x * DEC_PARSE_THREADS + threadIdx.x;
-	if (f >= nframes) return;
+	const int f = blockIdx.x;                            // every lane walks the same tags; lane 0 writes the jobs
+	const int lane = wave_lane();
+	const bool writer = lane == 0;
 	const uint8_t *d = samples + sample_stride * (size_t)f;
 	int16_t *cbase = coeffs + coeff_stride * (size_t)f;
 	const uint64_t size = sizes[f];
 	const int nch = P->num_channels;
-	for (int c = 0; c < nch; c++) {
+	if (writer) for (int c = 0; c < nch; c++) {
 		lowjobs[f * nch + c] = DecLowpassJob{ d, cbase + P->low[c].offset, 0, 0, P->low[c].pitch, 0 };
 		for (int lv = 0; lv < 3; lv++)
 			for (int b = 1; b < 4; b++) {
@@ -681,7 +682,7 @@ __global__ void __launch_bounds__(DEC_PARSE_THREADS) k_dec_parse(const uint8_t *
 				bandjobs[(size_t)P->slot[c][lv][b] * nframes + f] = DecBandJob{ d, 0u, cbase + pb.offset, pb.height * pb.pitch, 1 };
 			}
 	}
-	DecTagReader rd; rd.d = d; rd.base = ~(uint64_t)0;
+	DecTagReader rd; rd.d = d; rd.base = ~(uint64_t)0; rd.w = 0; rd.lane = lane;
 	uint64_t pos = 0, pending_at = 0;
 	uint32_t pending = 0, seen = 0, seen_low = 0;
 	int channel = 0, lv = -1, band = 0, bw = 0, bh = 0, bq = 1, bflags = 0, lw = 0, lh = 0;
@@ -720,7 +721,7 @@ __global__ void __launch_bounds__(DEC_PARSE_THREADS) k_dec_parse(const uint8_t *
 				if (pending == 0 || pos + bytes > end || end > size || channel >= nch) { bad = true; break; }
 				const DecPlanBand ll = P->low[channel];
 				if (lw != ll.width || lh != ll.height) { bad = true; break; }
-				lowjobs[f * nch + channel] = DecLowpassJob{ d + pos, cbase + ll.offset, ll.width, ll.height, ll.pitch, P->low_bias[channel] };
+				if (writer) lowjobs[f * nch + channel] = DecLowpassJob{ d + pos, cbase + ll.offset, ll.width, ll.height, ll.pitch, P->low_bias[channel] };
 				seen_low |= 1u << channel;
 				pos = end; pending = 0;
 			}
@@ -737,7 +738,7 @@ __global__ void __launch_bounds__(DEC_PARSE_THREADS) k_dec_parse(const uint8_t *
 			const DecPlanBand pb = P->high[channel][lv][band];
 			const int codebook = bflags & 0xf;
 			if (bw != pb.width || bh != pb.height || (pos & 3u) || (codebook != 0 && codebook != 1)) { bad = true; break; }
-			bandjobs[(size_t)P->slot[channel][lv][band] * nframes + f] = DecBandJob{ d + pos, (uint32_t)(end - 4 - pos), cbase + pb.offset, pb.height * pb.pitch, bq };
+			if (writer) bandjobs[(size_t)P->slot[channel][lv][band] * nframes + f] = DecBandJob{ d + pos, (uint32_t)(end - 4 - pos), cbase + pb.offset, pb.height * pb.pitch, bq };
 			seen |= 1u << ((channel * 3 + lv) * 3 + band - 1);
 			pos = end; pending = 0;
 			break; }
@@ -748,10 +749,10 @@ __global__ void __launch_bounds__(DEC_PARSE_THREADS) k_dec_parse(const uint8_t *
 	const uint32_t want = nch * 9 >= 32 ? 0xffffffffu : (1u << (nch * 9)) - 1u;
 	if (bad || width != P->width || display_height != P->display_height || encoded_format != P->encoded_format || num_channels != nch
 	    || seen != want || seen_low != (1u << nch) - 1u) {
-		for (int c = 0; c < nch; c++)
+		if (writer) for (int c = 0; c < nch; c++)
 			for (int l = 0; l < 3; l++)
 				for (int b = 1; b < 4; b++) bandjobs[(size_t)P->slot[c][l][b] * nframes + f].bytes = 0u;
-		atomic_or_u32((uint32_t *)errors, (uint32_t)DEC_ERR_PARSE);
+		if (writer) atomic_or_u32((uint32_t *)errors, (uint32_t)DEC_ERR_PARSE);
 	}
 }
 

@@ -118,15 +118,15 @@ extern "C" int emu_entropy_decode(const uint8_t *sample, size_t size, int pixel_
 	const int nb = (int)bands.size();
 	if (parallel == 2) {
 		// device-resident path: two copies of the sample, parsed by k_dec_parse (no host parser output reaches the kernels)
-		const size_t stride = (size + 64 + 63) & ~(size_t)63;
-		std::vector<uint8_t> raw(stride * 2 + 64, 0);
-		uint8_t *two = (uint8_t *)(((uintptr_t)raw.data() + 63) & ~(uintptr_t)63);
+		const size_t stride = (size + 256 + 255) & ~(size_t)255;
+		std::vector<uint8_t> raw(stride * 2 + 256, 0);
+		uint8_t *two = (uint8_t *)(((uintptr_t)raw.data() + 255) & ~(uintptr_t)255);
 		memcpy(two, sample, size); memcpy(two + stride, sample, size);
 		const uint32_t sizes[2] = { (uint32_t)size, (uint32_t)size };
 		std::vector<int16_t> pyr((size_t)plan.coeff_elems * 2, 77);
 		dev::DecPlan dp; dec_build_plan(plan, pixel_kind, &dp);
 		std::vector<dev::DecBandJob> bj((size_t)dp.bands_per_frame * 2); std::vector<dev::DecLowpassJob> lj((size_t)plan.num_channels * 2);
-		hipemu::launch(dim3(1), dim3(dev::DEC_PARSE_THREADS), [&] { dev::k_dec_parse(two, stride, sizes, 2, &dp, pyr.data(), plan.coeff_elems, bj.data(), lj.data(), &errors); });
+		hipemu::launch(dim3(2), dim3(dev::DEC_PARSE_THREADS), [&] { dev::k_dec_parse(two, stride, sizes, 2, &dp, pyr.data(), plan.coeff_elems, bj.data(), lj.data(), &errors); });
 		if (errors) return -20 - errors;
 		hipemu::launch(dim3((unsigned)bj.size()), dim3(dev::DECP_THREADS), [&] { dev::k_dec_bands_par(bj.data(), (const dev::DecTables *)tables.data(), &errors); });
 		hipemu::launch(dim3(4, (unsigned)lj.size()), dim3(256), [&] { dev::k_dec_lowpass(lj.data()); });

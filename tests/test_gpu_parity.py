@@ -184,7 +184,10 @@ def test_reference_harness_links_unchanged_and_prints_same_numbers():
         # The harness walks every pixel format at two resolutions; we only need its first two sections (YUY2, 2vuy at full
         # resolution), so read its output line by line and stop it (by PID) as soon as the third section starts.
         import time
-        proc = subprocess.Popen(["timeout", "150", "stdbuf", "-oL", binary, "-D"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, cwd="/tmp", start_new_session=True)
+        # OMP_NUM_THREADS=1: the harness's own frame generator (Example/qbist.cpp:284-310, the antialias pass) updates pixel LSBs in place
+        # while neighbouring OpenMP threads read them, so with several threads two runs of the same binary draw slightly different frames
+        proc = subprocess.Popen(["timeout", "150", "stdbuf", "-oL", binary, "-D"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, cwd="/tmp",
+                                start_new_session=True, env=dict(os.environ, OMP_NUM_THREADS="1"))
         res = {}; fmt = None; t0 = time.time()
         try:
             for line in proc.stdout:
@@ -203,17 +206,11 @@ def test_reference_harness_links_unchanged_and_prints_same_numbers():
             proc.wait()
         return res
     a, b = run(ours), run(theirs)
-    def psnr_ok():
-        return all(abs(pa - pb) <= 0.1 + 1e-6 for fmt in ("YUY2", "2vuy") for (_, pa), (_, pb) in zip(a.get(fmt, []), b.get(fmt, [])[:10]))
-    if not psnr_ok():
-        # the reference's threaded decoder has been seen to print one outlier (a frame 17 dB low) in an otherwise identical
-        # run; a second reference run must then agree with ours on every frame
-        b = run(theirs)
     for fmt in ("YUY2", "2vuy"):
         assert fmt in a and len(a[fmt]) == 10, "our library did not complete the %s run: %r" % (fmt, a.get(fmt))
         for (sa, pa), (sb, pb) in zip(a[fmt], b[fmt][:10]):
-            assert sa == sb, "%s compressed size %d vs reference %d" % (fmt, sa, sb)
-            assert abs(pa - pb) <= 0.1 + 1e-6, "%s PSNR %.1f vs reference %.1f" % (fmt, pa, pb)
+            assert sa == sb, "%s compressed size %d vs reference %d\nours %r\nreference %r" % (fmt, sa, sb, a, b)
+            assert abs(pa - pb) <= 0.1 + 1e-6, "%s PSNR %.1f vs reference %.1f\nours %r\nreference %r" % (fmt, pa, pb, a, b)
 
 
 def test_gpu_entropy_and_host_entropy_paths_agree():
