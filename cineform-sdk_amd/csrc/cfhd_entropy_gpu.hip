@@ -53,12 +53,12 @@ int GpuEntropyEncoder::prepare(const FramePlan &plan, int nframes, int16_t *d_co
 	build_sample_template(plan, hdr0, &tmpl_[0]);
 	EntHostJobs &jobs = host_->jobs;
 	if (!ent_build_band_jobs(plan, tmpl_[0], n_, d_coeffs, stride, &jobs)) return -3;
-	nbands_ = jobs.nbands; total_segs_ = (int)jobs.segband.size();
+	nbands_ = jobs.nbands; total_segs_ = (int)jobs.segjobs.size();
 	HIPCHK(hipMalloc(&d_bands_, jobs.bands.size() * sizeof(dev::EntBandJob)));
 	HIPCHK(hipMemcpy(d_bands_, jobs.bands.data(), jobs.bands.size() * sizeof(dev::EntBandJob), hipMemcpyHostToDevice));
-	HIPCHK(hipMalloc(&d_segband_, jobs.segband.size() * sizeof(int)));
-	HIPCHK(hipMemcpy(d_segband_, jobs.segband.data(), jobs.segband.size() * sizeof(int), hipMemcpyHostToDevice));
-	HIPCHK(hipMalloc(&d_segs_, jobs.segband.size() * sizeof(dev::EntSegState)));
+	HIPCHK(hipMalloc(&d_segband_, jobs.segjobs.size() * sizeof(dev::EntSegJob)));
+	HIPCHK(hipMemcpy(d_segband_, jobs.segjobs.data(), jobs.segjobs.size() * sizeof(dev::EntSegJob), hipMemcpyHostToDevice));
+	HIPCHK(hipMalloc(&d_segs_, jobs.segjobs.size() * sizeof(dev::EntSegState)));
 	HIPCHK(hipMalloc(&d_bandstate_, jobs.bands.size() * sizeof(dev::EntBandState)));
 	HIPCHK(hipMalloc((void **)&d_samples_, cap_ * n_));
 	HIPCHK(hipHostMalloc((void **)&h_samples_, cap_ * n_, hipHostMallocDefault));
@@ -101,15 +101,15 @@ int GpuEntropyEncoder::launch()
 	const dev::EntTables *T = (const dev::EntTables *)d_tables_;
 	(void)hipGetLastError();
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[0], st));
-	dev::k_ent_count<<<(total_segs_ + dev::ENT_WAVES - 1) / dev::ENT_WAVES, dev::ENT_THREADS, 0, st>>>((const dev::EntBandJob *)d_bands_, (const int *)d_segband_, total_segs_, (dev::EntSegState *)d_segs_, T);
+	dev::k_ent_count<<<(total_segs_ + dev::ENT_WAVES - 1) / dev::ENT_WAVES, dev::ENT_THREADS, 0, st>>>((const dev::EntSegJob *)d_segband_, total_segs_, (dev::EntSegState *)d_segs_, T);
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[1], st));
 	dev::k_ent_scan<<<nbands_ * n_, dev::ENT_THREADS, 0, st>>>((const dev::EntBandJob *)d_bands_, (dev::EntSegState *)d_segs_, (dev::EntBandState *)d_bandstate_, T);
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[2], st));
 	dev::k_ent_layout<<<n_, dev::ENT_THREADS, 0, st>>>((const dev::EntFrameJob *)d_frames_, (const dev::EntBandJob *)d_bands_, (const dev::EntSegState *)d_segs_,
 	                                                  (dev::EntBandState *)d_bandstate_, T);
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[3], st));
-	dev::k_ent_emit<<<(total_segs_ + dev::ENT_WAVES - 1) / dev::ENT_WAVES, dev::ENT_THREADS, 0, st>>>((const dev::EntBandJob *)d_bands_, (const int *)d_segband_, total_segs_, (const dev::EntSegState *)d_segs_,
-	                                                          (const dev::EntBandState *)d_bandstate_, (const dev::EntFrameJob *)d_frames_, T);
+	dev::k_ent_emit<<<(total_segs_ + dev::ENT_WAVES - 1) / dev::ENT_WAVES, dev::ENT_THREADS, 0, st>>>((const dev::EntSegJob *)d_segband_, total_segs_, (const dev::EntSegState *)d_segs_,
+	                                                          (const dev::EntBandState *)d_bandstate_, T);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[4], st));
 	timed_ = true;

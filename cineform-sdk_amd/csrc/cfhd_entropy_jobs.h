@@ -22,6 +22,7 @@ inline void ent_build_tables(dev::EntTables *h)
 	h->run_total[0] = 0;
 	for (int c = 1; c < 3072; c++) h->run_total[c] = (uint16_t)(t->run_size[c] + h->run_total[c - t->run_count[c]]);
 	h->band_end_bits = t->band_end_bits; h->band_end_size = t->band_end_size;
+	for (int c = 0; c < 3072; c++) { h->run_pack[c].x = t->run_bits[c]; h->run_pack[c].y = (uint32_t)t->run_size[c] | ((uint32_t)t->run_count[c] << 8); }
 }
 
 // Two-level decode tables from the base Huffman codes (cfhd_tables.cpp keeps them in EntropyTables::dec_lut for 12 bits;
@@ -30,7 +31,7 @@ std::vector<uint32_t> build_dec_tables(int codebook);
 
 struct EntHostJobs {
 	std::vector<dev::EntBandJob> bands;
-	std::vector<int> segband;
+	std::vector<dev::EntSegJob> segjobs;
 	std::vector<int> band_of_hole;      // template hole -> band job of frame 0 (-1 for lowpass holes)
 	int nbands = 0;                     // coded bands per frame
 };
@@ -38,7 +39,7 @@ struct EntHostJobs {
 inline bool ent_build_band_jobs(const FramePlan &plan, const SampleTemplate &t0, int nframes, int16_t *coeffs, size_t stride, EntHostJobs *out)
 {
 	if ((int)t0.holes.size() > dev::ENT_MAX_HOLES || (int)t0.patches.size() > kEntMaxPatches) return false;
-	out->bands.clear(); out->segband.clear();
+	out->bands.clear(); out->segjobs.clear();
 	out->band_of_hole.assign(t0.holes.size(), -1);
 	for (int f = 0; f < nframes; f++) {
 		int16_t *base = coeffs + (size_t)f * stride;
@@ -48,10 +49,10 @@ inline bool ent_build_band_jobs(const FramePlan &plan, const SampleTemplate &t0,
 			const BandDesc &bd = plan.ch[hole.channel].band[hole.level][hole.band];
 			dev::EntBandJob j;
 			j.coeffs = base + bd.offset; j.n = bd.height * bd.pitch;
-			j.nseg = (j.n + dev::ENT_SEG - 1) / dev::ENT_SEG; j.seg_base = (int)out->segband.size();
+			j.nseg = (j.n + dev::ENT_SEG - 1) / dev::ENT_SEG; j.seg_base = (int)out->segjobs.size();
 			j.frame = f; j.hole = (int)h;
 			if (f == 0) out->band_of_hole[h] = (int)out->bands.size();
-			for (int s = 0; s < j.nseg; s++) out->segband.push_back((int)out->bands.size());
+			for (int s = 0; s < j.nseg; s++) out->segjobs.push_back(dev::EntSegJob{ j.coeffs, j.n, s * dev::ENT_SEG, (int)out->bands.size() });
 			out->bands.push_back(j);
 		}
 	}

@@ -34,6 +34,7 @@ struct EntTables {
 	uint16_t run_count[3072];      // zeros covered by run_bits[]
 	uint8_t run_size[3072];
 	uint32_t band_end_bits; int band_end_size;
+	uint2 run_pack[3072];          // x = run_bits, y = run_size | run_count << 8: one load per run code in k_ent_emit
 };
 
 struct EntBandJob {
@@ -43,6 +44,13 @@ struct EntBandJob {
 	int frame, hole;               // frame of the batch, hole index in the frame's template
 };
 
+struct EntSegJob {                 // static per segment: everything k_ent_count / k_ent_emit need to find their coefficients with one scalar load
+	const int16_t *coeffs;         // band base
+	int n;                         // raster length of the band
+	int first;                     // raster index of the segment's first coefficient
+	int band;                      // band job index
+};
+
 struct EntSegState {               // per segment, written by k_ent_count / k_ent_scan
 	int first_nz, last_nz;         // raster index within the band, -1 when the segment is all zero
 	uint32_t bits;                 // k_ent_count: bits of its tokens without the run in front of first_nz; k_ent_scan: with it
@@ -50,7 +58,7 @@ struct EntSegState {               // per segment, written by k_ent_count / k_en
 	uint32_t bitoff;               // bit offset of its first token relative to the band payload
 };
 
-struct EntBandState { uint32_t seg_bits, tail_run, payload_bytes, base_byte; };
+struct EntBandState { uint32_t seg_bits, tail_run, payload_bytes, base_byte; uint8_t *out; /* payload address in the sample; null until k_ent_layout placed it */ };
 
 struct EntHole { int tmpl_offset, kind, fixed_bytes, band_job; const int16_t *lowpass; int lp_width, lp_height, lp_pitch; };
 struct EntPatch { int kind, at_tmpl, at_holes, start_tmpl, start_holes, end_tmpl, end_holes, tag; };
@@ -130,7 +138,7 @@ __device__ __forceinline__ uint32_t value_entry(const EntTables *T, int v)
 }
 
 // Loads the 16 coefficients of this lane (raster indices base .. base+15, zero beyond the band).
-__device__ __forceinline__ void ent_load16(const EntBandJob &job, int base, int *v)
+__device__ __forceinline__ void ent_load16(const EntSegJob &job, int base, int *v)
 {
 	if (base + ENT_PER_THREAD <= job.n) {
 		const uint4 q0 = *(const uint4 *)(job.coeffs + base), q1 = *(const uint4 *)(job.coeffs + base + 8);
@@ -152,13 +160,13 @@ __device__ __forceinline__ int wave_prev_nonzero(int my_last, int lane, unsigned
 }
 
 // =============================================================================================
-__global__ void __launch_bounds__(ENT_THREADS) k_ent_count(const EntBandJob *bands, const int *seg_band, int total_segs, EntSegState *segs, const EntTables *T)
+__global__ void __launch_bounds__(ENT_THREADS) k_ent_count(const EntSegJob *seg_jobs, int total_segs, EntSegState *segs, const EntTables *T)
 {
 	const int lane = wave_lane();
 	const int seg = wave_uniform((int)blockIdx.x * ENT_WAVES + (int)(threadIdx.x >> 6));
 	if (seg >= total_segs) return;                       // whole wave
-	const EntBandJob &job = bands[seg_band[seg]];
-	const int base = (seg - job.seg_base) * ENT_SEG + lane * ENT_PER_THREAD;
+	const EntSegJob job = seg_jobs[seg];
+	const int base = job.first + lane * ENT_PER_THREAD;
 	int v[ENT_PER_THREAD];
 	ent_load16(job, base, v);
 	int my_last = -1, my_first = -1;
@@ -216,7 +224,7 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_scan(const EntBandJob *band
 		b.tail_run = (uint32_t)(job.n - 1 - carry_prev);
 		uint32_t bits = carry_bits + run_bits_any(T, b.tail_run) + (uint32_t)T->band_end_size;
 		b.payload_bytes = ((bits + 31u) >> 5) << 2;
-		b.base_byte = 0;
+		b.base_byte = 0; b.out = nullptr;
 	}
 }
 
@@ -294,7 +302,7 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_layout(const EntFrameJob *f
 		} else {
 			const uint32_t bytes = band_state[hole.band_job].payload_bytes;
 			for (uint32_t i = tid; i < bytes / 4; i += ENT_THREADS) out[(base >> 2) + i] = 0;
-			if (tid == 0) band_state[hole.band_job].base_byte = base;
+			if (tid == 0) { band_state[hole.band_job].base_byte = base; band_state[hole.band_job].out = f.out + base; }
 		}
 	}
 	__syncthreads();
@@ -317,22 +325,20 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_layout(const EntFrameJob *f
 }
 
 // =============================================================================================
-__global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(const EntBandJob *bands, const int *seg_band, int total_segs, const EntSegState *segs,
-                                                           const EntBandState *band_state, const EntFrameJob *frames, const EntTables *T)
+__global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(const EntSegJob *seg_jobs, int total_segs, const EntSegState *segs, const EntBandState *band_state, const EntTables *T)
 {
 	__shared__ uint32_t s_words_all[ENT_WAVES][ENT_LDS_WORDS + 2];
 	const int lane = wave_lane();
 	const int wave = wave_uniform((int)(threadIdx.x >> 6));
 	const int seg = wave_uniform((int)blockIdx.x * ENT_WAVES + wave);
 	if (seg >= total_segs) return;
-	const int bj = seg_band[seg];
-	const EntBandJob &job = bands[bj];
+	const EntSegJob job = seg_jobs[seg];
 	const EntSegState st = segs[seg];
 	if (st.bits == 0) return;                            // wave-uniform: nothing starts in this segment
-	const EntFrameJob &f = frames[job.frame];
-	if (*f.sample_bytes == 0) return;                    // overflow detected by k_ent_layout
+	uint32_t *out = (uint32_t *)band_state[job.band].out;
+	if (!out) return;                                    // the sample overflowed its buffer (k_ent_layout reported size 0)
 	uint32_t *s_words = s_words_all[wave];
-	const int base = (seg - job.seg_base) * ENT_SEG + lane * ENT_PER_THREAD;
+	const int base = job.first + lane * ENT_PER_THREAD;
 	int v[ENT_PER_THREAD];
 	ent_load16(job, base, v);
 	int my_last = -1;
@@ -342,10 +348,13 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(const EntBandJob *band
 	if (prev < 0) prev = st.prev_nz;                     // the run in front of the segment's first nonzero reaches back into earlier segments
 	const int prev0 = prev;
 	uint32_t bits = 0;
+	uint32_t ve[ENT_PER_THREAD];                         // code words of the nonzero coefficients, looked up once
 #pragma unroll
 	for (int k = 0; k < ENT_PER_THREAD; k++) {
+		ve[k] = 0;
 		if (!v[k]) continue;
-		bits += run_bits_any(T, (uint32_t)(base + k - prev - 1)) + (value_entry(T, v[k]) >> 27);
+		ve[k] = value_entry(T, v[k]);
+		bits += run_bits_any(T, (uint32_t)(base + k - prev - 1)) + (ve[k] >> 27);
 		prev = base + k;
 	}
 	uint32_t incl = bits;                                // inclusive wave scan of the bit counts
@@ -353,7 +362,6 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(const EntBandJob *band
 	for (int d = 1; d < ENT_LANES; d <<= 1) { const uint32_t x = __shfl_up(incl, (unsigned)d); if (lane >= d) incl += x; }
 	const uint32_t my_off = incl - bits;
 
-	uint32_t *out = (uint32_t *)(f.out + band_state[bj].base_byte);
 	const uint64_t seg_pos = st.bitoff;                  // bit position of the segment inside the band payload
 	const uint32_t first_word = (uint32_t)(seg_pos >> 5), last_word = (uint32_t)((seg_pos + st.bits - 1) >> 5);
 	const uint32_t nwords = last_word - first_word + 1;
@@ -367,11 +375,11 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(const EntBandJob *band
 		for (int k = 0; k < ENT_PER_THREAD; k++) {
 			if (!v[k]) continue;
 			uint32_t run = (uint32_t)(base + k - prev - 1);
-			const uint32_t e = value_entry(T, v[k]);
+			const uint32_t e = ve[k];
 			// run codes, then the value code
 			for (int part = 0; ; part++) {
 				uint32_t code; int size;
-				if (run > 0) { const uint32_t idx = run < 3072 ? run : 3071; code = T->run_bits[idx]; size = T->run_size[idx]; run -= T->run_count[idx]; }
+				if (run > 0) { const uint2 rc = T->run_pack[run < 3072 ? run : 3071]; code = rc.x; size = (int)(rc.y & 0xffu); run -= rc.y >> 8; }
 				else { code = e & 0x7FFFFFFu; size = (int)(e >> 27); part = -1; }
 				const uint64_t val = (uint64_t)code << (64 - size - (int)(pos & 31));
 				const uint32_t hi = (uint32_t)(val >> 32), lo = (uint32_t)val;
