@@ -10,6 +10,7 @@ HBM peak (HIP events around every launch), `cpu_baseline` is the unmodified refe
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse, ctypes, json, os, sys, time
+os.environ.setdefault("HSA_ENABLE_SDMA", "1")   # D2H of the samples on the SDMA engines: blit-kernel copies stall the kernels they overlap with
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -134,14 +134,17 @@ int GpuEntropyEncoder::fetch_sizes()
 int GpuEntropyEncoder::download()
 {
 	hipStream_t st = (hipStream_t)stream_;
+	// CFHD_AMD_DOWNLOAD=kernel: k_ent_pack stores the dense samples straight into the pinned host buffer (device-visible), no copy
+	// command at all; default: pack in HBM, then one copy (SDMA engine when the runtime has it enabled).
+	static const bool direct = [] { const char *e = getenv("CFHD_AMD_DOWNLOAD"); return e && strcmp(e, "kernel") == 0; }();
 	(void)hipGetLastError();
 	dev::k_ent_pack_offsets<<<1, dev::ENT_THREADS, 0, st>>>(d_sizes_, n_, d_offsets_);
-	dev::k_ent_pack<<<dim3(8, (unsigned)n_), dev::ENT_THREADS, 0, st>>>(d_samples_, cap_, d_sizes_, d_offsets_, d_packed_);
+	dev::k_ent_pack<<<dim3(direct ? 2 : 8, (unsigned)n_), dev::ENT_THREADS, 0, st>>>(d_samples_, cap_, d_sizes_, d_offsets_, direct ? h_samples_ : d_packed_);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipMemcpyAsync(h_sizes_, d_sizes_, sizeof(uint32_t) * n_, hipMemcpyDeviceToHost, st));
 	HIPCHK(hipMemcpyAsync(h_offsets_, d_offsets_, sizeof(uint32_t) * (n_ + 1), hipMemcpyDeviceToHost, st));
 	HIPCHK(hipStreamSynchronize(st));
-	if (h_offsets_[n_]) HIPCHK(hipMemcpyAsync(h_samples_, d_packed_, h_offsets_[n_], hipMemcpyDeviceToHost, st));
+	if (!direct && h_offsets_[n_]) HIPCHK(hipMemcpyAsync(h_samples_, d_packed_, h_offsets_[n_], hipMemcpyDeviceToHost, st));
 	return 0;
 }
 

@@ -609,7 +609,11 @@ __global__ void __launch_bounds__(DECP_THREADS) k_dec_bands_par(const DecBandJob
 		__syncthreads();
 		uint32_t start = t ? (uint32_t)t * DECP_SUB_BITS : carry;
 		const uint32_t limit = (uint32_t)(t + 1) * DECP_SUB_BITS;
-		DecSub r = dec_sub<false>(s_words, s_lut1, T, start, limit, nullptr, 0u, 0u, 0);
+		// subsequences that begin behind the payload lie behind the band end marker as well: they start out finished, otherwise
+		// the marker would have to travel through them one lane per round
+		const bool behind = t && (uint64_t)seq0 * 32u + start >= (uint64_t)nwords * 32u;
+		if (behind) start = DECP_END;
+		DecSub r = behind ? DecSub{ DECP_END, 0u } : dec_sub<false>(s_words, s_lut1, T, start, limit, nullptr, 0u, 0u, 0);
 		for (int round = 0; ; round++) {
 			s_end[t] = r.end;
 			__syncthreads();
