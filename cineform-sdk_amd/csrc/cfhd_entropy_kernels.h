@@ -607,19 +607,20 @@ __global__ void __launch_bounds__(DECP_THREADS) k_dec_bands_par(const DecBandJob
 		__syncthreads();
 		for (int i = t; i < DECP_SEQ_WORDS + 4; i += DECP_THREADS) { const uint32_t w = seq0 + (uint32_t)i; s_words[i] = w < nwords ? bswap32(words[w]) : 0u; }
 		__syncthreads();
+		// only the subsequences that hold payload bits take part; the last of them stops at the end of the payload
+		const uint64_t left = (uint64_t)(nwords - seq0) * 32u;
+		const uint32_t seq_bits = left < (uint64_t)DECP_SEQ_BITS ? (uint32_t)left : (uint32_t)DECP_SEQ_BITS;
+		const int nsub = (int)((seq_bits + DECP_SUB_BITS - 1) / DECP_SUB_BITS);
+		const bool active = t < nsub;
 		uint32_t start = t ? (uint32_t)t * DECP_SUB_BITS : carry;
-		const uint32_t limit = (uint32_t)(t + 1) * DECP_SUB_BITS;
-		// subsequences that begin behind the payload lie behind the band end marker as well: they start out finished, otherwise
-		// the marker would have to travel through them one lane per round
-		const bool behind = t && (uint64_t)seq0 * 32u + start >= (uint64_t)nwords * 32u;
-		if (behind) start = DECP_END;
-		DecSub r = behind ? DecSub{ DECP_END, 0u } : dec_sub<false>(s_words, s_lut1, T, start, limit, nullptr, 0u, 0u, 0);
+		const uint32_t limit = (uint32_t)(t + 1) * DECP_SUB_BITS < seq_bits ? (uint32_t)(t + 1) * DECP_SUB_BITS : seq_bits;
+		DecSub r = active ? dec_sub<false>(s_words, s_lut1, T, start, limit, nullptr, 0u, 0u, 0) : DecSub{ DECP_END, 0u };
 		for (int round = 0; ; round++) {
 			s_end[t] = r.end;
 			__syncthreads();
 			if (t == 0) s_flag[(round + 1) & 1] = 0;
 			const uint32_t ns = t ? s_end[t - 1] : start;
-			const bool changed = ns != start;
+			const bool changed = active && ns != start;
 			if (changed) s_flag[round & 1] = 1;
 			__syncthreads();
 			if (!s_flag[round & 1]) break;
@@ -631,11 +632,12 @@ __global__ void __launch_bounds__(DECP_THREADS) k_dec_bands_par(const DecBandJob
 		}
 		int total;
 		const uint32_t my_idx = base_idx + (uint32_t)block_excl_sum((int)r.cnt, s_scan, &total);
-		const uint32_t last = s_end[DECP_THREADS - 1];
+		const uint32_t last = s_end[nsub - 1];
 		if (last == DECP_BAD) { err = 1; break; }
 		if ((uint32_t)total > n - base_idx) { err = 2; break; }   // more coefficients than the band holds
-		if (start < DECP_BAD && r.cnt) (void)dec_sub<true>(s_words, s_lut1, T, start, r.end, job.dst, my_idx, n, job.quant);
+		if (active && start < DECP_BAD && r.cnt) (void)dec_sub<true>(s_words, s_lut1, T, start, r.end, job.dst, my_idx, n, job.quant);
 		if (last == DECP_END) break;
+		if (seq_bits < (uint32_t)DECP_SEQ_BITS) { err = 3; break; }   // the payload ended without the band end marker
 		carry = last - DECP_SEQ_BITS;
 		base_idx += (uint32_t)total;
 	}
