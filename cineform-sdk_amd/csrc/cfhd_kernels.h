@@ -207,6 +207,22 @@ template <typename J> __device__ __forceinline__ void stage_job(J *dst, const J 
 	__syncthreads();
 }
 
+// XCD-aware tile order.  Workgroup b of a launch runs on XCD b % 8 (observed dispatch order, used for speed only) and every XCD has
+// its own L2, so in launch order horizontally adjacent tiles -- which share halo columns, i.e. whole cache lines of every band
+// row -- would sit behind different L2s and fetch those lines from HBM twice.  The logical tile index gives each XCD one
+// contiguous run of tiles (x fastest, then y, then the job) instead; neighbours then meet in the same L2 close in time.
+struct TileId { int x, y, z; };
+__device__ __forceinline__ TileId xcd_tile()
+{
+	const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+	const unsigned lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+	const unsigned q = total >> 3, r = total & 7u, xcd = lin & 7u, j = lin >> 3;
+	const unsigned logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+	TileId t;
+	t.x = (int)(logical % gx); t.y = (int)((logical / gx) % gy); t.z = (int)(logical / (gx * gy));
+	return t;
+}
+
 __device__ __forceinline__ int window_first_row(int r, int half_height, int height) { return r == 0 ? 0 : (r == half_height - 1 ? height - 6 : 2 * r - 2); }
 __device__ __forceinline__ int tile_first_row(int r0, int height) { int s = 2 * r0 - 2; if (s > height - 6) s = height - 6; return s < 0 ? 0 : s; }
 
@@ -215,11 +231,12 @@ __device__ __forceinline__ int tile_first_row(int r0, int height) { int s = 2 * 
 // =============================================================================================
 __global__ void __launch_bounds__(NTHREADS) k_fwd_plane(const FwdPlaneJob *jobs)
 {
+	const TileId tile = xcd_tile();
 	__shared__ FwdPlaneJob s_job;
-	stage_job(&s_job, &jobs[blockIdx.z]);
+	stage_job(&s_job, &jobs[tile.z]);
 	const FwdPlaneJob &job = s_job;
 	const int W = job.width, H = job.height, HW = W >> 1, HH = H >> 1;
-	const int c0 = blockIdx.x * TW, r0 = blockIdx.y * TH;
+	const int c0 = tile.x * TW, r0 = tile.y * TH;
 	__shared__ uint32_t s_in[ROWS][TW + 4];     // dword d of a row holds samples 2(c0-2+d), 2(c0-2+d)+1
 	__shared__ uint32_t s_l[ROWS][TW / 2];
 	__shared__ uint32_t s_h[ROWS][TW / 2];
@@ -278,13 +295,14 @@ __global__ void __launch_bounds__(NTHREADS) k_fwd_plane(const FwdPlaneJob *jobs)
 // =============================================================================================
 __global__ void __launch_bounds__(NTHREADS) k_fwd_yuv422(const FwdYuvJob *jobs)
 {
+	const TileId tile = xcd_tile();
 	__shared__ FwdYuvJob s_job;
-	stage_job(&s_job, &jobs[blockIdx.z]);
+	stage_job(&s_job, &jobs[tile.z]);
 	const FwdYuvJob &job = s_job;
 	const int W = job.width, H = job.height;          // luma samples
 	const int DW = W >> 1;                            // dwords per row = luma output columns = chroma samples
 	const int HH = H >> 1;
-	const int c0 = blockIdx.x * TW, r0 = blockIdx.y * TH;   // luma output tile origin
+	const int c0 = tile.x * TW, r0 = tile.y * TH;   // luma output tile origin
 	__shared__ uint32_t s_in[ROWS][TW + 4];           // dword d = packed pixel pair (c0 - 2 + d)
 	__shared__ uint32_t s_l[ROWS][TW];                // [0,32) luma pairs, [32,48) V pairs, [48,64) U pairs
 	__shared__ uint32_t s_h[ROWS][TW];
@@ -471,11 +489,12 @@ __device__ __forceinline__ void inv_stage_load(uint32_t (&va)[N], const int16_t 
 
 __global__ void __launch_bounds__(NTHREADS) k_inv_plane(const InvPlaneJob *jobs)
 {
+	const TileId tile = xcd_tile();
 	__shared__ InvPlaneJob s_job;
-	stage_job(&s_job, &jobs[blockIdx.z]);
+	stage_job(&s_job, &jobs[tile.z]);
 	const InvPlaneJob &job = s_job;
 	const int w = job.width, h = job.height;
-	const int c0 = blockIdx.x * ITW, r0 = blockIdx.y * ITH;
+	const int c0 = tile.x * ITW, r0 = tile.y * ITH;
 	__shared__ uint32_t s_low[2][ILROWS][IDW];          // LL, LH
 	__shared__ uint32_t s_high[2][ITH][IDW];            // HL, HH
 	__shared__ uint32_t s_v[2][2][ITH][IDW];            // [row parity][horizontal L/H]
@@ -572,12 +591,13 @@ __device__ __forceinline__ uint32_t dither_word(uint32_t seed, int row, int grou
 
 __global__ void __launch_bounds__(NTHREADS) k_inv_yuv422(const InvYuvJob *jobs, uint32_t launch_seed)
 {
+	const TileId tile = xcd_tile();
 	__shared__ InvYuvJob s_job;
-	stage_job(&s_job, &jobs[blockIdx.z]);
+	stage_job(&s_job, &jobs[tile.z]);
 	const InvYuvJob &job = s_job;
 	const uint32_t seed = job.dither_seed ^ launch_seed;
 	const int w = job.width, h = job.height;          // luma band ; chroma bands are w/2 wide
-	const int c0 = blockIdx.x * ITW, r0 = blockIdx.y * ITH;
+	const int c0 = tile.x * ITW, r0 = tile.y * ITH;
 	const int cw = w >> 1, cc0 = c0 >> 1;
 	enum { CDW = ITW / 2 + 4, CLD = CDW / 2 };          // chroma columns cc0-2 .. cc0+33, one (V, U) dword each; CLD dwords per band row to load
 	__shared__ uint32_t s_ylow[2][ILROWS][IDW], s_yhigh[2][ITH][IDW], s_vy[2][2][ITH][IDW];

@@ -15,6 +15,11 @@ def short_name(mangled):
     return mangled.replace(".kd", "")
 
 
+# kernels whose global loads are 16 bytes per lane: on gfx950 FETCH_SIZE counts such streaming reads at half their size
+# (MI355X_MICROARCH.md, HBM section; confirmed here by k_ent_pack, a plain copy: WRITE_SIZE = 2 x FETCH_SIZE)
+WIDE_LOADS = ("k_ent_count", "k_ent_emit", "k_ent_pack")
+
+
 def traffic_json(out, frames, dbs):
     acc = {}
     for path in dbs:
@@ -28,10 +33,12 @@ def traffic_json(out, frames, dbs):
     kernels = {}
     for k, v in acc.items():
         if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
-            kernels[k] = {"fetch_bytes_per_launch": int(v["FETCH_SIZE"]), "write_bytes_per_launch": int(v["WRITE_SIZE"]),
-                          "hbm_bytes_per_launch": int(v["FETCH_SIZE"] + v["WRITE_SIZE"])}
+            fetch = v["FETCH_SIZE"] * (2 if k in WIDE_LOADS else 1)
+            kernels[k] = {"fetch_bytes_per_launch": int(fetch), "write_bytes_per_launch": int(v["WRITE_SIZE"]),
+                          "hbm_bytes_per_launch": int(fetch + v["WRITE_SIZE"]), "fetch_counter_scale": 2 if k in WIDE_LOADS else 1}
     json.dump({"frames_per_launch": frames, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), KiB * 1024, largest launch of each kernel; "
-               "calibration: k_fwd_yuv422 WRITE_SIZE equals its band bytes exactly and FETCH_SIZE = packed input + 3 % halo with dword loads, so no gfx950 doubling is applied",
+               "calibration: k_fwd_yuv422 (dword loads) WRITE_SIZE equals its band bytes exactly and FETCH_SIZE = packed input + 3-5 % halo, so dword-load kernels are taken as reported; "
+               "kernels with 16-byte-per-lane loads (k_ent_count, k_ent_emit, k_ent_pack) are doubled as MI355X_MICROARCH.md prescribes (k_ent_pack, a plain copy, reports FETCH = WRITE / 2)",
                "kernels": kernels}, open(out, "w"), indent=1, sort_keys=True)
 
 
