@@ -184,8 +184,12 @@ def main():
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    frames_total = args.batch * args.steps * world
-    fps = frames_total / elapsed
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("frame_shards", os.path.join(ROOT, "cineform-sdk_amd", "host", "frame_shards.py"))
+    shards = importlib.util.module_from_spec(spec); spec.loader.exec_module(shards)
+    # weak scaling: every rank owns `batch` frames per step (rank r = frames [r*batch, (r+1)*batch) of each step's sequence), no data-path collective
+    assert shards.shard_bounds(args.batch * world, rank, world) == (rank * args.batch, (rank + 1) * args.batch)
+    fps = shards.whole_job_rate(args.batch * args.steps, world, elapsed)
 
     if rank == 0:
         kms = {k: v / args.steps for k, v in kms.items()}
