@@ -174,14 +174,20 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_count(const EntSegJob *seg_
 	for (int k = 0; k < ENT_PER_THREAD; k++) if (v[k]) { my_last = base + k; if (my_first < 0) my_first = base + k; }
 	const unsigned long long mask = __ballot(my_last >= 0);
 	int prev = wave_prev_nonzero(my_last, lane, mask);
-	uint32_t bits = 0;
+	// zero run in front of every nonzero coefficient (registers only), then all table lookups back to back (no branch in
+	// between: the loads overlap instead of one round trip per token), then the sum
+	uint32_t run[ENT_PER_THREAD];
 #pragma unroll
 	for (int k = 0; k < ENT_PER_THREAD; k++) {
-		if (!v[k]) continue;
-		if (prev >= 0) bits += T->run_total[base + k - prev - 1];  // run inside the segment: < 1024
-		bits += value_entry(T, v[k]) >> 27;
-		prev = base + k;
+		run[k] = 0;
+		if (v[k]) { if (prev >= 0) run[k] = (uint32_t)(base + k - prev - 1); prev = base + k; }   // inside the segment: < 1024
 	}
+	uint32_t ve[ENT_PER_THREAD], rt[ENT_PER_THREAD];
+#pragma unroll
+	for (int k = 0; k < ENT_PER_THREAD; k++) { ve[k] = value_entry(T, v[k]); rt[k] = T->run_total[run[k]]; }
+	uint32_t bits = 0;
+#pragma unroll
+	for (int k = 0; k < ENT_PER_THREAD; k++) if (v[k]) bits += rt[k] + (ve[k] >> 27);
 #pragma unroll
 	for (int m = 32; m > 0; m >>= 1) bits += __shfl_xor(bits, m);
 	const int first_nz = __shfl(my_first, mask ? __builtin_ctzll(mask) : 0), last_nz = __shfl(my_last, mask ? 63 - __builtin_clzll(mask) : 0);
@@ -346,16 +352,25 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(const EntSegJob *seg_j
 	for (int k = 0; k < ENT_PER_THREAD; k++) if (v[k]) my_last = base + k;
 	int prev = wave_prev_nonzero(my_last, lane, __ballot(my_last >= 0));
 	if (prev < 0) prev = st.prev_nz;                     // the run in front of the segment's first nonzero reaches back into earlier segments
-	const int prev0 = prev;
-	uint32_t bits = 0;
-	uint32_t ve[ENT_PER_THREAD];                         // code words of the nonzero coefficients, looked up once
+	// zero run in front of every nonzero coefficient (registers only), then every table lookup of the lane back to back
+	uint32_t run[ENT_PER_THREAD];
 #pragma unroll
 	for (int k = 0; k < ENT_PER_THREAD; k++) {
-		ve[k] = 0;
+		run[k] = 0;
+		if (v[k]) { run[k] = (uint32_t)(base + k - prev - 1); prev = base + k; }
+	}
+	uint32_t ve[ENT_PER_THREAD], rt[ENT_PER_THREAD];     // value code words; bits of the whole run in front (all its composite codes)
+	uint2 rp[ENT_PER_THREAD];                            // first composite run code
+#pragma unroll
+	for (int k = 0; k < ENT_PER_THREAD; k++) {
+		const uint32_t r = run[k] < 3072u ? run[k] : 3071u;
+		ve[k] = value_entry(T, v[k]); rt[k] = T->run_total[r]; rp[k] = T->run_pack[r];
+	}
+	uint32_t bits = 0;
+#pragma unroll
+	for (int k = 0; k < ENT_PER_THREAD; k++) {
 		if (!v[k]) continue;
-		ve[k] = value_entry(T, v[k]);
-		bits += run_bits_any(T, (uint32_t)(base + k - prev - 1)) + (ve[k] >> 27);
-		prev = base + k;
+		bits += (run[k] < 3072u ? rt[k] : run_bits_any(T, run[k])) + (ve[k] >> 27);   // only a segment's first token can reach back that far
 	}
 	uint32_t incl = bits;                                // inclusive wave scan of the bit counts
 #pragma unroll
@@ -370,26 +385,25 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(const EntSegJob *seg_j
 	CFHD_WAVE_SYNC();
 	{
 		uint64_t pos = seg_pos + my_off;
-		prev = prev0;
 #pragma unroll
 		for (int k = 0; k < ENT_PER_THREAD; k++) {
 			if (!v[k]) continue;
-			uint32_t run = (uint32_t)(base + k - prev - 1);
-			const uint32_t e = ve[k];
-			// run codes, then the value code
-			for (int part = 0; ; part++) {
+			uint32_t left = run[k];
+			uint2 rc = rp[k];
+			// run codes (the first one is already in registers), then the value code
+			for (bool last = false; !last;) {
 				uint32_t code; int size;
-				if (run > 0) { const uint2 rc = T->run_pack[run < 3072 ? run : 3071]; code = rc.x; size = (int)(rc.y & 0xffu); run -= rc.y >> 8; }
-				else { code = e & 0x7FFFFFFu; size = (int)(e >> 27); part = -1; }
+				if (left > 0) {
+					code = rc.x; size = (int)(rc.y & 0xffu); left -= rc.y >> 8;
+					if (left > 0) rc = T->run_pack[left < 3072u ? left : 3071u];
+				} else { code = ve[k] & 0x7FFFFFFu; size = (int)(ve[k] >> 27); last = true; }
 				const uint64_t val = (uint64_t)code << (64 - size - (int)(pos & 31));
 				const uint32_t hi = (uint32_t)(val >> 32), lo = (uint32_t)val;
 				const uint32_t w = (uint32_t)(pos >> 5);
 				if (use_lds) { atomic_or_u32(&s_words[w - first_word], hi); if (lo) atomic_or_u32(&s_words[w - first_word + 1], lo); }
 				else { atomic_or_u32(&out[w], bswap32(hi)); if (lo) atomic_or_u32(&out[w + 1], bswap32(lo)); }
 				pos += size;
-				if (part < 0) break;
 			}
-			prev = base + k;
 		}
 	}
 	CFHD_WAVE_SYNC();
