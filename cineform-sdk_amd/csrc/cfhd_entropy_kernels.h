@@ -334,6 +334,7 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_layout(const EntFrameJob *f
 __global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(const EntSegJob *seg_jobs, int total_segs, const EntSegState *segs, const EntBandState *band_state, const EntTables *T)
 {
 	__shared__ uint32_t s_words_all[ENT_WAVES][ENT_LDS_WORDS + 2];
+	__shared__ uint32_t s_tok_all[ENT_WAVES][ENT_SEG];   // the segment's tokens, compacted: local raster index << 16 | value (16 bits)
 	const int lane = wave_lane();
 	const int wave = wave_uniform((int)(threadIdx.x >> 6));
 	const int seg = wave_uniform((int)blockIdx.x * ENT_WAVES + wave);
@@ -343,60 +344,61 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(const EntSegJob *seg_j
 	if (st.bits == 0) return;                            // wave-uniform: nothing starts in this segment
 	uint32_t *out = (uint32_t *)band_state[job.band].out;
 	if (!out) return;                                    // the sample overflowed its buffer (k_ent_layout reported size 0)
-	uint32_t *s_words = s_words_all[wave];
-	const int base = job.first + lane * ENT_PER_THREAD;
+	uint32_t *s_words = s_words_all[wave], *s_tok = s_tok_all[wave];
 	int v[ENT_PER_THREAD];
-	ent_load16(job, base, v);
-	int my_last = -1;
+	ent_load16(job, job.first + lane * ENT_PER_THREAD, v);
+	// 1. compact the nonzero coefficients of the wave into a token list: the picture is sparse (about one coefficient in eight
+	//    is nonzero), so from here on the work is spread evenly over the lanes, one token per lane and round
+	int cnt = 0;
 #pragma unroll
-	for (int k = 0; k < ENT_PER_THREAD; k++) if (v[k]) my_last = base + k;
-	int prev = wave_prev_nonzero(my_last, lane, __ballot(my_last >= 0));
-	if (prev < 0) prev = st.prev_nz;                     // the run in front of the segment's first nonzero reaches back into earlier segments
-	// zero run in front of every nonzero coefficient (registers only), then every table lookup of the lane back to back
-	uint32_t run[ENT_PER_THREAD];
+	for (int k = 0; k < ENT_PER_THREAD; k++) cnt += v[k] != 0;
+	int incl = cnt;
 #pragma unroll
-	for (int k = 0; k < ENT_PER_THREAD; k++) {
-		run[k] = 0;
-		if (v[k]) { run[k] = (uint32_t)(base + k - prev - 1); prev = base + k; }
+	for (int d = 1; d < ENT_LANES; d <<= 1) { const int x = __shfl_up(incl, (unsigned)d); if (lane >= d) incl += x; }
+	const int ntok = __shfl(incl, ENT_LANES - 1);
+	{
+		int at = incl - cnt;
+#pragma unroll
+		for (int k = 0; k < ENT_PER_THREAD; k++)
+			if (v[k]) s_tok[at++] = ((uint32_t)(lane * ENT_PER_THREAD + k) << 16) | (uint32_t)(uint16_t)v[k];
 	}
-	uint32_t ve[ENT_PER_THREAD], rt[ENT_PER_THREAD];     // value code words; bits of the whole run in front (all its composite codes)
-	uint2 rp[ENT_PER_THREAD];                            // first composite run code
-#pragma unroll
-	for (int k = 0; k < ENT_PER_THREAD; k++) {
-		const uint32_t r = run[k] < 3072u ? run[k] : 3071u;
-		ve[k] = value_entry(T, v[k]); rt[k] = T->run_total[r]; rp[k] = T->run_pack[r];
-	}
-	uint32_t bits = 0;
-#pragma unroll
-	for (int k = 0; k < ENT_PER_THREAD; k++) {
-		if (!v[k]) continue;
-		bits += (run[k] < 3072u ? rt[k] : run_bits_any(T, run[k])) + (ve[k] >> 27);   // only a segment's first token can reach back that far
-	}
-	uint32_t incl = bits;                                // inclusive wave scan of the bit counts
-#pragma unroll
-	for (int d = 1; d < ENT_LANES; d <<= 1) { const uint32_t x = __shfl_up(incl, (unsigned)d); if (lane >= d) incl += x; }
-	const uint32_t my_off = incl - bits;
-
 	const uint64_t seg_pos = st.bitoff;                  // bit position of the segment inside the band payload
 	const uint32_t first_word = (uint32_t)(seg_pos >> 5), last_word = (uint32_t)((seg_pos + st.bits - 1) >> 5);
 	const uint32_t nwords = last_word - first_word + 1;
 	const bool use_lds = nwords <= ENT_LDS_WORDS;        // wave-uniform
 	if (use_lds) for (int i = lane; i < (int)nwords + 1; i += ENT_LANES) s_words[i] = 0;
 	CFHD_WAVE_SYNC();
-	{
-		uint64_t pos = seg_pos + my_off;
+	// 2. one token per lane and round: zero run in front (distance to the previous token; the segment's first token reaches back
+	//    to the last nonzero of the earlier segments), table lookups back to back, bit position by a wave scan, code words OR-ed
+	//    into the wave's LDS window
+	uint64_t round_pos = seg_pos;
+	for (int t0 = 0; t0 < ntok; t0 += ENT_LANES) {
+		const int t = t0 + lane;
+		const bool have = t < ntok;
+		const uint32_t tok = have ? s_tok[t] : 0u;
+		const uint32_t before = (have && t > 0) ? s_tok[t - 1] : 0u;
+		const int lp = (int)(tok >> 16);
+		uint32_t run = t > 0 ? (uint32_t)(lp - (int)(before >> 16) - 1) : (uint32_t)(job.first + lp - st.prev_nz - 1);
+		if (!have) run = 0;
+		const uint32_t r = run < 3072u ? run : 3071u;
+		const uint32_t ve = value_entry(T, (int)(int16_t)(tok & 0xffffu));
+		const uint32_t rt = T->run_total[r];
+		uint2 rc = T->run_pack[r];
+		uint32_t bits = 0;
+		if (have) bits = (run < 3072u ? rt : run_bits_any(T, run)) + (ve >> 27);
+		uint32_t sc = bits;
 #pragma unroll
-		for (int k = 0; k < ENT_PER_THREAD; k++) {
-			if (!v[k]) continue;
-			uint32_t left = run[k];
-			uint2 rc = rp[k];
-			// run codes (the first one is already in registers), then the value code
+		for (int d = 1; d < ENT_LANES; d <<= 1) { const uint32_t x = __shfl_up(sc, (unsigned)d); if (lane >= d) sc += x; }
+		uint64_t pos = round_pos + (sc - bits);
+		round_pos += __shfl(sc, ENT_LANES - 1);
+		if (have) {
+			uint32_t left = run;
 			for (bool last = false; !last;) {
 				uint32_t code; int size;
 				if (left > 0) {
 					code = rc.x; size = (int)(rc.y & 0xffu); left -= rc.y >> 8;
 					if (left > 0) rc = T->run_pack[left < 3072u ? left : 3071u];
-				} else { code = ve[k] & 0x7FFFFFFu; size = (int)(ve[k] >> 27); last = true; }
+				} else { code = ve & 0x7FFFFFFu; size = (int)(ve >> 27); last = true; }
 				const uint64_t val = (uint64_t)code << (64 - size - (int)(pos & 31));
 				const uint32_t hi = (uint32_t)(val >> 32), lo = (uint32_t)val;
 				const uint32_t w = (uint32_t)(pos >> 5);
