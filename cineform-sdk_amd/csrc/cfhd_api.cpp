@@ -31,7 +31,8 @@ enum {
 };
 
 #define FOURCC_BE(a, b, c, d) (((uint32_t)(a) << 24) | ((uint32_t)(b) << 16) | ((uint32_t)(c) << 8) | (uint32_t)(d))
-static const uint32_t FMT_YUY2 = FOURCC_BE('Y', 'U', 'Y', '2'), FMT_2VUY = FOURCC_BE('2', 'v', 'u', 'y'), FMT_YUYV = FOURCC_BE('y', 'u', 'y', 'v');
+static const uint32_t FMT_YUY2 = FOURCC_BE('Y', 'U', 'Y', '2'), FMT_2VUY = FOURCC_BE('2', 'v', 'u', 'y'), FMT_YUYV = FOURCC_BE('y', 'u', 'y', 'v'),
+                      FMT_RG48 = FOURCC_BE('R', 'G', '4', '8');
 
 namespace {
 
@@ -52,9 +53,12 @@ int pixel_kind_of(uint32_t fmt)
 {
 	if (fmt == FMT_YUY2 || fmt == FMT_YUYV) return PIX_YUY2;
 	if (fmt == FMT_2VUY) return PIX_2VUY;
+	if (fmt == FMT_RG48) return PIX_RG48;
 	return PIX_NONE;
 }
-int color_format_of(int kind) { return kind == PIX_2VUY ? 1 : 2; }           // COLOR_FORMAT_UYVY / COLOR_FORMAT_YUYV (Codec/color.h:64-65)
+// COLOR_FORMAT_UYVY = 1 / COLOR_FORMAT_YUYV = 2 / COLOR_FORMAT_RG48 = 120 (Codec/color.h)
+int color_format_of(int kind) { return kind == PIX_2VUY ? 1 : (kind == PIX_RG48 ? 120 : 2); }
+int pixel_bytes_of(int kind) { return kind == PIX_RG48 ? 6 : 2; }
 
 // ---- metadata handle shared by the encoder-side API (CSampleEncodeMetadata) ----
 struct EncMetadata {
@@ -147,21 +151,25 @@ int make_params(EncodeParams &p, int w, int h, uint32_t fmt, int encoded, uint32
 	p.valid = false;
 	int kind = pixel_kind_of(fmt);
 	if (kind == PIX_NONE) return ERR_BADFORMAT;
-	if (encoded != 0) return ERR_BADFORMAT;                               // CFHD_ENCODED_FORMAT_YUV_422 only (round 1 scope)
+	// CFHD_ENCODED_FORMAT_YUV_422 (0) from the packed 4:2:2 formats, CFHD_ENCODED_FORMAT_RGB_444 (1) from RG48; the cross
+	// combinations (4:4:4 input subsampled to 4:2:2, ...) go through ConvertLib in the reference and are not built
+	const bool rgb = kind == PIX_RG48;
+	if (encoded != (rgb ? 1 : 0)) return ERR_BADFORMAT;
 	if (flags & (1u << 0)) return ERR_BADFORMAT;                          // interlaced: not built yet
 	if (flags & (1u << 1)) return ERR_BADFORMAT;                          // 2-frame GOP: out of scope
-	p.width = w; p.height = h; p.pixel_format = fmt; p.pixel_kind = kind; p.encoded_format = ENC_YUV422; p.flags = flags;
+	const int enc = rgb ? ENC_RGB444 : ENC_YUV422;
+	p.width = w; p.height = h; p.pixel_format = fmt; p.pixel_kind = kind; p.encoded_format = enc; p.flags = flags;
 	p.quality = quality; p.progressive = true;
 	const int yuv601 = (flags & (1u << 2)) ? 1 : 2, vsrgb = (flags & (1u << 8)) ? 2 : 1;   // SampleEncoder.cpp:210-212
-	p.color_space = (yuv601 == 1 ? 1 : 2) | (vsrgb == 2 ? 4 : 0);
-	if (!build_frame_plan(&p.plan, w, h, kind, ENC_YUV422)) return ERR_BADFORMAT;
+	p.color_space = rgb ? 0 : ((yuv601 == 1 ? 1 : 2) | (vsrgb == 2 ? 4 : 0));           // RGB 4:4:4 samples carry no colour space tag
+	if (!build_frame_plan(&p.plan, w, h, kind, enc)) return ERR_BADFORMAT;
 	p.qstate = {0, -1, 0};
 	derive_quantization(&p.plan, quality, true, 0.0f, &p.qstate);
 	p.valid = true;
 	return ERR_OKAY;
 }
 
-size_t sample_capacity(const EncodeParams &p) { return (size_t)p.width * p.height * 2 + 65536; }   // SampleEncoder.cpp:387
+size_t sample_capacity(const EncodeParams &p) { return (size_t)p.width * p.height * pixel_bytes_of(p.pixel_kind) + 65536; }   // SampleEncoder.cpp:387
 
 // Where the run-length/VLC stage runs: on the GPU by default; CFHD_AMD_ENTROPY=host keeps the reference's arrangement
 // (host threads fed by one D2H copy of the quantized bands).  Both produce the same bytes.
@@ -334,9 +342,9 @@ CFHD_Error CFHD_OpenEncoder(CFHD_EncoderRef *out, CFHD_ALLOCATOR *)
 CFHD_Error CFHD_GetInputFormats(CFHD_EncoderRef ref, CFHD_PixelFormat *arr, int len, int *count)
 {
 	if (!ref || !arr) return ERR_INVALID_ARGUMENT;
-	const uint32_t fmts[] = { FMT_YUY2, FMT_2VUY };
+	const uint32_t fmts[] = { FMT_YUY2, FMT_2VUY, FMT_RG48 };
 	int n = 0;
-	for (; n < 2 && n < len; n++) arr[n] = fmts[n];
+	for (; n < 3 && n < len; n++) arr[n] = fmts[n];
 	if (count) *count = n;
 	return ERR_OKAY;
 }
@@ -602,9 +610,9 @@ CFHD_Error CFHD_OpenDecoder(CFHD_DecoderRef *out, CFHD_ALLOCATOR *)
 CFHD_Error CFHD_GetOutputFormats(CFHD_DecoderRef ref, void *, size_t, CFHD_PixelFormat *arr, int len, int *count)
 {
 	if (!ref || !arr) return ERR_INVALID_ARGUMENT;
-	const uint32_t fmts[] = { FMT_YUY2, FMT_2VUY };
+	const uint32_t fmts[] = { FMT_YUY2, FMT_2VUY, FMT_RG48 };
 	int n = 0;
-	for (; n < 2 && n < len; n++) arr[n] = fmts[n];
+	for (; n < 3 && n < len; n++) arr[n] = fmts[n];
 	if (count) *count = n;
 	return ERR_OKAY;
 }
@@ -637,9 +645,12 @@ CFHD_Error CFHD_PrepareToDecode(CFHD_DecoderRef ref, int, int, CFHD_PixelFormat 
 	Decoder *d = (Decoder *)ref;
 	if (parse_sample((const uint8_t *)sample, size, &d->header) < 0) return ERR_BADSAMPLE;
 	if (resolution != 1 && resolution != 0) return ERR_BAD_RESOLUTION;                 // full resolution only (round 1 scope)
-	if (d->header.encoded_format != ENC_YUV422 || d->header.transform_type != 0) return ERR_BADFORMAT;
+	if ((d->header.encoded_format != ENC_YUV422 && d->header.encoded_format != ENC_RGB444) || d->header.transform_type != 0) return ERR_BADFORMAT;
 	int kind = pixel_kind_of(fmt);
 	if (kind == PIX_NONE) return ERR_BADFORMAT;
+	// 4:2:2 samples decode to the packed 4:2:2 formats, RGB 4:4:4 samples to RG48 (wavelet.c:4947); colour conversions between the
+	// families (ConvertLib / the active-metadata pipeline in the reference) are not built
+	if ((d->header.encoded_format == ENC_RGB444) != (kind == PIX_RG48)) return ERR_BADFORMAT;
 	bool ok;
 	plan_from_sample(d->header, kind, &d->plan, &ok);
 	if (!ok) return ERR_BADSAMPLE;
@@ -705,10 +716,10 @@ CFHD_Error CFHD_DecodeSample(CFHD_DecoderRef ref, void *sample, size_t size, voi
 	    ps.num_channels != d->plan.num_channels) return fail_zero(ERR_BADSAMPLE);
 	if (!d->batch_ready) {
 		if (d->batch.prepare(d->plan, 1, d->out_kind, true)) return ERR_INTERNAL;
-		if (gpu_entropy_enabled() && d->batch.prepare_entropy((size_t)d->plan.width * d->plan.height * 2 + 65536)) return ERR_INTERNAL;
+		if (gpu_entropy_enabled() && d->batch.prepare_entropy((size_t)d->plan.width * d->plan.height * pixel_bytes_of(d->out_kind) + 65536)) return ERR_INTERNAL;
 		d->batch_ready = true;
 	}
-	if (d->batch.has_entropy() && size <= (size_t)d->plan.width * d->plan.height * 2 + 65536) {
+	if (d->batch.has_entropy() && size <= (size_t)d->plan.width * d->plan.height * pixel_bytes_of(d->out_kind) + 65536) {
 		// GPU entropy decoder: ship the sample bytes, one lane per band rebuilds the pyramid in HBM
 		if (d->batch.entropy().set_sample_host(0, s, size)) return fail_zero(ERR_BADSAMPLE);
 		if (d->batch.entropy().launch()) return ERR_INTERNAL;

@@ -213,7 +213,10 @@ void walk_sample(Sink &w, const FramePlan &plan, const SampleHeaderInfo &hdr)
 	{
 		unsigned table = 0;
 		for (int i = 0; i < kNumLevels; i++) table += (unsigned)plan.prescale[i] << (14 - i * 2);
-		w.tag_opt(TAG_PRESCALE_TABLE, (int)table);
+		// optional only while the table equals the decoder's built-in 10-bit spatial default {0,2,0} (codec.c:1515-1524,
+		// TestTransformPrescaleMatch wavelet.c:1784): the 12-bit table {0,2,2} must be transmitted
+		const bool is_default = plan.prescale[0] == 0 && plan.prescale[1] == 2 && plan.prescale[2] == 0;
+		if (is_default) w.tag_opt(TAG_PRESCALE_TABLE, (int)table); else w.tag(TAG_PRESCALE_TABLE, (int)table);
 	}
 
 	if (hdr.channel_number_tag) w.tag_opt(TAG_ENCODED_CHANNEL_NUMBER, 0);

@@ -40,9 +40,10 @@ dev::QuantParam make_q(int divisor, int mpq)
 }
 
 struct EncJobs {            // layout of the job table buffer of an EncodeBatch
-	dev::FwdYuvJob *yuv;    // [n]
+	dev::FwdYuvJob *yuv;    // [n]         level 1 of the packed 4:2:2 formats
 	dev::FwdPlaneJob *l2;   // [n * nch]
 	dev::FwdPlaneJob *l3;   // [n * nch]
+	dev::FwdPlaneJob *l1;   // [n * nch]   level 1 of the interleaved 16-bit 4:4:4(:4) formats (k_fwd_packed16)
 };
 EncJobs enc_jobs_at(void *base, int n, int nch)
 {
@@ -50,20 +51,32 @@ EncJobs enc_jobs_at(void *base, int n, int nch)
 	j.yuv = (dev::FwdYuvJob *)base;
 	j.l2 = (dev::FwdPlaneJob *)(j.yuv + n);
 	j.l3 = j.l2 + (size_t)n * nch;
+	j.l1 = j.l3 + (size_t)n * nch;
 	return j;
 }
-size_t enc_jobs_bytes(int n, int nch) { return (size_t)n * sizeof(dev::FwdYuvJob) + 2 * (size_t)n * nch * sizeof(dev::FwdPlaneJob); }
+size_t enc_jobs_bytes(int n, int nch) { return (size_t)n * sizeof(dev::FwdYuvJob) + 3 * (size_t)n * nch * sizeof(dev::FwdPlaneJob); }
 
-struct DecJobs { dev::InvPlaneJob *l3, *l2; dev::InvYuvJob *yuv; };
+struct DecJobs { dev::InvPlaneJob *l3, *l2; dev::InvYuvJob *yuv; dev::InvPlaneJob *l1; /* last level of the 4:4:4(:4) formats (k_inv_packed16) */ };
 DecJobs dec_jobs_at(void *base, int n, int nch)
 {
 	DecJobs j;
 	j.l3 = (dev::InvPlaneJob *)base;
 	j.l2 = j.l3 + (size_t)n * nch;
 	j.yuv = (dev::InvYuvJob *)(j.l2 + (size_t)n * nch);
+	j.l1 = (dev::InvPlaneJob *)(j.yuv + n);
 	return j;
 }
-size_t dec_jobs_bytes(int n, int nch) { return 2 * (size_t)n * nch * sizeof(dev::InvPlaneJob) + (size_t)n * sizeof(dev::InvYuvJob); }
+size_t dec_jobs_bytes(int n, int nch) { return 3 * (size_t)n * nch * sizeof(dev::InvPlaneJob) + (size_t)n * sizeof(dev::InvYuvJob); }
+
+// Word of component plane c inside an interleaved 16-bit pixel: planes are G, R, B(, A) (frame.c:6128-6157, convert.c:6750-6752),
+// RG48 pixels are R, G, B.
+int packed_word_of_channel(int pixel_kind, int c)
+{
+	static const int rg48[4] = { 1, 0, 2, 3 };
+	(void)pixel_kind;
+	return rg48[c & 3];
+}
+bool is_packed16(int pixel_kind) { return pixel_kind == PIX_RG48; }
 } // namespace
 
 const char *device_last_error() { return g_err.c_str(); }
@@ -131,7 +144,7 @@ int EncodeBatch::prepare(const FramePlan &plan, int nframes, bool own_input)
 	int rc = device_init();
 	if (rc) return rc;
 	release();
-	if (plan.pixel_kind != PIX_YUY2 && plan.pixel_kind != PIX_2VUY) { g_err = "pixel format not supported by the GPU path yet"; return -2; }
+	if (plan.pixel_kind != PIX_YUY2 && plan.pixel_kind != PIX_2VUY && !is_packed16(plan.pixel_kind)) { g_err = "pixel format not supported by the GPU path yet"; return -2; }
 	plan_ = plan; n_ = nframes; own_input_ = own_input;
 	HIPCHK(hipStreamCreateWithFlags((hipStream_t *)&stream_, hipStreamNonBlocking));
 	HIPCHK(hipEventCreate((hipEvent_t *)&ev0_));
@@ -163,11 +176,22 @@ int EncodeBatch::prepare(const FramePlan &plan, int nframes, bool own_input)
 			y.out_pitch[c] = plan.ch[c].band[0][0].pitch;
 			for (int b = 0; b < 4; b++) { y.out[c][b] = base + plan.ch[c].band[0][b].offset; y.q[c][b] = make_q(plan.ch[c].band[0][b].quant, mpq); }
 		}
+		if (is_packed16(plan.pixel_kind))
+			for (int c = 0; c < nch; c++) {
+				dev::FwdPlaneJob &p = j.l1[(size_t)i * nch + c];
+				const uint16_t *frame = own_input ? (const uint16_t *)(d_in_ + frame_bytes_ * i) : nullptr;
+				p.in = frame ? (const int16_t *)(frame + packed_word_of_channel(plan.pixel_kind, c)) : nullptr; p.in_pitch = in_pitch_ / 2;
+				p.width = plan.ch[c].width; p.height = plan.ch[c].height; p.prescale = plan.prescale[0];
+				p.xstride = nch; p.shift = 16 - plan.precision; p.display_height = plan.display_height;
+				p.out_pitch = plan.ch[c].band[0][0].pitch;
+				for (int b = 0; b < 4; b++) { p.out[b] = base + plan.ch[c].band[0][b].offset; p.q[b] = make_q(plan.ch[c].band[0][b].quant, mpq); }
+			}
 		for (int lv = 1; lv < 3; lv++)
 			for (int c = 0; c < nch; c++) {
 				dev::FwdPlaneJob &p = (lv == 1 ? j.l2 : j.l3)[(size_t)i * nch + c];
 				const BandDesc &src = plan.ch[c].band[lv - 1][0];
 				p.in = base + src.offset; p.in_pitch = src.pitch; p.width = src.width; p.height = src.height; p.prescale = plan.prescale[lv];
+				p.xstride = 1; p.shift = 0; p.display_height = src.height;
 				p.out_pitch = plan.ch[c].band[lv][0].pitch;
 				for (int b = 0; b < 4; b++) { p.out[b] = base + plan.ch[c].band[lv][b].offset; p.q[b] = make_q(plan.ch[c].band[lv][b].quant, mpq); }
 			}
@@ -207,6 +231,14 @@ int EncodeBatch::set_device_frame(int i, const void *d_frame, int pitch)
 {
 	if (i < 0 || i >= n_) return -1;
 	EncJobs j = enc_jobs_at(h_jobs_, n_, plan_.num_channels);
+	if (is_packed16(plan_.pixel_kind)) {
+		for (int c = 0; c < plan_.num_channels; c++) {
+			dev::FwdPlaneJob &p = j.l1[(size_t)i * plan_.num_channels + c];
+			p.in = (const int16_t *)((const uint16_t *)d_frame + packed_word_of_channel(plan_.pixel_kind, c)); p.in_pitch = pitch / 2;
+		}
+		jobs_dirty_ = true;
+		return 0;
+	}
 	if (j.yuv[i].in != d_frame || j.yuv[i].in_pitch != pitch) { j.yuv[i].in = (const uint8_t *)d_frame; j.yuv[i].in_pitch = pitch; jobs_dirty_ = true; }
 	return 0;
 }
@@ -221,7 +253,10 @@ int EncodeBatch::launch_forward()
 	(void)hipGetLastError();                            // drop stale sticky errors: the check below is for these launches only
 	timed_ = true;
 	HIPCHK(hipEventRecord((hipEvent_t)ev0_, st));
-	{
+	if (is_packed16(plan_.pixel_kind)) {
+		dim3 grid(((plan_.width / 2 + dev::TW - 1) / dev::TW) * nch, (plan_.height / 2 + dev::TH - 1) / dev::TH, n_);
+		dev::k_fwd_packed16<<<grid, dev::NTHREADS, 0, st>>>(j.l1, nch);
+	} else {
 		dim3 grid((plan_.width / 2 + dev::TW - 1) / dev::TW, (plan_.height / 2 + dev::TH - 1) / dev::TH, n_);
 		dev::k_fwd_yuv422<<<grid, dev::NTHREADS, 0, st>>>(j.yuv);
 	}
@@ -285,7 +320,9 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 	int rc = device_init();
 	if (rc) return rc;
 	release();
-	if ((out_kind != PIX_YUY2 && out_kind != PIX_2VUY) || plan.encoded_format != ENC_YUV422) { g_err = "output format not supported by the GPU path yet"; return -2; }
+	const bool yuv_ok = (out_kind == PIX_YUY2 || out_kind == PIX_2VUY) && plan.encoded_format == ENC_YUV422;
+	const bool rgb_ok = out_kind == PIX_RG48 && plan.encoded_format == ENC_RGB444 && plan.ch[0].band[0][0].width >= 16;   // k_inv_packed16's tail-column rule assumes the reference's vector path
+	if (!yuv_ok && !rgb_ok) { g_err = "output format not supported by the GPU path yet"; return -2; }
 	plan_ = plan; n_ = nframes; out_kind_ = out_kind; own_output_ = own_output;
 	HIPCHK(hipStreamCreateWithFlags((hipStream_t *)&stream_, hipStreamNonBlocking));
 	HIPCHK(hipEventCreate((hipEvent_t *)&ev0_));
@@ -318,7 +355,20 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 				p.width = plan.ch[c].band[lv][0].width; p.height = plan.ch[c].band[lv][0].height;
 				p.descale = plan.prescale[lv];                                  // wavelet.c:5685: prescaled levels use the Descale variant
 				p.out = base + plan.ch[c].band[lv - 1][0].offset; p.out_pitch = plan.ch[c].band[lv - 1][0].pitch;
+				p.xstride = 1; p.precision = 0; p.display_height = 2 * p.height;
 			}
+		if (is_packed16(out_kind)) {
+			for (int c = 0; c < nch; c++) {
+				dev::InvPlaneJob &p = j.l1[(size_t)i * nch + c];
+				for (int b = 0; b < 4; b++) p.band[b] = base + plan.ch[c].band[0][b].offset;
+				p.band_pitch = plan.ch[c].band[0][0].pitch;
+				p.width = plan.ch[c].band[0][0].width; p.height = plan.ch[c].band[0][0].height; p.descale = 0;
+				uint16_t *frame = own_output ? (uint16_t *)(d_out_ + frame_bytes_ * i) : nullptr;
+				p.out = frame ? (int16_t *)(frame + packed_word_of_channel(out_kind, c)) : nullptr; p.out_pitch = out_pitch_ / 2;
+				p.xstride = nch; p.precision = plan.precision; p.display_height = plan.display_height;
+			}
+			continue;
+		}
 		dev::InvYuvJob &y = j.yuv[i];
 		for (int c = 0; c < 3; c++) { y.band_pitch[c] = plan.ch[c].band[0][0].pitch; for (int b = 0; b < 4; b++) y.band[c][b] = base + plan.ch[c].band[0][b].offset; }
 		y.width = plan.ch[0].band[0][0].width; y.height = plan.ch[0].band[0][0].height; y.display_height = plan.display_height;
@@ -357,6 +407,14 @@ int DecodeBatch::set_device_output(int i, void *d_out, int pitch)
 {
 	if (i < 0 || i >= n_) return -1;
 	DecJobs j = dec_jobs_at(h_jobs_, n_, plan_.num_channels);
+	if (is_packed16(out_kind_)) {
+		for (int c = 0; c < plan_.num_channels; c++) {
+			dev::InvPlaneJob &p = j.l1[(size_t)i * plan_.num_channels + c];
+			p.out = (int16_t *)((uint16_t *)d_out + packed_word_of_channel(out_kind_, c)); p.out_pitch = pitch / 2;
+		}
+		jobs_dirty_ = true;
+		return 0;
+	}
 	if (j.yuv[i].out != d_out || j.yuv[i].out_pitch != pitch) { j.yuv[i].out = (uint8_t *)d_out; j.yuv[i].out_pitch = pitch; jobs_dirty_ = true; }
 	return 0;
 }
@@ -377,7 +435,11 @@ int DecodeBatch::launch_inverse(uint32_t dither_seed)
 		dev::k_inv_plane<<<grid, dev::NTHREADS, 0, st>>>(lv == 2 ? j.l3 : j.l2);
 		HIPCHK(hipEventRecord((hipEvent_t)evl_[2 - lv], st));
 	}
-	{
+	if (is_packed16(out_kind_)) {
+		const BandDesc &b = plan_.ch[0].band[0][0];
+		dim3 grid(((b.width + dev::ITW - 1) / dev::ITW) * nch, (b.height + dev::ITH - 1) / dev::ITH, n_);
+		dev::k_inv_packed16<<<grid, dev::NTHREADS, 0, st>>>(j.l1, nch);
+	} else {
 		const BandDesc &b = plan_.ch[0].band[0][0];
 		dim3 grid((b.width + dev::ITW - 1) / dev::ITW, (b.height + dev::ITH - 1) / dev::ITH, n_);
 		dev::k_inv_yuv422<<<grid, dev::NTHREADS, 0, st>>>(j.yuv, dither_seed);

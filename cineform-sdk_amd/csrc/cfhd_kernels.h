@@ -40,6 +40,10 @@ struct FwdPlaneJob {
 	int prescale;                           // 0 or 2
 	int16_t *out[4]; int out_pitch;         // LL, LH, HL, HH
 	QuantParam q[4];
+	// k_fwd_packed16 only: the plane is one component of interleaved unsigned 16-bit pixels (RG48, b64a): `in` points at the
+	// component's first word, samples are xstride words apart, >> shift brings them to the codec precision, rows beyond
+	// display_height repeat the last picture row (frame.c:6020-6024)
+	int xstride, shift, display_height;
 };
 
 struct FwdYuvJob {
@@ -55,6 +59,9 @@ struct InvPlaneJob {
 	int width, height;                      // band dimensions
 	int descale;                            // 0, or 2 when the encoder prescaled this level
 	int16_t *out; int out_pitch;
+	// k_inv_packed16 only: `out` is the component's first word inside interleaved unsigned 16-bit pixels, xstride words per pixel,
+	// out_pitch in words; samples are clamped to `precision` bits and shifted up to 16; rows >= display_height are not written
+	int xstride, precision, display_height;
 };
 
 struct InvYuvJob {
@@ -229,11 +236,17 @@ __device__ __forceinline__ int tile_first_row(int r0, int height) { int s = 2 * 
 // =============================================================================================
 // Forward, int16 plane source
 // =============================================================================================
-__global__ void __launch_bounds__(NTHREADS) k_fwd_plane(const FwdPlaneJob *jobs)
+// PACKED: level 1 of the 4:4:4(:4) formats straight from the interleaved 16-bit pixels (ConvertRGB48ToFrame16s frame.c:5968 /
+// ConvertBGRA64ToFrame_4444_16s :6569 + FilterSpatialQuant16s).  gridDim.x = tiles_x * nch: the nch component planes of one tile
+// are consecutive logical tiles, i.e. they run close together on one XCD and the pixel rows they share come out of its L2.
+template <bool PACKED>
+__device__ __forceinline__ void fwd_plane_tile(const FwdPlaneJob *jobs, int nch)
 {
-	const TileId tile = xcd_tile();
+	TileId tile = xcd_tile();
+	int comp = 0;
+	if (PACKED) { comp = tile.x % nch; tile.x /= nch; }
 	__shared__ FwdPlaneJob s_job;
-	stage_job(&s_job, &jobs[tile.z]);
+	stage_job(&s_job, &jobs[PACKED ? tile.z * nch + comp : tile.z]);
 	const FwdPlaneJob &job = s_job;
 	const int W = job.width, H = job.height, HW = W >> 1, HH = H >> 1;
 	const int c0 = tile.x * TW, r0 = tile.y * TH;
@@ -252,7 +265,13 @@ __global__ void __launch_bounds__(NTHREADS) k_fwd_plane(const FwdPlaneJob *jobs)
 			const int j = i / (TW + 4), d = i - j * (TW + 4);
 			const int y = row_start + j, dw = c0 - 2 + d;    // dword index within the plane row
 			va[k] = 0;
-			if (i < ROWS * (TW + 4) && y < H && dw >= 0 && dw < HW) va[k] = *(const uint32_t *)(job.in + (size_t)y * job.in_pitch + 2 * dw);
+			if (i < ROWS * (TW + 4) && y < H && dw >= 0 && dw < HW) {
+				if (PACKED) {
+					const int yy = y < job.display_height ? y : job.display_height - 1;
+					const uint16_t *px = (const uint16_t *)job.in + (size_t)yy * job.in_pitch + (size_t)(2 * dw) * job.xstride;
+					va[k] = ((uint32_t)px[0] >> job.shift) | (((uint32_t)px[job.xstride] >> job.shift) << 16);
+				} else va[k] = *(const uint32_t *)(job.in + (size_t)y * job.in_pitch + 2 * dw);
+			}
 		}
 #pragma unroll
 		for (int k = 0; k < NSTAGE; k++) {
@@ -289,6 +308,9 @@ __global__ void __launch_bounds__(NTHREADS) k_fwd_plane(const FwdPlaneJob *jobs)
 		}
 	}
 }
+
+__global__ void __launch_bounds__(NTHREADS) k_fwd_plane(const FwdPlaneJob *jobs) { fwd_plane_tile<false>(jobs, 1); }
+__global__ void __launch_bounds__(NTHREADS) k_fwd_packed16(const FwdPlaneJob *jobs, int nch) { fwd_plane_tile<true>(jobs, nch); }
 
 // =============================================================================================
 // Forward level 1, packed 8-bit 4:2:2 source (all three channels of a tile in one workgroup)
@@ -487,11 +509,29 @@ __device__ __forceinline__ void inv_stage_load(uint32_t (&va)[N], const int16_t 
 	}
 }
 
-__global__ void __launch_bounds__(NTHREADS) k_inv_plane(const InvPlaneJob *jobs)
+// 12-bit component -> 16-bit output word of the 4:4:4(:4) formats; v = lowfilter +/- high before the >>1.  The vector columns of
+// InvertHorizontalStrip16sToRow16u clamp to `precision` bits and shift up (InvertHorizontalStrip16s.c:16596, :16724-16750); the
+// columns its scalar loop handles (band columns >= w - w%8 - 9, :16876-16990) shift first and saturate to 65535.
+__device__ __forceinline__ uint32_t to16(int v, int precision, bool tail)
 {
-	const TileId tile = xcd_tile();
+	int x = v >> 1;
+	if (x < 0) x = 0;
+	if (tail) { x <<= 16 - precision; return (uint32_t)(x > 65535 ? 65535 : x); }
+	const int top = (1 << precision) - 1;
+	return (uint32_t)(x > top ? top : x) << (16 - precision);
+}
+
+// PACKED: the last level of the 4:4:4(:4) formats (wavelet.c:4947 TransformInverseRGB444ToRGB48: InvertSpatial*Row16sToYUV16 per
+// component + ConvertPlanarRGB16uToPackedRGB48): same synthesis, every sample converted with to16() and stored as one word of
+// the interleaved pixel.  gridDim.x = tiles_x * nch as in k_fwd_packed16.
+template <bool PACKED>
+__device__ __forceinline__ void inv_plane_tile(const InvPlaneJob *jobs, int nch)
+{
+	TileId tile = xcd_tile();
+	int comp = 0;
+	if (PACKED) { comp = tile.x % nch; tile.x /= nch; }
 	__shared__ InvPlaneJob s_job;
-	stage_job(&s_job, &jobs[tile.z]);
+	stage_job(&s_job, &jobs[PACKED ? tile.z * nch + comp : tile.z]);
 	const InvPlaneJob &job = s_job;
 	const int w = job.width, h = job.height;
 	const int c0 = tile.x * ITW, r0 = tile.y * ITH;
@@ -534,6 +574,29 @@ __global__ void __launch_bounds__(NTHREADS) k_inv_plane(const InvPlaneJob *jobs)
 			const uint32_t dm = L[-1], d0 = L[0], dp = L[1], hh = s_v[par][1][rl][p + 1];
 			uint32_t even, odd;
 			inv_horiz_pk((dm >> 16) | (d0 << 16), d0, (d0 >> 16) | (dp << 16), hh, even, odd);
+			if (PACKED) {
+				const int orow = 2 * r + par;
+				if (orow >= job.display_height) continue;
+				int e[2] = { lo16(even), hi16(even) }, o[2] = { lo16(odd), hi16(odd) };     // columns c, c + 1 before the >>1
+				if (c == 0 || c >= w - 2) {
+					const int l[6] = { lo16(dm), hi16(dm), lo16(d0), hi16(d0), lo16(dp), hi16(dp) };
+#pragma unroll
+					for (int k = 0; k < 2; k++) {
+						const int col = c + k;
+						if (col == 0 || col == w - 1) inv_horiz_border(l, 2 + k, k ? hi16(hh) : lo16(hh), col == 0 ? 0 : 2, e[k], o[k]);
+					}
+				}
+				const int tail0 = w - (w & 7) - 9;
+				uint16_t *dst = (uint16_t *)job.out + (size_t)orow * job.out_pitch + (size_t)(2 * c) * job.xstride;
+#pragma unroll
+				for (int k = 0; k < 2; k++) {
+					if (c + k >= w) break;
+					const bool tail = c + k >= tail0;
+					dst[(2 * k) * job.xstride] = (uint16_t)to16(e[k], job.precision, tail);
+					dst[(2 * k + 1) * job.xstride] = (uint16_t)to16(o[k], job.precision, tail);
+				}
+				continue;
+			}
 			if (job.descale) { even = pk_adds(even, even); odd = pk_adds(odd, odd); }
 			else { even = pk_sra(even, 1); odd = pk_sra(odd, 1); }
 			uint32_t o0 = pk_lolo(even, odd), o1 = pk_hihi(even, odd);      // (even, odd) of column c and of column c + 1
@@ -555,6 +618,9 @@ __global__ void __launch_bounds__(NTHREADS) k_inv_plane(const InvPlaneJob *jobs)
 		}
 	}
 }
+
+__global__ void __launch_bounds__(NTHREADS) k_inv_plane(const InvPlaneJob *jobs) { inv_plane_tile<false>(jobs, 1); }
+__global__ void __launch_bounds__(NTHREADS) k_inv_packed16(const InvPlaneJob *jobs, int nch) { inv_plane_tile<true>(jobs, nch); }
 
 // 10 -> 8 bit reduction of one reconstructed sample v (= lowfilter +/- high, before the >>1):
 // negative values clamp to zero first (the +2048 / subs_epu16 pair, InvertHorizontalStrip16s.c:4086-4089),

@@ -159,3 +159,52 @@ void orc_inv_spatial_to_yuv422(PIXEL16 *const bands[3][4], const int band_pitch[
 	}
 	for (ch = 0; ch < 3; ch++) { free(el[ch]); free(ol[ch]); free(eh[ch]); free(oh[ch]); free(even_px[ch]); free(odd_px[ch]); }
 }
+
+/* 12-bit sample of an RGB 4:4:4 plane -> 16-bit output word.  v = lowfilter +/- high before the >>1.
+ * InvertHorizontalStrip16s.c:16571 InvertHorizontalStrip16sToRow16u: interior columns clamp v to
+ * [0, 2^(precision+1) - 1] with the adds_epi16 / subs_epu16 "protection" pair (:16596, :16724-16726), halve, and shift left by
+ * 16 - precision (:16749); the border columns halve first and clamp through SATURATE_16U of the shifted value (:16650-16671).
+ * Both give clamp(v >> 1, 0, 2^precision - 1) << (16 - precision) on the values a decoder meets. */
+static inline unsigned to16(int v, int precision)
+{
+	int x = v >> 1, top = (1 << precision) - 1;
+	if (x < 0) x = 0;
+	if (x > top) x = top;
+	return (unsigned)x << (16 - precision);
+}
+
+/* The columns behind the SIMD loops -- band columns w - w%8 - 9 .. w-1 for w >= 16: the scalar loop after the last vector group
+ * and the right border (InvertHorizontalStrip16s.c:16876-16990) -- shift first and saturate the shifted value with SATURATE_16U,
+ * so a clipped highlight reads 65535 there and 4095 << 4 = 65520 in the vector columns. */
+static inline unsigned to16_tail(int v, int precision)
+{
+	int x = (v >> 1) << (16 - precision);
+	return (unsigned)(x < 0 ? 0 : (x > 65535 ? 65535 : x));
+}
+
+/* Codec/decoder.c:26887 (RGB 4:4:4 sample, RG48 output, no active metadata) -> wavelet.c:4947 TransformInverseRGB444ToRGB48:
+ * per band row and channel spatial.c:16985 InvertSpatial{Top,Middle,Bottom}Row16sToYUV16 (vertical synthesis in 32 bits with a
+ * final SATURATE, :17183-17230) + InvertHorizontalStrip16sToRow16u, then convert.c:6747 ConvertPlanarRGB16uToPackedRGB48
+ * (planes are G, R, B; output words R, G, B).  num_channels 4 adds the alpha plane as a fourth word (RG64 order R,G,B,A). */
+void orc_inv_spatial_to_rgb48(PIXEL16 *const bands[4][4], int band_pitch, int w, int h, int precision, int num_channels,
+                              uint16_t *out, int out_pitch_words)
+{
+	int ch, r, k, x;
+	PIXEL16 *el = (PIXEL16 *)malloc((size_t)w * 2), *ol = (PIXEL16 *)malloc((size_t)w * 2);
+	PIXEL16 *eh = (PIXEL16 *)malloc((size_t)w * 2), *oh = (PIXEL16 *)malloc((size_t)w * 2);
+	int *px[2]; px[0] = (int *)malloc((size_t)w * 2 * sizeof(int)); px[1] = (int *)malloc((size_t)w * 2 * sizeof(int));
+	static const int word_of_channel[4] = { 1, 0, 2, 3 };      /* plane G -> word 1, R -> 0, B -> 2, A -> 3 */
+	for (r = 0; r < h; r++)
+		for (ch = 0; ch < num_channels; ch++) {
+			inv_vertical_row(bands[ch][0], band_pitch, bands[ch][2] + (size_t)r * band_pitch, r, h, w, el, ol);
+			inv_vertical_row(bands[ch][1], band_pitch, bands[ch][3] + (size_t)r * band_pitch, r, h, w, eh, oh);
+			inv_horizontal_row_prepack(el, eh, w, px[0]);
+			inv_horizontal_row_prepack(ol, oh, w, px[1]);
+			for (k = 0; k < 2; k++) {
+				uint16_t *o = out + (size_t)(2 * r + k) * out_pitch_words + word_of_channel[ch];
+				const int tail = w - (w % 8) - 9;              /* first band column of the scalar loop (post_column + 7, :16876-16878) */
+				for (x = 0; x < 2 * w; x++) o[(size_t)x * num_channels] = (uint16_t)((x >> 1) >= tail ? to16_tail(px[k][x], precision) : to16(px[k][x], precision));
+			}
+		}
+	free(el); free(ol); free(eh); free(oh); free(px[0]); free(px[1]);
+}

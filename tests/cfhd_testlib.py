@@ -22,6 +22,9 @@ def fourcc(s):
 
 PIX_YUY2 = fourcc("YUY2")
 PIX_2VUY = fourcc("2vuy")
+PIX_RG48 = fourcc("RG48")
+ENCODED_RGB444 = 1      # CFHD_ENCODED_FORMAT_RGB_444
+COLOR_FORMAT_RG48 = 120 # Codec/color.h
 ENCODED_YUV422 = 0      # CFHD_ENCODED_FORMAT_YUV_422
 QUALITY_FILMSCAN1 = 4   # CFHD_ENCODING_QUALITY_FILMSCAN1
 COLOR_FORMAT_UYVY = 1   # Codec/color.h:64
@@ -251,6 +254,53 @@ def oracle_forward_yuv422(plan, frame, pitch, uyvy=0):
             bands = (c_i16p * 4)(*[o.ctypes.data_as(c_i16p) for o in outs])
             O.orc_fwd_spatial(src.ctypes.data_as(c_i16p), d["pitch"], d["width"], d["height"], plan.prescale[lv], iarr(q), plan.mpq, bands, outs[0].shape[1])
     return coeffs
+
+
+def rg48_planes(frame, pitch, w, h):
+    """G, R, B planes (12-bit, value >> 4) of an RG48 frame, the order and scaling of ConvertRGB48ToFrame16s (frame.c:6128-6157)."""
+    px = np.frombuffer(frame.tobytes(), dtype=np.uint16).reshape(h, pitch // 2)[:, : w * 3].reshape(h, w, 3)
+    return [(px[:, :, k] >> 4).astype(np.int16) for k in (1, 0, 2)]
+
+
+def oracle_forward_planes(plan, planes):
+    """Forward path of a 4:4:4(:4) frame with the oracle from its component planes (rows below the picture repeat the last row,
+    frame.c:6020-6024), written into the product's pyramid layout."""
+    O = oracle()
+    coeffs = np.zeros(plan.coeff_elems, dtype=np.int16)
+    H = plan.height; w = plan.width
+    for c, pl in enumerate(planes):
+        src = np.zeros((H, w), np.int16); src[: pl.shape[0]] = pl; src[pl.shape[0]:] = pl[-1]
+        for lv in (0, 1, 2):
+            if lv:
+                d = plan.band[(c, lv - 1, 0)]; v = plan.view(coeffs, c, lv - 1, 0)
+                sp, sp_pitch, sw, sh = v.ctypes.data_as(c_i16p), d["pitch"], d["width"], d["height"]
+            else:
+                sp, sp_pitch, sw, sh = src.ctypes.data_as(c_i16p), w, w, H
+            q = [plan.band[(c, lv, b)]["quant"] for b in range(4)]
+            outs = [plan.view(coeffs, c, lv, b) for b in range(4)]
+            bands = (c_i16p * 4)(*[o.ctypes.data_as(c_i16p) for o in outs])
+            O.orc_fwd_spatial(sp, sp_pitch, sw, sh, plan.prescale[lv], iarr(q), plan.mpq, bands, outs[0].shape[1])
+    return coeffs
+
+
+def oracle_inverse_rgb48(plan, coeffs):
+    """Whole inverse path with the oracle from a dequantized RGB 4:4:4 pyramid to packed RG48 words (display rows only)."""
+    O = oracle()
+    O.orc_inv_spatial_to_rgb48.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    work = coeffs.copy()
+    nch = plan.num_channels
+    for c in range(nch):
+        for lv in (2, 1):
+            d = plan.band[(c, lv, 0)]
+            bands = (c_i16p * 4)(*[plan.view(work, c, lv, b).ctypes.data_as(c_i16p) for b in range(4)])
+            dst = plan.view(work, c, lv - 1, 0)
+            O.orc_inv_spatial(bands, d["pitch"], d["width"], d["height"], plan.prescale[lv], dst.ctypes.data_as(c_i16p), plan.band[(c, lv - 1, 0)]["pitch"])
+    d = plan.band[(0, 0, 0)]
+    flat = [plan.view(work, c, 0, b).ctypes.data_as(c_i16p) for c in range(nch) for b in range(4)]
+    out = np.zeros((2 * d["height"], 2 * d["width"] * nch), np.uint16)
+    O.orc_inv_spatial_to_rgb48((c_i16p * 16)(*(flat + [None] * (16 - len(flat)))), d["pitch"], d["width"], d["height"], plan.precision, nch,
+                               out.ctypes.data_as(ctypes.c_void_p), 2 * d["width"] * nch)
+    return out
 
 
 def product_write_sample_host(plan, coeffs, frame_number, meta_global=b"", meta_local=b"", input_format=COLOR_FORMAT_YUYV, color_space=2):

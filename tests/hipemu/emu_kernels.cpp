@@ -4,6 +4,7 @@
 #include "hip_emu.h"
 dim3 threadIdx, blockIdx, blockDim, gridDim;
 #include "cfhd_kernels.h"
+#include <vector>
 
 using namespace cfhd::dev;
 
@@ -25,9 +26,41 @@ void emu_fwd_plane(const int16_t *in, int in_pitch, int width, int height, int p
 	FwdPlaneJob job;
 	job.in = in; job.in_pitch = in_pitch; job.width = width; job.height = height; job.prescale = prescale;
 	job.out[0] = ll; job.out[1] = lh; job.out[2] = hl; job.out[3] = hh; job.out_pitch = out_pitch;
+	job.xstride = 1; job.shift = 0; job.display_height = height;
 	for (int b = 0; b < 4; b++) job.q[b] = make_q(quant[b], mpq);
 	dim3 grid((width / 2 + TW - 1) / TW, (height / 2 + TH - 1) / TH, 1);
 	hipemu::launch(grid, dim3(NTHREADS), [&] { k_fwd_plane(&job); });
+}
+
+// Level 1 of a 4:4:4(:4) format from interleaved 16-bit pixels: nch component planes, quant[c*4+b], out[c*4+b].
+void emu_fwd_packed16(const uint16_t *in, int in_pitch_words, int width, int height, int display_height, int nch, int shift, const int *word_of_channel,
+                      const int *quant, int mpq, int16_t **out, int out_pitch)
+{
+	std::vector<FwdPlaneJob> jobs(nch);
+	for (int c = 0; c < nch; c++) {
+		FwdPlaneJob &job = jobs[c];
+		job.in = (const int16_t *)(in + word_of_channel[c]); job.in_pitch = in_pitch_words; job.width = width; job.height = height; job.prescale = 0;
+		job.xstride = nch; job.shift = shift; job.display_height = display_height;
+		for (int b = 0; b < 4; b++) { job.out[b] = out[c * 4 + b]; job.q[b] = make_q(quant[c * 4 + b], mpq); }
+		job.out_pitch = out_pitch;
+	}
+	dim3 grid(((width / 2 + TW - 1) / TW) * nch, (height / 2 + TH - 1) / TH, 1);
+	hipemu::launch(grid, dim3(NTHREADS), [&] { k_fwd_packed16(jobs.data(), nch); });
+}
+
+// Last level of a 4:4:4(:4) format to interleaved 16-bit pixels: bands[c*4+b].
+void emu_inv_packed16(int16_t **bands, int band_pitch, int w, int h, int display_height, int nch, int precision, const int *word_of_channel,
+                      uint16_t *out, int out_pitch_words)
+{
+	std::vector<InvPlaneJob> jobs(nch);
+	for (int c = 0; c < nch; c++) {
+		InvPlaneJob &job = jobs[c];
+		for (int b = 0; b < 4; b++) job.band[b] = bands[c * 4 + b];
+		job.band_pitch = band_pitch; job.width = w; job.height = h; job.descale = 0;
+		job.out = (int16_t *)(out + word_of_channel[c]); job.out_pitch = out_pitch_words; job.xstride = nch; job.precision = precision; job.display_height = display_height;
+	}
+	dim3 grid(((w + ITW - 1) / ITW) * nch, (h + ITH - 1) / ITH, 1);
+	hipemu::launch(grid, dim3(NTHREADS), [&] { k_inv_packed16(jobs.data(), nch); });
 }
 
 void emu_fwd_yuv422(const uint8_t *in, int in_pitch, int width, int height, int display_height, int uyvy, int shift,
@@ -47,6 +80,7 @@ void emu_inv_plane(const int16_t *ll, const int16_t *lh, const int16_t *hl, cons
 	InvPlaneJob job;
 	job.band[0] = ll; job.band[1] = lh; job.band[2] = hl; job.band[3] = hh; job.band_pitch = band_pitch;
 	job.width = w; job.height = h; job.descale = descale; job.out = out; job.out_pitch = out_pitch;
+	job.xstride = 1; job.precision = 0; job.display_height = 2 * h;
 	dim3 grid((w + ITW - 1) / ITW, (h + ITH - 1) / ITH, 1);
 	hipemu::launch(grid, dim3(NTHREADS), [&] { k_inv_plane(&job); });
 }

@@ -272,3 +272,59 @@ def test_batched_device_resident_round_trip(handoff, decoder):
             lo = oracle_inverse_yuv422(plan, deq, 0)[:h]; hi = oracle_inverse_yuv422(plan, deq, 1)[:h]
             assert ((img == lo) | (img == hi)).all(), "step %d frame %d" % (step, i)
     L.cfhd_amd_batch_destroy(b)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# RG48 -> RGB 4:4:4 12-bit (and back to RG48)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.skipif(not have_ref(), reason="Qbist generator and the reference encoder live in the reference build")
+@pytest.mark.parametrize("w,h", [(320, 240), (1920, 1080), (3840, 2160)])
+def test_rg48_encode_bitstream_identical(w, h):
+    frames, pitch = qbist_frames(10, 2 if w < 3840 else 1, w, h, PIX_RG48)
+    mine = amd_encode_frames(frames, pitch, w, h, PIX_RG48, encoded=ENCODED_RGB444)
+    refs = ref_encode_frames(frames, pitch, w, h, PIX_RG48, encoded=ENCODED_RGB444)
+    for i, (a, b) in enumerate(zip(mine, refs)):
+        assert len(a) == len(b), "frame %d: size %d vs reference %d" % (i, len(a), len(b))
+        assert mask_volatile_metadata(a) == mask_volatile_metadata(b), "frame %d" % i
+
+
+@pytest.mark.skipif(not have_ref(), reason="needs the reference decoder")
+@pytest.mark.parametrize("w,h", [(320, 240), (1920, 1080)])
+def test_rg48_decode_equals_reference_exactly(w, h):
+    """16-bit output has no dither: the GPU decode of a reference RGB 4:4:4 sample must equal the reference decoder word for word."""
+    frames, pitch = qbist_frames(10, 1, w, h, PIX_RG48)
+    sample = ref_encode_frames(frames, pitch, w, h, PIX_RG48, encoded=ENCODED_RGB444)[0]
+    want, wpitch = ref_decode_sample(sample, w, h, PIX_RG48)
+    got, gpitch, aw, ah = amd_decode_sample(sample, PIX_RG48)
+    assert (aw, ah) == (w, h)
+    a = np.frombuffer(got.tobytes(), np.uint16).reshape(h, gpitch // 2)[:, : w * 3]
+    b = np.frombuffer(want.tobytes(), np.uint16).reshape(h, wpitch // 2)[:, : w * 3]
+    assert np.array_equal(a, b)
+
+
+def test_rg48_round_trip_and_format_gates():
+    w, h = 640, 360
+    rng = np.random.default_rng(5)
+    y, x = np.mgrid[0:h, 0:w]
+    img = np.stack([(x * 97 + y * 13) % 65536, (x * 31 + y * 211) % 65536, ((x + y) * 149) % 65536], axis=2).astype(np.uint16)
+    img = (img // 8 + rng.integers(0, 2048, img.shape)).astype(np.uint16)
+    frame = img.reshape(-1).view(np.uint8).copy()
+    sample = amd_encode_frames([frame], w * 6, w, h, PIX_RG48, encoded=ENCODED_RGB444)[0]
+    out, pitch, aw, ah = amd_decode_sample(sample, PIX_RG48)
+    dec = np.frombuffer(out.tobytes(), np.uint16).reshape(h, pitch // 2)[:, : w * 3].reshape(h, w, 3)
+    mse = np.mean((dec.astype(np.float64) - img.astype(np.float64)) ** 2)
+    assert 10 * np.log10(65535.0 ** 2 / mse) > 40.0
+    # the CPU twin of the GPU path gives the same words
+    plan = Plan(w, h, pixkind=PIXKIND["RG48"], enc=3)
+    assert np.array_equal(oracle_inverse_rgb48(plan, host_decode_pyramid(sample, plan))[:h].reshape(h, w, 3), dec)
+    # gates: RG48 only with the RGB 4:4:4 encoded format, RGB samples only to RG48
+    L = product()
+    enc = ctypes.c_void_p(); assert L.CFHD_OpenEncoder(ctypes.byref(enc), None) == 0
+    assert L.CFHD_PrepareToEncode(enc, w, h, PIX_RG48, ENCODED_YUV422, 0, QUALITY_FILMSCAN1) == 3        # CFHD_ERROR_BADFORMAT
+    assert L.CFHD_PrepareToEncode(enc, w, h, PIX_YUY2, ENCODED_RGB444, 0, QUALITY_FILMSCAN1) == 3
+    L.CFHD_CloseEncoder(enc)
+    dec_ref = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec_ref), None) == 0
+    aw2 = ctypes.c_int(); ah2 = ctypes.c_int(); af2 = ctypes.c_uint32()
+    sb = ctypes.create_string_buffer(sample, len(sample))
+    assert L.CFHD_PrepareToDecode(dec_ref, 0, 0, PIX_YUY2, 1, 0, sb, 512, ctypes.byref(aw2), ctypes.byref(ah2), ctypes.byref(af2)) == 3
+    L.CFHD_CloseDecoder(dec_ref)

@@ -76,3 +76,18 @@ def test_parse_and_host_decode_roundtrip(w, h):
                 mag = np.minimum(np.abs(q), 1023)
                 want = np.sign(q) * expand[inv[mag]] * plan.band[(c, lv, b)]["quant"]
                 assert np.array_equal(plan.view(out, c, lv, b), want.astype(np.int16)), (c, lv, b)
+
+
+@pytest.mark.parametrize("w,h", [(192, 96), (320, 240), (1920, 1080)])
+def test_rg48_rgb444_sample_bytes_equal_reference(w, h):
+    """RG48 -> RGB 4:4:4 12-bit.  Unpack (>> 4, planes G, R, B) + oracle transform (prescale table {0,2,2}) +
+    product quantizer tables and sample writer = the reference encoder's sample, byte for byte."""
+    if not have_ref(): pytest.skip("reference .so not built")
+    frames, pitch = qbist_frames(10, 1, w, h, PIX_RG48)
+    rs = ref_encode_frames(frames, pitch, w, h, PIX_RG48, encoded=ENCODED_RGB444)[0]
+    plan = Plan(w, h, pixkind=PIXKIND["RG48"], enc=3)
+    assert plan.precision == 12 and plan.prescale[:3] == [0, 2, 2] and plan.num_channels == 3
+    coeffs = oracle_forward_planes(plan, rg48_planes(frames[0], pitch, w, h))
+    off, n = first_metadata_chunk(rs)
+    mine = product_write_sample_host(plan, coeffs, 1, meta_global=rs[off:off + n], input_format=COLOR_FORMAT_RG48, color_space=0)
+    assert mine == rs

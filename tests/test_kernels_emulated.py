@@ -203,3 +203,55 @@ def test_inv_plane_full_range_saturation(w, h, descale):
     oracle().orc_inv_spatial(bands, pitch, w, h, descale, p16(o), 2 * w)
     emu().emu_inv_plane(p16(b[0]), p16(b[1]), p16(b[2]), p16(b[3]), pitch, w, h, descale, p16(e), 2 * pitch)
     assert np.array_equal(e[:, :2 * w], o)
+
+
+@pytest.mark.parametrize("w,h,dh,nch", [(32, 16, 16, 3), (136, 40, 37, 3), (192, 64, 64, 4), (320, 48, 48, 3)])
+def test_fwd_packed16_level1_of_444_formats(w, h, dh, nch):
+    """k_fwd_packed16 (level 1 straight from interleaved 16-bit pixels, RG48 / b64a style) = unpack >> 4 + oracle plane transform per
+    component, rows below the display height repeating the last picture row (frame.c:6020-6024)."""
+    rng = np.random.default_rng(w + h + nch)
+    px = rng.integers(0, 65536, size=(dh, w, nch), dtype=np.int64).astype(np.uint16)
+    words = [1, 0, 2, 3][:nch]                         # plane order G, R, B(, A) inside R, G, B(, A) pixels
+    quant = [1, 12, 12, 24] * nch
+    pitch = (w // 2 + 7) // 8 * 8
+    outs = [np.zeros((h // 2, pitch), np.int16) for _ in range(4 * nch)]
+    ptrs = (c_i16p * (4 * nch))(*[p16(o) for o in outs])
+    E = emu()
+    E.emu_fwd_packed16.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                   ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    E.emu_fwd_packed16(px.ctypes.data_as(ctypes.c_void_p), w * nch, w, h, dh, nch, 4, iarr(words), iarr(quant), 2, ptrs, pitch)
+    for c in range(nch):
+        plane = np.zeros((h, w), np.int16)
+        plane[:dh] = (px[:, :, words[c]] >> 4).astype(np.int16)
+        plane[dh:] = plane[dh - 1]
+        want = [np.zeros((h // 2, pitch), np.int16) for _ in range(4)]
+        bands = (c_i16p * 4)(*[p16(o) for o in want])
+        oracle().orc_fwd_spatial(p16(plane), w, w, h, 0, iarr(quant[:4]), 2, bands, pitch)
+        for b in range(4):
+            assert np.array_equal(outs[4 * c + b][:, :w // 2], want[b][:, :w // 2]), (c, b)
+
+
+@pytest.mark.parametrize("w,h,dh,nch", [(16, 8, 16, 3), (68, 20, 37, 3), (96, 33, 66, 4), (160, 17, 34, 3)])
+def test_inv_packed16_last_level_of_444_formats(w, h, dh, nch):
+    """k_inv_packed16 = oracle RG48 / RG64 reconstruction (pinned against the reference decoder in test_oracle_vs_ref): exact, incl. the
+    65535-vs-65520 saturation difference between the reference's vector columns and its scalar tail columns."""
+    rng = np.random.default_rng(w * 3 + h + nch)
+    pitch = (w + 7) // 8 * 8
+    bands = []
+    for c in range(nch):
+        bs = [np.zeros((h, pitch), np.int16) for _ in range(4)]
+        bs[0][:, :w] = rand_plane(rng, w, h, 14)               # LL1 of 12-bit components: up to 4 * 4095, here beyond it to hit the clamps
+        for k in range(1, 4): bs[k][:, :w] = rand_plane(rng, w, h, 11, signed=True)
+        bands.append(bs)
+    words = [1, 0, 2, 3][:nch]
+    flat = [p16(a) for c in range(nch) for a in bands[c]]
+    O = oracle()
+    O.orc_inv_spatial_to_rgb48.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    want = np.zeros((2 * h, 2 * w * nch), np.uint16)
+    O.orc_inv_spatial_to_rgb48((c_i16p * 16)(*(flat + [None] * (16 - len(flat)))), pitch, w, h, 12, nch, want.ctypes.data_as(ctypes.c_void_p), 2 * w * nch)
+    got = np.full((dh, 2 * w * nch), 7, np.uint16)
+    E = emu()
+    E.emu_inv_packed16.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    E.emu_inv_packed16((c_i16p * len(flat))(*flat), pitch, w, h, dh, nch, 12, iarr(words), got.ctypes.data_as(ctypes.c_void_p), 2 * w * nch)
+    assert np.array_equal(got, want[:dh])
+    assert (want == 65535).any() and (want == 65520).any() and (want == 0).any()

@@ -91,3 +91,17 @@ def test_reference_decode_lies_in_oracle_dither_interval(w, h, fmt):
     assert ok.all(), "%d bytes outside" % (~ok).sum()
     differ = lo != hi
     assert 0.3 < (rimg[differ] == hi[differ]).mean() < 0.7
+
+
+@pytest.mark.parametrize("w,h", [(192, 96), (320, 240), (1920, 1080)])
+def test_reference_rg48_decode_equals_oracle(w, h):
+    """Pins orc_inv_spatial_to_rgb48 (and the descale levels at 12 bits): the reference decoder's RG48 output of an RGB 4:4:4 sample is
+    deterministic (no dither at 16 bits) and must equal the oracle reconstruction word for word, incl. clipped highlights (65520 in
+    the reference's vector columns, 65535 in its scalar tail columns)."""
+    frames, pitch = qbist_frames(10, 1, w, h, PIX_RG48)
+    sample = ref_encode_frames(frames, pitch, w, h, PIX_RG48, encoded=ENCODED_RGB444)[0]
+    dec, dpitch = ref_decode_sample(sample, w, h, PIX_RG48)
+    img = np.frombuffer(dec.tobytes(), dtype=np.uint16).reshape(h, dpitch // 2)[:, : w * 3]
+    plan = Plan(w, h, pixkind=PIXKIND["RG48"], enc=3)
+    mine = oracle_inverse_rgb48(plan, host_decode_pyramid(sample, plan))[:h]
+    assert np.array_equal(mine, img)
