@@ -69,14 +69,13 @@ DecJobs dec_jobs_at(void *base, int n, int nch)
 size_t dec_jobs_bytes(int n, int nch) { return 3 * (size_t)n * nch * sizeof(dev::InvPlaneJob) + (size_t)n * sizeof(dev::InvYuvJob); }
 
 // Word of component plane c inside an interleaved 16-bit pixel: planes are G, R, B(, A) (frame.c:6128-6157, convert.c:6750-6752),
-// RG48 pixels are R, G, B.
+// RG48 pixels are R, G, B; b64a pixels are A, R, G, B (frame.c:6676-6683).
 int packed_word_of_channel(int pixel_kind, int c)
 {
-	static const int rg48[4] = { 1, 0, 2, 3 };
-	(void)pixel_kind;
-	return rg48[c & 3];
+	static const int rg48[4] = { 1, 0, 2, 3 }, b64a[4] = { 2, 1, 3, 0 };
+	return (pixel_kind == PIX_B64A ? b64a : rg48)[c & 3];
 }
-bool is_packed16(int pixel_kind) { return pixel_kind == PIX_RG48; }
+bool is_packed16(int pixel_kind) { return pixel_kind == PIX_RG48 || pixel_kind == PIX_B64A; }
 } // namespace
 
 const char *device_last_error() { return g_err.c_str(); }
@@ -183,6 +182,7 @@ int EncodeBatch::prepare(const FramePlan &plan, int nframes, bool own_input)
 				p.in = frame ? (const int16_t *)(frame + packed_word_of_channel(plan.pixel_kind, c)) : nullptr; p.in_pitch = in_pitch_ / 2;
 				p.width = plan.ch[c].width; p.height = plan.ch[c].height; p.prescale = plan.prescale[0];
 				p.xstride = nch; p.shift = 16 - plan.precision; p.display_height = plan.display_height;
+				p.compand = plan.pixel_kind == PIX_B64A && c == 3;
 				p.out_pitch = plan.ch[c].band[0][0].pitch;
 				for (int b = 0; b < 4; b++) { p.out[b] = base + plan.ch[c].band[0][b].offset; p.q[b] = make_q(plan.ch[c].band[0][b].quant, mpq); }
 			}
@@ -191,7 +191,7 @@ int EncodeBatch::prepare(const FramePlan &plan, int nframes, bool own_input)
 				dev::FwdPlaneJob &p = (lv == 1 ? j.l2 : j.l3)[(size_t)i * nch + c];
 				const BandDesc &src = plan.ch[c].band[lv - 1][0];
 				p.in = base + src.offset; p.in_pitch = src.pitch; p.width = src.width; p.height = src.height; p.prescale = plan.prescale[lv];
-				p.xstride = 1; p.shift = 0; p.display_height = src.height;
+				p.xstride = 1; p.shift = 0; p.display_height = src.height; p.compand = 0;
 				p.out_pitch = plan.ch[c].band[lv][0].pitch;
 				for (int b = 0; b < 4; b++) { p.out[b] = base + plan.ch[c].band[lv][b].offset; p.q[b] = make_q(plan.ch[c].band[lv][b].quant, mpq); }
 			}

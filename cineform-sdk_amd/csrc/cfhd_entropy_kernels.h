@@ -714,7 +714,8 @@ __global__ void __launch_bounds__(DEC_PARSE_THREADS) k_dec_parse(const uint8_t *
 	}
 	DecTagReader rd; rd.d = d; rd.base = ~(uint64_t)0; rd.w = 0; rd.lane = lane;
 	uint64_t pos = 0, pending_at = 0;
-	uint32_t pending = 0, seen = 0, seen_low = 0;
+	uint32_t pending = 0, seen_low = 0;
+	uint64_t seen = 0;                                   // one bit per coded band: up to 4 channels x 9
 	int channel = 0, lv = -1, band = 0, bw = 0, bh = 0, bq = 1, bflags = 0, lw = 0, lh = 0;
 	int width = 0, height = 0, display_height = 0, num_channels = 0, encoded_format = 0;
 	bool bad = size < 4;
@@ -769,14 +770,14 @@ __global__ void __launch_bounds__(DEC_PARSE_THREADS) k_dec_parse(const uint8_t *
 			const int codebook = bflags & 0xf;
 			if (bw != pb.width || bh != pb.height || (pos & 3u) || (codebook != 0 && codebook != 1)) { bad = true; break; }
 			if (writer) bandjobs[(size_t)P->slot[channel][lv][band] * nframes + f] = DecBandJob{ d + pos, (uint32_t)(end - 4 - pos), cbase + pb.offset, pb.height * pb.pitch, bq };
-			seen |= 1u << ((channel * 3 + lv) * 3 + band - 1);
+			seen |= (uint64_t)1 << ((channel * 3 + lv) * 3 + band - 1);
 			pos = end; pending = 0;
 			break; }
 		default: break;
 		}
 	}
 	if (display_height == 0) display_height = height;
-	const uint32_t want = nch * 9 >= 32 ? 0xffffffffu : (1u << (nch * 9)) - 1u;
+	const uint64_t want = ((uint64_t)1 << (nch * 9)) - 1u;
 	if (bad || width != P->width || display_height != P->display_height || encoded_format != P->encoded_format || num_channels != nch
 	    || seen != want || seen_low != (1u << nch) - 1u) {
 		if (writer) for (int c = 0; c < nch; c++)

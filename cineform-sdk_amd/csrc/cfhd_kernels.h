@@ -44,6 +44,7 @@ struct FwdPlaneJob {
 	// component's first word, samples are xstride words apart, >> shift brings them to the codec precision, rows beyond
 	// display_height repeat the last picture row (frame.c:6020-6024)
 	int xstride, shift, display_height;
+	int compand;                            // alpha plane of b64a: 0 < a < 4095 -> ((a * 223 + 128) >> 8) + 256 (frame.c:6696-6707)
 };
 
 struct FwdYuvJob {
@@ -269,7 +270,12 @@ __device__ __forceinline__ void fwd_plane_tile(const FwdPlaneJob *jobs, int nch)
 				if (PACKED) {
 					const int yy = y < job.display_height ? y : job.display_height - 1;
 					const uint16_t *px = (const uint16_t *)job.in + (size_t)yy * job.in_pitch + (size_t)(2 * dw) * job.xstride;
-					va[k] = ((uint32_t)px[0] >> job.shift) | (((uint32_t)px[job.xstride] >> job.shift) << 16);
+					uint32_t s0 = (uint32_t)px[0] >> job.shift, s1 = (uint32_t)px[job.xstride] >> job.shift;
+					if (job.compand) {
+						if (s0 > 0 && s0 < 4095) s0 = ((s0 * 223 + 128) >> 8) + 256;
+						if (s1 > 0 && s1 < 4095) s1 = ((s1 * 223 + 128) >> 8) + 256;
+					}
+					va[k] = s0 | (s1 << 16);
 				} else va[k] = *(const uint32_t *)(job.in + (size_t)y * job.in_pitch + 2 * dw);
 			}
 		}

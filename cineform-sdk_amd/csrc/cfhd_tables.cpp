@@ -271,7 +271,10 @@ const int kChromaQ[4][17] = {
 void derive_quantization(FramePlan *plan, int quality, bool progressive, float framerate, QuantState *st)
 {
 	int qL[17], qC[17], qLmax[17], qCmax[17];
-	const bool chroma_full = plan->encoded_format != ENC_YUV422;
+	// encoder.c:1141 SetEncoderQuantization: ChromaFullRes = (input colour format >= COLOR_FORMAT_BAYER (100)): true for RG48 (120) and
+	// BYR4 (104), false for the packed 4:2:2 formats and -- although it is a 4:4:4:4 format -- for b64a (COLOR_FORMAT_BGRA64 = 30),
+	// whose R, B and A planes therefore get the chroma tables
+	const bool chroma_full = plan->pixel_kind == PIX_RG48 || plan->pixel_kind == PIX_BYR4;
 	const int precision = plan->precision;
 	int factor = quality & 0xff;
 	const int detail = (quality & 0x0e0000) >> 17;

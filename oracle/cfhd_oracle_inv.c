@@ -185,15 +185,21 @@ static inline unsigned to16_tail(int v, int precision)
 /* Codec/decoder.c:26887 (RGB 4:4:4 sample, RG48 output, no active metadata) -> wavelet.c:4947 TransformInverseRGB444ToRGB48:
  * per band row and channel spatial.c:16985 InvertSpatial{Top,Middle,Bottom}Row16sToYUV16 (vertical synthesis in 32 bits with a
  * final SATURATE, :17183-17230) + InvertHorizontalStrip16sToRow16u, then convert.c:6747 ConvertPlanarRGB16uToPackedRGB48
- * (planes are G, R, B; output words R, G, B).  num_channels 4 adds the alpha plane as a fourth word (RG64 order R,G,B,A). */
-void orc_inv_spatial_to_rgb48(PIXEL16 *const bands[4][4], int band_pitch, int w, int h, int precision, int num_channels,
-                              uint16_t *out, int out_pitch_words)
+ * (planes are G, R, B; output words R, G, B).
+ * The word order, the first scalar column and an alpha expansion a' = ((a - 256) << 3) * 9400 >> 16 (codec.h:164-165, the formula of
+ * InvertHorizontalStrip16s.c:13298 InvertHorizontalStrip16sRGB2B64A) are parameters; only the RG48 instance below is pinned against
+ * the reference decoder -- its b64a output of RGBA 4:4:4:4 samples goes through the active-metadata pipeline (bayer.c:13860
+ * Row16uFull2OutputFormat) with a 13-bit alpha, which is not restated here.
+ * word_of_channel[c] = position of plane c's word in the pixel, tail_start = first band column of the scalar code,
+ * alpha_channel = plane to expand (-1: none). */
+void orc_inv_spatial_to_packed16(PIXEL16 *const bands[4][4], int band_pitch, int w, int h, int precision, int num_channels,
+                                 const int *word_of_channel, int tail_start, int alpha_channel, uint16_t *out, int out_pitch_words)
 {
 	int ch, r, k, x;
 	PIXEL16 *el = (PIXEL16 *)malloc((size_t)w * 2), *ol = (PIXEL16 *)malloc((size_t)w * 2);
 	PIXEL16 *eh = (PIXEL16 *)malloc((size_t)w * 2), *oh = (PIXEL16 *)malloc((size_t)w * 2);
 	int *px[2]; px[0] = (int *)malloc((size_t)w * 2 * sizeof(int)); px[1] = (int *)malloc((size_t)w * 2 * sizeof(int));
-	static const int word_of_channel[4] = { 1, 0, 2, 3 };      /* plane G -> word 1, R -> 0, B -> 2, A -> 3 */
+	const int top = (1 << precision) - 1;
 	for (r = 0; r < h; r++)
 		for (ch = 0; ch < num_channels; ch++) {
 			inv_vertical_row(bands[ch][0], band_pitch, bands[ch][2] + (size_t)r * band_pitch, r, h, w, el, ol);
@@ -202,9 +208,29 @@ void orc_inv_spatial_to_rgb48(PIXEL16 *const bands[4][4], int band_pitch, int w,
 			inv_horizontal_row_prepack(ol, oh, w, px[1]);
 			for (k = 0; k < 2; k++) {
 				uint16_t *o = out + (size_t)(2 * r + k) * out_pitch_words + word_of_channel[ch];
-				const int tail = w - (w % 8) - 9;              /* first band column of the scalar loop (post_column + 7, :16876-16878) */
-				for (x = 0; x < 2 * w; x++) o[(size_t)x * num_channels] = (uint16_t)((x >> 1) >= tail ? to16_tail(px[k][x], precision) : to16(px[k][x], precision));
+				for (x = 0; x < 2 * w; x++) {
+					const int tail = (x >> 1) >= tail_start, v = px[k][x];
+					unsigned word;
+					if (ch == alpha_channel) {
+						int a = v >> 1;
+						if (!tail) { if (a < 0) a = 0; if (a > top) a = top; }
+						a -= 256;
+						if (!tail && a < 0) a = 0;
+						a = (int)(((long long)(a * 8) * 9400) >> 16);
+						if (a < 0) a = 0;
+						if (a > top) a = top;
+						word = (unsigned)a << (16 - precision);
+					} else word = tail ? to16_tail(v, precision) : to16(v, precision);
+					o[(size_t)x * num_channels] = (uint16_t)word;
+				}
 			}
 		}
 	free(el); free(ol); free(eh); free(oh); free(px[0]); free(px[1]);
+}
+
+void orc_inv_spatial_to_rgb48(PIXEL16 *const bands[4][4], int band_pitch, int w, int h, int precision, int num_channels,
+                              uint16_t *out, int out_pitch_words)
+{
+	static const int word_of_channel[4] = { 1, 0, 2, 3 };      /* plane G -> word 1, R -> 0, B -> 2 */
+	orc_inv_spatial_to_packed16(bands, band_pitch, w, h, precision, num_channels, word_of_channel, w - (w % 8) - 9, -1, out, out_pitch_words);
 }

@@ -23,6 +23,9 @@ def fourcc(s):
 PIX_YUY2 = fourcc("YUY2")
 PIX_2VUY = fourcc("2vuy")
 PIX_RG48 = fourcc("RG48")
+PIX_B64A = fourcc("b64a")
+ENCODED_RGBA4444 = 2    # CFHD_ENCODED_FORMAT_RGBA_4444
+COLOR_FORMAT_B64A = 30  # COLOR_FORMAT_BGRA64, Codec/color.h
 ENCODED_RGB444 = 1      # CFHD_ENCODED_FORMAT_RGB_444
 COLOR_FORMAT_RG48 = 120 # Codec/color.h
 ENCODED_YUV422 = 0      # CFHD_ENCODED_FORMAT_YUV_422
@@ -260,6 +263,15 @@ def rg48_planes(frame, pitch, w, h):
     """G, R, B planes (12-bit, value >> 4) of an RG48 frame, the order and scaling of ConvertRGB48ToFrame16s (frame.c:6128-6157)."""
     px = np.frombuffer(frame.tobytes(), dtype=np.uint16).reshape(h, pitch // 2)[:, : w * 3].reshape(h, w, 3)
     return [(px[:, :, k] >> 4).astype(np.int16) for k in (1, 0, 2)]
+
+
+def b64a_planes(frame, pitch, w, h):
+    """G, R, B, A planes of a b64a frame (words A, R, G, B; value >> 4; alpha companded for 0 < a < 4095), as
+    ConvertBGRA64ToFrame_4444_16s builds them (frame.c:6676-6707)."""
+    px = np.frombuffer(frame.tobytes(), dtype=np.uint16).reshape(h, pitch // 2)[:, : w * 4].reshape(h, w, 4)
+    a = (px[:, :, 0] >> 4).astype(np.int32)
+    a = np.where((a > 0) & (a < 4095), ((a * 223 + 128) >> 8) + 256, a)
+    return [(px[:, :, 2] >> 4).astype(np.int16), (px[:, :, 1] >> 4).astype(np.int16), (px[:, :, 3] >> 4).astype(np.int16), a.astype(np.int16)]
 
 
 def oracle_forward_planes(plan, planes):

@@ -26,21 +26,21 @@ void emu_fwd_plane(const int16_t *in, int in_pitch, int width, int height, int p
 	FwdPlaneJob job;
 	job.in = in; job.in_pitch = in_pitch; job.width = width; job.height = height; job.prescale = prescale;
 	job.out[0] = ll; job.out[1] = lh; job.out[2] = hl; job.out[3] = hh; job.out_pitch = out_pitch;
-	job.xstride = 1; job.shift = 0; job.display_height = height;
+	job.xstride = 1; job.shift = 0; job.display_height = height; job.compand = 0;
 	for (int b = 0; b < 4; b++) job.q[b] = make_q(quant[b], mpq);
 	dim3 grid((width / 2 + TW - 1) / TW, (height / 2 + TH - 1) / TH, 1);
 	hipemu::launch(grid, dim3(NTHREADS), [&] { k_fwd_plane(&job); });
 }
 
 // Level 1 of a 4:4:4(:4) format from interleaved 16-bit pixels: nch component planes, quant[c*4+b], out[c*4+b].
-void emu_fwd_packed16(const uint16_t *in, int in_pitch_words, int width, int height, int display_height, int nch, int shift, const int *word_of_channel,
+void emu_fwd_packed16(const uint16_t *in, int in_pitch_words, int width, int height, int display_height, int nch, int shift, const int *word_of_channel, int compand_channel,
                       const int *quant, int mpq, int16_t **out, int out_pitch)
 {
 	std::vector<FwdPlaneJob> jobs(nch);
 	for (int c = 0; c < nch; c++) {
 		FwdPlaneJob &job = jobs[c];
 		job.in = (const int16_t *)(in + word_of_channel[c]); job.in_pitch = in_pitch_words; job.width = width; job.height = height; job.prescale = 0;
-		job.xstride = nch; job.shift = shift; job.display_height = display_height;
+		job.xstride = nch; job.shift = shift; job.display_height = display_height; job.compand = c == compand_channel;
 		for (int b = 0; b < 4; b++) { job.out[b] = out[c * 4 + b]; job.q[b] = make_q(quant[c * 4 + b], mpq); }
 		job.out_pitch = out_pitch;
 	}

@@ -328,3 +328,17 @@ def test_rg48_round_trip_and_format_gates():
     sb = ctypes.create_string_buffer(sample, len(sample))
     assert L.CFHD_PrepareToDecode(dec_ref, 0, 0, PIX_YUY2, 1, 0, sb, 512, ctypes.byref(aw2), ctypes.byref(ah2), ctypes.byref(af2)) == 3
     L.CFHD_CloseDecoder(dec_ref)
+
+
+@pytest.mark.skipif(not have_ref(), reason="Qbist generator and the reference encoder live in the reference build")
+@pytest.mark.parametrize("w,h", [(320, 240), (1920, 1080)])
+def test_b64a_encode_bitstream_identical(w, h):
+    """Config C, encode side: b64a -> RGBA 4:4:4:4 (k_fwd_packed16 with four component planes and the alpha companding curve)."""
+    frames, pitch = qbist_frames(10, 1, w, h, PIX_B64A, alpha=1)
+    px = np.frombuffer(frames[0].tobytes(), dtype=np.uint16).reshape(h, pitch // 2).copy()
+    px[:, 0: w * 4: 4] = ((np.arange(h)[:, None] * 523 + np.arange(w)[None, :] * 97) % 65536).astype(np.uint16)
+    frame = px.reshape(-1).view(np.uint8).copy()
+    a = amd_encode_frames([frame], pitch, w, h, PIX_B64A, encoded=ENCODED_RGBA4444)[0]
+    b = ref_encode_frames([frame], pitch, w, h, PIX_B64A, encoded=ENCODED_RGBA4444)[0]
+    assert len(a) == len(b)
+    assert mask_volatile_metadata(a) == mask_volatile_metadata(b)

@@ -91,3 +91,22 @@ def test_rg48_rgb444_sample_bytes_equal_reference(w, h):
     off, n = first_metadata_chunk(rs)
     mine = product_write_sample_host(plan, coeffs, 1, meta_global=rs[off:off + n], input_format=COLOR_FORMAT_RG48, color_space=0)
     assert mine == rs
+
+
+@pytest.mark.parametrize("w,h", [(192, 96), (640, 360)])
+def test_b64a_rgba4444_sample_bytes_equal_reference(w, h):
+    """SURVEY 8a9 / config C (encode side): b64a -> RGBA 4:4:4:4 12-bit with the companded alpha plane; R, B and A take the chroma
+    quantizer tables because b64a's colour format code is below COLOR_FORMAT_BAYER (encoder.c:1141), and the quality word carries
+    the "4444 instead of 444" mark 0x20000000 (SampleEncoder.cpp:250-257)."""
+    if not have_ref(): pytest.skip("reference .so not built")
+    frames, pitch = qbist_frames(10, 1, w, h, PIX_B64A, alpha=1)
+    px = np.frombuffer(frames[0].tobytes(), dtype=np.uint16).reshape(h, pitch // 2).copy()
+    px[:, 0: w * 4: 4] = ((np.arange(h)[:, None] * 523 + np.arange(w)[None, :] * 97) % 65536).astype(np.uint16)   # a real alpha ramp (Qbist's is opaque)
+    frame = px.reshape(-1).view(np.uint8).copy()
+    rs = ref_encode_frames([frame], pitch, w, h, PIX_B64A, encoded=ENCODED_RGBA4444)[0]
+    plan = Plan(w, h, pixkind=PIXKIND["b64a"], enc=4, quality=QUALITY_FILMSCAN1 | 0x20000000)
+    assert plan.num_channels == 4 and plan.precision == 12
+    coeffs = oracle_forward_planes(plan, b64a_planes(frame, pitch, w, h))
+    off, n = first_metadata_chunk(rs)
+    mine = product_write_sample_host(plan, coeffs, 1, meta_global=rs[off:off + n], input_format=COLOR_FORMAT_B64A, color_space=0)
+    assert mine == rs

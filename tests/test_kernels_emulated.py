@@ -211,18 +211,21 @@ def test_fwd_packed16_level1_of_444_formats(w, h, dh, nch):
     component, rows below the display height repeating the last picture row (frame.c:6020-6024)."""
     rng = np.random.default_rng(w + h + nch)
     px = rng.integers(0, 65536, size=(dh, w, nch), dtype=np.int64).astype(np.uint16)
-    words = [1, 0, 2, 3][:nch]                         # plane order G, R, B(, A) inside R, G, B(, A) pixels
+    words = [1, 0, 2, 3][:nch] if nch == 3 else [2, 1, 3, 0]      # RG48: planes G, R, B in R, G, B pixels; b64a: planes G, R, B, A in A, R, G, B pixels
     quant = [1, 12, 12, 24] * nch
     pitch = (w // 2 + 7) // 8 * 8
     outs = [np.zeros((h // 2, pitch), np.int16) for _ in range(4 * nch)]
     ptrs = (c_i16p * (4 * nch))(*[p16(o) for o in outs])
     E = emu()
-    E.emu_fwd_packed16.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+    E.emu_fwd_packed16.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
                                    ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
-    E.emu_fwd_packed16(px.ctypes.data_as(ctypes.c_void_p), w * nch, w, h, dh, nch, 4, iarr(words), iarr(quant), 2, ptrs, pitch)
+    if nch == 4: px[::3, ::5, 0] = 0; px[1::4, 2::7, 0] = 65535          # alpha extremes stay uncompanded
+    E.emu_fwd_packed16(px.ctypes.data_as(ctypes.c_void_p), w * nch, w, h, dh, nch, 4, iarr(words), 3 if nch == 4 else -1, iarr(quant), 2, ptrs, pitch)
     for c in range(nch):
         plane = np.zeros((h, w), np.int16)
-        plane[:dh] = (px[:, :, words[c]] >> 4).astype(np.int16)
+        comp = (px[:, :, words[c]] >> 4).astype(np.int32)
+        if nch == 4 and c == 3: comp = np.where((comp > 0) & (comp < 4095), ((comp * 223 + 128) >> 8) + 256, comp)     # frame.c:6696-6707
+        plane[:dh] = comp.astype(np.int16)
         plane[dh:] = plane[dh - 1]
         want = [np.zeros((h // 2, pitch), np.int16) for _ in range(4)]
         bands = (c_i16p * 4)(*[p16(o) for o in want])
