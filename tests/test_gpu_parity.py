@@ -291,15 +291,24 @@ def test_rg48_encode_bitstream_identical(w, h):
 @pytest.mark.skipif(not have_ref(), reason="needs the reference decoder")
 @pytest.mark.parametrize("w,h", [(320, 240), (1920, 1080)])
 def test_rg48_decode_equals_reference_exactly(w, h):
-    """16-bit output has no dither: the GPU decode of a reference RGB 4:4:4 sample must equal the reference decoder word for word."""
+    """16-bit output has no dither: the GPU decode of a reference RGB 4:4:4 sample must equal the reference decoder word for word.
+    Both are compared with the oracle reconstruction (deterministic): ours must equal it always; the reference's threaded decoder has
+    been seen to return a damaged frame now and then on the 256-core GPU host (also as a 17 dB PSNR outlier in its own harness), so
+    it gets up to three attempts."""
     frames, pitch = qbist_frames(10, 1, w, h, PIX_RG48)
     sample = ref_encode_frames(frames, pitch, w, h, PIX_RG48, encoded=ENCODED_RGB444)[0]
-    want, wpitch = ref_decode_sample(sample, w, h, PIX_RG48)
+    plan = Plan(w, h, pixkind=PIXKIND["RG48"], enc=3)
+    exact = oracle_inverse_rgb48(plan, host_decode_pyramid(sample, plan))[:h]
     got, gpitch, aw, ah = amd_decode_sample(sample, PIX_RG48)
     assert (aw, ah) == (w, h)
     a = np.frombuffer(got.tobytes(), np.uint16).reshape(h, gpitch // 2)[:, : w * 3]
-    b = np.frombuffer(want.tobytes(), np.uint16).reshape(h, wpitch // 2)[:, : w * 3]
-    assert np.array_equal(a, b)
+    assert np.array_equal(a, exact)
+    for attempt in range(3):
+        want, wpitch = ref_decode_sample(sample, w, h, PIX_RG48)
+        b = np.frombuffer(want.tobytes(), np.uint16).reshape(h, wpitch // 2)[:, : w * 3]
+        if np.array_equal(b, exact): break
+    else:
+        raise AssertionError("the reference decoder never reproduced the oracle reconstruction")
 
 
 def test_rg48_round_trip_and_format_gates():
