@@ -32,7 +32,7 @@ enum {
 
 #define FOURCC_BE(a, b, c, d) (((uint32_t)(a) << 24) | ((uint32_t)(b) << 16) | ((uint32_t)(c) << 8) | (uint32_t)(d))
 static const uint32_t FMT_YUY2 = FOURCC_BE('Y', 'U', 'Y', '2'), FMT_2VUY = FOURCC_BE('2', 'v', 'u', 'y'), FMT_YUYV = FOURCC_BE('y', 'u', 'y', 'v'),
-                      FMT_RG48 = FOURCC_BE('R', 'G', '4', '8'), FMT_B64A = FOURCC_BE('b', '6', '4', 'a');
+                      FMT_RG48 = FOURCC_BE('R', 'G', '4', '8'), FMT_B64A = FOURCC_BE('b', '6', '4', 'a'), FMT_BYR4 = FOURCC_BE('B', 'Y', 'R', '4');
 
 namespace {
 
@@ -55,10 +55,11 @@ int pixel_kind_of(uint32_t fmt)
 	if (fmt == FMT_2VUY) return PIX_2VUY;
 	if (fmt == FMT_RG48) return PIX_RG48;
 	if (fmt == FMT_B64A) return PIX_B64A;
+	if (fmt == FMT_BYR4) return PIX_BYR4;
 	return PIX_NONE;
 }
 // COLOR_FORMAT_UYVY = 1 / COLOR_FORMAT_YUYV = 2 / COLOR_FORMAT_BGRA64 (b64a) = 30 / COLOR_FORMAT_RG48 = 120 (Codec/color.h)
-int color_format_of(int kind) { return kind == PIX_2VUY ? 1 : (kind == PIX_RG48 ? 120 : (kind == PIX_B64A ? 30 : 2)); }
+int color_format_of(int kind) { return kind == PIX_2VUY ? 1 : (kind == PIX_RG48 ? 120 : (kind == PIX_B64A ? 30 : (kind == PIX_BYR4 ? 104 : 2))); }   // BYR4 = 104
 int pixel_bytes_of(int kind) { return kind == PIX_RG48 ? 6 : (kind == PIX_B64A ? 8 : 2); }
 
 // ---- metadata handle shared by the encoder-side API (CSampleEncodeMetadata) ----
@@ -156,17 +157,19 @@ int make_params(EncodeParams &p, int w, int h, uint32_t fmt, int encoded, uint32
 	// combinations (4:4:4 input subsampled to 4:2:2, ...) go through ConvertLib in the reference and are not built
 	// CFHD_ENCODED_FORMAT_RGBA_4444 (2) from b64a
 	const bool rgb = kind == PIX_RG48 || kind == PIX_B64A;
-	if (encoded != (kind == PIX_RG48 ? 1 : (kind == PIX_B64A ? 2 : 0))) return ERR_BADFORMAT;
+	// CFHD_ENCODED_FORMAT_BAYER (3) from BYR4: default pixel order (red-green) and default encode curve (log 90), i.e. what the
+	// reference does without BAYER_FORMAT / ENCODE_CURVE metadata
+	if (encoded != (kind == PIX_RG48 ? 1 : (kind == PIX_B64A ? 2 : (kind == PIX_BYR4 ? 3 : 0)))) return ERR_BADFORMAT;
 	if (flags & (1u << 0)) return ERR_BADFORMAT;                          // interlaced: not built yet
 	if (flags & (1u << 1)) return ERR_BADFORMAT;                          // 2-frame GOP: out of scope
-	const int enc = kind == PIX_B64A ? ENC_RGBA4444 : (rgb ? ENC_RGB444 : ENC_YUV422);
+	const int enc = kind == PIX_BYR4 ? ENC_BAYER : (kind == PIX_B64A ? ENC_RGBA4444 : (rgb ? ENC_RGB444 : ENC_YUV422));
 	// b64a's default encoded format is RGB 4:4:4; asking for 4:4:4:4 marks the quality word (SampleEncoder.cpp:250-257), which the
 	// sample header then carries in QUALITY_H
 	if (kind == PIX_B64A) quality |= 0x20000000;
 	p.width = w; p.height = h; p.pixel_format = fmt; p.pixel_kind = kind; p.encoded_format = enc; p.flags = flags;
 	p.quality = quality; p.progressive = true;
 	const int yuv601 = (flags & (1u << 2)) ? 1 : 2, vsrgb = (flags & (1u << 8)) ? 2 : 1;   // SampleEncoder.cpp:210-212
-	p.color_space = rgb ? 0 : ((yuv601 == 1 ? 1 : 2) | (vsrgb == 2 ? 4 : 0));           // RGB 4:4:4 samples carry no colour space tag
+	p.color_space = (rgb || kind == PIX_BYR4) ? 0 : ((yuv601 == 1 ? 1 : 2) | (vsrgb == 2 ? 4 : 0));           // RGB 4:4:4 samples carry no colour space tag
 	if (!build_frame_plan(&p.plan, w, h, kind, enc)) return ERR_BADFORMAT;
 	p.qstate = {0, -1, 0};
 	derive_quantization(&p.plan, quality, true, 0.0f, &p.qstate);
@@ -347,9 +350,9 @@ CFHD_Error CFHD_OpenEncoder(CFHD_EncoderRef *out, CFHD_ALLOCATOR *)
 CFHD_Error CFHD_GetInputFormats(CFHD_EncoderRef ref, CFHD_PixelFormat *arr, int len, int *count)
 {
 	if (!ref || !arr) return ERR_INVALID_ARGUMENT;
-	const uint32_t fmts[] = { FMT_YUY2, FMT_2VUY, FMT_RG48, FMT_B64A };
+	const uint32_t fmts[] = { FMT_YUY2, FMT_2VUY, FMT_RG48, FMT_B64A, FMT_BYR4 };
 	int n = 0;
-	for (; n < 4 && n < len; n++) arr[n] = fmts[n];
+	for (; n < 5 && n < len; n++) arr[n] = fmts[n];
 	if (count) *count = n;
 	return ERR_OKAY;
 }
@@ -655,7 +658,7 @@ CFHD_Error CFHD_PrepareToDecode(CFHD_DecoderRef ref, int, int, CFHD_PixelFormat 
 	if (kind == PIX_NONE) return ERR_BADFORMAT;
 	// 4:2:2 samples decode to the packed 4:2:2 formats, RGB 4:4:4 samples to RG48 (wavelet.c:4947); colour conversions between the
 	// families (ConvertLib / the active-metadata pipeline in the reference) are not built
-	if (kind == PIX_B64A) return ERR_BADFORMAT;                                       // b64a output (InvertHorizontalStrip16sRGB2B64A) is not built yet
+	if (kind == PIX_B64A || kind == PIX_BYR4) return ERR_BADFORMAT;                   // b64a output (InvertHorizontalStrip16sRGB2B64A) is not built yet
 	if ((d->header.encoded_format == ENC_RGB444) != (kind == PIX_RG48)) return ERR_BADFORMAT;
 	bool ok;
 	plan_from_sample(d->header, kind, &d->plan, &ok);

@@ -87,6 +87,9 @@ void derive_quantization(FramePlan *plan, int quality, bool progressive, float f
 
 // Builds the pyramid geometry for the given encoded dimensions.
 bool build_frame_plan(FramePlan *plan, int width, int height, int pixel_kind, int encoded_format);
+// Default encode curve of the Bayer input path (log base 90 over 14-bit linear input, scaled to `precision` bits), frame.c:5219-5235.
+enum { kBayerCurveBits = 14 };
+void build_bayer_log90_curve(int precision, uint16_t *curve /* 1 << kBayerCurveBits entries */);
 
 static inline int align_up(int x, int a) { return (x + a - 1) / a * a; }
 

@@ -48,9 +48,10 @@ private:
 	int n_ = 0; bool own_input_ = false, jobs_dirty_ = true;
 	void *stream_ = nullptr, *ev0_ = nullptr, *ev1_ = nullptr, *evl_[2] = {nullptr, nullptr};
 	float level_ms_[3] = {0, 0, 0};
-	uint8_t *d_in_ = nullptr, *h_in_ = nullptr; size_t frame_bytes_ = 0; int in_pitch_ = 0;
+	uint8_t *d_in_ = nullptr, *h_in_ = nullptr; size_t frame_bytes_ = 0; int in_pitch_ = 0, in_rows_ = 0;
 	int16_t *d_coeff_ = nullptr, *h_coeff_ = nullptr;
 	void *d_jobs_ = nullptr, *h_jobs_ = nullptr; size_t jobs_bytes_ = 0;
+	int16_t *d_planes_ = nullptr; uint16_t *d_curve_ = nullptr; size_t plane_elems_ = 0;   // Bayer input: component planes + encode curve LUT
 	float kernel_ms_ = 0;
 	bool timed_ = false;
 	GpuEntropyEncoder ent_; bool ent_ready_ = false;

@@ -7,6 +7,7 @@
 #include "cfhd_kernels.h"
 #include <hip/hip_runtime.h>
 #include <string.h>
+#include <vector>
 #include <stdlib.h>
 #include <stdio.h>
 #include <mutex>
@@ -43,7 +44,8 @@ struct EncJobs {            // layout of the job table buffer of an EncodeBatch
 	dev::FwdYuvJob *yuv;    // [n]         level 1 of the packed 4:2:2 formats
 	dev::FwdPlaneJob *l2;   // [n * nch]
 	dev::FwdPlaneJob *l3;   // [n * nch]
-	dev::FwdPlaneJob *l1;   // [n * nch]   level 1 of the interleaved 16-bit 4:4:4(:4) formats (k_fwd_packed16)
+	dev::FwdPlaneJob *l1;   // [n * nch]   level 1 of the interleaved 16-bit 4:4:4(:4) formats (k_fwd_packed16) and of the Bayer planes (k_fwd_plane)
+	dev::BayerJob *bayer;   // [n]         Bayer mosaic -> component planes (k_unpack_byr4)
 };
 EncJobs enc_jobs_at(void *base, int n, int nch)
 {
@@ -52,9 +54,10 @@ EncJobs enc_jobs_at(void *base, int n, int nch)
 	j.l2 = (dev::FwdPlaneJob *)(j.yuv + n);
 	j.l3 = j.l2 + (size_t)n * nch;
 	j.l1 = j.l3 + (size_t)n * nch;
+	j.bayer = (dev::BayerJob *)(j.l1 + (size_t)n * nch);
 	return j;
 }
-size_t enc_jobs_bytes(int n, int nch) { return (size_t)n * sizeof(dev::FwdYuvJob) + 3 * (size_t)n * nch * sizeof(dev::FwdPlaneJob); }
+size_t enc_jobs_bytes(int n, int nch) { return (size_t)n * sizeof(dev::FwdYuvJob) + 3 * (size_t)n * nch * sizeof(dev::FwdPlaneJob) + (size_t)n * sizeof(dev::BayerJob); }
 
 struct DecJobs { dev::InvPlaneJob *l3, *l2; dev::InvYuvJob *yuv; dev::InvPlaneJob *l1; /* last level of the 4:4:4(:4) formats (k_inv_packed16) */ };
 DecJobs dec_jobs_at(void *base, int n, int nch)
@@ -131,6 +134,9 @@ void EncodeBatch::release()
 	if (h_coeff_) hipHostFree(h_coeff_);
 	if (d_jobs_) hipFree(d_jobs_);
 	if (h_jobs_) hipHostFree(h_jobs_);
+	if (d_planes_) hipFree(d_planes_);
+	if (d_curve_) hipFree(d_curve_);
+	d_planes_ = nullptr; d_curve_ = nullptr;
 	if (ev0_) hipEventDestroy((hipEvent_t)ev0_);
 	if (ev1_) hipEventDestroy((hipEvent_t)ev1_);
 	for (int k = 0; k < 2; k++) if (evl_[k]) { hipEventDestroy((hipEvent_t)evl_[k]); evl_[k] = nullptr; }
@@ -143,14 +149,25 @@ int EncodeBatch::prepare(const FramePlan &plan, int nframes, bool own_input)
 	int rc = device_init();
 	if (rc) return rc;
 	release();
-	if (plan.pixel_kind != PIX_YUY2 && plan.pixel_kind != PIX_2VUY && !is_packed16(plan.pixel_kind)) { g_err = "pixel format not supported by the GPU path yet"; return -2; }
+	const bool bayer = plan.pixel_kind == PIX_BYR4;
+	if (plan.pixel_kind != PIX_YUY2 && plan.pixel_kind != PIX_2VUY && !is_packed16(plan.pixel_kind) && !bayer) { g_err = "pixel format not supported by the GPU path yet"; return -2; }
 	plan_ = plan; n_ = nframes; own_input_ = own_input;
 	HIPCHK(hipStreamCreateWithFlags((hipStream_t *)&stream_, hipStreamNonBlocking));
 	HIPCHK(hipEventCreate((hipEvent_t *)&ev0_));
 	HIPCHK(hipEventCreate((hipEvent_t *)&ev1_));
 	for (int k = 0; k < 2; k++) HIPCHK(hipEventCreate((hipEvent_t *)&evl_[k]));
-	in_pitch_ = packed_frame_pitch(plan.pixel_kind, plan.width);
-	frame_bytes_ = (size_t)in_pitch_ * plan.display_height;
+	// Bayer: the plan describes the component planes (half the mosaic in both directions)
+	in_pitch_ = packed_frame_pitch(plan.pixel_kind, bayer ? 2 * plan.width : plan.width);
+	in_rows_ = bayer ? 2 * plan.display_height : plan.display_height;
+	frame_bytes_ = (size_t)in_pitch_ * in_rows_;
+	if (bayer) {
+		plane_elems_ = (size_t)plan.ch[0].band[0][0].pitch * 2 * plan.height;           // plane pitch = 2 x the level-1 band pitch (multiple of 16)
+		HIPCHK(hipMalloc((void **)&d_planes_, plane_elems_ * 2 * 4 * n_));
+		std::vector<uint16_t> curve((size_t)1 << kBayerCurveBits);
+		build_bayer_log90_curve(plan.precision, curve.data());
+		HIPCHK(hipMalloc((void **)&d_curve_, curve.size() * 2));
+		HIPCHK(hipMemcpy(d_curve_, curve.data(), curve.size() * 2, hipMemcpyHostToDevice));
+	}
 	if (own_input) {
 		HIPCHK(hipMalloc((void **)&d_in_, frame_bytes_ * n_));
 		HIPCHK(hipHostMalloc((void **)&h_in_, frame_bytes_ * n_, hipHostMallocDefault));
@@ -174,6 +191,21 @@ int EncodeBatch::prepare(const FramePlan &plan, int nframes, bool own_input)
 		for (int c = 0; c < 3; c++) {
 			y.out_pitch[c] = plan.ch[c].band[0][0].pitch;
 			for (int b = 0; b < 4; b++) { y.out[c][b] = base + plan.ch[c].band[0][b].offset; y.q[c][b] = make_q(plan.ch[c].band[0][b].quant, mpq); }
+		}
+		if (bayer) {
+			const int ppitch = plan.ch[0].band[0][0].pitch * 2;
+			dev::BayerJob &bj = j.bayer[i];
+			bj.in = own_input ? (const uint16_t *)(d_in_ + frame_bytes_ * i) : nullptr; bj.in_pitch = in_pitch_ / 2;
+			bj.width = plan.width; bj.height = plan.height; bj.display_height = plan.display_height;
+			bj.out_pitch = ppitch; bj.curve = d_curve_; bj.order = 0; bj.precision = plan.precision;
+			for (int c = 0; c < 4; c++) {
+				bj.out[c] = d_planes_ + ((size_t)i * 4 + c) * plane_elems_;
+				dev::FwdPlaneJob &p = j.l1[(size_t)i * nch + c];
+				p.in = bj.out[c]; p.in_pitch = ppitch; p.width = plan.ch[c].width; p.height = plan.ch[c].height; p.prescale = plan.prescale[0];
+				p.xstride = 1; p.shift = 0; p.display_height = plan.ch[c].height; p.compand = 0;
+				p.out_pitch = plan.ch[c].band[0][0].pitch;
+				for (int b = 0; b < 4; b++) { p.out[b] = base + plan.ch[c].band[0][b].offset; p.q[b] = make_q(plan.ch[c].band[0][b].quant, mpq); }
+			}
 		}
 		if (is_packed16(plan.pixel_kind))
 			for (int c = 0; c < nch; c++) {
@@ -219,10 +251,10 @@ int EncodeBatch::upload_frame(int i, const void *frame, int pitch)
 {
 	if (!own_input_ || i < 0 || i >= n_) return -1;
 	const uint8_t *src = (const uint8_t *)frame;
-	if (pitch < 0) { src += (ptrdiff_t)(plan_.display_height - 1) * pitch; pitch = -pitch; }     // encoder.c:1957
+	if (pitch < 0) { src += (ptrdiff_t)(in_rows_ - 1) * pitch; pitch = -pitch; }     // encoder.c:1957
 	uint8_t *dst = h_in_ + frame_bytes_ * i;
 	if (pitch == in_pitch_) memcpy(dst, src, frame_bytes_);
-	else for (int r = 0; r < plan_.display_height; r++) memcpy(dst + (size_t)r * in_pitch_, src + (size_t)r * pitch, (size_t)in_pitch_);
+	else for (int r = 0; r < in_rows_; r++) memcpy(dst + (size_t)r * in_pitch_, src + (size_t)r * pitch, (size_t)in_pitch_);
 	HIPCHK(hipMemcpyAsync(d_in_ + frame_bytes_ * i, dst, frame_bytes_, hipMemcpyHostToDevice, (hipStream_t)stream_));
 	return 0;
 }
@@ -231,6 +263,7 @@ int EncodeBatch::set_device_frame(int i, const void *d_frame, int pitch)
 {
 	if (i < 0 || i >= n_) return -1;
 	EncJobs j = enc_jobs_at(h_jobs_, n_, plan_.num_channels);
+	if (plan_.pixel_kind == PIX_BYR4) { j.bayer[i].in = (const uint16_t *)d_frame; j.bayer[i].in_pitch = pitch / 2; jobs_dirty_ = true; return 0; }
 	if (is_packed16(plan_.pixel_kind)) {
 		for (int c = 0; c < plan_.num_channels; c++) {
 			dev::FwdPlaneJob &p = j.l1[(size_t)i * plan_.num_channels + c];
@@ -253,7 +286,11 @@ int EncodeBatch::launch_forward()
 	(void)hipGetLastError();                            // drop stale sticky errors: the check below is for these launches only
 	timed_ = true;
 	HIPCHK(hipEventRecord((hipEvent_t)ev0_, st));
-	if (is_packed16(plan_.pixel_kind)) {
+	if (plan_.pixel_kind == PIX_BYR4) {
+		dev::k_unpack_byr4<<<dim3((plan_.width + dev::NTHREADS - 1) / dev::NTHREADS, plan_.height, n_), dev::NTHREADS, 0, st>>>(j.bayer);
+		dim3 grid((plan_.width / 2 + dev::TW - 1) / dev::TW, (plan_.height / 2 + dev::TH - 1) / dev::TH, n_ * nch);
+		dev::k_fwd_plane<<<grid, dev::NTHREADS, 0, st>>>(j.l1);
+	} else if (is_packed16(plan_.pixel_kind)) {
 		dim3 grid(((plan_.width / 2 + dev::TW - 1) / dev::TW) * nch, (plan_.height / 2 + dev::TH - 1) / dev::TH, n_);
 		dev::k_fwd_packed16<<<grid, dev::NTHREADS, 0, st>>>(j.l1, nch);
 	} else {

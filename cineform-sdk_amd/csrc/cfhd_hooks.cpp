@@ -53,7 +53,8 @@ int cfhd_amd_decode_bands_host(const uint8_t *sample, size_t size, int pixel_kin
 	int rc = parse_sample(sample, size, &ps);
 	if (rc) return rc < 0 ? rc : -30;
 	FramePlan plan;
-	if (!build_frame_plan(&plan, ps.width, ps.display_height, pixel_kind, ps.encoded_format)) return -20;
+	const int mosaic = ps.encoded_format == ENC_BAYER ? 2 : 1;       // a Bayer sample carries the component plane size; the plan is built from the mosaic's
+	if (!build_frame_plan(&plan, ps.width * mosaic, ps.display_height * mosaic, pixel_kind, ps.encoded_format)) return -20;
 	if (coeff_elems < plan.coeff_elems) return -21;
 	info[0] = ps.width; info[1] = ps.height; info[2] = ps.display_height; info[3] = ps.num_channels; info[4] = ps.precision;
 	info[5] = ps.encoded_format; info[6] = ps.prescale_table; info[7] = ps.frame_number;
@@ -83,3 +84,6 @@ int cfhd_amd_decode_bands_host(const uint8_t *sample, size_t size, int pixel_kin
 }
 
 } // extern "C"
+
+// Test hook: the Bayer encode curve the device path uploads (must equal the oracle's restatement entry for entry).
+extern "C" void cfhd_amd_bayer_curve(int precision, uint16_t *curve) { cfhd::build_bayer_log90_curve(precision, curve); }

@@ -74,6 +74,15 @@ struct InvYuvJob {
 	uint8_t *out; int out_pitch;            // bytes
 };
 
+struct BayerJob {                           // k_unpack_byr4: 16-bit Bayer mosaic -> component planes G, R-G, B-G, G1-G2
+	const uint16_t *in; int in_pitch;       // words per mosaic row
+	int width, height, display_height;      // component plane (half the mosaic); rows >= display_height repeat the last quad row
+	int16_t *out[4]; int out_pitch;
+	const uint16_t *curve;                  // encode curve over 14-bit linear input (log 90 by default)
+	int order;                              // BAYER_FORMAT_*: 0 R G / G B, 1 G R / B G, 2 G B / R G, 3 B G / G R (CFHDMetadataTags.h:72-75)
+	int precision;
+};
+
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int sat16(int x) { return x < -32768 ? -32768 : (x > 32767 ? 32767 : x); }
 __device__ __forceinline__ int adds16(int a, int b) { return sat16(a + b); }
@@ -781,6 +790,38 @@ __global__ void __launch_bounds__(NTHREADS) k_inv_yuv422(const InvYuvJob *jobs, 
 			*(uint2 *)(job.out + (size_t)orow * job.out_pitch + 8 * (size_t)cc) = o2;
 		}
 	}
+}
+
+// =============================================================================================
+// Bayer input (ConvertBYR4ToFrame16s, frame.c:4993, curve branch :5219-5393): every 2x2 quad of the mosaic gives one sample of the
+// four component planes: the encode curve LUT is applied to each photosite (>> 2 to the LUT's 14 bits), then g = (g1+g2)>>1,
+// rg = ((r-g)>>1) + mid, bg = ((b-g)>>1) + mid, gd = (g1-g2+2*mid)>>1 with mid = 2^(precision-1).  One lane per quad; a wave reads
+// 256 consecutive bytes of each of the two mosaic rows.  The planes then go through k_fwd_plane like any other level.
+// =============================================================================================
+__global__ void __launch_bounds__(NTHREADS) k_unpack_byr4(const BayerJob *jobs)
+{
+	__shared__ BayerJob s_job;
+	stage_job(&s_job, &jobs[blockIdx.z]);
+	const BayerJob &job = s_job;
+	const int x = blockIdx.x * NTHREADS + threadIdx.x, row = blockIdx.y;
+	if (x >= job.width || row >= job.height) return;
+	const int srow = row < job.display_height ? row : job.display_height - 1;
+	const uint16_t *l1 = job.in + (size_t)(2 * srow) * job.in_pitch, *l2 = l1 + job.in_pitch;
+	const uint32_t a = *(const uint32_t *)(l1 + 2 * x), b = *(const uint32_t *)(l2 + 2 * x);      // (left, right) photosites of the two rows
+	const int tl = job.curve[(a & 0xffffu) >> 2], tr = job.curve[a >> 18], bl = job.curve[(b & 0xffffu) >> 2], br = job.curve[b >> 18];
+	int r, g1, g2, bb;
+	switch (job.order) {
+	case 0: r = tl; g1 = tr; g2 = bl; bb = br; break;
+	case 1: g1 = tl; r = tr; bb = bl; g2 = br; break;
+	case 3: bb = tl; g1 = tr; g2 = bl; r = br; break;
+	default: g1 = tl; bb = tr; r = bl; g2 = br; break;
+	}
+	const int mid = 1 << (job.precision - 1), g = (g1 + g2) >> 1;
+	const size_t o = (size_t)row * job.out_pitch + x;
+	job.out[0][o] = (int16_t)g;
+	job.out[1][o] = (int16_t)(((r - g) >> 1) + mid);
+	job.out[2][o] = (int16_t)(((bb - g) >> 1) + mid);
+	job.out[3][o] = (int16_t)((g1 - g2 + 2 * mid) >> 1);
 }
 
 } // namespace dev

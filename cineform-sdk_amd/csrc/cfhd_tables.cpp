@@ -7,6 +7,7 @@
 #include "cfhd_core.h"
 #include "cfhd_codebook_data.h"
 #include <string.h>
+#include <math.h>
 #include <stdlib.h>
 #include <mutex>
 #include <algorithm>
@@ -250,6 +251,20 @@ bool build_frame_plan(FramePlan *plan, int width, int height, int pixel_kind, in
 	return true;
 }
 
+// BYR4_LOGTABLE (frame.c:5228) with CURVE_LIN2LOG = lin2log() (Common/AVIExtendedHeader.h:124,153): the float / double mix is the reference's, so
+// the truncation to int falls on the same side for every entry.
+void build_bayer_log90_curve(int precision, uint16_t *curve)
+{
+	const int max_value = 1 << kBayerCurveBits;
+	curve[0] = 0;
+	for (int i = 1; i < max_value; i++) {
+		const float x = (float)i / (float)max_value;
+		const float b = 90.0f;
+		const float y = (float)(log10(x * (b - 1.0) + 1.0) / log10(b));       /* lin2log() returns float (AVIExtendedHeader.h:153-156) */
+		curve[i] = (uint16_t)(int)(y * (float)((1 << precision) - 1));
+	}
+}
+
 // ------------------------------------------------------------------------------------------
 // Quantizer
 // ------------------------------------------------------------------------------------------
@@ -271,6 +286,9 @@ const int kChromaQ[4][17] = {
 void derive_quantization(FramePlan *plan, int quality, bool progressive, float framerate, QuantState *st)
 {
 	int qL[17], qC[17], qLmax[17], qCmax[17];
+	// Bayer input: the encoder pins the RGB quality bits before it derives the tables ("prevent increased quant on channels 1-3",
+	// encoder.c:2638); the sample header keeps the caller's quality word
+	if (plan->encoded_format == ENC_BAYER) quality |= 3 << 25;
 	// encoder.c:1141 SetEncoderQuantization: ChromaFullRes = (input colour format >= COLOR_FORMAT_BAYER (100)): true for RG48 (120) and
 	// BYR4 (104), false for the packed 4:2:2 formats and -- although it is a 4:4:4:4 format -- for b64a (COLOR_FORMAT_BGRA64 = 30),
 	// whose R, B and A planes therefore get the chroma tables

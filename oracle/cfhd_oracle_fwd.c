@@ -180,3 +180,35 @@ void orc_fwd_spatial_yuv422(const uint8_t *in, int in_pitch_bytes, int width, in
 	struct yuv_src s = { in, in_pitch_bytes, width, channel, shift, uyvy };
 	fwd_spatial_generic(yuv_row, &s, width, height, 0, quant, midpoint_prequant, bands, band_pitch);
 }
+
+/* Default encode curve of the Bayer input path: log base 90 over 14-bit linear input (MAX_INPUT_PRECISION, frame.c:4843), scaled to the codec
+ * precision.  Codec/frame.c:5219-5235 (BYR4_LOGTABLE with LOGBASE 90) and Common/AVIExtendedHeader.h:124,153 CURVE_LIN2LOG = lin2log(); the
+ * expression keeps the reference's float/double mix so that the truncation to int falls on the same side. */
+#include <math.h>
+void orc_byr4_log90_curve(int precision, int input_bits, uint16_t *curve)
+{
+	const int max_value = 1 << input_bits;
+	int i;
+	curve[0] = 0;
+	for (i = 1; i < max_value; i++) {
+		const float x = (float)i / (float)max_value;
+		const float b = 90.0f;
+		const float y = (float)(log10(x * (b - 1.0) + 1.0) / log10(b));       /* lin2log() returns float (AVIExtendedHeader.h:153-156) */
+		curve[i] = (uint16_t)(int)(y * (float)((1 << precision) - 1));
+	}
+}
+
+/* One row of 2x2 Bayer quads (red-green order: R G1 / G2 B) -> the four component planes G, R-G, B-G, G1-G2 of
+ * ConvertBYR4ToFrame16s (frame.c:5380-5393): curve first, then g = (g1+g2)>>1, rg = ((r-g)>>1) + mid, bg likewise,
+ * gd = (g1-g2+2*mid)>>1 with mid = 2^(precision-1). */
+void orc_byr4_unpack_row(const uint16_t *line1, const uint16_t *line2, int width, int precision, int input_bits, const uint16_t *curve,
+                         PIXEL16 *g_out, PIXEL16 *rg_out, PIXEL16 *bg_out, PIXEL16 *gd_out)
+{
+	const int mid = 1 << (precision - 1), sh = 16 - input_bits;
+	int x;
+	for (x = 0; x < width; x++) {
+		const int r = curve[line1[2 * x] >> sh], g1 = curve[line1[2 * x + 1] >> sh], g2 = curve[line2[2 * x] >> sh], b = curve[line2[2 * x + 1] >> sh];
+		const int g = (g1 + g2) >> 1;
+		g_out[x] = (PIXEL16)g; rg_out[x] = (PIXEL16)(((r - g) >> 1) + mid); bg_out[x] = (PIXEL16)(((b - g) >> 1) + mid); gd_out[x] = (PIXEL16)((g1 - g2 + 2 * mid) >> 1);
+	}
+}

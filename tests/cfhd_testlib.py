@@ -24,6 +24,9 @@ PIX_YUY2 = fourcc("YUY2")
 PIX_2VUY = fourcc("2vuy")
 PIX_RG48 = fourcc("RG48")
 PIX_B64A = fourcc("b64a")
+PIX_BYR4 = fourcc("BYR4")
+ENCODED_BAYER = 3       # CFHD_ENCODED_FORMAT_BAYER
+COLOR_FORMAT_BYR4 = 104 # Codec/color.h
 ENCODED_RGBA4444 = 2    # CFHD_ENCODED_FORMAT_RGBA_4444
 COLOR_FORMAT_B64A = 30  # COLOR_FORMAT_BGRA64, Codec/color.h
 ENCODED_RGB444 = 1      # CFHD_ENCODED_FORMAT_RGB_444
@@ -274,13 +277,37 @@ def b64a_planes(frame, pitch, w, h):
     return [(px[:, :, 2] >> 4).astype(np.int16), (px[:, :, 1] >> 4).astype(np.int16), (px[:, :, 3] >> 4).astype(np.int16), a.astype(np.int16)]
 
 
+def synth_bayer(width, height, seed):
+    """Deterministic 16-bit Bayer mosaic (red-green order) with smooth structure, texture and noise; TestCFHD has no BYR4 generator."""
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:height, 0:width]
+    lum = (np.sin(x / 37.0 + seed) * np.cos(y / 23.0) * 0.35 + 0.45) * 52000 + (x * y % 4099) * 2.0 + rng.normal(0, 120, (height, width))
+    gain = np.where((y % 2 == 0) & (x % 2 == 0), 0.8, np.where((y % 2 == 1) & (x % 2 == 1), 0.6, 1.0))       # R, B darker than the greens
+    return np.clip(lum * gain, 0, 65535).astype(np.uint16)
+
+
+def byr4_planes(mosaic):
+    """G, R-G, B-G, G1-G2 planes of a Bayer mosaic through the oracle's restatement of ConvertBYR4ToFrame16s (default log-90 curve)."""
+    O = oracle()
+    curve = np.zeros(1 << 14, np.uint16)
+    O.orc_byr4_log90_curve.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    O.orc_byr4_log90_curve(12, 14, curve.ctypes.data_as(ctypes.c_void_p))
+    O.orc_byr4_unpack_row.argtypes = [ctypes.c_void_p] * 2 + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 5
+    ph, pw = mosaic.shape[0] // 2, mosaic.shape[1] // 2
+    planes = [np.zeros((ph, pw), np.int16) for _ in range(4)]
+    for r in range(ph):
+        O.orc_byr4_unpack_row(mosaic[2 * r].ctypes.data_as(ctypes.c_void_p), mosaic[2 * r + 1].ctypes.data_as(ctypes.c_void_p), pw, 12, 14,
+                              curve.ctypes.data_as(ctypes.c_void_p), *[p[r].ctypes.data_as(ctypes.c_void_p) for p in planes])
+    return planes
+
+
 def oracle_forward_planes(plan, planes):
     """Forward path of a 4:4:4(:4) frame with the oracle from its component planes (rows below the picture repeat the last row,
     frame.c:6020-6024), written into the product's pyramid layout."""
     O = oracle()
     coeffs = np.zeros(plan.coeff_elems, dtype=np.int16)
-    H = plan.height; w = plan.width
     for c, pl in enumerate(planes):
+        H, w = 2 * plan.band[(c, 0, 0)]["height"], 2 * plan.band[(c, 0, 0)]["width"]     # component plane (half the mosaic for Bayer)
         src = np.zeros((H, w), np.int16); src[: pl.shape[0]] = pl; src[pl.shape[0]:] = pl[-1]
         for lv in (0, 1, 2):
             if lv:

@@ -63,6 +63,16 @@ void emu_inv_packed16(int16_t **bands, int band_pitch, int w, int h, int display
 	hipemu::launch(grid, dim3(NTHREADS), [&] { k_inv_packed16(jobs.data(), nch); });
 }
 
+void emu_unpack_byr4(const uint16_t *in, int in_pitch_words, int width, int height, int display_height, const uint16_t *curve, int order, int precision,
+                     int16_t **out /*[4]*/, int out_pitch)
+{
+	BayerJob job;
+	job.in = in; job.in_pitch = in_pitch_words; job.width = width; job.height = height; job.display_height = display_height;
+	job.curve = curve; job.order = order; job.precision = precision; job.out_pitch = out_pitch;
+	for (int c = 0; c < 4; c++) job.out[c] = out[c];
+	hipemu::launch(dim3((width + NTHREADS - 1) / NTHREADS, height, 1), dim3(NTHREADS), [&] { k_unpack_byr4(&job); });
+}
+
 void emu_fwd_yuv422(const uint8_t *in, int in_pitch, int width, int height, int display_height, int uyvy, int shift,
                     const int *quant /*[3][4]*/, int mpq, int16_t **out /*[3][4]*/, const int *out_pitch)
 {

@@ -351,3 +351,15 @@ def test_b64a_encode_bitstream_identical(w, h):
     b = ref_encode_frames([frame], pitch, w, h, PIX_B64A, encoded=ENCODED_RGBA4444)[0]
     assert len(a) == len(b)
     assert mask_volatile_metadata(a) == mask_volatile_metadata(b)
+
+
+@pytest.mark.skipif(not have_ref(), reason="needs the reference encoder")
+@pytest.mark.parametrize("w,h", [(192, 96), (1920, 1080), (3840, 2160)])
+def test_byr4_encode_bitstream_identical(w, h):
+    """Config D, Bayer half: BYR4 -> CFHD_ENCODED_FORMAT_BAYER (k_unpack_byr4 + k_fwd_plane), default pixel order and encode curve."""
+    frames = [synth_bayer(w, h, 7 + i).reshape(-1).view(np.uint8).copy() for i in range(2 if w < 3840 else 1)]
+    mine = amd_encode_frames(frames, w * 2, w, h, PIX_BYR4, encoded=ENCODED_BAYER)
+    refs = ref_encode_frames(frames, w * 2, w, h, PIX_BYR4, encoded=ENCODED_BAYER)
+    for i, (a, b) in enumerate(zip(mine, refs)):
+        assert len(a) == len(b), "frame %d: size %d vs reference %d" % (i, len(a), len(b))
+        assert mask_volatile_metadata(a) == mask_volatile_metadata(b), "frame %d" % i

@@ -110,3 +110,28 @@ def test_b64a_rgba4444_sample_bytes_equal_reference(w, h):
     off, n = first_metadata_chunk(rs)
     mine = product_write_sample_host(plan, coeffs, 1, meta_global=rs[off:off + n], input_format=COLOR_FORMAT_B64A, color_space=0)
     assert mine == rs
+
+
+@pytest.mark.parametrize("w,h", [(192, 96), (640, 352), (1920, 1080)])
+def test_byr4_bayer_sample_bytes_equal_reference(w, h):
+    """SURVEY 8a9 / config D (Bayer half): BYR4 mosaic -> four half-resolution planes through the log-90 encode curve -> Bayer sample
+    (RGB quality bits pinned for the quantizer only, encoder.c:2638).  Pins orc_byr4_* and the product's tables/writer on the reference."""
+    if not have_ref(): pytest.skip("reference .so not built")
+    mosaic = synth_bayer(w, h, 3)
+    frame = mosaic.reshape(-1).view(np.uint8).copy()
+    rs = ref_encode_frames([frame], w * 2, w, h, PIX_BYR4, encoded=ENCODED_BAYER)[0]
+    plan = Plan(w, h, pixkind=PIXKIND["BYR4"], enc=2)
+    assert plan.num_channels == 4 and plan.precision == 12
+    coeffs = oracle_forward_planes(plan, byr4_planes(mosaic))
+    off, n = first_metadata_chunk(rs)
+    mine = product_write_sample_host(plan, coeffs, 1, meta_global=rs[off:off + n], input_format=COLOR_FORMAT_BYR4, color_space=0)
+    assert mine == rs
+
+
+def test_bayer_curve_table_equals_oracle():
+    want = np.zeros(1 << 14, np.uint16); got = np.zeros(1 << 14, np.uint16)
+    oracle().orc_byr4_log90_curve.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    oracle().orc_byr4_log90_curve(12, 14, want.ctypes.data_as(ctypes.c_void_p))
+    product().cfhd_amd_bayer_curve.argtypes = [ctypes.c_int, ctypes.c_void_p]
+    product().cfhd_amd_bayer_curve(12, got.ctypes.data_as(ctypes.c_void_p))
+    assert np.array_equal(got, want)

@@ -258,3 +258,29 @@ def test_inv_packed16_last_level_of_444_formats(w, h, dh, nch):
     E.emu_inv_packed16((c_i16p * len(flat))(*flat), pitch, w, h, dh, nch, 12, iarr(words), got.ctypes.data_as(ctypes.c_void_p), 2 * w * nch)
     assert np.array_equal(got, want[:dh])
     assert (want == 65535).any() and (want == 65520).any() and (want == 0).any()
+
+
+@pytest.mark.parametrize("w,h,dh", [(40, 8, 8), (300, 24, 21)])
+def test_unpack_byr4_equals_oracle(w, h, dh):
+    """k_unpack_byr4 (Bayer mosaic -> G, R-G, B-G, G1-G2 planes through the log-90 curve) = oracle restatement of ConvertBYR4ToFrame16s
+    (pinned against the reference encoder's samples in test_host_bitstream); rows below the picture repeat the last quad row."""
+    rng = np.random.default_rng(w + h)
+    mosaic = rng.integers(0, 65536, size=(2 * dh, 2 * w), dtype=np.int64).astype(np.uint16)
+    O = oracle()
+    curve = np.zeros(1 << 14, np.uint16)
+    O.orc_byr4_log90_curve.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    O.orc_byr4_log90_curve(12, 14, curve.ctypes.data_as(ctypes.c_void_p))
+    assert curve[-1] == 4094 and curve[1] > 0 and np.all(np.diff(curve.astype(np.int32)) >= 0)
+    O.orc_byr4_unpack_row.argtypes = [ctypes.c_void_p] * 2 + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 5
+    pitch = (w + 15) // 16 * 16
+    want = [np.zeros((h, pitch), np.int16) for _ in range(4)]
+    for r in range(h):
+        sr = min(r, dh - 1)
+        O.orc_byr4_unpack_row(mosaic[2 * sr].ctypes.data_as(ctypes.c_void_p), mosaic[2 * sr + 1].ctypes.data_as(ctypes.c_void_p), w, 12, 14,
+                              curve.ctypes.data_as(ctypes.c_void_p), *[p[r].ctypes.data_as(ctypes.c_void_p) for p in want])
+    got = [np.zeros((h, pitch), np.int16) for _ in range(4)]
+    E = emu()
+    E.emu_unpack_byr4.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    E.emu_unpack_byr4(mosaic.ctypes.data_as(ctypes.c_void_p), 2 * w, w, h, dh, curve.ctypes.data_as(ctypes.c_void_p), 0, 12, (c_i16p * 4)(*[p16(g) for g in got]), pitch)
+    for c in range(4):
+        assert np.array_equal(got[c], want[c]), c
