@@ -255,13 +255,22 @@ bool build_frame_plan(FramePlan *plan, int width, int height, int pixel_kind, in
 // the truncation to int falls on the same side for every entry.
 void build_bayer_log90_curve(int precision, uint16_t *curve)
 {
+	// Every intermediate is rounded exactly where the reference (gcc, plain IEEE sequence) rounds it: no fused multiply-add, no
+	// reciprocal, the quotient narrowed to float before the scaling.  `volatile` pins the sequence whatever the host compiler's
+	// floating-point contraction default is (hipcc's differs from gcc's; two of the 16384 entries depend on it).
 	const int max_value = 1 << kBayerCurveBits;
+	const volatile double base_m1 = 89.0, log_base = log10(90.0);
+	const volatile float top = (float)((1 << precision) - 1);
 	curve[0] = 0;
 	for (int i = 1; i < max_value; i++) {
-		const float x = (float)i / (float)max_value;
-		const float b = 90.0f;
-		const float y = (float)(log10(x * (b - 1.0) + 1.0) / log10(b));       /* lin2log() returns float (AVIExtendedHeader.h:153-156) */
-		curve[i] = (uint16_t)(int)(y * (float)((1 << precision) - 1));
+		volatile float x = (float)i / (float)max_value;
+		volatile double prod = (double)x * base_m1;
+		volatile double arg = prod + 1.0;
+		volatile double lg = log10(arg);
+		volatile double quot = lg / log_base;
+		volatile float y = (float)quot;                    // lin2log() returns float (AVIExtendedHeader.h:153-156)
+		volatile float scaled = y * top;
+		curve[i] = (uint16_t)(int)scaled;
 	}
 }
 
