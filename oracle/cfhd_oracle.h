@@ -40,6 +40,8 @@ void orc_fwd_spatial_yuv422(const uint8_t *in, int in_pitch_bytes, int width, in
 /* ---- inverse path ---- */
 /* One 2-D inverse level: 4 bands (h x w) -> out (2h x 2w). descale!=0 selects the
  * "Descale" variant used when the encoder prescaled that level by 2 bits. */
+void orc_fwd_frame_yuv422(const uint8_t *in, int in_pitch_bytes, int width, int height, int channel, int shift, int uyvy,
+                          const int quant[4], int midpoint_prequant, PIXEL16 *bands[4], int band_pitch);
 void orc_byr4_log90_curve(int precision, int input_bits, uint16_t *curve);
 void orc_byr4_unpack_row(const uint16_t *line1, const uint16_t *line2, int width, int precision, int input_bits, const uint16_t *curve,
                          PIXEL16 *g_out, PIXEL16 *rg_out, PIXEL16 *bg_out, PIXEL16 *gd_out);

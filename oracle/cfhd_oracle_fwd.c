@@ -212,3 +212,51 @@ void orc_byr4_unpack_row(const uint16_t *line1, const uint16_t *line2, int width
 		g_out[x] = (PIXEL16)g; rg_out[x] = (PIXEL16)(((r - g) >> 1) + mid); bg_out[x] = (PIXEL16)(((b - g) >> 1) + mid); gd_out[x] = (PIXEL16)((g1 - g2 + 2 * mid) >> 1);
 	}
 }
+
+/* Interlaced ("frame") level 1 of a packed 4:2:2 picture, one channel.  Codec/wavelet.c:6076 TransformForwardFrameYUV: for every
+ * pair of rows (2k, 2k+1) the temporal pair low = r0 + r1, high = r1 - r0 of the samples << (precision - 8) (temporal.c:1915
+ * FilterTemporalRowYUYVChannelTo16s, saturating adds/subs :2160-2163), then
+ *   LL, LH = FilterHorizontalRow16s(low)             (LL stored as is, LH through QuantizeRow16sTo16s),
+ *   HL, HH = FilterHorizontalRowScaled16sDifferenceFiltered(high) (spatial.c:5327): the horizontal lowpass is quantized inside with
+ *            midpoint = divisor / midpoint_prequant (no "-1 for prequant 2" here, :5360-5363) and then difference coded along the
+ *            row, q[x] - q[x-1] (:5608-5611); HH through QuantizeRow16sTo16s.
+ * (The raw store behind the vector loop, :5621-5622, sits under !_PREROLL and is compiled out: rows whose width is not a multiple
+ * of 16 samples are regular too -- checked against reference samples of 720-wide pictures, chroma width 360.) */
+static int quant_inside(int v, int divisor, int mpq)
+{
+	int mid = (mpq >= 2 && mpq < 9) ? divisor / mpq : 0;
+	int mult = (int)((1u << 16) / (unsigned)divisor);
+	int a = v < 0 ? -v : v;
+	if (divisor <= 1) return v;
+	a = (int)(((long long)(a + mid) * mult) >> 16);
+	return v < 0 ? -a : a;
+}
+
+void orc_fwd_frame_yuv422(const uint8_t *in, int in_pitch_bytes, int width, int height, int channel, int shift, int uyvy,
+                          const int quant[4], int midpoint_prequant, PIXEL16 *bands[4], int band_pitch)
+{
+	const int half = width / 2;
+	PIXEL16 *r0 = (PIXEL16 *)malloc((size_t)width * 2), *r1 = (PIXEL16 *)malloc((size_t)width * 2);
+	PIXEL16 *tl = (PIXEL16 *)malloc((size_t)width * 2), *th = (PIXEL16 *)malloc((size_t)width * 2);
+	PIXEL16 *lo = (PIXEL16 *)malloc((size_t)half * 2), *hi = (PIXEL16 *)malloc((size_t)half * 2);
+	int k, x;
+	for (k = 0; k < height / 2; k++) {
+		orc_unpack_yuyv_row(in + (size_t)(2 * k) * in_pitch_bytes, r0, width, channel, shift, uyvy);
+		orc_unpack_yuyv_row(in + (size_t)(2 * k + 1) * in_pitch_bytes, r1, width, channel, shift, uyvy);
+		for (x = 0; x < width; x++) { tl[x] = (PIXEL16)adds(r0[x], r1[x]); th[x] = (PIXEL16)subs(r1[x], r0[x]); }
+		orc_fwd_horizontal(tl, width, 0, bands[0] + (size_t)k * band_pitch, hi);
+		orc_quantize_row(hi, bands[1] + (size_t)k * band_pitch, half, quant[1], midpoint_prequant);
+		orc_fwd_horizontal(th, width, 0, lo, hi);
+		{
+			PIXEL16 *hl = bands[2] + (size_t)k * band_pitch;
+			int prev = 0;
+			for (x = 0; x < half; x++) {
+				const int q = quant_inside(lo[x], quant[2], midpoint_prequant);
+				hl[x] = (PIXEL16)sat16(q - prev);
+				prev = q;
+			}
+		}
+		orc_quantize_row(hi, bands[3] + (size_t)k * band_pitch, half, quant[3], midpoint_prequant);
+	}
+	free(r0); free(r1); free(tl); free(th); free(lo); free(hi);
+}

@@ -105,3 +105,31 @@ def test_reference_rg48_decode_equals_oracle(w, h):
     plan = Plan(w, h, pixkind=PIXKIND["RG48"], enc=3)
     mine = oracle_inverse_rgb48(plan, host_decode_pyramid(sample, plan))[:h]
     assert np.array_equal(mine, img)
+
+
+@pytest.mark.parametrize("w,h", [(192, 96), (720, 480)])
+def test_interlaced_level1_oracle_equals_reference_coefficients(w, h):
+    """Groundwork for SURVEY 8 a8 (1080i, not built on the GPU yet): the oracle's restatement of the interlaced level-1 "frame"
+    transform -- temporal sum/difference of each row pair, horizontal 2/6, quantizer inside the difference-coded HL band -- equals
+    the coefficients of a reference sample encoded with CFHD_ENCODING_FLAGS_YUV_INTERLACED, band by band (HL1 is coded with
+    codebook 2 and difference coding, flags 18; decoded here with the product's host VLC decoder).  Content without peak values
+    (|coefficient| <= 250, codec.h:155)."""
+    frame, pitch = synth_yuy2(w, h, 3)
+    sample = ref_encode_frames([frame], pitch, w, h, PIX_YUY2, encoded=ENCODED_YUV422, flags=1)[0]
+    plan = Plan(w, h, progressive=0)
+    assert [plan.band[(0, 0, b)]["quant"] for b in (1, 2, 3)] == [36, 16, 36] and plan.band[(1, 0, 3)]["quant"] == 48
+    O = oracle()
+    coeffs = np.zeros(plan.coeff_elems, dtype=np.int16)
+    for c in range(3):
+        cw = w if c == 0 else w // 2
+        q = [plan.band[(c, 0, b)]["quant"] for b in range(4)]
+        outs = [plan.view(coeffs, c, 0, b) for b in range(4)]
+        bands = (c_i16p * 4)(*[o.ctypes.data_as(c_i16p) for o in outs])
+        O.orc_fwd_frame_yuv422(p8(frame), pitch, cw, plan.height, c, plan.precision - 8, 0, iarr(q), plan.mpq, bands, outs[0].shape[1])
+    deq = host_decode_pyramid(sample, plan, lowpass_offset=0)
+    for c in range(3):
+        for b in (1, 2, 3):
+            bw = plan.band[(c, 0, b)]["width"]
+            want = (plan.view(coeffs, c, 0, b).astype(np.int32) * plan.band[(c, 0, b)]["quant"]).astype(np.int16)
+            assert np.abs(plan.view(coeffs, c, 0, b)).max() <= 250
+            assert np.array_equal(plan.view(deq, c, 0, b)[:, :bw], want[:, :bw]), (c, b)
