@@ -22,10 +22,11 @@
 namespace cfhd {
 namespace dev {
 
-// A segment = 1024 consecutive raster coefficients of a band = the work of one wave (16 coefficients per lane); four waves per
+// A segment = 1024 consecutive raster coefficients of a band = the work of one wave (16 coefficients per lane; 512 was measured
+// slower: the per-wave descriptor loads dominate); four waves per
 // workgroup, no workgroup barriers in k_ent_count / k_ent_emit: all exchanges are wave-level (ballot / bpermute / shuffles).
 enum { ENT_THREADS = 256, ENT_LANES = 64, ENT_WAVES = ENT_THREADS / ENT_LANES, ENT_PER_THREAD = 16, ENT_SEG = ENT_LANES * ENT_PER_THREAD,
-       ENT_LDS_WORDS = 1024, ENT_MAX_HOLES = 40 };
+       ENT_LDS_WORDS = ENT_SEG, ENT_MAX_HOLES = 40 };
 
 struct EntTables {
 	uint32_t value_code[2048];     // size << 27 | code word, index = value & 0x7ff
@@ -137,14 +138,18 @@ __device__ __forceinline__ uint32_t value_entry(const EntTables *T, int v)
 	return T->value_code[v];
 }
 
-// Loads the 16 coefficients of this lane (raster indices base .. base+15, zero beyond the band).
+// Loads the ENT_PER_THREAD coefficients of this lane (raster indices base .. base+ENT_PER_THREAD-1, zero beyond the band) with 16-byte loads.
 __device__ __forceinline__ void ent_load16(const EntSegJob &job, int base, int *v)
 {
+	static_assert(ENT_PER_THREAD % 8 == 0, "whole uint4 loads");
 	if (base + ENT_PER_THREAD <= job.n) {
-		const uint4 q0 = *(const uint4 *)(job.coeffs + base), q1 = *(const uint4 *)(job.coeffs + base + 8);
-		const uint32_t w[8] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w };
 #pragma unroll
-		for (int k = 0; k < 8; k++) { v[2 * k] = (int)(int16_t)(w[k] & 0xffffu); v[2 * k + 1] = (int)(int16_t)(w[k] >> 16); }
+		for (int g = 0; g < ENT_PER_THREAD / 8; g++) {
+			const uint4 q = *(const uint4 *)(job.coeffs + base + 8 * g);
+			const uint32_t w[4] = { q.x, q.y, q.z, q.w };
+#pragma unroll
+			for (int k = 0; k < 4; k++) { v[8 * g + 2 * k] = (int)(int16_t)(w[k] & 0xffffu); v[8 * g + 2 * k + 1] = (int)(int16_t)(w[k] >> 16); }
+		}
 	} else {
 #pragma unroll
 		for (int k = 0; k < ENT_PER_THREAD; k++) v[k] = (base + k < job.n) ? (int)job.coeffs[base + k] : 0;
@@ -160,12 +165,24 @@ __device__ __forceinline__ int wave_prev_nonzero(int my_last, int lane, unsigned
 }
 
 // =============================================================================================
-__global__ void __launch_bounds__(ENT_THREADS) k_ent_count(const EntSegJob *seg_jobs, int total_segs, EntSegState *segs, const EntTables *T)
+// The segment table describes frame 0 only (every frame of a batch has the same geometry): frame f's segment s uses entry s with the
+// coefficient base moved by f pyramids and the band index by f * bands_per_frame, so the table (96 KB at 1080p) stays in L2 instead
+// of being streamed once per frame.
+struct EntBatchGeom { int segs_per_frame, bands_per_frame; size_t coeff_stride; };
+__device__ __forceinline__ EntSegJob ent_seg_job(const EntSegJob *seg_jobs, const EntBatchGeom &g, int seg)
+{
+	const int f = seg / g.segs_per_frame, s = seg - f * g.segs_per_frame;
+	EntSegJob job = seg_jobs[s];
+	job.coeffs += (size_t)f * g.coeff_stride; job.band += f * g.bands_per_frame;
+	return job;
+}
+
+__global__ void __launch_bounds__(ENT_THREADS) k_ent_count(const EntSegJob *seg_jobs, EntBatchGeom geom, int total_segs, EntSegState *segs, const EntTables *T)
 {
 	const int lane = wave_lane();
 	const int seg = wave_uniform((int)blockIdx.x * ENT_WAVES + (int)(threadIdx.x >> 6));
 	if (seg >= total_segs) return;                       // whole wave
-	const EntSegJob job = seg_jobs[seg];
+	const EntSegJob job = ent_seg_job(seg_jobs, geom, seg);
 	const int base = job.first + lane * ENT_PER_THREAD;
 	int v[ENT_PER_THREAD];
 	ent_load16(job, base, v);
@@ -331,7 +348,7 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_layout(const EntFrameJob *f
 }
 
 // =============================================================================================
-__global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(const EntSegJob *seg_jobs, int total_segs, const EntSegState *segs, const EntBandState *band_state, const EntTables *T)
+__global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(const EntSegJob *seg_jobs, EntBatchGeom geom, int total_segs, const EntSegState *segs, const EntBandState *band_state, const EntTables *T)
 {
 	__shared__ uint32_t s_words_all[ENT_WAVES][ENT_LDS_WORDS + 2];
 	__shared__ uint32_t s_tok_all[ENT_WAVES][ENT_SEG];   // the segment's tokens, compacted: local raster index << 16 | value (16 bits)
@@ -339,7 +356,7 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(const EntSegJob *seg_j
 	const int wave = wave_uniform((int)(threadIdx.x >> 6));
 	const int seg = wave_uniform((int)blockIdx.x * ENT_WAVES + wave);
 	if (seg >= total_segs) return;
-	const EntSegJob job = seg_jobs[seg];
+	const EntSegJob job = ent_seg_job(seg_jobs, geom, seg);
 	const EntSegState st = segs[seg];
 	if (st.bits == 0) return;                            // wave-uniform: nothing starts in this segment
 	uint32_t *out = (uint32_t *)band_state[job.band].out;
@@ -391,8 +408,32 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(const EntSegJob *seg_j
 		for (int d = 1; d < ENT_LANES; d <<= 1) { const uint32_t x = __shfl_up(sc, (unsigned)d); if (lane >= d) sc += x; }
 		uint64_t pos = round_pos + (sc - bits);
 		round_pos += __shfl(sc, ENT_LANES - 1);
+		// A run of 3072 zeros or more (the first token behind a flat stretch: up to the whole band) starts with nrep copies of the
+		// longest composite code (greedy loop, encoder.c:5488-5545).  One lane writing hundreds of them one after the other held
+		// its wave for > 100 us: the wave writes them together, 64 copies per step, and the lane goes on with the remainder.
+		uint32_t left = run;
+		{
+			const uint32_t cmax = T->run_count[3071], smax = T->run_size[3071], codemax = T->run_bits[3071];
+			const uint32_t nrep = (have && run >= 3072u) ? (run - 3072u) / cmax + 1u : 0u;
+			unsigned long long todo = __ballot(nrep != 0u);
+			while (todo) {                                   // wave-uniform
+				const int src = __builtin_ctzll(todo);
+				todo &= todo - 1;
+				const uint32_t n = __shfl(nrep, src);
+				const uint32_t p_lo = __shfl((uint32_t)pos, src), p_hi = __shfl((uint32_t)(pos >> 32), src);
+				const uint64_t p0 = ((uint64_t)p_hi << 32) | p_lo;
+				for (uint32_t i = (uint32_t)lane; i < n; i += ENT_LANES) {
+					const uint64_t p = p0 + (uint64_t)i * smax;
+					const uint64_t val = (uint64_t)codemax << (64 - (int)smax - (int)(p & 31));
+					const uint32_t hi = (uint32_t)(val >> 32), lo = (uint32_t)val;
+					const uint32_t w = (uint32_t)(p >> 5);
+					if (use_lds) { atomic_or_u32(&s_words[w - first_word], hi); if (lo) atomic_or_u32(&s_words[w - first_word + 1], lo); }
+					else { atomic_or_u32(&out[w], bswap32(hi)); if (lo) atomic_or_u32(&out[w + 1], bswap32(lo)); }
+				}
+			}
+			if (nrep) { left -= nrep * cmax; pos += (uint64_t)nrep * smax; rc = T->run_pack[left < 3072u ? left : 3071u]; }
+		}
 		if (have) {
-			uint32_t left = run;
 			for (bool last = false; !last;) {
 				uint32_t code; int size;
 				if (left > 0) {

@@ -136,10 +136,11 @@ extern "C" long emu_entropy_encode(int width, int height, int pixel_kind, int qu
 	std::vector<dev::EntSegState> segs(jobs.segjobs.size());
 	std::vector<dev::EntBandState> bstate(jobs.bands.size());
 	const int nseg = (int)jobs.segjobs.size(), nb = (int)jobs.bands.size();
-	hipemu::launch(dim3((nseg + dev::ENT_WAVES - 1) / dev::ENT_WAVES), dim3(dev::ENT_THREADS), [&] { dev::k_ent_count(jobs.segjobs.data(), nseg, segs.data(), &tables); });
+	const dev::EntBatchGeom geom = { nseg, nb, 0 };
+	hipemu::launch(dim3((nseg + dev::ENT_WAVES - 1) / dev::ENT_WAVES), dim3(dev::ENT_THREADS), [&] { dev::k_ent_count(jobs.segjobs.data(), geom, nseg, segs.data(), &tables); });
 	hipemu::launch(dim3(nb), dim3(dev::ENT_THREADS), [&] { dev::k_ent_scan(jobs.bands.data(), segs.data(), bstate.data(), &tables); });
 	hipemu::launch(dim3(1), dim3(dev::ENT_THREADS), [&] { dev::k_ent_layout(&fj, jobs.bands.data(), segs.data(), bstate.data(), &tables); });
-	hipemu::launch(dim3((nseg + dev::ENT_WAVES - 1) / dev::ENT_WAVES), dim3(dev::ENT_THREADS), [&] { dev::k_ent_emit(jobs.segjobs.data(), nseg, segs.data(), bstate.data(), &tables); });
+	hipemu::launch(dim3((nseg + dev::ENT_WAVES - 1) / dev::ENT_WAVES), dim3(dev::ENT_THREADS), [&] { dev::k_ent_emit(jobs.segjobs.data(), geom, nseg, segs.data(), bstate.data(), &tables); });
 	return (long)size;
 }
 

@@ -123,12 +123,12 @@ def test_gpu_entropy_stage_emulated_equals_host_writer(w, h, seed):
 
 def test_gpu_entropy_stage_emulated_extreme_bands():
     """All-zero frame (runs of hundreds of thousands of zeros spanning every segment), saturated values (clamp to +-1023),
-    dense noise (no zeros at all)."""
-    w, h = 208, 104
+    dense noise (no zeros at all), single tokens behind very long runs."""
+    w, h = 416, 208
     plan = Plan(w, h)
     rng = np.random.default_rng(5)
     meta = b"GUID\x10\x00\x00G" + bytes(16)
-    for mode in ("zero", "sparse", "dense", "huge"):
+    for mode in ("zero", "sparse", "lonely", "dense", "huge"):
         coeffs = np.zeros(plan.coeff_elems, dtype=np.int16)
         for c in range(3):
             plan.view(coeffs, c, 2, 0)[:, : plan.band[(c, 2, 0)]["width"]] = rng.integers(0, 16000, size=(plan.band[(c, 2, 0)]["height"], plan.band[(c, 2, 0)]["width"]))
@@ -136,6 +136,7 @@ def test_gpu_entropy_stage_emulated_extreme_bands():
                 for b in (1, 2, 3):
                     d = plan.band[(c, lv, b)]; v = plan.view(coeffs, c, lv, b)[:, : d["width"]]
                     if mode == "sparse": v[rng.random(v.shape) < 0.0005] = 3
+                    elif mode == "lonely": v[-1, -1] = -7; v[d["height"] // 2, 3] = 2         # runs of several thousand zeros in front of a token: many copies of the longest run code
                     elif mode == "dense": v[:] = rng.integers(1, 40, size=v.shape) * rng.choice([-1, 1], size=v.shape)
                     elif mode == "huge": v[:] = rng.choice([0, 0, 0, 5000, -5000, 1023, -1024, 1], size=v.shape)
         want = product_write_sample_host(plan, coeffs, 1, meta_global=meta)
