@@ -4,7 +4,8 @@
 //   EncoderSDK/CFHDEncoder.cpp + SampleEncoder.cpp (sync encode, metadata handling :744-939),
 //   EncoderSDK/CFHDEncoderPool.cpp + EncoderPool.cpp + AsyncEncoder.cpp (async pool, FIFO completion),
 //   DecoderSDK/CFHDDecoder.cpp + SampleDecoder.cpp (decode), DecoderSDK/CFHDMetadata.cpp (sample metadata access).
-// The reference's CPU thread pool is replaced by HIP-stream frame slots; host threads only run the entropy stage.
+// The reference's CPU thread pool is replaced by HIP-stream frame slots; host threads only submit launches and hand samples back
+// (with CFHD_AMD_ENTROPY=host they also run the entropy stage).
 #include "../../include/cfhd_amd.h"
 #include "cfhd_core.h"
 #include "cfhd_bitstream.h"
@@ -190,7 +191,7 @@ int prepare_batch(EncodeBatch &batch, const EncodeParams &p)
 	return ERR_OKAY;
 }
 
-// Encode one frame on one batch slot: upload, forward kernels, coefficients back, host entropy + syntax.
+// Encode one frame on one batch slot: upload, forward kernels, entropy kernels, finished sample back (host entropy + syntax with CFHD_AMD_ENTROPY=host).
 int encode_one(EncodeBatch &batch, EncodeParams &p, const void *frame, int pitch, uint32_t frame_number,
                MetaBlock global, MetaBlock local, uint8_t *out, size_t cap, size_t *size_out)
 {

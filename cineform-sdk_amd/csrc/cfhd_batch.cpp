@@ -1,9 +1,11 @@
 // cfhd_batch.cpp -- device-resident batched round trip (extension API, cfhd_amd_batch_*), used by bench.py and by
 // callers that keep frames in HBM: N frames -> forward kernels -> entropy coding -> N samples -> entropy decoding
-// -> inverse kernels -> N frames in HBM.  One launch per wavelet level covers the whole batch.
+// -> inverse kernels -> N frames in HBM.  One launch per stage covers the whole batch.
 //
-// Round-1 entropy stage: host threads (the reference's own arrangement, Codec/encoder.c:5386 / decoder.c:19534),
-// fed by one D2H copy of the quantized bands and followed by one H2D copy of the dequantized bands.
+// Default: every stage on the GPU; the decoder reads the samples where the encoder left them in HBM (k_dec_parse) while their
+// host copy travels beside it.  CFHD_AMD_HANDOFF=host sends the samples through the host parser and back;
+// CFHD_AMD_ENTROPY=host keeps the run-length/VLC stage on host threads (the reference's own arrangement, Codec/encoder.c:5386 /
+// decoder.c:19534), fed by one D2H copy of the quantized bands and followed by one H2D copy of the dequantized bands.
 #include "../../include/cfhd_amd.h"
 #include "cfhd_core.h"
 #include "cfhd_bitstream.h"
