@@ -80,7 +80,9 @@ void BitWriter::size_pop()
 // ------------------------------------------------------------------------------------------
 // Host VLC (encoder.c:5386)
 // ------------------------------------------------------------------------------------------
-void vlc_encode_band(BitWriter &w, const int16_t *band, int width, int height, int pitch, int codebook)
+// peaks != nullptr: EncodeQuantLongRunsPlusPeaks (encoder.c:4802): a coefficient beyond +-PEAK_THRESHOLD (250, codec.h:155) is coded as
+// +-251 and its value * quant goes to the peak table that follows the band.
+void vlc_encode_band(BitWriter &w, const int16_t *band, int width, int height, int pitch, int codebook, int quant, std::vector<int16_t> *peaks)
 {
 	const EntropyTables *t = entropy_tables(codebook);
 	const int gap = pitch - width;
@@ -98,6 +100,7 @@ void vlc_encode_band(BitWriter &w, const int16_t *band, int width, int height, i
 			int v = p[i];
 			if (v == 0) { count++; continue; }
 			if (count) { put_run(count); count = 0; }
+			if (peaks && (v > kPeakThreshold || v < -kPeakThreshold)) { peaks->push_back((int16_t)(v * quant)); v = v > 0 ? kPeakThreshold + 1 : -kPeakThreshold - 1; }
 			if (v < 0) { if (v <= -1024) v = -1023; v += 2048; } else if (v >= 1024) v = 1023;
 			uint32_t e = t->value_code[v];
 			w.put_bits(e & 0x7FFFFFFu, (int)(e >> 27));
@@ -139,11 +142,29 @@ struct HostSink {
 		}
 		w.pad32();
 	}
+	std::vector<int16_t> peaks; size_t peak_tags_at = 0; bool collect_peaks = false;
 	void band(int c, int lv, int b, int k, int codebook)
 	{
 		const BandDesc &bd = plan.ch[c].band[lv][b];
 		if (src.packed) w.put_bytes(src.packed[c * 9 + k], src.packed_bytes[c * 9 + k]);
-		else vlc_encode_band(w, src.coeffs + bd.offset, bd.width, bd.height, bd.pitch, codebook);
+		else vlc_encode_band(w, src.coeffs + bd.offset, bd.width, bd.height, bd.pitch, codebook, bd.quant, collect_peaks ? &peaks : nullptr);
+	}
+	// the three optional tags in front of a peak-coded band's size chunk (codec.c:1804-1809), zero until a table follows
+	void peak_tags() { peak_tags_at = w.bytes(); w.put_tag_opt(TAG_PEAK_TABLE_OFFSET_L, 0); w.put_tag_opt(TAG_PEAK_TABLE_OFFSET_H, 0); w.put_tag_opt(TAG_PEAK_LEVEL, 0); peaks.clear(); collect_peaks = true; }
+	// behind the band trailer: offset and level patched into the tags, then the table chunk -- 16-bit values in host order, padded
+	// to a whole longword (encoder.c:6543-6585)
+	void peak_table(int quant)
+	{
+		collect_peaks = false;
+		if (peaks.empty()) return;
+		const uint32_t offset = (uint32_t)(w.bytes() - peak_tags_at);
+		auto tagword = [](int t, uint32_t v) { return ((uint32_t)(uint16_t)(-t) << 16) | (v & 0xffffu); };
+		w.patch32(peak_tags_at, tagword(TAG_PEAK_TABLE_OFFSET_L, offset & 0xffffu));
+		w.patch32(peak_tags_at + 4, tagword(TAG_PEAK_TABLE_OFFSET_H, offset >> 16));
+		w.patch32(peak_tags_at + 8, tagword(TAG_PEAK_LEVEL, (uint32_t)(kPeakThreshold * quant)));
+		if (peaks.size() & 1) peaks.push_back(0);
+		w.put_tag_opt(TAG_PEAK_TABLE, (int)(peaks.size() / 2));
+		w.put_bytes(peaks.data(), peaks.size() * 2);
 	}
 };
 
@@ -174,6 +195,9 @@ struct TemplateSink {
 	void hole(int kind, int c, int lv, int bnd, int fixed) { SampleTemplate::Hole h = { (int)b.size(), kind, c, lv, bnd, fixed }; t.holes.push_back(h); holes++; }
 	void lowpass(int c) { const BandDesc &ll = t.plan.ch[c].band[2][0]; hole(0, c, 2, 0, (((ll.width * ll.height * 2) + 3) / 4) * 4); }
 	void band(int c, int lv, int bnd, int, int) { hole(1, c, lv, bnd, 0); }
+	// GPU entropy: the tags stay zero; a band that does need a peak table sends its frame through the host writer (see GpuEntropyEncoder)
+	void peak_tags() { tag_opt(TAG_PEAK_TABLE_OFFSET_L, 0); tag_opt(TAG_PEAK_TABLE_OFFSET_H, 0); tag_opt(TAG_PEAK_LEVEL, 0); }
+	void peak_table(int) {}
 };
 
 template <typename Sink>
@@ -283,21 +307,27 @@ void walk_sample(Sink &w, const FramePlan &plan, const SampleHeaderInfo &hdr)
 			w.push(TAG_LEVEL_SIZE);
 			for (int b = 1; b < 4; b++, subband++, k++) {
 				const BandDesc &bd = cp.band[lv][b];
-				const int codebook = 1;                      // SetCodingFlags (encoder.c:6120): progressive intra => code set 17
+				// SetCodingFlags (encoder.c:6120): code set 17 for every band of a progressive intra frame; an interlaced intra frame
+				// codes subband 8 (the temporal-highpass, horizontal-lowpass band of the frame wavelet) with code set 18, difference
+				// coding (flag 16) and a peak table
+				const bool diffband = !hdr.progressive && subband == 8;
+				const int codebook = diffband ? 2 : 1;
 				w.tag(TAG_MARKER, MARK_BAND_START);
 				w.tag(TAG_BAND_NUMBER, b);
-				w.tag(TAG_BAND_CODING_FLAGS, codebook);
+				w.tag(TAG_BAND_CODING_FLAGS, codebook + (diffband ? 16 : 0));
 				w.tag(TAG_BAND_WIDTH, bd.width);
 				w.tag(TAG_BAND_HEIGHT, bd.height);
 				w.tag(TAG_BAND_SUBBAND, subband);
 				w.tag(TAG_BAND_ENCODING, 3);                 // BAND_ENCODING_RUNLENGTHS
 				w.tag(TAG_BAND_QUANTIZATION, bd.quant);
 				w.tag(TAG_BAND_SCALE, bd.scale);
+				if (diffband) w.peak_tags();
 				w.push(TAG_SUBBAND_SIZE);
 				w.tag(TAG_BAND_HEADER, 0);
 				w.band(c, lv, b, k, codebook);
 				w.tag(TAG_BAND_TRAILER, 0);
 				w.pop();
+				if (diffband) w.peak_table(bd.quant);
 			}
 			w.tag(TAG_MARKER, MARK_HIGHPASS_END);
 			w.pop();

@@ -24,6 +24,7 @@ enum Tag : int {
 	TAG_SAMPLE_FLAGS = 68, TAG_FRAME_NUMBER = 69, TAG_PRECISION = 70, TAG_INPUT_FORMAT = 71, TAG_BAND_CODING_FLAGS = 72,
 	TAG_VERSION = 79, TAG_QUALITY_L = 80, TAG_QUALITY_H = 81, TAG_BAND_SECONDPASS = 82, TAG_PRESCALE_TABLE = 83,
 	TAG_ENCODED_FORMAT = 84, TAG_FRAME_DISPLAY_HEIGHT = 85, TAG_ENCODED_COLORSPACE = 91, TAG_ENCODED_CHANNEL_NUMBER = 93,
+	TAG_PEAK_LEVEL = 74, TAG_PEAK_TABLE_OFFSET_L = 75, TAG_PEAK_TABLE_OFFSET_H = 76, TAG_PEAK_TABLE = 0x4001,
 	TAG_SUBBAND_SIZE = 0x2000, TAG_LEVEL_SIZE = 0x2100, TAG_SAMPLE_SIZE = 0x2200,
 	TAG_METADATA = 0x4002,
 };
@@ -93,7 +94,8 @@ void build_sample_template(const FramePlan &plan, const SampleHeaderInfo &hdr, S
 size_t write_sample(const FramePlan &plan, const SampleHeaderInfo &hdr, const BandSource &src, uint8_t *out, size_t cap);
 
 // Host VLC of one band (the reference's EncodeQuantLongRuns + band end code + pad), appended to w.
-void vlc_encode_band(BitWriter &w, const int16_t *band, int width, int height, int pitch, int codebook);
+enum { kPeakThreshold = 250 };   // PEAK_THRESHOLD, Codec/codec.h:155
+void vlc_encode_band(BitWriter &w, const int16_t *band, int width, int height, int pitch, int codebook, int quant = 1, std::vector<int16_t> *peaks = nullptr);
 
 // ---- parser ----
 struct ParsedBand { uint32_t offset, bytes; int width, height, quant, codebook, subband; bool present; };

@@ -342,11 +342,32 @@ def oracle_inverse_rgb48(plan, coeffs):
     return out
 
 
-def product_write_sample_host(plan, coeffs, frame_number, meta_global=b"", meta_local=b"", input_format=COLOR_FORMAT_YUYV, color_space=2):
+def oracle_forward_interlaced_yuv422(plan, frame, pitch, uyvy=0):
+    """Forward path of one interlaced 4:2:2 frame with the oracle: "frame" wavelet at level 1 (temporal pair + horizontal 2/6,
+    difference-coded HL band), spatial wavelets at levels 2 and 3; product pyramid layout."""
+    O = oracle()
+    coeffs = np.zeros(plan.coeff_elems, dtype=np.int16)
+    for c in range(3):
+        cw = plan.width if c == 0 else plan.width // 2
+        q = [plan.band[(c, 0, b)]["quant"] for b in range(4)]
+        outs = [plan.view(coeffs, c, 0, b) for b in range(4)]
+        bands = (c_i16p * 4)(*[o.ctypes.data_as(c_i16p) for o in outs])
+        O.orc_fwd_frame_yuv422(p8(frame), pitch, cw, plan.height, c, plan.precision - 8, uyvy, iarr(q), plan.mpq, bands, outs[0].shape[1])
+        for lv in (1, 2):
+            src = plan.view(coeffs, c, lv - 1, 0)
+            d = plan.band[(c, lv - 1, 0)]
+            q = [plan.band[(c, lv, b)]["quant"] for b in range(4)]
+            outs = [plan.view(coeffs, c, lv, b) for b in range(4)]
+            bands = (c_i16p * 4)(*[o.ctypes.data_as(c_i16p) for o in outs])
+            O.orc_fwd_spatial(src.ctypes.data_as(c_i16p), d["pitch"], d["width"], d["height"], plan.prescale[lv], iarr(q), plan.mpq, bands, outs[0].shape[1])
+    return coeffs
+
+
+def product_write_sample_host(plan, coeffs, frame_number, meta_global=b"", meta_local=b"", input_format=COLOR_FORMAT_YUYV, color_space=2, progressive=1):
     out = np.zeros(plan.width * plan.height * 4 + 65536, dtype=np.uint8)
     mg = np.frombuffer(meta_global, dtype=np.uint8).copy() if meta_global else np.zeros(4, np.uint8)
     ml = np.frombuffer(meta_local, dtype=np.uint8).copy() if meta_local else np.zeros(4, np.uint8)
-    n = product().cfhd_amd_write_sample_host(plan.width, plan.height, plan.pixkind, plan.enc, plan.quality, 1, input_format, color_space,
+    n = product().cfhd_amd_write_sample_host(plan.width, plan.height, plan.pixkind, plan.enc, plan.quality, progressive, input_format, color_space,
                                              frame_number, p16(coeffs), p8(mg), len(meta_global), p8(ml), len(meta_local), p8(out), out.size)
     assert n > 0
     return bytes(out[:n])
