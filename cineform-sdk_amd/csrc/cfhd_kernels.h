@@ -74,6 +74,14 @@ struct InvYuvJob {
 	uint8_t *out; int out_pitch;            // bytes
 };
 
+struct FwdFrameJob {                        // k_fwd_frame_yuv422: interlaced level 1 of a packed 8-bit 4:2:2 frame
+	const uint8_t *in; int in_pitch;        // bytes
+	int width, height, display_height;      // luma samples, picture rows; rows >= display_height read as 0x80
+	int uyvy, shift;
+	int16_t *out[3][4]; int out_pitch[3];   // Y, V, U: LL, LH, HL, HH (one band row per pair of picture rows)
+	QuantParam q[3][4];                     // q[c][2] is the difference-coded HL band: its midpoint is divisor / prequant without the "-1" (spatial.c:5360-5363)
+};
+
 struct BayerJob {                           // k_unpack_byr4: 16-bit Bayer mosaic -> component planes G, R-G, B-G, G1-G2
 	const uint16_t *in; int in_pitch;       // words per mosaic row
 	int width, height, display_height;      // component plane (half the mosaic); rows >= display_height repeat the last quad row
@@ -788,6 +796,96 @@ __global__ void __launch_bounds__(NTHREADS) k_inv_yuv422(const InvYuvJob *jobs, 
 			if (job.uyvy) { o2.x = u0 | (y0 << 8) | (v0 << 16) | (y1 << 24); o2.y = u1 | (y2 << 8) | (v1 << 16) | (y3 << 24); }
 			else { o2.x = y0 | (u0 << 8) | (y1 << 16) | (v0 << 24); o2.y = y2 | (u1 << 8) | (y3 << 16) | (v1 << 24); }
 			*(uint2 *)(job.out + (size_t)orow * job.out_pitch + 8 * (size_t)cc) = o2;
+		}
+	}
+}
+
+// =============================================================================================
+// Interlaced level 1 ("frame" wavelet), packed 8-bit 4:2:2 source.  Codec/wavelet.c:6076 TransformForwardFrameYUV: the two rows of
+// a pair (one from each field) give the temporal pair low = r0 + r1, high = r1 - r0 of the samples << shift (temporal.c:1915), each
+// of which is split horizontally with the 2/6 filter: (LL, LH) from low, (HL, HH) from high.  No vertical filter at this level, so
+// a workgroup owns FRW row pairs x 128 luma band columns and needs no halo rows.  HL is quantized inside
+// FilterHorizontalRowScaled16sDifferenceFiltered (spatial.c:5327) and stored as the difference to its left neighbour.
+// =============================================================================================
+enum { FTW = 128, FRW = 4, FDW = FTW + 4 };         // band columns per tile (luma; chroma half), row pairs per tile, staged dwords per row
+
+__global__ void __launch_bounds__(NTHREADS) k_fwd_frame_yuv422(const FwdFrameJob *jobs)
+{
+	const TileId tile = xcd_tile();
+	__shared__ FwdFrameJob s_job;
+	stage_job(&s_job, &jobs[tile.z]);
+	const FwdFrameJob &job = s_job;
+	const int W = job.width, DW = W >> 1, HH = job.height >> 1;     // DW = pixel pairs per row = luma band columns
+	const int c0 = tile.x * FTW, r0 = tile.y * FRW;
+	// temporal low / high of the tile: luma sample pairs per dword; chroma (V, U) one sample each per pixel pair, kept as pairs of
+	// consecutive samples per dword as well: index 0 = low, 1 = high
+	__shared__ uint32_t s_y[2][FRW][FDW];
+	__shared__ uint32_t s_v[2][FRW][FDW / 2 + 1], s_u[2][FRW][FDW / 2 + 1];
+	const bool active = (c0 < DW) && (r0 < HH);
+	const int tid = threadIdx.x;
+	const int shift = job.shift;
+	if (active) {
+		// stage: dword d of the tile = pixel pair c0 - 2 + d (even so that chroma pairs stay whole)
+		for (int i = tid; i < FRW * FDW; i += NTHREADS) {
+			const int rl = i / FDW, d = i - rl * FDW;
+			const int r = r0 + rl, dw = c0 - 2 + d;
+			uint32_t a = 0x80808080u, b = 0x80808080u;
+			if (r < HH && dw >= 0 && dw < DW) {
+				const int y0 = 2 * r, y1 = 2 * r + 1;
+				if (y0 < job.display_height) a = *(const uint32_t *)(job.in + (size_t)y0 * job.in_pitch + 4 * (size_t)dw);
+				if (y1 < job.display_height) b = *(const uint32_t *)(job.in + (size_t)y1 * job.in_pitch + 4 * (size_t)dw);
+			}
+			const int ysh0 = job.uyvy ? 8 : 0, csh = job.uyvy ? 0 : 8;        // byte lanes: YUYV = Y0 U Y1 V, UYVY = U Y0 V Y1
+			const uint32_t ya = pack16((int)((a >> ysh0) & 0xffu) << shift, (int)((a >> (ysh0 + 16)) & 0xffu) << shift);
+			const uint32_t yb = pack16((int)((b >> ysh0) & 0xffu) << shift, (int)((b >> (ysh0 + 16)) & 0xffu) << shift);
+			s_y[0][rl][d] = pk_adds(ya, yb); s_y[1][rl][d] = pk_subs(yb, ya);
+			const int ua = (int)((a >> csh) & 0xffu) << shift, va = (int)((a >> (csh + 16)) & 0xffu) << shift;
+			const int ub = (int)((b >> csh) & 0xffu) << shift, vb = (int)((b >> (csh + 16)) & 0xffu) << shift;
+			int16_t *sv0 = (int16_t *)&s_v[0][rl][0], *sv1 = (int16_t *)&s_v[1][rl][0], *su0 = (int16_t *)&s_u[0][rl][0], *su1 = (int16_t *)&s_u[1][rl][0];
+			sv0[d] = (int16_t)adds16(va, vb); sv1[d] = (int16_t)subs16(vb, va);
+			su0[d] = (int16_t)adds16(ua, ub); su1[d] = (int16_t)subs16(ub, ua);
+		}
+	}
+	__syncthreads();
+	if (active) {
+		// items: (row pair, signal: temporal low / high, channel slot, band column pair).  Luma has FTW/2 pairs, V and U FTW/4 each.
+		enum { PAIRS = FTW / 2 + FTW / 4 + FTW / 4 };
+		for (int i = tid; i < FRW * 2 * PAIRS; i += NTHREADS) {
+			const int rl = i / (2 * PAIRS), rem = i - rl * (2 * PAIRS), sig = rem / PAIRS, slot = rem - sig * PAIRS;
+			const int r = r0 + rl;
+			if (r >= HH) continue;
+			int ch, p, cw, cbase;                      // channel, pair index inside the tile, band width of the channel, first band column of the tile
+			const uint32_t *row;
+			if (slot < FTW / 2) { ch = 0; p = slot; cw = DW; cbase = c0; row = s_y[sig][rl]; }
+			else if (slot < FTW / 2 + FTW / 4) { ch = 1; p = slot - FTW / 2; cw = DW >> 1; cbase = c0 >> 1; row = s_v[sig][rl]; }
+			else { ch = 2; p = slot - FTW / 2 - FTW / 4; cw = DW >> 1; cbase = c0 >> 1; row = s_u[sig][rl]; }
+			const int c = cbase + 2 * p;               // band column of the pair's first element
+			if (c >= cw) continue;
+			// samples x[2c-2 .. 2c+5] = sample pairs c-1 .. c+2; luma: staged dword index = c - (c0 - 2); chroma: samples start at pixel pair c0 - 2,
+			// i.e. chroma sample pair k sits at dword (k - (c0 - 2) / 2)
+			const int k0 = ch == 0 ? (c - (c0 - 2)) : (c - ((c0 - 2) >> 1));
+			uint32_t d[4];
+#pragma unroll
+			for (int k = 0; k < 4; k++) d[k] = row[k0 - 1 + k];
+			uint32_t lpk, hpk;
+			horiz_pair(d, row[k0 - 2 >= 0 ? k0 - 2 : 0], 0, c == 0, c == cw - 1, c + 1 == cw - 1, lpk, hpk);
+			const bool two = c + 1 < cw;
+			const size_t o = (size_t)r * job.out_pitch[ch] + c;
+			if (sig == 0) {
+				// LL as it is, LH through the band quantizer
+				const uint32_t lh = pack16(quantize(lo16(hpk), job.q[ch][1]), quantize(hi16(hpk), job.q[ch][1]));
+				if (two) { *(uint32_t *)(job.out[ch][0] + o) = lpk; *(uint32_t *)(job.out[ch][1] + o) = lh; }
+				else { job.out[ch][0][o] = (int16_t)lo16(lpk); job.out[ch][1][o] = (int16_t)lo16(lh); }
+			} else {
+				// HL: quantized lowpass of the temporal highpass, stored as the difference to the column on its left (0 in front of column 0)
+				const uint32_t prevpair = d[0];
+				const int qprev = c == 0 ? 0 : quantize(adds16(lo16(prevpair), hi16(prevpair)), job.q[ch][2]);
+				const int q0 = quantize(lo16(lpk), job.q[ch][2]), q1 = quantize(hi16(lpk), job.q[ch][2]);
+				const uint32_t hl = pack16(sat16(q0 - qprev), sat16(q1 - q0));
+				const uint32_t hh = pack16(quantize(lo16(hpk), job.q[ch][3]), quantize(hi16(hpk), job.q[ch][3]));
+				if (two) { *(uint32_t *)(job.out[ch][2] + o) = hl; *(uint32_t *)(job.out[ch][3] + o) = hh; }
+				else { job.out[ch][2][o] = (int16_t)lo16(hl); job.out[ch][3][o] = (int16_t)lo16(hh); }
+			}
 		}
 	}
 }

@@ -63,6 +63,22 @@ void emu_inv_packed16(int16_t **bands, int band_pitch, int w, int h, int display
 	hipemu::launch(grid, dim3(NTHREADS), [&] { k_inv_packed16(jobs.data(), nch); });
 }
 
+void emu_fwd_frame_yuv422(const uint8_t *in, int in_pitch, int width, int height, int display_height, int uyvy, int shift,
+                          const int *quant /*[3][4]*/, int mpq, int16_t **out /*[3][4]*/, const int *out_pitch)
+{
+	FwdFrameJob job;
+	job.in = in; job.in_pitch = in_pitch; job.width = width; job.height = height; job.display_height = display_height;
+	job.uyvy = uyvy; job.shift = shift;
+	for (int c = 0; c < 3; c++) {
+		job.out_pitch[c] = out_pitch[c];
+		for (int b = 0; b < 4; b++) { job.out[c][b] = out[c * 4 + b]; job.q[c][b] = make_q(quant[c * 4 + b], mpq); }
+		// the difference-coded band is quantized inside the horizontal filter with midpoint = divisor / prequant (no decrement)
+		if (quant[c * 4 + 2] > 1 && mpq >= 2 && mpq < 9) job.q[c][2].mid = quant[c * 4 + 2] / mpq;
+	}
+	dim3 grid((width / 2 + FTW - 1) / FTW, (height / 2 + FRW - 1) / FRW, 1);
+	hipemu::launch(grid, dim3(NTHREADS), [&] { k_fwd_frame_yuv422(&job); });
+}
+
 void emu_unpack_byr4(const uint16_t *in, int in_pitch_words, int width, int height, int display_height, const uint16_t *curve, int order, int precision,
                      int16_t **out /*[4]*/, int out_pitch)
 {

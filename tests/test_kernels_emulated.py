@@ -285,3 +285,31 @@ def test_unpack_byr4_equals_oracle(w, h, dh):
     E.emu_unpack_byr4(mosaic.ctypes.data_as(ctypes.c_void_p), 2 * w, w, h, dh, curve.ctypes.data_as(ctypes.c_void_p), 0, 12, (c_i16p * 4)(*[p16(g) for g in got]), pitch)
     for c in range(4):
         assert np.array_equal(got[c], want[c]), c
+
+
+@pytest.mark.parametrize("w,h,dh", [(64, 16, 16), (272, 24, 21), (720, 16, 16), (1920, 8, 8)])
+@pytest.mark.parametrize("uyvy", [0, 1])
+def test_fwd_frame_yuv422_interlaced_level1(w, h, dh, uyvy):
+    """k_fwd_frame_yuv422 = oracle restatement of TransformForwardFrameYUV (pinned on reference coefficients in test_oracle_vs_ref and,
+    through the host writer, on whole reference samples), incl. full-range field differences that quantize beyond the peak level."""
+    rng = np.random.default_rng(w + h + uyvy)
+    frame = rng.integers(0, 256, size=(dh, w * 2), dtype=np.int64).astype(np.uint8)
+    frame[0::2, : w] = rng.choice([0, 255], size=(len(frame[0::2]), w))          # strong field flicker on the left half
+    quant = [1, 36, 16, 36, 1, 36, 16, 48, 1, 36, 16, 48]
+    outs_o, outs_e, pitches = [], [], []
+    for c in range(3):
+        cw = (w if c == 0 else w // 2) // 2
+        pitch = (cw + 7) // 8 * 8; pitches.append(pitch)
+        outs_o.append([np.zeros((h // 2, pitch), np.int16) for _ in range(4)])
+        outs_e.append([np.zeros((h // 2, pitch), np.int16) for _ in range(4)])
+    padded = np.full((h, w * 2), 0x80, np.uint8); padded[:dh] = frame
+    O = oracle()
+    for c in range(3):
+        bands = (c_i16p * 4)(*[p16(a) for a in outs_o[c]])
+        O.orc_fwd_frame_yuv422(p8(padded), w * 2, w if c == 0 else w // 2, h, c, 2, uyvy, iarr(quant[4 * c: 4 * c + 4]), 2, bands, pitches[c])
+    ptrs = (c_i16p * 12)(*[p16(a) for c in range(3) for a in outs_e[c]])
+    emu().emu_fwd_frame_yuv422(p8(frame), w * 2, w, h, dh, uyvy, 2, iarr(quant), 2, ptrs, iarr(pitches))
+    for c in range(3):
+        cw = (w if c == 0 else w // 2) // 2
+        for b in range(4):
+            assert np.array_equal(outs_e[c][b][:, :cw], outs_o[c][b][:, :cw]), (c, b)
