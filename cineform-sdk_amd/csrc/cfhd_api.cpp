@@ -161,19 +161,22 @@ int make_params(EncodeParams &p, int w, int h, uint32_t fmt, int encoded, uint32
 	// CFHD_ENCODED_FORMAT_BAYER (3) from BYR4: default pixel order (red-green) and default encode curve (log 90), i.e. what the
 	// reference does without BAYER_FORMAT / ENCODE_CURVE metadata
 	if (encoded != (kind == PIX_RG48 ? 1 : (kind == PIX_B64A ? 2 : (kind == PIX_BYR4 ? 3 : 0)))) return ERR_BADFORMAT;
-	if (flags & (1u << 0)) return ERR_BADFORMAT;                          // interlaced: not built yet
+	// CFHD_ENCODING_FLAGS_YUV_INTERLACED: field-based level 1 (encoder.c:2093), built for the packed 4:2:2 formats
+	const bool interlaced = (flags & (1u << 0)) != 0;
+	if (interlaced && !(kind == PIX_YUY2 || kind == PIX_2VUY)) return ERR_BADFORMAT;
 	if (flags & (1u << 1)) return ERR_BADFORMAT;                          // 2-frame GOP: out of scope
 	const int enc = kind == PIX_BYR4 ? ENC_BAYER : (kind == PIX_B64A ? ENC_RGBA4444 : (rgb ? ENC_RGB444 : ENC_YUV422));
 	// b64a's default encoded format is RGB 4:4:4; asking for 4:4:4:4 marks the quality word (SampleEncoder.cpp:250-257), which the
 	// sample header then carries in QUALITY_H
 	if (kind == PIX_B64A) quality |= 0x20000000;
 	p.width = w; p.height = h; p.pixel_format = fmt; p.pixel_kind = kind; p.encoded_format = enc; p.flags = flags;
-	p.quality = quality; p.progressive = true;
+	p.quality = quality; p.progressive = !interlaced;
 	const int yuv601 = (flags & (1u << 2)) ? 1 : 2, vsrgb = (flags & (1u << 8)) ? 2 : 1;   // SampleEncoder.cpp:210-212
 	p.color_space = (rgb || kind == PIX_BYR4) ? 0 : ((yuv601 == 1 ? 1 : 2) | (vsrgb == 2 ? 4 : 0));           // RGB 4:4:4 samples carry no colour space tag
 	if (!build_frame_plan(&p.plan, w, h, kind, enc)) return ERR_BADFORMAT;
+	p.plan.interlaced = interlaced;
 	p.qstate = {0, -1, 0};
-	derive_quantization(&p.plan, quality, true, 0.0f, &p.qstate);
+	derive_quantization(&p.plan, quality, p.progressive, 0.0f, &p.qstate);
 	p.valid = true;
 	return ERR_OKAY;
 }
@@ -217,9 +220,20 @@ int encode_one(EncodeBatch &batch, EncodeParams &p, const void *frame, int pitch
 		if ((rc = batch.entropy().launch())) return ERR_INTERNAL;
 		if ((rc = batch.entropy().download())) return ERR_INTERNAL;
 		if ((rc = batch.wait())) return ERR_INTERNAL;
-		size_t n = batch.entropy().sample_bytes(0);
-		if (!n || n > cap) return ERR_CODEC_ERROR;
-		memcpy(out, batch.entropy().host_sample(0), n);
+		if (!batch.entropy().needs_peak_table(0)) {
+			size_t n = batch.entropy().sample_bytes(0);
+			if (!n || n > cap) return ERR_CODEC_ERROR;
+			memcpy(out, batch.entropy().host_sample(0), n);
+			*size_out = n;
+			return ERR_OKAY;
+		}
+		// an interlaced frame whose field-difference band needs a peak table (values beyond +-250, rare): the table sits in front of the
+		// band and changes its coding, so this sample is written by the host writer from the same GPU coefficients
+		if ((rc = batch.download_coeffs())) return ERR_INTERNAL;
+		if ((rc = batch.wait())) return ERR_INTERNAL;
+		BandSource src; src.coeffs = batch.host_coeffs(0);
+		size_t n = write_sample(p.plan, hdr, src, out, cap);
+		if (!n) return ERR_CODEC_ERROR;
 		*size_out = n;
 		return ERR_OKAY;
 	}

@@ -50,6 +50,7 @@ struct FramePlan {
 	int precision;               // 10 or 12 bits
 	int encoded_format;          // EncodedFormat
 	int pixel_kind;              // PixelKind of the packed frame
+	int interlaced;              // level 1 is the field ("frame") transform: temporal 2-tap between the two fields, horizontal 2/6 (encoder.c:2093)
 	int prescale[kNumLevels];    // per wavelet index (Codec/wavelet.c:1710)
 	int midpoint_prequant;       // Codec/quantize.c:183,211-213
 	ChannelPlan ch[kMaxChannels];

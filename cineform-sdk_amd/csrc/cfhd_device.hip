@@ -7,6 +7,7 @@
 #include "cfhd_kernels.h"
 #include <hip/hip_runtime.h>
 #include <string.h>
+#include <stddef.h>
 #include <vector>
 #include <stdlib.h>
 #include <stdio.h>
@@ -191,6 +192,9 @@ int EncodeBatch::prepare(const FramePlan &plan, int nframes, bool own_input)
 		for (int c = 0; c < 3; c++) {
 			y.out_pitch[c] = plan.ch[c].band[0][0].pitch;
 			for (int b = 0; b < 4; b++) { y.out[c][b] = base + plan.ch[c].band[0][b].offset; y.q[c][b] = make_q(plan.ch[c].band[0][b].quant, mpq); }
+			// interlaced: the difference-coded band is quantized inside the horizontal filter, midpoint = divisor / prequant without the decrement
+			const int dq = plan.ch[c].band[0][2].quant;
+			if (plan.interlaced && dq > 1 && mpq >= 2 && mpq < 9) y.q[c][2].mid = dq / mpq;
 		}
 		if (bayer) {
 			const int ppitch = plan.ch[0].band[0][0].pitch * 2;
@@ -293,6 +297,10 @@ int EncodeBatch::launch_forward()
 	} else if (is_packed16(plan_.pixel_kind)) {
 		dim3 grid(((plan_.width / 2 + dev::TW - 1) / dev::TW) * nch, (plan_.height / 2 + dev::TH - 1) / dev::TH, n_);
 		dev::k_fwd_packed16<<<grid, dev::NTHREADS, 0, st>>>(j.l1, nch);
+	} else if (plan_.interlaced) {
+		static_assert(sizeof(dev::FwdFrameJob) == sizeof(dev::FwdYuvJob) && offsetof(dev::FwdFrameJob, q) == offsetof(dev::FwdYuvJob, q), "the two level-1 jobs share one table");
+		dim3 grid((plan_.width / 2 + dev::FTW - 1) / dev::FTW, (plan_.height / 2 + dev::FRW - 1) / dev::FRW, n_);
+		dev::k_fwd_frame_yuv422<<<grid, dev::NTHREADS, 0, st>>>((const dev::FwdFrameJob *)j.yuv);
 	} else {
 		dim3 grid((plan_.width / 2 + dev::TW - 1) / dev::TW, (plan_.height / 2 + dev::TH - 1) / dev::TH, n_);
 		dev::k_fwd_yuv422<<<grid, dev::NTHREADS, 0, st>>>(j.yuv);

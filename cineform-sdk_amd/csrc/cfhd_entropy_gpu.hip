@@ -42,13 +42,12 @@ int GpuEntropyEncoder::prepare(const FramePlan &plan, int nframes, int16_t *d_co
 	plan_ = plan; n_ = nframes; cap_ = (sample_cap + 255) & ~(size_t)255; stream_ = stream; d_coeffs_ = d_coeffs; coeff_stride_ = stride;
 	if (cap_ * (size_t)n_ >= ((size_t)1 << 32)) { fprintf(stderr, "[cfhd_amd] batch of %d frames exceeds the 4 GiB sample arena\n", n_); return -5; }   // packed offsets are 32-bit
 	{
-		dev::EntTables *h = new dev::EntTables;
-		ent_build_tables(h);
-		HIPCHK(hipMalloc(&d_tables_, sizeof(dev::EntTables)));
-		HIPCHK(hipMemcpy(d_tables_, h, sizeof(dev::EntTables), hipMemcpyHostToDevice));
-		delete h;
+		std::vector<dev::EntTables> h(2);
+		ent_build_tables(&h[0], 1); ent_build_tables(&h[1], 2);
+		HIPCHK(hipMalloc(&d_tables_, 2 * sizeof(dev::EntTables)));
+		HIPCHK(hipMemcpy(d_tables_, h.data(), 2 * sizeof(dev::EntTables), hipMemcpyHostToDevice));
 	}
-	SampleHeaderInfo hdr0 = { 1, 2, 2, 4, true, nullptr, 0, nullptr, 0 };
+	SampleHeaderInfo hdr0 = { 1, 2, 2, 4, !plan.interlaced, nullptr, 0, nullptr, 0 };
 	tmpl_.assign(n_, SampleTemplate());
 	build_sample_template(plan, hdr0, &tmpl_[0]);
 	EntHostJobs &jobs = host_->jobs;
@@ -62,9 +61,9 @@ int GpuEntropyEncoder::prepare(const FramePlan &plan, int nframes, int16_t *d_co
 	HIPCHK(hipMalloc(&d_bandstate_, jobs.bands.size() * sizeof(dev::EntBandState)));
 	HIPCHK(hipMalloc((void **)&d_samples_, cap_ * n_));
 	HIPCHK(hipHostMalloc((void **)&h_samples_, cap_ * n_, hipHostMallocDefault));
-	HIPCHK(hipMalloc((void **)&d_sizes_, sizeof(uint32_t) * n_));
-	HIPCHK(hipHostMalloc((void **)&h_sizes_, sizeof(uint32_t) * n_, hipHostMallocDefault));
-	memset(h_sizes_, 0, sizeof(uint32_t) * n_);
+	HIPCHK(hipMalloc((void **)&d_sizes_, sizeof(uint32_t) * 2 * n_));                   // [n] sample sizes, [n] peak flags
+	HIPCHK(hipHostMalloc((void **)&h_sizes_, sizeof(uint32_t) * 2 * n_, hipHostMallocDefault));
+	memset(h_sizes_, 0, sizeof(uint32_t) * 2 * n_);
 	HIPCHK(hipMalloc((void **)&d_packed_, cap_ * n_));
 	HIPCHK(hipMalloc((void **)&d_offsets_, sizeof(uint32_t) * (n_ + 1)));
 	HIPCHK(hipHostMalloc((void **)&h_offsets_, sizeof(uint32_t) * (n_ + 1), hipHostMallocDefault));
@@ -101,8 +100,10 @@ int GpuEntropyEncoder::launch()
 	const dev::EntTables *T = (const dev::EntTables *)d_tables_;
 	const dev::EntBatchGeom geom = { total_segs_ / n_, nbands_, coeff_stride_ };
 	(void)hipGetLastError();
+	if (plan_.interlaced) HIPCHK(hipMemsetAsync(d_sizes_ + n_, 0, sizeof(uint32_t) * n_, st));
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[0], st));
-	dev::k_ent_count<<<(total_segs_ + dev::ENT_WAVES - 1) / dev::ENT_WAVES, dev::ENT_THREADS, 0, st>>>((const dev::EntSegJob *)d_segband_, geom, total_segs_, (dev::EntSegState *)d_segs_, T);
+	dev::k_ent_count<<<(total_segs_ + dev::ENT_WAVES - 1) / dev::ENT_WAVES, dev::ENT_THREADS, 0, st>>>((const dev::EntSegJob *)d_segband_, geom, total_segs_, (dev::EntSegState *)d_segs_, T,
+	                                                                                                    d_sizes_ + n_);
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[1], st));
 	dev::k_ent_scan<<<nbands_ * n_, dev::ENT_THREADS, 0, st>>>((const dev::EntBandJob *)d_bands_, (dev::EntSegState *)d_segs_, (dev::EntBandState *)d_bandstate_, T);
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[2], st));
@@ -127,7 +128,7 @@ float GpuEntropyEncoder::kernel_ms(int k)
 int GpuEntropyEncoder::fetch_sizes()
 {
 	hipStream_t st = (hipStream_t)stream_;
-	HIPCHK(hipMemcpyAsync(h_sizes_, d_sizes_, sizeof(uint32_t) * n_, hipMemcpyDeviceToHost, st));
+	HIPCHK(hipMemcpyAsync(h_sizes_, d_sizes_, sizeof(uint32_t) * 2 * n_, hipMemcpyDeviceToHost, st));
 	HIPCHK(hipStreamSynchronize(st));
 	return 0;
 }
@@ -142,7 +143,7 @@ int GpuEntropyEncoder::download()
 	dev::k_ent_pack_offsets<<<1, dev::ENT_THREADS, 0, st>>>(d_sizes_, n_, d_offsets_);
 	dev::k_ent_pack<<<dim3(direct ? 2 : 8, (unsigned)n_), dev::ENT_THREADS, 0, st>>>(d_samples_, cap_, d_sizes_, d_offsets_, direct ? h_samples_ : d_packed_);
 	HIPCHK(hipGetLastError());
-	HIPCHK(hipMemcpyAsync(h_sizes_, d_sizes_, sizeof(uint32_t) * n_, hipMemcpyDeviceToHost, st));
+	HIPCHK(hipMemcpyAsync(h_sizes_, d_sizes_, sizeof(uint32_t) * 2 * n_, hipMemcpyDeviceToHost, st));
 	HIPCHK(hipMemcpyAsync(h_offsets_, d_offsets_, sizeof(uint32_t) * (n_ + 1), hipMemcpyDeviceToHost, st));
 	HIPCHK(hipStreamSynchronize(st));
 	if (!direct && h_offsets_[n_]) HIPCHK(hipMemcpyAsync(h_samples_, d_packed_, h_offsets_[n_], hipMemcpyDeviceToHost, st));

@@ -13,9 +13,11 @@ namespace cfhd {
 enum { kEntTmplBytes = 6144, kEntWordHolesBytes = 1536, kEntHolesBytes = dev::ENT_MAX_HOLES * (int)sizeof(dev::EntHole), kEntMaxPatches = 64,
        kEntPatchBytes = kEntMaxPatches * (int)sizeof(dev::EntPatch), kEntTmplStride = kEntTmplBytes + kEntWordHolesBytes + kEntHolesBytes + kEntPatchBytes };
 
-inline void ent_build_tables(dev::EntTables *h)
+// Table 0: code set 17 (codebook 1), every band of a progressive intra frame (encoder.c:6120); table 1: code set 18 (codebook 2), the
+// difference-coded band of an interlaced frame.
+inline void ent_build_tables(dev::EntTables *h, int codebook = 1)
 {
-	const EntropyTables *t = entropy_tables(1);      // code set 17: progressive intra frames use codebook 1 for every band (encoder.c:6120)
+	const EntropyTables *t = entropy_tables(codebook);
 	memcpy(h->value_code, t->value_code, sizeof(h->value_code));
 	memcpy(h->run_bits, t->run_bits, sizeof(h->run_bits));
 	for (int c = 0; c < 3072; c++) { h->run_count[c] = t->run_count[c]; h->run_size[c] = t->run_size[c]; }
@@ -51,8 +53,9 @@ inline bool ent_build_band_jobs(const FramePlan &plan, const SampleTemplate &t0,
 			j.coeffs = base + bd.offset; j.n = bd.height * bd.pitch;
 			j.nseg = (j.n + dev::ENT_SEG - 1) / dev::ENT_SEG; j.seg_base = (int)out->segjobs.size();
 			j.frame = f; j.hole = (int)h;
+			j.table = plan.interlaced && hole.level == 0 && hole.band == 2;      // subband 8 of the channel (cfhd_bitstream.cpp walk_sample)
 			if (f == 0) out->band_of_hole[h] = (int)out->bands.size();
-			for (int s = 0; s < j.nseg; s++) out->segjobs.push_back(dev::EntSegJob{ j.coeffs, j.n, s * dev::ENT_SEG, (int)out->bands.size() });
+			for (int s = 0; s < j.nseg; s++) out->segjobs.push_back(dev::EntSegJob{ j.coeffs, j.n, s * dev::ENT_SEG, (int)out->bands.size(), j.table });
 			out->bands.push_back(j);
 		}
 	}

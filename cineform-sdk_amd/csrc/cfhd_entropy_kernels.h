@@ -43,6 +43,7 @@ struct EntBandJob {
 	int n;                         // raster length = height * pitch
 	int seg_base, nseg;            // its segments in the per-segment arrays
 	int frame, hole;               // frame of the batch, hole index in the frame's template
+	int table;                     // 0: code set 17 (codebook 1), 1: code set 18 (codebook 2, the difference-coded band of interlaced frames)
 };
 
 struct EntSegJob {                 // static per segment: everything k_ent_count / k_ent_emit need to find their coefficients with one scalar load
@@ -50,6 +51,7 @@ struct EntSegJob {                 // static per segment: everything k_ent_count
 	int n;                         // raster length of the band
 	int first;                     // raster index of the segment's first coefficient
 	int band;                      // band job index
+	int table;                     // entropy table of the band (EntBandJob::table); such a band is also the one that may need a peak table
 };
 
 struct EntSegState {               // per segment, written by k_ent_count / k_ent_scan
@@ -169,26 +171,39 @@ __device__ __forceinline__ int wave_prev_nonzero(int my_last, int lane, unsigned
 // coefficient base moved by f pyramids and the band index by f * bands_per_frame, so the table (96 KB at 1080p) stays in L2 instead
 // of being streamed once per frame.
 struct EntBatchGeom { int segs_per_frame, bands_per_frame; size_t coeff_stride; };
-__device__ __forceinline__ EntSegJob ent_seg_job(const EntSegJob *seg_jobs, const EntBatchGeom &g, int seg)
+__device__ __forceinline__ EntSegJob ent_seg_job(const EntSegJob *seg_jobs, const EntBatchGeom &g, int seg, int *frame = nullptr)
 {
 	const int f = seg / g.segs_per_frame, s = seg - f * g.segs_per_frame;
+	if (frame) *frame = f;
 	EntSegJob job = seg_jobs[s];
 	job.coeffs += (size_t)f * g.coeff_stride; job.band += f * g.bands_per_frame;
 	return job;
 }
 
-__global__ void __launch_bounds__(ENT_THREADS) k_ent_count(const EntSegJob *seg_jobs, EntBatchGeom geom, int total_segs, EntSegState *segs, const EntTables *T)
+// peak_flags[frame] is raised when a band coded with table 1 holds a coefficient beyond +-ENT_PEAK_THRESHOLD: the reference then appends a
+// peak table (encoder.c:4802, :6543), which this stage does not produce -- the caller sends that frame through the host writer.
+enum { ENT_PEAK_THRESHOLD = 250 };
+__global__ void __launch_bounds__(ENT_THREADS) k_ent_count(const EntSegJob *seg_jobs, EntBatchGeom geom, int total_segs, EntSegState *segs, const EntTables *tables,
+                                                            uint32_t *peak_flags)
 {
 	const int lane = wave_lane();
 	const int seg = wave_uniform((int)blockIdx.x * ENT_WAVES + (int)(threadIdx.x >> 6));
 	if (seg >= total_segs) return;                       // whole wave
-	const EntSegJob job = ent_seg_job(seg_jobs, geom, seg);
+	int frame;
+	const EntSegJob job = ent_seg_job(seg_jobs, geom, seg, &frame);
+	const EntTables *T = tables + job.table;
 	const int base = job.first + lane * ENT_PER_THREAD;
 	int v[ENT_PER_THREAD];
 	ent_load16(job, base, v);
 	int my_last = -1, my_first = -1;
 #pragma unroll
 	for (int k = 0; k < ENT_PER_THREAD; k++) if (v[k]) { my_last = base + k; if (my_first < 0) my_first = base + k; }
+	if (job.table) {
+		bool peak = false;
+#pragma unroll
+		for (int k = 0; k < ENT_PER_THREAD; k++) peak |= v[k] > ENT_PEAK_THRESHOLD || v[k] < -ENT_PEAK_THRESHOLD;
+		if (__ballot(peak) && lane == 0) atomic_or_u32(&peak_flags[frame], 1u);
+	}
 	const unsigned long long mask = __ballot(my_last >= 0);
 	int prev = wave_prev_nonzero(my_last, lane, mask);
 	// zero run in front of every nonzero coefficient (registers only), then all table lookups back to back (no branch in
@@ -217,10 +232,11 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_count(const EntSegJob *seg_
 }
 
 // =============================================================================================
-__global__ void __launch_bounds__(ENT_THREADS) k_ent_scan(const EntBandJob *bands, EntSegState *segs, EntBandState *band_state, const EntTables *T)
+__global__ void __launch_bounds__(ENT_THREADS) k_ent_scan(const EntBandJob *bands, EntSegState *segs, EntBandState *band_state, const EntTables *tables)
 {
 	__shared__ int s_scan[ENT_THREADS];
 	const EntBandJob &job = bands[blockIdx.x];
+	const EntTables *T = tables + job.table;
 	int carry_prev = -1; uint32_t carry_bits = 0;
 	for (int c0 = 0; c0 < job.nseg; c0 += ENT_THREADS) {
 		const int i = c0 + threadIdx.x;
@@ -264,7 +280,7 @@ __device__ __forceinline__ void put_code_plain(uint32_t *words, uint64_t pos, ui
 
 // =============================================================================================
 __global__ void __launch_bounds__(ENT_THREADS) k_ent_layout(const EntFrameJob *frames, const EntBandJob *bands, const EntSegState *segs,
-                                                             EntBandState *band_state, const EntTables *T)
+                                                             EntBandState *band_state, const EntTables *tables)
 {
 	const EntFrameJob &f = frames[blockIdx.x];
 	__shared__ uint32_t s_cum[ENT_MAX_HOLES + 1];       // bytes of the holes in front of hole h
@@ -334,6 +350,7 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_layout(const EntFrameJob *f
 		const EntHole &hole = f.holes[h];
 		if (hole.kind != 1) continue;
 		const EntBandState &b = band_state[hole.band_job];
+		const EntTables *T = tables + bands[hole.band_job].table;
 		uint32_t *words = out + ((hole.tmpl_offset + s_cum[h]) >> 2);
 		uint64_t pos = b.seg_bits;
 		uint32_t run = b.tail_run;
@@ -348,7 +365,7 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_layout(const EntFrameJob *f
 }
 
 // =============================================================================================
-__global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(const EntSegJob *seg_jobs, EntBatchGeom geom, int total_segs, const EntSegState *segs, const EntBandState *band_state, const EntTables *T)
+__global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(const EntSegJob *seg_jobs, EntBatchGeom geom, int total_segs, const EntSegState *segs, const EntBandState *band_state, const EntTables *tables)
 {
 	__shared__ uint32_t s_words_all[ENT_WAVES][ENT_LDS_WORDS + 2];
 	__shared__ uint32_t s_tok_all[ENT_WAVES][ENT_SEG];   // the segment's tokens, compacted: local raster index << 16 | value (16 bits)
@@ -357,6 +374,7 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(const EntSegJob *seg_j
 	const int seg = wave_uniform((int)blockIdx.x * ENT_WAVES + wave);
 	if (seg >= total_segs) return;
 	const EntSegJob job = ent_seg_job(seg_jobs, geom, seg);
+	const EntTables *T = tables + job.table;
 	const EntSegState st = segs[seg];
 	if (st.bits == 0) return;                            // wave-uniform: nothing starts in this segment
 	uint32_t *out = (uint32_t *)band_state[job.band].out;

@@ -239,11 +239,21 @@ class Plan:
         return coeffs[d["offset"]: d["offset"] + d["pitch"] * d["height"]].reshape(d["height"], d["pitch"])
 
 
+def pad_yuv422_rows(plan, frame, pitch):
+    """The codec works on a height rounded up to a multiple of 8; the encoder fills the extra rows of a packed 4:2:2 frame with 0x80
+    bytes (encoder.c:2442-2478).  Returns (frame, encoded height)."""
+    H = plan.band[(0, 0, 0)]["height"] * 2
+    if H == plan.height: return frame, H
+    padded = np.full(H * pitch, 0x80, dtype=np.uint8)
+    padded[: plan.height * pitch] = np.asarray(frame).reshape(-1)[: plan.height * pitch]
+    return padded, H
+
+
 def oracle_forward_yuv422(plan, frame, pitch, uyvy=0):
     """Whole forward path of one 4:2:2 frame with the oracle, written into the product's pyramid layout."""
     O = oracle()
     coeffs = np.zeros(plan.coeff_elems, dtype=np.int16)
-    H = plan.height
+    frame, H = pad_yuv422_rows(plan, frame, pitch)
     for c in range(3):
         cw = plan.width if c == 0 else plan.width // 2
         # level 1 straight from the packed frame
@@ -342,17 +352,30 @@ def oracle_inverse_rgb48(plan, coeffs):
     return out
 
 
+def field_flicker_frame(w, h):
+    """Interlaced torture picture: the two fields differ by nearly the full range and swap sign at vertical edges, so the
+    difference-coded HL1 band holds quantized steps beyond +-250 (peak values)."""
+    f = np.zeros((h, w * 2), np.uint8)
+    f[:, 1::2] = 128
+    x = np.arange(w)
+    band = (x // 37) % 2
+    f[0::2, 0::2] = np.where(band, 255, 0)
+    f[1::2, 0::2] = np.where(band, 0, 255)
+    return f.reshape(-1).copy(), w * 2
+
+
 def oracle_forward_interlaced_yuv422(plan, frame, pitch, uyvy=0):
     """Forward path of one interlaced 4:2:2 frame with the oracle: "frame" wavelet at level 1 (temporal pair + horizontal 2/6,
     difference-coded HL band), spatial wavelets at levels 2 and 3; product pyramid layout."""
     O = oracle()
     coeffs = np.zeros(plan.coeff_elems, dtype=np.int16)
+    frame, H = pad_yuv422_rows(plan, frame, pitch)
     for c in range(3):
         cw = plan.width if c == 0 else plan.width // 2
         q = [plan.band[(c, 0, b)]["quant"] for b in range(4)]
         outs = [plan.view(coeffs, c, 0, b) for b in range(4)]
         bands = (c_i16p * 4)(*[o.ctypes.data_as(c_i16p) for o in outs])
-        O.orc_fwd_frame_yuv422(p8(frame), pitch, cw, plan.height, c, plan.precision - 8, uyvy, iarr(q), plan.mpq, bands, outs[0].shape[1])
+        O.orc_fwd_frame_yuv422(p8(frame), pitch, cw, H, c, plan.precision - 8, uyvy, iarr(q), plan.mpq, bands, outs[0].shape[1])
         for lv in (1, 2):
             src = plan.view(coeffs, c, lv - 1, 0)
             d = plan.band[(c, lv - 1, 0)]

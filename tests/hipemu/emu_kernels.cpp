@@ -130,15 +130,18 @@ void emu_inv_yuv422(int16_t **bands /*[3][4]*/, const int *band_pitch, int w, in
 // ------------------------------------------------------------------------------------------------------------
 #include "cfhd_entropy_jobs.h"
 
-extern "C" long emu_entropy_encode(int width, int height, int pixel_kind, int quality, unsigned frame_number, int16_t *coeffs /* product pyramid layout */,
-                                   const uint8_t *meta, size_t meta_size, uint8_t *out, size_t cap)
+// interlaced != 0: the plan of a field-coded frame (code set 18 for the difference band); returns -100 when that band needs a peak table,
+// which the GPU stage only detects.
+extern "C" long emu_entropy_encode2(int width, int height, int pixel_kind, int quality, unsigned frame_number, int16_t *coeffs /* product pyramid layout */,
+                                    const uint8_t *meta, size_t meta_size, uint8_t *out, size_t cap, int interlaced)
 {
 	using namespace cfhd;
 	FramePlan plan;
 	if (!build_frame_plan(&plan, width, height, pixel_kind, ENC_YUV422)) return -1;
+	plan.interlaced = interlaced != 0;
 	QuantState st = {0, -1, 0};
-	derive_quantization(&plan, quality, true, 0.0f, &st);
-	SampleHeaderInfo hdr = { frame_number, pixel_kind == PIX_2VUY ? 1 : 2, 2, quality, true, meta, meta_size, nullptr, 0 };
+	derive_quantization(&plan, quality, !interlaced, 0.0f, &st);
+	SampleHeaderInfo hdr = { frame_number, pixel_kind == PIX_2VUY ? 1 : 2, 2, quality, !interlaced, meta, meta_size, nullptr, 0 };
 	SampleTemplate t;
 	build_sample_template(plan, hdr, &t);
 	EntHostJobs jobs;
@@ -147,17 +150,24 @@ extern "C" long emu_entropy_encode(int width, int height, int pixel_kind, int qu
 	if (!ent_fill_frame_block(plan, t, 0, jobs, coeffs, block.data())) return -3;
 	uint32_t size = 0;
 	dev::EntFrameJob fj = ent_frame_job(t, block.data(), out, (uint32_t)cap, &size);
-	static dev::EntTables tables; static bool ready = false;
-	if (!ready) { ent_build_tables(&tables); ready = true; }
+	static dev::EntTables tables[2]; static bool ready = false;
+	if (!ready) { ent_build_tables(&tables[0], 1); ent_build_tables(&tables[1], 2); ready = true; }
+	uint32_t peak_flag = 0;
 	std::vector<dev::EntSegState> segs(jobs.segjobs.size());
 	std::vector<dev::EntBandState> bstate(jobs.bands.size());
 	const int nseg = (int)jobs.segjobs.size(), nb = (int)jobs.bands.size();
 	const dev::EntBatchGeom geom = { nseg, nb, 0 };
-	hipemu::launch(dim3((nseg + dev::ENT_WAVES - 1) / dev::ENT_WAVES), dim3(dev::ENT_THREADS), [&] { dev::k_ent_count(jobs.segjobs.data(), geom, nseg, segs.data(), &tables); });
-	hipemu::launch(dim3(nb), dim3(dev::ENT_THREADS), [&] { dev::k_ent_scan(jobs.bands.data(), segs.data(), bstate.data(), &tables); });
-	hipemu::launch(dim3(1), dim3(dev::ENT_THREADS), [&] { dev::k_ent_layout(&fj, jobs.bands.data(), segs.data(), bstate.data(), &tables); });
-	hipemu::launch(dim3((nseg + dev::ENT_WAVES - 1) / dev::ENT_WAVES), dim3(dev::ENT_THREADS), [&] { dev::k_ent_emit(jobs.segjobs.data(), geom, nseg, segs.data(), bstate.data(), &tables); });
-	return (long)size;
+	hipemu::launch(dim3((nseg + dev::ENT_WAVES - 1) / dev::ENT_WAVES), dim3(dev::ENT_THREADS), [&] { dev::k_ent_count(jobs.segjobs.data(), geom, nseg, segs.data(), tables, &peak_flag); });
+	hipemu::launch(dim3(nb), dim3(dev::ENT_THREADS), [&] { dev::k_ent_scan(jobs.bands.data(), segs.data(), bstate.data(), tables); });
+	hipemu::launch(dim3(1), dim3(dev::ENT_THREADS), [&] { dev::k_ent_layout(&fj, jobs.bands.data(), segs.data(), bstate.data(), tables); });
+	hipemu::launch(dim3((nseg + dev::ENT_WAVES - 1) / dev::ENT_WAVES), dim3(dev::ENT_THREADS), [&] { dev::k_ent_emit(jobs.segjobs.data(), geom, nseg, segs.data(), bstate.data(), tables); });
+	return peak_flag ? -100 : (long)size;
+}
+
+extern "C" long emu_entropy_encode(int width, int height, int pixel_kind, int quality, unsigned frame_number, int16_t *coeffs, const uint8_t *meta, size_t meta_size,
+                                   uint8_t *out, size_t cap)
+{
+	return emu_entropy_encode2(width, height, pixel_kind, quality, frame_number, coeffs, meta, meta_size, out, cap, 0);
 }
 
 // GPU entropy decoder under emulation: parse on the host (product parser), decode every band with k_dec_bands / k_dec_lowpass.

@@ -363,3 +363,41 @@ def test_byr4_encode_bitstream_identical(w, h):
     for i, (a, b) in enumerate(zip(mine, refs)):
         assert len(a) == len(b), "frame %d: size %d vs reference %d" % (i, len(a), len(b))
         assert mask_volatile_metadata(a) == mask_volatile_metadata(b), "frame %d" % i
+
+
+@pytest.mark.skipif(not have_ref(), reason="needs the reference encoder")
+@pytest.mark.parametrize("w,h,pixfmt", [(320, 240, PIX_YUY2), (720, 486, PIX_2VUY), (1920, 1080, PIX_YUY2)])
+def test_interlaced_encode_bitstream_identical(w, h, pixfmt):
+    """Config D, 1080i half (encode): CFHD_ENCODING_FLAGS_YUV_INTERLACED -> k_fwd_frame_yuv422 (field transform with the
+    difference-coded, in-filter-quantized HL band) and the second entropy table (code set 18) for subband 8."""
+    if (w, h) == (1920, 1080):
+        frames, pitch = qbist_frames(10, 2)
+    else:
+        frames, pitch = [synth_yuy2(w, h, s)[0] for s in (2, 6)], w * 2
+        for k, f in enumerate(frames):                      # make the fields differ: shift every other row
+            v = f.reshape(h, pitch); v[1::2] = np.roll(v[1::2], 8 * (k + 1), axis=1)
+    mine = amd_encode_frames(frames, pitch, w, h, pixfmt, flags=1)
+    refs = ref_encode_frames(frames, pitch, w, h, pixfmt, flags=1)
+    for i, (a, b) in enumerate(zip(mine, refs)):
+        assert len(a) == len(b), "frame %d: size %d vs reference %d" % (i, len(a), len(b))
+        ma, mb = mask_volatile_metadata(a), mask_volatile_metadata(b)
+        if ma != mb:
+            first = next(k for k in range(len(ma)) if ma[k] != mb[k])
+            raise AssertionError("frame %d differs from the reference at byte %d of %d" % (i, first, len(ma)))
+    prog = amd_encode_frames(frames[:1], pitch, w, h, pixfmt)
+    assert mask_volatile_metadata(prog[0]) != mask_volatile_metadata(mine[0])
+
+
+@pytest.mark.skipif(not have_ref(), reason="needs the reference encoder")
+def test_interlaced_encode_peak_table_frames():
+    """Field-difference steps beyond +-250 make the reference append a peak table to subband 8; the GPU stage flags such a frame and
+    its sample is written by the host writer from the GPU coefficients.  Ordinary frames before and after it stay on the GPU path."""
+    w, h = 320, 64
+    calm = synth_yuy2(w, h, 3)[0]
+    frames = [calm, field_flicker_frame(w, h)[0], calm.copy()]
+    mine = amd_encode_frames(frames, w * 2, w, h, PIX_YUY2, flags=1)
+    refs = ref_encode_frames(frames, w * 2, w, h, PIX_YUY2, flags=1)
+    for i, (a, b) in enumerate(zip(mine, refs)):
+        assert len(a) == len(b), "frame %d: size %d vs reference %d" % (i, len(a), len(b))
+        assert mask_volatile_metadata(a) == mask_volatile_metadata(b), "frame %d" % i
+    assert len(refs[1]) != len(refs[0])

@@ -7,7 +7,7 @@ from cfhd_testlib import *
 needs_ref = [pytest.mark.ref, pytest.mark.skipif(not have_ref(), reason="reference .so not built")]
 
 
-@pytest.mark.parametrize("w,h", [(320, 240), (640, 480), (1920, 1080)])
+@pytest.mark.parametrize("w,h", [(320, 240), (640, 480), (336, 252), (1920, 1080)])
 def test_sample_bytes_equal_reference_synthetic(w, h):
     for m in needs_ref: pass
     if not have_ref(): pytest.skip("reference .so not built")
@@ -137,26 +137,14 @@ def test_bayer_curve_table_equals_oracle():
     assert np.array_equal(got, want)
 
 
-def _field_flicker_frame(w, h):
-    """Interlaced torture picture: the two fields differ by nearly the full range and swap sign at vertical edges, so the
-    difference-coded HL1 band holds quantized steps beyond +-250 (peak values)."""
-    f = np.zeros((h, w * 2), np.uint8)
-    f[:, 1::2] = 128
-    x = np.arange(w)
-    band = (x // 37) % 2
-    f[0::2, 0::2] = np.where(band, 255, 0)
-    f[1::2, 0::2] = np.where(band, 0, 255)
-    return f.reshape(-1).copy(), w * 2
-
-
-@pytest.mark.parametrize("w,h,kind", [(192, 96, "smooth"), (720, 480, "smooth"), (1920, 1080, "qbist"), (320, 64, "peaks")])
+@pytest.mark.parametrize("w,h,kind", [(192, 96, "smooth"), (720, 480, "smooth"), (720, 486, "smooth"), (1920, 1080, "qbist"), (320, 64, "peaks")])
 def test_interlaced_sample_bytes_equal_reference(w, h, kind):
     """SURVEY 8a8 (encode side, host twin): CFHD_ENCODING_FLAGS_YUV_INTERLACED.  Oracle frame transform + product quantizer tables
     (interlaced variants) + product sample writer (no SAMPLE_FLAGS tag, HL1 coded with code set 18 + difference flag, peak tags and,
     for coefficients beyond +-250, the peak table) = reference sample."""
     if not have_ref(): pytest.skip("reference .so not built")
     if kind == "qbist": frames, pitch = qbist_frames(10, 1, w, h); frame = frames[0]
-    elif kind == "peaks": frame, pitch = _field_flicker_frame(w, h)
+    elif kind == "peaks": frame, pitch = field_flicker_frame(w, h)
     else: frame, pitch = synth_yuy2(w, h, 3)
     rs = ref_encode_frames([frame], pitch, w, h, PIX_YUY2, encoded=ENCODED_YUV422, flags=1)[0]
     plan = Plan(w, h, progressive=0)

@@ -144,6 +144,44 @@ def test_gpu_entropy_stage_emulated_extreme_bands():
         assert got == want, mode
 
 
+def _emu_entropy_interlaced(plan, coeffs, frame_number, meta):
+    E = emu()
+    out = np.zeros(plan.width * plan.height * 4 + 65536, dtype=np.uint8)
+    m = np.frombuffer(meta, dtype=np.uint8).copy()
+    E.emu_entropy_encode2.restype = ctypes.c_long
+    E.emu_entropy_encode2.argtypes = [ctypes.c_int] * 4 + [ctypes.c_uint, c_i16p, c_u8p, ctypes.c_size_t, c_u8p, ctypes.c_size_t, ctypes.c_int]
+    n = E.emu_entropy_encode2(plan.width, plan.height, plan.pixkind, plan.quality, frame_number, p16(coeffs), p8(m), len(meta), p8(out), out.size, 1)
+    return n, bytes(out[:max(n, 0)])
+
+
+@pytest.mark.parametrize("w,h,seed", [(192, 96, 1), (336, 252, 3), (720, 480, 4)])
+def test_gpu_entropy_stage_emulated_interlaced(w, h, seed):
+    """Interlaced frames: the field-difference band (subband 8 of every channel) goes through the second entropy table (code set 18);
+    the sample equals the host writer's, which test_host_bitstream pins against the reference.  A difference band beyond the peak
+    threshold raises the per-frame flag instead (the API then writes that sample on the host)."""
+    frame, pitch = synth_yuy2(w, h, seed)
+    plan = Plan(w, h, progressive=0)
+    coeffs = oracle_forward_interlaced_yuv422(plan, frame, pitch)
+    for c in range(3): np.clip(plan.view(coeffs, c, 0, 2), -250, 250, out=plan.view(coeffs, c, 0, 2))
+    meta = b"GUID\x10\x00\x00G" + bytes(range(16))
+    want = product_write_sample_host(plan, coeffs, 3, meta_global=meta, progressive=0)
+    n, got = _emu_entropy_interlaced(plan, coeffs, 3, meta)
+    assert n > 0, n
+    assert len(got) == len(want)
+    if got != want:
+        first = next(k for k in range(len(got)) if got[k] != want[k])
+        raise AssertionError("first difference at byte %d of %d" % (first, len(got)))
+    for c, v in ((2, 251), (0, -251)):
+        peaky = coeffs.copy()
+        d = plan.band[(c, 0, 2)]
+        plan.view(peaky, c, 0, 2)[d["height"] - 1, d["width"] - 1] = v
+        assert _emu_entropy_interlaced(plan, peaky, 3, meta)[0] == -100
+    ok = coeffs.copy()
+    plan.view(ok, 0, 0, 1)[0, 0] = 900                # other bands may hold anything
+    plan.view(ok, 0, 0, 2)[0, 0] = 250
+    assert _emu_entropy_interlaced(plan, ok, 3, meta)[0] > 0
+
+
 @pytest.mark.parametrize("parallel", [0, 1, 2])
 @pytest.mark.parametrize("w,h,seed", [(192, 96, 1), (336, 252, 3), (720, 480, 4)])
 def test_gpu_entropy_decoder_emulated_equals_host_decoder(w, h, seed, parallel):
