@@ -366,7 +366,8 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 	if (rc) return rc;
 	release();
 	const bool yuv_ok = (out_kind == PIX_YUY2 || out_kind == PIX_2VUY) && plan.encoded_format == ENC_YUV422;
-	const bool rgb_ok = out_kind == PIX_RG48 && plan.encoded_format == ENC_RGB444 && plan.ch[0].band[0][0].width >= 16;   // k_inv_packed16's tail-column rule assumes the reference's vector path
+	const bool rgb_ok = ((out_kind == PIX_RG48 && plan.encoded_format == ENC_RGB444) || (out_kind == PIX_B64A && plan.encoded_format == ENC_RGBA4444)) &&
+	                    plan.ch[0].band[0][0].width >= 16;   // k_inv_packed16's tail-column rule assumes the reference's vector path
 	if (!yuv_ok && !rgb_ok) { g_err = "output format not supported by the GPU path yet"; return -2; }
 	plan_ = plan; n_ = nframes; out_kind_ = out_kind; own_output_ = own_output;
 	HIPCHK(hipStreamCreateWithFlags((hipStream_t *)&stream_, hipStreamNonBlocking));
@@ -411,6 +412,7 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 				uint16_t *frame = own_output ? (uint16_t *)(d_out_ + frame_bytes_ * i) : nullptr;
 				p.out = frame ? (int16_t *)(frame + packed_word_of_channel(out_kind, c)) : nullptr; p.out_pitch = out_pitch_ / 2;
 				p.xstride = nch; p.precision = plan.precision; p.display_height = plan.display_height;
+				p.alpha = out_kind == PIX_B64A && c == 3;
 			}
 			continue;
 		}

@@ -63,6 +63,7 @@ struct InvPlaneJob {
 	// k_inv_packed16 only: `out` is the component's first word inside interleaved unsigned 16-bit pixels, xstride words per pixel,
 	// out_pitch in words; samples are clamped to `precision` bits and shifted up to 16; rows >= display_height are not written
 	int xstride, precision, display_height;
+	int alpha;                              // k_inv_packed16: this component is the companded alpha plane of an RGBA 4:4:4:4 sample
 };
 
 struct InvYuvJob {
@@ -544,6 +545,15 @@ __device__ __forceinline__ uint32_t to16(int v, int precision, bool tail)
 	return (uint32_t)(x > top ? top : x) << (16 - precision);
 }
 
+// Alpha plane of RGBA 4:4:4:4 -> b64a: the encoder companded alpha into [256, 4095 * 223 / 256 + 256] (frame.c:6696-6707); the decoder expands the
+// finished 16-bit word again (codec.h:164-165; the scalar loop of Convert4444LinesToOutput, bayer.c:16212-16226).
+__device__ __forceinline__ uint32_t expand_alpha16(uint32_t word)
+{
+	int a = (int)(word >> 4) - 256;
+	a = (a * 8 * 9400) >> 12;
+	return (uint32_t)(a < 0 ? 0 : (a > 65535 ? 65535 : a));
+}
+
 // PACKED: the last level of the 4:4:4(:4) formats (wavelet.c:4947 TransformInverseRGB444ToRGB48: InvertSpatial*Row16sToYUV16 per
 // component + ConvertPlanarRGB16uToPackedRGB48): same synthesis, every sample converted with to16() and stored as one word of
 // the interleaved pixel.  gridDim.x = tiles_x * nch as in k_fwd_packed16.
@@ -615,8 +625,10 @@ __device__ __forceinline__ void inv_plane_tile(const InvPlaneJob *jobs, int nch)
 				for (int k = 0; k < 2; k++) {
 					if (c + k >= w) break;
 					const bool tail = c + k >= tail0;
-					dst[(2 * k) * job.xstride] = (uint16_t)to16(e[k], job.precision, tail);
-					dst[(2 * k + 1) * job.xstride] = (uint16_t)to16(o[k], job.precision, tail);
+					uint32_t we = to16(e[k], job.precision, tail), wo = to16(o[k], job.precision, tail);
+					if (job.alpha) { we = expand_alpha16(we); wo = expand_alpha16(wo); }
+					dst[(2 * k) * job.xstride] = (uint16_t)we;
+					dst[(2 * k + 1) * job.xstride] = (uint16_t)wo;
 				}
 				continue;
 			}

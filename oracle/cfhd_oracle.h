@@ -56,6 +56,7 @@ void orc_inv_spatial_to_yuv422(PIXEL16 *const bands[3][4], const int band_pitch[
 /* ---- quantizer tables (host side of the path) ---- */
 void orc_inv_spatial_to_packed16(PIXEL16 *const bands[4][4], int band_pitch, int w, int h, int precision, int num_channels,
                                  const int *word_of_channel, int tail_start, int alpha_channel, uint16_t *out, int out_pitch_words);
+void orc_inv_spatial_to_b64a(PIXEL16 *const bands[4][4], int band_pitch, int w, int h, int precision, uint16_t *out, int out_pitch_words);
 void orc_inv_spatial_to_rgb48(PIXEL16 *const bands[4][4], int band_pitch, int w, int h, int precision, int num_channels,
                               uint16_t *out, int out_pitch_words);
 

@@ -186,10 +186,12 @@ static inline unsigned to16_tail(int v, int precision)
  * per band row and channel spatial.c:16985 InvertSpatial{Top,Middle,Bottom}Row16sToYUV16 (vertical synthesis in 32 bits with a
  * final SATURATE, :17183-17230) + InvertHorizontalStrip16sToRow16u, then convert.c:6747 ConvertPlanarRGB16uToPackedRGB48
  * (planes are G, R, B; output words R, G, B).
- * The word order, the first scalar column and an alpha expansion a' = ((a - 256) << 3) * 9400 >> 16 (codec.h:164-165, the formula of
- * InvertHorizontalStrip16s.c:13298 InvertHorizontalStrip16sRGB2B64A) are parameters; only the RG48 instance below is pinned against
- * the reference decoder -- its b64a output of RGBA 4:4:4:4 samples goes through the active-metadata pipeline (bayer.c:13860
- * Row16uFull2OutputFormat) with a 13-bit alpha, which is not restated here.
+ * The word order, the first scalar column and the alpha plane are parameters.  b64a output of an RGBA 4:4:4:4 sample takes another
+ * route in the reference (bayer.c:7147 forces its "active metadata" decoder for alpha output): decoder.c:26805
+ * TransformInverseSpatialUniversalThreadedToRow16u -> the same InvertHorizontalStrip16sToRow16u per plane, then per row
+ * bayer.c:11916 Row16uFull2OutputFormat -> convert.c:6031 ConvertPlanarGRBAToPlanarRGBA -> bayer.c:15966 Convert4444LinesToOutput,
+ * which expands the companded alpha (codec.h:164-165, scalar loop bayer.c:16212-16226) and interleaves A, R, G, B (:17098-17106).
+ * Both instances are pinned against the reference decoder (tests/test_oracle_vs_ref.py).
  * word_of_channel[c] = position of plane c's word in the pixel, tail_start = first band column of the scalar code,
  * alpha_channel = plane to expand (-1: none). */
 void orc_inv_spatial_to_packed16(PIXEL16 *const bands[4][4], int band_pitch, int w, int h, int precision, int num_channels,
@@ -211,21 +213,25 @@ void orc_inv_spatial_to_packed16(PIXEL16 *const bands[4][4], int band_pitch, int
 				for (x = 0; x < 2 * w; x++) {
 					const int tail = (x >> 1) >= tail_start, v = px[k][x];
 					unsigned word;
+					word = tail ? to16_tail(v, precision) : to16(v, precision);
 					if (ch == alpha_channel) {
-						int a = v >> 1;
-						if (!tail) { if (a < 0) a = 0; if (a > top) a = top; }
-						a -= 256;
-						if (!tail && a < 0) a = 0;
-						a = (int)(((long long)(a * 8) * 9400) >> 16);
-						if (a < 0) a = 0;
-						if (a > top) a = top;
-						word = (unsigned)a << (16 - precision);
-					} else word = tail ? to16_tail(v, precision) : to16(v, precision);
+						/* bayer.c:16212-16226 (16-bit planar rows; the vector loop above it never runs because of its
+						 * `(width*3) & ~15` guard): undo the encoder's alpha companding on the finished 16-bit word */
+						int a = (int)(word >> 4);
+						a -= 256; a <<= 3; a *= 9400; a >>= 12;
+						word = (unsigned)(a < 0 ? 0 : (a > 65535 ? 65535 : a));
+					}
 					o[(size_t)x * num_channels] = (uint16_t)word;
 				}
 			}
 		}
 	free(el); free(ol); free(eh); free(oh); free(px[0]); free(px[1]);
+}
+
+void orc_inv_spatial_to_b64a(PIXEL16 *const bands[4][4], int band_pitch, int w, int h, int precision, uint16_t *out, int out_pitch_words)
+{
+	static const int word_of_channel[4] = { 2, 1, 3, 0 };      /* planes G, R, B, A -> words A, R, G, B */
+	orc_inv_spatial_to_packed16(bands, band_pitch, w, h, precision, 4, word_of_channel, w - (w % 8) - 9, 3, out, out_pitch_words);
 }
 
 void orc_inv_spatial_to_rgb48(PIXEL16 *const bands[4][4], int band_pitch, int w, int h, int precision, int num_channels,

@@ -332,10 +332,12 @@ def oracle_forward_planes(plan, planes):
     return coeffs
 
 
-def oracle_inverse_rgb48(plan, coeffs):
-    """Whole inverse path with the oracle from a dequantized RGB 4:4:4 pyramid to packed RG48 words (display rows only)."""
+def oracle_inverse_rgb48(plan, coeffs, b64a=False):
+    """Whole inverse path with the oracle from a dequantized RGB 4:4:4 pyramid to packed RG48 words (display rows only);
+    b64a: RGBA 4:4:4:4 pyramid to packed A,R,G,B words with the alpha expansion."""
     O = oracle()
     O.orc_inv_spatial_to_rgb48.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    O.orc_inv_spatial_to_b64a.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
     work = coeffs.copy()
     nch = plan.num_channels
     for c in range(nch):
@@ -347,6 +349,10 @@ def oracle_inverse_rgb48(plan, coeffs):
     d = plan.band[(0, 0, 0)]
     flat = [plan.view(work, c, 0, b).ctypes.data_as(c_i16p) for c in range(nch) for b in range(4)]
     out = np.zeros((2 * d["height"], 2 * d["width"] * nch), np.uint16)
+    if b64a:
+        assert nch == 4
+        O.orc_inv_spatial_to_b64a((c_i16p * 16)(*flat), d["pitch"], d["width"], d["height"], plan.precision, out.ctypes.data_as(ctypes.c_void_p), 2 * d["width"] * nch)
+        return out
     O.orc_inv_spatial_to_rgb48((c_i16p * 16)(*(flat + [None] * (16 - len(flat)))), d["pitch"], d["width"], d["height"], plan.precision, nch,
                                out.ctypes.data_as(ctypes.c_void_p), 2 * d["width"] * nch)
     return out

@@ -50,7 +50,7 @@ void emu_fwd_packed16(const uint16_t *in, int in_pitch_words, int width, int hei
 
 // Last level of a 4:4:4(:4) format to interleaved 16-bit pixels: bands[c*4+b].
 void emu_inv_packed16(int16_t **bands, int band_pitch, int w, int h, int display_height, int nch, int precision, const int *word_of_channel,
-                      uint16_t *out, int out_pitch_words)
+                      uint16_t *out, int out_pitch_words, int alpha_channel)
 {
 	std::vector<InvPlaneJob> jobs(nch);
 	for (int c = 0; c < nch; c++) {
@@ -58,6 +58,7 @@ void emu_inv_packed16(int16_t **bands, int band_pitch, int w, int h, int display
 		for (int b = 0; b < 4; b++) job.band[b] = bands[c * 4 + b];
 		job.band_pitch = band_pitch; job.width = w; job.height = h; job.descale = 0;
 		job.out = (int16_t *)(out + word_of_channel[c]); job.out_pitch = out_pitch_words; job.xstride = nch; job.precision = precision; job.display_height = display_height;
+		job.alpha = c == alpha_channel;
 	}
 	dim3 grid(((w + ITW - 1) / ITW) * nch, (h + ITH - 1) / ITH, 1);
 	hipemu::launch(grid, dim3(NTHREADS), [&] { k_inv_packed16(jobs.data(), nch); });

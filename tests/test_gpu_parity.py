@@ -401,3 +401,76 @@ def test_interlaced_encode_peak_table_frames():
         assert len(a) == len(b), "frame %d: size %d vs reference %d" % (i, len(a), len(b))
         assert mask_volatile_metadata(a) == mask_volatile_metadata(b), "frame %d" % i
     assert len(refs[1]) != len(refs[0])
+
+
+@pytest.mark.skipif(not have_ref(), reason="needs the reference codec")
+@pytest.mark.parametrize("w,h", [(320, 240), (1920, 1080)])
+def test_b64a_decode_equals_reference(w, h):
+    """Config C, decode side: RGBA 4:4:4:4 sample -> b64a (k_inv_packed16 with four components and the alpha expansion).  Ours equals
+    the oracle reconstruction word for word (which test_oracle_vs_ref pins on the reference decoder); the reference decoder is checked
+    beside it -- colour words exact, alpha rows either expanded or, where its worker threads raced on `alpha_Companded`, left companded."""
+    frames, pitch = qbist_frames(10, 1, w, h, PIX_B64A, alpha=1)
+    px = np.frombuffer(frames[0].tobytes(), dtype=np.uint16).reshape(h, pitch // 2).copy()
+    px[:, 0: w * 4: 4] = ((np.arange(h)[:, None] * 523 + np.arange(w)[None, :] * 97) % 65536).astype(np.uint16)
+    frame = px.reshape(-1).view(np.uint8).copy()
+    sample = amd_encode_frames([frame], pitch, w, h, PIX_B64A, encoded=ENCODED_RGBA4444)[0]
+    plan = Plan(w, h, pixkind=PIXKIND["b64a"], enc=ENC["4444"])
+    pyramid = host_decode_pyramid(sample, plan)
+    exact = oracle_inverse_rgb48(plan, pyramid, b64a=True)[:h]
+    got, gpitch, aw, ah = amd_decode_sample(sample, PIX_B64A)
+    assert (aw, ah, gpitch) == (w, h, w * 8)
+    a = np.frombuffer(got.tobytes(), np.uint16).reshape(h, gpitch // 2)
+    assert np.array_equal(a, exact)
+    mse = np.mean((a.astype(np.float64) - px[:, : w * 4].astype(np.float64)) ** 2)
+    assert 10 * np.log10(65535.0 ** 2 / mse) > 30.0                   # the alpha plane here is noise-like; colour alone is far better
+    raw = oracle_inverse_rgb48(plan, pyramid, b64a=False)[:h]
+    for attempt in range(3):
+        want, wpitch = ref_decode_sample(sample, w, h, PIX_B64A)
+        b = np.frombuffer(want.tobytes(), np.uint16).reshape(h, wpitch // 2)[:, : w * 4]
+        colour = all(np.array_equal(b[:, k::4], exact[:, k::4]) for k in (1, 2, 3))
+        rows = (b[:, 0::4] == exact[:, 0::4]).all(axis=1) | (b[:, 0::4] == raw[:, 3::4]).all(axis=1)
+        if colour and rows.all(): break
+    else:
+        raise AssertionError("the reference decoder never reproduced the oracle reconstruction")
+    # gates
+    L = product()
+    dec_ref = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec_ref), None) == 0
+    aw2 = ctypes.c_int(); ah2 = ctypes.c_int(); af2 = ctypes.c_uint32()
+    sb = ctypes.create_string_buffer(sample, len(sample))
+    assert L.CFHD_PrepareToDecode(dec_ref, 0, 0, PIX_RG48, 1, 0, sb, 512, ctypes.byref(aw2), ctypes.byref(ah2), ctypes.byref(af2)) == 3
+    L.CFHD_CloseDecoder(dec_ref)
+
+
+def test_interlaced_samples_are_refused_by_the_decoder():
+    w, h = 320, 240
+    sample = amd_encode_frames([synth_yuy2(w, h, 3)[0]], w * 2, w, h, PIX_YUY2, flags=1)[0]
+    L = product()
+    dec = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
+    aw = ctypes.c_int(); ah = ctypes.c_int(); af = ctypes.c_uint32()
+    sb = ctypes.create_string_buffer(sample, len(sample))
+    assert L.CFHD_PrepareToDecode(dec, 0, 0, PIX_YUY2, 1, 0, sb, 512, ctypes.byref(aw), ctypes.byref(ah), ctypes.byref(af)) == 3   # CFHD_ERROR_BADFORMAT
+    L.CFHD_CloseDecoder(dec)
+
+
+@pytest.mark.skipif(not have_ref(), reason="needs the reference encoder")
+def test_b64a_8k_config_c_round_trip():
+    """Config C at its full size, 7680 x 4320 b64a (265 MB per frame): encode byte-identical to the reference, decode equal to the oracle."""
+    w, h = 7680, 4320
+    y, x = np.mgrid[0:h, 0:w].astype(np.uint32)
+    px = np.empty((h, w, 4), np.uint16)
+    px[..., 0] = ((x * 7 + y * 3) % 4096 * 16).astype(np.uint16)                       # alpha ramp
+    px[..., 1] = ((x * 5 + y) % 65536 // 2 + 8000).astype(np.uint16)
+    px[..., 2] = (((x // 64 + y // 64) % 2) * 30000 + (x * y) % 1024).astype(np.uint16)   # checkerboard + texture
+    px[..., 3] = ((x + 2 * y) * 3 % 50000).astype(np.uint16)
+    del x, y
+    frame = px.reshape(-1).view(np.uint8)
+    pitch = w * 8
+    a = amd_encode_frames([frame], pitch, w, h, PIX_B64A, encoded=ENCODED_RGBA4444)[0]
+    b = ref_encode_frames([frame], pitch, w, h, PIX_B64A, encoded=ENCODED_RGBA4444)[0]
+    assert len(a) == len(b)
+    assert mask_volatile_metadata(a) == mask_volatile_metadata(b)
+    plan = Plan(w, h, pixkind=PIXKIND["b64a"], enc=ENC["4444"])
+    exact = oracle_inverse_rgb48(plan, host_decode_pyramid(a, plan), b64a=True)[:h]
+    got, gpitch, aw, ah = amd_decode_sample(a, PIX_B64A)
+    assert (aw, ah) == (w, h)
+    assert np.array_equal(np.frombuffer(got.tobytes(), np.uint16).reshape(h, gpitch // 2), exact)

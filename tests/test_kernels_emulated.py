@@ -273,10 +273,11 @@ def test_fwd_packed16_level1_of_444_formats(w, h, dh, nch):
             assert np.array_equal(outs[4 * c + b][:, :w // 2], want[b][:, :w // 2]), (c, b)
 
 
-@pytest.mark.parametrize("w,h,dh,nch", [(16, 8, 16, 3), (68, 20, 37, 3), (96, 33, 66, 4), (160, 17, 34, 3)])
-def test_inv_packed16_last_level_of_444_formats(w, h, dh, nch):
-    """k_inv_packed16 = oracle RG48 / RG64 reconstruction (pinned against the reference decoder in test_oracle_vs_ref): exact, incl. the
-    65535-vs-65520 saturation difference between the reference's vector columns and its scalar tail columns."""
+@pytest.mark.parametrize("w,h,dh,nch,b64a", [(16, 8, 16, 3, 0), (68, 20, 37, 3, 0), (96, 33, 66, 4, 0), (160, 17, 34, 3, 0), (96, 33, 66, 4, 1), (40, 9, 17, 4, 1)])
+def test_inv_packed16_last_level_of_444_formats(w, h, dh, nch, b64a):
+    """k_inv_packed16 = oracle RG48 / RG64 / b64a reconstruction (pinned against the reference decoder in test_oracle_vs_ref): exact, incl.
+    the 65535-vs-65520 saturation difference between the reference's vector columns and its scalar tail columns and, for b64a, the
+    expansion of the companded alpha plane."""
     rng = np.random.default_rng(w * 3 + h + nch)
     pitch = (w + 7) // 8 * 8
     bands = []
@@ -285,17 +286,22 @@ def test_inv_packed16_last_level_of_444_formats(w, h, dh, nch):
         bs[0][:, :w] = rand_plane(rng, w, h, 14)               # LL1 of 12-bit components: up to 4 * 4095, here beyond it to hit the clamps
         for k in range(1, 4): bs[k][:, :w] = rand_plane(rng, w, h, 11, signed=True)
         bands.append(bs)
-    words = [1, 0, 2, 3][:nch]
+    words = [2, 1, 3, 0] if b64a else [1, 0, 2, 3][:nch]
     flat = [p16(a) for c in range(nch) for a in bands[c]]
     O = oracle()
     O.orc_inv_spatial_to_rgb48.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    O.orc_inv_spatial_to_b64a.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
     want = np.zeros((2 * h, 2 * w * nch), np.uint16)
-    O.orc_inv_spatial_to_rgb48((c_i16p * 16)(*(flat + [None] * (16 - len(flat)))), pitch, w, h, 12, nch, want.ctypes.data_as(ctypes.c_void_p), 2 * w * nch)
+    if b64a: O.orc_inv_spatial_to_b64a((c_i16p * 16)(*flat), pitch, w, h, 12, want.ctypes.data_as(ctypes.c_void_p), 2 * w * nch)
+    else: O.orc_inv_spatial_to_rgb48((c_i16p * 16)(*(flat + [None] * (16 - len(flat)))), pitch, w, h, 12, nch, want.ctypes.data_as(ctypes.c_void_p), 2 * w * nch)
     got = np.full((dh, 2 * w * nch), 7, np.uint16)
     E = emu()
-    E.emu_inv_packed16.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
-    E.emu_inv_packed16((c_i16p * len(flat))(*flat), pitch, w, h, dh, nch, 12, iarr(words), got.ctypes.data_as(ctypes.c_void_p), 2 * w * nch)
+    E.emu_inv_packed16.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    E.emu_inv_packed16((c_i16p * len(flat))(*flat), pitch, w, h, dh, nch, 12, iarr(words), got.ctypes.data_as(ctypes.c_void_p), 2 * w * nch, 3 if b64a else -1)
     assert np.array_equal(got, want[:dh])
+    if b64a:
+        a = want[:, 0::4]
+        assert (a == 0).any() and (a == 65535).any() and ((a > 0) & (a < 65535)).any()
     assert (want == 65535).any() and (want == 65520).any() and (want == 0).any()
 
 

@@ -107,6 +107,32 @@ def test_reference_rg48_decode_equals_oracle(w, h):
     assert np.array_equal(mine, img)
 
 
+@pytest.mark.parametrize("w,h", [(192, 96), (320, 240), (1920, 1080)])
+def test_reference_b64a_decode_equals_oracle(w, h):
+    """Pins orc_inv_spatial_to_b64a: the reference decodes an RGBA 4:4:4:4 sample to b64a through its planar 16-bit rows
+    (Row16uFull2OutputFormat), expanding the companded alpha plane; word for word equal to the oracle.  (The reference marks the alpha
+    as expanded from a worker thread while others may still convert rows, bayer.c:13871 / :16034 -- a row that loses that race keeps
+    the companded alpha; accept exactly that alternative.)"""
+    frames, pitch = qbist_frames(10, 1, w, h, PIX_B64A, alpha=1)
+    px = np.frombuffer(frames[0].tobytes(), dtype=np.uint16).reshape(h, pitch // 2).copy()
+    px[:, 0: w * 4: 4] = ((np.arange(h)[:, None] * 523 + np.arange(w)[None, :] * 97) % 65536).astype(np.uint16)
+    sample = ref_encode_frames([px.reshape(-1).view(np.uint8).copy()], pitch, w, h, PIX_B64A, encoded=ENCODED_RGBA4444)[0]
+    dec, dpitch = ref_decode_sample(sample, w, h, PIX_B64A)
+    img = np.frombuffer(dec.tobytes(), dtype=np.uint16).reshape(h, dpitch // 2)[:, : w * 4]
+    plan = Plan(w, h, pixkind=PIXKIND["b64a"], enc=ENC["4444"])
+    mine = oracle_inverse_rgb48(plan, host_decode_pyramid(sample, plan), b64a=True)[:h]
+    assert np.array_equal(mine[:, 1::4], img[:, 1::4]) and np.array_equal(mine[:, 2::4], img[:, 2::4]) and np.array_equal(mine[:, 3::4], img[:, 3::4])
+    rows_ok = (mine[:, 0::4] == img[:, 0::4]).all(axis=1)
+    assert rows_ok.mean() > 0.9
+    if not rows_ok.all():
+        raw = oracle_inverse_rgb48(plan, host_decode_pyramid(sample, plan), b64a=False)[:h]      # same planes without the alpha expansion
+        bad = np.where(~rows_ok)[0]
+        assert np.array_equal(img[bad][:, 0::4], raw[bad][:, 3::4])
+    # the expansion undoes the encoder's companding to within the quantization error
+    err = np.abs(mine[:, 0::4].astype(np.int64) - px[:, 0: w * 4: 4].astype(np.int64))
+    assert np.median(err) < 600
+
+
 @pytest.mark.parametrize("w,h", [(192, 96), (720, 480)])
 def test_interlaced_level1_oracle_equals_reference_coefficients(w, h):
     """Groundwork for SURVEY 8 a8 (1080i, not built on the GPU yet): the oracle's restatement of the interlaced level-1 "frame"
