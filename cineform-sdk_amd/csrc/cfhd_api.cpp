@@ -670,7 +670,6 @@ CFHD_Error CFHD_PrepareToDecode(CFHD_DecoderRef ref, int, int, CFHD_PixelFormat 
 	if (resolution != 1 && resolution != 0) return ERR_BAD_RESOLUTION;                 // full resolution only (round 1 scope)
 	const int encf = d->header.encoded_format;
 	if ((encf != ENC_YUV422 && encf != ENC_RGB444 && encf != ENC_RGBA4444) || d->header.transform_type != 0) return ERR_BADFORMAT;
-	if (!d->header.progressive) return ERR_BADFORMAT;                               // the inverse field transform is not built (encode only)
 	int kind = pixel_kind_of(fmt);
 	if (kind == PIX_NONE) return ERR_BADFORMAT;
 	// 4:2:2 samples decode to the packed 4:2:2 formats, RGB 4:4:4 samples to RG48 (wavelet.c:4947), RGBA 4:4:4:4 samples to b64a
@@ -740,7 +739,9 @@ CFHD_Error CFHD_DecodeSample(CFHD_DecoderRef ref, void *sample, size_t size, voi
 	};
 	if (parse_sample(s, size, &ps) != 0) return fail_zero(ERR_BADSAMPLE);
 	if (ps.width != d->header.width || ps.display_height != d->header.display_height || ps.encoded_format != d->header.encoded_format ||
-	    ps.num_channels != d->plan.num_channels || !ps.progressive) return fail_zero(ERR_BADSAMPLE);
+	    ps.num_channels != d->plan.num_channels) return fail_zero(ERR_BADSAMPLE);
+	// interlaced samples (no SAMPLE_FLAGS tag; it lies behind the 512 bytes CFHD_PrepareToDecode sees): the inverse field transform is not built
+	if (!ps.progressive) return fail_zero(ERR_BADFORMAT);
 	if (!d->batch_ready) {
 		if (d->batch.prepare(d->plan, 1, d->out_kind, true)) return ERR_INTERNAL;
 		if (gpu_entropy_enabled() && d->batch.prepare_entropy((size_t)d->plan.width * d->plan.height * pixel_bytes_of(d->out_kind) + 65536)) return ERR_INTERNAL;

@@ -442,13 +442,18 @@ def test_b64a_decode_equals_reference(w, h):
 
 
 def test_interlaced_samples_are_refused_by_the_decoder():
+    """The inverse field transform is not built: CFHD_DecodeSample refuses an interlaced sample (BADFORMAT, output zero-filled)
+    instead of running the progressive inverse on it."""
     w, h = 320, 240
     sample = amd_encode_frames([synth_yuy2(w, h, 3)[0]], w * 2, w, h, PIX_YUY2, flags=1)[0]
     L = product()
     dec = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
     aw = ctypes.c_int(); ah = ctypes.c_int(); af = ctypes.c_uint32()
     sb = ctypes.create_string_buffer(sample, len(sample))
-    assert L.CFHD_PrepareToDecode(dec, 0, 0, PIX_YUY2, 1, 0, sb, 512, ctypes.byref(aw), ctypes.byref(ah), ctypes.byref(af)) == 3   # CFHD_ERROR_BADFORMAT
+    assert L.CFHD_PrepareToDecode(dec, 0, 0, PIX_YUY2, 1, 0, sb, 512, ctypes.byref(aw), ctypes.byref(ah), ctypes.byref(af)) == 0
+    out = np.full(w * 2 * h, 7, np.uint8)
+    assert L.CFHD_DecodeSample(dec, sb, len(sample), out.ctypes.data_as(ctypes.c_void_p), w * 2) == 3   # CFHD_ERROR_BADFORMAT
+    assert not out.any()
     L.CFHD_CloseDecoder(dec)
 
 
