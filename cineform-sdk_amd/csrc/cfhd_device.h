@@ -72,6 +72,7 @@ public:
 	int prepare_entropy(size_t sample_cap);
 	GpuEntropyDecoder &entropy() { return ent_; }
 	bool has_entropy() const { return ent_ready_; }
+	bool strip_inverse() const;                     // the last level of 4:2:2 runs as k_inv_yuv422_strip (else k_inv_yuv422)
 	int set_device_output(int i, void *d_out, int pitch_bytes);
 	int launch_inverse(uint32_t dither_seed);          // async
 	int download_frame(int i, void *out, int pitch_bytes);   // async D2H into pinned staging, then row copy after wait

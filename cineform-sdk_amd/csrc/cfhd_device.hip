@@ -466,6 +466,18 @@ int DecodeBatch::set_device_output(int i, void *d_out, int pitch)
 	return 0;
 }
 
+// k_inv_yuv422_strip serves luma bands of whole 16-column blocks up to 126 x 8 columns and writes 16-byte words; everything else (and
+// CFHD_AMD_INVERSE=tile, for A/B runs) takes the LDS-tiled k_inv_yuv422.  Both produce the same bytes.
+bool DecodeBatch::strip_inverse() const
+{
+	static const bool forced_tile = [] { const char *e = getenv("CFHD_AMD_INVERSE"); return e && strcmp(e, "tile") == 0; }();
+	const int bw = plan_.ch[0].band[0][0].width;
+	if (forced_tile || is_packed16(out_kind_) || bw % 16 || bw / dev::SBLK > dev::SMAX_LUMA_BLOCKS) return false;
+	DecJobs j = dec_jobs_at(h_jobs_, n_, plan_.num_channels);
+	for (int i = 0; i < n_; i++) if (((uintptr_t)j.yuv[i].out & 15) || (j.yuv[i].out_pitch & 15)) return false;
+	return true;
+}
+
 int DecodeBatch::launch_inverse(uint32_t dither_seed)
 {
 	int rc = sync_jobs();
@@ -486,6 +498,9 @@ int DecodeBatch::launch_inverse(uint32_t dither_seed)
 		const BandDesc &b = plan_.ch[0].band[0][0];
 		dim3 grid(((b.width + dev::ITW - 1) / dev::ITW) * nch, (b.height + dev::ITH - 1) / dev::ITH, n_);
 		dev::k_inv_packed16<<<grid, dev::NTHREADS, 0, st>>>(j.l1, nch);
+	} else if (strip_inverse()) {
+		const BandDesc &b = plan_.ch[0].band[0][0];
+		dev::k_inv_yuv422_strip<<<dim3(1, (b.height + dev::SR - 1) / dev::SR, n_), dev::NTHREADS, 0, st>>>(j.yuv, dither_seed);
 	} else {
 		const BandDesc &b = plan_.ch[0].band[0][0];
 		dim3 grid((b.width + dev::ITW - 1) / dev::ITW, (b.height + dev::ITH - 1) / dev::ITH, n_);

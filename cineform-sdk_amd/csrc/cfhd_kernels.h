@@ -774,7 +774,7 @@ __global__ void __launch_bounds__(NTHREADS) k_inv_yuv422(const InvYuvJob *jobs, 
 			const uint32_t cm = C[-1], cz = C[0], cp = C[1], chh = s_vc[par][1][rl][p + 2];
 			uint32_t ce, co;                              // (V, U): even output, odd output
 			inv_horiz_pk(cm, cz, cp, chh, ce, co);
-			const uint32_t dz = sh >= 2 ? dither_word(seed, orow, cc) : 0u;
+			const uint32_t dz = sh >= 2 ? dither_word(seed, orow, cc >> 2) >> (8 * (cc & 3)) : 0u;    // one hash word per 4 chroma columns, one byte each
 			// 8-bit samples in 16-bit lanes: te = (y0, y2), to = (y1, y3), tce = (v0, u0), tco = (v1, u1)
 			uint32_t te = pk_to8(ye, sh, (dz & 1u) | ((dz << 14) & 0x10000u)), to = pk_to8(yo, sh, ((dz >> 1) & 1u) | ((dz << 13) & 0x10000u));
 			uint32_t tce = pk_to8(ce, sh, ((dz >> 4) & 1u) | ((dz << 11) & 0x10000u)), tco = pk_to8(co, sh, ((dz >> 6) & 1u) | ((dz << 9) & 0x10000u));
@@ -809,6 +809,184 @@ __global__ void __launch_bounds__(NTHREADS) k_inv_yuv422(const InvYuvJob *jobs, 
 			else { o2.x = y0 | (u0 << 8) | (y1 << 16) | (v0 << 24); o2.y = y2 | (u1 << 8) | (y3 << 16) | (v1 << 24); }
 			*(uint2 *)(job.out + (size_t)orow * job.out_pitch + 8 * (size_t)cc) = o2;
 		}
+	}
+}
+
+// =============================================================================================
+// k_inv_yuv422_strip: the same last level as k_inv_yuv422, organised around registers instead of LDS tiles.
+//
+// k_inv_yuv422 is bound by instruction issue, not by bytes (tools/microbench_inv_yuv422.hip: its loads and stores alone run at
+// 3.8 TB/s, the same bytes with 16-byte accesses at 5.7 TB/s, the kernel at 2.2 TB/s): per-item index arithmetic, two LDS round
+// trips and dword accesses.  Here a workgroup owns a full-width strip of SR band rows and walks down it:
+//   waves 0, 1: luma, one lane per block of 8 band columns (the two waves overlap by two blocks so that every stored block has both
+//               neighbours inside its wave); wave 2: V; wave 3: U -- the chroma bands are half as wide, so the roles balance;
+//   each lane streams its 8 columns of LL, LH, HL, HH with one 16-byte load per band row, keeps the three-row window of the vertical
+//   filter in registers, gets the two neighbouring column pairs of the horizontal filter from the adjacent lanes, and produces 16
+//   output samples per output row;
+//   the chroma waves leave their 8-bit samples in LDS (2 KB per output row), the luma lanes interleave them with their own and
+//   write 32 contiguous bytes each.  One barrier per band row (the chroma buffer is double-buffered).
+// Same arithmetic, same dither bits as k_inv_yuv422 -- the two kernels are interchangeable and tested against each other.
+// Geometry served: width % 32 == 0 (chroma band a multiple of 8 columns) and width <= 1984 (126 luma blocks); others take k_inv_yuv422.
+// =============================================================================================
+enum { SR = 16, SBLK = 8, SLUMA_STEP = 62, SMAX_LUMA_BLOCKS = 2 * SLUMA_STEP + 2, SPLANE = 1024 };
+
+#if defined(CFHD_HIPEMU)
+struct emu_u4 { uint32_t x, y, z, w; };
+typedef emu_u4 cfhd_u4;
+#define CFHD_LDG128(p) (*(const cfhd_u4 *)(p))
+__device__ __forceinline__ uint32_t byte_perm(uint32_t s0, uint32_t s1, uint32_t sel)
+{
+	const uint64_t src = ((uint64_t)s0 << 32) | s1;
+	uint32_t r = 0;
+	for (int k = 0; k < 4; k++) { const uint32_t b = (sel >> (8 * k)) & 0xffu; r |= (b < 8 ? (uint32_t)((src >> (8 * b)) & 0xffu) : (b == 0x0c ? 0u : 0xffu)) << (8 * k); }
+	return r;
+}
+#else
+typedef uint32_t cfhd_u4 __attribute__((ext_vector_type(4)));
+#define CFHD_LDG128(p) (*(const __attribute__((address_space(1))) cfhd_u4 *)(p))
+__device__ __forceinline__ uint32_t byte_perm(uint32_t s0, uint32_t s1, uint32_t sel) { return __builtin_amdgcn_perm(s0, s1, sel); }
+#endif
+
+struct StripRow { uint32_t d[4]; };                   // 8 band columns = 4 column pairs
+__device__ __forceinline__ StripRow strip_load(const int16_t *p) { const cfhd_u4 v = CFHD_LDG128(p); StripRow r; r.d[0] = v.x; r.d[1] = v.y; r.d[2] = v.z; r.d[3] = v.w; return r; }
+
+// Horizontal synthesis + 10 -> 8 bit of one output row of a block: L, H = the vertically synthesised low / high rows of the block,
+// prev / next = the neighbouring column pairs.  te[d], to[d] = 8-bit samples in 16-bit lanes: (s(4d), s(4d+2)), (s(4d+1), s(4d+3)).
+// dbits = one dither bit per sample, sample s of the block at bit s.
+__device__ __forceinline__ void strip_row_to8(const uint32_t (&L)[4], const uint32_t (&H)[4], uint32_t prev, uint32_t next, bool first, bool last,
+                                              int sh, uint32_t dbits, uint32_t (&te)[4], uint32_t (&to)[4])
+{
+	const uint32_t ext[6] = { prev, L[0], L[1], L[2], L[3], next };
+#pragma unroll
+	for (int d = 0; d < 4; d++) {
+		const uint32_t dm = ext[d], d0 = ext[d + 1], dp = ext[d + 2];
+		uint32_t e, o;
+		inv_horiz_pk((dm >> 16) | (d0 << 16), d0, (d0 >> 16) | (dp << 16), H[d], e, o);
+		const uint32_t b = dbits >> (4 * d);
+		te[d] = pk_to8(e, sh, (b & 1u) | ((b << 14) & 0x10000u));
+		to[d] = pk_to8(o, sh, ((b >> 1) & 1u) | ((b << 13) & 0x10000u));
+	}
+	if (first) {                                          // column 0 of the band: 32-bit border taps
+		const int l[6] = { 0, 0, lo16(L[0]), hi16(L[0]), lo16(L[1]), hi16(L[1]) };
+		int e, o;
+		inv_horiz_border(l, 2, lo16(H[0]), 0, e, o);
+		te[0] = (te[0] & 0xffff0000u) | to8(e, sh, (int)(dbits & 1u)); to[0] = (to[0] & 0xffff0000u) | to8(o, sh, (int)((dbits >> 1) & 1u));
+	}
+	if (last) {                                           // last column of the band
+		const int l[6] = { lo16(L[2]), hi16(L[2]), lo16(L[3]), hi16(L[3]), 0, 0 };
+		int e, o;
+		inv_horiz_border(l, 3, hi16(H[3]), 2, e, o);
+		te[3] = (te[3] & 0xffffu) | (to8(e, sh, (int)((dbits >> 14) & 1u)) << 16); to[3] = (to[3] & 0xffffu) | (to8(o, sh, (int)((dbits >> 15) & 1u)) << 16);
+	}
+}
+
+__global__ void __launch_bounds__(NTHREADS) k_inv_yuv422_strip(const InvYuvJob *jobs, uint32_t launch_seed)
+{
+	const TileId tile = xcd_tile();
+	__shared__ InvYuvJob s_job;
+	stage_job(&s_job, &jobs[tile.z]);
+	const InvYuvJob &job = s_job;
+	__shared__ uint32_t s_chroma[2][2][2][SPLANE / 4];    // [buffer][output row parity][V, U][bytes of the row's samples]
+	const uint32_t seed = job.dither_seed ^ launch_seed;
+	const int h = job.height, r0 = tile.y * SR;
+	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+	const bool luma = wave < 2;
+	const int comp = luma ? 0 : wave - 1;                 // 0 Y, 1 V, 2 U
+	const int w = luma ? job.width : job.width >> 1;      // band columns of this lane's component
+	const int nblk = w / SBLK;
+	const int want = luma ? lane + SLUMA_STEP * wave : lane;
+	const int blk = want < nblk ? want : nblk - 1;        // lanes beyond the band recompute the last block and store nothing
+	const bool stores = want < nblk && (!luma || (wave == 0 ? lane < SLUMA_STEP + 1 : lane > 0));
+	const bool first = blk == 0, last = blk == nblk - 1;
+	const int pitch = job.band_pitch[comp];
+	const int16_t *pLL = job.band[comp][0] + SBLK * blk, *pLH = job.band[comp][1] + SBLK * blk;
+	const int16_t *pHL = job.band[comp][2] + SBLK * blk, *pHH = job.band[comp][3] + SBLK * blk;
+	if (r0 >= h) return;                                  // whole workgroup
+	const int nrows = h - r0 < SR ? h - r0 : SR;
+	int j = inv_window_first_row(r0, h);
+	StripRow ll0 = strip_load(pLL + (size_t)j * pitch), ll1 = strip_load(pLL + (size_t)(j + 1) * pitch), ll2 = strip_load(pLL + (size_t)(j + 2) * pitch);
+	StripRow lh0 = strip_load(pLH + (size_t)j * pitch), lh1 = strip_load(pLH + (size_t)(j + 1) * pitch), lh2 = strip_load(pLH + (size_t)(j + 2) * pitch);
+	StripRow hl = strip_load(pHL + (size_t)r0 * pitch), hh = strip_load(pHH + (size_t)r0 * pitch);
+	const int sh = job.shift;
+	for (int s = 0; s < nrows; s++) {
+		const int r = r0 + s;
+		// loads of the next band row go out before this row's arithmetic
+		const bool more = s + 1 < nrows;
+		const int jn = more ? inv_window_first_row(r + 1, h) : j;
+		const bool advance = jn != j;
+		StripRow nll = ll2, nlh = lh2, nhl = hl, nhh = hh;
+		if (advance) { nll = strip_load(pLL + (size_t)(jn + 2) * pitch); nlh = strip_load(pLH + (size_t)(jn + 2) * pitch); }
+		if (more) { nhl = strip_load(pHL + (size_t)(r + 1) * pitch); nhh = strip_load(pHH + (size_t)(r + 1) * pitch); }
+		// vertical synthesis: rows 2r (even) and 2r + 1 (odd) of the horizontal-low and horizontal-high halves
+		const int pos = r == 0 ? 0 : (r == h - 1 ? 2 : 1);
+		uint32_t Lv[2][4], Hv[2][4];
+#pragma unroll
+		for (int d = 0; d < 4; d++) {
+			inv_vert_pk(ll0.d[d], ll1.d[d], ll2.d[d], hl.d[d], pos, Lv[0][d], Lv[1][d]);
+			inv_vert_pk(lh0.d[d], lh1.d[d], lh2.d[d], hh.d[d], pos, Hv[0][d], Hv[1][d]);
+		}
+		uint32_t (*cbuf)[2][SPLANE / 4] = s_chroma[s & 1];
+		uint32_t te[2][4], to[2][4];
+#pragma unroll
+		for (int par = 0; par < 2; par++) {
+			const int orow = 2 * r + par;
+			const uint32_t prev = __shfl(Lv[par][3], lane - 1), next = __shfl(Lv[par][0], lane + 1);
+			// dither bits: one hash word per (output row, group of 16 luma samples = 4 chroma columns); byte j of it belongs to chroma
+			// column 4g + j: bits 0-3 its four luma samples, 4 / 6 its two V samples, 5 / 7 its two U samples
+			uint32_t dbits = 0;
+			if (sh >= 2) {
+				if (luma) {
+					const uint32_t z = dither_word(seed, orow, blk);
+					dbits = (z & 0xfu) | ((z >> 4) & 0xf0u) | ((z >> 8) & 0xf00u) | ((z >> 12) & 0xf000u);
+				} else {
+					const uint32_t z0 = dither_word(seed, orow, 2 * blk), z1 = dither_word(seed, orow, 2 * blk + 1);
+					const int b0 = comp == 1 ? 4 : 5;             // even sample of a column at bit b0, odd sample at b0 + 2 of the column's byte
+#pragma unroll
+					for (int c = 0; c < 8; c++) {                 // chroma column c of the block -> samples 2c, 2c + 1
+						const uint32_t byte = ((c < 4 ? z0 : z1) >> (8 * (c & 3))) & 0xffu;
+						// strip_row_to8 expects sample s of the block at bit s
+						dbits |= ((byte >> b0) & 1u) << (2 * c) | ((byte >> (b0 + 2)) & 1u) << (2 * c + 1);
+					}
+				}
+			}
+			strip_row_to8(Lv[par], Hv[par], prev, next, first, last, sh, dbits, te[par], to[par]);
+			if (!luma && stores && orow < job.display_height) {
+				// bytes in sample order: (s(4d), s(4d+1), s(4d+2), s(4d+3)) = te | to << 8
+				uint32_t *dst = &cbuf[par][comp - 1][4 * blk];
+#pragma unroll
+				for (int d = 0; d < 4; d++) dst[d] = te[par][d] | (to[par][d] << 8);
+			}
+		}
+		__syncthreads();
+		if (luma && stores) {
+#pragma unroll
+			for (int par = 0; par < 2; par++) {
+				const int orow = 2 * r + par;
+				if (orow >= job.display_height) continue;
+				// pixel pair k of the block (k = 0..7): luma samples 2k, 2k + 1 and chroma sample 8 blk + k
+				const uint32_t v0 = cbuf[par][0][2 * blk], v1 = cbuf[par][0][2 * blk + 1], u0 = cbuf[par][1][2 * blk], u1 = cbuf[par][1][2 * blk + 1];
+				uint32_t o[8];
+#pragma unroll
+				for (int d = 0; d < 4; d++) {
+					const uint32_t pa = pk_lolo(te[par][d], to[par][d]), pb = pk_hihi(te[par][d], to[par][d]);    // (y(4d), y(4d+1)), (y(4d+2), y(4d+3))
+					const uint32_t vv = d < 2 ? v0 : v1, uu = d < 2 ? u0 : u1;
+					const int m = (2 * d) & 3;                     // byte of the chroma dwords for pixel pair 2d; 2d + 1 is the next byte
+					if (job.uyvy) {
+						o[2 * d] = (pa << 8) | byte_perm(vv, uu, (uint32_t)m | 0x0c00u | ((uint32_t)(4 + m) << 16) | 0x0c000000u);
+						o[2 * d + 1] = (pb << 8) | byte_perm(vv, uu, (uint32_t)(m + 1) | 0x0c00u | ((uint32_t)(5 + m) << 16) | 0x0c000000u);
+					} else {
+						o[2 * d] = pa | byte_perm(vv, uu, 0x0cu | ((uint32_t)m << 8) | 0x0c0000u | ((uint32_t)(4 + m) << 24));
+						o[2 * d + 1] = pb | byte_perm(vv, uu, 0x0cu | ((uint32_t)(m + 1) << 8) | 0x0c0000u | ((uint32_t)(5 + m) << 24));
+					}
+				}
+				uint4 *dst = (uint4 *)(job.out + (size_t)orow * job.out_pitch + 32 * (size_t)blk);
+				uint4 q0, q1;
+				q0.x = o[0]; q0.y = o[1]; q0.z = o[2]; q0.w = o[3]; q1.x = o[4]; q1.y = o[5]; q1.z = o[6]; q1.w = o[7];
+				dst[0] = q0; dst[1] = q1;
+			}
+		}
+		if (advance) { ll0 = ll1; ll1 = ll2; ll2 = nll; lh0 = lh1; lh1 = lh2; lh2 = nlh; j = jn; }
+		hl = nhl; hh = nhh;
 	}
 }
 

@@ -94,6 +94,42 @@ def test_inv_yuv422(w, h, dh, uyvy):
     assert np.any(e != outs[0]) and np.any(e != outs[1])        # the dither really toggles
 
 
+@pytest.mark.parametrize("w,h,dh", [(16, 8, 16), (32, 17, 33), (96, 20, 40), (480, 35, 70), (1008, 16, 31), (1024, 8, 16)])
+@pytest.mark.parametrize("uyvy", [0, 1])
+def test_inv_yuv422_strip_kernel(w, h, dh, uyvy):
+    """k_inv_yuv422_strip (register windows + lane exchange instead of LDS tiles) vs the oracle, and byte for byte equal to
+    k_inv_yuv422 with the same dither seed: the two kernels are interchangeable.  1008 = the widest band it serves (126 blocks)."""
+    rng = np.random.default_rng(w + 3 * h + uyvy)
+    bands, pitches = [], []
+    for ch in range(3):
+        cw = w if ch == 0 else w // 2
+        pitch = (cw + 7) // 8 * 8 + (8 if ch == 1 else 0); pitches.append(pitch)
+        bs = [rng.integers(-50, 50, size=(h, pitch)).astype(np.int16) for _ in range(4)]          # the pad columns hold junk: they must not matter
+        bs[0][:, :cw] = rand_plane(rng, cw, h, 11)
+        for k in range(1, 4): bs[k][:, :cw] = rand_plane(rng, cw, h, 9, signed=True)
+        bands.append(bs)
+    ptrs = (c_i16p * 12)(*[p16(a) for ch in range(3) for a in bands[ch]])
+    E = emu()
+    got = np.full((dh, 4 * w + 16), 7, np.uint8)
+    rc = E.emu_inv_yuv422_strip(ptrs, iarr(pitches), w, h, dh, uyvy, 2, 99, p8(got), 4 * w + 16)
+    if w > 1008:
+        assert rc == -1
+        return
+    assert rc == 0
+    assert np.all(got[:, 4 * w:] == 7)
+    outs = []
+    for dither in (0, 1):
+        o = np.zeros((2 * h, 4 * w), np.uint8)
+        oracle().orc_inv_spatial_to_yuv422(ptrs, iarr(pitches), w, h, 10, uyvy, dither, p8(o), 4 * w)
+        outs.append(o[:dh])
+    e = got[:, :4 * w]
+    assert np.all((e == outs[0]) | (e == outs[1]))
+    assert np.any(e != outs[0]) and np.any(e != outs[1])
+    tile = np.zeros((dh, 4 * w), np.uint8)
+    E.emu_inv_yuv422(ptrs, iarr(pitches), w, h, dh, uyvy, 2, 99, p8(tile), 4 * w)
+    assert np.array_equal(tile, e)
+
+
 def _emu_entropy(plan, coeffs, frame_number, meta):
     out = np.zeros(plan.width * plan.height * 4 + 65536, dtype=np.uint8)
     m = np.frombuffer(meta, dtype=np.uint8).copy()
