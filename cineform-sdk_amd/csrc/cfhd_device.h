@@ -34,6 +34,7 @@ public:
 	int prepare_entropy(size_t sample_cap);
 	GpuEntropyEncoder &entropy() { return ent_; }
 	bool has_entropy() const { return ent_ready_; }
+	bool strip_forward() const;                     // level 1 of 4:2:2 runs as k_fwd_yuv422_strip (else k_fwd_yuv422)
 	int download_coeffs();                             // async: final (entropy coded) region of every frame -> pinned host
 	int wait();
 	const int16_t *host_coeffs(int i) const { return h_coeff_ + (size_t)i * plan_.final_elems; }

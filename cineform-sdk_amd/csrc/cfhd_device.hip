@@ -280,6 +280,17 @@ int EncodeBatch::set_device_frame(int i, const void *d_frame, int pitch)
 	return 0;
 }
 
+// k_fwd_yuv422_strip serves progressive 4:2:2 frames of whole 32-pixel blocks up to 2016 pixels wide whose rows are 16-byte aligned;
+// everything else (and CFHD_AMD_FORWARD=tile, for A/B runs) takes the LDS-tiled k_fwd_yuv422.  Both produce the same coefficients.
+bool EncodeBatch::strip_forward() const
+{
+	static const bool forced_tile = [] { const char *e = getenv("CFHD_AMD_FORWARD"); return e && strcmp(e, "tile") == 0; }();
+	if (forced_tile || plan_.interlaced || plan_.encoded_format != ENC_YUV422 || plan_.width % 32 || plan_.width / 16 > dev::SMAX_LUMA_BLOCKS) return false;
+	EncJobs j = enc_jobs_at(h_jobs_, n_, plan_.num_channels);
+	for (int i = 0; i < n_; i++) if (((uintptr_t)j.yuv[i].in & 15) || (j.yuv[i].in_pitch & 15)) return false;
+	return true;
+}
+
 int EncodeBatch::launch_forward()
 {
 	int rc = sync_jobs();
@@ -301,6 +312,8 @@ int EncodeBatch::launch_forward()
 		static_assert(sizeof(dev::FwdFrameJob) == sizeof(dev::FwdYuvJob) && offsetof(dev::FwdFrameJob, q) == offsetof(dev::FwdYuvJob, q), "the two level-1 jobs share one table");
 		dim3 grid((plan_.width / 2 + dev::FTW - 1) / dev::FTW, (plan_.height / 2 + dev::FRW - 1) / dev::FRW, n_);
 		dev::k_fwd_frame_yuv422<<<grid, dev::NTHREADS, 0, st>>>((const dev::FwdFrameJob *)j.yuv);
+	} else if (strip_forward()) {
+		dev::k_fwd_yuv422_strip<<<dim3(1, (plan_.height / 2 + dev::SRF - 1) / dev::SRF, n_), dev::NTHREADS, 0, st>>>(j.yuv);
 	} else {
 		dim3 grid((plan_.width / 2 + dev::TW - 1) / dev::TW, (plan_.height / 2 + dev::TH - 1) / dev::TH, n_);
 		dev::k_fwd_yuv422<<<grid, dev::NTHREADS, 0, st>>>(j.yuv);

@@ -118,6 +118,16 @@ __device__ __forceinline__ uint32_t pk_lolo(uint32_t a, uint32_t b) { return __b
 __device__ __forceinline__ uint32_t pk_hihi(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
 #endif
 __device__ __forceinline__ uint32_t pk_set(int v) { return pack16(v, v); }
+// wrapping (non-saturating) packed add / negate and signed max: the quantizer's 16-bit arithmetic (quantize.c:1395)
+#if defined(CFHD_HIPEMU)
+__device__ __forceinline__ uint32_t pk_addw(uint32_t a, uint32_t b) { return pack16(lo16(a) + lo16(b), hi16(a) + hi16(b)); }
+__device__ __forceinline__ uint32_t pk_negw(uint32_t a) { return pack16(-lo16(a), -hi16(a)); }
+__device__ __forceinline__ uint32_t pk_maxs(uint32_t a, uint32_t b) { return pack16(lo16(a) > lo16(b) ? lo16(a) : lo16(b), hi16(a) > hi16(b) ? hi16(a) : hi16(b)); }
+#else
+__device__ __forceinline__ uint32_t pk_addw(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (cfhd_s2)(__builtin_bit_cast(cfhd_s2, a) + __builtin_bit_cast(cfhd_s2, b))); }
+__device__ __forceinline__ uint32_t pk_negw(uint32_t a) { return __builtin_bit_cast(uint32_t, (cfhd_s2)(-__builtin_bit_cast(cfhd_s2, a))); }
+__device__ __forceinline__ uint32_t pk_maxs(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(cfhd_s2, a), __builtin_bit_cast(cfhd_s2, b))); }
+#endif
 
 // 2/6 analysis highpass on two lanes at once (SIMD association order, spatial.c:326-397 / :10301-10351)
 __device__ __forceinline__ uint32_t pk_hp_mid(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4, uint32_t a5)
@@ -139,6 +149,18 @@ __device__ __forceinline__ int quantize(int v, const QuantParam &q)
 	unsigned a = ((unsigned)(neg ? -v : v) + (unsigned)q.mid) & 0xffffu;
 	int r = (int)((a * q.mult) >> 16);
 	return (int)(int16_t)(neg ? -r : r);
+}
+
+// the same on two packed values: |x| as an unsigned 16-bit number (wrapping negate, so -32768 -> 32768), + mid with 16-bit wrap,
+// the 16 x 16 -> high 16 multiply per half, sign restored with (r ^ s) - s
+__device__ __forceinline__ uint32_t pk_quantize(uint32_t v, const QuantParam &q)
+{
+	if (q.divisor <= 1) return v;
+	const uint32_t s = pk_sra(v, 15);
+	uint32_t a = pk_maxs(v, pk_negw(v));
+	a = pk_addw(a, pk_set(q.mid));
+	const uint32_t r = (((a & 0xffffu) * q.mult) >> 16) | (((a >> 16) * q.mult) & 0xffff0000u);
+	return pk_addw(r ^ s, pk_negw(s));
 }
 
 // 2/6 analysis highpass, interior tap (SIMD association order, spatial.c:326-397 / :10301-10351)
@@ -826,7 +848,7 @@ __global__ void __launch_bounds__(NTHREADS) k_inv_yuv422(const InvYuvJob *jobs, 
 //   the chroma waves leave their 8-bit samples in LDS (2 KB per output row), the luma lanes interleave them with their own and
 //   write 32 contiguous bytes each.  One barrier per band row (the chroma buffer is double-buffered).
 // Same arithmetic, same dither bits as k_inv_yuv422 -- the two kernels are interchangeable and tested against each other.
-// Geometry served: width % 32 == 0 (chroma band a multiple of 8 columns) and width <= 1984 (126 luma blocks); others take k_inv_yuv422.
+// Geometry served: width % 32 == 0 (chroma band a multiple of 8 columns) and width <= 2016 (126 luma blocks); others take k_inv_yuv422.
 // =============================================================================================
 enum { SR = 16, SBLK = 8, SLUMA_STEP = 62, SMAX_LUMA_BLOCKS = 2 * SLUMA_STEP + 2, SPLANE = 1024 };
 
@@ -880,7 +902,8 @@ __device__ __forceinline__ void strip_row_to8(const uint32_t (&L)[4], const uint
 	}
 }
 
-__global__ void __launch_bounds__(NTHREADS) k_inv_yuv422_strip(const InvYuvJob *jobs, uint32_t launch_seed)
+template <int ROWS_PER_STRIP>
+__device__ __forceinline__ void inv_yuv422_strip(const InvYuvJob *jobs, uint32_t launch_seed)
 {
 	const TileId tile = xcd_tile();
 	__shared__ InvYuvJob s_job;
@@ -888,7 +911,7 @@ __global__ void __launch_bounds__(NTHREADS) k_inv_yuv422_strip(const InvYuvJob *
 	const InvYuvJob &job = s_job;
 	__shared__ uint32_t s_chroma[2][2][2][SPLANE / 4];    // [buffer][output row parity][V, U][bytes of the row's samples]
 	const uint32_t seed = job.dither_seed ^ launch_seed;
-	const int h = job.height, r0 = tile.y * SR;
+	const int h = job.height, r0 = tile.y * ROWS_PER_STRIP;
 	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 	const bool luma = wave < 2;
 	const int comp = luma ? 0 : wave - 1;                 // 0 Y, 1 V, 2 U
@@ -902,7 +925,7 @@ __global__ void __launch_bounds__(NTHREADS) k_inv_yuv422_strip(const InvYuvJob *
 	const int16_t *pLL = job.band[comp][0] + SBLK * blk, *pLH = job.band[comp][1] + SBLK * blk;
 	const int16_t *pHL = job.band[comp][2] + SBLK * blk, *pHH = job.band[comp][3] + SBLK * blk;
 	if (r0 >= h) return;                                  // whole workgroup
-	const int nrows = h - r0 < SR ? h - r0 : SR;
+	const int nrows = h - r0 < ROWS_PER_STRIP ? h - r0 : ROWS_PER_STRIP;
 	int j = inv_window_first_row(r0, h);
 	StripRow ll0 = strip_load(pLL + (size_t)j * pitch), ll1 = strip_load(pLL + (size_t)(j + 1) * pitch), ll2 = strip_load(pLL + (size_t)(j + 2) * pitch);
 	StripRow lh0 = strip_load(pLH + (size_t)j * pitch), lh1 = strip_load(pLH + (size_t)(j + 1) * pitch), lh2 = strip_load(pLH + (size_t)(j + 2) * pitch);
@@ -989,6 +1012,172 @@ __global__ void __launch_bounds__(NTHREADS) k_inv_yuv422_strip(const InvYuvJob *
 		hl = nhl; hh = nhh;
 	}
 }
+__global__ void __launch_bounds__(NTHREADS) k_inv_yuv422_strip(const InvYuvJob *jobs, uint32_t launch_seed) { inv_yuv422_strip<SR>(jobs, launch_seed); }
+
+// =============================================================================================
+// k_fwd_yuv422_strip: level 1 of the packed 4:2:2 formats with the organisation of k_inv_yuv422_strip (registers and lane exchange instead
+// of LDS tiles, 16-byte accesses).  A workgroup walks down a full-width strip of SRF band rows:
+//   waves 0, 1: one lane per 16 pixels (32 bytes of every picture row): 8 luma pairs -> 8 band columns; the lane also cuts the 4 V and
+//               4 U sample pairs out of its pixels and leaves them in LDS;  wave 2: V, wave 3: U, one lane per 8 chroma band columns
+//               (16 samples = 8 pairs read back from LDS).  From the pairs on, luma and chroma lanes run the same code:
+//   horizontal 2/6 analysis of the row's 8 pairs (neighbour pairs from the adjacent lanes), results pushed into a six-row register
+//   window; every second row the vertical 2/6 analysis + quantizer emits one row of LL, LH, HL, HH, 16 bytes per band.
+// One barrier per picture row pair (the LDS chroma rows are double-buffered).  Same arithmetic as k_fwd_yuv422, tested against it.
+// Geometry served: width % 32 == 0 and width <= 2016, 16-byte aligned rows; everything else takes k_fwd_yuv422.
+// =============================================================================================
+enum { SRF = 32, SFPLANE = 512 };                       // band rows per strip; chroma pairs per picture row (dwords) the LDS buffer holds per channel
+
+// Horizontal analysis of one picture row of a block: p = its 8 sample pairs, prev / next = the neighbouring pairs.
+__device__ __forceinline__ void strip_fwd_row(const uint32_t (&p)[8], uint32_t prev, uint32_t next, bool first, bool last, uint32_t (&L)[4], uint32_t (&H)[4])
+{
+	const uint32_t ext[10] = { prev, p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], next };
+#pragma unroll
+	for (int m = 0; m < 4; m++) horiz_pair(&ext[2 * m], 0u, 0, first && m == 0, false, last && m == 3, L[m], H[m]);
+}
+
+// Per-lane state of k_fwd_yuv422_strip.
+struct FwdStrip {
+	uint32_t LW[6][4], HW[6][4];                          // window of horizontally analysed rows: picture rows wtop .. wtop + 5
+	cfhd_u4 raw[2][2];                                    // luma lanes: the 32 bytes of the next two picture rows, in flight
+};
+
+// Fetch of the lane's 32 bytes of picture rows y, y + 1 (luma lanes); rows below the picture read as 0x80 (encoder.c:2442-2478).
+__device__ __forceinline__ void strip_fwd_fetch(FwdStrip &st, const FwdYuvJob &job, const uint8_t *in, int y)
+{
+#pragma unroll
+	for (int k = 0; k < 2; k++) {
+		if (y + k < job.display_height) { const uint8_t *p = in + (size_t)(y + k) * job.in_pitch; st.raw[k][0] = CFHD_LDG128(p); st.raw[k][1] = CFHD_LDG128(p + 16); }
+		else { cfhd_u4 g; g.x = g.y = g.z = g.w = 0x80808080u; st.raw[k][0] = g; st.raw[k][1] = g; }
+	}
+}
+
+// Pushes picture rows y, y + 1 into window slots SLOT, SLOT + 1: the luma lanes take them from st.raw (and start the fetch of rows
+// y + 2, y + 3 when `prefetch`), leave the chroma sample pairs in LDS; the chroma lanes pick theirs up behind the barrier.
+template <int SLOT>
+__device__ __forceinline__ void strip_fwd_push(FwdStrip &st, const FwdYuvJob &job, const uint8_t *in, uint32_t (*buf)[2][SFPLANE], int y, bool prefetch,
+                                               bool luma, int comp, int blk, int lane, bool stores, bool first, bool last, int shift, int ysh0, uint32_t usel, uint32_t vsel)
+{
+	uint32_t p[2][8];
+	if (luma) {
+		uint32_t a[2][8];
+#pragma unroll
+		for (int k = 0; k < 2; k++) {
+			a[k][0] = st.raw[k][0].x; a[k][1] = st.raw[k][0].y; a[k][2] = st.raw[k][0].z; a[k][3] = st.raw[k][0].w;
+			a[k][4] = st.raw[k][1].x; a[k][5] = st.raw[k][1].y; a[k][6] = st.raw[k][1].z; a[k][7] = st.raw[k][1].w;
+		}
+		if (prefetch) strip_fwd_fetch(st, job, in, y + 2);       // the next pair's loads go out before this pair's arithmetic
+#pragma unroll
+		for (int k = 0; k < 2; k++) {
+#pragma unroll
+			for (int i = 0; i < 8; i++) p[k][i] = ((a[k][i] >> ysh0) & 0x00ff00ffu) << shift;
+			if (stores) {
+#pragma unroll
+				for (int i = 0; i < 4; i++) {
+					buf[k][0][4 * blk + i] = byte_perm(a[k][2 * i + 1], a[k][2 * i], vsel) << shift;
+					buf[k][1][4 * blk + i] = byte_perm(a[k][2 * i + 1], a[k][2 * i], usel) << shift;
+				}
+			}
+		}
+	}
+	__syncthreads();
+	if (!luma) {
+#pragma unroll
+		for (int k = 0; k < 2; k++) {
+#pragma unroll
+			for (int i = 0; i < 8; i++) p[k][i] = buf[k][comp - 1][8 * blk + i];
+		}
+	}
+#pragma unroll
+	for (int k = 0; k < 2; k++) {
+		const uint32_t prev = __shfl(p[k][7], lane - 1), next = __shfl(p[k][0], lane + 1);
+		strip_fwd_row(p[k], prev, next, first, last, st.LW[SLOT + k], st.HW[SLOT + k]);
+	}
+}
+
+template <int ROWS_PER_STRIP>
+__device__ __forceinline__ void fwd_yuv422_strip(const FwdYuvJob *jobs)
+{
+	const TileId tile = xcd_tile();
+	__shared__ FwdYuvJob s_job;
+	stage_job(&s_job, &jobs[tile.z]);
+	const FwdYuvJob &job = s_job;
+	__shared__ uint32_t s_pairs[2][2][2][SFPLANE];        // [buffer][row of the pair][V, U][chroma sample pairs of the row]
+	const int W = job.width, H = job.height, HH = H >> 1;
+	const int r0 = tile.y * ROWS_PER_STRIP;
+	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+	const bool luma = wave < 2;
+	const int comp = luma ? 0 : wave - 1;                 // 0 Y, 1 V, 2 U
+	const QuantParam q_lh = job.q[comp][1], q_hl = job.q[comp][2], q_hh = job.q[comp][3];
+	const int nblk = luma ? W / 16 : W / 32;              // blocks of 8 band columns
+	const int want = luma ? lane + SLUMA_STEP * wave : lane;
+	const int blk = want < nblk ? want : nblk - 1;
+	const bool stores = want < nblk && (!luma || (wave == 0 ? lane < SLUMA_STEP + 1 : lane > 0));
+	const bool first = blk == 0, last = blk == nblk - 1;
+	if (r0 >= HH) return;
+	const int r1 = r0 + ROWS_PER_STRIP < HH ? r0 + ROWS_PER_STRIP : HH;
+	const int shift = job.shift;
+	const int ysh0 = job.uyvy ? 8 : 0, ub = job.uyvy ? 0 : 1, vb = job.uyvy ? 2 : 3;       // byte lanes of Y0, U, V in a pixel-pair dword
+	const uint32_t usel = (uint32_t)ub | 0x0c00u | ((uint32_t)(4 + ub) << 16) | 0x0c000000u;   // (byte ub of a0, 0, byte ub of a1, 0)
+	const uint32_t vsel = (uint32_t)vb | 0x0c00u | ((uint32_t)(4 + vb) << 16) | 0x0c000000u;
+	const uint8_t *in = job.in + 32 * (size_t)blk;
+	FwdStrip st;
+	int wtop = window_first_row(r0, HH, H);
+	const int lastrow = window_first_row(r1 - 1, HH, H) + 5;     // last picture row this strip reads
+	int t = 0;                                            // row pairs pushed so far (selects the LDS buffer)
+#define CFHD_PUSH(SLOT, Y) strip_fwd_push<SLOT>(st, job, in, s_pairs[t & 1], (Y), (Y) + 2 <= lastrow, luma, comp, blk, lane, stores, first, last, shift, ysh0, usel, vsel); t++
+	if (luma) strip_fwd_fetch(st, job, in, wtop);
+	CFHD_PUSH(0, wtop); CFHD_PUSH(2, wtop + 2); CFHD_PUSH(4, wtop + 4);
+	for (int r = r0; r < r1; r++) {
+		const int need = window_first_row(r, HH, H);
+		if (need != wtop) {                               // the window moves down by two picture rows
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+#pragma unroll
+				for (int d = 0; d < 4; d++) { st.LW[k][d] = st.LW[k + 2][d]; st.HW[k][d] = st.HW[k + 2][d]; }
+			}
+			wtop = need;
+			CFHD_PUSH(4, wtop + 4);
+		}
+		// vertical analysis + quantizer of band row r
+		const int pos = r == 0 ? 0 : (r == HH - 1 ? 2 : 1);
+		uint32_t o[4][4];
+#pragma unroll
+		for (int d = 0; d < 4; d++) {
+			uint32_t ll, lh, hl, hh;
+			if (pos == 1) {
+				ll = pk_adds(st.LW[2][d], st.LW[3][d]); hl = pk_hp_mid(st.LW[0][d], st.LW[1][d], st.LW[2][d], st.LW[3][d], st.LW[4][d], st.LW[5][d]);
+				lh = pk_adds(st.HW[2][d], st.HW[3][d]); hh = pk_hp_mid(st.HW[0][d], st.HW[1][d], st.HW[2][d], st.HW[3][d], st.HW[4][d], st.HW[5][d]);
+			} else {
+				int res[4][2];
+#pragma unroll
+				for (int e = 0; e < 2; e++) {
+					int a[6], b[6];
+#pragma unroll
+					for (int k = 0; k < 6; k++) { a[k] = e ? hi16(st.LW[k][d]) : lo16(st.LW[k][d]); b[k] = e ? hi16(st.HW[k][d]) : lo16(st.HW[k][d]); }
+					if (pos == 0) {
+						res[0][e] = sat16(a[0] + a[1]); res[2][e] = hp_first(a[0], a[1], a[2], a[3], a[4], a[5]);
+						res[1][e] = sat16(b[0] + b[1]); res[3][e] = hp_first(b[0], b[1], b[2], b[3], b[4], b[5]);
+					} else {
+						res[0][e] = sat16(a[4] + a[5]); res[2][e] = hp_last(a[0], a[1], a[2], a[3], a[4], a[5]);
+						res[1][e] = sat16(b[4] + b[5]); res[3][e] = hp_last(b[0], b[1], b[2], b[3], b[4], b[5]);
+					}
+				}
+				ll = pack16(res[0][0], res[0][1]); lh = pack16(res[1][0], res[1][1]); hl = pack16(res[2][0], res[2][1]); hh = pack16(res[3][0], res[3][1]);
+			}
+			o[0][d] = ll; o[1][d] = pk_quantize(lh, q_lh);                              // the lowpass band is never quantized (quantize.c:3216)
+			o[2][d] = pk_quantize(hl, q_hl); o[3][d] = pk_quantize(hh, q_hh);
+		}
+		if (stores) {
+#pragma unroll
+			for (int b = 0; b < 4; b++) {
+				uint4 v; v.x = o[b][0]; v.y = o[b][1]; v.z = o[b][2]; v.w = o[b][3];
+				*(uint4 *)(job.out[comp][b] + (size_t)r * job.out_pitch[comp] + SBLK * blk) = v;
+			}
+		}
+	}
+#undef CFHD_PUSH
+}
+__global__ void __launch_bounds__(NTHREADS) k_fwd_yuv422_strip(const FwdYuvJob *jobs) { fwd_yuv422_strip<SRF>(jobs); }
 
 // =============================================================================================
 // Interlaced level 1 ("frame" wavelet), packed 8-bit 4:2:2 source.  Codec/wavelet.c:6076 TransformForwardFrameYUV: the two rows of

@@ -101,6 +101,18 @@ void emu_fwd_yuv422(const uint8_t *in, int in_pitch, int width, int height, int 
 	hipemu::launch(grid, dim3(NTHREADS), [&] { k_fwd_yuv422(&job); });
 }
 
+int emu_fwd_yuv422_strip(const uint8_t *in, int in_pitch, int width, int height, int display_height, int uyvy, int shift,
+                         const int *quant /*[3][4]*/, int mpq, int16_t **out /*[3][4]*/, const int *out_pitch)
+{
+	if (width % 32 || width / 16 > SMAX_LUMA_BLOCKS) return -1;
+	FwdYuvJob job;
+	job.in = in; job.in_pitch = in_pitch; job.width = width; job.height = height; job.display_height = display_height;
+	job.uyvy = uyvy; job.shift = shift;
+	for (int c = 0; c < 3; c++) { job.out_pitch[c] = out_pitch[c]; for (int b = 0; b < 4; b++) { job.out[c][b] = out[c * 4 + b]; job.q[c][b] = make_q(quant[c * 4 + b], mpq); } }
+	hipemu::launch(dim3(1, (height / 2 + SRF - 1) / SRF, 1), dim3(NTHREADS), [&] { k_fwd_yuv422_strip(&job); });
+	return 0;
+}
+
 void emu_inv_plane(const int16_t *ll, const int16_t *lh, const int16_t *hl, const int16_t *hh, int band_pitch, int w, int h, int descale,
                    int16_t *out, int out_pitch)
 {

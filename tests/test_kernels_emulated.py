@@ -54,6 +54,38 @@ def test_fwd_yuv422(w, h, dh, uyvy):
             assert np.array_equal(outs_e[ch][k][:, :outs_o[ch][k].shape[1]], outs_o[ch][k]), (ch, k)
 
 
+@pytest.mark.parametrize("w,h,dh", [(32, 8, 8), (64, 16, 13), (192, 40, 34), (960, 72, 72), (2048, 8, 8), (2016, 16, 16)])
+@pytest.mark.parametrize("uyvy", [0, 1])
+def test_fwd_yuv422_strip_kernel(w, h, dh, uyvy):
+    """k_fwd_yuv422_strip (register windows + lane exchange, 16-byte accesses) = oracle, incl. full-range samples, strips that start
+    inside the picture (h > 32), rows below the display height and the widest frame it serves (2016)."""
+    rng = np.random.default_rng(w + 7 * h + uyvy)
+    frame = rng.integers(0, 256, size=(dh, w * 2), dtype=np.int64).astype(np.uint8)
+    frame[: dh // 2, : w] = rng.choice([0, 255], size=(dh // 2, w))
+    padded = np.full((h, w * 2), 128, np.uint8); padded[:dh] = frame
+    quant = [1, 24, 24, 36, 1, 24, 24, 48, 1, 3, 1, 48]
+    outs_e, outs_o, pitches = [], [], []
+    for ch in range(3):
+        cw = (w if ch == 0 else w // 2) // 2
+        pitches.append((cw + 7) // 8 * 8 + (8 if ch == 2 else 0))
+        outs_e.append([np.full((h // 2, pitches[-1]), 77, np.int16) for _ in range(4)])
+        outs_o.append([np.zeros((h // 2, cw), np.int16) for _ in range(4)])
+    E = emu()
+    ptrs = (c_i16p * 12)(*[p16(a) for ch in range(3) for a in outs_e[ch]])
+    rc = E.emu_fwd_yuv422_strip(p8(frame), w * 2, w, h, dh, uyvy, 2, iarr(quant), 2, ptrs, iarr(pitches))
+    if w > 2016:
+        assert rc == -1
+        return
+    assert rc == 0
+    for ch in range(3):
+        cw = (w if ch == 0 else w // 2) // 2
+        bands = (c_i16p * 4)(*[p16(a) for a in outs_o[ch]])
+        oracle().orc_fwd_spatial_yuv422(p8(padded), w * 2, cw * 2, h, ch, 2, uyvy, iarr(quant[4 * ch:4 * ch + 4]), 2, bands, cw)
+        for k in range(4):
+            assert np.array_equal(outs_e[ch][k][:, :cw], outs_o[ch][k]), (ch, k)
+            assert np.all(outs_e[ch][k][:, cw:] == 77)                       # nothing written beyond the band
+
+
 @pytest.mark.parametrize("w,h", [(8, 4), (45, 17), (64, 8), (120, 135), (130, 20), (66, 33), (129, 18), (64, 16), (200, 35), (3, 3)])
 @pytest.mark.parametrize("descale", [0, 2])
 def test_inv_plane(w, h, descale):

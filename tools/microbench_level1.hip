@@ -1,14 +1,18 @@
-// tools/microbench_inv_yuv422.hip -- development aid (not part of the library, not used by the tests): times k_inv_yuv422 against
+// tools/microbench_level1.hip -- development aid (not part of the library, not used by the tests): times k_inv_yuv422 against
 // stripped variants of itself on a synthetic 1080p batch, to tell which resource bounds it:
 //   tile        the LDS-tiled product kernel k_inv_yuv422
 //   strip       the register-strip product kernel k_inv_yuv422_strip
 //   access      the same dword loads and 8-byte stores, no LDS, no arithmetic  (floor of this access pattern)
 //   wide        16-byte loads of the tile interior, 16-byte stores              (floor of a wide access pattern)
-// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -Icineform-sdk_amd/csrc tools/microbench_inv_yuv422.hip -o gpurun_out/mb_inv
+// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -Icineform-sdk_amd/csrc tools/microbench_level1.hip -o tools/_build/mb_level1
 #include "cfhd_kernels.h"
 #include <stdio.h>
 #include <vector>
 using namespace cfhd::dev;
+__global__ void __launch_bounds__(NTHREADS) mb_inv_strip32(const InvYuvJob *jobs, uint32_t seed) { inv_yuv422_strip<32>(jobs, seed); }
+__global__ void __launch_bounds__(NTHREADS) mb_inv_strip8(const InvYuvJob *jobs, uint32_t seed) { inv_yuv422_strip<8>(jobs, seed); }
+__global__ void __launch_bounds__(NTHREADS) mb_fwd_strip32(const FwdYuvJob *jobs) { fwd_yuv422_strip<32>(jobs); }
+__global__ void __launch_bounds__(NTHREADS) mb_fwd_strip8(const FwdYuvJob *jobs) { fwd_yuv422_strip<8>(jobs); }
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
@@ -135,20 +139,64 @@ int main(int argc, char **argv)
 	const double bytes = (double)(frame_in + frame_out) * n;
 	for (int variant = 0; variant < 4; variant++) {
 
-		const char *name = variant == 0 ? "tile" : variant == 1 ? "access" : variant == 2 ? "wide" : "strip";
+		const char *name = variant == 0 ? "tile" : variant == 1 ? "access" : variant == 2 ? "wide" : variant == 3 ? "strip" : variant == 4 ? "str32" : "str8";
 		float best = 1e9f, sum = 0;
 		for (int r = 0; r < reps + 3; r++) {
 			CK(hipEventRecord(e0, st));
 			if (variant == 0) k_inv_yuv422<<<grid, NTHREADS, 0, st>>>(d_jobs, 1u);
 			else if (variant == 1) mb_access<<<grid, NTHREADS, 0, st>>>(d_jobs);
 			else if (variant == 2) mb_wide<<<grid, NTHREADS, 0, st>>>(d_jobs);
-			else k_inv_yuv422_strip<<<dim3(1, (h + SR - 1) / SR, n), NTHREADS, 0, st>>>(d_jobs, 1u);
+			else if (variant == 3) k_inv_yuv422_strip<<<dim3(1, (h + SR - 1) / SR, n), NTHREADS, 0, st>>>(d_jobs, 1u);
+			else if (variant == 4) mb_inv_strip32<<<dim3(1, (h + 31) / 32, n), NTHREADS, 0, st>>>(d_jobs, 1u);
+			else mb_inv_strip8<<<dim3(1, (h + 7) / 8, n), NTHREADS, 0, st>>>(d_jobs, 1u);
 			CK(hipEventRecord(e1, st));
 			CK(hipStreamSynchronize(st));
 			float ms; CK(hipEventElapsedTime(&ms, e0, e1));
 			if (r >= 3) { sum += ms; if (ms < best) best = ms; }
 		}
 		printf("%-7s frames %d  avg %.3f ms  best %.3f ms  %.0f GB/s (avg)\n", name, n, sum / reps, best, bytes / (sum / reps) * 1e-6);
+	}
+	// ---- forward level 1: k_fwd_yuv422 (LDS tiles) vs k_fwd_yuv422_strip
+	{
+		const int W = 1920, H = 1080;
+		const size_t fbytes = (size_t)W * 2 * H, obytes = 4 * ybytes + 8 * cbytes;
+		uint8_t *d_f; int16_t *d_o; FwdYuvJob *d_fj;
+		CK(hipMalloc(&d_f, fbytes * n)); CK(hipMalloc(&d_o, obytes * n)); CK(hipMalloc(&d_fj, sizeof(FwdYuvJob) * n));
+		{
+			std::vector<uint8_t> host(fbytes);
+			uint32_t s = 777;
+			for (size_t i = 0; i < fbytes; i++) { s = s * 1664525u + 1013904223u; host[i] = (uint8_t)(128 + ((s >> 24) % 9) - 4 + (i / 64) % 50); }
+			for (int i = 0; i < n; i++) CK(hipMemcpy(d_f + fbytes * i, host.data(), fbytes, hipMemcpyHostToDevice));
+		}
+		std::vector<FwdYuvJob> fj(n);
+		const int quant[3][4] = { {1, 36, 24, 24}, {1, 48, 24, 24}, {1, 48, 24, 24} };
+		for (int i = 0; i < n; i++) {
+			FwdYuvJob &j = fj[i];
+			j.in = d_f + fbytes * i; j.in_pitch = W * 2; j.width = W; j.height = 1080 + 0; j.display_height = H; j.uyvy = 0; j.shift = 2;
+			j.height = 1080;
+			uint8_t *p = (uint8_t *)d_o + obytes * i;
+			for (int b = 0; b < 4; b++) { j.out[0][b] = (int16_t *)p; p += ybytes; }
+			for (int c = 1; c < 3; c++) for (int b = 0; b < 4; b++) { j.out[c][b] = (int16_t *)p; p += cbytes; }
+			j.out_pitch[0] = w; j.out_pitch[1] = j.out_pitch[2] = cw;
+			for (int c = 0; c < 3; c++) for (int b = 0; b < 4; b++) { QuantParam q; q.divisor = quant[c][b]; q.mid = q.divisor > 1 ? q.divisor / 2 - 1 : 0; q.mult = q.divisor > 1 ? (65536u / q.divisor) & 0xffffu : 0; j.q[c][b] = q; }
+		}
+		CK(hipMemcpy(d_fj, fj.data(), sizeof(FwdYuvJob) * n, hipMemcpyHostToDevice));
+		const double fb = (double)(fbytes + obytes) * n;
+		for (int variant = 0; variant < 4; variant++) {
+			float best = 1e9f, sum = 0;
+			for (int r = 0; r < reps + 3; r++) {
+				CK(hipEventRecord(e0, st));
+				if (variant == 0) k_fwd_yuv422<<<dim3((W / 2 + TW - 1) / TW, (1080 / 2 + TH - 1) / TH, n), NTHREADS, 0, st>>>(d_fj);
+				else if (variant == 1) k_fwd_yuv422_strip<<<dim3(1, (1080 / 2 + SRF - 1) / SRF, n), NTHREADS, 0, st>>>(d_fj);
+				else if (variant == 2) mb_fwd_strip32<<<dim3(1, (1080 / 2 + 31) / 32, n), NTHREADS, 0, st>>>(d_fj);
+				else mb_fwd_strip8<<<dim3(1, (1080 / 2 + 7) / 8, n), NTHREADS, 0, st>>>(d_fj);
+				CK(hipEventRecord(e1, st));
+				CK(hipStreamSynchronize(st));
+				float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+				if (r >= 3) { sum += ms; if (ms < best) best = ms; }
+			}
+			printf("fwd %-5s frames %d  avg %.3f ms  best %.3f ms  %.0f GB/s (avg)\n", variant == 0 ? "tile" : variant == 1 ? "strip" : variant == 2 ? "str32" : "str8", n, sum / reps, best, fb / (sum / reps) * 1e-6);
+		}
 	}
 	return 0;
 }
