@@ -26,7 +26,12 @@ namespace dev {
 // slower: the per-wave descriptor loads dominate); four waves per
 // workgroup, no workgroup barriers in k_ent_count / k_ent_emit: all exchanges are wave-level (ballot / bpermute / shuffles).
 enum { ENT_THREADS = 256, ENT_LANES = 64, ENT_WAVES = ENT_THREADS / ENT_LANES, ENT_PER_THREAD = 16, ENT_SEG = ENT_LANES * ENT_PER_THREAD,
-       ENT_LDS_WORDS = ENT_SEG, ENT_MAX_HOLES = 40 };
+       ENT_LDS_WORDS = 256, ENT_TOK_CAP = 256, ENT_MAX_HOLES = 40 };
+// ENT_LDS_WORDS: 32-bit words of the per-wave bit window in LDS (a segment of ordinary pictures codes into 10-40 words; beyond the window
+// the code words go to the payload with global atomics).  ENT_TOK_CAP: tokens (nonzero coefficients) of a segment held in LDS at a
+// time (ordinary: ~80 of 1024; a denser segment is worked off in passes).  Both are sized for occupancy, not for the worst case:
+// with worst-case windows (4 KB + 4 KB per wave) LDS capped k_ent_emit at 4 waves per SIMD and the kernel, a chain of dependent
+// lookups, ran latency-bound.
 
 struct EntTables {
 	uint32_t value_code[2048];     // size << 27 | code word, index = value & 0x7ff
@@ -368,7 +373,7 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_layout(const EntFrameJob *f
 __global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(const EntSegJob *seg_jobs, EntBatchGeom geom, int total_segs, const EntSegState *segs, const EntBandState *band_state, const EntTables *tables)
 {
 	__shared__ uint32_t s_words_all[ENT_WAVES][ENT_LDS_WORDS + 2];
-	__shared__ uint32_t s_tok_all[ENT_WAVES][ENT_SEG];   // the segment's tokens, compacted: local raster index << 16 | value (16 bits)
+	__shared__ uint32_t s_tok_all[ENT_WAVES][ENT_TOK_CAP];   // tokens of the current pass, compacted: local raster index << 16 | value (16 bits)
 	const int lane = wave_lane();
 	const int wave = wave_uniform((int)(threadIdx.x >> 6));
 	const int seg = wave_uniform((int)blockIdx.x * ENT_WAVES + wave);
@@ -391,12 +396,6 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(const EntSegJob *seg_j
 #pragma unroll
 	for (int d = 1; d < ENT_LANES; d <<= 1) { const int x = __shfl_up(incl, (unsigned)d); if (lane >= d) incl += x; }
 	const int ntok = __shfl(incl, ENT_LANES - 1);
-	{
-		int at = incl - cnt;
-#pragma unroll
-		for (int k = 0; k < ENT_PER_THREAD; k++)
-			if (v[k]) s_tok[at++] = ((uint32_t)(lane * ENT_PER_THREAD + k) << 16) | (uint32_t)(uint16_t)v[k];
-	}
 	const uint64_t seg_pos = st.bitoff;                  // bit position of the segment inside the band payload
 	const uint32_t first_word = (uint32_t)(seg_pos >> 5), last_word = (uint32_t)((seg_pos + st.bits - 1) >> 5);
 	const uint32_t nwords = last_word - first_word + 1;
@@ -407,11 +406,22 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(const EntSegJob *seg_j
 	//    to the last nonzero of the earlier segments), table lookups back to back, bit position by a wave scan, code words OR-ed
 	//    into the wave's LDS window
 	uint64_t round_pos = seg_pos;
-	for (int t0 = 0; t0 < ntok; t0 += ENT_LANES) {
-		const int t = t0 + lane;
-		const bool have = t < ntok;
-		const uint32_t tok = have ? s_tok[t] : 0u;
-		const uint32_t before = (have && t > 0) ? s_tok[t - 1] : 0u;
+	uint32_t carry_tok = 0;                              // last token of the previous pass
+	for (int lo = 0; lo < ntok; lo += ENT_TOK_CAP) {     // wave-uniform: one pass unless the segment is unusually dense
+		if (lo) { carry_tok = s_tok[ENT_TOK_CAP - 1]; CFHD_WAVE_SYNC(); }
+		{
+			int at = incl - cnt - lo;
+#pragma unroll
+			for (int k = 0; k < ENT_PER_THREAD; k++)
+				if (v[k]) { if ((unsigned)at < (unsigned)ENT_TOK_CAP) s_tok[at] = ((uint32_t)(lane * ENT_PER_THREAD + k) << 16) | (uint32_t)(uint16_t)v[k]; at++; }
+		}
+		CFHD_WAVE_SYNC();
+		const int hi = ntok - lo < ENT_TOK_CAP ? ntok - lo : ENT_TOK_CAP;
+	for (int t0 = 0; t0 < hi; t0 += ENT_LANES) {
+		const int tl = t0 + lane, t = lo + tl;
+		const bool have = tl < hi;
+		const uint32_t tok = have ? s_tok[tl] : 0u;
+		const uint32_t before = (have && t > 0) ? (tl > 0 ? s_tok[tl - 1] : carry_tok) : 0u;
 		const int lp = (int)(tok >> 16);
 		uint32_t run = t > 0 ? (uint32_t)(lp - (int)(before >> 16) - 1) : (uint32_t)(job.first + lp - st.prev_nz - 1);
 		if (!have) run = 0;
@@ -466,6 +476,7 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(const EntSegJob *seg_j
 				pos += size;
 			}
 		}
+	}
 	}
 	CFHD_WAVE_SYNC();
 	if (use_lds) {
