@@ -92,6 +92,31 @@ __device__ __forceinline__ uint32_t atomic_or_u32(uint32_t *p, uint32_t v) { ret
 #define CFHD_WAVE_SYNC() hipemu::wave_sync()
 __device__ __forceinline__ int wave_uniform(int x) { return x; }
 __device__ __forceinline__ int wave_lane() { return (int)hipemu::lane_id(); }
+// inclusive prefix sum over the 64 lanes / value of one lane (uniform index)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x)
+{
+	const int lane = wave_lane();
+	for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, (unsigned)d); if (lane >= d) x += y; }
+	return x;
+}
+__device__ __forceinline__ uint32_t wave_get(uint32_t x, int lane) { return __shfl(x, lane); }
+#else
+// Inclusive prefix sum over the 64 lanes on the DPP data path (no LDS crossbar round trips): Hillis-Steele inside the rows of 16 lanes
+// (row_shr 1, 2, 4, 8; lanes without a source add 0), then lane 15 of every row into rows 1 and 3 (row_bcast:15, row mask 0xa) and
+// lane 31 into rows 2 and 3 (row_bcast:31, row mask 0xc).
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x)
+{
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
+	return x;
+}
+__device__ __forceinline__ uint32_t wave_get(uint32_t x, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)x, lane); }
+#endif
+#if defined(CFHD_HIPEMU)
 #else
 #define CFHD_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 __device__ __forceinline__ int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
@@ -191,6 +216,7 @@ enum { ENT_PEAK_THRESHOLD = 250 };
 __global__ void __launch_bounds__(ENT_THREADS) k_ent_count(const EntSegJob *seg_jobs, EntBatchGeom geom, int total_segs, EntSegState *segs, const EntTables *tables,
                                                             uint32_t *peak_flags)
 {
+	__shared__ uint32_t s_tok_all[ENT_WAVES][ENT_TOK_CAP];   // tokens of the current pass: local raster index << 16 | value (16 bits)
 	const int lane = wave_lane();
 	const int seg = wave_uniform((int)blockIdx.x * ENT_WAVES + (int)(threadIdx.x >> 6));
 	if (seg >= total_segs) return;                       // whole wave
@@ -210,23 +236,41 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_count(const EntSegJob *seg_
 		if (__ballot(peak) && lane == 0) atomic_or_u32(&peak_flags[frame], 1u);
 	}
 	const unsigned long long mask = __ballot(my_last >= 0);
-	int prev = wave_prev_nonzero(my_last, lane, mask);
-	// zero run in front of every nonzero coefficient (registers only), then all table lookups back to back (no branch in
-	// between: the loads overlap instead of one round trip per token), then the sum
-	uint32_t run[ENT_PER_THREAD];
+	// The picture is sparse (about one coefficient in twelve is nonzero): looking up all 16 x 64 coefficients kept the CU's
+	// texture-address path busy with gathers for zeros (32 gather instructions per wave: the kernel was bound by them, not by
+	// bytes).  The nonzero coefficients are compacted into a token list in LDS first -- as k_ent_emit does -- and the lookups
+	// run over the list, one token per lane and round.
+	uint32_t *s_tok = s_tok_all[wave_uniform((int)(threadIdx.x >> 6))];
+	int cnt = 0;
 #pragma unroll
-	for (int k = 0; k < ENT_PER_THREAD; k++) {
-		run[k] = 0;
-		if (v[k]) { if (prev >= 0) run[k] = (uint32_t)(base + k - prev - 1); prev = base + k; }   // inside the segment: < 1024
+	for (int k = 0; k < ENT_PER_THREAD; k++) cnt += v[k] != 0;
+	const int incl = (int)wave_incl_scan((uint32_t)cnt);
+	const int ntok = (int)wave_get((uint32_t)incl, ENT_LANES - 1);
+	uint32_t bits = 0, carry_tok = 0;
+	for (int lo = 0; lo < ntok; lo += ENT_TOK_CAP) {     // wave-uniform: one pass unless the segment is unusually dense
+		if (lo) { carry_tok = s_tok[ENT_TOK_CAP - 1]; CFHD_WAVE_SYNC(); }
+		{
+			int at = incl - cnt - lo;
+#pragma unroll
+			for (int k = 0; k < ENT_PER_THREAD; k++)
+				if (v[k]) { if ((unsigned)at < (unsigned)ENT_TOK_CAP) s_tok[at] = ((uint32_t)(lane * ENT_PER_THREAD + k) << 16) | (uint32_t)(uint16_t)v[k]; at++; }
+		}
+		CFHD_WAVE_SYNC();
+		const int hi = ntok - lo < ENT_TOK_CAP ? ntok - lo : ENT_TOK_CAP;
+		for (int t0 = 0; t0 < hi; t0 += ENT_LANES) {
+			const int tl = t0 + lane, t = lo + tl;
+			const bool have = tl < hi;
+			const uint32_t tok = have ? s_tok[tl] : 0u;
+			const uint32_t before = (have && t > 0) ? (tl > 0 ? s_tok[tl - 1] : carry_tok) : 0u;
+			// zero run in front of the token, inside the segment (< 1024); the run in front of the segment's first token reaches into
+			// the earlier segments and is added by k_ent_scan
+			const uint32_t run = (have && t > 0) ? (tok >> 16) - (before >> 16) - 1u : 0u;
+			const uint32_t ve = value_entry(T, (int)(int16_t)(tok & 0xffffu));
+			const uint32_t rt = T->run_total[run];
+			if (have) bits += rt + (ve >> 27);
+		}
 	}
-	uint32_t ve[ENT_PER_THREAD], rt[ENT_PER_THREAD];
-#pragma unroll
-	for (int k = 0; k < ENT_PER_THREAD; k++) { ve[k] = value_entry(T, v[k]); rt[k] = T->run_total[run[k]]; }
-	uint32_t bits = 0;
-#pragma unroll
-	for (int k = 0; k < ENT_PER_THREAD; k++) if (v[k]) bits += rt[k] + (ve[k] >> 27);
-#pragma unroll
-	for (int m = 32; m > 0; m >>= 1) bits += __shfl_xor(bits, m);
+	bits = wave_get(wave_incl_scan(bits), ENT_LANES - 1);
 	const int first_nz = __shfl(my_first, mask ? __builtin_ctzll(mask) : 0), last_nz = __shfl(my_last, mask ? 63 - __builtin_clzll(mask) : 0);
 	if (lane == 0) {
 		EntSegState &s = segs[seg];
@@ -392,10 +436,8 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(const EntSegJob *seg_j
 	int cnt = 0;
 #pragma unroll
 	for (int k = 0; k < ENT_PER_THREAD; k++) cnt += v[k] != 0;
-	int incl = cnt;
-#pragma unroll
-	for (int d = 1; d < ENT_LANES; d <<= 1) { const int x = __shfl_up(incl, (unsigned)d); if (lane >= d) incl += x; }
-	const int ntok = __shfl(incl, ENT_LANES - 1);
+	const int incl = (int)wave_incl_scan((uint32_t)cnt);
+	const int ntok = (int)wave_get((uint32_t)incl, ENT_LANES - 1);
 	const uint64_t seg_pos = st.bitoff;                  // bit position of the segment inside the band payload
 	const uint32_t first_word = (uint32_t)(seg_pos >> 5), last_word = (uint32_t)((seg_pos + st.bits - 1) >> 5);
 	const uint32_t nwords = last_word - first_word + 1;
@@ -431,11 +473,9 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(const EntSegJob *seg_j
 		uint2 rc = T->run_pack[r];
 		uint32_t bits = 0;
 		if (have) bits = (run < 3072u ? rt : run_bits_any(T, run)) + (ve >> 27);
-		uint32_t sc = bits;
-#pragma unroll
-		for (int d = 1; d < ENT_LANES; d <<= 1) { const uint32_t x = __shfl_up(sc, (unsigned)d); if (lane >= d) sc += x; }
+		const uint32_t sc = wave_incl_scan(bits);
 		uint64_t pos = round_pos + (sc - bits);
-		round_pos += __shfl(sc, ENT_LANES - 1);
+		round_pos += wave_get(sc, ENT_LANES - 1);
 		// A run of 3072 zeros or more (the first token behind a flat stretch: up to the whole band) starts with nrep copies of the
 		// longest composite code (greedy loop, encoder.c:5488-5545).  One lane writing hundreds of them one after the other held
 		// its wave for > 100 us: the wave writes them together, 64 copies per step, and the lane goes on with the remainder.
