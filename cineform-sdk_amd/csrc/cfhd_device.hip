@@ -280,6 +280,32 @@ int EncodeBatch::set_device_frame(int i, const void *d_frame, int pitch)
 	return 0;
 }
 
+// Levels 2 and 3 in the register-strip kernels: one launch per run of equally wide channels (luma | both chroma planes of 4:2:2 | all planes
+// of 4:4:4 / Bayer).  false: some channel's geometry is outside what the strip kernels serve (or CFHD_AMD_PLANES=tile) -> tiled kernel.
+static bool planes_as_strips(const FramePlan &plan, int lv /* wavelet index whose bands are produced / consumed */)
+{
+	static const bool forced_tile = [] { const char *e = getenv("CFHD_AMD_PLANES"); return e && strcmp(e, "tile") == 0; }();
+	if (forced_tile) return false;
+	for (int c = 0; c < plan.num_channels; c++) {
+		const BandDesc &b = plan.ch[c].band[lv][0];
+		if (b.width % dev::SBLK || b.width / dev::SBLK > 64 || plan.ch[c].band[lv - 1][0].width != 2 * b.width || plan.ch[c].band[lv - 1][0].height != 2 * b.height ||
+		    (plan.ch[c].band[lv - 1][0].pitch & 7) || (b.pitch & 7)) return false;
+	}
+	return true;
+}
+template <typename F> static void for_channel_runs(const FramePlan &plan, int lv, F f)
+{
+	for (int c0 = 0; c0 < plan.num_channels;) {
+		int nc = 1;
+		while (c0 + nc < plan.num_channels && plan.ch[c0 + nc].band[lv][0].width == plan.ch[c0].band[lv][0].width &&
+		       plan.ch[c0 + nc].band[lv][0].height == plan.ch[c0].band[lv][0].height) nc++;
+		const BandDesc &b = plan.ch[c0].band[lv][0];
+		int glog = 0; while ((1 << glog) < b.width / dev::SBLK) glog++;
+		f(c0, nc, glog, b);
+		c0 += nc;
+	}
+}
+
 // k_fwd_yuv422_strip serves progressive 4:2:2 frames of whole 32-pixel blocks up to 2016 pixels wide whose rows are 16-byte aligned;
 // everything else (and CFHD_AMD_FORWARD=tile, for A/B runs) takes the LDS-tiled k_fwd_yuv422.  Both produce the same coefficients.
 bool EncodeBatch::strip_forward() const
@@ -321,8 +347,17 @@ int EncodeBatch::launch_forward()
 	for (int lv = 1; lv < 3; lv++) {
 		HIPCHK(hipEventRecord((hipEvent_t)evl_[lv - 1], st));
 		const BandDesc &src = plan_.ch[0].band[lv - 1][0];     // luma is the widest plane of the level
+		const dev::FwdPlaneJob *jobs = lv == 1 ? j.l2 : j.l3;
+		if (planes_as_strips(plan_, lv)) {
+			const int n = n_;
+			for_channel_runs(plan_, lv, [&](int c0, int nc, int glog, const BandDesc &b) {
+				const int nstrips = (b.height + dev::SRP - 1) / dev::SRP, per_wave = 64 >> glog, waves = ((n * nc + per_wave - 1) / per_wave) * nstrips;
+				dev::k_fwd_plane_strip<<<(waves + 3) / 4, dev::NTHREADS, 0, st>>>(jobs, n, nch, c0, nc, glog, nstrips, 2 * b.width, 2 * b.height);
+			});
+			continue;
+		}
 		dim3 grid((src.width / 2 + dev::TW - 1) / dev::TW, (src.height / 2 + dev::TH - 1) / dev::TH, n_ * nch);
-		dev::k_fwd_plane<<<grid, dev::NTHREADS, 0, st>>>(lv == 1 ? j.l2 : j.l3);
+		dev::k_fwd_plane<<<grid, dev::NTHREADS, 0, st>>>(jobs);
 	}
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord((hipEvent_t)ev1_, st));
@@ -503,8 +538,18 @@ int DecodeBatch::launch_inverse(uint32_t dither_seed)
 	HIPCHK(hipEventRecord((hipEvent_t)ev0_, st));
 	for (int lv = 2; lv >= 1; lv--) {
 		const BandDesc &b = plan_.ch[0].band[lv][0];
+		const dev::InvPlaneJob *jobs = lv == 2 ? j.l3 : j.l2;
+		if (planes_as_strips(plan_, lv)) {
+			const int n = n_;
+			for_channel_runs(plan_, lv, [&](int c0, int nc, int glog, const BandDesc &cb) {
+				const int nstrips = (cb.height + dev::SRP - 1) / dev::SRP, per_wave = 64 >> glog, waves = ((n * nc + per_wave - 1) / per_wave) * nstrips;
+				dev::k_inv_plane_strip<<<(waves + 3) / 4, dev::NTHREADS, 0, st>>>(jobs, n, nch, c0, nc, glog, nstrips, cb.width, cb.height);
+			});
+			HIPCHK(hipEventRecord((hipEvent_t)evl_[2 - lv], st));
+			continue;
+		}
 		dim3 grid((b.width + dev::ITW - 1) / dev::ITW, (b.height + dev::ITH - 1) / dev::ITH, n_ * nch);
-		dev::k_inv_plane<<<grid, dev::NTHREADS, 0, st>>>(lv == 2 ? j.l3 : j.l2);
+		dev::k_inv_plane<<<grid, dev::NTHREADS, 0, st>>>(jobs);
 		HIPCHK(hipEventRecord((hipEvent_t)evl_[2 - lv], st));
 	}
 	if (is_packed16(out_kind_)) {

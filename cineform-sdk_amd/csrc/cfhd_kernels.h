@@ -1028,11 +1028,11 @@ __global__ void __launch_bounds__(NTHREADS) k_inv_yuv422_strip(const InvYuvJob *
 enum { SRF = 32, SFPLANE = 512 };                       // band rows per strip; chroma pairs per picture row (dwords) the LDS buffer holds per channel
 
 // Horizontal analysis of one picture row of a block: p = its 8 sample pairs, prev / next = the neighbouring pairs.
-__device__ __forceinline__ void strip_fwd_row(const uint32_t (&p)[8], uint32_t prev, uint32_t next, bool first, bool last, uint32_t (&L)[4], uint32_t (&H)[4])
+__device__ __forceinline__ void strip_fwd_row(const uint32_t (&p)[8], uint32_t prev, uint32_t next, bool first, bool last, uint32_t (&L)[4], uint32_t (&H)[4], int prescale = 0)
 {
 	const uint32_t ext[10] = { prev, p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], next };
 #pragma unroll
-	for (int m = 0; m < 4; m++) horiz_pair(&ext[2 * m], 0u, 0, first && m == 0, false, last && m == 3, L[m], H[m]);
+	for (int m = 0; m < 4; m++) horiz_pair(&ext[2 * m], 0u, prescale, first && m == 0, false, last && m == 3, L[m], H[m]);
 }
 
 // Per-lane state of k_fwd_yuv422_strip.
@@ -1178,6 +1178,201 @@ __device__ __forceinline__ void fwd_yuv422_strip(const FwdYuvJob *jobs)
 #undef CFHD_PUSH
 }
 __global__ void __launch_bounds__(NTHREADS) k_fwd_yuv422_strip(const FwdYuvJob *jobs) { fwd_yuv422_strip<SRF>(jobs); }
+
+// =============================================================================================
+// k_inv_plane_strip / k_fwd_plane_strip: levels 2 and 3 (int16 planes on both sides) in the register-strip organisation.  These planes
+// are narrow (1080p: 60 / 30 / 15 blocks of 8 band columns), so a wave carries 64 >> glog planes side by side, 1 << glog lanes each
+// (the same strip of consecutive jobs: geometry and row position are wave-uniform), and needs neither LDS nor barriers: the neighbour
+// columns come from the adjacent lanes, and the lanes at the edges of a group sit on the band borders, whose taps do not look outside.
+// One launch per group of equally wide channels (luma | the two chroma planes of 4:2:2 | all planes of 4:4:4).
+// Geometry served: band width a multiple of 8 and at most 512 columns; everything else takes k_inv_plane / k_fwd_plane.
+// =============================================================================================
+enum { SRP = 16 };
+
+struct StripWho { int job; int blk; bool stores; int strip; };
+// wave -> (strip of rows, group of 64 >> glog consecutive selected jobs); lane -> (job of the group, block of 8 columns)
+__device__ __forceinline__ StripWho strip_who(int nframes, int nch, int c0, int nc, int glog, int nstrips, int nblk, bool *wave_idle)
+{
+	const int lane = threadIdx.x & 63, gwave = (int)blockIdx.x * (NTHREADS / 64) + (int)(threadIdx.x >> 6);
+	const int per_wave = 64 >> glog, sub = lane >> glog, b = lane & ((1 << glog) - 1);
+	const int strip = gwave % nstrips, first_sel = (gwave / nstrips) * per_wave, nsel = nframes * nc;
+	*wave_idle = first_sel >= nsel;
+	int sel = first_sel + sub;
+	const bool job_ok = sel < nsel;
+	if (!job_ok) sel = nsel - 1;
+	StripWho w;
+	w.job = (sel / nc) * nch + c0 + sel % nc;
+	w.stores = job_ok && b < nblk;
+	w.blk = b < nblk ? b : nblk - 1;
+	w.strip = strip;
+	return w;
+}
+
+__global__ void __launch_bounds__(NTHREADS) k_inv_plane_strip(const InvPlaneJob *jobs, int nframes, int nch, int c0, int nc, int glog, int nstrips, int w, int h)
+{
+	const int lane = threadIdx.x & 63;
+	const int nblk = w / SBLK;
+	bool idle;
+	const StripWho who = strip_who(nframes, nch, c0, nc, glog, nstrips, nblk, &idle);
+	if (idle) return;                                     // whole wave
+	const InvPlaneJob *job = &jobs[who.job];
+	const int blk = who.blk, pitch = job->band_pitch, descale = job->descale;
+	const bool first = blk == 0, last = blk == nblk - 1;
+	const int16_t *pLL = job->band[0] + SBLK * blk, *pLH = job->band[1] + SBLK * blk, *pHL = job->band[2] + SBLK * blk, *pHH = job->band[3] + SBLK * blk;
+	int16_t *out = job->out + 2 * SBLK * blk;
+	const int out_pitch = job->out_pitch;
+	const int r0 = who.strip * SRP;
+	const int nrows = h - r0 < SRP ? h - r0 : SRP;
+	int j = inv_window_first_row(r0, h);
+	StripRow ll0 = strip_load(pLL + (size_t)j * pitch), ll1 = strip_load(pLL + (size_t)(j + 1) * pitch), ll2 = strip_load(pLL + (size_t)(j + 2) * pitch);
+	StripRow lh0 = strip_load(pLH + (size_t)j * pitch), lh1 = strip_load(pLH + (size_t)(j + 1) * pitch), lh2 = strip_load(pLH + (size_t)(j + 2) * pitch);
+	StripRow hl = strip_load(pHL + (size_t)r0 * pitch), hh = strip_load(pHH + (size_t)r0 * pitch);
+	for (int s = 0; s < nrows; s++) {
+		const int r = r0 + s;
+		const bool more = s + 1 < nrows;
+		const int jn = more ? inv_window_first_row(r + 1, h) : j;
+		const bool advance = jn != j;
+		StripRow nll = ll2, nlh = lh2, nhl = hl, nhh = hh;
+		if (advance) { nll = strip_load(pLL + (size_t)(jn + 2) * pitch); nlh = strip_load(pLH + (size_t)(jn + 2) * pitch); }
+		if (more) { nhl = strip_load(pHL + (size_t)(r + 1) * pitch); nhh = strip_load(pHH + (size_t)(r + 1) * pitch); }
+		const int pos = r == 0 ? 0 : (r == h - 1 ? 2 : 1);
+		uint32_t Lv[2][4], Hv[2][4];
+#pragma unroll
+		for (int d = 0; d < 4; d++) {
+			inv_vert_pk(ll0.d[d], ll1.d[d], ll2.d[d], hl.d[d], pos, Lv[0][d], Lv[1][d]);
+			inv_vert_pk(lh0.d[d], lh1.d[d], lh2.d[d], hh.d[d], pos, Hv[0][d], Hv[1][d]);
+		}
+#pragma unroll
+		for (int par = 0; par < 2; par++) {
+			const uint32_t (&L)[4] = Lv[par];
+			const uint32_t (&H)[4] = Hv[par];
+			const uint32_t prev = __shfl(L[3], lane - 1), next = __shfl(L[0], lane + 1);
+			const uint32_t ext[6] = { prev, L[0], L[1], L[2], L[3], next };
+			uint32_t o[8];
+#pragma unroll
+			for (int d = 0; d < 4; d++) {
+				const uint32_t dm = ext[d], d0 = ext[d + 1], dp = ext[d + 2];
+				uint32_t even, odd;
+				inv_horiz_pk((dm >> 16) | (d0 << 16), d0, (d0 >> 16) | (dp << 16), H[d], even, odd);
+				if (descale) { even = pk_adds(even, even); odd = pk_adds(odd, odd); }
+				else { even = pk_sra(even, 1); odd = pk_sra(odd, 1); }
+				o[2 * d] = pk_lolo(even, odd); o[2 * d + 1] = pk_hihi(even, odd);      // (even, odd) of column 2d and of column 2d + 1
+			}
+			if (first) {
+				const int l[6] = { 0, 0, lo16(L[0]), hi16(L[0]), lo16(L[1]), hi16(L[1]) };
+				int e, od;
+				inv_horiz_border(l, 2, lo16(H[0]), 0, e, od);
+				if (descale) { e = sat16(e * 2); od = sat16(od * 2); } else { e = sat16(e >> 1); od = sat16(od >> 1); }
+				o[0] = pack16(e, od);
+			}
+			if (last) {
+				const int l[6] = { lo16(L[2]), hi16(L[2]), lo16(L[3]), hi16(L[3]), 0, 0 };
+				int e, od;
+				inv_horiz_border(l, 3, hi16(H[3]), 2, e, od);
+				if (descale) { e = sat16(e * 2); od = sat16(od * 2); } else { e = sat16(e >> 1); od = sat16(od >> 1); }
+				o[7] = pack16(e, od);
+			}
+			if (who.stores) {
+				uint4 *dst = (uint4 *)(out + (size_t)(2 * r + par) * out_pitch);
+				uint4 q0, q1;
+				q0.x = o[0]; q0.y = o[1]; q0.z = o[2]; q0.w = o[3]; q1.x = o[4]; q1.y = o[5]; q1.z = o[6]; q1.w = o[7];
+				dst[0] = q0; dst[1] = q1;
+			}
+		}
+		if (advance) { ll0 = ll1; ll1 = ll2; ll2 = nll; lh0 = lh1; lh1 = lh2; lh2 = nlh; j = jn; }
+		hl = nhl; hh = nhh;
+	}
+}
+
+// Vertical 2/6 analysis + quantizer of one band row from the six-row window (shared by the strip kernels).
+__device__ __forceinline__ void strip_fwd_emit(const uint32_t (&LW)[6][4], const uint32_t (&HW)[6][4], int pos, const QuantParam &q_lh, const QuantParam &q_hl, const QuantParam &q_hh,
+                                               uint32_t (&o)[4][4])
+{
+#pragma unroll
+	for (int d = 0; d < 4; d++) {
+		uint32_t ll, lh, hl, hh;
+		if (pos == 1) {
+			ll = pk_adds(LW[2][d], LW[3][d]); hl = pk_hp_mid(LW[0][d], LW[1][d], LW[2][d], LW[3][d], LW[4][d], LW[5][d]);
+			lh = pk_adds(HW[2][d], HW[3][d]); hh = pk_hp_mid(HW[0][d], HW[1][d], HW[2][d], HW[3][d], HW[4][d], HW[5][d]);
+		} else {
+			int res[4][2];
+#pragma unroll
+			for (int e = 0; e < 2; e++) {
+				int a[6], b[6];
+#pragma unroll
+				for (int k = 0; k < 6; k++) { a[k] = e ? hi16(LW[k][d]) : lo16(LW[k][d]); b[k] = e ? hi16(HW[k][d]) : lo16(HW[k][d]); }
+				if (pos == 0) {
+					res[0][e] = sat16(a[0] + a[1]); res[2][e] = hp_first(a[0], a[1], a[2], a[3], a[4], a[5]);
+					res[1][e] = sat16(b[0] + b[1]); res[3][e] = hp_first(b[0], b[1], b[2], b[3], b[4], b[5]);
+				} else {
+					res[0][e] = sat16(a[4] + a[5]); res[2][e] = hp_last(a[0], a[1], a[2], a[3], a[4], a[5]);
+					res[1][e] = sat16(b[4] + b[5]); res[3][e] = hp_last(b[0], b[1], b[2], b[3], b[4], b[5]);
+				}
+			}
+			ll = pack16(res[0][0], res[0][1]); lh = pack16(res[1][0], res[1][1]); hl = pack16(res[2][0], res[2][1]); hh = pack16(res[3][0], res[3][1]);
+		}
+		o[0][d] = ll; o[1][d] = pk_quantize(lh, q_lh);                                    // the lowpass band is never quantized (quantize.c:3216)
+		o[2][d] = pk_quantize(hl, q_hl); o[3][d] = pk_quantize(hh, q_hh);
+	}
+}
+
+// Two rows of an int16 plane -> window slots SLOT, SLOT + 1 (k_fwd_plane_strip).
+template <int SLOT>
+__device__ __forceinline__ void strip_plane_push(uint32_t (&LW)[6][4], uint32_t (&HW)[6][4], const int16_t *in, int pitch, int y, int prescale, int lane, bool first, bool last)
+{
+	cfhd_u4 raw[2][2];
+#pragma unroll
+	for (int k = 0; k < 2; k++) { const int16_t *p = in + (size_t)(y + k) * pitch; raw[k][0] = CFHD_LDG128(p); raw[k][1] = CFHD_LDG128(p + 8); }
+#pragma unroll
+	for (int k = 0; k < 2; k++) {
+		const uint32_t p[8] = { raw[k][0].x, raw[k][0].y, raw[k][0].z, raw[k][0].w, raw[k][1].x, raw[k][1].y, raw[k][1].z, raw[k][1].w };
+		const uint32_t prev = __shfl(p[7], lane - 1), next = __shfl(p[0], lane + 1);
+		strip_fwd_row(p, prev, next, first, last, LW[SLOT + k], HW[SLOT + k], prescale);
+	}
+}
+
+__global__ void __launch_bounds__(NTHREADS) k_fwd_plane_strip(const FwdPlaneJob *jobs, int nframes, int nch, int c0, int nc, int glog, int nstrips, int W, int H)
+{
+	const int lane = threadIdx.x & 63;
+	const int nblk = W / (2 * SBLK), HH = H >> 1;
+	bool idle;
+	const StripWho who = strip_who(nframes, nch, c0, nc, glog, nstrips, nblk, &idle);
+	if (idle) return;                                     // whole wave
+	const FwdPlaneJob *job = &jobs[who.job];
+	const int blk = who.blk, pitch = job->in_pitch, prescale = job->prescale, out_pitch = job->out_pitch;
+	const bool first = blk == 0, last = blk == nblk - 1;
+	const int16_t *in = job->in + 2 * SBLK * blk;
+	const QuantParam q_lh = job->q[1], q_hl = job->q[2], q_hh = job->q[3];
+	int16_t *const out0 = job->out[0] + SBLK * blk, *const out1 = job->out[1] + SBLK * blk, *const out2 = job->out[2] + SBLK * blk, *const out3 = job->out[3] + SBLK * blk;
+	const int r0 = who.strip * SRP, r1 = r0 + SRP < HH ? r0 + SRP : HH;
+	uint32_t LW[6][4], HW[6][4];
+	int wtop = window_first_row(r0, HH, H);
+	strip_plane_push<0>(LW, HW, in, pitch, wtop, prescale, lane, first, last);
+	strip_plane_push<2>(LW, HW, in, pitch, wtop + 2, prescale, lane, first, last);
+	strip_plane_push<4>(LW, HW, in, pitch, wtop + 4, prescale, lane, first, last);
+	for (int r = r0; r < r1; r++) {
+		const int need = window_first_row(r, HH, H);
+		if (need != wtop) {
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+#pragma unroll
+				for (int d = 0; d < 4; d++) { LW[k][d] = LW[k + 2][d]; HW[k][d] = HW[k + 2][d]; }
+			}
+			wtop = need;
+			strip_plane_push<4>(LW, HW, in, pitch, wtop + 4, prescale, lane, first, last);
+		}
+		uint32_t o[4][4];
+		strip_fwd_emit(LW, HW, r == 0 ? 0 : (r == HH - 1 ? 2 : 1), q_lh, q_hl, q_hh, o);
+		if (who.stores) {
+			const size_t at = (size_t)r * out_pitch;
+			uint4 v;
+			v.x = o[0][0]; v.y = o[0][1]; v.z = o[0][2]; v.w = o[0][3]; *(uint4 *)(out0 + at) = v;
+			v.x = o[1][0]; v.y = o[1][1]; v.z = o[1][2]; v.w = o[1][3]; *(uint4 *)(out1 + at) = v;
+			v.x = o[2][0]; v.y = o[2][1]; v.z = o[2][2]; v.w = o[2][3]; *(uint4 *)(out2 + at) = v;
+			v.x = o[3][0]; v.y = o[3][1]; v.z = o[3][2]; v.w = o[3][3]; *(uint4 *)(out3 + at) = v;
+		}
+	}
+}
 
 // =============================================================================================
 // Interlaced level 1 ("frame" wavelet), packed 8-bit 4:2:2 source.  Codec/wavelet.c:6076 TransformForwardFrameYUV: the two rows of

@@ -148,6 +148,41 @@ int emu_inv_yuv422_strip(int16_t **bands /*[3][4]*/, const int *band_pitch, int 
 	return 0;
 }
 
+// nplanes planes of the same geometry (plane k: in[k] -> out[4k..4k+3]) through one launch of k_fwd_plane_strip
+int emu_fwd_plane_strip(int16_t **in, int nplanes, int in_pitch, int width, int height, int prescale, const int *quant, int mpq, int16_t **out, int out_pitch)
+{
+	if (width % (2 * SBLK) || width / (2 * SBLK) > 64) return -1;
+	std::vector<FwdPlaneJob> jobs(nplanes);
+	for (int k = 0; k < nplanes; k++) {
+		FwdPlaneJob &job = jobs[k];
+		job.in = in[k]; job.in_pitch = in_pitch; job.width = width; job.height = height; job.prescale = prescale;
+		for (int b = 0; b < 4; b++) { job.out[b] = out[4 * k + b]; job.q[b] = make_q(quant[b], mpq); }
+		job.out_pitch = out_pitch; job.xstride = 1; job.shift = 0; job.display_height = height; job.compand = 0;
+	}
+	int glog = 0; while ((1 << glog) < width / (2 * SBLK)) glog++;
+	const int nstrips = (height / 2 + SRP - 1) / SRP, per_wave = 64 >> glog, waves = ((nplanes + per_wave - 1) / per_wave) * nstrips;
+	hipemu::launch(dim3((waves + 3) / 4), dim3(NTHREADS), [&] { k_fwd_plane_strip(jobs.data(), nplanes, 1, 0, 1, glog, nstrips, width, height); });
+	return 0;
+}
+
+// nplanes independent planes of the same geometry (plane k: bands[4k..4k+3] -> out[k]) through one launch of the strip kernel, as the
+// product batches the channel planes of many frames: the wave packing (64 >> glog planes per wave) is part of what is tested.
+int emu_inv_plane_strip(int16_t **bands, int nplanes, int band_pitch, int w, int h, int descale, int16_t **out, int out_pitch)
+{
+	if (w % SBLK || w / SBLK > 64) return -1;
+	std::vector<InvPlaneJob> jobs(nplanes);
+	for (int k = 0; k < nplanes; k++) {
+		InvPlaneJob &job = jobs[k];
+		for (int b = 0; b < 4; b++) job.band[b] = bands[4 * k + b];
+		job.band_pitch = band_pitch; job.width = w; job.height = h; job.descale = descale; job.out = out[k]; job.out_pitch = out_pitch;
+		job.xstride = 1; job.precision = 0; job.display_height = 2 * h; job.alpha = 0;
+	}
+	int glog = 0; while ((1 << glog) < w / SBLK) glog++;
+	const int nstrips = (h + SRP - 1) / SRP, per_wave = 64 >> glog, waves = ((nplanes + per_wave - 1) / per_wave) * nstrips;
+	hipemu::launch(dim3((waves + 3) / 4), dim3(NTHREADS), [&] { k_inv_plane_strip(jobs.data(), nplanes, 1, 0, 1, glog, nstrips, w, h); });
+	return 0;
+}
+
 } // extern "C"
 
 // ------------------------------------------------------------------------------------------------------------

@@ -101,6 +101,67 @@ def test_inv_plane(w, h, descale):
     assert np.array_equal(e[:, :2 * w], o)
 
 
+@pytest.mark.parametrize("w,h,nplanes", [(16, 8, 9), (64, 16, 5), (240, 134, 3), (480, 66, 3), (960, 40, 2), (1024, 8, 1), (1040, 8, 1)])
+@pytest.mark.parametrize("prescale", [0, 2])
+def test_fwd_plane_strip_kernel(w, h, nplanes, prescale):
+    """k_fwd_plane_strip (levels 2 / 3: several planes per wave, six-row register window, packed quantizer) = oracle, plane by plane."""
+    rng = np.random.default_rng(w * 13 + h + prescale)
+    quant = [1, 24, 12, 36] if prescale == 0 else [1, 6, 6, 3]
+    hw, hh = w // 2, h // 2
+    pitch = (hw + 7) // 8 * 8 + 8
+    ins, want, got = [], [], []
+    for k in range(nplanes):
+        x = np.zeros((h, w + 8), np.int16); x[:, w:] = 1234
+        x[:, :w] = rand_plane(rng, w, h, 12 if prescale == 0 else 14)
+        if k == 1 and prescale == 0: x[:, :w] = rng.choice(np.array([-32768, 32767, 0], np.int16), size=(h, w))       # saturating arithmetic and the quantizer's wrap
+        ins.append(x)
+        o = [np.zeros((hh, hw), np.int16) for _ in range(4)]
+        oracle().orc_fwd_spatial(p16(x), w + 8, w, h, prescale, iarr(quant), 2, (c_i16p * 4)(*[p16(a) for a in o]), hw)
+        want.append(o)
+        got.append([np.full((hh, pitch), 77, np.int16) for _ in range(4)])
+    E = emu()
+    E.emu_fwd_plane_strip.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    rc = E.emu_fwd_plane_strip((c_i16p * nplanes)(*[p16(x) for x in ins]), nplanes, w + 8, w, h, prescale, iarr(quant), 2,
+                               (c_i16p * (4 * nplanes))(*[p16(a) for g in got for a in g]), pitch)
+    if w > 1024:
+        assert rc == -1
+        return
+    assert rc == 0
+    for k in range(nplanes):
+        for b in range(4):
+            assert np.array_equal(got[k][b][:, :hw], want[k][b]), (k, b)
+            assert np.all(got[k][b][:, hw:] == 77)
+
+
+@pytest.mark.parametrize("w,h,nplanes", [(8, 4, 9), (64, 8, 3), (120, 135, 5), (240, 33, 3), (480, 18, 2), (512, 16, 1), (520, 8, 1)])
+@pytest.mark.parametrize("descale", [0, 2])
+def test_inv_plane_strip_kernel(w, h, nplanes, descale):
+    """k_inv_plane_strip (several planes side by side in one wave, neighbours by lane exchange, 16-byte accesses) = oracle, plane by plane."""
+    rng = np.random.default_rng(w * 7 + h + descale)
+    pitch = (w + 7) // 8 * 8 + 8
+    planes, outs, want = [], [], []
+    for k in range(nplanes):
+        b = [rng.integers(-9, 9, size=(h, pitch)).astype(np.int16) for _ in range(4)]               # junk in the pad columns
+        b[0][:, :w] = rand_plane(rng, w, h, 13)
+        for i in range(1, 4): b[i][:, :w] = rand_plane(rng, w, h, 11, signed=True)
+        planes.append(b)
+        outs.append(np.full((2 * h, 2 * pitch), 55, np.int16))
+        o = np.zeros((2 * h, 2 * w), np.int16)
+        oracle().orc_inv_spatial((c_i16p * 4)(*[p16(a) for a in b]), pitch, w, h, descale, p16(o), 2 * w)
+        want.append(o)
+    E = emu()
+    E.emu_inv_plane_strip.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    rc = E.emu_inv_plane_strip((c_i16p * (4 * nplanes))(*[p16(a) for b in planes for a in b]), nplanes, pitch, w, h, descale,
+                               (c_i16p * nplanes)(*[p16(o) for o in outs]), 2 * pitch)
+    if w > 512:
+        assert rc == -1
+        return
+    assert rc == 0
+    for k in range(nplanes):
+        assert np.array_equal(outs[k][:, :2 * w], want[k]), k
+        assert np.all(outs[k][:, 2 * w:] == 55)
+
+
 @pytest.mark.parametrize("w,h,dh", [(32, 8, 16), (96, 20, 40), (360, 30, 58), (128, 17, 34), (132, 33, 66), (64, 16, 32), (260, 19, 37)])
 @pytest.mark.parametrize("uyvy", [0, 1])
 def test_inv_yuv422(w, h, dh, uyvy):
