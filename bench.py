@@ -166,9 +166,13 @@ def main():
         assert L.cfhd_amd_batch_roundtrip(b) > 0, T.amd_last_error()
     barrier()
     t0 = time.perf_counter()
-    KERNELS = [("k_fwd_yuv422", 0), ("k_fwd_plane[L2]", 1), ("k_fwd_plane[L3]", 2), ("k_ent_count", 8), ("k_ent_scan", 9), ("k_ent_layout", 10),
-               ("k_ent_emit", 11), ("k_dec_parse", 12), ("k_dec_bands_par", 13), ("k_dec_lowpass", 14), ("k_inv_plane[L3]", 5), ("k_inv_plane[L2]", 4),
-               ("k_inv_yuv422", 3)]
+    # kernel names as they appear in a rocprofv3 trace of this run: the register-strip kernels serve 1920x1080 unless an A/B switch asks for the tiled ones
+    FWD1 = "k_fwd_yuv422" if os.environ.get("CFHD_AMD_FORWARD") == "tile" else "k_fwd_yuv422_strip"
+    INV1 = "k_inv_yuv422" if os.environ.get("CFHD_AMD_INVERSE") == "tile" else "k_inv_yuv422_strip"
+    PF, PI = ("k_fwd_plane", "k_inv_plane") if os.environ.get("CFHD_AMD_PLANES") == "tile" else ("k_fwd_plane_strip", "k_inv_plane_strip")
+    KERNELS = [(FWD1, 0), (PF + "[L2]", 1), (PF + "[L3]", 2), ("k_ent_count", 8), ("k_ent_scan", 9), ("k_ent_layout", 10),
+               ("k_ent_emit", 11), ("k_dec_parse", 12), ("k_dec_bands_par", 13), ("k_dec_lowpass", 14), (PI + "[L3]", 5), (PI + "[L2]", 4),
+               (INV1, 3)]
     kms = {name: 0.0 for name, _ in KERNELS}; stage = [0.0] * 4; total_bytes = 0
     for _ in range(args.steps):
         n = L.cfhd_amd_batch_roundtrip(b)
@@ -197,17 +201,18 @@ def main():
         # algorithmic bytes per frame of every kernel: samples are 8-bit in the packed frame, 16-bit in the pyramid
         S = W * ((H + 7) // 8 * 8) * 2                   # samples per 4:2:2 frame (luma + both chroma) = packed bytes
         coded = (S - S // 64) * 2                        # bytes of the 27 entropy-coded bands (everything but the three LL3 bands)
-        algo = {"k_fwd_yuv422": S + 2 * S, "k_fwd_plane[L2]": S, "k_fwd_plane[L3]": S // 4,        # 12 441 600 B per 1080p frame
+        algo = {FWD1: S + 2 * S, PF + "[L2]": S, PF + "[L3]": S // 4,                               # 12 441 600 B per 1080p frame
                 "k_ent_count": coded, "k_ent_emit": coded + sample_bytes, "k_dec_bands_par": sample_bytes + coded,
-                "k_inv_plane[L3]": S // 4, "k_inv_plane[L2]": S, "k_inv_yuv422": 2 * S + S}
+                PI + "[L3]": S // 4, PI + "[L2]": S, INV1: 2 * S + S}
         dom = max(algo, key=lambda k: kms[k])            # the dominant kernel = the longest launch of the step
         ms = kms[dom]
         achieved = algo[dom] * args.batch / (ms * 1e-3) / 1e9
         traffic = None
         try:                                             # HBM bytes per launch from the committed PMC passes (profiles/, same batch size), else null
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if pmc.get("frames_per_launch") == args.batch and dom in pmc["kernels"]:
-                traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"]
+            base = dom.split("[")[0]                      # the per-level launches of the plane kernels share one trace name
+            if pmc.get("frames_per_launch") == args.batch and base in pmc["kernels"]:
+                traffic = pmc["kernels"][base]["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
         handoff = os.environ.get("CFHD_AMD_HANDOFF", "device")

@@ -11,6 +11,9 @@
 using namespace cfhd::dev;
 __global__ void __launch_bounds__(NTHREADS) mb_inv_strip32(const InvYuvJob *jobs, uint32_t seed) { inv_yuv422_strip<32>(jobs, seed); }
 __global__ void __launch_bounds__(NTHREADS) mb_inv_strip8(const InvYuvJob *jobs, uint32_t seed) { inv_yuv422_strip<8>(jobs, seed); }
+__global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(5, 5))) mb_inv_strip16_w5(const InvYuvJob *jobs, uint32_t seed) { inv_yuv422_strip<16>(jobs, seed); }
+__global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(5, 5))) mb_inv_strip32_w5(const InvYuvJob *jobs, uint32_t seed) { inv_yuv422_strip<32>(jobs, seed); }
+__global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) mb_fwd_strip32_w4(const FwdYuvJob *jobs) { fwd_yuv422_strip<32>(jobs); }
 __global__ void __launch_bounds__(NTHREADS) mb_fwd_strip32(const FwdYuvJob *jobs) { fwd_yuv422_strip<32>(jobs); }
 __global__ void __launch_bounds__(NTHREADS) mb_fwd_strip8(const FwdYuvJob *jobs) { fwd_yuv422_strip<8>(jobs); }
 
@@ -139,7 +142,7 @@ int main(int argc, char **argv)
 	const double bytes = (double)(frame_in + frame_out) * n;
 	for (int variant = 0; variant < 4; variant++) {
 
-		const char *name = variant == 0 ? "tile" : variant == 1 ? "access" : variant == 2 ? "wide" : variant == 3 ? "strip" : variant == 4 ? "str32" : "str8";
+		const char *name = variant == 0 ? "tile" : variant == 1 ? "access" : variant == 2 ? "wide" : variant == 3 ? "strip" : variant == 4 ? "str32" : variant == 5 ? "str8" : variant == 6 ? "s16w5" : "s32w5";
 		float best = 1e9f, sum = 0;
 		for (int r = 0; r < reps + 3; r++) {
 			CK(hipEventRecord(e0, st));
@@ -148,7 +151,9 @@ int main(int argc, char **argv)
 			else if (variant == 2) mb_wide<<<grid, NTHREADS, 0, st>>>(d_jobs);
 			else if (variant == 3) k_inv_yuv422_strip<<<dim3(1, (h + SR - 1) / SR, n), NTHREADS, 0, st>>>(d_jobs, 1u);
 			else if (variant == 4) mb_inv_strip32<<<dim3(1, (h + 31) / 32, n), NTHREADS, 0, st>>>(d_jobs, 1u);
-			else mb_inv_strip8<<<dim3(1, (h + 7) / 8, n), NTHREADS, 0, st>>>(d_jobs, 1u);
+			else if (variant == 5) mb_inv_strip8<<<dim3(1, (h + 7) / 8, n), NTHREADS, 0, st>>>(d_jobs, 1u);
+			else if (variant == 6) mb_inv_strip16_w5<<<dim3(1, (h + 15) / 16, n), NTHREADS, 0, st>>>(d_jobs, 1u);
+			else mb_inv_strip32_w5<<<dim3(1, (h + 31) / 32, n), NTHREADS, 0, st>>>(d_jobs, 1u);
 			CK(hipEventRecord(e1, st));
 			CK(hipStreamSynchronize(st));
 			float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -182,20 +187,21 @@ int main(int argc, char **argv)
 		}
 		CK(hipMemcpy(d_fj, fj.data(), sizeof(FwdYuvJob) * n, hipMemcpyHostToDevice));
 		const double fb = (double)(fbytes + obytes) * n;
-		for (int variant = 0; variant < 4; variant++) {
+		for (int variant = 0; variant < 5; variant++) {
 			float best = 1e9f, sum = 0;
 			for (int r = 0; r < reps + 3; r++) {
 				CK(hipEventRecord(e0, st));
 				if (variant == 0) k_fwd_yuv422<<<dim3((W / 2 + TW - 1) / TW, (1080 / 2 + TH - 1) / TH, n), NTHREADS, 0, st>>>(d_fj);
 				else if (variant == 1) k_fwd_yuv422_strip<<<dim3(1, (1080 / 2 + SRF - 1) / SRF, n), NTHREADS, 0, st>>>(d_fj);
 				else if (variant == 2) mb_fwd_strip32<<<dim3(1, (1080 / 2 + 31) / 32, n), NTHREADS, 0, st>>>(d_fj);
-				else mb_fwd_strip8<<<dim3(1, (1080 / 2 + 7) / 8, n), NTHREADS, 0, st>>>(d_fj);
+				else if (variant == 3) mb_fwd_strip8<<<dim3(1, (1080 / 2 + 7) / 8, n), NTHREADS, 0, st>>>(d_fj);
+				else mb_fwd_strip32_w4<<<dim3(1, (1080 / 2 + 31) / 32, n), NTHREADS, 0, st>>>(d_fj);
 				CK(hipEventRecord(e1, st));
 				CK(hipStreamSynchronize(st));
 				float ms; CK(hipEventElapsedTime(&ms, e0, e1));
 				if (r >= 3) { sum += ms; if (ms < best) best = ms; }
 			}
-			printf("fwd %-5s frames %d  avg %.3f ms  best %.3f ms  %.0f GB/s (avg)\n", variant == 0 ? "tile" : variant == 1 ? "strip" : variant == 2 ? "str32" : "str8", n, sum / reps, best, fb / (sum / reps) * 1e-6);
+			printf("fwd %-5s frames %d  avg %.3f ms  best %.3f ms  %.0f GB/s (avg)\n", variant == 0 ? "tile" : variant == 1 ? "strip" : variant == 2 ? "str32" : variant == 3 ? "str8" : "s32w4", n, sum / reps, best, fb / (sum / reps) * 1e-6);
 		}
 	}
 	return 0;
