@@ -112,8 +112,10 @@ long long cfhd_amd_batch_roundtrip(cfhd_amd_batch *b)
 		// the samples on the GPU and decodes, while the finished samples travel to the host (the encoder's product) on the
 		// encoder's stream beside it.
 		for (auto &c : b->chunks) {
+			// the transform kernels start first: the host serialises the 256 sample headers (0.5 ms) while they run
+			if (c->enc.launch_forward()) return -2;
 			for (int l = 0; l < c->n; l++) if (c->enc.entropy().set_frame_header(l, header(c->first + l))) return -6;
-			if (c->enc.launch_forward() || c->enc.entropy().launch()) return -2;
+			if (c->enc.entropy().launch()) return -2;
 			if (c->dec.after(c->enc.stream())) return -5;
 			if (c->dec.entropy().set_samples_device(c->enc.entropy().device_sample(0), c->enc.entropy().sample_cap(), c->enc.entropy().device_sizes())) return -4;
 			if (c->dec.entropy().launch() || c->dec.launch_inverse(seed + (uint32_t)c->first)) return -5;
