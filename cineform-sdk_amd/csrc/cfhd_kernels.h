@@ -845,12 +845,13 @@ __global__ void __launch_bounds__(NTHREADS) k_inv_yuv422(const InvYuvJob *jobs, 
 //   each lane streams its 8 columns of LL, LH, HL, HH with one 16-byte load per band row, keeps the three-row window of the vertical
 //   filter in registers, gets the two neighbouring column pairs of the horizontal filter from the adjacent lanes, and produces 16
 //   output samples per output row;
-//   the chroma waves leave their 8-bit samples in LDS (2 KB per output row), the luma lanes interleave them with their own and
-//   write 32 contiguous bytes each.  One barrier per band row (the chroma buffer is double-buffered).
+//   every lane leaves its 16 8-bit samples per output row in LDS (4 KB per row: Y | V | U), and behind one barrier per band row every
+//   thread of the workgroup interleaves one 16-byte word of each of the two output rows (v_perm_b32) and stores it -- nothing but the
+//   filter window stays in registers across the barrier, and the four waves share the interleave evenly.  The rows are double-buffered.
 // Same arithmetic, same dither bits as k_inv_yuv422 -- the two kernels are interchangeable and tested against each other.
 // Geometry served: width % 32 == 0 (chroma band a multiple of 8 columns) and width <= 2016 (126 luma blocks); others take k_inv_yuv422.
 // =============================================================================================
-enum { SR = 16, SBLK = 8, SLUMA_STEP = 62, SMAX_LUMA_BLOCKS = 2 * SLUMA_STEP + 2, SPLANE = 1024 };
+enum { SR = 16, SBLK = 8, SLUMA_STEP = 62, SMAX_LUMA_BLOCKS = 2 * SLUMA_STEP + 2, SROW = SMAX_LUMA_BLOCKS * 32 };   // SROW: bytes of one output row at most
 
 #if defined(CFHD_HIPEMU)
 struct emu_u4 { uint32_t x, y, z, w; };
@@ -867,6 +868,19 @@ __device__ __forceinline__ uint32_t byte_perm(uint32_t s0, uint32_t s1, uint32_t
 typedef uint32_t cfhd_u4 __attribute__((ext_vector_type(4)));
 #define CFHD_LDG128(p) (*(const __attribute__((address_space(1))) cfhd_u4 *)(p))
 __device__ __forceinline__ uint32_t byte_perm(uint32_t s0, uint32_t s1, uint32_t sel) { return __builtin_amdgcn_perm(s0, s1, sel); }
+#endif
+
+// A pointer every lane of the wave holds the same value of, moved to scalar registers: the per-lane part of an address is then one
+// 32-bit offset (global_load ... v_off, s[base]) instead of a 64-bit pointer per band.
+#if defined(CFHD_HIPEMU)
+template <typename T> __device__ __forceinline__ T *wave_uniform_ptr(T *p) { return p; }
+#else
+template <typename T> __device__ __forceinline__ T *wave_uniform_ptr(T *p)
+{
+	const uint64_t v = (uint64_t)p;
+	const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+	return (T *)(((uint64_t)hi << 32) | lo);
+}
 #endif
 
 struct StripRow { uint32_t d[4]; };                   // 8 band columns = 4 column pairs
@@ -902,14 +916,14 @@ __device__ __forceinline__ void strip_row_to8(const uint32_t (&L)[4], const uint
 	}
 }
 
-template <int ROWS_PER_STRIP>
+template <int ROWS_PER_STRIP, bool LATE_LOADS = false>
 __device__ __forceinline__ void inv_yuv422_strip(const InvYuvJob *jobs, uint32_t launch_seed)
 {
 	const TileId tile = xcd_tile();
 	__shared__ InvYuvJob s_job;
 	stage_job(&s_job, &jobs[tile.z]);
 	const InvYuvJob &job = s_job;
-	__shared__ uint32_t s_chroma[2][2][2][SPLANE / 4];    // [buffer][output row parity][V, U][bytes of the row's samples]
+	__shared__ uint32_t s_rows[2][2][SROW / 4];           // [buffer][output row parity][bytes: Y samples of the row | V samples | U samples]
 	const uint32_t seed = job.dither_seed ^ launch_seed;
 	const int h = job.height, r0 = tile.y * ROWS_PER_STRIP;
 	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -920,10 +934,19 @@ __device__ __forceinline__ void inv_yuv422_strip(const InvYuvJob *jobs, uint32_t
 	const int want = luma ? lane + SLUMA_STEP * wave : lane;
 	const int blk = want < nblk ? want : nblk - 1;        // lanes beyond the band recompute the last block and store nothing
 	const bool stores = want < nblk && (!luma || (wave == 0 ? lane < SLUMA_STEP + 1 : lane > 0));
+	// LDS row layout in dwords: Y samples of the output row (width / 2 dwords; job.width = luma band columns), then V, then U (width / 4 each)
+	const int v_base = job.width >> 1, u_base = v_base + (job.width >> 2), plane_base = luma ? 0 : (comp == 1 ? v_base : u_base);
+	const int nquads = job.width >> 2;                    // 16-byte words of an output row
 	const bool first = blk == 0, last = blk == nblk - 1;
 	const int pitch = job.band_pitch[comp];
-	const int16_t *pLL = job.band[comp][0] + SBLK * blk, *pLH = job.band[comp][1] + SBLK * blk;
-	const int16_t *pHL = job.band[comp][2] + SBLK * blk, *pHH = job.band[comp][3] + SBLK * blk;
+	// the component is the same for the whole wave: band bases in scalar registers, the lane's block as one 32-bit element offset
+	const int16_t *const bLL = wave_uniform_ptr(job.band[comp][0]), *const bLH = wave_uniform_ptr(job.band[comp][1]);
+	const int16_t *const bHL = wave_uniform_ptr(job.band[comp][2]), *const bHH = wave_uniform_ptr(job.band[comp][3]);
+	const uint32_t boff = (uint32_t)(SBLK * blk);
+#define pLL (bLL + boff)
+#define pLH (bLH + boff)
+#define pHL (bHL + boff)
+#define pHH (bHH + boff)
 	if (r0 >= h) return;                                  // whole workgroup
 	const int nrows = h - r0 < ROWS_PER_STRIP ? h - r0 : ROWS_PER_STRIP;
 	int j = inv_window_first_row(r0, h);
@@ -938,8 +961,10 @@ __device__ __forceinline__ void inv_yuv422_strip(const InvYuvJob *jobs, uint32_t
 		const int jn = more ? inv_window_first_row(r + 1, h) : j;
 		const bool advance = jn != j;
 		StripRow nll = ll2, nlh = lh2, nhl = hl, nhh = hh;
-		if (advance) { nll = strip_load(pLL + (size_t)(jn + 2) * pitch); nlh = strip_load(pLH + (size_t)(jn + 2) * pitch); }
-		if (more) { nhl = strip_load(pHL + (size_t)(r + 1) * pitch); nhh = strip_load(pHH + (size_t)(r + 1) * pitch); }
+		if (!LATE_LOADS) {
+			if (advance) { nll = strip_load(pLL + (size_t)(jn + 2) * pitch); nlh = strip_load(pLH + (size_t)(jn + 2) * pitch); }
+			if (more) { nhl = strip_load(pHL + (size_t)(r + 1) * pitch); nhh = strip_load(pHH + (size_t)(r + 1) * pitch); }
+		}
 		// vertical synthesis: rows 2r (even) and 2r + 1 (odd) of the horizontal-low and horizontal-high halves
 		const int pos = r == 0 ? 0 : (r == h - 1 ? 2 : 1);
 		uint32_t Lv[2][4], Hv[2][4];
@@ -948,8 +973,8 @@ __device__ __forceinline__ void inv_yuv422_strip(const InvYuvJob *jobs, uint32_t
 			inv_vert_pk(ll0.d[d], ll1.d[d], ll2.d[d], hl.d[d], pos, Lv[0][d], Lv[1][d]);
 			inv_vert_pk(lh0.d[d], lh1.d[d], lh2.d[d], hh.d[d], pos, Hv[0][d], Hv[1][d]);
 		}
-		uint32_t (*cbuf)[2][SPLANE / 4] = s_chroma[s & 1];
-		uint32_t te[2][4], to[2][4];
+		// every lane leaves the 16 8-bit samples of its block in LDS (bytes in sample order), luma and chroma alike ...
+		uint32_t (*rowbuf)[SROW / 4] = s_rows[s & 1];
 #pragma unroll
 		for (int par = 0; par < 2; par++) {
 			const int orow = 2 * r + par;
@@ -972,47 +997,50 @@ __device__ __forceinline__ void inv_yuv422_strip(const InvYuvJob *jobs, uint32_t
 					}
 				}
 			}
-			strip_row_to8(Lv[par], Hv[par], prev, next, first, last, sh, dbits, te[par], to[par]);
-			if (!luma && stores && orow < job.display_height) {
-				// bytes in sample order: (s(4d), s(4d+1), s(4d+2), s(4d+3)) = te | to << 8
-				uint32_t *dst = &cbuf[par][comp - 1][4 * blk];
+			uint32_t te[4], to[4];
+			strip_row_to8(Lv[par], Hv[par], prev, next, first, last, sh, dbits, te, to);
+			if (stores) {
+				// bytes in sample order: (s(4d), s(4d+1), s(4d+2), s(4d+3)) = te | to << 8; row layout: Y samples | V samples | U samples
+				uint32_t *dst = &rowbuf[par][plane_base + 4 * blk];
 #pragma unroll
-				for (int d = 0; d < 4; d++) dst[d] = te[par][d] | (to[par][d] << 8);
+				for (int d = 0; d < 4; d++) dst[d] = te[d] | (to[d] << 8);
 			}
 		}
 		__syncthreads();
-		if (luma && stores) {
+		// ... and every thread of the workgroup interleaves one 16-byte word (4 pixel pairs) of each of the two output rows
+		if (tid < nquads) {
 #pragma unroll
 			for (int par = 0; par < 2; par++) {
 				const int orow = 2 * r + par;
 				if (orow >= job.display_height) continue;
-				// pixel pair k of the block (k = 0..7): luma samples 2k, 2k + 1 and chroma sample 8 blk + k
-				const uint32_t v0 = cbuf[par][0][2 * blk], v1 = cbuf[par][0][2 * blk + 1], u0 = cbuf[par][1][2 * blk], u1 = cbuf[par][1][2 * blk + 1];
-				uint32_t o[8];
-#pragma unroll
-				for (int d = 0; d < 4; d++) {
-					const uint32_t pa = pk_lolo(te[par][d], to[par][d]), pb = pk_hihi(te[par][d], to[par][d]);    // (y(4d), y(4d+1)), (y(4d+2), y(4d+3))
-					const uint32_t vv = d < 2 ? v0 : v1, uu = d < 2 ? u0 : u1;
-					const int m = (2 * d) & 3;                     // byte of the chroma dwords for pixel pair 2d; 2d + 1 is the next byte
-					if (job.uyvy) {
-						o[2 * d] = (pa << 8) | byte_perm(vv, uu, (uint32_t)m | 0x0c00u | ((uint32_t)(4 + m) << 16) | 0x0c000000u);
-						o[2 * d + 1] = (pb << 8) | byte_perm(vv, uu, (uint32_t)(m + 1) | 0x0c00u | ((uint32_t)(5 + m) << 16) | 0x0c000000u);
-					} else {
-						o[2 * d] = pa | byte_perm(vv, uu, 0x0cu | ((uint32_t)m << 8) | 0x0c0000u | ((uint32_t)(4 + m) << 24));
-						o[2 * d + 1] = pb | byte_perm(vv, uu, 0x0cu | ((uint32_t)(m + 1) << 8) | 0x0c0000u | ((uint32_t)(5 + m) << 24));
-					}
+				const uint32_t *row = rowbuf[par];
+				const uint32_t y0 = row[2 * tid], y1 = row[2 * tid + 1], vv = row[v_base + tid], uu = row[u_base + tid];
+				// (u0, v0, u1, v1) and (u2, v2, u3, v3), then y(2m), u(m), y(2m+1), v(m) -- or u, y, v, y for UYVY
+				const uint32_t uv01 = byte_perm(vv, uu, 0x05010400u), uv23 = byte_perm(vv, uu, 0x07030602u);
+				uint4 q;
+				if (job.uyvy) {
+					q.x = byte_perm(uv01, y0, 0x01050004u); q.y = byte_perm(uv01, y0, 0x03070206u);
+					q.z = byte_perm(uv23, y1, 0x01050004u); q.w = byte_perm(uv23, y1, 0x03070206u);
+				} else {
+					q.x = byte_perm(uv01, y0, 0x05010400u); q.y = byte_perm(uv01, y0, 0x07030602u);
+					q.z = byte_perm(uv23, y1, 0x05010400u); q.w = byte_perm(uv23, y1, 0x07030602u);
 				}
-				uint4 *dst = (uint4 *)(job.out + (size_t)orow * job.out_pitch + 32 * (size_t)blk);
-				uint4 q0, q1;
-				q0.x = o[0]; q0.y = o[1]; q0.z = o[2]; q0.w = o[3]; q1.x = o[4]; q1.y = o[5]; q1.z = o[6]; q1.w = o[7];
-				dst[0] = q0; dst[1] = q1;
+				*(uint4 *)(job.out + (size_t)orow * job.out_pitch + 16 * (size_t)tid) = q;
 			}
+		}
+		if (LATE_LOADS) {
+			if (advance) { nll = strip_load(pLL + (size_t)(jn + 2) * pitch); nlh = strip_load(pLH + (size_t)(jn + 2) * pitch); }
+			if (more) { nhl = strip_load(pHL + (size_t)(r + 1) * pitch); nhh = strip_load(pHH + (size_t)(r + 1) * pitch); }
 		}
 		if (advance) { ll0 = ll1; ll1 = ll2; ll2 = nll; lh0 = lh1; lh1 = lh2; lh2 = nlh; j = jn; }
 		hl = nhl; hh = nhh;
 	}
+#undef pLL
+#undef pLH
+#undef pHL
+#undef pHH
 }
-__global__ void __launch_bounds__(NTHREADS) k_inv_yuv422_strip(const InvYuvJob *jobs, uint32_t launch_seed) { inv_yuv422_strip<SR>(jobs, launch_seed); }
+__global__ void __launch_bounds__(NTHREADS) k_inv_yuv422_strip(const InvYuvJob *jobs, uint32_t launch_seed) { inv_yuv422_strip<SR, true>(jobs, launch_seed); }
 
 // =============================================================================================
 // k_fwd_yuv422_strip: level 1 of the packed 4:2:2 formats with the organisation of k_inv_yuv422_strip (registers and lane exchange instead

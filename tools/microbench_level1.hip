@@ -9,6 +9,9 @@
 #include <stdio.h>
 #include <vector>
 using namespace cfhd::dev;
+template <int PAD> __device__ __forceinline__ void lds_pad() { __shared__ uint32_t pad[PAD / 4]; if (threadIdx.x == 1023) pad[threadIdx.x] = 1; asm volatile("" :: "v"(pad[0]) : "memory"); }
+__global__ void __launch_bounds__(NTHREADS) mb_inv_strip_occ2(const InvYuvJob *jobs, uint32_t seed) { inv_yuv422_strip<16, true>(jobs, seed); }
+__global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) mb_inv_strip_occ1(const InvYuvJob *jobs, uint32_t seed) { inv_yuv422_strip<16, true>(jobs, seed); }
 __global__ void __launch_bounds__(NTHREADS) mb_inv_strip32(const InvYuvJob *jobs, uint32_t seed) { inv_yuv422_strip<32>(jobs, seed); }
 __global__ void __launch_bounds__(NTHREADS) mb_inv_strip8(const InvYuvJob *jobs, uint32_t seed) { inv_yuv422_strip<8>(jobs, seed); }
 __global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(5, 5))) mb_inv_strip16_w5(const InvYuvJob *jobs, uint32_t seed) { inv_yuv422_strip<16>(jobs, seed); }
@@ -140,9 +143,9 @@ int main(int argc, char **argv)
 	hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
 	dim3 grid((w + ITW - 1) / ITW, (h + ITH - 1) / ITH, n);
 	const double bytes = (double)(frame_in + frame_out) * n;
-	for (int variant = 0; variant < 4; variant++) {
+	for (int variant = 0; variant < 8; variant++) {
 
-		const char *name = variant == 0 ? "tile" : variant == 1 ? "access" : variant == 2 ? "wide" : variant == 3 ? "strip" : variant == 4 ? "str32" : variant == 5 ? "str8" : variant == 6 ? "s16w5" : "s32w5";
+		const char *name = variant == 0 ? "tile" : variant == 1 ? "access" : variant == 2 ? "wide" : variant == 3 ? "strip" : variant == 4 ? "str32" : variant == 5 ? "str8" : variant == 6 ? "late" : "latew6";
 		float best = 1e9f, sum = 0;
 		for (int r = 0; r < reps + 3; r++) {
 			CK(hipEventRecord(e0, st));
@@ -152,8 +155,8 @@ int main(int argc, char **argv)
 			else if (variant == 3) k_inv_yuv422_strip<<<dim3(1, (h + SR - 1) / SR, n), NTHREADS, 0, st>>>(d_jobs, 1u);
 			else if (variant == 4) mb_inv_strip32<<<dim3(1, (h + 31) / 32, n), NTHREADS, 0, st>>>(d_jobs, 1u);
 			else if (variant == 5) mb_inv_strip8<<<dim3(1, (h + 7) / 8, n), NTHREADS, 0, st>>>(d_jobs, 1u);
-			else if (variant == 6) mb_inv_strip16_w5<<<dim3(1, (h + 15) / 16, n), NTHREADS, 0, st>>>(d_jobs, 1u);
-			else mb_inv_strip32_w5<<<dim3(1, (h + 31) / 32, n), NTHREADS, 0, st>>>(d_jobs, 1u);
+			else if (variant == 6) mb_inv_strip_occ2<<<dim3(1, (h + 15) / 16, n), NTHREADS, 0, st>>>(d_jobs, 1u);
+			else mb_inv_strip_occ1<<<dim3(1, (h + 15) / 16, n), NTHREADS, 0, st>>>(d_jobs, 1u);
 			CK(hipEventRecord(e1, st));
 			CK(hipStreamSynchronize(st));
 			float ms; CK(hipEventElapsedTime(&ms, e0, e1));
