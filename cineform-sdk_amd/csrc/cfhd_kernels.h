@@ -1063,6 +1063,7 @@ __device__ __forceinline__ void strip_fwd_row(const uint32_t (&p)[8], uint32_t p
 	for (int m = 0; m < 4; m++) horiz_pair(&ext[2 * m], 0u, prescale, first && m == 0, false, last && m == 3, L[m], H[m]);
 }
 
+enum { FWD_LATE_LOADS = 1 };
 // Per-lane state of k_fwd_yuv422_strip.
 struct FwdStrip {
 	uint32_t LW[6][4], HW[6][4];                          // window of horizontally analysed rows: picture rows wtop .. wtop + 5
@@ -1093,7 +1094,7 @@ __device__ __forceinline__ void strip_fwd_push(FwdStrip &st, const FwdYuvJob &jo
 			a[k][0] = st.raw[k][0].x; a[k][1] = st.raw[k][0].y; a[k][2] = st.raw[k][0].z; a[k][3] = st.raw[k][0].w;
 			a[k][4] = st.raw[k][1].x; a[k][5] = st.raw[k][1].y; a[k][6] = st.raw[k][1].z; a[k][7] = st.raw[k][1].w;
 		}
-		if (prefetch) strip_fwd_fetch(st, job, in, y + 2);       // the next pair's loads go out before this pair's arithmetic
+		if (prefetch && !FWD_LATE_LOADS) strip_fwd_fetch(st, job, in, y + 2);       // the next pair's loads go out before this pair's arithmetic
 #pragma unroll
 		for (int k = 0; k < 2; k++) {
 #pragma unroll
@@ -1120,6 +1121,9 @@ __device__ __forceinline__ void strip_fwd_push(FwdStrip &st, const FwdYuvJob &jo
 		const uint32_t prev = __shfl(p[k][7], lane - 1), next = __shfl(p[k][0], lane + 1);
 		strip_fwd_row(p[k], prev, next, first, last, st.LW[SLOT + k], st.HW[SLOT + k]);
 	}
+	// (FWD_LATE_LOADS) the next pair's loads go out behind this pair's arithmetic: nothing but the window is live across it, which is
+	// worth one more wave per SIMD -- and the kernel's throughput follows the number of resident waves, not the distance of its loads
+	if (luma && prefetch && FWD_LATE_LOADS) strip_fwd_fetch(st, job, in, y + 2);
 }
 
 template <int ROWS_PER_STRIP>
