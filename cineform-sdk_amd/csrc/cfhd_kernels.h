@@ -1063,7 +1063,7 @@ __device__ __forceinline__ void strip_fwd_row(const uint32_t (&p)[8], uint32_t p
 	for (int m = 0; m < 4; m++) horiz_pair(&ext[2 * m], 0u, prescale, first && m == 0, false, last && m == 3, L[m], H[m]);
 }
 
-enum { FWD_LATE_LOADS = 1 };
+enum { FWD_LATE_LOADS = 2 };   // 0: a row pair ahead of the arithmetic, 1: behind the horizontal pass, 2: at the start of the pair
 // Per-lane state of k_fwd_yuv422_strip.
 struct FwdStrip {
 	uint32_t LW[6][4], HW[6][4];                          // window of horizontally analysed rows: picture rows wtop .. wtop + 5
@@ -1088,6 +1088,7 @@ __device__ __forceinline__ void strip_fwd_push(FwdStrip &st, const FwdYuvJob &jo
 {
 	uint32_t p[2][8];
 	if (luma) {
+		if (FWD_LATE_LOADS == 2) strip_fwd_fetch(st, job, in, y);      // no load in flight across the vertical pass at all
 		uint32_t a[2][8];
 #pragma unroll
 		for (int k = 0; k < 2; k++) {
@@ -1123,7 +1124,7 @@ __device__ __forceinline__ void strip_fwd_push(FwdStrip &st, const FwdYuvJob &jo
 	}
 	// (FWD_LATE_LOADS) the next pair's loads go out behind this pair's arithmetic: nothing but the window is live across it, which is
 	// worth one more wave per SIMD -- and the kernel's throughput follows the number of resident waves, not the distance of its loads
-	if (luma && prefetch && FWD_LATE_LOADS) strip_fwd_fetch(st, job, in, y + 2);
+	if (luma && prefetch && FWD_LATE_LOADS == 1) strip_fwd_fetch(st, job, in, y + 2);
 }
 
 template <int ROWS_PER_STRIP>
@@ -1157,7 +1158,7 @@ __device__ __forceinline__ void fwd_yuv422_strip(const FwdYuvJob *jobs)
 	const int lastrow = window_first_row(r1 - 1, HH, H) + 5;     // last picture row this strip reads
 	int t = 0;                                            // row pairs pushed so far (selects the LDS buffer)
 #define CFHD_PUSH(SLOT, Y) strip_fwd_push<SLOT>(st, job, in, s_pairs[t & 1], (Y), (Y) + 2 <= lastrow, luma, comp, blk, lane, stores, first, last, shift, ysh0, usel, vsel); t++
-	if (luma) strip_fwd_fetch(st, job, in, wtop);
+	if (luma && FWD_LATE_LOADS != 2) strip_fwd_fetch(st, job, in, wtop);
 	CFHD_PUSH(0, wtop); CFHD_PUSH(2, wtop + 2); CFHD_PUSH(4, wtop + 4);
 	for (int r = r0; r < r1; r++) {
 		const int need = window_first_row(r, HH, H);
@@ -1265,8 +1266,6 @@ __global__ void __launch_bounds__(NTHREADS) k_inv_plane_strip(const InvPlaneJob 
 		const int jn = more ? inv_window_first_row(r + 1, h) : j;
 		const bool advance = jn != j;
 		StripRow nll = ll2, nlh = lh2, nhl = hl, nhh = hh;
-		if (advance) { nll = strip_load(pLL + (size_t)(jn + 2) * pitch); nlh = strip_load(pLH + (size_t)(jn + 2) * pitch); }
-		if (more) { nhl = strip_load(pHL + (size_t)(r + 1) * pitch); nhh = strip_load(pHH + (size_t)(r + 1) * pitch); }
 		const int pos = r == 0 ? 0 : (r == h - 1 ? 2 : 1);
 		uint32_t Lv[2][4], Hv[2][4];
 #pragma unroll
@@ -1311,6 +1310,9 @@ __global__ void __launch_bounds__(NTHREADS) k_inv_plane_strip(const InvPlaneJob 
 				dst[0] = q0; dst[1] = q1;
 			}
 		}
+		// the next row's loads go out behind this row's arithmetic (fewer live registers, one more wave per SIMD; cf. k_inv_yuv422_strip)
+		if (advance) { nll = strip_load(pLL + (size_t)(jn + 2) * pitch); nlh = strip_load(pLH + (size_t)(jn + 2) * pitch); }
+		if (more) { nhl = strip_load(pHL + (size_t)(r + 1) * pitch); nhh = strip_load(pHH + (size_t)(r + 1) * pitch); }
 		if (advance) { ll0 = ll1; ll1 = ll2; ll2 = nll; lh0 = lh1; lh1 = lh2; lh2 = nlh; j = jn; }
 		hl = nhl; hh = nhh;
 	}
