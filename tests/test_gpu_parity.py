@@ -89,9 +89,11 @@ def _check_decode(sample, source, w, h, pixfmt=PIX_YUY2):
     frac = (img[lo != hi] == hi[lo != hi]).mean()
     assert 0.35 < frac < 0.65, "dither is not balanced: %.3f" % frac
     if have_ref():
-        rout, rpitch = ref_decode_sample(sample, w, h, pixfmt)
-        rimg = rout.reshape(h, rpitch)[:, : w * 2]
-        rok = (rimg == lo) | (rimg == hi)
+        for attempt in range(3):                        # the reference's threaded decoder occasionally damages a frame: three attempts
+            rout, rpitch = ref_decode_sample(sample, w, h, pixfmt)
+            rimg = rout.reshape(h, rpitch)[:, : w * 2]
+            rok = (rimg == lo) | (rimg == hi)
+            if rok.all(): break
         assert rok.all(), "the reference's own output leaves the dither interval: oracle out of date"
         src = source.reshape(h, -1)[:, : w * 2]
         assert abs(psnr_yuy2(img, src) - psnr_yuy2(rimg, src)) < 0.1

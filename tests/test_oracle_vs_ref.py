@@ -80,14 +80,16 @@ def test_reference_decode_lies_in_oracle_dither_interval(w, h, fmt):
     every byte the reference decoder produces (it adds rand()&1 before the 10->8 bit shift)."""
     f, p = synth_yuy2(w, h, 7)
     sample = ref_encode_frames([f], p, w, h, fmt)[0]
-    rout, rpitch = ref_decode_sample(sample, w, h, fmt)
-    rimg = rout.reshape(h, rpitch)[:, : w * 2]
     uyvy = int(fmt == PIX_2VUY)
     plan = Plan(w, h, pixkind=2 if uyvy else 1)
     coeffs = host_decode_pyramid(sample, plan)
     lo = oracle_inverse_yuv422(plan, coeffs, 0, uyvy)[:h]
     hi = oracle_inverse_yuv422(plan, coeffs, 1, uyvy)[:h]
-    ok = (rimg == lo) | (rimg == hi)
+    for attempt in range(3):                            # the reference's threaded decoder occasionally damages a frame: three attempts
+        rout, rpitch = ref_decode_sample(sample, w, h, fmt)
+        rimg = rout.reshape(h, rpitch)[:, : w * 2]
+        ok = (rimg == lo) | (rimg == hi)
+        if ok.all(): break
     assert ok.all(), "%d bytes outside" % (~ok).sum()
     differ = lo != hi
     assert 0.3 < (rimg[differ] == hi[differ]).mean() < 0.7
@@ -100,10 +102,14 @@ def test_reference_rg48_decode_equals_oracle(w, h):
     the reference's vector columns, 65535 in its scalar tail columns)."""
     frames, pitch = qbist_frames(10, 1, w, h, PIX_RG48)
     sample = ref_encode_frames(frames, pitch, w, h, PIX_RG48, encoded=ENCODED_RGB444)[0]
-    dec, dpitch = ref_decode_sample(sample, w, h, PIX_RG48)
-    img = np.frombuffer(dec.tobytes(), dtype=np.uint16).reshape(h, dpitch // 2)[:, : w * 3]
     plan = Plan(w, h, pixkind=PIXKIND["RG48"], enc=3)
     mine = oracle_inverse_rgb48(plan, host_decode_pyramid(sample, plan))[:h]
+    # the reference's threaded decoder now and then returns a frame with damaged stretches (seen on 8 and on 256 cores, also as PSNR
+    # outliers in its own harness): it gets three attempts to reproduce the deterministic reconstruction
+    for attempt in range(3):
+        dec, dpitch = ref_decode_sample(sample, w, h, PIX_RG48)
+        img = np.frombuffer(dec.tobytes(), dtype=np.uint16).reshape(h, dpitch // 2)[:, : w * 3]
+        if np.array_equal(mine, img): break
     assert np.array_equal(mine, img)
 
 
@@ -117,10 +123,12 @@ def test_reference_b64a_decode_equals_oracle(w, h):
     px = np.frombuffer(frames[0].tobytes(), dtype=np.uint16).reshape(h, pitch // 2).copy()
     px[:, 0: w * 4: 4] = ((np.arange(h)[:, None] * 523 + np.arange(w)[None, :] * 97) % 65536).astype(np.uint16)
     sample = ref_encode_frames([px.reshape(-1).view(np.uint8).copy()], pitch, w, h, PIX_B64A, encoded=ENCODED_RGBA4444)[0]
-    dec, dpitch = ref_decode_sample(sample, w, h, PIX_B64A)
-    img = np.frombuffer(dec.tobytes(), dtype=np.uint16).reshape(h, dpitch // 2)[:, : w * 4]
     plan = Plan(w, h, pixkind=PIXKIND["b64a"], enc=ENC["4444"])
     mine = oracle_inverse_rgb48(plan, host_decode_pyramid(sample, plan), b64a=True)[:h]
+    for attempt in range(3):                            # see test_reference_rg48_decode_equals_oracle
+        dec, dpitch = ref_decode_sample(sample, w, h, PIX_B64A)
+        img = np.frombuffer(dec.tobytes(), dtype=np.uint16).reshape(h, dpitch // 2)[:, : w * 4]
+        if all(np.array_equal(mine[:, k::4], img[:, k::4]) for k in (1, 2, 3)): break
     assert np.array_equal(mine[:, 1::4], img[:, 1::4]) and np.array_equal(mine[:, 2::4], img[:, 2::4]) and np.array_equal(mine[:, 3::4], img[:, 3::4])
     rows_ok = (mine[:, 0::4] == img[:, 0::4]).all(axis=1)
     assert rows_ok.mean() > 0.9
