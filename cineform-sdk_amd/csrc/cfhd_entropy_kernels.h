@@ -667,7 +667,22 @@ __global__ void __launch_bounds__(DEC_THREADS) k_dec_bands(const DecBandJob *job
 // ---------------------------------------------------------------------------------------------
 enum { DECP_THREADS = 256, DECP_SUB_BITS = 256, DECP_SEQ_BITS = DECP_THREADS * DECP_SUB_BITS, DECP_SEQ_WORDS = DECP_SEQ_BITS / 32 };
 enum : uint32_t { DECP_END = 0xFFFFFFFFu, DECP_BAD = 0xFFFFFFFEu };
-static_assert((int)DECP_THREADS == (int)ENT_THREADS, "block_excl_sum() is sized for ENT_THREADS");
+
+// Exclusive prefix sum over the DECP_THREADS threads of the workgroup: DPP scan inside the waves, the wave totals through LDS (two
+// barriers instead of the 2 log2(n) of a Hillis-Steele scan in LDS).
+__device__ __forceinline__ uint32_t decp_excl_sum(uint32_t v, uint32_t *s_wsum /*[DECP_THREADS / 64]*/, uint32_t *total)
+{
+	const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+	const uint32_t incl = wave_incl_scan(v);
+	__syncthreads();                                     // s_wsum may still be read from the previous use
+	if (lane == 63) s_wsum[wave] = incl;
+	__syncthreads();
+	uint32_t before = 0, all = 0;
+#pragma unroll
+	for (int w = 0; w < DECP_THREADS / 64; w++) { const uint32_t x = s_wsum[w]; if (w < wave) before += x; all += x; }
+	*total = all;
+	return before + incl - v;
+}
 
 struct DecSub { uint32_t end, cnt; };
 
@@ -713,7 +728,7 @@ __global__ void __launch_bounds__(DECP_THREADS) k_dec_bands_par(const DecBandJob
 	__shared__ uint32_t s_lut1[1 << DEC_K1];             // 16 KB
 	__shared__ uint32_t s_words[DECP_SEQ_WORDS + 4];     // 8 KB: the current sequence of the payload
 	__shared__ uint32_t s_end[DECP_THREADS];
-	__shared__ int s_scan[DECP_THREADS];
+	__shared__ uint32_t s_wsum[DECP_THREADS / 64];
 	__shared__ int s_flag[2];
 	const int t = threadIdx.x;
 	const DecBandJob job = jobs[blockIdx.x];
@@ -756,16 +771,16 @@ __global__ void __launch_bounds__(DECP_THREADS) k_dec_bands_par(const DecBandJob
 				else r = dec_sub<false>(s_words, s_lut1, T, start, limit, nullptr, 0u, 0u, 0);
 			}
 		}
-		int total;
-		const uint32_t my_idx = base_idx + (uint32_t)block_excl_sum((int)r.cnt, s_scan, &total);
+		uint32_t total;
+		const uint32_t my_idx = base_idx + decp_excl_sum(r.cnt, s_wsum, &total);
 		const uint32_t last = s_end[nsub - 1];
 		if (last == DECP_BAD) { err = 1; break; }
-		if ((uint32_t)total > n - base_idx) { err = 2; break; }   // more coefficients than the band holds
+		if (total > n - base_idx) { err = 2; break; }   // more coefficients than the band holds
 		if (active && start < DECP_BAD && r.cnt) (void)dec_sub<true>(s_words, s_lut1, T, start, r.end, job.dst, my_idx, n, job.quant);
 		if (last == DECP_END) break;
 		if (seq_bits < (uint32_t)DECP_SEQ_BITS) { err = 3; break; }   // the payload ended without the band end marker
 		carry = last - DECP_SEQ_BITS;
-		base_idx += (uint32_t)total;
+		base_idx += total;
 	}
 	if (err && t == 0) atomic_or_u32((uint32_t *)errors, 1u << err);
 }
