@@ -306,12 +306,12 @@ template <typename F> static void for_channel_runs(const FramePlan &plan, int lv
 	}
 }
 
-// k_fwd_yuv422_strip serves progressive 4:2:2 frames of whole 32-pixel blocks up to 2016 pixels wide whose rows are 16-byte aligned;
+// k_fwd_yuv422_strip serves progressive 4:2:2 frames of whole 32-pixel blocks whose rows are 16-byte aligned;
 // everything else (and CFHD_AMD_FORWARD=tile, for A/B runs) takes the LDS-tiled k_fwd_yuv422.  Both produce the same coefficients.
 bool EncodeBatch::strip_forward() const
 {
 	static const bool forced_tile = [] { const char *e = getenv("CFHD_AMD_FORWARD"); return e && strcmp(e, "tile") == 0; }();
-	if (forced_tile || plan_.interlaced || plan_.encoded_format != ENC_YUV422 || plan_.width % 32 || plan_.width / 16 > dev::SMAX_LUMA_BLOCKS) return false;
+	if (forced_tile || plan_.interlaced || plan_.encoded_format != ENC_YUV422 || plan_.width % 32) return false;
 	EncJobs j = enc_jobs_at(h_jobs_, n_, plan_.num_channels);
 	for (int i = 0; i < n_; i++) if (((uintptr_t)j.yuv[i].in & 15) || (j.yuv[i].in_pitch & 15)) return false;
 	return true;
@@ -339,7 +339,8 @@ int EncodeBatch::launch_forward()
 		dim3 grid((plan_.width / 2 + dev::FTW - 1) / dev::FTW, (plan_.height / 2 + dev::FRW - 1) / dev::FRW, n_);
 		dev::k_fwd_frame_yuv422<<<grid, dev::NTHREADS, 0, st>>>((const dev::FwdFrameJob *)j.yuv);
 	} else if (strip_forward()) {
-		dev::k_fwd_yuv422_strip<<<dim3(1, (plan_.height / 2 + dev::SRF - 1) / dev::SRF, n_), dev::NTHREADS, 0, st>>>(j.yuv);
+		const int nseg = (plan_.width / 16 + dev::SSEG - 1) / dev::SSEG;      // segments of 124 luma blocks (1984 pixels)
+		dev::k_fwd_yuv422_strip<<<dim3(nseg, (plan_.height / 2 + dev::SRF - 1) / dev::SRF, n_), dev::NTHREADS, 0, st>>>(j.yuv);
 	} else {
 		dim3 grid((plan_.width / 2 + dev::TW - 1) / dev::TW, (plan_.height / 2 + dev::TH - 1) / dev::TH, n_);
 		dev::k_fwd_yuv422<<<grid, dev::NTHREADS, 0, st>>>(j.yuv);
@@ -514,13 +515,13 @@ int DecodeBatch::set_device_output(int i, void *d_out, int pitch)
 	return 0;
 }
 
-// k_inv_yuv422_strip serves luma bands of whole 16-column blocks up to 126 x 8 columns and writes 16-byte words; everything else (and
+// k_inv_yuv422_strip serves luma bands of whole 16-column blocks and writes 16-byte words; everything else (and
 // CFHD_AMD_INVERSE=tile, for A/B runs) takes the LDS-tiled k_inv_yuv422.  Both produce the same bytes.
 bool DecodeBatch::strip_inverse() const
 {
 	static const bool forced_tile = [] { const char *e = getenv("CFHD_AMD_INVERSE"); return e && strcmp(e, "tile") == 0; }();
 	const int bw = plan_.ch[0].band[0][0].width;
-	if (forced_tile || is_packed16(out_kind_) || bw % 16 || bw / dev::SBLK > dev::SMAX_LUMA_BLOCKS) return false;
+	if (forced_tile || is_packed16(out_kind_) || bw % 16) return false;
 	DecJobs j = dec_jobs_at(h_jobs_, n_, plan_.num_channels);
 	for (int i = 0; i < n_; i++) if (((uintptr_t)j.yuv[i].out & 15) || (j.yuv[i].out_pitch & 15)) return false;
 	return true;
@@ -558,7 +559,8 @@ int DecodeBatch::launch_inverse(uint32_t dither_seed)
 		dev::k_inv_packed16<<<grid, dev::NTHREADS, 0, st>>>(j.l1, nch);
 	} else if (strip_inverse()) {
 		const BandDesc &b = plan_.ch[0].band[0][0];
-		dev::k_inv_yuv422_strip<<<dim3(1, (b.height + dev::SR - 1) / dev::SR, n_), dev::NTHREADS, 0, st>>>(j.yuv, dither_seed);
+		const int nseg = (b.width / dev::SBLK + dev::SSEG - 1) / dev::SSEG;
+		dev::k_inv_yuv422_strip<<<dim3(nseg, (b.height + dev::SR - 1) / dev::SR, n_), dev::NTHREADS, 0, st>>>(j.yuv, dither_seed);
 	} else {
 		const BandDesc &b = plan_.ch[0].band[0][0];
 		dim3 grid((b.width + dev::ITW - 1) / dev::ITW, (b.height + dev::ITH - 1) / dev::ITH, n_);

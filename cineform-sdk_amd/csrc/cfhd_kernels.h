@@ -840,8 +840,8 @@ __global__ void __launch_bounds__(NTHREADS) k_inv_yuv422(const InvYuvJob *jobs, 
 // k_inv_yuv422 is bound by instruction issue, not by bytes (tools/microbench_inv_yuv422.hip: its loads and stores alone run at
 // 3.8 TB/s, the same bytes with 16-byte accesses at 5.7 TB/s, the kernel at 2.2 TB/s): per-item index arithmetic, two LDS round
 // trips and dword accesses.  Here a workgroup owns a full-width strip of SR band rows and walks down it:
-//   waves 0, 1: luma, one lane per block of 8 band columns (the two waves overlap by two blocks so that every stored block has both
-//               neighbours inside its wave); wave 2: V; wave 3: U -- the chroma bands are half as wide, so the roles balance;
+//   waves 0, 1: luma, one lane per block of 8 band columns (lanes 1..62 of a wave are stored, lanes 0 and 63 only supply neighbours, so
+//               the two waves overlap by two blocks); wave 2: V; wave 3: U -- the chroma bands are half as wide, so the roles balance;
 //   each lane streams its 8 columns of LL, LH, HL, HH with one 16-byte load per band row, keeps the three-row window of the vertical
 //   filter in registers, gets the two neighbouring column pairs of the horizontal filter from the adjacent lanes, and produces 16
 //   output samples per output row;
@@ -849,9 +849,10 @@ __global__ void __launch_bounds__(NTHREADS) k_inv_yuv422(const InvYuvJob *jobs, 
 //   thread of the workgroup interleaves one 16-byte word of each of the two output rows (v_perm_b32) and stores it -- nothing but the
 //   filter window stays in registers across the barrier, and the four waves share the interleave evenly.  The rows are double-buffered.
 // Same arithmetic, same dither bits as k_inv_yuv422 -- the two kernels are interchangeable and tested against each other.
-// Geometry served: width % 32 == 0 (chroma band a multiple of 8 columns) and width <= 2016 (126 luma blocks); others take k_inv_yuv422.
+// Geometry served: width % 32 == 0 (chroma band a multiple of 8 columns), any width (segments of 124 luma blocks = 1984 pixels, one
+// workgroup each, overlapping by the two neighbour lanes); others take k_inv_yuv422.
 // =============================================================================================
-enum { SR = 16, SBLK = 8, SLUMA_STEP = 62, SMAX_LUMA_BLOCKS = 2 * SLUMA_STEP + 2, SROW = SMAX_LUMA_BLOCKS * 32 };   // SROW: bytes of one output row at most
+enum { SR = 16, SBLK = 8, SLUMA_STEP = 62, SSEG = 2 * SLUMA_STEP, SROW = SSEG * 32 };   // SSEG: luma blocks per segment; SROW: bytes of a segment's output row
 
 #if defined(CFHD_HIPEMU)
 struct emu_u4 { uint32_t x, y, z, w; };
@@ -931,12 +932,19 @@ __device__ __forceinline__ void inv_yuv422_strip(const InvYuvJob *jobs, uint32_t
 	const int comp = luma ? 0 : wave - 1;                 // 0 Y, 1 V, 2 U
 	const int w = luma ? job.width : job.width >> 1;      // band columns of this lane's component
 	const int nblk = w / SBLK;
-	const int want = luma ? lane + SLUMA_STEP * wave : lane;
-	const int blk = want < nblk ? want : nblk - 1;        // lanes beyond the band recompute the last block and store nothing
-	const bool stores = want < nblk && (!luma || (wave == 0 ? lane < SLUMA_STEP + 1 : lane > 0));
-	// LDS row layout in dwords: Y samples of the output row (width / 2 dwords; job.width = luma band columns), then V, then U (width / 4 each)
-	const int v_base = job.width >> 1, u_base = v_base + (job.width >> 2), plane_base = luma ? 0 : (comp == 1 ? v_base : u_base);
-	const int nquads = job.width >> 2;                    // 16-byte words of an output row
+	// A workgroup serves one segment of SSEG luma blocks (tile.x) and the SSEG / 2 chroma blocks under it.  Lane l of a wave holds block
+	// base - 1 + l: lanes 1..62 are stored, lanes 0 and 63 only supply the neighbouring column pairs (the second luma wave starts
+	// 62 blocks further on); blocks outside the band are clamped and store nothing.
+	const int seg_first = tile.x * SSEG;                  // first luma block of the segment
+	const int base = luma ? seg_first + SLUMA_STEP * wave : seg_first >> 1;
+	const int want = base - 1 + lane;
+	const int blk = want < 0 ? 0 : (want < nblk ? want : nblk - 1);
+	const bool stores = lane >= 1 && lane <= SLUMA_STEP && want < nblk;
+	// LDS row layout in dwords, relative to the segment: Y samples (4 dwords per luma block) | V samples | U samples (4 per chroma block)
+	const int v_base = SSEG * 4, u_base = v_base + SSEG * 2;
+	const int lds_at = luma ? 4 * (want - seg_first) : (comp == 1 ? v_base : u_base) + 4 * (want - (seg_first >> 1));
+	const int seg_blocks = job.width / SBLK - seg_first < SSEG ? job.width / SBLK - seg_first : SSEG;
+	const int nquads = 2 * seg_blocks;                    // 16-byte words of the segment's part of an output row
 	const bool first = blk == 0, last = blk == nblk - 1;
 	const int pitch = job.band_pitch[comp];
 	// the component is the same for the whole wave: band bases in scalar registers, the lane's block as one 32-bit element offset
@@ -1001,7 +1009,7 @@ __device__ __forceinline__ void inv_yuv422_strip(const InvYuvJob *jobs, uint32_t
 			strip_row_to8(Lv[par], Hv[par], prev, next, first, last, sh, dbits, te, to);
 			if (stores) {
 				// bytes in sample order: (s(4d), s(4d+1), s(4d+2), s(4d+3)) = te | to << 8; row layout: Y samples | V samples | U samples
-				uint32_t *dst = &rowbuf[par][plane_base + 4 * blk];
+				uint32_t *dst = &rowbuf[par][lds_at];
 #pragma unroll
 				for (int d = 0; d < 4; d++) dst[d] = te[d] | (to[d] << 8);
 			}
@@ -1025,7 +1033,7 @@ __device__ __forceinline__ void inv_yuv422_strip(const InvYuvJob *jobs, uint32_t
 					q.x = byte_perm(uv01, y0, 0x05010400u); q.y = byte_perm(uv01, y0, 0x07030602u);
 					q.z = byte_perm(uv23, y1, 0x05010400u); q.w = byte_perm(uv23, y1, 0x07030602u);
 				}
-				*(uint4 *)(job.out + (size_t)orow * job.out_pitch + 16 * (size_t)tid) = q;
+				*(uint4 *)(job.out + (size_t)orow * job.out_pitch + 32 * (size_t)seg_first + 16 * (size_t)tid) = q;
 			}
 		}
 		if (LATE_LOADS) {
@@ -1051,7 +1059,7 @@ __global__ void __launch_bounds__(NTHREADS) k_inv_yuv422_strip(const InvYuvJob *
 //   horizontal 2/6 analysis of the row's 8 pairs (neighbour pairs from the adjacent lanes), results pushed into a six-row register
 //   window; every second row the vertical 2/6 analysis + quantizer emits one row of LL, LH, HL, HH, 16 bytes per band.
 // One barrier per picture row pair (the LDS chroma rows are double-buffered).  Same arithmetic as k_fwd_yuv422, tested against it.
-// Geometry served: width % 32 == 0 and width <= 2016, 16-byte aligned rows; everything else takes k_fwd_yuv422.
+// Geometry served: width % 32 == 0 (segments of 1984 pixels), 16-byte aligned rows; everything else takes k_fwd_yuv422.
 // =============================================================================================
 enum { SRF = 32, SFPLANE = 512 };                       // band rows per strip; chroma pairs per picture row (dwords) the LDS buffer holds per channel
 
@@ -1084,7 +1092,7 @@ __device__ __forceinline__ void strip_fwd_fetch(FwdStrip &st, const FwdYuvJob &j
 // y + 2, y + 3 when `prefetch`), leave the chroma sample pairs in LDS; the chroma lanes pick theirs up behind the barrier.
 template <int SLOT>
 __device__ __forceinline__ void strip_fwd_push(FwdStrip &st, const FwdYuvJob &job, const uint8_t *in, uint32_t (*buf)[2][SFPLANE], int y, bool prefetch,
-                                               bool luma, int comp, int blk, int lane, bool stores, bool first, bool last, int shift, int ysh0, uint32_t usel, uint32_t vsel)
+                                               bool luma, int comp, int lds_write_at, int lds_read_at, int lane, bool first, bool last, int shift, int ysh0, uint32_t usel, uint32_t vsel)
 {
 	uint32_t p[2][8];
 	if (luma) {
@@ -1100,11 +1108,11 @@ __device__ __forceinline__ void strip_fwd_push(FwdStrip &st, const FwdYuvJob &jo
 		for (int k = 0; k < 2; k++) {
 #pragma unroll
 			for (int i = 0; i < 8; i++) p[k][i] = ((a[k][i] >> ysh0) & 0x00ff00ffu) << shift;
-			if (stores) {
+			if (lds_write_at >= 0) {
 #pragma unroll
 				for (int i = 0; i < 4; i++) {
-					buf[k][0][4 * blk + i] = byte_perm(a[k][2 * i + 1], a[k][2 * i], vsel) << shift;
-					buf[k][1][4 * blk + i] = byte_perm(a[k][2 * i + 1], a[k][2 * i], usel) << shift;
+					buf[k][0][lds_write_at + i] = byte_perm(a[k][2 * i + 1], a[k][2 * i], vsel) << shift;
+					buf[k][1][lds_write_at + i] = byte_perm(a[k][2 * i + 1], a[k][2 * i], usel) << shift;
 				}
 			}
 		}
@@ -1114,7 +1122,7 @@ __device__ __forceinline__ void strip_fwd_push(FwdStrip &st, const FwdYuvJob &jo
 #pragma unroll
 		for (int k = 0; k < 2; k++) {
 #pragma unroll
-			for (int i = 0; i < 8; i++) p[k][i] = buf[k][comp - 1][8 * blk + i];
+			for (int i = 0; i < 8; i++) p[k][i] = buf[k][comp - 1][lds_read_at + i < 0 ? 0 : lds_read_at + i];
 		}
 	}
 #pragma unroll
@@ -1142,10 +1150,18 @@ __device__ __forceinline__ void fwd_yuv422_strip(const FwdYuvJob *jobs)
 	const int comp = luma ? 0 : wave - 1;                 // 0 Y, 1 V, 2 U
 	const QuantParam q_lh = job.q[comp][1], q_hl = job.q[comp][2], q_hh = job.q[comp][3];
 	const int nblk = luma ? W / 16 : W / 32;              // blocks of 8 band columns
-	const int want = luma ? lane + SLUMA_STEP * wave : lane;
-	const int blk = want < nblk ? want : nblk - 1;
-	const bool stores = want < nblk && (!luma || (wave == 0 ? lane < SLUMA_STEP + 1 : lane > 0));
+	// segments and lanes as in k_inv_yuv422_strip: lane l of a wave holds block base - 1 + l, lanes 1..62 store
+	const int seg_first = tile.x * SSEG;
+	const int base = luma ? seg_first + SLUMA_STEP * wave : seg_first >> 1;
+	const int want = base - 1 + lane;
+	const int blk = want < 0 ? 0 : (want < nblk ? want : nblk - 1);
+	const bool stores = lane >= 1 && lane <= SLUMA_STEP && want < nblk;
 	const bool first = blk == 0, last = blk == nblk - 1;
+	// chroma sample pairs in LDS, relative to luma block seg_first - 1 (4 pairs per luma block): every luma block of the segment and
+	// its two neighbours is written once (wave 0: lanes 0..62, wave 1: lanes 1..63); chroma lane l reads the 8 pairs from 8 l - 4 on
+	// (the outer halves of the two halo lanes are never used)
+	const int lds_write_at = (luma && want >= 0 && want < nblk && (wave == 0 ? lane <= SLUMA_STEP : lane >= 1)) ? 4 * (want - seg_first + 1) : -1;
+	const int lds_read_at = 8 * lane - 4;
 	if (r0 >= HH) return;
 	const int r1 = r0 + ROWS_PER_STRIP < HH ? r0 + ROWS_PER_STRIP : HH;
 	const int shift = job.shift;
@@ -1157,7 +1173,7 @@ __device__ __forceinline__ void fwd_yuv422_strip(const FwdYuvJob *jobs)
 	int wtop = window_first_row(r0, HH, H);
 	const int lastrow = window_first_row(r1 - 1, HH, H) + 5;     // last picture row this strip reads
 	int t = 0;                                            // row pairs pushed so far (selects the LDS buffer)
-#define CFHD_PUSH(SLOT, Y) strip_fwd_push<SLOT>(st, job, in, s_pairs[t & 1], (Y), (Y) + 2 <= lastrow, luma, comp, blk, lane, stores, first, last, shift, ysh0, usel, vsel); t++
+#define CFHD_PUSH(SLOT, Y) strip_fwd_push<SLOT>(st, job, in, s_pairs[t & 1], (Y), (Y) + 2 <= lastrow, luma, comp, lds_write_at, lds_read_at, lane, first, last, shift, ysh0, usel, vsel); t++
 	if (luma && FWD_LATE_LOADS != 2) strip_fwd_fetch(st, job, in, wtop);
 	CFHD_PUSH(0, wtop); CFHD_PUSH(2, wtop + 2); CFHD_PUSH(4, wtop + 4);
 	for (int r = r0; r < r1; r++) {

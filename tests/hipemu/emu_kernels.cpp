@@ -104,12 +104,12 @@ void emu_fwd_yuv422(const uint8_t *in, int in_pitch, int width, int height, int 
 int emu_fwd_yuv422_strip(const uint8_t *in, int in_pitch, int width, int height, int display_height, int uyvy, int shift,
                          const int *quant /*[3][4]*/, int mpq, int16_t **out /*[3][4]*/, const int *out_pitch)
 {
-	if (width % 32 || width / 16 > SMAX_LUMA_BLOCKS) return -1;
+	if (width % 32) return -1;
 	FwdYuvJob job;
 	job.in = in; job.in_pitch = in_pitch; job.width = width; job.height = height; job.display_height = display_height;
 	job.uyvy = uyvy; job.shift = shift;
 	for (int c = 0; c < 3; c++) { job.out_pitch[c] = out_pitch[c]; for (int b = 0; b < 4; b++) { job.out[c][b] = out[c * 4 + b]; job.q[c][b] = make_q(quant[c * 4 + b], mpq); } }
-	hipemu::launch(dim3(1, (height / 2 + SRF - 1) / SRF, 1), dim3(NTHREADS), [&] { k_fwd_yuv422_strip(&job); });
+	hipemu::launch(dim3((width / 16 + SSEG - 1) / SSEG, (height / 2 + SRF - 1) / SRF, 1), dim3(NTHREADS), [&] { k_fwd_yuv422_strip(&job); });
 	return 0;
 }
 
@@ -135,16 +135,16 @@ void emu_inv_yuv422(int16_t **bands /*[3][4]*/, const int *band_pitch, int w, in
 	hipemu::launch(grid, dim3(NTHREADS), [&] { k_inv_yuv422(&job, 0u); });
 }
 
-// the register-strip variant of the same level (luma band width a multiple of 16, at most 126 blocks of 8 columns)
+// the register-strip variant of the same level (luma band width a multiple of 16; segments of 124 blocks of 8 columns)
 int emu_inv_yuv422_strip(int16_t **bands /*[3][4]*/, const int *band_pitch, int w, int h, int display_height, int uyvy, int shift,
                          unsigned dither_seed, uint8_t *out, int out_pitch)
 {
-	if (w % 16 || w / SBLK > SMAX_LUMA_BLOCKS) return -1;
+	if (w % 16) return -1;
 	InvYuvJob job;
 	for (int c = 0; c < 3; c++) { job.band_pitch[c] = band_pitch[c]; for (int b = 0; b < 4; b++) job.band[c][b] = bands[c * 4 + b]; }
 	job.width = w; job.height = h; job.display_height = display_height; job.uyvy = uyvy; job.shift = shift;
 	job.dither_seed = dither_seed; job.out = out; job.out_pitch = out_pitch;
-	hipemu::launch(dim3(1, (h + SR - 1) / SR, 1), dim3(NTHREADS), [&] { k_inv_yuv422_strip(&job, 0u); });
+	hipemu::launch(dim3((w / SBLK + SSEG - 1) / SSEG, (h + SR - 1) / SR, 1), dim3(NTHREADS), [&] { k_inv_yuv422_strip(&job, 0u); });
 	return 0;
 }
 

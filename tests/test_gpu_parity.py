@@ -481,3 +481,13 @@ def test_b64a_8k_config_c_round_trip():
     got, gpitch, aw, ah = amd_decode_sample(a, PIX_B64A)
     assert (aw, ah) == (w, h)
     assert np.array_equal(np.frombuffer(got.tobytes(), np.uint16).reshape(h, gpitch // 2), exact)
+
+
+@pytest.mark.skipif(not have_ref(), reason="needs the reference encoder")
+def test_yuy2_4k_two_segments():
+    """3840 x 2160 YUY2: the strip kernels work on two segments of 1984 / 1856 pixels per row; sample byte-identical to the reference,
+    decode inside the dither interval."""
+    w, h = 3840, 2160
+    f, p = synth_yuy2(w, h, 21)
+    mine = _check_encode([f], p, w, h)
+    _check_decode(mine[0], f, w, h)

@@ -54,11 +54,11 @@ def test_fwd_yuv422(w, h, dh, uyvy):
             assert np.array_equal(outs_e[ch][k][:, :outs_o[ch][k].shape[1]], outs_o[ch][k]), (ch, k)
 
 
-@pytest.mark.parametrize("w,h,dh", [(32, 8, 8), (64, 16, 13), (192, 40, 34), (960, 72, 72), (2048, 8, 8), (2016, 16, 16)])
+@pytest.mark.parametrize("w,h,dh", [(32, 8, 8), (64, 16, 13), (192, 40, 34), (960, 72, 72), (1984, 8, 8), (2016, 16, 16), (2048, 8, 8), (3840, 16, 14), (48, 8, 8)])
 @pytest.mark.parametrize("uyvy", [0, 1])
 def test_fwd_yuv422_strip_kernel(w, h, dh, uyvy):
     """k_fwd_yuv422_strip (register windows + lane exchange, 16-byte accesses) = oracle, incl. full-range samples, strips that start
-    inside the picture (h > 32), rows below the display height and the widest frame it serves (2016)."""
+    inside the picture (h > 32), rows below the display height and frames of several segments (1984 pixels each)."""
     rng = np.random.default_rng(w + 7 * h + uyvy)
     frame = rng.integers(0, 256, size=(dh, w * 2), dtype=np.int64).astype(np.uint8)
     frame[: dh // 2, : w] = rng.choice([0, 255], size=(dh // 2, w))
@@ -73,7 +73,7 @@ def test_fwd_yuv422_strip_kernel(w, h, dh, uyvy):
     E = emu()
     ptrs = (c_i16p * 12)(*[p16(a) for ch in range(3) for a in outs_e[ch]])
     rc = E.emu_fwd_yuv422_strip(p8(frame), w * 2, w, h, dh, uyvy, 2, iarr(quant), 2, ptrs, iarr(pitches))
-    if w > 2016:
+    if w % 32:
         assert rc == -1
         return
     assert rc == 0
@@ -187,11 +187,12 @@ def test_inv_yuv422(w, h, dh, uyvy):
     assert np.any(e != outs[0]) and np.any(e != outs[1])        # the dither really toggles
 
 
-@pytest.mark.parametrize("w,h,dh", [(16, 8, 16), (32, 17, 33), (96, 20, 40), (480, 35, 70), (1008, 16, 31), (1024, 8, 16)])
+@pytest.mark.parametrize("w,h,dh", [(16, 8, 16), (32, 17, 33), (96, 20, 40), (480, 35, 70), (992, 16, 31), (1008, 16, 31), (1024, 8, 16), (1920, 8, 15), (24, 8, 16)])
 @pytest.mark.parametrize("uyvy", [0, 1])
 def test_inv_yuv422_strip_kernel(w, h, dh, uyvy):
     """k_inv_yuv422_strip (register windows + lane exchange instead of LDS tiles) vs the oracle, and byte for byte equal to
-    k_inv_yuv422 with the same dither seed: the two kernels are interchangeable.  1008 = the widest band it serves (126 blocks)."""
+    k_inv_yuv422 with the same dither seed: the two kernels are interchangeable.  Bands wider than 992 columns (124 blocks) take several
+    segments (1008: a second segment of two blocks; 1920: the 3840-pixel frame); 24 is not a multiple of 16 and is refused."""
     rng = np.random.default_rng(w + 3 * h + uyvy)
     bands, pitches = [], []
     for ch in range(3):
@@ -205,7 +206,7 @@ def test_inv_yuv422_strip_kernel(w, h, dh, uyvy):
     E = emu()
     got = np.full((dh, 4 * w + 16), 7, np.uint8)
     rc = E.emu_inv_yuv422_strip(ptrs, iarr(pitches), w, h, dh, uyvy, 2, 99, p8(got), 4 * w + 16)
-    if w > 1008:
+    if w % 16:
         assert rc == -1
         return
     assert rc == 0
