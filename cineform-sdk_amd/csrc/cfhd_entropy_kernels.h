@@ -665,12 +665,16 @@ __global__ void __launch_bounds__(DEC_THREADS) k_dec_bands(const DecBandJob *job
 // position and a last pass writes the dequantized values.  Same result as the one-lane kernel above and as
 // Codec/decoder.c:19534; the workgroup also zeroes its band first (the reference memset()s the band, decoder.c:19563).
 // ---------------------------------------------------------------------------------------------
-enum { DECP_THREADS = 256, DECP_SUB_BITS = 256, DECP_SEQ_BITS = DECP_THREADS * DECP_SUB_BITS, DECP_SEQ_WORDS = DECP_SEQ_BITS / 32 };
+// Two instantiations: 256 threads x 256-bit subsequences for throughput (a batch of frames keeps every CU busy with six workgroups), 512
+// threads x 128-bit subsequences for latency (a single frame's decode waits for the serial steps of its longest band: 0.37 -> 0.22 ms;
+// at 256 frames this shape is 6 % slower).  Both walk 8 KB of payload per step.
+enum { DECP_THREADS = 256, DECP_SUB_BITS = 256, DECP_LL_THREADS = 512, DECP_LL_SUB_BITS = 128 };
 enum : uint32_t { DECP_END = 0xFFFFFFFFu, DECP_BAD = 0xFFFFFFFEu };
 
 // Exclusive prefix sum over the DECP_THREADS threads of the workgroup: DPP scan inside the waves, the wave totals through LDS (two
 // barriers instead of the 2 log2(n) of a Hillis-Steele scan in LDS).
-__device__ __forceinline__ uint32_t decp_excl_sum(uint32_t v, uint32_t *s_wsum /*[DECP_THREADS / 64]*/, uint32_t *total)
+template <int NT>
+__device__ __forceinline__ uint32_t decp_excl_sum(uint32_t v, uint32_t *s_wsum /*[NT / 64]*/, uint32_t *total)
 {
 	const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
 	const uint32_t incl = wave_incl_scan(v);
@@ -679,7 +683,7 @@ __device__ __forceinline__ uint32_t decp_excl_sum(uint32_t v, uint32_t *s_wsum /
 	__syncthreads();
 	uint32_t before = 0, all = 0;
 #pragma unroll
-	for (int w = 0; w < DECP_THREADS / 64; w++) { const uint32_t x = s_wsum[w]; if (w < wave) before += x; all += x; }
+	for (int w = 0; w < NT / 64; w++) { const uint32_t x = s_wsum[w]; if (w < wave) before += x; all += x; }
 	*total = all;
 	return before + incl - v;
 }
@@ -723,8 +727,10 @@ __device__ __forceinline__ DecSub dec_sub(const uint32_t *s_words, const uint32_
 	return DecSub{ p, cnt };
 }
 
-__global__ void __launch_bounds__(DECP_THREADS) k_dec_bands_par(const DecBandJob *jobs, const DecTables *T, int *errors)
+template <int NT, int SUB_BITS>
+__device__ __forceinline__ void dec_bands_par(const DecBandJob *jobs, const DecTables *T, int *errors)
 {
+	enum { DECP_THREADS = NT, DECP_SUB_BITS = SUB_BITS, DECP_SEQ_BITS = NT * SUB_BITS, DECP_SEQ_WORDS = DECP_SEQ_BITS / 32 };
 	__shared__ uint32_t s_lut1[1 << DEC_K1];             // 16 KB
 	__shared__ uint32_t s_words[DECP_SEQ_WORDS + 4];     // 8 KB: the current sequence of the payload
 	__shared__ uint32_t s_end[DECP_THREADS];
@@ -772,7 +778,7 @@ __global__ void __launch_bounds__(DECP_THREADS) k_dec_bands_par(const DecBandJob
 			}
 		}
 		uint32_t total;
-		const uint32_t my_idx = base_idx + decp_excl_sum(r.cnt, s_wsum, &total);
+		const uint32_t my_idx = base_idx + decp_excl_sum<NT>(r.cnt, s_wsum, &total);
 		const uint32_t last = s_end[nsub - 1];
 		if (last == DECP_BAD) { err = 1; break; }
 		if (total > n - base_idx) { err = 2; break; }   // more coefficients than the band holds
@@ -784,6 +790,8 @@ __global__ void __launch_bounds__(DECP_THREADS) k_dec_bands_par(const DecBandJob
 	}
 	if (err && t == 0) atomic_or_u32((uint32_t *)errors, 1u << err);
 }
+__global__ void __launch_bounds__(DECP_THREADS) k_dec_bands_par(const DecBandJob *jobs, const DecTables *T, int *errors) { dec_bands_par<DECP_THREADS, DECP_SUB_BITS>(jobs, T, errors); }
+__global__ void __launch_bounds__(DECP_LL_THREADS) k_dec_bands_par_ll(const DecBandJob *jobs, const DecTables *T, int *errors) { dec_bands_par<DECP_LL_THREADS, DECP_LL_SUB_BITS>(jobs, T, errors); }
 
 // ---------------------------------------------------------------------------------------------
 // Sample parser on the GPU, for samples that already live in HBM (the batched round trip hands the encoder's output straight

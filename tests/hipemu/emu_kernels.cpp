@@ -270,7 +270,9 @@ extern "C" int emu_entropy_decode(const uint8_t *sample, size_t size, int pixel_
 		}
 		return 0;
 	}
-	if (parallel)
+	if (parallel == 3)       // the low-latency shape: 512 threads on 128-bit subsequences
+		hipemu::launch(dim3(nb), dim3(dev::DECP_LL_THREADS), [&] { dev::k_dec_bands_par_ll(bands.data(), (const dev::DecTables *)tables.data(), &errors); });
+	else if (parallel)
 		hipemu::launch(dim3(nb), dim3(dev::DECP_THREADS), [&] { dev::k_dec_bands_par(bands.data(), (const dev::DecTables *)tables.data(), &errors); });
 	else
 		hipemu::launch(dim3((nb + dev::DEC_THREADS - 1) / dev::DEC_THREADS), dim3(dev::DEC_THREADS),

@@ -312,10 +312,10 @@ def test_gpu_entropy_stage_emulated_interlaced(w, h, seed):
     assert _emu_entropy_interlaced(plan, ok, 3, meta)[0] > 0
 
 
-@pytest.mark.parametrize("parallel", [0, 1, 2])
+@pytest.mark.parametrize("parallel", [0, 1, 2, 3])
 @pytest.mark.parametrize("w,h,seed", [(192, 96, 1), (336, 252, 3), (720, 480, 4)])
 def test_gpu_entropy_decoder_emulated_equals_host_decoder(w, h, seed, parallel):
-    """k_dec_bands (one lane per band), k_dec_bands_par (one workgroup per band; 2: fed by the GPU parser k_dec_parse) + k_dec_lowpass under emulation reproduce the product's host VLC decoder (dequantized pyramid incl. lowpass bias)."""
+    """k_dec_bands (one lane per band), k_dec_bands_par (one workgroup per band; 2: fed by the GPU parser k_dec_parse; 3: the low-latency shape k_dec_bands_par_ll) + k_dec_lowpass under emulation reproduce the product's host VLC decoder (dequantized pyramid incl. lowpass bias)."""
     frame, pitch = synth_yuy2(w, h, seed)
     plan = Plan(w, h)
     coeffs = oracle_forward_yuv422(plan, frame, pitch)
@@ -334,7 +334,7 @@ def test_gpu_entropy_decoder_emulated_equals_host_decoder(w, h, seed, parallel):
         assert np.array_equal(plan.view(got, c, lv, b)[:, :cols], plan.view(want, c, lv, b)[:, :cols]), (c, lv, b)
 
 
-@pytest.mark.parametrize("parallel", [1, 2])
+@pytest.mark.parametrize("parallel", [1, 2, 3])
 def test_gpu_entropy_decoder_emulated_survives_damaged_samples(parallel):
     """Truncated samples are refused; garbage inside the code words never writes outside the band nor hangs (error flag or wrong values, no crash)."""
     w, h = 336, 252
