@@ -331,7 +331,11 @@ __device__ __forceinline__ void put_code_plain(uint32_t *words, uint64_t pos, ui
 __global__ void __launch_bounds__(ENT_THREADS) k_ent_layout(const EntFrameJob *frames, const EntBandJob *bands, const EntSegState *segs,
                                                              EntBandState *band_state, const EntTables *tables)
 {
+	// gridDim.y workgroups share a frame: every one of them works out the layout (40 holes), workgroup 0 writes the template words and
+	// the size fields, and the payload holes -- raw lowpass bands, zero fill and trailer of the coded bands: the bytes of this kernel --
+	// are dealt out hole by hole.  (One workgroup per frame left 255 CUs with four waves each: 0.20 ms for 137 MB.)
 	const EntFrameJob &f = frames[blockIdx.x];
+	const int part = blockIdx.y, nparts = gridDim.y;
 	__shared__ uint32_t s_cum[ENT_MAX_HOLES + 1];       // bytes of the holes in front of hole h
 	__shared__ int s_ok;
 	const int tid = threadIdx.x;
@@ -345,17 +349,17 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_layout(const EntFrameJob *f
 		s_cum[f.nholes] = cum;
 		const uint32_t total = (uint32_t)f.tmpl_bytes + cum;
 		s_ok = total <= f.out_cap;
-		*f.sample_bytes = s_ok ? total : 0u;
+		if (part == 0) *f.sample_bytes = s_ok ? total : 0u;
 	}
 	__syncthreads();
 	if (!s_ok) return;                                   // uniform: the whole workgroup leaves
 	uint32_t *out = (uint32_t *)f.out;
 	// 1. fixed words of the template
 	const uint32_t *tw = (const uint32_t *)f.tmpl;
-	for (int i = tid; i < f.tmpl_bytes / 4; i += ENT_THREADS) out[i + (s_cum[f.word_holes[i]] >> 2)] = tw[i];
+	if (part == 0) for (int i = tid; i < f.tmpl_bytes / 4; i += ENT_THREADS) out[i + (s_cum[f.word_holes[i]] >> 2)] = tw[i];
 	__syncthreads();
 	// 2. size fields
-	for (int i = tid; i < f.npatches; i += ENT_THREADS) {
+	for (int i = tid; part == 0 && i < f.npatches; i += ENT_THREADS) {
 		const EntPatch &p = f.patches[i];
 		const uint32_t at = (uint32_t)p.at_tmpl + s_cum[p.at_holes], end = (uint32_t)p.end_tmpl + s_cum[p.end_holes];
 		if (p.kind == 0) {
@@ -369,8 +373,8 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_layout(const EntFrameJob *f
 			out[at >> 2] = bswap32(end - start);
 		}
 	}
-	// 3. payload holes
-	for (int h = 0; h < f.nholes; h++) {
+	// 3. payload holes, hole h by workgroup h % nparts
+	for (int h = part; h < f.nholes; h += nparts) {
 		const EntHole &hole = f.holes[h];
 		const uint32_t base = (uint32_t)hole.tmpl_offset + s_cum[h];
 		if (hole.kind == 0) {
@@ -397,7 +401,7 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_layout(const EntFrameJob *f
 	// 4. trailing zero run + band end marker of every band (one thread per band; the payload words were zeroed above)
 	for (int h = tid; h < f.nholes; h += ENT_THREADS) {
 		const EntHole &hole = f.holes[h];
-		if (hole.kind != 1) continue;
+		if (hole.kind != 1 || h % nparts != part) continue;
 		const EntBandState &b = band_state[hole.band_job];
 		const EntTables *T = tables + bands[hole.band_job].table;
 		uint32_t *words = out + ((hole.tmpl_offset + s_cum[h]) >> 2);
