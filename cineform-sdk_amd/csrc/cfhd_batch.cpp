@@ -116,7 +116,8 @@ long long cfhd_amd_batch_roundtrip(cfhd_amd_batch *b)
 			if (c->enc.launch_forward()) return -2;
 			for (int l = 0; l < c->n; l++) if (c->enc.entropy().set_frame_header(l, header(c->first + l))) return -6;
 			if (c->enc.entropy().launch()) return -2;
-			if (c->dec.after(c->enc.stream())) return -5;
+			// the parser only needs the headers and size fields (k_ent_layout): it runs beside k_ent_emit, the band decoder waits for the payloads
+			c->dec.entropy().set_producer_events(c->enc.entropy().headers_event(), c->enc.entropy().samples_event());
 			if (c->dec.entropy().set_samples_device(c->enc.entropy().device_sample(0), c->enc.entropy().sample_cap(), c->enc.entropy().device_sizes())) return -4;
 			if (c->dec.entropy().launch() || c->dec.launch_inverse(seed + (uint32_t)c->first)) return -5;
 		}

@@ -28,6 +28,10 @@ public:
 	int total_segments() const { return total_segs_; }
 	// HIP-event time of kernel k of the last launch() (0 k_ent_count, 1 k_ent_scan, 2 k_ent_layout, 3 k_ent_emit); valid once the stream was synchronised
 	float kernel_ms(int k);
+	// Events of the last launch() on the encoder's stream: every sample's header, size fields and raw lowpass bands are in place
+	// (k_ent_layout done) / the samples are complete (k_ent_emit done).  A consumer on another stream can parse behind the first.
+	void *headers_event() const { return ev_[3]; }
+	void *samples_event() const { return ev_[4]; }
 private:
 	struct Host; Host *host_;           // host mirrors of the job tables (types live in the kernel headers)
 	void release();
@@ -59,6 +63,9 @@ public:
 	// All n samples already in HBM (sample i at d_samples + i * stride_bytes, its size in d_sizes[i]): nothing touches the host,
 	// k_dec_parse walks the tag streams on the GPU.  Stays in force until a set_sample_host()/set_sample_device() call.
 	int set_samples_device(const uint8_t *d_samples, size_t stride_bytes, const uint32_t *d_sizes);
+	// Optional, for device-resident samples still being written by another stream: the next launch() lets k_dec_parse wait for
+	// `headers` only (it reads the tag stream, not the coded payloads) and the band decoder for `payloads`.
+	void set_producer_events(void *headers, void *payloads) { ev_headers_ = headers; ev_payloads_ = payloads; }
 	int launch();                        // async: (H2D samples, job tables | k_dec_parse), k_dec_bands_par + k_dec_lowpass
 	int check();                         // after the stream was synchronised: 0 when every band decoded cleanly
 	float kernel_ms(int k);              // last launch(): 0 k_dec_parse (device-resident samples only), 1 k_dec_bands(_par), 2 k_dec_lowpass
@@ -69,10 +76,12 @@ private:
 	int16_t *d_coeffs_ = nullptr;
 	uint8_t *d_samples_ = nullptr, *h_samples_ = nullptr;
 	void *d_tables_ = nullptr, *d_bandjobs_ = nullptr, *d_lowjobs_ = nullptr, *d_plan_ = nullptr;
+	void *ev_headers_ = nullptr, *ev_payloads_ = nullptr;
 	const uint8_t *ext_samples_ = nullptr; size_t ext_stride_ = 0; const uint32_t *ext_sizes_ = nullptr;   // set_samples_device()
 	int *d_errors_ = nullptr, *h_errors_ = nullptr;
 	bool lane_kernel_ = false;
-	void *ev_[4] = {nullptr, nullptr, nullptr, nullptr}; bool timed_ = false;
+	void *ev_[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; bool timed_ = false;    // [4]: end of k_dec_parse when the band decoder waits for a second event behind it
+	bool parse_end_ = false;
 };
 
 } // namespace cfhd

@@ -242,9 +242,13 @@ int GpuEntropyDecoder::launch()
 		const int nch = plan_.num_channels, nb = n_ * nch * 9;
 		HIPCHK(hipMemsetAsync(d_errors_, 0, sizeof(int), st));
 		(void)hipGetLastError();
+		if (ev_headers_) HIPCHK(hipStreamWaitEvent(st, (hipEvent_t)ev_headers_, 0));
 		HIPCHK(hipEventRecord((hipEvent_t)ev_[0], st));
 		dev::k_dec_parse<<<n_, dev::DEC_PARSE_THREADS, 0, st>>>(ext_samples_, ext_stride_, ext_sizes_, n_,
 			(const dev::DecPlan *)d_plan_, d_coeffs_, coeff_stride_, (dev::DecBandJob *)d_bandjobs_, (dev::DecLowpassJob *)d_lowjobs_, d_errors_);
+		parse_end_ = ev_payloads_ != nullptr;
+		if (parse_end_) { HIPCHK(hipEventRecord((hipEvent_t)ev_[4], st)); HIPCHK(hipStreamWaitEvent(st, (hipEvent_t)ev_payloads_, 0)); }
+		ev_headers_ = ev_payloads_ = nullptr;
 		HIPCHK(hipEventRecord((hipEvent_t)ev_[1], st));
 		// few frames: the latency shape (the launch lasts as long as the longest band's serial steps); many: the throughput shape
 		if (n_ <= kLowLatencyFrames) dev::k_dec_bands_par_ll<<<nb, dev::DECP_LL_THREADS, 0, st>>>((const dev::DecBandJob *)d_bandjobs_, (const dev::DecTables *)d_tables_, d_errors_);
@@ -257,6 +261,7 @@ int GpuEntropyDecoder::launch()
 		HIPCHK(hipMemcpyAsync(h_errors_, d_errors_, sizeof(int), hipMemcpyDeviceToHost, st));
 		return 0;
 	}
+	parse_end_ = false;
 	const bool lane_kernel = lane_kernel_;
 	dev::DecBandJob *fb = host_->flat_bands; dev::DecLowpassJob *fl = host_->flat_lows;
 	size_t nfb = 0, nfl = 0, per_frame = 0;
@@ -294,7 +299,8 @@ int GpuEntropyDecoder::check() { return *h_errors_ ? -1 : 0; }
 float GpuEntropyDecoder::kernel_ms(int k)
 {
 	float ms = 0;
-	if (!timed_ || k < 0 || k > 2 || hipEventElapsedTime(&ms, (hipEvent_t)ev_[k], (hipEvent_t)ev_[k + 1]) != hipSuccess) { (void)hipGetLastError(); return 0; }
+	void *end = (k == 0 && parse_end_) ? ev_[4] : ev_[k + 1];      // the parser's own end, not the start of the band decoder that waited for the payloads
+	if (!timed_ || k < 0 || k > 2 || hipEventElapsedTime(&ms, (hipEvent_t)ev_[k], (hipEvent_t)end) != hipSuccess) { (void)hipGetLastError(); return 0; }
 	return ms;
 }
 
