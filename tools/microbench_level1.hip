@@ -9,16 +9,6 @@
 #include <stdio.h>
 #include <vector>
 using namespace cfhd::dev;
-template <int PAD> __device__ __forceinline__ void lds_pad() { __shared__ uint32_t pad[PAD / 4]; if (threadIdx.x == 1023) pad[threadIdx.x] = 1; asm volatile("" :: "v"(pad[0]) : "memory"); }
-__global__ void __launch_bounds__(NTHREADS) mb_inv_strip_occ2(const InvYuvJob *jobs, uint32_t seed) { inv_yuv422_strip<16, true>(jobs, seed); }
-__global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) mb_inv_strip_occ1(const InvYuvJob *jobs, uint32_t seed) { inv_yuv422_strip<16, true>(jobs, seed); }
-__global__ void __launch_bounds__(NTHREADS) mb_inv_strip32(const InvYuvJob *jobs, uint32_t seed) { inv_yuv422_strip<32>(jobs, seed); }
-__global__ void __launch_bounds__(NTHREADS) mb_inv_strip8(const InvYuvJob *jobs, uint32_t seed) { inv_yuv422_strip<8>(jobs, seed); }
-__global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(5, 5))) mb_inv_strip16_w5(const InvYuvJob *jobs, uint32_t seed) { inv_yuv422_strip<16>(jobs, seed); }
-__global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(5, 5))) mb_inv_strip32_w5(const InvYuvJob *jobs, uint32_t seed) { inv_yuv422_strip<32>(jobs, seed); }
-__global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) mb_fwd_strip32_w4(const FwdYuvJob *jobs) { fwd_yuv422_strip<32>(jobs); }
-__global__ void __launch_bounds__(NTHREADS) mb_fwd_strip32(const FwdYuvJob *jobs) { fwd_yuv422_strip<32>(jobs); }
-__global__ void __launch_bounds__(NTHREADS) mb_fwd_strip8(const FwdYuvJob *jobs) { fwd_yuv422_strip<8>(jobs); }
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
@@ -143,26 +133,21 @@ int main(int argc, char **argv)
 	hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
 	dim3 grid((w + ITW - 1) / ITW, (h + ITH - 1) / ITH, n);
 	const double bytes = (double)(frame_in + frame_out) * n;
-	for (int variant = 0; variant < 8; variant++) {
-
-		const char *name = variant == 0 ? "tile" : variant == 1 ? "access" : variant == 2 ? "wide" : variant == 3 ? "strip" : variant == 4 ? "str32" : variant == 5 ? "str8" : variant == 6 ? "late" : "latew6";
+	for (int variant = 0; variant < 4; variant++) {
+		const char *name = variant == 0 ? "tile" : variant == 1 ? "access" : variant == 2 ? "wide" : "strip";
 		float best = 1e9f, sum = 0;
 		for (int r = 0; r < reps + 3; r++) {
 			CK(hipEventRecord(e0, st));
 			if (variant == 0) k_inv_yuv422<<<grid, NTHREADS, 0, st>>>(d_jobs, 1u);
 			else if (variant == 1) mb_access<<<grid, NTHREADS, 0, st>>>(d_jobs);
 			else if (variant == 2) mb_wide<<<grid, NTHREADS, 0, st>>>(d_jobs);
-			else if (variant == 3) k_inv_yuv422_strip<<<dim3(1, (h + SR - 1) / SR, n), NTHREADS, 0, st>>>(d_jobs, 1u);
-			else if (variant == 4) mb_inv_strip32<<<dim3(1, (h + 31) / 32, n), NTHREADS, 0, st>>>(d_jobs, 1u);
-			else if (variant == 5) mb_inv_strip8<<<dim3(1, (h + 7) / 8, n), NTHREADS, 0, st>>>(d_jobs, 1u);
-			else if (variant == 6) mb_inv_strip_occ2<<<dim3(1, (h + 15) / 16, n), NTHREADS, 0, st>>>(d_jobs, 1u);
-			else mb_inv_strip_occ1<<<dim3(1, (h + 15) / 16, n), NTHREADS, 0, st>>>(d_jobs, 1u);
+			else k_inv_yuv422_strip<<<dim3((w / SBLK + SSEG - 1) / SSEG, (h + SR - 1) / SR, n), NTHREADS, 0, st>>>(d_jobs, 1u);
 			CK(hipEventRecord(e1, st));
 			CK(hipStreamSynchronize(st));
 			float ms; CK(hipEventElapsedTime(&ms, e0, e1));
 			if (r >= 3) { sum += ms; if (ms < best) best = ms; }
 		}
-		printf("%-7s frames %d  avg %.3f ms  best %.3f ms  %.0f GB/s (avg)\n", name, n, sum / reps, best, bytes / (sum / reps) * 1e-6);
+		printf("inv %-7s frames %d  avg %.3f ms  best %.3f ms  %.0f GB/s (avg)\n", name, n, sum / reps, best, bytes / (sum / reps) * 1e-6);
 	}
 	// ---- forward level 1: k_fwd_yuv422 (LDS tiles) vs k_fwd_yuv422_strip
 	{
@@ -190,21 +175,18 @@ int main(int argc, char **argv)
 		}
 		CK(hipMemcpy(d_fj, fj.data(), sizeof(FwdYuvJob) * n, hipMemcpyHostToDevice));
 		const double fb = (double)(fbytes + obytes) * n;
-		for (int variant = 0; variant < 5; variant++) {
+		for (int variant = 0; variant < 2; variant++) {
 			float best = 1e9f, sum = 0;
 			for (int r = 0; r < reps + 3; r++) {
 				CK(hipEventRecord(e0, st));
 				if (variant == 0) k_fwd_yuv422<<<dim3((W / 2 + TW - 1) / TW, (1080 / 2 + TH - 1) / TH, n), NTHREADS, 0, st>>>(d_fj);
-				else if (variant == 1) k_fwd_yuv422_strip<<<dim3(1, (1080 / 2 + SRF - 1) / SRF, n), NTHREADS, 0, st>>>(d_fj);
-				else if (variant == 2) mb_fwd_strip32<<<dim3(1, (1080 / 2 + 31) / 32, n), NTHREADS, 0, st>>>(d_fj);
-				else if (variant == 3) mb_fwd_strip8<<<dim3(1, (1080 / 2 + 7) / 8, n), NTHREADS, 0, st>>>(d_fj);
-				else mb_fwd_strip32_w4<<<dim3(1, (1080 / 2 + 31) / 32, n), NTHREADS, 0, st>>>(d_fj);
+				else k_fwd_yuv422_strip<<<dim3((W / 16 + SSEG - 1) / SSEG, (1080 / 2 + SRF - 1) / SRF, n), NTHREADS, 0, st>>>(d_fj);
 				CK(hipEventRecord(e1, st));
 				CK(hipStreamSynchronize(st));
 				float ms; CK(hipEventElapsedTime(&ms, e0, e1));
 				if (r >= 3) { sum += ms; if (ms < best) best = ms; }
 			}
-			printf("fwd %-5s frames %d  avg %.3f ms  best %.3f ms  %.0f GB/s (avg)\n", variant == 0 ? "tile" : variant == 1 ? "strip" : variant == 2 ? "str32" : variant == 3 ? "str8" : "s32w4", n, sum / reps, best, fb / (sum / reps) * 1e-6);
+			printf("fwd %-7s frames %d  avg %.3f ms  best %.3f ms  %.0f GB/s (avg)\n", variant ? "strip" : "tile", n, sum / reps, best, fb / (sum / reps) * 1e-6);
 		}
 	}
 	return 0;
