@@ -110,7 +110,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=256, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=512, help="frames per step per GPU")
     ap.add_argument("--threads", type=int, default=0, help="host entropy threads per rank (0 = cores / ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
