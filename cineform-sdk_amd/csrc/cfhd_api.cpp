@@ -319,7 +319,7 @@ struct EncoderPool {
 
 // ---- decoder ----
 struct Decoder {
-	ParsedSample header; bool prepared = false;
+	ParsedSample header; bool prepared = false, half = false;
 	uint32_t out_format = 0; int out_kind = 0;
 	FramePlan plan;
 	DecodeBatch batch; bool batch_ready = false;
@@ -667,8 +667,12 @@ CFHD_Error CFHD_PrepareToDecode(CFHD_DecoderRef ref, int, int, CFHD_PixelFormat 
 	if (!ref || !sample) return ERR_INVALID_ARGUMENT;
 	Decoder *d = (Decoder *)ref;
 	if (parse_sample((const uint8_t *)sample, size, &d->header) < 0) return ERR_BADSAMPLE;
-	if (resolution != 1 && resolution != 0) return ERR_BAD_RESOLUTION;                 // full resolution only (round 1 scope)
+	// CFHD_DECODED_RESOLUTION_FULL (1; 0 = unknown is taken as full) and, for 4:2:2 samples, _HALF (2): the level-1 lowpass planes shown as
+	// the picture (decoder.c:14124).  Quarter / thumbnail resolutions are not built.
+	if (resolution != 1 && resolution != 0 && resolution != 2) return ERR_BAD_RESOLUTION;
+	const bool half = resolution == 2;
 	const int encf = d->header.encoded_format;
+	if (half && encf != ENC_YUV422) return ERR_BAD_RESOLUTION;
 	if ((encf != ENC_YUV422 && encf != ENC_RGB444 && encf != ENC_RGBA4444) || d->header.transform_type != 0) return ERR_BADFORMAT;
 	int kind = pixel_kind_of(fmt);
 	if (kind == PIX_NONE) return ERR_BADFORMAT;
@@ -680,9 +684,9 @@ CFHD_Error CFHD_PrepareToDecode(CFHD_DecoderRef ref, int, int, CFHD_PixelFormat 
 	bool ok;
 	plan_from_sample(d->header, kind, &d->plan, &ok);
 	if (!ok) return ERR_BADSAMPLE;
-	d->out_format = fmt; d->out_kind = kind; d->prepared = true; d->batch_ready = false;
-	if (aw) *aw = d->header.width;
-	if (ah) *ah = d->header.display_height;
+	d->out_format = fmt; d->out_kind = kind; d->prepared = true; d->batch_ready = false; d->half = half;
+	if (aw) *aw = half ? d->header.width / 2 : d->header.width;
+	if (ah) *ah = half ? d->header.display_height / 2 : d->header.display_height;
 	if (af) *af = fmt;
 	return ERR_OKAY;
 }
@@ -733,8 +737,8 @@ CFHD_Error CFHD_DecodeSample(CFHD_DecoderRef ref, void *sample, size_t size, voi
 	const uint8_t *s = (const uint8_t *)sample;
 	ParsedSample ps;
 	auto fail_zero = [&](int err) {                                               // decode failure zero-fills the output (decoder.c:11850-11859)
-		int rowbytes = packed_frame_pitch(d->out_kind, d->plan.width);
-		for (int r = 0; r < d->plan.display_height; r++) memset((uint8_t *)out + (ptrdiff_t)r * pitch, 0, (size_t)rowbytes);
+		const int rowbytes = packed_frame_pitch(d->out_kind, d->half ? d->plan.width / 2 : d->plan.width), rows = d->half ? d->plan.display_height / 2 : d->plan.display_height;
+		for (int r = 0; r < rows; r++) memset((uint8_t *)out + (ptrdiff_t)r * pitch, 0, (size_t)rowbytes);
 		return err;
 	};
 	if (parse_sample(s, size, &ps) != 0) return fail_zero(ERR_BADSAMPLE);
@@ -743,7 +747,7 @@ CFHD_Error CFHD_DecodeSample(CFHD_DecoderRef ref, void *sample, size_t size, voi
 	// interlaced samples (no SAMPLE_FLAGS tag; it lies behind the 512 bytes CFHD_PrepareToDecode sees): the inverse field transform is not built
 	if (!ps.progressive) return fail_zero(ERR_BADFORMAT);
 	if (!d->batch_ready) {
-		if (d->batch.prepare(d->plan, 1, d->out_kind, true)) return ERR_INTERNAL;
+		if (d->batch.prepare(d->plan, 1, d->out_kind, true, d->half)) return ERR_INTERNAL;
 		if (gpu_entropy_enabled() && d->batch.prepare_entropy((size_t)d->plan.width * d->plan.height * pixel_bytes_of(d->out_kind) + 65536)) return ERR_INTERNAL;
 		d->batch_ready = true;
 	}

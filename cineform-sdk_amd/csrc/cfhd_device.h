@@ -62,7 +62,8 @@ class DecodeBatch {
 public:
 	DecodeBatch();
 	~DecodeBatch();
-	int prepare(const FramePlan &plan, int nframes, int out_pixel_kind, bool own_output);
+	// half: CFHD_DECODED_RESOLUTION_HALF of 4:2:2 samples -- the last wavelet level is not run, the level-1 lowpass planes are the picture
+	int prepare(const FramePlan &plan, int nframes, int out_pixel_kind, bool own_output, bool half = false);
 	int nframes() const { return n_; }
 	const FramePlan &plan() const { return plan_; }
 	int16_t *host_coeffs(int i) { return h_coeff_ + (size_t)i * plan_.final_elems; }   // host entropy decoder writes here
@@ -87,11 +88,11 @@ private:
 	void release();
 	int sync_jobs();
 	FramePlan plan_;
-	int n_ = 0, out_kind_ = 0; bool own_output_ = false, jobs_dirty_ = true;
+	int n_ = 0, out_kind_ = 0; bool own_output_ = false, jobs_dirty_ = true, half_ = false;
 	void *stream_ = nullptr, *ev0_ = nullptr, *ev1_ = nullptr, *evl_[2] = {nullptr, nullptr};
 	float level_ms_[3] = {0, 0, 0};
 	int16_t *d_coeff_ = nullptr, *h_coeff_ = nullptr;
-	uint8_t *d_out_ = nullptr, *h_out_ = nullptr; size_t frame_bytes_ = 0; int out_pitch_ = 0;
+	uint8_t *d_out_ = nullptr, *h_out_ = nullptr; size_t frame_bytes_ = 0; int out_pitch_ = 0, out_rows_ = 0;
 	void *d_jobs_ = nullptr, *h_jobs_ = nullptr; size_t jobs_bytes_ = 0;
 	float kernel_ms_ = 0;
 	bool timed_ = false;

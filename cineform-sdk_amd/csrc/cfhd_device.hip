@@ -60,7 +60,7 @@ EncJobs enc_jobs_at(void *base, int n, int nch)
 }
 size_t enc_jobs_bytes(int n, int nch) { return (size_t)n * sizeof(dev::FwdYuvJob) + 3 * (size_t)n * nch * sizeof(dev::FwdPlaneJob) + (size_t)n * sizeof(dev::BayerJob); }
 
-struct DecJobs { dev::InvPlaneJob *l3, *l2; dev::InvYuvJob *yuv; dev::InvPlaneJob *l1; /* last level of the 4:4:4(:4) formats (k_inv_packed16) */ };
+struct DecJobs { dev::InvPlaneJob *l3, *l2; dev::InvYuvJob *yuv; dev::InvPlaneJob *l1; /* last level of the 4:4:4(:4) formats (k_inv_packed16) */ dev::HalfYuvJob *half; /* [n] half-resolution output */ };
 DecJobs dec_jobs_at(void *base, int n, int nch)
 {
 	DecJobs j;
@@ -68,9 +68,10 @@ DecJobs dec_jobs_at(void *base, int n, int nch)
 	j.l2 = j.l3 + (size_t)n * nch;
 	j.yuv = (dev::InvYuvJob *)(j.l2 + (size_t)n * nch);
 	j.l1 = (dev::InvPlaneJob *)(j.yuv + n);
+	j.half = (dev::HalfYuvJob *)(j.l1 + (size_t)n * nch);
 	return j;
 }
-size_t dec_jobs_bytes(int n, int nch) { return 3 * (size_t)n * nch * sizeof(dev::InvPlaneJob) + (size_t)n * sizeof(dev::InvYuvJob); }
+size_t dec_jobs_bytes(int n, int nch) { return 3 * (size_t)n * nch * sizeof(dev::InvPlaneJob) + (size_t)n * sizeof(dev::InvYuvJob) + (size_t)n * sizeof(dev::HalfYuvJob); }
 
 // Word of component plane c inside an interleaved 16-bit pixel: planes are G, R, B(, A) (frame.c:6128-6157, convert.c:6750-6752),
 // RG48 pixels are R, G, B; b64a pixels are A, R, G, B (frame.c:6676-6683).
@@ -409,11 +410,13 @@ void DecodeBatch::release()
 	d_out_ = h_out_ = nullptr; d_coeff_ = h_coeff_ = nullptr; d_jobs_ = h_jobs_ = nullptr; stream_ = ev0_ = ev1_ = nullptr; n_ = 0;
 }
 
-int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool own_output)
+int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool own_output, bool half)
 {
 	int rc = device_init();
 	if (rc) return rc;
 	release();
+	half_ = half;
+	if (half && !((out_kind == PIX_YUY2 || out_kind == PIX_2VUY) && plan.encoded_format == ENC_YUV422)) { g_err = "half resolution is built for 4:2:2 samples only"; return -2; }
 	const bool yuv_ok = (out_kind == PIX_YUY2 || out_kind == PIX_2VUY) && plan.encoded_format == ENC_YUV422;
 	const bool rgb_ok = ((out_kind == PIX_RG48 && plan.encoded_format == ENC_RGB444) || (out_kind == PIX_B64A && plan.encoded_format == ENC_RGBA4444)) &&
 	                    plan.ch[0].band[0][0].width >= 16;   // k_inv_packed16's tail-column rule assumes the reference's vector path
@@ -423,8 +426,9 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 	HIPCHK(hipEventCreate((hipEvent_t *)&ev0_));
 	HIPCHK(hipEventCreate((hipEvent_t *)&ev1_));
 	for (int k = 0; k < 2; k++) HIPCHK(hipEventCreate((hipEvent_t *)&evl_[k]));
-	out_pitch_ = packed_frame_pitch(out_kind, plan.width);
-	frame_bytes_ = (size_t)out_pitch_ * plan.display_height;
+	out_rows_ = half ? plan.display_height / 2 : plan.display_height;
+	out_pitch_ = packed_frame_pitch(out_kind, half ? plan.width / 2 : plan.width);
+	frame_bytes_ = (size_t)out_pitch_ * out_rows_;
 	if (own_output) {
 		HIPCHK(hipMalloc((void **)&d_out_, frame_bytes_ * n_));
 		HIPCHK(hipHostMalloc((void **)&h_out_, frame_bytes_ * n_, hipHostMallocDefault));
@@ -465,6 +469,12 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 			}
 			continue;
 		}
+		if (half) {
+			dev::HalfYuvJob &hj = j.half[i];
+			for (int c = 0; c < 3; c++) { hj.ll[c] = base + plan.ch[c].band[0][0].offset; hj.pitch[c] = plan.ch[c].band[0][0].pitch; }
+			hj.width = plan.ch[0].band[0][0].width; hj.rows = out_rows_; hj.uyvy = out_kind == PIX_2VUY;
+			hj.out = own_output ? d_out_ + frame_bytes_ * i : nullptr; hj.out_pitch = out_pitch_;
+		}
 		dev::InvYuvJob &y = j.yuv[i];
 		for (int c = 0; c < 3; c++) { y.band_pitch[c] = plan.ch[c].band[0][0].pitch; for (int b = 0; b < 4; b++) y.band[c][b] = base + plan.ch[c].band[0][b].offset; }
 		y.width = plan.ch[0].band[0][0].width; y.height = plan.ch[0].band[0][0].height; y.display_height = plan.display_height;
@@ -477,6 +487,7 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 
 int DecodeBatch::prepare_entropy(size_t sample_cap)
 {
+	ent_.set_skip_level1(half_);                         // half resolution never looks at the level-1 highpass bands
 	int rc = ent_.prepare(plan_, n_, d_coeff_, plan_.coeff_elems, sample_cap, out_kind_, stream_);
 	ent_ready_ = rc == 0;
 	return rc;
@@ -511,6 +522,7 @@ int DecodeBatch::set_device_output(int i, void *d_out, int pitch)
 		jobs_dirty_ = true;
 		return 0;
 	}
+	if (half_) { j.half[i].out = (uint8_t *)d_out; j.half[i].out_pitch = pitch; jobs_dirty_ = true; return 0; }
 	if (j.yuv[i].out != d_out || j.yuv[i].out_pitch != pitch) { j.yuv[i].out = (uint8_t *)d_out; j.yuv[i].out_pitch = pitch; jobs_dirty_ = true; }
 	return 0;
 }
@@ -553,7 +565,10 @@ int DecodeBatch::launch_inverse(uint32_t dither_seed)
 		dev::k_inv_plane<<<grid, dev::NTHREADS, 0, st>>>(jobs);
 		HIPCHK(hipEventRecord((hipEvent_t)evl_[2 - lv], st));
 	}
-	if (is_packed16(out_kind_)) {
+	if (half_) {
+		const BandDesc &b = plan_.ch[0].band[0][0];
+		dev::k_half_yuv422<<<dim3((b.width / 8 + dev::NTHREADS - 1) / dev::NTHREADS, out_rows_, n_), dev::NTHREADS, 0, st>>>(j.half);
+	} else if (is_packed16(out_kind_)) {
 		const BandDesc &b = plan_.ch[0].band[0][0];
 		dim3 grid(((b.width + dev::ITW - 1) / dev::ITW) * nch, (b.height + dev::ITH - 1) / dev::ITH, n_);
 		dev::k_inv_packed16<<<grid, dev::NTHREADS, 0, st>>>(j.l1, nch);
@@ -606,7 +621,7 @@ int DecodeBatch::finish_frame(int i, void *out, int pitch)
 	const uint8_t *src = h_out_ + frame_bytes_ * i;
 	uint8_t *dst = (uint8_t *)out;
 	if (pitch == out_pitch_) memcpy(dst, src, frame_bytes_);
-	else for (int r = 0; r < plan_.display_height; r++) memcpy(dst + (ptrdiff_t)r * pitch, src + (size_t)r * out_pitch_, (size_t)out_pitch_);
+	else for (int r = 0; r < out_rows_; r++) memcpy(dst + (ptrdiff_t)r * pitch, src + (size_t)r * out_pitch_, (size_t)out_pitch_);
 	return 0;
 }
 

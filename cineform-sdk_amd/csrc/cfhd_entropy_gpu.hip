@@ -228,7 +228,7 @@ int GpuEntropyDecoder::set_sample_device(int i, const uint8_t *d_sample, const u
 	if (parse_sample(host_copy, size, &ps) != 0) return -2;
 	if (ps.width != plan_.width || ps.display_height != plan_.display_height || ps.encoded_format != plan_.encoded_format || ps.num_channels != plan_.num_channels) return -3;
 	host_->bands[i].clear(); host_->lows[i].clear(); host_->host_bytes[i] = 0;
-	if (!dec_build_jobs(ps, plan_, d_sample, d_coeffs_ + (size_t)i * coeff_stride_, out_kind_, &host_->bands[i], &host_->lows[i])) return -4;
+	if (!dec_build_jobs(ps, plan_, d_sample, d_coeffs_ + (size_t)i * coeff_stride_, out_kind_, &host_->bands[i], &host_->lows[i], skip_level1_)) return -4;
 	return 0;
 }
 

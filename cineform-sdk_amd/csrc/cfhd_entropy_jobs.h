@@ -111,7 +111,7 @@ inline dev::EntFrameJob ent_frame_job(const SampleTemplate &t, uint8_t *block_ad
 // Decode jobs of one parsed sample. `sample_addr` / `coeff_base` are the addresses the kernels will see (device, or host under
 // emulation).  Returns false when the sample does not match the plan.
 inline bool dec_build_jobs(const ParsedSample &ps, const FramePlan &plan, const uint8_t *sample_addr, int16_t *coeff_base, int out_pixel_kind,
-                           std::vector<dev::DecBandJob> *bands, std::vector<dev::DecLowpassJob> *lowpass)
+                           std::vector<dev::DecBandJob> *bands, std::vector<dev::DecLowpassJob> *lowpass, bool skip_level1 = false)
 {
 	for (int c = 0; c < plan.num_channels; c++) {
 		const ParsedBand &lp = ps.lowpass[c];
@@ -119,7 +119,7 @@ inline bool dec_build_jobs(const ParsedSample &ps, const FramePlan &plan, const 
 		if (!lp.present || lp.width != ll.width || lp.height != ll.height) return false;
 		dev::DecLowpassJob lj = { sample_addr + lp.offset, coeff_base + ll.offset, ll.width, ll.height, ll.pitch, lowpass_bias(plan.precision, ll.width, out_pixel_kind) };
 		lowpass->push_back(lj);
-		for (int lv = 0; lv < kNumLevels; lv++)
+		for (int lv = skip_level1 ? 1 : 0; lv < kNumLevels; lv++)      // half resolution: the level-1 highpass bands are not needed
 			for (int b = 1; b < 4; b++) {
 				const ParsedBand &pb = ps.high[c][lv][b];
 				const BandDesc &bd = plan.ch[c].band[lv][b];

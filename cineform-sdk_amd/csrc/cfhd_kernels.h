@@ -75,6 +75,13 @@ struct InvYuvJob {
 	uint8_t *out; int out_pitch;            // bytes
 };
 
+struct HalfYuvJob {                         // k_half_yuv422: the level-1 lowpass planes as a half-resolution packed 8-bit 4:2:2 frame
+	const int16_t *ll[3]; int pitch[3];     // LL1 of Y, V, U
+	int width, rows;                        // luma band columns (= output pixels per row), output rows
+	int uyvy;
+	uint8_t *out; int out_pitch;            // bytes
+};
+
 struct FwdFrameJob {                        // k_fwd_frame_yuv422: interlaced level 1 of a packed 8-bit 4:2:2 frame
 	const uint8_t *in; int in_pitch;        // bytes
 	int width, height, display_height;      // luma samples, picture rows; rows >= display_height read as 0x80
@@ -1422,6 +1429,39 @@ __global__ void __launch_bounds__(NTHREADS) k_fwd_plane_strip(const FwdPlaneJob 
 			v.x = o[3][0]; v.y = o[3][1]; v.z = o[3][2]; v.w = o[3][3]; *(uint4 *)(out3 + at) = v;
 		}
 	}
+}
+
+// =============================================================================================
+// Half-resolution decode of 4:2:2 samples (CFHD_DECODED_RESOLUTION_HALF): the reference does not run the last wavelet level at all
+// and shows the level-1 lowpass planes, four times the 10-bit sample, as the picture: decoder.c:14124 -> :22883 CopyLowpass16sToBuffer
+// -> frame.c:11742 ConvertLowpass16s10bitToYUV, scalar loop: SATURATE_8U(value >> 4), bytes Y U Y V from the planes Y, U, V (channel
+// order of the codec: Y, V, U).  No dither.  One thread = 8 pixels = 16 output bytes.
+// =============================================================================================
+__device__ __forceinline__ uint32_t half_pair8(uint32_t v)       // two int16 lowpass values -> two 8-bit samples in 16-bit lanes
+{
+	int a = lo16(v) >> 4, b = hi16(v) >> 4;
+	a = a < 0 ? 0 : (a > 255 ? 255 : a); b = b < 0 ? 0 : (b > 255 ? 255 : b);
+	return (uint32_t)a | ((uint32_t)b << 16);
+}
+__global__ void __launch_bounds__(NTHREADS) k_half_yuv422(const HalfYuvJob *jobs)
+{
+	const HalfYuvJob &job = jobs[blockIdx.z];
+	const int row = blockIdx.y, c8 = (int)(blockIdx.x * NTHREADS + threadIdx.x);        // block of 8 pixels
+	if (8 * c8 >= job.width) return;
+	const cfhd_u4 y = CFHD_LDG128(job.ll[0] + (size_t)row * job.pitch[0] + 8 * c8);
+	const uint2 v = *(const uint2 *)(job.ll[1] + (size_t)row * job.pitch[1] + 4 * c8);
+	const uint2 u = *(const uint2 *)(job.ll[2] + (size_t)row * job.pitch[2] + 4 * c8);
+	const uint32_t yy[4] = { half_pair8(y.x), half_pair8(y.y), half_pair8(y.z), half_pair8(y.w) };      // (y0, y1) ...
+	const uint32_t vv[2] = { half_pair8(v.x), half_pair8(v.y) }, uu[2] = { half_pair8(u.x), half_pair8(u.y) };   // (c0, c1), (c2, c3)
+	uint32_t o[4];
+#pragma unroll
+	for (int k = 0; k < 4; k++) {                         // pixel pair k: luma pair k, chroma sample k
+		const uint32_t cu = (k & 1) ? uu[k >> 1] >> 16 : uu[k >> 1] & 0xffu, cv = (k & 1) ? vv[k >> 1] >> 16 : vv[k >> 1] & 0xffu;
+		const uint32_t y0 = yy[k] & 0xffu, y1 = yy[k] >> 16;
+		o[k] = job.uyvy ? (cu | (y0 << 8) | (cv << 16) | (y1 << 24)) : (y0 | (cu << 8) | (y1 << 16) | (cv << 24));
+	}
+	uint4 q; q.x = o[0]; q.y = o[1]; q.z = o[2]; q.w = o[3];
+	*(uint4 *)(job.out + (size_t)row * job.out_pitch + 16 * (size_t)c8) = q;
 }
 
 // =============================================================================================

@@ -162,14 +162,14 @@ def ref_encode_frames(frames, pitch, width, height, pixfmt=PIX_YUY2, encoded=ENC
     return out
 
 
-def ref_decode_sample(sample, width, height, pixfmt=PIX_YUY2):
-    """Decode through the reference's C ABI exactly as Example/TestCFHD.cpp:218-437 does (full resolution)."""
+def ref_decode_sample(sample, width, height, pixfmt=PIX_YUY2, resolution=1):
+    """Decode through the reference's C ABI exactly as Example/TestCFHD.cpp:218-437 does (resolution 1 = full, 2 = half)."""
     L = ref()
     dec = ctypes.c_void_p()
     assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
     aw = ctypes.c_int(); ah = ctypes.c_int(); af = ctypes.c_uint32()
     sb = ctypes.create_string_buffer(sample, len(sample))
-    assert L.CFHD_PrepareToDecode(dec, 0, 0, pixfmt, 1, 0, sb, 512, ctypes.byref(aw), ctypes.byref(ah), ctypes.byref(af)) == 0
+    assert L.CFHD_PrepareToDecode(dec, 0, 0, pixfmt, resolution, 0, sb, 512, ctypes.byref(aw), ctypes.byref(ah), ctypes.byref(af)) == 0
     pitch = ctypes.c_int32()
     assert L.CFHD_GetImagePitch(aw.value, af.value, ctypes.byref(pitch)) == 0
     out = np.zeros(pitch.value * ah.value + 64, dtype=np.uint8)
@@ -358,6 +358,32 @@ def oracle_inverse_rgb48(plan, coeffs, b64a=False):
     return out
 
 
+def half_resolution_model(Y, V, U, uyvy=0):
+    """Half-resolution picture of a 4:2:2 sample from its level-1 lowpass planes: SATURATE_8U(value >> 4), no dither
+    (frame.c:11742 ConvertLowpass16s10bitToYUV, scalar loop)."""
+    rows, w = Y.shape
+    out = np.zeros((rows, 2 * w), np.uint8)
+    yo, co = (1, 0) if uyvy else (0, 1)
+    out[:, yo::2] = np.clip(Y.astype(np.int32) >> 4, 0, 255)
+    out[:, co::4] = np.clip(U.astype(np.int32) >> 4, 0, 255)
+    out[:, co + 2::4] = np.clip(V.astype(np.int32) >> 4, 0, 255)
+    return out
+
+
+def oracle_half_resolution(plan, coeffs, uyvy=0):
+    """Levels 3 -> 2 -> 1 with the oracle, then the half-resolution model; rows = display height / 2."""
+    O = oracle()
+    work = coeffs.copy()
+    for c in range(3):
+        for lv in (2, 1):
+            d = plan.band[(c, lv, 0)]
+            bands = (c_i16p * 4)(*[plan.view(work, c, lv, b).ctypes.data_as(c_i16p) for b in range(4)])
+            dst = plan.view(work, c, lv - 1, 0)
+            O.orc_inv_spatial(bands, d["pitch"], d["width"], d["height"], plan.prescale[lv], dst.ctypes.data_as(c_i16p), plan.band[(c, lv - 1, 0)]["pitch"])
+    P = [plan.view(work, c, 0, 0)[:, : plan.band[(c, 0, 0)]["width"]] for c in range(3)]
+    return half_resolution_model(P[0], P[1], P[2], uyvy)[: plan.height // 2]
+
+
 def field_flicker_frame(w, h):
     """Interlaced torture picture: the two fields differ by nearly the full range and swap sign at vertical edges, so the
     difference-coded HL1 band holds quantized steps beyond +-250 (peak values)."""
@@ -468,14 +494,14 @@ def amd_last_error():
     return (L.cfhd_amd_last_error() or b"").decode()
 
 
-def amd_decode_sample(sample, pixfmt=PIX_YUY2, pitch=None, decoder=None):
+def amd_decode_sample(sample, pixfmt=PIX_YUY2, pitch=None, decoder=None, resolution=1):
     L = product()
     dec = decoder or ctypes.c_void_p()
     if decoder is None:
         assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
     aw = ctypes.c_int(); ah = ctypes.c_int(); af = ctypes.c_uint32()
     sb = ctypes.create_string_buffer(sample, len(sample))
-    rc = L.CFHD_PrepareToDecode(dec, 0, 0, pixfmt, 1, 0, sb, 512, ctypes.byref(aw), ctypes.byref(ah), ctypes.byref(af))
+    rc = L.CFHD_PrepareToDecode(dec, 0, 0, pixfmt, resolution, 0, sb, 512, ctypes.byref(aw), ctypes.byref(ah), ctypes.byref(af))
     assert rc == 0, "CFHD_PrepareToDecode -> %d" % rc
     p = ctypes.c_int32()
     assert L.CFHD_GetImagePitch(aw.value, af.value, ctypes.byref(p)) == 0

@@ -148,6 +148,14 @@ int emu_inv_yuv422_strip(int16_t **bands /*[3][4]*/, const int *band_pitch, int 
 	return 0;
 }
 
+void emu_half_yuv422(int16_t **ll /*[3]: Y, V, U*/, const int *pitch, int width, int rows, int uyvy, uint8_t *out, int out_pitch)
+{
+	HalfYuvJob job;
+	for (int c = 0; c < 3; c++) { job.ll[c] = ll[c]; job.pitch[c] = pitch[c]; }
+	job.width = width; job.rows = rows; job.uyvy = uyvy; job.out = out; job.out_pitch = out_pitch;
+	hipemu::launch(dim3((width / 8 + NTHREADS - 1) / NTHREADS, rows, 1), dim3(NTHREADS), [&] { k_half_yuv422(&job); });
+}
+
 // nplanes planes of the same geometry (plane k: in[k] -> out[4k..4k+3]) through one launch of k_fwd_plane_strip
 int emu_fwd_plane_strip(int16_t **in, int nplanes, int in_pitch, int width, int height, int prescale, const int *quant, int mpq, int16_t **out, int out_pitch)
 {

@@ -491,3 +491,30 @@ def test_yuy2_4k_two_segments():
     f, p = synth_yuy2(w, h, 21)
     mine = _check_encode([f], p, w, h)
     _check_decode(mine[0], f, w, h)
+
+
+@pytest.mark.parametrize("w,h,fmt", [(320, 240, PIX_YUY2), (336, 252, PIX_2VUY), (1920, 1080, PIX_YUY2)])
+def test_half_resolution_decode(w, h, fmt):
+    """CFHD_DECODED_RESOLUTION_HALF through the C ABI: levels 3 and 2 on the GPU (the level-1 highpass bands are not even entropy-decoded),
+    then k_half_yuv422.  No dither at this resolution, so the output equals the oracle model -- and the reference decoder -- byte for byte."""
+    f, p = synth_yuy2(w, h, 11)
+    sample = amd_encode_frames([f], p, w, h, fmt)[0]
+    uyvy = int(fmt == PIX_2VUY)
+    plan = Plan(w, h, pixkind=2 if uyvy else 1)
+    want = oracle_half_resolution(plan, host_decode_pyramid(sample, plan), uyvy)
+    out, pitch, aw, ah = amd_decode_sample(sample, fmt, resolution=2)
+    assert (aw, ah, pitch) == (w // 2, h // 2, w)
+    assert np.array_equal(out.reshape(ah, pitch), want)
+    if have_ref():
+        for attempt in range(3):
+            rout, rpitch = ref_decode_sample(sample, w, h, fmt, resolution=2)
+            if np.array_equal(rout.reshape(-1, rpitch)[:, :w], want): break
+        else:
+            raise AssertionError("the reference decoder never reproduced the model")
+    # quarter resolution is not built; RGB samples have no half-resolution path here
+    L = product()
+    dec = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
+    aw2 = ctypes.c_int(); ah2 = ctypes.c_int(); af2 = ctypes.c_uint32()
+    sb = ctypes.create_string_buffer(sample, len(sample))
+    assert L.CFHD_PrepareToDecode(dec, 0, 0, fmt, 3, 0, sb, 512, ctypes.byref(aw2), ctypes.byref(ah2), ctypes.byref(af2)) != 0
+    L.CFHD_CloseDecoder(dec)

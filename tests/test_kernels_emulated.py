@@ -101,6 +101,25 @@ def test_inv_plane(w, h, descale):
     assert np.array_equal(e[:, :2 * w], o)
 
 
+@pytest.mark.parametrize("w,rows,uyvy", [(8, 3, 0), (168, 5, 1), (960, 4, 0), (2056, 2, 1)])
+def test_half_resolution_output_kernel(w, rows, uyvy):
+    """k_half_yuv422: SATURATE_8U(lowpass >> 4) of the level-1 lowpass planes, interleaved Y U Y V / U Y V Y (pinned against the reference's
+    half-resolution decode in the GPU tests and, as this model, on the CPU: tests/test_oracle_vs_ref.py)."""
+    rng = np.random.default_rng(w + rows + uyvy)
+    planes, pitches = [], []
+    for c in range(3):
+        cw = w if c == 0 else w // 2
+        pitch = (cw + 7) // 8 * 8 + 8
+        p = rng.integers(-300, 4800, size=(rows, pitch)).astype(np.int16)
+        planes.append(p); pitches.append(pitch)
+    out = np.full((rows, 2 * w + 16), 9, np.uint8)
+    emu().emu_half_yuv422((c_i16p * 3)(*[p16(p) for p in planes]), iarr(pitches), w, rows, uyvy, p8(out), 2 * w + 16)
+    want = half_resolution_model(planes[0][:, :w], planes[1][:, :w // 2], planes[2][:, :w // 2], uyvy)
+    assert np.array_equal(out[:, :2 * w], want)
+    assert np.all(out[:, 2 * w:] == 9)
+    assert (want == 0).any() and (want == 255).any()
+
+
 @pytest.mark.parametrize("w,h,nplanes", [(16, 8, 9), (64, 16, 5), (240, 134, 3), (480, 66, 3), (960, 40, 2), (1024, 8, 1), (1040, 8, 1)])
 @pytest.mark.parametrize("prescale", [0, 2])
 def test_fwd_plane_strip_kernel(w, h, nplanes, prescale):

@@ -95,6 +95,23 @@ def test_reference_decode_lies_in_oracle_dither_interval(w, h, fmt):
     assert 0.3 < (rimg[differ] == hi[differ]).mean() < 0.7
 
 
+@pytest.mark.parametrize("w,h,fmt", [(320, 240, PIX_YUY2), (336, 252, PIX_YUY2), (720, 486, PIX_2VUY), (1920, 1080, PIX_YUY2)])
+def test_reference_half_resolution_decode_equals_model(w, h, fmt):
+    """CFHD_DECODED_RESOLUTION_HALF of a 4:2:2 sample: the reference stops in front of the last wavelet level and shows the level-1 lowpass
+    planes, SATURATE_8U(value >> 4), width / 2 x display height / 2, no dither -- byte for byte the oracle's levels 3 and 2 + this model."""
+    f, p = synth_yuy2(w, h, 7)
+    sample = ref_encode_frames([f], p, w, h, fmt)[0]
+    uyvy = int(fmt == PIX_2VUY)
+    plan = Plan(w, h, pixkind=2 if uyvy else 1)
+    want = oracle_half_resolution(plan, host_decode_pyramid(sample, plan), uyvy)
+    assert want.shape == (h // 2, w)
+    for attempt in range(3):                            # the reference's threaded decoder occasionally damages a frame: three attempts
+        out, pitch = ref_decode_sample(sample, w, h, fmt, resolution=2)
+        img = out.reshape(-1, pitch)[:, : w]
+        if img.shape[0] == h // 2 and np.array_equal(img, want): break
+    assert img.shape[0] == h // 2 and np.array_equal(img, want)
+
+
 @pytest.mark.parametrize("w,h", [(192, 96), (320, 240), (1920, 1080)])
 def test_reference_rg48_decode_equals_oracle(w, h):
     """Pins orc_inv_spatial_to_rgb48 (and the descale levels at 12 bits): the reference decoder's RG48 output of an RGB 4:4:4 sample is
