@@ -667,12 +667,12 @@ CFHD_Error CFHD_PrepareToDecode(CFHD_DecoderRef ref, int, int, CFHD_PixelFormat 
 	if (!ref || !sample) return ERR_INVALID_ARGUMENT;
 	Decoder *d = (Decoder *)ref;
 	if (parse_sample((const uint8_t *)sample, size, &d->header) < 0) return ERR_BADSAMPLE;
-	// CFHD_DECODED_RESOLUTION_FULL (1; 0 = unknown is taken as full) and, for 4:2:2 samples, _HALF (2): the level-1 lowpass planes shown as
-	// the picture (decoder.c:14124).  Quarter / thumbnail resolutions are not built.
+	// CFHD_DECODED_RESOLUTION_FULL (1; 0 = unknown is taken as full) and _HALF (2): the level-1 lowpass planes shown as the picture
+	// (decoder.c:14124, :26752).  Quarter / thumbnail resolutions are not built.
 	if (resolution != 1 && resolution != 0 && resolution != 2) return ERR_BAD_RESOLUTION;
 	const bool half = resolution == 2;
 	const int encf = d->header.encoded_format;
-	if (half && encf != ENC_YUV422) return ERR_BAD_RESOLUTION;
+
 	if ((encf != ENC_YUV422 && encf != ENC_RGB444 && encf != ENC_RGBA4444) || d->header.transform_type != 0) return ERR_BADFORMAT;
 	int kind = pixel_kind_of(fmt);
 	if (kind == PIX_NONE) return ERR_BADFORMAT;

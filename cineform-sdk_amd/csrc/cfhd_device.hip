@@ -60,7 +60,7 @@ EncJobs enc_jobs_at(void *base, int n, int nch)
 }
 size_t enc_jobs_bytes(int n, int nch) { return (size_t)n * sizeof(dev::FwdYuvJob) + 3 * (size_t)n * nch * sizeof(dev::FwdPlaneJob) + (size_t)n * sizeof(dev::BayerJob); }
 
-struct DecJobs { dev::InvPlaneJob *l3, *l2; dev::InvYuvJob *yuv; dev::InvPlaneJob *l1; /* last level of the 4:4:4(:4) formats (k_inv_packed16) */ dev::HalfYuvJob *half; /* [n] half-resolution output */ };
+struct DecJobs { dev::InvPlaneJob *l3, *l2; dev::InvYuvJob *yuv; dev::InvPlaneJob *l1; /* last level of the 4:4:4(:4) formats (k_inv_packed16) */ dev::HalfYuvJob *half; /* [n] half-resolution output */ dev::HalfPackedJob *halfp; /* [n] the same for the 4:4:4(:4) formats */ };
 DecJobs dec_jobs_at(void *base, int n, int nch)
 {
 	DecJobs j;
@@ -69,9 +69,10 @@ DecJobs dec_jobs_at(void *base, int n, int nch)
 	j.yuv = (dev::InvYuvJob *)(j.l2 + (size_t)n * nch);
 	j.l1 = (dev::InvPlaneJob *)(j.yuv + n);
 	j.half = (dev::HalfYuvJob *)(j.l1 + (size_t)n * nch);
+	j.halfp = (dev::HalfPackedJob *)(j.half + n);
 	return j;
 }
-size_t dec_jobs_bytes(int n, int nch) { return 3 * (size_t)n * nch * sizeof(dev::InvPlaneJob) + (size_t)n * sizeof(dev::InvYuvJob) + (size_t)n * sizeof(dev::HalfYuvJob); }
+size_t dec_jobs_bytes(int n, int nch) { return 3 * (size_t)n * nch * sizeof(dev::InvPlaneJob) + (size_t)n * sizeof(dev::InvYuvJob) + (size_t)n * sizeof(dev::HalfYuvJob) + (size_t)n * sizeof(dev::HalfPackedJob); }
 
 // Word of component plane c inside an interleaved 16-bit pixel: planes are G, R, B(, A) (frame.c:6128-6157, convert.c:6750-6752),
 // RG48 pixels are R, G, B; b64a pixels are A, R, G, B (frame.c:6676-6683).
@@ -416,7 +417,7 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 	if (rc) return rc;
 	release();
 	half_ = half;
-	if (half && !((out_kind == PIX_YUY2 || out_kind == PIX_2VUY) && plan.encoded_format == ENC_YUV422)) { g_err = "half resolution is built for 4:2:2 samples only"; return -2; }
+
 	const bool yuv_ok = (out_kind == PIX_YUY2 || out_kind == PIX_2VUY) && plan.encoded_format == ENC_YUV422;
 	const bool rgb_ok = ((out_kind == PIX_RG48 && plan.encoded_format == ENC_RGB444) || (out_kind == PIX_B64A && plan.encoded_format == ENC_RGBA4444)) &&
 	                    plan.ch[0].band[0][0].width >= 16;   // k_inv_packed16's tail-column rule assumes the reference's vector path
@@ -469,7 +470,13 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 			}
 			continue;
 		}
-		if (half) {
+		if (half && is_packed16(out_kind)) {
+			dev::HalfPackedJob &hp = j.halfp[i];
+			for (int c = 0; c < nch; c++) { hp.ll[c] = base + plan.ch[c].band[0][0].offset; hp.word[c] = packed_word_of_channel(out_kind, c); }
+			hp.pitch = plan.ch[0].band[0][0].pitch; hp.width = plan.ch[0].band[0][0].width; hp.rows = out_rows_; hp.nch = nch;
+			hp.shift = 16 - plan.precision - 2; hp.alpha = out_kind == PIX_B64A;
+			hp.out = own_output ? (uint16_t *)(d_out_ + frame_bytes_ * i) : nullptr; hp.out_pitch = out_pitch_;
+		} else if (half) {
 			dev::HalfYuvJob &hj = j.half[i];
 			for (int c = 0; c < 3; c++) { hj.ll[c] = base + plan.ch[c].band[0][0].offset; hj.pitch[c] = plan.ch[c].band[0][0].pitch; }
 			hj.width = plan.ch[0].band[0][0].width; hj.rows = out_rows_; hj.uyvy = out_kind == PIX_2VUY;
@@ -522,6 +529,7 @@ int DecodeBatch::set_device_output(int i, void *d_out, int pitch)
 		jobs_dirty_ = true;
 		return 0;
 	}
+	if (half_ && is_packed16(out_kind_)) { j.halfp[i].out = (uint16_t *)d_out; j.halfp[i].out_pitch = pitch; jobs_dirty_ = true; return 0; }
 	if (half_) { j.half[i].out = (uint8_t *)d_out; j.half[i].out_pitch = pitch; jobs_dirty_ = true; return 0; }
 	if (j.yuv[i].out != d_out || j.yuv[i].out_pitch != pitch) { j.yuv[i].out = (uint8_t *)d_out; j.yuv[i].out_pitch = pitch; jobs_dirty_ = true; }
 	return 0;
@@ -565,7 +573,10 @@ int DecodeBatch::launch_inverse(uint32_t dither_seed)
 		dev::k_inv_plane<<<grid, dev::NTHREADS, 0, st>>>(jobs);
 		HIPCHK(hipEventRecord((hipEvent_t)evl_[2 - lv], st));
 	}
-	if (half_) {
+	if (half_ && is_packed16(out_kind_)) {
+		const BandDesc &b = plan_.ch[0].band[0][0];
+		dev::k_half_packed16<<<dim3((b.width / 8 + dev::NTHREADS - 1) / dev::NTHREADS, out_rows_, n_), dev::NTHREADS, 0, st>>>(j.halfp);
+	} else if (half_) {
 		const BandDesc &b = plan_.ch[0].band[0][0];
 		dev::k_half_yuv422<<<dim3((b.width / 8 + dev::NTHREADS - 1) / dev::NTHREADS, out_rows_, n_), dev::NTHREADS, 0, st>>>(j.half);
 	} else if (is_packed16(out_kind_)) {

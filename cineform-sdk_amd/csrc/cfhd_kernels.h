@@ -82,6 +82,14 @@ struct HalfYuvJob {                         // k_half_yuv422: the level-1 lowpas
 	uint8_t *out; int out_pitch;            // bytes
 };
 
+struct HalfPackedJob {                      // k_half_packed16: level-1 lowpass planes of a 4:4:4(:4) sample as half-resolution 16-bit pixels
+	const int16_t *ll[4]; int pitch;        // LL1 of the component planes (G, R, B[, A])
+	int width, rows, nch;                   // band columns (= output pixels per row), output rows, components
+	int word[4];                            // word of plane c inside the pixel
+	int shift, alpha;                       // left shift to 16 bits (16 - precision - 2); alpha: plane 3 is the companded alpha of b64a
+	uint16_t *out; int out_pitch;           // bytes
+};
+
 struct FwdFrameJob {                        // k_fwd_frame_yuv422: interlaced level 1 of a packed 8-bit 4:2:2 frame
 	const uint8_t *in; int in_pitch;        // bytes
 	int width, height, display_height;      // luma samples, picture rows; rows >= display_height read as 0x80
@@ -1462,6 +1470,55 @@ __global__ void __launch_bounds__(NTHREADS) k_half_yuv422(const HalfYuvJob *jobs
 	}
 	uint4 q; q.x = o[0]; q.y = o[1]; q.z = o[2]; q.w = o[3];
 	*(uint4 *)(job.out + (size_t)row * job.out_pitch + 16 * (size_t)c8) = q;
+}
+
+// The same for RGB 4:4:4 -> RG48 and RGBA 4:4:4:4 -> b64a.  RG48: decoder.c:26752 CopyLowpassRGB444ToBuffer -> frame.c:7256
+// ConvertLowpassRGB444ToRGB48: value << (16 - precision - 2), saturated to [0, 65535].  b64a goes through the reference's planar
+// 16-bit rows as at full resolution (bayer.c:12900: clamped to 14 bits, then shifted; the alpha word expanded like k_inv_packed16's).  Pinned on the reference
+// decoder (tests/test_oracle_vs_ref.py).  One thread = 8 pixels = 3 or 4 16-byte words.
+__global__ void __launch_bounds__(NTHREADS) k_half_packed16(const HalfPackedJob *jobs)
+{
+	const HalfPackedJob &job = jobs[blockIdx.z];
+	const int row = blockIdx.y, c8 = (int)(blockIdx.x * NTHREADS + threadIdx.x);
+	if (8 * c8 >= job.width) return;
+	uint32_t px[8][2];                                   // pixel k: words 0, 1 in px[k][0], words 2, 3 in px[k][1]
+#pragma unroll
+	for (int k = 0; k < 8; k++) px[k][0] = px[k][1] = 0;
+	for (int c = 0; c < job.nch; c++) {
+		const cfhd_u4 v = CFHD_LDG128(job.ll[c] + (size_t)row * job.pitch + 8 * c8);
+		const uint32_t d[4] = { v.x, v.y, v.z, v.w };
+		const int wd = job.word[c];
+#pragma unroll
+		for (int k = 0; k < 8; k++) {
+			int x = (k & 1) ? hi16(d[k >> 1]) : lo16(d[k >> 1]);
+			// RG48: shifted, then saturated to 65535 (frame.c:7340); the planar 16-bit rows of the b64a route clamp to 14 bits first, so a
+			// clipped highlight reads 65532 there (bayer.c:12921-12934)
+			if (job.alpha) { const int top = 65535 >> job.shift; x = x < 0 ? 0 : (x > top ? top : x); }
+			x <<= job.shift;
+			uint32_t w16 = (uint32_t)(x < 0 ? 0 : (x > 65535 ? 65535 : x));
+			if (job.alpha && c == 3) w16 = expand_alpha16(w16);
+			const uint32_t placed = w16 << (16 * (wd & 1));
+			if (wd < 2) px[k][0] |= placed; else px[k][1] |= placed;    // (uniform) keeps the pixel registers statically indexed
+		}
+	}
+	uint8_t *dst = (uint8_t *)job.out + (size_t)row * job.out_pitch;
+	if (job.nch == 4) {
+		uint4 *o = (uint4 *)(dst + 64 * (size_t)c8);
+#pragma unroll
+		for (int q = 0; q < 4; q++) { uint4 t; t.x = px[2 * q][0]; t.y = px[2 * q][1]; t.z = px[2 * q + 1][0]; t.w = px[2 * q + 1][1]; o[q] = t; }
+	} else {
+		// three words per pixel: 8 pixels = 24 words = 12 dwords
+		uint32_t w[12];
+#pragma unroll
+		for (int k = 0; k < 8; k += 2) {                 // pixels k, k + 1 -> 3 dwords: (w0 w1) (w2 | w0') (w1' w2')
+			w[3 * (k >> 1)] = px[k][0];
+			w[3 * (k >> 1) + 1] = (px[k][1] & 0xffffu) | (px[k + 1][0] << 16);
+			w[3 * (k >> 1) + 2] = (px[k + 1][0] >> 16) | (px[k + 1][1] << 16);
+		}
+		uint4 *o = (uint4 *)(dst + 48 * (size_t)c8);
+#pragma unroll
+		for (int q = 0; q < 3; q++) { uint4 t; t.x = w[4 * q]; t.y = w[4 * q + 1]; t.z = w[4 * q + 2]; t.w = w[4 * q + 3]; o[q] = t; }
+	}
 }
 
 // =============================================================================================

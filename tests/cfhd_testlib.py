@@ -370,6 +370,45 @@ def half_resolution_model(Y, V, U, uyvy=0):
     return out
 
 
+def half16_equal(img, want, raw, nch):
+    """Reference output == model; for b64a a row may keep its companded alpha (`raw`): the reference marks the alpha as expanded from a
+    worker thread while others still convert rows (bayer.c:13871 / :16034)."""
+    if nch == 3: return np.array_equal(img, want)
+    if not all(np.array_equal(img[:, k::4], want[:, k::4]) for k in (1, 2, 3)): return False
+    rows = (img[:, 0::4] == want[:, 0::4]).all(axis=1) | (img[:, 0::4] == raw[:, 0::4]).all(axis=1)
+    return bool(rows.all())
+
+
+def half_resolution_model16(planes, b64a=False, expand_alpha=True):
+    """Half-resolution picture of an RGB 4:4:4 (RG48 out) or RGBA 4:4:4:4 (b64a out) sample from its level-1 lowpass planes G, R, B[, A]:
+    value << 2 saturated to 16 bits (frame.c:7256 ConvertLowpassRGB444ToRGB48); b64a: words A, R, G, B, alpha expanded as at full resolution."""
+    rows, w = planes[0].shape
+    if b64a: v = [np.clip(p.astype(np.int64), 0, 16383) << 2 for p in planes]      # the planar-row route clamps to 14 bits first (bayer.c:12921-12934)
+    else: v = [np.clip(p.astype(np.int64) << 2, 0, 65535) for p in planes]
+    if b64a:
+        a = np.clip((((v[3] >> 4) - 256) * 8 * 9400) >> 12, 0, 65535) if expand_alpha else v[3]
+        order = [a, v[1], v[0], v[2]]
+    else:
+        order = [v[1], v[0], v[2]]
+    out = np.zeros((rows, w * len(order)), np.uint16)
+    for k, p in enumerate(order): out[:, k::len(order)] = p
+    return out
+
+
+def oracle_half_resolution16(plan, coeffs, b64a=False, expand_alpha=True):
+    O = oracle()
+    work = coeffs.copy()
+    nch = plan.num_channels
+    for c in range(nch):
+        for lv in (2, 1):
+            d = plan.band[(c, lv, 0)]
+            bands = (c_i16p * 4)(*[plan.view(work, c, lv, b).ctypes.data_as(c_i16p) for b in range(4)])
+            dst = plan.view(work, c, lv - 1, 0)
+            O.orc_inv_spatial(bands, d["pitch"], d["width"], d["height"], plan.prescale[lv], dst.ctypes.data_as(c_i16p), plan.band[(c, lv - 1, 0)]["pitch"])
+    P = [plan.view(work, c, 0, 0)[: plan.height // 2, : plan.band[(c, 0, 0)]["width"]] for c in range(nch)]
+    return half_resolution_model16(P, b64a, expand_alpha)
+
+
 def oracle_half_resolution(plan, coeffs, uyvy=0):
     """Levels 3 -> 2 -> 1 with the oracle, then the half-resolution model; rows = display height / 2."""
     O = oracle()

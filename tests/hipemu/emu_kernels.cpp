@@ -148,6 +148,14 @@ int emu_inv_yuv422_strip(int16_t **bands /*[3][4]*/, const int *band_pitch, int 
 	return 0;
 }
 
+void emu_half_packed16(int16_t **ll, int nch, int pitch, int width, int rows, const int *word, int shift, int alpha, uint16_t *out, int out_pitch_bytes)
+{
+	HalfPackedJob job;
+	for (int c = 0; c < 4; c++) { job.ll[c] = c < nch ? ll[c] : nullptr; job.word[c] = c < nch ? word[c] : 0; }
+	job.pitch = pitch; job.width = width; job.rows = rows; job.nch = nch; job.shift = shift; job.alpha = alpha; job.out = out; job.out_pitch = out_pitch_bytes;
+	hipemu::launch(dim3((width / 8 + NTHREADS - 1) / NTHREADS, rows, 1), dim3(NTHREADS), [&] { k_half_packed16(&job); });
+}
+
 void emu_half_yuv422(int16_t **ll /*[3]: Y, V, U*/, const int *pitch, int width, int rows, int uyvy, uint8_t *out, int out_pitch)
 {
 	HalfYuvJob job;

@@ -518,3 +518,24 @@ def test_half_resolution_decode(w, h, fmt):
     sb = ctypes.create_string_buffer(sample, len(sample))
     assert L.CFHD_PrepareToDecode(dec, 0, 0, fmt, 3, 0, sb, 512, ctypes.byref(aw2), ctypes.byref(ah2), ctypes.byref(af2)) != 0
     L.CFHD_CloseDecoder(dec)
+
+
+@pytest.mark.skipif(not have_ref(), reason="Qbist generator lives in the reference build")
+@pytest.mark.parametrize("w,h,b64a", [(320, 240, 0), (1920, 1080, 0), (320, 240, 1), (1920, 1080, 1)])
+def test_half_resolution_decode_16bit(w, h, b64a):
+    """Half-resolution decode of RGB 4:4:4 -> RG48 and RGBA 4:4:4:4 -> b64a (k_half_packed16) = the model = the reference decoder."""
+    fmt, enc, kind, encname = (PIX_B64A, ENCODED_RGBA4444, "b64a", "4444") if b64a else (PIX_RG48, ENCODED_RGB444, "RG48", "444")
+    frames, pitch = qbist_frames(10, 1, w, h, fmt, alpha=1) if b64a else qbist_frames(10, 1, w, h, fmt)
+    sample = amd_encode_frames(frames, pitch, w, h, fmt, encoded=enc)[0]
+    plan = Plan(w, h, pixkind=PIXKIND[kind], enc=ENC[encname])
+    want = oracle_half_resolution16(plan, host_decode_pyramid(sample, plan), bool(b64a))
+    nch = 4 if b64a else 3
+    out, opitch, aw, ah = amd_decode_sample(sample, fmt, resolution=2)
+    assert (aw, ah) == (w // 2, h // 2)
+    assert np.array_equal(np.frombuffer(out.tobytes(), np.uint16).reshape(ah, opitch // 2)[:, : aw * nch], want)
+    raw = oracle_half_resolution16(plan, host_decode_pyramid(sample, plan), bool(b64a), expand_alpha=False)
+    for attempt in range(3):
+        rout, rpitch = ref_decode_sample(sample, w, h, fmt, resolution=2)
+        if half16_equal(np.frombuffer(rout.tobytes(), np.uint16).reshape(-1, rpitch // 2)[:, : aw * nch], want, raw, nch): break
+    else:
+        raise AssertionError("the reference decoder never reproduced the model")

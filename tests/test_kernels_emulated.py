@@ -101,6 +101,24 @@ def test_inv_plane(w, h, descale):
     assert np.array_equal(e[:, :2 * w], o)
 
 
+@pytest.mark.parametrize("w,rows,b64a", [(8, 2, 0), (160, 3, 1), (960, 2, 0), (2056, 2, 1)])
+def test_half_resolution_output_kernel_16bit(w, rows, b64a):
+    """k_half_packed16 = the model of the reference's half-resolution RG48 / b64a output (pinned in tests/test_oracle_vs_ref.py)."""
+    rng = np.random.default_rng(w + rows + b64a)
+    nch = 4 if b64a else 3
+    pitch = (w + 7) // 8 * 8 + 8
+    planes = [rng.integers(-200, 17000, size=(rows, pitch)).astype(np.int16) for _ in range(nch)]
+    want = half_resolution_model16([p[:, :w] for p in planes], bool(b64a))
+    words = [2, 1, 3, 0] if b64a else [1, 0, 2]
+    out = np.full((rows, w * nch + 8), 9, np.uint16)
+    E = emu()
+    E.emu_half_packed16.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    E.emu_half_packed16((c_i16p * nch)(*[p16(p) for p in planes]), nch, pitch, w, rows, iarr(words), 2, b64a, out.ctypes.data_as(ctypes.c_void_p), (w * nch + 8) * 2)
+    assert np.array_equal(out[:, : w * nch], want)
+    assert np.all(out[:, w * nch:] == 9)
+    assert (want == 0).any() and (want == 65535).any()
+
+
 @pytest.mark.parametrize("w,rows,uyvy", [(8, 3, 0), (168, 5, 1), (960, 4, 0), (2056, 2, 1)])
 def test_half_resolution_output_kernel(w, rows, uyvy):
     """k_half_yuv422: SATURATE_8U(lowpass >> 4) of the level-1 lowpass planes, interleaved Y U Y V / U Y V Y (pinned against the reference's

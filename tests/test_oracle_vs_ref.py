@@ -112,6 +112,23 @@ def test_reference_half_resolution_decode_equals_model(w, h, fmt):
     assert img.shape[0] == h // 2 and np.array_equal(img, want)
 
 
+@pytest.mark.parametrize("w,h,b64a", [(320, 240, 0), (336, 252, 0), (320, 240, 1), (1920, 1080, 1)])
+def test_reference_half_resolution_16bit_equals_model(w, h, b64a):
+    """CFHD_DECODED_RESOLUTION_HALF of RGB 4:4:4 -> RG48 and RGBA 4:4:4:4 -> b64a samples: lowpass << 2 saturated; alpha expanded."""
+    fmt, enc, kind, encname = (PIX_B64A, ENCODED_RGBA4444, "b64a", "4444") if b64a else (PIX_RG48, ENCODED_RGB444, "RG48", "444")
+    frames, pitch = qbist_frames(10, 1, w, h, fmt, alpha=1) if b64a else qbist_frames(10, 1, w, h, fmt)
+    sample = ref_encode_frames(frames, pitch, w, h, fmt, encoded=enc)[0]
+    plan = Plan(w, h, pixkind=PIXKIND[kind], enc=ENC[encname])
+    want = oracle_half_resolution16(plan, host_decode_pyramid(sample, plan), bool(b64a))
+    raw = oracle_half_resolution16(plan, host_decode_pyramid(sample, plan), bool(b64a), expand_alpha=False)
+    nch = 4 if b64a else 3
+    for attempt in range(3):
+        out, dpitch = ref_decode_sample(sample, w, h, fmt, resolution=2)
+        img = np.frombuffer(out.tobytes(), np.uint16).reshape(-1, dpitch // 2)[:, : (w // 2) * nch]
+        if img.shape == want.shape and half16_equal(img, want, raw, nch): break
+    assert img.shape == want.shape and half16_equal(img, want, raw, nch)
+
+
 @pytest.mark.parametrize("w,h", [(192, 96), (320, 240), (1920, 1080)])
 def test_reference_rg48_decode_equals_oracle(w, h):
     """Pins orc_inv_spatial_to_rgb48 (and the descale levels at 12 bits): the reference decoder's RG48 output of an RGB 4:4:4 sample is
