@@ -457,6 +457,13 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 				p.out = base + plan.ch[c].band[lv - 1][0].offset; p.out_pitch = plan.ch[c].band[lv - 1][0].pitch;
 				p.xstride = 1; p.precision = 0; p.display_height = 2 * p.height;
 			}
+		if (half && is_packed16(out_kind)) {
+			dev::HalfPackedJob &hp = j.halfp[i];
+			for (int c = 0; c < nch; c++) { hp.ll[c] = base + plan.ch[c].band[0][0].offset; hp.word[c] = packed_word_of_channel(out_kind, c); }
+			hp.pitch = plan.ch[0].band[0][0].pitch; hp.width = plan.ch[0].band[0][0].width; hp.rows = out_rows_; hp.nch = nch;
+			hp.shift = 16 - plan.precision - 2; hp.alpha = out_kind == PIX_B64A;
+			hp.out = own_output ? (uint16_t *)(d_out_ + frame_bytes_ * i) : nullptr; hp.out_pitch = out_pitch_;
+		}
 		if (is_packed16(out_kind)) {
 			for (int c = 0; c < nch; c++) {
 				dev::InvPlaneJob &p = j.l1[(size_t)i * nch + c];
@@ -470,13 +477,7 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 			}
 			continue;
 		}
-		if (half && is_packed16(out_kind)) {
-			dev::HalfPackedJob &hp = j.halfp[i];
-			for (int c = 0; c < nch; c++) { hp.ll[c] = base + plan.ch[c].band[0][0].offset; hp.word[c] = packed_word_of_channel(out_kind, c); }
-			hp.pitch = plan.ch[0].band[0][0].pitch; hp.width = plan.ch[0].band[0][0].width; hp.rows = out_rows_; hp.nch = nch;
-			hp.shift = 16 - plan.precision - 2; hp.alpha = out_kind == PIX_B64A;
-			hp.out = own_output ? (uint16_t *)(d_out_ + frame_bytes_ * i) : nullptr; hp.out_pitch = out_pitch_;
-		} else if (half) {
+		if (half && !is_packed16(out_kind)) {
 			dev::HalfYuvJob &hj = j.half[i];
 			for (int c = 0; c < 3; c++) { hj.ll[c] = base + plan.ch[c].band[0][0].offset; hj.pitch[c] = plan.ch[c].band[0][0].pitch; }
 			hj.width = plan.ch[0].band[0][0].width; hj.rows = out_rows_; hj.uyvy = out_kind == PIX_2VUY;
