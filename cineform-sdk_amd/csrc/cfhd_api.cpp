@@ -805,7 +805,50 @@ CFHD_Error CFHD_SetActiveMetadata(CFHD_DecoderRef ref, CFHD_MetadataRef, unsigne
 	return ref ? ERR_OKAY : ERR_INVALID_ARGUMENT;
 }
 CFHD_Error CFHD_ClearActiveMetadata(CFHD_DecoderRef ref, CFHD_MetadataRef) { return ref ? ERR_OKAY : ERR_INVALID_ARGUMENT; }
-CFHD_Error CFHD_GetThumbnail(CFHD_DecoderRef, void *, size_t, void *, size_t, uint32_t, size_t *, size_t *, size_t *) { return ERR_BAD_RESOLUTION; }
+// 1/8 x 1/8 thumbnail straight from the raw lowpass bands of the sample, no decode and no GPU involved (host code as in the reference:
+// Codec/thumbnail.c:65 GenerateThumbnail).  Output: 10-bit RGB, one big-endian dword per pixel, r << 22 | g << 12 | b << 2 ("DPX0").
+//   4:2:2: per pixel pair, y = (lowpass >> 4 & 0x3ff) - 64, Cr / Cb = (lowpass >> 4 & 0x3ff) - 512 from channels 1 / 2, then the fixed-point
+//          709 matrix of thumbnail.c:205-222;  4:4:4(:4): the G, R, B lowpass values >> 4.  Bayer samples are not built.
+CFHD_Error CFHD_GetThumbnail(CFHD_DecoderRef ref, void *sample, size_t size, void *out, size_t out_size, uint32_t, size_t *rw, size_t *rh, size_t *rsize)
+{
+	if (!ref || !sample || !out) return ERR_INVALID_ARGUMENT;
+	ParsedSample ps;
+	if (parse_sample((const uint8_t *)sample, size, &ps) != 0) return ERR_BADSAMPLE;
+	const int enc = ps.encoded_format;
+	if (enc != ENC_YUV422 && enc != ENC_RGB444 && enc != ENC_RGBA4444) return ERR_BADFORMAT;
+	const int w = (ps.width + 7) / 8, h = (ps.height + 7) / 8;
+	for (int c = 0; c < 3; c++) {
+		const ParsedBand &lp = ps.lowpass[c];
+		const int cw = (enc == ENC_YUV422 && c) ? w / 2 : w;
+		if (!lp.present || lp.width != cw || lp.height != h || (size_t)lp.offset + (size_t)cw * h * 2 > size) return ERR_BADSAMPLE;
+	}
+	if ((w & 1) || out_size < (size_t)w * h * 4) return ERR_INVALID_ARGUMENT;
+	const uint8_t *s = (const uint8_t *)sample;
+	auto be16 = [&](const ParsedBand &b, size_t i) { const uint8_t *p = s + b.offset + 2 * i; return (int)((p[0] << 8) | p[1]); };
+	auto clamp10 = [](int v) { return v < 0 ? 0 : (v > 0x3ff ? 0x3ff : v); };
+	auto put = [&](size_t i, int r, int g, int b) {
+		const uint32_t rgb = ((uint32_t)r << 22) | ((uint32_t)g << 12) | ((uint32_t)b << 2);
+		uint8_t *o = (uint8_t *)out + 4 * i;
+		o[0] = (uint8_t)(rgb >> 24); o[1] = (uint8_t)(rgb >> 16); o[2] = (uint8_t)(rgb >> 8); o[3] = (uint8_t)rgb;
+	};
+	const size_t n = (size_t)w * h;
+	if (enc == ENC_YUV422) {
+		for (size_t i = 0; i < n; i += 2) {
+			const int cr = ((be16(ps.lowpass[1], i / 2) >> 4) & 0x3ff) - 0x200, cb = ((be16(ps.lowpass[2], i / 2) >> 4) & 0x3ff) - 0x200;
+			for (int k = 0; k < 2; k++) {
+				const int y = ((be16(ps.lowpass[0], i + k) >> 4) & 0x3ff) - 64;
+				put(i + k, clamp10((1192 * y + 1836 * cr) >> 10), clamp10((1192 * y - 547 * cr - 218 * cb) >> 10), clamp10((1192 * y + 2166 * cb) >> 10));
+			}
+		}
+	} else {
+		for (size_t i = 0; i < n; i++)
+			put(i, (be16(ps.lowpass[1], i) >> 4) & 0x3ff, (be16(ps.lowpass[0], i) >> 4) & 0x3ff, (be16(ps.lowpass[2], i) >> 4) & 0x3ff);
+	}
+	if (rw) *rw = (size_t)w;
+	if (rh) *rh = (size_t)h;
+	if (rsize) *rsize = n * 4;
+	return ERR_OKAY;
+}
 
 CFHD_Error CFHD_CloseDecoder(CFHD_DecoderRef ref)
 {

@@ -1,5 +1,6 @@
 """Product host layer (plan geometry, quantizer derivation, sample writer, host VLC, parser) checked on CPU:
 oracle forward transform -> product sample writer must reproduce the reference encoder's sample byte for byte."""
+import ctypes
 import numpy as np
 import pytest
 from cfhd_testlib import *
@@ -154,3 +155,32 @@ def test_interlaced_sample_bytes_equal_reference(w, h, kind):
     mine = product_write_sample_host(plan, coeffs, 1, meta_global=rs[off:off + n], progressive=0)
     assert len(mine) == len(rs)
     assert mine == rs
+
+
+def _thumbnail(L, sample):
+    dec = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
+    sb = ctypes.create_string_buffer(sample, len(sample))
+    out = np.zeros(512 * 512 * 4, np.uint8)
+    w = ctypes.c_size_t(); h = ctypes.c_size_t(); n = ctypes.c_size_t()
+    L.CFHD_GetThumbnail.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32,
+                                    ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
+    rc = L.CFHD_GetThumbnail(dec, sb, len(sample), out.ctypes.data_as(ctypes.c_void_p), out.size, 0, ctypes.byref(w), ctypes.byref(h), ctypes.byref(n))
+    L.CFHD_CloseDecoder(dec)
+    return rc, w.value, h.value, bytes(out[: n.value])
+
+
+@pytest.mark.parametrize("w,h,fmt,enc", [(320, 240, PIX_YUY2, ENCODED_YUV422), (1920, 1080, PIX_YUY2, ENCODED_YUV422), (336, 252, PIX_2VUY, ENCODED_YUV422),
+                                         (320, 240, PIX_RG48, ENCODED_RGB444), (320, 240, PIX_B64A, ENCODED_RGBA4444)])
+def test_thumbnail_equals_reference(w, h, fmt, enc):
+    """CFHD_GetThumbnail (host code, no GPU): the 1/8 x 1/8 10-bit RGB picture the reference cuts out of the raw lowpass bands
+    (Codec/thumbnail.c:65), byte for byte."""
+    if not have_ref(): pytest.skip("reference .so not built")
+    if fmt in (PIX_YUY2, PIX_2VUY): frames, pitch = [synth_yuy2(w, h, 5)[0]], w * 2
+    else: frames, pitch = qbist_frames(10, 1, w, h, fmt, alpha=1) if fmt == PIX_B64A else qbist_frames(10, 1, w, h, fmt)
+    sample = ref_encode_frames(frames, pitch, w, h, fmt, encoded=enc)[0]
+    want = _thumbnail(ref(), sample)
+    got = _thumbnail(product(), sample)
+    assert want[0] == 0 and got[0] == 0
+    assert got[1:3] == want[1:3] == (w // 8, (h + 7) // 8)
+    assert got[3] == want[3]
+    assert len(set(got[3])) > 16                      # a picture, not a constant
