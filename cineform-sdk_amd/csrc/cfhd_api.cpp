@@ -630,12 +630,18 @@ CFHD_Error CFHD_OpenDecoder(CFHD_DecoderRef *out, CFHD_ALLOCATOR *)
 	return *out ? ERR_OKAY : ERR_OUTOFMEMORY;
 }
 
-CFHD_Error CFHD_GetOutputFormats(CFHD_DecoderRef ref, void *, size_t, CFHD_PixelFormat *arr, int len, int *count)
+// The output formats this decoder offers for the given sample (all of them without one): what CFHD_PrepareToDecode accepts for its encoded format.
+CFHD_Error CFHD_GetOutputFormats(CFHD_DecoderRef ref, void *sample, size_t size, CFHD_PixelFormat *arr, int len, int *count)
 {
 	if (!ref || !arr) return ERR_INVALID_ARGUMENT;
-	const uint32_t fmts[] = { FMT_YUY2, FMT_2VUY, FMT_RG48 };
+	ParsedSample ps;
+	const bool known = sample && parse_sample((const uint8_t *)sample, size, &ps) >= 0;
+	uint32_t fmts[4]; int total = 0;
+	if (!known || ps.encoded_format == ENC_YUV422) { fmts[total++] = FMT_YUY2; fmts[total++] = FMT_2VUY; }
+	if (!known || ps.encoded_format == ENC_RGB444) fmts[total++] = FMT_RG48;
+	if (!known || ps.encoded_format == ENC_RGBA4444) fmts[total++] = FMT_B64A;
 	int n = 0;
-	for (; n < 3 && n < len; n++) arr[n] = fmts[n];
+	for (; n < total && n < len; n++) arr[n] = fmts[n];
 	if (count) *count = n;
 	return ERR_OKAY;
 }
