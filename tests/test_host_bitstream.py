@@ -184,3 +184,28 @@ def test_thumbnail_equals_reference(w, h, fmt, enc):
     assert got[1:3] == want[1:3] == (w // 8, (h + 7) // 8)
     assert got[3] == want[3]
     assert len(set(got[3])) > 16                      # a picture, not a constant
+
+
+def test_thumbnail_and_output_formats_argument_handling():
+    """No GPU involved: argument checks of CFHD_GetThumbnail and the sample-aware CFHD_GetOutputFormats."""
+    L = product()
+    w, h = 320, 240
+    frame, pitch = synth_yuy2(w, h, 5)
+    plan = Plan(w, h)
+    sample = product_write_sample_host(plan, oracle_forward_yuv422(plan, frame, pitch), 1)
+    dec = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
+    sb = ctypes.create_string_buffer(sample, len(sample))
+    small = np.zeros(16, np.uint8)
+    L.CFHD_GetThumbnail.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32,
+                                    ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
+    assert L.CFHD_GetThumbnail(dec, sb, len(sample), small.ctypes.data_as(ctypes.c_void_p), small.size, 0, None, None, None) == 1   # buffer too small
+    assert L.CFHD_GetThumbnail(dec, None, 0, small.ctypes.data_as(ctypes.c_void_p), small.size, 0, None, None, None) == 1
+    big = np.zeros(40 * 30 * 4, np.uint8)
+    assert L.CFHD_GetThumbnail(dec, sb, 200, big.ctypes.data_as(ctypes.c_void_p), big.size, 0, None, None, None) == 5               # truncated sample
+    assert L.CFHD_GetThumbnail(dec, sb, len(sample), big.ctypes.data_as(ctypes.c_void_p), big.size, 0, None, None, None) == 0
+    fmts = (ctypes.c_uint32 * 8)(); n = ctypes.c_int()
+    L.CFHD_GetOutputFormats.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    assert L.CFHD_GetOutputFormats(dec, sb, len(sample), fmts, 8, ctypes.byref(n)) == 0
+    assert [fmts[i] for i in range(n.value)] == [PIX_YUY2, PIX_2VUY]
+    assert L.CFHD_GetOutputFormats(dec, None, 0, fmts, 8, ctypes.byref(n)) == 0 and n.value == 4
+    L.CFHD_CloseDecoder(dec)
