@@ -815,9 +815,9 @@ CFHD_Error CFHD_ClearActiveMetadata(CFHD_DecoderRef ref, CFHD_MetadataRef) { ret
 // Codec/thumbnail.c:65 GenerateThumbnail).  Output: 10-bit RGB, one big-endian dword per pixel, r << 22 | g << 12 | b << 2 ("DPX0").
 //   4:2:2: per pixel pair, y = (lowpass >> 4 & 0x3ff) - 64, Cr / Cb = (lowpass >> 4 & 0x3ff) - 512 from channels 1 / 2, then the fixed-point
 //          709 matrix of thumbnail.c:205-222;  4:4:4(:4): the G, R, B lowpass values >> 4.  Bayer samples are not built.
-CFHD_Error CFHD_GetThumbnail(CFHD_DecoderRef ref, void *sample, size_t size, void *out, size_t out_size, uint32_t, size_t *rw, size_t *rh, size_t *rsize)
+static int thumbnail_from_sample(const void *sample, size_t size, void *out, size_t out_size, size_t *rw, size_t *rh, size_t *rsize)
 {
-	if (!ref || !sample || !out) return ERR_INVALID_ARGUMENT;
+	if (!sample) return ERR_INVALID_ARGUMENT;
 	ParsedSample ps;
 	if (parse_sample((const uint8_t *)sample, size, &ps) != 0) return ERR_BADSAMPLE;
 	const int enc = ps.encoded_format;
@@ -827,6 +827,12 @@ CFHD_Error CFHD_GetThumbnail(CFHD_DecoderRef ref, void *sample, size_t size, voi
 		const ParsedBand &lp = ps.lowpass[c];
 		const int cw = (enc == ENC_YUV422 && c) ? w / 2 : w;
 		if (!lp.present || lp.width != cw || lp.height != h || (size_t)lp.offset + (size_t)cw * h * 2 > size) return ERR_BADSAMPLE;
+	}
+	if (!out) {                                          // size query (thumbnail.c:30 GetThumbnailInfo)
+		if (rw) *rw = (size_t)w;
+		if (rh) *rh = (size_t)h;
+		if (rsize) *rsize = (size_t)w * h * 4;
+		return ERR_OKAY;
 	}
 	if ((w & 1) || out_size < (size_t)w * h * 4) return ERR_INVALID_ARGUMENT;
 	const uint8_t *s = (const uint8_t *)sample;
@@ -853,6 +859,51 @@ CFHD_Error CFHD_GetThumbnail(CFHD_DecoderRef ref, void *sample, size_t size, voi
 	if (rw) *rw = (size_t)w;
 	if (rh) *rh = (size_t)h;
 	if (rsize) *rsize = n * 4;
+	return ERR_OKAY;
+}
+
+CFHD_Error CFHD_GetThumbnail(CFHD_DecoderRef ref, void *sample, size_t size, void *out, size_t out_size, uint32_t, size_t *rw, size_t *rh, size_t *rsize)
+{
+	if (!ref || !sample || !out) return ERR_INVALID_ARGUMENT;
+	return thumbnail_from_sample(sample, size, out, out_size, rw, rh, rsize);
+}
+
+// EncoderSDK/CFHDEncoder.cpp:593: the same thumbnail, asked of an encoder for a sample it produced.
+CFHD_Error CFHD_GetEncodeThumbnail(CFHD_EncoderRef ref, void *sample, size_t size, void *out, size_t out_size, uint32_t, size_t *rw, size_t *rh, size_t *rsize)
+{
+	if (!ref || !sample || !out) return ERR_INVALID_ARGUMENT;
+	return thumbnail_from_sample(sample, size, out, out_size, rw, rh, rsize);
+}
+
+// EncoderSDK/CFHDEncoderPool.cpp:620: thumbnail of a sample buffer of the encoder pool; without an output buffer only the dimensions.
+CFHD_Error CFHD_GetSampleThumbnail(CFHD_SampleBufferRef ref, void *out, size_t out_size, uint32_t, uint_least16_t *rw, uint_least16_t *rh,
+                                   CFHD_PixelFormat *fmt, size_t *rsize)
+{
+	if (!ref) return ERR_INVALID_ARGUMENT;
+	SampleBuffer *sb = (SampleBuffer *)ref;
+	size_t w = 0, h = 0, n = 0;
+	const int rc = thumbnail_from_sample(sb->data.data(), sb->size, out_size ? out : nullptr, out_size, &w, &h, &n);
+	if (rc != ERR_OKAY) return ERR_CODEC_ERROR;
+	if (rw) *rw = (uint_least16_t)w;
+	if (rh) *rh = (uint_least16_t)h;
+	if (fmt) *fmt = FOURCC_BE('D', 'P', 'X', '0');
+	if (rsize) *rsize = n;
+	return ERR_OKAY;
+}
+
+// DecoderSDK/CFHDDecoder.cpp:443 (obsoleted there by CFHD_GetSampleInfo): encoded format, field type and frame size of a sample.  The
+// reference's CFHD_SampleHeader is a class of exactly these four ints (Common/CFHDSampleHeader.h:32).
+CFHD_Error CFHD_ParseSampleHeader(void *sample, size_t size, CFHD_SampleHeader *hdr)
+{
+	if (!sample || !hdr) return ERR_INVALID_ARGUMENT;
+	ParsedSample ps;
+	if (parse_sample((const uint8_t *)sample, size, &ps) < 0) return ERR_BADSAMPLE;
+	hdr->encoded_format = ps.encoded_format == ENC_RGB444 ? 1 : (ps.encoded_format == ENC_RGBA4444 ? 2 : (ps.encoded_format == ENC_BAYER ? 3 : 0));
+	// CSampleDecoder::FieldType (SampleDecoder.cpp:1886): 1 progressive; interlaced: 2 upper field first unless the optional interlaced
+	// flags say interlaced (bit 0) without field-1-first (bit 1), then 3 lower field first
+	if (ps.progressive || ps.encoded_format == ENC_BAYER) hdr->field_type = 1;
+	else hdr->field_type = ((ps.interlaced_flags & 1) && !(ps.interlaced_flags & 2)) ? 3 : 2;
+	hdr->width = ps.width; hdr->height = ps.display_height;
 	return ERR_OKAY;
 }
 

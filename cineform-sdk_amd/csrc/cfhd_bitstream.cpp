@@ -410,6 +410,7 @@ int parse_sample(const uint8_t *d, size_t size, ParsedSample *ps)
 		case TAG_QUALITY_H: ps->quality = (ps->quality & 0xffff) | (value << 16); break;
 		case TAG_PRESCALE_TABLE: ps->prescale_table = value; break;
 		case TAG_SAMPLE_FLAGS: ps->progressive = value & 1; break;
+		case TAG_INTERLACED_FLAGS: ps->interlaced_flags = value; break;
 		case TAG_LOWPASS_WIDTH: lw = value; break;
 		case TAG_LOWPASS_HEIGHT: lh = value; break;
 		case TAG_MARKER:

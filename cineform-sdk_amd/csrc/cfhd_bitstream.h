@@ -102,7 +102,7 @@ struct ParsedBand { uint32_t offset, bytes; int width, height, quant, codebook, 
 struct ParsedSample {
 	int width = 0, height = 0, display_height = 0, num_channels = 0, precision = 0, encoded_format = 0;
 	int input_format = 0, color_space = 0, quality = 0, prescale_table = 0, frame_number = 0, progressive = 0, version = 0;
-	int transform_type = 0, num_spatial = 0, num_wavelets = 0;
+	int transform_type = 0, num_spatial = 0, num_wavelets = 0, interlaced_flags = 0;
 	ParsedBand lowpass[kMaxChannels];                     // raw 16-bit big-endian pairs
 	ParsedBand high[kMaxChannels][kNumLevels][kNumBands]; // [ch][wavelet index][band 1..3]
 	uint32_t metadata_offset = 0, metadata_bytes = 0;     // first metadata chunk

@@ -107,7 +107,16 @@ CFHD_Error CFHD_SetActiveMetadata(CFHD_DecoderRef decoderRef, CFHD_MetadataRef m
                                   CFHD_MetadataType type, void *data, unsigned int size);                /* CFHDDecoder.h:272 (accepted, ignored) */
 CFHD_Error CFHD_ClearActiveMetadata(CFHD_DecoderRef decoderRef, CFHD_MetadataRef metadataRef);
 CFHD_Error CFHD_GetThumbnail(CFHD_DecoderRef decoderRef, void *samplePtr, size_t sampleSize, void *outputBuffer,
-                             size_t outputBufferSize, uint32_t flags, size_t *retWidth, size_t *retHeight, size_t *retSize);
+                             size_t outputBufferSize, uint32_t flags, size_t *retWidth, size_t *retHeight, size_t *retSize); /* CFHDDecoder.cpp:1512 */
+/* the same 1/8 x 1/8 10-bit RGB thumbnail through the encoder-side handles */
+CFHD_Error CFHD_GetEncodeThumbnail(CFHD_EncoderRef encoderRef, void *samplePtr, size_t sampleSize, void *outputBuffer,
+                                   size_t outputBufferSize, uint32_t flags, size_t *retWidth, size_t *retHeight, size_t *retSize); /* CFHDEncoder.cpp:593 */
+CFHD_Error CFHD_GetSampleThumbnail(CFHD_SampleBufferRef sampleBufferRef, void *thumbnailBuffer, size_t bufferSize, uint32_t flags,
+                                   uint_least16_t *actualWidthOut, uint_least16_t *actualHeightOut, CFHD_PixelFormat *pixelFormatOut,
+                                   size_t *actualSizeOut);                                              /* CFHDEncoderPool.cpp:620 */
+/* obsolete in the reference (use CFHD_GetSampleInfo); layout of Common/CFHDSampleHeader.h:32 */
+typedef struct CFHD_SampleHeader { int encoded_format; int field_type; int width; int height; } CFHD_SampleHeader;
+CFHD_Error CFHD_ParseSampleHeader(void *samplePtr, size_t sampleSize, CFHD_SampleHeader *sampleHeader);   /* CFHDDecoder.cpp:443 */
 CFHD_Error CFHD_CloseDecoder(CFHD_DecoderRef decoderRef);                                                /* CFHDDecoder.h:300 */
 
 /* ---------------- decoder-side metadata: DecoderSDK/CFHDMetadata.cpp ---------------- */

@@ -209,3 +209,29 @@ def test_thumbnail_and_output_formats_argument_handling():
     assert [fmts[i] for i in range(n.value)] == [PIX_YUY2, PIX_2VUY]
     assert L.CFHD_GetOutputFormats(dec, None, 0, fmts, 8, ctypes.byref(n)) == 0 and n.value == 4
     L.CFHD_CloseDecoder(dec)
+
+
+@pytest.mark.parametrize("w,h,fmt,enc,flags", [(320, 240, PIX_YUY2, ENCODED_YUV422, 0), (336, 252, PIX_YUY2, ENCODED_YUV422, 1), (320, 240, PIX_RG48, ENCODED_RGB444, 0),
+                                               (320, 240, PIX_B64A, ENCODED_RGBA4444, 0)])
+def test_obsolete_header_parser_and_encoder_side_thumbnail_equal_reference(w, h, fmt, enc, flags):
+    """CFHD_ParseSampleHeader (four ints: encoded format, field type, width, height) and CFHD_GetEncodeThumbnail, host code, against the
+    reference's on the same sample."""
+    if not have_ref(): pytest.skip("reference .so not built")
+    if fmt == PIX_YUY2: frames, pitch = [synth_yuy2(w, h, 5)[0]], w * 2
+    else: frames, pitch = qbist_frames(10, 1, w, h, fmt, alpha=1) if fmt == PIX_B64A else qbist_frames(10, 1, w, h, fmt)
+    sample = ref_encode_frames(frames, pitch, w, h, fmt, encoded=enc, flags=flags)[0]
+    sb = ctypes.create_string_buffer(sample, len(sample))
+    got = []
+    for L in (ref(), product()):
+        hdr = (ctypes.c_int * 4)(-1, -1, -1, -1)
+        assert L.CFHD_ParseSampleHeader(sb, ctypes.c_size_t(len(sample)), hdr) == 0
+        enc_ref = ctypes.c_void_p(); assert L.CFHD_OpenEncoder(ctypes.byref(enc_ref), None) == 0
+        out = np.zeros(64 * 64 * 4, np.uint8)
+        tw = ctypes.c_size_t(); th = ctypes.c_size_t(); tn = ctypes.c_size_t()
+        L.CFHD_GetEncodeThumbnail.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32,
+                                              ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
+        assert L.CFHD_GetEncodeThumbnail(enc_ref, sb, len(sample), out.ctypes.data_as(ctypes.c_void_p), out.size, 0, ctypes.byref(tw), ctypes.byref(th), ctypes.byref(tn)) == 0
+        L.CFHD_CloseEncoder(enc_ref)
+        got.append((list(hdr), tw.value, th.value, bytes(out[: tn.value])))
+    assert got[0] == got[1]
+    assert got[0][0][2:] == [w, h]
