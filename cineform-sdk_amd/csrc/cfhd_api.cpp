@@ -37,19 +37,6 @@ static const uint32_t FMT_YUY2 = FOURCC_BE('Y', 'U', 'Y', '2'), FMT_2VUY = FOURC
 
 namespace {
 
-std::mutex g_guid_mutex;
-bool g_guid_fixed = false;
-unsigned char g_guid[16];
-
-void new_guid(unsigned char out[16])
-{
-	std::lock_guard<std::mutex> lk(g_guid_mutex);
-	if (g_guid_fixed) { memcpy(out, g_guid, 16); return; }
-	std::random_device rd;
-	for (int i = 0; i < 16; i += 4) { uint32_t r = rd(); memcpy(out + i, &r, 4); }
-	out[6] = (out[6] & 0x0f) | 0x40; out[8] = (out[8] & 0x3f) | 0x80;    // RFC 4122 version 4
-}
-
 int pixel_kind_of(uint32_t fmt)
 {
 	if (fmt == FMT_YUY2 || fmt == FMT_YUYV) return PIX_YUY2;
@@ -68,72 +55,6 @@ struct EncMetadata {
 	std::mutex lock;
 	MetaBlock global, local;
 	bool changed = false;
-};
-
-// ---- the per-encoder metadata state machine (EncoderSDK/SampleEncoder.cpp:744-939 HandleMetadata) ----
-struct MetaState {
-	MetaBlock global, local;
-	int last_timecode_base = 0, last_timecode_frame = -1, last_unique_frame = -1;
-
-	void handle()
-	{
-		if (global.empty()) { unsigned char g[16]; new_guid(g); meta_add(global, MTAG_CLIP_GUID, 'G', 16, g); }
-		time_t clock = time(NULL);
-		struct tm tmv; localtime_r(&clock, &tmv);
-		char datestr[32], timestr[32], tmp[32];
-		snprintf(datestr, sizeof(datestr), "%04d-%02d-%02d", tmv.tm_year + 1900, tmv.tm_mon + 1, tmv.tm_mday);
-		snprintf(timestr, sizeof(timestr), "%02d:%02d:%02d", tmv.tm_hour, tmv.tm_min, tmv.tm_sec);
-		meta_add(global, MTAG_ENCODE_DATE, 'c', 10, datestr);
-		meta_add(global, MTAG_ENCODE_TIME, 'c', 8, timestr);
-
-		bool in_local = false;
-		uint32_t sz; unsigned char ty;
-		const uint8_t *data = meta_find(global.data(), global.size(), MTAG_TIMECODE, &sz, &ty);
-		if (!data) {
-			data = meta_find(local.data(), local.size(), MTAG_TIMECODE, &sz, &ty);
-			if (!data) {
-				last_timecode_base = 24;
-				last_timecode_frame = tmv.tm_hour * 3600 * 24 + tmv.tm_min * 60 * 24 + tmv.tm_sec * 24;
-				snprintf(tmp, sizeof(tmp), "%02d:%02d:%02d:00", tmv.tm_hour, tmv.tm_min, tmv.tm_sec);
-				meta_add(global, MTAG_TIMECODE, 'c', 11, tmp);
-			} else in_local = true;
-		}
-		if (data) {
-			const char *tc = (const char *)data;
-			int hours = (tc[0] - '0') * 10 + (tc[1] - '0'), mins = (tc[3] - '0') * 10 + (tc[4] - '0');
-			int secs = (tc[6] - '0') * 10 + (tc[7] - '0'), frms = (tc[9] - '0') * 10 + (tc[10] - '0');
-			if (last_timecode_base == 0) {
-				const uint8_t *b = meta_find(local.data(), local.size(), MTAG_TIMECODE_BASE, &sz, &ty);
-				if (!b) b = meta_find(global.data(), global.size(), MTAG_TIMECODE_BASE, &sz, &ty);
-				last_timecode_base = b ? *b : 24;
-				if (last_timecode_base == 0) last_timecode_base = 24;
-			}
-			int base = last_timecode_base;
-			int framenum = hours * 3600 * base + mins * 60 * base + secs * base + frms;
-			if (last_timecode_frame == -1) last_timecode_frame = framenum;
-			else if (framenum == last_timecode_frame && base <= 30) {
-				framenum = ++last_timecode_frame;
-				frms = framenum % base; framenum /= base;
-				secs = framenum % 60; framenum /= 60;
-				mins = framenum % 60; framenum /= 60;
-				hours = framenum % 60;
-				snprintf(tmp, sizeof(tmp), "%02d:%02d:%02d:%02d", hours, mins, secs, frms);
-				meta_add(in_local ? local : global, MTAG_TIMECODE, 'c', 11, tmp);
-			}
-		}
-		in_local = false;
-		data = meta_find(global.data(), global.size(), MTAG_UNIQUE_FRAMENUM, &sz, &ty);
-		if (!data) {
-			data = meta_find(local.data(), local.size(), MTAG_UNIQUE_FRAMENUM, &sz, &ty);
-			if (!data) { last_unique_frame = 0; uint32_t v = 0; meta_add(global, MTAG_UNIQUE_FRAMENUM, 'L', 4, &v); }
-			else in_local = true;
-		}
-		if (data) {
-			int32_t n; memcpy(&n, data, 4);
-			if (last_unique_frame == -1) last_unique_frame = n;
-			else if (n <= last_unique_frame) { uint32_t v = (uint32_t)++last_unique_frame; meta_add(in_local ? local : global, MTAG_UNIQUE_FRAMENUM, 'L', 4, &v); }
-		}
-	}
 };
 
 struct EncodeParams {
@@ -212,10 +133,33 @@ int encode_one(EncodeBatch &batch, EncodeParams &p, const void *frame, int pitch
 		if (!v) v = meta_find(local.data(), local.size(), VCHN, &sz, &ty);
 		if (v) { uint32_t n; memcpy(&n, v, 4); if (n > 1) return ERR_BADFORMAT; hdr.channel_number_tag = true; }
 	}
+	// Rate feedback (encoder.c:9442 QuantizationSetQuality + quantize.c:2865 SetTransformQuantization run per frame with the size of the
+	// previous sample, encoder.c:9911): FILMSCAN2/3 steer their limiter with it, LOW..HIGH at <= 1080p the bit-rate limiter.  The
+	// tables only move when the previous size says so; the device job tables are rewritten only then.
+	if (p.qstate.lastgopbitcount) {
+		FramePlan next = p.plan;
+		derive_quantization(&next, p.quality, p.progressive, 0.0f, &p.qstate);
+		bool changed = false;
+		for (int c = 0; c < next.num_channels && !changed; c++)
+			for (int lv = 0; lv < kNumLevels && !changed; lv++)
+				for (int b = 0; b < kNumBands; b++) if (next.ch[c].band[lv][b].quant != p.plan.ch[c].band[lv][b].quant) { changed = true; break; }
+		p.plan = next;
+		if (changed && batch.update_quant(p.plan)) return ERR_INTERNAL;
+	}
 	if ((rc = batch.upload_frame(0, frame, pitch))) return ERR_INTERNAL;
-	if (batch.has_entropy()) {
-		// GPU entropy stage: the finished sample comes back, not the coefficients
-		if (batch.entropy().set_frame_header(0, hdr)) return ERR_CODEC_ERROR;
+	auto host_write = [&]() -> int {
+		if ((rc = batch.download_coeffs())) return ERR_INTERNAL;
+		if ((rc = batch.wait())) return ERR_INTERNAL;
+		BandSource src; src.coeffs = batch.host_coeffs(0);
+		size_t n = write_sample(p.plan, hdr, src, out, cap);
+		if (!n) return ERR_CODEC_ERROR;
+		*size_out = n;
+		p.qstate.lastgopbitcount = (int64_t)n * 8;
+		return ERR_OKAY;
+	};
+	// GPU entropy stage: the finished sample comes back, not the coefficients.  A header that does not fit the device template block
+	// (several KB of user metadata; the reference takes up to 256 KB) is written by the host writer from the same GPU coefficients.
+	if (batch.has_entropy() && batch.entropy().set_frame_header(0, hdr) == 0) {
 		if ((rc = batch.launch_forward())) return ERR_INTERNAL;
 		if ((rc = batch.entropy().launch())) return ERR_INTERNAL;
 		if ((rc = batch.entropy().download())) return ERR_INTERNAL;
@@ -225,26 +169,15 @@ int encode_one(EncodeBatch &batch, EncodeParams &p, const void *frame, int pitch
 			if (!n || n > cap) return ERR_CODEC_ERROR;
 			memcpy(out, batch.entropy().host_sample(0), n);
 			*size_out = n;
+			p.qstate.lastgopbitcount = (int64_t)n * 8;
 			return ERR_OKAY;
 		}
 		// an interlaced frame whose field-difference band needs a peak table (values beyond +-250, rare): the table sits in front of the
 		// band and changes its coding, so this sample is written by the host writer from the same GPU coefficients
-		if ((rc = batch.download_coeffs())) return ERR_INTERNAL;
-		if ((rc = batch.wait())) return ERR_INTERNAL;
-		BandSource src; src.coeffs = batch.host_coeffs(0);
-		size_t n = write_sample(p.plan, hdr, src, out, cap);
-		if (!n) return ERR_CODEC_ERROR;
-		*size_out = n;
-		return ERR_OKAY;
+		return host_write();
 	}
 	if ((rc = batch.launch_forward())) return ERR_INTERNAL;
-	if ((rc = batch.download_coeffs())) return ERR_INTERNAL;
-	if ((rc = batch.wait())) return ERR_INTERNAL;
-	BandSource src; src.coeffs = batch.host_coeffs(0);
-	size_t n = write_sample(p.plan, hdr, src, out, cap);
-	if (!n) return ERR_CODEC_ERROR;
-	*size_out = n;
-	return ERR_OKAY;
+	return host_write();
 }
 
 struct Encoder {
@@ -270,6 +203,7 @@ struct PoolJob {
 
 struct PoolWorker {
 	EncodeBatch batch;
+	EncodeParams params;                      // this worker's encoder state (quantizer feedback is per encoder: each CAsyncEncoder owns an ENCODER)
 	uint32_t encoded = 0;                     // per-"encoder" frame counter (the reference numbers frames per CAsyncEncoder)
 	std::thread thread;
 	std::deque<std::shared_ptr<PoolJob>> inbox;
@@ -298,8 +232,7 @@ struct EncoderPool {
 			}
 			job->sample.reset(new SampleBuffer);
 			job->sample->data.resize(sample_capacity(params));
-			EncodeParams p = params;
-			job->error = encode_one(w->batch, p, job->frame, (int)job->pitch, ++w->encoded, job->global, job->local,
+			job->error = encode_one(w->batch, w->params, job->frame, (int)job->pitch, ++w->encoded, job->global, job->local,
 			                        job->sample->data.data(), job->sample->data.size(), &job->sample->size);
 			{
 				std::lock_guard<std::mutex> lk(m);
@@ -343,11 +276,7 @@ void plan_from_sample(const ParsedSample &ps, int out_kind, FramePlan *plan, boo
 extern "C" {
 
 int cfhd_amd_device_count(void) { return device_count(); }
-void cfhd_amd_set_clip_guid(const unsigned char guid[16])
-{
-	std::lock_guard<std::mutex> lk(g_guid_mutex);
-	if (guid) { memcpy(g_guid, guid, 16); g_guid_fixed = true; } else g_guid_fixed = false;
-}
+void cfhd_amd_set_clip_guid(const unsigned char guid[16]) { meta_fix_guid(guid); }
 const char *cfhd_amd_last_error(void) { return device_last_error(); }
 
 // =============================================================================================
@@ -377,10 +306,12 @@ CFHD_Error CFHD_PrepareToEncode(CFHD_EncoderRef ref, int w, int h, CFHD_PixelFor
 {
 	if (!ref) return ERR_INVALID_ARGUMENT;
 	Encoder *e = (Encoder *)ref;
-	if (e->params.valid && e->params.width == w && e->params.height == h && e->params.pixel_format == fmt) {
-		// "just changing quality" (SampleEncoder.cpp:322-327)
+	const int want_encoded = e->params.encoded_format == ENC_RGB444 ? 1 : (e->params.encoded_format == ENC_RGBA4444 ? 2 : (e->params.encoded_format == ENC_BAYER ? 3 : 0));
+	if (e->params.valid && e->params.width == w && e->params.height == h && e->params.pixel_format == fmt && e->params.flags == (uint32_t)flags &&
+	    want_encoded == (int)encoded) {
+		// "just changing quality" (SampleEncoder.cpp:322-327); a different encoded format or other flags take the full path below
 		e->params.quality = (int)((0xffff0000u & (uint32_t)e->params.quality) | (0xffffu & (uint32_t)quality));
-		derive_quantization(&e->params.plan, e->params.quality, true, 0.0f, &e->params.qstate);
+		derive_quantization(&e->params.plan, e->params.quality, e->params.progressive, 0.0f, &e->params.qstate);
 		e->batch_ready = false;
 		return ERR_OKAY;
 	}
@@ -446,7 +377,7 @@ CFHD_Error CFHD_MetadataAdd(CFHD_MetadataRef ref, uint32_t tag, CFHD_MetadataTyp
 	if (!ctype) return ERR_INVALID_ARGUMENT;
 	std::lock_guard<std::mutex> lk(m->lock);
 	m->changed = true;
-	if (m->global.empty() && tag != MTAG_CLIP_GUID && !local) { unsigned char g[16]; new_guid(g); meta_add(m->global, MTAG_CLIP_GUID, 'G', 16, g); }
+	if (m->global.empty() && tag != MTAG_CLIP_GUID && !local) { unsigned char g[16]; meta_new_guid(g); meta_add(m->global, MTAG_CLIP_GUID, 'G', 16, g); }
 	return meta_add(local ? m->local : m->global, tag, ctype, (uint32_t)size, data) ? ERR_OKAY : ERR_UNEXPECTED;
 }
 
@@ -524,6 +455,7 @@ CFHD_Error CFHD_StartEncoderPool(CFHD_EncoderPoolRef ref)
 	for (int i = 0; i < p->nworkers; i++) {
 		std::unique_ptr<PoolWorker> w(new PoolWorker);
 		if (prepare_batch(w->batch, p->params)) return ERR_INTERNAL;
+		w->params = p->params;
 		p->workers.push_back(std::move(w));
 	}
 	for (auto &w : p->workers) { PoolWorker *pw = w.get(); pw->thread = std::thread([p, pw] { p->worker_loop(pw); }); }
@@ -654,11 +586,13 @@ CFHD_Error CFHD_GetSampleInfo(CFHD_DecoderRef ref, void *sample, size_t size, CF
 	int32_t v = 0;
 	switch (tag) {
 	case 0: v = 1; break;                                 // CFHD_SAMPLE_INFO_CHANNELS (video channels: 2D)
-	case 1: v = ps.width; break;                          // CFHD_SAMPLE_DISPLAY_WIDTH
-	case 2: v = ps.display_height; break;                 // CFHD_SAMPLE_DISPLAY_HEIGHT
+	case 1: v = ps.encoded_format == ENC_BAYER ? 2 * ps.width : ps.width; break;   // CFHD_SAMPLE_DISPLAY_WIDTH (Bayer samples carry the component plane size, decoder.c:2617)
+	case 2: v = 0; break;                                 // CFHD_SAMPLE_DISPLAY_HEIGHT: the reference answers 0 for every sample (its parser keeps the tag in a local, decoder.c:2156, and SAMPLE_HEADER::display_height stays cleared); callers take the height from CFHD_PrepareToDecode
 	case 3: v = 1; break;                                 // CFHD_SAMPLE_KEY_FRAME (intra only)
 	case 4: v = ps.progressive; break;                    // CFHD_SAMPLE_PROGRESSIVE
-	case 5: v = ps.encoded_format; break;                 // CFHD_SAMPLE_ENCODED_FORMAT
+	// CFHD_SAMPLE_ENCODED_FORMAT: the public CFHD_EncodedFormat enum (YUV_422 0, RGB_444 1, RGBA_4444 2, BAYER 3), not the bitstream's
+	// ENCODED_FORMAT code (SampleDecoder.cpp:821-840)
+	case 5: v = ps.encoded_format == ENC_RGB444 ? 1 : (ps.encoded_format == ENC_RGBA4444 ? 2 : (ps.encoded_format == ENC_BAYER ? 3 : 0)); break;
 	case 6: v = (10 << 16) | (1 << 8) | 0; break;         // CFHD_SAMPLE_SDK_VERSION
 	case 7: v = ((ps.version >> 12) << 16) | (((ps.version >> 8) & 0xf) << 8) | (ps.version & 0xff); break;   // CFHD_SAMPLE_ENCODE_VERSION
 	default: return ERR_INVALID_ARGUMENT;

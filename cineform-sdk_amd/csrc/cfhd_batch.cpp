@@ -32,7 +32,8 @@ struct cfhd_amd_batch {
 	cfhd_amd_chunk &chunk_of(int i, int *local) { for (auto &c : chunks) if (i < c->first + c->n) { *local = i - c->first; return *c; } *local = 0; return *chunks[0]; }
 	std::vector<std::vector<uint8_t>> samples;
 	std::vector<size_t> sample_size;
-	MetaBlock meta;
+	MetaState meta;                    // the metadata a synchronous encoder attaches on its own (SampleEncoder.cpp:744-939): frame i of the batch = the (steps * n + i + 1)-th CFHD_EncodeSample call
+	std::vector<MetaBlock> frame_meta;  // per frame: the global block as it stood when the frame was "submitted"
 	uint32_t steps = 0;
 	bool gpu_entropy = true;
 	bool device_handoff = true;        // the decoder reads the samples where the encoder left them in HBM (k_dec_parse); the host copy arrives beside it
@@ -80,8 +81,6 @@ cfhd_amd_batch *cfhd_amd_batch_create(int width, int height, uint32_t pixel_form
 	}
 	b->samples.resize(nframes); b->sample_size.assign(nframes, 0);
 	if (!b->gpu_entropy) for (auto &s : b->samples) s.resize(cap);
-	unsigned char guid[16] = {0};
-	meta_add(b->meta, MTAG_CLIP_GUID, 'G', 16, guid);
 	return b;
 }
 
@@ -105,7 +104,11 @@ long long cfhd_amd_batch_roundtrip(cfhd_amd_batch *b)
 	double t0 = now(), t1, t2, t3;
 	std::atomic<int> bad(0);
 	const uint32_t base_number = b->steps * (uint32_t)b->n;
-	auto header = [&](int i) { SampleHeaderInfo h = { base_number + (uint32_t)i + 1, b->pixel_kind == PIX_2VUY ? 1 : 2, 2, b->quality, true, b->meta.data(), b->meta.size(), nullptr, 0 }; return h; };
+	// every frame gets the metadata CFHD_EncodeSample would give it: GUID, encode date / time, a timecode and a unique frame number that advance per frame
+	b->frame_meta.resize(b->n);
+	bool meta_ready = false;
+	auto prepare_meta = [&] { if (meta_ready) return; meta_ready = true; for (int i = 0; i < b->n; i++) { b->meta.handle(); b->frame_meta[i] = b->meta.global; meta_remove_hidden(b->frame_meta[i]); } };
+	auto header = [&](int i) { SampleHeaderInfo h = { base_number + (uint32_t)i + 1, b->pixel_kind == PIX_2VUY ? 1 : 2, 2, b->quality, true, b->frame_meta[i].data(), b->frame_meta[i].size(), nullptr, 0 }; return h; };
 	const uint32_t seed = 0xA511E9B3u * (b->steps + 1);
 	if (b->gpu_entropy && b->device_handoff) {
 		// Samples stay in HBM between the encoder and the decoder: the decoder's stream waits for the encoder's kernels, parses
@@ -114,6 +117,7 @@ long long cfhd_amd_batch_roundtrip(cfhd_amd_batch *b)
 		for (auto &c : b->chunks) {
 			// the transform kernels start first: the host serialises the 256 sample headers (0.5 ms) while they run
 			if (c->enc.launch_forward()) return -2;
+			prepare_meta();
 			for (int l = 0; l < c->n; l++) if (c->enc.entropy().set_frame_header(l, header(c->first + l))) return -6;
 			if (c->enc.entropy().launch()) return -2;
 			// the parser only needs the headers and size fields (k_ent_layout): it runs beside k_ent_emit, the band decoder waits for the payloads
@@ -130,6 +134,7 @@ long long cfhd_amd_batch_roundtrip(cfhd_amd_batch *b)
 		for (auto &c : b->chunks) { if (c->dec.wait()) return -5; if (c->dec.entropy().check()) return -7; }
 	} else if (b->gpu_entropy) {
 		// 1. every chunk: forward transform + entropy coding, queued on the chunk's own stream
+		prepare_meta();
 		for (auto &c : b->chunks) {
 			for (int l = 0; l < c->n; l++) if (c->enc.entropy().set_frame_header(l, header(c->first + l))) return -6;
 			if (c->enc.launch_forward() || c->enc.entropy().launch()) return -2;
@@ -154,6 +159,7 @@ long long cfhd_amd_batch_roundtrip(cfhd_amd_batch *b)
 		for (auto &c : b->chunks) { if (c->dec.wait()) return -5; if (c->dec.entropy().check()) return -7; }
 	} else {
 		cfhd_amd_chunk &c = *b->chunks[0];
+		prepare_meta();
 		if (c.enc.launch_forward() || c.enc.download_coeffs() || c.enc.wait()) return -2;
 		t1 = now();
 		parallel_for(b->n, b->nthreads, [&](int i) {

@@ -15,7 +15,7 @@
 
 namespace cfhd {
 
-enum { kMaxChannels = 4, kNumLevels = 3, kNumBands = 4 };
+enum { kMaxChannels = 4, kNumLevels = 3, kNumBands = 4, kMaxFrameDim = 16384 };
 
 // Internal pixel formats handled by the unpack (encode) / pack (decode) kernels.
 enum PixelKind : int {

@@ -30,6 +30,7 @@ public:
 	// Use frames that already live in HBM (bench / device-resident callers).
 	int set_device_frame(int i, const void *d_frame, int pitch_bytes);
 	int launch_forward();                              // async: all levels, all frames
+	int update_quant(const FramePlan &plan);           // same geometry, new quantizer tables (per-frame rate feedback)
 	// GPU entropy stage (cfhd_entropy_kernels.h): complete samples are produced in HBM after launch_forward().
 	int prepare_entropy(size_t sample_cap);
 	GpuEntropyEncoder &entropy() { return ent_; }
@@ -45,6 +46,7 @@ public:
 private:
 	void release();
 	int sync_jobs();
+	void fill_jobs();
 	FramePlan plan_;
 	int n_ = 0; bool own_input_ = false, jobs_dirty_ = true;
 	void *stream_ = nullptr, *ev0_ = nullptr, *ev1_ = nullptr, *evl_[2] = {nullptr, nullptr};

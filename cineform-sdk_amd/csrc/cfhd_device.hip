@@ -183,6 +183,17 @@ int EncodeBatch::prepare(const FramePlan &plan, int nframes, bool own_input)
 	HIPCHK(hipHostMalloc(&h_jobs_, jobs_bytes_, hipHostMallocDefault));
 	memset(h_jobs_, 0, jobs_bytes_);
 
+	fill_jobs();
+	return 0;
+}
+
+// (Re)writes the job tables from plan_: geometry, band addresses and quantizer parameters.  Input frame pointers set with
+// set_device_frame() are kept.
+void EncodeBatch::fill_jobs()
+{
+	const FramePlan &plan = plan_;
+	const bool own_input = own_input_;
+	const bool bayer = plan.pixel_kind == PIX_BYR4;
 	const int nch = plan.num_channels, mpq = plan.midpoint_prequant;
 	EncJobs j = enc_jobs_at(h_jobs_, n_, nch);
 	for (int i = 0; i < n_; i++) {
@@ -235,6 +246,29 @@ int EncodeBatch::prepare(const FramePlan &plan, int nframes, bool own_input)
 			}
 	}
 	jobs_dirty_ = true;
+}
+
+// New quantizer tables for the frames encoded from now on (rate feedback re-derives them per frame: quantize.c:186, :2865): the band
+// geometry is unchanged, only the divisors in the job tables and in the sample headers move.
+int EncodeBatch::update_quant(const FramePlan &plan)
+{
+	if (plan.coeff_elems != plan_.coeff_elems || plan.num_channels != plan_.num_channels) return -1;
+	if (stream_) HIPCHK(hipStreamSynchronize((hipStream_t)stream_));      // the pinned job table may still be in flight
+	EncJobs j = enc_jobs_at(h_jobs_, n_, plan_.num_channels);
+	std::vector<const void *> keep_yuv(n_), keep_bayer(n_), keep_l1((size_t)n_ * plan_.num_channels);
+	std::vector<int> keep_pitch(n_), keep_bpitch(n_), keep_l1pitch((size_t)n_ * plan_.num_channels);
+	for (int i = 0; i < n_; i++) {
+		keep_yuv[i] = j.yuv[i].in; keep_pitch[i] = j.yuv[i].in_pitch; keep_bayer[i] = j.bayer[i].in; keep_bpitch[i] = j.bayer[i].in_pitch;
+		for (int c = 0; c < plan_.num_channels; c++) { keep_l1[(size_t)i * plan_.num_channels + c] = j.l1[(size_t)i * plan_.num_channels + c].in; keep_l1pitch[(size_t)i * plan_.num_channels + c] = j.l1[(size_t)i * plan_.num_channels + c].in_pitch; }
+	}
+	plan_ = plan;
+	fill_jobs();
+	if (!own_input_) for (int i = 0; i < n_; i++) {
+		j.yuv[i].in = (const uint8_t *)keep_yuv[i]; j.yuv[i].in_pitch = keep_pitch[i];
+		if (plan_.pixel_kind == PIX_BYR4) { j.bayer[i].in = (const uint16_t *)keep_bayer[i]; j.bayer[i].in_pitch = keep_bpitch[i]; }
+		if (is_packed16(plan_.pixel_kind)) for (int c = 0; c < plan_.num_channels; c++) { j.l1[(size_t)i * plan_.num_channels + c].in = (const int16_t *)keep_l1[(size_t)i * plan_.num_channels + c]; j.l1[(size_t)i * plan_.num_channels + c].in_pitch = keep_l1pitch[(size_t)i * plan_.num_channels + c]; }
+	}
+	if (ent_ready_) ent_.set_plan(plan);
 	return 0;
 }
 
@@ -522,6 +556,7 @@ int DecodeBatch::set_device_output(int i, void *d_out, int pitch)
 {
 	if (i < 0 || i >= n_) return -1;
 	DecJobs j = dec_jobs_at(h_jobs_, n_, plan_.num_channels);
+	if (half_ && is_packed16(out_kind_)) { j.halfp[i].out = (uint16_t *)d_out; j.halfp[i].out_pitch = pitch; jobs_dirty_ = true; return 0; }
 	if (is_packed16(out_kind_)) {
 		for (int c = 0; c < plan_.num_channels; c++) {
 			dev::InvPlaneJob &p = j.l1[(size_t)i * plan_.num_channels + c];
@@ -530,7 +565,6 @@ int DecodeBatch::set_device_output(int i, void *d_out, int pitch)
 		jobs_dirty_ = true;
 		return 0;
 	}
-	if (half_ && is_packed16(out_kind_)) { j.halfp[i].out = (uint16_t *)d_out; j.halfp[i].out_pitch = pitch; jobs_dirty_ = true; return 0; }
 	if (half_) { j.half[i].out = (uint8_t *)d_out; j.half[i].out_pitch = pitch; jobs_dirty_ = true; return 0; }
 	if (j.yuv[i].out != d_out || j.yuv[i].out_pitch != pitch) { j.yuv[i].out = (uint8_t *)d_out; j.yuv[i].out_pitch = pitch; jobs_dirty_ = true; }
 	return 0;

@@ -14,6 +14,7 @@ public:
 	// coeffs: device pyramid of frame 0; frames are coeff_stride elements apart.
 	int prepare(const FramePlan &plan, int nframes, int16_t *d_coeffs, size_t coeff_stride_elems, size_t sample_cap, void *stream);
 	int set_frame_header(int i, const SampleHeaderInfo &hdr);        // header fields / metadata of frame i's sample
+	void set_plan(const FramePlan &plan) { plan_ = plan; }          // same geometry, new quantizer values: the headers written from now on carry them
 	int launch();                                                    // async: templates H2D + 4 kernels
 	int download();                                                  // sizes + packed offsets -> sync -> one async copy of all sample bytes (wait on the stream afterwards)
 	int fetch_sizes();                                               // sizes only (device-resident consumers); synchronises the stream

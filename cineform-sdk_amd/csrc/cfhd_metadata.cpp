@@ -1,5 +1,9 @@
 #include "cfhd_metadata.h"
 #include <string.h>
+#include <stdio.h>
+#include <time.h>
+#include <mutex>
+#include <random>
 
 namespace cfhd {
 
@@ -75,6 +79,87 @@ void meta_remove_hidden(MetaBlock &b)
 		uint32_t entry = 8 + padded(ts & 0xffffff);
 		if ((ts >> 24) == 'h' && pos + entry <= b.size()) b.erase(b.begin() + pos, b.begin() + pos + entry);
 		else pos += entry;
+	}
+}
+
+namespace {
+std::mutex g_guid_mutex;
+bool g_guid_fixed = false;
+unsigned char g_guid[16];
+}
+
+void meta_new_guid(unsigned char out[16])
+{
+	std::lock_guard<std::mutex> lk(g_guid_mutex);
+	if (g_guid_fixed) { memcpy(out, g_guid, 16); return; }
+	std::random_device rd;
+	for (int i = 0; i < 16; i += 4) { uint32_t r = rd(); memcpy(out + i, &r, 4); }
+	out[6] = (out[6] & 0x0f) | 0x40; out[8] = (out[8] & 0x3f) | 0x80;    // RFC 4122 version 4
+}
+
+void meta_fix_guid(const unsigned char guid[16])
+{
+	std::lock_guard<std::mutex> lk(g_guid_mutex);
+	if (guid) { memcpy(g_guid, guid, 16); g_guid_fixed = true; } else g_guid_fixed = false;
+}
+
+void MetaState::handle()
+{
+	if (global.empty()) { unsigned char g[16]; meta_new_guid(g); meta_add(global, MTAG_CLIP_GUID, 'G', 16, g); }
+	time_t clock = time(NULL);
+	struct tm tmv; localtime_r(&clock, &tmv);
+	char datestr[32], timestr[32], tmp[32];
+	snprintf(datestr, sizeof(datestr), "%04d-%02d-%02d", tmv.tm_year + 1900, tmv.tm_mon + 1, tmv.tm_mday);
+	snprintf(timestr, sizeof(timestr), "%02d:%02d:%02d", tmv.tm_hour, tmv.tm_min, tmv.tm_sec);
+	meta_add(global, MTAG_ENCODE_DATE, 'c', 10, datestr);
+	meta_add(global, MTAG_ENCODE_TIME, 'c', 8, timestr);
+
+	bool in_local = false;
+	uint32_t sz; unsigned char ty;
+	const uint8_t *data = meta_find(global.data(), global.size(), MTAG_TIMECODE, &sz, &ty);
+	if (!data) {
+		data = meta_find(local.data(), local.size(), MTAG_TIMECODE, &sz, &ty);
+		if (!data) {
+			last_timecode_base = 24;
+			last_timecode_frame = tmv.tm_hour * 3600 * 24 + tmv.tm_min * 60 * 24 + tmv.tm_sec * 24;
+			snprintf(tmp, sizeof(tmp), "%02d:%02d:%02d:00", tmv.tm_hour, tmv.tm_min, tmv.tm_sec);
+			meta_add(global, MTAG_TIMECODE, 'c', 11, tmp);
+		} else in_local = true;
+	}
+	if (data) {
+		const char *tc = (const char *)data;
+		int hours = (tc[0] - '0') * 10 + (tc[1] - '0'), mins = (tc[3] - '0') * 10 + (tc[4] - '0');
+		int secs = (tc[6] - '0') * 10 + (tc[7] - '0'), frms = (tc[9] - '0') * 10 + (tc[10] - '0');
+		if (last_timecode_base == 0) {
+			const uint8_t *b = meta_find(local.data(), local.size(), MTAG_TIMECODE_BASE, &sz, &ty);
+			if (!b) b = meta_find(global.data(), global.size(), MTAG_TIMECODE_BASE, &sz, &ty);
+			last_timecode_base = b ? *b : 24;
+			if (last_timecode_base == 0) last_timecode_base = 24;
+		}
+		int base = last_timecode_base;
+		int framenum = hours * 3600 * base + mins * 60 * base + secs * base + frms;
+		if (last_timecode_frame == -1) last_timecode_frame = framenum;
+		else if (framenum == last_timecode_frame && base <= 30) {
+			framenum = ++last_timecode_frame;
+			frms = framenum % base; framenum /= base;
+			secs = framenum % 60; framenum /= 60;
+			mins = framenum % 60; framenum /= 60;
+			hours = framenum % 60;
+			snprintf(tmp, sizeof(tmp), "%02d:%02d:%02d:%02d", hours, mins, secs, frms);
+			meta_add(in_local ? local : global, MTAG_TIMECODE, 'c', 11, tmp);
+		}
+	}
+	in_local = false;
+	data = meta_find(global.data(), global.size(), MTAG_UNIQUE_FRAMENUM, &sz, &ty);
+	if (!data) {
+		data = meta_find(local.data(), local.size(), MTAG_UNIQUE_FRAMENUM, &sz, &ty);
+		if (!data) { last_unique_frame = 0; uint32_t v = 0; meta_add(global, MTAG_UNIQUE_FRAMENUM, 'L', 4, &v); }
+		else in_local = true;
+	}
+	if (data) {
+		int32_t n; memcpy(&n, data, 4);
+		if (last_unique_frame == -1) last_unique_frame = n;
+		else if (n <= last_unique_frame) { uint32_t v = (uint32_t)++last_unique_frame; meta_add(in_local ? local : global, MTAG_UNIQUE_FRAMENUM, 'L', 4, &v); }
 	}
 }
 

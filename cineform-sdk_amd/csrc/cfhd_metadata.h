@@ -23,4 +23,17 @@ const uint8_t *meta_find(const uint8_t *block, size_t block_size, uint32_t tag, 
 // Drops tuples of the hidden type 'h' (Codec/encoder.c:8906 RemoveHiddenMetadata).
 void meta_remove_hidden(MetaBlock &block);
 
+// Clip GUID of a new metadata block: random (RFC 4122 version 4) unless pinned with meta_fix_guid (cfhd_amd_set_clip_guid, for tests).
+void meta_new_guid(unsigned char out[16]);
+void meta_fix_guid(const unsigned char guid[16] /* NULL: random again */);
+
+// The per-encoder metadata state machine (EncoderSDK/SampleEncoder.cpp:744-939 HandleMetadata): before every frame the encoder makes
+// sure the global block carries a clip GUID, today's encode date / time, a timecode that advances by one frame per sample and a
+// unique frame number that increases per sample.
+struct MetaState {
+	MetaBlock global, local;
+	int last_timecode_base = 0, last_timecode_frame = -1, last_unique_frame = -1;
+	void handle();
+};
+
 } // namespace cfhd

@@ -208,7 +208,9 @@ int slow_decode_symbol(int codebook, uint32_t window /*next 32 bits, MSB first*/
 bool build_frame_plan(FramePlan *plan, int width, int height, int pixel_kind, int encoded_format)
 {
 	memset(plan, 0, sizeof(*plan));
-	if (width <= 0 || height <= 0) return false;
+	// Dimensions come from untrusted sample headers (16-bit fields): beyond kMaxFrameDim the 32-bit band offsets below could wrap and a
+	// crafted sample would make the decoder write outside its pyramid.  16384 x 16384 x 4 channels x 21/16 = 1.4 G elements fits.
+	if (width <= 0 || height <= 0 || width > kMaxFrameDim || height > kMaxFrameDim) return false;
 	plan->display_height = height;
 	plan->encoded_format = encoded_format;
 	plan->pixel_kind = pixel_kind;
@@ -228,11 +230,11 @@ bool build_frame_plan(FramePlan *plan, int width, int height, int pixel_kind, in
 	if ((chroma_width % 8) != 0 || (width % 8) != 0) return false;
 
 	// Final (entropy coded) bands first, then the two intermediate LL planes of every channel.
-	uint32_t off = 0;
+	uint64_t off = 0;
 	auto place = [&](BandDesc &b, int w, int h) {
-		b.width = w; b.height = h; b.pitch = align_up(w, 8); b.offset = off; b.quant = 1; b.scale = 1;
-		uint32_t elems = (uint32_t)b.pitch * (uint32_t)h;
-		off += (elems + 63u) & ~63u;      // 128-byte aligned bands
+		b.width = w; b.height = h; b.pitch = align_up(w, 8); b.offset = (uint32_t)off; b.quant = 1; b.scale = 1;
+		uint64_t elems = (uint64_t)b.pitch * (uint64_t)h;
+		off += (elems + 63u) & ~(uint64_t)63;      // 128-byte aligned bands
 	};
 	for (int c = 0; c < plan->num_channels; c++) {
 		ChannelPlan &cp = plan->ch[c];
@@ -241,13 +243,14 @@ bool build_frame_plan(FramePlan *plan, int width, int height, int pixel_kind, in
 		for (int lv = 2; lv >= 0; lv--)
 			for (int b = 1; b < 4; b++) place(cp.band[lv][b], cp.width >> (lv + 1), cp.height >> (lv + 1));
 	}
-	plan->final_elems = off;
+	plan->final_elems = (uint32_t)off;
 	for (int c = 0; c < plan->num_channels; c++) {
 		ChannelPlan &cp = plan->ch[c];
 		place(cp.band[0][0], cp.width >> 1, cp.height >> 1);
 		place(cp.band[1][0], cp.width >> 2, cp.height >> 2);
 	}
-	plan->coeff_elems = off;
+	if (off >= ((uint64_t)1 << 31)) return false;      // element offsets and raster indices stay inside 31 bits everywhere
+	plan->coeff_elems = (uint32_t)off;
 	return true;
 }
 

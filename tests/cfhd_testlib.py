@@ -202,17 +202,40 @@ _product = None
 
 
 def product():
+    """libcfhd_amd.so: the CFHD_* C ABI and the cfhd_amd_batch_* extension (needs a GPU for anything that computes)."""
     global _product
     if _product is None:
         if not os.path.exists(PRODUCT_SO):
             subprocess.check_call(["make", "-C", PRODUCT_DIR])
         L = ctypes.CDLL(PRODUCT_SO)
-        L.cfhd_amd_write_sample_host.restype = ctypes.c_size_t
-        L.cfhd_amd_write_sample_host.argtypes = [ctypes.c_int] * 8 + [ctypes.c_uint, c_i16p, c_u8p, ctypes.c_size_t, c_u8p, ctypes.c_size_t, c_u8p, ctypes.c_size_t]
-        L.cfhd_amd_decode_bands_host.argtypes = [c_u8p, ctypes.c_size_t, ctypes.c_int, c_i16p, ctypes.c_size_t, c_intp, ctypes.c_int]
         declare_cfhd_api(L)
         _product = L
     return _product
+
+
+HOOKS_SO = os.path.join(ROOT, "tests", "_build", "libcfhd_hooks.so")
+_hooks = None
+
+
+def hooks():
+    """Test-only library: tests/hooks/cfhd_hooks.cpp + the product's host-only sources (plan geometry, quantizer derivation, sample
+    writer / parser, host VLC), compiled with g++.  Not part of libcfhd_amd.so."""
+    global _hooks
+    if _hooks is None:
+        csrc = os.path.join(PRODUCT_DIR, "csrc")
+        srcs = [os.path.join(ROOT, "tests", "hooks", "cfhd_hooks.cpp")] + [os.path.join(csrc, f) for f in ("cfhd_tables.cpp", "cfhd_bitstream.cpp", "cfhd_metadata.cpp")]
+        deps = srcs + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".h")]
+        if not os.path.exists(HOOKS_SO) or any(os.path.getmtime(d) > os.path.getmtime(HOOKS_SO) for d in deps):
+            os.makedirs(os.path.dirname(HOOKS_SO), exist_ok=True)
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + csrc, "-I" + os.path.join(ROOT, "include")] + srcs + ["-o", HOOKS_SO])
+        L = ctypes.CDLL(HOOKS_SO)
+        L.cfhd_amd_write_sample_host.restype = ctypes.c_size_t
+        L.cfhd_amd_write_sample_host.argtypes = [ctypes.c_int] * 8 + [ctypes.c_uint, c_i16p, c_u8p, ctypes.c_size_t, c_u8p, ctypes.c_size_t, c_u8p, ctypes.c_size_t]
+        L.cfhd_amd_decode_bands_host.argtypes = [c_u8p, ctypes.c_size_t, ctypes.c_int, c_i16p, ctypes.c_size_t, c_intp, ctypes.c_int]
+        L.cfhd_amd_quant_sequence.argtypes = [ctypes.c_int] * 6 + [ctypes.POINTER(ctypes.c_longlong), ctypes.c_int, c_intp]
+        L.cfhd_amd_sample_quants.argtypes = [c_u8p, ctypes.c_size_t, c_intp]
+        _hooks = L
+    return _hooks
 
 
 class Plan:
@@ -220,7 +243,7 @@ class Plan:
 
     def __init__(self, width, height, pixkind=1, enc=1, quality=QUALITY_FILMSCAN1, progressive=1):
         buf = (ctypes.c_int * 512)()
-        n = product().cfhd_amd_plan_info(width, height, pixkind, enc, quality, progressive, buf)
+        n = hooks().cfhd_amd_plan_info(width, height, pixkind, enc, quality, progressive, buf)
         assert n > 0, "plan_info failed"
         v = list(buf[:n])
         self.coeff_elems, self.final_elems, self.num_channels, self.precision, self.mpq = v[0:5]
@@ -461,7 +484,7 @@ def product_write_sample_host(plan, coeffs, frame_number, meta_global=b"", meta_
     out = np.zeros(plan.width * plan.height * 4 + 65536, dtype=np.uint8)
     mg = np.frombuffer(meta_global, dtype=np.uint8).copy() if meta_global else np.zeros(4, np.uint8)
     ml = np.frombuffer(meta_local, dtype=np.uint8).copy() if meta_local else np.zeros(4, np.uint8)
-    n = product().cfhd_amd_write_sample_host(plan.width, plan.height, plan.pixkind, plan.enc, plan.quality, progressive, input_format, color_space,
+    n = hooks().cfhd_amd_write_sample_host(plan.width, plan.height, plan.pixkind, plan.enc, plan.quality, progressive, input_format, color_space,
                                              frame_number, p16(coeffs), p8(mg), len(meta_global), p8(ml), len(meta_local), p8(out), out.size)
     assert n > 0
     return bytes(out[:n])
@@ -560,7 +583,7 @@ def host_decode_pyramid(sample, plan, lowpass_offset=1):
     out = np.zeros(plan.coeff_elems, dtype=np.int16)
     info = (ctypes.c_int * 8)()
     s = np.frombuffer(sample, dtype=np.uint8).copy()
-    rc = product().cfhd_amd_decode_bands_host(p8(s), len(sample), plan.pixkind, p16(out), out.size, info, lowpass_offset)
+    rc = hooks().cfhd_amd_decode_bands_host(p8(s), len(sample), plan.pixkind, p16(out), out.size, info, lowpass_offset)
     assert rc == 0, rc
     return out
 

@@ -1,6 +1,7 @@
-// cfhd_hooks.cpp -- host-only entry points (prefix cfhd_amd_) used by the CPU-side tests to exercise the
-// product's own syntax layer (plan geometry, quantizer derivation, sample writer/parser, host VLC)
-// without a GPU.  They are not part of the CFHD_* drop-in ABI and never touch the device.
+// tests/hooks/cfhd_hooks.cpp -- TEST INFRASTRUCTURE ONLY.  Host-only entry points (prefix cfhd_amd_) with which the CPU-side tests
+// exercise the product's own syntax layer (plan geometry, quantizer derivation, sample writer/parser, host VLC) without a GPU.
+// Built by tests/cfhd_testlib.py into tests/_build/libcfhd_hooks.so together with the product's host-only sources
+// (cfhd_tables.cpp, cfhd_bitstream.cpp, cfhd_metadata.cpp); not linked into libcfhd_amd.so.
 #include "cfhd_core.h"
 #include "cfhd_bitstream.h"
 #include <string.h>
@@ -27,6 +28,39 @@ int cfhd_amd_plan_info(int width, int height, int pixel_kind, int encoded_format
 				const BandDesc &d = plan.ch[c].band[lv][b];
 				out[n++] = d.width; out[n++] = d.height; out[n++] = d.pitch; out[n++] = (int)d.offset; out[n++] = d.quant; out[n++] = d.scale;
 			}
+	return n;
+}
+
+// Quantizer tables of a sequence of frames under rate feedback: frame f is derived with lastgopbitcount = 8 * sample_bytes[f - 1]
+// (0 for the first), the state carried from frame to frame as the encoder carries it.  out: per frame, per channel, the 9 highpass
+// divisors in coding order (level 3 LH HL HH, level 2, level 1).
+int cfhd_amd_quant_sequence(int width, int height, int pixel_kind, int encoded_format, int quality, int progressive,
+                            const long long *sample_bytes, int nframes, int *out)
+{
+	FramePlan plan;
+	if (!build_frame_plan(&plan, width, height, pixel_kind, encoded_format)) return -1;
+	plan.interlaced = !progressive;
+	QuantState st = {0, -1, 0};
+	int n = 0;
+	for (int f = 0; f < nframes; f++) {
+		st.lastgopbitcount = f ? (int64_t)sample_bytes[f - 1] * 8 : 0;
+		derive_quantization(&plan, quality, progressive != 0, 0.0f, &st);
+		for (int c = 0; c < plan.num_channels; c++)
+			for (int lv = kNumLevels - 1; lv >= 0; lv--)
+				for (int b = 1; b < kNumBands; b++) out[n++] = plan.ch[c].band[lv][b].quant;
+	}
+	return n;
+}
+
+// Highpass divisors a sample's band headers carry, same order as above (9 per channel).  Returns the count or < 0.
+int cfhd_amd_sample_quants(const uint8_t *sample, size_t size, int *out)
+{
+	ParsedSample ps;
+	if (parse_sample(sample, size, &ps) != 0) return -1;
+	int n = 0;
+	for (int c = 0; c < ps.num_channels; c++)
+		for (int lv = kNumLevels - 1; lv >= 0; lv--)
+			for (int b = 1; b < kNumBands; b++) out[n++] = ps.high[c][lv][b].quant;
 	return n;
 }
 

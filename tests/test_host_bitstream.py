@@ -60,7 +60,7 @@ def test_parse_and_host_decode_roundtrip(w, h):
     out = np.zeros(plan.coeff_elems, dtype=np.int16)
     info = (ctypes.c_int * 8)()
     s = np.frombuffer(sample, dtype=np.uint8).copy()
-    rc = product().cfhd_amd_decode_bands_host(p8(s), len(sample), 1, p16(out), out.size, info, 0)
+    rc = hooks().cfhd_amd_decode_bands_host(p8(s), len(sample), 1, p16(out), out.size, info, 0)
     assert rc == 0
     assert list(info)[:5] == [w, plan.height, h, 3, 10]
     # expected: companding curve applied by the encoder LUT, expanded and dequantized by the decoder
@@ -133,8 +133,8 @@ def test_bayer_curve_table_equals_oracle():
     want = np.zeros(1 << 14, np.uint16); got = np.zeros(1 << 14, np.uint16)
     oracle().orc_byr4_log90_curve.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     oracle().orc_byr4_log90_curve(12, 14, want.ctypes.data_as(ctypes.c_void_p))
-    product().cfhd_amd_bayer_curve.argtypes = [ctypes.c_int, ctypes.c_void_p]
-    product().cfhd_amd_bayer_curve(12, got.ctypes.data_as(ctypes.c_void_p))
+    hooks().cfhd_amd_bayer_curve.argtypes = [ctypes.c_int, ctypes.c_void_p]
+    hooks().cfhd_amd_bayer_curve(12, got.ctypes.data_as(ctypes.c_void_p))
     assert np.array_equal(got, want)
 
 
@@ -235,3 +235,57 @@ def test_obsolete_header_parser_and_encoder_side_thumbnail_equal_reference(w, h,
         got.append((list(hdr), tw.value, th.value, bytes(out[: tn.value])))
     assert got[0] == got[1]
     assert got[0][0][2:] == [w, h]
+
+
+@pytest.mark.parametrize("w,h,fmt,enc", [(320, 240, PIX_YUY2, ENCODED_YUV422), (320, 240, PIX_RG48, ENCODED_RGB444), (320, 240, PIX_B64A, ENCODED_RGBA4444),
+                                         (320, 240, PIX_BYR4, 3)])
+def test_sample_info_equals_reference(w, h, fmt, enc):
+    """CFHD_GetSampleInfo, every tag, against the reference on the same sample -- CFHD_SAMPLE_ENCODED_FORMAT in particular is the public
+    CFHD_EncodedFormat value (SampleDecoder.cpp:821-840), not the bitstream's code."""
+    if not have_ref(): pytest.skip("reference .so not built")
+    if fmt == PIX_YUY2: frames, pitch = [synth_yuy2(w, h, 5)[0]], w * 2
+    elif fmt == PIX_BYR4:
+        mosaic = synth_bayer(w, h, 3); frames, pitch = [mosaic.reshape(-1).view(np.uint8).copy()], w * 2
+    else: frames, pitch = qbist_frames(10, 1, w, h, fmt, alpha=1) if fmt == PIX_B64A else qbist_frames(10, 1, w, h, fmt)
+    sample = ref_encode_frames(frames, pitch, w, h, fmt, encoded=enc)[0]
+    sb = ctypes.create_string_buffer(sample, len(sample))
+    got = []
+    for L in (ref(), product()):
+        dec = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
+        vals = []
+        for tag in (1, 2, 3, 4, 5):                  # display width / height, key frame, progressive, encoded format
+            v = ctypes.c_int32(-7)
+            rc = L.CFHD_GetSampleInfo(dec, sb, ctypes.c_size_t(len(sample)), tag, ctypes.byref(v), ctypes.c_size_t(4))
+            vals.append((rc, v.value))
+        L.CFHD_CloseDecoder(dec)
+        got.append(vals)
+    assert got[0] == got[1]
+    assert got[1][4] == (0, enc)
+
+
+@pytest.mark.parametrize("quality", [5, 6, 2])
+def test_rate_feedback_quantizers_follow_the_reference(quality):
+    """Multi-frame encodes at FILMSCAN2 / FILMSCAN3 (and MEDIUM, whose bit-rate limiter looks at the previous sample) re-derive the
+    quantizer tables every frame from the size of the previous sample (encoder.c:9442, :9911; quantize.c:186-300, :2994).  The product's
+    derivation, fed with the reference's own sample sizes, must produce the divisors the reference wrote into its band headers."""
+    if not have_ref(): pytest.skip("reference .so not built")
+    w, h, n = 640, 360, 6
+    rng = np.random.default_rng(3)
+    frames = []
+    for i in range(n):                               # busy frames: the limiter has something to react to
+        f = synth_yuy2(w, h, 40 + i)[0].reshape(h, w * 2).astype(np.int32)
+        f += rng.integers(-40, 41, f.shape) * (1 + i % 3)
+        frames.append(np.clip(f, 0, 255).astype(np.uint8).reshape(-1).copy())
+    samples = ref_encode_frames(frames, w * 2, w, h, quality=quality)
+    sizes = (ctypes.c_longlong * n)(*[len(s) for s in samples])
+    mine = (ctypes.c_int * (n * 27))()
+    assert hooks().cfhd_amd_quant_sequence(w, h, 1, 1, quality, 1, sizes, n, mine) == n * 27
+    moved = False
+    for f, s in enumerate(samples):
+        theirs = (ctypes.c_int * 64)()
+        a = np.frombuffer(s, np.uint8).copy()
+        assert hooks().cfhd_amd_sample_quants(p8(a), len(s), theirs) == 27
+        assert list(theirs[:27]) == list(mine[27 * f: 27 * f + 27]), "frame %d" % f
+        moved |= f > 0 and list(mine[27 * f: 27 * f + 27]) != list(mine[:27])
+    if quality >= 5:
+        assert moved, "the test frames never moved the limiter: nothing was tested"
