@@ -146,6 +146,18 @@ def synth_yuy2(width, height, seed):
     return f.reshape(-1).copy(), width * 2
 
 
+def feedback_test_frames(w=640, h=360, n=6):
+    """Frames whose compressed size changes from one to the next (noise of varying strength on the gradients), so that the rate
+    feedback of FILMSCAN2/3 and the bit-rate limiter have something to react to; the samples stay below the sample buffer size."""
+    rng = np.random.default_rng(3)
+    frames = []
+    for i in range(n):
+        f = synth_yuy2(w, h, 40 + i)[0].reshape(h, w * 2).astype(np.int32)
+        f += rng.integers(-9, 10, f.shape) * (1 + i % 3)
+        frames.append(np.clip(f, 0, 255).astype(np.uint8).reshape(-1).copy())
+    return frames
+
+
 def ref_encode_frames(frames, pitch, width, height, pixfmt=PIX_YUY2, encoded=ENCODED_YUV422, quality=QUALITY_FILMSCAN1, flags=0):
     """Encode through the reference's own C ABI (CFHD_OpenEncoder ... CFHD_GetSampleData); returns list of bytes."""
     L = ref()

@@ -582,12 +582,7 @@ def test_multi_frame_rate_feedback_bitstream_identical(quality):
     """FILMSCAN2 / FILMSCAN3 / MEDIUM re-derive their quantizer tables every frame from the size of the previous sample
     (encoder.c:9442, :9911): a sequence must stay byte-identical to the reference beyond the first frame."""
     w, h, n = 640, 360, 6
-    rng = np.random.default_rng(3)
-    frames = []
-    for i in range(n):
-        f = synth_yuy2(w, h, 40 + i)[0].reshape(h, w * 2).astype(np.int32)
-        f += rng.integers(-40, 41, f.shape) * (1 + i % 3)
-        frames.append(np.clip(f, 0, 255).astype(np.uint8).reshape(-1).copy())
+    frames = feedback_test_frames(w, h, n)
     _check_encode(frames, w * 2, w, h, quality=quality)
 
 

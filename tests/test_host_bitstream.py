@@ -270,12 +270,7 @@ def test_rate_feedback_quantizers_follow_the_reference(quality):
     derivation, fed with the reference's own sample sizes, must produce the divisors the reference wrote into its band headers."""
     if not have_ref(): pytest.skip("reference .so not built")
     w, h, n = 640, 360, 6
-    rng = np.random.default_rng(3)
-    frames = []
-    for i in range(n):                               # busy frames: the limiter has something to react to
-        f = synth_yuy2(w, h, 40 + i)[0].reshape(h, w * 2).astype(np.int32)
-        f += rng.integers(-40, 41, f.shape) * (1 + i % 3)
-        frames.append(np.clip(f, 0, 255).astype(np.uint8).reshape(-1).copy())
+    frames = feedback_test_frames(w, h, n)
     samples = ref_encode_frames(frames, w * 2, w, h, quality=quality)
     sizes = (ctypes.c_longlong * n)(*[len(s) for s in samples])
     mine = (ctypes.c_int * (n * 27))()
