@@ -1,29 +1,32 @@
 #!/usr/bin/env python3
-"""bench.py -- 1080p YUY2 4:2:2 encode+decode round trip on MI355X (BASELINE.json metric).
+"""bench.py -- CineForm encode+decode round trip on MI355X (BASELINE.json metric: 1080p YUY2 encode+decode fps, % of the HBM roofline,
+bitstream-exact).
 
 A step = one pass of the hot path over one batch of synthetic frames that are already resident in HBM:
-forward kernels -> entropy coding -> samples -> entropy decoding -> inverse kernels -> frames in HBM.
-`value` is whole-job frames per second (all ranks), `roofline` is the longest kernel of the step against the
-HBM peak (HIP events around every launch), `cpu_baseline` is the unmodified reference (oracle/_ref) timed on this box's host cores on a bounded sample.
+forward kernels -> entropy coding -> samples -> entropy decoding -> inverse kernels -> frames in HBM, and the host copy of every sample.
+`value` is whole-job frames per second (all ranks); `roofline` is the longest kernel of the step against the HBM peak (HIP events around
+every launch, on the stream it runs on); `cpu_baseline` is the unmodified reference (oracle/_ref) timed on this box's host cores on a
+bounded sample.  After the timed region rank 0 checks what it timed: sample 0 of the last step against the reference encoder's golden
+hash, decoded frame 0 against the exact reconstruction (`config.parity_checked`), and measures the same codec through the reference's own
+C ABI from host buffers (`config.c_abi_fps`, PCIe inclusive, never `value`).
 
-  python bench.py --gpus 1 --steps 20 --warmup 3
+  python bench.py --gpus 1 --steps 20 --warmup 3 [--workload 1080p|2160p]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
-import argparse, ctypes, json, os, sys, time
+import argparse, ctypes, hashlib, json, os, struct, sys, threading, time
 os.environ.setdefault("HSA_ENABLE_SDMA", "1")   # D2H of the samples on the SDMA engines: blit-kernel copies stall the kernels they overlap with
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
-W, H = 1920, 1080
+WORKLOADS = {"1080p": (1920, 1080, 512), "2160p": (3840, 2160, 128)}      # width, height, default frames per step
 
 
-def cpu_baseline(frames, pitch, seconds_budget=20.0):
+def cpu_baseline(frames, pitch, W, H, seconds_budget=20.0):
     """Reference SSE2 path on the host cores: async pool encode (POOL_THREADS = cores) + decode of the same samples."""
     import cfhd_testlib as T
-    if not T.have_ref():
-        return None
+    import numpy as np
     L = T.ref()
     cores = os.cpu_count() or 1
     nfr = len(frames)
@@ -47,19 +50,17 @@ def cpu_baseline(frames, pitch, seconds_budget=20.0):
             return False
         p = ctypes.c_void_p(); n = ctypes.c_size_t()
         L.CFHD_GetEncodedSample(sb, ctypes.byref(p), ctypes.byref(n))
-        if len(samples) < nfr:
-            samples.append(ctypes.string_at(p, n.value))
-        else:
-            samples.append(None)
+        samples.append(ctypes.string_at(p, n.value) if len(samples) < nfr else None)
         L.CFHD_ReleaseSampleBuffer(pool, sb)
         return True
+    fail = lambda why: {"value": None, "unit": "fps", "cores": cores, "kind": "reference", "sample": why}
     t0 = time.time(); sent = 0; target = 4 * nfr
     qlen = max(2, cores * 3 // 2)
     while True:
         # the job queue holds finished jobs until they are collected: never submit into a full queue (TestCFHD.cpp:903 does the same)
         while sent - len(samples) >= qlen:
             if not collect(True):
-                return {"value": None, "unit": "fps", "cores": cores, "kind": "reference", "sample": "reference pool failed"}
+                return fail("reference pool failed")
         frms = 24 * 3600 + sent
         tc = ctypes.create_string_buffer(("%02d:%02d:%02d:%02d" % ((frms // 86400) % 24, (frms // 1440) % 60, (frms // 24) % 60, frms % 24)).encode(), 12)
         L.CFHD_MetadataAdd(meta, mtag("TIMC"), 1, 11, ctypes.cast(tc, ctypes.c_void_p), False)
@@ -67,7 +68,7 @@ def cpu_baseline(frames, pitch, seconds_budget=20.0):
         L.CFHD_MetadataAdd(meta, mtag("UFRM"), 2, 4, ctypes.cast(ctypes.pointer(uf), ctypes.c_void_p), False)
         rc = L.CFHD_EncodeAsyncSample(pool, sent + 1, frames[sent % nfr].ctypes.data_as(ctypes.c_void_p), pitch, meta)
         if rc != 0:
-            return {"value": None, "unit": "fps", "cores": cores, "kind": "reference", "sample": "reference pool returned error %d" % rc}
+            return fail("reference pool returned error %d" % rc)
         sent += 1
         while collect(False):
             pass
@@ -75,7 +76,7 @@ def cpu_baseline(frames, pitch, seconds_budget=20.0):
             break
     while len(samples) < sent:
         if not collect(True):
-            return {"value": None, "unit": "fps", "cores": cores, "kind": "reference", "sample": "reference pool failed while draining"}
+            return fail("reference pool failed while draining")
     t_enc = time.time() - t0
     L.CFHD_ReleaseEncoderPool(pool)
     L.CFHD_MetadataClose(meta)
@@ -85,14 +86,13 @@ def cpu_baseline(frames, pitch, seconds_budget=20.0):
     aw = ctypes.c_int(); ah = ctypes.c_int(); af = ctypes.c_uint32()
     sbuf = [ctypes.create_string_buffer(s, len(s)) for s in samples[:nfr]]
     L.CFHD_PrepareToDecode(dec, 0, 0, T.PIX_YUY2, 1, 0, sbuf[0], 512, ctypes.byref(aw), ctypes.byref(ah), ctypes.byref(af))
-    import numpy as np
     out = np.zeros(W * 2 * H, dtype=np.uint8)
     t0 = time.time(); done = 0
     while True:
         s = sbuf[done % nfr]
         rc = L.CFHD_DecodeSample(dec, s, len(s), out.ctypes.data_as(ctypes.c_void_p), W * 2)
         if rc != 0:
-            return {"value": None, "unit": "fps", "cores": cores, "kind": "reference", "sample": "reference decoder returned error %d" % rc}
+            return fail("reference decoder returned error %d" % rc)
         done += 1
         if done >= 2 * nfr and time.time() - t0 > seconds_budget / 2:
             break
@@ -101,20 +101,190 @@ def cpu_baseline(frames, pitch, seconds_budget=20.0):
     dec_fps = done / t_dec
     rt = 1.0 / (1.0 / enc_fps + 1.0 / dec_fps)
     return {"value": round(rt, 1), "unit": "fps", "cores": cores, "kind": "reference",
-            "sample": "%d frames async-pool encode (%.1f fps, %d threads) + %d frames decode (%.1f fps) of 1920x1080 YUY2, reference SSE2 build"
-                      % (sent, enc_fps, cores, done, dec_fps)}
+            "sample": "%d frames async-pool encode (%.1f fps, %d threads) + %d frames decode (%.1f fps) of %dx%d YUY2, reference SSE2 build"
+                      % (sent, enc_fps, cores, done, dec_fps, W, H)}
+
+
+def c_abi_rates(frames, pitch, W, H, seconds=1.5, registered=False):
+    """The product through the reference's own C ABI, host buffers in and out (PCIe inclusive): what a caller of CFHD_* sees.
+    sync: one handle, one thread; pool: CFHD_*EncoderPool with `workers` HIP-stream workers; handles: N decoders on N host threads;
+    round_trip: the pool encoding and N decoders decoding its samples at the same time, frames per second through both.
+    registered: the caller page-locked its frame and output buffers once (cfhd_amd_register_host_buffer, an optional extension), so the
+    library DMAs between them and HBM without its staging copy."""
+    import cfhd_testlib as T
+    import numpy as np
+    L = T.product()
+    L.cfhd_amd_register_host_buffer.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    L.cfhd_amd_unregister_host_buffer.argtypes = [ctypes.c_void_p]
+    nfr = len(frames)
+    res = {}
+    if registered:
+        for f in frames: assert L.cfhd_amd_register_host_buffer(f.ctypes.data, f.nbytes) == 0
+    def new_output():
+        out = np.zeros(W * 2 * H, np.uint8)
+        if registered: assert L.cfhd_amd_register_host_buffer(out.ctypes.data, out.nbytes) == 0
+        return out
+    def drop_output(out):
+        if registered: L.cfhd_amd_unregister_host_buffer(out.ctypes.data)
+    enc = ctypes.c_void_p(); assert L.CFHD_OpenEncoder(ctypes.byref(enc), None) == 0
+    assert L.CFHD_PrepareToEncode(enc, W, H, T.PIX_YUY2, T.ENCODED_YUV422, 0, T.QUALITY_FILMSCAN1) == 0
+    samples = []
+    def enc_one(i):
+        assert L.CFHD_EncodeSample(enc, frames[i % nfr].ctypes.data_as(ctypes.c_void_p), pitch) == 0
+    for i in range(nfr):
+        enc_one(i)
+        p = ctypes.c_void_p(); sz = ctypes.c_size_t()
+        assert L.CFHD_GetSampleData(enc, ctypes.byref(p), ctypes.byref(sz)) == 0
+        samples.append(ctypes.string_at(p, sz.value))
+    t0 = time.perf_counter(); n = 0
+    while time.perf_counter() - t0 < seconds:
+        enc_one(n); n += 1
+    res["sync_encode_fps"] = round(n / (time.perf_counter() - t0), 1)
+    L.CFHD_CloseEncoder(enc)
+    sbs = [ctypes.create_string_buffer(s, len(s)) for s in samples]
+
+    def decoder_loop(stop, ready, done, k):
+        dec = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
+        aw = ctypes.c_int(); ah = ctypes.c_int(); af = ctypes.c_uint32()
+        assert L.CFHD_PrepareToDecode(dec, 0, 0, T.PIX_YUY2, 1, 0, sbs[0], 512, ctypes.byref(aw), ctypes.byref(ah), ctypes.byref(af)) == 0
+        out = new_output()
+        i = k
+        while not stop.is_set():
+            assert L.CFHD_DecodeSample(dec, sbs[i % nfr], len(samples[i % nfr]), out.ctypes.data_as(ctypes.c_void_p), W * 2) == 0
+            i += 1
+            done[k] += 1
+            if done[k] == 3: ready[k] = True               # buffers allocated, pipeline warm
+        L.CFHD_CloseDecoder(dec)
+        drop_output(out)
+
+    def decode_rate(nthreads):
+        stop = threading.Event(); ready = [False] * nthreads; done = [0] * nthreads
+        th = [threading.Thread(target=decoder_loop, args=(stop, ready, done, k)) for k in range(nthreads)]
+        for t in th: t.start()
+        while not all(ready): time.sleep(0.005)
+        a = sum(done); t0 = time.perf_counter()
+        time.sleep(seconds)
+        b = sum(done); t1 = time.perf_counter()
+        stop.set()
+        for t in th: t.join()
+        return (b - a) / (t1 - t0)
+    res["sync_decode_fps"] = round(decode_rate(1), 1)
+    handles = 8
+    res["decode_fps_%d_handles" % handles] = round(decode_rate(handles), 1)
+
+    def pool_run(workers, consumer=None):
+        pool = ctypes.c_void_p()
+        assert L.CFHD_CreateEncoderPool(ctypes.byref(pool), workers, 2 * workers, None) == 0
+        assert L.CFHD_PrepareEncoderPool(pool, W, H, T.PIX_YUY2, T.ENCODED_YUV422, 0, T.QUALITY_FILMSCAN1) == 0
+        assert L.CFHD_StartEncoderPool(pool) == 0
+        got = 0
+        def collect(wait):
+            num = ctypes.c_uint32(); sb = ctypes.c_void_p()
+            rc = (L.CFHD_WaitForSample if wait else L.CFHD_TestForSample)(pool, ctypes.byref(num), ctypes.byref(sb))
+            if rc == 0:
+                if consumer: consumer(sb)
+                L.CFHD_ReleaseSampleBuffer(pool, sb)
+            return rc == 0
+        t0 = time.perf_counter(); sent = 0
+        while time.perf_counter() - t0 < seconds or sent < 4 * workers:
+            assert L.CFHD_EncodeAsyncSample(pool, sent, frames[sent % nfr].ctypes.data_as(ctypes.c_void_p), pitch, None) == 0
+            sent += 1
+            while collect(False): got += 1
+        while got < sent:
+            if collect(True): got += 1
+        dt = time.perf_counter() - t0
+        L.CFHD_ReleaseEncoderPool(pool)
+        return sent / dt
+    workers = 16
+    res["pool_encode_fps_%d_workers" % workers] = round(pool_run(workers), 1)
+
+    # round trip through CFHD_* only: the pool's samples go straight to decoder threads (bounded queue), frames counted when decoded
+    import queue
+    q = queue.Queue(maxsize=4 * handles); decoded = [0]; lock = threading.Lock()
+    def rt_decoder():
+        dec = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
+        aw = ctypes.c_int(); ah = ctypes.c_int(); af = ctypes.c_uint32()
+        assert L.CFHD_PrepareToDecode(dec, 0, 0, T.PIX_YUY2, 1, 0, sbs[0], 512, ctypes.byref(aw), ctypes.byref(ah), ctypes.byref(af)) == 0
+        out = new_output()
+        while True:
+            s = q.get()
+            if s is None: break
+            assert L.CFHD_DecodeSample(dec, s, len(s), out.ctypes.data_as(ctypes.c_void_p), W * 2) == 0
+            with lock: decoded[0] += 1
+        L.CFHD_CloseDecoder(dec)
+        drop_output(out)
+    th = [threading.Thread(target=rt_decoder) for _ in range(handles)]
+    for t in th: t.start()
+    def hand_over(sb):
+        p = ctypes.c_void_p(); sz = ctypes.c_size_t()
+        L.CFHD_GetEncodedSample(sb, ctypes.byref(p), ctypes.byref(sz))
+        q.put(ctypes.string_at(p, sz.value))
+    t0 = time.perf_counter()
+    pool_run(workers, hand_over)
+    for _ in th: q.put(None)
+    for t in th: t.join()
+    res["round_trip_fps_pool%d_plus_%d_decoders" % (workers, handles)] = round(decoded[0] / (time.perf_counter() - t0), 1)
+    if registered:
+        for f in frames: L.cfhd_amd_unregister_host_buffer(f.ctypes.data)
+    return res
+
+
+def normalise_counters(sample):
+    """Frame number (tag 69, optional = negated) and the unique frame number tuple count per encoder call: set both to frame 1's."""
+    b = bytearray(sample)
+    k = bytes(b[:160]).find(struct.pack(">h", -69))
+    if k >= 0: b[k + 2:k + 4] = b"\x00\x01"
+    u = bytes(b[:1024]).find(b"UFRM")
+    if u >= 0: b[u + 8:u + 12] = b"\0\0\0\0"
+    return bytes(b)
+
+
+def parity_check(L, b, frames, pitch, W, H, rank):
+    """What was timed is what the reference produces: sample 0 of the last step (frame / unique-frame counters set back to the first frame's)
+    against the reference encoder's golden hash (rank 0 encodes Qbist seed 10, the frames of tests/golden), and decoded frame 0 inside the
+    dither interval of the exact integer reconstruction of its own sample (oracle, test infrastructure, used here as the checker only)."""
+    import numpy as np
+    import cfhd_testlib as T
+    p = ctypes.c_void_p(); sz = ctypes.c_size_t()
+    assert L.cfhd_amd_batch_get_sample(b, 0, ctypes.byref(p), ctypes.byref(sz)) == 0
+    sample = ctypes.string_at(p, sz.value)
+    out = {}
+    if rank == 0 and (W, H) == (1920, 1080):
+        g = json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))
+        digest = hashlib.sha256(T.mask_volatile_metadata(normalise_counters(sample))).hexdigest()
+        assert len(sample) == g["qbist_seed10_frame1_size"] and digest == g["qbist_seed10_frame1_masked_sha256"], "sample 0 differs from the reference encoder's golden sample"
+        out["sample0_masked_sha256"] = digest
+    else:
+        ref_sample = T.ref_encode_frames([frames[0]], pitch, W, H)[0]
+        assert T.mask_volatile_metadata(normalise_counters(sample)) == T.mask_volatile_metadata(normalise_counters(ref_sample)), "sample 0 differs from the reference encoder's"
+        out["sample0_equals_reference_encoder"] = True
+    img = np.zeros(H * W * 2, dtype=np.uint8)
+    assert L.cfhd_amd_batch_download_output(b, 0, img.ctypes.data_as(ctypes.c_void_p), W * 2) == 0
+    img = img.reshape(H, W * 2)
+    plan = T.Plan(W, H)
+    deq = T.host_decode_pyramid(sample, plan)
+    lo = T.oracle_inverse_yuv422(plan, deq, 0)[:H]; hi = T.oracle_inverse_yuv422(plan, deq, 1)[:H]
+    assert ((img == lo) | (img == hi)).all(), "decoded frame 0 leaves the dither interval of the exact reconstruction"
+    out["decoded_frame0_in_dither_interval"] = True
+    out["psnr_db"] = round(float(T.psnr_yuy2(img, frames[0].reshape(H, pitch)[:, : W * 2])), 2)
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=512, help="frames per step per GPU")
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="1080p", help="1080p = BASELINE.json configs[1] (the metric's configuration)")
+    ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (0 = the workload's default)")
+    ap.add_argument("--unique", type=int, default=0, help="distinct Qbist frames per rank (0 = 32 at 1080p, 8 at 2160p); the batch cycles through them")
     ap.add_argument("--threads", type=int, default=0, help="host entropy threads per rank (0 = cores / ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-c-abi", action="store_true")
     args = ap.parse_args()
 
+    W, H, default_batch = WORKLOADS[args.workload]
+    batch = args.batch or default_batch
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("CFHD_AMD_DEVICE", str(local_rank))
@@ -123,6 +293,8 @@ def main():
     import cfhd_testlib as T
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libcfhd_amd has no CPU fallback")
+    if not T.have_ref():
+        raise SystemExit("oracle/_ref/libcfhd_ref.so is missing: it holds the Qbist generator of the benchmark frames and the cpu_baseline (run __graft_entry__.build() where /root/reference exists)")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -139,21 +311,20 @@ def main():
     L.cfhd_amd_batch_kernel_ms.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.cfhd_amd_batch_stage_seconds.restype = ctypes.c_double
     L.cfhd_amd_batch_stage_seconds.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.cfhd_amd_batch_get_sample.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
+    L.cfhd_amd_batch_download_output.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
     L.cfhd_amd_batch_destroy.argtypes = [ctypes.c_void_p]
 
     cores = os.cpu_count() or 1
     threads = args.threads or max(1, cores // world)
-    nuniq = 8
-    if T.have_ref():
-        frames, pitch = T.qbist_frames(10 + rank, nuniq)            # Qbist seed 10 (BASELINE configs), QBIST_UNIQUE frames
-        data = "synthetic Qbist 1920x1080 YUY2 (seed %d, %d unique frames per rank)" % (10, nuniq)
-    else:
-        frames = [T.synth_yuy2(W, H, 100 * rank + i)[0] for i in range(nuniq)]; pitch = W * 2
-        data = "synthetic gradients+noise 1920x1080 YUY2"
-    b = L.cfhd_amd_batch_create(W, H, T.PIX_YUY2, T.QUALITY_FILMSCAN1, args.batch, threads)
+    nuniq = args.unique or (32 if args.workload == "1080p" else 8)
+    nuniq = min(nuniq, batch)
+    frames, pitch = T.qbist_frames(10 + rank, nuniq, W, H)            # Qbist seed 10 (BASELINE configs), QBIST_UNIQUE frames
+    data = "synthetic Qbist %dx%d YUY2 (seed %d, %d unique frames per rank, cycled through the batch)" % (W, H, 10, nuniq)
+    b = L.cfhd_amd_batch_create(W, H, T.PIX_YUY2, T.QUALITY_FILMSCAN1, batch, threads)
     if not b:
         raise SystemExit("cfhd_amd_batch_create failed: " + T.amd_last_error())
-    for i in range(args.batch):
+    for i in range(batch):
         assert L.cfhd_amd_batch_upload(b, i, frames[i % nuniq].ctypes.data_as(ctypes.c_void_p), pitch) == 0
 
     def barrier():
@@ -164,16 +335,17 @@ def main():
 
     for _ in range(args.warmup):
         assert L.cfhd_amd_batch_roundtrip(b) > 0, T.amd_last_error()
-    barrier()
-    t0 = time.perf_counter()
-    # kernel names as they appear in a rocprofv3 trace of this run: the register-strip kernels serve 1920x1080 unless an A/B switch asks for the tiled ones
+    # kernel names as they appear in a rocprofv3 trace of this run: the register-strip kernels serve these widths unless an A/B switch asks for the tiled ones
     FWD1 = "k_fwd_yuv422" if os.environ.get("CFHD_AMD_FORWARD") == "tile" else "k_fwd_yuv422_strip"
     INV1 = "k_inv_yuv422" if os.environ.get("CFHD_AMD_INVERSE") == "tile" else "k_inv_yuv422_strip"
     PF, PI = ("k_fwd_plane", "k_inv_plane") if os.environ.get("CFHD_AMD_PLANES") == "tile" else ("k_fwd_plane_strip", "k_inv_plane_strip")
+    old_dec = os.environ.get("CFHD_AMD_DEC") in ("par", "lane")
+    DEC = [("k_dec_bands_par", 13)] if old_dec else [("k_dec_plan+k_dec_index", 15), ("k_dec_chain", 16), ("k_dec_tiles", 17)]
     KERNELS = [(FWD1, 0), (PF + "[L2]", 1), (PF + "[L3]", 2), ("k_ent_count", 8), ("k_ent_scan", 9), ("k_ent_layout", 10),
-               ("k_ent_emit", 11), ("k_dec_parse", 12), ("k_dec_bands_par", 13), ("k_dec_lowpass", 14), (PI + "[L3]", 5), (PI + "[L2]", 4),
-               (INV1, 3)]
+               ("k_ent_emit", 11), ("k_dec_parse", 12)] + DEC + [("k_dec_lowpass", 14), (PI + "[L3]", 5), (PI + "[L2]", 4), (INV1, 3)]
     kms = {name: 0.0 for name, _ in KERNELS}; stage = [0.0] * 4; total_bytes = 0
+    barrier()
+    t0 = time.perf_counter()
     for _ in range(args.steps):
         n = L.cfhd_amd_batch_roundtrip(b)
         assert n > 0, T.amd_last_error()
@@ -192,51 +364,66 @@ def main():
     spec = importlib.util.spec_from_file_location("frame_shards", os.path.join(ROOT, "cineform-sdk_amd", "host", "frame_shards.py"))
     shards = importlib.util.module_from_spec(spec); spec.loader.exec_module(shards)
     # weak scaling: every rank owns `batch` frames per step (rank r = frames [r*batch, (r+1)*batch) of each step's sequence), no data-path collective
-    assert shards.shard_bounds(args.batch * world, rank, world) == (rank * args.batch, (rank + 1) * args.batch)
-    fps = shards.whole_job_rate(args.batch * args.steps, world, elapsed)
+    assert shards.shard_bounds(batch * world, rank, world) == (rank * batch, (rank + 1) * batch)
+    fps = shards.whole_job_rate(batch * args.steps, world, elapsed)
 
+    parity = parity_check(L, b, frames, pitch, W, H, rank) if rank == 0 else None
     if rank == 0:
         kms = {k: v / args.steps for k, v in kms.items()}
-        sample_bytes = total_bytes / args.batch
+        sample_bytes = total_bytes / batch
         # algorithmic bytes per frame of every kernel: samples are 8-bit in the packed frame, 16-bit in the pyramid
         S = W * ((H + 7) // 8 * 8) * 2                   # samples per 4:2:2 frame (luma + both chroma) = packed bytes
         coded = (S - S // 64) * 2                        # bytes of the 27 entropy-coded bands (everything but the three LL3 bands)
         algo = {FWD1: S + 2 * S, PF + "[L2]": S, PF + "[L3]": S // 4,                               # 12 441 600 B per 1080p frame
-                "k_ent_count": coded, "k_ent_emit": coded + sample_bytes, "k_dec_bands_par": sample_bytes + coded,
+                "k_ent_count": coded, "k_ent_emit": coded + sample_bytes,
                 PI + "[L3]": S // 4, PI + "[L2]": S, INV1: 2 * S + S}
+        if old_dec: algo["k_dec_bands_par"] = sample_bytes + coded
+        else: algo.update({"k_dec_plan+k_dec_index": sample_bytes, "k_dec_tiles": sample_bytes + coded})
         dom = max(algo, key=lambda k: kms[k])            # the dominant kernel = the longest launch of the step
         ms = kms[dom]
-        achieved = algo[dom] * args.batch / (ms * 1e-3) / 1e9
-        traffic = None
-        try:                                             # HBM bytes per launch from the committed PMC passes (profiles/, same batch size), else null
+        achieved = algo[dom] * batch / (ms * 1e-3) / 1e9
+        traffic = None; traffic_source = None
+        try:                                             # HBM bytes per launch from the committed PMC passes of this command (profiles/, same batch size), else null
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            base = dom.split("[")[0]                      # the per-level launches of the plane kernels share one trace name
-            if pmc.get("frames_per_launch") == args.batch and base in pmc["kernels"]:
+            base = dom.split("[")[0].split("+")[-1]      # the per-level launches of the plane kernels share one trace name
+            if pmc.get("frames_per_launch") == batch and pmc.get("workload", "1080p") == args.workload and base in pmc["kernels"]:
                 traffic = pmc["kernels"][base]["hbm_bytes_per_launch"]
+                traffic_source = "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command; FETCH_SIZE x2 + WRITE_SIZE per the gfx950 correction)"
         except Exception:
             traffic = None
         handoff = os.environ.get("CFHD_AMD_HANDOFF", "device")
         ent = os.environ.get("CFHD_AMD_ENTROPY", "gpu")
+        sum_kernels = sum(v for k, v in kms.items() if k != "k_dec_parse")
+        round_trip_bytes = 2 * (S + 2 * S)                # encode S_in + 2 N_coef, decode 2 N_coef + S_out
         line = {
-            "metric": "1080p YUY2 encode+decode fps", "value": round(fps, 1), "unit": "fps", "n_gpus": world, "steps": args.steps,
+            "metric": "%s YUY2 encode+decode fps" % args.workload, "value": round(fps, 1), "unit": "fps", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int16", "data": data,
-            "config": {"workload": "1920x1080 YUY2 4:2:2 FILMSCAN1 encode+decode round trip, frames resident in HBM", "frames_per_step_per_gpu": args.batch,
+            "config": {"workload": "%dx%d YUY2 4:2:2 FILMSCAN1 encode+decode round trip, frames resident in HBM" % (W, H), "frames_per_step_per_gpu": batch,
                        "entropy_stage": ("host, %d threads" % threads) if ent == "host" else "gpu (k_ent_* / k_dec_* kernels)",
                        "sample_handoff": "n/a" if ent == "host" else ("decoder reads the samples in HBM (k_dec_parse); host copy of every sample downloaded inside the step" if handoff != "host" else "samples cross PCIe to the host parser and back"),
                        "sample_bytes_per_frame": int(sample_bytes),
+                       "parity_checked": bool(parity), "parity": parity,
+                       "whole_path": {"algorithmic_bytes_per_frame": round_trip_bytes, "gbs": round(round_trip_bytes * batch / (1e6 * elapsed / args.steps) / 1e3, 1),
+                                      "frac_of_hbm_peak": round(round_trip_bytes * batch / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                                      "sum_of_kernels_ms": round(sum_kernels, 3)},
                        "stage_ms_per_step": {"submit": round(1000 * stage[0] / args.steps, 3), "encode_wait+sample_d2h": round(1000 * stage[1] / args.steps, 3),
                                              "decode_parse+stage": round(1000 * stage[2] / args.steps, 3), "decode_wait": round(1000 * stage[3] / args.steps, 3)},
                        "kernel_ms_per_step": {k: round(v, 4) for k, v in kms.items()}},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "launch_ms": round(ms, 4),
-                         "algorithmic_bytes_per_launch": int(algo[dom] * args.batch),
-                         "other_kernels_gbs": {k: round(algo[k] * args.batch / (kms[k] * 1e-3) / 1e9, 1) for k in algo if kms[k] > 0 and k != dom}},
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source, "launch_ms": round(ms, 4),
+                         "algorithmic_bytes_per_launch": int(algo[dom] * batch),
+                         "other_kernels_gbs": {k: round(algo[k] * batch / (kms[k] * 1e-3) / 1e9, 1) for k in algo if kms[k] > 0 and k != dom}},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(frames, pitch)
-        print(json.dumps(line), flush=True)
     L.cfhd_amd_batch_destroy(b)
+    if rank == 0:
+        if world == 1 and not args.no_c_abi:
+            line["config"]["c_abi_fps"] = {"frame": "%dx%d YUY2, frames and samples in host memory (PCIe inclusive)" % (W, H),
+                                           "plain_buffers": c_abi_rates(frames[:8], pitch, W, H),
+                                           "buffers_registered_by_the_caller": c_abi_rates(frames[:8], pitch, W, H, registered=True)}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(frames[:8], pitch, W, H)
+        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -57,6 +57,22 @@ struct EncMetadata {
 	bool changed = false;
 };
 
+// CFHD_AMD_PROFILE=1: where the wall time of the synchronous calls goes (printed when the handle is closed)
+bool profile_enabled() { static const bool on = [] { const char *e = getenv("CFHD_AMD_PROFILE"); return e && atoi(e) != 0; }(); return on; }
+double wall_now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+struct StageProfile {
+	double t[6] = {0, 0, 0, 0, 0, 0}; long calls = 0; double last = 0;
+	void start() { if (profile_enabled()) last = wall_now(); }
+	void mark(int k) { if (profile_enabled()) { const double n = wall_now(); t[k] += n - last; last = n; } }
+	void report(const char *what, const char *const *names, int n) const
+	{
+		if (!profile_enabled() || !calls) return;
+		fprintf(stderr, "[cfhd_amd] %s: %ld calls;", what, calls);
+		for (int k = 0; k < n; k++) fprintf(stderr, " %s %.1f us;", names[k], 1e6 * t[k] / calls);
+		fprintf(stderr, "\n");
+	}
+};
+
 struct EncodeParams {
 	int width = 0, height = 0;
 	uint32_t pixel_format = 0;
@@ -187,6 +203,7 @@ struct Encoder {
 	bool batch_ready = false;
 	uint32_t frame_number = 0;
 	std::vector<uint8_t> sample; size_t sample_size = 0;
+	StageProfile prof;
 };
 
 // ---- async pool ----
@@ -257,9 +274,11 @@ struct Decoder {
 	FramePlan plan;
 	DecodeBatch batch; bool batch_ready = false;
 	uint32_t frames_decoded = 0;
+	StageProfile prof;
 };
 
 struct DecMetadata { std::vector<uint8_t> block; size_t cursor = 0; };
+
 
 void plan_from_sample(const ParsedSample &ps, int out_kind, FramePlan *plan, bool *ok)
 {
@@ -278,6 +297,11 @@ extern "C" {
 int cfhd_amd_device_count(void) { return device_count(); }
 void cfhd_amd_set_clip_guid(const unsigned char guid[16]) { meta_fix_guid(guid); }
 const char *cfhd_amd_last_error(void) { return device_last_error(); }
+// Extension: a caller that reuses its frame / output buffers may page-lock them once; CFHD_EncodeSample, the encoder pool and
+// CFHD_DecodeSample then DMA between them and HBM directly instead of staging through the library's own pinned memory.  The caller
+// keeps the buffer alive and unregisters it before freeing it.  Buffers that were never registered work as before.
+int cfhd_amd_register_host_buffer(void *buffer, size_t bytes) { return host_buffer_register(buffer, bytes); }
+int cfhd_amd_unregister_host_buffer(void *buffer) { return host_buffer_unregister(buffer); }
 
 // =============================================================================================
 // Synchronous encoder
@@ -337,8 +361,10 @@ CFHD_Error CFHD_EncodeSample(CFHD_EncoderRef ref, void *frame, int pitch)
 		if (prepare_batch(e->batch, e->params)) return ERR_INTERNAL;
 		e->batch_ready = true;
 	}
+	e->prof.start();
 	int rc = encode_one(e->batch, e->params, frame, pitch, ++e->frame_number, e->meta.global, e->meta.local,
 	                    e->sample.data(), e->sample.size(), &e->sample_size);
+	e->prof.mark(0); e->prof.calls++;
 	e->meta.local.clear();                                                // FreeLocalMetadata (CFHDEncoder.cpp:351)
 	return rc;
 }
@@ -354,6 +380,8 @@ CFHD_Error CFHD_GetSampleData(CFHD_EncoderRef ref, void **data, size_t *size)
 CFHD_Error CFHD_CloseEncoder(CFHD_EncoderRef ref)
 {
 	if (!ref) return ERR_INVALID_ARGUMENT;
+	static const char *const names[] = { "encode_one" };
+	((Encoder *)ref)->prof.report("CFHD_EncodeSample", names, 1);
 	delete (Encoder *)ref;
 	return ERR_OKAY;
 }
@@ -692,14 +720,19 @@ CFHD_Error CFHD_DecodeSample(CFHD_DecoderRef ref, void *sample, size_t size, voi
 		d->batch_ready = true;
 	}
 	if (d->batch.has_entropy() && size <= (size_t)d->plan.width * d->plan.height * pixel_bytes_of(d->out_kind) + 65536) {
-		// GPU entropy decoder: ship the sample bytes, one lane per band rebuilds the pyramid in HBM
+		// GPU entropy decoder: ship the sample bytes, the pyramid is rebuilt in HBM
+		d->prof.start();
 		if (d->batch.entropy().set_sample_host(0, s, size)) return fail_zero(ERR_BADSAMPLE);
+		d->prof.mark(0);
 		if (d->batch.entropy().launch()) return ERR_INTERNAL;
 		if (d->batch.launch_inverse(0x2545F491u * ++d->frames_decoded)) return ERR_INTERNAL;
 		if (d->batch.download_frame(0, out, pitch)) return ERR_INTERNAL;
+		d->prof.mark(1);
 		if (d->batch.wait()) return ERR_INTERNAL;
+		d->prof.mark(2);
 		if (d->batch.entropy().check()) return fail_zero(ERR_BADSAMPLE);
 		d->batch.finish_frame(0, out, pitch);
+		d->prof.mark(3); d->prof.calls++;
 		return ERR_OKAY;
 	}
 	// Entropy decode on the host into the pinned coefficient staging (dequantized values, as the reference's FSM delivers them).
@@ -844,6 +877,8 @@ CFHD_Error CFHD_ParseSampleHeader(void *sample, size_t size, CFHD_SampleHeader *
 CFHD_Error CFHD_CloseDecoder(CFHD_DecoderRef ref)
 {
 	if (!ref) return ERR_INVALID_ARGUMENT;
+	static const char *const names[] = { "parse+stage", "submit", "gpu+copies", "copy out" };
+	((Decoder *)ref)->prof.report("CFHD_DecodeSample", names, 4);
 	delete (Decoder *)ref;
 	return ERR_OKAY;
 }

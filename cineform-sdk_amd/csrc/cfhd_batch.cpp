@@ -207,7 +207,8 @@ long long cfhd_amd_batch_roundtrip(cfhd_amd_batch *b)
 }
 
 // which: 0..2 forward level launches (0 = k_fwd_yuv422), 3..5 inverse level launches (3 = k_inv_yuv422), 6 forward total, 7 inverse total,
-// 8..11 k_ent_count / k_ent_scan / k_ent_layout / k_ent_emit, 12..14 k_dec_parse / k_dec_bands_par / k_dec_lowpass (ms, HIP events on the launch streams)
+// 8..11 k_ent_count / k_ent_scan / k_ent_layout / k_ent_emit, 12..14 k_dec_parse / band decoder (all its kernels) / k_dec_lowpass,
+// 15..17 k_dec_plan + k_dec_index / k_dec_chain / k_dec_tiles (ms, HIP events on the launch streams)
 float cfhd_amd_batch_kernel_ms(cfhd_amd_batch *b, int which)
 {
 	if (!b) return 0;
@@ -216,7 +217,7 @@ float cfhd_amd_batch_kernel_ms(cfhd_amd_batch *b, int which)
 		if (which < 3) ms += c->enc.last_level_ms(which);
 		else if (which < 6) ms += c->dec.last_level_ms(which - 3);
 		else if (which >= 8 && which < 12) ms += b->gpu_entropy ? c->enc.entropy().kernel_ms(which - 8) : 0.0f;
-		else if (which >= 12 && which < 15) ms += b->gpu_entropy ? c->dec.entropy().kernel_ms(which - 12) : 0.0f;
+		else if (which >= 12 && which < 18) ms += b->gpu_entropy ? c->dec.entropy().kernel_ms(which - 12) : 0.0f;
 		else ms += which == 6 ? c->enc.last_kernel_ms() : c->dec.last_kernel_ms();
 	}
 	return ms;

@@ -77,6 +77,11 @@ struct EntropyTables {
 
 const EntropyTables *entropy_tables(int codebook /*1 = cs17 cubic, 2 = cs18 linear*/);
 
+// The base code words of a code set, one entry per symbol: kind 0 zero run (payload = zeros), 1 magnitude (payload = index 1..255 into
+// EntropyTables::mag_expand; a sign bit follows the code word), 2 band end marker.  What the decoder tables are built from.
+struct RawCode { uint32_t bits; int len; int kind; int payload; };
+int raw_codes(int codebook, RawCode *out /* 300 entries */);
+
 // ---- quantizer ----
 struct QuantState {            // mirrors the reference's cross-frame quantizer state (Codec/quantize.h QUANTIZER)
 	int overbitrate;

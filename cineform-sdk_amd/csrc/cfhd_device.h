@@ -6,6 +6,7 @@
 #include "cfhd_entropy_gpu.h"
 #include <stdint.h>
 #include <stddef.h>
+#include <vector>
 
 namespace cfhd {
 
@@ -95,6 +96,7 @@ private:
 	float level_ms_[3] = {0, 0, 0};
 	int16_t *d_coeff_ = nullptr, *h_coeff_ = nullptr;
 	uint8_t *d_out_ = nullptr, *h_out_ = nullptr; size_t frame_bytes_ = 0; int out_pitch_ = 0, out_rows_ = 0;
+	std::vector<char> direct_;                      // frame i went straight to the caller's (registered) buffer: finish_frame has nothing to copy
 	void *d_jobs_ = nullptr, *h_jobs_ = nullptr; size_t jobs_bytes_ = 0;
 	float kernel_ms_ = 0;
 	bool timed_ = false;
@@ -103,5 +105,11 @@ private:
 };
 
 int packed_frame_pitch(int pixel_kind, int width);     // bytes per row of a tightly packed frame
+
+// Host buffers the caller promised to keep alive (cfhd_amd_register_host_buffer): page-locked once, then frames and samples travel between
+// them and HBM without the staging copy through the library's own pinned memory.  Everything else is staged.
+int host_buffer_register(void *p, size_t bytes);       // 0, or a hipError_t
+int host_buffer_unregister(void *p);
+bool host_buffer_is_registered(const void *p, size_t bytes);
 
 } // namespace cfhd

@@ -13,6 +13,7 @@
 #include <stdio.h>
 #include <mutex>
 #include <string>
+#include <utility>
 
 namespace cfhd {
 
@@ -85,6 +86,38 @@ bool is_packed16(int pixel_kind) { return pixel_kind == PIX_RG48 || pixel_kind =
 } // namespace
 
 const char *device_last_error() { return g_err.c_str(); }
+
+namespace {
+std::mutex g_pins_mutex;
+std::vector<std::pair<uintptr_t, size_t>> g_pins;
+}
+int host_buffer_register(void *p, size_t bytes)
+{
+	if (!p || !bytes) return -1;
+	int rc = device_init();
+	if (rc) return rc;
+	std::lock_guard<std::mutex> lk(g_pins_mutex);
+	for (auto &e : g_pins) if (e.first == (uintptr_t)p) return e.second >= bytes ? 0 : -1;
+	HIPCHK(hipHostRegister(p, bytes, hipHostRegisterDefault));
+	g_pins.push_back({ (uintptr_t)p, bytes });
+	return 0;
+}
+int host_buffer_unregister(void *p)
+{
+	std::lock_guard<std::mutex> lk(g_pins_mutex);
+	for (size_t i = 0; i < g_pins.size(); i++) if (g_pins[i].first == (uintptr_t)p) {
+		g_pins.erase(g_pins.begin() + (ptrdiff_t)i);
+		HIPCHK(hipHostUnregister(p));
+		return 0;
+	}
+	return -1;
+}
+bool host_buffer_is_registered(const void *p, size_t bytes)
+{
+	std::lock_guard<std::mutex> lk(g_pins_mutex);
+	for (auto &e : g_pins) if ((uintptr_t)p >= e.first && (uintptr_t)p + bytes <= e.first + e.second) return true;
+	return false;
+}
 
 int device_count()
 {
@@ -292,6 +325,11 @@ int EncodeBatch::upload_frame(int i, const void *frame, int pitch)
 	if (!own_input_ || i < 0 || i >= n_) return -1;
 	const uint8_t *src = (const uint8_t *)frame;
 	if (pitch < 0) { src += (ptrdiff_t)(in_rows_ - 1) * pitch; pitch = -pitch; }     // encoder.c:1957
+	if (pitch >= in_pitch_ && host_buffer_is_registered(src, (size_t)pitch * (in_rows_ - 1) + in_pitch_)) {
+		// a buffer the caller registered: DMA straight out of it (the frame is borrowed until the encode completes, as in the reference)
+		HIPCHK(hipMemcpy2DAsync(d_in_ + frame_bytes_ * i, (size_t)in_pitch_, src, (size_t)pitch, (size_t)in_pitch_, (size_t)in_rows_, hipMemcpyHostToDevice, (hipStream_t)stream_));
+		return 0;
+	}
 	uint8_t *dst = h_in_ + frame_bytes_ * i;
 	if (pitch == in_pitch_) memcpy(dst, src, frame_bytes_);
 	else for (int r = 0; r < in_rows_; r++) memcpy(dst + (size_t)r * in_pitch_, src + (size_t)r * pitch, (size_t)in_pitch_);
@@ -632,9 +670,16 @@ int DecodeBatch::launch_inverse(uint32_t dither_seed)
 	return 0;
 }
 
-int DecodeBatch::download_frame(int i, void *, int)
+int DecodeBatch::download_frame(int i, void *out, int pitch)
 {
 	if (!own_output_ || i < 0 || i >= n_) return -1;
+	if (direct_.size() != (size_t)n_) direct_.assign((size_t)n_, 0);
+	direct_[i] = 0;
+	if (out && pitch >= out_pitch_ && host_buffer_is_registered(out, (size_t)pitch * (out_rows_ - 1) + out_pitch_)) {
+		HIPCHK(hipMemcpy2DAsync(out, (size_t)pitch, d_out_ + frame_bytes_ * i, (size_t)out_pitch_, (size_t)out_pitch_, (size_t)out_rows_, hipMemcpyDeviceToHost, (hipStream_t)stream_));
+		direct_[i] = 1;
+		return 0;
+	}
 	HIPCHK(hipMemcpyAsync(h_out_ + frame_bytes_ * i, d_out_ + frame_bytes_ * i, frame_bytes_, hipMemcpyDeviceToHost, (hipStream_t)stream_));
 	return 0;
 }
@@ -664,6 +709,7 @@ int DecodeBatch::wait()
 int DecodeBatch::finish_frame(int i, void *out, int pitch)
 {
 	if (!own_output_ || i < 0 || i >= n_) return -1;
+	if (direct_.size() == (size_t)n_ && direct_[i]) return 0;            // already in the caller's buffer
 	const uint8_t *src = h_out_ + frame_bytes_ * i;
 	uint8_t *dst = (uint8_t *)out;
 	if (pitch == out_pitch_) memcpy(dst, src, frame_bytes_);

@@ -162,8 +162,12 @@ GpuEntropyDecoder::~GpuEntropyDecoder() { release(); delete host_; }
 
 void GpuEntropyDecoder::release()
 {
-	void *dev[] = { d_samples_, d_tables_, d_bandjobs_, d_lowjobs_, d_errors_, d_plan_ };
+	void *dev[] = { d_samples_, d_tables_, d_bandjobs_, d_lowjobs_, d_errors_, d_plan_, d_idx_tables_, d_entries_, d_recs_, d_chunk_base_, d_chunk_job_, d_sums_, d_counters_ };
 	for (void *p : dev) if (p) (void)hipFree(p);
+	d_idx_tables_ = d_entries_ = d_recs_ = d_chunk_base_ = d_chunk_job_ = d_sums_ = d_counters_ = nullptr;
+	if (h_chunk_job_) (void)hipHostFree(h_chunk_job_);
+	if (h_counters_) (void)hipHostFree(h_counters_);
+	h_chunk_job_ = h_counters_ = nullptr;
 	if (h_samples_) (void)hipHostFree(h_samples_);
 	if (h_errors_) (void)hipHostFree(h_errors_);
 	if (host_->flat_bands) { (void)hipHostFree(host_->flat_bands); host_->flat_bands = nullptr; }
@@ -192,7 +196,32 @@ int GpuEntropyDecoder::prepare(const FramePlan &plan, int nframes, int16_t *d_co
 	HIPCHK(hipMalloc((void **)&d_errors_, sizeof(int)));
 	HIPCHK(hipHostMalloc((void **)&h_errors_, sizeof(int), hipHostMallocDefault));
 	*h_errors_ = 0;
-	{ const char *e = getenv("CFHD_AMD_DEC"); lane_kernel_ = e && strcmp(e, "lane") == 0; }   // A/B switch: the one-lane-per-band kernel
+	{ const char *e = getenv("CFHD_AMD_DEC"); lane_kernel_ = e && strcmp(e, "lane") == 0; dx_ = !(e && (strcmp(e, "lane") == 0 || strcmp(e, "par") == 0)); }   // A/B switches: the round-1 kernels
+	if (dx_) {
+		dev::DecIdxTables *it = new dev::DecIdxTables;
+		const bool ok = build_dec_index_tables(1, it);
+		if (ok) { hipError_t e = hipMalloc(&d_idx_tables_, sizeof(*it)); if (e == hipSuccess) e = hipMemcpy(d_idx_tables_, it, sizeof(*it), hipMemcpyHostToDevice); if (e != hipSuccess) { delete it; return g_fail(e, "decoder tables"); } }
+		delete it;
+		if (!ok) return -6;
+		// chunk arrays for the worst case: every frame's sample as long as its slot, every band with a partial chunk
+		const size_t per_frame = cap_ / dev::DX_CHUNK_BYTES + (size_t)kMaxChannels * 9 + 1;
+		if (per_frame * (size_t)n_ >= ((size_t)1 << 31) / dev::DX_ENTRY_STRIDE * 8) return -5;
+		max_chunks_ = (uint32_t)(per_frame * (size_t)n_);
+		HIPCHK(hipMalloc(&d_entries_, (size_t)max_chunks_ * dev::DX_ENTRY_STRIDE * 4));
+		HIPCHK(hipMalloc(&d_recs_, (size_t)max_chunks_ * sizeof(dev::DxChunkRec)));
+		HIPCHK(hipMalloc(&d_chunk_base_, (size_t)max_chunks_ * 4));
+		HIPCHK(hipMalloc(&d_chunk_job_, (size_t)max_chunks_ * 4));
+		HIPCHK(hipMalloc(&d_sums_, max_bands * sizeof(dev::DxBandSum)));
+		HIPCHK(hipMalloc(&d_counters_, 16));
+		HIPCHK(hipHostMalloc((void **)&h_chunk_job_, (size_t)max_chunks_ * 4, hipHostMallocDefault));
+		HIPCHK(hipHostMalloc((void **)&h_counters_, 16, hipHostMallocDefault));
+		int cus = 256;
+		(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
+		const char *g1 = getenv("CFHD_AMD_DX_GRID_INDEX"), *g3 = getenv("CFHD_AMD_DX_GRID_TILES");
+		grid_index_ = g1 ? atoi(g1) : cus * 5; grid_tiles_ = g3 ? atoi(g3) : cus * 5;      // workgroups that fit a CU at once (LDS: ~30 KB each)
+		if (grid_index_ < 1) grid_index_ = 1;
+		if (grid_tiles_ < 1) grid_tiles_ = 1;
+	}
 	{
 		dev::DecPlan dp;
 		dec_build_plan(plan, out_kind, &dp);
@@ -228,6 +257,14 @@ int GpuEntropyDecoder::set_sample_device(int i, const uint8_t *d_sample, const u
 	if (parse_sample(host_copy, size, &ps) != 0) return -2;
 	if (ps.width != plan_.width || ps.display_height != plan_.display_height || ps.encoded_format != plan_.encoded_format || ps.num_channels != plan_.num_channels) return -3;
 	host_->bands[i].clear(); host_->lows[i].clear(); host_->host_bytes[i] = 0;
+	if (dx_) {
+		// rows of the [slot][frame] job table, by slot
+		dev::DecPlan dp; dec_build_plan(plan_, out_kind_, &dp);
+		host_->bands[i].assign((size_t)dp.bands_per_frame, dev::DecBandJob());
+		host_->lows[i].assign((size_t)plan_.num_channels, dev::DecLowpassJob());
+		if (!dx_build_jobs(ps, plan_, dp, d_sample, d_coeffs_ + (size_t)i * coeff_stride_, out_kind_, 0, 1, host_->bands[i].data(), host_->lows[i].data(), skip_level1_)) return -4;
+		return 0;
+	}
 	if (!dec_build_jobs(ps, plan_, d_sample, d_coeffs_ + (size_t)i * coeff_stride_, out_kind_, &host_->bands[i], &host_->lows[i], skip_level1_)) return -4;
 	return 0;
 }
@@ -251,7 +288,8 @@ int GpuEntropyDecoder::launch()
 		ev_headers_ = ev_payloads_ = nullptr;
 		HIPCHK(hipEventRecord((hipEvent_t)ev_[1], st));
 		// few frames: the latency shape (the launch lasts as long as the longest band's serial steps); many: the throughput shape
-		if (n_ <= kLowLatencyFrames) dev::k_dec_bands_par_ll<<<nb, dev::DECP_LL_THREADS, 0, st>>>((const dev::DecBandJob *)d_bandjobs_, (const dev::DecTables *)d_tables_, d_errors_);
+		if (dx_) { const int rc_dx = launch_dx(true, nb, 0u); if (rc_dx) return rc_dx; }
+		else if (n_ <= kLowLatencyFrames) dev::k_dec_bands_par_ll<<<nb, dev::DECP_LL_THREADS, 0, st>>>((const dev::DecBandJob *)d_bandjobs_, (const dev::DecTables *)d_tables_, d_errors_);
 		else dev::k_dec_bands_par<<<nb, dev::DECP_THREADS, 0, st>>>((const dev::DecBandJob *)d_bandjobs_, (const dev::DecTables *)d_tables_, d_errors_);
 		HIPCHK(hipEventRecord((hipEvent_t)ev_[2], st));
 		dev::k_dec_lowpass<<<dim3(8, (unsigned)(n_ * nch)), 256, 0, st>>>((const dev::DecLowpassJob *)d_lowjobs_);
@@ -262,6 +300,41 @@ int GpuEntropyDecoder::launch()
 		return 0;
 	}
 	parse_end_ = false;
+	if (dx_) {
+		// host-parsed samples: the [slot][frame] job table and the chunk numbering come from the host
+		dev::DecPlan dp; dec_build_plan(plan_, out_kind_, &dp);
+		const int nch = plan_.num_channels, nb = dp.bands_per_frame * n_;
+		HIPCHK(hipStreamSynchronize(st));                                     // the pinned tables of the previous launch may still be in flight
+		for (int f = 0; f < n_; f++) {
+			if ((int)host_->bands[f].size() != dp.bands_per_frame || (int)host_->lows[f].size() != nch) return -1;
+			for (int s = 0; s < dp.bands_per_frame; s++) host_->flat_bands[(size_t)s * n_ + f] = host_->bands[f][s];
+			for (int c = 0; c < nch; c++) host_->flat_lows[(size_t)f * nch + c] = host_->lows[f][c];
+		}
+		std::vector<uint32_t> cj;
+		const uint32_t nchunks = dx_number_chunks(host_->flat_bands, nb, &cj);
+		if (nchunks > max_chunks_) return -5;
+		memcpy(h_chunk_job_, cj.data(), cj.size() * 4);
+		h_counters_[0] = nchunks;
+		HIPCHK(hipMemsetAsync(d_errors_, 0, sizeof(int), st));
+		for (int f = 0; f < n_; f++)
+			if (host_->host_bytes[f]) HIPCHK(hipMemcpyAsync(d_samples_ + cap_ * f, h_samples_ + cap_ * f, host_->host_bytes[f], hipMemcpyHostToDevice, st));
+		HIPCHK(hipMemcpyAsync(d_bandjobs_, host_->flat_bands, (size_t)nb * sizeof(dev::DecBandJob), hipMemcpyHostToDevice, st));
+		HIPCHK(hipMemcpyAsync(d_lowjobs_, host_->flat_lows, (size_t)n_ * nch * sizeof(dev::DecLowpassJob), hipMemcpyHostToDevice, st));
+		HIPCHK(hipMemcpyAsync(d_chunk_job_, h_chunk_job_, (size_t)nchunks * 4, hipMemcpyHostToDevice, st));
+		HIPCHK(hipMemcpyAsync(d_counters_, h_counters_, 16, hipMemcpyHostToDevice, st));
+		(void)hipGetLastError();
+		HIPCHK(hipEventRecord((hipEvent_t)ev_[0], st));
+		HIPCHK(hipEventRecord((hipEvent_t)ev_[1], st));
+		int rc = launch_dx(false, nb, nchunks);
+		if (rc) return rc;
+		HIPCHK(hipEventRecord((hipEvent_t)ev_[2], st));
+		dev::k_dec_lowpass<<<dim3(8, (unsigned)(n_ * nch)), 256, 0, st>>>((const dev::DecLowpassJob *)d_lowjobs_);
+		HIPCHK(hipGetLastError());
+		HIPCHK(hipEventRecord((hipEvent_t)ev_[3], st));
+		timed_ = true;
+		HIPCHK(hipMemcpyAsync(h_errors_, d_errors_, sizeof(int), hipMemcpyDeviceToHost, st));
+		return 0;
+	}
 	const bool lane_kernel = lane_kernel_;
 	dev::DecBandJob *fb = host_->flat_bands; dev::DecLowpassJob *fl = host_->flat_lows;
 	size_t nfb = 0, nfl = 0, per_frame = 0;
@@ -294,11 +367,44 @@ int GpuEntropyDecoder::launch()
 	return 0;
 }
 
+// The chunk-indexed decoder on the batch's stream.  device_jobs: the job table was filled by k_dec_parse (chunks are numbered on the device).
+int GpuEntropyDecoder::launch_dx(bool device_jobs, int njobs, uint32_t host_chunks)
+{
+	hipStream_t st = (hipStream_t)stream_;
+	dev::DecBandJob *jobs = (dev::DecBandJob *)d_bandjobs_;
+	const dev::DecIdxTables *T = (const dev::DecIdxTables *)d_idx_tables_;
+	dev::DecPlan dp; dec_build_plan(plan_, out_kind_, &dp);
+	const dev::DxTilePlan tp = dx_tile_plan(plan_, dp, n_, skip_level1_);
+	const char *spec_env = getenv("CFHD_AMD_DX_SPECULATE");
+	const bool speculate = !(spec_env && atoi(spec_env) == 0);            // 0: every chunk goes through the repair path (tests)
+	if (device_jobs) dev::k_dec_plan<<<1, 1024, 0, st>>>(jobs, njobs, (uint32_t *)d_chunk_job_, max_chunks_, (uint32_t *)d_counters_, d_errors_);
+	// grid-stride kernels: as many workgroups as the chip holds at once, fewer when there is less work
+	const uint32_t chunk_bound = device_jobs ? max_chunks_ : host_chunks;
+	int g1 = grid_index_, g3 = grid_tiles_;
+	if ((uint32_t)g1 * dev::DX_WAVES > chunk_bound) g1 = (int)((chunk_bound + dev::DX_WAVES - 1) / dev::DX_WAVES);
+	if ((uint32_t)g3 * dev::DX_WAVES > tp.total) g3 = (int)((tp.total + dev::DX_WAVES - 1) / dev::DX_WAVES);
+	if (g1 < 1) g1 = 1;
+	if (g3 < 1) g3 = 1;
+	dev::k_dec_index<<<g1, dev::DX_THREADS, 0, st>>>(jobs, (const uint32_t *)d_chunk_job_, (const uint32_t *)d_counters_, T, (uint32_t *)d_entries_, (dev::DxChunkRec *)d_recs_, speculate ? 1 : 0);
+	HIPCHK(hipEventRecord((hipEvent_t)ev_[5], st));
+	dev::k_dec_chain<<<(njobs + dev::DX_WAVES - 1) / dev::DX_WAVES, dev::DX_THREADS, 0, st>>>(jobs, njobs, T, (uint32_t *)d_entries_, (dev::DxChunkRec *)d_recs_, (uint32_t *)d_chunk_base_, (dev::DxBandSum *)d_sums_, d_errors_);
+	HIPCHK(hipEventRecord((hipEvent_t)ev_[6], st));
+	dev::k_dec_tiles<<<g3, dev::DX_THREADS, 0, st>>>(jobs, tp, T, (const uint32_t *)d_entries_, (const uint32_t *)d_chunk_base_, (const dev::DxBandSum *)d_sums_);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+
 int GpuEntropyDecoder::check() { return *h_errors_ ? -1 : 0; }
 
 float GpuEntropyDecoder::kernel_ms(int k)
 {
 	float ms = 0;
+	if (k >= 3) {                                                // the chunk-indexed decoder's own kernels
+		if (!timed_ || !dx_ || k > 5) return 0;
+		void *a = k == 3 ? ev_[1] : (k == 4 ? ev_[5] : ev_[6]), *b = k == 3 ? ev_[5] : (k == 4 ? ev_[6] : ev_[2]);
+		if (hipEventElapsedTime(&ms, (hipEvent_t)a, (hipEvent_t)b) != hipSuccess) { (void)hipGetLastError(); return 0; }
+		return ms;
+	}
 	void *end = (k == 0 && parse_end_) ? ev_[4] : ev_[k + 1];      // the parser's own end, not the start of the band decoder that waited for the payloads
 	if (!timed_ || k < 0 || k > 2 || hipEventElapsedTime(&ms, (hipEvent_t)ev_[k], (hipEvent_t)end) != hipSuccess) { (void)hipGetLastError(); return 0; }
 	return ms;

@@ -4,6 +4,7 @@
 #include "cfhd_core.h"
 #include "cfhd_bitstream.h"
 #include "cfhd_entropy_kernels.h"
+#include "cfhd_dec_kernels.h"
 #include <vector>
 #include <algorithm>
 #include <string.h>
@@ -30,6 +31,90 @@ inline void ent_build_tables(dev::EntTables *h, int codebook = 1)
 // Two-level decode tables from the base Huffman codes (cfhd_tables.cpp keeps them in EntropyTables::dec_lut for 12 bits;
 // here every code word up to 26 bits is resolved by table lookups only).  Returns the serialised dev::DecTables.
 std::vector<uint32_t> build_dec_tables(int codebook);
+
+// Tables of k_dec_index / k_dec_chain / k_dec_tiles (cfhd_dec_kernels.h) from the base code words of a code set.  false: the code set does
+// not fit the table layout (cannot happen with code sets 17 and 18; checked, not assumed).
+inline bool build_dec_index_tables(int codebook, dev::DecIdxTables *T)
+{
+	using namespace dev;
+	memset(T, 0, sizeof(*T));
+	RawCode codes[300];
+	const int ncodes = raw_codes(codebook, codes);
+	const EntropyTables *et = entropy_tables(codebook);
+	for (int m = 0; m < 256; m++) T->mag_expand[m] = et->mag_expand[m];
+	auto type_of = [](const RawCode &c) { return c.kind == 0 ? DX_T_RUN : (c.kind == 1 ? DX_T_VALUE : DX_T_END); };
+	// first level: code words of up to 12 bits directly, longer ones through their 12-bit prefix
+	uint32_t nlong = 0;
+	int l2_of_prefix[1 << DX_K];
+	for (int p = 0; p < (1 << DX_K); p++) l2_of_prefix[p] = -1;
+	for (int i = 0; i < ncodes; i++) {
+		const RawCode &c = codes[i];
+		if (c.len <= DX_K) {
+			if (c.kind == 2 || c.payload >= (1 << 11) || c.len > 12) return false;
+			const uint32_t base = c.bits << (DX_K - c.len);
+			const uint16_t e = (uint16_t)(c.len | (c.kind == 1 ? 16 : 0) | (c.payload << 5));
+			for (uint32_t k = 0; k < (1u << (DX_K - c.len)); k++) T->sym12[base + k] = e;
+		} else {
+			if (c.len > DX_K + 2 * DX_L2_BITS) return false;
+			const uint32_t p = c.bits >> (c.len - DX_K);
+			if (l2_of_prefix[p] < 0) {
+				if (nlong + (1u << DX_L2_BITS) > DX_LONG_MAX || nlong >= (1u << 11)) return false;
+				l2_of_prefix[p] = (int)nlong; nlong += 1u << DX_L2_BITS;
+				T->sym12[p] = (uint16_t)(16u | ((uint32_t)l2_of_prefix[p] << 5));       // length 0 + bit 4: escape
+			}
+		}
+	}
+	// second level: 7 more bits; code words of up to 19 bits end here, longer ones escape once more
+	struct L3 { uint32_t key; int maxlen; uint32_t base; };
+	std::vector<L3> l3;
+	for (int i = 0; i < ncodes; i++) {
+		const RawCode &c = codes[i];
+		if (c.len <= DX_K + DX_L2_BITS) continue;
+		const uint32_t key = c.bits >> (c.len - DX_K - DX_L2_BITS);
+		auto it = std::find_if(l3.begin(), l3.end(), [&](const L3 &x) { return x.key == key; });
+		if (it == l3.end()) l3.push_back(L3{ key, c.len, 0 }); else if (c.len > it->maxlen) it->maxlen = c.len;
+	}
+	for (L3 &x : l3) {
+		const int nb = x.maxlen - DX_K - DX_L2_BITS;
+		if (nlong + (1u << nb) > DX_LONG_MAX) return false;
+		x.base = nlong; nlong += 1u << nb;
+		const uint32_t p = x.key >> DX_L2_BITS;
+		T->long_tab[(uint32_t)l2_of_prefix[p] + (x.key & ((1u << DX_L2_BITS) - 1u))] = (uint32_t)nb | ((uint32_t)DX_T_ESCAPE << 5) | (x.base << 8);
+	}
+	for (int i = 0; i < ncodes; i++) {
+		const RawCode &c = codes[i];
+		if (c.len <= DX_K) continue;
+		const uint32_t entry = (uint32_t)c.len | ((uint32_t)type_of(c) << 5) | ((uint32_t)c.payload << 8);
+		if (c.len <= DX_K + DX_L2_BITS) {
+			const uint32_t p = c.bits >> (c.len - DX_K);
+			const int spare = DX_K + DX_L2_BITS - c.len;
+			const uint32_t base = (uint32_t)l2_of_prefix[p] + ((c.bits & ((1u << (c.len - DX_K)) - 1u)) << spare);
+			for (uint32_t k = 0; k < (1u << spare); k++) T->long_tab[base + k] = entry;
+		} else {
+			const uint32_t key = c.bits >> (c.len - DX_K - DX_L2_BITS);
+			const L3 &x = *std::find_if(l3.begin(), l3.end(), [&](const L3 &y) { return y.key == key; });
+			const int nb = x.maxlen - DX_K - DX_L2_BITS, rest = c.len - DX_K - DX_L2_BITS, spare = nb - rest;
+			const uint32_t base = x.base + ((c.bits & ((1u << rest) - 1u)) << spare);
+			for (uint32_t k = 0; k < (1u << spare); k++) T->long_tab[base + k] = entry;
+		}
+	}
+	T->nlong = nlong;
+	// several code words per lookup: as many whole ones (sign bits included) as the 12-bit window holds
+	for (uint32_t win = 0; win < (1u << DX_K); win++) {
+		int used = 0; uint32_t count = 0;
+		for (;;) {
+			const uint32_t rest = (win << used) & ((1u << DX_K) - 1u);
+			const uint16_t e = T->sym12[rest];
+			const int len = e & 15, total = len + ((e & 16) ? 1 : 0);
+			if (!len || total > DX_K - used) break;
+			const uint32_t add = (e & 16) ? 1u : (uint32_t)(e >> 5);
+			if (count + add > 4095u) break;
+			used += total; count += add;
+		}
+		T->cnt12[win] = (uint16_t)(used | (count << 4));
+	}
+	return true;
+}
 
 struct EntHostJobs {
 	std::vector<dev::EntBandJob> bands;
@@ -153,6 +238,66 @@ inline void dec_build_plan(const FramePlan &plan, int out_pixel_kind, dev::DecPl
 	std::stable_sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) { return a.area > b.area; });
 	for (size_t k = 0; k < keys.size(); k++) dp->slot[keys[k].c][keys[k].lv][keys[k].b] = (int)k;
 	dp->bands_per_frame = (int)keys.size();
+}
+
+// ---- cfhd_dec_kernels.h: job table [band slot][frame], tiles, chunk numbering ----
+// Frame f's rows of the [slot][frame] band job table (slots as dec_build_plan numbers them) and its lowpass jobs from a parsed sample.
+// Bands the caller does not want (skip_level1: half resolution) keep bytes = 0 and produce no work.
+inline bool dx_build_jobs(const ParsedSample &ps, const FramePlan &plan, const dev::DecPlan &dp, const uint8_t *sample_addr, int16_t *coeff_base, int out_pixel_kind,
+                          int f, int nframes, dev::DecBandJob *table, dev::DecLowpassJob *lowpass /* [num_channels] */, bool skip_level1 = false)
+{
+	for (int c = 0; c < plan.num_channels; c++) {
+		const ParsedBand &lp = ps.lowpass[c];
+		const BandDesc &ll = plan.ch[c].band[2][0];
+		if (!lp.present || lp.width != ll.width || lp.height != ll.height) return false;
+		lowpass[c] = dev::DecLowpassJob{ sample_addr + lp.offset, coeff_base + ll.offset, ll.width, ll.height, ll.pitch, lowpass_bias(plan.precision, ll.width, out_pixel_kind) };
+		for (int lv = 0; lv < kNumLevels; lv++)
+			for (int b = 1; b < 4; b++) {
+				const ParsedBand &pb = ps.high[c][lv][b];
+				const BandDesc &bd = plan.ch[c].band[lv][b];
+				dev::DecBandJob &bj = table[(size_t)dp.slot[c][lv][b] * nframes + f];
+				bj = dev::DecBandJob{ sample_addr, 0u, coeff_base + bd.offset, bd.height * bd.pitch, 1, 0u };
+				if (skip_level1 && lv == 0) continue;
+				if (!pb.present || pb.width != bd.width || pb.height != bd.height || (pb.offset & 3) || (pb.codebook != 1 && pb.codebook != 0) || (bd.offset & 7) || (bd.pitch & 7)) return false;
+				bj.bits = sample_addr + pb.offset; bj.bytes = pb.bytes; bj.quant = pb.quant;
+			}
+	}
+	return true;
+}
+
+// Tiles of the job table: slot s has ceil(n / DX_TILE) tiles per band, for every frame.
+inline dev::DxTilePlan dx_tile_plan(const FramePlan &plan, const dev::DecPlan &dp, int nframes, bool skip_level1 = false)
+{
+	dev::DxTilePlan tp;
+	memset(&tp, 0, sizeof(tp));
+	tp.nslots = dp.bands_per_frame; tp.nframes = nframes;
+	for (int c = 0; c < plan.num_channels; c++)
+		for (int lv = 0; lv < kNumLevels; lv++)
+			for (int b = 1; b < 4; b++) {
+				const BandDesc &bd = plan.ch[c].band[lv][b];
+				const uint32_t n = (uint32_t)(bd.height * bd.pitch);
+				tp.per_band[dp.slot[c][lv][b]] = (skip_level1 && lv == 0) ? 0u : (n + dev::DX_TILE - 1) / dev::DX_TILE;
+			}
+	uint32_t cum = 0;
+	for (int s = 0; s < tp.nslots; s++) { tp.cum[s] = cum; cum += tp.per_band[s] * (uint32_t)nframes; }
+	tp.total = cum;
+	// slots without tiles must not be looked at by the kernel's division: give them one (unreachable) tile per band
+	for (int s = 0; s < tp.nslots; s++) if (!tp.per_band[s]) tp.per_band[s] = 1;
+	return tp;
+}
+
+// Chunk numbering on the host (what k_dec_plan does on the device): returns the number of chunks.
+inline uint32_t dx_number_chunks(dev::DecBandJob *jobs, int njobs, std::vector<uint32_t> *chunk_job)
+{
+	uint32_t at = 0;
+	chunk_job->clear();
+	for (int j = 0; j < njobs; j++) {
+		const uint32_t n = (jobs[j].bytes + dev::DX_CHUNK_BYTES - 1) / dev::DX_CHUNK_BYTES;
+		jobs[j].chunk0 = at;
+		for (uint32_t c = 0; c < n; c++) chunk_job->push_back((uint32_t)j);
+		at += n;
+	}
+	return at;
 }
 
 } // namespace cfhd

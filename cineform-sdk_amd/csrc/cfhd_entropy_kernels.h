@@ -594,6 +594,7 @@ struct DecBandJob {
 	const uint8_t *bits; uint32_t bytes;      // coded payload (after BAND_HEADER, before BAND_TRAILER); 4-byte aligned
 	int16_t *dst; int n;                      // band raster (height * pitch), zeroed beforehand
 	int quant;
+	uint32_t chunk0;                          // cfhd_dec_kernels.h: first chunk of the band in the chunk arrays
 };
 
 struct DecLowpassJob { const uint8_t *src; int16_t *dst; int width, height, pitch, bias; };

@@ -183,6 +183,20 @@ std::vector<uint32_t> build_dec_tables(int codebook)
 	return out;
 }
 
+int raw_codes(int codebook, RawCode *out)
+{
+	const uint8_t *ml = codebook == 2 ? cfhd_cs18_mag_len : cfhd_cs17_mag_len;
+	const uint32_t *mc = codebook == 2 ? cfhd_cs18_mag_code : cfhd_cs17_mag_code;
+	const uint32_t (*rn)[3] = codebook == 2 ? cfhd_cs18_run : cfhd_cs17_run;
+	const uint32_t *be = codebook == 2 ? cfhd_cs18_band_end : cfhd_cs17_band_end;
+	int n = 0;
+	out[n++] = RawCode{ mc[0], ml[0], 0, 1 };                          // magnitude 0 = a single zero
+	for (int m = 1; m < 256; m++) out[n++] = RawCode{ mc[m], ml[m], 1, m };
+	for (int i = 0; i < 7; i++) out[n++] = RawCode{ rn[i][0], (int)rn[i][1], 0, (int)rn[i][2] };
+	out[n++] = RawCode{ be[0], (int)be[1], 2, 0 };
+	return n;
+}
+
 // Raw base codes for slow-path decoding of code words longer than kDecBits.
 int slow_decode_symbol(int codebook, uint32_t window /*next 32 bits, MSB first*/, int *size, int *run, int *mag, bool *band_end)
 {

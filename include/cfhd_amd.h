@@ -134,6 +134,10 @@ typedef struct cfhd_amd_batch cfhd_amd_batch;
 int  cfhd_amd_device_count(void);
 /* Fixes the otherwise random clip GUID that every new encoder stamps into its samples (16 bytes), for bit-exact diffs. */
 void cfhd_amd_set_clip_guid(const unsigned char guid[16]);
+/* Optional: page-lock a frame / output buffer the caller reuses, so that CFHD_EncodeSample, the encoder pool and CFHD_DecodeSample
+ * move it over PCIe without a staging copy.  The caller keeps it alive and unregisters it before freeing it.  Returns 0 on success. */
+int  cfhd_amd_register_host_buffer(void *buffer, size_t bytes);
+int  cfhd_amd_unregister_host_buffer(void *buffer);
 
 #ifdef __cplusplus
 }

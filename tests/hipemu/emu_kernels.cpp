@@ -296,3 +296,57 @@ extern "C" int emu_entropy_decode(const uint8_t *sample, size_t size, int pixel_
 	hipemu::launch(dim3(4, (unsigned)lows.size()), dim3(256), [&] { dev::k_dec_lowpass(lows.data()); });
 	return errors ? -10 - errors : 0;
 }
+
+// The round-2 decoder (cfhd_dec_kernels.h) under emulation.  mode 0: host parser, speculation on; 1: speculation off (every chunk but the first
+// assumes a wrong start, so k_dec_chain has to index them again: the repair path); 2: two copies of the sample in "device" memory, parsed by
+// k_dec_parse and numbered by k_dec_plan.  grid: workgroups of the grid-stride kernels (small grids exercise the stride loops).
+extern "C" int emu_entropy_decode_dx(const uint8_t *sample, size_t size, int pixel_kind, int16_t *coeffs, size_t coeff_elems, int mode, int grid)
+{
+	using namespace cfhd;
+	ParsedSample ps;
+	if (parse_sample(sample, size, &ps) != 0) return -1;
+	FramePlan plan;
+	if (!build_frame_plan(&plan, ps.width, ps.display_height, pixel_kind, ps.encoded_format)) return -2;
+	plan.precision = ps.precision;
+	if (coeff_elems < plan.coeff_elems) return -3;
+	static dev::DecIdxTables tables; static bool ready = false;
+	if (!ready) { if (!build_dec_index_tables(1, &tables)) return -5; ready = true; }
+	dev::DecPlan dp; dec_build_plan(plan, pixel_kind, &dp);
+	const int nframes = mode == 2 ? 2 : 1, nch = plan.num_channels, njobs = dp.bands_per_frame * nframes;
+	std::vector<dev::DecBandJob> jobs((size_t)njobs);
+	std::vector<dev::DecLowpassJob> lows((size_t)nch * nframes);
+	std::vector<int16_t> pyr((size_t)plan.coeff_elems * nframes, 77);       // the tile kernel must write every coefficient of every band itself
+	const size_t stride = (size + 256 + 255) & ~(size_t)255;
+	std::vector<uint8_t> raw(stride * 2 + 512, 0);
+	uint8_t *two = (uint8_t *)(((uintptr_t)raw.data() + 255) & ~(uintptr_t)255);
+	memcpy(two, sample, size); memcpy(two + stride, sample, size);
+	int errors = 0;
+	const uint32_t max_chunks = (uint32_t)(nframes * (size / dev::DX_CHUNK_BYTES + dp.bands_per_frame + 1));
+	std::vector<uint32_t> chunk_job(max_chunks), counters(4, 0);
+	if (mode == 2) {
+		const uint32_t sizes[2] = { (uint32_t)size, (uint32_t)size };
+		hipemu::launch(dim3(2), dim3(dev::DEC_PARSE_THREADS), [&] { dev::k_dec_parse(two, stride, sizes, 2, &dp, pyr.data(), plan.coeff_elems, jobs.data(), lows.data(), &errors); });
+		if (errors) return -20 - errors;
+		hipemu::launch(dim3(1), dim3(1024), [&] { dev::k_dec_plan(jobs.data(), njobs, chunk_job.data(), max_chunks, counters.data(), &errors); });
+		if (errors) return -40 - errors;
+	} else {
+		if (!dx_build_jobs(ps, plan, dp, two, pyr.data(), pixel_kind, 0, 1, jobs.data(), lows.data())) return -4;
+		std::vector<uint32_t> cj;
+		counters[0] = dx_number_chunks(jobs.data(), njobs, &cj);
+		if (counters[0] > max_chunks) return -6;
+		std::copy(cj.begin(), cj.end(), chunk_job.begin());
+	}
+	const uint32_t nchunks = counters[0];
+	std::vector<uint32_t> entries((size_t)nchunks * dev::DX_ENTRY_STRIDE + 16, 0xdeadbeefu), chunk_base(nchunks + 1, 0xdeadbeefu);
+	std::vector<dev::DxChunkRec> recs(nchunks + 1);
+	std::vector<dev::DxBandSum> sums((size_t)njobs);
+	const dev::DxTilePlan tp = dx_tile_plan(plan, dp, nframes);
+	hipemu::launch(dim3((unsigned)grid), dim3(dev::DX_THREADS), [&] { dev::k_dec_index(jobs.data(), chunk_job.data(), counters.data(), &tables, entries.data(), recs.data(), mode != 1); });
+	hipemu::launch(dim3((unsigned)(njobs + dev::DX_WAVES - 1) / dev::DX_WAVES), dim3(dev::DX_THREADS), [&] { dev::k_dec_chain(jobs.data(), njobs, &tables, entries.data(), recs.data(), chunk_base.data(), sums.data(), &errors); });
+	hipemu::launch(dim3((unsigned)grid), dim3(dev::DX_THREADS), [&] { dev::k_dec_tiles(jobs.data(), tp, &tables, entries.data(), chunk_base.data(), sums.data()); });
+	hipemu::launch(dim3(4, (unsigned)lows.size()), dim3(256), [&] { dev::k_dec_lowpass(lows.data()); });
+	if (errors) return -10 - errors;
+	memcpy(coeffs, pyr.data() + (size_t)(nframes - 1) * plan.coeff_elems, (size_t)plan.coeff_elems * 2);
+	if (nframes == 2 && memcmp(pyr.data(), pyr.data() + plan.coeff_elems, (size_t)plan.final_elems * 2)) return -30;
+	return 0;
+}

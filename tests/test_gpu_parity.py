@@ -226,7 +226,7 @@ def test_gpu_entropy_and_host_entropy_paths_agree():
         assert mask_volatile_metadata(x) == mask_volatile_metadata(y)
 
 
-@pytest.mark.parametrize("handoff,decoder", [("device", "par"), ("host", "par"), ("host", "lane")])
+@pytest.mark.parametrize("handoff,decoder", [("device", "dx"), ("host", "dx"), ("device", "dx-repair"), ("device", "par"), ("host", "par"), ("host", "lane")])
 def test_batched_device_resident_round_trip(handoff, decoder):
     """cfhd_amd_batch_* (what bench.py times): several chunks on their own streams; every sample must equal oracle transform +
     product syntax, every decoded frame must lie in the oracle's dither interval of its own sample.  handoff=device: the decoder
@@ -245,11 +245,17 @@ def test_batched_device_resident_round_trip(handoff, decoder):
     frames = [synth_yuy2(w, h, 70 + i)[0] for i in range(n)]
     os.environ["CFHD_AMD_CHUNK"] = "2"
     os.environ["CFHD_AMD_HANDOFF"] = handoff
-    os.environ["CFHD_AMD_DEC"] = decoder
+    os.environ["CFHD_AMD_DEC"] = decoder.split("-")[0]
+    if decoder == "dx-repair": os.environ["CFHD_AMD_DX_SPECULATE"] = "0"      # every chunk assumes a wrong start: k_dec_chain repairs them all
     try:
-        b = L.cfhd_amd_batch_create(w, h, PIX_YUY2, QUALITY_FILMSCAN1, n, 4)
+        _batched_round_trip_body(L, w, h, n, frames)
     finally:
         del os.environ["CFHD_AMD_CHUNK"], os.environ["CFHD_AMD_HANDOFF"], os.environ["CFHD_AMD_DEC"]
+        os.environ.pop("CFHD_AMD_DX_SPECULATE", None)
+
+
+def _batched_round_trip_body(L, w, h, n, frames):
+    b = L.cfhd_amd_batch_create(w, h, PIX_YUY2, QUALITY_FILMSCAN1, n, 4)
     assert b
     for i, f in enumerate(frames):
         assert L.cfhd_amd_batch_upload(b, i, f.ctypes.data_as(ctypes.c_void_p), w * 2) == 0

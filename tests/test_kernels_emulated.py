@@ -524,3 +524,86 @@ def test_fwd_frame_yuv422_interlaced_level1(w, h, dh, uyvy):
         cw = (w if c == 0 else w // 2) // 2
         for b in range(4):
             assert np.array_equal(outs_e[c][b][:, :cw], outs_o[c][b][:, :cw]), (c, b)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Round-2 decoder (cfhd_dec_kernels.h: k_dec_plan / k_dec_index / k_dec_chain / k_dec_tiles), same kernel source under emulation
+# ---------------------------------------------------------------------------------------------------------------
+def _dx_decode(sample, plan, mode, grid, size=None, guard=0):
+    E = emu()
+    E.emu_entropy_decode_dx.argtypes = [c_u8p, ctypes.c_size_t, ctypes.c_int, c_i16p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int]
+    got = np.full(plan.coeff_elems + guard, 99, dtype=np.int16)
+    s = np.frombuffer(sample, dtype=np.uint8).copy() if not isinstance(sample, np.ndarray) else sample
+    rc = E.emu_entropy_decode_dx(p8(s), size if size is not None else len(s), 1, p16(got), plan.coeff_elems, mode, grid)
+    return rc, got
+
+
+@pytest.mark.parametrize("mode,grid", [(0, 3), (1, 2), (2, 1), (0, 64)])
+@pytest.mark.parametrize("w,h,seed", [(192, 96, 1), (336, 252, 3), (720, 480, 4)])
+def test_dx_decoder_emulated_equals_host_decoder(w, h, seed, mode, grid):
+    """The chunk-indexed decoder reproduces the product's host VLC decoder coefficient for coefficient, every element of every band incl.
+    its pitch padding written by the tile kernel itself.  mode 1 switches the run-in speculation off, so every chunk but a band's first
+    assumes a wrong start and k_dec_chain has to repair it; mode 2 parses two copies of the sample with k_dec_parse / k_dec_plan."""
+    frame, pitch = synth_yuy2(w, h, seed)
+    if seed == 4:                                   # busy picture: long payloads, several chunks per band
+        rng = np.random.default_rng(9)
+        f = frame.reshape(h, pitch).astype(np.int32) + rng.integers(-30, 31, (h, pitch))
+        frame = np.clip(f, 0, 255).astype(np.uint8).reshape(-1).copy()
+    plan = Plan(w, h)
+    coeffs = oracle_forward_yuv422(plan, frame, pitch)
+    if seed == 3:                                   # long code words: values up to the +-1023 clamp
+        v = plan.view(coeffs, 0, 0, 1); v[::7, ::5] = 1023; v[1::9, 2::11] = -1023; v[3::5, 1::13] = 300
+    sample = product_write_sample_host(plan, coeffs, 1, meta_global=b"GUID\x10\x00\x00G" + bytes(16))
+    want = host_decode_pyramid(sample, plan)
+    rc, got = _dx_decode(sample, plan, mode, grid)
+    assert rc == 0
+    for (c, lv, b) in plan.band:
+        if b == 0 and lv != 2: continue
+        cols = plan.band[(c, lv, b)]["width"] if b == 0 else None
+        assert np.array_equal(plan.view(got, c, lv, b)[:, :cols], plan.view(want, c, lv, b)[:, :cols]), (c, lv, b)
+
+
+def test_dx_decoder_emulated_sparse_and_dense_bands():
+    """Extremes of the code: a band that is one single zero run (the tiles behind the first are never touched by a code word), a band with a
+    value in every position (three bits per coefficient and more: many pieces per tile), values at the very first and very last position."""
+    w, h = 336, 252
+    plan = Plan(w, h)
+    frame, pitch = synth_yuy2(w, h, 8)
+    coeffs = oracle_forward_yuv422(plan, frame, pitch)
+    rng = np.random.default_rng(2)
+    plan.view(coeffs, 0, 0, 1)[:] = 0                                           # all zero (pitch padding too)
+    d = plan.band[(0, 0, 2)]
+    dense = plan.view(coeffs, 0, 0, 2); dense[:] = 0
+    dense[:, : d["width"]] = rng.integers(1, 40, (d["height"], d["width"])) * rng.choice([-1, 1], (d["height"], d["width"]))
+    e = plan.view(coeffs, 0, 0, 3); e[:] = 0; e[0, 0] = -5; e[-1, plan.band[(0, 0, 3)]["width"] - 1] = 7
+    sample = product_write_sample_host(plan, coeffs, 1, meta_global=b"GUID\x10\x00\x00G" + bytes(16))
+    want = host_decode_pyramid(sample, plan)
+    for mode, grid in ((0, 5), (1, 1)):
+        rc, got = _dx_decode(sample, plan, mode, grid)
+        assert rc == 0
+        for (c, lv, b) in plan.band:
+            if b == 0: continue
+            assert np.array_equal(plan.view(got, c, lv, b), plan.view(want, c, lv, b)), (mode, c, lv, b)
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+def test_dx_decoder_emulated_survives_damaged_samples(mode):
+    """Truncated samples are refused; garbage inside the code words never writes outside the pyramid nor hangs (error flag or wrong values, no crash)."""
+    w, h = 336, 252
+    frame, pitch = synth_yuy2(w, h, 5)
+    plan = Plan(w, h)
+    coeffs = oracle_forward_yuv422(plan, frame, pitch)
+    sample = product_write_sample_host(plan, coeffs, 1, meta_global=b"GUID\x10\x00\x00G" + bytes(16))
+    s = np.frombuffer(sample, dtype=np.uint8).copy()
+    rc, _ = _dx_decode(s, plan, mode, 2, size=len(sample) // 2 & ~3)
+    assert rc < 0
+    rng = np.random.default_rng(11)
+    flagged = 0
+    for trial in range(6):
+        t = s.copy()
+        lo = len(t) // 3 + trial * 1000
+        t[lo: lo + 600] = rng.integers(0, 256, 600, dtype=np.uint8)
+        rc, got = _dx_decode(t, plan, mode, 2, guard=4096)
+        flagged += rc != 0
+        assert np.all(got[plan.coeff_elems:] == 99)
+    assert flagged >= 1
