@@ -368,6 +368,12 @@ def main():
     fps = shards.whole_job_rate(batch * args.steps, world, elapsed)
 
     parity = parity_check(L, b, frames, pitch, W, H, rank) if rank == 0 else None
+    dx_stats = None
+    if os.environ.get("CFHD_AMD_DX_STATS"):               # convergence counters of the chunk-indexed entropy decoder (diagnostics, slows the kernels a little)
+        st = (ctypes.c_uint32 * 16)()
+        L.cfhd_amd_batch_dx_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
+        if L.cfhd_amd_batch_dx_stats(b, st) == 0:
+            dx_stats = {"rounds": st[0], "chunks_indexed": st[1], "max_rounds": st[2], "chunks_repaired": st[3], "lanes_restarted_per_round": [st[4 + k] for k in range(12)]}
     if rank == 0:
         kms = {k: v / args.steps for k, v in kms.items()}
         sample_bytes = total_bytes / batch
@@ -403,7 +409,7 @@ def main():
                        "entropy_stage": ("host, %d threads" % threads) if ent == "host" else "gpu (k_ent_* / k_dec_* kernels)",
                        "sample_handoff": "n/a" if ent == "host" else ("decoder reads the samples in HBM (k_dec_parse); host copy of every sample downloaded inside the step" if handoff != "host" else "samples cross PCIe to the host parser and back"),
                        "sample_bytes_per_frame": int(sample_bytes),
-                       "parity_checked": bool(parity), "parity": parity,
+                       "parity_checked": bool(parity), "parity": parity, **({"dx_stats": dx_stats} if dx_stats else {}),
                        "whole_path": {"algorithmic_bytes_per_frame": round_trip_bytes, "gbs": round(round_trip_bytes * batch / (1e6 * elapsed / args.steps) / 1e3, 1),
                                       "frac_of_hbm_peak": round(round_trip_bytes * batch / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
                                       "sum_of_kernels_ms": round(sum_kernels, 3)},

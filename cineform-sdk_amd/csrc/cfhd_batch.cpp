@@ -230,6 +230,16 @@ double cfhd_amd_batch_stage_seconds(cfhd_amd_batch *b, int which)
 	switch (which) { case 0: return b->t_fwd; case 1: return b->t_entropy_enc; case 2: return b->t_entropy_dec; default: return b->t_inv; }
 }
 
+// CFHD_AMD_DX_STATS=1: convergence counters of the chunk-indexed entropy decoder, summed over the chunks (16 words; GpuEntropyDecoder::stats)
+int cfhd_amd_batch_dx_stats(cfhd_amd_batch *b, uint32_t *out)
+{
+	if (!b || !out) return -1;
+	for (int k = 0; k < 16; k++) out[k] = 0;
+	int rc = -1;
+	for (auto &c : b->chunks) { uint32_t s[16]; if (c->dec.entropy().stats(s) == 0) { rc = 0; for (int k = 0; k < 16; k++) out[k] = k == 2 ? (s[k] > out[k] ? s[k] : out[k]) : out[k] + s[k]; } }
+	return rc;
+}
+
 int cfhd_amd_batch_get_sample(cfhd_amd_batch *b, int i, const void **data, size_t *size)
 {
 	if (!b || i < 0 || i >= b->n) return -1;

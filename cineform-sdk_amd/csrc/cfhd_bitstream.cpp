@@ -366,6 +366,7 @@ int parse_sample(const uint8_t *d, size_t size, ParsedSample *ps)
 	size_t pos = 0;
 	int channel = 0, lv = -1, band = 0, bw = 0, bh = 0, bq = 1, bflags = 0, bsub = 0;
 	int lw = 0, lh = 0;
+	size_t peak_base = 0; uint32_t peak_offset = 0; int peak_level = 0;
 	uint32_t pending_chunk = 0;   // bytes of the SUBBAND_SIZE chunk that was just opened
 	bool truncated = false;       // ran off the end of the supplied bytes (callers that only need the header pass 512 bytes)
 	size_t pending_at = 0;
@@ -428,6 +429,10 @@ int parse_sample(const uint8_t *d, size_t size, ParsedSample *ps)
 		case TAG_WAVELET_NUMBER: lv = value - 1; if (lv < 0 || lv >= kNumLevels) return -5; break;
 		case TAG_BAND_NUMBER: band = value; if (band < 1 || band > 3) return -6; bflags = 0; break;
 		case TAG_BAND_CODING_FLAGS: bflags = value; break;
+		// peak table of the band that follows: offset (bytes) from the word behind the OFFSET_L tuple, level (decoder.c:23978-23993)
+		case TAG_PEAK_TABLE_OFFSET_L: peak_offset = (peak_offset & ~0xffffu) | (uint32_t)value; peak_base = pos; peak_level = 0; break;
+		case TAG_PEAK_TABLE_OFFSET_H: peak_offset = (peak_offset & 0xffffu) | ((uint32_t)value << 16); peak_level = 0; break;
+		case TAG_PEAK_LEVEL: peak_level = value; break;
 		case TAG_BAND_WIDTH: bw = value; break;
 		case TAG_BAND_HEIGHT: bh = value; break;
 		case TAG_BAND_SUBBAND: bsub = value; break;
@@ -440,6 +445,9 @@ int parse_sample(const uint8_t *d, size_t size, ParsedSample *ps)
 			if (end > size) { truncated = true; break; }
 			pb.offset = (uint32_t)pos; pb.bytes = (uint32_t)(end - 4 - pos);
 			pb.width = bw; pb.height = bh; pb.quant = bq; pb.codebook = bflags & 0xf; pb.subband = bsub; pb.present = true;
+			pb.difference = (bflags >> 4) & 1; pb.peak_level = peak_level; pb.peak_offset = peak_level ? (uint32_t)(peak_base + peak_offset) : 0u;
+			if (pb.peak_level && (size_t)pb.peak_offset + 2 > size) return -8;
+			peak_level = 0;
 			pos = end; pending_chunk = 0;
 			break; }
 		default: break;
@@ -496,6 +504,20 @@ int vlc_decode_band(const uint8_t *data, size_t bytes, int width, int height, in
 			idx += (size_t)run;
 		}
 		if (have < 0) return -2;
+	}
+}
+
+void finish_difference_band(int16_t *band, int width, int height, int pitch, const uint8_t *peaks, size_t peak_bytes, int peak_level)
+{
+	size_t next = 0;
+	for (int y = 0; y < height; y++) {
+		int16_t *line = band + (size_t)y * pitch;
+		if (peak_level && peaks)
+			for (int x = 0; x < width; x++) {
+				const int v = line[x];
+				if ((v < 0 ? -v : v) > peak_level && next + 2 <= peak_bytes) { line[x] = (int16_t)(peaks[next] | (peaks[next + 1] << 8)); next += 2; }
+			}
+		for (int x = 1; x < width; x++) line[x] = (int16_t)(line[x] + line[x - 1]);
 	}
 }
 

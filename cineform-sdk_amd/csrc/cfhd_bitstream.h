@@ -98,7 +98,13 @@ enum { kPeakThreshold = 250 };   // PEAK_THRESHOLD, Codec/codec.h:155
 void vlc_encode_band(BitWriter &w, const int16_t *band, int width, int height, int pitch, int codebook, int quant = 1, std::vector<int16_t> *peaks = nullptr);
 
 // ---- parser ----
-struct ParsedBand { uint32_t offset, bytes; int width, height, quant, codebook, subband; bool present; };
+struct ParsedBand {
+	uint32_t offset, bytes; int width, height, quant, codebook, subband; bool present;
+	// the difference-coded band of an interlaced frame (subband 8 of every channel): coefficients are coded as the difference to their left
+	// neighbour (BAND_CODING_FLAGS bit 4, decoder.c:23974, :20822); peak_level != 0: values beyond it were coded as +-(level / quant + 1)
+	// and the real (dequantized) values follow in raster order as 16-bit little-endian words at peak_offset (decoder.c:23978-23993, :19809)
+	bool difference; int peak_level; uint32_t peak_offset;
+};
 struct ParsedSample {
 	int width = 0, height = 0, display_height = 0, num_channels = 0, precision = 0, encoded_format = 0;
 	int input_format = 0, color_space = 0, quality = 0, prescale_table = 0, frame_number = 0, progressive = 0, version = 0;
@@ -114,5 +120,8 @@ int parse_sample(const uint8_t *data, size_t size, ParsedSample *out);
 int lowpass_bias(int precision, int lowpass_width, int out_pixel_kind);
 // Host VLC decode of one band into a zeroed band. Returns 0 on success.
 int vlc_decode_band(const uint8_t *data, size_t bytes, int width, int height, int pitch, int quant, int codebook, int16_t *band);
+// What the reference does to a decoded difference band (DecodeBandFSM16sNoGapWithPeaks decoder.c:19809 + :20822): coefficients beyond the peak
+// level take their values from the peak table, then every row becomes its running sum.  peaks may be NULL (level 0).
+void finish_difference_band(int16_t *band, int width, int height, int pitch, const uint8_t *peaks, size_t peak_bytes, int peak_level);
 
 } // namespace cfhd

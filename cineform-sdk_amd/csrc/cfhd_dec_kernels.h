@@ -43,6 +43,7 @@ enum {
 	DX_L2_BITS = 7,
 	DX_TILE = 2048,                   // coefficients per output tile
 	DX_THREADS = 256, DX_WAVES = DX_THREADS / 64,
+	DX_MEMO = 6,                      // outcomes a lane of k_dec_index remembers (start -> end, count)
 	DX_OFF_INVALID = 31,              // entry: no code word of the true sequence starts in this piece (behind the band end marker / the payload)
 };
 enum : uint32_t { DX_END = 0xFFFFFFFFu, DX_BAD = 0xFFFFFFFEu, DX_SPECIAL = 0xFFFFFFFEu };
@@ -62,6 +63,7 @@ struct DecIdxTables {
 // One coded band of one frame = DecBandJob (cfhd_entropy_kernels.h); the job table is [band slot][frame], a band that is not wanted -- half
 // resolution skips level 1 -- has bytes 0.  chunk0 = first chunk of the band in the chunk arrays (k_dec_plan / host).
 typedef DecBandJob DxBandJob;
+struct DxChunkDesc { const uint8_t *bits; uint32_t bytes, k; };   // chunk c of the launch: payload of its band, chunk number inside the band (k_dec_plan / host)
 struct DxChunkRec { uint32_t start, end, count, flags; };   // start / end: bit offset of the first code word relative to the chunk's / the next chunk's first bit
 struct DxBandSum { uint32_t total; int last_chunk; };        // coefficients the band's code words cover; chunk that holds the band end marker
 
@@ -83,132 +85,225 @@ __device__ __forceinline__ DxSym dx_symbol(const uint16_t *s_sym, const uint32_t
 	return s;
 }
 
-// The 32 bits that start at bit position p of a word stream held in LDS (words already in big-endian bit order).
-__device__ __forceinline__ uint32_t dx_window(const uint32_t *s_words, uint32_t p)
-{
-	const uint32_t wi = p >> 5, sh = p & 31u;
-	const uint32_t w0 = s_words[wi], w1 = s_words[wi + 1];
-	return sh ? (w0 << sh) | (w1 >> (32u - sh)) : w0;
-}
+// The payload words of a chunk in LDS: staging word i sits at i + i / 8, so that the 64 lanes of a wave, each walking its own 8 words, hit
+// 64 different banks when they move in step (a plain layout puts lanes 4 apart on the same bank).
+__device__ __forceinline__ uint32_t dx_phys(uint32_t i) { return i + (i >> 3); }
+enum { DX_STAGE_PHYS = DX_STAGE_WORDS + DX_STAGE_WORDS / 8 + 1, DX_FETCH = (DX_STAGE_WORDS + 63) / 64 };
+
+// Bit reader over the staged words: the next 32 bits sit on top of `acc`; one LDS read per 32 bits consumed.
+struct DxBits {
+	uint64_t acc; int have; uint32_t next;
+	__device__ __forceinline__ void seek(const uint32_t *s_words, uint32_t pos)
+	{
+		const uint32_t wi = pos >> 5, sh = pos & 31u;
+		acc = (((uint64_t)s_words[dx_phys(wi)] << 32) | s_words[dx_phys(wi + 1)]) << sh;
+		have = 64 - (int)sh; next = wi + 2;
+	}
+	__device__ __forceinline__ uint32_t window() const { return (uint32_t)(acc >> 32); }
+	__device__ __forceinline__ void skip(const uint32_t *s_words, int n)
+	{
+		acc <<= n; have -= n;
+		if (have < 32) { acc |= (uint64_t)s_words[dx_phys(next < (uint32_t)DX_STAGE_WORDS ? next : (uint32_t)DX_STAGE_WORDS - 1u)] << (32 - have); have += 32; next++; }
+	}
+};
 
 struct DxLane {                       // state of one lane of k_dec_index
 	uint32_t start, end;              // bit positions in staging coordinates (lane t owns [256 t, 256 t + 256)); end may be DX_END / DX_BAD
 	uint32_t cnt;                     // coefficients covered by the code words that start in the lane's range
-	uint32_t rec_off[DX_SUBS], rec_cnt[DX_SUBS];    // per 64-bit piece: first code word's offset into the piece (DX_OFF_INVALID: none), coefficients of the lane in front of it
+	uint32_t rec_offs;                // per 64-bit piece, one byte each: first code word's offset into the piece (DX_OFF_INVALID: none)
+	uint32_t rec_cnt[DX_SUBS];        // coefficients of the lane in front of that code word
 };
+enum : uint32_t { DX_OFFS_NONE = DX_OFF_INVALID * 0x01010101u };
+__device__ __forceinline__ uint32_t dx_off_get(uint32_t offs, int k) { return (offs >> (8 * k)) & 0xffu; }
+__device__ __forceinline__ uint32_t dx_off_set(uint32_t offs, int k, uint32_t v) { return (offs & ~(0xffu << (8 * k))) | (v << (8 * k)); }
+// pieces k .. 3 hold no code word of this walk
+__device__ __forceinline__ uint32_t dx_off_clear_from(uint32_t offs, int k) { const uint32_t m = k >= 4 ? 0u : 0xffffffffu << (8 * k); return (offs & ~m) | ((uint32_t)DX_OFFS_NONE & m); }
 
-// Walks the code words of one lane from bit `pos` to the end of the lane's range.  MERGE: stop as soon as the walk reaches a 64-bit mark at
+// Walks the code words of one lane from bit `pos` to the end of the lane's range.  merge: stop as soon as the walk reaches a 64-bit mark at
 // the offset recorded by the previous walk -- from there on the two chains are the same, only the counts in front shift.
-template <bool MERGE>
-__device__ __forceinline__ void dx_walk(DxLane &L, uint32_t pos, const uint32_t lane_base, const uint32_t limit, const uint32_t *s_words, const uint16_t *s_cnt,
+__device__ __forceinline__ void dx_walk(DxLane &L, uint32_t pos, const bool merge, const uint32_t lane_base, const uint32_t limit, const uint32_t *s_words, const uint16_t *s_cnt,
                                         const uint16_t *s_sym, const uint32_t *s_long)
 {
 	uint32_t cnt = 0, end = 0;
 	bool done = false;
-#pragma unroll
+	uint32_t offs = merge ? L.rec_offs : (uint32_t)DX_OFFS_NONE;
+	DxBits B;
+	B.seek(s_words, pos);
+#pragma unroll 1
 	for (int k = 0; k < DX_SUBS; k++) {
 		const uint32_t mark = lane_base + (uint32_t)k * DX_SUB_BITS, next = mark + DX_SUB_BITS;
-		if (done) { if (!MERGE) L.rec_off[k] = DX_OFF_INVALID; continue; }
-		if (pos >= next) { L.rec_off[k] = DX_OFF_INVALID; continue; }       // a walk that starts beyond this piece (the first walk of a piece never does: a code word is shorter than 64 bits)
-		if (pos >= limit) { L.rec_off[k] = DX_OFF_INVALID; end = pos; done = true; if (MERGE) for (int j = k + 1; j < DX_SUBS; j++) L.rec_off[j] = DX_OFF_INVALID; continue; }
+		if (pos >= next) { offs = dx_off_set(offs, k, DX_OFF_INVALID); continue; }      // a walk that starts beyond this piece
+		if (pos >= limit) { offs = dx_off_clear_from(offs, k); end = pos; done = true; break; }
 		const uint32_t off = pos - mark;
-		if (MERGE && k > 0 && L.rec_off[k] == off) {
+		if (merge && k > 0 && dx_off_get(offs, k) == off) {
 			// same chain from here on: the counts recorded behind this mark move by the difference in front of it
-			const uint32_t delta = cnt - L.rec_cnt[k];
+			uint32_t old = 0;
 #pragma unroll
-			for (int j = 0; j < DX_SUBS; j++) if (j >= k && L.rec_off[j] != DX_OFF_INVALID) L.rec_cnt[j] += delta;
+			for (int j = 1; j < DX_SUBS; j++) if (j == k) old = L.rec_cnt[j];
+			const uint32_t delta = cnt - old;
+#pragma unroll
+			for (int j = 1; j < DX_SUBS; j++) if (j >= k && dx_off_get(offs, j) != (uint32_t)DX_OFF_INVALID) L.rec_cnt[j] += delta;
 			L.cnt += delta;
+			L.rec_offs = offs;
 			return;                                           // L.end stays
 		}
-		L.rec_off[k] = off; L.rec_cnt[k] = cnt;
+		offs = dx_off_set(offs, k, off);
+#pragma unroll
+		for (int j = 0; j < DX_SUBS; j++) if (j == k) L.rec_cnt[j] = cnt;
 		while (pos < next) {
 			if (pos >= limit) { end = pos; done = true; break; }
-			const uint32_t win = dx_window(s_words, pos);
+			const uint32_t win = B.window();
 			const uint32_t m = s_cnt[win >> (32 - DX_K)];
 			const uint32_t used = m & 15u;
-			if (used && pos + used <= next) { pos += used; cnt += m >> 4; continue; }       // several whole code words, none of them beyond the mark
+			if (used && pos + used <= next) { pos += used; cnt += m >> 4; B.skip(s_words, (int)used); continue; }       // several whole code words, none of them beyond the mark
 			const DxSym s = dx_symbol(s_sym, s_long, win);
-			if (s.type == DX_T_RUN) { pos += (uint32_t)s.len; cnt += (uint32_t)s.payload; }
-			else if (s.type == DX_T_VALUE) { pos += (uint32_t)s.len + 1u; cnt += 1u; }
+			if (s.type == DX_T_RUN) { pos += (uint32_t)s.len; cnt += (uint32_t)s.payload; B.skip(s_words, s.len); }
+			else if (s.type == DX_T_VALUE) { pos += (uint32_t)s.len + 1u; cnt += 1u; B.skip(s_words, s.len + 1); }
 			else { end = s.type == DX_T_END ? DX_END : DX_BAD; done = true; break; }
 		}
-		if (MERGE && done) for (int j = k + 1; j < DX_SUBS; j++) L.rec_off[j] = DX_OFF_INVALID;
+		if (done) { offs = dx_off_clear_from(offs, k + 1); break; }
 	}
+	L.rec_offs = offs;
 	L.cnt = cnt;
 	L.end = done ? end : pos;
 }
 
-// Index of one chunk by one wave.  exact_start: DX_BAD = the run-in lane finds it (speculation, checked by k_dec_chain); else the bit offset
-// (relative to the chunk's first bit) at which the chunk's first code word starts.  s_words: DX_STAGE_WORDS words of this wave.
-__device__ __forceinline__ void dx_index_chunk(const DxBandJob &job, const uint32_t k, const uint32_t exact_start, uint32_t *s_words, const uint16_t *s_cnt, const uint16_t *s_sym,
-                                               const uint32_t *s_long, uint32_t *entries, DxChunkRec *recs)
+// Staging of chunk k of a band: fetch the words into registers (the loads can be in flight while the previous chunk is walked), then put them
+// into the wave's LDS area in big-endian bit order.  Staging word i = payload word k * DX_CHUNK_WORDS - 8 + i; words outside the payload read 0.
+struct DxFetch { uint32_t w[DX_FETCH]; };
+__device__ __forceinline__ void dx_fetch_chunk(const uint8_t *bits, const uint32_t bytes, const uint32_t k, DxFetch &F)
 {
 	const int lane = wave_lane();
-	const uint32_t nwords = job.bytes >> 2;
-	const uint32_t *words = (const uint32_t *)job.bits;
-	// staging word i = payload word k * DX_CHUNK_WORDS - 8 + i
+	const uint32_t nwords = bytes >> 2;
+	const uint32_t *words = (const uint32_t *)bits;
 	const int64_t first = (int64_t)k * DX_CHUNK_WORDS - (DX_LANE_BITS / 32);
-	for (int i = lane; i < DX_STAGE_WORDS; i += 64) {
-		const int64_t g = first + i;
-		s_words[i] = (g >= 0 && g < (int64_t)nwords) ? bswap32(words[g]) : 0u;
+#pragma unroll
+	for (int r = 0; r < DX_FETCH; r++) {
+		const int64_t g = first + lane + 64 * r;
+		F.w[r] = (g >= 0 && g < (int64_t)nwords && lane + 64 * r < DX_STAGE_WORDS) ? words[g] : 0u;
 	}
+}
+__device__ __forceinline__ void dx_store_stage(const DxFetch &F, uint32_t *s_words)
+{
+	const int lane = wave_lane();
+#pragma unroll
+	for (int r = 0; r < DX_FETCH; r++) if (lane + 64 * r < DX_STAGE_WORDS) s_words[dx_phys((uint32_t)(lane + 64 * r))] = bswap32(F.w[r]);
 	CFHD_WAVE_SYNC();
+}
+
+// Index of one staged chunk by one wave.  exact_start: DX_BAD = the run-in lane finds it (speculation, checked by k_dec_chain); else the bit
+// offset (relative to the chunk's first bit) at which the chunk's first code word starts.  s_words: DX_STAGE_PHYS words of this wave.
+__device__ __forceinline__ void dx_index_staged(const uint32_t bytes, const uint32_t gchunk, const uint32_t k, const uint32_t exact_start, const uint32_t *s_words, const uint16_t *s_cnt, const uint16_t *s_sym,
+                                                const uint32_t *s_long, uint32_t *entries, DxChunkRec *recs, uint32_t *stats = nullptr)
+{
+	const int lane = wave_lane();
+	const uint32_t nwords = bytes >> 2;
+	const int64_t first = (int64_t)k * DX_CHUNK_WORDS - (DX_LANE_BITS / 32);
 	const int64_t left = (int64_t)nwords - first;           // payload words from the start of the staging area on
 	const uint32_t limit = left <= 0 ? 0u : (left * 32 > (int64_t)(64 * DX_LANE_BITS + 64) ? (uint32_t)(64 * DX_LANE_BITS + 64) : (uint32_t)(left * 32));   // staging bit position behind the payload
 	const uint32_t lane_base = (uint32_t)lane * DX_LANE_BITS;
 	const bool runin = exact_start == DX_BAD && k > 0;
+	// lanes whose range lies behind the payload take no part: the last lane with payload bits carries the end of the chain
+	const bool live = lane_base < limit && lane >= 1;
+	const int last_live = limit == 0u ? 0 : (int)((limit - 1u) / DX_LANE_BITS) < 63 ? (int)((limit - 1u) / DX_LANE_BITS) : 63;
 	DxLane L;
-	L.start = lane_base; L.end = lane_base; L.cnt = 0;
+	L.start = DX_BAD; L.end = lane_base; L.cnt = 0; L.rec_offs = DX_OFFS_NONE;
 #pragma unroll
-	for (int j = 0; j < DX_SUBS; j++) { L.rec_off[j] = DX_OFF_INVALID; L.rec_cnt[j] = 0; }
-	if (lane == 0) {
-		if (runin) dx_walk<false>(L, lane_base, lane_base, limit, s_words, s_cnt, s_sym, s_long);
-		else L.end = DX_LANE_BITS + (exact_start == DX_BAD ? 0u : exact_start);      // the chunk's first code word, exactly (a band's first chunk starts on its first bit)
-	} else {
-		dx_walk<false>(L, lane_base, lane_base, limit, s_words, s_cnt, s_sym, s_long);
-	}
-	// every lane takes over where its left neighbour ended, until nothing moves any more
-	for (int round = 0; round < 64; round++) {
-		const uint32_t ns = __shfl_up(L.end, 1u);
-		const bool changed = lane >= 1 && ns != L.start;
-		if (!__ballot(changed)) break;
-		if (changed) {
-			L.start = ns;
-			if (ns >= DX_SPECIAL) {                            // behind the band end marker (or a broken code): nothing of the true sequence starts here
-				L.end = ns; L.cnt = 0;
+	for (int j = 0; j < DX_SUBS; j++) L.rec_cnt[j] = 0;
+	if (lane == 0 && !runin) { L.start = 0u; L.end = DX_LANE_BITS + (exact_start == DX_BAD ? 0u : exact_start); }   // the chunk's first code word, exactly (a band's first chunk starts on its first bit)
+	// Every lane first walks from a guessed start (its own boundary), then takes over where its left neighbour ended, until nothing moves any
+	// more.  Ordinary data falls in step within a few code words, so one round settles almost every lane (the repeated walk stops at the
+	// first 64-bit mark where it meets the old one).  A stretch of identical code words (a smooth gradient: the same value in every
+	// position) has no unique alignment: a lane cannot know its phase before its neighbour does, and the true starts move through the chunk
+	// one lane per round.  A lane meets at most as many different starts as the pattern has phases, so every lane remembers the outcome of
+	// the starts it has walked (DX_MEMO of them): once the phases are known a round costs a lookup, not a walk.  The per-piece records are
+	// brought up to date in one last pass.
+	uint32_t memo_s[DX_MEMO], memo_e[DX_MEMO], memo_c[DX_MEMO];
+	int memo_at = 0;
 #pragma unroll
-				for (int j = 0; j < DX_SUBS; j++) L.rec_off[j] = DX_OFF_INVALID;
-			} else if (ns < lane_base || ns >= lane_base + DX_LANE_BITS) {   // the neighbour stopped in front of this lane (the payload ended) or reaches over it: nothing starts here
-				L.end = ns; L.cnt = 0;
-#pragma unroll
-				for (int j = 0; j < DX_SUBS; j++) L.rec_off[j] = DX_OFF_INVALID;
-			} else dx_walk<true>(L, ns, lane_base, limit, s_words, s_cnt, s_sym, s_long);
+	for (int i = 0; i < DX_MEMO; i++) { memo_s[i] = DX_BAD; memo_e[i] = 0; memo_c[i] = 0; }
+	uint32_t rec_start = DX_BAD;                          // the start the per-piece records were made for
+	bool finishing = false;
+#pragma unroll 1
+	for (int round = 0; round < 70; round++) {
+		uint32_t want; bool need;
+		if (finishing) {
+			// records for the final start (a lane that ended on a remembered outcome still holds the records of another walk)
+			const bool special = L.start >= DX_SPECIAL || L.start < lane_base || L.start >= lane_base + DX_LANE_BITS;
+			if (live && special) L.rec_offs = DX_OFFS_NONE;
+			want = L.start; need = live && !special && rec_start != L.start;
+		} else if (round == 0) {
+			want = lane_base; need = live || (lane == 0 && runin);
+		} else {
+			want = __shfl_up(L.end, 1u); need = live && want != L.start;
 		}
+		const unsigned long long moved = __ballot(need);
+		if (!finishing && round > 0) {
+			if (stats && lane == 0 && moved) atomicAdd(&stats[4 + (round - 1 < 11 ? round - 1 : 11)], (uint32_t)__builtin_popcountll(moved));
+			if (!moved) {
+				if (stats && lane == 0) { atomicAdd(&stats[0], (uint32_t)round - 1u); atomicAdd(&stats[1], 1u); atomicMax(&stats[2], (uint32_t)round - 1u); }
+				finishing = true; round--;                    // nothing moves any more: one more pass for the records
+				continue;
+			}
+		}
+		if (finishing && !moved) break;
+		if (need) {
+			L.start = want;
+			if (want >= DX_SPECIAL || want < lane_base || want >= lane_base + DX_LANE_BITS) {
+				// behind the band end marker (or a broken code), or the neighbour's chain does not reach this lane: nothing of the true sequence starts here
+				L.end = want >= DX_SPECIAL ? want : (uint32_t)DX_BAD; L.cnt = 0;
+			} else {
+				int hit = -1;
+#pragma unroll
+				for (int i = 0; i < DX_MEMO; i++) if (memo_s[i] == want) hit = i;
+				if (hit >= 0 && !finishing) {
+#pragma unroll
+					for (int i = 0; i < DX_MEMO; i++) if (i == hit) { L.end = memo_e[i]; L.cnt = memo_c[i]; }
+				} else {
+					dx_walk(L, want, !finishing && rec_start != DX_BAD, lane_base, limit, s_words, s_cnt, s_sym, s_long);
+					rec_start = want;
+#pragma unroll
+					for (int i = 0; i < DX_MEMO; i++) if (i == memo_at) { memo_s[i] = want; memo_e[i] = L.end; memo_c[i] = L.cnt; }
+					memo_at = memo_at + 1 < DX_MEMO ? memo_at + 1 : 0;
+				}
+			}
+		}
+		if (finishing) break;
 	}
 	// entries: offset of the first code word | coefficients of the chunk in front of it
-	const uint32_t own = lane >= 1 ? L.cnt : 0u;
+	const uint32_t own = live ? L.cnt : 0u;
 	const uint32_t incl = wave_incl_scan(own);
 	const uint32_t before = incl - own;
-	const size_t slot = ((size_t)job.chunk0 + k) * DX_ENTRY_STRIDE + (size_t)lane * DX_SUBS;
+	const size_t slot = (size_t)gchunk * DX_ENTRY_STRIDE + (size_t)lane * DX_SUBS;
 	if (lane >= 1) {
 		uint4 e;
 		uint32_t v[DX_SUBS];
 #pragma unroll
-		for (int j = 0; j < DX_SUBS; j++) v[j] = L.rec_off[j] == DX_OFF_INVALID ? (uint32_t)DX_OFF_INVALID : (L.rec_off[j] | ((before + L.rec_cnt[j]) << 5));
+		for (int j = 0; j < DX_SUBS; j++) v[j] = (!live || dx_off_get(L.rec_offs, j) == (uint32_t)DX_OFF_INVALID) ? (uint32_t)DX_OFF_INVALID : (dx_off_get(L.rec_offs, j) | ((before + L.rec_cnt[j]) << 5));
 		e.x = v[0]; e.y = v[1]; e.z = v[2]; e.w = v[3];
 		*(uint4 *)(entries + slot) = e;
 	}
-	const uint32_t total = wave_get(incl, 63), e0 = wave_get(L.end, 0), e63 = wave_get(L.end, 63);
+	const uint32_t total = wave_get(incl, 63), e0 = wave_get(L.end, 0), el = wave_get(L.end, last_live);
 	if (lane == 0) {
 		DxChunkRec r;
 		r.start = e0 >= DX_SPECIAL ? e0 : e0 - DX_LANE_BITS;
 		// a chain that stops in front of the chunk's end without the band end marker ran off the payload
-		r.end = e63 >= DX_SPECIAL ? e63 : (e63 < 64u * DX_LANE_BITS ? (uint32_t)DX_BAD : e63 - 64u * DX_LANE_BITS);
+		r.end = el >= DX_SPECIAL ? el : ((last_live < 63 || el < 64u * DX_LANE_BITS) ? (uint32_t)DX_BAD : el - 64u * DX_LANE_BITS);
 		r.count = total;
 		r.flags = (r.end == DX_END ? DX_FLAG_END : 0u) | (r.end == DX_BAD ? DX_FLAG_BAD : 0u);
-		recs[(size_t)job.chunk0 + k] = r;
+		recs[gchunk] = r;
 	}
 	CFHD_WAVE_SYNC();
+}
+
+// Stage + index, not pipelined: the repair path of k_dec_chain (rare; kept out of line so that it does not weigh on the common path's registers).
+__device__ __attribute__((noinline)) void dx_index_chunk(const uint8_t *bits, const uint32_t bytes, const uint32_t gchunk, const uint32_t k, const uint32_t exact_start, uint32_t *s_words,
+                                                         const uint16_t *s_cnt, const uint16_t *s_sym, const uint32_t *s_long, uint32_t *entries, DxChunkRec *recs, uint32_t *stats)
+{
+	DxFetch F;
+	dx_fetch_chunk(bits, bytes, k, F);
+	dx_store_stage(F, s_words);
+	dx_index_staged(bytes, gchunk, k, exact_start, s_words, s_cnt, s_sym, s_long, entries, recs, stats);
 }
 
 __device__ __forceinline__ void dx_load_tables(const DecIdxTables *T, uint16_t *s_cnt, uint16_t *s_sym, uint32_t *s_long, bool want_cnt)
@@ -220,8 +315,8 @@ __device__ __forceinline__ void dx_load_tables(const DecIdxTables *T, uint16_t *
 
 __device__ __forceinline__ uint32_t dx_nchunks(uint32_t bytes) { return (bytes + DX_CHUNK_BYTES - 1) / DX_CHUNK_BYTES; }
 
-// chunk_job[c] = band job of chunk c; jobs[j].chunk0 = first chunk of job j; counters[0] = number of chunks.  One workgroup.
-__global__ void __launch_bounds__(1024) k_dec_plan(DxBandJob *jobs, int njobs, uint32_t *chunk_job, uint32_t max_chunks, uint32_t *counters, int *errors)
+// chunk_desc[c] = payload and number of chunk c; jobs[j].chunk0 = first chunk of job j; counters[0] = number of chunks.  One workgroup.
+__global__ void __launch_bounds__(1024) k_dec_plan(DxBandJob *jobs, int njobs, DxChunkDesc *chunk_desc, uint32_t max_chunks, uint32_t *counters, int *errors)
 {
 	__shared__ uint32_t s_part[1024];
 	const int t = threadIdx.x, per = (njobs + 1023) / 1024;
@@ -244,28 +339,40 @@ __global__ void __launch_bounds__(1024) k_dec_plan(DxBandJob *jobs, int njobs, u
 		if (j >= njobs) break;
 		const uint32_t n = dx_nchunks(jobs[j].bytes);
 		jobs[j].chunk0 = at;
-		for (uint32_t c = 0; c < n; c++) chunk_job[at + c] = (uint32_t)j;
+		const DxBandJob job = jobs[j];
+		for (uint32_t c = 0; c < n; c++) chunk_desc[at + c] = DxChunkDesc{ job.bits, job.bytes, c };
 		at += n;
 	}
 }
 
-__global__ void __launch_bounds__(DX_THREADS) k_dec_index(const DxBandJob *jobs, const uint32_t *chunk_job, const uint32_t *counters, const DecIdxTables *T,
-                                                          uint32_t *entries, DxChunkRec *recs, int speculate)
+__global__ void __launch_bounds__(DX_THREADS) k_dec_index(const DxChunkDesc *chunk_desc, const uint32_t *counters, const DecIdxTables *T,
+                                                          uint32_t *entries, DxChunkRec *recs, int speculate, uint32_t *stats)
 {
 	__shared__ uint16_t s_cnt[1 << DX_K], s_sym[1 << DX_K];
 	__shared__ uint32_t s_long[DX_LONG_MAX];
-	__shared__ uint32_t s_words_all[DX_WAVES][DX_STAGE_WORDS];
+	__shared__ uint32_t s_words_all[DX_WAVES][DX_STAGE_PHYS];
 	dx_load_tables(T, s_cnt, s_sym, s_long, true);
 	__syncthreads();
 	const uint32_t total = counters[0];
 	const int wave = wave_uniform((int)(threadIdx.x >> 6));
+	uint32_t *s_words = s_words_all[wave];
 	const uint32_t gwave = (uint32_t)blockIdx.x * DX_WAVES + (uint32_t)wave, nwaves = (uint32_t)gridDim.x * DX_WAVES;
-	for (uint32_t c = gwave; c < total; c += nwaves) {
-		const uint32_t j = chunk_job[c];
-		const DxBandJob job = jobs[j];
-		const uint32_t k = c - job.chunk0;
+	// software pipeline over this wave's chunks: while chunk c is walked, the payload words of chunk c + nwaves are already on their way
+	// into registers
+	uint32_t c = gwave;
+	if (c >= total) return;
+	DxChunkDesc d = chunk_desc[c];
+	DxFetch F;
+	dx_fetch_chunk(d.bits, d.bytes, d.k, F);
+#pragma unroll 1
+	for (; c < total; c += nwaves) {
+		dx_store_stage(F, s_words);
+		const uint32_t c1 = c + nwaves;
+		DxChunkDesc d1 = d;
+		if (c1 < total) { d1 = chunk_desc[c1]; dx_fetch_chunk(d1.bits, d1.bytes, d1.k, F); }
 		// speculate == 0 (tests): every chunk assumes that a code word starts on its first bit, which is wrong for most of them -- k_dec_chain has to repair them
-		dx_index_chunk(job, k, (k == 0 || !speculate) ? 0u : (uint32_t)DX_BAD, s_words_all[wave], s_cnt, s_sym, s_long, entries, recs);
+		dx_index_staged(d.bytes, c, d.k, (d.k == 0 || !speculate) ? 0u : (uint32_t)DX_BAD, s_words, s_cnt, s_sym, s_long, entries, recs, stats);
+		d = d1;
 	}
 }
 
@@ -279,23 +386,20 @@ __device__ __forceinline__ void dx_load_tables_wave(const DecIdxTables *T, uint1
 	for (int i = lane; i < DX_LONG_MAX; i += 64) s_long[i] = T->long_tab[i];
 }
 
-// One wave per band: every chunk must start where its predecessor ended; chunk_base[c] = raster position of chunk c's first code word.
-__global__ void __launch_bounds__(DX_THREADS) k_dec_chain(const DxBandJob *jobs, int njobs, const DecIdxTables *T, uint32_t *entries, DxChunkRec *recs, uint32_t *chunk_base,
-                                                          DxBandSum *sums, int *errors)
+// One band's chain of chunks, by one wave: every chunk must start where its predecessor ended; chunk_base[c] = raster position of chunk c's
+// first code word.  REPAIR: a chunk that started elsewhere -- its run-in lane never fell in step: data without a unique alignment -- is
+// indexed again from the exact position; otherwise the band is only reported (false) and left to k_dec_repair.
+template <bool REPAIR>
+__device__ __forceinline__ bool dx_chain_band(const DxBandJob &job, const int j, const DecIdxTables *T, uint16_t *s_cnt, uint16_t *s_sym, uint32_t *s_long, uint32_t *s_words,
+                                              uint32_t *entries, DxChunkRec *recs, uint32_t *chunk_base, DxBandSum *sums, int *errors, uint32_t *stats)
 {
-	__shared__ uint16_t s_cnt[1 << DX_K], s_sym[1 << DX_K];
-	__shared__ uint32_t s_long[DX_LONG_MAX];
-	__shared__ uint32_t s_words_all[DX_WAVES][DX_STAGE_WORDS];
-	const int wave = wave_uniform((int)(threadIdx.x >> 6));
-	uint32_t *s_words = s_words_all[wave];
-	const int j = (int)blockIdx.x * DX_WAVES + wave, lane = wave_lane();
-	if (j >= njobs) return;
-	const DxBandJob job = jobs[j];
+	const int lane = wave_lane();
 	const uint32_t nch = dx_nchunks(job.bytes);
-	if (nch == 0) { if (lane == 0) { sums[j].total = 0; sums[j].last_chunk = -1; } return; }
+	if (nch == 0) { if (lane == 0) { sums[j].total = 0; sums[j].last_chunk = -1; } return true; }
 	bool tables = false;
 	uint32_t prev_end = 0, base = 0;
 	int last = -1, err = 0;
+#pragma unroll 1
 	for (uint32_t c0 = 0; c0 < nch && last < 0 && !err; c0 += 64) {
 		const uint32_t c = c0 + (uint32_t)lane;
 		const bool have = c < nch;
@@ -305,18 +409,27 @@ __global__ void __launch_bounds__(DX_THREADS) k_dec_chain(const DxBandJob *jobs,
 		uint32_t pe = __shfl_up(r.end, 1u);
 		if (lane == 0) pe = prev_end;
 		unsigned long long bad = __ballot(have && r.start != pe);
-		while (bad) {                                     // rare: index the first offending chunk again from the exact position, then look again
+		// the band ends in the first chunk that met the end marker (or a broken code); chunks behind it hold padding and may start anywhere
+		{
+			const unsigned long long stop0 = __ballot(have && (r.flags & (DX_FLAG_END | DX_FLAG_BAD)));
+			if (stop0) bad &= (2ull << __builtin_ctzll(stop0)) - 1ull;
+		}
+		if (bad && !REPAIR) return false;
+#pragma unroll 1
+		while (REPAIR && bad) {                           // rare: index the first offending chunk again from the exact position, then look again
 			const int b = __builtin_ctzll(bad);
 			const uint32_t exact = b == 0 ? prev_end : __shfl(r.end, b - 1);
 			if (exact >= DX_SPECIAL) break;                 // the predecessor holds the end of the band (or a broken code): what follows is padding
 			if (!tables) { dx_load_tables_wave(T, s_cnt, s_sym, s_long); tables = true; CFHD_WAVE_SYNC(); }
-			dx_index_chunk(job, c0 + (uint32_t)b, exact, s_words, s_cnt, s_sym, s_long, entries, recs);
+			if (stats && lane == 0) atomicAdd(&stats[3], 1u);
+			dx_index_chunk(job.bits, job.bytes, job.chunk0 + c0 + (uint32_t)b, c0 + (uint32_t)b, exact, s_words, s_cnt, s_sym, s_long, entries, recs, nullptr);
 			if (have) r = recs[(size_t)job.chunk0 + c];
 			pe = __shfl_up(r.end, 1u);
 			if (lane == 0) pe = prev_end;
 			bad = __ballot(have && r.start != pe) & ~((2ull << b) - 1ull);        // chunks up to b are settled now
+			const unsigned long long stop1 = __ballot(have && (r.flags & (DX_FLAG_END | DX_FLAG_BAD)));
+			if (stop1) bad &= (2ull << __builtin_ctzll(stop1)) - 1ull;
 		}
-		// the band ends in the first chunk that met the end marker (or a broken code); chunks behind it hold padding
 		const unsigned long long stop = __ballot(have && (r.flags & (DX_FLAG_END | DX_FLAG_BAD)));
 		const int nvalid = stop ? __builtin_ctzll(stop) + 1 : (nch - c0 < 64u ? (int)(nch - c0) : 64);
 		const uint32_t cntv = lane < nvalid ? r.count : 0u;
@@ -335,13 +448,82 @@ __global__ void __launch_bounds__(DX_THREADS) k_dec_chain(const DxBandJob *jobs,
 		sums[j].total = base; sums[j].last_chunk = last < 0 ? (int)nch - 1 : last;
 		if (err) atomic_or_u32((uint32_t *)errors, (uint32_t)err);
 	}
+	return true;
+}
+
+// One wave per band, the common case only: bands with a chunk that needs indexing again go on the repair list (counters[1] = their number).
+__global__ void __launch_bounds__(DX_THREADS) k_dec_chain(const DxBandJob *jobs, int njobs, const DxChunkRec *recs, uint32_t *chunk_base, DxBandSum *sums, int *errors,
+                                                          uint32_t *repair_list, uint32_t *counters)
+{
+	const int j = (int)blockIdx.x * DX_WAVES + wave_uniform((int)(threadIdx.x >> 6));
+	if (j >= njobs) return;
+	const DxBandJob job = jobs[j];
+	if (!dx_chain_band<false>(job, j, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, (DxChunkRec *)recs, chunk_base, sums, errors, nullptr) && wave_lane() == 0)
+		repair_list[atomicAdd(&counters[1], 1u)] = (uint32_t)j;
+}
+
+// The bands of the repair list, a wave each (a small grid strides over the list; usually it is empty).
+__global__ void __launch_bounds__(DX_THREADS) k_dec_repair(const DxBandJob *jobs, const DecIdxTables *T, uint32_t *entries, DxChunkRec *recs, uint32_t *chunk_base, DxBandSum *sums,
+                                                           int *errors, const uint32_t *repair_list, const uint32_t *counters, uint32_t *stats)
+{
+	__shared__ uint16_t s_cnt[1 << DX_K], s_sym[1 << DX_K];
+	__shared__ uint32_t s_long[DX_LONG_MAX];
+	__shared__ uint32_t s_words_all[DX_WAVES][DX_STAGE_PHYS];
+	const uint32_t n = counters[1];
+	const int wave = wave_uniform((int)(threadIdx.x >> 6));
+	for (uint32_t i = (uint32_t)blockIdx.x * DX_WAVES + (uint32_t)wave; i < n; i += (uint32_t)gridDim.x * DX_WAVES) {
+		const int j = (int)repair_list[i];
+		const DxBandJob job = jobs[j];
+		(void)dx_chain_band<true>(job, j, T, s_cnt, s_sym, s_long, s_words_all[wave], entries, recs, chunk_base, sums, errors, stats);
+	}
 }
 
 // Tiles of the [slot][frame] job table: tile_cum[s] = tiles in front of slot s (all frames), tiles_per_band[s] = tiles of one band of slot s.
 struct DxTilePlan { int nslots, nframes; uint32_t cum[40]; uint32_t per_band[40]; uint32_t total; };
 
+enum : uint32_t { DX_TILE_EMPTY = 0xFFFFFFFFu };
+
+__device__ __forceinline__ void dx_tile_of(const DxTilePlan &plan, uint32_t t, int *job, uint32_t *ti)
+{
+	int slot = 0;
+	while (slot + 1 < plan.nslots && t >= plan.cum[slot + 1]) slot++;
+	const uint32_t r = t - plan.cum[slot], per = plan.per_band[slot];
+	const uint32_t f = r / per;
+	*ti = r - f * per;
+	*job = slot * plan.nframes + (int)f;
+}
+
+// One thread per output tile: the 64-bit piece of payload that holds the code word at (or the last one in front of) the tile's first
+// coefficient -- where k_dec_tiles starts to decode.  Two binary searches over what k_dec_index / k_dec_chain left: chunks, then pieces.
+__global__ void __launch_bounds__(DX_THREADS) k_dec_tile_index(const DxBandJob *jobs, DxTilePlan plan, const uint32_t *entries, const uint32_t *chunk_base, const DxBandSum *sums,
+                                                               uint32_t *tile_start)
+{
+	const uint32_t t = (uint32_t)blockIdx.x * DX_THREADS + (uint32_t)threadIdx.x;
+	if (t >= plan.total) return;
+	int j; uint32_t ti;
+	dx_tile_of(plan, t, &j, &ti);
+	const DxBandJob job = jobs[j];
+	const DxBandSum sum = sums[j];
+	const uint32_t T0 = ti * DX_TILE;
+	uint32_t q0 = DX_TILE_EMPTY;
+	if (job.bytes != 0u && sum.last_chunk >= 0 && T0 < sum.total && T0 < (uint32_t)job.n) {
+		const uint32_t *cb = chunk_base + job.chunk0;
+		uint32_t lo = 0, hi = (uint32_t)sum.last_chunk;       // largest chunk k with cb[k] <= T0 (cb[0] = 0)
+		while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (cb[mid] <= T0) lo = mid; else hi = mid - 1; }
+		const uint32_t kc = lo, base = cb[kc];
+		const uint32_t *e = entries + ((size_t)job.chunk0 + kc) * DX_ENTRY_STRIDE + DX_SUBS;      // the chunk's 252 pieces, in order
+		uint32_t a = 0, b = DX_CHUNK_SUBS - 1;                // largest piece whose first code word lies at or in front of T0 (piece 0 does)
+		while (a < b) {
+			const uint32_t mid = (a + b + 1) >> 1, v = e[mid];
+			if ((v & 31u) != (uint32_t)DX_OFF_INVALID && base + (v >> 5) <= T0) a = mid; else b = mid - 1;
+		}
+		q0 = kc * DX_CHUNK_SUBS + a;
+	}
+	tile_start[t] = q0;
+}
+
 __global__ void __launch_bounds__(DX_THREADS) k_dec_tiles(const DxBandJob *jobs, DxTilePlan plan, const DecIdxTables *T, const uint32_t *entries, const uint32_t *chunk_base,
-                                                          const DxBandSum *sums)
+                                                          const DxBandSum *sums, const uint32_t *tile_start)
 {
 	__shared__ uint16_t s_sym[1 << DX_K];
 	__shared__ uint32_t s_long[DX_LONG_MAX];
@@ -355,79 +537,63 @@ __global__ void __launch_bounds__(DX_THREADS) k_dec_tiles(const DxBandJob *jobs,
 	__syncthreads();
 	const uint32_t gwave = (uint32_t)blockIdx.x * DX_WAVES + (uint32_t)wave, nwaves = (uint32_t)gridDim.x * DX_WAVES;
 	for (uint32_t t = gwave; t < plan.total; t += nwaves) {
-		int slot = 0;
-		while (slot + 1 < plan.nslots && t >= plan.cum[slot + 1]) slot++;
-		const uint32_t r = t - plan.cum[slot], per = plan.per_band[slot];
-		const uint32_t f = r / per, ti = r - f * per;
-		const int j = slot * plan.nframes + (int)f;
+		int j; uint32_t ti;
+		dx_tile_of(plan, t, &j, &ti);
+		const uint32_t first_sub = tile_start[t];            // independent of the two loads below: one round trip for the three
 		const DxBandJob job = jobs[j];
+		const DxBandSum sum = sums[j];
 		const uint32_t T0 = ti * DX_TILE, T1 = T0 + DX_TILE < (uint32_t)job.n ? T0 + DX_TILE : (uint32_t)job.n;
 		if (job.bytes == 0u || T0 >= (uint32_t)job.n) continue;               // wave-uniform
-		const DxBandSum sum = sums[j];
-		if (sum.last_chunk >= 0 && T0 < sum.total) {
-			// 1. the chunk that holds raster position T0
-			const uint32_t nch = (uint32_t)sum.last_chunk + 1u;
-			uint32_t kc = 0;
-			for (uint32_t c0 = 0; c0 < nch; c0 += 64) {
-				const uint32_t c = c0 + (uint32_t)lane;
-				const bool le = c < nch && chunk_base[(size_t)job.chunk0 + c] <= T0;
-				const unsigned long long m = __ballot(le);
-				if (!m) break;
-				kc = c0 + (uint32_t)(63 - __builtin_clzll(m));
-				if (~m & ((c0 + 64 <= nch) ? ~0ull : ((1ull << (nch - c0)) - 1ull))) break;      // some chunk of this block lies behind T0
-			}
-			// 2. the 64-bit piece inside it whose first code word is the last one at or in front of T0
-			uint32_t first_sub;
-			{
-				const uint32_t cb = chunk_base[(size_t)job.chunk0 + kc];
-				const uint4 e = *(const uint4 *)(entries + ((size_t)job.chunk0 + kc) * DX_ENTRY_STRIDE + (size_t)lane * DX_SUBS);
-				const uint32_t v[DX_SUBS] = { e.x, e.y, e.z, e.w };
-				uint32_t nle = 0;
-#pragma unroll
-				for (int s = 0; s < DX_SUBS; s++) {
-					const bool le = lane >= 1 && (v[s] & 31u) != (uint32_t)DX_OFF_INVALID && cb + (v[s] >> 5) <= T0;
-					nle += (uint32_t)__builtin_popcountll(__ballot(le));
-				}
-				first_sub = kc * DX_CHUNK_SUBS + (nle ? nle - 1u : 0u);
-			}
-			// 3. piece by piece, one per lane, until the pieces start behind the tile
-			const uint32_t last_sub = nch * DX_CHUNK_SUBS;
+		if (first_sub != DX_TILE_EMPTY) {
+			// piece by piece, one per lane, until the pieces start behind the tile
+			const uint32_t last_sub = ((uint32_t)sum.last_chunk + 1u) * DX_CHUNK_SUBS;
 			for (uint32_t q0 = first_sub; q0 < last_sub; q0 += 64) {
 				const uint32_t q = q0 + (uint32_t)lane;
-				bool active = q < last_sub;
-				uint32_t ent = DX_OFF_INVALID, idx = 0;
+				const bool active = q < last_sub;
+				uint32_t ent = DX_OFF_INVALID, cb = 0, d[4] = { 0u, 0u, 0u, 0u };
 				if (active) {
+					// entry, chunk position and the next 128 bits of the payload from the piece on (the walk needs at most 64 + 26 + 27 of them): three independent loads
 					const uint32_t kq = q / DX_CHUNK_SUBS, within = q - kq * DX_CHUNK_SUBS;
 					ent = entries[((size_t)job.chunk0 + kq) * DX_ENTRY_STRIDE + DX_SUBS + within];
-					idx = chunk_base[(size_t)job.chunk0 + kq] + (ent >> 5);
+					cb = chunk_base[(size_t)job.chunk0 + kq];
+					const uint32_t byte0 = q * (DX_SUB_BITS / 8);
+					const uint32_t *src = (const uint32_t *)(job.bits + byte0);
+#pragma unroll
+					for (int i = 0; i < 4; i++) d[i] = byte0 + 4u * (uint32_t)i + 4u <= job.bytes ? src[i] : 0u;
 				}
 				const uint32_t off = ent & 31u;
+				uint32_t idx = cb + (ent >> 5);
 				const bool valid = active && off != (uint32_t)DX_OFF_INVALID;
 				const bool inside = valid && idx < T1;
 				if (inside) {
-					// the next 128 bits of the payload from the piece on; the walk needs at most 64 + 26 + 27 of them
-					const uint32_t byte0 = q * (DX_SUB_BITS / 8);
-					const uint32_t *src = (const uint32_t *)(job.bits + byte0);
-					uint32_t d[4];
-#pragma unroll
-					for (int i = 0; i < 4; i++) d[i] = byte0 + 4u * (uint32_t)i + 4u <= job.bytes ? bswap32(src[i]) : 0u;
-					uint64_t acc = (((uint64_t)d[0] << 32) | d[1]) << off;
+					uint64_t acc = (((uint64_t)bswap32(d[0]) << 32) | bswap32(d[1])) << off;
 					int have = 64 - (int)off;
-					uint32_t nextw = d[2], afterw = d[3];
+					uint32_t nextw = bswap32(d[2]), afterw = bswap32(d[3]);
 					uint32_t pos = off;
+					const int quant = job.quant;
 					while (pos < (uint32_t)DX_SUB_BITS && idx < T1) {
 						if (have < 32) { acc |= (uint64_t)nextw << (32 - have); have += 32; nextw = afterw; afterw = 0u; }
-						const DxSym s = dx_symbol(s_sym, s_long, (uint32_t)(acc >> 32));
-						if (s.type == DX_T_RUN) { idx += (uint32_t)s.payload; acc <<= s.len; have -= s.len; pos += (uint32_t)s.len; }
-						else if (s.type == DX_T_VALUE) {
-							const int negative = (int)((acc << s.len) >> 63);
-							if (idx >= T0) {
-								const int v = (int)s_mag[s.payload] * job.quant;
-								((int16_t *)s_tile)[idx - T0] = (int16_t)(negative ? -v : v);
-							}
-							idx++;
-							acc <<= s.len + 1; have -= s.len + 1; pos += (uint32_t)s.len + 1u;
-						} else break;                                        // band end marker (or a broken code, reported by k_dec_chain)
+						const uint32_t win = (uint32_t)(acc >> 32);
+						// the two shortest code words without a table: '0' = one zero coefficient (a stretch of them at once), '10' + sign = +-1
+						const int z = win ? __builtin_clz(win) : 32;
+						if (z) {
+							int n = (int)DX_SUB_BITS - (int)pos;          // only code words that start inside this piece
+							if (z < n) n = z;
+							idx += (uint32_t)n; acc <<= n; have -= n; pos += (uint32_t)n;
+							continue;
+						}
+						int len, v;
+						if (!(win & 0x40000000u)) { len = 2; v = (int)s_mag[1] * quant; }
+						else {
+							const DxSym s = dx_symbol(s_sym, s_long, win);
+							if (s.type == DX_T_RUN) { idx += (uint32_t)s.payload; acc <<= s.len; have -= s.len; pos += (uint32_t)s.len; continue; }
+							if (s.type != DX_T_VALUE) break;                 // band end marker (or a broken code, reported by k_dec_chain)
+							len = s.len; v = (int)s_mag[s.payload] * quant;
+						}
+						const int negative = (int)((acc << len) >> 63);
+						if (idx >= T0) ((int16_t *)s_tile)[idx - T0] = (int16_t)(negative ? -v : v);
+						idx++;
+						acc <<= len + 1; have -= len + 1; pos += (uint32_t)len + 1u;
 					}
 				}
 				// pieces are in raster order: once a valid one starts behind the tile, all later ones do
@@ -435,7 +601,7 @@ __global__ void __launch_bounds__(DX_THREADS) k_dec_tiles(const DxBandJob *jobs,
 			}
 		}
 		CFHD_WAVE_SYNC();
-		// 4. the tile goes out in 16-byte words and is cleared for the next one
+		// the tile goes out in 16-byte words and is cleared for the next one
 		{
 			uint4 *dst = (uint4 *)(job.dst + T0);
 			const uint32_t n16 = (T1 - T0) / 8;

@@ -70,8 +70,9 @@ public:
 	void set_producer_events(void *headers, void *payloads) { ev_headers_ = headers; ev_payloads_ = payloads; }
 	int launch();                        // async: (H2D samples, job tables | k_dec_parse), k_dec_bands_par + k_dec_lowpass
 	int check();                         // after the stream was synchronised: 0 when every band decoded cleanly
-	float kernel_ms(int k);              // last launch(): 0 k_dec_parse (device-resident samples only), 1 band decoder (all its kernels), 2 k_dec_lowpass, 3 k_dec_plan + k_dec_index, 4 k_dec_chain, 5 k_dec_tiles
+	float kernel_ms(int k);              // last launch(): 0 k_dec_parse (device-resident samples only), 1 band decoder (all its kernels), 2 k_dec_lowpass, 3 k_dec_plan + k_dec_index, 4 k_dec_chain + k_dec_tile_index, 5 k_dec_tiles
 	bool chunk_indexed() const { return dx_; }
+	int stats(uint32_t out[16]);         // CFHD_AMD_DX_STATS=1: convergence counters of the chunk index (see the .hip)
 private:
 	struct Host; Host *host_;
 	void release();
@@ -86,8 +87,9 @@ private:
 	bool lane_kernel_ = false;
 	// cfhd_dec_kernels.h (default): chunk index + tile decode.  CFHD_AMD_DEC=par / lane select the round-1 kernels for A/B runs.
 	bool dx_ = true;
+	void *d_tile_start_ = nullptr, *d_stats_ = nullptr, *d_repair_ = nullptr;
 	void *d_idx_tables_ = nullptr, *d_entries_ = nullptr, *d_recs_ = nullptr, *d_chunk_base_ = nullptr, *d_chunk_job_ = nullptr, *d_sums_ = nullptr, *d_counters_ = nullptr;
-	uint32_t max_chunks_ = 0, *h_chunk_job_ = nullptr, *h_counters_ = nullptr;
+	uint32_t max_chunks_ = 0, *h_counters_ = nullptr; void *h_chunk_job_ = nullptr;
 	int grid_index_ = 0, grid_tiles_ = 0;
 	int launch_dx(bool device_jobs, int njobs, uint32_t host_chunks);
 	void *ev_[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; bool timed_ = false;    // [4]: end of k_dec_parse when the band decoder waits for a second event behind it; [5], [6]: behind k_dec_index / k_dec_chain

@@ -162,12 +162,12 @@ GpuEntropyDecoder::~GpuEntropyDecoder() { release(); delete host_; }
 
 void GpuEntropyDecoder::release()
 {
-	void *dev[] = { d_samples_, d_tables_, d_bandjobs_, d_lowjobs_, d_errors_, d_plan_, d_idx_tables_, d_entries_, d_recs_, d_chunk_base_, d_chunk_job_, d_sums_, d_counters_ };
+	void *dev[] = { d_samples_, d_tables_, d_bandjobs_, d_lowjobs_, d_errors_, d_plan_, d_idx_tables_, d_entries_, d_recs_, d_chunk_base_, d_chunk_job_, d_sums_, d_counters_, d_tile_start_, d_stats_, d_repair_ };
 	for (void *p : dev) if (p) (void)hipFree(p);
-	d_idx_tables_ = d_entries_ = d_recs_ = d_chunk_base_ = d_chunk_job_ = d_sums_ = d_counters_ = nullptr;
+	d_idx_tables_ = d_entries_ = d_recs_ = d_chunk_base_ = d_chunk_job_ = d_sums_ = d_counters_ = d_tile_start_ = d_stats_ = d_repair_ = nullptr;
 	if (h_chunk_job_) (void)hipHostFree(h_chunk_job_);
 	if (h_counters_) (void)hipHostFree(h_counters_);
-	h_chunk_job_ = h_counters_ = nullptr;
+	h_chunk_job_ = nullptr; h_counters_ = nullptr;
 	if (h_samples_) (void)hipHostFree(h_samples_);
 	if (h_errors_) (void)hipHostFree(h_errors_);
 	if (host_->flat_bands) { (void)hipHostFree(host_->flat_bands); host_->flat_bands = nullptr; }
@@ -210,10 +210,18 @@ int GpuEntropyDecoder::prepare(const FramePlan &plan, int nframes, int16_t *d_co
 		HIPCHK(hipMalloc(&d_entries_, (size_t)max_chunks_ * dev::DX_ENTRY_STRIDE * 4));
 		HIPCHK(hipMalloc(&d_recs_, (size_t)max_chunks_ * sizeof(dev::DxChunkRec)));
 		HIPCHK(hipMalloc(&d_chunk_base_, (size_t)max_chunks_ * 4));
-		HIPCHK(hipMalloc(&d_chunk_job_, (size_t)max_chunks_ * 4));
+		HIPCHK(hipMalloc(&d_chunk_job_, (size_t)max_chunks_ * sizeof(dev::DxChunkDesc)));
 		HIPCHK(hipMalloc(&d_sums_, max_bands * sizeof(dev::DxBandSum)));
 		HIPCHK(hipMalloc(&d_counters_, 16));
-		HIPCHK(hipHostMalloc((void **)&h_chunk_job_, (size_t)max_chunks_ * 4, hipHostMallocDefault));
+		HIPCHK(hipMalloc(&d_repair_, max_bands * 4));
+		{
+			dev::DecPlan dp0; dec_build_plan(plan, out_kind, &dp0);
+			const dev::DxTilePlan tp0 = dx_tile_plan(plan, dp0, n_, false);
+			HIPCHK(hipMalloc(&d_tile_start_, ((size_t)tp0.total + 1) * 4));
+			const char *se = getenv("CFHD_AMD_DX_STATS");
+			if (se && atoi(se)) { HIPCHK(hipMalloc(&d_stats_, 64)); HIPCHK(hipMemset(d_stats_, 0, 64)); }
+		}
+		HIPCHK(hipHostMalloc((void **)&h_chunk_job_, (size_t)max_chunks_ * sizeof(dev::DxChunkDesc), hipHostMallocDefault));
 		HIPCHK(hipHostMalloc((void **)&h_counters_, 16, hipHostMallocDefault));
 		int cus = 256;
 		(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
@@ -310,17 +318,17 @@ int GpuEntropyDecoder::launch()
 			for (int s = 0; s < dp.bands_per_frame; s++) host_->flat_bands[(size_t)s * n_ + f] = host_->bands[f][s];
 			for (int c = 0; c < nch; c++) host_->flat_lows[(size_t)f * nch + c] = host_->lows[f][c];
 		}
-		std::vector<uint32_t> cj;
+		std::vector<dev::DxChunkDesc> cj;
 		const uint32_t nchunks = dx_number_chunks(host_->flat_bands, nb, &cj);
 		if (nchunks > max_chunks_) return -5;
-		memcpy(h_chunk_job_, cj.data(), cj.size() * 4);
-		h_counters_[0] = nchunks;
+		memcpy(h_chunk_job_, cj.data(), cj.size() * sizeof(dev::DxChunkDesc));
+		h_counters_[0] = nchunks; h_counters_[1] = 0;
 		HIPCHK(hipMemsetAsync(d_errors_, 0, sizeof(int), st));
 		for (int f = 0; f < n_; f++)
 			if (host_->host_bytes[f]) HIPCHK(hipMemcpyAsync(d_samples_ + cap_ * f, h_samples_ + cap_ * f, host_->host_bytes[f], hipMemcpyHostToDevice, st));
 		HIPCHK(hipMemcpyAsync(d_bandjobs_, host_->flat_bands, (size_t)nb * sizeof(dev::DecBandJob), hipMemcpyHostToDevice, st));
 		HIPCHK(hipMemcpyAsync(d_lowjobs_, host_->flat_lows, (size_t)n_ * nch * sizeof(dev::DecLowpassJob), hipMemcpyHostToDevice, st));
-		HIPCHK(hipMemcpyAsync(d_chunk_job_, h_chunk_job_, (size_t)nchunks * 4, hipMemcpyHostToDevice, st));
+		HIPCHK(hipMemcpyAsync(d_chunk_job_, h_chunk_job_, (size_t)nchunks * sizeof(dev::DxChunkDesc), hipMemcpyHostToDevice, st));
 		HIPCHK(hipMemcpyAsync(d_counters_, h_counters_, 16, hipMemcpyHostToDevice, st));
 		(void)hipGetLastError();
 		HIPCHK(hipEventRecord((hipEvent_t)ev_[0], st));
@@ -377,7 +385,8 @@ int GpuEntropyDecoder::launch_dx(bool device_jobs, int njobs, uint32_t host_chun
 	const dev::DxTilePlan tp = dx_tile_plan(plan_, dp, n_, skip_level1_);
 	const char *spec_env = getenv("CFHD_AMD_DX_SPECULATE");
 	const bool speculate = !(spec_env && atoi(spec_env) == 0);            // 0: every chunk goes through the repair path (tests)
-	if (device_jobs) dev::k_dec_plan<<<1, 1024, 0, st>>>(jobs, njobs, (uint32_t *)d_chunk_job_, max_chunks_, (uint32_t *)d_counters_, d_errors_);
+	if (device_jobs) HIPCHK(hipMemsetAsync((uint32_t *)d_counters_ + 1, 0, 4, st));      // the repair list starts empty (the host path uploads zeroed counters)
+	if (device_jobs) dev::k_dec_plan<<<1, 1024, 0, st>>>(jobs, njobs, (dev::DxChunkDesc *)d_chunk_job_, max_chunks_, (uint32_t *)d_counters_, d_errors_);
 	// grid-stride kernels: as many workgroups as the chip holds at once, fewer when there is less work
 	const uint32_t chunk_bound = device_jobs ? max_chunks_ : host_chunks;
 	int g1 = grid_index_, g3 = grid_tiles_;
@@ -385,16 +394,32 @@ int GpuEntropyDecoder::launch_dx(bool device_jobs, int njobs, uint32_t host_chun
 	if ((uint32_t)g3 * dev::DX_WAVES > tp.total) g3 = (int)((tp.total + dev::DX_WAVES - 1) / dev::DX_WAVES);
 	if (g1 < 1) g1 = 1;
 	if (g3 < 1) g3 = 1;
-	dev::k_dec_index<<<g1, dev::DX_THREADS, 0, st>>>(jobs, (const uint32_t *)d_chunk_job_, (const uint32_t *)d_counters_, T, (uint32_t *)d_entries_, (dev::DxChunkRec *)d_recs_, speculate ? 1 : 0);
+	dev::k_dec_index<<<g1, dev::DX_THREADS, 0, st>>>((const dev::DxChunkDesc *)d_chunk_job_, (const uint32_t *)d_counters_, T, (uint32_t *)d_entries_, (dev::DxChunkRec *)d_recs_, speculate ? 1 : 0, (uint32_t *)d_stats_);
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[5], st));
-	dev::k_dec_chain<<<(njobs + dev::DX_WAVES - 1) / dev::DX_WAVES, dev::DX_THREADS, 0, st>>>(jobs, njobs, T, (uint32_t *)d_entries_, (dev::DxChunkRec *)d_recs_, (uint32_t *)d_chunk_base_, (dev::DxBandSum *)d_sums_, d_errors_);
+	dev::k_dec_chain<<<(njobs + dev::DX_WAVES - 1) / dev::DX_WAVES, dev::DX_THREADS, 0, st>>>(jobs, njobs, (const dev::DxChunkRec *)d_recs_, (uint32_t *)d_chunk_base_, (dev::DxBandSum *)d_sums_, d_errors_,
+	                                                                                            (uint32_t *)d_repair_, (uint32_t *)d_counters_);
+	dev::k_dec_repair<<<njobs < 256 ? (njobs + dev::DX_WAVES - 1) / dev::DX_WAVES : 64, dev::DX_THREADS, 0, st>>>(jobs, T, (uint32_t *)d_entries_, (dev::DxChunkRec *)d_recs_, (uint32_t *)d_chunk_base_, (dev::DxBandSum *)d_sums_,
+	                                                                                                  d_errors_, (const uint32_t *)d_repair_, (const uint32_t *)d_counters_, (uint32_t *)d_stats_);
+	dev::k_dec_tile_index<<<(tp.total + dev::DX_THREADS - 1) / dev::DX_THREADS, dev::DX_THREADS, 0, st>>>(jobs, tp, (const uint32_t *)d_entries_, (const uint32_t *)d_chunk_base_, (const dev::DxBandSum *)d_sums_,
+	                                                                                                  (uint32_t *)d_tile_start_);
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[6], st));
-	dev::k_dec_tiles<<<g3, dev::DX_THREADS, 0, st>>>(jobs, tp, T, (const uint32_t *)d_entries_, (const uint32_t *)d_chunk_base_, (const dev::DxBandSum *)d_sums_);
+	dev::k_dec_tiles<<<g3, dev::DX_THREADS, 0, st>>>(jobs, tp, T, (const uint32_t *)d_entries_, (const uint32_t *)d_chunk_base_, (const dev::DxBandSum *)d_sums_, (const uint32_t *)d_tile_start_);
 	HIPCHK(hipGetLastError());
 	return 0;
 }
 
 int GpuEntropyDecoder::check() { return *h_errors_ ? -1 : 0; }
+
+// CFHD_AMD_DX_STATS=1: counters of k_dec_index / k_dec_chain since prepare(): [0] rounds, [1] chunks indexed, [2] most rounds of a chunk, [3] chunks repaired,
+// [4..15] lanes that restarted in round 0..10, 11+.  Synchronises the stream.
+int GpuEntropyDecoder::stats(uint32_t out[16])
+{
+	memset(out, 0, 64);
+	if (!d_stats_) return -1;
+	HIPCHK(hipStreamSynchronize((hipStream_t)stream_));
+	HIPCHK(hipMemcpy(out, d_stats_, 64, hipMemcpyDeviceToHost));
+	return 0;
+}
 
 float GpuEntropyDecoder::kernel_ms(int k)
 {

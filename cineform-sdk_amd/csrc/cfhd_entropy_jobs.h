@@ -287,14 +287,14 @@ inline dev::DxTilePlan dx_tile_plan(const FramePlan &plan, const dev::DecPlan &d
 }
 
 // Chunk numbering on the host (what k_dec_plan does on the device): returns the number of chunks.
-inline uint32_t dx_number_chunks(dev::DecBandJob *jobs, int njobs, std::vector<uint32_t> *chunk_job)
+inline uint32_t dx_number_chunks(dev::DecBandJob *jobs, int njobs, std::vector<dev::DxChunkDesc> *chunk_desc)
 {
 	uint32_t at = 0;
-	chunk_job->clear();
+	chunk_desc->clear();
 	for (int j = 0; j < njobs; j++) {
 		const uint32_t n = (jobs[j].bytes + dev::DX_CHUNK_BYTES - 1) / dev::DX_CHUNK_BYTES;
 		jobs[j].chunk0 = at;
-		for (uint32_t c = 0; c < n; c++) chunk_job->push_back((uint32_t)j);
+		for (uint32_t c = 0; c < n; c++) chunk_desc->push_back(dev::DxChunkDesc{ jobs[j].bits, jobs[j].bytes, c });
 		at += n;
 	}
 	return at;

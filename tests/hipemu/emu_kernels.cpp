@@ -300,8 +300,11 @@ extern "C" int emu_entropy_decode(const uint8_t *sample, size_t size, int pixel_
 // The round-2 decoder (cfhd_dec_kernels.h) under emulation.  mode 0: host parser, speculation on; 1: speculation off (every chunk but the first
 // assumes a wrong start, so k_dec_chain has to index them again: the repair path); 2: two copies of the sample in "device" memory, parsed by
 // k_dec_parse and numbered by k_dec_plan.  grid: workgroups of the grid-stride kernels (small grids exercise the stride loops).
+uint32_t g_dx_stats[16];
+extern "C" uint32_t *emu_dx_stats() { return g_dx_stats; }
 extern "C" int emu_entropy_decode_dx(const uint8_t *sample, size_t size, int pixel_kind, int16_t *coeffs, size_t coeff_elems, int mode, int grid)
 {
+	memset(g_dx_stats, 0, sizeof(g_dx_stats));
 	using namespace cfhd;
 	ParsedSample ps;
 	if (parse_sample(sample, size, &ps) != 0) return -1;
@@ -322,7 +325,7 @@ extern "C" int emu_entropy_decode_dx(const uint8_t *sample, size_t size, int pix
 	memcpy(two, sample, size); memcpy(two + stride, sample, size);
 	int errors = 0;
 	const uint32_t max_chunks = (uint32_t)(nframes * (size / dev::DX_CHUNK_BYTES + dp.bands_per_frame + 1));
-	std::vector<uint32_t> chunk_job(max_chunks), counters(4, 0);
+	std::vector<dev::DxChunkDesc> chunk_job(max_chunks); std::vector<uint32_t> counters(4, 0);
 	if (mode == 2) {
 		const uint32_t sizes[2] = { (uint32_t)size, (uint32_t)size };
 		hipemu::launch(dim3(2), dim3(dev::DEC_PARSE_THREADS), [&] { dev::k_dec_parse(two, stride, sizes, 2, &dp, pyr.data(), plan.coeff_elems, jobs.data(), lows.data(), &errors); });
@@ -331,7 +334,7 @@ extern "C" int emu_entropy_decode_dx(const uint8_t *sample, size_t size, int pix
 		if (errors) return -40 - errors;
 	} else {
 		if (!dx_build_jobs(ps, plan, dp, two, pyr.data(), pixel_kind, 0, 1, jobs.data(), lows.data())) return -4;
-		std::vector<uint32_t> cj;
+		std::vector<dev::DxChunkDesc> cj;
 		counters[0] = dx_number_chunks(jobs.data(), njobs, &cj);
 		if (counters[0] > max_chunks) return -6;
 		std::copy(cj.begin(), cj.end(), chunk_job.begin());
@@ -341,9 +344,14 @@ extern "C" int emu_entropy_decode_dx(const uint8_t *sample, size_t size, int pix
 	std::vector<dev::DxChunkRec> recs(nchunks + 1);
 	std::vector<dev::DxBandSum> sums((size_t)njobs);
 	const dev::DxTilePlan tp = dx_tile_plan(plan, dp, nframes);
-	hipemu::launch(dim3((unsigned)grid), dim3(dev::DX_THREADS), [&] { dev::k_dec_index(jobs.data(), chunk_job.data(), counters.data(), &tables, entries.data(), recs.data(), mode != 1); });
-	hipemu::launch(dim3((unsigned)(njobs + dev::DX_WAVES - 1) / dev::DX_WAVES), dim3(dev::DX_THREADS), [&] { dev::k_dec_chain(jobs.data(), njobs, &tables, entries.data(), recs.data(), chunk_base.data(), sums.data(), &errors); });
-	hipemu::launch(dim3((unsigned)grid), dim3(dev::DX_THREADS), [&] { dev::k_dec_tiles(jobs.data(), tp, &tables, entries.data(), chunk_base.data(), sums.data()); });
+	hipemu::launch(dim3((unsigned)grid), dim3(dev::DX_THREADS), [&] { dev::k_dec_index(chunk_job.data(), counters.data(), &tables, entries.data(), recs.data(), mode != 1, g_dx_stats); });
+	std::vector<uint32_t> repair_list((size_t)njobs + 1);
+	counters[1] = 0;
+	hipemu::launch(dim3((unsigned)(njobs + dev::DX_WAVES - 1) / dev::DX_WAVES), dim3(dev::DX_THREADS), [&] { dev::k_dec_chain(jobs.data(), njobs, recs.data(), chunk_base.data(), sums.data(), &errors, repair_list.data(), counters.data()); });
+	hipemu::launch(dim3(2), dim3(dev::DX_THREADS), [&] { dev::k_dec_repair(jobs.data(), &tables, entries.data(), recs.data(), chunk_base.data(), sums.data(), &errors, repair_list.data(), counters.data(), g_dx_stats); });
+	std::vector<uint32_t> tile_start(tp.total + 1, 0xdeadbeefu);
+	hipemu::launch(dim3((tp.total + dev::DX_THREADS - 1) / dev::DX_THREADS), dim3(dev::DX_THREADS), [&] { dev::k_dec_tile_index(jobs.data(), tp, entries.data(), chunk_base.data(), sums.data(), tile_start.data()); });
+	hipemu::launch(dim3((unsigned)grid), dim3(dev::DX_THREADS), [&] { dev::k_dec_tiles(jobs.data(), tp, &tables, entries.data(), chunk_base.data(), sums.data(), tile_start.data()); });
 	hipemu::launch(dim3(4, (unsigned)lows.size()), dim3(256), [&] { dev::k_dec_lowpass(lows.data()); });
 	if (errors) return -10 - errors;
 	memcpy(coeffs, pyr.data() + (size_t)(nframes - 1) * plan.coeff_elems, (size_t)plan.coeff_elems * 2);

@@ -115,6 +115,8 @@ inline unsigned long long __ballot(int pred)
 	return m;
 }
 using std::min; using std::max;
+template <typename T> inline T atomicAdd(T *p, T v) { T o = *p; *p = o + v; return o; }
+template <typename T> inline T atomicMax(T *p, T v) { T o = *p; if (v > o) *p = v; return o; }
 
 namespace hipemu {
 template <typename F>

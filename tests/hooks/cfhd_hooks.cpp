@@ -112,6 +112,8 @@ int cfhd_amd_decode_bands_host(const uint8_t *sample, size_t size, int pixel_kin
 				if (!pb.present || pb.width != bd.width || pb.height != bd.height) return -23;
 				rc = vlc_decode_band(sample + pb.offset, pb.bytes, bd.width, bd.height, bd.pitch, pb.quant, pb.codebook, coeffs + bd.offset);
 				if (rc) return rc * 100 - (c * 9 + lv * 3 + b);
+				if (pb.difference) finish_difference_band(coeffs + bd.offset, bd.width, bd.height, bd.pitch, pb.peak_level ? sample + pb.peak_offset : nullptr,
+				                                          pb.peak_level ? size - pb.peak_offset : 0, pb.peak_level);
 			}
 	}
 	return 0;

@@ -586,6 +586,31 @@ def test_dx_decoder_emulated_sparse_and_dense_bands():
             assert np.array_equal(plan.view(got, c, lv, b), plan.view(want, c, lv, b)), (mode, c, lv, b)
 
 
+def test_dx_decoder_emulated_code_without_unique_alignment():
+    """A smooth gradient gives a band the same value in every position: the same code word over and over, a bit pattern that parses
+    consistently at several alignments, so no lane can find its phase on its own and the true starts travel through a chunk lane by lane
+    (and from chunk to chunk through k_dec_chain's repair path).  The result must still be exact."""
+    w, h = 720, 480
+    plan = Plan(w, h)
+    frame, pitch = synth_yuy2(w, h, 8)
+    coeffs = oracle_forward_yuv422(plan, frame, pitch)
+    for (c, lv, b), val in (((0, 0, 2), 3), ((1, 0, 1), -7), ((0, 1, 2), 21)):
+        d = plan.band[(c, lv, b)]
+        v = plan.view(coeffs, c, lv, b); v[:] = 0; v[:, : d["width"]] = val
+    sample = product_write_sample_host(plan, coeffs, 1, meta_global=b"GUID\x10\x00\x00G" + bytes(16))
+    want = host_decode_pyramid(sample, plan)
+    for mode, grid in ((0, 4), (1, 3)):
+        rc, got = _dx_decode(sample, plan, mode, grid)
+        assert rc == 0
+        for (c, lv, b) in plan.band:
+            if b == 0: continue
+            assert np.array_equal(plan.view(got, c, lv, b), plan.view(want, c, lv, b)), (mode, c, lv, b)
+    E = emu(); E.emu_dx_stats.restype = ctypes.POINTER(ctypes.c_uint32)
+    rc, got = _dx_decode(sample, plan, 0, 4)
+    st = E.emu_dx_stats()
+    assert st[2] >= 20, "the constant bands were expected to need many rounds (%d): the test does not exercise what it is for" % st[2]
+
+
 @pytest.mark.parametrize("mode", [0, 2])
 def test_dx_decoder_emulated_survives_damaged_samples(mode):
     """Truncated samples are refused; garbage inside the code words never writes outside the pyramid nor hangs (error flag or wrong values, no crash)."""
