@@ -121,51 +121,54 @@ __device__ __forceinline__ uint32_t dx_off_clear_from(uint32_t offs, int k) { co
 
 // Walks the code words of one lane from bit `pos` to the end of the lane's range.  merge: stop as soon as the walk reaches a 64-bit mark at
 // the offset recorded by the previous walk -- from there on the two chains are the same, only the counts in front shift.
+// One flat loop: the lanes of a wave cross their marks at different times, and a loop per piece would make every lane wait for the slowest
+// one four times over.
 __device__ __forceinline__ void dx_walk(DxLane &L, uint32_t pos, const bool merge, const uint32_t lane_base, const uint32_t limit, const uint32_t *s_words, const uint16_t *s_cnt,
                                         const uint16_t *s_sym, const uint32_t *s_long)
 {
-	uint32_t cnt = 0, end = 0;
-	bool done = false;
+	uint32_t cnt = 0;
 	uint32_t offs = merge ? L.rec_offs : (uint32_t)DX_OFFS_NONE;
+	const uint32_t lane_end = lane_base + DX_LANE_BITS;
+	uint32_t next = lane_base;                            // first bit of the piece the walk has not entered yet
+	int piece = -1;
 	DxBits B;
 	B.seek(s_words, pos);
-#pragma unroll 1
-	for (int k = 0; k < DX_SUBS; k++) {
-		const uint32_t mark = lane_base + (uint32_t)k * DX_SUB_BITS, next = mark + DX_SUB_BITS;
-		if (pos >= next) { offs = dx_off_set(offs, k, DX_OFF_INVALID); continue; }      // a walk that starts beyond this piece
-		if (pos >= limit) { offs = dx_off_clear_from(offs, k); end = pos; done = true; break; }
-		const uint32_t off = pos - mark;
-		if (merge && k > 0 && dx_off_get(offs, k) == off) {
-			// same chain from here on: the counts recorded behind this mark move by the difference in front of it
-			uint32_t old = 0;
+	for (;;) {
+		if (pos >= lane_end) { L.end = pos; break; }
+		if (pos >= limit) { L.end = pos; offs = dx_off_clear_from(offs, piece + 1); break; }
+		if (pos >= next) {
+			// the walk enters a new piece (a code word is shorter than a piece: none is skipped, except in front of a late start)
+			const int k = (int)((pos - lane_base) / DX_SUB_BITS);
+			for (int j = piece + 1; j < k; j++) offs = dx_off_set(offs, j, DX_OFF_INVALID);
+			const uint32_t off = pos - (lane_base + (uint32_t)k * DX_SUB_BITS);
+			if (merge && k > 0 && dx_off_get(offs, k) == off) {
+				// same chain from here on: the counts recorded behind this mark move by the difference in front of it
+				uint32_t old = 0;
 #pragma unroll
-			for (int j = 1; j < DX_SUBS; j++) if (j == k) old = L.rec_cnt[j];
-			const uint32_t delta = cnt - old;
+				for (int j = 1; j < DX_SUBS; j++) if (j == k) old = L.rec_cnt[j];
+				const uint32_t delta = cnt - old;
 #pragma unroll
-			for (int j = 1; j < DX_SUBS; j++) if (j >= k && dx_off_get(offs, j) != (uint32_t)DX_OFF_INVALID) L.rec_cnt[j] += delta;
-			L.cnt += delta;
-			L.rec_offs = offs;
-			return;                                           // L.end stays
+				for (int j = 1; j < DX_SUBS; j++) if (j >= k && dx_off_get(offs, j) != (uint32_t)DX_OFF_INVALID) L.rec_cnt[j] += delta;
+				L.cnt += delta;
+				L.rec_offs = offs;
+				return;                                       // L.end stays
+			}
+			offs = dx_off_set(offs, k, off);
+#pragma unroll
+			for (int j = 0; j < DX_SUBS; j++) if (j == k) L.rec_cnt[j] = cnt;
+			piece = k; next = lane_base + (uint32_t)(k + 1) * DX_SUB_BITS;
 		}
-		offs = dx_off_set(offs, k, off);
-#pragma unroll
-		for (int j = 0; j < DX_SUBS; j++) if (j == k) L.rec_cnt[j] = cnt;
-		while (pos < next) {
-			if (pos >= limit) { end = pos; done = true; break; }
-			const uint32_t win = B.window();
-			const uint32_t m = s_cnt[win >> (32 - DX_K)];
-			const uint32_t used = m & 15u;
-			if (used && pos + used <= next) { pos += used; cnt += m >> 4; B.skip(s_words, (int)used); continue; }       // several whole code words, none of them beyond the mark
-			const DxSym s = dx_symbol(s_sym, s_long, win);
-			if (s.type == DX_T_RUN) { pos += (uint32_t)s.len; cnt += (uint32_t)s.payload; B.skip(s_words, s.len); }
-			else if (s.type == DX_T_VALUE) { pos += (uint32_t)s.len + 1u; cnt += 1u; B.skip(s_words, s.len + 1); }
-			else { end = s.type == DX_T_END ? DX_END : DX_BAD; done = true; break; }
-		}
-		if (done) { offs = dx_off_clear_from(offs, k + 1); break; }
+		const uint32_t win = B.window();
+		const uint32_t m = s_cnt[win >> (32 - DX_K)];
+		const uint32_t used = m & 15u;
+		if (used && pos + used <= next) { pos += used; cnt += m >> 4; B.skip(s_words, (int)used); continue; }       // several whole code words, none of them beyond the mark
+		const DxSym s = dx_symbol(s_sym, s_long, win);
+		if (s.type == DX_T_RUN) { pos += (uint32_t)s.len; cnt += (uint32_t)s.payload; B.skip(s_words, s.len); }
+		else if (s.type == DX_T_VALUE) { pos += (uint32_t)s.len + 1u; cnt += 1u; B.skip(s_words, s.len + 1); }
+		else { L.end = s.type == DX_T_END ? DX_END : DX_BAD; offs = dx_off_clear_from(offs, piece + 1); break; }
 	}
 	L.rec_offs = offs;
 	L.cnt = cnt;
-	L.end = done ? end : pos;
 }
 
 // Staging of chunk k of a band: fetch the words into registers (the loads can be in flight while the previous chunk is walked), then put them
@@ -222,7 +225,7 @@ __device__ __forceinline__ void dx_index_staged(const uint32_t bytes, const uint
 	int memo_at = 0;
 #pragma unroll
 	for (int i = 0; i < DX_MEMO; i++) { memo_s[i] = DX_BAD; memo_e[i] = 0; memo_c[i] = 0; }
-	uint32_t rec_start = DX_BAD;                          // the start the per-piece records were made for
+	uint32_t rec_start = DX_BAD, rec_end = 0, rec_total = 0;     // the walk the per-piece records belong to: its start, end and coefficient count
 	bool finishing = false;
 #pragma unroll 1
 	for (int round = 0; round < 70; round++) {
@@ -260,8 +263,9 @@ __device__ __forceinline__ void dx_index_staged(const uint32_t bytes, const uint
 #pragma unroll
 					for (int i = 0; i < DX_MEMO; i++) if (i == hit) { L.end = memo_e[i]; L.cnt = memo_c[i]; }
 				} else {
+					L.end = rec_end; L.cnt = rec_total;           // a walk that meets the recorded one continues from ITS outcome (a remembered outcome may have replaced it meanwhile)
 					dx_walk(L, want, !finishing && rec_start != DX_BAD, lane_base, limit, s_words, s_cnt, s_sym, s_long);
-					rec_start = want;
+					rec_start = want; rec_end = L.end; rec_total = L.cnt;
 #pragma unroll
 					for (int i = 0; i < DX_MEMO; i++) if (i == memo_at) { memo_s[i] = want; memo_e[i] = L.end; memo_c[i] = L.cnt; }
 					memo_at = memo_at + 1 < DX_MEMO ? memo_at + 1 : 0;
@@ -315,8 +319,8 @@ __device__ __forceinline__ void dx_load_tables(const DecIdxTables *T, uint16_t *
 
 __device__ __forceinline__ uint32_t dx_nchunks(uint32_t bytes) { return (bytes + DX_CHUNK_BYTES - 1) / DX_CHUNK_BYTES; }
 
-// chunk_desc[c] = payload and number of chunk c; jobs[j].chunk0 = first chunk of job j; counters[0] = number of chunks.  One workgroup.
-__global__ void __launch_bounds__(1024) k_dec_plan(DxBandJob *jobs, int njobs, DxChunkDesc *chunk_desc, uint32_t max_chunks, uint32_t *counters, int *errors)
+// jobs[j].chunk0 = first chunk of job j; counters[0] = number of chunks.  One workgroup (a scan over a few thousand numbers).
+__global__ void __launch_bounds__(1024) k_dec_plan(DxBandJob *jobs, int njobs, uint32_t max_chunks, uint32_t *counters, int *errors)
 {
 	__shared__ uint32_t s_part[1024];
 	const int t = threadIdx.x, per = (njobs + 1023) / 1024;
@@ -333,16 +337,21 @@ __global__ void __launch_bounds__(1024) k_dec_plan(DxBandJob *jobs, int njobs, D
 	uint32_t at = s_part[t] - sum;
 	const uint32_t total = s_part[1023];
 	if (t == 0) { counters[0] = total <= max_chunks ? total : 0u; if (total > max_chunks) atomic_or_u32((uint32_t *)errors, (uint32_t)DX_ERR_SPACE); }
-	if (total > max_chunks) return;
 	for (int i = 0; i < per; i++) {
 		const int j = t * per + i;
 		if (j >= njobs) break;
-		const uint32_t n = dx_nchunks(jobs[j].bytes);
 		jobs[j].chunk0 = at;
-		const DxBandJob job = jobs[j];
-		for (uint32_t c = 0; c < n; c++) chunk_desc[at + c] = DxChunkDesc{ job.bits, job.bytes, c };
-		at += n;
+		at += dx_nchunks(jobs[j].bytes);
 	}
+}
+// chunk_desc[c] = payload and number of chunk c: one wave per band writes its band's descriptors.
+__global__ void __launch_bounds__(DX_THREADS) k_dec_plan_fill(const DxBandJob *jobs, int njobs, DxChunkDesc *chunk_desc, const uint32_t *counters)
+{
+	const int j = (int)blockIdx.x * DX_WAVES + wave_uniform((int)(threadIdx.x >> 6));
+	if (j >= njobs || counters[0] == 0u) return;
+	const DxBandJob job = jobs[j];
+	const uint32_t n = dx_nchunks(job.bytes);
+	for (uint32_t c = (uint32_t)wave_lane(); c < n; c += 64) chunk_desc[job.chunk0 + c] = DxChunkDesc{ job.bits, job.bytes, c };
 }
 
 __global__ void __launch_bounds__(DX_THREADS) k_dec_index(const DxChunkDesc *chunk_desc, const uint32_t *counters, const DecIdxTables *T,
@@ -522,6 +531,39 @@ __global__ void __launch_bounds__(DX_THREADS) k_dec_tile_index(const DxBandJob *
 	tile_start[t] = q0;
 }
 
+// What a wave of k_dec_tiles needs to know about a tile, and the first 64 pieces of payload that may reach into it: both are fetched
+// one tile ahead, so that the loads are in flight while the previous tile is decoded.
+struct DxTileMeta { int j; uint32_t ti, first_sub; DxBandJob job; DxBandSum sum; };
+struct DxPieces { uint32_t ent, cb, d[4]; };
+__device__ __forceinline__ void dx_tile_meta(const DxTilePlan &plan, uint32_t t, int &slot, const DxBandJob *jobs, const DxBandSum *sums, const uint32_t *tile_start, DxTileMeta &M)
+{
+	while (slot + 1 < plan.nslots && t >= plan.cum[slot + 1]) slot++;       // tiles come in increasing order: the slot only moves forward
+	const uint32_t r = t - plan.cum[slot], per = plan.per_band[slot];
+	const uint32_t f = r / per;
+	M.ti = r - f * per; M.j = slot * plan.nframes + (int)f;
+	M.first_sub = tile_start[t];
+	M.job = jobs[M.j];
+	M.sum = sums[M.j];
+}
+__device__ __forceinline__ void dx_tile_pieces(const DxTileMeta &M, uint32_t q, uint32_t last_sub, const uint32_t *entries, const uint32_t *chunk_base, DxPieces &P)
+{
+	P.ent = DX_OFF_INVALID; P.cb = 0;
+#pragma unroll
+	for (int i = 0; i < 4; i++) P.d[i] = 0u;
+	if (q < last_sub) {
+		// entry, chunk position and the next 128 bits of the payload from the piece on (the walk needs at most 64 + 26 + 27 of them): independent loads
+		const uint32_t kq = q / DX_CHUNK_SUBS, within = q - kq * DX_CHUNK_SUBS;
+		P.ent = entries[((size_t)M.job.chunk0 + kq) * DX_ENTRY_STRIDE + DX_SUBS + within];
+		P.cb = chunk_base[(size_t)M.job.chunk0 + kq];
+		const uint32_t byte0 = q * (DX_SUB_BITS / 8);
+		const uint32_t *src = (const uint32_t *)(M.job.bits + byte0);
+#pragma unroll
+		for (int i = 0; i < 4; i++) P.d[i] = byte0 + 4u * (uint32_t)i + 4u <= M.job.bytes ? src[i] : 0u;
+	}
+}
+__device__ __forceinline__ bool dx_tile_has_work(const DxTileMeta &M) { return M.job.bytes != 0u && M.ti * DX_TILE < (uint32_t)M.job.n && M.first_sub != DX_TILE_EMPTY; }
+__device__ __forceinline__ uint32_t dx_tile_last_sub(const DxTileMeta &M) { return ((uint32_t)M.sum.last_chunk + 1u) * DX_CHUNK_SUBS; }
+
 __global__ void __launch_bounds__(DX_THREADS) k_dec_tiles(const DxBandJob *jobs, DxTilePlan plan, const DecIdxTables *T, const uint32_t *entries, const uint32_t *chunk_base,
                                                           const DxBandSum *sums, const uint32_t *tile_start)
 {
@@ -536,73 +578,77 @@ __global__ void __launch_bounds__(DX_THREADS) k_dec_tiles(const DxBandJob *jobs,
 	for (int i = lane; i < DX_TILE / 2; i += 64) s_tile[i] = 0u;
 	__syncthreads();
 	const uint32_t gwave = (uint32_t)blockIdx.x * DX_WAVES + (uint32_t)wave, nwaves = (uint32_t)gridDim.x * DX_WAVES;
-	for (uint32_t t = gwave; t < plan.total; t += nwaves) {
-		int j; uint32_t ti;
-		dx_tile_of(plan, t, &j, &ti);
-		const uint32_t first_sub = tile_start[t];            // independent of the two loads below: one round trip for the three
-		const DxBandJob job = jobs[j];
-		const DxBandSum sum = sums[j];
-		const uint32_t T0 = ti * DX_TILE, T1 = T0 + DX_TILE < (uint32_t)job.n ? T0 + DX_TILE : (uint32_t)job.n;
-		if (job.bytes == 0u || T0 >= (uint32_t)job.n) continue;               // wave-uniform
-		if (first_sub != DX_TILE_EMPTY) {
-			// piece by piece, one per lane, until the pieces start behind the tile
-			const uint32_t last_sub = ((uint32_t)sum.last_chunk + 1u) * DX_CHUNK_SUBS;
-			for (uint32_t q0 = first_sub; q0 < last_sub; q0 += 64) {
-				const uint32_t q = q0 + (uint32_t)lane;
-				const bool active = q < last_sub;
-				uint32_t ent = DX_OFF_INVALID, cb = 0, d[4] = { 0u, 0u, 0u, 0u };
-				if (active) {
-					// entry, chunk position and the next 128 bits of the payload from the piece on (the walk needs at most 64 + 26 + 27 of them): three independent loads
-					const uint32_t kq = q / DX_CHUNK_SUBS, within = q - kq * DX_CHUNK_SUBS;
-					ent = entries[((size_t)job.chunk0 + kq) * DX_ENTRY_STRIDE + DX_SUBS + within];
-					cb = chunk_base[(size_t)job.chunk0 + kq];
-					const uint32_t byte0 = q * (DX_SUB_BITS / 8);
-					const uint32_t *src = (const uint32_t *)(job.bits + byte0);
-#pragma unroll
-					for (int i = 0; i < 4; i++) d[i] = byte0 + 4u * (uint32_t)i + 4u <= job.bytes ? src[i] : 0u;
-				}
-				const uint32_t off = ent & 31u;
-				uint32_t idx = cb + (ent >> 5);
-				const bool valid = active && off != (uint32_t)DX_OFF_INVALID;
-				const bool inside = valid && idx < T1;
-				if (inside) {
-					uint64_t acc = (((uint64_t)bswap32(d[0]) << 32) | bswap32(d[1])) << off;
-					int have = 64 - (int)off;
-					uint32_t nextw = bswap32(d[2]), afterw = bswap32(d[3]);
-					uint32_t pos = off;
-					const int quant = job.quant;
-					while (pos < (uint32_t)DX_SUB_BITS && idx < T1) {
-						if (have < 32) { acc |= (uint64_t)nextw << (32 - have); have += 32; nextw = afterw; afterw = 0u; }
-						const uint32_t win = (uint32_t)(acc >> 32);
-						// the two shortest code words without a table: '0' = one zero coefficient (a stretch of them at once), '10' + sign = +-1
-						const int z = win ? __builtin_clz(win) : 32;
-						if (z) {
-							int n = (int)DX_SUB_BITS - (int)pos;          // only code words that start inside this piece
-							if (z < n) n = z;
-							idx += (uint32_t)n; acc <<= n; have -= n; pos += (uint32_t)n;
-							continue;
-						}
-						int len, v;
-						if (!(win & 0x40000000u)) { len = 2; v = (int)s_mag[1] * quant; }
-						else {
-							const DxSym s = dx_symbol(s_sym, s_long, win);
-							if (s.type == DX_T_RUN) { idx += (uint32_t)s.payload; acc <<= s.len; have -= s.len; pos += (uint32_t)s.len; continue; }
-							if (s.type != DX_T_VALUE) break;                 // band end marker (or a broken code, reported by k_dec_chain)
-							len = s.len; v = (int)s_mag[s.payload] * quant;
-						}
-						const int negative = (int)((acc << len) >> 63);
-						if (idx >= T0) ((int16_t *)s_tile)[idx - T0] = (int16_t)(negative ? -v : v);
-						idx++;
-						acc <<= len + 1; have -= len + 1; pos += (uint32_t)len + 1u;
-					}
-				}
-				// pieces are in raster order: once a valid one starts behind the tile, all later ones do
-				if (__ballot(valid && !inside) || !__ballot(active)) break;
-			}
-		}
-		CFHD_WAVE_SYNC();
-		// the tile goes out in 16-byte words and is cleared for the next one
+	uint32_t t = gwave;
+	if (t >= plan.total) return;
+	// software pipeline: tile t is decoded while the descriptors of tile t + 2 nwaves and the payload pieces of tile t + nwaves are on their way
+	int slot = 0;
+	DxTileMeta M, M1;
+	dx_tile_meta(plan, t, slot, jobs, sums, tile_start, M);
+	M1 = M;
+	if (t + nwaves < plan.total) dx_tile_meta(plan, t + nwaves, slot, jobs, sums, tile_start, M1);
+	DxPieces P;
+	dx_tile_pieces(M, dx_tile_has_work(M) ? M.first_sub + (uint32_t)lane : 0xFFFFFFFFu, dx_tile_has_work(M) ? dx_tile_last_sub(M) : 0u, entries, chunk_base, P);
+#pragma unroll 1
+	for (; t < plan.total; t += nwaves) {
+		DxTileMeta M2 = M1;
+		DxPieces P1;
+		if (t + 2 * nwaves < plan.total) dx_tile_meta(plan, t + 2 * nwaves, slot, jobs, sums, tile_start, M2);
 		{
+			const bool w1 = t + nwaves < plan.total && dx_tile_has_work(M1);
+			dx_tile_pieces(M1, w1 ? M1.first_sub + (uint32_t)lane : 0xFFFFFFFFu, w1 ? dx_tile_last_sub(M1) : 0u, entries, chunk_base, P1);
+		}
+		const DxBandJob &job = M.job;
+		const uint32_t T0 = M.ti * DX_TILE, T1 = T0 + DX_TILE < (uint32_t)job.n ? T0 + DX_TILE : (uint32_t)job.n;
+		if (job.bytes != 0u && T0 < (uint32_t)job.n) {                         // wave-uniform
+			if (M.first_sub != DX_TILE_EMPTY) {
+				// piece by piece, one per lane, until the pieces start behind the tile
+				const uint32_t last_sub = dx_tile_last_sub(M);
+				const int quant = job.quant;
+#pragma unroll 1
+				for (uint32_t q0 = M.first_sub; q0 < last_sub; q0 += 64) {
+					const uint32_t q = q0 + (uint32_t)lane;
+					const bool active = q < last_sub;
+					if (q0 != M.first_sub) dx_tile_pieces(M, q, last_sub, entries, chunk_base, P);     // a second round is rare (a dense tile)
+					const uint32_t off = P.ent & 31u;
+					uint32_t idx = P.cb + (P.ent >> 5);
+					const bool valid = active && off != (uint32_t)DX_OFF_INVALID;
+					const bool inside = valid && idx < T1;
+					if (inside) {
+						uint64_t acc = (((uint64_t)bswap32(P.d[0]) << 32) | bswap32(P.d[1])) << off;
+						int have = 64 - (int)off;
+						uint32_t nextw = bswap32(P.d[2]), afterw = bswap32(P.d[3]);
+						uint32_t pos = off;
+						while (pos < (uint32_t)DX_SUB_BITS && idx < T1) {
+							if (have < 32) { acc |= (uint64_t)nextw << (32 - have); have += 32; nextw = afterw; afterw = 0u; }
+							const uint32_t win = (uint32_t)(acc >> 32);
+							// the two shortest code words without a table: '0' = one zero coefficient (a stretch of them at once), '10' + sign = +-1
+							const int z = win ? __builtin_clz(win) : 32;
+							if (z) {
+								int n = (int)DX_SUB_BITS - (int)pos;          // only code words that start inside this piece
+								if (z < n) n = z;
+								idx += (uint32_t)n; acc <<= n; have -= n; pos += (uint32_t)n;
+								continue;
+							}
+							int len, v;
+							if (!(win & 0x40000000u)) { len = 2; v = (int)s_mag[1] * quant; }
+							else {
+								const DxSym s = dx_symbol(s_sym, s_long, win);
+								if (s.type == DX_T_RUN) { idx += (uint32_t)s.payload; acc <<= s.len; have -= s.len; pos += (uint32_t)s.len; continue; }
+								if (s.type != DX_T_VALUE) break;                 // band end marker (or a broken code, reported by k_dec_chain)
+								len = s.len; v = (int)s_mag[s.payload] * quant;
+							}
+							const int negative = (int)((acc << len) >> 63);
+							if (idx >= T0) ((int16_t *)s_tile)[idx - T0] = (int16_t)(negative ? -v : v);
+							idx++;
+							acc <<= len + 1; have -= len + 1; pos += (uint32_t)len + 1u;
+						}
+					}
+					// pieces are in raster order: once a valid one starts behind the tile, all later ones do
+					if (__ballot(valid && !inside) || !__ballot(active)) break;
+				}
+			}
+			CFHD_WAVE_SYNC();
+			// the tile goes out in 16-byte words and is cleared for the next one
 			uint4 *dst = (uint4 *)(job.dst + T0);
 			const uint32_t n16 = (T1 - T0) / 8;
 			const uint4 zero = { 0u, 0u, 0u, 0u };
@@ -611,8 +657,9 @@ __global__ void __launch_bounds__(DX_THREADS) k_dec_tiles(const DxBandJob *jobs,
 				((uint4 *)s_tile)[i] = zero;
 				if (i < n16) dst[i] = v;
 			}
+			CFHD_WAVE_SYNC();
 		}
-		CFHD_WAVE_SYNC();
+		M = M1; M1 = M2; P = P1;
 	}
 }
 

@@ -386,7 +386,10 @@ int GpuEntropyDecoder::launch_dx(bool device_jobs, int njobs, uint32_t host_chun
 	const char *spec_env = getenv("CFHD_AMD_DX_SPECULATE");
 	const bool speculate = !(spec_env && atoi(spec_env) == 0);            // 0: every chunk goes through the repair path (tests)
 	if (device_jobs) HIPCHK(hipMemsetAsync((uint32_t *)d_counters_ + 1, 0, 4, st));      // the repair list starts empty (the host path uploads zeroed counters)
-	if (device_jobs) dev::k_dec_plan<<<1, 1024, 0, st>>>(jobs, njobs, (dev::DxChunkDesc *)d_chunk_job_, max_chunks_, (uint32_t *)d_counters_, d_errors_);
+	if (device_jobs) {
+		dev::k_dec_plan<<<1, 1024, 0, st>>>(jobs, njobs, max_chunks_, (uint32_t *)d_counters_, d_errors_);
+		dev::k_dec_plan_fill<<<(njobs + dev::DX_WAVES - 1) / dev::DX_WAVES, dev::DX_THREADS, 0, st>>>(jobs, njobs, (dev::DxChunkDesc *)d_chunk_job_, (const uint32_t *)d_counters_);
+	}
 	// grid-stride kernels: as many workgroups as the chip holds at once, fewer when there is less work
 	const uint32_t chunk_bound = device_jobs ? max_chunks_ : host_chunks;
 	int g1 = grid_index_, g3 = grid_tiles_;

@@ -330,7 +330,8 @@ extern "C" int emu_entropy_decode_dx(const uint8_t *sample, size_t size, int pix
 		const uint32_t sizes[2] = { (uint32_t)size, (uint32_t)size };
 		hipemu::launch(dim3(2), dim3(dev::DEC_PARSE_THREADS), [&] { dev::k_dec_parse(two, stride, sizes, 2, &dp, pyr.data(), plan.coeff_elems, jobs.data(), lows.data(), &errors); });
 		if (errors) return -20 - errors;
-		hipemu::launch(dim3(1), dim3(1024), [&] { dev::k_dec_plan(jobs.data(), njobs, chunk_job.data(), max_chunks, counters.data(), &errors); });
+		hipemu::launch(dim3(1), dim3(1024), [&] { dev::k_dec_plan(jobs.data(), njobs, max_chunks, counters.data(), &errors); });
+		hipemu::launch(dim3((unsigned)(njobs + dev::DX_WAVES - 1) / dev::DX_WAVES), dim3(dev::DX_THREADS), [&] { dev::k_dec_plan_fill(jobs.data(), njobs, chunk_job.data(), counters.data()); });
 		if (errors) return -40 - errors;
 	} else {
 		if (!dx_build_jobs(ps, plan, dp, two, pyr.data(), pixel_kind, 0, 1, jobs.data(), lows.data())) return -4;
