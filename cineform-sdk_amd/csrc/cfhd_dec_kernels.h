@@ -43,11 +43,13 @@ enum {
 	DX_L2_BITS = 7,
 	DX_TILE = 2048,                   // coefficients per output tile
 	DX_THREADS = 256, DX_WAVES = DX_THREADS / 64,
+	DX_TILE_THREADS = 512, DX_TILE_WAVES = DX_TILE_THREADS / 64,      // k_dec_tiles: eight waves share the tables
+	DX_KM = 11,                       // bits of the window of the multi-symbol table of k_dec_tiles
 	DX_MEMO = 6,                      // outcomes a lane of k_dec_index remembers (start -> end, count)
 	DX_OFF_INVALID = 31,              // entry: no code word of the true sequence starts in this piece (behind the band end marker / the payload)
 };
 enum : uint32_t { DX_END = 0xFFFFFFFFu, DX_BAD = 0xFFFFFFFEu, DX_SPECIAL = 0xFFFFFFFEu };
-enum { DX_FLAG_END = 1, DX_FLAG_BAD = 2, DX_ERR_BAD = 1 << 1, DX_ERR_OVERFLOW = 1 << 2, DX_ERR_NOEND = 1 << 3, DX_ERR_SPACE = 1 << 4 };
+enum { DX_FLAG_END = 1, DX_FLAG_BAD = 2, DX_FLAG_UNRESOLVED = 4, DX_ERR_BAD = 1 << 1, DX_ERR_OVERFLOW = 1 << 2, DX_ERR_NOEND = 1 << 3, DX_ERR_SPACE = 1 << 4 };
 // type field of a long-table entry
 enum { DX_T_INVALID = 0, DX_T_RUN = 1, DX_T_VALUE = 2, DX_T_END = 3, DX_T_ESCAPE = 4 };
 
@@ -58,13 +60,23 @@ struct DecIdxTables {
 	uint16_t mag_expand[256];         // magnitude after undoing the companding curve, by index
 	uint32_t long_tab[DX_LONG_MAX];   // bits 0-4 length (escape: index bits of the next level), bits 5-7 type, bits 8-31 run / magnitude index / base of the next level
 	uint32_t nlong;
+	// k_dec_tiles: everything that fits completely (sign bits included) into the next 11 bits, up to two values with the zero runs around
+	// them: x = bits 0-3 bits used (0: nothing fits -> one code word at a time), bits 4-15 zeros in front of v1, bits 16-31 v1 (signed; 0: none);
+	// y = bits 0-7 zeros between v1 and v2, bits 8-15 zeros behind the last value, bits 16-31 v2.  Values this short are below the knee of the
+	// companding curve (magnitude = index), so the table serves both code sets.
+	uint2 multi[1 << DX_KM];
 };
 
 // One coded band of one frame = DecBandJob (cfhd_entropy_kernels.h); the job table is [band slot][frame], a band that is not wanted -- half
 // resolution skips level 1 -- has bytes 0.  chunk0 = first chunk of the band in the chunk arrays (k_dec_plan / host).
 typedef DecBandJob DxBandJob;
 struct DxChunkDesc { const uint8_t *bits; uint32_t bytes, k; };   // chunk c of the launch: payload of its band, chunk number inside the band (k_dec_plan / host)
-struct DxChunkRec { uint32_t start, end, count, flags; };   // start / end: bit offset of the first code word relative to the chunk's / the next chunk's first bit
+struct DxChunkRec { uint32_t start, end, count, flags; };   // start / end: bit offset of the first code word relative to the chunk's / the next chunk's first bit; flags: DX_FLAG_* | candidates << 8
+// A chunk in front of which the code has no unique alignment (its run-in from every possible offset leaves several candidates for its first
+// code word) is indexed once per candidate: the record holds candidate 0 (the entries are written for it), this the others.
+enum { DX_MAX_ALT = 3 };
+struct DxChunkAlt { uint32_t start[DX_MAX_ALT], end[DX_MAX_ALT], count[DX_MAX_ALT]; };
+struct DxReindex { uint32_t chunk, k, start; int job; };      // a chunk whose entries have to be written again for the start that turned out to be the true one
 struct DxBandSum { uint32_t total; int last_chunk; };        // coefficients the band's code words cover; chunk that holds the band end marker
 
 struct DxSym { int len, type, payload; };                    // len without the sign bit
@@ -194,10 +206,51 @@ __device__ __forceinline__ void dx_store_stage(const DxFetch &F, uint32_t *s_wor
 	CFHD_WAVE_SYNC();
 }
 
-// Index of one staged chunk by one wave.  exact_start: DX_BAD = the run-in lane finds it (speculation, checked by k_dec_chain); else the bit
-// offset (relative to the chunk's first bit) at which the chunk's first code word starts.  s_words: DX_STAGE_PHYS words of this wave.
-__device__ __forceinline__ void dx_index_staged(const uint32_t bytes, const uint32_t gchunk, const uint32_t k, const uint32_t exact_start, const uint32_t *s_words, const uint16_t *s_cnt, const uint16_t *s_sym,
-                                                const uint32_t *s_long, uint32_t *entries, DxChunkRec *recs, uint32_t *stats = nullptr)
+// Where the code words that pass through the 256 bits in front of a chunk can enter the chunk: lanes 0..26 walk that range from every
+// offset a first code word can have; the distinct outcomes (bit offsets into the chunk) are the candidates for the chunk's first code word.
+// Ordinary data leaves one; returns their number (at most DX_MAX_ALT + 2: more than DX_MAX_ALT + 1 means "too many"), 0 when every walk
+// ended on the band end marker or a broken code (the chunk holds padding).
+__device__ __forceinline__ int dx_runin_candidates(const uint32_t bytes, const uint32_t k, const uint32_t *s_words, const uint16_t *s_cnt, const uint16_t *s_sym, const uint32_t *s_long,
+                                                   uint32_t (&cand)[DX_MAX_ALT + 2])
+{
+	const int lane = wave_lane();
+	const uint32_t nwords = bytes >> 2;
+	const int64_t first = (int64_t)k * DX_CHUNK_WORDS - (DX_LANE_BITS / 32);
+	const int64_t left = (int64_t)nwords - first;
+	const uint32_t limit = left <= 0 ? 0u : (left * 32 > (int64_t)(64 * DX_LANE_BITS + 64) ? (uint32_t)(64 * DX_LANE_BITS + 64) : (uint32_t)(left * 32));
+	uint32_t pos = (uint32_t)lane, end = DX_BAD;
+	if (lane < 27) {
+		DxBits B;
+		B.seek(s_words, pos);
+		for (;;) {
+			if (pos >= (uint32_t)DX_LANE_BITS) { end = pos; break; }
+			if (pos >= limit) break;
+			const uint32_t win = B.window();
+			const uint32_t m = s_cnt[win >> (32 - DX_K)];
+			const uint32_t used = m & 15u;
+			if (used && pos + used <= (uint32_t)DX_LANE_BITS) { pos += used; B.skip(s_words, (int)used); continue; }
+			const DxSym sy = dx_symbol(s_sym, s_long, win);
+			if (sy.type == DX_T_RUN) { pos += (uint32_t)sy.len; B.skip(s_words, sy.len); }
+			else if (sy.type == DX_T_VALUE) { pos += (uint32_t)sy.len + 1u; B.skip(s_words, sy.len + 1); }
+			else break;
+		}
+	}
+	unsigned long long mask = __ballot(lane < 27 && end < DX_SPECIAL);
+	int n = 0;
+#pragma unroll 1
+	while (mask && n < DX_MAX_ALT + 2) {
+		const int l = __builtin_ctzll(mask);
+		const uint32_t v = wave_get(end, l);
+		cand[n++] = v - DX_LANE_BITS;
+		mask &= ~__ballot(end == v);
+	}
+	return n;
+}
+
+// Index of one staged chunk by one wave from the bit offset (relative to the chunk's first bit) at which its first code word starts; the
+// per-piece entries are written when `entries` is given.  Returns the chunk's record (start, end, count, flags) in every lane.
+__device__ __forceinline__ DxChunkRec dx_index_staged(const uint32_t bytes, const uint32_t gchunk, const uint32_t k, const uint32_t exact_start, const uint32_t *s_words, const uint16_t *s_cnt,
+                                                      const uint16_t *s_sym, const uint32_t *s_long, uint32_t *entries, uint32_t *stats = nullptr)
 {
 	const int lane = wave_lane();
 	const uint32_t nwords = bytes >> 2;
@@ -205,7 +258,7 @@ __device__ __forceinline__ void dx_index_staged(const uint32_t bytes, const uint
 	const int64_t left = (int64_t)nwords - first;           // payload words from the start of the staging area on
 	const uint32_t limit = left <= 0 ? 0u : (left * 32 > (int64_t)(64 * DX_LANE_BITS + 64) ? (uint32_t)(64 * DX_LANE_BITS + 64) : (uint32_t)(left * 32));   // staging bit position behind the payload
 	const uint32_t lane_base = (uint32_t)lane * DX_LANE_BITS;
-	const bool runin = exact_start == DX_BAD && k > 0;
+	const bool runin = false;
 	// lanes whose range lies behind the payload take no part: the last lane with payload bits carries the end of the chain
 	const bool live = lane_base < limit && lane >= 1;
 	const int last_live = limit == 0u ? 0 : (int)((limit - 1u) / DX_LANE_BITS) < 63 ? (int)((limit - 1u) / DX_LANE_BITS) : 63;
@@ -213,7 +266,7 @@ __device__ __forceinline__ void dx_index_staged(const uint32_t bytes, const uint
 	L.start = DX_BAD; L.end = lane_base; L.cnt = 0; L.rec_offs = DX_OFFS_NONE;
 #pragma unroll
 	for (int j = 0; j < DX_SUBS; j++) L.rec_cnt[j] = 0;
-	if (lane == 0 && !runin) { L.start = 0u; L.end = DX_LANE_BITS + (exact_start == DX_BAD ? 0u : exact_start); }   // the chunk's first code word, exactly (a band's first chunk starts on its first bit)
+	if (lane == 0) { L.start = 0u; L.end = exact_start >= DX_SPECIAL ? exact_start : DX_LANE_BITS + exact_start; }   // the chunk's first code word
 	// Every lane first walks from a guessed start (its own boundary), then takes over where its left neighbour ended, until nothing moves any
 	// more.  Ordinary data falls in step within a few code words, so one round settles almost every lane (the repeated walk stops at the
 	// first 64-bit mark where it meets the old one).  A stretch of identical code words (a smooth gradient: the same value in every
@@ -279,7 +332,7 @@ __device__ __forceinline__ void dx_index_staged(const uint32_t bytes, const uint
 	const uint32_t incl = wave_incl_scan(own);
 	const uint32_t before = incl - own;
 	const size_t slot = (size_t)gchunk * DX_ENTRY_STRIDE + (size_t)lane * DX_SUBS;
-	if (lane >= 1) {
+	if (lane >= 1 && entries) {
 		uint4 e;
 		uint32_t v[DX_SUBS];
 #pragma unroll
@@ -287,27 +340,27 @@ __device__ __forceinline__ void dx_index_staged(const uint32_t bytes, const uint
 		e.x = v[0]; e.y = v[1]; e.z = v[2]; e.w = v[3];
 		*(uint4 *)(entries + slot) = e;
 	}
-	const uint32_t total = wave_get(incl, 63), e0 = wave_get(L.end, 0), el = wave_get(L.end, last_live);
-	if (lane == 0) {
-		DxChunkRec r;
-		r.start = e0 >= DX_SPECIAL ? e0 : e0 - DX_LANE_BITS;
-		// a chain that stops in front of the chunk's end without the band end marker ran off the payload
-		r.end = el >= DX_SPECIAL ? el : ((last_live < 63 || el < 64u * DX_LANE_BITS) ? (uint32_t)DX_BAD : el - 64u * DX_LANE_BITS);
-		r.count = total;
-		r.flags = (r.end == DX_END ? DX_FLAG_END : 0u) | (r.end == DX_BAD ? DX_FLAG_BAD : 0u);
-		recs[gchunk] = r;
-	}
+	const uint32_t total = wave_get(incl, 63), el = wave_get(L.end, last_live);
+	DxChunkRec r;
+	r.start = exact_start;
+	// a chain that stops in front of the chunk's end without the band end marker ran off the payload
+	r.end = el >= DX_SPECIAL ? el : ((last_live < 63 || el < 64u * DX_LANE_BITS) ? (uint32_t)DX_BAD : el - 64u * DX_LANE_BITS);
+	r.count = total;
+	r.flags = (r.end == DX_END ? DX_FLAG_END : 0u) | (r.end == DX_BAD ? DX_FLAG_BAD : 0u);
 	CFHD_WAVE_SYNC();
+	return r;
 }
 
-// Stage + index, not pipelined: the repair path of k_dec_chain (rare; kept out of line so that it does not weigh on the common path's registers).
-__device__ __attribute__((noinline)) void dx_index_chunk(const uint8_t *bits, const uint32_t bytes, const uint32_t gchunk, const uint32_t k, const uint32_t exact_start, uint32_t *s_words,
-                                                         const uint16_t *s_cnt, const uint16_t *s_sym, const uint32_t *s_long, uint32_t *entries, DxChunkRec *recs, uint32_t *stats)
+// Stage + index from an exact start, not pipelined: the repair and re-index paths (rare; out of line so that it does not weigh on the callers' registers).
+__device__ __attribute__((noinline)) DxChunkRec dx_index_chunk(const uint8_t *bits, const uint32_t bytes, const uint32_t gchunk, const uint32_t k, const uint32_t exact_start, uint32_t *s_words,
+                                                               const uint16_t *s_cnt, const uint16_t *s_sym, const uint32_t *s_long, uint32_t *entries, DxChunkRec *recs, uint32_t *stats)
 {
 	DxFetch F;
 	dx_fetch_chunk(bits, bytes, k, F);
 	dx_store_stage(F, s_words);
-	dx_index_staged(bytes, gchunk, k, exact_start, s_words, s_cnt, s_sym, s_long, entries, recs, stats);
+	const DxChunkRec r = dx_index_staged(bytes, gchunk, k, exact_start, s_words, s_cnt, s_sym, s_long, entries, stats);
+	if (wave_lane() == 0 && recs) recs[gchunk] = r;
+	return r;                                             // the same in every lane
 }
 
 __device__ __forceinline__ void dx_load_tables(const DecIdxTables *T, uint16_t *s_cnt, uint16_t *s_sym, uint32_t *s_long, bool want_cnt)
@@ -355,7 +408,7 @@ __global__ void __launch_bounds__(DX_THREADS) k_dec_plan_fill(const DxBandJob *j
 }
 
 __global__ void __launch_bounds__(DX_THREADS) k_dec_index(const DxChunkDesc *chunk_desc, const uint32_t *counters, const DecIdxTables *T,
-                                                          uint32_t *entries, DxChunkRec *recs, int speculate, uint32_t *stats)
+                                                          uint32_t *entries, DxChunkRec *recs, DxChunkAlt *alts, int speculate, uint32_t *stats)
 {
 	__shared__ uint16_t s_cnt[1 << DX_K], s_sym[1 << DX_K];
 	__shared__ uint32_t s_long[DX_LONG_MAX];
@@ -379,8 +432,34 @@ __global__ void __launch_bounds__(DX_THREADS) k_dec_index(const DxChunkDesc *chu
 		const uint32_t c1 = c + nwaves;
 		DxChunkDesc d1 = d;
 		if (c1 < total) { d1 = chunk_desc[c1]; dx_fetch_chunk(d1.bits, d1.bytes, d1.k, F); }
-		// speculate == 0 (tests): every chunk assumes that a code word starts on its first bit, which is wrong for most of them -- k_dec_chain has to repair them
-		dx_index_staged(d.bytes, c, d.k, (d.k == 0 || !speculate) ? 0u : (uint32_t)DX_BAD, s_words, s_cnt, s_sym, s_long, entries, recs, stats);
+		// A band's first chunk starts on its first bit; every other chunk finds the candidates for its first code word by running in through
+		// the 256 bits in front of it from every possible offset.  speculate == 0 (tests): assume offset 0 instead, which is wrong for most
+		// chunks -- k_dec_chain has to repair them.
+		uint32_t cand[DX_MAX_ALT + 2] = { 0u, 0u, 0u, 0u, 0u };
+		int n = 1;
+		if (d.k != 0 && speculate) n = dx_runin_candidates(d.bytes, d.k, s_words, s_cnt, s_sym, s_long, cand);
+		if (n == 0) {                                        // behind the band end marker: padding
+			if (wave_lane() == 0) recs[c] = DxChunkRec{ (uint32_t)DX_END, (uint32_t)DX_END, 0u, (uint32_t)DX_FLAG_END | (1u << 8) };
+		} else {
+			const bool unresolved = n > DX_MAX_ALT + 1;
+			if (unresolved) n = 1;
+			DxChunkRec r = dx_index_staged(d.bytes, c, d.k, cand[0], s_words, s_cnt, s_sym, s_long, entries, stats);
+			r.flags |= ((uint32_t)n << 8) | (unresolved ? (uint32_t)DX_FLAG_UNRESOLVED : 0u);
+			if (wave_lane() == 0) recs[c] = r;
+			if (n > 1) {
+				DxChunkAlt a;
+#pragma unroll
+				for (int i = 0; i < DX_MAX_ALT; i++) { a.start[i] = DX_BAD; a.end[i] = DX_BAD; a.count[i] = 0; }
+#pragma unroll 1
+				for (int i = 1; i < n; i++) {
+					const DxChunkRec ri = dx_index_staged(d.bytes, c, d.k, cand[i], s_words, s_cnt, s_sym, s_long, nullptr, nullptr);
+#pragma unroll
+					for (int q = 0; q < DX_MAX_ALT; q++) if (q == i - 1) { a.start[q] = ri.start; a.end[q] = ri.end; a.count[q] = ri.count; }
+				}
+				if (wave_lane() == 0) alts[c] = a;
+				if (stats && wave_lane() == 0) atomicAdd(&stats[3], 1u << 16);       // chunks with more than one candidate (upper half of the repair counter)
+			}
+		}
 		d = d1;
 	}
 }
@@ -395,12 +474,14 @@ __device__ __forceinline__ void dx_load_tables_wave(const DecIdxTables *T, uint1
 	for (int i = lane; i < DX_LONG_MAX; i += 64) s_long[i] = T->long_tab[i];
 }
 
-// One band's chain of chunks, by one wave: every chunk must start where its predecessor ended; chunk_base[c] = raster position of chunk c's
-// first code word.  REPAIR: a chunk that started elsewhere -- its run-in lane never fell in step: data without a unique alignment -- is
-// indexed again from the exact position; otherwise the band is only reported (false) and left to k_dec_repair.
+// One band's chain of chunks, by one wave: every chunk starts where its predecessor ended; chunk_base[c] = raster position of chunk c's first
+// code word.  A chunk indexed for several candidate starts contributes the outcome of the one that is true (and goes on the re-index list when
+// that is not the one its entries were written for).  A chunk none of whose candidates is true -- more candidates than k_dec_index keeps -- is
+// indexed again on the spot when REPAIR is set; otherwise the band is only reported (false) and left to k_dec_repair.
 template <bool REPAIR>
 __device__ __forceinline__ bool dx_chain_band(const DxBandJob &job, const int j, const DecIdxTables *T, uint16_t *s_cnt, uint16_t *s_sym, uint32_t *s_long, uint32_t *s_words,
-                                              uint32_t *entries, DxChunkRec *recs, uint32_t *chunk_base, DxBandSum *sums, int *errors, uint32_t *stats)
+                                              uint32_t *entries, DxChunkRec *recs, const DxChunkAlt *alts, uint32_t *chunk_base, DxBandSum *sums, int *errors,
+                                              DxReindex *reindex_list, uint32_t *counters, uint32_t *stats)
 {
 	const int lane = wave_lane();
 	const uint32_t nch = dx_nchunks(job.bytes);
@@ -412,44 +493,59 @@ __device__ __forceinline__ bool dx_chain_band(const DxBandJob &job, const int j,
 	for (uint32_t c0 = 0; c0 < nch && last < 0 && !err; c0 += 64) {
 		const uint32_t c = c0 + (uint32_t)lane;
 		const bool have = c < nch;
+		const int nblock = nch - c0 < 64u ? (int)(nch - c0) : 64;
 		DxChunkRec r = { 0u, 0u, 0u, 0u };
 		if (have) r = recs[(size_t)job.chunk0 + c];
-		// a chunk is good when it started where its predecessor ended
+		uint32_t my_end = r.end, my_cnt = r.count;
+		int nvalid = nblock;
+		bool stop = false;
+		// the common case: every chunk's first candidate starts where the predecessor's ended, up to the chunk that holds the end of the band
 		uint32_t pe = __shfl_up(r.end, 1u);
 		if (lane == 0) pe = prev_end;
 		unsigned long long bad = __ballot(have && r.start != pe);
-		// the band ends in the first chunk that met the end marker (or a broken code); chunks behind it hold padding and may start anywhere
-		{
-			const unsigned long long stop0 = __ballot(have && (r.flags & (DX_FLAG_END | DX_FLAG_BAD)));
-			if (stop0) bad &= (2ull << __builtin_ctzll(stop0)) - 1ull;
-		}
-		if (bad && !REPAIR) return false;
+		const unsigned long long stop0 = __ballot(have && (r.end >= DX_SPECIAL));
+		if (stop0) bad &= (2ull << __builtin_ctzll(stop0)) - 1ull;
+		if (!bad) {
+			if (stop0) { nvalid = __builtin_ctzll(stop0) + 1; stop = true; }
+		} else {
+			// chunk by chunk: which candidate is the true one depends on where the predecessor ended
+			uint32_t cur = prev_end;
 #pragma unroll 1
-		while (REPAIR && bad) {                           // rare: index the first offending chunk again from the exact position, then look again
-			const int b = __builtin_ctzll(bad);
-			const uint32_t exact = b == 0 ? prev_end : __shfl(r.end, b - 1);
-			if (exact >= DX_SPECIAL) break;                 // the predecessor holds the end of the band (or a broken code): what follows is padding
-			if (!tables) { dx_load_tables_wave(T, s_cnt, s_sym, s_long); tables = true; CFHD_WAVE_SYNC(); }
-			if (stats && lane == 0) atomicAdd(&stats[3], 1u);
-			dx_index_chunk(job.bits, job.bytes, job.chunk0 + c0 + (uint32_t)b, c0 + (uint32_t)b, exact, s_words, s_cnt, s_sym, s_long, entries, recs, nullptr);
-			if (have) r = recs[(size_t)job.chunk0 + c];
-			pe = __shfl_up(r.end, 1u);
-			if (lane == 0) pe = prev_end;
-			bad = __ballot(have && r.start != pe) & ~((2ull << b) - 1ull);        // chunks up to b are settled now
-			const unsigned long long stop1 = __ballot(have && (r.flags & (DX_FLAG_END | DX_FLAG_BAD)));
-			if (stop1) bad &= (2ull << __builtin_ctzll(stop1)) - 1ull;
+			for (int i = 0; i < nblock; i++) {
+				if (cur >= DX_SPECIAL) { nvalid = i; stop = true; break; }
+				const uint32_t st = wave_get(r.start, i), fl = wave_get(r.flags, i);
+				uint32_t e = wave_get(r.end, i), cn = wave_get(r.count, i);
+				if (st != cur) {
+					bool found = false;
+					if (((fl >> 8) & 0xffu) > 1u) {
+						const DxChunkAlt a = alts[(size_t)job.chunk0 + c0 + (uint32_t)i];
+#pragma unroll
+						for (int q = 0; q < DX_MAX_ALT; q++) if (!found && a.start[q] == cur) { e = a.end[q]; cn = a.count[q]; found = true; }
+					}
+					if (found) {                                // the entries were written for another candidate: once more, later, in parallel with the others
+						if (lane == 0) reindex_list[atomicAdd(&counters[2], 1u)] = DxReindex{ job.chunk0 + c0 + (uint32_t)i, c0 + (uint32_t)i, cur, j };
+					} else {
+						if (!REPAIR) return false;
+						if (!tables) { dx_load_tables_wave(T, s_cnt, s_sym, s_long); tables = true; CFHD_WAVE_SYNC(); }
+						if (stats && lane == 0) atomicAdd(&stats[3], 1u);
+						const DxChunkRec rr = dx_index_chunk(job.bits, job.bytes, job.chunk0 + c0 + (uint32_t)i, c0 + (uint32_t)i, cur, s_words, s_cnt, s_sym, s_long, entries, recs, nullptr);
+						e = rr.end; cn = rr.count;
+					}
+				}
+				if (lane == i) { my_end = e; my_cnt = cn; }
+				cur = e;
+				if (e >= DX_SPECIAL) { nvalid = i + 1; stop = true; break; }
+			}
 		}
-		const unsigned long long stop = __ballot(have && (r.flags & (DX_FLAG_END | DX_FLAG_BAD)));
-		const int nvalid = stop ? __builtin_ctzll(stop) + 1 : (nch - c0 < 64u ? (int)(nch - c0) : 64);
-		const uint32_t cntv = lane < nvalid ? r.count : 0u;
+		const uint32_t cntv = lane < nvalid ? my_cnt : 0u;
 		const uint32_t incl = wave_incl_scan(cntv);
 		if (lane < nvalid) chunk_base[(size_t)job.chunk0 + c] = base + incl - cntv;
 		base += wave_get(incl, 63);
 		if (stop) {
 			last = (int)c0 + nvalid - 1;
-			if (wave_get(r.flags, nvalid - 1) & DX_FLAG_BAD) err |= DX_ERR_BAD;
+			if (nvalid == 0 || wave_get(my_end, nvalid > 0 ? nvalid - 1 : 0) == (uint32_t)DX_BAD) err |= DX_ERR_BAD;
 		}
-		prev_end = wave_get(r.end, 63);
+		prev_end = wave_get(my_end, 63);
 	}
 	if (last < 0 && !err) err |= DX_ERR_NOEND;           // ran off the payload without meeting the end marker
 	if (base > (uint32_t)job.n) err |= DX_ERR_OVERFLOW;   // more coefficients than the band holds (the tile kernel never writes outside its tile)
@@ -460,20 +556,20 @@ __device__ __forceinline__ bool dx_chain_band(const DxBandJob &job, const int j,
 	return true;
 }
 
-// One wave per band, the common case only: bands with a chunk that needs indexing again go on the repair list (counters[1] = their number).
-__global__ void __launch_bounds__(DX_THREADS) k_dec_chain(const DxBandJob *jobs, int njobs, const DxChunkRec *recs, uint32_t *chunk_base, DxBandSum *sums, int *errors,
-                                                          uint32_t *repair_list, uint32_t *counters)
+// One wave per band, without the means to index a chunk again: bands that need it go on the repair list (counters[1] = their number).
+__global__ void __launch_bounds__(DX_THREADS) k_dec_chain(const DxBandJob *jobs, int njobs, const DxChunkRec *recs, const DxChunkAlt *alts, uint32_t *chunk_base, DxBandSum *sums, int *errors,
+                                                          uint32_t *repair_list, DxReindex *reindex_list, uint32_t *counters)
 {
 	const int j = (int)blockIdx.x * DX_WAVES + wave_uniform((int)(threadIdx.x >> 6));
 	if (j >= njobs) return;
 	const DxBandJob job = jobs[j];
-	if (!dx_chain_band<false>(job, j, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, (DxChunkRec *)recs, chunk_base, sums, errors, nullptr) && wave_lane() == 0)
+	if (!dx_chain_band<false>(job, j, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, (DxChunkRec *)recs, alts, chunk_base, sums, errors, reindex_list, counters, nullptr) && wave_lane() == 0)
 		repair_list[atomicAdd(&counters[1], 1u)] = (uint32_t)j;
 }
 
 // The bands of the repair list, a wave each (a small grid strides over the list; usually it is empty).
-__global__ void __launch_bounds__(DX_THREADS) k_dec_repair(const DxBandJob *jobs, const DecIdxTables *T, uint32_t *entries, DxChunkRec *recs, uint32_t *chunk_base, DxBandSum *sums,
-                                                           int *errors, const uint32_t *repair_list, const uint32_t *counters, uint32_t *stats)
+__global__ void __launch_bounds__(DX_THREADS) k_dec_repair(const DxBandJob *jobs, const DecIdxTables *T, uint32_t *entries, DxChunkRec *recs, const DxChunkAlt *alts, uint32_t *chunk_base,
+                                                           DxBandSum *sums, int *errors, const uint32_t *repair_list, DxReindex *reindex_list, uint32_t *counters, uint32_t *stats)
 {
 	__shared__ uint16_t s_cnt[1 << DX_K], s_sym[1 << DX_K];
 	__shared__ uint32_t s_long[DX_LONG_MAX];
@@ -483,7 +579,27 @@ __global__ void __launch_bounds__(DX_THREADS) k_dec_repair(const DxBandJob *jobs
 	for (uint32_t i = (uint32_t)blockIdx.x * DX_WAVES + (uint32_t)wave; i < n; i += (uint32_t)gridDim.x * DX_WAVES) {
 		const int j = (int)repair_list[i];
 		const DxBandJob job = jobs[j];
-		(void)dx_chain_band<true>(job, j, T, s_cnt, s_sym, s_long, s_words_all[wave], entries, recs, chunk_base, sums, errors, stats);
+		(void)dx_chain_band<true>(job, j, T, s_cnt, s_sym, s_long, s_words_all[wave], entries, recs, alts, chunk_base, sums, errors, reindex_list, counters, stats);
+	}
+}
+
+// The chunks whose entries were written for a candidate start that turned out not to be the true one: once more from the true start, a wave
+// each (counters[2] = their number; all of them at once, nothing depends on anything any more).
+__global__ void __launch_bounds__(DX_THREADS) k_dec_reindex(const DxBandJob *jobs, const DecIdxTables *T, uint32_t *entries, const DxReindex *reindex_list, const uint32_t *counters, uint32_t *stats)
+{
+	__shared__ uint16_t s_cnt[1 << DX_K], s_sym[1 << DX_K];
+	__shared__ uint32_t s_long[DX_LONG_MAX];
+	__shared__ uint32_t s_words_all[DX_WAVES][DX_STAGE_PHYS];
+	const uint32_t n = counters[2];
+	if ((uint32_t)blockIdx.x * DX_WAVES >= n) return;
+	dx_load_tables(T, s_cnt, s_sym, s_long, true);
+	__syncthreads();
+	const int wave = wave_uniform((int)(threadIdx.x >> 6));
+	for (uint32_t i = (uint32_t)blockIdx.x * DX_WAVES + (uint32_t)wave; i < n; i += (uint32_t)gridDim.x * DX_WAVES) {
+		const DxReindex x = reindex_list[i];
+		const DxBandJob job = jobs[x.job];
+		dx_index_chunk(job.bits, job.bytes, x.chunk, x.k, x.start, s_words_all[wave], s_cnt, s_sym, s_long, entries, nullptr, nullptr);
+		if (stats && wave_lane() == 0) atomicAdd(&stats[3], 1u << 8);
 	}
 }
 
@@ -564,20 +680,22 @@ __device__ __forceinline__ void dx_tile_pieces(const DxTileMeta &M, uint32_t q, 
 __device__ __forceinline__ bool dx_tile_has_work(const DxTileMeta &M) { return M.job.bytes != 0u && M.ti * DX_TILE < (uint32_t)M.job.n && M.first_sub != DX_TILE_EMPTY; }
 __device__ __forceinline__ uint32_t dx_tile_last_sub(const DxTileMeta &M) { return ((uint32_t)M.sum.last_chunk + 1u) * DX_CHUNK_SUBS; }
 
-__global__ void __launch_bounds__(DX_THREADS) k_dec_tiles(const DxBandJob *jobs, DxTilePlan plan, const DecIdxTables *T, const uint32_t *entries, const uint32_t *chunk_base,
-                                                          const DxBandSum *sums, const uint32_t *tile_start)
+__global__ void __launch_bounds__(DX_TILE_THREADS) k_dec_tiles(const DxBandJob *jobs, DxTilePlan plan, const DecIdxTables *T, const uint32_t *entries, const uint32_t *chunk_base,
+                                                               const DxBandSum *sums, const uint32_t *tile_start)
 {
+	__shared__ uint2 s_multi[1 << DX_KM];
 	__shared__ uint16_t s_sym[1 << DX_K];
 	__shared__ uint32_t s_long[DX_LONG_MAX];
 	__shared__ uint16_t s_mag[256];
-	__shared__ uint32_t s_tile_all[DX_WAVES][DX_TILE / 2];
+	__shared__ uint32_t s_tile_all[DX_TILE_WAVES][DX_TILE / 2];
 	dx_load_tables(T, nullptr, s_sym, s_long, false);
 	for (int i = threadIdx.x; i < 256; i += blockDim.x) s_mag[i] = T->mag_expand[i];
+	for (int i = threadIdx.x; i < (1 << DX_KM); i += blockDim.x) s_multi[i] = T->multi[i];
 	const int lane = wave_lane(), wave = wave_uniform((int)(threadIdx.x >> 6));
 	uint32_t *s_tile = s_tile_all[wave];
 	for (int i = lane; i < DX_TILE / 2; i += 64) s_tile[i] = 0u;
 	__syncthreads();
-	const uint32_t gwave = (uint32_t)blockIdx.x * DX_WAVES + (uint32_t)wave, nwaves = (uint32_t)gridDim.x * DX_WAVES;
+	const uint32_t gwave = (uint32_t)blockIdx.x * DX_TILE_WAVES + (uint32_t)wave, nwaves = (uint32_t)gridDim.x * DX_TILE_WAVES;
 	uint32_t t = gwave;
 	if (t >= plan.total) return;
 	// software pipeline: tile t is decoded while the descriptors of tile t + 2 nwaves and the payload pieces of tile t + nwaves are on their way
@@ -618,29 +736,33 @@ __global__ void __launch_bounds__(DX_THREADS) k_dec_tiles(const DxBandJob *jobs,
 						int have = 64 - (int)off;
 						uint32_t nextw = bswap32(P.d[2]), afterw = bswap32(P.d[3]);
 						uint32_t pos = off;
+						int16_t *tile16 = (int16_t *)s_tile;
 						while (pos < (uint32_t)DX_SUB_BITS && idx < T1) {
 							if (have < 32) { acc |= (uint64_t)nextw << (32 - have); have += 32; nextw = afterw; afterw = 0u; }
 							const uint32_t win = (uint32_t)(acc >> 32);
-							// the two shortest code words without a table: '0' = one zero coefficient (a stretch of them at once), '10' + sign = +-1
-							const int z = win ? __builtin_clz(win) : 32;
-							if (z) {
-								int n = (int)DX_SUB_BITS - (int)pos;          // only code words that start inside this piece
-								if (z < n) n = z;
-								idx += (uint32_t)n; acc <<= n; have -= n; pos += (uint32_t)n;
+							// up to two values and the zero runs around them per lookup.  A group may reach over the end of the piece: the lane of the
+							// next piece then writes the same values to the same places again.
+							const uint2 e = s_multi[win >> (32 - DX_KM)];
+							const int used = (int)(e.x & 15u);
+							if (used) {
+								idx += (e.x >> 4) & 0xfffu;
+								const int v1 = (int)(int16_t)(e.x >> 16), v2 = (int)(int16_t)(e.y >> 16);
+								if (v1) { if (idx - T0 < (uint32_t)DX_TILE) tile16[idx - T0] = (int16_t)(v1 * quant); idx++; }
+								idx += e.y & 0xffu;
+								if (v2) { if (idx - T0 < (uint32_t)DX_TILE) tile16[idx - T0] = (int16_t)(v2 * quant); idx++; }
+								idx += (e.y >> 8) & 0xffu;
+								acc <<= used; have -= used; pos += (uint32_t)used;
 								continue;
 							}
-							int len, v;
-							if (!(win & 0x40000000u)) { len = 2; v = (int)s_mag[1] * quant; }
-							else {
-								const DxSym s = dx_symbol(s_sym, s_long, win);
-								if (s.type == DX_T_RUN) { idx += (uint32_t)s.payload; acc <<= s.len; have -= s.len; pos += (uint32_t)s.len; continue; }
-								if (s.type != DX_T_VALUE) break;                 // band end marker (or a broken code, reported by k_dec_chain)
-								len = s.len; v = (int)s_mag[s.payload] * quant;
-							}
-							const int negative = (int)((acc << len) >> 63);
-							if (idx >= T0) ((int16_t *)s_tile)[idx - T0] = (int16_t)(negative ? -v : v);
+							// a code word of more than 11 bits (a large value, a long run, the band end marker): alone, through the full tables
+							const DxSym sy = dx_symbol(s_sym, s_long, win);
+							if (sy.type == DX_T_RUN) { idx += (uint32_t)sy.payload; acc <<= sy.len; have -= sy.len; pos += (uint32_t)sy.len; continue; }
+							if (sy.type != DX_T_VALUE) break;                 // band end marker (or a broken code, reported by k_dec_chain)
+							const int v = (int)s_mag[sy.payload] * quant;
+							const int negative = (int)((acc << sy.len) >> 63);
+							if (idx - T0 < (uint32_t)DX_TILE) tile16[idx - T0] = (int16_t)(negative ? -v : v);
 							idx++;
-							acc <<= len + 1; have -= len + 1; pos += (uint32_t)len + 1u;
+							acc <<= sy.len + 1; have -= sy.len + 1; pos += (uint32_t)sy.len + 1u;
 						}
 					}
 					// pieces are in raster order: once a valid one starts behind the tile, all later ones do

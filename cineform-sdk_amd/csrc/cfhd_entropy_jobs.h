@@ -113,6 +113,32 @@ inline bool build_dec_index_tables(int codebook, dev::DecIdxTables *T)
 		}
 		T->cnt12[win] = (uint16_t)(used | (count << 4));
 	}
+	// k_dec_tiles: up to two values and the zero runs around them from an 11-bit window
+	for (uint32_t win = 0; win < (1u << DX_KM); win++) {
+		int used = 0, pre = 0, mid = 0, post = 0, v1 = 0, v2 = 0;
+		for (;;) {
+			const uint32_t rest = ((win << (DX_K - DX_KM)) << used) & ((1u << DX_K) - 1u);     // remaining bits, left aligned in 12 (the 12th bit of the window is unknown: 0)
+			const uint16_t e = T->sym12[rest];
+			const int len = e & 15, total = len + ((e & 16) ? 1 : 0);
+			if (!len || total > DX_KM - used) break;
+			if (e & 16) {
+				if (v2) break;
+				const int m = e >> 5;
+				if (T->mag_expand[m] != m || m > 0x7fff) return false;                     // the table relies on magnitude = index for such short code words
+				const int negative = (int)((rest >> (DX_K - len - 1)) & 1u);
+				if (!v1) v1 = negative ? -m : m; else v2 = negative ? -m : m;
+			} else {
+				const int run = e >> 5;
+				int *slot = v2 ? &post : (v1 ? &mid : &pre);
+				if (*slot + run > (slot == &pre ? 0xfff : 0xff)) break;
+				*slot += run;
+			}
+			used += total;
+		}
+		if (v1 && !v2) { post = mid; mid = 0; }             // zeros behind the only value
+		T->multi[win].x = (uint32_t)(used & 15) | ((uint32_t)pre << 4) | ((uint32_t)(uint16_t)(int16_t)v1 << 16);
+		T->multi[win].y = (uint32_t)(mid & 0xff) | ((uint32_t)(post & 0xff) << 8) | ((uint32_t)(uint16_t)(int16_t)v2 << 16);
+	}
 	return true;
 }
 

@@ -609,6 +609,8 @@ def test_dx_decoder_emulated_code_without_unique_alignment():
     rc, got = _dx_decode(sample, plan, 0, 4)
     st = E.emu_dx_stats()
     assert st[2] >= 20, "the constant bands were expected to need many rounds (%d): the test does not exercise what it is for" % st[2]
+    # chunks inside such a stretch are indexed for every candidate start and the chain picks the true one: none is left to the serial repair
+    assert (st[3] >> 16) > 0 and st[13] > 0 and st[12] == 0, "candidates %d, re-indexed %d, bands repaired serially %d" % (st[3] >> 16, st[13], st[12])
 
 
 @pytest.mark.parametrize("mode", [0, 2])
