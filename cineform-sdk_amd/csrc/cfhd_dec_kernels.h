@@ -45,6 +45,7 @@ enum {
 	DX_THREADS = 256, DX_WAVES = DX_THREADS / 64,
 	DX_TILE_THREADS = 512, DX_TILE_WAVES = DX_TILE_THREADS / 64,      // k_dec_tiles: eight waves share the tables
 	DX_KM = 11,                       // bits of the window of the multi-symbol table of k_dec_tiles
+	DX_RUNIN_SHORT = 96, DX_LEAD = 96,    // bits of the quick run-in in front of a chunk / of the lead-in in front of a lane
 	DX_MEMO = 6,                      // outcomes a lane of k_dec_index remembers (start -> end, count)
 	DX_OFF_INVALID = 31,              // entry: no code word of the true sequence starts in this piece (behind the band end marker / the payload)
 };
@@ -135,10 +136,13 @@ __device__ __forceinline__ uint32_t dx_off_clear_from(uint32_t offs, int k) { co
 // the offset recorded by the previous walk -- from there on the two chains are the same, only the counts in front shift.
 // One flat loop: the lanes of a wave cross their marks at different times, and a loop per piece would make every lane wait for the slowest
 // one four times over.
+// A walk may start in front of the lane (a lead-in through the neighbour's last bits, to fall in step before the lane begins): counting starts
+// with the first code word inside the lane, whose position is returned in L.start.
 __device__ __forceinline__ void dx_walk(DxLane &L, uint32_t pos, const bool merge, const uint32_t lane_base, const uint32_t limit, const uint32_t *s_words, const uint16_t *s_cnt,
                                         const uint16_t *s_sym, const uint32_t *s_long)
 {
 	uint32_t cnt = 0;
+	L.start = pos;
 	uint32_t offs = merge ? L.rec_offs : (uint32_t)DX_OFFS_NONE;
 	const uint32_t lane_end = lane_base + DX_LANE_BITS;
 	uint32_t next = lane_base;                            // first bit of the piece the walk has not entered yet
@@ -151,6 +155,7 @@ __device__ __forceinline__ void dx_walk(DxLane &L, uint32_t pos, const bool merg
 		if (pos >= next) {
 			// the walk enters a new piece (a code word is shorter than a piece: none is skipped, except in front of a late start)
 			const int k = (int)((pos - lane_base) / DX_SUB_BITS);
+			if (piece < 0) { cnt = 0; L.start = pos; }        // the first code word of the lane
 			for (int j = piece + 1; j < k; j++) offs = dx_off_set(offs, j, DX_OFF_INVALID);
 			const uint32_t off = pos - (lane_base + (uint32_t)k * DX_SUB_BITS);
 			if (merge && k > 0 && dx_off_get(offs, k) == off) {
@@ -210,15 +215,15 @@ __device__ __forceinline__ void dx_store_stage(const DxFetch &F, uint32_t *s_wor
 // offset a first code word can have; the distinct outcomes (bit offsets into the chunk) are the candidates for the chunk's first code word.
 // Ordinary data leaves one; returns their number (at most DX_MAX_ALT + 2: more than DX_MAX_ALT + 1 means "too many"), 0 when every walk
 // ended on the band end marker or a broken code (the chunk holds padding).
-__device__ __forceinline__ int dx_runin_candidates(const uint32_t bytes, const uint32_t k, const uint32_t *s_words, const uint16_t *s_cnt, const uint16_t *s_sym, const uint32_t *s_long,
-                                                   uint32_t (&cand)[DX_MAX_ALT + 2])
+__device__ __forceinline__ int dx_runin_candidates(const uint32_t bytes, const uint32_t k, const uint32_t runin_bits, const uint32_t *s_words, const uint16_t *s_cnt, const uint16_t *s_sym,
+                                                   const uint32_t *s_long, uint32_t (&cand)[DX_MAX_ALT + 2])
 {
 	const int lane = wave_lane();
 	const uint32_t nwords = bytes >> 2;
 	const int64_t first = (int64_t)k * DX_CHUNK_WORDS - (DX_LANE_BITS / 32);
 	const int64_t left = (int64_t)nwords - first;
 	const uint32_t limit = left <= 0 ? 0u : (left * 32 > (int64_t)(64 * DX_LANE_BITS + 64) ? (uint32_t)(64 * DX_LANE_BITS + 64) : (uint32_t)(left * 32));
-	uint32_t pos = (uint32_t)lane, end = DX_BAD;
+	uint32_t pos = (uint32_t)DX_LANE_BITS - runin_bits + (uint32_t)lane, end = DX_BAD;
 	if (lane < 27) {
 		DxBits B;
 		B.seek(s_words, pos);
@@ -258,7 +263,6 @@ __device__ __forceinline__ DxChunkRec dx_index_staged(const uint32_t bytes, cons
 	const int64_t left = (int64_t)nwords - first;           // payload words from the start of the staging area on
 	const uint32_t limit = left <= 0 ? 0u : (left * 32 > (int64_t)(64 * DX_LANE_BITS + 64) ? (uint32_t)(64 * DX_LANE_BITS + 64) : (uint32_t)(left * 32));   // staging bit position behind the payload
 	const uint32_t lane_base = (uint32_t)lane * DX_LANE_BITS;
-	const bool runin = false;
 	// lanes whose range lies behind the payload take no part: the last lane with payload bits carries the end of the chain
 	const bool live = lane_base < limit && lane >= 1;
 	const int last_live = limit == 0u ? 0 : (int)((limit - 1u) / DX_LANE_BITS) < 63 ? (int)((limit - 1u) / DX_LANE_BITS) : 63;
@@ -289,7 +293,9 @@ __device__ __forceinline__ DxChunkRec dx_index_staged(const uint32_t bytes, cons
 			if (live && special) L.rec_offs = DX_OFFS_NONE;
 			want = L.start; need = live && !special && rec_start != L.start;
 		} else if (round == 0) {
-			want = lane_base; need = live || (lane == 0 && runin);
+			// lane 1 follows lane 0 (the chunk's first code word is known); every other lane leads in through its neighbour's last bits
+			const uint32_t first = __shfl_up(L.end, 1u);
+			want = lane == 1 ? first : lane_base - DX_LEAD; need = live;
 		} else {
 			want = __shfl_up(L.end, 1u); need = live && want != L.start;
 		}
@@ -305,22 +311,25 @@ __device__ __forceinline__ DxChunkRec dx_index_staged(const uint32_t bytes, cons
 		if (finishing && !moved) break;
 		if (need) {
 			L.start = want;
-			if (want >= DX_SPECIAL || want < lane_base || want >= lane_base + DX_LANE_BITS) {
+			const bool lead = !finishing && round == 0 && lane >= 2;
+			if (!lead && (want >= DX_SPECIAL || want < lane_base || want >= lane_base + DX_LANE_BITS)) {
 				// behind the band end marker (or a broken code), or the neighbour's chain does not reach this lane: nothing of the true sequence starts here
 				L.end = want >= DX_SPECIAL ? want : (uint32_t)DX_BAD; L.cnt = 0;
 			} else {
 				int hit = -1;
 #pragma unroll
 				for (int i = 0; i < DX_MEMO; i++) if (memo_s[i] == want) hit = i;
-				if (hit >= 0 && !finishing) {
+				if (hit >= 0 && !finishing && !lead) {
 #pragma unroll
 					for (int i = 0; i < DX_MEMO; i++) if (i == hit) { L.end = memo_e[i]; L.cnt = memo_c[i]; }
 				} else {
 					L.end = rec_end; L.cnt = rec_total;           // a walk that meets the recorded one continues from ITS outcome (a remembered outcome may have replaced it meanwhile)
 					dx_walk(L, want, !finishing && rec_start != DX_BAD, lane_base, limit, s_words, s_cnt, s_sym, s_long);
-					rec_start = want; rec_end = L.end; rec_total = L.cnt;
+					const uint32_t walked = lead ? L.start : want;        // a lead-in reports the first code word inside the lane
+					L.start = walked;
+					rec_start = walked; rec_end = L.end; rec_total = L.cnt;
 #pragma unroll
-					for (int i = 0; i < DX_MEMO; i++) if (i == memo_at) { memo_s[i] = want; memo_e[i] = L.end; memo_c[i] = L.cnt; }
+					for (int i = 0; i < DX_MEMO; i++) if (i == memo_at) { memo_s[i] = walked; memo_e[i] = L.end; memo_c[i] = L.cnt; }
 					memo_at = memo_at + 1 < DX_MEMO ? memo_at + 1 : 0;
 				}
 			}
@@ -437,7 +446,11 @@ __global__ void __launch_bounds__(DX_THREADS) k_dec_index(const DxChunkDesc *chu
 		// chunks -- k_dec_chain has to repair them.
 		uint32_t cand[DX_MAX_ALT + 2] = { 0u, 0u, 0u, 0u, 0u };
 		int n = 1;
-		if (d.k != 0 && speculate) n = dx_runin_candidates(d.bytes, d.k, s_words, s_cnt, s_sym, s_long, cand);
+		if (d.k != 0 && speculate) {
+			// the last 96 bits settle ordinary data; only when they leave more than one candidate the whole 256 are walked
+			n = dx_runin_candidates(d.bytes, d.k, DX_RUNIN_SHORT, s_words, s_cnt, s_sym, s_long, cand);
+			if (n != 1) n = dx_runin_candidates(d.bytes, d.k, DX_LANE_BITS, s_words, s_cnt, s_sym, s_long, cand);
+		}
 		if (n == 0) {                                        // behind the band end marker: padding
 			if (wave_lane() == 0) recs[c] = DxChunkRec{ (uint32_t)DX_END, (uint32_t)DX_END, 0u, (uint32_t)DX_FLAG_END | (1u << 8) };
 		} else {
