@@ -712,9 +712,12 @@ CFHD_Error CFHD_DecodeSample(CFHD_DecoderRef ref, void *sample, size_t size, voi
 	if (parse_sample(s, size, &ps) != 0) return fail_zero(ERR_BADSAMPLE);
 	if (ps.width != d->header.width || ps.display_height != d->header.display_height || ps.encoded_format != d->header.encoded_format ||
 	    ps.num_channels != d->plan.num_channels) return fail_zero(ERR_BADSAMPLE);
-	// interlaced samples (no SAMPLE_FLAGS tag; it lies behind the 512 bytes CFHD_PrepareToDecode sees): the inverse field transform is not built
-	if (!ps.progressive) return fail_zero(ERR_BADFORMAT);
+	// interlaced samples (known only now: the SAMPLE_FLAGS tag lies behind the 512 bytes CFHD_PrepareToDecode sees): 4:2:2 at full resolution
+	const bool interlaced = !ps.progressive;
+	if (interlaced && (ps.encoded_format != ENC_YUV422 || d->half)) return fail_zero(ERR_BADFORMAT);
+	if (d->batch_ready && d->batch.interlaced() != interlaced) d->batch_ready = false;
 	if (!d->batch_ready) {
+		d->batch.set_interlaced(interlaced);
 		if (d->batch.prepare(d->plan, 1, d->out_kind, true, d->half)) return ERR_INTERNAL;
 		if (gpu_entropy_enabled() && d->batch.prepare_entropy((size_t)d->plan.width * d->plan.height * pixel_bytes_of(d->out_kind) + 65536)) return ERR_INTERNAL;
 		d->batch_ready = true;
@@ -761,6 +764,10 @@ CFHD_Error CFHD_DecodeSample(CFHD_DecoderRef ref, void *sample, size_t size, voi
 				const BandDesc &bd = plan.ch[c].band[lv][b];
 				if (!pb.present || pb.width != bd.width || pb.height != bd.height) return fail_zero(ERR_BADSAMPLE);
 				if (vlc_decode_band(s + pb.offset, pb.bytes, bd.width, bd.height, bd.pitch, pb.quant, pb.codebook, coeffs + bd.offset)) return fail_zero(ERR_BADSAMPLE);
+				if (pb.difference) {
+					if (pb.peak_level && (size_t)pb.peak_offset + 2 > size) return fail_zero(ERR_BADSAMPLE);
+					finish_difference_band(coeffs + bd.offset, bd.width, bd.height, bd.pitch, pb.peak_level ? s + pb.peak_offset : nullptr, pb.peak_level ? size - pb.peak_offset : 0, pb.peak_level);
+				}
 			}
 	}
 	if (d->batch.upload_coeffs()) return ERR_INTERNAL;

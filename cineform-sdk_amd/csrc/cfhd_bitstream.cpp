@@ -361,6 +361,7 @@ void build_sample_template(const FramePlan &plan, const SampleHeaderInfo &hdr, S
 int parse_sample(const uint8_t *d, size_t size, ParsedSample *ps)
 {
 	*ps = ParsedSample();
+	ps->size = size;
 	memset(ps->lowpass, 0, sizeof(ps->lowpass));
 	memset(ps->high, 0, sizeof(ps->high));
 	size_t pos = 0;

@@ -112,6 +112,7 @@ struct ParsedSample {
 	ParsedBand lowpass[kMaxChannels];                     // raw 16-bit big-endian pairs
 	ParsedBand high[kMaxChannels][kNumLevels][kNumBands]; // [ch][wavelet index][band 1..3]
 	uint32_t metadata_offset = 0, metadata_bytes = 0;     // first metadata chunk
+	size_t size = 0;                                      // bytes handed to parse_sample
 };
 // Returns 0 on success, 1 when the header parsed but the data ends early (header sniffing), <0 on malformed input.
 int parse_sample(const uint8_t *data, size_t size, ParsedSample *out);

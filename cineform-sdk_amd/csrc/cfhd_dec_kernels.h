@@ -28,6 +28,13 @@
 #include <stdint.h>
 #include "cfhd_entropy_kernels.h"
 
+#ifndef CFHD_DX_TILE
+#define CFHD_DX_TILE 2048
+#endif
+#ifndef CFHD_DX_TILE_THREADS
+#define CFHD_DX_TILE_THREADS 512
+#endif
+
 namespace cfhd {
 namespace dev {
 
@@ -41,9 +48,9 @@ enum {
 	DX_STAGE_WORDS = 64 * (DX_LANE_BITS / 32) + 2, // payload words of a chunk + run-in lane + two words of look-ahead
 	DX_LONG_MAX = 1408,               // entries of the second / third level tables (code words of 13..26 bits)
 	DX_L2_BITS = 7,
-	DX_TILE = 2048,                   // coefficients per output tile
+	DX_TILE = CFHD_DX_TILE,           // coefficients per output tile
 	DX_THREADS = 256, DX_WAVES = DX_THREADS / 64,
-	DX_TILE_THREADS = 512, DX_TILE_WAVES = DX_TILE_THREADS / 64,      // k_dec_tiles: eight waves share the tables
+	DX_TILE_THREADS = CFHD_DX_TILE_THREADS, DX_TILE_WAVES = DX_TILE_THREADS / 64,      // k_dec_tiles: its waves share the tables
 	DX_KM = 11,                       // bits of the window of the multi-symbol table of k_dec_tiles
 	DX_RUNIN_SHORT = 96, DX_LEAD = 96,    // bits of the quick run-in in front of a chunk / of the lead-in in front of a lane
 	DX_MEMO = 6,                      // outcomes a lane of k_dec_index remembers (start -> end, count)
@@ -58,7 +65,7 @@ struct DecIdxTables {
 	uint16_t cnt12[1 << DX_K];        // as many whole code words (sign bits included) as fit into the next 12 bits: bits 0-3 bits used (0: none fits), bits 4-15 coefficients covered
 	uint16_t sym12[1 << DX_K];        // first code word: bits 0-3 length without the sign bit (0: longer than 12 bits or invalid), bit 4 value (else zero run) -- with length 0: escape --,
 	                                  // bits 5-15 run length / index of the magnitude / base of the second-level table
-	uint16_t mag_expand[256];         // magnitude after undoing the companding curve, by index
+	uint16_t mag_expand[2][256];      // magnitude after undoing the companding curve, by index: [0] code set 17 (cubic), [1] code set 18 (linear)
 	uint32_t long_tab[DX_LONG_MAX];   // bits 0-4 length (escape: index bits of the next level), bits 5-7 type, bits 8-31 run / magnitude index / base of the next level
 	uint32_t nlong;
 	// k_dec_tiles: everything that fits completely (sign bits included) into the next 11 bits, up to two values with the zero runs around
@@ -663,6 +670,25 @@ __global__ void __launch_bounds__(DX_THREADS) k_dec_tile_index(const DxBandJob *
 // What a wave of k_dec_tiles needs to know about a tile, and the first 64 pieces of payload that may reach into it: both are fetched
 // one tile ahead, so that the loads are in flight while the previous tile is decoded.
 struct DxTileMeta { int j; uint32_t ti, first_sub; DxBandJob job; DxBandSum sum; };
+// 0 in every lane, but not to the compiler: an address with it added is per-lane, so the load becomes a vector load (counted by vmcnt) and
+// not a scalar one -- scalar loads share their counter with LDS, and the first LDS read of the decode loop would wait for the prefetch.
+__device__ __forceinline__ uint32_t dx_lane_zero() { return __builtin_amdgcn_mbcnt_lo(0u, 0u); }
+template <typename T> __device__ __forceinline__ void dx_vload(T &dst, const T *src)
+{
+	static_assert(sizeof(T) % 4 == 0, "dwords");
+	const uint32_t *p = (const uint32_t *)src + dx_lane_zero();
+	uint32_t *d = (uint32_t *)&dst;
+#pragma unroll
+	for (int i = 0; i < (int)(sizeof(T) / 4); i++) d[i] = p[i];
+}
+template <typename T> __device__ __forceinline__ T dx_uniform(const T &v)    // back to scalar registers (the value is the same in every lane)
+{
+	T r;
+	const uint32_t *s = (const uint32_t *)&v; uint32_t *d = (uint32_t *)&r;
+#pragma unroll
+	for (int i = 0; i < (int)(sizeof(T) / 4); i++) d[i] = (uint32_t)wave_uniform((int)s[i]);
+	return r;
+}
 struct DxPieces { uint32_t ent, cb, d[4]; };
 __device__ __forceinline__ void dx_tile_meta(const DxTilePlan &plan, uint32_t t, int &slot, const DxBandJob *jobs, const DxBandSum *sums, const uint32_t *tile_start, DxTileMeta &M)
 {
@@ -670,9 +696,9 @@ __device__ __forceinline__ void dx_tile_meta(const DxTilePlan &plan, uint32_t t,
 	const uint32_t r = t - plan.cum[slot], per = plan.per_band[slot];
 	const uint32_t f = r / per;
 	M.ti = r - f * per; M.j = slot * plan.nframes + (int)f;
-	M.first_sub = tile_start[t];
-	M.job = jobs[M.j];
-	M.sum = sums[M.j];
+	dx_vload(M.first_sub, tile_start + t);
+	dx_vload(M.job, jobs + M.j);
+	dx_vload(M.sum, sums + M.j);
 }
 __device__ __forceinline__ void dx_tile_pieces(const DxTileMeta &M, uint32_t q, uint32_t last_sub, const uint32_t *entries, const uint32_t *chunk_base, DxPieces &P)
 {
@@ -699,10 +725,10 @@ __global__ void __launch_bounds__(DX_TILE_THREADS) k_dec_tiles(const DxBandJob *
 	__shared__ uint2 s_multi[1 << DX_KM];
 	__shared__ uint16_t s_sym[1 << DX_K];
 	__shared__ uint32_t s_long[DX_LONG_MAX];
-	__shared__ uint16_t s_mag[256];
+	__shared__ uint16_t s_mag_all[2][256];
 	__shared__ uint32_t s_tile_all[DX_TILE_WAVES][DX_TILE / 2];
 	dx_load_tables(T, nullptr, s_sym, s_long, false);
-	for (int i = threadIdx.x; i < 256; i += blockDim.x) s_mag[i] = T->mag_expand[i];
+	for (int i = threadIdx.x; i < 512; i += blockDim.x) (&s_mag_all[0][0])[i] = (&T->mag_expand[0][0])[i];
 	for (int i = threadIdx.x; i < (1 << DX_KM); i += blockDim.x) s_multi[i] = T->multi[i];
 	const int lane = wave_lane(), wave = wave_uniform((int)(threadIdx.x >> 6));
 	uint32_t *s_tile = s_tile_all[wave];
@@ -728,18 +754,20 @@ __global__ void __launch_bounds__(DX_TILE_THREADS) k_dec_tiles(const DxBandJob *
 			const bool w1 = t + nwaves < plan.total && dx_tile_has_work(M1);
 			dx_tile_pieces(M1, w1 ? M1.first_sub + (uint32_t)lane : 0xFFFFFFFFu, w1 ? dx_tile_last_sub(M1) : 0u, entries, chunk_base, P1);
 		}
-		const DxBandJob &job = M.job;
+		const DxBandJob job = dx_uniform(M.job);
+		const uint32_t first_sub = (uint32_t)wave_uniform((int)M.first_sub);
 		const uint32_t T0 = M.ti * DX_TILE, T1 = T0 + DX_TILE < (uint32_t)job.n ? T0 + DX_TILE : (uint32_t)job.n;
 		if (job.bytes != 0u && T0 < (uint32_t)job.n) {                         // wave-uniform
-			if (M.first_sub != DX_TILE_EMPTY) {
+			if (first_sub != DX_TILE_EMPTY) {
 				// piece by piece, one per lane, until the pieces start behind the tile
-				const uint32_t last_sub = dx_tile_last_sub(M);
+				const uint32_t last_sub = (uint32_t)wave_uniform((int)dx_tile_last_sub(M));
 				const int quant = job.quant;
+				const uint16_t *s_mag = s_mag_all[job.table & 1];
 #pragma unroll 1
-				for (uint32_t q0 = M.first_sub; q0 < last_sub; q0 += 64) {
+				for (uint32_t q0 = first_sub; q0 < last_sub; q0 += 64) {
 					const uint32_t q = q0 + (uint32_t)lane;
 					const bool active = q < last_sub;
-					if (q0 != M.first_sub) dx_tile_pieces(M, q, last_sub, entries, chunk_base, P);     // a second round is rare (a dense tile)
+					if (q0 != first_sub) dx_tile_pieces(M, q, last_sub, entries, chunk_base, P);     // a second round is rare (a dense tile)
 					const uint32_t off = P.ent & 31u;
 					uint32_t idx = P.cb + (P.ent >> 5);
 					const bool valid = active && off != (uint32_t)DX_OFF_INVALID;
@@ -795,6 +823,63 @@ __global__ void __launch_bounds__(DX_TILE_THREADS) k_dec_tiles(const DxBandJob *
 			CFHD_WAVE_SYNC();
 		}
 		M = M1; M1 = M2; P = P1;
+	}
+}
+
+// The difference-coded band of interlaced frames (subband 8 of every channel) after k_dec_tiles: coefficients beyond the peak level take their
+// values from the peak table in raster order (Codec/decoder.c:19809 DecodeBandFSM16sNoGapWithPeaks), then every row becomes its running sum
+// (decoder.c:20822).  One workgroup per band walks down the rows: every thread holds a run of consecutive columns, block-wide prefix sums give
+// the number of peaks in front of it and the sum of the columns in front of it.
+enum { DXU_THREADS = 256, DXU_MAX = 16 };               // columns per thread: rows of up to 4096 coefficients
+__global__ void __launch_bounds__(DXU_THREADS) k_dec_undiff(const DecDiffJob *jobs, int *errors)
+{
+	__shared__ uint32_t s_w[2][DXU_THREADS / 64];
+	const DecDiffJob job = jobs[blockIdx.x];
+	if (!job.band || job.width <= 0) return;
+	const int t = threadIdx.x, lane = wave_lane(), wave = t >> 6;
+	const int per = (job.width + DXU_THREADS - 1) / DXU_THREADS;
+	if (per > DXU_MAX) { if (t == 0) atomic_or_u32((uint32_t *)errors, (uint32_t)DX_ERR_SPACE); return; }
+	const int c0 = t * per, c1 = c0 + per < job.width ? c0 + per : job.width;
+	uint32_t peaks_seen = 0;
+	for (int y = 0; y < job.height; y++) {
+		int16_t *line = job.band + (size_t)y * job.pitch;
+		int v[DXU_MAX];
+		uint32_t marks = 0;
+#pragma unroll
+		for (int i = 0; i < DXU_MAX; i++) {
+			v[i] = (i < per && c0 + i < c1) ? (int)line[c0 + i] : 0;
+			if (job.level && (v[i] > job.level || v[i] < -job.level)) marks++;
+		}
+		if (job.level) {
+			// peak values in raster order: block-wide exclusive count of the marked coefficients in front of this thread's columns
+			const uint32_t incl = wave_incl_scan(marks);
+			if (lane == 63) s_w[0][wave] = incl;
+			__syncthreads();
+			uint32_t before = incl - marks, row_total = 0;
+#pragma unroll
+			for (int k = 0; k < DXU_THREADS / 64; k++) { const uint32_t x = s_w[0][k]; if (k < wave) before += x; row_total += x; }
+			uint32_t at = peaks_seen + before;
+#pragma unroll
+			for (int i = 0; i < DXU_MAX; i++)
+				if (i < per && c0 + i < c1 && (v[i] > job.level || v[i] < -job.level)) {
+					if (2u * at + 2u <= job.peak_bytes) v[i] = (int)(int16_t)((uint32_t)job.peaks[2 * at] | ((uint32_t)job.peaks[2 * at + 1] << 8));
+					at++;
+				}
+			peaks_seen += row_total;
+		}
+		// running sums: inside the thread, then over the threads in front of it (16-bit wrap, as the reference's PIXEL arithmetic)
+		int sum = 0;
+#pragma unroll
+		for (int i = 0; i < DXU_MAX; i++) { sum += v[i]; v[i] = sum; }
+		const uint32_t incl = wave_incl_scan((uint32_t)sum);
+		if (lane == 63) s_w[1][wave] = incl;
+		__syncthreads();
+		uint32_t before = incl - (uint32_t)sum;
+#pragma unroll
+		for (int k = 0; k < DXU_THREADS / 64; k++) if (k < wave) before += s_w[1][k];
+#pragma unroll
+		for (int i = 0; i < DXU_MAX; i++) if (i < per && c0 + i < c1) line[c0 + i] = (int16_t)((uint32_t)v[i] + before);
+		__syncthreads();                                  // s_w is written again by the next row
 	}
 }
 

@@ -67,6 +67,9 @@ public:
 	~DecodeBatch();
 	// half: CFHD_DECODED_RESOLUTION_HALF of 4:2:2 samples -- the last wavelet level is not run, the level-1 lowpass planes are the picture
 	int prepare(const FramePlan &plan, int nframes, int out_pixel_kind, bool own_output, bool half = false);
+	// interlaced 4:2:2 samples: the last level is the inverse frame transform (k_inv_frame_yuv422); 8-bit 4:2:2 output, full resolution
+	void set_interlaced(bool on) { interlaced_ = on; ent_.set_interlaced(on); }
+	bool interlaced() const { return interlaced_; }
 	int nframes() const { return n_; }
 	const FramePlan &plan() const { return plan_; }
 	int16_t *host_coeffs(int i) { return h_coeff_ + (size_t)i * plan_.final_elems; }   // host entropy decoder writes here
@@ -91,7 +94,7 @@ private:
 	void release();
 	int sync_jobs();
 	FramePlan plan_;
-	int n_ = 0, out_kind_ = 0; bool own_output_ = false, jobs_dirty_ = true, half_ = false;
+	int n_ = 0, out_kind_ = 0; bool own_output_ = false, jobs_dirty_ = true, half_ = false, interlaced_ = false;
 	void *stream_ = nullptr, *ev0_ = nullptr, *ev1_ = nullptr, *evl_[2] = {nullptr, nullptr};
 	float level_ms_[3] = {0, 0, 0};
 	int16_t *d_coeff_ = nullptr, *h_coeff_ = nullptr;

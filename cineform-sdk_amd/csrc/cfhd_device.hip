@@ -646,6 +646,7 @@ int DecodeBatch::launch_inverse(uint32_t dither_seed)
 		dev::k_inv_plane<<<grid, dev::NTHREADS, 0, st>>>(jobs);
 		HIPCHK(hipEventRecord((hipEvent_t)evl_[2 - lv], st));
 	}
+	if (interlaced_ && (half_ || is_packed16(out_kind_))) return -1;
 	if (half_ && is_packed16(out_kind_)) {
 		const BandDesc &b = plan_.ch[0].band[0][0];
 		dev::k_half_packed16<<<dim3((b.width / 8 + dev::NTHREADS - 1) / dev::NTHREADS, out_rows_, n_), dev::NTHREADS, 0, st>>>(j.halfp);
@@ -656,6 +657,9 @@ int DecodeBatch::launch_inverse(uint32_t dither_seed)
 		const BandDesc &b = plan_.ch[0].band[0][0];
 		dim3 grid(((b.width + dev::ITW - 1) / dev::ITW) * nch, (b.height + dev::ITH - 1) / dev::ITH, n_);
 		dev::k_inv_packed16<<<grid, dev::NTHREADS, 0, st>>>(j.l1, nch);
+	} else if (interlaced_) {
+		const BandDesc &b = plan_.ch[0].band[0][0];
+		dev::k_inv_frame_yuv422<<<dim3((b.width / 2 + dev::NTHREADS - 1) / dev::NTHREADS, b.height, n_), dev::NTHREADS, 0, st>>>(j.yuv, dither_seed);
 	} else if (strip_inverse()) {
 		const BandDesc &b = plan_.ch[0].band[0][0];
 		const int nseg = (b.width / dev::SBLK + dev::SSEG - 1) / dev::SSEG;

@@ -154,7 +154,8 @@ struct GpuEntropyDecoder::Host {
 	std::vector<std::vector<dev::DecBandJob>> bands;      // per frame
 	std::vector<std::vector<dev::DecLowpassJob>> lows;
 	std::vector<size_t> host_bytes;                       // bytes to copy H2D per frame (0: sample already in HBM)
-	dev::DecBandJob *flat_bands = nullptr; dev::DecLowpassJob *flat_lows = nullptr;   // pinned
+	std::vector<std::vector<dev::DecDiffJob>> diffs;     // per frame: the difference-coded band of every channel (interlaced samples)
+	dev::DecBandJob *flat_bands = nullptr; dev::DecLowpassJob *flat_lows = nullptr; dev::DecDiffJob *flat_diffs = nullptr;   // pinned
 };
 
 GpuEntropyDecoder::GpuEntropyDecoder() : host_(new Host) {}
@@ -162,9 +163,9 @@ GpuEntropyDecoder::~GpuEntropyDecoder() { release(); delete host_; }
 
 void GpuEntropyDecoder::release()
 {
-	void *dev[] = { d_samples_, d_tables_, d_bandjobs_, d_lowjobs_, d_errors_, d_plan_, d_idx_tables_, d_entries_, d_recs_, d_chunk_base_, d_chunk_job_, d_sums_, d_counters_, d_tile_start_, d_stats_, d_repair_, d_alts_, d_reindex_ };
+	void *dev[] = { d_samples_, d_tables_, d_bandjobs_, d_lowjobs_, d_errors_, d_plan_, d_idx_tables_, d_entries_, d_recs_, d_chunk_base_, d_chunk_job_, d_sums_, d_counters_, d_tile_start_, d_stats_, d_repair_, d_alts_, d_reindex_, d_diffjobs_ };
 	for (void *p : dev) if (p) (void)hipFree(p);
-	d_idx_tables_ = d_entries_ = d_recs_ = d_chunk_base_ = d_chunk_job_ = d_sums_ = d_counters_ = d_tile_start_ = d_stats_ = d_repair_ = d_alts_ = d_reindex_ = nullptr;
+	d_idx_tables_ = d_entries_ = d_recs_ = d_chunk_base_ = d_chunk_job_ = d_sums_ = d_counters_ = d_tile_start_ = d_stats_ = d_repair_ = d_alts_ = d_reindex_ = d_diffjobs_ = nullptr;
 	if (h_chunk_job_) (void)hipHostFree(h_chunk_job_);
 	if (h_counters_) (void)hipHostFree(h_counters_);
 	h_chunk_job_ = nullptr; h_counters_ = nullptr;
@@ -172,6 +173,7 @@ void GpuEntropyDecoder::release()
 	if (h_errors_) (void)hipHostFree(h_errors_);
 	if (host_->flat_bands) { (void)hipHostFree(host_->flat_bands); host_->flat_bands = nullptr; }
 	if (host_->flat_lows) { (void)hipHostFree(host_->flat_lows); host_->flat_lows = nullptr; }
+	if (host_->flat_diffs) { (void)hipHostFree(host_->flat_diffs); host_->flat_diffs = nullptr; }
 	for (void *&e : ev_) if (e) { (void)hipEventDestroy((hipEvent_t)e); e = nullptr; }
 	timed_ = false;
 	d_samples_ = h_samples_ = nullptr; d_tables_ = d_bandjobs_ = d_lowjobs_ = d_plan_ = nullptr; d_errors_ = h_errors_ = nullptr; n_ = 0; ext_samples_ = nullptr;
@@ -193,6 +195,8 @@ int GpuEntropyDecoder::prepare(const FramePlan &plan, int nframes, int16_t *d_co
 	HIPCHK(hipMalloc(&d_lowjobs_, max_lows * sizeof(dev::DecLowpassJob)));
 	HIPCHK(hipHostMalloc((void **)&host_->flat_bands, max_bands * sizeof(dev::DecBandJob), hipHostMallocDefault));
 	HIPCHK(hipHostMalloc((void **)&host_->flat_lows, max_lows * sizeof(dev::DecLowpassJob), hipHostMallocDefault));
+	HIPCHK(hipMalloc(&d_diffjobs_, max_lows * sizeof(dev::DecDiffJob)));
+	HIPCHK(hipHostMalloc((void **)&host_->flat_diffs, max_lows * sizeof(dev::DecDiffJob), hipHostMallocDefault));
 	HIPCHK(hipMalloc((void **)&d_errors_, sizeof(int)));
 	HIPCHK(hipHostMalloc((void **)&h_errors_, sizeof(int), hipHostMallocDefault));
 	*h_errors_ = 0;
@@ -238,7 +242,7 @@ int GpuEntropyDecoder::prepare(const FramePlan &plan, int nframes, int16_t *d_co
 		HIPCHK(hipMalloc(&d_plan_, sizeof(dp)));
 		HIPCHK(hipMemcpy(d_plan_, &dp, sizeof(dp), hipMemcpyHostToDevice));
 	}
-	host_->bands.assign(n_, {}); host_->lows.assign(n_, {}); host_->host_bytes.assign(n_, 0);
+	host_->bands.assign(n_, {}); host_->lows.assign(n_, {}); host_->diffs.assign(n_, {}); host_->host_bytes.assign(n_, 0);
 	for (void *&e : ev_) HIPCHK(hipEventCreate((hipEvent_t *)&e));
 	return 0;
 }
@@ -272,9 +276,12 @@ int GpuEntropyDecoder::set_sample_device(int i, const uint8_t *d_sample, const u
 		dev::DecPlan dp; dec_build_plan(plan_, out_kind_, &dp);
 		host_->bands[i].assign((size_t)dp.bands_per_frame, dev::DecBandJob());
 		host_->lows[i].assign((size_t)plan_.num_channels, dev::DecLowpassJob());
-		if (!dx_build_jobs(ps, plan_, dp, d_sample, d_coeffs_ + (size_t)i * coeff_stride_, out_kind_, 0, 1, host_->bands[i].data(), host_->lows[i].data(), skip_level1_)) return -4;
+		host_->diffs[i].assign((size_t)plan_.num_channels, dev::DecDiffJob());
+		if (!dx_build_jobs(ps, plan_, dp, d_sample, d_coeffs_ + (size_t)i * coeff_stride_, out_kind_, 0, 1, host_->bands[i].data(), host_->lows[i].data(), skip_level1_,
+		                   interlaced_ ? host_->diffs[i].data() : nullptr)) return -4;
 		return 0;
 	}
+	if (interlaced_) return -4;                        // the round-1 kernels know one code set
 	if (!dec_build_jobs(ps, plan_, d_sample, d_coeffs_ + (size_t)i * coeff_stride_, out_kind_, &host_->bands[i], &host_->lows[i], skip_level1_)) return -4;
 	return 0;
 }
@@ -292,7 +299,8 @@ int GpuEntropyDecoder::launch()
 		if (ev_headers_) HIPCHK(hipStreamWaitEvent(st, (hipEvent_t)ev_headers_, 0));
 		HIPCHK(hipEventRecord((hipEvent_t)ev_[0], st));
 		dev::k_dec_parse<<<n_, dev::DEC_PARSE_THREADS, 0, st>>>(ext_samples_, ext_stride_, ext_sizes_, n_,
-			(const dev::DecPlan *)d_plan_, d_coeffs_, coeff_stride_, (dev::DecBandJob *)d_bandjobs_, (dev::DecLowpassJob *)d_lowjobs_, d_errors_);
+			(const dev::DecPlan *)d_plan_, d_coeffs_, coeff_stride_, (dev::DecBandJob *)d_bandjobs_, (dev::DecLowpassJob *)d_lowjobs_, d_errors_,
+			interlaced_ && dx_ ? (dev::DecDiffJob *)d_diffjobs_ : nullptr);
 		parse_end_ = ev_payloads_ != nullptr;
 		if (parse_end_) { HIPCHK(hipEventRecord((hipEvent_t)ev_[4], st)); HIPCHK(hipStreamWaitEvent(st, (hipEvent_t)ev_payloads_, 0)); }
 		ev_headers_ = ev_payloads_ = nullptr;
@@ -319,6 +327,7 @@ int GpuEntropyDecoder::launch()
 			if ((int)host_->bands[f].size() != dp.bands_per_frame || (int)host_->lows[f].size() != nch) return -1;
 			for (int s = 0; s < dp.bands_per_frame; s++) host_->flat_bands[(size_t)s * n_ + f] = host_->bands[f][s];
 			for (int c = 0; c < nch; c++) host_->flat_lows[(size_t)f * nch + c] = host_->lows[f][c];
+			if (interlaced_) { if ((int)host_->diffs[f].size() != nch) return -1; for (int c = 0; c < nch; c++) host_->flat_diffs[(size_t)f * nch + c] = host_->diffs[f][c]; }
 		}
 		std::vector<dev::DxChunkDesc> cj;
 		const uint32_t nchunks = dx_number_chunks(host_->flat_bands, nb, &cj);
@@ -330,6 +339,7 @@ int GpuEntropyDecoder::launch()
 			if (host_->host_bytes[f]) HIPCHK(hipMemcpyAsync(d_samples_ + cap_ * f, h_samples_ + cap_ * f, host_->host_bytes[f], hipMemcpyHostToDevice, st));
 		HIPCHK(hipMemcpyAsync(d_bandjobs_, host_->flat_bands, (size_t)nb * sizeof(dev::DecBandJob), hipMemcpyHostToDevice, st));
 		HIPCHK(hipMemcpyAsync(d_lowjobs_, host_->flat_lows, (size_t)n_ * nch * sizeof(dev::DecLowpassJob), hipMemcpyHostToDevice, st));
+		if (interlaced_) HIPCHK(hipMemcpyAsync(d_diffjobs_, host_->flat_diffs, (size_t)n_ * nch * sizeof(dev::DecDiffJob), hipMemcpyHostToDevice, st));
 		HIPCHK(hipMemcpyAsync(d_chunk_job_, h_chunk_job_, (size_t)nchunks * sizeof(dev::DxChunkDesc), hipMemcpyHostToDevice, st));
 		HIPCHK(hipMemcpyAsync(d_counters_, h_counters_, 16, hipMemcpyHostToDevice, st));
 		(void)hipGetLastError();

@@ -41,7 +41,8 @@ inline bool build_dec_index_tables(int codebook, dev::DecIdxTables *T)
 	RawCode codes[300];
 	const int ncodes = raw_codes(codebook, codes);
 	const EntropyTables *et = entropy_tables(codebook);
-	for (int m = 0; m < 256; m++) T->mag_expand[m] = et->mag_expand[m];
+	for (int m = 0; m < 256; m++) { T->mag_expand[0][m] = entropy_tables(1)->mag_expand[m]; T->mag_expand[1][m] = entropy_tables(2)->mag_expand[m]; }
+	(void)et;
 	auto type_of = [](const RawCode &c) { return c.kind == 0 ? DX_T_RUN : (c.kind == 1 ? DX_T_VALUE : DX_T_END); };
 	// first level: code words of up to 12 bits directly, longer ones through their 12-bit prefix
 	uint32_t nlong = 0;
@@ -124,7 +125,7 @@ inline bool build_dec_index_tables(int codebook, dev::DecIdxTables *T)
 			if (e & 16) {
 				if (v2) break;
 				const int m = e >> 5;
-				if (T->mag_expand[m] != m || m > 0x7fff) return false;                     // the table relies on magnitude = index for such short code words
+				if (T->mag_expand[0][m] != m || T->mag_expand[1][m] != m || m > 0x7fff) return false;                     // the table relies on magnitude = index for such short code words
 				const int negative = (int)((rest >> (DX_K - len - 1)) & 1u);
 				if (!v1) v1 = negative ? -m : m; else v2 = negative ? -m : m;
 			} else {
@@ -270,9 +271,11 @@ inline void dec_build_plan(const FramePlan &plan, int out_pixel_kind, dev::DecPl
 // Frame f's rows of the [slot][frame] band job table (slots as dec_build_plan numbers them) and its lowpass jobs from a parsed sample.
 // Bands the caller does not want (skip_level1: half resolution) keep bytes = 0 and produce no work.
 inline bool dx_build_jobs(const ParsedSample &ps, const FramePlan &plan, const dev::DecPlan &dp, const uint8_t *sample_addr, int16_t *coeff_base, int out_pixel_kind,
-                          int f, int nframes, dev::DecBandJob *table, dev::DecLowpassJob *lowpass /* [num_channels] */, bool skip_level1 = false)
+                          int f, int nframes, dev::DecBandJob *table, dev::DecLowpassJob *lowpass /* [num_channels] */, bool skip_level1 = false,
+                          dev::DecDiffJob *diff = nullptr /* [num_channels]: interlaced samples (code set 18, difference coding, peak tables) are accepted */)
 {
 	for (int c = 0; c < plan.num_channels; c++) {
+		if (diff) diff[c] = dev::DecDiffJob{ nullptr, 0, 0, 0, nullptr, 0u, 0 };
 		const ParsedBand &lp = ps.lowpass[c];
 		const BandDesc &ll = plan.ch[c].band[2][0];
 		if (!lp.present || lp.width != ll.width || lp.height != ll.height) return false;
@@ -282,10 +285,16 @@ inline bool dx_build_jobs(const ParsedSample &ps, const FramePlan &plan, const d
 				const ParsedBand &pb = ps.high[c][lv][b];
 				const BandDesc &bd = plan.ch[c].band[lv][b];
 				dev::DecBandJob &bj = table[(size_t)dp.slot[c][lv][b] * nframes + f];
-				bj = dev::DecBandJob{ sample_addr, 0u, coeff_base + bd.offset, bd.height * bd.pitch, 1, 0u };
+				bj = dev::DecBandJob{ sample_addr, 0u, coeff_base + bd.offset, bd.height * bd.pitch, 1, 0u, 0 };
 				if (skip_level1 && lv == 0) continue;
-				if (!pb.present || pb.width != bd.width || pb.height != bd.height || (pb.offset & 3) || (pb.codebook != 1 && pb.codebook != 0) || (bd.offset & 7) || (bd.pitch & 7)) return false;
-				bj.bits = sample_addr + pb.offset; bj.bytes = pb.bytes; bj.quant = pb.quant;
+				if (!pb.present || pb.width != bd.width || pb.height != bd.height || (pb.offset & 3) || pb.codebook < 0 || pb.codebook > 2 || (bd.offset & 7) || (bd.pitch & 7)) return false;
+				if ((pb.codebook == 2 || pb.difference) && !diff) return false;
+				bj.bits = sample_addr + pb.offset; bj.bytes = pb.bytes; bj.quant = pb.quant; bj.table = pb.codebook == 2;
+				if (pb.difference) {
+					if (pb.peak_level && (size_t)pb.peak_offset + 2 > ps.size) return false;
+					diff[c] = dev::DecDiffJob{ coeff_base + bd.offset, bd.width, bd.height, bd.pitch, pb.peak_level ? sample_addr + pb.peak_offset : nullptr,
+					                           pb.peak_level ? (uint32_t)(ps.size - pb.peak_offset) : 0u, pb.peak_level };
+				}
 			}
 	}
 	return true;

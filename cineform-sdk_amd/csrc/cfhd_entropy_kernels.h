@@ -595,7 +595,11 @@ struct DecBandJob {
 	int16_t *dst; int n;                      // band raster (height * pitch), zeroed beforehand
 	int quant;
 	uint32_t chunk0;                          // cfhd_dec_kernels.h: first chunk of the band in the chunk arrays
+	int table;                                // 0: code set 17 (cubic companding), 1: code set 18 (linear; the difference-coded band of interlaced frames)
 };
+
+// The difference-coded band of one channel of an interlaced frame, after its code words were decoded: peak values (if any) and running sums.
+struct DecDiffJob { int16_t *band; int width, height, pitch; const uint8_t *peaks; uint32_t peak_bytes; int level; };
 
 struct DecLowpassJob { const uint8_t *src; int16_t *dst; int width, height, pitch, bias; };
 
@@ -833,7 +837,8 @@ struct DecTagReader {
 };
 
 __global__ void __launch_bounds__(DEC_PARSE_THREADS) k_dec_parse(const uint8_t *samples, size_t sample_stride, const uint32_t *sizes, int nframes, const DecPlan *P,
-                                                                 int16_t *coeffs, size_t coeff_stride, DecBandJob *bandjobs, DecLowpassJob *lowjobs, int *errors)
+                                                                 int16_t *coeffs, size_t coeff_stride, DecBandJob *bandjobs, DecLowpassJob *lowjobs, int *errors,
+                                                                 DecDiffJob *diffjobs /* [nframes * channels], may be null: progressive samples only */)
 {
 	const int f = blockIdx.x;                            // every lane walks the same tags; lane 0 writes the jobs
 	const int lane = wave_lane();
@@ -851,8 +856,10 @@ __global__ void __launch_bounds__(DEC_PARSE_THREADS) k_dec_parse(const uint8_t *
 			}
 	}
 	DecTagReader rd; rd.d = d; rd.base = ~(uint64_t)0; rd.w = 0; rd.lane = lane;
-	uint64_t pos = 0, pending_at = 0;
-	uint32_t pending = 0, seen_low = 0;
+	uint64_t pos = 0, pending_at = 0, peak_base = 0;
+	uint32_t pending = 0, seen_low = 0, peak_offset = 0;
+	int peak_level = 0;
+	if (writer && diffjobs) for (int c = 0; c < nch; c++) diffjobs[f * nch + c] = DecDiffJob{ nullptr, 0, 0, 0, nullptr, 0u, 0 };
 	uint64_t seen = 0;                                   // one bit per coded band: up to 4 channels x 9
 	int channel = 0, lv = -1, band = 0, bw = 0, bh = 0, bq = 1, bflags = 0, lw = 0, lh = 0;
 	int width = 0, height = 0, display_height = 0, num_channels = 0, encoded_format = 0;
@@ -898,6 +905,9 @@ __global__ void __launch_bounds__(DEC_PARSE_THREADS) k_dec_parse(const uint8_t *
 		case 38: lv = value - 1; if (lv < 0 || lv >= 3) bad = true; break;          // TAG_WAVELET_NUMBER
 		case 48: band = value; if (band < 1 || band > 3) bad = true; bflags = 0; break;   // TAG_BAND_NUMBER
 		case 72: bflags = value; break;                                              // TAG_BAND_CODING_FLAGS
+		case 75: peak_offset = (peak_offset & ~0xffffu) | (uint32_t)value; peak_base = pos; peak_level = 0; break;     // TAG_PEAK_TABLE_OFFSET_L (decoder.c:23978)
+		case 76: peak_offset = (peak_offset & 0xffffu) | ((uint32_t)value << 16); peak_level = 0; break;               // TAG_PEAK_TABLE_OFFSET_H
+		case 74: peak_level = value; break;                                          // TAG_PEAK_LEVEL
 		case 49: bw = value; break;                                                  // TAG_BAND_WIDTH
 		case 50: bh = value; break;                                                  // TAG_BAND_HEIGHT
 		case 53: bq = value; break;                                                  // TAG_BAND_QUANTIZATION
@@ -906,8 +916,13 @@ __global__ void __launch_bounds__(DEC_PARSE_THREADS) k_dec_parse(const uint8_t *
 			if (lv < 0 || pending == 0 || end < pos + 4 || end > size || channel >= nch || band < 1) { bad = true; break; }
 			const DecPlanBand pb = P->high[channel][lv][band];
 			const int codebook = bflags & 0xf;
-			if (bw != pb.width || bh != pb.height || (pos & 3u) || (codebook != 0 && codebook != 1)) { bad = true; break; }
-			if (writer) bandjobs[(size_t)P->slot[channel][lv][band] * nframes + f] = DecBandJob{ d + pos, (uint32_t)(end - 4 - pos), cbase + pb.offset, pb.height * pb.pitch, bq };
+			const bool difference = (bflags >> 4) & 1;
+			if (bw != pb.width || bh != pb.height || (pos & 3u) || codebook > 2 || ((codebook == 2 || difference) && !diffjobs)) { bad = true; break; }
+			if (peak_level && peak_base + peak_offset + 2 > size) { bad = true; break; }
+			if (writer) bandjobs[(size_t)P->slot[channel][lv][band] * nframes + f] = DecBandJob{ d + pos, (uint32_t)(end - 4 - pos), cbase + pb.offset, pb.height * pb.pitch, bq, 0u, codebook == 2 };
+			if (writer && difference) diffjobs[f * nch + channel] = DecDiffJob{ cbase + pb.offset, pb.width, pb.height, pb.pitch, peak_level ? d + peak_base + peak_offset : nullptr,
+			                                                                    peak_level ? (uint32_t)(size - (peak_base + peak_offset)) : 0u, peak_level };
+			peak_level = 0;
 			seen |= (uint64_t)1 << ((channel * 3 + lv) * 3 + band - 1);
 			pos = end; pending = 0;
 			break; }

@@ -1612,6 +1612,66 @@ __global__ void __launch_bounds__(NTHREADS) k_fwd_frame_yuv422(const FwdFrameJob
 }
 
 // =============================================================================================
+// Interlaced last level: the inverse of k_fwd_frame_yuv422 (Codec/decoder.c:21493 TransformInverseFrameToYUV, :24304 threaded;
+// Codec/temporal.c:5961 InvertInterlacedRow16s10bitToYUV, :6498 ToUYVY).  Band row r of the level-1 wavelet gives two picture rows: the
+// horizontal synthesis of (LL, LH) is the temporal lowpass row, that of (HL, HH) -- HL un-differenced by k_dec_undiff -- the temporal
+// highpass row (spatial.c:19302 InvertHorizontalRow16s8sTo16sBuffered: the usual 2/6 synthesis, >> 1, saturated); row 2r = low - high,
+// row 2r + 1 = low + high (saturating), then 10 -> 8 bits like every other 4:2:2 output.  No vertical filter, hence no halo rows and no
+// LDS: one thread per chroma column (two luma columns: 4 + 2 + 2 samples = 8 bytes of each of the two rows), any width.
+// =============================================================================================
+__device__ __forceinline__ void frame_synth(const int16_t *lo, const int16_t *hi, int c, int w, int &even, int &odd)
+{
+	const int l0 = lo[c], h = hi[c];
+	int e, o;
+	if (c == 0) inv_horiz(0, l0, lo[1], lo[2], h, 0, e, o);
+	else if (c == w - 1) inv_horiz(lo[c - 1], l0, 0, lo[c - 2], h, 2, e, o);
+	else inv_horiz(lo[c - 1], l0, lo[c + 1], 0, h, 1, e, o);
+	even = sat16(e >> 1); odd = sat16(o >> 1);
+}
+
+__global__ void __launch_bounds__(NTHREADS) k_inv_frame_yuv422(const InvYuvJob *jobs, uint32_t launch_seed)
+{
+	const InvYuvJob &job = jobs[blockIdx.z];
+	const int w = job.width, cw = w >> 1;                // luma / chroma band columns
+	const int cc = (int)(blockIdx.x * NTHREADS + threadIdx.x), r = blockIdx.y;
+	if (cc >= cw || r >= job.height) return;
+	const uint32_t seed = job.dither_seed ^ launch_seed;
+	const int sh = job.shift;
+	// temporal low / high samples: 4 luma (columns 2cc, 2cc + 1: even, odd each), 2 V, 2 U
+	int tl[8], th[8];
+	{
+		const size_t o = (size_t)r * job.band_pitch[0];
+		frame_synth(job.band[0][0] + o, job.band[0][1] + o, 2 * cc, w, tl[0], tl[1]);
+		frame_synth(job.band[0][0] + o, job.band[0][1] + o, 2 * cc + 1, w, tl[2], tl[3]);
+		frame_synth(job.band[0][2] + o, job.band[0][3] + o, 2 * cc, w, th[0], th[1]);
+		frame_synth(job.band[0][2] + o, job.band[0][3] + o, 2 * cc + 1, w, th[2], th[3]);
+	}
+#pragma unroll
+	for (int x = 0; x < 2; x++) {                         // V, U
+		const size_t o = (size_t)r * job.band_pitch[1 + x];
+		frame_synth(job.band[1 + x][0] + o, job.band[1 + x][1] + o, cc, cw, tl[4 + 2 * x], tl[5 + 2 * x]);
+		frame_synth(job.band[1 + x][2] + o, job.band[1 + x][3] + o, cc, cw, th[4 + 2 * x], th[5 + 2 * x]);
+	}
+#pragma unroll
+	for (int par = 0; par < 2; par++) {
+		const int orow = 2 * r + par;
+		if (orow >= job.display_height) continue;
+		const uint32_t dz = sh >= 2 ? dither_word(seed, orow, cc >> 2) >> (8 * (cc & 3)) : 0u;      // same bit assignment as the progressive kernels
+		uint32_t b[8];
+#pragma unroll
+		for (int i = 0; i < 8; i++) {
+			const int v = par ? adds16(tl[i], th[i]) : subs16(tl[i], th[i]);
+			b[i] = to8(v, sh, (int)((dz >> i) & 1u));     // the temporal lowpass is the sum of the two rows: clamp at zero, halve, dither, >> shift, saturate (temporal.c:6071-6120)
+		}
+		const uint32_t y0 = b[0], y1 = b[1], y2 = b[2], y3 = b[3], v0 = b[4], v1 = b[5], u0 = b[6], u1 = b[7];
+		uint2 o2;
+		if (job.uyvy) { o2.x = u0 | (y0 << 8) | (v0 << 16) | (y1 << 24); o2.y = u1 | (y2 << 8) | (v1 << 16) | (y3 << 24); }
+		else { o2.x = y0 | (u0 << 8) | (y1 << 16) | (v0 << 24); o2.y = y2 | (u1 << 8) | (y3 << 16) | (v1 << 24); }
+		*(uint2 *)(job.out + (size_t)orow * job.out_pitch + 8 * (size_t)cc) = o2;
+	}
+}
+
+// =============================================================================================
 // Bayer input (ConvertBYR4ToFrame16s, frame.c:4993, curve branch :5219-5393): every 2x2 quad of the mosaic gives one sample of the
 // four component planes: the encode curve LUT is applied to each photosite (>> 2 to the LUT's 14 bits), then g = (g1+g2)>>1,
 // rg = ((r-g)>>1) + mid, bg = ((b-g)>>1) + mid, gd = (g1-g2+2*mid)>>1 with mid = 2^(precision-1).  One lane per quad; a wave reads

@@ -54,6 +54,9 @@ void orc_inv_spatial_to_yuv422(PIXEL16 *const bands[3][4], const int band_pitch[
                                int precision, int uyvy, int dither, uint8_t *out, int out_pitch);
 
 /* ---- quantizer tables (host side of the path) ---- */
+/* interlaced last level (decoder.c:21493 + temporal.c:5961): temporal pair after the horizontal synthesis, same packing */
+void orc_inv_frame_to_yuv422(PIXEL16 *const bands[3][4], const int band_pitch[3], int luma_w, int h,
+                             int precision, int uyvy, int dither, uint8_t *out, int out_pitch);
 void orc_inv_spatial_to_packed16(PIXEL16 *const bands[4][4], int band_pitch, int w, int h, int precision, int num_channels,
                                  const int *word_of_channel, int tail_start, int alpha_channel, uint16_t *out, int out_pitch_words);
 void orc_inv_spatial_to_b64a(PIXEL16 *const bands[4][4], int band_pitch, int w, int h, int precision, uint16_t *out, int out_pitch_words);

@@ -160,6 +160,47 @@ void orc_inv_spatial_to_yuv422(PIXEL16 *const bands[3][4], const int band_pitch[
 	for (ch = 0; ch < 3; ch++) { free(el[ch]); free(ol[ch]); free(eh[ch]); free(oh[ch]); free(even_px[ch]); free(odd_px[ch]); }
 }
 
+/* Interlaced ("frame" transform) last level -> packed 8-bit 4:2:2.
+ * Codec/decoder.c:21493 TransformInverseFrameToYUV (:24304 threaded): per band row r of the level-1 wavelet, per channel,
+ * spatial.c:19302 InvertHorizontalRow16s8sTo16sBuffered turns (LL, LH) into the temporal lowpass row and (HL, HH) into the temporal
+ * highpass row (the same horizontal synthesis as everywhere, >> 1, saturated); HL arrives as running sums (the decoder undoes the
+ * difference coding, decoder.c:20822).  temporal.c:5961 InvertInterlacedRow16s10bitToYUV (:6498 ToUYVY) then gives picture row 2r =
+ * low - high and row 2r + 1 = low + high (saturating 16-bit), clamped to [0, 2047] by the adds / subs_epu16 pair (:6071-6078),
+ * halved, + dither, >> 2, packed with unsigned saturation.  The columns behind the last group of 8 chroma columns take the scalar
+ * loop (:6276-6390): (low -+ high) / 2 >> 2 without dither -- inside the same interval.  Channel order Y, V, U as everywhere. */
+void orc_inv_frame_to_yuv422(PIXEL16 *const bands[3][4], const int band_pitch[3], int luma_w, int h,
+                             int precision, int uyvy, int dither, uint8_t *out, int out_pitch)
+{
+	const int shift = precision - 8;
+	int ch, r, k, x;
+	PIXEL16 *low[3], *high[3];
+	for (ch = 0; ch < 3; ch++) {
+		const int w = ch ? luma_w / 2 : luma_w;
+		low[ch] = (PIXEL16 *)malloc((size_t)w * 4); high[ch] = (PIXEL16 *)malloc((size_t)w * 4);
+	}
+	for (r = 0; r < h; r++) {
+		for (ch = 0; ch < 3; ch++) {
+			const int w = ch ? luma_w / 2 : luma_w;
+			const size_t o = (size_t)r * band_pitch[ch];
+			inv_horizontal_row(bands[ch][0] + o, bands[ch][1] + o, w, 0, low[ch]);
+			inv_horizontal_row(bands[ch][2] + o, bands[ch][3] + o, w, 0, high[ch]);
+		}
+		for (k = 0; k < 2; k++) {
+			uint8_t *o = out + (size_t)(2 * r + k) * out_pitch;
+			for (x = 0; x < luma_w; x++) {           /* 2 * luma_w luma samples, luma_w samples of each chroma channel */
+				int px[4];                               /* y0, y1, v, u */
+				const int l[4] = { low[0][2 * x], low[0][2 * x + 1], low[1][x], low[2][x] };
+				const int g[4] = { high[0][2 * x], high[0][2 * x + 1], high[1][x], high[2][x] };
+				int i;
+				for (i = 0; i < 4; i++) px[i] = to8(k ? adds(l[i], g[i]) : subs(l[i], g[i]), shift, dither);
+				if (uyvy) { o[4 * x] = (uint8_t)px[3]; o[4 * x + 1] = (uint8_t)px[0]; o[4 * x + 2] = (uint8_t)px[2]; o[4 * x + 3] = (uint8_t)px[1]; }
+				else      { o[4 * x] = (uint8_t)px[0]; o[4 * x + 1] = (uint8_t)px[3]; o[4 * x + 2] = (uint8_t)px[1]; o[4 * x + 3] = (uint8_t)px[2]; }
+			}
+		}
+	}
+	for (ch = 0; ch < 3; ch++) { free(low[ch]); free(high[ch]); }
+}
+
 /* 12-bit sample of an RGB 4:4:4 plane -> 16-bit output word.  v = lowfilter +/- high before the >>1.
  * InvertHorizontalStrip16s.c:16571 InvertHorizontalStrip16sToRow16u: interior columns clamp v to
  * [0, 2^(precision+1) - 1] with the adds_epi16 / subs_epu16 "protection" pair (:16596, :16724-16726), halve, and shift left by

@@ -135,6 +135,17 @@ void emu_inv_yuv422(int16_t **bands /*[3][4]*/, const int *band_pitch, int w, in
 	hipemu::launch(grid, dim3(NTHREADS), [&] { k_inv_yuv422(&job, 0u); });
 }
 
+// interlaced frames: the inverse frame transform (any width)
+void emu_inv_frame_yuv422(int16_t **bands /*[3][4]*/, const int *band_pitch, int w, int h, int display_height, int uyvy, int shift,
+                          unsigned dither_seed, uint8_t *out, int out_pitch)
+{
+	InvYuvJob job;
+	for (int c = 0; c < 3; c++) { job.band_pitch[c] = band_pitch[c]; for (int b = 0; b < 4; b++) job.band[c][b] = bands[c * 4 + b]; }
+	job.width = w; job.height = h; job.display_height = display_height; job.uyvy = uyvy; job.shift = shift;
+	job.dither_seed = dither_seed; job.out = out; job.out_pitch = out_pitch;
+	hipemu::launch(dim3((w / 2 + NTHREADS - 1) / NTHREADS, h, 1), dim3(NTHREADS), [&] { k_inv_frame_yuv422(&job, 0u); });
+}
+
 // the register-strip variant of the same level (luma band width a multiple of 16; segments of 124 blocks of 8 columns)
 int emu_inv_yuv422_strip(int16_t **bands /*[3][4]*/, const int *band_pitch, int w, int h, int display_height, int uyvy, int shift,
                          unsigned dither_seed, uint8_t *out, int out_pitch)
@@ -274,7 +285,7 @@ extern "C" int emu_entropy_decode(const uint8_t *sample, size_t size, int pixel_
 		std::vector<int16_t> pyr((size_t)plan.coeff_elems * 2, 77);
 		dev::DecPlan dp; dec_build_plan(plan, pixel_kind, &dp);
 		std::vector<dev::DecBandJob> bj((size_t)dp.bands_per_frame * 2); std::vector<dev::DecLowpassJob> lj((size_t)plan.num_channels * 2);
-		hipemu::launch(dim3(2), dim3(dev::DEC_PARSE_THREADS), [&] { dev::k_dec_parse(two, stride, sizes, 2, &dp, pyr.data(), plan.coeff_elems, bj.data(), lj.data(), &errors); });
+		hipemu::launch(dim3(2), dim3(dev::DEC_PARSE_THREADS), [&] { dev::k_dec_parse(two, stride, sizes, 2, &dp, pyr.data(), plan.coeff_elems, bj.data(), lj.data(), &errors, nullptr); });
 		if (errors) return -20 - errors;
 		hipemu::launch(dim3((unsigned)bj.size()), dim3(dev::DECP_THREADS), [&] { dev::k_dec_bands_par(bj.data(), (const dev::DecTables *)tables.data(), &errors); });
 		hipemu::launch(dim3(4, (unsigned)lj.size()), dim3(256), [&] { dev::k_dec_lowpass(lj.data()); });
@@ -318,6 +329,7 @@ extern "C" int emu_entropy_decode_dx(const uint8_t *sample, size_t size, int pix
 	const int nframes = mode == 2 ? 2 : 1, nch = plan.num_channels, njobs = dp.bands_per_frame * nframes;
 	std::vector<dev::DecBandJob> jobs((size_t)njobs);
 	std::vector<dev::DecLowpassJob> lows((size_t)nch * nframes);
+	std::vector<dev::DecDiffJob> diffs((size_t)nch * nframes);            // interlaced samples: the difference-coded band of every channel
 	std::vector<int16_t> pyr((size_t)plan.coeff_elems * nframes, 77);       // the tile kernel must write every coefficient of every band itself
 	const size_t stride = (size + 256 + 255) & ~(size_t)255;
 	std::vector<uint8_t> raw(stride * 2 + 512, 0);
@@ -328,13 +340,13 @@ extern "C" int emu_entropy_decode_dx(const uint8_t *sample, size_t size, int pix
 	std::vector<dev::DxChunkDesc> chunk_job(max_chunks); std::vector<uint32_t> counters(4, 0);
 	if (mode == 2) {
 		const uint32_t sizes[2] = { (uint32_t)size, (uint32_t)size };
-		hipemu::launch(dim3(2), dim3(dev::DEC_PARSE_THREADS), [&] { dev::k_dec_parse(two, stride, sizes, 2, &dp, pyr.data(), plan.coeff_elems, jobs.data(), lows.data(), &errors); });
+		hipemu::launch(dim3(2), dim3(dev::DEC_PARSE_THREADS), [&] { dev::k_dec_parse(two, stride, sizes, 2, &dp, pyr.data(), plan.coeff_elems, jobs.data(), lows.data(), &errors, diffs.data()); });
 		if (errors) return -20 - errors;
 		hipemu::launch(dim3(1), dim3(1024), [&] { dev::k_dec_plan(jobs.data(), njobs, max_chunks, counters.data(), &errors); });
 		hipemu::launch(dim3((unsigned)(njobs + dev::DX_WAVES - 1) / dev::DX_WAVES), dim3(dev::DX_THREADS), [&] { dev::k_dec_plan_fill(jobs.data(), njobs, chunk_job.data(), counters.data()); });
 		if (errors) return -40 - errors;
 	} else {
-		if (!dx_build_jobs(ps, plan, dp, two, pyr.data(), pixel_kind, 0, 1, jobs.data(), lows.data())) return -4;
+		if (!dx_build_jobs(ps, plan, dp, two, pyr.data(), pixel_kind, 0, 1, jobs.data(), lows.data(), false, diffs.data())) return -4;
 		std::vector<dev::DxChunkDesc> cj;
 		counters[0] = dx_number_chunks(jobs.data(), njobs, &cj);
 		if (counters[0] > max_chunks) return -6;
@@ -357,6 +369,7 @@ extern "C" int emu_entropy_decode_dx(const uint8_t *sample, size_t size, int pix
 	std::vector<uint32_t> tile_start(tp.total + 1, 0xdeadbeefu);
 	hipemu::launch(dim3((tp.total + dev::DX_THREADS - 1) / dev::DX_THREADS), dim3(dev::DX_THREADS), [&] { dev::k_dec_tile_index(jobs.data(), tp, entries.data(), chunk_base.data(), sums.data(), tile_start.data()); });
 	hipemu::launch(dim3((unsigned)grid), dim3(dev::DX_TILE_THREADS), [&] { dev::k_dec_tiles(jobs.data(), tp, &tables, entries.data(), chunk_base.data(), sums.data(), tile_start.data()); });
+	hipemu::launch(dim3((unsigned)diffs.size()), dim3(dev::DXU_THREADS), [&] { dev::k_dec_undiff(diffs.data(), &errors); });
 	hipemu::launch(dim3(4, (unsigned)lows.size()), dim3(256), [&] { dev::k_dec_lowpass(lows.data()); });
 	if (errors) return -10 - errors;
 	memcpy(coeffs, pyr.data() + (size_t)(nframes - 1) * plan.coeff_elems, (size_t)plan.coeff_elems * 2);

@@ -73,14 +73,15 @@ def test_encode_matches_golden_small_fixture():
     assert mask_volatile_metadata(mine) == mask_volatile_metadata(want)
 
 
-def _check_decode(sample, source, w, h, pixfmt=PIX_YUY2):
-    out, pitch, aw, ah = amd_decode_sample(sample, pixfmt)
+def _check_decode(sample, source, w, h, pixfmt=PIX_YUY2, interlaced=False, decoder=None):
+    out, pitch, aw, ah = amd_decode_sample(sample, pixfmt, decoder=decoder)
     assert (aw, ah) == (w, h)
     img = out.reshape(ah, pitch)[:, : w * 2]
-    plan = Plan(w, h, pixkind=2 if pixfmt == PIX_2VUY else 1)
+    plan = Plan(w, h, pixkind=2 if pixfmt == PIX_2VUY else 1, progressive=0 if interlaced else 1)
     coeffs = host_decode_pyramid(sample, plan)
-    lo = oracle_inverse_yuv422(plan, coeffs, 0, uyvy=int(pixfmt == PIX_2VUY))[:h]
-    hi = oracle_inverse_yuv422(plan, coeffs, 1, uyvy=int(pixfmt == PIX_2VUY))[:h]
+    inverse = oracle_inverse_interlaced_yuv422 if interlaced else oracle_inverse_yuv422
+    lo = inverse(plan, coeffs, 0, uyvy=int(pixfmt == PIX_2VUY))[:h]
+    hi = inverse(plan, coeffs, 1, uyvy=int(pixfmt == PIX_2VUY))[:h]
     ok = (img == lo) | (img == hi)
     assert ok.all(), "%d of %d bytes are outside the dither interval of the exact reconstruction" % ((~ok).sum(), ok.size)
     frac = (img[lo != hi] == hi[lo != hi]).mean()
@@ -438,18 +439,59 @@ def test_b64a_decode_equals_reference(w, h):
     L.CFHD_CloseDecoder(dec_ref)
 
 
-def test_interlaced_samples_are_refused_by_the_decoder():
-    """The inverse field transform is not built: CFHD_DecodeSample refuses an interlaced sample (BADFORMAT, output zero-filled)
-    instead of running the progressive inverse on it."""
+@pytest.mark.parametrize("w,h,pixfmt", [(320, 240, PIX_YUY2), (720, 486, PIX_2VUY), (1920, 1080, PIX_YUY2)])
+def test_interlaced_decode_reference_samples(w, h, pixfmt):
+    """Config D, 1080i half (decode): samples written by the reference with CFHD_ENCODING_FLAGS_YUV_INTERLACED.  The band
+    decoder reads subband 8 of every channel in the second code set, k_dec_undiff turns the row differences back into coefficients and
+    k_inv_frame_yuv422 runs the inverse frame transform.  Same bar as the progressive decode: every byte inside the dither interval of
+    the exact reconstruction, the reference's own output inside it too, PSNR within 0.1 dB of the reference's.  One decoder handle takes
+    an interlaced sample, a progressive one and an interlaced one again."""
+    if (w, h) == (1920, 1080):
+        frames, pitch = qbist_frames(10, 2)
+    else:
+        frames, pitch = [synth_yuy2(w, h, s)[0] for s in (2, 6)], w * 2
+        for k, f in enumerate(frames):
+            v = f.reshape(h, pitch); v[1::2] = np.roll(v[1::2], 8 * (k + 1), axis=1)
+    inter = ref_encode_frames(frames, pitch, w, h, pixfmt, flags=1)
+    prog = ref_encode_frames(frames[:1], pitch, w, h, pixfmt)
+    L = product()
+    dec = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
+    a = _check_decode(inter[0], frames[0], w, h, pixfmt, interlaced=True, decoder=dec)
+    _check_decode(prog[0], frames[0], w, h, pixfmt, decoder=dec)
+    b = _check_decode(inter[1], frames[1], w, h, pixfmt, interlaced=True, decoder=dec)
+    L.CFHD_CloseDecoder(dec)
+    assert psnr_yuy2(a, frames[0].reshape(h, -1)[:, : w * 2]) > 38 and psnr_yuy2(b, frames[1].reshape(h, -1)[:, : w * 2]) > 38
+
+
+def test_interlaced_decode_peak_table_frames():
+    """Field flicker: the difference band of the sample carries a peak table (values beyond +-250 quantization steps); k_dec_undiff
+    takes them from the table in raster order."""
+    w, h = 320, 64
+    calm = synth_yuy2(w, h, 3)[0]
+    frames = [calm, field_flicker_frame(w, h)[0]]
+    samples = ref_encode_frames(frames, w * 2, w, h, PIX_YUY2, flags=1)
+    assert len(samples[1]) != len(samples[0])
+    for smp, f in zip(samples, frames):
+        _check_decode(smp, f, w, h, PIX_YUY2, interlaced=True)
+    os.environ["CFHD_AMD_ENTROPY"] = "host"          # the host entropy decoder with the same inverse kernels
+    try:
+        for smp, f in zip(samples, frames):
+            _check_decode(smp, f, w, h, PIX_YUY2, interlaced=True)
+    finally:
+        del os.environ["CFHD_AMD_ENTROPY"]
+
+
+def test_interlaced_samples_at_half_resolution_are_refused():
+    """Half-resolution output of interlaced samples is not built: CFHD_DecodeSample says BADFORMAT and zero-fills the output."""
     w, h = 320, 240
     sample = amd_encode_frames([synth_yuy2(w, h, 3)[0]], w * 2, w, h, PIX_YUY2, flags=1)[0]
     L = product()
     dec = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
     aw = ctypes.c_int(); ah = ctypes.c_int(); af = ctypes.c_uint32()
     sb = ctypes.create_string_buffer(sample, len(sample))
-    assert L.CFHD_PrepareToDecode(dec, 0, 0, PIX_YUY2, 1, 0, sb, 512, ctypes.byref(aw), ctypes.byref(ah), ctypes.byref(af)) == 0
-    out = np.full(w * 2 * h, 7, np.uint8)
-    assert L.CFHD_DecodeSample(dec, sb, len(sample), out.ctypes.data_as(ctypes.c_void_p), w * 2) == 3   # CFHD_ERROR_BADFORMAT
+    assert L.CFHD_PrepareToDecode(dec, 0, 0, PIX_YUY2, 2, 0, sb, 512, ctypes.byref(aw), ctypes.byref(ah), ctypes.byref(af)) == 0
+    out = np.full(w * h, 7, np.uint8)
+    assert L.CFHD_DecodeSample(dec, sb, len(sample), out.ctypes.data_as(ctypes.c_void_p), w) == 3   # CFHD_ERROR_BADFORMAT
     assert not out.any()
     L.CFHD_CloseDecoder(dec)
 

@@ -634,3 +634,59 @@ def test_dx_decoder_emulated_survives_damaged_samples(mode):
         flagged += rc != 0
         assert np.all(got[plan.coeff_elems:] == 99)
     assert flagged >= 1
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Interlaced samples: code set 18 + difference coding + peak tables (k_dec_parse / k_dec_tiles / k_dec_undiff), inverse frame transform
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("w,h,seed,peaks", [(192, 96, 1, 0), (336, 252, 3, 1), (720, 480, 4, 1)])
+def test_dx_decoder_emulated_interlaced_samples(w, h, seed, peaks):
+    """The field-difference band of every channel arrives in the second code set, difference coded along the row and -- when a value lies
+    beyond the peak threshold -- with its large values in a peak table behind the band.  The emulated kernels must rebuild exactly the
+    pyramid of the product's host decoder (pinned against the reference's by test_oracle_vs_ref / test_host_bitstream)."""
+    frame, pitch = field_flicker_frame(w, h) if peaks else synth_yuy2(w, h, seed)       # field flicker: quantized steps beyond +-250 in the difference band
+    if peaks:
+        rng = np.random.default_rng(seed)
+        frame = np.clip(frame.astype(np.int32) + rng.integers(-6, 7, frame.shape), 0, 255).astype(np.uint8)
+    plan = Plan(w, h, progressive=0)
+    coeffs = oracle_forward_interlaced_yuv422(plan, frame, pitch)
+    sample = product_write_sample_host(plan, coeffs, 1, meta_global=b"GUID\x10\x00\x00G" + bytes(16), progressive=0)
+    levels = [int.from_bytes(sample[i + 2:i + 4], "big") for i in range(0, len(sample) - 4, 4) if sample[i:i + 2] == b"\xff\xb6"]      # TAG_PEAK_LEVEL (optional)
+    assert any(levels) == bool(peaks)
+    want = host_decode_pyramid(sample, plan)
+    for mode, grid in ((0, 3), (2, 2)):
+        rc, got = _dx_decode(sample, plan, mode, grid)
+        assert rc == 0, (mode, rc)
+        for (c, lv, b) in plan.band:
+            if b == 0 and lv != 2: continue
+            cols = plan.band[(c, lv, b)]["width"]
+            assert np.array_equal(plan.view(got, c, lv, b)[:, :cols], plan.view(want, c, lv, b)[:, :cols]), (mode, c, lv, b)
+
+
+@pytest.mark.parametrize("w,h,dh", [(32, 8, 16), (96, 20, 40), (360, 30, 58), (128, 17, 34), (132, 33, 66), (260, 19, 37), (960, 6, 12)])
+@pytest.mark.parametrize("uyvy", [0, 1])
+def test_inv_frame_yuv422(w, h, dh, uyvy):
+    """Emulated inverse frame transform vs the oracle (itself pinned against the reference decoder): every output byte must equal the
+    oracle's with dither 0 or with dither 1, and rows beyond the display height stay untouched."""
+    rng = np.random.default_rng(w + h + uyvy)
+    bands, pitches = [], []
+    for ch in range(3):
+        cw = w if ch == 0 else w // 2
+        pitch = (cw + 7) // 8 * 8 + (8 if ch == 2 else 0); pitches.append(pitch)
+        bs = [rng.integers(-50, 50, size=(h, pitch)).astype(np.int16) for _ in range(4)]
+        bs[0][:, :cw] = rand_plane(rng, cw, h, 11)
+        for k in range(1, 4): bs[k][:, :cw] = rand_plane(rng, cw, h, 9, signed=True)
+        bs[2][:, :cw] *= 3                                      # temporal highpass beyond the lowpass: low - high below zero, low + high above the range
+        bands.append(bs)
+    ptrs = (c_i16p * 12)(*[p16(a) for ch in range(3) for a in bands[ch]])
+    outs = []
+    for dither in (0, 1):
+        o = np.zeros((2 * h, 4 * w), np.uint8)
+        oracle().orc_inv_frame_to_yuv422(ptrs, iarr(pitches), w, h, 10, uyvy, dither, p8(o), 4 * w)
+        outs.append(o[:dh])
+    e = np.full((2 * h, 4 * w + 16), 7, np.uint8)
+    emu().emu_inv_frame_yuv422(ptrs, iarr(pitches), w, h, dh, uyvy, 2, 1234, p8(e), 4 * w + 16)
+    assert np.all(e[:, 4 * w:] == 7) and np.all(e[dh:] == 7)
+    e = e[:dh, :4 * w]
+    assert np.all((e == outs[0]) | (e == outs[1]))
+    assert np.any(e != outs[0]) and np.any(e != outs[1])

@@ -203,3 +203,27 @@ def test_interlaced_level1_oracle_equals_reference_coefficients(w, h):
                 want[:, :bw] = np.cumsum(want[:, :bw].astype(np.int64), axis=1).astype(np.int16)
             assert np.abs(plan.view(coeffs, c, 0, b)).max() <= 250
             assert np.array_equal(plan.view(deq, c, 0, b)[:, :bw], want[:, :bw]), (c, b)
+
+
+@pytest.mark.parametrize("w,h,fmt,kind", [(320, 240, PIX_YUY2, "plain"), (720, 486, PIX_2VUY, "plain"), (1920, 1080, PIX_YUY2, "qbist"), (336, 252, PIX_YUY2, "peaks")])
+def test_reference_interlaced_decode_lies_in_oracle_dither_interval(w, h, fmt, kind):
+    """Pins the oracle's inverse field transform (orc_inv_frame_to_yuv422) and the host twin of the difference / peak decode
+    (finish_difference_band) on the reference decoder: every byte it produces for a reference interlaced sample lies between the
+    oracle's dither-0 and dither-1 reconstructions (it adds rand() & 1 before the 10 -> 8 bit shift)."""
+    if kind == "qbist": frames, pitch = qbist_frames(10, 1, w, h, fmt); frame = frames[0]
+    elif kind == "peaks": frame, pitch = field_flicker_frame(w, h)
+    else: frame, pitch = synth_yuy2(w, h, 7)
+    sample = ref_encode_frames([frame], pitch, w, h, fmt, flags=1)[0]
+    uyvy = int(fmt == PIX_2VUY)
+    plan = Plan(w, h, pixkind=2 if uyvy else 1, progressive=0)
+    coeffs = host_decode_pyramid(sample, plan)
+    lo = oracle_inverse_interlaced_yuv422(plan, coeffs, 0, uyvy)[:h]
+    hi = oracle_inverse_interlaced_yuv422(plan, coeffs, 1, uyvy)[:h]
+    for attempt in range(6):
+        rout, rpitch = ref_decode_sample(sample, w, h, fmt)
+        rimg = rout.reshape(h, rpitch)[:, : w * 2]
+        ok = (rimg == lo) | (rimg == hi)
+        if ok.all(): break
+    assert ok.all(), "%d bytes outside" % (~ok).sum()
+    src = np.asarray(frame).reshape(h, pitch)[:, : w * 2]
+    assert psnr_yuy2(rimg, src) > 30
