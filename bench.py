@@ -20,10 +20,21 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
-WORKLOADS = {"1080p": (1920, 1080, 512), "2160p": (3840, 2160, 128)}      # width, height, default frames per step
+# BASELINE.json configs: [1] = "1080p" (the metric's configuration; "2160p" is the same path on the 3840x2160 Qbist frames north_star names),
+# [2] = "rg48-2160p" (encode), [3] = "b64a-4320p" (encode + decode; the 8-GPU sharding is --gpus N), [4] = "byr4-2160p" (encode) and "1080i".
+# fmt / enc / flags are the CFHD_PrepareToEncode arguments; mode 0 = encode + decode, 1 = encode only; bpp = bytes per pixel of the packed frame;
+# comps = coefficient planes per frame in units of width x height samples (4:2:2: 1 + 1/2 + 1/2; Bayer: four quarter-size planes)
+WORKLOADS = {
+    "1080p":      dict(w=1920, h=1080, batch=512, unique=32, fmt="YUY2", enc=0, flags=0, mode=0, bpp=2, comps=2, label="YUY2 4:2:2"),
+    "2160p":      dict(w=3840, h=2160, batch=128, unique=8,  fmt="YUY2", enc=0, flags=0, mode=0, bpp=2, comps=2, label="YUY2 4:2:2"),
+    "rg48-2160p": dict(w=3840, h=2160, batch=48,  unique=4,  fmt="RG48", enc=1, flags=0, mode=1, bpp=6, comps=3, label="RG48 RGB 4:4:4 12-bit"),
+    "b64a-4320p": dict(w=7680, h=4320, batch=8,   unique=2,  fmt="b64a", enc=2, flags=0, mode=0, bpp=8, comps=4, label="b64a RGBA 4:4:4:4"),
+    "byr4-2160p": dict(w=3840, h=2160, batch=96,  unique=4,  fmt="BYR4", enc=3, flags=0, mode=1, bpp=2, comps=1, label="BYR4 12-bit Bayer RAW"),
+    "1080i":      dict(w=1920, h=1080, batch=512, unique=32, fmt="YUY2", enc=0, flags=1, mode=0, bpp=2, comps=2, label="YUY2 4:2:2 interlaced (frame transform)"),
+}
 
 
-def cpu_baseline(frames, pitch, W, H, seconds_budget=20.0):
+def cpu_baseline(frames, pitch, W, H, seconds_budget=20.0, fmt=None, enc=0, flags=0, decode=True, bpp=2, label="YUY2"):
     """Reference SSE2 path on the host cores: async pool encode (POOL_THREADS = cores) + decode of the same samples."""
     import cfhd_testlib as T
     import numpy as np
@@ -38,7 +49,8 @@ def cpu_baseline(frames, pitch, W, H, seconds_budget=20.0):
     meta = ctypes.c_void_p()
     assert L.CFHD_MetadataOpen(ctypes.byref(meta)) == 0
     L.CFHD_AttachEncoderPoolMetadata(pool, meta)
-    assert L.CFHD_PrepareEncoderPool(pool, W, H, T.PIX_YUY2, T.ENCODED_YUV422, 0, T.QUALITY_FILMSCAN1) == 0
+    fmt = fmt or T.PIX_YUY2
+    assert L.CFHD_PrepareEncoderPool(pool, W, H, fmt, enc, flags, T.QUALITY_FILMSCAN1) == 0
     L.CFHD_AttachEncoderPoolMetadata(pool, meta)
     assert L.CFHD_StartEncoderPool(pool) == 0
     mtag = lambda t: ord(t[0]) | (ord(t[1]) << 8) | (ord(t[2]) << 16) | (ord(t[3]) << 24)
@@ -81,16 +93,19 @@ def cpu_baseline(frames, pitch, W, H, seconds_budget=20.0):
     L.CFHD_ReleaseEncoderPool(pool)
     L.CFHD_MetadataClose(meta)
     enc_fps = sent / t_enc
+    if not decode:
+        return {"value": round(enc_fps, 1), "unit": "fps", "cores": cores, "kind": "reference",
+                "sample": "%d frames async-pool encode (%d threads) of %dx%d %s, reference SSE2 build" % (sent, cores, W, H, label)}
     # decode: one decoder (it spawns its own worker threads, TAG_CPU_MAX unset = all cores)
     dec = ctypes.c_void_p(); L.CFHD_OpenDecoder(ctypes.byref(dec), None)
     aw = ctypes.c_int(); ah = ctypes.c_int(); af = ctypes.c_uint32()
     sbuf = [ctypes.create_string_buffer(s, len(s)) for s in samples[:nfr]]
-    L.CFHD_PrepareToDecode(dec, 0, 0, T.PIX_YUY2, 1, 0, sbuf[0], 512, ctypes.byref(aw), ctypes.byref(ah), ctypes.byref(af))
-    out = np.zeros(W * 2 * H, dtype=np.uint8)
+    L.CFHD_PrepareToDecode(dec, 0, 0, fmt, 1, 0, sbuf[0], 512, ctypes.byref(aw), ctypes.byref(ah), ctypes.byref(af))
+    out = np.zeros(W * bpp * H, dtype=np.uint8)
     t0 = time.time(); done = 0
     while True:
         s = sbuf[done % nfr]
-        rc = L.CFHD_DecodeSample(dec, s, len(s), out.ctypes.data_as(ctypes.c_void_p), W * 2)
+        rc = L.CFHD_DecodeSample(dec, s, len(s), out.ctypes.data_as(ctypes.c_void_p), W * bpp)
         if rc != 0:
             return fail("reference decoder returned error %d" % rc)
         done += 1
@@ -101,8 +116,8 @@ def cpu_baseline(frames, pitch, W, H, seconds_budget=20.0):
     dec_fps = done / t_dec
     rt = 1.0 / (1.0 / enc_fps + 1.0 / dec_fps)
     return {"value": round(rt, 1), "unit": "fps", "cores": cores, "kind": "reference",
-            "sample": "%d frames async-pool encode (%.1f fps, %d threads) + %d frames decode (%.1f fps) of %dx%d YUY2, reference SSE2 build"
-                      % (sent, enc_fps, cores, done, dec_fps, W, H)}
+            "sample": "%d frames async-pool encode (%.1f fps, %d threads) + %d frames decode (%.1f fps) of %dx%d %s, reference SSE2 build"
+                      % (sent, enc_fps, cores, done, dec_fps, W, H, label)}
 
 
 def c_abi_rates(frames, pitch, W, H, seconds=1.5, registered=False):
@@ -239,34 +254,48 @@ def normalise_counters(sample):
     return bytes(b)
 
 
-def parity_check(L, b, frames, pitch, W, H, rank):
+def parity_check(L, b, frames, pitch, W, H, rank, wl):
     """What was timed is what the reference produces: sample 0 of the last step (frame / unique-frame counters set back to the first frame's)
-    against the reference encoder's golden hash (rank 0 encodes Qbist seed 10, the frames of tests/golden), and decoded frame 0 inside the
-    dither interval of the exact integer reconstruction of its own sample (oracle, test infrastructure, used here as the checker only)."""
+    against the reference encoder (its golden hash where tests/golden holds one: rank 0 encodes Qbist seed 10, else the reference encoder run
+    here on the same frame), and decoded frame 0 against the exact integer reconstruction of its own sample (oracle, test infrastructure,
+    used here as the checker only): inside its dither interval for 8-bit 4:2:2 output, word for word for 16-bit output."""
     import numpy as np
     import cfhd_testlib as T
+    fmt = getattr(T, "PIX_" + wl["fmt"].upper())
     p = ctypes.c_void_p(); sz = ctypes.c_size_t()
     assert L.cfhd_amd_batch_get_sample(b, 0, ctypes.byref(p), ctypes.byref(sz)) == 0
     sample = ctypes.string_at(p, sz.value)
     out = {}
-    if rank == 0 and (W, H) == (1920, 1080):
+    if rank == 0 and (W, H) == (1920, 1080) and wl["fmt"] == "YUY2" and not wl["flags"]:
         g = json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))
         digest = hashlib.sha256(T.mask_volatile_metadata(normalise_counters(sample))).hexdigest()
         assert len(sample) == g["qbist_seed10_frame1_size"] and digest == g["qbist_seed10_frame1_masked_sha256"], "sample 0 differs from the reference encoder's golden sample"
         out["sample0_masked_sha256"] = digest
     else:
-        ref_sample = T.ref_encode_frames([frames[0]], pitch, W, H)[0]
+        ref_sample = T.ref_encode_frames([frames[0]], pitch, W, H, fmt, encoded=wl["enc"], flags=wl["flags"])[0]
         assert T.mask_volatile_metadata(normalise_counters(sample)) == T.mask_volatile_metadata(normalise_counters(ref_sample)), "sample 0 differs from the reference encoder's"
         out["sample0_equals_reference_encoder"] = True
-    img = np.zeros(H * W * 2, dtype=np.uint8)
-    assert L.cfhd_amd_batch_download_output(b, 0, img.ctypes.data_as(ctypes.c_void_p), W * 2) == 0
-    img = img.reshape(H, W * 2)
-    plan = T.Plan(W, H)
-    deq = T.host_decode_pyramid(sample, plan)
-    lo = T.oracle_inverse_yuv422(plan, deq, 0)[:H]; hi = T.oracle_inverse_yuv422(plan, deq, 1)[:H]
-    assert ((img == lo) | (img == hi)).all(), "decoded frame 0 leaves the dither interval of the exact reconstruction"
-    out["decoded_frame0_in_dither_interval"] = True
-    out["psnr_db"] = round(float(T.psnr_yuy2(img, frames[0].reshape(H, pitch)[:, : W * 2])), 2)
+    if wl["mode"] != 0:
+        return out
+    bpp = wl["bpp"]
+    img = np.zeros(H * W * bpp, dtype=np.uint8)
+    assert L.cfhd_amd_batch_download_output(b, 0, img.ctypes.data_as(ctypes.c_void_p), W * bpp) == 0
+    if wl["fmt"] == "YUY2":
+        img = img.reshape(H, W * 2)
+        plan = T.Plan(W, H, progressive=0 if wl["flags"] & 1 else 1)
+        deq = T.host_decode_pyramid(sample, plan)
+        inverse = T.oracle_inverse_interlaced_yuv422 if wl["flags"] & 1 else T.oracle_inverse_yuv422
+        lo = inverse(plan, deq, 0)[:H]; hi = inverse(plan, deq, 1)[:H]
+        assert ((img == lo) | (img == hi)).all(), "decoded frame 0 leaves the dither interval of the exact reconstruction"
+        out["decoded_frame0_in_dither_interval"] = True
+        out["psnr_db"] = round(float(T.psnr_yuy2(img, frames[0].reshape(H, pitch)[:, : W * 2])), 2)
+    else:
+        b64a = wl["fmt"] == "b64a"
+        plan = T.Plan(W, H, pixkind=T.PIXKIND[wl["fmt"]], enc=T.ENC["4444" if b64a else "444"])
+        exact = T.oracle_inverse_rgb48(plan, T.host_decode_pyramid(sample, plan), b64a=b64a)[:H]
+        got = np.frombuffer(img.tobytes(), np.uint16).reshape(H, W * bpp // 2)
+        assert np.array_equal(got, exact), "decoded frame 0 differs from the exact reconstruction"
+        out["decoded_frame0_equals_exact_reconstruction"] = True
     return out
 
 
@@ -283,8 +312,10 @@ def main():
     ap.add_argument("--no-c-abi", action="store_true")
     args = ap.parse_args()
 
-    W, H, default_batch = WORKLOADS[args.workload]
-    batch = args.batch or default_batch
+    wl = WORKLOADS[args.workload]
+    W, H = wl["w"], wl["h"]
+    batch = args.batch or wl["batch"]
+    headline = wl["fmt"] == "YUY2" and not wl["flags"]     # the metric's own pixel format and transform
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("CFHD_AMD_DEVICE", str(local_rank))
@@ -302,8 +333,8 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     L = T.product()
-    L.cfhd_amd_batch_create.restype = ctypes.c_void_p
-    L.cfhd_amd_batch_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    L.cfhd_amd_batch_create_ex.restype = ctypes.c_void_p
+    L.cfhd_amd_batch_create_ex.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     L.cfhd_amd_batch_upload.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
     L.cfhd_amd_batch_roundtrip.restype = ctypes.c_longlong
     L.cfhd_amd_batch_roundtrip.argtypes = [ctypes.c_void_p]
@@ -317,13 +348,13 @@ def main():
 
     cores = os.cpu_count() or 1
     threads = args.threads or max(1, cores // world)
-    nuniq = args.unique or (32 if args.workload == "1080p" else 8)
-    nuniq = min(nuniq, batch)
-    frames, pitch = T.qbist_frames(10 + rank, nuniq, W, H)            # Qbist seed 10 (BASELINE configs), QBIST_UNIQUE frames
-    data = "synthetic Qbist %dx%d YUY2 (seed %d, %d unique frames per rank, cycled through the batch)" % (W, H, 10, nuniq)
-    b = L.cfhd_amd_batch_create(W, H, T.PIX_YUY2, T.QUALITY_FILMSCAN1, batch, threads)
+    nuniq = min(args.unique or wl["unique"], batch)
+    fmt = getattr(T, "PIX_" + wl["fmt"].upper())
+    frames, pitch = T.qbist_frames(10 + rank, nuniq, W, H, fmt, alpha=1 if wl["fmt"] == "b64a" else 0)   # Qbist seed 10 (BASELINE configs), QBIST_UNIQUE frames
+    data = "synthetic Qbist %dx%d %s (seed %d, %d unique frames per rank, cycled through the batch)" % (W, H, wl["fmt"], 10, nuniq)
+    b = L.cfhd_amd_batch_create_ex(W, H, fmt, wl["enc"], wl["flags"], T.QUALITY_FILMSCAN1, batch, threads, wl["mode"])
     if not b:
-        raise SystemExit("cfhd_amd_batch_create failed: " + T.amd_last_error())
+        raise SystemExit("cfhd_amd_batch_create_ex failed: " + T.amd_last_error())
     for i in range(batch):
         assert L.cfhd_amd_batch_upload(b, i, frames[i % nuniq].ctypes.data_as(ctypes.c_void_p), pitch) == 0
 
@@ -339,10 +370,16 @@ def main():
     FWD1 = "k_fwd_yuv422" if os.environ.get("CFHD_AMD_FORWARD") == "tile" else "k_fwd_yuv422_strip"
     INV1 = "k_inv_yuv422" if os.environ.get("CFHD_AMD_INVERSE") == "tile" else "k_inv_yuv422_strip"
     PF, PI = ("k_fwd_plane", "k_inv_plane") if os.environ.get("CFHD_AMD_PLANES") == "tile" else ("k_fwd_plane_strip", "k_inv_plane_strip")
+    TILES = "k_dec_tiles"
+    if wl["flags"] & 1: FWD1, INV1, TILES = "k_fwd_frame_yuv422", "k_inv_frame_yuv422", "k_dec_tiles+k_dec_undiff"
+    elif wl["fmt"] in ("RG48", "b64a"): FWD1, INV1 = "k_fwd_packed16", "k_inv_packed16"
+    elif wl["fmt"] == "BYR4": FWD1 = "k_unpack_byr4+k_fwd_plane[L1]"
+    if not headline: PF, PI = "k_fwd_plane*", "k_inv_plane*"          # the tiled or the strip variant, by band width (cfhd_device.hip planes_as_strips)
     old_dec = os.environ.get("CFHD_AMD_DEC") in ("par", "lane")
-    DEC = [("k_dec_bands_par", 13)] if old_dec else [("k_dec_plan+k_dec_index", 15), ("k_dec_chain", 16), ("k_dec_tiles", 17)]
-    KERNELS = [(FWD1, 0), (PF + "[L2]", 1), (PF + "[L3]", 2), ("k_ent_count", 8), ("k_ent_scan", 9), ("k_ent_layout", 10),
-               ("k_ent_emit", 11), ("k_dec_parse", 12)] + DEC + [("k_dec_lowpass", 14), (PI + "[L3]", 5), (PI + "[L2]", 4), (INV1, 3)]
+    DEC = [("k_dec_bands_par", 13)] if old_dec else [("k_dec_plan+k_dec_index", 15), ("k_dec_chain", 16), (TILES, 17)]
+    KERNELS = [(FWD1, 0), (PF + "[L2]", 1), (PF + "[L3]", 2), ("k_ent_count", 8), ("k_ent_scan", 9), ("k_ent_layout", 10), ("k_ent_emit", 11)]
+    if wl["mode"] == 0:
+        KERNELS += [("k_dec_parse", 12)] + DEC + [("k_dec_lowpass", 14), (PI + "[L3]", 5), (PI + "[L2]", 4), (INV1, 3)]
     kms = {name: 0.0 for name, _ in KERNELS}; stage = [0.0] * 4; total_bytes = 0
     barrier()
     t0 = time.perf_counter()
@@ -367,7 +404,7 @@ def main():
     assert shards.shard_bounds(batch * world, rank, world) == (rank * batch, (rank + 1) * batch)
     fps = shards.whole_job_rate(batch * args.steps, world, elapsed)
 
-    parity = parity_check(L, b, frames, pitch, W, H, rank) if rank == 0 else None
+    parity = parity_check(L, b, frames, pitch, W, H, rank, wl) if rank == 0 else None
     dx_stats = None
     if os.environ.get("CFHD_AMD_DX_STATS"):               # convergence counters of the chunk-indexed entropy decoder (diagnostics, slows the kernels a little)
         st = (ctypes.c_uint32 * 16)()
@@ -378,13 +415,16 @@ def main():
         kms = {k: v / args.steps for k, v in kms.items()}
         sample_bytes = total_bytes / batch
         # algorithmic bytes per frame of every kernel: samples are 8-bit in the packed frame, 16-bit in the pyramid
-        S = W * ((H + 7) // 8 * 8) * 2                   # samples per 4:2:2 frame (luma + both chroma) = packed bytes
-        coded = (S - S // 64) * 2                        # bytes of the 27 entropy-coded bands (everything but the three LL3 bands)
-        algo = {FWD1: S + 2 * S, PF + "[L2]": S, PF + "[L3]": S // 4,                               # 12 441 600 B per 1080p frame
-                "k_ent_count": coded, "k_ent_emit": coded + sample_bytes,
-                PI + "[L3]": S // 4, PI + "[L2]": S, INV1: 2 * S + S}
-        if old_dec: algo["k_dec_bands_par"] = sample_bytes + coded
-        else: algo.update({"k_dec_plan+k_dec_index": sample_bytes, "k_dec_tiles": sample_bytes + coded})
+        Hp = (H + 7) // 8 * 8
+        S = W * Hp * wl["comps"]                         # coefficients per frame (4:2:2: luma + both chroma = the packed bytes of the 8-bit frame)
+        P = W * Hp * wl["bpp"]                           # bytes of the packed frame
+        coded = (S - S // 64) * 2                        # bytes of the entropy-coded bands (everything but the LL3 bands)
+        algo = {FWD1: P + 2 * S, PF + "[L2]": S, PF + "[L3]": S // 4,                               # 12 441 600 B per 1080p 4:2:2 frame
+                "k_ent_count": coded, "k_ent_emit": coded + sample_bytes}
+        if wl["mode"] == 0:
+            algo.update({PI + "[L3]": S // 4, PI + "[L2]": S, INV1: 2 * S + P})
+            if old_dec: algo["k_dec_bands_par"] = sample_bytes + coded
+            else: algo.update({"k_dec_plan+k_dec_index": sample_bytes, TILES: sample_bytes + coded})
         dom = max(algo, key=lambda k: kms[k])            # the dominant kernel = the longest launch of the step
         ms = kms[dom]
         achieved = algo[dom] * batch / (ms * 1e-3) / 1e9
@@ -400,12 +440,12 @@ def main():
         handoff = os.environ.get("CFHD_AMD_HANDOFF", "device")
         ent = os.environ.get("CFHD_AMD_ENTROPY", "gpu")
         sum_kernels = sum(v for k, v in kms.items() if k != "k_dec_parse")
-        round_trip_bytes = 2 * (S + 2 * S)                # encode S_in + 2 N_coef, decode 2 N_coef + S_out
+        round_trip_bytes = (2 if wl["mode"] == 0 else 1) * (P + 2 * S)     # encode S_in + 2 N_coef, decode 2 N_coef + S_out
         line = {
-            "metric": "%s YUY2 encode+decode fps" % args.workload, "value": round(fps, 1), "unit": "fps", "n_gpus": world, "steps": args.steps,
+            "metric": "%s %s %s fps" % (args.workload.split("-")[-1], wl["fmt"], "encode+decode" if wl["mode"] == 0 else "encode"), "value": round(fps, 1), "unit": "fps", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int16", "data": data,
-            "config": {"workload": "%dx%d YUY2 4:2:2 FILMSCAN1 encode+decode round trip, frames resident in HBM" % (W, H), "frames_per_step_per_gpu": batch,
+            "config": {"workload": "%dx%d %s FILMSCAN1 %s, frames resident in HBM" % (W, H, wl["label"], "encode+decode round trip" if wl["mode"] == 0 else "encode"), "frames_per_step_per_gpu": batch,
                        "entropy_stage": ("host, %d threads" % threads) if ent == "host" else "gpu (k_ent_* / k_dec_* kernels)",
                        "sample_handoff": "n/a" if ent == "host" else ("decoder reads the samples in HBM (k_dec_parse); host copy of every sample downloaded inside the step" if handoff != "host" else "samples cross PCIe to the host parser and back"),
                        "sample_bytes_per_frame": int(sample_bytes),
@@ -423,12 +463,12 @@ def main():
         }
     L.cfhd_amd_batch_destroy(b)
     if rank == 0:
-        if world == 1 and not args.no_c_abi:
+        if world == 1 and not args.no_c_abi and headline:
             line["config"]["c_abi_fps"] = {"frame": "%dx%d YUY2, frames and samples in host memory (PCIe inclusive)" % (W, H),
                                            "plain_buffers": c_abi_rates(frames[:8], pitch, W, H),
                                            "buffers_registered_by_the_caller": c_abi_rates(frames[:8], pitch, W, H, registered=True)}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(frames[:8], pitch, W, H)
+            line["cpu_baseline"] = cpu_baseline(frames[:8], pitch, W, H, fmt=fmt, enc=wl["enc"], flags=wl["flags"], decode=wl["mode"] == 0, bpp=wl["bpp"], label=wl["fmt"])
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -10,6 +10,7 @@
 #include "cfhd_core.h"
 #include "cfhd_bitstream.h"
 #include "cfhd_device.h"
+#include "cfhd_params.h"
 #include "cfhd_metadata.h"
 #include <string.h>
 #include <stdio.h>
@@ -291,6 +292,19 @@ void plan_from_sample(const ParsedSample &ps, int out_kind, FramePlan *plan, boo
 }
 
 } // namespace
+
+namespace cfhd {
+int front_end_params(int width, int height, uint32_t pixel_format, int encoded_format, uint32_t encoding_flags, int quality, FrontEndParams *out)
+{
+	EncodeParams p;
+	const int rc = make_params(p, width, height, pixel_format, encoded_format, encoding_flags, quality);
+	if (rc) return rc;
+	out->pixel_kind = p.pixel_kind; out->encoded_format = p.encoded_format; out->pixel_bytes = pixel_bytes_of(p.pixel_kind);
+	out->color_format = color_format_of(p.pixel_kind); out->color_space = p.color_space; out->quality = p.quality; out->progressive = p.progressive;
+	out->plan = p.plan;
+	return 0;
+}
+}
 
 extern "C" {
 

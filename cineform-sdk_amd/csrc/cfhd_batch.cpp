@@ -11,6 +11,7 @@
 #include "cfhd_bitstream.h"
 #include "cfhd_device.h"
 #include "cfhd_metadata.h"
+#include "cfhd_params.h"
 #include <string.h>
 #include <stdlib.h>
 #include <vector>
@@ -26,6 +27,8 @@ struct cfhd_amd_chunk { EncodeBatch enc; DecodeBatch dec; int first = 0, n = 0; 
 struct cfhd_amd_batch {
 	FramePlan plan;
 	int n = 0, nthreads = 1, quality = 4, pixel_kind = PIX_YUY2;
+	int color_format = 2, color_space = 2; bool progressive = true;
+	bool decode = true;                // false: encode only (cfhd_amd_batch_create_ex mode 1; Bayer samples, which this library does not decode)
 	// The batch is cut into chunks with their own HIP streams: while one chunk's entropy decode (latency bound: one lane per
 	// band) is in flight, the next chunk's bandwidth-bound kernels and PCIe copies run beside it.
 	std::vector<std::unique_ptr<cfhd_amd_chunk>> chunks;
@@ -55,33 +58,47 @@ double now() { return std::chrono::duration<double>(std::chrono::steady_clock::n
 
 extern "C" {
 
-cfhd_amd_batch *cfhd_amd_batch_create(int width, int height, uint32_t pixel_format, int quality, int nframes, int nthreads)
+// width x height frames of `pixel_format` encoded as `encoded_format` with `encoding_flags` (the CFHD_PrepareToEncode arguments: YUY2 / 2vuy ->
+// 4:2:2, optionally interlaced; RG48 -> RGB 4:4:4; b64a -> RGBA 4:4:4:4; BYR4 -> Bayer).  mode 0: encode + decode back to the same pixel
+// format; mode 1: encode only (the only mode for BYR4).
+cfhd_amd_batch *cfhd_amd_batch_create_ex(int width, int height, uint32_t pixel_format, int encoded_format, uint32_t encoding_flags, int quality, int nframes, int nthreads, int mode)
 {
-	int kind = pixel_format == 0x32767579u /* '2vuy' */ ? PIX_2VUY : PIX_YUY2;
+	FrontEndParams fp;
+	if (nframes < 1 || front_end_params(width, height, pixel_format, encoded_format, encoding_flags, quality, &fp)) return nullptr;
+	const int kind = fp.pixel_kind;
+	const bool yuv = kind == PIX_YUY2 || kind == PIX_2VUY;
 	cfhd_amd_batch *b = new (std::nothrow) cfhd_amd_batch;
 	if (!b) return nullptr;
-	b->n = nframes; b->nthreads = nthreads > 0 ? nthreads : 1; b->quality = quality; b->pixel_kind = kind;
-	if (!build_frame_plan(&b->plan, width, height, kind, ENC_YUV422)) { delete b; return nullptr; }
-	QuantState st = {0, -1, 0};
-	derive_quantization(&b->plan, quality, true, 0.0f, &st);
+	b->n = nframes; b->nthreads = nthreads > 0 ? nthreads : 1; b->quality = fp.quality; b->pixel_kind = kind;
+	b->color_format = fp.color_format; b->color_space = fp.color_space; b->progressive = fp.progressive;
+	b->decode = mode == 0;
+	b->plan = fp.plan;
+	if (b->decode && kind == PIX_BYR4) { delete b; return nullptr; }
 	const char *e = getenv("CFHD_AMD_ENTROPY");
 	b->gpu_entropy = !(e && strcmp(e, "host") == 0);
+	if (!b->gpu_entropy && (!yuv || !b->progressive || !b->decode)) { delete b; return nullptr; }      // the host-entropy arrangement is kept for the headline workload only
 	const char *ho = getenv("CFHD_AMD_HANDOFF");
 	b->device_handoff = b->gpu_entropy && !(ho && strcmp(ho, "host") == 0);
 	const char *cs = getenv("CFHD_AMD_CHUNK");
 	int chunk = cs ? atoi(cs) : 0;                     // 0 = whole batch in one chunk (measured fastest: launches are already batch-wide)
 	if (chunk <= 0 || !b->gpu_entropy) chunk = nframes;
-	const size_t cap = (size_t)width * height * 2 + 65536;
+	const size_t cap = (size_t)width * height * fp.pixel_bytes + 65536;        // SampleEncoder.cpp:387
 	for (int first = 0; first < nframes; first += chunk) {
 		std::unique_ptr<cfhd_amd_chunk> c(new cfhd_amd_chunk);
 		c->first = first; c->n = nframes - first < chunk ? nframes - first : chunk;
-		if (c->enc.prepare(b->plan, c->n, true) || c->dec.prepare(b->plan, c->n, kind, true)) { delete b; return nullptr; }
-		if (b->gpu_entropy && (c->enc.prepare_entropy(cap) || c->dec.prepare_entropy(cap))) { delete b; return nullptr; }
+		if (c->enc.prepare(b->plan, c->n, true)) { delete b; return nullptr; }
+		if (b->decode) { c->dec.set_interlaced(!b->progressive); if (c->dec.prepare(b->plan, c->n, kind, true)) { delete b; return nullptr; } }
+		if (b->gpu_entropy && (c->enc.prepare_entropy(cap) || (b->decode && c->dec.prepare_entropy(cap)))) { delete b; return nullptr; }
 		b->chunks.push_back(std::move(c));
 	}
 	b->samples.resize(nframes); b->sample_size.assign(nframes, 0);
 	if (!b->gpu_entropy) for (auto &s : b->samples) s.resize(cap);
 	return b;
+}
+
+cfhd_amd_batch *cfhd_amd_batch_create(int width, int height, uint32_t pixel_format, int quality, int nframes, int nthreads)
+{
+	return cfhd_amd_batch_create_ex(width, height, pixel_format == 0x32767579u /* '2vuy' */ ? pixel_format : 0x59555932u /* 'YUY2' */, 0, 0, quality, nframes, nthreads, 0);
 }
 
 void cfhd_amd_batch_destroy(cfhd_amd_batch *b) { delete b; }
@@ -108,7 +125,7 @@ long long cfhd_amd_batch_roundtrip(cfhd_amd_batch *b)
 	b->frame_meta.resize(b->n);
 	bool meta_ready = false;
 	auto prepare_meta = [&] { if (meta_ready) return; meta_ready = true; for (int i = 0; i < b->n; i++) { b->meta.handle(); b->frame_meta[i] = b->meta.global; meta_remove_hidden(b->frame_meta[i]); } };
-	auto header = [&](int i) { SampleHeaderInfo h = { base_number + (uint32_t)i + 1, b->pixel_kind == PIX_2VUY ? 1 : 2, 2, b->quality, true, b->frame_meta[i].data(), b->frame_meta[i].size(), nullptr, 0 }; return h; };
+	auto header = [&](int i) { SampleHeaderInfo h = { base_number + (uint32_t)i + 1, b->color_format, b->color_space, b->quality, b->progressive, b->frame_meta[i].data(), b->frame_meta[i].size(), nullptr, 0 }; return h; };
 	const uint32_t seed = 0xA511E9B3u * (b->steps + 1);
 	if (b->gpu_entropy && b->device_handoff) {
 		// Samples stay in HBM between the encoder and the decoder: the decoder's stream waits for the encoder's kernels, parses
@@ -120,6 +137,7 @@ long long cfhd_amd_batch_roundtrip(cfhd_amd_batch *b)
 			prepare_meta();
 			for (int l = 0; l < c->n; l++) if (c->enc.entropy().set_frame_header(l, header(c->first + l))) return -6;
 			if (c->enc.entropy().launch()) return -2;
+			if (!b->decode) continue;
 			// the parser only needs the headers and size fields (k_ent_layout): it runs beside k_ent_emit, the band decoder waits for the payloads
 			c->dec.entropy().set_producer_events(c->enc.entropy().headers_event(), c->enc.entropy().samples_event());
 			if (c->dec.entropy().set_samples_device(c->enc.entropy().device_sample(0), c->enc.entropy().sample_cap(), c->enc.entropy().device_sizes())) return -4;
@@ -128,10 +146,13 @@ long long cfhd_amd_batch_roundtrip(cfhd_amd_batch *b)
 		t1 = now();
 		for (auto &c : b->chunks) {
 			if (c->enc.entropy().download() || c->enc.wait()) return -2;
-			for (int l = 0; l < c->n; l++) { size_t n = c->enc.entropy().sample_bytes(l); if (!n) return -3; b->sample_size[c->first + l] = n; }
+			for (int l = 0; l < c->n; l++) {
+				size_t n = c->enc.entropy().sample_bytes(l); if (!n) return -3; b->sample_size[c->first + l] = n;
+				if (c->enc.entropy().needs_peak_table(l)) return -8;      // an interlaced frame with field differences beyond +-250 steps: only CFHD_EncodeSample writes those (host writer)
+			}
 		}
 		t2 = t3 = now();
-		for (auto &c : b->chunks) { if (c->dec.wait()) return -5; if (c->dec.entropy().check()) return -7; }
+		if (b->decode) for (auto &c : b->chunks) { if (c->dec.wait()) return -5; if (c->dec.entropy().check()) return -7; }
 	} else if (b->gpu_entropy) {
 		// 1. every chunk: forward transform + entropy coding, queued on the chunk's own stream
 		prepare_meta();
@@ -145,8 +166,12 @@ long long cfhd_amd_batch_roundtrip(cfhd_amd_batch *b)
 		for (auto &c : b->chunks) {
 			double a = now();
 			if (c->enc.entropy().download() || c->enc.wait()) return -2;
-			for (int l = 0; l < c->n; l++) { size_t n = c->enc.entropy().sample_bytes(l); if (!n) return -3; b->sample_size[c->first + l] = n; }
+			for (int l = 0; l < c->n; l++) {
+				size_t n = c->enc.entropy().sample_bytes(l); if (!n) return -3; b->sample_size[c->first + l] = n;
+				if (c->enc.entropy().needs_peak_table(l)) return -8;
+			}
 			double m = now();
+			if (!b->decode) { wait_s += m - a; continue; }
 			cfhd_amd_chunk *cp = c.get();
 			parallel_for(c->n, b->nthreads < 16 ? b->nthreads : 16, [&, cp](int l) {
 				if (cp->dec.entropy().set_sample_host(l, cp->enc.entropy().host_sample(l), b->sample_size[cp->first + l])) bad++; });
@@ -156,7 +181,7 @@ long long cfhd_amd_batch_roundtrip(cfhd_amd_batch *b)
 		}
 		t2 = t1 + wait_s; t3 = t2 + stage_s;
 		// 3. drain
-		for (auto &c : b->chunks) { if (c->dec.wait()) return -5; if (c->dec.entropy().check()) return -7; }
+		if (b->decode) for (auto &c : b->chunks) { if (c->dec.wait()) return -5; if (c->dec.entropy().check()) return -7; }
 	} else {
 		cfhd_amd_chunk &c = *b->chunks[0];
 		prepare_meta();
@@ -214,6 +239,7 @@ float cfhd_amd_batch_kernel_ms(cfhd_amd_batch *b, int which)
 	if (!b) return 0;
 	float ms = 0;                                        // summed over the chunks (each chunk times its own launches with HIP events on its stream)
 	for (auto &c : b->chunks) {
+		if (which >= 3 && which != 6 && !(which >= 8 && which < 12) && !b->decode) continue;
 		if (which < 3) ms += c->enc.last_level_ms(which);
 		else if (which < 6) ms += c->dec.last_level_ms(which - 3);
 		else if (which >= 8 && which < 12) ms += b->gpu_entropy ? c->enc.entropy().kernel_ms(which - 8) : 0.0f;
@@ -236,7 +262,7 @@ int cfhd_amd_batch_dx_stats(cfhd_amd_batch *b, uint32_t *out)
 	if (!b || !out) return -1;
 	for (int k = 0; k < 16; k++) out[k] = 0;
 	int rc = -1;
-	for (auto &c : b->chunks) { uint32_t s[16]; if (c->dec.entropy().stats(s) == 0) { rc = 0; for (int k = 0; k < 16; k++) out[k] = k == 2 ? (s[k] > out[k] ? s[k] : out[k]) : out[k] + s[k]; } }
+	if (b->decode) for (auto &c : b->chunks) { uint32_t s[16]; if (c->dec.entropy().stats(s) == 0) { rc = 0; for (int k = 0; k < 16; k++) out[k] = k == 2 ? (s[k] > out[k] ? s[k] : out[k]) : out[k] + s[k]; } }
 	return rc;
 }
 
@@ -250,7 +276,7 @@ int cfhd_amd_batch_get_sample(cfhd_amd_batch *b, int i, const void **data, size_
 
 int cfhd_amd_batch_download_output(cfhd_amd_batch *b, int i, void *out, int pitch)
 {
-	if (!b || i < 0 || i >= b->n) return -1;
+	if (!b || i < 0 || i >= b->n || !b->decode) return -1;
 	int l; cfhd_amd_chunk &c = b->chunk_of(i, &l);
 	if (c.dec.download_frame(l, out, pitch) || c.dec.wait()) return -2;
 	return c.dec.finish_frame(l, out, pitch);

@@ -131,7 +131,24 @@ CFHD_Error CFHD_CloseMetadata(CFHD_MetadataRef metadataRef);                    
 /* ---------------- extensions of this library (not in the reference ABI) ---------------- */
 /* Batched, device-resident round trip used by bench.py: frames already in HBM -> samples -> frames in HBM. */
 typedef struct cfhd_amd_batch cfhd_amd_batch;
+/* nframes frames of one geometry travel through every stage together, one launch per stage (cfhd_batch.cpp).  The arguments are those of
+ * CFHD_PrepareToEncode; mode 0: encode + decode back to the same pixel format, mode 1: encode only (the only mode for BYR4).
+ * cfhd_amd_batch_create: 4:2:2 progressive round trip (YUY2 / 2vuy), kept for callers of the first release. */
+cfhd_amd_batch *cfhd_amd_batch_create_ex(int width, int height, uint32_t pixel_format, int encoded_format, uint32_t encoding_flags,
+                                         int quality, int nframes, int nthreads, int mode);
+cfhd_amd_batch *cfhd_amd_batch_create(int width, int height, uint32_t pixel_format, int quality, int nframes, int nthreads);
+void cfhd_amd_batch_destroy(cfhd_amd_batch *batch);
+int  cfhd_amd_batch_upload(cfhd_amd_batch *batch, int frame, const void *pixels, int pitch);   /* host frame -> HBM (outside any timed region) */
+long long cfhd_amd_batch_roundtrip(cfhd_amd_batch *batch);                                     /* one pass; total sample bytes, or < 0 */
+int  cfhd_amd_batch_get_sample(cfhd_amd_batch *batch, int frame, const void **data, size_t *size);
+int  cfhd_amd_batch_download_output(cfhd_amd_batch *batch, int frame, void *out, int pitch);
+float cfhd_amd_batch_kernel_ms(cfhd_amd_batch *batch, int which);                              /* HIP-event time of the kernels of the last pass */
+double cfhd_amd_batch_stage_seconds(cfhd_amd_batch *batch, int which);
+int  cfhd_amd_batch_dx_stats(cfhd_amd_batch *batch, uint32_t *out16);
 int  cfhd_amd_device_count(void);
+/* Text of the last HIP / device failure behind a CFHD_ERROR_INTERNAL (the library has no CPU fallback: without a gfx950 device every
+ * compute call fails and says why here). */
+const char *cfhd_amd_last_error(void);
 /* Fixes the otherwise random clip GUID that every new encoder stamps into its samples (16 bytes), for bit-exact diffs. */
 void cfhd_amd_set_clip_guid(const unsigned char guid[16]);
 /* Optional: page-lock a frame / output buffer the caller reuses, so that CFHD_EncodeSample, the encoder pool and CFHD_DecodeSample

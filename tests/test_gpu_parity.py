@@ -84,8 +84,9 @@ def _check_decode(sample, source, w, h, pixfmt=PIX_YUY2, interlaced=False, decod
     hi = inverse(plan, coeffs, 1, uyvy=int(pixfmt == PIX_2VUY))[:h]
     ok = (img == lo) | (img == hi)
     assert ok.all(), "%d of %d bytes are outside the dither interval of the exact reconstruction" % ((~ok).sum(), ok.size)
-    frac = (img[lo != hi] == hi[lo != hi]).mean()
-    assert 0.35 < frac < 0.65, "dither is not balanced: %.3f" % frac
+    if (lo != hi).sum() > 1000:                      # (a picture of saturated blacks and whites has no byte the dither could move)
+        frac = (img[lo != hi] == hi[lo != hi]).mean()
+        assert 0.35 < frac < 0.65, "dither is not balanced: %.3f" % frac
     for attempt in range(3):                        # the reference's threaded decoder occasionally damages a frame: three attempts
         rout, rpitch = ref_decode_sample(sample, w, h, pixfmt)
         rimg = rout.reshape(h, rpitch)[:, : w * 2]
@@ -588,7 +589,59 @@ def _batch_api():
     L.cfhd_amd_batch_get_sample.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
     L.cfhd_amd_batch_download_output.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
     L.cfhd_amd_batch_destroy.argtypes = [ctypes.c_void_p]
+    L.cfhd_amd_batch_create_ex.restype = ctypes.c_void_p
+    L.cfhd_amd_batch_create_ex.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     return L
+
+
+@pytest.mark.parametrize("name,w,h,n,fmt,enc,flags,mode", [
+    ("rg48", 1920, 1080, 6, PIX_RG48, ENCODED_RGB444, 0, 0), ("rg48-encode", 3840, 2160, 3, PIX_RG48, ENCODED_RGB444, 0, 1),
+    ("b64a", 1920, 1080, 5, PIX_B64A, ENCODED_RGBA4444, 0, 0), ("byr4", 3840, 2160, 4, PIX_BYR4, ENCODED_BAYER, 0, 1),
+    ("1080i", 1920, 1080, 12, PIX_YUY2, ENCODED_YUV422, 1, 0)])
+def test_batched_path_of_the_other_configurations_equals_reference(name, w, h, n, fmt, enc, flags, mode):
+    """cfhd_amd_batch_create_ex: configs B (RG48 encode), C (b64a round trip), D (BYR4 encode, 1080i round trip) through the batched,
+    device-resident path bench.py times.  Every sample equals the reference encoder's n consecutive CFHD_EncodeSample calls; decoded frames
+    equal the exact reconstruction (16-bit output) or lie in its dither interval (8-bit 4:2:2)."""
+    L = _batch_api()
+    bpp = {PIX_RG48: 6, PIX_B64A: 8, PIX_BYR4: 2, PIX_YUY2: 2}[fmt]
+    nuniq = 2
+    uniq, pitch = qbist_frames(10, nuniq, w, h, fmt, alpha=1 if fmt == PIX_B64A else 0)
+    frames = [uniq[i % nuniq] for i in range(n)]
+    refs = ref_encode_frames(frames, pitch, w, h, fmt, encoded=enc, flags=flags)
+    b = L.cfhd_amd_batch_create_ex(w, h, fmt, enc, flags, QUALITY_FILMSCAN1, n, 4, mode)
+    assert b, amd_last_error()
+    for i, f in enumerate(frames):
+        assert L.cfhd_amd_batch_upload(b, i, f.ctypes.data_as(ctypes.c_void_p), pitch) == 0
+    assert L.cfhd_amd_batch_roundtrip(b) > 0, amd_last_error()
+    exact = {}
+    for i in range(n):
+        p = ctypes.c_void_p(); sz = ctypes.c_size_t()
+        assert L.cfhd_amd_batch_get_sample(b, i, ctypes.byref(p), ctypes.byref(sz)) == 0
+        sample = ctypes.string_at(p, sz.value)
+        assert len(sample) == len(refs[i]), "frame %d: %d bytes vs reference %d" % (i, len(sample), len(refs[i]))
+        assert mask_volatile_metadata(sample) == mask_volatile_metadata(refs[i]), "frame %d differs from the reference" % i
+        out = np.zeros(h * w * bpp, dtype=np.uint8)
+        rc = L.cfhd_amd_batch_download_output(b, i, out.ctypes.data_as(ctypes.c_void_p), w * bpp)
+        if mode == 1:
+            assert rc != 0                                     # encode only: there is no decoded frame
+            continue
+        assert rc == 0
+        if fmt == PIX_YUY2:
+            if i % nuniq not in exact:
+                plan = Plan(w, h, progressive=0)
+                deq = host_decode_pyramid(sample, plan)
+                exact[i % nuniq] = (oracle_inverse_interlaced_yuv422(plan, deq, 0)[:h], oracle_inverse_interlaced_yuv422(plan, deq, 1)[:h])
+            lo, hi = exact[i % nuniq]
+            img = out.reshape(h, w * 2)
+            ok = (img == lo) | (img == hi)
+            assert ok.all(), "frame %d: %d bytes outside the dither interval" % (i, (~ok).sum())
+        else:
+            if i % nuniq not in exact:
+                plan = Plan(w, h, pixkind=PIXKIND["b64a" if fmt == PIX_B64A else "RG48"], enc=ENC["4444" if fmt == PIX_B64A else "444"])
+                exact[i % nuniq] = oracle_inverse_rgb48(plan, host_decode_pyramid(sample, plan), b64a=fmt == PIX_B64A)[:h]
+            got = np.frombuffer(out.tobytes(), np.uint16).reshape(h, w * bpp // 2)
+            assert np.array_equal(got, exact[i % nuniq]), "frame %d" % i
+    L.cfhd_amd_batch_destroy(b)
 
 
 @pytest.mark.parametrize("w,h,n,nuniq", [(1920, 1080, 64, 16), (3840, 2160, 40, 4)])
