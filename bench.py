@@ -273,7 +273,10 @@ def parity_check(L, b, frames, pitch, W, H, rank, wl):
         out["sample0_masked_sha256"] = digest
     else:
         ref_sample = T.ref_encode_frames([frames[0]], pitch, W, H, fmt, encoded=wl["enc"], flags=wl["flags"])[0]
-        assert T.mask_volatile_metadata(normalise_counters(sample)) == T.mask_volatile_metadata(normalise_counters(ref_sample)), "sample 0 differs from the reference encoder's"
+        ma, mb = T.mask_volatile_metadata(normalise_counters(sample)), T.mask_volatile_metadata(normalise_counters(ref_sample))
+        if ma != mb:
+            first = next((k for k in range(min(len(ma), len(mb))) if ma[k] != mb[k]), -1)
+            raise AssertionError("sample 0 differs from the reference encoder's: %d vs %d bytes, first difference at byte %d" % (len(ma), len(mb), first))
         out["sample0_equals_reference_encoder"] = True
     if wl["mode"] != 0:
         return out

@@ -26,7 +26,8 @@ namespace dev {
 // slower: the per-wave descriptor loads dominate); four waves per
 // workgroup, no workgroup barriers in k_ent_count / k_ent_emit: all exchanges are wave-level (ballot / bpermute / shuffles).
 enum { ENT_THREADS = 256, ENT_LANES = 64, ENT_WAVES = ENT_THREADS / ENT_LANES, ENT_PER_THREAD = 16, ENT_SEG = ENT_LANES * ENT_PER_THREAD,
-       ENT_LDS_WORDS = 256, ENT_TOK_CAP = 256, ENT_MAX_HOLES = 40 };
+       ENT_LDS_WORDS = 256, ENT_TOK_CAP = 256, ENT_MAX_HOLES = 40,
+       ENT_FILL = 16384 /* bytes of a sample one workgroup of k_ent_layout fills at a time */ };
 // ENT_LDS_WORDS: 32-bit words of the per-wave bit window in LDS (a segment of ordinary pictures codes into 10-40 words; beyond the window
 // the code words go to the payload with global atomics).  ENT_TOK_CAP: tokens (nonzero coefficients) of a segment held in LDS at a
 // time (ordinary: ~80 of 1024; a denser segment is worked off in passes).  Both are sized for occupancy, not for the worst case:
@@ -373,47 +374,58 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_layout(const EntFrameJob *f
 			out[at >> 2] = bswap32(end - start);
 		}
 	}
-	// 3. payload holes, hole h by workgroup h % nparts
-	for (int h = part; h < f.nholes; h += nparts) {
+	// 3. payload holes in pieces of ENT_FILL bytes, piece p by workgroup p % nparts (a hole's last piece takes the remainder, so it is never
+	//    shorter than ENT_FILL unless it is the whole hole: the trailer of a coded band lies inside it)
+	__shared__ uint32_t s_piece[ENT_MAX_HOLES + 1];     // pieces in front of hole h
+	if (tid == 0) {
+		uint32_t np = 0;
+		for (int h = 0; h < f.nholes; h++) { s_piece[h] = np; const uint32_t bytes = s_cum[h + 1] - s_cum[h]; np += bytes / ENT_FILL ? bytes / ENT_FILL : 1u; }
+		s_piece[f.nholes] = np;
+	}
+	__syncthreads();
+	const uint32_t npieces = s_piece[f.nholes];
+	int h = 0;
+	for (uint32_t p = (uint32_t)part; p < npieces; p += (uint32_t)nparts) {
+		while (s_piece[h + 1] <= p) h++;                  // pieces come in rising order
 		const EntHole &hole = f.holes[h];
-		const uint32_t base = (uint32_t)hole.tmpl_offset + s_cum[h];
+		const uint32_t base = (uint32_t)hole.tmpl_offset + s_cum[h], bytes = s_cum[h + 1] - s_cum[h];
+		const uint32_t k = p - s_piece[h], last = s_piece[h + 1] - s_piece[h] - 1;
+		const uint32_t w0 = k * (ENT_FILL / 4), w1 = k == last ? bytes / 4 : w0 + ENT_FILL / 4;
 		if (hole.kind == 0) {
 			// raw lowpass: 16-bit big-endian, row after row without the pitch padding, zero padded to 32 bits (encoder.c:4423-4441)
 			const int count = hole.lp_width * hole.lp_height;
-			for (int i = tid; i < hole.fixed_bytes / 4; i += ENT_THREADS) {
+			for (uint32_t i = w0 + tid; i < w1; i += ENT_THREADS) {
 				uint32_t w = 0;
 #pragma unroll
-				for (int k = 0; k < 2; k++) {
-					const int e = 2 * i + k;
+				for (int q = 0; q < 2; q++) {
+					const int e = 2 * (int)i + q;
 					uint32_t v = 0;
 					if (e < count) { const int r = e / hole.lp_width, c = e - r * hole.lp_width; v = (uint16_t)hole.lowpass[(size_t)r * hole.lp_pitch + c]; }
 					w = (w << 16) | v;
 				}
 				out[(base >> 2) + i] = bswap32(w);
 			}
-		} else {
-			const uint32_t bytes = band_state[hole.band_job].payload_bytes;
-			for (uint32_t i = tid; i < bytes / 4; i += ENT_THREADS) out[(base >> 2) + i] = 0;
-			if (tid == 0) { band_state[hole.band_job].base_byte = base; band_state[hole.band_job].out = f.out + base; }
+			continue;
 		}
-	}
-	__syncthreads();
-	// 4. trailing zero run + band end marker of every band (one thread per band; the payload words were zeroed above)
-	for (int h = tid; h < f.nholes; h += ENT_THREADS) {
-		const EntHole &hole = f.holes[h];
-		if (hole.kind != 1 || h % nparts != part) continue;
-		const EntBandState &b = band_state[hole.band_job];
-		const EntTables *T = tables + bands[hole.band_job].table;
-		uint32_t *words = out + ((hole.tmpl_offset + s_cum[h]) >> 2);
-		uint64_t pos = b.seg_bits;
-		uint32_t run = b.tail_run;
-		while (run > 0) {
-			const uint32_t idx = run < 3072 ? run : 3071;
-			put_code_plain(words, pos, T->run_bits[idx], T->run_size[idx]);
-			pos += T->run_size[idx];
-			run -= T->run_count[idx];
+		for (uint32_t i = w0 + tid; i < w1; i += ENT_THREADS) out[(base >> 2) + i] = 0;
+		if (k != last) continue;
+		__syncthreads();                                  // (uniform: k, last are) the zeroed words of the last piece are in place
+		if (tid == 0) {
+			// 4. trailing zero run + band end marker of the band
+			EntBandState &b = band_state[hole.band_job];
+			b.base_byte = base; b.out = f.out + base;
+			const EntTables *T = tables + bands[hole.band_job].table;
+			uint32_t *words = out + (base >> 2);
+			uint64_t pos = b.seg_bits;
+			uint32_t run = b.tail_run;
+			while (run > 0) {
+				const uint32_t idx = run < 3072 ? run : 3071;
+				put_code_plain(words, pos, T->run_bits[idx], T->run_size[idx]);
+				pos += T->run_size[idx];
+				run -= T->run_count[idx];
+			}
+			put_code_plain(words, pos, T->band_end_bits, T->band_end_size);
 		}
-		put_code_plain(words, pos, T->band_end_bits, T->band_end_size);
 	}
 }
 

@@ -491,7 +491,7 @@ def test_interlaced_samples_at_half_resolution_are_refused():
     aw = ctypes.c_int(); ah = ctypes.c_int(); af = ctypes.c_uint32()
     sb = ctypes.create_string_buffer(sample, len(sample))
     assert L.CFHD_PrepareToDecode(dec, 0, 0, PIX_YUY2, 2, 0, sb, 512, ctypes.byref(aw), ctypes.byref(ah), ctypes.byref(af)) == 0
-    out = np.full(w * h, 7, np.uint8)
+    out = np.full(w * (h // 2), 7, np.uint8)
     assert L.CFHD_DecodeSample(dec, sb, len(sample), out.ctypes.data_as(ctypes.c_void_p), w) == 3   # CFHD_ERROR_BADFORMAT
     assert not out.any()
     L.CFHD_CloseDecoder(dec)

@@ -2,7 +2,7 @@
 """Turn a rocprofv3 rocpd database (bench_results.db) into the plain-text per-kernel summary we commit under profiles/.
 
 usage: tools/rocprof_summary.py <kernel-trace db> [<pmc db> ...] > profiles/<name>.txt
-       tools/rocprof_summary.py --traffic-json profiles/pmc_traffic.json --frames N <FETCH_SIZE db> <WRITE_SIZE db>
+       tools/rocprof_summary.py --traffic-json profiles/pmc_traffic.json --frames N [--workload W] <FETCH_SIZE db> <WRITE_SIZE db>
          (HBM bytes per launch of every kernel = FETCH_SIZE + WRITE_SIZE, KiB -> bytes; bench.py reads the file for roofline.traffic)
 """
 import json, re, sqlite3, sys
@@ -23,7 +23,7 @@ def short_name(mangled):
 FETCH_SCALE = 2
 
 
-def traffic_json(out, frames, dbs):
+def traffic_json(out, frames, dbs, workload="1080p"):
     acc = {}
     for path in dbs:
         cur = sqlite3.connect(path).cursor()
@@ -39,7 +39,7 @@ def traffic_json(out, frames, dbs):
             fetch = v["FETCH_SIZE"] * (FETCH_SCALE if k.startswith("k_") else 1)
             kernels[k] = {"fetch_bytes_per_launch": int(fetch), "write_bytes_per_launch": int(v["WRITE_SIZE"]),
                           "hbm_bytes_per_launch": int(fetch + v["WRITE_SIZE"]), "fetch_counter_scale": FETCH_SCALE if k.startswith("k_") else 1}
-    json.dump({"frames_per_launch": frames, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), KiB * 1024, largest launch of each kernel; "
+    json.dump({"frames_per_launch": frames, "workload": workload, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), KiB * 1024, largest launch of each kernel; "
                "FETCH_SIZE of our kernels doubled (gfx950 counts coalesced 128-byte read requests at 64 bytes; calibrated on k_ent_pack, a plain copy, and on the read-once lower bound of every kernel), WRITE_SIZE as reported",
                "kernels": kernels}, open(out, "w"), indent=1, sort_keys=True)
 
@@ -52,7 +52,10 @@ def tables(cur):
 
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--traffic-json":
-        return traffic_json(sys.argv[2], int(sys.argv[4]), sys.argv[5:])
+        rest = sys.argv[5:]
+        workload = "1080p"
+        if rest and rest[0] == "--workload": workload = rest[1]; rest = rest[2:]
+        return traffic_json(sys.argv[2], int(sys.argv[4]), rest, workload)
     for path in sys.argv[1:]:
         cur = sqlite3.connect(path).cursor()
         t = tables(cur)
