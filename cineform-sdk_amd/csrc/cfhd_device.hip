@@ -324,6 +324,13 @@ int EncodeBatch::upload_frame(int i, const void *frame, int pitch)
 {
 	if (!own_input_ || i < 0 || i >= n_) return -1;
 	const uint8_t *src = (const uint8_t *)frame;
+	if (plan_.pixel_kind == PIX_BYR4) {
+		// The reference reads a BYR4 frame as tightly packed rows whatever pitch it was given (frame.c:5376-5377: line1 = data + row * width * 4,
+		// line2 = line1 + width * 2, in 16-bit words of the component plane width); only the sign of the pitch moves the start (encoder.c:1957,
+		// with the pitch doubled by SampleEncoder.cpp:494 and the display height of the component planes).  Same bytes here.
+		if (pitch < 0) src += (ptrdiff_t)(plan_.display_height - 1) * 2 * pitch;
+		pitch = in_pitch_;
+	}
 	if (pitch < 0) { src += (ptrdiff_t)(in_rows_ - 1) * pitch; pitch = -pitch; }     // encoder.c:1957
 	if (pitch >= in_pitch_ && host_buffer_is_registered(src, (size_t)pitch * (in_rows_ - 1) + in_pitch_)) {
 		// a buffer the caller registered: DMA straight out of it (the frame is borrowed until the encode completes, as in the reference)

@@ -24,7 +24,7 @@ public:
 	uint32_t sample_bytes(int i) const { return h_sizes_[i]; }
 	// Interlaced frames: true when frame i's difference-coded band holds values beyond the peak threshold, i.e. the reference appends a
 	// peak table (encoder.c:4802); the GPU sample of such a frame is not valid, the caller writes it on the host from the coefficients.
-	bool needs_peak_table(int i) const { return h_sizes_[n_ + i] != 0; }
+	bool needs_peak_table(int i) const { return plan_.interlaced && h_sizes_[n_ + i] != 0; }     // (the flags are only cleared and written for interlaced plans)
 	size_t sample_cap() const { return cap_; }
 	int total_segments() const { return total_segs_; }
 	// HIP-event time of kernel k of the last launch() (0 k_ent_count, 1 k_ent_scan, 2 k_ent_layout, 3 k_ent_emit); valid once the stream was synchronised

@@ -42,6 +42,18 @@ def p16(a):
     return a.ctypes.data_as(c_i16p)
 
 
+def _build_once(target, cmd, deps):
+    """Compile `target` under a file lock (pytest-xdist workers find the same stale library at the same time) and move it into place whole."""
+    import fcntl
+    with open(target + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not os.path.exists(target) or any(os.path.getmtime(d) > os.path.getmtime(target) for d in deps):      # (a worker in front of us may have built it)
+            tmp = "%s.%d.tmp" % (target, os.getpid())
+            subprocess.check_call(cmd + ["-o", tmp])
+            os.replace(tmp, target)
+        fcntl.flock(lock, fcntl.LOCK_UN)
+
+
 def p8(a):
     assert a.dtype == np.uint8 and a.flags["C_CONTIGUOUS"]
     return a.ctypes.data_as(c_u8p)
@@ -239,7 +251,7 @@ def hooks():
         deps = srcs + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".h")]
         if not os.path.exists(HOOKS_SO) or any(os.path.getmtime(d) > os.path.getmtime(HOOKS_SO) for d in deps):
             os.makedirs(os.path.dirname(HOOKS_SO), exist_ok=True)
-            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + csrc, "-I" + os.path.join(ROOT, "include")] + srcs + ["-o", HOOKS_SO])
+            _build_once(HOOKS_SO, ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + csrc, "-I" + os.path.join(ROOT, "include")] + srcs, deps)
         L = ctypes.CDLL(HOOKS_SO)
         L.cfhd_amd_write_sample_host.restype = ctypes.c_size_t
         L.cfhd_amd_write_sample_host.argtypes = [ctypes.c_int] * 8 + [ctypes.c_uint, c_i16p, c_u8p, ctypes.c_size_t, c_u8p, ctypes.c_size_t, c_u8p, ctypes.c_size_t]
@@ -536,8 +548,7 @@ def emu():
             os.makedirs(os.path.dirname(EMU_SO), exist_ok=True)
             csrc = os.path.join(PRODUCT_DIR, "csrc")
             host = [os.path.join(csrc, f) for f in ("cfhd_tables.cpp", "cfhd_bitstream.cpp")]      # host-only product sources the entropy emulation needs
-            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + os.path.dirname(src),
-                                   "-I" + csrc, src] + host + ["-o", EMU_SO])
+            _build_once(EMU_SO, ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + os.path.dirname(src), "-I" + csrc, src] + host, deps)
         _emu = ctypes.CDLL(EMU_SO)
     return _emu
 

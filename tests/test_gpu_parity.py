@@ -367,6 +367,15 @@ def test_byr4_encode_bitstream_identical(w, h):
         assert mask_volatile_metadata(a) == mask_volatile_metadata(b), "frame %d" % i
 
 
+def test_byr4_encode_with_a_wide_pitch_reads_what_the_reference_reads():
+    """The reference ignores the pitch of a BYR4 frame (frame.c:5376: tightly packed rows); so does CFHD_EncodeSample here."""
+    w, h, pitch = 192, 96, 192 * 2 + 48
+    buf = np.random.default_rng(4).integers(0, 256, pitch * h).astype(np.uint8)
+    a = amd_encode_frames([buf], pitch, w, h, PIX_BYR4, encoded=ENCODED_BAYER)[0]
+    b = ref_encode_frames([buf], pitch, w, h, PIX_BYR4, encoded=ENCODED_BAYER)[0]
+    assert len(a) == len(b) and mask_volatile_metadata(a) == mask_volatile_metadata(b)
+
+
 @pytest.mark.parametrize("w,h,pixfmt", [(320, 240, PIX_YUY2), (720, 486, PIX_2VUY), (1920, 1080, PIX_YUY2)])
 def test_interlaced_encode_bitstream_identical(w, h, pixfmt):
     """Config D, 1080i half (encode): CFHD_ENCODING_FLAGS_YUV_INTERLACED -> k_fwd_frame_yuv422 (field transform with the

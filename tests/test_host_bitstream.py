@@ -129,6 +129,23 @@ def test_byr4_bayer_sample_bytes_equal_reference(w, h):
     assert mine == rs
 
 
+def test_byr4_pitch_is_ignored_by_the_reference():
+    """The reference's BYR4 unpack (frame.c:5376) walks the mosaic as tightly packed rows whatever pitch the caller passes.  A drop-in has to
+    read the same bytes: the product does (EncodeBatch::upload_frame), this pins the behaviour on the reference itself."""
+    if not have_ref(): pytest.skip("reference .so not built")
+    w, h, pitch = 192, 96, 192 * 2 + 48
+    rng = np.random.default_rng(4)
+    buf = rng.integers(0, 256, pitch * h).astype(np.uint8)
+    rs = ref_encode_frames([buf], pitch, w, h, PIX_BYR4, encoded=ENCODED_BAYER)[0]
+    plan = Plan(w, h, pixkind=PIXKIND["BYR4"], enc=2)
+    off, n = first_metadata_chunk(rs)
+    tight = np.ascontiguousarray(buf[: 2 * w * h]).view(np.uint16).reshape(h, w)
+    strided = np.ascontiguousarray(buf.reshape(h, pitch)[:, : 2 * w]).view(np.uint16)
+    write = lambda m: product_write_sample_host(plan, oracle_forward_planes(plan, byr4_planes(m)), 1, meta_global=rs[off:off + n], input_format=COLOR_FORMAT_BYR4, color_space=0)
+    assert write(tight) == rs
+    assert write(strided) != rs
+
+
 def test_bayer_curve_table_equals_oracle():
     want = np.zeros(1 << 14, np.uint16); got = np.zeros(1 << 14, np.uint16)
     oracle().orc_byr4_log90_curve.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
