@@ -353,8 +353,13 @@ def main():
     threads = args.threads or max(1, cores // world)
     nuniq = min(args.unique or wl["unique"], batch)
     fmt = getattr(T, "PIX_" + wl["fmt"].upper())
-    frames, pitch = T.qbist_frames(10 + rank, nuniq, W, H, fmt, alpha=1 if wl["fmt"] == "b64a" else 0)   # Qbist seed 10 (BASELINE configs), QBIST_UNIQUE frames
-    data = "synthetic Qbist %dx%d %s (seed %d, %d unique frames per rank, cycled through the batch)" % (W, H, wl["fmt"], 10, nuniq)
+    if wl["fmt"] == "BYR4":
+        # TestCFHD has no Bayer generator (its Qbist writer would fill the buffer with 8-bit RGB bytes: noise as 16-bit photosites)
+        frames = [T.synth_bayer(W, H, 10 + rank + i).reshape(-1).view(np.uint8).copy() for i in range(nuniq)]; pitch = W * 2
+        data = "synthetic %dx%d Bayer mosaic, red-green order (tests/cfhd_testlib.py synth_bayer: smooth structure + texture + sensor noise; %d unique frames per rank, cycled through the batch)" % (W, H, nuniq)
+    else:
+        frames, pitch = T.qbist_frames(10 + rank, nuniq, W, H, fmt, alpha=1 if wl["fmt"] == "b64a" else 0)   # Qbist seed 10 (BASELINE configs), QBIST_UNIQUE frames
+        data = "synthetic Qbist %dx%d %s (seed %d, %d unique frames per rank, cycled through the batch)" % (W, H, wl["fmt"], 10, nuniq)
     b = L.cfhd_amd_batch_create_ex(W, H, fmt, wl["enc"], wl["flags"], T.QUALITY_FILMSCAN1, batch, threads, wl["mode"])
     if not b:
         raise SystemExit("cfhd_amd_batch_create_ex failed: " + T.amd_last_error())

@@ -25,9 +25,12 @@ namespace dev {
 // A segment = 1024 consecutive raster coefficients of a band = the work of one wave (16 coefficients per lane; 512 was measured
 // slower: the per-wave descriptor loads dominate); four waves per
 // workgroup, no workgroup barriers in k_ent_count / k_ent_emit: all exchanges are wave-level (ballot / bpermute / shuffles).
+#ifndef CFHD_ENT_FILL
+#define CFHD_ENT_FILL 16384      // (the emulated tests build with a few words, so that trailers span many pieces)
+#endif
 enum { ENT_THREADS = 256, ENT_LANES = 64, ENT_WAVES = ENT_THREADS / ENT_LANES, ENT_PER_THREAD = 16, ENT_SEG = ENT_LANES * ENT_PER_THREAD,
        ENT_LDS_WORDS = 256, ENT_TOK_CAP = 256, ENT_MAX_HOLES = 40,
-       ENT_FILL = 16384 /* bytes of a sample one workgroup of k_ent_layout fills at a time */ };
+       ENT_FILL = CFHD_ENT_FILL /* bytes of a sample one workgroup of k_ent_layout fills at a time */ };
 // ENT_LDS_WORDS: 32-bit words of the per-wave bit window in LDS (a segment of ordinary pictures codes into 10-40 words; beyond the window
 // the code words go to the payload with global atomics).  ENT_TOK_CAP: tokens (nonzero coefficients) of a segment held in LDS at a
 // time (ordinary: ~80 of 1024; a denser segment is worked off in passes).  Both are sized for occupancy, not for the worst case:
@@ -399,17 +402,38 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_layout(const EntFrameJob *f
 			}
 			continue;
 		}
-		for (uint32_t i = w0 + tid; i < w1; i += ENT_THREADS) out[(base >> 2) + i] = 0;
+		// coded band: k_ent_emit ORs its code words into zeroed words.  Everything from the word that holds the first bit of the trailer
+		// (trailing zero run + band end marker) belongs to the workgroup of the last piece, which stores those words whole.
+		const EntBandState bs = band_state[hole.band_job];
+		const uint32_t tail_word = (uint32_t)(bs.seg_bits >> 5) < bytes / 4 ? (uint32_t)(bs.seg_bits >> 5) : bytes / 4;
+		for (uint32_t i = w0 + tid; i < (w1 < tail_word ? w1 : tail_word); i += ENT_THREADS) out[(base >> 2) + i] = 0;
 		if (k != last) continue;
-		__syncthreads();                                  // (uniform: k, last are) the zeroed words of the last piece are in place
+		// 4. the trailer.  A band that ends in a long zero run (an empty alpha plane of an 8K frame: 8 million zeros) takes thousands of
+		//    copies of the longest run code: the lanes compute the words of that periodic stretch in closed form; the few codes behind it
+		//    and the end marker are appended by one thread.
+		const EntTables *T = tables + bands[hole.band_job].table;
+		const uint32_t maxc = T->run_count[3071], maxs = T->run_size[3071], maxb = T->run_bits[3071];
+		const uint32_t copies = bs.tail_run >= 3071u ? (bs.tail_run - 3071u) / maxc + 1u : 0u;
+		const uint64_t p0 = bs.seg_bits, p1 = p0 + (uint64_t)copies * maxs;          // the copies cover bits [p0, p1) of the payload
+		uint32_t *words = out + (base >> 2);
+		for (uint32_t i = tail_word + tid; i < bytes / 4; i += ENT_THREADS) {
+			uint32_t w = 0;
+			const uint64_t lo = (uint64_t)i * 32u, hi = lo + 32u;
+			if (copies && hi > p0 && lo < p1) {
+				uint64_t j = lo > p0 ? (lo - p0) / maxs : 0u;                         // first copy that reaches into this word
+				for (; j < copies && p0 + j * maxs < hi; j++) {
+					const int64_t sh = (int64_t)(hi - (p0 + j * maxs)) - (int64_t)maxs;   // distance of the code's last bit from the word's last bit
+					w |= sh >= 0 ? (sh < 32 ? maxb << sh : 0u) : maxb >> (-sh);
+				}
+			}
+			words[i] = bswap32(w);
+		}
+		__syncthreads();                                  // (uniform: k, last are) the words of the trailer are in place
 		if (tid == 0) {
-			// 4. trailing zero run + band end marker of the band
 			EntBandState &b = band_state[hole.band_job];
 			b.base_byte = base; b.out = f.out + base;
-			const EntTables *T = tables + bands[hole.band_job].table;
-			uint32_t *words = out + (base >> 2);
-			uint64_t pos = b.seg_bits;
-			uint32_t run = b.tail_run;
+			uint64_t pos = p1;
+			uint32_t run = bs.tail_run - copies * maxc;
 			while (run > 0) {
 				const uint32_t idx = run < 3072 ? run : 3071;
 				put_code_plain(words, pos, T->run_bits[idx], T->run_size[idx]);

@@ -2,6 +2,7 @@
 // Runs the product's HIP kernels (cineform-sdk_amd/csrc/cfhd_kernels.h, unmodified source) on the CPU through
 // hip_emu.h so the `-m "not gpu"` suite can check their tiling / LDS / border logic against the oracle.
 #include "hip_emu.h"
+#define CFHD_ENT_FILL 64          // k_ent_layout: pieces of 16 words, so that the small test frames give holes of many pieces
 dim3 threadIdx, blockIdx, blockDim, gridDim;
 #include "cfhd_kernels.h"
 #include <vector>

@@ -690,3 +690,21 @@ def test_inv_frame_yuv422(w, h, dh, uyvy):
     e = e[:dh, :4 * w]
     assert np.all((e == outs[0]) | (e == outs[1]))
     assert np.any(e != outs[0]) and np.any(e != outs[1])
+
+
+def test_gpu_entropy_stage_emulated_long_trailers():
+    """Empty bands of a larger frame: the trailer of a band is dozens of copies of the longest run code, more than one piece of k_ent_layout's
+    fill (the emulated build uses pieces of 16 words), written in closed form by the lanes; a single value in the middle of one band splits
+    its zeros into a run for k_ent_emit and a trailer."""
+    w, h = 1280, 720
+    plan = Plan(w, h)
+    meta = b"GUID\x10\x00\x00G" + bytes(16)
+    coeffs = np.zeros(plan.coeff_elems, dtype=np.int16)
+    for c in range(3):
+        d = plan.band[(c, 2, 0)]
+        plan.view(coeffs, c, 2, 0)[:, : d["width"]] = 4000
+    d = plan.band[(0, 0, 1)]
+    plan.view(coeffs, 0, 0, 1)[d["height"] // 3, 7] = -9
+    want = product_write_sample_host(plan, coeffs, 1, meta_global=meta)
+    got = _emu_entropy(plan, coeffs, 1, meta)
+    assert got == want
