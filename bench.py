@@ -438,11 +438,12 @@ def main():
         achieved = algo[dom] * batch / (ms * 1e-3) / 1e9
         traffic = None; traffic_source = None
         try:                                             # HBM bytes per launch from the committed PMC passes of this command (profiles/, same batch size), else null
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            pmc_file = "pmc_traffic.json" if args.workload == "1080p" else "pmc_traffic_%s.json" % args.workload
+            pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
             base = dom.split("[")[0].split("+")[-1]      # the per-level launches of the plane kernels share one trace name
             if pmc.get("frames_per_launch") == batch and pmc.get("workload", "1080p") == args.workload and base in pmc["kernels"]:
                 traffic = pmc["kernels"][base]["hbm_bytes_per_launch"]
-                traffic_source = "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command; FETCH_SIZE x2 + WRITE_SIZE per the gfx950 correction)"
+                traffic_source = "profiles/%s (rocprofv3 --pmc passes of this command; FETCH_SIZE x2 + WRITE_SIZE per the gfx950 correction)" % pmc_file
         except Exception:
             traffic = None
         handoff = os.environ.get("CFHD_AMD_HANDOFF", "device")
