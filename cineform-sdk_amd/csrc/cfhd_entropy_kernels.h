@@ -667,6 +667,7 @@ __global__ void __launch_bounds__(DEC_THREADS) k_dec_bands(const DecBandJob *job
 			idx += mid;
 			if (v2) { if (idx >= n) { err = 2; break; } job.dst[idx++] = (int16_t)(v2 * quant); }
 			idx += post;
+			if (idx > n) { err = 2; break; }              // runs may only reach the end of the band: idx never grows far enough to wrap
 		} else {
 			// a code word longer than the window (or the band end marker): resolve it alone through lut1 / lut2
 			uint32_t e = T->lut1[(uint32_t)(acc >> (64 - DEC_K1))];
@@ -685,7 +686,7 @@ __global__ void __launch_bounds__(DEC_THREADS) k_dec_bands(const DecBandJob *job
 				if (idx >= n) { err = 2; break; }
 				const int v = (int)mag * quant;
 				job.dst[idx++] = (int16_t)(negative ? -v : v);
-			} else idx += (int)((e >> 5) & 0x7ffu);
+			} else { idx += (int)((e >> 5) & 0x7ffu); if (idx > n) { err = 2; break; } }
 		}
 		if (wpos > nwords + 6) { err = 3; break; }       // ran off the payload without meeting the end marker
 	}
