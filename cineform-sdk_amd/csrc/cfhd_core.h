@@ -7,10 +7,12 @@
 #include <stdint.h>
 #include <stddef.h>
 
-#if defined(__HIPCC__) || defined(CFHD_HIPEMU)
+#ifndef CFHD_HD
+#if defined(__HIPCC__)
 #define CFHD_HD __host__ __device__
 #else
 #define CFHD_HD
+#endif
 #endif
 
 namespace cfhd {

@@ -13,11 +13,7 @@
 // the zeroed pad columns (the reference's `count += gap`, :5640) and across segments (resolved by k_ent_scan).
 #pragma once
 #include <stdint.h>
-#if defined(CFHD_HIPEMU)
-#include "hip_emu.h"
-#else
-#include <hip/hip_runtime.h>
-#endif
+#include <cfhd_gfx950.h>
 
 namespace cfhd {
 namespace dev {
@@ -85,47 +81,6 @@ struct EntFrameJob {
 };
 
 __device__ __forceinline__ uint32_t bswap32(uint32_t v) { return (v >> 24) | ((v >> 8) & 0xff00u) | ((v << 8) & 0xff0000u) | (v << 24); }
-
-#if defined(CFHD_HIPEMU)
-__device__ __forceinline__ uint32_t atomic_or_u32(uint32_t *p, uint32_t v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
-#else
-__device__ __forceinline__ uint32_t atomic_or_u32(uint32_t *p, uint32_t v) { return atomicOr(p, v); }
-#endif
-
-#if defined(CFHD_HIPEMU)
-#define CFHD_WAVE_SYNC() hipemu::wave_sync()
-__device__ __forceinline__ int wave_uniform(int x) { return x; }
-__device__ __forceinline__ int wave_lane() { return (int)hipemu::lane_id(); }
-// inclusive prefix sum over the 64 lanes / value of one lane (uniform index)
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x)
-{
-	const int lane = wave_lane();
-	for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, (unsigned)d); if (lane >= d) x += y; }
-	return x;
-}
-__device__ __forceinline__ uint32_t wave_get(uint32_t x, int lane) { return __shfl(x, lane); }
-#else
-// Inclusive prefix sum over the 64 lanes on the DPP data path (no LDS crossbar round trips): Hillis-Steele inside the rows of 16 lanes
-// (row_shr 1, 2, 4, 8; lanes without a source add 0), then lane 15 of every row into rows 1 and 3 (row_bcast:15, row mask 0xa) and
-// lane 31 into rows 2 and 3 (row_bcast:31, row mask 0xc).
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x)
-{
-	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);
-	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);
-	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);
-	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);
-	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);
-	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
-	return x;
-}
-__device__ __forceinline__ uint32_t wave_get(uint32_t x, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)x, lane); }
-#endif
-#if defined(CFHD_HIPEMU)
-#else
-#define CFHD_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
-__device__ __forceinline__ int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
-__device__ __forceinline__ int wave_lane() { return (int)(threadIdx.x & 63u); }
-#endif
 
 // Exclusive block scans over ENT_THREADS values (Hillis-Steele in LDS; the arrays are tiny, the barriers dominate).
 __device__ __forceinline__ int block_excl_sum(int v, int *buf, int *total)
@@ -850,11 +805,6 @@ enum { DEC_PARSE_THREADS = 64, DEC_ERR_PARSE = 0x100 };   // one wave per workgr
 
 // One wave per sample: the 64 lanes fetch 256 consecutive bytes of the tag stream with one coalesced load, the (wave-uniform) walk
 // reads its tags out of the lanes' registers; a band header and the size chunk in front of it usually come with one fetch.
-#if defined(CFHD_HIPEMU)
-__device__ __forceinline__ uint32_t wave_read(uint32_t v, int lane) { return __shfl(v, lane); }
-#else
-__device__ __forceinline__ uint32_t wave_read(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(lane)); }
-#endif
 struct DecTagReader {
 	const uint8_t *d; uint64_t base; uint32_t w; int lane;
 	__device__ __forceinline__ uint32_t word(uint64_t pos)

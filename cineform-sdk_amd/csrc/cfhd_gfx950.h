@@ -1,0 +1,74 @@
+// cfhd_gfx950.h -- the gfx950 primitives the kernels are written in: wave-level data movement on the DPP / readlane path, packed 16-bit
+// arithmetic, address-space qualified loads.  Included as <cfhd_gfx950.h>: the CPU test build (tests/hipemu) puts its own header of the
+// same name first on the include path and gets the same kernels in scalar C; nothing of that lives in this directory.
+#pragma once
+#include <stdint.h>
+#include <hip/hip_runtime.h>
+
+namespace cfhd {
+namespace dev {
+
+__device__ __forceinline__ uint32_t atomic_or_u32(uint32_t *p, uint32_t v) { return atomicOr(p, v); }
+
+// ---- wave64
+#define CFHD_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+__device__ __forceinline__ int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ int wave_lane() { return (int)(threadIdx.x & 63u); }
+// Inclusive prefix sum over the 64 lanes on the DPP data path (no LDS crossbar round trips): Hillis-Steele inside the rows of 16 lanes
+// (row_shr 1, 2, 4, 8; lanes without a source add 0), then lane 15 of every row into rows 1 and 3 (row_bcast:15, row mask 0xa) and
+// lane 31 into rows 2 and 3 (row_bcast:31, row mask 0xc).  All 64 lanes must be active.
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x)
+{
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
+	return x;
+}
+__device__ __forceinline__ uint32_t wave_get(uint32_t x, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)x, lane); }                       // uniform lane index
+__device__ __forceinline__ uint32_t wave_read(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(lane)); }
+// A pointer every lane of the wave holds the same value of, moved to scalar registers: the per-lane part of an address is then one
+// 32-bit offset (global_load ... v_off, s[base]) instead of a 64-bit pointer per band.
+template <typename T> __device__ __forceinline__ T *wave_uniform_ptr(T *p)
+{
+	const uint64_t v = (uint64_t)p;
+	const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+	return (T *)(((uint64_t)hi << 32) | lo);
+}
+
+// ---- packed 2 x int16 arithmetic: v_pk_add_i16 / v_pk_sub_i16 with clamp are exactly SSE2's _mm_adds_epi16 / _mm_subs_epi16 on two
+// lanes, so the reference's saturating SIMD bodies map one to one onto CDNA4 packed math (half the VALU issue slots of the
+// scalar form, saturation for free).
+typedef short cfhd_s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_adds(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(cfhd_s2, a), __builtin_bit_cast(cfhd_s2, b))); }
+__device__ __forceinline__ uint32_t pk_subs(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(cfhd_s2, a), __builtin_bit_cast(cfhd_s2, b))); }
+__device__ __forceinline__ uint32_t pk_sra(uint32_t a, int n) { cfhd_s2 x = __builtin_bit_cast(cfhd_s2, a); x = x >> (short)n; return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ uint32_t pk_lolo(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }          // (a.lo, b.lo)
+__device__ __forceinline__ uint32_t pk_hihi(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }          // (a.hi, b.hi)
+// wrapping (non-saturating) packed add / negate and signed max: the quantizer's 16-bit arithmetic (quantize.c:1395)
+__device__ __forceinline__ uint32_t pk_addw(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (cfhd_s2)(__builtin_bit_cast(cfhd_s2, a) + __builtin_bit_cast(cfhd_s2, b))); }
+__device__ __forceinline__ uint32_t pk_negw(uint32_t a) { return __builtin_bit_cast(uint32_t, (cfhd_s2)(-__builtin_bit_cast(cfhd_s2, a))); }
+__device__ __forceinline__ uint32_t pk_maxs(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(cfhd_s2, a), __builtin_bit_cast(cfhd_s2, b))); }
+// 10 -> 8 bits on two lanes: clamp at zero, halve, add the dither bit, >> shift, saturate (v_pk_max_i16 / v_pk_ashrrev_i16 / v_pk_min_i16)
+__device__ __forceinline__ uint32_t pk_to8(uint32_t v, int shift, uint32_t dither)
+{
+	cfhd_s2 x = __builtin_bit_cast(cfhd_s2, v);
+	const cfhd_s2 zero = { 0, 0 }, top = { 255, 255 };
+	x = __builtin_elementwise_max(x, zero);
+	x = (x >> (short)1) + __builtin_bit_cast(cfhd_s2, dither);
+	x = x >> (short)shift;
+	x = __builtin_elementwise_min(x, top);
+	return __builtin_bit_cast(uint32_t, x);
+}
+__device__ __forceinline__ uint32_t byte_perm(uint32_t s0, uint32_t s1, uint32_t sel) { return __builtin_amdgcn_perm(s0, s1, sel); }
+
+// ---- loads through the global address space (global_load_dword): a flat load would tick lgkmcnt as well and every LDS access in
+// between would drain the loads in flight
+typedef uint32_t cfhd_u4 __attribute__((ext_vector_type(4)));
+#define CFHD_LDG32(p) (*(const __attribute__((address_space(1))) uint32_t *)(p))
+#define CFHD_LDG128(p) (*(const __attribute__((address_space(1))) cfhd_u4 *)(p))
+
+} // namespace dev
+} // namespace cfhd

@@ -21,11 +21,7 @@
 //   Codec/InvertHorizontalStrip16s.c:459/:1700/:3770/:5025, Codec/spatial.c:31341-31975 InvertSpatial*Row16sToOutput.
 #pragma once
 #include <stdint.h>
-#if defined(CFHD_HIPEMU)
-#include "hip_emu.h"
-#else
-#include <hip/hip_runtime.h>
-#endif
+#include <cfhd_gfx950.h>
 
 namespace cfhd {
 namespace dev {
@@ -115,35 +111,8 @@ __device__ __forceinline__ int lo16(uint32_t v) { return (int)(int16_t)(v & 0xff
 __device__ __forceinline__ int hi16(uint32_t v) { return (int)(int16_t)(v >> 16); }
 __device__ __forceinline__ uint32_t pack16(int lo, int hi) { return ((uint32_t)(uint16_t)lo) | ((uint32_t)(uint16_t)hi << 16); }
 
-// ---- packed 2 x int16 arithmetic: v_pk_add_i16 / v_pk_sub_i16 with clamp are exactly SSE2's _mm_adds_epi16 / _mm_subs_epi16 on two
-// lanes, so the reference's saturating SIMD bodies map one to one onto CDNA4 packed math (half the VALU issue slots of the
-// scalar form, saturation for free).  Under tests/hipemu the same operations are spelled out in scalar C.
-#if defined(CFHD_HIPEMU)
-__device__ __forceinline__ uint32_t pk_adds(uint32_t a, uint32_t b) { return pack16(adds16(lo16(a), lo16(b)), adds16(hi16(a), hi16(b))); }
-__device__ __forceinline__ uint32_t pk_subs(uint32_t a, uint32_t b) { return pack16(subs16(lo16(a), lo16(b)), subs16(hi16(a), hi16(b))); }
-__device__ __forceinline__ uint32_t pk_sra(uint32_t a, int n) { return pack16(lo16(a) >> n, hi16(a) >> n); }
-__device__ __forceinline__ uint32_t pk_lolo(uint32_t a, uint32_t b) { return (a & 0xffffu) | (b << 16); }          // (a.lo, b.lo)
-__device__ __forceinline__ uint32_t pk_hihi(uint32_t a, uint32_t b) { return (a >> 16) | (b & 0xffff0000u); }       // (a.hi, b.hi)
-#else
-typedef short cfhd_s2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pk_adds(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(cfhd_s2, a), __builtin_bit_cast(cfhd_s2, b))); }
-__device__ __forceinline__ uint32_t pk_subs(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(cfhd_s2, a), __builtin_bit_cast(cfhd_s2, b))); }
-__device__ __forceinline__ uint32_t pk_sra(uint32_t a, int n) { cfhd_s2 x = __builtin_bit_cast(cfhd_s2, a); x = x >> (short)n; return __builtin_bit_cast(uint32_t, x); }
-__device__ __forceinline__ uint32_t pk_lolo(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }
-__device__ __forceinline__ uint32_t pk_hihi(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
-#endif
+// packed 2 x int16 arithmetic (pk_adds, pk_subs, pk_sra, ...): cfhd_gfx950.h
 __device__ __forceinline__ uint32_t pk_set(int v) { return pack16(v, v); }
-// wrapping (non-saturating) packed add / negate and signed max: the quantizer's 16-bit arithmetic (quantize.c:1395)
-#if defined(CFHD_HIPEMU)
-__device__ __forceinline__ uint32_t pk_addw(uint32_t a, uint32_t b) { return pack16(lo16(a) + lo16(b), hi16(a) + hi16(b)); }
-__device__ __forceinline__ uint32_t pk_negw(uint32_t a) { return pack16(-lo16(a), -hi16(a)); }
-__device__ __forceinline__ uint32_t pk_maxs(uint32_t a, uint32_t b) { return pack16(lo16(a) > lo16(b) ? lo16(a) : lo16(b), hi16(a) > hi16(b) ? hi16(a) : hi16(b)); }
-#else
-__device__ __forceinline__ uint32_t pk_addw(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (cfhd_s2)(__builtin_bit_cast(cfhd_s2, a) + __builtin_bit_cast(cfhd_s2, b))); }
-__device__ __forceinline__ uint32_t pk_negw(uint32_t a) { return __builtin_bit_cast(uint32_t, (cfhd_s2)(-__builtin_bit_cast(cfhd_s2, a))); }
-__device__ __forceinline__ uint32_t pk_maxs(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(cfhd_s2, a), __builtin_bit_cast(cfhd_s2, b))); }
-#endif
-
 // 2/6 analysis highpass on two lanes at once (SIMD association order, spatial.c:326-397 / :10301-10351)
 __device__ __forceinline__ uint32_t pk_hp_mid(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4, uint32_t a5)
 {
@@ -544,11 +513,6 @@ __device__ __forceinline__ void inv_horiz_border(const int *l, int idx, int hi, 
 // Loads of one staged region (two bands b0, b1 of the same geometry), all issued before the first LDS store: item i ->
 // (band q, row j, dword d).  The band pointers are passed in registers and the loads go through the global address space
 // (global_load_dword): a flat load would tick lgkmcnt as well and every LDS access in between would drain the loads in flight.
-#if defined(CFHD_HIPEMU)
-#define CFHD_LDG32(p) (*(const uint32_t *)(p))
-#else
-#define CFHD_LDG32(p) (*(const __attribute__((address_space(1))) uint32_t *)(p))
-#endif
 template <int NROWS, int NDW, int N>
 __device__ __forceinline__ void inv_stage_load(uint32_t (&va)[N], const int16_t *b0, const int16_t *b1, int pitch, int row0, int h, int dw0, int wdw)
 {
@@ -703,21 +667,7 @@ __device__ __forceinline__ uint32_t to8(int v, int shift, int dither)
 	int x = ((v >> 1) + dither) >> shift;
 	return (uint32_t)(x > 255 ? 255 : x);
 }
-// the same on two 16-bit lanes (v_pk_max_i16 / v_pk_ashrrev_i16 / v_pk_min_i16)
-#if defined(CFHD_HIPEMU)
-__device__ __forceinline__ uint32_t pk_to8(uint32_t v, int shift, uint32_t dither) { return to8(lo16(v), shift, (int)(dither & 1u)) | (to8(hi16(v), shift, (int)((dither >> 16) & 1u)) << 16); }
-#else
-__device__ __forceinline__ uint32_t pk_to8(uint32_t v, int shift, uint32_t dither)
-{
-	cfhd_s2 x = __builtin_bit_cast(cfhd_s2, v);
-	const cfhd_s2 zero = { 0, 0 }, top = { 255, 255 };
-	x = __builtin_elementwise_max(x, zero);
-	x = (x >> (short)1) + __builtin_bit_cast(cfhd_s2, dither);
-	x = x >> (short)shift;
-	x = __builtin_elementwise_min(x, top);
-	return __builtin_bit_cast(uint32_t, x);
-}
-#endif
+// pk_to8: the same on two 16-bit lanes (cfhd_gfx950.h)
 
 // Counter-based stand-in for the reference's libc rand() dither: one word of random bits per (frame seed, output row, pixel group).
 __device__ __forceinline__ uint32_t dither_word(uint32_t seed, int row, int group)
@@ -868,36 +818,6 @@ __global__ void __launch_bounds__(NTHREADS) k_inv_yuv422(const InvYuvJob *jobs, 
 // workgroup each, overlapping by the two neighbour lanes); others take k_inv_yuv422.
 // =============================================================================================
 enum { SR = 16, SBLK = 8, SLUMA_STEP = 62, SSEG = 2 * SLUMA_STEP, SROW = SSEG * 32 };   // SSEG: luma blocks per segment; SROW: bytes of a segment's output row
-
-#if defined(CFHD_HIPEMU)
-struct emu_u4 { uint32_t x, y, z, w; };
-typedef emu_u4 cfhd_u4;
-#define CFHD_LDG128(p) (*(const cfhd_u4 *)(p))
-__device__ __forceinline__ uint32_t byte_perm(uint32_t s0, uint32_t s1, uint32_t sel)
-{
-	const uint64_t src = ((uint64_t)s0 << 32) | s1;
-	uint32_t r = 0;
-	for (int k = 0; k < 4; k++) { const uint32_t b = (sel >> (8 * k)) & 0xffu; r |= (b < 8 ? (uint32_t)((src >> (8 * b)) & 0xffu) : (b == 0x0c ? 0u : 0xffu)) << (8 * k); }
-	return r;
-}
-#else
-typedef uint32_t cfhd_u4 __attribute__((ext_vector_type(4)));
-#define CFHD_LDG128(p) (*(const __attribute__((address_space(1))) cfhd_u4 *)(p))
-__device__ __forceinline__ uint32_t byte_perm(uint32_t s0, uint32_t s1, uint32_t sel) { return __builtin_amdgcn_perm(s0, s1, sel); }
-#endif
-
-// A pointer every lane of the wave holds the same value of, moved to scalar registers: the per-lane part of an address is then one
-// 32-bit offset (global_load ... v_off, s[base]) instead of a 64-bit pointer per band.
-#if defined(CFHD_HIPEMU)
-template <typename T> __device__ __forceinline__ T *wave_uniform_ptr(T *p) { return p; }
-#else
-template <typename T> __device__ __forceinline__ T *wave_uniform_ptr(T *p)
-{
-	const uint64_t v = (uint64_t)p;
-	const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
-	return (T *)(((uint64_t)hi << 32) | lo);
-}
-#endif
 
 struct StripRow { uint32_t d[4]; };                   // 8 band columns = 4 column pairs
 __device__ __forceinline__ StripRow strip_load(const int16_t *p) { const cfhd_u4 v = CFHD_LDG128(p); StripRow r; r.d[0] = v.x; r.d[1] = v.y; r.d[2] = v.z; r.d[3] = v.w; return r; }
