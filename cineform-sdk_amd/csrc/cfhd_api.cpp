@@ -276,10 +276,116 @@ struct Decoder {
 	DecodeBatch batch; bool batch_ready = false;
 	uint32_t frames_decoded = 0;
 	StageProfile prof;
+	struct DecodeService *service = nullptr; bool service_interlaced = false;
 };
 
 struct DecMetadata { std::vector<uint8_t> block; size_t cursor = 0; };
 
+
+// ---- concurrent CFHD_DecodeSample calls share launches -------------------------------------------------------------------------------
+// The reference decoder is synchronous per handle; applications get throughput by decoding on several handles from several threads.  One
+// frame per launch sequence leaves the GPU mostly idle (a dozen launches of kernels that see a single frame), so calls that arrive while
+// another call of the same geometry is in flight are gathered: every caller stages its sample into a slot of a shared DecodeBatch, one
+// of two dispatcher threads (one per batch, each with its own HIP stream) launches whatever has gathered as one multi-frame pass, and every
+// caller copies its own frame out.  A lone caller never comes here (CFHD_DecodeSample uses the handle's own batch).  CFHD_AMD_DECODE_BATCH=n
+// sets the slots per batch (default 8, 0 switches the gathering off).
+struct DecodeServiceKey {
+	int width, height, display_height, encoded_format, precision, prescale[3], out_kind; bool half, interlaced;
+	bool operator==(const DecodeServiceKey &o) const { return memcmp(this, &o, sizeof(*this)) == 0; }
+};
+struct DecodeService {
+	struct Gather {
+		DecodeBatch batch;
+		int claimed = 0, ready = 0, released = 0, state = 0 /* 0 collecting, 1 running, 2 done */, rc = 0;
+		bool bad = false; uint32_t gen = 0;
+		std::vector<void *> out; std::vector<int> pitch;
+		std::thread worker;
+	};
+	DecodeServiceKey key;
+	int slots = 8; bool ok = false, stop = false;
+	std::mutex m; std::condition_variable cv_callers, cv_workers;
+	Gather g[2];
+	std::atomic<int> inflight{0};
+	uint32_t launches = 0;
+
+	bool start(const FramePlan &plan, int out_kind, bool half, bool interlaced, int nslots)
+	{
+		slots = nslots;
+		const size_t cap = (size_t)plan.width * plan.height * pixel_bytes_of(out_kind) + 65536;
+		for (Gather &x : g) {
+			x.batch.set_interlaced(interlaced);
+			if (x.batch.prepare(plan, slots, out_kind, true, half) || x.batch.prepare_entropy(cap) || !x.batch.entropy().chunk_indexed()) return false;
+			x.out.assign((size_t)slots, nullptr); x.pitch.assign((size_t)slots, 0);
+		}
+		for (int k = 0; k < 2; k++) g[k].worker = std::thread([this, k] { run(g[k]); });
+		ok = true;
+		return true;
+	}
+	void run(Gather &x)
+	{
+		(void)device_init();                               // the device is selected per thread
+		std::unique_lock<std::mutex> lk(m);
+		for (;;) {
+			cv_workers.wait(lk, [&] { return stop || (x.state == 0 && x.claimed > 0 && x.ready == x.claimed); });
+			if (stop) return;
+			x.state = 1;
+			const int n = x.claimed; const bool bad = x.bad; const uint32_t seed = 0x2545F491u * ++launches;
+			lk.unlock();
+			int rc = 0;
+			if (!bad) {
+				x.batch.set_active(n);
+				rc = x.batch.entropy().launch();
+				if (!rc) rc = x.batch.launch_inverse(seed);
+				for (int i = 0; i < n && !rc; i++) rc = x.batch.download_frame(i, x.out[i], x.pitch[i]);
+				if (!rc) rc = x.batch.wait(); else (void)x.batch.wait();
+				if (!rc && x.batch.entropy().check()) rc = 1;
+			}
+			lk.lock();
+			x.rc = rc; x.state = 2;
+			cv_callers.notify_all();
+		}
+	}
+	// 0: decoded into out; 1: not decoded here (a damaged sample in the gathered pass, or a device error): the caller takes its own path
+	int decode(const uint8_t *sample, size_t size, void *out, int pitch)
+	{
+		std::unique_lock<std::mutex> lk(m);
+		Gather *x = nullptr;
+		cv_callers.wait(lk, [&] {
+			// join the pass that is gathering; else open one on a free batch
+			for (Gather &c : g) if (c.state == 0 && c.claimed > 0 && c.claimed < slots) { x = &c; return true; }
+			for (Gather &c : g) if (c.state == 0 && c.claimed == 0) { x = &c; return true; }
+			return false;
+		});
+		const int i = x->claimed++; const uint32_t gen = x->gen;
+		x->out[i] = out; x->pitch[i] = pitch;
+		lk.unlock();
+		const int staged = x->batch.entropy().set_sample_host(i, sample, size);      // parse + copy into the slot's pinned memory, beside the other callers
+		lk.lock();
+		if (staged) x->bad = true;
+		x->ready++;
+		cv_workers.notify_all();
+		cv_callers.wait(lk, [&] { return x->state == 2 && x->gen == gen; });
+		const bool failed = x->bad || x->rc != 0;
+		lk.unlock();
+		if (!failed) x->batch.finish_frame(i, out, pitch);                            // every caller copies its own frame out of the pinned staging
+		lk.lock();
+		if (++x->released == x->claimed) { x->claimed = x->ready = x->released = 0; x->bad = false; x->rc = 0; x->state = 0; x->gen++; cv_callers.notify_all(); cv_workers.notify_all(); }
+		return failed ? 1 : 0;
+	}
+};
+struct DecodeServices {
+	std::mutex m;
+	std::vector<DecodeService *> list;         // never freed: the dispatcher threads and their HIP objects live as long as the process
+	DecodeService *find(const DecodeServiceKey &key)
+	{
+		std::lock_guard<std::mutex> lk(m);
+		for (DecodeService *s : list) if (s->key == key) return s;
+		DecodeService *s = new DecodeService; s->key = key; list.push_back(s);
+		return s;
+	}
+};
+DecodeServices &decode_services() { static DecodeServices *s = new DecodeServices; return *s; }
+int decode_gather_slots() { static const int n = [] { const char *e = getenv("CFHD_AMD_DECODE_BATCH"); int v = e ? atoi(e) : 8; return v < 0 ? 0 : (v > 64 ? 64 : v); }(); return n; }
 
 void plan_from_sample(const ParsedSample &ps, int out_kind, FramePlan *plan, bool *ok)
 {
@@ -711,6 +817,8 @@ CFHD_Error CFHD_GetImageSize(uint32_t width, uint32_t height, CFHD_PixelFormat f
 	return ERR_OKAY;
 }
 
+static CFHD_Error decode_on_handle(Decoder *d, const ParsedSample &ps, const uint8_t *s, size_t size, void *out, int32_t pitch, bool interlaced);
+
 CFHD_Error CFHD_DecodeSample(CFHD_DecoderRef ref, void *sample, size_t size, void *out, int32_t pitch)
 {
 	if (!ref || !sample || !out) return ERR_INVALID_ARGUMENT;
@@ -729,6 +837,40 @@ CFHD_Error CFHD_DecodeSample(CFHD_DecoderRef ref, void *sample, size_t size, voi
 	// interlaced samples (known only now: the SAMPLE_FLAGS tag lies behind the 512 bytes CFHD_PrepareToDecode sees): 4:2:2 at full resolution
 	const bool interlaced = !ps.progressive;
 	if (interlaced && (ps.encoded_format != ENC_YUV422 || d->half)) return fail_zero(ERR_BADFORMAT);
+	// another call of this geometry in flight right now: decode together with it (see DecodeService)
+	if (decode_gather_slots() > 1 && gpu_entropy_enabled() && size <= (size_t)d->plan.width * d->plan.height * pixel_bytes_of(d->out_kind) + 65536) {
+		if (!d->service || d->service_interlaced != interlaced) {
+			DecodeServiceKey key; memset(&key, 0, sizeof(key));
+			key.width = d->plan.width; key.height = d->plan.height; key.display_height = d->plan.display_height; key.encoded_format = d->plan.encoded_format;
+			key.precision = d->plan.precision; for (int k = 0; k < 3; k++) key.prescale[k] = d->plan.prescale[k];
+			key.out_kind = d->out_kind; key.half = d->half; key.interlaced = interlaced;
+			d->service = decode_services().find(key); d->service_interlaced = interlaced;
+		}
+		DecodeService *svc = d->service;
+		struct InFlight { std::atomic<int> &n; int before; InFlight(std::atomic<int> &c) : n(c), before(c.fetch_add(1)) {} ~InFlight() { n.fetch_sub(1); } } mark(svc->inflight);
+		if (mark.before > 0) {
+			bool usable;
+			{
+				std::lock_guard<std::mutex> lk(svc->m);
+				if (!svc->ok && !svc->stop) { if (!svc->start(d->plan, d->out_kind, d->half, interlaced, decode_gather_slots())) svc->stop = true; }   // (stop without ok: could not be set up, never tried again)
+				usable = svc->ok;
+			}
+			if (usable && svc->decode(s, size, out, pitch) == 0) return ERR_OKAY;
+			// not decoded there (damaged sample in the pass, device trouble): this handle's own path gives this sample its own verdict
+		}
+		return decode_on_handle(d, ps, s, size, out, pitch, interlaced);
+	}
+	return decode_on_handle(d, ps, s, size, out, pitch, interlaced);
+}
+
+// One sample on the handle's own batch of one frame (the only path of a caller that decodes alone).
+static CFHD_Error decode_on_handle(Decoder *d, const ParsedSample &ps, const uint8_t *s, size_t size, void *out, int32_t pitch, bool interlaced)
+{
+	auto fail_zero = [&](int err) {                                               // decode failure zero-fills the output (decoder.c:11850-11859)
+		const int rowbytes = packed_frame_pitch(d->out_kind, d->half ? d->plan.width / 2 : d->plan.width), rows = d->half ? d->plan.display_height / 2 : d->plan.display_height;
+		for (int r = 0; r < rows; r++) memset((uint8_t *)out + (ptrdiff_t)r * pitch, 0, (size_t)rowbytes);
+		return err;
+	};
 	if (d->batch_ready && d->batch.interlaced() != interlaced) d->batch_ready = false;
 	if (!d->batch_ready) {
 		d->batch.set_interlaced(interlaced);

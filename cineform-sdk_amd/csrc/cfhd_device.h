@@ -70,6 +70,8 @@ public:
 	// interlaced 4:2:2 samples: the last level is the inverse frame transform (k_inv_frame_yuv422); 8-bit 4:2:2 output, full resolution
 	void set_interlaced(bool on) { interlaced_ = on; ent_.set_interlaced(on); }
 	bool interlaced() const { return interlaced_; }
+	// the next launches (entropy decoder with host-parsed samples, inverse transform) cover frames 0 .. k-1 only (0 = all)
+	void set_active(int k) { active_ = k; ent_.set_active(k); }
 	int nframes() const { return n_; }
 	const FramePlan &plan() const { return plan_; }
 	int16_t *host_coeffs(int i) { return h_coeff_ + (size_t)i * plan_.final_elems; }   // host entropy decoder writes here
@@ -94,7 +96,7 @@ private:
 	void release();
 	int sync_jobs();
 	FramePlan plan_;
-	int n_ = 0, out_kind_ = 0; bool own_output_ = false, jobs_dirty_ = true, half_ = false, interlaced_ = false;
+	int n_ = 0, out_kind_ = 0; bool own_output_ = false, jobs_dirty_ = true, half_ = false, interlaced_ = false; int active_ = 0;
 	void *stream_ = nullptr, *ev0_ = nullptr, *ev1_ = nullptr, *evl_[2] = {nullptr, nullptr};
 	float level_ms_[3] = {0, 0, 0};
 	int16_t *d_coeff_ = nullptr, *h_coeff_ = nullptr;

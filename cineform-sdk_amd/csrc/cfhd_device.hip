@@ -633,6 +633,7 @@ int DecodeBatch::launch_inverse(uint32_t dither_seed)
 	if (rc) return rc;
 	hipStream_t st = (hipStream_t)stream_;
 	const int nch = plan_.num_channels;
+	const int act = active_ > 0 && active_ < n_ ? active_ : n_;      // frames 0 .. act-1 carry pyramids (set_active)
 	DecJobs j = dec_jobs_at(d_jobs_, n_, nch);
 	(void)hipGetLastError();
 	timed_ = true;
@@ -641,7 +642,7 @@ int DecodeBatch::launch_inverse(uint32_t dither_seed)
 		const BandDesc &b = plan_.ch[0].band[lv][0];
 		const dev::InvPlaneJob *jobs = lv == 2 ? j.l3 : j.l2;
 		if (planes_as_strips(plan_, lv)) {
-			const int n = n_;
+			const int n = act;
 			for_channel_runs(plan_, lv, [&](int c0, int nc, int glog, const BandDesc &cb) {
 				const int nstrips = (cb.height + dev::SRP - 1) / dev::SRP, per_wave = 64 >> glog, waves = ((n * nc + per_wave - 1) / per_wave) * nstrips;
 				dev::k_inv_plane_strip<<<(waves + 3) / 4, dev::NTHREADS, 0, st>>>(jobs, n, nch, c0, nc, glog, nstrips, cb.width, cb.height);
@@ -649,31 +650,31 @@ int DecodeBatch::launch_inverse(uint32_t dither_seed)
 			HIPCHK(hipEventRecord((hipEvent_t)evl_[2 - lv], st));
 			continue;
 		}
-		dim3 grid((b.width + dev::ITW - 1) / dev::ITW, (b.height + dev::ITH - 1) / dev::ITH, n_ * nch);
+		dim3 grid((b.width + dev::ITW - 1) / dev::ITW, (b.height + dev::ITH - 1) / dev::ITH, act * nch);
 		dev::k_inv_plane<<<grid, dev::NTHREADS, 0, st>>>(jobs);
 		HIPCHK(hipEventRecord((hipEvent_t)evl_[2 - lv], st));
 	}
 	if (interlaced_ && (half_ || is_packed16(out_kind_))) return -1;
 	if (half_ && is_packed16(out_kind_)) {
 		const BandDesc &b = plan_.ch[0].band[0][0];
-		dev::k_half_packed16<<<dim3((b.width / 8 + dev::NTHREADS - 1) / dev::NTHREADS, out_rows_, n_), dev::NTHREADS, 0, st>>>(j.halfp);
+		dev::k_half_packed16<<<dim3((b.width / 8 + dev::NTHREADS - 1) / dev::NTHREADS, out_rows_, act), dev::NTHREADS, 0, st>>>(j.halfp);
 	} else if (half_) {
 		const BandDesc &b = plan_.ch[0].band[0][0];
-		dev::k_half_yuv422<<<dim3((b.width / 8 + dev::NTHREADS - 1) / dev::NTHREADS, out_rows_, n_), dev::NTHREADS, 0, st>>>(j.half);
+		dev::k_half_yuv422<<<dim3((b.width / 8 + dev::NTHREADS - 1) / dev::NTHREADS, out_rows_, act), dev::NTHREADS, 0, st>>>(j.half);
 	} else if (is_packed16(out_kind_)) {
 		const BandDesc &b = plan_.ch[0].band[0][0];
-		dim3 grid(((b.width + dev::ITW - 1) / dev::ITW) * nch, (b.height + dev::ITH - 1) / dev::ITH, n_);
+		dim3 grid(((b.width + dev::ITW - 1) / dev::ITW) * nch, (b.height + dev::ITH - 1) / dev::ITH, act);
 		dev::k_inv_packed16<<<grid, dev::NTHREADS, 0, st>>>(j.l1, nch);
 	} else if (interlaced_) {
 		const BandDesc &b = plan_.ch[0].band[0][0];
-		dev::k_inv_frame_yuv422<<<dim3((b.width / 2 + dev::NTHREADS - 1) / dev::NTHREADS, b.height, n_), dev::NTHREADS, 0, st>>>(j.yuv, dither_seed);
+		dev::k_inv_frame_yuv422<<<dim3((b.width / 2 + dev::NTHREADS - 1) / dev::NTHREADS, b.height, act), dev::NTHREADS, 0, st>>>(j.yuv, dither_seed);
 	} else if (strip_inverse()) {
 		const BandDesc &b = plan_.ch[0].band[0][0];
 		const int nseg = (b.width / dev::SBLK + dev::SSEG - 1) / dev::SSEG;
-		dev::k_inv_yuv422_strip<<<dim3(nseg, (b.height + dev::SR - 1) / dev::SR, n_), dev::NTHREADS, 0, st>>>(j.yuv, dither_seed);
+		dev::k_inv_yuv422_strip<<<dim3(nseg, (b.height + dev::SR - 1) / dev::SR, act), dev::NTHREADS, 0, st>>>(j.yuv, dither_seed);
 	} else {
 		const BandDesc &b = plan_.ch[0].band[0][0];
-		dim3 grid((b.width + dev::ITW - 1) / dev::ITW, (b.height + dev::ITH - 1) / dev::ITH, n_);
+		dim3 grid((b.width + dev::ITW - 1) / dev::ITW, (b.height + dev::ITH - 1) / dev::ITH, act);
 		dev::k_inv_yuv422<<<grid, dev::NTHREADS, 0, st>>>(j.yuv, dither_seed);
 	}
 	HIPCHK(hipGetLastError());

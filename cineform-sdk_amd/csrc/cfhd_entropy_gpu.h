@@ -58,6 +58,8 @@ public:
 	~GpuEntropyDecoder();
 	// before the samples are set: interlaced samples (frame transform; one band per channel in code set 18, difference coded, maybe with a peak table)
 	void set_interlaced(bool on) { interlaced_ = on; }
+	// host-parsed samples only: the next launch() covers frames 0 .. k-1 of the batch (0 = all; a batch that gathers concurrent callers is rarely full)
+	void set_active(int k) { active_ = k; }
 	void set_skip_level1(bool skip) { skip_level1_ = skip; }            // before prepare(): host-parsed samples decode levels 2 and 3 only
 	int prepare(const FramePlan &plan, int nframes, int16_t *d_coeffs, size_t coeff_stride_elems, size_t sample_cap, int out_pixel_kind, void *stream);
 	// Sample bytes on the host: staged through pinned memory and copied to HBM by launch().
@@ -84,6 +86,8 @@ private:
 	void *d_tables_ = nullptr, *d_bandjobs_ = nullptr, *d_lowjobs_ = nullptr, *d_plan_ = nullptr;
 	void *ev_headers_ = nullptr, *ev_payloads_ = nullptr;
 	bool skip_level1_ = false, interlaced_ = false; void *d_diffjobs_ = nullptr;
+	int active_ = 0;
+	int active_frames() const { return active_ > 0 && active_ < n_ ? active_ : n_; }
 	const uint8_t *ext_samples_ = nullptr; size_t ext_stride_ = 0; const uint32_t *ext_sizes_ = nullptr;   // set_samples_device()
 	int *d_errors_ = nullptr, *h_errors_ = nullptr;
 	bool lane_kernel_ = false;

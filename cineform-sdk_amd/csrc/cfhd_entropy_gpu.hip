@@ -323,11 +323,11 @@ int GpuEntropyDecoder::launch()
 	if (dx_) {
 		// host-parsed samples: the [slot][frame] job table and the chunk numbering come from the host
 		dev::DecPlan dp; dec_build_plan(plan_, out_kind_, &dp);
-		const int nch = plan_.num_channels, nb = dp.bands_per_frame * n_;
+		const int nch = plan_.num_channels, act = active_frames(), nb = dp.bands_per_frame * act;      // frames 0 .. act-1 of the batch carry samples
 		HIPCHK(hipStreamSynchronize(st));                                     // the pinned tables of the previous launch may still be in flight
-		for (int f = 0; f < n_; f++) {
+		for (int f = 0; f < act; f++) {
 			if ((int)host_->bands[f].size() != dp.bands_per_frame || (int)host_->lows[f].size() != nch) return -1;
-			for (int s = 0; s < dp.bands_per_frame; s++) host_->flat_bands[(size_t)s * n_ + f] = host_->bands[f][s];
+			for (int s = 0; s < dp.bands_per_frame; s++) host_->flat_bands[(size_t)s * act + f] = host_->bands[f][s];
 			for (int c = 0; c < nch; c++) host_->flat_lows[(size_t)f * nch + c] = host_->lows[f][c];
 			if (interlaced_) { if ((int)host_->diffs[f].size() != nch) return -1; for (int c = 0; c < nch; c++) host_->flat_diffs[(size_t)f * nch + c] = host_->diffs[f][c]; }
 		}
@@ -337,11 +337,11 @@ int GpuEntropyDecoder::launch()
 		memcpy(h_chunk_job_, cj.data(), cj.size() * sizeof(dev::DxChunkDesc));
 		h_counters_[0] = nchunks; h_counters_[1] = 0; h_counters_[2] = 0;
 		HIPCHK(hipMemsetAsync(d_errors_, 0, sizeof(int), st));
-		for (int f = 0; f < n_; f++)
+		for (int f = 0; f < act; f++)
 			if (host_->host_bytes[f]) HIPCHK(hipMemcpyAsync(d_samples_ + cap_ * f, h_samples_ + cap_ * f, host_->host_bytes[f], hipMemcpyHostToDevice, st));
 		HIPCHK(hipMemcpyAsync(d_bandjobs_, host_->flat_bands, (size_t)nb * sizeof(dev::DecBandJob), hipMemcpyHostToDevice, st));
-		HIPCHK(hipMemcpyAsync(d_lowjobs_, host_->flat_lows, (size_t)n_ * nch * sizeof(dev::DecLowpassJob), hipMemcpyHostToDevice, st));
-		if (interlaced_) HIPCHK(hipMemcpyAsync(d_diffjobs_, host_->flat_diffs, (size_t)n_ * nch * sizeof(dev::DecDiffJob), hipMemcpyHostToDevice, st));
+		HIPCHK(hipMemcpyAsync(d_lowjobs_, host_->flat_lows, (size_t)act * nch * sizeof(dev::DecLowpassJob), hipMemcpyHostToDevice, st));
+		if (interlaced_) HIPCHK(hipMemcpyAsync(d_diffjobs_, host_->flat_diffs, (size_t)act * nch * sizeof(dev::DecDiffJob), hipMemcpyHostToDevice, st));
 		HIPCHK(hipMemcpyAsync(d_chunk_job_, h_chunk_job_, (size_t)nchunks * sizeof(dev::DxChunkDesc), hipMemcpyHostToDevice, st));
 		HIPCHK(hipMemcpyAsync(d_counters_, h_counters_, 16, hipMemcpyHostToDevice, st));
 		(void)hipGetLastError();
@@ -350,7 +350,7 @@ int GpuEntropyDecoder::launch()
 		int rc = launch_dx(false, nb, nchunks);
 		if (rc) return rc;
 		HIPCHK(hipEventRecord((hipEvent_t)ev_[2], st));
-		dev::k_dec_lowpass<<<dim3(8, (unsigned)(n_ * nch)), 256, 0, st>>>((const dev::DecLowpassJob *)d_lowjobs_);
+		dev::k_dec_lowpass<<<dim3(8, (unsigned)(act * nch)), 256, 0, st>>>((const dev::DecLowpassJob *)d_lowjobs_);
 		HIPCHK(hipGetLastError());
 		HIPCHK(hipEventRecord((hipEvent_t)ev_[3], st));
 		timed_ = true;
@@ -396,7 +396,8 @@ int GpuEntropyDecoder::launch_dx(bool device_jobs, int njobs, uint32_t host_chun
 	dev::DecBandJob *jobs = (dev::DecBandJob *)d_bandjobs_;
 	const dev::DecIdxTables *T = (const dev::DecIdxTables *)d_idx_tables_;
 	dev::DecPlan dp; dec_build_plan(plan_, out_kind_, &dp);
-	const dev::DxTilePlan tp = dx_tile_plan(plan_, dp, n_, skip_level1_);
+	const int frames = device_jobs ? n_ : active_frames();
+	const dev::DxTilePlan tp = dx_tile_plan(plan_, dp, frames, skip_level1_);
 	const char *spec_env = getenv("CFHD_AMD_DX_SPECULATE");
 	const bool speculate = !(spec_env && atoi(spec_env) == 0);            // 0: every chunk goes through the repair path (tests)
 	if (device_jobs) HIPCHK(hipMemsetAsync((uint32_t *)d_counters_ + 1, 0, 8, st));      // the repair and re-index lists start empty (the host path uploads zeroed counters)
@@ -423,7 +424,7 @@ int GpuEntropyDecoder::launch_dx(bool device_jobs, int njobs, uint32_t host_chun
 	                                                                                                  (uint32_t *)d_tile_start_);
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[6], st));
 	dev::k_dec_tiles<<<g3, dev::DX_TILE_THREADS, 0, st>>>(jobs, tp, T, (const uint32_t *)d_entries_, (const uint32_t *)d_chunk_base_, (const dev::DxBandSum *)d_sums_, (const uint32_t *)d_tile_start_);
-	if (interlaced_) dev::k_dec_undiff<<<n_ * plan_.num_channels, dev::DXU_THREADS, 0, st>>>((const dev::DecDiffJob *)d_diffjobs_, d_errors_);
+	if (interlaced_) dev::k_dec_undiff<<<frames * plan_.num_channels, dev::DXU_THREADS, 0, st>>>((const dev::DecDiffJob *)d_diffjobs_, d_errors_);
 	HIPCHK(hipGetLastError());
 	return 0;
 }

@@ -717,3 +717,57 @@ def test_large_user_metadata_takes_the_host_writer():
         L.CFHD_MetadataClose(md); L.CFHD_CloseEncoder(enc)
     assert len(outs[0]) == len(outs[1]) and mask_volatile_metadata(outs[0]) == mask_volatile_metadata(outs[1])
     assert blob in outs[0]
+
+
+def test_concurrent_decoders_share_launches_and_stay_exact():
+    """Eight threads, each with its own decoder handle, decode different samples at the same time: calls that overlap are gathered into
+    multi-frame launches (cfhd_api.cpp DecodeService).  Every frame must come out as if decoded alone -- inside the dither interval of the
+    exact reconstruction of *its* sample -- and a damaged sample must fail on its own handle only (BADSAMPLE, zero-filled output) while the
+    calls gathered with it succeed."""
+    import threading
+    w, h, nthreads, rounds = 1280, 720, 8, 12
+    frames = [synth_yuy2(w, h, 40 + k)[0] for k in range(4)]
+    samples = ref_encode_frames(frames, w * 2, w, h)
+    plan = Plan(w, h)
+    bounds = []
+    for smp in samples:
+        deq = host_decode_pyramid(smp, plan)
+        bounds.append((oracle_inverse_yuv422(plan, deq, 0)[:h], oracle_inverse_yuv422(plan, deq, 1)[:h]))
+    damaged = bytearray(samples[0]); damaged[len(damaged) // 2: len(damaged) // 2 + 64] = bytes(64)
+    damaged = bytes(damaged)
+    L = product()
+    errors = []
+
+    def worker(t):
+        try:
+            dec = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
+            aw = ctypes.c_int(); ah = ctypes.c_int(); af = ctypes.c_uint32()
+            first = ctypes.create_string_buffer(samples[0], len(samples[0]))
+            assert L.CFHD_PrepareToDecode(dec, 0, 0, PIX_YUY2, 1, 0, first, 512, ctypes.byref(aw), ctypes.byref(ah), ctypes.byref(af)) == 0
+            out = np.zeros(h * w * 2, np.uint8)
+            for r in range(rounds):
+                k = (t + r) % len(samples)
+                bad = t == 3 and r % 4 == 1
+                data = damaged if bad else samples[k]
+                sb = ctypes.create_string_buffer(data, len(data))
+                out[:] = 7
+                rc = L.CFHD_DecodeSample(dec, sb, len(data), out.ctypes.data_as(ctypes.c_void_p), w * 2)
+                if bad:
+                    if rc == 0:                                        # the damage may happen to decode (zeros are valid code words)
+                        assert out.any()
+                    else:
+                        assert rc == 5 and not out.any(), (rc, t, r)    # CFHD_ERROR_BADSAMPLE, zero-filled
+                    continue
+                assert rc == 0, (rc, t, r, amd_last_error())
+                img = out.reshape(h, w * 2)
+                lo, hi = bounds[k]
+                ok = (img == lo) | (img == hi)
+                assert ok.all(), "thread %d round %d: %d bytes outside the dither interval" % (t, r, (~ok).sum())
+            L.CFHD_CloseDecoder(dec)
+        except BaseException as e:                                 # noqa: surfaced in the main thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(nthreads)]
+    for t in threads: t.start()
+    for t in threads: t.join()
+    if errors: raise errors[0]
