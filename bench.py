@@ -120,128 +120,26 @@ def cpu_baseline(frames, pitch, W, H, seconds_budget=20.0, fmt=None, enc=0, flag
                       % (sent, enc_fps, cores, done, dec_fps, W, H, label)}
 
 
-def c_abi_rates(frames, pitch, W, H, seconds=1.5, registered=False):
-    """The product through the reference's own C ABI, host buffers in and out (PCIe inclusive): what a caller of CFHD_* sees.
-    sync: one handle, one thread; pool: CFHD_*EncoderPool with `workers` HIP-stream workers; handles: N decoders on N host threads;
-    round_trip: the pool encoding and N decoders decoding its samples at the same time, frames per second through both.
-    registered: the caller page-locked its frame and output buffers once (cfhd_amd_register_host_buffer, an optional extension), so the
-    library DMAs between them and HBM without its staging copy."""
-    import cfhd_testlib as T
-    import numpy as np
-    L = T.product()
-    L.cfhd_amd_register_host_buffer.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
-    L.cfhd_amd_unregister_host_buffer.argtypes = [ctypes.c_void_p]
-    nfr = len(frames)
-    res = {}
-    if registered:
-        for f in frames: assert L.cfhd_amd_register_host_buffer(f.ctypes.data, f.nbytes) == 0
-    def new_output():
-        out = np.zeros(W * 2 * H, np.uint8)
-        if registered: assert L.cfhd_amd_register_host_buffer(out.ctypes.data, out.nbytes) == 0
-        return out
-    def drop_output(out):
-        if registered: L.cfhd_amd_unregister_host_buffer(out.ctypes.data)
-    enc = ctypes.c_void_p(); assert L.CFHD_OpenEncoder(ctypes.byref(enc), None) == 0
-    assert L.CFHD_PrepareToEncode(enc, W, H, T.PIX_YUY2, T.ENCODED_YUV422, 0, T.QUALITY_FILMSCAN1) == 0
-    samples = []
-    def enc_one(i):
-        assert L.CFHD_EncodeSample(enc, frames[i % nfr].ctypes.data_as(ctypes.c_void_p), pitch) == 0
-    for i in range(nfr):
-        enc_one(i)
-        p = ctypes.c_void_p(); sz = ctypes.c_size_t()
-        assert L.CFHD_GetSampleData(enc, ctypes.byref(p), ctypes.byref(sz)) == 0
-        samples.append(ctypes.string_at(p, sz.value))
-    t0 = time.perf_counter(); n = 0
-    while time.perf_counter() - t0 < seconds:
-        enc_one(n); n += 1
-    res["sync_encode_fps"] = round(n / (time.perf_counter() - t0), 1)
-    L.CFHD_CloseEncoder(enc)
-    sbs = [ctypes.create_string_buffer(s, len(s)) for s in samples]
-
-    def decoder_loop(stop, ready, done, k):
-        dec = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
-        aw = ctypes.c_int(); ah = ctypes.c_int(); af = ctypes.c_uint32()
-        assert L.CFHD_PrepareToDecode(dec, 0, 0, T.PIX_YUY2, 1, 0, sbs[0], 512, ctypes.byref(aw), ctypes.byref(ah), ctypes.byref(af)) == 0
-        out = new_output()
-        i = k
-        while not stop.is_set():
-            assert L.CFHD_DecodeSample(dec, sbs[i % nfr], len(samples[i % nfr]), out.ctypes.data_as(ctypes.c_void_p), W * 2) == 0
-            i += 1
-            done[k] += 1
-            if done[k] == 3: ready[k] = True               # buffers allocated, pipeline warm
-        L.CFHD_CloseDecoder(dec)
-        drop_output(out)
-
-    def decode_rate(nthreads):
-        stop = threading.Event(); ready = [False] * nthreads; done = [0] * nthreads
-        th = [threading.Thread(target=decoder_loop, args=(stop, ready, done, k)) for k in range(nthreads)]
-        for t in th: t.start()
-        while not all(ready): time.sleep(0.005)
-        a = sum(done); t0 = time.perf_counter()
-        time.sleep(seconds)
-        b = sum(done); t1 = time.perf_counter()
-        stop.set()
-        for t in th: t.join()
-        return (b - a) / (t1 - t0)
-    res["sync_decode_fps"] = round(decode_rate(1), 1)
-    handles = 8
-    res["decode_fps_%d_handles" % handles] = round(decode_rate(handles), 1)
-
-    def pool_run(workers, consumer=None):
-        pool = ctypes.c_void_p()
-        assert L.CFHD_CreateEncoderPool(ctypes.byref(pool), workers, 2 * workers, None) == 0
-        assert L.CFHD_PrepareEncoderPool(pool, W, H, T.PIX_YUY2, T.ENCODED_YUV422, 0, T.QUALITY_FILMSCAN1) == 0
-        assert L.CFHD_StartEncoderPool(pool) == 0
-        got = 0
-        def collect(wait):
-            num = ctypes.c_uint32(); sb = ctypes.c_void_p()
-            rc = (L.CFHD_WaitForSample if wait else L.CFHD_TestForSample)(pool, ctypes.byref(num), ctypes.byref(sb))
-            if rc == 0:
-                if consumer: consumer(sb)
-                L.CFHD_ReleaseSampleBuffer(pool, sb)
-            return rc == 0
-        t0 = time.perf_counter(); sent = 0
-        while time.perf_counter() - t0 < seconds or sent < 4 * workers:
-            assert L.CFHD_EncodeAsyncSample(pool, sent, frames[sent % nfr].ctypes.data_as(ctypes.c_void_p), pitch, None) == 0
-            sent += 1
-            while collect(False): got += 1
-        while got < sent:
-            if collect(True): got += 1
-        dt = time.perf_counter() - t0
-        L.CFHD_ReleaseEncoderPool(pool)
-        return sent / dt
-    workers = 16
-    res["pool_encode_fps_%d_workers" % workers] = round(pool_run(workers), 1)
-
-    # round trip through CFHD_* only: the pool's samples go straight to decoder threads (bounded queue), frames counted when decoded
-    import queue
-    q = queue.Queue(maxsize=4 * handles); decoded = [0]; lock = threading.Lock()
-    def rt_decoder():
-        dec = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
-        aw = ctypes.c_int(); ah = ctypes.c_int(); af = ctypes.c_uint32()
-        assert L.CFHD_PrepareToDecode(dec, 0, 0, T.PIX_YUY2, 1, 0, sbs[0], 512, ctypes.byref(aw), ctypes.byref(ah), ctypes.byref(af)) == 0
-        out = new_output()
-        while True:
-            s = q.get()
-            if s is None: break
-            assert L.CFHD_DecodeSample(dec, s, len(s), out.ctypes.data_as(ctypes.c_void_p), W * 2) == 0
-            with lock: decoded[0] += 1
-        L.CFHD_CloseDecoder(dec)
-        drop_output(out)
-    th = [threading.Thread(target=rt_decoder) for _ in range(handles)]
-    for t in th: t.start()
-    def hand_over(sb):
-        p = ctypes.c_void_p(); sz = ctypes.c_size_t()
-        L.CFHD_GetEncodedSample(sb, ctypes.byref(p), ctypes.byref(sz))
-        q.put(ctypes.string_at(p, sz.value))
-    t0 = time.perf_counter()
-    pool_run(workers, hand_over)
-    for _ in th: q.put(None)
-    for t in th: t.join()
-    res["round_trip_fps_pool%d_plus_%d_decoders" % (workers, handles)] = round(decoded[0] / (time.perf_counter() - t0), 1)
-    if registered:
-        for f in frames: L.cfhd_amd_unregister_host_buffer(f.ctypes.data)
-    return res
+def c_abi_rates(frames, pitch, W, H, seconds=1.5, registered=False, decoders=8, workers=16):
+    """The product through the reference's own C ABI, host buffers in and out (PCIe inclusive): what a C/C++ caller of CFHD_* sees, measured
+    by a plain C++ program (tools/cabi_bench.cpp, built against include/cfhd_amd.h and the library only).
+    sync: one handle, one thread; pool: CFHD_*EncoderPool with `workers` HIP-stream workers; handles: N decoders on N host threads (calls
+    that overlap share launches); round_trip: the pool encoding and N decoder threads decoding its samples at the same time, frames per
+    second through both.  registered: the caller page-locked its frame and output buffers once (cfhd_amd_register_host_buffer, an optional
+    extension), so the library DMAs between them and HBM without its staging copy."""
+    import subprocess, tempfile
+    tool = os.path.join(ROOT, "tools", "_build", "cabi_bench")
+    if not os.path.exists(tool):
+        return {"error": "tools/_build/cabi_bench is not built (run __graft_entry__.build())"}
+    with tempfile.NamedTemporaryFile(suffix=".yuy2") as f:
+        for fr in frames:
+            f.write(fr.reshape(H, pitch)[:, : W * 2].tobytes())
+        f.flush()
+        out = subprocess.run([tool, str(W), str(H), f.name, str(len(frames)), str(seconds), "1" if registered else "0", str(decoders), str(workers)],
+                             capture_output=True, text=True, timeout=300)
+    if out.returncode != 0:
+        return {"error": (out.stderr or out.stdout).strip()[-300:]}
+    return json.loads(out.stdout.strip().splitlines()[-1])
 
 
 def normalise_counters(sample):
@@ -475,6 +373,7 @@ def main():
         if world == 1 and not args.no_c_abi and headline:
             line["config"]["c_abi_fps"] = {"frame": "%dx%d YUY2, frames and samples in host memory (PCIe inclusive)" % (W, H),
                                            "plain_buffers": c_abi_rates(frames[:8], pitch, W, H),
+                                           "plain_buffers_16_decoder_threads": c_abi_rates(frames[:8], pitch, W, H, decoders=16),
                                            "buffers_registered_by_the_caller": c_abi_rates(frames[:8], pitch, W, H, registered=True)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(frames[:8], pitch, W, H, fmt=fmt, enc=wl["enc"], flags=wl["flags"], decode=wl["mode"] == 0, bpp=wl["bpp"], label=wl["fmt"])
