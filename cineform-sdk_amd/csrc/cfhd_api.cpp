@@ -197,6 +197,162 @@ int encode_one(EncodeBatch &batch, EncodeParams &p, const void *frame, int pitch
 	return host_write();
 }
 
+// ---- calls that overlap share launches -----------------------------------------------------------------------------------------------
+// The reference's decoder is synchronous per handle and its encoder pool runs one CPU encoder per thread; applications get throughput by
+// working on several frames from several threads.  On the GPU one frame per launch sequence leaves the chip mostly idle (a dozen launches
+// of kernels that see a single frame), so calls of the same geometry that are in flight at the same time are gathered: every caller stages
+// its frame or sample into a slot of a shared batch, one of two dispatcher threads (one per batch, each with its own HIP stream) launches
+// whatever has gathered as one multi-frame pass, and every caller copies its own result out.  A lone caller never comes here (the handle's
+// own batch of one frame serves it).  CFHD_AMD_DECODE_BATCH=n / CFHD_AMD_ENCODE_BATCH=n set the slots per batch (default 8, 0 = off).
+template <class BatchT> struct Gatherer {
+	struct Pass {
+		BatchT batch;
+		int claimed = 0, ready = 0, released = 0, state = 0 /* 0 collecting, 1 running, 2 done */, rc = 0;
+		bool bad = false; uint32_t gen = 0;
+		std::vector<void *> ptr; std::vector<int> num;      // per slot: what the pass needs from the caller (output buffer + pitch of a decode)
+		std::thread worker;
+	};
+	int slots = 8; bool ok = false, dead = false;
+	std::mutex m; std::condition_variable cv_callers, cv_workers;
+	Pass g[2];
+	std::atomic<int> inflight{0};
+	uint32_t launches = 0;
+	int (*run_pass)(Pass &, int n, uint32_t launch) = nullptr;
+
+	void start_workers()
+	{
+		for (Pass &x : g) { x.ptr.assign((size_t)slots, nullptr); x.num.assign((size_t)slots, 0); }
+		for (int k = 0; k < 2; k++) g[k].worker = std::thread([this, k] { run(g[k]); });
+		ok = true;
+	}
+	void run(Pass &x)
+	{
+		(void)device_init();                               // the device is selected per thread
+		std::unique_lock<std::mutex> lk(m);
+		for (;;) {
+			cv_workers.wait(lk, [&] { return x.state == 0 && x.claimed > 0 && x.ready == x.claimed; });
+			x.state = 1;
+			const int n = x.claimed; const bool bad = x.bad; const uint32_t launch = ++launches;
+			lk.unlock();
+			const int rc = bad ? 0 : run_pass(x, n, launch);
+			lk.lock();
+			x.rc = rc; x.state = 2;
+			cv_callers.notify_all();
+		}
+	}
+	// stage(batch, slot, pass) != 0: this caller's input cannot go through a gathered pass (nobody of the pass is served here then);
+	// finish(batch, slot) copies the caller's result out.  Returns 0 when served, 1 when the caller has to take its own path.
+	template <class Stage, class Finish> int submit(Stage stage, Finish finish)
+	{
+		std::unique_lock<std::mutex> lk(m);
+		Pass *x = nullptr;
+		cv_callers.wait(lk, [&] {
+			// join the pass that is gathering; else open one on a free batch
+			for (Pass &c : g) if (c.state == 0 && c.claimed > 0 && c.claimed < slots) { x = &c; return true; }
+			for (Pass &c : g) if (c.state == 0 && c.claimed == 0) { x = &c; return true; }
+			return false;
+		});
+		const int i = x->claimed++; const uint32_t gen = x->gen;
+		lk.unlock();
+		const int staged = stage(x->batch, i, *x);            // beside the other callers: parse / copy into the slot's pinned memory
+		lk.lock();
+		if (staged) x->bad = true;
+		x->ready++;
+		cv_workers.notify_all();
+		cv_callers.wait(lk, [&] { return x->state == 2 && x->gen == gen; });
+		const bool failed = x->bad || x->rc != 0;
+		lk.unlock();
+		if (!failed) finish(x->batch, i);
+		lk.lock();
+		if (++x->released == x->claimed) { x->claimed = x->ready = x->released = 0; x->bad = false; x->rc = 0; x->state = 0; x->gen++; cv_callers.notify_all(); cv_workers.notify_all(); }
+		return failed ? 1 : 0;
+	}
+};
+int gather_slots(const char *env) { const char *e = getenv(env); int v = e ? atoi(e) : 8; return v < 0 ? 0 : (v > 64 ? 64 : v); }
+
+
+// The encoder side: workers of a pool (or several pools) that encode at the same time.  Only where no frame depends on the previous one:
+// qualities whose quantizer follows the size of the last sample (rate feedback, encode_one) keep one launch sequence per frame.
+struct EncodeServiceKey {
+	int width, height, pixel_kind, encoded_format, quality, color_space; uint32_t flags;
+	bool operator==(const EncodeServiceKey &o) const { return memcmp(this, &o, sizeof(*this)) == 0; }
+};
+struct EncodeService : Gatherer<EncodeBatch> {
+	EncodeServiceKey key;
+	bool start(const EncodeParams &p, int nslots)
+	{
+		slots = nslots;
+		for (Pass &x : g) if (x.batch.prepare(p.plan, slots, true) || x.batch.prepare_entropy(sample_capacity(p))) return false;
+		run_pass = [](Pass &x, int n, uint32_t) {
+			x.batch.set_active(n);
+			int rc = x.batch.launch_forward();
+			if (!rc) rc = x.batch.entropy().launch();
+			if (!rc) rc = x.batch.entropy().download();
+			if (!rc) rc = x.batch.wait(); else (void)x.batch.wait();
+			for (int i = 0; i < n && !rc; i++) if (!x.batch.entropy().sample_bytes(i) || x.batch.entropy().needs_peak_table(i)) rc = 1;   // overflow / peak table: every caller takes its own path
+			return rc;
+		};
+		start_workers();
+		return true;
+	}
+	int encode(const SampleHeaderInfo &hdr, const void *frame, int pitch, uint8_t *out, size_t cap, size_t *size_out)
+	{
+		return submit([&](EncodeBatch &b, int i, Pass &) { int rc = b.upload_frame(i, frame, pitch); if (!rc) rc = b.entropy().set_frame_header(i, hdr); return rc; },
+		              [&](EncodeBatch &b, int i) { const size_t n = b.entropy().sample_bytes(i); if (n <= cap) { memcpy(out, b.entropy().host_sample(i), n); *size_out = n; } else *size_out = 0; });
+	}
+};
+struct EncodeServices {
+	std::mutex m;
+	std::vector<EncodeService *> list;         // never freed (see DecodeServices)
+	EncodeService *find(const EncodeServiceKey &key)
+	{
+		std::lock_guard<std::mutex> lk(m);
+		for (EncodeService *s : list) if (s->key == key) return s;
+		EncodeService *s = new EncodeService; s->key = key; list.push_back(s);
+		return s;
+	}
+};
+EncodeServices &encode_services() { static EncodeServices *s = new EncodeServices; return *s; }
+int encode_gather_slots() { static const int n = gather_slots("CFHD_AMD_ENCODE_BATCH"); return n; }
+// true when the quantizer tables of a sequence never move: FILMSCAN1 (and anything above 1080p for LOW..HIGH) -- decided by asking the
+// derivation itself whether a large previous sample would change them
+bool quantizer_is_static(const EncodeParams &p)
+{
+	FramePlan probe = p.plan; QuantState st = p.qstate;
+	st.lastgopbitcount = (int64_t)p.width * p.height * 64;               // an absurdly large previous sample
+	derive_quantization(&probe, p.quality, p.progressive, 0.0f, &st);
+	for (int c = 0; c < probe.num_channels; c++)
+		for (int lv = 0; lv < kNumLevels; lv++)
+			for (int b = 0; b < kNumBands; b++) if (probe.ch[c].band[lv][b].quant != p.plan.ch[c].band[lv][b].quant) return false;
+	return true;
+}
+
+// encode_one for a caller that may share its launches with others encoding the same geometry right now
+int encode_one_gathered(EncodeBatch &own, EncodeParams &p, const void *frame, int pitch, uint32_t frame_number,
+                        MetaBlock global, MetaBlock local, uint8_t *out, size_t cap, size_t *size_out, EncodeService *svc)
+{
+	if (svc) {
+		struct InFlight { std::atomic<int> &n; int before; InFlight(std::atomic<int> &c) : n(c), before(c.fetch_add(1)) {} ~InFlight() { n.fetch_sub(1); } } mark(svc->inflight);
+		if (mark.before > 0) {
+			bool usable;
+			{
+				std::lock_guard<std::mutex> lk(svc->m);
+				if (!svc->ok && !svc->dead) { if (!svc->start(p, encode_gather_slots())) svc->dead = true; }
+				usable = svc->ok;
+			}
+			MetaBlock g2 = global, l2 = local;
+			meta_remove_hidden(g2); meta_remove_hidden(l2);
+			SampleHeaderInfo hdr = { frame_number, color_format_of(p.pixel_kind), p.color_space, p.quality, p.progressive, g2.data(), g2.size(), l2.data(), l2.size() };
+			uint32_t sz; unsigned char ty;
+			const uint32_t VCHN = CFHD_FOURCC('V', 'C', 'H', 'N');
+			const bool vchn = meta_find(g2.data(), g2.size(), VCHN, &sz, &ty) || meta_find(l2.data(), l2.size(), VCHN, &sz, &ty);       // rare syntax switch: encode_one knows it
+			if (usable && !vchn && svc->encode(hdr, frame, pitch, out, cap, size_out) == 0 && *size_out) return ERR_OKAY;
+		}
+		return encode_one(own, p, frame, pitch, frame_number, global, local, out, cap, size_out);
+	}
+	return encode_one(own, p, frame, pitch, frame_number, global, local, out, cap, size_out);
+}
+
 struct Encoder {
 	EncodeParams params;
 	MetaState meta;
@@ -236,6 +392,7 @@ struct EncoderPool {
 	std::deque<std::shared_ptr<PoolJob>> fifo;               // submission order
 	bool started = false, stopping = false;
 	int next_worker = 0;
+	EncodeService *service = nullptr;          // set by CFHD_StartEncoderPool when the sequence has no frame-to-frame dependency
 
 	void worker_loop(PoolWorker *w)
 	{
@@ -250,8 +407,8 @@ struct EncoderPool {
 			}
 			job->sample.reset(new SampleBuffer);
 			job->sample->data.resize(sample_capacity(params));
-			job->error = encode_one(w->batch, w->params, job->frame, (int)job->pitch, ++w->encoded, job->global, job->local,
-			                        job->sample->data.data(), job->sample->data.size(), &job->sample->size);
+			job->error = encode_one_gathered(w->batch, w->params, job->frame, (int)job->pitch, ++w->encoded, job->global, job->local,
+			                                 job->sample->data.data(), job->sample->data.size(), &job->sample->size, service);
 			{
 				std::lock_guard<std::mutex> lk(m);
 				job->finished = true;
@@ -282,95 +439,36 @@ struct Decoder {
 struct DecMetadata { std::vector<uint8_t> block; size_t cursor = 0; };
 
 
-// ---- concurrent CFHD_DecodeSample calls share launches -------------------------------------------------------------------------------
-// The reference decoder is synchronous per handle; applications get throughput by decoding on several handles from several threads.  One
-// frame per launch sequence leaves the GPU mostly idle (a dozen launches of kernels that see a single frame), so calls that arrive while
-// another call of the same geometry is in flight are gathered: every caller stages its sample into a slot of a shared DecodeBatch, one
-// of two dispatcher threads (one per batch, each with its own HIP stream) launches whatever has gathered as one multi-frame pass, and every
-// caller copies its own frame out.  A lone caller never comes here (CFHD_DecodeSample uses the handle's own batch).  CFHD_AMD_DECODE_BATCH=n
-// sets the slots per batch (default 8, 0 switches the gathering off).
 struct DecodeServiceKey {
 	int width, height, display_height, encoded_format, precision, prescale[3], out_kind; bool half, interlaced;
 	bool operator==(const DecodeServiceKey &o) const { return memcmp(this, &o, sizeof(*this)) == 0; }
 };
-struct DecodeService {
-	struct Gather {
-		DecodeBatch batch;
-		int claimed = 0, ready = 0, released = 0, state = 0 /* 0 collecting, 1 running, 2 done */, rc = 0;
-		bool bad = false; uint32_t gen = 0;
-		std::vector<void *> out; std::vector<int> pitch;
-		std::thread worker;
-	};
+struct DecodeService : Gatherer<DecodeBatch> {
 	DecodeServiceKey key;
-	int slots = 8; bool ok = false, stop = false;
-	std::mutex m; std::condition_variable cv_callers, cv_workers;
-	Gather g[2];
-	std::atomic<int> inflight{0};
-	uint32_t launches = 0;
-
 	bool start(const FramePlan &plan, int out_kind, bool half, bool interlaced, int nslots)
 	{
 		slots = nslots;
 		const size_t cap = (size_t)plan.width * plan.height * pixel_bytes_of(out_kind) + 65536;
-		for (Gather &x : g) {
+		for (Pass &x : g) {
 			x.batch.set_interlaced(interlaced);
 			if (x.batch.prepare(plan, slots, out_kind, true, half) || x.batch.prepare_entropy(cap) || !x.batch.entropy().chunk_indexed()) return false;
-			x.out.assign((size_t)slots, nullptr); x.pitch.assign((size_t)slots, 0);
 		}
-		for (int k = 0; k < 2; k++) g[k].worker = std::thread([this, k] { run(g[k]); });
-		ok = true;
+		run_pass = [](Pass &x, int n, uint32_t launch) {
+			x.batch.set_active(n);
+			int rc = x.batch.entropy().launch();
+			if (!rc) rc = x.batch.launch_inverse(0x2545F491u * launch);
+			for (int i = 0; i < n && !rc; i++) rc = x.batch.download_frame(i, x.ptr[i], x.num[i]);
+			if (!rc) rc = x.batch.wait(); else (void)x.batch.wait();
+			if (!rc && x.batch.entropy().check()) rc = 1;      // a damaged sample somewhere in the pass: every caller decodes alone and gets its own verdict
+			return rc;
+		};
+		start_workers();
 		return true;
 	}
-	void run(Gather &x)
-	{
-		(void)device_init();                               // the device is selected per thread
-		std::unique_lock<std::mutex> lk(m);
-		for (;;) {
-			cv_workers.wait(lk, [&] { return stop || (x.state == 0 && x.claimed > 0 && x.ready == x.claimed); });
-			if (stop) return;
-			x.state = 1;
-			const int n = x.claimed; const bool bad = x.bad; const uint32_t seed = 0x2545F491u * ++launches;
-			lk.unlock();
-			int rc = 0;
-			if (!bad) {
-				x.batch.set_active(n);
-				rc = x.batch.entropy().launch();
-				if (!rc) rc = x.batch.launch_inverse(seed);
-				for (int i = 0; i < n && !rc; i++) rc = x.batch.download_frame(i, x.out[i], x.pitch[i]);
-				if (!rc) rc = x.batch.wait(); else (void)x.batch.wait();
-				if (!rc && x.batch.entropy().check()) rc = 1;
-			}
-			lk.lock();
-			x.rc = rc; x.state = 2;
-			cv_callers.notify_all();
-		}
-	}
-	// 0: decoded into out; 1: not decoded here (a damaged sample in the gathered pass, or a device error): the caller takes its own path
 	int decode(const uint8_t *sample, size_t size, void *out, int pitch)
 	{
-		std::unique_lock<std::mutex> lk(m);
-		Gather *x = nullptr;
-		cv_callers.wait(lk, [&] {
-			// join the pass that is gathering; else open one on a free batch
-			for (Gather &c : g) if (c.state == 0 && c.claimed > 0 && c.claimed < slots) { x = &c; return true; }
-			for (Gather &c : g) if (c.state == 0 && c.claimed == 0) { x = &c; return true; }
-			return false;
-		});
-		const int i = x->claimed++; const uint32_t gen = x->gen;
-		x->out[i] = out; x->pitch[i] = pitch;
-		lk.unlock();
-		const int staged = x->batch.entropy().set_sample_host(i, sample, size);      // parse + copy into the slot's pinned memory, beside the other callers
-		lk.lock();
-		if (staged) x->bad = true;
-		x->ready++;
-		cv_workers.notify_all();
-		cv_callers.wait(lk, [&] { return x->state == 2 && x->gen == gen; });
-		const bool failed = x->bad || x->rc != 0;
-		lk.unlock();
-		if (!failed) x->batch.finish_frame(i, out, pitch);                            // every caller copies its own frame out of the pinned staging
-		lk.lock();
-		if (++x->released == x->claimed) { x->claimed = x->ready = x->released = 0; x->bad = false; x->rc = 0; x->state = 0; x->gen++; cv_callers.notify_all(); cv_workers.notify_all(); }
-		return failed ? 1 : 0;
+		return submit([&](DecodeBatch &b, int i, Pass &x) { x.ptr[i] = out; x.num[i] = pitch; return b.entropy().set_sample_host(i, sample, size); },
+		              [&](DecodeBatch &b, int i) { b.finish_frame(i, out, pitch); });       // every caller copies its own frame out of the pinned staging
 	}
 };
 struct DecodeServices {
@@ -385,7 +483,7 @@ struct DecodeServices {
 	}
 };
 DecodeServices &decode_services() { static DecodeServices *s = new DecodeServices; return *s; }
-int decode_gather_slots() { static const int n = [] { const char *e = getenv("CFHD_AMD_DECODE_BATCH"); int v = e ? atoi(e) : 8; return v < 0 ? 0 : (v > 64 ? 64 : v); }(); return n; }
+int decode_gather_slots() { static const int n = gather_slots("CFHD_AMD_DECODE_BATCH"); return n; }
 
 void plan_from_sample(const ParsedSample &ps, int out_kind, FramePlan *plan, bool *ok)
 {
@@ -605,6 +703,13 @@ CFHD_Error CFHD_StartEncoderPool(CFHD_EncoderPoolRef ref)
 		if (prepare_batch(w->batch, p->params)) return ERR_INTERNAL;
 		w->params = p->params;
 		p->workers.push_back(std::move(w));
+	}
+	p->service = nullptr;
+	if (encode_gather_slots() > 1 && p->nworkers > 1 && gpu_entropy_enabled() && quantizer_is_static(p->params)) {
+		EncodeServiceKey key; memset(&key, 0, sizeof(key));
+		key.width = p->params.width; key.height = p->params.height; key.pixel_kind = p->params.pixel_kind; key.encoded_format = p->params.encoded_format;
+		key.quality = p->params.quality; key.color_space = p->params.color_space; key.flags = p->params.flags;
+		p->service = encode_services().find(key);
 	}
 	for (auto &w : p->workers) { PoolWorker *pw = w.get(); pw->thread = std::thread([p, pw] { p->worker_loop(pw); }); }
 	p->started = true;
@@ -852,7 +957,7 @@ CFHD_Error CFHD_DecodeSample(CFHD_DecoderRef ref, void *sample, size_t size, voi
 			bool usable;
 			{
 				std::lock_guard<std::mutex> lk(svc->m);
-				if (!svc->ok && !svc->stop) { if (!svc->start(d->plan, d->out_kind, d->half, interlaced, decode_gather_slots())) svc->stop = true; }   // (stop without ok: could not be set up, never tried again)
+				if (!svc->ok && !svc->dead) { if (!svc->start(d->plan, d->out_kind, d->half, interlaced, decode_gather_slots())) svc->dead = true; }   // (could not be set up: never tried again)
 				usable = svc->ok;
 			}
 			if (usable && svc->decode(s, size, out, pitch) == 0) return ERR_OKAY;

@@ -30,6 +30,8 @@ public:
 	int upload_frame(int i, const void *frame, int pitch_bytes);
 	// Use frames that already live in HBM (bench / device-resident callers).
 	int set_device_frame(int i, const void *d_frame, int pitch_bytes);
+	// the next launches (forward transform, entropy coder, sample download) cover frames 0 .. k-1 only (0 = all)
+	void set_active(int k) { active_ = k; ent_.set_active(k); }
 	int launch_forward();                              // async: all levels, all frames
 	int update_quant(const FramePlan &plan);           // same geometry, new quantizer tables (per-frame rate feedback)
 	// GPU entropy stage (cfhd_entropy_kernels.h): complete samples are produced in HBM after launch_forward().
@@ -49,7 +51,7 @@ private:
 	int sync_jobs();
 	void fill_jobs();
 	FramePlan plan_;
-	int n_ = 0; bool own_input_ = false, jobs_dirty_ = true;
+	int n_ = 0, active_ = 0; bool own_input_ = false, jobs_dirty_ = true;
 	void *stream_ = nullptr, *ev0_ = nullptr, *ev1_ = nullptr, *evl_[2] = {nullptr, nullptr};
 	float level_ms_[3] = {0, 0, 0};
 	uint8_t *d_in_ = nullptr, *h_in_ = nullptr; size_t frame_bytes_ = 0; int in_pitch_ = 0, in_rows_ = 0;

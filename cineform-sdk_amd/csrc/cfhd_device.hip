@@ -404,26 +404,27 @@ int EncodeBatch::launch_forward()
 	if (rc) return rc;
 	hipStream_t st = (hipStream_t)stream_;
 	const int nch = plan_.num_channels;
+	const int act = active_ > 0 && active_ < n_ ? active_ : n_;      // frames 0 .. act-1 of the batch hold frames (set_active)
 	EncJobs j = enc_jobs_at(d_jobs_, n_, nch);
 	(void)hipGetLastError();                            // drop stale sticky errors: the check below is for these launches only
 	timed_ = true;
 	HIPCHK(hipEventRecord((hipEvent_t)ev0_, st));
 	if (plan_.pixel_kind == PIX_BYR4) {
-		dev::k_unpack_byr4<<<dim3((plan_.width + dev::NTHREADS - 1) / dev::NTHREADS, plan_.height, n_), dev::NTHREADS, 0, st>>>(j.bayer);
-		dim3 grid((plan_.width / 2 + dev::TW - 1) / dev::TW, (plan_.height / 2 + dev::TH - 1) / dev::TH, n_ * nch);
+		dev::k_unpack_byr4<<<dim3((plan_.width + dev::NTHREADS - 1) / dev::NTHREADS, plan_.height, act), dev::NTHREADS, 0, st>>>(j.bayer);
+		dim3 grid((plan_.width / 2 + dev::TW - 1) / dev::TW, (plan_.height / 2 + dev::TH - 1) / dev::TH, act * nch);
 		dev::k_fwd_plane<<<grid, dev::NTHREADS, 0, st>>>(j.l1);
 	} else if (is_packed16(plan_.pixel_kind)) {
-		dim3 grid(((plan_.width / 2 + dev::TW - 1) / dev::TW) * nch, (plan_.height / 2 + dev::TH - 1) / dev::TH, n_);
+		dim3 grid(((plan_.width / 2 + dev::TW - 1) / dev::TW) * nch, (plan_.height / 2 + dev::TH - 1) / dev::TH, act);
 		dev::k_fwd_packed16<<<grid, dev::NTHREADS, 0, st>>>(j.l1, nch);
 	} else if (plan_.interlaced) {
 		static_assert(sizeof(dev::FwdFrameJob) == sizeof(dev::FwdYuvJob) && offsetof(dev::FwdFrameJob, q) == offsetof(dev::FwdYuvJob, q), "the two level-1 jobs share one table");
-		dim3 grid((plan_.width / 2 + dev::FTW - 1) / dev::FTW, (plan_.height / 2 + dev::FRW - 1) / dev::FRW, n_);
+		dim3 grid((plan_.width / 2 + dev::FTW - 1) / dev::FTW, (plan_.height / 2 + dev::FRW - 1) / dev::FRW, act);
 		dev::k_fwd_frame_yuv422<<<grid, dev::NTHREADS, 0, st>>>((const dev::FwdFrameJob *)j.yuv);
 	} else if (strip_forward()) {
 		const int nseg = (plan_.width / 16 + dev::SSEG - 1) / dev::SSEG;      // segments of 124 luma blocks (1984 pixels)
-		dev::k_fwd_yuv422_strip<<<dim3(nseg, (plan_.height / 2 + dev::SRF - 1) / dev::SRF, n_), dev::NTHREADS, 0, st>>>(j.yuv);
+		dev::k_fwd_yuv422_strip<<<dim3(nseg, (plan_.height / 2 + dev::SRF - 1) / dev::SRF, act), dev::NTHREADS, 0, st>>>(j.yuv);
 	} else {
-		dim3 grid((plan_.width / 2 + dev::TW - 1) / dev::TW, (plan_.height / 2 + dev::TH - 1) / dev::TH, n_);
+		dim3 grid((plan_.width / 2 + dev::TW - 1) / dev::TW, (plan_.height / 2 + dev::TH - 1) / dev::TH, act);
 		dev::k_fwd_yuv422<<<grid, dev::NTHREADS, 0, st>>>(j.yuv);
 	}
 	for (int lv = 1; lv < 3; lv++) {
@@ -431,14 +432,14 @@ int EncodeBatch::launch_forward()
 		const BandDesc &src = plan_.ch[0].band[lv - 1][0];     // luma is the widest plane of the level
 		const dev::FwdPlaneJob *jobs = lv == 1 ? j.l2 : j.l3;
 		if (planes_as_strips(plan_, lv)) {
-			const int n = n_;
+			const int n = act;
 			for_channel_runs(plan_, lv, [&](int c0, int nc, int glog, const BandDesc &b) {
 				const int nstrips = (b.height + dev::SRP - 1) / dev::SRP, per_wave = 64 >> glog, waves = ((n * nc + per_wave - 1) / per_wave) * nstrips;
 				dev::k_fwd_plane_strip<<<(waves + 3) / 4, dev::NTHREADS, 0, st>>>(jobs, n, nch, c0, nc, glog, nstrips, 2 * b.width, 2 * b.height);
 			});
 			continue;
 		}
-		dim3 grid((src.width / 2 + dev::TW - 1) / dev::TW, (src.height / 2 + dev::TH - 1) / dev::TH, n_ * nch);
+		dim3 grid((src.width / 2 + dev::TW - 1) / dev::TW, (src.height / 2 + dev::TH - 1) / dev::TH, act * nch);
 		dev::k_fwd_plane<<<grid, dev::NTHREADS, 0, st>>>(jobs);
 	}
 	HIPCHK(hipGetLastError());

@@ -24,6 +24,8 @@ public:
 	uint32_t sample_bytes(int i) const { return h_sizes_[i]; }
 	// Interlaced frames: true when frame i's difference-coded band holds values beyond the peak threshold, i.e. the reference appends a
 	// peak table (encoder.c:4802); the GPU sample of such a frame is not valid, the caller writes it on the host from the coefficients.
+	// the next launch() / download() cover frames 0 .. k-1 of the batch (0 = all)
+	void set_active(int k) { active_ = k; }
 	bool needs_peak_table(int i) const { return plan_.interlaced && h_sizes_[n_ + i] != 0; }     // (the flags are only cleared and written for interlaced plans)
 	size_t sample_cap() const { return cap_; }
 	int total_segments() const { return total_segs_; }
@@ -36,7 +38,8 @@ public:
 private:
 	struct Host; Host *host_;           // host mirrors of the job tables (types live in the kernel headers)
 	void release();
-	FramePlan plan_; int n_ = 0; size_t cap_ = 0; void *stream_ = nullptr;
+	FramePlan plan_; int n_ = 0, active_ = 0; size_t cap_ = 0; void *stream_ = nullptr;
+	int active_frames() const { return active_ > 0 && active_ < n_ ? active_ : n_; }
 	int nbands_ = 0, total_segs_ = 0;
 	std::vector<SampleTemplate> tmpl_;
 	uint8_t *d_samples_ = nullptr, *h_samples_ = nullptr;

@@ -99,20 +99,21 @@ int GpuEntropyEncoder::launch()
 	}
 	const dev::EntTables *T = (const dev::EntTables *)d_tables_;
 	const dev::EntBatchGeom geom = { total_segs_ / n_, nbands_, coeff_stride_ };
+	const int act = active_frames(), total_segs = total_segs_ / n_ * act;      // frames 0 .. act-1 (set_active)
 	(void)hipGetLastError();
 	if (plan_.interlaced) HIPCHK(hipMemsetAsync(d_sizes_ + n_, 0, sizeof(uint32_t) * n_, st));
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[0], st));
-	dev::k_ent_count<<<(total_segs_ + dev::ENT_WAVES - 1) / dev::ENT_WAVES, dev::ENT_THREADS, 0, st>>>((const dev::EntSegJob *)d_segband_, geom, total_segs_, (dev::EntSegState *)d_segs_, T,
+	dev::k_ent_count<<<(total_segs + dev::ENT_WAVES - 1) / dev::ENT_WAVES, dev::ENT_THREADS, 0, st>>>((const dev::EntSegJob *)d_segband_, geom, total_segs, (dev::EntSegState *)d_segs_, T,
 	                                                                                                    d_sizes_ + n_);
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[1], st));
-	dev::k_ent_scan<<<nbands_ * n_, dev::ENT_THREADS, 0, st>>>((const dev::EntBandJob *)d_bands_, (dev::EntSegState *)d_segs_, (dev::EntBandState *)d_bandstate_, T);
+	dev::k_ent_scan<<<nbands_ * act, dev::ENT_THREADS, 0, st>>>((const dev::EntBandJob *)d_bands_, (dev::EntSegState *)d_segs_, (dev::EntBandState *)d_bandstate_, T);
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[2], st));
 	// workgroups per frame: enough to fill the chip for short batches of large frames, at least the 8 that 512 1080p frames were tuned with
-	const unsigned layout_parts = n_ >= 256 ? 8u : (unsigned)((2048 + n_ - 1) / n_ > 256 ? 256 : (2048 + n_ - 1) / n_);
-	dev::k_ent_layout<<<dim3((unsigned)n_, layout_parts), dev::ENT_THREADS, 0, st>>>((const dev::EntFrameJob *)d_frames_, (const dev::EntBandJob *)d_bands_, (const dev::EntSegState *)d_segs_,
+	const unsigned layout_parts = act >= 256 ? 8u : (unsigned)((2048 + act - 1) / act > 256 ? 256 : (2048 + act - 1) / act);
+	dev::k_ent_layout<<<dim3((unsigned)act, layout_parts), dev::ENT_THREADS, 0, st>>>((const dev::EntFrameJob *)d_frames_, (const dev::EntBandJob *)d_bands_, (const dev::EntSegState *)d_segs_,
 	                                                  (dev::EntBandState *)d_bandstate_, T);
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[3], st));
-	dev::k_ent_emit<<<(total_segs_ + dev::ENT_WAVES - 1) / dev::ENT_WAVES, dev::ENT_THREADS, 0, st>>>((const dev::EntSegJob *)d_segband_, geom, total_segs_, (const dev::EntSegState *)d_segs_,
+	dev::k_ent_emit<<<(total_segs + dev::ENT_WAVES - 1) / dev::ENT_WAVES, dev::ENT_THREADS, 0, st>>>((const dev::EntSegJob *)d_segband_, geom, total_segs, (const dev::EntSegState *)d_segs_,
 	                                                          (const dev::EntBandState *)d_bandstate_, T);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[4], st));
@@ -142,13 +143,14 @@ int GpuEntropyEncoder::download()
 	// command at all; default: pack in HBM, then one copy (SDMA engine when the runtime has it enabled).
 	static const bool direct = [] { const char *e = getenv("CFHD_AMD_DOWNLOAD"); return e && strcmp(e, "kernel") == 0; }();
 	(void)hipGetLastError();
-	dev::k_ent_pack_offsets<<<1, dev::ENT_THREADS, 0, st>>>(d_sizes_, n_, d_offsets_);
-	dev::k_ent_pack<<<dim3(direct ? 2 : 8, (unsigned)n_), dev::ENT_THREADS, 0, st>>>(d_samples_, cap_, d_sizes_, d_offsets_, direct ? h_samples_ : d_packed_);
+	const int act = active_frames();
+	dev::k_ent_pack_offsets<<<1, dev::ENT_THREADS, 0, st>>>(d_sizes_, act, d_offsets_);
+	dev::k_ent_pack<<<dim3(direct ? 2 : 8, (unsigned)act), dev::ENT_THREADS, 0, st>>>(d_samples_, cap_, d_sizes_, d_offsets_, direct ? h_samples_ : d_packed_);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipMemcpyAsync(h_sizes_, d_sizes_, sizeof(uint32_t) * 2 * n_, hipMemcpyDeviceToHost, st));
-	HIPCHK(hipMemcpyAsync(h_offsets_, d_offsets_, sizeof(uint32_t) * (n_ + 1), hipMemcpyDeviceToHost, st));
+	HIPCHK(hipMemcpyAsync(h_offsets_, d_offsets_, sizeof(uint32_t) * (act + 1), hipMemcpyDeviceToHost, st));
 	HIPCHK(hipStreamSynchronize(st));
-	if (!direct && h_offsets_[n_]) HIPCHK(hipMemcpyAsync(h_samples_, d_packed_, h_offsets_[n_], hipMemcpyDeviceToHost, st));
+	if (!direct && h_offsets_[act]) HIPCHK(hipMemcpyAsync(h_samples_, d_packed_, h_offsets_[act], hipMemcpyDeviceToHost, st));
 	return 0;
 }
 
