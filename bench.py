@@ -272,20 +272,18 @@ def main():
 
     for _ in range(args.warmup):
         assert L.cfhd_amd_batch_roundtrip(b) > 0, T.amd_last_error()
-    # kernel names as they appear in a rocprofv3 trace of this run: the register-strip kernels serve these widths unless an A/B switch asks for the tiled ones
-    FWD1 = "k_fwd_yuv422" if os.environ.get("CFHD_AMD_FORWARD") == "tile" else "k_fwd_yuv422_strip"
-    INV1 = "k_inv_yuv422" if os.environ.get("CFHD_AMD_INVERSE") == "tile" else "k_inv_yuv422_strip"
-    PF, PI = ("k_fwd_plane", "k_inv_plane") if os.environ.get("CFHD_AMD_PLANES") == "tile" else ("k_fwd_plane_strip", "k_inv_plane_strip")
-    TILES = "k_dec_tiles"
-    if wl["flags"] & 1: FWD1, INV1, TILES = "k_fwd_frame_yuv422", "k_inv_frame_yuv422", "k_dec_tiles+k_dec_undiff"
-    elif wl["fmt"] in ("RG48", "b64a"): FWD1, INV1 = "k_fwd_packed16", "k_inv_packed16"
-    elif wl["fmt"] == "BYR4": FWD1 = "k_unpack_byr4+k_fwd_plane[L1]"
-    if not headline: PF, PI = "k_fwd_plane*", "k_inv_plane*"          # the tiled or the strip variant, by band width (cfhd_device.hip planes_as_strips)
+    # kernel names as they appear in a rocprofv3 trace of this run (the library picks the register-strip or the LDS-tiled shape by geometry and batch size)
+    L.cfhd_amd_batch_kernel_name.restype = ctypes.c_char_p
+    L.cfhd_amd_batch_kernel_name.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    kname = lambda which: L.cfhd_amd_batch_kernel_name(b, which).decode()
+    FWD1, PF2, PF3 = kname(0), kname(1) + "[L2]", kname(2) + "[L3]"
+    INV1, PI2, PI3 = (kname(3), kname(4) + "[L2]", kname(5) + "[L3]") if wl["mode"] == 0 else ("", "", "")
+    TILES = "k_dec_tiles+k_dec_undiff" if wl["flags"] & 1 else "k_dec_tiles"
     old_dec = os.environ.get("CFHD_AMD_DEC") in ("par", "lane")
     DEC = [("k_dec_bands_par", 13)] if old_dec else [("k_dec_plan+k_dec_index", 15), ("k_dec_chain", 16), (TILES, 17)]
-    KERNELS = [(FWD1, 0), (PF + "[L2]", 1), (PF + "[L3]", 2), ("k_ent_count", 8), ("k_ent_scan", 9), ("k_ent_layout", 10), ("k_ent_emit", 11)]
+    KERNELS = [(FWD1, 0), (PF2, 1), (PF3, 2), ("k_ent_count", 8), ("k_ent_scan", 9), ("k_ent_layout", 10), ("k_ent_emit", 11)]
     if wl["mode"] == 0:
-        KERNELS += [("k_dec_parse", 12)] + DEC + [("k_dec_lowpass", 14), (PI + "[L3]", 5), (PI + "[L2]", 4), (INV1, 3)]
+        KERNELS += [("k_dec_parse", 12)] + DEC + [("k_dec_lowpass", 14), (PI3, 5), (PI2, 4), (INV1, 3)]
     kms = {name: 0.0 for name, _ in KERNELS}; stage = [0.0] * 4; total_bytes = 0
     barrier()
     t0 = time.perf_counter()
@@ -325,10 +323,10 @@ def main():
         S = W * Hp * wl["comps"]                         # coefficients per frame (4:2:2: luma + both chroma = the packed bytes of the 8-bit frame)
         P = W * Hp * wl["bpp"]                           # bytes of the packed frame
         coded = (S - S // 64) * 2                        # bytes of the entropy-coded bands (everything but the LL3 bands)
-        algo = {FWD1: P + 2 * S, PF + "[L2]": S, PF + "[L3]": S // 4,                               # 12 441 600 B per 1080p 4:2:2 frame
+        algo = {FWD1: P + 2 * S, PF2: S, PF3: S // 4,                               # 12 441 600 B per 1080p 4:2:2 frame
                 "k_ent_count": coded, "k_ent_emit": coded + sample_bytes}
         if wl["mode"] == 0:
-            algo.update({PI + "[L3]": S // 4, PI + "[L2]": S, INV1: 2 * S + P})
+            algo.update({PI3: S // 4, PI2: S, INV1: 2 * S + P})
             if old_dec: algo["k_dec_bands_par"] = sample_bytes + coded
             else: algo.update({"k_dec_plan+k_dec_index": sample_bytes, TILES: sample_bytes + coded})
         dom = max(algo, key=lambda k: kms[k])            # the dominant kernel = the longest launch of the step

@@ -249,6 +249,13 @@ float cfhd_amd_batch_kernel_ms(cfhd_amd_batch *b, int which)
 	return ms;
 }
 
+// which as in cfhd_amd_batch_kernel_ms, 0..5: the name of the transform kernel behind that number (the shape depends on geometry and batch size)
+const char *cfhd_amd_batch_kernel_name(cfhd_amd_batch *b, int which)
+{
+	if (!b || which < 0 || which > 5 || b->chunks.empty() || (which >= 3 && !b->decode)) return "";
+	return which < 3 ? b->chunks[0]->enc.level_kernel(which) : b->chunks[0]->dec.level_kernel(which - 3);
+}
+
 // which: 0 forward (kernels + D2H), 1 host entropy encode + syntax, 2 host parse + entropy decode, 3 H2D + inverse kernels (wall seconds)
 double cfhd_amd_batch_stage_seconds(cfhd_amd_batch *b, int which)
 {

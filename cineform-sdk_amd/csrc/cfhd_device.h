@@ -39,6 +39,7 @@ public:
 	GpuEntropyEncoder &entropy() { return ent_; }
 	bool has_entropy() const { return ent_ready_; }
 	bool strip_forward() const;                     // level 1 of 4:2:2 runs as k_fwd_yuv422_strip (else k_fwd_yuv422)
+	const char *level_kernel(int level) const;      // name of the kernel the next launch_forward() uses for level 0 / 1 / 2 (as a profiler shows it)
 	int download_coeffs();                             // async: final (entropy coded) region of every frame -> pinned host
 	int wait();
 	const int16_t *host_coeffs(int i) const { return h_coeff_ + (size_t)i * plan_.final_elems; }
@@ -85,6 +86,7 @@ public:
 	GpuEntropyDecoder &entropy() { return ent_; }
 	bool has_entropy() const { return ent_ready_; }
 	bool strip_inverse() const;                     // the last level of 4:2:2 runs as k_inv_yuv422_strip (else k_inv_yuv422)
+	const char *level_kernel(int level) const;      // name of the kernel the next launch_inverse() uses for level 0 / 1 / 2
 	int set_device_output(int i, void *d_out, int pitch_bytes);
 	int launch_inverse(uint32_t dither_seed);          // async
 	int download_frame(int i, void *out, int pitch_bytes);   // async D2H into pinned staging, then row copy after wait

@@ -363,10 +363,21 @@ int EncodeBatch::set_device_frame(int i, const void *d_frame, int pitch)
 
 // Levels 2 and 3 in the register-strip kernels: one launch per run of equally wide channels (luma | both chroma planes of 4:2:2 | all planes
 // of 4:4:4 / Bayer).  false: some channel's geometry is outside what the strip kernels serve (or CFHD_AMD_PLANES=tile) -> tiled kernel.
-static bool planes_as_strips(const FramePlan &plan, int lv /* wavelet index whose bands are produced / consumed */)
+// The register-strip kernels are the throughput shape: a wave walks down its strip of the plane row by row, so a launch lasts at least one
+// such walk (about 80 us at 1080p) however few frames it covers, and fills the chip only with a few hundred frames' worth of strips.  The
+// LDS-tiled kernels are many short workgroups: 8x faster on a single frame, slower from a hundred-odd frames on.  Measured crossovers at
+// 1080p (tools/small_batch_sweep.sh; frames per launch): plane levels 140-230, forward level 1 about 32, inverse level 1 about 12; larger
+// frames count in proportion to their area.  CFHD_AMD_PLANES / _FORWARD / _INVERSE = tile | strip force one shape (A/B runs).
+static double frames_1080p_equivalent(const FramePlan &plan, int frames) { return (double)frames * plan.width * plan.height / (1920.0 * 1080.0); }
+static int shape_override(const char *name)           // 0: by size, 1: tile, 2: strip
 {
-	static const bool forced_tile = [] { const char *e = getenv("CFHD_AMD_PLANES"); return e && strcmp(e, "tile") == 0; }();
-	if (forced_tile) return false;
+	const char *e = getenv(name);
+	return !e ? 0 : (strcmp(e, "tile") == 0 ? 1 : (strcmp(e, "strip") == 0 ? 2 : 0));
+}
+static bool planes_as_strips(const FramePlan &plan, int lv /* wavelet index whose bands are produced / consumed */, int frames)
+{
+	static const int forced = shape_override("CFHD_AMD_PLANES");
+	if (forced == 1 || (forced == 0 && frames_1080p_equivalent(plan, frames) < 160.0)) return false;
 	for (int c = 0; c < plan.num_channels; c++) {
 		const BandDesc &b = plan.ch[c].band[lv][0];
 		if (b.width % dev::SBLK || b.width / dev::SBLK > 64 || plan.ch[c].band[lv - 1][0].width != 2 * b.width || plan.ch[c].band[lv - 1][0].height != 2 * b.height ||
@@ -391,11 +402,23 @@ template <typename F> static void for_channel_runs(const FramePlan &plan, int lv
 // everything else (and CFHD_AMD_FORWARD=tile, for A/B runs) takes the LDS-tiled k_fwd_yuv422.  Both produce the same coefficients.
 bool EncodeBatch::strip_forward() const
 {
-	static const bool forced_tile = [] { const char *e = getenv("CFHD_AMD_FORWARD"); return e && strcmp(e, "tile") == 0; }();
-	if (forced_tile || plan_.interlaced || plan_.encoded_format != ENC_YUV422 || plan_.width % 32) return false;
+	static const int forced = shape_override("CFHD_AMD_FORWARD");
+	const int act = active_ > 0 && active_ < n_ ? active_ : n_;
+	if (forced == 1 || (forced == 0 && frames_1080p_equivalent(plan_, act) < 32.0)) return false;
+	if (plan_.interlaced || plan_.encoded_format != ENC_YUV422 || plan_.width % 32) return false;
 	EncJobs j = enc_jobs_at(h_jobs_, n_, plan_.num_channels);
 	for (int i = 0; i < n_; i++) if (((uintptr_t)j.yuv[i].in & 15) || (j.yuv[i].in_pitch & 15)) return false;
 	return true;
+}
+
+const char *EncodeBatch::level_kernel(int level) const
+{
+	const int act = active_ > 0 && active_ < n_ ? active_ : n_;
+	if (level > 0) return planes_as_strips(plan_, level, act) ? "k_fwd_plane_strip" : "k_fwd_plane";
+	if (plan_.pixel_kind == PIX_BYR4) return "k_unpack_byr4+k_fwd_plane";
+	if (is_packed16(plan_.pixel_kind)) return "k_fwd_packed16";
+	if (plan_.interlaced) return "k_fwd_frame_yuv422";
+	return strip_forward() ? "k_fwd_yuv422_strip" : "k_fwd_yuv422";
 }
 
 int EncodeBatch::launch_forward()
@@ -431,7 +454,7 @@ int EncodeBatch::launch_forward()
 		HIPCHK(hipEventRecord((hipEvent_t)evl_[lv - 1], st));
 		const BandDesc &src = plan_.ch[0].band[lv - 1][0];     // luma is the widest plane of the level
 		const dev::FwdPlaneJob *jobs = lv == 1 ? j.l2 : j.l3;
-		if (planes_as_strips(plan_, lv)) {
+		if (planes_as_strips(plan_, lv, act)) {
 			const int n = act;
 			for_channel_runs(plan_, lv, [&](int c0, int nc, int glog, const BandDesc &b) {
 				const int nstrips = (b.height + dev::SRP - 1) / dev::SRP, per_wave = 64 >> glog, waves = ((n * nc + per_wave - 1) / per_wave) * nstrips;
@@ -620,12 +643,24 @@ int DecodeBatch::set_device_output(int i, void *d_out, int pitch)
 // CFHD_AMD_INVERSE=tile, for A/B runs) takes the LDS-tiled k_inv_yuv422.  Both produce the same bytes.
 bool DecodeBatch::strip_inverse() const
 {
-	static const bool forced_tile = [] { const char *e = getenv("CFHD_AMD_INVERSE"); return e && strcmp(e, "tile") == 0; }();
+	static const int forced = shape_override("CFHD_AMD_INVERSE");
 	const int bw = plan_.ch[0].band[0][0].width;
-	if (forced_tile || is_packed16(out_kind_) || bw % 16) return false;
+	const int act = active_ > 0 && active_ < n_ ? active_ : n_;
+	if (forced == 1 || (forced == 0 && frames_1080p_equivalent(plan_, act) < 12.0)) return false;
+	if (is_packed16(out_kind_) || bw % 16) return false;
 	DecJobs j = dec_jobs_at(h_jobs_, n_, plan_.num_channels);
 	for (int i = 0; i < n_; i++) if (((uintptr_t)j.yuv[i].out & 15) || (j.yuv[i].out_pitch & 15)) return false;
 	return true;
+}
+
+const char *DecodeBatch::level_kernel(int level) const
+{
+	const int act = active_ > 0 && active_ < n_ ? active_ : n_;
+	if (level > 0) return planes_as_strips(plan_, level, act) ? "k_inv_plane_strip" : "k_inv_plane";
+	if (half_) return is_packed16(out_kind_) ? "k_half_packed16" : "k_half_yuv422";
+	if (is_packed16(out_kind_)) return "k_inv_packed16";
+	if (interlaced_) return "k_inv_frame_yuv422";
+	return strip_inverse() ? "k_inv_yuv422_strip" : "k_inv_yuv422";
 }
 
 int DecodeBatch::launch_inverse(uint32_t dither_seed)
@@ -642,7 +677,7 @@ int DecodeBatch::launch_inverse(uint32_t dither_seed)
 	for (int lv = 2; lv >= 1; lv--) {
 		const BandDesc &b = plan_.ch[0].band[lv][0];
 		const dev::InvPlaneJob *jobs = lv == 2 ? j.l3 : j.l2;
-		if (planes_as_strips(plan_, lv)) {
+		if (planes_as_strips(plan_, lv, act)) {
 			const int n = act;
 			for_channel_runs(plan_, lv, [&](int c0, int nc, int glog, const BandDesc &cb) {
 				const int nstrips = (cb.height + dev::SRP - 1) / dev::SRP, per_wave = 64 >> glog, waves = ((n * nc + per_wave - 1) / per_wave) * nstrips;

@@ -143,6 +143,7 @@ long long cfhd_amd_batch_roundtrip(cfhd_amd_batch *batch);                      
 int  cfhd_amd_batch_get_sample(cfhd_amd_batch *batch, int frame, const void **data, size_t *size);
 int  cfhd_amd_batch_download_output(cfhd_amd_batch *batch, int frame, void *out, int pitch);
 float cfhd_amd_batch_kernel_ms(cfhd_amd_batch *batch, int which);                              /* HIP-event time of the kernels of the last pass */
+const char *cfhd_amd_batch_kernel_name(cfhd_amd_batch *batch, int which);                      /* which 0..5: the transform kernel behind that time */
 double cfhd_amd_batch_stage_seconds(cfhd_amd_batch *batch, int which);
 int  cfhd_amd_batch_dx_stats(cfhd_amd_batch *batch, uint32_t *out16);
 int  cfhd_amd_device_count(void);
