@@ -370,9 +370,9 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_c_abi and headline:
             line["config"]["c_abi_fps"] = {"frame": "%dx%d YUY2, frames and samples in host memory (PCIe inclusive)" % (W, H),
-                                           "plain_buffers": c_abi_rates(frames[:8], pitch, W, H),
-                                           "plain_buffers_16_decoder_threads": c_abi_rates(frames[:8], pitch, W, H, decoders=16),
-                                           "buffers_registered_by_the_caller": c_abi_rates(frames[:8], pitch, W, H, registered=True)}
+                                           "plain_buffers": c_abi_rates(frames[:8], pitch, W, H, decoders=8, workers=8),
+                                           "plain_buffers_16_threads": c_abi_rates(frames[:8], pitch, W, H, decoders=16, workers=16),
+                                           "buffers_registered_by_the_caller_16_threads": c_abi_rates(frames[:8], pitch, W, H, registered=True, decoders=16, workers=16)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(frames[:8], pitch, W, H, fmt=fmt, enc=wl["enc"], flags=wl["flags"], decode=wl["mode"] == 0, bpp=wl["bpp"], label=wl["fmt"])
         print(json.dumps(line), flush=True)

@@ -203,7 +203,7 @@ int encode_one(EncodeBatch &batch, EncodeParams &p, const void *frame, int pitch
 // of kernels that see a single frame), so calls of the same geometry that are in flight at the same time are gathered: every caller stages
 // its frame or sample into a slot of a shared batch, one of two dispatcher threads (one per batch, each with its own HIP stream) launches
 // whatever has gathered as one multi-frame pass, and every caller copies its own result out.  A lone caller never comes here (the handle's
-// own batch of one frame serves it).  CFHD_AMD_DECODE_BATCH=n / CFHD_AMD_ENCODE_BATCH=n set the slots per batch (default 8, 0 = off).
+// own batch of one frame serves it).  CFHD_AMD_DECODE_BATCH=n (default 8) / CFHD_AMD_ENCODE_BATCH=n (default 0 = off) set the slots per batch.
 template <class BatchT> struct Gatherer {
 	struct Pass {
 		BatchT batch;
@@ -268,7 +268,7 @@ template <class BatchT> struct Gatherer {
 		return failed ? 1 : 0;
 	}
 };
-int gather_slots(const char *env) { const char *e = getenv(env); int v = e ? atoi(e) : 8; return v < 0 ? 0 : (v > 64 ? 64 : v); }
+int gather_slots(const char *env, int dflt) { const char *e = getenv(env); int v = e ? atoi(e) : dflt; return v < 0 ? 0 : (v > 64 ? 64 : v); }
 
 
 // The encoder side: workers of a pool (or several pools) that encode at the same time.  Only where no frame depends on the previous one:
@@ -313,7 +313,9 @@ struct EncodeServices {
 	}
 };
 EncodeServices &encode_services() { static EncodeServices *s = new EncodeServices; return *s; }
-int encode_gather_slots() { static const int n = gather_slots("CFHD_AMD_ENCODE_BATCH"); return n; }
+// Off unless asked for: measured on one MI355X at 1080p, pool workers on their own streams reach 8.7-11.8 k fps, gathered into shared passes
+// 5.6-8.2 k (the pass keeps its callers in lock step); only with decoders competing for the GPU did the round trip sometimes gain (3.9 -> 4.6 k).
+int encode_gather_slots() { static const int n = gather_slots("CFHD_AMD_ENCODE_BATCH", 0); return n; }
 // true when the quantizer tables of a sequence never move: FILMSCAN1 (and anything above 1080p for LOW..HIGH) -- decided by asking the
 // derivation itself whether a large previous sample would change them
 bool quantizer_is_static(const EncodeParams &p)
@@ -483,7 +485,7 @@ struct DecodeServices {
 	}
 };
 DecodeServices &decode_services() { static DecodeServices *s = new DecodeServices; return *s; }
-int decode_gather_slots() { static const int n = gather_slots("CFHD_AMD_DECODE_BATCH"); return n; }
+int decode_gather_slots() { static const int n = gather_slots("CFHD_AMD_DECODE_BATCH", 8); return n; }
 
 void plan_from_sample(const ParsedSample &ps, int out_kind, FramePlan *plan, bool *ok)
 {
