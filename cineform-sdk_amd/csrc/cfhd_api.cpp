@@ -34,7 +34,7 @@ enum {
 
 #define FOURCC_BE(a, b, c, d) (((uint32_t)(a) << 24) | ((uint32_t)(b) << 16) | ((uint32_t)(c) << 8) | (uint32_t)(d))
 static const uint32_t FMT_YUY2 = FOURCC_BE('Y', 'U', 'Y', '2'), FMT_2VUY = FOURCC_BE('2', 'v', 'u', 'y'), FMT_YUYV = FOURCC_BE('y', 'u', 'y', 'v'),
-                      FMT_RG48 = FOURCC_BE('R', 'G', '4', '8'), FMT_B64A = FOURCC_BE('b', '6', '4', 'a'), FMT_BYR4 = FOURCC_BE('B', 'Y', 'R', '4');
+                      FMT_RG48 = FOURCC_BE('R', 'G', '4', '8'), FMT_B64A = FOURCC_BE('b', '6', '4', 'a'), FMT_BYR4 = FOURCC_BE('B', 'Y', 'R', '4'), FMT_YU64 = FOURCC_BE('Y', 'U', '6', '4'), FMT_V210 = FOURCC_BE('v', '2', '1', '0');
 
 namespace {
 
@@ -45,11 +45,13 @@ int pixel_kind_of(uint32_t fmt)
 	if (fmt == FMT_RG48) return PIX_RG48;
 	if (fmt == FMT_B64A) return PIX_B64A;
 	if (fmt == FMT_BYR4) return PIX_BYR4;
+	if (fmt == FMT_YU64) return PIX_YU64;
+	if (fmt == FMT_V210) return PIX_V210;
 	return PIX_NONE;
 }
 // COLOR_FORMAT_UYVY = 1 / COLOR_FORMAT_YUYV = 2 / COLOR_FORMAT_BGRA64 (b64a) = 30 / COLOR_FORMAT_RG48 = 120 (Codec/color.h)
-int color_format_of(int kind) { return kind == PIX_2VUY ? 1 : (kind == PIX_RG48 ? 120 : (kind == PIX_B64A ? 30 : (kind == PIX_BYR4 ? 104 : 2))); }   // BYR4 = 104
-int pixel_bytes_of(int kind) { return kind == PIX_RG48 ? 6 : (kind == PIX_B64A ? 8 : 2); }
+int color_format_of(int kind) { return kind == PIX_2VUY ? 1 : (kind == PIX_RG48 ? 120 : (kind == PIX_B64A ? 30 : (kind == PIX_BYR4 ? 104 : (kind == PIX_YU64 ? 12 : (kind == PIX_V210 ? 10 : 2))))); }   // COLOR_FORMAT_* of Codec/color.h
+int pixel_bytes_of(int kind) { return kind == PIX_RG48 ? 6 : (kind == PIX_B64A ? 8 : (kind == PIX_YU64 || kind == PIX_V210 ? 4 : 2)); }
 
 // ---- metadata handle shared by the encoder-side API (CSampleEncodeMetadata) ----
 struct EncMetadata {
@@ -538,7 +540,7 @@ CFHD_Error CFHD_OpenEncoder(CFHD_EncoderRef *out, CFHD_ALLOCATOR *)
 CFHD_Error CFHD_GetInputFormats(CFHD_EncoderRef ref, CFHD_PixelFormat *arr, int len, int *count)
 {
 	if (!ref || !arr) return ERR_INVALID_ARGUMENT;
-	const uint32_t fmts[] = { FMT_YUY2, FMT_2VUY, FMT_RG48, FMT_B64A, FMT_BYR4 };
+	const uint32_t fmts[] = { FMT_YUY2, FMT_2VUY, FMT_RG48, FMT_B64A, FMT_BYR4, FMT_YU64, FMT_V210 };
 	int n = 0;
 	for (; n < 5 && n < len; n++) arr[n] = fmts[n];
 	if (count) *count = n;
@@ -874,7 +876,7 @@ CFHD_Error CFHD_PrepareToDecode(CFHD_DecoderRef ref, int, int, CFHD_PixelFormat 
 	// 4:2:2 samples decode to the packed 4:2:2 formats, RGB 4:4:4 samples to RG48 (wavelet.c:4947), RGBA 4:4:4:4 samples to b64a
 	// (bayer.c:11916 Row16uFull2OutputFormat); colour conversions between the families (ConvertLib / the colour part of the
 	// active-metadata pipeline in the reference) are not built
-	if (kind == PIX_BYR4) return ERR_BADFORMAT;
+	if (kind == PIX_BYR4 || kind == PIX_YU64 || kind == PIX_V210) return ERR_BADFORMAT;     // encoder inputs only
 	if ((encf == ENC_RGB444) != (kind == PIX_RG48) || (encf == ENC_RGBA4444) != (kind == PIX_B64A)) return ERR_BADFORMAT;
 	bool ok;
 	plan_from_sample(d->header, kind, &d->plan, &ok);

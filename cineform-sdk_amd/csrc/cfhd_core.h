@@ -27,6 +27,8 @@ enum PixelKind : int {
 	PIX_RG48,      // 16-bit RGB 4:4:4          (COLOR_FORMAT_RGB48 = 120)
 	PIX_B64A,      // 16-bit ARGB 4:4:4:4       (COLOR_FORMAT_BGRA64 = 30)
 	PIX_BYR4,      // 16-bit Bayer              (COLOR_FORMAT_BYR4 = 104)
+	PIX_YU64,      // 16-bit 4:2:2  Y0 C1 Y1 C2  (COLOR_FORMAT_YU64 = 12; encoder input only)
+	PIX_V210,      // 10-bit 4:2:2, six pixels in four 32-bit words (COLOR_FORMAT_V210 = 10; encoder input only)
 };
 
 // ENCODED_FORMAT_* values as written into the bitstream (Codec/codec.h)

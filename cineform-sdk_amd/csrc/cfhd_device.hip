@@ -83,6 +83,12 @@ int packed_word_of_channel(int pixel_kind, int c)
 	return (pixel_kind == PIX_B64A ? b64a : rg48)[c & 3];
 }
 bool is_packed16(int pixel_kind) { return pixel_kind == PIX_RG48 || pixel_kind == PIX_B64A; }
+// encoder input made of 16-bit words that k_fwd_packed16 picks apart (per channel: first word, words from sample to sample, right shift).
+// YU64 (Codec/frame.c:1556 ConvertYU64ToFrame16s + convert.c:3345, :14375): words Y0 C1 Y1 C2, every word >> 6 to 10 bits, channel 1 = C1, 2 = C2.
+// v210 (frame.c:1431 ConvertV210ToFrame16s): three 10-bit samples per 32-bit word, FwdPlaneJob::layout tells the loader which component to pick.
+static bool enc_packed16(int pixel_kind) { return is_packed16(pixel_kind) || pixel_kind == PIX_YU64 || pixel_kind == PIX_V210; }
+static int enc_word_of_channel(int pixel_kind, int c) { return pixel_kind == PIX_V210 ? 0 : (pixel_kind == PIX_YU64 ? (c == 0 ? 0 : (c == 1 ? 1 : 3)) : packed_word_of_channel(pixel_kind, c)); }
+static int enc_stride_of_channel(int pixel_kind, int c, int nch) { return pixel_kind == PIX_YU64 ? (c == 0 ? 2 : 4) : nch; }
 } // namespace
 
 const char *device_last_error() { return g_err.c_str(); }
@@ -150,6 +156,8 @@ int packed_frame_pitch(int pixel_kind, int width)
 	case PIX_RG48: return width * 6;
 	case PIX_B64A: return width * 8;
 	case PIX_BYR4: return width * 2;
+	case PIX_YU64: return width * 4;
+	case PIX_V210: return (width + 47) / 48 * 128;      // six pixels in 16 bytes, rows padded to 48 pixels (Example/utils.cpp:84-90)
 	default: return 0;
 	}
 }
@@ -186,7 +194,7 @@ int EncodeBatch::prepare(const FramePlan &plan, int nframes, bool own_input)
 	if (rc) return rc;
 	release();
 	const bool bayer = plan.pixel_kind == PIX_BYR4;
-	if (plan.pixel_kind != PIX_YUY2 && plan.pixel_kind != PIX_2VUY && !is_packed16(plan.pixel_kind) && !bayer) { g_err = "pixel format not supported by the GPU path yet"; return -2; }
+	if (plan.pixel_kind != PIX_YUY2 && plan.pixel_kind != PIX_2VUY && !enc_packed16(plan.pixel_kind) && !bayer) { g_err = "pixel format not supported by the GPU path yet"; return -2; }
 	plan_ = plan; n_ = nframes; own_input_ = own_input;
 	HIPCHK(hipStreamCreateWithFlags((hipStream_t *)&stream_, hipStreamNonBlocking));
 	HIPCHK(hipEventCreate((hipEvent_t *)&ev0_));
@@ -257,14 +265,15 @@ void EncodeBatch::fill_jobs()
 				for (int b = 0; b < 4; b++) { p.out[b] = base + plan.ch[c].band[0][b].offset; p.q[b] = make_q(plan.ch[c].band[0][b].quant, mpq); }
 			}
 		}
-		if (is_packed16(plan.pixel_kind))
+		if (enc_packed16(plan.pixel_kind))
 			for (int c = 0; c < nch; c++) {
 				dev::FwdPlaneJob &p = j.l1[(size_t)i * nch + c];
 				const uint16_t *frame = own_input ? (const uint16_t *)(d_in_ + frame_bytes_ * i) : nullptr;
-				p.in = frame ? (const int16_t *)(frame + packed_word_of_channel(plan.pixel_kind, c)) : nullptr; p.in_pitch = in_pitch_ / 2;
+				p.in = frame ? (const int16_t *)(frame + enc_word_of_channel(plan.pixel_kind, c)) : nullptr; p.in_pitch = in_pitch_ / 2;
 				p.width = plan.ch[c].width; p.height = plan.ch[c].height; p.prescale = plan.prescale[0];
-				p.xstride = nch; p.shift = 16 - plan.precision; p.display_height = plan.display_height;
+				p.xstride = enc_stride_of_channel(plan.pixel_kind, c, nch); p.shift = 16 - plan.precision; p.display_height = plan.display_height;
 				p.compand = plan.pixel_kind == PIX_B64A && c == 3;
+				p.layout = plan.pixel_kind == PIX_V210 ? c + 1 : 0; p.tail_from = (plan.width - plan.width % 48) / 2;
 				p.out_pitch = plan.ch[c].band[0][0].pitch;
 				for (int b = 0; b < 4; b++) { p.out[b] = base + plan.ch[c].band[0][b].offset; p.q[b] = make_q(plan.ch[c].band[0][b].quant, mpq); }
 			}
@@ -299,7 +308,7 @@ int EncodeBatch::update_quant(const FramePlan &plan)
 	if (!own_input_) for (int i = 0; i < n_; i++) {
 		j.yuv[i].in = (const uint8_t *)keep_yuv[i]; j.yuv[i].in_pitch = keep_pitch[i];
 		if (plan_.pixel_kind == PIX_BYR4) { j.bayer[i].in = (const uint16_t *)keep_bayer[i]; j.bayer[i].in_pitch = keep_bpitch[i]; }
-		if (is_packed16(plan_.pixel_kind)) for (int c = 0; c < plan_.num_channels; c++) { j.l1[(size_t)i * plan_.num_channels + c].in = (const int16_t *)keep_l1[(size_t)i * plan_.num_channels + c]; j.l1[(size_t)i * plan_.num_channels + c].in_pitch = keep_l1pitch[(size_t)i * plan_.num_channels + c]; }
+		if (enc_packed16(plan_.pixel_kind)) for (int c = 0; c < plan_.num_channels; c++) { j.l1[(size_t)i * plan_.num_channels + c].in = (const int16_t *)keep_l1[(size_t)i * plan_.num_channels + c]; j.l1[(size_t)i * plan_.num_channels + c].in_pitch = keep_l1pitch[(size_t)i * plan_.num_channels + c]; }
 	}
 	if (ent_ready_) ent_.set_plan(plan);
 	return 0;
@@ -349,10 +358,10 @@ int EncodeBatch::set_device_frame(int i, const void *d_frame, int pitch)
 	if (i < 0 || i >= n_) return -1;
 	EncJobs j = enc_jobs_at(h_jobs_, n_, plan_.num_channels);
 	if (plan_.pixel_kind == PIX_BYR4) { j.bayer[i].in = (const uint16_t *)d_frame; j.bayer[i].in_pitch = pitch / 2; jobs_dirty_ = true; return 0; }
-	if (is_packed16(plan_.pixel_kind)) {
+	if (enc_packed16(plan_.pixel_kind)) {
 		for (int c = 0; c < plan_.num_channels; c++) {
 			dev::FwdPlaneJob &p = j.l1[(size_t)i * plan_.num_channels + c];
-			p.in = (const int16_t *)((const uint16_t *)d_frame + packed_word_of_channel(plan_.pixel_kind, c)); p.in_pitch = pitch / 2;
+			p.in = (const int16_t *)((const uint16_t *)d_frame + enc_word_of_channel(plan_.pixel_kind, c)); p.in_pitch = pitch / 2;
 		}
 		jobs_dirty_ = true;
 		return 0;
@@ -416,7 +425,7 @@ const char *EncodeBatch::level_kernel(int level) const
 	const int act = active_ > 0 && active_ < n_ ? active_ : n_;
 	if (level > 0) return planes_as_strips(plan_, level, act) ? "k_fwd_plane_strip" : "k_fwd_plane";
 	if (plan_.pixel_kind == PIX_BYR4) return "k_unpack_byr4+k_fwd_plane";
-	if (is_packed16(plan_.pixel_kind)) return "k_fwd_packed16";
+	if (enc_packed16(plan_.pixel_kind)) return "k_fwd_packed16";
 	if (plan_.interlaced) return "k_fwd_frame_yuv422";
 	return strip_forward() ? "k_fwd_yuv422_strip" : "k_fwd_yuv422";
 }
@@ -436,7 +445,7 @@ int EncodeBatch::launch_forward()
 		dev::k_unpack_byr4<<<dim3((plan_.width + dev::NTHREADS - 1) / dev::NTHREADS, plan_.height, act), dev::NTHREADS, 0, st>>>(j.bayer);
 		dim3 grid((plan_.width / 2 + dev::TW - 1) / dev::TW, (plan_.height / 2 + dev::TH - 1) / dev::TH, act * nch);
 		dev::k_fwd_plane<<<grid, dev::NTHREADS, 0, st>>>(j.l1);
-	} else if (is_packed16(plan_.pixel_kind)) {
+	} else if (enc_packed16(plan_.pixel_kind)) {
 		dim3 grid(((plan_.width / 2 + dev::TW - 1) / dev::TW) * nch, (plan_.height / 2 + dev::TH - 1) / dev::TH, act);
 		dev::k_fwd_packed16<<<grid, dev::NTHREADS, 0, st>>>(j.l1, nch);
 	} else if (plan_.interlaced) {

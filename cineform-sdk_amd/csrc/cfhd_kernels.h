@@ -41,6 +41,11 @@ struct FwdPlaneJob {
 	// display_height repeat the last picture row (frame.c:6020-6024)
 	int xstride, shift, display_height;
 	int compand;                            // alpha plane of b64a: 0 < a < 4095 -> ((a * 223 + 128) >> 8) + 256 (frame.c:6696-6707)
+	// v210 (10-bit 4:2:2, three samples per 32-bit word; convert.c:3968 ConvertV210RowToPlanar16s): layout 1 = luma, 2 = channel 1 (Cr),
+	// 3 = channel 2 (Cb); `in` is the start of the frame, rows beyond display_height are zero (frame.c:1481 stops there), and from sample
+	// tail_from on -- what the reference's 48-pixel SIMD loop leaves to its scalar loop -- channel 1 repeats the first Cr of every group of
+	// three (the scalar loop stores `v` before it has read the next one, convert.c:4530-4535).  layout 0: everything above.
+	int layout, tail_from;
 };
 
 struct FwdYuvJob {
@@ -264,6 +269,21 @@ __device__ __forceinline__ int tile_first_row(int r0, int height) { int s = 2 * 
 // PACKED: level 1 of the 4:4:4(:4) formats straight from the interleaved 16-bit pixels (ConvertRGB48ToFrame16s frame.c:5968 /
 // ConvertBGRA64ToFrame_4444_16s :6569 + FilterSpatialQuant16s).  gridDim.x = tiles_x * nch: the nch component planes of one tile
 // are consecutive logical tiles, i.e. they run close together on one XCD and the pixel rows they share come out of its L2.
+// One 10-bit sample of a v210 row (groups of six pixels in four words: Cb0 Y0 Cr0 | Y1 Cb1 Y2 | Cr1 Y3 Cb2 | Y4 Cr2 Y5, low bits first)
+__device__ __forceinline__ uint32_t v210_sample(const uint32_t *row, int layout, int x, int tail_from)
+{
+	int g, word, shift;
+	if (layout == 1) {
+		g = x / 6; const int r = x - 6 * g;
+		word = (0x332110 >> (4 * r)) & 15; shift = (0x2805500a >> (5 * r)) & 31;          // words 0 1 1 2 3 3, shifts 10 0 20 10 0 20
+	} else {
+		g = x / 3; int r = x - 3 * g;
+		if (layout == 2) { if (x >= tail_from && r) r--; word = (0x320 >> (4 * r)) & 15; shift = (0x2814 >> (5 * r)) & 31; }   // Cr: words 0 2 3, shifts 20 0 10
+		else { word = r; shift = 10 * r; }                                                                                  // Cb: words 0 1 2, shifts 0 10 20
+	}
+	return (row[4 * g + word] >> shift) & 0x3ffu;
+}
+
 template <bool PACKED>
 __device__ __forceinline__ void fwd_plane_tile(const FwdPlaneJob *jobs, int nch)
 {
@@ -291,7 +311,12 @@ __device__ __forceinline__ void fwd_plane_tile(const FwdPlaneJob *jobs, int nch)
 			const int y = row_start + j, dw = c0 - 2 + d;    // dword index within the plane row
 			va[k] = 0;
 			if (i < ROWS * (TW + 4) && y < H && dw >= 0 && dw < HW) {
-				if (PACKED) {
+				if (PACKED && job.layout) {
+					if (y < job.display_height) {
+						const uint32_t *row = (const uint32_t *)((const uint16_t *)job.in + (size_t)y * job.in_pitch);
+						va[k] = v210_sample(row, job.layout, 2 * dw, job.tail_from) | (v210_sample(row, job.layout, 2 * dw + 1, job.tail_from) << 16);
+					}
+				} else if (PACKED) {
 					const int yy = y < job.display_height ? y : job.display_height - 1;
 					const uint16_t *px = (const uint16_t *)job.in + (size_t)yy * job.in_pitch + (size_t)(2 * dw) * job.xstride;
 					uint32_t s0 = (uint32_t)px[0] >> job.shift, s1 = (uint32_t)px[job.xstride] >> job.shift;

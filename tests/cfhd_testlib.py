@@ -25,6 +25,8 @@ PIX_2VUY = fourcc("2vuy")
 PIX_RG48 = fourcc("RG48")
 PIX_B64A = fourcc("b64a")
 PIX_BYR4 = fourcc("BYR4")
+PIX_YU64 = fourcc("YU64")
+PIX_V210 = fourcc("v210")
 ENCODED_BAYER = 3       # CFHD_ENCODED_FORMAT_BAYER
 COLOR_FORMAT_BYR4 = 104 # Codec/color.h
 ENCODED_RGBA4444 = 2    # CFHD_ENCODED_FORMAT_RGBA_4444
@@ -220,7 +222,7 @@ def mask_volatile_metadata(sample):
 # ------------------------------------------------------------------------------------------
 PRODUCT_DIR = os.path.join(ROOT, "cineform-sdk_amd")
 PRODUCT_SO = os.path.join(PRODUCT_DIR, "libcfhd_amd.so")
-PIXKIND = {"YUY2": 1, "2vuy": 2, "RG48": 3, "b64a": 4, "BYR4": 5}
+PIXKIND = {"YUY2": 1, "2vuy": 2, "RG48": 3, "b64a": 4, "BYR4": 5, "YU64": 6, "v210": 7}
 ENC = {"422": 1, "bayer": 2, "444": 3, "4444": 4}
 _product = None
 
@@ -341,6 +343,43 @@ def synth_bayer(width, height, seed):
     lum = (np.sin(x / 37.0 + seed) * np.cos(y / 23.0) * 0.35 + 0.45) * 52000 + (x * y % 4099) * 2.0 + rng.normal(0, 120, (height, width))
     gain = np.where((y % 2 == 0) & (x % 2 == 0), 0.8, np.where((y % 2 == 1) & (x % 2 == 1), 0.6, 1.0))       # R, B darker than the greens
     return np.clip(lum * gain, 0, 65535).astype(np.uint16)
+
+
+def synth_v210(width, height, seed):
+    """A 10-bit 4:2:2 picture and its v210 packing (six pixels in four little-endian 32-bit words: Cb0 Y0 Cr0 | Y1 Cb1 Y2 | Cr1 Y3 Cb2 |
+    Y4 Cr2 Y5; rows padded to 48 pixels = 128 bytes).  TestCFHD has no v210 generator.  Returns (frame bytes, pitch, Y, Cb, Cr)."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:height, 0:width]
+    Y = np.clip(512 + 300 * np.sin(xx / 23.0 + seed) * np.cos(yy / 17.0) + rng.normal(0, 6, (height, width)), 4, 1019).astype(np.uint32)
+    Cb = np.clip(512 + 200 * np.sin(xx[:, ::2] / 41.0) + rng.normal(0, 4, (height, width // 2)), 4, 1019).astype(np.uint32)
+    Cr = np.clip(512 + 200 * np.cos(yy[:, ::2] / 31.0 + seed) + rng.normal(0, 4, (height, width // 2)), 4, 1019).astype(np.uint32)
+    wp = (width + 47) // 48 * 48
+    Yp = np.zeros((height, wp), np.uint32); Yp[:, :width] = Y
+    Cbp = np.zeros((height, wp // 2), np.uint32); Cbp[:, : width // 2] = Cb
+    Crp = np.zeros((height, wp // 2), np.uint32); Crp[:, : width // 2] = Cr
+    out = np.zeros((height, wp // 6 * 4), np.uint32)
+    out[:, 0::4] = Cbp[:, 0::3] | (Yp[:, 0::6] << 10) | (Crp[:, 0::3] << 20)
+    out[:, 1::4] = Yp[:, 1::6] | (Cbp[:, 1::3] << 10) | (Yp[:, 2::6] << 20)
+    out[:, 2::4] = Crp[:, 1::3] | (Yp[:, 3::6] << 10) | (Cbp[:, 2::3] << 20)
+    out[:, 3::4] = Yp[:, 4::6] | (Crp[:, 2::3] << 10) | (Yp[:, 5::6] << 20)
+    return out.reshape(-1).view(np.uint8).copy(), out.shape[1] * 4, Y, Cb, Cr
+
+
+def v210_planes(plan, Y, Cb, Cr):
+    """The three planes the reference's v210 unpack produces (Codec/convert.c:3968): channel 1 = Cr, channel 2 = Cb, rows below the picture
+    zero; behind the last whole 48 pixels its scalar loop stores every group's first Cr twice (Cr0 Cr0 Cr1 instead of Cr0 Cr1 Cr2)."""
+    h, w = Y.shape
+    H = 2 * plan.band[(0, 0, 0)]["height"]
+    cr = Cr.astype(np.int64).copy()
+    t = (w - w % 48) // 2
+    k = np.arange(t, w // 2)
+    src = np.where((k - t) % 3 == 0, k, k - 1)           # local 0 -> 0, 1 -> 0, 2 -> 1 of the group
+    cr[:, t:] = Cr[:, src]
+    planes = []
+    for pl in (Y, cr, Cb):
+        p = np.zeros((H, pl.shape[1]), np.int16); p[:h] = pl
+        planes.append(p)
+    return planes
 
 
 def byr4_planes(mosaic):

@@ -49,6 +49,38 @@ void emu_fwd_packed16(const uint16_t *in, int in_pitch_words, int width, int hei
 	hipemu::launch(grid, dim3(NTHREADS), [&] { k_fwd_packed16(jobs.data(), nch); });
 }
 
+// Level 1 of a 4:2:2 frame from 16-bit words Y0 C1 Y1 C2 (YU64): the same kernel with per-channel first word, stride and width, as
+// EncodeBatch::fill_jobs sets it up.  quant[c*4+b], out[c*4+b]; out_pitch[c].
+void emu_fwd_yu64(const uint16_t *in, int in_pitch_words, int width, int height, int display_height, const int *quant, int mpq, int16_t **out, const int *out_pitch)
+{
+	std::vector<FwdPlaneJob> jobs(3);
+	for (int c = 0; c < 3; c++) {
+		FwdPlaneJob &job = jobs[c];
+		job.in = (const int16_t *)(in + (c == 0 ? 0 : (c == 1 ? 1 : 3))); job.in_pitch = in_pitch_words; job.width = c ? width / 2 : width; job.height = height; job.prescale = 0;
+		job.xstride = c ? 4 : 2; job.shift = 6; job.display_height = display_height; job.compand = 0;
+		for (int b = 0; b < 4; b++) { job.out[b] = out[c * 4 + b]; job.q[b] = make_q(quant[c * 4 + b], mpq); }
+		job.out_pitch = out_pitch[c];
+	}
+	dim3 grid(((width / 2 + TW - 1) / TW) * 3, (height / 2 + TH - 1) / TH, 1);
+	hipemu::launch(grid, dim3(NTHREADS), [&] { k_fwd_packed16(jobs.data(), 3); });
+}
+
+// Level 1 of a 4:2:2 frame from v210 words: the loader picks the 10-bit fields (FwdPlaneJob::layout), as EncodeBatch::fill_jobs sets it up.
+void emu_fwd_v210(const uint32_t *in, int in_pitch_bytes, int width, int height, int display_height, const int *quant, int mpq, int16_t **out, const int *out_pitch)
+{
+	std::vector<FwdPlaneJob> jobs(3);
+	for (int c = 0; c < 3; c++) {
+		FwdPlaneJob &job = jobs[c];
+		job.in = (const int16_t *)in; job.in_pitch = in_pitch_bytes / 2; job.width = c ? width / 2 : width; job.height = height; job.prescale = 0;
+		job.xstride = 3; job.shift = 6; job.display_height = display_height; job.compand = 0;
+		job.layout = c + 1; job.tail_from = (width - width % 48) / 2;
+		for (int b = 0; b < 4; b++) { job.out[b] = out[c * 4 + b]; job.q[b] = make_q(quant[c * 4 + b], mpq); }
+		job.out_pitch = out_pitch[c];
+	}
+	dim3 grid(((width / 2 + TW - 1) / TW) * 3, (height / 2 + TH - 1) / TH, 1);
+	hipemu::launch(grid, dim3(NTHREADS), [&] { k_fwd_packed16(jobs.data(), 3); });
+}
+
 // Last level of a 4:4:4(:4) format to interleaved 16-bit pixels: bands[c*4+b].
 void emu_inv_packed16(int16_t **bands, int band_pitch, int w, int h, int display_height, int nch, int precision, const int *word_of_channel,
                       uint16_t *out, int out_pitch_words, int alpha_channel)

@@ -367,6 +367,53 @@ def test_byr4_encode_bitstream_identical(w, h):
         assert mask_volatile_metadata(a) == mask_volatile_metadata(b), "frame %d" % i
 
 
+@pytest.mark.parametrize("w,h", [(320, 240), (720, 486), (1920, 1080)])
+def test_yu64_encode_bitstream_identical_and_decodes_as_422(w, h):
+    """YU64 input (16-bit 4:2:2) through k_fwd_packed16 with per-channel word strides.  Byte-identical to the reference,
+    through CFHD_EncodeSample and through the batched path; the sample is an ordinary 4:2:2 sample and decodes to YUY2 like one."""
+    frames, pitch = qbist_frames(10, 2, w, h, PIX_YU64)
+    mine = amd_encode_frames(frames, pitch, w, h, PIX_YU64, encoded=ENCODED_YUV422)
+    refs = ref_encode_frames(frames, pitch, w, h, PIX_YU64, encoded=ENCODED_YUV422)
+    for i, (a, b) in enumerate(zip(mine, refs)):
+        assert len(a) == len(b), "frame %d: size %d vs reference %d" % (i, len(a), len(b))
+        assert mask_volatile_metadata(a) == mask_volatile_metadata(b), "frame %d" % i
+    words = np.frombuffer(frames[0].tobytes(), np.uint16).reshape(h, pitch // 2)[:, : w * 2]
+    as8 = (words >> 8).astype(np.uint8)                          # the same picture as 8-bit YUY2 words Y0 C1 Y1 C2
+    _check_decode(mine[0], as8.reshape(-1), w, h)
+    L = _batch_api()
+    b = L.cfhd_amd_batch_create_ex(w, h, PIX_YU64, ENCODED_YUV422, 0, QUALITY_FILMSCAN1, 3, 2, 1)
+    assert b, amd_last_error()
+    for i in range(3): assert L.cfhd_amd_batch_upload(b, i, frames[i % 2].ctypes.data_as(ctypes.c_void_p), pitch) == 0
+    assert L.cfhd_amd_batch_roundtrip(b) > 0, amd_last_error()
+    three = ref_encode_frames([frames[0], frames[1], frames[0]], pitch, w, h, PIX_YU64, encoded=ENCODED_YUV422)
+    for i in range(3):
+        p = ctypes.c_void_p(); sz = ctypes.c_size_t()
+        assert L.cfhd_amd_batch_get_sample(b, i, ctypes.byref(p), ctypes.byref(sz)) == 0
+        assert mask_volatile_metadata(ctypes.string_at(p, sz.value)) == mask_volatile_metadata(three[i]), "batched frame %d" % i
+    L.cfhd_amd_batch_destroy(b)
+
+
+@pytest.mark.parametrize("w,h", [(320, 240), (400, 120), (720, 480), (1280, 720), (1920, 1080)])
+def test_v210_encode_bitstream_identical(w, h):
+    """v210 input (10-bit 4:2:2, three samples per word).  Byte-identical to the reference incl. the widths whose last pixels go
+    through the reference's scalar loop (320, 400); decodes like any 4:2:2 sample.  1080 rows: the reference transforms eight uninitialised
+    rows below the picture (tests/test_host_bitstream.py), so there the sample is only required to decode to the picture."""
+    frames = [synth_v210(w, h, 3 + k) for k in range(2)]
+    pitch = frames[0][1]
+    data = [f[0] for f in frames]
+    mine = amd_encode_frames(data, pitch, w, h, PIX_V210, encoded=ENCODED_YUV422)
+    if h % 8 == 0:
+        refs = ref_encode_frames(data, pitch, w, h, PIX_V210, encoded=ENCODED_YUV422)
+        for i, (a, b) in enumerate(zip(mine, refs)):
+            assert len(a) == len(b), "frame %d: size %d vs reference %d" % (i, len(a), len(b))
+            assert mask_volatile_metadata(a) == mask_volatile_metadata(b), "frame %d" % i
+    _, _, Y, Cb, Cr = frames[0]
+    as8 = np.zeros((h, 2 * w), np.uint8)
+    as8[:, 0::2] = (Y >> 2); as8[:, 1::4] = (Cb >> 2); as8[:, 3::4] = (Cr >> 2)
+    img = _check_decode(mine[0], as8.reshape(-1), w, h)
+    assert psnr_yuy2(img[:, : (w - w % 48) * 2], as8[:, : (w - w % 48) * 2]) > 40      # (the columns behind the last whole 48 pixels carry the reference's repeated Cr)
+
+
 def test_byr4_encode_with_a_wide_pitch_reads_what_the_reference_reads():
     """The reference ignores the pitch of a BYR4 frame (frame.c:5376: tightly packed rows); so does CFHD_EncodeSample here."""
     w, h, pitch = 192, 96, 192 * 2 + 48

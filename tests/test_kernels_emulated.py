@@ -708,3 +708,51 @@ def test_gpu_entropy_stage_emulated_long_trailers():
     want = product_write_sample_host(plan, coeffs, 1, meta_global=meta)
     got = _emu_entropy(plan, coeffs, 1, meta)
     assert got == want
+
+
+@pytest.mark.parametrize("w,h,dh", [(32, 16, 16), (144, 40, 37), (336, 24, 24)])
+def test_fwd_packed16_level1_of_yu64(w, h, dh):
+    """YU64 input (16-bit words Y0 C1 Y1 C2, each >> 6 to 10 bits; Codec/frame.c:1556): k_fwd_packed16 with a first word, a stride and a
+    width per channel = the oracle's plane transform of the three unpacked planes (rows below the picture repeat the last row)."""
+    rng = np.random.default_rng(w + h)
+    words = rng.integers(0, 65536, size=(dh, 2 * w), dtype=np.int64).astype(np.uint16)
+    quant = [1, 24, 24, 12] * 3
+    pitches = [(cw // 2 + 7) // 8 * 8 for cw in (w, w // 2, w // 2)]
+    outs = [np.zeros((h // 2, pitches[c]), np.int16) for c in range(3) for _ in range(4)]
+    ptrs = (c_i16p * 12)(*[p16(o) for o in outs])
+    E = emu()
+    E.emu_fwd_yu64.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    E.emu_fwd_yu64(words.ctypes.data_as(ctypes.c_void_p), 2 * w, w, h, dh, iarr(quant), 2, ptrs, iarr(pitches))
+    planes = [words[:, 0::2] >> 6, words[:, 1::4] >> 6, words[:, 3::4] >> 6]
+    for c in range(3):
+        cw = w if c == 0 else w // 2
+        plane = np.zeros((h, cw), np.int16); plane[:dh] = planes[c].astype(np.int16); plane[dh:] = plane[dh - 1]
+        want = [np.zeros((h // 2, pitches[c]), np.int16) for _ in range(4)]
+        bands = (c_i16p * 4)(*[p16(o) for o in want])
+        oracle().orc_fwd_spatial(p16(plane), cw, cw, h, 0, iarr(quant[:4]), 2, bands, pitches[c])
+        for b in range(4):
+            assert np.array_equal(outs[4 * c + b][:, :cw // 2], want[b][:, :cw // 2]), (c, b)
+
+
+@pytest.mark.parametrize("w,h,dh", [(48, 16, 16), (144, 40, 37), (320, 24, 24), (400, 16, 13)])
+def test_fwd_packed16_level1_of_v210(w, h, dh):
+    """v210 input: the loader of k_fwd_packed16 picks the 10-bit fields out of the 32-bit words = the oracle's plane transform of the planes
+    the reference's unpack produces (v210_planes: zero rows below the picture, the repeated Cr of the scalar tail)."""
+    frame, pitch, Y, Cb, Cr = synth_v210(w, dh, w + h)
+    plan_like = type("P", (), {"band": {(0, 0, 0): {"height": h // 2}}})()
+    planes = v210_planes(plan_like, Y, Cb, Cr)
+    quant = [1, 24, 24, 12] * 3
+    pitches = [(cw // 2 + 7) // 8 * 8 for cw in (w, w // 2, w // 2)]
+    outs = [np.zeros((h // 2, pitches[c]), np.int16) for c in range(3) for _ in range(4)]
+    ptrs = (c_i16p * 12)(*[p16(o) for o in outs])
+    E = emu()
+    E.emu_fwd_v210.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    E.emu_fwd_v210(frame.ctypes.data_as(ctypes.c_void_p), pitch, w, h, dh, iarr(quant), 2, ptrs, iarr(pitches))
+    for c in range(3):
+        cw = w if c == 0 else w // 2
+        plane = np.ascontiguousarray(planes[c][:h])
+        want = [np.zeros((h // 2, pitches[c]), np.int16) for _ in range(4)]
+        bands = (c_i16p * 4)(*[p16(o) for o in want])
+        oracle().orc_fwd_spatial(p16(plane), cw, cw, h, 0, iarr(quant[:4]), 2, bands, pitches[c])
+        for b in range(4):
+            assert np.array_equal(outs[4 * c + b][:, :cw // 2], want[b][:, :cw // 2]), (c, b)
