@@ -45,7 +45,7 @@ private:
 	uint8_t *d_samples_ = nullptr, *h_samples_ = nullptr;
 	uint32_t *d_sizes_ = nullptr, *h_sizes_ = nullptr;
 	uint8_t *d_packed_ = nullptr; uint32_t *d_offsets_ = nullptr, *h_offsets_ = nullptr;   // dense copy of the samples for the D2H transfer
-	void *d_tables_ = nullptr, *d_bands_ = nullptr, *d_segband_ = nullptr, *d_segs_ = nullptr, *d_bandstate_ = nullptr, *d_frames_ = nullptr;
+	void *d_tables_ = nullptr, *d_bands_ = nullptr, *d_segband_ = nullptr, *d_segs_ = nullptr, *d_bandstate_ = nullptr, *d_frames_ = nullptr, *d_tokens_ = nullptr;
 	uint8_t *d_tmpl_ = nullptr, *h_tmpl_ = nullptr;
 	bool dirty_ = true;
 	void *ev_[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; bool timed_ = false;

@@ -20,7 +20,7 @@ GpuEntropyEncoder::~GpuEntropyEncoder() { release(); delete host_; }
 
 void GpuEntropyEncoder::release()
 {
-	void *dev[] = { d_samples_, d_sizes_, d_tables_, d_bands_, d_segband_, d_segs_, d_bandstate_, d_frames_, d_tmpl_, d_packed_, d_offsets_ };
+	void *dev[] = { d_samples_, d_sizes_, d_tables_, d_bands_, d_segband_, d_segs_, d_bandstate_, d_frames_, d_tmpl_, d_packed_, d_offsets_, d_tokens_ };
 	for (void *p : dev) if (p) (void)hipFree(p);
 	if (h_samples_) (void)hipHostFree(h_samples_);
 	if (h_sizes_) (void)hipHostFree(h_sizes_);
@@ -30,7 +30,7 @@ void GpuEntropyEncoder::release()
 	if (host_->frames) { (void)hipHostFree(host_->frames); host_->frames = nullptr; }
 	for (void *&e : ev_) if (e) { (void)hipEventDestroy((hipEvent_t)e); e = nullptr; }
 	timed_ = false;
-	d_samples_ = h_samples_ = nullptr; d_sizes_ = h_sizes_ = nullptr; d_tables_ = d_bands_ = d_segband_ = d_segs_ = d_bandstate_ = d_frames_ = nullptr;
+	d_samples_ = h_samples_ = nullptr; d_sizes_ = h_sizes_ = nullptr; d_tables_ = d_bands_ = d_segband_ = d_segs_ = d_bandstate_ = d_frames_ = d_tokens_ = nullptr;
 	d_tmpl_ = h_tmpl_ = nullptr; n_ = 0;
 }
 
@@ -58,6 +58,7 @@ int GpuEntropyEncoder::prepare(const FramePlan &plan, int nframes, int16_t *d_co
 	HIPCHK(hipMalloc(&d_segband_, jobs.segjobs.size() * sizeof(dev::EntSegJob)));
 	HIPCHK(hipMemcpy(d_segband_, jobs.segjobs.data(), jobs.segjobs.size() * sizeof(dev::EntSegJob), hipMemcpyHostToDevice));
 	HIPCHK(hipMalloc(&d_segs_, jobs.segjobs.size() * sizeof(dev::EntSegState)));
+	HIPCHK(hipMalloc(&d_tokens_, jobs.segjobs.size() * (size_t)dev::ENT_SEG * sizeof(uint32_t)));      // token lists: worst case one token per coefficient, only the used part is ever touched
 	HIPCHK(hipMalloc(&d_bandstate_, jobs.bands.size() * sizeof(dev::EntBandState)));
 	HIPCHK(hipMalloc((void **)&d_samples_, cap_ * n_));
 	HIPCHK(hipHostMalloc((void **)&h_samples_, cap_ * n_, hipHostMallocDefault));
@@ -104,7 +105,7 @@ int GpuEntropyEncoder::launch()
 	if (plan_.interlaced) HIPCHK(hipMemsetAsync(d_sizes_ + n_, 0, sizeof(uint32_t) * n_, st));
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[0], st));
 	dev::k_ent_count<<<(total_segs + dev::ENT_WAVES - 1) / dev::ENT_WAVES, dev::ENT_THREADS, 0, st>>>((const dev::EntSegJob *)d_segband_, geom, total_segs, (dev::EntSegState *)d_segs_, T,
-	                                                                                                    d_sizes_ + n_);
+	                                                                                                    d_sizes_ + n_, (uint32_t *)d_tokens_);
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[1], st));
 	dev::k_ent_scan<<<nbands_ * act, dev::ENT_THREADS, 0, st>>>((const dev::EntBandJob *)d_bands_, (dev::EntSegState *)d_segs_, (dev::EntBandState *)d_bandstate_, T);
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[2], st));
@@ -114,7 +115,7 @@ int GpuEntropyEncoder::launch()
 	                                                  (dev::EntBandState *)d_bandstate_, T);
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[3], st));
 	dev::k_ent_emit<<<(total_segs + dev::ENT_WAVES - 1) / dev::ENT_WAVES, dev::ENT_THREADS, 0, st>>>((const dev::EntSegJob *)d_segband_, geom, total_segs, (const dev::EntSegState *)d_segs_,
-	                                                          (const dev::EntBandState *)d_bandstate_, T);
+	                                                          (const dev::EntBandState *)d_bandstate_, T, (const uint32_t *)d_tokens_);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[4], st));
 	timed_ = true;

@@ -64,6 +64,7 @@ struct EntSegState {               // per segment, written by k_ent_count / k_en
 	uint32_t bits;                 // k_ent_count: bits of its tokens without the run in front of first_nz; k_ent_scan: with it
 	int prev_nz;                   // last nonzero before this segment (-1: none)
 	uint32_t bitoff;               // bit offset of its first token relative to the band payload
+	uint32_t ntok;                 // k_ent_count: nonzero coefficients of the segment = entries of its token list
 };
 
 struct EntBandState { uint32_t seg_bits, tail_run, payload_bytes, base_byte; uint8_t *out; /* payload address in the sample; null until k_ent_layout placed it */ };
@@ -172,8 +173,10 @@ __device__ __forceinline__ EntSegJob ent_seg_job(const EntSegJob *seg_jobs, cons
 // peak_flags[frame] is raised when a band coded with table 1 holds a coefficient beyond +-ENT_PEAK_THRESHOLD: the reference then appends a
 // peak table (encoder.c:4802, :6543), which this stage does not produce -- the caller sends that frame through the host writer.
 enum { ENT_PEAK_THRESHOLD = 250 };
+// The compacted token list of every segment (local raster index << 16 | value) is kept in `tokens` (ENT_SEG words per segment, the first
+// ntok used): k_ent_emit codes from that list -- a sixth of the bytes -- instead of reading and compacting the coefficients a second time.
 __global__ void __launch_bounds__(ENT_THREADS) k_ent_count(const EntSegJob *seg_jobs, EntBatchGeom geom, int total_segs, EntSegState *segs, const EntTables *tables,
-                                                            uint32_t *peak_flags)
+                                                            uint32_t *peak_flags, uint32_t *tokens)
 {
 	__shared__ uint32_t s_tok_all[ENT_WAVES][ENT_TOK_CAP];   // tokens of the current pass: local raster index << 16 | value (16 bits)
 	const int lane = wave_lane();
@@ -226,7 +229,7 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_count(const EntSegJob *seg_
 			const uint32_t run = (have && t > 0) ? (tok >> 16) - (before >> 16) - 1u : 0u;
 			const uint32_t ve = value_entry(T, (int)(int16_t)(tok & 0xffffu));
 			const uint32_t rt = T->run_total[run];
-			if (have) bits += rt + (ve >> 27);
+			if (have) { bits += rt + (ve >> 27); tokens[(size_t)seg * ENT_SEG + (size_t)t] = tok; }
 		}
 	}
 	bits = wave_get(wave_incl_scan(bits), ENT_LANES - 1);
@@ -236,6 +239,7 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_count(const EntSegJob *seg_
 		s.first_nz = mask ? first_nz : -1;
 		s.last_nz = mask ? last_nz : -1;
 		s.bits = bits;
+		s.ntok = (uint32_t)ntok;
 	}
 }
 
@@ -401,10 +405,10 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_layout(const EntFrameJob *f
 }
 
 // =============================================================================================
-__global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(const EntSegJob *seg_jobs, EntBatchGeom geom, int total_segs, const EntSegState *segs, const EntBandState *band_state, const EntTables *tables)
+__global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(const EntSegJob *seg_jobs, EntBatchGeom geom, int total_segs, const EntSegState *segs, const EntBandState *band_state, const EntTables *tables,
+                                                           const uint32_t *tokens)
 {
 	__shared__ uint32_t s_words_all[ENT_WAVES][ENT_LDS_WORDS + 2];
-	__shared__ uint32_t s_tok_all[ENT_WAVES][ENT_TOK_CAP];   // tokens of the current pass, compacted: local raster index << 16 | value (16 bits)
 	const int lane = wave_lane();
 	const int wave = wave_uniform((int)(threadIdx.x >> 6));
 	const int seg = wave_uniform((int)blockIdx.x * ENT_WAVES + wave);
@@ -415,16 +419,11 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(const EntSegJob *seg_j
 	if (st.bits == 0) return;                            // wave-uniform: nothing starts in this segment
 	uint32_t *out = (uint32_t *)band_state[job.band].out;
 	if (!out) return;                                    // the sample overflowed its buffer (k_ent_layout reported size 0)
-	uint32_t *s_words = s_words_all[wave], *s_tok = s_tok_all[wave];
-	int v[ENT_PER_THREAD];
-	ent_load16(job, job.first + lane * ENT_PER_THREAD, v);
-	// 1. compact the nonzero coefficients of the wave into a token list: the picture is sparse (about one coefficient in eight
-	//    is nonzero), so from here on the work is spread evenly over the lanes, one token per lane and round
-	int cnt = 0;
-#pragma unroll
-	for (int k = 0; k < ENT_PER_THREAD; k++) cnt += v[k] != 0;
-	const int incl = (int)wave_incl_scan((uint32_t)cnt);
-	const int ntok = (int)wave_get((uint32_t)incl, ENT_LANES - 1);
+	uint32_t *s_words = s_words_all[wave];
+	// 1. the segment's token list as k_ent_count left it (the picture is sparse, about one coefficient in eight is nonzero: from here on
+	//    the work is spread evenly over the lanes, one token per lane and round)
+	const uint32_t *seg_tok = tokens + (size_t)seg * ENT_SEG;
+	const int ntok = (int)st.ntok;
 	const uint64_t seg_pos = st.bitoff;                  // bit position of the segment inside the band payload
 	const uint32_t first_word = (uint32_t)(seg_pos >> 5), last_word = (uint32_t)((seg_pos + st.bits - 1) >> 5);
 	const uint32_t nwords = last_word - first_word + 1;
@@ -435,22 +434,14 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(const EntSegJob *seg_j
 	//    to the last nonzero of the earlier segments), table lookups back to back, bit position by a wave scan, code words OR-ed
 	//    into the wave's LDS window
 	uint64_t round_pos = seg_pos;
-	uint32_t carry_tok = 0;                              // last token of the previous pass
-	for (int lo = 0; lo < ntok; lo += ENT_TOK_CAP) {     // wave-uniform: one pass unless the segment is unusually dense
-		if (lo) { carry_tok = s_tok[ENT_TOK_CAP - 1]; CFHD_WAVE_SYNC(); }
-		{
-			int at = incl - cnt - lo;
-#pragma unroll
-			for (int k = 0; k < ENT_PER_THREAD; k++)
-				if (v[k]) { if ((unsigned)at < (unsigned)ENT_TOK_CAP) s_tok[at] = ((uint32_t)(lane * ENT_PER_THREAD + k) << 16) | (uint32_t)(uint16_t)v[k]; at++; }
-		}
-		CFHD_WAVE_SYNC();
-		const int hi = ntok - lo < ENT_TOK_CAP ? ntok - lo : ENT_TOK_CAP;
-	for (int t0 = 0; t0 < hi; t0 += ENT_LANES) {
-		const int tl = t0 + lane, t = lo + tl;
-		const bool have = tl < hi;
-		const uint32_t tok = have ? s_tok[tl] : 0u;
-		const uint32_t before = (have && t > 0) ? (tl > 0 ? s_tok[tl - 1] : carry_tok) : 0u;
+	uint32_t carry_tok = 0;                              // last token of the previous round
+	{
+	for (int t = lane, t0 = 0; t0 < ntok; t0 += ENT_LANES, t += ENT_LANES) {
+		const bool have = t < ntok;
+		const uint32_t tok = have ? seg_tok[t] : 0u;
+		uint32_t before = __shfl_up(tok, 1u);
+		if (lane == 0) before = carry_tok;
+		carry_tok = wave_get(tok, ENT_LANES - 1);
 		const int lp = (int)(tok >> 16);
 		uint32_t run = t > 0 ? (uint32_t)(lp - (int)(before >> 16) - 1) : (uint32_t)(job.first + lp - st.prev_nz - 1);
 		if (!have) run = 0;
