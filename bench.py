@@ -324,7 +324,7 @@ def main():
         P = W * Hp * wl["bpp"]                           # bytes of the packed frame
         coded = (S - S // 64) * 2                        # bytes of the entropy-coded bands (everything but the LL3 bands)
         algo = {FWD1: P + 2 * S, PF2: S, PF3: S // 4,                               # 12 441 600 B per 1080p 4:2:2 frame
-                "k_ent_count": coded, "k_ent_emit": coded + sample_bytes}
+                "k_ent_count": coded, "k_ent_emit": coded // 4 + sample_bytes}          # emit reads k_ent_count's token lists (4 bytes per nonzero coefficient, about one in eight), not the pyramid
         if wl["mode"] == 0:
             algo.update({PI3: S // 4, PI2: S, INV1: 2 * S + P})
             if old_dec: algo["k_dec_bands_par"] = sample_bytes + coded
