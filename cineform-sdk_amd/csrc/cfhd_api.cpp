@@ -943,9 +943,10 @@ CFHD_Error CFHD_DecodeSample(CFHD_DecoderRef ref, void *sample, size_t size, voi
 	if (parse_sample(s, size, &ps) != 0) return fail_zero(ERR_BADSAMPLE);
 	if (ps.width != d->header.width || ps.display_height != d->header.display_height || ps.encoded_format != d->header.encoded_format ||
 	    ps.num_channels != d->plan.num_channels) return fail_zero(ERR_BADSAMPLE);
-	// interlaced samples (known only now: the SAMPLE_FLAGS tag lies behind the 512 bytes CFHD_PrepareToDecode sees): 4:2:2 at full resolution
+	// interlaced samples (known only now: the SAMPLE_FLAGS tag lies behind the 512 bytes CFHD_PrepareToDecode sees): 4:2:2, full resolution through the
+	// inverse frame transform, half resolution from the level-1 lowpass planes like any other sample (the reference's output is the same model)
 	const bool interlaced = !ps.progressive;
-	if (interlaced && (ps.encoded_format != ENC_YUV422 || d->half)) return fail_zero(ERR_BADFORMAT);
+	if (interlaced && ps.encoded_format != ENC_YUV422) return fail_zero(ERR_BADFORMAT);
 	// another call of this geometry in flight right now: decode together with it (see DecodeService)
 	if (decode_gather_slots() > 1 && gpu_entropy_enabled() && size <= (size_t)d->plan.width * d->plan.height * pixel_bytes_of(d->out_kind) + 65536) {
 		if (!d->service || d->service_interlaced != interlaced) {

@@ -699,7 +699,7 @@ int DecodeBatch::launch_inverse(uint32_t dither_seed)
 		dev::k_inv_plane<<<grid, dev::NTHREADS, 0, st>>>(jobs);
 		HIPCHK(hipEventRecord((hipEvent_t)evl_[2 - lv], st));
 	}
-	if (interlaced_ && (half_ || is_packed16(out_kind_))) return -1;
+	if (interlaced_ && !half_ && is_packed16(out_kind_)) return -1;
 	if (half_ && is_packed16(out_kind_)) {
 		const BandDesc &b = plan_.ch[0].band[0][0];
 		dev::k_half_packed16<<<dim3((b.width / 8 + dev::NTHREADS - 1) / dev::NTHREADS, out_rows_, act), dev::NTHREADS, 0, st>>>(j.halfp);
@@ -710,7 +710,7 @@ int DecodeBatch::launch_inverse(uint32_t dither_seed)
 		const BandDesc &b = plan_.ch[0].band[0][0];
 		dim3 grid(((b.width + dev::ITW - 1) / dev::ITW) * nch, (b.height + dev::ITH - 1) / dev::ITH, act);
 		dev::k_inv_packed16<<<grid, dev::NTHREADS, 0, st>>>(j.l1, nch);
-	} else if (interlaced_) {
+	} else if (interlaced_) {                           // (half resolution was served above: the level-1 lowpass planes need no inverse frame transform)
 		const BandDesc &b = plan_.ch[0].band[0][0];
 		dev::k_inv_frame_yuv422<<<dim3((b.width / 2 + dev::NTHREADS - 1) / dev::NTHREADS, b.height, act), dev::NTHREADS, 0, st>>>(j.yuv, dither_seed);
 	} else if (strip_inverse()) {

@@ -538,19 +538,24 @@ def test_interlaced_decode_peak_table_frames():
         del os.environ["CFHD_AMD_ENTROPY"]
 
 
-def test_interlaced_samples_at_half_resolution_are_refused():
-    """Half-resolution output of interlaced samples is not built: CFHD_DecodeSample says BADFORMAT and zero-fills the output."""
-    w, h = 320, 240
-    sample = amd_encode_frames([synth_yuy2(w, h, 3)[0]], w * 2, w, h, PIX_YUY2, flags=1)[0]
-    L = product()
-    dec = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
-    aw = ctypes.c_int(); ah = ctypes.c_int(); af = ctypes.c_uint32()
-    sb = ctypes.create_string_buffer(sample, len(sample))
-    assert L.CFHD_PrepareToDecode(dec, 0, 0, PIX_YUY2, 2, 0, sb, 512, ctypes.byref(aw), ctypes.byref(ah), ctypes.byref(af)) == 0
-    out = np.full(w * (h // 2), 7, np.uint8)
-    assert L.CFHD_DecodeSample(dec, sb, len(sample), out.ctypes.data_as(ctypes.c_void_p), w) == 3   # CFHD_ERROR_BADFORMAT
-    assert not out.any()
-    L.CFHD_CloseDecoder(dec)
+@pytest.mark.parametrize("w,h,fmt", [(320, 240, PIX_YUY2), (720, 486, PIX_2VUY), (1920, 1080, PIX_YUY2)])
+def test_interlaced_samples_at_half_resolution(w, h, fmt):
+    """Half resolution of an interlaced sample = the level-1 lowpass planes, exactly as for progressive samples (the reference's output
+    equals the same model: tests/test_oracle_vs_ref.py); byte-identical to the reference decoder, no dither at this resolution."""
+    f = synth_yuy2(w, h, 3)[0]
+    v = f.reshape(h, w * 2); v[1::2] = np.roll(v[1::2], 8, axis=1)
+    sample = ref_encode_frames([f], w * 2, w, h, fmt, flags=1)[0]
+    got, pitch, aw, ah = amd_decode_sample(sample, fmt, resolution=2)
+    assert (aw, ah) == (w // 2, h // 2)
+    img = got.reshape(ah, pitch)[:, : aw * 2]
+    plan = Plan(w, h, pixkind=2 if fmt == PIX_2VUY else 1, progressive=0)
+    want = oracle_half_resolution(plan, host_decode_pyramid(sample, plan), int(fmt == PIX_2VUY))
+    assert np.array_equal(img, want)
+    for attempt in range(4):
+        out, rpitch = ref_decode_sample(sample, w, h, fmt, resolution=2)
+        if np.array_equal(out.reshape(-1, rpitch)[:, : aw * 2], want): break
+    else:
+        raise AssertionError("the reference decoder never reproduced the model")
 
 
 def test_b64a_8k_config_c_round_trip():
@@ -818,3 +823,46 @@ def test_concurrent_decoders_share_launches_and_stay_exact():
     for t in threads: t.start()
     for t in threads: t.join()
     if errors: raise errors[0]
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("interlaced", [0, 1])
+def test_decoder_survives_fuzzed_samples(interlaced):
+    """Damaged samples through CFHD_DecodeSample: bursts of garbage, bit flips, oversized size fields, truncation.  Every call returns
+    (OKAY with some picture, BADSAMPLE / BADFORMAT with a zero-filled one), nothing is written outside the output buffer, and the handle decodes the
+    intact sample correctly afterwards."""
+    w, h = 640, 360
+    f = synth_yuy2(w, h, 9)[0]
+    if interlaced:
+        f = field_flicker_frame(w, h)[0]
+    sample = ref_encode_frames([f], w * 2, w, h, PIX_YUY2, flags=interlaced)[0]
+    s = np.frombuffer(sample, dtype=np.uint8).copy()
+    L = product()
+    dec = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
+    aw = ctypes.c_int(); ah = ctypes.c_int(); af = ctypes.c_uint32()
+    first = ctypes.create_string_buffer(sample, len(sample))
+    assert L.CFHD_PrepareToDecode(dec, 0, 0, PIX_YUY2, 1, 0, first, 512, ctypes.byref(aw), ctypes.byref(ah), ctypes.byref(af)) == 0
+    out = np.zeros(h * w * 2 + 4096, np.uint8)
+    rng = np.random.default_rng(31 + interlaced)
+    codes = {}
+    for trial in range(32):
+        t = s.copy()
+        kind = trial % 4
+        if kind == 0:
+            lo = int(rng.integers(600, len(t) - 128)); n = int(rng.integers(1, 128)); t[lo: lo + n] = rng.integers(0, 256, n, dtype=np.uint8)
+        elif kind == 1:
+            for _ in range(int(rng.integers(1, 6))):
+                i = int(rng.integers(600, len(t))); t[i] ^= np.uint8(1 << int(rng.integers(0, 8)))
+        elif kind == 2:
+            i = int(rng.integers(150, len(t) // 4)) * 4; t[i: i + 4] = [0x20 | int(rng.integers(0, 32)), int(rng.integers(0, 256)), 0xff, 0xff]
+        size = len(t) if kind != 3 else int(rng.integers(1024, len(t))) & ~3
+        out[:] = 7
+        sb = ctypes.create_string_buffer(t.tobytes(), len(t))
+        rc = L.CFHD_DecodeSample(dec, sb, size, out.ctypes.data_as(ctypes.c_void_p), w * 2)
+        codes[rc] = codes.get(rc, 0) + 1
+        assert rc in (0, 3, 5), (trial, rc, amd_last_error())
+        assert np.all(out[h * w * 2:] == 7), "trial %d wrote behind the output buffer" % trial
+        if rc: assert not out[: h * w * 2].any()
+    assert sum(v for k, v in codes.items() if k) >= 4, codes
+    img = _check_decode(sample, f, w, h, PIX_YUY2, interlaced=bool(interlaced), decoder=dec)
+    L.CFHD_CloseDecoder(dec)

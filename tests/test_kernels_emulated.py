@@ -756,3 +756,38 @@ def test_fwd_packed16_level1_of_v210(w, h, dh):
         oracle().orc_fwd_spatial(p16(plane), cw, cw, h, 0, iarr(quant[:4]), 2, bands, pitches[c])
         for b in range(4):
             assert np.array_equal(outs[4 * c + b][:, :cw // 2], want[b][:, :cw // 2]), (c, b)
+
+
+@pytest.mark.parametrize("interlaced", [0, 1])
+def test_dx_decoder_emulated_fuzzed_samples(interlaced):
+    """Random damage anywhere in a sample -- headers, size fields, peak table tags, code words, single bit flips, truncation: the kernels
+    (device parser included) either flag an error or decode something, never write outside the pyramid and never hang."""
+    w, h = 192, 96
+    plan = Plan(w, h, progressive=0 if interlaced else 1)
+    if interlaced:
+        frame, pitch = field_flicker_frame(w, h)
+        coeffs = oracle_forward_interlaced_yuv422(plan, frame, pitch)
+    else:
+        frame, pitch = synth_yuy2(w, h, 5)
+        coeffs = oracle_forward_yuv422(plan, frame, pitch)
+    sample = product_write_sample_host(plan, coeffs, 1, meta_global=b"GUID\x10\x00\x00G" + bytes(16), progressive=0 if interlaced else 1)
+    s = np.frombuffer(sample, dtype=np.uint8).copy()
+    rng = np.random.default_rng(23 + interlaced)
+    outcomes = {0: 0}
+    for trial in range(24):
+        t = s.copy()
+        kind = trial % 4
+        if kind == 0:                                   # a burst of garbage at a random place (the header area in every other trial of this kind)
+            lo = int(rng.integers(0, 600)) if trial % 8 == 0 else int(rng.integers(0, len(t) - 64))
+            n = int(rng.integers(1, 64)); t[lo: lo + n] = rng.integers(0, 256, n, dtype=np.uint8)
+        elif kind == 1:                                 # single bit flips
+            for _ in range(int(rng.integers(1, 6))):
+                i = int(rng.integers(0, len(t))); t[i] ^= np.uint8(1 << int(rng.integers(0, 8)))
+        elif kind == 2:                                 # a size / tag word overwritten with a large value
+            i = int(rng.integers(0, len(t) // 4)) * 4; t[i: i + 4] = [0x20 | int(rng.integers(0, 32)), int(rng.integers(0, 256)), 0xff, 0xff]
+        size = len(t) if kind != 3 else int(rng.integers(16, len(t))) & ~3
+        for mode in (0, 2):
+            rc, got = _dx_decode(t, plan, mode, 2, size=size, guard=4096)
+            outcomes[rc != 0] = outcomes.get(rc != 0, 0) + 1
+            assert np.all(got[plan.coeff_elems:] == 99), (trial, mode)
+    assert outcomes.get(True, 0) >= 4                  # (some damage must have been noticed)

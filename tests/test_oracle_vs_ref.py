@@ -95,14 +95,18 @@ def test_reference_decode_lies_in_oracle_dither_interval(w, h, fmt):
     assert 0.3 < (rimg[differ] == hi[differ]).mean() < 0.7
 
 
+@pytest.mark.parametrize("interlaced", [0, 1])
 @pytest.mark.parametrize("w,h,fmt", [(320, 240, PIX_YUY2), (336, 252, PIX_YUY2), (720, 486, PIX_2VUY), (1920, 1080, PIX_YUY2)])
-def test_reference_half_resolution_decode_equals_model(w, h, fmt):
+def test_reference_half_resolution_decode_equals_model(w, h, fmt, interlaced):
     """CFHD_DECODED_RESOLUTION_HALF of a 4:2:2 sample: the reference stops in front of the last wavelet level and shows the level-1 lowpass
-    planes, SATURATE_8U(value >> 4), width / 2 x display height / 2, no dither -- byte for byte the oracle's levels 3 and 2 + this model."""
+    planes, SATURATE_8U(value >> 4), width / 2 x display height / 2, no dither -- byte for byte the oracle's levels 3 and 2 + this model.
+    Interlaced samples (level 1 = frame transform) give the same: their level-1 lowpass is scaled like the spatial one."""
     f, p = synth_yuy2(w, h, 7)
-    sample = ref_encode_frames([f], p, w, h, fmt)[0]
+    if interlaced:
+        v = f.reshape(h, p); v[1::2] = np.roll(v[1::2], 8, axis=1)
+    sample = ref_encode_frames([f], p, w, h, fmt, flags=interlaced)[0]
     uyvy = int(fmt == PIX_2VUY)
-    plan = Plan(w, h, pixkind=2 if uyvy else 1)
+    plan = Plan(w, h, pixkind=2 if uyvy else 1, progressive=0 if interlaced else 1)
     want = oracle_half_resolution(plan, host_decode_pyramid(sample, plan), uyvy)
     assert want.shape == (h // 2, w)
     for attempt in range(6):                            # the reference's threaded decoder occasionally damages a frame: three attempts
