@@ -367,170 +367,6 @@ __device__ __forceinline__ DxChunkRec dx_index_staged(const uint32_t bytes, cons
 	return r;
 }
 
-// ---- the same, with the correction rounds of the workgroup's four chunks pooled ---------------------------------------------------------
-// A correction round restarts two or three lanes of a chunk, yet costs its wave a whole walk (the other sixty lanes wait).  Here the four
-// waves of a workgroup index their chunks in lock step; a wave with few lanes to restart posts them as requests (start, lane, wave) in LDS and
-// wave 0 walks the requests of all four chunks at once between two barriers, each of its lanes on the staged bits of the chunk the request
-// came from.  Round 0 (every lane walks) and crowded rounds stay with their wave.  Called by all waves of the workgroup together; `active`:
-// this wave has a chunk.  Same result as dx_index_staged (a pooled walk is a fresh walk: no merging with the lane's earlier marks).
-enum { DX_POOL_MAX = 16, DX_POOL_PER_WAVE = 8 };
-struct DxPool {
-	uint32_t nreq[2], alive[2];
-	uint32_t req[2][DX_POOL_MAX];                         // start (16 bits) | lane << 16 | wave << 22; DX_BAD: empty
-	uint32_t res[DX_POOL_MAX][8];                         // start, end, cnt, rec_offs, rec_cnt[4]
-	uint32_t limit[DX_WAVES];
-};
-__device__ __forceinline__ void dx_block_sync() { __syncthreads(); }
-__device__ __forceinline__ DxChunkRec dx_index_pooled(const bool active, const uint32_t bytes, const uint32_t gchunk, const uint32_t k, const uint32_t exact_start,
-                                                      const uint32_t (*s_words_all)[DX_STAGE_PHYS], const int wave, DxPool &P, const uint16_t *s_cnt, const uint16_t *s_sym,
-                                                      const uint32_t *s_long, uint32_t *entries, uint32_t *stats)
-{
-	const int lane = wave_lane();
-	const uint32_t *s_words = s_words_all[wave];
-	const uint32_t nwords = bytes >> 2;
-	const int64_t first = (int64_t)k * DX_CHUNK_WORDS - (DX_LANE_BITS / 32);
-	const int64_t left = (int64_t)nwords - first;
-	const uint32_t limit = (!active || left <= 0) ? 0u : (left * 32 > (int64_t)(64 * DX_LANE_BITS + 64) ? (uint32_t)(64 * DX_LANE_BITS + 64) : (uint32_t)(left * 32));
-	const uint32_t lane_base = (uint32_t)lane * DX_LANE_BITS;
-	const bool live = active && lane_base < limit && lane >= 1;
-	const int last_live = limit == 0u ? 0 : (int)((limit - 1u) / DX_LANE_BITS) < 63 ? (int)((limit - 1u) / DX_LANE_BITS) : 63;
-	DxLane L;
-	L.start = DX_BAD; L.end = lane_base; L.cnt = 0; L.rec_offs = DX_OFFS_NONE;
-#pragma unroll
-	for (int j = 0; j < DX_SUBS; j++) L.rec_cnt[j] = 0;
-	if (lane == 0) { L.start = 0u; L.end = exact_start >= DX_SPECIAL ? exact_start : DX_LANE_BITS + exact_start; }
-	uint32_t memo_s[DX_MEMO], memo_e[DX_MEMO], memo_c[DX_MEMO];
-	int memo_at = 0;
-#pragma unroll
-	for (int i = 0; i < DX_MEMO; i++) { memo_s[i] = DX_BAD; memo_e[i] = 0; memo_c[i] = 0; }
-	uint32_t rec_start = DX_BAD, rec_end = 0, rec_total = 0;
-	bool finishing = false, done = !active;
-	if (threadIdx.x == 0) { P.nreq[0] = P.nreq[1] = 0; P.alive[0] = P.alive[1] = 0; }
-	if (threadIdx.x < 2 * DX_POOL_MAX) (&P.req[0][0])[threadIdx.x] = DX_BAD;
-	if (lane == 0) P.limit[wave] = limit;
-	dx_block_sync();
-#pragma unroll 1
-	for (int round = 0; round < 140; round++) {
-		const int par = round & 1;
-		uint32_t want = 0; bool need = false, walker = false, lead = false;
-		if (!done) {
-			if (finishing) {
-				const bool special = L.start >= DX_SPECIAL || L.start < lane_base || L.start >= lane_base + DX_LANE_BITS;
-				if (live && special) L.rec_offs = DX_OFFS_NONE;
-				want = L.start; need = live && !special && rec_start != L.start;
-			} else if (round == 0) {
-				const uint32_t first_end = __shfl_up(L.end, 1u);
-				want = lane == 1 ? first_end : lane_base - DX_LEAD; need = live;
-			} else {
-				want = __shfl_up(L.end, 1u); need = live && want != L.start;
-			}
-			unsigned long long moved = __ballot(need);
-			if (!finishing && round > 0) {
-				if (stats && lane == 0 && moved) atomicAdd(&stats[4 + (round - 1 < 11 ? round - 1 : 11)], (uint32_t)__builtin_popcountll(moved));
-				if (!moved) {
-					if (stats && lane == 0) { atomicAdd(&stats[0], (uint32_t)round - 1u); atomicAdd(&stats[1], 1u); atomicMax(&stats[2], (uint32_t)round - 1u); }
-					// nothing moves any more: this round brings the records up to date (a lane that ended on a remembered outcome holds another walk's)
-					finishing = true;
-					const bool special = L.start >= DX_SPECIAL || L.start < lane_base || L.start >= lane_base + DX_LANE_BITS;
-					if (live && special) L.rec_offs = DX_OFFS_NONE;
-					want = L.start; need = live && !special && rec_start != L.start;
-					moved = __ballot(need);
-				}
-			}
-			if (finishing && !moved) done = true;
-			if (!done && need) {
-				L.start = want;
-				lead = !finishing && round == 0 && lane >= 2;
-				if (!lead && (want >= DX_SPECIAL || want < lane_base || want >= lane_base + DX_LANE_BITS)) {
-					L.end = want >= DX_SPECIAL ? want : (uint32_t)DX_BAD; L.cnt = 0;
-				} else {
-					int hit = -1;
-#pragma unroll
-					for (int i = 0; i < DX_MEMO; i++) if (memo_s[i] == want) hit = i;
-					if (hit >= 0 && !finishing && !lead) {
-#pragma unroll
-						for (int i = 0; i < DX_MEMO; i++) if (i == hit) { L.end = memo_e[i]; L.cnt = memo_c[i]; }
-					} else walker = true;
-				}
-			}
-		}
-		// who walks: the wave itself (round 0, crowded rounds, no room in the pool) or wave 0 for everybody
-		const unsigned long long wmask = __ballot(walker);
-		const int nw = __builtin_popcountll(wmask);
-		bool pooled = !done && nw > 0 && nw <= DX_POOL_PER_WAVE && round > 0;
-		uint32_t slot0 = 0;
-		if (pooled) {
-			if (lane == 0) slot0 = atomicAdd(&P.nreq[par], (uint32_t)nw);
-			slot0 = wave_get(slot0, 0);
-			if (slot0 + (uint32_t)nw > (uint32_t)DX_POOL_MAX) pooled = false;
-		}
-		const uint32_t my_slot = slot0 + (uint32_t)__builtin_popcountll(wmask & ((1ull << lane) - 1ull));
-		if (pooled && walker) P.req[par][my_slot] = want | ((uint32_t)lane << 16) | ((uint32_t)wave << 22);
-		if (!pooled && walker) {
-			L.end = rec_end; L.cnt = rec_total;
-			dx_walk(L, want, !finishing && rec_start != DX_BAD, lane_base, limit, s_words, s_cnt, s_sym, s_long);
-		}
-		if (!done && lane == 0) atomic_or_u32(&P.alive[par], 1u);
-		dx_block_sync();                                      // ---- A: the requests of this round are posted
-		const uint32_t any_alive = P.alive[par];
-		uint32_t nreq = P.nreq[par];
-		if (nreq > (uint32_t)DX_POOL_MAX) nreq = DX_POOL_MAX;
-		if (threadIdx.x == 0) { P.nreq[par ^ 1] = 0; P.alive[par ^ 1] = 0; }
-		if (threadIdx.x < DX_POOL_MAX) P.req[par ^ 1][threadIdx.x] = DX_BAD;
-		if (!any_alive) break;                                // (uniform) every chunk of the workgroup is indexed
-		if (wave == 0 && (uint32_t)lane < nreq) {
-			const uint32_t rq = P.req[par][lane];
-			if (rq != (uint32_t)DX_BAD) {
-				const uint32_t rw = rq >> 22, rl = (rq >> 16) & 63u, rs = rq & 0xffffu;
-				DxLane R;
-				R.start = rs; R.end = 0; R.cnt = 0; R.rec_offs = DX_OFFS_NONE;
-#pragma unroll
-				for (int j = 0; j < DX_SUBS; j++) R.rec_cnt[j] = 0;
-				dx_walk(R, rs, false, rl * DX_LANE_BITS, P.limit[rw], s_words_all[rw], s_cnt, s_sym, s_long);
-				P.res[lane][0] = R.start; P.res[lane][1] = R.end; P.res[lane][2] = R.cnt; P.res[lane][3] = R.rec_offs;
-#pragma unroll
-				for (int j = 0; j < DX_SUBS; j++) P.res[lane][4 + j] = R.rec_cnt[j];
-			}
-		}
-		dx_block_sync();                                      // ---- B: the pooled walks are done
-		if (pooled && walker) {
-			L.end = P.res[my_slot][1]; L.cnt = P.res[my_slot][2]; L.rec_offs = P.res[my_slot][3];
-#pragma unroll
-			for (int j = 0; j < DX_SUBS; j++) L.rec_cnt[j] = P.res[my_slot][4 + j];
-		}
-		if (walker) {
-			const uint32_t walked = lead ? L.start : want;        // a lead-in reports the first code word inside the lane
-			L.start = walked;
-			rec_start = walked; rec_end = L.end; rec_total = L.cnt;
-#pragma unroll
-			for (int i = 0; i < DX_MEMO; i++) if (i == memo_at) { memo_s[i] = walked; memo_e[i] = L.end; memo_c[i] = L.cnt; }
-			memo_at = memo_at + 1 < DX_MEMO ? memo_at + 1 : 0;
-		}
-		if (finishing) done = true;
-	}
-	// entries: offset of the first code word | coefficients of the chunk in front of it
-	const uint32_t own = live ? L.cnt : 0u;
-	const uint32_t incl = wave_incl_scan(own);
-	const uint32_t before = incl - own;
-	const size_t slot = (size_t)gchunk * DX_ENTRY_STRIDE + (size_t)lane * DX_SUBS;
-	if (active && lane >= 1 && entries) {
-		uint4 e;
-		uint32_t v[DX_SUBS];
-#pragma unroll
-		for (int j = 0; j < DX_SUBS; j++) v[j] = (!live || dx_off_get(L.rec_offs, j) == (uint32_t)DX_OFF_INVALID) ? (uint32_t)DX_OFF_INVALID : (dx_off_get(L.rec_offs, j) | ((before + L.rec_cnt[j]) << 5));
-		e.x = v[0]; e.y = v[1]; e.z = v[2]; e.w = v[3];
-		*(uint4 *)(entries + slot) = e;
-	}
-	const uint32_t total = wave_get(incl, 63), el = wave_get(L.end, last_live);
-	DxChunkRec r;
-	r.start = exact_start;
-	r.end = el >= DX_SPECIAL ? el : ((last_live < 63 || el < 64u * DX_LANE_BITS) ? (uint32_t)DX_BAD : el - 64u * DX_LANE_BITS);
-	r.count = total;
-	r.flags = (r.end == DX_END ? DX_FLAG_END : 0u) | (r.end == DX_BAD ? DX_FLAG_BAD : 0u);
-	dx_block_sync();                                          // the staging areas may be overwritten now
-	return r;
-}
-
 // Stage + index from an exact start, not pipelined: the repair and re-index paths (rare; out of line so that it does not weigh on the callers' registers).
 __device__ __attribute__((noinline)) DxChunkRec dx_index_chunk(const uint8_t *bits, const uint32_t bytes, const uint32_t gchunk, const uint32_t k, const uint32_t exact_start, uint32_t *s_words,
                                                                const uint16_t *s_cnt, const uint16_t *s_sym, const uint32_t *s_long, uint32_t *entries, DxChunkRec *recs, uint32_t *stats)
@@ -645,71 +481,6 @@ __global__ void __launch_bounds__(DX_THREADS) k_dec_index(const DxChunkDesc *chu
 			}
 		}
 		d = d1;
-	}
-}
-
-// k_dec_index with the correction rounds pooled per workgroup (dx_index_pooled): the four waves take four consecutive chunks per step and stay
-// in lock step; everything else as above.  The default; CFHD_AMD_DX_POOL=0 selects k_dec_index.
-__global__ void __launch_bounds__(DX_THREADS) k_dec_index_pooled(const DxChunkDesc *chunk_desc, const uint32_t *counters, const DecIdxTables *T,
-                                                                 uint32_t *entries, DxChunkRec *recs, DxChunkAlt *alts, int speculate, uint32_t *stats)
-{
-	__shared__ uint16_t s_cnt[1 << DX_K], s_sym[1 << DX_K];
-	__shared__ uint32_t s_long[DX_LONG_MAX];
-	__shared__ uint32_t s_words_all[DX_WAVES][DX_STAGE_PHYS];
-	__shared__ DxPool s_pool;
-	dx_load_tables(T, s_cnt, s_sym, s_long, true);
-	__syncthreads();
-	const uint32_t total = counters[0];
-	const int wave = wave_uniform((int)(threadIdx.x >> 6));
-	uint32_t *s_words = s_words_all[wave];
-	const uint32_t nwaves = (uint32_t)gridDim.x * DX_WAVES;
-	uint32_t c = (uint32_t)blockIdx.x * DX_WAVES + (uint32_t)wave;
-	DxChunkDesc d = DxChunkDesc{ nullptr, 0u, 0u };
-	DxFetch F;
-#pragma unroll
-	for (int r = 0; r < DX_FETCH; r++) F.w[r] = 0u;
-	if (c < total) { d = chunk_desc[c]; dx_fetch_chunk(d.bits, d.bytes, d.k, F); }
-#pragma unroll 1
-	for (uint32_t base = (uint32_t)blockIdx.x * DX_WAVES; base < total; base += nwaves, c += nwaves) {      // the same number of steps for every wave of the workgroup
-		const bool active = c < total;
-		uint32_t cand[DX_MAX_ALT + 2] = { 0u, 0u, 0u, 0u, 0u };
-		int n = 0;
-		DxChunkDesc d1 = d;
-		if (active) {
-			dx_store_stage(F, s_words);
-			const uint32_t c1 = c + nwaves;
-			if (c1 < total) { d1 = chunk_desc[c1]; dx_fetch_chunk(d1.bits, d1.bytes, d1.k, F); }
-			n = 1;
-			if (d.k != 0 && speculate) {
-				n = dx_runin_candidates(d.bytes, d.k, DX_RUNIN_SHORT, s_words, s_cnt, s_sym, s_long, cand);
-				if (n != 1) n = dx_runin_candidates(d.bytes, d.k, DX_LANE_BITS, s_words, s_cnt, s_sym, s_long, cand);
-			}
-		}
-		const bool unresolved = n > DX_MAX_ALT + 1;
-		if (unresolved) n = 1;
-		__syncthreads();                                  // every wave's chunk is staged: wave 0 may read any of them
-		DxChunkRec r = dx_index_pooled(active && n > 0, d.bytes, c, d.k, cand[0], s_words_all, wave, s_pool, s_cnt, s_sym, s_long, entries, stats);
-		if (active && n == 0) {                              // behind the band end marker: padding
-			if (wave_lane() == 0) recs[c] = DxChunkRec{ (uint32_t)DX_END, (uint32_t)DX_END, 0u, (uint32_t)DX_FLAG_END | (1u << 8) };
-		} else if (active) {
-			r.flags |= ((uint32_t)n << 8) | (unresolved ? (uint32_t)DX_FLAG_UNRESOLVED : 0u);
-			if (wave_lane() == 0) recs[c] = r;
-			if (n > 1) {
-				DxChunkAlt a;
-#pragma unroll
-				for (int i = 0; i < DX_MAX_ALT; i++) { a.start[i] = DX_BAD; a.end[i] = DX_BAD; a.count[i] = 0; }
-#pragma unroll 1
-				for (int i = 1; i < n; i++) {
-					const DxChunkRec ri = dx_index_staged(d.bytes, c, d.k, cand[i], s_words, s_cnt, s_sym, s_long, nullptr, nullptr);
-#pragma unroll
-					for (int q = 0; q < DX_MAX_ALT; q++) if (q == i - 1) { a.start[q] = ri.start; a.end[q] = ri.end; a.count[q] = ri.count; }
-				}
-				if (wave_lane() == 0) alts[c] = a;
-				if (stats && wave_lane() == 0) atomicAdd(&stats[3], 1u << 16);
-			}
-		}
-		d = d1;
-		__syncthreads();                                  // the alternates of every wave are done before anybody stages its next chunk
 	}
 }
 

@@ -349,8 +349,6 @@ uint32_t g_dx_stats[16];
 extern "C" uint32_t *emu_dx_stats() { return g_dx_stats; }
 extern "C" int emu_entropy_decode_dx(const uint8_t *sample, size_t size, int pixel_kind, int16_t *coeffs, size_t coeff_elems, int mode, int grid)
 {
-	const bool classic_index = (mode & 4) != 0;          // +4: k_dec_index (every wave corrects its own chunk) instead of k_dec_index_pooled
-	mode &= 3;
 	memset(g_dx_stats, 0, sizeof(g_dx_stats));
 	using namespace cfhd;
 	ParsedSample ps;
@@ -397,8 +395,7 @@ extern "C" int emu_entropy_decode_dx(const uint8_t *sample, size_t size, int pix
 	std::vector<dev::DxReindex> reindex((size_t)nchunks + 1);
 	std::vector<uint32_t> repair_list((size_t)njobs + 1);
 	counters[1] = 0; counters[2] = 0;
-	if (classic_index) hipemu::launch(dim3((unsigned)grid), dim3(dev::DX_THREADS), [&] { dev::k_dec_index(chunk_job.data(), counters.data(), &tables, entries.data(), recs.data(), alts.data(), mode != 1, g_dx_stats); });
-	else hipemu::launch(dim3((unsigned)grid), dim3(dev::DX_THREADS), [&] { dev::k_dec_index_pooled(chunk_job.data(), counters.data(), &tables, entries.data(), recs.data(), alts.data(), mode != 1, g_dx_stats); });
+	hipemu::launch(dim3((unsigned)grid), dim3(dev::DX_THREADS), [&] { dev::k_dec_index(chunk_job.data(), counters.data(), &tables, entries.data(), recs.data(), alts.data(), mode != 1, g_dx_stats); });
 	hipemu::launch(dim3((unsigned)(njobs + dev::DX_WAVES - 1) / dev::DX_WAVES), dim3(dev::DX_THREADS), [&] { dev::k_dec_chain(jobs.data(), njobs, recs.data(), alts.data(), chunk_base.data(), sums.data(), &errors, repair_list.data(), reindex.data(), counters.data()); });
 	hipemu::launch(dim3(2), dim3(dev::DX_THREADS), [&] { dev::k_dec_repair(jobs.data(), &tables, entries.data(), recs.data(), alts.data(), chunk_base.data(), sums.data(), &errors, repair_list.data(), reindex.data(), counters.data(), g_dx_stats); });
 	hipemu::launch(dim3(3), dim3(dev::DX_THREADS), [&] { dev::k_dec_reindex(jobs.data(), &tables, entries.data(), reindex.data(), counters.data(), g_dx_stats); });
