@@ -38,6 +38,19 @@
 namespace cfhd {
 namespace dev {
 
+#ifndef CFHD_DX_MEMO
+#define CFHD_DX_MEMO 6
+#endif
+// k_dec_index waits on chains of dependent LDS lookups: a fifth wave per SIMD (what its 31 KB of LDS allow: five workgroups per CU) is worth more
+// than the 56 bytes of scratch the compiler needs to get from 113 to 96 registers (3.30 -> 2.93 ms per 512 frames; tools/dx_index_sweep.sh).
+#ifndef CFHD_DX_WAVES
+#define CFHD_DX_WAVES 5
+#endif
+#if CFHD_DX_WAVES > 0
+#define CFHD_DX_INDEX_ATTR __attribute__((amdgpu_waves_per_eu(CFHD_DX_WAVES, CFHD_DX_WAVES)))
+#else
+#define CFHD_DX_INDEX_ATTR
+#endif
 enum {
 	DX_K = 12,                        // bits of the first-level tables
 	DX_LANE_BITS = 256, DX_SUB_BITS = 64, DX_SUBS = DX_LANE_BITS / DX_SUB_BITS,
@@ -53,7 +66,7 @@ enum {
 	DX_TILE_THREADS = CFHD_DX_TILE_THREADS, DX_TILE_WAVES = DX_TILE_THREADS / 64,      // k_dec_tiles: its waves share the tables
 	DX_KM = 11,                       // bits of the window of the multi-symbol table of k_dec_tiles
 	DX_RUNIN_SHORT = 96, DX_LEAD = 96,    // bits of the quick run-in in front of a chunk / of the lead-in in front of a lane
-	DX_MEMO = 6,                      // outcomes a lane of k_dec_index remembers (start -> end, count)
+	DX_MEMO = CFHD_DX_MEMO,           // outcomes a lane of k_dec_index remembers (start -> end, count)
 	DX_OFF_INVALID = 31,              // entry: no code word of the true sequence starts in this piece (behind the band end marker / the payload)
 };
 enum : uint32_t { DX_END = 0xFFFFFFFFu, DX_BAD = 0xFFFFFFFEu, DX_SPECIAL = 0xFFFFFFFEu };
@@ -423,7 +436,7 @@ __global__ void __launch_bounds__(DX_THREADS) k_dec_plan_fill(const DxBandJob *j
 	for (uint32_t c = (uint32_t)wave_lane(); c < n; c += 64) chunk_desc[job.chunk0 + c] = DxChunkDesc{ job.bits, job.bytes, c };
 }
 
-__global__ void __launch_bounds__(DX_THREADS) k_dec_index(const DxChunkDesc *chunk_desc, const uint32_t *counters, const DecIdxTables *T,
+__global__ void __launch_bounds__(DX_THREADS) CFHD_DX_INDEX_ATTR k_dec_index(const DxChunkDesc *chunk_desc, const uint32_t *counters, const DecIdxTables *T,
                                                           uint32_t *entries, DxChunkRec *recs, DxChunkAlt *alts, int speculate, uint32_t *stats)
 {
 	__shared__ uint16_t s_cnt[1 << DX_K], s_sym[1 << DX_K];
@@ -447,7 +460,9 @@ __global__ void __launch_bounds__(DX_THREADS) k_dec_index(const DxChunkDesc *chu
 		dx_store_stage(F, s_words);
 		const uint32_t c1 = c + nwaves;
 		DxChunkDesc d1 = d;
+#if !defined(CFHD_DX_NOPREFETCH)
 		if (c1 < total) { d1 = chunk_desc[c1]; dx_fetch_chunk(d1.bits, d1.bytes, d1.k, F); }
+#endif
 		// A band's first chunk starts on its first bit; every other chunk finds the candidates for its first code word by running in through
 		// the 256 bits in front of it from every possible offset.  speculate == 0 (tests): assume offset 0 instead, which is wrong for most
 		// chunks -- k_dec_chain has to repair them.
@@ -480,6 +495,9 @@ __global__ void __launch_bounds__(DX_THREADS) k_dec_index(const DxChunkDesc *chu
 				if (stats && wave_lane() == 0) atomicAdd(&stats[3], 1u << 16);       // chunks with more than one candidate (upper half of the repair counter)
 			}
 		}
+#if defined(CFHD_DX_NOPREFETCH)
+		if (c1 < total) { d1 = chunk_desc[c1]; dx_fetch_chunk(d1.bits, d1.bytes, d1.k, F); }
+#endif
 		d = d1;
 	}
 }
