@@ -708,7 +708,7 @@ int DecodeBatch::launch_inverse(uint32_t dither_seed)
 		dev::k_half_yuv422<<<dim3((b.width / 8 + dev::NTHREADS - 1) / dev::NTHREADS, out_rows_, act), dev::NTHREADS, 0, st>>>(j.half);
 	} else if (is_packed16(out_kind_)) {
 		const BandDesc &b = plan_.ch[0].band[0][0];
-		dim3 grid(((b.width + dev::ITW - 1) / dev::ITW) * nch, (b.height + dev::ITH - 1) / dev::ITH, act);
+		dim3 grid((b.width + dev::ITW - 1) / dev::ITW, (b.height + dev::ITH - 1) / dev::ITH, act);      // one workgroup per tile, all components
 		dev::k_inv_packed16<<<grid, dev::NTHREADS, 0, st>>>(j.l1, nch);
 	} else if (interlaced_) {                           // (half resolution was served above: the level-1 lowpass planes need no inverse frame transform)
 		const BandDesc &b = plan_.ch[0].band[0][0];

@@ -586,20 +586,26 @@ __device__ __forceinline__ uint32_t expand_alpha16(uint32_t word)
 template <bool PACKED>
 __device__ __forceinline__ void inv_plane_tile(const InvPlaneJob *jobs, int nch)
 {
-	TileId tile = xcd_tile();
-	int comp = 0;
-	if (PACKED) { comp = tile.x % nch; tile.x /= nch; }
+	const TileId tile = xcd_tile();
 	__shared__ InvPlaneJob s_job;
+	__shared__ uint32_t s_low[2][ILROWS][IDW];          // LL, LH
+	__shared__ uint32_t s_high[2][ITH][IDW];            // HL, HH
+	__shared__ uint32_t s_v[2][2][ITH][IDW];            // [row parity][horizontal L/H]
+	// PACKED: the workgroup runs the tile of every component in turn and collects the finished words in LDS, pixel by pixel; the rows of the
+	// tile then leave as whole pixels in coalesced dwords (one workgroup per component wrote 2 bytes of every 6 or 8: a quarter of each line)
+	__shared__ uint16_t s_out[PACKED ? 2 * ITH * 2 * ITW * 4 : 1];
+	const int tid = threadIdx.x;
+	const uint16_t *frame = nullptr;                     // PACKED: first word of the packed frame
+	if (PACKED) { uintptr_t lo = (uintptr_t)jobs[tile.z * nch].out; for (int c = 1; c < nch; c++) { const uintptr_t p = (uintptr_t)jobs[tile.z * nch + c].out; lo = p < lo ? p : lo; } frame = (const uint16_t *)lo; }
+	for (int comp = 0; comp < (PACKED ? nch : 1); comp++) {
+	if (comp) __syncthreads();                           // the previous component's tile is finished with s_job and the staging arrays
 	stage_job(&s_job, &jobs[PACKED ? tile.z * nch + comp : tile.z]);
 	const InvPlaneJob &job = s_job;
 	const int w = job.width, h = job.height;
 	const int c0 = tile.x * ITW, r0 = tile.y * ITH;
-	__shared__ uint32_t s_low[2][ILROWS][IDW];          // LL, LH
-	__shared__ uint32_t s_high[2][ITH][IDW];            // HL, HH
-	__shared__ uint32_t s_v[2][2][ITH][IDW];            // [row parity][horizontal L/H]
 	const bool active = (c0 < w) && (r0 < h);
-	const int tid = threadIdx.x;
 	const int rs = inv_tile_first_row(r0, h);
+	const int word = PACKED ? (int)((const uint16_t *)job.out - frame) : 0;
 	if (active) {
 		enum { NL = (2 * ILROWS * IDW + NTHREADS - 1) / NTHREADS, NH = (2 * ITH * IDW + NTHREADS - 1) / NTHREADS };
 		uint32_t vl[NL], vh[NH];
@@ -646,15 +652,15 @@ __device__ __forceinline__ void inv_plane_tile(const InvPlaneJob *jobs, int nch)
 					}
 				}
 				const int tail0 = w - (w & 7) - 9;
-				uint16_t *dst = (uint16_t *)job.out + (size_t)orow * job.out_pitch + (size_t)(2 * c) * job.xstride;
+				uint16_t *dst = s_out + ((size_t)(2 * rl + par) * (2 * ITW) + (size_t)(4 * p)) * nch + word;      // pixel 2 (c - c0) of tile row 2 rl + par
 #pragma unroll
 				for (int k = 0; k < 2; k++) {
 					if (c + k >= w) break;
 					const bool tail = c + k >= tail0;
 					uint32_t we = to16(e[k], job.precision, tail), wo = to16(o[k], job.precision, tail);
 					if (job.alpha) { we = expand_alpha16(we); wo = expand_alpha16(wo); }
-					dst[(2 * k) * job.xstride] = (uint16_t)we;
-					dst[(2 * k + 1) * job.xstride] = (uint16_t)wo;
+					dst[(2 * k) * nch] = (uint16_t)we;
+					dst[(2 * k + 1) * nch] = (uint16_t)wo;
 				}
 				continue;
 			}
@@ -676,6 +682,23 @@ __device__ __forceinline__ void inv_plane_tile(const InvPlaneJob *jobs, int nch)
 			int16_t *dst = job.out + (size_t)(2 * r + par) * job.out_pitch + 2 * c;
 			if (c + 1 < w) { uint2 v2; v2.x = o0; v2.y = o1; *(uint2 *)dst = v2; }
 			else *(uint32_t *)dst = o0;
+		}
+	}
+	}
+	if (PACKED) {
+		__syncthreads();
+		const InvPlaneJob &job = s_job;                   // geometry is the same for every component
+		const int w = job.width, h = job.height, c0 = tile.x * ITW, r0 = tile.y * ITH;
+		if (c0 < w && r0 < h) {
+			const int npx = 2 * ((w - c0) < ITW ? (w - c0) : ITW);                       // pixels of the tile's rows inside the frame
+			const int row_dw = npx * nch / 2;                                            // (an even number of pixels: whole dwords)
+			for (int i = tid; i < 2 * ITH * row_dw; i += NTHREADS) {
+				const int orl = i / row_dw, d = i - orl * row_dw;
+				const int orow = 2 * r0 + orl;
+				if (orow >= job.display_height || orow >= 2 * h) continue;
+				const uint32_t v = *(const uint32_t *)(s_out + (size_t)orl * (2 * ITW) * nch + 2 * d);
+				*(uint32_t *)((uint16_t *)frame + (size_t)orow * job.out_pitch + (size_t)(2 * c0) * nch + 2 * d) = v;
+			}
 		}
 	}
 }

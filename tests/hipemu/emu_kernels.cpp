@@ -93,7 +93,7 @@ void emu_inv_packed16(int16_t **bands, int band_pitch, int w, int h, int display
 		job.out = (int16_t *)(out + word_of_channel[c]); job.out_pitch = out_pitch_words; job.xstride = nch; job.precision = precision; job.display_height = display_height;
 		job.alpha = c == alpha_channel;
 	}
-	dim3 grid(((w + ITW - 1) / ITW) * nch, (h + ITH - 1) / ITH, 1);
+	dim3 grid((w + ITW - 1) / ITW, (h + ITH - 1) / ITH, 1);
 	hipemu::launch(grid, dim3(NTHREADS), [&] { k_inv_packed16(jobs.data(), nch); });
 }
 
