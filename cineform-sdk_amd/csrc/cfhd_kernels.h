@@ -591,8 +591,8 @@ __device__ __forceinline__ void inv_plane_tile(const InvPlaneJob *jobs, int nch)
 	__shared__ uint32_t s_low[2][ILROWS][IDW];          // LL, LH
 	__shared__ uint32_t s_high[2][ITH][IDW];            // HL, HH
 	__shared__ uint32_t s_v[2][2][ITH][IDW];            // [row parity][horizontal L/H]
-	// PACKED: the workgroup runs the tile of every component in turn and collects the finished words in LDS, one plane per word of the pixel;
-	// the rows of the tile then leave as whole pixels in coalesced dwords (one workgroup per component wrote 2 bytes of every 6 or 8: a quarter of each line)
+	// PACKED: the workgroup runs the tile of every component in turn and collects the finished words in LDS, pixel by pixel; the rows of the
+	// tile then leave as whole pixels in coalesced dwords (one workgroup per component wrote 2 bytes of every 6 or 8: a quarter of each line)
 	__shared__ uint16_t s_out[PACKED ? 2 * ITH * 2 * ITW * 4 : 1];
 	const int tid = threadIdx.x;
 	const uint16_t *frame = nullptr;                     // PACKED: first word of the packed frame
@@ -652,18 +652,16 @@ __device__ __forceinline__ void inv_plane_tile(const InvPlaneJob *jobs, int nch)
 					}
 				}
 				const int tail0 = w - (w & 7) - 9;
-				// the component's plane of the tile in LDS: four samples (columns 2c .. 2c + 3 of the output row) = one 8-byte store
-				uint32_t wv[4] = { 0u, 0u, 0u, 0u };
+				uint16_t *dst = s_out + ((size_t)(2 * rl + par) * (2 * ITW) + (size_t)(4 * p)) * nch + word;      // pixel 2 (c - c0) of tile row 2 rl + par
 #pragma unroll
 				for (int k = 0; k < 2; k++) {
 					if (c + k >= w) break;
 					const bool tail = c + k >= tail0;
 					uint32_t we = to16(e[k], job.precision, tail), wo = to16(o[k], job.precision, tail);
 					if (job.alpha) { we = expand_alpha16(we); wo = expand_alpha16(wo); }
-					wv[2 * k] = we; wv[2 * k + 1] = wo;
+					dst[(2 * k) * nch] = (uint16_t)we;
+					dst[(2 * k + 1) * nch] = (uint16_t)wo;
 				}
-				uint2 pk; pk.x = wv[0] | (wv[1] << 16); pk.y = wv[2] | (wv[3] << 16);
-				*(uint2 *)(s_out + ((size_t)word * (2 * ITH) + (size_t)(2 * rl + par)) * (2 * ITW) + (size_t)(4 * p)) = pk;
 				continue;
 			}
 			if (job.descale) { even = pk_adds(even, even); odd = pk_adds(odd, odd); }
@@ -698,10 +696,7 @@ __device__ __forceinline__ void inv_plane_tile(const InvPlaneJob *jobs, int nch)
 				const int orl = i / row_dw, d = i - orl * row_dw;
 				const int orow = 2 * r0 + orl;
 				if (orow >= job.display_height || orow >= 2 * h) continue;
-				const int w0 = 2 * d, w1 = 2 * d + 1;          // words of the row segment: word k = component k % nch of pixel k / nch
-				const int p0 = w0 / nch, p1 = w1 / nch;
-				const uint32_t v = (uint32_t)s_out[((size_t)(w0 - p0 * nch) * (2 * ITH) + orl) * (2 * ITW) + p0] |
-				                   ((uint32_t)s_out[((size_t)(w1 - p1 * nch) * (2 * ITH) + orl) * (2 * ITW) + p1] << 16);
+				const uint32_t v = *(const uint32_t *)(s_out + (size_t)orl * (2 * ITW) * nch + 2 * d);
 				*(uint32_t *)((uint16_t *)frame + (size_t)orow * job.out_pitch + (size_t)(2 * c0) * nch + 2 * d) = v;
 			}
 		}
