@@ -96,7 +96,7 @@ struct DxChunkRec { uint32_t start, end, count, flags; };   // start / end: bit 
 // A chunk in front of which the code has no unique alignment (its run-in from every possible offset leaves several candidates for its first
 // code word) is indexed once per candidate: the record holds candidate 0 (the entries are written for it), this the others.
 enum { DX_MAX_ALT = 3 };
-struct DxChunkAlt { uint32_t start[DX_MAX_ALT], end[DX_MAX_ALT], count[DX_MAX_ALT]; };
+struct DxChunkAlt { uint32_t start[DX_MAX_ALT], end[DX_MAX_ALT], count[DX_MAX_ALT]; uint32_t slot; };      // slot: the candidates' entries sit in alt_entries[slot + q] (DX_BAD: not kept)
 struct DxReindex { uint32_t chunk, k, start; int job; };      // a chunk whose entries have to be written again for the start that turned out to be the true one
 struct DxBandSum { uint32_t total; int last_chunk; };        // coefficients the band's code words cover; chunk that holds the band end marker
 
@@ -437,7 +437,8 @@ __global__ void __launch_bounds__(DX_THREADS) k_dec_plan_fill(const DxBandJob *j
 }
 
 __global__ void __launch_bounds__(DX_THREADS) CFHD_DX_INDEX_ATTR k_dec_index(const DxChunkDesc *chunk_desc, const uint32_t *counters, const DecIdxTables *T,
-                                                          uint32_t *entries, DxChunkRec *recs, DxChunkAlt *alts, int speculate, uint32_t *stats)
+                                                          uint32_t *entries, DxChunkRec *recs, DxChunkAlt *alts, int speculate, uint32_t *stats,
+                                                          uint32_t *alt_entries, uint32_t alt_slots, uint32_t *alt_counter)
 {
 	__shared__ uint16_t s_cnt[1 << DX_K], s_sym[1 << DX_K];
 	__shared__ uint32_t s_long[DX_LONG_MAX];
@@ -485,9 +486,19 @@ __global__ void __launch_bounds__(DX_THREADS) CFHD_DX_INDEX_ATTR k_dec_index(con
 				DxChunkAlt a;
 #pragma unroll
 				for (int i = 0; i < DX_MAX_ALT; i++) { a.start[i] = DX_BAD; a.end[i] = DX_BAD; a.count[i] = 0; }
+				// the entries of the other candidates are kept too (a slot each in alt_entries, while there is room): when k_dec_chain finds one
+				// of them to be the true start, k_dec_reindex copies 1 KB instead of indexing the chunk again
+				uint32_t slot0 = DX_BAD;
+				if (alt_entries) {
+					if (wave_lane() == 0) slot0 = atomicAdd(alt_counter, (uint32_t)(n - 1));
+					slot0 = wave_get(slot0, 0);
+					if (slot0 + (uint32_t)(n - 1) > alt_slots) slot0 = DX_BAD;
+				}
+				a.slot = slot0;
 #pragma unroll 1
 				for (int i = 1; i < n; i++) {
-					const DxChunkRec ri = dx_index_staged(d.bytes, c, d.k, cand[i], s_words, s_cnt, s_sym, s_long, nullptr, nullptr);
+					const DxChunkRec ri = dx_index_staged(d.bytes, slot0 == (uint32_t)DX_BAD ? c : slot0 + (uint32_t)(i - 1), d.k, cand[i], s_words, s_cnt, s_sym, s_long,
+					                                      slot0 == (uint32_t)DX_BAD ? nullptr : alt_entries, nullptr);
 #pragma unroll
 					for (int q = 0; q < DX_MAX_ALT; q++) if (q == i - 1) { a.start[q] = ri.start; a.end[q] = ri.end; a.count[q] = ri.count; }
 				}
@@ -623,18 +634,34 @@ __global__ void __launch_bounds__(DX_THREADS) k_dec_repair(const DxBandJob *jobs
 
 // The chunks whose entries were written for a candidate start that turned out not to be the true one: once more from the true start, a wave
 // each (counters[2] = their number; all of them at once, nothing depends on anything any more).
-__global__ void __launch_bounds__(DX_THREADS) k_dec_reindex(const DxBandJob *jobs, const DecIdxTables *T, uint32_t *entries, const DxReindex *reindex_list, const uint32_t *counters, uint32_t *stats)
+__global__ void __launch_bounds__(DX_THREADS) k_dec_reindex(const DxBandJob *jobs, const DecIdxTables *T, uint32_t *entries, const DxReindex *reindex_list, const uint32_t *counters, uint32_t *stats,
+                                                            const DxChunkAlt *alts, const uint32_t *alt_entries)
 {
 	__shared__ uint16_t s_cnt[1 << DX_K], s_sym[1 << DX_K];
 	__shared__ uint32_t s_long[DX_LONG_MAX];
 	__shared__ uint32_t s_words_all[DX_WAVES][DX_STAGE_PHYS];
 	const uint32_t n = counters[2];
 	if ((uint32_t)blockIdx.x * DX_WAVES >= n) return;
-	dx_load_tables(T, s_cnt, s_sym, s_long, true);
-	__syncthreads();
 	const int wave = wave_uniform((int)(threadIdx.x >> 6));
+	bool tables = false;                                  // (workgroup-uniform use below: loaded by the first wave that needs them, for itself)
 	for (uint32_t i = (uint32_t)blockIdx.x * DX_WAVES + (uint32_t)wave; i < n; i += (uint32_t)gridDim.x * DX_WAVES) {
 		const DxReindex x = reindex_list[i];
+		// the usual case: k_dec_index kept the entries of this candidate -- copy them into the chunk's place
+		if (alts && alt_entries) {
+			const DxChunkAlt a = alts[x.chunk];
+			int q = -1;
+#pragma unroll
+			for (int k = 0; k < DX_MAX_ALT; k++) if (q < 0 && a.start[k] == x.start) q = k;
+			if (q >= 0 && a.slot != (uint32_t)DX_BAD) {
+				const uint4 *src = (const uint4 *)(alt_entries + ((size_t)a.slot + (size_t)q) * DX_ENTRY_STRIDE);
+				uint4 *dst = (uint4 *)(entries + (size_t)x.chunk * DX_ENTRY_STRIDE);
+				const int lane = wave_lane();
+				if (lane >= 1) dst[lane] = src[lane];           // lane t's four pieces (lane 0 is the run-in: it has no entries)
+				if (stats && lane == 0) atomicAdd(&stats[3], 1u << 8);
+				continue;
+			}
+		}
+		if (!tables) { dx_load_tables_wave(T, s_cnt, s_sym, s_long); tables = true; CFHD_WAVE_SYNC(); }
 		const DxBandJob job = jobs[x.job];
 		dx_index_chunk(job.bits, job.bytes, x.chunk, x.k, x.start, s_words_all[wave], s_cnt, s_sym, s_long, entries, nullptr, nullptr);
 		if (stats && wave_lane() == 0) atomicAdd(&stats[3], 1u << 8);

@@ -168,9 +168,9 @@ GpuEntropyDecoder::~GpuEntropyDecoder() { release(); delete host_; }
 
 void GpuEntropyDecoder::release()
 {
-	void *dev[] = { d_samples_, d_tables_, d_bandjobs_, d_lowjobs_, d_errors_, d_plan_, d_idx_tables_, d_entries_, d_recs_, d_chunk_base_, d_chunk_job_, d_sums_, d_counters_, d_tile_start_, d_stats_, d_repair_, d_alts_, d_reindex_, d_diffjobs_ };
+	void *dev[] = { d_samples_, d_tables_, d_bandjobs_, d_lowjobs_, d_errors_, d_plan_, d_idx_tables_, d_entries_, d_recs_, d_chunk_base_, d_chunk_job_, d_sums_, d_counters_, d_tile_start_, d_stats_, d_repair_, d_alts_, d_reindex_, d_diffjobs_, d_alt_entries_ };
 	for (void *p : dev) if (p) (void)hipFree(p);
-	d_idx_tables_ = d_entries_ = d_recs_ = d_chunk_base_ = d_chunk_job_ = d_sums_ = d_counters_ = d_tile_start_ = d_stats_ = d_repair_ = d_alts_ = d_reindex_ = d_diffjobs_ = nullptr;
+	d_idx_tables_ = d_entries_ = d_recs_ = d_chunk_base_ = d_chunk_job_ = d_sums_ = d_counters_ = d_tile_start_ = d_stats_ = d_repair_ = d_alts_ = d_reindex_ = d_diffjobs_ = d_alt_entries_ = nullptr;
 	if (h_chunk_job_) (void)hipHostFree(h_chunk_job_);
 	if (h_counters_) (void)hipHostFree(h_counters_);
 	h_chunk_job_ = nullptr; h_counters_ = nullptr;
@@ -225,6 +225,8 @@ int GpuEntropyDecoder::prepare(const FramePlan &plan, int nframes, int16_t *d_co
 		HIPCHK(hipMalloc(&d_repair_, max_bands * 4));
 		HIPCHK(hipMalloc(&d_alts_, (size_t)max_chunks_ * sizeof(dev::DxChunkAlt)));
 		HIPCHK(hipMalloc(&d_reindex_, (size_t)max_chunks_ * sizeof(dev::DxReindex)));
+		alt_slots_ = max_chunks_ / 8 > 64u ? max_chunks_ / 8 : 64u;          // entries of the extra candidates of chunks without a unique alignment (a few per cent of the chunks)
+		HIPCHK(hipMalloc(&d_alt_entries_, (size_t)alt_slots_ * dev::DX_ENTRY_STRIDE * 4));
 		{
 			dev::DecPlan dp0; dec_build_plan(plan, out_kind, &dp0);
 			const dev::DxTilePlan tp0 = dx_tile_plan(plan, dp0, n_, false);
@@ -338,7 +340,7 @@ int GpuEntropyDecoder::launch()
 		const uint32_t nchunks = dx_number_chunks(host_->flat_bands, nb, &cj);
 		if (nchunks > max_chunks_) return -5;
 		memcpy(h_chunk_job_, cj.data(), cj.size() * sizeof(dev::DxChunkDesc));
-		h_counters_[0] = nchunks; h_counters_[1] = 0; h_counters_[2] = 0;
+		h_counters_[0] = nchunks; h_counters_[1] = 0; h_counters_[2] = 0; h_counters_[3] = 0;
 		HIPCHK(hipMemsetAsync(d_errors_, 0, sizeof(int), st));
 		for (int f = 0; f < act; f++)
 			if (host_->host_bytes[f]) HIPCHK(hipMemcpyAsync(d_samples_ + cap_ * f, h_samples_ + cap_ * f, host_->host_bytes[f], hipMemcpyHostToDevice, st));
@@ -403,7 +405,7 @@ int GpuEntropyDecoder::launch_dx(bool device_jobs, int njobs, uint32_t host_chun
 	const dev::DxTilePlan tp = dx_tile_plan(plan_, dp, frames, skip_level1_);
 	const char *spec_env = getenv("CFHD_AMD_DX_SPECULATE");
 	const bool speculate = !(spec_env && atoi(spec_env) == 0);            // 0: every chunk goes through the repair path (tests)
-	if (device_jobs) HIPCHK(hipMemsetAsync((uint32_t *)d_counters_ + 1, 0, 8, st));      // the repair and re-index lists start empty (the host path uploads zeroed counters)
+	if (device_jobs) HIPCHK(hipMemsetAsync((uint32_t *)d_counters_ + 1, 0, 12, st));     // the repair and re-index lists and the alternate-entry slots start empty (the host path uploads zeroed counters)
 	if (device_jobs) {
 		dev::k_dec_plan<<<1, 1024, 0, st>>>(jobs, njobs, max_chunks_, (uint32_t *)d_counters_, d_errors_);
 		dev::k_dec_plan_fill<<<(njobs + dev::DX_WAVES - 1) / dev::DX_WAVES, dev::DX_THREADS, 0, st>>>(jobs, njobs, (dev::DxChunkDesc *)d_chunk_job_, (const uint32_t *)d_counters_);
@@ -415,14 +417,16 @@ int GpuEntropyDecoder::launch_dx(bool device_jobs, int njobs, uint32_t host_chun
 	if ((uint32_t)g3 * dev::DX_TILE_WAVES > tp.total) g3 = (int)((tp.total + dev::DX_TILE_WAVES - 1) / dev::DX_TILE_WAVES);
 	if (g1 < 1) g1 = 1;
 	if (g3 < 1) g3 = 1;
-	dev::k_dec_index<<<g1, dev::DX_THREADS, 0, st>>>((const dev::DxChunkDesc *)d_chunk_job_, (const uint32_t *)d_counters_, T, (uint32_t *)d_entries_, (dev::DxChunkRec *)d_recs_, (dev::DxChunkAlt *)d_alts_, speculate ? 1 : 0, (uint32_t *)d_stats_);
+	dev::k_dec_index<<<g1, dev::DX_THREADS, 0, st>>>((const dev::DxChunkDesc *)d_chunk_job_, (const uint32_t *)d_counters_, T, (uint32_t *)d_entries_, (dev::DxChunkRec *)d_recs_, (dev::DxChunkAlt *)d_alts_, speculate ? 1 : 0, (uint32_t *)d_stats_,
+	                                                 (uint32_t *)d_alt_entries_, alt_slots_, (uint32_t *)d_counters_ + 3);
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[5], st));
 	dev::k_dec_chain<<<(njobs + dev::DX_WAVES - 1) / dev::DX_WAVES, dev::DX_THREADS, 0, st>>>(jobs, njobs, (const dev::DxChunkRec *)d_recs_, (const dev::DxChunkAlt *)d_alts_, (uint32_t *)d_chunk_base_,
 	                                                                                            (dev::DxBandSum *)d_sums_, d_errors_, (uint32_t *)d_repair_, (dev::DxReindex *)d_reindex_, (uint32_t *)d_counters_);
 	const int small_grid = njobs < 256 ? (njobs + dev::DX_WAVES - 1) / dev::DX_WAVES : 64;
 	dev::k_dec_repair<<<small_grid, dev::DX_THREADS, 0, st>>>(jobs, T, (uint32_t *)d_entries_, (dev::DxChunkRec *)d_recs_, (const dev::DxChunkAlt *)d_alts_, (uint32_t *)d_chunk_base_, (dev::DxBandSum *)d_sums_,
 	                                                         d_errors_, (const uint32_t *)d_repair_, (dev::DxReindex *)d_reindex_, (uint32_t *)d_counters_, (uint32_t *)d_stats_);
-	dev::k_dec_reindex<<<g1, dev::DX_THREADS, 0, st>>>(jobs, T, (uint32_t *)d_entries_, (const dev::DxReindex *)d_reindex_, (const uint32_t *)d_counters_, (uint32_t *)d_stats_);
+	dev::k_dec_reindex<<<g1, dev::DX_THREADS, 0, st>>>(jobs, T, (uint32_t *)d_entries_, (const dev::DxReindex *)d_reindex_, (const uint32_t *)d_counters_, (uint32_t *)d_stats_,
+	                                                   (const dev::DxChunkAlt *)d_alts_, (const uint32_t *)d_alt_entries_);
 	dev::k_dec_tile_index<<<(tp.total + dev::DX_THREADS - 1) / dev::DX_THREADS, dev::DX_THREADS, 0, st>>>(jobs, tp, (const uint32_t *)d_entries_, (const uint32_t *)d_chunk_base_, (const dev::DxBandSum *)d_sums_,
 	                                                                                                  (uint32_t *)d_tile_start_);
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[6], st));
