@@ -163,7 +163,8 @@ def test_invalid_arguments_and_unsupported_formats():
     L = product()
     assert L.CFHD_OpenEncoder(None, None) == 1
     enc = ctypes.c_void_p(); L.CFHD_OpenEncoder(ctypes.byref(enc), None)
-    assert L.CFHD_PrepareToEncode(enc, 1920, 1080, fourcc("v210"), 0, 0, 4) == 3       # CFHD_ERROR_BADFORMAT
+    assert L.CFHD_PrepareToEncode(enc, 1920, 1080, fourcc("r210"), 1, 0, 4) == 3       # CFHD_ERROR_BADFORMAT (10-bit RGB input is not built)
+    assert L.CFHD_PrepareToEncode(enc, 1920, 1080, fourcc("v210"), 1, 0, 4) == 3       # v210 is 4:2:2 only
     assert L.CFHD_EncodeSample(enc, None, 0) == 1
     L.CFHD_CloseEncoder(enc)
     dec = ctypes.c_void_p(); L.CFHD_OpenDecoder(ctypes.byref(dec), None)
