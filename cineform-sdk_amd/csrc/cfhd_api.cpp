@@ -310,6 +310,7 @@ struct EncodeServices {
 	{
 		std::lock_guard<std::mutex> lk(m);
 		for (EncodeService *s : list) if (s->key == key) return s;
+		if (list.size() >= 8) return nullptr;
 		EncodeService *s = new EncodeService; s->key = key; list.push_back(s);
 		return s;
 	}
@@ -482,6 +483,7 @@ struct DecodeServices {
 	{
 		std::lock_guard<std::mutex> lk(m);
 		for (DecodeService *s : list) if (s->key == key) return s;
+		if (list.size() >= 8) return nullptr;          // (a service holds two batches in HBM and pinned memory for good: a process that decodes more geometries than this at once does without)
 		DecodeService *s = new DecodeService; s->key = key; list.push_back(s);
 		return s;
 	}
@@ -882,6 +884,7 @@ CFHD_Error CFHD_PrepareToDecode(CFHD_DecoderRef ref, int, int, CFHD_PixelFormat 
 	plan_from_sample(d->header, kind, &d->plan, &ok);
 	if (!ok) return ERR_BADSAMPLE;
 	d->out_format = fmt; d->out_kind = kind; d->prepared = true; d->batch_ready = false; d->half = half;
+	d->service = nullptr;                                 // (looked up again for the new geometry by the next concurrent decode)
 	if (aw) *aw = half ? d->header.width / 2 : d->header.width;
 	if (ah) *ah = half ? d->header.display_height / 2 : d->header.display_height;
 	if (af) *af = fmt;
@@ -957,6 +960,7 @@ CFHD_Error CFHD_DecodeSample(CFHD_DecoderRef ref, void *sample, size_t size, voi
 			d->service = decode_services().find(key); d->service_interlaced = interlaced;
 		}
 		DecodeService *svc = d->service;
+		if (!svc) return decode_on_handle(d, ps, s, size, out, pitch, interlaced);
 		struct InFlight { std::atomic<int> &n; int before; InFlight(std::atomic<int> &c) : n(c), before(c.fetch_add(1)) {} ~InFlight() { n.fetch_sub(1); } } mark(svc->inflight);
 		if (mark.before > 0) {
 			bool usable;
