@@ -773,26 +773,29 @@ def test_large_user_metadata_takes_the_host_writer():
 
 
 def test_concurrent_decoders_share_launches_and_stay_exact():
-    """Eight threads, each with its own decoder handle, decode different samples at the same time: calls that overlap are gathered into
-    multi-frame launches (cfhd_api.cpp DecodeService).  Every frame must come out as if decoded alone -- inside the dither interval of the
-    exact reconstruction of *its* sample -- and a damaged sample must fail on its own handle only (BADSAMPLE, zero-filled output) while the
-    calls gathered with it succeed."""
+    """Eight threads, each with its own decoder handle, decode different samples at the same time -- two geometries, four threads each: calls
+    that overlap are gathered into multi-frame launches per geometry (cfhd_api.cpp DecodeService).  Every frame must come out as if decoded
+    alone -- inside the dither interval of the exact reconstruction of *its* sample -- and a damaged sample must fail on its own handle only
+    (BADSAMPLE, zero-filled output) while the calls gathered with it succeed."""
     import threading
-    w, h, nthreads, rounds = 1280, 720, 8, 12
-    frames = [synth_yuy2(w, h, 40 + k)[0] for k in range(4)]
-    samples = ref_encode_frames(frames, w * 2, w, h)
-    plan = Plan(w, h)
-    bounds = []
-    for smp in samples:
-        deq = host_decode_pyramid(smp, plan)
-        bounds.append((oracle_inverse_yuv422(plan, deq, 0)[:h], oracle_inverse_yuv422(plan, deq, 1)[:h]))
-    damaged = bytearray(samples[0]); damaged[len(damaged) // 2: len(damaged) // 2 + 64] = bytes(64)
-    damaged = bytes(damaged)
+    nthreads, rounds = 8, 12
+    geoms = []
+    for (w, h) in ((1280, 720), (640, 360)):
+        frames = [synth_yuy2(w, h, 40 + k)[0] for k in range(4)]
+        samples = ref_encode_frames(frames, w * 2, w, h)
+        plan = Plan(w, h)
+        bounds = []
+        for smp in samples:
+            deq = host_decode_pyramid(smp, plan)
+            bounds.append((oracle_inverse_yuv422(plan, deq, 0)[:h], oracle_inverse_yuv422(plan, deq, 1)[:h]))
+        damaged = bytearray(samples[0]); damaged[len(damaged) // 2: len(damaged) // 2 + 64] = bytes(64)
+        geoms.append((w, h, samples, bounds, bytes(damaged)))
     L = product()
     errors = []
 
     def worker(t):
         try:
+            w, h, samples, bounds, damaged = geoms[t % 2]
             dec = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
             aw = ctypes.c_int(); ah = ctypes.c_int(); af = ctypes.c_uint32()
             first = ctypes.create_string_buffer(samples[0], len(samples[0]))
