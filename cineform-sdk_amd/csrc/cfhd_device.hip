@@ -662,13 +662,25 @@ bool DecodeBatch::strip_inverse() const
 	return true;
 }
 
+// k_inv_frame_yuv422_quad: four band columns per thread with 8-byte loads and 16-byte stores (CFHD_AMD_INVERSE=tile: the one-column kernel)
+bool DecodeBatch::frame_inverse_quads() const
+{
+	static const int forced = shape_override("CFHD_AMD_INVERSE");
+	const BandDesc &b = plan_.ch[0].band[0][0];
+	if (forced == 1 || b.width % 4 || b.width < 8) return false;
+	for (int c = 0; c < 3; c++) if (plan_.ch[c].band[0][0].pitch % 4) return false;
+	DecJobs j = dec_jobs_at(h_jobs_, n_, plan_.num_channels);
+	for (int i = 0; i < n_; i++) if (((uintptr_t)j.yuv[i].out & 15) || (j.yuv[i].out_pitch & 15)) return false;
+	return true;
+}
+
 const char *DecodeBatch::level_kernel(int level) const
 {
 	const int act = active_ > 0 && active_ < n_ ? active_ : n_;
 	if (level > 0) return planes_as_strips(plan_, level, act) ? "k_inv_plane_strip" : "k_inv_plane";
 	if (half_) return is_packed16(out_kind_) ? "k_half_packed16" : "k_half_yuv422";
 	if (is_packed16(out_kind_)) return "k_inv_packed16";
-	if (interlaced_) return "k_inv_frame_yuv422";
+	if (interlaced_) return frame_inverse_quads() ? "k_inv_frame_yuv422_quad" : "k_inv_frame_yuv422";
 	return strip_inverse() ? "k_inv_yuv422_strip" : "k_inv_yuv422";
 }
 
@@ -712,7 +724,8 @@ int DecodeBatch::launch_inverse(uint32_t dither_seed)
 		dev::k_inv_packed16<<<grid, dev::NTHREADS, 0, st>>>(j.l1, nch);
 	} else if (interlaced_) {                           // (half resolution was served above: the level-1 lowpass planes need no inverse frame transform)
 		const BandDesc &b = plan_.ch[0].band[0][0];
-		dev::k_inv_frame_yuv422<<<dim3((b.width / 2 + dev::NTHREADS - 1) / dev::NTHREADS, b.height, act), dev::NTHREADS, 0, st>>>(j.yuv, dither_seed);
+		if (frame_inverse_quads()) dev::k_inv_frame_yuv422_quad<<<dim3((b.width / 4 + dev::NTHREADS - 1) / dev::NTHREADS, b.height, act), dev::NTHREADS, 0, st>>>(j.yuv, dither_seed);
+		else dev::k_inv_frame_yuv422<<<dim3((b.width / 2 + dev::NTHREADS - 1) / dev::NTHREADS, b.height, act), dev::NTHREADS, 0, st>>>(j.yuv, dither_seed);
 	} else if (strip_inverse()) {
 		const BandDesc &b = plan_.ch[0].band[0][0];
 		const int nseg = (b.width / dev::SBLK + dev::SSEG - 1) / dev::SSEG;

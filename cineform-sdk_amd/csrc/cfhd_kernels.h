@@ -1639,6 +1639,107 @@ __global__ void __launch_bounds__(NTHREADS) k_inv_frame_yuv422(const InvYuvJob *
 	}
 }
 
+// The same, four luma band columns (eight pixels of both picture rows) per thread: the bands are read with 8-byte loads, the columns next
+// to a thread's four come from its neighbours' registers (the first and last lane of a wave fetch theirs), and each picture row leaves as one
+// 16-byte store per thread.  Same bytes as k_inv_frame_yuv422 (same dither bit per sample); needs the luma band width to be a multiple of 4
+// and 8-byte aligned band rows, which every frame the codec accepts has.
+struct Quad16 { int v[4]; };
+__device__ __forceinline__ Quad16 quad_load(const int16_t *p) { const uint2 q = *(const uint2 *)p; Quad16 r; r.v[0] = lo16(q.x); r.v[1] = hi16(q.x); r.v[2] = lo16(q.y); r.v[3] = hi16(q.y); return r; }
+__device__ __forceinline__ Quad16 pair_load(const int16_t *p) { const uint32_t q = *(const uint32_t *)p; Quad16 r; r.v[0] = lo16(q); r.v[1] = hi16(q); r.v[2] = 0; r.v[3] = 0; return r; }
+// horizontal synthesis of n (4 or 2) adjacent columns starting at band column c: out[2k], out[2k + 1] = even, odd sample of column c + k
+template <int N>
+__device__ __forceinline__ void frame_synth_run(const Quad16 &lo, const Quad16 &hi, int left, int right, int c, int w, int *out)
+{
+#pragma unroll
+	for (int k = 0; k < N; k++) {
+		const int col = c + k;
+		const int lm1 = k ? lo.v[k - 1] : left, lp1 = k + 1 < N ? lo.v[k + 1] : right;
+		int e, o;
+		if (col == 0) inv_horiz(0, lo.v[k], lp1, k + 2 < N ? lo.v[k + 2] : right, hi.v[k], 0, e, o);      // (k + 2 < N: always, the first column is a thread's first)
+		else if (col == w - 1) inv_horiz(lm1, lo.v[k], 0, k >= 2 ? lo.v[k - 2] : left, hi.v[k], 2, e, o);
+		else inv_horiz(lm1, lo.v[k], lp1, 0, hi.v[k], 1, e, o);
+		out[2 * k] = sat16(e >> 1); out[2 * k + 1] = sat16(o >> 1);
+	}
+}
+__global__ void __launch_bounds__(NTHREADS) k_inv_frame_yuv422_quad(const InvYuvJob *jobs, uint32_t launch_seed)
+{
+	const InvYuvJob &job = jobs[blockIdx.z];
+	const int w = job.width, cw = w >> 1;
+	const int t = (int)(blockIdx.x * NTHREADS + threadIdx.x), r = blockIdx.y;
+	const int c = 4 * t, cc = 2 * t;                          // first luma / chroma band column of this thread
+	const bool have = c < w && r < job.height;
+	const int lane = (int)(threadIdx.x & 63u);
+	const uint32_t seed = job.dither_seed ^ launch_seed;
+	const int sh = job.shift;
+	int tl[16], th[16];                                       // temporal low / high samples: 8 luma, 4 V, 4 U
+	// one (lowpass, highpass) band pair at a time: luma (LL, LH) -> temporal low, (HL, HH) -> temporal high, then the same for V and U
+#pragma unroll
+	for (int pair = 0; pair < 2; pair++) {
+		int *dst = pair ? th : tl;
+		{
+			const size_t o = (size_t)r * job.band_pitch[0];
+			const int16_t *lo = job.band[0][2 * pair] + o, *hi = job.band[0][2 * pair + 1] + o;
+			Quad16 L = { { 0, 0, 0, 0 } }, H = { { 0, 0, 0, 0 } };
+			if (have) { L = quad_load(lo + c); H = quad_load(hi + c); }
+			int left = __shfl_up(L.v[3], 1u), right = __shfl_down(L.v[0], 1u);
+			if (have && lane == 0 && c > 0) left = lo[c - 1];
+			if (have && (lane == 63 || c + 4 >= w) && c + 4 < w) right = lo[c + 4];
+			if (have) frame_synth_run<4>(L, H, left, right, c, w, dst);
+		}
+#pragma unroll
+		for (int x = 0; x < 2; x++) {
+			const size_t o = (size_t)r * job.band_pitch[1 + x];
+			const int16_t *lo = job.band[1 + x][2 * pair] + o, *hi = job.band[1 + x][2 * pair + 1] + o;
+			Quad16 L = { { 0, 0, 0, 0 } }, H = { { 0, 0, 0, 0 } };
+			if (have) { L = pair_load(lo + cc); H = pair_load(hi + cc); }
+			int left = __shfl_up(L.v[1], 1u), right = __shfl_down(L.v[0], 1u);
+			if (have && lane == 0 && cc > 0) left = lo[cc - 1];
+			if (have && (lane == 63 || cc + 2 >= cw) && cc + 2 < cw) right = lo[cc + 2];
+			if (have) {
+				// two columns: the far taps of the first / last column of the band lie outside a pair
+				int out4[4];
+#pragma unroll
+				for (int k = 0; k < 2; k++) {
+					const int col = cc + k;
+					const int lm1 = k ? L.v[0] : left, lp1 = k ? right : L.v[1];
+					int e, od;
+					if (col == 0) inv_horiz(0, L.v[0], L.v[1], right, H.v[0], 0, e, od);
+					else if (col == cw - 1) inv_horiz(L.v[0], L.v[1], 0, left, H.v[1], 2, e, od);
+					else inv_horiz(lm1, L.v[k], lp1, 0, H.v[k], 1, e, od);
+					out4[2 * k] = sat16(e >> 1); out4[2 * k + 1] = sat16(od >> 1);
+				}
+#pragma unroll
+				for (int k = 0; k < 4; k++) dst[8 + 4 * x + k] = out4[k];
+			}
+		}
+	}
+	if (!have) return;
+#pragma unroll
+	for (int par = 0; par < 2; par++) {
+		const int orow = 2 * r + par;
+		if (orow >= job.display_height) continue;
+		uint32_t words[4];
+#pragma unroll
+		for (int half = 0; half < 2; half++) {                 // chroma column cc + half: the bits the one-column kernel uses for it
+			const int ccol = cc + half;
+			const uint32_t dz = sh >= 2 ? dither_word(seed, orow, ccol >> 2) >> (8 * (ccol & 3)) : 0u;
+			uint32_t b[8];
+#pragma unroll
+			for (int i = 0; i < 8; i++) {
+				// sample order of the one-column kernel: four luma (columns 2 ccol, 2 ccol + 1: even, odd each), two V, two U
+				const int idx = i < 4 ? 4 * half + i : (i < 6 ? 8 + 2 * half + (i - 4) : 12 + 2 * half + (i - 6));
+				const int v = par ? adds16(tl[idx], th[idx]) : subs16(tl[idx], th[idx]);
+				b[i] = to8(v, sh, (int)((dz >> i) & 1u));
+			}
+			const uint32_t y0 = b[0], y1 = b[1], y2 = b[2], y3 = b[3], v0 = b[4], v1 = b[5], u0 = b[6], u1 = b[7];
+			if (job.uyvy) { words[2 * half] = u0 | (y0 << 8) | (v0 << 16) | (y1 << 24); words[2 * half + 1] = u1 | (y2 << 8) | (v1 << 16) | (y3 << 24); }
+			else { words[2 * half] = y0 | (u0 << 8) | (y1 << 16) | (v0 << 24); words[2 * half + 1] = y2 | (u1 << 8) | (y3 << 16) | (v1 << 24); }
+		}
+		uint4 o4; o4.x = words[0]; o4.y = words[1]; o4.z = words[2]; o4.w = words[3];
+		*(uint4 *)(job.out + (size_t)orow * job.out_pitch + 16 * (size_t)t) = o4;
+	}
+}
+
 // =============================================================================================
 // Bayer input (ConvertBYR4ToFrame16s, frame.c:4993, curve branch :5219-5393): every 2x2 quad of the mosaic gives one sample of the
 // four component planes: the encode curve LUT is applied to each photosite (>> 2 to the LUT's 14 bits), then g = (g1+g2)>>1,

@@ -179,6 +179,19 @@ void emu_inv_frame_yuv422(int16_t **bands /*[3][4]*/, const int *band_pitch, int
 	hipemu::launch(dim3((w / 2 + NTHREADS - 1) / NTHREADS, h, 1), dim3(NTHREADS), [&] { k_inv_frame_yuv422(&job, 0u); });
 }
 
+// the same with four band columns per thread (luma band width a multiple of 4)
+int emu_inv_frame_yuv422_quad(int16_t **bands /*[3][4]*/, const int *band_pitch, int w, int h, int display_height, int uyvy, int shift,
+                              unsigned dither_seed, uint8_t *out, int out_pitch)
+{
+	if (w % 4) return -1;
+	InvYuvJob job;
+	for (int c = 0; c < 3; c++) { job.band_pitch[c] = band_pitch[c]; for (int b = 0; b < 4; b++) job.band[c][b] = bands[c * 4 + b]; }
+	job.width = w; job.height = h; job.display_height = display_height; job.uyvy = uyvy; job.shift = shift;
+	job.dither_seed = dither_seed; job.out = out; job.out_pitch = out_pitch;
+	hipemu::launch(dim3((w / 4 + NTHREADS - 1) / NTHREADS, h, 1), dim3(NTHREADS), [&] { k_inv_frame_yuv422_quad(&job, 0u); });
+	return 0;
+}
+
 // the register-strip variant of the same level (luma band width a multiple of 16; segments of 124 blocks of 8 columns)
 int emu_inv_yuv422_strip(int16_t **bands /*[3][4]*/, const int *band_pitch, int w, int h, int display_height, int uyvy, int shift,
                          unsigned dither_seed, uint8_t *out, int out_pitch)

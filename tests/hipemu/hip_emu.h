@@ -102,6 +102,7 @@ inline void __syncthreads()
 // wave-level intrinsics (wave64).  Lanes that already returned do not take part; their slot keeps its last value.
 template <typename T> inline T __shfl(T v, int lane) { return hipemu::exchange(v, lane); }
 template <typename T> inline T __shfl_up(T v, unsigned d) { const int l = (int)hipemu::lane_id(); return hipemu::exchange(v, l - (int)d >= 0 ? l - (int)d : -1); }
+template <typename T> inline T __shfl_down(T v, unsigned d) { const int l = (int)hipemu::lane_id(); return hipemu::exchange(v, l + (int)d < (int)hipemu::kWave ? l + (int)d : -1); }
 template <typename T> inline T __shfl_xor(T v, int m) { return hipemu::exchange(v, (int)hipemu::lane_id() ^ m); }
 inline unsigned long long __ballot(int pred)
 {

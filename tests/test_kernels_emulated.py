@@ -663,7 +663,7 @@ def test_dx_decoder_emulated_interlaced_samples(w, h, seed, peaks):
             assert np.array_equal(plan.view(got, c, lv, b)[:, :cols], plan.view(want, c, lv, b)[:, :cols]), (mode, c, lv, b)
 
 
-@pytest.mark.parametrize("w,h,dh", [(32, 8, 16), (96, 20, 40), (360, 30, 58), (128, 17, 34), (132, 33, 66), (260, 19, 37), (960, 6, 12)])
+@pytest.mark.parametrize("w,h,dh", [(32, 8, 16), (96, 20, 40), (360, 30, 58), (128, 17, 34), (132, 33, 66), (260, 19, 37), (960, 6, 12), (1032, 4, 8), (8, 4, 8)])
 @pytest.mark.parametrize("uyvy", [0, 1])
 def test_inv_frame_yuv422(w, h, dh, uyvy):
     """Emulated inverse frame transform vs the oracle (itself pinned against the reference decoder): every output byte must equal the
@@ -687,6 +687,10 @@ def test_inv_frame_yuv422(w, h, dh, uyvy):
     e = np.full((2 * h, 4 * w + 16), 7, np.uint8)
     emu().emu_inv_frame_yuv422(ptrs, iarr(pitches), w, h, dh, uyvy, 2, 1234, p8(e), 4 * w + 16)
     assert np.all(e[:, 4 * w:] == 7) and np.all(e[dh:] == 7)
+    # four band columns per thread (8-byte loads, neighbours from the adjacent lanes, 16-byte stores): byte for byte the same picture
+    q = np.full((2 * h, 4 * w + 16), 7, np.uint8)
+    assert emu().emu_inv_frame_yuv422_quad(ptrs, iarr(pitches), w, h, dh, uyvy, 2, 1234, p8(q), 4 * w + 16) == 0
+    assert np.array_equal(q, e)
     e = e[:dh, :4 * w]
     assert np.all((e == outs[0]) | (e == outs[1]))
     assert np.any(e != outs[0]) and np.any(e != outs[1])
