@@ -875,7 +875,7 @@ __global__ void __launch_bounds__(DX_TILE_THREADS) k_dec_tiles(const DxBandJob *
 // values from the peak table in raster order (Codec/decoder.c:19809 DecodeBandFSM16sNoGapWithPeaks), then every row becomes its running sum
 // (decoder.c:20822).  One workgroup per band walks down the rows: every thread holds a run of consecutive columns, block-wide prefix sums give
 // the number of peaks in front of it and the sum of the columns in front of it.
-enum { DXU_THREADS = 256, DXU_MAX = 16 };               // columns per thread: rows of up to 4096 coefficients
+enum { DXU_THREADS = 256, DXU_MAX = 16 /* columns per thread: rows of up to 4096 coefficients */, DXU_SPLIT = 32 /* workgroups per band (grid y) */ };
 __global__ void __launch_bounds__(DXU_THREADS) k_dec_undiff(const DecDiffJob *jobs, int *errors)
 {
 	__shared__ uint32_t s_w[2][DXU_THREADS / 64];
@@ -886,7 +886,12 @@ __global__ void __launch_bounds__(DXU_THREADS) k_dec_undiff(const DecDiffJob *jo
 	if (per > DXU_MAX) { if (t == 0) atomic_or_u32((uint32_t *)errors, (uint32_t)DX_ERR_SPACE); return; }
 	const int c0 = t * per, c1 = c0 + per < job.width ? c0 + per : job.width;
 	uint32_t peaks_seen = 0;
-	for (int y = 0; y < job.height; y++) {
+	// the rows are independent unless the band has a peak table (whose values are consumed in raster order: rare, one workgroup walks the band);
+	// otherwise the gridDim.y workgroups of the band share its rows
+	if (job.level && blockIdx.y) return;
+	const int rows_per = (job.height + (int)gridDim.y - 1) / (int)gridDim.y;
+	const int y_first = job.level ? 0 : (int)blockIdx.y * rows_per, y_last = job.level ? job.height : (y_first + rows_per < job.height ? y_first + rows_per : job.height);
+	for (int y = y_first; y < y_last; y++) {
 		int16_t *line = job.band + (size_t)y * job.pitch;
 		int v[DXU_MAX];
 		uint32_t marks = 0;

@@ -431,7 +431,7 @@ int GpuEntropyDecoder::launch_dx(bool device_jobs, int njobs, uint32_t host_chun
 	                                                                                                  (uint32_t *)d_tile_start_);
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[6], st));
 	dev::k_dec_tiles<<<g3, dev::DX_TILE_THREADS, 0, st>>>(jobs, tp, T, (const uint32_t *)d_entries_, (const uint32_t *)d_chunk_base_, (const dev::DxBandSum *)d_sums_, (const uint32_t *)d_tile_start_);
-	if (interlaced_) dev::k_dec_undiff<<<frames * plan_.num_channels, dev::DXU_THREADS, 0, st>>>((const dev::DecDiffJob *)d_diffjobs_, d_errors_);
+	if (interlaced_) dev::k_dec_undiff<<<dim3((unsigned)(frames * plan_.num_channels), dev::DXU_SPLIT), dev::DXU_THREADS, 0, st>>>((const dev::DecDiffJob *)d_diffjobs_, d_errors_);
 	HIPCHK(hipGetLastError());
 	return 0;
 }

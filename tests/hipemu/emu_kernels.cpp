@@ -418,7 +418,7 @@ extern "C" int emu_entropy_decode_dx(const uint8_t *sample, size_t size, int pix
 	std::vector<uint32_t> tile_start(tp.total + 1, 0xdeadbeefu);
 	hipemu::launch(dim3((tp.total + dev::DX_THREADS - 1) / dev::DX_THREADS), dim3(dev::DX_THREADS), [&] { dev::k_dec_tile_index(jobs.data(), tp, entries.data(), chunk_base.data(), sums.data(), tile_start.data()); });
 	hipemu::launch(dim3((unsigned)grid), dim3(dev::DX_TILE_THREADS), [&] { dev::k_dec_tiles(jobs.data(), tp, &tables, entries.data(), chunk_base.data(), sums.data(), tile_start.data()); });
-	hipemu::launch(dim3((unsigned)diffs.size()), dim3(dev::DXU_THREADS), [&] { dev::k_dec_undiff(diffs.data(), &errors); });
+	hipemu::launch(dim3((unsigned)diffs.size(), 5), dim3(dev::DXU_THREADS), [&] { dev::k_dec_undiff(diffs.data(), &errors); });
 	hipemu::launch(dim3(4, (unsigned)lows.size()), dim3(256), [&] { dev::k_dec_lowpass(lows.data()); });
 	if (errors) return -10 - errors;
 	memcpy(coeffs, pyr.data() + (size_t)(nframes - 1) * plan.coeff_elems, (size_t)plan.coeff_elems * 2);
