@@ -24,8 +24,14 @@ namespace dev {
 #ifndef CFHD_ENT_FILL
 #define CFHD_ENT_FILL 16384      // (the emulated tests build with a few words, so that trailers span many pieces)
 #endif
-enum { ENT_THREADS = 256, ENT_LANES = 64, ENT_WAVES = ENT_THREADS / ENT_LANES, ENT_PER_THREAD = 16, ENT_SEG = ENT_LANES * ENT_PER_THREAD,
-       ENT_LDS_WORDS = 256, ENT_TOK_CAP = 256, ENT_MAX_HOLES = 40,
+#ifndef CFHD_ENT_PER_THREAD
+#define CFHD_ENT_PER_THREAD 16
+#endif
+#ifndef CFHD_ENT_TOK_CAP
+#define CFHD_ENT_TOK_CAP 256
+#endif
+enum { ENT_THREADS = 256, ENT_LANES = 64, ENT_WAVES = ENT_THREADS / ENT_LANES, ENT_PER_THREAD = CFHD_ENT_PER_THREAD, ENT_SEG = ENT_LANES * ENT_PER_THREAD,
+       ENT_LDS_WORDS = 256, ENT_TOK_CAP = CFHD_ENT_TOK_CAP, ENT_MAX_HOLES = 40,
        ENT_FILL = CFHD_ENT_FILL /* bytes of a sample one workgroup of k_ent_layout fills at a time */ };
 // ENT_LDS_WORDS: 32-bit words of the per-wave bit window in LDS (a segment of ordinary pictures codes into 10-40 words; beyond the window
 // the code words go to the payload with global atomics).  ENT_TOK_CAP: tokens (nonzero coefficients) of a segment held in LDS at a
