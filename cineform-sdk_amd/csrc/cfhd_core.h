@@ -29,6 +29,9 @@ enum PixelKind : int {
 	PIX_BYR4,      // 16-bit Bayer              (COLOR_FORMAT_BYR4 = 104)
 	PIX_YU64,      // 16-bit 4:2:2  Y0 C1 Y1 C2  (COLOR_FORMAT_YU64 = 12; encoder input only)
 	PIX_V210,      // 10-bit 4:2:2, six pixels in four 32-bit words (COLOR_FORMAT_V210 = 10; encoder input only)
+	PIX_RG24,      // 8-bit B, G, R bytes, bottom row first (COLOR_FORMAT_RGB24 = 7; encoder input only, to RGB 4:4:4)
+	PIX_BGRA,      // 8-bit B, G, R, A bytes, bottom row first ('BGRA', format code 32; encoder input only, to RGB 4:4:4: alpha dropped)
+	PIX_BGRa,      // the same, top row first ('BGRa', format code 9)
 };
 
 // ENCODED_FORMAT_* values as written into the bitstream (Codec/codec.h)

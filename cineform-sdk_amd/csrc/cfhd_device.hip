@@ -86,8 +86,10 @@ bool is_packed16(int pixel_kind) { return pixel_kind == PIX_RG48 || pixel_kind =
 // encoder input made of 16-bit words that k_fwd_packed16 picks apart (per channel: first word, words from sample to sample, right shift).
 // YU64 (Codec/frame.c:1556 ConvertYU64ToFrame16s + convert.c:3345, :14375): words Y0 C1 Y1 C2, every word >> 6 to 10 bits, channel 1 = C1, 2 = C2.
 // v210 (frame.c:1431 ConvertV210ToFrame16s): three 10-bit samples per 32-bit word, FwdPlaneJob::layout tells the loader which component to pick.
-static bool enc_packed16(int pixel_kind) { return is_packed16(pixel_kind) || pixel_kind == PIX_YU64 || pixel_kind == PIX_V210; }
-static int enc_word_of_channel(int pixel_kind, int c) { return pixel_kind == PIX_V210 ? 0 : (pixel_kind == PIX_YU64 ? (c == 0 ? 0 : (c == 1 ? 1 : 3)) : packed_word_of_channel(pixel_kind, c)); }
+// RG24 (frame.c:6173 ConvertRGBtoRGB48): bytes B, G, R, bottom row first, byte << 4; planes G, R, B.
+static bool enc_packed16(int pixel_kind) { return is_packed16(pixel_kind) || pixel_kind == PIX_YU64 || pixel_kind == PIX_V210 || pixel_kind == PIX_RG24 || pixel_kind == PIX_BGRA || pixel_kind == PIX_BGRa; }
+static bool enc_bytes8(int pixel_kind) { return pixel_kind == PIX_RG24 || pixel_kind == PIX_BGRA || pixel_kind == PIX_BGRa; }
+static int enc_word_of_channel(int pixel_kind, int c) { return pixel_kind == PIX_V210 || enc_bytes8(pixel_kind) ? 0 : (pixel_kind == PIX_YU64 ? (c == 0 ? 0 : (c == 1 ? 1 : 3)) : packed_word_of_channel(pixel_kind, c)); }
 static int enc_stride_of_channel(int pixel_kind, int c, int nch) { return pixel_kind == PIX_YU64 ? (c == 0 ? 2 : 4) : nch; }
 } // namespace
 
@@ -157,6 +159,8 @@ int packed_frame_pitch(int pixel_kind, int width)
 	case PIX_B64A: return width * 8;
 	case PIX_BYR4: return width * 2;
 	case PIX_YU64: return width * 4;
+	case PIX_RG24: return width * 3;
+	case PIX_BGRA: case PIX_BGRa: return width * 4;
 	case PIX_V210: return (width + 47) / 48 * 128;      // six pixels in 16 bytes, rows padded to 48 pixels (Example/utils.cpp:84-90)
 	default: return 0;
 	}
@@ -274,6 +278,7 @@ void EncodeBatch::fill_jobs()
 				p.xstride = enc_stride_of_channel(plan.pixel_kind, c, nch); p.shift = 16 - plan.precision; p.display_height = plan.display_height;
 				p.compand = plan.pixel_kind == PIX_B64A && c == 3;
 				p.layout = plan.pixel_kind == PIX_V210 ? c + 1 : 0; p.tail_from = (plan.width - plan.width % 48) / 2;
+				if (enc_bytes8(plan.pixel_kind)) { p.layout = plan.pixel_kind == PIX_BGRa ? 5 : 4; p.in_pitch = in_pitch_; p.xstride = plan.pixel_kind == PIX_RG24 ? 3 : 4; p.tail_from = c == 0 ? 1 : (c == 1 ? 2 : 0); }     // planes G, R, B of bytes B, G, R(, A)
 				p.out_pitch = plan.ch[c].band[0][0].pitch;
 				for (int b = 0; b < 4; b++) { p.out[b] = base + plan.ch[c].band[0][b].offset; p.q[b] = make_q(plan.ch[c].band[0][b].quant, mpq); }
 			}
@@ -361,7 +366,7 @@ int EncodeBatch::set_device_frame(int i, const void *d_frame, int pitch)
 	if (enc_packed16(plan_.pixel_kind)) {
 		for (int c = 0; c < plan_.num_channels; c++) {
 			dev::FwdPlaneJob &p = j.l1[(size_t)i * plan_.num_channels + c];
-			p.in = (const int16_t *)((const uint16_t *)d_frame + enc_word_of_channel(plan_.pixel_kind, c)); p.in_pitch = pitch / 2;
+			p.in = (const int16_t *)((const uint16_t *)d_frame + enc_word_of_channel(plan_.pixel_kind, c)); p.in_pitch = enc_bytes8(plan_.pixel_kind) ? pitch : pitch / 2;
 		}
 		jobs_dirty_ = true;
 		return 0;

@@ -45,6 +45,9 @@ struct FwdPlaneJob {
 	// 3 = channel 2 (Cb); `in` is the start of the frame, rows beyond display_height are zero (frame.c:1481 stops there), and from sample
 	// tail_from on -- what the reference's 48-pixel SIMD loop leaves to its scalar loop -- channel 1 repeats the first Cr of every group of
 	// three (the scalar loop stores `v` before it has read the next one, convert.c:4530-4535).  layout 0: everything above.
+	// layout 4 / 5: 8-bit interleaved pixels, bottom / top row first (RG24, BGRA / BGRa; frame.c:6173 ConvertRGBtoRGB48, :6286 ConvertRGBAtoRGB48):
+	// `in` is the start of the frame, in_pitch is in BYTES, xstride = bytes per pixel, tail_from = the component's byte inside the pixel;
+	// sample = byte << 4; rows beyond display_height zero.
 	int layout, tail_from;
 };
 
@@ -311,7 +314,12 @@ __device__ __forceinline__ void fwd_plane_tile(const FwdPlaneJob *jobs, int nch)
 			const int y = row_start + j, dw = c0 - 2 + d;    // dword index within the plane row
 			va[k] = 0;
 			if (i < ROWS * (TW + 4) && y < H && dw >= 0 && dw < HW) {
-				if (PACKED && job.layout) {
+				if (PACKED && job.layout >= 4) {
+					if (y < job.display_height) {
+						const uint8_t *row = (const uint8_t *)job.in + (size_t)(job.layout == 4 ? job.display_height - 1 - y : y) * job.in_pitch + job.tail_from;
+						va[k] = ((uint32_t)row[(size_t)(2 * dw) * job.xstride] << 4) | ((uint32_t)row[(size_t)(2 * dw + 1) * job.xstride] << 20);
+					}
+				} else if (PACKED && job.layout) {
 					if (y < job.display_height) {
 						const uint32_t *row = (const uint32_t *)((const uint16_t *)job.in + (size_t)y * job.in_pitch);
 						va[k] = v210_sample(row, job.layout, 2 * dw, job.tail_from) | (v210_sample(row, job.layout, 2 * dw + 1, job.tail_from) << 16);

@@ -27,6 +27,9 @@ PIX_B64A = fourcc("b64a")
 PIX_BYR4 = fourcc("BYR4")
 PIX_YU64 = fourcc("YU64")
 PIX_V210 = fourcc("v210")
+PIX_RG24 = fourcc("RG24")
+PIX_BGRA = fourcc("BGRA")
+PIX_BGRa = fourcc("BGRa")
 ENCODED_BAYER = 3       # CFHD_ENCODED_FORMAT_BAYER
 COLOR_FORMAT_BYR4 = 104 # Codec/color.h
 ENCODED_RGBA4444 = 2    # CFHD_ENCODED_FORMAT_RGBA_4444
@@ -222,7 +225,7 @@ def mask_volatile_metadata(sample):
 # ------------------------------------------------------------------------------------------
 PRODUCT_DIR = os.path.join(ROOT, "cineform-sdk_amd")
 PRODUCT_SO = os.path.join(PRODUCT_DIR, "libcfhd_amd.so")
-PIXKIND = {"YUY2": 1, "2vuy": 2, "RG48": 3, "b64a": 4, "BYR4": 5, "YU64": 6, "v210": 7}
+PIXKIND = {"YUY2": 1, "2vuy": 2, "RG48": 3, "b64a": 4, "BYR4": 5, "YU64": 6, "v210": 7, "RG24": 8, "BGRA": 9, "BGRa": 10}
 ENC = {"422": 1, "bayer": 2, "444": 3, "4444": 4}
 _product = None
 

@@ -81,6 +81,22 @@ void emu_fwd_v210(const uint32_t *in, int in_pitch_bytes, int width, int height,
 	hipemu::launch(grid, dim3(NTHREADS), [&] { k_fwd_packed16(jobs.data(), 3); });
 }
 
+// Level 1 of an RGB 4:4:4 frame from 8-bit B, G, R bytes, bottom row first (RG24): FwdPlaneJob::layout 4, as EncodeBatch::fill_jobs sets it up.
+void emu_fwd_rg24(const uint8_t *in, int in_pitch_bytes, int width, int height, int display_height, const int *quant, int mpq, int16_t **out, int out_pitch)
+{
+	std::vector<FwdPlaneJob> jobs(3);
+	for (int c = 0; c < 3; c++) {
+		FwdPlaneJob &job = jobs[c];
+		job.in = (const int16_t *)in; job.in_pitch = in_pitch_bytes; job.width = width; job.height = height; job.prescale = 0;
+		job.xstride = 3; job.shift = 4; job.display_height = display_height; job.compand = 0;
+		job.layout = 4; job.tail_from = c == 0 ? 1 : (c == 1 ? 2 : 0);
+		for (int b = 0; b < 4; b++) { job.out[b] = out[c * 4 + b]; job.q[b] = make_q(quant[c * 4 + b], mpq); }
+		job.out_pitch = out_pitch;
+	}
+	dim3 grid(((width / 2 + TW - 1) / TW) * 3, (height / 2 + TH - 1) / TH, 1);
+	hipemu::launch(grid, dim3(NTHREADS), [&] { k_fwd_packed16(jobs.data(), 3); });
+}
+
 // Last level of a 4:4:4(:4) format to interleaved 16-bit pixels: bands[c*4+b].
 void emu_inv_packed16(int16_t **bands, int band_pitch, int w, int h, int display_height, int nch, int precision, const int *word_of_channel,
                       uint16_t *out, int out_pitch_words, int alpha_channel)

@@ -415,6 +415,49 @@ def test_v210_encode_bitstream_identical(w, h):
     assert psnr_yuy2(img[:, : (w - w % 48) * 2], as8[:, : (w - w % 48) * 2]) > 40      # (the columns behind the last whole 48 pixels carry the reference's repeated Cr)
 
 
+@pytest.mark.parametrize("name,flip", [("BGRA", 1), ("BGRa", 0)])
+@pytest.mark.parametrize("w,h", [(320, 240), (1280, 720)])
+def test_bgra_encode_to_rgb444_bitstream_identical(w, h, name, flip):
+    """8-bit BGRA (bottom-up) / BGRa (top-down) -> RGB 4:4:4, alpha dropped: byte-identical to the reference; decodes to the picture."""
+    fmt = fourcc(name)
+    frames, pitch = qbist_frames(10, 2, w, h, fmt, alpha=1)
+    mine = amd_encode_frames(frames, pitch, w, h, fmt, encoded=ENCODED_RGB444)
+    refs = ref_encode_frames(frames, pitch, w, h, fmt, encoded=ENCODED_RGB444)
+    for i, (a, b) in enumerate(zip(mine, refs)):
+        assert len(a) == len(b), "frame %d: size %d vs reference %d" % (i, len(a), len(b))
+        assert mask_volatile_metadata(a) == mask_volatile_metadata(b), "frame %d" % i
+    got, gpitch, aw, ah = amd_decode_sample(mine[0], PIX_RG48)
+    rgb = np.frombuffer(got.tobytes(), np.uint16).reshape(h, gpitch // 2)[:, : w * 3].reshape(h, w, 3)
+    px = frames[0].reshape(h, pitch)[:, : w * 4].reshape(h, w, 4)
+    if flip: px = px[::-1]
+    src = px[:, :, 2::-1].astype(np.float64) * 257.0            # B, G, R bytes -> R, G, B 16-bit
+    assert 10 * np.log10(65535.0 ** 2 / np.mean((rgb.astype(np.float64) - src) ** 2)) > 40.0
+    L = product()
+    enc = ctypes.c_void_p(); L.CFHD_OpenEncoder(ctypes.byref(enc), None)
+    assert L.CFHD_PrepareToEncode(enc, w, h, fmt, ENCODED_RGBA4444, 0, 4) == 3      # 8-bit RGBA -> RGBA 4:4:4:4 is not built (BADFORMAT)
+    L.CFHD_CloseEncoder(enc)
+
+
+@pytest.mark.parametrize("w,h", [(320, 240), (1280, 720), (1920, 1080)])
+def test_rg24_encode_to_rgb444_bitstream_identical(w, h):
+    """RG24 (8-bit B, G, R bytes, bottom-up) -> RGB 4:4:4 through k_fwd_packed16's byte loader.  Byte-identical to the reference
+    where the reference is defined (heights that are multiples of 8: below the display height it transforms uninitialised rows); the sample
+    decodes to RG48 like any RGB 4:4:4 sample and shows the picture."""
+    frames, pitch = qbist_frames(10, 2, w, h, PIX_RG24)
+    mine = amd_encode_frames(frames, pitch, w, h, PIX_RG24, encoded=ENCODED_RGB444)
+    if h % 8 == 0:
+        refs = ref_encode_frames(frames, pitch, w, h, PIX_RG24, encoded=ENCODED_RGB444)
+        for i, (a, b) in enumerate(zip(mine, refs)):
+            assert len(a) == len(b), "frame %d: size %d vs reference %d" % (i, len(a), len(b))
+            assert mask_volatile_metadata(a) == mask_volatile_metadata(b), "frame %d" % i
+    got, gpitch, aw, ah = amd_decode_sample(mine[0], PIX_RG48)
+    assert (aw, ah) == (w, h)
+    rgb = np.frombuffer(got.tobytes(), np.uint16).reshape(h, gpitch // 2)[:, : w * 3].reshape(h, w, 3)          # R, G, B words, top row first
+    src = frames[0].reshape(h, pitch)[:, : w * 3].reshape(h, w, 3)[::-1, :, ::-1].astype(np.float64) * 257.0  # B, G, R bytes bottom-up -> R, G, B 16-bit
+    mse = np.mean((rgb.astype(np.float64) - src) ** 2)
+    assert 10 * np.log10(65535.0 ** 2 / mse) > 40.0
+
+
 def test_byr4_encode_with_a_wide_pitch_reads_what_the_reference_reads():
     """The reference ignores the pitch of a BYR4 frame (frame.c:5376: tightly packed rows); so does CFHD_EncodeSample here."""
     w, h, pitch = 192, 96, 192 * 2 + 48

@@ -176,6 +176,40 @@ def test_v210_reference_is_not_reproducible_for_padded_heights():
     if len(sizes) == 1: pytest.skip("the reference happened to see the same memory four times")
 
 
+@pytest.mark.parametrize("w,h", [(320, 240), (720, 480)])
+def test_rg24_rgb444_sample_bytes_equal_reference(w, h):
+    """RG24 (8-bit B, G, R bytes, bottom row first) -> RGB 4:4:4: the reference lifts every byte to 12 bits (<< 4) into planes G, R, B
+    (frame.c:6173 ConvertRGBtoRGB48) and goes on as for RG48; input format 7, the quality word marked 0x09a0 in its upper half.  Heights
+    that are multiples of 8 only: the reference's conversion stops at the display height and transforms uninitialised rows below it."""
+    if not have_ref(): pytest.skip("reference .so not built")
+    frames, pitch = qbist_frames(10, 1, w, h, PIX_RG24)
+    rs = ref_encode_frames(frames, pitch, w, h, PIX_RG24, encoded=ENCODED_RGB444)[0]
+    px = frames[0].reshape(h, pitch)[:, : w * 3].reshape(h, w, 3)[::-1]
+    plan = Plan(w, h, pixkind=PIXKIND["RG24"], enc=3, quality=QUALITY_FILMSCAN1 | 0x09a00000)
+    planes = [px[:, :, 1].astype(np.int16) << 4, px[:, :, 2].astype(np.int16) << 4, px[:, :, 0].astype(np.int16) << 4]
+    off, n = first_metadata_chunk(rs)
+    mine = product_write_sample_host(plan, oracle_forward_planes(plan, planes), 1, meta_global=rs[off:off + n], input_format=7, color_space=0)
+    assert mine == rs
+
+
+@pytest.mark.parametrize("name,flip,code", [("BGRA", 1, 32), ("BGRa", 0, 9)])
+def test_bgra_rgb444_sample_bytes_equal_reference(name, flip, code):
+    """8-bit B, G, R, A pixels -> RGB 4:4:4 (frame.c:6286 ConvertRGBAtoRGB48): as RG24 with four bytes per pixel, alpha dropped; 'BGRA' frames
+    are stored bottom row first, 'BGRa' top row first; input format codes 32 / 9."""
+    if not have_ref(): pytest.skip("reference .so not built")
+    w, h = 320, 240
+    fmt = fourcc(name)
+    frames, pitch = qbist_frames(10, 1, w, h, fmt, alpha=1)
+    rs = ref_encode_frames(frames, pitch, w, h, fmt, encoded=ENCODED_RGB444)[0]
+    px = frames[0].reshape(h, pitch)[:, : w * 4].reshape(h, w, 4)
+    if flip: px = px[::-1]
+    plan = Plan(w, h, pixkind=PIXKIND[name], enc=3, quality=QUALITY_FILMSCAN1 | 0x09a00000)
+    planes = [px[:, :, 1].astype(np.int16) << 4, px[:, :, 2].astype(np.int16) << 4, px[:, :, 0].astype(np.int16) << 4]
+    off, n = first_metadata_chunk(rs)
+    mine = product_write_sample_host(plan, oracle_forward_planes(plan, planes), 1, meta_global=rs[off:off + n], input_format=code, color_space=0)
+    assert mine == rs
+
+
 def test_byr4_pitch_is_ignored_by_the_reference():
     """The reference's BYR4 unpack (frame.c:5376) walks the mosaic as tightly packed rows whatever pitch the caller passes.  A drop-in has to
     read the same bytes: the product does (EncodeBatch::upload_frame), this pins the behaviour on the reference itself."""

@@ -795,3 +795,27 @@ def test_dx_decoder_emulated_fuzzed_samples(interlaced):
             outcomes[rc != 0] = outcomes.get(rc != 0, 0) + 1
             assert np.all(got[plan.coeff_elems:] == 99), (trial, mode)
     assert outcomes.get(True, 0) >= 4                  # (some damage must have been noticed)
+
+
+@pytest.mark.parametrize("w,h,dh", [(32, 16, 16), (136, 40, 37), (320, 48, 48)])
+def test_fwd_packed16_level1_of_rg24(w, h, dh):
+    """RG24 input (8-bit B, G, R, bottom row first; Codec/frame.c:6173): the loader of k_fwd_packed16 lifts the bytes to 12 bits and flips the
+    rows = the oracle's plane transform of the planes G, R, B (rows below the picture zero)."""
+    rng = np.random.default_rng(w + h)
+    pitch = w * 3 + 5
+    buf = rng.integers(0, 256, size=(dh, pitch), dtype=np.int64).astype(np.uint8)
+    quant = [1, 12, 12, 24] * 3
+    opitch = (w // 2 + 7) // 8 * 8
+    outs = [np.zeros((h // 2, opitch), np.int16) for _ in range(12)]
+    ptrs = (c_i16p * 12)(*[p16(o) for o in outs])
+    E = emu()
+    E.emu_fwd_rg24.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    E.emu_fwd_rg24(buf.ctypes.data_as(ctypes.c_void_p), pitch, w, h, dh, iarr(quant), 2, ptrs, opitch)
+    px = buf[:, : w * 3].reshape(dh, w, 3)[::-1]
+    for c, byte in enumerate((1, 2, 0)):
+        plane = np.zeros((h, w), np.int16); plane[:dh] = px[:, :, byte].astype(np.int16) << 4
+        want = [np.zeros((h // 2, opitch), np.int16) for _ in range(4)]
+        bands = (c_i16p * 4)(*[p16(o) for o in want])
+        oracle().orc_fwd_spatial(p16(plane), w, w, h, 0, iarr(quant[:4]), 2, bands, opitch)
+        for b in range(4):
+            assert np.array_equal(outs[4 * c + b][:, :w // 2], want[b][:, :w // 2]), (c, b)
