@@ -34,7 +34,8 @@ enum {
 
 #define FOURCC_BE(a, b, c, d) (((uint32_t)(a) << 24) | ((uint32_t)(b) << 16) | ((uint32_t)(c) << 8) | (uint32_t)(d))
 static const uint32_t FMT_YUY2 = FOURCC_BE('Y', 'U', 'Y', '2'), FMT_2VUY = FOURCC_BE('2', 'v', 'u', 'y'), FMT_YUYV = FOURCC_BE('y', 'u', 'y', 'v'),
-                      FMT_RG48 = FOURCC_BE('R', 'G', '4', '8'), FMT_B64A = FOURCC_BE('b', '6', '4', 'a'), FMT_BYR4 = FOURCC_BE('B', 'Y', 'R', '4'), FMT_YU64 = FOURCC_BE('Y', 'U', '6', '4'), FMT_V210 = FOURCC_BE('v', '2', '1', '0'), FMT_RG24 = FOURCC_BE('R', 'G', '2', '4'), FMT_BGRA = FOURCC_BE('B', 'G', 'R', 'A'), FMT_BGRa = FOURCC_BE('B', 'G', 'R', 'a');
+                      FMT_RG48 = FOURCC_BE('R', 'G', '4', '8'), FMT_B64A = FOURCC_BE('b', '6', '4', 'a'), FMT_BYR4 = FOURCC_BE('B', 'Y', 'R', '4'), FMT_YU64 = FOURCC_BE('Y', 'U', '6', '4'), FMT_V210 = FOURCC_BE('v', '2', '1', '0'), FMT_RG24 = FOURCC_BE('R', 'G', '2', '4'), FMT_BGRA = FOURCC_BE('B', 'G', 'R', 'A'), FMT_BGRa = FOURCC_BE('B', 'G', 'R', 'a'),
+                      FMT_R210 = FOURCC_BE('r', '2', '1', '0'), FMT_DPX0 = FOURCC_BE('D', 'P', 'X', '0'), FMT_AB10 = FOURCC_BE('A', 'B', '1', '0'), FMT_AR10 = FOURCC_BE('A', 'R', '1', '0');
 
 namespace {
 
@@ -50,11 +51,15 @@ int pixel_kind_of(uint32_t fmt)
 	if (fmt == FMT_RG24) return PIX_RG24;
 	if (fmt == FMT_BGRA) return PIX_BGRA;
 	if (fmt == FMT_BGRa) return PIX_BGRa;
+	if (fmt == FMT_R210) return PIX_R210;
+	if (fmt == FMT_DPX0) return PIX_DPX0;
+	if (fmt == FMT_AB10) return PIX_AB10;
+	if (fmt == FMT_AR10) return PIX_AR10;
 	return PIX_NONE;
 }
 // COLOR_FORMAT_UYVY = 1 / COLOR_FORMAT_YUYV = 2 / COLOR_FORMAT_BGRA64 (b64a) = 30 / COLOR_FORMAT_RG48 = 120 (Codec/color.h)
-int color_format_of(int kind) { return kind == PIX_2VUY ? 1 : (kind == PIX_RG48 ? 120 : (kind == PIX_B64A ? 30 : (kind == PIX_BYR4 ? 104 : (kind == PIX_YU64 ? 12 : (kind == PIX_V210 ? 10 : (kind == PIX_RG24 ? 7 : (kind == PIX_BGRA ? 32 : (kind == PIX_BGRa ? 9 : 2)))))))); }   // COLOR_FORMAT_* of Codec/color.h
-int pixel_bytes_of(int kind) { return kind == PIX_RG24 ? 3 : (kind == PIX_BGRA || kind == PIX_BGRa) ? 4 : kind == PIX_RG48 ? 6 : (kind == PIX_B64A ? 8 : (kind == PIX_YU64 || kind == PIX_V210 ? 4 : 2)); }
+int color_format_of(int kind) { return kind == PIX_2VUY ? 1 : (kind == PIX_RG48 ? 120 : (kind == PIX_B64A ? 30 : (kind == PIX_BYR4 ? 104 : (kind == PIX_YU64 ? 12 : (kind == PIX_V210 ? 10 : (kind == PIX_RG24 ? 7 : (kind == PIX_BGRA ? 32 : (kind == PIX_BGRa ? 9 : (kind == PIX_R210 ? 123 : (kind == PIX_DPX0 ? 128 : (kind == PIX_AB10 ? 125 : (kind == PIX_AR10 ? 124 : 2)))))))))))); }   // COLOR_FORMAT_* of Codec/color.h
+int pixel_bytes_of(int kind) { return kind == PIX_RG24 ? 3 : (kind == PIX_BGRA || kind == PIX_BGRa || (kind >= PIX_R210 && kind <= PIX_AR10)) ? 4 : kind == PIX_RG48 ? 6 : (kind == PIX_B64A ? 8 : (kind == PIX_YU64 || kind == PIX_V210 ? 4 : 2)); }
 
 // ---- metadata handle shared by the encoder-side API (CSampleEncodeMetadata) ----
 struct EncMetadata {
@@ -101,10 +106,11 @@ int make_params(EncodeParams &p, int w, int h, uint32_t fmt, int encoded, uint32
 	// combinations (4:4:4 input subsampled to 4:2:2, ...) go through ConvertLib in the reference and are not built
 	// CFHD_ENCODED_FORMAT_RGBA_4444 (2) from b64a
 	const bool rgb8 = kind == PIX_RG24 || kind == PIX_BGRA || kind == PIX_BGRa;       // 8-bit RGB(A) input, built towards RGB 4:4:4 only (alpha dropped)
-	const bool rgb = kind == PIX_RG48 || kind == PIX_B64A || rgb8;
+	const bool rgb10 = kind >= PIX_R210 && kind <= PIX_AR10;                             // 10-bit RGB in 32-bit words, to RGB 4:4:4
+	const bool rgb = kind == PIX_RG48 || kind == PIX_B64A || rgb8 || rgb10;
 	// CFHD_ENCODED_FORMAT_BAYER (3) from BYR4: default pixel order (red-green) and default encode curve (log 90), i.e. what the
 	// reference does without BAYER_FORMAT / ENCODE_CURVE metadata
-	if (encoded != (kind == PIX_RG48 || rgb8 ? 1 : (kind == PIX_B64A ? 2 : (kind == PIX_BYR4 ? 3 : 0)))) return ERR_BADFORMAT;
+	if (encoded != (kind == PIX_RG48 || rgb8 || rgb10 ? 1 : (kind == PIX_B64A ? 2 : (kind == PIX_BYR4 ? 3 : 0)))) return ERR_BADFORMAT;
 	// CFHD_ENCODING_FLAGS_YUV_INTERLACED: field-based level 1 (encoder.c:2093), built for the packed 4:2:2 formats
 	const bool interlaced = (flags & (1u << 0)) != 0;
 	if (interlaced && !(kind == PIX_YUY2 || kind == PIX_2VUY)) return ERR_BADFORMAT;
@@ -548,7 +554,7 @@ CFHD_Error CFHD_OpenEncoder(CFHD_EncoderRef *out, CFHD_ALLOCATOR *)
 CFHD_Error CFHD_GetInputFormats(CFHD_EncoderRef ref, CFHD_PixelFormat *arr, int len, int *count)
 {
 	if (!ref || !arr) return ERR_INVALID_ARGUMENT;
-	const uint32_t fmts[] = { FMT_YUY2, FMT_2VUY, FMT_RG48, FMT_B64A, FMT_BYR4, FMT_YU64, FMT_V210, FMT_RG24, FMT_BGRA, FMT_BGRa };
+	const uint32_t fmts[] = { FMT_YUY2, FMT_2VUY, FMT_RG48, FMT_B64A, FMT_BYR4, FMT_YU64, FMT_V210, FMT_RG24, FMT_BGRA, FMT_BGRa, FMT_R210, FMT_DPX0, FMT_AB10, FMT_AR10 };
 	int n = 0;
 	for (; n < 5 && n < len; n++) arr[n] = fmts[n];
 	if (count) *count = n;
@@ -884,7 +890,7 @@ CFHD_Error CFHD_PrepareToDecode(CFHD_DecoderRef ref, int, int, CFHD_PixelFormat 
 	// 4:2:2 samples decode to the packed 4:2:2 formats, RGB 4:4:4 samples to RG48 (wavelet.c:4947), RGBA 4:4:4:4 samples to b64a
 	// (bayer.c:11916 Row16uFull2OutputFormat); colour conversions between the families (ConvertLib / the colour part of the
 	// active-metadata pipeline in the reference) are not built
-	if (kind == PIX_BYR4 || kind == PIX_YU64 || kind == PIX_V210 || kind == PIX_RG24 || kind == PIX_BGRA || kind == PIX_BGRa) return ERR_BADFORMAT;     // encoder inputs only
+	if (kind == PIX_BYR4 || kind == PIX_YU64 || kind == PIX_V210 || kind == PIX_RG24 || kind == PIX_BGRA || kind == PIX_BGRa || (kind >= PIX_R210 && kind <= PIX_AR10)) return ERR_BADFORMAT;     // encoder inputs only
 	if ((encf == ENC_RGB444) != (kind == PIX_RG48) || (encf == ENC_RGBA4444) != (kind == PIX_B64A)) return ERR_BADFORMAT;
 	bool ok;
 	plan_from_sample(d->header, kind, &d->plan, &ok);

@@ -32,6 +32,10 @@ enum PixelKind : int {
 	PIX_RG24,      // 8-bit B, G, R bytes, bottom row first (COLOR_FORMAT_RGB24 = 7; encoder input only, to RGB 4:4:4)
 	PIX_BGRA,      // 8-bit B, G, R, A bytes, bottom row first ('BGRA', format code 32; encoder input only, to RGB 4:4:4: alpha dropped)
 	PIX_BGRa,      // the same, top row first ('BGRa', format code 9)
+	PIX_R210,      // 10-bit RGB in a big-endian 32-bit word, R bits 20-29, G 10-19, B 0-9 (COLOR_FORMAT_R210 = 123; encoder input only, to RGB 4:4:4)
+	PIX_DPX0,      // big-endian, R 22-31, G 12-21, B 2-11 (128)
+	PIX_AB10,      // little-endian, R 0-9, G 10-19, B 20-29 (125)
+	PIX_AR10,      // little-endian, R 20-29, G 10-19, B 0-9 (124)
 };
 
 // ENCODED_FORMAT_* values as written into the bitstream (Codec/codec.h)

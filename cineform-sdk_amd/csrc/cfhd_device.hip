@@ -87,9 +87,12 @@ bool is_packed16(int pixel_kind) { return pixel_kind == PIX_RG48 || pixel_kind =
 // YU64 (Codec/frame.c:1556 ConvertYU64ToFrame16s + convert.c:3345, :14375): words Y0 C1 Y1 C2, every word >> 6 to 10 bits, channel 1 = C1, 2 = C2.
 // v210 (frame.c:1431 ConvertV210ToFrame16s): three 10-bit samples per 32-bit word, FwdPlaneJob::layout tells the loader which component to pick.
 // RG24 (frame.c:6173 ConvertRGBtoRGB48): bytes B, G, R, bottom row first, byte << 4; planes G, R, B.
-static bool enc_packed16(int pixel_kind) { return is_packed16(pixel_kind) || pixel_kind == PIX_YU64 || pixel_kind == PIX_V210 || pixel_kind == PIX_RG24 || pixel_kind == PIX_BGRA || pixel_kind == PIX_BGRa; }
+static bool enc_packed16(int pixel_kind) { return is_packed16(pixel_kind) || pixel_kind == PIX_YU64 || pixel_kind == PIX_V210 || pixel_kind == PIX_RG24 || pixel_kind == PIX_BGRA || pixel_kind == PIX_BGRa || (pixel_kind >= PIX_R210 && pixel_kind <= PIX_AR10); }
 static bool enc_bytes8(int pixel_kind) { return pixel_kind == PIX_RG24 || pixel_kind == PIX_BGRA || pixel_kind == PIX_BGRa; }
-static int enc_word_of_channel(int pixel_kind, int c) { return pixel_kind == PIX_V210 || enc_bytes8(pixel_kind) ? 0 : (pixel_kind == PIX_YU64 ? (c == 0 ? 0 : (c == 1 ? 1 : 3)) : packed_word_of_channel(pixel_kind, c)); }
+static bool enc_rgb10(int pixel_kind) { return pixel_kind >= PIX_R210 && pixel_kind <= PIX_AR10; }
+// bit position of plane c (G, R, B) inside the pixel word of the 10-bit RGB formats
+static int rgb10_shift(int pixel_kind, int c) { const int r = pixel_kind == PIX_DPX0 ? 22 : (pixel_kind == PIX_AB10 ? 0 : 20), g = pixel_kind == PIX_DPX0 ? 12 : 10, b = pixel_kind == PIX_DPX0 ? 2 : (pixel_kind == PIX_AB10 ? 20 : 0); return c == 0 ? g : (c == 1 ? r : b); }
+static int enc_word_of_channel(int pixel_kind, int c) { return pixel_kind == PIX_V210 || enc_bytes8(pixel_kind) || enc_rgb10(pixel_kind) ? 0 : (pixel_kind == PIX_YU64 ? (c == 0 ? 0 : (c == 1 ? 1 : 3)) : packed_word_of_channel(pixel_kind, c)); }
 static int enc_stride_of_channel(int pixel_kind, int c, int nch) { return pixel_kind == PIX_YU64 ? (c == 0 ? 2 : 4) : nch; }
 } // namespace
 
@@ -160,7 +163,7 @@ int packed_frame_pitch(int pixel_kind, int width)
 	case PIX_BYR4: return width * 2;
 	case PIX_YU64: return width * 4;
 	case PIX_RG24: return width * 3;
-	case PIX_BGRA: case PIX_BGRa: return width * 4;
+	case PIX_BGRA: case PIX_BGRa: case PIX_R210: case PIX_DPX0: case PIX_AB10: case PIX_AR10: return width * 4;
 	case PIX_V210: return (width + 47) / 48 * 128;      // six pixels in 16 bytes, rows padded to 48 pixels (Example/utils.cpp:84-90)
 	default: return 0;
 	}
@@ -279,6 +282,7 @@ void EncodeBatch::fill_jobs()
 				p.compand = plan.pixel_kind == PIX_B64A && c == 3;
 				p.layout = plan.pixel_kind == PIX_V210 ? c + 1 : 0; p.tail_from = (plan.width - plan.width % 48) / 2;
 				if (enc_bytes8(plan.pixel_kind)) { p.layout = plan.pixel_kind == PIX_BGRa ? 5 : 4; p.in_pitch = in_pitch_; p.xstride = plan.pixel_kind == PIX_RG24 ? 3 : 4; p.tail_from = c == 0 ? 1 : (c == 1 ? 2 : 0); }     // planes G, R, B of bytes B, G, R(, A)
+				if (enc_rgb10(plan.pixel_kind)) { p.layout = 6; p.in_pitch = in_pitch_ / 4; p.xstride = plan.pixel_kind == PIX_R210 || plan.pixel_kind == PIX_DPX0; p.tail_from = rgb10_shift(plan.pixel_kind, c); }
 				p.out_pitch = plan.ch[c].band[0][0].pitch;
 				for (int b = 0; b < 4; b++) { p.out[b] = base + plan.ch[c].band[0][b].offset; p.q[b] = make_q(plan.ch[c].band[0][b].quant, mpq); }
 			}
@@ -366,7 +370,7 @@ int EncodeBatch::set_device_frame(int i, const void *d_frame, int pitch)
 	if (enc_packed16(plan_.pixel_kind)) {
 		for (int c = 0; c < plan_.num_channels; c++) {
 			dev::FwdPlaneJob &p = j.l1[(size_t)i * plan_.num_channels + c];
-			p.in = (const int16_t *)((const uint16_t *)d_frame + enc_word_of_channel(plan_.pixel_kind, c)); p.in_pitch = enc_bytes8(plan_.pixel_kind) ? pitch : pitch / 2;
+			p.in = (const int16_t *)((const uint16_t *)d_frame + enc_word_of_channel(plan_.pixel_kind, c)); p.in_pitch = enc_bytes8(plan_.pixel_kind) ? pitch : (enc_rgb10(plan_.pixel_kind) ? pitch / 4 : pitch / 2);
 		}
 		jobs_dirty_ = true;
 		return 0;

@@ -48,6 +48,9 @@ struct FwdPlaneJob {
 	// layout 4 / 5: 8-bit interleaved pixels, bottom / top row first (RG24, BGRA / BGRa; frame.c:6173 ConvertRGBtoRGB48, :6286 ConvertRGBAtoRGB48):
 	// `in` is the start of the frame, in_pitch is in BYTES, xstride = bytes per pixel, tail_from = the component's byte inside the pixel;
 	// sample = byte << 4; rows beyond display_height zero.
+	// layout 6: 10-bit RGB in one 32-bit word per pixel (r210, DPX0: big-endian; AB10, AR10: little-endian; wavelet.c:3595): in_pitch in 32-bit
+	// words, xstride = 1 for big-endian words, tail_from = bit position of the component; sample = field << 2; rows beyond display_height repeat
+	// the last row (a choice: the reference's fused row pipeline treats them its own way, parity is claimed for heights that are multiples of 8).
 	int layout, tail_from;
 };
 
@@ -314,7 +317,13 @@ __device__ __forceinline__ void fwd_plane_tile(const FwdPlaneJob *jobs, int nch)
 			const int y = row_start + j, dw = c0 - 2 + d;    // dword index within the plane row
 			va[k] = 0;
 			if (i < ROWS * (TW + 4) && y < H && dw >= 0 && dw < HW) {
-				if (PACKED && job.layout >= 4) {
+				if (PACKED && job.layout == 6) {
+					const int yy = y < job.display_height ? y : job.display_height - 1;
+					const uint32_t *row = (const uint32_t *)job.in + (size_t)yy * job.in_pitch;
+					uint32_t p0 = row[2 * dw], p1 = row[2 * dw + 1];
+					if (job.xstride) { p0 = __builtin_bswap32(p0); p1 = __builtin_bswap32(p1); }
+					va[k] = (((p0 >> job.tail_from) & 0x3ffu) << 2) | (((p1 >> job.tail_from) & 0x3ffu) << 18);
+				} else if (PACKED && job.layout >= 4) {
 					if (y < job.display_height) {
 						const uint8_t *row = (const uint8_t *)job.in + (size_t)(job.layout == 4 ? job.display_height - 1 - y : y) * job.in_pitch + job.tail_from;
 						va[k] = ((uint32_t)row[(size_t)(2 * dw) * job.xstride] << 4) | ((uint32_t)row[(size_t)(2 * dw + 1) * job.xstride] << 20);

@@ -30,6 +30,8 @@ PIX_V210 = fourcc("v210")
 PIX_RG24 = fourcc("RG24")
 PIX_BGRA = fourcc("BGRA")
 PIX_BGRa = fourcc("BGRa")
+# 10-bit RGB in 32-bit words: name -> (byte order of the word, bit positions of R, G, B, COLOR_FORMAT code)
+RGB10_FORMATS = {"r210": (">", (20, 10, 0), 123), "DPX0": (">", (22, 12, 2), 128), "AB10": ("<", (0, 10, 20), 125), "AR10": ("<", (20, 10, 0), 124)}
 ENCODED_BAYER = 3       # CFHD_ENCODED_FORMAT_BAYER
 COLOR_FORMAT_BYR4 = 104 # Codec/color.h
 ENCODED_RGBA4444 = 2    # CFHD_ENCODED_FORMAT_RGBA_4444
@@ -225,7 +227,7 @@ def mask_volatile_metadata(sample):
 # ------------------------------------------------------------------------------------------
 PRODUCT_DIR = os.path.join(ROOT, "cineform-sdk_amd")
 PRODUCT_SO = os.path.join(PRODUCT_DIR, "libcfhd_amd.so")
-PIXKIND = {"YUY2": 1, "2vuy": 2, "RG48": 3, "b64a": 4, "BYR4": 5, "YU64": 6, "v210": 7, "RG24": 8, "BGRA": 9, "BGRa": 10}
+PIXKIND = {"YUY2": 1, "2vuy": 2, "RG48": 3, "b64a": 4, "BYR4": 5, "YU64": 6, "v210": 7, "RG24": 8, "BGRA": 9, "BGRa": 10, "r210": 11, "DPX0": 12, "AB10": 13, "AR10": 14}
 ENC = {"422": 1, "bayer": 2, "444": 3, "4444": 4}
 _product = None
 

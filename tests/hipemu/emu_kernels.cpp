@@ -97,6 +97,23 @@ void emu_fwd_rg24(const uint8_t *in, int in_pitch_bytes, int width, int height, 
 	hipemu::launch(grid, dim3(NTHREADS), [&] { k_fwd_packed16(jobs.data(), 3); });
 }
 
+// Level 1 of an RGB 4:4:4 frame from 10-bit fields of one 32-bit word per pixel (r210 ...): FwdPlaneJob::layout 6.  shifts[c]: bit position of plane c.
+void emu_fwd_rgb10(const uint32_t *in, int in_pitch_bytes, int width, int height, int display_height, int big_endian, const int *shifts, const int *quant, int mpq,
+                   int16_t **out, int out_pitch)
+{
+	std::vector<FwdPlaneJob> jobs(3);
+	for (int c = 0; c < 3; c++) {
+		FwdPlaneJob &job = jobs[c];
+		job.in = (const int16_t *)in; job.in_pitch = in_pitch_bytes / 4; job.width = width; job.height = height; job.prescale = 0;
+		job.xstride = big_endian; job.shift = 0; job.display_height = display_height; job.compand = 0;
+		job.layout = 6; job.tail_from = shifts[c];
+		for (int b = 0; b < 4; b++) { job.out[b] = out[c * 4 + b]; job.q[b] = make_q(quant[c * 4 + b], mpq); }
+		job.out_pitch = out_pitch;
+	}
+	dim3 grid(((width / 2 + TW - 1) / TW) * 3, (height / 2 + TH - 1) / TH, 1);
+	hipemu::launch(grid, dim3(NTHREADS), [&] { k_fwd_packed16(jobs.data(), 3); });
+}
+
 // Last level of a 4:4:4(:4) format to interleaved 16-bit pixels: bands[c*4+b].
 void emu_inv_packed16(int16_t **bands, int band_pitch, int w, int h, int display_height, int nch, int precision, const int *word_of_channel,
                       uint16_t *out, int out_pitch_words, int alpha_channel)

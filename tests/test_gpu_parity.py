@@ -163,7 +163,7 @@ def test_invalid_arguments_and_unsupported_formats():
     L = product()
     assert L.CFHD_OpenEncoder(None, None) == 1
     enc = ctypes.c_void_p(); L.CFHD_OpenEncoder(ctypes.byref(enc), None)
-    assert L.CFHD_PrepareToEncode(enc, 1920, 1080, fourcc("r210"), 1, 0, 4) == 3       # CFHD_ERROR_BADFORMAT (10-bit RGB input is not built)
+    assert L.CFHD_PrepareToEncode(enc, 1920, 1080, fourcc("r210"), 0, 0, 4) == 3       # CFHD_ERROR_BADFORMAT (RGB -> 4:2:2 needs a colour conversion that is not built)
     assert L.CFHD_PrepareToEncode(enc, 1920, 1080, fourcc("v210"), 1, 0, 4) == 3       # v210 is 4:2:2 only
     assert L.CFHD_EncodeSample(enc, None, 0) == 1
     L.CFHD_CloseEncoder(enc)
@@ -413,6 +413,26 @@ def test_v210_encode_bitstream_identical(w, h):
     as8[:, 0::2] = (Y >> 2); as8[:, 1::4] = (Cb >> 2); as8[:, 3::4] = (Cr >> 2)
     img = _check_decode(mine[0], as8.reshape(-1), w, h)
     assert psnr_yuy2(img[:, : (w - w % 48) * 2], as8[:, : (w - w % 48) * 2]) > 40      # (the columns behind the last whole 48 pixels carry the reference's repeated Cr)
+
+
+@pytest.mark.parametrize("name", sorted(RGB10_FORMATS))
+@pytest.mark.parametrize("w,h", [(320, 240), (1280, 720)])
+def test_rgb10_encode_to_rgb444_bitstream_identical(w, h, name):
+    """10-bit RGB packed in 32-bit words (r210, DPX0 big-endian; AB10, AR10 little-endian) -> RGB 4:4:4 through k_fwd_packed16's field loader:
+    byte-identical to the reference (heights that are multiples of 8); decodes to the picture."""
+    order, shifts, code = RGB10_FORMATS[name]
+    fmt = fourcc(name)
+    frames, pitch = qbist_frames(10, 2, w, h, fmt)
+    mine = amd_encode_frames(frames, pitch, w, h, fmt, encoded=ENCODED_RGB444)
+    refs = ref_encode_frames(frames, pitch, w, h, fmt, encoded=ENCODED_RGB444)
+    for i, (a, b) in enumerate(zip(mine, refs)):
+        assert len(a) == len(b), "frame %d: size %d vs reference %d" % (i, len(a), len(b))
+        assert mask_volatile_metadata(a) == mask_volatile_metadata(b), "frame %d" % i
+    got, gpitch, aw, ah = amd_decode_sample(mine[0], PIX_RG48)
+    rgb = np.frombuffer(got.tobytes(), np.uint16).reshape(h, gpitch // 2)[:, : w * 3].reshape(h, w, 3)
+    words = np.frombuffer(frames[0].tobytes(), order + "u4").reshape(h, pitch // 4)[:, :w]
+    src = np.stack([((words >> s) & 0x3ff) for s in shifts], axis=2).astype(np.float64) * 64.0
+    assert 10 * np.log10(65535.0 ** 2 / np.mean((rgb.astype(np.float64) - src) ** 2)) > 40.0
 
 
 @pytest.mark.parametrize("name,flip", [("BGRA", 1), ("BGRa", 0)])

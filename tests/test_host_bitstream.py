@@ -210,6 +210,25 @@ def test_bgra_rgb444_sample_bytes_equal_reference(name, flip, code):
     assert mine == rs
 
 
+@pytest.mark.parametrize("name", sorted(RGB10_FORMATS))
+def test_rgb10_rgb444_sample_bytes_equal_reference(name):
+    """r210 / DPX0 / AB10 / AR10 (10-bit RGB in one 32-bit word) -> RGB 4:4:4: every field << 2 into planes G, R, B, rows top-down, input
+    format codes 123 / 128 / 125 / 124 (the reference runs a fused unpack + transform, wavelet.c:3595; its result for a height that is a
+    multiple of 8 is the plane transform of these planes)."""
+    if not have_ref(): pytest.skip("reference .so not built")
+    w, h = 320, 240
+    order, shifts, code = RGB10_FORMATS[name]
+    fmt = fourcc(name)
+    frames, pitch = qbist_frames(10, 1, w, h, fmt)
+    rs = ref_encode_frames(frames, pitch, w, h, fmt, encoded=ENCODED_RGB444)[0]
+    words = np.frombuffer(frames[0].tobytes(), order + "u4").reshape(h, pitch // 4)[:, :w]
+    r, g, b = [((words >> s) & 0x3ff).astype(np.int16) << 2 for s in shifts]
+    plan = Plan(w, h, pixkind=PIXKIND[name], enc=3)
+    off, n = first_metadata_chunk(rs)
+    mine = product_write_sample_host(plan, oracle_forward_planes(plan, [g, r, b]), 1, meta_global=rs[off:off + n], input_format=code, color_space=0)
+    assert mine == rs
+
+
 def test_byr4_pitch_is_ignored_by_the_reference():
     """The reference's BYR4 unpack (frame.c:5376) walks the mosaic as tightly packed rows whatever pitch the caller passes.  A drop-in has to
     read the same bytes: the product does (EncodeBatch::upload_frame), this pins the behaviour on the reference itself."""

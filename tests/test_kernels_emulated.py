@@ -819,3 +819,27 @@ def test_fwd_packed16_level1_of_rg24(w, h, dh):
         oracle().orc_fwd_spatial(p16(plane), w, w, h, 0, iarr(quant[:4]), 2, bands, opitch)
         for b in range(4):
             assert np.array_equal(outs[4 * c + b][:, :w // 2], want[b][:, :w // 2]), (c, b)
+
+
+@pytest.mark.parametrize("w,h,dh,big_endian", [(32, 16, 16, 1), (136, 40, 37, 0), (320, 48, 48, 1)])
+def test_fwd_packed16_level1_of_rgb10(w, h, dh, big_endian):
+    """10-bit RGB fields of a 32-bit word per pixel (r210 / DPX0 big-endian, AB10 / AR10 little-endian): the loader of k_fwd_packed16 takes a byte
+    order and a bit position per plane = the oracle's plane transform of the fields << 2 (rows below the picture repeat the last row)."""
+    rng = np.random.default_rng(w + h)
+    words = rng.integers(0, 1 << 32, size=(dh, w + 3), dtype=np.uint64).astype(np.uint32)
+    buf = words.astype(">u4" if big_endian else "<u4")
+    shifts = [12, 22, 2] if big_endian else [10, 0, 20]
+    quant = [1, 12, 12, 24] * 3
+    opitch = (w // 2 + 7) // 8 * 8
+    outs = [np.zeros((h // 2, opitch), np.int16) for _ in range(12)]
+    ptrs = (c_i16p * 12)(*[p16(o) for o in outs])
+    E = emu()
+    E.emu_fwd_rgb10.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    E.emu_fwd_rgb10(buf.ctypes.data_as(ctypes.c_void_p), (w + 3) * 4, w, h, dh, big_endian, iarr(shifts), iarr(quant), 2, ptrs, opitch)
+    for c in range(3):
+        plane = np.zeros((h, w), np.int16); plane[:dh] = (((words[:, :w] >> shifts[c]) & 0x3ff) << 2).astype(np.int16); plane[dh:] = plane[dh - 1]
+        want = [np.zeros((h // 2, opitch), np.int16) for _ in range(4)]
+        bands = (c_i16p * 4)(*[p16(o) for o in want])
+        oracle().orc_fwd_spatial(p16(plane), w, w, h, 0, iarr(quant[:4]), 2, bands, opitch)
+        for b in range(4):
+            assert np.array_equal(outs[4 * c + b][:, :w // 2], want[b][:, :w // 2]), (c, b)
