@@ -110,15 +110,16 @@ int make_params(EncodeParams &p, int w, int h, uint32_t fmt, int encoded, uint32
 	const bool rgb = kind == PIX_RG48 || kind == PIX_B64A || rgb8 || rgb10;
 	// CFHD_ENCODED_FORMAT_BAYER (3) from BYR4: default pixel order (red-green) and default encode curve (log 90), i.e. what the
 	// reference does without BAYER_FORMAT / ENCODE_CURVE metadata
-	if (encoded != (kind == PIX_RG48 || rgb8 || rgb10 ? 1 : (kind == PIX_B64A ? 2 : (kind == PIX_BYR4 ? 3 : 0)))) return ERR_BADFORMAT;
+	// b64a also encodes to RGB 4:4:4 (its default in the reference): the alpha words are dropped, R, G, B as for 4:4:4:4
+	if (!(kind == PIX_B64A && encoded == 1) && encoded != (kind == PIX_RG48 || rgb8 || rgb10 ? 1 : (kind == PIX_B64A ? 2 : (kind == PIX_BYR4 ? 3 : 0)))) return ERR_BADFORMAT;
 	// CFHD_ENCODING_FLAGS_YUV_INTERLACED: field-based level 1 (encoder.c:2093), built for the packed 4:2:2 formats
 	const bool interlaced = (flags & (1u << 0)) != 0;
 	if (interlaced && !(kind == PIX_YUY2 || kind == PIX_2VUY)) return ERR_BADFORMAT;
 	if (flags & (1u << 1)) return ERR_BADFORMAT;                          // 2-frame GOP: out of scope
-	const int enc = kind == PIX_BYR4 ? ENC_BAYER : (kind == PIX_B64A ? ENC_RGBA4444 : (rgb ? ENC_RGB444 : ENC_YUV422));
+	const int enc = kind == PIX_BYR4 ? ENC_BAYER : (kind == PIX_B64A && encoded == 2 ? ENC_RGBA4444 : (rgb ? ENC_RGB444 : ENC_YUV422));
 	// b64a's default encoded format is RGB 4:4:4; asking for 4:4:4:4 marks the quality word (SampleEncoder.cpp:250-257), which the
 	// sample header then carries in QUALITY_H
-	if (kind == PIX_B64A) quality |= 0x20000000;
+	if (kind == PIX_B64A && encoded == 2) quality |= 0x20000000;
 	// 8-bit RGB sources are marked in the quality word too (encoder.c:2344-2345 ORs 0x1a00000 into it; the header's QUALITY_H reads 0x09a0)
 	if (rgb8) quality |= 0x09a00000;
 	p.width = w; p.height = h; p.pixel_format = fmt; p.pixel_kind = kind; p.encoded_format = enc; p.flags = flags;

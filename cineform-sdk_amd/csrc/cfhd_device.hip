@@ -93,7 +93,7 @@ static bool enc_rgb10(int pixel_kind) { return pixel_kind >= PIX_R210 && pixel_k
 // bit position of plane c (G, R, B) inside the pixel word of the 10-bit RGB formats
 static int rgb10_shift(int pixel_kind, int c) { const int r = pixel_kind == PIX_DPX0 ? 22 : (pixel_kind == PIX_AB10 ? 0 : 20), g = pixel_kind == PIX_DPX0 ? 12 : 10, b = pixel_kind == PIX_DPX0 ? 2 : (pixel_kind == PIX_AB10 ? 20 : 0); return c == 0 ? g : (c == 1 ? r : b); }
 static int enc_word_of_channel(int pixel_kind, int c) { return pixel_kind == PIX_V210 || enc_bytes8(pixel_kind) || enc_rgb10(pixel_kind) ? 0 : (pixel_kind == PIX_YU64 ? (c == 0 ? 0 : (c == 1 ? 1 : 3)) : packed_word_of_channel(pixel_kind, c)); }
-static int enc_stride_of_channel(int pixel_kind, int c, int nch) { return pixel_kind == PIX_YU64 ? (c == 0 ? 2 : 4) : nch; }
+static int enc_stride_of_channel(int pixel_kind, int c, int nch) { return pixel_kind == PIX_YU64 ? (c == 0 ? 2 : 4) : (pixel_kind == PIX_B64A ? 4 : nch); }     // (b64a to RGB 4:4:4 has three planes of four-word pixels)
 } // namespace
 
 const char *device_last_error() { return g_err.c_str(); }

@@ -415,6 +415,21 @@ def test_v210_encode_bitstream_identical(w, h):
     assert psnr_yuy2(img[:, : (w - w % 48) * 2], as8[:, : (w - w % 48) * 2]) > 40      # (the columns behind the last whole 48 pixels carry the reference's repeated Cr)
 
 
+@pytest.mark.parametrize("w,h", [(320, 240), (1920, 1080)])
+def test_b64a_encode_to_rgb444_bitstream_identical(w, h):
+    """b64a -> RGB 4:4:4 (alpha dropped): byte-identical to the reference; the sample decodes to RG48."""
+    frames, pitch = qbist_frames(10, 2, w, h, PIX_B64A, alpha=1)
+    mine = amd_encode_frames(frames, pitch, w, h, PIX_B64A, encoded=ENCODED_RGB444)
+    refs = ref_encode_frames(frames, pitch, w, h, PIX_B64A, encoded=ENCODED_RGB444)
+    for i, (a, b) in enumerate(zip(mine, refs)):
+        assert len(a) == len(b), "frame %d: size %d vs reference %d" % (i, len(a), len(b))
+        assert mask_volatile_metadata(a) == mask_volatile_metadata(b), "frame %d" % i
+    got, gpitch, aw, ah = amd_decode_sample(mine[0], PIX_RG48)
+    rgb = np.frombuffer(got.tobytes(), np.uint16).reshape(h, gpitch // 2)[:, : w * 3].reshape(h, w, 3)
+    src = np.frombuffer(frames[0].tobytes(), np.uint16).reshape(h, pitch // 2)[:, : w * 4].reshape(h, w, 4)[:, :, 1:].astype(np.float64)
+    assert 10 * np.log10(65535.0 ** 2 / np.mean((rgb.astype(np.float64) - src) ** 2)) > 40.0
+
+
 @pytest.mark.parametrize("name", sorted(RGB10_FORMATS))
 @pytest.mark.parametrize("w,h", [(320, 240), (1280, 720)])
 def test_rgb10_encode_to_rgb444_bitstream_identical(w, h, name):

@@ -229,6 +229,21 @@ def test_rgb10_rgb444_sample_bytes_equal_reference(name):
     assert mine == rs
 
 
+def test_b64a_rgb444_sample_bytes_equal_reference():
+    """b64a -> RGB 4:4:4 (the reference's default for b64a input): alpha dropped, planes G, R, B = words >> 4, with the quantizer tables the
+    colour format code 30 selects (the chroma tables for R and B, as for 4:4:4:4) and no mark in the quality word."""
+    if not have_ref(): pytest.skip("reference .so not built")
+    w, h = 320, 240
+    frames, pitch = qbist_frames(10, 1, w, h, PIX_B64A, alpha=1)
+    rs = ref_encode_frames(frames, pitch, w, h, PIX_B64A, encoded=ENCODED_RGB444)[0]
+    px = np.frombuffer(frames[0].tobytes(), np.uint16).reshape(h, pitch // 2)[:, : w * 4].reshape(h, w, 4)
+    plan = Plan(w, h, pixkind=PIXKIND["b64a"], enc=3)
+    planes = [(px[:, :, 2] >> 4).astype(np.int16), (px[:, :, 1] >> 4).astype(np.int16), (px[:, :, 3] >> 4).astype(np.int16)]
+    off, n = first_metadata_chunk(rs)
+    mine = product_write_sample_host(plan, oracle_forward_planes(plan, planes), 1, meta_global=rs[off:off + n], input_format=30, color_space=0)
+    assert mine == rs
+
+
 def test_byr4_pitch_is_ignored_by_the_reference():
     """The reference's BYR4 unpack (frame.c:5376) walks the mosaic as tightly packed rows whatever pitch the caller passes.  A drop-in has to
     read the same bytes: the product does (EncodeBatch::upload_frame), this pins the behaviour on the reference itself."""
