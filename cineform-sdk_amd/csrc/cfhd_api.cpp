@@ -331,7 +331,7 @@ struct EncodeServices {
 EncodeServices &encode_services() { static EncodeServices *s = new EncodeServices; return *s; }
 // Off unless asked for: measured on one MI355X at 1080p, pool workers on their own streams reach 8.7-11.8 k fps, gathered into shared passes
 // 5.6-8.2 k (the pass keeps its callers in lock step); only with decoders competing for the GPU did the round trip sometimes gain (3.9 -> 4.6 k).
-int encode_gather_slots() { static const int n = gather_slots("CFHD_AMD_ENCODE_BATCH", 0); return n; }
+int encode_gather_slots() { return gather_slots("CFHD_AMD_ENCODE_BATCH", 0); }        // (read when a pool starts)
 // true when the quantizer tables of a sequence never move: FILMSCAN1 (and anything above 1080p for LOW..HIGH) -- decided by asking the
 // derivation itself whether a large previous sample would change them
 bool quantizer_is_static(const EncodeParams &p)

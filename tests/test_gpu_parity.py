@@ -120,7 +120,17 @@ def test_round_trip_psnr_1080p():
     assert psnr_yuy2(img, f.reshape(h, p)) > 40.0
 
 
-def test_encoder_pool_is_fifo_and_matches_sync():
+@pytest.mark.parametrize("gather", [0, 8])
+def test_encoder_pool_is_fifo_and_matches_sync(gather):
+    """gather: CFHD_AMD_ENCODE_BATCH -- pool workers that encode at the same time share launches (off by default)."""
+    if gather: os.environ["CFHD_AMD_ENCODE_BATCH"] = str(gather)
+    try:
+        _pool_is_fifo_and_matches_sync()
+    finally:
+        os.environ.pop("CFHD_AMD_ENCODE_BATCH", None)
+
+
+def _pool_is_fifo_and_matches_sync():
     L = product()
     w, h = 640, 480
     frames = [synth_yuy2(w, h, 30 + i)[0] for i in range(12)]
