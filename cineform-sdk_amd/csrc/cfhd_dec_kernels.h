@@ -118,6 +118,31 @@ __device__ __forceinline__ DxSym dx_symbol(const uint16_t *s_sym, const uint32_t
 	return s;
 }
 
+// k_dec_index and its helpers look code words up in ONE 32-bit table (a single LDS read per step, nothing that depends on a second one
+// for code words of up to 12 bits): cnt12 and sym12 of the same window side by side.  Bits 0-3 o1 = bits of the first code word, sign bit
+// included (0: longer than 12 bits or invalid -- then bits 16-31 hold the sym12 entry for the second-level lookup), bits 4-7 bits of all
+// whole code words in the window (cnt12), bits 8-19 coefficients the first code word covers, bits 20-31 coefficients all of them cover.
+__device__ __forceinline__ uint32_t dx_tab_entry(const uint32_t c /* cnt12 */, const uint32_t e /* sym12 */)
+{
+	const uint32_t len = e & 15u;
+	if (!len) return e << 16;
+	const uint32_t isval = (e >> 4) & 1u;
+	return (len + isval) | ((c & 15u) << 4) | ((isval ? 1u : (e >> 5)) << 8) | ((c >> 4) << 20);
+}
+// the code word behind a first-level entry without a length (e = its sym12 entry)
+__device__ __forceinline__ DxSym dx_long_symbol(const uint32_t e, const uint32_t *s_long, uint32_t win)
+{
+	DxSym s;
+	if (!(e & 16u)) { s.len = 0; s.type = DX_T_INVALID; s.payload = 0; return s; }
+	uint32_t x = s_long[(e >> 5) + ((win >> (32 - DX_K - DX_L2_BITS)) & ((1u << DX_L2_BITS) - 1u))];
+	if (((x >> 5) & 7u) == DX_T_ESCAPE) {
+		const int nb = (int)(x & 31u);
+		x = s_long[(x >> 8) + ((win << (DX_K + DX_L2_BITS)) >> (32 - nb))];
+	}
+	s.len = (int)(x & 31u); s.type = (int)((x >> 5) & 7u); s.payload = (int)(x >> 8);
+	return s;
+}
+
 // The payload words of a chunk in LDS: staging word i sits at i + i / 8, so that the 64 lanes of a wave, each walking its own 8 words, hit
 // 64 different banks when they move in step (a plain layout puts lanes 4 apart on the same bank).
 __device__ __forceinline__ uint32_t dx_phys(uint32_t i) { return i + (i >> 3); }
@@ -140,6 +165,26 @@ struct DxBits {
 	}
 };
 
+// The same reader with the word for the next refill already in a register: the LDS read that replaces it is issued together with the table
+// lookup of the step (prefetch()) and is not waited for before the step after it, so a step waits for one LDS round trip, not two.
+struct DxBitsAhead {
+	uint64_t acc; int have; uint32_t next, nw;            // nw = staging word `next`
+	__device__ __forceinline__ static uint32_t word(const uint32_t *s_words, uint32_t i) { return s_words[dx_phys(i < (uint32_t)DX_STAGE_WORDS ? i : (uint32_t)DX_STAGE_WORDS - 1u)]; }
+	__device__ __forceinline__ void seek(const uint32_t *s_words, uint32_t pos)
+	{
+		const uint32_t wi = pos >> 5, sh = pos & 31u;
+		acc = (((uint64_t)s_words[dx_phys(wi)] << 32) | s_words[dx_phys(wi + 1)]) << sh;
+		have = 64 - (int)sh; next = wi + 2; nw = word(s_words, next);
+	}
+	__device__ __forceinline__ uint32_t window() const { return (uint32_t)(acc >> 32); }
+	__device__ __forceinline__ uint32_t prefetch(const uint32_t *s_words) const { return word(s_words, next + 1u); }
+	__device__ __forceinline__ void skip(int n, uint32_t ahead /* prefetch() of this step */)
+	{
+		acc <<= n; have -= n;
+		if (have < 32) { acc |= (uint64_t)nw << (32 - have); have += 32; next++; nw = ahead; }
+	}
+};
+
 struct DxLane {                       // state of one lane of k_dec_index
 	uint32_t start, end;              // bit positions in staging coordinates (lane t owns [256 t, 256 t + 256)); end may be DX_END / DX_BAD
 	uint32_t cnt;                     // coefficients covered by the code words that start in the lane's range
@@ -158,8 +203,8 @@ __device__ __forceinline__ uint32_t dx_off_clear_from(uint32_t offs, int k) { co
 // one four times over.
 // A walk may start in front of the lane (a lead-in through the neighbour's last bits, to fall in step before the lane begins): counting starts
 // with the first code word inside the lane, whose position is returned in L.start.
-__device__ __forceinline__ void dx_walk(DxLane &L, uint32_t pos, const bool merge, const uint32_t lane_base, const uint32_t limit, const uint32_t *s_words, const uint16_t *s_cnt,
-                                        const uint16_t *s_sym, const uint32_t *s_long)
+__device__ __forceinline__ void dx_walk(DxLane &L, uint32_t pos, const bool merge, const uint32_t lane_base, const uint32_t limit, const uint32_t *s_words, const uint32_t *s_tab,
+                                        const uint32_t *s_long)
 {
 	uint32_t cnt = 0;
 	L.start = pos;
@@ -167,11 +212,11 @@ __device__ __forceinline__ void dx_walk(DxLane &L, uint32_t pos, const bool merg
 	const uint32_t lane_end = lane_base + DX_LANE_BITS;
 	uint32_t next = lane_base;                            // first bit of the piece the walk has not entered yet
 	int piece = -1;
-	DxBits B;
+	const uint32_t stop = lane_end < limit ? lane_end : limit;
+	DxBitsAhead B;
 	B.seek(s_words, pos);
 	for (;;) {
-		if (pos >= lane_end) { L.end = pos; break; }
-		if (pos >= limit) { L.end = pos; offs = dx_off_clear_from(offs, piece + 1); break; }
+		if (pos >= stop) { L.end = pos; if (pos < lane_end) offs = dx_off_clear_from(offs, piece + 1); break; }      // the end of the lane, or of the payload in front of it
 		if (pos >= next) {
 			// the walk enters a new piece (a code word is shorter than a piece: none is skipped, except in front of a late start)
 			const int k = (int)((pos - lane_base) / DX_SUB_BITS);
@@ -196,13 +241,19 @@ __device__ __forceinline__ void dx_walk(DxLane &L, uint32_t pos, const bool merg
 			piece = k; next = lane_base + (uint32_t)(k + 1) * DX_SUB_BITS;
 		}
 		const uint32_t win = B.window();
-		const uint32_t m = s_cnt[win >> (32 - DX_K)];
-		const uint32_t used = m & 15u;
-		if (used && pos + used <= next) { pos += used; cnt += m >> 4; B.skip(s_words, (int)used); continue; }       // several whole code words, none of them beyond the mark
-		const DxSym s = dx_symbol(s_sym, s_long, win);
-		if (s.type == DX_T_RUN) { pos += (uint32_t)s.len; cnt += (uint32_t)s.payload; B.skip(s_words, s.len); }
-		else if (s.type == DX_T_VALUE) { pos += (uint32_t)s.len + 1u; cnt += 1u; B.skip(s_words, s.len + 1); }
-		else { L.end = s.type == DX_T_END ? DX_END : DX_BAD; offs = dx_off_clear_from(offs, piece + 1); break; }
+		const uint32_t t = s_tab[win >> (32 - DX_K)];
+		const uint32_t ahead = B.prefetch(s_words);
+		const uint32_t used = (t >> 4) & 15u;
+		uint32_t adv = t & 15u, add = (t >> 8) & 0xfffu;      // the first code word ...
+		if (adv) {
+			if (used && pos + used <= next) { adv = used; add = t >> 20; }      // ... or several whole ones, none of them beyond the mark
+		} else {
+			const DxSym s = dx_long_symbol(t >> 16, s_long, win);
+			if (s.type == DX_T_RUN) { adv = (uint32_t)s.len; add = (uint32_t)s.payload; }
+			else if (s.type == DX_T_VALUE) { adv = (uint32_t)s.len + 1u; add = 1u; }
+			else { L.end = s.type == DX_T_END ? DX_END : DX_BAD; offs = dx_off_clear_from(offs, piece + 1); break; }
+		}
+		pos += adv; cnt += add; B.skip((int)adv, ahead);
 	}
 	L.rec_offs = offs;
 	L.cnt = cnt;
@@ -235,7 +286,7 @@ __device__ __forceinline__ void dx_store_stage(const DxFetch &F, uint32_t *s_wor
 // offset a first code word can have; the distinct outcomes (bit offsets into the chunk) are the candidates for the chunk's first code word.
 // Ordinary data leaves one; returns their number (at most DX_MAX_ALT + 2: more than DX_MAX_ALT + 1 means "too many"), 0 when every walk
 // ended on the band end marker or a broken code (the chunk holds padding).
-__device__ __forceinline__ int dx_runin_candidates(const uint32_t bytes, const uint32_t k, const uint32_t runin_bits, const uint32_t *s_words, const uint16_t *s_cnt, const uint16_t *s_sym,
+__device__ __forceinline__ int dx_runin_candidates(const uint32_t bytes, const uint32_t k, const uint32_t runin_bits, const uint32_t *s_words, const uint32_t *s_tab,
                                                    const uint32_t *s_long, uint32_t (&cand)[DX_MAX_ALT + 2])
 {
 	const int lane = wave_lane();
@@ -245,19 +296,25 @@ __device__ __forceinline__ int dx_runin_candidates(const uint32_t bytes, const u
 	const uint32_t limit = left <= 0 ? 0u : (left * 32 > (int64_t)(64 * DX_LANE_BITS + 64) ? (uint32_t)(64 * DX_LANE_BITS + 64) : (uint32_t)(left * 32));
 	uint32_t pos = (uint32_t)DX_LANE_BITS - runin_bits + (uint32_t)lane, end = DX_BAD;
 	if (lane < 27) {
-		DxBits B;
+		DxBitsAhead B;
 		B.seek(s_words, pos);
 		for (;;) {
 			if (pos >= (uint32_t)DX_LANE_BITS) { end = pos; break; }
 			if (pos >= limit) break;
 			const uint32_t win = B.window();
-			const uint32_t m = s_cnt[win >> (32 - DX_K)];
-			const uint32_t used = m & 15u;
-			if (used && pos + used <= (uint32_t)DX_LANE_BITS) { pos += used; B.skip(s_words, (int)used); continue; }
-			const DxSym sy = dx_symbol(s_sym, s_long, win);
-			if (sy.type == DX_T_RUN) { pos += (uint32_t)sy.len; B.skip(s_words, sy.len); }
-			else if (sy.type == DX_T_VALUE) { pos += (uint32_t)sy.len + 1u; B.skip(s_words, sy.len + 1); }
-			else break;
+			const uint32_t t = s_tab[win >> (32 - DX_K)];
+			const uint32_t ahead = B.prefetch(s_words);
+			const uint32_t used = (t >> 4) & 15u;
+			uint32_t adv = t & 15u;
+			if (adv) {
+				if (used && pos + used <= (uint32_t)DX_LANE_BITS) adv = used;
+			} else {
+				const DxSym sy = dx_long_symbol(t >> 16, s_long, win);
+				if (sy.type == DX_T_RUN) adv = (uint32_t)sy.len;
+				else if (sy.type == DX_T_VALUE) adv = (uint32_t)sy.len + 1u;
+				else break;
+			}
+			pos += adv; B.skip((int)adv, ahead);
 		}
 	}
 	unsigned long long mask = __ballot(lane < 27 && end < DX_SPECIAL);
@@ -274,8 +331,8 @@ __device__ __forceinline__ int dx_runin_candidates(const uint32_t bytes, const u
 
 // Index of one staged chunk by one wave from the bit offset (relative to the chunk's first bit) at which its first code word starts; the
 // per-piece entries are written when `entries` is given.  Returns the chunk's record (start, end, count, flags) in every lane.
-__device__ __forceinline__ DxChunkRec dx_index_staged(const uint32_t bytes, const uint32_t gchunk, const uint32_t k, const uint32_t exact_start, const uint32_t *s_words, const uint16_t *s_cnt,
-                                                      const uint16_t *s_sym, const uint32_t *s_long, uint32_t *entries, uint32_t *stats = nullptr)
+__device__ __forceinline__ DxChunkRec dx_index_staged(const uint32_t bytes, const uint32_t gchunk, const uint32_t k, const uint32_t exact_start, const uint32_t *s_words, const uint32_t *s_tab,
+                                                      const uint32_t *s_long, uint32_t *entries, uint32_t *stats = nullptr)
 {
 	const int lane = wave_lane();
 	const uint32_t nwords = bytes >> 2;
@@ -344,7 +401,7 @@ __device__ __forceinline__ DxChunkRec dx_index_staged(const uint32_t bytes, cons
 					for (int i = 0; i < DX_MEMO; i++) if (i == hit) { L.end = memo_e[i]; L.cnt = memo_c[i]; }
 				} else {
 					L.end = rec_end; L.cnt = rec_total;           // a walk that meets the recorded one continues from ITS outcome (a remembered outcome may have replaced it meanwhile)
-					dx_walk(L, want, !finishing && rec_start != DX_BAD, lane_base, limit, s_words, s_cnt, s_sym, s_long);
+					dx_walk(L, want, !finishing && rec_start != DX_BAD, lane_base, limit, s_words, s_tab, s_long);
 					const uint32_t walked = lead ? L.start : want;        // a lead-in reports the first code word inside the lane
 					L.start = walked;
 					rec_start = walked; rec_end = L.end; rec_total = L.cnt;
@@ -382,12 +439,12 @@ __device__ __forceinline__ DxChunkRec dx_index_staged(const uint32_t bytes, cons
 
 // Stage + index from an exact start, not pipelined: the repair and re-index paths (rare; out of line so that it does not weigh on the callers' registers).
 __device__ __attribute__((noinline)) DxChunkRec dx_index_chunk(const uint8_t *bits, const uint32_t bytes, const uint32_t gchunk, const uint32_t k, const uint32_t exact_start, uint32_t *s_words,
-                                                               const uint16_t *s_cnt, const uint16_t *s_sym, const uint32_t *s_long, uint32_t *entries, DxChunkRec *recs, uint32_t *stats)
+                                                               const uint32_t *s_tab, const uint32_t *s_long, uint32_t *entries, DxChunkRec *recs, uint32_t *stats)
 {
 	DxFetch F;
 	dx_fetch_chunk(bits, bytes, k, F);
 	dx_store_stage(F, s_words);
-	const DxChunkRec r = dx_index_staged(bytes, gchunk, k, exact_start, s_words, s_cnt, s_sym, s_long, entries, stats);
+	const DxChunkRec r = dx_index_staged(bytes, gchunk, k, exact_start, s_words, s_tab, s_long, entries, stats);
 	if (wave_lane() == 0 && recs) recs[gchunk] = r;
 	return r;                                             // the same in every lane
 }
@@ -396,6 +453,13 @@ __device__ __forceinline__ void dx_load_tables(const DecIdxTables *T, uint16_t *
 {
 	const uint32_t *c = (const uint32_t *)T->cnt12, *s = (const uint32_t *)T->sym12;
 	for (int i = threadIdx.x; i < (1 << DX_K) / 2; i += blockDim.x) { if (want_cnt) ((uint32_t *)s_cnt)[i] = c[i]; ((uint32_t *)s_sym)[i] = s[i]; }
+	for (int i = threadIdx.x; i < DX_LONG_MAX; i += blockDim.x) s_long[i] = T->long_tab[i];
+}
+
+// the combined first-level table of the index walk (dx_tab_entry) and the long-code table, by the whole workgroup
+__device__ __forceinline__ void dx_load_tab(const DecIdxTables *T, uint32_t *s_tab, uint32_t *s_long)
+{
+	for (int i = threadIdx.x; i < (1 << DX_K); i += blockDim.x) s_tab[i] = dx_tab_entry(T->cnt12[i], T->sym12[i]);
 	for (int i = threadIdx.x; i < DX_LONG_MAX; i += blockDim.x) s_long[i] = T->long_tab[i];
 }
 
@@ -440,10 +504,10 @@ __global__ void __launch_bounds__(DX_THREADS) CFHD_DX_INDEX_ATTR k_dec_index(con
                                                           uint32_t *entries, DxChunkRec *recs, DxChunkAlt *alts, int speculate, uint32_t *stats,
                                                           uint32_t *alt_entries, uint32_t alt_slots, uint32_t *alt_counter)
 {
-	__shared__ uint16_t s_cnt[1 << DX_K], s_sym[1 << DX_K];
+	__shared__ uint32_t s_tab[1 << DX_K];
 	__shared__ uint32_t s_long[DX_LONG_MAX];
 	__shared__ uint32_t s_words_all[DX_WAVES][DX_STAGE_PHYS];
-	dx_load_tables(T, s_cnt, s_sym, s_long, true);
+	dx_load_tab(T, s_tab, s_long);
 	__syncthreads();
 	const uint32_t total = counters[0];
 	const int wave = wave_uniform((int)(threadIdx.x >> 6));
@@ -471,15 +535,15 @@ __global__ void __launch_bounds__(DX_THREADS) CFHD_DX_INDEX_ATTR k_dec_index(con
 		int n = 1;
 		if (d.k != 0 && speculate) {
 			// the last 96 bits settle ordinary data; only when they leave more than one candidate the whole 256 are walked
-			n = dx_runin_candidates(d.bytes, d.k, DX_RUNIN_SHORT, s_words, s_cnt, s_sym, s_long, cand);
-			if (n != 1) n = dx_runin_candidates(d.bytes, d.k, DX_LANE_BITS, s_words, s_cnt, s_sym, s_long, cand);
+			n = dx_runin_candidates(d.bytes, d.k, DX_RUNIN_SHORT, s_words, s_tab, s_long, cand);
+			if (n != 1) n = dx_runin_candidates(d.bytes, d.k, DX_LANE_BITS, s_words, s_tab, s_long, cand);
 		}
 		if (n == 0) {                                        // behind the band end marker: padding
 			if (wave_lane() == 0) recs[c] = DxChunkRec{ (uint32_t)DX_END, (uint32_t)DX_END, 0u, (uint32_t)DX_FLAG_END | (1u << 8) };
 		} else {
 			const bool unresolved = n > DX_MAX_ALT + 1;
 			if (unresolved) n = 1;
-			DxChunkRec r = dx_index_staged(d.bytes, c, d.k, cand[0], s_words, s_cnt, s_sym, s_long, entries, stats);
+			DxChunkRec r = dx_index_staged(d.bytes, c, d.k, cand[0], s_words, s_tab, s_long, entries, stats);
 			r.flags |= ((uint32_t)n << 8) | (unresolved ? (uint32_t)DX_FLAG_UNRESOLVED : 0u);
 			if (wave_lane() == 0) recs[c] = r;
 			if (n > 1) {
@@ -497,7 +561,7 @@ __global__ void __launch_bounds__(DX_THREADS) CFHD_DX_INDEX_ATTR k_dec_index(con
 				a.slot = slot0;
 #pragma unroll 1
 				for (int i = 1; i < n; i++) {
-					const DxChunkRec ri = dx_index_staged(d.bytes, slot0 == (uint32_t)DX_BAD ? c : slot0 + (uint32_t)(i - 1), d.k, cand[i], s_words, s_cnt, s_sym, s_long,
+					const DxChunkRec ri = dx_index_staged(d.bytes, slot0 == (uint32_t)DX_BAD ? c : slot0 + (uint32_t)(i - 1), d.k, cand[i], s_words, s_tab, s_long,
 					                                      slot0 == (uint32_t)DX_BAD ? nullptr : alt_entries, nullptr);
 #pragma unroll
 					for (int q = 0; q < DX_MAX_ALT; q++) if (q == i - 1) { a.start[q] = ri.start; a.end[q] = ri.end; a.count[q] = ri.count; }
@@ -515,11 +579,10 @@ __global__ void __launch_bounds__(DX_THREADS) CFHD_DX_INDEX_ATTR k_dec_index(con
 
 // The tables for a wave that has to repair a chunk: loaded by that wave alone, no workgroup barrier (another wave of the workgroup doing the
 // same writes the same words).
-__device__ __forceinline__ void dx_load_tables_wave(const DecIdxTables *T, uint16_t *s_cnt, uint16_t *s_sym, uint32_t *s_long)
+__device__ __forceinline__ void dx_load_tables_wave(const DecIdxTables *T, uint32_t *s_tab, uint32_t *s_long)
 {
 	const int lane = wave_lane();
-	const uint32_t *c = (const uint32_t *)T->cnt12, *s = (const uint32_t *)T->sym12;
-	for (int i = lane; i < (1 << DX_K) / 2; i += 64) { ((uint32_t *)s_cnt)[i] = c[i]; ((uint32_t *)s_sym)[i] = s[i]; }
+	for (int i = lane; i < (1 << DX_K); i += 64) s_tab[i] = dx_tab_entry(T->cnt12[i], T->sym12[i]);
 	for (int i = lane; i < DX_LONG_MAX; i += 64) s_long[i] = T->long_tab[i];
 }
 
@@ -528,7 +591,7 @@ __device__ __forceinline__ void dx_load_tables_wave(const DecIdxTables *T, uint1
 // that is not the one its entries were written for).  A chunk none of whose candidates is true -- more candidates than k_dec_index keeps -- is
 // indexed again on the spot when REPAIR is set; otherwise the band is only reported (false) and left to k_dec_repair.
 template <bool REPAIR>
-__device__ __forceinline__ bool dx_chain_band(const DxBandJob &job, const int j, const DecIdxTables *T, uint16_t *s_cnt, uint16_t *s_sym, uint32_t *s_long, uint32_t *s_words,
+__device__ __forceinline__ bool dx_chain_band(const DxBandJob &job, const int j, const DecIdxTables *T, uint32_t *s_tab, uint32_t *s_long, uint32_t *s_words,
                                               uint32_t *entries, DxChunkRec *recs, const DxChunkAlt *alts, uint32_t *chunk_base, DxBandSum *sums, int *errors,
                                               DxReindex *reindex_list, uint32_t *counters, uint32_t *stats)
 {
@@ -575,9 +638,9 @@ __device__ __forceinline__ bool dx_chain_band(const DxBandJob &job, const int j,
 						if (lane == 0) reindex_list[atomicAdd(&counters[2], 1u)] = DxReindex{ job.chunk0 + c0 + (uint32_t)i, c0 + (uint32_t)i, cur, j };
 					} else {
 						if (!REPAIR) return false;
-						if (!tables) { dx_load_tables_wave(T, s_cnt, s_sym, s_long); tables = true; CFHD_WAVE_SYNC(); }
+						if (!tables) { dx_load_tables_wave(T, s_tab, s_long); tables = true; CFHD_WAVE_SYNC(); }
 						if (stats && lane == 0) atomicAdd(&stats[3], 1u);
-						const DxChunkRec rr = dx_index_chunk(job.bits, job.bytes, job.chunk0 + c0 + (uint32_t)i, c0 + (uint32_t)i, cur, s_words, s_cnt, s_sym, s_long, entries, recs, nullptr);
+						const DxChunkRec rr = dx_index_chunk(job.bits, job.bytes, job.chunk0 + c0 + (uint32_t)i, c0 + (uint32_t)i, cur, s_words, s_tab, s_long, entries, recs, nullptr);
 						e = rr.end; cn = rr.count;
 					}
 				}
@@ -612,7 +675,7 @@ __global__ void __launch_bounds__(DX_THREADS) k_dec_chain(const DxBandJob *jobs,
 	const int j = (int)blockIdx.x * DX_WAVES + wave_uniform((int)(threadIdx.x >> 6));
 	if (j >= njobs) return;
 	const DxBandJob job = jobs[j];
-	if (!dx_chain_band<false>(job, j, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, (DxChunkRec *)recs, alts, chunk_base, sums, errors, reindex_list, counters, nullptr) && wave_lane() == 0)
+	if (!dx_chain_band<false>(job, j, nullptr, nullptr, nullptr, nullptr, nullptr, (DxChunkRec *)recs, alts, chunk_base, sums, errors, reindex_list, counters, nullptr) && wave_lane() == 0)
 		repair_list[atomicAdd(&counters[1], 1u)] = (uint32_t)j;
 }
 
@@ -620,7 +683,7 @@ __global__ void __launch_bounds__(DX_THREADS) k_dec_chain(const DxBandJob *jobs,
 __global__ void __launch_bounds__(DX_THREADS) k_dec_repair(const DxBandJob *jobs, const DecIdxTables *T, uint32_t *entries, DxChunkRec *recs, const DxChunkAlt *alts, uint32_t *chunk_base,
                                                            DxBandSum *sums, int *errors, const uint32_t *repair_list, DxReindex *reindex_list, uint32_t *counters, uint32_t *stats)
 {
-	__shared__ uint16_t s_cnt[1 << DX_K], s_sym[1 << DX_K];
+	__shared__ uint32_t s_tab[1 << DX_K];
 	__shared__ uint32_t s_long[DX_LONG_MAX];
 	__shared__ uint32_t s_words_all[DX_WAVES][DX_STAGE_PHYS];
 	const uint32_t n = counters[1];
@@ -628,7 +691,7 @@ __global__ void __launch_bounds__(DX_THREADS) k_dec_repair(const DxBandJob *jobs
 	for (uint32_t i = (uint32_t)blockIdx.x * DX_WAVES + (uint32_t)wave; i < n; i += (uint32_t)gridDim.x * DX_WAVES) {
 		const int j = (int)repair_list[i];
 		const DxBandJob job = jobs[j];
-		(void)dx_chain_band<true>(job, j, T, s_cnt, s_sym, s_long, s_words_all[wave], entries, recs, alts, chunk_base, sums, errors, reindex_list, counters, stats);
+		(void)dx_chain_band<true>(job, j, T, s_tab, s_long, s_words_all[wave], entries, recs, alts, chunk_base, sums, errors, reindex_list, counters, stats);
 	}
 }
 
@@ -637,7 +700,7 @@ __global__ void __launch_bounds__(DX_THREADS) k_dec_repair(const DxBandJob *jobs
 __global__ void __launch_bounds__(DX_THREADS) k_dec_reindex(const DxBandJob *jobs, const DecIdxTables *T, uint32_t *entries, const DxReindex *reindex_list, const uint32_t *counters, uint32_t *stats,
                                                             const DxChunkAlt *alts, const uint32_t *alt_entries)
 {
-	__shared__ uint16_t s_cnt[1 << DX_K], s_sym[1 << DX_K];
+	__shared__ uint32_t s_tab[1 << DX_K];
 	__shared__ uint32_t s_long[DX_LONG_MAX];
 	__shared__ uint32_t s_words_all[DX_WAVES][DX_STAGE_PHYS];
 	const uint32_t n = counters[2];
@@ -661,9 +724,9 @@ __global__ void __launch_bounds__(DX_THREADS) k_dec_reindex(const DxBandJob *job
 				continue;
 			}
 		}
-		if (!tables) { dx_load_tables_wave(T, s_cnt, s_sym, s_long); tables = true; CFHD_WAVE_SYNC(); }
+		if (!tables) { dx_load_tables_wave(T, s_tab, s_long); tables = true; CFHD_WAVE_SYNC(); }
 		const DxBandJob job = jobs[x.job];
-		dx_index_chunk(job.bits, job.bytes, x.chunk, x.k, x.start, s_words_all[wave], s_cnt, s_sym, s_long, entries, nullptr, nullptr);
+		dx_index_chunk(job.bits, job.bytes, x.chunk, x.k, x.start, s_words_all[wave], s_tab, s_long, entries, nullptr, nullptr);
 		if (stats && wave_lane() == 0) atomicAdd(&stats[3], 1u << 8);
 	}
 }
