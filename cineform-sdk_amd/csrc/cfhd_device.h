@@ -39,6 +39,7 @@ public:
 	GpuEntropyEncoder &entropy() { return ent_; }
 	bool has_entropy() const { return ent_ready_; }
 	bool strip_forward() const;                     // level 1 of 4:2:2 runs as k_fwd_yuv422_strip (else k_fwd_yuv422)
+	bool strip_forward_packed16() const;            // level 1 of RG48 / b64a runs as k_fwd_packed16_strip (else k_fwd_packed16)
 	const char *level_kernel(int level) const;      // name of the kernel the next launch_forward() uses for level 0 / 1 / 2 (as a profiler shows it)
 	int download_coeffs();                             // async: final (entropy coded) region of every frame -> pinned host
 	int wait();

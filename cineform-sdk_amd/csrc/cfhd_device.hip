@@ -429,11 +429,29 @@ bool EncodeBatch::strip_forward() const
 	return true;
 }
 
+// k_fwd_packed16_strip serves RG48 / b64a frames of whole 8-pixel blocks whose rows are 16-byte aligned, from the launch size on at which
+// the strip kernels pay (as strip_forward()); everything else takes the LDS-tiled k_fwd_packed16.
+bool EncodeBatch::strip_forward_packed16() const
+{
+	static const int forced = shape_override("CFHD_AMD_FORWARD");
+	const int act = active_ > 0 && active_ < n_ ? active_ : n_;
+	if (forced == 1 || (forced == 0 && frames_1080p_equivalent(plan_, act) < 32.0)) return false;
+	if (!is_packed16(plan_.pixel_kind) || plan_.width % 8 || plan_.num_channels < 3) return false;
+	EncJobs j = enc_jobs_at(h_jobs_, n_, plan_.num_channels);
+	for (int i = 0; i < n_; i++) {
+		const dev::FwdPlaneJob &p = j.l1[(size_t)i * plan_.num_channels];
+		const uintptr_t frame = (uintptr_t)((const uint16_t *)p.in - packed_word_of_channel(plan_.pixel_kind, 0));
+		if ((frame & 15) || ((p.in_pitch * 2) & 15) || p.layout != 0 || p.width % 8) return false;
+	}
+	return true;
+}
+
 const char *EncodeBatch::level_kernel(int level) const
 {
 	const int act = active_ > 0 && active_ < n_ ? active_ : n_;
 	if (level > 0) return planes_as_strips(plan_, level, act) ? "k_fwd_plane_strip" : "k_fwd_plane";
 	if (plan_.pixel_kind == PIX_BYR4) return "k_unpack_byr4+k_fwd_plane";
+	if (strip_forward_packed16()) return "k_fwd_packed16_strip";
 	if (enc_packed16(plan_.pixel_kind)) return "k_fwd_packed16";
 	if (plan_.interlaced) return "k_fwd_frame_yuv422";
 	return strip_forward() ? "k_fwd_yuv422_strip" : "k_fwd_yuv422";
@@ -454,6 +472,12 @@ int EncodeBatch::launch_forward()
 		dev::k_unpack_byr4<<<dim3((plan_.width + dev::NTHREADS - 1) / dev::NTHREADS, plan_.height, act), dev::NTHREADS, 0, st>>>(j.bayer);
 		dim3 grid((plan_.width / 2 + dev::TW - 1) / dev::TW, (plan_.height / 2 + dev::TH - 1) / dev::TH, act * nch);
 		dev::k_fwd_plane<<<grid, dev::NTHREADS, 0, st>>>(j.l1);
+	} else if (strip_forward_packed16()) {
+		const int nseg = (plan_.width / 8 + dev::PSTEP - 1) / dev::PSTEP, nstrips = (plan_.height / 2 + dev::PSR - 1) / dev::PSR, waves = act * nseg * nstrips;
+		const dim3 grid((waves + 3) / 4);
+		if (plan_.pixel_kind == PIX_RG48) dev::k_fwd_packed16_strip<3, 3><<<grid, dev::NTHREADS, 0, st>>>(j.l1, act, nseg, nstrips);
+		else if (nch == 4) dev::k_fwd_packed16_strip<4, 4><<<grid, dev::NTHREADS, 0, st>>>(j.l1, act, nseg, nstrips);
+		else dev::k_fwd_packed16_strip<4, 3><<<grid, dev::NTHREADS, 0, st>>>(j.l1, act, nseg, nstrips);
 	} else if (enc_packed16(plan_.pixel_kind)) {
 		dim3 grid(((plan_.width / 2 + dev::TW - 1) / dev::TW) * nch, (plan_.height / 2 + dev::TH - 1) / dev::TH, act);
 		dev::k_fwd_packed16<<<grid, dev::NTHREADS, 0, st>>>(j.l1, nch);

@@ -1335,11 +1335,12 @@ __global__ void __launch_bounds__(NTHREADS) k_inv_plane_strip(const InvPlaneJob 
 }
 
 // Vertical 2/6 analysis + quantizer of one band row from the six-row window (shared by the strip kernels).
-__device__ __forceinline__ void strip_fwd_emit(const uint32_t (&LW)[6][4], const uint32_t (&HW)[6][4], int pos, const QuantParam &q_lh, const QuantParam &q_hl, const QuantParam &q_hh,
-                                               uint32_t (&o)[4][4])
+template <int ND>
+__device__ __forceinline__ void strip_fwd_emit(const uint32_t (&LW)[6][ND], const uint32_t (&HW)[6][ND], int pos, const QuantParam &q_lh, const QuantParam &q_hl, const QuantParam &q_hh,
+                                               uint32_t (&o)[4][ND])
 {
 #pragma unroll
-	for (int d = 0; d < 4; d++) {
+	for (int d = 0; d < ND; d++) {
 		uint32_t ll, lh, hl, hh;
 		if (pos == 1) {
 			ll = pk_adds(LW[2][d], LW[3][d]); hl = pk_hp_mid(LW[0][d], LW[1][d], LW[2][d], LW[3][d], LW[4][d], LW[5][d]);
@@ -1420,6 +1421,137 @@ __global__ void __launch_bounds__(NTHREADS) k_fwd_plane_strip(const FwdPlaneJob 
 			v.x = o[1][0]; v.y = o[1][1]; v.z = o[1][2]; v.w = o[1][3]; *(uint4 *)(out1 + at) = v;
 			v.x = o[2][0]; v.y = o[2][1]; v.z = o[2][2]; v.w = o[2][3]; *(uint4 *)(out2 + at) = v;
 			v.x = o[3][0]; v.y = o[3][1]; v.z = o[3][2]; v.w = o[3][3]; *(uint4 *)(out3 + at) = v;
+		}
+	}
+}
+
+// =============================================================================================
+// k_fwd_packed16_strip: level 1 of RG48 / b64a (interleaved 16-bit pixels, FwdPlaneJob layout 0) in the register-strip organisation.
+// One lane = 8 pixels of every picture row of its strip, ALL component planes: WPP 16-byte loads bring the pixels in once, the components
+// are cut out of the registers (constant word positions), and every plane runs the horizontal 2/6 analysis of its 4 sample pairs
+// (neighbour pairs from the adjacent lanes) into its own six-row window; every second row the vertical analysis + quantizer emits one row
+// of LL, LH, HL, HH per plane, 8 bytes per band.  A wave covers a segment of 62 blocks (lanes 0 and 63 only feed their neighbours) and
+// PSR band rows; no LDS, no barriers.  Same arithmetic as k_fwd_packed16 (tested against it), which stays for other geometries, small
+// launches and the other word layouts.  Geometry served: width % 8 == 0, 16-byte aligned rows.
+// WPP words per pixel, NCH planes: RG48 (3, 3): planes G R B = words 1 0 2; b64a (4, 4): planes G R B A = words 2 1 3 0; b64a to RGB 4:4:4 (4, 3).
+// =============================================================================================
+enum { PSR = 32, PSTEP = 62 };
+template <int WPP> __device__ __forceinline__ constexpr int packed16_word(int c) { return WPP == 3 ? (c == 0 ? 1 : (c == 1 ? 0 : 2)) : (c == 0 ? 2 : (c == 1 ? 1 : (c == 2 ? 3 : 0))); }
+
+template <int WPP> struct PxRows { cfhd_u4 v[2][WPP]; };     // the lane's 8 pixels of two picture rows
+template <int WPP>
+__device__ __forceinline__ void px_fetch(PxRows<WPP> &R, const uint16_t *px, int in_pitch, int y, int display_height)
+{
+#pragma unroll
+	for (int k = 0; k < 2; k++) {
+		const int yy = y + k < display_height ? y + k : display_height - 1;     // rows beyond the picture repeat the last one (frame.c:6020-6024)
+		const uint16_t *p = px + (size_t)yy * in_pitch;
+#pragma unroll
+		for (int j = 0; j < WPP; j++) R.v[k][j] = CFHD_LDG128(p + 8 * j);
+	}
+}
+// sample pair m (pixels 2m, 2m + 1) of the component at word `word` of every pixel, >> shift
+template <int WPP>
+__device__ __forceinline__ uint32_t px_pair(const uint32_t (&w)[4 * WPP], int m, int word, int shift, bool compand)
+{
+	uint32_t s[2];
+#pragma unroll
+	for (int e = 0; e < 2; e++) {
+		const int i = (2 * m + e) * WPP + word;           // 16-bit word of the lane's row
+		const uint32_t d = w[i >> 1];
+		s[e] = (i & 1) ? d >> (16 + shift) : (d & 0xffffu) >> shift;
+		if (compand && s[e] > 0 && s[e] < 4095) s[e] = ((s[e] * 223 + 128) >> 8) + 256;     // alpha, frame.c:6696-6707
+	}
+	return s[0] | (s[1] << 16);
+}
+// Two picture rows of every plane -> window slots SLOT, SLOT + 1
+template <int WPP, int NCH, int SLOT>
+__device__ __forceinline__ void px_push(uint32_t (&LW)[NCH][6][2], uint32_t (&HW)[NCH][6][2], const PxRows<WPP> &R, int shift, bool compand_alpha, int prescale, int lane, bool first, bool last)
+{
+#pragma unroll
+	for (int k = 0; k < 2; k++) {
+		uint32_t w[4 * WPP];
+#pragma unroll
+		for (int j = 0; j < WPP; j++) { w[4 * j] = R.v[k][j].x; w[4 * j + 1] = R.v[k][j].y; w[4 * j + 2] = R.v[k][j].z; w[4 * j + 3] = R.v[k][j].w; }
+#pragma unroll
+		for (int c = 0; c < NCH; c++) {
+			uint32_t ext[6];
+#pragma unroll
+			for (int m = 0; m < 4; m++) ext[1 + m] = px_pair<WPP>(w, m, packed16_word<WPP>(c), shift, compand_alpha && c == 3);
+			ext[0] = __shfl(ext[4], lane - 1); ext[5] = __shfl(ext[1], lane + 1);
+#pragma unroll
+			for (int m = 0; m < 2; m++) horiz_pair(&ext[2 * m], 0u, prescale, first && m == 0, false, last && m == 1, LW[c][SLOT + k][m], HW[c][SLOT + k][m]);
+		}
+	}
+}
+
+// Two waves per SIMD (180 / 236 registers, nothing spilled) with the next rows' loads in flight beat three or four waves with spills:
+// RG48 1.09 vs 1.28 / 3.15 ms per 48 4K frames, b64a 1.03 vs 2.87 ms per 8 8K frames (the tiled kernel: 1.90 / 2.18 ms).
+#ifndef CFHD_PX_WAVES
+#define CFHD_PX_WAVES 2
+#endif
+template <int WPP, int NCH>
+__global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(CFHD_PX_WAVES, CFHD_PX_WAVES))) k_fwd_packed16_strip(const FwdPlaneJob *jobs, int nframes, int nseg, int nstrips)
+{
+	const int lane = threadIdx.x & 63, gwave = (int)blockIdx.x * (NTHREADS / 64) + wave_uniform((int)(threadIdx.x >> 6));     // (scalar: the job fields stay out of the vector registers)
+	const int seg = gwave % nseg, strip = (gwave / nseg) % nstrips, frame = gwave / (nseg * nstrips);
+	if (frame >= nframes) return;                         // whole wave
+	const FwdPlaneJob *job = jobs + (size_t)frame * NCH;
+	const int W = job->width, H = job->height, HH = H >> 1, nblk = W / 8;
+	const int b = seg * PSTEP - 1 + lane;
+	const bool stores = b >= 0 && b < nblk && lane >= 1 && lane <= PSTEP;
+	const int blk = b < 0 ? 0 : (b >= nblk ? nblk - 1 : b);
+	const bool first = blk == 0, last = blk == nblk - 1;
+	const int in_pitch = job->in_pitch, shift = job->shift, dh = job->display_height, prescale = job->prescale, out_pitch = job->out_pitch;
+	const bool compand_alpha = NCH == 4 && job[NCH - 1].compand;
+	const uint16_t *px = (const uint16_t *)job->in - packed16_word<WPP>(0) + (size_t)blk * 8 * WPP;
+	const int r0 = strip * PSR, r1 = r0 + PSR < HH ? r0 + PSR : HH;
+	QuantParam q[NCH][3];
+	int16_t *out[NCH][4];
+#pragma unroll
+	for (int c = 0; c < NCH; c++) {
+#pragma unroll
+		for (int k = 0; k < 3; k++) q[c][k] = job[c].q[1 + k];
+#pragma unroll
+		for (int k = 0; k < 4; k++) out[c][k] = job[c].out[k];      // (wave-uniform: scalar registers; the lane's place goes into the 32-bit offset below)
+	}
+	uint32_t LW[NCH][6][2], HW[NCH][6][2];
+	int wtop = window_first_row(r0, HH, H);
+	PxRows<WPP> R;
+	px_fetch<WPP>(R, px, in_pitch, wtop, dh);
+	px_push<WPP, NCH, 0>(LW, HW, R, shift, compand_alpha, prescale, lane, first, last);
+	px_fetch<WPP>(R, px, in_pitch, wtop + 2, dh);
+	px_push<WPP, NCH, 2>(LW, HW, R, shift, compand_alpha, prescale, lane, first, last);
+	px_fetch<WPP>(R, px, in_pitch, wtop + 4, dh);
+	px_push<WPP, NCH, 4>(LW, HW, R, shift, compand_alpha, prescale, lane, first, last);
+	// the rows of the next window step are fetched a band row ahead of their use
+	int fetched = -1;
+	for (int r = r0; r < r1; r++) {
+		const int need = window_first_row(r, HH, H);
+		if (need != wtop) {
+			if (fetched != need + 4) px_fetch<WPP>(R, px, in_pitch, need + 4, dh);
+#pragma unroll
+			for (int c = 0; c < NCH; c++) {
+#pragma unroll
+				for (int k = 0; k < 4; k++) { LW[c][k][0] = LW[c][k + 2][0]; LW[c][k][1] = LW[c][k + 2][1]; HW[c][k][0] = HW[c][k + 2][0]; HW[c][k][1] = HW[c][k + 2][1]; }
+			}
+			wtop = need;
+			px_push<WPP, NCH, 4>(LW, HW, R, shift, compand_alpha, prescale, lane, first, last);
+		}
+		if (r + 1 < r1) {
+			const int next_need = window_first_row(r + 1, HH, H);
+			if (next_need != wtop) { px_fetch<WPP>(R, px, in_pitch, next_need + 4, dh); fetched = next_need + 4; }
+		}
+		const int pos = r == 0 ? 0 : (r == HH - 1 ? 2 : 1);
+		const uint32_t at = ((uint32_t)r * (uint32_t)out_pitch + (uint32_t)blk * 4u) * 2u;     // bytes into the band
+#pragma unroll
+		for (int c = 0; c < NCH; c++) {
+			uint32_t o[4][2];
+			strip_fwd_emit<2>(LW[c], HW[c], pos, q[c][0], q[c][1], q[c][2], o);
+			if (stores) {
+#pragma unroll
+				for (int bnd = 0; bnd < 4; bnd++) { uint2 v; v.x = o[bnd][0]; v.y = o[bnd][1]; *(uint2 *)((char *)out[c][bnd] + at) = v; }
+			}
 		}
 	}
 }

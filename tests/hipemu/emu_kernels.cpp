@@ -49,6 +49,33 @@ void emu_fwd_packed16(const uint16_t *in, int in_pitch_words, int width, int hei
 	hipemu::launch(grid, dim3(NTHREADS), [&] { k_fwd_packed16(jobs.data(), nch); });
 }
 
+// The same level through k_fwd_packed16 (which = 0) or k_fwd_packed16_strip (which = 1): RG48 (wpp 3) / b64a (wpp 4, nch 4 or 3) with the
+// word order EncodeBatch::fill_jobs uses.  The two kernels have to agree bit for bit.
+void emu_fwd_packed16_shapes(int which, const uint16_t *in, int in_pitch_words, int width, int height, int display_height, int wpp, int nch, int shift, int compand_alpha,
+                             const int *quant, int mpq, int16_t **out, int out_pitch)
+{
+	static const int rg48[4] = { 1, 0, 2, 3 }, b64a[4] = { 2, 1, 3, 0 };
+	std::vector<FwdPlaneJob> jobs(nch);
+	for (int c = 0; c < nch; c++) {
+		FwdPlaneJob &job = jobs[c];
+		memset(&job, 0, sizeof(job));
+		job.in = (const int16_t *)(in + (wpp == 3 ? rg48 : b64a)[c]); job.in_pitch = in_pitch_words; job.width = width; job.height = height; job.prescale = 0;
+		job.xstride = wpp; job.shift = shift; job.display_height = display_height; job.compand = compand_alpha && c == 3;
+		for (int b = 0; b < 4; b++) { job.out[b] = out[c * 4 + b]; job.q[b] = make_q(quant[c * 4 + b], mpq); }
+		job.out_pitch = out_pitch;
+	}
+	if (!which) {
+		dim3 grid(((width / 2 + TW - 1) / TW) * nch, (height / 2 + TH - 1) / TH, 1);
+		hipemu::launch(grid, dim3(NTHREADS), [&] { k_fwd_packed16(jobs.data(), nch); });
+		return;
+	}
+	const int nseg = (width / 8 + PSTEP - 1) / PSTEP, nstrips = (height / 2 + PSR - 1) / PSR, waves = nseg * nstrips;
+	const dim3 grid((waves + 3) / 4);
+	if (wpp == 3) hipemu::launch(grid, dim3(NTHREADS), [&] { k_fwd_packed16_strip<3, 3>(jobs.data(), 1, nseg, nstrips); });
+	else if (nch == 4) hipemu::launch(grid, dim3(NTHREADS), [&] { k_fwd_packed16_strip<4, 4>(jobs.data(), 1, nseg, nstrips); });
+	else hipemu::launch(grid, dim3(NTHREADS), [&] { k_fwd_packed16_strip<4, 3>(jobs.data(), 1, nseg, nstrips); });
+}
+
 // Level 1 of a 4:2:2 frame from 16-bit words Y0 C1 Y1 C2 (YU64): the same kernel with per-channel first word, stride and width, as
 // EncodeBatch::fill_jobs sets it up.  quant[c*4+b], out[c*4+b]; out_pitch[c].
 void emu_fwd_yu64(const uint16_t *in, int in_pitch_words, int width, int height, int display_height, const int *quant, int mpq, int16_t **out, const int *out_pitch)

@@ -440,6 +440,30 @@ def test_fwd_packed16_level1_of_444_formats(w, h, dh, nch):
             assert np.array_equal(outs[4 * c + b][:, :w // 2], want[b][:, :w // 2]), (c, b)
 
 
+@pytest.mark.parametrize("w,h,dh,wpp,nch", [(8, 8, 8, 3, 3), (16, 16, 16, 4, 4), (72, 24, 21, 3, 3), (496, 16, 16, 3, 3), (504, 72, 70, 4, 4), (1000, 40, 40, 4, 3),
+                                            (1024, 136, 131, 3, 3), (136, 8, 8, 4, 4)])
+def test_fwd_packed16_strip_equals_the_tiled_kernel(w, h, dh, wpp, nch):
+    """k_fwd_packed16_strip (register strips: a lane = 8 pixels of all planes, segments of 62 blocks, strips of 32 band rows) writes the
+    same bands as k_fwd_packed16 (checked against the oracle above): one / several segments and strips, the lanes at the borders, rows
+    below the display height, companded alpha, b64a pixels with three planes."""
+    rng = np.random.default_rng(w * 7 + h + wpp + nch)
+    px = rng.integers(0, 65536, size=(dh, w, wpp), dtype=np.int64).astype(np.uint16)
+    if wpp == 4: px[::3, ::5, 0] = 0; px[1::4, 2::7, 0] = 65535; px[2::5, 1::3, 0] >>= 6
+    quant = [1, 12, 12, 24, 1, 8, 24, 36, 1, 12, 6, 48, 1, 24, 12, 12][:4 * nch]
+    pitch = (w // 2 + 7) // 8 * 8
+    E = emu()
+    E.emu_fwd_packed16_shapes.argtypes = [ctypes.c_int, ctypes.c_void_p] + [ctypes.c_int] * 8 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    got = []
+    for which in (0, 1):
+        outs = [np.full((h // 2, pitch), -7, np.int16) for _ in range(4 * nch)]
+        ptrs = (c_i16p * (4 * nch))(*[p16(o) for o in outs])
+        E.emu_fwd_packed16_shapes(which, px.ctypes.data_as(ctypes.c_void_p), w * wpp, w, h, dh, wpp, nch, 4, int(nch == 4), iarr(quant), 2, ptrs, pitch)
+        got.append(outs)
+    for k in range(4 * nch):
+        assert np.array_equal(got[0][k][:, :w // 2], got[1][k][:, :w // 2]), (k // 4, k % 4)
+        assert (got[1][k][:, w // 2:] == -7).all()            # nothing written beside the band
+
+
 @pytest.mark.parametrize("w,h,dh,nch,b64a", [(16, 8, 16, 3, 0), (68, 20, 37, 3, 0), (96, 33, 66, 4, 0), (160, 17, 34, 3, 0), (96, 33, 66, 4, 1), (40, 9, 17, 4, 1)])
 def test_inv_packed16_last_level_of_444_formats(w, h, dh, nch, b64a):
     """k_inv_packed16 = oracle RG48 / RG64 / b64a reconstruction (pinned against the reference decoder in test_oracle_vs_ref): exact, incl.
