@@ -87,6 +87,7 @@ public:
 	GpuEntropyDecoder &entropy() { return ent_; }
 	bool has_entropy() const { return ent_ready_; }
 	bool strip_inverse() const;                     // the last level of 4:2:2 runs as k_inv_yuv422_strip (else k_inv_yuv422)
+	bool strip_inverse_packed16() const;            // the last level of RG48 / b64a output runs as k_inv_packed16_strip (else k_inv_packed16)
 	bool frame_inverse_quads() const;               // interlaced samples: k_inv_frame_yuv422_quad (else k_inv_frame_yuv422)
 	const char *level_kernel(int level) const;      // name of the kernel the next launch_inverse() uses for level 0 / 1 / 2
 	int set_device_output(int i, void *d_out, int pitch_bytes);

@@ -695,6 +695,23 @@ bool DecodeBatch::strip_inverse() const
 	return true;
 }
 
+// k_inv_packed16_strip serves RG48 / b64a output of whole 8-pixel blocks whose rows are 16-byte aligned, from the launch size on at which the
+// strip kernels pay; everything else takes the LDS-tiled k_inv_packed16.
+bool DecodeBatch::strip_inverse_packed16() const
+{
+	static const int forced = shape_override("CFHD_AMD_INVERSE");
+	const int act = active_ > 0 && active_ < n_ ? active_ : n_;
+	if (forced == 1 || (forced == 0 && frames_1080p_equivalent(plan_, act) < 12.0)) return false;
+	if (!is_packed16(out_kind_) || half_ || plan_.ch[0].band[0][0].width % 4) return false;
+	DecJobs j = dec_jobs_at(h_jobs_, n_, plan_.num_channels);
+	for (int i = 0; i < n_; i++) {
+		const dev::InvPlaneJob &p = j.l1[(size_t)i * plan_.num_channels];
+		const uintptr_t frame = (uintptr_t)((const uint16_t *)p.out - packed_word_of_channel(out_kind_, 0));
+		if ((frame & 15) || ((p.out_pitch * 2) & 15) || (p.band_pitch & 3)) return false;
+	}
+	return true;
+}
+
 // k_inv_frame_yuv422_quad: four band columns per thread with 8-byte loads and 16-byte stores (CFHD_AMD_INVERSE=tile: the one-column kernel)
 bool DecodeBatch::frame_inverse_quads() const
 {
@@ -712,7 +729,7 @@ const char *DecodeBatch::level_kernel(int level) const
 	const int act = active_ > 0 && active_ < n_ ? active_ : n_;
 	if (level > 0) return planes_as_strips(plan_, level, act) ? "k_inv_plane_strip" : "k_inv_plane";
 	if (half_) return is_packed16(out_kind_) ? "k_half_packed16" : "k_half_yuv422";
-	if (is_packed16(out_kind_)) return "k_inv_packed16";
+	if (is_packed16(out_kind_)) return strip_inverse_packed16() ? "k_inv_packed16_strip" : "k_inv_packed16";
 	if (interlaced_) return frame_inverse_quads() ? "k_inv_frame_yuv422_quad" : "k_inv_frame_yuv422";
 	return strip_inverse() ? "k_inv_yuv422_strip" : "k_inv_yuv422";
 }
@@ -751,6 +768,11 @@ int DecodeBatch::launch_inverse(uint32_t dither_seed)
 	} else if (half_) {
 		const BandDesc &b = plan_.ch[0].band[0][0];
 		dev::k_half_yuv422<<<dim3((b.width / 8 + dev::NTHREADS - 1) / dev::NTHREADS, out_rows_, act), dev::NTHREADS, 0, st>>>(j.half);
+	} else if (strip_inverse_packed16()) {
+		const BandDesc &b = plan_.ch[0].band[0][0];
+		const int nseg = (b.width / 4 + dev::PSTEP - 1) / dev::PSTEP, nstrips = (b.height + dev::QSR - 1) / dev::QSR, waves = act * nseg * nstrips;
+		if (nch == 4) dev::k_inv_packed16_strip<4><<<(waves + 3) / 4, dev::NTHREADS, 0, st>>>(j.l1, act, nseg, nstrips);
+		else dev::k_inv_packed16_strip<3><<<(waves + 3) / 4, dev::NTHREADS, 0, st>>>(j.l1, act, nseg, nstrips);
 	} else if (is_packed16(out_kind_)) {
 		const BandDesc &b = plan_.ch[0].band[0][0];
 		dim3 grid((b.width + dev::ITW - 1) / dev::ITW, (b.height + dev::ITH - 1) / dev::ITH, act);      // one workgroup per tile, all components

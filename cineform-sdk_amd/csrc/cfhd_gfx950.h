@@ -68,6 +68,8 @@ __device__ __forceinline__ uint32_t byte_perm(uint32_t s0, uint32_t s1, uint32_t
 // between would drain the loads in flight
 typedef uint32_t cfhd_u4 __attribute__((ext_vector_type(4)));
 #define CFHD_LDG32(p) (*(const __attribute__((address_space(1))) uint32_t *)(p))
+typedef uint32_t cfhd_u2 __attribute__((ext_vector_type(2)));
+#define CFHD_LDG64(p) (*(const __attribute__((address_space(1))) cfhd_u2 *)(p))
 #define CFHD_LDG128(p) (*(const __attribute__((address_space(1))) cfhd_u4 *)(p))
 
 } // namespace dev

@@ -1557,6 +1557,112 @@ __global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(C
 }
 
 // =============================================================================================
+// k_inv_packed16_strip: the last level of RGB 4:4:4 -> RG48 / RGBA 4:4:4:4 -> b64a in the register-strip organisation, the mirror image of
+// k_fwd_packed16_strip.  One lane = 4 band columns of every plane (8-byte loads of LL, LH, HL, HH; a three-row window of the vertical-lowpass
+// bands in registers) -> 8 finished pixels of two output rows, all components, stored as NCH 16-byte words per row.  Segments of 62
+// blocks per wave (lanes 0 and 63 only feed their neighbours), QSR band rows per strip; no LDS.  Same arithmetic and the same words as
+// k_inv_packed16 (tested against it), which stays for other geometries and small launches.  Geometry served: band width % 4 == 0.
+// =============================================================================================
+enum { QSR = 16 };
+struct InvPxRow { cfhd_u2 ll, lh, hl, hh; };
+__device__ __forceinline__ cfhd_u2 ldg64_at(const int16_t *base, uint32_t byte_off) { return CFHD_LDG64((const char *)base + byte_off); }
+
+template <int NCH>
+__global__ void __launch_bounds__(NTHREADS) k_inv_packed16_strip(const InvPlaneJob *jobs, int nframes, int nseg, int nstrips)
+{
+	const int lane = threadIdx.x & 63, gwave = (int)blockIdx.x * (NTHREADS / 64) + wave_uniform((int)(threadIdx.x >> 6));
+	const int seg = gwave % nseg, strip = (gwave / nseg) % nstrips, frame = gwave / (nseg * nstrips);
+	if (frame >= nframes) return;                         // whole wave
+	const InvPlaneJob *job = jobs + (size_t)frame * NCH;
+	const int w = job->width, h = job->height, nblk = w / 4;
+	const int b = seg * PSTEP - 1 + lane;
+	const bool stores = b >= 0 && b < nblk && lane >= 1 && lane <= PSTEP;
+	const int blk = b < 0 ? 0 : (b >= nblk ? nblk - 1 : b);
+	const bool first = blk == 0, last = blk == nblk - 1;
+	const int pitch = job->band_pitch, precision = job->precision, dh = job->display_height, out_pitch = job->out_pitch;
+	const bool alpha = NCH == 4 && job[NCH - 1].alpha;
+	uint16_t *const frame_out = (uint16_t *)job->out - packed16_word<NCH>(0);
+	const int16_t *band[NCH][4];
+#pragma unroll
+	for (int c = 0; c < NCH; c++) {
+#pragma unroll
+		for (int k = 0; k < 4; k++) band[c][k] = job[c].band[k];      // (wave-uniform: scalar registers)
+	}
+	const int tail0 = w - (w & 7) - 9;                    // band columns from here on: the reference's scalar loop (to16)
+	const int r0 = strip * QSR, nrows = h - r0 < QSR ? h - r0 : QSR;
+	const uint32_t col_off = (uint32_t)blk * 8u;          // bytes into a band row
+	int j = inv_window_first_row(r0, h);
+	cfhd_u2 ll[NCH][3], lh[NCH][3], hl[NCH], hh[NCH];
+#pragma unroll
+	for (int c = 0; c < NCH; c++) {
+#pragma unroll
+		for (int k = 0; k < 3; k++) { const uint32_t at = (uint32_t)(j + k) * (uint32_t)pitch * 2u + col_off; ll[c][k] = ldg64_at(band[c][0], at); lh[c][k] = ldg64_at(band[c][1], at); }
+		const uint32_t at = (uint32_t)r0 * (uint32_t)pitch * 2u + col_off;
+		hl[c] = ldg64_at(band[c][2], at); hh[c] = ldg64_at(band[c][3], at);
+	}
+	for (int s = 0; s < nrows; s++) {
+		const int r = r0 + s;
+		const bool more = s + 1 < nrows;
+		const int jn = more ? inv_window_first_row(r + 1, h) : j;
+		const bool advance = jn != j;
+		// the next band row's loads are in flight while this one is synthesised
+		cfhd_u2 nll[NCH], nlh[NCH], nhl[NCH], nhh[NCH];
+#pragma unroll
+		for (int c = 0; c < NCH; c++) {
+			nll[c] = ll[c][2]; nlh[c] = lh[c][2]; nhl[c] = hl[c]; nhh[c] = hh[c];
+			if (advance) { const uint32_t at = (uint32_t)(jn + 2) * (uint32_t)pitch * 2u + col_off; nll[c] = ldg64_at(band[c][0], at); nlh[c] = ldg64_at(band[c][1], at); }
+			if (more) { const uint32_t at = (uint32_t)(r + 1) * (uint32_t)pitch * 2u + col_off; nhl[c] = ldg64_at(band[c][2], at); nhh[c] = ldg64_at(band[c][3], at); }
+		}
+		const int pos = r == 0 ? 0 : (r == h - 1 ? 2 : 1);
+		uint32_t Lv[NCH][2][2], Hv[NCH][2][2];              // [plane][row parity][column pair]
+#pragma unroll
+		for (int c = 0; c < NCH; c++) {
+			inv_vert_pk(ll[c][0].x, ll[c][1].x, ll[c][2].x, hl[c].x, pos, Lv[c][0][0], Lv[c][1][0]);
+			inv_vert_pk(ll[c][0].y, ll[c][1].y, ll[c][2].y, hl[c].y, pos, Lv[c][0][1], Lv[c][1][1]);
+			inv_vert_pk(lh[c][0].x, lh[c][1].x, lh[c][2].x, hh[c].x, pos, Hv[c][0][0], Hv[c][1][0]);
+			inv_vert_pk(lh[c][0].y, lh[c][1].y, lh[c][2].y, hh[c].y, pos, Hv[c][0][1], Hv[c][1][1]);
+		}
+#pragma unroll
+		for (int par = 0; par < 2; par++) {
+			uint32_t px[4 * NCH];                             // the lane's 8 pixels of this output row, two 16-bit words per dword
+#pragma unroll
+			for (int i = 0; i < 4 * NCH; i++) px[i] = 0u;
+#pragma unroll
+			for (int c = 0; c < NCH; c++) {
+				const uint32_t L0 = Lv[c][par][0], L1 = Lv[c][par][1], H0 = Hv[c][par][0], H1 = Hv[c][par][1];
+				const uint32_t prev = __shfl(L1, lane - 1), next = __shfl(L0, lane + 1);
+				uint32_t ev[2], od[2];
+				inv_horiz_pk((prev >> 16) | (L0 << 16), L0, (L0 >> 16) | (L1 << 16), H0, ev[0], od[0]);
+				inv_horiz_pk((L0 >> 16) | (L1 << 16), L1, (L1 >> 16) | (next << 16), H1, ev[1], od[1]);
+				int e[4] = { lo16(ev[0]), hi16(ev[0]), lo16(ev[1]), hi16(ev[1]) }, o[4] = { lo16(od[0]), hi16(od[0]), lo16(od[1]), hi16(od[1]) };     // columns 0..3 before the >>1
+				if (first) { const int l[6] = { 0, 0, lo16(L0), hi16(L0), lo16(L1), hi16(L1) }; inv_horiz_border(l, 2, lo16(H0), 0, e[0], o[0]); }
+				if (last) { const int l[6] = { lo16(L0), hi16(L0), lo16(L1), hi16(L1), 0, 0 }; inv_horiz_border(l, 3, hi16(H1), 2, e[3], o[3]); }
+#pragma unroll
+				for (int k = 0; k < 4; k++) {
+					const bool tail = 4 * blk + k >= tail0;
+					uint32_t we = to16(e[k], precision, tail), wo = to16(o[k], precision, tail);
+					if (alpha && c == 3) { we = expand_alpha16(we); wo = expand_alpha16(wo); }
+					const int ie = (2 * k) * NCH + packed16_word<NCH>(c), io = (2 * k + 1) * NCH + packed16_word<NCH>(c);     // 16-bit word of the lane's row
+					px[ie >> 1] |= we << (16 * (ie & 1)); px[io >> 1] |= wo << (16 * (io & 1));
+				}
+			}
+			const int orow = 2 * r + par;
+			if (stores && orow < dh) {
+				uint4 *dst = (uint4 *)(frame_out + (size_t)orow * out_pitch + (size_t)blk * 8 * NCH);
+#pragma unroll
+				for (int i = 0; i < NCH; i++) { uint4 v; v.x = px[4 * i]; v.y = px[4 * i + 1]; v.z = px[4 * i + 2]; v.w = px[4 * i + 3]; dst[i] = v; }
+			}
+		}
+#pragma unroll
+		for (int c = 0; c < NCH; c++) {
+			if (advance) { ll[c][0] = ll[c][1]; ll[c][1] = ll[c][2]; ll[c][2] = nll[c]; lh[c][0] = lh[c][1]; lh[c][1] = lh[c][2]; lh[c][2] = nlh[c]; }
+			hl[c] = nhl[c]; hh[c] = nhh[c];
+		}
+		if (advance) j = jn;
+	}
+}
+
+// =============================================================================================
 // Half-resolution decode of 4:2:2 samples (CFHD_DECODED_RESOLUTION_HALF): the reference does not run the last wavelet level at all
 // and shows the level-1 lowpass planes, four times the 10-bit sample, as the picture: decoder.c:14124 -> :22883 CopyLowpass16sToBuffer
 // -> frame.c:11742 ConvertLowpass16s10bitToYUV, scalar loop: SATURATE_8U(value >> 4), bytes Y U Y V from the planes Y, U, V (channel

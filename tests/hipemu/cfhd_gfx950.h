@@ -50,6 +50,9 @@ inline uint32_t byte_perm(uint32_t s0, uint32_t s1, uint32_t sel)
 struct emu_u4 { uint32_t x, y, z, w; };
 typedef emu_u4 cfhd_u4;
 #define CFHD_LDG32(p) (*(const uint32_t *)(p))
+struct emu_u2 { uint32_t x, y; };
+typedef emu_u2 cfhd_u2;
+#define CFHD_LDG64(p) (*(const cfhd::dev::cfhd_u2 *)(p))
 #define CFHD_LDG128(p) (*(const cfhd::dev::cfhd_u4 *)(p))
 
 } // namespace dev

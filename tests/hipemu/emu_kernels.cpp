@@ -142,6 +142,7 @@ void emu_fwd_rgb10(const uint32_t *in, int in_pitch_bytes, int width, int height
 }
 
 // Last level of a 4:4:4(:4) format to interleaved 16-bit pixels: bands[c*4+b].
+static int g_inv_packed16_strip = 0;
 void emu_inv_packed16(int16_t **bands, int band_pitch, int w, int h, int display_height, int nch, int precision, const int *word_of_channel,
                       uint16_t *out, int out_pitch_words, int alpha_channel)
 {
@@ -153,9 +154,16 @@ void emu_inv_packed16(int16_t **bands, int band_pitch, int w, int h, int display
 		job.out = (int16_t *)(out + word_of_channel[c]); job.out_pitch = out_pitch_words; job.xstride = nch; job.precision = precision; job.display_height = display_height;
 		job.alpha = c == alpha_channel;
 	}
+	if (g_inv_packed16_strip) {                           // (word_of_channel has to be the RG48 / b64a order the kernel is built for)
+		const int nseg = (w / 4 + PSTEP - 1) / PSTEP, nstrips = (h + QSR - 1) / QSR, waves = nseg * nstrips;
+		if (nch == 4) hipemu::launch(dim3((waves + 3) / 4), dim3(NTHREADS), [&] { k_inv_packed16_strip<4>(jobs.data(), 1, nseg, nstrips); });
+		else hipemu::launch(dim3((waves + 3) / 4), dim3(NTHREADS), [&] { k_inv_packed16_strip<3>(jobs.data(), 1, nseg, nstrips); });
+		return;
+	}
 	dim3 grid((w + ITW - 1) / ITW, (h + ITH - 1) / ITH, 1);
 	hipemu::launch(grid, dim3(NTHREADS), [&] { k_inv_packed16(jobs.data(), nch); });
 }
+void emu_inv_packed16_use_strip(int on) { g_inv_packed16_strip = on; }
 
 void emu_fwd_frame_yuv422(const uint8_t *in, int in_pitch, int width, int height, int display_height, int uyvy, int shift,
                           const int *quant /*[3][4]*/, int mpq, int16_t **out /*[3][4]*/, const int *out_pitch)

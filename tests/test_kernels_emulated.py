@@ -464,7 +464,8 @@ def test_fwd_packed16_strip_equals_the_tiled_kernel(w, h, dh, wpp, nch):
         assert (got[1][k][:, w // 2:] == -7).all()            # nothing written beside the band
 
 
-@pytest.mark.parametrize("w,h,dh,nch,b64a", [(16, 8, 16, 3, 0), (68, 20, 37, 3, 0), (96, 33, 66, 4, 0), (160, 17, 34, 3, 0), (96, 33, 66, 4, 1), (40, 9, 17, 4, 1)])
+@pytest.mark.parametrize("w,h,dh,nch,b64a", [(16, 8, 16, 3, 0), (68, 20, 37, 3, 0), (96, 33, 66, 4, 0), (160, 17, 34, 3, 0), (96, 33, 66, 4, 1), (40, 9, 17, 4, 1),
+                                             (252, 40, 77, 3, 0), (500, 18, 36, 4, 1), (248, 16, 32, 3, 0)])
 def test_inv_packed16_last_level_of_444_formats(w, h, dh, nch, b64a):
     """k_inv_packed16 = oracle RG48 / RG64 / b64a reconstruction (pinned against the reference decoder in test_oracle_vs_ref): exact, incl.
     the 65535-vs-65520 saturation difference between the reference's vector columns and its scalar tail columns and, for b64a, the
@@ -490,6 +491,13 @@ def test_inv_packed16_last_level_of_444_formats(w, h, dh, nch, b64a):
     E.emu_inv_packed16.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     E.emu_inv_packed16((c_i16p * len(flat))(*flat), pitch, w, h, dh, nch, 12, iarr(words), got.ctypes.data_as(ctypes.c_void_p), 2 * w * nch, 3 if b64a else -1)
     assert np.array_equal(got, want[:dh])
+    if w % 4 == 0 and (b64a or nch == 3):
+        # k_inv_packed16_strip (register strips: a lane = 4 band columns of all planes, segments of 62 blocks, strips of 16 band rows): the same words
+        got2 = np.full((dh, 2 * w * nch), 7, np.uint16)
+        E.emu_inv_packed16_use_strip(1)
+        try: E.emu_inv_packed16((c_i16p * len(flat))(*flat), pitch, w, h, dh, nch, 12, iarr(words), got2.ctypes.data_as(ctypes.c_void_p), 2 * w * nch, 3 if b64a else -1)
+        finally: E.emu_inv_packed16_use_strip(0)
+        assert np.array_equal(got2, want[:dh])
     if b64a:
         a = want[:, 0::4]
         assert (a == 0).any() and (a == 65535).any() and ((a > 0) & (a < 65535)).any()
