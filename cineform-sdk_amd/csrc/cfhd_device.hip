@@ -387,14 +387,14 @@ int EncodeBatch::set_device_frame(int i, const void *d_frame, int pitch)
 // 1080p (tools/small_batch_sweep.sh; frames per launch): plane levels 140-230, forward level 1 about 32, inverse level 1 about 12; larger
 // frames count in proportion to their area.  CFHD_AMD_PLANES / _FORWARD / _INVERSE = tile | strip force one shape (A/B runs).
 static double frames_1080p_equivalent(const FramePlan &plan, int frames) { return (double)frames * plan.width * plan.height / (1920.0 * 1080.0); }
-static int shape_override(const char *name)           // 0: by size, 1: tile, 2: strip
+static int shape_override(const char *name)           // 0: by size, 1: tile, 2: strip (read at every launch: tests switch shapes within one process)
 {
 	const char *e = getenv(name);
 	return !e ? 0 : (strcmp(e, "tile") == 0 ? 1 : (strcmp(e, "strip") == 0 ? 2 : 0));
 }
 static bool planes_as_strips(const FramePlan &plan, int lv /* wavelet index whose bands are produced / consumed */, int frames)
 {
-	static const int forced = shape_override("CFHD_AMD_PLANES");
+	const int forced = shape_override("CFHD_AMD_PLANES");
 	if (forced == 1 || (forced == 0 && frames_1080p_equivalent(plan, frames) < 160.0)) return false;
 	for (int c = 0; c < plan.num_channels; c++) {
 		const BandDesc &b = plan.ch[c].band[lv][0];
@@ -420,7 +420,7 @@ template <typename F> static void for_channel_runs(const FramePlan &plan, int lv
 // everything else (and CFHD_AMD_FORWARD=tile, for A/B runs) takes the LDS-tiled k_fwd_yuv422.  Both produce the same coefficients.
 bool EncodeBatch::strip_forward() const
 {
-	static const int forced = shape_override("CFHD_AMD_FORWARD");
+	const int forced = shape_override("CFHD_AMD_FORWARD");
 	const int act = active_ > 0 && active_ < n_ ? active_ : n_;
 	if (forced == 1 || (forced == 0 && frames_1080p_equivalent(plan_, act) < 32.0)) return false;
 	if (plan_.interlaced || plan_.encoded_format != ENC_YUV422 || plan_.width % 32) return false;
@@ -433,7 +433,7 @@ bool EncodeBatch::strip_forward() const
 // the strip kernels pay (as strip_forward()); everything else takes the LDS-tiled k_fwd_packed16.
 bool EncodeBatch::strip_forward_packed16() const
 {
-	static const int forced = shape_override("CFHD_AMD_FORWARD");
+	const int forced = shape_override("CFHD_AMD_FORWARD");
 	const int act = active_ > 0 && active_ < n_ ? active_ : n_;
 	if (forced == 1 || (forced == 0 && frames_1080p_equivalent(plan_, act) < 32.0)) return false;
 	if (!is_packed16(plan_.pixel_kind) || plan_.width % 8 || plan_.num_channels < 3) return false;
@@ -685,7 +685,7 @@ int DecodeBatch::set_device_output(int i, void *d_out, int pitch)
 // CFHD_AMD_INVERSE=tile, for A/B runs) takes the LDS-tiled k_inv_yuv422.  Both produce the same bytes.
 bool DecodeBatch::strip_inverse() const
 {
-	static const int forced = shape_override("CFHD_AMD_INVERSE");
+	const int forced = shape_override("CFHD_AMD_INVERSE");
 	const int bw = plan_.ch[0].band[0][0].width;
 	const int act = active_ > 0 && active_ < n_ ? active_ : n_;
 	if (forced == 1 || (forced == 0 && frames_1080p_equivalent(plan_, act) < 12.0)) return false;
@@ -699,7 +699,7 @@ bool DecodeBatch::strip_inverse() const
 // strip kernels pay; everything else takes the LDS-tiled k_inv_packed16.
 bool DecodeBatch::strip_inverse_packed16() const
 {
-	static const int forced = shape_override("CFHD_AMD_INVERSE");
+	const int forced = shape_override("CFHD_AMD_INVERSE");
 	const int act = active_ > 0 && active_ < n_ ? active_ : n_;
 	if (forced == 1 || (forced == 0 && frames_1080p_equivalent(plan_, act) < 12.0)) return false;
 	if (!is_packed16(out_kind_) || half_ || plan_.ch[0].band[0][0].width % 4) return false;
@@ -715,7 +715,7 @@ bool DecodeBatch::strip_inverse_packed16() const
 // k_inv_frame_yuv422_quad: four band columns per thread with 8-byte loads and 16-byte stores (CFHD_AMD_INVERSE=tile: the one-column kernel)
 bool DecodeBatch::frame_inverse_quads() const
 {
-	static const int forced = shape_override("CFHD_AMD_INVERSE");
+	const int forced = shape_override("CFHD_AMD_INVERSE");
 	const BandDesc &b = plan_.ch[0].band[0][0];
 	if (forced == 1 || b.width % 4 || b.width < 8) return false;
 	for (int c = 0; c < 3; c++) if (plan_.ch[c].band[0][0].pitch % 4) return false;

@@ -794,6 +794,49 @@ def test_batched_path_of_the_other_configurations_equals_reference(name, w, h, n
     L.cfhd_amd_batch_destroy(b)
 
 
+@pytest.mark.parametrize("name,w,h,n,fmt,enc,mode", [
+    ("rg48", 1000, 562, 3, PIX_RG48, ENCODED_RGB444, 0), ("rg48-one-block-rows", 504, 242, 2, PIX_RG48, ENCODED_RGB444, 0),
+    ("b64a", 1920, 1080, 2, PIX_B64A, ENCODED_RGBA4444, 0), ("b64a-narrow", 136, 120, 2, PIX_B64A, ENCODED_RGBA4444, 0),
+    ("b64a-to-444", 1016, 304, 2, PIX_B64A, ENCODED_RGB444, 1), ("rg48-4k", 3840, 2160, 2, PIX_RG48, ENCODED_RGB444, 0)])
+def test_packed16_strip_kernels_equal_reference(name, w, h, n, fmt, enc, mode):
+    """k_fwd_packed16_strip / k_inv_packed16_strip (the shape large launches of RG48 / b64a take; forced here with CFHD_AMD_FORWARD / _INVERSE =
+    strip on small batches): several segments of 62 blocks with a partial last one, strips with pad rows below the picture, three planes out
+    of four-word pixels.  Samples equal the reference encoder's, decoded frames the exact reconstruction.  (b64a heights are
+    multiples of 8: the reference's b64a unpack stops at the display height, frame.c:6644, and transforms whatever its heap holds below it.)"""
+    L = _batch_api()
+    L.cfhd_amd_batch_kernel_name.restype = ctypes.c_char_p
+    L.cfhd_amd_batch_kernel_name.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    bpp = {PIX_RG48: 6, PIX_B64A: 8}[fmt]
+    frames, pitch = qbist_frames(10, n, w, h, fmt, alpha=1 if fmt == PIX_B64A else 0)
+    refs = ref_encode_frames(frames, pitch, w, h, fmt, encoded=enc)
+    old = {k: os.environ.get(k) for k in ("CFHD_AMD_FORWARD", "CFHD_AMD_INVERSE")}
+    os.environ["CFHD_AMD_FORWARD"] = "strip"; os.environ["CFHD_AMD_INVERSE"] = "strip"
+    try:
+        b = L.cfhd_amd_batch_create_ex(w, h, fmt, enc, 0, QUALITY_FILMSCAN1, n, 4, mode)
+        assert b, amd_last_error()
+        for i, f in enumerate(frames):
+            assert L.cfhd_amd_batch_upload(b, i, f.ctypes.data_as(ctypes.c_void_p), pitch) == 0
+        assert L.cfhd_amd_batch_kernel_name(b, 0) == b"k_fwd_packed16_strip"
+        if mode == 0: assert L.cfhd_amd_batch_kernel_name(b, 3) == b"k_inv_packed16_strip"
+        assert L.cfhd_amd_batch_roundtrip(b) > 0, amd_last_error()
+        for i in range(n):
+            p = ctypes.c_void_p(); sz = ctypes.c_size_t()
+            assert L.cfhd_amd_batch_get_sample(b, i, ctypes.byref(p), ctypes.byref(sz)) == 0
+            sample = ctypes.string_at(p, sz.value)
+            assert mask_volatile_metadata(sample) == mask_volatile_metadata(refs[i]), "frame %d differs from the reference" % i
+            if mode: continue
+            out = np.zeros(h * w * bpp, dtype=np.uint8)
+            assert L.cfhd_amd_batch_download_output(b, i, out.ctypes.data_as(ctypes.c_void_p), w * bpp) == 0
+            plan = Plan(w, h, pixkind=PIXKIND["b64a" if fmt == PIX_B64A else "RG48"], enc=ENC["4444" if fmt == PIX_B64A else "444"])
+            want = oracle_inverse_rgb48(plan, host_decode_pyramid(sample, plan), b64a=fmt == PIX_B64A)[:h]
+            assert np.array_equal(np.frombuffer(out.tobytes(), np.uint16).reshape(h, w * bpp // 2), want), "frame %d" % i
+        L.cfhd_amd_batch_destroy(b)
+    finally:
+        for k, v in old.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+
+
 @pytest.mark.parametrize("w,h,n,nuniq", [(1920, 1080, 64, 16), (3840, 2160, 40, 4)])
 def test_batched_round_trip_at_bench_sizes_equals_reference(w, h, n, nuniq):
     L = _batch_api()
