@@ -203,58 +203,78 @@ __device__ __forceinline__ uint32_t dx_off_clear_from(uint32_t offs, int k) { co
 // one four times over.
 // A walk may start in front of the lane (a lead-in through the neighbour's last bits, to fall in step before the lane begins): counting starts
 // with the first code word inside the lane, whose position is returned in L.start.
+__device__ __forceinline__ uint32_t dx_low_pieces(int n) { return n >= 4 ? 0xffffffffu : (1u << (8 * n)) - 1u; }      // the offset bytes of pieces 0 .. n-1
 __device__ __forceinline__ void dx_walk(DxLane &L, uint32_t pos, const bool merge, const uint32_t lane_base, const uint32_t limit, const uint32_t *s_words, const uint32_t *s_tab,
                                         const uint32_t *s_long)
 {
-	uint32_t cnt = 0;
-	L.start = pos;
+	// Written as one loop with one way out and plain selects inside: with `break`s at three depths the compiler spent a third of the loop on
+	// copies of the state and on bookkeeping of the execution mask.
+	uint32_t cnt = 0, start = pos, endv = pos;
 	uint32_t offs = merge ? L.rec_offs : (uint32_t)DX_OFFS_NONE;
+	uint32_t rc0 = L.rec_cnt[0], rc1 = L.rec_cnt[1], rc2 = L.rec_cnt[2], rc3 = L.rec_cnt[3];
 	const uint32_t lane_end = lane_base + DX_LANE_BITS;
-	uint32_t next = lane_base;                            // first bit of the piece the walk has not entered yet
-	int piece = -1;
 	const uint32_t stop = lane_end < limit ? lane_end : limit;
+	uint32_t next = lane_base;                            // first bit of the piece the walk has not entered yet
+	int piece = -1, merged_at = 0;
+	bool alive = true, clear = false, merged = false;
 	DxBitsAhead B;
 	B.seek(s_words, pos);
-	for (;;) {
-		if (pos >= stop) { L.end = pos; if (pos < lane_end) offs = dx_off_clear_from(offs, piece + 1); break; }      // the end of the lane, or of the payload in front of it
-		if (pos >= next) {
-			// the walk enters a new piece (a code word is shorter than a piece: none is skipped, except in front of a late start)
-			const int k = (int)((pos - lane_base) / DX_SUB_BITS);
-			if (piece < 0) { cnt = 0; L.start = pos; }        // the first code word of the lane
-			for (int j = piece + 1; j < k; j++) offs = dx_off_set(offs, j, DX_OFF_INVALID);
-			const uint32_t off = pos - (lane_base + (uint32_t)k * DX_SUB_BITS);
-			if (merge && k > 0 && dx_off_get(offs, k) == off) {
-				// same chain from here on: the counts recorded behind this mark move by the difference in front of it
-				uint32_t old = 0;
-#pragma unroll
-				for (int j = 1; j < DX_SUBS; j++) if (j == k) old = L.rec_cnt[j];
-				const uint32_t delta = cnt - old;
-#pragma unroll
-				for (int j = 1; j < DX_SUBS; j++) if (j >= k && dx_off_get(offs, j) != (uint32_t)DX_OFF_INVALID) L.rec_cnt[j] += delta;
-				L.cnt += delta;
-				L.rec_offs = offs;
-				return;                                       // L.end stays
-			}
-			offs = dx_off_set(offs, k, off);
-#pragma unroll
-			for (int j = 0; j < DX_SUBS; j++) if (j == k) L.rec_cnt[j] = cnt;
-			piece = k; next = lane_base + (uint32_t)(k + 1) * DX_SUB_BITS;
-		}
-		const uint32_t win = B.window();
-		const uint32_t t = s_tab[win >> (32 - DX_K)];
-		const uint32_t ahead = B.prefetch(s_words);
-		const uint32_t used = (t >> 4) & 15u;
-		uint32_t adv = t & 15u, add = (t >> 8) & 0xfffu;      // the first code word ...
-		if (adv) {
-			if (used && pos + used <= next) { adv = used; add = t >> 20; }      // ... or several whole ones, none of them beyond the mark
+	do {
+		if (pos >= stop) {                                // the end of the lane, or of the payload in front of it
+			endv = pos; clear = pos < lane_end; alive = false;
 		} else {
-			const DxSym s = dx_long_symbol(t >> 16, s_long, win);
-			if (s.type == DX_T_RUN) { adv = (uint32_t)s.len; add = (uint32_t)s.payload; }
-			else if (s.type == DX_T_VALUE) { adv = (uint32_t)s.len + 1u; add = 1u; }
-			else { L.end = s.type == DX_T_END ? DX_END : DX_BAD; offs = dx_off_clear_from(offs, piece + 1); break; }
+			bool go = true;
+			if (pos >= next) {
+				// the walk enters a new piece (a code word is shorter than a piece: none is skipped, except in front of a late start)
+				const uint32_t rel = pos - lane_base, off = rel & (DX_SUB_BITS - 1u);
+				const int k = (int)(rel / DX_SUB_BITS);
+				const bool first = piece < 0;                 // the first code word of the lane
+				cnt = first ? 0u : cnt; start = first ? pos : start;
+				const uint32_t skipped = dx_low_pieces(k) & ~dx_low_pieces(piece + 1);
+				offs = (offs & ~skipped) | ((uint32_t)DX_OFFS_NONE & skipped);
+				if (merge && k > 0 && dx_off_get(offs, k) == off) {
+					merged = true; merged_at = k; alive = false; go = false;     // same chain from here on
+				} else {
+					offs = dx_off_set(offs, k, off);
+					rc0 = k == 0 ? cnt : rc0; rc1 = k == 1 ? cnt : rc1; rc2 = k == 2 ? cnt : rc2; rc3 = k == 3 ? cnt : rc3;
+					piece = k; next = lane_base + (uint32_t)(k + 1) * DX_SUB_BITS;
+				}
+			}
+			if (go) {
+				const uint32_t win = B.window();
+				const uint32_t t = s_tab[win >> (32 - DX_K)];
+				const uint32_t ahead = B.prefetch(s_words);
+				const uint32_t used = (t >> 4) & 15u;
+				uint32_t adv = t & 15u, add = (t >> 8) & 0xfffu;      // the first code word ...
+				const bool all = adv != 0u && used != 0u && pos + used <= next;
+				adv = all ? used : adv; add = all ? t >> 20 : add;      // ... or several whole ones, none of them beyond the mark
+				if (adv == 0u) {
+					const DxSym sy = dx_long_symbol(t >> 16, s_long, win);
+					if (sy.type == DX_T_RUN) { adv = (uint32_t)sy.len; add = (uint32_t)sy.payload; }
+					else if (sy.type == DX_T_VALUE) { adv = (uint32_t)sy.len + 1u; add = 1u; }
+					else { endv = sy.type == DX_T_END ? (uint32_t)DX_END : (uint32_t)DX_BAD; clear = true; alive = false; go = false; }
+				}
+				if (go) { pos += adv; cnt += add; B.skip((int)adv, ahead); }
+			}
 		}
-		pos += adv; cnt += add; B.skip((int)adv, ahead);
+	} while (alive);
+	if (merged) {
+		// the counts recorded behind the mark where the chains met move by the difference in front of it; L.end stays
+		const int k = merged_at;
+		const uint32_t old = k == 1 ? L.rec_cnt[1] : (k == 2 ? L.rec_cnt[2] : L.rec_cnt[3]);
+		const uint32_t delta = cnt - old;
+		L.rec_cnt[0] = rc0;
+		L.rec_cnt[1] = k <= 1 ? (dx_off_get(offs, 1) != (uint32_t)DX_OFF_INVALID ? L.rec_cnt[1] + delta : L.rec_cnt[1]) : rc1;
+		L.rec_cnt[2] = k <= 2 ? (dx_off_get(offs, 2) != (uint32_t)DX_OFF_INVALID ? L.rec_cnt[2] + delta : L.rec_cnt[2]) : rc2;
+		L.rec_cnt[3] = dx_off_get(offs, 3) != (uint32_t)DX_OFF_INVALID ? L.rec_cnt[3] + delta : L.rec_cnt[3];
+		L.cnt += delta;
+		L.rec_offs = offs;
+		L.start = start;
+		return;
 	}
+	if (clear) offs = dx_off_clear_from(offs, piece + 1);
+	L.rec_cnt[0] = rc0; L.rec_cnt[1] = rc1; L.rec_cnt[2] = rc2; L.rec_cnt[3] = rc3;
+	L.start = start; L.end = endv;
 	L.rec_offs = offs;
 	L.cnt = cnt;
 }

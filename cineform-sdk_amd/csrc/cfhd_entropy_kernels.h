@@ -89,38 +89,38 @@ struct EntFrameJob {
 
 __device__ __forceinline__ uint32_t bswap32(uint32_t v) { return (v >> 24) | ((v >> 8) & 0xff00u) | ((v << 8) & 0xff0000u) | (v << 24); }
 
-// Exclusive block scans over ENT_THREADS values (Hillis-Steele in LDS; the arrays are tiny, the barriers dominate).
+// Exclusive block scans over ENT_THREADS values: a scan inside every wave (lane exchange), the waves' totals through LDS -- two barriers per
+// scan (the Hillis-Steele loop in LDS they replace took eighteen: k_ent_scan walks the 8100 segments of a level-1 band of an 8K frame in 32
+// rounds of two scans, 0.44 ms per launch before, with one workgroup per band).  buf: at least ENT_WAVES words.
 __device__ __forceinline__ int block_excl_sum(int v, int *buf, int *total)
 {
-	const int t = threadIdx.x;
-	buf[t] = v;
+	const int lane = wave_lane(), wave = (int)(threadIdx.x >> 6);
+	const int incl = (int)wave_incl_scan((uint32_t)v);
+	if (lane == ENT_LANES - 1) buf[wave] = incl;
 	__syncthreads();
-	for (int d = 1; d < ENT_THREADS; d <<= 1) {
-		int x = t >= d ? buf[t - d] : 0;
-		__syncthreads();
-		buf[t] += x;
-		__syncthreads();
-	}
-	int incl = buf[t];
-	if (total) *total = buf[ENT_THREADS - 1];
+	int base = 0, tot = 0;
+#pragma unroll
+	for (int w = 0; w < ENT_WAVES; w++) { const int x = buf[w]; if (w < wave) base += x; tot += x; }
+	if (total) *total = tot;
 	__syncthreads();
-	return incl - v;
+	return base + incl - v;
 }
 __device__ __forceinline__ int block_excl_max(int v, int *buf, int *total)
 {
-	const int t = threadIdx.x;
-	buf[t] = v;
+	const int lane = wave_lane(), wave = (int)(threadIdx.x >> 6);
+	int incl = v;
+#pragma unroll
+	for (int d = 1; d < ENT_LANES; d <<= 1) { const int x = __shfl_up(incl, (unsigned)d); if (lane >= d && x > incl) incl = x; }
+	if (lane == ENT_LANES - 1) buf[wave] = incl;
+	int excl = __shfl_up(incl, 1u);
+	if (lane == 0) excl = -1;
 	__syncthreads();
-	for (int d = 1; d < ENT_THREADS; d <<= 1) {
-		int x = t >= d ? buf[t - d] : -1;
-		__syncthreads();
-		if (x > buf[t]) buf[t] = x;
-		__syncthreads();
-	}
-	int excl = t > 0 ? buf[t - 1] : -1;
-	if (total) *total = buf[ENT_THREADS - 1];
+	int base = -1, tot = -1;
+#pragma unroll
+	for (int w = 0; w < ENT_WAVES; w++) { const int x = buf[w]; if (w < wave && x > base) base = x; if (x > tot) tot = x; }
+	if (total) *total = tot;
 	__syncthreads();
-	return excl;
+	return excl > base ? excl : base;
 }
 
 __device__ __forceinline__ uint32_t run_bits_any(const EntTables *T, uint32_t run)
@@ -252,25 +252,46 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_count(const EntSegJob *seg_
 // =============================================================================================
 __global__ void __launch_bounds__(ENT_THREADS) k_ent_scan(const EntBandJob *bands, EntSegState *segs, EntBandState *band_state, const EntTables *tables)
 {
+	// One workgroup per band, ENT_SCAN_PER consecutive segments per thread and round: a round is a chain of three dependent memory round trips
+	// (segment states, run-length table, stores) whatever it covers, and a level-1 band of an 8K frame has 8100 segments.
+	enum { ENT_SCAN_PER = 4 };
 	__shared__ int s_scan[ENT_THREADS];
 	const EntBandJob &job = bands[blockIdx.x];
 	const EntTables *T = tables + job.table;
 	int carry_prev = -1; uint32_t carry_bits = 0;
-	for (int c0 = 0; c0 < job.nseg; c0 += ENT_THREADS) {
-		const int i = c0 + threadIdx.x;
-		const bool valid = i < job.nseg;
-		EntSegState s; s.first_nz = -1; s.last_nz = -1; s.bits = 0;
-		if (valid) s = segs[job.seg_base + i];
+	for (int c0 = 0; c0 < job.nseg; c0 += ENT_THREADS * ENT_SCAN_PER) {
+		const int i0 = c0 + (int)threadIdx.x * ENT_SCAN_PER;
+		EntSegState s[ENT_SCAN_PER];
+#pragma unroll
+		for (int k = 0; k < ENT_SCAN_PER; k++) {
+			s[k].first_nz = -1; s[k].last_nz = -1; s[k].bits = 0;
+			if (i0 + k < job.nseg) s[k] = segs[job.seg_base + i0 + k];
+		}
+		int mine = -1;
+#pragma unroll
+		for (int k = 0; k < ENT_SCAN_PER; k++) mine = s[k].last_nz > mine ? s[k].last_nz : mine;
 		int chunk_last;
-		int prev = block_excl_max(s.last_nz, s_scan, &chunk_last);
+		int prev = block_excl_max(mine, s_scan, &chunk_last);
 		if (prev < carry_prev) prev = carry_prev;
-		uint32_t bits = s.bits;
-		if (s.first_nz >= 0) bits += run_bits_any(T, (uint32_t)(s.first_nz - prev - 1));
+		int prevs[ENT_SCAN_PER]; uint32_t bits[ENT_SCAN_PER];
+#pragma unroll
+		for (int k = 0; k < ENT_SCAN_PER; k++) { prevs[k] = prev; prev = s[k].last_nz > prev ? s[k].last_nz : prev; }
+		uint32_t total = 0;
+#pragma unroll
+		for (int k = 0; k < ENT_SCAN_PER; k++) {
+			bits[k] = s[k].bits;
+			if (s[k].first_nz >= 0) bits[k] += run_bits_any(T, (uint32_t)(s[k].first_nz - prevs[k] - 1));
+			total += bits[k];
+		}
 		int chunk_bits;
-		int off = block_excl_sum((int)bits, s_scan, &chunk_bits);
-		if (valid) {
-			EntSegState &o = segs[job.seg_base + i];
-			o.prev_nz = prev; o.bits = bits; o.bitoff = carry_bits + (uint32_t)off;
+		uint32_t off = carry_bits + (uint32_t)block_excl_sum((int)total, s_scan, &chunk_bits);
+#pragma unroll
+		for (int k = 0; k < ENT_SCAN_PER; k++) {
+			if (i0 + k < job.nseg) {
+				EntSegState &o = segs[job.seg_base + i0 + k];
+				o.prev_nz = prevs[k]; o.bits = bits[k]; o.bitoff = off;
+			}
+			off += bits[k];
 		}
 		if (chunk_last > carry_prev) carry_prev = chunk_last;
 		carry_bits += (uint32_t)chunk_bits;
