@@ -906,33 +906,37 @@ __global__ void __launch_bounds__(DX_TILE_THREADS) k_dec_tiles(const DxBandJob *
 						uint32_t nextw = bswap32(P.d[2]), afterw = bswap32(P.d[3]);
 						uint32_t pos = off;
 						int16_t *tile16 = (int16_t *)s_tile;
-						while (pos < (uint32_t)DX_SUB_BITS && idx < T1) {
+						// one loop with one way out, the two kinds of step (a group out of the multi-symbol table | one long code word) feeding the
+						// same stores: fewer instructions per pass than separate paths with their own stores and `continue` / `break`
+						bool alive = true;
+						do {
 							if (have < 32) { acc |= (uint64_t)nextw << (32 - have); have += 32; nextw = afterw; afterw = 0u; }
 							const uint32_t win = (uint32_t)(acc >> 32);
 							// up to two values and the zero runs around them per lookup.  A group may reach over the end of the piece: the lane of the
 							// next piece then writes the same values to the same places again.
 							const uint2 e = s_multi[win >> (32 - DX_KM)];
-							const int used = (int)(e.x & 15u);
-							if (used) {
-								idx += (e.x >> 4) & 0xfffu;
-								const int v1 = (int)(int16_t)(e.x >> 16), v2 = (int)(int16_t)(e.y >> 16);
-								if (v1) { if (idx - T0 < (uint32_t)DX_TILE) tile16[idx - T0] = (int16_t)(v1 * quant); idx++; }
-								idx += e.y & 0xffu;
-								if (v2) { if (idx - T0 < (uint32_t)DX_TILE) tile16[idx - T0] = (int16_t)(v2 * quant); idx++; }
-								idx += (e.y >> 8) & 0xffu;
-								acc <<= used; have -= used; pos += (uint32_t)used;
-								continue;
+							int adv = (int)(e.x & 15u);
+							uint32_t pre = (e.x >> 4) & 0xfffu, mid = e.y & 0xffu, post = (e.y >> 8) & 0xffu;
+							int v1 = (int)(int16_t)(e.x >> 16), v2 = (int)(int16_t)(e.y >> 16);
+							bool has1 = v1 != 0;
+							if (adv == 0) {
+								// a code word of more than 11 bits (a large value, a long run, the band end marker): alone, through the full tables
+								const DxSym sy = dx_symbol(s_sym, s_long, win);
+								pre = 0u; mid = 0u; post = 0u; v1 = 0; v2 = 0;
+								if (sy.type == DX_T_RUN) { pre = (uint32_t)sy.payload; adv = sy.len; }
+								else if (sy.type == DX_T_VALUE) {
+									const int m = (int)s_mag[sy.payload];
+									v1 = (int)((acc << sy.len) >> 63) ? -m : m; has1 = true; adv = sy.len + 1;
+								} else alive = false;                         // band end marker (or a broken code, reported by k_dec_chain)
 							}
-							// a code word of more than 11 bits (a large value, a long run, the band end marker): alone, through the full tables
-							const DxSym sy = dx_symbol(s_sym, s_long, win);
-							if (sy.type == DX_T_RUN) { idx += (uint32_t)sy.payload; acc <<= sy.len; have -= sy.len; pos += (uint32_t)sy.len; continue; }
-							if (sy.type != DX_T_VALUE) break;                 // band end marker (or a broken code, reported by k_dec_chain)
-							const int v = (int)s_mag[sy.payload] * quant;
-							const int negative = (int)((acc << sy.len) >> 63);
-							if (idx - T0 < (uint32_t)DX_TILE) tile16[idx - T0] = (int16_t)(negative ? -v : v);
-							idx++;
-							acc <<= sy.len + 1; have -= sy.len + 1; pos += (uint32_t)sy.len + 1u;
-						}
+							idx += pre;
+							if (has1) { if (idx - T0 < (uint32_t)DX_TILE) tile16[idx - T0] = (int16_t)(v1 * quant); idx++; }
+							idx += mid;
+							if (v2) { if (idx - T0 < (uint32_t)DX_TILE) tile16[idx - T0] = (int16_t)(v2 * quant); idx++; }
+							idx += post;
+							acc <<= adv; have -= adv; pos += (uint32_t)adv;
+							alive = alive && pos < (uint32_t)DX_SUB_BITS && idx < T1;
+						} while (alive);
 					}
 					// pieces are in raster order: once a valid one starts behind the tile, all later ones do
 					if (__ballot(valid && !inside) || !__ballot(active)) break;

@@ -125,8 +125,13 @@ __device__ __forceinline__ int block_excl_max(int v, int *buf, int *total)
 
 __device__ __forceinline__ uint32_t run_bits_any(const EntTables *T, uint32_t run)
 {
+	// the greedy loop of the reference (encoder.c:5488-5545) takes the longest run code while at least 3072 zeros are left: in closed form
+	// (the all-zero alpha band of an 8K frame is 2700 such steps, which one thread of k_ent_scan used to walk one dependent load at a time)
 	uint32_t bits = 0;
-	while (run >= 3072) { bits += T->run_size[3071]; run -= T->run_count[3071]; }
+	if (run >= 3072u) {
+		const uint32_t c = T->run_count[3071], n = (run - 3072u) / c + 1u;
+		bits = n * T->run_size[3071]; run -= n * c;
+	}
 	return bits + T->run_total[run];
 }
 
