@@ -840,8 +840,8 @@ CFHD_Error CFHD_GetOutputFormats(CFHD_DecoderRef ref, void *sample, size_t size,
 	if (!ref || !arr) return ERR_INVALID_ARGUMENT;
 	ParsedSample ps;
 	const bool known = sample && parse_sample((const uint8_t *)sample, size, &ps) >= 0;
-	uint32_t fmts[4]; int total = 0;
-	if (!known || ps.encoded_format == ENC_YUV422) { fmts[total++] = FMT_YUY2; fmts[total++] = FMT_2VUY; }
+	uint32_t fmts[5]; int total = 0;
+	if (!known || ps.encoded_format == ENC_YUV422) { fmts[total++] = FMT_YUY2; fmts[total++] = FMT_2VUY; fmts[total++] = FMT_YU64; }
 	if (!known || ps.encoded_format == ENC_RGB444) fmts[total++] = FMT_RG48;
 	if (!known || ps.encoded_format == ENC_RGBA4444) fmts[total++] = FMT_B64A;
 	int n = 0;
@@ -891,8 +891,11 @@ CFHD_Error CFHD_PrepareToDecode(CFHD_DecoderRef ref, int, int, CFHD_PixelFormat 
 	// 4:2:2 samples decode to the packed 4:2:2 formats, RGB 4:4:4 samples to RG48 (wavelet.c:4947), RGBA 4:4:4:4 samples to b64a
 	// (bayer.c:11916 Row16uFull2OutputFormat); colour conversions between the families (ConvertLib / the colour part of the
 	// active-metadata pipeline in the reference) are not built
-	if (kind == PIX_BYR4 || kind == PIX_YU64 || kind == PIX_V210 || kind == PIX_RG24 || kind == PIX_BGRA || kind == PIX_BGRa || (kind >= PIX_R210 && kind <= PIX_AR10)) return ERR_BADFORMAT;     // encoder inputs only
+	// ... and to YU64 (16-bit words Y0 C1 Y1 C2; the reference's planar 16-bit row route, full resolution, progressive samples)
+	if (kind == PIX_YU64 && (encf != ENC_YUV422 || half)) return ERR_BADFORMAT;
+	if (kind == PIX_BYR4 || kind == PIX_V210 || kind == PIX_RG24 || kind == PIX_BGRA || kind == PIX_BGRa || (kind >= PIX_R210 && kind <= PIX_AR10)) return ERR_BADFORMAT;     // encoder inputs only
 	if ((encf == ENC_RGB444) != (kind == PIX_RG48) || (encf == ENC_RGBA4444) != (kind == PIX_B64A)) return ERR_BADFORMAT;
+	if (kind == PIX_YU64 && d->header.width < 128) return ERR_BADFORMAT;      // (the tail-column rule of the 16-bit rows is restated for chroma bands of 16 columns and more)
 	bool ok;
 	plan_from_sample(d->header, kind, &d->plan, &ok);
 	if (!ok) return ERR_BADSAMPLE;
@@ -962,7 +965,7 @@ CFHD_Error CFHD_DecodeSample(CFHD_DecoderRef ref, void *sample, size_t size, voi
 	// interlaced samples (known only now: the SAMPLE_FLAGS tag lies behind the 512 bytes CFHD_PrepareToDecode sees): 4:2:2, full resolution through the
 	// inverse frame transform, half resolution from the level-1 lowpass planes like any other sample (the reference's output is the same model)
 	const bool interlaced = !ps.progressive;
-	if (interlaced && ps.encoded_format != ENC_YUV422) return fail_zero(ERR_BADFORMAT);
+	if (interlaced && (ps.encoded_format != ENC_YUV422 || d->out_kind == PIX_YU64)) return fail_zero(ERR_BADFORMAT);      // (YU64 output of interlaced samples is not built)
 	// another call of this geometry in flight right now: decode together with it (see DecodeService)
 	if (decode_gather_slots() > 1 && gpu_entropy_enabled() && size <= (size_t)d->plan.width * d->plan.height * pixel_bytes_of(d->out_kind) + 65536) {
 		if (!d->service || d->service_interlaced != interlaced) {

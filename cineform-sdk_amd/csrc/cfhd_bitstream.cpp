@@ -465,7 +465,8 @@ int lowpass_bias(int precision, int lowpass_width, int out_pixel_kind)
 	const bool even = (lowpass_width & 1) == 0;
 	if (precision == 8) return 32;
 	if (precision == 10) {
-		(void)out_pixel_kind;              // YUY2 / 2vuy here; YU64, YR16 and V210 outputs would use 4 on the even-width path
+		// decoder.c:12265-12276: the 16-bit and 10-bit 4:2:2 outputs (YU64, YR16, V210) take 4 where the 8-bit ones take 24; odd widths: :12479
+		if (out_pixel_kind == PIX_YU64 || out_pixel_kind == PIX_V210) return even ? 4 : 5;
 		return even ? 24 : 5;
 	}
 	return 0;                              // 12-bit: RG48 / b64a outputs carry no bias

@@ -83,6 +83,13 @@ int packed_word_of_channel(int pixel_kind, int c)
 	return (pixel_kind == PIX_B64A ? b64a : rg48)[c & 3];
 }
 bool is_packed16(int pixel_kind) { return pixel_kind == PIX_RG48 || pixel_kind == PIX_B64A; }
+// decoder outputs made of 16-bit words that k_inv_packed16 writes plane by plane: the interleaved RGB(A) pixels, and YU64 (words Y0 C1 Y1 C2:
+// luma every second word, the half-width chroma planes every fourth; the reference decodes 4:2:2 samples to YU64 through the same planar
+// 16-bit rows as RGB 4:4:4 to RG48, oracle/cfhd_oracle_inv.c orc_inv_spatial_to_yu64)
+static bool dec_planes16(int out_kind) { return is_packed16(out_kind) || out_kind == PIX_YU64; }
+static int dec_word_of_channel(int out_kind, int c) { return out_kind == PIX_YU64 ? (c == 0 ? 0 : (c == 1 ? 1 : 3)) : packed_word_of_channel(out_kind, c); }
+static int dec_stride_of_channel(int out_kind, int c, int nch) { return out_kind == PIX_YU64 ? (c == 0 ? 2 : 4) : nch; }
+static int dec_words_per_position(int out_kind, int nch) { return out_kind == PIX_YU64 ? 2 : nch; }
 // encoder input made of 16-bit words that k_fwd_packed16 picks apart (per channel: first word, words from sample to sample, right shift).
 // YU64 (Codec/frame.c:1556 ConvertYU64ToFrame16s + convert.c:3345, :14375): words Y0 C1 Y1 C2, every word >> 6 to 10 bits, channel 1 = C1, 2 = C2.
 // v210 (frame.c:1431 ConvertV210ToFrame16s): three 10-bit samples per 32-bit word, FwdPlaneJob::layout tells the loader which component to pick.
@@ -566,7 +573,8 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 	const bool yuv_ok = (out_kind == PIX_YUY2 || out_kind == PIX_2VUY) && plan.encoded_format == ENC_YUV422;
 	const bool rgb_ok = ((out_kind == PIX_RG48 && plan.encoded_format == ENC_RGB444) || (out_kind == PIX_B64A && plan.encoded_format == ENC_RGBA4444)) &&
 	                    plan.ch[0].band[0][0].width >= 16;   // k_inv_packed16's tail-column rule assumes the reference's vector path
-	if (!yuv_ok && !rgb_ok) { g_err = "output format not supported by the GPU path yet"; return -2; }
+	const bool yu64_ok = out_kind == PIX_YU64 && plan.encoded_format == ENC_YUV422 && !half && plan.ch[1].band[0][0].width >= 16;
+	if (!yuv_ok && !rgb_ok && !yu64_ok) { g_err = "output format not supported by the GPU path yet"; return -2; }
 	plan_ = plan; n_ = nframes; out_kind_ = out_kind; own_output_ = own_output;
 	HIPCHK(hipStreamCreateWithFlags((hipStream_t *)&stream_, hipStreamNonBlocking));
 	HIPCHK(hipEventCreate((hipEvent_t *)&ev0_));
@@ -609,15 +617,15 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 			hp.shift = 16 - plan.precision - 2; hp.alpha = out_kind == PIX_B64A;
 			hp.out = own_output ? (uint16_t *)(d_out_ + frame_bytes_ * i) : nullptr; hp.out_pitch = out_pitch_;
 		}
-		if (is_packed16(out_kind)) {
+		if (dec_planes16(out_kind)) {
 			for (int c = 0; c < nch; c++) {
 				dev::InvPlaneJob &p = j.l1[(size_t)i * nch + c];
 				for (int b = 0; b < 4; b++) p.band[b] = base + plan.ch[c].band[0][b].offset;
 				p.band_pitch = plan.ch[c].band[0][0].pitch;
 				p.width = plan.ch[c].band[0][0].width; p.height = plan.ch[c].band[0][0].height; p.descale = 0;
 				uint16_t *frame = own_output ? (uint16_t *)(d_out_ + frame_bytes_ * i) : nullptr;
-				p.out = frame ? (int16_t *)(frame + packed_word_of_channel(out_kind, c)) : nullptr; p.out_pitch = out_pitch_ / 2;
-				p.xstride = nch; p.precision = plan.precision; p.display_height = plan.display_height;
+				p.out = frame ? (int16_t *)(frame + dec_word_of_channel(out_kind, c)) : nullptr; p.out_pitch = out_pitch_ / 2;
+				p.xstride = dec_stride_of_channel(out_kind, c, nch); p.precision = plan.precision; p.display_height = plan.display_height;
 				p.alpha = out_kind == PIX_B64A && c == 3;
 			}
 			continue;
@@ -668,10 +676,10 @@ int DecodeBatch::set_device_output(int i, void *d_out, int pitch)
 	if (i < 0 || i >= n_) return -1;
 	DecJobs j = dec_jobs_at(h_jobs_, n_, plan_.num_channels);
 	if (half_ && is_packed16(out_kind_)) { j.halfp[i].out = (uint16_t *)d_out; j.halfp[i].out_pitch = pitch; jobs_dirty_ = true; return 0; }
-	if (is_packed16(out_kind_)) {
+	if (dec_planes16(out_kind_)) {
 		for (int c = 0; c < plan_.num_channels; c++) {
 			dev::InvPlaneJob &p = j.l1[(size_t)i * plan_.num_channels + c];
-			p.out = (int16_t *)((uint16_t *)d_out + packed_word_of_channel(out_kind_, c)); p.out_pitch = pitch / 2;
+			p.out = (int16_t *)((uint16_t *)d_out + dec_word_of_channel(out_kind_, c)); p.out_pitch = pitch / 2;
 		}
 		jobs_dirty_ = true;
 		return 0;
@@ -689,7 +697,7 @@ bool DecodeBatch::strip_inverse() const
 	const int bw = plan_.ch[0].band[0][0].width;
 	const int act = active_ > 0 && active_ < n_ ? active_ : n_;
 	if (forced == 1 || (forced == 0 && frames_1080p_equivalent(plan_, act) < 12.0)) return false;
-	if (is_packed16(out_kind_) || bw % 16) return false;
+	if (dec_planes16(out_kind_) || bw % 16) return false;
 	DecJobs j = dec_jobs_at(h_jobs_, n_, plan_.num_channels);
 	for (int i = 0; i < n_; i++) if (((uintptr_t)j.yuv[i].out & 15) || (j.yuv[i].out_pitch & 15)) return false;
 	return true;
@@ -729,7 +737,7 @@ const char *DecodeBatch::level_kernel(int level) const
 	const int act = active_ > 0 && active_ < n_ ? active_ : n_;
 	if (level > 0) return planes_as_strips(plan_, level, act) ? "k_inv_plane_strip" : "k_inv_plane";
 	if (half_) return is_packed16(out_kind_) ? "k_half_packed16" : "k_half_yuv422";
-	if (is_packed16(out_kind_)) return strip_inverse_packed16() ? "k_inv_packed16_strip" : "k_inv_packed16";
+	if (dec_planes16(out_kind_)) return strip_inverse_packed16() ? "k_inv_packed16_strip" : "k_inv_packed16";
 	if (interlaced_) return frame_inverse_quads() ? "k_inv_frame_yuv422_quad" : "k_inv_frame_yuv422";
 	return strip_inverse() ? "k_inv_yuv422_strip" : "k_inv_yuv422";
 }
@@ -761,7 +769,7 @@ int DecodeBatch::launch_inverse(uint32_t dither_seed)
 		dev::k_inv_plane<<<grid, dev::NTHREADS, 0, st>>>(jobs);
 		HIPCHK(hipEventRecord((hipEvent_t)evl_[2 - lv], st));
 	}
-	if (interlaced_ && !half_ && is_packed16(out_kind_)) return -1;
+	if (interlaced_ && !half_ && dec_planes16(out_kind_)) return -1;
 	if (half_ && is_packed16(out_kind_)) {
 		const BandDesc &b = plan_.ch[0].band[0][0];
 		dev::k_half_packed16<<<dim3((b.width / 8 + dev::NTHREADS - 1) / dev::NTHREADS, out_rows_, act), dev::NTHREADS, 0, st>>>(j.halfp);
@@ -773,10 +781,10 @@ int DecodeBatch::launch_inverse(uint32_t dither_seed)
 		const int nseg = (b.width / 4 + dev::PSTEP - 1) / dev::PSTEP, nstrips = (b.height + dev::QSR - 1) / dev::QSR, waves = act * nseg * nstrips;
 		if (nch == 4) dev::k_inv_packed16_strip<4><<<(waves + 3) / 4, dev::NTHREADS, 0, st>>>(j.l1, act, nseg, nstrips);
 		else dev::k_inv_packed16_strip<3><<<(waves + 3) / 4, dev::NTHREADS, 0, st>>>(j.l1, act, nseg, nstrips);
-	} else if (is_packed16(out_kind_)) {
+	} else if (dec_planes16(out_kind_)) {
 		const BandDesc &b = plan_.ch[0].band[0][0];
 		dim3 grid((b.width + dev::ITW - 1) / dev::ITW, (b.height + dev::ITH - 1) / dev::ITH, act);      // one workgroup per tile, all components
-		dev::k_inv_packed16<<<grid, dev::NTHREADS, 0, st>>>(j.l1, nch);
+		dev::k_inv_packed16<<<grid, dev::NTHREADS, 0, st>>>(j.l1, nch, dec_words_per_position(out_kind_, nch));
 	} else if (interlaced_) {                           // (half resolution was served above: the level-1 lowpass planes need no inverse frame transform)
 		const BandDesc &b = plan_.ch[0].band[0][0];
 		if (frame_inverse_quads()) dev::k_inv_frame_yuv422_quad<<<dim3((b.width / 4 + dev::NTHREADS - 1) / dev::NTHREADS, b.height, act), dev::NTHREADS, 0, st>>>(j.yuv, dither_seed);

@@ -601,8 +601,11 @@ __device__ __forceinline__ uint32_t expand_alpha16(uint32_t word)
 // component + ConvertPlanarRGB16uToPackedRGB48): same synthesis, every sample converted with to16() and stored as one word of
 // the interleaved pixel.  gridDim.x = tiles_x * nch as in k_fwd_packed16.
 template <bool PACKED>
-__device__ __forceinline__ void inv_plane_tile(const InvPlaneJob *jobs, int nch)
+__device__ __forceinline__ void inv_plane_tile(const InvPlaneJob *jobs, int nch, int wps = 0)
 {
+	// wps (PACKED): 16-bit words per sample position of plane 0 in the output row -- nch for the interleaved RGB(A) pixels; 2 for YU64
+	// (words Y0 C1 Y1 C2: luma every second word, the two half-width chroma planes every fourth, InvPlaneJob::xstride), where a tile of
+	// ITW luma band columns covers ITW / 2 chroma band columns.
 	const TileId tile = xcd_tile();
 	__shared__ InvPlaneJob s_job;
 	__shared__ uint32_t s_low[2][ILROWS][IDW];          // LL, LH
@@ -613,16 +616,19 @@ __device__ __forceinline__ void inv_plane_tile(const InvPlaneJob *jobs, int nch)
 	__shared__ uint16_t s_out[PACKED ? 2 * ITH * 2 * ITW * 4 : 1];
 	const int tid = threadIdx.x;
 	const uint16_t *frame = nullptr;                     // PACKED: first word of the packed frame
+	int w_first = 0;                                     // PACKED: band width of plane 0 (the geometry the tile grid is laid out on)
 	if (PACKED) { uintptr_t lo = (uintptr_t)jobs[tile.z * nch].out; for (int c = 1; c < nch; c++) { const uintptr_t p = (uintptr_t)jobs[tile.z * nch + c].out; lo = p < lo ? p : lo; } frame = (const uint16_t *)lo; }
 	for (int comp = 0; comp < (PACKED ? nch : 1); comp++) {
 	if (comp) __syncthreads();                           // the previous component's tile is finished with s_job and the staging arrays
 	stage_job(&s_job, &jobs[PACKED ? tile.z * nch + comp : tile.z]);
 	const InvPlaneJob &job = s_job;
 	const int w = job.width, h = job.height;
-	const int c0 = tile.x * ITW, r0 = tile.y * ITH;
+	const int tw = PACKED ? ITW * wps / job.xstride : ITW;     // band columns of this plane under the tile
+	const int c0 = tile.x * tw, r0 = tile.y * ITH;
 	const bool active = (c0 < w) && (r0 < h);
 	const int rs = inv_tile_first_row(r0, h);
 	const int word = PACKED ? (int)((const uint16_t *)job.out - frame) : 0;
+	if (PACKED && comp == 0) { w_first = w; }
 	if (active) {
 		enum { NL = (2 * ILROWS * IDW + NTHREADS - 1) / NTHREADS, NH = (2 * ITH * IDW + NTHREADS - 1) / NTHREADS };
 		uint32_t vl[NL], vh[NH];
@@ -651,7 +657,7 @@ __device__ __forceinline__ void inv_plane_tile(const InvPlaneJob *jobs, int nch)
 		for (int i = tid; i < 2 * ITH * (ITW / 2); i += NTHREADS) {
 			const int par = i / (ITH * (ITW / 2)), rem = i - par * (ITH * (ITW / 2)), rl = rem / (ITW / 2), p = rem - rl * (ITW / 2);
 			const int r = r0 + rl, c = c0 + 2 * p;
-			if (r >= h || c >= w) continue;
+			if (r >= h || c >= w || 2 * p >= tw) continue;
 			const uint32_t *L = &s_v[par][0][rl][p + 1];
 			const uint32_t dm = L[-1], d0 = L[0], dp = L[1], hh = s_v[par][1][rl][p + 1];
 			uint32_t even, odd;
@@ -669,15 +675,16 @@ __device__ __forceinline__ void inv_plane_tile(const InvPlaneJob *jobs, int nch)
 					}
 				}
 				const int tail0 = w - (w & 7) - 9;
-				uint16_t *dst = s_out + ((size_t)(2 * rl + par) * (2 * ITW) + (size_t)(4 * p)) * nch + word;      // pixel 2 (c - c0) of tile row 2 rl + par
+				const int xs = job.xstride;
+				uint16_t *dst = s_out + (size_t)(2 * rl + par) * (2 * ITW) * wps + (size_t)(4 * p) * xs + word;      // sample 2 (c - c0) of tile row 2 rl + par
 #pragma unroll
 				for (int k = 0; k < 2; k++) {
 					if (c + k >= w) break;
 					const bool tail = c + k >= tail0;
 					uint32_t we = to16(e[k], job.precision, tail), wo = to16(o[k], job.precision, tail);
 					if (job.alpha) { we = expand_alpha16(we); wo = expand_alpha16(wo); }
-					dst[(2 * k) * nch] = (uint16_t)we;
-					dst[(2 * k + 1) * nch] = (uint16_t)wo;
+					dst[(2 * k) * xs] = (uint16_t)we;
+					dst[(2 * k + 1) * xs] = (uint16_t)wo;
 				}
 				continue;
 			}
@@ -704,24 +711,24 @@ __device__ __forceinline__ void inv_plane_tile(const InvPlaneJob *jobs, int nch)
 	}
 	if (PACKED) {
 		__syncthreads();
-		const InvPlaneJob &job = s_job;                   // geometry is the same for every component
-		const int w = job.width, h = job.height, c0 = tile.x * ITW, r0 = tile.y * ITH;
+		const InvPlaneJob &job = s_job;                   // (height, display height and pitch are the same for every component)
+		const int w = w_first, h = job.height, c0 = tile.x * ITW, r0 = tile.y * ITH;
 		if (c0 < w && r0 < h) {
-			const int npx = 2 * ((w - c0) < ITW ? (w - c0) : ITW);                       // pixels of the tile's rows inside the frame
-			const int row_dw = npx * nch / 2;                                            // (an even number of pixels: whole dwords)
+			const int npx = 2 * ((w - c0) < ITW ? (w - c0) : ITW);                       // sample positions of plane 0 in the tile's rows inside the frame
+			const int row_dw = npx * wps / 2;                                            // (an even number: whole dwords)
 			for (int i = tid; i < 2 * ITH * row_dw; i += NTHREADS) {
 				const int orl = i / row_dw, d = i - orl * row_dw;
 				const int orow = 2 * r0 + orl;
 				if (orow >= job.display_height || orow >= 2 * h) continue;
-				const uint32_t v = *(const uint32_t *)(s_out + (size_t)orl * (2 * ITW) * nch + 2 * d);
-				*(uint32_t *)((uint16_t *)frame + (size_t)orow * job.out_pitch + (size_t)(2 * c0) * nch + 2 * d) = v;
+				const uint32_t v = *(const uint32_t *)(s_out + (size_t)orl * (2 * ITW) * wps + 2 * d);
+				*(uint32_t *)((uint16_t *)frame + (size_t)orow * job.out_pitch + (size_t)(2 * c0) * wps + 2 * d) = v;
 			}
 		}
 	}
 }
 
 __global__ void __launch_bounds__(NTHREADS) k_inv_plane(const InvPlaneJob *jobs) { inv_plane_tile<false>(jobs, 1); }
-__global__ void __launch_bounds__(NTHREADS) k_inv_packed16(const InvPlaneJob *jobs, int nch) { inv_plane_tile<true>(jobs, nch); }
+__global__ void __launch_bounds__(NTHREADS) k_inv_packed16(const InvPlaneJob *jobs, int nch, int wps) { inv_plane_tile<true>(jobs, nch, wps); }
 
 // 10 -> 8 bit reduction of one reconstructed sample v (= lowfilter +/- high, before the >>1):
 // negative values clamp to zero first (the +2048 / subs_epu16 pair, InvertHorizontalStrip16s.c:4086-4089),

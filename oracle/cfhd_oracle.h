@@ -55,6 +55,8 @@ void orc_inv_spatial_to_yuv422(PIXEL16 *const bands[3][4], const int band_pitch[
 
 /* ---- quantizer tables (host side of the path) ---- */
 /* interlaced last level (decoder.c:21493 + temporal.c:5961): temporal pair after the horizontal synthesis, same packing */
+/* 4:2:2 sample -> YU64 (16-bit words Y0 C1 Y1 C2): the planar 16-bit row route (InvertHorizontalStrip16sToRow16u per plane), see cfhd_oracle_inv.c */
+void orc_inv_spatial_to_yu64(PIXEL16 *const bands[3][4], const int band_pitch[3], int luma_w, int h, int precision, uint16_t *out, int out_pitch_words);
 void orc_inv_frame_to_yuv422(PIXEL16 *const bands[3][4], const int band_pitch[3], int luma_w, int h,
                              int precision, int uyvy, int dither, uint8_t *out, int out_pitch);
 void orc_inv_spatial_to_packed16(PIXEL16 *const bands[4][4], int band_pitch, int w, int h, int precision, int num_channels,

@@ -281,3 +281,37 @@ void orc_inv_spatial_to_rgb48(PIXEL16 *const bands[4][4], int band_pitch, int w,
 	static const int word_of_channel[4] = { 1, 0, 2, 3 };      /* plane G -> word 1, R -> 0, B -> 2 */
 	orc_inv_spatial_to_packed16(bands, band_pitch, w, h, precision, num_channels, word_of_channel, w - (w % 8) - 9, -1, out, out_pitch_words);
 }
+
+/* ---- 4:2:2 samples decoded to YU64 (16-bit words Y0 C1 Y1 C2) -------------------------------------------------------------------
+ * The reference library does NOT take the row-pair route its source suggests at first sight (decoder.c:14446 -> wavelet.c:5403
+ * TransformInverseSpatialToV210, whose "10 bit limit" horizontal pass clamps every column but the first to 1023): probing the built
+ * library shows the signature of the planar 16-bit row route instead -- the one RG48 / b64a output takes (decoder.c:26500-26545
+ * TransformInverseSpatialUniversalThreadedToRow16u + ConvertRow16uToOutput): per plane InvertHorizontalStrip16sToRow16u, i.e. clamp to
+ * `precision` bits and shift up in the vector columns, shift first and saturate to 65535 in the columns of its scalar loop (band columns
+ * >= w - w % 8 - 9, per plane: the chroma planes are half as wide), then the planes interleaved as Y | channel 1, Y | channel 2
+ * (convert.c:14139-14162).  Pinned against the reference decoder in tests/test_oracle_vs_ref.py, highlights included. */
+void orc_inv_spatial_to_yu64(PIXEL16 *const bands[3][4], const int band_pitch[3], int luma_w, int h, int precision, uint16_t *out, int out_pitch_words)
+{
+	int ch, r, k, x;
+	PIXEL16 *el = (PIXEL16 *)malloc((size_t)luma_w * 2), *ol = (PIXEL16 *)malloc((size_t)luma_w * 2);
+	PIXEL16 *eh = (PIXEL16 *)malloc((size_t)luma_w * 2), *oh = (PIXEL16 *)malloc((size_t)luma_w * 2);
+	int *px[2]; px[0] = (int *)malloc((size_t)luma_w * 2 * sizeof(int)); px[1] = (int *)malloc((size_t)luma_w * 2 * sizeof(int));
+	for (r = 0; r < h; r++)
+		for (ch = 0; ch < 3; ch++) {
+			const int w = ch ? luma_w / 2 : luma_w, bp = band_pitch[ch], tail_start = w - (w % 8) - 9;
+			inv_vertical_row(bands[ch][0], bp, bands[ch][2] + (size_t)r * bp, r, h, w, el, ol);
+			inv_vertical_row(bands[ch][1], bp, bands[ch][3] + (size_t)r * bp, r, h, w, eh, oh);
+			inv_horizontal_row_prepack(el, eh, w, px[0]);
+			inv_horizontal_row_prepack(ol, oh, w, px[1]);
+			for (k = 0; k < 2; k++) {
+				uint16_t *o = out + (size_t)(2 * r + k) * out_pitch_words;
+				for (x = 0; x < 2 * w; x++) {
+					const int tail = (x >> 1) >= tail_start, v = px[k][x];
+					const unsigned word = tail ? to16_tail(v, precision) : to16(v, precision);
+					if (ch == 0) o[2 * x] = (uint16_t)word;                 /* luma sample x -> word 2x */
+					else o[4 * x + (ch == 1 ? 1 : 3)] = (uint16_t)word;     /* chroma sample x sits in pixel pair x: channel 1 behind Y0, channel 2 behind Y1 */
+				}
+			}
+		}
+	free(el); free(ol); free(eh); free(oh); free(px[0]); free(px[1]);
+}

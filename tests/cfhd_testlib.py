@@ -673,6 +673,25 @@ def oracle_inverse_yuv422(plan, coeffs, dither, uyvy=0):
     return out
 
 
+def oracle_inverse_yu64(plan, coeffs):
+    """Whole inverse path with the oracle from a dequantized 4:2:2 pyramid to YU64 words (Y0 C1 Y1 C2, 16 bits each; no dither)."""
+    O = oracle()
+    work = coeffs.copy()
+    for c in range(3):
+        for lv in (2, 1):
+            d = plan.band[(c, lv, 0)]
+            bands = (c_i16p * 4)(*[plan.view(work, c, lv, b).ctypes.data_as(c_i16p) for b in range(4)])
+            dst = plan.view(work, c, lv - 1, 0)
+            O.orc_inv_spatial(bands, d["pitch"], d["width"], d["height"], plan.prescale[lv], dst.ctypes.data_as(c_i16p), plan.band[(c, lv - 1, 0)]["pitch"])
+    ptrs = (c_i16p * 12)(*[plan.view(work, c, 0, b).ctypes.data_as(c_i16p) for c in range(3) for b in range(4)])
+    pitches = [plan.band[(c, 0, 0)]["pitch"] for c in range(3)]
+    w = plan.band[(0, 0, 0)]["width"]; h = plan.band[(0, 0, 0)]["height"]
+    out = np.zeros((2 * h, 4 * w), np.uint16)
+    O.orc_inv_spatial_to_yu64.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    O.orc_inv_spatial_to_yu64(ptrs, iarr(pitches), w, h, plan.precision, out.ctypes.data_as(ctypes.c_void_p), 4 * w)
+    return out
+
+
 def oracle_inverse_interlaced_yuv422(plan, coeffs, dither, uyvy=0):
     """Inverse path of an interlaced 4:2:2 sample with the oracle: spatial levels 3 and 2, then the inverse "frame" transform
     (horizontal synthesis of the temporal low / high rows, temporal pair, 10 -> 8 bits)."""

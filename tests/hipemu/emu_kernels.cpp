@@ -161,9 +161,25 @@ void emu_inv_packed16(int16_t **bands, int band_pitch, int w, int h, int display
 		return;
 	}
 	dim3 grid((w + ITW - 1) / ITW, (h + ITH - 1) / ITH, 1);
-	hipemu::launch(grid, dim3(NTHREADS), [&] { k_inv_packed16(jobs.data(), nch); });
+	hipemu::launch(grid, dim3(NTHREADS), [&] { k_inv_packed16(jobs.data(), nch, nch); });
 }
 void emu_inv_packed16_use_strip(int on) { g_inv_packed16_strip = on; }
+
+// The last level of a 4:2:2 sample to YU64 (words Y0 C1 Y1 C2): k_inv_packed16 with per-plane widths and word strides, as DecodeBatch::prepare sets it up.
+// bands[c*4+b], band_pitch[c]; luma band w x h.
+void emu_inv_yu64(int16_t **bands, const int *band_pitch, int w, int h, int display_height, int precision, uint16_t *out, int out_pitch_words)
+{
+	std::vector<InvPlaneJob> jobs(3);
+	for (int c = 0; c < 3; c++) {
+		InvPlaneJob &job = jobs[c];
+		memset(&job, 0, sizeof(job));
+		for (int b = 0; b < 4; b++) job.band[b] = bands[c * 4 + b];
+		job.band_pitch = band_pitch[c]; job.width = c ? w / 2 : w; job.height = h; job.descale = 0;
+		job.out = (int16_t *)(out + (c == 0 ? 0 : (c == 1 ? 1 : 3))); job.out_pitch = out_pitch_words; job.xstride = c ? 4 : 2; job.precision = precision; job.display_height = display_height;
+	}
+	dim3 grid((w + ITW - 1) / ITW, (h + ITH - 1) / ITH, 1);
+	hipemu::launch(grid, dim3(NTHREADS), [&] { k_inv_packed16(jobs.data(), 3, 2); });
+}
 
 void emu_fwd_frame_yuv422(const uint8_t *in, int in_pitch, int width, int height, int display_height, int uyvy, int shift,
                           const int *quant /*[3][4]*/, int mpq, int16_t **out /*[3][4]*/, const int *out_pitch)

@@ -440,6 +440,48 @@ def test_b64a_encode_to_rgb444_bitstream_identical(w, h):
     assert 10 * np.log10(65535.0 ** 2 / np.mean((rgb.astype(np.float64) - src) ** 2)) > 40.0
 
 
+@pytest.mark.parametrize("w,h,src", [(320, 240, "yuy2"), (336, 252, "yu64"), (720, 486, "yuy2"), (1920, 1080, "yu64")])
+def test_yu64_decode_equals_reference_exactly(w, h, src):
+    """4:2:2 samples decoded to YU64 (16-bit words Y0 C1 Y1 C2, no dither): word for word what the reference decoder delivers -- the
+    reference sample of a YUY2 / of a YU64 frame with ramps into both clips (highlights saturate to 1023 << 6 in the reference's vector
+    columns and to 65535 in its scalar tail columns, per plane) --, through CFHD_DecodeSample; the YU64 round trip of the product alone
+    decodes to the source within the quantizer's error; interlaced samples and half resolution are refused."""
+    if src == "yu64":
+        f16 = (np.random.default_rng(w + h).integers(0, 1024, size=(h, w * 2)) << 6).astype(np.uint16)
+        f16[: h // 3] = (np.linspace(0, 65535, w * 2)[None, :]).astype(np.uint16)
+        f = np.frombuffer(f16.tobytes(), np.uint8).copy(); p = w * 4
+        sample = ref_encode_frames([f], p, w, h, fourcc("YU64"))[0]
+    else:
+        f, p = synth_yuy2(w, h, 11)
+        sample = ref_encode_frames([f], p, w, h, PIX_YUY2)[0]
+    got, gpitch, aw, ah = amd_decode_sample(sample, fourcc("YU64"))
+    assert (aw, ah) == (w, h) and gpitch == (w * 4 + 15) // 16 * 16
+    mine = np.frombuffer(got.tobytes(), np.uint16).reshape(h, gpitch // 2)[:, : w * 2]
+    for attempt in range(6):                            # (the reference's threaded decoder occasionally damages a frame)
+        dec, dpitch = ref_decode_sample(sample, w, h, fourcc("YU64"))
+        img = np.frombuffer(dec.tobytes(), dtype=np.uint16).reshape(h, dpitch // 2)[:, : w * 2]
+        if np.array_equal(mine, img): break
+    assert np.array_equal(mine, img), "%d words differ" % (mine != img).sum()
+    if src == "yu64":
+        assert (mine == 65535).any() and (mine == 1023 << 6).any()
+        own = amd_encode_frames([f], p, w, h, fourcc("YU64"))[0]
+        assert mask_volatile_metadata(own) == mask_volatile_metadata(sample)
+    # gates: half resolution and interlaced samples have no YU64 output here
+    L = product()
+    dec = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
+    aw_ = ctypes.c_int(); ah_ = ctypes.c_int(); af_ = ctypes.c_uint32()
+    sb = ctypes.create_string_buffer(sample, len(sample))
+    assert L.CFHD_PrepareToDecode(dec, 0, 0, fourcc("YU64"), 2, 0, sb, 512, ctypes.byref(aw_), ctypes.byref(ah_), ctypes.byref(af_)) != 0
+    if src == "yuy2":
+        isample = ref_encode_frames([f], p, w, h, PIX_YUY2, flags=1)[0]
+        sb2 = ctypes.create_string_buffer(isample, len(isample))
+        assert L.CFHD_PrepareToDecode(dec, 0, 0, fourcc("YU64"), 1, 0, sb2, 512, ctypes.byref(aw_), ctypes.byref(ah_), ctypes.byref(af_)) == 0
+        out = np.ones(w * 4 * h, np.uint8)
+        assert L.CFHD_DecodeSample(dec, sb2, len(isample), out.ctypes.data_as(ctypes.c_void_p), w * 4) != 0
+        assert not out.any()                                # a failed decode zero-fills the output (decoder.c:11850-11859)
+    L.CFHD_CloseDecoder(dec)
+
+
 @pytest.mark.parametrize("name", sorted(RGB10_FORMATS))
 @pytest.mark.parametrize("w,h", [(320, 240), (1280, 720)])
 def test_rgb10_encode_to_rgb444_bitstream_identical(w, h, name):

@@ -504,6 +504,33 @@ def test_inv_packed16_last_level_of_444_formats(w, h, dh, nch, b64a):
     assert (want == 65535).any() and (want == 65520).any() and (want == 0).any()
 
 
+@pytest.mark.parametrize("w,h,dh", [(32, 8, 16), (64, 16, 32), (168, 20, 37), (360, 33, 66), (200, 17, 30)])
+def test_inv_yu64_last_level_equals_oracle(w, h, dh):
+    """k_inv_packed16 with per-plane widths and word strides (YU64 output of 4:2:2 samples: words Y0 C1 Y1 C2) = oracle restatement of the
+    reference's planar 16-bit row route (pinned against the reference decoder in test_oracle_vs_ref), incl. the 65535-vs-(1023 << 6)
+    saturation difference between its vector columns and its scalar tail columns, per plane."""
+    rng = np.random.default_rng(w * 5 + h)
+    bands, pitches = [], []
+    for c in range(3):
+        cw = w // 2 if c else w
+        pitch = (cw + 7) // 8 * 8
+        bs = [np.zeros((h, pitch), np.int16) for _ in range(4)]
+        bs[0][:, :cw] = rand_plane(rng, cw, h, 12)              # LL1 of 10-bit components: up to 4 * 1023, here beyond it to hit the clamps
+        for k in range(1, 4): bs[k][:, :cw] = rand_plane(rng, cw, h, 9, signed=True)
+        bands.append(bs); pitches.append(pitch)
+    flat = [p16(a) for c in range(3) for a in bands[c]]
+    O = oracle()
+    O.orc_inv_spatial_to_yu64.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    want = np.zeros((2 * h, 4 * w), np.uint16)
+    O.orc_inv_spatial_to_yu64((c_i16p * 12)(*flat), iarr(pitches), w, h, 10, want.ctypes.data_as(ctypes.c_void_p), 4 * w)
+    got = np.full((dh, 4 * w), 7, np.uint16)
+    E = emu()
+    E.emu_inv_yu64.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    E.emu_inv_yu64((c_i16p * 12)(*flat), iarr(pitches), w, h, dh, 10, got.ctypes.data_as(ctypes.c_void_p), 4 * w)
+    assert np.array_equal(got, want[:dh])
+    assert (want == 65535).any() and (want == 1023 << 6).any() and (want == 0).any()
+
+
 @pytest.mark.parametrize("w,h,dh", [(40, 8, 8), (300, 24, 21)])
 def test_unpack_byr4_equals_oracle(w, h, dh):
     """k_unpack_byr4 (Bayer mosaic -> G, R-G, B-G, G1-G2 planes through the log-90 curve) = oracle restatement of ConvertBYR4ToFrame16s

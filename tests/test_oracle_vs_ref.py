@@ -151,6 +151,30 @@ def test_reference_rg48_decode_equals_oracle(w, h):
     assert np.array_equal(mine, img)
 
 
+@pytest.mark.parametrize("w,h,src", [(192, 96, "yuy2"), (320, 240, "yuy2"), (336, 252, "yu64"), (720, 486, "yuy2"), (1920, 1080, "yu64")])
+def test_reference_yu64_decode_equals_oracle(w, h, src):
+    """Pins orc_inv_spatial_to_yu64: the reference decodes a 4:2:2 sample to YU64 (16-bit words Y0 C1 Y1 C2) through its 10-bit row
+    routines (wavelet.c:5403) -- deterministic, no dither; the top and bottom band rows take the ordinary horizontal pass, the rows between
+    the "10 bit limit" pass, so highlights clip at 65535 in the first two and last two picture rows (and the first / last column) and at
+    1023 << 6 elsewhere.  Word for word."""
+    if src == "yu64":
+        f16 = (np.random.default_rng(w + h).integers(0, 1024, size=(h, w * 2)) << 6).astype(np.uint16)
+        f16[: h // 3] = (np.linspace(0, 65535, w * 2)[None, :]).astype(np.uint16)            # ramps into both clips
+        f = np.frombuffer(f16.tobytes(), np.uint8).copy(); p = w * 4
+        sample = ref_encode_frames([f], p, w, h, fourcc("YU64"))[0]
+    else:
+        f, p = synth_yuy2(w, h, 11)
+        sample = ref_encode_frames([f], p, w, h, PIX_YUY2)[0]
+    plan = Plan(w, h, pixkind=PIXKIND["YU64"])            # (the output format decides the bias of the lowpass band: 4 instead of 24, decoder.c:12270)
+    mine = oracle_inverse_yu64(plan, host_decode_pyramid(sample, plan))[:h]
+    for attempt in range(6):                            # (the reference's threaded decoder occasionally damages a frame)
+        dec, dpitch = ref_decode_sample(sample, w, h, fourcc("YU64"))
+        img = np.frombuffer(dec.tobytes(), dtype=np.uint16).reshape(h, dpitch // 2)[:, : w * 2]
+        if np.array_equal(mine, img): break
+    bad = np.argwhere(mine != img)
+    assert len(bad) == 0, (len(bad), bad[:8].tolist(), [(int(mine[r, c]), int(img[r, c])) for r, c in bad[:8]])
+
+
 @pytest.mark.parametrize("w,h", [(192, 96), (320, 240), (1920, 1080)])
 def test_reference_b64a_decode_equals_oracle(w, h):
     """Pins orc_inv_spatial_to_b64a: the reference decodes an RGBA 4:4:4:4 sample to b64a through its planar 16-bit rows
