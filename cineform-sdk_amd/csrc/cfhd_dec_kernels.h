@@ -318,24 +318,26 @@ __device__ __forceinline__ int dx_runin_candidates(const uint32_t bytes, const u
 	if (lane < 27) {
 		DxBitsAhead B;
 		B.seek(s_words, pos);
-		for (;;) {
-			if (pos >= (uint32_t)DX_LANE_BITS) { end = pos; break; }
-			if (pos >= limit) break;
-			const uint32_t win = B.window();
-			const uint32_t t = s_tab[win >> (32 - DX_K)];
-			const uint32_t ahead = B.prefetch(s_words);
-			const uint32_t used = (t >> 4) & 15u;
-			uint32_t adv = t & 15u;
-			if (adv) {
-				if (used && pos + used <= (uint32_t)DX_LANE_BITS) adv = used;
-			} else {
-				const DxSym sy = dx_long_symbol(t >> 16, s_long, win);
-				if (sy.type == DX_T_RUN) adv = (uint32_t)sy.len;
-				else if (sy.type == DX_T_VALUE) adv = (uint32_t)sy.len + 1u;
-				else break;
+		bool alive = true;                                    // (one loop, one way out: see dx_walk)
+		do {
+			if (pos >= (uint32_t)DX_LANE_BITS) { end = pos; alive = false; }
+			else if (pos >= limit) alive = false;
+			else {
+				const uint32_t win = B.window();
+				const uint32_t t = s_tab[win >> (32 - DX_K)];
+				const uint32_t ahead = B.prefetch(s_words);
+				const uint32_t used = (t >> 4) & 15u;
+				uint32_t adv = t & 15u;
+				adv = (adv != 0u && used != 0u && pos + used <= (uint32_t)DX_LANE_BITS) ? used : adv;
+				if (adv == 0u) {
+					const DxSym sy = dx_long_symbol(t >> 16, s_long, win);
+					if (sy.type == DX_T_RUN) adv = (uint32_t)sy.len;
+					else if (sy.type == DX_T_VALUE) adv = (uint32_t)sy.len + 1u;
+					else alive = false;
+				}
+				if (alive) { pos += adv; B.skip((int)adv, ahead); }
 			}
-			pos += adv; B.skip((int)adv, ahead);
-		}
+		} while (alive);
 	}
 	unsigned long long mask = __ballot(lane < 27 && end < DX_SPECIAL);
 	int n = 0;
