@@ -524,7 +524,7 @@ __global__ void __launch_bounds__(DX_THREADS) k_dec_plan_fill(const DxBandJob *j
 
 __global__ void __launch_bounds__(DX_THREADS) CFHD_DX_INDEX_ATTR k_dec_index(const DxChunkDesc *chunk_desc, const uint32_t *counters, const DecIdxTables *T,
                                                           uint32_t *entries, DxChunkRec *recs, DxChunkAlt *alts, int speculate, uint32_t *stats,
-                                                          uint32_t *alt_entries, uint32_t alt_slots, uint32_t *alt_counter)
+                                                          uint32_t *alt_entries, uint32_t alt_slots, uint32_t *alt_counter, uint32_t *next_chunk)
 {
 	__shared__ uint32_t s_tab[1 << DX_K];
 	__shared__ uint32_t s_long[DX_LONG_MAX];
@@ -535,17 +535,21 @@ __global__ void __launch_bounds__(DX_THREADS) CFHD_DX_INDEX_ATTR k_dec_index(con
 	const int wave = wave_uniform((int)(threadIdx.x >> 6));
 	uint32_t *s_words = s_words_all[wave];
 	const uint32_t gwave = (uint32_t)blockIdx.x * DX_WAVES + (uint32_t)wave, nwaves = (uint32_t)gridDim.x * DX_WAVES;
-	// software pipeline over this wave's chunks: while chunk c is walked, the payload words of chunk c + nwaves are already on their way
-	// into registers
+	// software pipeline over this wave's chunks: while chunk c is walked, the payload words of its next chunk are already on their way
+	// into registers.  The first chunk of a wave is its own number, the others are handed out by a counter (*next_chunk, zero at launch):
+	// chunks differ in cost, and with a fixed stride a workgroup that gets its CU late -- another queue's kernel holds it: the blit kernel of
+	// a sample download, say -- made the whole launch wait for a full second pass (seen under rocprofv3 as 2x the launch time).
 	uint32_t c = gwave;
 	if (c >= total) return;
 	DxChunkDesc d = chunk_desc[c];
 	DxFetch F;
 	dx_fetch_chunk(d.bits, d.bytes, d.k, F);
 #pragma unroll 1
-	for (; c < total; c += nwaves) {
+	for (; c < total;) {
 		dx_store_stage(F, s_words);
-		const uint32_t c1 = c + nwaves;
+		uint32_t c1 = 0;
+		if (wave_lane() == 0) c1 = nwaves + atomicAdd(next_chunk, 1u);
+		c1 = wave_get(c1, 0);
 		DxChunkDesc d1 = d;
 #if !defined(CFHD_DX_NOPREFETCH)
 		if (c1 < total) { d1 = chunk_desc[c1]; dx_fetch_chunk(d1.bits, d1.bytes, d1.k, F); }
@@ -595,7 +599,7 @@ __global__ void __launch_bounds__(DX_THREADS) CFHD_DX_INDEX_ATTR k_dec_index(con
 #if defined(CFHD_DX_NOPREFETCH)
 		if (c1 < total) { d1 = chunk_desc[c1]; dx_fetch_chunk(d1.bits, d1.bytes, d1.k, F); }
 #endif
-		d = d1;
+		d = d1; c = c1;
 	}
 }
 

@@ -221,7 +221,7 @@ int GpuEntropyDecoder::prepare(const FramePlan &plan, int nframes, int16_t *d_co
 		HIPCHK(hipMalloc(&d_chunk_base_, (size_t)max_chunks_ * 4));
 		HIPCHK(hipMalloc(&d_chunk_job_, (size_t)max_chunks_ * sizeof(dev::DxChunkDesc)));
 		HIPCHK(hipMalloc(&d_sums_, max_bands * sizeof(dev::DxBandSum)));
-		HIPCHK(hipMalloc(&d_counters_, 16));
+		HIPCHK(hipMalloc(&d_counters_, 32));          // [0] chunks, [1] bands to repair, [2] chunks to re-index, [3] alternate-entry slots taken, [4] next chunk of k_dec_index
 		HIPCHK(hipMalloc(&d_repair_, max_bands * 4));
 		HIPCHK(hipMalloc(&d_alts_, (size_t)max_chunks_ * sizeof(dev::DxChunkAlt)));
 		HIPCHK(hipMalloc(&d_reindex_, (size_t)max_chunks_ * sizeof(dev::DxReindex)));
@@ -235,7 +235,7 @@ int GpuEntropyDecoder::prepare(const FramePlan &plan, int nframes, int16_t *d_co
 			if (se && atoi(se)) { HIPCHK(hipMalloc(&d_stats_, 64)); HIPCHK(hipMemset(d_stats_, 0, 64)); }
 		}
 		HIPCHK(hipHostMalloc((void **)&h_chunk_job_, (size_t)max_chunks_ * sizeof(dev::DxChunkDesc), hipHostMallocDefault));
-		HIPCHK(hipHostMalloc((void **)&h_counters_, 16, hipHostMallocDefault));
+		HIPCHK(hipHostMalloc((void **)&h_counters_, 32, hipHostMallocDefault));
 		int cus = 256;
 		(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
 		const char *g1 = getenv("CFHD_AMD_DX_GRID_INDEX"), *g3 = getenv("CFHD_AMD_DX_GRID_TILES");
@@ -340,7 +340,7 @@ int GpuEntropyDecoder::launch()
 		const uint32_t nchunks = dx_number_chunks(host_->flat_bands, nb, &cj);
 		if (nchunks > max_chunks_) return -5;
 		memcpy(h_chunk_job_, cj.data(), cj.size() * sizeof(dev::DxChunkDesc));
-		h_counters_[0] = nchunks; h_counters_[1] = 0; h_counters_[2] = 0; h_counters_[3] = 0;
+		h_counters_[0] = nchunks; h_counters_[1] = 0; h_counters_[2] = 0; h_counters_[3] = 0; h_counters_[4] = 0;
 		HIPCHK(hipMemsetAsync(d_errors_, 0, sizeof(int), st));
 		for (int f = 0; f < act; f++)
 			if (host_->host_bytes[f]) HIPCHK(hipMemcpyAsync(d_samples_ + cap_ * f, h_samples_ + cap_ * f, host_->host_bytes[f], hipMemcpyHostToDevice, st));
@@ -348,7 +348,7 @@ int GpuEntropyDecoder::launch()
 		HIPCHK(hipMemcpyAsync(d_lowjobs_, host_->flat_lows, (size_t)act * nch * sizeof(dev::DecLowpassJob), hipMemcpyHostToDevice, st));
 		if (interlaced_) HIPCHK(hipMemcpyAsync(d_diffjobs_, host_->flat_diffs, (size_t)act * nch * sizeof(dev::DecDiffJob), hipMemcpyHostToDevice, st));
 		HIPCHK(hipMemcpyAsync(d_chunk_job_, h_chunk_job_, (size_t)nchunks * sizeof(dev::DxChunkDesc), hipMemcpyHostToDevice, st));
-		HIPCHK(hipMemcpyAsync(d_counters_, h_counters_, 16, hipMemcpyHostToDevice, st));
+		HIPCHK(hipMemcpyAsync(d_counters_, h_counters_, 20, hipMemcpyHostToDevice, st));
 		(void)hipGetLastError();
 		HIPCHK(hipEventRecord((hipEvent_t)ev_[0], st));
 		HIPCHK(hipEventRecord((hipEvent_t)ev_[1], st));
@@ -405,7 +405,7 @@ int GpuEntropyDecoder::launch_dx(bool device_jobs, int njobs, uint32_t host_chun
 	const dev::DxTilePlan tp = dx_tile_plan(plan_, dp, frames, skip_level1_);
 	const char *spec_env = getenv("CFHD_AMD_DX_SPECULATE");
 	const bool speculate = !(spec_env && atoi(spec_env) == 0);            // 0: every chunk goes through the repair path (tests)
-	if (device_jobs) HIPCHK(hipMemsetAsync((uint32_t *)d_counters_ + 1, 0, 12, st));     // the repair and re-index lists and the alternate-entry slots start empty (the host path uploads zeroed counters)
+	if (device_jobs) HIPCHK(hipMemsetAsync((uint32_t *)d_counters_ + 1, 0, 16, st));     // the repair and re-index lists, the alternate-entry slots and the chunk counter start at zero (the host path uploads zeroed counters)
 	if (device_jobs) {
 		dev::k_dec_plan<<<1, 1024, 0, st>>>(jobs, njobs, max_chunks_, (uint32_t *)d_counters_, d_errors_);
 		dev::k_dec_plan_fill<<<(njobs + dev::DX_WAVES - 1) / dev::DX_WAVES, dev::DX_THREADS, 0, st>>>(jobs, njobs, (dev::DxChunkDesc *)d_chunk_job_, (const uint32_t *)d_counters_);
@@ -418,7 +418,7 @@ int GpuEntropyDecoder::launch_dx(bool device_jobs, int njobs, uint32_t host_chun
 	if (g1 < 1) g1 = 1;
 	if (g3 < 1) g3 = 1;
 	dev::k_dec_index<<<g1, dev::DX_THREADS, 0, st>>>((const dev::DxChunkDesc *)d_chunk_job_, (const uint32_t *)d_counters_, T, (uint32_t *)d_entries_, (dev::DxChunkRec *)d_recs_, (dev::DxChunkAlt *)d_alts_, speculate ? 1 : 0, (uint32_t *)d_stats_,
-	                                                 (uint32_t *)d_alt_entries_, alt_slots_, (uint32_t *)d_counters_ + 3);
+	                                                 (uint32_t *)d_alt_entries_, alt_slots_, (uint32_t *)d_counters_ + 3, (uint32_t *)d_counters_ + 4);
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[5], st));
 	dev::k_dec_chain<<<(njobs + dev::DX_WAVES - 1) / dev::DX_WAVES, dev::DX_THREADS, 0, st>>>(jobs, njobs, (const dev::DxChunkRec *)d_recs_, (const dev::DxChunkAlt *)d_alts_, (uint32_t *)d_chunk_base_,
 	                                                                                            (dev::DxBandSum *)d_sums_, d_errors_, (uint32_t *)d_repair_, (dev::DxReindex *)d_reindex_, (uint32_t *)d_counters_);

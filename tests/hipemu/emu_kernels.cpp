@@ -468,7 +468,7 @@ extern "C" int emu_entropy_decode_dx(const uint8_t *sample, size_t size, int pix
 	memcpy(two, sample, size); memcpy(two + stride, sample, size);
 	int errors = 0;
 	const uint32_t max_chunks = (uint32_t)(nframes * (size / dev::DX_CHUNK_BYTES + dp.bands_per_frame + 1));
-	std::vector<dev::DxChunkDesc> chunk_job(max_chunks); std::vector<uint32_t> counters(4, 0);
+	std::vector<dev::DxChunkDesc> chunk_job(max_chunks); std::vector<uint32_t> counters(8, 0);
 	if (mode == 2) {
 		const uint32_t sizes[2] = { (uint32_t)size, (uint32_t)size };
 		hipemu::launch(dim3(2), dim3(dev::DEC_PARSE_THREADS), [&] { dev::k_dec_parse(two, stride, sizes, 2, &dp, pyr.data(), plan.coeff_elems, jobs.data(), lows.data(), &errors, diffs.data()); });
@@ -491,10 +491,10 @@ extern "C" int emu_entropy_decode_dx(const uint8_t *sample, size_t size, int pix
 	std::vector<dev::DxChunkAlt> alts(nchunks + 1);
 	std::vector<dev::DxReindex> reindex((size_t)nchunks + 1);
 	std::vector<uint32_t> repair_list((size_t)njobs + 1);
-	counters[1] = 0; counters[2] = 0; counters[3] = 0;
+	counters[1] = 0; counters[2] = 0; counters[3] = 0; counters[4] = 0;
 	const uint32_t alt_slots = 3;                       // room for the candidates of one or two chunks only: both ways of k_dec_reindex (copy, index again) are exercised
 	std::vector<uint32_t> alt_entries((size_t)alt_slots * dev::DX_ENTRY_STRIDE + 16, 0xdeadbeefu);
-	hipemu::launch(dim3((unsigned)grid), dim3(dev::DX_THREADS), [&] { dev::k_dec_index(chunk_job.data(), counters.data(), &tables, entries.data(), recs.data(), alts.data(), mode != 1, g_dx_stats, alt_entries.data(), alt_slots, &counters[3]); });
+	hipemu::launch(dim3((unsigned)grid), dim3(dev::DX_THREADS), [&] { dev::k_dec_index(chunk_job.data(), counters.data(), &tables, entries.data(), recs.data(), alts.data(), mode != 1, g_dx_stats, alt_entries.data(), alt_slots, &counters[3], &counters[4]); });
 	hipemu::launch(dim3((unsigned)(njobs + dev::DX_WAVES - 1) / dev::DX_WAVES), dim3(dev::DX_THREADS), [&] { dev::k_dec_chain(jobs.data(), njobs, recs.data(), alts.data(), chunk_base.data(), sums.data(), &errors, repair_list.data(), reindex.data(), counters.data()); });
 	hipemu::launch(dim3(2), dim3(dev::DX_THREADS), [&] { dev::k_dec_repair(jobs.data(), &tables, entries.data(), recs.data(), alts.data(), chunk_base.data(), sums.data(), &errors, repair_list.data(), reindex.data(), counters.data(), g_dx_stats); });
 	hipemu::launch(dim3(3), dim3(dev::DX_THREADS), [&] { dev::k_dec_reindex(jobs.data(), &tables, entries.data(), reindex.data(), counters.data(), g_dx_stats, alts.data(), alt_entries.data()); });
