@@ -840,9 +840,9 @@ CFHD_Error CFHD_GetOutputFormats(CFHD_DecoderRef ref, void *sample, size_t size,
 	if (!ref || !arr) return ERR_INVALID_ARGUMENT;
 	ParsedSample ps;
 	const bool known = sample && parse_sample((const uint8_t *)sample, size, &ps) >= 0;
-	uint32_t fmts[5]; int total = 0;
+	uint32_t fmts[8]; int total = 0;
 	if (!known || ps.encoded_format == ENC_YUV422) { fmts[total++] = FMT_YUY2; fmts[total++] = FMT_2VUY; fmts[total++] = FMT_YU64; }
-	if (!known || ps.encoded_format == ENC_RGB444) fmts[total++] = FMT_RG48;
+	if (!known || ps.encoded_format == ENC_RGB444) { fmts[total++] = FMT_RG48; fmts[total++] = FMT_RG24; fmts[total++] = FMT_BGRA; fmts[total++] = FMT_BGRa; }
 	if (!known || ps.encoded_format == ENC_RGBA4444) fmts[total++] = FMT_B64A;
 	int n = 0;
 	for (; n < total && n < len; n++) arr[n] = fmts[n];
@@ -893,8 +893,11 @@ CFHD_Error CFHD_PrepareToDecode(CFHD_DecoderRef ref, int, int, CFHD_PixelFormat 
 	// active-metadata pipeline in the reference) are not built
 	// ... and to YU64 (16-bit words Y0 C1 Y1 C2; the reference's planar 16-bit row route, full resolution, progressive samples)
 	if (kind == PIX_YU64 && (encf != ENC_YUV422 || half)) return ERR_BADFORMAT;
-	if (kind == PIX_BYR4 || kind == PIX_V210 || kind == PIX_RG24 || kind == PIX_BGRA || kind == PIX_BGRa || (kind >= PIX_R210 && kind <= PIX_AR10)) return ERR_BADFORMAT;     // encoder inputs only
-	if ((encf == ENC_RGB444) != (kind == PIX_RG48) || (encf == ENC_RGBA4444) != (kind == PIX_B64A)) return ERR_BADFORMAT;
+	// ... and RGB 4:4:4 samples to the 8-bit pixels RG24 / BGRA / BGRa (the RG48 reconstruction reduced with the reference's four-bit dither; full resolution)
+	const bool rgb8 = kind == PIX_RG24 || kind == PIX_BGRA || kind == PIX_BGRa;
+	if (rgb8 && (encf != ENC_RGB444 || half || d->header.width < 32)) return ERR_BADFORMAT;
+	if (kind == PIX_BYR4 || kind == PIX_V210 || (kind >= PIX_R210 && kind <= PIX_AR10)) return ERR_BADFORMAT;     // encoder inputs only
+	if ((encf == ENC_RGB444) != (kind == PIX_RG48 || rgb8) || (encf == ENC_RGBA4444) != (kind == PIX_B64A)) return ERR_BADFORMAT;
 	if (kind == PIX_YU64 && d->header.width < 128) return ERR_BADFORMAT;      // (the tail-column rule of the 16-bit rows is restated for chroma bands of 16 columns and more)
 	bool ok;
 	plan_from_sample(d->header, kind, &d->plan, &ok);

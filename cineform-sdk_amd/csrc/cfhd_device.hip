@@ -86,10 +86,16 @@ bool is_packed16(int pixel_kind) { return pixel_kind == PIX_RG48 || pixel_kind =
 // decoder outputs made of 16-bit words that k_inv_packed16 writes plane by plane: the interleaved RGB(A) pixels, and YU64 (words Y0 C1 Y1 C2:
 // luma every second word, the half-width chroma planes every fourth; the reference decodes 4:2:2 samples to YU64 through the same planar
 // 16-bit rows as RGB 4:4:4 to RG48, oracle/cfhd_oracle_inv.c orc_inv_spatial_to_yu64)
-static bool dec_planes16(int out_kind) { return is_packed16(out_kind) || out_kind == PIX_YU64; }
-static int dec_word_of_channel(int out_kind, int c) { return out_kind == PIX_YU64 ? (c == 0 ? 0 : (c == 1 ? 1 : 3)) : packed_word_of_channel(out_kind, c); }
-static int dec_stride_of_channel(int out_kind, int c, int nch) { return out_kind == PIX_YU64 ? (c == 0 ? 2 : 4) : nch; }
-static int dec_words_per_position(int out_kind, int nch) { return out_kind == PIX_YU64 ? 2 : nch; }
+// ... and the 8-bit RGB pixels B, G, R(, A) of RGB 4:4:4 samples (RG24, BGRA: bottom row first; BGRa: top row first), which the same kernel writes
+// in its byte mode: the 12-bit component doubled + 9 + a four-bit dither, >> 5 (orc_inv_spatial_to_rgb8: the reference's model)
+static bool dec_rgb8(int out_kind) { return out_kind == PIX_RG24 || out_kind == PIX_BGRA || out_kind == PIX_BGRa; }
+static int rgb8_bytes(int out_kind) { return out_kind == PIX_RG24 ? 3 : 4; }
+static bool dec_planes16(int out_kind) { return is_packed16(out_kind) || out_kind == PIX_YU64 || dec_rgb8(out_kind); }
+// position of plane c inside the pixel: 16-bit word, or byte for the 8-bit formats (planes G, R, B -> bytes 1, 2, 0)
+static int dec_word_of_channel(int out_kind, int c) { return out_kind == PIX_YU64 ? (c == 0 ? 0 : (c == 1 ? 1 : 3)) : (dec_rgb8(out_kind) ? (c == 0 ? 1 : (c == 1 ? 2 : 0)) : packed_word_of_channel(out_kind, c)); }
+static int dec_stride_of_channel(int out_kind, int c, int nch) { return out_kind == PIX_YU64 ? (c == 0 ? 2 : 4) : (dec_rgb8(out_kind) ? rgb8_bytes(out_kind) : nch); }
+static int dec_words_per_position(int out_kind, int nch) { return out_kind == PIX_YU64 ? 2 : (dec_rgb8(out_kind) ? rgb8_bytes(out_kind) : nch); }
+static int16_t *dec_plane_out(void *frame, int out_kind, int c) { return dec_rgb8(out_kind) ? (int16_t *)((uint8_t *)frame + dec_word_of_channel(out_kind, c)) : (int16_t *)((uint16_t *)frame + dec_word_of_channel(out_kind, c)); }
 // encoder input made of 16-bit words that k_fwd_packed16 picks apart (per channel: first word, words from sample to sample, right shift).
 // YU64 (Codec/frame.c:1556 ConvertYU64ToFrame16s + convert.c:3345, :14375): words Y0 C1 Y1 C2, every word >> 6 to 10 bits, channel 1 = C1, 2 = C2.
 // v210 (frame.c:1431 ConvertV210ToFrame16s): three 10-bit samples per 32-bit word, FwdPlaneJob::layout tells the loader which component to pick.
@@ -574,7 +580,8 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 	const bool rgb_ok = ((out_kind == PIX_RG48 && plan.encoded_format == ENC_RGB444) || (out_kind == PIX_B64A && plan.encoded_format == ENC_RGBA4444)) &&
 	                    plan.ch[0].band[0][0].width >= 16;   // k_inv_packed16's tail-column rule assumes the reference's vector path
 	const bool yu64_ok = out_kind == PIX_YU64 && plan.encoded_format == ENC_YUV422 && !half && plan.ch[1].band[0][0].width >= 16;
-	if (!yuv_ok && !rgb_ok && !yu64_ok) { g_err = "output format not supported by the GPU path yet"; return -2; }
+	const bool rgb8_ok = dec_rgb8(out_kind) && plan.encoded_format == ENC_RGB444 && !half && plan.ch[0].band[0][0].width >= 16 && plan.ch[0].band[0][0].width % 2 == 0;
+	if (!yuv_ok && !rgb_ok && !yu64_ok && !rgb8_ok) { g_err = "output format not supported by the GPU path yet"; return -2; }
 	plan_ = plan; n_ = nframes; out_kind_ = out_kind; own_output_ = own_output;
 	HIPCHK(hipStreamCreateWithFlags((hipStream_t *)&stream_, hipStreamNonBlocking));
 	HIPCHK(hipEventCreate((hipEvent_t *)&ev0_));
@@ -624,9 +631,10 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 				p.band_pitch = plan.ch[c].band[0][0].pitch;
 				p.width = plan.ch[c].band[0][0].width; p.height = plan.ch[c].band[0][0].height; p.descale = 0;
 				uint16_t *frame = own_output ? (uint16_t *)(d_out_ + frame_bytes_ * i) : nullptr;
-				p.out = frame ? (int16_t *)(frame + dec_word_of_channel(out_kind, c)) : nullptr; p.out_pitch = out_pitch_ / 2;
+				p.out = frame ? dec_plane_out(frame, out_kind, c) : nullptr; p.out_pitch = dec_rgb8(out_kind) ? out_pitch_ : out_pitch_ / 2;
 				p.xstride = dec_stride_of_channel(out_kind, c, nch); p.precision = plan.precision; p.display_height = plan.display_height;
 				p.alpha = out_kind == PIX_B64A && c == 3;
+				p.bytes8 = dec_rgb8(out_kind); p.bottom_up = out_kind == PIX_RG24 || out_kind == PIX_BGRA; p.dither_seed = 0x9E3779B9u * (uint32_t)(i + 1);
 			}
 			continue;
 		}
@@ -679,7 +687,7 @@ int DecodeBatch::set_device_output(int i, void *d_out, int pitch)
 	if (dec_planes16(out_kind_)) {
 		for (int c = 0; c < plan_.num_channels; c++) {
 			dev::InvPlaneJob &p = j.l1[(size_t)i * plan_.num_channels + c];
-			p.out = (int16_t *)((uint16_t *)d_out + dec_word_of_channel(out_kind_, c)); p.out_pitch = pitch / 2;
+			p.out = dec_plane_out(d_out, out_kind_, c); p.out_pitch = dec_rgb8(out_kind_) ? pitch : pitch / 2;
 		}
 		jobs_dirty_ = true;
 		return 0;
@@ -784,7 +792,7 @@ int DecodeBatch::launch_inverse(uint32_t dither_seed)
 	} else if (dec_planes16(out_kind_)) {
 		const BandDesc &b = plan_.ch[0].band[0][0];
 		dim3 grid((b.width + dev::ITW - 1) / dev::ITW, (b.height + dev::ITH - 1) / dev::ITH, act);      // one workgroup per tile, all components
-		dev::k_inv_packed16<<<grid, dev::NTHREADS, 0, st>>>(j.l1, nch, dec_words_per_position(out_kind_, nch));
+		dev::k_inv_packed16<<<grid, dev::NTHREADS, 0, st>>>(j.l1, nch, dec_words_per_position(out_kind_, nch), dither_seed);
 	} else if (interlaced_) {                           // (half resolution was served above: the level-1 lowpass planes need no inverse frame transform)
 		const BandDesc &b = plan_.ch[0].band[0][0];
 		if (frame_inverse_quads()) dev::k_inv_frame_yuv422_quad<<<dim3((b.width / 4 + dev::NTHREADS - 1) / dev::NTHREADS, b.height, act), dev::NTHREADS, 0, st>>>(j.yuv, dither_seed);

@@ -71,6 +71,12 @@ struct InvPlaneJob {
 	// out_pitch in words; samples are clamped to `precision` bits and shifted up to 16; rows >= display_height are not written
 	int xstride, precision, display_height;
 	int alpha;                              // k_inv_packed16: this component is the companded alpha plane of an RGBA 4:4:4:4 sample
+	// k_inv_packed16, 8-bit RGB output (RG24, BGRA, BGRa of RGB 4:4:4 samples): `out` is the component's BYTE inside the first pixel, xstride =
+	// bytes per pixel, out_pitch in BYTES; every byte = (12-bit component * 2 + 9 + r) >> 5 with a four-bit dither r per sample (the
+	// reference's model, oracle/cfhd_oracle_inv.c orc_inv_spatial_to_rgb8); bottom_up: picture row y goes to output row display_height - 1 - y;
+	// the fourth byte of four-byte pixels is 255
+	int bytes8, bottom_up;
+	uint32_t dither_seed;
 };
 
 struct InvYuvJob {
@@ -576,6 +582,14 @@ __device__ __forceinline__ void inv_stage_load(uint32_t (&va)[N], const int16_t 
 	}
 }
 
+// Counter-based stand-in for the reference's libc rand() dither: one word of random bits per (frame seed, output row, pixel group).
+__device__ __forceinline__ uint32_t dither_word(uint32_t seed, int row, int group)
+{
+	uint32_t x = seed ^ ((uint32_t)row * 0x9E3779B1u) ^ ((uint32_t)group * 0x85EBCA77u);
+	x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12; x *= 0x297A2D39u; x ^= x >> 15;
+	return x;
+}
+
 // 12-bit component -> 16-bit output word of the 4:4:4(:4) formats; v = lowfilter +/- high before the >>1.  The vector columns of
 // InvertHorizontalStrip16sToRow16u clamp to `precision` bits and shift up (InvertHorizontalStrip16s.c:16596, :16724-16750); the
 // columns its scalar loop handles (band columns >= w - w%8 - 9, :16876-16990) shift first and saturate to 65535.
@@ -601,7 +615,7 @@ __device__ __forceinline__ uint32_t expand_alpha16(uint32_t word)
 // component + ConvertPlanarRGB16uToPackedRGB48): same synthesis, every sample converted with to16() and stored as one word of
 // the interleaved pixel.  gridDim.x = tiles_x * nch as in k_fwd_packed16.
 template <bool PACKED>
-__device__ __forceinline__ void inv_plane_tile(const InvPlaneJob *jobs, int nch, int wps = 0)
+__device__ __forceinline__ void inv_plane_tile(const InvPlaneJob *jobs, int nch, int wps = 0, uint32_t launch_seed = 0u)
 {
 	// wps (PACKED): 16-bit words per sample position of plane 0 in the output row -- nch for the interleaved RGB(A) pixels; 2 for YU64
 	// (words Y0 C1 Y1 C2: luma every second word, the two half-width chroma planes every fourth, InvPlaneJob::xstride), where a tile of
@@ -627,7 +641,8 @@ __device__ __forceinline__ void inv_plane_tile(const InvPlaneJob *jobs, int nch,
 	const int c0 = tile.x * tw, r0 = tile.y * ITH;
 	const bool active = (c0 < w) && (r0 < h);
 	const int rs = inv_tile_first_row(r0, h);
-	const int word = PACKED ? (int)((const uint16_t *)job.out - frame) : 0;
+	const bool bytes8 = PACKED && job.bytes8;
+	const int word = PACKED ? (bytes8 ? (int)((const uint8_t *)job.out - (const uint8_t *)frame) : (int)((const uint16_t *)job.out - frame)) : 0;
 	if (PACKED && comp == 0) { w_first = w; }
 	if (active) {
 		enum { NL = (2 * ILROWS * IDW + NTHREADS - 1) / NTHREADS, NH = (2 * ITH * IDW + NTHREADS - 1) / NTHREADS };
@@ -676,13 +691,22 @@ __device__ __forceinline__ void inv_plane_tile(const InvPlaneJob *jobs, int nch,
 				}
 				const int tail0 = w - (w & 7) - 9;
 				const int xs = job.xstride;
-				uint16_t *dst = s_out + (size_t)(2 * rl + par) * (2 * ITW) * wps + (size_t)(4 * p) * xs + word;      // sample 2 (c - c0) of tile row 2 rl + par
+				const size_t at = (size_t)(2 * rl + par) * (2 * ITW) * wps + (size_t)(4 * p) * xs + word;      // sample 2 (c - c0) of tile row 2 rl + par
+				uint16_t *dst = s_out + at;
+				uint8_t *dst8 = (uint8_t *)s_out + at;
+				const uint32_t dz = bytes8 ? dither_word((job.dither_seed ^ launch_seed) + (uint32_t)word * 0x632BE5ABu, orow, c >> 2) >> (16 * (p & 1)) : 0u;      // four bits per sample
 #pragma unroll
 				for (int k = 0; k < 2; k++) {
 					if (c + k >= w) break;
 					const bool tail = c + k >= tail0;
 					uint32_t we = to16(e[k], job.precision, tail), wo = to16(o[k], job.precision, tail);
 					if (job.alpha) { we = expand_alpha16(we); wo = expand_alpha16(wo); }
+					if (bytes8) {
+						we = ((we >> 3) + 9u + ((dz >> (8 * k)) & 15u)) >> 5; wo = ((wo >> 3) + 9u + ((dz >> (8 * k + 4)) & 15u)) >> 5;
+						dst8[(2 * k) * xs] = (uint8_t)(we > 255u ? 255u : we);
+						dst8[(2 * k + 1) * xs] = (uint8_t)(wo > 255u ? 255u : wo);
+						continue;
+					}
 					dst[(2 * k) * xs] = (uint16_t)we;
 					dst[(2 * k + 1) * xs] = (uint16_t)wo;
 				}
@@ -715,6 +739,19 @@ __device__ __forceinline__ void inv_plane_tile(const InvPlaneJob *jobs, int nch,
 		const int w = w_first, h = job.height, c0 = tile.x * ITW, r0 = tile.y * ITH;
 		if (c0 < w && r0 < h) {
 			const int npx = 2 * ((w - c0) < ITW ? (w - c0) : ITW);                       // sample positions of plane 0 in the tile's rows inside the frame
+			if (job.bytes8) {
+				// wps = bytes per pixel here; an even band width makes npx a multiple of 4: whole dwords for three-byte pixels too
+				const int row_dw = npx * wps / 4;
+				for (int i = tid; i < 2 * ITH * row_dw; i += NTHREADS) {
+					const int orl = i / row_dw, d = i - orl * row_dw;
+					const int orow = 2 * r0 + orl;
+					if (orow >= job.display_height || orow >= 2 * h) continue;
+					uint32_t v = *(const uint32_t *)((const uint8_t *)s_out + (size_t)orl * (2 * ITW) * wps + 4 * d);
+					if (wps == 4) v |= 0xff000000u;                                          // alpha
+					const int yrow = job.bottom_up ? job.display_height - 1 - orow : orow;
+					*(uint32_t *)((uint8_t *)frame + (size_t)yrow * job.out_pitch + (size_t)(2 * c0) * wps + 4 * d) = v;
+				}
+			} else {
 			const int row_dw = npx * wps / 2;                                            // (an even number: whole dwords)
 			for (int i = tid; i < 2 * ITH * row_dw; i += NTHREADS) {
 				const int orl = i / row_dw, d = i - orl * row_dw;
@@ -723,12 +760,13 @@ __device__ __forceinline__ void inv_plane_tile(const InvPlaneJob *jobs, int nch,
 				const uint32_t v = *(const uint32_t *)(s_out + (size_t)orl * (2 * ITW) * wps + 2 * d);
 				*(uint32_t *)((uint16_t *)frame + (size_t)orow * job.out_pitch + (size_t)(2 * c0) * wps + 2 * d) = v;
 			}
+			}
 		}
 	}
 }
 
 __global__ void __launch_bounds__(NTHREADS) k_inv_plane(const InvPlaneJob *jobs) { inv_plane_tile<false>(jobs, 1); }
-__global__ void __launch_bounds__(NTHREADS) k_inv_packed16(const InvPlaneJob *jobs, int nch, int wps) { inv_plane_tile<true>(jobs, nch, wps); }
+__global__ void __launch_bounds__(NTHREADS) k_inv_packed16(const InvPlaneJob *jobs, int nch, int wps, uint32_t launch_seed) { inv_plane_tile<true>(jobs, nch, wps, launch_seed); }
 
 // 10 -> 8 bit reduction of one reconstructed sample v (= lowfilter +/- high, before the >>1):
 // negative values clamp to zero first (the +2048 / subs_epu16 pair, InvertHorizontalStrip16s.c:4086-4089),
@@ -740,14 +778,6 @@ __device__ __forceinline__ uint32_t to8(int v, int shift, int dither)
 	return (uint32_t)(x > 255 ? 255 : x);
 }
 // pk_to8: the same on two 16-bit lanes (cfhd_gfx950.h)
-
-// Counter-based stand-in for the reference's libc rand() dither: one word of random bits per (frame seed, output row, pixel group).
-__device__ __forceinline__ uint32_t dither_word(uint32_t seed, int row, int group)
-{
-	uint32_t x = seed ^ ((uint32_t)row * 0x9E3779B1u) ^ ((uint32_t)group * 0x85EBCA77u);
-	x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12; x *= 0x297A2D39u; x ^= x >> 15;
-	return x;
-}
 
 __global__ void __launch_bounds__(NTHREADS) k_inv_yuv422(const InvYuvJob *jobs, uint32_t launch_seed)
 {

@@ -315,3 +315,30 @@ void orc_inv_spatial_to_yu64(PIXEL16 *const bands[3][4], const int band_pitch[3]
 		}
 	free(el); free(ol); free(eh); free(oh); free(px[0]); free(px[1]);
 }
+
+/* ---- RGB 4:4:4 samples decoded to the 8-bit RGB formats (RG24, BGRA: bottom row first; BGRa: top row first) ------------------------
+ * Probed on the built reference (tests/test_oracle_vs_ref.py): every byte is the 12-bit component of the RG48 decode, doubled, plus 9,
+ * plus a random r in 0..15 per component, >> 5, saturated to 255 -- i.e. out = (v12 + (9 + r) / 2) >> 4: never above the plain
+ * >> 4 by more than one, always equal to it when the low four bits of v12 are <= 3, always one above when they are >= 12 (measured
+ * P(+1) = 0, 0, 0, 0, 1/16, 3/16, ... 15/16, 1, 1, 1, 1 by the low four bits).  The reference draws r with rand(); the oracle takes
+ * it as an input so that both ends of the interval can be computed.  Bytes B, G, R (, A = 255); planes are G, R, B. */
+void orc_inv_spatial_to_rgb8(PIXEL16 *const bands[4][4], int band_pitch, int w, int h, int precision, int display_height, int bytes_per_pixel, int bottom_up,
+                             int r, uint8_t *out, int out_pitch_bytes)
+{
+	const int W = 2 * w;
+	uint16_t *tmp = (uint16_t *)malloc((size_t)2 * h * W * 3 * sizeof(uint16_t));
+	int y, x, c;
+	orc_inv_spatial_to_rgb48(bands, band_pitch, w, h, precision, 3, tmp, W * 3);
+	for (y = 0; y < display_height; y++) {
+		uint8_t *o = out + (size_t)(bottom_up ? display_height - 1 - y : y) * out_pitch_bytes;
+		for (x = 0; x < W; x++) {
+			for (c = 0; c < 3; c++) {                      /* RG48 words R, G, B -> bytes B, G, R */
+				const int a = tmp[((size_t)y * W + x) * 3 + c];
+				int v = ((a >> 3) + 9 + r) >> 5;
+				o[(size_t)x * bytes_per_pixel + (2 - c)] = (uint8_t)(v > 255 ? 255 : v);
+			}
+			if (bytes_per_pixel == 4) o[(size_t)x * 4 + 3] = 255;
+		}
+	}
+	free(tmp);
+}

@@ -673,6 +673,25 @@ def oracle_inverse_yuv422(plan, coeffs, dither, uyvy=0):
     return out
 
 
+def oracle_inverse_rgb8(plan, coeffs, bytes_per_pixel, bottom_up, r):
+    """Whole inverse path with the oracle from a dequantized RGB 4:4:4 pyramid to 8-bit B, G, R(, A) pixels with the dither value r (0..15)."""
+    O = oracle()
+    work = coeffs.copy()
+    for c in range(3):
+        for lv in (2, 1):
+            d = plan.band[(c, lv, 0)]
+            bands = (c_i16p * 4)(*[plan.view(work, c, lv, b).ctypes.data_as(c_i16p) for b in range(4)])
+            dst = plan.view(work, c, lv - 1, 0)
+            O.orc_inv_spatial(bands, d["pitch"], d["width"], d["height"], plan.prescale[lv], dst.ctypes.data_as(c_i16p), plan.band[(c, lv - 1, 0)]["pitch"])
+    d = plan.band[(0, 0, 0)]
+    flat = [plan.view(work, c, 0, b).ctypes.data_as(c_i16p) for c in range(3) for b in range(4)]
+    out = np.zeros((plan.height, 2 * d["width"] * bytes_per_pixel), np.uint8)
+    O.orc_inv_spatial_to_rgb8.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 8 + [ctypes.c_void_p, ctypes.c_int]
+    O.orc_inv_spatial_to_rgb8((c_i16p * 16)(*(flat + [None] * 4)), d["pitch"], d["width"], d["height"], plan.precision, plan.height, bytes_per_pixel, int(bottom_up), r,
+                              out.ctypes.data_as(ctypes.c_void_p), out.shape[1])
+    return out
+
+
 def oracle_inverse_yu64(plan, coeffs):
     """Whole inverse path with the oracle from a dequantized 4:2:2 pyramid to YU64 words (Y0 C1 Y1 C2, 16 bits each; no dither)."""
     O = oracle()

@@ -161,7 +161,7 @@ void emu_inv_packed16(int16_t **bands, int band_pitch, int w, int h, int display
 		return;
 	}
 	dim3 grid((w + ITW - 1) / ITW, (h + ITH - 1) / ITH, 1);
-	hipemu::launch(grid, dim3(NTHREADS), [&] { k_inv_packed16(jobs.data(), nch, nch); });
+	hipemu::launch(grid, dim3(NTHREADS), [&] { k_inv_packed16(jobs.data(), nch, nch, 0u); });
 }
 void emu_inv_packed16_use_strip(int on) { g_inv_packed16_strip = on; }
 
@@ -178,7 +178,24 @@ void emu_inv_yu64(int16_t **bands, const int *band_pitch, int w, int h, int disp
 		job.out = (int16_t *)(out + (c == 0 ? 0 : (c == 1 ? 1 : 3))); job.out_pitch = out_pitch_words; job.xstride = c ? 4 : 2; job.precision = precision; job.display_height = display_height;
 	}
 	dim3 grid((w + ITW - 1) / ITW, (h + ITH - 1) / ITH, 1);
-	hipemu::launch(grid, dim3(NTHREADS), [&] { k_inv_packed16(jobs.data(), 3, 2); });
+	hipemu::launch(grid, dim3(NTHREADS), [&] { k_inv_packed16(jobs.data(), 3, 2, 0u); });
+}
+
+// The last level of an RGB 4:4:4 sample to 8-bit pixels B, G, R(, A): k_inv_packed16 in its byte mode, as DecodeBatch::prepare sets it up.
+void emu_inv_rgb8(int16_t **bands, int band_pitch, int w, int h, int display_height, int precision, int bytes_per_pixel, int bottom_up, uint32_t seed,
+                  uint8_t *out, int out_pitch_bytes)
+{
+	std::vector<InvPlaneJob> jobs(3);
+	for (int c = 0; c < 3; c++) {
+		InvPlaneJob &job = jobs[c];
+		memset(&job, 0, sizeof(job));
+		for (int b = 0; b < 4; b++) job.band[b] = bands[c * 4 + b];
+		job.band_pitch = band_pitch; job.width = w; job.height = h; job.descale = 0;
+		job.out = (int16_t *)(out + (c == 0 ? 1 : (c == 1 ? 2 : 0))); job.out_pitch = out_pitch_bytes; job.xstride = bytes_per_pixel; job.precision = precision; job.display_height = display_height;
+		job.bytes8 = 1; job.bottom_up = bottom_up; job.dither_seed = seed;
+	}
+	dim3 grid((w + ITW - 1) / ITW, (h + ITH - 1) / ITH, 1);
+	hipemu::launch(grid, dim3(NTHREADS), [&] { k_inv_packed16(jobs.data(), 3, bytes_per_pixel, 0x1234u); });
 }
 
 void emu_fwd_frame_yuv422(const uint8_t *in, int in_pitch, int width, int height, int display_height, int uyvy, int shift,

@@ -482,6 +482,46 @@ def test_yu64_decode_equals_reference_exactly(w, h, src):
     L.CFHD_CloseDecoder(dec)
 
 
+@pytest.mark.parametrize("w,h,name", [(320, 240, "RG24"), (336, 252, "BGRA"), (1920, 1080, "BGRa"), (1920, 1080, "RG24")])
+def test_rgb8_decode_lies_in_the_reference_interval(w, h, name):
+    """RGB 4:4:4 samples decoded to RG24 / BGRA (bottom row first) / BGRa: every byte inside the interval of the reference's dither model
+    (oracle reconstruction with the dither value 0 and with 15; the reference decoder's own output is pinned to the same interval in
+    test_oracle_vs_ref), both ends about equally often, alpha 255; the picture survives the RG24 -> RGB 4:4:4 -> RG24 round trip of the
+    product alone; half resolution is refused."""
+    frames, pitch = qbist_frames(10, 1, w, h, PIX_RG48)
+    sample = ref_encode_frames(frames, pitch, w, h, PIX_RG48, encoded=ENCODED_RGB444)[0]
+    plan = Plan(w, h, pixkind=PIXKIND["RG48"], enc=3)
+    coeffs = host_decode_pyramid(sample, plan)
+    bpp = 3 if name == "RG24" else 4
+    lo = oracle_inverse_rgb8(plan, coeffs, bpp, name != "BGRa", 0)
+    hi = oracle_inverse_rgb8(plan, coeffs, bpp, name != "BGRa", 15)
+    got, gpitch, aw, ah = amd_decode_sample(sample, fourcc(name))
+    assert (aw, ah) == (w, h) and gpitch == (w * bpp + 15) // 16 * 16
+    img = got.reshape(h, gpitch)[:, : w * bpp]
+    ok = (img >= lo) & (img <= hi)
+    assert ok.all(), "%d bytes outside the interval" % (~ok).sum()
+    differ = lo != hi
+    assert 0.4 < (img[differ] == hi[differ]).mean() < 0.6
+    if bpp == 4: assert (img[:, 3::4] == 255).all()
+    # the reference's own decode of the same sample is as close as two dithers of the same picture can be
+    rdec, rpitch = ref_decode_sample(sample, w, h, fourcc(name))
+    rimg = rdec.reshape(h, rpitch)[:, : w * bpp]
+    assert np.abs(rimg.astype(int) - img.astype(int)).max() <= 1
+    # own round trip from 8-bit pixels
+    mine = amd_encode_frames([np.ascontiguousarray(rimg).reshape(-1)], w * bpp, w, h, fourcc(name), encoded=ENCODED_RGB444)[0]
+    back, bpitch, _, _ = amd_decode_sample(mine, fourcc(name))
+    bimg = back.reshape(h, bpitch)[:, : w * bpp].astype(np.float64)
+    sel = np.ones(w * bpp, bool)
+    if bpp == 4: sel[3::4] = False
+    assert 10 * np.log10(255.0 ** 2 / np.mean((bimg[:, sel] - rimg[:, sel]) ** 2)) > 40.0
+    L = product()
+    dec = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
+    aw_ = ctypes.c_int(); ah_ = ctypes.c_int(); af_ = ctypes.c_uint32()
+    sb = ctypes.create_string_buffer(sample, len(sample))
+    assert L.CFHD_PrepareToDecode(dec, 0, 0, fourcc(name), 2, 0, sb, 512, ctypes.byref(aw_), ctypes.byref(ah_), ctypes.byref(af_)) != 0
+    L.CFHD_CloseDecoder(dec)
+
+
 @pytest.mark.parametrize("name", sorted(RGB10_FORMATS))
 @pytest.mark.parametrize("w,h", [(320, 240), (1280, 720)])
 def test_rgb10_encode_to_rgb444_bitstream_identical(w, h, name):

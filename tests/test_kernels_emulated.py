@@ -531,6 +531,42 @@ def test_inv_yu64_last_level_equals_oracle(w, h, dh):
     assert (want == 65535).any() and (want == 1023 << 6).any() and (want == 0).any()
 
 
+@pytest.mark.parametrize("w,h,dh,bpp,bottom_up", [(16, 8, 16, 3, 1), (68, 20, 37, 4, 1), (160, 17, 34, 4, 0), (250, 33, 66, 3, 1), (96, 16, 30, 4, 1)])
+def test_inv_rgb8_last_level_lies_in_oracle_interval(w, h, dh, bpp, bottom_up):
+    """k_inv_packed16 in its byte mode (RG24 / BGRA / BGRa output of RGB 4:4:4 samples): every byte between the oracle's reconstruction with the
+    dither value 0 and with 15 (the model pinned on the reference decoder in test_oracle_vs_ref), both ends hit about equally often, alpha
+    255, bottom-up row order, nothing written beside the picture."""
+    rng = np.random.default_rng(w * 3 + h + bpp)
+    pitch = (w + 7) // 8 * 8
+    bands = []
+    for c in range(3):
+        bs = [np.zeros((h, pitch), np.int16) for _ in range(4)]
+        bs[0][:, :w] = rand_plane(rng, w, h, 14)
+        for k in range(1, 4): bs[k][:, :w] = rand_plane(rng, w, h, 11, signed=True)
+        bands.append(bs)
+    flat = [p16(a) for c in range(3) for a in bands[c]]
+    O = oracle()
+    O.orc_inv_spatial_to_rgb8.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 8 + [ctypes.c_void_p, ctypes.c_int]
+    ends = []
+    for r in (0, 15):
+        o = np.zeros((dh, 2 * w * bpp), np.uint8)
+        O.orc_inv_spatial_to_rgb8((c_i16p * 16)(*(flat + [None] * 4)), pitch, w, h, 12, dh, bpp, bottom_up, r, o.ctypes.data_as(ctypes.c_void_p), 2 * w * bpp)
+        ends.append(o)
+    lo, hi = ends
+    opitch = 2 * w * bpp + 16
+    got = np.full((dh, opitch), 7, np.uint8)
+    E = emu()
+    E.emu_inv_rgb8.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 7 + [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_int]
+    E.emu_inv_rgb8((c_i16p * 12)(*flat), pitch, w, h, dh, 12, bpp, bottom_up, 77, got.ctypes.data_as(ctypes.c_void_p), opitch)
+    img = got[:, : 2 * w * bpp]
+    assert ((img >= lo) & (img <= hi)).all()
+    differ = lo != hi
+    assert 0.4 < (img[differ] == hi[differ]).mean() < 0.6
+    assert (got[:, 2 * w * bpp:] == 7).all()
+    if bpp == 4: assert (img[:, 3::4] == 255).all()
+    assert (img == 255).any() and (img == 0).any()
+
+
 @pytest.mark.parametrize("w,h,dh", [(40, 8, 8), (300, 24, 21)])
 def test_unpack_byr4_equals_oracle(w, h, dh):
     """k_unpack_byr4 (Bayer mosaic -> G, R-G, B-G, G1-G2 planes through the log-90 curve) = oracle restatement of ConvertBYR4ToFrame16s

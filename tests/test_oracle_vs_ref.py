@@ -175,6 +175,30 @@ def test_reference_yu64_decode_equals_oracle(w, h, src):
     assert len(bad) == 0, (len(bad), bad[:8].tolist(), [(int(mine[r, c]), int(img[r, c])) for r, c in bad[:8]])
 
 
+@pytest.mark.parametrize("w,h,name", [(192, 96, "BGRa"), (320, 240, "RG24"), (336, 252, "BGRA"), (1920, 1080, "BGRA")])
+def test_reference_rgb8_decode_lies_in_oracle_dither_interval(w, h, name):
+    """Pins orc_inv_spatial_to_rgb8: the reference decodes RGB 4:4:4 samples to RG24 / BGRA (bottom row first) / BGRa with a random four-bit
+    dither per component; every byte lies between the oracle's reconstruction with r = 0 and with r = 15, both ends occur, and the share of
+    bytes at the upper end follows the low bits of the 12-bit component as the model says (0 up to 3, 1 from 12 on)."""
+    frames, pitch = qbist_frames(10, 1, w, h, PIX_RG48)
+    sample = ref_encode_frames(frames, pitch, w, h, PIX_RG48, encoded=ENCODED_RGB444)[0]
+    plan = Plan(w, h, pixkind=PIXKIND["RG48"], enc=3)
+    coeffs = host_decode_pyramid(sample, plan)
+    bpp = 3 if name == "RG24" else 4
+    lo = oracle_inverse_rgb8(plan, coeffs, bpp, name != "BGRa", 0)
+    hi = oracle_inverse_rgb8(plan, coeffs, bpp, name != "BGRa", 15)
+    assert ((hi.astype(int) - lo) >= 0).all() and ((hi.astype(int) - lo) <= 1).all()
+    for attempt in range(6):                            # (the reference's threaded decoder occasionally damages a frame)
+        dec, dpitch = ref_decode_sample(sample, w, h, fourcc(name))
+        img = dec.reshape(h, dpitch)[:, : w * bpp]
+        ok = (img >= lo) & (img <= hi)
+        if ok.all(): break
+    assert ok.all(), "%d bytes outside the interval" % (~ok).sum()
+    differ = lo != hi
+    assert 0.35 < (img[differ] == hi[differ]).mean() < 0.65
+    if bpp == 4: assert (img[:, 3::4] == 255).all()
+
+
 @pytest.mark.parametrize("w,h", [(192, 96), (320, 240), (1920, 1080)])
 def test_reference_b64a_decode_equals_oracle(w, h):
     """Pins orc_inv_spatial_to_b64a: the reference decodes an RGBA 4:4:4:4 sample to b64a through its planar 16-bit rows
