@@ -504,8 +504,10 @@ def test_rgb8_decode_lies_in_the_reference_interval(w, h, name):
     assert 0.4 < (img[differ] == hi[differ]).mean() < 0.6
     if bpp == 4: assert (img[:, 3::4] == 255).all()
     # the reference's own decode of the same sample is as close as two dithers of the same picture can be
-    rdec, rpitch = ref_decode_sample(sample, w, h, fourcc(name))
-    rimg = rdec.reshape(h, rpitch)[:, : w * bpp]
+    for attempt in range(6):                            # (the reference's threaded decoder occasionally damages a frame)
+        rdec, rpitch = ref_decode_sample(sample, w, h, fourcc(name))
+        rimg = rdec.reshape(h, rpitch)[:, : w * bpp]
+        if np.abs(rimg.astype(int) - img.astype(int)).max() <= 1: break
     assert np.abs(rimg.astype(int) - img.astype(int)).max() <= 1
     # own round trip from 8-bit pixels
     mine = amd_encode_frames([np.ascontiguousarray(rimg).reshape(-1)], w * bpp, w, h, fourcc(name), encoded=ENCODED_RGB444)[0]
