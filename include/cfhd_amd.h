@@ -8,7 +8,8 @@
  *
  * Scope: intra-frame encode of YUY2 / 2vuy (progressive and interlaced), YU64 and v210 -> YUV 4:2:2 10-bit, RG48 / RG24 / BGRA / BGRa /
  * r210 / DPX0 / AB10 / AR10 / b64a -> RGB 4:4:4 12-bit, b64a -> RGBA 4:4:4:4 12-bit, BYR4 -> Bayer 12-bit; decode of 4:2:2 samples to
- * YUY2 / 2vuy (full and half resolution, interlaced samples too) and YU64 (full resolution), RGB 4:4:4 samples to RG48 and RGBA 4:4:4:4
+ * YUY2 / 2vuy (full and half resolution, interlaced samples too) and YU64 (full resolution), RGB 4:4:4 samples to RG48 (and RG24 / BGRA / BGRa
+ * at full resolution) and RGBA 4:4:4:4
  * samples to b64a at full and half resolution (DESIGN.md section 1 lists what each round added).  Anything else
  * returns CFHD_ERROR_BADFORMAT (3) / CFHD_ERROR_BAD_RESOLUTION (11).
  * There is no CPU fallback: without a HIP device the encode/decode calls return CFHD_ERROR_INTERNAL (6).
