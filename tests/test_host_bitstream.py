@@ -343,6 +343,39 @@ def test_thumbnail_and_output_formats_argument_handling():
     L.CFHD_CloseDecoder(dec)
 
 
+
+def test_decoder_output_format_gates():
+    """CFHD_PrepareToDecode (host code: no GPU involved) accepts exactly the (encoded format, output format, resolution) combinations the
+    library decodes and answers CFHD_ERROR_BADFORMAT (3) for the rest: 4:2:2 -> YUY2 / 2vuy (full, half), YU64 (full); RGB 4:4:4 -> RG48
+    (full, half), RG24 / BGRA / BGRa (full); RGBA 4:4:4:4 -> b64a (full, half)."""
+    if not have_ref(): pytest.skip("reference .so not built")
+    L = product()
+    w, h = 320, 240
+    f422, p422 = synth_yuy2(w, h, 3)
+    frgb, prgb = qbist_frames(10, 1, w, h, PIX_RG48)
+    fa, pa = qbist_frames(10, 1, w, h, PIX_B64A, alpha=1)
+    samples = {"422": ref_encode_frames([f422], p422, w, h, PIX_YUY2)[0],
+               "444": ref_encode_frames(frgb, prgb, w, h, PIX_RG48, encoded=ENCODED_RGB444)[0],
+               "4444": ref_encode_frames(fa, pa, w, h, PIX_B64A, encoded=ENCODED_RGBA4444)[0]}
+    accepted = {("422", "YUY2", 1), ("422", "YUY2", 2), ("422", "2vuy", 1), ("422", "2vuy", 2), ("422", "YU64", 1),
+                ("444", "RG48", 1), ("444", "RG48", 2), ("444", "RG24", 1), ("444", "BGRA", 1), ("444", "BGRa", 1),
+                ("4444", "b64a", 1), ("4444", "b64a", 2)}
+    dec = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
+    aw = ctypes.c_int(); ah = ctypes.c_int(); af = ctypes.c_uint32()
+    for enc, sample in samples.items():
+        sb = ctypes.create_string_buffer(sample, len(sample))
+        for name in ("YUY2", "2vuy", "YU64", "v210", "RG48", "RG24", "BGRA", "BGRa", "b64a", "r210", "BYR4"):
+            for res in (1, 2):
+                rc = L.CFHD_PrepareToDecode(dec, 0, 0, fourcc(name), res, 0, sb, 512, ctypes.byref(aw), ctypes.byref(ah), ctypes.byref(af))
+                if (enc, name, res) in accepted:
+                    assert rc == 0, (enc, name, res, rc)
+                    assert (aw.value, ah.value, af.value) == (w // res, h // res, fourcc(name))
+                else:
+                    assert rc == 3, (enc, name, res, rc)
+        assert L.CFHD_PrepareToDecode(dec, 0, 0, PIX_YUY2 if enc == "422" else (PIX_RG48 if enc == "444" else PIX_B64A), 3, 0, sb, 512, ctypes.byref(aw), ctypes.byref(ah), ctypes.byref(af)) == 11   # quarter: CFHD_ERROR_BAD_RESOLUTION
+    L.CFHD_CloseDecoder(dec)
+
+
 @pytest.mark.parametrize("w,h,fmt,enc,flags", [(320, 240, PIX_YUY2, ENCODED_YUV422, 0), (336, 252, PIX_YUY2, ENCODED_YUV422, 1), (320, 240, PIX_RG48, ENCODED_RGB444, 0),
                                                (320, 240, PIX_B64A, ENCODED_RGBA4444, 0)])
 def test_obsolete_header_parser_and_encoder_side_thumbnail_equal_reference(w, h, fmt, enc, flags):
