@@ -111,12 +111,19 @@ int make_params(EncodeParams &p, int w, int h, uint32_t fmt, int encoded, uint32
 	// CFHD_ENCODED_FORMAT_BAYER (3) from BYR4: default pixel order (red-green) and default encode curve (log 90), i.e. what the
 	// reference does without BAYER_FORMAT / ENCODE_CURVE metadata
 	// b64a also encodes to RGB 4:4:4 (its default in the reference): the alpha words are dropped, R, G, B as for 4:4:4:4
-	if (!(kind == PIX_B64A && encoded == 1) && encoded != (kind == PIX_RG48 || rgb8 || rgb10 ? 1 : (kind == PIX_B64A ? 2 : (kind == PIX_BYR4 ? 3 : 0)))) return ERR_BADFORMAT;
+	// RG48 / b64a encoded as YUV 4:2:2 (rows of TestCFHD's format table): the integer 709 / 601 conversion of frame.c:6731 in the loader of the level-1
+	// kernel.  Model and kernel are verified on the CPU (reference sample bytes; emulated kernel); the path waits for its first run on hardware behind
+	// CFHD_AMD_UNVERIFIED=1 and answers BADFORMAT without it.
+	const char *unverified = getenv("CFHD_AMD_UNVERIFIED");
+	const bool deep_rgb_as_422 = (kind == PIX_RG48 || kind == PIX_B64A) && encoded == 0 && unverified && atoi(unverified) != 0;
+	if (!deep_rgb_as_422 && !(kind == PIX_B64A && encoded == 1) && encoded != (kind == PIX_RG48 || rgb8 || rgb10 ? 1 : (kind == PIX_B64A ? 2 : (kind == PIX_BYR4 ? 3 : 0)))) return ERR_BADFORMAT;
 	// CFHD_ENCODING_FLAGS_YUV_INTERLACED: field-based level 1 (encoder.c:2093), built for the packed 4:2:2 formats
 	const bool interlaced = (flags & (1u << 0)) != 0;
 	if (interlaced && !(kind == PIX_YUY2 || kind == PIX_2VUY)) return ERR_BADFORMAT;
 	if (flags & (1u << 1)) return ERR_BADFORMAT;                          // 2-frame GOP: out of scope
-	const int enc = kind == PIX_BYR4 ? ENC_BAYER : (kind == PIX_B64A && encoded == 2 ? ENC_RGBA4444 : (rgb ? ENC_RGB444 : ENC_YUV422));
+	const int enc = kind == PIX_BYR4 ? ENC_BAYER : (kind == PIX_B64A && encoded == 2 ? ENC_RGBA4444 : (rgb && !deep_rgb_as_422 ? ENC_RGB444 : ENC_YUV422));
+	// an encoded format other than the default of the input format marks the quality word (SampleEncoder.cpp:216-219; QUALITY_H 0x0800 in the header)
+	if (deep_rgb_as_422) quality |= 0x08000000;
 	// b64a's default encoded format is RGB 4:4:4; asking for 4:4:4:4 marks the quality word (SampleEncoder.cpp:250-257), which the
 	// sample header then carries in QUALITY_H
 	if (kind == PIX_B64A && encoded == 2) quality |= 0x20000000;
@@ -125,8 +132,9 @@ int make_params(EncodeParams &p, int w, int h, uint32_t fmt, int encoded, uint32
 	p.width = w; p.height = h; p.pixel_format = fmt; p.pixel_kind = kind; p.encoded_format = enc; p.flags = flags;
 	p.quality = quality; p.progressive = !interlaced;
 	const int yuv601 = (flags & (1u << 2)) ? 1 : 2, vsrgb = (flags & (1u << 8)) ? 2 : 1;   // SampleEncoder.cpp:210-212
-	p.color_space = (rgb || kind == PIX_BYR4) ? 0 : ((yuv601 == 1 ? 1 : 2) | (vsrgb == 2 ? 4 : 0));           // RGB 4:4:4 samples carry no colour space tag
+	p.color_space = ((rgb && !deep_rgb_as_422) || kind == PIX_BYR4) ? 0 : ((yuv601 == 1 ? 1 : 2) | (vsrgb == 2 ? 4 : 0));           // RGB 4:4:4 samples carry no colour space tag
 	if (!build_frame_plan(&p.plan, w, h, kind, enc)) return ERR_BADFORMAT;
+	p.plan.color_matrix = (p.color_space & 4 ? 1 : 0) + ((p.color_space & 3) == 1 ? 2 : 0);
 	p.plan.interlaced = interlaced;
 	p.qstate = {0, -1, 0};
 	derive_quantization(&p.plan, quality, p.progressive, 0.0f, &p.qstate);

@@ -61,6 +61,7 @@ struct FramePlan {
 	int precision;               // 10 or 12 bits
 	int encoded_format;          // EncodedFormat
 	int pixel_kind;              // PixelKind of the packed frame
+	int color_matrix;            // deep RGB input encoded as 4:2:2: the conversion matrix (0 computer-systems 709, 1 video 709, 2 computer 601, 3 video 601; frame.c:6803)
 	int interlaced;              // level 1 is the field ("frame") transform: temporal 2-tap between the two fields, horizontal 2/6 (encoder.c:2093)
 	int prescale[kNumLevels];    // per wavelet index (Codec/wavelet.c:1710)
 	int midpoint_prequant;       // Codec/quantize.c:183,211-213

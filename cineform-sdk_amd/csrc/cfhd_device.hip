@@ -105,6 +105,8 @@ static bool enc_bytes8(int pixel_kind) { return pixel_kind == PIX_RG24 || pixel_
 static bool enc_rgb10(int pixel_kind) { return pixel_kind >= PIX_R210 && pixel_kind <= PIX_AR10; }
 // bit position of plane c (G, R, B) inside the pixel word of the 10-bit RGB formats
 static int rgb10_shift(int pixel_kind, int c) { const int r = pixel_kind == PIX_DPX0 ? 22 : (pixel_kind == PIX_AB10 ? 0 : 20), g = pixel_kind == PIX_DPX0 ? 12 : 10, b = pixel_kind == PIX_DPX0 ? 2 : (pixel_kind == PIX_AB10 ? 20 : 0); return c == 0 ? g : (c == 1 ? r : b); }
+// RG48 / b64a encoded as YUV 4:2:2: the loader of k_fwd_packed16 converts the pixels (FwdPlaneJob::layout 7); every plane reads from the R word
+static bool enc_rgb_as_422(const FramePlan &plan) { return is_packed16(plan.pixel_kind) && plan.encoded_format == ENC_YUV422; }
 static int enc_word_of_channel(int pixel_kind, int c) { return pixel_kind == PIX_V210 || enc_bytes8(pixel_kind) || enc_rgb10(pixel_kind) ? 0 : (pixel_kind == PIX_YU64 ? (c == 0 ? 0 : (c == 1 ? 1 : 3)) : packed_word_of_channel(pixel_kind, c)); }
 static int enc_stride_of_channel(int pixel_kind, int c, int nch) { return pixel_kind == PIX_YU64 ? (c == 0 ? 2 : 4) : (pixel_kind == PIX_B64A ? 4 : nch); }     // (b64a to RGB 4:4:4 has three planes of four-word pixels)
 } // namespace
@@ -296,6 +298,10 @@ void EncodeBatch::fill_jobs()
 				p.layout = plan.pixel_kind == PIX_V210 ? c + 1 : 0; p.tail_from = (plan.width - plan.width % 48) / 2;
 				if (enc_bytes8(plan.pixel_kind)) { p.layout = plan.pixel_kind == PIX_BGRa ? 5 : 4; p.in_pitch = in_pitch_; p.xstride = plan.pixel_kind == PIX_RG24 ? 3 : 4; p.tail_from = c == 0 ? 1 : (c == 1 ? 2 : 0); }     // planes G, R, B of bytes B, G, R(, A)
 				if (enc_rgb10(plan.pixel_kind)) { p.layout = 6; p.in_pitch = in_pitch_ / 4; p.xstride = plan.pixel_kind == PIX_R210 || plan.pixel_kind == PIX_DPX0; p.tail_from = rgb10_shift(plan.pixel_kind, c); }
+				if (enc_rgb_as_422(plan)) {
+					p.in = frame ? (const int16_t *)(frame + (plan.pixel_kind == PIX_B64A ? 1 : 0)) : nullptr;
+					p.layout = 7; p.xstride = plan.pixel_kind == PIX_B64A ? 4 : 3; p.tail_from = c; p.shift = plan.color_matrix; p.compand = 0;
+				}
 				p.out_pitch = plan.ch[c].band[0][0].pitch;
 				for (int b = 0; b < 4; b++) { p.out[b] = base + plan.ch[c].band[0][b].offset; p.q[b] = make_q(plan.ch[c].band[0][b].quant, mpq); }
 			}
@@ -384,6 +390,7 @@ int EncodeBatch::set_device_frame(int i, const void *d_frame, int pitch)
 		for (int c = 0; c < plan_.num_channels; c++) {
 			dev::FwdPlaneJob &p = j.l1[(size_t)i * plan_.num_channels + c];
 			p.in = (const int16_t *)((const uint16_t *)d_frame + enc_word_of_channel(plan_.pixel_kind, c)); p.in_pitch = enc_bytes8(plan_.pixel_kind) ? pitch : (enc_rgb10(plan_.pixel_kind) ? pitch / 4 : pitch / 2);
+			if (enc_rgb_as_422(plan_)) p.in = (const int16_t *)((const uint16_t *)d_frame + (plan_.pixel_kind == PIX_B64A ? 1 : 0));
 		}
 		jobs_dirty_ = true;
 		return 0;
@@ -449,7 +456,7 @@ bool EncodeBatch::strip_forward_packed16() const
 	const int forced = shape_override("CFHD_AMD_FORWARD");
 	const int act = active_ > 0 && active_ < n_ ? active_ : n_;
 	if (forced == 1 || (forced == 0 && frames_1080p_equivalent(plan_, act) < 32.0)) return false;
-	if (!is_packed16(plan_.pixel_kind) || plan_.width % 8 || plan_.num_channels < 3) return false;
+	if (!is_packed16(plan_.pixel_kind) || plan_.encoded_format == ENC_YUV422 || plan_.width % 8 || plan_.num_channels < 3) return false;
 	EncJobs j = enc_jobs_at(h_jobs_, n_, plan_.num_channels);
 	for (int i = 0; i < n_; i++) {
 		const dev::FwdPlaneJob &p = j.l1[(size_t)i * plan_.num_channels];

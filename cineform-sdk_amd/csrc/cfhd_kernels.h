@@ -51,8 +51,35 @@ struct FwdPlaneJob {
 	// layout 6: 10-bit RGB in one 32-bit word per pixel (r210, DPX0: big-endian; AB10, AR10: little-endian; wavelet.c:3595): in_pitch in 32-bit
 	// words, xstride = 1 for big-endian words, tail_from = bit position of the component; sample = field << 2; rows beyond display_height repeat
 	// the last row (a choice: the reference's fused row pipeline treats them its own way, parity is claimed for heights that are multiples of 8).
+	// layout 7: deep RGB converted to one plane of a 10-bit 4:2:2 frame on the way in (Codec/frame.c:6731 ConvertAnyDeep444to422; RG48 / b64a encoded
+	// as YUV 4:2:2): `in` = the R word of the first pixel (G, B behind it), xstride = words per pixel, tail_from = the plane (0 Y, 1 channel 1 = v,
+	// 2 channel 2 = u), shift = colour space (0 computer-systems 709, 1 video 709, 2 computer 601, 3 video 601); a chroma sample is the mean of
+	// its pixel pair; rows beyond display_height repeat the last row.
 	int layout, tail_from;
 };
+
+// One sample of plane `which` (0 Y, 1 v, 2 u) from the deep RGB pixels at p (luma: pixel x; chroma: pixels 2x, 2x + 1): the reference's integer
+// matrices, arithmetic shifts of the signed sums, clamps to 10 bits (frame.c:6803-6870, :7040-7170).
+__device__ __forceinline__ uint32_t rgb16_to_yuv_sample(const uint16_t *p, int wpp, int which, int color_space, int x)
+{
+	const int m[4][10] = { { 2998, 10060, 1016, 64, 1655, 5538, 7193, 7193, 6537, 655 }, { 3490, 11715, 1180, 0, 1917, 6455, 8372, 8372, 7602, 770 },
+	                       { 4211, 8258, 1606, 64, 2425, 4768, 7193, 7193, 6029, 1163 }, { 4899, 9617, 1868, 0, 2818, 5554, 8372, 8372, 7012, 1360 } };
+	const int cs = color_space & 3;
+	if (which == 0) {
+		const uint16_t *q = p + (size_t)x * wpp;
+		const int y = ((m[cs][0] * (int)q[0] + m[cs][1] * (int)q[1] + m[cs][2] * (int)q[2]) >> 20) + m[cs][3];
+		return (uint32_t)(y < 0 ? 0 : (y > 1023 ? 1023 : y));
+	}
+	int acc = 0;
+#pragma unroll
+	for (int k = 0; k < 2; k++) {
+		const uint16_t *q = p + (size_t)(2 * x + k) * wpp;
+		const int r = q[0], g = q[1], b = q[2];
+		acc += which == 2 ? (-m[cs][4] * r - m[cs][5] * g + m[cs][6] * b) >> 20 : (m[cs][7] * r - m[cs][8] * g - m[cs][9] * b) >> 20;
+	}
+	acc = (acc >> 1) + 512;
+	return (uint32_t)(acc < 0 ? 0 : (acc > 1023 ? 1023 : acc));
+}
 
 struct FwdYuvJob {
 	const uint8_t *in; int in_pitch;        // bytes
@@ -323,7 +350,11 @@ __device__ __forceinline__ void fwd_plane_tile(const FwdPlaneJob *jobs, int nch)
 			const int y = row_start + j, dw = c0 - 2 + d;    // dword index within the plane row
 			va[k] = 0;
 			if (i < ROWS * (TW + 4) && y < H && dw >= 0 && dw < HW) {
-				if (PACKED && job.layout == 6) {
+				if (PACKED && job.layout == 7) {
+					const int yy = y < job.display_height ? y : job.display_height - 1;
+					const uint16_t *row = (const uint16_t *)job.in + (size_t)yy * job.in_pitch;
+					va[k] = rgb16_to_yuv_sample(row, job.xstride, job.tail_from, job.shift, 2 * dw) | (rgb16_to_yuv_sample(row, job.xstride, job.tail_from, job.shift, 2 * dw + 1) << 16);
+				} else if (PACKED && job.layout == 6) {
 					const int yy = y < job.display_height ? y : job.display_height - 1;
 					const uint32_t *row = (const uint32_t *)job.in + (size_t)yy * job.in_pitch;
 					uint32_t p0 = row[2 * dw], p1 = row[2 * dw + 1];

@@ -260,3 +260,38 @@ void orc_fwd_frame_yuv422(const uint8_t *in, int in_pitch_bytes, int width, int 
 	}
 	free(r0); free(r1); free(tl); free(th); free(lo); free(hi);
 }
+
+/* ---- deep RGB -> YUV 4:2:2 10-bit planes (RG48 / b64a encoded as CFHD_ENCODED_FORMAT_YUV_422) ------------------------------------
+ * Codec/frame.c:6731 ConvertAnyDeep444to422: per pixel y = ((yr r + yg g + yb b) >> 20) + y_offset, clamped to [0, 1023]; per pixel pair
+ * u = ((u0 + u1) >> 1) + 512 with u_i = (-ur r - ug g + ub b) >> 20 (arithmetic shifts of negative sums), v likewise, clamped; planes Y,
+ * channel 1 = v, channel 2 = u (:6795-6797); picture rows beyond the display height repeat the last row (:7176).  16-bit words r, g, b at
+ * `words_per_pixel` apart, r at in[0].  color_space: 0 = computer-systems 709 (what the SDK passes by default), 1 = video-systems 709,
+ * 2 = computer-systems 601, 3 = video-systems 601 (:6803-6870). */
+static const int k_rgb2yuv[4][10] = {
+	{ 2998, 10060, 1016, 64, 1655, 5538, 7193, 7193, 6537, 655 },
+	{ 3490, 11715, 1180, 0, 1917, 6455, 8372, 8372, 7602, 770 },
+	{ 4211, 8258, 1606, 64, 2425, 4768, 7193, 7193, 6029, 1163 },
+	{ 4899, 9617, 1868, 0, 2818, 5554, 8372, 8372, 7012, 1360 },
+};
+void orc_rgb16_to_yuv422(const uint16_t *in, int in_pitch_words, int words_per_pixel, int width, int display_height, int height, int color_space,
+                         PIXEL16 *y_plane, int y_pitch, PIXEL16 *c1_plane, PIXEL16 *c2_plane, int c_pitch)
+{
+	const int *m = k_rgb2yuv[color_space & 3];
+	int row, x;
+	for (row = 0; row < height; row++) {
+		const uint16_t *p = in + (size_t)(row < display_height ? row : display_height - 1) * in_pitch_words;
+		for (x = 0; x < width; x += 2) {
+			int u = 0, v = 0, k;
+			for (k = 0; k < 2; k++) {
+				const int r = p[(size_t)(x + k) * words_per_pixel], g = p[(size_t)(x + k) * words_per_pixel + 1], b = p[(size_t)(x + k) * words_per_pixel + 2];
+				int y = ((m[0] * r + m[1] * g + m[2] * b) >> 20) + m[3];
+				u += (-m[4] * r - m[5] * g + m[6] * b) >> 20;
+				v += (m[7] * r - m[8] * g - m[9] * b) >> 20;
+				y_plane[(size_t)row * y_pitch + x + k] = (PIXEL16)(y < 0 ? 0 : (y > 1023 ? 1023 : y));
+			}
+			u = (u >> 1) + 512; v = (v >> 1) + 512;
+			c2_plane[(size_t)row * c_pitch + x / 2] = (PIXEL16)(u < 0 ? 0 : (u > 1023 ? 1023 : u));
+			c1_plane[(size_t)row * c_pitch + x / 2] = (PIXEL16)(v < 0 ? 0 : (v > 1023 ? 1023 : v));
+		}
+	}
+}

@@ -673,6 +673,18 @@ def oracle_inverse_yuv422(plan, coeffs, dither, uyvy=0):
     return out
 
 
+def oracle_rgb16_to_yuv422_planes(words, words_per_pixel, r_word, w, h, color_space=0):
+    """Deep RGB pixels (uint16 array h x w*words_per_pixel, r at word r_word of every pixel, then g, b) -> the three 10-bit planes Y,
+    channel 1, channel 2 of a 4:2:2 frame with the oracle (Codec/frame.c:6731 ConvertAnyDeep444to422)."""
+    O = oracle()
+    O.orc_rgb16_to_yuv422.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 6 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    src = np.ascontiguousarray(words[:, r_word:])
+    flat = np.zeros(h * w * words_per_pixel + 8, np.uint16); flat[: words.size - r_word] = words.reshape(-1)[r_word:]
+    Y = np.zeros((h, w), np.int16); C1 = np.zeros((h, w // 2), np.int16); C2 = np.zeros((h, w // 2), np.int16)
+    O.orc_rgb16_to_yuv422(flat.ctypes.data_as(ctypes.c_void_p), w * words_per_pixel, words_per_pixel, w, h, h, color_space, p16(Y), w, p16(C1), p16(C2), w // 2)
+    return [Y, C1, C2]
+
+
 def oracle_inverse_rgb8(plan, coeffs, bytes_per_pixel, bottom_up, r):
     """Whole inverse path with the oracle from a dequantized RGB 4:4:4 pyramid to 8-bit B, G, R(, A) pixels with the dither value r (0..15)."""
     O = oracle()

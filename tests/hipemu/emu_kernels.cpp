@@ -76,6 +76,24 @@ void emu_fwd_packed16_shapes(int which, const uint16_t *in, int in_pitch_words, 
 	else hipemu::launch(grid, dim3(NTHREADS), [&] { k_fwd_packed16_strip<4, 3>(jobs.data(), 1, nseg, nstrips); });
 }
 
+// Level 1 of a 4:2:2 frame from deep RGB pixels (RG48: wpp 3, r_word 0; b64a: wpp 4, r_word 1): the conversion happens in the loader of
+// k_fwd_packed16 (layout 7), as EncodeBatch::fill_jobs sets it up.  quant[c*4+b], out[c*4+b]; out_pitch[c].
+void emu_fwd_rgb16_to_yuv422(const uint16_t *in, int in_pitch_words, int wpp, int r_word, int width, int height, int display_height, int color_space,
+                             const int *quant, int mpq, int16_t **out, const int *out_pitch)
+{
+	std::vector<FwdPlaneJob> jobs(3);
+	for (int c = 0; c < 3; c++) {
+		FwdPlaneJob &job = jobs[c];
+		memset(&job, 0, sizeof(job));
+		job.in = (const int16_t *)(in + r_word); job.in_pitch = in_pitch_words; job.width = c ? width / 2 : width; job.height = height; job.prescale = 0;
+		job.xstride = wpp; job.shift = color_space; job.display_height = display_height; job.layout = 7; job.tail_from = c;
+		for (int b = 0; b < 4; b++) { job.out[b] = out[c * 4 + b]; job.q[b] = make_q(quant[c * 4 + b], mpq); }
+		job.out_pitch = out_pitch[c];
+	}
+	dim3 grid(((width / 2 + TW - 1) / TW) * 3, (height / 2 + TH - 1) / TH, 1);
+	hipemu::launch(grid, dim3(NTHREADS), [&] { k_fwd_packed16(jobs.data(), 3); });
+}
+
 // Level 1 of a 4:2:2 frame from 16-bit words Y0 C1 Y1 C2 (YU64): the same kernel with per-channel first word, stride and width, as
 // EncodeBatch::fill_jobs sets it up.  quant[c*4+b], out[c*4+b]; out_pitch[c].
 void emu_fwd_yu64(const uint16_t *in, int in_pitch_words, int width, int height, int display_height, const int *quant, int mpq, int16_t **out, const int *out_pitch)

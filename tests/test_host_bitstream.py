@@ -145,6 +145,28 @@ def test_yu64_sample_bytes_equal_reference(w, h):
     assert mine == rs
 
 
+@pytest.mark.parametrize("w,h,name", [(192, 96, "RG48"), (320, 240, "b64a"), (336, 252, "RG48"), (720, 486, "b64a"), (1920, 1080, "RG48")])
+def test_deep_rgb_to_yuv422_sample_bytes_equal_reference(w, h, name):
+    """RG48 / b64a encoded as YUV 4:2:2 (rows of TestCFHD's format table): the reference converts every pixel pair with its integer
+    709 matrix (Codec/frame.c:6731 ConvertAnyDeep444to422: 10-bit Y per pixel, chroma of the pair averaged, alpha dropped) and goes on as for
+    YU64; the quality word carries 0x0800 in its upper half (an encoded format other than the input's default, SampleEncoder.cpp:218) and the
+    header the input's format code.  Oracle conversion + oracle plane transform + product syntax = reference sample, byte for byte, heights
+    that are not multiples of 8 included (the conversion repeats the last picture row, :7176)."""
+    if not have_ref(): pytest.skip("reference .so not built")
+    fmt = PIX_RG48 if name == "RG48" else PIX_B64A
+    wpp = 3 if name == "RG48" else 4
+    frames, pitch = qbist_frames(10, 1, w, h, fmt, alpha=int(name == "b64a"))
+    words = np.frombuffer(frames[0].tobytes(), np.uint16).reshape(h, pitch // 2)[:, : w * wpp]
+    rs = ref_encode_frames(frames, pitch, w, h, fmt, encoded=ENCODED_YUV422)[0]
+    plan = Plan(w, h, pixkind=PIXKIND["YU64"], enc=1)
+    planes = oracle_rgb16_to_yuv422_planes(words, wpp, 0 if name == "RG48" else 1, w, h)
+    off, n = first_metadata_chunk(rs)
+    mine = product_write_sample_host(plan, oracle_forward_planes(plan, planes), 1, meta_global=rs[off:off + n], input_format=120 if name == "RG48" else 30, color_space=2)
+    assert len(mine) == len(rs)
+    diff = [i for i, (a, b) in enumerate(zip(mine, rs)) if a != b]
+    assert diff == [90] and rs[88:92] == bytes([0xff, 0xaf, 0x08, 0x00])      # the quality mark (the host writer of this test passes no quality word)
+
+
 @pytest.mark.parametrize("w,h", [(192, 96), (320, 240), (400, 120), (720, 480)])
 def test_v210_sample_bytes_equal_reference(w, h):
     """v210 (10-bit 4:2:2) -> YUV 4:2:2 sample, input format 10.  Pins the reading of the reference's unpack (convert.c:3968), including its
@@ -342,6 +364,23 @@ def test_thumbnail_and_output_formats_argument_handling():
     assert L.CFHD_GetOutputFormats(dec, None, 0, fmts, 8, ctypes.byref(n)) == 0 and n.value == 8
     L.CFHD_CloseDecoder(dec)
 
+
+
+def test_deep_rgb_as_yuv422_stays_behind_its_gate():
+    """RG48 / b64a -> YUV 4:2:2 is answered with CFHD_ERROR_BADFORMAT (3) unless CFHD_AMD_UNVERIFIED=1 is set (then the call goes on to the GPU:
+    any answer but 3 here, where there is none)."""
+    L = product()
+    enc = ctypes.c_void_p(); assert L.CFHD_OpenEncoder(ctypes.byref(enc), None) == 0
+    old = os.environ.pop("CFHD_AMD_UNVERIFIED", None)
+    try:
+        for fmt in (PIX_RG48, PIX_B64A):
+            assert L.CFHD_PrepareToEncode(enc, 320, 240, fmt, ENCODED_YUV422, 0, QUALITY_FILMSCAN1) == 3
+        os.environ["CFHD_AMD_UNVERIFIED"] = "1"
+        assert L.CFHD_PrepareToEncode(enc, 320, 240, PIX_RG48, ENCODED_YUV422, 0, QUALITY_FILMSCAN1) != 3
+    finally:
+        os.environ.pop("CFHD_AMD_UNVERIFIED", None)
+        if old is not None: os.environ["CFHD_AMD_UNVERIFIED"] = old
+    L.CFHD_CloseEncoder(enc)
 
 
 def test_decoder_output_format_gates():

@@ -833,6 +833,35 @@ def test_fwd_packed16_level1_of_yu64(w, h, dh):
             assert np.array_equal(outs[4 * c + b][:, :cw // 2], want[b][:, :cw // 2]), (c, b)
 
 
+@pytest.mark.parametrize("w,h,dh,wpp,cs", [(32, 16, 16, 3, 0), (144, 40, 37, 4, 0), (336, 24, 24, 3, 1), (208, 16, 13, 4, 2), (64, 8, 8, 3, 3)])
+def test_fwd_packed16_level1_of_deep_rgb_as_yuv422(w, h, dh, wpp, cs):
+    """RG48 / b64a encoded as YUV 4:2:2: the loader of k_fwd_packed16 converts the pixels on the way in (layout 7) = the oracle's conversion
+    (pinned on reference samples in test_host_bitstream) + the oracle's plane transform of the three planes; all four matrices, clamps at
+    both ends of the 10-bit range (saturated primaries), rows below the picture repeating the last one."""
+    rng = np.random.default_rng(w + h + wpp)
+    px = rng.integers(0, 65536, size=(dh, w, wpp), dtype=np.int64).astype(np.uint16)
+    r_word = 0 if wpp == 3 else 1
+    px[::3, ::4, r_word:r_word + 3] = [65535, 0, 0]; px[1::3, 1::4, r_word:r_word + 3] = [0, 0, 65535]; px[2::5, 2::6, r_word:r_word + 3] = [65535, 65535, 65535]; px[::7, 3::5, r_word:r_word + 3] = 0
+    words = px.reshape(dh, w * wpp)
+    quant = [1, 24, 24, 12] * 3
+    pitches = [(cw // 2 + 7) // 8 * 8 for cw in (w, w // 2, w // 2)]
+    outs = [np.zeros((h // 2, pitches[c]), np.int16) for c in range(3) for _ in range(4)]
+    ptrs = (c_i16p * 12)(*[p16(o) for o in outs])
+    E = emu()
+    E.emu_fwd_rgb16_to_yuv422.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 7 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    E.emu_fwd_rgb16_to_yuv422(words.ctypes.data_as(ctypes.c_void_p), w * wpp, wpp, r_word, w, h, dh, cs, iarr(quant), 2, ptrs, iarr(pitches))
+    planes = oracle_rgb16_to_yuv422_planes(words, wpp, r_word, w, dh, cs)
+    assert planes[0].max() == 1023 or cs in (0, 2)
+    for c in range(3):
+        cw = w if c == 0 else w // 2
+        plane = np.zeros((h, cw), np.int16); plane[:dh] = planes[c]; plane[dh:] = plane[dh - 1]
+        want = [np.zeros((h // 2, pitches[c]), np.int16) for _ in range(4)]
+        bands = (c_i16p * 4)(*[p16(o) for o in want])
+        oracle().orc_fwd_spatial(p16(plane), cw, cw, h, 0, iarr(quant[:4]), 2, bands, pitches[c])
+        for b in range(4):
+            assert np.array_equal(outs[4 * c + b][:, :cw // 2], want[b][:, :cw // 2]), (c, b)
+
+
 @pytest.mark.parametrize("w,h,dh", [(48, 16, 16), (144, 40, 37), (320, 24, 24), (400, 16, 13)])
 def test_fwd_packed16_level1_of_v210(w, h, dh):
     """v210 input: the loader of k_fwd_packed16 picks the 10-bit fields out of the 32-bit words = the oracle's plane transform of the planes
