@@ -90,10 +90,12 @@ bool is_packed16(int pixel_kind) { return pixel_kind == PIX_RG48 || pixel_kind =
 // in its byte mode: the 12-bit component doubled + 9 + a four-bit dither, >> 5 (orc_inv_spatial_to_rgb8: the reference's model)
 static bool dec_rgb8(int out_kind) { return out_kind == PIX_RG24 || out_kind == PIX_BGRA || out_kind == PIX_BGRa; }
 static int rgb8_bytes(int out_kind) { return out_kind == PIX_RG24 ? 3 : 4; }
-static bool dec_planes16(int out_kind) { return is_packed16(out_kind) || out_kind == PIX_YU64 || dec_rgb8(out_kind); }
+// ... and the 10-bit RGB words (r210, DPX0: big-endian; AB10, AR10: little-endian) through k_inv_rgb10 (orc_inv_spatial_to_rgb10)
+static bool dec_rgb10(int out_kind) { return out_kind >= PIX_R210 && out_kind <= PIX_AR10; }
+static bool dec_planes16(int out_kind) { return is_packed16(out_kind) || out_kind == PIX_YU64 || dec_rgb8(out_kind) || dec_rgb10(out_kind); }
 // position of plane c inside the pixel: 16-bit word, or byte for the 8-bit formats (planes G, R, B -> bytes 1, 2, 0)
-static int dec_word_of_channel(int out_kind, int c) { return out_kind == PIX_YU64 ? (c == 0 ? 0 : (c == 1 ? 1 : 3)) : (dec_rgb8(out_kind) ? (c == 0 ? 1 : (c == 1 ? 2 : 0)) : packed_word_of_channel(out_kind, c)); }
-static int dec_stride_of_channel(int out_kind, int c, int nch) { return out_kind == PIX_YU64 ? (c == 0 ? 2 : 4) : (dec_rgb8(out_kind) ? rgb8_bytes(out_kind) : nch); }
+static int dec_word_of_channel(int out_kind, int c) { return dec_rgb10(out_kind) ? 0 : out_kind == PIX_YU64 ? (c == 0 ? 0 : (c == 1 ? 1 : 3)) : (dec_rgb8(out_kind) ? (c == 0 ? 1 : (c == 1 ? 2 : 0)) : packed_word_of_channel(out_kind, c)); }
+static int dec_stride_of_channel(int out_kind, int c, int nch) { return out_kind == PIX_YU64 ? (c == 0 ? 2 : 4) : (dec_rgb8(out_kind) ? rgb8_bytes(out_kind) : (dec_rgb10(out_kind) ? 3 : nch)); }
 static int dec_words_per_position(int out_kind, int nch) { return out_kind == PIX_YU64 ? 2 : (dec_rgb8(out_kind) ? rgb8_bytes(out_kind) : nch); }
 static int16_t *dec_plane_out(void *frame, int out_kind, int c) { return dec_rgb8(out_kind) ? (int16_t *)((uint8_t *)frame + dec_word_of_channel(out_kind, c)) : (int16_t *)((uint16_t *)frame + dec_word_of_channel(out_kind, c)); }
 // encoder input made of 16-bit words that k_fwd_packed16 picks apart (per channel: first word, words from sample to sample, right shift).
@@ -588,7 +590,8 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 	                    plan.ch[0].band[0][0].width >= 16;   // k_inv_packed16's tail-column rule assumes the reference's vector path
 	const bool yu64_ok = out_kind == PIX_YU64 && plan.encoded_format == ENC_YUV422 && !half && plan.ch[1].band[0][0].width >= 16;
 	const bool rgb8_ok = dec_rgb8(out_kind) && plan.encoded_format == ENC_RGB444 && !half && plan.ch[0].band[0][0].width >= 16 && plan.ch[0].band[0][0].width % 2 == 0;
-	if (!yuv_ok && !rgb_ok && !yu64_ok && !rgb8_ok) { g_err = "output format not supported by the GPU path yet"; return -2; }
+	const bool rgb10_ok = dec_rgb10(out_kind) && plan.encoded_format == ENC_RGB444 && !half && plan.ch[0].band[0][0].width >= 16;
+	if (!yuv_ok && !rgb_ok && !yu64_ok && !rgb8_ok && !rgb10_ok) { g_err = "output format not supported by the GPU path yet"; return -2; }
 	plan_ = plan; n_ = nframes; out_kind_ = out_kind; own_output_ = own_output;
 	HIPCHK(hipStreamCreateWithFlags((hipStream_t *)&stream_, hipStreamNonBlocking));
 	HIPCHK(hipEventCreate((hipEvent_t *)&ev0_));
@@ -642,6 +645,7 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 				p.xstride = dec_stride_of_channel(out_kind, c, nch); p.precision = plan.precision; p.display_height = plan.display_height;
 				p.alpha = out_kind == PIX_B64A && c == 3;
 				p.bytes8 = dec_rgb8(out_kind); p.bottom_up = out_kind == PIX_RG24 || out_kind == PIX_BGRA; p.dither_seed = 0x9E3779B9u * (uint32_t)(i + 1);
+				if (dec_rgb10(out_kind)) { p.out = (int16_t *)frame; p.out_pitch = out_pitch_ / 4; p.bit_shift = rgb10_shift(out_kind, c); p.big_endian = out_kind == PIX_R210 || out_kind == PIX_DPX0; }
 			}
 			continue;
 		}
@@ -694,7 +698,7 @@ int DecodeBatch::set_device_output(int i, void *d_out, int pitch)
 	if (dec_planes16(out_kind_)) {
 		for (int c = 0; c < plan_.num_channels; c++) {
 			dev::InvPlaneJob &p = j.l1[(size_t)i * plan_.num_channels + c];
-			p.out = dec_plane_out(d_out, out_kind_, c); p.out_pitch = dec_rgb8(out_kind_) ? pitch : pitch / 2;
+			p.out = dec_plane_out(d_out, out_kind_, c); p.out_pitch = dec_rgb8(out_kind_) ? pitch : (dec_rgb10(out_kind_) ? pitch / 4 : pitch / 2);
 		}
 		jobs_dirty_ = true;
 		return 0;
@@ -752,6 +756,7 @@ const char *DecodeBatch::level_kernel(int level) const
 	const int act = active_ > 0 && active_ < n_ ? active_ : n_;
 	if (level > 0) return planes_as_strips(plan_, level, act) ? "k_inv_plane_strip" : "k_inv_plane";
 	if (half_) return is_packed16(out_kind_) ? "k_half_packed16" : "k_half_yuv422";
+	if (dec_rgb10(out_kind_)) return "k_inv_rgb10";
 	if (dec_planes16(out_kind_)) return strip_inverse_packed16() ? "k_inv_packed16_strip" : "k_inv_packed16";
 	if (interlaced_) return frame_inverse_quads() ? "k_inv_frame_yuv422_quad" : "k_inv_frame_yuv422";
 	return strip_inverse() ? "k_inv_yuv422_strip" : "k_inv_yuv422";
@@ -799,7 +804,8 @@ int DecodeBatch::launch_inverse(uint32_t dither_seed)
 	} else if (dec_planes16(out_kind_)) {
 		const BandDesc &b = plan_.ch[0].band[0][0];
 		dim3 grid((b.width + dev::ITW - 1) / dev::ITW, (b.height + dev::ITH - 1) / dev::ITH, act);      // one workgroup per tile, all components
-		dev::k_inv_packed16<<<grid, dev::NTHREADS, 0, st>>>(j.l1, nch, dec_words_per_position(out_kind_, nch), dither_seed);
+		if (dec_rgb10(out_kind_)) dev::k_inv_rgb10<<<grid, dev::NTHREADS, 0, st>>>(j.l1);
+		else dev::k_inv_packed16<<<grid, dev::NTHREADS, 0, st>>>(j.l1, nch, dec_words_per_position(out_kind_, nch), dither_seed);
 	} else if (interlaced_) {                           // (half resolution was served above: the level-1 lowpass planes need no inverse frame transform)
 		const BandDesc &b = plan_.ch[0].band[0][0];
 		if (frame_inverse_quads()) dev::k_inv_frame_yuv422_quad<<<dim3((b.width / 4 + dev::NTHREADS - 1) / dev::NTHREADS, b.height, act), dev::NTHREADS, 0, st>>>(j.yuv, dither_seed);

@@ -104,6 +104,9 @@ struct InvPlaneJob {
 	// the fourth byte of four-byte pixels is 255
 	int bytes8, bottom_up;
 	uint32_t dither_seed;
+	// k_inv_rgb10 (r210 / DPX0 / AB10 / AR10 output of RGB 4:4:4 samples: one 32-bit word per pixel; orc_inv_spatial_to_rgb10): bit position of this
+	// plane's 10 bits, words stored byte-swapped; `out` = the frame, out_pitch in 32-bit words
+	int bit_shift, big_endian;
 };
 
 struct InvYuvJob {
@@ -645,7 +648,10 @@ __device__ __forceinline__ uint32_t expand_alpha16(uint32_t word)
 // PACKED: the last level of the 4:4:4(:4) formats (wavelet.c:4947 TransformInverseRGB444ToRGB48: InvertSpatial*Row16sToYUV16 per
 // component + ConvertPlanarRGB16uToPackedRGB48): same synthesis, every sample converted with to16() and stored as one word of
 // the interleaved pixel.  gridDim.x = tiles_x * nch as in k_fwd_packed16.
-template <bool PACKED>
+// MODE 1 (own kernel, k_inv_rgb10: the code below it is compiled out of the other instantiations): every plane's sample becomes 10 bits of its
+// pixel's 32-bit word -- (value before the final >> 1, + 3) >> 3, clamped -- collected in LDS by plain read-modify-write (the same thread
+// handles the same pixels for every plane, a barrier between planes) and stored as whole words.
+template <bool PACKED, int MODE = 0>
 __device__ __forceinline__ void inv_plane_tile(const InvPlaneJob *jobs, int nch, int wps = 0, uint32_t launch_seed = 0u)
 {
 	// wps (PACKED): 16-bit words per sample position of plane 0 in the output row -- nch for the interleaved RGB(A) pixels; 2 for YU64
@@ -720,6 +726,18 @@ __device__ __forceinline__ void inv_plane_tile(const InvPlaneJob *jobs, int nch,
 						if (col == 0 || col == w - 1) inv_horiz_border(l, 2 + k, k ? hi16(hh) : lo16(hh), col == 0 ? 0 : 2, e[k], o[k]);
 					}
 				}
+				if (MODE == 1) {
+					uint32_t *d32 = (uint32_t *)s_out + (size_t)(2 * rl + par) * (2 * ITW) + 4 * p;
+#pragma unroll
+					for (int k = 0; k < 2; k++) {
+						if (c + k >= w) break;
+						int se = (e[k] + 3) >> 3, so = (o[k] + 3) >> 3;
+						se = se < 0 ? 0 : (se > 1023 ? 1023 : se); so = so < 0 ? 0 : (so > 1023 ? 1023 : so);
+						const uint32_t be = (uint32_t)se << job.bit_shift, bo = (uint32_t)so << job.bit_shift;
+						if (comp == 0) { d32[2 * k] = be; d32[2 * k + 1] = bo; } else { d32[2 * k] |= be; d32[2 * k + 1] |= bo; }
+					}
+					continue;
+				}
 				const int tail0 = w - (w & 7) - 9;
 				const int xs = job.xstride;
 				const size_t at = (size_t)(2 * rl + par) * (2 * ITW) * wps + (size_t)(4 * p) * xs + word;      // sample 2 (c - c0) of tile row 2 rl + par
@@ -770,7 +788,16 @@ __device__ __forceinline__ void inv_plane_tile(const InvPlaneJob *jobs, int nch,
 		const int w = w_first, h = job.height, c0 = tile.x * ITW, r0 = tile.y * ITH;
 		if (c0 < w && r0 < h) {
 			const int npx = 2 * ((w - c0) < ITW ? (w - c0) : ITW);                       // sample positions of plane 0 in the tile's rows inside the frame
-			if (job.bytes8) {
+			if (MODE == 1) {
+				for (int i = tid; i < 2 * ITH * npx; i += NTHREADS) {
+					const int orl = i / npx, d = i - orl * npx;
+					const int orow = 2 * r0 + orl;
+					if (orow >= job.display_height || orow >= 2 * h) continue;
+					uint32_t v = ((const uint32_t *)s_out)[(size_t)orl * (2 * ITW) + d];
+					if (job.big_endian) v = __builtin_bswap32(v);
+					((uint32_t *)frame)[(size_t)orow * job.out_pitch + (size_t)(2 * c0) + d] = v;
+				}
+			} else if (job.bytes8) {
 				// wps = bytes per pixel here; an even band width makes npx a multiple of 4: whole dwords for three-byte pixels too
 				const int row_dw = npx * wps / 4;
 				for (int i = tid; i < 2 * ITH * row_dw; i += NTHREADS) {
@@ -798,6 +825,7 @@ __device__ __forceinline__ void inv_plane_tile(const InvPlaneJob *jobs, int nch,
 
 __global__ void __launch_bounds__(NTHREADS) k_inv_plane(const InvPlaneJob *jobs) { inv_plane_tile<false>(jobs, 1); }
 __global__ void __launch_bounds__(NTHREADS) k_inv_packed16(const InvPlaneJob *jobs, int nch, int wps, uint32_t launch_seed) { inv_plane_tile<true>(jobs, nch, wps, launch_seed); }
+__global__ void __launch_bounds__(NTHREADS) k_inv_rgb10(const InvPlaneJob *jobs) { inv_plane_tile<true, 1>(jobs, 3, 3, 0u); }
 
 // 10 -> 8 bit reduction of one reconstructed sample v (= lowfilter +/- high, before the >>1):
 // negative values clamp to zero first (the +2048 / subs_epu16 pair, InvertHorizontalStrip16s.c:4086-4089),

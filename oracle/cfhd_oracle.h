@@ -58,6 +58,11 @@ void orc_inv_spatial_to_yuv422(PIXEL16 *const bands[3][4], const int band_pitch[
 /* deep RGB (16-bit words r, g, b) -> 10-bit Y, channel 1 (v), channel 2 (u) planes of a 4:2:2 frame: Codec/frame.c:6731 ConvertAnyDeep444to422 */
 void orc_rgb16_to_yuv422(const uint16_t *in, int in_pitch_words, int words_per_pixel, int width, int display_height, int height, int color_space,
                          PIXEL16 *y_plane, int y_pitch, PIXEL16 *c1_plane, PIXEL16 *c2_plane, int c_pitch);
+/* one plane's last-level reconstruction before the final >> 1 (test probes of further output formats start from it) */
+void orc_inv_spatial_prepack(PIXEL16 *const bands[4], int band_pitch, int w, int h, int32_t *out, int out_pitch);
+/* RGB 4:4:4 sample -> r210 / DPX0 / AB10 / AR10: (reconstruction before the final >> 1, + 3) >> 3 per component, see cfhd_oracle_inv.c */
+void orc_inv_spatial_to_rgb10(PIXEL16 *const bands[4][4], int band_pitch, int w, int h, int display_height, int shift_r, int shift_g, int shift_b, int big_endian,
+                              uint32_t *out, int out_pitch_words);
 /* RGB 4:4:4 sample -> RG24 / BGRA (bottom_up) / BGRa: the RG48 reconstruction reduced to 8 bits with the dither value r (0..15) the caller picks, see cfhd_oracle_inv.c */
 void orc_inv_spatial_to_rgb8(PIXEL16 *const bands[4][4], int band_pitch, int w, int h, int precision, int display_height, int bytes_per_pixel, int bottom_up,
                              int r, uint8_t *out, int out_pitch_bytes);

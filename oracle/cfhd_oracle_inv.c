@@ -342,3 +342,48 @@ void orc_inv_spatial_to_rgb8(PIXEL16 *const bands[4][4], int band_pitch, int w, 
 	}
 	free(tmp);
 }
+
+/* One plane's last-level reconstruction BEFORE the final >> 1 (v = lowfilter +/- high): the value the reference's output routines start
+ * from; probes of further output formats are fitted on it (tests only). */
+void orc_inv_spatial_prepack(PIXEL16 *const bands[4], int band_pitch, int w, int h, int32_t *out, int out_pitch)
+{
+	PIXEL16 *el = (PIXEL16 *)malloc((size_t)w * 2), *ol = (PIXEL16 *)malloc((size_t)w * 2);
+	PIXEL16 *eh = (PIXEL16 *)malloc((size_t)w * 2), *oh = (PIXEL16 *)malloc((size_t)w * 2);
+	int r;
+	for (r = 0; r < h; r++) {
+		inv_vertical_row(bands[0], band_pitch, bands[2] + (size_t)r * band_pitch, r, h, w, el, ol);
+		inv_vertical_row(bands[1], band_pitch, bands[3] + (size_t)r * band_pitch, r, h, w, eh, oh);
+		inv_horizontal_row_prepack(el, eh, w, out + (size_t)(2 * r) * out_pitch);
+		inv_horizontal_row_prepack(ol, oh, w, out + (size_t)(2 * r + 1) * out_pitch);
+	}
+	free(el); free(ol); free(eh); free(oh);
+}
+
+/* ---- RGB 4:4:4 samples decoded to the 10-bit RGB words r210 / DPX0 (big-endian) / AB10 / AR10 (little-endian) -------------------
+ * Probed on the built reference and pinned in tests/test_oracle_vs_ref.py: every component is the last-level reconstruction before its
+ * final >> 1 (13 bits for 12-bit samples), + 3, >> 3, clamped to [0, 1023] -- one rounding from 13 to 10 bits, not the 12-bit value
+ * shifted --, at the bit positions the encoder reads them from (r210: R 20-29, G 10-19, B 0-9; DPX0: 22 / 12 / 2; AB10: R 0-9, G 10-19,
+ * B 20-29; AR10: R 20-29, G 10-19, B 0-9).  Planes are G, R, B.  shift_r/g/b: bit positions; big_endian: words stored byte-swapped. */
+void orc_inv_spatial_to_rgb10(PIXEL16 *const bands[4][4], int band_pitch, int w, int h, int display_height, int shift_r, int shift_g, int shift_b, int big_endian,
+                              uint32_t *out, int out_pitch_words)
+{
+	const int W = 2 * w, shifts[3] = { shift_g, shift_r, shift_b };
+	int32_t *v = (int32_t *)malloc((size_t)2 * h * W * sizeof(int32_t));
+	int c, y, x;
+	for (y = 0; y < display_height; y++) for (x = 0; x < W; x++) out[(size_t)y * out_pitch_words + x] = 0;
+	for (c = 0; c < 3; c++) {
+		orc_inv_spatial_prepack(bands[c], band_pitch, w, h, v, W);
+		for (y = 0; y < display_height; y++)
+			for (x = 0; x < W; x++) {
+				int s = (v[(size_t)y * W + x] + 3) >> 3;
+				s = s < 0 ? 0 : (s > 1023 ? 1023 : s);
+				out[(size_t)y * out_pitch_words + x] |= (uint32_t)s << shifts[c];
+			}
+	}
+	if (big_endian)
+		for (y = 0; y < display_height; y++) for (x = 0; x < W; x++) {
+			const uint32_t u = out[(size_t)y * out_pitch_words + x];
+			out[(size_t)y * out_pitch_words + x] = (u >> 24) | ((u >> 8) & 0xff00u) | ((u << 8) & 0xff0000u) | (u << 24);
+		}
+	free(v);
+}

@@ -685,6 +685,26 @@ def oracle_rgb16_to_yuv422_planes(words, words_per_pixel, r_word, w, h, color_sp
     return [Y, C1, C2]
 
 
+def oracle_inverse_rgb10(plan, coeffs, name):
+    """Whole inverse path with the oracle from a dequantized RGB 4:4:4 pyramid to the 32-bit words of r210 / DPX0 / AB10 / AR10 (as they lie in memory)."""
+    O = oracle()
+    work = coeffs.copy()
+    for c in range(3):
+        for lv in (2, 1):
+            d = plan.band[(c, lv, 0)]
+            bands = (c_i16p * 4)(*[plan.view(work, c, lv, b).ctypes.data_as(c_i16p) for b in range(4)])
+            dst = plan.view(work, c, lv - 1, 0)
+            O.orc_inv_spatial(bands, d["pitch"], d["width"], d["height"], plan.prescale[lv], dst.ctypes.data_as(c_i16p), plan.band[(c, lv - 1, 0)]["pitch"])
+    d = plan.band[(0, 0, 0)]
+    flat = [plan.view(work, c, 0, b).ctypes.data_as(c_i16p) for c in range(3) for b in range(4)]
+    order, shifts, code = RGB10_FORMATS[name]
+    out = np.zeros((plan.height, 2 * d["width"]), np.uint32)
+    O.orc_inv_spatial_to_rgb10.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 8 + [ctypes.c_void_p, ctypes.c_int]
+    O.orc_inv_spatial_to_rgb10((c_i16p * 16)(*(flat + [None] * 4)), d["pitch"], d["width"], d["height"], plan.height, shifts[0], shifts[1], shifts[2], int(order == ">"),
+                               out.ctypes.data_as(ctypes.c_void_p), out.shape[1])
+    return out
+
+
 def oracle_inverse_rgb8(plan, coeffs, bytes_per_pixel, bottom_up, r):
     """Whole inverse path with the oracle from a dequantized RGB 4:4:4 pyramid to 8-bit B, G, R(, A) pixels with the dither value r (0..15)."""
     O = oracle()

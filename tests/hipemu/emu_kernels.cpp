@@ -216,6 +216,23 @@ void emu_inv_rgb8(int16_t **bands, int band_pitch, int w, int h, int display_hei
 	hipemu::launch(grid, dim3(NTHREADS), [&] { k_inv_packed16(jobs.data(), 3, bytes_per_pixel, 0x1234u); });
 }
 
+// The last level of an RGB 4:4:4 sample to 10-bit RGB words (r210 / DPX0 / AB10 / AR10): k_inv_rgb10, as DecodeBatch::prepare sets it up.
+void emu_inv_rgb10(int16_t **bands, int band_pitch, int w, int h, int display_height, int shift_r, int shift_g, int shift_b, int big_endian, uint32_t *out, int out_pitch_words)
+{
+	std::vector<InvPlaneJob> jobs(3);
+	const int shifts[3] = { shift_g, shift_r, shift_b };      // planes G, R, B
+	for (int c = 0; c < 3; c++) {
+		InvPlaneJob &job = jobs[c];
+		memset(&job, 0, sizeof(job));
+		for (int b = 0; b < 4; b++) job.band[b] = bands[c * 4 + b];
+		job.band_pitch = band_pitch; job.width = w; job.height = h; job.descale = 0;
+		job.out = (int16_t *)out; job.out_pitch = out_pitch_words; job.xstride = 3; job.precision = 12; job.display_height = display_height;
+		job.bit_shift = shifts[c]; job.big_endian = big_endian;
+	}
+	dim3 grid((w + ITW - 1) / ITW, (h + ITH - 1) / ITH, 1);
+	hipemu::launch(grid, dim3(NTHREADS), [&] { k_inv_rgb10(jobs.data()); });
+}
+
 void emu_fwd_frame_yuv422(const uint8_t *in, int in_pitch, int width, int height, int display_height, int uyvy, int shift,
                           const int *quant /*[3][4]*/, int mpq, int16_t **out /*[3][4]*/, const int *out_pitch)
 {

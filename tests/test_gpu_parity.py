@@ -525,6 +525,31 @@ def test_rgb8_decode_lies_in_the_reference_interval(w, h, name):
 
 
 @pytest.mark.skipif(os.environ.get("CFHD_AMD_RUN_UNVERIFIED", "0") == "0", reason="first hardware run of this path is pending (set CFHD_AMD_RUN_UNVERIFIED=1): "
+                    "model pinned on the reference decoder and kernel verified in the emulator on the CPU, DESIGN.md section 1")
+@pytest.mark.parametrize("w,h,name", [(320, 240, "r210"), (336, 252, "DPX0"), (1280, 720, "AB10"), (1920, 1080, "AR10")])
+def test_rgb10_decode_equals_reference_exactly(w, h, name):
+    """RGB 4:4:4 samples decoded to r210 / DPX0 / AB10 / AR10 (behind CFHD_AMD_UNVERIFIED=1 until this test has run on hardware): word for word
+    the reference decoder's output; the 10-bit RGB round trip of the product alone decodes to the source."""
+    order, shifts, code = RGB10_FORMATS[name]
+    frames, pitch = qbist_frames(10, 1, w, h, PIX_RG48)
+    sample = ref_encode_frames(frames, pitch, w, h, PIX_RG48, encoded=ENCODED_RGB444)[0]
+    old = os.environ.get("CFHD_AMD_UNVERIFIED")
+    os.environ["CFHD_AMD_UNVERIFIED"] = "1"
+    try:
+        got, gpitch, aw, ah = amd_decode_sample(sample, fourcc(name))
+    finally:
+        if old is None: os.environ.pop("CFHD_AMD_UNVERIFIED", None)
+        else: os.environ["CFHD_AMD_UNVERIFIED"] = old
+    assert (aw, ah) == (w, h)
+    mine = np.frombuffer(got.tobytes(), np.uint32).reshape(h, gpitch // 4)[:, :w]
+    for attempt in range(6):                            # (the reference's threaded decoder occasionally damages a frame)
+        dec, dpitch = ref_decode_sample(sample, w, h, fourcc(name))
+        img = np.frombuffer(dec.tobytes(), dtype=np.uint32).reshape(h, dpitch // 4)[:, :w]
+        if np.array_equal(mine, img): break
+    assert np.array_equal(mine, img), "%d words differ" % (mine != img).sum()
+
+
+@pytest.mark.skipif(os.environ.get("CFHD_AMD_RUN_UNVERIFIED", "0") == "0", reason="first hardware run of this path is pending (set CFHD_AMD_RUN_UNVERIFIED=1): "
                     "model pinned on reference samples and kernel verified in the emulator on the CPU, DESIGN.md section 1")
 @pytest.mark.parametrize("w,h,name", [(320, 240, "RG48"), (336, 252, "b64a"), (1920, 1080, "RG48")])
 def test_deep_rgb_encode_to_yuv422_bitstream_identical(w, h, name):

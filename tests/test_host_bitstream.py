@@ -377,6 +377,17 @@ def test_deep_rgb_as_yuv422_stays_behind_its_gate():
             assert L.CFHD_PrepareToEncode(enc, 320, 240, fmt, ENCODED_YUV422, 0, QUALITY_FILMSCAN1) == 3
         os.environ["CFHD_AMD_UNVERIFIED"] = "1"
         assert L.CFHD_PrepareToEncode(enc, 320, 240, PIX_RG48, ENCODED_YUV422, 0, QUALITY_FILMSCAN1) != 3
+        if have_ref():
+            # the same switch opens the 10-bit RGB decoder outputs (CFHD_PrepareToDecode is host code)
+            frgb, prgb = qbist_frames(10, 1, 320, 240, PIX_RG48)
+            sample = ref_encode_frames(frgb, prgb, 320, 240, PIX_RG48, encoded=ENCODED_RGB444)[0]
+            dec = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
+            aw = ctypes.c_int(); ah = ctypes.c_int(); af = ctypes.c_uint32()
+            sb = ctypes.create_string_buffer(sample, len(sample))
+            for name in sorted(RGB10_FORMATS):
+                assert L.CFHD_PrepareToDecode(dec, 0, 0, fourcc(name), 1, 0, sb, 512, ctypes.byref(aw), ctypes.byref(ah), ctypes.byref(af)) == 0
+                assert L.CFHD_PrepareToDecode(dec, 0, 0, fourcc(name), 2, 0, sb, 512, ctypes.byref(aw), ctypes.byref(ah), ctypes.byref(af)) == 3
+            L.CFHD_CloseDecoder(dec)
     finally:
         os.environ.pop("CFHD_AMD_UNVERIFIED", None)
         if old is not None: os.environ["CFHD_AMD_UNVERIFIED"] = old

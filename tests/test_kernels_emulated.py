@@ -567,6 +567,35 @@ def test_inv_rgb8_last_level_lies_in_oracle_interval(w, h, dh, bpp, bottom_up):
     assert (img == 255).any() and (img == 0).any()
 
 
+@pytest.mark.parametrize("w,h,dh,name", [(16, 8, 16, "r210"), (68, 20, 37, "DPX0"), (160, 17, 34, "AB10"), (250, 33, 66, "AR10")])
+def test_inv_rgb10_last_level_equals_oracle(w, h, dh, name):
+    """k_inv_rgb10 (r210 / DPX0 / AB10 / AR10 output of RGB 4:4:4 samples: one 32-bit word per pixel, big- or little-endian) = oracle model
+    pinned on the reference decoder in test_oracle_vs_ref: (value before the final >> 1, + 3) >> 3 per component, clamped at both ends."""
+    rng = np.random.default_rng(w * 3 + h)
+    pitch = (w + 7) // 8 * 8
+    bands = []
+    for c in range(3):
+        bs = [np.zeros((h, pitch), np.int16) for _ in range(4)]
+        bs[0][:, :w] = rand_plane(rng, w, h, 14)
+        for k in range(1, 4): bs[k][:, :w] = rand_plane(rng, w, h, 11, signed=True)
+        bands.append(bs)
+    flat = [p16(a) for c in range(3) for a in bands[c]]
+    order, shifts, code = RGB10_FORMATS[name]
+    O = oracle()
+    O.orc_inv_spatial_to_rgb10.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 8 + [ctypes.c_void_p, ctypes.c_int]
+    want = np.zeros((dh, 2 * w), np.uint32)
+    O.orc_inv_spatial_to_rgb10((c_i16p * 16)(*(flat + [None] * 4)), pitch, w, h, dh, shifts[0], shifts[1], shifts[2], int(order == ">"), want.ctypes.data_as(ctypes.c_void_p), 2 * w)
+    got = np.full((dh, 2 * w + 4), 7, np.uint32)
+    E = emu()
+    E.emu_inv_rgb10.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 8 + [ctypes.c_void_p, ctypes.c_int]
+    E.emu_inv_rgb10((c_i16p * 12)(*flat), pitch, w, h, dh, shifts[0], shifts[1], shifts[2], int(order == ">"), got.ctypes.data_as(ctypes.c_void_p), 2 * w + 4)
+    assert np.array_equal(got[:, : 2 * w], want)
+    assert (got[:, 2 * w:] == 7).all()
+    words = want.byteswap() if order == ">" else want
+    comp = (words >> shifts[1]) & 0x3ff
+    assert (comp == 1023).any() and (comp == 0).any()
+
+
 @pytest.mark.parametrize("w,h,dh", [(40, 8, 8), (300, 24, 21)])
 def test_unpack_byr4_equals_oracle(w, h, dh):
     """k_unpack_byr4 (Bayer mosaic -> G, R-G, B-G, G1-G2 planes through the log-90 curve) = oracle restatement of ConvertBYR4ToFrame16s

@@ -175,6 +175,33 @@ def test_reference_yu64_decode_equals_oracle(w, h, src):
     assert len(bad) == 0, (len(bad), bad[:8].tolist(), [(int(mine[r, c]), int(img[r, c])) for r, c in bad[:8]])
 
 
+@pytest.mark.parametrize("w,h,name,ramps", [(192, 96, "AR10", 0), (320, 240, "r210", 1), (336, 252, "DPX0", 1), (720, 486, "AB10", 1), (1920, 1080, "r210", 0)])
+def test_reference_rgb10_decode_equals_oracle(w, h, name, ramps):
+    """Pins orc_inv_spatial_to_rgb10: the reference decodes RGB 4:4:4 samples to the 10-bit RGB words deterministically -- every component the
+    last-level reconstruction before its final >> 1, + 3, >> 3, clamped to 10 bits (a model fitted by probing, not read off the source) --
+    word for word, with ramps into both clips."""
+    frames, pitch = qbist_frames(10, 1, w, h, PIX_RG48)
+    if ramps:
+        px = np.frombuffer(frames[0].tobytes(), np.uint16).reshape(h, pitch // 2).copy()
+        px[: h // 4, : w * 3] = np.repeat(np.linspace(0, 65535, w), 3)[None, :].astype(np.uint16)
+        px[h // 4: h // 2, : w * 3: 3] = 65535; px[h // 4: h // 2, 1: w * 3: 3] = 0       # saturated red next to black green: ringing beyond both ends
+        frames = [np.frombuffer(px.tobytes(), np.uint8).copy()]
+    sample = ref_encode_frames(frames, pitch, w, h, PIX_RG48, encoded=ENCODED_RGB444)[0]
+    plan = Plan(w, h, pixkind=PIXKIND["RG48"], enc=3)
+    mine = oracle_inverse_rgb10(plan, host_decode_pyramid(sample, plan), name)[:h, :w]
+    for attempt in range(6):                            # (the reference's threaded decoder occasionally damages a frame)
+        dec, dpitch = ref_decode_sample(sample, w, h, fourcc(name))
+        img = np.frombuffer(dec.tobytes(), dtype=np.uint32).reshape(h, dpitch // 4)[:, :w]
+        if np.array_equal(mine, img): break
+    bad = np.argwhere(mine != img)
+    assert len(bad) == 0, (len(bad), bad[:6].tolist(), [(hex(int(mine[r, c])), hex(int(img[r, c]))) for r, c in bad[:6]])
+    if ramps:
+        order, shifts, code = RGB10_FORMATS[name]
+        words = img.byteswap() if order == ">" else img
+        comp = (words >> shifts[0]) & 0x3ff
+        assert (comp == 1023).any() and (comp == 0).any()
+
+
 @pytest.mark.parametrize("w,h,name", [(192, 96, "BGRa"), (320, 240, "RG24"), (336, 252, "BGRA"), (1920, 1080, "BGRA")])
 def test_reference_rgb8_decode_lies_in_oracle_dither_interval(w, h, name):
     """Pins orc_inv_spatial_to_rgb8: the reference decodes RGB 4:4:4 samples to RG24 / BGRA (bottom row first) / BGRa with a random four-bit
