@@ -387,3 +387,30 @@ void orc_inv_spatial_to_rgb10(PIXEL16 *const bands[4][4], int band_pitch, int w,
 		}
 	free(v);
 }
+
+/* ---- 4:2:2 samples decoded to v210 (three 10-bit samples per 32-bit word; groups of six pixels in four words: Cb0 Y0 Cr0 | Y1 Cb1 Y2 |
+ * Cr1 Y3 Cb2 | Y4 Cr2 Y5, low bits first) ------------------------------------------------------------------------------------------------
+ * Probed on the built reference (tests/test_oracle_vs_ref.py): the 10-bit samples are the YU64 words >> 6 -- the same planar 16-bit row
+ * route --, Cb = channel 2, Cr = channel 1.  Whole groups of six pixels only (the pin covers widths that are multiples of 6). */
+void orc_inv_spatial_to_v210(PIXEL16 *const bands[3][4], const int band_pitch[3], int luma_w, int h, int precision, uint32_t *out, int out_pitch_words)
+{
+	const int W = 2 * luma_w;
+	uint16_t *yu = (uint16_t *)malloc((size_t)2 * h * W * 2 * sizeof(uint16_t));
+	int y, g;
+	orc_inv_spatial_to_yu64(bands, band_pitch, luma_w, h, precision, yu, W * 2);
+	for (y = 0; y < 2 * h; y++) {
+		const uint16_t *r = yu + (size_t)y * W * 2;           /* words Y0 C1 Y1 C2 per pixel pair */
+		uint32_t *o = out + (size_t)y * out_pitch_words;
+		for (g = 0; g + 6 <= W; g += 6) {
+			uint32_t Y[6], Cb[3], Cr[3];
+			int k;
+			for (k = 0; k < 6; k++) Y[k] = r[2 * (g + k)] >> 6;
+			for (k = 0; k < 3; k++) { Cr[k] = r[2 * (g + 2 * k) + 1] >> 6; Cb[k] = r[2 * (g + 2 * k + 1) + 1] >> 6; }
+			o[4 * (g / 6) + 0] = Cb[0] | (Y[0] << 10) | (Cr[0] << 20);
+			o[4 * (g / 6) + 1] = Y[1] | (Cb[1] << 10) | (Y[2] << 20);
+			o[4 * (g / 6) + 2] = Cr[1] | (Y[3] << 10) | (Cb[2] << 20);
+			o[4 * (g / 6) + 3] = Y[4] | (Cr[2] << 10) | (Y[5] << 20);
+		}
+	}
+	free(yu);
+}

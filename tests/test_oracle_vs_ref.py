@@ -175,6 +175,43 @@ def test_reference_yu64_decode_equals_oracle(w, h, src):
     assert len(bad) == 0, (len(bad), bad[:8].tolist(), [(int(mine[r, c]), int(img[r, c])) for r, c in bad[:8]])
 
 
+@pytest.mark.parametrize("w,h,src", [(192, 96, "yuy2"), (336, 252, "yu64"), (720, 480, "yuy2"), (1920, 1080, "yu64")])
+def test_reference_v210_decode_equals_oracle(w, h, src):
+    """Pins orc_inv_spatial_to_v210 (groundwork: the product does not offer v210 output yet): the reference decodes a 4:2:2 sample to v210 as
+    the YU64 words >> 6 packed three to a 32-bit word, Cb from channel 2, Cr from channel 1 -- word for word on widths that are multiples of 6,
+    highlight ramps included."""
+    if src == "yu64":
+        f16 = (np.random.default_rng(w + h).integers(0, 1024, size=(h, w * 2)) << 6).astype(np.uint16)
+        f16[: h // 3] = (np.linspace(0, 65535, w * 2)[None, :]).astype(np.uint16)
+        f = np.frombuffer(f16.tobytes(), np.uint8).copy(); p = w * 4
+        sample = ref_encode_frames([f], p, w, h, fourcc("YU64"))[0]
+    else:
+        f, p = synth_yuy2(w, h, 11)
+        sample = ref_encode_frames([f], p, w, h, PIX_YUY2)[0]
+    plan = Plan(w, h, pixkind=PIXKIND["YU64"])
+    coeffs = host_decode_pyramid(sample, plan)
+    O = oracle()
+    work = coeffs.copy()
+    for c in range(3):
+        for lv in (2, 1):
+            d = plan.band[(c, lv, 0)]
+            bands = (c_i16p * 4)(*[plan.view(work, c, lv, b).ctypes.data_as(c_i16p) for b in range(4)])
+            dst = plan.view(work, c, lv - 1, 0)
+            O.orc_inv_spatial(bands, d["pitch"], d["width"], d["height"], plan.prescale[lv], dst.ctypes.data_as(c_i16p), plan.band[(c, lv - 1, 0)]["pitch"])
+    ptrs = (c_i16p * 12)(*[plan.view(work, c, 0, b).ctypes.data_as(c_i16p) for c in range(3) for b in range(4)])
+    pitches = [plan.band[(c, 0, 0)]["pitch"] for c in range(3)]
+    bw = plan.band[(0, 0, 0)]["width"]; bh = plan.band[(0, 0, 0)]["height"]
+    nwords = (w // 6) * 4
+    mine = np.zeros((2 * bh, nwords), np.uint32)
+    O.orc_inv_spatial_to_v210.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    O.orc_inv_spatial_to_v210(ptrs, iarr(pitches), bw, bh, plan.precision, mine.ctypes.data_as(ctypes.c_void_p), nwords)
+    for attempt in range(6):                            # (the reference's threaded decoder occasionally damages a frame)
+        dec, dpitch = ref_decode_sample(sample, w, h, fourcc("v210"))
+        img = np.frombuffer(dec.tobytes(), dtype=np.uint32).reshape(h, dpitch // 4)[:, :nwords]
+        if np.array_equal(mine[:h], img): break
+    assert np.array_equal(mine[:h], img), "%d words differ" % (mine[:h] != img).sum()
+
+
 @pytest.mark.parametrize("w,h,name,ramps", [(192, 96, "AR10", 0), (320, 240, "r210", 1), (336, 252, "DPX0", 1), (720, 486, "AB10", 1), (1920, 1080, "r210", 0)])
 def test_reference_rgb10_decode_equals_oracle(w, h, name, ramps):
     """Pins orc_inv_spatial_to_rgb10: the reference decodes RGB 4:4:4 samples to the 10-bit RGB words deterministically -- every component the
