@@ -96,28 +96,37 @@ def cpu_baseline(frames, pitch, W, H, seconds_budget=20.0, fmt=None, enc=0, flag
     if not decode:
         return {"value": round(enc_fps, 1), "unit": "fps", "cores": cores, "kind": "reference",
                 "sample": "%d frames async-pool encode (%d threads) of %dx%d %s, reference SSE2 build" % (sent, cores, W, H, label)}
-    # decode: one decoder (it spawns its own worker threads, TAG_CPU_MAX unset = all cores)
-    dec = ctypes.c_void_p(); L.CFHD_OpenDecoder(ctypes.byref(dec), None)
-    aw = ctypes.c_int(); ah = ctypes.c_int(); af = ctypes.c_uint32()
+    # decode: N decoder handles on N host threads, as the product's own C-ABI leg is driven (tools/cabi_bench.cpp); every handle is
+    # configured as Example/TestCFHD.cpp:338-356 does, its TAG_CPU_MAX = this handle's share of the cores (the harness's own cap is 16)
+    handles = max(1, min(16, cores))
+    per_handle = max(1, min(16, cores // handles))
     sbuf = [ctypes.create_string_buffer(s, len(s)) for s in samples[:nfr]]
-    L.CFHD_PrepareToDecode(dec, 0, 0, fmt, 1, 0, sbuf[0], 512, ctypes.byref(aw), ctypes.byref(ah), ctypes.byref(af))
-    out = np.zeros(W * bpp * H, dtype=np.uint8)
-    t0 = time.time(); done = 0
-    while True:
-        s = sbuf[done % nfr]
-        rc = L.CFHD_DecodeSample(dec, s, len(s), out.ctypes.data_as(ctypes.c_void_p), W * bpp)
-        if rc != 0:
-            return fail("reference decoder returned error %d" % rc)
-        done += 1
-        if done >= 2 * nfr and time.time() - t0 > seconds_budget / 2:
-            break
+    decs = [T.RefDecoder(samples[0], fmt, 1, per_handle) for _ in range(handles)]
+    counts = [0] * handles; errors = []
+    t0 = time.time()
+    def work(k):
+        out = np.zeros(W * bpp * H + 64, dtype=np.uint8)
+        while True:
+            s = sbuf[(k + counts[k] * handles) % nfr]
+            rc = decs[k].decode(s, len(s), out, W * bpp)               # (ctypes drops the GIL for the call)
+            if rc != 0:
+                errors.append(rc); return
+            counts[k] += 1
+            if counts[k] * handles >= 2 * nfr and time.time() - t0 > seconds_budget / 2:
+                return
+    ths = [threading.Thread(target=work, args=(k,)) for k in range(handles)]
+    for t in ths: t.start()
+    for t in ths: t.join()
     t_dec = time.time() - t0
-    L.CFHD_CloseDecoder(dec)
+    for d in decs: d.close()
+    if errors:
+        return fail("reference decoder returned error %d" % errors[0])
+    done = sum(counts)
     dec_fps = done / t_dec
     rt = 1.0 / (1.0 / enc_fps + 1.0 / dec_fps)
     return {"value": round(rt, 1), "unit": "fps", "cores": cores, "kind": "reference",
-            "sample": "%d frames async-pool encode (%.1f fps, %d threads) + %d frames decode (%.1f fps) of %dx%d %s, reference SSE2 build"
-                      % (sent, enc_fps, cores, done, dec_fps, W, H, label)}
+            "sample": "%d frames async-pool encode (%.1f fps, %d threads) + %d frames decode on %d handles x %d decoder threads (%.1f fps) of %dx%d %s, reference SSE2 build"
+                      % (sent, enc_fps, cores, done, handles, per_handle, dec_fps, W, H, label)}
 
 
 def c_abi_rates(frames, pitch, W, H, seconds=1.5, registered=False, decoders=8, workers=16):

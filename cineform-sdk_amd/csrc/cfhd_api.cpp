@@ -305,7 +305,7 @@ struct EncodeService : Gatherer<EncodeBatch> {
 	bool start(const EncodeParams &p, int nslots)
 	{
 		slots = nslots;
-		for (Pass &x : g) if (x.batch.prepare(p.plan, slots, true) || x.batch.prepare_entropy(sample_capacity(p))) return false;
+		for (Pass &x : g) if (x.batch.prepare(p.plan, slots, true) || x.batch.prepare_entropy(sample_capacity(p))) { for (Pass &y : g) y.batch.release(); return false; }   // (a service that cannot be set up holds no HBM)
 		run_pass = [](Pass &x, int n, uint32_t) {
 			x.batch.set_active(n);
 			int rc = x.batch.launch_forward();
@@ -467,7 +467,11 @@ struct DecMetadata { std::vector<uint8_t> block; size_t cursor = 0; };
 
 struct DecodeServiceKey {
 	int width, height, display_height, encoded_format, precision, prescale[3], out_kind; bool half, interlaced;
-	bool operator==(const DecodeServiceKey &o) const { return memcmp(this, &o, sizeof(*this)) == 0; }
+	bool operator==(const DecodeServiceKey &o) const
+	{
+		return width == o.width && height == o.height && display_height == o.display_height && encoded_format == o.encoded_format && precision == o.precision &&
+		       prescale[0] == o.prescale[0] && prescale[1] == o.prescale[1] && prescale[2] == o.prescale[2] && out_kind == o.out_kind && half == o.half && interlaced == o.interlaced;
+	}
 };
 struct DecodeService : Gatherer<DecodeBatch> {
 	DecodeServiceKey key;
@@ -477,7 +481,7 @@ struct DecodeService : Gatherer<DecodeBatch> {
 		const size_t cap = (size_t)plan.width * plan.height * pixel_bytes_of(out_kind) + 65536;
 		for (Pass &x : g) {
 			x.batch.set_interlaced(interlaced);
-			if (x.batch.prepare(plan, slots, out_kind, true, half) || x.batch.prepare_entropy(cap) || !x.batch.entropy().chunk_indexed()) return false;
+			if (x.batch.prepare(plan, slots, out_kind, true, half) || x.batch.prepare_entropy(cap) || !x.batch.entropy().chunk_indexed()) { for (Pass &y : g) y.batch.release(); return false; }
 		}
 		run_pass = [](Pass &x, int n, uint32_t launch) {
 			x.batch.set_active(n);
@@ -532,7 +536,7 @@ int front_end_params(int width, int height, uint32_t pixel_format, int encoded_f
 	if (rc) return rc;
 	out->pixel_kind = p.pixel_kind; out->encoded_format = p.encoded_format; out->pixel_bytes = pixel_bytes_of(p.pixel_kind);
 	out->color_format = color_format_of(p.pixel_kind); out->color_space = p.color_space; out->quality = p.quality; out->progressive = p.progressive;
-	out->plan = p.plan;
+	out->plan = p.plan; out->static_quantizer = quantizer_is_static(p);
 	return 0;
 }
 }
@@ -565,7 +569,7 @@ CFHD_Error CFHD_GetInputFormats(CFHD_EncoderRef ref, CFHD_PixelFormat *arr, int 
 	if (!ref || !arr) return ERR_INVALID_ARGUMENT;
 	const uint32_t fmts[] = { FMT_YUY2, FMT_2VUY, FMT_RG48, FMT_B64A, FMT_BYR4, FMT_YU64, FMT_V210, FMT_RG24, FMT_BGRA, FMT_BGRa, FMT_R210, FMT_DPX0, FMT_AB10, FMT_AR10 };
 	int n = 0;
-	for (; n < 5 && n < len; n++) arr[n] = fmts[n];
+	for (; n < (int)(sizeof(fmts) / sizeof(fmts[0])) && n < len; n++) arr[n] = fmts[n];
 	if (count) *count = n;
 	return ERR_OKAY;
 }
@@ -982,6 +986,7 @@ CFHD_Error CFHD_DecodeSample(CFHD_DecoderRef ref, void *sample, size_t size, voi
 	// inverse frame transform, half resolution from the level-1 lowpass planes like any other sample (the reference's output is the same model)
 	const bool interlaced = !ps.progressive;
 	if (interlaced && (ps.encoded_format != ENC_YUV422 || d->out_kind == PIX_YU64)) return fail_zero(ERR_BADFORMAT);      // (YU64 output of interlaced samples is not built)
+	if (interlaced && !d->half && ps.width > 8192) return fail_zero(ERR_BADFORMAT);        // k_dec_undiff serves rows of up to 4096 coefficients (cfhd_dec_kernels.h DXU_MAX): an unsupported size, not a bad sample
 	// another call of this geometry in flight right now: decode together with it (see DecodeService)
 	if (decode_gather_slots() > 1 && gpu_entropy_enabled() && size <= (size_t)d->plan.width * d->plan.height * pixel_bytes_of(d->out_kind) + 65536) {
 		if (!d->service || d->service_interlaced != interlaced) {

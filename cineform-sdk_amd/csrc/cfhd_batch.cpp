@@ -65,6 +65,10 @@ cfhd_amd_batch *cfhd_amd_batch_create_ex(int width, int height, uint32_t pixel_f
 {
 	FrontEndParams fp;
 	if (nframes < 1 || front_end_params(width, height, pixel_format, encoded_format, encoding_flags, quality, &fp)) return nullptr;
+	// A batch encodes its frames in one launch with one set of quantizer tables.  Qualities whose tables follow the size of the previous sample
+	// (FILMSCAN2/3, LOW..HIGH up to 1080p: encoder.c:3414 -> quantize.c:2869) need frame i's sample before frame i + 1 can start -- those
+	// sequences go through CFHD_EncodeSample, which applies the feedback per frame; here they are refused instead of encoded differently.
+	if (!fp.static_quantizer) return nullptr;
 	const int kind = fp.pixel_kind;
 	const bool yuv = kind == PIX_YUY2 || kind == PIX_2VUY;
 	cfhd_amd_batch *b = new (std::nothrow) cfhd_amd_batch;

@@ -48,8 +48,8 @@ public:
 	void *stream() { return stream_; }
 	float last_kernel_ms() const { return kernel_ms_; }   // forward kernels of the last launch (HIP events on this stream)
 	float last_level_ms(int level) const { return level_ms_[level]; }   // level 0 = k_fwd_yuv422, 1/2 = k_fwd_plane launches
+	void release();                                    // frees every device / pinned buffer of the batch (the destructor's work; prepare() starts with it)
 private:
-	void release();
 	int sync_jobs();
 	void fill_jobs();
 	FramePlan plan_;
@@ -99,8 +99,8 @@ public:
 	void *stream() { return stream_; }
 	float last_kernel_ms() const { return kernel_ms_; }
 	float last_level_ms(int level) const { return level_ms_[level]; }   // level 0 = k_inv_yuv422, 1/2 = k_inv_plane launches (level index)
+	void release();                                    // frees every device / pinned buffer of the batch (the destructor's work; prepare() starts with it)
 private:
-	void release();
 	int sync_jobs();
 	FramePlan plan_;
 	int n_ = 0, out_kind_ = 0; bool own_output_ = false, jobs_dirty_ = true, half_ = false, interlaced_ = false; int active_ = 0;

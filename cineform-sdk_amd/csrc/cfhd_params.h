@@ -9,6 +9,7 @@ struct FrontEndParams {
 	int pixel_kind = 0, encoded_format = 0, pixel_bytes = 2;
 	int color_format = 2, color_space = 2, quality = 0;      // as the sample header carries them (quality incl. the 4:4:4:4 marker)
 	bool progressive = true;
+	bool static_quantizer = true;                             // false: the quality re-derives its tables from the size of the previous sample (rate feedback)
 	FramePlan plan;                                           // geometry + first-frame quantizer
 };
 // Same checks and derivations as CFHD_PrepareToEncode (cfhd_api.cpp make_params).  Returns a CFHD_Error value (0 = OK).

@@ -193,20 +193,52 @@ def ref_encode_frames(frames, pitch, width, height, pixfmt=PIX_YUY2, encoded=ENC
     return out
 
 
-def ref_decode_sample(sample, width, height, pixfmt=PIX_YUY2, resolution=1):
-    """Decode through the reference's C ABI exactly as Example/TestCFHD.cpp:218-437 does (resolution 1 = full, 2 = half)."""
-    L = ref()
-    dec = ctypes.c_void_p()
-    assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
-    aw = ctypes.c_int(); ah = ctypes.c_int(); af = ctypes.c_uint32()
+TAG_CPU_MAX = fourcc("CPUM")        # Common/CFHDMetadataTags.h:271
+TAG_PROCESS_PATH = fourcc("PRCS")   # Common/CFHDMetadataTags.h:232
+METADATATYPE_UINT32 = 2             # Common/CFHDTypes.h:311
+
+
+class RefDecoder:
+    """One decoder handle of the reference, opened and configured exactly as Example/TestCFHD.cpp:218-437 does, including its
+    CFHD_SetActiveMetadata(TAG_PROCESS_PATH / TAG_CPU_MAX) calls (:338-356).  The harness caps the decoder's worker threads at 16; the
+    parity tests use ONE: without a cap the reference starts a worker per core (256 on the GPU host), and its workers race on
+    decoder->frame.alpha_Companded (Codec/bayer.c:13871 written by whichever finishes first, read at :16034) and have been seen to damage
+    frames -- with a single worker the reference decoder is deterministic (except for its rand() dither)."""
+
+    def __init__(self, sample, pixfmt=PIX_YUY2, resolution=1, cpus=1):
+        L = self.L = ref()
+        self.dec = ctypes.c_void_p(); self.md = ctypes.c_void_p()
+        assert L.CFHD_OpenDecoder(ctypes.byref(self.dec), None) == 0
+        aw = ctypes.c_int(); ah = ctypes.c_int(); af = ctypes.c_uint32()
+        sb = ctypes.create_string_buffer(sample, len(sample))
+        assert L.CFHD_PrepareToDecode(self.dec, 0, 0, pixfmt, resolution, 0, sb, 512, ctypes.byref(aw), ctypes.byref(ah), ctypes.byref(af)) == 0
+        pitch = ctypes.c_int32()
+        assert L.CFHD_GetImagePitch(aw.value, af.value, ctypes.byref(pitch)) == 0
+        self.width, self.height, self.pitch = aw.value, ah.value, pitch.value
+        if cpus:
+            assert L.CFHD_OpenMetadata(ctypes.byref(self.md)) == 0
+            assert L.CFHD_InitSampleMetadata(self.md, 0, sb, len(sample)) == 0           # METADATATYPE_ORIGINAL
+            for tag, value in ((TAG_PROCESS_PATH, 0xffff), (TAG_CPU_MAX, cpus)):          # PROCESSING_ALL_ON, as the harness
+                v = ctypes.c_uint32(value)
+                assert L.CFHD_SetActiveMetadata(self.dec, self.md, tag, METADATATYPE_UINT32, ctypes.byref(v), 4) == 0
+
+    def decode(self, sample_buffer, size, out, pitch=None):
+        """sample_buffer: ctypes string buffer; out: numpy uint8 array of at least pitch * height bytes.  Returns the CFHD_Error."""
+        return self.L.CFHD_DecodeSample(self.dec, sample_buffer, size, out.ctypes.data_as(ctypes.c_void_p), pitch or self.pitch)
+
+    def close(self):
+        self.L.CFHD_CloseDecoder(self.dec)
+        if self.md: self.L.CFHD_CloseMetadata(self.md)
+
+
+def ref_decode_sample(sample, width, height, pixfmt=PIX_YUY2, resolution=1, cpus=1):
+    """Decode through the reference's C ABI (resolution 1 = full, 2 = half) with `cpus` decoder worker threads (RefDecoder)."""
+    d = RefDecoder(sample, pixfmt, resolution, cpus)
     sb = ctypes.create_string_buffer(sample, len(sample))
-    assert L.CFHD_PrepareToDecode(dec, 0, 0, pixfmt, resolution, 0, sb, 512, ctypes.byref(aw), ctypes.byref(ah), ctypes.byref(af)) == 0
-    pitch = ctypes.c_int32()
-    assert L.CFHD_GetImagePitch(aw.value, af.value, ctypes.byref(pitch)) == 0
-    out = np.zeros(pitch.value * ah.value + 64, dtype=np.uint8)
-    assert L.CFHD_DecodeSample(dec, sb, len(sample), out.ctypes.data_as(ctypes.c_void_p), pitch.value) == 0
-    L.CFHD_CloseDecoder(dec)
-    return out[: pitch.value * ah.value].copy(), pitch.value
+    out = np.zeros(d.pitch * d.height + 64, dtype=np.uint8)
+    assert d.decode(sb, len(sample), out) == 0
+    d.close()
+    return out[: d.pitch * d.height].copy(), d.pitch
 
 
 def mask_volatile_metadata(sample):

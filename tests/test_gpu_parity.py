@@ -216,12 +216,24 @@ def test_reference_harness_links_unchanged_and_prints_same_numbers():
                 pass
             proc.wait()
         return res
-    a, b = run(ours), run(theirs)
+    # The reference harness decodes with 16 worker threads (Example/TestCFHD.cpp:345) and its decoder has been seen to damage a frame now and
+    # then on the 256-core GPU host (a 17 dB outlier in its own printout): sizes must agree in every run; a PSNR line of the reference that
+    # disagrees gets two more runs of the reference, and the frame passes when any of them prints our number.
+    a, refs = run(ours), [run(theirs)]
     for fmt in ("YUY2", "2vuy"):
         assert fmt in a and len(a[fmt]) == 10, "our library did not complete the %s run: %r" % (fmt, a.get(fmt))
-        for (sa, pa), (sb, pb) in zip(a[fmt], b[fmt][:10]):
-            assert sa == sb, "%s compressed size %d vs reference %d\nours %r\nreference %r" % (fmt, sa, sb, a, b)
-            assert abs(pa - pb) <= 0.1 + 1e-6, "%s PSNR %.1f vs reference %.1f\nours %r\nreference %r" % (fmt, pa, pb, a, b)
+    def agree(b):
+        return all(len(b.get(fmt, [])) >= 10 and all(abs(pa - pb) <= 0.1 + 1e-6 for (sa, pa), (sb, pb) in zip(a[fmt], b[fmt][:10])) for fmt in ("YUY2", "2vuy"))
+    while not agree(refs[-1]) and len(refs) < 3:
+        refs.append(run(theirs))
+    for fmt in ("YUY2", "2vuy"):
+        for b in refs:
+            assert len(b.get(fmt, [])) >= 10, "the reference harness did not complete the %s run: %r" % (fmt, b.get(fmt))
+            for (sa, pa), (sb, pb) in zip(a[fmt], b[fmt][:10]):
+                assert sa == sb, "%s compressed size %d vs reference %d\nours %r\nreference %r" % (fmt, sa, sb, a, b)
+        for k, (sa, pa) in enumerate(a[fmt]):
+            theirs_db = [b[fmt][k][1] for b in refs]
+            assert any(abs(pa - pb) <= 0.1 + 1e-6 for pb in theirs_db), "%s frame %d PSNR %.1f vs reference %r\nours %r" % (fmt, k, pa, theirs_db, a)
 
 
 def test_gpu_entropy_and_host_entropy_paths_agree():
@@ -524,52 +536,49 @@ def test_rgb8_decode_lies_in_the_reference_interval(w, h, name):
     L.CFHD_CloseDecoder(dec)
 
 
-# Paths whose first run on hardware is pending (the GPU budget of round 2 was spent before they were finished): models pinned on the reference and
-# kernels verified in the emulator on the CPU; the library answers BADFORMAT for them unless CFHD_AMD_UNVERIFIED=1.  Their GPU tests
-# exist only when CFHD_AMD_RUN_UNVERIFIED=1: one green run, then the switch goes and the tests join the suite.
-if os.environ.get("CFHD_AMD_RUN_UNVERIFIED", "0") != "0":
-    @pytest.mark.parametrize("w,h,name", [(320, 240, "r210"), (336, 252, "DPX0"), (1280, 720, "AB10"), (1920, 1080, "AR10")])
-    def test_rgb10_decode_equals_reference_exactly(w, h, name):
-        """RGB 4:4:4 samples decoded to r210 / DPX0 / AB10 / AR10 (behind CFHD_AMD_UNVERIFIED=1 until this test has run on hardware): word for word
-        the reference decoder's output; the 10-bit RGB round trip of the product alone decodes to the source."""
-        order, shifts, code = RGB10_FORMATS[name]
-        frames, pitch = qbist_frames(10, 1, w, h, PIX_RG48)
-        sample = ref_encode_frames(frames, pitch, w, h, PIX_RG48, encoded=ENCODED_RGB444)[0]
-        old = os.environ.get("CFHD_AMD_UNVERIFIED")
-        os.environ["CFHD_AMD_UNVERIFIED"] = "1"
-        try:
-            got, gpitch, aw, ah = amd_decode_sample(sample, fourcc(name))
-        finally:
-            if old is None: os.environ.pop("CFHD_AMD_UNVERIFIED", None)
-            else: os.environ["CFHD_AMD_UNVERIFIED"] = old
-        assert (aw, ah) == (w, h)
-        mine = np.frombuffer(got.tobytes(), np.uint32).reshape(h, gpitch // 4)[:, :w]
-        for attempt in range(6):                            # (the reference's threaded decoder occasionally damages a frame)
-            dec, dpitch = ref_decode_sample(sample, w, h, fourcc(name))
-            img = np.frombuffer(dec.tobytes(), dtype=np.uint32).reshape(h, dpitch // 4)[:, :w]
-            if np.array_equal(mine, img): break
-        assert np.array_equal(mine, img), "%d words differ" % (mine != img).sum()
+# RGB 4:4:4 -> 10-bit RGB words and deep RGB -> YUV 4:2:2 (round 2 left these behind CFHD_AMD_UNVERIFIED=1 for want of a hardware run).
+@pytest.mark.parametrize("w,h,name", [(320, 240, "r210"), (336, 252, "DPX0"), (1280, 720, "AB10"), (1920, 1080, "AR10")])
+def test_rgb10_decode_equals_reference_exactly(w, h, name):
+    """RGB 4:4:4 samples decoded to r210 / DPX0 / AB10 / AR10 (behind CFHD_AMD_UNVERIFIED=1 until this test has run on hardware): word for word
+    the reference decoder's output; the 10-bit RGB round trip of the product alone decodes to the source."""
+    order, shifts, code = RGB10_FORMATS[name]
+    frames, pitch = qbist_frames(10, 1, w, h, PIX_RG48)
+    sample = ref_encode_frames(frames, pitch, w, h, PIX_RG48, encoded=ENCODED_RGB444)[0]
+    old = os.environ.get("CFHD_AMD_UNVERIFIED")
+    os.environ["CFHD_AMD_UNVERIFIED"] = "1"
+    try:
+        got, gpitch, aw, ah = amd_decode_sample(sample, fourcc(name))
+    finally:
+        if old is None: os.environ.pop("CFHD_AMD_UNVERIFIED", None)
+        else: os.environ["CFHD_AMD_UNVERIFIED"] = old
+    assert (aw, ah) == (w, h)
+    mine = np.frombuffer(got.tobytes(), np.uint32).reshape(h, gpitch // 4)[:, :w]
+    for attempt in range(6):                            # (the reference's threaded decoder occasionally damages a frame)
+        dec, dpitch = ref_decode_sample(sample, w, h, fourcc(name))
+        img = np.frombuffer(dec.tobytes(), dtype=np.uint32).reshape(h, dpitch // 4)[:, :w]
+        if np.array_equal(mine, img): break
+    assert np.array_equal(mine, img), "%d words differ" % (mine != img).sum()
 
 
-    @pytest.mark.parametrize("w,h,name", [(320, 240, "RG48"), (336, 252, "b64a"), (1920, 1080, "RG48")])
-    def test_deep_rgb_encode_to_yuv422_bitstream_identical(w, h, name):
-        """RG48 / b64a encoded as YUV 4:2:2 (behind CFHD_AMD_UNVERIFIED=1 until this test has run on hardware): byte-identical to the reference;
-        the sample decodes to YUY2 like any other 4:2:2 sample."""
-        fmt = PIX_RG48 if name == "RG48" else PIX_B64A
-        frames, pitch = qbist_frames(10, 2, w, h, fmt, alpha=int(name == "b64a"))
-        old = os.environ.get("CFHD_AMD_UNVERIFIED")
-        os.environ["CFHD_AMD_UNVERIFIED"] = "1"
-        try:
-            mine = amd_encode_frames(frames, pitch, w, h, fmt, encoded=ENCODED_YUV422)
-        finally:
-            if old is None: os.environ.pop("CFHD_AMD_UNVERIFIED", None)
-            else: os.environ["CFHD_AMD_UNVERIFIED"] = old
-        refs = ref_encode_frames(frames, pitch, w, h, fmt, encoded=ENCODED_YUV422)
-        for i, (a, b) in enumerate(zip(mine, refs)):
-            assert len(a) == len(b), "frame %d: size %d vs reference %d" % (i, len(a), len(b))
-            assert mask_volatile_metadata(a) == mask_volatile_metadata(b), "frame %d" % i
-        got, gpitch, aw, ah = amd_decode_sample(mine[0], PIX_YUY2)
-        assert (aw, ah) == (w, h)
+@pytest.mark.parametrize("w,h,name", [(320, 240, "RG48"), (336, 252, "b64a"), (1920, 1080, "RG48")])
+def test_deep_rgb_encode_to_yuv422_bitstream_identical(w, h, name):
+    """RG48 / b64a encoded as YUV 4:2:2 (behind CFHD_AMD_UNVERIFIED=1 until this test has run on hardware): byte-identical to the reference;
+    the sample decodes to YUY2 like any other 4:2:2 sample."""
+    fmt = PIX_RG48 if name == "RG48" else PIX_B64A
+    frames, pitch = qbist_frames(10, 2, w, h, fmt, alpha=int(name == "b64a"))
+    old = os.environ.get("CFHD_AMD_UNVERIFIED")
+    os.environ["CFHD_AMD_UNVERIFIED"] = "1"
+    try:
+        mine = amd_encode_frames(frames, pitch, w, h, fmt, encoded=ENCODED_YUV422)
+    finally:
+        if old is None: os.environ.pop("CFHD_AMD_UNVERIFIED", None)
+        else: os.environ["CFHD_AMD_UNVERIFIED"] = old
+    refs = ref_encode_frames(frames, pitch, w, h, fmt, encoded=ENCODED_YUV422)
+    for i, (a, b) in enumerate(zip(mine, refs)):
+        assert len(a) == len(b), "frame %d: size %d vs reference %d" % (i, len(a), len(b))
+        assert mask_volatile_metadata(a) == mask_volatile_metadata(b), "frame %d" % i
+    got, gpitch, aw, ah = amd_decode_sample(mine[0], PIX_YUY2)
+    assert (aw, ah) == (w, h)
 
 
 @pytest.mark.parametrize("name", sorted(RGB10_FORMATS))
@@ -969,9 +978,13 @@ def test_packed16_strip_kernels_equal_reference(name, w, h, n, fmt, enc, mode):
             else: os.environ[k] = v
 
 
-@pytest.mark.parametrize("w,h,n,nuniq", [(1920, 1080, 64, 16), (3840, 2160, 40, 4)])
-def test_batched_round_trip_at_bench_sizes_equals_reference(w, h, n, nuniq):
+def _batched_yuy2_round_trip_equals_reference(w, h, n, nuniq, expect=None):
+    """n frames through cfhd_amd_batch_roundtrip: every sample against the reference encoder's bytes (one reference encoder, n consecutive
+    CFHD_EncodeSample calls), every decoded frame inside the dither interval of the exact reconstruction of its sample.
+    expect: {kernel slot: name} the library must report for this batch (cfhd_amd_batch_kernel_name)."""
     L = _batch_api()
+    L.cfhd_amd_batch_kernel_name.restype = ctypes.c_char_p
+    L.cfhd_amd_batch_kernel_name.argtypes = [ctypes.c_void_p, ctypes.c_int]
     uniq, pitch = qbist_frames(10, nuniq, w, h)
     frames = [uniq[i % nuniq] for i in range(n)]
     refs = ref_encode_frames(frames, pitch, w, h)               # one reference encoder, n consecutive CFHD_EncodeSample calls
@@ -979,6 +992,8 @@ def test_batched_round_trip_at_bench_sizes_equals_reference(w, h, n, nuniq):
     assert b, amd_last_error()
     for i, f in enumerate(frames):
         assert L.cfhd_amd_batch_upload(b, i, f.ctypes.data_as(ctypes.c_void_p), pitch) == 0
+    for slot, name in (expect or {}).items():
+        assert L.cfhd_amd_batch_kernel_name(b, slot).decode() == name, "slot %d runs %s" % (slot, L.cfhd_amd_batch_kernel_name(b, slot).decode())
     assert L.cfhd_amd_batch_roundtrip(b) > 0, amd_last_error()
     plan = Plan(w, h)
     interval = {}
@@ -1001,6 +1016,31 @@ def test_batched_round_trip_at_bench_sizes_equals_reference(w, h, n, nuniq):
         ok = (img == lo) | (img == hi)
         assert ok.all(), "frame %d: %d bytes outside the dither interval" % (i, (~ok).sum())
     L.cfhd_amd_batch_destroy(b)
+
+
+@pytest.mark.parametrize("w,h,n,nuniq", [(1920, 1080, 64, 16), (3840, 2160, 40, 4)])
+def test_batched_round_trip_at_bench_sizes_equals_reference(w, h, n, nuniq):
+    """The batch sizes at which the library picks the kernels bench.py times by itself (>= 32 1080p-equivalents per launch: register strips
+    at level 1; the plane levels switch at 160)."""
+    _batched_yuy2_round_trip_equals_reference(w, h, n, nuniq, expect={0: "k_fwd_yuv422_strip", 3: "k_inv_yuv422_strip"})
+
+
+@pytest.mark.parametrize("w,h,n", [(1920, 1080, 3), (3840, 2160, 2), (2048, 600, 3), (1952, 250, 2)])
+def test_yuv422_strip_kernels_equal_reference(w, h, n):
+    """The kernels bench.py times -- k_fwd_yuv422_strip, k_fwd_plane_strip, k_inv_plane_strip, k_inv_yuv422_strip -- forced on small batches
+    (CFHD_AMD_FORWARD / _PLANES / _INVERSE = strip): 1080p; 3840 and 2048 pixels = two segments of 1984 (the second one partial); a height
+    with pad rows and a partial last strip.  Samples equal the reference encoder's, decoded frames lie in the dither interval."""
+    keys = ("CFHD_AMD_FORWARD", "CFHD_AMD_INVERSE", "CFHD_AMD_PLANES")
+    old = {k: os.environ.get(k) for k in keys}
+    for k in keys: os.environ[k] = "strip"
+    try:
+        expect = {0: "k_fwd_yuv422_strip", 3: "k_inv_yuv422_strip"}
+        if w in (1920, 2048): expect.update({1: "k_fwd_plane_strip", 2: "k_fwd_plane_strip", 4: "k_inv_plane_strip", 5: "k_inv_plane_strip"})
+        _batched_yuy2_round_trip_equals_reference(w, h, n, n, expect=expect)
+    finally:
+        for k, v in old.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
 
 
 @pytest.mark.parametrize("quality", [5, 6, 2])
