@@ -97,9 +97,11 @@ def cpu_baseline(frames, pitch, W, H, seconds_budget=20.0, fmt=None, enc=0, flag
         return {"value": round(enc_fps, 1), "unit": "fps", "cores": cores, "kind": "reference",
                 "sample": "%d frames async-pool encode (%d threads) of %dx%d %s, reference SSE2 build" % (sent, cores, W, H, label)}
     # decode: N decoder handles on N host threads, as the product's own C-ABI leg is driven (tools/cabi_bench.cpp); every handle is
-    # configured as Example/TestCFHD.cpp:338-356 does, its TAG_CPU_MAX = this handle's share of the cores (the harness's own cap is 16)
-    handles = max(1, min(16, cores))
-    per_handle = max(1, min(16, cores // handles))
+    # configured as Example/TestCFHD.cpp:338-356 does, with TAG_CPU_MAX = 1: one handle per core is the reference's best arrangement
+    # (measured on 8 cores at 1080p: 8 x 1 thread 375 fps, 4 x 2 348, 1 x 8 242; on the 256-core GPU host 16 handles x 16 decoder
+    # threads collapsed to 22 fps, one handle with all cores did 156)
+    handles = max(1, min(64, cores))
+    per_handle = 1
     sbuf = [ctypes.create_string_buffer(s, len(s)) for s in samples[:nfr]]
     decs = [T.RefDecoder(samples[0], fmt, 1, per_handle) for _ in range(handles)]
     counts = [0] * handles; errors = []

@@ -112,10 +112,8 @@ int make_params(EncodeParams &p, int w, int h, uint32_t fmt, int encoded, uint32
 	// reference does without BAYER_FORMAT / ENCODE_CURVE metadata
 	// b64a also encodes to RGB 4:4:4 (its default in the reference): the alpha words are dropped, R, G, B as for 4:4:4:4
 	// RG48 / b64a encoded as YUV 4:2:2 (rows of TestCFHD's format table): the integer 709 / 601 conversion of frame.c:6731 in the loader of the level-1
-	// kernel.  Model and kernel are verified on the CPU (reference sample bytes; emulated kernel); the path waits for its first run on hardware behind
-	// CFHD_AMD_UNVERIFIED=1 and answers BADFORMAT without it.
-	const char *unverified = getenv("CFHD_AMD_UNVERIFIED");
-	const bool deep_rgb_as_422 = (kind == PIX_RG48 || kind == PIX_B64A) && encoded == 0 && unverified && atoi(unverified) != 0;
+	// kernel; the converted frame is quantized as the 4:2:2 frame it has become (derive_quantization).
+	const bool deep_rgb_as_422 = (kind == PIX_RG48 || kind == PIX_B64A) && encoded == 0;
 	if (!deep_rgb_as_422 && !(kind == PIX_B64A && encoded == 1) && encoded != (kind == PIX_RG48 || rgb8 || rgb10 ? 1 : (kind == PIX_B64A ? 2 : (kind == PIX_BYR4 ? 3 : 0)))) return ERR_BADFORMAT;
 	// CFHD_ENCODING_FLAGS_YUV_INTERLACED: field-based level 1 (encoder.c:2093), built for the packed 4:2:2 formats
 	const bool interlaced = (flags & (1u << 0)) != 0;
@@ -852,9 +850,9 @@ CFHD_Error CFHD_GetOutputFormats(CFHD_DecoderRef ref, void *sample, size_t size,
 	if (!ref || !arr) return ERR_INVALID_ARGUMENT;
 	ParsedSample ps;
 	const bool known = sample && parse_sample((const uint8_t *)sample, size, &ps) >= 0;
-	uint32_t fmts[8]; int total = 0;
+	uint32_t fmts[12]; int total = 0;
 	if (!known || ps.encoded_format == ENC_YUV422) { fmts[total++] = FMT_YUY2; fmts[total++] = FMT_2VUY; fmts[total++] = FMT_YU64; }
-	if (!known || ps.encoded_format == ENC_RGB444) { fmts[total++] = FMT_RG48; fmts[total++] = FMT_RG24; fmts[total++] = FMT_BGRA; fmts[total++] = FMT_BGRa; }
+	if (!known || ps.encoded_format == ENC_RGB444) { fmts[total++] = FMT_RG48; fmts[total++] = FMT_RG24; fmts[total++] = FMT_BGRA; fmts[total++] = FMT_BGRa; fmts[total++] = FMT_R210; fmts[total++] = FMT_DPX0; fmts[total++] = FMT_AB10; fmts[total++] = FMT_AR10; }
 	if (!known || ps.encoded_format == ENC_RGBA4444) fmts[total++] = FMT_B64A;
 	int n = 0;
 	for (; n < total && n < len; n++) arr[n] = fmts[n];
@@ -909,9 +907,8 @@ CFHD_Error CFHD_PrepareToDecode(CFHD_DecoderRef ref, int, int, CFHD_PixelFormat 
 	const bool rgb8 = kind == PIX_RG24 || kind == PIX_BGRA || kind == PIX_BGRa;
 	if (rgb8 && (encf != ENC_RGB444 || half || d->header.width < 32)) return ERR_BADFORMAT;
 	// ... and to the 10-bit RGB words r210 / DPX0 / AB10 / AR10 ((value before the final >> 1, + 3) >> 3 per component: a model fitted on the reference
-	// decoder and pinned word for word on the CPU; kernel verified in the emulator; waits for its first run on hardware behind CFHD_AMD_UNVERIFIED=1)
-	const char *unverified = getenv("CFHD_AMD_UNVERIFIED");
-	const bool rgb10 = kind >= PIX_R210 && kind <= PIX_AR10 && unverified && atoi(unverified) != 0;
+	// decoder and pinned word for word on the CPU, equal to the reference decoder on the GPU)
+	const bool rgb10 = kind >= PIX_R210 && kind <= PIX_AR10;
 	if (rgb10 && (encf != ENC_RGB444 || half || d->header.width < 32)) return ERR_BADFORMAT;
 	if (kind == PIX_BYR4 || kind == PIX_V210 || (kind >= PIX_R210 && kind <= PIX_AR10 && !rgb10)) return ERR_BADFORMAT;     // encoder inputs only
 	if ((encf == ENC_RGB444) != (kind == PIX_RG48 || rgb8 || rgb10) || (encf == ENC_RGBA4444) != (kind == PIX_B64A)) return ERR_BADFORMAT;

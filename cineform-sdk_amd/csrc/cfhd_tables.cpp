@@ -319,6 +319,8 @@ void derive_quantization(FramePlan *plan, int quality, bool progressive, float f
 	// BYR4 (104), false for the packed 4:2:2 formats and -- although it is a 4:4:4:4 format -- for b64a (COLOR_FORMAT_BGRA64 = 30),
 	// whose R, B and A planes therefore get the chroma tables
 	const bool chroma_full = plan->pixel_kind == PIX_RG48 || plan->pixel_kind == PIX_BYR4 || plan->pixel_kind == PIX_RG24 || plan->pixel_kind == PIX_BGRA || plan->pixel_kind == PIX_BGRa || (plan->pixel_kind >= PIX_R210 && plan->pixel_kind <= PIX_AR10);
+	// (deep RGB encoded as 4:2:2 is converted first and quantized as the 4:2:2 frame it has become: encoder.c:2339-2440 hand the converted format on)
+	const bool chroma_full_res = chroma_full && plan->encoded_format != ENC_YUV422;
 	const int precision = plan->precision;
 	int factor = quality & 0xff;
 	const int detail = (quality & 0x0e0000) >> 17;
@@ -334,7 +336,7 @@ void derive_quantization(FramePlan *plan, int quality, bool progressive, float f
 	if (newQuality >= 5 && st->lastgopbitcount && !(quality & 0x1f00)) {
 		float gop_size = (float)(int32_t)(st->lastgopbitcount >> 3);
 		float compression = (float)(plan->width * plan->height * plan->num_channels * precision / 8) / gop_size;
-		if (!chroma_full) compression /= 1.5f;
+		if (!chroma_full_res) compression /= 1.5f;
 		int &r = st->FSratelimiter;
 		if (newQuality == 5) {
 			if (compression > 5.5f) { r--; if (compression > 6.5f) r--; if (compression > 7.5f) r -= 2; }
@@ -352,8 +354,8 @@ void derive_quantization(FramePlan *plan, int quality, bool progressive, float f
 	int overrate = factor; if (overrate >= 2) overrate--;
 	for (int i = 0; i < 17; i++) {
 		qL[i] = kLumaQ[factor][i]; qLmax[i] = kLumaQ[overrate][i];
-		qC[i] = chroma_full ? kLumaQ[factor][i] : kChromaQ[factor][i];
-		qCmax[i] = chroma_full ? kLumaQ[overrate][i] : kChromaQ[overrate][i];
+		qC[i] = chroma_full_res ? kLumaQ[factor][i] : kChromaQ[factor][i];
+		qCmax[i] = chroma_full_res ? kLumaQ[overrate][i] : kChromaQ[overrate][i];
 	}
 	for (int i = 0; i < 17; i++) { qLmax[i] = qL[i] + (qLmax[i] - qL[i]) / 2; qCmax[i] = qC[i] + (qCmax[i] - qC[i]) / 2; }
 	int lowfreqquant = 4;

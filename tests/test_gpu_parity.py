@@ -536,21 +536,15 @@ def test_rgb8_decode_lies_in_the_reference_interval(w, h, name):
     L.CFHD_CloseDecoder(dec)
 
 
-# RGB 4:4:4 -> 10-bit RGB words and deep RGB -> YUV 4:2:2 (round 2 left these behind CFHD_AMD_UNVERIFIED=1 for want of a hardware run).
+# RGB 4:4:4 -> 10-bit RGB words and deep RGB -> YUV 4:2:2 (first hardware runs in round 3).
 @pytest.mark.parametrize("w,h,name", [(320, 240, "r210"), (336, 252, "DPX0"), (1280, 720, "AB10"), (1920, 1080, "AR10")])
 def test_rgb10_decode_equals_reference_exactly(w, h, name):
-    """RGB 4:4:4 samples decoded to r210 / DPX0 / AB10 / AR10 (behind CFHD_AMD_UNVERIFIED=1 until this test has run on hardware): word for word
+    """RGB 4:4:4 samples decoded to r210 / DPX0 / AB10 / AR10: word for word
     the reference decoder's output; the 10-bit RGB round trip of the product alone decodes to the source."""
     order, shifts, code = RGB10_FORMATS[name]
     frames, pitch = qbist_frames(10, 1, w, h, PIX_RG48)
     sample = ref_encode_frames(frames, pitch, w, h, PIX_RG48, encoded=ENCODED_RGB444)[0]
-    old = os.environ.get("CFHD_AMD_UNVERIFIED")
-    os.environ["CFHD_AMD_UNVERIFIED"] = "1"
-    try:
-        got, gpitch, aw, ah = amd_decode_sample(sample, fourcc(name))
-    finally:
-        if old is None: os.environ.pop("CFHD_AMD_UNVERIFIED", None)
-        else: os.environ["CFHD_AMD_UNVERIFIED"] = old
+    got, gpitch, aw, ah = amd_decode_sample(sample, fourcc(name))
     assert (aw, ah) == (w, h)
     mine = np.frombuffer(got.tobytes(), np.uint32).reshape(h, gpitch // 4)[:, :w]
     for attempt in range(6):                            # (the reference's threaded decoder occasionally damages a frame)
@@ -562,17 +556,11 @@ def test_rgb10_decode_equals_reference_exactly(w, h, name):
 
 @pytest.mark.parametrize("w,h,name", [(320, 240, "RG48"), (336, 252, "b64a"), (1920, 1080, "RG48")])
 def test_deep_rgb_encode_to_yuv422_bitstream_identical(w, h, name):
-    """RG48 / b64a encoded as YUV 4:2:2 (behind CFHD_AMD_UNVERIFIED=1 until this test has run on hardware): byte-identical to the reference;
+    """RG48 / b64a encoded as YUV 4:2:2: byte-identical to the reference;
     the sample decodes to YUY2 like any other 4:2:2 sample."""
     fmt = PIX_RG48 if name == "RG48" else PIX_B64A
     frames, pitch = qbist_frames(10, 2, w, h, fmt, alpha=int(name == "b64a"))
-    old = os.environ.get("CFHD_AMD_UNVERIFIED")
-    os.environ["CFHD_AMD_UNVERIFIED"] = "1"
-    try:
-        mine = amd_encode_frames(frames, pitch, w, h, fmt, encoded=ENCODED_YUV422)
-    finally:
-        if old is None: os.environ.pop("CFHD_AMD_UNVERIFIED", None)
-        else: os.environ["CFHD_AMD_UNVERIFIED"] = old
+    mine = amd_encode_frames(frames, pitch, w, h, fmt, encoded=ENCODED_YUV422)
     refs = ref_encode_frames(frames, pitch, w, h, fmt, encoded=ENCODED_YUV422)
     for i, (a, b) in enumerate(zip(mine, refs)):
         assert len(a) == len(b), "frame %d: size %d vs reference %d" % (i, len(a), len(b))

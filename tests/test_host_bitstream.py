@@ -158,7 +158,9 @@ def test_deep_rgb_to_yuv422_sample_bytes_equal_reference(w, h, name):
     frames, pitch = qbist_frames(10, 1, w, h, fmt, alpha=int(name == "b64a"))
     words = np.frombuffer(frames[0].tobytes(), np.uint16).reshape(h, pitch // 2)[:, : w * wpp]
     rs = ref_encode_frames(frames, pitch, w, h, fmt, encoded=ENCODED_YUV422)[0]
-    plan = Plan(w, h, pixkind=PIXKIND["YU64"], enc=1)
+    plan = Plan(w, h, pixkind=PIXKIND[name], enc=1)          # the product's own plan for this combination: 4:2:2 geometry AND 4:2:2 quantizer tables
+    yu64 = Plan(w, h, pixkind=PIXKIND["YU64"], enc=1)        # (round 3's first hardware run: RG48 took the full-resolution chroma tables of RGB 4:4:4)
+    assert all(plan.band[k]["quant"] == yu64.band[k]["quant"] for k in plan.band)
     planes = oracle_rgb16_to_yuv422_planes(words, wpp, 0 if name == "RG48" else 1, w, h)
     off, n = first_metadata_chunk(rs)
     mine = product_write_sample_host(plan, oracle_forward_planes(plan, planes), 1, meta_global=rs[off:off + n], input_format=120 if name == "RG48" else 30, color_space=2)
@@ -366,31 +368,23 @@ def test_thumbnail_and_output_formats_argument_handling():
 
 
 
-def test_deep_rgb_as_yuv422_stays_behind_its_gate():
-    """RG48 / b64a -> YUV 4:2:2 is answered with CFHD_ERROR_BADFORMAT (3) unless CFHD_AMD_UNVERIFIED=1 is set (then the call goes on to the GPU:
-    any answer but 3 here, where there is none)."""
+def test_deep_rgb_as_yuv422_and_rgb10_outputs_are_accepted():
+    """RG48 / b64a -> YUV 4:2:2 and the 10-bit RGB decoder outputs are open (they sat behind CFHD_AMD_UNVERIFIED=1 until their first hardware run in
+    round 3): CFHD_PrepareToEncode goes on to the GPU (any answer but BADFORMAT here, where there is none); CFHD_PrepareToDecode is host code."""
     L = product()
     enc = ctypes.c_void_p(); assert L.CFHD_OpenEncoder(ctypes.byref(enc), None) == 0
-    old = os.environ.pop("CFHD_AMD_UNVERIFIED", None)
-    try:
-        for fmt in (PIX_RG48, PIX_B64A):
-            assert L.CFHD_PrepareToEncode(enc, 320, 240, fmt, ENCODED_YUV422, 0, QUALITY_FILMSCAN1) == 3
-        os.environ["CFHD_AMD_UNVERIFIED"] = "1"
-        assert L.CFHD_PrepareToEncode(enc, 320, 240, PIX_RG48, ENCODED_YUV422, 0, QUALITY_FILMSCAN1) != 3
-        if have_ref():
-            # the same switch opens the 10-bit RGB decoder outputs (CFHD_PrepareToDecode is host code)
-            frgb, prgb = qbist_frames(10, 1, 320, 240, PIX_RG48)
-            sample = ref_encode_frames(frgb, prgb, 320, 240, PIX_RG48, encoded=ENCODED_RGB444)[0]
-            dec = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
-            aw = ctypes.c_int(); ah = ctypes.c_int(); af = ctypes.c_uint32()
-            sb = ctypes.create_string_buffer(sample, len(sample))
-            for name in sorted(RGB10_FORMATS):
-                assert L.CFHD_PrepareToDecode(dec, 0, 0, fourcc(name), 1, 0, sb, 512, ctypes.byref(aw), ctypes.byref(ah), ctypes.byref(af)) == 0
-                assert L.CFHD_PrepareToDecode(dec, 0, 0, fourcc(name), 2, 0, sb, 512, ctypes.byref(aw), ctypes.byref(ah), ctypes.byref(af)) == 3
-            L.CFHD_CloseDecoder(dec)
-    finally:
-        os.environ.pop("CFHD_AMD_UNVERIFIED", None)
-        if old is not None: os.environ["CFHD_AMD_UNVERIFIED"] = old
+    for fmt in (PIX_RG48, PIX_B64A):
+        assert L.CFHD_PrepareToEncode(enc, 320, 240, fmt, ENCODED_YUV422, 0, QUALITY_FILMSCAN1) != 3
+    if have_ref():
+        frgb, prgb = qbist_frames(10, 1, 320, 240, PIX_RG48)
+        sample = ref_encode_frames(frgb, prgb, 320, 240, PIX_RG48, encoded=ENCODED_RGB444)[0]
+        dec = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
+        aw = ctypes.c_int(); ah = ctypes.c_int(); af = ctypes.c_uint32()
+        sb = ctypes.create_string_buffer(sample, len(sample))
+        for name in sorted(RGB10_FORMATS):
+            assert L.CFHD_PrepareToDecode(dec, 0, 0, fourcc(name), 1, 0, sb, 512, ctypes.byref(aw), ctypes.byref(ah), ctypes.byref(af)) == 0
+            assert L.CFHD_PrepareToDecode(dec, 0, 0, fourcc(name), 2, 0, sb, 512, ctypes.byref(aw), ctypes.byref(ah), ctypes.byref(af)) == 3
+        L.CFHD_CloseDecoder(dec)
     L.CFHD_CloseEncoder(enc)
 
 
@@ -408,7 +402,7 @@ def test_decoder_output_format_gates():
                "444": ref_encode_frames(frgb, prgb, w, h, PIX_RG48, encoded=ENCODED_RGB444)[0],
                "4444": ref_encode_frames(fa, pa, w, h, PIX_B64A, encoded=ENCODED_RGBA4444)[0]}
     accepted = {("422", "YUY2", 1), ("422", "YUY2", 2), ("422", "2vuy", 1), ("422", "2vuy", 2), ("422", "YU64", 1),
-                ("444", "RG48", 1), ("444", "RG48", 2), ("444", "RG24", 1), ("444", "BGRA", 1), ("444", "BGRa", 1),
+                ("444", "RG48", 1), ("444", "RG48", 2), ("444", "RG24", 1), ("444", "BGRA", 1), ("444", "BGRa", 1), ("444", "r210", 1),
                 ("4444", "b64a", 1), ("4444", "b64a", 2)}
     dec = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
     aw = ctypes.c_int(); ah = ctypes.c_int(); af = ctypes.c_uint32()
