@@ -28,11 +28,14 @@
 #include <stdint.h>
 #include "cfhd_entropy_kernels.h"
 
+// k_dec_tiles: a wave owns a tile of 4096 coefficients (8 KB of LDS), sixteen waves -- one workgroup per CU -- share the tables.  Ordinary
+// pictures spend about 0.9 payload bits per coefficient: a tile of 2048 (round 2) met ~29 pieces of 64 bits, so that fewer than half of a wave's
+// lanes had a piece to decode (SQ counters, profiles/r03_a_*: 19.6 active lanes per vector instruction); with 4096 it is ~58.
 #ifndef CFHD_DX_TILE
-#define CFHD_DX_TILE 2048
+#define CFHD_DX_TILE 4096
 #endif
 #ifndef CFHD_DX_TILE_THREADS
-#define CFHD_DX_TILE_THREADS 512
+#define CFHD_DX_TILE_THREADS 1024
 #endif
 
 namespace cfhd {
@@ -65,6 +68,7 @@ enum {
 	DX_THREADS = 256, DX_WAVES = DX_THREADS / 64,
 	DX_TILE_THREADS = CFHD_DX_TILE_THREADS, DX_TILE_WAVES = DX_TILE_THREADS / 64,      // k_dec_tiles: its waves share the tables
 	DX_KM = 11,                       // bits of the window of the multi-symbol table of k_dec_tiles
+	DX_L11_BITS = 7, DX_LONG11_MAX = 1664,   // k_dec_tiles' own tables for the code words that do not fit the 11-bit window: second level 7 bits, third level the rest (up to 26 in all)
 	DX_RUNIN_SHORT = 96, DX_LEAD = 96,    // bits of the quick run-in in front of a chunk / of the lead-in in front of a lane
 	DX_MEMO = CFHD_DX_MEMO,           // outcomes a lane of k_dec_index remembers (start -> end, count)
 	DX_OFF_INVALID = 31,              // entry: no code word of the true sequence starts in this piece (behind the band end marker / the payload)
@@ -85,7 +89,12 @@ struct DecIdxTables {
 	// them: x = bits 0-3 bits used (0: nothing fits -> one code word at a time), bits 4-15 zeros in front of v1, bits 16-31 v1 (signed; 0: none);
 	// y = bits 0-7 zeros between v1 and v2, bits 8-15 zeros behind the last value, bits 16-31 v2.  Values this short are below the knee of the
 	// companding curve (magnitude = index), so the table serves both code sets.
+	// x & 15 == 0 (the first code word does not fit the window): y is an entry in the format of long11[] -- the code word itself when only its
+	// sign bit lies outside the window, else an escape to long11[] indexed by the next DX_L11_BITS bits (and once more for code words beyond 18 bits).
 	uint2 multi[1 << DX_KM];
+	// bits 0-4 length without the sign bit (escape: index bits of the next level), bits 5-7 type (DX_T_*), bits 8-19 zero run | magnitude under code
+	// set 17's companding curve | base of the next level, bits 20-31 magnitude under code set 18's (linear) curve
+	uint32_t long11[DX_LONG11_MAX];
 };
 
 // One coded band of one frame = DecBandJob (cfhd_entropy_kernels.h); the job table is [band slot][frame], a band that is not wanted -- half
@@ -853,20 +862,22 @@ __device__ __forceinline__ void dx_tile_pieces(const DxTileMeta &M, uint32_t q, 
 __device__ __forceinline__ bool dx_tile_has_work(const DxTileMeta &M) { return M.job.bytes != 0u && M.ti * DX_TILE < (uint32_t)M.job.n && M.first_sub != DX_TILE_EMPTY; }
 __device__ __forceinline__ uint32_t dx_tile_last_sub(const DxTileMeta &M) { return ((uint32_t)M.sum.last_chunk + 1u) * DX_CHUNK_SUBS; }
 
+// The LDS image of a wave's tile: DX_TILE coefficients and, behind them, one dump slot per lane -- a store that has nothing to write (no value
+// in this step, or a position outside the tile: a piece reaches in from the tile in front or out into the next one) goes there instead of being
+// masked out, which keeps the decode loop free of execution-mask bookkeeping.
+enum { DX_TILE_WORDS = DX_TILE / 2 + 32 };
+
 __global__ void __launch_bounds__(DX_TILE_THREADS) k_dec_tiles(const DxBandJob *jobs, DxTilePlan plan, const DecIdxTables *T, const uint32_t *entries, const uint32_t *chunk_base,
                                                                const DxBandSum *sums, const uint32_t *tile_start)
 {
 	__shared__ uint2 s_multi[1 << DX_KM];
-	__shared__ uint16_t s_sym[1 << DX_K];
-	__shared__ uint32_t s_long[DX_LONG_MAX];
-	__shared__ uint16_t s_mag_all[2][256];
-	__shared__ uint32_t s_tile_all[DX_TILE_WAVES][DX_TILE / 2];
-	dx_load_tables(T, nullptr, s_sym, s_long, false);
-	for (int i = threadIdx.x; i < 512; i += blockDim.x) (&s_mag_all[0][0])[i] = (&T->mag_expand[0][0])[i];
+	__shared__ uint32_t s_long[DX_LONG11_MAX];
+	__shared__ uint32_t s_tile_all[DX_TILE_WAVES][DX_TILE_WORDS];
+	for (int i = threadIdx.x; i < DX_LONG11_MAX; i += blockDim.x) s_long[i] = T->long11[i];
 	for (int i = threadIdx.x; i < (1 << DX_KM); i += blockDim.x) s_multi[i] = T->multi[i];
 	const int lane = wave_lane(), wave = wave_uniform((int)(threadIdx.x >> 6));
 	uint32_t *s_tile = s_tile_all[wave];
-	for (int i = lane; i < DX_TILE / 2; i += 64) s_tile[i] = 0u;
+	for (int i = lane; i < DX_TILE_WORDS; i += 64) s_tile[i] = 0u;
 	__syncthreads();
 	const uint32_t gwave = (uint32_t)blockIdx.x * DX_TILE_WAVES + (uint32_t)wave, nwaves = (uint32_t)gridDim.x * DX_TILE_WAVES;
 	uint32_t t = gwave;
@@ -879,6 +890,8 @@ __global__ void __launch_bounds__(DX_TILE_THREADS) k_dec_tiles(const DxBandJob *
 	if (t + nwaves < plan.total) dx_tile_meta(plan, t + nwaves, slot, jobs, sums, tile_start, M1);
 	DxPieces P;
 	dx_tile_pieces(M, dx_tile_has_work(M) ? M.first_sub + (uint32_t)lane : 0xFFFFFFFFu, dx_tile_has_work(M) ? dx_tile_last_sub(M) : 0u, entries, chunk_base, P);
+	int16_t *tile16 = (int16_t *)s_tile;
+	const uint32_t dump = (uint32_t)DX_TILE + (uint32_t)lane;           // this lane's dump slot (16-bit index)
 #pragma unroll 1
 	for (; t < plan.total; t += nwaves) {
 		DxTileMeta M2 = M1;
@@ -895,53 +908,59 @@ __global__ void __launch_bounds__(DX_TILE_THREADS) k_dec_tiles(const DxBandJob *
 			if (first_sub != DX_TILE_EMPTY) {
 				// piece by piece, one per lane, until the pieces start behind the tile
 				const uint32_t last_sub = (uint32_t)wave_uniform((int)dx_tile_last_sub(M));
-				const int quant = job.quant;
-				const uint16_t *s_mag = s_mag_all[job.table & 1];
+				const uint32_t quant = (uint32_t)job.quant;        // (only the low 16 bits of value x divisor are kept, as in the reference's PIXEL arithmetic)
+				const bool linear = (job.table & 1) != 0;                      // code set 18: the second magnitude of the long entries
+				const int len_tile = (int)(T1 - T0);
 #pragma unroll 1
 				for (uint32_t q0 = first_sub; q0 < last_sub; q0 += 64) {
 					const uint32_t q = q0 + (uint32_t)lane;
 					const bool active = q < last_sub;
-					if (q0 != first_sub) dx_tile_pieces(M, q, last_sub, entries, chunk_base, P);     // a second round is rare (a dense tile)
+					if (q0 != first_sub) dx_tile_pieces(M, q, last_sub, entries, chunk_base, P);     // further rounds: a dense tile (more than 64 pieces)
 					const uint32_t off = P.ent & 31u;
-					uint32_t idx = P.cb + (P.ent >> 5);
+					const uint32_t idx0 = P.cb + (P.ent >> 5);
 					const bool valid = active && off != (uint32_t)DX_OFF_INVALID;
-					const bool inside = valid && idx < T1;
+					const bool inside = valid && idx0 < T1;
 					if (inside) {
-						uint64_t acc = (((uint64_t)bswap32(P.d[0]) << 32) | bswap32(P.d[1])) << off;
-						int have = 64 - (int)off;
-						uint32_t nextw = bswap32(P.d[2]), afterw = bswap32(P.d[3]);
+						// The walk starts at bit `off` (< 31) of the piece and goes on while it is inside the piece's 64 bits; a code word has at most 27
+						// bits, so every 32-bit window the walk looks at lies in the piece's first 96 bits: three words, no refill state -- the window at bit
+						// position pos is cut out of the word pair it starts in.
+						const uint32_t w0 = bswap32(P.d[0]), w1 = bswap32(P.d[1]), w2 = bswap32(P.d[2]);
 						uint32_t pos = off;
-						int16_t *tile16 = (int16_t *)s_tile;
-						// one loop with one way out, the two kinds of step (a group out of the multi-symbol table | one long code word) feeding the
-						// same stores: fewer instructions per pass than separate paths with their own stores and `continue` / `break`
+						uint32_t rel = idx0 - T0;                          // position inside the tile; "negative" (the piece starts in front of the tile) wraps to a huge number
+						// one loop with one way out; both kinds of step (a group out of the multi-symbol table | one long code word) feed the same two
+						// unconditional stores
 						bool alive = true;
 						do {
-							if (have < 32) { acc |= (uint64_t)nextw << (32 - have); have += 32; nextw = afterw; afterw = 0u; }
-							const uint32_t win = (uint32_t)(acc >> 32);
+							const bool second = pos >= 32u;
+							const uint32_t win = (uint32_t)(((((uint64_t)(second ? w1 : w0)) << 32) | (second ? w2 : w1)) << (pos & 31u) >> 32);
 							// up to two values and the zero runs around them per lookup.  A group may reach over the end of the piece: the lane of the
 							// next piece then writes the same values to the same places again.
 							const uint2 e = s_multi[win >> (32 - DX_KM)];
-							int adv = (int)(e.x & 15u);
+							uint32_t adv = e.x & 15u;
 							uint32_t pre = (e.x >> 4) & 0xfffu, mid = e.y & 0xffu, post = (e.y >> 8) & 0xffu;
 							int v1 = (int)(int16_t)(e.x >> 16), v2 = (int)(int16_t)(e.y >> 16);
-							bool has1 = v1 != 0;
-							if (adv == 0) {
-								// a code word of more than 11 bits (a large value, a long run, the band end marker): alone, through the full tables
-								const DxSym sy = dx_symbol(s_sym, s_long, win);
-								pre = 0u; mid = 0u; post = 0u; v1 = 0; v2 = 0;
-								if (sy.type == DX_T_RUN) { pre = (uint32_t)sy.payload; adv = sy.len; }
-								else if (sy.type == DX_T_VALUE) {
-									const int m = (int)s_mag[sy.payload];
-									v1 = (int)((acc << sy.len) >> 63) ? -m : m; has1 = true; adv = sy.len + 1;
-								} else alive = false;                         // band end marker (or a broken code, reported by k_dec_chain)
+							if (adv == 0u) {
+								// a code word that does not fit the window (a large value, a long run, the band end marker): alone, through its own trie
+								uint32_t le = e.y;
+								if (((le >> 5) & 7u) == (uint32_t)DX_T_ESCAPE) {
+									le = s_long[((le >> 8) & 0xfffu) + ((win << DX_KM) >> (32 - DX_L11_BITS))];
+									if (((le >> 5) & 7u) == (uint32_t)DX_T_ESCAPE) le = s_long[((le >> 8) & 0xfffu) + ((win << (DX_KM + DX_L11_BITS)) >> (32 - (le & 31u)))];
+								}
+								const uint32_t ty = (le >> 5) & 7u, ln = le & 31u;
+								const int m = (int)(linear ? le >> 20 : (le >> 8) & 0xfffu);
+								const bool isval = ty == (uint32_t)DX_T_VALUE, isrun = ty == (uint32_t)DX_T_RUN;
+								pre = isrun ? (le >> 8) & 0xfffu : 0u; mid = 0u; post = 0u; v2 = 0;
+								v1 = isval ? (((win << ln) >> 31) ? -m : m) : 0;
+								adv = isval ? ln + 1u : ln;
+								alive = isval || isrun;                       // else: the band end marker (or a broken code, reported by k_dec_chain)
 							}
-							idx += pre;
-							if (has1) { if (idx - T0 < (uint32_t)DX_TILE) tile16[idx - T0] = (int16_t)(v1 * quant); idx++; }
-							idx += mid;
-							if (v2) { if (idx - T0 < (uint32_t)DX_TILE) tile16[idx - T0] = (int16_t)(v2 * quant); idx++; }
-							idx += post;
-							acc <<= adv; have -= adv; pos += (uint32_t)adv;
-							alive = alive && pos < (uint32_t)DX_SUB_BITS && idx < T1;
+							rel += pre;
+							{ const bool st = v1 != 0 && rel < (uint32_t)DX_TILE; tile16[st ? rel : dump] = (int16_t)mul_u24((uint32_t)v1, quant); rel += v1 != 0 ? 1u : 0u; }
+							rel += mid;
+							{ const bool st = v2 != 0 && rel < (uint32_t)DX_TILE; tile16[st ? rel : dump] = (int16_t)mul_u24((uint32_t)v2, quant); rel += v2 != 0 ? 1u : 0u; }
+							rel += post;
+							pos += adv;
+							alive = alive && pos < (uint32_t)DX_SUB_BITS && (int)rel < len_tile;
 						} while (alive);
 					}
 					// pieces are in raster order: once a valid one starts behind the tile, all later ones do

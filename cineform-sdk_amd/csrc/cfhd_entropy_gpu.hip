@@ -58,7 +58,7 @@ int GpuEntropyEncoder::prepare(const FramePlan &plan, int nframes, int16_t *d_co
 	HIPCHK(hipMalloc(&d_segband_, jobs.segjobs.size() * sizeof(dev::EntSegJob)));
 	HIPCHK(hipMemcpy(d_segband_, jobs.segjobs.data(), jobs.segjobs.size() * sizeof(dev::EntSegJob), hipMemcpyHostToDevice));
 	HIPCHK(hipMalloc(&d_segs_, jobs.segjobs.size() * sizeof(dev::EntSegState)));
-	HIPCHK(hipMalloc(&d_tokens_, jobs.segjobs.size() * (size_t)dev::ENT_SEG * sizeof(uint32_t)));      // token lists: worst case one token per coefficient, only the used part is ever touched
+	HIPCHK(hipMalloc(&d_tokens_, jobs.segjobs.size() * (size_t)dev::ENT_TOK_STRIDE * sizeof(uint32_t)));      // token lists and finished bit strings: worst case one per coefficient, only the used part is ever touched
 	HIPCHK(hipMalloc(&d_bandstate_, jobs.bands.size() * sizeof(dev::EntBandState)));
 	HIPCHK(hipMalloc((void **)&d_samples_, cap_ * n_));
 	HIPCHK(hipHostMalloc((void **)&h_samples_, cap_ * n_, hipHostMallocDefault));
@@ -239,7 +239,7 @@ int GpuEntropyDecoder::prepare(const FramePlan &plan, int nframes, int16_t *d_co
 		int cus = 256;
 		(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
 		const char *g1 = getenv("CFHD_AMD_DX_GRID_INDEX"), *g3 = getenv("CFHD_AMD_DX_GRID_TILES");
-		grid_index_ = g1 ? atoi(g1) : cus * 5; grid_tiles_ = g3 ? atoi(g3) : cus * 2;      // workgroups that fit a CU at once (LDS: ~30 KB / ~62 KB each)
+		grid_index_ = g1 ? atoi(g1) : cus * 5; grid_tiles_ = g3 ? atoi(g3) : cus * (dev::DX_TILE_THREADS >= 1024 ? 1 : 2);      // workgroups that fit a CU at once (LDS: ~30 KB / ~150 KB each)
 		if (grid_index_ < 1) grid_index_ = 1;
 		if (grid_tiles_ < 1) grid_tiles_ = 1;
 	}

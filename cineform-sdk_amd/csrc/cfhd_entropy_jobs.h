@@ -140,6 +140,69 @@ inline bool build_dec_index_tables(int codebook, dev::DecIdxTables *T)
 		T->multi[win].x = (uint32_t)(used & 15) | ((uint32_t)pre << 4) | ((uint32_t)(uint16_t)(int16_t)v1 << 16);
 		T->multi[win].y = (uint32_t)(mid & 0xff) | ((uint32_t)(post & 0xff) << 8) | ((uint32_t)(uint16_t)(int16_t)v2 << 16);
 	}
+	// k_dec_tiles, windows whose first code word does not fit (multi[win].x & 15 == 0): the code word through a trie of its own -- 11 bits (the
+	// window), DX_L11_BITS more, the rest -- whose entries carry everything the kernel needs (length, kind, run or both magnitudes): one LDS read
+	// for code words of 12 to 18 bits, two beyond, none when only the sign bit lies outside the window.
+	{
+		auto entry_of = [&](const RawCode &c, bool *ok) {
+			const uint32_t a = c.kind == 1 ? T->mag_expand[0][c.payload] : (uint32_t)c.payload, b = c.kind == 1 ? T->mag_expand[1][c.payload] : 0u;
+			if (a >= (1u << 12) || b >= (1u << 12) || c.len > 31) *ok = false;
+			return (uint32_t)c.len | ((uint32_t)type_of(c) << 5) | (a << 8) | (b << 20);
+		};
+		bool ok = true;
+		uint32_t n11 = 0;
+		int l2_of[1 << DX_KM];
+		for (int p = 0; p < (1 << DX_KM); p++) l2_of[p] = -1;
+		struct L3b { uint32_t key; int maxlen; uint32_t base; };
+		std::vector<L3b> l3b;
+		for (int i = 0; i < ncodes; i++) {
+			const RawCode &c = codes[i];
+			const int total = c.len + (c.kind == 1 ? 1 : 0);
+			if (total <= DX_KM) continue;                       // served by the multi-symbol entries
+			if (c.len <= DX_KM) {                               // the code word ends inside the window, its sign bit does not
+				const uint32_t base = c.bits << (DX_KM - c.len);
+				for (uint32_t k = 0; k < (1u << (DX_KM - c.len)); k++) { if (T->multi[base + k].x & 15u) ok = false; T->multi[base + k].y = entry_of(c, &ok); }
+				continue;
+			}
+			const uint32_t p11 = c.bits >> (c.len - DX_KM);
+			if (l2_of[p11] < 0) {
+				if (n11 + (1u << DX_L11_BITS) > DX_LONG11_MAX) return false;
+				l2_of[p11] = (int)n11; n11 += 1u << DX_L11_BITS;
+				if (T->multi[p11].x & 15u) ok = false;
+				T->multi[p11].y = (uint32_t)DX_L11_BITS | ((uint32_t)DX_T_ESCAPE << 5) | ((uint32_t)l2_of[p11] << 8);
+			}
+			if (c.len > DX_KM + DX_L11_BITS) {
+				const uint32_t key = c.bits >> (c.len - DX_KM - DX_L11_BITS);
+				auto it = std::find_if(l3b.begin(), l3b.end(), [&](const L3b &x) { return x.key == key; });
+				if (it == l3b.end()) l3b.push_back(L3b{ key, c.len, 0 }); else if (c.len > it->maxlen) it->maxlen = c.len;
+			}
+		}
+		for (L3b &x : l3b) {
+			const int nb = x.maxlen - DX_KM - DX_L11_BITS;
+			if (n11 + (1u << nb) > DX_LONG11_MAX) return false;
+			x.base = n11; n11 += 1u << nb;
+			T->long11[(uint32_t)l2_of[x.key >> DX_L11_BITS] + (x.key & ((1u << DX_L11_BITS) - 1u))] = (uint32_t)nb | ((uint32_t)DX_T_ESCAPE << 5) | (x.base << 8);
+		}
+		for (int i = 0; i < ncodes; i++) {
+			const RawCode &c = codes[i];
+			if (c.len <= DX_KM) continue;
+			const uint32_t e = entry_of(c, &ok);
+			if (c.len <= DX_KM + DX_L11_BITS) {
+				const int spare = DX_KM + DX_L11_BITS - c.len;
+				const uint32_t base = (uint32_t)l2_of[c.bits >> (c.len - DX_KM)] + ((c.bits & ((1u << (c.len - DX_KM)) - 1u)) << spare);
+				for (uint32_t k = 0; k < (1u << spare); k++) T->long11[base + k] = e;
+			} else {
+				const uint32_t key = c.bits >> (c.len - DX_KM - DX_L11_BITS);
+				const L3b &x = *std::find_if(l3b.begin(), l3b.end(), [&](const L3b &y) { return y.key == key; });
+				const int nb = x.maxlen - DX_KM - DX_L11_BITS, rest = c.len - DX_KM - DX_L11_BITS, spare = nb - rest;
+				const uint32_t base = x.base + ((c.bits & ((1u << rest) - 1u)) << spare);
+				for (uint32_t k = 0; k < (1u << spare); k++) T->long11[base + k] = e;
+			}
+		}
+		if (!ok) return false;
+		// (windows that are no prefix of any code word keep y = 0: type DX_T_INVALID)
+		for (uint32_t win = 0; win < (1u << DX_KM); win++) if ((T->multi[win].x & 15u) == 0 && (T->multi[win].x >> 4)) return false;   // nothing but the flag in x
+	}
 	return true;
 }
 

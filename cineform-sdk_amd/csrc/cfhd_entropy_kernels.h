@@ -32,7 +32,11 @@ namespace dev {
 #endif
 enum { ENT_THREADS = 256, ENT_LANES = 64, ENT_WAVES = ENT_THREADS / ENT_LANES, ENT_PER_THREAD = CFHD_ENT_PER_THREAD, ENT_SEG = ENT_LANES * ENT_PER_THREAD,
        ENT_LDS_WORDS = 256, ENT_TOK_CAP = CFHD_ENT_TOK_CAP, ENT_MAX_HOLES = 40,
-       ENT_FILL = CFHD_ENT_FILL /* bytes of a sample one workgroup of k_ent_layout fills at a time */ };
+       ENT_FILL = CFHD_ENT_FILL /* bytes of a sample one workgroup of k_ent_layout fills at a time */,
+       // what k_ent_count leaves per segment for k_ent_emit (32-bit words): ENT_SEG tokens (local raster index << 16 | value), then ENT_SEG finished
+       // bit strings of two words each (run code + value code of the token, left aligned in 58 bits, length in the low 6 bits)
+       ENT_TOK_STRIDE = 3 * ENT_SEG, ENT_CODE_COMPLEX = 63 /* length field: the token's run takes several run codes -- k_ent_emit walks the tables for it */,
+       ENT_RUN_COMPLEX = 0xff /* EntSegState::run_size: the run in front of the segment's first token takes several run codes */ };
 // ENT_LDS_WORDS: 32-bit words of the per-wave bit window in LDS (a segment of ordinary pictures codes into 10-40 words; beyond the window
 // the code words go to the payload with global atomics).  ENT_TOK_CAP: tokens (nonzero coefficients) of a segment held in LDS at a
 // time (ordinary: ~80 of 1024; a denser segment is worked off in passes).  Both are sized for occupancy, not for the worst case:
@@ -71,6 +75,8 @@ struct EntSegState {               // per segment, written by k_ent_count / k_en
 	int prev_nz;                   // last nonzero before this segment (-1: none)
 	uint32_t bitoff;               // bit offset of its first token relative to the band payload
 	uint32_t ntok;                 // k_ent_count: nonzero coefficients of the segment = entries of its token list
+	uint32_t run_code, run_size;   // k_ent_scan: the run code in front of the segment's first token (reaches back into earlier segments) when one code covers it; run_size ENT_RUN_COMPLEX otherwise
+	uint32_t run_bits;             // k_ent_scan: bits of all the run codes in front of the first token
 };
 
 struct EntBandState { uint32_t seg_bits, tail_run, payload_bytes, base_byte; uint8_t *out; /* payload address in the sample; null until k_ent_layout placed it */ };
@@ -240,7 +246,21 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_count(const EntSegJob *seg_
 			const uint32_t run = (have && t > 0) ? (tok >> 16) - (before >> 16) - 1u : 0u;
 			const uint32_t ve = value_entry(T, (int)(int16_t)(tok & 0xffffu));
 			const uint32_t rt = T->run_total[run];
-			if (have) { bits += rt + (ve >> 27); tokens[(size_t)seg * ENT_SEG + (size_t)t] = tok; }
+			const uint2 rp = T->run_pack[run];
+			if (have) {
+				bits += rt + (ve >> 27);
+				uint32_t *seg_out = tokens + (size_t)seg * ENT_TOK_STRIDE;
+				seg_out[t] = tok;
+				// the token's finished bit string for k_ent_emit: run code (when one code covers the run: nearly always) + value code, at most
+				// 31 + 27 bits, left aligned; the first token of the segment carries its value code only (its run reaches into the earlier
+				// segments: k_ent_scan works that one out)
+				const uint32_t vs = ve >> 27, vc = ve & 0x7FFFFFFu, rs = run ? rp.y & 0xffu : 0u;
+				const bool simple = run == 0u || (rp.y >> 8) == run;
+				const uint64_t str = simple ? (((uint64_t)(run ? rp.x : 0u) << vs) | vc) << (64u - rs - vs) : 0ull;      // (rs + vs >= 2: a value code has at least its sign)
+				const uint32_t len = simple ? rs + vs : (uint32_t)ENT_CODE_COMPLEX;
+				uint2 rec; rec.x = (uint32_t)str | len; rec.y = (uint32_t)(str >> 32);
+				((uint2 *)(seg_out + ENT_SEG))[t] = rec;
+			}
 		}
 	}
 	bits = wave_get(wave_incl_scan(bits), ENT_LANES - 1);
@@ -278,14 +298,21 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_scan(const EntBandJob *band
 		int chunk_last;
 		int prev = block_excl_max(mine, s_scan, &chunk_last);
 		if (prev < carry_prev) prev = carry_prev;
-		int prevs[ENT_SCAN_PER]; uint32_t bits[ENT_SCAN_PER];
+		int prevs[ENT_SCAN_PER]; uint32_t bits[ENT_SCAN_PER], rcode[ENT_SCAN_PER], rsize[ENT_SCAN_PER], rbits[ENT_SCAN_PER];
 #pragma unroll
 		for (int k = 0; k < ENT_SCAN_PER; k++) { prevs[k] = prev; prev = s[k].last_nz > prev ? s[k].last_nz : prev; }
 		uint32_t total = 0;
 #pragma unroll
 		for (int k = 0; k < ENT_SCAN_PER; k++) {
 			bits[k] = s[k].bits;
-			if (s[k].first_nz >= 0) bits[k] += run_bits_any(T, (uint32_t)(s[k].first_nz - prevs[k] - 1));
+			rcode[k] = 0u; rsize[k] = 0u; rbits[k] = 0u;
+			if (s[k].first_nz >= 0) {
+				const uint32_t run = (uint32_t)(s[k].first_nz - prevs[k] - 1);
+				rbits[k] = run_bits_any(T, run);
+				bits[k] += rbits[k];
+				if (run > 0u && run < 3072u && T->run_count[run] == run) { rcode[k] = T->run_bits[run]; rsize[k] = T->run_size[run]; }
+				else if (run > 0u) rsize[k] = (uint32_t)ENT_RUN_COMPLEX;
+			}
 			total += bits[k];
 		}
 		int chunk_bits;
@@ -294,7 +321,7 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_scan(const EntBandJob *band
 		for (int k = 0; k < ENT_SCAN_PER; k++) {
 			if (i0 + k < job.nseg) {
 				EntSegState &o = segs[job.seg_base + i0 + k];
-				o.prev_nz = prevs[k]; o.bits = bits[k]; o.bitoff = off;
+				o.prev_nz = prevs[k]; o.bits = bits[k]; o.bitoff = off; o.run_code = rcode[k]; o.run_size = rsize[k]; o.run_bits = rbits[k];
 			}
 			off += bits[k];
 		}
@@ -437,14 +464,60 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_layout(const EntFrameJob *f
 }
 
 // =============================================================================================
+// ORs a left-aligned bit string of up to 64 bits (zero beyond its length) into a big-endian bit stream at bit position pos.  LDS: words of
+// the wave's window (host byte order, swapped on the way out); else the payload itself with global atomics.
+__device__ __forceinline__ void ent_put_string(uint32_t *s_words, uint32_t *out, bool use_lds, uint32_t first_word, uint64_t pos, uint64_t str)
+{
+	const uint32_t sh = (uint32_t)pos & 31u, w = (uint32_t)(pos >> 5);
+	const uint64_t top = str >> sh;                                     // words w, w + 1
+	const uint32_t a = (uint32_t)(top >> 32), b = (uint32_t)top, c = (uint32_t)(((uint64_t)(uint32_t)str << 32) >> sh);      // c: what the shift pushed out of the second word
+	if (use_lds) {
+		atomic_or_u32(&s_words[w - first_word], a);
+		if (b) atomic_or_u32(&s_words[w - first_word + 1], b);
+		if (c) atomic_or_u32(&s_words[w - first_word + 2], c);
+	} else {
+		atomic_or_u32(&out[w], bswap32(a));
+		if (b) atomic_or_u32(&out[w + 1], bswap32(b));
+		if (c) atomic_or_u32(&out[w + 2], bswap32(c));
+	}
+}
+
+// The run codes of `run` zeros from bit position pos on, by the whole wave: the copies of the longest composite code a run of 3072 zeros or more
+// starts with (greedy loop, encoder.c:5488-5545) are written 64 at a time, the rest by lane `owner` (one lane writing hundreds of copies one
+// after the other held its wave for > 100 us).  Wave-uniform arguments.
+__device__ __forceinline__ void ent_put_long_run(const EntTables *T, uint32_t *s_words, uint32_t *out, bool use_lds, uint32_t first_word, uint64_t pos, uint32_t run, int owner)
+{
+	const int lane = wave_lane();
+	const uint32_t cmax = T->run_count[3071], smax = T->run_size[3071], codemax = T->run_bits[3071];
+	const uint32_t nrep = run >= 3072u ? (run - 3072u) / cmax + 1u : 0u;
+	for (uint32_t i = (uint32_t)lane; i < nrep; i += ENT_LANES) ent_put_string(s_words, out, use_lds, first_word, pos + (uint64_t)i * smax, (uint64_t)codemax << (64u - smax));
+	if (lane == owner) {
+		uint32_t left = run - nrep * cmax;
+		pos += (uint64_t)nrep * smax;
+		while (left > 0u) {
+			const uint2 rc = T->run_pack[left < 3072u ? left : 3071u];
+			const uint32_t size = rc.y & 0xffu;
+			ent_put_string(s_words, out, use_lds, first_word, pos, (uint64_t)rc.x << (64u - size));
+			pos += size; left -= rc.y >> 8;
+		}
+	}
+}
+
 __global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(const EntSegJob *seg_jobs, EntBatchGeom geom, int total_segs, const EntSegState *segs, const EntBandState *band_state, const EntTables *tables,
                                                            const uint32_t *tokens)
 {
-	__shared__ uint32_t s_words_all[ENT_WAVES][ENT_LDS_WORDS + 2];
+	__shared__ uint32_t s_words_all[ENT_WAVES][ENT_LDS_WORDS + 3];
 	const int lane = wave_lane();
 	const int wave = wave_uniform((int)(threadIdx.x >> 6));
 	const int seg = wave_uniform((int)blockIdx.x * ENT_WAVES + wave);
 	if (seg >= total_segs) return;
+	// The segment's finished bit strings as k_ent_count left them (one per nonzero coefficient: run code + value code): this kernel only
+	// adds up their lengths and puts them in place -- no table is consulted for an ordinary token, so what a wave waits for is one round
+	// of independent loads (descriptor, state, strings), not a chain of them.  (Round 2 looked the codes up here: three dependent gathers
+	// behind the token load; SQ counters showed the waves parked on memory 79 % of their time.)
+	const uint32_t *seg_tok = tokens + (size_t)seg * ENT_TOK_STRIDE;
+	const uint2 *seg_str = (const uint2 *)(seg_tok + ENT_SEG);
+	const uint2 first_rec = seg_str[lane];                 // (issued before anything is known about the segment: at worst 512 bytes read for nothing)
 	const EntSegJob job = ent_seg_job(seg_jobs, geom, seg);
 	const EntTables *T = tables + job.table;
 	const EntSegState st = segs[seg];
@@ -452,81 +525,48 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(const EntSegJob *seg_j
 	uint32_t *out = (uint32_t *)band_state[job.band].out;
 	if (!out) return;                                    // the sample overflowed its buffer (k_ent_layout reported size 0)
 	uint32_t *s_words = s_words_all[wave];
-	// 1. the segment's token list as k_ent_count left it (the picture is sparse, about one coefficient in eight is nonzero: from here on
-	//    the work is spread evenly over the lanes, one token per lane and round)
-	const uint32_t *seg_tok = tokens + (size_t)seg * ENT_SEG;
 	const int ntok = (int)st.ntok;
 	const uint64_t seg_pos = st.bitoff;                  // bit position of the segment inside the band payload
 	const uint32_t first_word = (uint32_t)(seg_pos >> 5), last_word = (uint32_t)((seg_pos + st.bits - 1) >> 5);
 	const uint32_t nwords = last_word - first_word + 1;
 	const bool use_lds = nwords <= ENT_LDS_WORDS;        // wave-uniform
-	if (use_lds) for (int i = lane; i < (int)nwords + 1; i += ENT_LANES) s_words[i] = 0;
+	if (use_lds) for (int i = lane; i < (int)nwords + 2; i += ENT_LANES) s_words[i] = 0;
 	CFHD_WAVE_SYNC();
-	// 2. one token per lane and round: zero run in front (distance to the previous token; the segment's first token reaches back
-	//    to the last nonzero of the earlier segments), table lookups back to back, bit position by a wave scan, code words OR-ed
-	//    into the wave's LDS window
-	uint64_t round_pos = seg_pos;
-	uint32_t carry_tok = 0;                              // last token of the previous round
-	{
+	// 1. the run in front of the first token (it reaches back to the last nonzero of the earlier segments; k_ent_scan left its code)
+	if (st.run_size == (uint32_t)ENT_RUN_COMPLEX) ent_put_long_run(T, s_words, out, use_lds, first_word, seg_pos, (uint32_t)(job.first + (int)(seg_tok[0] >> 16) - st.prev_nz - 1), 0);
+	else if (st.run_size && lane == 0) ent_put_string(s_words, out, use_lds, first_word, seg_pos, (uint64_t)st.run_code << (64u - st.run_size));
+	// 2. one token per lane and round: bit position by a wave scan over the lengths, the string OR-ed into the wave's LDS window
+	uint64_t round_pos = seg_pos + st.run_bits;
 	for (int t = lane, t0 = 0; t0 < ntok; t0 += ENT_LANES, t += ENT_LANES) {
 		const bool have = t < ntok;
-		const uint32_t tok = have ? seg_tok[t] : 0u;
-		uint32_t before = __shfl_up(tok, 1u);
-		if (lane == 0) before = carry_tok;
-		carry_tok = wave_get(tok, ENT_LANES - 1);
-		const int lp = (int)(tok >> 16);
-		uint32_t run = t > 0 ? (uint32_t)(lp - (int)(before >> 16) - 1) : (uint32_t)(job.first + lp - st.prev_nz - 1);
-		if (!have) run = 0;
-		const uint32_t r = run < 3072u ? run : 3071u;
-		const uint32_t ve = value_entry(T, (int)(int16_t)(tok & 0xffffu));
-		const uint32_t rt = T->run_total[r];
-		uint2 rc = T->run_pack[r];
-		uint32_t bits = 0;
-		if (have) bits = (run < 3072u ? rt : run_bits_any(T, run)) + (ve >> 27);
-		const uint32_t sc = wave_incl_scan(bits);
-		uint64_t pos = round_pos + (sc - bits);
+		uint2 rec = t0 == 0 ? first_rec : seg_str[have ? t : 0];
+		if (!have) { rec.x = 0u; rec.y = 0u; }
+		uint32_t len = rec.x & 63u;
+		const bool complex = len == (uint32_t)ENT_CODE_COMPLEX;
+		uint32_t run = 0, ve = 0;
+		if (__ballot(complex)) {
+			// rare: a run inside the segment that one composite code does not cover -- this lane walks the tables for its token
+			if (complex) {
+				const uint32_t tok = seg_tok[t], before = seg_tok[t - 1];      // (t > 0: the first token's run is k_ent_scan's)
+				run = (tok >> 16) - (before >> 16) - 1u;
+				ve = value_entry(T, (int)(int16_t)(tok & 0xffffu));
+				len = (uint32_t)T->run_total[run] + (ve >> 27);
+			}
+		}
+		const uint32_t sc = wave_incl_scan(len);
+		uint64_t pos = round_pos + (sc - len);
 		round_pos += wave_get(sc, ENT_LANES - 1);
-		// A run of 3072 zeros or more (the first token behind a flat stretch: up to the whole band) starts with nrep copies of the
-		// longest composite code (greedy loop, encoder.c:5488-5545).  One lane writing hundreds of them one after the other held
-		// its wave for > 100 us: the wave writes them together, 64 copies per step, and the lane goes on with the remainder.
-		uint32_t left = run;
-		{
-			const uint32_t cmax = T->run_count[3071], smax = T->run_size[3071], codemax = T->run_bits[3071];
-			const uint32_t nrep = (have && run >= 3072u) ? (run - 3072u) / cmax + 1u : 0u;
-			unsigned long long todo = __ballot(nrep != 0u);
-			while (todo) {                                   // wave-uniform
-				const int src = __builtin_ctzll(todo);
-				todo &= todo - 1;
-				const uint32_t n = __shfl(nrep, src);
-				const uint32_t p_lo = __shfl((uint32_t)pos, src), p_hi = __shfl((uint32_t)(pos >> 32), src);
-				const uint64_t p0 = ((uint64_t)p_hi << 32) | p_lo;
-				for (uint32_t i = (uint32_t)lane; i < n; i += ENT_LANES) {
-					const uint64_t p = p0 + (uint64_t)i * smax;
-					const uint64_t val = (uint64_t)codemax << (64 - (int)smax - (int)(p & 31));
-					const uint32_t hi = (uint32_t)(val >> 32), lo = (uint32_t)val;
-					const uint32_t w = (uint32_t)(p >> 5);
-					if (use_lds) { atomic_or_u32(&s_words[w - first_word], hi); if (lo) atomic_or_u32(&s_words[w - first_word + 1], lo); }
-					else { atomic_or_u32(&out[w], bswap32(hi)); if (lo) atomic_or_u32(&out[w + 1], bswap32(lo)); }
-				}
+		if (have && !complex) ent_put_string(s_words, out, use_lds, first_word, pos, ((uint64_t)rec.y << 32) | (rec.x & ~63u));
+		if (complex) {
+			uint32_t left = run;
+			while (left > 0u) {
+				const uint2 rc = T->run_pack[left];
+				const uint32_t size = rc.y & 0xffu;
+				ent_put_string(s_words, out, use_lds, first_word, pos, (uint64_t)rc.x << (64u - size));
+				pos += size; left -= rc.y >> 8;
 			}
-			if (nrep) { left -= nrep * cmax; pos += (uint64_t)nrep * smax; rc = T->run_pack[left < 3072u ? left : 3071u]; }
+			ent_put_string(s_words, out, use_lds, first_word, pos, (uint64_t)(ve & 0x7FFFFFFu) << (64u - (ve >> 27)));
 		}
-		if (have) {
-			for (bool last = false; !last;) {
-				uint32_t code; int size;
-				if (left > 0) {
-					code = rc.x; size = (int)(rc.y & 0xffu); left -= rc.y >> 8;
-					if (left > 0) rc = T->run_pack[left < 3072u ? left : 3071u];
-				} else { code = ve & 0x7FFFFFFu; size = (int)(ve >> 27); last = true; }
-				const uint64_t val = (uint64_t)code << (64 - size - (int)(pos & 31));
-				const uint32_t hi = (uint32_t)(val >> 32), lo = (uint32_t)val;
-				const uint32_t w = (uint32_t)(pos >> 5);
-				if (use_lds) { atomic_or_u32(&s_words[w - first_word], hi); if (lo) atomic_or_u32(&s_words[w - first_word + 1], lo); }
-				else { atomic_or_u32(&out[w], bswap32(hi)); if (lo) atomic_or_u32(&out[w + 1], bswap32(lo)); }
-				pos += size;
-			}
-		}
-	}
 	}
 	CFHD_WAVE_SYNC();
 	if (use_lds) {

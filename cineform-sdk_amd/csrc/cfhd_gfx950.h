@@ -63,6 +63,9 @@ __device__ __forceinline__ uint32_t pk_to8(uint32_t v, int shift, uint32_t dithe
 	return __builtin_bit_cast(uint32_t, x);
 }
 __device__ __forceinline__ uint32_t byte_perm(uint32_t s0, uint32_t s1, uint32_t sel) { return __builtin_amdgcn_perm(s0, s1, sel); }
+// product of the low 24 bits (v_mul_u32_u24, full rate; the compiler turns a plain 32-bit multiply whose low half alone is used into the
+// quarter-rate v_mul_lo_u32): the low 16 bits equal those of the full product, which is all the 16-bit coefficient arithmetic keeps
+__device__ __forceinline__ uint32_t mul_u24(uint32_t a, uint32_t b) { uint32_t r; asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
 // ---- loads through the global address space (global_load_dword): a flat load would tick lgkmcnt as well and every LDS access in
 // between would drain the loads in flight

@@ -39,6 +39,7 @@ inline uint32_t pk_addw(uint32_t a, uint32_t b) { using namespace emu16; return 
 inline uint32_t pk_negw(uint32_t a) { using namespace emu16; return pack(-lo(a), -hi(a)); }
 inline uint32_t pk_maxs(uint32_t a, uint32_t b) { using namespace emu16; return pack(lo(a) > lo(b) ? lo(a) : lo(b), hi(a) > hi(b) ? hi(a) : hi(b)); }
 inline uint32_t pk_to8(uint32_t v, int shift, uint32_t dither) { using namespace emu16; return to8(lo(v), shift, (int)(dither & 1u)) | (to8(hi(v), shift, (int)((dither >> 16) & 1u)) << 16); }
+inline uint32_t mul_u24(uint32_t a, uint32_t b) { return (a & 0xffffffu) * (b & 0xffffffu); }
 inline uint32_t byte_perm(uint32_t s0, uint32_t s1, uint32_t sel)
 {
 	const uint64_t src = ((uint64_t)s0 << 32) | s1;

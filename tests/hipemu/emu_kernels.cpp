@@ -427,7 +427,7 @@ extern "C" long emu_entropy_encode2(int width, int height, int pixel_kind, int q
 	std::vector<dev::EntBandState> bstate(jobs.bands.size());
 	const int nseg = (int)jobs.segjobs.size(), nb = (int)jobs.bands.size();
 	const dev::EntBatchGeom geom = { nseg, nb, 0 };
-	std::vector<uint32_t> tokens((size_t)nseg * dev::ENT_SEG, 0xdeadbeefu);       // k_ent_count's token lists for k_ent_emit
+	std::vector<uint32_t> tokens((size_t)nseg * dev::ENT_TOK_STRIDE, 0xdeadbeefu);       // k_ent_count's token lists for k_ent_emit
 	hipemu::launch(dim3((nseg + dev::ENT_WAVES - 1) / dev::ENT_WAVES), dim3(dev::ENT_THREADS), [&] { dev::k_ent_count(jobs.segjobs.data(), geom, nseg, segs.data(), tables, &peak_flag, tokens.data()); });
 	hipemu::launch(dim3(nb), dim3(dev::ENT_THREADS), [&] { dev::k_ent_scan(jobs.bands.data(), segs.data(), bstate.data(), tables); });
 	hipemu::launch(dim3(1, 3), dim3(dev::ENT_THREADS), [&] { dev::k_ent_layout(&fj, jobs.bands.data(), segs.data(), bstate.data(), tables); });

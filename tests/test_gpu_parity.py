@@ -353,10 +353,10 @@ def test_rg48_round_trip_and_format_gates():
     # the CPU twin of the GPU path gives the same words
     plan = Plan(w, h, pixkind=PIXKIND["RG48"], enc=3)
     assert np.array_equal(oracle_inverse_rgb48(plan, host_decode_pyramid(sample, plan))[:h].reshape(h, w, 3), dec)
-    # gates: RG48 only with the RGB 4:4:4 encoded format, RGB samples only to RG48
+    # gates: RG48 to RGB 4:4:4 or YUV 4:2:2 (not 4:4:4:4 or Bayer), RGB samples only to RGB output formats
     L = product()
     enc = ctypes.c_void_p(); assert L.CFHD_OpenEncoder(ctypes.byref(enc), None) == 0
-    assert L.CFHD_PrepareToEncode(enc, w, h, PIX_RG48, ENCODED_YUV422, 0, QUALITY_FILMSCAN1) == 3        # CFHD_ERROR_BADFORMAT
+    assert L.CFHD_PrepareToEncode(enc, w, h, PIX_RG48, ENCODED_RGBA4444, 0, QUALITY_FILMSCAN1) == 3        # CFHD_ERROR_BADFORMAT
     assert L.CFHD_PrepareToEncode(enc, w, h, PIX_YUY2, ENCODED_RGB444, 0, QUALITY_FILMSCAN1) == 3
     L.CFHD_CloseEncoder(enc)
     dec_ref = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec_ref), None) == 0

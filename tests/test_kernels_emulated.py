@@ -295,8 +295,9 @@ def test_gpu_entropy_stage_emulated_extreme_bands():
     plan = Plan(w, h)
     rng = np.random.default_rng(5)
     meta = b"GUID\x10\x00\x00G" + bytes(16)
-    for mode in ("zero", "sparse", "lonely", "dense", "huge"):
+    for mode in ("zero", "sparse", "lonely", "dense", "huge", "ladder"):
         coeffs = np.zeros(plan.coeff_elems, dtype=np.int16)
+        first_gap = 0
         for c in range(3):
             plan.view(coeffs, c, 2, 0)[:, : plan.band[(c, 2, 0)]["width"]] = rng.integers(0, 16000, size=(plan.band[(c, 2, 0)]["height"], plan.band[(c, 2, 0)]["width"]))
             for lv in range(3):
@@ -306,6 +307,14 @@ def test_gpu_entropy_stage_emulated_extreme_bands():
                     elif mode == "lonely": v[-1, -1] = -7; v[d["height"] // 2, 3] = 2         # runs of several thousand zeros in front of a token: many copies of the longest run code
                     elif mode == "dense": v[:] = rng.integers(1, 40, size=v.shape) * rng.choice([-1, 1], size=v.shape)
                     elif mode == "huge": v[:] = rng.choice([0, 0, 0, 5000, -5000, 1023, -1024, 1], size=v.shape)
+                    elif mode == "ladder":
+                        # zero runs of every length from 0 to beyond a segment, one after the other (band by band): every composite run code, and
+                        # the runs one code does not cover (the bit strings k_ent_count marks for k_ent_emit's table walk)
+                        flat = np.zeros(v.size, dtype=np.int16); at = 0; gap = first_gap
+                        while at + gap < flat.size:
+                            at += gap; flat[at] = 1 + gap % 7; at += 1; gap += 1
+                        v[:] = flat.reshape(v.shape)                       # (runs continue through the zero pad columns: the effective lengths shift a little)
+                        first_gap = gap if gap < 1200 else 0
         want = product_write_sample_host(plan, coeffs, 1, meta_global=meta)
         got = _emu_entropy(plan, coeffs, 1, meta)
         assert got == want, mode
