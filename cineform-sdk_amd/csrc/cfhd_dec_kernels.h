@@ -212,69 +212,91 @@ __device__ __forceinline__ uint32_t dx_off_clear_from(uint32_t offs, int k) { co
 // one four times over.
 // A walk may start in front of the lane (a lead-in through the neighbour's last bits, to fall in step before the lane begins): counting starts
 // with the first code word inside the lane, whose position is returned in L.start.
-__device__ __forceinline__ uint32_t dx_low_pieces(int n) { return n >= 4 ? 0xffffffffu : (1u << (8 * n)) - 1u; }      // the offset bytes of pieces 0 .. n-1
+// The steps of a walk up to a mark: one table lookup per step -- the first code word, or as many whole code words as fit the 12-bit window without
+// passing `lim` -- until the position reaches lim.  This is the loop the kernel lives in; everything that happens once per 64-bit piece (records,
+// the merge test) is outside it.  COUNT: add up the coefficients the code words cover.  Returns false when the walk met the band end marker or a
+// broken code (endv says which).
+template <bool COUNT>
+__device__ __forceinline__ bool dx_steps(DxBitsAhead &B, uint32_t &pos, uint32_t &cnt, const uint32_t lim, uint32_t &endv, const uint32_t *s_words, const uint32_t *s_tab, const uint32_t *s_long)
+{
+	bool ok = true;
+	bool go = pos < lim;
+	while (go) {
+		const uint32_t win = B.window();
+		const uint32_t t = s_tab[win >> (32 - DX_K)];
+		const uint32_t ahead = B.prefetch(s_words);
+		const uint32_t used = (t >> 4) & 15u;
+		uint32_t adv = t & 15u, add = (t >> 8) & 0xfffu;      // the first code word ...
+		const bool all = adv != 0u && used != 0u && pos + used <= lim;
+		adv = all ? used : adv; add = all ? t >> 20 : add;      // ... or several whole ones, none of them beyond the mark
+		if (adv == 0u) {
+			const DxSym sy = dx_long_symbol(t >> 16, s_long, win);
+			const bool isrun = sy.type == DX_T_RUN, isval = sy.type == DX_T_VALUE;
+			adv = isrun ? (uint32_t)sy.len : (isval ? (uint32_t)sy.len + 1u : 0u);
+			add = isrun ? (uint32_t)sy.payload : (isval ? 1u : 0u);
+			if (!isrun && !isval) { endv = sy.type == DX_T_END ? (uint32_t)DX_END : (uint32_t)DX_BAD; ok = false; }
+		}
+		pos += adv;
+		if (COUNT) cnt += add;
+		B.skip((int)adv, ahead);
+		go = ok && pos < lim;
+	}
+	return ok;
+}
+
+// Walks the code words of one lane from bit `pos` to the end of the lane's range.  merge: stop as soon as the walk enters a 64-bit piece at the
+// offset recorded by the previous walk -- from there on the two chains are the same, only the counts in front shift.
+// A walk may start in front of the lane (a lead-in through the neighbour's last bits, to fall in step before the lane begins): counting starts
+// with the first code word inside the lane, whose position is returned in L.start.
+// Round 2 ran this as ONE flat loop with the per-piece bookkeeping inside (so that no lane waits at a piece boundary for the slowest one): about
+// 100 instructions per step, most of them bookkeeping of the execution mask.  Piece by piece the steps are a loop of about 30 (dx_steps); the
+// lanes of a wave wait for each other five times per walk instead of once, which costs far less than it saves.
 __device__ __forceinline__ void dx_walk(DxLane &L, uint32_t pos, const bool merge, const uint32_t lane_base, const uint32_t limit, const uint32_t *s_words, const uint32_t *s_tab,
                                         const uint32_t *s_long)
 {
-	// Written as one loop with one way out and plain selects inside: with `break`s at three depths the compiler spent a third of the loop on
-	// copies of the state and on bookkeeping of the execution mask.
 	uint32_t cnt = 0, start = pos, endv = pos;
 	uint32_t offs = merge ? L.rec_offs : (uint32_t)DX_OFFS_NONE;
-	uint32_t rc0 = L.rec_cnt[0], rc1 = L.rec_cnt[1], rc2 = L.rec_cnt[2], rc3 = L.rec_cnt[3];
+	uint32_t rc[DX_SUBS] = { L.rec_cnt[0], L.rec_cnt[1], L.rec_cnt[2], L.rec_cnt[3] };
 	const uint32_t lane_end = lane_base + DX_LANE_BITS;
 	const uint32_t stop = lane_end < limit ? lane_end : limit;
-	uint32_t next = lane_base;                            // first bit of the piece the walk has not entered yet
 	int piece = -1, merged_at = 0;
-	bool alive = true, clear = false, merged = false;
+	bool done = false, clear = false, merged = false;
 	DxBitsAhead B;
 	B.seek(s_words, pos);
-	do {
-		if (pos >= stop) {                                // the end of the lane, or of the payload in front of it
-			endv = pos; clear = pos < lane_end; alive = false;
-		} else {
-			bool go = true;
-			if (pos >= next) {
-				// the walk enters a new piece (a code word is shorter than a piece: none is skipped, except in front of a late start)
-				const uint32_t rel = pos - lane_base, off = rel & (DX_SUB_BITS - 1u);
-				const int k = (int)(rel / DX_SUB_BITS);
-				const bool first = piece < 0;                 // the first code word of the lane
-				cnt = first ? 0u : cnt; start = first ? pos : start;
-				const uint32_t skipped = dx_low_pieces(k) & ~dx_low_pieces(piece + 1);
-				offs = (offs & ~skipped) | ((uint32_t)DX_OFFS_NONE & skipped);
+	// the approach through the bits in front of the lane (a lead-in): nothing is counted
+	{
+		const uint32_t lim = lane_base < stop ? lane_base : stop;
+		if (!dx_steps<false>(B, pos, cnt, lim, endv, s_words, s_tab, s_long)) { clear = true; done = true; }
+	}
+#pragma unroll
+	for (int k = 0; k < DX_SUBS; k++) {
+		const uint32_t mark_lo = lane_base + (uint32_t)k * DX_SUB_BITS, mark = mark_lo + DX_SUB_BITS;
+		if (!done) {
+			if (pos >= stop) {                                // the end of the lane, or of the payload in front of it
+				endv = pos; clear = pos < lane_end; done = true;
+			} else if (pos < mark) {
+				// a code word starts in piece k
+				const uint32_t off = pos - mark_lo;
+				if (piece < 0) { cnt = 0u; start = pos; }     // the first code word of the lane
 				if (merge && k > 0 && dx_off_get(offs, k) == off) {
-					merged = true; merged_at = k; alive = false; go = false;     // same chain from here on
+					merged = true; merged_at = k; done = true;    // same chain from here on
 				} else {
-					offs = dx_off_set(offs, k, off);
-					rc0 = k == 0 ? cnt : rc0; rc1 = k == 1 ? cnt : rc1; rc2 = k == 2 ? cnt : rc2; rc3 = k == 3 ? cnt : rc3;
-					piece = k; next = lane_base + (uint32_t)(k + 1) * DX_SUB_BITS;
+					offs = dx_off_set(offs, k, off); rc[k] = cnt; piece = k;
+					const uint32_t lim = mark < stop ? mark : stop;
+					if (!dx_steps<true>(B, pos, cnt, lim, endv, s_words, s_tab, s_long)) { clear = true; done = true; }
 				}
-			}
-			if (go) {
-				const uint32_t win = B.window();
-				const uint32_t t = s_tab[win >> (32 - DX_K)];
-				const uint32_t ahead = B.prefetch(s_words);
-				const uint32_t used = (t >> 4) & 15u;
-				uint32_t adv = t & 15u, add = (t >> 8) & 0xfffu;      // the first code word ...
-				const bool all = adv != 0u && used != 0u && pos + used <= next;
-				adv = all ? used : adv; add = all ? t >> 20 : add;      // ... or several whole ones, none of them beyond the mark
-				if (adv == 0u) {
-					const DxSym sy = dx_long_symbol(t >> 16, s_long, win);
-					if (sy.type == DX_T_RUN) { adv = (uint32_t)sy.len; add = (uint32_t)sy.payload; }
-					else if (sy.type == DX_T_VALUE) { adv = (uint32_t)sy.len + 1u; add = 1u; }
-					else { endv = sy.type == DX_T_END ? (uint32_t)DX_END : (uint32_t)DX_BAD; clear = true; alive = false; go = false; }
-				}
-				if (go) { pos += adv; cnt += add; B.skip((int)adv, ahead); }
-			}
+			} else offs = dx_off_set(offs, k, (uint32_t)DX_OFF_INVALID);      // a late start: no code word of this walk begins in piece k
 		}
-	} while (alive);
+	}
+	if (!done) { endv = pos; clear = pos < lane_end; }     // through all four pieces
 	if (merged) {
 		// the counts recorded behind the mark where the chains met move by the difference in front of it; L.end stays
 		const int k = merged_at;
 		const uint32_t old = k == 1 ? L.rec_cnt[1] : (k == 2 ? L.rec_cnt[2] : L.rec_cnt[3]);
 		const uint32_t delta = cnt - old;
-		L.rec_cnt[0] = rc0;
-		L.rec_cnt[1] = k <= 1 ? (dx_off_get(offs, 1) != (uint32_t)DX_OFF_INVALID ? L.rec_cnt[1] + delta : L.rec_cnt[1]) : rc1;
-		L.rec_cnt[2] = k <= 2 ? (dx_off_get(offs, 2) != (uint32_t)DX_OFF_INVALID ? L.rec_cnt[2] + delta : L.rec_cnt[2]) : rc2;
+		L.rec_cnt[0] = rc[0];
+		L.rec_cnt[1] = k <= 1 ? (dx_off_get(offs, 1) != (uint32_t)DX_OFF_INVALID ? L.rec_cnt[1] + delta : L.rec_cnt[1]) : rc[1];
+		L.rec_cnt[2] = k <= 2 ? (dx_off_get(offs, 2) != (uint32_t)DX_OFF_INVALID ? L.rec_cnt[2] + delta : L.rec_cnt[2]) : rc[2];
 		L.rec_cnt[3] = dx_off_get(offs, 3) != (uint32_t)DX_OFF_INVALID ? L.rec_cnt[3] + delta : L.rec_cnt[3];
 		L.cnt += delta;
 		L.rec_offs = offs;
@@ -282,7 +304,7 @@ __device__ __forceinline__ void dx_walk(DxLane &L, uint32_t pos, const bool merg
 		return;
 	}
 	if (clear) offs = dx_off_clear_from(offs, piece + 1);
-	L.rec_cnt[0] = rc0; L.rec_cnt[1] = rc1; L.rec_cnt[2] = rc2; L.rec_cnt[3] = rc3;
+	L.rec_cnt[0] = rc[0]; L.rec_cnt[1] = rc[1]; L.rec_cnt[2] = rc[2]; L.rec_cnt[3] = rc[3];
 	L.start = start; L.end = endv;
 	L.rec_offs = offs;
 	L.cnt = cnt;

@@ -115,7 +115,7 @@ int GpuEntropyEncoder::launch()
 	                                                  (dev::EntBandState *)d_bandstate_, T);
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[3], st));
 	dev::k_ent_emit<<<(total_segs + dev::ENT_WAVES - 1) / dev::ENT_WAVES, dev::ENT_THREADS, 0, st>>>((const dev::EntSegJob *)d_segband_, geom, total_segs, (const dev::EntSegState *)d_segs_,
-	                                                          (const dev::EntBandState *)d_bandstate_, T, (const uint32_t *)d_tokens_);
+	                                                          (const dev::EntBandState *)d_bandstate_, T, (const uint32_t *)d_tokens_, []{ const char *e = getenv("CFHD_AMD_EMIT_PROBE"); return e ? atoi(e) : 0; }());
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[4], st));
 	timed_ = true;

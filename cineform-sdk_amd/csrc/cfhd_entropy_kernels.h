@@ -77,6 +77,10 @@ struct EntSegState {               // per segment, written by k_ent_count / k_en
 	uint32_t ntok;                 // k_ent_count: nonzero coefficients of the segment = entries of its token list
 	uint32_t run_code, run_size;   // k_ent_scan: the run code in front of the segment's first token (reaches back into earlier segments) when one code covers it; run_size ENT_RUN_COMPLEX otherwise
 	uint32_t run_bits;             // k_ent_scan: bits of all the run codes in front of the first token
+	// The first bits of the segment's code words (left aligned) and how many of them are known (up to 32): k_ent_count leaves those of its
+	// token strings, k_ent_scan puts the first run's code in front.  The segment in FRONT writes the payload word the two share, with these
+	// bits merged in, as a plain store: no atomic on the payload for ordinary segments (ent_neighbours_merge()).
+	uint32_t lead32, lead_valid;
 };
 
 struct EntBandState { uint32_t seg_bits, tail_run, payload_bytes, base_byte; uint8_t *out; /* payload address in the sample; null until k_ent_layout placed it */ };
@@ -225,7 +229,7 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_count(const EntSegJob *seg_
 	for (int k = 0; k < ENT_PER_THREAD; k++) cnt += v[k] != 0;
 	const int incl = (int)wave_incl_scan((uint32_t)cnt);
 	const int ntok = (int)wave_get((uint32_t)incl, ENT_LANES - 1);
-	uint32_t bits = 0, carry_tok = 0;
+	uint32_t bits = 0, carry_tok = 0, lead32 = 0, lead_valid = 0;
 	for (int lo = 0; lo < ntok; lo += ENT_TOK_CAP) {     // wave-uniform: one pass unless the segment is unusually dense
 		if (lo) { carry_tok = s_tok[ENT_TOK_CAP - 1]; CFHD_WAVE_SYNC(); }
 		{
@@ -247,6 +251,7 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_count(const EntSegJob *seg_
 			const uint32_t ve = value_entry(T, (int)(int16_t)(tok & 0xffffu));
 			const uint32_t rt = T->run_total[run];
 			const uint2 rp = T->run_pack[run];
+			uint32_t my_top = 0, my_len = 0;
 			if (have) {
 				bits += rt + (ve >> 27);
 				uint32_t *seg_out = tokens + (size_t)seg * ENT_TOK_STRIDE;
@@ -260,6 +265,20 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_count(const EntSegJob *seg_
 				const uint32_t len = simple ? rs + vs : (uint32_t)ENT_CODE_COMPLEX;
 				uint2 rec; rec.x = (uint32_t)str | len; rec.y = (uint32_t)(str >> 32);
 				((uint2 *)(seg_out + ENT_SEG))[t] = rec;
+				my_top = rec.y; my_len = len;
+			}
+			if (t0 == 0 && lo == 0) {
+				// the first 32 bits of the strings of this round, as far as they are plain strings (up to the first token that needs the table walk)
+				const unsigned long long cx = __ballot(have && my_len == (uint32_t)ENT_CODE_COMPLEX);
+				const uint32_t l = (have && my_len != (uint32_t)ENT_CODE_COMPLEX) ? my_len : 0u;
+				const uint32_t sc = wave_incl_scan(l), ex = sc - l;
+				const int stop_lane = cx ? __builtin_ctzll(cx) : (hi < ENT_LANES ? hi : ENT_LANES);      // strings of lanes 0 .. stop_lane-1 count
+				uint32_t part = (lane < stop_lane && ex < 32u) ? my_top >> ex : 0u;
+#pragma unroll
+				for (int d = 1; d < ENT_LANES; d <<= 1) part |= __shfl_xor(part, d);
+				lead32 = part;
+				const uint32_t known = stop_lane > 0 ? wave_get(sc, stop_lane - 1) : 0u;
+				lead_valid = known < 32u ? known : 32u;
 			}
 		}
 	}
@@ -271,6 +290,7 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_count(const EntSegJob *seg_
 		s.last_nz = mask ? last_nz : -1;
 		s.bits = bits;
 		s.ntok = (uint32_t)ntok;
+		s.lead32 = lead32; s.lead_valid = lead_valid;
 	}
 }
 
@@ -289,7 +309,7 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_scan(const EntBandJob *band
 		EntSegState s[ENT_SCAN_PER];
 #pragma unroll
 		for (int k = 0; k < ENT_SCAN_PER; k++) {
-			s[k].first_nz = -1; s[k].last_nz = -1; s[k].bits = 0;
+			s[k].first_nz = -1; s[k].last_nz = -1; s[k].bits = 0; s[k].lead32 = 0; s[k].lead_valid = 0;
 			if (i0 + k < job.nseg) s[k] = segs[job.seg_base + i0 + k];
 		}
 		int mine = -1;
@@ -312,6 +332,13 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_scan(const EntBandJob *band
 				bits[k] += rbits[k];
 				if (run > 0u && run < 3072u && T->run_count[run] == run) { rcode[k] = T->run_bits[run]; rsize[k] = T->run_size[run]; }
 				else if (run > 0u) rsize[k] = (uint32_t)ENT_RUN_COMPLEX;
+				// the segment's first bits: the run code in front of what k_ent_count collected
+				const uint32_t rs = rsize[k];
+				if (rs == (uint32_t)ENT_RUN_COMPLEX) { s[k].lead32 = 0u; s[k].lead_valid = 0u; }
+				else if (rs) {
+					s[k].lead32 = (rcode[k] << (32u - rs)) | (s[k].lead32 >> rs);
+					s[k].lead_valid = s[k].lead_valid + rs < 32u ? s[k].lead_valid + rs : 32u;
+				}
 			}
 			total += bits[k];
 		}
@@ -321,7 +348,7 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_scan(const EntBandJob *band
 		for (int k = 0; k < ENT_SCAN_PER; k++) {
 			if (i0 + k < job.nseg) {
 				EntSegState &o = segs[job.seg_base + i0 + k];
-				o.prev_nz = prevs[k]; o.bits = bits[k]; o.bitoff = off; o.run_code = rcode[k]; o.run_size = rsize[k]; o.run_bits = rbits[k];
+				o.prev_nz = prevs[k]; o.bits = bits[k]; o.bitoff = off; o.run_code = rcode[k]; o.run_size = rsize[k]; o.run_bits = rbits[k]; o.lead32 = s[k].lead32; o.lead_valid = s[k].lead_valid;
 			}
 			off += bits[k];
 		}
@@ -503,10 +530,26 @@ __device__ __forceinline__ void ent_put_long_run(const EntTables *T, uint32_t *s
 	}
 }
 
+// Two consecutive segments a, b of one band share the payload word in which a ends and b begins (unless b begins on a word boundary).  When
+// both are ordinary -- at least 32 bits each, so that nobody else touches that word, and short enough for the LDS window -- and b's first bits
+// are known, a stores the word whole with b's bits merged in and b leaves it alone; otherwise both OR their part into the zeroed payload with
+// atomics.  Both waves evaluate this on the same numbers.  (Atomics on payload lines that other waves fill with plain partial stores cost
+// k_ent_emit 0.8 of its 2.0 ms in round 2: profiles/r03_*.)
+__device__ __forceinline__ bool ent_ordinary(const EntSegState &st)
+{
+	return st.bits >= 32u && (uint32_t)((st.bitoff + st.bits - 1u) >> 5) - (uint32_t)(st.bitoff >> 5) + 1u <= (uint32_t)ENT_LDS_WORDS;
+}
+__device__ __forceinline__ bool ent_neighbours_merge(const EntSegState &a, const EntSegState &b)
+{
+	const uint32_t o = b.bitoff & 31u;
+	return o != 0u && ent_ordinary(a) && ent_ordinary(b) && b.lead_valid >= 32u - o;
+}
+
 __global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(const EntSegJob *seg_jobs, EntBatchGeom geom, int total_segs, const EntSegState *segs, const EntBandState *band_state, const EntTables *tables,
-                                                           const uint32_t *tokens)
+                                                           const uint32_t *tokens, int probe = 0 /* timing experiments: 1 leave at once, 2 behind the descriptor loads, 3 without the final stores, 4 plain stores for the shared words, 5 no plain stores */)
 {
 	__shared__ uint32_t s_words_all[ENT_WAVES][ENT_LDS_WORDS + 3];
+	if (probe == 1) return;
 	const int lane = wave_lane();
 	const int wave = wave_uniform((int)(threadIdx.x >> 6));
 	const int seg = wave_uniform((int)blockIdx.x * ENT_WAVES + wave);
@@ -522,8 +565,15 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(const EntSegJob *seg_j
 	const EntTables *T = tables + job.table;
 	const EntSegState st = segs[seg];
 	if (st.bits == 0) return;                            // wave-uniform: nothing starts in this segment
+	// the neighbours in the band (the segments of a band are consecutive): who writes the words shared with them
+	const bool has_prev = job.first != 0, has_next = job.first + ENT_SEG < job.n;
+	const bool prev_writes_first = has_prev && ent_neighbours_merge(segs[seg - 1], st);
+	EntSegState nx = st;
+	if (has_next) nx = segs[seg + 1];
+	const bool merge_next = has_next && ent_neighbours_merge(st, nx);
 	uint32_t *out = (uint32_t *)band_state[job.band].out;
 	if (!out) return;                                    // the sample overflowed its buffer (k_ent_layout reported size 0)
+	if (probe == 2) { if (first_rec.x == 0x12345u && lane == 0) out[0] = 1; return; }
 	uint32_t *s_words = s_words_all[wave];
 	const int ntok = (int)st.ntok;
 	const uint64_t seg_pos = st.bitoff;                  // bit position of the segment inside the band payload
@@ -569,13 +619,19 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(const EntSegJob *seg_j
 		}
 	}
 	CFHD_WAVE_SYNC();
+	if (probe == 3) { if (s_words[lane] == 0x12345u) out[0] = 1; return; }
 	if (use_lds) {
 		// interior words belong to this segment alone: plain coalesced stores; the first and last word may be shared with
 		// the neighbouring segments (or the band's trailer): OR them into the zeroed payload
+		const bool first_shared = (seg_pos & 31u) != 0u, last_shared = ((seg_pos + st.bits) & 31u) != 0u;
 		for (int i = lane; i < (int)nwords; i += ENT_LANES) {
-			const uint32_t w = bswap32(s_words[i]);
-			if (i == 0 || i == (int)nwords - 1) { if (w) atomic_or_u32(&out[first_word + i], w); }
-			else out[first_word + i] = w;
+			uint32_t w = s_words[i];
+			const bool is_first = i == 0, is_last = i == (int)nwords - 1;
+			if (is_first && prev_writes_first) continue;                       // the segment in front stores this word, our bits included
+			if (is_last && merge_next) w |= nx.lead32 >> ((seg_pos + st.bits) & 31u);      // the next segment's first bits: the word is complete
+			w = bswap32(w);
+			if (((is_first && first_shared) || (is_last && last_shared && !merge_next)) && probe != 4) { if (w) atomic_or_u32(&out[first_word + i], w); }
+			else if (probe != 5) out[first_word + i] = w;
 		}
 	}
 }

@@ -8,7 +8,7 @@ if [ -n "$KEXPR" ]; then
   ( time python -m pytest tests -m gpu -q -x -p no:cacheprovider -k "$KEXPR" ) > gpurun_out/${TAG}_tests.log 2>&1
   tail -4 gpurun_out/${TAG}_tests.log
 fi
-python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-c-abi "$@" > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
+python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-c-abi --no-other-workloads "$@" > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 python - <<PY
 import json
 try:
