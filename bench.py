@@ -131,7 +131,7 @@ def cpu_baseline(frames, pitch, W, H, seconds_budget=20.0, fmt=None, enc=0, flag
                       % (sent, enc_fps, cores, done, handles, per_handle, dec_fps, W, H, label)}
 
 
-def c_abi_rates(frames, pitch, W, H, seconds=1.5, registered=False, decoders=8, workers=16):
+def c_abi_rates(frames, pitch, W, H, seconds=1.5, registered=False, decoders=8, workers=16, all_devices=False):
     """The product through the reference's own C ABI, host buffers in and out (PCIe inclusive): what a C/C++ caller of CFHD_* sees, measured
     by a plain C++ program (tools/cabi_bench.cpp, built against include/cfhd_amd.h and the library only).
     sync: one handle, one thread; pool: CFHD_*EncoderPool with `workers` HIP-stream workers; handles: N decoders on N host threads (calls
@@ -146,8 +146,11 @@ def c_abi_rates(frames, pitch, W, H, seconds=1.5, registered=False, decoders=8, 
         for fr in frames:
             f.write(fr.reshape(H, pitch)[:, : W * 2].tobytes())
         f.flush()
+        env = dict(os.environ)
+        if all_devices:                                  # no pin: the pool's workers and the decoder handles spread over every GPU the process sees
+            env.pop("CFHD_AMD_DEVICE", None); env.pop("LOCAL_RANK", None)
         out = subprocess.run([tool, str(W), str(H), f.name, str(len(frames)), str(seconds), "1" if registered else "0", str(decoders), str(workers)],
-                             capture_output=True, text=True, timeout=300)
+                             capture_output=True, text=True, timeout=300, env=env)
     if out.returncode != 0:
         return {"error": (out.stderr or out.stdout).strip()[-300:]}
     return json.loads(out.stdout.strip().splitlines()[-1])
@@ -424,6 +427,9 @@ def main():
                                            "plain_buffers": c_abi_rates(frames[:8], pitch, W, H, decoders=8, workers=8),
                                            "plain_buffers_16_threads": c_abi_rates(frames[:8], pitch, W, H, decoders=16, workers=16),
                                            "buffers_registered_by_the_caller_16_threads": c_abi_rates(frames[:8], pitch, W, H, registered=True, decoders=16, workers=16)}
+            ngpu = torch.cuda.device_count()
+            if ngpu > 1:                                 # host-fed, one process, every GPU of the node: pool workers and decoder handles dealt round robin (strong scaling of the C ABI)
+                line["config"]["c_abi_fps"]["one_process_all_%d_gpus_plain_buffers" % ngpu] = c_abi_rates(frames[:8], pitch, W, H, decoders=4 * ngpu, workers=4 * ngpu, all_devices=True)
         if world == 1 and not args.no_cpu_baseline:
             fmt = getattr(T, "PIX_" + wl["fmt"].upper())
             line["cpu_baseline"] = cpu_baseline(frames[:8], pitch, W, H, fmt=fmt, enc=wl["enc"], flags=wl["flags"], decode=wl["mode"] == 0, bpp=wl["bpp"], label=wl["fmt"])

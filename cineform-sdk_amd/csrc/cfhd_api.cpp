@@ -233,7 +233,7 @@ template <class BatchT> struct Gatherer {
 		std::vector<void *> ptr; std::vector<int> num;      // per slot: what the pass needs from the caller (output buffer + pitch of a decode)
 		std::thread worker;
 	};
-	int slots = 8; bool ok = false, dead = false;
+	int slots = 8, device = -1; bool ok = false, dead = false;      // device: the GPU the two batches live on (-1: the process default)
 	std::mutex m; std::condition_variable cv_callers, cv_workers;
 	Pass g[2];
 	std::atomic<int> inflight{0};
@@ -248,7 +248,7 @@ template <class BatchT> struct Gatherer {
 	}
 	void run(Pass &x)
 	{
-		(void)device_init();                               // the device is selected per thread
+		(void)device_select(device);                       // the device is selected per thread
 		std::unique_lock<std::mutex> lk(m);
 		for (;;) {
 			cv_workers.wait(lk, [&] { return x.state == 0 && x.claimed > 0 && x.ready == x.claimed; });
@@ -387,6 +387,15 @@ struct Encoder {
 	StageProfile prof;
 };
 
+// ---- devices ----
+// Worker i of an encoder pool / the i-th decoder handle of the process on a node with several GPUs (cfhd_core.h unit_device): -1 = the process default.
+int device_of_unit(int i)
+{
+	const char *pinned = getenv("CFHD_AMD_DEVICE");
+	if (!pinned) pinned = getenv("LOCAL_RANK");
+	return unit_device(i, device_count(), pinned, getenv("CFHD_AMD_POOL_DEVICES"));
+}
+
 // ---- async pool ----
 struct SampleBuffer { std::vector<uint8_t> data; size_t size = 0; };
 
@@ -400,6 +409,7 @@ struct PoolJob {
 };
 
 struct PoolWorker {
+	int device = -1;                          // the GPU this worker's batch lives on (-1: the process default)
 	EncodeBatch batch;
 	EncodeParams params;                      // this worker's encoder state (quantizer feedback is per encoder: each CAsyncEncoder owns an ENCODER)
 	uint32_t encoded = 0;                     // per-"encoder" frame counter (the reference numbers frames per CAsyncEncoder)
@@ -420,7 +430,7 @@ struct EncoderPool {
 
 	void worker_loop(PoolWorker *w)
 	{
-		device_init();
+		device_select(w->device);                  // (per thread: everything this worker launches goes to its own GPU)
 		for (;;) {
 			std::shared_ptr<PoolJob> job;
 			{
@@ -451,6 +461,7 @@ struct EncoderPool {
 
 // ---- decoder ----
 struct Decoder {
+	int device = -1;                          // the GPU this handle decodes on (dealt round robin when the process owns several, -1: the process default)
 	ParsedSample header; bool prepared = false, half = false;
 	uint32_t out_format = 0; int out_kind = 0;
 	FramePlan plan;
@@ -464,10 +475,10 @@ struct DecMetadata { std::vector<uint8_t> block; size_t cursor = 0; };
 
 
 struct DecodeServiceKey {
-	int width, height, display_height, encoded_format, precision, prescale[3], out_kind; bool half, interlaced;
+	int width, height, display_height, encoded_format, precision, prescale[3], out_kind, device; bool half, interlaced;
 	bool operator==(const DecodeServiceKey &o) const
 	{
-		return width == o.width && height == o.height && display_height == o.display_height && encoded_format == o.encoded_format && precision == o.precision &&
+		return device == o.device && width == o.width && height == o.height && display_height == o.display_height && encoded_format == o.encoded_format && precision == o.precision &&
 		       prescale[0] == o.prescale[0] && prescale[1] == o.prescale[1] && prescale[2] == o.prescale[2] && out_kind == o.out_kind && half == o.half && interlaced == o.interlaced;
 	}
 };
@@ -477,6 +488,8 @@ struct DecodeService : Gatherer<DecodeBatch> {
 	{
 		slots = nslots;
 		const size_t cap = (size_t)plan.width * plan.height * pixel_bytes_of(out_kind) + 65536;
+		device = key.device;
+		struct OnDevice { OnDevice(int d) { device_select(d); } ~OnDevice() { device_select(-1); } } on(device);      // the batches are prepared on the service's GPU
 		for (Pass &x : g) {
 			x.batch.set_interlaced(interlaced);
 			if (x.batch.prepare(plan, slots, out_kind, true, half) || x.batch.prepare_entropy(cap) || !x.batch.entropy().chunk_indexed()) { for (Pass &y : g) y.batch.release(); return false; }
@@ -729,12 +742,20 @@ CFHD_Error CFHD_StartEncoderPool(CFHD_EncoderPoolRef ref)
 	p->workers.clear();
 	for (int i = 0; i < p->nworkers; i++) {
 		std::unique_ptr<PoolWorker> w(new PoolWorker);
-		if (prepare_batch(w->batch, p->params)) return ERR_INTERNAL;
+		// the workers spread over the GPUs of the node round robin (one process per GPU -- CFHD_AMD_DEVICE / LOCAL_RANK set -- keeps them all on
+		// its own); every worker owns its stream, tables and scratch on its device; delivery stays in submission order (the FIFO below)
+		w->device = device_of_unit(i);
+		device_select(w->device);
+		const int prc = prepare_batch(w->batch, p->params);
+		device_select(-1);
+		if (prc) return ERR_INTERNAL;
 		w->params = p->params;
 		p->workers.push_back(std::move(w));
 	}
 	p->service = nullptr;
-	if (encode_gather_slots() > 1 && p->nworkers > 1 && gpu_entropy_enabled() && quantizer_is_static(p->params)) {
+	bool one_device = true;
+	for (auto &w : p->workers) if (w->batch.device() != p->workers[0]->batch.device()) one_device = false;
+	if (one_device && encode_gather_slots() > 1 && p->nworkers > 1 && gpu_entropy_enabled() && quantizer_is_static(p->params)) {
 		EncodeServiceKey key; memset(&key, 0, sizeof(key));
 		key.width = p->params.width; key.height = p->params.height; key.pixel_kind = p->params.pixel_kind; key.encoded_format = p->params.encoded_format;
 		key.quality = p->params.quality; key.color_space = p->params.color_space; key.flags = p->params.flags;
@@ -841,6 +862,9 @@ CFHD_Error CFHD_OpenDecoder(CFHD_DecoderRef *out, CFHD_ALLOCATOR *)
 {
 	if (!out) return ERR_INVALID_ARGUMENT;
 	*out = new (std::nothrow) Decoder;
+	// a process that owns several GPUs deals its decoder handles over them round robin (one process per GPU keeps them on its own)
+	static std::atomic<int> handles{0};
+	if (*out) ((Decoder *)*out)->device = device_of_unit(handles.fetch_add(1));
 	return *out ? ERR_OKAY : ERR_OUTOFMEMORY;
 }
 
@@ -990,7 +1014,7 @@ CFHD_Error CFHD_DecodeSample(CFHD_DecoderRef ref, void *sample, size_t size, voi
 			DecodeServiceKey key; memset(&key, 0, sizeof(key));
 			key.width = d->plan.width; key.height = d->plan.height; key.display_height = d->plan.display_height; key.encoded_format = d->plan.encoded_format;
 			key.precision = d->plan.precision; for (int k = 0; k < 3; k++) key.prescale[k] = d->plan.prescale[k];
-			key.out_kind = d->out_kind; key.half = d->half; key.interlaced = interlaced;
+			key.out_kind = d->out_kind; key.half = d->half; key.interlaced = interlaced; key.device = d->device;
 			d->service = decode_services().find(key); d->service_interlaced = interlaced;
 		}
 		DecodeService *svc = d->service;
@@ -1022,8 +1046,11 @@ static CFHD_Error decode_on_handle(Decoder *d, const ParsedSample &ps, const uin
 	if (d->batch_ready && d->batch.interlaced() != interlaced) d->batch_ready = false;
 	if (!d->batch_ready) {
 		d->batch.set_interlaced(interlaced);
-		if (d->batch.prepare(d->plan, 1, d->out_kind, true, d->half)) return ERR_INTERNAL;
-		if (gpu_entropy_enabled() && d->batch.prepare_entropy((size_t)d->plan.width * d->plan.height * pixel_bytes_of(d->out_kind) + 65536)) return ERR_INTERNAL;
+		device_select(d->device);                      // the handle's GPU (the batch remembers it: later calls may come from any thread)
+		int prc = d->batch.prepare(d->plan, 1, d->out_kind, true, d->half);
+		if (!prc && gpu_entropy_enabled()) prc = d->batch.prepare_entropy((size_t)d->plan.width * d->plan.height * pixel_bytes_of(d->out_kind) + 65536);
+		device_select(-1);
+		if (prc) return ERR_INTERNAL;
 		d->batch_ready = true;
 	}
 	if (d->batch.has_entropy() && size <= (size_t)d->plan.width * d->plan.height * pixel_bytes_of(d->out_kind) + 65536) {

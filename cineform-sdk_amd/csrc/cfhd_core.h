@@ -105,6 +105,14 @@ void derive_quantization(FramePlan *plan, int quality, bool progressive, float f
 
 // Builds the pyramid geometry for the given encoded dimensions.
 bool build_frame_plan(FramePlan *plan, int width, int height, int pixel_kind, int encoded_format);
+
+// Which GPU serves unit i (worker i of an encoder pool, the i-th decoder handle of the process) on a node with `ndevices` GPUs.
+//   pinned (CFHD_AMD_DEVICE or LOCAL_RANK is set: one process per GPU, the launcher dealt the devices) -> -1 for everybody: the process default
+//   list   (CFHD_AMD_POOL_DEVICES, e.g. "0,1,2,3" or "0,0": devices may repeat)                      -> list[i % length], each taken modulo ndevices
+//   else                                                                                             -> i % ndevices (round robin, as the reference's
+//          pool deals frames to its encoder threads, EncoderSDK/EncoderPool.cpp:281-291)
+// Frames keep their submission order whatever device encodes them (the pool's FIFO, EncoderPool.cpp:297-380).
+int unit_device(int i, int ndevices, const char *pinned_env, const char *list_env);
 // Default encode curve of the Bayer input path (log base 90 over 14-bit linear input, scaled to `precision` bits), frame.c:5219-5235.
 enum { kBayerCurveBits = 14 };
 void build_bayer_log90_curve(int precision, uint16_t *curve /* 1 << kBayerCurveBits entries */);

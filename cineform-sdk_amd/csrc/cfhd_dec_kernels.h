@@ -68,6 +68,7 @@ enum {
 	DX_THREADS = 256, DX_WAVES = DX_THREADS / 64,
 	DX_TILE_THREADS = CFHD_DX_TILE_THREADS, DX_TILE_WAVES = DX_TILE_THREADS / 64,      // k_dec_tiles: its waves share the tables
 	DX_KM = 11,                       // bits of the window of the multi-symbol table of k_dec_tiles
+	DX_NO_VALUE = 0x8000,             // multi[]: offset of a value the lookup does not hold (beyond any tile whatever the position in front of it: a piece starts at most a few thousand coefficients in front of its tile)
 	DX_L11_BITS = 7, DX_LONG11_MAX = 1664,   // k_dec_tiles' own tables for the code words that do not fit the 11-bit window: second level 7 bits, third level the rest (up to 26 in all)
 	DX_RUNIN_SHORT = 96, DX_LEAD = 96,    // bits of the quick run-in in front of a chunk / of the lead-in in front of a lane
 	DX_MEMO = CFHD_DX_MEMO,           // outcomes a lane of k_dec_index remembers (start -> end, count)
@@ -86,9 +87,10 @@ struct DecIdxTables {
 	uint32_t long_tab[DX_LONG_MAX];   // bits 0-4 length (escape: index bits of the next level), bits 5-7 type, bits 8-31 run / magnitude index / base of the next level
 	uint32_t nlong;
 	// k_dec_tiles: everything that fits completely (sign bits included) into the next 11 bits, up to two values with the zero runs around
-	// them: x = bits 0-3 bits used (0: nothing fits -> one code word at a time), bits 4-15 zeros in front of v1, bits 16-31 v1 (signed; 0: none);
-	// y = bits 0-7 zeros between v1 and v2, bits 8-15 zeros behind the last value, bits 16-31 v2.  Values this short are below the knee of the
-	// companding curve (magnitude = index), so the table serves both code sets.
+	// them: x = bits 0-3 bits used (0: nothing fits -> one code word at a time), bits 4-15 coefficients the lookup covers, bits 16-31 position of
+	// the first value relative to the position in front of the lookup (DX_NO_VALUE: none); y = bits 0-15 position of the second value (likewise),
+	// bits 16-23 / 24-31 the values (signed).  Values this short are below the knee of the companding curve (magnitude = index), so the table
+	// serves both code sets.
 	// x & 15 == 0 (the first code word does not fit the window): y is an entry in the format of long11[] -- the code word itself when only its
 	// sign bit lies outside the window, else an escape to long11[] indexed by the next DX_L11_BITS bits (and once more for code words beyond 18 bits).
 	uint2 multi[1 << DX_KM];
@@ -958,9 +960,8 @@ __global__ void __launch_bounds__(DX_TILE_THREADS) k_dec_tiles(const DxBandJob *
 							// up to two values and the zero runs around them per lookup.  A group may reach over the end of the piece: the lane of the
 							// next piece then writes the same values to the same places again.
 							const uint2 e = s_multi[win >> (32 - DX_KM)];
-							uint32_t adv = e.x & 15u;
-							uint32_t pre = (e.x >> 4) & 0xfffu, mid = e.y & 0xffu, post = (e.y >> 8) & 0xffu;
-							int v1 = (int)(int16_t)(e.x >> 16), v2 = (int)(int16_t)(e.y >> 16);
+							uint32_t adv = e.x & 15u, total = (e.x >> 4) & 0xfffu, o1 = e.x >> 16, o2 = e.y & 0xffffu;
+							int v1 = (int)(int8_t)(e.y >> 16), v2 = (int)(int8_t)(e.y >> 24);
 							if (adv == 0u) {
 								// a code word that does not fit the window (a large value, a long run, the band end marker): alone, through its own trie
 								uint32_t le = e.y;
@@ -971,16 +972,17 @@ __global__ void __launch_bounds__(DX_TILE_THREADS) k_dec_tiles(const DxBandJob *
 								const uint32_t ty = (le >> 5) & 7u, ln = le & 31u;
 								const int m = (int)(linear ? le >> 20 : (le >> 8) & 0xfffu);
 								const bool isval = ty == (uint32_t)DX_T_VALUE, isrun = ty == (uint32_t)DX_T_RUN;
-								pre = isrun ? (le >> 8) & 0xfffu : 0u; mid = 0u; post = 0u; v2 = 0;
-								v1 = isval ? (((win << ln) >> 31) ? -m : m) : 0;
+								total = isrun ? (le >> 8) & 0xfffu : (isval ? 1u : 0u);
+								o1 = isval ? 0u : (uint32_t)DX_NO_VALUE; o2 = (uint32_t)DX_NO_VALUE;
+								v1 = ((win << ln) >> 31) ? -m : m; v2 = 0;
 								adv = isval ? ln + 1u : ln;
 								alive = isval || isrun;                       // else: the band end marker (or a broken code, reported by k_dec_chain)
 							}
-							rel += pre;
-							{ const bool st = v1 != 0 && rel < (uint32_t)DX_TILE; tile16[st ? rel : dump] = (int16_t)mul_u24((uint32_t)v1, quant); rel += v1 != 0 ? 1u : 0u; }
-							rel += mid;
-							{ const bool st = v2 != 0 && rel < (uint32_t)DX_TILE; tile16[st ? rel : dump] = (int16_t)mul_u24((uint32_t)v2, quant); rel += v2 != 0 ? 1u : 0u; }
-							rel += post;
+							// a value whose place lies outside the tile (or that is not there at all) goes to the lane's dump slot: min() does both
+							const uint32_t p1 = rel + o1, p2 = rel + o2;
+							tile16[p1 < dump ? p1 : dump] = (int16_t)mul_u24((uint32_t)v1, quant);
+							tile16[p2 < dump ? p2 : dump] = (int16_t)mul_u24((uint32_t)v2, quant);
+							rel += total;
 							pos += adv;
 							alive = alive && pos < (uint32_t)DX_SUB_BITS && (int)rel < len_tile;
 						} while (alive);

@@ -14,6 +14,8 @@ namespace cfhd {
 // CFHD_ERROR_INTERNAL and the message is available from device_last_error().
 int device_init();                 // picks the device from CFHD_AMD_DEVICE, else LOCAL_RANK, else 0
 int device_count();
+int device_select(int dev);        // this thread prepares its batches on device `dev` from now on (-1: the process default again); returns the device in effect, -1 on failure
+int device_current();              // the device device_init() puts this thread on
 const char *device_last_error();
 
 // N frames that travel through the forward path together: one launch per wavelet level covers every channel of
@@ -46,6 +48,7 @@ public:
 	const int16_t *host_coeffs(int i) const { return h_coeff_ + (size_t)i * plan_.final_elems; }
 	int16_t *device_coeffs(int i) { return d_coeff_ + (size_t)i * plan_.coeff_elems; }
 	void *stream() { return stream_; }
+	int device() const { return device_; }
 	float last_kernel_ms() const { return kernel_ms_; }   // forward kernels of the last launch (HIP events on this stream)
 	float last_level_ms(int level) const { return level_ms_[level]; }   // level 0 = k_fwd_yuv422, 1/2 = k_fwd_plane launches
 	void release();                                    // frees every device / pinned buffer of the batch (the destructor's work; prepare() starts with it)
@@ -53,7 +56,7 @@ private:
 	int sync_jobs();
 	void fill_jobs();
 	FramePlan plan_;
-	int n_ = 0, active_ = 0; bool own_input_ = false, jobs_dirty_ = true;
+	int n_ = 0, active_ = 0, device_ = 0; bool own_input_ = false, jobs_dirty_ = true;
 	void *stream_ = nullptr, *ev0_ = nullptr, *ev1_ = nullptr, *evl_[2] = {nullptr, nullptr};
 	float level_ms_[3] = {0, 0, 0};
 	uint8_t *d_in_ = nullptr, *h_in_ = nullptr; size_t frame_bytes_ = 0; int in_pitch_ = 0, in_rows_ = 0;
@@ -103,7 +106,7 @@ public:
 private:
 	int sync_jobs();
 	FramePlan plan_;
-	int n_ = 0, out_kind_ = 0; bool own_output_ = false, jobs_dirty_ = true, half_ = false, interlaced_ = false; int active_ = 0;
+	int n_ = 0, out_kind_ = 0, device_ = 0; bool own_output_ = false, jobs_dirty_ = true, half_ = false, interlaced_ = false; int active_ = 0;
 	void *stream_ = nullptr, *ev0_ = nullptr, *ev1_ = nullptr, *evl_[2] = {nullptr, nullptr};
 	float level_ms_[3] = {0, 0, 0};
 	int16_t *d_coeff_ = nullptr, *h_coeff_ = nullptr;

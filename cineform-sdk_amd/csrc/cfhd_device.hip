@@ -126,7 +126,7 @@ int host_buffer_register(void *p, size_t bytes)
 	if (rc) return rc;
 	std::lock_guard<std::mutex> lk(g_pins_mutex);
 	for (auto &e : g_pins) if (e.first == (uintptr_t)p) return e.second >= bytes ? 0 : -1;
-	HIPCHK(hipHostRegister(p, bytes, hipHostRegisterDefault));
+	HIPCHK(hipHostRegister(p, bytes, hipHostRegisterPortable));
 	g_pins.push_back({ (uintptr_t)p, bytes });
 	return 0;
 }
@@ -154,6 +154,17 @@ int device_count()
 	return n;
 }
 
+// The device the calling thread prepares its objects on: the process default (CFHD_AMD_DEVICE / LOCAL_RANK / 0) unless the thread asked for
+// another one -- a worker of an encoder pool that spreads over the node's GPUs, a decoder handle that was dealt one (cfhd_api.cpp).
+static thread_local int t_device = -1;
+int device_select(int dev)
+{
+	t_device = dev;
+	const int rc = device_init();
+	return rc ? -1 : device_current();
+}
+int device_current() { return t_device >= 0 ? t_device : g_device; }
+
 int device_init()
 {
 	std::call_once(g_init_once, [] {
@@ -167,7 +178,11 @@ int device_init()
 		if (e != hipSuccess) { fail(e, "hipSetDevice"); g_init_rc = (int)e; return; }
 		g_init_rc = 0;
 	});
-	if (g_init_rc == 0) hipSetDevice(g_device);      // per calling thread
+	if (g_init_rc == 0) {
+		int n = 1; (void)hipGetDeviceCount(&n);
+		if (t_device >= n) t_device = t_device % (n > 0 ? n : 1);
+		hipSetDevice(device_current());              // per calling thread
+	}
 	return g_init_rc;
 }
 
@@ -194,6 +209,7 @@ EncodeBatch::~EncodeBatch() { release(); }
 
 void EncodeBatch::release()
 {
+	(void)hipSetDevice(device_);
 	if (stream_) hipStreamSynchronize((hipStream_t)stream_);
 	ent_ready_ = false;
 	if (d_in_) hipFree(d_in_);
@@ -217,6 +233,7 @@ int EncodeBatch::prepare(const FramePlan &plan, int nframes, bool own_input)
 	int rc = device_init();
 	if (rc) return rc;
 	release();
+	device_ = device_current(); (void)hipSetDevice(device_);      // (release() went to the device of the buffers it freed)
 	const bool bayer = plan.pixel_kind == PIX_BYR4;
 	if (plan.pixel_kind != PIX_YUY2 && plan.pixel_kind != PIX_2VUY && !enc_packed16(plan.pixel_kind) && !bayer) { g_err = "pixel format not supported by the GPU path yet"; return -2; }
 	plan_ = plan; n_ = nframes; own_input_ = own_input;
@@ -238,14 +255,14 @@ int EncodeBatch::prepare(const FramePlan &plan, int nframes, bool own_input)
 	}
 	if (own_input) {
 		HIPCHK(hipMalloc((void **)&d_in_, frame_bytes_ * n_));
-		HIPCHK(hipHostMalloc((void **)&h_in_, frame_bytes_ * n_, hipHostMallocDefault));
+		HIPCHK(hipHostMalloc((void **)&h_in_, frame_bytes_ * n_, hipHostMallocPortable));
 	}
 	HIPCHK(hipMalloc((void **)&d_coeff_, (size_t)plan.coeff_elems * 2 * n_));
 	HIPCHK(hipMemsetAsync(d_coeff_, 0, (size_t)plan.coeff_elems * 2 * n_, (hipStream_t)stream_));   // pad columns stay zero forever
-	HIPCHK(hipHostMalloc((void **)&h_coeff_, (size_t)plan.final_elems * 2 * n_, hipHostMallocDefault));
+	HIPCHK(hipHostMalloc((void **)&h_coeff_, (size_t)plan.final_elems * 2 * n_, hipHostMallocPortable));
 	jobs_bytes_ = enc_jobs_bytes(n_, plan.num_channels);
 	HIPCHK(hipMalloc(&d_jobs_, jobs_bytes_));
-	HIPCHK(hipHostMalloc(&h_jobs_, jobs_bytes_, hipHostMallocDefault));
+	HIPCHK(hipHostMalloc(&h_jobs_, jobs_bytes_, hipHostMallocPortable));
 	memset(h_jobs_, 0, jobs_bytes_);
 
 	fill_jobs();
@@ -324,6 +341,7 @@ void EncodeBatch::fill_jobs()
 // geometry is unchanged, only the divisors in the job tables and in the sample headers move.
 int EncodeBatch::update_quant(const FramePlan &plan)
 {
+	(void)hipSetDevice(device_);
 	if (plan.coeff_elems != plan_.coeff_elems || plan.num_channels != plan_.num_channels) return -1;
 	if (stream_) HIPCHK(hipStreamSynchronize((hipStream_t)stream_));      // the pinned job table may still be in flight
 	EncJobs j = enc_jobs_at(h_jobs_, n_, plan_.num_channels);
@@ -353,6 +371,7 @@ int EncodeBatch::prepare_entropy(size_t sample_cap)
 
 int EncodeBatch::sync_jobs()
 {
+	(void)hipSetDevice(device_);
 	if (!jobs_dirty_) return 0;
 	HIPCHK(hipMemcpyAsync(d_jobs_, h_jobs_, jobs_bytes_, hipMemcpyHostToDevice, (hipStream_t)stream_));
 	jobs_dirty_ = false;
@@ -361,6 +380,7 @@ int EncodeBatch::sync_jobs()
 
 int EncodeBatch::upload_frame(int i, const void *frame, int pitch)
 {
+	(void)hipSetDevice(device_);
 	if (!own_input_ || i < 0 || i >= n_) return -1;
 	const uint8_t *src = (const uint8_t *)frame;
 	if (plan_.pixel_kind == PIX_BYR4) {
@@ -481,6 +501,7 @@ const char *EncodeBatch::level_kernel(int level) const
 
 int EncodeBatch::launch_forward()
 {
+	(void)hipSetDevice(device_);
 	int rc = sync_jobs();
 	if (rc) return rc;
 	hipStream_t st = (hipStream_t)stream_;
@@ -536,6 +557,7 @@ int EncodeBatch::launch_forward()
 
 int EncodeBatch::download_coeffs()
 {
+	(void)hipSetDevice(device_);
 	HIPCHK(hipMemcpy2DAsync(h_coeff_, (size_t)plan_.final_elems * 2, d_coeff_, (size_t)plan_.coeff_elems * 2,
 	                        (size_t)plan_.final_elems * 2, n_, hipMemcpyDeviceToHost, (hipStream_t)stream_));
 	return 0;
@@ -543,6 +565,7 @@ int EncodeBatch::download_coeffs()
 
 int EncodeBatch::wait()
 {
+	(void)hipSetDevice(device_);
 	HIPCHK(hipStreamSynchronize((hipStream_t)stream_));
 	float ms = 0;
 	if (!timed_) return 0;
@@ -562,6 +585,7 @@ DecodeBatch::~DecodeBatch() { release(); }
 
 void DecodeBatch::release()
 {
+	(void)hipSetDevice(device_);
 	if (stream_) hipStreamSynchronize((hipStream_t)stream_);
 	ent_ready_ = false;
 	if (d_out_) hipFree(d_out_);
@@ -583,6 +607,7 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 	int rc = device_init();
 	if (rc) return rc;
 	release();
+	device_ = device_current(); (void)hipSetDevice(device_);      // (release() went to the device of the buffers it freed)
 	half_ = half;
 
 	const bool yuv_ok = (out_kind == PIX_YUY2 || out_kind == PIX_2VUY) && plan.encoded_format == ENC_YUV422;
@@ -602,15 +627,15 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 	frame_bytes_ = (size_t)out_pitch_ * out_rows_;
 	if (own_output) {
 		HIPCHK(hipMalloc((void **)&d_out_, frame_bytes_ * n_));
-		HIPCHK(hipHostMalloc((void **)&h_out_, frame_bytes_ * n_, hipHostMallocDefault));
+		HIPCHK(hipHostMalloc((void **)&h_out_, frame_bytes_ * n_, hipHostMallocPortable));
 	}
 	HIPCHK(hipMalloc((void **)&d_coeff_, (size_t)plan.coeff_elems * 2 * n_));
 	HIPCHK(hipMemsetAsync(d_coeff_, 0, (size_t)plan.coeff_elems * 2 * n_, (hipStream_t)stream_));
-	HIPCHK(hipHostMalloc((void **)&h_coeff_, (size_t)plan.final_elems * 2 * n_, hipHostMallocDefault));
+	HIPCHK(hipHostMalloc((void **)&h_coeff_, (size_t)plan.final_elems * 2 * n_, hipHostMallocPortable));
 	memset(h_coeff_, 0, (size_t)plan.final_elems * 2 * n_);
 	jobs_bytes_ = dec_jobs_bytes(n_, plan.num_channels);
 	HIPCHK(hipMalloc(&d_jobs_, jobs_bytes_));
-	HIPCHK(hipHostMalloc(&h_jobs_, jobs_bytes_, hipHostMallocDefault));
+	HIPCHK(hipHostMalloc(&h_jobs_, jobs_bytes_, hipHostMallocPortable));
 	memset(h_jobs_, 0, jobs_bytes_);
 
 	const int nch = plan.num_channels;
@@ -675,6 +700,7 @@ int DecodeBatch::prepare_entropy(size_t sample_cap)
 
 int DecodeBatch::sync_jobs()
 {
+	(void)hipSetDevice(device_);
 	if (!jobs_dirty_) return 0;
 	HIPCHK(hipMemcpyAsync(d_jobs_, h_jobs_, jobs_bytes_, hipMemcpyHostToDevice, (hipStream_t)stream_));
 	jobs_dirty_ = false;
@@ -685,6 +711,7 @@ void DecodeBatch::clear_host_coeffs(int i) { memset(h_coeff_ + (size_t)i * plan_
 
 int DecodeBatch::upload_coeffs()
 {
+	(void)hipSetDevice(device_);
 	HIPCHK(hipMemcpy2DAsync(d_coeff_, (size_t)plan_.coeff_elems * 2, h_coeff_, (size_t)plan_.final_elems * 2,
 	                        (size_t)plan_.final_elems * 2, n_, hipMemcpyHostToDevice, (hipStream_t)stream_));
 	return 0;
@@ -764,6 +791,7 @@ const char *DecodeBatch::level_kernel(int level) const
 
 int DecodeBatch::launch_inverse(uint32_t dither_seed)
 {
+	(void)hipSetDevice(device_);
 	int rc = sync_jobs();
 	if (rc) return rc;
 	hipStream_t st = (hipStream_t)stream_;
@@ -826,6 +854,7 @@ int DecodeBatch::launch_inverse(uint32_t dither_seed)
 
 int DecodeBatch::download_frame(int i, void *out, int pitch)
 {
+	(void)hipSetDevice(device_);
 	if (!own_output_ || i < 0 || i >= n_) return -1;
 	if (direct_.size() != (size_t)n_) direct_.assign((size_t)n_, 0);
 	direct_[i] = 0;
@@ -841,6 +870,7 @@ int DecodeBatch::download_frame(int i, void *out, int pitch)
 // Orders everything queued on this batch's stream from now on behind what the producer stream holds at this moment.
 int DecodeBatch::after(void *producer_stream)
 {
+	(void)hipSetDevice(device_);
 	if (!evdep_) { hipEvent_t e; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); evdep_ = e; }
 	HIPCHK(hipEventRecord((hipEvent_t)evdep_, (hipStream_t)producer_stream));
 	HIPCHK(hipStreamWaitEvent((hipStream_t)stream_, (hipEvent_t)evdep_, 0));
@@ -849,6 +879,7 @@ int DecodeBatch::after(void *producer_stream)
 
 int DecodeBatch::wait()
 {
+	(void)hipSetDevice(device_);
 	HIPCHK(hipStreamSynchronize((hipStream_t)stream_));
 	float ms = 0;
 	if (!timed_) return 0;

@@ -38,7 +38,7 @@ public:
 private:
 	struct Host; Host *host_;           // host mirrors of the job tables (types live in the kernel headers)
 	void release();
-	FramePlan plan_; int n_ = 0, active_ = 0; size_t cap_ = 0; void *stream_ = nullptr;
+	FramePlan plan_; int n_ = 0, active_ = 0, device_ = 0 /* the GPU prepare() ran on */; size_t cap_ = 0; void *stream_ = nullptr;
 	int active_frames() const { return active_ > 0 && active_ < n_ ? active_ : n_; }
 	int nbands_ = 0, total_segs_ = 0;
 	std::vector<SampleTemplate> tmpl_;
@@ -100,6 +100,7 @@ private:
 	void *d_idx_tables_ = nullptr, *d_entries_ = nullptr, *d_recs_ = nullptr, *d_chunk_base_ = nullptr, *d_chunk_job_ = nullptr, *d_sums_ = nullptr, *d_counters_ = nullptr;
 	uint32_t max_chunks_ = 0, *h_counters_ = nullptr; void *h_chunk_job_ = nullptr;
 	int grid_index_ = 0, grid_tiles_ = 0;
+	int device_ = 0;                       // the GPU prepare() ran on: every launch selects it for the calling thread
 	int launch_dx(bool device_jobs, int njobs, uint32_t host_chunks);
 	void *ev_[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; bool timed_ = false;    // [4]: end of k_dec_parse when the band decoder waits for a second event behind it; [5], [6]: behind k_dec_index / k_dec_chain
 	bool parse_end_ = false;

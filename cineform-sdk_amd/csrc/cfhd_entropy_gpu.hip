@@ -10,6 +10,7 @@
 namespace cfhd {
 
 int device_init();
+int device_current();
 namespace { int g_fail(hipError_t e, const char *what) { fprintf(stderr, "[cfhd_amd] %s: %s\n", what, hipGetErrorString(e)); return (int)e ? (int)e : -1; } }
 #define HIPCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return g_fail(_e, #expr); } while (0)
 
@@ -20,6 +21,7 @@ GpuEntropyEncoder::~GpuEntropyEncoder() { release(); delete host_; }
 
 void GpuEntropyEncoder::release()
 {
+	(void)hipSetDevice(device_);
 	void *dev[] = { d_samples_, d_sizes_, d_tables_, d_bands_, d_segband_, d_segs_, d_bandstate_, d_frames_, d_tmpl_, d_packed_, d_offsets_, d_tokens_ };
 	for (void *p : dev) if (p) (void)hipFree(p);
 	if (h_samples_) (void)hipHostFree(h_samples_);
@@ -39,6 +41,7 @@ int GpuEntropyEncoder::prepare(const FramePlan &plan, int nframes, int16_t *d_co
 	int rc = device_init();
 	if (rc) return rc;
 	release();
+	device_ = device_current(); (void)hipSetDevice(device_);
 	plan_ = plan; n_ = nframes; cap_ = (sample_cap + 255) & ~(size_t)255; stream_ = stream; d_coeffs_ = d_coeffs; coeff_stride_ = stride;
 	if (cap_ * (size_t)n_ >= ((size_t)1 << 32)) { fprintf(stderr, "[cfhd_amd] batch of %d frames exceeds the 4 GiB sample arena\n", n_); return -5; }   // packed offsets are 32-bit
 	{
@@ -61,19 +64,19 @@ int GpuEntropyEncoder::prepare(const FramePlan &plan, int nframes, int16_t *d_co
 	HIPCHK(hipMalloc(&d_tokens_, jobs.segjobs.size() * (size_t)dev::ENT_TOK_STRIDE * sizeof(uint32_t)));      // token lists and finished bit strings: worst case one per coefficient, only the used part is ever touched
 	HIPCHK(hipMalloc(&d_bandstate_, jobs.bands.size() * sizeof(dev::EntBandState)));
 	HIPCHK(hipMalloc((void **)&d_samples_, cap_ * n_));
-	HIPCHK(hipHostMalloc((void **)&h_samples_, cap_ * n_, hipHostMallocDefault));
+	HIPCHK(hipHostMalloc((void **)&h_samples_, cap_ * n_, hipHostMallocPortable));
 	HIPCHK(hipMalloc((void **)&d_sizes_, sizeof(uint32_t) * 2 * n_));                   // [n] sample sizes, [n] peak flags
-	HIPCHK(hipHostMalloc((void **)&h_sizes_, sizeof(uint32_t) * 2 * n_, hipHostMallocDefault));
+	HIPCHK(hipHostMalloc((void **)&h_sizes_, sizeof(uint32_t) * 2 * n_, hipHostMallocPortable));
 	memset(h_sizes_, 0, sizeof(uint32_t) * 2 * n_);
 	HIPCHK(hipMalloc((void **)&d_packed_, cap_ * n_));
 	HIPCHK(hipMalloc((void **)&d_offsets_, sizeof(uint32_t) * (n_ + 1)));
-	HIPCHK(hipHostMalloc((void **)&h_offsets_, sizeof(uint32_t) * (n_ + 1), hipHostMallocDefault));
+	HIPCHK(hipHostMalloc((void **)&h_offsets_, sizeof(uint32_t) * (n_ + 1), hipHostMallocPortable));
 	memset(h_offsets_, 0, sizeof(uint32_t) * (n_ + 1));
 	HIPCHK(hipMalloc((void **)&d_tmpl_, (size_t)kEntTmplStride * n_));
-	HIPCHK(hipHostMalloc((void **)&h_tmpl_, (size_t)kEntTmplStride * n_, hipHostMallocDefault));
+	HIPCHK(hipHostMalloc((void **)&h_tmpl_, (size_t)kEntTmplStride * n_, hipHostMallocPortable));
 	memset(h_tmpl_, 0, (size_t)kEntTmplStride * n_);
 	HIPCHK(hipMalloc(&d_frames_, n_ * sizeof(dev::EntFrameJob)));
-	HIPCHK(hipHostMalloc((void **)&host_->frames, n_ * sizeof(dev::EntFrameJob), hipHostMallocDefault));
+	HIPCHK(hipHostMalloc((void **)&host_->frames, n_ * sizeof(dev::EntFrameJob), hipHostMallocPortable));
 	for (int f = 0; f < n_; f++) { SampleHeaderInfo h = hdr0; h.frame_number = (uint32_t)f + 1; if ((rc = set_frame_header(f, h))) return rc; }
 	for (void *&e : ev_) HIPCHK(hipEventCreate((hipEvent_t *)&e));
 	return 0;
@@ -92,6 +95,7 @@ int GpuEntropyEncoder::set_frame_header(int f, const SampleHeaderInfo &hdr)
 
 int GpuEntropyEncoder::launch()
 {
+	(void)hipSetDevice(device_);
 	hipStream_t st = (hipStream_t)stream_;
 	if (dirty_) {
 		HIPCHK(hipMemcpyAsync(d_tmpl_, h_tmpl_, (size_t)kEntTmplStride * n_, hipMemcpyHostToDevice, st));
@@ -105,7 +109,7 @@ int GpuEntropyEncoder::launch()
 	if (plan_.interlaced) HIPCHK(hipMemsetAsync(d_sizes_ + n_, 0, sizeof(uint32_t) * n_, st));
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[0], st));
 	dev::k_ent_count<<<(total_segs + dev::ENT_WAVES - 1) / dev::ENT_WAVES, dev::ENT_THREADS, 0, st>>>((const dev::EntSegJob *)d_segband_, geom, total_segs, (dev::EntSegState *)d_segs_, T,
-	                                                                                                    d_sizes_ + n_, (uint32_t *)d_tokens_);
+	                                                                                                    d_sizes_ + n_, (uint32_t *)d_tokens_, []{ const char *e = getenv("CFHD_AMD_COUNT_PROBE"); return e ? atoi(e) : 0; }());
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[1], st));
 	dev::k_ent_scan<<<nbands_ * act, dev::ENT_THREADS, 0, st>>>((const dev::EntBandJob *)d_bands_, (dev::EntSegState *)d_segs_, (dev::EntBandState *)d_bandstate_, T);
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[2], st));
@@ -131,6 +135,7 @@ float GpuEntropyEncoder::kernel_ms(int k)
 
 int GpuEntropyEncoder::fetch_sizes()
 {
+	(void)hipSetDevice(device_);
 	hipStream_t st = (hipStream_t)stream_;
 	HIPCHK(hipMemcpyAsync(h_sizes_, d_sizes_, sizeof(uint32_t) * 2 * n_, hipMemcpyDeviceToHost, st));
 	HIPCHK(hipStreamSynchronize(st));
@@ -139,6 +144,7 @@ int GpuEntropyEncoder::fetch_sizes()
 
 int GpuEntropyEncoder::download()
 {
+	(void)hipSetDevice(device_);
 	hipStream_t st = (hipStream_t)stream_;
 	// CFHD_AMD_DOWNLOAD=kernel: k_ent_pack stores the dense samples straight into the pinned host buffer (device-visible), no copy
 	// command at all; default: pack in HBM, then one copy (SDMA engine when the runtime has it enabled).
@@ -168,6 +174,7 @@ GpuEntropyDecoder::~GpuEntropyDecoder() { release(); delete host_; }
 
 void GpuEntropyDecoder::release()
 {
+	(void)hipSetDevice(device_);
 	void *dev[] = { d_samples_, d_tables_, d_bandjobs_, d_lowjobs_, d_errors_, d_plan_, d_idx_tables_, d_entries_, d_recs_, d_chunk_base_, d_chunk_job_, d_sums_, d_counters_, d_tile_start_, d_stats_, d_repair_, d_alts_, d_reindex_, d_diffjobs_, d_alt_entries_ };
 	for (void *p : dev) if (p) (void)hipFree(p);
 	d_idx_tables_ = d_entries_ = d_recs_ = d_chunk_base_ = d_chunk_job_ = d_sums_ = d_counters_ = d_tile_start_ = d_stats_ = d_repair_ = d_alts_ = d_reindex_ = d_diffjobs_ = d_alt_entries_ = nullptr;
@@ -189,21 +196,22 @@ int GpuEntropyDecoder::prepare(const FramePlan &plan, int nframes, int16_t *d_co
 	int rc = device_init();
 	if (rc) return rc;
 	release();
+	device_ = device_current(); (void)hipSetDevice(device_);
 	plan_ = plan; n_ = nframes; cap_ = (sample_cap + 255) & ~(size_t)255; stream_ = stream; d_coeffs_ = d_coeffs; coeff_stride_ = stride; out_kind_ = out_kind;
 	std::vector<uint32_t> t = build_dec_tables(1);
 	HIPCHK(hipMalloc(&d_tables_, t.size() * 4));
 	HIPCHK(hipMemcpy(d_tables_, t.data(), t.size() * 4, hipMemcpyHostToDevice));
 	HIPCHK(hipMalloc((void **)&d_samples_, cap_ * n_));
-	HIPCHK(hipHostMalloc((void **)&h_samples_, cap_ * n_, hipHostMallocDefault));
+	HIPCHK(hipHostMalloc((void **)&h_samples_, cap_ * n_, hipHostMallocPortable));
 	const size_t max_bands = (size_t)n_ * kMaxChannels * 9, max_lows = (size_t)n_ * kMaxChannels;
 	HIPCHK(hipMalloc(&d_bandjobs_, max_bands * sizeof(dev::DecBandJob)));
 	HIPCHK(hipMalloc(&d_lowjobs_, max_lows * sizeof(dev::DecLowpassJob)));
-	HIPCHK(hipHostMalloc((void **)&host_->flat_bands, max_bands * sizeof(dev::DecBandJob), hipHostMallocDefault));
-	HIPCHK(hipHostMalloc((void **)&host_->flat_lows, max_lows * sizeof(dev::DecLowpassJob), hipHostMallocDefault));
+	HIPCHK(hipHostMalloc((void **)&host_->flat_bands, max_bands * sizeof(dev::DecBandJob), hipHostMallocPortable));
+	HIPCHK(hipHostMalloc((void **)&host_->flat_lows, max_lows * sizeof(dev::DecLowpassJob), hipHostMallocPortable));
 	HIPCHK(hipMalloc(&d_diffjobs_, max_lows * sizeof(dev::DecDiffJob)));
-	HIPCHK(hipHostMalloc((void **)&host_->flat_diffs, max_lows * sizeof(dev::DecDiffJob), hipHostMallocDefault));
+	HIPCHK(hipHostMalloc((void **)&host_->flat_diffs, max_lows * sizeof(dev::DecDiffJob), hipHostMallocPortable));
 	HIPCHK(hipMalloc((void **)&d_errors_, sizeof(int)));
-	HIPCHK(hipHostMalloc((void **)&h_errors_, sizeof(int), hipHostMallocDefault));
+	HIPCHK(hipHostMalloc((void **)&h_errors_, sizeof(int), hipHostMallocPortable));
 	*h_errors_ = 0;
 	{ const char *e = getenv("CFHD_AMD_DEC"); lane_kernel_ = e && strcmp(e, "lane") == 0; dx_ = !(e && (strcmp(e, "lane") == 0 || strcmp(e, "par") == 0)); }   // A/B switches: the round-1 kernels
 	if (dx_) {
@@ -234,10 +242,10 @@ int GpuEntropyDecoder::prepare(const FramePlan &plan, int nframes, int16_t *d_co
 			const char *se = getenv("CFHD_AMD_DX_STATS");
 			if (se && atoi(se)) { HIPCHK(hipMalloc(&d_stats_, 64)); HIPCHK(hipMemset(d_stats_, 0, 64)); }
 		}
-		HIPCHK(hipHostMalloc((void **)&h_chunk_job_, (size_t)max_chunks_ * sizeof(dev::DxChunkDesc), hipHostMallocDefault));
-		HIPCHK(hipHostMalloc((void **)&h_counters_, 32, hipHostMallocDefault));
+		HIPCHK(hipHostMalloc((void **)&h_chunk_job_, (size_t)max_chunks_ * sizeof(dev::DxChunkDesc), hipHostMallocPortable));
+		HIPCHK(hipHostMalloc((void **)&h_counters_, 32, hipHostMallocPortable));
 		int cus = 256;
-		(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
+		(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_current());
 		const char *g1 = getenv("CFHD_AMD_DX_GRID_INDEX"), *g3 = getenv("CFHD_AMD_DX_GRID_TILES");
 		grid_index_ = g1 ? atoi(g1) : cus * 5; grid_tiles_ = g3 ? atoi(g3) : cus * (dev::DX_TILE_THREADS >= 1024 ? 1 : 2);      // workgroups that fit a CU at once (LDS: ~30 KB / ~150 KB each)
 		if (grid_index_ < 1) grid_index_ = 1;
@@ -297,6 +305,7 @@ enum { kLowLatencyFrames = 32 };     // up to here k_dec_bands_par_ll: measured 
 
 int GpuEntropyDecoder::launch()
 {
+	(void)hipSetDevice(device_);
 	hipStream_t st = (hipStream_t)stream_;
 	if (ext_samples_) {
 		// device-resident samples: parse on the GPU; the job tables have one row per band type (largest first), nframes wide
@@ -442,6 +451,7 @@ int GpuEntropyDecoder::check() { return *h_errors_ ? -1 : 0; }
 // [4..15] lanes that restarted in round 0..10, 11+.  Synchronises the stream.
 int GpuEntropyDecoder::stats(uint32_t out[16])
 {
+	(void)hipSetDevice(device_);
 	memset(out, 0, 64);
 	if (!d_stats_) return -1;
 	HIPCHK(hipStreamSynchronize((hipStream_t)stream_));

@@ -137,8 +137,13 @@ inline bool build_dec_index_tables(int codebook, dev::DecIdxTables *T)
 			used += total;
 		}
 		if (v1 && !v2) { post = mid; mid = 0; }             // zeros behind the only value
-		T->multi[win].x = (uint32_t)(used & 15) | ((uint32_t)pre << 4) | ((uint32_t)(uint16_t)(int16_t)v1 << 16);
-		T->multi[win].y = (uint32_t)(mid & 0xff) | ((uint32_t)(post & 0xff) << 8) | ((uint32_t)(uint16_t)(int16_t)v2 << 16);
+		// as the kernel wants it: how far the lookup moves the raster position, where its values land relative to the position in front of it
+		// (DX_NO_VALUE: none -- far outside any tile, the store goes to the dump slot), the values themselves
+		const int total = pre + (v1 ? 1 : 0) + mid + (v2 ? 1 : 0) + post;
+		const uint32_t o1 = v1 ? (uint32_t)pre : (uint32_t)DX_NO_VALUE, o2 = v2 ? (uint32_t)(pre + 1 + mid) : (uint32_t)DX_NO_VALUE;
+		if (total > 0xfff || v1 < -128 || v1 > 127 || v2 < -128 || v2 > 127 || (v1 && pre >= (int)DX_NO_VALUE) || (v2 && pre + 1 + mid >= (int)DX_NO_VALUE)) return false;
+		T->multi[win].x = (uint32_t)(used & 15) | ((uint32_t)total << 4) | (o1 << 16);
+		T->multi[win].y = o2 | ((uint32_t)(uint8_t)(int8_t)v1 << 16) | ((uint32_t)(uint8_t)(int8_t)v2 << 24);
 	}
 	// k_dec_tiles, windows whose first code word does not fit (multi[win].x & 15 == 0): the code word through a trie of its own -- 11 bits (the
 	// window), DX_L11_BITS more, the rest -- whose entries carry everything the kernel needs (length, kind, run or both magnitudes): one LDS read
@@ -201,7 +206,7 @@ inline bool build_dec_index_tables(int codebook, dev::DecIdxTables *T)
 		}
 		if (!ok) return false;
 		// (windows that are no prefix of any code word keep y = 0: type DX_T_INVALID)
-		for (uint32_t win = 0; win < (1u << DX_KM); win++) if ((T->multi[win].x & 15u) == 0 && (T->multi[win].x >> 4)) return false;   // nothing but the flag in x
+		for (uint32_t win = 0; win < (1u << DX_KM); win++) if ((T->multi[win].x & 15u) == 0 && (T->multi[win].x & 0xffffu)) return false;   // (a window nothing fits into covers no coefficients)
 	}
 	return true;
 }

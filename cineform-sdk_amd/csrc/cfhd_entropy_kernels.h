@@ -197,7 +197,7 @@ enum { ENT_PEAK_THRESHOLD = 250 };
 // The compacted token list of every segment (local raster index << 16 | value) is kept in `tokens` (ENT_SEG words per segment, the first
 // ntok used): k_ent_emit codes from that list -- a sixth of the bytes -- instead of reading and compacting the coefficients a second time.
 __global__ void __launch_bounds__(ENT_THREADS) k_ent_count(const EntSegJob *seg_jobs, EntBatchGeom geom, int total_segs, EntSegState *segs, const EntTables *tables,
-                                                            uint32_t *peak_flags, uint32_t *tokens)
+                                                            uint32_t *peak_flags, uint32_t *tokens, int probe = 0 /* timing experiments: 1 behind the loads, 2 behind the scan, 3 behind the compaction, 4 no token stores */)
 {
 	__shared__ uint32_t s_tok_all[ENT_WAVES][ENT_TOK_CAP];   // tokens of the current pass: local raster index << 16 | value (16 bits)
 	const int lane = wave_lane();
@@ -219,6 +219,7 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_count(const EntSegJob *seg_
 		if (__ballot(peak) && lane == 0) atomic_or_u32(&peak_flags[frame], 1u);
 	}
 	const unsigned long long mask = __ballot(my_last >= 0);
+	if (probe == 1) { if (lane == 0) { EntSegState &z = segs[seg]; z.first_nz = -1; z.last_nz = -1; z.bits = mask == 0x123456789ull; z.ntok = 0; z.lead32 = 0; z.lead_valid = 0; } return; }
 	// The picture is sparse (about one coefficient in twelve is nonzero): looking up all 16 x 64 coefficients kept the CU's
 	// texture-address path busy with gathers for zeros (32 gather instructions per wave: the kernel was bound by them, not by
 	// bytes).  The nonzero coefficients are compacted into a token list in LDS first -- as k_ent_emit does -- and the lookups
@@ -230,6 +231,7 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_count(const EntSegJob *seg_
 	const int incl = (int)wave_incl_scan((uint32_t)cnt);
 	const int ntok = (int)wave_get((uint32_t)incl, ENT_LANES - 1);
 	uint32_t bits = 0, carry_tok = 0, lead32 = 0, lead_valid = 0;
+	if (probe == 2) { if (lane == 0) { EntSegState &z = segs[seg]; z.first_nz = -1; z.last_nz = -1; z.bits = ntok == 0x12345; z.ntok = 0; z.lead32 = 0; z.lead_valid = 0; } return; }
 	for (int lo = 0; lo < ntok; lo += ENT_TOK_CAP) {     // wave-uniform: one pass unless the segment is unusually dense
 		if (lo) { carry_tok = s_tok[ENT_TOK_CAP - 1]; CFHD_WAVE_SYNC(); }
 		{
@@ -239,6 +241,7 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_count(const EntSegJob *seg_
 				if (v[k]) { if ((unsigned)at < (unsigned)ENT_TOK_CAP) s_tok[at] = ((uint32_t)(lane * ENT_PER_THREAD + k) << 16) | (uint32_t)(uint16_t)v[k]; at++; }
 		}
 		CFHD_WAVE_SYNC();
+		if (probe == 3) { const unsigned long long q = __ballot(s_tok[lane] == 0x12345u); if (lane == 0) { EntSegState &z = segs[seg]; z.first_nz = -1; z.last_nz = -1; z.bits = q == 0x123456789ull; z.ntok = 0; z.lead32 = 0; z.lead_valid = 0; } return; }
 		const int hi = ntok - lo < ENT_TOK_CAP ? ntok - lo : ENT_TOK_CAP;
 		for (int t0 = 0; t0 < hi; t0 += ENT_LANES) {
 			const int tl = t0 + lane, t = lo + tl;
@@ -255,7 +258,7 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_count(const EntSegJob *seg_
 			if (have) {
 				bits += rt + (ve >> 27);
 				uint32_t *seg_out = tokens + (size_t)seg * ENT_TOK_STRIDE;
-				seg_out[t] = tok;
+				if (probe != 4) seg_out[t] = tok;
 				// the token's finished bit string for k_ent_emit: run code (when one code covers the run: nearly always) + value code, at most
 				// 31 + 27 bits, left aligned; the first token of the segment carries its value code only (its run reaches into the earlier
 				// segments: k_ent_scan works that one out)
@@ -264,7 +267,7 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_count(const EntSegJob *seg_
 				const uint64_t str = simple ? (((uint64_t)(run ? rp.x : 0u) << vs) | vc) << (64u - rs - vs) : 0ull;      // (rs + vs >= 2: a value code has at least its sign)
 				const uint32_t len = simple ? rs + vs : (uint32_t)ENT_CODE_COMPLEX;
 				uint2 rec; rec.x = (uint32_t)str | len; rec.y = (uint32_t)(str >> 32);
-				((uint2 *)(seg_out + ENT_SEG))[t] = rec;
+				if (probe != 4) ((uint2 *)(seg_out + ENT_SEG))[t] = rec;
 				my_top = rec.y; my_len = len;
 			}
 			if (t0 == 0 && lo == 0) {

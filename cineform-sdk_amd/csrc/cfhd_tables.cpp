@@ -448,4 +448,23 @@ void derive_quantization(FramePlan *plan, int quality, bool progressive, float f
 	}
 }
 
+int unit_device(int i, int ndevices, const char *pinned_env, const char *list_env)
+{
+	if (ndevices < 1) ndevices = 1;
+	if (i < 0) i = 0;
+	if (list_env && *list_env) {
+		int list[64], n = 0;
+		for (const char *p = list_env; *p && n < 64;) {
+			while (*p == ',' || *p == ' ') p++;
+			if (*p < '0' || *p > '9') break;
+			int v = 0;
+			while (*p >= '0' && *p <= '9') v = v * 10 + (*p++ - '0');
+			list[n++] = v % ndevices;
+		}
+		if (n) return list[i % n];
+	}
+	if (pinned_env && *pinned_env) return -1;
+	return i % ndevices;
+}
+
 } // namespace cfhd

@@ -31,6 +31,9 @@ int cfhd_amd_plan_info(int width, int height, int pixel_kind, int encoded_format
 	return n;
 }
 
+// The device an encoder-pool worker / decoder handle is dealt (cfhd_core.h unit_device): host logic, no GPU involved.
+int cfhd_amd_unit_device(int i, int ndevices, const char *pinned_env, const char *list_env) { return unit_device(i, ndevices, pinned_env, list_env); }
+
 // Quantizer tables of a sequence of frames under rate feedback: frame f is derived with lastgopbitcount = 8 * sample_bytes[f - 1]
 // (0 for the first), the state carried from frame to frame as the encoder carries it.  out: per frame, per channel, the 9 highpass
 // divisors in coding order (level 3 LH HL HH, level 2, level 1).

@@ -130,6 +130,37 @@ def test_encoder_pool_is_fifo_and_matches_sync(gather):
         os.environ.pop("CFHD_AMD_ENCODE_BATCH", None)
 
 
+def test_encoder_pool_and_decoders_over_several_devices_keep_order_and_bytes():
+    """A process that owns several GPUs spreads its pool workers and decoder handles over them (cfhd_core.h unit_device); the frames come
+    back in submission order and byte for byte as from the synchronous encoder.  On a box with one GPU the list CFHD_AMD_POOL_DEVICES names it
+    three times: the same code path -- a device selected per worker thread, tables / scratch / streams per worker, handles that remember
+    their device -- on one piece of hardware."""
+    old = os.environ.get("CFHD_AMD_POOL_DEVICES")
+    L = product()
+    L.cfhd_amd_device_count.restype = ctypes.c_int
+    ndev = L.cfhd_amd_device_count()
+    assert ndev >= 1
+    os.environ["CFHD_AMD_POOL_DEVICES"] = ",".join(str(k % ndev) for k in range(3))
+    try:
+        _pool_is_fifo_and_matches_sync()
+        # three decoder handles, dealt the three list entries, decode the same sample to the same picture as a handle on the default device
+        w, h = 640, 480
+        f, p = synth_yuy2(w, h, 77)
+        sample = amd_encode_frames([f], p, w, h)[0]
+        outs = [amd_decode_sample(sample)[0] for _ in range(3)]
+        os.environ.pop("CFHD_AMD_POOL_DEVICES")
+        ref_out = amd_decode_sample(sample)[0]
+        plan = Plan(w, h)
+        coeffs = host_decode_pyramid(sample, plan)
+        lo = oracle_inverse_yuv422(plan, coeffs, 0)[:h]; hi = oracle_inverse_yuv422(plan, coeffs, 1)[:h]
+        for o in outs + [ref_out]:
+            img = o.reshape(h, -1)[:, : w * 2]
+            assert ((img == lo) | (img == hi)).all()
+    finally:
+        os.environ.pop("CFHD_AMD_POOL_DEVICES", None)
+        if old is not None: os.environ["CFHD_AMD_POOL_DEVICES"] = old
+
+
 def _pool_is_fifo_and_matches_sync():
     L = product()
     w, h = 640, 480
