@@ -94,6 +94,7 @@ struct EncodeParams {
 	int color_space = 2;
 	FramePlan plan;
 	QuantState qstate = {0, -1, 0};
+	bool gop = false; GopPlan gplan;              // CFHD_ENCODING_FLAGS_YUV_2FRAME_GOP: two frames per sample (cfhd_gop.h)
 	bool valid = false;
 };
 
@@ -118,7 +119,10 @@ int make_params(EncodeParams &p, int w, int h, uint32_t fmt, int encoded, uint32
 	// CFHD_ENCODING_FLAGS_YUV_INTERLACED: field-based level 1 (encoder.c:2093), built for the packed 4:2:2 formats
 	const bool interlaced = (flags & (1u << 0)) != 0;
 	if (interlaced && !(kind == PIX_YUY2 || kind == PIX_2VUY)) return ERR_BADFORMAT;
-	if (flags & (1u << 1)) return ERR_BADFORMAT;                          // 2-frame GOP: out of scope
+	// CFHD_ENCODING_FLAGS_YUV_2FRAME_GOP (CFHDTypes.h:254, "YUV 4:2:2 only"): two frames per sample through the temporal transform (cfhd_gop.h).
+	// Progressive frames, qualities whose tables do not follow the size of the previous group.
+	const bool gop = (flags & (1u << 1)) != 0;
+	if (gop && (interlaced || !(kind == PIX_YUY2 || kind == PIX_2VUY))) return ERR_BADFORMAT;
 	const int enc = kind == PIX_BYR4 ? ENC_BAYER : (kind == PIX_B64A && encoded == 2 ? ENC_RGBA4444 : (rgb && !deep_rgb_as_422 ? ENC_RGB444 : ENC_YUV422));
 	// an encoded format other than the default of the input format marks the quality word (SampleEncoder.cpp:216-219; QUALITY_H 0x0800 in the header)
 	if (deep_rgb_as_422) quality |= 0x08000000;
@@ -136,6 +140,8 @@ int make_params(EncodeParams &p, int w, int h, uint32_t fmt, int encoded, uint32
 	p.plan.interlaced = interlaced;
 	p.qstate = {0, -1, 0};
 	derive_quantization(&p.plan, quality, p.progressive, 0.0f, &p.qstate);
+	p.gop = gop;
+	if (gop && (!build_gop_plan(&p.gplan, w, h, kind) || !derive_gop_quantization(&p.gplan, quality))) return ERR_BADFORMAT;
 	p.valid = true;
 	return ERR_OKAY;
 }
@@ -382,6 +388,7 @@ struct Encoder {
 	MetaState meta;
 	EncodeBatch batch;
 	bool batch_ready = false;
+	GopBatch gop_batch; bool gop_ready = false; uint32_t gop_calls = 0;      // two-frame groups: calls since CFHD_PrepareToEncode
 	uint32_t frame_number = 0;
 	std::vector<uint8_t> sample; size_t sample_size = 0;
 	StageProfile prof;
@@ -469,6 +476,8 @@ struct Decoder {
 	uint32_t frames_decoded = 0;
 	StageProfile prof;
 	struct DecodeService *service = nullptr; bool service_interlaced = false;
+	// samples of two-frame groups (cfhd_gop.h): the group decodes both frames, the P-frame sample behind it hands out the second one
+	bool gop = false, gop_ready = false, gop_second = false; GopPlan gplan; GopBatch gop_batch;
 };
 
 struct DecMetadata { std::vector<uint8_t> block; size_t cursor = 0; };
@@ -597,6 +606,7 @@ CFHD_Error CFHD_PrepareToEncode(CFHD_EncoderRef ref, int w, int h, CFHD_PixelFor
 		e->params.quality = (int)((0xffff0000u & (uint32_t)e->params.quality) | (0xffffu & (uint32_t)quality));
 		derive_quantization(&e->params.plan, e->params.quality, e->params.progressive, 0.0f, &e->params.qstate);
 		e->batch_ready = false;
+		if (e->params.gop) { if (!derive_gop_quantization(&e->params.gplan, e->params.quality)) return ERR_BADFORMAT; e->gop_ready = false; }
 		return ERR_OKAY;
 	}
 	int rc = make_params(e->params, w, h, fmt, encoded, flags, quality);
@@ -605,6 +615,7 @@ CFHD_Error CFHD_PrepareToEncode(CFHD_EncoderRef ref, int w, int h, CFHD_PixelFor
 	e->frame_number = 0;
 	e->sample.assign(sample_capacity(e->params), 0);
 	e->sample_size = 0;
+	e->gop_calls = 0; e->gop_ready = false;
 	return ERR_OKAY;
 }
 
@@ -617,6 +628,34 @@ CFHD_Error CFHD_EncodeSample(CFHD_EncoderRef ref, void *frame, int pitch)
 	Encoder *e = (Encoder *)ref;
 	if (!e->params.valid) return ERR_CODEC_ERROR;
 	e->meta.handle();
+	if (e->params.gop) {
+		// Two frames per sample (encoder.c:3282-3380): the first call of a sequence answers with the sequence header, the call that completes a
+		// pair with the group, the calls in between with the header of the group's second frame.  Frame numbers: group g carries 2 g + 1,
+		// and so does the P-frame header behind it (pinned on the reference's samples).
+		if (!e->gop_ready) {
+			if (e->gop_batch.prepare(e->params.gplan, false, e->params.pixel_kind)) return ERR_INTERNAL;
+			e->gop_ready = true;
+			e->sample.assign(2 * sample_capacity(e->params), 0);
+		}
+		const uint32_t n = e->gop_calls++;
+		if (e->gop_batch.upload_frame((int)(n & 1u), frame, pitch)) return ERR_INTERNAL;
+		size_t bytes;
+		if (!(n & 1u)) {
+			if (e->gop_batch.wait()) return ERR_INTERNAL;              // the caller's frame is borrowed for the call only: it is in pinned memory now
+			bytes = n == 0 ? write_sequence_header(e->params.gplan, color_format_of(e->params.pixel_kind), e->sample.data(), e->sample.size())
+			               : write_pframe_sample(e->params.gplan, n - 1, e->sample.data(), e->sample.size());
+		} else {
+			if (e->gop_batch.launch_forward() || e->gop_batch.download_coeffs() || e->gop_batch.wait()) return ERR_INTERNAL;
+			MetaBlock global = e->meta.global, local = e->meta.local;
+			meta_remove_hidden(global); meta_remove_hidden(local);
+			SampleHeaderInfo hdr = { n, color_format_of(e->params.pixel_kind), e->params.color_space, e->params.quality, true, global.data(), global.size(), local.data(), local.size() };
+			bytes = write_group_sample(e->params.gplan, hdr, e->gop_batch.host_coeffs(), e->sample.data(), e->sample.size());
+		}
+		e->meta.local.clear();
+		if (!bytes) return ERR_CODEC_ERROR;
+		e->sample_size = bytes;
+		return ERR_OKAY;
+	}
 	if (!e->batch_ready) {
 		if (prepare_batch(e->batch, e->params)) return ERR_INTERNAL;
 		e->batch_ready = true;
@@ -716,6 +755,7 @@ CFHD_Error CFHD_PrepareEncoderPool(CFHD_EncoderPoolRef ref, uint_least16_t w, ui
 	if (!ref) return ERR_INVALID_ARGUMENT;
 	EncoderPool *p = (EncoderPool *)ref;
 	if (p->started) return ERR_UNEXPECTED;
+	if ((uint32_t)flags & 2u) return ERR_BADFORMAT;      // two-frame groups are sequential (a frame pair per sample): the synchronous encoder serves them
 	return make_params(p->params, w, h, fmt, encoded, flags, quality);
 }
 
@@ -912,6 +952,30 @@ CFHD_Error CFHD_PrepareToDecode(CFHD_DecoderRef ref, int, int, CFHD_PixelFormat 
 {
 	if (!ref || !sample) return ERR_INVALID_ARGUMENT;
 	Decoder *d = (Decoder *)ref;
+	{
+		// a stream of two-frame groups starts with a sequence header, or is entered at a group (or at the header of a group's second frame)
+		const uint8_t *s8 = (const uint8_t *)sample;
+		const int first_tag = size >= 4 ? (int16_t)((s8[0] << 8) | s8[1]) : 0, sample_type = size >= 4 ? ((s8[2] << 8) | s8[3]) : 0;
+		ParsedGroup pg;
+		const bool group_stream = first_tag == TAG_SAMPLE && (sample_type == 7 || sample_type == 2 || sample_type == 1);
+		if (group_stream) {
+			// (only the header tags matter here: the caller may pass the first 512 bytes of the sample)
+			(void)parse_group_sample(s8, size < 160 ? size : 160, &pg);
+			if (pg.width <= 0 || pg.height <= 0) return ERR_BADSAMPLE;
+			const int kind = pixel_kind_of(fmt);
+			if ((kind != PIX_YUY2 && kind != PIX_2VUY) || (resolution != 1 && resolution != 0)) return ERR_BADFORMAT;      // packed 8-bit 4:2:2 at full resolution
+			const int display = pg.display_height ? pg.display_height : pg.height;
+			if (!build_gop_plan(&d->gplan, pg.width, display, kind)) return ERR_BADFORMAT;
+			d->gop = true; d->gop_ready = false; d->gop_second = false;
+			d->out_format = fmt; d->out_kind = kind; d->half = false; d->prepared = true;
+			d->plan = FramePlan(); d->plan.width = pg.width; d->plan.height = d->gplan.height; d->plan.display_height = display;
+			if (aw) *aw = pg.width;
+			if (ah) *ah = display;
+			if (af) *af = fmt;
+			return ERR_OKAY;
+		}
+		d->gop = false;
+	}
 	if (parse_sample((const uint8_t *)sample, size, &d->header) < 0) return ERR_BADSAMPLE;
 	// CFHD_DECODED_RESOLUTION_FULL (1; 0 = unknown is taken as full) and _HALF (2): the level-1 lowpass planes shown as the picture
 	// (decoder.c:14124, :26752).  Quarter / thumbnail resolutions are not built.
@@ -988,12 +1052,80 @@ CFHD_Error CFHD_GetImageSize(uint32_t width, uint32_t height, CFHD_PixelFormat f
 
 static CFHD_Error decode_on_handle(Decoder *d, const ParsedSample &ps, const uint8_t *s, size_t size, void *out, int32_t pitch, bool interlaced);
 
+// Samples of a stream of two-frame groups (decoder.c:11180 DecodeSampleGroup, :11426 DecodeSampleFrame): the sequence header changes nothing, the
+// group is decoded whole -- run-length / VLC stage on the host, the inverse transforms on the GPU (GopBatch) -- and gives its first frame, the
+// P-frame sample behind it gives the second.
+static CFHD_Error decode_group_sample(Decoder *d, const uint8_t *s, size_t size, void *out, int32_t pitch)
+{
+	const GopPlan &gp = d->gplan;
+	auto fail_zero = [&](int err) {
+		const int rowbytes = packed_frame_pitch(d->out_kind, gp.width);
+		for (int r = 0; r < gp.display_height; r++) memset((uint8_t *)out + (ptrdiff_t)r * pitch, 0, (size_t)rowbytes);
+		return err;
+	};
+	ParsedGroup pg;
+	const int rc = parse_group_sample(s, size, &pg);
+	if (rc < 0) return fail_zero(ERR_BADSAMPLE);
+	if (pg.sample_type == 7) return ERR_OKAY;                            // sequence header: no picture (the reference leaves the buffer alone too)
+	if (pg.sample_type == 1) {                                           // the second frame of the last group
+		if (!d->gop_second) return fail_zero(ERR_BADSAMPLE);
+		d->gop_batch.finish_frame(1, out, pitch);
+		d->gop_second = false;
+		return ERR_OKAY;
+	}
+	if (pg.sample_type != 2 || pg.width != gp.width || pg.height != gp.height || pg.precision != 10) return fail_zero(ERR_BADSAMPLE);
+	if (!d->gop_ready) {
+		device_select(d->device);
+		const int prc = d->gop_batch.prepare(gp, true, d->out_kind);
+		device_select(-1);
+		if (prc) return ERR_INTERNAL;
+		d->gop_ready = true;
+	}
+	int16_t *coeffs = d->gop_batch.host_coeffs_rw();
+	memset(coeffs, 0, gp.coeff_elems * 2);
+	for (int c = 0; c < 3; c++) {
+		const GopChannel &ch = gp.ch[c];
+		const ParsedBand &lp = pg.lowpass[c];
+		const GopWavelet &top = ch.w[5];
+		if (!lp.present || lp.width != top.width || lp.height != top.height) return fail_zero(ERR_BADSAMPLE);
+		// the bias the reference adds to the lowpass band while unpacking it: twice the intra frame's for a group (decoder.c:12265 `num_frames == 2 ? 48 : 24`)
+		const int bias = 2 * lowpass_bias(10, top.width, d->out_kind);
+		for (int r = 0; r < top.height; r++) {
+			const uint8_t *p = s + lp.offset + (size_t)r * top.width * 2;
+			int16_t *dst = coeffs + top.offset[0] + (size_t)r * top.pitch;
+			for (int x = 0; x < top.width; x++) { int v = (int16_t)((p[2 * x] << 8) | p[2 * x + 1]); v += bias; dst[x] = (int16_t)(v > 0x7fff ? 0x7fff : v); }
+		}
+		static const int coded[5] = { 5, 4, 3, 1, 0 };
+		for (int k : coded) {
+			const GopWavelet &wv = ch.w[k];
+			for (int b = (k == 3 ? 0 : 1); b < 4; b++) {
+				const ParsedBand &pb = pg.band[c][k][b];
+				if (!pb.present || pb.width != wv.width || pb.height != wv.height) return fail_zero(ERR_BADSAMPLE);
+				int16_t *dst = coeffs + wv.offset[b];
+				if (pb.codebook < 0) {                                       // raw 16-bit words (the lowpass band of the temporal highpass wavelet)
+					if ((size_t)pb.bytes < (size_t)wv.width * wv.height * 2) return fail_zero(ERR_BADSAMPLE);
+					for (int r = 0; r < wv.height; r++) {
+						const uint8_t *p = s + pb.offset + (size_t)r * wv.width * 2;
+						for (int x = 0; x < wv.width; x++) dst[(size_t)r * wv.pitch + x] = (int16_t)(((p[2 * x] << 8) | p[2 * x + 1]) * pb.quant);
+					}
+				} else if (vlc_decode_band(s + pb.offset, pb.bytes, wv.width, wv.height, wv.pitch, pb.quant, pb.codebook, dst)) return fail_zero(ERR_BADSAMPLE);
+			}
+		}
+	}
+	if (d->gop_batch.launch_inverse(0x2545F491u * ++d->frames_decoded)) return ERR_INTERNAL;
+	if (d->gop_batch.download_frame(0, nullptr, 0) || d->gop_batch.download_frame(1, nullptr, 0) || d->gop_batch.wait()) return ERR_INTERNAL;
+	d->gop_batch.finish_frame(0, out, pitch);
+	d->gop_second = true;
+	return ERR_OKAY;
+}
+
 CFHD_Error CFHD_DecodeSample(CFHD_DecoderRef ref, void *sample, size_t size, void *out, int32_t pitch)
 {
 	if (!ref || !sample || !out) return ERR_INVALID_ARGUMENT;
 	Decoder *d = (Decoder *)ref;
 	if (!d->prepared) return ERR_UNEXPECTED;
 	const uint8_t *s = (const uint8_t *)sample;
+	if (d->gop) return decode_group_sample(d, s, size, out, pitch);
 	ParsedSample ps;
 	auto fail_zero = [&](int err) {                                               // decode failure zero-fills the output (decoder.c:11850-11859)
 		const int rowbytes = packed_frame_pitch(d->out_kind, d->half ? d->plan.width / 2 : d->plan.width), rows = d->half ? d->plan.display_height / 2 : d->plan.display_height;

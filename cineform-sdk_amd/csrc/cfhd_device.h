@@ -4,6 +4,7 @@
 #include "cfhd_core.h"
 #include "cfhd_bitstream.h"
 #include "cfhd_entropy_gpu.h"
+#include "cfhd_gop.h"
 #include <stdint.h>
 #include <stddef.h>
 #include <vector>
@@ -117,6 +118,37 @@ private:
 	bool timed_ = false;
 	void *evdep_ = nullptr;
 	GpuEntropyDecoder ent_; bool ent_ready_ = false;
+};
+
+// One two-frame group on the GPU (cfhd_gop.h): the kernels of the intra path (level 1 of both frames, the plane transforms of the three spatial
+// wavelets) around the temporal step, forward for the encoder and inverse for the decoder.  The run-length / VLC stage of a group stays on the
+// host (write_group_sample / vlc_decode_band): the coefficient pyramid crosses PCIe, as BASELINE.json's north_star arranges the codec.
+class GopBatch {
+public:
+	GopBatch();
+	~GopBatch();
+	int prepare(const GopPlan &plan, bool decode, int out_pixel_kind);
+	const GopPlan &plan() const { return plan_; }
+	void set_plan(const GopPlan &plan);              // same geometry, new quantizer tables
+	// encoder
+	int upload_frame(int f, const void *frame, int pitch_bytes);      // f = 0, 1: stage one frame of the pair and start its H2D copy
+	int launch_forward();                            // async: level 1 of both frames, temporal step, three spatial transforms per channel
+	int download_coeffs();                           // async: the group pyramid -> pinned host
+	const int16_t *host_coeffs() const { return h_coeff_; }
+	// decoder
+	int16_t *host_coeffs_rw() { return h_coeff_; }   // the host entropy decoder writes the dequantized bands here
+	int launch_inverse(uint32_t dither_seed);        // async: pyramid H2D, three inverse spatial transforms, temporal step, last level of both frames
+	int download_frame(int f, void *out, int pitch_bytes);
+	int finish_frame(int f, void *out, int pitch_bytes);
+	int wait();
+	void release();
+private:
+	void fill_jobs();
+	GopPlan plan_; bool decode_ = false; int out_kind_ = 0, device_ = 0;
+	void *stream_ = nullptr;
+	uint8_t *d_frames_ = nullptr, *h_frames_ = nullptr; size_t frame_bytes_ = 0; int pitch_ = 0, rows_ = 0;
+	int16_t *d_coeff_ = nullptr, *h_coeff_ = nullptr;
+	void *d_jobs_ = nullptr, *h_jobs_ = nullptr; size_t jobs_bytes_ = 0; bool jobs_dirty_ = true;
 };
 
 int packed_frame_pitch(int pixel_kind, int width);     // bytes per row of a tightly packed frame

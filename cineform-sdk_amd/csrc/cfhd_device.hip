@@ -902,4 +902,202 @@ int DecodeBatch::finish_frame(int i, void *out, int pitch)
 	return 0;
 }
 
+// =============================================================================================
+// GopBatch
+// =============================================================================================
+namespace {
+struct GopJobs {            // layout of a GopBatch's job table
+	dev::FwdYuvJob *yuv;        // [2]      level 1 of the two frames
+	dev::GopTemporalJob *temp;  // [3]      per channel
+	dev::FwdPlaneJob *mid;      // [6]      w[3] (from the temporal highpass band) and w[4] (from the lowpass band), per channel
+	dev::FwdPlaneJob *top;      // [3]      w[5]
+	dev::InvPlaneJob *itop;     // [3]      w[5] -> lowpass band of w[4]
+	dev::InvPlaneJob *imid;     // [6]      w[4] -> temporal lowpass, w[3] -> temporal highpass
+	dev::InvYuvJob *iyuv;       // [2]
+};
+GopJobs gop_jobs_at(void *base)
+{
+	GopJobs j;
+	j.yuv = (dev::FwdYuvJob *)base; j.temp = (dev::GopTemporalJob *)(j.yuv + 2); j.mid = (dev::FwdPlaneJob *)(j.temp + 3); j.top = j.mid + 6;
+	j.itop = (dev::InvPlaneJob *)(j.top + 3); j.imid = j.itop + 3; j.iyuv = (dev::InvYuvJob *)(j.imid + 6);
+	return j;
+}
+size_t gop_jobs_bytes() { return 2 * sizeof(dev::FwdYuvJob) + 3 * sizeof(dev::GopTemporalJob) + 9 * sizeof(dev::FwdPlaneJob) + 9 * sizeof(dev::InvPlaneJob) + 2 * sizeof(dev::InvYuvJob); }
+}
+
+GopBatch::GopBatch() {}
+GopBatch::~GopBatch() { release(); }
+
+void GopBatch::release()
+{
+	(void)hipSetDevice(device_);
+	if (stream_) hipStreamSynchronize((hipStream_t)stream_);
+	if (d_frames_) hipFree(d_frames_);
+	if (h_frames_) hipHostFree(h_frames_);
+	if (d_coeff_) hipFree(d_coeff_);
+	if (h_coeff_) hipHostFree(h_coeff_);
+	if (d_jobs_) hipFree(d_jobs_);
+	if (h_jobs_) hipHostFree(h_jobs_);
+	if (stream_) hipStreamDestroy((hipStream_t)stream_);
+	d_frames_ = h_frames_ = nullptr; d_coeff_ = h_coeff_ = nullptr; d_jobs_ = h_jobs_ = nullptr; stream_ = nullptr;
+}
+
+int GopBatch::prepare(const GopPlan &plan, bool decode, int out_pixel_kind)
+{
+	int rc = device_init();
+	if (rc) return rc;
+	release();
+	device_ = device_current(); (void)hipSetDevice(device_);
+	plan_ = plan; decode_ = decode; out_kind_ = out_pixel_kind;
+	HIPCHK(hipStreamCreateWithFlags((hipStream_t *)&stream_, hipStreamNonBlocking));
+	pitch_ = packed_frame_pitch(decode ? out_pixel_kind : plan.pixel_kind, plan.width); rows_ = plan.display_height;
+	frame_bytes_ = (size_t)pitch_ * rows_;
+	HIPCHK(hipMalloc((void **)&d_frames_, 2 * frame_bytes_));
+	HIPCHK(hipHostMalloc((void **)&h_frames_, 2 * frame_bytes_, hipHostMallocPortable));
+	HIPCHK(hipMalloc((void **)&d_coeff_, plan.coeff_elems * 2));
+	HIPCHK(hipMemsetAsync(d_coeff_, 0, plan.coeff_elems * 2, (hipStream_t)stream_));      // pad columns stay zero forever
+	HIPCHK(hipHostMalloc((void **)&h_coeff_, plan.coeff_elems * 2, hipHostMallocPortable));
+	memset(h_coeff_, 0, plan.coeff_elems * 2);
+	jobs_bytes_ = gop_jobs_bytes();
+	HIPCHK(hipMalloc(&d_jobs_, jobs_bytes_));
+	HIPCHK(hipHostMalloc(&h_jobs_, jobs_bytes_, hipHostMallocPortable));
+	memset(h_jobs_, 0, jobs_bytes_);
+	fill_jobs();
+	return 0;
+}
+
+void GopBatch::set_plan(const GopPlan &plan)
+{
+	if (stream_) (void)hipStreamSynchronize((hipStream_t)stream_);
+	plan_ = plan;
+	fill_jobs();
+}
+
+void GopBatch::fill_jobs()
+{
+	const GopPlan &plan = plan_;
+	GopJobs j = gop_jobs_at(h_jobs_);
+	const int mpq = plan.midpoint_prequant;
+	int16_t *base = d_coeff_;
+	for (int f = 0; f < 2; f++) {
+		dev::FwdYuvJob &y = j.yuv[f];
+		y.in = d_frames_ + frame_bytes_ * f; y.in_pitch = pitch_;
+		y.width = plan.width; y.height = plan.height; y.display_height = plan.display_height;
+		y.uyvy = plan.pixel_kind == PIX_2VUY; y.shift = plan.precision - 8;
+		dev::InvYuvJob &iy = j.iyuv[f];
+		for (int c = 0; c < 3; c++) {
+			const GopWavelet &w = plan.ch[c].w[f];
+			y.out_pitch[c] = w.pitch; iy.band_pitch[c] = w.pitch;
+			for (int b = 0; b < 4; b++) { y.out[c][b] = base + w.offset[b]; y.q[c][b] = make_q(w.quant[b], mpq); iy.band[c][b] = base + w.offset[b]; }
+		}
+		iy.width = plan.ch[0].w[f].width; iy.height = plan.ch[0].w[f].height; iy.display_height = plan.display_height;
+		iy.uyvy = out_kind_ == PIX_2VUY; iy.shift = plan.precision - 8; iy.dither_seed = 0x9E3779B9u * (uint32_t)(f + 1);
+		iy.out = d_frames_ + frame_bytes_ * f; iy.out_pitch = pitch_;
+	}
+	auto fwd = [&](dev::FwdPlaneJob &p, const int16_t *in, const GopWavelet &src, const GopWavelet &dst) {
+		p.in = in; p.in_pitch = src.pitch; p.width = src.width; p.height = src.height; p.prescale = dst.prescale;
+		p.xstride = 1; p.shift = 0; p.display_height = src.height; p.compand = 0; p.layout = 0; p.tail_from = 0;
+		p.out_pitch = dst.pitch;
+		for (int b = 0; b < 4; b++) { p.out[b] = base + dst.offset[b]; p.q[b] = make_q(dst.quant[b], mpq); }
+	};
+	auto inv = [&](dev::InvPlaneJob &p, const GopWavelet &src, int16_t *out, int out_pitch) {
+		memset(&p, 0, sizeof(p));
+		for (int b = 0; b < 4; b++) p.band[b] = base + src.offset[b];
+		p.band_pitch = src.pitch; p.width = src.width; p.height = src.height; p.descale = src.prescale;
+		p.out = out; p.out_pitch = out_pitch; p.xstride = 1; p.precision = 0; p.display_height = 2 * src.height;
+	};
+	for (int c = 0; c < 3; c++) {
+		const GopChannel &ch = plan.ch[c];
+		dev::GopTemporalJob &t = j.temp[c];
+		t.pitch = ch.w[2].pitch; t.height = ch.w[2].height; t.width = ch.w[2].width;
+		if (!decode_) { t.a = base + ch.w[0].offset[0]; t.b = base + ch.w[1].offset[0]; t.x = base + ch.w[2].offset[0]; t.y = base + ch.w[2].offset[1]; }
+		else { t.a = base + ch.w[2].offset[0]; t.b = base + ch.w[2].offset[1]; t.x = base + ch.w[0].offset[0]; t.y = base + ch.w[1].offset[0]; }
+		fwd(j.mid[2 * c], base + ch.w[2].offset[1], ch.w[2], ch.w[3]);      // the temporal highpass band
+		fwd(j.mid[2 * c + 1], base + ch.w[2].offset[0], ch.w[2], ch.w[4]);  // the temporal lowpass band
+		fwd(j.top[c], base + ch.w[4].offset[0], ch.w[4], ch.w[5]);
+		inv(j.itop[c], ch.w[5], base + ch.w[4].offset[0], ch.w[4].pitch);
+		inv(j.imid[2 * c], ch.w[4], base + ch.w[2].offset[0], ch.w[2].pitch);
+		inv(j.imid[2 * c + 1], ch.w[3], base + ch.w[2].offset[1], ch.w[2].pitch);
+	}
+	jobs_dirty_ = true;
+}
+
+int GopBatch::upload_frame(int f, const void *frame, int pitch)
+{
+	(void)hipSetDevice(device_);
+	if (decode_ || f < 0 || f > 1) return -1;
+	const uint8_t *src = (const uint8_t *)frame;
+	if (pitch < 0) { src += (ptrdiff_t)(rows_ - 1) * pitch; pitch = -pitch; }     // encoder.c:1957
+	uint8_t *dst = h_frames_ + frame_bytes_ * f;
+	if (pitch == pitch_) memcpy(dst, src, frame_bytes_);
+	else for (int r = 0; r < rows_; r++) memcpy(dst + (size_t)r * pitch_, src + (size_t)r * pitch, (size_t)pitch_);
+	HIPCHK(hipMemcpyAsync(d_frames_ + frame_bytes_ * f, dst, frame_bytes_, hipMemcpyHostToDevice, (hipStream_t)stream_));
+	return 0;
+}
+
+int GopBatch::launch_forward()
+{
+	(void)hipSetDevice(device_);
+	hipStream_t st = (hipStream_t)stream_;
+	if (jobs_dirty_) { HIPCHK(hipMemcpyAsync(d_jobs_, h_jobs_, jobs_bytes_, hipMemcpyHostToDevice, st)); jobs_dirty_ = false; }
+	GopJobs j = gop_jobs_at(d_jobs_);
+	(void)hipGetLastError();
+	dev::k_fwd_yuv422<<<dim3((plan_.width / 2 + dev::TW - 1) / dev::TW, (plan_.height / 2 + dev::TH - 1) / dev::TH, 2), dev::NTHREADS, 0, st>>>(j.yuv);
+	const GopWavelet &t = plan_.ch[0].w[2];
+	dev::k_gop_temporal_fwd<<<dim3((unsigned)((t.pitch * t.height / 2 + dev::NTHREADS - 1) / dev::NTHREADS), 3), dev::NTHREADS, 0, st>>>(j.temp);
+	dev::k_fwd_plane<<<dim3((t.width / 2 + dev::TW - 1) / dev::TW, (t.height / 2 + dev::TH - 1) / dev::TH, 6), dev::NTHREADS, 0, st>>>(j.mid);
+	const GopWavelet &m = plan_.ch[0].w[4];
+	dev::k_fwd_plane<<<dim3((m.width / 2 + dev::TW - 1) / dev::TW, (m.height / 2 + dev::TH - 1) / dev::TH, 3), dev::NTHREADS, 0, st>>>(j.top);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+
+int GopBatch::download_coeffs()
+{
+	(void)hipSetDevice(device_);
+	HIPCHK(hipMemcpyAsync(h_coeff_, d_coeff_, plan_.coeff_elems * 2, hipMemcpyDeviceToHost, (hipStream_t)stream_));
+	return 0;
+}
+
+int GopBatch::launch_inverse(uint32_t dither_seed)
+{
+	(void)hipSetDevice(device_);
+	hipStream_t st = (hipStream_t)stream_;
+	if (jobs_dirty_) { HIPCHK(hipMemcpyAsync(d_jobs_, h_jobs_, jobs_bytes_, hipMemcpyHostToDevice, st)); jobs_dirty_ = false; }
+	HIPCHK(hipMemcpyAsync(d_coeff_, h_coeff_, plan_.coeff_elems * 2, hipMemcpyHostToDevice, st));
+	GopJobs j = gop_jobs_at(d_jobs_);
+	(void)hipGetLastError();
+	const GopWavelet &top = plan_.ch[0].w[5], &mid = plan_.ch[0].w[4], &t = plan_.ch[0].w[2], &l1 = plan_.ch[0].w[0];
+	dev::k_inv_plane<<<dim3((top.width + dev::ITW - 1) / dev::ITW, (top.height + dev::ITH - 1) / dev::ITH, 3), dev::NTHREADS, 0, st>>>(j.itop);
+	dev::k_inv_plane<<<dim3((mid.width + dev::ITW - 1) / dev::ITW, (mid.height + dev::ITH - 1) / dev::ITH, 6), dev::NTHREADS, 0, st>>>(j.imid);
+	dev::k_gop_temporal_inv<<<dim3((unsigned)((t.pitch * t.height / 2 + dev::NTHREADS - 1) / dev::NTHREADS), 3), dev::NTHREADS, 0, st>>>(j.temp);
+	dev::k_inv_yuv422<<<dim3((l1.width + dev::ITW - 1) / dev::ITW, (l1.height + dev::ITH - 1) / dev::ITH, 2), dev::NTHREADS, 0, st>>>(j.iyuv, dither_seed);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+
+int GopBatch::download_frame(int f, void *, int)
+{
+	(void)hipSetDevice(device_);
+	if (!decode_ || f < 0 || f > 1) return -1;
+	HIPCHK(hipMemcpyAsync(h_frames_ + frame_bytes_ * f, d_frames_ + frame_bytes_ * f, frame_bytes_, hipMemcpyDeviceToHost, (hipStream_t)stream_));
+	return 0;
+}
+
+int GopBatch::finish_frame(int f, void *out, int pitch)
+{
+	if (!decode_ || f < 0 || f > 1) return -1;
+	const uint8_t *src = h_frames_ + frame_bytes_ * f;
+	if (pitch == pitch_) memcpy(out, src, frame_bytes_);
+	else for (int r = 0; r < rows_; r++) memcpy((uint8_t *)out + (ptrdiff_t)r * pitch, src + (size_t)r * pitch_, (size_t)pitch_);
+	return 0;
+}
+
+int GopBatch::wait()
+{
+	(void)hipSetDevice(device_);
+	HIPCHK(hipStreamSynchronize((hipStream_t)stream_));
+	return 0;
+}
+
 } // namespace cfhd

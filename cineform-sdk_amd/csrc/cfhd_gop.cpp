@@ -1,0 +1,385 @@
+// cfhd_gop.cpp -- see cfhd_gop.h: plan, quantizer tables and sample syntax of the two-frame group (host code).
+#include "cfhd_gop.h"
+#include <string.h>
+
+namespace cfhd {
+
+void derive_subband_tables_for_gop(FramePlan *plan, int quality, QuantState *st, int out[4][17], int *factor, int *new_quality);   // cfhd_tables.cpp
+
+bool build_gop_plan(GopPlan *plan, int width, int height, int pixel_kind)
+{
+	if (width <= 0 || height <= 0 || width > kMaxFrameDim || height > kMaxFrameDim) return false;
+	if (pixel_kind != PIX_YUY2 && pixel_kind != PIX_2VUY) return false;              // CFHD_ENCODING_FLAGS_YUV_2FRAME_GOP: "YUV 4:2:2 only" (CFHDTypes.h:254)
+	const int enc_height = (height + 7) & ~7;                                        // encoder.c:1569-1571
+	// the chroma planes halve once per level on whole pairs: level 1, the two levels on the temporal lowpass band
+	if ((width / 2) % 8 || width % 16) return false;
+	plan->width = width; plan->height = enc_height; plan->display_height = height;
+	plan->num_channels = 3; plan->precision = 10; plan->pixel_kind = pixel_kind;
+	size_t at = 0;
+	auto pitch_of = [](int w) { return (w + 7) & ~7; };
+	for (int c = 0; c < 3; c++) {
+		GopChannel &ch = plan->ch[c];
+		ch.width = c == 0 ? width : width / 2; ch.height = enc_height;
+		// type, level, bands, divisor of the channel's dimensions
+		static const int type[kGopWavelets] = { 5, 5, 4, 3, 3, 3 }, level[kGopWavelets] = { 1, 1, 2, 3, 3, 4 }, nb[kGopWavelets] = { 4, 4, 2, 4, 4, 4 }, div[kGopWavelets] = { 2, 2, 2, 4, 4, 8 };
+		for (int k = 0; k < kGopWavelets; k++) {
+			GopWavelet &w = ch.w[k];
+			w.type = type[k]; w.level = level[k]; w.nbands = nb[k];
+			if (ch.width % div[k] || ch.height % div[k]) return false;
+			w.width = ch.width / div[k]; w.height = ch.height / div[k]; w.pitch = pitch_of(w.width);
+			for (int b = 0; b < 4; b++) {
+				w.offset[b] = at; w.quant[b] = 1; w.scale[b] = 0;
+				if (b < w.nbands) at += ((size_t)w.pitch * w.height + 63) & ~(size_t)63;      // bands start on 128-byte boundaries
+			}
+			w.prescale = 0;
+		}
+		ch.w[4].prescale = 2;                                                           // 10-bit FIELDPLUS: {0, 0, 0, 0, 2, 0, 0, 0} (wavelet.c:1745)
+		// wavelet.c:7142 SetTransformScale, TRANSFORM_TYPE_FIELDPLUS
+		const int frame_scale[4] = { 4, 2, 2, 1 };
+		for (int k = 0; k < 2; k++) for (int b = 0; b < 4; b++) ch.w[k].scale[b] = frame_scale[b];
+		ch.w[2].scale[0] = 2 * frame_scale[0]; ch.w[2].scale[1] = frame_scale[0];
+		auto spatial = [](GopWavelet &w, int s) { w.scale[0] = 4 * s; w.scale[1] = 2 * s; w.scale[2] = 2 * s; w.scale[3] = s; };
+		spatial(ch.w[3], ch.w[2].scale[1]);
+		spatial(ch.w[4], ch.w[2].scale[0]);
+		spatial(ch.w[5], ch.w[4].scale[0]);
+	}
+	plan->coeff_elems = at;
+	return true;
+}
+
+bool derive_gop_quantization(GopPlan *plan, int quality)
+{
+	// the subband tables of QuantizationSetQuality, before any sample exists (no rate feedback: see the header)
+	FramePlan fp;
+	if (!build_frame_plan(&fp, plan->width, plan->display_height, plan->pixel_kind, ENC_YUV422)) return false;
+	QuantState st = { 0, -1, 0 };
+	int tabs[4][17], factor, new_quality;
+	derive_subband_tables_for_gop(&fp, quality, &st, tabs, &factor, &new_quality);
+	{
+		// the same question quantizer_is_static() asks of the intra tables: would a (large) previous sample move them?
+		QuantState big = st; big.lastgopbitcount = (int64_t)plan->width * plan->height * 64;
+		int t2[4][17], f2, q2;
+		FramePlan fp2 = fp;
+		derive_subband_tables_for_gop(&fp2, quality, &big, t2, &f2, &q2);
+		if (memcmp(tabs, t2, sizeof(tabs)) != 0) return false;
+		// the bit-rate limiter of LOW .. HIGH at <= 1080p (quantize.c:2994) is rate feedback too
+		if (factor != 0 && !(plan->width > 1920 || plan->height > 1080 || new_quality > 3)) return false;
+	}
+	plan->midpoint_prequant = fp.midpoint_prequant;
+	const int mpq = plan->midpoint_prequant;
+	auto midpoint = [&](int q) { if (mpq) { q *= mpq; q /= (mpq - 1) * 2; } else q /= 2; return q; };
+	for (int c = 0; c < 3; c++) {
+		const int *quant = tabs[c ? 1 : 0];
+		GopChannel &ch = plan->ch[c];
+		int subband = 1;
+		// quantize.c:3480: the two spatial wavelets on the temporal lowpass band, top first (VSCALE(q, qmax, 256) = 256 q; quantScaleFactor 2)
+		for (int k = 5; k >= 4; k--) {
+			ch.w[k].quant[0] = 1;
+			for (int b = 1; b < 4; b++, subband++) {
+				int q = ((quant[subband] * 256 * ch.w[k].scale[b]) >> 8) >> 2;
+				if (!(quality & 0x10000000)) q = midpoint(q);
+				ch.w[k].quant[b] = q;
+			}
+		}
+		subband++;                                                                    // subband 7: the lowpass band of w[3], kept at 1 for 10-bit sources (encoder.c:8538)
+		ch.w[3].quant[0] = 1;
+		for (int b = 1; b < 4; b++, subband++) {
+			int q = ((quant[subband] * 256 * ch.w[3].scale[b]) >> 8) >> 2;
+			if (!(quality & 0x10000000)) q = midpoint(q);
+			ch.w[3].quant[b] = q;
+		}
+		ch.w[2].quant[0] = ch.w[2].quant[1] = 1;
+		for (int k = 1; k >= 0; k--) {                                                // the frame wavelets: frame 1 first (subbands 11-13), then frame 0
+			ch.w[k].quant[0] = 1;
+			for (int b = 1; b < 4; b++, subband++) ch.w[k].quant[b] = midpoint((quant[subband] * 256) >> 8);
+		}
+	}
+	return true;
+}
+
+// ------------------------------------------------------------------------------------------
+// Writer
+// ------------------------------------------------------------------------------------------
+namespace {
+void put_band_header(BitWriter &w, int band, const GopWavelet &wv, int subband, int encoding)
+{
+	w.put_tag(TAG_MARKER, MARK_BAND_START);
+	w.put_tag(TAG_BAND_NUMBER, band);
+	w.put_tag(TAG_BAND_CODING_FLAGS, 1);                 // code set 17, no difference coding (encoder.c:6120 SetCodingFlags for a progressive group)
+	w.put_tag(TAG_BAND_WIDTH, wv.width);
+	w.put_tag(TAG_BAND_HEIGHT, wv.height);
+	w.put_tag(TAG_BAND_SUBBAND, subband);
+	w.put_tag(TAG_BAND_ENCODING, encoding);
+	w.put_tag(TAG_BAND_QUANTIZATION, wv.quant[band]);
+	w.put_tag(TAG_BAND_SCALE, wv.scale[band]);
+	w.size_push(TAG_SUBBAND_SIZE);
+	w.put_tag(TAG_BAND_HEADER, 0);
+}
+void put_wavelet_header(BitWriter &w, const GopWavelet &wv, int number)
+{
+	w.put_tag(TAG_MARKER, MARK_HIGHPASS_START);
+	w.put_tag(TAG_WAVELET_TYPE, wv.type);
+	w.put_tag(TAG_WAVELET_NUMBER, number);
+	w.put_tag(TAG_WAVELET_LEVEL, wv.level);
+	w.put_tag(TAG_NUM_BANDS, wv.nbands);
+	w.put_tag(TAG_HIGHPASS_WIDTH, wv.width);
+	w.put_tag(TAG_HIGHPASS_HEIGHT, wv.height);
+	w.put_tag(TAG_LOWPASS_BORDER, 0);
+	w.put_tag(TAG_HIGHPASS_BORDER, 0);
+	w.put_tag(TAG_LOWPASS_SCALE, wv.scale[0]);
+	w.put_tag(TAG_LOWPASS_DIVISOR, 0);
+	w.size_push(TAG_LEVEL_SIZE);
+}
+void put_raw16(BitWriter &w, const int16_t *band, int width, int height, int pitch)
+{
+	// 16-bit big-endian coefficients, row after row without the pitch padding (encoder.c:4423 lowpass, :5850 EncodeQuant16s)
+	for (int r = 0; r < height; r++)
+		for (int x = 0; x < width; x++) w.put_bits((uint16_t)band[(size_t)r * pitch + x], 16);
+}
+}
+
+size_t write_group_sample(const GopPlan &plan, const SampleHeaderInfo &hdr, const int16_t *coeffs, uint8_t *out, size_t cap)
+{
+	BitWriter w(out, cap);
+	const int nch = plan.num_channels;
+	// --- PutVideoGroupHeader (codec.c:835) ---
+	w.put_tag(TAG_SAMPLE, 2);                            // SAMPLE_TYPE_GROUP
+	w.put_tag(TAG_INDEX, nch);
+	const size_t index_at = w.bytes();
+	for (int i = 0; i < nch; i++) w.put_tag(TAG_ENTRY, i);
+	w.put_tag(TAG_TRANSFORM_TYPE, 2);                    // TRANSFORM_TYPE_FIELDPLUS
+	w.put_tag(TAG_NUM_FRAMES, 2);
+	w.put_tag(TAG_NUM_CHANNELS, nch);
+	w.put_tag_opt(TAG_INPUT_FORMAT, hdr.input_format);
+	{ const int cs = hdr.color_space & ~4; if (cs) w.put_tag_opt(TAG_ENCODED_COLORSPACE, cs); }
+	w.put_tag(TAG_NUM_WAVELETS, kGopWavelets);
+	w.put_tag(TAG_NUM_SUBBANDS, kGopSubbands);
+	w.put_tag(TAG_NUM_SPATIAL, 3);
+	w.put_tag(TAG_FIRST_WAVELET, 3);
+	w.put_tag(TAG_FRAME_WIDTH, plan.width);
+	w.put_tag(TAG_FRAME_HEIGHT, plan.height);
+	w.put_tag_opt(TAG_FRAME_NUMBER, (int)(hdr.frame_number & 0xffff));
+	w.put_tag(TAG_PRECISION, plan.precision);
+	w.put_tag_opt(TAG_FRAME_DISPLAY_HEIGHT, plan.display_height);
+	w.put_tag_opt(TAG_VERSION, (10 << 12) | (1 << 8) | 0);
+	w.put_tag_opt(TAG_QUALITY_L, hdr.encoder_quality & 0xffff);
+	w.put_tag_opt(TAG_QUALITY_H, (hdr.encoder_quality >> 16) & 0xffff);
+	{
+		unsigned table = 0;
+		for (int k = 0; k < kGopWavelets; k++) table += (unsigned)plan.ch[0].w[k].prescale << (14 - 2 * k);
+		w.put_tag_opt(TAG_PRESCALE_TABLE, (int)table);     // the decoder's built-in FIELDPLUS default: optional (codec.c:1040)
+	}
+	if (hdr.channel_number_tag) w.put_tag_opt(TAG_ENCODED_CHANNEL_NUMBER, 0);
+	// --- EncodeQuantizedGroup (encoder.c:7559-7620) ---
+	w.size_push(TAG_SAMPLE_SIZE);
+	auto put_metadata = [&](const uint8_t *block, size_t size) {
+		if (!block || !size) return;
+		w.put_tag_opt(TAG_METADATA, (int)(size >> 2));
+		w.put_bytes(block, size);
+	};
+	put_metadata(hdr.meta_global, hdr.meta_global_size);
+	put_metadata(hdr.meta_local, hdr.meta_local_size);
+	{
+		uint8_t freespace[512];
+		memset(freespace, 0, sizeof(freespace));
+		memcpy(freespace, "FREE", 4);
+		freespace[4] = (uint8_t)(504 & 0xff); freespace[5] = (uint8_t)(504 >> 8);
+		put_metadata(freespace, sizeof(freespace));
+	}
+	w.put_tag_opt(TAG_INTERLACED_FLAGS, 0);
+	w.put_tag_opt(TAG_PROTECTION_FLAGS, 0);
+	w.put_tag_opt(TAG_PICTURE_ASPECT_X, 16);
+	w.put_tag_opt(TAG_PICTURE_ASPECT_Y, 9);
+	if (hdr.progressive) w.put_tag(TAG_SAMPLE_FLAGS, 1);
+
+	for (int c = 0; c < nch; c++) {
+		const GopChannel &ch = plan.ch[c];
+		if (c > 0) { w.put_tag(TAG_SAMPLE, SAMPLE_TYPE_CHANNEL); w.put_tag(TAG_CHANNEL, c); }
+		const size_t ch_start = w.bytes();
+		// --- the sample's lowpass band: w[5]'s (encoder.c:4251) ---
+		const GopWavelet &top = ch.w[5];
+		w.put_tag(TAG_MARKER, MARK_LOWPASS_START);
+		w.put_tag(TAG_LOWPASS_SUBBAND, 0);
+		w.put_tag(TAG_NUM_LEVELS, 4);
+		w.put_tag(TAG_LOWPASS_WIDTH, top.width);
+		w.put_tag(TAG_LOWPASS_HEIGHT, top.height);
+		w.put_tag(TAG_MARGIN_LEFT, 0); w.put_tag(TAG_MARGIN_TOP, 0); w.put_tag(TAG_MARGIN_RIGHT, 0); w.put_tag(TAG_MARGIN_BOTTOM, 0);
+		w.put_tag(TAG_PIXEL_OFFSET, 0);
+		w.put_tag(TAG_QUANTIZATION, 1);
+		w.put_tag(TAG_PIXEL_DEPTH, 16);
+		w.size_push(TAG_SUBBAND_SIZE);
+		w.put_tag(TAG_MARKER, MARK_COEFF_START);
+		put_raw16(w, coeffs + top.offset[0], top.width, top.height, top.pitch);
+		w.pad32();
+		w.put_tag(TAG_MARKER, MARK_LOWPASS_END);
+		w.size_pop();
+		// --- EncodeQuantizedFieldPlusTransform (encoder.c:8078) ---
+		int subband = 1;
+		for (int k = 5; k >= 4; k--) {                     // the spatial wavelets on the temporal lowpass band
+			const GopWavelet &wv = ch.w[k];
+			put_wavelet_header(w, wv, k + 1);
+			for (int b = 1; b < 4; b++, subband++) {
+				put_band_header(w, b, wv, subband, 3);         // BAND_ENCODING_RUNLENGTHS
+				vlc_encode_band(w, coeffs + wv.offset[b], wv.width, wv.height, wv.pitch, 1, wv.quant[b]);
+				w.put_tag(TAG_BAND_TRAILER, 0);
+				w.size_pop();
+			}
+			w.put_tag(TAG_MARKER, MARK_HIGHPASS_END);
+			w.size_pop();
+		}
+		{                                                  // the spatial wavelet on the temporal highpass band: all four bands, the lowpass one as raw words
+			const GopWavelet &wv = ch.w[3];
+			put_wavelet_header(w, wv, 4);
+			for (int b = 0; b < 4; b++, subband++) {
+				put_band_header(w, b, wv, subband, b == 0 ? 4 : 3);      // BAND_ENCODING_16BIT for the lowpass band (encoder.c:8219, precision >= 10)
+				if (b == 0) {
+					put_raw16(w, coeffs + wv.offset[0], wv.width, wv.height, wv.pitch);
+					// FinishEncodeBand: the band end code of code set 17, padded to a whole word
+					vlc_encode_band(w, nullptr, 0, 0, 0, 1, 1);
+				} else vlc_encode_band(w, coeffs + wv.offset[b], wv.width, wv.height, wv.pitch, 1, wv.quant[b]);
+				w.put_tag(TAG_BAND_TRAILER, 0);
+				w.size_pop();
+			}
+			w.put_tag(TAG_MARKER, MARK_HIGHPASS_END);
+			w.size_pop();
+		}
+		{                                                  // the temporal wavelet: a header and one empty band (encoder.c:6607 EncodeEmptyQuantBand, subband 255)
+			const GopWavelet &wv = ch.w[2];
+			put_wavelet_header(w, wv, 3);
+			put_band_header(w, 1, wv, 255, 3);
+			w.put_tag(TAG_BAND_TRAILER, 0);
+			w.size_pop();
+			w.put_tag(TAG_MARKER, MARK_HIGHPASS_END);
+			w.size_pop();
+		}
+		for (int k = 1; k >= 0; k--) {                     // the frame wavelets, the second frame first
+			const GopWavelet &wv = ch.w[k];
+			put_wavelet_header(w, wv, k + 1);
+			for (int b = 1; b < 4; b++, subband++) {
+				put_band_header(w, b, wv, subband, 3);
+				vlc_encode_band(w, coeffs + wv.offset[b], wv.width, wv.height, wv.pitch, 1, wv.quant[b]);
+				w.put_tag(TAG_BAND_TRAILER, 0);
+				w.size_pop();
+			}
+			w.put_tag(TAG_MARKER, MARK_HIGHPASS_END);
+			w.size_pop();
+		}
+		// the channel's size in the index (encoder.c:7828: bytes, big-endian)
+		w.patch32(index_at + 4 * (size_t)c, (uint32_t)(w.bytes() - ch_start));
+	}
+	// --- PutVideoGroupTrailer (codec.c:1075) ---
+	w.put_tag(TAG_SAMPLE, 6);                            // SAMPLE_TYPE_GROUP_TRAILER
+	w.put_tag(TAG_GROUP_TRAILER, 0);
+	w.size_pop();
+	return w.overflow() ? 0 : w.bytes();
+}
+
+size_t write_sequence_header(const GopPlan &plan, int input_format, uint8_t *out, size_t cap)
+{
+	BitWriter w(out, cap);
+	w.put_tag(TAG_SAMPLE, 7);                            // SAMPLE_TYPE_SEQUENCE_HEADER (codec.c:736)
+	w.put_tag(5, 0); w.put_tag(6, 1); w.put_tag(7, 0); w.put_tag(8, 0);      // version 0.1.0.0 (encoder.c:2930)
+	w.put_tag(9, 0);                                     // sequence flags
+	w.put_tag(TAG_FRAME_WIDTH, plan.width);
+	w.put_tag(TAG_FRAME_HEIGHT, plan.height);
+	w.put_tag(TAG_FRAME_FORMAT, 2);                       // (the reference writes 2 for YUY2 and 2vuy alike: pinned on its samples)
+	w.put_tag_opt(TAG_INPUT_FORMAT, input_format);
+	return w.overflow() ? 0 : w.bytes();
+}
+
+size_t write_pframe_sample(const GopPlan &plan, uint32_t frame_number, uint8_t *out, size_t cap)
+{
+	BitWriter w(out, cap);
+	w.put_tag(TAG_SAMPLE, 1);                            // SAMPLE_TYPE_FRAME (codec.c:1258)
+	w.put_tag(TAG_FRAME_TYPE, 2);                        // FRAME_TYPE_PFRAME
+	w.put_tag(TAG_FRAME_WIDTH, plan.width);
+	w.put_tag(TAG_FRAME_HEIGHT, plan.height);
+	w.put_tag_opt(TAG_FRAME_NUMBER, (int)(frame_number & 0xffff));
+	w.put_tag(TAG_FRAME_INDEX, 1);
+	return w.overflow() ? 0 : w.bytes();
+}
+
+// ------------------------------------------------------------------------------------------
+// Parser
+// ------------------------------------------------------------------------------------------
+int parse_group_sample(const uint8_t *d, size_t size, ParsedGroup *pg)
+{
+	*pg = ParsedGroup();
+	memset(pg->lowpass, 0, sizeof(pg->lowpass));
+	memset(pg->band, 0, sizeof(pg->band));
+	size_t pos = 0;
+	int channel = 0, wavelet = -1, band = 0, bw = 0, bh = 0, bq = 1, bflags = 0, bsub = 0, benc = 3, lw = 0, lh = 0;
+	uint32_t pending = 0; size_t pending_at = 0;
+	bool first = true;
+	auto rd = [&](size_t o) { return ((uint32_t)d[o] << 24) | ((uint32_t)d[o + 1] << 16) | ((uint32_t)d[o + 2] << 8) | d[o + 3]; };
+	while (pos + 4 <= size) {
+		const uint32_t word = rd(pos);
+		int tag = (int16_t)(word >> 16);
+		const int value = (int)(word & 0xffff);
+		if (tag < 0) tag = -tag;
+		pos += 4;
+		if (first) { if (tag != TAG_SAMPLE) return -1; pg->sample_type = value; first = false; if (value != 2) { /* keep reading the few header tags */ } continue; }
+		if (tag & 0x4000) {
+			const uint32_t bytes = (tag & 0x2000) ? ((((uint32_t)(tag & 0xff) << 16) | (uint32_t)value) * 4) : (uint32_t)value * 4;
+			if (pos + bytes > size) return -2;
+			pos += bytes;
+			continue;
+		}
+		if (tag & 0x2000) {
+			const uint32_t longs = ((uint32_t)(tag & 0xff) << 16) | (uint32_t)value;
+			if ((tag & 0xff00) == 0x2000) { pending = longs * 4; pending_at = pos; }
+			continue;
+		}
+		switch (tag) {
+		case TAG_SAMPLE: break;                            // channel headers, the group trailer
+		case TAG_INDEX: pos += 4 * (size_t)value; break;
+		case TAG_CHANNEL: channel = value; if (channel < 0 || channel >= 3) return -3; break;
+		case TAG_NUM_CHANNELS: pg->num_channels = value; break;
+		case TAG_INPUT_FORMAT: pg->input_format = value; break;
+		case TAG_FRAME_WIDTH: pg->width = value; break;
+		case TAG_FRAME_HEIGHT: pg->height = value; break;
+		case TAG_FRAME_DISPLAY_HEIGHT: pg->display_height = value; break;
+		case TAG_FRAME_NUMBER: pg->frame_number = value; break;
+		case TAG_PRECISION: pg->precision = value; break;
+		case TAG_SAMPLE_FLAGS: pg->progressive = value & 1; break;
+		case TAG_LOWPASS_WIDTH: lw = value; break;
+		case TAG_LOWPASS_HEIGHT: lh = value; break;
+		case TAG_MARKER:
+			if (value == MARK_COEFF_START) {
+				ParsedBand &pb = pg->lowpass[channel];
+				pb.offset = (uint32_t)pos; pb.width = lw; pb.height = lh; pb.quant = 1; pb.present = true; pb.bytes = (uint32_t)((size_t)lw * lh * 2);
+				if (!pending) return -4;
+				const size_t end = pending_at + pending;
+				if (pos + pb.bytes > end || end > size) return -4;
+				pos = end; pending = 0;
+			}
+			break;
+		case TAG_WAVELET_NUMBER: wavelet = value - 1; if (wavelet < 0 || wavelet >= kGopWavelets) return -5; break;
+		case TAG_BAND_NUMBER: band = value; if (band < 0 || band > 3) return -6; bflags = 0; benc = 3; break;
+		case TAG_BAND_CODING_FLAGS: bflags = value; break;
+		case TAG_BAND_WIDTH: bw = value; break;
+		case TAG_BAND_HEIGHT: bh = value; break;
+		case TAG_BAND_SUBBAND: bsub = value; break;
+		case TAG_BAND_ENCODING: benc = value; break;
+		case TAG_BAND_QUANTIZATION: bq = value; break;
+		case TAG_BAND_HEADER: {
+			if (wavelet < 0 || !pending) return -7;
+			ParsedBand &pb = pg->band[channel][wavelet][band];
+			const size_t end = pending_at + pending;
+			if (end < pos + 4 || end > size) return -7;
+			pb.offset = (uint32_t)pos; pb.bytes = (uint32_t)(end - 4 - pos);
+			pb.width = bw; pb.height = bh; pb.quant = bq; pb.subband = bsub; pb.present = true;
+			pb.codebook = benc == 4 ? -1 : (bflags & 0xf);      // -1: raw 16-bit words (BAND_ENCODING_16BIT)
+			pb.difference = false; pb.peak_level = 0; pb.peak_offset = 0;
+			pos = end; pending = 0;
+			break; }
+		default: break;
+		}
+	}
+	if (pg->sample_type != 2) return 1;
+	if (pg->display_height == 0) pg->display_height = pg->height;
+	if (!(pg->width > 0 && pg->height > 0 && pg->num_channels == 3)) return -1;
+	return 0;
+}
+
+} // namespace cfhd

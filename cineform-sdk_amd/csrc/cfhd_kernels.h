@@ -2123,5 +2123,45 @@ __global__ void __launch_bounds__(NTHREADS) k_unpack_byr4(const BayerJob *jobs)
 	job.out[3][o] = (int16_t)((g1 - g2 + 2 * mid) >> 1);
 }
 
+// =============================================================================================
+// Two-frame group (cfhd_gop.h): the temporal step between the level-1 lowpass bands of the two frames
+// =============================================================================================
+// Forward (Codec/temporal.c:498 FilterTemporal16s): low = sat16(a + b), high = sat16(b - a) -- _mm_adds_epi16 / _mm_subs_epi16 in the reference,
+// v_pk_add_i16 / v_pk_sub_i16 with clamp here.  The planes of a job share pitch and height (pad columns are zero in, zero out).
+// Inverse (Codec/wavelet.c TransformInverseTemporal): frame 0 = sat16(low - high) >> 1, frame 1 = sat16(low + high) >> 1 in the columns the
+// reference's 8-wide loop covers; the `width % 8` tail columns divide by two towards zero instead (its scalar loop).
+struct GopTemporalJob { const int16_t *a, *b; int16_t *x, *y; int pitch, height, width; };
+__global__ void __launch_bounds__(NTHREADS) k_gop_temporal_fwd(const GopTemporalJob *jobs)
+{
+	const GopTemporalJob job = jobs[blockIdx.y];
+	const int ndw = job.pitch * job.height / 2;
+	const uint32_t *a = (const uint32_t *)job.a, *b = (const uint32_t *)job.b;
+	uint32_t *lo = (uint32_t *)job.x, *hi = (uint32_t *)job.y;
+	for (int i = (int)(blockIdx.x * NTHREADS + threadIdx.x); i < ndw; i += (int)(gridDim.x * NTHREADS)) {
+		const uint32_t va = a[i], vb = b[i];
+		lo[i] = pk_adds(va, vb);
+		hi[i] = pk_subs(vb, va);
+	}
+}
+__global__ void __launch_bounds__(NTHREADS) k_gop_temporal_inv(const GopTemporalJob *jobs)
+{
+	const GopTemporalJob job = jobs[blockIdx.y];
+	const int ndw = job.pitch * job.height / 2, row_dw = job.pitch / 2;
+	const int tail_from = job.width - job.width % 8;       // first column of the reference's scalar loop
+	const uint32_t *lo = (const uint32_t *)job.a, *hi = (const uint32_t *)job.b;
+	uint32_t *f0 = (uint32_t *)job.x, *f1 = (uint32_t *)job.y;
+	for (int i = (int)(blockIdx.x * NTHREADS + threadIdx.x); i < ndw; i += (int)(gridDim.x * NTHREADS)) {
+		const uint32_t l = lo[i], h = hi[i];
+		uint32_t even = pk_sra(pk_subs(l, h), 1), odd = pk_sra(pk_adds(l, h), 1);
+		const int col = 2 * (i % row_dw);
+		if (col >= tail_from) {                               // (low +- high) / 2 in 32-bit arithmetic, rounded towards zero
+			const int l0 = (int)(int16_t)(l & 0xffffu), l1 = (int)(int16_t)(l >> 16), h0 = (int)(int16_t)(h & 0xffffu), h1 = (int)(int16_t)(h >> 16);
+			even = (uint32_t)(uint16_t)(int16_t)((l0 - h0) / 2) | ((uint32_t)(uint16_t)(int16_t)((l1 - h1) / 2) << 16);
+			odd = (uint32_t)(uint16_t)(int16_t)((l0 + h0) / 2) | ((uint32_t)(uint16_t)(int16_t)((l1 + h1) / 2) << 16);
+		}
+		f0[i] = even; f1[i] = odd;
+	}
+}
+
 } // namespace dev
 } // namespace cfhd

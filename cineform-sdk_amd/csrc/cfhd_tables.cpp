@@ -309,9 +309,87 @@ const int kChromaQ[4][17] = {
 };
 }
 
+// The subband divisors before they are dealt to the bands of a wavelet tree (QuantizationSetQuality quantize.c:186 up to the intra remap at :548):
+// out[0] luma, [1] chroma, [2] luma under the bit-rate limiter, [3] chroma under it -- 17 entries each, the numbering of the 2-frame group.
+static void derive_subband_tables(FramePlan *plan, int quality, bool progressive, QuantState *st, int out[4][17], int *factor_out, int *new_quality_out);
+
 void derive_quantization(FramePlan *plan, int quality, bool progressive, float framerate, QuantState *st)
 {
-	int qL[17], qC[17], qLmax[17], qCmax[17];
+	int tabs[4][17], factor, newQuality;
+	derive_subband_tables(plan, quality, progressive, st, tabs, &factor, &newQuality);
+	int *qL = tabs[0], *qC = tabs[1], *qLmax = tabs[2], *qCmax = tabs[3];
+	const int precision = plan->precision;
+	const int mpq = plan->midpoint_prequant;
+	(void)precision;
+	// an intra frame has no temporal wavelet: its level-2 bands take the divisors of the group's frame wavelets (quantize.c:548-565)
+	for (int i = 0; i < 3; i++) { qL[7 + i] = qL[11 + i]; qC[7 + i] = qC[11 + i]; qLmax[7 + i] = qLmax[11 + i]; qCmax[7 + i] = qCmax[11 + i]; }
+	const int fixedQuality = factor;     // 0 => bitrate mode (not supported: treated as quality 3 tables w/o VBR)
+
+	plan->prescale[0] = 0; plan->prescale[1] = precision >= 10 ? 2 : 0; plan->prescale[2] = precision == 12 ? 2 : 0;
+
+	// Bit-rate limiter (quantize.c:2994-3100): active only for qualities <= HIGH on <= 1080p 3-channel YUV.
+	int64_t prevbits = st->lastgopbitcount;
+	float fr = (framerate > 10.0f && framerate < 120.0f) ? framerate : 30.0f;
+	int currentbitrate = (int)((float)(int32_t)prevbits * fr);
+	bool limiter_on = fixedQuality != 0 && !(plan->width > 1920 || plan->height > 1080 || plan->num_channels > 3 ||
+	                                          newQuality > 3 || plan->encoded_format == ENC_RGB444);
+	if (st->overbitrate < 0 || st->overbitrate > 16) st->overbitrate = 0;
+
+	for (int c = 0; c < plan->num_channels; c++) {
+		int quant[17], quantMAX[17];
+		memcpy(quant, c ? qC : qL, sizeof(quant)); memcpy(quantMAX, c ? qCmax : qLmax, sizeof(quantMAX));
+		if (limiter_on) {
+			const int BR_LIMIT = 130000000, BR_STEPS = 10000000;
+			int upper = fixedQuality == 1 ? BR_LIMIT - 2 * BR_STEPS : (fixedQuality == 3 ? BR_LIMIT + 2 * BR_STEPS : BR_LIMIT);
+			if (currentbitrate > upper) {
+				memcpy(quant, quantMAX, sizeof(quant));
+				if (c == 0) {
+					if (st->overbitrate == 0) st->overbitrate = 1;
+					if (currentbitrate > upper * 12 / 10) st->overbitrate++;
+					if (st->overbitrate > 16) st->overbitrate = 16;
+				}
+			} else if (st->overbitrate > 0) {
+				if (c == 0) {
+					if (st->overbitrate > 1 && currentbitrate < upper) st->overbitrate--;
+					else if (st->overbitrate == 1 && currentbitrate < upper * 8 / 10) st->overbitrate = 0;
+				}
+				if (st->overbitrate > 0) memcpy(quant, quantMAX, sizeof(quant));
+			}
+			if (st->overbitrate > 1) {
+				int rc = st->overbitrate - 1;
+				if (progressive) { for (int i = 11; i < 17; i++) quant[i] = (quant[i] * (rc + 4)) >> 2; }
+				else {
+					for (int i : {11, 14}) quant[i] = (quant[i] * (rc + 4)) >> 2;
+					for (int i : {12, 15, 13, 16}) quant[i] = (quant[i] * (rc / 8 + 4)) >> 2;
+				}
+			}
+		}
+		ChannelPlan &cp = plan->ch[c];
+		int scale[3][4] = {{4, 2, 2, 1}};
+		for (int k = 1; k < 3; k++) { int s = scale[k - 1][0]; scale[k][0] = 4 * s; scale[k][1] = 2 * s; scale[k][2] = 2 * s; scale[k][3] = s; }
+		for (int k = 0; k < 3; k++) for (int b = 0; b < 4; b++) { cp.band[k][b].scale = scale[k][b]; }
+		int subband = 1;
+		auto midpoint = [&](int q) { if (mpq) { q *= mpq; q /= (mpq - 1) * 2; } else q /= 2; return q; };
+		for (int index = 2; index >= 1; index--) {
+			cp.band[index][0].quant = 1;
+			for (int b = 1; b < 4; b++, subband++) {
+				int vscale = (quantMAX[subband] - quant[subband]) * 256 - 256 * quantMAX[subband] + 512 * quant[subband];
+				int q = ((vscale * scale[index][b]) >> 8) >> 2;
+				if (!(quality & 0x10000000)) q = midpoint(q);
+				cp.band[index][b].quant = q;
+			}
+		}
+		cp.band[0][0].quant = 1;
+		for (int b = 1; b < 4; b++, subband++) {
+			int vscale = (quantMAX[subband] - quant[subband]) * 256 - 256 * quantMAX[subband] + 512 * quant[subband];
+			cp.band[0][b].quant = midpoint(vscale >> 8);
+		}
+	}
+}
+
+static void derive_subband_tables(FramePlan *plan, int quality, bool progressive, QuantState *st, int out[4][17], int *factor_out, int *new_quality_out)
+{
+	int *qL = out[0], *qC = out[1], *qLmax = out[2], *qCmax = out[3];
 	// Bayer input: the encoder pins the RGB quality bits before it derives the tables ("prevent increased quant on channels 1-3",
 	// encoder.c:2638); the sample header keeps the caller's quality word
 	if (plan->encoded_format == ENC_BAYER) quality |= 3 << 25;
@@ -383,69 +461,13 @@ void derive_quantization(FramePlan *plan, int quality, bool progressive, float f
 		if (factor == 2) for (int i : {12, 13, 15, 16}) { qLmax[i] = qL[i]; qCmax[i] = qC[i]; }
 		for (int *a : {qL, qC, qLmax, qCmax}) { a[11] = a[11] * 3 / 2; a[12] = a[12] * 2 / 3; a[14] = a[14] * 3 / 2; a[15] = a[15] * 2 / 3; }
 	}
-	for (int i = 0; i < 3; i++) { qL[7 + i] = qL[11 + i]; qC[7 + i] = qC[11 + i]; qLmax[7 + i] = qLmax[11 + i]; qCmax[7 + i] = qCmax[11 + i]; }
-	const int fixedQuality = factor;     // 0 => bitrate mode (not supported: treated as quality 3 tables w/o VBR)
+	*factor_out = factor; *new_quality_out = newQuality;
+}
 
-	plan->prescale[0] = 0; plan->prescale[1] = precision >= 10 ? 2 : 0; plan->prescale[2] = precision == 12 ? 2 : 0;
-
-	// Bit-rate limiter (quantize.c:2994-3100): active only for qualities <= HIGH on <= 1080p 3-channel YUV.
-	int64_t prevbits = st->lastgopbitcount;
-	float fr = (framerate > 10.0f && framerate < 120.0f) ? framerate : 30.0f;
-	int currentbitrate = (int)((float)(int32_t)prevbits * fr);
-	bool limiter_on = fixedQuality != 0 && !(plan->width > 1920 || plan->height > 1080 || plan->num_channels > 3 ||
-	                                          newQuality > 3 || plan->encoded_format == ENC_RGB444);
-	if (st->overbitrate < 0 || st->overbitrate > 16) st->overbitrate = 0;
-
-	for (int c = 0; c < plan->num_channels; c++) {
-		int quant[17], quantMAX[17];
-		memcpy(quant, c ? qC : qL, sizeof(quant)); memcpy(quantMAX, c ? qCmax : qLmax, sizeof(quantMAX));
-		if (limiter_on) {
-			const int BR_LIMIT = 130000000, BR_STEPS = 10000000;
-			int upper = fixedQuality == 1 ? BR_LIMIT - 2 * BR_STEPS : (fixedQuality == 3 ? BR_LIMIT + 2 * BR_STEPS : BR_LIMIT);
-			if (currentbitrate > upper) {
-				memcpy(quant, quantMAX, sizeof(quant));
-				if (c == 0) {
-					if (st->overbitrate == 0) st->overbitrate = 1;
-					if (currentbitrate > upper * 12 / 10) st->overbitrate++;
-					if (st->overbitrate > 16) st->overbitrate = 16;
-				}
-			} else if (st->overbitrate > 0) {
-				if (c == 0) {
-					if (st->overbitrate > 1 && currentbitrate < upper) st->overbitrate--;
-					else if (st->overbitrate == 1 && currentbitrate < upper * 8 / 10) st->overbitrate = 0;
-				}
-				if (st->overbitrate > 0) memcpy(quant, quantMAX, sizeof(quant));
-			}
-			if (st->overbitrate > 1) {
-				int rc = st->overbitrate - 1;
-				if (progressive) { for (int i = 11; i < 17; i++) quant[i] = (quant[i] * (rc + 4)) >> 2; }
-				else {
-					for (int i : {11, 14}) quant[i] = (quant[i] * (rc + 4)) >> 2;
-					for (int i : {12, 15, 13, 16}) quant[i] = (quant[i] * (rc / 8 + 4)) >> 2;
-				}
-			}
-		}
-		ChannelPlan &cp = plan->ch[c];
-		int scale[3][4] = {{4, 2, 2, 1}};
-		for (int k = 1; k < 3; k++) { int s = scale[k - 1][0]; scale[k][0] = 4 * s; scale[k][1] = 2 * s; scale[k][2] = 2 * s; scale[k][3] = s; }
-		for (int k = 0; k < 3; k++) for (int b = 0; b < 4; b++) { cp.band[k][b].scale = scale[k][b]; }
-		int subband = 1;
-		auto midpoint = [&](int q) { if (mpq) { q *= mpq; q /= (mpq - 1) * 2; } else q /= 2; return q; };
-		for (int index = 2; index >= 1; index--) {
-			cp.band[index][0].quant = 1;
-			for (int b = 1; b < 4; b++, subband++) {
-				int vscale = (quantMAX[subband] - quant[subband]) * 256 - 256 * quantMAX[subband] + 512 * quant[subband];
-				int q = ((vscale * scale[index][b]) >> 8) >> 2;
-				if (!(quality & 0x10000000)) q = midpoint(q);
-				cp.band[index][b].quant = q;
-			}
-		}
-		cp.band[0][0].quant = 1;
-		for (int b = 1; b < 4; b++, subband++) {
-			int vscale = (quantMAX[subband] - quant[subband]) * 256 - 256 * quantMAX[subband] + 512 * quant[subband];
-			cp.band[0][b].quant = midpoint(vscale >> 8);
-		}
-	}
+// (cfhd_gop.cpp) the tables of a progressive two-frame group: the same derivation, without the intra remap
+void derive_subband_tables_for_gop(FramePlan *plan, int quality, QuantState *st, int out[4][17], int *factor, int *new_quality)
+{
+	derive_subband_tables(plan, quality, true, st, out, factor, new_quality);
 }
 
 int unit_device(int i, int ndevices, const char *pinned_env, const char *list_env)

@@ -286,7 +286,7 @@ def hooks():
     global _hooks
     if _hooks is None:
         csrc = os.path.join(PRODUCT_DIR, "csrc")
-        srcs = [os.path.join(ROOT, "tests", "hooks", "cfhd_hooks.cpp")] + [os.path.join(csrc, f) for f in ("cfhd_tables.cpp", "cfhd_bitstream.cpp", "cfhd_metadata.cpp")]
+        srcs = [os.path.join(ROOT, "tests", "hooks", "cfhd_hooks.cpp")] + [os.path.join(csrc, f) for f in ("cfhd_tables.cpp", "cfhd_bitstream.cpp", "cfhd_metadata.cpp", "cfhd_gop.cpp")]
         deps = srcs + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".h")]
         if not os.path.exists(HOOKS_SO) or any(os.path.getmtime(d) > os.path.getmtime(HOOKS_SO) for d in deps):
             os.makedirs(os.path.dirname(HOOKS_SO), exist_ok=True)
@@ -623,7 +623,7 @@ def emu():
         if not os.path.exists(EMU_SO) or any(os.path.getmtime(d) > os.path.getmtime(EMU_SO) for d in deps):
             os.makedirs(os.path.dirname(EMU_SO), exist_ok=True)
             csrc = os.path.join(PRODUCT_DIR, "csrc")
-            host = [os.path.join(csrc, f) for f in ("cfhd_tables.cpp", "cfhd_bitstream.cpp")]      # host-only product sources the entropy emulation needs
+            host = [os.path.join(csrc, f) for f in ("cfhd_tables.cpp", "cfhd_bitstream.cpp", "cfhd_gop.cpp")]      # host-only product sources the entropy emulation needs
             _build_once(EMU_SO, ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + os.path.dirname(src), "-I" + csrc, src] + host, deps)
         _emu = ctypes.CDLL(EMU_SO)
     return _emu
@@ -798,3 +798,126 @@ def psnr_yuy2(a, b):
     d = a.astype(np.float64) - b.astype(np.float64)
     mse = np.mean(d * d)
     return 99.0 if mse == 0 else 10 * np.log10(255.0 * 255.0 / mse)
+
+
+# ------------------------------------------------------------------------------------------
+# Two-frame group (CFHD_ENCODING_FLAGS_YUV_2FRAME_GOP; cineform-sdk_amd/csrc/cfhd_gop.h)
+# ------------------------------------------------------------------------------------------
+ENCODING_FLAGS_2FRAME_GOP = 2       # Common/CFHDTypes.h:254
+
+
+class GopPlan:
+    """Python view of cfhd::GopPlan (six wavelets per channel) as the product derives it."""
+
+    def __init__(self, width, height, pixkind=1, quality=QUALITY_FILMSCAN1):
+        L = hooks()
+        L.cfhd_amd_gop_plan_info.argtypes = [ctypes.c_int] * 4 + [ctypes.POINTER(ctypes.c_longlong)]
+        buf = (ctypes.c_longlong * 512)()
+        n = L.cfhd_amd_gop_plan_info(width, height, pixkind, quality, buf)
+        assert n > 0, "gop_plan_info failed"
+        v = list(buf[:n])
+        self.coeff_elems, self.enc_height, self.mpq = v[0:3]
+        self.width, self.height, self.pixkind, self.quality = width, height, pixkind, quality
+        self.w = {}
+        i = 3
+        for c in range(3):
+            for k in range(6):
+                d = dict(zip(("type", "level", "nbands", "width", "height", "pitch", "prescale"), v[i:i + 7])); i += 7
+                d["offset"] = []; d["quant"] = []; d["scale"] = []
+                for b in range(4):
+                    d["offset"].append(v[i]); d["quant"].append(v[i + 1]); d["scale"].append(v[i + 2]); i += 3
+                self.w[(c, k)] = d
+
+    def view(self, coeffs, c, k, b):
+        d = self.w[(c, k)]
+        o = d["offset"][b]
+        return coeffs[o: o + d["pitch"] * d["height"]].reshape(d["height"], d["pitch"])
+
+
+def oracle_forward_gop(gp, frame0, frame1, pitch, uyvy=0):
+    """The group transform with the oracle (oracle/cfhd_oracle_fwd.c for the spatial steps; the temporal step is a saturating sum /
+    difference, Codec/temporal.c:498), written into the product's group pyramid layout."""
+    O = oracle()
+    coeffs = np.zeros(gp.coeff_elems, dtype=np.int16)
+    H = gp.enc_height
+    for f, frame in enumerate((frame0, frame1)):
+        if H != gp.height:
+            padded = np.full(H * pitch, 0x80, dtype=np.uint8); padded[: gp.height * pitch] = np.asarray(frame).reshape(-1)[: gp.height * pitch]; frame = padded
+        for c in range(3):
+            d = gp.w[(c, f)]
+            outs = [gp.view(coeffs, c, f, b) for b in range(4)]
+            bands = (c_i16p * 4)(*[o.ctypes.data_as(c_i16p) for o in outs])
+            cw = gp.width if c == 0 else gp.width // 2
+            O.orc_fwd_spatial_yuv422(p8(np.ascontiguousarray(frame)), pitch, cw, H, c, 2, uyvy, iarr(d["quant"]), gp.mpq, bands, d["pitch"])
+    def spatial(c, src, dst):
+        d = gp.w[(c, dst)]
+        outs = [gp.view(coeffs, c, dst, b) for b in range(4)]
+        bands = (c_i16p * 4)(*[o.ctypes.data_as(c_i16p) for o in outs])
+        srcc = np.ascontiguousarray(src)
+        O.orc_fwd_spatial(srcc.ctypes.data_as(c_i16p), srcc.shape[1], 2 * d["width"], 2 * d["height"], d["prescale"], iarr(d["quant"]), gp.mpq, bands, d["pitch"])
+    for c in range(3):
+        a = gp.view(coeffs, c, 0, 0).astype(np.int32); b = gp.view(coeffs, c, 1, 0).astype(np.int32)
+        gp.view(coeffs, c, 2, 0)[:] = np.clip(a + b, -32768, 32767).astype(np.int16)
+        gp.view(coeffs, c, 2, 1)[:] = np.clip(b - a, -32768, 32767).astype(np.int16)
+        # (pad columns: zero in both inputs, zero in both outputs)
+        spatial(c, gp.view(coeffs, c, 2, 1), 3)
+        spatial(c, gp.view(coeffs, c, 2, 0), 4)
+        spatial(c, gp.view(coeffs, c, 4, 0), 5)
+    return coeffs
+
+
+def product_write_gop_host(gp, kind, coeffs=None, frame_number=1, meta_global=b""):
+    """kind 0: group sample from a group pyramid; 1: sequence header; 2: P-frame sample -- the product's host writer."""
+    L = hooks()
+    L.cfhd_amd_write_gop_host.restype = ctypes.c_size_t
+    L.cfhd_amd_write_gop_host.argtypes = [ctypes.c_int] * 5 + [ctypes.c_uint, c_i16p, c_u8p, ctypes.c_size_t, c_u8p, ctypes.c_size_t]
+    out = np.zeros(gp.width * gp.enc_height * 4 + 65536, dtype=np.uint8)
+    mg = np.frombuffer(meta_global, dtype=np.uint8).copy() if meta_global else np.zeros(4, np.uint8)
+    cf = coeffs if coeffs is not None else np.zeros(8, np.int16)
+    n = L.cfhd_amd_write_gop_host(kind, gp.width, gp.height, gp.pixkind, gp.quality, frame_number, p16(cf), p8(mg), len(meta_global), p8(out), out.size)
+    assert n > 0
+    return out[:n].tobytes()
+
+
+def host_decode_group(sample, gp):
+    """Dequantized group pyramid of a group sample via the product's host parser + VLC decoder (CPU only)."""
+    L = hooks()
+    L.cfhd_amd_decode_group_host.argtypes = [c_u8p, ctypes.c_size_t, ctypes.c_int, c_i16p, ctypes.c_size_t]
+    out = np.zeros(gp.coeff_elems, dtype=np.int16)
+    sb = np.frombuffer(sample, dtype=np.uint8).copy()
+    rc = L.cfhd_amd_decode_group_host(p8(sb), len(sample), gp.pixkind, p16(out), out.size)
+    assert rc == 0, "decode_group_host -> %d" % rc
+    return out
+
+
+def oracle_inverse_gop(gp, coeffs, dither, uyvy=0):
+    """The inverse group transform with the oracle from a dequantized group pyramid: spatial synthesis of w[5], w[4], w[3] (orc_inv_spatial,
+    the descale variant where the encoder prescaled), the temporal step of Codec/wavelet.c TransformInverseTemporal (frame 0 = sat(low - high)
+    >> 1, frame 1 = sat(low + high) >> 1; the width % 8 tail columns divide towards zero), the last level of both frames.  Returns two
+    packed 8-bit 4:2:2 pictures."""
+    O = oracle()
+    work = coeffs.copy()
+    def inv(c, k, dst_k, dst_b):
+        d = gp.w[(c, k)]
+        bands = (c_i16p * 4)(*[gp.view(work, c, k, b).ctypes.data_as(c_i16p) for b in range(4)])
+        dst = gp.view(work, c, dst_k, dst_b)
+        O.orc_inv_spatial(bands, d["pitch"], d["width"], d["height"], d["prescale"], dst.ctypes.data_as(c_i16p), gp.w[(c, dst_k)]["pitch"])
+    for c in range(3):
+        inv(c, 5, 4, 0); inv(c, 4, 2, 0); inv(c, 3, 2, 1)
+        d = gp.w[(c, 2)]
+        lo = gp.view(work, c, 2, 0).astype(np.int32); hi = gp.view(work, c, 2, 1).astype(np.int32)
+        even = np.clip(lo - hi, -32768, 32767) >> 1; odd = np.clip(lo + hi, -32768, 32767) >> 1
+        tail = d["width"] - d["width"] % 8
+        if tail < d["width"]:
+            tz = lambda v: np.where(v < 0, -((-v) // 2), v // 2)
+            even[:, tail:] = tz(lo[:, tail:] - hi[:, tail:]); odd[:, tail:] = tz(lo[:, tail:] + hi[:, tail:])
+        gp.view(work, c, 0, 0)[:] = even.astype(np.int16); gp.view(work, c, 1, 0)[:] = odd.astype(np.int16)
+    outs = []
+    for f in range(2):
+        ptrs = (c_i16p * 12)(*[gp.view(work, c, f, b).ctypes.data_as(c_i16p) for c in range(3) for b in range(4)])
+        pitches = [gp.w[(c, f)]["pitch"] for c in range(3)]
+        w = gp.w[(0, f)]["width"]; h = gp.w[(0, f)]["height"]
+        out = np.zeros((2 * h, 4 * w), np.uint8)
+        O.orc_inv_spatial_to_yuv422(ptrs, iarr(pitches), w, h, 10, uyvy, dither, p8(out), 4 * w)
+        outs.append(out)
+    return outs

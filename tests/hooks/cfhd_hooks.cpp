@@ -4,6 +4,7 @@
 // (cfhd_tables.cpp, cfhd_bitstream.cpp, cfhd_metadata.cpp); not linked into libcfhd_amd.so.
 #include "cfhd_core.h"
 #include "cfhd_bitstream.h"
+#include "cfhd_gop.h"
 #include <string.h>
 #include <vector>
 
@@ -29,6 +30,73 @@ int cfhd_amd_plan_info(int width, int height, int pixel_kind, int encoded_format
 				out[n++] = d.width; out[n++] = d.height; out[n++] = d.pitch; out[n++] = (int)d.offset; out[n++] = d.quant; out[n++] = d.scale;
 			}
 	return n;
+}
+
+// Two-frame group (cfhd_gop.h): plan geometry + quantizer as the product derives them.  out: coeff_elems, then per channel, per wavelet (6):
+// type, level, nbands, width, height, pitch, prescale, then per band (4): offset, quant, scale.  Returns the number of ints, -1 when the
+// geometry / quality is not served.
+int cfhd_amd_gop_plan_info(int width, int height, int pixel_kind, int quality, long long *out)
+{
+	GopPlan plan;
+	if (!build_gop_plan(&plan, width, height, pixel_kind) || !derive_gop_quantization(&plan, quality)) return -1;
+	int n = 0;
+	out[n++] = (long long)plan.coeff_elems; out[n++] = plan.height; out[n++] = plan.midpoint_prequant;
+	for (int c = 0; c < 3; c++)
+		for (int k = 0; k < kGopWavelets; k++) {
+			const GopWavelet &w = plan.ch[c].w[k];
+			out[n++] = w.type; out[n++] = w.level; out[n++] = w.nbands; out[n++] = w.width; out[n++] = w.height; out[n++] = w.pitch; out[n++] = w.prescale;
+			for (int b = 0; b < 4; b++) { out[n++] = (long long)w.offset[b]; out[n++] = w.quant[b]; out[n++] = w.scale[b]; }
+		}
+	return n;
+}
+// The group sample / sequence header / P-frame sample from a group pyramid (host writer).  kind 0 group, 1 sequence header, 2 P-frame.
+size_t cfhd_amd_write_gop_host(int kind, int width, int height, int pixel_kind, int quality, unsigned frame_number, const int16_t *coeffs,
+                               const uint8_t *meta_global, size_t meta_global_size, uint8_t *out, size_t cap)
+{
+	GopPlan plan;
+	if (!build_gop_plan(&plan, width, height, pixel_kind) || !derive_gop_quantization(&plan, quality)) return 0;
+	const int input_format = pixel_kind == PIX_2VUY ? 1 : 2;
+	if (kind == 1) return write_sequence_header(plan, input_format, out, cap);
+	if (kind == 2) return write_pframe_sample(plan, frame_number, out, cap);
+	SampleHeaderInfo hdr = { frame_number, input_format, 2, quality, true, meta_global, meta_global_size, nullptr, 0 };
+	return write_group_sample(plan, hdr, coeffs, out, cap);
+}
+
+// The dequantized group pyramid of a group sample (host parser + host VLC decoder; lowpass bias as the reference's decoder applies it to groups
+// for 8-bit output).  0 on success.
+int cfhd_amd_decode_group_host(const uint8_t *sample, size_t size, int pixel_kind, int16_t *coeffs, size_t coeff_elems)
+{
+	ParsedGroup pg;
+	if (parse_group_sample(sample, size, &pg) != 0) return -1;
+	GopPlan gp;
+	if (!build_gop_plan(&gp, pg.width, pg.display_height ? pg.display_height : pg.height, pixel_kind) || gp.coeff_elems != coeff_elems) return -2;
+	memset(coeffs, 0, coeff_elems * 2);
+	for (int c = 0; c < 3; c++) {
+		const GopWavelet &top = gp.ch[c].w[5];
+		const ParsedBand &lp = pg.lowpass[c];
+		if (!lp.present || lp.width != top.width || lp.height != top.height) return -3;
+		const int bias = 2 * lowpass_bias(10, top.width, pixel_kind);
+		for (int r = 0; r < top.height; r++)
+			for (int x = 0; x < top.width; x++) {
+				const uint8_t *p = sample + lp.offset + ((size_t)r * top.width + x) * 2;
+				int v = (int16_t)((p[0] << 8) | p[1]); v += bias;
+				coeffs[top.offset[0] + (size_t)r * top.pitch + x] = (int16_t)(v > 0x7fff ? 0x7fff : v);
+			}
+		static const int coded[5] = { 5, 4, 3, 1, 0 };
+		for (int k : coded) {
+			const GopWavelet &wv = gp.ch[c].w[k];
+			for (int b = (k == 3 ? 0 : 1); b < 4; b++) {
+				const ParsedBand &pb = pg.band[c][k][b];
+				if (!pb.present || pb.width != wv.width || pb.height != wv.height) return -4;
+				int16_t *dst = coeffs + wv.offset[b];
+				if (pb.codebook < 0) {
+					for (int r = 0; r < wv.height; r++)
+						for (int x = 0; x < wv.width; x++) { const uint8_t *p = sample + pb.offset + ((size_t)r * wv.width + x) * 2; dst[(size_t)r * wv.pitch + x] = (int16_t)(((p[0] << 8) | p[1]) * pb.quant); }
+				} else if (vlc_decode_band(sample + pb.offset, pb.bytes, wv.width, wv.height, wv.pitch, pb.quant, pb.codebook, dst)) return -5;
+			}
+		}
+	}
+	return 0;
 }
 
 // The device an encoder-pool worker / decoder handle is dealt (cfhd_core.h unit_device): host logic, no GPU involved.

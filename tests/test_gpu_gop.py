@@ -1,0 +1,88 @@
+"""Two-frame groups on the GPU through the C ABI: CFHD_EncodeSample with CFHD_ENCODING_FLAGS_YUV_2FRAME_GOP gives
+the reference encoder's samples byte for byte (sequence header, groups, P-frame headers); CFHD_DecodeSample decodes the reference's group
+samples to pictures inside the dither interval of the exact reconstruction (the oracle's inverse model, tests/test_gop.py)."""
+import ctypes
+import numpy as np
+import pytest
+from cfhd_testlib import *
+
+pytestmark = pytest.mark.gpu
+
+
+def _frames(w, h, n, fmt):
+    fr = [synth_yuy2(w, h, 70 + i)[0] for i in range(n)]
+    if fmt == PIX_2VUY: fr = [f.reshape(-1, 2)[:, ::-1].reshape(-1).copy() for f in fr]
+    return fr
+
+
+@pytest.mark.parametrize("w,h,fmt", [(320, 240, PIX_YUY2), (720, 486, PIX_2VUY), (1920, 1080, PIX_YUY2)])
+def test_gop_encode_bitstream_identical(w, h, fmt):
+    assert have_ref(), "oracle/_ref/libcfhd_ref.so is missing"
+    frames = _frames(w, h, 6, fmt) if (w, h) != (1920, 1080) else qbist_frames(10, 6, w, h)[0]
+    mine = amd_encode_frames(frames, w * 2, w, h, fmt, flags=ENCODING_FLAGS_2FRAME_GOP)
+    refs = ref_encode_frames(frames, w * 2, w, h, pixfmt=fmt, flags=ENCODING_FLAGS_2FRAME_GOP)
+    assert [len(s) for s in mine] == [len(s) for s in refs]
+    for i, (a, b) in enumerate(zip(mine, refs)):
+        assert mask_volatile_metadata(a) == mask_volatile_metadata(b), "sample %d differs from the reference" % i
+
+
+def test_gop_gates():
+    L = product()
+    enc = ctypes.c_void_p(); assert L.CFHD_OpenEncoder(ctypes.byref(enc), None) == 0
+    assert L.CFHD_PrepareToEncode(enc, 320, 240, PIX_YUY2, ENCODED_YUV422, ENCODING_FLAGS_2FRAME_GOP | 1, QUALITY_FILMSCAN1) == 3     # interlaced groups: not built
+    assert L.CFHD_PrepareToEncode(enc, 320, 240, PIX_RG48, ENCODED_RGB444, ENCODING_FLAGS_2FRAME_GOP, QUALITY_FILMSCAN1) == 3        # 4:2:2 only
+    assert L.CFHD_PrepareToEncode(enc, 320, 240, PIX_YUY2, ENCODED_YUV422, ENCODING_FLAGS_2FRAME_GOP, 5) == 3                       # rate feedback (FILMSCAN2)
+    assert L.CFHD_PrepareToEncode(enc, 320, 240, PIX_YUY2, ENCODED_YUV422, ENCODING_FLAGS_2FRAME_GOP, QUALITY_FILMSCAN1) == 0
+    L.CFHD_CloseEncoder(enc)
+    pool = ctypes.c_void_p(); assert L.CFHD_CreateEncoderPool(ctypes.byref(pool), 2, 2, None) == 0
+    assert L.CFHD_PrepareEncoderPool(pool, 320, 240, PIX_YUY2, ENCODED_YUV422, ENCODING_FLAGS_2FRAME_GOP, QUALITY_FILMSCAN1) == 3
+    L.CFHD_ReleaseEncoderPool(pool)
+
+
+@pytest.mark.parametrize("w,h,fmt", [(320, 240, PIX_YUY2), (336, 252, PIX_YUY2), (720, 480, PIX_2VUY), (1920, 1080, PIX_YUY2)])
+def test_gop_decode_reference_samples(w, h, fmt):
+    assert have_ref(), "oracle/_ref/libcfhd_ref.so is missing"
+    kind = 2 if fmt == PIX_2VUY else 1
+    frames = _frames(w, h, 4, fmt)
+    samples = ref_encode_frames(frames, w * 2, w, h, pixfmt=fmt, flags=ENCODING_FLAGS_2FRAME_GOP)
+    gp = GopPlan(w, h, pixkind=kind)
+    L = product()
+    dec = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
+    aw = ctypes.c_int(); ah = ctypes.c_int(); af = ctypes.c_uint32()
+    sb = ctypes.create_string_buffer(samples[0], len(samples[0]))
+    assert L.CFHD_PrepareToDecode(dec, 0, 0, fmt, 1, 0, sb, len(samples[0]), ctypes.byref(aw), ctypes.byref(ah), ctypes.byref(af)) == 0
+    assert (aw.value, ah.value) == (w, (h + 7) // 8 * 8)               # as the reference: the sequence header carries the coded height
+    H = ah.value
+    outs = []
+    for s in samples:
+        sb = ctypes.create_string_buffer(s, len(s)); out = np.full(w * 2 * H, 7, np.uint8)
+        assert L.CFHD_DecodeSample(dec, sb, len(s), out.ctypes.data_as(ctypes.c_void_p), w * 2) == 0, amd_last_error()
+        outs.append(out.reshape(H, w * 2))
+    L.CFHD_CloseDecoder(dec)
+    assert (outs[0] == 7).all()                                          # the sequence header decodes to nothing
+    for g in range(2):
+        co = host_decode_group(samples[2 * g + 1], gp)
+        lo = oracle_inverse_gop(gp, co, 0, uyvy=int(fmt == PIX_2VUY)); hi = oracle_inverse_gop(gp, co, 1, uyvy=int(fmt == PIX_2VUY))
+        for f in range(2):
+            img = outs[2 * g + 1 + f][:h]
+            ok = (img == lo[f][:h]) | (img == hi[f][:h])
+            assert ok.all(), "group %d frame %d: %d bytes outside the dither interval" % (g, f, (~ok).sum())
+            assert psnr_yuy2(img, frames[2 * g + f].reshape(h, w * 2)) > 40.0
+
+
+def test_gop_round_trip_of_the_product_alone():
+    """Encode and decode with the product only, entered at a group (no sequence header): every frame comes back at intra-like quality."""
+    w, h = 640, 360
+    frames = _frames(w, h, 4, PIX_YUY2)
+    samples = amd_encode_frames(frames, w * 2, w, h, PIX_YUY2, flags=ENCODING_FLAGS_2FRAME_GOP)
+    L = product()
+    dec = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
+    aw = ctypes.c_int(); ah = ctypes.c_int(); af = ctypes.c_uint32()
+    sb = ctypes.create_string_buffer(samples[1], len(samples[1]))
+    assert L.CFHD_PrepareToDecode(dec, 0, 0, PIX_YUY2, 1, 0, sb, 512, ctypes.byref(aw), ctypes.byref(ah), ctypes.byref(af)) == 0
+    assert (aw.value, ah.value) == (w, h)
+    for i, s in enumerate(samples[1:]):
+        sb = ctypes.create_string_buffer(s, len(s)); out = np.zeros(w * 2 * h, np.uint8)
+        assert L.CFHD_DecodeSample(dec, sb, len(s), out.ctypes.data_as(ctypes.c_void_p), w * 2) == 0
+        assert psnr_yuy2(out.reshape(h, w * 2), frames[i].reshape(h, w * 2)) > 40.0, i
+    L.CFHD_CloseDecoder(dec)
