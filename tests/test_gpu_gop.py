@@ -43,7 +43,7 @@ def test_gop_gates():
 def test_gop_decode_reference_samples(w, h, fmt):
     assert have_ref(), "oracle/_ref/libcfhd_ref.so is missing"
     kind = 2 if fmt == PIX_2VUY else 1
-    frames = _frames(w, h, 4, fmt)
+    frames = _frames(w, h, 5, fmt)               # sequence header, group, P-frame header, group, P-frame header
     samples = ref_encode_frames(frames, w * 2, w, h, pixfmt=fmt, flags=ENCODING_FLAGS_2FRAME_GOP)
     gp = GopPlan(w, h, pixkind=kind)
     L = product()
