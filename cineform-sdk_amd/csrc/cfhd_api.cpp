@@ -914,8 +914,8 @@ CFHD_Error CFHD_GetOutputFormats(CFHD_DecoderRef ref, void *sample, size_t size,
 	if (!ref || !arr) return ERR_INVALID_ARGUMENT;
 	ParsedSample ps;
 	const bool known = sample && parse_sample((const uint8_t *)sample, size, &ps) >= 0;
-	uint32_t fmts[12]; int total = 0;
-	if (!known || ps.encoded_format == ENC_YUV422) { fmts[total++] = FMT_YUY2; fmts[total++] = FMT_2VUY; fmts[total++] = FMT_YU64; }
+	uint32_t fmts[13]; int total = 0;
+	if (!known || ps.encoded_format == ENC_YUV422) { fmts[total++] = FMT_YUY2; fmts[total++] = FMT_2VUY; fmts[total++] = FMT_YU64; fmts[total++] = FMT_V210; }
 	if (!known || ps.encoded_format == ENC_RGB444) { fmts[total++] = FMT_RG48; fmts[total++] = FMT_RG24; fmts[total++] = FMT_BGRA; fmts[total++] = FMT_BGRa; fmts[total++] = FMT_R210; fmts[total++] = FMT_DPX0; fmts[total++] = FMT_AB10; fmts[total++] = FMT_AR10; }
 	if (!known || ps.encoded_format == ENC_RGBA4444) fmts[total++] = FMT_B64A;
 	int n = 0;
@@ -998,7 +998,9 @@ CFHD_Error CFHD_PrepareToDecode(CFHD_DecoderRef ref, int, int, CFHD_PixelFormat 
 	// decoder and pinned word for word on the CPU, equal to the reference decoder on the GPU)
 	const bool rgb10 = kind >= PIX_R210 && kind <= PIX_AR10;
 	if (rgb10 && (encf != ENC_RGB444 || half || d->header.width < 32)) return ERR_BADFORMAT;
-	if (kind == PIX_BYR4 || kind == PIX_V210 || (kind >= PIX_R210 && kind <= PIX_AR10 && !rgb10)) return ERR_BADFORMAT;     // encoder inputs only
+	// ... and 4:2:2 samples to v210 (the YU64 words >> 6, three to a 32-bit word: DecodeBatch / k_yu64_to_v210; widths of whole six-pixel groups)
+	if (kind == PIX_V210 && (encf != ENC_YUV422 || half || d->header.width % 6 || d->header.width < 128)) return ERR_BADFORMAT;
+	if (kind == PIX_BYR4 || (kind >= PIX_R210 && kind <= PIX_AR10 && !rgb10)) return ERR_BADFORMAT;     // encoder inputs only
 	if ((encf == ENC_RGB444) != (kind == PIX_RG48 || rgb8 || rgb10) || (encf == ENC_RGBA4444) != (kind == PIX_B64A)) return ERR_BADFORMAT;
 	if (kind == PIX_YU64 && d->header.width < 128) return ERR_BADFORMAT;      // (the tail-column rule of the 16-bit rows is restated for chroma bands of 16 columns and more)
 	bool ok;
@@ -1036,6 +1038,7 @@ CFHD_Error CFHD_GetPixelSize(CFHD_PixelFormat fmt, uint32_t *out)
 CFHD_Error CFHD_GetImagePitch(uint32_t width, CFHD_PixelFormat fmt, int32_t *out)
 {
 	if (!out) return ERR_INVALID_ARGUMENT;
+	if (fmt == FMT_V210) { *out = (int32_t)((width + 47u) / 48u * 128u); return ERR_OKAY; }      // six pixels in 16 bytes, rows of whole 48-pixel groups (as the reference answers)
 	*out = (int32_t)(((width * (uint32_t)pixel_size_of(fmt)) + 15u) & ~15u);              // SampleDecoder.cpp:290-305
 	return ERR_OKAY;
 }
@@ -1138,7 +1141,7 @@ CFHD_Error CFHD_DecodeSample(CFHD_DecoderRef ref, void *sample, size_t size, voi
 	// interlaced samples (known only now: the SAMPLE_FLAGS tag lies behind the 512 bytes CFHD_PrepareToDecode sees): 4:2:2, full resolution through the
 	// inverse frame transform, half resolution from the level-1 lowpass planes like any other sample (the reference's output is the same model)
 	const bool interlaced = !ps.progressive;
-	if (interlaced && (ps.encoded_format != ENC_YUV422 || d->out_kind == PIX_YU64)) return fail_zero(ERR_BADFORMAT);      // (YU64 output of interlaced samples is not built)
+	if (interlaced && (ps.encoded_format != ENC_YUV422 || d->out_kind == PIX_YU64 || d->out_kind == PIX_V210)) return fail_zero(ERR_BADFORMAT);      // (YU64 output of interlaced samples is not built)
 	if (interlaced && !d->half && ps.width > 8192) return fail_zero(ERR_BADFORMAT);        // k_dec_undiff serves rows of up to 4096 coefficients (cfhd_dec_kernels.h DXU_MAX): an unsupported size, not a bad sample
 	// another call of this geometry in flight right now: decode together with it (see DecodeService)
 	if (decode_gather_slots() > 1 && gpu_entropy_enabled() && size <= (size_t)d->plan.width * d->plan.height * pixel_bytes_of(d->out_kind) + 65536) {

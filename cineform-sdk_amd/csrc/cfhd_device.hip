@@ -589,6 +589,7 @@ void DecodeBatch::release()
 	if (stream_) hipStreamSynchronize((hipStream_t)stream_);
 	ent_ready_ = false;
 	if (d_out_) hipFree(d_out_);
+	if (d_tmp_) { hipFree(d_tmp_); d_tmp_ = nullptr; }
 	if (h_out_) hipHostFree(h_out_);
 	if (d_coeff_) hipFree(d_coeff_);
 	if (h_coeff_) hipHostFree(h_coeff_);
@@ -609,6 +610,11 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 	release();
 	device_ = device_current(); (void)hipSetDevice(device_);      // (release() went to the device of the buffers it freed)
 	half_ = half;
+	// v210 output (10-bit 4:2:2, three samples per 32-bit word): the reference's samples are its YU64 words >> 6 (oracle/cfhd_oracle_inv.c
+	// orc_inv_spatial_to_v210, pinned on the reference decoder for widths that are multiples of six) -- the frames are computed as YU64 rows into a
+	// scratch buffer and k_yu64_to_v210 packs them into the output
+	v210_ = out_kind == PIX_V210;
+	if (v210_) { if (plan.width % 6 || !own_output || half) { g_err = "v210 output: widths that are multiples of 6, full resolution"; return -2; } out_kind = PIX_YU64; }
 
 	const bool yuv_ok = (out_kind == PIX_YUY2 || out_kind == PIX_2VUY) && plan.encoded_format == ENC_YUV422;
 	const bool rgb_ok = ((out_kind == PIX_RG48 && plan.encoded_format == ENC_RGB444) || (out_kind == PIX_B64A && plan.encoded_format == ENC_RGBA4444)) &&
@@ -625,10 +631,19 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 	out_rows_ = half ? plan.display_height / 2 : plan.display_height;
 	out_pitch_ = packed_frame_pitch(out_kind, half ? plan.width / 2 : plan.width);
 	frame_bytes_ = (size_t)out_pitch_ * out_rows_;
+	uint8_t *job_out = nullptr; size_t job_frame_bytes = frame_bytes_;      // where the last-level kernel writes frame i: the output, or the YU64 scratch of v210 output
+	if (v210_) {
+		HIPCHK(hipMalloc((void **)&d_tmp_, frame_bytes_ * n_));
+		job_out = d_tmp_; tmp_pitch_ = out_pitch_; tmp_frame_bytes_ = frame_bytes_;
+		out_pitch_ = packed_frame_pitch(PIX_V210, plan.width); frame_bytes_ = (size_t)out_pitch_ * out_rows_;
+	}
 	if (own_output) {
 		HIPCHK(hipMalloc((void **)&d_out_, frame_bytes_ * n_));
 		HIPCHK(hipHostMalloc((void **)&h_out_, frame_bytes_ * n_, hipHostMallocPortable));
+		if (v210_) HIPCHK(hipMemsetAsync(d_out_, 0, frame_bytes_ * n_, (hipStream_t)stream_));      // (row padding beyond the last whole group of 48 pixels stays zero)
 	}
+	if (!v210_) job_out = d_out_;
+	const int job_pitch = v210_ ? tmp_pitch_ : out_pitch_;
 	HIPCHK(hipMalloc((void **)&d_coeff_, (size_t)plan.coeff_elems * 2 * n_));
 	HIPCHK(hipMemsetAsync(d_coeff_, 0, (size_t)plan.coeff_elems * 2 * n_, (hipStream_t)stream_));
 	HIPCHK(hipHostMalloc((void **)&h_coeff_, (size_t)plan.final_elems * 2 * n_, hipHostMallocPortable));
@@ -665,12 +680,12 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 				for (int b = 0; b < 4; b++) p.band[b] = base + plan.ch[c].band[0][b].offset;
 				p.band_pitch = plan.ch[c].band[0][0].pitch;
 				p.width = plan.ch[c].band[0][0].width; p.height = plan.ch[c].band[0][0].height; p.descale = 0;
-				uint16_t *frame = own_output ? (uint16_t *)(d_out_ + frame_bytes_ * i) : nullptr;
-				p.out = frame ? dec_plane_out(frame, out_kind, c) : nullptr; p.out_pitch = dec_rgb8(out_kind) ? out_pitch_ : out_pitch_ / 2;
+				uint16_t *frame = own_output ? (uint16_t *)(job_out + job_frame_bytes * i) : nullptr;
+				p.out = frame ? dec_plane_out(frame, out_kind, c) : nullptr; p.out_pitch = dec_rgb8(out_kind) ? job_pitch : job_pitch / 2;
 				p.xstride = dec_stride_of_channel(out_kind, c, nch); p.precision = plan.precision; p.display_height = plan.display_height;
 				p.alpha = out_kind == PIX_B64A && c == 3;
 				p.bytes8 = dec_rgb8(out_kind); p.bottom_up = out_kind == PIX_RG24 || out_kind == PIX_BGRA; p.dither_seed = 0x9E3779B9u * (uint32_t)(i + 1);
-				if (dec_rgb10(out_kind)) { p.out = (int16_t *)frame; p.out_pitch = out_pitch_ / 4; p.bit_shift = rgb10_shift(out_kind, c); p.big_endian = out_kind == PIX_R210 || out_kind == PIX_DPX0; }
+				if (dec_rgb10(out_kind)) { p.out = (int16_t *)frame; p.out_pitch = job_pitch / 4; p.bit_shift = rgb10_shift(out_kind, c); p.big_endian = out_kind == PIX_R210 || out_kind == PIX_DPX0; }
 			}
 			continue;
 		}
@@ -846,6 +861,11 @@ int DecodeBatch::launch_inverse(uint32_t dither_seed)
 		const BandDesc &b = plan_.ch[0].band[0][0];
 		dim3 grid((b.width + dev::ITW - 1) / dev::ITW, (b.height + dev::ITH - 1) / dev::ITH, act);
 		dev::k_inv_yuv422<<<grid, dev::NTHREADS, 0, st>>>(j.yuv, dither_seed);
+	}
+	if (v210_) {
+		const int groups = plan_.width / 6;
+		dev::k_yu64_to_v210<<<dim3((unsigned)((groups + dev::NTHREADS - 1) / dev::NTHREADS), (unsigned)out_rows_, (unsigned)act), dev::NTHREADS, 0, st>>>(
+			(const uint16_t *)d_tmp_, tmp_pitch_ / 2, tmp_frame_bytes_ / 2, (uint32_t *)d_out_, out_pitch_ / 4, frame_bytes_ / 4, groups);
 	}
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord((hipEvent_t)ev1_, st));

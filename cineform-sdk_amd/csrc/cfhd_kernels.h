@@ -2163,5 +2163,24 @@ __global__ void __launch_bounds__(NTHREADS) k_gop_temporal_inv(const GopTemporal
 	}
 }
 
+// v210 output (DecodeBatch): six pixels of a YU64 row (words Y0 C1 Y1 C2 per pixel pair, C1 = channel 1 = Cr, C2 = channel 2 = Cb) >> 6 into four
+// 32-bit words Cb0 Y0 Cr0 | Y1 Cb1 Y2 | Cr1 Y3 Cb2 | Y4 Cr2 Y5, low bits first (oracle/cfhd_oracle_inv.c orc_inv_spatial_to_v210).  One thread per group.
+__global__ void __launch_bounds__(NTHREADS) k_yu64_to_v210(const uint16_t *yu64, int in_pitch_words, size_t in_frame_words, uint32_t *out, int out_pitch_words, size_t out_frame_words, int groups)
+{
+	const int g = (int)(blockIdx.x * NTHREADS + threadIdx.x);
+	if (g >= groups) return;
+	const uint16_t *r = yu64 + (size_t)blockIdx.z * in_frame_words + (size_t)blockIdx.y * in_pitch_words + 12 * (size_t)g;
+	uint32_t *o = out + (size_t)blockIdx.z * out_frame_words + (size_t)blockIdx.y * out_pitch_words + 4 * (size_t)g;
+	uint32_t Y[6], Cb[3], Cr[3];
+#pragma unroll
+	for (int k = 0; k < 6; k++) Y[k] = (uint32_t)r[2 * k] >> 6;
+#pragma unroll
+	for (int k = 0; k < 3; k++) { Cr[k] = (uint32_t)r[4 * k + 1] >> 6; Cb[k] = (uint32_t)r[4 * k + 3] >> 6; }
+	o[0] = Cb[0] | (Y[0] << 10) | (Cr[0] << 20);
+	o[1] = Y[1] | (Cb[1] << 10) | (Y[2] << 20);
+	o[2] = Cr[1] | (Y[3] << 10) | (Cb[2] << 20);
+	o[3] = Y[4] | (Cr[2] << 10) | (Y[5] << 20);
+}
+
 } // namespace dev
 } // namespace cfhd

@@ -525,6 +525,52 @@ def test_yu64_decode_equals_reference_exactly(w, h, src):
     L.CFHD_CloseDecoder(dec)
 
 
+@pytest.mark.parametrize("w,h,src", [(192, 96, "yuy2"), (336, 252, "yu64"), (720, 480, "yuy2"), (1920, 1080, "yu64")])
+def test_v210_decode_equals_reference_exactly(w, h, src):
+    """4:2:2 samples decoded to v210 (10-bit 4:2:2, three samples per 32-bit word; no dither): word for word what the reference decoder
+    delivers on widths of whole six-pixel groups -- its YU64 words >> 6, Cb from channel 2 (k_inv_packed16 into a YU64 scratch, then
+    k_yu64_to_v210); rows are as long as the reference's (whole groups of 48 pixels, CFHD_GetImagePitch); other widths are refused."""
+    if src == "yu64":
+        f16 = (np.random.default_rng(w + h).integers(0, 1024, size=(h, w * 2)) << 6).astype(np.uint16)
+        f16[: h // 3] = (np.linspace(0, 65535, w * 2)[None, :]).astype(np.uint16)
+        f = np.frombuffer(f16.tobytes(), np.uint8).copy(); p = w * 4
+        sample = ref_encode_frames([f], p, w, h, fourcc("YU64"))[0]
+    else:
+        f, p = synth_yuy2(w, h, 11)
+        sample = ref_encode_frames([f], p, w, h, PIX_YUY2)[0]
+    if w < 128:
+        L = product()
+        dec = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
+        a = ctypes.c_int(); b = ctypes.c_int(); c = ctypes.c_uint32()
+        sb = ctypes.create_string_buffer(sample, len(sample))
+        assert L.CFHD_PrepareToDecode(dec, 0, 0, fourcc("v210"), 1, 0, sb, 512, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)) == 3
+        L.CFHD_CloseDecoder(dec)
+        return
+    got, gpitch, aw, ah = amd_decode_sample(sample, fourcc("v210"))
+    assert (aw, ah) == (w, h) and gpitch == (w + 47) // 48 * 128
+    nwords = (w // 6) * 4
+    mine = np.frombuffer(got.tobytes(), np.uint32).reshape(h, gpitch // 4)[:, :nwords]
+    for attempt in range(3):
+        dec, dpitch = ref_decode_sample(sample, w, h, fourcc("v210"))
+        assert dpitch == gpitch
+        img = np.frombuffer(dec.tobytes(), dtype=np.uint32).reshape(h, dpitch // 4)[:, :nwords]
+        if np.array_equal(mine, img): break
+    assert np.array_equal(mine, img), "%d words differ" % (mine != img).sum()
+    # v210 in, v210 out through the product alone: the 10-bit samples come back within the quantizer's error
+    if src == "yuy2" and w % 48 == 0:
+        rng = np.random.default_rng(5)
+        words = np.zeros((h, gpitch // 4), np.uint32)
+        smooth = (512 + 300 * np.sin(np.arange(w * 2) / 60.0)).astype(np.uint32)
+        vals = np.clip(smooth[None, :] + rng.integers(-8, 9, size=(h, w * 2)), 4, 1019).astype(np.uint32)
+        for k in range(w * 2 // 3): words[:, k] = vals[:, 3 * k] | (vals[:, 3 * k + 1] << 10) | (vals[:, 3 * k + 2] << 20)
+        frame = words.reshape(-1).view(np.uint8).copy()
+        own = amd_encode_frames([frame], gpitch, w, h, fourcc("v210"))[0]
+        back, bp, _, _ = amd_decode_sample(own, fourcc("v210"))
+        bw = np.frombuffer(back.tobytes(), np.uint32).reshape(h, bp // 4)[:, : w * 2 // 3]
+        err = [np.abs(((bw >> s) & 1023).astype(int) - ((words[:, : w * 2 // 3] >> s) & 1023).astype(int)).mean() for s in (0, 10, 20)]
+        assert max(err) < 6.0, err                          # (noise of +-8 on the samples: about what the level-1 divisors take away)
+
+
 @pytest.mark.parametrize("w,h,name", [(320, 240, "RG24"), (336, 252, "BGRA"), (1920, 1080, "BGRa"), (1920, 1080, "RG24")])
 def test_rgb8_decode_lies_in_the_reference_interval(w, h, name):
     """RGB 4:4:4 samples decoded to RG24 / BGRA (bottom row first) / BGRa: every byte inside the interval of the reference's dither model

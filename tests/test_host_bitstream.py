@@ -362,7 +362,7 @@ def test_thumbnail_and_output_formats_argument_handling():
     fmts = (ctypes.c_uint32 * 8)(); n = ctypes.c_int()
     L.CFHD_GetOutputFormats.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
     assert L.CFHD_GetOutputFormats(dec, sb, len(sample), fmts, 8, ctypes.byref(n)) == 0
-    assert [fmts[i] for i in range(n.value)] == [PIX_YUY2, PIX_2VUY, fourcc("YU64")]
+    assert [fmts[i] for i in range(n.value)] == [PIX_YUY2, PIX_2VUY, fourcc("YU64"), fourcc("v210")]
     assert L.CFHD_GetOutputFormats(dec, None, 0, fmts, 8, ctypes.byref(n)) == 0 and n.value == 8
     L.CFHD_CloseDecoder(dec)
 
