@@ -106,7 +106,7 @@ int make_params(EncodeParams &p, int w, int h, uint32_t fmt, int encoded, uint32
 	// CFHD_ENCODED_FORMAT_YUV_422 (0) from the packed 4:2:2 formats, CFHD_ENCODED_FORMAT_RGB_444 (1) from RG48; the cross
 	// combinations (4:4:4 input subsampled to 4:2:2, ...) go through ConvertLib in the reference and are not built
 	// CFHD_ENCODED_FORMAT_RGBA_4444 (2) from b64a
-	const bool rgb8 = kind == PIX_RG24 || kind == PIX_BGRA || kind == PIX_BGRa;       // 8-bit RGB(A) input, built towards RGB 4:4:4 only (alpha dropped)
+	const bool rgb8 = kind == PIX_RG24 || kind == PIX_BGRA || kind == PIX_BGRa;       // 8-bit RGB(A) input, towards RGB 4:4:4 and YUV 4:2:2 (alpha dropped)
 	const bool rgb10 = kind >= PIX_R210 && kind <= PIX_AR10;                             // 10-bit RGB in 32-bit words, to RGB 4:4:4
 	const bool rgb = kind == PIX_RG48 || kind == PIX_B64A || rgb8 || rgb10;
 	// CFHD_ENCODED_FORMAT_BAYER (3) from BYR4: default pixel order (red-green) and default encode curve (log 90), i.e. what the
@@ -114,8 +114,12 @@ int make_params(EncodeParams &p, int w, int h, uint32_t fmt, int encoded, uint32
 	// b64a also encodes to RGB 4:4:4 (its default in the reference): the alpha words are dropped, R, G, B as for 4:4:4:4
 	// RG48 / b64a encoded as YUV 4:2:2 (rows of TestCFHD's format table): the integer 709 / 601 conversion of frame.c:6731 in the loader of the level-1
 	// kernel; the converted frame is quantized as the 4:2:2 frame it has become (derive_quantization).
-	const bool deep_rgb_as_422 = (kind == PIX_RG48 || kind == PIX_B64A) && encoded == 0;
-	if (!deep_rgb_as_422 && !(kind == PIX_B64A && encoded == 1) && encoded != (kind == PIX_RG48 || rgb8 || rgb10 ? 1 : (kind == PIX_B64A ? 2 : (kind == PIX_BYR4 ? 3 : 0)))) return ERR_BADFORMAT;
+	// RG24 / BGRA / BGRa encoded as YUV 4:2:2 (the default encoded format of these inputs): frame.c:378 ConvertRGB32to10bitYUVFrame in the loader.
+	const bool rgb8_as_422 = rgb8 && encoded == 0;
+	const bool deep_rgb_as_422 = ((kind == PIX_RG48 || kind == PIX_B64A) && encoded == 0) || rgb8_as_422;
+	// BGRA / BGRa encoded as RGBA 4:4:4:4 (frame.c:6415 ConvertRGBAtoRGBA64): the alpha byte joins as the fourth plane, curved as b64a's
+	const bool rgba8_as_4444 = (kind == PIX_BGRA || kind == PIX_BGRa) && encoded == 2;
+	if (!deep_rgb_as_422 && !rgba8_as_4444 && !(kind == PIX_B64A && encoded == 1) && encoded != (kind == PIX_RG48 || rgb8 || rgb10 ? 1 : (kind == PIX_B64A ? 2 : (kind == PIX_BYR4 ? 3 : 0)))) return ERR_BADFORMAT;
 	// CFHD_ENCODING_FLAGS_YUV_INTERLACED: field-based level 1 (encoder.c:2093), built for the packed 4:2:2 formats
 	const bool interlaced = (flags & (1u << 0)) != 0;
 	if (interlaced && !(kind == PIX_YUY2 || kind == PIX_2VUY)) return ERR_BADFORMAT;
@@ -123,14 +127,15 @@ int make_params(EncodeParams &p, int w, int h, uint32_t fmt, int encoded, uint32
 	// Progressive frames, qualities whose tables do not follow the size of the previous group.
 	const bool gop = (flags & (1u << 1)) != 0;
 	if (gop && (interlaced || !(kind == PIX_YUY2 || kind == PIX_2VUY))) return ERR_BADFORMAT;
-	const int enc = kind == PIX_BYR4 ? ENC_BAYER : (kind == PIX_B64A && encoded == 2 ? ENC_RGBA4444 : (rgb && !deep_rgb_as_422 ? ENC_RGB444 : ENC_YUV422));
+	const int enc = kind == PIX_BYR4 ? ENC_BAYER : ((kind == PIX_B64A && encoded == 2) || rgba8_as_4444 ? ENC_RGBA4444 : (rgb && !deep_rgb_as_422 ? ENC_RGB444 : ENC_YUV422));
 	// an encoded format other than the default of the input format marks the quality word (SampleEncoder.cpp:216-219; QUALITY_H 0x0800 in the header)
-	if (deep_rgb_as_422) quality |= 0x08000000;
+	if (deep_rgb_as_422 && !rgb8_as_422) quality |= 0x08000000;
 	// b64a's default encoded format is RGB 4:4:4; asking for 4:4:4:4 marks the quality word (SampleEncoder.cpp:250-257), which the
 	// sample header then carries in QUALITY_H
 	if (kind == PIX_B64A && encoded == 2) quality |= 0x20000000;
 	// 8-bit RGB sources are marked in the quality word too (encoder.c:2344-2345 ORs 0x1a00000 into it; the header's QUALITY_H reads 0x09a0)
-	if (rgb8) quality |= 0x09a00000;
+	// (for 8-bit RGB the format that is "other" is RGB 4:4:4: 0x0800 on top of the 0x01a0 of every 8-bit RGB source)
+	if (rgb8) quality |= rgb8_as_422 ? 0x01a00000 : (rgba8_as_4444 ? 0x21a00000 : 0x09a00000);
 	p.width = w; p.height = h; p.pixel_format = fmt; p.pixel_kind = kind; p.encoded_format = enc; p.flags = flags;
 	p.quality = quality; p.progressive = !interlaced;
 	const int yuv601 = (flags & (1u << 2)) ? 1 : 2, vsrgb = (flags & (1u << 8)) ? 2 : 1;   // SampleEncoder.cpp:210-212

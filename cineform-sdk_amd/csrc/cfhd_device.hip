@@ -315,12 +315,13 @@ void EncodeBatch::fill_jobs()
 				p.xstride = enc_stride_of_channel(plan.pixel_kind, c, nch); p.shift = 16 - plan.precision; p.display_height = plan.display_height;
 				p.compand = plan.pixel_kind == PIX_B64A && c == 3;
 				p.layout = plan.pixel_kind == PIX_V210 ? c + 1 : 0; p.tail_from = (plan.width - plan.width % 48) / 2;
-				if (enc_bytes8(plan.pixel_kind)) { p.layout = plan.pixel_kind == PIX_BGRa ? 5 : 4; p.in_pitch = in_pitch_; p.xstride = plan.pixel_kind == PIX_RG24 ? 3 : 4; p.tail_from = c == 0 ? 1 : (c == 1 ? 2 : 0); }     // planes G, R, B of bytes B, G, R(, A)
+				if (enc_bytes8(plan.pixel_kind)) { p.layout = plan.pixel_kind == PIX_BGRa ? 5 : 4; p.in_pitch = in_pitch_; p.xstride = plan.pixel_kind == PIX_RG24 ? 3 : 4; p.tail_from = c == 0 ? 1 : (c == 1 ? 2 : (c == 2 ? 0 : 3)); p.compand = c == 3; }     // planes G, R, B(, A) of bytes B, G, R(, A)
 				if (enc_rgb10(plan.pixel_kind)) { p.layout = 6; p.in_pitch = in_pitch_ / 4; p.xstride = plan.pixel_kind == PIX_R210 || plan.pixel_kind == PIX_DPX0; p.tail_from = rgb10_shift(plan.pixel_kind, c); }
 				if (enc_rgb_as_422(plan)) {
 					p.in = frame ? (const int16_t *)(frame + (plan.pixel_kind == PIX_B64A ? 1 : 0)) : nullptr;
 					p.layout = 7; p.xstride = plan.pixel_kind == PIX_B64A ? 4 : 3; p.tail_from = c; p.shift = plan.color_matrix; p.compand = 0;
 				}
+				if (enc_bytes8(plan.pixel_kind) && plan.encoded_format == ENC_YUV422) { p.layout = plan.pixel_kind == PIX_BGRa ? 9 : 8; p.tail_from = c; p.shift = plan.color_matrix; }
 				p.out_pitch = plan.ch[c].band[0][0].pitch;
 				for (int b = 0; b < 4; b++) { p.out[b] = base + plan.ch[c].band[0][b].offset; p.q[b] = make_q(plan.ch[c].band[0][b].quant, mpq); }
 			}

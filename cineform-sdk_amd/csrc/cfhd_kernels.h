@@ -47,10 +47,12 @@ struct FwdPlaneJob {
 	// three (the scalar loop stores `v` before it has read the next one, convert.c:4530-4535).  layout 0: everything above.
 	// layout 4 / 5: 8-bit interleaved pixels, bottom / top row first (RG24, BGRA / BGRa; frame.c:6173 ConvertRGBtoRGB48, :6286 ConvertRGBAtoRGB48):
 	// `in` is the start of the frame, in_pitch is in BYTES, xstride = bytes per pixel, tail_from = the component's byte inside the pixel;
-	// sample = byte << 4; rows beyond display_height zero.
+	// sample = byte << 4 (compand: the alpha byte of a 4:4:4:4 encode, curved as b64a's); rows beyond display_height zero.
 	// layout 6: 10-bit RGB in one 32-bit word per pixel (r210, DPX0: big-endian; AB10, AR10: little-endian; wavelet.c:3595): in_pitch in 32-bit
 	// words, xstride = 1 for big-endian words, tail_from = bit position of the component; sample = field << 2; rows beyond display_height repeat
 	// the last row (a choice: the reference's fused row pipeline treats them its own way, parity is claimed for heights that are multiples of 8).
+	// layout 8 / 9: 8-bit interleaved pixels (bottom / top row first) converted to one plane of a 10-bit 4:2:2 frame on the way in (frame.c:378; RG24 /
+	// BGRA / BGRa encoded as YUV 4:2:2): xstride = bytes per pixel, tail_from = the plane (0 Y, 1 v, 2 u), shift = the matrix as for layout 7.
 	// layout 7: deep RGB converted to one plane of a 10-bit 4:2:2 frame on the way in (Codec/frame.c:6731 ConvertAnyDeep444to422; RG48 / b64a encoded
 	// as YUV 4:2:2): `in` = the R word of the first pixel (G, B behind it), xstride = words per pixel, tail_from = the plane (0 Y, 1 channel 1 = v,
 	// 2 channel 2 = u), shift = colour space (0 computer-systems 709, 1 video 709, 2 computer 601, 3 video 601); a chroma sample is the mean of
@@ -79,6 +81,25 @@ __device__ __forceinline__ uint32_t rgb16_to_yuv_sample(const uint16_t *p, int w
 	}
 	acc = (acc >> 1) + 512;
 	return (uint32_t)(acc < 0 ? 0 : (acc > 1023 ? 1023 : acc));
+}
+
+// One sample of plane `which` (0 Y, 1 v, 2 u) from 8-bit pixels (bytes B, G, R(, A)) encoded as 4:2:2 (frame.c:378 ConvertRGB32to10bitYUVFrame): the
+// 13-bit coefficients of RGB2YUV.c:1404 on 15-bit samples (byte << 7), every product shifted down 16 on its own, the sum << 2 plus the 14-bit
+// offset clamped to 14 bits; 10 bits of it.  Chroma is the EVEN pixel's, not the pair's mean (RGB2YUV.c:846-873 keeps the low word of every
+// 32-bit pair; its averaging tail starts at width & ~15, and coded widths are multiples of 16 here).
+__device__ __forceinline__ uint32_t rgb8_to_yuv_sample(const uint8_t *row, int bpp, int which, int color_space, int x)
+{
+	const int m[4][9] = { { 1499, 5029, 507, 827, 2768, 3596, 3596, 3268, 327 }, { 1744, 5857, 589, 958, 3227, 4186, 4186, 3801, 385 },
+	                      { 2105, 4128, 802, 1212, 2383, 3596, 3596, 3014, 581 }, { 2449, 4808, 933, 1409, 2777, 4186, 4186, 3506, 679 } };
+	const int cs = color_space & 3;
+	const uint8_t *q = row + (size_t)(which ? 2 * x : x) * bpp;
+	const int b = (int)q[0] << 7, g = (int)q[1] << 7, r = (int)q[2] << 7;
+	int v;
+	if (which == 0) v = ((((m[cs][0] * r) >> 16) + ((m[cs][1] * g) >> 16) + ((m[cs][2] * b) >> 16)) << 2) + ((cs & 1) ? 0 : 1024);
+	else if (which == 2) v = ((((-m[cs][3] * r) >> 16) + ((-m[cs][4] * g) >> 16) + ((m[cs][5] * b) >> 16)) * 4) + 8192;
+	else v = ((((m[cs][6] * r) >> 16) + ((-m[cs][7] * g) >> 16) + ((-m[cs][8] * b) >> 16)) * 4) + 8192;
+	v = v < 0 ? 0 : (v > 16383 ? 16383 : v);
+	return (uint32_t)v >> 4;
 }
 
 struct FwdYuvJob {
@@ -357,6 +378,11 @@ __device__ __forceinline__ void fwd_plane_tile(const FwdPlaneJob *jobs, int nch)
 					const int yy = y < job.display_height ? y : job.display_height - 1;
 					const uint16_t *row = (const uint16_t *)job.in + (size_t)yy * job.in_pitch;
 					va[k] = rgb16_to_yuv_sample(row, job.xstride, job.tail_from, job.shift, 2 * dw) | (rgb16_to_yuv_sample(row, job.xstride, job.tail_from, job.shift, 2 * dw + 1) << 16);
+				} else if (PACKED && job.layout >= 8) {
+					if (y < job.display_height) {
+						const uint8_t *row = (const uint8_t *)job.in + (size_t)(job.layout == 8 ? job.display_height - 1 - y : y) * job.in_pitch;
+						va[k] = rgb8_to_yuv_sample(row, job.xstride, job.tail_from, job.shift, 2 * dw) | (rgb8_to_yuv_sample(row, job.xstride, job.tail_from, job.shift, 2 * dw + 1) << 16);
+					} else va[k] = job.tail_from ? 0x02000200u : 0x00400040u;       // rows below the picture: Y 64, chroma 512 (frame.c:466-500)
 				} else if (PACKED && job.layout == 6) {
 					const int yy = y < job.display_height ? y : job.display_height - 1;
 					const uint32_t *row = (const uint32_t *)job.in + (size_t)yy * job.in_pitch;
@@ -366,7 +392,12 @@ __device__ __forceinline__ void fwd_plane_tile(const FwdPlaneJob *jobs, int nch)
 				} else if (PACKED && job.layout >= 4) {
 					if (y < job.display_height) {
 						const uint8_t *row = (const uint8_t *)job.in + (size_t)(job.layout == 4 ? job.display_height - 1 - y : y) * job.in_pitch + job.tail_from;
-						va[k] = ((uint32_t)row[(size_t)(2 * dw) * job.xstride] << 4) | ((uint32_t)row[(size_t)(2 * dw + 1) * job.xstride] << 20);
+						uint32_t s0 = (uint32_t)row[(size_t)(2 * dw) * job.xstride] << 4, s1 = (uint32_t)row[(size_t)(2 * dw + 1) * job.xstride] << 4;
+						if (job.compand) {           // alpha of BGRA / BGRa encoded as 4:4:4:4 (frame.c:6415 ConvertRGBAtoRGBA64: the open interval ends at 255 << 4)
+							if (s0 > 0 && s0 < 4080) s0 = ((s0 * 223 + 128) >> 8) + 256;
+							if (s1 > 0 && s1 < 4080) s1 = ((s1 * 223 + 128) >> 8) + 256;
+						}
+						va[k] = s0 | (s1 << 16);
 					}
 				} else if (PACKED && job.layout) {
 					if (y < job.display_height) {

@@ -58,6 +58,9 @@ void orc_inv_spatial_to_yuv422(PIXEL16 *const bands[3][4], const int band_pitch[
 /* deep RGB (16-bit words r, g, b) -> 10-bit Y, channel 1 (v), channel 2 (u) planes of a 4:2:2 frame: Codec/frame.c:6731 ConvertAnyDeep444to422 */
 void orc_rgb16_to_yuv422(const uint16_t *in, int in_pitch_words, int words_per_pixel, int width, int display_height, int height, int color_space,
                          PIXEL16 *y_plane, int y_pitch, PIXEL16 *c1_plane, PIXEL16 *c2_plane, int c_pitch);
+/* 8-bit RGB(A) (bytes B, G, R(, A)) -> the same three planes: Codec/frame.c:378 ConvertRGB32to10bitYUVFrame */
+void orc_rgb8_to_yuv422(const uint8_t *in, int in_pitch, int bytes_per_pixel, int top_down, int width, int display_height, int height, int color_space,
+                        PIXEL16 *y_plane, int y_pitch, PIXEL16 *c1_plane, PIXEL16 *c2_plane, int c_pitch);
 /* one plane's last-level reconstruction before the final >> 1 (test probes of further output formats start from it) */
 void orc_inv_spatial_prepack(PIXEL16 *const bands[4], int band_pitch, int w, int h, int32_t *out, int out_pitch);
 /* RGB 4:4:4 sample -> r210 / DPX0 / AB10 / AR10: (reconstruction before the final >> 1, + 3) >> 3 per component, see cfhd_oracle_inv.c */

@@ -295,3 +295,61 @@ void orc_rgb16_to_yuv422(const uint16_t *in, int in_pitch_words, int words_per_p
 		}
 	}
 }
+
+/* ---- 8-bit RGB(A) -> YUV 4:2:2 10-bit planes (RG24 / BGRA / BGRa encoded as CFHD_ENCODED_FORMAT_YUV_422) ---------------------------------
+ * Codec/frame.c:378 ConvertRGB32to10bitYUVFrame, row by row: bytes B, G, R(, A) become 16-bit planes (byte << 8, RGB2YUV.c:326, :365),
+ * RGB2YUV.c:1404 PlanarRGB16toPlanarYUV16 turns them into 16-bit Y, U, V (13-bit coefficients from the float constants of the matrix, each
+ * product of a 15-bit sample shifted down 16 on its own, sum << 2 plus the 14-bit offset, clamped to 14 bits, << 2), and RGB2YUV.c:736
+ * PlanarYUV16toChannelYUYV16 stores Y >> 6 and one chroma sample per pixel pair: the EVEN pixel's chroma >> 6 in the 16-pixel blocks its vector
+ * loop covers (:846-873), the pair's average (a + b) >> 7 in the columns after them (:877-883).  U goes to channel 2, V to channel 1 (frame.c:424-428).
+ * Source rows are read bottom row first (frame.c:419-420; top row first when `top_down`: the caller flipped RGB32_INVERTED before, encoder.c:2398-2402);
+ * picture rows beyond the display height hold Y = 64, U = V = 512 (frame.c:466-500).  color_space as in orc_rgb16_to_yuv422. */
+void orc_rgb8_to_yuv422(const uint8_t *in, int in_pitch, int bytes_per_pixel, int top_down, int width, int display_height, int height, int color_space,
+                        PIXEL16 *y_plane, int y_pitch, PIXEL16 *c1_plane, PIXEL16 *c2_plane, int c_pitch)
+{
+	const float fp = (float)(1 << 13);
+	static const float k[4][9] = {
+		{ 0.183f, 0.614f, 0.062f, 0.101f, 0.338f, 0.439f, 0.439f, 0.399f, 0.040f },      /* computer-systems 709 (the default) */
+		{ 0.213f, 0.715f, 0.072f, 0.117f, 0.394f, 0.511f, 0.511f, 0.464f, 0.047f },      /* video-systems 709 */
+		{ 0.257f, 0.504f, 0.098f, 0.148f, 0.291f, 0.439f, 0.439f, 0.368f, 0.071f },      /* computer-systems 601 */
+		{ 0.299f, 0.587f, 0.114f, 0.172f, 0.339f, 0.511f, 0.511f, 0.428f, 0.083f },      /* video-systems 601 */
+	};
+	const int cs = color_space & 3;
+	const int y_offset = (cs == 0 || cs == 2) ? (((65536 * 16) >> 8) >> 2) : 0, c_offset = 32768 >> 2;
+	const int width16 = width & 0xfff0;
+	int m[9], i, row, x;
+	uint16_t *yuv = (uint16_t *)malloc((size_t)width * 3 * sizeof(uint16_t));
+	for (i = 0; i < 9; i++) m[i] = (int)(fp * k[cs][i]);
+	for (row = 0; row < height; row++) {
+		PIXEL16 *yo = y_plane + (size_t)row * y_pitch, *c1 = c1_plane + (size_t)row * c_pitch, *c2 = c2_plane + (size_t)row * c_pitch;
+		if (row >= display_height) {
+			for (x = 0; x < width; x++) yo[x] = 64;
+			for (x = 0; x < width / 2; x++) c1[x] = c2[x] = 512;
+			continue;
+		}
+		{
+			const uint8_t *p = in + (size_t)(top_down ? row : display_height - 1 - row) * in_pitch;
+			for (x = 0; x < width; x++) {
+				const int B = (p[(size_t)x * bytes_per_pixel] << 8) >> 1, G = (p[(size_t)x * bytes_per_pixel + 1] << 8) >> 1, R = (p[(size_t)x * bytes_per_pixel + 2] << 8) >> 1;
+				int Y = ((((m[0] * R) >> 16) + ((m[1] * G) >> 16) + ((m[2] * B) >> 16)) << 2) + y_offset;
+				int U = ((((-m[3] * R) >> 16) + ((-m[4] * G) >> 16) + ((m[5] * B) >> 16)) * 4) + c_offset;
+				int V = ((((m[6] * R) >> 16) + ((-m[7] * G) >> 16) + ((-m[8] * B) >> 16)) * 4) + c_offset;
+				if (Y < 0) Y = 0; if (Y > 16383) Y = 16383;
+				if (U < 0) U = 0; if (U > 16383) U = 16383;
+				if (V < 0) V = 0; if (V > 16383) V = 16383;
+				yuv[x] = (uint16_t)(Y << 2); yuv[width + x] = (uint16_t)(U << 2); yuv[2 * width + x] = (uint16_t)(V << 2);
+			}
+		}
+		for (x = 0; x < width; x += 2) {
+			yo[x] = (PIXEL16)(yuv[x] >> 6); yo[x + 1] = (PIXEL16)(yuv[x + 1] >> 6);
+			if (x < width16) {
+				c2[x / 2] = (PIXEL16)((((yuv[width + x] >> 1) & 0xffff) << 1) >> 6);
+				c1[x / 2] = (PIXEL16)((((yuv[2 * width + x] >> 1) & 0xffff) << 1) >> 6);
+			} else {
+				c2[x / 2] = (PIXEL16)((yuv[width + x] + yuv[width + x + 1]) >> 7);
+				c1[x / 2] = (PIXEL16)((yuv[2 * width + x] + yuv[2 * width + x + 1]) >> 7);
+			}
+		}
+	}
+	free(yuv);
+}

@@ -921,3 +921,14 @@ def oracle_inverse_gop(gp, coeffs, dither, uyvy=0):
         O.orc_inv_spatial_to_yuv422(ptrs, iarr(pitches), w, h, 10, uyvy, dither, p8(out), 4 * w)
         outs.append(out)
     return outs
+
+
+def oracle_rgb8_to_yuv422_planes(frame, pitch, bytes_per_pixel, top_down, w, h, enc_height, color_space=0):
+    """8-bit RGB(A) frame (bytes B, G, R(, A)) -> the three 10-bit planes Y, channel 1, channel 2 of a 4:2:2 frame at the coded height, with the
+    oracle (Codec/frame.c:378 ConvertRGB32to10bitYUVFrame)."""
+    O = oracle()
+    O.orc_rgb8_to_yuv422.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 7 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    src = np.ascontiguousarray(np.frombuffer(frame.tobytes(), np.uint8))
+    Y = np.zeros((enc_height, w), np.int16); C1 = np.zeros((enc_height, w // 2), np.int16); C2 = np.zeros((enc_height, w // 2), np.int16)
+    O.orc_rgb8_to_yuv422(src.ctypes.data_as(ctypes.c_void_p), pitch, bytes_per_pixel, top_down, w, h, enc_height, color_space, p16(Y), w, p16(C1), p16(C2), w // 2)
+    return [Y, C1, C2]

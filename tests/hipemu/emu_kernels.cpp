@@ -94,6 +94,24 @@ void emu_fwd_rgb16_to_yuv422(const uint16_t *in, int in_pitch_words, int wpp, in
 	hipemu::launch(grid, dim3(NTHREADS), [&] { k_fwd_packed16(jobs.data(), 3); });
 }
 
+// Level 1 of a 4:2:2 frame from 8-bit pixels B, G, R(, A) (RG24 / BGRA: bottom row first, layout 8; BGRa: top row first, layout 9), as
+// EncodeBatch::fill_jobs sets it up.
+void emu_fwd_rgb8_to_yuv422(const uint8_t *in, int in_pitch, int bpp, int top_down, int width, int height, int display_height, int color_space,
+                            const int *quant, int mpq, int16_t **out, const int *out_pitch)
+{
+	std::vector<FwdPlaneJob> jobs(3);
+	for (int c = 0; c < 3; c++) {
+		FwdPlaneJob &job = jobs[c];
+		memset(&job, 0, sizeof(job));
+		job.in = (const int16_t *)in; job.in_pitch = in_pitch; job.width = c ? width / 2 : width; job.height = height; job.prescale = 0;
+		job.xstride = bpp; job.shift = color_space; job.display_height = display_height; job.layout = top_down ? 9 : 8; job.tail_from = c;
+		for (int b = 0; b < 4; b++) { job.out[b] = out[c * 4 + b]; job.q[b] = make_q(quant[c * 4 + b], mpq); }
+		job.out_pitch = out_pitch[c];
+	}
+	dim3 grid(((width / 2 + TW - 1) / TW) * 3, (height / 2 + TH - 1) / TH, 1);
+	hipemu::launch(grid, dim3(NTHREADS), [&] { k_fwd_packed16(jobs.data(), 3); });
+}
+
 // Level 1 of a 4:2:2 frame from 16-bit words Y0 C1 Y1 C2 (YU64): the same kernel with per-channel first word, stride and width, as
 // EncodeBatch::fill_jobs sets it up.  quant[c*4+b], out[c*4+b]; out_pitch[c].
 void emu_fwd_yu64(const uint16_t *in, int in_pitch_words, int width, int height, int display_height, const int *quant, int mpq, int16_t **out, const int *out_pitch)
@@ -140,6 +158,23 @@ void emu_fwd_rg24(const uint8_t *in, int in_pitch_bytes, int width, int height, 
 	}
 	dim3 grid(((width / 2 + TW - 1) / TW) * 3, (height / 2 + TH - 1) / TH, 1);
 	hipemu::launch(grid, dim3(NTHREADS), [&] { k_fwd_packed16(jobs.data(), 3); });
+}
+
+// Level 1 of an RGBA 4:4:4:4 frame from 8-bit B, G, R, A bytes (BGRA: bottom row first, layout 4; BGRa: top row first, layout 5); the alpha plane is curved.
+void emu_fwd_rgba8(const uint8_t *in, int in_pitch_bytes, int top_down, int width, int height, int display_height, const int *quant, int mpq, int16_t **out, int out_pitch)
+{
+	std::vector<FwdPlaneJob> jobs(4);
+	for (int c = 0; c < 4; c++) {
+		FwdPlaneJob &job = jobs[c];
+		memset(&job, 0, sizeof(job));
+		job.in = (const int16_t *)in; job.in_pitch = in_pitch_bytes; job.width = width; job.height = height; job.prescale = 0;
+		job.xstride = 4; job.shift = 4; job.display_height = display_height; job.compand = c == 3;
+		job.layout = top_down ? 5 : 4; job.tail_from = c == 0 ? 1 : (c == 1 ? 2 : (c == 2 ? 0 : 3));
+		for (int b = 0; b < 4; b++) { job.out[b] = out[c * 4 + b]; job.q[b] = make_q(quant[c * 4 + b], mpq); }
+		job.out_pitch = out_pitch;
+	}
+	dim3 grid(((width / 2 + TW - 1) / TW) * 4, (height / 2 + TH - 1) / TH, 1);
+	hipemu::launch(grid, dim3(NTHREADS), [&] { k_fwd_packed16(jobs.data(), 4); });
 }
 
 // Level 1 of an RGB 4:4:4 frame from 10-bit fields of one 32-bit word per pixel (r210 ...): FwdPlaneJob::layout 6.  shifts[c]: bit position of plane c.

@@ -169,6 +169,59 @@ def test_deep_rgb_to_yuv422_sample_bytes_equal_reference(w, h, name):
     assert diff == [90] and rs[88:92] == bytes([0xff, 0xaf, 0x08, 0x00])      # the quality mark (the host writer of this test passes no quality word)
 
 
+@pytest.mark.parametrize("w,h,name,flags", [(320, 240, "RG24", 0), (336, 252, "BGRA", 0), (208, 120, "BGRa", 0), (336, 252, "BGRa", 4), (320, 240, "BGRA", 0x100),
+                                              (320, 240, "RG24", 0x104), (1920, 1080, "RG24", 0)])
+def test_rgb8_to_yuv422_sample_bytes_equal_reference(w, h, name, flags):
+    """RG24 / BGRA / BGRa encoded as YUV 4:2:2 -- the default encoded format of these inputs and three rows of TestCFHD's format table.  The reference
+    converts row by row (frame.c:378 ConvertRGB32to10bitYUVFrame: 13-bit matrix on 15-bit samples, the EVEN pixel's chroma kept, Y 64 / chroma 512
+    in the rows below the picture) and goes on as for YU64; the quality word carries 0x01a0 in its upper half (encoder.c:2351).  Oracle conversion +
+    oracle plane transform + product syntax = reference sample, byte for byte: both row orders, the four matrices (flags 4 = 601, 0x100 = video
+    range), a height that is not a multiple of 8."""
+    if not have_ref(): pytest.skip("reference .so not built")
+    fmt = {"RG24": PIX_RG24, "BGRA": PIX_BGRA, "BGRa": PIX_BGRa}[name]
+    frames, pitch = qbist_frames(10, 1, w, h, fmt)
+    rs = ref_encode_frames(frames, pitch, w, h, fmt, encoded=ENCODED_YUV422, flags=flags)[0]
+    plan = Plan(w, h, pixkind=PIXKIND[name], enc=1)
+    yu64 = Plan(w, h, pixkind=PIXKIND["YU64"], enc=1)
+    assert all(plan.band[k]["quant"] == yu64.band[k]["quant"] for k in plan.band)
+    cs = (1 if flags & 0x100 else 0) + (2 if flags & 4 else 0)
+    planes = oracle_rgb8_to_yuv422_planes(frames[0], pitch, 3 if name == "RG24" else 4, int(name == "BGRa"), w, h, 2 * plan.band[(0, 0, 0)]["height"], cs)
+    off, n = first_metadata_chunk(rs)
+    mine = product_write_sample_host(plan, oracle_forward_planes(plan, planes), 1, meta_global=rs[off:off + n], input_format={"RG24": 7, "BGRA": 32, "BGRa": 9}[name],
+                                     color_space=(1 if flags & 4 else 2) | (4 if flags & 0x100 else 0))
+    assert len(mine) == len(rs)
+    diff = [i for i, (a, b) in enumerate(zip(mine, rs)) if a != b]
+    assert diff == [90, 91] and rs[88:92] == bytes([0xff, 0xaf, 0x01, 0xa0])      # the quality mark (the host writer of this test passes no quality word)
+
+
+@pytest.mark.parametrize("w,h,name", [(320, 240, "BGRA"), (336, 256, "BGRa"), (720, 480, "BGRa"), (1920, 1088, "BGRA")])
+def test_rgba8_to_rgba4444_sample_bytes_equal_reference(w, h, name):
+    """BGRA / BGRa encoded as RGBA 4:4:4:4 (two rows of TestCFHD's table): planes G, R, B = byte << 4 and the alpha byte << 4 curved like b64a's, but
+    with the interval ending at 255 << 4 (frame.c:6415 ConvertRGBAtoRGBA64); the frame goes on as COLOR_FORMAT_RG64 -- above COLOR_FORMAT_BAYER, so all
+    four planes take the full-resolution quantizer tables (b64a's R, B, A planes take the chroma tables; encoder.c:1141) -- and the quality word reads
+    0x21a0.  The rows below a picture whose height is not a multiple of 8 are never written by the reference: zeros from a fresh allocation, whatever the
+    heap held otherwise (336 x 252 gives samples of different sizes from call to call) -- parity is claimed for heights that are multiples of 8; the
+    library writes zeros there."""
+    if not have_ref(): pytest.skip("reference .so not built")
+    fmt = {"BGRA": PIX_BGRA, "BGRa": PIX_BGRa}[name]
+    frames, pitch = qbist_frames(10, 1, w, h, fmt, alpha=1)
+    rs = ref_encode_frames(frames, pitch, w, h, fmt, encoded=ENCODED_RGBA4444)[0]
+    px = np.frombuffer(frames[0].tobytes(), np.uint8).reshape(h, pitch)[:, : w * 4].reshape(h, w, 4).astype(np.int32)
+    if name == "BGRA": px = px[::-1]
+    a = px[:, :, 3] << 4
+    a = np.where((a > 0) & (a < 4080), ((a * 223 + 128) >> 8) + 256, a)
+    plan = Plan(w, h, pixkind=PIXKIND[name], enc=4)
+    b64a = Plan(w, h, pixkind=PIXKIND["b64a"], enc=4)
+    assert plan.num_channels == 4 and plan.band[(1, 0, 3)]["quant"] < b64a.band[(1, 0, 3)]["quant"]
+    eh = 2 * plan.band[(0, 0, 0)]["height"]
+    planes = [np.vstack([p.astype(np.int16), np.zeros((eh - h, w), np.int16)]) for p in ((px[:, :, 1] << 4), (px[:, :, 2] << 4), (px[:, :, 0] << 4), a)]
+    off, n = first_metadata_chunk(rs)
+    mine = product_write_sample_host(plan, oracle_forward_planes(plan, planes), 1, meta_global=rs[off:off + n], input_format={"BGRA": 32, "BGRa": 9}[name], color_space=0)
+    assert len(mine) == len(rs)
+    diff = [i for i, (x, y) in enumerate(zip(mine, rs)) if x != y]
+    assert diff == [90, 91] and rs[88:92] == bytes([0xff, 0xaf, 0x21, 0xa0])
+
+
 @pytest.mark.parametrize("w,h", [(192, 96), (320, 240), (400, 120), (720, 480)])
 def test_v210_sample_bytes_equal_reference(w, h):
     """v210 (10-bit 4:2:2) -> YUV 4:2:2 sample, input format 10.  Pins the reading of the reference's unpack (convert.c:3968), including its
@@ -373,8 +426,11 @@ def test_deep_rgb_as_yuv422_and_rgb10_outputs_are_accepted():
     round 3): CFHD_PrepareToEncode goes on to the GPU (any answer but BADFORMAT here, where there is none); CFHD_PrepareToDecode is host code."""
     L = product()
     enc = ctypes.c_void_p(); assert L.CFHD_OpenEncoder(ctypes.byref(enc), None) == 0
-    for fmt in (PIX_RG48, PIX_B64A):
+    for fmt in (PIX_RG48, PIX_B64A, PIX_RG24, PIX_BGRA, PIX_BGRa):           # (8-bit RGB -> 4:2:2: added later in round 3)
         assert L.CFHD_PrepareToEncode(enc, 320, 240, fmt, ENCODED_YUV422, 0, QUALITY_FILMSCAN1) != 3
+    assert L.CFHD_PrepareToEncode(enc, 328, 240, PIX_BGRA, ENCODED_YUV422, 0, QUALITY_FILMSCAN1) == 3          # chroma width must divide by 8
+    for fmt in (PIX_BGRA, PIX_BGRa): assert L.CFHD_PrepareToEncode(enc, 320, 240, fmt, ENCODED_RGBA4444, 0, QUALITY_FILMSCAN1) != 3
+    assert L.CFHD_PrepareToEncode(enc, 320, 240, PIX_RG24, ENCODED_RGBA4444, 0, QUALITY_FILMSCAN1) == 3           # no alpha to encode
     if have_ref():
         frgb, prgb = qbist_frames(10, 1, 320, 240, PIX_RG48)
         sample = ref_encode_frames(frgb, prgb, 320, 240, PIX_RG48, encoded=ENCODED_RGB444)[0]

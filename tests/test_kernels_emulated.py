@@ -900,6 +900,33 @@ def test_fwd_packed16_level1_of_deep_rgb_as_yuv422(w, h, dh, wpp, cs):
             assert np.array_equal(outs[4 * c + b][:, :cw // 2], want[b][:, :cw // 2]), (c, b)
 
 
+@pytest.mark.parametrize("w,h,dh,bpp,top_down,cs", [(32, 16, 16, 3, 0, 0), (144, 40, 37, 4, 0, 0), (336, 24, 24, 4, 1, 1), (208, 16, 13, 3, 0, 2), (64, 8, 8, 4, 1, 3)])
+def test_fwd_packed16_level1_of_rgb8_as_yuv422(w, h, dh, bpp, top_down, cs):
+    """RG24 / BGRA / BGRa encoded as YUV 4:2:2: the loader of k_fwd_packed16 converts the pixels on the way in (layout 8 / 9) = the oracle's
+    conversion (pinned on reference samples in test_host_bitstream) + the oracle's plane transform of the three planes; all four matrices,
+    saturated primaries, both row orders, the constant rows (Y 64, chroma 512) below the picture."""
+    rng = np.random.default_rng(w + h + bpp)
+    px = rng.integers(0, 256, size=(dh, w, bpp), dtype=np.int64).astype(np.uint8)
+    px[::3, ::4, :3] = [255, 0, 0]; px[1::3, 1::4, :3] = [0, 0, 255]; px[2::5, 2::6, :3] = [255, 255, 255]; px[::7, 3::5, :3] = 0; px[1::4, 2::7, :3] = [0, 255, 0]
+    frame = np.ascontiguousarray(px.reshape(dh, w * bpp))
+    quant = [1, 24, 24, 12] * 3
+    pitches = [(cw // 2 + 7) // 8 * 8 for cw in (w, w // 2, w // 2)]
+    outs = [np.zeros((h // 2, pitches[c]), np.int16) for c in range(3) for _ in range(4)]
+    ptrs = (c_i16p * 12)(*[p16(o) for o in outs])
+    E = emu()
+    E.emu_fwd_rgb8_to_yuv422.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 7 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    E.emu_fwd_rgb8_to_yuv422(frame.ctypes.data_as(ctypes.c_void_p), w * bpp, bpp, top_down, w, h, dh, cs, iarr(quant), 2, ptrs, iarr(pitches))
+    planes = oracle_rgb8_to_yuv422_planes(frame, w * bpp, bpp, top_down, w, dh, h, cs)
+    assert planes[1].max() > 850 and planes[2].min() < 200 and planes[0].max() >= 930
+    for c in range(3):
+        cw = w if c == 0 else w // 2
+        want = [np.zeros((h // 2, pitches[c]), np.int16) for _ in range(4)]
+        bands = (c_i16p * 4)(*[p16(o) for o in want])
+        oracle().orc_fwd_spatial(p16(np.ascontiguousarray(planes[c])), cw, cw, h, 0, iarr(quant[:4]), 2, bands, pitches[c])
+        for b in range(4):
+            assert np.array_equal(outs[4 * c + b][:, :cw // 2], want[b][:, :cw // 2]), (c, b)
+
+
 @pytest.mark.parametrize("w,h,dh", [(48, 16, 16), (144, 40, 37), (320, 24, 24), (400, 16, 13)])
 def test_fwd_packed16_level1_of_v210(w, h, dh):
     """v210 input: the loader of k_fwd_packed16 picks the 10-bit fields out of the 32-bit words = the oracle's plane transform of the planes
@@ -976,6 +1003,33 @@ def test_fwd_packed16_level1_of_rg24(w, h, dh):
     px = buf[:, : w * 3].reshape(dh, w, 3)[::-1]
     for c, byte in enumerate((1, 2, 0)):
         plane = np.zeros((h, w), np.int16); plane[:dh] = px[:, :, byte].astype(np.int16) << 4
+        want = [np.zeros((h // 2, opitch), np.int16) for _ in range(4)]
+        bands = (c_i16p * 4)(*[p16(o) for o in want])
+        oracle().orc_fwd_spatial(p16(plane), w, w, h, 0, iarr(quant[:4]), 2, bands, opitch)
+        for b in range(4):
+            assert np.array_equal(outs[4 * c + b][:, :w // 2], want[b][:, :w // 2]), (c, b)
+
+
+@pytest.mark.parametrize("w,h,dh,top_down", [(32, 16, 16, 0), (136, 40, 37, 1), (320, 24, 24, 0)])
+def test_fwd_packed16_level1_of_rgba8(w, h, dh, top_down):
+    """BGRA / BGRa encoded as RGBA 4:4:4:4: planes G, R, B = byte << 4, alpha = byte << 4 curved inside the open interval (0, 255 << 4) (frame.c:6415
+    ConvertRGBAtoRGBA64; every alpha byte value occurs), zero rows below the picture."""
+    rng = np.random.default_rng(w + h)
+    px = rng.integers(0, 256, size=(dh, w, 4), dtype=np.int64).astype(np.uint8)
+    px.reshape(-1, 4)[:256, 3] = np.arange(256)
+    buf = np.ascontiguousarray(px.reshape(dh, w * 4))
+    quant = [1, 12, 12, 24] * 4
+    opitch = (w // 2 + 7) // 8 * 8
+    outs = [np.zeros((h // 2, opitch), np.int16) for _ in range(16)]
+    ptrs = (c_i16p * 16)(*[p16(o) for o in outs])
+    E = emu()
+    E.emu_fwd_rgba8.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    E.emu_fwd_rgba8(buf.ctypes.data_as(ctypes.c_void_p), w * 4, top_down, w, h, dh, iarr(quant), 2, ptrs, opitch)
+    src = px if top_down else px[::-1]
+    for c, byte in enumerate((1, 2, 0, 3)):
+        v = src[:, :, byte].astype(np.int32) << 4
+        if c == 3: v = np.where((v > 0) & (v < 4080), ((v * 223 + 128) >> 8) + 256, v)
+        plane = np.zeros((h, w), np.int16); plane[:dh] = v.astype(np.int16)
         want = [np.zeros((h // 2, opitch), np.int16) for _ in range(4)]
         bands = (c_i16p * 4)(*[p16(o) for o in want])
         oracle().orc_fwd_spatial(p16(plane), w, w, h, 0, iarr(quant[:4]), 2, bands, opitch)
