@@ -998,7 +998,9 @@ CFHD_Error CFHD_PrepareToDecode(CFHD_DecoderRef ref, int, int, CFHD_PixelFormat 
 	if (kind == PIX_YU64 && (encf != ENC_YUV422 || half)) return ERR_BADFORMAT;
 	// ... and RGB 4:4:4 samples to the 8-bit pixels RG24 / BGRA / BGRa (the RG48 reconstruction reduced with the reference's four-bit dither; full resolution)
 	const bool rgb8 = kind == PIX_RG24 || kind == PIX_BGRA || kind == PIX_BGRa;
-	if (rgb8 && (encf != ENC_RGB444 || half || d->header.width < 32)) return ERR_BADFORMAT;
+	// ... and RGBA 4:4:4:4 samples to BGRA / BGRa (no dither there: (12-bit component + 2) >> 4, the alpha expanded from that rounded value)
+	const bool rgba8 = (kind == PIX_BGRA || kind == PIX_BGRa) && encf == ENC_RGBA4444;
+	if (rgb8 && ((encf != ENC_RGB444 && !rgba8) || half || d->header.width < 32)) return ERR_BADFORMAT;
 	// ... and to the 10-bit RGB words r210 / DPX0 / AB10 / AR10 ((value before the final >> 1, + 3) >> 3 per component: a model fitted on the reference
 	// decoder and pinned word for word on the CPU, equal to the reference decoder on the GPU)
 	const bool rgb10 = kind >= PIX_R210 && kind <= PIX_AR10;
@@ -1006,7 +1008,7 @@ CFHD_Error CFHD_PrepareToDecode(CFHD_DecoderRef ref, int, int, CFHD_PixelFormat 
 	// ... and 4:2:2 samples to v210 (the YU64 words >> 6, three to a 32-bit word: DecodeBatch / k_yu64_to_v210; widths of whole six-pixel groups)
 	if (kind == PIX_V210 && (encf != ENC_YUV422 || half || d->header.width % 6 || d->header.width < 128)) return ERR_BADFORMAT;
 	if (kind == PIX_BYR4 || (kind >= PIX_R210 && kind <= PIX_AR10 && !rgb10)) return ERR_BADFORMAT;     // encoder inputs only
-	if ((encf == ENC_RGB444) != (kind == PIX_RG48 || rgb8 || rgb10) || (encf == ENC_RGBA4444) != (kind == PIX_B64A)) return ERR_BADFORMAT;
+	if ((encf == ENC_RGB444) != (kind == PIX_RG48 || (rgb8 && !rgba8) || rgb10) || (encf == ENC_RGBA4444) != (kind == PIX_B64A || rgba8)) return ERR_BADFORMAT;
 	if (kind == PIX_YU64 && d->header.width < 128) return ERR_BADFORMAT;      // (the tail-column rule of the 16-bit rows is restated for chroma bands of 16 columns and more)
 	bool ok;
 	plan_from_sample(d->header, kind, &d->plan, &ok);

@@ -93,8 +93,8 @@ static int rgb8_bytes(int out_kind) { return out_kind == PIX_RG24 ? 3 : 4; }
 // ... and the 10-bit RGB words (r210, DPX0: big-endian; AB10, AR10: little-endian) through k_inv_rgb10 (orc_inv_spatial_to_rgb10)
 static bool dec_rgb10(int out_kind) { return out_kind >= PIX_R210 && out_kind <= PIX_AR10; }
 static bool dec_planes16(int out_kind) { return is_packed16(out_kind) || out_kind == PIX_YU64 || dec_rgb8(out_kind) || dec_rgb10(out_kind); }
-// position of plane c inside the pixel: 16-bit word, or byte for the 8-bit formats (planes G, R, B -> bytes 1, 2, 0)
-static int dec_word_of_channel(int out_kind, int c) { return dec_rgb10(out_kind) ? 0 : out_kind == PIX_YU64 ? (c == 0 ? 0 : (c == 1 ? 1 : 3)) : (dec_rgb8(out_kind) ? (c == 0 ? 1 : (c == 1 ? 2 : 0)) : packed_word_of_channel(out_kind, c)); }
+// position of plane c inside the pixel: 16-bit word, or byte for the 8-bit formats (planes G, R, B(, A) -> bytes 1, 2, 0(, 3))
+static int dec_word_of_channel(int out_kind, int c) { return dec_rgb10(out_kind) ? 0 : out_kind == PIX_YU64 ? (c == 0 ? 0 : (c == 1 ? 1 : 3)) : (dec_rgb8(out_kind) ? (c == 0 ? 1 : (c == 1 ? 2 : (c == 2 ? 0 : 3))) : packed_word_of_channel(out_kind, c)); }
 static int dec_stride_of_channel(int out_kind, int c, int nch) { return out_kind == PIX_YU64 ? (c == 0 ? 2 : 4) : (dec_rgb8(out_kind) ? rgb8_bytes(out_kind) : (dec_rgb10(out_kind) ? 3 : nch)); }
 static int dec_words_per_position(int out_kind, int nch) { return out_kind == PIX_YU64 ? 2 : (dec_rgb8(out_kind) ? rgb8_bytes(out_kind) : nch); }
 static int16_t *dec_plane_out(void *frame, int out_kind, int c) { return dec_rgb8(out_kind) ? (int16_t *)((uint8_t *)frame + dec_word_of_channel(out_kind, c)) : (int16_t *)((uint16_t *)frame + dec_word_of_channel(out_kind, c)); }
@@ -684,8 +684,8 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 				uint16_t *frame = own_output ? (uint16_t *)(job_out + job_frame_bytes * i) : nullptr;
 				p.out = frame ? dec_plane_out(frame, out_kind, c) : nullptr; p.out_pitch = dec_rgb8(out_kind) ? job_pitch : job_pitch / 2;
 				p.xstride = dec_stride_of_channel(out_kind, c, nch); p.precision = plan.precision; p.display_height = plan.display_height;
-				p.alpha = out_kind == PIX_B64A && c == 3;
-				p.bytes8 = dec_rgb8(out_kind); p.bottom_up = out_kind == PIX_RG24 || out_kind == PIX_BGRA; p.dither_seed = 0x9E3779B9u * (uint32_t)(i + 1);
+				p.alpha = (out_kind == PIX_B64A || dec_rgb8(out_kind)) && c == 3;
+				p.bytes8 = dec_rgb8(out_kind) ? (nch == 4 ? 2 : 1) : 0;        // 2: BGRA / BGRa of an RGBA 4:4:4:4 sample (alpha from the fourth plane, no dither) p.bottom_up = out_kind == PIX_RG24 || out_kind == PIX_BGRA; p.dither_seed = 0x9E3779B9u * (uint32_t)(i + 1);
 				if (dec_rgb10(out_kind)) { p.out = (int16_t *)frame; p.out_pitch = job_pitch / 4; p.bit_shift = rgb10_shift(out_kind, c); p.big_endian = out_kind == PIX_R210 || out_kind == PIX_DPX0; }
 			}
 			continue;

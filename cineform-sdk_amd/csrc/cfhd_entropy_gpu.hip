@@ -115,7 +115,7 @@ int GpuEntropyEncoder::launch()
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[2], st));
 	// workgroups per frame: enough to fill the chip for short batches of large frames, at least the 8 that 512 1080p frames were tuned with
 	const unsigned layout_parts = act >= 256 ? 8u : (unsigned)((2048 + act - 1) / act > 256 ? 256 : (2048 + act - 1) / act);
-	dev::k_ent_layout<<<dim3((unsigned)act, layout_parts), dev::ENT_THREADS, 0, st>>>((const dev::EntFrameJob *)d_frames_, (const dev::EntBandJob *)d_bands_, (const dev::EntSegState *)d_segs_,
+	dev::k_ent_layout<<<dim3((unsigned)act, layout_parts), dev::ENT_THREADS, 0, st>>>((const dev::EntFrameJob *)d_frames_, (const dev::EntBandJob *)d_bands_, (dev::EntSegState *)d_segs_,
 	                                                  (dev::EntBandState *)d_bandstate_, T);
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[3], st));
 	dev::k_ent_emit<<<(total_segs + dev::ENT_WAVES - 1) / dev::ENT_WAVES, dev::ENT_THREADS, 0, st>>>((const dev::EntSegJob *)d_segband_, geom, total_segs, (const dev::EntSegState *)d_segs_,

@@ -33,9 +33,9 @@ namespace dev {
 enum { ENT_THREADS = 256, ENT_LANES = 64, ENT_WAVES = ENT_THREADS / ENT_LANES, ENT_PER_THREAD = CFHD_ENT_PER_THREAD, ENT_SEG = ENT_LANES * ENT_PER_THREAD,
        ENT_LDS_WORDS = 256, ENT_TOK_CAP = CFHD_ENT_TOK_CAP, ENT_MAX_HOLES = 40,
        ENT_FILL = CFHD_ENT_FILL /* bytes of a sample one workgroup of k_ent_layout fills at a time */,
-       // what k_ent_count leaves per segment for k_ent_emit (32-bit words): ENT_SEG tokens (local raster index << 16 | value), then ENT_SEG finished
-       // bit strings of two words each (run code + value code of the token, left aligned in 58 bits, length in the low 6 bits)
-       ENT_TOK_STRIDE = 3 * ENT_SEG, ENT_CODE_COMPLEX = 63 /* length field: the token's run takes several run codes -- k_ent_emit walks the tables for it */,
+       // what k_ent_count leaves per segment for k_ent_emit (32-bit words): one finished bit string of two words per token (run code + value code, left
+       // aligned in 58 bits, length in the low 6 bits; a token whose run takes several run codes carries run << 16 | value in its second word instead)
+       ENT_TOK_STRIDE = 2 * ENT_SEG, ENT_CODE_COMPLEX = 63 /* length field: the token's run takes several run codes -- k_ent_emit walks the tables for it */,
        ENT_RUN_COMPLEX = 0xff /* EntSegState::run_size: the run in front of the segment's first token takes several run codes */ };
 // ENT_LDS_WORDS: 32-bit words of the per-wave bit window in LDS (a segment of ordinary pictures codes into 10-40 words; beyond the window
 // the code words go to the payload with global atomics).  ENT_TOK_CAP: tokens (nonzero coefficients) of a segment held in LDS at a
@@ -81,7 +81,13 @@ struct EntSegState {               // per segment, written by k_ent_count / k_en
 	// token strings, k_ent_scan puts the first run's code in front.  The segment in FRONT writes the payload word the two share, with these
 	// bits merged in, as a plain store: no atomic on the payload for ordinary segments (ent_neighbours_merge()).
 	uint32_t lead32, lead_valid;
+	// What k_ent_emit would otherwise have to fetch through two more tables, one load behind the other (segment job -> band state): where the band's
+	// payload lies (k_ent_layout; null while the sample is not placed or overflowed its buffer) and bit 0: a segment of the same band precedes,
+	// bit 1: one follows, bits 8..: the band's entropy table (k_ent_count).  One 64-byte record per segment, three scalar loads per emitting wave.
+	uint8_t *out;
+	uint32_t info, reserved;
 };
+static_assert(sizeof(EntSegState) == 64, "one segment state per 64 bytes");
 
 struct EntBandState { uint32_t seg_bits, tail_run, payload_bytes, base_byte; uint8_t *out; /* payload address in the sample; null until k_ent_layout placed it */ };
 
@@ -147,34 +153,8 @@ __device__ __forceinline__ uint32_t run_bits_any(const EntTables *T, uint32_t ru
 
 __device__ __forceinline__ uint32_t value_entry(const EntTables *T, int v)
 {
-	if (v < 0) { if (v <= -1024) v = -1023; v += 2048; } else if (v >= 1024) v = 1023;
-	return T->value_code[v];
-}
-
-// Loads the ENT_PER_THREAD coefficients of this lane (raster indices base .. base+ENT_PER_THREAD-1, zero beyond the band) with 16-byte loads.
-__device__ __forceinline__ void ent_load16(const EntSegJob &job, int base, int *v)
-{
-	static_assert(ENT_PER_THREAD % 8 == 0, "whole uint4 loads");
-	if (base + ENT_PER_THREAD <= job.n) {
-#pragma unroll
-		for (int g = 0; g < ENT_PER_THREAD / 8; g++) {
-			const uint4 q = *(const uint4 *)(job.coeffs + base + 8 * g);
-			const uint32_t w[4] = { q.x, q.y, q.z, q.w };
-#pragma unroll
-			for (int k = 0; k < 4; k++) { v[8 * g + 2 * k] = (int)(int16_t)(w[k] & 0xffffu); v[8 * g + 2 * k + 1] = (int)(int16_t)(w[k] >> 16); }
-		}
-	} else {
-#pragma unroll
-		for (int k = 0; k < ENT_PER_THREAD; k++) v[k] = (base + k < job.n) ? (int)job.coeffs[base + k] : 0;
-	}
-}
-
-// Last nonzero in front of this lane inside the wave's segment (-1: none): the nearest lower lane that holds one.
-__device__ __forceinline__ int wave_prev_nonzero(int my_last, int lane, unsigned long long mask)
-{
-	const unsigned long long lower = mask & ((1ull << lane) - 1ull);
-	const int prev = __shfl(my_last, lower ? 63 - __builtin_clzll(lower) : lane);
-	return lower ? prev : -1;
+	v = v < -1023 ? -1023 : (v > 1023 ? 1023 : v);       // (one v_med3; a negative value's entry sits at value + 2048)
+	return T->value_code[v & 2047];
 }
 
 // =============================================================================================
@@ -194,106 +174,110 @@ __device__ __forceinline__ EntSegJob ent_seg_job(const EntSegJob *seg_jobs, cons
 // peak_flags[frame] is raised when a band coded with table 1 holds a coefficient beyond +-ENT_PEAK_THRESHOLD: the reference then appends a
 // peak table (encoder.c:4802, :6543), which this stage does not produce -- the caller sends that frame through the host writer.
 enum { ENT_PEAK_THRESHOLD = 250 };
-// The compacted token list of every segment (local raster index << 16 | value) is kept in `tokens` (ENT_SEG words per segment, the first
-// ntok used): k_ent_emit codes from that list -- a sixth of the bytes -- instead of reading and compacting the coefficients a second time.
+// The finished bit string of every token (nonzero coefficient) of every segment is kept in `tokens` (ENT_TOK_STRIDE words per segment, the first
+// 2 * ntok used): k_ent_emit places those -- a third of the bytes -- instead of reading, compacting and coding the coefficients a second time.
 __global__ void __launch_bounds__(ENT_THREADS) k_ent_count(const EntSegJob *seg_jobs, EntBatchGeom geom, int total_segs, EntSegState *segs, const EntTables *tables,
-                                                            uint32_t *peak_flags, uint32_t *tokens, int probe = 0 /* timing experiments: 1 behind the loads, 2 behind the scan, 3 behind the compaction, 4 no token stores */)
+                                                            uint32_t *peak_flags, uint32_t *tokens, int probe = 0 /* timing experiments: 1 behind the loads, 2 behind the compaction, 4 no token stores */)
 {
-	__shared__ uint32_t s_tok_all[ENT_WAVES][ENT_TOK_CAP];   // tokens of the current pass: local raster index << 16 | value (16 bits)
+	__shared__ uint32_t s_tok_all[ENT_WAVES][ENT_SEG];       // the segment's tokens: local raster index << 16 | value (16 bits); every coefficient may be one
 	const int lane = wave_lane();
 	const int seg = wave_uniform((int)blockIdx.x * ENT_WAVES + (int)(threadIdx.x >> 6));
 	if (seg >= total_segs) return;                       // whole wave
 	int frame;
 	const EntSegJob job = ent_seg_job(seg_jobs, geom, seg, &frame);
 	const EntTables *T = tables + job.table;
-	const int base = job.first + lane * ENT_PER_THREAD;
-	int v[ENT_PER_THREAD];
-	ent_load16(job, base, v);
-	int my_last = -1, my_first = -1;
+	// The picture is sparse (about one coefficient in twelve is nonzero), so the code lookups run over a compacted token list, one token per lane
+	// and round.  Compaction is what this kernel's instructions went into while every lane held 16 consecutive coefficients (a count, a wave scan and
+	// 16 predicated LDS stores per lane: VALU-bound at 1.7 ms).  Now lane L holds the dwords j * 64 + L of the segment (coalesced 4-byte loads):
+	// raster order is then j-major, lane, low / high half, which is the order of a ballot -- a token's position is the number of nonzero halves
+	// in the rounds before (scalar popcounts) plus those in the lanes below (v_mbcnt), no scan, no per-lane count.
+	const int rem = job.n - job.first;                   // coefficients from the segment's start to the end of the band (>= 1)
+	const uint32_t *src = (const uint32_t *)(job.coeffs + job.first);
+	uint32_t w[ENT_SEG / 128];
+	if (rem >= ENT_SEG) {                                // wave-uniform: every segment of a band but its last
 #pragma unroll
-	for (int k = 0; k < ENT_PER_THREAD; k++) if (v[k]) { my_last = base + k; if (my_first < 0) my_first = base + k; }
-	if (job.table) {
-		bool peak = false;
+		for (int j = 0; j < ENT_SEG / 128; j++) w[j] = CFHD_LDG32(src + j * ENT_LANES + lane);
+	} else {
 #pragma unroll
-		for (int k = 0; k < ENT_PER_THREAD; k++) peak |= v[k] > ENT_PEAK_THRESHOLD || v[k] < -ENT_PEAK_THRESHOLD;
-		if (__ballot(peak) && lane == 0) atomic_or_u32(&peak_flags[frame], 1u);
+		for (int j = 0; j < ENT_SEG / 128; j++) {
+			const int d = j * ENT_LANES + lane;
+			uint32_t x = 2 * d < rem ? CFHD_LDG32(src + d) : 0u;
+			if (2 * d + 1 >= rem) x &= 0xffffu;
+			w[j] = x;
+		}
 	}
-	const unsigned long long mask = __ballot(my_last >= 0);
-	if (probe == 1) { if (lane == 0) { EntSegState &z = segs[seg]; z.first_nz = -1; z.last_nz = -1; z.bits = mask == 0x123456789ull; z.ntok = 0; z.lead32 = 0; z.lead_valid = 0; } return; }
-	// The picture is sparse (about one coefficient in twelve is nonzero): looking up all 16 x 64 coefficients kept the CU's
-	// texture-address path busy with gathers for zeros (32 gather instructions per wave: the kernel was bound by them, not by
-	// bytes).  The nonzero coefficients are compacted into a token list in LDS first -- as k_ent_emit does -- and the lookups
-	// run over the list, one token per lane and round.
+	if (probe == 1) { uint32_t o = 0; for (int j = 0; j < ENT_SEG / 128; j++) o |= w[j]; const unsigned long long q = __ballot(o == 0x12345u); if (lane == 0) { EntSegState &z = segs[seg]; z.first_nz = -1; z.last_nz = -1; z.bits = q == 0x123456789ull; z.ntok = 0; z.lead32 = 0; z.lead_valid = 0; } return; }
 	uint32_t *s_tok = s_tok_all[wave_uniform((int)(threadIdx.x >> 6))];
-	int cnt = 0;
+	int ntok = 0;                                        // wave-uniform
 #pragma unroll
-	for (int k = 0; k < ENT_PER_THREAD; k++) cnt += v[k] != 0;
-	const int incl = (int)wave_incl_scan((uint32_t)cnt);
-	const int ntok = (int)wave_get((uint32_t)incl, ENT_LANES - 1);
-	uint32_t bits = 0, carry_tok = 0, lead32 = 0, lead_valid = 0;
-	if (probe == 2) { if (lane == 0) { EntSegState &z = segs[seg]; z.first_nz = -1; z.last_nz = -1; z.bits = ntok == 0x12345; z.ntok = 0; z.lead32 = 0; z.lead_valid = 0; } return; }
-	for (int lo = 0; lo < ntok; lo += ENT_TOK_CAP) {     // wave-uniform: one pass unless the segment is unusually dense
-		if (lo) { carry_tok = s_tok[ENT_TOK_CAP - 1]; CFHD_WAVE_SYNC(); }
-		{
-			int at = incl - cnt - lo;
-#pragma unroll
-			for (int k = 0; k < ENT_PER_THREAD; k++)
-				if (v[k]) { if ((unsigned)at < (unsigned)ENT_TOK_CAP) s_tok[at] = ((uint32_t)(lane * ENT_PER_THREAD + k) << 16) | (uint32_t)(uint16_t)v[k]; at++; }
+	for (int j = 0; j < ENT_SEG / 128; j++) {
+		const uint32_t vl = w[j] & 0xffffu, vh = w[j] >> 16;
+		const unsigned long long ml = __ballot(vl != 0u), mh = __ballot(vh != 0u);
+		const int pl = ntok + (int)wave_mbcnt(ml) + (int)wave_mbcnt(mh);
+		const uint32_t idx = (uint32_t)(j * 128 + 2 * lane) << 16;
+		if (vl) s_tok[pl] = idx | vl;
+		if (vh) s_tok[pl + (vl != 0u)] = (idx + 0x10000u) | vh;
+		ntok += __popcll(ml) + __popcll(mh);
+	}
+	CFHD_WAVE_SYNC();
+	uint32_t bits = 0, lead32 = 0, lead_valid = 0;
+	if (probe == 2) { const unsigned long long q = __ballot(s_tok[lane] == 0x12345u); if (lane == 0) { EntSegState &z = segs[seg]; z.first_nz = -1; z.last_nz = -1; z.bits = q == 0x123456789ull && ntok == 0x12345; z.ntok = 0; z.lead32 = 0; z.lead_valid = 0; } return; }
+	bool peak = false;
+	for (int t0 = 0; t0 < ntok; t0 += ENT_LANES) {       // wave-uniform
+		const int t = t0 + lane;
+		const bool have = t < ntok;
+		const uint32_t tok = have ? s_tok[t] : 0u;
+		const uint32_t before = (have && t > 0) ? s_tok[t - 1] : 0u;
+		// zero run in front of the token, inside the segment (< 1024); the run in front of the segment's first token reaches into
+		// the earlier segments and is added by k_ent_scan
+		const uint32_t run = (have && t > 0) ? (tok >> 16) - (before >> 16) - 1u : 0u;
+		const int value = (int)(int16_t)(tok & 0xffffu);
+		peak |= value > ENT_PEAK_THRESHOLD || value < -ENT_PEAK_THRESHOLD;
+		const uint32_t ve = value_entry(T, value);
+		const uint32_t rt = T->run_total[run];
+		const uint2 rp = T->run_pack[run];
+		uint32_t my_top = 0, my_len = 0;
+		if (have) {
+			bits += rt + (ve >> 27);
+			uint32_t *seg_out = tokens + (size_t)seg * ENT_TOK_STRIDE;
+			// the token's finished bit string for k_ent_emit: run code (when one code covers the run: nearly always) + value code, at most
+			// 31 + 27 bits, left aligned; the first token of the segment carries its value code only (its run reaches into the earlier
+			// segments: k_ent_scan works that one out)
+			const uint32_t vs = ve >> 27, vc = ve & 0x7FFFFFFu, rs = run ? rp.y & 0xffu : 0u;
+			const bool simple = run == 0u || (rp.y >> 8) == run;
+			const uint64_t str = simple ? (((uint64_t)(run ? rp.x : 0u) << vs) | vc) << (64u - rs - vs) : 0ull;      // (rs + vs >= 2: a value code has at least its sign)
+			const uint32_t len = simple ? rs + vs : (uint32_t)ENT_CODE_COMPLEX;
+			uint2 rec; rec.x = (uint32_t)str | len; rec.y = simple ? (uint32_t)(str >> 32) : (run << 16) | (tok & 0xffffu);
+			if (probe != 4) ((uint2 *)seg_out)[t] = rec;
+			my_top = rec.y; my_len = len;
 		}
-		CFHD_WAVE_SYNC();
-		if (probe == 3) { const unsigned long long q = __ballot(s_tok[lane] == 0x12345u); if (lane == 0) { EntSegState &z = segs[seg]; z.first_nz = -1; z.last_nz = -1; z.bits = q == 0x123456789ull; z.ntok = 0; z.lead32 = 0; z.lead_valid = 0; } return; }
-		const int hi = ntok - lo < ENT_TOK_CAP ? ntok - lo : ENT_TOK_CAP;
-		for (int t0 = 0; t0 < hi; t0 += ENT_LANES) {
-			const int tl = t0 + lane, t = lo + tl;
-			const bool have = tl < hi;
-			const uint32_t tok = have ? s_tok[tl] : 0u;
-			const uint32_t before = (have && t > 0) ? (tl > 0 ? s_tok[tl - 1] : carry_tok) : 0u;
-			// zero run in front of the token, inside the segment (< 1024); the run in front of the segment's first token reaches into
-			// the earlier segments and is added by k_ent_scan
-			const uint32_t run = (have && t > 0) ? (tok >> 16) - (before >> 16) - 1u : 0u;
-			const uint32_t ve = value_entry(T, (int)(int16_t)(tok & 0xffffu));
-			const uint32_t rt = T->run_total[run];
-			const uint2 rp = T->run_pack[run];
-			uint32_t my_top = 0, my_len = 0;
-			if (have) {
-				bits += rt + (ve >> 27);
-				uint32_t *seg_out = tokens + (size_t)seg * ENT_TOK_STRIDE;
-				if (probe != 4) seg_out[t] = tok;
-				// the token's finished bit string for k_ent_emit: run code (when one code covers the run: nearly always) + value code, at most
-				// 31 + 27 bits, left aligned; the first token of the segment carries its value code only (its run reaches into the earlier
-				// segments: k_ent_scan works that one out)
-				const uint32_t vs = ve >> 27, vc = ve & 0x7FFFFFFu, rs = run ? rp.y & 0xffu : 0u;
-				const bool simple = run == 0u || (rp.y >> 8) == run;
-				const uint64_t str = simple ? (((uint64_t)(run ? rp.x : 0u) << vs) | vc) << (64u - rs - vs) : 0ull;      // (rs + vs >= 2: a value code has at least its sign)
-				const uint32_t len = simple ? rs + vs : (uint32_t)ENT_CODE_COMPLEX;
-				uint2 rec; rec.x = (uint32_t)str | len; rec.y = (uint32_t)(str >> 32);
-				if (probe != 4) ((uint2 *)(seg_out + ENT_SEG))[t] = rec;
-				my_top = rec.y; my_len = len;
-			}
-			if (t0 == 0 && lo == 0) {
-				// the first 32 bits of the strings of this round, as far as they are plain strings (up to the first token that needs the table walk)
-				const unsigned long long cx = __ballot(have && my_len == (uint32_t)ENT_CODE_COMPLEX);
-				const uint32_t l = (have && my_len != (uint32_t)ENT_CODE_COMPLEX) ? my_len : 0u;
-				const uint32_t sc = wave_incl_scan(l), ex = sc - l;
-				const int stop_lane = cx ? __builtin_ctzll(cx) : (hi < ENT_LANES ? hi : ENT_LANES);      // strings of lanes 0 .. stop_lane-1 count
-				uint32_t part = (lane < stop_lane && ex < 32u) ? my_top >> ex : 0u;
+		if (t0 == 0) {
+			// the first 32 bits of the strings of this round, as far as they are plain strings (up to the first token that needs the table walk)
+			const int hi = ntok < ENT_LANES ? ntok : ENT_LANES;
+			const unsigned long long cx = __ballot(have && my_len == (uint32_t)ENT_CODE_COMPLEX);
+			const uint32_t l = (have && my_len != (uint32_t)ENT_CODE_COMPLEX) ? my_len : 0u;
+			const uint32_t sc = wave_incl_scan(l), ex = sc - l;
+			const int stop_lane = cx ? __builtin_ctzll(cx) : hi;      // strings of lanes 0 .. stop_lane-1 count
+			uint32_t part = (lane < stop_lane && ex < 32u) ? my_top >> ex : 0u;
 #pragma unroll
-				for (int d = 1; d < ENT_LANES; d <<= 1) part |= __shfl_xor(part, d);
-				lead32 = part;
-				const uint32_t known = stop_lane > 0 ? wave_get(sc, stop_lane - 1) : 0u;
-				lead_valid = known < 32u ? known : 32u;
-			}
+			for (int d = 1; d < ENT_LANES; d <<= 1) part |= __shfl_xor(part, d);
+			lead32 = part;
+			const uint32_t known = stop_lane > 0 ? wave_get(sc, stop_lane - 1) : 0u;
+			lead_valid = known < 32u ? known : 32u;
 		}
 	}
+	// raised when a band coded with table 1 holds a coefficient beyond the peak threshold (see above)
+	if (job.table && __ballot(peak) && lane == 0) atomic_or_u32(&peak_flags[frame], 1u);
 	bits = wave_get(wave_incl_scan(bits), ENT_LANES - 1);
-	const int first_nz = __shfl(my_first, mask ? __builtin_ctzll(mask) : 0), last_nz = __shfl(my_last, mask ? 63 - __builtin_clzll(mask) : 0);
 	if (lane == 0) {
 		EntSegState &s = segs[seg];
-		s.first_nz = mask ? first_nz : -1;
-		s.last_nz = mask ? last_nz : -1;
+		s.first_nz = ntok ? job.first + (int)(s_tok[0] >> 16) : -1;
+		s.last_nz = ntok ? job.first + (int)(s_tok[ntok - 1] >> 16) : -1;
 		s.bits = bits;
 		s.ntok = (uint32_t)ntok;
 		s.lead32 = lead32; s.lead_valid = lead_valid;
+		s.out = nullptr;
+		s.info = (job.first != 0 ? 1u : 0u) | (job.first + ENT_SEG < job.n ? 2u : 0u) | ((uint32_t)job.table << 8);
 	}
 }
 
@@ -380,7 +364,7 @@ __device__ __forceinline__ void put_code_plain(uint32_t *words, uint64_t pos, ui
 }
 
 // =============================================================================================
-__global__ void __launch_bounds__(ENT_THREADS) k_ent_layout(const EntFrameJob *frames, const EntBandJob *bands, const EntSegState *segs,
+__global__ void __launch_bounds__(ENT_THREADS) k_ent_layout(const EntFrameJob *frames, const EntBandJob *bands, EntSegState *segs,
                                                              EntBandState *band_state, const EntTables *tables)
 {
 	// gridDim.y workgroups share a frame: every one of them works out the layout (40 holes), workgroup 0 writes the template words and
@@ -477,6 +461,7 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_layout(const EntFrameJob *f
 			words[i] = bswap32(w);
 		}
 		__syncthreads();                                  // (uniform: k, last are) the words of the trailer are in place
+		for (int i = tid; i < bands[hole.band_job].nseg; i += ENT_THREADS) segs[bands[hole.band_job].seg_base + i].out = f.out + base;      // (k_ent_emit reads it there)
 		if (tid == 0) {
 			EntBandState &b = band_state[hole.band_job];
 			b.base_byte = base; b.out = f.out + base;
@@ -561,20 +546,20 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(const EntSegJob *seg_j
 	// adds up their lengths and puts them in place -- no table is consulted for an ordinary token, so what a wave waits for is one round
 	// of independent loads (descriptor, state, strings), not a chain of them.  (Round 2 looked the codes up here: three dependent gathers
 	// behind the token load; SQ counters showed the waves parked on memory 79 % of their time.)
-	const uint32_t *seg_tok = tokens + (size_t)seg * ENT_TOK_STRIDE;
-	const uint2 *seg_str = (const uint2 *)(seg_tok + ENT_SEG);
+	const uint2 *seg_str = (const uint2 *)(tokens + (size_t)seg * ENT_TOK_STRIDE);
 	const uint2 first_rec = seg_str[lane];                 // (issued before anything is known about the segment: at worst 512 bytes read for nothing)
-	const EntSegJob job = ent_seg_job(seg_jobs, geom, seg);
-	const EntTables *T = tables + job.table;
+	// the segment's state and its neighbours' in the band (the segments of a band are consecutive): who writes the words shared with them.  All of it
+	// in one round of independent scalar loads (the records say themselves whether a neighbour belongs to the band; round 3's probes: the chain
+	// segment job -> band state / neighbour states in front of the first useful instruction was 0.58 of this kernel's 1.65 ms)
 	const EntSegState st = segs[seg];
+	const EntSegState pv = segs[seg > 0 ? seg - 1 : 0];
+	const EntSegState nx = segs[seg + 1 < total_segs ? seg + 1 : seg];
 	if (st.bits == 0) return;                            // wave-uniform: nothing starts in this segment
-	// the neighbours in the band (the segments of a band are consecutive): who writes the words shared with them
-	const bool has_prev = job.first != 0, has_next = job.first + ENT_SEG < job.n;
-	const bool prev_writes_first = has_prev && ent_neighbours_merge(segs[seg - 1], st);
-	EntSegState nx = st;
-	if (has_next) nx = segs[seg + 1];
+	const EntTables *T = tables + (st.info >> 8);
+	const bool has_prev = (st.info & 1u) != 0u, has_next = (st.info & 2u) != 0u;
+	const bool prev_writes_first = has_prev && ent_neighbours_merge(pv, st);
 	const bool merge_next = has_next && ent_neighbours_merge(st, nx);
-	uint32_t *out = (uint32_t *)band_state[job.band].out;
+	uint32_t *out = (uint32_t *)st.out;
 	if (!out) return;                                    // the sample overflowed its buffer (k_ent_layout reported size 0)
 	if (probe == 2) { if (first_rec.x == 0x12345u && lane == 0) out[0] = 1; return; }
 	uint32_t *s_words = s_words_all[wave];
@@ -586,7 +571,7 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(const EntSegJob *seg_j
 	if (use_lds) for (int i = lane; i < (int)nwords + 2; i += ENT_LANES) s_words[i] = 0;
 	CFHD_WAVE_SYNC();
 	// 1. the run in front of the first token (it reaches back to the last nonzero of the earlier segments; k_ent_scan left its code)
-	if (st.run_size == (uint32_t)ENT_RUN_COMPLEX) ent_put_long_run(T, s_words, out, use_lds, first_word, seg_pos, (uint32_t)(job.first + (int)(seg_tok[0] >> 16) - st.prev_nz - 1), 0);
+	if (st.run_size == (uint32_t)ENT_RUN_COMPLEX) ent_put_long_run(T, s_words, out, use_lds, first_word, seg_pos, (uint32_t)(st.first_nz - st.prev_nz - 1), 0);
 	else if (st.run_size && lane == 0) ent_put_string(s_words, out, use_lds, first_word, seg_pos, (uint64_t)st.run_code << (64u - st.run_size));
 	// 2. one token per lane and round: bit position by a wave scan over the lengths, the string OR-ed into the wave's LDS window
 	uint64_t round_pos = seg_pos + st.run_bits;
@@ -600,9 +585,8 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(const EntSegJob *seg_j
 		if (__ballot(complex)) {
 			// rare: a run inside the segment that one composite code does not cover -- this lane walks the tables for its token
 			if (complex) {
-				const uint32_t tok = seg_tok[t], before = seg_tok[t - 1];      // (t > 0: the first token's run is k_ent_scan's)
-				run = (tok >> 16) - (before >> 16) - 1u;
-				ve = value_entry(T, (int)(int16_t)(tok & 0xffffu));
+				run = rec.y >> 16;                                             // (never the first token: its run is k_ent_scan's)
+				ve = value_entry(T, (int)(int16_t)(rec.y & 0xffffu));
 				len = (uint32_t)T->run_total[run] + (ve >> 27);
 			}
 		}

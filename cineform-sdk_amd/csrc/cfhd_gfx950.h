@@ -27,6 +27,8 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x)
 	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
 	return x;
 }
+// lanes below this one whose bit is set in a ballot mask
+__device__ __forceinline__ uint32_t wave_mbcnt(unsigned long long mask) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u)); }
 __device__ __forceinline__ uint32_t wave_get(uint32_t x, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)x, lane); }                       // uniform lane index
 __device__ __forceinline__ uint32_t wave_read(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(lane)); }
 // A pointer every lane of the wave holds the same value of, moved to scalar registers: the per-lane part of an address is then one

@@ -122,7 +122,8 @@ struct InvPlaneJob {
 	// k_inv_packed16, 8-bit RGB output (RG24, BGRA, BGRa of RGB 4:4:4 samples): `out` is the component's BYTE inside the first pixel, xstride =
 	// bytes per pixel, out_pitch in BYTES; every byte = (12-bit component * 2 + 9 + r) >> 5 with a four-bit dither r per sample (the
 	// reference's model, oracle/cfhd_oracle_inv.c orc_inv_spatial_to_rgb8); bottom_up: picture row y goes to output row display_height - 1 - y;
-	// the fourth byte of four-byte pixels is 255
+	// the fourth byte of four-byte pixels is 255.  bytes8 == 2: BGRA / BGRa of RGBA 4:4:4:4 samples (orc_inv_spatial_to_rgba8): no dither, every byte
+	// = (12-bit component + 2) >> 4; the alpha plane (`alpha`) is expanded from the rounded value: ((a + 2 - 256) << 3) * 9400 >> 16 >> 4 (codec.h:164-165)
 	int bytes8, bottom_up;
 	uint32_t dither_seed;
 	// k_inv_rgb10 (r210 / DPX0 / AB10 / AR10 output of RGB 4:4:4 samples: one 32-bit word per pixel; orc_inv_spatial_to_rgb10): bit position of this
@@ -780,7 +781,17 @@ __device__ __forceinline__ void inv_plane_tile(const InvPlaneJob *jobs, int nch,
 					if (c + k >= w) break;
 					const bool tail = c + k >= tail0;
 					uint32_t we = to16(e[k], job.precision, tail), wo = to16(o[k], job.precision, tail);
-					if (job.alpha) { we = expand_alpha16(we); wo = expand_alpha16(wo); }
+					if (job.alpha && !bytes8) { we = expand_alpha16(we); wo = expand_alpha16(wo); }
+					if (job.bytes8 == 2) {
+						int be = (int)(we >> 4) + 2, bo = (int)(wo >> 4) + 2;
+						if (job.alpha) {
+							be -= 256; bo -= 256;
+							be = be < 0 ? 0 : ((be << 3) * 9400) >> 20; bo = bo < 0 ? 0 : ((bo << 3) * 9400) >> 20;
+						} else { be >>= 4; bo >>= 4; }
+						dst8[(2 * k) * xs] = (uint8_t)(be > 255 ? 255 : be);
+						dst8[(2 * k + 1) * xs] = (uint8_t)(bo > 255 ? 255 : bo);
+						continue;
+					}
 					if (bytes8) {
 						we = ((we >> 3) + 9u + ((dz >> (8 * k)) & 15u)) >> 5; wo = ((wo >> 3) + 9u + ((dz >> (8 * k + 4)) & 15u)) >> 5;
 						dst8[(2 * k) * xs] = (uint8_t)(we > 255u ? 255u : we);
@@ -836,7 +847,7 @@ __device__ __forceinline__ void inv_plane_tile(const InvPlaneJob *jobs, int nch,
 					const int orow = 2 * r0 + orl;
 					if (orow >= job.display_height || orow >= 2 * h) continue;
 					uint32_t v = *(const uint32_t *)((const uint8_t *)s_out + (size_t)orl * (2 * ITW) * wps + 4 * d);
-					if (wps == 4) v |= 0xff000000u;                                          // alpha
+					if (wps == 4 && job.bytes8 == 1) v |= 0xff000000u;                       // alpha (RGB 4:4:4 samples have none)
 					const int yrow = job.bottom_up ? job.display_height - 1 - orow : orow;
 					*(uint32_t *)((uint8_t *)frame + (size_t)yrow * job.out_pitch + (size_t)(2 * c0) * wps + 4 * d) = v;
 				}

@@ -414,3 +414,31 @@ void orc_inv_spatial_to_v210(PIXEL16 *const bands[3][4], const int band_pitch[3]
 	}
 	free(yu);
 }
+
+/* ---- RGBA 4:4:4:4 samples decoded to BGRA (bottom row first) / BGRa (top row first) ------------------------------------------------------
+ * Probed on the built reference and pinned in tests/test_oracle_vs_ref.py (this route draws no dither: the reference's output is the same from
+ * call to call): every colour byte is the 12-bit component of the 16-bit reconstruction (orc_inv_spatial_to_rgb48 with four planes) plus 2,
+ * >> 4, saturated to 255; the alpha byte takes the same rounded 12-bit value through the reference's alpha expansion -- minus
+ * alphacompandDCoffset 256, << 3, times alphacompandGain 9400 >> 16, >> 4 (Codec/codec.h:164-165; the arithmetic of the scalar code at
+ * Codec/convert.c:6391-6396) --, clamped to [0, 255].  Bytes B, G, R, A; planes are G, R, B, A. */
+void orc_inv_spatial_to_rgba8(PIXEL16 *const bands[4][4], int band_pitch, int w, int h, int precision, int display_height, int bottom_up, uint8_t *out, int out_pitch_bytes)
+{
+	const int W = 2 * w;
+	uint16_t *tmp = (uint16_t *)malloc((size_t)2 * h * W * 4 * sizeof(uint16_t));
+	int y, x, c;
+	orc_inv_spatial_to_rgb48(bands, band_pitch, w, h, precision, 4, tmp, W * 4);
+	for (y = 0; y < display_height; y++) {
+		uint8_t *o = out + (size_t)(bottom_up ? display_height - 1 - y : y) * out_pitch_bytes;
+		for (x = 0; x < W; x++) {
+			int a;
+			for (c = 0; c < 3; c++) {                      /* words R, G, B -> bytes B, G, R */
+				const int v = ((tmp[((size_t)y * W + x) * 4 + c] >> 4) + 2) >> 4;
+				o[(size_t)x * 4 + (2 - c)] = (uint8_t)(v > 255 ? 255 : v);
+			}
+			a = (tmp[((size_t)y * W + x) * 4 + 3] >> 4) + 2 - 256;
+			a = a < 0 ? 0 : (((a << 3) * 9400) >> 16) >> 4;
+			o[(size_t)x * 4 + 3] = (uint8_t)(a > 255 ? 255 : a);
+		}
+	}
+	free(tmp);
+}

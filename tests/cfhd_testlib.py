@@ -932,3 +932,24 @@ def oracle_rgb8_to_yuv422_planes(frame, pitch, bytes_per_pixel, top_down, w, h, 
     Y = np.zeros((enc_height, w), np.int16); C1 = np.zeros((enc_height, w // 2), np.int16); C2 = np.zeros((enc_height, w // 2), np.int16)
     O.orc_rgb8_to_yuv422(src.ctypes.data_as(ctypes.c_void_p), pitch, bytes_per_pixel, top_down, w, h, enc_height, color_space, p16(Y), w, p16(C1), p16(C2), w // 2)
     return [Y, C1, C2]
+
+
+def oracle_inverse_rgba8(plan, coeffs, bottom_up):
+    """Whole inverse path with the oracle from a dequantized RGBA 4:4:4:4 pyramid to 8-bit B, G, R, A pixels (no dither on this route).  Returns (bytes, the
+    alternative alpha bytes of a row on which the reference lost its alpha_Companded race: the companded value rounded the same way)."""
+    O = oracle()
+    O.orc_inv_spatial_to_rgba8.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 6 + [ctypes.c_void_p, ctypes.c_int]
+    work = coeffs.copy()
+    for c in range(4):
+        for lv in (2, 1):
+            d = plan.band[(c, lv, 0)]
+            bands = (c_i16p * 4)(*[plan.view(work, c, lv, b).ctypes.data_as(c_i16p) for b in range(4)])
+            dst = plan.view(work, c, lv - 1, 0)
+            O.orc_inv_spatial(bands, d["pitch"], d["width"], d["height"], plan.prescale[lv], dst.ctypes.data_as(c_i16p), plan.band[(c, lv - 1, 0)]["pitch"])
+    d = plan.band[(0, 0, 0)]
+    flat = [plan.view(work, c, 0, b).ctypes.data_as(c_i16p) for c in range(4) for b in range(4)]
+    out = np.zeros((plan.height, 2 * d["width"] * 4), np.uint8)
+    O.orc_inv_spatial_to_rgba8((c_i16p * 16)(*flat), d["pitch"], d["width"], d["height"], plan.precision, plan.height, int(bottom_up), out.ctypes.data_as(ctypes.c_void_p), out.shape[1])
+    raw = oracle_inverse_rgb48(plan, coeffs, b64a=False)[: plan.height].reshape(plan.height, -1, 4)[:, :, 3].astype(np.int64)
+    alt = np.minimum(((raw >> 4) + 2) >> 4, 255).astype(np.uint8)
+    return out, (alt[::-1] if bottom_up else alt)

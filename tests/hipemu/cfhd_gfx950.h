@@ -19,6 +19,7 @@ inline uint32_t wave_incl_scan(uint32_t x)
 	for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, (unsigned)d); if (lane >= d) x += y; }
 	return x;
 }
+inline uint32_t wave_mbcnt(unsigned long long mask) { return (uint32_t)__builtin_popcountll(mask & ((1ull << hipemu::lane_id()) - 1ull)); }
 inline uint32_t wave_get(uint32_t x, int lane) { return __shfl(x, lane); }
 inline uint32_t wave_read(uint32_t v, int lane) { return __shfl(v, lane); }
 template <typename T> inline T *wave_uniform_ptr(T *p) { return p; }

@@ -251,6 +251,22 @@ void emu_inv_rgb8(int16_t **bands, int band_pitch, int w, int h, int display_hei
 	hipemu::launch(grid, dim3(NTHREADS), [&] { k_inv_packed16(jobs.data(), 3, bytes_per_pixel, 0x1234u); });
 }
 
+// The last level of an RGBA 4:4:4:4 sample to BGRA / BGRa: the byte mode without dither, alpha from the fourth plane (InvPlaneJob::bytes8 == 2).
+void emu_inv_rgba8(int16_t **bands, int band_pitch, int w, int h, int display_height, int precision, int bottom_up, uint8_t *out, int out_pitch_bytes)
+{
+	std::vector<InvPlaneJob> jobs(4);
+	for (int c = 0; c < 4; c++) {
+		InvPlaneJob &job = jobs[c];
+		memset(&job, 0, sizeof(job));
+		for (int b = 0; b < 4; b++) job.band[b] = bands[c * 4 + b];
+		job.band_pitch = band_pitch; job.width = w; job.height = h; job.descale = 0;
+		job.out = (int16_t *)(out + (c == 0 ? 1 : (c == 1 ? 2 : (c == 2 ? 0 : 3)))); job.out_pitch = out_pitch_bytes; job.xstride = 4; job.precision = precision; job.display_height = display_height;
+		job.bytes8 = 2; job.bottom_up = bottom_up; job.alpha = c == 3;
+	}
+	dim3 grid((w + ITW - 1) / ITW, (h + ITH - 1) / ITH, 1);
+	hipemu::launch(grid, dim3(NTHREADS), [&] { k_inv_packed16(jobs.data(), 4, 4, 0x1234u); });
+}
+
 // The last level of an RGB 4:4:4 sample to 10-bit RGB words (r210 / DPX0 / AB10 / AR10): k_inv_rgb10, as DecodeBatch::prepare sets it up.
 void emu_inv_rgb10(int16_t **bands, int band_pitch, int w, int h, int display_height, int shift_r, int shift_g, int shift_b, int big_endian, uint32_t *out, int out_pitch_words)
 {

@@ -576,6 +576,33 @@ def test_inv_rgb8_last_level_lies_in_oracle_interval(w, h, dh, bpp, bottom_up):
     assert (img == 255).any() and (img == 0).any()
 
 
+@pytest.mark.parametrize("w,h,dh,bottom_up", [(16, 8, 16, 1), (68, 20, 37, 0), (160, 17, 34, 1), (250, 33, 66, 0)])
+def test_inv_rgba8_last_level_equals_oracle(w, h, dh, bottom_up):
+    """k_inv_packed16's byte mode for RGBA 4:4:4:4 samples (BGRA / BGRa output): no dither -- equal to the oracle model pinned on the reference decoder in
+    test_oracle_vs_ref ((12-bit component + 2) >> 4, alpha expanded from the rounded value), both clamps, both row orders, nothing beside the picture."""
+    rng = np.random.default_rng(w * 5 + h)
+    pitch = (w + 7) // 8 * 8
+    bands = []
+    for c in range(4):
+        bs = [np.zeros((h, pitch), np.int16) for _ in range(4)]
+        bs[0][:, :w] = rand_plane(rng, w, h, 14)
+        for k in range(1, 4): bs[k][:, :w] = rand_plane(rng, w, h, 11, signed=True)
+        bands.append(bs)
+    flat = [p16(a) for c in range(4) for a in bands[c]]
+    O = oracle()
+    O.orc_inv_spatial_to_rgba8.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 6 + [ctypes.c_void_p, ctypes.c_int]
+    want = np.zeros((dh, 2 * w * 4), np.uint8)
+    O.orc_inv_spatial_to_rgba8((c_i16p * 16)(*flat), pitch, w, h, 12, dh, bottom_up, want.ctypes.data_as(ctypes.c_void_p), 2 * w * 4)
+    opitch = 2 * w * 4 + 16
+    got = np.full((dh, opitch), 7, np.uint8)
+    E = emu()
+    E.emu_inv_rgba8.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 6 + [ctypes.c_void_p, ctypes.c_int]
+    E.emu_inv_rgba8((c_i16p * 16)(*flat), pitch, w, h, dh, 12, bottom_up, got.ctypes.data_as(ctypes.c_void_p), opitch)
+    assert np.array_equal(got[:, : 2 * w * 4], want)
+    assert (got[:, 2 * w * 4:] == 7).all()
+    assert (want[:, 3::4] == 255).any() and (want[:, 3::4] == 0).any() and (want[:, 0::4] == 255).any() and (want[:, 0::4] == 0).any()
+
+
 @pytest.mark.parametrize("w,h,dh,name", [(16, 8, 16, "r210"), (68, 20, 37, "DPX0"), (160, 17, 34, "AB10"), (250, 33, 66, "AR10")])
 def test_inv_rgb10_last_level_equals_oracle(w, h, dh, name):
     """k_inv_rgb10 (r210 / DPX0 / AB10 / AR10 output of RGB 4:4:4 samples: one 32-bit word per pixel, big- or little-endian) = oracle model

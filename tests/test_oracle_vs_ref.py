@@ -263,6 +263,35 @@ def test_reference_rgb8_decode_lies_in_oracle_dither_interval(w, h, name):
     if bpp == 4: assert (img[:, 3::4] == 255).all()
 
 
+@pytest.mark.parametrize("w,h,name,seed", [(320, 240, "BGRA", 10), (336, 252, "BGRa", 11), (400, 122, "BGRA", 12), (720, 486, "BGRa", 13), (64, 64, "BGRA", 14), (1280, 720, "BGRa", 15),
+                                             (1920, 1080, "BGRA", 16), (144, 90, "BGRa", 17)])
+def test_reference_rgba8_decode_of_4444_equals_oracle(w, h, name, seed):
+    """Pins orc_inv_spatial_to_rgba8 (a model fitted by probing, so: eight geometries, four of them with heights that are not multiples of 8, eight
+    pictures): the reference decodes an RGBA 4:4:4:4 sample to BGRA / BGRa without dither -- every colour byte (12-bit component + 2) >> 4, the alpha byte
+    the same rounded value through the alpha expansion of codec.h:164-165 -- byte for byte.  As for b64a output, a row on which the reference's
+    workers raced on `alpha_Companded` (bayer.c:13871 / :16034) keeps its companded alpha: exactly that alternative is accepted, for few rows."""
+    fmt = PIX_BGRA if name == "BGRA" else PIX_BGRa
+    frames, pitch = qbist_frames(seed, 1, w, h, fmt, alpha=1)
+    sample = ref_encode_frames(frames, pitch, w, h, fmt, encoded=ENCODED_RGBA4444)[0]
+    plan = Plan(w, h, pixkind=PIXKIND[name], enc=ENC["4444"])
+    want, alt = oracle_inverse_rgba8(plan, host_decode_pyramid(sample, plan), name == "BGRA")
+    # Heights that are not multiples of 8: the reference's last display rows come out differently from call to call (equal to the oracle in a fresh
+    # process, one or two steps off in six rows after other decodes in the same process: something below the picture is not rewritten); they are left
+    # out of the comparison here.
+    rows = h if h % 8 == 0 else h - 8
+    sl = slice(0, rows) if name == "BGRa" else slice(h - rows, h)
+    want, alt = want[sl], alt[sl]
+    for attempt in range(6):                            # see test_reference_rg48_decode_equals_oracle
+        dec, dpitch = ref_decode_sample(sample, w, h, fmt)
+        img = np.frombuffer(dec.tobytes(), np.uint8).reshape(h, dpitch)[sl, : w * 4]
+        if all(np.array_equal(img[:, k::4], want[:, k::4]) for k in range(3)): break
+    for k in range(3): assert np.array_equal(img[:, k::4], want[:, k::4]), "colour byte %d" % k
+    a_ok = img[:, 3::4] == want[:, 3::4]
+    assert a_ok.mean() > 0.9 and np.array_equal(img[:, 3::4][~a_ok], alt[~a_ok])          # (the race is lost for parts of rows, too)
+    src = np.frombuffer(frames[0].tobytes(), np.uint8).reshape(h, pitch)[sl, : w * 4]
+    assert np.abs(want.astype(int) - src.astype(int)).mean() < 3.0
+
+
 @pytest.mark.parametrize("w,h", [(192, 96), (320, 240), (1920, 1080)])
 def test_reference_b64a_decode_equals_oracle(w, h):
     """Pins orc_inv_spatial_to_b64a: the reference decodes an RGBA 4:4:4:4 sample to b64a through its planar 16-bit rows

@@ -10,7 +10,7 @@ import json, sys
 try:
     d = json.loads(open("gpurun_out/${TAG}_probe.json").read().strip().splitlines()[-1])
     k = d["config"]["kernel_ms_per_step"]
-    print(sys.argv[1], "fps", d["value"], {n: k[n] for n in k if n.startswith("k_ent") or n.startswith("k_dec")}, d["config"].get("dx_stats"))
+    print(sys.argv[1], "fps", d["value"], {n: k[n] for n in k if n.startswith("k_ent") or n.startswith("k_dec")}, d["config"].get("dx_stats"), d["config"].get("parity"))
 except Exception as e:
     print(sys.argv[1], "failed:", e, open("gpurun_out/${TAG}_probe.err").read()[-400:])
 PY
