@@ -1008,7 +1008,9 @@ CFHD_Error CFHD_PrepareToDecode(CFHD_DecoderRef ref, int, int, CFHD_PixelFormat 
 	// ... and 4:2:2 samples to v210 (the YU64 words >> 6, three to a 32-bit word: DecodeBatch / k_yu64_to_v210; widths of whole six-pixel groups)
 	if (kind == PIX_V210 && (encf != ENC_YUV422 || half || d->header.width % 6 || d->header.width < 128)) return ERR_BADFORMAT;
 	if (kind == PIX_BYR4 || (kind >= PIX_R210 && kind <= PIX_AR10 && !rgb10)) return ERR_BADFORMAT;     // encoder inputs only
-	if ((encf == ENC_RGB444) != (kind == PIX_RG48 || (rgb8 && !rgba8) || rgb10) || (encf == ENC_RGBA4444) != (kind == PIX_B64A || rgba8)) return ERR_BADFORMAT;
+	// ... and RGB 4:4:4 samples to b64a (the RG48 words behind a constant alpha word 0xfff0, full resolution: what TestCFHD's b64a -> RGB 4:4:4 row decodes to)
+	const bool b64a_of_444 = kind == PIX_B64A && encf == ENC_RGB444 && !half;
+	if ((encf == ENC_RGB444) != (kind == PIX_RG48 || (rgb8 && !rgba8) || rgb10 || b64a_of_444) || (encf == ENC_RGBA4444) != ((kind == PIX_B64A && !b64a_of_444) || rgba8)) return ERR_BADFORMAT;
 	if (kind == PIX_YU64 && d->header.width < 128) return ERR_BADFORMAT;      // (the tail-column rule of the 16-bit rows is restated for chroma bands of 16 columns and more)
 	bool ok;
 	plan_from_sample(d->header, kind, &d->plan, &ok);

@@ -95,8 +95,8 @@ static bool dec_rgb10(int out_kind) { return out_kind >= PIX_R210 && out_kind <=
 static bool dec_planes16(int out_kind) { return is_packed16(out_kind) || out_kind == PIX_YU64 || dec_rgb8(out_kind) || dec_rgb10(out_kind); }
 // position of plane c inside the pixel: 16-bit word, or byte for the 8-bit formats (planes G, R, B(, A) -> bytes 1, 2, 0(, 3))
 static int dec_word_of_channel(int out_kind, int c) { return dec_rgb10(out_kind) ? 0 : out_kind == PIX_YU64 ? (c == 0 ? 0 : (c == 1 ? 1 : 3)) : (dec_rgb8(out_kind) ? (c == 0 ? 1 : (c == 1 ? 2 : (c == 2 ? 0 : 3))) : packed_word_of_channel(out_kind, c)); }
-static int dec_stride_of_channel(int out_kind, int c, int nch) { return out_kind == PIX_YU64 ? (c == 0 ? 2 : 4) : (dec_rgb8(out_kind) ? rgb8_bytes(out_kind) : (dec_rgb10(out_kind) ? 3 : nch)); }
-static int dec_words_per_position(int out_kind, int nch) { return out_kind == PIX_YU64 ? 2 : (dec_rgb8(out_kind) ? rgb8_bytes(out_kind) : nch); }
+static int dec_stride_of_channel(int out_kind, int c, int nch) { return out_kind == PIX_YU64 ? (c == 0 ? 2 : 4) : (dec_rgb8(out_kind) ? rgb8_bytes(out_kind) : (dec_rgb10(out_kind) ? 3 : (out_kind == PIX_B64A ? 4 : nch))); }     // (b64a from RGB 4:4:4: three planes, four words)
+static int dec_words_per_position(int out_kind, int nch) { return out_kind == PIX_YU64 ? 2 : (dec_rgb8(out_kind) ? rgb8_bytes(out_kind) : (out_kind == PIX_B64A ? 4 : nch)); }
 static int16_t *dec_plane_out(void *frame, int out_kind, int c) { return dec_rgb8(out_kind) ? (int16_t *)((uint8_t *)frame + dec_word_of_channel(out_kind, c)) : (int16_t *)((uint16_t *)frame + dec_word_of_channel(out_kind, c)); }
 // encoder input made of 16-bit words that k_fwd_packed16 picks apart (per channel: first word, words from sample to sample, right shift).
 // YU64 (Codec/frame.c:1556 ConvertYU64ToFrame16s + convert.c:3345, :14375): words Y0 C1 Y1 C2, every word >> 6 to 10 bits, channel 1 = C1, 2 = C2.
@@ -618,10 +618,12 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 	if (v210_) { if (plan.width % 6 || !own_output || half) { g_err = "v210 output: widths that are multiples of 6, full resolution"; return -2; } out_kind = PIX_YU64; }
 
 	const bool yuv_ok = (out_kind == PIX_YUY2 || out_kind == PIX_2VUY) && plan.encoded_format == ENC_YUV422;
-	const bool rgb_ok = ((out_kind == PIX_RG48 && plan.encoded_format == ENC_RGB444) || (out_kind == PIX_B64A && plan.encoded_format == ENC_RGBA4444)) &&
+	// (b64a from an RGB 4:4:4 sample: the three colour planes and a constant alpha word, full resolution)
+	const bool rgb_ok = ((out_kind == PIX_RG48 && plan.encoded_format == ENC_RGB444) || (out_kind == PIX_B64A && plan.encoded_format == ENC_RGBA4444) ||
+	                     (out_kind == PIX_B64A && plan.encoded_format == ENC_RGB444 && !half)) &&
 	                    plan.ch[0].band[0][0].width >= 16;   // k_inv_packed16's tail-column rule assumes the reference's vector path
 	const bool yu64_ok = out_kind == PIX_YU64 && plan.encoded_format == ENC_YUV422 && !half && plan.ch[1].band[0][0].width >= 16;
-	const bool rgb8_ok = dec_rgb8(out_kind) && plan.encoded_format == ENC_RGB444 && !half && plan.ch[0].band[0][0].width >= 16 && plan.ch[0].band[0][0].width % 2 == 0;
+	const bool rgb8_ok = dec_rgb8(out_kind) && (plan.encoded_format == ENC_RGB444 || (plan.encoded_format == ENC_RGBA4444 && out_kind != PIX_RG24)) && !half && plan.ch[0].band[0][0].width >= 16 && plan.ch[0].band[0][0].width % 2 == 0;
 	const bool rgb10_ok = dec_rgb10(out_kind) && plan.encoded_format == ENC_RGB444 && !half && plan.ch[0].band[0][0].width >= 16;
 	if (!yuv_ok && !rgb_ok && !yu64_ok && !rgb8_ok && !rgb10_ok) { g_err = "output format not supported by the GPU path yet"; return -2; }
 	plan_ = plan; n_ = nframes; out_kind_ = out_kind; own_output_ = own_output;
@@ -685,7 +687,9 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 				p.out = frame ? dec_plane_out(frame, out_kind, c) : nullptr; p.out_pitch = dec_rgb8(out_kind) ? job_pitch : job_pitch / 2;
 				p.xstride = dec_stride_of_channel(out_kind, c, nch); p.precision = plan.precision; p.display_height = plan.display_height;
 				p.alpha = (out_kind == PIX_B64A || dec_rgb8(out_kind)) && c == 3;
-				p.bytes8 = dec_rgb8(out_kind) ? (nch == 4 ? 2 : 1) : 0;        // 2: BGRA / BGRa of an RGBA 4:4:4:4 sample (alpha from the fourth plane, no dither) p.bottom_up = out_kind == PIX_RG24 || out_kind == PIX_BGRA; p.dither_seed = 0x9E3779B9u * (uint32_t)(i + 1);
+				p.alpha_const = out_kind == PIX_B64A && nch == 3 ? 0xfff0 : 0;
+				p.bytes8 = dec_rgb8(out_kind) ? (nch == 4 ? 2 : 1) : 0;        // 2: BGRA / BGRa of an RGBA 4:4:4:4 sample (alpha from the fourth plane, no dither)
+				p.bottom_up = out_kind == PIX_RG24 || out_kind == PIX_BGRA; p.dither_seed = 0x9E3779B9u * (uint32_t)(i + 1);
 				if (dec_rgb10(out_kind)) { p.out = (int16_t *)frame; p.out_pitch = job_pitch / 4; p.bit_shift = rgb10_shift(out_kind, c); p.big_endian = out_kind == PIX_R210 || out_kind == PIX_DPX0; }
 			}
 			continue;
@@ -772,7 +776,7 @@ bool DecodeBatch::strip_inverse_packed16() const
 	const int forced = shape_override("CFHD_AMD_INVERSE");
 	const int act = active_ > 0 && active_ < n_ ? active_ : n_;
 	if (forced == 1 || (forced == 0 && frames_1080p_equivalent(plan_, act) < 12.0)) return false;
-	if (!is_packed16(out_kind_) || half_ || plan_.ch[0].band[0][0].width % 4) return false;
+	if (!is_packed16(out_kind_) || half_ || plan_.ch[0].band[0][0].width % 4 || (out_kind_ == PIX_B64A && plan_.num_channels == 3)) return false;
 	DecJobs j = dec_jobs_at(h_jobs_, n_, plan_.num_channels);
 	for (int i = 0; i < n_; i++) {
 		const dev::InvPlaneJob &p = j.l1[(size_t)i * plan_.num_channels];

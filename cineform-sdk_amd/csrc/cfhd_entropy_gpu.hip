@@ -108,7 +108,7 @@ int GpuEntropyEncoder::launch()
 	(void)hipGetLastError();
 	if (plan_.interlaced) HIPCHK(hipMemsetAsync(d_sizes_ + n_, 0, sizeof(uint32_t) * n_, st));
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[0], st));
-	dev::k_ent_count<<<(total_segs + dev::ENT_WAVES - 1) / dev::ENT_WAVES, dev::ENT_THREADS, 0, st>>>((const dev::EntSegJob *)d_segband_, geom, total_segs, (dev::EntSegState *)d_segs_, T,
+	dev::k_ent_count<<<(total_segs + dev::ENT_WAVES * dev::ENT_COUNT_SEGS - 1) / (dev::ENT_WAVES * dev::ENT_COUNT_SEGS), dev::ENT_THREADS, 0, st>>>((const dev::EntSegJob *)d_segband_, geom, total_segs, (dev::EntSegState *)d_segs_, T,
 	                                                                                                    d_sizes_ + n_, (uint32_t *)d_tokens_, []{ const char *e = getenv("CFHD_AMD_COUNT_PROBE"); return e ? atoi(e) : 0; }());
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[1], st));
 	dev::k_ent_scan<<<nbands_ * act, dev::ENT_THREADS, 0, st>>>((const dev::EntBandJob *)d_bands_, (dev::EntSegState *)d_segs_, (dev::EntBandState *)d_bandstate_, T);
@@ -118,8 +118,8 @@ int GpuEntropyEncoder::launch()
 	dev::k_ent_layout<<<dim3((unsigned)act, layout_parts), dev::ENT_THREADS, 0, st>>>((const dev::EntFrameJob *)d_frames_, (const dev::EntBandJob *)d_bands_, (dev::EntSegState *)d_segs_,
 	                                                  (dev::EntBandState *)d_bandstate_, T);
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[3], st));
-	dev::k_ent_emit<<<(total_segs + dev::ENT_WAVES - 1) / dev::ENT_WAVES, dev::ENT_THREADS, 0, st>>>((const dev::EntSegJob *)d_segband_, geom, total_segs, (const dev::EntSegState *)d_segs_,
-	                                                          (const dev::EntBandState *)d_bandstate_, T, (const uint32_t *)d_tokens_, []{ const char *e = getenv("CFHD_AMD_EMIT_PROBE"); return e ? atoi(e) : 0; }());
+	dev::k_ent_emit<<<(total_segs + dev::ENT_WAVES * dev::ENT_EMIT_SEGS - 1) / (dev::ENT_WAVES * dev::ENT_EMIT_SEGS), dev::ENT_THREADS, 0, st>>>(total_segs, (const dev::EntSegState *)d_segs_,
+	                                                          T, (const uint32_t *)d_tokens_, []{ const char *e = getenv("CFHD_AMD_EMIT_PROBE"); return e ? atoi(e) : 0; }());
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[4], st));
 	timed_ = true;

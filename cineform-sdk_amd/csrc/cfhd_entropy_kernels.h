@@ -33,9 +33,10 @@ namespace dev {
 enum { ENT_THREADS = 256, ENT_LANES = 64, ENT_WAVES = ENT_THREADS / ENT_LANES, ENT_PER_THREAD = CFHD_ENT_PER_THREAD, ENT_SEG = ENT_LANES * ENT_PER_THREAD,
        ENT_LDS_WORDS = 256, ENT_TOK_CAP = CFHD_ENT_TOK_CAP, ENT_MAX_HOLES = 40,
        ENT_FILL = CFHD_ENT_FILL /* bytes of a sample one workgroup of k_ent_layout fills at a time */,
-       // what k_ent_count leaves per segment for k_ent_emit (32-bit words): one finished bit string of two words per token (run code + value code, left
-       // aligned in 58 bits, length in the low 6 bits; a token whose run takes several run codes carries run << 16 | value in its second word instead)
-       ENT_TOK_STRIDE = 2 * ENT_SEG, ENT_CODE_COMPLEX = 63 /* length field: the token's run takes several run codes -- k_ent_emit walks the tables for it */,
+       // what k_ent_count leaves per segment for k_ent_emit: one 32-bit word per token -- its finished bit string (run code + value code, left aligned in
+       // the upper 26 bits) and its length in the low 6 bits; a token whose run takes several run codes or whose string is longer than 26 bits carries
+       // run << 22 | value << 6 | ENT_CODE_COMPLEX instead and k_ent_emit walks the tables for it (rare: long codes belong to large values)
+       ENT_TOK_STRIDE = ENT_SEG, ENT_STR_BITS = 26, ENT_CODE_COMPLEX = 63 /* length field: the token's run takes several run codes -- k_ent_emit walks the tables for it */,
        ENT_RUN_COMPLEX = 0xff /* EntSegState::run_size: the run in front of the segment's first token takes several run codes */ };
 // ENT_LDS_WORDS: 32-bit words of the per-wave bit window in LDS (a segment of ordinary pictures codes into 10-40 words; beyond the window
 // the code words go to the payload with global atomics).  ENT_TOK_CAP: tokens (nonzero coefficients) of a segment held in LDS at a
@@ -176,24 +177,11 @@ __device__ __forceinline__ EntSegJob ent_seg_job(const EntSegJob *seg_jobs, cons
 enum { ENT_PEAK_THRESHOLD = 250 };
 // The finished bit string of every token (nonzero coefficient) of every segment is kept in `tokens` (ENT_TOK_STRIDE words per segment, the first
 // 2 * ntok used): k_ent_emit places those -- a third of the bytes -- instead of reading, compacting and coding the coefficients a second time.
-__global__ void __launch_bounds__(ENT_THREADS) k_ent_count(const EntSegJob *seg_jobs, EntBatchGeom geom, int total_segs, EntSegState *segs, const EntTables *tables,
-                                                            uint32_t *peak_flags, uint32_t *tokens, int probe = 0 /* timing experiments: 1 behind the loads, 2 behind the compaction, 4 no token stores */)
+// The coefficients of one segment as lane L of the wave holds them: dwords j * 64 + L (coalesced 4-byte loads), zero beyond the band.
+__device__ __forceinline__ void ent_load_segment(const EntSegJob &job, int lane, uint32_t *w)
 {
-	__shared__ uint32_t s_tok_all[ENT_WAVES][ENT_SEG];       // the segment's tokens: local raster index << 16 | value (16 bits); every coefficient may be one
-	const int lane = wave_lane();
-	const int seg = wave_uniform((int)blockIdx.x * ENT_WAVES + (int)(threadIdx.x >> 6));
-	if (seg >= total_segs) return;                       // whole wave
-	int frame;
-	const EntSegJob job = ent_seg_job(seg_jobs, geom, seg, &frame);
-	const EntTables *T = tables + job.table;
-	// The picture is sparse (about one coefficient in twelve is nonzero), so the code lookups run over a compacted token list, one token per lane
-	// and round.  Compaction is what this kernel's instructions went into while every lane held 16 consecutive coefficients (a count, a wave scan and
-	// 16 predicated LDS stores per lane: VALU-bound at 1.7 ms).  Now lane L holds the dwords j * 64 + L of the segment (coalesced 4-byte loads):
-	// raster order is then j-major, lane, low / high half, which is the order of a ballot -- a token's position is the number of nonzero halves
-	// in the rounds before (scalar popcounts) plus those in the lanes below (v_mbcnt), no scan, no per-lane count.
 	const int rem = job.n - job.first;                   // coefficients from the segment's start to the end of the band (>= 1)
 	const uint32_t *src = (const uint32_t *)(job.coeffs + job.first);
-	uint32_t w[ENT_SEG / 128];
 	if (rem >= ENT_SEG) {                                // wave-uniform: every segment of a band but its last
 #pragma unroll
 		for (int j = 0; j < ENT_SEG / 128; j++) w[j] = CFHD_LDG32(src + j * ENT_LANES + lane);
@@ -206,8 +194,19 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_count(const EntSegJob *seg_
 			w[j] = x;
 		}
 	}
+}
+
+// One segment of k_ent_count: the wave's loaded coefficients -> token strings in `tokens`, the segment's state in segs[seg].
+// The picture is sparse (about one coefficient in twelve is nonzero), so the code lookups run over a compacted token list, one token per lane
+// and round.  Compaction is what this kernel's instructions went into while every lane held 16 consecutive coefficients (a count, a wave scan and
+// 16 predicated LDS stores per lane: VALU-bound at 1.7 ms).  With lane L holding the dwords j * 64 + L raster order is j-major, lane, low / high
+// half, which is the order of a ballot -- a token's position is the number of nonzero halves in the rounds before (scalar popcounts) plus those in
+// the lanes below (v_mbcnt): no scan, no per-lane count.
+__device__ __forceinline__ void ent_count_segment(int seg, const EntSegJob &job, int frame, const uint32_t *w, int lane, uint32_t *s_tok, EntSegState *segs, const EntTables *tables,
+                                                  uint32_t *peak_flags, uint32_t *tokens, int probe)
+{
+	const EntTables *T = tables + job.table;
 	if (probe == 1) { uint32_t o = 0; for (int j = 0; j < ENT_SEG / 128; j++) o |= w[j]; const unsigned long long q = __ballot(o == 0x12345u); if (lane == 0) { EntSegState &z = segs[seg]; z.first_nz = -1; z.last_nz = -1; z.bits = q == 0x123456789ull; z.ntok = 0; z.lead32 = 0; z.lead_valid = 0; } return; }
-	uint32_t *s_tok = s_tok_all[wave_uniform((int)(threadIdx.x >> 6))];
 	int ntok = 0;                                        // wave-uniform
 #pragma unroll
 	for (int j = 0; j < ENT_SEG / 128; j++) {
@@ -240,16 +239,15 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_count(const EntSegJob *seg_
 		if (have) {
 			bits += rt + (ve >> 27);
 			uint32_t *seg_out = tokens + (size_t)seg * ENT_TOK_STRIDE;
-			// the token's finished bit string for k_ent_emit: run code (when one code covers the run: nearly always) + value code, at most
-			// 31 + 27 bits, left aligned; the first token of the segment carries its value code only (its run reaches into the earlier
-			// segments: k_ent_scan works that one out)
+			// the token's finished bit string for k_ent_emit: run code (when one code covers the run: nearly always) + value code, left aligned;
+			// the first token of the segment carries its value code only (its run reaches into the earlier segments: k_ent_scan works that one out)
 			const uint32_t vs = ve >> 27, vc = ve & 0x7FFFFFFu, rs = run ? rp.y & 0xffu : 0u;
-			const bool simple = run == 0u || (rp.y >> 8) == run;
-			const uint64_t str = simple ? (((uint64_t)(run ? rp.x : 0u) << vs) | vc) << (64u - rs - vs) : 0ull;      // (rs + vs >= 2: a value code has at least its sign)
+			const bool simple = (run == 0u || (rp.y >> 8) == run) && rs + vs <= (uint32_t)ENT_STR_BITS;
+			const uint32_t str = simple ? (((run ? rp.x : 0u) << vs) | vc) << (32u - rs - vs) : 0u;      // (rs + vs >= 2: a value code has at least its sign)
 			const uint32_t len = simple ? rs + vs : (uint32_t)ENT_CODE_COMPLEX;
-			uint2 rec; rec.x = (uint32_t)str | len; rec.y = simple ? (uint32_t)(str >> 32) : (run << 16) | (tok & 0xffffu);
-			if (probe != 4) ((uint2 *)seg_out)[t] = rec;
-			my_top = rec.y; my_len = len;
+			const uint32_t rec = simple ? str | len : (run << 22) | ((tok & 0xffffu) << 6) | len;
+			if (probe != 4) seg_out[t] = rec;
+			my_top = str; my_len = len;
 		}
 		if (t0 == 0) {
 			// the first 32 bits of the strings of this round, as far as they are plain strings (up to the first token that needs the table walk)
@@ -279,6 +277,31 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_count(const EntSegJob *seg_
 		s.out = nullptr;
 		s.info = (job.first != 0 ? 1u : 0u) | (job.first + ENT_SEG < job.n ? 2u : 0u) | ((uint32_t)job.table << 8);
 	}
+}
+
+// ENT_COUNT_SEGS consecutive segments per wave, the loads of all of them issued before the first is worked on.  Measured with 2 (round 3): no change
+// (1.33 ms either way) -- the kernel moves 4.2 GB in and 0.7 GB out, 0.81 ms of it are the loads at 5.2 TB/s: it is at the memory system's pace, not
+// waiting on latency.  Kept at 1.
+enum { ENT_COUNT_SEGS = 1 };
+__global__ void __launch_bounds__(ENT_THREADS) k_ent_count(const EntSegJob *seg_jobs, EntBatchGeom geom, int total_segs, EntSegState *segs, const EntTables *tables,
+                                                            uint32_t *peak_flags, uint32_t *tokens, int probe = 0 /* timing experiments: 1 behind the loads, 2 behind the compaction, 4 no token stores */)
+{
+	__shared__ uint32_t s_tok_all[ENT_WAVES][ENT_SEG];       // the segment's tokens: local raster index << 16 | value (16 bits); every coefficient may be one
+	const int lane = wave_lane();
+	const int wave = wave_uniform((int)(threadIdx.x >> 6));
+	const int seg0 = wave_uniform(((int)blockIdx.x * ENT_WAVES + wave) * ENT_COUNT_SEGS);
+	if (seg0 >= total_segs) return;                      // whole wave
+	EntSegJob job[ENT_COUNT_SEGS]; int frame[ENT_COUNT_SEGS];
+	uint32_t w[ENT_COUNT_SEGS][ENT_SEG / 128];
+#pragma unroll
+	for (int k = 0; k < ENT_COUNT_SEGS; k++)
+		if (seg0 + k < total_segs) { job[k] = ent_seg_job(seg_jobs, geom, seg0 + k, &frame[k]); ent_load_segment(job[k], lane, w[k]); }
+#pragma unroll
+	for (int k = 0; k < ENT_COUNT_SEGS; k++)
+		if (seg0 + k < total_segs) {
+			ent_count_segment(seg0 + k, job[k], frame[k], w[k], lane, s_tok_all[wave], segs, tables, peak_flags, tokens, probe);
+			CFHD_WAVE_SYNC();                                 // the next segment reuses the token window
+		}
 }
 
 // =============================================================================================
@@ -497,6 +520,20 @@ __device__ __forceinline__ void ent_put_string(uint32_t *s_words, uint32_t *out,
 	}
 }
 
+// The same for a string of up to 32 bits: two words at most, 32-bit shifts only (what an ordinary token takes).
+__device__ __forceinline__ void ent_put_string32(uint32_t *s_words, uint32_t *out, bool use_lds, uint32_t first_word, uint64_t pos, uint32_t str)
+{
+	const uint32_t sh = (uint32_t)pos & 31u, w = (uint32_t)(pos >> 5);
+	const uint32_t a = str >> sh, b = sh ? str << (32u - sh) : 0u;
+	if (use_lds) {
+		atomic_or_u32(&s_words[w - first_word], a);
+		if (b) atomic_or_u32(&s_words[w - first_word + 1], b);
+	} else {
+		atomic_or_u32(&out[w], bswap32(a));
+		if (b) atomic_or_u32(&out[w + 1], bswap32(b));
+	}
+}
+
 // The run codes of `run` zeros from bit position pos on, by the whole wave: the copies of the longest composite code a run of 3072 zeros or more
 // starts with (greedy loop, encoder.c:5488-5545) are written 64 at a time, the rest by lane `owner` (one lane writing hundreds of copies one
 // after the other held its wave for > 100 us).  Wave-uniform arguments.
@@ -533,27 +570,13 @@ __device__ __forceinline__ bool ent_neighbours_merge(const EntSegState &a, const
 	return o != 0u && ent_ordinary(a) && ent_ordinary(b) && b.lead_valid >= 32u - o;
 }
 
-__global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(const EntSegJob *seg_jobs, EntBatchGeom geom, int total_segs, const EntSegState *segs, const EntBandState *band_state, const EntTables *tables,
-                                                           const uint32_t *tokens, int probe = 0 /* timing experiments: 1 leave at once, 2 behind the descriptor loads, 3 without the final stores, 4 plain stores for the shared words, 5 no plain stores */)
+// One segment of k_ent_emit.  The segment's finished bit strings as k_ent_count left them (one per nonzero coefficient: run code + value code): this
+// kernel only adds up their lengths and puts them in place -- no table is consulted for an ordinary token.  (Round 2 looked the codes up here: three
+// dependent gathers behind the token load; SQ counters showed the waves parked on memory 79 % of their time.)
+// st / pv / nx: the segment's state and its neighbours' in the band (the segments of a band are consecutive): who writes the words shared with them.
+__device__ __forceinline__ void ent_emit_segment(const EntSegState &st, const EntSegState &pv, const EntSegState &nx, const uint32_t first_rec, const uint32_t *seg_str, int lane,
+                                                 uint32_t *s_words, const EntTables *tables, int probe)
 {
-	__shared__ uint32_t s_words_all[ENT_WAVES][ENT_LDS_WORDS + 3];
-	if (probe == 1) return;
-	const int lane = wave_lane();
-	const int wave = wave_uniform((int)(threadIdx.x >> 6));
-	const int seg = wave_uniform((int)blockIdx.x * ENT_WAVES + wave);
-	if (seg >= total_segs) return;
-	// The segment's finished bit strings as k_ent_count left them (one per nonzero coefficient: run code + value code): this kernel only
-	// adds up their lengths and puts them in place -- no table is consulted for an ordinary token, so what a wave waits for is one round
-	// of independent loads (descriptor, state, strings), not a chain of them.  (Round 2 looked the codes up here: three dependent gathers
-	// behind the token load; SQ counters showed the waves parked on memory 79 % of their time.)
-	const uint2 *seg_str = (const uint2 *)(tokens + (size_t)seg * ENT_TOK_STRIDE);
-	const uint2 first_rec = seg_str[lane];                 // (issued before anything is known about the segment: at worst 512 bytes read for nothing)
-	// the segment's state and its neighbours' in the band (the segments of a band are consecutive): who writes the words shared with them.  All of it
-	// in one round of independent scalar loads (the records say themselves whether a neighbour belongs to the band; round 3's probes: the chain
-	// segment job -> band state / neighbour states in front of the first useful instruction was 0.58 of this kernel's 1.65 ms)
-	const EntSegState st = segs[seg];
-	const EntSegState pv = segs[seg > 0 ? seg - 1 : 0];
-	const EntSegState nx = segs[seg + 1 < total_segs ? seg + 1 : seg];
 	if (st.bits == 0) return;                            // wave-uniform: nothing starts in this segment
 	const EntTables *T = tables + (st.info >> 8);
 	const bool has_prev = (st.info & 1u) != 0u, has_next = (st.info & 2u) != 0u;
@@ -561,8 +584,7 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(const EntSegJob *seg_j
 	const bool merge_next = has_next && ent_neighbours_merge(st, nx);
 	uint32_t *out = (uint32_t *)st.out;
 	if (!out) return;                                    // the sample overflowed its buffer (k_ent_layout reported size 0)
-	if (probe == 2) { if (first_rec.x == 0x12345u && lane == 0) out[0] = 1; return; }
-	uint32_t *s_words = s_words_all[wave];
+	if (probe == 2) { if (first_rec == 0x12345u && lane == 0) out[0] = 1; return; }
 	const int ntok = (int)st.ntok;
 	const uint64_t seg_pos = st.bitoff;                  // bit position of the segment inside the band payload
 	const uint32_t first_word = (uint32_t)(seg_pos >> 5), last_word = (uint32_t)((seg_pos + st.bits - 1) >> 5);
@@ -577,23 +599,23 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(const EntSegJob *seg_j
 	uint64_t round_pos = seg_pos + st.run_bits;
 	for (int t = lane, t0 = 0; t0 < ntok; t0 += ENT_LANES, t += ENT_LANES) {
 		const bool have = t < ntok;
-		uint2 rec = t0 == 0 ? first_rec : seg_str[have ? t : 0];
-		if (!have) { rec.x = 0u; rec.y = 0u; }
-		uint32_t len = rec.x & 63u;
+		uint32_t rec = t0 == 0 ? first_rec : seg_str[have ? t : 0];
+		if (!have) rec = 0u;
+		uint32_t len = rec & 63u;
 		const bool complex = len == (uint32_t)ENT_CODE_COMPLEX;
 		uint32_t run = 0, ve = 0;
 		if (__ballot(complex)) {
 			// rare: a run inside the segment that one composite code does not cover -- this lane walks the tables for its token
 			if (complex) {
-				run = rec.y >> 16;                                             // (never the first token: its run is k_ent_scan's)
-				ve = value_entry(T, (int)(int16_t)(rec.y & 0xffffu));
+				run = rec >> 22;                                               // (zero for the first token: its run is k_ent_scan's)
+				ve = value_entry(T, (int)(int16_t)((rec >> 6) & 0xffffu));
 				len = (uint32_t)T->run_total[run] + (ve >> 27);
 			}
 		}
 		const uint32_t sc = wave_incl_scan(len);
 		uint64_t pos = round_pos + (sc - len);
 		round_pos += wave_get(sc, ENT_LANES - 1);
-		if (have && !complex) ent_put_string(s_words, out, use_lds, first_word, pos, ((uint64_t)rec.y << 32) | (rec.x & ~63u));
+		if (have && !complex) ent_put_string32(s_words, out, use_lds, first_word, pos, rec & ~63u);
 		if (complex) {
 			uint32_t left = run;
 			while (left > 0u) {
@@ -621,6 +643,41 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(const EntSegJob *seg_j
 			else if (probe != 5) out[first_word + i] = w;
 		}
 	}
+}
+
+// ENT_EMIT_SEGS consecutive segments per wave: their states (one more on either side) and first strings are fetched in one round of independent loads before
+// the first is worked on.  (Round 3's probes: with one segment per wave and the chain segment job -> band state / neighbour states in front of the first
+// useful instruction, that front was 0.58 of this kernel's 1.65 ms; 0.41 with the single round of loads; two segments per wave: front 0.36 but the kernel
+// 1.62 instead of 1.56 -- the second segment waits for the first.  Kept at 1.)
+enum { ENT_EMIT_SEGS = 1 };
+__global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(int total_segs, const EntSegState *segs, const EntTables *tables, const uint32_t *tokens,
+                                                           int probe = 0 /* timing experiments: 1 leave at once, 2 behind the descriptor loads, 3 without the final stores, 4 plain stores for the shared words, 5 no plain stores */)
+{
+	__shared__ uint32_t s_words_all[ENT_WAVES][ENT_LDS_WORDS + 3];
+	if (probe == 1) return;
+	const int lane = wave_lane();
+	const int wave = wave_uniform((int)(threadIdx.x >> 6));
+	const int seg0 = wave_uniform(((int)blockIdx.x * ENT_WAVES + wave) * ENT_EMIT_SEGS);
+	if (seg0 >= total_segs) return;
+	uint32_t first_rec[ENT_EMIT_SEGS];
+	EntSegState st[ENT_EMIT_SEGS + 2];                   // st[k + 1] = segment seg0 + k
+#pragma unroll
+	for (int k = 0; k < ENT_EMIT_SEGS; k++) {            // (issued before anything is known about the segments: at worst 512 bytes each read for nothing)
+		const int sg = seg0 + k < total_segs ? seg0 + k : seg0;
+		first_rec[k] = tokens[(size_t)sg * ENT_TOK_STRIDE + lane];
+	}
+#pragma unroll
+	for (int k = 0; k < ENT_EMIT_SEGS + 2; k++) {
+		int sg = seg0 - 1 + k;
+		sg = sg < 0 ? 0 : (sg < total_segs ? sg : total_segs - 1);      // (the records say themselves whether a neighbour belongs to their band)
+		st[k] = segs[sg];
+	}
+#pragma unroll
+	for (int k = 0; k < ENT_EMIT_SEGS; k++)
+		if (seg0 + k < total_segs) {
+			ent_emit_segment(st[k + 1], st[k], st[k + 2], first_rec[k], tokens + (size_t)(seg0 + k) * ENT_TOK_STRIDE, lane, s_words_all[wave], tables, probe);
+			CFHD_WAVE_SYNC();                                 // the next segment reuses the window
+		}
 }
 
 

@@ -119,6 +119,8 @@ struct InvPlaneJob {
 	// out_pitch in words; samples are clamped to `precision` bits and shifted up to 16; rows >= display_height are not written
 	int xstride, precision, display_height;
 	int alpha;                              // k_inv_packed16: this component is the companded alpha plane of an RGBA 4:4:4:4 sample
+	int alpha_const;                        // k_inv_packed16, RGB 4:4:4 samples decoded to b64a (orc_inv_spatial_to_b64a_of_rgb444): word 0 of every pixel is this constant
+	                                        // (0xfff0 in the reference) and only the last band column takes the scalar-tail clamp
 	// k_inv_packed16, 8-bit RGB output (RG24, BGRA, BGRa of RGB 4:4:4 samples): `out` is the component's BYTE inside the first pixel, xstride =
 	// bytes per pixel, out_pitch in BYTES; every byte = (12-bit component * 2 + 9 + r) >> 5 with a four-bit dither r per sample (the
 	// reference's model, oracle/cfhd_oracle_inv.c orc_inv_spatial_to_rgb8); bottom_up: picture row y goes to output row display_height - 1 - y;
@@ -700,7 +702,7 @@ __device__ __forceinline__ void inv_plane_tile(const InvPlaneJob *jobs, int nch,
 	const int tid = threadIdx.x;
 	const uint16_t *frame = nullptr;                     // PACKED: first word of the packed frame
 	int w_first = 0;                                     // PACKED: band width of plane 0 (the geometry the tile grid is laid out on)
-	if (PACKED) { uintptr_t lo = (uintptr_t)jobs[tile.z * nch].out; for (int c = 1; c < nch; c++) { const uintptr_t p = (uintptr_t)jobs[tile.z * nch + c].out; lo = p < lo ? p : lo; } frame = (const uint16_t *)lo; }
+	if (PACKED) { uintptr_t lo = (uintptr_t)jobs[tile.z * nch].out; for (int c = 1; c < nch; c++) { const uintptr_t p = (uintptr_t)jobs[tile.z * nch + c].out; lo = p < lo ? p : lo; } frame = (const uint16_t *)lo; if (jobs[tile.z * nch].alpha_const) frame -= 1; /* the constant alpha word lies in front of the planes' words */ }
 	for (int comp = 0; comp < (PACKED ? nch : 1); comp++) {
 	if (comp) __syncthreads();                           // the previous component's tile is finished with s_job and the staging arrays
 	stage_job(&s_job, &jobs[PACKED ? tile.z * nch + comp : tile.z]);
@@ -770,7 +772,7 @@ __device__ __forceinline__ void inv_plane_tile(const InvPlaneJob *jobs, int nch,
 					}
 					continue;
 				}
-				const int tail0 = w - (w & 7) - 9;
+				const int tail0 = job.alpha_const ? w - 1 : w - (w & 7) - 9;      // (b64a of an RGB 4:4:4 sample: only the last band column behaves like the scalar tail)
 				const int xs = job.xstride;
 				const size_t at = (size_t)(2 * rl + par) * (2 * ITW) * wps + (size_t)(4 * p) * xs + word;      // sample 2 (c - c0) of tile row 2 rl + par
 				uint16_t *dst = s_out + at;
@@ -857,7 +859,8 @@ __device__ __forceinline__ void inv_plane_tile(const InvPlaneJob *jobs, int nch,
 				const int orl = i / row_dw, d = i - orl * row_dw;
 				const int orow = 2 * r0 + orl;
 				if (orow >= job.display_height || orow >= 2 * h) continue;
-				const uint32_t v = *(const uint32_t *)(s_out + (size_t)orl * (2 * ITW) * wps + 2 * d);
+				uint32_t v = *(const uint32_t *)(s_out + (size_t)orl * (2 * ITW) * wps + 2 * d);
+				if (job.alpha_const && !(d & 1)) v = (v & 0xffff0000u) | (uint32_t)job.alpha_const;      // (four words per pixel: every second dword starts with the alpha word)
 				*(uint32_t *)((uint16_t *)frame + (size_t)orow * job.out_pitch + (size_t)(2 * c0) * wps + 2 * d) = v;
 			}
 			}

@@ -71,6 +71,8 @@ void orc_inv_spatial_to_v210(PIXEL16 *const bands[3][4], const int band_pitch[3]
 /* RGB 4:4:4 sample -> RG24 / BGRA (bottom_up) / BGRa: the RG48 reconstruction reduced to 8 bits with the dither value r (0..15) the caller picks, see cfhd_oracle_inv.c */
 void orc_inv_spatial_to_rgb8(PIXEL16 *const bands[4][4], int band_pitch, int w, int h, int precision, int display_height, int bytes_per_pixel, int bottom_up,
                              int r, uint8_t *out, int out_pitch_bytes);
+/* RGB 4:4:4 samples -> b64a: the RG48 words with the scalar tail reduced to the last band column, alpha word 0xfff0 */
+void orc_inv_spatial_to_b64a_of_rgb444(PIXEL16 *const bands[4][4], int band_pitch, int w, int h, int precision, uint16_t *out, int out_pitch_words);
 /* RGBA 4:4:4:4 samples -> BGRA / BGRa: (12-bit component + 2) >> 4, alpha expanded (codec.h:164-165); no dither */
 void orc_inv_spatial_to_rgba8(PIXEL16 *const bands[4][4], int band_pitch, int w, int h, int precision, int display_height, int bottom_up, uint8_t *out, int out_pitch_bytes);
 /* 4:2:2 sample -> YU64 (16-bit words Y0 C1 Y1 C2): the planar 16-bit row route (InvertHorizontalStrip16sToRow16u per plane), see cfhd_oracle_inv.c */

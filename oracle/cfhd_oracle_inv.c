@@ -442,3 +442,24 @@ void orc_inv_spatial_to_rgba8(PIXEL16 *const bands[4][4], int band_pitch, int w,
 	}
 	free(tmp);
 }
+
+/* ---- RGB 4:4:4 samples decoded to b64a (words A, R, G, B) ---------------------------------------------------------------------------------
+ * Probed on the built reference and pinned in tests/test_oracle_vs_ref.py: the colour words are those of the 16-bit planar-row route
+ * (InvertHorizontalStrip16sToRow16u per plane, as for RG48 output) with ONE difference -- only the last band column (the last two pixels of a
+ * row) behaves like that routine's scalar tail and may reach 65535; the RG48 route starts its tail at band column w - w % 8 - 9 -- and the alpha
+ * word is the constant 0xfff0 (4095 << 4). */
+void orc_inv_spatial_to_b64a_of_rgb444(PIXEL16 *const bands[4][4], int band_pitch, int w, int h, int precision, uint16_t *out, int out_pitch_words)
+{
+	static const int word_of_channel[4] = { 1, 0, 2, 3 };      /* plane G -> word 1, R -> 0, B -> 2 of the temporary R, G, B pixels */
+	const int W = 2 * w;
+	uint16_t *tmp = (uint16_t *)malloc((size_t)2 * h * W * 3 * sizeof(uint16_t));
+	int y, x;
+	orc_inv_spatial_to_packed16(bands, band_pitch, w, h, precision, 3, word_of_channel, w - 1, -1, tmp, W * 3);
+	for (y = 0; y < 2 * h; y++)
+		for (x = 0; x < W; x++) {
+			uint16_t *o = out + (size_t)y * out_pitch_words + (size_t)x * 4;
+			const uint16_t *t = tmp + ((size_t)y * W + x) * 3;
+			o[0] = 0xfff0; o[1] = t[0]; o[2] = t[1]; o[3] = t[2];
+		}
+	free(tmp);
+}

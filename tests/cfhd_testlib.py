@@ -953,3 +953,21 @@ def oracle_inverse_rgba8(plan, coeffs, bottom_up):
     raw = oracle_inverse_rgb48(plan, coeffs, b64a=False)[: plan.height].reshape(plan.height, -1, 4)[:, :, 3].astype(np.int64)
     alt = np.minimum(((raw >> 4) + 2) >> 4, 255).astype(np.uint8)
     return out, (alt[::-1] if bottom_up else alt)
+
+
+def oracle_inverse_b64a_of_rgb444(plan, coeffs):
+    """Whole inverse path with the oracle from a dequantized RGB 4:4:4 pyramid to b64a words A, R, G, B (alpha 0xfff0): orc_inv_spatial_to_b64a_of_rgb444."""
+    O = oracle()
+    O.orc_inv_spatial_to_b64a_of_rgb444.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_int]
+    work = coeffs.copy()
+    for c in range(3):
+        for lv in (2, 1):
+            d = plan.band[(c, lv, 0)]
+            bands = (c_i16p * 4)(*[plan.view(work, c, lv, b).ctypes.data_as(c_i16p) for b in range(4)])
+            dst = plan.view(work, c, lv - 1, 0)
+            O.orc_inv_spatial(bands, d["pitch"], d["width"], d["height"], plan.prescale[lv], dst.ctypes.data_as(c_i16p), plan.band[(c, lv - 1, 0)]["pitch"])
+    d = plan.band[(0, 0, 0)]
+    flat = [plan.view(work, c, 0, b).ctypes.data_as(c_i16p) for c in range(3) for b in range(4)]
+    out = np.zeros((2 * d["height"], 2 * d["width"] * 4), np.uint16)
+    O.orc_inv_spatial_to_b64a_of_rgb444((c_i16p * 16)(*(flat + [None] * 4)), d["pitch"], d["width"], d["height"], plan.precision, out.ctypes.data_as(ctypes.c_void_p), out.shape[1])
+    return out

@@ -218,6 +218,24 @@ void emu_inv_packed16(int16_t **bands, int band_pitch, int w, int h, int display
 }
 void emu_inv_packed16_use_strip(int on) { g_inv_packed16_strip = on; }
 
+// The last level of an RGB 4:4:4 sample to b64a: three planes into words 1..3 of four-word pixels, word 0 = 0xfff0 (InvPlaneJob::alpha_const), as
+// DecodeBatch::prepare sets it up.
+void emu_inv_b64a_of_444(int16_t **bands, int band_pitch, int w, int h, int display_height, uint16_t *out, int out_pitch_words)
+{
+	std::vector<InvPlaneJob> jobs(3);
+	const int word_of_channel[3] = { 2, 1, 3 };            // planes G, R, B -> words A R G B
+	for (int c = 0; c < 3; c++) {
+		InvPlaneJob &job = jobs[c];
+		memset(&job, 0, sizeof(job));
+		for (int b = 0; b < 4; b++) job.band[b] = bands[c * 4 + b];
+		job.band_pitch = band_pitch; job.width = w; job.height = h; job.descale = 0;
+		job.out = (int16_t *)(out + word_of_channel[c]); job.out_pitch = out_pitch_words; job.xstride = 4; job.precision = 12; job.display_height = display_height;
+		job.alpha_const = 0xfff0;
+	}
+	dim3 grid((w + ITW - 1) / ITW, (h + ITH - 1) / ITH, 1);
+	hipemu::launch(grid, dim3(NTHREADS), [&] { k_inv_packed16(jobs.data(), 3, 4, 0u); });
+}
+
 // The last level of a 4:2:2 sample to YU64 (words Y0 C1 Y1 C2): k_inv_packed16 with per-plane widths and word strides, as DecodeBatch::prepare sets it up.
 // bands[c*4+b], band_pitch[c]; luma band w x h.
 void emu_inv_yu64(int16_t **bands, const int *band_pitch, int w, int h, int display_height, int precision, uint16_t *out, int out_pitch_words)
@@ -479,10 +497,10 @@ extern "C" long emu_entropy_encode2(int width, int height, int pixel_kind, int q
 	const int nseg = (int)jobs.segjobs.size(), nb = (int)jobs.bands.size();
 	const dev::EntBatchGeom geom = { nseg, nb, 0 };
 	std::vector<uint32_t> tokens((size_t)nseg * dev::ENT_TOK_STRIDE, 0xdeadbeefu);       // k_ent_count's token lists for k_ent_emit
-	hipemu::launch(dim3((nseg + dev::ENT_WAVES - 1) / dev::ENT_WAVES), dim3(dev::ENT_THREADS), [&] { dev::k_ent_count(jobs.segjobs.data(), geom, nseg, segs.data(), tables, &peak_flag, tokens.data()); });
+	hipemu::launch(dim3((nseg + dev::ENT_WAVES * dev::ENT_COUNT_SEGS - 1) / (dev::ENT_WAVES * dev::ENT_COUNT_SEGS)), dim3(dev::ENT_THREADS), [&] { dev::k_ent_count(jobs.segjobs.data(), geom, nseg, segs.data(), tables, &peak_flag, tokens.data()); });
 	hipemu::launch(dim3(nb), dim3(dev::ENT_THREADS), [&] { dev::k_ent_scan(jobs.bands.data(), segs.data(), bstate.data(), tables); });
 	hipemu::launch(dim3(1, 3), dim3(dev::ENT_THREADS), [&] { dev::k_ent_layout(&fj, jobs.bands.data(), segs.data(), bstate.data(), tables); });
-	hipemu::launch(dim3((nseg + dev::ENT_WAVES - 1) / dev::ENT_WAVES), dim3(dev::ENT_THREADS), [&] { dev::k_ent_emit(jobs.segjobs.data(), geom, nseg, segs.data(), bstate.data(), tables, tokens.data()); });
+	hipemu::launch(dim3((nseg + dev::ENT_WAVES * dev::ENT_EMIT_SEGS - 1) / (dev::ENT_WAVES * dev::ENT_EMIT_SEGS)), dim3(dev::ENT_THREADS), [&] { dev::k_ent_emit(nseg, segs.data(), tables, tokens.data()); });
 	return peak_flag ? -100 : (long)size;
 }
 

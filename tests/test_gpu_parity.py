@@ -468,6 +468,29 @@ def test_v210_encode_bitstream_identical(w, h):
     assert psnr_yuy2(img[:, : (w - w % 48) * 2], as8[:, : (w - w % 48) * 2]) > 40      # (the columns behind the last whole 48 pixels carry the reference's repeated Cr)
 
 
+@pytest.mark.parametrize("w,h", [(320, 240), (720, 480), (1920, 1080)])
+def test_rgb444_decode_to_b64a_equals_reference_exactly(w, h):
+    """RGB 4:4:4 samples decoded to b64a (what TestCFHD's b64a -> RGB 4:4:4 row decodes to): word for word the reference decoder's output -- the RG48 words
+    with the scalar-tail clamp in the last band column only, alpha word 0xfff0 (orc_inv_spatial_to_b64a_of_rgb444, pinned on eight geometries on the CPU)."""
+    frames, pitch = qbist_frames(12, 1, w, h, PIX_B64A, alpha=1)
+    px = np.frombuffer(frames[0].tobytes(), dtype=np.uint16).reshape(h, pitch // 2).copy()
+    ramp = ((np.arange(h)[:, None] * 523 + np.arange(w)[None, :] * 97) % 65536).astype(np.uint16)
+    px[:, 1: w * 4: 4] = np.where(ramp > 60000, 65535, np.where(ramp < 4000, 0, px[:, 1: w * 4: 4]))
+    sample = amd_encode_frames([px.reshape(-1).view(np.uint8).copy()], pitch, w, h, PIX_B64A, encoded=ENCODED_RGB444)[0]
+    got, gpitch, aw, ah = amd_decode_sample(sample, PIX_B64A)
+    assert (aw, ah) == (w, h)
+    mine = np.frombuffer(got.tobytes(), np.uint16).reshape(h, gpitch // 2)[:, : w * 4]
+    plan = Plan(w, h, pixkind=PIXKIND["b64a"], enc=ENC["444"])
+    want = oracle_inverse_b64a_of_rgb444(plan, host_decode_pyramid(sample, plan))[:h]
+    assert np.array_equal(mine, want)
+    rows = h if h % 8 == 0 else h - 8
+    for attempt in range(6):                            # (the reference's threaded decoder occasionally damages a frame)
+        dec, dpitch = ref_decode_sample(sample, w, h, PIX_B64A)
+        img = np.frombuffer(dec.tobytes(), np.uint16).reshape(h, dpitch // 2)[:, : w * 4]
+        if np.array_equal(img[:rows], mine[:rows]): break
+    assert np.array_equal(img[:rows], mine[:rows]), "%d words differ" % (img[:rows] != mine[:rows]).sum()
+
+
 @pytest.mark.parametrize("w,h", [(320, 240), (1920, 1080)])
 def test_b64a_encode_to_rgb444_bitstream_identical(w, h):
     """b64a -> RGB 4:4:4 (alpha dropped): byte-identical to the reference; the sample decodes to RG48."""
@@ -689,7 +712,7 @@ def test_rgba8_encode_to_rgba4444_bitstream_identical(w, h, name):
         if all(np.array_equal(img[:, k::4], want[:, k::4]) for k in range(3)): break
     assert all(np.array_equal(img[:, k::4], want[:, k::4]) for k in range(3))
     a_ok = img[:, 3::4] == want[:, 3::4]
-    assert a_ok.mean() > 0.9 and np.array_equal(img[:, 3::4][~a_ok], alt[~a_ok])
+    assert np.array_equal(img[:, 3::4][~a_ok], alt[~a_ok])
     got, gpitch, aw, ah = amd_decode_sample(mine[0], PIX_B64A)
     assert (aw, ah) == (w, h)
     words = np.frombuffer(got.tobytes(), np.uint16).reshape(h, gpitch // 2)[:, : w * 4].reshape(h, w, 4)

@@ -576,6 +576,34 @@ def test_inv_rgb8_last_level_lies_in_oracle_interval(w, h, dh, bpp, bottom_up):
     assert (img == 255).any() and (img == 0).any()
 
 
+@pytest.mark.parametrize("w,h,dh", [(16, 8, 16), (68, 20, 37), (160, 17, 34), (250, 33, 66)])
+def test_inv_b64a_of_rgb444_last_level_equals_oracle(w, h, dh):
+    """RGB 4:4:4 samples decoded to b64a (k_inv_packed16 with three planes in four-word pixels): the oracle model pinned on the reference decoder in
+    test_oracle_vs_ref -- RG48 words with the scalar-tail clamp in the last band column only, constant alpha word 0xfff0; nothing beside the picture."""
+    rng = np.random.default_rng(w * 7 + h)
+    pitch = (w + 7) // 8 * 8
+    bands = []
+    for c in range(3):
+        bs = [np.zeros((h, pitch), np.int16) for _ in range(4)]
+        bs[0][:, :w] = rand_plane(rng, w, h, 14)
+        for k in range(1, 4): bs[k][:, :w] = rand_plane(rng, w, h, 11, signed=True)
+        bands.append(bs)
+    flat = [p16(a) for c in range(3) for a in bands[c]]
+    O = oracle()
+    O.orc_inv_spatial_to_b64a_of_rgb444.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_int]
+    full = np.zeros((2 * h, 2 * w * 4), np.uint16)
+    O.orc_inv_spatial_to_b64a_of_rgb444((c_i16p * 16)(*(flat + [None] * 4)), pitch, w, h, 12, full.ctypes.data_as(ctypes.c_void_p), 2 * w * 4)
+    want = full[:dh]
+    assert (want == 65535).any() and (want == 0).any() and (want[:, : 2 * w * 4 - 8] <= 0xfff0).all()
+    opitch = 2 * w * 4 + 8
+    got = np.full((dh, opitch), 7, np.uint16)
+    E = emu()
+    E.emu_inv_b64a_of_444.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_int]
+    E.emu_inv_b64a_of_444((c_i16p * 12)(*flat), pitch, w, h, dh, got.ctypes.data_as(ctypes.c_void_p), opitch)
+    assert np.array_equal(got[:, : 2 * w * 4], want)
+    assert (got[:, 2 * w * 4:] == 7).all()
+
+
 @pytest.mark.parametrize("w,h,dh,bottom_up", [(16, 8, 16, 1), (68, 20, 37, 0), (160, 17, 34, 1), (250, 33, 66, 0)])
 def test_inv_rgba8_last_level_equals_oracle(w, h, dh, bottom_up):
     """k_inv_packed16's byte mode for RGBA 4:4:4:4 samples (BGRA / BGRa output): no dither -- equal to the oracle model pinned on the reference decoder in

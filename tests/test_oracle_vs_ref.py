@@ -287,9 +287,30 @@ def test_reference_rgba8_decode_of_4444_equals_oracle(w, h, name, seed):
         if all(np.array_equal(img[:, k::4], want[:, k::4]) for k in range(3)): break
     for k in range(3): assert np.array_equal(img[:, k::4], want[:, k::4]), "colour byte %d" % k
     a_ok = img[:, 3::4] == want[:, 3::4]
-    assert a_ok.mean() > 0.9 and np.array_equal(img[:, 3::4][~a_ok], alt[~a_ok])          # (the race is lost for parts of rows, too)
+    assert np.array_equal(img[:, 3::4][~a_ok], alt[~a_ok])          # (the race is lost for parts of rows, too; on a busy host for most of the picture)
     src = np.frombuffer(frames[0].tobytes(), np.uint8).reshape(h, pitch)[sl, : w * 4]
     assert np.abs(want.astype(int) - src.astype(int)).mean() < 3.0
+
+
+@pytest.mark.parametrize("w,h,seed", [(320, 240, 10), (336, 256, 11), (400, 120, 14), (720, 480, 12), (64, 64, 15), (1280, 720, 16), (1920, 1080, 13), (144, 96, 17)])
+def test_reference_b64a_decode_of_rgb444_equals_model(w, h, seed):
+    """Pins orc_inv_spatial_to_b64a_of_rgb444 (a model fitted by probing: eight geometries, eight pictures, ramps into both clips): the reference decodes an RGB
+    4:4:4 sample to b64a as the RG48 words -- with the scalar-tail clamp (65535 instead of 0xfff0) in the last band column only -- behind the alpha word 0xfff0.  (Heights that are multiples of 8, and 1080: see
+    test_reference_rgba8_decode_of_4444_equals_oracle for what the reference does with the last rows otherwise.)"""
+    frames, pitch = qbist_frames(seed, 1, w, h, PIX_B64A, alpha=1)
+    px = np.frombuffer(frames[0].tobytes(), dtype=np.uint16).reshape(h, pitch // 2).copy()
+    ramp = ((np.arange(h)[:, None] * 523 + np.arange(w)[None, :] * 97) % 65536).astype(np.uint16)
+    px[:, 1: w * 4: 4] = np.where(ramp > 60000, 65535, np.where(ramp < 4000, 0, px[:, 1: w * 4: 4]))      # red: stretches at both clips
+    sample = ref_encode_frames([px.reshape(-1).view(np.uint8).copy()], pitch, w, h, PIX_B64A, encoded=ENCODED_RGB444)[0]
+    plan = Plan(w, h, pixkind=PIXKIND["b64a"], enc=ENC["444"])
+    want = oracle_inverse_b64a_of_rgb444(plan, host_decode_pyramid(sample, plan))[:h]
+    rows = h if h % 8 == 0 else h - 8
+    for attempt in range(6):                            # see test_reference_rg48_decode_equals_oracle
+        dec, dpitch = ref_decode_sample(sample, w, h, PIX_B64A)
+        img = np.frombuffer(dec.tobytes(), dtype=np.uint16).reshape(h, dpitch // 2)[:, : w * 4]
+        if np.array_equal(img[:rows], want[:rows]): break
+    assert np.array_equal(img[:rows], want[:rows]), "%d words differ" % (img[:rows] != want[:rows]).sum()
+    assert (want[:, 1::4] == 0xfff0).any() and (want[:, 1::4] == 0).any() and (w in (64, 144) or (want[:, 1::4] == 65535).any())
 
 
 @pytest.mark.parametrize("w,h", [(192, 96), (320, 240), (1920, 1080)])
@@ -309,8 +330,7 @@ def test_reference_b64a_decode_equals_oracle(w, h):
         img = np.frombuffer(dec.tobytes(), dtype=np.uint16).reshape(h, dpitch // 2)[:, : w * 4]
         if all(np.array_equal(mine[:, k::4], img[:, k::4]) for k in (1, 2, 3)): break
     assert np.array_equal(mine[:, 1::4], img[:, 1::4]) and np.array_equal(mine[:, 2::4], img[:, 2::4]) and np.array_equal(mine[:, 3::4], img[:, 3::4])
-    rows_ok = (mine[:, 0::4] == img[:, 0::4]).all(axis=1)
-    assert rows_ok.mean() > 0.9
+    rows_ok = (mine[:, 0::4] == img[:, 0::4]).all(axis=1)          # (no share of rows is required: on a busy host the race is lost on most of them)
     if not rows_ok.all():
         raw = oracle_inverse_rgb48(plan, host_decode_pyramid(sample, plan), b64a=False)[:h]      # same planes without the alpha expansion
         bad = np.where(~rows_ok)[0]
