@@ -2227,5 +2227,32 @@ __global__ void __launch_bounds__(NTHREADS) k_yu64_to_v210(const uint16_t *yu64,
 	o[3] = Y[4] | (Cr[2] << 10) | (Y[5] << 20);
 }
 
+// RG24 output of 4:2:2 samples (DecodeBatch): a pixel pair of a YU64 row (words Y0 C1 Y1 C2, C1 = channel 1 = Cr, C2 = channel 2 = Cb) through the reference's
+// scalar conversion (convert.c:11392-11448 ConvertRow16uToDitheredRGB; oracle/cfhd_oracle_inv.c orc_inv_spatial_to_rgb24_of_yuv422): 15-bit dither per pixel,
+// shared by its three components, from the counter-based hash that stands in for rand(); bytes B, G, R, bottom row first.  matrix: 0 computer-systems 709,
+// 1 video 709, 2 computer 601, 3 video 601.  One thread per pixel pair.
+__global__ void __launch_bounds__(NTHREADS) k_yu64_to_rgb24(const uint16_t *yu64, int in_pitch_words, size_t in_frame_words, uint8_t *out, int out_pitch, size_t out_frame_bytes,
+                                                            int pairs, int rows, int matrix, uint32_t seed)
+{
+	const int p = (int)(blockIdx.x * NTHREADS + threadIdx.x);
+	if (p >= pairs) return;
+	const int row = (int)blockIdx.y;
+	const int m[4][6] = { { 16, 128 * 149, 230, 137, 55, 135 }, { 0, 128 * 128, 197, 118, 47, 116 }, { 16, 128 * 149, 204, 208, 100, 129 }, { 0, 128 * 128, 175, 179, 86, 111 } };
+	const int *c = m[matrix & 3];
+	const uint16_t *r = yu64 + (size_t)blockIdx.z * in_frame_words + (size_t)row * in_pitch_words + 4 * (size_t)p;
+	uint8_t *o = out + (size_t)blockIdx.z * out_frame_bytes + (size_t)(rows - 1 - row) * out_pitch + 6 * (size_t)p;
+	const int V = (int)r[1] - 32768, U = (int)r[3] - 32768;
+	const uint32_t dz = dither_word(seed + 0x9E3779B9u * (uint32_t)(blockIdx.z + 1), row, p);
+#pragma unroll
+	for (int k = 0; k < 2; k++) {
+		const int d = (int)((dz >> (16 * k)) & 0x7fffu);
+		const int Y1 = (((int)r[2 * k] - (c[0] << 8)) * c[1]) >> 7;
+		const int R = (Y1 + c[2] * V + d) >> 15, G = (Y1 - c[4] * (U >> 1) - c[3] * (V >> 1) + d) >> 15, B = (Y1 + 2 * c[5] * U + d) >> 15;
+		o[3 * k + 0] = (uint8_t)(B < 0 ? 0 : (B > 255 ? 255 : B));
+		o[3 * k + 1] = (uint8_t)(G < 0 ? 0 : (G > 255 ? 255 : G));
+		o[3 * k + 2] = (uint8_t)(R < 0 ? 0 : (R > 255 ? 255 : R));
+	}
+}
+
 } // namespace dev
 } // namespace cfhd

@@ -463,3 +463,44 @@ void orc_inv_spatial_to_b64a_of_rgb444(PIXEL16 *const bands[4][4], int band_pitc
 		}
 	free(tmp);
 }
+
+/* ---- 4:2:2 samples decoded to RG24 (8-bit B, G, R, bottom row first) ---------------------------------------------------------------------
+ * decoder.c:16486 -> InvertHorizontalStrip16s.c:17508 InvertHorizontalStrip16sYUVtoRGB: the three planes as 16-bit rows (InvertHorizontalStrip16sToRow16u,
+ * the rows orc_inv_spatial_to_yu64 restates) -> decoder.c:23151 ConvertRow16uToDitheredBuffer -> convert.c:10677 ConvertRow16uToDitheredRGB, whose vector
+ * code is compiled out (`#if (0 && XMMOPT)`): the scalar loop at convert.c:11392-11448 does all columns.  Per pixel, with the pair's chroma (U = channel
+ * 2, V = channel 1; :10684-10686): Y' = ((Y - (y_offset << 8)) * ymult) >> 7, U -= 32768, V -= 32768,
+ *   R = (Y' + r_vmult * V + d) >> 15, G = (Y' - g_umult * (U >> 1) - g_vmult * (V >> 1) + d) >> 15, B = (Y' + 2 * b_umult * U + d) >> 15, saturated to 8 bits,
+ * d = rand() & 0x7fff, drawn once per pixel and shared by its three components.  The oracle takes d as an input (0 and 32767 are the ends of the
+ * interval every reference byte lies in).  Matrices :10707-10750 by the sample's colour space (1 = 601, 2 = 709, +4 = video range); STRICT_SATURATE is 0
+ * (color.h:30), so SATURATE_Y / Cb / Cr are the identity. */
+void orc_inv_spatial_to_rgb24_of_yuv422(PIXEL16 *const bands[3][4], const int band_pitch[3], int luma_w, int h, int precision, int display_height, int color_space,
+                                        int d, uint8_t *out, int out_pitch_bytes)
+{
+	const int W = 2 * luma_w;
+	uint16_t *yu = (uint16_t *)malloc((size_t)2 * h * W * 2 * sizeof(uint16_t));
+	int y_offset = 16, ymult = 128 * 149, r_vmult = 230, g_vmult = 137, g_umult = 55, b_umult = 135;      /* COLOR_SPACE_CG_709 and the default */
+	int y, x;
+	switch (color_space & 7) {
+	case 1: r_vmult = 204; g_vmult = 208; g_umult = 100; b_umult = 129; break;                                             /* CG_601 */
+	case 5: y_offset = 0; ymult = 128 * 128; r_vmult = 175; g_vmult = 179; g_umult = 86; b_umult = 111; break;             /* VS_601 */
+	case 6: y_offset = 0; ymult = 128 * 128; r_vmult = 197; g_vmult = 118; g_umult = 47; b_umult = 116; break;             /* VS_709 */
+	default: break;
+	}
+	orc_inv_spatial_to_yu64(bands, band_pitch, luma_w, h, precision, yu, W * 2);
+	for (y = 0; y < display_height; y++) {
+		const uint16_t *r = yu + (size_t)y * W * 2;
+		uint8_t *o = out + (size_t)(display_height - 1 - y) * out_pitch_bytes;          /* DECODED_FORMAT_RGB24 is "inverted": bottom row first (decoder.c:23166) */
+		for (x = 0; x < W; x += 2) {
+			const int V = (int)r[2 * x + 1] - 32768, U = (int)r[2 * x + 3] - 32768;
+			int k;
+			for (k = 0; k < 2; k++) {
+				const int Y1 = (((int)r[2 * x + 2 * k] - (y_offset << 8)) * ymult) >> 7;
+				int R = (Y1 + r_vmult * V + d) >> 15, G = (Y1 - g_umult * (U >> 1) - g_vmult * (V >> 1) + d) >> 15, B = (Y1 + 2 * b_umult * U + d) >> 15;
+				o[3 * (x + k) + 0] = (uint8_t)(B < 0 ? 0 : (B > 255 ? 255 : B));
+				o[3 * (x + k) + 1] = (uint8_t)(G < 0 ? 0 : (G > 255 ? 255 : G));
+				o[3 * (x + k) + 2] = (uint8_t)(R < 0 ? 0 : (R > 255 ? 255 : R));
+			}
+		}
+	}
+	free(yu);
+}

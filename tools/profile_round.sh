@@ -8,10 +8,10 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-python $ROOT/bench.py "$@" --steps 10 --warmup 2 > $OUT/bench_plain.json 2> $OUT/bench_plain.err
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- python $ROOT/bench.py "$@" --steps 5 --warmup 2 --no-cpu-baseline --no-c-abi > $OUT/bench_traced.json 2> $OUT/trace.err
-rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o bench -- python $ROOT/bench.py "$@" --steps 3 --warmup 1 --no-cpu-baseline --no-c-abi > /dev/null 2> $OUT/fetch.err
-rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o bench -- python $ROOT/bench.py "$@" --steps 3 --warmup 1 --no-cpu-baseline --no-c-abi > /dev/null 2> $OUT/write.err
+python $ROOT/bench.py "$@" --steps 10 --warmup 2 --no-cpu-baseline --no-c-abi --no-other-workloads > $OUT/bench_plain.json 2> $OUT/bench_plain.err
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- python $ROOT/bench.py "$@" --steps 5 --warmup 2 --no-cpu-baseline --no-c-abi --no-other-workloads > $OUT/bench_traced.json 2> $OUT/trace.err
+rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o bench -- python $ROOT/bench.py "$@" --steps 3 --warmup 1 --no-cpu-baseline --no-c-abi --no-other-workloads > /dev/null 2> $OUT/fetch.err
+rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o bench -- python $ROOT/bench.py "$@" --steps 3 --warmup 1 --no-cpu-baseline --no-c-abi --no-other-workloads > /dev/null 2> $OUT/write.err
 T=$(find $OUT/trace -name '*.db' | head -1); F=$(find $OUT/fetch -name '*.db' | head -1); W=$(find $OUT/write -name '*.db' | head -1)
 {
   echo "# python bench.py $* (plain run, then under rocprofv3 --kernel-trace --stats, then --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs)"

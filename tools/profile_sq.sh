@@ -16,7 +16,7 @@ PASSES=(
 )
 i=0
 for P in "${PASSES[@]}"; do
-  rocprofv3 --pmc $P -d $OUT/p$i -o bench -- python $ROOT/bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline --no-c-abi > $OUT/bench_p$i.json 2> $OUT/p$i.err
+  rocprofv3 --pmc $P -d $OUT/p$i -o bench -- python $ROOT/bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline --no-c-abi --no-other-workloads > $OUT/bench_p$i.json 2> $OUT/p$i.err
   D=$(find $OUT/p$i -name '*.db' | head -1)
   [ -n "$D" ] && python $ROOT/tools/rocprof_summary.py $D > $OUT/summary_p$i.txt 2>> $OUT/p$i.err
   rm -rf $OUT/p$i
