@@ -546,6 +546,9 @@ void plan_from_sample(const ParsedSample &ps, int out_kind, FramePlan *plan, boo
 	*ok = build_frame_plan(plan, ps.width, ps.display_height, out_kind, ps.encoded_format);
 	if (!*ok) return;
 	plan->precision = ps.precision;
+	// for outputs that convert YUV to RGB: 601 or 709 by the sample's colour space tag, always the computer-systems range -- probed on the reference decoder: a
+	// sample encoded with CFHD_ENCODING_FLAGS_YUV_VSRGB decodes with the CG matrix all the same (26 dB against its source instead of 31)
+	plan->color_matrix = (ps.color_space & 3) == 1 ? 2 : 0;
 	if (ps.prescale_table) for (int i = 0; i < kNumLevels; i++) plan->prescale[i] = (ps.prescale_table >> (14 - 2 * i)) & 3;
 	else { plan->prescale[0] = 0; plan->prescale[1] = ps.precision >= 10 ? 2 : 0; plan->prescale[2] = ps.precision == 12 ? 2 : 0; }
 	if (plan->height != ps.height) *ok = false;
@@ -1000,7 +1003,9 @@ CFHD_Error CFHD_PrepareToDecode(CFHD_DecoderRef ref, int, int, CFHD_PixelFormat 
 	const bool rgb8 = kind == PIX_RG24 || kind == PIX_BGRA || kind == PIX_BGRa;
 	// ... and RGBA 4:4:4:4 samples to BGRA / BGRa (no dither there: (12-bit component + 2) >> 4, the alpha expanded from that rounded value)
 	const bool rgba8 = (kind == PIX_BGRA || kind == PIX_BGRa) && encf == ENC_RGBA4444;
-	if (rgb8 && ((encf != ENC_RGB444 && !rgba8) || half || d->header.width < 32)) return ERR_BADFORMAT;
+	// ... and 4:2:2 samples to RG24: the YU64 rows through the reference's scalar colour conversion with its 15-bit dither (DecodeBatch / k_yu64_to_rgb24)
+	const bool rgb24_of_422 = kind == PIX_RG24 && encf == ENC_YUV422 && !half && d->header.width >= 128;
+	if (rgb8 && ((encf != ENC_RGB444 && !rgba8 && !rgb24_of_422) || half || d->header.width < 32)) return ERR_BADFORMAT;
 	// ... and to the 10-bit RGB words r210 / DPX0 / AB10 / AR10 ((value before the final >> 1, + 3) >> 3 per component: a model fitted on the reference
 	// decoder and pinned word for word on the CPU, equal to the reference decoder on the GPU)
 	const bool rgb10 = kind >= PIX_R210 && kind <= PIX_AR10;
@@ -1010,7 +1015,7 @@ CFHD_Error CFHD_PrepareToDecode(CFHD_DecoderRef ref, int, int, CFHD_PixelFormat 
 	if (kind == PIX_BYR4 || (kind >= PIX_R210 && kind <= PIX_AR10 && !rgb10)) return ERR_BADFORMAT;     // encoder inputs only
 	// ... and RGB 4:4:4 samples to b64a (the RG48 words behind a constant alpha word 0xfff0, full resolution: what TestCFHD's b64a -> RGB 4:4:4 row decodes to)
 	const bool b64a_of_444 = kind == PIX_B64A && encf == ENC_RGB444 && !half;
-	if ((encf == ENC_RGB444) != (kind == PIX_RG48 || (rgb8 && !rgba8) || rgb10 || b64a_of_444) || (encf == ENC_RGBA4444) != ((kind == PIX_B64A && !b64a_of_444) || rgba8)) return ERR_BADFORMAT;
+	if ((encf == ENC_RGB444) != (kind == PIX_RG48 || (rgb8 && !rgba8 && !rgb24_of_422) || rgb10 || b64a_of_444) || (encf == ENC_RGBA4444) != ((kind == PIX_B64A && !b64a_of_444) || rgba8)) return ERR_BADFORMAT;
 	if (kind == PIX_YU64 && d->header.width < 128) return ERR_BADFORMAT;      // (the tail-column rule of the 16-bit rows is restated for chroma bands of 16 columns and more)
 	bool ok;
 	plan_from_sample(d->header, kind, &d->plan, &ok);
@@ -1150,7 +1155,7 @@ CFHD_Error CFHD_DecodeSample(CFHD_DecoderRef ref, void *sample, size_t size, voi
 	// interlaced samples (known only now: the SAMPLE_FLAGS tag lies behind the 512 bytes CFHD_PrepareToDecode sees): 4:2:2, full resolution through the
 	// inverse frame transform, half resolution from the level-1 lowpass planes like any other sample (the reference's output is the same model)
 	const bool interlaced = !ps.progressive;
-	if (interlaced && (ps.encoded_format != ENC_YUV422 || d->out_kind == PIX_YU64 || d->out_kind == PIX_V210)) return fail_zero(ERR_BADFORMAT);      // (YU64 output of interlaced samples is not built)
+	if (interlaced && (ps.encoded_format != ENC_YUV422 || d->out_kind == PIX_YU64 || d->out_kind == PIX_V210 || d->out_kind == PIX_RG24)) return fail_zero(ERR_BADFORMAT);      // (YU64 output of interlaced samples is not built)
 	if (interlaced && !d->half && ps.width > 8192) return fail_zero(ERR_BADFORMAT);        // k_dec_undiff serves rows of up to 4096 coefficients (cfhd_dec_kernels.h DXU_MAX): an unsupported size, not a bad sample
 	// another call of this geometry in flight right now: decode together with it (see DecodeService)
 	if (decode_gather_slots() > 1 && gpu_entropy_enabled() && size <= (size_t)d->plan.width * d->plan.height * pixel_bytes_of(d->out_kind) + 65536) {
@@ -1223,7 +1228,7 @@ static CFHD_Error decode_on_handle(Decoder *d, const ParsedSample &ps, const uin
 		const ParsedBand &lp = ps.lowpass[c];
 		const BandDesc &ll = plan.ch[c].band[2][0];
 		if (!lp.present || lp.width != ll.width || lp.height != ll.height) return fail_zero(ERR_BADSAMPLE);
-		const int lowpass_offset = lowpass_bias(plan.precision, ll.width, d->out_kind);
+		const int lowpass_offset = lowpass_bias(plan.precision, ll.width, d->out_kind, c);
 		for (int r = 0; r < ll.height; r++) {
 			const uint8_t *p = s + lp.offset + (size_t)r * ll.width * 2;
 			int16_t *dst = coeffs + ll.offset + (size_t)r * ll.pitch;

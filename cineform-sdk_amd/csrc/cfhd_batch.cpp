@@ -220,7 +220,7 @@ long long cfhd_amd_batch_roundtrip(cfhd_amd_batch *b)
 			for (int ch = 0; ch < plan.num_channels; ch++) {
 				const ParsedBand &lp = ps.lowpass[ch];
 				const BandDesc &ll = plan.ch[ch].band[2][0];
-				const int bias = lowpass_bias(plan.precision, ll.width, b->pixel_kind);
+				const int bias = lowpass_bias(plan.precision, ll.width, b->pixel_kind, ch);
 				for (int r = 0; r < ll.height; r++) {
 					const uint8_t *p = s + lp.offset + (size_t)r * ll.width * 2;
 					int16_t *dst = coeffs + ll.offset + (size_t)r * ll.pitch;

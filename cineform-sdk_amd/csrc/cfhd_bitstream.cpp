@@ -460,13 +460,16 @@ int parse_sample(const uint8_t *d, size_t size, ParsedSample *ps)
 	return truncated ? 1 : 0;
 }
 
-int lowpass_bias(int precision, int lowpass_width, int out_pixel_kind)
+int lowpass_bias(int precision, int lowpass_width, int out_pixel_kind, int channel)
 {
 	const bool even = (lowpass_width & 1) == 0;
 	if (precision == 8) return 32;
 	if (precision == 10) {
 		// decoder.c:12265-12276: the 16-bit and 10-bit 4:2:2 outputs (YU64, YR16, V210) take 4 where the 8-bit ones take 24; odd widths: :12479
 		if (out_pixel_kind == PIX_YU64 || out_pixel_kind == PIX_V210) return even ? 4 : 5;
+		// RGB24 / RGB32 output (bottom row first: RG24, BGRA -- not the top-down BGRa) of a 10-bit sample, bit-serial path of odd widths only: the reference
+		// takes 8 off the luma bias and 4 off the chroma bias ("fixed rounding error introduced by YUV->RGB", decoder.c:12500-12508)
+		if (!even && (out_pixel_kind == PIX_RG24 || out_pixel_kind == PIX_BGRA)) return channel == 0 ? 5 - 8 : 5 - 4;
 		return even ? 24 : 5;
 	}
 	return 0;                              // 12-bit: RG48 / b64a outputs carry no bias

@@ -118,7 +118,7 @@ struct ParsedSample {
 int parse_sample(const uint8_t *data, size_t size, ParsedSample *out);
 // Bias the reference decoder adds to every lowpass coefficient while unpacking it (Codec/decoder.c:12240-12290 fast path for
 // even widths, :12468-12545 bit-serial path for odd widths): depends on the sample precision and the output pixel format.
-int lowpass_bias(int precision, int lowpass_width, int out_pixel_kind);
+int lowpass_bias(int precision, int lowpass_width, int out_pixel_kind, int channel = 0);
 // Host VLC decode of one band into a zeroed band. Returns 0 on success.
 int vlc_decode_band(const uint8_t *data, size_t bytes, int width, int height, int pitch, int quant, int codebook, int16_t *band);
 // What the reference does to a decoded difference band (DecodeBandFSM16sNoGapWithPeaks decoder.c:19809 + :20822): coefficients beyond the peak

@@ -616,6 +616,12 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 	// scratch buffer and k_yu64_to_v210 packs them into the output
 	v210_ = out_kind == PIX_V210;
 	if (v210_) { if (plan.width % 6 || !own_output || half) { g_err = "v210 output: widths that are multiples of 6, full resolution"; return -2; } out_kind = PIX_YU64; }
+	// RG24 output of 4:2:2 samples: the reference computes the three planes as 16-bit rows (the YU64 route) and converts them pixel by pixel
+	// (convert.c:11392 ConvertRow16uToDitheredRGB, oracle orc_inv_spatial_to_rgb24_of_yuv422): the same two steps here
+	lowpass_kind_ = out_kind;
+	rgb24_of_422_ = out_kind == PIX_RG24 && plan.encoded_format == ENC_YUV422;
+	if (rgb24_of_422_) { if (!own_output || half) { g_err = "RG24 output of 4:2:2 samples: full resolution"; return -2; } out_kind = PIX_YU64; }
+	const bool repack = v210_ || rgb24_of_422_;
 
 	const bool yuv_ok = (out_kind == PIX_YUY2 || out_kind == PIX_2VUY) && plan.encoded_format == ENC_YUV422;
 	// (b64a from an RGB 4:4:4 sample: the three colour planes and a constant alpha word, full resolution)
@@ -635,18 +641,18 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 	out_pitch_ = packed_frame_pitch(out_kind, half ? plan.width / 2 : plan.width);
 	frame_bytes_ = (size_t)out_pitch_ * out_rows_;
 	uint8_t *job_out = nullptr; size_t job_frame_bytes = frame_bytes_;      // where the last-level kernel writes frame i: the output, or the YU64 scratch of v210 output
-	if (v210_) {
+	if (repack) {
 		HIPCHK(hipMalloc((void **)&d_tmp_, frame_bytes_ * n_));
 		job_out = d_tmp_; tmp_pitch_ = out_pitch_; tmp_frame_bytes_ = frame_bytes_;
-		out_pitch_ = packed_frame_pitch(PIX_V210, plan.width); frame_bytes_ = (size_t)out_pitch_ * out_rows_;
+		out_pitch_ = packed_frame_pitch(v210_ ? PIX_V210 : PIX_RG24, plan.width); frame_bytes_ = (size_t)out_pitch_ * out_rows_;
 	}
 	if (own_output) {
 		HIPCHK(hipMalloc((void **)&d_out_, frame_bytes_ * n_));
 		HIPCHK(hipHostMalloc((void **)&h_out_, frame_bytes_ * n_, hipHostMallocPortable));
 		if (v210_) HIPCHK(hipMemsetAsync(d_out_, 0, frame_bytes_ * n_, (hipStream_t)stream_));      // (row padding beyond the last whole group of 48 pixels stays zero)
 	}
-	if (!v210_) job_out = d_out_;
-	const int job_pitch = v210_ ? tmp_pitch_ : out_pitch_;
+	if (!repack) job_out = d_out_;
+	const int job_pitch = repack ? tmp_pitch_ : out_pitch_;
 	HIPCHK(hipMalloc((void **)&d_coeff_, (size_t)plan.coeff_elems * 2 * n_));
 	HIPCHK(hipMemsetAsync(d_coeff_, 0, (size_t)plan.coeff_elems * 2 * n_, (hipStream_t)stream_));
 	HIPCHK(hipHostMalloc((void **)&h_coeff_, (size_t)plan.final_elems * 2 * n_, hipHostMallocPortable));
@@ -713,7 +719,7 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 int DecodeBatch::prepare_entropy(size_t sample_cap)
 {
 	ent_.set_skip_level1(half_);                         // half resolution never looks at the level-1 highpass bands
-	int rc = ent_.prepare(plan_, n_, d_coeff_, plan_.coeff_elems, sample_cap, out_kind_, stream_);
+	int rc = ent_.prepare(plan_, n_, d_coeff_, plan_.coeff_elems, sample_cap, lowpass_kind_, stream_);
 	ent_ready_ = rc == 0;
 	return rc;
 }
@@ -866,6 +872,11 @@ int DecodeBatch::launch_inverse(uint32_t dither_seed)
 		const BandDesc &b = plan_.ch[0].band[0][0];
 		dim3 grid((b.width + dev::ITW - 1) / dev::ITW, (b.height + dev::ITH - 1) / dev::ITH, act);
 		dev::k_inv_yuv422<<<grid, dev::NTHREADS, 0, st>>>(j.yuv, dither_seed);
+	}
+	if (rgb24_of_422_) {
+		const int pairs = plan_.width / 2;
+		dev::k_yu64_to_rgb24<<<dim3((unsigned)((pairs + dev::NTHREADS - 1) / dev::NTHREADS), (unsigned)out_rows_, (unsigned)act), dev::NTHREADS, 0, st>>>(
+			(const uint16_t *)d_tmp_, tmp_pitch_ / 2, tmp_frame_bytes_ / 2, d_out_, out_pitch_, frame_bytes_, pairs, out_rows_, plan_.color_matrix, dither_seed);
 	}
 	if (v210_) {
 		const int groups = plan_.width / 6;

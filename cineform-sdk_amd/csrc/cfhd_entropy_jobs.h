@@ -297,7 +297,7 @@ inline bool dec_build_jobs(const ParsedSample &ps, const FramePlan &plan, const 
 		const ParsedBand &lp = ps.lowpass[c];
 		const BandDesc &ll = plan.ch[c].band[2][0];
 		if (!lp.present || lp.width != ll.width || lp.height != ll.height) return false;
-		dev::DecLowpassJob lj = { sample_addr + lp.offset, coeff_base + ll.offset, ll.width, ll.height, ll.pitch, lowpass_bias(plan.precision, ll.width, out_pixel_kind) };
+		dev::DecLowpassJob lj = { sample_addr + lp.offset, coeff_base + ll.offset, ll.width, ll.height, ll.pitch, lowpass_bias(plan.precision, ll.width, out_pixel_kind, c) };
 		lowpass->push_back(lj);
 		for (int lv = skip_level1 ? 1 : 0; lv < kNumLevels; lv++)      // half resolution: the level-1 highpass bands are not needed
 			for (int b = 1; b < 4; b++) {
@@ -322,7 +322,7 @@ inline void dec_build_plan(const FramePlan &plan, int out_pixel_kind, dev::DecPl
 	for (int c = 0; c < plan.num_channels; c++) {
 		const BandDesc &ll = plan.ch[c].band[2][0];
 		dp->low[c] = dev::DecPlanBand{ ll.width, ll.height, ll.pitch, (int)ll.offset };
-		dp->low_bias[c] = lowpass_bias(plan.precision, ll.width, out_pixel_kind);
+		dp->low_bias[c] = lowpass_bias(plan.precision, ll.width, out_pixel_kind, c);
 		for (int lv = 0; lv < kNumLevels; lv++)
 			for (int b = 1; b < 4; b++) {
 				const BandDesc &bd = plan.ch[c].band[lv][b];
@@ -347,7 +347,7 @@ inline bool dx_build_jobs(const ParsedSample &ps, const FramePlan &plan, const d
 		const ParsedBand &lp = ps.lowpass[c];
 		const BandDesc &ll = plan.ch[c].band[2][0];
 		if (!lp.present || lp.width != ll.width || lp.height != ll.height) return false;
-		lowpass[c] = dev::DecLowpassJob{ sample_addr + lp.offset, coeff_base + ll.offset, ll.width, ll.height, ll.pitch, lowpass_bias(plan.precision, ll.width, out_pixel_kind) };
+		lowpass[c] = dev::DecLowpassJob{ sample_addr + lp.offset, coeff_base + ll.offset, ll.width, ll.height, ll.pitch, lowpass_bias(plan.precision, ll.width, out_pixel_kind, c) };
 		for (int lv = 0; lv < kNumLevels; lv++)
 			for (int b = 1; b < 4; b++) {
 				const ParsedBand &pb = ps.high[c][lv][b];

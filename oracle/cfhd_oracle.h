@@ -77,6 +77,7 @@ void orc_inv_spatial_to_b64a_of_rgb444(PIXEL16 *const bands[4][4], int band_pitc
 void orc_inv_spatial_to_rgba8(PIXEL16 *const bands[4][4], int band_pitch, int w, int h, int precision, int display_height, int bottom_up, uint8_t *out, int out_pitch_bytes);
 /* 4:2:2 sample -> YU64 (16-bit words Y0 C1 Y1 C2): the planar 16-bit row route (InvertHorizontalStrip16sToRow16u per plane), see cfhd_oracle_inv.c */
 /* 4:2:2 sample -> RG24: the YU64 rows through the scalar loop of ConvertRow16uToDitheredRGB (convert.c:11392) with the 15-bit dither value d the caller picks */
+void orc_yu64_to_rgb24(const uint16_t *yu, int yu_pitch_words, int width, int rows, int color_space, int d, uint8_t *out, int out_pitch_bytes);
 void orc_inv_spatial_to_rgb24_of_yuv422(PIXEL16 *const bands[3][4], const int band_pitch[3], int luma_w, int h, int precision, int display_height, int color_space,
                                         int d, uint8_t *out, int out_pitch_bytes);
 void orc_inv_spatial_to_yu64(PIXEL16 *const bands[3][4], const int band_pitch[3], int luma_w, int h, int precision, uint16_t *out, int out_pitch_words);

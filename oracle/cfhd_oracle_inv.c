@@ -473,11 +473,9 @@ void orc_inv_spatial_to_b64a_of_rgb444(PIXEL16 *const bands[4][4], int band_pitc
  * d = rand() & 0x7fff, drawn once per pixel and shared by its three components.  The oracle takes d as an input (0 and 32767 are the ends of the
  * interval every reference byte lies in).  Matrices :10707-10750 by the sample's colour space (1 = 601, 2 = 709, +4 = video range); STRICT_SATURATE is 0
  * (color.h:30), so SATURATE_Y / Cb / Cr are the identity. */
-void orc_inv_spatial_to_rgb24_of_yuv422(PIXEL16 *const bands[3][4], const int band_pitch[3], int luma_w, int h, int precision, int display_height, int color_space,
-                                        int d, uint8_t *out, int out_pitch_bytes)
+/* The conversion alone: `rows` rows of YU64 words (Y0 C1 Y1 C2 per pixel pair, `width` pixels) -> RG24 rows, bottom row first. */
+void orc_yu64_to_rgb24(const uint16_t *yu, int yu_pitch_words, int width, int rows, int color_space, int d, uint8_t *out, int out_pitch_bytes)
 {
-	const int W = 2 * luma_w;
-	uint16_t *yu = (uint16_t *)malloc((size_t)2 * h * W * 2 * sizeof(uint16_t));
 	int y_offset = 16, ymult = 128 * 149, r_vmult = 230, g_vmult = 137, g_umult = 55, b_umult = 135;      /* COLOR_SPACE_CG_709 and the default */
 	int y, x;
 	switch (color_space & 7) {
@@ -486,11 +484,10 @@ void orc_inv_spatial_to_rgb24_of_yuv422(PIXEL16 *const bands[3][4], const int ba
 	case 6: y_offset = 0; ymult = 128 * 128; r_vmult = 197; g_vmult = 118; g_umult = 47; b_umult = 116; break;             /* VS_709 */
 	default: break;
 	}
-	orc_inv_spatial_to_yu64(bands, band_pitch, luma_w, h, precision, yu, W * 2);
-	for (y = 0; y < display_height; y++) {
-		const uint16_t *r = yu + (size_t)y * W * 2;
-		uint8_t *o = out + (size_t)(display_height - 1 - y) * out_pitch_bytes;          /* DECODED_FORMAT_RGB24 is "inverted": bottom row first (decoder.c:23166) */
-		for (x = 0; x < W; x += 2) {
+	for (y = 0; y < rows; y++) {
+		const uint16_t *r = yu + (size_t)y * yu_pitch_words;
+		uint8_t *o = out + (size_t)(rows - 1 - y) * out_pitch_bytes;          /* DECODED_FORMAT_RGB24 is "inverted": bottom row first (decoder.c:23166) */
+		for (x = 0; x < width; x += 2) {
 			const int V = (int)r[2 * x + 1] - 32768, U = (int)r[2 * x + 3] - 32768;
 			int k;
 			for (k = 0; k < 2; k++) {
@@ -502,5 +499,14 @@ void orc_inv_spatial_to_rgb24_of_yuv422(PIXEL16 *const bands[3][4], const int ba
 			}
 		}
 	}
+}
+
+void orc_inv_spatial_to_rgb24_of_yuv422(PIXEL16 *const bands[3][4], const int band_pitch[3], int luma_w, int h, int precision, int display_height, int color_space,
+                                        int d, uint8_t *out, int out_pitch_bytes)
+{
+	const int W = 2 * luma_w;
+	uint16_t *yu = (uint16_t *)malloc((size_t)2 * h * W * 2 * sizeof(uint16_t));
+	orc_inv_spatial_to_yu64(bands, band_pitch, luma_w, h, precision, yu, W * 2);
+	orc_yu64_to_rgb24(yu, W * 2, W, display_height, color_space, d, out, out_pitch_bytes);
 	free(yu);
 }

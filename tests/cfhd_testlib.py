@@ -971,3 +971,22 @@ def oracle_inverse_b64a_of_rgb444(plan, coeffs):
     out = np.zeros((2 * d["height"], 2 * d["width"] * 4), np.uint16)
     O.orc_inv_spatial_to_b64a_of_rgb444((c_i16p * 16)(*(flat + [None] * 4)), d["pitch"], d["width"], d["height"], plan.precision, out.ctypes.data_as(ctypes.c_void_p), out.shape[1])
     return out
+
+
+def oracle_inverse_rgb24_of_yuv422(plan, coeffs, d, color_space=2):
+    """Whole inverse path with the oracle from a dequantized 4:2:2 pyramid to RG24 bytes (bottom row first) with the 15-bit dither value d (0 .. 32767)."""
+    O = oracle()
+    O.orc_inv_spatial_to_rgb24_of_yuv422.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 6 + [ctypes.c_void_p, ctypes.c_int]
+    work = coeffs.copy()
+    for c in range(3):
+        for lv in (2, 1):
+            dsc = plan.band[(c, lv, 0)]
+            bands = (c_i16p * 4)(*[plan.view(work, c, lv, b).ctypes.data_as(c_i16p) for b in range(4)])
+            dst = plan.view(work, c, lv - 1, 0)
+            O.orc_inv_spatial(bands, dsc["pitch"], dsc["width"], dsc["height"], plan.prescale[lv], dst.ctypes.data_as(c_i16p), plan.band[(c, lv - 1, 0)]["pitch"])
+    ptrs = (c_i16p * 12)(*[plan.view(work, c, 0, b).ctypes.data_as(c_i16p) for c in range(3) for b in range(4)])
+    pitches = [plan.band[(c, 0, 0)]["pitch"] for c in range(3)]
+    w = plan.band[(0, 0, 0)]["width"]; h = plan.band[(0, 0, 0)]["height"]
+    out = np.zeros((plan.height, 2 * w * 3), np.uint8)
+    O.orc_inv_spatial_to_rgb24_of_yuv422(ptrs, iarr(pitches), w, h, plan.precision, plan.height, color_space, d, out.ctypes.data_as(ctypes.c_void_p), out.shape[1])
+    return out

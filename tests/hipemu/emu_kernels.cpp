@@ -218,6 +218,13 @@ void emu_inv_packed16(int16_t **bands, int band_pitch, int w, int h, int display
 }
 void emu_inv_packed16_use_strip(int on) { g_inv_packed16_strip = on; }
 
+// YU64 rows -> RG24 (k_yu64_to_rgb24, the second step of decoding 4:2:2 samples to RG24), as DecodeBatch launches it.
+void emu_yu64_to_rgb24(const uint16_t *yu64, int in_pitch_words, int width, int rows, int matrix, uint32_t seed, uint8_t *out, int out_pitch)
+{
+	const int pairs = width / 2;
+	hipemu::launch(dim3((pairs + NTHREADS - 1) / NTHREADS, rows, 1), dim3(NTHREADS), [&] { k_yu64_to_rgb24(yu64, in_pitch_words, 0, out, out_pitch, 0, pairs, rows, matrix, seed); });
+}
+
 // The last level of an RGB 4:4:4 sample to b64a: three planes into words 1..3 of four-word pixels, word 0 = 0xfff0 (InvPlaneJob::alpha_const), as
 // DecodeBatch::prepare sets it up.
 void emu_inv_b64a_of_444(int16_t **bands, int band_pitch, int w, int h, int display_height, uint16_t *out, int out_pitch_words)

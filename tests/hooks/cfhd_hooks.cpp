@@ -168,7 +168,7 @@ int cfhd_amd_decode_bands_host(const uint8_t *sample, size_t size, int pixel_kin
 		const ParsedBand &lp = ps.lowpass[c];
 		const BandDesc &ll = plan.ch[c].band[2][0];
 		if (!lp.present || lp.width != ll.width || lp.height != ll.height) return -22;
-		const int lowpass_offset = apply_lowpass_bias ? lowpass_bias(plan.precision, ll.width, pixel_kind) : 0;
+		const int lowpass_offset = apply_lowpass_bias ? lowpass_bias(plan.precision, ll.width, pixel_kind, c) : 0;
 		for (int r = 0; r < ll.height; r++)
 			for (int x = 0; x < ll.width; x++) {
 				const uint8_t *p = sample + lp.offset + ((size_t)r * ll.width + x) * 2;

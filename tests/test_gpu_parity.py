@@ -468,6 +468,33 @@ def test_v210_encode_bitstream_identical(w, h):
     assert psnr_yuy2(img[:, : (w - w % 48) * 2], as8[:, : (w - w % 48) * 2]) > 40      # (the columns behind the last whole 48 pixels carry the reference's repeated Cr)
 
 
+@pytest.mark.parametrize("w,h,flags", [(320, 240, 0), (336, 256, 4), (720, 480, 0), (1920, 1080, 0)])
+def test_yuv422_decode_to_rg24_lies_in_the_reference_interval(w, h, flags):
+    """4:2:2 samples decoded to RG24 (TestCFHD's RG24 -> YUV 4:2:2 row): the YU64 rows through the reference's scalar colour conversion -- every byte between
+    the oracle's results for the dither values 0 and 32767 (pinned on the reference decoder on the CPU), both ends about equally often; PSNR against the
+    source equal to the reference decoder's to 0.1 dB; odd lowpass widths (336 / 16) take the RGB bias of decoder.c:12500."""
+    frames, pitch = qbist_frames(12, 1, w, h, PIX_RG24)
+    sample = amd_encode_frames(frames, pitch, w, h, PIX_RG24, encoded=ENCODED_YUV422, flags=flags)[0]
+    got, gpitch, aw, ah = amd_decode_sample(sample, PIX_RG24)
+    assert (aw, ah) == (w, h)
+    img = got.reshape(h, gpitch)[:, : w * 3]
+    plan = Plan(w, h, pixkind=PIXKIND["RG24"], enc=1)
+    cs = 1 if flags & 4 else 2
+    co = host_decode_pyramid(sample, plan)
+    lo = oracle_inverse_rgb24_of_yuv422(plan, co, 0, cs); hi = oracle_inverse_rgb24_of_yuv422(plan, co, 32767, cs)
+    ok = (img >= lo) & (img <= hi)
+    assert ok.all(), "%d bytes outside the interval" % (~ok).sum()
+    differ = lo != hi
+    assert 0.45 < (img[differ] == hi[differ]).mean() < 0.55
+    src = np.frombuffer(frames[0].tobytes(), np.uint8).reshape(h, pitch)[:, : w * 3].astype(np.float64)
+    mine_db = 10 * np.log10(255.0 ** 2 / np.mean((img - src) ** 2))
+    for attempt in range(4):
+        dec, dpitch = ref_decode_sample(sample, w, h, PIX_RG24)
+        ref_db = 10 * np.log10(255.0 ** 2 / np.mean((np.frombuffer(dec.tobytes(), np.uint8).reshape(h, dpitch)[:, : w * 3] - src) ** 2))
+        if abs(mine_db - ref_db) < 0.1: break
+    assert abs(mine_db - ref_db) < 0.1, (mine_db, ref_db)
+
+
 @pytest.mark.parametrize("w,h", [(320, 240), (720, 480), (1920, 1080)])
 def test_rgb444_decode_to_b64a_equals_reference_exactly(w, h):
     """RGB 4:4:4 samples decoded to b64a (what TestCFHD's b64a -> RGB 4:4:4 row decodes to): word for word the reference decoder's output -- the RG48 words

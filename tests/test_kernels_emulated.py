@@ -576,6 +576,34 @@ def test_inv_rgb8_last_level_lies_in_oracle_interval(w, h, dh, bpp, bottom_up):
     assert (img == 255).any() and (img == 0).any()
 
 
+@pytest.mark.parametrize("w,rows,matrix,cs", [(16, 3, 0, 2), (130, 7, 2, 1), (338, 5, 1, 6), (64, 4, 3, 5)])
+def test_yu64_to_rgb24_lies_in_oracle_interval(w, rows, matrix, cs):
+    """k_yu64_to_rgb24 (4:2:2 samples decoded to RG24, second step): every byte between the oracle's conversion with dither 0 and with 32767 (the scalar loop
+    of the reference restated, pinned on the reference decoder in test_oracle_vs_ref), both ends about equally often,
+    three bytes never sit at opposite ends unless one of them cannot move), all four matrices, full-range words, bottom row first, nothing beside the picture."""
+    rng = np.random.default_rng(w + rows)
+    yu = rng.integers(0, 65536, size=(rows, 2 * w), dtype=np.int64).astype(np.uint16)
+    yu[0, :8] = 65535; yu[0, 8:16] = 0
+    O = oracle()
+    O.orc_yu64_to_rgb24.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_int]
+    ends = []
+    for d in (0, 32767):
+        o = np.zeros((rows, 3 * w), np.uint8)
+        O.orc_yu64_to_rgb24(yu.ctypes.data_as(ctypes.c_void_p), 2 * w, w, rows, cs, d, o.ctypes.data_as(ctypes.c_void_p), 3 * w)
+        ends.append(o)
+    lo, hi = ends
+    opitch = 3 * w + 5
+    got = np.full((rows, opitch), 7, np.uint8)
+    E = emu()
+    E.emu_yu64_to_rgb24.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_int]
+    E.emu_yu64_to_rgb24(yu.ctypes.data_as(ctypes.c_void_p), 2 * w, w, rows, matrix, 99, got.ctypes.data_as(ctypes.c_void_p), opitch)
+    img = got[:, : 3 * w]
+    assert ((img >= lo) & (img <= hi)).all()
+    differ = lo != hi
+    assert 0.35 < (img[differ] == hi[differ]).mean() < 0.65
+    assert (got[:, 3 * w:] == 7).all() and (img == 255).any() and (img == 0).any()
+
+
 @pytest.mark.parametrize("w,h,dh", [(16, 8, 16), (68, 20, 37), (160, 17, 34), (250, 33, 66)])
 def test_inv_b64a_of_rgb444_last_level_equals_oracle(w, h, dh):
     """RGB 4:4:4 samples decoded to b64a (k_inv_packed16 with three planes in four-word pixels): the oracle model pinned on the reference decoder in

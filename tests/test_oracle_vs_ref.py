@@ -292,6 +292,30 @@ def test_reference_rgba8_decode_of_4444_equals_oracle(w, h, name, seed):
     assert np.abs(want.astype(int) - src.astype(int)).mean() < 3.0
 
 
+@pytest.mark.parametrize("w,h,flags,seed", [(320, 240, 0, 10), (336, 256, 4, 11), (720, 480, 0x100, 12), (1920, 1080, 0, 13), (400, 120, 0x104, 14)])
+def test_reference_rgb24_decode_of_yuv422_lies_in_oracle_interval(w, h, flags, seed):
+    """Pins orc_inv_spatial_to_rgb24_of_yuv422 (restated from convert.c:11392-11448, the only code of ConvertRow16uToDitheredRGB that is compiled in): the
+    reference decodes a 4:2:2 sample to RG24 with a 15-bit rand() dither per pixel -- every byte lies between the oracle's result for d = 0 and for
+    d = 32767, both ends about equally often; the matrix follows the 601 / 709 bit of the sample's colour space tag (flags 4), not its video-range bit."""
+    frames, pitch = qbist_frames(seed, 1, w, h, PIX_RG24)
+    sample = ref_encode_frames(frames, pitch, w, h, PIX_RG24, encoded=ENCODED_YUV422, flags=flags)[0]
+    plan = Plan(w, h, pixkind=PIXKIND["RG24"], enc=1)     # (the output format decides the lowpass bias: odd lowpass widths -- 336 / 16 = 21 for chroma -- take -3 / +1, decoder.c:12500)
+    cs = 1 if flags & 4 else 2                           # (the reference decoder ignores the video-range bit of the sample's tag: probed, PSNR drops to 26 dB)
+    co = host_decode_pyramid(sample, plan)
+    lo = oracle_inverse_rgb24_of_yuv422(plan, co, 0, cs); hi = oracle_inverse_rgb24_of_yuv422(plan, co, 32767, cs)
+    rows = h if h % 8 == 0 else h - 8                   # (bottom row first: the picture's last rows are the first rows of the buffer)
+    for attempt in range(6):                            # see test_reference_rg48_decode_equals_oracle
+        dec, dpitch = ref_decode_sample(sample, w, h, PIX_RG24)
+        img = np.frombuffer(dec.tobytes(), np.uint8).reshape(h, dpitch)[h - rows:, : w * 3]
+        ok = (img >= lo[h - rows:]) & (img <= hi[h - rows:])
+        if ok.all(): break
+    assert ok.all(), "%d bytes outside the interval" % (~ok).sum()
+    differ = (lo != hi)[h - rows:]
+    assert 0.4 < (img[differ] == hi[h - rows:][differ]).mean() < 0.6
+    src = np.frombuffer(frames[0].tobytes(), np.uint8).reshape(h, pitch)[h - rows:, : w * 3].astype(np.float64)
+    assert 10 * np.log10(255.0 ** 2 / np.mean((img - src) ** 2)) > 18.0      # (sanity only: 4:2:2 subsampling of saturated Qbist colours: TestCFHD's "lower PSNR" rows)
+
+
 @pytest.mark.parametrize("w,h,seed", [(320, 240, 10), (336, 256, 11), (400, 120, 14), (720, 480, 12), (64, 64, 15), (1280, 720, 16), (1920, 1080, 13), (144, 96, 17)])
 def test_reference_b64a_decode_of_rgb444_equals_model(w, h, seed):
     """Pins orc_inv_spatial_to_b64a_of_rgb444 (a model fitted by probing: eight geometries, eight pictures, ramps into both clips): the reference decodes an RGB
