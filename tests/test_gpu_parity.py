@@ -219,16 +219,18 @@ def test_reference_harness_links_unchanged_and_prints_same_numbers():
     reference library and once against libcfhd_amd.so (oracle/Makefile `testcfhd`): the `-D` quality test must print the
     same compressed sizes (user metadata included) and the same PSNR to the printed 0.1 dB for the formats we support."""
     import re, subprocess
+    FORMATS = {"YUY2": 10, "2vuy": 10, "YU64": 10, "RG24": 20}
     ours = os.path.join(ORACLE_DIR, "_ref", "TestCFHD_amd"); theirs = os.path.join(ORACLE_DIR, "_ref", "TestCFHD_ref")
     if not (os.path.exists(ours) and os.path.exists(theirs)):
         pytest.fail("harness binaries not built: __graft_entry__.build() runs `make -C oracle testcfhd` where /root/reference exists and they travel with the tree")
     def run(binary):
-        # The harness walks every pixel format at two resolutions; we only need its first two sections (YUY2, 2vuy at full
-        # resolution), so read its output line by line and stop it (by PID) as soon as the third section starts.
+        # The harness walks every pixel format at two resolutions and stops at the first error.  Its first five sections (YUY2, 2vuy, YU64, RG24 -> 4:2:2,
+        # RG24 -> RGB 4:4:4 at full resolution) decode to the row's own pixel format here; the sixth (BGRA from a 4:2:2 sample) does not, so read its
+        # output line by line and stop it (by PID) as soon as that section starts.  (The two RG24 sections print the same header: 20 lines under one key.)
         import time
         # OMP_NUM_THREADS=1: the harness's own frame generator (Example/qbist.cpp:284-310, the antialias pass) updates pixel LSBs in place
         # while neighbouring OpenMP threads read them, so with several threads two runs of the same binary draw slightly different frames
-        proc = subprocess.Popen(["timeout", "150", "stdbuf", "-oL", binary, "-D"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, cwd="/tmp",
+        proc = subprocess.Popen(["timeout", "420", "stdbuf", "-oL", binary, "-D"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, cwd="/tmp",
                                 start_new_session=True, env=dict(os.environ, OMP_NUM_THREADS="1"))
         res = {}; fmt = None; t0 = time.time()
         try:
@@ -236,10 +238,10 @@ def test_reference_harness_links_unchanged_and_prints_same_numbers():
                 m = re.match(r"Pixel format: (\S+)", line)
                 if m:
                     fmt = m.group(1)
-                    if fmt not in ("YUY2", "2vuy"): break
+                    if fmt not in FORMATS: break
                 m = re.match(r"(\d+): source (\d+) compressed to (\d+) in .*PSNR ([0-9.]+)dB", line)
                 if m and fmt: res.setdefault(fmt, []).append((int(m.group(3)), float(m.group(4))))
-                if time.time() - t0 > 120 or (len(res.get("YUY2", [])) >= 10 and len(res.get("2vuy", [])) >= 10): break
+                if time.time() - t0 > 380 or all(len(res.get(f, [])) >= n for f, n in FORMATS.items()): break
         finally:
             try:
                 os.killpg(proc.pid, 9)          # the process group we started (timeout + stdbuf + harness), nothing else
@@ -250,17 +252,20 @@ def test_reference_harness_links_unchanged_and_prints_same_numbers():
     # The reference harness decodes with 16 worker threads (Example/TestCFHD.cpp:345) and its decoder has been seen to damage a frame now and
     # then on the 256-core GPU host (a 17 dB outlier in its own printout): sizes must agree in every run; a PSNR line of the reference that
     # disagrees gets two more runs of the reference, and the frame passes when any of them prints our number.
-    a, refs = run(ours), [run(theirs)]
-    for fmt in ("YUY2", "2vuy"):
-        assert fmt in a and len(a[fmt]) == 10, "our library did not complete the %s run: %r" % (fmt, a.get(fmt))
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(2) as ex:                   # (side by side: most of a run is the harness drawing its Qbist frames on one core)
+        fa, fb = ex.submit(run, ours), ex.submit(run, theirs)
+        a, refs = fa.result(), [fb.result()]
+    for fmt in FORMATS:
+        assert fmt in a and len(a[fmt]) == FORMATS[fmt], "our library did not complete the %s run: %r" % (fmt, a.get(fmt))
     def agree(b):
-        return all(len(b.get(fmt, [])) >= 10 and all(abs(pa - pb) <= 0.1 + 1e-6 for (sa, pa), (sb, pb) in zip(a[fmt], b[fmt][:10])) for fmt in ("YUY2", "2vuy"))
+        return all(len(b.get(fmt, [])) >= FORMATS[fmt] and all(abs(pa - pb) <= 0.1 + 1e-6 for (sa, pa), (sb, pb) in zip(a[fmt], b[fmt][:FORMATS[fmt]])) for fmt in FORMATS)
     while not agree(refs[-1]) and len(refs) < 3:
         refs.append(run(theirs))
-    for fmt in ("YUY2", "2vuy"):
+    for fmt in FORMATS:
         for b in refs:
-            assert len(b.get(fmt, [])) >= 10, "the reference harness did not complete the %s run: %r" % (fmt, b.get(fmt))
-            for (sa, pa), (sb, pb) in zip(a[fmt], b[fmt][:10]):
+            assert len(b.get(fmt, [])) >= FORMATS[fmt], "the reference harness did not complete the %s run: %r" % (fmt, b.get(fmt))
+            for (sa, pa), (sb, pb) in zip(a[fmt], b[fmt][:FORMATS[fmt]]):
                 assert sa == sb, "%s compressed size %d vs reference %d\nours %r\nreference %r" % (fmt, sa, sb, a, b)
         for k, (sa, pa) in enumerate(a[fmt]):
             theirs_db = [b[fmt][k][1] for b in refs]
