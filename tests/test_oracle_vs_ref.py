@@ -151,7 +151,8 @@ def test_reference_rg48_decode_equals_oracle(w, h):
     assert np.array_equal(mine, img)
 
 
-@pytest.mark.parametrize("w,h,src", [(192, 96, "yuy2"), (320, 240, "yuy2"), (336, 252, "yu64"), (720, 486, "yuy2"), (1920, 1080, "yu64")])
+@pytest.mark.parametrize("w,h,src", [(192, 96, "yuy2"), (320, 240, "yuy2"), (336, 252, "yu64"), (720, 486, "yuy2"), (1920, 1080, "yu64"), (400, 122, "yu64"), (1280, 720, "yuy2"), (144, 90, "yu64"),
+                                     (2048, 858, "yuy2")])
 def test_reference_yu64_decode_equals_oracle(w, h, src):
     """Pins orc_inv_spatial_to_yu64: the reference decodes a 4:2:2 sample to YU64 (16-bit words Y0 C1 Y1 C2) through its 10-bit row
     routines (wavelet.c:5403) -- deterministic, no dither; the top and bottom band rows take the ordinary horizontal pass, the rows between
@@ -175,7 +176,7 @@ def test_reference_yu64_decode_equals_oracle(w, h, src):
     assert len(bad) == 0, (len(bad), bad[:8].tolist(), [(int(mine[r, c]), int(img[r, c])) for r, c in bad[:8]])
 
 
-@pytest.mark.parametrize("w,h,src", [(192, 96, "yuy2"), (336, 252, "yu64"), (720, 480, "yuy2"), (1920, 1080, "yu64")])
+@pytest.mark.parametrize("w,h,src", [(192, 96, "yuy2"), (336, 252, "yu64"), (720, 480, "yuy2"), (1920, 1080, "yu64"), (480, 122, "yu64"), (1344, 756, "yuy2"), (144, 90, "yu64"), (288, 162, "yuy2")])
 def test_reference_v210_decode_equals_oracle(w, h, src):
     """Pins orc_inv_spatial_to_v210 (groundwork: the product does not offer v210 output yet): the reference decodes a 4:2:2 sample to v210 as
     the YU64 words >> 6 packed three to a 32-bit word, Cb from channel 2, Cr from channel 1 -- word for word on widths that are multiples of 6,
@@ -212,7 +213,8 @@ def test_reference_v210_decode_equals_oracle(w, h, src):
     assert np.array_equal(mine[:h], img), "%d words differ" % (mine[:h] != img).sum()
 
 
-@pytest.mark.parametrize("w,h,name,ramps", [(192, 96, "AR10", 0), (320, 240, "r210", 1), (336, 252, "DPX0", 1), (720, 486, "AB10", 1), (1920, 1080, "r210", 0)])
+@pytest.mark.parametrize("w,h,name,ramps", [(192, 96, "AR10", 0), (320, 240, "r210", 1), (336, 252, "DPX0", 1), (720, 486, "AB10", 1), (1920, 1080, "r210", 0), (400, 122, "DPX0", 1), (1280, 720, "AB10", 0),
+                                            (144, 90, "AR10", 1)])
 def test_reference_rgb10_decode_equals_oracle(w, h, name, ramps):
     """Pins orc_inv_spatial_to_rgb10: the reference decodes RGB 4:4:4 samples to the 10-bit RGB words deterministically -- every component the
     last-level reconstruction before its final >> 1, + 3, >> 3, clamped to 10 bits (a model fitted by probing, not read off the source) --
@@ -239,7 +241,7 @@ def test_reference_rgb10_decode_equals_oracle(w, h, name, ramps):
         assert (comp == 1023).any() and (comp == 0).any()
 
 
-@pytest.mark.parametrize("w,h,name", [(192, 96, "BGRa"), (320, 240, "RG24"), (336, 252, "BGRA"), (1920, 1080, "BGRA")])
+@pytest.mark.parametrize("w,h,name", [(192, 96, "BGRa"), (320, 240, "RG24"), (336, 252, "BGRA"), (1920, 1080, "BGRA"), (400, 122, "RG24"), (720, 486, "BGRa"), (1280, 720, "RG24"), (144, 90, "BGRA")])
 def test_reference_rgb8_decode_lies_in_oracle_dither_interval(w, h, name):
     """Pins orc_inv_spatial_to_rgb8: the reference decodes RGB 4:4:4 samples to RG24 / BGRA (bottom row first) / BGRa with a random four-bit
     dither per component; every byte lies between the oracle's reconstruction with r = 0 and with r = 15, both ends occur, and the share of
