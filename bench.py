@@ -161,8 +161,13 @@ def c_abi_rates(frames, pitch, W, H, seconds=1.5, registered=False, decoders=8, 
         env = dict(os.environ)
         if all_devices:                                  # no pin: the pool's workers and the decoder handles spread over every GPU the process sees
             env.pop("CFHD_AMD_DEVICE", None); env.pop("LOCAL_RANK", None)
-        out = subprocess.run([tool, str(W), str(H), f.name, str(len(frames)), str(seconds), "1" if registered else "0", str(decoders), str(workers)],
-                             capture_output=True, text=True, timeout=300, env=env)
+        else:                                            # one GPU, whatever the node has (an unpinned process deals its workers to all of them: INTEGRATION.md section 5)
+            env.setdefault("CFHD_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0"))
+        try:
+            out = subprocess.run([tool, str(W), str(H), f.name, str(len(frames)), str(seconds), "1" if registered else "0", str(decoders), str(workers)],
+                                 capture_output=True, text=True, timeout=300, env=env)
+        except subprocess.TimeoutExpired:
+            return {"error": "tools/_build/cabi_bench did not finish within 300 s"}
     if out.returncode != 0:
         return {"error": (out.stderr or out.stdout).strip()[-300:]}
     return json.loads(out.stdout.strip().splitlines()[-1])
@@ -441,7 +446,10 @@ def main():
                                            "buffers_registered_by_the_caller_16_threads": c_abi_rates(frames[:8], pitch, W, H, registered=True, decoders=16, workers=16)}
             ngpu = torch.cuda.device_count()
             if ngpu > 1:                                 # host-fed, one process, every GPU of the node: pool workers and decoder handles dealt round robin (strong scaling of the C ABI)
-                line["config"]["c_abi_fps"]["one_process_all_%d_gpus_plain_buffers" % ngpu] = c_abi_rates(frames[:8], pitch, W, H, decoders=4 * ngpu, workers=4 * ngpu, all_devices=True)
+                try:                                     # (first run on a multi-GPU node is the driver's: a failure here is reported, it does not take the line with it)
+                    line["config"]["c_abi_fps"]["one_process_all_%d_gpus_plain_buffers" % ngpu] = c_abi_rates(frames[:8], pitch, W, H, decoders=4 * ngpu, workers=4 * ngpu, all_devices=True)
+                except (Exception, SystemExit) as e:
+                    line["config"]["c_abi_fps"]["one_process_all_%d_gpus_plain_buffers" % ngpu] = {"error": str(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             fmt = getattr(T, "PIX_" + wl["fmt"].upper())
             line["cpu_baseline"] = cpu_baseline(frames[:8], pitch, W, H, fmt=fmt, enc=wl["enc"], flags=wl["flags"], decode=wl["mode"] == 0, bpp=wl["bpp"], label=wl["fmt"])
