@@ -35,7 +35,8 @@ enum {
 #define FOURCC_BE(a, b, c, d) (((uint32_t)(a) << 24) | ((uint32_t)(b) << 16) | ((uint32_t)(c) << 8) | (uint32_t)(d))
 static const uint32_t FMT_YUY2 = FOURCC_BE('Y', 'U', 'Y', '2'), FMT_2VUY = FOURCC_BE('2', 'v', 'u', 'y'), FMT_YUYV = FOURCC_BE('y', 'u', 'y', 'v'),
                       FMT_RG48 = FOURCC_BE('R', 'G', '4', '8'), FMT_B64A = FOURCC_BE('b', '6', '4', 'a'), FMT_BYR4 = FOURCC_BE('B', 'Y', 'R', '4'), FMT_YU64 = FOURCC_BE('Y', 'U', '6', '4'), FMT_V210 = FOURCC_BE('v', '2', '1', '0'), FMT_RG24 = FOURCC_BE('R', 'G', '2', '4'), FMT_BGRA = FOURCC_BE('B', 'G', 'R', 'A'), FMT_BGRa = FOURCC_BE('B', 'G', 'R', 'a'),
-                      FMT_R210 = FOURCC_BE('r', '2', '1', '0'), FMT_DPX0 = FOURCC_BE('D', 'P', 'X', '0'), FMT_AB10 = FOURCC_BE('A', 'B', '1', '0'), FMT_AR10 = FOURCC_BE('A', 'R', '1', '0');
+                      FMT_R210 = FOURCC_BE('r', '2', '1', '0'), FMT_DPX0 = FOURCC_BE('D', 'P', 'X', '0'), FMT_AB10 = FOURCC_BE('A', 'B', '1', '0'), FMT_AR10 = FOURCC_BE('A', 'R', '1', '0'),
+                      FMT_RG30 = FOURCC_BE('R', 'G', '3', '0'), FMT_BYR5 = FOURCC_BE('B', 'Y', 'R', '5');      // (AJA's name for the AB10 word layout: same pixels, its own colour format code in the sample header)
 
 namespace {
 
@@ -46,6 +47,7 @@ int pixel_kind_of(uint32_t fmt)
 	if (fmt == FMT_RG48) return PIX_RG48;
 	if (fmt == FMT_B64A) return PIX_B64A;
 	if (fmt == FMT_BYR4) return PIX_BYR4;
+	if (fmt == FMT_BYR5) return PIX_BYR5;
 	if (fmt == FMT_YU64) return PIX_YU64;
 	if (fmt == FMT_V210) return PIX_V210;
 	if (fmt == FMT_RG24) return PIX_RG24;
@@ -53,12 +55,12 @@ int pixel_kind_of(uint32_t fmt)
 	if (fmt == FMT_BGRa) return PIX_BGRa;
 	if (fmt == FMT_R210) return PIX_R210;
 	if (fmt == FMT_DPX0) return PIX_DPX0;
-	if (fmt == FMT_AB10) return PIX_AB10;
+	if (fmt == FMT_AB10 || fmt == FMT_RG30) return PIX_AB10;
 	if (fmt == FMT_AR10) return PIX_AR10;
 	return PIX_NONE;
 }
 // COLOR_FORMAT_UYVY = 1 / COLOR_FORMAT_YUYV = 2 / COLOR_FORMAT_BGRA64 (b64a) = 30 / COLOR_FORMAT_RG48 = 120 (Codec/color.h)
-int color_format_of(int kind) { return kind == PIX_2VUY ? 1 : (kind == PIX_RG48 ? 120 : (kind == PIX_B64A ? 30 : (kind == PIX_BYR4 ? 104 : (kind == PIX_YU64 ? 12 : (kind == PIX_V210 ? 10 : (kind == PIX_RG24 ? 7 : (kind == PIX_BGRA ? 32 : (kind == PIX_BGRa ? 9 : (kind == PIX_R210 ? 123 : (kind == PIX_DPX0 ? 128 : (kind == PIX_AB10 ? 125 : (kind == PIX_AR10 ? 124 : 2)))))))))))); }   // COLOR_FORMAT_* of Codec/color.h
+int color_format_of(int kind) { return kind == PIX_2VUY ? 1 : (kind == PIX_RG48 ? 120 : (kind == PIX_B64A ? 30 : (kind == PIX_BYR4 ? 104 : (kind == PIX_BYR5 ? 105 : (kind == PIX_YU64 ? 12 : (kind == PIX_V210 ? 10 : (kind == PIX_RG24 ? 7 : (kind == PIX_BGRA ? 32 : (kind == PIX_BGRa ? 9 : (kind == PIX_R210 ? 123 : (kind == PIX_DPX0 ? 128 : (kind == PIX_AB10 ? 125 : (kind == PIX_AR10 ? 124 : 2))))))))))))); }   // COLOR_FORMAT_* of Codec/color.h
 int pixel_bytes_of(int kind) { return kind == PIX_RG24 ? 3 : (kind == PIX_BGRA || kind == PIX_BGRa || (kind >= PIX_R210 && kind <= PIX_AR10)) ? 4 : kind == PIX_RG48 ? 6 : (kind == PIX_B64A ? 8 : (kind == PIX_YU64 || kind == PIX_V210 ? 4 : 2)); }
 
 // ---- metadata handle shared by the encoder-side API (CSampleEncodeMetadata) ----
@@ -119,7 +121,7 @@ int make_params(EncodeParams &p, int w, int h, uint32_t fmt, int encoded, uint32
 	const bool deep_rgb_as_422 = ((kind == PIX_RG48 || kind == PIX_B64A) && encoded == 0) || rgb8_as_422;
 	// BGRA / BGRa encoded as RGBA 4:4:4:4 (frame.c:6415 ConvertRGBAtoRGBA64): the alpha byte joins as the fourth plane, curved as b64a's
 	const bool rgba8_as_4444 = (kind == PIX_BGRA || kind == PIX_BGRa) && encoded == 2;
-	if (!deep_rgb_as_422 && !rgba8_as_4444 && !(kind == PIX_B64A && encoded == 1) && encoded != (kind == PIX_RG48 || rgb8 || rgb10 ? 1 : (kind == PIX_B64A ? 2 : (kind == PIX_BYR4 ? 3 : 0)))) return ERR_BADFORMAT;
+	if (!deep_rgb_as_422 && !rgba8_as_4444 && !(kind == PIX_B64A && encoded == 1) && encoded != (kind == PIX_RG48 || rgb8 || rgb10 ? 1 : (kind == PIX_B64A ? 2 : (kind == PIX_BYR4 || kind == PIX_BYR5 ? 3 : 0)))) return ERR_BADFORMAT;
 	// CFHD_ENCODING_FLAGS_YUV_INTERLACED: field-based level 1 (encoder.c:2093), built for the packed 4:2:2 formats
 	const bool interlaced = (flags & (1u << 0)) != 0;
 	if (interlaced && !(kind == PIX_YUY2 || kind == PIX_2VUY)) return ERR_BADFORMAT;
@@ -127,7 +129,7 @@ int make_params(EncodeParams &p, int w, int h, uint32_t fmt, int encoded, uint32
 	// Progressive frames, qualities whose tables do not follow the size of the previous group.
 	const bool gop = (flags & (1u << 1)) != 0;
 	if (gop && (interlaced || !(kind == PIX_YUY2 || kind == PIX_2VUY))) return ERR_BADFORMAT;
-	const int enc = kind == PIX_BYR4 ? ENC_BAYER : ((kind == PIX_B64A && encoded == 2) || rgba8_as_4444 ? ENC_RGBA4444 : (rgb && !deep_rgb_as_422 ? ENC_RGB444 : ENC_YUV422));
+	const int enc = kind == PIX_BYR4 || kind == PIX_BYR5 ? ENC_BAYER : ((kind == PIX_B64A && encoded == 2) || rgba8_as_4444 ? ENC_RGBA4444 : (rgb && !deep_rgb_as_422 ? ENC_RGB444 : ENC_YUV422));
 	// an encoded format other than the default of the input format marks the quality word (SampleEncoder.cpp:216-219; QUALITY_H 0x0800 in the header)
 	if (deep_rgb_as_422 && !rgb8_as_422) quality |= 0x08000000;
 	// b64a's default encoded format is RGB 4:4:4; asking for 4:4:4:4 marks the quality word (SampleEncoder.cpp:250-257), which the
@@ -139,7 +141,7 @@ int make_params(EncodeParams &p, int w, int h, uint32_t fmt, int encoded, uint32
 	p.width = w; p.height = h; p.pixel_format = fmt; p.pixel_kind = kind; p.encoded_format = enc; p.flags = flags;
 	p.quality = quality; p.progressive = !interlaced;
 	const int yuv601 = (flags & (1u << 2)) ? 1 : 2, vsrgb = (flags & (1u << 8)) ? 2 : 1;   // SampleEncoder.cpp:210-212
-	p.color_space = ((rgb && !deep_rgb_as_422) || kind == PIX_BYR4) ? 0 : ((yuv601 == 1 ? 1 : 2) | (vsrgb == 2 ? 4 : 0));           // RGB 4:4:4 samples carry no colour space tag
+	p.color_space = ((rgb && !deep_rgb_as_422) || kind == PIX_BYR4 || kind == PIX_BYR5) ? 0 : ((yuv601 == 1 ? 1 : 2) | (vsrgb == 2 ? 4 : 0));           // RGB 4:4:4 samples carry no colour space tag
 	if (!build_frame_plan(&p.plan, w, h, kind, enc)) return ERR_BADFORMAT;
 	p.plan.color_matrix = (p.color_space & 4 ? 1 : 0) + ((p.color_space & 3) == 1 ? 2 : 0);
 	p.plan.interlaced = interlaced;
@@ -170,7 +172,7 @@ int encode_one(EncodeBatch &batch, EncodeParams &p, const void *frame, int pitch
 {
 	int rc;
 	meta_remove_hidden(global); meta_remove_hidden(local);
-	SampleHeaderInfo hdr = { frame_number, color_format_of(p.pixel_kind), p.color_space, p.quality, p.progressive,
+	SampleHeaderInfo hdr = { frame_number, p.pixel_format == FMT_RG30 ? 122 /* COLOR_FORMAT_RG30 */ : color_format_of(p.pixel_kind), p.color_space, p.quality, p.progressive,
 	                         global.data(), global.size(), local.data(), local.size() };
 	{
 		// The one metadata override that changes the sample syntax for 2-D clips (Codec/encoder.c:9043-9046 UpdateEncoderOverrides):
@@ -377,7 +379,7 @@ int encode_one_gathered(EncodeBatch &own, EncodeParams &p, const void *frame, in
 			}
 			MetaBlock g2 = global, l2 = local;
 			meta_remove_hidden(g2); meta_remove_hidden(l2);
-			SampleHeaderInfo hdr = { frame_number, color_format_of(p.pixel_kind), p.color_space, p.quality, p.progressive, g2.data(), g2.size(), l2.data(), l2.size() };
+			SampleHeaderInfo hdr = { frame_number, p.pixel_format == FMT_RG30 ? 122 : color_format_of(p.pixel_kind), p.color_space, p.quality, p.progressive, g2.data(), g2.size(), l2.data(), l2.size() };
 			uint32_t sz; unsigned char ty;
 			const uint32_t VCHN = CFHD_FOURCC('V', 'C', 'H', 'N');
 			const bool vchn = meta_find(g2.data(), g2.size(), VCHN, &sz, &ty) || meta_find(l2.data(), l2.size(), VCHN, &sz, &ty);       // rare syntax switch: encode_one knows it
@@ -563,7 +565,7 @@ int front_end_params(int width, int height, uint32_t pixel_format, int encoded_f
 	const int rc = make_params(p, width, height, pixel_format, encoded_format, encoding_flags, quality);
 	if (rc) return rc;
 	out->pixel_kind = p.pixel_kind; out->encoded_format = p.encoded_format; out->pixel_bytes = pixel_bytes_of(p.pixel_kind);
-	out->color_format = color_format_of(p.pixel_kind); out->color_space = p.color_space; out->quality = p.quality; out->progressive = p.progressive;
+	out->color_format = p.pixel_format == FMT_RG30 ? 122 : color_format_of(p.pixel_kind); out->color_space = p.color_space; out->quality = p.quality; out->progressive = p.progressive;
 	out->plan = p.plan; out->static_quantizer = quantizer_is_static(p);
 	return 0;
 }
@@ -595,7 +597,7 @@ CFHD_Error CFHD_OpenEncoder(CFHD_EncoderRef *out, CFHD_ALLOCATOR *)
 CFHD_Error CFHD_GetInputFormats(CFHD_EncoderRef ref, CFHD_PixelFormat *arr, int len, int *count)
 {
 	if (!ref || !arr) return ERR_INVALID_ARGUMENT;
-	const uint32_t fmts[] = { FMT_YUY2, FMT_2VUY, FMT_RG48, FMT_B64A, FMT_BYR4, FMT_YU64, FMT_V210, FMT_RG24, FMT_BGRA, FMT_BGRa, FMT_R210, FMT_DPX0, FMT_AB10, FMT_AR10 };
+	const uint32_t fmts[] = { FMT_YUY2, FMT_2VUY, FMT_RG48, FMT_B64A, FMT_BYR4, FMT_YU64, FMT_V210, FMT_RG24, FMT_BGRA, FMT_BGRa, FMT_R210, FMT_DPX0, FMT_AB10, FMT_AR10, FMT_RG30, FMT_BYR5 };
 	int n = 0;
 	for (; n < (int)(sizeof(fmts) / sizeof(fmts[0])) && n < len; n++) arr[n] = fmts[n];
 	if (count) *count = n;
@@ -922,10 +924,11 @@ CFHD_Error CFHD_GetOutputFormats(CFHD_DecoderRef ref, void *sample, size_t size,
 	if (!ref || !arr) return ERR_INVALID_ARGUMENT;
 	ParsedSample ps;
 	const bool known = sample && parse_sample((const uint8_t *)sample, size, &ps) >= 0;
-	uint32_t fmts[13]; int total = 0;
-	if (!known || ps.encoded_format == ENC_YUV422) { fmts[total++] = FMT_YUY2; fmts[total++] = FMT_2VUY; fmts[total++] = FMT_YU64; fmts[total++] = FMT_V210; }
-	if (!known || ps.encoded_format == ENC_RGB444) { fmts[total++] = FMT_RG48; fmts[total++] = FMT_RG24; fmts[total++] = FMT_BGRA; fmts[total++] = FMT_BGRa; fmts[total++] = FMT_R210; fmts[total++] = FMT_DPX0; fmts[total++] = FMT_AB10; fmts[total++] = FMT_AR10; }
-	if (!known || ps.encoded_format == ENC_RGBA4444) fmts[total++] = FMT_B64A;
+	uint32_t fmts[32]; int total = 0;
+	auto add = [&](uint32_t f) { for (int i = 0; i < total; i++) if (fmts[i] == f) return; fmts[total++] = f; };      // (without a sample: every format once)
+	if (!known || ps.encoded_format == ENC_YUV422) { add(FMT_YUY2); add(FMT_2VUY); add(FMT_YU64); add(FMT_V210); add(FMT_RG24); }
+	if (!known || ps.encoded_format == ENC_RGB444) { add(FMT_RG48); add(FMT_RG24); add(FMT_BGRA); add(FMT_BGRa); add(FMT_R210); add(FMT_DPX0); add(FMT_AB10); add(FMT_AR10); add(FMT_RG30); add(FMT_B64A); }
+	if (!known || ps.encoded_format == ENC_RGBA4444) { add(FMT_B64A); add(FMT_BGRA); add(FMT_BGRa); }
 	int n = 0;
 	for (; n < total && n < len; n++) arr[n] = fmts[n];
 	if (count) *count = n;
@@ -1012,7 +1015,7 @@ CFHD_Error CFHD_PrepareToDecode(CFHD_DecoderRef ref, int, int, CFHD_PixelFormat 
 	if (rgb10 && (encf != ENC_RGB444 || half || d->header.width < 32)) return ERR_BADFORMAT;
 	// ... and 4:2:2 samples to v210 (the YU64 words >> 6, three to a 32-bit word: DecodeBatch / k_yu64_to_v210; widths of whole six-pixel groups)
 	if (kind == PIX_V210 && (encf != ENC_YUV422 || half || d->header.width % 6 || d->header.width < 128)) return ERR_BADFORMAT;
-	if (kind == PIX_BYR4 || (kind >= PIX_R210 && kind <= PIX_AR10 && !rgb10)) return ERR_BADFORMAT;     // encoder inputs only
+	if (kind == PIX_BYR4 || kind == PIX_BYR5 || (kind >= PIX_R210 && kind <= PIX_AR10 && !rgb10)) return ERR_BADFORMAT;     // encoder inputs only
 	// ... and RGB 4:4:4 samples to b64a (the RG48 words behind a constant alpha word 0xfff0, full resolution: what TestCFHD's b64a -> RGB 4:4:4 row decodes to)
 	const bool b64a_of_444 = kind == PIX_B64A && encf == ENC_RGB444 && !half;
 	if ((encf == ENC_RGB444) != (kind == PIX_RG48 || (rgb8 && !rgba8 && !rgb24_of_422) || rgb10 || b64a_of_444) || (encf == ENC_RGBA4444) != ((kind == PIX_B64A && !b64a_of_444) || rgba8)) return ERR_BADFORMAT;

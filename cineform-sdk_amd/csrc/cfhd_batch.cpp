@@ -77,7 +77,7 @@ cfhd_amd_batch *cfhd_amd_batch_create_ex(int width, int height, uint32_t pixel_f
 	b->color_format = fp.color_format; b->color_space = fp.color_space; b->progressive = fp.progressive;
 	b->decode = mode == 0;
 	b->plan = fp.plan;
-	if (b->decode && kind == PIX_BYR4) { delete b; return nullptr; }
+	if (b->decode && (kind == PIX_BYR4 || kind == PIX_BYR5)) { delete b; return nullptr; }
 	const char *e = getenv("CFHD_AMD_ENTROPY");
 	b->gpu_entropy = !(e && strcmp(e, "host") == 0);
 	if (!b->gpu_entropy && (!yuv || !b->progressive || !b->decode)) { delete b; return nullptr; }      // the host-entropy arrangement is kept for the headline workload only

@@ -193,6 +193,7 @@ int packed_frame_pitch(int pixel_kind, int width)
 	case PIX_RG48: return width * 6;
 	case PIX_B64A: return width * 8;
 	case PIX_BYR4: return width * 2;
+	case PIX_BYR5: return width * 3;       // per row PAIR of the mosaic: 4 x width / 2 samples of 12 bits (the unit the frame is laid out in)
 	case PIX_YU64: return width * 4;
 	case PIX_RG24: return width * 3;
 	case PIX_BGRA: case PIX_BGRa: case PIX_R210: case PIX_DPX0: case PIX_AB10: case PIX_AR10: return width * 4;
@@ -234,7 +235,7 @@ int EncodeBatch::prepare(const FramePlan &plan, int nframes, bool own_input)
 	if (rc) return rc;
 	release();
 	device_ = device_current(); (void)hipSetDevice(device_);      // (release() went to the device of the buffers it freed)
-	const bool bayer = plan.pixel_kind == PIX_BYR4;
+	const bool bayer = plan.pixel_kind == PIX_BYR4 || plan.pixel_kind == PIX_BYR5;
 	if (plan.pixel_kind != PIX_YUY2 && plan.pixel_kind != PIX_2VUY && !enc_packed16(plan.pixel_kind) && !bayer) { g_err = "pixel format not supported by the GPU path yet"; return -2; }
 	plan_ = plan; n_ = nframes; own_input_ = own_input;
 	HIPCHK(hipStreamCreateWithFlags((hipStream_t *)&stream_, hipStreamNonBlocking));
@@ -243,7 +244,7 @@ int EncodeBatch::prepare(const FramePlan &plan, int nframes, bool own_input)
 	for (int k = 0; k < 2; k++) HIPCHK(hipEventCreate((hipEvent_t *)&evl_[k]));
 	// Bayer: the plan describes the component planes (half the mosaic in both directions)
 	in_pitch_ = packed_frame_pitch(plan.pixel_kind, bayer ? 2 * plan.width : plan.width);
-	in_rows_ = bayer ? 2 * plan.display_height : plan.display_height;
+	in_rows_ = plan.pixel_kind == PIX_BYR4 ? 2 * plan.display_height : plan.display_height;      // (BYR5: one packed row per row pair)
 	frame_bytes_ = (size_t)in_pitch_ * in_rows_;
 	if (bayer) {
 		plane_elems_ = (size_t)plan.ch[0].band[0][0].pitch * 2 * plan.height;           // plane pitch = 2 x the level-1 band pitch (multiple of 16)
@@ -275,7 +276,7 @@ void EncodeBatch::fill_jobs()
 {
 	const FramePlan &plan = plan_;
 	const bool own_input = own_input_;
-	const bool bayer = plan.pixel_kind == PIX_BYR4;
+	const bool bayer = plan.pixel_kind == PIX_BYR4 || plan.pixel_kind == PIX_BYR5;
 	const int nch = plan.num_channels, mpq = plan.midpoint_prequant;
 	EncJobs j = enc_jobs_at(h_jobs_, n_, nch);
 	for (int i = 0; i < n_; i++) {
@@ -296,7 +297,7 @@ void EncodeBatch::fill_jobs()
 			dev::BayerJob &bj = j.bayer[i];
 			bj.in = own_input ? (const uint16_t *)(d_in_ + frame_bytes_ * i) : nullptr; bj.in_pitch = in_pitch_ / 2;
 			bj.width = plan.width; bj.height = plan.height; bj.display_height = plan.display_height;
-			bj.out_pitch = ppitch; bj.curve = d_curve_; bj.order = 0; bj.precision = plan.precision;
+			bj.out_pitch = ppitch; bj.curve = d_curve_; bj.order = 0; bj.precision = plan.precision; bj.packed12 = plan.pixel_kind == PIX_BYR5;
 			for (int c = 0; c < 4; c++) {
 				bj.out[c] = d_planes_ + ((size_t)i * 4 + c) * plane_elems_;
 				dev::FwdPlaneJob &p = j.l1[(size_t)i * nch + c];
@@ -356,7 +357,7 @@ int EncodeBatch::update_quant(const FramePlan &plan)
 	fill_jobs();
 	if (!own_input_) for (int i = 0; i < n_; i++) {
 		j.yuv[i].in = (const uint8_t *)keep_yuv[i]; j.yuv[i].in_pitch = keep_pitch[i];
-		if (plan_.pixel_kind == PIX_BYR4) { j.bayer[i].in = (const uint16_t *)keep_bayer[i]; j.bayer[i].in_pitch = keep_bpitch[i]; }
+		if (plan_.pixel_kind == PIX_BYR4 || plan_.pixel_kind == PIX_BYR5) { j.bayer[i].in = (const uint16_t *)keep_bayer[i]; j.bayer[i].in_pitch = keep_bpitch[i]; }
 		if (enc_packed16(plan_.pixel_kind)) for (int c = 0; c < plan_.num_channels; c++) { j.l1[(size_t)i * plan_.num_channels + c].in = (const int16_t *)keep_l1[(size_t)i * plan_.num_channels + c]; j.l1[(size_t)i * plan_.num_channels + c].in_pitch = keep_l1pitch[(size_t)i * plan_.num_channels + c]; }
 	}
 	if (ent_ready_) ent_.set_plan(plan);
@@ -391,6 +392,7 @@ int EncodeBatch::upload_frame(int i, const void *frame, int pitch)
 		if (pitch < 0) src += (ptrdiff_t)(plan_.display_height - 1) * 2 * pitch;
 		pitch = in_pitch_;
 	}
+	if (plan_.pixel_kind == PIX_BYR5) pitch = in_pitch_;      // frame.c:5515 walks the frame as tightly packed row pairs of width * 4 * 3 / 2 bytes, whatever the pitch
 	if (pitch < 0) { src += (ptrdiff_t)(in_rows_ - 1) * pitch; pitch = -pitch; }     // encoder.c:1957
 	if (pitch >= in_pitch_ && host_buffer_is_registered(src, (size_t)pitch * (in_rows_ - 1) + in_pitch_)) {
 		// a buffer the caller registered: DMA straight out of it (the frame is borrowed until the encode completes, as in the reference)
@@ -408,7 +410,7 @@ int EncodeBatch::set_device_frame(int i, const void *d_frame, int pitch)
 {
 	if (i < 0 || i >= n_) return -1;
 	EncJobs j = enc_jobs_at(h_jobs_, n_, plan_.num_channels);
-	if (plan_.pixel_kind == PIX_BYR4) { j.bayer[i].in = (const uint16_t *)d_frame; j.bayer[i].in_pitch = pitch / 2; jobs_dirty_ = true; return 0; }
+	if (plan_.pixel_kind == PIX_BYR4 || plan_.pixel_kind == PIX_BYR5) { j.bayer[i].in = (const uint16_t *)d_frame; j.bayer[i].in_pitch = pitch / 2; jobs_dirty_ = true; return 0; }
 	if (enc_packed16(plan_.pixel_kind)) {
 		for (int c = 0; c < plan_.num_channels; c++) {
 			dev::FwdPlaneJob &p = j.l1[(size_t)i * plan_.num_channels + c];
@@ -493,7 +495,7 @@ const char *EncodeBatch::level_kernel(int level) const
 {
 	const int act = active_ > 0 && active_ < n_ ? active_ : n_;
 	if (level > 0) return planes_as_strips(plan_, level, act) ? "k_fwd_plane_strip" : "k_fwd_plane";
-	if (plan_.pixel_kind == PIX_BYR4) return "k_unpack_byr4+k_fwd_plane";
+	if (plan_.pixel_kind == PIX_BYR4 || plan_.pixel_kind == PIX_BYR5) return "k_unpack_byr4+k_fwd_plane";
 	if (strip_forward_packed16()) return "k_fwd_packed16_strip";
 	if (enc_packed16(plan_.pixel_kind)) return "k_fwd_packed16";
 	if (plan_.interlaced) return "k_fwd_frame_yuv422";
@@ -512,7 +514,7 @@ int EncodeBatch::launch_forward()
 	(void)hipGetLastError();                            // drop stale sticky errors: the check below is for these launches only
 	timed_ = true;
 	HIPCHK(hipEventRecord((hipEvent_t)ev0_, st));
-	if (plan_.pixel_kind == PIX_BYR4) {
+	if (plan_.pixel_kind == PIX_BYR4 || plan_.pixel_kind == PIX_BYR5) {
 		dev::k_unpack_byr4<<<dim3((plan_.width + dev::NTHREADS - 1) / dev::NTHREADS, plan_.height, act), dev::NTHREADS, 0, st>>>(j.bayer);
 		dim3 grid((plan_.width / 2 + dev::TW - 1) / dev::TW, (plan_.height / 2 + dev::TH - 1) / dev::TH, act * nch);
 		dev::k_fwd_plane<<<grid, dev::NTHREADS, 0, st>>>(j.l1);

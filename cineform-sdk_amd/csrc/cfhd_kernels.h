@@ -172,6 +172,9 @@ struct BayerJob {                           // k_unpack_byr4: 16-bit Bayer mosai
 	const uint16_t *curve;                  // encode curve over 14-bit linear input (log 90 by default)
 	int order;                              // BAYER_FORMAT_*: 0 R G / G B, 1 G R / B G, 2 G B / R G, 3 B G / G R (CFHDMetadataTags.h:72-75)
 	int precision;
+	// BYR5 (frame.c:5473 ConvertBYR5ToFrame16s): `in` is a byte stream; per row pair 4 x width samples of 12 bits -- first their high bytes as four runs of `width`
+	// (for order 0: R, G1, G2, B), then their low nibbles, two to a byte (the even sample's in the low half) -- and no curve: the values are used as they are
+	int packed12;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -2150,9 +2153,18 @@ __global__ void __launch_bounds__(NTHREADS) k_unpack_byr4(const BayerJob *jobs)
 	const int x = blockIdx.x * NTHREADS + threadIdx.x, row = blockIdx.y;
 	if (x >= job.width || row >= job.height) return;
 	const int srow = row < job.display_height ? row : job.display_height - 1;
-	const uint16_t *l1 = job.in + (size_t)(2 * srow) * job.in_pitch, *l2 = l1 + job.in_pitch;
-	const uint32_t a = *(const uint32_t *)(l1 + 2 * x), b = *(const uint32_t *)(l2 + 2 * x);      // (left, right) photosites of the two rows
-	const int tl = job.curve[(a & 0xffffu) >> 2], tr = job.curve[a >> 18], bl = job.curve[(b & 0xffffu) >> 2], br = job.curve[b >> 18];
+	int tl, tr, bl, br;
+	if (job.packed12) {
+		const uint8_t *base = (const uint8_t *)job.in + (size_t)srow * job.width * 6, *nib = base + (size_t)job.width * 4;
+		int v[4];
+#pragma unroll
+		for (int k = 0; k < 4; k++) { const int s = k * job.width + x; v[k] = ((int)base[s] << 4) | ((nib[s >> 1] >> (4 * (s & 1))) & 15); }
+		tl = v[0]; tr = v[1]; bl = v[2]; br = v[3];      // the four runs in the order of a row pair's photosites
+	} else {
+		const uint16_t *l1 = job.in + (size_t)(2 * srow) * job.in_pitch, *l2 = l1 + job.in_pitch;
+		const uint32_t a = *(const uint32_t *)(l1 + 2 * x), b = *(const uint32_t *)(l2 + 2 * x);      // (left, right) photosites of the two rows
+		tl = job.curve[(a & 0xffffu) >> 2]; tr = job.curve[a >> 18]; bl = job.curve[(b & 0xffffu) >> 2]; br = job.curve[b >> 18];
+	}
 	int r, g1, g2, bb;
 	switch (job.order) {
 	case 0: r = tl; g1 = tr; g2 = bl; bb = br; break;

@@ -55,6 +55,8 @@ void orc_inv_spatial_to_yuv422(PIXEL16 *const bands[3][4], const int band_pitch[
 
 /* ---- quantizer tables (host side of the path) ---- */
 /* interlaced last level (decoder.c:21493 + temporal.c:5961): temporal pair after the horizontal synthesis, same packing */
+/* BYR5: one row pair of the 12-bit packed mosaic -> one row of the planes G, R-G, B-G, G1-G2 (Codec/frame.c:5473 ConvertBYR5ToFrame16s; no curve) */
+void orc_byr5_unpack_row(const uint8_t *row, int width, PIXEL16 *g, PIXEL16 *rg, PIXEL16 *bg, PIXEL16 *dg);
 /* deep RGB (16-bit words r, g, b) -> 10-bit Y, channel 1 (v), channel 2 (u) planes of a 4:2:2 frame: Codec/frame.c:6731 ConvertAnyDeep444to422 */
 void orc_rgb16_to_yuv422(const uint16_t *in, int in_pitch_words, int words_per_pixel, int width, int display_height, int height, int color_space,
                          PIXEL16 *y_plane, int y_pitch, PIXEL16 *c1_plane, PIXEL16 *c2_plane, int c_pitch);

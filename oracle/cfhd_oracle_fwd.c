@@ -353,3 +353,25 @@ void orc_rgb8_to_yuv422(const uint8_t *in, int in_pitch, int bytes_per_pixel, in
 	}
 	free(yuv);
 }
+
+/* ---- BYR5 (12-bit Bayer, "packed line of 8-bit then line of 4-bit remainder") -> the four component planes ---------------------------------
+ * Codec/frame.c:5473 ConvertBYR5ToFrame16s, one row pair of the mosaic = one row of the planes: 4 * width samples lie as 4 * width high bytes
+ * (four runs of `width`: for the red-green order R, G1, G2, B -- :5591-5596) followed by 2 * width bytes of low nibbles, the even sample's in the low
+ * half of the byte (:5540-5563: value = high << 4 | nibble).  No encode curve: G = (G1 + G2) >> 1, then (R - G + 4096) >> 1, (B - G + 4096) >> 1,
+ * (G1 - G2 + 4096) >> 1 (:5647-5663).  `row` points at the 6 * width bytes of the row pair. */
+void orc_byr5_unpack_row(const uint8_t *row, int width, PIXEL16 *g, PIXEL16 *rg, PIXEL16 *bg, PIXEL16 *dg)
+{
+	const uint8_t *nib = row + (size_t)4 * width;
+	int x, k;
+	for (x = 0; x < width; x++) {
+		int v[4];
+		for (k = 0; k < 4; k++) { const int s = k * width + x; v[k] = (row[s] << 4) | ((nib[s >> 1] >> (4 * (s & 1))) & 15); }
+		{
+			const int gg = (v[1] + v[2]) >> 1;
+			g[x] = (PIXEL16)gg;
+			rg[x] = (PIXEL16)((v[0] - gg + 4096) >> 1);
+			bg[x] = (PIXEL16)((v[3] - gg + 4096) >> 1);
+			dg[x] = (PIXEL16)((v[1] - v[2] + 4096) >> 1);
+		}
+	}
+}

@@ -259,7 +259,7 @@ def mask_volatile_metadata(sample):
 # ------------------------------------------------------------------------------------------
 PRODUCT_DIR = os.path.join(ROOT, "cineform-sdk_amd")
 PRODUCT_SO = os.path.join(PRODUCT_DIR, "libcfhd_amd.so")
-PIXKIND = {"YUY2": 1, "2vuy": 2, "RG48": 3, "b64a": 4, "BYR4": 5, "YU64": 6, "v210": 7, "RG24": 8, "BGRA": 9, "BGRa": 10, "r210": 11, "DPX0": 12, "AB10": 13, "AR10": 14}
+PIXKIND = {"YUY2": 1, "2vuy": 2, "RG48": 3, "b64a": 4, "BYR4": 5, "YU64": 6, "v210": 7, "RG24": 8, "BGRA": 9, "BGRa": 10, "r210": 11, "DPX0": 12, "AB10": 13, "AR10": 14, "BYR5": 15}
 ENC = {"422": 1, "bayer": 2, "444": 3, "4444": 4}
 _product = None
 
@@ -990,3 +990,27 @@ def oracle_inverse_rgb24_of_yuv422(plan, coeffs, d, color_space=2):
     out = np.zeros((plan.height, 2 * w * 3), np.uint8)
     O.orc_inv_spatial_to_rgb24_of_yuv422(ptrs, iarr(pitches), w, h, plan.precision, plan.height, color_space, d, out.ctypes.data_as(ctypes.c_void_p), out.shape[1])
     return out
+
+
+def pack_byr5(mosaic):
+    """A 16-bit Bayer mosaic (red-green order) as a BYR5 frame: 12-bit values (>> 4), per row pair the four components R, G1, G2, B as runs of high bytes, then
+    their low nibbles two to a byte, the even sample's in the low half (CFHDTypes.h: "packed line of 8-bit then line a 4-bit reminder")."""
+    H, W = mosaic.shape
+    v = (mosaic >> 4).astype(np.uint16)
+    rows = []
+    for r in range(H // 2):
+        comp = np.concatenate([v[2 * r, 0::2], v[2 * r, 1::2], v[2 * r + 1, 0::2], v[2 * r + 1, 1::2]])
+        lo = (comp & 15).astype(np.uint8)
+        rows.append(np.concatenate([(comp >> 4).astype(np.uint8), (lo[0::2] | (lo[1::2] << 4)).astype(np.uint8)]))
+    return np.concatenate(rows)
+
+
+def byr5_planes(frame, w, h):
+    """G, R-G, B-G, G1-G2 planes (w x h each) of a BYR5 frame through the oracle's restatement of ConvertBYR5ToFrame16s."""
+    O = oracle()
+    O.orc_byr5_unpack_row.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 4
+    rows = np.ascontiguousarray(np.asarray(frame, np.uint8).reshape(h, 6 * w))
+    planes = [np.zeros((h, w), np.int16) for _ in range(4)]
+    for r in range(h):
+        O.orc_byr5_unpack_row(rows[r].ctypes.data_as(ctypes.c_void_p), w, *[p[r].ctypes.data_as(ctypes.c_void_p) for p in planes])
+    return planes

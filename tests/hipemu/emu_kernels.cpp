@@ -329,8 +329,20 @@ void emu_unpack_byr4(const uint16_t *in, int in_pitch_words, int width, int heig
                      int16_t **out /*[4]*/, int out_pitch)
 {
 	BayerJob job;
+	memset(&job, 0, sizeof(job));
 	job.in = in; job.in_pitch = in_pitch_words; job.width = width; job.height = height; job.display_height = display_height;
 	job.curve = curve; job.order = order; job.precision = precision; job.out_pitch = out_pitch;
+	for (int c = 0; c < 4; c++) job.out[c] = out[c];
+	hipemu::launch(dim3((width + NTHREADS - 1) / NTHREADS, height, 1), dim3(NTHREADS), [&] { k_unpack_byr4(&job); });
+}
+
+// BYR5 input: the same kernel reading the packed 12-bit rows (BayerJob::packed12), as EncodeBatch::fill_jobs sets it up.
+void emu_unpack_byr5(const uint8_t *in, int width, int height, int display_height, int order, int16_t **out /*[4]*/, int out_pitch)
+{
+	BayerJob job;
+	memset(&job, 0, sizeof(job));
+	job.in = (const uint16_t *)in; job.in_pitch = width * 3; job.width = width; job.height = height; job.display_height = display_height;
+	job.order = order; job.precision = 12; job.out_pitch = out_pitch; job.packed12 = 1;
 	for (int c = 0; c < 4; c++) job.out[c] = out[c];
 	hipemu::launch(dim3((width + NTHREADS - 1) / NTHREADS, height, 1), dim3(NTHREADS), [&] { k_unpack_byr4(&job); });
 }

@@ -500,6 +500,20 @@ def test_yuv422_decode_to_rg24_lies_in_the_reference_interval(w, h, flags):
     assert abs(mine_db - ref_db) < 0.1, (mine_db, ref_db)
 
 
+def test_rg30_is_ab10_under_another_name():
+    """RG30 (AJA's name for the AB10 word layout): the same sample as AB10 except for the input format code in its header (122 instead of 125), byte-identical
+    to the reference; RGB 4:4:4 samples decode to RG30 exactly as to AB10."""
+    w, h = 320, 240
+    frames, pitch = qbist_frames(10, 1, w, h, fourcc("AB10"))
+    mine = amd_encode_frames(frames, pitch, w, h, fourcc("RG30"), encoded=ENCODED_RGB444)[0]
+    ref = ref_encode_frames(frames, pitch, w, h, fourcc("RG30"), encoded=ENCODED_RGB444)[0]
+    ab10 = amd_encode_frames(frames, pitch, w, h, fourcc("AB10"), encoded=ENCODED_RGB444)[0]
+    assert mask_volatile_metadata(mine) == mask_volatile_metadata(ref)
+    assert [i for i, (x, y) in enumerate(zip(mask_volatile_metadata(mine), mask_volatile_metadata(ab10))) if x != y] == [35]
+    a, pa, _, _ = amd_decode_sample(mine, fourcc("RG30")); b, pb, _, _ = amd_decode_sample(mine, fourcc("AB10"))
+    assert pa == pb and np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("w,h", [(320, 240), (720, 480), (1920, 1080)])
 def test_rgb444_decode_to_b64a_equals_reference_exactly(w, h):
     """RGB 4:4:4 samples decoded to b64a (what TestCFHD's b64a -> RGB 4:4:4 row decodes to): word for word the reference decoder's output -- the RG48 words
@@ -812,6 +826,17 @@ def test_rg24_encode_to_rgb444_bitstream_identical(w, h):
     src = frames[0].reshape(h, pitch)[:, : w * 3].reshape(h, w, 3)[::-1, :, ::-1].astype(np.float64) * 257.0  # B, G, R bytes bottom-up -> R, G, B 16-bit
     mse = np.mean((rgb.astype(np.float64) - src) ** 2)
     assert 10 * np.log10(65535.0 ** 2 / mse) > 40.0
+
+
+@pytest.mark.parametrize("w,h", [(320, 240), (1920, 1080), (3840, 2160)])
+def test_byr5_encode_bitstream_identical(w, h):
+    """BYR5 (12-bit packed Bayer) -> CFHD_ENCODED_FORMAT_BAYER: k_unpack_byr4 reading the packed rows, no encode curve; byte-identical to the reference."""
+    frames = [pack_byr5(synth_bayer(w, h, 7 + i)) for i in range(2 if w < 3840 else 1)]
+    mine = amd_encode_frames(frames, w * 2, w, h, fourcc("BYR5"), encoded=ENCODED_BAYER)
+    refs = ref_encode_frames(frames, w * 2, w, h, fourcc("BYR5"), encoded=ENCODED_BAYER)
+    for i, (a, b) in enumerate(zip(mine, refs)):
+        assert len(a) == len(b), "frame %d: size %d vs reference %d" % (i, len(a), len(b))
+        assert mask_volatile_metadata(a) == mask_volatile_metadata(b), "frame %d" % i
 
 
 def test_byr4_encode_with_a_wide_pitch_reads_what_the_reference_reads():

@@ -129,6 +129,21 @@ def test_byr4_bayer_sample_bytes_equal_reference(w, h):
     assert mine == rs
 
 
+@pytest.mark.parametrize("w,h", [(320, 240), (640, 360), (1920, 1080)])
+def test_byr5_sample_bytes_equal_reference(w, h):
+    """BYR5 (12-bit Bayer, CFHDTypes.h: "packed line of 8-bit then line a 4-bit reminder") -> CFHD_ENCODED_FORMAT_BAYER: the reference unpacks the four
+    components of every row pair without an encode curve (frame.c:5473 ConvertBYR5ToFrame16s) and goes on as for BYR4; input format 105 in the header.
+    Oracle unpack + oracle plane transform + product syntax = reference sample, byte for byte (1080: the last row pair repeated below the picture)."""
+    if not have_ref(): pytest.skip("reference .so not built")
+    frame = pack_byr5(synth_bayer(w, h, 3))
+    rs = ref_encode_frames([frame], w * 2, w, h, fourcc("BYR5"), encoded=ENCODED_BAYER)[0]
+    plan = Plan(w, h, pixkind=PIXKIND["BYR5"], enc=2)
+    assert plan.num_channels == 4 and plan.precision == 12
+    off, n = first_metadata_chunk(rs)
+    mine = product_write_sample_host(plan, oracle_forward_planes(plan, byr5_planes(frame, w // 2, h // 2)), 1, meta_global=rs[off:off + n], input_format=105, color_space=0)
+    assert mine == rs
+
+
 @pytest.mark.parametrize("w,h", [(320, 240), (720, 486)])
 def test_yu64_sample_bytes_equal_reference(w, h):
     """YU64 (16-bit 4:2:2 words Y0 C1 Y1 C2) -> YUV 4:2:2 sample: the reference unpacks every word >> 6 into three planes (channel 1 = the
@@ -415,8 +430,10 @@ def test_thumbnail_and_output_formats_argument_handling():
     fmts = (ctypes.c_uint32 * 8)(); n = ctypes.c_int()
     L.CFHD_GetOutputFormats.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
     assert L.CFHD_GetOutputFormats(dec, sb, len(sample), fmts, 8, ctypes.byref(n)) == 0
-    assert [fmts[i] for i in range(n.value)] == [PIX_YUY2, PIX_2VUY, fourcc("YU64"), fourcc("v210")]
+    assert [fmts[i] for i in range(n.value)] == [PIX_YUY2, PIX_2VUY, fourcc("YU64"), fourcc("v210"), PIX_RG24]
     assert L.CFHD_GetOutputFormats(dec, None, 0, fmts, 8, ctypes.byref(n)) == 0 and n.value == 8
+    many = (ctypes.c_uint32 * 32)()
+    assert L.CFHD_GetOutputFormats(dec, None, 0, many, 32, ctypes.byref(n)) == 0 and n.value == 14 and len(set(many[: n.value])) == 14      # every format once, RG30 among them
     L.CFHD_CloseDecoder(dec)
 
 

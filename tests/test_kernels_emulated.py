@@ -714,6 +714,27 @@ def test_unpack_byr4_equals_oracle(w, h, dh):
         assert np.array_equal(got[c], want[c]), c
 
 
+@pytest.mark.parametrize("w,h,dh", [(40, 8, 8), (300, 24, 21)])
+def test_unpack_byr5_equals_oracle(w, h, dh):
+    """k_unpack_byr4 on BYR5 input (12-bit samples: runs of high bytes, then low nibbles; no curve) = oracle restatement of ConvertBYR5ToFrame16s (pinned
+    against the reference encoder's samples in test_host_bitstream); all 4096 values of every component; rows below the picture repeat the last row pair."""
+    rng = np.random.default_rng(w + h)
+    frame = rng.integers(0, 256, size=(dh, 6 * w), dtype=np.int64).astype(np.uint8)
+    O = oracle()
+    O.orc_byr5_unpack_row.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 4
+    pitch = (w + 15) // 16 * 16
+    want = [np.zeros((h, pitch), np.int16) for _ in range(4)]
+    for r in range(h):
+        O.orc_byr5_unpack_row(frame[min(r, dh - 1)].ctypes.data_as(ctypes.c_void_p), w, *[p[r].ctypes.data_as(ctypes.c_void_p) for p in want])
+    got = [np.zeros((h, pitch), np.int16) for _ in range(4)]
+    E = emu()
+    E.emu_unpack_byr5.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_int]
+    E.emu_unpack_byr5(frame.ctypes.data_as(ctypes.c_void_p), w, h, dh, 0, (c_i16p * 4)(*[p16(g) for g in got]), pitch)
+    for c in range(4):
+        assert np.array_equal(got[c], want[c]), c
+    assert want[0].max() > 3900 and want[3].min() < 300
+
+
 @pytest.mark.parametrize("w,h,dh", [(64, 16, 16), (272, 24, 21), (720, 16, 16), (1920, 8, 8)])
 @pytest.mark.parametrize("uyvy", [0, 1])
 def test_fwd_frame_yuv422_interlaced_level1(w, h, dh, uyvy):
