@@ -36,7 +36,7 @@ enum {
 static const uint32_t FMT_YUY2 = FOURCC_BE('Y', 'U', 'Y', '2'), FMT_2VUY = FOURCC_BE('2', 'v', 'u', 'y'), FMT_YUYV = FOURCC_BE('y', 'u', 'y', 'v'),
                       FMT_RG48 = FOURCC_BE('R', 'G', '4', '8'), FMT_B64A = FOURCC_BE('b', '6', '4', 'a'), FMT_BYR4 = FOURCC_BE('B', 'Y', 'R', '4'), FMT_YU64 = FOURCC_BE('Y', 'U', '6', '4'), FMT_V210 = FOURCC_BE('v', '2', '1', '0'), FMT_RG24 = FOURCC_BE('R', 'G', '2', '4'), FMT_BGRA = FOURCC_BE('B', 'G', 'R', 'A'), FMT_BGRa = FOURCC_BE('B', 'G', 'R', 'a'),
                       FMT_R210 = FOURCC_BE('r', '2', '1', '0'), FMT_DPX0 = FOURCC_BE('D', 'P', 'X', '0'), FMT_AB10 = FOURCC_BE('A', 'B', '1', '0'), FMT_AR10 = FOURCC_BE('A', 'R', '1', '0'),
-                      FMT_RG30 = FOURCC_BE('R', 'G', '3', '0'), FMT_BYR5 = FOURCC_BE('B', 'Y', 'R', '5');      // (AJA's name for the AB10 word layout: same pixels, its own colour format code in the sample header)
+                      FMT_RG30 = FOURCC_BE('R', 'G', '3', '0'), FMT_BYR5 = FOURCC_BE('B', 'Y', 'R', '5'), FMT_RG64 = FOURCC_BE('R', 'G', '6', '4');      // (AJA's name for the AB10 word layout: same pixels, its own colour format code in the sample header)
 
 namespace {
 
@@ -48,6 +48,7 @@ int pixel_kind_of(uint32_t fmt)
 	if (fmt == FMT_B64A) return PIX_B64A;
 	if (fmt == FMT_BYR4) return PIX_BYR4;
 	if (fmt == FMT_BYR5) return PIX_BYR5;
+	if (fmt == FMT_RG64) return PIX_RG64;
 	if (fmt == FMT_YU64) return PIX_YU64;
 	if (fmt == FMT_V210) return PIX_V210;
 	if (fmt == FMT_RG24) return PIX_RG24;
@@ -60,8 +61,8 @@ int pixel_kind_of(uint32_t fmt)
 	return PIX_NONE;
 }
 // COLOR_FORMAT_UYVY = 1 / COLOR_FORMAT_YUYV = 2 / COLOR_FORMAT_BGRA64 (b64a) = 30 / COLOR_FORMAT_RG48 = 120 (Codec/color.h)
-int color_format_of(int kind) { return kind == PIX_2VUY ? 1 : (kind == PIX_RG48 ? 120 : (kind == PIX_B64A ? 30 : (kind == PIX_BYR4 ? 104 : (kind == PIX_BYR5 ? 105 : (kind == PIX_YU64 ? 12 : (kind == PIX_V210 ? 10 : (kind == PIX_RG24 ? 7 : (kind == PIX_BGRA ? 32 : (kind == PIX_BGRa ? 9 : (kind == PIX_R210 ? 123 : (kind == PIX_DPX0 ? 128 : (kind == PIX_AB10 ? 125 : (kind == PIX_AR10 ? 124 : 2))))))))))))); }   // COLOR_FORMAT_* of Codec/color.h
-int pixel_bytes_of(int kind) { return kind == PIX_RG24 ? 3 : (kind == PIX_BGRA || kind == PIX_BGRa || (kind >= PIX_R210 && kind <= PIX_AR10)) ? 4 : kind == PIX_RG48 ? 6 : (kind == PIX_B64A ? 8 : (kind == PIX_YU64 || kind == PIX_V210 ? 4 : 2)); }
+int color_format_of(int kind) { return kind == PIX_2VUY ? 1 : (kind == PIX_RG48 ? 120 : (kind == PIX_B64A ? 30 : (kind == PIX_BYR4 ? 104 : (kind == PIX_BYR5 ? 105 : (kind == PIX_RG64 ? 121 : (kind == PIX_YU64 ? 12 : (kind == PIX_V210 ? 10 : (kind == PIX_RG24 ? 7 : (kind == PIX_BGRA ? 32 : (kind == PIX_BGRa ? 9 : (kind == PIX_R210 ? 123 : (kind == PIX_DPX0 ? 128 : (kind == PIX_AB10 ? 125 : (kind == PIX_AR10 ? 124 : 2)))))))))))))); }   // COLOR_FORMAT_* of Codec/color.h
+int pixel_bytes_of(int kind) { return kind == PIX_RG24 ? 3 : (kind == PIX_BGRA || kind == PIX_BGRa || (kind >= PIX_R210 && kind <= PIX_AR10)) ? 4 : kind == PIX_RG48 ? 6 : (kind == PIX_B64A || kind == PIX_RG64 ? 8 : (kind == PIX_YU64 || kind == PIX_V210 ? 4 : 2)); }
 
 // ---- metadata handle shared by the encoder-side API (CSampleEncodeMetadata) ----
 struct EncMetadata {
@@ -110,7 +111,10 @@ int make_params(EncodeParams &p, int w, int h, uint32_t fmt, int encoded, uint32
 	// CFHD_ENCODED_FORMAT_RGBA_4444 (2) from b64a
 	const bool rgb8 = kind == PIX_RG24 || kind == PIX_BGRA || kind == PIX_BGRa;       // 8-bit RGB(A) input, towards RGB 4:4:4 and YUV 4:2:2 (alpha dropped)
 	const bool rgb10 = kind >= PIX_R210 && kind <= PIX_AR10;                             // 10-bit RGB in 32-bit words, to RGB 4:4:4
-	const bool rgb = kind == PIX_RG48 || kind == PIX_B64A || rgb8 || rgb10;
+	// RG64 (16-bit words R, G, B, A; frame.c ConvertRGBA64ToFrame16s): b64a's three encoded formats and marks with the words in another order; its colour format
+	// code 121 lies above COLOR_FORMAT_BAYER, so all planes take the full-resolution quantizer tables (RG48's rule, not b64a's; pinned on the reference)
+	const bool rg64 = kind == PIX_RG64;
+	const bool rgb = kind == PIX_RG48 || kind == PIX_B64A || rg64 || rgb8 || rgb10;
 	// CFHD_ENCODED_FORMAT_BAYER (3) from BYR4: default pixel order (red-green) and default encode curve (log 90), i.e. what the
 	// reference does without BAYER_FORMAT / ENCODE_CURVE metadata
 	// b64a also encodes to RGB 4:4:4 (its default in the reference): the alpha words are dropped, R, G, B as for 4:4:4:4
@@ -118,10 +122,10 @@ int make_params(EncodeParams &p, int w, int h, uint32_t fmt, int encoded, uint32
 	// kernel; the converted frame is quantized as the 4:2:2 frame it has become (derive_quantization).
 	// RG24 / BGRA / BGRa encoded as YUV 4:2:2 (the default encoded format of these inputs): frame.c:378 ConvertRGB32to10bitYUVFrame in the loader.
 	const bool rgb8_as_422 = rgb8 && encoded == 0;
-	const bool deep_rgb_as_422 = ((kind == PIX_RG48 || kind == PIX_B64A) && encoded == 0) || rgb8_as_422;
+	const bool deep_rgb_as_422 = ((kind == PIX_RG48 || kind == PIX_B64A || rg64) && encoded == 0) || rgb8_as_422;
 	// BGRA / BGRa encoded as RGBA 4:4:4:4 (frame.c:6415 ConvertRGBAtoRGBA64): the alpha byte joins as the fourth plane, curved as b64a's
 	const bool rgba8_as_4444 = (kind == PIX_BGRA || kind == PIX_BGRa) && encoded == 2;
-	if (!deep_rgb_as_422 && !rgba8_as_4444 && !(kind == PIX_B64A && encoded == 1) && encoded != (kind == PIX_RG48 || rgb8 || rgb10 ? 1 : (kind == PIX_B64A ? 2 : (kind == PIX_BYR4 || kind == PIX_BYR5 ? 3 : 0)))) return ERR_BADFORMAT;
+	if (!deep_rgb_as_422 && !rgba8_as_4444 && !((kind == PIX_B64A || rg64) && (encoded == 1 || encoded == 2)) && encoded != (kind == PIX_RG48 || rgb8 || rgb10 ? 1 : (kind == PIX_B64A ? 2 : (kind == PIX_BYR4 || kind == PIX_BYR5 ? 3 : 0)))) return ERR_BADFORMAT;
 	// CFHD_ENCODING_FLAGS_YUV_INTERLACED: field-based level 1 (encoder.c:2093), built for the packed 4:2:2 formats
 	const bool interlaced = (flags & (1u << 0)) != 0;
 	if (interlaced && !(kind == PIX_YUY2 || kind == PIX_2VUY)) return ERR_BADFORMAT;
@@ -129,12 +133,12 @@ int make_params(EncodeParams &p, int w, int h, uint32_t fmt, int encoded, uint32
 	// Progressive frames, qualities whose tables do not follow the size of the previous group.
 	const bool gop = (flags & (1u << 1)) != 0;
 	if (gop && (interlaced || !(kind == PIX_YUY2 || kind == PIX_2VUY))) return ERR_BADFORMAT;
-	const int enc = kind == PIX_BYR4 || kind == PIX_BYR5 ? ENC_BAYER : ((kind == PIX_B64A && encoded == 2) || rgba8_as_4444 ? ENC_RGBA4444 : (rgb && !deep_rgb_as_422 ? ENC_RGB444 : ENC_YUV422));
+	const int enc = kind == PIX_BYR4 || kind == PIX_BYR5 ? ENC_BAYER : (((kind == PIX_B64A || rg64) && encoded == 2) || rgba8_as_4444 ? ENC_RGBA4444 : (rgb && !deep_rgb_as_422 ? ENC_RGB444 : ENC_YUV422));
 	// an encoded format other than the default of the input format marks the quality word (SampleEncoder.cpp:216-219; QUALITY_H 0x0800 in the header)
 	if (deep_rgb_as_422 && !rgb8_as_422) quality |= 0x08000000;
 	// b64a's default encoded format is RGB 4:4:4; asking for 4:4:4:4 marks the quality word (SampleEncoder.cpp:250-257), which the
 	// sample header then carries in QUALITY_H
-	if (kind == PIX_B64A && encoded == 2) quality |= 0x20000000;
+	if ((kind == PIX_B64A || rg64) && encoded == 2) quality |= 0x20000000;
 	// 8-bit RGB sources are marked in the quality word too (encoder.c:2344-2345 ORs 0x1a00000 into it; the header's QUALITY_H reads 0x09a0)
 	// (for 8-bit RGB the format that is "other" is RGB 4:4:4: 0x0800 on top of the 0x01a0 of every 8-bit RGB source)
 	if (rgb8) quality |= rgb8_as_422 ? 0x01a00000 : (rgba8_as_4444 ? 0x21a00000 : 0x09a00000);
@@ -597,7 +601,7 @@ CFHD_Error CFHD_OpenEncoder(CFHD_EncoderRef *out, CFHD_ALLOCATOR *)
 CFHD_Error CFHD_GetInputFormats(CFHD_EncoderRef ref, CFHD_PixelFormat *arr, int len, int *count)
 {
 	if (!ref || !arr) return ERR_INVALID_ARGUMENT;
-	const uint32_t fmts[] = { FMT_YUY2, FMT_2VUY, FMT_RG48, FMT_B64A, FMT_BYR4, FMT_YU64, FMT_V210, FMT_RG24, FMT_BGRA, FMT_BGRa, FMT_R210, FMT_DPX0, FMT_AB10, FMT_AR10, FMT_RG30, FMT_BYR5 };
+	const uint32_t fmts[] = { FMT_YUY2, FMT_2VUY, FMT_RG48, FMT_B64A, FMT_BYR4, FMT_YU64, FMT_V210, FMT_RG24, FMT_BGRA, FMT_BGRa, FMT_R210, FMT_DPX0, FMT_AB10, FMT_AR10, FMT_RG30, FMT_BYR5, FMT_RG64 };
 	int n = 0;
 	for (; n < (int)(sizeof(fmts) / sizeof(fmts[0])) && n < len; n++) arr[n] = fmts[n];
 	if (count) *count = n;
@@ -1015,7 +1019,7 @@ CFHD_Error CFHD_PrepareToDecode(CFHD_DecoderRef ref, int, int, CFHD_PixelFormat 
 	if (rgb10 && (encf != ENC_RGB444 || half || d->header.width < 32)) return ERR_BADFORMAT;
 	// ... and 4:2:2 samples to v210 (the YU64 words >> 6, three to a 32-bit word: DecodeBatch / k_yu64_to_v210; widths of whole six-pixel groups)
 	if (kind == PIX_V210 && (encf != ENC_YUV422 || half || d->header.width % 6 || d->header.width < 128)) return ERR_BADFORMAT;
-	if (kind == PIX_BYR4 || kind == PIX_BYR5 || (kind >= PIX_R210 && kind <= PIX_AR10 && !rgb10)) return ERR_BADFORMAT;     // encoder inputs only
+	if (kind == PIX_BYR4 || kind == PIX_BYR5 || kind == PIX_RG64 || (kind >= PIX_R210 && kind <= PIX_AR10 && !rgb10)) return ERR_BADFORMAT;     // encoder inputs only
 	// ... and RGB 4:4:4 samples to b64a (the RG48 words behind a constant alpha word 0xfff0, full resolution: what TestCFHD's b64a -> RGB 4:4:4 row decodes to)
 	const bool b64a_of_444 = kind == PIX_B64A && encf == ENC_RGB444 && !half;
 	if ((encf == ENC_RGB444) != (kind == PIX_RG48 || (rgb8 && !rgba8 && !rgb24_of_422) || rgb10 || b64a_of_444) || (encf == ENC_RGBA4444) != ((kind == PIX_B64A && !b64a_of_444) || rgba8)) return ERR_BADFORMAT;

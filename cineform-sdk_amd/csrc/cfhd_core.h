@@ -36,6 +36,7 @@ enum PixelKind : int {
 	PIX_DPX0,      // big-endian, R 22-31, G 12-21, B 2-11 (128)
 	PIX_AB10,      // little-endian, R 0-9, G 10-19, B 20-29 (125)
 	PIX_AR10,      // little-endian, R 20-29, G 10-19, B 0-9 (124)
+	PIX_RG64,      // 16-bit words R, G, B, A (COLOR_FORMAT_RG64 = 121; encoder input only: to RGBA 4:4:4:4, RGB 4:4:4 or YUV 4:2:2 like b64a, quantized like RG48)
 	PIX_BYR5,      // 12-bit Bayer, per row pair the four components as runs of high bytes, then their low nibbles (COLOR_FORMAT_BYR5 = 105; encoder input only)
 };
 

@@ -102,13 +102,13 @@ static int16_t *dec_plane_out(void *frame, int out_kind, int c) { return dec_rgb
 // YU64 (Codec/frame.c:1556 ConvertYU64ToFrame16s + convert.c:3345, :14375): words Y0 C1 Y1 C2, every word >> 6 to 10 bits, channel 1 = C1, 2 = C2.
 // v210 (frame.c:1431 ConvertV210ToFrame16s): three 10-bit samples per 32-bit word, FwdPlaneJob::layout tells the loader which component to pick.
 // RG24 (frame.c:6173 ConvertRGBtoRGB48): bytes B, G, R, bottom row first, byte << 4; planes G, R, B.
-static bool enc_packed16(int pixel_kind) { return is_packed16(pixel_kind) || pixel_kind == PIX_YU64 || pixel_kind == PIX_V210 || pixel_kind == PIX_RG24 || pixel_kind == PIX_BGRA || pixel_kind == PIX_BGRa || (pixel_kind >= PIX_R210 && pixel_kind <= PIX_AR10); }
+static bool enc_packed16(int pixel_kind) { return is_packed16(pixel_kind) || pixel_kind == PIX_RG64 || pixel_kind == PIX_YU64 || pixel_kind == PIX_V210 || pixel_kind == PIX_RG24 || pixel_kind == PIX_BGRA || pixel_kind == PIX_BGRa || (pixel_kind >= PIX_R210 && pixel_kind <= PIX_AR10); }
 static bool enc_bytes8(int pixel_kind) { return pixel_kind == PIX_RG24 || pixel_kind == PIX_BGRA || pixel_kind == PIX_BGRa; }
 static bool enc_rgb10(int pixel_kind) { return pixel_kind >= PIX_R210 && pixel_kind <= PIX_AR10; }
 // bit position of plane c (G, R, B) inside the pixel word of the 10-bit RGB formats
 static int rgb10_shift(int pixel_kind, int c) { const int r = pixel_kind == PIX_DPX0 ? 22 : (pixel_kind == PIX_AB10 ? 0 : 20), g = pixel_kind == PIX_DPX0 ? 12 : 10, b = pixel_kind == PIX_DPX0 ? 2 : (pixel_kind == PIX_AB10 ? 20 : 0); return c == 0 ? g : (c == 1 ? r : b); }
 // RG48 / b64a encoded as YUV 4:2:2: the loader of k_fwd_packed16 converts the pixels (FwdPlaneJob::layout 7); every plane reads from the R word
-static bool enc_rgb_as_422(const FramePlan &plan) { return is_packed16(plan.pixel_kind) && plan.encoded_format == ENC_YUV422; }
+static bool enc_rgb_as_422(const FramePlan &plan) { return (is_packed16(plan.pixel_kind) || plan.pixel_kind == PIX_RG64) && plan.encoded_format == ENC_YUV422; }
 static int enc_word_of_channel(int pixel_kind, int c) { return pixel_kind == PIX_V210 || enc_bytes8(pixel_kind) || enc_rgb10(pixel_kind) ? 0 : (pixel_kind == PIX_YU64 ? (c == 0 ? 0 : (c == 1 ? 1 : 3)) : packed_word_of_channel(pixel_kind, c)); }
 static int enc_stride_of_channel(int pixel_kind, int c, int nch) { return pixel_kind == PIX_YU64 ? (c == 0 ? 2 : 4) : (pixel_kind == PIX_B64A ? 4 : nch); }     // (b64a to RGB 4:4:4 has three planes of four-word pixels)
 } // namespace
@@ -191,7 +191,7 @@ int packed_frame_pitch(int pixel_kind, int width)
 	switch (pixel_kind) {
 	case PIX_YUY2: case PIX_2VUY: return width * 2;
 	case PIX_RG48: return width * 6;
-	case PIX_B64A: return width * 8;
+	case PIX_B64A: case PIX_RG64: return width * 8;
 	case PIX_BYR4: return width * 2;
 	case PIX_BYR5: return width * 3;       // per row PAIR of the mosaic: 4 x width / 2 samples of 12 bits (the unit the frame is laid out in)
 	case PIX_YU64: return width * 4;
@@ -314,13 +314,13 @@ void EncodeBatch::fill_jobs()
 				p.in = frame ? (const int16_t *)(frame + enc_word_of_channel(plan.pixel_kind, c)) : nullptr; p.in_pitch = in_pitch_ / 2;
 				p.width = plan.ch[c].width; p.height = plan.ch[c].height; p.prescale = plan.prescale[0];
 				p.xstride = enc_stride_of_channel(plan.pixel_kind, c, nch); p.shift = 16 - plan.precision; p.display_height = plan.display_height;
-				p.compand = plan.pixel_kind == PIX_B64A && c == 3;
+				p.compand = (plan.pixel_kind == PIX_B64A || plan.pixel_kind == PIX_RG64) && c == 3;
 				p.layout = plan.pixel_kind == PIX_V210 ? c + 1 : 0; p.tail_from = (plan.width - plan.width % 48) / 2;
 				if (enc_bytes8(plan.pixel_kind)) { p.layout = plan.pixel_kind == PIX_BGRa ? 5 : 4; p.in_pitch = in_pitch_; p.xstride = plan.pixel_kind == PIX_RG24 ? 3 : 4; p.tail_from = c == 0 ? 1 : (c == 1 ? 2 : (c == 2 ? 0 : 3)); p.compand = c == 3; }     // planes G, R, B(, A) of bytes B, G, R(, A)
 				if (enc_rgb10(plan.pixel_kind)) { p.layout = 6; p.in_pitch = in_pitch_ / 4; p.xstride = plan.pixel_kind == PIX_R210 || plan.pixel_kind == PIX_DPX0; p.tail_from = rgb10_shift(plan.pixel_kind, c); }
 				if (enc_rgb_as_422(plan)) {
 					p.in = frame ? (const int16_t *)(frame + (plan.pixel_kind == PIX_B64A ? 1 : 0)) : nullptr;
-					p.layout = 7; p.xstride = plan.pixel_kind == PIX_B64A ? 4 : 3; p.tail_from = c; p.shift = plan.color_matrix; p.compand = 0;
+					p.layout = 7; p.xstride = plan.pixel_kind == PIX_RG48 ? 3 : 4; p.tail_from = c; p.shift = plan.color_matrix; p.compand = 0;
 				}
 				if (enc_bytes8(plan.pixel_kind) && plan.encoded_format == ENC_YUV422) { p.layout = plan.pixel_kind == PIX_BGRa ? 9 : 8; p.tail_from = c; p.shift = plan.color_matrix; }
 				p.out_pitch = plan.ch[c].band[0][0].pitch;

@@ -396,7 +396,7 @@ static void derive_subband_tables(FramePlan *plan, int quality, bool progressive
 	// encoder.c:1141 SetEncoderQuantization: ChromaFullRes = (input colour format >= COLOR_FORMAT_BAYER (100)): true for RG48 (120) and
 	// BYR4 (104), false for the packed 4:2:2 formats and -- although it is a 4:4:4:4 format -- for b64a (COLOR_FORMAT_BGRA64 = 30),
 	// whose R, B and A planes therefore get the chroma tables
-	const bool chroma_full = plan->pixel_kind == PIX_RG48 || plan->pixel_kind == PIX_BYR4 || plan->pixel_kind == PIX_BYR5 || plan->pixel_kind == PIX_RG24 || plan->pixel_kind == PIX_BGRA || plan->pixel_kind == PIX_BGRa || (plan->pixel_kind >= PIX_R210 && plan->pixel_kind <= PIX_AR10);
+	const bool chroma_full = plan->pixel_kind == PIX_RG48 || plan->pixel_kind == PIX_BYR4 || plan->pixel_kind == PIX_BYR5 || plan->pixel_kind == PIX_RG64 || plan->pixel_kind == PIX_RG24 || plan->pixel_kind == PIX_BGRA || plan->pixel_kind == PIX_BGRa || (plan->pixel_kind >= PIX_R210 && plan->pixel_kind <= PIX_AR10);
 	// (deep RGB encoded as 4:2:2 is converted first and quantized as the 4:2:2 frame it has become: encoder.c:2339-2440 hand the converted format on)
 	const bool chroma_full_res = chroma_full && plan->encoded_format != ENC_YUV422;
 	const int precision = plan->precision;

@@ -259,7 +259,7 @@ def mask_volatile_metadata(sample):
 # ------------------------------------------------------------------------------------------
 PRODUCT_DIR = os.path.join(ROOT, "cineform-sdk_amd")
 PRODUCT_SO = os.path.join(PRODUCT_DIR, "libcfhd_amd.so")
-PIXKIND = {"YUY2": 1, "2vuy": 2, "RG48": 3, "b64a": 4, "BYR4": 5, "YU64": 6, "v210": 7, "RG24": 8, "BGRA": 9, "BGRa": 10, "r210": 11, "DPX0": 12, "AB10": 13, "AR10": 14, "BYR5": 15}
+PIXKIND = {"YUY2": 1, "2vuy": 2, "RG48": 3, "b64a": 4, "BYR4": 5, "YU64": 6, "v210": 7, "RG24": 8, "BGRA": 9, "BGRa": 10, "r210": 11, "DPX0": 12, "AB10": 13, "AR10": 14, "RG64": 15, "BYR5": 16}
 ENC = {"422": 1, "bayer": 2, "444": 3, "4444": 4}
 _product = None
 
@@ -1014,3 +1014,11 @@ def byr5_planes(frame, w, h):
     for r in range(h):
         O.orc_byr5_unpack_row(rows[r].ctypes.data_as(ctypes.c_void_p), w, *[p[r].ctypes.data_as(ctypes.c_void_p) for p in planes])
     return planes
+
+
+def rg64_frame(seed, w, h):
+    """An RG64 frame (16-bit words R, G, B, A) with the picture and alpha of the harness's b64a Qbist frame: (bytes, pitch, words h x w x 4)."""
+    fb, pb = qbist_frames(seed, 1, w, h, PIX_B64A, alpha=1)
+    b = np.frombuffer(fb[0].tobytes(), np.uint16).reshape(h, pb // 2)[:, : w * 4].reshape(h, w, 4)
+    words = np.ascontiguousarray(b[:, :, [1, 2, 3, 0]])
+    return np.frombuffer(words.tobytes(), np.uint8).copy(), w * 8, words

@@ -500,6 +500,24 @@ def test_yuv422_decode_to_rg24_lies_in_the_reference_interval(w, h, flags):
     assert abs(mine_db - ref_db) < 0.1, (mine_db, ref_db)
 
 
+@pytest.mark.parametrize("w,h,encoded", [(320, 240, ENCODED_RGBA4444), (336, 256, ENCODED_RGB444), (320, 240, ENCODED_YUV422), (1920, 1080, ENCODED_RGBA4444), (1920, 1080, ENCODED_YUV422)])
+def test_rg64_encode_bitstream_identical(w, h, encoded):
+    """RG64 (16-bit words R, G, B, A) to RGBA 4:4:4:4, RGB 4:4:4 and YUV 4:2:2: byte-identical to the reference; the samples decode like any other of their kind."""
+    frame, pitch, words = rg64_frame(10, w, h)
+    frame2, _, _ = rg64_frame(11, w, h)
+    mine = amd_encode_frames([frame, frame2], pitch, w, h, fourcc("RG64"), encoded=encoded)
+    refs = ref_encode_frames([frame, frame2], pitch, w, h, fourcc("RG64"), encoded=encoded)
+    for i, (a, b) in enumerate(zip(mine, refs)):
+        assert len(a) == len(b), "frame %d: size %d vs reference %d" % (i, len(a), len(b))
+        assert mask_volatile_metadata(a) == mask_volatile_metadata(b), "frame %d" % i
+    out_fmt = {ENCODED_RGBA4444: PIX_B64A, ENCODED_RGB444: PIX_RG48, ENCODED_YUV422: PIX_YUY2}[encoded]
+    got, gpitch, aw, ah = amd_decode_sample(mine[0], out_fmt)
+    assert (aw, ah) == (w, h)
+    if encoded == ENCODED_RGB444:
+        rgb = np.frombuffer(got.tobytes(), np.uint16).reshape(h, gpitch // 2)[:, : w * 3].reshape(h, w, 3).astype(np.float64)
+        assert 10 * np.log10(65535.0 ** 2 / np.mean((rgb - words[:, :, :3]) ** 2)) > 40.0
+
+
 def test_rg30_is_ab10_under_another_name():
     """RG30 (AJA's name for the AB10 word layout): the same sample as AB10 except for the input format code in its header (122 instead of 125), byte-identical
     to the reference; RGB 4:4:4 samples decode to RG30 exactly as to AB10."""
