@@ -110,7 +110,7 @@ static int rgb10_shift(int pixel_kind, int c) { const int r = pixel_kind == PIX_
 // RG48 / b64a encoded as YUV 4:2:2: the loader of k_fwd_packed16 converts the pixels (FwdPlaneJob::layout 7); every plane reads from the R word
 static bool enc_rgb_as_422(const FramePlan &plan) { return (is_packed16(plan.pixel_kind) || plan.pixel_kind == PIX_RG64) && plan.encoded_format == ENC_YUV422; }
 static int enc_word_of_channel(int pixel_kind, int c) { return pixel_kind == PIX_V210 || enc_bytes8(pixel_kind) || enc_rgb10(pixel_kind) ? 0 : (pixel_kind == PIX_YU64 ? (c == 0 ? 0 : (c == 1 ? 1 : 3)) : packed_word_of_channel(pixel_kind, c)); }
-static int enc_stride_of_channel(int pixel_kind, int c, int nch) { return pixel_kind == PIX_YU64 ? (c == 0 ? 2 : 4) : (pixel_kind == PIX_B64A ? 4 : nch); }     // (b64a to RGB 4:4:4 has three planes of four-word pixels)
+static int enc_stride_of_channel(int pixel_kind, int c, int nch) { return pixel_kind == PIX_YU64 ? (c == 0 ? 2 : 4) : (pixel_kind == PIX_B64A || pixel_kind == PIX_RG64 ? 4 : nch); }     // (b64a / RG64 to RGB 4:4:4 have three planes of four-word pixels)
 } // namespace
 
 const char *device_last_error() { return g_err.c_str(); }
