@@ -57,7 +57,11 @@ struct FwdPlaneJob {
 	// as YUV 4:2:2): `in` = the R word of the first pixel (G, B behind it), xstride = words per pixel, tail_from = the plane (0 Y, 1 channel 1 = v,
 	// 2 channel 2 = u), shift = colour space (0 computer-systems 709, 1 video 709, 2 computer 601, 3 video 601); a chroma sample is the mean of
 	// its pixel pair; rows beyond display_height repeat the last row.
+	// layout 10 / 11: one component plane of a Bayer mosaic computed on the way in (BYR4: 16-bit photosites through the encode curve; BYR5: the packed 12-bit
+	// rows, no curve -- what k_unpack_byr4 writes as planes, without the planes): `in` = the frame, in_pitch = words per mosaic row (BYR4), xstride = pixel order
+	// (BAYER_FORMAT_*), tail_from = the plane (0 G, 1 R-G, 2 B-G, 3 G1-G2), shift = precision, width / display_height those of the component planes.
 	int layout, tail_from;
+	const uint16_t *curve;                  // layout 10: encode curve over 14-bit linear input
 };
 
 // One sample of plane `which` (0 Y, 1 v, 2 u) from the deep RGB pixels at p (luma: pixel x; chroma: pixels 2x, 2x + 1): the reference's integer
@@ -100,6 +104,33 @@ __device__ __forceinline__ uint32_t rgb8_to_yuv_sample(const uint8_t *row, int b
 	else v = ((((m[cs][6] * r) >> 16) + ((-m[cs][7] * g) >> 16) + ((-m[cs][8] * b) >> 16)) * 4) + 8192;
 	v = v < 0 ? 0 : (v > 16383 ? 16383 : v);
 	return (uint32_t)v >> 4;
+}
+
+// One sample of component plane job.tail_from of a Bayer frame (FwdPlaneJob::layout 10 / 11), the arithmetic of k_unpack_byr4.
+__device__ __forceinline__ uint32_t bayer_plane_sample(const FwdPlaneJob &job, int row, int x)
+{
+	int tl, tr, bl, br;
+	if (job.layout == 11) {
+		const uint8_t *base = (const uint8_t *)job.in + (size_t)row * job.width * 6, *nib = base + (size_t)job.width * 4;
+		int v[4];
+#pragma unroll
+		for (int k = 0; k < 4; k++) { const int s = k * job.width + x; v[k] = ((int)base[s] << 4) | ((nib[s >> 1] >> (4 * (s & 1))) & 15); }
+		tl = v[0]; tr = v[1]; bl = v[2]; br = v[3];
+	} else {
+		const uint16_t *l1 = (const uint16_t *)job.in + (size_t)(2 * row) * job.in_pitch, *l2 = l1 + job.in_pitch;
+		const uint32_t a = *(const uint32_t *)(l1 + 2 * x), b = *(const uint32_t *)(l2 + 2 * x);
+		tl = job.curve[(a & 0xffffu) >> 2]; tr = job.curve[a >> 18]; bl = job.curve[(b & 0xffffu) >> 2]; br = job.curve[b >> 18];
+	}
+	int r, g1, g2, bb;
+	switch (job.xstride) {
+	case 0: r = tl; g1 = tr; g2 = bl; bb = br; break;
+	case 1: g1 = tl; r = tr; bb = bl; g2 = br; break;
+	case 3: bb = tl; g1 = tr; g2 = bl; r = br; break;
+	default: g1 = tl; bb = tr; r = bl; g2 = br; break;
+	}
+	const int mid = 1 << (job.shift - 1), g = (g1 + g2) >> 1;
+	const int v = job.tail_from == 0 ? g : (job.tail_from == 1 ? ((r - g) >> 1) + mid : (job.tail_from == 2 ? ((bb - g) >> 1) + mid : (g1 - g2 + 2 * mid) >> 1));
+	return (uint32_t)(uint16_t)v;
 }
 
 struct FwdYuvJob {
@@ -380,7 +411,10 @@ __device__ __forceinline__ void fwd_plane_tile(const FwdPlaneJob *jobs, int nch)
 			const int y = row_start + j, dw = c0 - 2 + d;    // dword index within the plane row
 			va[k] = 0;
 			if (i < ROWS * (TW + 4) && y < H && dw >= 0 && dw < HW) {
-				if (PACKED && job.layout == 7) {
+				if (PACKED && job.layout >= 10) {
+					const int yy = y < job.display_height ? y : job.display_height - 1;
+					va[k] = bayer_plane_sample(job, yy, 2 * dw) | (bayer_plane_sample(job, yy, 2 * dw + 1) << 16);
+				} else if (PACKED && job.layout == 7) {
 					const int yy = y < job.display_height ? y : job.display_height - 1;
 					const uint16_t *row = (const uint16_t *)job.in + (size_t)yy * job.in_pitch;
 					va[k] = rgb16_to_yuv_sample(row, job.xstride, job.tail_from, job.shift, 2 * dw) | (rgb16_to_yuv_sample(row, job.xstride, job.tail_from, job.shift, 2 * dw + 1) << 16);

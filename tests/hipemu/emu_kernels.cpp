@@ -336,6 +336,24 @@ void emu_unpack_byr4(const uint16_t *in, int in_pitch_words, int width, int heig
 	hipemu::launch(dim3((width + NTHREADS - 1) / NTHREADS, height, 1), dim3(NTHREADS), [&] { k_unpack_byr4(&job); });
 }
 
+// Bayer level 1 without the planes: k_fwd_packed16 computing every component plane in its loader (FwdPlaneJob::layout 10 BYR4 / 11 BYR5), as
+// EncodeBatch::fill_jobs sets it up.  width / height: the component planes (coded height); quant[c*4+b], out[c*4+b].
+void emu_fwd_bayer(const void *in, int in_pitch_words, int width, int height, int display_height, int packed12, const uint16_t *curve, int order,
+                   const int *quant, int mpq, int16_t **out, int out_pitch)
+{
+	std::vector<FwdPlaneJob> jobs(4);
+	for (int c = 0; c < 4; c++) {
+		FwdPlaneJob &job = jobs[c];
+		memset(&job, 0, sizeof(job));
+		job.in = (const int16_t *)in; job.in_pitch = in_pitch_words; job.width = width; job.height = height; job.prescale = 0;
+		job.layout = packed12 ? 11 : 10; job.tail_from = c; job.xstride = order; job.shift = 12; job.display_height = display_height; job.curve = curve;
+		for (int b = 0; b < 4; b++) { job.out[b] = out[c * 4 + b]; job.q[b] = make_q(quant[c * 4 + b], mpq); }
+		job.out_pitch = out_pitch;
+	}
+	dim3 grid(((width / 2 + TW - 1) / TW) * 4, (height / 2 + TH - 1) / TH, 1);
+	hipemu::launch(grid, dim3(NTHREADS), [&] { k_fwd_packed16(jobs.data(), 4); });
+}
+
 // BYR5 input: the same kernel reading the packed 12-bit rows (BayerJob::packed12), as EncodeBatch::fill_jobs sets it up.
 void emu_unpack_byr5(const uint8_t *in, int width, int height, int display_height, int order, int16_t **out /*[4]*/, int out_pitch)
 {

@@ -714,6 +714,45 @@ def test_unpack_byr4_equals_oracle(w, h, dh):
         assert np.array_equal(got[c], want[c]), c
 
 
+@pytest.mark.parametrize("w,h,dh,packed12", [(40, 8, 8, 0), (304, 24, 21, 0), (48, 16, 13, 1), (304, 24, 24, 1)])
+def test_fwd_bayer_level1_without_planes(w, h, dh, packed12):
+    """Bayer level 1 straight from the mosaic (k_fwd_packed16, loader layouts 10 / 11: what the product runs) = the oracle's unpack (BYR4 through the log-90
+    curve, BYR5 without) + the oracle's plane transform of the four component planes; rows below the picture repeat the last row pair."""
+    rng = np.random.default_rng(w + h + packed12)
+    O = oracle()
+    pitch = (w // 2 + 7) // 8 * 8
+    planes = [np.zeros((h, w), np.int16) for _ in range(4)]
+    curve = np.zeros(1 << 14, np.uint16)
+    if packed12:
+        frame = rng.integers(0, 256, size=(dh, 6 * w), dtype=np.int64).astype(np.uint8)
+        O.orc_byr5_unpack_row.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 4
+        for r in range(h):
+            O.orc_byr5_unpack_row(frame[min(r, dh - 1)].ctypes.data_as(ctypes.c_void_p), w, *[p[r].ctypes.data_as(ctypes.c_void_p) for p in planes])
+        in_pitch = 3 * w
+    else:
+        frame = rng.integers(0, 65536, size=(2 * dh, 2 * w), dtype=np.int64).astype(np.uint16)
+        O.orc_byr4_log90_curve.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        O.orc_byr4_log90_curve(12, 14, curve.ctypes.data_as(ctypes.c_void_p))
+        O.orc_byr4_unpack_row.argtypes = [ctypes.c_void_p] * 2 + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 5
+        for r in range(h):
+            sr = min(r, dh - 1)
+            O.orc_byr4_unpack_row(frame[2 * sr].ctypes.data_as(ctypes.c_void_p), frame[2 * sr + 1].ctypes.data_as(ctypes.c_void_p), w, 12, 14,
+                                  curve.ctypes.data_as(ctypes.c_void_p), *[p[r].ctypes.data_as(ctypes.c_void_p) for p in planes])
+        in_pitch = 2 * w
+    quant = [1, 24, 24, 12, 1, 36, 36, 18, 1, 36, 36, 18, 1, 48, 48, 24]
+    outs = [np.zeros((h // 2, pitch), np.int16) for _ in range(16)]
+    ptrs = (c_i16p * 16)(*[p16(o) for o in outs])
+    E = emu()
+    E.emu_fwd_bayer.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    E.emu_fwd_bayer(frame.ctypes.data_as(ctypes.c_void_p), in_pitch, w, h, dh, packed12, curve.ctypes.data_as(ctypes.c_void_p), 0, iarr(quant), 2, ptrs, pitch)
+    for c in range(4):
+        want = [np.zeros((h // 2, pitch), np.int16) for _ in range(4)]
+        bands = (c_i16p * 4)(*[p16(o) for o in want])
+        O.orc_fwd_spatial(p16(planes[c]), w, w, h, 0, iarr(quant[4 * c: 4 * c + 4]), 2, bands, pitch)
+        for b in range(4):
+            assert np.array_equal(outs[4 * c + b][:, : w // 2], want[b][:, : w // 2]), (c, b)
+
+
 @pytest.mark.parametrize("w,h,dh", [(40, 8, 8), (300, 24, 21)])
 def test_unpack_byr5_equals_oracle(w, h, dh):
     """k_unpack_byr4 on BYR5 input (12-bit samples: runs of high bytes, then low nibbles; no curve) = oracle restatement of ConvertBYR5ToFrame16s (pinned
