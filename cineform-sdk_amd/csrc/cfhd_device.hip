@@ -532,7 +532,7 @@ int EncodeBatch::launch_forward()
 		dim3 grid(((plan_.width / 2 + dev::TW - 1) / dev::TW) * nch, (plan_.height / 2 + dev::TH - 1) / dev::TH, act);
 		dev::k_fwd_packed16<<<grid, dev::NTHREADS, 0, st>>>(j.l1, nch);
 	} else if (plan_.pixel_kind == PIX_BYR4 || plan_.pixel_kind == PIX_BYR5) {
-		dev::k_unpack_byr4<<<dim3((plan_.width + dev::NTHREADS - 1) / dev::NTHREADS, plan_.height, act), dev::NTHREADS, 0, st>>>(j.bayer);
+		dev::k_unpack_byr4<<<dim3((plan_.width / 2 + dev::NTHREADS - 1) / dev::NTHREADS, plan_.height, act), dev::NTHREADS, 0, st>>>(j.bayer);      // two quads per thread
 		dim3 grid((plan_.width / 2 + dev::TW - 1) / dev::TW, (plan_.height / 2 + dev::TH - 1) / dev::TH, act * nch);
 		dev::k_fwd_plane<<<grid, dev::NTHREADS, 0, st>>>(j.l1);
 	} else if (strip_forward_packed16()) {

@@ -2184,34 +2184,45 @@ __global__ void __launch_bounds__(NTHREADS) k_unpack_byr4(const BayerJob *jobs)
 	__shared__ BayerJob s_job;
 	stage_job(&s_job, &jobs[blockIdx.z]);
 	const BayerJob &job = s_job;
-	const int x = blockIdx.x * NTHREADS + threadIdx.x, row = blockIdx.y;
+	// two quads per thread: 8-byte loads of both mosaic rows, 4-byte stores into the four planes (plane widths are multiples of 8)
+	const int x = 2 * (int)(blockIdx.x * NTHREADS + threadIdx.x), row = blockIdx.y;
 	if (x >= job.width || row >= job.height) return;
 	const int srow = row < job.display_height ? row : job.display_height - 1;
-	int tl, tr, bl, br;
+	int tl[2], tr[2], bl[2], br[2];
 	if (job.packed12) {
 		const uint8_t *base = (const uint8_t *)job.in + (size_t)srow * job.width * 6, *nib = base + (size_t)job.width * 4;
-		int v[4];
 #pragma unroll
-		for (int k = 0; k < 4; k++) { const int s = k * job.width + x; v[k] = ((int)base[s] << 4) | ((nib[s >> 1] >> (4 * (s & 1))) & 15); }
-		tl = v[0]; tr = v[1]; bl = v[2]; br = v[3];      // the four runs in the order of a row pair's photosites
+		for (int q = 0; q < 2; q++) {
+			int v[4];
+#pragma unroll
+			for (int k = 0; k < 4; k++) { const int s = k * job.width + x + q; v[k] = ((int)base[s] << 4) | ((nib[s >> 1] >> (4 * (s & 1))) & 15); }
+			tl[q] = v[0]; tr[q] = v[1]; bl[q] = v[2]; br[q] = v[3];      // the four runs in the order of a row pair's photosites
+		}
 	} else {
 		const uint16_t *l1 = job.in + (size_t)(2 * srow) * job.in_pitch, *l2 = l1 + job.in_pitch;
-		const uint32_t a = *(const uint32_t *)(l1 + 2 * x), b = *(const uint32_t *)(l2 + 2 * x);      // (left, right) photosites of the two rows
-		tl = job.curve[(a & 0xffffu) >> 2]; tr = job.curve[a >> 18]; bl = job.curve[(b & 0xffffu) >> 2]; br = job.curve[b >> 18];
+		const uint2 a = *(const uint2 *)(l1 + 2 * x), b = *(const uint2 *)(l2 + 2 * x);      // (left, right) photosites of the two rows, two quads
+		tl[0] = job.curve[(a.x & 0xffffu) >> 2]; tr[0] = job.curve[a.x >> 18]; bl[0] = job.curve[(b.x & 0xffffu) >> 2]; br[0] = job.curve[b.x >> 18];
+		tl[1] = job.curve[(a.y & 0xffffu) >> 2]; tr[1] = job.curve[a.y >> 18]; bl[1] = job.curve[(b.y & 0xffffu) >> 2]; br[1] = job.curve[b.y >> 18];
 	}
-	int r, g1, g2, bb;
-	switch (job.order) {
-	case 0: r = tl; g1 = tr; g2 = bl; bb = br; break;
-	case 1: g1 = tl; r = tr; bb = bl; g2 = br; break;
-	case 3: bb = tl; g1 = tr; g2 = bl; r = br; break;
-	default: g1 = tl; bb = tr; r = bl; g2 = br; break;
+	const int mid = 1 << (job.precision - 1);
+	int o0[2], o1[2], o2[2], o3[2];
+#pragma unroll
+	for (int q = 0; q < 2; q++) {
+		int r, g1, g2, bb;
+		switch (job.order) {
+		case 0: r = tl[q]; g1 = tr[q]; g2 = bl[q]; bb = br[q]; break;
+		case 1: g1 = tl[q]; r = tr[q]; bb = bl[q]; g2 = br[q]; break;
+		case 3: bb = tl[q]; g1 = tr[q]; g2 = bl[q]; r = br[q]; break;
+		default: g1 = tl[q]; bb = tr[q]; r = bl[q]; g2 = br[q]; break;
+		}
+		const int g = (g1 + g2) >> 1;
+		o0[q] = g; o1[q] = ((r - g) >> 1) + mid; o2[q] = ((bb - g) >> 1) + mid; o3[q] = (g1 - g2 + 2 * mid) >> 1;
 	}
-	const int mid = 1 << (job.precision - 1), g = (g1 + g2) >> 1;
 	const size_t o = (size_t)row * job.out_pitch + x;
-	job.out[0][o] = (int16_t)g;
-	job.out[1][o] = (int16_t)(((r - g) >> 1) + mid);
-	job.out[2][o] = (int16_t)(((bb - g) >> 1) + mid);
-	job.out[3][o] = (int16_t)((g1 - g2 + 2 * mid) >> 1);
+	*(uint32_t *)(job.out[0] + o) = pack16(o0[0], o0[1]);
+	*(uint32_t *)(job.out[1] + o) = pack16(o1[0], o1[1]);
+	*(uint32_t *)(job.out[2] + o) = pack16(o2[0], o2[1]);
+	*(uint32_t *)(job.out[3] + o) = pack16(o3[0], o3[1]);
 }
 
 // =============================================================================================

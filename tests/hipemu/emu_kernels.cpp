@@ -333,7 +333,7 @@ void emu_unpack_byr4(const uint16_t *in, int in_pitch_words, int width, int heig
 	job.in = in; job.in_pitch = in_pitch_words; job.width = width; job.height = height; job.display_height = display_height;
 	job.curve = curve; job.order = order; job.precision = precision; job.out_pitch = out_pitch;
 	for (int c = 0; c < 4; c++) job.out[c] = out[c];
-	hipemu::launch(dim3((width + NTHREADS - 1) / NTHREADS, height, 1), dim3(NTHREADS), [&] { k_unpack_byr4(&job); });
+	hipemu::launch(dim3((width / 2 + NTHREADS - 1) / NTHREADS, height, 1), dim3(NTHREADS), [&] { k_unpack_byr4(&job); });
 }
 
 // Bayer level 1 without the planes: k_fwd_packed16 computing every component plane in its loader (FwdPlaneJob::layout 10 BYR4 / 11 BYR5), as
@@ -362,7 +362,7 @@ void emu_unpack_byr5(const uint8_t *in, int width, int height, int display_heigh
 	job.in = (const uint16_t *)in; job.in_pitch = width * 3; job.width = width; job.height = height; job.display_height = display_height;
 	job.order = order; job.precision = 12; job.out_pitch = out_pitch; job.packed12 = 1;
 	for (int c = 0; c < 4; c++) job.out[c] = out[c];
-	hipemu::launch(dim3((width + NTHREADS - 1) / NTHREADS, height, 1), dim3(NTHREADS), [&] { k_unpack_byr4(&job); });
+	hipemu::launch(dim3((width / 2 + NTHREADS - 1) / NTHREADS, height, 1), dim3(NTHREADS), [&] { k_unpack_byr4(&job); });
 }
 
 void emu_fwd_yuv422(const uint8_t *in, int in_pitch, int width, int height, int display_height, int uyvy, int shift,
