@@ -290,7 +290,8 @@ def measure(workload, steps, warmup, batch, unique, threads, rank, world, barrie
     TILES = "k_dec_tiles+k_dec_undiff" if wl["flags"] & 1 else "k_dec_tiles"
     old_dec = os.environ.get("CFHD_AMD_DEC") in ("par", "lane")
     DEC = [("k_dec_bands_par", 13)] if old_dec else [("k_dec_plan+k_dec_index", 15), ("k_dec_chain", 16), (TILES, 17)]
-    KERNELS = [(FWD1, 0), (PF2, 1), (PF3, 2), ("k_ent_count", 8), ("k_ent_scan", 9), ("k_ent_layout", 10), ("k_ent_emit", 11)]
+    COUNT1 = "k_ent_count[L1 bands, beside the L2 / L3 transforms]"      # the level-1 bands are counted on a second stream while levels 2 and 3 are transformed
+    KERNELS = [(FWD1, 0), (PF2, 1), (PF3, 2), (COUNT1, 18), ("k_ent_count", 8), ("k_ent_scan", 9), ("k_ent_layout", 10), ("k_ent_emit", 11)]
     if wl["mode"] == 0:
         KERNELS += [("k_dec_parse", 12)] + DEC + [("k_dec_lowpass", 14), (PI3, 5), (PI2, 4), (INV1, 3)]
     kms = {name: 0.0 for name, _ in KERNELS}; stage = [0.0] * 4; total_bytes = 0
@@ -331,6 +332,10 @@ def measure(workload, steps, warmup, batch, unique, threads, rank, world, barrie
         coded = (S - S // 64) * 2                        # bytes of the entropy-coded bands (everything but the LL3 bands)
         algo = {FWD1: P + 2 * S, PF2: S, PF3: S // 4,                               # 12 441 600 B per 1080p 4:2:2 frame
                 "k_ent_count": coded, "k_ent_emit": coded // 2 + sample_bytes}          # emit reads the bit strings k_ent_count leaves (8 bytes per nonzero coefficient, about one in eight), not the pyramid
+        if kms.get(COUNT1, 0.0) > 0.0:                   # the count is split: its level-1 part (three quarters of the coefficients) and the rest, each with its own bytes and time
+            algo[COUNT1] = S * 3 // 4 * 2; algo["k_ent_count"] = coded - S * 3 // 4 * 2
+        else:
+            kms.pop(COUNT1, None)
         if wl["mode"] == 0:
             algo.update({PI3: S // 4, PI2: S, INV1: 2 * S + P})
             if old_dec: algo["k_dec_bands_par"] = sample_bytes + coded

@@ -376,6 +376,8 @@ int EncodeBatch::prepare_entropy(size_t sample_cap)
 {
 	int rc = ent_.prepare(plan_, n_, d_coeff_, plan_.coeff_elems, sample_cap, stream_);
 	ent_ready_ = rc == 0;
+	// the level-1 bands can be counted while levels 2 and 3 are still being transformed (CFHD_AMD_COUNT_SPLIT=0: everything behind level 3, one launch)
+	{ const char *e = getenv("CFHD_AMD_COUNT_SPLIT"); if (ent_ready_ && !(e && e[0] == '0')) ent_.set_level1_event(evl_[0]); }
 	return rc;
 }
 

@@ -29,10 +29,14 @@ public:
 	bool needs_peak_table(int i) const { return plan_.interlaced && h_sizes_[n_ + i] != 0; }     // (the flags are only cleared and written for interlaced plans)
 	size_t sample_cap() const { return cap_; }
 	int total_segments() const { return total_segs_; }
-	// HIP-event time of kernel k of the last launch() (0 k_ent_count, 1 k_ent_scan, 2 k_ent_layout, 3 k_ent_emit); valid once the stream was synchronised
+	// HIP-event time of kernel k of the last launch() (0 k_ent_count -- when the level-1 bands are counted on the second stream: the launches on the main stream
+	// only --, 1 k_ent_scan, 2 k_ent_layout, 3 k_ent_emit, 4 the level-1 part of k_ent_count on the second stream, 0 when there is none); valid once the stream was synchronised
 	float kernel_ms(int k);
 	// Events of the last launch() on the encoder's stream: every sample's header, size fields and raw lowpass bands are in place
 	// (k_ent_layout done) / the samples are complete (k_ent_emit done).  A consumer on another stream can parse behind the first.
+	// Optional: the event behind the level-1 transform of the frames about to be coded (on the stream given to prepare()).  With it launch() counts the level-1
+	// bands on a stream of its own, beside the level-2 / level-3 transforms that are still queued in front of it on the main stream.
+	void set_level1_event(void *ev) { ev_level1_ = ev; }
 	void *headers_event() const { return ev_[3]; }
 	void *samples_event() const { return ev_[4]; }
 private:
@@ -49,6 +53,7 @@ private:
 	uint8_t *d_tmpl_ = nullptr, *h_tmpl_ = nullptr;
 	bool dirty_ = true;
 	void *ev_[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; bool timed_ = false;
+	bool split_ = false; void *ev_level1_ = nullptr, *stream2_ = nullptr, *ev2_[3] = {nullptr, nullptr, nullptr};      // the level-1 part of k_ent_count on its own stream
 	int16_t *d_coeffs_ = nullptr; size_t coeff_stride_ = 0;
 };
 

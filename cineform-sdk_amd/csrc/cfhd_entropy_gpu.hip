@@ -31,6 +31,8 @@ void GpuEntropyEncoder::release()
 	if (h_tmpl_) (void)hipHostFree(h_tmpl_);
 	if (host_->frames) { (void)hipHostFree(host_->frames); host_->frames = nullptr; }
 	for (void *&e : ev_) if (e) { (void)hipEventDestroy((hipEvent_t)e); e = nullptr; }
+	for (void *&e : ev2_) if (e) { (void)hipEventDestroy((hipEvent_t)e); e = nullptr; }
+	if (stream2_) { (void)hipStreamDestroy((hipStream_t)stream2_); stream2_ = nullptr; }
 	timed_ = false;
 	d_samples_ = h_samples_ = nullptr; d_sizes_ = h_sizes_ = nullptr; d_tables_ = d_bands_ = d_segband_ = d_segs_ = d_bandstate_ = d_frames_ = d_tokens_ = nullptr;
 	d_tmpl_ = h_tmpl_ = nullptr; n_ = 0;
@@ -79,6 +81,8 @@ int GpuEntropyEncoder::prepare(const FramePlan &plan, int nframes, int16_t *d_co
 	HIPCHK(hipHostMalloc((void **)&host_->frames, n_ * sizeof(dev::EntFrameJob), hipHostMallocPortable));
 	for (int f = 0; f < n_; f++) { SampleHeaderInfo h = hdr0; h.frame_number = (uint32_t)f + 1; if ((rc = set_frame_header(f, h))) return rc; }
 	for (void *&e : ev_) HIPCHK(hipEventCreate((hipEvent_t *)&e));
+	for (void *&e : ev2_) HIPCHK(hipEventCreate((hipEvent_t *)&e));
+	HIPCHK(hipStreamCreateWithFlags((hipStream_t *)&stream2_, hipStreamNonBlocking));
 	return 0;
 }
 
@@ -106,10 +110,28 @@ int GpuEntropyEncoder::launch()
 	const dev::EntBatchGeom geom = { total_segs_ / n_, nbands_, coeff_stride_ };
 	const int act = active_frames(), total_segs = total_segs_ / n_ * act;      // frames 0 .. act-1 (set_active)
 	(void)hipGetLastError();
-	if (plan_.interlaced) HIPCHK(hipMemsetAsync(d_sizes_ + n_, 0, sizeof(uint32_t) * n_, st));
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[0], st));
-	dev::k_ent_count<<<(total_segs + dev::ENT_WAVES * dev::ENT_COUNT_SEGS - 1) / (dev::ENT_WAVES * dev::ENT_COUNT_SEGS), dev::ENT_THREADS, 0, st>>>((const dev::EntSegJob *)d_segband_, geom, total_segs, (dev::EntSegState *)d_segs_, T,
-	                                                                                                    d_sizes_ + n_, (uint32_t *)d_tokens_, []{ const char *e = getenv("CFHD_AMD_COUNT_PROBE"); return e ? atoi(e) : 0; }());
+	const int count_probe = []{ const char *e = getenv("CFHD_AMD_COUNT_PROBE"); return e ? atoi(e) : 0; }();
+	auto count_range = [&](hipStream_t s, int lo, int n) {
+		const int total = n * act;
+		dev::k_ent_count<<<(total + dev::ENT_WAVES - 1) / dev::ENT_WAVES, dev::ENT_THREADS, 0, s>>>((const dev::EntSegJob *)d_segband_, geom, total, (dev::EntSegState *)d_segs_, T,
+		                                                                                          d_sizes_ + n_, (uint32_t *)d_tokens_, lo, n, count_probe);
+	};
+	split_ = ev_level1_ && stream2_ && !host_->jobs.ranges_l1.empty() && act >= 8;      // (a single frame gains nothing from six launches instead of one)
+	// the peak flags are raised by the difference-coded band only, a level-1 band: cleared on the stream that counts it
+	if (plan_.interlaced && !split_) HIPCHK(hipMemsetAsync(d_sizes_ + n_, 0, sizeof(uint32_t) * n_, st));
+	if (split_) {
+		// the level-1 bands on the second stream as soon as the level-1 transform is done; the bands of levels 2 and 3 here, behind their transforms; the scan waits for both
+		hipStream_t s2 = (hipStream_t)stream2_;
+		HIPCHK(hipStreamWaitEvent(s2, (hipEvent_t)ev_level1_, 0));
+		if (plan_.interlaced) HIPCHK(hipMemsetAsync(d_sizes_ + n_, 0, sizeof(uint32_t) * n_, s2));
+		HIPCHK(hipEventRecord((hipEvent_t)ev2_[0], s2));
+		for (const auto &r : host_->jobs.ranges_l1) count_range(s2, r.first, r.second);
+		HIPCHK(hipEventRecord((hipEvent_t)ev2_[1], s2));
+		for (const auto &r : host_->jobs.ranges_rest) count_range(st, r.first, r.second);
+		HIPCHK(hipEventRecord((hipEvent_t)ev2_[2], st));
+		HIPCHK(hipStreamWaitEvent(st, (hipEvent_t)ev2_[1], 0));
+	} else count_range(st, 0, total_segs_ / n_);
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[1], st));
 	dev::k_ent_scan<<<nbands_ * act, dev::ENT_THREADS, 0, st>>>((const dev::EntBandJob *)d_bands_, (dev::EntSegState *)d_segs_, (dev::EntBandState *)d_bandstate_, T);
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[2], st));
@@ -129,7 +151,13 @@ int GpuEntropyEncoder::launch()
 float GpuEntropyEncoder::kernel_ms(int k)
 {
 	float ms = 0;
-	if (!timed_ || k < 0 || k > 3 || hipEventElapsedTime(&ms, (hipEvent_t)ev_[k], (hipEvent_t)ev_[k + 1]) != hipSuccess) { (void)hipGetLastError(); return 0; }
+	if (!timed_ || k < 0 || k > 4) return 0;
+	if (k == 4) {                                        // the level-1 part of k_ent_count on the second stream (it runs beside the level-2 / level-3 transforms: its own events)
+		if (!split_ || hipEventElapsedTime(&ms, (hipEvent_t)ev2_[0], (hipEvent_t)ev2_[1]) != hipSuccess) { (void)hipGetLastError(); return 0; }
+		return ms;
+	}
+	void *end = (k == 0 && split_) ? ev2_[2] : ev_[k + 1];      // (the main stream's own launches, not its wait for the second stream)
+	if (hipEventElapsedTime(&ms, (hipEvent_t)ev_[k], (hipEvent_t)end) != hipSuccess) { (void)hipGetLastError(); return 0; }
 	return ms;
 }
 

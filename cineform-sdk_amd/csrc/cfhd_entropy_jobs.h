@@ -216,12 +216,14 @@ struct EntHostJobs {
 	std::vector<dev::EntSegJob> segjobs;
 	std::vector<int> band_of_hole;      // template hole -> band job of frame 0 (-1 for lowpass holes)
 	int nbands = 0;                     // coded bands per frame
+	// segment ranges [first, count) inside one frame's table: the level-1 bands (final once the level-1 transform has run) and everything else
+	std::vector<std::pair<int, int>> ranges_l1, ranges_rest;
 };
 
 inline bool ent_build_band_jobs(const FramePlan &plan, const SampleTemplate &t0, int nframes, int16_t *coeffs, size_t stride, EntHostJobs *out)
 {
 	if ((int)t0.holes.size() > dev::ENT_MAX_HOLES || (int)t0.patches.size() > kEntMaxPatches) return false;
-	out->bands.clear(); out->segjobs.clear();
+	out->bands.clear(); out->segjobs.clear(); out->ranges_l1.clear(); out->ranges_rest.clear();
 	out->band_of_hole.assign(t0.holes.size(), -1);
 	for (int f = 0; f < nframes; f++) {
 		int16_t *base = coeffs + (size_t)f * stride;
@@ -234,7 +236,11 @@ inline bool ent_build_band_jobs(const FramePlan &plan, const SampleTemplate &t0,
 			j.nseg = (j.n + dev::ENT_SEG - 1) / dev::ENT_SEG; j.seg_base = (int)out->segjobs.size();
 			j.frame = f; j.hole = (int)h;
 			j.table = plan.interlaced && hole.level == 0 && hole.band == 2;      // subband 8 of the channel (cfhd_bitstream.cpp walk_sample)
-			if (f == 0) out->band_of_hole[h] = (int)out->bands.size();
+			if (f == 0) {
+				out->band_of_hole[h] = (int)out->bands.size();
+				std::vector<std::pair<int, int>> &r = hole.level == 0 ? out->ranges_l1 : out->ranges_rest;
+				if (!r.empty() && r.back().first + r.back().second == j.seg_base) r.back().second += j.nseg; else r.push_back({ j.seg_base, j.nseg });
+			}
 			for (int s = 0; s < j.nseg; s++) out->segjobs.push_back(dev::EntSegJob{ j.coeffs, j.n, s * dev::ENT_SEG, (int)out->bands.size(), j.table });
 			out->bands.push_back(j);
 		}

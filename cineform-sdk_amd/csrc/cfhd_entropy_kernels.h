@@ -283,22 +283,28 @@ __device__ __forceinline__ void ent_count_segment(int seg, const EntSegJob &job,
 // (1.33 ms either way) -- the kernel moves 4.2 GB in and 0.7 GB out, 0.81 ms of it are the loads at 5.2 TB/s: it is at the memory system's pace, not
 // waiting on latency.  Kept at 1.
 enum { ENT_COUNT_SEGS = 1 };
+// range_lo / range_n: the launch covers segments range_lo .. range_lo + range_n - 1 of every frame's table (0 / segs_per_frame: all of them); total_segs
+// = frames x range_n.  The level-1 bands -- three quarters of the coefficients, final when the level-1 transform is done -- are counted on a second stream
+// beside the level-2 / level-3 transforms (GpuEntropyEncoder::launch).
 __global__ void __launch_bounds__(ENT_THREADS) k_ent_count(const EntSegJob *seg_jobs, EntBatchGeom geom, int total_segs, EntSegState *segs, const EntTables *tables,
-                                                            uint32_t *peak_flags, uint32_t *tokens, int probe = 0 /* timing experiments: 1 behind the loads, 2 behind the compaction, 4 no token stores */)
+                                                            uint32_t *peak_flags, uint32_t *tokens, int range_lo, int range_n,
+                                                            int probe = 0 /* timing experiments: 1 behind the loads, 2 behind the compaction, 4 no token stores */)
 {
 	__shared__ uint32_t s_tok_all[ENT_WAVES][ENT_SEG];       // the segment's tokens: local raster index << 16 | value (16 bits); every coefficient may be one
 	const int lane = wave_lane();
 	const int wave = wave_uniform((int)(threadIdx.x >> 6));
-	const int seg0 = wave_uniform(((int)blockIdx.x * ENT_WAVES + wave) * ENT_COUNT_SEGS);
-	if (seg0 >= total_segs) return;                      // whole wave
+	const int idx0 = wave_uniform(((int)blockIdx.x * ENT_WAVES + wave) * ENT_COUNT_SEGS);
+	if (idx0 >= total_segs) return;                      // whole wave
+	const int seg0 = (idx0 / range_n) * geom.segs_per_frame + range_lo + idx0 % range_n;      // (ENT_COUNT_SEGS == 1: one index, one segment)
+	static_assert(ENT_COUNT_SEGS == 1, "the range mapping takes one segment per wave");
 	EntSegJob job[ENT_COUNT_SEGS]; int frame[ENT_COUNT_SEGS];
 	uint32_t w[ENT_COUNT_SEGS][ENT_SEG / 128];
 #pragma unroll
 	for (int k = 0; k < ENT_COUNT_SEGS; k++)
-		if (seg0 + k < total_segs) { job[k] = ent_seg_job(seg_jobs, geom, seg0 + k, &frame[k]); ent_load_segment(job[k], lane, w[k]); }
+		if (idx0 + k < total_segs) { job[k] = ent_seg_job(seg_jobs, geom, seg0 + k, &frame[k]); ent_load_segment(job[k], lane, w[k]); }
 #pragma unroll
 	for (int k = 0; k < ENT_COUNT_SEGS; k++)
-		if (seg0 + k < total_segs) {
+		if (idx0 + k < total_segs) {
 			ent_count_segment(seg0 + k, job[k], frame[k], w[k], lane, s_tok_all[wave], segs, tables, peak_flags, tokens, probe);
 			CFHD_WAVE_SYNC();                                 // the next segment reuses the token window
 		}

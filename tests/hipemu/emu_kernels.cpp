@@ -534,7 +534,7 @@ extern "C" long emu_entropy_encode2(int width, int height, int pixel_kind, int q
 	const int nseg = (int)jobs.segjobs.size(), nb = (int)jobs.bands.size();
 	const dev::EntBatchGeom geom = { nseg, nb, 0 };
 	std::vector<uint32_t> tokens((size_t)nseg * dev::ENT_TOK_STRIDE, 0xdeadbeefu);       // k_ent_count's token lists for k_ent_emit
-	hipemu::launch(dim3((nseg + dev::ENT_WAVES * dev::ENT_COUNT_SEGS - 1) / (dev::ENT_WAVES * dev::ENT_COUNT_SEGS)), dim3(dev::ENT_THREADS), [&] { dev::k_ent_count(jobs.segjobs.data(), geom, nseg, segs.data(), tables, &peak_flag, tokens.data()); });
+	hipemu::launch(dim3((nseg + dev::ENT_WAVES * dev::ENT_COUNT_SEGS - 1) / (dev::ENT_WAVES * dev::ENT_COUNT_SEGS)), dim3(dev::ENT_THREADS), [&] { dev::k_ent_count(jobs.segjobs.data(), geom, nseg, segs.data(), tables, &peak_flag, tokens.data(), 0, nseg); });
 	hipemu::launch(dim3(nb), dim3(dev::ENT_THREADS), [&] { dev::k_ent_scan(jobs.bands.data(), segs.data(), bstate.data(), tables); });
 	hipemu::launch(dim3(1, 3), dim3(dev::ENT_THREADS), [&] { dev::k_ent_layout(&fj, jobs.bands.data(), segs.data(), bstate.data(), tables); });
 	hipemu::launch(dim3((nseg + dev::ENT_WAVES * dev::ENT_EMIT_SEGS - 1) / (dev::ENT_WAVES * dev::ENT_EMIT_SEGS)), dim3(dev::ENT_THREADS), [&] { dev::k_ent_emit(nseg, segs.data(), tables, tokens.data()); });
