@@ -791,7 +791,10 @@ __global__ void __launch_bounds__(DX_THREADS) k_dec_reindex(const DxBandJob *job
 }
 
 // Tiles of the [slot][frame] job table: tile_cum[s] = tiles in front of slot s (all frames), tiles_per_band[s] = tiles of one band of slot s.
-struct DxTilePlan { int nslots, nframes; uint32_t cum[40]; uint32_t per_band[40]; uint32_t total; };
+// Tiles are numbered position by position: position p holds the tiles of band slot slot_of[p] for every frame (cum[p] tiles lie in front of it, per_band[p] per
+// band).  The positions of the level-2 and level-3 bands come first (tiles 0 .. split - 1), those of the level-1 bands behind them, so that a launch over
+// [first, total) can decode one group while the inverse transforms of the other run (GpuEntropyDecoder::launch_dx).
+struct DxTilePlan { int nslots, nframes; uint32_t cum[40]; uint32_t per_band[40]; uint32_t total, first, split; uint8_t slot_of[40]; };
 
 enum : uint32_t { DX_TILE_EMPTY = 0xFFFFFFFFu };
 
@@ -802,7 +805,7 @@ __device__ __forceinline__ void dx_tile_of(const DxTilePlan &plan, uint32_t t, i
 	const uint32_t r = t - plan.cum[slot], per = plan.per_band[slot];
 	const uint32_t f = r / per;
 	*ti = r - f * per;
-	*job = slot * plan.nframes + (int)f;
+	*job = (int)plan.slot_of[slot] * plan.nframes + (int)f;
 }
 
 // One thread per output tile: the 64-bit piece of payload that holds the code word at (or the last one in front of) the tile's first
@@ -862,7 +865,7 @@ __device__ __forceinline__ void dx_tile_meta(const DxTilePlan &plan, uint32_t t,
 	while (slot + 1 < plan.nslots && t >= plan.cum[slot + 1]) slot++;       // tiles come in increasing order: the slot only moves forward
 	const uint32_t r = t - plan.cum[slot], per = plan.per_band[slot];
 	const uint32_t f = r / per;
-	M.ti = r - f * per; M.j = slot * plan.nframes + (int)f;
+	M.ti = r - f * per; M.j = (int)plan.slot_of[slot] * plan.nframes + (int)f;
 	dx_vload(M.first_sub, tile_start + t);
 	dx_vload(M.job, jobs + M.j);
 	dx_vload(M.sum, sums + M.j);
@@ -904,7 +907,7 @@ __global__ void __launch_bounds__(DX_TILE_THREADS) k_dec_tiles(const DxBandJob *
 	for (int i = lane; i < DX_TILE_WORDS; i += 64) s_tile[i] = 0u;
 	__syncthreads();
 	const uint32_t gwave = (uint32_t)blockIdx.x * DX_TILE_WAVES + (uint32_t)wave, nwaves = (uint32_t)gridDim.x * DX_TILE_WAVES;
-	uint32_t t = gwave;
+	uint32_t t = plan.first + gwave;
 	if (t >= plan.total) return;
 	// software pipeline: tile t is decoded while the descriptors of tile t + 2 nwaves and the payload pieces of tile t + nwaves are on their way
 	int slot = 0;

@@ -117,6 +117,8 @@ private:
 	int16_t *d_coeff_ = nullptr, *h_coeff_ = nullptr;
 	uint8_t *d_out_ = nullptr, *h_out_ = nullptr; size_t frame_bytes_ = 0; int out_pitch_ = 0, out_rows_ = 0;
 	bool v210_ = false; uint8_t *d_tmp_ = nullptr; int tmp_pitch_ = 0; size_t tmp_frame_bytes_ = 0;      // v210 output: YU64 rows first, packed by k_yu64_to_v210
+	// levels 3 and 2 of the inverse transform on a stream of their own when the entropy decoder finished their bands ahead of the level-1 bands (GpuEntropyDecoder::levels23_event)
+	void *stream2_ = nullptr, *ev2_[3] = {nullptr, nullptr, nullptr}; bool inv_split_ = false;
 	int lowpass_kind_ = 0;             // the output format as the lowpass bias rule sees it (lowpass_bias(): RG24 of a 4:2:2 sample is not YU64 there)
 	bool rgb24_of_422_ = false;        // RG24 output of 4:2:2 samples: YU64 rows first, converted by k_yu64_to_rgb24 (the reference's route: 16-bit rows, then colour conversion)
 	std::vector<char> direct_;                      // frame i went straight to the caller's (registered) buffer: finish_frame has nothing to copy

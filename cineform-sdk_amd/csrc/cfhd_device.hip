@@ -621,6 +621,8 @@ void DecodeBatch::release()
 	if (ev1_) hipEventDestroy((hipEvent_t)ev1_);
 	for (int k = 0; k < 2; k++) if (evl_[k]) { hipEventDestroy((hipEvent_t)evl_[k]); evl_[k] = nullptr; }
 	if (evdep_) { hipEventDestroy((hipEvent_t)evdep_); evdep_ = nullptr; }
+	for (int k = 0; k < 3; k++) if (ev2_[k]) { hipEventDestroy((hipEvent_t)ev2_[k]); ev2_[k] = nullptr; }
+	if (stream2_) { hipStreamDestroy((hipStream_t)stream2_); stream2_ = nullptr; }
 	if (stream_) hipStreamDestroy((hipStream_t)stream_);
 	d_out_ = h_out_ = nullptr; d_coeff_ = h_coeff_ = nullptr; d_jobs_ = h_jobs_ = nullptr; stream_ = ev0_ = ev1_ = nullptr; n_ = 0;
 }
@@ -658,6 +660,8 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 	HIPCHK(hipEventCreate((hipEvent_t *)&ev0_));
 	HIPCHK(hipEventCreate((hipEvent_t *)&ev1_));
 	for (int k = 0; k < 2; k++) HIPCHK(hipEventCreate((hipEvent_t *)&evl_[k]));
+	for (int k = 0; k < 3; k++) HIPCHK(hipEventCreate((hipEvent_t *)&ev2_[k]));
+	HIPCHK(hipStreamCreateWithFlags((hipStream_t *)&stream2_, hipStreamNonBlocking));
 	out_rows_ = half ? plan.display_height / 2 : plan.display_height;
 	out_pitch_ = packed_frame_pitch(out_kind, half ? plan.width / 2 : plan.width);
 	frame_bytes_ = (size_t)out_pitch_ * out_rows_;
@@ -839,6 +843,7 @@ const char *DecodeBatch::level_kernel(int level) const
 int DecodeBatch::launch_inverse(uint32_t dither_seed)
 {
 	(void)hipSetDevice(device_);
+	const bool jobs_uploaded_now = jobs_dirty_;          // (the upload is queued on `st`: a second stream must not read the tables before it)
 	int rc = sync_jobs();
 	if (rc) return rc;
 	hipStream_t st = (hipStream_t)stream_;
@@ -847,6 +852,12 @@ int DecodeBatch::launch_inverse(uint32_t dither_seed)
 	DecJobs j = dec_jobs_at(d_jobs_, n_, nch);
 	(void)hipGetLastError();
 	timed_ = true;
+	// The entropy decoder may have finished the bands of levels 3 and 2 ahead of the level-1 bands (its tile pass over those is still queued on `st`): then the
+	// inverse transforms of levels 3 and 2 run on a second stream beside it, and level 1 waits for both.
+	void *l23 = ent_ready_ ? ent_.levels23_event() : nullptr;
+	inv_split_ = l23 && stream2_ && !jobs_uploaded_now;
+	hipStream_t sl = inv_split_ ? (hipStream_t)stream2_ : st;      // the stream of levels 3 and 2
+	if (inv_split_) { HIPCHK(hipStreamWaitEvent(sl, (hipEvent_t)l23, 0)); HIPCHK(hipEventRecord((hipEvent_t)ev2_[0], sl)); }
 	HIPCHK(hipEventRecord((hipEvent_t)ev0_, st));
 	for (int lv = 2; lv >= 1; lv--) {
 		const BandDesc &b = plan_.ch[0].band[lv][0];
@@ -855,14 +866,18 @@ int DecodeBatch::launch_inverse(uint32_t dither_seed)
 			const int n = act;
 			for_channel_runs(plan_, lv, [&](int c0, int nc, int glog, const BandDesc &cb) {
 				const int nstrips = (cb.height + dev::SRP - 1) / dev::SRP, per_wave = 64 >> glog, waves = ((n * nc + per_wave - 1) / per_wave) * nstrips;
-				dev::k_inv_plane_strip<<<(waves + 3) / 4, dev::NTHREADS, 0, st>>>(jobs, n, nch, c0, nc, glog, nstrips, cb.width, cb.height);
+				dev::k_inv_plane_strip<<<(waves + 3) / 4, dev::NTHREADS, 0, sl>>>(jobs, n, nch, c0, nc, glog, nstrips, cb.width, cb.height);
 			});
-			HIPCHK(hipEventRecord((hipEvent_t)evl_[2 - lv], st));
+			HIPCHK(hipEventRecord((hipEvent_t)(inv_split_ ? ev2_[3 - lv] : evl_[2 - lv]), sl));
 			continue;
 		}
 		dim3 grid((b.width + dev::ITW - 1) / dev::ITW, (b.height + dev::ITH - 1) / dev::ITH, act * nch);
-		dev::k_inv_plane<<<grid, dev::NTHREADS, 0, st>>>(jobs);
-		HIPCHK(hipEventRecord((hipEvent_t)evl_[2 - lv], st));
+		dev::k_inv_plane<<<grid, dev::NTHREADS, 0, sl>>>(jobs);
+		HIPCHK(hipEventRecord((hipEvent_t)(inv_split_ ? ev2_[3 - lv] : evl_[2 - lv]), sl));
+	}
+	if (inv_split_) {                                   // level 1 behind the level-1 tiles (stream order) and behind levels 3 and 2 (this wait)
+		HIPCHK(hipStreamWaitEvent(st, (hipEvent_t)ev2_[2], 0));
+		HIPCHK(hipEventRecord((hipEvent_t)evl_[1], st));
 	}
 	if (interlaced_ && !half_ && dec_planes16(out_kind_)) return -1;
 	if (half_ && is_packed16(out_kind_)) {
@@ -942,8 +957,13 @@ int DecodeBatch::wait()
 	if (!timed_) return 0;
 	timed_ = false;
 	if (hipEventElapsedTime(&ms, (hipEvent_t)ev0_, (hipEvent_t)ev1_) == hipSuccess) kernel_ms_ = ms;
-	if (hipEventElapsedTime(&ms, (hipEvent_t)ev0_, (hipEvent_t)evl_[0]) == hipSuccess) level_ms_[2] = ms;
-	if (hipEventElapsedTime(&ms, (hipEvent_t)evl_[0], (hipEvent_t)evl_[1]) == hipSuccess) level_ms_[1] = ms;
+	if (inv_split_) {                                   // levels 3 and 2 ran on the second stream: their own events
+		if (hipEventElapsedTime(&ms, (hipEvent_t)ev2_[0], (hipEvent_t)ev2_[1]) == hipSuccess) level_ms_[2] = ms;
+		if (hipEventElapsedTime(&ms, (hipEvent_t)ev2_[1], (hipEvent_t)ev2_[2]) == hipSuccess) level_ms_[1] = ms;
+	} else {
+		if (hipEventElapsedTime(&ms, (hipEvent_t)ev0_, (hipEvent_t)evl_[0]) == hipSuccess) level_ms_[2] = ms;
+		if (hipEventElapsedTime(&ms, (hipEvent_t)evl_[0], (hipEvent_t)evl_[1]) == hipSuccess) level_ms_[1] = ms;
+	}
 	if (hipEventElapsedTime(&ms, (hipEvent_t)evl_[1], (hipEvent_t)ev1_) == hipSuccess) level_ms_[0] = ms;
 	return 0;
 }

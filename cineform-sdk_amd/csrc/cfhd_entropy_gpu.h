@@ -84,6 +84,9 @@ public:
 	int check();                         // after the stream was synchronised: 0 when every band decoded cleanly
 	float kernel_ms(int k);              // last launch(): 0 k_dec_parse (device-resident samples only), 1 band decoder (all its kernels), 2 k_dec_lowpass, 3 k_dec_plan + k_dec_index, 4 k_dec_chain + k_dec_tile_index, 5 k_dec_tiles
 	bool chunk_indexed() const { return dx_; }
+	// Set by launch() when it decoded the bands of levels 2 and 3 (and the lowpass bands) first and recorded this event behind them: the inverse transforms of
+	// those levels may start there, beside the tile pass over the level-1 bands that is still queued on the decoder's stream.  Null otherwise.
+	void *levels23_event() const { return l23_split_ ? ev_l23_ : nullptr; }
 	int stats(uint32_t out[16]);         // CFHD_AMD_DX_STATS=1: convergence counters of the chunk index (see the .hip)
 private:
 	struct Host; Host *host_;
@@ -106,7 +109,8 @@ private:
 	uint32_t max_chunks_ = 0, *h_counters_ = nullptr; void *h_chunk_job_ = nullptr;
 	int grid_index_ = 0, grid_tiles_ = 0;
 	int device_ = 0;                       // the GPU prepare() ran on: every launch selects it for the calling thread
-	int launch_dx(bool device_jobs, int njobs, uint32_t host_chunks);
+	int launch_dx(bool device_jobs, int njobs, uint32_t host_chunks, int lowpass_jobs);
+	void *ev_l23_ = nullptr, *ev_low_ = nullptr; bool l23_split_ = false;      // ev_low_: in front of k_dec_lowpass when it runs between the two tile passes      // recorded behind the tiles of the level-2 / level-3 bands and the lowpass bands when the tile pass is split
 	void *ev_[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; bool timed_ = false;    // [4]: end of k_dec_parse when the band decoder waits for a second event behind it; [5], [6]: behind k_dec_index / k_dec_chain
 	bool parse_end_ = false;
 };

@@ -215,6 +215,8 @@ void GpuEntropyDecoder::release()
 	if (host_->flat_lows) { (void)hipHostFree(host_->flat_lows); host_->flat_lows = nullptr; }
 	if (host_->flat_diffs) { (void)hipHostFree(host_->flat_diffs); host_->flat_diffs = nullptr; }
 	for (void *&e : ev_) if (e) { (void)hipEventDestroy((hipEvent_t)e); e = nullptr; }
+	if (ev_l23_) { (void)hipEventDestroy((hipEvent_t)ev_l23_); ev_l23_ = nullptr; }
+	if (ev_low_) { (void)hipEventDestroy((hipEvent_t)ev_low_); ev_low_ = nullptr; }
 	timed_ = false;
 	d_samples_ = h_samples_ = nullptr; d_tables_ = d_bandjobs_ = d_lowjobs_ = d_plan_ = nullptr; d_errors_ = h_errors_ = nullptr; n_ = 0; ext_samples_ = nullptr;
 }
@@ -287,6 +289,8 @@ int GpuEntropyDecoder::prepare(const FramePlan &plan, int nframes, int16_t *d_co
 	}
 	host_->bands.assign(n_, {}); host_->lows.assign(n_, {}); host_->diffs.assign(n_, {}); host_->host_bytes.assign(n_, 0);
 	for (void *&e : ev_) HIPCHK(hipEventCreate((hipEvent_t *)&e));
+	HIPCHK(hipEventCreate((hipEvent_t *)&ev_l23_));
+	HIPCHK(hipEventCreate((hipEvent_t *)&ev_low_));
 	return 0;
 }
 
@@ -335,6 +339,7 @@ int GpuEntropyDecoder::launch()
 {
 	(void)hipSetDevice(device_);
 	hipStream_t st = (hipStream_t)stream_;
+	l23_split_ = false;
 	if (ext_samples_) {
 		// device-resident samples: parse on the GPU; the job tables have one row per band type (largest first), nframes wide
 		const int nch = plan_.num_channels, nb = n_ * nch * 9;
@@ -350,11 +355,12 @@ int GpuEntropyDecoder::launch()
 		ev_headers_ = ev_payloads_ = nullptr;
 		HIPCHK(hipEventRecord((hipEvent_t)ev_[1], st));
 		// few frames: the latency shape (the launch lasts as long as the longest band's serial steps); many: the throughput shape
-		if (dx_) { const int rc_dx = launch_dx(true, nb, 0u); if (rc_dx) return rc_dx; }
+		l23_split_ = false;
+		if (dx_) { const int rc_dx = launch_dx(true, nb, 0u, n_ * nch); if (rc_dx) return rc_dx; }
 		else if (n_ <= kLowLatencyFrames) dev::k_dec_bands_par_ll<<<nb, dev::DECP_LL_THREADS, 0, st>>>((const dev::DecBandJob *)d_bandjobs_, (const dev::DecTables *)d_tables_, d_errors_);
 		else dev::k_dec_bands_par<<<nb, dev::DECP_THREADS, 0, st>>>((const dev::DecBandJob *)d_bandjobs_, (const dev::DecTables *)d_tables_, d_errors_);
 		HIPCHK(hipEventRecord((hipEvent_t)ev_[2], st));
-		dev::k_dec_lowpass<<<dim3(8, (unsigned)(n_ * nch)), 256, 0, st>>>((const dev::DecLowpassJob *)d_lowjobs_);
+		if (!l23_split_) dev::k_dec_lowpass<<<dim3(8, (unsigned)(n_ * nch)), 256, 0, st>>>((const dev::DecLowpassJob *)d_lowjobs_);      // (split: launched between the two tile passes)
 		HIPCHK(hipGetLastError());
 		HIPCHK(hipEventRecord((hipEvent_t)ev_[3], st));
 		timed_ = true;
@@ -389,10 +395,11 @@ int GpuEntropyDecoder::launch()
 		(void)hipGetLastError();
 		HIPCHK(hipEventRecord((hipEvent_t)ev_[0], st));
 		HIPCHK(hipEventRecord((hipEvent_t)ev_[1], st));
-		int rc = launch_dx(false, nb, nchunks);
+		l23_split_ = false;
+		int rc = launch_dx(false, nb, nchunks, act * nch);
 		if (rc) return rc;
 		HIPCHK(hipEventRecord((hipEvent_t)ev_[2], st));
-		dev::k_dec_lowpass<<<dim3(8, (unsigned)(act * nch)), 256, 0, st>>>((const dev::DecLowpassJob *)d_lowjobs_);
+		if (!l23_split_) dev::k_dec_lowpass<<<dim3(8, (unsigned)(act * nch)), 256, 0, st>>>((const dev::DecLowpassJob *)d_lowjobs_);
 		HIPCHK(hipGetLastError());
 		HIPCHK(hipEventRecord((hipEvent_t)ev_[3], st));
 		timed_ = true;
@@ -432,7 +439,7 @@ int GpuEntropyDecoder::launch()
 }
 
 // The chunk-indexed decoder on the batch's stream.  device_jobs: the job table was filled by k_dec_parse (chunks are numbered on the device).
-int GpuEntropyDecoder::launch_dx(bool device_jobs, int njobs, uint32_t host_chunks)
+int GpuEntropyDecoder::launch_dx(bool device_jobs, int njobs, uint32_t host_chunks, int lowpass_jobs)
 {
 	hipStream_t st = (hipStream_t)stream_;
 	dev::DecBandJob *jobs = (dev::DecBandJob *)d_bandjobs_;
@@ -467,6 +474,24 @@ int GpuEntropyDecoder::launch_dx(bool device_jobs, int njobs, uint32_t host_chun
 	dev::k_dec_tile_index<<<(tp.total + dev::DX_THREADS - 1) / dev::DX_THREADS, dev::DX_THREADS, 0, st>>>(jobs, tp, (const uint32_t *)d_entries_, (const uint32_t *)d_chunk_base_, (const dev::DxBandSum *)d_sums_,
 	                                                                                                  (uint32_t *)d_tile_start_);
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[6], st));
+	// Many frames: the tiles of the level-2 / level-3 bands (a quarter of them) and the lowpass bands first, an event behind them, then the level-1 tiles -- the caller
+	// may run the inverse transforms of levels 3 and 2 on another stream beside the second launch (DecodeBatch::launch_inverse).  Off unless CFHD_AMD_TILES_SPLIT=1:
+	// measured in round 3 (1080p, 512 frames), the step does not get shorter (48.1 k fps either way) -- k_dec_tiles is bound by instruction issue and owns its CUs' LDS,
+	// the plane kernels beside it only stretch it from 1.67 to 2.25 ms.  (The same idea pays on the encoder side, where the kernel that shares the chip waits on memory.)
+	const char *split_env = getenv("CFHD_AMD_TILES_SPLIT");
+	l23_split_ = frames >= 8 && !skip_level1_ && tp.split > 0 && tp.split < tp.total && split_env && split_env[0] == '1';
+	if (l23_split_) {
+		dev::DxTilePlan ta = tp, tb = tp;
+		ta.total = tp.split; tb.first = tp.split;
+		int ga = g3, gb = g3;
+		if ((uint32_t)ga * dev::DX_TILE_WAVES > ta.total) ga = (int)((ta.total + dev::DX_TILE_WAVES - 1) / dev::DX_TILE_WAVES);
+		if ((uint32_t)gb * dev::DX_TILE_WAVES > tb.total - tb.first) gb = (int)((tb.total - tb.first + dev::DX_TILE_WAVES - 1) / dev::DX_TILE_WAVES);
+		dev::k_dec_tiles<<<ga < 1 ? 1 : ga, dev::DX_TILE_THREADS, 0, st>>>(jobs, ta, T, (const uint32_t *)d_entries_, (const uint32_t *)d_chunk_base_, (const dev::DxBandSum *)d_sums_, (const uint32_t *)d_tile_start_);
+		HIPCHK(hipEventRecord((hipEvent_t)ev_low_, st));
+		dev::k_dec_lowpass<<<dim3(8, (unsigned)lowpass_jobs), 256, 0, st>>>((const dev::DecLowpassJob *)d_lowjobs_);
+		HIPCHK(hipEventRecord((hipEvent_t)ev_l23_, st));
+		dev::k_dec_tiles<<<gb < 1 ? 1 : gb, dev::DX_TILE_THREADS, 0, st>>>(jobs, tb, T, (const uint32_t *)d_entries_, (const uint32_t *)d_chunk_base_, (const dev::DxBandSum *)d_sums_, (const uint32_t *)d_tile_start_);
+	} else
 	dev::k_dec_tiles<<<g3, dev::DX_TILE_THREADS, 0, st>>>(jobs, tp, T, (const uint32_t *)d_entries_, (const uint32_t *)d_chunk_base_, (const dev::DxBandSum *)d_sums_, (const uint32_t *)d_tile_start_);
 	if (interlaced_) dev::k_dec_undiff<<<dim3((unsigned)(frames * plan_.num_channels), dev::DXU_SPLIT), dev::DXU_THREADS, 0, st>>>((const dev::DecDiffJob *)d_diffjobs_, d_errors_);
 	HIPCHK(hipGetLastError());
@@ -494,6 +519,14 @@ float GpuEntropyDecoder::kernel_ms(int k)
 		if (!timed_ || !dx_ || k > 5) return 0;
 		void *a = k == 3 ? ev_[1] : (k == 4 ? ev_[5] : ev_[6]), *b = k == 3 ? ev_[5] : (k == 4 ? ev_[6] : ev_[2]);
 		if (hipEventElapsedTime(&ms, (hipEvent_t)a, (hipEvent_t)b) != hipSuccess) { (void)hipGetLastError(); return 0; }
+		if (k == 5 && l23_split_) {                          // k_dec_lowpass ran between the two tile passes: not part of k_dec_tiles
+			float low = 0;
+			if (hipEventElapsedTime(&low, (hipEvent_t)ev_low_, (hipEvent_t)ev_l23_) == hipSuccess) ms -= low; else (void)hipGetLastError();
+		}
+		return ms;
+	}
+	if (k == 2 && l23_split_ && timed_) {                        // k_dec_lowpass between the two tile passes
+		if (hipEventElapsedTime(&ms, (hipEvent_t)ev_low_, (hipEvent_t)ev_l23_) != hipSuccess) { (void)hipGetLastError(); return 0; }
 		return ms;
 	}
 	void *end = (k == 0 && parse_end_) ? ev_[4] : ev_[k + 1];      // the parser's own end, not the start of the band decoder that waited for the payloads

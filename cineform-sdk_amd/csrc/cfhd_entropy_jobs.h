@@ -380,18 +380,25 @@ inline dev::DxTilePlan dx_tile_plan(const FramePlan &plan, const dev::DecPlan &d
 	dev::DxTilePlan tp;
 	memset(&tp, 0, sizeof(tp));
 	tp.nslots = dp.bands_per_frame; tp.nframes = nframes;
-	for (int c = 0; c < plan.num_channels; c++)
-		for (int lv = 0; lv < kNumLevels; lv++)
-			for (int b = 1; b < 4; b++) {
-				const BandDesc &bd = plan.ch[c].band[lv][b];
-				const uint32_t n = (uint32_t)(bd.height * bd.pitch);
-				tp.per_band[dp.slot[c][lv][b]] = (skip_level1 && lv == 0) ? 0u : (n + dev::DX_TILE - 1) / dev::DX_TILE;
-			}
+	int pos = 0;
 	uint32_t cum = 0;
-	for (int s = 0; s < tp.nslots; s++) { tp.cum[s] = cum; cum += tp.per_band[s] * (uint32_t)nframes; }
-	tp.total = cum;
-	// slots without tiles must not be looked at by the kernel's division: give them one (unreachable) tile per band
-	for (int s = 0; s < tp.nslots; s++) if (!tp.per_band[s]) tp.per_band[s] = 1;
+	for (int group = 0; group < 2; group++) {            // positions: the bands of levels 2 and 3 first, the level-1 bands behind them
+		for (int c = 0; c < plan.num_channels; c++)
+			for (int lv = 0; lv < kNumLevels; lv++) {
+				if ((lv == 0) != (group == 1)) continue;
+				for (int b = 1; b < 4; b++) {
+					const BandDesc &bd = plan.ch[c].band[lv][b];
+					const uint32_t n = (uint32_t)(bd.height * bd.pitch);
+					const uint32_t per = (skip_level1 && lv == 0) ? 0u : (n + dev::DX_TILE - 1) / dev::DX_TILE;
+					tp.slot_of[pos] = (uint8_t)dp.slot[c][lv][b];
+					tp.cum[pos] = cum; cum += per * (uint32_t)nframes;
+					tp.per_band[pos] = per ? per : 1;      // positions without tiles must not be looked at by the kernel's division: one (unreachable) tile per band
+					pos++;
+				}
+			}
+		if (group == 0) tp.split = cum;
+	}
+	tp.total = cum; tp.first = 0;
 	return tp;
 }
 
