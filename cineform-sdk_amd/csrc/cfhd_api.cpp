@@ -932,7 +932,7 @@ CFHD_Error CFHD_GetOutputFormats(CFHD_DecoderRef ref, void *sample, size_t size,
 	auto add = [&](uint32_t f) { for (int i = 0; i < total; i++) if (fmts[i] == f) return; fmts[total++] = f; };      // (without a sample: every format once)
 	if (!known || ps.encoded_format == ENC_YUV422) { add(FMT_YUY2); add(FMT_2VUY); add(FMT_YU64); add(FMT_V210); add(FMT_RG24); }
 	if (!known || ps.encoded_format == ENC_RGB444) { add(FMT_RG48); add(FMT_RG24); add(FMT_BGRA); add(FMT_BGRa); add(FMT_R210); add(FMT_DPX0); add(FMT_AB10); add(FMT_AR10); add(FMT_RG30); add(FMT_B64A); }
-	if (!known || ps.encoded_format == ENC_RGBA4444) { add(FMT_B64A); add(FMT_BGRA); add(FMT_BGRa); }
+	if (!known || ps.encoded_format == ENC_RGBA4444) { add(FMT_B64A); add(FMT_BGRA); add(FMT_BGRa); add(FMT_RG48); }
 	int n = 0;
 	for (; n < total && n < len; n++) arr[n] = fmts[n];
 	if (count) *count = n;
@@ -1022,7 +1022,9 @@ CFHD_Error CFHD_PrepareToDecode(CFHD_DecoderRef ref, int, int, CFHD_PixelFormat 
 	if (kind == PIX_BYR4 || kind == PIX_BYR5 || kind == PIX_RG64 || (kind >= PIX_R210 && kind <= PIX_AR10 && !rgb10)) return ERR_BADFORMAT;     // encoder inputs only
 	// ... and RGB 4:4:4 samples to b64a (the RG48 words behind a constant alpha word 0xfff0, full resolution: what TestCFHD's b64a -> RGB 4:4:4 row decodes to)
 	const bool b64a_of_444 = kind == PIX_B64A && encf == ENC_RGB444 && !half;
-	if ((encf == ENC_RGB444) != (kind == PIX_RG48 || (rgb8 && !rgba8 && !rgb24_of_422) || rgb10 || b64a_of_444) || (encf == ENC_RGBA4444) != ((kind == PIX_B64A && !b64a_of_444) || rgba8)) return ERR_BADFORMAT;
+	// ... and RGBA 4:4:4:4 samples to RG48 (the RG48 route on planes G, R, B, the alpha plane left behind; full and half resolution)
+	const bool rg48_of_4444 = kind == PIX_RG48 && encf == ENC_RGBA4444;
+	if ((encf == ENC_RGB444) != ((kind == PIX_RG48 && !rg48_of_4444) || (rgb8 && !rgba8 && !rgb24_of_422) || rgb10 || b64a_of_444) || (encf == ENC_RGBA4444) != ((kind == PIX_B64A && !b64a_of_444) || rgba8 || rg48_of_4444)) return ERR_BADFORMAT;
 	if (kind == PIX_YU64 && d->header.width < 128) return ERR_BADFORMAT;      // (the tail-column rule of the 16-bit rows is restated for chroma bands of 16 columns and more)
 	bool ok;
 	plan_from_sample(d->header, kind, &d->plan, &ok);

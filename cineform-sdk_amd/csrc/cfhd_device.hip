@@ -92,6 +92,9 @@ static bool dec_rgb8(int out_kind) { return out_kind == PIX_RG24 || out_kind == 
 static int rgb8_bytes(int out_kind) { return out_kind == PIX_RG24 ? 3 : 4; }
 // ... and the 10-bit RGB words (r210, DPX0: big-endian; AB10, AR10: little-endian) through k_inv_rgb10 (orc_inv_spatial_to_rgb10)
 static bool dec_rgb10(int out_kind) { return out_kind >= PIX_R210 && out_kind <= PIX_AR10; }
+// planes of the sample that reach the output pixel: an RGBA 4:4:4:4 sample decoded to RG48 leaves its alpha plane behind (the reference's RG48 route on planes G, R, B;
+// pinned on eight geometries, tests/test_oracle_vs_ref.py)
+static int dec_out_channels(int out_kind, int nch) { return out_kind == PIX_RG48 && nch == 4 ? 3 : nch; }
 static bool dec_planes16(int out_kind) { return is_packed16(out_kind) || out_kind == PIX_YU64 || dec_rgb8(out_kind) || dec_rgb10(out_kind); }
 // position of plane c inside the pixel: 16-bit word, or byte for the 8-bit formats (planes G, R, B(, A) -> bytes 1, 2, 0(, 3))
 static int dec_word_of_channel(int out_kind, int c) { return dec_rgb10(out_kind) ? 0 : out_kind == PIX_YU64 ? (c == 0 ? 0 : (c == 1 ? 1 : 3)) : (dec_rgb8(out_kind) ? (c == 0 ? 1 : (c == 1 ? 2 : (c == 2 ? 0 : 3))) : packed_word_of_channel(out_kind, c)); }
@@ -649,7 +652,7 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 	const bool yuv_ok = (out_kind == PIX_YUY2 || out_kind == PIX_2VUY) && plan.encoded_format == ENC_YUV422;
 	// (b64a from an RGB 4:4:4 sample: the three colour planes and a constant alpha word, full resolution)
 	const bool rgb_ok = ((out_kind == PIX_RG48 && plan.encoded_format == ENC_RGB444) || (out_kind == PIX_B64A && plan.encoded_format == ENC_RGBA4444) ||
-	                     (out_kind == PIX_B64A && plan.encoded_format == ENC_RGB444 && !half)) &&
+	                     (out_kind == PIX_B64A && plan.encoded_format == ENC_RGB444 && !half) || (out_kind == PIX_RG48 && plan.encoded_format == ENC_RGBA4444)) &&
 	                    plan.ch[0].band[0][0].width >= 16;   // k_inv_packed16's tail-column rule assumes the reference's vector path
 	const bool yu64_ok = out_kind == PIX_YU64 && plan.encoded_format == ENC_YUV422 && !half && plan.ch[1].band[0][0].width >= 16;
 	const bool rgb8_ok = dec_rgb8(out_kind) && (plan.encoded_format == ENC_RGB444 || (plan.encoded_format == ENC_RGBA4444 && out_kind != PIX_RG24)) && !half && plan.ch[0].band[0][0].width >= 16 && plan.ch[0].band[0][0].width % 2 == 0;
@@ -687,7 +690,7 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 	HIPCHK(hipHostMalloc(&h_jobs_, jobs_bytes_, hipHostMallocPortable));
 	memset(h_jobs_, 0, jobs_bytes_);
 
-	const int nch = plan.num_channels;
+	const int nch = plan.num_channels, onch = dec_out_channels(out_kind, nch);
 	DecJobs j = dec_jobs_at(h_jobs_, n_, nch);
 	for (int i = 0; i < n_; i++) {
 		int16_t *base = d_coeff_ + (size_t)i * plan.coeff_elems;
@@ -703,20 +706,20 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 			}
 		if (half && is_packed16(out_kind)) {
 			dev::HalfPackedJob &hp = j.halfp[i];
-			for (int c = 0; c < nch; c++) { hp.ll[c] = base + plan.ch[c].band[0][0].offset; hp.word[c] = packed_word_of_channel(out_kind, c); }
-			hp.pitch = plan.ch[0].band[0][0].pitch; hp.width = plan.ch[0].band[0][0].width; hp.rows = out_rows_; hp.nch = nch;
+			for (int c = 0; c < onch; c++) { hp.ll[c] = base + plan.ch[c].band[0][0].offset; hp.word[c] = packed_word_of_channel(out_kind, c); }
+			hp.pitch = plan.ch[0].band[0][0].pitch; hp.width = plan.ch[0].band[0][0].width; hp.rows = out_rows_; hp.nch = onch;
 			hp.shift = 16 - plan.precision - 2; hp.alpha = out_kind == PIX_B64A;
 			hp.out = own_output ? (uint16_t *)(d_out_ + frame_bytes_ * i) : nullptr; hp.out_pitch = out_pitch_;
 		}
 		if (dec_planes16(out_kind)) {
-			for (int c = 0; c < nch; c++) {
-				dev::InvPlaneJob &p = j.l1[(size_t)i * nch + c];
+			for (int c = 0; c < onch; c++) {
+				dev::InvPlaneJob &p = j.l1[(size_t)i * onch + c];
 				for (int b = 0; b < 4; b++) p.band[b] = base + plan.ch[c].band[0][b].offset;
 				p.band_pitch = plan.ch[c].band[0][0].pitch;
 				p.width = plan.ch[c].band[0][0].width; p.height = plan.ch[c].band[0][0].height; p.descale = 0;
 				uint16_t *frame = own_output ? (uint16_t *)(job_out + job_frame_bytes * i) : nullptr;
 				p.out = frame ? dec_plane_out(frame, out_kind, c) : nullptr; p.out_pitch = dec_rgb8(out_kind) ? job_pitch : job_pitch / 2;
-				p.xstride = dec_stride_of_channel(out_kind, c, nch); p.precision = plan.precision; p.display_height = plan.display_height;
+				p.xstride = dec_stride_of_channel(out_kind, c, onch); p.precision = plan.precision; p.display_height = plan.display_height;
 				p.alpha = (out_kind == PIX_B64A || dec_rgb8(out_kind)) && c == 3;
 				p.alpha_const = out_kind == PIX_B64A && nch == 3 ? 0xfff0 : 0;
 				p.bytes8 = dec_rgb8(out_kind) ? (nch == 4 ? 2 : 1) : 0;        // 2: BGRA / BGRa of an RGBA 4:4:4:4 sample (alpha from the fourth plane, no dither)
@@ -809,8 +812,9 @@ bool DecodeBatch::strip_inverse_packed16() const
 	if (forced == 1 || (forced == 0 && frames_1080p_equivalent(plan_, act) < 12.0)) return false;
 	if (!is_packed16(out_kind_) || half_ || plan_.ch[0].band[0][0].width % 4 || (out_kind_ == PIX_B64A && plan_.num_channels == 3)) return false;
 	DecJobs j = dec_jobs_at(h_jobs_, n_, plan_.num_channels);
+	const int onch = dec_out_channels(out_kind_, plan_.num_channels);
 	for (int i = 0; i < n_; i++) {
-		const dev::InvPlaneJob &p = j.l1[(size_t)i * plan_.num_channels];
+		const dev::InvPlaneJob &p = j.l1[(size_t)i * onch];
 		const uintptr_t frame = (uintptr_t)((const uint16_t *)p.out - packed_word_of_channel(out_kind_, 0));
 		if ((frame & 15) || ((p.out_pitch * 2) & 15) || (p.band_pitch & 3)) return false;
 	}
@@ -889,13 +893,13 @@ int DecodeBatch::launch_inverse(uint32_t dither_seed)
 	} else if (strip_inverse_packed16()) {
 		const BandDesc &b = plan_.ch[0].band[0][0];
 		const int nseg = (b.width / 4 + dev::PSTEP - 1) / dev::PSTEP, nstrips = (b.height + dev::QSR - 1) / dev::QSR, waves = act * nseg * nstrips;
-		if (nch == 4) dev::k_inv_packed16_strip<4><<<(waves + 3) / 4, dev::NTHREADS, 0, st>>>(j.l1, act, nseg, nstrips);
+		if (dec_out_channels(out_kind_, nch) == 4) dev::k_inv_packed16_strip<4><<<(waves + 3) / 4, dev::NTHREADS, 0, st>>>(j.l1, act, nseg, nstrips);
 		else dev::k_inv_packed16_strip<3><<<(waves + 3) / 4, dev::NTHREADS, 0, st>>>(j.l1, act, nseg, nstrips);
 	} else if (dec_planes16(out_kind_)) {
 		const BandDesc &b = plan_.ch[0].band[0][0];
 		dim3 grid((b.width + dev::ITW - 1) / dev::ITW, (b.height + dev::ITH - 1) / dev::ITH, act);      // one workgroup per tile, all components
 		if (dec_rgb10(out_kind_)) dev::k_inv_rgb10<<<grid, dev::NTHREADS, 0, st>>>(j.l1);
-		else dev::k_inv_packed16<<<grid, dev::NTHREADS, 0, st>>>(j.l1, nch, dec_words_per_position(out_kind_, nch), dither_seed);
+		else { const int onch = dec_out_channels(out_kind_, nch); dev::k_inv_packed16<<<grid, dev::NTHREADS, 0, st>>>(j.l1, onch, dec_words_per_position(out_kind_, onch), dither_seed); }
 	} else if (interlaced_) {                           // (half resolution was served above: the level-1 lowpass planes need no inverse frame transform)
 		const BandDesc &b = plan_.ch[0].band[0][0];
 		if (frame_inverse_quads()) dev::k_inv_frame_yuv422_quad<<<dim3((b.width / 4 + dev::NTHREADS - 1) / dev::NTHREADS, b.height, act), dev::NTHREADS, 0, st>>>(j.yuv, dither_seed);

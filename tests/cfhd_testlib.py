@@ -3,7 +3,7 @@
 
 oracle/ is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it.
 """
-import ctypes, os, subprocess
+import ctypes, os, subprocess, sys
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -241,6 +241,20 @@ def ref_decode_sample(sample, width, height, pixfmt=PIX_YUY2, resolution=1, cpus
     return out[: d.pitch * d.height].copy(), d.pitch
 
 
+def ref_decode_sample_fresh_process(sample, width, height, pixfmt=PIX_YUY2, resolution=1, cpus=1):
+    """ref_decode_sample in a child process of its own.  For routes of the reference whose output depends on what the process did before (its half-resolution
+    RG48 decode of RGBA 4:4:4:4 samples returns other words in one colour component once `import torch` has run in the process -- uninitialised state
+    somewhere in its planar rows; a fresh process gives the same words every time)."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "sample"), "wb").write(sample)
+        code = ("import sys; sys.path.insert(0, %r); import numpy as np; from cfhd_testlib import *; "
+                "out, pitch = ref_decode_sample(open(%r, 'rb').read(), %d, %d, %d, %d, %d); open(%r, 'wb').write(out.tobytes()); print(pitch)"
+                % (os.path.join(ROOT, "tests"), os.path.join(d, "sample"), width, height, pixfmt, resolution, cpus, os.path.join(d, "out")))
+        pitch = int(subprocess.check_output([sys.executable, "-c", code]).split()[-1])
+        return np.frombuffer(open(os.path.join(d, "out"), "rb").read(), np.uint8).copy(), pitch
+
+
 def mask_volatile_metadata(sample):
     """Zero the bytes of a sample that legitimately differ between two encoders:
     the payloads of the GUID / DATE / TIME / TIMC tuples in the first metadata chunk
@@ -265,8 +279,11 @@ _product = None
 
 
 def product():
-    """libcfhd_amd.so: the CFHD_* C ABI and the cfhd_amd_batch_* extension (needs a GPU for anything that computes)."""
+    """libcfhd_amd.so: the CFHD_* C ABI and the cfhd_amd_batch_* extension (needs a GPU for anything that computes).
+    Inside `with emulated_product():` the same sources built over the CPU stand-in for the HIP runtime (product_emulated)."""
     global _product
+    if _use_emulated_product:
+        return product_emulated()
     if _product is None:
         if not os.path.exists(PRODUCT_SO):
             subprocess.check_call(["make", "-C", PRODUCT_DIR])
@@ -274,6 +291,51 @@ def product():
         declare_cfhd_api(L)
         _product = L
     return _product
+
+
+EMU_PRODUCT_SO = os.path.join(ROOT, "tests", "_build", "libcfhd_amd_hipemu.so")
+_emu_product = None
+_use_emulated_product = False
+
+
+def product_emulated():
+    """TEST INFRASTRUCTURE: the whole product library -- C ABI, batch front end, job builders, entropy drivers, unmodified kernel source -- compiled by g++ over
+    tests/hipemu/hip/hip_runtime.h (host memory, synchronous copies) and hip_emu.h (fibers for GPU threads); kernel launches rewritten by
+    tests/hipemu/translate_launches.py.  Lets the CPU suite drive the C ABI end to end at small frame sizes, in particular the job tables between the ABI and
+    the kernels, which the kernel-level emulation (emu()) never saw.  Never part of libcfhd_amd.so; the product has no CPU path."""
+    global _emu_product
+    if _emu_product is None:
+        csrc = os.path.join(PRODUCT_DIR, "csrc"); hipemu = os.path.join(ROOT, "tests", "hipemu")
+        gen = os.path.join(ROOT, "tests", "_build", "hipemu_product")
+        deps = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [os.path.join(hipemu, f) for f in ("hip_emu.h", "cfhd_gfx950.h", "emu_runtime.cpp", "translate_launches.py")] + [
+            os.path.join(hipemu, "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "cfhd_amd.h")]
+        if not os.path.exists(EMU_PRODUCT_SO) or any(os.path.getmtime(d) > os.path.getmtime(EMU_PRODUCT_SO) for d in deps):
+            os.makedirs(gen, exist_ok=True)
+            sys.path.insert(0, hipemu)
+            from translate_launches import translate
+            sys.path.pop(0)
+            srcs = [os.path.join(hipemu, "emu_runtime.cpp")] + [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith(".cpp")]
+            for f in sorted(os.listdir(csrc)):
+                if f.endswith(".hip"):
+                    out = os.path.join(gen, f[:-4] + ".%d.cpp" % os.getpid())
+                    with open(out, "w") as fh: fh.write("// generated from cineform-sdk_amd/csrc/%s by tests/hipemu/translate_launches.py -- test infrastructure\n" % f + translate(open(os.path.join(csrc, f)).read()))
+                    srcs.append(out)
+            _build_once(EMU_PRODUCT_SO, ["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + hipemu, "-I" + csrc, "-I" + os.path.join(ROOT, "include")] + srcs, deps)
+        L = ctypes.CDLL(EMU_PRODUCT_SO)
+        declare_cfhd_api(L)
+        _emu_product = L
+    return _emu_product
+
+
+class emulated_product:
+    """with emulated_product(): amd_encode_frames / amd_decode_sample / product() address the emulated build of the product library."""
+    def __enter__(self):
+        global _use_emulated_product
+        self.before = _use_emulated_product; _use_emulated_product = True
+        return product_emulated()
+    def __exit__(self, *a):
+        global _use_emulated_product
+        _use_emulated_product = self.before
 
 
 HOOKS_SO = os.path.join(ROOT, "tests", "_build", "libcfhd_hooks.so")

@@ -36,10 +36,37 @@ struct int2 { int x, y; };
 extern dim3 threadIdx, blockIdx, blockDim, gridDim;
 
 namespace hipemu {
-struct Fiber { ucontext_t ctx; char *stack; bool done; dim3 tid; unsigned lin; };
+// Switching fibers.  glibc's swapcontext() saves and restores the signal mask with a system call on every switch -- a barrier among 256 fibers is
+// hundreds of switches --, so on x86-64 a switch is done by hand: push the callee-saved registers, exchange the stack pointers, pop, return.  Other
+// architectures keep ucontext.
+#if defined(__x86_64__)
+#define HIPEMU_FAST_SWITCH 1
+struct Context { void *sp; };
+__attribute__((naked, noinline)) inline void switch_context(Context * /* save: rdi */, Context * /* load: rsi */)
+{
+	asm volatile("pushq %rbp\n\tpushq %rbx\n\tpushq %r12\n\tpushq %r13\n\tpushq %r14\n\tpushq %r15\n\t"
+	             "movq %rsp, (%rdi)\n\tmovq (%rsi), %rsp\n\t"
+	             "popq %r15\n\tpopq %r14\n\tpopq %r13\n\tpopq %r12\n\tpopq %rbx\n\tpopq %rbp\n\tret");
+}
+inline void make_context(Context *c, char *stack, size_t bytes, void (*entry)())
+{
+	// a frame switch_context() can "return" into: six register slots, the entry point as the return address; the entry function then sees the
+	// stack as after a call (rsp = 16 n + 8) and never returns (fiber_entry switches back to the scheduler)
+	uintptr_t top = ((uintptr_t)stack + bytes) & ~(uintptr_t)15;
+	void **sp = (void **)(top - 64);
+	for (int k = 0; k < 6; k++) sp[k] = nullptr;
+	sp[6] = (void *)entry; sp[7] = nullptr;
+	c->sp = sp;
+}
+#else
+#define HIPEMU_FAST_SWITCH 0
+struct Context { ucontext_t uc; };
+inline void switch_context(Context *save, Context *load) { swapcontext(&save->uc, &load->uc); }
+#endif
+struct Fiber { Context ctx; char *stack; bool done; dim3 tid; unsigned lin; };
 enum { kWave = 64, kMaxWaves = 16 };
 struct Sched {
-	ucontext_t main; Fiber *current; std::function<void()> *body;
+	Context main; Fiber *current; std::function<void()> *body;
 	// counting barriers: a barrier completes when every fiber of its scope that is still running has arrived (finished fibers
 	// drop out of the count), so scopes may execute different numbers of barriers (a wave that left early, wave-level exchanges)
 	unsigned block_live, block_arrived, block_gen;
@@ -51,7 +78,7 @@ inline void yield()
 {
 	Sched &s = sched();
 	Fiber *me = s.current;
-	swapcontext(&me->ctx, &s.main);
+	switch_context(&me->ctx, &s.main);
 	threadIdx = me->tid;
 }
 inline void fiber_entry()
@@ -60,7 +87,8 @@ inline void fiber_entry()
 	(*s.body)();
 	s.current->done = true;
 	s.block_live--; s.wave_live[s.current->lin / kWave]--;
-	swapcontext(&s.current->ctx, &s.main);
+	switch_context(&s.current->ctx, &s.main);
+	__builtin_trap();                                    // (a finished fiber is never resumed)
 }
 // barrier among the running fibers of this thread's wave (the hardware executes a wave in lock step; fibers need the rendezvous)
 inline void wave_sync()
@@ -131,7 +159,9 @@ void launch(dim3 grid, dim3 block, F body_fn)
 	std::function<void()> body = body_fn;
 	s.body = &body;
 	std::vector<Fiber> fibers(nthreads);
-	for (auto &f : fibers) f.stack = (char *)malloc(stack_bytes);
+	static std::vector<char *> stacks;                    // kept from launch to launch (launches never overlap: hip_runtime.h's launch_sync holds a lock, emu_kernels.cpp is single-threaded)
+	while (stacks.size() < nthreads) stacks.push_back((char *)malloc(stack_bytes));
+	for (unsigned t = 0; t < nthreads; t++) fibers[t].stack = stacks[t];
 	blockDim = block; gridDim = grid;
 	for (unsigned bz = 0; bz < grid.z; bz++)
 		for (unsigned by = 0; by < grid.y; by++)
@@ -145,9 +175,13 @@ void launch(dim3 grid, dim3 block, F body_fn)
 					Fiber &f = fibers[t];
 					f.done = false; f.lin = t;
 					f.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
-					getcontext(&f.ctx);
-					f.ctx.uc_stack.ss_sp = f.stack; f.ctx.uc_stack.ss_size = stack_bytes; f.ctx.uc_link = &s.main;
-					makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+#if HIPEMU_FAST_SWITCH
+					make_context(&f.ctx, f.stack, stack_bytes, fiber_entry);
+#else
+					getcontext(&f.ctx.uc);
+					f.ctx.uc.uc_stack.ss_sp = f.stack; f.ctx.uc.uc_stack.ss_size = stack_bytes; f.ctx.uc.uc_link = &s.main.uc;
+					makecontext(&f.ctx.uc, (void (*)())fiber_entry, 0);
+#endif
 				}
 				for (bool any = true; any;) {
 					any = false;
@@ -155,11 +189,10 @@ void launch(dim3 grid, dim3 block, F body_fn)
 						Fiber &f = fibers[t];
 						if (f.done) continue;
 						s.current = &f; threadIdx = f.tid;
-						swapcontext(&s.main, &f.ctx);
+						switch_context(&s.main, &f.ctx);
 						if (!f.done) any = true;
 					}
 				}
 			}
-	for (auto &f : fibers) free(f.stack);
 }
 }

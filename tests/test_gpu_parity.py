@@ -533,6 +533,36 @@ def test_rg30_is_ab10_under_another_name():
 
 
 @pytest.mark.parametrize("w,h", [(320, 240), (720, 480), (1920, 1080)])
+def test_rgba4444_decode_to_rg48_equals_reference_exactly(w, h):
+    """RGBA 4:4:4:4 samples decoded to RG48, full and half resolution: the RG48 route on planes G, R, B (alpha left behind) -- the oracle's exact reconstruction
+    (pinned on the reference on eight geometries: test_reference_rg48_decode_of_rgba4444_equals_oracle) and the reference decoder's own output, word for word."""
+    frames, pitch = qbist_frames(14, 1, w, h, PIX_B64A, alpha=1)
+    px = np.frombuffer(frames[0].tobytes(), dtype=np.uint16).reshape(h, pitch // 2).copy()
+    ramp = ((np.arange(h)[:, None] * 523 + np.arange(w)[None, :] * 97) % 65536).astype(np.uint16)
+    for word in (1, 2, 3):
+        px[:, word: w * 4: 4] = np.where(ramp > 60000, 65535, np.where(ramp < 4000, 0, px[:, word: w * 4: 4]))
+    sample = amd_encode_frames([px.reshape(-1).view(np.uint8).copy()], pitch, w, h, PIX_B64A, encoded=ENCODED_RGBA4444)[0]
+    plan = Plan(w, h, pixkind=PIXKIND["b64a"], enc=ENC["4444"])
+    deq = host_decode_pyramid(sample, plan)
+    got, gpitch, aw, ah = amd_decode_sample(sample, PIX_RG48)
+    assert (aw, ah) == (w, h)
+    mine = np.frombuffer(got.tobytes(), np.uint16).reshape(h, gpitch // 2)[:, : w * 3]
+    want = oracle_inverse_rgb48(plan, deq)[:h].reshape(h, w, 4)[:, :, :3].reshape(h, w * 3)
+    assert np.array_equal(mine, want), "%d words differ from the exact reconstruction" % (mine != want).sum()
+    rows = h if h % 8 == 0 else h - 8
+    for attempt in range(6):                            # (the reference's threaded decoder occasionally damages a frame)
+        dec, dpitch = ref_decode_sample(sample, w, h, PIX_RG48)
+        img = np.frombuffer(dec.tobytes(), np.uint16).reshape(h, dpitch // 2)[:, : w * 3]
+        if np.array_equal(img[:rows], mine[:rows]): break
+    assert np.array_equal(img[:rows], mine[:rows]), "%d words differ" % (img[:rows] != mine[:rows]).sum()
+    got, gpitch, aw, ah = amd_decode_sample(sample, PIX_RG48, resolution=2)
+    assert (aw, ah) == (w // 2, h // 2)
+    mine = np.frombuffer(got.tobytes(), np.uint16).reshape(h // 2, gpitch // 2)[:, : (w // 2) * 3]
+    half = oracle_half_resolution16(plan, deq)[: h // 2]                  # (its RG48 form takes planes G, R, B only)
+    assert np.array_equal(mine, half)
+
+
+@pytest.mark.parametrize("w,h", [(320, 240), (720, 480), (1920, 1080)])
 def test_rgb444_decode_to_b64a_equals_reference_exactly(w, h):
     """RGB 4:4:4 samples decoded to b64a (what TestCFHD's b64a -> RGB 4:4:4 row decodes to): word for word the reference decoder's output -- the RG48 words
     with the scalar-tail clamp in the last band column only, alpha word 0xfff0 (orc_inv_spatial_to_b64a_of_rgb444, pinned on eight geometries on the CPU)."""
@@ -774,9 +804,9 @@ def test_rgba8_encode_to_rgba4444_bitstream_identical(w, h, name):
         dec, dpitch = ref_decode_sample(mine[0], w, h, fmt)
         img = np.frombuffer(dec.tobytes(), np.uint8).reshape(h, dpitch)[sl, : w * 4]
         if all(np.array_equal(img[:, k::4], want[:, k::4]) for k in range(3)): break
-    assert all(np.array_equal(img[:, k::4], want[:, k::4]) for k in range(3))
+    assert all(np.array_equal(img[:, k::4], want[:, k::4]) for k in range(3)), "colour bytes: %s differ from the reference decoder's" % [int((img[:, k::4] != want[:, k::4]).sum()) for k in range(3)]
     a_ok = img[:, 3::4] == want[:, 3::4]
-    assert np.array_equal(img[:, 3::4][~a_ok], alt[~a_ok])
+    assert np.array_equal(img[:, 3::4][~a_ok], alt[~a_ok]), "alpha bytes: %d are neither the expanded nor the companded value" % int((img[:, 3::4][~a_ok] != alt[~a_ok]).sum())
     got, gpitch, aw, ah = amd_decode_sample(mine[0], PIX_B64A)
     assert (aw, ah) == (w, h)
     words = np.frombuffer(got.tobytes(), np.uint16).reshape(h, gpitch // 2)[:, : w * 4].reshape(h, w, 4)
@@ -935,7 +965,7 @@ def test_b64a_decode_equals_reference(w, h):
     dec_ref = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec_ref), None) == 0
     aw2 = ctypes.c_int(); ah2 = ctypes.c_int(); af2 = ctypes.c_uint32()
     sb = ctypes.create_string_buffer(sample, len(sample))
-    assert L.CFHD_PrepareToDecode(dec_ref, 0, 0, PIX_RG48, 1, 0, sb, 512, ctypes.byref(aw2), ctypes.byref(ah2), ctypes.byref(af2)) == 3
+    assert L.CFHD_PrepareToDecode(dec_ref, 0, 0, PIX_YUY2, 1, 0, sb, 512, ctypes.byref(aw2), ctypes.byref(ah2), ctypes.byref(af2)) == 3      # (RGBA -> 4:2:2 output: not built)
     L.CFHD_CloseDecoder(dec_ref)
 
 

@@ -339,6 +339,35 @@ def test_reference_b64a_decode_of_rgb444_equals_model(w, h, seed):
     assert (want[:, 1::4] == 0xfff0).any() and (want[:, 1::4] == 0).any() and (w in (64, 144) or (want[:, 1::4] == 65535).any())
 
 
+@pytest.mark.parametrize("w,h,seed", [(320, 240, 3), (336, 248, 9), (400, 120, 14), (720, 480, 5), (64, 64, 15), (1280, 720, 16), (1920, 1080, 7), (144, 96, 17)])
+def test_reference_rg48_decode_of_rgba4444_equals_oracle(w, h, seed):
+    """An RGBA 4:4:4:4 sample decoded to RG48: the reference runs its RG48 route (wavelet.c:4947 TransformInverseRGB444ToRGB48, oracle orc_inv_spatial_to_rgb48) on planes
+    G, R, B and leaves the alpha plane behind -- word for word, on eight geometries with ramps into both clips of every colour component; at half resolution the level-1 lowpass
+    planes << 2, saturated (frame.c:7256), exactly as for RGB 4:4:4 samples."""
+    frames, pitch = qbist_frames(seed, 1, w, h, PIX_B64A, alpha=1)
+    px = np.frombuffer(frames[0].tobytes(), dtype=np.uint16).reshape(h, pitch // 2).copy()
+    ramp = ((np.arange(h)[:, None] * 523 + np.arange(w)[None, :] * 97) % 65536).astype(np.uint16)
+    for word in (1, 2, 3):
+        px[:, word: w * 4: 4] = np.where(ramp > 60000, 65535, np.where(ramp < 4000, 0, px[:, word: w * 4: 4]))
+    sample = ref_encode_frames([px.reshape(-1).view(np.uint8).copy()], pitch, w, h, PIX_B64A, encoded=ENCODED_RGBA4444)[0]
+    plan = Plan(w, h, pixkind=PIXKIND["b64a"], enc=ENC["4444"])
+    deq = host_decode_pyramid(sample, plan)
+    want = oracle_inverse_rgb48(plan, deq)[:h].reshape(h, w, 4)[:, :, :3].reshape(h, w * 3)
+    rows = h if h % 8 == 0 else h - 8                   # (1080: the reference's encoder transforms whatever its heap holds below the picture, its decoder's last rows change from call to call -- test_reference_rgba8_decode_of_4444_equals_oracle; the other heights are multiples of 8)
+    for attempt in range(6):
+        dec, dpitch = ref_decode_sample(sample, w, h, PIX_RG48)
+        img = np.frombuffer(dec.tobytes(), dtype=np.uint16).reshape(h, dpitch // 2)[:, : w * 3]
+        if np.array_equal(img[:rows], want[:rows]): break
+    assert np.array_equal(img[:rows], want[:rows]), "%d words differ" % (img[:rows] != want[:rows]).sum()
+    assert (want == 0).any() and (w == 64 or (want == 0xfff0).any())
+    if w not in (320, 720, 1920): return                # (half resolution on three of the geometries: a child process each)
+    half = oracle_half_resolution16(plan, deq)[: h // 2]                  # (its RG48 form takes planes G, R, B only)
+    dec, dpitch = ref_decode_sample_fresh_process(sample, w, h, PIX_RG48, resolution=2)      # (in this process the reference's answer depends on what ran before: see there)
+    img = np.frombuffer(dec.tobytes(), dtype=np.uint16).reshape(-1, dpitch // 2)[: h // 2, : (w // 2) * 3]
+    hrows = h // 2 if h % 8 == 0 else h // 2 - 4
+    assert np.array_equal(img[:hrows], half[:hrows])
+
+
 @pytest.mark.parametrize("w,h", [(192, 96), (320, 240), (1920, 1080)])
 def test_reference_b64a_decode_equals_oracle(w, h):
     """Pins orc_inv_spatial_to_b64a: the reference decodes an RGBA 4:4:4:4 sample to b64a through its planar 16-bit rows
