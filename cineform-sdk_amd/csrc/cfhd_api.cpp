@@ -549,7 +549,8 @@ int decode_gather_slots() { static const int n = gather_slots("CFHD_AMD_DECODE_B
 
 void plan_from_sample(const ParsedSample &ps, int out_kind, FramePlan *plan, bool *ok)
 {
-	*ok = build_frame_plan(plan, ps.width, ps.display_height, out_kind, ps.encoded_format);
+	const int quad = ps.encoded_format == ENC_BAYER ? 2 : 1;      // (build_frame_plan takes the mosaic's size)
+	*ok = build_frame_plan(plan, quad * ps.width, quad * ps.display_height, out_kind, ps.encoded_format);
 	if (!*ok) return;
 	plan->precision = ps.precision;
 	// for outputs that convert YUV to RGB: 601 or 709 by the sample's colour space tag, always the computer-systems range -- probed on the reference decoder: a
@@ -933,6 +934,7 @@ CFHD_Error CFHD_GetOutputFormats(CFHD_DecoderRef ref, void *sample, size_t size,
 	if (!known || ps.encoded_format == ENC_YUV422) { add(FMT_YUY2); add(FMT_2VUY); add(FMT_YU64); add(FMT_V210); add(FMT_RG24); }
 	if (!known || ps.encoded_format == ENC_RGB444) { add(FMT_RG48); add(FMT_RG24); add(FMT_BGRA); add(FMT_BGRa); add(FMT_R210); add(FMT_DPX0); add(FMT_AB10); add(FMT_AR10); add(FMT_RG30); add(FMT_B64A); }
 	if (!known || ps.encoded_format == ENC_RGBA4444) { add(FMT_B64A); add(FMT_BGRA); add(FMT_BGRa); add(FMT_RG48); }
+	if (!known || ps.encoded_format == ENC_BAYER) add(FMT_BYR4);
 	int n = 0;
 	for (; n < total && n < len; n++) arr[n] = fmts[n];
 	if (count) *count = n;
@@ -998,7 +1000,7 @@ CFHD_Error CFHD_PrepareToDecode(CFHD_DecoderRef ref, int, int, CFHD_PixelFormat 
 	const bool half = resolution == 2;
 	const int encf = d->header.encoded_format;
 
-	if ((encf != ENC_YUV422 && encf != ENC_RGB444 && encf != ENC_RGBA4444) || d->header.transform_type != 0) return ERR_BADFORMAT;
+	if ((encf != ENC_YUV422 && encf != ENC_RGB444 && encf != ENC_RGBA4444 && encf != ENC_BAYER) || d->header.transform_type != 0) return ERR_BADFORMAT;
 	int kind = pixel_kind_of(fmt);
 	if (kind == PIX_NONE) return ERR_BADFORMAT;
 	// 4:2:2 samples decode to the packed 4:2:2 formats, RGB 4:4:4 samples to RG48 (wavelet.c:4947), RGBA 4:4:4:4 samples to b64a
@@ -1019,7 +1021,11 @@ CFHD_Error CFHD_PrepareToDecode(CFHD_DecoderRef ref, int, int, CFHD_PixelFormat 
 	if (rgb10 && (encf != ENC_RGB444 || half || d->header.width < 32)) return ERR_BADFORMAT;
 	// ... and 4:2:2 samples to v210 (the YU64 words >> 6, three to a 32-bit word: DecodeBatch / k_yu64_to_v210; widths of whole six-pixel groups)
 	if (kind == PIX_V210 && (encf != ENC_YUV422 || half || d->header.width % 6 || d->header.width < 128)) return ERR_BADFORMAT;
-	if (kind == PIX_BYR4 || kind == PIX_BYR5 || kind == PIX_RG64 || (kind >= PIX_R210 && kind <= PIX_AR10 && !rgb10)) return ERR_BADFORMAT;     // encoder inputs only
+	// ... and Bayer samples to BYR4: the raw mosaic, no demosaic (the four planes as 16-bit rows, recombined per quad and sent through the reference's linear-restore
+	// table: DecodeBatch / k_bayer_to_byr4; full resolution)
+	const bool byr4_of_bayer = kind == PIX_BYR4 && encf == ENC_BAYER && !half && d->header.width >= 32;
+	if ((encf == ENC_BAYER) != byr4_of_bayer) return ERR_BADFORMAT;
+	if ((kind == PIX_BYR4 && !byr4_of_bayer) || kind == PIX_BYR5 || kind == PIX_RG64 || (kind >= PIX_R210 && kind <= PIX_AR10 && !rgb10)) return ERR_BADFORMAT;     // encoder inputs only
 	// ... and RGB 4:4:4 samples to b64a (the RG48 words behind a constant alpha word 0xfff0, full resolution: what TestCFHD's b64a -> RGB 4:4:4 row decodes to)
 	const bool b64a_of_444 = kind == PIX_B64A && encf == ENC_RGB444 && !half;
 	// ... and RGBA 4:4:4:4 samples to RG48 (the RG48 route on planes G, R, B, the alpha plane left behind; full and half resolution)
@@ -1031,8 +1037,9 @@ CFHD_Error CFHD_PrepareToDecode(CFHD_DecoderRef ref, int, int, CFHD_PixelFormat 
 	if (!ok) return ERR_BADSAMPLE;
 	d->out_format = fmt; d->out_kind = kind; d->prepared = true; d->batch_ready = false; d->half = half;
 	d->service = nullptr;                                 // (looked up again for the new geometry by the next concurrent decode)
-	if (aw) *aw = half ? d->header.width / 2 : d->header.width;
-	if (ah) *ah = half ? d->header.display_height / 2 : d->header.display_height;
+	const int quad = encf == ENC_BAYER ? 2 : 1;         // (Bayer samples carry the size of their component planes)
+	if (aw) *aw = half ? d->header.width / 2 : quad * d->header.width;
+	if (ah) *ah = half ? d->header.display_height / 2 : quad * d->header.display_height;
 	if (af) *af = fmt;
 	return ERR_OKAY;
 }
@@ -1154,7 +1161,8 @@ CFHD_Error CFHD_DecodeSample(CFHD_DecoderRef ref, void *sample, size_t size, voi
 	if (d->gop) return decode_group_sample(d, s, size, out, pitch);
 	ParsedSample ps;
 	auto fail_zero = [&](int err) {                                               // decode failure zero-fills the output (decoder.c:11850-11859)
-		const int rowbytes = packed_frame_pitch(d->out_kind, d->half ? d->plan.width / 2 : d->plan.width), rows = d->half ? d->plan.display_height / 2 : d->plan.display_height;
+		const int quad = d->plan.encoded_format == ENC_BAYER ? 2 : 1;      // (the plan of a Bayer sample counts photosite quads)
+		const int rowbytes = packed_frame_pitch(d->out_kind, d->half ? d->plan.width / 2 : quad * d->plan.width), rows = d->half ? d->plan.display_height / 2 : quad * d->plan.display_height;
 		for (int r = 0; r < rows; r++) memset((uint8_t *)out + (ptrdiff_t)r * pitch, 0, (size_t)rowbytes);
 		return err;
 	};
@@ -1197,7 +1205,8 @@ CFHD_Error CFHD_DecodeSample(CFHD_DecoderRef ref, void *sample, size_t size, voi
 static CFHD_Error decode_on_handle(Decoder *d, const ParsedSample &ps, const uint8_t *s, size_t size, void *out, int32_t pitch, bool interlaced)
 {
 	auto fail_zero = [&](int err) {                                               // decode failure zero-fills the output (decoder.c:11850-11859)
-		const int rowbytes = packed_frame_pitch(d->out_kind, d->half ? d->plan.width / 2 : d->plan.width), rows = d->half ? d->plan.display_height / 2 : d->plan.display_height;
+		const int quad = d->plan.encoded_format == ENC_BAYER ? 2 : 1;      // (the plan of a Bayer sample counts photosite quads)
+		const int rowbytes = packed_frame_pitch(d->out_kind, d->half ? d->plan.width / 2 : quad * d->plan.width), rows = d->half ? d->plan.display_height / 2 : quad * d->plan.display_height;
 		for (int r = 0; r < rows; r++) memset((uint8_t *)out + (ptrdiff_t)r * pitch, 0, (size_t)rowbytes);
 		return err;
 	};

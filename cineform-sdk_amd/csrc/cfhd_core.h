@@ -118,6 +118,8 @@ int unit_device(int i, int ndevices, const char *pinned_env, const char *list_en
 // Default encode curve of the Bayer input path (log base 90 over 14-bit linear input, scaled to `precision` bits), frame.c:5219-5235.
 enum { kBayerCurveBits = 14 };
 void build_bayer_log90_curve(int precision, uint16_t *curve /* 1 << kBayerCurveBits entries */);
+// The decoder's way back for BYR4 output (decoder.c:10714 BYR4LinearRestore, log base 90): index = 16-bit value >> 2.
+void build_bayer_linear_restore_curve(uint16_t *curve /* 1 << kBayerCurveBits entries */);
 
 static inline int align_up(int x, int a) { return (x + a - 1) / a * a; }
 

@@ -120,6 +120,7 @@ private:
 	// levels 3 and 2 of the inverse transform on a stream of their own when the entropy decoder finished their bands ahead of the level-1 bands (GpuEntropyDecoder::levels23_event)
 	void *stream2_ = nullptr, *ev2_[3] = {nullptr, nullptr, nullptr}; bool inv_split_ = false;
 	int lowpass_kind_ = 0;             // the output format as the lowpass bias rule sees it (lowpass_bias(): RG24 of a 4:2:2 sample is not YU64 there)
+	bool byr4_ = false; uint16_t *d_restore_ = nullptr;   // BYR4 output of Bayer samples: the four planes as 16-bit words per quad first, turned into the mosaic by k_bayer_to_byr4 (linear-restore table in HBM)
 	bool rgb24_of_422_ = false;        // RG24 output of 4:2:2 samples: YU64 rows first, converted by k_yu64_to_rgb24 (the reference's route: 16-bit rows, then colour conversion)
 	std::vector<char> direct_;                      // frame i went straight to the caller's (registered) buffer: finish_frame has nothing to copy
 	void *d_jobs_ = nullptr, *h_jobs_ = nullptr; size_t jobs_bytes_ = 0;

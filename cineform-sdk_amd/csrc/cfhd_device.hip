@@ -94,7 +94,7 @@ static int rgb8_bytes(int out_kind) { return out_kind == PIX_RG24 ? 3 : 4; }
 static bool dec_rgb10(int out_kind) { return out_kind >= PIX_R210 && out_kind <= PIX_AR10; }
 // planes of the sample that reach the output pixel: an RGBA 4:4:4:4 sample decoded to RG48 leaves its alpha plane behind (the reference's RG48 route on planes G, R, B;
 // pinned on eight geometries, tests/test_oracle_vs_ref.py)
-static int dec_out_channels(int out_kind, int nch) { return out_kind == PIX_RG48 && nch == 4 ? 3 : nch; }
+static int dec_out_channels(int out_kind, const FramePlan &plan) { return out_kind == PIX_RG48 && plan.encoded_format == ENC_RGBA4444 ? 3 : plan.num_channels; }
 static bool dec_planes16(int out_kind) { return is_packed16(out_kind) || out_kind == PIX_YU64 || dec_rgb8(out_kind) || dec_rgb10(out_kind); }
 // position of plane c inside the pixel: 16-bit word, or byte for the 8-bit formats (planes G, R, B(, A) -> bytes 1, 2, 0(, 3))
 static int dec_word_of_channel(int out_kind, int c) { return dec_rgb10(out_kind) ? 0 : out_kind == PIX_YU64 ? (c == 0 ? 0 : (c == 1 ? 1 : 3)) : (dec_rgb8(out_kind) ? (c == 0 ? 1 : (c == 1 ? 2 : (c == 2 ? 0 : 3))) : packed_word_of_channel(out_kind, c)); }
@@ -615,6 +615,7 @@ void DecodeBatch::release()
 	ent_ready_ = false;
 	if (d_out_) hipFree(d_out_);
 	if (d_tmp_) { hipFree(d_tmp_); d_tmp_ = nullptr; }
+	if (d_restore_) { hipFree(d_restore_); d_restore_ = nullptr; }
 	if (h_out_) hipHostFree(h_out_);
 	if (d_coeff_) hipFree(d_coeff_);
 	if (h_coeff_) hipHostFree(h_coeff_);
@@ -647,12 +648,16 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 	lowpass_kind_ = out_kind;
 	rgb24_of_422_ = out_kind == PIX_RG24 && plan.encoded_format == ENC_YUV422;
 	if (rgb24_of_422_) { if (!own_output || half) { g_err = "RG24 output of 4:2:2 samples: full resolution"; return -2; } out_kind = PIX_YU64; }
-	const bool repack = v210_ || rgb24_of_422_;
+	// BYR4 output of Bayer samples (decoder.c:14738 + bayer.c:13233 GenerateBYR2): the four component planes as 16-bit rows -- the RG48 route with four planes,
+	// four words per photosite quad -- then k_bayer_to_byr4
+	byr4_ = out_kind == PIX_BYR4;
+	if (byr4_) { if (plan.encoded_format != ENC_BAYER || !own_output || half) { g_err = "BYR4 output: Bayer samples, full resolution"; return -2; } out_kind = PIX_RG48; }
+	const bool repack = v210_ || rgb24_of_422_ || byr4_;
 
 	const bool yuv_ok = (out_kind == PIX_YUY2 || out_kind == PIX_2VUY) && plan.encoded_format == ENC_YUV422;
 	// (b64a from an RGB 4:4:4 sample: the three colour planes and a constant alpha word, full resolution)
 	const bool rgb_ok = ((out_kind == PIX_RG48 && plan.encoded_format == ENC_RGB444) || (out_kind == PIX_B64A && plan.encoded_format == ENC_RGBA4444) ||
-	                     (out_kind == PIX_B64A && plan.encoded_format == ENC_RGB444 && !half) || (out_kind == PIX_RG48 && plan.encoded_format == ENC_RGBA4444)) &&
+	                     (out_kind == PIX_B64A && plan.encoded_format == ENC_RGB444 && !half) || (out_kind == PIX_RG48 && plan.encoded_format == ENC_RGBA4444) || byr4_) &&
 	                    plan.ch[0].band[0][0].width >= 16;   // k_inv_packed16's tail-column rule assumes the reference's vector path
 	const bool yu64_ok = out_kind == PIX_YU64 && plan.encoded_format == ENC_YUV422 && !half && plan.ch[1].band[0][0].width >= 16;
 	const bool rgb8_ok = dec_rgb8(out_kind) && (plan.encoded_format == ENC_RGB444 || (plan.encoded_format == ENC_RGBA4444 && out_kind != PIX_RG24)) && !half && plan.ch[0].band[0][0].width >= 16 && plan.ch[0].band[0][0].width % 2 == 0;
@@ -666,13 +671,20 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 	for (int k = 0; k < 3; k++) HIPCHK(hipEventCreate((hipEvent_t *)&ev2_[k]));
 	HIPCHK(hipStreamCreateWithFlags((hipStream_t *)&stream2_, hipStreamNonBlocking));
 	out_rows_ = half ? plan.display_height / 2 : plan.display_height;
-	out_pitch_ = packed_frame_pitch(out_kind, half ? plan.width / 2 : plan.width);
+	out_pitch_ = byr4_ ? plan.width * 8 : packed_frame_pitch(out_kind, half ? plan.width / 2 : plan.width);      // (BYR4: the scratch rows hold four words per quad)
 	frame_bytes_ = (size_t)out_pitch_ * out_rows_;
 	uint8_t *job_out = nullptr; size_t job_frame_bytes = frame_bytes_;      // where the last-level kernel writes frame i: the output, or the YU64 scratch of v210 output
 	if (repack) {
 		HIPCHK(hipMalloc((void **)&d_tmp_, frame_bytes_ * n_));
 		job_out = d_tmp_; tmp_pitch_ = out_pitch_; tmp_frame_bytes_ = frame_bytes_;
-		out_pitch_ = packed_frame_pitch(v210_ ? PIX_V210 : PIX_RG24, plan.width); frame_bytes_ = (size_t)out_pitch_ * out_rows_;
+		if (byr4_) {
+			out_rows_ = 2 * plan.display_height; out_pitch_ = packed_frame_pitch(PIX_BYR4, 2 * plan.width);      // (the plan counts quads)
+			std::vector<uint16_t> curve((size_t)1 << kBayerCurveBits);
+			build_bayer_linear_restore_curve(curve.data());
+			HIPCHK(hipMalloc((void **)&d_restore_, curve.size() * 2));
+			HIPCHK(hipMemcpy(d_restore_, curve.data(), curve.size() * 2, hipMemcpyHostToDevice));
+		} else out_pitch_ = packed_frame_pitch(v210_ ? PIX_V210 : PIX_RG24, plan.width);
+		frame_bytes_ = (size_t)out_pitch_ * out_rows_;
 	}
 	if (own_output) {
 		HIPCHK(hipMalloc((void **)&d_out_, frame_bytes_ * n_));
@@ -690,7 +702,7 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 	HIPCHK(hipHostMalloc(&h_jobs_, jobs_bytes_, hipHostMallocPortable));
 	memset(h_jobs_, 0, jobs_bytes_);
 
-	const int nch = plan.num_channels, onch = dec_out_channels(out_kind, nch);
+	const int nch = plan.num_channels, onch = dec_out_channels(out_kind, plan);
 	DecJobs j = dec_jobs_at(h_jobs_, n_, nch);
 	for (int i = 0; i < n_; i++) {
 		int16_t *base = d_coeff_ + (size_t)i * plan.coeff_elems;
@@ -810,9 +822,9 @@ bool DecodeBatch::strip_inverse_packed16() const
 	const int forced = shape_override("CFHD_AMD_INVERSE");
 	const int act = active_ > 0 && active_ < n_ ? active_ : n_;
 	if (forced == 1 || (forced == 0 && frames_1080p_equivalent(plan_, act) < 12.0)) return false;
-	if (!is_packed16(out_kind_) || half_ || plan_.ch[0].band[0][0].width % 4 || (out_kind_ == PIX_B64A && plan_.num_channels == 3)) return false;
+	if (!is_packed16(out_kind_) || half_ || plan_.ch[0].band[0][0].width % 4 || (out_kind_ == PIX_B64A && plan_.num_channels == 3) || byr4_) return false;      // (the strip kernel knows the RG48 and b64a pixels only)
 	DecJobs j = dec_jobs_at(h_jobs_, n_, plan_.num_channels);
-	const int onch = dec_out_channels(out_kind_, plan_.num_channels);
+	const int onch = dec_out_channels(out_kind_, plan_);
 	for (int i = 0; i < n_; i++) {
 		const dev::InvPlaneJob &p = j.l1[(size_t)i * onch];
 		const uintptr_t frame = (uintptr_t)((const uint16_t *)p.out - packed_word_of_channel(out_kind_, 0));
@@ -893,13 +905,13 @@ int DecodeBatch::launch_inverse(uint32_t dither_seed)
 	} else if (strip_inverse_packed16()) {
 		const BandDesc &b = plan_.ch[0].band[0][0];
 		const int nseg = (b.width / 4 + dev::PSTEP - 1) / dev::PSTEP, nstrips = (b.height + dev::QSR - 1) / dev::QSR, waves = act * nseg * nstrips;
-		if (dec_out_channels(out_kind_, nch) == 4) dev::k_inv_packed16_strip<4><<<(waves + 3) / 4, dev::NTHREADS, 0, st>>>(j.l1, act, nseg, nstrips);
+		if (dec_out_channels(out_kind_, plan_) == 4) dev::k_inv_packed16_strip<4><<<(waves + 3) / 4, dev::NTHREADS, 0, st>>>(j.l1, act, nseg, nstrips);
 		else dev::k_inv_packed16_strip<3><<<(waves + 3) / 4, dev::NTHREADS, 0, st>>>(j.l1, act, nseg, nstrips);
 	} else if (dec_planes16(out_kind_)) {
 		const BandDesc &b = plan_.ch[0].band[0][0];
 		dim3 grid((b.width + dev::ITW - 1) / dev::ITW, (b.height + dev::ITH - 1) / dev::ITH, act);      // one workgroup per tile, all components
 		if (dec_rgb10(out_kind_)) dev::k_inv_rgb10<<<grid, dev::NTHREADS, 0, st>>>(j.l1);
-		else { const int onch = dec_out_channels(out_kind_, nch); dev::k_inv_packed16<<<grid, dev::NTHREADS, 0, st>>>(j.l1, onch, dec_words_per_position(out_kind_, onch), dither_seed); }
+		else { const int onch = dec_out_channels(out_kind_, plan_); dev::k_inv_packed16<<<grid, dev::NTHREADS, 0, st>>>(j.l1, onch, dec_words_per_position(out_kind_, onch), dither_seed); }
 	} else if (interlaced_) {                           // (half resolution was served above: the level-1 lowpass planes need no inverse frame transform)
 		const BandDesc &b = plan_.ch[0].band[0][0];
 		if (frame_inverse_quads()) dev::k_inv_frame_yuv422_quad<<<dim3((b.width / 4 + dev::NTHREADS - 1) / dev::NTHREADS, b.height, act), dev::NTHREADS, 0, st>>>(j.yuv, dither_seed);
@@ -917,6 +929,11 @@ int DecodeBatch::launch_inverse(uint32_t dither_seed)
 		const int pairs = plan_.width / 2;
 		dev::k_yu64_to_rgb24<<<dim3((unsigned)((pairs + dev::NTHREADS - 1) / dev::NTHREADS), (unsigned)out_rows_, (unsigned)act), dev::NTHREADS, 0, st>>>(
 			(const uint16_t *)d_tmp_, tmp_pitch_ / 2, tmp_frame_bytes_ / 2, d_out_, out_pitch_, frame_bytes_, pairs, out_rows_, plan_.color_matrix, dither_seed);
+	}
+	if (byr4_) {
+		const int quads = plan_.width;
+		dev::k_bayer_to_byr4<<<dim3((unsigned)((quads + dev::NTHREADS - 1) / dev::NTHREADS), (unsigned)plan_.display_height, (unsigned)act), dev::NTHREADS, 0, st>>>(
+			(const uint16_t *)d_tmp_, tmp_pitch_ / 2, tmp_frame_bytes_ / 2, (uint16_t *)d_out_, out_pitch_ / 2, frame_bytes_ / 2, quads, d_restore_);
 	}
 	if (v210_) {
 		const int groups = plan_.width / 6;

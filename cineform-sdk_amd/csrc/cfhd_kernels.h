@@ -2311,5 +2311,24 @@ __global__ void __launch_bounds__(NTHREADS) k_yu64_to_rgb24(const uint16_t *yu64
 	}
 }
 
+// BYR4 output of Bayer samples (DecodeBatch): the four component planes arrive as the 16-bit words R-G, G, B-G, G1-G2 of one photosite quad (the RG48 route of
+// k_inv_packed16 with four planes = the reference's RawBayer16 rows) and leave as the quad's four samples -- r = ((rg - 32768) << 1) + g, b likewise,
+// g1 = g + (gd - 32768), g2 = g - (gd - 32768), clamped to 16 bits, each through the linear-restore table [x >> 2] (bayer.c:13233 GenerateBYR2 with
+// decoder.c:10714 BYR4LinearRestore; red-green phase: rows r g1 / g2 b).  One thread per quad: 8 bytes in, 2 x 4 bytes out, four gathers from a 32 KB table.
+__global__ void __launch_bounds__(NTHREADS) k_bayer_to_byr4(const uint16_t *raw, int in_pitch_words, size_t in_frame_words, uint16_t *out, int out_pitch_words, size_t out_frame_words,
+                                                            int quads, const uint16_t *curve)
+{
+	const int q = (int)(blockIdx.x * NTHREADS + threadIdx.x);
+	if (q >= quads) return;
+	const cfhd_u2 w = CFHD_LDG64(raw + (size_t)blockIdx.z * in_frame_words + (size_t)blockIdx.y * in_pitch_words + 4 * (size_t)q);
+	const int rg = (int)(w.x & 0xffffu), g = (int)(w.x >> 16), bg = (int)(w.y & 0xffffu), gd = (int)(w.y >> 16) - 32768;
+	int r = ((rg - 32768) << 1) + g, b = ((bg - 32768) << 1) + g, g1 = g + gd, g2 = g - gd;
+	r = r < 0 ? 0 : (r > 0xffff ? 0xffff : r); b = b < 0 ? 0 : (b > 0xffff ? 0xffff : b);
+	g1 = g1 < 0 ? 0 : (g1 > 0xffff ? 0xffff : g1); g2 = g2 < 0 ? 0 : (g2 > 0xffff ? 0xffff : g2);
+	uint16_t *o = out + (size_t)blockIdx.z * out_frame_words + (size_t)(2 * blockIdx.y) * out_pitch_words + 2 * (size_t)q;
+	*(uint32_t *)o = (uint32_t)curve[r >> 2] | ((uint32_t)curve[g1 >> 2] << 16);
+	*(uint32_t *)(o + out_pitch_words) = (uint32_t)curve[g2 >> 2] | ((uint32_t)curve[b >> 2] << 16);
+}
+
 } // namespace dev
 } // namespace cfhd

@@ -291,6 +291,24 @@ void build_bayer_log90_curve(int precision, uint16_t *curve)
 	}
 }
 
+// BYR4LinearRestore (decoder.c:10714-10783) for a sample without encode-curve metadata: log base 90 undone, 14-bit index -> 16-bit linear value;
+// log2lin() (Common/AVIExtendedHeader.h:148) evaluates pow() in double and returns float, the scaling by 65535 is a float product.
+void build_bayer_linear_restore_curve(uint16_t *curve)
+{
+	const volatile float base = 90.0f;
+	for (int j = 0; j < (1 << kBayerCurveBits); j++) {
+		volatile float i = (float)j / 16384.0f;
+		volatile double p = pow((double)base, (double)i);
+		volatile double num = p - 1.0;
+		volatile double den = (double)base - 1.0;
+		volatile double quot = num / den;
+		volatile float lin = (float)quot;
+		volatile float scaled = lin * 65535.0f;
+		int val = (int)scaled;
+		curve[j] = (uint16_t)(val < 0 ? 0 : (val > 65535 ? 65535 : val));
+	}
+}
+
 // ------------------------------------------------------------------------------------------
 // Quantizer
 // ------------------------------------------------------------------------------------------

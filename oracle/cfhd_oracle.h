@@ -80,6 +80,10 @@ void orc_inv_spatial_to_rgba8(PIXEL16 *const bands[4][4], int band_pitch, int w,
 /* 4:2:2 sample -> YU64 (16-bit words Y0 C1 Y1 C2): the planar 16-bit row route (InvertHorizontalStrip16sToRow16u per plane), see cfhd_oracle_inv.c */
 /* 4:2:2 sample -> RG24: the YU64 rows through the scalar loop of ConvertRow16uToDitheredRGB (convert.c:11392) with the 15-bit dither value d the caller picks */
 void orc_yu64_to_rgb24(const uint16_t *yu, int yu_pitch_words, int width, int rows, int color_space, int d, uint8_t *out, int out_pitch_bytes);
+/* Bayer samples -> BYR4 (decoder.c:14738 + bayer.c:13233 GenerateBYR2 + the linear-restore table of decoder.c:10714): see cfhd_oracle_inv.c */
+void orc_byr4_linear_restore_curve(uint16_t curve[16384]);
+void orc_inv_spatial_to_byr4(PIXEL16 *const bands[4][4], int band_pitch, int w, int h, int precision, int display_quad_rows, const uint16_t *curve,
+                             uint16_t *out, int out_pitch_words);
 void orc_inv_spatial_to_rgb24_of_yuv422(PIXEL16 *const bands[3][4], const int band_pitch[3], int luma_w, int h, int precision, int display_height, int color_space,
                                         int d, uint8_t *out, int out_pitch_bytes);
 void orc_inv_spatial_to_yu64(PIXEL16 *const bands[3][4], const int band_pitch[3], int luma_w, int h, int precision, uint16_t *out, int out_pitch_words);

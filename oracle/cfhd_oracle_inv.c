@@ -6,6 +6,7 @@
 #include "cfhd_oracle.h"
 #include <stdlib.h>
 #include <string.h>
+#include <math.h>
 
 static inline int sat16(int x) { return x < -32768 ? -32768 : (x > 32767 ? 32767 : x); }
 static inline int adds(int a, int b) { return sat16(a + b); }
@@ -509,4 +510,50 @@ void orc_inv_spatial_to_rgb24_of_yuv422(PIXEL16 *const bands[3][4], const int ba
 	orc_inv_spatial_to_yu64(bands, band_pitch, luma_w, h, precision, yu, W * 2);
 	orc_yu64_to_rgb24(yu, W * 2, W, display_height, color_space, d, out, out_pitch_bytes);
 	free(yu);
+}
+
+/* ---- Bayer samples decoded to BYR4 (the raw mosaic, no demosaic) ------------------------------------------------------------------------
+ * Codec/decoder.c:14738 (full resolution, BYR2 / BYR4 output): the four planes G, R-G, B-G, G1-G2 are reconstructed as 16-bit rows -- the planar
+ * row route of RG48 output, orc_inv_spatial_to_rgb48 with four planes -- into decoder->RawBayer16, then Codec/bayer.c:13233 GenerateBYR2 turns every
+ * quad back into its four samples: r = ((rg - 32768) << 1) + g, b likewise, g1 = g + (gd - 32768), g2 = g - (gd - 32768), each clamped to 16 bits,
+ * and -- for BYR4 output of a sample without an encode-curve preset -- sent through BYR4LinearRestore[x >> 2], the table decoder.c:10714-10783
+ * builds: (int)(log2lin(j / 16384, 90) * 65535) in float, with log2lin (Common/AVIExtendedHeader.h:148) = (float)((pow(b, i) - 1) / (b - 1)) evaluated
+ * in double.  Red-green phase (BAYER_FORMAT_RED_GRN, the default without Bayer metadata): rows r g1 / g2 b.  Pinned word for word against the reference
+ * decoder in tests/test_oracle_vs_ref.py. */
+void orc_byr4_linear_restore_curve(uint16_t curve[16384])
+{
+	int j;
+	const float base = 90.0f;                           /* encode_curve == 0: CURVE_TYPE_LOG, base 90 (decoder.c:10729-10733) */
+	for (j = 0; j < 16384; j++) {
+		const float i = (float)j / 16384.0f;
+		const float lin = (float)((pow(base, i) - 1.0) / (base - 1.0));
+		int val = (int)(lin * 65535.0f);
+		if (val < 0) val = 0;
+		if (val > 65535) val = 65535;
+		curve[j] = (uint16_t)val;
+	}
+}
+
+void orc_inv_spatial_to_byr4(PIXEL16 *const bands[4][4], int band_pitch, int w, int h, int precision, int display_quad_rows, const uint16_t *curve,
+                             uint16_t *out, int out_pitch_words)
+{
+	const int W = 2 * w;                                /* quads per row */
+	uint16_t *raw = (uint16_t *)malloc((size_t)2 * h * W * 4 * sizeof(uint16_t));
+	int y, x;
+	orc_inv_spatial_to_rgb48(bands, band_pitch, w, h, precision, 4, raw, W * 4);      /* words R-G, G, B-G, G1-G2 per quad (planes G, R-G, B-G, G1-G2 -> words 1, 0, 2, 3) */
+	for (y = 0; y < display_quad_rows; y++) {
+		uint16_t *a = out + (size_t)(2 * y) * out_pitch_words, *b = a + out_pitch_words;
+		for (x = 0; x < W; x++) {
+			const uint16_t *q = raw + ((size_t)y * W + x) * 4;
+			const int g = q[1], rg = q[0], bg = q[2], gd = (int)q[3] - 32768;
+			int r = ((rg - 32768) << 1) + g, bl = ((bg - 32768) << 1) + g, g1 = g + gd, g2 = g - gd;
+			r = r < 0 ? 0 : (r > 0xffff ? 0xffff : r); bl = bl < 0 ? 0 : (bl > 0xffff ? 0xffff : bl);
+			g1 = g1 < 0 ? 0 : (g1 > 0xffff ? 0xffff : g1); g2 = g2 < 0 ? 0 : (g2 > 0xffff ? 0xffff : g2);
+			if (curve) { r = curve[r >> 2]; g1 = curve[g1 >> 2]; g2 = curve[g2 >> 2]; bl = curve[bl >> 2]; }
+			else { r &= 0xfffe; g1 &= 0xfffe; g2 &= 0xfffe; bl &= 0xfffe; }      /* (BYR2 output, or a curve preset: bayer.c:13302-13308) */
+			a[2 * x] = (uint16_t)r; a[2 * x + 1] = (uint16_t)g1;
+			b[2 * x] = (uint16_t)g2; b[2 * x + 1] = (uint16_t)bl;
+		}
+	}
+	free(raw);
 }

@@ -320,7 +320,9 @@ def product_emulated():
                     out = os.path.join(gen, f[:-4] + ".%d.cpp" % os.getpid())
                     with open(out, "w") as fh: fh.write("// generated from cineform-sdk_amd/csrc/%s by tests/hipemu/translate_launches.py -- test infrastructure\n" % f + translate(open(os.path.join(csrc, f)).read()))
                     srcs.append(out)
-            _build_once(EMU_PRODUCT_SO, ["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + hipemu, "-I" + csrc, "-I" + os.path.join(ROOT, "include")] + srcs, deps)
+            _build_once(EMU_PRODUCT_SO, ["g++", "-O1", "-w", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + hipemu, "-I" + csrc, "-I" + os.path.join(ROOT, "include")] + srcs, deps)
+            for f in srcs:
+                if f.startswith(gen): os.replace(f, os.path.join(gen, os.path.basename(f).split(".")[0] + ".cpp"))      # (kept for reading: what the compiler saw)
         L = ctypes.CDLL(EMU_PRODUCT_SO)
         declare_cfhd_api(L)
         _emu_product = L
@@ -1051,6 +1053,29 @@ def oracle_inverse_rgb24_of_yuv422(plan, coeffs, d, color_space=2):
     w = plan.band[(0, 0, 0)]["width"]; h = plan.band[(0, 0, 0)]["height"]
     out = np.zeros((plan.height, 2 * w * 3), np.uint8)
     O.orc_inv_spatial_to_rgb24_of_yuv422(ptrs, iarr(pitches), w, h, plan.precision, plan.height, color_space, d, out.ctypes.data_as(ctypes.c_void_p), out.shape[1])
+    return out
+
+
+def oracle_inverse_byr4(plan, coeffs, curve=True, quad_rows=None):
+    """Whole inverse path with the oracle from a dequantized Bayer pyramid (planes G, R-G, B-G, G1-G2) to the BYR4 mosaic (rows r g1 / g2 b), through the
+    reference's linear-restore table (orc_byr4_linear_restore_curve) unless curve is False: orc_inv_spatial_to_byr4."""
+    O = oracle()
+    O.orc_inv_spatial_to_byr4.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    work = coeffs.copy()
+    for c in range(4):
+        for lv in (2, 1):
+            d = plan.band[(c, lv, 0)]
+            bands = (c_i16p * 4)(*[plan.view(work, c, lv, b).ctypes.data_as(c_i16p) for b in range(4)])
+            dst = plan.view(work, c, lv - 1, 0)
+            O.orc_inv_spatial(bands, d["pitch"], d["width"], d["height"], plan.prescale[lv], dst.ctypes.data_as(c_i16p), plan.band[(c, lv - 1, 0)]["pitch"])
+    d = plan.band[(0, 0, 0)]
+    flat = [plan.view(work, c, 0, b).ctypes.data_as(c_i16p) for c in range(4) for b in range(4)]
+    lut = np.zeros(16384, np.uint16)
+    O.orc_byr4_linear_restore_curve(lut.ctypes.data_as(ctypes.c_void_p))
+    quad_rows = quad_rows or 2 * d["height"]
+    out = np.zeros((2 * quad_rows, 4 * d["width"]), np.uint16)
+    O.orc_inv_spatial_to_byr4((c_i16p * 16)(*flat), d["pitch"], d["width"], d["height"], plan.precision, quad_rows, lut.ctypes.data_as(ctypes.c_void_p) if curve else None,
+                              out.ctypes.data_as(ctypes.c_void_p), out.shape[1])
     return out
 
 

@@ -532,6 +532,35 @@ def test_rg30_is_ab10_under_another_name():
     assert pa == pb and np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("w,h", [(320, 240), (336, 248), (720, 480), (1920, 1080), (3840, 2160)])
+def test_bayer_decode_to_byr4_equals_reference_exactly(w, h):
+    """Bayer samples decoded to BYR4 (the raw mosaic, no demosaic: decoder.c:14738 + bayer.c:13233 GenerateBYR2 + the linear-restore table of decoder.c:10714): word for
+    word the oracle's reconstruction (pinned on the reference on ten geometries, test_reference_byr4_decode_of_bayer_equals_oracle) and the reference decoder's own
+    output, on the product's own sample (byte-identical to the reference encoder's) with ramps into both clips; half resolution and other outputs are refused."""
+    from test_oracle_vs_ref import bayer_test_mosaic
+    mosaic = bayer_test_mosaic(w, h, w + h)
+    frame = np.frombuffer(mosaic.tobytes(), np.uint8).copy()
+    sample = amd_encode_frames([frame], w * 2, w, h, fourcc("BYR4"), encoded=ENCODED_BAYER)[0]
+    got, gpitch, aw, ah = amd_decode_sample(sample, fourcc("BYR4"))
+    assert (aw, ah, gpitch) == (w, h, w * 2)
+    mine = np.frombuffer(got.tobytes(), np.uint16).reshape(h, gpitch // 2)[:, :w]
+    plan = Plan(w, h, pixkind=PIXKIND["BYR4"], enc=ENC["bayer"])
+    want = oracle_inverse_byr4(plan, host_decode_pyramid(sample, plan))[:h, :w]
+    assert np.array_equal(mine, want), "%d words differ from the exact reconstruction" % (mine != want).sum()
+    for attempt in range(6):                            # (the reference's threaded decoder occasionally returns a damaged frame)
+        dec, dpitch = ref_decode_sample(sample, w, h, fourcc("BYR4"))
+        img = np.frombuffer(dec.tobytes(), np.uint16).reshape(h, dpitch // 2)[:, :w]
+        if np.array_equal(img, mine): break
+    assert np.array_equal(img, mine), "%d words differ" % (img != mine).sum()
+    L = product()
+    dec = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
+    a = ctypes.c_int(); b = ctypes.c_int(); c = ctypes.c_uint32()
+    sb = ctypes.create_string_buffer(sample, len(sample))
+    assert L.CFHD_PrepareToDecode(dec, 0, 0, fourcc("BYR4"), 2, 0, sb, 512, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)) == 3      # half resolution: not built
+    assert L.CFHD_PrepareToDecode(dec, 0, 0, PIX_RG48, 1, 0, sb, 512, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)) == 3             # demosaic: out of scope
+    L.CFHD_CloseDecoder(dec)
+
+
 @pytest.mark.parametrize("w,h", [(320, 240), (720, 480), (1920, 1080)])
 def test_rgba4444_decode_to_rg48_equals_reference_exactly(w, h):
     """RGBA 4:4:4:4 samples decoded to RG48, full and half resolution: the RG48 route on planes G, R, B (alpha left behind) -- the oracle's exact reconstruction

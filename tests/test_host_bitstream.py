@@ -458,7 +458,7 @@ def test_thumbnail_and_output_formats_argument_handling():
     assert [fmts[i] for i in range(n.value)] == [PIX_YUY2, PIX_2VUY, fourcc("YU64"), fourcc("v210"), PIX_RG24]
     assert L.CFHD_GetOutputFormats(dec, None, 0, fmts, 8, ctypes.byref(n)) == 0 and n.value == 8
     many = (ctypes.c_uint32 * 32)()
-    assert L.CFHD_GetOutputFormats(dec, None, 0, many, 32, ctypes.byref(n)) == 0 and n.value == 14 and len(set(many[: n.value])) == 14      # every format once, RG30 among them
+    assert L.CFHD_GetOutputFormats(dec, None, 0, many, 32, ctypes.byref(n)) == 0 and n.value == 15 and len(set(many[: n.value])) == 15      # every format once, RG30 and BYR4 among them
     L.CFHD_CloseDecoder(dec)
 
 
