@@ -1014,11 +1014,12 @@ CFHD_Error CFHD_PrepareToDecode(CFHD_DecoderRef ref, int, int, CFHD_PixelFormat 
 	const bool rgba8 = (kind == PIX_BGRA || kind == PIX_BGRa) && encf == ENC_RGBA4444;
 	// ... and 4:2:2 samples to RG24: the YU64 rows through the reference's scalar colour conversion with its 15-bit dither (DecodeBatch / k_yu64_to_rgb24)
 	const bool rgb24_of_422 = kind == PIX_RG24 && encf == ENC_YUV422 && !half && d->header.width >= 128;
-	if (rgb8 && ((encf != ENC_RGB444 && !rgba8 && !rgb24_of_422) || half || d->header.width < 32)) return ERR_BADFORMAT;
+	// (half resolution -- frame.c:7150 ConvertLowpassRGB444ToRGB -- for the outputs of RGB 4:4:4 samples: 8-bit, 10-bit, b64a; k_half_rgb)
+	if (rgb8 && ((encf != ENC_RGB444 && !rgba8 && !rgb24_of_422) || (half && encf != ENC_RGB444) || d->header.width < 32)) return ERR_BADFORMAT;
 	// ... and to the 10-bit RGB words r210 / DPX0 / AB10 / AR10 ((value before the final >> 1, + 3) >> 3 per component: a model fitted on the reference
 	// decoder and pinned word for word on the CPU, equal to the reference decoder on the GPU)
 	const bool rgb10 = kind >= PIX_R210 && kind <= PIX_AR10;
-	if (rgb10 && (encf != ENC_RGB444 || half || d->header.width < 32)) return ERR_BADFORMAT;
+	if (rgb10 && (encf != ENC_RGB444 || d->header.width < 32)) return ERR_BADFORMAT;
 	// ... and 4:2:2 samples to v210 (the YU64 words >> 6, three to a 32-bit word: DecodeBatch / k_yu64_to_v210; widths of whole six-pixel groups)
 	if (kind == PIX_V210 && (encf != ENC_YUV422 || half || d->header.width % 6 || d->header.width < 128)) return ERR_BADFORMAT;
 	// ... and Bayer samples to BYR4: the raw mosaic, no demosaic (the four planes as 16-bit rows, recombined per quad and sent through the reference's linear-restore
@@ -1027,7 +1028,7 @@ CFHD_Error CFHD_PrepareToDecode(CFHD_DecoderRef ref, int, int, CFHD_PixelFormat 
 	if ((encf == ENC_BAYER) != byr4_of_bayer) return ERR_BADFORMAT;
 	if ((kind == PIX_BYR4 && !byr4_of_bayer) || kind == PIX_BYR5 || kind == PIX_RG64 || (kind >= PIX_R210 && kind <= PIX_AR10 && !rgb10)) return ERR_BADFORMAT;     // encoder inputs only
 	// ... and RGB 4:4:4 samples to b64a (the RG48 words behind a constant alpha word 0xfff0, full resolution: what TestCFHD's b64a -> RGB 4:4:4 row decodes to)
-	const bool b64a_of_444 = kind == PIX_B64A && encf == ENC_RGB444 && !half;
+	const bool b64a_of_444 = kind == PIX_B64A && encf == ENC_RGB444;
 	// ... and RGBA 4:4:4:4 samples to RG48 (the RG48 route on planes G, R, B, the alpha plane left behind; full and half resolution)
 	const bool rg48_of_4444 = kind == PIX_RG48 && encf == ENC_RGBA4444;
 	if ((encf == ENC_RGB444) != ((kind == PIX_RG48 && !rg48_of_4444) || (rgb8 && !rgba8 && !rgb24_of_422) || rgb10 || b64a_of_444) || (encf == ENC_RGBA4444) != ((kind == PIX_B64A && !b64a_of_444) || rgba8 || rg48_of_4444)) return ERR_BADFORMAT;

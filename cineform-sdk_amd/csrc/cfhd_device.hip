@@ -657,11 +657,11 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 	const bool yuv_ok = (out_kind == PIX_YUY2 || out_kind == PIX_2VUY) && plan.encoded_format == ENC_YUV422;
 	// (b64a from an RGB 4:4:4 sample: the three colour planes and a constant alpha word, full resolution)
 	const bool rgb_ok = ((out_kind == PIX_RG48 && plan.encoded_format == ENC_RGB444) || (out_kind == PIX_B64A && plan.encoded_format == ENC_RGBA4444) ||
-	                     (out_kind == PIX_B64A && plan.encoded_format == ENC_RGB444 && !half) || (out_kind == PIX_RG48 && plan.encoded_format == ENC_RGBA4444) || byr4_) &&
+	                     (out_kind == PIX_B64A && plan.encoded_format == ENC_RGB444) || (out_kind == PIX_RG48 && plan.encoded_format == ENC_RGBA4444) || byr4_) &&
 	                    plan.ch[0].band[0][0].width >= 16;   // k_inv_packed16's tail-column rule assumes the reference's vector path
 	const bool yu64_ok = out_kind == PIX_YU64 && plan.encoded_format == ENC_YUV422 && !half && plan.ch[1].band[0][0].width >= 16;
-	const bool rgb8_ok = dec_rgb8(out_kind) && (plan.encoded_format == ENC_RGB444 || (plan.encoded_format == ENC_RGBA4444 && out_kind != PIX_RG24)) && !half && plan.ch[0].band[0][0].width >= 16 && plan.ch[0].band[0][0].width % 2 == 0;
-	const bool rgb10_ok = dec_rgb10(out_kind) && plan.encoded_format == ENC_RGB444 && !half && plan.ch[0].band[0][0].width >= 16;
+	const bool rgb8_ok = dec_rgb8(out_kind) && (plan.encoded_format == ENC_RGB444 || (plan.encoded_format == ENC_RGBA4444 && out_kind != PIX_RG24 && !half)) && plan.ch[0].band[0][0].width >= 16 && plan.ch[0].band[0][0].width % 2 == 0;
+	const bool rgb10_ok = dec_rgb10(out_kind) && plan.encoded_format == ENC_RGB444 && plan.ch[0].band[0][0].width >= 16;
 	if (!yuv_ok && !rgb_ok && !yu64_ok && !rgb8_ok && !rgb10_ok) { g_err = "output format not supported by the GPU path yet"; return -2; }
 	plan_ = plan; n_ = nframes; out_kind_ = out_kind; own_output_ = own_output;
 	HIPCHK(hipStreamCreateWithFlags((hipStream_t *)&stream_, hipStreamNonBlocking));
@@ -716,6 +716,16 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 				p.out = base + plan.ch[c].band[lv - 1][0].offset; p.out_pitch = plan.ch[c].band[lv - 1][0].pitch;
 				p.xstride = 1; p.precision = 0; p.display_height = 2 * p.height;
 			}
+		if (half && (dec_rgb8(out_kind) || dec_rgb10(out_kind) || (out_kind == PIX_B64A && nch == 3))) {      // k_half_rgb
+			dev::HalfPackedJob &hp = j.halfp[i];
+			for (int c = 0; c < 3; c++) { hp.ll[c] = base + plan.ch[c].band[0][0].offset; hp.word[c] = dec_rgb10(out_kind) ? rgb10_shift(out_kind, c) : 0; }
+			hp.pitch = plan.ch[0].band[0][0].pitch; hp.width = plan.ch[0].band[0][0].width; hp.rows = out_rows_; hp.nch = 3;
+			hp.mode = dec_rgb8(out_kind) ? 1 : (dec_rgb10(out_kind) ? 2 : 3); hp.bias = dec_rgb8(out_kind) ? 8 : (dec_rgb10(out_kind) ? 6 : 0);
+			hp.bytes = dec_rgb8(out_kind) ? rgb8_bytes(out_kind) : 0; hp.bottom_up = out_kind == PIX_RG24 || out_kind == PIX_BGRA;
+			hp.big_endian = out_kind == PIX_R210 || out_kind == PIX_DPX0; hp.dither_seed = 0x9E3779B9u * (uint32_t)(i + 1);
+			hp.out = own_output ? (uint16_t *)(d_out_ + frame_bytes_ * i) : nullptr; hp.out_pitch = out_pitch_;
+			continue;
+		}
 		if (half && is_packed16(out_kind)) {
 			dev::HalfPackedJob &hp = j.halfp[i];
 			for (int c = 0; c < onch; c++) { hp.ll[c] = base + plan.ch[c].band[0][0].offset; hp.word[c] = packed_word_of_channel(out_kind, c); }
@@ -896,7 +906,10 @@ int DecodeBatch::launch_inverse(uint32_t dither_seed)
 		HIPCHK(hipEventRecord((hipEvent_t)evl_[1], st));
 	}
 	if (interlaced_ && !half_ && dec_planes16(out_kind_)) return -1;
-	if (half_ && is_packed16(out_kind_)) {
+	if (half_ && (dec_rgb8(out_kind_) || dec_rgb10(out_kind_) || (out_kind_ == PIX_B64A && nch == 3))) {
+		const BandDesc &b = plan_.ch[0].band[0][0];
+		dev::k_half_rgb<<<dim3((b.width + dev::NTHREADS - 1) / dev::NTHREADS, out_rows_, act), dev::NTHREADS, 0, st>>>(j.halfp, dither_seed);
+	} else if (half_ && is_packed16(out_kind_)) {
 		const BandDesc &b = plan_.ch[0].band[0][0];
 		dev::k_half_packed16<<<dim3((b.width / 8 + dev::NTHREADS - 1) / dev::NTHREADS, out_rows_, act), dev::NTHREADS, 0, st>>>(j.halfp);
 	} else if (half_) {

@@ -186,6 +186,9 @@ struct HalfPackedJob {                      // k_half_packed16: level-1 lowpass 
 	int word[4];                            // word of plane c inside the pixel
 	int shift, alpha;                       // left shift to 16 bits (16 - precision - 2); alpha: plane 3 is the companded alpha of b64a
 	uint16_t *out; int out_pitch;           // bytes
+	// k_half_rgb (the other outputs of RGB 4:4:4 samples): mode 1 = 8-bit pixels B G R (A = 255), 2 = one 10-bit RGB word (word[c] = bit position of plane c),
+	// 3 = b64a words with the constant alpha 65535; bias = what the reference's lowpass bias (decoder.c:12290-12312) has become at level 1
+	int mode, bias, bytes, bottom_up, big_endian; uint32_t dither_seed;
 };
 
 struct FwdFrameJob {                        // k_fwd_frame_yuv422: interlaced level 1 of a packed 8-bit 4:2:2 frame
@@ -2308,6 +2311,45 @@ __global__ void __launch_bounds__(NTHREADS) k_yu64_to_rgb24(const uint16_t *yu64
 		o[3 * k + 0] = (uint8_t)(B < 0 ? 0 : (B > 255 ? 255 : B));
 		o[3 * k + 1] = (uint8_t)(G < 0 ? 0 : (G > 255 ? 255 : G));
 		o[3 * k + 2] = (uint8_t)(R < 0 ? 0 : (R > 255 ? 255 : R));
+	}
+}
+
+// Half resolution of RGB 4:4:4 samples for the 8-bit, 10-bit and b64a outputs (decoder.c:26752 CopyLowpassRGB444ToBuffer -> frame.c:7150 ConvertLowpassRGB444ToRGB):
+// the level-1 lowpass planes G, R, B (14 bits for 12-bit samples), to which the reference's lowpass bias of the output format has come down unchanged
+// (8 for the 8-bit, 6 for the 10-bit formats: an even offset passes the descaling inverse levels exactly), then
+//   8 bit (frame.c:7226 / :7241 -> convert.c:6151 ConvertPlanarRGB16uToPackedRGB32 with shift 6): (v + 9 + r) clamped to 14 bits, >> 6, r = rand() & 31 shared by
+//          the three components of a pixel (here: a counter-based hash); RG24 / BGRA bottom row first;
+//   10 bit (frame.c:7662 ConvertLowpassRGB444ToRGB30): (v << 2) saturated to 16 bits, >> 6, at the format's bit positions;
+//   b64a (frame.c:7494 ConvertLowpassRGB444ToB64A): (v << 2) saturated, alpha 65535.
+// Pinned on the reference decoder (tests/test_oracle_vs_ref.py).  One thread per pixel: a quarter of the frame, nowhere near a bench line.
+__global__ void __launch_bounds__(NTHREADS) k_half_rgb(const HalfPackedJob *jobs, uint32_t launch_seed)
+{
+	const HalfPackedJob &job = jobs[blockIdx.z];
+	const int row = blockIdx.y, x = (int)(blockIdx.x * NTHREADS + threadIdx.x);
+	if (x >= job.width) return;
+	int v[3];
+#pragma unroll
+	for (int c = 0; c < 3; c++) v[c] = (int)job.ll[c][(size_t)row * job.pitch + x] + job.bias;      // G, R, B
+	if (job.mode == 1) {
+		const int r = (int)(dither_word(job.dither_seed ^ launch_seed, row, x) & 31u);
+		const int yrow = job.bottom_up ? job.rows - 1 - row : row;
+		uint8_t *o = (uint8_t *)job.out + (size_t)yrow * job.out_pitch + (size_t)x * job.bytes;
+		const int order[3] = { 2, 0, 1 };                  // bytes B, G, R <- planes B, G, R
+#pragma unroll
+		for (int k = 0; k < 3; k++) { int t = v[order[k]] + 9 + r; t = t < 0 ? 0 : (t > 0x3fff ? 0x3fff : t); o[k] = (uint8_t)(t >> 6); }
+		if (job.bytes == 4) o[3] = 255;
+	} else if (job.mode == 2) {
+		uint32_t w = 0;
+#pragma unroll
+		for (int c = 0; c < 3; c++) { int t = v[c] << 2; t = t < 0 ? 0 : (t > 65535 ? 65535 : t); w |= (uint32_t)(t >> 6) << job.word[c]; }
+		if (job.big_endian) w = __builtin_bswap32(w);
+		*(uint32_t *)((uint8_t *)job.out + (size_t)row * job.out_pitch + 4 * (size_t)x) = w;
+	} else {
+		uint32_t t[3];
+#pragma unroll
+		for (int c = 0; c < 3; c++) { const int q = v[c] << 2; t[c] = (uint32_t)(q < 0 ? 0 : (q > 65535 ? 65535 : q)); }
+		uint2 px; px.x = 0xffffu | (t[1] << 16); px.y = t[0] | (t[2] << 16);      // words A, R, G, B
+		*(uint2 *)((uint8_t *)job.out + (size_t)row * job.out_pitch + 8 * (size_t)x) = px;
 	}
 }
 

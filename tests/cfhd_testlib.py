@@ -596,6 +596,38 @@ def oracle_half_resolution16(plan, coeffs, b64a=False, expand_alpha=True):
     return half_resolution_model16(P, b64a, expand_alpha)
 
 
+def oracle_half_resolution_rgb(plan, coeffs, name, r=0):
+    """Half-resolution picture of an RGB 4:4:4 sample in the 8-bit (RG24 / BGRA / BGRa), 10-bit (r210 / DPX0 / AB10 / AR10) and b64a output formats, restated from
+    frame.c:7150 ConvertLowpassRGB444ToRGB: the level-1 lowpass planes G, R, B plus the lowpass bias of the output format (decoder.c:12290-12312: 8 for 8-bit RGB,
+    6 for 10-bit RGB -- an even bias comes down the descaling levels unchanged), then 8 bit: (v + 9 + r) clamped to 14 bits >> 6 with r = rand() & 31 per pixel
+    (convert.c:6151, shift 6; the caller passes r = 0 / 31 for the two ends), RG24 / BGRA bottom row first; 10 bit: (v << 2) saturated >> 6 (frame.c:7662);
+    b64a: (v << 2) saturated, alpha 65535 (frame.c:7494).  Returns rows of bytes / 32-bit words / 16-bit words."""
+    O = oracle()
+    work = coeffs.copy()
+    for c in range(3):
+        for lv in (2, 1):
+            d = plan.band[(c, lv, 0)]
+            bands = (c_i16p * 4)(*[plan.view(work, c, lv, b).ctypes.data_as(c_i16p) for b in range(4)])
+            dst = plan.view(work, c, lv - 1, 0)
+            O.orc_inv_spatial(bands, d["pitch"], d["width"], d["height"], plan.prescale[lv], dst.ctypes.data_as(c_i16p), plan.band[(c, lv - 1, 0)]["pitch"])
+    rows = plan.height // 2
+    G, R, B = [plan.view(work, c, 0, 0)[:rows, : plan.band[(c, 0, 0)]["width"]].astype(np.int64) for c in range(3)]
+    if name in ("RG24", "BGRA", "BGRa"):
+        bpp = 3 if name == "RG24" else 4
+        out = np.full((rows, G.shape[1], bpp), 255, np.uint8)
+        for byte, pl in ((0, B), (1, G), (2, R)):
+            out[:, :, byte] = np.clip(pl + 8 + 9 + r, 0, 16383) >> 6
+        return out.reshape(rows, -1)
+    if name == "b64a":
+        out = np.zeros((rows, G.shape[1], 4), np.uint16)
+        out[:, :, 0] = 65535
+        for word, pl in ((1, R), (2, G), (3, B)): out[:, :, word] = np.clip(pl << 2, 0, 65535)
+        return out.reshape(rows, -1)
+    shifts = {"r210": (20, 10, 0), "DPX0": (22, 12, 2), "AB10": (0, 10, 20), "AR10": (20, 10, 0), "RG30": (0, 10, 20)}[name]
+    words = sum((np.clip((pl + 6) << 2, 0, 65535) >> 6) << sh for sh, pl in zip(shifts, (R, G, B))).astype(np.uint32)
+    return words.byteswap() if name in ("r210", "DPX0") else words
+
+
 def oracle_half_resolution(plan, coeffs, uyvy=0):
     """Levels 3 -> 2 -> 1 with the oracle, then the half-resolution model; rows = display height / 2."""
     O = oracle()

@@ -532,6 +532,41 @@ def test_rg30_is_ab10_under_another_name():
     assert pa == pb and np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("w,h", [(320, 240), (336, 248), (1920, 1080)])
+def test_half_resolution_decode_of_rgb444_to_the_8bit_10bit_and_b64a_outputs(w, h):
+    """CFHD_DECODED_RESOLUTION_HALF for the other outputs of RGB 4:4:4 samples (TestCFHD decodes every row of its table at full and at half resolution): r210 / DPX0 /
+    AB10 / AR10 / RG30 / b64a word for word the restated conversion (oracle_half_resolution_rgb, pinned on the reference on eight geometries), RG24 / BGRA / BGRa inside
+    its dither interval with both ends reached -- and against the reference decoder's own half-resolution output of the same sample."""
+    from test_oracle_vs_ref import rgb444_sample_with_clips, half_rgb_view
+    sample = rgb444_sample_with_clips(w, h, w + h)
+    plan = Plan(w, h, pixkind=PIXKIND["RG48"], enc=ENC["444"])
+    deq = host_decode_pyramid(sample, plan)
+    hh = h // 2 if h % 8 == 0 else h // 2 - 4
+    for name in ("r210", "DPX0", "AB10", "AR10", "RG30", "b64a"):
+        got, gpitch, aw, ah = amd_decode_sample(sample, fourcc(name), resolution=2)
+        assert (aw, ah) == (w // 2, h // 2)
+        mine = half_rgb_view(got, gpitch, w, h, name)
+        assert np.array_equal(mine, oracle_half_resolution_rgb(plan, deq, name)[: h // 2]), name
+        if name == "RG30": continue                     # (the reference knows AJA's name for AB10 as a decoder output too; one comparison is enough)
+        for attempt in range(6):
+            dec, dpitch = ref_decode_sample(sample, w, h, fourcc(name), resolution=2)
+            if np.array_equal(half_rgb_view(dec, dpitch, w, h, name)[:hh], mine[:hh]): break
+        assert np.array_equal(half_rgb_view(dec, dpitch, w, h, name)[:hh], mine[:hh]), name
+    for name in ("RG24", "BGRA", "BGRa"):
+        got, gpitch, aw, ah = amd_decode_sample(sample, fourcc(name), resolution=2)
+        assert (aw, ah) == (w // 2, h // 2)
+        mine = half_rgb_view(got, gpitch, w, h, name)
+        lo, hi = oracle_half_resolution_rgb(plan, deq, name, 0)[: h // 2], oracle_half_resolution_rgb(plan, deq, name, 31)[: h // 2]
+        assert ((mine >= lo) & (mine <= hi)).all(), name
+        moving = lo != hi
+        assert (mine[moving] == lo[moving]).any() and (mine[moving] == hi[moving]).any()
+        for attempt in range(6):
+            dec, dpitch = ref_decode_sample(sample, w, h, fourcc(name), resolution=2)
+            ref_img = half_rgb_view(dec, dpitch, w, h, name)
+            if (np.abs(ref_img[:hh].astype(np.int16) - mine[:hh]) <= 1).all(): break
+        assert (np.abs(ref_img[:hh].astype(np.int16) - mine[:hh]) <= 1).all(), name       # (both inside the same interval of width one)
+
+
 @pytest.mark.parametrize("w,h", [(320, 240), (336, 248), (720, 480), (1920, 1080), (3840, 2160)])
 def test_bayer_decode_to_byr4_equals_reference_exactly(w, h):
     """Bayer samples decoded to BYR4 (the raw mosaic, no demosaic: decoder.c:14738 + bayer.c:13233 GenerateBYR2 + the linear-restore table of decoder.c:10714): word for
@@ -722,7 +757,7 @@ def test_rgb8_decode_lies_in_the_reference_interval(w, h, name):
     """RGB 4:4:4 samples decoded to RG24 / BGRA (bottom row first) / BGRa: every byte inside the interval of the reference's dither model
     (oracle reconstruction with the dither value 0 and with 15; the reference decoder's own output is pinned to the same interval in
     test_oracle_vs_ref), both ends about equally often, alpha 255; the picture survives the RG24 -> RGB 4:4:4 -> RG24 round trip of the
-    product alone; half resolution is refused."""
+    product alone; quarter resolution is refused."""
     frames, pitch = qbist_frames(10, 1, w, h, PIX_RG48)
     sample = ref_encode_frames(frames, pitch, w, h, PIX_RG48, encoded=ENCODED_RGB444)[0]
     plan = Plan(w, h, pixkind=PIXKIND["RG48"], enc=3)
@@ -755,7 +790,8 @@ def test_rgb8_decode_lies_in_the_reference_interval(w, h, name):
     dec = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
     aw_ = ctypes.c_int(); ah_ = ctypes.c_int(); af_ = ctypes.c_uint32()
     sb = ctypes.create_string_buffer(sample, len(sample))
-    assert L.CFHD_PrepareToDecode(dec, 0, 0, fourcc(name), 2, 0, sb, 512, ctypes.byref(aw_), ctypes.byref(ah_), ctypes.byref(af_)) != 0
+    assert L.CFHD_PrepareToDecode(dec, 0, 0, fourcc(name), 2, 0, sb, 512, ctypes.byref(aw_), ctypes.byref(ah_), ctypes.byref(af_)) == 0      # (half resolution: test_half_resolution_decode_of_rgb444_...)
+    assert L.CFHD_PrepareToDecode(dec, 0, 0, fourcc(name), 3, 0, sb, 512, ctypes.byref(aw_), ctypes.byref(ah_), ctypes.byref(af_)) != 0      # quarter resolution: not built
     L.CFHD_CloseDecoder(dec)
 
 

@@ -481,7 +481,7 @@ def test_deep_rgb_as_yuv422_and_rgb10_outputs_are_accepted():
         sb = ctypes.create_string_buffer(sample, len(sample))
         for name in sorted(RGB10_FORMATS):
             assert L.CFHD_PrepareToDecode(dec, 0, 0, fourcc(name), 1, 0, sb, 512, ctypes.byref(aw), ctypes.byref(ah), ctypes.byref(af)) == 0
-            assert L.CFHD_PrepareToDecode(dec, 0, 0, fourcc(name), 2, 0, sb, 512, ctypes.byref(aw), ctypes.byref(ah), ctypes.byref(af)) == 3
+            assert L.CFHD_PrepareToDecode(dec, 0, 0, fourcc(name), 2, 0, sb, 512, ctypes.byref(aw), ctypes.byref(ah), ctypes.byref(af)) == 0 and (aw.value, ah.value) == (160, 120)      # half resolution: k_half_rgb
         L.CFHD_CloseDecoder(dec)
     L.CFHD_CloseEncoder(enc)
 
@@ -489,7 +489,7 @@ def test_deep_rgb_as_yuv422_and_rgb10_outputs_are_accepted():
 def test_decoder_output_format_gates():
     """CFHD_PrepareToDecode (host code: no GPU involved) accepts exactly the (encoded format, output format, resolution) combinations the
     library decodes and answers CFHD_ERROR_BADFORMAT (3) for the rest: 4:2:2 -> YUY2 / 2vuy (full, half), YU64 (full); RGB 4:4:4 -> RG48
-    (full, half), RG24 / BGRA / BGRa (full); RGBA 4:4:4:4 -> b64a and RG48 (full, half), BGRA / BGRa (full); RGB 4:4:4 -> b64a (full)."""
+    (full, half), RG24 / BGRA / BGRa / 10-bit RGB / b64a (full, half); RGBA 4:4:4:4 -> b64a and RG48 (full, half), BGRA / BGRa (full)."""
     if not have_ref(): pytest.skip("reference .so not built")
     L = product()
     w, h = 320, 240
@@ -501,7 +501,8 @@ def test_decoder_output_format_gates():
                "4444": ref_encode_frames(fa, pa, w, h, PIX_B64A, encoded=ENCODED_RGBA4444)[0]}
     accepted = {("422", "YUY2", 1), ("422", "YUY2", 2), ("422", "2vuy", 1), ("422", "2vuy", 2), ("422", "YU64", 1),
                 ("444", "RG48", 1), ("444", "RG48", 2), ("444", "RG24", 1), ("444", "BGRA", 1), ("444", "BGRa", 1), ("444", "r210", 1),
-                ("4444", "b64a", 1), ("4444", "b64a", 2), ("4444", "BGRA", 1), ("4444", "BGRa", 1), ("444", "b64a", 1), ("422", "RG24", 1), ("4444", "RG48", 1), ("4444", "RG48", 2)}
+                ("4444", "b64a", 1), ("4444", "b64a", 2), ("4444", "BGRA", 1), ("4444", "BGRa", 1), ("444", "b64a", 1), ("422", "RG24", 1), ("4444", "RG48", 1), ("4444", "RG48", 2),
+                ("444", "RG24", 2), ("444", "BGRA", 2), ("444", "BGRa", 2), ("444", "r210", 2), ("444", "b64a", 2)}
     dec = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
     aw = ctypes.c_int(); ah = ctypes.c_int(); af = ctypes.c_uint32()
     for enc, sample in samples.items():

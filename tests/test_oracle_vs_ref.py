@@ -368,6 +368,50 @@ def test_reference_rg48_decode_of_rgba4444_equals_oracle(w, h, seed):
     assert np.array_equal(img[:hrows], half[:hrows])
 
 
+def rgb444_sample_with_clips(w, h, seed):
+    frames, pitch = qbist_frames(seed, 1, w, h, PIX_RG48)
+    px = np.frombuffer(frames[0].tobytes(), dtype=np.uint16).reshape(h, pitch // 2).copy()
+    ramp = ((np.arange(h)[:, None] * 523 + np.arange(w)[None, :] * 97) % 65536).astype(np.uint16)
+    for k in range(3): px[:, k: w * 3: 3] = np.where(ramp > 60000, 65535, np.where(ramp < 4000, 0, px[:, k: w * 3: 3]))
+    return ref_encode_frames([px.reshape(-1).view(np.uint8).copy()], pitch, w, h, PIX_RG48, encoded=ENCODED_RGB444)[0]
+
+
+def half_rgb_view(buf, pitch, w, h, name):
+    """Rows of a half-resolution decode as oracle_half_resolution_rgb lays them out (top row first)."""
+    hw, hh = w // 2, h // 2
+    if name in ("RG24", "BGRA", "BGRa"):
+        img = np.frombuffer(buf.tobytes(), np.uint8).reshape(-1, pitch)[:hh, : hw * (3 if name == "RG24" else 4)]
+        return img if name == "BGRa" else img[::-1]
+    if name == "b64a": return np.frombuffer(buf.tobytes(), np.uint16).reshape(-1, pitch // 2)[:hh, : hw * 4]
+    return np.frombuffer(buf.tobytes(), np.uint32).reshape(-1, pitch // 4)[:hh, :hw]
+
+
+@pytest.mark.parametrize("w,h,seed", [(320, 240, 7), (336, 248, 3), (400, 120, 4), (720, 480, 5), (64, 64, 6), (1280, 720, 8), (1920, 1080, 9), (144, 96, 10)])
+def test_reference_half_resolution_of_rgb444_equals_model(w, h, seed):
+    """Pins oracle_half_resolution_rgb (restated from frame.c:7150 ConvertLowpassRGB444ToRGB and its callees, with the lowpass biases of decoder.c:12290-12312) on eight
+    geometries with ramps into both clips: the reference's half-resolution decode of an RGB 4:4:4 sample equals it word for word for r210 / DPX0 / AB10 / AR10 / b64a and
+    lies inside [r = 0, r = 31] for RG24 / BGRA / BGRa, reaching both ends."""
+    sample = rgb444_sample_with_clips(w, h, seed)
+    plan = Plan(w, h, pixkind=PIXKIND["RG48"], enc=ENC["444"])
+    deq = host_decode_pyramid(sample, plan)
+    hh = h // 2 if h % 8 == 0 else h // 2 - 4          # (1080: the reference's last rows, see test_reference_rgba8_decode_of_4444_equals_oracle)
+    for name in ("r210", "DPX0", "AB10", "AR10", "b64a"):
+        want = oracle_half_resolution_rgb(plan, deq, name)[: h // 2]
+        for attempt in range(6):                        # (now and then the reference returns a damaged frame: a few attempts, as for its full-resolution routes)
+            dec, dpitch = ref_decode_sample(sample, w, h, fourcc(name), resolution=2)
+            if np.array_equal(half_rgb_view(dec, dpitch, w, h, name)[:hh], want[:hh]): break
+        assert np.array_equal(half_rgb_view(dec, dpitch, w, h, name)[:hh], want[:hh]), name
+    for name in ("RG24", "BGRA", "BGRa"):
+        lo, hi = oracle_half_resolution_rgb(plan, deq, name, 0)[: h // 2], oracle_half_resolution_rgb(plan, deq, name, 31)[: h // 2]
+        for attempt in range(6):
+            dec, dpitch = ref_decode_sample(sample, w, h, fourcc(name), resolution=2)
+            img = half_rgb_view(dec, dpitch, w, h, name)
+            if ((img[:hh] >= lo[:hh]) & (img[:hh] <= hi[:hh])).all(): break
+        assert ((img[:hh] >= lo[:hh]) & (img[:hh] <= hi[:hh])).all(), name
+        moving = lo[:hh] != hi[:hh]
+        assert (img[:hh][moving] == lo[:hh][moving]).any() and (img[:hh][moving] == hi[:hh][moving]).any()
+
+
 def bayer_test_mosaic(w, h, seed):
     """synth_bayer with stretches at both clips (whole quads and single photosites) and a block of saturated red beside black green: r, b, g1, g2 clamp on both sides."""
     mosaic = synth_bayer(w, h, seed).copy()
