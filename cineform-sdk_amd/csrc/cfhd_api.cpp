@@ -1007,7 +1007,7 @@ CFHD_Error CFHD_PrepareToDecode(CFHD_DecoderRef ref, int, int, CFHD_PixelFormat 
 	// (bayer.c:11916 Row16uFull2OutputFormat); colour conversions between the families (ConvertLib / the colour part of the
 	// active-metadata pipeline in the reference) are not built
 	// ... and to YU64 (16-bit words Y0 C1 Y1 C2; the reference's planar 16-bit row route, full resolution, progressive samples)
-	if (kind == PIX_YU64 && (encf != ENC_YUV422 || half)) return ERR_BADFORMAT;
+	if (kind == PIX_YU64 && encf != ENC_YUV422) return ERR_BADFORMAT;      // (half resolution: frame.c:11146 ConvertLowpass16sToYUV64, k_half_yu64)
 	// ... and RGB 4:4:4 samples to the 8-bit pixels RG24 / BGRA / BGRa (the RG48 reconstruction reduced with the reference's four-bit dither; full resolution)
 	const bool rgb8 = kind == PIX_RG24 || kind == PIX_BGRA || kind == PIX_BGRa;
 	// ... and RGBA 4:4:4:4 samples to BGRA / BGRa (no dither there: (12-bit component + 2) >> 4, the alpha expanded from that rounded value)

@@ -659,7 +659,7 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 	const bool rgb_ok = ((out_kind == PIX_RG48 && plan.encoded_format == ENC_RGB444) || (out_kind == PIX_B64A && plan.encoded_format == ENC_RGBA4444) ||
 	                     (out_kind == PIX_B64A && plan.encoded_format == ENC_RGB444) || (out_kind == PIX_RG48 && plan.encoded_format == ENC_RGBA4444) || byr4_) &&
 	                    plan.ch[0].band[0][0].width >= 16;   // k_inv_packed16's tail-column rule assumes the reference's vector path
-	const bool yu64_ok = out_kind == PIX_YU64 && plan.encoded_format == ENC_YUV422 && !half && plan.ch[1].band[0][0].width >= 16;
+	const bool yu64_ok = out_kind == PIX_YU64 && plan.encoded_format == ENC_YUV422 && plan.ch[1].band[0][0].width >= 16;
 	const bool rgb8_ok = dec_rgb8(out_kind) && (plan.encoded_format == ENC_RGB444 || (plan.encoded_format == ENC_RGBA4444 && out_kind != PIX_RG24 && !half)) && plan.ch[0].band[0][0].width >= 16 && plan.ch[0].band[0][0].width % 2 == 0;
 	const bool rgb10_ok = dec_rgb10(out_kind) && plan.encoded_format == ENC_RGB444 && plan.ch[0].band[0][0].width >= 16;
 	if (!yuv_ok && !rgb_ok && !yu64_ok && !rgb8_ok && !rgb10_ok) { g_err = "output format not supported by the GPU path yet"; return -2; }
@@ -732,6 +732,13 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 			hp.pitch = plan.ch[0].band[0][0].pitch; hp.width = plan.ch[0].band[0][0].width; hp.rows = out_rows_; hp.nch = onch;
 			hp.shift = 16 - plan.precision - 2; hp.alpha = out_kind == PIX_B64A;
 			hp.out = own_output ? (uint16_t *)(d_out_ + frame_bytes_ * i) : nullptr; hp.out_pitch = out_pitch_;
+		}
+		if (half && out_kind == PIX_YU64) {                 // k_half_yu64
+			dev::HalfYuvJob &hj = j.half[i];
+			for (int c = 0; c < 3; c++) { hj.ll[c] = base + plan.ch[c].band[0][0].offset; hj.pitch[c] = plan.ch[c].band[0][0].pitch; }
+			hj.width = plan.ch[0].band[0][0].width; hj.rows = out_rows_; hj.uyvy = 0;
+			hj.out = own_output ? d_out_ + frame_bytes_ * i : nullptr; hj.out_pitch = out_pitch_;
+			continue;
 		}
 		if (dec_planes16(out_kind)) {
 			for (int c = 0; c < onch; c++) {
@@ -909,6 +916,9 @@ int DecodeBatch::launch_inverse(uint32_t dither_seed)
 	if (half_ && (dec_rgb8(out_kind_) || dec_rgb10(out_kind_) || (out_kind_ == PIX_B64A && nch == 3))) {
 		const BandDesc &b = plan_.ch[0].band[0][0];
 		dev::k_half_rgb<<<dim3((b.width + dev::NTHREADS - 1) / dev::NTHREADS, out_rows_, act), dev::NTHREADS, 0, st>>>(j.halfp, dither_seed);
+	} else if (half_ && out_kind_ == PIX_YU64) {
+		const BandDesc &b = plan_.ch[0].band[0][0];
+		dev::k_half_yu64<<<dim3((b.width / 2 + dev::NTHREADS - 1) / dev::NTHREADS, out_rows_, act), dev::NTHREADS, 0, st>>>(j.half);
 	} else if (half_ && is_packed16(out_kind_)) {
 		const BandDesc &b = plan_.ch[0].band[0][0];
 		dev::k_half_packed16<<<dim3((b.width / 8 + dev::NTHREADS - 1) / dev::NTHREADS, out_rows_, act), dev::NTHREADS, 0, st>>>(j.halfp);

@@ -2314,6 +2314,21 @@ __global__ void __launch_bounds__(NTHREADS) k_yu64_to_rgb24(const uint16_t *yu64
 	}
 }
 
+// Half resolution of 4:2:2 samples as YU64 (decoder.c:23066 -> frame.c:11146 ConvertLowpass16sToYUV64, its 10-bit branch): the level-1 lowpass planes (12 bits for
+// 10-bit samples, lowpass bias 4 as for every YU64 decode) clamped to [0, 4095], << 4, words Y0 C1 Y1 C2.  One thread per pixel pair.
+__global__ void __launch_bounds__(NTHREADS) k_half_yu64(const HalfYuvJob *jobs)
+{
+	const HalfYuvJob &job = jobs[blockIdx.z];
+	const int row = blockIdx.y, p = (int)(blockIdx.x * NTHREADS + threadIdx.x);
+	if (2 * p >= job.width) return;
+	auto word = [](int v) { return (uint32_t)(v < 0 ? 0 : (v > 4095 ? 4095 : v)) << 4; };
+	const int16_t *y = job.ll[0] + (size_t)row * job.pitch[0] + 2 * p;
+	uint2 px;
+	px.x = word(y[0]) | (word(job.ll[1][(size_t)row * job.pitch[1] + p]) << 16);
+	px.y = word(y[1]) | (word(job.ll[2][(size_t)row * job.pitch[2] + p]) << 16);
+	*(uint2 *)(job.out + (size_t)row * job.out_pitch + 8 * (size_t)p) = px;
+}
+
 // Half resolution of RGB 4:4:4 samples for the 8-bit, 10-bit and b64a outputs (decoder.c:26752 CopyLowpassRGB444ToBuffer -> frame.c:7150 ConvertLowpassRGB444ToRGB):
 // the level-1 lowpass planes G, R, B (14 bits for 12-bit samples), to which the reference's lowpass bias of the output format has come down unchanged
 // (8 for the 8-bit, 6 for the 10-bit formats: an even offset passes the descaling inverse levels exactly), then

@@ -596,6 +596,24 @@ def oracle_half_resolution16(plan, coeffs, b64a=False, expand_alpha=True):
     return half_resolution_model16(P, b64a, expand_alpha)
 
 
+def oracle_half_resolution_yu64(plan, coeffs):
+    """Half-resolution picture of a 4:2:2 sample as YU64 (frame.c:11146 ConvertLowpass16sToYUV64, 10-bit branch): the level-1 lowpass planes clamped to [0, 4095], << 4,
+    words Y0 C1 Y1 C2.  coeffs: decoded with the YU64 lowpass bias (Plan(..., pixkind=PIXKIND["YU64"]))."""
+    O = oracle()
+    work = coeffs.copy()
+    for c in range(3):
+        for lv in (2, 1):
+            d = plan.band[(c, lv, 0)]
+            bands = (c_i16p * 4)(*[plan.view(work, c, lv, b).ctypes.data_as(c_i16p) for b in range(4)])
+            dst = plan.view(work, c, lv - 1, 0)
+            O.orc_inv_spatial(bands, d["pitch"], d["width"], d["height"], plan.prescale[lv], dst.ctypes.data_as(c_i16p), plan.band[(c, lv - 1, 0)]["pitch"])
+    rows = plan.height // 2
+    Y, C1, C2 = [np.clip(plan.view(work, c, 0, 0)[:rows, : plan.band[(c, 0, 0)]["width"]].astype(np.int64), 0, 4095) << 4 for c in range(3)]
+    out = np.zeros((rows, 2 * Y.shape[1]), np.uint16)
+    out[:, 0::2] = Y; out[:, 1::4] = C1; out[:, 3::4] = C2
+    return out
+
+
 def oracle_half_resolution_rgb(plan, coeffs, name, r=0):
     """Half-resolution picture of an RGB 4:4:4 sample in the 8-bit (RG24 / BGRA / BGRa), 10-bit (r210 / DPX0 / AB10 / AR10) and b64a output formats, restated from
     frame.c:7150 ConvertLowpassRGB444ToRGB: the level-1 lowpass planes G, R, B plus the lowpass bias of the output format (decoder.c:12290-12312: 8 for 8-bit RGB,

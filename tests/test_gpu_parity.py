@@ -533,6 +533,25 @@ def test_rg30_is_ab10_under_another_name():
 
 
 @pytest.mark.parametrize("w,h", [(320, 240), (336, 248), (1920, 1080)])
+def test_half_resolution_decode_to_yu64_equals_reference_exactly(w, h):
+    """CFHD_DECODED_RESOLUTION_HALF of 4:2:2 samples as YU64 (TestCFHD's YU64 row at half resolution): the level-1 lowpass planes clamped to 12 bits, << 4 (frame.c:11146) --
+    word for word the model pinned on the reference (test_reference_half_resolution_yu64_equals_model) and the reference decoder's own output."""
+    from test_oracle_vs_ref import yu64_frame_with_ramps
+    sample = amd_encode_frames([yu64_frame_with_ramps(w, h, w + h)], w * 4, w, h, fourcc("YU64"))[0]
+    got, gpitch, aw, ah = amd_decode_sample(sample, fourcc("YU64"), resolution=2)
+    assert (aw, ah, gpitch) == (w // 2, h // 2, (w // 2) * 4)
+    mine = np.frombuffer(got.tobytes(), np.uint16).reshape(h // 2, gpitch // 2)
+    plan = Plan(w, h, pixkind=PIXKIND["YU64"])
+    assert np.array_equal(mine, oracle_half_resolution_yu64(plan, host_decode_pyramid(sample, plan))[: h // 2])
+    hh = h // 2 if h % 8 == 0 else h // 2 - 4
+    for attempt in range(6):
+        dec, dpitch = ref_decode_sample(sample, w, h, fourcc("YU64"), resolution=2)
+        img = np.frombuffer(dec.tobytes(), np.uint16).reshape(-1, dpitch // 2)[: h // 2, : w]
+        if np.array_equal(img[:hh], mine[:hh]): break
+    assert np.array_equal(img[:hh], mine[:hh])
+
+
+@pytest.mark.parametrize("w,h", [(320, 240), (336, 248), (1920, 1080)])
 def test_half_resolution_decode_of_rgb444_to_the_8bit_10bit_and_b64a_outputs(w, h):
     """CFHD_DECODED_RESOLUTION_HALF for the other outputs of RGB 4:4:4 samples (TestCFHD decodes every row of its table at full and at half resolution): r210 / DPX0 /
     AB10 / AR10 / RG30 / b64a word for word the restated conversion (oracle_half_resolution_rgb, pinned on the reference on eight geometries), RG24 / BGRA / BGRa inside
@@ -669,7 +688,7 @@ def test_yu64_decode_equals_reference_exactly(w, h, src):
     """4:2:2 samples decoded to YU64 (16-bit words Y0 C1 Y1 C2, no dither): word for word what the reference decoder delivers -- the
     reference sample of a YUY2 / of a YU64 frame with ramps into both clips (highlights saturate to 1023 << 6 in the reference's vector
     columns and to 65535 in its scalar tail columns, per plane) --, through CFHD_DecodeSample; the YU64 round trip of the product alone
-    decodes to the source within the quantizer's error; interlaced samples and half resolution are refused."""
+    decodes to the source within the quantizer's error; interlaced samples and quarter resolution are refused."""
     if src == "yu64":
         f16 = (np.random.default_rng(w + h).integers(0, 1024, size=(h, w * 2)) << 6).astype(np.uint16)
         f16[: h // 3] = (np.linspace(0, 65535, w * 2)[None, :]).astype(np.uint16)
@@ -695,7 +714,7 @@ def test_yu64_decode_equals_reference_exactly(w, h, src):
     dec = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
     aw_ = ctypes.c_int(); ah_ = ctypes.c_int(); af_ = ctypes.c_uint32()
     sb = ctypes.create_string_buffer(sample, len(sample))
-    assert L.CFHD_PrepareToDecode(dec, 0, 0, fourcc("YU64"), 2, 0, sb, 512, ctypes.byref(aw_), ctypes.byref(ah_), ctypes.byref(af_)) != 0
+    assert L.CFHD_PrepareToDecode(dec, 0, 0, fourcc("YU64"), 3, 0, sb, 512, ctypes.byref(aw_), ctypes.byref(ah_), ctypes.byref(af_)) != 0      # quarter resolution
     if src == "yuy2":
         isample = ref_encode_frames([f], p, w, h, PIX_YUY2, flags=1)[0]
         sb2 = ctypes.create_string_buffer(isample, len(isample))

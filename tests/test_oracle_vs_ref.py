@@ -412,6 +412,30 @@ def test_reference_half_resolution_of_rgb444_equals_model(w, h, seed):
         assert (img[:hh][moving] == lo[:hh][moving]).any() and (img[:hh][moving] == hi[:hh][moving]).any()
 
 
+def yu64_frame_with_ramps(w, h, seed):
+    f16 = (np.random.default_rng(seed).integers(0, 1024, size=(h, w * 2)) << 6).astype(np.uint16)
+    f16[: h // 3] = (np.linspace(0, 65535, w * 2)[None, :]).astype(np.uint16)
+    f16[h // 3: h // 2, : w] = 65535                      # a saturated block: the level-1 lowpass leaves the 12-bit range
+    f16[h // 3: h // 2, w:] = 0
+    return np.frombuffer(f16.tobytes(), np.uint8).copy()
+
+
+@pytest.mark.parametrize("w,h,seed", [(320, 240, 3), (336, 248, 4), (400, 120, 5), (720, 480, 6), (128, 64, 7), (1280, 720, 8), (1920, 1080, 9), (144, 96, 10)])
+def test_reference_half_resolution_yu64_equals_model(w, h, seed):
+    """Pins oracle_half_resolution_yu64 (frame.c:11146 ConvertLowpass16sToYUV64, 10-bit branch; lowpass bias 4, decoder.c:12265) on eight geometries with ramps and
+    saturated blocks: the reference's half-resolution YU64 decode of a 4:2:2 sample, word for word."""
+    sample = ref_encode_frames([yu64_frame_with_ramps(w, h, seed)], w * 4, w, h, fourcc("YU64"))[0]
+    plan = Plan(w, h, pixkind=PIXKIND["YU64"])
+    want = oracle_half_resolution_yu64(plan, host_decode_pyramid(sample, plan))[: h // 2]
+    hh = h // 2 if h % 8 == 0 else h // 2 - 4
+    for attempt in range(6):
+        dec, dpitch = ref_decode_sample(sample, w, h, fourcc("YU64"), resolution=2)
+        img = np.frombuffer(dec.tobytes(), np.uint16).reshape(-1, dpitch // 2)[: h // 2, : w]
+        if np.array_equal(img[:hh], want[:hh]): break
+    assert np.array_equal(img[:hh], want[:hh]), "%d words differ" % (img[:hh] != want[:hh]).sum()
+    assert (want == 0).any() and (want == 4095 << 4).any()
+
+
 def bayer_test_mosaic(w, h, seed):
     """synth_bayer with stretches at both clips (whole quads and single photosites) and a block of saturated red beside black green: r, b, g1, g2 clamp on both sides."""
     mosaic = synth_bayer(w, h, seed).copy()
