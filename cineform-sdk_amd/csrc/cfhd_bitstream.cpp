@@ -472,7 +472,12 @@ int lowpass_bias(int precision, int lowpass_width, int out_pixel_kind, int chann
 		if (!even && (out_pixel_kind == PIX_RG24 || out_pixel_kind == PIX_BGRA)) return channel == 0 ? 5 - 8 : 5 - 4;
 		return even ? 24 : 5;
 	}
-	return 0;                              // 12-bit: RG48 / b64a outputs carry no bias
+	if (precision == 12) {
+		// decoder.c:12290-12312: the 8-bit RGB outputs take 8, the 10-bit RGB words 6, the 16-bit outputs (RG48, b64a, ...) none; Bayer samples never any (:12316)
+		if (out_pixel_kind == PIX_RG24 || out_pixel_kind == PIX_BGRA || out_pixel_kind == PIX_BGRa) return 8;
+		if (out_pixel_kind >= PIX_R210 && out_pixel_kind <= PIX_AR10) return 6;
+	}
+	return 0;
 }
 
 // ------------------------------------------------------------------------------------------

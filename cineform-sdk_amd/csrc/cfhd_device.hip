@@ -720,7 +720,7 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 			dev::HalfPackedJob &hp = j.halfp[i];
 			for (int c = 0; c < 3; c++) { hp.ll[c] = base + plan.ch[c].band[0][0].offset; hp.word[c] = dec_rgb10(out_kind) ? rgb10_shift(out_kind, c) : 0; }
 			hp.pitch = plan.ch[0].band[0][0].pitch; hp.width = plan.ch[0].band[0][0].width; hp.rows = out_rows_; hp.nch = 3;
-			hp.mode = dec_rgb8(out_kind) ? 1 : (dec_rgb10(out_kind) ? 2 : 3); hp.bias = dec_rgb8(out_kind) ? 8 : (dec_rgb10(out_kind) ? 6 : 0);
+			hp.mode = dec_rgb8(out_kind) ? 1 : (dec_rgb10(out_kind) ? 2 : 3);
 			hp.bytes = dec_rgb8(out_kind) ? rgb8_bytes(out_kind) : 0; hp.bottom_up = out_kind == PIX_RG24 || out_kind == PIX_BGRA;
 			hp.big_endian = out_kind == PIX_R210 || out_kind == PIX_DPX0; hp.dither_seed = 0x9E3779B9u * (uint32_t)(i + 1);
 			hp.out = own_output ? (uint16_t *)(d_out_ + frame_bytes_ * i) : nullptr; hp.out_pitch = out_pitch_;

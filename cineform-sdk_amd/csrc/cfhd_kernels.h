@@ -187,8 +187,8 @@ struct HalfPackedJob {                      // k_half_packed16: level-1 lowpass 
 	int shift, alpha;                       // left shift to 16 bits (16 - precision - 2); alpha: plane 3 is the companded alpha of b64a
 	uint16_t *out; int out_pitch;           // bytes
 	// k_half_rgb (the other outputs of RGB 4:4:4 samples): mode 1 = 8-bit pixels B G R (A = 255), 2 = one 10-bit RGB word (word[c] = bit position of plane c),
-	// 3 = b64a words with the constant alpha 65535; bias = what the reference's lowpass bias (decoder.c:12290-12312) has become at level 1
-	int mode, bias, bytes, bottom_up, big_endian; uint32_t dither_seed;
+	// 3 = b64a words with the constant alpha 65535
+	int mode, bytes, bottom_up, big_endian; uint32_t dither_seed;
 };
 
 struct FwdFrameJob {                        // k_fwd_frame_yuv422: interlaced level 1 of a packed 8-bit 4:2:2 frame
@@ -805,7 +805,7 @@ __device__ __forceinline__ void inv_plane_tile(const InvPlaneJob *jobs, int nch,
 #pragma unroll
 					for (int k = 0; k < 2; k++) {
 						if (c + k >= w) break;
-						int se = (e[k] + 3) >> 3, so = (o[k] + 3) >> 3;
+						int se = e[k] >> 3, so = o[k] >> 3;      // (13 bits -> 10; the format's lowpass bias of 6, decoder.c:12304, is the rounding)
 						se = se < 0 ? 0 : (se > 1023 ? 1023 : se); so = so < 0 ? 0 : (so > 1023 ? 1023 : so);
 						const uint32_t be = (uint32_t)se << job.bit_shift, bo = (uint32_t)so << job.bit_shift;
 						if (comp == 0) { d32[2 * k] = be; d32[2 * k + 1] = bo; } else { d32[2 * k] |= be; d32[2 * k + 1] |= bo; }
@@ -817,7 +817,7 @@ __device__ __forceinline__ void inv_plane_tile(const InvPlaneJob *jobs, int nch,
 				const size_t at = (size_t)(2 * rl + par) * (2 * ITW) * wps + (size_t)(4 * p) * xs + word;      // sample 2 (c - c0) of tile row 2 rl + par
 				uint16_t *dst = s_out + at;
 				uint8_t *dst8 = (uint8_t *)s_out + at;
-				const uint32_t dz = bytes8 ? dither_word((job.dither_seed ^ launch_seed) + (uint32_t)word * 0x632BE5ABu, orow, c >> 2) >> (16 * (p & 1)) : 0u;      // four bits per sample
+				const uint32_t dz = bytes8 ? dither_word((job.dither_seed ^ launch_seed) + (uint32_t)word * 0x632BE5ABu, orow, c >> 1) : 0u;      // seven bits for each of the thread's four samples
 #pragma unroll
 				for (int k = 0; k < 2; k++) {
 					if (c + k >= w) break;
@@ -825,7 +825,7 @@ __device__ __forceinline__ void inv_plane_tile(const InvPlaneJob *jobs, int nch,
 					uint32_t we = to16(e[k], job.precision, tail), wo = to16(o[k], job.precision, tail);
 					if (job.alpha && !bytes8) { we = expand_alpha16(we); wo = expand_alpha16(wo); }
 					if (job.bytes8 == 2) {
-						int be = (int)(we >> 4) + 2, bo = (int)(wo >> 4) + 2;
+						int be = (int)(we >> 4), bo = (int)(wo >> 4);      // (12-bit values; the lowpass bias of 8, decoder.c:12294, has become their + 2)
 						if (job.alpha) {
 							be -= 256; bo -= 256;
 							be = be < 0 ? 0 : ((be << 3) * 9400) >> 20; bo = bo < 0 ? 0 : ((bo << 3) * 9400) >> 20;
@@ -835,7 +835,8 @@ __device__ __forceinline__ void inv_plane_tile(const InvPlaneJob *jobs, int nch,
 						continue;
 					}
 					if (bytes8) {
-						we = ((we >> 3) + 9u + ((dz >> (8 * k)) & 15u)) >> 5; wo = ((wo >> 3) + 9u + ((dz >> (8 * k + 4)) & 15u)) >> 5;
+						we = we + 39u + ((dz >> (16 * k)) & 127u); wo = wo + 39u + ((dz >> (16 * k + 8)) & 127u);      // convert.c:6151 with shift 8: (rand() & 127) + 10 * 127 / 32, unsigned saturating add
+						we = (we > 65535u ? 65535u : we) >> 8; wo = (wo > 65535u ? 65535u : wo) >> 8;
 						dst8[(2 * k) * xs] = (uint8_t)(we > 255u ? 255u : we);
 						dst8[(2 * k + 1) * xs] = (uint8_t)(wo > 255u ? 255u : wo);
 						continue;
@@ -2330,8 +2331,8 @@ __global__ void __launch_bounds__(NTHREADS) k_half_yu64(const HalfYuvJob *jobs)
 }
 
 // Half resolution of RGB 4:4:4 samples for the 8-bit, 10-bit and b64a outputs (decoder.c:26752 CopyLowpassRGB444ToBuffer -> frame.c:7150 ConvertLowpassRGB444ToRGB):
-// the level-1 lowpass planes G, R, B (14 bits for 12-bit samples), to which the reference's lowpass bias of the output format has come down unchanged
-// (8 for the 8-bit, 6 for the 10-bit formats: an even offset passes the descaling inverse levels exactly), then
+// the level-1 lowpass planes G, R, B (14 bits for 12-bit samples; they carry the lowpass bias of the output format, decoder.c:12290-12312: 8 for the 8-bit,
+// 6 for the 10-bit formats), then
 //   8 bit (frame.c:7226 / :7241 -> convert.c:6151 ConvertPlanarRGB16uToPackedRGB32 with shift 6): (v + 9 + r) clamped to 14 bits, >> 6, r = rand() & 31 shared by
 //          the three components of a pixel (here: a counter-based hash); RG24 / BGRA bottom row first;
 //   10 bit (frame.c:7662 ConvertLowpassRGB444ToRGB30): (v << 2) saturated to 16 bits, >> 6, at the format's bit positions;
@@ -2344,7 +2345,7 @@ __global__ void __launch_bounds__(NTHREADS) k_half_rgb(const HalfPackedJob *jobs
 	if (x >= job.width) return;
 	int v[3];
 #pragma unroll
-	for (int c = 0; c < 3; c++) v[c] = (int)job.ll[c][(size_t)row * job.pitch + x] + job.bias;      // G, R, B
+	for (int c = 0; c < 3; c++) v[c] = (int)job.ll[c][(size_t)row * job.pitch + x];      // G, R, B (the lowpass bias of the output format is in them: lowpass_bias())
 	if (job.mode == 1) {
 		const int r = (int)(dither_word(job.dither_seed ^ launch_seed, row, x) & 31u);
 		const int yrow = job.bottom_up ? job.rows - 1 - row : row;

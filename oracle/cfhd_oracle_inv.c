@@ -318,11 +318,11 @@ void orc_inv_spatial_to_yu64(PIXEL16 *const bands[3][4], const int band_pitch[3]
 }
 
 /* ---- RGB 4:4:4 samples decoded to the 8-bit RGB formats (RG24, BGRA: bottom row first; BGRa: top row first) ------------------------
- * Probed on the built reference (tests/test_oracle_vs_ref.py): every byte is the 12-bit component of the RG48 decode, doubled, plus 9,
- * plus a random r in 0..15 per component, >> 5, saturated to 255 -- i.e. out = (v12 + (9 + r) / 2) >> 4: never above the plain
- * >> 4 by more than one, always equal to it when the low four bits of v12 are <= 3, always one above when they are >= 12 (measured
- * P(+1) = 0, 0, 0, 0, 1/16, 3/16, ... 15/16, 1, 1, 1, 1 by the low four bits).  The reference draws r with rand(); the oracle takes
- * it as an input so that both ends of the interval can be computed.  Bytes B, G, R (, A = 255); planes are G, R, B. */
+ * Codec/wavelet.c:4700-4950 TransformInverseRGB444ToRGB32: the planes as 16-bit rows (InvertSpatial*Row16sToYUV16: orc_inv_spatial_to_rgb48), packed two rows at
+ * a time by Codec/convert.c:6151 ConvertPlanarRGB16uToPackedRGB32 / :6475 ...RGB24 with shift 8: every word takes an unsigned saturating add of
+ * (rand() & 127) + 10 * 127 / 32 -- the same eight-lane rounding vector for the three components -- and loses its low byte.  The pyramid this runs on carries the
+ * lowpass bias of these output formats, 8 (Codec/decoder.c:12290-12296): the caller adds it.  The reference draws with rand(); the oracle takes r in 0..127 as an
+ * input so that both ends of the interval can be computed (pinned: every byte of the reference inside, both ends reached).  Bytes B, G, R (, A = 255). */
 void orc_inv_spatial_to_rgb8(PIXEL16 *const bands[4][4], int band_pitch, int w, int h, int precision, int display_height, int bytes_per_pixel, int bottom_up,
                              int r, uint8_t *out, int out_pitch_bytes)
 {
@@ -335,8 +335,9 @@ void orc_inv_spatial_to_rgb8(PIXEL16 *const bands[4][4], int band_pitch, int w, 
 		for (x = 0; x < W; x++) {
 			for (c = 0; c < 3; c++) {                      /* RG48 words R, G, B -> bytes B, G, R */
 				const int a = tmp[((size_t)y * W + x) * 3 + c];
-				int v = ((a >> 3) + 9 + r) >> 5;
-				o[(size_t)x * bytes_per_pixel + (2 - c)] = (uint8_t)(v > 255 ? 255 : v);
+				int v = a + 39 + r;                          /* _mm_adds_epu16(word, (rand() & 127) + 10 * 127 / 32) */
+				v = (v > 65535 ? 65535 : v) >> 8;
+				o[(size_t)x * bytes_per_pixel + (2 - c)] = (uint8_t)v;
 			}
 			if (bytes_per_pixel == 4) o[(size_t)x * 4 + 3] = 255;
 		}
@@ -361,10 +362,11 @@ void orc_inv_spatial_prepack(PIXEL16 *const bands[4], int band_pitch, int w, int
 }
 
 /* ---- RGB 4:4:4 samples decoded to the 10-bit RGB words r210 / DPX0 (big-endian) / AB10 / AR10 (little-endian) -------------------
- * Probed on the built reference and pinned in tests/test_oracle_vs_ref.py: every component is the last-level reconstruction before its
- * final >> 1 (13 bits for 12-bit samples), + 3, >> 3, clamped to [0, 1023] -- one rounding from 13 to 10 bits, not the 12-bit value
- * shifted --, at the bit positions the encoder reads them from (r210: R 20-29, G 10-19, B 0-9; DPX0: 22 / 12 / 2; AB10: R 0-9, G 10-19,
- * B 20-29; AR10: R 20-29, G 10-19, B 0-9).  Planes are G, R, B.  shift_r/g/b: bit positions; big_endian: words stored byte-swapped. */
+ * First fitted by probing (round 2: "(v + 3) >> 3"), now explained: the reference adds a lowpass bias of 6 for these output formats (Codec/decoder.c:12304-12310),
+ * which reaches the last-level reconstruction before its final >> 1 as + 3 (an even bias passes the descaling levels unchanged), and its output stage
+ * truncates that 13-bit value to 10 bits.  So: the caller's pyramid carries the bias, every component is v >> 3 clamped to [0, 1023], at the bit positions the
+ * encoder reads them from (r210: R 20-29, G 10-19, B 0-9; DPX0: 22 / 12 / 2; AB10: R 0-9, G 10-19, B 20-29; AR10: R 20-29, G 10-19, B 0-9).  Pinned word for word
+ * in tests/test_oracle_vs_ref.py.  Planes are G, R, B.  shift_r/g/b: bit positions; big_endian: words stored byte-swapped. */
 void orc_inv_spatial_to_rgb10(PIXEL16 *const bands[4][4], int band_pitch, int w, int h, int display_height, int shift_r, int shift_g, int shift_b, int big_endian,
                               uint32_t *out, int out_pitch_words)
 {
@@ -376,7 +378,7 @@ void orc_inv_spatial_to_rgb10(PIXEL16 *const bands[4][4], int band_pitch, int w,
 		orc_inv_spatial_prepack(bands[c], band_pitch, w, h, v, W);
 		for (y = 0; y < display_height; y++)
 			for (x = 0; x < W; x++) {
-				int s = (v[(size_t)y * W + x] + 3) >> 3;
+				int s = v[(size_t)y * W + x] >> 3;          /* 13 bits -> 10; rounding comes from the lowpass bias (6) the caller's pyramid carries */
 				s = s < 0 ? 0 : (s > 1023 ? 1023 : s);
 				out[(size_t)y * out_pitch_words + x] |= (uint32_t)s << shifts[c];
 			}
@@ -418,8 +420,9 @@ void orc_inv_spatial_to_v210(PIXEL16 *const bands[3][4], const int band_pitch[3]
 
 /* ---- RGBA 4:4:4:4 samples decoded to BGRA (bottom row first) / BGRa (top row first) ------------------------------------------------------
  * Probed on the built reference and pinned in tests/test_oracle_vs_ref.py (this route draws no dither: the reference's output is the same from
- * call to call): every colour byte is the 12-bit component of the 16-bit reconstruction (orc_inv_spatial_to_rgb48 with four planes) plus 2,
- * >> 4, saturated to 255; the alpha byte takes the same rounded 12-bit value through the reference's alpha expansion -- minus
+ * call to call): every colour byte is the 12-bit component of the 16-bit reconstruction (orc_inv_spatial_to_rgb48 with four planes; the caller's pyramid
+ * carries the lowpass bias 8 of the 8-bit RGB outputs, Codec/decoder.c:12294, which arrives here as + 2 -- the "rounding" the first fit of this model found)
+ * >> 4, saturated to 255; the alpha byte takes the same 12-bit value through the reference's alpha expansion -- minus
  * alphacompandDCoffset 256, << 3, times alphacompandGain 9400 >> 16, >> 4 (Codec/codec.h:164-165; the arithmetic of the scalar code at
  * Codec/convert.c:6391-6396) --, clamped to [0, 255].  Bytes B, G, R, A; planes are G, R, B, A. */
 void orc_inv_spatial_to_rgba8(PIXEL16 *const bands[4][4], int band_pitch, int w, int h, int precision, int display_height, int bottom_up, uint8_t *out, int out_pitch_bytes)
@@ -433,10 +436,10 @@ void orc_inv_spatial_to_rgba8(PIXEL16 *const bands[4][4], int band_pitch, int w,
 		for (x = 0; x < W; x++) {
 			int a;
 			for (c = 0; c < 3; c++) {                      /* words R, G, B -> bytes B, G, R */
-				const int v = ((tmp[((size_t)y * W + x) * 4 + c] >> 4) + 2) >> 4;
+				const int v = (tmp[((size_t)y * W + x) * 4 + c] >> 4) >> 4;
 				o[(size_t)x * 4 + (2 - c)] = (uint8_t)(v > 255 ? 255 : v);
 			}
-			a = (tmp[((size_t)y * W + x) * 4 + 3] >> 4) + 2 - 256;
+			a = (tmp[((size_t)y * W + x) * 4 + 3] >> 4) - 256;
 			a = a < 0 ? 0 : (((a << 3) * 9400) >> 16) >> 4;
 			o[(size_t)x * 4 + 3] = (uint8_t)(a > 255 ? 255 : a);
 		}

@@ -616,12 +616,12 @@ def oracle_half_resolution_yu64(plan, coeffs):
 
 def oracle_half_resolution_rgb(plan, coeffs, name, r=0):
     """Half-resolution picture of an RGB 4:4:4 sample in the 8-bit (RG24 / BGRA / BGRa), 10-bit (r210 / DPX0 / AB10 / AR10) and b64a output formats, restated from
-    frame.c:7150 ConvertLowpassRGB444ToRGB: the level-1 lowpass planes G, R, B plus the lowpass bias of the output format (decoder.c:12290-12312: 8 for 8-bit RGB,
-    6 for 10-bit RGB -- an even bias comes down the descaling levels unchanged), then 8 bit: (v + 9 + r) clamped to 14 bits >> 6 with r = rand() & 31 per pixel
+    frame.c:7150 ConvertLowpassRGB444ToRGB: the level-1 lowpass planes G, R, B of a pyramid that carries the lowpass bias of the output format (decoder.c:12290-12312:
+    8 for 8-bit RGB, 6 for 10-bit RGB: with_lowpass_bias), then 8 bit: (v + 9 + r) clamped to 14 bits >> 6 with r = rand() & 31 per pixel
     (convert.c:6151, shift 6; the caller passes r = 0 / 31 for the two ends), RG24 / BGRA bottom row first; 10 bit: (v << 2) saturated >> 6 (frame.c:7662);
     b64a: (v << 2) saturated, alpha 65535 (frame.c:7494).  Returns rows of bytes / 32-bit words / 16-bit words."""
     O = oracle()
-    work = coeffs.copy()
+    work = with_lowpass_bias(plan, coeffs, 8 if name in ("RG24", "BGRA", "BGRa") else (0 if name == "b64a" else 6))
     for c in range(3):
         for lv in (2, 1):
             d = plan.band[(c, lv, 0)]
@@ -634,7 +634,7 @@ def oracle_half_resolution_rgb(plan, coeffs, name, r=0):
         bpp = 3 if name == "RG24" else 4
         out = np.full((rows, G.shape[1], bpp), 255, np.uint8)
         for byte, pl in ((0, B), (1, G), (2, R)):
-            out[:, :, byte] = np.clip(pl + 8 + 9 + r, 0, 16383) >> 6
+            out[:, :, byte] = np.clip(pl + 9 + r, 0, 16383) >> 6
         return out.reshape(rows, -1)
     if name == "b64a":
         out = np.zeros((rows, G.shape[1], 4), np.uint16)
@@ -642,7 +642,7 @@ def oracle_half_resolution_rgb(plan, coeffs, name, r=0):
         for word, pl in ((1, R), (2, G), (3, B)): out[:, :, word] = np.clip(pl << 2, 0, 65535)
         return out.reshape(rows, -1)
     shifts = {"r210": (20, 10, 0), "DPX0": (22, 12, 2), "AB10": (0, 10, 20), "AR10": (20, 10, 0), "RG30": (0, 10, 20)}[name]
-    words = sum((np.clip((pl + 6) << 2, 0, 65535) >> 6) << sh for sh, pl in zip(shifts, (R, G, B))).astype(np.uint32)
+    words = sum((np.clip(pl << 2, 0, 65535) >> 6) << sh for sh, pl in zip(shifts, (R, G, B))).astype(np.uint32)
     return words.byteswap() if name in ("r210", "DPX0") else words
 
 
@@ -831,10 +831,22 @@ def oracle_rgb16_to_yuv422_planes(words, words_per_pixel, r_word, w, h, color_sp
     return [Y, C1, C2]
 
 
+def with_lowpass_bias(plan, coeffs, want):
+    """A copy of a pyramid from host_decode_pyramid(sample, plan) whose lowpass bands carry the bias `want` of the output format in question (decoder.c:12290-12312:
+    8 for the 8-bit RGB outputs of 12-bit samples, 6 for the 10-bit RGB words, 0 for the 16-bit ones) whatever output kind the plan was made for."""
+    applied = 0
+    if plan.precision == 12:
+        applied = 8 if plan.pixkind in (PIXKIND["RG24"], PIXKIND["BGRA"], PIXKIND["BGRa"]) else (6 if plan.pixkind in (PIXKIND["r210"], PIXKIND["DPX0"], PIXKIND["AB10"], PIXKIND["AR10"]) else 0)
+    out = coeffs.copy()
+    if want != applied:
+        for c in range(plan.num_channels): plan.view(out, c, 2, 0)[:] += want - applied
+    return out
+
+
 def oracle_inverse_rgb10(plan, coeffs, name):
     """Whole inverse path with the oracle from a dequantized RGB 4:4:4 pyramid to the 32-bit words of r210 / DPX0 / AB10 / AR10 (as they lie in memory)."""
     O = oracle()
-    work = coeffs.copy()
+    work = with_lowpass_bias(plan, coeffs, 6)
     for c in range(3):
         for lv in (2, 1):
             d = plan.band[(c, lv, 0)]
@@ -852,9 +864,9 @@ def oracle_inverse_rgb10(plan, coeffs, name):
 
 
 def oracle_inverse_rgb8(plan, coeffs, bytes_per_pixel, bottom_up, r):
-    """Whole inverse path with the oracle from a dequantized RGB 4:4:4 pyramid to 8-bit B, G, R(, A) pixels with the dither value r (0..15)."""
+    """Whole inverse path with the oracle from a dequantized RGB 4:4:4 pyramid to 8-bit B, G, R(, A) pixels with the dither value r (0..127)."""
     O = oracle()
-    work = coeffs.copy()
+    work = with_lowpass_bias(plan, coeffs, 8)
     for c in range(3):
         for lv in (2, 1):
             d = plan.band[(c, lv, 0)]
@@ -1053,7 +1065,8 @@ def oracle_inverse_rgba8(plan, coeffs, bottom_up):
     alternative alpha bytes of a row on which the reference lost its alpha_Companded race: the companded value rounded the same way)."""
     O = oracle()
     O.orc_inv_spatial_to_rgba8.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 6 + [ctypes.c_void_p, ctypes.c_int]
-    work = coeffs.copy()
+    work = with_lowpass_bias(plan, coeffs, 8)
+    biased = work.copy()
     for c in range(4):
         for lv in (2, 1):
             d = plan.band[(c, lv, 0)]
@@ -1064,8 +1077,8 @@ def oracle_inverse_rgba8(plan, coeffs, bottom_up):
     flat = [plan.view(work, c, 0, b).ctypes.data_as(c_i16p) for c in range(4) for b in range(4)]
     out = np.zeros((plan.height, 2 * d["width"] * 4), np.uint8)
     O.orc_inv_spatial_to_rgba8((c_i16p * 16)(*flat), d["pitch"], d["width"], d["height"], plan.precision, plan.height, int(bottom_up), out.ctypes.data_as(ctypes.c_void_p), out.shape[1])
-    raw = oracle_inverse_rgb48(plan, coeffs, b64a=False)[: plan.height].reshape(plan.height, -1, 4)[:, :, 3].astype(np.int64)
-    alt = np.minimum(((raw >> 4) + 2) >> 4, 255).astype(np.uint8)
+    raw = oracle_inverse_rgb48(plan, biased, b64a=False)[: plan.height].reshape(plan.height, -1, 4)[:, :, 3].astype(np.int64)
+    alt = np.minimum((raw >> 4) >> 4, 255).astype(np.uint8)
     return out, (alt[::-1] if bottom_up else alt)
 
 

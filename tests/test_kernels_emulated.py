@@ -557,7 +557,7 @@ def test_inv_rgb8_last_level_lies_in_oracle_interval(w, h, dh, bpp, bottom_up):
     O = oracle()
     O.orc_inv_spatial_to_rgb8.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 8 + [ctypes.c_void_p, ctypes.c_int]
     ends = []
-    for r in (0, 15):
+    for r in (0, 127):
         o = np.zeros((dh, 2 * w * bpp), np.uint8)
         O.orc_inv_spatial_to_rgb8((c_i16p * 16)(*(flat + [None] * 4)), pitch, w, h, 12, dh, bpp, bottom_up, r, o.ctypes.data_as(ctypes.c_void_p), 2 * w * bpp)
         ends.append(o)

@@ -252,7 +252,7 @@ def test_reference_rgb8_decode_lies_in_oracle_dither_interval(w, h, name):
     coeffs = host_decode_pyramid(sample, plan)
     bpp = 3 if name == "RG24" else 4
     lo = oracle_inverse_rgb8(plan, coeffs, bpp, name != "BGRa", 0)
-    hi = oracle_inverse_rgb8(plan, coeffs, bpp, name != "BGRa", 15)
+    hi = oracle_inverse_rgb8(plan, coeffs, bpp, name != "BGRa", 127)
     assert ((hi.astype(int) - lo) >= 0).all() and ((hi.astype(int) - lo) <= 1).all()
     for attempt in range(6):                            # (the reference's threaded decoder occasionally damages a frame)
         dec, dpitch = ref_decode_sample(sample, w, h, fourcc(name))
