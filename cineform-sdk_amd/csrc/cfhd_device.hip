@@ -660,7 +660,7 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 	                     (out_kind == PIX_B64A && plan.encoded_format == ENC_RGB444) || (out_kind == PIX_RG48 && plan.encoded_format == ENC_RGBA4444) || byr4_) &&
 	                    plan.ch[0].band[0][0].width >= 16;   // k_inv_packed16's tail-column rule assumes the reference's vector path
 	const bool yu64_ok = out_kind == PIX_YU64 && plan.encoded_format == ENC_YUV422 && plan.ch[1].band[0][0].width >= 16;
-	const bool rgb8_ok = dec_rgb8(out_kind) && (plan.encoded_format == ENC_RGB444 || (plan.encoded_format == ENC_RGBA4444 && out_kind != PIX_RG24 && !half)) && plan.ch[0].band[0][0].width >= 16 && plan.ch[0].band[0][0].width % 2 == 0;
+	const bool rgb8_ok = dec_rgb8(out_kind) && (plan.encoded_format == ENC_RGB444 || (plan.encoded_format == ENC_RGBA4444 && out_kind != PIX_RG24)) && plan.ch[0].band[0][0].width >= 16 && plan.ch[0].band[0][0].width % 2 == 0;
 	const bool rgb10_ok = dec_rgb10(out_kind) && plan.encoded_format == ENC_RGB444 && plan.ch[0].band[0][0].width >= 16;
 	if (!yuv_ok && !rgb_ok && !yu64_ok && !rgb8_ok && !rgb10_ok) { g_err = "output format not supported by the GPU path yet"; return -2; }
 	plan_ = plan; n_ = nframes; out_kind_ = out_kind; own_output_ = own_output;
@@ -719,7 +719,8 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 		if (half && (dec_rgb8(out_kind) || dec_rgb10(out_kind) || (out_kind == PIX_B64A && nch == 3))) {      // k_half_rgb
 			dev::HalfPackedJob &hp = j.halfp[i];
 			for (int c = 0; c < 3; c++) { hp.ll[c] = base + plan.ch[c].band[0][0].offset; hp.word[c] = dec_rgb10(out_kind) ? rgb10_shift(out_kind, c) : 0; }
-			hp.pitch = plan.ch[0].band[0][0].pitch; hp.width = plan.ch[0].band[0][0].width; hp.rows = out_rows_; hp.nch = 3;
+			hp.pitch = plan.ch[0].band[0][0].pitch; hp.width = plan.ch[0].band[0][0].width; hp.rows = out_rows_; hp.nch = dec_rgb8(out_kind) && nch == 4 ? 4 : 3;
+			if (hp.nch == 4) hp.ll[3] = base + plan.ch[3].band[0][0].offset;
 			hp.mode = dec_rgb8(out_kind) ? 1 : (dec_rgb10(out_kind) ? 2 : 3);
 			hp.bytes = dec_rgb8(out_kind) ? rgb8_bytes(out_kind) : 0; hp.bottom_up = out_kind == PIX_RG24 || out_kind == PIX_BGRA;
 			hp.big_endian = out_kind == PIX_R210 || out_kind == PIX_DPX0; hp.dither_seed = 0x9E3779B9u * (uint32_t)(i + 1);

@@ -2351,9 +2351,15 @@ __global__ void __launch_bounds__(NTHREADS) k_half_rgb(const HalfPackedJob *jobs
 		const int yrow = job.bottom_up ? job.rows - 1 - row : row;
 		uint8_t *o = (uint8_t *)job.out + (size_t)yrow * job.out_pitch + (size_t)x * job.bytes;
 		const int order[3] = { 2, 0, 1 };                  // bytes B, G, R <- planes B, G, R
+		const bool four = job.nch == 4;                    // BGRA / BGRa of an RGBA 4:4:4:4 sample: the planar-row route, no dither (as at full resolution: the 12-bit value >> 4)
 #pragma unroll
-		for (int k = 0; k < 3; k++) { int t = v[order[k]] + 9 + r; t = t < 0 ? 0 : (t > 0x3fff ? 0x3fff : t); o[k] = (uint8_t)(t >> 6); }
-		if (job.bytes == 4) o[3] = 255;
+		for (int k = 0; k < 3; k++) { int t = v[order[k]] + (four ? 0 : 9 + r); t = t < 0 ? 0 : (t > 0x3fff ? 0x3fff : t); o[k] = (uint8_t)(t >> 6); }
+		if (four) {
+			int a = (int)job.ll[3][(size_t)row * job.pitch + x];
+			a = (a < 0 ? 0 : (a > 0x3fff ? 0x3fff : a)) >> 2;      // 12 bits, then the alpha expansion of codec.h:164-165
+			a -= 256; a = a < 0 ? 0 : (((a << 3) * 9400) >> 16) >> 4;
+			o[3] = (uint8_t)(a > 255 ? 255 : a);
+		} else if (job.bytes == 4) o[3] = 255;
 	} else if (job.mode == 2) {
 		uint32_t w = 0;
 #pragma unroll

@@ -596,6 +596,27 @@ def oracle_half_resolution16(plan, coeffs, b64a=False, expand_alpha=True):
     return half_resolution_model16(P, b64a, expand_alpha)
 
 
+def oracle_half_resolution_rgba8(plan, coeffs):
+    """Half-resolution picture of an RGBA 4:4:4:4 sample as BGRa bytes (top row first; BGRA is the same upside down): the level-1 lowpass planes of a pyramid with the
+    lowpass bias 8 of the 8-bit RGB outputs, clamped to 14 bits; colour = >> 6, alpha = the 12-bit value (>> 2) through the alpha expansion of codec.h:164-165 -- the
+    planar-row route of the full-resolution decode (orc_inv_spatial_to_rgba8) fed with the lowpass planes; no dither.  Pinned on the reference decoder."""
+    O = oracle()
+    work = with_lowpass_bias(plan, coeffs, 8)
+    for c in range(4):
+        for lv in (2, 1):
+            d = plan.band[(c, lv, 0)]
+            bands = (c_i16p * 4)(*[plan.view(work, c, lv, b).ctypes.data_as(c_i16p) for b in range(4)])
+            dst = plan.view(work, c, lv - 1, 0)
+            O.orc_inv_spatial(bands, d["pitch"], d["width"], d["height"], plan.prescale[lv], dst.ctypes.data_as(c_i16p), plan.band[(c, lv - 1, 0)]["pitch"])
+    rows = plan.height // 2
+    G, R, B, A = [np.clip(plan.view(work, c, 0, 0)[:rows, : plan.band[(c, 0, 0)]["width"]].astype(np.int64), 0, 16383) for c in range(4)]
+    out = np.zeros((rows, G.shape[1], 4), np.uint8)
+    out[:, :, 0] = B >> 6; out[:, :, 1] = G >> 6; out[:, :, 2] = R >> 6
+    a = np.maximum((A >> 2) - 256, 0)
+    out[:, :, 3] = np.clip((((a << 3) * 9400) >> 16) >> 4, 0, 255)
+    return out.reshape(rows, -1)
+
+
 def oracle_half_resolution_yu64(plan, coeffs):
     """Half-resolution picture of a 4:2:2 sample as YU64 (frame.c:11146 ConvertLowpass16sToYUV64, 10-bit branch): the level-1 lowpass planes clamped to [0, 4095], << 4,
     words Y0 C1 Y1 C2.  coeffs: decoded with the YU64 lowpass bias (Plan(..., pixkind=PIXKIND["YU64"]))."""

@@ -533,6 +533,29 @@ def test_rg30_is_ab10_under_another_name():
 
 
 @pytest.mark.parametrize("w,h", [(320, 240), (336, 248), (1920, 1080)])
+def test_half_resolution_decode_of_rgba4444_to_bgra(w, h):
+    """CFHD_DECODED_RESOLUTION_HALF of RGBA 4:4:4:4 samples as BGRA / BGRa (TestCFHD's BGRA / BGRa -> 4:4:4:4 rows at half resolution): byte for byte the model pinned on the
+    reference (test_reference_half_resolution_bgra_of_rgba4444_equals_model; no dither on this route), and the reference decoder's own colour bytes."""
+    from test_oracle_vs_ref import rgba4444_sample_with_clips
+    sample = rgba4444_sample_with_clips(w, h, w + h)
+    plan = Plan(w, h, pixkind=PIXKIND["b64a"], enc=ENC["4444"])
+    want = oracle_half_resolution_rgba8(plan, host_decode_pyramid(sample, plan))[: h // 2]
+    hh = h // 2 if h % 8 == 0 else h // 2 - 4
+    for name in ("BGRa", "BGRA"):
+        got, gpitch, aw, ah = amd_decode_sample(sample, fourcc(name), resolution=2)
+        assert (aw, ah) == (w // 2, h // 2)
+        mine = np.frombuffer(got.tobytes(), np.uint8).reshape(h // 2, gpitch)[:, : (w // 2) * 4]
+        if name == "BGRA": mine = mine[::-1]
+        assert np.array_equal(mine, want), name
+        for attempt in range(6):
+            dec, dpitch = ref_decode_sample(sample, w, h, fourcc(name), resolution=2)
+            img = np.frombuffer(dec.tobytes(), np.uint8).reshape(-1, dpitch)[: h // 2, : (w // 2) * 4]
+            if name == "BGRA": img = img[::-1]
+            if all(np.array_equal(img[:hh, k::4], mine[:hh, k::4]) for k in range(3)): break
+        assert all(np.array_equal(img[:hh, k::4], mine[:hh, k::4]) for k in range(3)), name
+
+
+@pytest.mark.parametrize("w,h", [(320, 240), (336, 248), (1920, 1080)])
 def test_half_resolution_decode_to_yu64_equals_reference_exactly(w, h):
     """CFHD_DECODED_RESOLUTION_HALF of 4:2:2 samples as YU64 (TestCFHD's YU64 row at half resolution): the level-1 lowpass planes clamped to 12 bits, << 4 (frame.c:11146) --
     word for word the model pinned on the reference (test_reference_half_resolution_yu64_equals_model) and the reference decoder's own output."""

@@ -502,7 +502,7 @@ def test_decoder_output_format_gates():
     accepted = {("422", "YUY2", 1), ("422", "YUY2", 2), ("422", "2vuy", 1), ("422", "2vuy", 2), ("422", "YU64", 1), ("422", "YU64", 2),
                 ("444", "RG48", 1), ("444", "RG48", 2), ("444", "RG24", 1), ("444", "BGRA", 1), ("444", "BGRa", 1), ("444", "r210", 1),
                 ("4444", "b64a", 1), ("4444", "b64a", 2), ("4444", "BGRA", 1), ("4444", "BGRa", 1), ("444", "b64a", 1), ("422", "RG24", 1), ("4444", "RG48", 1), ("4444", "RG48", 2),
-                ("444", "RG24", 2), ("444", "BGRA", 2), ("444", "BGRa", 2), ("444", "r210", 2), ("444", "b64a", 2)}
+                ("444", "RG24", 2), ("444", "BGRA", 2), ("444", "BGRa", 2), ("444", "r210", 2), ("444", "b64a", 2), ("4444", "BGRA", 2), ("4444", "BGRa", 2)}
     dec = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
     aw = ctypes.c_int(); ah = ctypes.c_int(); af = ctypes.c_uint32()
     for enc, sample in samples.items():

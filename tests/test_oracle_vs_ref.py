@@ -412,6 +412,33 @@ def test_reference_half_resolution_of_rgb444_equals_model(w, h, seed):
         assert (img[:hh][moving] == lo[:hh][moving]).any() and (img[:hh][moving] == hi[:hh][moving]).any()
 
 
+def rgba4444_sample_with_clips(w, h, seed):
+    frames, pitch = qbist_frames(seed, 1, w, h, PIX_B64A, alpha=1)
+    px = np.frombuffer(frames[0].tobytes(), dtype=np.uint16).reshape(h, pitch // 2).copy()
+    ramp = ((np.arange(h)[:, None] * 523 + np.arange(w)[None, :] * 97) % 65536).astype(np.uint16)
+    for k in range(4): px[:, k: w * 4: 4] = np.where(ramp > 60000, 65535, np.where(ramp < 4000, 0, px[:, k: w * 4: 4]))
+    return ref_encode_frames([px.reshape(-1).view(np.uint8).copy()], pitch, w, h, PIX_B64A, encoded=ENCODED_RGBA4444)[0]
+
+
+@pytest.mark.parametrize("w,h,seed", [(320, 240, 7), (336, 248, 3), (400, 120, 4), (720, 480, 5), (64, 64, 6), (1280, 720, 8), (1920, 1080, 9), (144, 96, 10)])
+def test_reference_half_resolution_bgra_of_rgba4444_equals_model(w, h, seed):
+    """Pins oracle_half_resolution_rgba8 on eight geometries with ramps into both clips of all four components: the reference's half-resolution BGRa / BGRA decode of an RGBA
+    4:4:4:4 sample, byte for byte (a row of the reference that lost its alpha_Companded race -- bayer.c:13871 / :16034 -- is accepted with the companded alpha, as at full resolution)."""
+    sample = rgba4444_sample_with_clips(w, h, seed)
+    plan = Plan(w, h, pixkind=PIXKIND["b64a"], enc=ENC["4444"])
+    want = oracle_half_resolution_rgba8(plan, host_decode_pyramid(sample, plan))[: h // 2]
+    hh = h // 2 if h % 8 == 0 else h // 2 - 4
+    for name in ("BGRa", "BGRA"):
+        for attempt in range(6):
+            dec, dpitch = ref_decode_sample(sample, w, h, fourcc(name), resolution=2)
+            img = np.frombuffer(dec.tobytes(), np.uint8).reshape(-1, dpitch)[: h // 2, : (w // 2) * 4]
+            if name == "BGRA": img = img[::-1]
+            colour = all(np.array_equal(img[:hh, k::4], want[:hh, k::4]) for k in range(3))
+            if colour and (img[:hh, 3::4] == want[:hh, 3::4]).mean() > 0.99: break
+        assert colour, name
+        assert (img[:hh, 3::4] == want[:hh, 3::4]).mean() > 0.99, name
+
+
 def yu64_frame_with_ramps(w, h, seed):
     f16 = (np.random.default_rng(seed).integers(0, 1024, size=(h, w * 2)) << 6).astype(np.uint16)
     f16[: h // 3] = (np.linspace(0, 65535, w * 2)[None, :]).astype(np.uint16)
