@@ -1021,7 +1021,7 @@ CFHD_Error CFHD_PrepareToDecode(CFHD_DecoderRef ref, int, int, CFHD_PixelFormat 
 	const bool rgb10 = kind >= PIX_R210 && kind <= PIX_AR10;
 	if (rgb10 && (encf != ENC_RGB444 || d->header.width < 32)) return ERR_BADFORMAT;
 	// ... and 4:2:2 samples to v210 (the YU64 words >> 6, three to a 32-bit word: DecodeBatch / k_yu64_to_v210; widths of whole six-pixel groups)
-	if (kind == PIX_V210 && (encf != ENC_YUV422 || half || d->header.width % 6 || d->header.width < 128)) return ERR_BADFORMAT;
+	if (kind == PIX_V210 && (encf != ENC_YUV422 || (half ? d->header.width / 2 : d->header.width) % 6 || d->header.width < 128)) return ERR_BADFORMAT;      // (half resolution: frame.c:12139 ConvertLowpass16s10bitToV210 = the half-resolution YU64 words >> 6)
 	// ... and Bayer samples to BYR4: the raw mosaic, no demosaic (the four planes as 16-bit rows, recombined per quad and sent through the reference's linear-restore
 	// table: DecodeBatch / k_bayer_to_byr4; full resolution)
 	const bool byr4_of_bayer = kind == PIX_BYR4 && encf == ENC_BAYER && !half && d->header.width >= 32;

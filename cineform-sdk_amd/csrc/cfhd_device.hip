@@ -642,7 +642,7 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 	// orc_inv_spatial_to_v210, pinned on the reference decoder for widths that are multiples of six) -- the frames are computed as YU64 rows into a
 	// scratch buffer and k_yu64_to_v210 packs them into the output
 	v210_ = out_kind == PIX_V210;
-	if (v210_) { if (plan.width % 6 || !own_output || half) { g_err = "v210 output: widths that are multiples of 6, full resolution"; return -2; } out_kind = PIX_YU64; }
+	if (v210_) { if ((half ? plan.width / 2 : plan.width) % 6 || !own_output) { g_err = "v210 output: widths that are multiples of 6"; return -2; } out_kind = PIX_YU64; }      // (half resolution: k_half_yu64 feeds the same repack)
 	// RG24 output of 4:2:2 samples: the reference computes the three planes as 16-bit rows (the YU64 route) and converts them pixel by pixel
 	// (convert.c:11392 ConvertRow16uToDitheredRGB, oracle orc_inv_spatial_to_rgb24_of_yuv422): the same two steps here
 	lowpass_kind_ = out_kind;
@@ -683,7 +683,7 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 			build_bayer_linear_restore_curve(curve.data());
 			HIPCHK(hipMalloc((void **)&d_restore_, curve.size() * 2));
 			HIPCHK(hipMemcpy(d_restore_, curve.data(), curve.size() * 2, hipMemcpyHostToDevice));
-		} else out_pitch_ = packed_frame_pitch(v210_ ? PIX_V210 : PIX_RG24, plan.width);
+		} else out_pitch_ = packed_frame_pitch(v210_ ? PIX_V210 : PIX_RG24, half ? plan.width / 2 : plan.width);
 		frame_bytes_ = (size_t)out_pitch_ * out_rows_;
 	}
 	if (own_output) {
@@ -738,7 +738,7 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 			dev::HalfYuvJob &hj = j.half[i];
 			for (int c = 0; c < 3; c++) { hj.ll[c] = base + plan.ch[c].band[0][0].offset; hj.pitch[c] = plan.ch[c].band[0][0].pitch; }
 			hj.width = plan.ch[0].band[0][0].width; hj.rows = out_rows_; hj.uyvy = 0;
-			hj.out = own_output ? d_out_ + frame_bytes_ * i : nullptr; hj.out_pitch = out_pitch_;
+			hj.out = own_output ? job_out + job_frame_bytes * i : nullptr; hj.out_pitch = job_pitch;      // (v210 output: the scratch frame k_yu64_to_v210 reads)
 			continue;
 		}
 		if (dec_planes16(out_kind)) {
@@ -960,7 +960,7 @@ int DecodeBatch::launch_inverse(uint32_t dither_seed)
 			(const uint16_t *)d_tmp_, tmp_pitch_ / 2, tmp_frame_bytes_ / 2, (uint16_t *)d_out_, out_pitch_ / 2, frame_bytes_ / 2, quads, d_restore_);
 	}
 	if (v210_) {
-		const int groups = plan_.width / 6;
+		const int groups = (half_ ? plan_.width / 2 : plan_.width) / 6;
 		dev::k_yu64_to_v210<<<dim3((unsigned)((groups + dev::NTHREADS - 1) / dev::NTHREADS), (unsigned)out_rows_, (unsigned)act), dev::NTHREADS, 0, st>>>(
 			(const uint16_t *)d_tmp_, tmp_pitch_ / 2, tmp_frame_bytes_ / 2, (uint32_t *)d_out_, out_pitch_ / 4, frame_bytes_ / 4, groups);
 	}

@@ -635,6 +635,22 @@ def oracle_half_resolution_yu64(plan, coeffs):
     return out
 
 
+def oracle_half_resolution_v210(plan, coeffs):
+    """Half-resolution picture of a 4:2:2 sample as v210 (frame.c:12139 ConvertLowpass16s10bitToV210): the level-1 lowpass planes >> 2 clamped to 10 bits -- the words of
+    oracle_half_resolution_yu64 >> 6 --, groups of six pixels in four words (Cb Y Cr | Y Cb Y | Cr Y Cb | Y Cr Y, low bits first), Cb = plane 2, Cr = plane 1.  coeffs: decoded
+    with the lowpass bias 4 of the 10-bit 4:2:2 outputs (Plan(..., pixkind=PIXKIND["v210"]) or ["YU64"])."""
+    yu = oracle_half_resolution_yu64(plan, coeffs).astype(np.uint32) >> 6
+    rows, n = yu.shape[0], yu.shape[1] // 2                # n pixels per row
+    g = n // 6
+    Y = yu[:, 0::2][:, : 6 * g].reshape(rows, g, 6); Cr = yu[:, 1::4][:, : 3 * g].reshape(rows, g, 3); Cb = yu[:, 3::4][:, : 3 * g].reshape(rows, g, 3)
+    out = np.zeros((rows, g, 4), np.uint32)
+    out[:, :, 0] = Cb[:, :, 0] | (Y[:, :, 0] << 10) | (Cr[:, :, 0] << 20)
+    out[:, :, 1] = Y[:, :, 1] | (Cb[:, :, 1] << 10) | (Y[:, :, 2] << 20)
+    out[:, :, 2] = Cr[:, :, 1] | (Y[:, :, 3] << 10) | (Cb[:, :, 2] << 20)
+    out[:, :, 3] = Y[:, :, 4] | (Cr[:, :, 2] << 10) | (Y[:, :, 5] << 20)
+    return out.reshape(rows, 4 * g)
+
+
 def oracle_half_resolution_rgb(plan, coeffs, name, r=0):
     """Half-resolution picture of an RGB 4:4:4 sample in the 8-bit (RG24 / BGRA / BGRa), 10-bit (r210 / DPX0 / AB10 / AR10) and b64a output formats, restated from
     frame.c:7150 ConvertLowpassRGB444ToRGB: the level-1 lowpass planes G, R, B of a pyramid that carries the lowpass bias of the output format (decoder.c:12290-12312:

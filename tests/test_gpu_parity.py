@@ -555,6 +555,34 @@ def test_half_resolution_decode_of_rgba4444_to_bgra(w, h):
         assert all(np.array_equal(img[:hh, k::4], mine[:hh, k::4]) for k in range(3)), name
 
 
+@pytest.mark.parametrize("w,h", [(336, 248), (720, 480), (1920, 1080)])
+def test_half_resolution_decode_to_v210_equals_reference_exactly(w, h):
+    """CFHD_DECODED_RESOLUTION_HALF of 4:2:2 samples as v210 (frame.c:12139): the half-resolution YU64 words >> 6 in v210's groups of six pixels -- word for word the model
+    pinned on the reference (test_reference_half_resolution_v210_equals_model) and the reference decoder's own output; half widths that are no multiple of 6 are refused."""
+    from test_oracle_vs_ref import yu64_frame_with_ramps
+    sample = amd_encode_frames([yu64_frame_with_ramps(w, h, w + h)], w * 4, w, h, fourcc("YU64"))[0]
+    got, gpitch, aw, ah = amd_decode_sample(sample, fourcc("v210"), resolution=2)
+    assert (aw, ah) == (w // 2, h // 2)
+    plan = Plan(w, h, pixkind=PIXKIND["v210"])
+    want = oracle_half_resolution_v210(plan, host_decode_pyramid(sample, plan))[: h // 2]
+    mine = np.frombuffer(got.tobytes(), np.uint32).reshape(h // 2, gpitch // 4)[:, : want.shape[1]]
+    assert np.array_equal(mine, want)
+    hh = h // 2 if h % 8 == 0 else h // 2 - 4
+    for attempt in range(6):
+        dec, dpitch = ref_decode_sample(sample, w, h, fourcc("v210"), resolution=2)
+        img = np.frombuffer(dec.tobytes(), np.uint32).reshape(-1, dpitch // 4)[: h // 2, : want.shape[1]]
+        if np.array_equal(img[:hh], mine[:hh]): break
+    assert np.array_equal(img[:hh], mine[:hh])
+    if w == 336:
+        odd = amd_encode_frames([yu64_frame_with_ramps(320, 240, 1)], 320 * 4, 320, 240, fourcc("YU64"))[0]
+        L = product()
+        dec = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
+        a = ctypes.c_int(); b = ctypes.c_int(); c = ctypes.c_uint32()
+        sb = ctypes.create_string_buffer(odd, len(odd))
+        assert L.CFHD_PrepareToDecode(dec, 0, 0, fourcc("v210"), 2, 0, sb, 512, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)) == 3      # 160 pixels: no whole groups of six
+        L.CFHD_CloseDecoder(dec)
+
+
 @pytest.mark.parametrize("w,h", [(320, 240), (336, 248), (1920, 1080)])
 def test_half_resolution_decode_to_yu64_equals_reference_exactly(w, h):
     """CFHD_DECODED_RESOLUTION_HALF of 4:2:2 samples as YU64 (TestCFHD's YU64 row at half resolution): the level-1 lowpass planes clamped to 12 bits, << 4 (frame.c:11146) --

@@ -463,6 +463,21 @@ def test_reference_half_resolution_yu64_equals_model(w, h, seed):
     assert (want == 0).any() and (want == 4095 << 4).any()
 
 
+@pytest.mark.parametrize("w,h,seed", [(336, 248, 4), (720, 480, 6), (1920, 1080, 9), (144, 96, 10), (384, 120, 5), (1296, 720, 8), (192, 64, 7), (3840, 2160, 11)])
+def test_reference_half_resolution_v210_equals_model(w, h, seed):
+    """Pins oracle_half_resolution_v210 (frame.c:12139 ConvertLowpass16s10bitToV210) on eight geometries whose half width is a multiple of 6: the reference's half-resolution
+    v210 decode of a 4:2:2 sample, word for word."""
+    sample = ref_encode_frames([yu64_frame_with_ramps(w, h, seed)], w * 4, w, h, fourcc("YU64"))[0]
+    plan = Plan(w, h, pixkind=PIXKIND["v210"])
+    want = oracle_half_resolution_v210(plan, host_decode_pyramid(sample, plan))[: h // 2]
+    hh = h // 2 if h % 8 == 0 else h // 2 - 4
+    for attempt in range(6):
+        dec, dpitch = ref_decode_sample(sample, w, h, fourcc("v210"), resolution=2)
+        img = np.frombuffer(dec.tobytes(), np.uint32).reshape(-1, dpitch // 4)[: h // 2, : want.shape[1]]
+        if np.array_equal(img[:hh], want[:hh]): break
+    assert np.array_equal(img[:hh], want[:hh]), "%d words differ" % (img[:hh] != want[:hh]).sum()
+
+
 def bayer_test_mosaic(w, h, seed):
     """synth_bayer with stretches at both clips (whole quads and single photosites) and a block of saturated red beside black green: r, b, g1, g2 clamp on both sides."""
     mosaic = synth_bayer(w, h, seed).copy()
