@@ -1013,9 +1013,9 @@ CFHD_Error CFHD_PrepareToDecode(CFHD_DecoderRef ref, int, int, CFHD_PixelFormat 
 	// ... and RGBA 4:4:4:4 samples to BGRA / BGRa (no dither there: (12-bit component + 2) >> 4, the alpha expanded from that rounded value)
 	const bool rgba8 = (kind == PIX_BGRA || kind == PIX_BGRa) && encf == ENC_RGBA4444;
 	// ... and 4:2:2 samples to RG24: the YU64 rows through the reference's scalar colour conversion with its 15-bit dither (DecodeBatch / k_yu64_to_rgb24)
-	const bool rgb24_of_422 = kind == PIX_RG24 && encf == ENC_YUV422 && !half && d->header.width >= 128;
+	const bool rgb24_of_422 = kind == PIX_RG24 && encf == ENC_YUV422 && d->header.width >= 128;      // (half resolution: frame.c:8504, k_half_rgb24)
 	// (half resolution -- frame.c:7150 ConvertLowpassRGB444ToRGB -- for the outputs of RGB 4:4:4 samples: 8-bit, 10-bit, b64a; k_half_rgb)
-	if (rgb8 && ((encf != ENC_RGB444 && !rgba8 && !rgb24_of_422) || (half && encf != ENC_RGB444 && !rgba8) || d->header.width < 32)) return ERR_BADFORMAT;
+	if (rgb8 && ((encf != ENC_RGB444 && !rgba8 && !rgb24_of_422) || (half && encf != ENC_RGB444 && !rgba8 && !rgb24_of_422) || d->header.width < 32)) return ERR_BADFORMAT;
 	// ... and to the 10-bit RGB words r210 / DPX0 / AB10 / AR10 ((value before the final >> 1, + 3) >> 3 per component: a model fitted on the reference
 	// decoder and pinned word for word on the CPU, equal to the reference decoder on the GPU)
 	const bool rgb10 = kind >= PIX_R210 && kind <= PIX_AR10;

@@ -647,7 +647,9 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 	// (convert.c:11392 ConvertRow16uToDitheredRGB, oracle orc_inv_spatial_to_rgb24_of_yuv422): the same two steps here
 	lowpass_kind_ = out_kind;
 	rgb24_of_422_ = out_kind == PIX_RG24 && plan.encoded_format == ENC_YUV422;
-	if (rgb24_of_422_) { if (!own_output || half) { g_err = "RG24 output of 4:2:2 samples: full resolution"; return -2; } out_kind = PIX_YU64; }
+	if (rgb24_of_422_) { if (!own_output) { g_err = "RG24 output of 4:2:2 samples: into the library's own output frames"; return -2; } if (!half) out_kind = PIX_YU64; }
+	const bool rgb24_half = rgb24_of_422_ && half;      // (half resolution: k_half_rgb24 straight from the lowpass planes, no scratch frame)
+	if (rgb24_half) rgb24_of_422_ = false;
 	// BYR4 output of Bayer samples (decoder.c:14738 + bayer.c:13233 GenerateBYR2): the four component planes as 16-bit rows -- the RG48 route with four planes,
 	// four words per photosite quad -- then k_bayer_to_byr4
 	byr4_ = out_kind == PIX_BYR4;
@@ -662,7 +664,7 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 	const bool yu64_ok = out_kind == PIX_YU64 && plan.encoded_format == ENC_YUV422 && plan.ch[1].band[0][0].width >= 16;
 	const bool rgb8_ok = dec_rgb8(out_kind) && (plan.encoded_format == ENC_RGB444 || (plan.encoded_format == ENC_RGBA4444 && out_kind != PIX_RG24)) && plan.ch[0].band[0][0].width >= 16 && plan.ch[0].band[0][0].width % 2 == 0;
 	const bool rgb10_ok = dec_rgb10(out_kind) && plan.encoded_format == ENC_RGB444 && plan.ch[0].band[0][0].width >= 16;
-	if (!yuv_ok && !rgb_ok && !yu64_ok && !rgb8_ok && !rgb10_ok) { g_err = "output format not supported by the GPU path yet"; return -2; }
+	if (!yuv_ok && !rgb_ok && !yu64_ok && !rgb8_ok && !rgb10_ok && !rgb24_half) { g_err = "output format not supported by the GPU path yet"; return -2; }
 	plan_ = plan; n_ = nframes; out_kind_ = out_kind; own_output_ = own_output;
 	HIPCHK(hipStreamCreateWithFlags((hipStream_t *)&stream_, hipStreamNonBlocking));
 	HIPCHK(hipEventCreate((hipEvent_t *)&ev0_));
@@ -716,7 +718,7 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 				p.out = base + plan.ch[c].band[lv - 1][0].offset; p.out_pitch = plan.ch[c].band[lv - 1][0].pitch;
 				p.xstride = 1; p.precision = 0; p.display_height = 2 * p.height;
 			}
-		if (half && (dec_rgb8(out_kind) || dec_rgb10(out_kind) || (out_kind == PIX_B64A && nch == 3))) {      // k_half_rgb
+		if (half && plan.encoded_format != ENC_YUV422 && (dec_rgb8(out_kind) || dec_rgb10(out_kind) || (out_kind == PIX_B64A && nch == 3))) {      // k_half_rgb
 			dev::HalfPackedJob &hp = j.halfp[i];
 			for (int c = 0; c < 3; c++) { hp.ll[c] = base + plan.ch[c].band[0][0].offset; hp.word[c] = dec_rgb10(out_kind) ? rgb10_shift(out_kind, c) : 0; }
 			hp.pitch = plan.ch[0].band[0][0].pitch; hp.width = plan.ch[0].band[0][0].width; hp.rows = out_rows_; hp.nch = dec_rgb8(out_kind) && nch == 4 ? 4 : 3;
@@ -733,6 +735,13 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 			hp.pitch = plan.ch[0].band[0][0].pitch; hp.width = plan.ch[0].band[0][0].width; hp.rows = out_rows_; hp.nch = onch;
 			hp.shift = 16 - plan.precision - 2; hp.alpha = out_kind == PIX_B64A;
 			hp.out = own_output ? (uint16_t *)(d_out_ + frame_bytes_ * i) : nullptr; hp.out_pitch = out_pitch_;
+		}
+		if (half && out_kind == PIX_RG24 && plan.encoded_format == ENC_YUV422) {      // k_half_rgb24
+			dev::HalfYuvJob &hj = j.half[i];
+			for (int c = 0; c < 3; c++) { hj.ll[c] = base + plan.ch[c].band[0][0].offset; hj.pitch[c] = plan.ch[c].band[0][0].pitch; }
+			hj.width = plan.ch[0].band[0][0].width; hj.rows = out_rows_; hj.uyvy = 0; hj.matrix = plan.color_matrix;
+			hj.out = own_output ? d_out_ + frame_bytes_ * i : nullptr; hj.out_pitch = out_pitch_;
+			continue;
 		}
 		if (half && out_kind == PIX_YU64) {                 // k_half_yu64
 			dev::HalfYuvJob &hj = j.half[i];
@@ -914,7 +923,10 @@ int DecodeBatch::launch_inverse(uint32_t dither_seed)
 		HIPCHK(hipEventRecord((hipEvent_t)evl_[1], st));
 	}
 	if (interlaced_ && !half_ && dec_planes16(out_kind_)) return -1;
-	if (half_ && (dec_rgb8(out_kind_) || dec_rgb10(out_kind_) || (out_kind_ == PIX_B64A && nch == 3))) {
+	if (half_ && out_kind_ == PIX_RG24 && plan_.encoded_format == ENC_YUV422) {
+		const BandDesc &b = plan_.ch[0].band[0][0];
+		dev::k_half_rgb24<<<dim3((b.width / 2 + dev::NTHREADS - 1) / dev::NTHREADS, out_rows_, act), dev::NTHREADS, 0, st>>>(j.half);
+	} else if (half_ && (dec_rgb8(out_kind_) || dec_rgb10(out_kind_) || (out_kind_ == PIX_B64A && nch == 3))) {
 		const BandDesc &b = plan_.ch[0].band[0][0];
 		dev::k_half_rgb<<<dim3((b.width + dev::NTHREADS - 1) / dev::NTHREADS, out_rows_, act), dev::NTHREADS, 0, st>>>(j.halfp, dither_seed);
 	} else if (half_ && out_kind_ == PIX_YU64) {

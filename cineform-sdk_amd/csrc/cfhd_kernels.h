@@ -178,6 +178,7 @@ struct HalfYuvJob {                         // k_half_yuv422: the level-1 lowpas
 	int width, rows;                        // luma band columns (= output pixels per row), output rows
 	int uyvy;
 	uint8_t *out; int out_pitch;            // bytes
+	int matrix;                             // k_half_rgb24: 0 computer-systems 709, 1 video 709, 2 computer 601, 3 video 601 (as k_yu64_to_rgb24)
 };
 
 struct HalfPackedJob {                      // k_half_packed16: level-1 lowpass planes of a 4:4:4(:4) sample as half-resolution 16-bit pixels
@@ -2328,6 +2329,30 @@ __global__ void __launch_bounds__(NTHREADS) k_half_yu64(const HalfYuvJob *jobs)
 	px.x = word(y[0]) | (word(job.ll[1][(size_t)row * job.pitch[1] + p]) << 16);
 	px.y = word(y[1]) | (word(job.ll[2][(size_t)row * job.pitch[2] + p]) << 16);
 	*(uint2 *)(job.out + (size_t)row * job.out_pitch + 8 * (size_t)p) = px;
+}
+
+// Half resolution of 4:2:2 samples as RG24 (decoder.c:22924 -> frame.c:8504 ConvertLowpass16sToRGBNoIPPFast, whose vector code is compiled out -- MMXSUPPORTED is not defined --,
+// so the scalar loop at :9153 does every column): the level-1 lowpass planes >> 4 to 8 bits (no clamp: color.h:49-51), Y = ((Y - y_offset) * ymult) >> 7,
+// R = (Y + r_vmult V) >> 7, G = (2 Y - g_umult U - g_vmult V) >> 8, B = (Y + 2 b_umult U) >> 7, saturated to bytes B, G, R; no dither; bottom row first.
+// One thread per pixel pair.
+__global__ void __launch_bounds__(NTHREADS) k_half_rgb24(const HalfYuvJob *jobs)
+{
+	const HalfYuvJob &job = jobs[blockIdx.z];
+	const int row = blockIdx.y, p = (int)(blockIdx.x * NTHREADS + threadIdx.x);
+	if (2 * p >= job.width) return;
+	const int m[4][6] = { { 16, 128 * 149, 230, 137, 55, 135 }, { 0, 128 * 128, 197, 118, 47, 116 }, { 16, 128 * 149, 204, 208, 100, 129 }, { 0, 128 * 128, 175, 179, 86, 111 } };
+	const int *c = m[job.matrix & 3];
+	const int16_t *y = job.ll[0] + (size_t)row * job.pitch[0] + 2 * p;
+	const int V = ((int)job.ll[1][(size_t)row * job.pitch[1] + p] >> 4) - 128, U = ((int)job.ll[2][(size_t)row * job.pitch[2] + p] >> 4) - 128;
+	uint8_t *o = job.out + (size_t)(job.rows - 1 - row) * job.out_pitch + 6 * (size_t)p;
+#pragma unroll
+	for (int k = 0; k < 2; k++) {
+		const int Y = ((((int)y[k] >> 4) - c[0]) * c[1]) >> 7;
+		const int R = (Y + c[2] * V) >> 7, G = (2 * Y - c[4] * U - c[3] * V) >> 8, B = (Y + 2 * c[5] * U) >> 7;
+		o[3 * k + 0] = (uint8_t)(B < 0 ? 0 : (B > 255 ? 255 : B));
+		o[3 * k + 1] = (uint8_t)(G < 0 ? 0 : (G > 255 ? 255 : G));
+		o[3 * k + 2] = (uint8_t)(R < 0 ? 0 : (R > 255 ? 255 : R));
+	}
 }
 
 // Half resolution of RGB 4:4:4 samples for the 8-bit, 10-bit and b64a outputs (decoder.c:26752 CopyLowpassRGB444ToBuffer -> frame.c:7150 ConvertLowpassRGB444ToRGB):

@@ -651,6 +651,28 @@ def oracle_half_resolution_v210(plan, coeffs):
     return out.reshape(rows, 4 * g)
 
 
+def oracle_half_resolution_rgb24_of_yuv422(plan, coeffs, color_space=2):
+    """Half-resolution picture of a 4:2:2 sample as RG24 (bottom row first), restated from the scalar loop of frame.c:9153 (ConvertLowpass16sToRGBNoIPPFast; its vector code is
+    compiled out): lowpass planes >> 4, Y = ((Y - y_offset) * ymult) >> 7, R = (Y + r_vmult V) >> 7, G = (2 Y - g_umult U - g_vmult V) >> 8, B = (Y + 2 b_umult U) >> 7, no dither.
+    coeffs: decoded with the lowpass bias of RG24 output (Plan(..., pixkind=PIXKIND["RG24"])).  color_space: 2 = 709 (the default), 1 = 601 (computer-systems range both)."""
+    O = oracle()
+    work = coeffs.copy()
+    for c in range(3):
+        for lv in (2, 1):
+            d = plan.band[(c, lv, 0)]
+            bands = (c_i16p * 4)(*[plan.view(work, c, lv, b).ctypes.data_as(c_i16p) for b in range(4)])
+            dst = plan.view(work, c, lv - 1, 0)
+            O.orc_inv_spatial(bands, d["pitch"], d["width"], d["height"], plan.prescale[lv], dst.ctypes.data_as(c_i16p), plan.band[(c, lv - 1, 0)]["pitch"])
+    rows = plan.height // 2
+    Yp, C1, C2 = [plan.view(work, c, 0, 0)[:rows, : plan.band[(c, 0, 0)]["width"]].astype(np.int64) for c in range(3)]
+    yo, ym, rv, gv, gu, bu = (16, 128 * 149, 204, 208, 100, 129) if color_space == 1 else (16, 128 * 149, 230, 137, 55, 135)
+    Y = (((Yp >> 4) - yo) * ym) >> 7
+    V = np.repeat(C1 >> 4, 2, axis=1) - 128; U = np.repeat(C2 >> 4, 2, axis=1) - 128
+    out = np.zeros((rows, Y.shape[1], 3), np.uint8)
+    out[:, :, 2] = np.clip((Y + rv * V) >> 7, 0, 255); out[:, :, 1] = np.clip((2 * Y - gu * U - gv * V) >> 8, 0, 255); out[:, :, 0] = np.clip((Y + 2 * bu * U) >> 7, 0, 255)
+    return out[::-1].reshape(rows, -1)
+
+
 def oracle_half_resolution_rgb(plan, coeffs, name, r=0):
     """Half-resolution picture of an RGB 4:4:4 sample in the 8-bit (RG24 / BGRA / BGRa), 10-bit (r210 / DPX0 / AB10 / AR10) and b64a output formats, restated from
     frame.c:7150 ConvertLowpassRGB444ToRGB: the level-1 lowpass planes G, R, B of a pyramid that carries the lowpass bias of the output format (decoder.c:12290-12312:

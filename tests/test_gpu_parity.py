@@ -555,6 +555,26 @@ def test_half_resolution_decode_of_rgba4444_to_bgra(w, h):
         assert all(np.array_equal(img[:hh, k::4], mine[:hh, k::4]) for k in range(3)), name
 
 
+@pytest.mark.parametrize("w,h,flags", [(320, 240, 0), (336, 248, 4), (1920, 1080, 0)])
+def test_half_resolution_decode_of_yuv422_to_rg24_equals_reference_exactly(w, h, flags):
+    """CFHD_DECODED_RESOLUTION_HALF of 4:2:2 samples as RG24 (TestCFHD's RG24 -> 4:2:2 row at half resolution): the scalar loop of frame.c:9153 on the level-1 lowpass planes,
+    no dither -- byte for byte the model pinned on the reference (test_reference_half_resolution_rg24_of_yuv422_equals_model) and the reference decoder's own output; 709 and 601."""
+    f, p = synth_yuy2(w, h, w + h)
+    sample = amd_encode_frames([f], p, w, h, PIX_YUY2, flags=flags)[0]
+    got, gpitch, aw, ah = amd_decode_sample(sample, fourcc("RG24"), resolution=2)
+    assert (aw, ah) == (w // 2, h // 2)
+    mine = np.frombuffer(got.tobytes(), np.uint8).reshape(h // 2, gpitch)[:, : (w // 2) * 3]
+    plan = Plan(w, h, pixkind=PIXKIND["RG24"])
+    want = oracle_half_resolution_rgb24_of_yuv422(plan, host_decode_pyramid(sample, plan), 1 if flags & 4 else 2)
+    assert np.array_equal(mine, want[want.shape[0] - h // 2:])
+    hh = h // 2 if h % 8 == 0 else h // 2 - 4
+    for attempt in range(6):
+        dec, dpitch = ref_decode_sample(sample, w, h, fourcc("RG24"), resolution=2)
+        img = np.frombuffer(dec.tobytes(), np.uint8).reshape(-1, dpitch)[: h // 2, : (w // 2) * 3]
+        if np.array_equal(img[h // 2 - hh:], mine[h // 2 - hh:]): break
+    assert np.array_equal(img[h // 2 - hh:], mine[h // 2 - hh:])
+
+
 @pytest.mark.parametrize("w,h", [(336, 248), (720, 480), (1920, 1080)])
 def test_half_resolution_decode_to_v210_equals_reference_exactly(w, h):
     """CFHD_DECODED_RESOLUTION_HALF of 4:2:2 samples as v210 (frame.c:12139): the half-resolution YU64 words >> 6 in v210's groups of six pixels -- word for word the model

@@ -499,7 +499,7 @@ def test_decoder_output_format_gates():
     samples = {"422": ref_encode_frames([f422], p422, w, h, PIX_YUY2)[0],
                "444": ref_encode_frames(frgb, prgb, w, h, PIX_RG48, encoded=ENCODED_RGB444)[0],
                "4444": ref_encode_frames(fa, pa, w, h, PIX_B64A, encoded=ENCODED_RGBA4444)[0]}
-    accepted = {("422", "YUY2", 1), ("422", "YUY2", 2), ("422", "2vuy", 1), ("422", "2vuy", 2), ("422", "YU64", 1), ("422", "YU64", 2),
+    accepted = {("422", "YUY2", 1), ("422", "YUY2", 2), ("422", "2vuy", 1), ("422", "2vuy", 2), ("422", "YU64", 1), ("422", "YU64", 2), ("422", "RG24", 2),
                 ("444", "RG48", 1), ("444", "RG48", 2), ("444", "RG24", 1), ("444", "BGRA", 1), ("444", "BGRa", 1), ("444", "r210", 1),
                 ("4444", "b64a", 1), ("4444", "b64a", 2), ("4444", "BGRA", 1), ("4444", "BGRa", 1), ("444", "b64a", 1), ("422", "RG24", 1), ("4444", "RG48", 1), ("4444", "RG48", 2),
                 ("444", "RG24", 2), ("444", "BGRA", 2), ("444", "BGRa", 2), ("444", "r210", 2), ("444", "b64a", 2), ("4444", "BGRA", 2), ("4444", "BGRa", 2)}

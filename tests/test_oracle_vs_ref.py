@@ -286,10 +286,10 @@ def test_reference_rgba8_decode_of_4444_equals_oracle(w, h, name, seed):
     for attempt in range(6):                            # see test_reference_rg48_decode_equals_oracle
         dec, dpitch = ref_decode_sample(sample, w, h, fmt)
         img = np.frombuffer(dec.tobytes(), np.uint8).reshape(h, dpitch)[sl, : w * 4]
-        if all(np.array_equal(img[:, k::4], want[:, k::4]) for k in range(3)): break
-    for k in range(3): assert np.array_equal(img[:, k::4], want[:, k::4]), "colour byte %d" % k
-    a_ok = img[:, 3::4] == want[:, 3::4]
-    assert np.array_equal(img[:, 3::4][~a_ok], alt[~a_ok])          # (the race is lost for parts of rows, too; on a busy host for most of the picture)
+        a_ok = img[:, 3::4] == want[:, 3::4]
+        if all(np.array_equal(img[:, k::4], want[:, k::4]) for k in range(3)) and np.array_equal(img[:, 3::4][~a_ok], alt[~a_ok]): break
+    for k in range(3): assert np.array_equal(img[:, k::4], want[:, k::4]), "colour byte %d: %d differ" % (k, (img[:, k::4] != want[:, k::4]).sum())
+    assert np.array_equal(img[:, 3::4][~a_ok], alt[~a_ok]), "%d alpha bytes are neither the expanded nor the companded value" % (img[:, 3::4][~a_ok] != alt[~a_ok]).sum()          # (the race is lost for parts of rows, too; on a busy host for most of the picture)
     src = np.frombuffer(frames[0].tobytes(), np.uint8).reshape(h, pitch)[sl, : w * 4]
     assert np.abs(want.astype(int) - src.astype(int)).mean() < 3.0
 
@@ -476,6 +476,23 @@ def test_reference_half_resolution_v210_equals_model(w, h, seed):
         img = np.frombuffer(dec.tobytes(), np.uint32).reshape(-1, dpitch // 4)[: h // 2, : want.shape[1]]
         if np.array_equal(img[:hh], want[:hh]): break
     assert np.array_equal(img[:hh], want[:hh]), "%d words differ" % (img[:hh] != want[:hh]).sum()
+
+
+@pytest.mark.parametrize("w,h,seed,flags", [(320, 240, 3, 0), (336, 248, 4, 0), (400, 120, 5, 0), (720, 480, 6, 4), (128, 64, 7, 0), (1280, 720, 8, 4), (1920, 1080, 9, 0), (144, 96, 10, 0)])
+def test_reference_half_resolution_rg24_of_yuv422_equals_model(w, h, seed, flags):
+    """Pins oracle_half_resolution_rgb24_of_yuv422 (the scalar loop of frame.c:9153) on eight geometries, 709 and 601 (CFHD_ENCODING_FLAGS_YUV_601 = 4), even and odd lowpass
+    widths (336: the bias rule of decoder.c:12500): the reference's half-resolution RG24 decode of a 4:2:2 sample, byte for byte -- this route draws no dither."""
+    f, p = synth_yuy2(w, h, seed)
+    sample = ref_encode_frames([f], p, w, h, PIX_YUY2, flags=flags)[0]
+    plan = Plan(w, h, pixkind=PIXKIND["RG24"])
+    want = oracle_half_resolution_rgb24_of_yuv422(plan, host_decode_pyramid(sample, plan), 1 if flags & 4 else 2)
+    want = want[want.shape[0] - h // 2:]                  # (bottom row first: the picture's rows are the last h / 2 of the padded plane)
+    hh = h // 2 if h % 8 == 0 else h // 2 - 4
+    for attempt in range(6):
+        dec, dpitch = ref_decode_sample(sample, w, h, fourcc("RG24"), resolution=2)
+        img = np.frombuffer(dec.tobytes(), np.uint8).reshape(-1, dpitch)[: h // 2, : (w // 2) * 3]
+        if np.array_equal(img[h // 2 - hh:], want[h // 2 - hh:]): break
+    assert np.array_equal(img[h // 2 - hh:], want[h // 2 - hh:]), "%d bytes differ" % (img[h // 2 - hh:] != want[h // 2 - hh:]).sum()
 
 
 def bayer_test_mosaic(w, h, seed):
