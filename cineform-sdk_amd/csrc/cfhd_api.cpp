@@ -1173,7 +1173,8 @@ CFHD_Error CFHD_DecodeSample(CFHD_DecoderRef ref, void *sample, size_t size, voi
 	// interlaced samples (known only now: the SAMPLE_FLAGS tag lies behind the 512 bytes CFHD_PrepareToDecode sees): 4:2:2, full resolution through the
 	// inverse frame transform, half resolution from the level-1 lowpass planes like any other sample (the reference's output is the same model)
 	const bool interlaced = !ps.progressive;
-	if (interlaced && (ps.encoded_format != ENC_YUV422 || d->out_kind == PIX_YU64 || d->out_kind == PIX_V210 || d->out_kind == PIX_RG24)) return fail_zero(ERR_BADFORMAT);      // (YU64 output of interlaced samples is not built)
+	// (YU64 / v210 output of interlaced samples: at half resolution only -- the level-1 lowpass planes, as for progressive samples; RG24 takes another route there: not built)
+	if (interlaced && (ps.encoded_format != ENC_YUV422 || ((d->out_kind == PIX_YU64 || d->out_kind == PIX_V210) && !d->half) || d->out_kind == PIX_RG24)) return fail_zero(ERR_BADFORMAT);
 	if (interlaced && !d->half && ps.width > 8192) return fail_zero(ERR_BADFORMAT);        // k_dec_undiff serves rows of up to 4096 coefficients (cfhd_dec_kernels.h DXU_MAX): an unsupported size, not a bad sample
 	// another call of this geometry in flight right now: decode together with it (see DecodeService)
 	if (decode_gather_slots() > 1 && gpu_entropy_enabled() && size <= (size_t)d->plan.width * d->plan.height * pixel_bytes_of(d->out_kind) + 65536) {

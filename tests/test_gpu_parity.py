@@ -575,6 +575,30 @@ def test_half_resolution_decode_of_yuv422_to_rg24_equals_reference_exactly(w, h,
     assert np.array_equal(img[h // 2 - hh:], mine[h // 2 - hh:])
 
 
+@pytest.mark.parametrize("w,h", [(320, 240), (720, 486), (1920, 1080)])
+def test_interlaced_samples_at_half_resolution_as_yu64_and_v210(w, h):
+    """Interlaced samples at half resolution as YU64 / v210: the level-1 lowpass planes as for progressive samples -- the model pinned on the reference
+    (test_reference_half_resolution_of_interlaced_samples_as_yu64_and_v210), word for word; at full resolution these outputs of interlaced samples stay refused."""
+    f, p = synth_yuy2(w, h, w + h)
+    sample = amd_encode_frames([f], p, w, h, PIX_YUY2, flags=1)[0]
+    for name in ("YU64", "v210"):
+        if name == "v210" and (w // 2) % 6: continue
+        got, gpitch, aw, ah = amd_decode_sample(sample, fourcc(name), resolution=2)
+        assert (aw, ah) == (w // 2, h // 2)
+        plan = Plan(w, h, pixkind=PIXKIND[name], progressive=0)
+        want = (oracle_half_resolution_yu64 if name == "YU64" else oracle_half_resolution_v210)(plan, host_decode_pyramid(sample, plan))[: h // 2]
+        mine = np.frombuffer(got.tobytes(), np.uint16 if name == "YU64" else np.uint32).reshape(h // 2, gpitch // (2 if name == "YU64" else 4))[:, : want.shape[1]]
+        assert np.array_equal(mine, want), name
+    L = product()
+    dec = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
+    a = ctypes.c_int(); b = ctypes.c_int(); c = ctypes.c_uint32()
+    sb = ctypes.create_string_buffer(sample, len(sample))
+    assert L.CFHD_PrepareToDecode(dec, 0, 0, fourcc("YU64"), 1, 0, sb, 512, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)) == 0      # (the flag lies behind the 512 bytes: the decode call refuses)
+    out = np.zeros(w * 4 * h, np.uint8)
+    assert L.CFHD_DecodeSample(dec, sb, len(sample), out.ctypes.data_as(ctypes.c_void_p), w * 4) == 3
+    L.CFHD_CloseDecoder(dec)
+
+
 @pytest.mark.parametrize("w,h", [(336, 248), (720, 480), (1920, 1080)])
 def test_half_resolution_decode_to_v210_equals_reference_exactly(w, h):
     """CFHD_DECODED_RESOLUTION_HALF of 4:2:2 samples as v210 (frame.c:12139): the half-resolution YU64 words >> 6 in v210's groups of six pixels -- word for word the model

@@ -495,6 +495,25 @@ def test_reference_half_resolution_rg24_of_yuv422_equals_model(w, h, seed, flags
     assert np.array_equal(img[h // 2 - hh:], want[h // 2 - hh:]), "%d bytes differ" % (img[h // 2 - hh:] != want[h // 2 - hh:]).sum()
 
 
+@pytest.mark.parametrize("w,h,seed", [(320, 240, 3), (720, 486, 5), (1920, 1080, 7), (336, 248, 4)])
+def test_reference_half_resolution_of_interlaced_samples_as_yu64_and_v210(w, h, seed):
+    """Interlaced 4:2:2 samples at half resolution as YU64 / v210: the level-1 lowpass planes exactly as for progressive samples (oracle_half_resolution_yu64 / _v210), word for
+    word what the reference decoder returns."""
+    f, p = synth_yuy2(w, h, seed)
+    sample = ref_encode_frames([f], p, w, h, PIX_YUY2, flags=1)[0]
+    hh = h // 2 if h % 8 == 0 else h // 2 - 4
+    for name in ("YU64", "v210"):
+        if name == "v210" and (w // 2) % 6: continue
+        plan = Plan(w, h, pixkind=PIXKIND[name], progressive=0)
+        deq = host_decode_pyramid(sample, plan)
+        want = (oracle_half_resolution_yu64 if name == "YU64" else oracle_half_resolution_v210)(plan, deq)[: h // 2]
+        for attempt in range(6):
+            dec, dpitch = ref_decode_sample(sample, w, h, fourcc(name), resolution=2)
+            img = np.frombuffer(dec.tobytes(), np.uint16 if name == "YU64" else np.uint32).reshape(-1, dpitch // (2 if name == "YU64" else 4))[: h // 2, : want.shape[1]]
+            if np.array_equal(img[:hh], want[:hh]): break
+        assert np.array_equal(img[:hh], want[:hh]), name
+
+
 def bayer_test_mosaic(w, h, seed):
     """synth_bayer with stretches at both clips (whole quads and single photosites) and a block of saturated red beside black green: r, b, g1, g2 clamp on both sides."""
     mosaic = synth_bayer(w, h, seed).copy()
