@@ -1108,6 +1108,10 @@ static CFHD_Error decode_group_sample(Decoder *d, const uint8_t *s, size_t size,
 		return ERR_OKAY;
 	}
 	if (pg.sample_type != 2 || pg.width != gp.width || pg.height != gp.height || pg.precision != 10) return fail_zero(ERR_BADSAMPLE);
+	// Groups of interlaced frames (YUV_INTERLACED | 2FRAME_GOP: no SAMPLE_FLAGS tag, field transform at level 1, difference-coded bands) are not built:
+	// refuse them instead of running the progressive inverse over them (decoder.c:13397 sets `progressive` only from the tag).
+	if (!pg.progressive) return fail_zero(ERR_BADFORMAT);
+	for (int c = 0; c < 3; c++) for (int k = 0; k < kGopWavelets; k++) for (int b = 0; b < 4; b++) if (pg.band[c][k][b].present && pg.band[c][k][b].difference) return fail_zero(ERR_BADFORMAT);
 	if (!d->gop_ready) {
 		device_select(d->device);
 		const int prc = d->gop_batch.prepare(gp, true, d->out_kind);

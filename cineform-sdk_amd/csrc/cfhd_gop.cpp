@@ -370,7 +370,7 @@ int parse_group_sample(const uint8_t *d, size_t size, ParsedGroup *pg)
 			pb.offset = (uint32_t)pos; pb.bytes = (uint32_t)(end - 4 - pos);
 			pb.width = bw; pb.height = bh; pb.quant = bq; pb.subband = bsub; pb.present = true;
 			pb.codebook = benc == 4 ? -1 : (bflags & 0xf);      // -1: raw 16-bit words (BAND_ENCODING_16BIT)
-			pb.difference = false; pb.peak_level = 0; pb.peak_offset = 0;
+			pb.difference = (bflags & 0x10) != 0; pb.peak_level = 0; pb.peak_offset = 0;      // (difference-coded bands: interlaced groups, refused by the decoder)
 			pos = end; pending = 0;
 			break; }
 		default: break;

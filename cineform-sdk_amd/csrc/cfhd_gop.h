@@ -51,7 +51,8 @@ size_t write_pframe_sample(const GopPlan &plan, uint32_t frame_number, uint8_t *
 // ---- decoder side ----
 struct ParsedGroup {
 	int sample_type = 0;                     // 2 group, 1 frame (the P-frame header), 7 sequence header
-	int width = 0, height = 0, display_height = 0, num_channels = 0, precision = 0, input_format = 0, frame_number = 0, progressive = 1;
+	int width = 0, height = 0, display_height = 0, num_channels = 0, precision = 0, input_format = 0, frame_number = 0;
+	int progressive = 0;                     // the reference's default (codec.c:263); set only by TAG_SAMPLE_FLAGS (decoder.c:13397): an interlaced group carries no such tag
 	ParsedBand lowpass[3];                   // w[5]'s lowpass band, raw 16-bit big-endian
 	ParsedBand band[3][kGopWavelets][4];     // [channel][wavelet][band]: coded bands (w[3] band 0: raw 16-bit, codebook -1)
 };

@@ -3,7 +3,6 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-sys.path.insert(0, os.path.join(ROOT, "cineform-sdk_amd", "python"))
 
 
 def pytest_configure(config):
@@ -36,15 +35,31 @@ GPU_FIRST = [
     "test_interlaced_decode_reference_samples",
     "test_interlaced_decode_peak_table_frames",
     "test_yuy2_4k_two_segments",
-    "test_reference_harness_links_unchanged_and_prints_same_numbers",
     "test_encoder_pool_is_fifo_and_matches_sync",
     "test_concurrent_decoders_share_launches_and_stay_exact",
+    "test_gop_encode_bitstream_identical",
+    "test_gop_decode_reference_samples",
+    "test_gop_round_trip_of_the_product_alone",
+    "test_gop_gates",
+    "test_encoder_pool_and_decoders_over_several_devices_keep_order_and_bytes",
 ]
+# ... and what runs last: the reference's own harness linked against the library (minutes of Qbist drawing on one core; compared with a committed fixture, no live reference).
+GPU_LAST = ["test_reference_harness_links_unchanged_and_prints_same_numbers"]
 
 
 def pytest_collection_modifyitems(session, config, items):
     rank = {name: k for k, name in enumerate(GPU_FIRST)}
     def key(item):
         if "test_gpu_" not in item.nodeid: return (0, 0)            # the other files keep their place in front
-        return (1, rank.get(getattr(item, "originalname", None) or item.name.split("[")[0], len(GPU_FIRST)))
+        name = getattr(item, "originalname", None) or item.name.split("[")[0]
+        return (1, len(GPU_FIRST) + 1 if name in GPU_LAST else rank.get(name, len(GPU_FIRST)))
     items.sort(key=key)                                               # stable: file order inside one rank
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """Live-reference legs that never agreed (cfhd_testlib.reference_leg): reported, never a failure -- the gate of those tests is product == oracle."""
+    import cfhd_testlib
+    if cfhd_testlib.REFERENCE_DISAGREEMENTS:
+        terminalreporter.section("live reference disagreements (not failures)")
+        for name, what, detail in cfhd_testlib.REFERENCE_DISAGREEMENTS:
+            terminalreporter.write_line("%s: %s %s" % (name, what, detail or ""))

@@ -86,3 +86,22 @@ def test_gop_round_trip_of_the_product_alone():
         assert L.CFHD_DecodeSample(dec, sb, len(s), out.ctypes.data_as(ctypes.c_void_p), w * 2) == 0
         assert psnr_yuy2(out.reshape(h, w * 2), frames[i].reshape(h, w * 2)) > 40.0, i
     L.CFHD_CloseDecoder(dec)
+
+
+def test_interlaced_group_samples_are_refused_not_misdecoded():
+    """A reference-encoded group of interlaced frames (YUV_INTERLACED | 2FRAME_GOP) carries no SAMPLE_FLAGS tag: `progressive` stays at the reference's default 0
+    (codec.c:263, decoder.c:13397).  The field transform of groups is not built, so the decoder must answer CFHD_ERROR_BADFORMAT with a zero-filled picture -- not run
+    the progressive inverse over it and return a wrong picture with CFHD_ERROR_OKAY (advisor finding, round 3)."""
+    assert have_ref(), "oracle/_ref/libcfhd_ref.so is missing"
+    w, h = 320, 240
+    frames = _frames(w, h, 3, PIX_YUY2)
+    samples = ref_encode_frames(frames, w * 2, w, h, flags=ENCODING_FLAGS_2FRAME_GOP | 1)
+    L = product()
+    dec = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
+    aw = ctypes.c_int(); ah = ctypes.c_int(); af = ctypes.c_uint32()
+    sb = ctypes.create_string_buffer(samples[1], len(samples[1]))
+    assert L.CFHD_PrepareToDecode(dec, 0, 0, PIX_YUY2, 1, 0, sb, min(512, len(samples[1])), ctypes.byref(aw), ctypes.byref(ah), ctypes.byref(af)) == 0
+    out = np.full(w * 2 * ah.value, 7, np.uint8)
+    assert L.CFHD_DecodeSample(dec, sb, len(samples[1]), out.ctypes.data_as(ctypes.c_void_p), w * 2) == 3          # CFHD_ERROR_BADFORMAT
+    assert not out.reshape(ah.value, w * 2)[:h].any()
+    L.CFHD_CloseDecoder(dec)

@@ -87,14 +87,17 @@ def _check_decode(sample, source, w, h, pixfmt=PIX_YUY2, interlaced=False, decod
     if (lo != hi).sum() > 1000:                      # (a picture of saturated blacks and whites has no byte the dither could move)
         frac = (img[lo != hi] == hi[lo != hi]).mean()
         assert 0.35 < frac < 0.65, "dither is not balanced: %.3f" % frac
-    for attempt in range(3):                        # the reference's threaded decoder occasionally damages a frame: three attempts
+    src = source.reshape(h, -1)[:, : w * 2]
+    mine_db = psnr_yuy2(img, src)
+    ends = (psnr_yuy2(lo, src), psnr_yuy2(hi, src))         # any picture inside the interval lies between its two ends (to the printed 0.1 dB)
+    assert min(ends) - 0.1 < mine_db < max(ends) + 0.1
+    def leg():                                        # witness: the reference decoder on this box (its model is pinned on the CPU, test_oracle_vs_ref)
         rout, rpitch = ref_decode_sample(sample, w, h, pixfmt)
         rimg = rout.reshape(h, rpitch)[:, : w * 2]
-        rok = (rimg == lo) | (rimg == hi)
-        if rok.all(): break
-    assert rok.all(), "the reference's own output leaves the dither interval: oracle out of date"
-    src = source.reshape(h, -1)[:, : w * 2]
-    assert abs(psnr_yuy2(img, src) - psnr_yuy2(rimg, src)) < 0.1
+        if not ((rimg == lo) | (rimg == hi)).all(): return "the reference's own output leaves the dither interval"
+        d = abs(mine_db - psnr_yuy2(rimg, src))
+        return d < 0.1 or "PSNR differs by %.2f dB" % d
+    reference_leg(leg, 3, "4:2:2 -> 8-bit 4:2:2")
     return img
 
 
@@ -214,62 +217,60 @@ def test_invalid_arguments_and_unsupported_formats():
     L.CFHD_CloseDecoder(dec)
 
 
-def test_reference_harness_links_unchanged_and_prints_same_numbers():
-    """Example/TestCFHD.cpp of the reference, compiled unmodified against the reference headers, linked once against the
-    reference library and once against libcfhd_amd.so (oracle/Makefile `testcfhd`): the `-D` quality test must print the
-    same compressed sizes (user metadata included) and the same PSNR to the printed 0.1 dB for the formats we support."""
-    import re, subprocess
-    FORMATS = {"YUY2": 10, "2vuy": 10, "YU64": 10, "RG24": 20}
-    ours = os.path.join(ORACLE_DIR, "_ref", "TestCFHD_amd"); theirs = os.path.join(ORACLE_DIR, "_ref", "TestCFHD_ref")
-    if not (os.path.exists(ours) and os.path.exists(theirs)):
-        pytest.fail("harness binaries not built: __graft_entry__.build() runs `make -C oracle testcfhd` where /root/reference exists and they travel with the tree")
-    def run(binary):
-        # The harness walks every pixel format at two resolutions and stops at the first error.  Its first five sections (YUY2, 2vuy, YU64, RG24 -> 4:2:2,
-        # RG24 -> RGB 4:4:4 at full resolution) decode to the row's own pixel format here; the sixth (BGRA from a 4:2:2 sample) does not, so read its
-        # output line by line and stop it (by PID) as soon as that section starts.  (The two RG24 sections print the same header: 20 lines under one key.)
-        import time
-        # OMP_NUM_THREADS=1: the harness's own frame generator (Example/qbist.cpp:284-310, the antialias pass) updates pixel LSBs in place
-        # while neighbouring OpenMP threads read them, so with several threads two runs of the same binary draw slightly different frames
-        proc = subprocess.Popen(["timeout", "420", "stdbuf", "-oL", binary, "-D"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, cwd="/tmp",
-                                start_new_session=True, env=dict(os.environ, OMP_NUM_THREADS="1"))
-        res = {}; fmt = None; t0 = time.time()
+HARNESS_FIXTURE = os.path.join(os.path.dirname(__file__), "golden", "testcfhd_D.json")
+HARNESS_MIN_SECTIONS = 5        # YUY2, 2vuy, YU64, RG24 -> 4:2:2, RG24 -> RGB 4:4:4 at full resolution (what round 3 served; more sections = more checked)
+
+
+def run_harness(binary, limit_s=600, stop_after=None):
+    """`TestCFHD -D` (Example/TestCFHD.cpp:1049-1300): every row of its format table at full, then at half resolution, ten Qbist frames each; it stops at the first
+    error.  Returns the sections it printed (tools/gen_testcfhd_fixture.py parse_harness_output).  The process group we start is the only thing stopped."""
+    import subprocess, sys, time
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from gen_testcfhd_fixture import parse_harness_output
+    # OMP_NUM_THREADS=1: the harness's own frame generator (Example/qbist.cpp:284-310, the antialias pass) updates pixel LSBs in place while neighbouring OpenMP
+    # threads read them, so with several threads two runs of the same binary can draw slightly different frames
+    proc = subprocess.Popen(["timeout", str(limit_s), "stdbuf", "-oL", binary, "-D"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, cwd="/tmp",
+                            start_new_session=True, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    lines = []; t0 = time.time()
+    try:
+        for line in proc.stdout:
+            lines.append(line)
+            if time.time() - t0 > limit_s - 20: break
+            if stop_after and line.startswith("Pixel format:") and sum(l.startswith("Pixel format:") for l in lines) > stop_after: break
+    finally:
         try:
-            for line in proc.stdout:
-                m = re.match(r"Pixel format: (\S+)", line)
-                if m:
-                    fmt = m.group(1)
-                    if fmt not in FORMATS: break
-                m = re.match(r"(\d+): source (\d+) compressed to (\d+) in .*PSNR ([0-9.]+)dB", line)
-                if m and fmt: res.setdefault(fmt, []).append((int(m.group(3)), float(m.group(4))))
-                if time.time() - t0 > 380 or all(len(res.get(f, [])) >= n for f, n in FORMATS.items()): break
-        finally:
-            try:
-                os.killpg(proc.pid, 9)          # the process group we started (timeout + stdbuf + harness), nothing else
-            except ProcessLookupError:
-                pass
-            proc.wait()
-        return res
-    # The reference harness decodes with 16 worker threads (Example/TestCFHD.cpp:345) and its decoder has been seen to damage a frame now and
-    # then on the 256-core GPU host (a 17 dB outlier in its own printout): sizes must agree in every run; a PSNR line of the reference that
-    # disagrees gets two more runs of the reference, and the frame passes when any of them prints our number.
-    from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(2) as ex:                   # (side by side: most of a run is the harness drawing its Qbist frames on one core)
-        fa, fb = ex.submit(run, ours), ex.submit(run, theirs)
-        a, refs = fa.result(), [fb.result()]
-    for fmt in FORMATS:
-        assert fmt in a and len(a[fmt]) == FORMATS[fmt], "our library did not complete the %s run: %r" % (fmt, a.get(fmt))
-    def agree(b):
-        return all(len(b.get(fmt, [])) >= FORMATS[fmt] and all(abs(pa - pb) <= 0.1 + 1e-6 for (sa, pa), (sb, pb) in zip(a[fmt], b[fmt][:FORMATS[fmt]])) for fmt in FORMATS)
-    while not agree(refs[-1]) and len(refs) < 3:
-        refs.append(run(theirs))
-    for fmt in FORMATS:
-        for b in refs:
-            assert len(b.get(fmt, [])) >= FORMATS[fmt], "the reference harness did not complete the %s run: %r" % (fmt, b.get(fmt))
-            for (sa, pa), (sb, pb) in zip(a[fmt], b[fmt][:FORMATS[fmt]]):
-                assert sa == sb, "%s compressed size %d vs reference %d\nours %r\nreference %r" % (fmt, sa, sb, a, b)
-        for k, (sa, pa) in enumerate(a[fmt]):
-            theirs_db = [b[fmt][k][1] for b in refs]
-            assert any(abs(pa - pb) <= 0.1 + 1e-6 for pb in theirs_db), "%s frame %d PSNR %.1f vs reference %r\nours %r" % (fmt, k, pa, theirs_db, a)
+            os.killpg(proc.pid, 9)
+        except ProcessLookupError:
+            pass
+        proc.wait()
+    return parse_harness_output("".join(lines))
+
+
+def test_reference_harness_links_unchanged_and_prints_same_numbers():
+    """Example/TestCFHD.cpp of the reference, compiled unmodified against the reference headers and linked against libcfhd_amd.so (oracle/Makefile `testcfhd`):
+    its `-D` quality test must print the same compressed sizes (user metadata included) and the same PSNR to the printed 0.1 dB as the same harness linked against the
+    reference library.  The reference's numbers are a committed fixture (tests/golden/testcfhd_D.json, written by tools/gen_testcfhd_fixture.py from three runs of
+    oracle/_ref/TestCFHD_ref on the build container): only OUR binary runs on the GPU box -- the reference harness decodes with 16 racing worker threads and a rand()
+    dither and has no place in a `-x` suite (it failed the round-3 hardware run on its own printout).  Every section our library completes is compared; the harness
+    stops at the first format pair the library does not serve, and at least HARNESS_MIN_SECTIONS must complete."""
+    ours = os.path.join(ORACLE_DIR, "_ref", "TestCFHD_amd")
+    if not os.path.exists(ours):
+        pytest.fail("harness binary not built: __graft_entry__.build() runs `make -C oracle testcfhd` where /root/reference exists and it travels with the tree")
+    want = json.load(open(HARNESS_FIXTURE))["sections"]
+    got = run_harness(ours)
+    done = [s for s in got if len(s["frames"]) == 10]
+    assert len(done) >= HARNESS_MIN_SECTIONS, "our library completed %d sections: %r" % (len(done), [(s["format"], s["encode"], s["decode"], len(s["frames"])) for s in got])
+    for k, s in enumerate(done):
+        w = want[k]
+        assert (s["format"], s["encode"], s["decode"]) == (w["format"], w["encode"], w["decode"]), "section %d: %r" % (k, s)
+        for i, ((size, db), f) in enumerate(zip(s["frames"], w["frames"])):
+            where = "%s %s %s frame %d" % (s["format"], s["encode"], s["decode"], i + 1)
+            assert size == f["size"], "%s: compressed size %d vs reference %d" % (where, size, f["size"])
+            # the reference's own spread over the fixture's runs (rand() dither; its alpha race on 4:4:4:4 -> BGRA moves a frame by 0.1-0.3 dB), without the frames
+            # its 16 racing decoder threads damaged (7-40 dB outliers in its printout)
+            seen = [x for x in (f["psnr_seen"] or [f["psnr"]]) if abs(x - f["psnr"]) <= 1.0]
+            assert min(seen) - 0.1 - 1e-6 <= db <= max(seen) + 0.1 + 1e-6, "%s: PSNR %.1f dB vs reference %r" % (where, db, seen)
+    print("harness: %d of %d sections completed and equal to the reference's printout" % (len(done), len(want)))
 
 
 def test_gpu_entropy_and_host_entropy_paths_agree():
@@ -366,12 +367,10 @@ def test_rg48_decode_equals_reference_exactly(w, h):
     assert (aw, ah) == (w, h)
     a = np.frombuffer(got.tobytes(), np.uint16).reshape(h, gpitch // 2)[:, : w * 3]
     assert np.array_equal(a, exact)
-    for attempt in range(3):
+    def leg():
         want, wpitch = ref_decode_sample(sample, w, h, PIX_RG48)
-        b = np.frombuffer(want.tobytes(), np.uint16).reshape(h, wpitch // 2)[:, : w * 3]
-        if np.array_equal(b, exact): break
-    else:
-        raise AssertionError("the reference decoder never reproduced the oracle reconstruction")
+        return np.array_equal(np.frombuffer(want.tobytes(), np.uint16).reshape(h, wpitch // 2)[:, : w * 3], exact)
+    reference_leg(leg, 3, "RGB 4:4:4 -> RG48")
 
 
 def test_rg48_round_trip_and_format_gates():
@@ -492,12 +491,14 @@ def test_yuv422_decode_to_rg24_lies_in_the_reference_interval(w, h, flags):
     differ = lo != hi
     assert 0.45 < (img[differ] == hi[differ]).mean() < 0.55
     src = np.frombuffer(frames[0].tobytes(), np.uint8).reshape(h, pitch)[:, : w * 3].astype(np.float64)
-    mine_db = 10 * np.log10(255.0 ** 2 / np.mean((img - src) ** 2))
-    for attempt in range(4):
+    db = lambda x: 10 * np.log10(255.0 ** 2 / np.mean((x - src) ** 2))
+    mine_db = db(img)
+    assert min(db(lo), db(hi)) - 0.1 < mine_db < max(db(lo), db(hi)) + 0.1
+    def leg():
         dec, dpitch = ref_decode_sample(sample, w, h, PIX_RG24)
-        ref_db = 10 * np.log10(255.0 ** 2 / np.mean((np.frombuffer(dec.tobytes(), np.uint8).reshape(h, dpitch)[:, : w * 3] - src) ** 2))
-        if abs(mine_db - ref_db) < 0.1: break
-    assert abs(mine_db - ref_db) < 0.1, (mine_db, ref_db)
+        ref_db = db(np.frombuffer(dec.tobytes(), np.uint8).reshape(h, dpitch)[:, : w * 3])
+        return abs(mine_db - ref_db) < 0.1 or "PSNR %.2f vs reference %.2f" % (mine_db, ref_db)
+    reference_leg(leg, 4, "4:2:2 -> RG24")
 
 
 @pytest.mark.parametrize("w,h,encoded", [(320, 240, ENCODED_RGBA4444), (336, 256, ENCODED_RGB444), (320, 240, ENCODED_YUV422), (1920, 1080, ENCODED_RGBA4444), (1920, 1080, ENCODED_YUV422)])
@@ -547,12 +548,12 @@ def test_half_resolution_decode_of_rgba4444_to_bgra(w, h):
         mine = np.frombuffer(got.tobytes(), np.uint8).reshape(h // 2, gpitch)[:, : (w // 2) * 4]
         if name == "BGRA": mine = mine[::-1]
         assert np.array_equal(mine, want), name
-        for attempt in range(6):
+        def leg():
             dec, dpitch = ref_decode_sample(sample, w, h, fourcc(name), resolution=2)
             img = np.frombuffer(dec.tobytes(), np.uint8).reshape(-1, dpitch)[: h // 2, : (w // 2) * 4]
             if name == "BGRA": img = img[::-1]
-            if all(np.array_equal(img[:hh, k::4], mine[:hh, k::4]) for k in range(3)): break
-        assert all(np.array_equal(img[:hh, k::4], mine[:hh, k::4]) for k in range(3)), name
+            return all(np.array_equal(img[:hh, k::4], mine[:hh, k::4]) for k in range(3))
+        reference_leg(leg, 6, "RGBA 4:4:4:4 -> %s at half resolution" % name)
 
 
 @pytest.mark.parametrize("w,h,flags", [(320, 240, 0), (336, 248, 4), (1920, 1080, 0)])
@@ -568,11 +569,11 @@ def test_half_resolution_decode_of_yuv422_to_rg24_equals_reference_exactly(w, h,
     want = oracle_half_resolution_rgb24_of_yuv422(plan, host_decode_pyramid(sample, plan), 1 if flags & 4 else 2)
     assert np.array_equal(mine, want[want.shape[0] - h // 2:])
     hh = h // 2 if h % 8 == 0 else h // 2 - 4
-    for attempt in range(6):
+    def leg():
         dec, dpitch = ref_decode_sample(sample, w, h, fourcc("RG24"), resolution=2)
         img = np.frombuffer(dec.tobytes(), np.uint8).reshape(-1, dpitch)[: h // 2, : (w // 2) * 3]
-        if np.array_equal(img[h // 2 - hh:], mine[h // 2 - hh:]): break
-    assert np.array_equal(img[h // 2 - hh:], mine[h // 2 - hh:])
+        return np.array_equal(img[h // 2 - hh:], mine[h // 2 - hh:])
+    reference_leg(leg, 6, "4:2:2 -> RG24 at half resolution")
 
 
 @pytest.mark.parametrize("w,h", [(320, 240), (720, 486), (1920, 1080)])
@@ -612,11 +613,11 @@ def test_half_resolution_decode_to_v210_equals_reference_exactly(w, h):
     mine = np.frombuffer(got.tobytes(), np.uint32).reshape(h // 2, gpitch // 4)[:, : want.shape[1]]
     assert np.array_equal(mine, want)
     hh = h // 2 if h % 8 == 0 else h // 2 - 4
-    for attempt in range(6):
+    def leg():
         dec, dpitch = ref_decode_sample(sample, w, h, fourcc("v210"), resolution=2)
         img = np.frombuffer(dec.tobytes(), np.uint32).reshape(-1, dpitch // 4)[: h // 2, : want.shape[1]]
-        if np.array_equal(img[:hh], mine[:hh]): break
-    assert np.array_equal(img[:hh], mine[:hh])
+        return np.array_equal(img[:hh], mine[:hh])
+    reference_leg(leg, 6, "4:2:2 -> v210 at half resolution")
     if w == 336:
         odd = amd_encode_frames([yu64_frame_with_ramps(320, 240, 1)], 320 * 4, 320, 240, fourcc("YU64"))[0]
         L = product()
@@ -639,11 +640,11 @@ def test_half_resolution_decode_to_yu64_equals_reference_exactly(w, h):
     plan = Plan(w, h, pixkind=PIXKIND["YU64"])
     assert np.array_equal(mine, oracle_half_resolution_yu64(plan, host_decode_pyramid(sample, plan))[: h // 2])
     hh = h // 2 if h % 8 == 0 else h // 2 - 4
-    for attempt in range(6):
+    def leg():
         dec, dpitch = ref_decode_sample(sample, w, h, fourcc("YU64"), resolution=2)
         img = np.frombuffer(dec.tobytes(), np.uint16).reshape(-1, dpitch // 2)[: h // 2, : w]
-        if np.array_equal(img[:hh], mine[:hh]): break
-    assert np.array_equal(img[:hh], mine[:hh])
+        return np.array_equal(img[:hh], mine[:hh])
+    reference_leg(leg, 6, "4:2:2 -> YU64 at half resolution")
 
 
 @pytest.mark.parametrize("w,h", [(320, 240), (336, 248), (1920, 1080)])
@@ -662,10 +663,10 @@ def test_half_resolution_decode_of_rgb444_to_the_8bit_10bit_and_b64a_outputs(w, 
         mine = half_rgb_view(got, gpitch, w, h, name)
         assert np.array_equal(mine, oracle_half_resolution_rgb(plan, deq, name)[: h // 2]), name
         if name == "RG30": continue                     # (the reference knows AJA's name for AB10 as a decoder output too; one comparison is enough)
-        for attempt in range(6):
+        def leg():
             dec, dpitch = ref_decode_sample(sample, w, h, fourcc(name), resolution=2)
-            if np.array_equal(half_rgb_view(dec, dpitch, w, h, name)[:hh], mine[:hh]): break
-        assert np.array_equal(half_rgb_view(dec, dpitch, w, h, name)[:hh], mine[:hh]), name
+            return np.array_equal(half_rgb_view(dec, dpitch, w, h, name)[:hh], mine[:hh])
+        reference_leg(leg, 6, "RGB 4:4:4 -> %s at half resolution" % name)
     for name in ("RG24", "BGRA", "BGRa"):
         got, gpitch, aw, ah = amd_decode_sample(sample, fourcc(name), resolution=2)
         assert (aw, ah) == (w // 2, h // 2)
@@ -674,11 +675,11 @@ def test_half_resolution_decode_of_rgb444_to_the_8bit_10bit_and_b64a_outputs(w, 
         assert ((mine >= lo) & (mine <= hi)).all(), name
         moving = lo != hi
         assert (mine[moving] == lo[moving]).any() and (mine[moving] == hi[moving]).any()
-        for attempt in range(6):
+        def leg():
             dec, dpitch = ref_decode_sample(sample, w, h, fourcc(name), resolution=2)
             ref_img = half_rgb_view(dec, dpitch, w, h, name)
-            if (np.abs(ref_img[:hh].astype(np.int16) - mine[:hh]) <= 1).all(): break
-        assert (np.abs(ref_img[:hh].astype(np.int16) - mine[:hh]) <= 1).all(), name       # (both inside the same interval of width one)
+            return bool((np.abs(ref_img[:hh].astype(np.int16) - mine[:hh]) <= 1).all())        # (both inside the same interval of width one)
+        reference_leg(leg, 6, "RGB 4:4:4 -> %s at half resolution" % name)
 
 
 @pytest.mark.parametrize("w,h", [(320, 240), (336, 248), (720, 480), (1920, 1080), (3840, 2160)])
@@ -696,11 +697,11 @@ def test_bayer_decode_to_byr4_equals_reference_exactly(w, h):
     plan = Plan(w, h, pixkind=PIXKIND["BYR4"], enc=ENC["bayer"])
     want = oracle_inverse_byr4(plan, host_decode_pyramid(sample, plan))[:h, :w]
     assert np.array_equal(mine, want), "%d words differ from the exact reconstruction" % (mine != want).sum()
-    for attempt in range(6):                            # (the reference's threaded decoder occasionally returns a damaged frame)
+    def leg():
         dec, dpitch = ref_decode_sample(sample, w, h, fourcc("BYR4"))
         img = np.frombuffer(dec.tobytes(), np.uint16).reshape(h, dpitch // 2)[:, :w]
-        if np.array_equal(img, mine): break
-    assert np.array_equal(img, mine), "%d words differ" % (img != mine).sum()
+        return np.array_equal(img, mine) or "%d words differ" % (img != mine).sum()
+    reference_leg(leg, 6, "Bayer -> BYR4")
     L = product()
     dec = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
     a = ctypes.c_int(); b = ctypes.c_int(); c = ctypes.c_uint32()
@@ -728,11 +729,12 @@ def test_rgba4444_decode_to_rg48_equals_reference_exactly(w, h):
     want = oracle_inverse_rgb48(plan, deq)[:h].reshape(h, w, 4)[:, :, :3].reshape(h, w * 3)
     assert np.array_equal(mine, want), "%d words differ from the exact reconstruction" % (mine != want).sum()
     rows = h if h % 8 == 0 else h - 8
-    for attempt in range(6):                            # (the reference's threaded decoder occasionally damages a frame)
+    full = mine
+    def leg():
         dec, dpitch = ref_decode_sample(sample, w, h, PIX_RG48)
         img = np.frombuffer(dec.tobytes(), np.uint16).reshape(h, dpitch // 2)[:, : w * 3]
-        if np.array_equal(img[:rows], mine[:rows]): break
-    assert np.array_equal(img[:rows], mine[:rows]), "%d words differ" % (img[:rows] != mine[:rows]).sum()
+        return np.array_equal(img[:rows], full[:rows]) or "%d words differ" % (img[:rows] != full[:rows]).sum()
+    reference_leg(leg, 6, "RGBA 4:4:4:4 -> RG48")
     got, gpitch, aw, ah = amd_decode_sample(sample, PIX_RG48, resolution=2)
     assert (aw, ah) == (w // 2, h // 2)
     mine = np.frombuffer(got.tobytes(), np.uint16).reshape(h // 2, gpitch // 2)[:, : (w // 2) * 3]
@@ -756,11 +758,11 @@ def test_rgb444_decode_to_b64a_equals_reference_exactly(w, h):
     want = oracle_inverse_b64a_of_rgb444(plan, host_decode_pyramid(sample, plan))[:h]
     assert np.array_equal(mine, want)
     rows = h if h % 8 == 0 else h - 8
-    for attempt in range(6):                            # (the reference's threaded decoder occasionally damages a frame)
+    def leg():
         dec, dpitch = ref_decode_sample(sample, w, h, PIX_B64A)
         img = np.frombuffer(dec.tobytes(), np.uint16).reshape(h, dpitch // 2)[:, : w * 4]
-        if np.array_equal(img[:rows], mine[:rows]): break
-    assert np.array_equal(img[:rows], mine[:rows]), "%d words differ" % (img[:rows] != mine[:rows]).sum()
+        return np.array_equal(img[:rows], mine[:rows]) or "%d words differ" % (img[:rows] != mine[:rows]).sum()
+    reference_leg(leg, 6, "RGB 4:4:4 -> b64a")
 
 
 @pytest.mark.parametrize("w,h", [(320, 240), (1920, 1080)])
@@ -795,11 +797,14 @@ def test_yu64_decode_equals_reference_exactly(w, h, src):
     got, gpitch, aw, ah = amd_decode_sample(sample, fourcc("YU64"))
     assert (aw, ah) == (w, h) and gpitch == (w * 4 + 15) // 16 * 16
     mine = np.frombuffer(got.tobytes(), np.uint16).reshape(h, gpitch // 2)[:, : w * 2]
-    for attempt in range(6):                            # (the reference's threaded decoder occasionally damages a frame)
+    plan = Plan(w, h, pixkind=PIXKIND["YU64"])
+    want = oracle_inverse_yu64(plan, host_decode_pyramid(sample, plan))[:h]       # (pinned on the reference decoder on nine geometries: test_reference_yu64_decode_equals_oracle)
+    assert np.array_equal(mine, want), "%d words differ from the exact reconstruction" % (mine != want).sum()
+    def leg():
         dec, dpitch = ref_decode_sample(sample, w, h, fourcc("YU64"))
         img = np.frombuffer(dec.tobytes(), dtype=np.uint16).reshape(h, dpitch // 2)[:, : w * 2]
-        if np.array_equal(mine, img): break
-    assert np.array_equal(mine, img), "%d words differ" % (mine != img).sum()
+        return np.array_equal(mine, img) or "%d words differ" % (mine != img).sum()
+    reference_leg(leg, 6, "4:2:2 -> YU64")
     if src == "yu64":
         assert (mine == 65535).any() and (mine == 1023 << 6).any()
         own = amd_encode_frames([f], p, w, h, fourcc("YU64"))[0]
@@ -845,12 +850,15 @@ def test_v210_decode_equals_reference_exactly(w, h, src):
     assert (aw, ah) == (w, h) and gpitch == (w + 47) // 48 * 128
     nwords = (w // 6) * 4
     mine = np.frombuffer(got.tobytes(), np.uint32).reshape(h, gpitch // 4)[:, :nwords]
-    for attempt in range(3):
+    plan = Plan(w, h, pixkind=PIXKIND["YU64"])
+    want = oracle_inverse_v210(plan, host_decode_pyramid(sample, plan), w)[:h]    # (pinned on the reference decoder on eight geometries: test_reference_v210_decode_equals_oracle)
+    assert np.array_equal(mine, want), "%d words differ from the exact reconstruction" % (mine != want).sum()
+    def leg():
         dec, dpitch = ref_decode_sample(sample, w, h, fourcc("v210"))
-        assert dpitch == gpitch
+        if dpitch != gpitch: return "pitch %d vs reference %d" % (gpitch, dpitch)
         img = np.frombuffer(dec.tobytes(), dtype=np.uint32).reshape(h, dpitch // 4)[:, :nwords]
-        if np.array_equal(mine, img): break
-    assert np.array_equal(mine, img), "%d words differ" % (mine != img).sum()
+        return np.array_equal(mine, img) or "%d words differ" % (mine != img).sum()
+    reference_leg(leg, 3, "4:2:2 -> v210")
     # v210 in, v210 out through the product alone: the 10-bit samples come back within the quantizer's error
     if src == "yuy2" and w % 48 == 0:
         rng = np.random.default_rng(5)
@@ -888,12 +896,12 @@ def test_rgb8_decode_lies_in_the_reference_interval(w, h, name):
     assert 0.4 < (img[differ] == hi[differ]).mean() < 0.6
     if bpp == 4: assert (img[:, 3::4] == 255).all()
     # the reference's own decode of the same sample is as close as two dithers of the same picture can be
-    for attempt in range(6):                            # (the reference's threaded decoder occasionally damages a frame)
+    def leg():
         rdec, rpitch = ref_decode_sample(sample, w, h, fourcc(name))
-        rimg = rdec.reshape(h, rpitch)[:, : w * bpp]
-        if np.abs(rimg.astype(int) - img.astype(int)).max() <= 1: break
-    assert np.abs(rimg.astype(int) - img.astype(int)).max() <= 1
+        return bool(np.abs(rdec.reshape(h, rpitch)[:, : w * bpp].astype(int) - img.astype(int)).max() <= 1)
+    reference_leg(leg, 6, "RGB 4:4:4 -> %s" % name)
     # own round trip from 8-bit pixels
+    rimg = img
     mine = amd_encode_frames([np.ascontiguousarray(rimg).reshape(-1)], w * bpp, w, h, fourcc(name), encoded=ENCODED_RGB444)[0]
     back, bpitch, _, _ = amd_decode_sample(mine, fourcc(name))
     bimg = back.reshape(h, bpitch)[:, : w * bpp].astype(np.float64)
@@ -920,11 +928,14 @@ def test_rgb10_decode_equals_reference_exactly(w, h, name):
     got, gpitch, aw, ah = amd_decode_sample(sample, fourcc(name))
     assert (aw, ah) == (w, h)
     mine = np.frombuffer(got.tobytes(), np.uint32).reshape(h, gpitch // 4)[:, :w]
-    for attempt in range(6):                            # (the reference's threaded decoder occasionally damages a frame)
+    plan = Plan(w, h, pixkind=PIXKIND["RG48"], enc=3)
+    want = oracle_inverse_rgb10(plan, host_decode_pyramid(sample, plan), name)[:h, :w]      # (pinned on the reference decoder on eight geometries: test_reference_rgb10_decode_equals_oracle)
+    assert np.array_equal(mine, want), "%d words differ from the exact reconstruction" % (mine != want).sum()
+    def leg():
         dec, dpitch = ref_decode_sample(sample, w, h, fourcc(name))
         img = np.frombuffer(dec.tobytes(), dtype=np.uint32).reshape(h, dpitch // 4)[:, :w]
-        if np.array_equal(mine, img): break
-    assert np.array_equal(mine, img), "%d words differ" % (mine != img).sum()
+        return np.array_equal(mine, img) or "%d words differ" % (mine != img).sum()
+    reference_leg(leg, 6, "RGB 4:4:4 -> %s" % name)
 
 
 @pytest.mark.parametrize("w,h,name", [(320, 240, "RG48"), (336, 252, "b64a"), (1920, 1080, "RG48")])
@@ -979,13 +990,14 @@ def test_rgba8_encode_to_rgba4444_bitstream_identical(w, h, name):
     rows = h if h % 8 == 0 else h - 8                   # (the reference's last display rows are not reproducible for such heights: test_oracle_vs_ref)
     sl = slice(0, rows) if name == "BGRa" else slice(h - rows, h)
     want, alt = want[sl], alt[sl]
-    for attempt in range(6):                            # (the reference's threaded decoder occasionally damages a frame)
+    def leg():
         dec, dpitch = ref_decode_sample(mine[0], w, h, fmt)
         img = np.frombuffer(dec.tobytes(), np.uint8).reshape(h, dpitch)[sl, : w * 4]
-        if all(np.array_equal(img[:, k::4], want[:, k::4]) for k in range(3)): break
-    assert all(np.array_equal(img[:, k::4], want[:, k::4]) for k in range(3)), "colour bytes: %s differ from the reference decoder's" % [int((img[:, k::4] != want[:, k::4]).sum()) for k in range(3)]
-    a_ok = img[:, 3::4] == want[:, 3::4]
-    assert np.array_equal(img[:, 3::4][~a_ok], alt[~a_ok]), "alpha bytes: %d are neither the expanded nor the companded value" % int((img[:, 3::4][~a_ok] != alt[~a_ok]).sum())
+        if not all(np.array_equal(img[:, k::4], want[:, k::4]) for k in range(3)):
+            return "colour bytes: %s differ from the reference decoder's" % [int((img[:, k::4] != want[:, k::4]).sum()) for k in range(3)]
+        a_ok = img[:, 3::4] == want[:, 3::4]
+        return np.array_equal(img[:, 3::4][~a_ok], alt[~a_ok]) or "alpha bytes: %d are neither the expanded nor the companded value" % int((img[:, 3::4][~a_ok] != alt[~a_ok]).sum())
+    reference_leg(leg, 6, "RGBA 4:4:4:4 -> %s" % name)
     got, gpitch, aw, ah = amd_decode_sample(mine[0], PIX_B64A)
     assert (aw, ah) == (w, h)
     words = np.frombuffer(got.tobytes(), np.uint16).reshape(h, gpitch // 2)[:, : w * 4].reshape(h, w, 4)
@@ -1131,14 +1143,13 @@ def test_b64a_decode_equals_reference(w, h):
     mse = np.mean((a.astype(np.float64) - px[:, : w * 4].astype(np.float64)) ** 2)
     assert 10 * np.log10(65535.0 ** 2 / mse) > 30.0                   # the alpha plane here is noise-like; colour alone is far better
     raw = oracle_inverse_rgb48(plan, pyramid, b64a=False)[:h]
-    for attempt in range(3):
+    def leg():
         want, wpitch = ref_decode_sample(sample, w, h, PIX_B64A)
         b = np.frombuffer(want.tobytes(), np.uint16).reshape(h, wpitch // 2)[:, : w * 4]
         colour = all(np.array_equal(b[:, k::4], exact[:, k::4]) for k in (1, 2, 3))
         rows = (b[:, 0::4] == exact[:, 0::4]).all(axis=1) | (b[:, 0::4] == raw[:, 3::4]).all(axis=1)
-        if colour and rows.all(): break
-    else:
-        raise AssertionError("the reference decoder never reproduced the oracle reconstruction")
+        return bool(colour and rows.all())
+    reference_leg(leg, 3, "RGBA 4:4:4:4 -> b64a")
     # gates
     L = product()
     dec_ref = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec_ref), None) == 0
@@ -1203,11 +1214,10 @@ def test_interlaced_samples_at_half_resolution(w, h, fmt):
     plan = Plan(w, h, pixkind=2 if fmt == PIX_2VUY else 1, progressive=0)
     want = oracle_half_resolution(plan, host_decode_pyramid(sample, plan), int(fmt == PIX_2VUY))
     assert np.array_equal(img, want)
-    for attempt in range(4):
+    def leg():
         out, rpitch = ref_decode_sample(sample, w, h, fmt, resolution=2)
-        if np.array_equal(out.reshape(-1, rpitch)[:, : aw * 2], want): break
-    else:
-        raise AssertionError("the reference decoder never reproduced the model")
+        return np.array_equal(out.reshape(-1, rpitch)[:, : aw * 2], want)
+    reference_leg(leg, 4, "interlaced 4:2:2 at half resolution")
 
 
 def test_b64a_8k_config_c_round_trip():
@@ -1254,11 +1264,10 @@ def test_half_resolution_decode(w, h, fmt):
     out, pitch, aw, ah = amd_decode_sample(sample, fmt, resolution=2)
     assert (aw, ah, pitch) == (w // 2, h // 2, w)
     assert np.array_equal(out.reshape(ah, pitch), want)
-    for attempt in range(3):
+    def leg():
         rout, rpitch = ref_decode_sample(sample, w, h, fmt, resolution=2)
-        if np.array_equal(rout.reshape(-1, rpitch)[:, :w], want): break
-    else:
-        raise AssertionError("the reference decoder never reproduced the model")
+        return np.array_equal(rout.reshape(-1, rpitch)[:, :w], want)
+    reference_leg(leg, 3, "4:2:2 at half resolution")
     # quarter resolution is not built; RGB samples have no half-resolution path here
     L = product()
     dec = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
@@ -1281,14 +1290,13 @@ def test_half_resolution_decode_16bit(w, h, b64a):
     assert (aw, ah) == (w // 2, h // 2)
     assert np.array_equal(np.frombuffer(out.tobytes(), np.uint16).reshape(ah, opitch // 2)[:, : aw * nch], want)
     raw = oracle_half_resolution16(plan, host_decode_pyramid(sample, plan), bool(b64a), expand_alpha=False)
-    for attempt in range(3):
-        rout, rpitch = ref_decode_sample(sample, w, h, fmt, resolution=2)
-        if half16_equal(np.frombuffer(rout.tobytes(), np.uint16).reshape(-1, rpitch // 2)[:, : aw * nch], want, raw, nch): break
-    else:
-        # (the reference's half-resolution 16-bit decode depends on what its process did before -- other words in one colour component once `import torch` has run in
-        # it, as in the CPU suite where this test runs on the emulated product after the torch tests; a fresh process gives the same words every time: cfhd_testlib)
-        rout, rpitch = ref_decode_sample_fresh_process(sample, w, h, fmt, resolution=2)
-        assert half16_equal(np.frombuffer(rout.tobytes(), np.uint16).reshape(-1, rpitch // 2)[:, : aw * nch], want, raw, nch), "the reference decoder never reproduced the model"
+    # (the reference's half-resolution 16-bit decode depends on what its process did before -- other words in one colour component once `import torch` has run in
+    # it, as in the CPU suite where this test runs on the emulated product after the torch tests; a fresh process gives the same words every time: cfhd_testlib)
+    calls = [ref_decode_sample, ref_decode_sample, ref_decode_sample, ref_decode_sample_fresh_process]
+    def leg():
+        rout, rpitch = calls.pop(0)(sample, w, h, fmt, resolution=2)
+        return half16_equal(np.frombuffer(rout.tobytes(), np.uint16).reshape(-1, rpitch // 2)[:, : aw * nch], want, raw, nch)
+    reference_leg(leg, 4, "%s at half resolution" % kind)
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -190,22 +190,8 @@ def test_reference_v210_decode_equals_oracle(w, h, src):
         f, p = synth_yuy2(w, h, 11)
         sample = ref_encode_frames([f], p, w, h, PIX_YUY2)[0]
     plan = Plan(w, h, pixkind=PIXKIND["YU64"])
-    coeffs = host_decode_pyramid(sample, plan)
-    O = oracle()
-    work = coeffs.copy()
-    for c in range(3):
-        for lv in (2, 1):
-            d = plan.band[(c, lv, 0)]
-            bands = (c_i16p * 4)(*[plan.view(work, c, lv, b).ctypes.data_as(c_i16p) for b in range(4)])
-            dst = plan.view(work, c, lv - 1, 0)
-            O.orc_inv_spatial(bands, d["pitch"], d["width"], d["height"], plan.prescale[lv], dst.ctypes.data_as(c_i16p), plan.band[(c, lv - 1, 0)]["pitch"])
-    ptrs = (c_i16p * 12)(*[plan.view(work, c, 0, b).ctypes.data_as(c_i16p) for c in range(3) for b in range(4)])
-    pitches = [plan.band[(c, 0, 0)]["pitch"] for c in range(3)]
-    bw = plan.band[(0, 0, 0)]["width"]; bh = plan.band[(0, 0, 0)]["height"]
     nwords = (w // 6) * 4
-    mine = np.zeros((2 * bh, nwords), np.uint32)
-    O.orc_inv_spatial_to_v210.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
-    O.orc_inv_spatial_to_v210(ptrs, iarr(pitches), bw, bh, plan.precision, mine.ctypes.data_as(ctypes.c_void_p), nwords)
+    mine = oracle_inverse_v210(plan, host_decode_pyramid(sample, plan), w)
     for attempt in range(6):                            # (the reference's threaded decoder occasionally damages a frame)
         dec, dpitch = ref_decode_sample(sample, w, h, fourcc("v210"))
         img = np.frombuffer(dec.tobytes(), dtype=np.uint32).reshape(h, dpitch // 4)[:, :nwords]

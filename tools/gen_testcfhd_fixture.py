@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE: writes tests/golden/testcfhd_D.json -- what the reference's own harness prints for `TestCFHD -D`
+(Example/TestCFHD.cpp:1049-1300: every row of its format table at full and at half resolution, ten Qbist frames each) when it is
+linked against the *reference* library (oracle/_ref/TestCFHD_ref, built by `make -C oracle testcfhd` where /root/reference exists).
+
+The GPU test `test_reference_harness_links_unchanged_and_prints_same_numbers` runs only oracle/_ref/TestCFHD_amd (the same harness
+objects linked against libcfhd_amd.so) on the GPU box and compares with this file: the live reference is a threaded decoder with a
+rand() dither on a 256-core host and has no place in a `-x` suite.
+
+Per section and frame the fixture keeps the compressed size (deterministic: the encoder is single-threaded; OMP_NUM_THREADS=1 keeps
+the harness's own Qbist generator, Example/qbist.cpp:284-310, from racing on pixel LSBs) and the PSNR the reference printed: the value
+most of the runs agree on, plus every value seen (the 8-bit routes draw their dither from rand()).
+
+usage: python tools/gen_testcfhd_fixture.py [--runs 3] [--logs a.log b.log ...]     (logs: output of earlier `TestCFHD_ref -D` runs)
+"""
+import argparse, collections, json, os, re, subprocess, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "TestCFHD_ref")
+OUT = os.path.join(ROOT, "tests", "golden", "testcfhd_D.json")
+
+
+def parse_harness_output(text):
+    """-> list of sections {"format", "encode", "decode", "frames": [(size, psnr), ...]} in the order the harness printed them."""
+    sections = []; cur = None
+    for line in text.splitlines():
+        m = re.match(r"Pixel format: (\S+)", line)
+        if m:
+            cur = {"format": m.group(1), "encode": None, "decode": None, "frames": []}; sections.append(cur); continue
+        if cur is None: continue
+        m = re.match(r"Encode:\s+(\d+)", line)
+        if m: cur["encode"] = int(m.group(1)); continue
+        m = re.match(r"Decode:\s+(\S+) res", line)
+        if m: cur["decode"] = m.group(1).lower(); continue
+        m = re.match(r"(\d+): source (\d+) compressed to (\d+) in .*PSNR (\S+?)dB", line)
+        if m:
+            try: db = float(m.group(4))
+            except ValueError: db = float("nan")
+            cur["frames"].append((int(m.group(3)), db))
+    return sections
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--runs", type=int, default=3)
+    ap.add_argument("--logs", nargs="*")
+    a = ap.parse_args()
+    texts = []
+    if a.logs:
+        texts = [open(p).read() for p in a.logs]
+    else:
+        procs = [subprocess.Popen([REF_BIN, "-D"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, cwd="/tmp",
+                                  env=dict(os.environ, OMP_NUM_THREADS="1")) for _ in range(a.runs)]
+        texts = [p.communicate()[0] for p in procs]
+    runs = [parse_harness_output(t) for t in texts]
+    nsec = min(len(r) for r in runs)
+    out = []
+    for k in range(nsec):
+        secs = [r[k] for r in runs]
+        head = {key: secs[0][key] for key in ("format", "encode", "decode")}
+        assert all({key: s[key] for key in head} == head for s in secs), "runs disagree on the order of the sections"
+        nfr = min(len(s["frames"]) for s in secs)
+        frames = []
+        for i in range(nfr):
+            sizes = collections.Counter(s["frames"][i][0] for s in secs)
+            dbs = collections.Counter(s["frames"][i][1] for s in secs if s["frames"][i][1] == s["frames"][i][1])
+            size, votes = sizes.most_common(1)[0]
+            if votes != len(secs): print("section %d frame %d: sizes %r" % (k, i + 1, dict(sizes)), file=sys.stderr)
+            frames.append({"size": size, "psnr": dbs.most_common(1)[0][0] if dbs else None, "psnr_seen": sorted(dbs)})
+        out.append(dict(head, frames=frames))
+    json.dump({"generator": "tools/gen_testcfhd_fixture.py", "binary": "oracle/_ref/TestCFHD_ref -D (OMP_NUM_THREADS=1)", "runs": len(runs), "sections": out},
+              open(OUT, "w"), indent=0)
+    print("wrote %s: %d sections" % (OUT, len(out)))
+
+
+if __name__ == "__main__":
+    main()
