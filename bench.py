@@ -290,7 +290,9 @@ def measure(workload, steps, warmup, batch, unique, threads, rank, world, barrie
     TILES = "k_dec_tiles+k_dec_undiff" if wl["flags"] & 1 else "k_dec_tiles"
     old_dec = os.environ.get("CFHD_AMD_DEC") in ("par", "lane")
     DEC = [("k_dec_bands_par", 13)] if old_dec else [("k_dec_plan+k_dec_index", 15), ("k_dec_chain", 16), (TILES, 17)]
-    COUNT1 = "k_ent_count[L1 bands, beside the L2 / L3 transforms]"      # the level-1 bands are counted on a second stream while levels 2 and 3 are transformed
+    # the level-1 bands are counted on a second stream while levels 2 and 3 are transformed -- from the block lists the forward strip kernel leaves (k_ent_count_blocks)
+    # where it runs, else from the dense bands (k_ent_count)
+    COUNT1 = ("k_ent_count_blocks" if FWD1.endswith("_blocks") else "k_ent_count") + "[L1 bands, beside the L2 / L3 transforms]"
     KERNELS = [(FWD1, 0), (PF2, 1), (PF3, 2), (COUNT1, 18), ("k_ent_count", 8), ("k_ent_scan", 9), ("k_ent_layout", 10), ("k_ent_emit", 11)]
     if wl["mode"] == 0:
         KERNELS += [("k_dec_parse", 12)] + DEC + [("k_dec_lowpass", 14), (PI3, 5), (PI2, 4), (INV1, 3)]

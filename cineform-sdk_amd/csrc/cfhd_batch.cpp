@@ -145,7 +145,7 @@ long long cfhd_amd_batch_roundtrip(cfhd_amd_batch *b)
 			cfhd_amd_chunk *c = b->chunks[k].get();
 			auto fail = [&](int code) { int z = 0; err.compare_exchange_strong(z, code); };
 			// the transform kernels start first: the host serialises the sample headers (0.5 ms per 256) while they run
-			if (c->enc.launch_forward()) return fail(-2);
+			if (c->enc.launch_forward(false)) return fail(-2);      // (nothing but the entropy stage reads these coefficients)
 			for (int l = 0; l < c->n; l++) if (c->enc.entropy().set_frame_header(l, header(c->first + l))) return fail(-6);
 			if (c->enc.entropy().launch()) return fail(-2);
 			if (b->decode) {
@@ -173,7 +173,7 @@ long long cfhd_amd_batch_roundtrip(cfhd_amd_batch *b)
 		prepare_meta();
 		for (auto &c : b->chunks) {
 			for (int l = 0; l < c->n; l++) if (c->enc.entropy().set_frame_header(l, header(c->first + l))) return -6;
-			if (c->enc.launch_forward() || c->enc.entropy().launch()) return -2;
+			if (c->enc.launch_forward(false) || c->enc.entropy().launch()) return -2;
 		}
 		t1 = now();
 		// 2. as each chunk's samples arrive on the host (the encoder's product), hand them to the decoder and queue its work

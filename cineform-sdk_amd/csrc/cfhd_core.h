@@ -123,4 +123,20 @@ void build_bayer_linear_restore_curve(uint16_t *curve /* 1 << kBayerCurveBits en
 
 static inline int align_up(int x, int a) { return (x + a - 1) / a * a; }
 
+// Block lists of the quantized level-1 bands (dev::FwdBlockLists in cfhd_kernels.h; k_fwd_yuv422_strip_blocks writes them, k_ent_count_blocks reads them): every band
+// row is cut into chunks of kBlockChunkCols coefficients, one 64-bit occupancy mask per chunk.  mask_base[c][b]: the first chunk of band (c, b) in a frame's mask
+// array (chunks by band row, then by position in the row); returns the masks per frame.
+enum { kBlockChunkCols = 496 };
+static inline int block_list_layout(const FramePlan &plan, int mask_base[kMaxChannels][kNumBands])
+{
+	int at = 0;
+	for (int c = 0; c < plan.num_channels; c++)
+		for (int b = 0; b < kNumBands; b++) {
+			const BandDesc &bd = plan.ch[c].band[0][b];
+			mask_base[c][b] = b ? at : -1;
+			if (b) at += bd.height * ((bd.pitch + kBlockChunkCols - 1) / kBlockChunkCols);
+		}
+	return at;
+}
+
 } // namespace cfhd

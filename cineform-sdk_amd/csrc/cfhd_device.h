@@ -35,13 +35,16 @@ public:
 	int set_device_frame(int i, const void *d_frame, int pitch_bytes);
 	// the next launches (forward transform, entropy coder, sample download) cover frames 0 .. k-1 only (0 = all)
 	void set_active(int k) { active_ = k; ent_.set_active(k); }
-	int launch_forward();                              // async: all levels, all frames
+	// async: all levels, all frames.  coeffs_needed = false: nothing but the GPU entropy stage will read this launch's coefficients -- where the level-1 bands
+	// leave as block lists (k_fwd_yuv422_strip_blocks, cfhd_kernels.h FwdBlockLists) their dense rows are then not written at all.
+	int launch_forward(bool coeffs_needed = true);
 	int update_quant(const FramePlan &plan);           // same geometry, new quantizer tables (per-frame rate feedback)
 	// GPU entropy stage (cfhd_entropy_kernels.h): complete samples are produced in HBM after launch_forward().
 	int prepare_entropy(size_t sample_cap);
 	GpuEntropyEncoder &entropy() { return ent_; }
 	bool has_entropy() const { return ent_ready_; }
 	bool strip_forward() const;                     // level 1 of 4:2:2 runs as k_fwd_yuv422_strip (else k_fwd_yuv422)
+	bool block_lists_forward() const;               // ... and leaves the quantized level-1 bands as block lists for k_ent_count_blocks (k_fwd_yuv422_strip_blocks)
 	bool strip_forward_packed16() const;            // level 1 of RG48 / b64a runs as k_fwd_packed16_strip (else k_fwd_packed16)
 	const char *level_kernel(int level) const;      // name of the kernel the next launch_forward() uses for level 0 / 1 / 2 (as a profiler shows it)
 	int download_coeffs();                             // async: final (entropy coded) region of every frame -> pinned host
@@ -56,6 +59,7 @@ public:
 private:
 	int sync_jobs();
 	void fill_jobs();
+	void fill_block_lists();
 	FramePlan plan_;
 	int n_ = 0, active_ = 0, device_ = 0; bool own_input_ = false, jobs_dirty_ = true;
 	void *stream_ = nullptr, *ev0_ = nullptr, *ev1_ = nullptr, *evl_[2] = {nullptr, nullptr};

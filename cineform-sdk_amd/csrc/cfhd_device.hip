@@ -379,9 +379,28 @@ int EncodeBatch::prepare_entropy(size_t sample_cap)
 {
 	int rc = ent_.prepare(plan_, n_, d_coeff_, plan_.coeff_elems, sample_cap, stream_);
 	ent_ready_ = rc == 0;
+	if (ent_ready_) fill_block_lists();
 	// the level-1 bands can be counted while levels 2 and 3 are still being transformed (CFHD_AMD_COUNT_SPLIT=0: everything behind level 3, one launch)
 	{ const char *e = getenv("CFHD_AMD_COUNT_SPLIT"); if (ent_ready_ && !(e && e[0] == '0')) ent_.set_level1_event(evl_[0]); }
 	return rc;
+}
+
+// Where the forward strip kernel leaves the block lists of the level-1 bands (the entropy stage owns the buffers: GpuEntropyEncoder::prepare).
+void EncodeBatch::fill_block_lists()
+{
+	EncJobs j = enc_jobs_at(h_jobs_, n_, plan_.num_channels);
+	int mask_base[kMaxChannels][kNumBands];
+	block_list_layout(plan_, mask_base);
+	static_assert((int)kBlockChunkCols == (int)dev::FWD_CHUNK_COLS, "one chunk geometry");
+	for (int i = 0; i < n_; i++) {
+		dev::FwdBlockLists &l = j.yuv[i].lists;
+		const bool on = ent_ready_ && ent_.block_slots();
+		l.blocks = on ? (uint4 *)ent_.block_slots() : nullptr;
+		l.masks = on ? ent_.block_masks(i) : nullptr;
+		l.base = d_coeff_;                               // (block slots are numbered over the whole batch's pyramids, as the entropy stage's segment jobs address them)
+		for (int c = 0; c < 3; c++) for (int b = 0; b < 4; b++) l.mask_base[c][b] = mask_base[c][b];
+	}
+	jobs_dirty_ = true;
 }
 
 int EncodeBatch::sync_jobs()
@@ -516,12 +535,23 @@ const char *EncodeBatch::level_kernel(int level) const
 	if (strip_forward_packed16()) return "k_fwd_packed16_strip";
 	if (enc_packed16(plan_.pixel_kind)) return "k_fwd_packed16";
 	if (plan_.interlaced) return "k_fwd_frame_yuv422";
-	return strip_forward() ? "k_fwd_yuv422_strip" : "k_fwd_yuv422";
+	return strip_forward() ? (block_lists_forward() ? "k_fwd_yuv422_strip_blocks" : "k_fwd_yuv422_strip") : "k_fwd_yuv422";
 }
 
-int EncodeBatch::launch_forward()
+// Level-1 bands as block lists for the GPU entropy stage (k_fwd_yuv422_strip_blocks -> k_ent_count_blocks): wherever the 4:2:2 strip kernel runs in front of the
+// GPU entropy stage.  CFHD_AMD_BLOCKS=0: dense bands and k_ent_count (A/B runs).
+bool EncodeBatch::block_lists_forward() const
+{
+	static const int blocks_env = [] { const char *e = getenv("CFHD_AMD_BLOCKS"); return e ? atoi(e) : 1; }();
+	return blocks_env && ent_ready_ && ent_.block_slots() && (plan_.pixel_kind == PIX_YUY2 || plan_.pixel_kind == PIX_2VUY) && strip_forward();
+}
+
+int EncodeBatch::launch_forward(bool coeffs_needed)
 {
 	(void)hipSetDevice(device_);
+	static const int dense_env = [] { const char *e = getenv("CFHD_AMD_DENSE_L1"); return e ? atoi(e) : 0; }();      // (1: the dense level-1 bands are always written beside the block lists)
+	const bool blocks = block_lists_forward();
+	if (ent_ready_) ent_.set_block_lists(blocks);
 	int rc = sync_jobs();
 	if (rc) return rc;
 	hipStream_t st = (hipStream_t)stream_;
@@ -555,7 +585,9 @@ int EncodeBatch::launch_forward()
 		dev::k_fwd_frame_yuv422<<<grid, dev::NTHREADS, 0, st>>>((const dev::FwdFrameJob *)j.yuv);
 	} else if (strip_forward()) {
 		const int nseg = (plan_.width / 16 + dev::SSEG - 1) / dev::SSEG;      // segments of 124 luma blocks (1984 pixels)
-		dev::k_fwd_yuv422_strip<<<dim3(nseg, (plan_.height / 2 + dev::SRF - 1) / dev::SRF, act), dev::NTHREADS, 0, st>>>(j.yuv);
+		const dim3 grid(nseg, (plan_.height / 2 + dev::SRF - 1) / dev::SRF, act);
+		if (blocks) dev::k_fwd_yuv422_strip_blocks<<<grid, dev::NTHREADS, 0, st>>>(j.yuv, coeffs_needed || dense_env);
+		else dev::k_fwd_yuv422_strip<<<grid, dev::NTHREADS, 0, st>>>(j.yuv);
 	} else {
 		dim3 grid((plan_.width / 2 + dev::TW - 1) / dev::TW, (plan_.height / 2 + dev::TH - 1) / dev::TH, act);
 		dev::k_fwd_yuv422<<<grid, dev::NTHREADS, 0, st>>>(j.yuv);

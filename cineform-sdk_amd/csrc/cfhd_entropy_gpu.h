@@ -37,6 +37,12 @@ public:
 	// Optional: the event behind the level-1 transform of the frames about to be coded (on the stream given to prepare()).  With it launch() counts the level-1
 	// bands on a stream of its own, beside the level-2 / level-3 transforms that are still queued in front of it on the main stream.
 	void set_level1_event(void *ev) { ev_level1_ = ev; }
+	// Block lists of the level-1 bands (cfhd_kernels.h FwdBlockLists): the buffers the forward strip kernel fills (null when the geometry has none), and whether the
+	// next launch() counts the level-1 bands from them (k_ent_count_blocks) instead of reading the dense bands (k_ent_count).
+	void *block_slots() const { return d_blocks_; }
+	unsigned long long *block_masks(int frame) const { return d_masks_ ? d_masks_ + (size_t)frame * masks_per_frame_ : nullptr; }
+	void set_block_lists(bool on) { use_blocks_ = on && d_blocks_; }
+	bool block_lists() const { return use_blocks_; }
 	void *headers_event() const { return ev_[3]; }
 	void *samples_event() const { return ev_[4]; }
 private:
@@ -55,6 +61,7 @@ private:
 	void *ev_[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; bool timed_ = false;
 	bool split_ = false; void *ev_level1_ = nullptr, *stream2_ = nullptr, *ev2_[3] = {nullptr, nullptr, nullptr};      // the level-1 part of k_ent_count on its own stream
 	int16_t *d_coeffs_ = nullptr; size_t coeff_stride_ = 0;
+	void *d_blocks_ = nullptr; unsigned long long *d_masks_ = nullptr; size_t masks_per_frame_ = 0; bool use_blocks_ = false;
 };
 
 

@@ -22,7 +22,7 @@ GpuEntropyEncoder::~GpuEntropyEncoder() { release(); delete host_; }
 void GpuEntropyEncoder::release()
 {
 	(void)hipSetDevice(device_);
-	void *dev[] = { d_samples_, d_sizes_, d_tables_, d_bands_, d_segband_, d_segs_, d_bandstate_, d_frames_, d_tmpl_, d_packed_, d_offsets_, d_tokens_ };
+	void *dev[] = { d_samples_, d_sizes_, d_tables_, d_bands_, d_segband_, d_segs_, d_bandstate_, d_frames_, d_tmpl_, d_packed_, d_offsets_, d_tokens_, d_blocks_, d_masks_ };
 	for (void *p : dev) if (p) (void)hipFree(p);
 	if (h_samples_) (void)hipHostFree(h_samples_);
 	if (h_sizes_) (void)hipHostFree(h_sizes_);
@@ -36,6 +36,7 @@ void GpuEntropyEncoder::release()
 	timed_ = false;
 	d_samples_ = h_samples_ = nullptr; d_sizes_ = h_sizes_ = nullptr; d_tables_ = d_bands_ = d_segband_ = d_segs_ = d_bandstate_ = d_frames_ = d_tokens_ = nullptr;
 	d_tmpl_ = h_tmpl_ = nullptr; n_ = 0;
+	d_blocks_ = nullptr; d_masks_ = nullptr; masks_per_frame_ = 0; use_blocks_ = false;
 }
 
 int GpuEntropyEncoder::prepare(const FramePlan &plan, int nframes, int16_t *d_coeffs, size_t stride, size_t sample_cap, void *stream)
@@ -65,6 +66,15 @@ int GpuEntropyEncoder::prepare(const FramePlan &plan, int nframes, int16_t *d_co
 	HIPCHK(hipMalloc(&d_segs_, jobs.segjobs.size() * sizeof(dev::EntSegState)));
 	HIPCHK(hipMalloc(&d_tokens_, jobs.segjobs.size() * (size_t)dev::ENT_TOK_STRIDE * sizeof(uint32_t)));      // token lists and finished bit strings: worst case one per coefficient, only the used part is ever touched
 	HIPCHK(hipMalloc(&d_bandstate_, jobs.bands.size() * sizeof(dev::EntBandState)));
+	// block lists of the level-1 bands, for the geometries k_fwd_yuv422_strip_blocks serves (EncodeBatch::strip_forward): one 16-byte slot per block of the
+	// pyramid (only the slots of listed blocks are ever touched), one mask per chunk
+	static_assert((int)kBlockChunkCols == (int)dev::FWD_CHUNK_COLS_ENT, "one chunk geometry");
+	if (!plan.interlaced && plan.encoded_format == ENC_YUV422 && (plan.pixel_kind == PIX_YUY2 || plan.pixel_kind == PIX_2VUY) && plan.width % 32 == 0) {
+		int mask_base[kMaxChannels][kNumBands];
+		masks_per_frame_ = (size_t)block_list_layout(plan, mask_base);
+		HIPCHK(hipMalloc(&d_blocks_, stride * 2 * (size_t)n_));
+		HIPCHK(hipMalloc((void **)&d_masks_, masks_per_frame_ * 8 * (size_t)n_));
+	}
 	HIPCHK(hipMalloc((void **)&d_samples_, cap_ * n_));
 	HIPCHK(hipHostMalloc((void **)&h_samples_, cap_ * n_, hipHostMallocPortable));
 	HIPCHK(hipMalloc((void **)&d_sizes_, sizeof(uint32_t) * 2 * n_));                   // [n] sample sizes, [n] peak flags
@@ -112,10 +122,15 @@ int GpuEntropyEncoder::launch()
 	(void)hipGetLastError();
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[0], st));
 	const int count_probe = []{ const char *e = getenv("CFHD_AMD_COUNT_PROBE"); return e ? atoi(e) : 0; }();
-	auto count_range = [&](hipStream_t s, int lo, int n) {
+	const dev::EntBlockLists lists = { (const uint4 *)d_blocks_, d_masks_, d_coeffs_, masks_per_frame_ };
+	auto count_range = [&](hipStream_t s, int lo, int n, bool level1 = false) {
 		const int total = n * act;
-		dev::k_ent_count<<<(total + dev::ENT_WAVES - 1) / dev::ENT_WAVES, dev::ENT_THREADS, 0, s>>>((const dev::EntSegJob *)d_segband_, geom, total, (dev::EntSegState *)d_segs_, T,
-		                                                                                          d_sizes_ + n_, (uint32_t *)d_tokens_, lo, n, count_probe);
+		if (level1 && use_blocks_)
+			dev::k_ent_count_blocks<<<(total + dev::ENT_WAVES - 1) / dev::ENT_WAVES, dev::ENT_THREADS, 0, s>>>((const dev::EntSegJob *)d_segband_, geom, total, (dev::EntSegState *)d_segs_, T,
+			                                                                                                 d_sizes_ + n_, (uint32_t *)d_tokens_, lo, n, lists);
+		else
+			dev::k_ent_count<<<(total + dev::ENT_WAVES - 1) / dev::ENT_WAVES, dev::ENT_THREADS, 0, s>>>((const dev::EntSegJob *)d_segband_, geom, total, (dev::EntSegState *)d_segs_, T,
+			                                                                                          d_sizes_ + n_, (uint32_t *)d_tokens_, lo, n, count_probe);
 	};
 	split_ = ev_level1_ && stream2_ && !host_->jobs.ranges_l1.empty() && act >= 8;      // (a single frame gains nothing from six launches instead of one)
 	// the peak flags are raised by the difference-coded band only, a level-1 band: cleared on the stream that counts it
@@ -126,11 +141,14 @@ int GpuEntropyEncoder::launch()
 		HIPCHK(hipStreamWaitEvent(s2, (hipEvent_t)ev_level1_, 0));
 		if (plan_.interlaced) HIPCHK(hipMemsetAsync(d_sizes_ + n_, 0, sizeof(uint32_t) * n_, s2));
 		HIPCHK(hipEventRecord((hipEvent_t)ev2_[0], s2));
-		for (const auto &r : host_->jobs.ranges_l1) count_range(s2, r.first, r.second);
+		for (const auto &r : host_->jobs.ranges_l1) count_range(s2, r.first, r.second, true);
 		HIPCHK(hipEventRecord((hipEvent_t)ev2_[1], s2));
 		for (const auto &r : host_->jobs.ranges_rest) count_range(st, r.first, r.second);
 		HIPCHK(hipEventRecord((hipEvent_t)ev2_[2], st));
 		HIPCHK(hipStreamWaitEvent(st, (hipEvent_t)ev2_[1], 0));
+	} else if (use_blocks_) {
+		for (const auto &r : host_->jobs.ranges_l1) count_range(st, r.first, r.second, true);
+		for (const auto &r : host_->jobs.ranges_rest) count_range(st, r.first, r.second);
 	} else count_range(st, 0, total_segs_ / n_);
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[1], st));
 	dev::k_ent_scan<<<nbands_ * act, dev::ENT_THREADS, 0, st>>>((const dev::EntBandJob *)d_bands_, (dev::EntSegState *)d_segs_, (dev::EntBandState *)d_bandstate_, T);

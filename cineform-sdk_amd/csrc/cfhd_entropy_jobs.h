@@ -225,6 +225,8 @@ inline bool ent_build_band_jobs(const FramePlan &plan, const SampleTemplate &t0,
 	if ((int)t0.holes.size() > dev::ENT_MAX_HOLES || (int)t0.patches.size() > kEntMaxPatches) return false;
 	out->bands.clear(); out->segjobs.clear(); out->ranges_l1.clear(); out->ranges_rest.clear();
 	out->band_of_hole.assign(t0.holes.size(), -1);
+	int mask_base[kMaxChannels][kNumBands];
+	block_list_layout(plan, mask_base);
 	for (int f = 0; f < nframes; f++) {
 		int16_t *base = coeffs + (size_t)f * stride;
 		for (size_t h = 0; h < t0.holes.size(); h++) {
@@ -241,7 +243,8 @@ inline bool ent_build_band_jobs(const FramePlan &plan, const SampleTemplate &t0,
 				std::vector<std::pair<int, int>> &r = hole.level == 0 ? out->ranges_l1 : out->ranges_rest;
 				if (!r.empty() && r.back().first + r.back().second == j.seg_base) r.back().second += j.nseg; else r.push_back({ j.seg_base, j.nseg });
 			}
-			for (int s = 0; s < j.nseg; s++) out->segjobs.push_back(dev::EntSegJob{ j.coeffs, j.n, s * dev::ENT_SEG, (int)out->bands.size(), j.table });
+			for (int s = 0; s < j.nseg; s++) out->segjobs.push_back(dev::EntSegJob{ j.coeffs, j.n, s * dev::ENT_SEG, (int)out->bands.size(), j.table, bd.pitch,
+			                                                                        hole.level == 0 ? mask_base[hole.channel][hole.band] : -1 });
 			out->bands.push_back(j);
 		}
 	}

@@ -30,6 +30,7 @@ namespace dev {
 #ifndef CFHD_ENT_TOK_CAP
 #define CFHD_ENT_TOK_CAP 256
 #endif
+enum { FWD_CHUNK_COLS_ENT = 496 };      // = FWD_CHUNK_COLS of cfhd_kernels.h (static_assert in cfhd_device.hip, which sees both headers)
 enum { ENT_THREADS = 256, ENT_LANES = 64, ENT_WAVES = ENT_THREADS / ENT_LANES, ENT_PER_THREAD = CFHD_ENT_PER_THREAD, ENT_SEG = ENT_LANES * ENT_PER_THREAD,
        ENT_LDS_WORDS = 256, ENT_TOK_CAP = CFHD_ENT_TOK_CAP, ENT_MAX_HOLES = 40,
        ENT_FILL = CFHD_ENT_FILL /* bytes of a sample one workgroup of k_ent_layout fills at a time */,
@@ -68,6 +69,8 @@ struct EntSegJob {                 // static per segment: everything k_ent_count
 	int first;                     // raster index of the segment's first coefficient
 	int band;                      // band job index
 	int table;                     // entropy table of the band (EntBandJob::table); such a band is also the one that may need a peak table
+	int pitch;                     // coefficients per band row (k_ent_count_blocks: a level-1 band's chunks are cut row by row)
+	int mask_base;                 // the band's first chunk in a frame's mask array (FwdBlockLists::mask_base); -1: the band has no block lists
 };
 
 struct EntSegState {               // per segment, written by k_ent_count / k_ent_scan
@@ -196,6 +199,9 @@ __device__ __forceinline__ void ent_load_segment(const EntSegJob &job, int lane,
 	}
 }
 
+__device__ __forceinline__ void ent_count_tokens(int seg, const EntSegJob &job, int frame, int ntok, int lane, uint32_t *s_tok, EntSegState *segs, const EntTables *tables,
+                                                 uint32_t *peak_flags, uint32_t *tokens, int probe);
+
 // One segment of k_ent_count: the wave's loaded coefficients -> token strings in `tokens`, the segment's state in segs[seg].
 // The picture is sparse (about one coefficient in twelve is nonzero), so the code lookups run over a compacted token list, one token per lane
 // and round.  Compaction is what this kernel's instructions went into while every lane held 16 consecutive coefficients (a count, a wave scan and
@@ -205,7 +211,6 @@ __device__ __forceinline__ void ent_load_segment(const EntSegJob &job, int lane,
 __device__ __forceinline__ void ent_count_segment(int seg, const EntSegJob &job, int frame, const uint32_t *w, int lane, uint32_t *s_tok, EntSegState *segs, const EntTables *tables,
                                                   uint32_t *peak_flags, uint32_t *tokens, int probe)
 {
-	const EntTables *T = tables + job.table;
 	if (probe == 1) { uint32_t o = 0; for (int j = 0; j < ENT_SEG / 128; j++) o |= w[j]; const unsigned long long q = __ballot(o == 0x12345u); if (lane == 0) { EntSegState &z = segs[seg]; z.first_nz = -1; z.last_nz = -1; z.bits = q == 0x123456789ull; z.ntok = 0; z.lead32 = 0; z.lead_valid = 0; } return; }
 	int ntok = 0;                                        // wave-uniform
 #pragma unroll
@@ -219,6 +224,15 @@ __device__ __forceinline__ void ent_count_segment(int seg, const EntSegJob &job,
 		ntok += __popcll(ml) + __popcll(mh);
 	}
 	CFHD_WAVE_SYNC();
+	ent_count_tokens(seg, job, frame, ntok, lane, s_tok, segs, tables, peak_flags, tokens, probe);
+}
+
+// The second half of a segment's count, from its compacted token list s_tok[0 .. ntok) (local raster index << 16 | value): the tokens' finished bit strings into
+// `tokens`, the segment's state into segs[seg].  Shared by k_ent_count (tokens compacted from the dense band) and k_ent_count_blocks (from the block lists).
+__device__ __forceinline__ void ent_count_tokens(int seg, const EntSegJob &job, int frame, int ntok, int lane, uint32_t *s_tok, EntSegState *segs, const EntTables *tables,
+                                                 uint32_t *peak_flags, uint32_t *tokens, int probe)
+{
+	const EntTables *T = tables + job.table;
 	uint32_t bits = 0, lead32 = 0, lead_valid = 0;
 	if (probe == 2) { const unsigned long long q = __ballot(s_tok[lane] == 0x12345u); if (lane == 0) { EntSegState &z = segs[seg]; z.first_nz = -1; z.last_nz = -1; z.bits = q == 0x123456789ull && ntok == 0x12345; z.ntok = 0; z.lead32 = 0; z.lead_valid = 0; } return; }
 	bool peak = false;
@@ -308,6 +322,57 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_count(const EntSegJob *seg_
 			ent_count_segment(seg0 + k, job[k], frame[k], w[k], lane, s_tok_all[wave], segs, tables, peak_flags, tokens, probe);
 			CFHD_WAVE_SYNC();                                 // the next segment reuses the token window
 		}
+}
+
+// k_ent_count over the block lists k_fwd_yuv422_strip_blocks leaves of the level-1 bands (cfhd_kernels.h FwdBlockLists) instead of the dense bands: a segment's
+// 1024 raster coefficients lie in up to five chunks (a chunk = up to 62 blocks of 8 coefficients of one band row); of every chunk the wave takes the occupancy
+// mask, lane i the chunk's block i when it is listed and inside the segment, and the nonzero coefficients go to the token list in raster order (lanes in block
+// order: a scan of the lanes' counts).  What it reads are the nonzero blocks -- a third of the band on ordinary pictures -- and 8 bytes per chunk.
+// Same segment states and token strings as k_ent_count, by construction (the same second half).
+struct EntBlockLists { const uint4 *blocks; const unsigned long long *masks; const int16_t *coeff0; size_t masks_per_frame; };
+__global__ void __launch_bounds__(ENT_THREADS) k_ent_count_blocks(const EntSegJob *seg_jobs, EntBatchGeom geom, int total_segs, EntSegState *segs, const EntTables *tables,
+                                                                   uint32_t *peak_flags, uint32_t *tokens, int range_lo, int range_n, EntBlockLists lists)
+{
+	__shared__ uint32_t s_tok_all[ENT_WAVES][ENT_SEG];
+	const int lane = wave_lane();
+	const int wave = wave_uniform((int)(threadIdx.x >> 6));
+	const int idx0 = wave_uniform((int)blockIdx.x * ENT_WAVES + wave);
+	if (idx0 >= total_segs) return;                      // whole wave
+	const int seg = (idx0 / range_n) * geom.segs_per_frame + range_lo + idx0 % range_n;
+	int frame;
+	const EntSegJob job = ent_seg_job(seg_jobs, geom, seg, &frame);
+	uint32_t *s_tok = s_tok_all[wave];
+	const int pitch = job.pitch, cpr = (pitch + FWD_CHUNK_COLS_ENT - 1) / FWD_CHUNK_COLS_ENT;
+	const int end = job.first + ENT_SEG < job.n ? job.first + ENT_SEG : job.n;
+	const size_t band_blocks = (size_t)(job.coeffs - lists.coeff0) / 8;      // first block slot of the band (bands start on 128-byte boundaries)
+	const unsigned long long *masks = lists.masks + (size_t)frame * lists.masks_per_frame + job.mask_base;
+	int ntok = 0;                                        // wave-uniform
+	for (int pos = job.first; pos < end; ) {             // wave-uniform: chunk by chunk
+		const int r = pos / pitch, c = pos - r * pitch, k = c / FWD_CHUNK_COLS_ENT, c0 = k * FWD_CHUNK_COLS_ENT;
+		const int c1 = c0 + FWD_CHUNK_COLS_ENT < pitch ? c0 + FWD_CHUNK_COLS_ENT : pitch;
+		const int stop = r * pitch + c1 < end ? r * pitch + c1 : end;        // the segment's part of the chunk: raster [pos, stop), whole blocks
+		const unsigned long long m = masks[r * cpr + k];
+		const int col = c0 + 8 * lane;                   // lane i: block i of the chunk
+		const bool mine = lane < FWD_CHUNK_COLS_ENT / 8 && ((m >> lane) & 1ull) && col >= c && r * pitch + col < stop;
+		uint32_t w[4] = { 0u, 0u, 0u, 0u };
+		if (mine) { const cfhd_u4 v = CFHD_LDG128(&lists.blocks[band_blocks + (size_t)(r * pitch + c0) / 8 + wave_mbcnt(m)]); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
+		uint32_t cnt = 0;
+#pragma unroll
+		for (int d = 0; d < 4; d++) cnt += ((w[d] & 0xffffu) != 0u) + ((w[d] >> 16) != 0u);
+		const uint32_t incl = wave_incl_scan(cnt);
+		uint32_t p = (uint32_t)ntok + incl - cnt;
+		const uint32_t local = (uint32_t)(r * pitch + col - job.first);      // raster index of the block's first coefficient within the segment
+#pragma unroll
+		for (int d = 0; d < 4; d++) {
+			const uint32_t vl = w[d] & 0xffffu, vh = w[d] >> 16;
+			if (vl) s_tok[p++] = ((local + 2u * d) << 16) | vl;
+			if (vh) s_tok[p++] = ((local + 2u * d + 1u) << 16) | vh;
+		}
+		ntok += (int)wave_get(incl, ENT_LANES - 1);
+		pos = stop;
+	}
+	CFHD_WAVE_SYNC();
+	ent_count_tokens(seg, job, frame, ntok, lane, s_tok, segs, tables, peak_flags, tokens, 0);
 }
 
 // =============================================================================================

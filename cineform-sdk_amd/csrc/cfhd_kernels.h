@@ -133,12 +133,27 @@ __device__ __forceinline__ uint32_t bayer_plane_sample(const FwdPlaneJob &job, i
 	return (uint32_t)(uint16_t)v;
 }
 
+// Block lists (k_fwd_yuv422_strip_blocks -> k_ent_count_blocks, cfhd_entropy_kernels.h): the entropy coder wants the nonzero coefficients of the quantized
+// level-1 bands, about one in eleven.  Instead of storing those bands densely and having k_ent_count read all of them back (4.2 GB per 512 1080p frames), the
+// strip kernel -- which holds every band row in registers as blocks of 8 coefficients per lane -- stores only the blocks that are not all zero, compacted per
+// (band row, wave) = "chunk" of FWD_CHUNK_BLOCKS blocks, plus the chunk's 64-bit occupancy mask.  blocks[]: one 16-byte slot per block of the pyramid, indexed by
+// (element offset of the chunk's first coefficient) / 8 + rank of the block among the chunk's nonzero blocks; masks[]: one word per chunk.
+enum { FWD_CHUNK_BLOCKS = 62, FWD_CHUNK_COLS = FWD_CHUNK_BLOCKS * 8 };
+struct FwdBlockLists {
+	uint4 *blocks;                          // null: off (the bands are stored densely only)
+	unsigned long long *masks;              // this frame's chunk masks
+	const int16_t *base;                    // this frame's pyramid: out[c][b] - base = element offset of a band
+	int mask_base[3][4];                    // first chunk of band (c, b) in masks[] (chunks by band row, then by position in the row)
+	int reserved[2];
+};
+
 struct FwdYuvJob {
 	const uint8_t *in; int in_pitch;        // bytes
 	int width, height, display_height;      // luma samples; rows >= display_height read as 0x80
 	int uyvy, shift;
 	int16_t *out[3][4]; int out_pitch[3];   // channel order Y, V, U (reference order)
 	QuantParam q[3][4];
+	FwdBlockLists lists;
 };
 
 struct InvPlaneJob {
@@ -198,6 +213,7 @@ struct FwdFrameJob {                        // k_fwd_frame_yuv422: interlaced le
 	int uyvy, shift;
 	int16_t *out[3][4]; int out_pitch[3];   // Y, V, U: LL, LH, HL, HH (one band row per pair of picture rows)
 	QuantParam q[3][4];                     // q[c][2] is the difference-coded HL band: its midpoint is divisor / prequant without the "-1" (spatial.c:5360-5363)
+	FwdBlockLists lists;                    // (unused: the two level-1 jobs share one table)
 };
 
 struct BayerJob {                           // k_unpack_byr4: 16-bit Bayer mosaic -> component planes G, R-G, B-G, G1-G2
@@ -1318,8 +1334,10 @@ __device__ __forceinline__ void strip_fwd_push(FwdStrip &st, const FwdYuvJob &jo
 	if (luma && prefetch && FWD_LATE_LOADS == 1) strip_fwd_fetch(st, job, in, y + 2);
 }
 
-template <int ROWS_PER_STRIP>
-__device__ __forceinline__ void fwd_yuv422_strip(const FwdYuvJob *jobs)
+// BLOCKS: the quantized bands leave as block lists (FwdBlockLists); `dense`: and as dense rows of the pyramid as well (whatever reads the pyramid afterwards --
+// the host writer, a download of the coefficients -- needs them; the GPU entropy stage alone does not).
+template <int ROWS_PER_STRIP, bool BLOCKS = false>
+__device__ __forceinline__ void fwd_yuv422_strip(const FwdYuvJob *jobs, bool dense_too = true)
 {
 	const TileId tile = xcd_tile();
 	__shared__ FwdYuvJob s_job;
@@ -1352,6 +1370,10 @@ __device__ __forceinline__ void fwd_yuv422_strip(const FwdYuvJob *jobs)
 	const uint32_t usel = (uint32_t)ub | 0x0c00u | ((uint32_t)(4 + ub) << 16) | 0x0c000000u;   // (byte ub of a0, 0, byte ub of a1, 0)
 	const uint32_t vsel = (uint32_t)vb | 0x0c00u | ((uint32_t)(4 + vb) << 16) | 0x0c000000u;
 	const uint8_t *in = job.in + 32 * (size_t)blk;
+	// block lists: this wave's chunk of every band row = the blocks its lanes 1 .. SLUMA_STEP store (chunk `base / FWD_CHUNK_BLOCKS` of the row)
+	static_assert(SLUMA_STEP == FWD_CHUNK_BLOCKS, "a chunk is what one wave stores of a band row");
+	const int chunks_per_row = BLOCKS ? (nblk + FWD_CHUNK_BLOCKS - 1) / FWD_CHUNK_BLOCKS : 0, chunk = BLOCKS ? base / FWD_CHUNK_BLOCKS : 0;
+	const bool dense = !BLOCKS || dense_too;
 	FwdStrip st;
 	int wtop = window_first_row(r0, HH, H);
 	const int lastrow = window_first_row(r1 - 1, HH, H) + 5;     // last picture row this strip reads
@@ -1399,9 +1421,22 @@ __device__ __forceinline__ void fwd_yuv422_strip(const FwdYuvJob *jobs)
 			o[0][d] = ll; o[1][d] = pk_quantize(lh, q_lh);                              // the lowpass band is never quantized (quantize.c:3216)
 			o[2][d] = pk_quantize(hl, q_hl); o[3][d] = pk_quantize(hh, q_hh);
 		}
+		if (BLOCKS) {
+			// the quantized bands as block lists: a lane's block goes out only when it holds a nonzero coefficient, to the slot its rank among the
+			// chunk's nonzero blocks gives it (lanes in block order: a ballot + v_mbcnt), and lane 0 leaves the chunk's occupancy mask
+#pragma unroll
+			for (int b = 1; b < 4; b++) {
+				const bool nz = stores && (o[b][0] | o[b][1] | o[b][2] | o[b][3]) != 0u;
+				const unsigned long long m = __ballot(nz);
+				const size_t row0 = (size_t)(job.out[comp][b] - job.lists.base) + (size_t)r * job.out_pitch[comp];      // element offset of the band row (a multiple of 8)
+				if (nz) { uint4 v; v.x = o[b][0]; v.y = o[b][1]; v.z = o[b][2]; v.w = o[b][3]; job.lists.blocks[row0 / 8 + (size_t)(FWD_CHUNK_BLOCKS * chunk) + wave_mbcnt(m)] = v; }      // (lane 0 never stores: the rank among lanes 1 ..)
+				if (lane == 0 && chunk < chunks_per_row) job.lists.masks[job.lists.mask_base[comp][b] + r * chunks_per_row + chunk] = m >> 1;       // bit i: block i of the chunk (lane i + 1); a wave beyond the last block of the row has no chunk
+			}
+		}
 		if (stores) {
 #pragma unroll
 			for (int b = 0; b < 4; b++) {
+				if (b && !dense) continue;
 				uint4 v; v.x = o[b][0]; v.y = o[b][1]; v.z = o[b][2]; v.w = o[b][3];
 				*(uint4 *)(job.out[comp][b] + (size_t)r * job.out_pitch[comp] + SBLK * blk) = v;
 			}
@@ -1410,6 +1445,7 @@ __device__ __forceinline__ void fwd_yuv422_strip(const FwdYuvJob *jobs)
 #undef CFHD_PUSH
 }
 __global__ void __launch_bounds__(NTHREADS) k_fwd_yuv422_strip(const FwdYuvJob *jobs) { fwd_yuv422_strip<SRF>(jobs); }
+__global__ void __launch_bounds__(NTHREADS) k_fwd_yuv422_strip_blocks(const FwdYuvJob *jobs, int dense_too) { fwd_yuv422_strip<SRF, true>(jobs, dense_too != 0); }
 
 // =============================================================================================
 // k_inv_plane_strip / k_fwd_plane_strip: levels 2 and 3 (int16 planes on both sides) in the register-strip organisation.  These planes

@@ -1455,7 +1455,7 @@ def _batched_yuy2_round_trip_equals_reference(w, h, n, nuniq, expect=None):
 def test_batched_round_trip_at_bench_sizes_equals_reference(w, h, n, nuniq):
     """The batch sizes at which the library picks the kernels bench.py times by itself (>= 32 1080p-equivalents per launch: register strips
     at level 1; the plane levels switch at 160)."""
-    _batched_yuy2_round_trip_equals_reference(w, h, n, nuniq, expect={0: "k_fwd_yuv422_strip", 3: "k_inv_yuv422_strip"})
+    _batched_yuy2_round_trip_equals_reference(w, h, n, nuniq, expect={0: "k_fwd_yuv422_strip_blocks", 3: "k_inv_yuv422_strip"})
 
 
 @pytest.mark.parametrize("w,h,n", [(1920, 1080, 3), (3840, 2160, 2), (2048, 600, 3), (1952, 250, 2)])
@@ -1467,7 +1467,7 @@ def test_yuv422_strip_kernels_equal_reference(w, h, n):
     old = {k: os.environ.get(k) for k in keys}
     for k in keys: os.environ[k] = "strip"
     try:
-        expect = {0: "k_fwd_yuv422_strip", 3: "k_inv_yuv422_strip"}
+        expect = {0: "k_fwd_yuv422_strip_blocks", 3: "k_inv_yuv422_strip"}      # (level-1 bands as block lists for k_ent_count_blocks; CFHD_AMD_BLOCKS=0: dense bands + k_ent_count)
         if w in (1920, 2048): expect.update({1: "k_fwd_plane_strip", 2: "k_fwd_plane_strip", 4: "k_inv_plane_strip", 5: "k_inv_plane_strip"})
         _batched_yuy2_round_trip_equals_reference(w, h, n, n, expect=expect)
     finally:
