@@ -586,7 +586,8 @@ int EncodeBatch::launch_forward(bool coeffs_needed)
 	} else if (strip_forward()) {
 		const int nseg = (plan_.width / 16 + dev::SSEG - 1) / dev::SSEG;      // segments of 124 luma blocks (1984 pixels)
 		const dim3 grid(nseg, (plan_.height / 2 + dev::SRF - 1) / dev::SRF, act);
-		if (blocks) dev::k_fwd_yuv422_strip_blocks<<<grid, dev::NTHREADS, 0, st>>>(j.yuv, coeffs_needed || dense_env);
+		if (blocks && (coeffs_needed || dense_env)) dev::k_fwd_yuv422_strip_blocks_dense<<<grid, dev::NTHREADS, 0, st>>>(j.yuv);
+		else if (blocks) dev::k_fwd_yuv422_strip_blocks<<<grid, dev::NTHREADS, 0, st>>>(j.yuv);
 		else dev::k_fwd_yuv422_strip<<<grid, dev::NTHREADS, 0, st>>>(j.yuv);
 	} else {
 		dim3 grid((plan_.width / 2 + dev::TW - 1) / dev::TW, (plan_.height / 2 + dev::TH - 1) / dev::TH, act);

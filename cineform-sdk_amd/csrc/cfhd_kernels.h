@@ -1334,10 +1334,10 @@ __device__ __forceinline__ void strip_fwd_push(FwdStrip &st, const FwdYuvJob &jo
 	if (luma && prefetch && FWD_LATE_LOADS == 1) strip_fwd_fetch(st, job, in, y + 2);
 }
 
-// BLOCKS: the quantized bands leave as block lists (FwdBlockLists); `dense`: and as dense rows of the pyramid as well (whatever reads the pyramid afterwards --
+// BLOCKS: the quantized bands leave as block lists (FwdBlockLists); DENSE: and as dense rows of the pyramid as well (whatever reads the pyramid afterwards --
 // the host writer, a download of the coefficients -- needs them; the GPU entropy stage alone does not).
-template <int ROWS_PER_STRIP, bool BLOCKS = false>
-__device__ __forceinline__ void fwd_yuv422_strip(const FwdYuvJob *jobs, bool dense_too = true)
+template <int ROWS_PER_STRIP, bool BLOCKS = false, bool DENSE = true>
+__device__ __forceinline__ void fwd_yuv422_strip(const FwdYuvJob *jobs)
 {
 	const TileId tile = xcd_tile();
 	__shared__ FwdYuvJob s_job;
@@ -1373,7 +1373,17 @@ __device__ __forceinline__ void fwd_yuv422_strip(const FwdYuvJob *jobs, bool den
 	// block lists: this wave's chunk of every band row = the blocks its lanes 1 .. SLUMA_STEP store (chunk `base / FWD_CHUNK_BLOCKS` of the row)
 	static_assert(SLUMA_STEP == FWD_CHUNK_BLOCKS, "a chunk is what one wave stores of a band row");
 	const int chunks_per_row = BLOCKS ? (nblk + FWD_CHUNK_BLOCKS - 1) / FWD_CHUNK_BLOCKS : 0, chunk = BLOCKS ? base / FWD_CHUNK_BLOCKS : 0;
-	const bool dense = !BLOCKS || dense_too;
+	// per band, wave-uniform (scalar registers; hoisted: the barrier inside the row loop keeps the compiler from keeping LDS job fields across rows): the slot of the
+	// chunk's first block in band row 0 and the chunk's mask in band row 0
+	uint4 *slot0[3]; unsigned long long *mask0[3];
+	const int pitch8 = wave_uniform(job.out_pitch[comp] >> 3);
+	if (BLOCKS) {
+#pragma unroll
+		for (int b = 1; b < 4; b++) {
+			slot0[b - 1] = wave_uniform_ptr(job.lists.blocks + (size_t)(job.out[comp][b] - job.lists.base) / 8 + (size_t)(FWD_CHUNK_BLOCKS * chunk));
+			mask0[b - 1] = wave_uniform_ptr(job.lists.masks + job.lists.mask_base[comp][b] + chunk);
+		}
+	}
 	FwdStrip st;
 	int wtop = window_first_row(r0, HH, H);
 	const int lastrow = window_first_row(r1 - 1, HH, H) + 5;     // last picture row this strip reads
@@ -1428,15 +1438,15 @@ __device__ __forceinline__ void fwd_yuv422_strip(const FwdYuvJob *jobs, bool den
 			for (int b = 1; b < 4; b++) {
 				const bool nz = stores && (o[b][0] | o[b][1] | o[b][2] | o[b][3]) != 0u;
 				const unsigned long long m = __ballot(nz);
-				const size_t row0 = (size_t)(job.out[comp][b] - job.lists.base) + (size_t)r * job.out_pitch[comp];      // element offset of the band row (a multiple of 8)
-				if (nz) { uint4 v; v.x = o[b][0]; v.y = o[b][1]; v.z = o[b][2]; v.w = o[b][3]; job.lists.blocks[row0 / 8 + (size_t)(FWD_CHUNK_BLOCKS * chunk) + wave_mbcnt(m)] = v; }      // (lane 0 never stores: the rank among lanes 1 ..)
-				if (lane == 0 && chunk < chunks_per_row) job.lists.masks[job.lists.mask_base[comp][b] + r * chunks_per_row + chunk] = m >> 1;       // bit i: block i of the chunk (lane i + 1); a wave beyond the last block of the row has no chunk
+				uint4 *rowslots = wave_uniform_ptr(slot0[b - 1] + (size_t)(r * pitch8));      // (scalar base + one 32-bit lane offset)
+				if (nz) { uint4 v; v.x = o[b][0]; v.y = o[b][1]; v.z = o[b][2]; v.w = o[b][3]; rowslots[wave_mbcnt(m)] = v; }      // (lane 0 never stores: the rank among lanes 1 ..)
+				if (lane == 0 && chunk < chunks_per_row) mask0[b - 1][r * chunks_per_row] = m >> 1;       // bit i: block i of the chunk (lane i + 1); a wave beyond the last block of the row has no chunk
 			}
 		}
 		if (stores) {
 #pragma unroll
 			for (int b = 0; b < 4; b++) {
-				if (b && !dense) continue;
+				if (b && BLOCKS && !DENSE) continue;
 				uint4 v; v.x = o[b][0]; v.y = o[b][1]; v.z = o[b][2]; v.w = o[b][3];
 				*(uint4 *)(job.out[comp][b] + (size_t)r * job.out_pitch[comp] + SBLK * blk) = v;
 			}
@@ -1445,7 +1455,8 @@ __device__ __forceinline__ void fwd_yuv422_strip(const FwdYuvJob *jobs, bool den
 #undef CFHD_PUSH
 }
 __global__ void __launch_bounds__(NTHREADS) k_fwd_yuv422_strip(const FwdYuvJob *jobs) { fwd_yuv422_strip<SRF>(jobs); }
-__global__ void __launch_bounds__(NTHREADS) k_fwd_yuv422_strip_blocks(const FwdYuvJob *jobs, int dense_too) { fwd_yuv422_strip<SRF, true>(jobs, dense_too != 0); }
+__global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) k_fwd_yuv422_strip_blocks(const FwdYuvJob *jobs) { fwd_yuv422_strip<SRF, true, false>(jobs); }
+__global__ void __launch_bounds__(NTHREADS) k_fwd_yuv422_strip_blocks_dense(const FwdYuvJob *jobs) { fwd_yuv422_strip<SRF, true, true>(jobs); }
 
 // =============================================================================================
 // k_inv_plane_strip / k_fwd_plane_strip: levels 2 and 3 (int16 planes on both sides) in the register-strip organisation.  These planes
