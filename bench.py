@@ -173,6 +173,9 @@ def c_abi_rates(frames, pitch, W, H, seconds=1.5, registered=False, decoders=8, 
     return json.loads(out.stdout.strip().splitlines()[-1])
 
 
+DEFAULT_DEPTH = 1
+
+
 def normalise_counters(sample):
     """Frame number (tag 69, optional = negated) and the unique frame number tuple count per encoder call: set both to frame 1's."""
     b = bytearray(sample)
@@ -183,51 +186,55 @@ def normalise_counters(sample):
     return bytes(b)
 
 
-def parity_check(L, b, frames, pitch, W, H, rank, wl):
-    """What was timed is what the reference produces: sample 0 of the last step (frame / unique-frame counters set back to the first frame's)
-    against the reference encoder (its golden hash where tests/golden holds one: rank 0 encodes Qbist seed 10, else the reference encoder run
-    here on the same frame), and decoded frame 0 against the exact integer reconstruction of its own sample (oracle, test infrastructure,
-    used here as the checker only): inside its dither interval for 8-bit 4:2:2 output, word for word for 16-bit output."""
+def parity_check(L, b, frames, pitch, W, H, rank, wl, batch, nuniq):
+    """What was timed is what the reference produces -- checked on frames spread over the batch of the last step (eight of them at 1080p, fewer for the larger
+    formats: the checker is scalar C): every checked sample (frame / unique-frame counters set back to the first frame's) against the reference encoder run here on
+    the same frame (sample 0 of the 1080p YUY2 workload also against the golden hash in tests/golden), and the decoded frame against the exact integer reconstruction
+    of its own sample (oracle, test infrastructure, used here as the checker only): inside its dither interval for 8-bit 4:2:2 output, word for word for 16-bit output."""
     import numpy as np
     import cfhd_testlib as T
     fmt = getattr(T, "PIX_" + wl["fmt"].upper())
-    p = ctypes.c_void_p(); sz = ctypes.c_size_t()
-    assert L.cfhd_amd_batch_get_sample(b, 0, ctypes.byref(p), ctypes.byref(sz)) == 0
-    sample = ctypes.string_at(p, sz.value)
-    out = {}
-    if rank == 0 and (W, H) == (1920, 1080) and wl["fmt"] == "YUY2" and not wl["flags"]:
-        g = json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))
-        digest = hashlib.sha256(T.mask_volatile_metadata(normalise_counters(sample))).hexdigest()
-        assert len(sample) == g["qbist_seed10_frame1_size"] and digest == g["qbist_seed10_frame1_masked_sha256"], "sample 0 differs from the reference encoder's golden sample"
-        out["sample0_masked_sha256"] = digest
-    else:
-        ref_sample = T.ref_encode_frames([frames[0]], pitch, W, H, fmt, encoded=wl["enc"], flags=wl["flags"])[0]
+    nchk = 8 if W * H <= 1920 * 1080 else (2 if W * H <= 3840 * 2160 else 1)
+    checked = sorted({(k * batch) // nchk for k in range(nchk)})
+    out = {"frames_checked": checked}
+    bpp = wl["bpp"]
+    psnr = []
+    for i in checked:
+        frame = frames[i % nuniq]
+        p = ctypes.c_void_p(); sz = ctypes.c_size_t()
+        assert L.cfhd_amd_batch_get_sample(b, i, ctypes.byref(p), ctypes.byref(sz)) == 0
+        sample = ctypes.string_at(p, sz.value)
+        if i == 0 and rank == 0 and (W, H) == (1920, 1080) and wl["fmt"] == "YUY2" and not wl["flags"]:
+            g = json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))
+            digest = hashlib.sha256(T.mask_volatile_metadata(normalise_counters(sample))).hexdigest()
+            assert len(sample) == g["qbist_seed10_frame1_size"] and digest == g["qbist_seed10_frame1_masked_sha256"], "sample 0 differs from the reference encoder's golden sample"
+            out["sample0_masked_sha256"] = digest
+        ref_sample = T.ref_encode_frames([frame], pitch, W, H, fmt, encoded=wl["enc"], flags=wl["flags"])[0]
         ma, mb = T.mask_volatile_metadata(normalise_counters(sample)), T.mask_volatile_metadata(normalise_counters(ref_sample))
         if ma != mb:
             first = next((k for k in range(min(len(ma), len(mb))) if ma[k] != mb[k]), -1)
-            raise AssertionError("sample 0 differs from the reference encoder's: %d vs %d bytes, first difference at byte %d" % (len(ma), len(mb), first))
-        out["sample0_equals_reference_encoder"] = True
-    if wl["mode"] != 0:
-        return out
-    bpp = wl["bpp"]
-    img = np.zeros(H * W * bpp, dtype=np.uint8)
-    assert L.cfhd_amd_batch_download_output(b, 0, img.ctypes.data_as(ctypes.c_void_p), W * bpp) == 0
-    if wl["fmt"] == "YUY2":
-        img = img.reshape(H, W * 2)
-        plan = T.Plan(W, H, progressive=0 if wl["flags"] & 1 else 1)
-        deq = T.host_decode_pyramid(sample, plan)
-        inverse = T.oracle_inverse_interlaced_yuv422 if wl["flags"] & 1 else T.oracle_inverse_yuv422
-        lo = inverse(plan, deq, 0)[:H]; hi = inverse(plan, deq, 1)[:H]
-        assert ((img == lo) | (img == hi)).all(), "decoded frame 0 leaves the dither interval of the exact reconstruction"
-        out["decoded_frame0_in_dither_interval"] = True
-        out["psnr_db"] = round(float(T.psnr_yuy2(img, frames[0].reshape(H, pitch)[:, : W * 2])), 2)
-    else:
-        b64a = wl["fmt"] == "b64a"
-        plan = T.Plan(W, H, pixkind=T.PIXKIND[wl["fmt"]], enc=T.ENC["4444" if b64a else "444"])
-        exact = T.oracle_inverse_rgb48(plan, T.host_decode_pyramid(sample, plan), b64a=b64a)[:H]
-        got = np.frombuffer(img.tobytes(), np.uint16).reshape(H, W * bpp // 2)
-        assert np.array_equal(got, exact), "decoded frame 0 differs from the exact reconstruction"
-        out["decoded_frame0_equals_exact_reconstruction"] = True
+            raise AssertionError("sample %d differs from the reference encoder's: %d vs %d bytes, first difference at byte %d" % (i, len(ma), len(mb), first))
+        if wl["mode"] != 0: continue
+        img = np.zeros(H * W * bpp, dtype=np.uint8)
+        assert L.cfhd_amd_batch_download_output(b, i, img.ctypes.data_as(ctypes.c_void_p), W * bpp) == 0
+        if wl["fmt"] == "YUY2":
+            img = img.reshape(H, W * 2)
+            plan = T.Plan(W, H, progressive=0 if wl["flags"] & 1 else 1)
+            deq = T.host_decode_pyramid(sample, plan)
+            inverse = T.oracle_inverse_interlaced_yuv422 if wl["flags"] & 1 else T.oracle_inverse_yuv422
+            lo = inverse(plan, deq, 0)[:H]; hi = inverse(plan, deq, 1)[:H]
+            assert ((img == lo) | (img == hi)).all(), "decoded frame %d leaves the dither interval of the exact reconstruction" % i
+            psnr.append(round(float(T.psnr_yuy2(img, frame.reshape(H, pitch)[:, : W * 2])), 2))
+        else:
+            b64a = wl["fmt"] == "b64a"
+            plan = T.Plan(W, H, pixkind=T.PIXKIND[wl["fmt"]], enc=T.ENC["4444" if b64a else "444"])
+            exact = T.oracle_inverse_rgb48(plan, T.host_decode_pyramid(sample, plan), b64a=b64a)[:H]
+            got = np.frombuffer(img.tobytes(), np.uint16).reshape(H, W * bpp // 2)
+            assert np.array_equal(got, exact), "decoded frame %d differs from the exact reconstruction" % i
+    out["samples_equal_reference_encoder"] = True
+    if wl["mode"] == 0:
+        if wl["fmt"] == "YUY2": out["decoded_frames_in_dither_interval"] = True; out["psnr_db"] = psnr
+        else: out["decoded_frames_equal_exact_reconstruction"] = True
     return out
 
 
@@ -244,6 +251,9 @@ def batch_api():
         L.cfhd_amd_batch_upload.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
         L.cfhd_amd_batch_roundtrip.restype = ctypes.c_longlong
         L.cfhd_amd_batch_roundtrip.argtypes = [ctypes.c_void_p]
+        L.cfhd_amd_batch_submit.argtypes = [ctypes.c_void_p]
+        L.cfhd_amd_batch_wait.restype = ctypes.c_longlong
+        L.cfhd_amd_batch_wait.argtypes = [ctypes.c_void_p]
         L.cfhd_amd_batch_kernel_ms.restype = ctypes.c_float
         L.cfhd_amd_batch_kernel_ms.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.cfhd_amd_batch_stage_seconds.restype = ctypes.c_double
@@ -257,9 +267,11 @@ def batch_api():
     return L
 
 
-def measure(workload, steps, warmup, batch, unique, threads, rank, world, barrier, reduce_max):
+def measure(workload, steps, warmup, batch, unique, threads, rank, world, barrier, reduce_max, depth=1):
     """One workload through the batched device-resident path: frames generated and uploaded, `warmup` untimed steps, `steps` timed ones between
-    barriers, parity check of what was timed on rank 0.  Returns (line fields of this workload, frames, pitch)."""
+    barriers, parity check of what was timed on rank 0.  Returns (line fields of this workload, frames, pitch).
+    depth: batches in flight (the frame queue, cfhd_amd_batch_submit / _wait): step k + 1 is submitted while step k is still on the GPU; every step is still one
+    complete pass over one batch of `batch` frames, and all `steps` of them start and finish inside the timed region."""
     import numpy as np
     import cfhd_testlib as T
     wl = dict(WORKLOADS[workload])
@@ -276,13 +288,19 @@ def measure(workload, steps, warmup, batch, unique, threads, rank, world, barrie
     else:
         frames, pitch = T.qbist_frames(10 + rank, nuniq, W, H, fmt, alpha=1 if wl["fmt"] == "b64a" else 0)   # Qbist seed 10 (BASELINE configs), QBIST_UNIQUE frames
         data = "synthetic Qbist %dx%d %s (seed %d, %d unique frames per rank, cycled through the batch)" % (W, H, wl["fmt"], 10, nuniq)
-    b = L.cfhd_amd_batch_create_ex(W, H, fmt, wl["enc"], wl["flags"], T.QUALITY_FILMSCAN1, batch, threads, wl["mode"])
-    if not b:
-        raise SystemExit("cfhd_amd_batch_create_ex failed: " + T.amd_last_error())
-    for i in range(batch):
-        assert L.cfhd_amd_batch_upload(b, i, frames[i % nuniq].ctypes.data_as(ctypes.c_void_p), pitch) == 0
+    depth = max(1, min(depth, steps))
+    slots = []
+    for _ in range(depth):
+        b = L.cfhd_amd_batch_create_ex(W, H, fmt, wl["enc"], wl["flags"], T.QUALITY_FILMSCAN1, batch, threads, wl["mode"])
+        if not b:
+            raise SystemExit("cfhd_amd_batch_create_ex failed: " + T.amd_last_error())
+        for i in range(batch):
+            assert L.cfhd_amd_batch_upload(b, i, frames[i % nuniq].ctypes.data_as(ctypes.c_void_p), pitch) == 0
+        slots.append(b)
+    b = slots[0]
     for _ in range(warmup):
-        assert L.cfhd_amd_batch_roundtrip(b) > 0, T.amd_last_error()
+        for q in slots: assert L.cfhd_amd_batch_submit(q) == 0
+        for q in slots: assert L.cfhd_amd_batch_wait(q) > 0, T.amd_last_error()
     # kernel names as they appear in a rocprofv3 trace of this run (the library picks the register-strip or the LDS-tiled shape by geometry and batch size)
     kname = lambda which: L.cfhd_amd_batch_kernel_name(b, which).decode()
     FWD1, PF2, PF3 = kname(0), kname(1) + "[L2]", kname(2) + "[L3]"
@@ -299,14 +317,22 @@ def measure(workload, steps, warmup, batch, unique, threads, rank, world, barrie
     kms = {name: 0.0 for name, _ in KERNELS}; stage = [0.0] * 4; total_bytes = 0
     barrier()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        n = L.cfhd_amd_batch_roundtrip(b)
+    def collect(q):
+        nonlocal total_bytes
+        n = L.cfhd_amd_batch_wait(q)
         assert n > 0, T.amd_last_error()
         total_bytes = n
         for name, which in KERNELS:                    # HIP events recorded around each launch on the stream it runs on
-            kms[name] += L.cfhd_amd_batch_kernel_ms(b, which)
+            kms[name] += L.cfhd_amd_batch_kernel_ms(q, which)
         for k in range(4):
-            stage[k] += L.cfhd_amd_batch_stage_seconds(b, k)
+            stage[k] += L.cfhd_amd_batch_stage_seconds(q, k)
+    for s in range(steps):                             # the frame queue: at most `depth` steps in flight, collected in submission order
+        q = slots[s % depth]
+        if s >= depth: collect(q)
+        assert L.cfhd_amd_batch_submit(q) == 0
+    for s in range(steps - depth, steps):
+        collect(slots[s % depth])
+    b = slots[(steps - 1) % depth]                      # the batch that ran the last step: what the parity check looks at
     barrier()
     elapsed = reduce_max(time.perf_counter() - t0)
     import importlib.util
@@ -316,7 +342,7 @@ def measure(workload, steps, warmup, batch, unique, threads, rank, world, barrie
     assert shards.shard_bounds(batch * world, rank, world) == (rank * batch, (rank + 1) * batch)
     fps = shards.whole_job_rate(batch * steps, world, elapsed)
 
-    parity = parity_check(L, b, frames, pitch, W, H, rank, wl) if rank == 0 and not probing else None
+    parity = parity_check(L, b, frames, pitch, W, H, rank, wl, batch, nuniq) if rank == 0 and not probing else None
     dx_stats = None
     if os.environ.get("CFHD_AMD_DX_STATS"):               # convergence counters of the chunk-indexed entropy decoder (diagnostics, slows the kernels a little)
         st = (ctypes.c_uint32 * 16)()
@@ -364,6 +390,7 @@ def measure(workload, steps, warmup, batch, unique, threads, rank, world, barrie
             "warmup": warmup, "ms_per_step": round(1000.0 * elapsed / steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int16", "data": data,
             "config": {"workload": "%dx%d %s FILMSCAN1 %s, frames resident in HBM" % (W, H, wl["label"], "encode+decode round trip" if wl["mode"] == 0 else "encode"), "frames_per_step_per_gpu": batch,
+                       "steps_in_flight": depth,
                        "entropy_stage": ("host, %d threads" % threads) if ent == "host" else "gpu (k_ent_* / k_dec_* kernels)",
                        "sample_handoff": "n/a" if ent == "host" else ("decoder reads the samples in HBM (k_dec_parse); host copy of every sample downloaded inside the step" if handoff != "host" else "samples cross PCIe to the host parser and back"),
                        "sample_bytes_per_frame": int(sample_bytes),
@@ -379,7 +406,7 @@ def measure(workload, steps, warmup, batch, unique, threads, rank, world, barrie
                          "algorithmic_bytes_per_launch": int(algo[dom] * batch),
                          "other_kernels_gbs": {k: round(algo[k] * batch / (kms[k] * 1e-3) / 1e9, 1) for k in algo if kms[k] > 0 and k != dom}},
         }
-    L.cfhd_amd_batch_destroy(b)
+    for q in slots: L.cfhd_amd_batch_destroy(q)
     return line, frames, pitch
 
 
@@ -395,6 +422,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c-abi", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the short runs of the other BASELINE configs behind the timed region")
+    ap.add_argument("--depth", type=int, default=DEFAULT_DEPTH, help="steps in flight (frame queue of batch objects: cfhd_amd_batch_submit / _wait); 1 = one synchronous pass after the other")
     args = ap.parse_args()
 
     wl = WORKLOADS[args.workload]
@@ -431,7 +459,7 @@ def main():
 
     cores = os.cpu_count() or 1
     threads = args.threads or max(1, cores // world)
-    line, frames, pitch = measure(args.workload, args.steps, args.warmup, batch, args.unique, threads, rank, world, barrier, reduce_max)
+    line, frames, pitch = measure(args.workload, args.steps, args.warmup, batch, args.unique, threads, rank, world, barrier, reduce_max, depth=args.depth)
     if rank == 0:
         if world == 1 and args.workload == "1080p" and not args.no_other_workloads:
             # the other BASELINE configs (and north_star's 3840x2160 frames) through the same path, a few steps each, behind the timed region of the

@@ -41,6 +41,9 @@ struct cfhd_amd_batch {
 	bool gpu_entropy = true;
 	bool device_handoff = true;        // the decoder reads the samples where the encoder left them in HBM (k_dec_parse); the host copy arrives beside it
 	double t_fwd = 0, t_entropy_enc = 0, t_entropy_dec = 0, t_inv = 0;   // wall seconds of the last round trip
+	// the frame queue (cfhd_amd_batch_submit / _wait): the pass in flight runs on a thread of its own, on the batch's own HIP streams
+	std::thread worker; bool in_flight = false; long long pending = -1;
+	~cfhd_amd_batch() { if (worker.joinable()) worker.join(); }
 };
 
 namespace {
@@ -244,6 +247,27 @@ long long cfhd_amd_batch_roundtrip(cfhd_amd_batch *b)
 	long long total = 0;
 	for (int i = 0; i < b->n; i++) total += (long long)b->sample_size[i];
 	return total;
+}
+
+// The streaming form (north_star: "the EncoderPool / AsyncEncoder thread pool is replaced by a HIP-stream frame queue"; semantics of the reference's queue:
+// EncoderSDK/EncoderPool.cpp:239-380 -- submit returns at once, results are collected in submission order).  A batch object is one slot of the queue: submit starts
+// its pass (all launches asynchronous on the batch's own streams, driven by a thread of its own), wait collects it.  Several batch objects in flight overlap: while
+// one pass is in its instruction-bound entropy kernels another's bandwidth-bound transforms run beside them, which a single synchronous pass cannot have
+// (tools/dual_batch.py).  The caller keeps FIFO order by waiting in the order it submitted.
+int cfhd_amd_batch_submit(cfhd_amd_batch *b)
+{
+	if (!b || b->in_flight) return -1;
+	b->in_flight = true; b->pending = -1;
+	b->worker = std::thread([b] { b->pending = cfhd_amd_batch_roundtrip(b); });
+	return 0;
+}
+
+long long cfhd_amd_batch_wait(cfhd_amd_batch *b)
+{
+	if (!b || !b->in_flight) return -1;
+	b->worker.join();
+	b->in_flight = false;
+	return b->pending;
 }
 
 // which: 0..2 forward level launches (0 = k_fwd_yuv422), 3..5 inverse level launches (3 = k_inv_yuv422), 6 forward total, 7 inverse total,

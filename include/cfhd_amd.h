@@ -142,6 +142,10 @@ cfhd_amd_batch *cfhd_amd_batch_create(int width, int height, uint32_t pixel_form
 void cfhd_amd_batch_destroy(cfhd_amd_batch *batch);
 int  cfhd_amd_batch_upload(cfhd_amd_batch *batch, int frame, const void *pixels, int pitch);   /* host frame -> HBM (outside any timed region) */
 long long cfhd_amd_batch_roundtrip(cfhd_amd_batch *batch);                                     /* one pass; total sample bytes, or < 0 */
+/* The same pass as a slot of a frame queue (replaces the reference's EncoderPool job queue, EncoderSDK/EncoderPool.cpp:239-380): submit returns at once, wait
+ * returns what cfhd_amd_batch_roundtrip would have; batches in flight at the same time overlap on the GPU.  One pass per batch at a time. */
+int  cfhd_amd_batch_submit(cfhd_amd_batch *batch);
+long long cfhd_amd_batch_wait(cfhd_amd_batch *batch);
 int  cfhd_amd_batch_get_sample(cfhd_amd_batch *batch, int frame, const void **data, size_t *size);
 int  cfhd_amd_batch_download_output(cfhd_amd_batch *batch, int frame, void *out, int pitch);
 float cfhd_amd_batch_kernel_ms(cfhd_amd_batch *batch, int which);                              /* HIP-event time of the kernels of the last pass */
