@@ -173,7 +173,7 @@ def c_abi_rates(frames, pitch, W, H, seconds=1.5, registered=False, decoders=8, 
     return json.loads(out.stdout.strip().splitlines()[-1])
 
 
-DEFAULT_DEPTH = 1
+DEFAULT_DEPTH = 3      # steps in flight in the timed region (measured on the MI355X, gpurun_out/r04c: 47.5 / 50.1 / 52.5 / 52.5 k fps at depth 1 / 2 / 3 / 4)
 
 
 def normalise_counters(sample):
@@ -335,6 +335,16 @@ def measure(workload, steps, warmup, batch, unique, threads, rank, world, barrie
     b = slots[(steps - 1) % depth]                      # the batch that ran the last step: what the parity check looks at
     barrier()
     elapsed = reduce_max(time.perf_counter() - t0)
+    # With several steps in flight the kernels of concurrent steps share the GPU, and the HIP events around a launch then time that sharing, not the kernel (as-run
+    # times: config.kernel_ms_per_step).  The roofline of a kernel is a statement about the kernel: right behind the timed region the same pass runs ALONE_STEPS more
+    # times one at a time on the batch of the last step, with the same events -- those launch times feed `roofline` (and agree with a rocprofv3 trace of --depth 1).
+    kms_alone = None
+    if depth > 1:
+        ALONE_STEPS = 3
+        kms_alone = {name: 0.0 for name, _ in KERNELS}
+        for _ in range(ALONE_STEPS):
+            assert L.cfhd_amd_batch_roundtrip(b) > 0, T.amd_last_error()
+            for name, which in KERNELS: kms_alone[name] += L.cfhd_amd_batch_kernel_ms(b, which) / ALONE_STEPS
     import importlib.util
     spec = importlib.util.spec_from_file_location("frame_shards", os.path.join(ROOT, "cineform-sdk_amd", "host", "frame_shards.py"))
     shards = importlib.util.module_from_spec(spec); spec.loader.exec_module(shards)
@@ -351,7 +361,8 @@ def measure(workload, steps, warmup, batch, unique, threads, rank, world, barrie
             dx_stats = {"rounds": st[0], "chunks_indexed": st[1], "max_rounds": st[2], "chunks_repaired": st[3], "lanes_restarted_per_round": [st[4 + k] for k in range(12)]}
     line = None
     if rank == 0:
-        kms = {k: v / steps for k, v in kms.items()}
+        kms_run = {k: v / steps for k, v in kms.items()}
+        kms = dict(kms_alone) if kms_alone else dict(kms_run)      # what the roofline is computed from
         sample_bytes = total_bytes / batch
         # algorithmic bytes per frame of every kernel: samples are 8-bit in the packed frame, 16-bit in the pyramid
         Hp = (H + 7) // 8 * 8
@@ -363,7 +374,7 @@ def measure(workload, steps, warmup, batch, unique, threads, rank, world, barrie
         if kms.get(COUNT1, 0.0) > 0.0:                   # the count is split: its level-1 part (three quarters of the coefficients) and the rest, each with its own bytes and time
             algo[COUNT1] = S * 3 // 4 * 2; algo["k_ent_count"] = coded - S * 3 // 4 * 2
         else:
-            kms.pop(COUNT1, None)
+            kms.pop(COUNT1, None); kms_run.pop(COUNT1, None)
         if wl["mode"] == 0:
             algo.update({PI3: S // 4, PI2: S, INV1: 2 * S + P})
             if old_dec: algo["k_dec_bands_par"] = sample_bytes + coded
@@ -400,9 +411,13 @@ def measure(workload, steps, warmup, batch, unique, threads, rank, world, barrie
                                       "sum_of_kernels_ms": round(sum_kernels, 3)},
                        "stage_ms_per_step": {"submit": round(1000 * stage[0] / steps, 3), "encode_wait+sample_d2h": round(1000 * stage[1] / steps, 3),
                                              "decode_parse+stage": round(1000 * stage[2] / steps, 3), "decode_wait": round(1000 * stage[3] / steps, 3)},
-                       "kernel_ms_per_step": {k: round(v, 4) for k, v in kms.items()}},
+                       "kernel_ms_per_step": {k: round(v, 4) for k, v in kms_run.items()},
+                       **({"kernel_ms_one_step_at_a_time": {k: round(v, 4) for k, v in kms.items()}} if kms_alone else {})},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source, "launch_ms": round(ms, 4),
+                         "launch_ms_measured": ("HIP events around the launch, average over the %d timed steps" % steps) if not kms_alone else
+                                               ("HIP events around the launch, average over 3 passes run one at a time right behind the timed region (inside it %d steps are in flight and share the GPU: "
+                                                "this kernel's event time there is %.4f ms)" % (depth, kms_run.get(dom, 0.0))),
                          "algorithmic_bytes_per_launch": int(algo[dom] * batch),
                          "other_kernels_gbs": {k: round(algo[k] * batch / (kms[k] * 1e-3) / 1e9, 1) for k in algo if kms[k] > 0 and k != dom}},
         }

@@ -37,6 +37,7 @@ GPU_FIRST = [
     "test_yuy2_4k_two_segments",
     "test_encoder_pool_is_fifo_and_matches_sync",
     "test_concurrent_decoders_share_launches_and_stay_exact",
+    "test_frame_queue_of_batches_equals_synchronous_passes",
     "test_gop_encode_bitstream_identical",
     "test_gop_decode_reference_samples",
     "test_gop_round_trip_of_the_product_alone",

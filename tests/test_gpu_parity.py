@@ -1451,6 +1451,48 @@ def _batched_yuy2_round_trip_equals_reference(w, h, n, nuniq, expect=None):
     L.cfhd_amd_batch_destroy(b)
 
 
+def test_frame_queue_of_batches_equals_synchronous_passes():
+    """cfhd_amd_batch_submit / _wait (the HIP-stream frame queue bench.py runs with several steps in flight): two batch objects submitted back to back and collected
+    in submission order give, pass after pass, the samples and pictures of cfhd_amd_batch_roundtrip on the same frames; a second submit on a batch in flight and a
+    wait without a submit are refused."""
+    L = _batch_api()
+    L.cfhd_amd_batch_submit.argtypes = [ctypes.c_void_p]
+    L.cfhd_amd_batch_wait.restype = ctypes.c_longlong; L.cfhd_amd_batch_wait.argtypes = [ctypes.c_void_p]
+    w, h, n = 320, 240, 3
+    frames = [synth_yuy2(w, h, 60 + i)[0] for i in range(2 * n)]
+    refs = [ref_encode_frames(frames[k * n:(k + 1) * n], w * 2, w, h) for k in range(2)]
+    slots = []
+    for k in range(2):
+        b = L.cfhd_amd_batch_create(w, h, PIX_YUY2, QUALITY_FILMSCAN1, n, 2)
+        assert b, amd_last_error()
+        for i in range(n): assert L.cfhd_amd_batch_upload(b, i, frames[k * n + i].ctypes.data_as(ctypes.c_void_p), w * 2) == 0
+        slots.append(b)
+    assert L.cfhd_amd_batch_wait(slots[0]) < 0                       # nothing in flight
+    for rounds in range(2):
+        for b in slots: assert L.cfhd_amd_batch_submit(b) == 0
+        assert L.cfhd_amd_batch_submit(slots[1]) != 0                # one pass per batch at a time
+        for k, b in enumerate(slots):
+            assert L.cfhd_amd_batch_wait(b) > 0, amd_last_error()
+            plan = Plan(w, h)
+            for i in range(n):
+                p = ctypes.c_void_p(); sz = ctypes.c_size_t()
+                assert L.cfhd_amd_batch_get_sample(b, i, ctypes.byref(p), ctypes.byref(sz)) == 0
+                sample = ctypes.string_at(p, sz.value)
+                a, r = bytearray(mask_volatile_metadata(sample)), bytearray(mask_volatile_metadata(refs[k][i]))
+                for buf in (a, r):                                   # (the second round numbers its frames n + 1 ..: counters set to zero on both sides)
+                    import struct
+                    kk = bytes(buf[:160]).find(struct.pack(">h", -69)); buf[kk + 2:kk + 4] = b"\0\0"
+                    u = bytes(buf[:1024]).find(b"UFRM"); buf[u + 8:u + 12] = b"\0\0\0\0"
+                assert bytes(a) == bytes(r), "round %d batch %d frame %d" % (rounds, k, i)
+                deq = host_decode_pyramid(sample, plan)
+                lo, hi = oracle_inverse_yuv422(plan, deq, 0)[:h], oracle_inverse_yuv422(plan, deq, 1)[:h]
+                out = np.zeros(h * w * 2, dtype=np.uint8)
+                assert L.cfhd_amd_batch_download_output(b, i, out.ctypes.data_as(ctypes.c_void_p), w * 2) == 0
+                img = out.reshape(h, w * 2)
+                assert ((img == lo) | (img == hi)).all()
+    for b in slots: L.cfhd_amd_batch_destroy(b)
+
+
 @pytest.mark.parametrize("w,h,n,nuniq", [(1920, 1080, 64, 16), (3840, 2160, 40, 4)])
 def test_batched_round_trip_at_bench_sizes_equals_reference(w, h, n, nuniq):
     """The batch sizes at which the library picks the kernels bench.py times by itself (>= 32 1080p-equivalents per launch: register strips
