@@ -1172,6 +1172,10 @@ void GopBatch::fill_jobs()
 		for (int b = 0; b < 4; b++) p.band[b] = base + src.offset[b];
 		p.band_pitch = src.pitch; p.width = src.width; p.height = src.height; p.descale = src.prescale;
 		p.out = out; p.out_pitch = out_pitch; p.xstride = 1; p.precision = 0; p.display_height = 2 * src.height;
+		// the unprescaled wavelets of a group (w[5] and w[3]) go through the reference's InvertSpatialQuantOverflowProtected16s and inherit the defect of its last
+		// row (InvPlaneJob::ll_bottom_row_high): the reference decoder's pictures are the parity bar.  CFHD_AMD_GOP_BOTTOM_ROWS=fixed: the filter as meant (+5 dB).
+		static const bool fixed = [] { const char *e = getenv("CFHD_AMD_GOP_BOTTOM_ROWS"); return e && strcmp(e, "fixed") == 0; }();
+		p.ll_bottom_row_high = (src.prescale == 0 && !fixed) ? 1 : 0;
 	};
 	for (int c = 0; c < 3; c++) {
 		const GopChannel &ch = plan.ch[c];

@@ -177,6 +177,11 @@ struct InvPlaneJob {
 	// k_inv_rgb10 (r210 / DPX0 / AB10 / AR10 output of RGB 4:4:4 samples: one 32-bit word per pixel; orc_inv_spatial_to_rgb10): bit position of this
 	// plane's 10 bits, words stored byte-swapped; `out` = the frame, out_pitch in 32-bit words
 	int bit_shift, big_endian;
+	// k_inv_plane, two-frame groups: the wavelet goes through the reference's InvertSpatialQuantOverflowProtected16s (Codec/spatial.c:21114; the unprescaled
+	// wavelets of a group, wavelet.c:5759 / :5886), whose border filter of the LAST coefficient row reads the LL band one row too high -- rows h-2, h-3, h-4 instead
+	// of h-1, h-2, h-3: the row pointer's advance behind the middle rows is compiled out (spatial.c:21770-21776 `#if (0 && XMMOPT)`).  1: reproduce it (what the
+	// reference decoder's pictures are made of: 42 dB instead of 47 on the bottom 16 rows' account), 0: the filter as meant.
+	int ll_bottom_row_high;
 };
 
 struct InvYuvJob {
@@ -649,7 +654,7 @@ __device__ __forceinline__ void inv_horiz(int lm1, int l0, int lp1, int lfar, in
 // horizontal pass combines three neighbouring dwords per output pair.
 enum { ITW = 64, ITH = 16, IDW = ITW / 2 + 2, ILROWS = ITH + 2 };
 
-__device__ __forceinline__ int inv_tile_first_row(int r0, int h) { int s = r0 - 1; if (s > h - 3) s = h - 3; return s < 0 ? 0 : s; }
+__device__ __forceinline__ int inv_tile_first_row(int r0, int h, int extra = 0) { int s = r0 - 1; if (s > h - 3 - extra) s = h - 3 - extra; return s < 0 ? 0 : s; }
 __device__ __forceinline__ int inv_window_first_row(int r, int h) { return r == 0 ? 0 : (r == h - 1 ? h - 3 : r - 1); }
 
 // Vertical synthesis of two adjacent columns: a, b, c = three consecutive rows of the vertical-lowpass band starting at
@@ -768,7 +773,8 @@ __device__ __forceinline__ void inv_plane_tile(const InvPlaneJob *jobs, int nch,
 	const int tw = PACKED ? ITW * wps / job.xstride : ITW;     // band columns of this plane under the tile
 	const int c0 = tile.x * tw, r0 = tile.y * ITH;
 	const bool active = (c0 < w) && (r0 < h);
-	const int rs = inv_tile_first_row(r0, h);
+	const int ll_high = (!PACKED && job.ll_bottom_row_high && h >= 4) ? 1 : 0;      // (InvPlaneJob::ll_bottom_row_high: the last row's LL window starts a row higher)
+	const int rs = inv_tile_first_row(r0, h, ll_high);
 	const bool bytes8 = PACKED && job.bytes8;
 	const int word = PACKED ? (bytes8 ? (int)((const uint8_t *)job.out - (const uint8_t *)frame) : (int)((const uint16_t *)job.out - frame)) : 0;
 	if (PACKED && comp == 0) { w_first = w; }
@@ -789,7 +795,7 @@ __device__ __forceinline__ void inv_plane_tile(const InvPlaneJob *jobs, int nch,
 			const int q = i / (ITH * IDW), rem = i - q * (ITH * IDW), rl = rem / IDW, d = rem - rl * IDW;
 			const int r = r0 + rl;
 			if (r >= h) continue;
-			const int j = inv_window_first_row(r, h) - rs, pos = r == 0 ? 0 : (r == h - 1 ? 2 : 1);
+			const int j = inv_window_first_row(r, h) - rs - ((q == 0 && r == h - 1) ? ll_high : 0), pos = r == 0 ? 0 : (r == h - 1 ? 2 : 1);
 			uint32_t e, o;
 			inv_vert_pk(s_low[q][j][d], s_low[q][j + 1][d], s_low[q][j + 2][d], s_high[q][rl][d], pos, e, o);
 			s_v[0][q][rl][d] = e; s_v[1][q][rl][d] = o;

@@ -85,6 +85,46 @@ void orc_inv_spatial(PIXEL16 *const bands[4], int band_pitch, int w, int h, int 
 	free(el); free(ol); free(eh); free(oh);
 }
 
+/* Codec/spatial.c:21114 InvertSpatialQuantOverflowProtected16s -- what the reference's GROUP decoder runs for the wavelets that were not prescaled: the top
+ * wavelet of the temporal lowpass (level 4: wavelet.c:5759 `input->level >= 4`) and the wavelet of the temporal highpass (wavelet.c:5886).  Vertical pass in 32
+ * bits with one saturation at the end (:21658-21700), the ordinary horizontal pass (InvertHorizontalStrip16s).  It carries a defect that a decoder which wants the
+ * reference's pictures has to reproduce: the lowpass row pointer is not advanced behind the loop over the middle rows (the advance at :21770-21776 sits inside
+ * `#if (0 && XMMOPT)`), so the border filter of the LAST coefficient row (:21799-21830) reads the lowpass rows h-2, h-3, h-4 where rows h-1, h-2, h-3 are meant.
+ * The highpass-side bands (LH with HH) go through a ring of three row pointers that is right (:21762-21774).  Pinned on the reference decoder's group output. */
+void orc_inv_spatial_overflow_protected(PIXEL16 *const bands[4], int band_pitch, int w, int h, PIXEL16 *out, int out_pitch)
+{
+	PIXEL16 *el = (PIXEL16 *)malloc((size_t)w * 2), *ol = (PIXEL16 *)malloc((size_t)w * 2);
+	PIXEL16 *eh = (PIXEL16 *)malloc((size_t)w * 2), *oh = (PIXEL16 *)malloc((size_t)w * 2);
+	int r, c, side;
+	for (r = 0; r < h; r++) {
+		for (side = 0; side < 2; side++) {
+			const PIXEL16 *low = bands[side], *high = bands[2 + side] + (size_t)r * band_pitch;
+			PIXEL16 *e = side ? eh : el, *o = side ? oh : ol;
+			for (c = 0; c < w; c++) {
+				int even, odd, hi = high[c];
+				if (r == 0) {
+					int l0 = low[c], l1 = low[band_pitch + c], l2 = low[2 * band_pitch + c];
+					even = (((11 * l0 - 4 * l1 + l2 + 4) >> 3) + hi) >> 1;
+					odd  = (((5 * l0 + 4 * l1 - l2 + 4) >> 3) - hi) >> 1;
+				} else if (r == h - 1) {
+					const int last = (side == 0 && h >= 4) ? r - 1 : r;      /* the defect: the LL band is read one row too high */
+					int l0 = low[(size_t)last * band_pitch + c], l1 = low[(size_t)(last - 1) * band_pitch + c], l2 = low[(size_t)(last - 2) * band_pitch + c];
+					even = (((5 * l0 + 4 * l1 - l2 + 4) >> 3) + hi) >> 1;
+					odd  = (((11 * l0 - 4 * l1 + l2 + 4) >> 3) - hi) >> 1;
+				} else {
+					int a = low[(size_t)(r - 1) * band_pitch + c], b = low[(size_t)r * band_pitch + c], d = low[(size_t)(r + 1) * band_pitch + c];
+					even = (((a - d + 4) >> 3) + b + hi) >> 1;
+					odd  = (((d - a + 4) >> 3) + b - hi) >> 1;
+				}
+				e[c] = (PIXEL16)sat16(even); o[c] = (PIXEL16)sat16(odd);
+			}
+		}
+		inv_horizontal_row(el, eh, w, 0, out + (size_t)(2 * r) * out_pitch);
+		inv_horizontal_row(ol, oh, w, 0, out + (size_t)(2 * r + 1) * out_pitch);
+	}
+	free(el); free(ol); free(eh); free(oh);
+}
+
 /* One reconstructed 4:2:2 sample before the 10->8 bit reduction:
  * v = lowfilter +/- high (before the >>1), clamped at zero as the SIMD body does with the
  * +2048 / subs_epu16 pair (InvertHorizontalStrip16s.c:4086-4089); then (v>>1 + dither) >> shift,

@@ -1127,9 +1127,10 @@ def host_decode_group(sample, gp):
     return out
 
 
-def oracle_inverse_gop(gp, coeffs, dither, uyvy=0):
-    """The inverse group transform with the oracle from a dequantized group pyramid: spatial synthesis of w[5], w[4], w[3] (orc_inv_spatial,
-    the descale variant where the encoder prescaled), the temporal step of Codec/wavelet.c TransformInverseTemporal (frame 0 = sat(low - high)
+def oracle_inverse_gop(gp, coeffs, dither, uyvy=0, reference_defect=True):
+    """The inverse group transform with the oracle from a dequantized group pyramid: spatial synthesis of w[5], w[4], w[3] (orc_inv_spatial: the descale variant where
+    the encoder prescaled; orc_inv_spatial_overflow_protected -- the routine the reference's group decoder runs, defect of its last row included -- where it did not;
+    reference_defect=False: the filter as meant, 5 dB better than the reference's own pictures), the temporal step of Codec/wavelet.c TransformInverseTemporal (frame 0 = sat(low - high)
     >> 1, frame 1 = sat(low + high) >> 1; the width % 8 tail columns divide towards zero), the last level of both frames.  Returns two
     packed 8-bit 4:2:2 pictures."""
     O = oracle()
@@ -1138,7 +1139,12 @@ def oracle_inverse_gop(gp, coeffs, dither, uyvy=0):
         d = gp.w[(c, k)]
         bands = (c_i16p * 4)(*[gp.view(work, c, k, b).ctypes.data_as(c_i16p) for b in range(4)])
         dst = gp.view(work, c, dst_k, dst_b)
-        O.orc_inv_spatial(bands, d["pitch"], d["width"], d["height"], d["prescale"], dst.ctypes.data_as(c_i16p), gp.w[(c, dst_k)]["pitch"])
+        if d["prescale"] == 0 and reference_defect:
+            # the wavelets the reference's group decoder sends through InvertSpatialQuantOverflowProtected16s (no prescale: w[5] at level 4, wavelet.c:5759, and the
+            # temporal-highpass wavelet w[3], wavelet.c:5886), whose last coefficient row reads the lowpass band one row too high (spatial.c:21770-21830)
+            O.orc_inv_spatial_overflow_protected(bands, d["pitch"], d["width"], d["height"], dst.ctypes.data_as(c_i16p), gp.w[(c, dst_k)]["pitch"])
+        else:
+            O.orc_inv_spatial(bands, d["pitch"], d["width"], d["height"], d["prescale"], dst.ctypes.data_as(c_i16p), gp.w[(c, dst_k)]["pitch"])
     for c in range(3):
         inv(c, 5, 4, 0); inv(c, 4, 2, 0); inv(c, 3, 2, 1)
         d = gp.w[(c, 2)]
@@ -1158,6 +1164,30 @@ def oracle_inverse_gop(gp, coeffs, dither, uyvy=0):
         O.orc_inv_spatial_to_yuv422(ptrs, iarr(pitches), w, h, 10, uyvy, dither, p8(out), 4 * w)
         outs.append(out)
     return outs
+
+
+def ref_decode_group_frames(samples, width, height, pixfmt=PIX_YUY2):
+    """The pictures the reference decoder gives for a stream of two-frame groups (samples: [sequence header,] group, P-frame header, group, ...): a list of
+    (frame 0, frame 1) per group, cropped to width x height.  How the reference has to be driven (probed; Codec/decoder.c:11180 DecodeSampleGroup, :11482
+    DecodeSampleFrame): the handle is prepared on the first GROUP sample (the 40-byte sequence header carries the coded height only), one worker thread
+    (TAG_CPU_MAX = 1, as every RefDecoder here), and every group sample is decoded TWICE -- the first CFHD_DecodeSample of a new group returns a picture put
+    together from the previous group's wavelets (its entropy decode runs behind the reconstruction of the first frame; noise for the first group of a stream,
+    a 20 dB ghost of the previous group afterwards), the second call on the same sample returns the group's first frame; the P-frame sample behind it then
+    returns the second."""
+    groups = [k for k, s in enumerate(samples) if len(s) > 64]
+    d = RefDecoder(samples[groups[0]], pixfmt, 1, 1)
+    def dec(s):
+        sb = ctypes.create_string_buffer(s, len(s)); out = np.zeros(d.pitch * d.height + 64, np.uint8)
+        assert d.decode(sb, len(s), out) == 0
+        return out[: d.pitch * d.height].reshape(d.height, d.pitch)[:height, : width * 2].copy()
+    frames = []
+    for k in groups:
+        dec(samples[k])
+        f0 = dec(samples[k])
+        f1 = dec(samples[k + 1]) if k + 1 < len(samples) and len(samples[k + 1]) <= 64 else None
+        frames.append((f0, f1))
+    d.close()
+    return frames
 
 
 def oracle_rgb8_to_yuv422_planes(frame, pitch, bytes_per_pixel, top_down, w, h, enc_height, color_space=0):

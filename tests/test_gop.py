@@ -56,40 +56,30 @@ def test_group_quantizer_known_answers_and_gates():
     assert L.cfhd_amd_gop_plan_info(328, 240, 1, 4, buf) == -1          # chroma would not halve on whole pairs
 
 
-@pytest.mark.parametrize("w,h", [(320, 240), (336, 252)])
-def test_group_inverse_model_reconstructs_like_the_intra_path(w, h):
-    """Reference group sample -> host parser / VLC decoder -> oracle inverse (lowpass bias 48 for groups, decoder.c:12265): PSNR against the
-    source within 0.3 dB of what the reference decoder gives the same frames coded as intra frames; and a characterisation of the
-    reference's own group decoder, which is why it is not the decode gate: fed its own samples through CFHD_DecodeSample it returns the first
-    group as noise and later groups of moving content at < 30 dB (it does reach ~42 dB on static content)."""
-    frames = _frames(w, h, 6, PIX_YUY2)
-    samples = ref_encode_frames(frames, w * 2, w, h, flags=ENCODING_FLAGS_2FRAME_GOP)
-    gp = GopPlan(w, h)
-    for g in range(2):
+@pytest.mark.parametrize("w,h,fmt", [(320, 240, PIX_YUY2), (336, 252, PIX_YUY2), (720, 480, PIX_2VUY), (400, 120, PIX_YUY2), (1920, 1080, PIX_YUY2)])
+def test_group_inverse_model_equals_the_reference_group_decoder(w, h, fmt):
+    """Pins oracle_inverse_gop on the reference's own group decoder (Codec/decoder.c:11180 DecodeSampleGroup + :11482 DecodeSampleFrame, driven as
+    cfhd_testlib.ref_decode_group_frames documents): reference group samples -> host parser / VLC decoder -> oracle inverse (lowpass bias 48 for groups,
+    decoder.c:12265; the unprescaled wavelets through the restated InvertSpatialQuantOverflowProtected16s, spatial.c:21114, whose last coefficient row reads the LL
+    band one row too high) -- every byte of both frames of every group of the reference decoder's output lies inside the oracle's dither interval, the PSNR against
+    the source agrees to 0.1 dB.  The same inverse without that defect reconstructs the frames better than the reference does (the bottom 16 rows), which is why the
+    defect is part of the model: the reference's pictures are the bar, not the best picture."""
+    kind = 2 if fmt == PIX_2VUY else 1
+    frames = _frames(w, h, 6 if w < 1920 else 2, fmt)
+    samples = ref_encode_frames(frames, w * 2, w, h, pixfmt=fmt, flags=ENCODING_FLAGS_2FRAME_GOP)
+    gp = GopPlan(w, h, pixkind=kind)
+    got = ref_decode_group_frames(samples, w, h, fmt)
+    assert len(got) == len(frames) // 2
+    for g, pair in enumerate(got):
         co = host_decode_group(samples[2 * g + 1], gp)
-        lo = oracle_inverse_gop(gp, co, 0); hi = oracle_inverse_gop(gp, co, 1)
-        for f in range(2):
+        lo = oracle_inverse_gop(gp, co, 0, uyvy=int(kind == 2)); hi = oracle_inverse_gop(gp, co, 1, uyvy=int(kind == 2))
+        better = oracle_inverse_gop(gp, co, 0, uyvy=int(kind == 2), reference_defect=False)
+        for f, img in enumerate(pair):
+            if img is None: continue                     # (the last group of the stream has no P-frame sample behind it)
+            ok = (img == lo[f][:h]) | (img == hi[f][:h])
+            assert ok.all(), "group %d frame %d: %d of %d bytes of the reference decoder's picture lie outside the oracle's dither interval" % (g, f, (~ok).sum(), ok.size)
             src = frames[2 * g + f].reshape(h, w * 2)
-            intra = ref_encode_frames([frames[2 * g + f]], w * 2, w, h)[0]
-            want = 0.0
-            for attempt in range(4):                    # (the reference's threaded decoder occasionally damages a frame: its best decode counts)
-                o, p = ref_decode_sample(intra, w, h)
-                want = max(want, psnr_yuy2(o.reshape(h, p)[:, : w * 2], src))
-                if abs(psnr_yuy2(lo[f][:h], src) - want) < 0.3: break
-            got = psnr_yuy2(lo[f][:h], src)
-            assert got > 40.0 and abs(got - want) < 0.3, (g, f, got, want)
-            assert (np.abs(lo[f].astype(int) - hi[f].astype(int)) <= 1).all()
-    # the reference decoder on its own group samples
-    L = ref()
-    dec = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
-    aw = ctypes.c_int(); ah = ctypes.c_int(); af = ctypes.c_uint32()
-    sb = ctypes.create_string_buffer(samples[0], len(samples[0]))
-    assert L.CFHD_PrepareToDecode(dec, 0, 0, PIX_YUY2, 1, 0, sb, len(samples[0]), ctypes.byref(aw), ctypes.byref(ah), ctypes.byref(af)) == 0
-    assert (aw.value, ah.value) == (w, (h + 7) // 8 * 8)          # (the sequence header carries the coded height only: 252 comes back as 256)
-    best = []
-    for s in samples:
-        sb = ctypes.create_string_buffer(s, len(s)); out = np.zeros(w * 2 * ah.value, np.uint8)
-        assert L.CFHD_DecodeSample(dec, sb, len(s), out.ctypes.data_as(ctypes.c_void_p), w * 2) == 0
-        best.append(max(psnr_yuy2(out.reshape(ah.value, w * 2)[:h], f.reshape(h, w * 2)) for f in frames))
-    L.CFHD_CloseDecoder(dec)
-    assert max(best) < 30.0, best
+            if kind == 2: src = src.reshape(-1, 2)[:, ::-1].reshape(h, w * 2); img = img.reshape(-1, 2)[:, ::-1].reshape(h, w * 2); lo_f = lo[f][:h].reshape(-1, 2)[:, ::-1].reshape(h, w * 2); b_f = better[f][:h].reshape(-1, 2)[:, ::-1].reshape(h, w * 2)
+            else: lo_f = lo[f][:h]; b_f = better[f][:h]
+            assert abs(psnr_yuy2(img, src) - psnr_yuy2(lo_f, src)) < 0.1
+            assert psnr_yuy2(b_f, src) > psnr_yuy2(img, src) + 1.0
