@@ -313,6 +313,7 @@ int gather_slots(const char *env, int dflt) { const char *e = getenv(env); int v
 // qualities whose quantizer follows the size of the last sample (rate feedback, encode_one) keep one launch sequence per frame.
 struct EncodeServiceKey {
 	int width, height, pixel_kind, encoded_format, quality, color_space; uint32_t flags;
+	int device;                                // the GPU the pool's workers were dealt (two pools on different GPUs do not share a service)
 	bool operator==(const EncodeServiceKey &o) const { return memcmp(this, &o, sizeof(*this)) == 0; }
 };
 struct EncodeService : Gatherer<EncodeBatch> {
@@ -320,6 +321,8 @@ struct EncodeService : Gatherer<EncodeBatch> {
 	bool start(const EncodeParams &p, int nslots)
 	{
 		slots = nslots;
+		device = key.device;
+		struct OnDevice { OnDevice(int d) { device_select(d); } ~OnDevice() { device_select(-1); } } on(device);      // the shared batches live on the GPU of the workers they serve
 		for (Pass &x : g) if (x.batch.prepare(p.plan, slots, true) || x.batch.prepare_entropy(sample_capacity(p))) { for (Pass &y : g) y.batch.release(); return false; }   // (a service that cannot be set up holds no HBM)
 		run_pass = [](Pass &x, int n, uint32_t) {
 			x.batch.set_active(n);
@@ -612,6 +615,7 @@ CFHD_Error CFHD_GetInputFormats(CFHD_EncoderRef ref, CFHD_PixelFormat *arr, int 
 CFHD_Error CFHD_PrepareToEncode(CFHD_EncoderRef ref, int w, int h, CFHD_PixelFormat fmt, CFHD_EncodedFormat encoded,
                                 CFHD_EncodingFlags flags, CFHD_EncodingQuality quality)
 {
+	CallerDevice caller_device;                      // (the caller's current HIP device is put back on the way out)
 	if (!ref) return ERR_INVALID_ARGUMENT;
 	Encoder *e = (Encoder *)ref;
 	const int want_encoded = e->params.encoded_format == ENC_RGB444 ? 1 : (e->params.encoded_format == ENC_RGBA4444 ? 2 : (e->params.encoded_format == ENC_BAYER ? 3 : 0));
@@ -639,6 +643,7 @@ CFHD_Error CFHD_SetEncodeLicense2(CFHD_EncoderRef ref, unsigned char *, uint32_t
 
 CFHD_Error CFHD_EncodeSample(CFHD_EncoderRef ref, void *frame, int pitch)
 {
+	CallerDevice caller_device;                      // (the caller's current HIP device is put back on the way out)
 	if (!ref || !frame) return ERR_INVALID_ARGUMENT;
 	Encoder *e = (Encoder *)ref;
 	if (!e->params.valid) return ERR_CODEC_ERROR;
@@ -693,6 +698,7 @@ CFHD_Error CFHD_GetSampleData(CFHD_EncoderRef ref, void **data, size_t *size)
 
 CFHD_Error CFHD_CloseEncoder(CFHD_EncoderRef ref)
 {
+	CallerDevice caller_device;                      // (the caller's current HIP device is put back on the way out)
 	if (!ref) return ERR_INVALID_ARGUMENT;
 	static const char *const names[] = { "encode_one" };
 	((Encoder *)ref)->prof.report("CFHD_EncodeSample", names, 1);
@@ -767,6 +773,7 @@ CFHD_Error CFHD_GetAsyncInputFormats(CFHD_EncoderPoolRef ref, CFHD_PixelFormat *
 CFHD_Error CFHD_PrepareEncoderPool(CFHD_EncoderPoolRef ref, uint_least16_t w, uint_least16_t h, CFHD_PixelFormat fmt,
                                    CFHD_EncodedFormat encoded, CFHD_EncodingFlags flags, CFHD_EncodingQuality quality)
 {
+	CallerDevice caller_device;                      // (the caller's current HIP device is put back on the way out)
 	if (!ref) return ERR_INVALID_ARGUMENT;
 	EncoderPool *p = (EncoderPool *)ref;
 	if (p->started) return ERR_UNEXPECTED;
@@ -789,6 +796,7 @@ CFHD_Error CFHD_AttachEncoderPoolMetadata(CFHD_EncoderPoolRef ref, CFHD_Metadata
 
 CFHD_Error CFHD_StartEncoderPool(CFHD_EncoderPoolRef ref)
 {
+	CallerDevice caller_device;                      // (the caller's current HIP device is put back on the way out)
 	if (!ref) return ERR_INVALID_ARGUMENT;
 	EncoderPool *p = (EncoderPool *)ref;
 	if (!p->params.valid) return ERR_ENCODING_NOT_STARTED;
@@ -814,6 +822,7 @@ CFHD_Error CFHD_StartEncoderPool(CFHD_EncoderPoolRef ref)
 		EncodeServiceKey key; memset(&key, 0, sizeof(key));
 		key.width = p->params.width; key.height = p->params.height; key.pixel_kind = p->params.pixel_kind; key.encoded_format = p->params.encoded_format;
 		key.quality = p->params.quality; key.color_space = p->params.color_space; key.flags = p->params.flags;
+		key.device = p->workers[0]->batch.device();
 		p->service = encode_services().find(key);
 	}
 	for (auto &w : p->workers) { PoolWorker *pw = w.get(); pw->thread = std::thread([p, pw] { p->worker_loop(pw); }); }
@@ -823,6 +832,7 @@ CFHD_Error CFHD_StartEncoderPool(CFHD_EncoderPoolRef ref)
 
 CFHD_Error CFHD_StopEncoderPool(CFHD_EncoderPoolRef ref)
 {
+	CallerDevice caller_device;                      // (the caller's current HIP device is put back on the way out)
 	if (!ref) return ERR_INVALID_ARGUMENT;
 	((EncoderPool *)ref)->stop();
 	return ERR_OKAY;
@@ -830,6 +840,7 @@ CFHD_Error CFHD_StopEncoderPool(CFHD_EncoderPoolRef ref)
 
 CFHD_Error CFHD_EncodeAsyncSample(CFHD_EncoderPoolRef ref, uint32_t frame_number, void *frame, intptr_t pitch, CFHD_MetadataRef mref)
 {
+	CallerDevice caller_device;                      // (the caller's current HIP device is put back on the way out)
 	if (!ref || !frame) return ERR_INVALID_ARGUMENT;
 	EncoderPool *p = (EncoderPool *)ref;
 	if (!p->started) return ERR_ENCODING_NOT_STARTED;
@@ -903,6 +914,7 @@ CFHD_Error CFHD_ReleaseSampleBuffer(CFHD_EncoderPoolRef, CFHD_SampleBufferRef re
 
 CFHD_Error CFHD_ReleaseEncoderPool(CFHD_EncoderPoolRef ref)
 {
+	CallerDevice caller_device;                      // (the caller's current HIP device is put back on the way out)
 	if (!ref) return ERR_INVALID_ARGUMENT;
 	EncoderPool *p = (EncoderPool *)ref;
 	p->stop();
@@ -967,6 +979,7 @@ CFHD_Error CFHD_GetSampleInfo(CFHD_DecoderRef ref, void *sample, size_t size, CF
 CFHD_Error CFHD_PrepareToDecode(CFHD_DecoderRef ref, int, int, CFHD_PixelFormat fmt, CFHD_DecodedResolution resolution, CFHD_DecodingFlags,
                                 void *sample, size_t size, int *aw, int *ah, CFHD_PixelFormat *af)
 {
+	CallerDevice caller_device;                      // (the caller's current HIP device is put back on the way out)
 	if (!ref || !sample) return ERR_INVALID_ARGUMENT;
 	Decoder *d = (Decoder *)ref;
 	{
@@ -1159,6 +1172,7 @@ static CFHD_Error decode_group_sample(Decoder *d, const uint8_t *s, size_t size,
 
 CFHD_Error CFHD_DecodeSample(CFHD_DecoderRef ref, void *sample, size_t size, void *out, int32_t pitch)
 {
+	CallerDevice caller_device;                      // (the caller's current HIP device is put back on the way out)
 	if (!ref || !sample || !out) return ERR_INVALID_ARGUMENT;
 	Decoder *d = (Decoder *)ref;
 	if (!d->prepared) return ERR_UNEXPECTED;
@@ -1387,6 +1401,7 @@ CFHD_Error CFHD_ParseSampleHeader(void *sample, size_t size, CFHD_SampleHeader *
 
 CFHD_Error CFHD_CloseDecoder(CFHD_DecoderRef ref)
 {
+	CallerDevice caller_device;                      // (the caller's current HIP device is put back on the way out)
 	if (!ref) return ERR_INVALID_ARGUMENT;
 	static const char *const names[] = { "parse+stage", "submit", "gpu+copies", "copy out" };
 	((Decoder *)ref)->prof.report("CFHD_DecodeSample", names, 4);

@@ -66,6 +66,7 @@ extern "C" {
 // format; mode 1: encode only (the only mode for BYR4).
 cfhd_amd_batch *cfhd_amd_batch_create_ex(int width, int height, uint32_t pixel_format, int encoded_format, uint32_t encoding_flags, int quality, int nframes, int nthreads, int mode)
 {
+	CallerDevice caller_device;
 	FrontEndParams fp;
 	if (nframes < 1 || front_end_params(width, height, pixel_format, encoded_format, encoding_flags, quality, &fp)) return nullptr;
 	// A batch encodes its frames in one launch with one set of quantizer tables.  Qualities whose tables follow the size of the previous sample
@@ -108,11 +109,12 @@ cfhd_amd_batch *cfhd_amd_batch_create(int width, int height, uint32_t pixel_form
 	return cfhd_amd_batch_create_ex(width, height, pixel_format == 0x32767579u /* '2vuy' */ ? pixel_format : 0x59555932u /* 'YUY2' */, 0, 0, quality, nframes, nthreads, 0);
 }
 
-void cfhd_amd_batch_destroy(cfhd_amd_batch *b) { delete b; }
+void cfhd_amd_batch_destroy(cfhd_amd_batch *b) { CallerDevice caller_device; delete b; }
 
 // Puts frame i into HBM (outside the timed region of the benchmark).
 int cfhd_amd_batch_upload(cfhd_amd_batch *b, int i, const void *frame, int pitch)
 {
+	CallerDevice caller_device;
 	if (!b || i < 0 || i >= b->n) return -1;
 	int l; cfhd_amd_chunk &c = b->chunk_of(i, &l);
 	int rc = c.enc.upload_frame(l, frame, pitch);
@@ -123,6 +125,7 @@ int cfhd_amd_batch_upload(cfhd_amd_batch *b, int i, const void *frame, int pitch
 // One step of the hot path over the whole batch.  Returns the total number of sample bytes, or < 0.
 long long cfhd_amd_batch_roundtrip(cfhd_amd_batch *b)
 {
+	CallerDevice caller_device;
 	if (!b) return -1;
 	const FramePlan &plan = b->plan;
 	double t0 = now(), t1, t2, t3;
@@ -324,6 +327,7 @@ int cfhd_amd_batch_get_sample(cfhd_amd_batch *b, int i, const void **data, size_
 
 int cfhd_amd_batch_download_output(cfhd_amd_batch *b, int i, void *out, int pitch)
 {
+	CallerDevice caller_device;
 	if (!b || i < 0 || i >= b->n || !b->decode) return -1;
 	int l; cfhd_amd_chunk &c = b->chunk_of(i, &l);
 	if (c.dec.download_frame(l, out, pitch) || c.dec.wait()) return -2;

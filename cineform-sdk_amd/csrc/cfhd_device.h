@@ -17,6 +17,11 @@ int device_init();                 // picks the device from CFHD_AMD_DEVICE, els
 int device_count();
 int device_select(int dev);        // this thread prepares its batches on device `dev` from now on (-1: the process default again); returns the device in effect, -1 on failure
 int device_current();              // the device device_init() puts this thread on
+// The HIP device the calling thread had current when it entered the library, put back when it leaves: a handle that was dealt another GPU (unit_device)
+// must not leave the application's thread on that GPU -- its own HIP / PyTorch work would land there.  Every public entry point that can select a device holds one.
+int device_caller_save();          // the caller's current device, -1 when there is none to restore
+void device_caller_restore(int dev);
+struct CallerDevice { int dev; CallerDevice() : dev(device_caller_save()) {} ~CallerDevice() { device_caller_restore(dev); } CallerDevice(const CallerDevice &) = delete; };
 const char *device_last_error();
 
 // N frames that travel through the forward path together: one launch per wavelet level covers every channel of

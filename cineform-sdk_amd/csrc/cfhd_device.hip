@@ -18,7 +18,10 @@
 namespace cfhd {
 
 namespace {
-std::string g_err;
+// Text of the last failure: written from whatever thread failed (the chunks of a batch run on threads of their own), read through cfhd_amd_last_error()
+std::string g_err_text; std::mutex g_err_mutex;
+thread_local std::string t_err_copy;
+struct ErrSlot { ErrSlot &operator=(const char *t) { std::lock_guard<std::mutex> l(g_err_mutex); g_err_text = t; return *this; } } g_err;
 std::once_flag g_init_once;
 int g_init_rc = -1;
 int g_device = 0;
@@ -116,7 +119,7 @@ static int enc_word_of_channel(int pixel_kind, int c) { return pixel_kind == PIX
 static int enc_stride_of_channel(int pixel_kind, int c, int nch) { return pixel_kind == PIX_YU64 ? (c == 0 ? 2 : 4) : (pixel_kind == PIX_B64A || pixel_kind == PIX_RG64 ? 4 : nch); }     // (b64a / RG64 to RGB 4:4:4 have three planes of four-word pixels)
 } // namespace
 
-const char *device_last_error() { return g_err.c_str(); }
+const char *device_last_error() { std::lock_guard<std::mutex> l(g_err_mutex); t_err_copy = g_err_text; return t_err_copy.c_str(); }
 
 namespace {
 std::mutex g_pins_mutex;
@@ -167,6 +170,8 @@ int device_select(int dev)
 	return rc ? -1 : device_current();
 }
 int device_current() { return t_device >= 0 ? t_device : g_device; }
+int device_caller_save() { int d = -1; if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); return -1; } return d; }
+void device_caller_restore(int dev) { if (dev >= 0) { int now = -1; if (hipGetDevice(&now) == hipSuccess && now != dev) (void)hipSetDevice(dev); } }
 
 int device_init()
 {

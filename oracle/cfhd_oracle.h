@@ -69,6 +69,11 @@ void orc_inv_spatial_prepack(PIXEL16 *const bands[4], int band_pitch, int w, int
 void orc_inv_spatial_to_rgb10(PIXEL16 *const bands[4][4], int band_pitch, int w, int h, int display_height, int shift_r, int shift_g, int shift_b, int big_endian,
                               uint32_t *out, int out_pitch_words);
 /* 4:2:2 sample -> v210 (the YU64 words >> 6, packed three to a word; whole groups of six pixels) */
+void orc_yu64_to_rgb16(const uint16_t *yu, int yu_pitch_words, int width, int rows, int color_space, int b64a, uint16_t *out, int out_pitch_words);
+void orc_inv_spatial_to_rgb16_of_yuv422(PIXEL16 *const bands[3][4], const int band_pitch[3], int luma_w, int h, int precision, int display_height, int color_space, int b64a,
+                                        uint16_t *out, int out_pitch_words);
+void orc_inv_spatial_to_rgb32_of_yuv422(PIXEL16 *const bands[3][4], const int band_pitch[3], int luma_w, int h, int precision, int display_height, int color_space,
+                                        int bottom_up, uint8_t *out, int out_pitch_bytes);
 void orc_inv_spatial_overflow_protected(PIXEL16 *const bands[4], int band_pitch, int w, int h, PIXEL16 *out, int out_pitch);
 void orc_inv_spatial_to_v210(PIXEL16 *const bands[3][4], const int band_pitch[3], int luma_w, int h, int precision, uint32_t *out, int out_pitch_words);
 /* RGB 4:4:4 sample -> RG24 / BGRA (bottom_up) / BGRa: the RG48 reconstruction reduced to 8 bits with the dither value r (0..15) the caller picks, see cfhd_oracle_inv.c */

@@ -385,6 +385,117 @@ void orc_inv_spatial_to_rgb8(PIXEL16 *const bands[4][4], int band_pitch, int w, 
 	free(tmp);
 }
 
+/* ---- 4:2:2 samples decoded to RG48 / b64a (TestCFHD's RG48 -> 4:2:2 and b64a -> 4:2:2 rows at full resolution) -----------------------------------------
+ * Traced on the instrumented reference (tools/trace_reference.md): Codec/decoder.c ReconstructSampleFrameYUV422ToBuffer -> TransformInverseSpatialUniversalThreadedToRow16u
+ * (the planes as 16-bit rows, InvertHorizontalStrip16sToRow16u: the YU64 route, orc_inv_spatial_to_yu64, on a pyramid with the DEFAULT lowpass bias 24 / 5 --
+ * decoder.c:12268-12276 names only YU64 / YR16 / V210 for the small one) -> Codec/bayer.c:11916 Row16uFull2OutputFormat, ENCODED_FORMAT_YUV_422 without active
+ * metadata (:12168-12176): RGB2YUV.c:1308 ChannelYUYV16toPlanarYUV16 (every chroma word serves two pixels; plane 1 is V, plane 2 is U) -> RGB2YUV.c:1760
+ * PlanarYUV16toPlanarRGB16 (15-bit samples, 13-bit coefficients with the "tweak" offsets of :55-58, _mm_mulhi_epi16 products, saturating sums, << 2, a clamp to
+ * [0, 16383] by the 0x7fff - 0x3fff add / unsigned subtract pair, << 2) -> bayer.c:478 ConvertLinesToOutput with white point 16: the words as they are, R G B (RG48,
+ * :1358-1373) or 0xffff R G B (b64a, :1090-1106).  Widths are multiples of 16 here, so the vector body serves every column.  color_space: 1 = 601, 2 = 709
+ * (computer-systems range: what a sample without other colour tags says). */
+static int mulhi16(int a, int b) { return (a * b) >> 16; }
+static int wrap16(int x) { return (int)(int16_t)(uint16_t)x; }
+void orc_yu64_to_rgb16(const uint16_t *yu, int yu_pitch_words, int width, int rows, int color_space, int b64a, uint16_t *out, int out_pitch_words)
+{
+	/* PlanarYUV16toPlanarRGB16: fprecision = 8192; (int)(8192 * 1.164f) ... + tweakYUV2RGB_CG601 / _CG709 */
+	const int is601 = color_space == 1;
+	const int y_offset = 2048 + (is601 ? -28 : -32), ymult = 9535 + (is601 ? 14 : 11);
+	const int r_vmult = (is601 ? 13074 : 14688) + 6, g_vmult = (is601 ? 6660 + 1 : 4374 - 17), g_umult = (is601 ? 3203 + 7 : 1744 - 6), b_umult = (is601 ? 16531 + 3 : 17326 + 0);
+	const int u_offset = (1 << 14) + (is601 ? 23 : 22), v_offset = (1 << 14) + (is601 ? 23 : 22);
+	int y, x, c;
+	for (y = 0; y < rows; y++) {
+		const uint16_t *row = yu + (size_t)y * yu_pitch_words;
+		uint16_t *o = out + (size_t)y * out_pitch_words;
+		for (x = 0; x < width; x++) {
+			const int Y = row[2 * x], V = row[4 * (x >> 1) + 1], U = row[4 * (x >> 1) + 3];      /* words Y0 C1 Y1 C2: channel 1 = V, channel 2 = U */
+			int yy = sat16((Y >> 1) - y_offset), uu = sat16((U >> 1) - u_offset), vv = sat16((V >> 1) - v_offset);
+			int comp[3];
+			yy = mulhi16(yy, ymult);
+			comp[0] = sat16(mulhi16(vv, r_vmult) + yy);
+			comp[1] = sat16(sat16(yy + mulhi16(uu, -g_umult)) + mulhi16(vv, -g_vmult));
+			comp[2] = sat16(mulhi16(uu, b_umult) + yy);
+			for (c = 0; c < 3; c++) {
+				int v = wrap16(comp[c] << 2);                                /* 12 -> 14 bits (a 16-bit shift) */
+				v = sat16(v + (0x7fff - 0x3fff));                            /* adds_epi16 */
+				v = (v & 0xffff) - (0x7fff - 0x3fff); if (v < 0) v = 0;      /* subs_epu16 */
+				comp[c] = (v << 2) & 0xffff;                                 /* 14 -> 16 bits */
+			}
+			if (b64a) { o[4 * x] = 0xffff; o[4 * x + 1] = (uint16_t)comp[0]; o[4 * x + 2] = (uint16_t)comp[1]; o[4 * x + 3] = (uint16_t)comp[2]; }
+			else { o[3 * x] = (uint16_t)comp[0]; o[3 * x + 1] = (uint16_t)comp[1]; o[3 * x + 2] = (uint16_t)comp[2]; }
+		}
+	}
+}
+
+void orc_inv_spatial_to_rgb16_of_yuv422(PIXEL16 *const bands[3][4], const int band_pitch[3], int luma_w, int h, int precision, int display_height, int color_space, int b64a,
+                                        uint16_t *out, int out_pitch_words)
+{
+	const int W = 2 * luma_w;
+	uint16_t *yu = (uint16_t *)malloc((size_t)2 * h * W * 2 * sizeof(uint16_t));
+	orc_inv_spatial_to_yu64(bands, band_pitch, luma_w, h, precision, yu, W * 2);
+	orc_yu64_to_rgb16(yu, W * 2, W, display_height, color_space, b64a, out, out_pitch_words);
+	free(yu);
+}
+
+/* ---- 4:2:2 samples decoded to BGRA (bottom row first) / BGRa (top row first) (TestCFHD's BGRA -> 4:2:2 and BGRa -> 4:2:2 rows at full resolution) ----------------
+ * Traced: ReconstructSampleFrameYUV422ToBuffer -> TransformInverseSpatialThreadedYUV422ToBuffer -> InvertSpatial{Top,Middle,Bottom}Row16sToOutput (the vertical
+ * pass of every other last level) -> Codec/spatial.c:29577 InvertHorizontalStripYUV16sToPackedRGB32: the horizontal pass of the 8-bit 4:2:2 route WITHOUT dither (its
+ * rand() block is compiled out, :29737 `#if 0`) fused with an 8-bit colour conversion whose coefficients come from dither.c:264 ComputeColorCoefficientsYUVToRGB.
+ *   vector columns (band columns below post_column, :29640-29644): samples clamped to [0, 255] (luma after its offset), Y << 7 mulhi 128 * 149 << 1, chroma
+ *     products in wrapping 16-bit arithmetic shifted to six fraction bits, + 32 >> 6, packus (:30440-30520);
+ *   scalar columns (the rest, :30839-31180): no clamp of the samples, Y * ymult >> 7, seven / eight fraction bits, SATURATE_8U.
+ * Every chroma sample serves two pixels.  Bytes B, G, R, 255.  The pyramid carries the bias of decoder.c:12268 / :12479 (24; odd lowpass widths: 5, and for the
+ * bottom-up format -3 / +1 / +1 by channel, :12500-12508): the caller applies it. */
+void orc_inv_spatial_to_rgb32_of_yuv422(PIXEL16 *const bands[3][4], const int band_pitch[3], int luma_w, int h, int precision, int display_height, int color_space,
+                                        int bottom_up, uint8_t *out, int out_pitch_bytes)
+{
+	const int is601 = color_space == 1, shift = precision - 8;
+	const int ymult = 128 * 149, r_vmult = is601 ? 204 : 230, g_vmult = is601 ? 208 : 137, g_umult = is601 ? 100 : 55, b_umult = is601 ? 129 : 135, luma_offset = 16;
+	int post_column = luma_w - (luma_w % 16), ch, r, k, x;
+	PIXEL16 *el = (PIXEL16 *)malloc((size_t)luma_w * 2), *ol = (PIXEL16 *)malloc((size_t)luma_w * 2);
+	PIXEL16 *eh = (PIXEL16 *)malloc((size_t)luma_w * 2), *oh = (PIXEL16 *)malloc((size_t)luma_w * 2);
+	int *px[3][2];
+	while (post_column > luma_w - 2 - 2) post_column -= 16;
+	for (ch = 0; ch < 3; ch++) for (k = 0; k < 2; k++) px[ch][k] = (int *)malloc((size_t)luma_w * 2 * sizeof(int));
+	for (r = 0; r < h; r++) {
+		for (ch = 0; ch < 3; ch++) {
+			const int w = ch ? luma_w / 2 : luma_w, bp = band_pitch[ch];
+			inv_vertical_row(bands[ch][0], bp, bands[ch][2] + (size_t)r * bp, r, h, w, el, ol);
+			inv_vertical_row(bands[ch][1], bp, bands[ch][3] + (size_t)r * bp, r, h, w, eh, oh);
+			inv_horizontal_row_prepack(el, eh, w, px[ch][0]);
+			inv_horizontal_row_prepack(ol, oh, w, px[ch][1]);
+		}
+		for (k = 0; k < 2; k++) {
+			const int row = 2 * r + k;
+			uint8_t *o;
+			if (row >= display_height) continue;
+			o = out + (size_t)(bottom_up ? display_height - 1 - row : row) * out_pitch_bytes;
+			for (x = 0; x < 2 * luma_w; x++) {
+				/* samples before the colour conversion: (value before the last >> 1) >> 1 >> shift; channel 1 = V, channel 2 = U; chroma sample x / 2 */
+				const int ys = (px[0][k][x] >> 1) >> shift, vs = (px[1][k][x >> 1] >> 1) >> shift, us = (px[2][k][x >> 1] >> 1) >> shift;
+				int rr, gg, bb;
+				if ((x >> 1) < post_column) {
+					int yy = ys - luma_offset, uu = us, vv = vs, t;
+					yy = yy < 0 ? 0 : (yy > 255 ? 255 : yy); uu = (uu < 0 ? 0 : (uu > 255 ? 255 : uu)) - 128; vv = (vv < 0 ? 0 : (vv > 255 ? 255 : vv)) - 128;
+					yy = wrap16(mulhi16(wrap16(yy << 7), ymult) << 1);
+					t = wrap16(vv * r_vmult) >> 1; rr = sat16(sat16(yy + t) + 32) >> 6;
+					t = wrap16(vv * g_vmult) >> 2; gg = sat16(yy - t); t = wrap16(uu * g_umult) >> 2; gg = sat16(gg - t); gg = sat16(gg + 32) >> 6;
+					t = wrap16(uu * b_umult); bb = sat16(sat16(yy + t) + 32) >> 6;
+				} else {
+					const int yy = ((ys - luma_offset) * ymult) >> 7, uu = us - 128, vv = vs - 128;
+					rr = (yy + r_vmult * vv + 64) >> 7;
+					gg = (yy * 2 - g_umult * uu - g_vmult * vv + 128) >> 8;
+					bb = (yy + 2 * b_umult * uu + 64) >> 7;
+				}
+				o[4 * x] = (uint8_t)(bb < 0 ? 0 : (bb > 255 ? 255 : bb)); o[4 * x + 1] = (uint8_t)(gg < 0 ? 0 : (gg > 255 ? 255 : gg));
+				o[4 * x + 2] = (uint8_t)(rr < 0 ? 0 : (rr > 255 ? 255 : rr)); o[4 * x + 3] = 255;
+			}
+		}
+	}
+	for (ch = 0; ch < 3; ch++) for (k = 0; k < 2; k++) free(px[ch][k]);
+	free(el); free(ol); free(eh); free(oh);
+}
+
 /* One plane's last-level reconstruction BEFORE the final >> 1 (v = lowfilter +/- high): the value the reference's output routines start
  * from; probes of further output formats are fitted on it (tests only). */
 void orc_inv_spatial_prepack(PIXEL16 *const bands[4], int band_pitch, int w, int h, int32_t *out, int out_pitch)

@@ -354,6 +354,10 @@ def product_emulated():
             _build_once(EMU_PRODUCT_SO, ["g++", "-O1", "-w", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + hipemu, "-I" + csrc, "-I" + os.path.join(ROOT, "include")] + srcs, deps)
             for f in srcs:
                 if f.startswith(gen): os.replace(f, os.path.join(gen, os.path.basename(f).split(".")[0] + ".cpp"))      # (kept for reading: what the compiler saw)
+        # Four emulated GPUs with separate, protected heaps (tests/hipemu/hip/hip_runtime.h): an unpinned process deals its pool workers and decoder handles over all
+        # of them (cfhd_core.h unit_device), so every pool / handle test of the emulated suite is a several-device run in which a pointer, a stream or an event that
+        # crosses devices -- or host code that dereferences device memory -- ends the test loudly.  (Read when the library makes its first HIP call.)
+        os.environ.setdefault("HIPEMU_DEVICES", "4")
         L = ctypes.CDLL(EMU_PRODUCT_SO)
         declare_cfhd_api(L)
         _emu_product = L
@@ -1257,6 +1261,44 @@ def oracle_inverse_rgb24_of_yuv422(plan, coeffs, d, color_space=2):
     w = plan.band[(0, 0, 0)]["width"]; h = plan.band[(0, 0, 0)]["height"]
     out = np.zeros((plan.height, 2 * w * 3), np.uint8)
     O.orc_inv_spatial_to_rgb24_of_yuv422(ptrs, iarr(pitches), w, h, plan.precision, plan.height, color_space, d, out.ctypes.data_as(ctypes.c_void_p), out.shape[1])
+    return out
+
+
+def _oracle_levels_3_2_of_yuv422(plan, coeffs):
+    """The upper two inverse levels of a 4:2:2 pyramid with the oracle; returns (work pyramid, band pointers of level 1, pitches, band width, band height)."""
+    O = oracle()
+    work = coeffs.copy()
+    for c in range(3):
+        for lv in (2, 1):
+            dsc = plan.band[(c, lv, 0)]
+            bands = (c_i16p * 4)(*[plan.view(work, c, lv, b).ctypes.data_as(c_i16p) for b in range(4)])
+            dst = plan.view(work, c, lv - 1, 0)
+            O.orc_inv_spatial(bands, dsc["pitch"], dsc["width"], dsc["height"], plan.prescale[lv], dst.ctypes.data_as(c_i16p), plan.band[(c, lv - 1, 0)]["pitch"])
+    ptrs = (c_i16p * 12)(*[plan.view(work, c, 0, b).ctypes.data_as(c_i16p) for c in range(3) for b in range(4)])
+    return work, ptrs, [plan.band[(c, 0, 0)]["pitch"] for c in range(3)], plan.band[(0, 0, 0)]["width"], plan.band[(0, 0, 0)]["height"]
+
+
+def oracle_inverse_rgb16_of_yuv422(plan, coeffs, b64a, color_space=2):
+    """Whole inverse path with the oracle from a dequantized 4:2:2 pyramid (Plan(..., pixkind=PIXKIND["RG48"] or ["b64a"], enc=ENC["422"]): lowpass bias 24 / 5) to
+    RG48 words (R, G, B) or b64a words (0xffff, R, G, B): orc_inv_spatial_to_rgb16_of_yuv422, pinned on the reference decoder."""
+    O = oracle()
+    O.orc_inv_spatial_to_rgb16_of_yuv422.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 6 + [ctypes.c_void_p, ctypes.c_int]
+    work, ptrs, pitches, w, h = _oracle_levels_3_2_of_yuv422(plan, coeffs)
+    nw = 4 if b64a else 3
+    out = np.zeros((plan.height, 2 * w * nw), np.uint16)
+    O.orc_inv_spatial_to_rgb16_of_yuv422(ptrs, iarr(pitches), w, h, plan.precision, plan.height, color_space, int(bool(b64a)), out.ctypes.data_as(ctypes.c_void_p), out.shape[1])
+    return out
+
+
+def oracle_inverse_rgb32_of_yuv422(plan, coeffs, bottom_up, color_space=2):
+    """Whole inverse path with the oracle from a dequantized 4:2:2 pyramid (Plan(..., pixkind=PIXKIND["BGRA"] or ["BGRa"], enc=ENC["422"]): the bias of these outputs,
+    which for odd lowpass widths differs between the two) to bytes B, G, R, 255 -- BGRA: bottom row first, BGRa: top row first: orc_inv_spatial_to_rgb32_of_yuv422,
+    pinned on the reference decoder (no dither on this route)."""
+    O = oracle()
+    O.orc_inv_spatial_to_rgb32_of_yuv422.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 6 + [ctypes.c_void_p, ctypes.c_int]
+    work, ptrs, pitches, w, h = _oracle_levels_3_2_of_yuv422(plan, coeffs)
+    out = np.zeros((plan.height, 2 * w * 4), np.uint8)
+    O.orc_inv_spatial_to_rgb32_of_yuv422(ptrs, iarr(pitches), w, h, plan.precision, plan.height, color_space, int(bool(bottom_up)), out.ctypes.data_as(ctypes.c_void_p), out.shape[1])
     return out
 
 

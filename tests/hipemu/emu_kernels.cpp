@@ -388,10 +388,19 @@ int emu_fwd_yuv422_strip(const uint8_t *in, int in_pitch, int width, int height,
 	return 0;
 }
 
+void emu_inv_plane_ex(const int16_t *ll, const int16_t *lh, const int16_t *hl, const int16_t *hh, int band_pitch, int w, int h, int descale,
+                      int16_t *out, int out_pitch, int ll_bottom_row_high);
 void emu_inv_plane(const int16_t *ll, const int16_t *lh, const int16_t *hl, const int16_t *hh, int band_pitch, int w, int h, int descale,
                    int16_t *out, int out_pitch)
 {
-	InvPlaneJob job;
+	emu_inv_plane_ex(ll, lh, hl, hh, band_pitch, w, h, descale, out, out_pitch, 0);
+}
+// ll_bottom_row_high: the wavelets of a two-frame group that the reference sends through InvertSpatialQuantOverflowProtected16s (InvPlaneJob::ll_bottom_row_high)
+void emu_inv_plane_ex(const int16_t *ll, const int16_t *lh, const int16_t *hl, const int16_t *hh, int band_pitch, int w, int h, int descale,
+                      int16_t *out, int out_pitch, int ll_bottom_row_high)
+{
+	InvPlaneJob job = {};
+	job.ll_bottom_row_high = ll_bottom_row_high;
 	job.band[0] = ll; job.band[1] = lh; job.band[2] = hl; job.band[3] = hh; job.band_pitch = band_pitch;
 	job.width = w; job.height = h; job.descale = descale; job.out = out; job.out_pitch = out_pitch;
 	job.xstride = 1; job.precision = 0; job.display_height = 2 * h;

@@ -45,3 +45,12 @@ def test_no_test_infrastructure_in_the_product_library():
     assert not bad, bad
     undocumented = sorted(n for n in exp if n.startswith(("CFHD_", "cfhd_amd_")) and n not in declared_functions())
     assert not undocumented, "exported but not declared in the header: %s" % undocumented
+
+
+def test_library_exports_exactly_the_declared_c_abi():
+    """cineform-sdk_amd/exports.map: nothing but the CFHD_* / cfhd_amd_* entry points leaves the library -- no mangled C++ (cfhd::EncodeBatch::...), no kernel host
+    stubs (__device_stub__k_*), no data symbols: a drop-in for libCFHDCodec does not leak its object model."""
+    out = subprocess.check_output(["nm", "-D", "--defined-only", LIB], text=True)
+    names = {line.split()[-1] for line in out.splitlines() if line.strip()}
+    extra = sorted(n for n in names if n not in declared_functions())
+    assert not extra, "exported beyond the C ABI: %s" % extra[:20]

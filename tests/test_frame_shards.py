@@ -120,3 +120,77 @@ def test_two_ranks_gloo_sharded_group_encode_equals_unsharded():
     merged = {}
     for part in gathered: merged.update(part)
     assert merged == _encode_groups(range(1, TOTAL + 2))
+
+
+def _product_samples(frame_numbers):
+    """The frames with these (1-based) numbers through the PRODUCT's batched path -- the emulated build of the whole library (tests/cfhd_testlib.py product_emulated:
+    C ABI, batch front end, job tables, unmodified kernels on the CPU) -- as bench.py drives it per rank: one batch of the rank's shard, one pass.  Returns
+    {frame number: hash of its sample with the per-encoder counters (frame number, unique frame number) and the volatile metadata zeroed}."""
+    import ctypes, struct
+    import cfhd_testlib as T
+    numbers = list(frame_numbers)
+    out = {}
+    with T.emulated_product() as L:
+        L.cfhd_amd_batch_create.restype = ctypes.c_void_p
+        L.cfhd_amd_batch_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.cfhd_amd_batch_upload.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+        L.cfhd_amd_batch_roundtrip.restype = ctypes.c_longlong; L.cfhd_amd_batch_roundtrip.argtypes = [ctypes.c_void_p]
+        L.cfhd_amd_batch_get_sample.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
+        L.cfhd_amd_batch_destroy.argtypes = [ctypes.c_void_p]
+        L.cfhd_amd_device_count.restype = ctypes.c_int
+        b = L.cfhd_amd_batch_create(W, H, T.PIX_YUY2, T.QUALITY_FILMSCAN1, len(numbers), 1)
+        assert b, T.amd_last_error()
+        for i, n in enumerate(numbers):
+            frame, pitch = T.synth_yuy2(W, H, 1000 + n)
+            assert L.cfhd_amd_batch_upload(b, i, frame.ctypes.data_as(ctypes.c_void_p), pitch) == 0
+        assert L.cfhd_amd_batch_roundtrip(b) > 0, T.amd_last_error()
+        for i, n in enumerate(numbers):
+            p = ctypes.c_void_p(); sz = ctypes.c_size_t()
+            assert L.cfhd_amd_batch_get_sample(b, i, ctypes.byref(p), ctypes.byref(sz)) == 0
+            s = bytearray(T.mask_volatile_metadata(ctypes.string_at(p, sz.value)))
+            k = bytes(s[:160]).find(struct.pack(">h", -69)); s[k + 2:k + 4] = b"\0\0"
+            u = bytes(s[:1024]).find(b"UFRM"); s[u + 8:u + 12] = b"\0\0\0\0"
+            out[n] = hashlib.sha256(bytes(s)).hexdigest()
+        L.cfhd_amd_batch_destroy(b)
+        ndev = L.cfhd_amd_device_count()
+    return out, ndev
+
+
+def _worker_product(rank, world, port, q):
+    """One process per GPU as bench.py launches them: LOCAL_RANK pins the process to its own (emulated) device, the rank runs its shard through the product."""
+    os.environ["LOCAL_RANK"] = str(rank); os.environ["HIPEMU_DEVICES"] = str(world)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    S = _shards()
+    mine, ndev = _product_samples(S.frame_numbers(TOTAL, rank, world))
+    dist.barrier()
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (mine, ndev))
+    if rank == 0: q.put(gathered)
+    dist.destroy_process_group()
+
+
+def test_two_ranks_gloo_product_batches_on_their_own_devices_equal_the_unsharded_run():
+    """The product's own bookkeeping under the launch bench.py gets for N > 1: two processes, each pinned by LOCAL_RANK to its own emulated GPU (separate, protected
+    heaps: tests/hipemu/hip/hip_runtime.h), each encoding + decoding its contiguous shard with cfhd_amd_batch_roundtrip; the samples, gathered over gloo, equal those
+    of one process running the whole sequence."""
+    import torch.multiprocessing as mp
+    import cfhd_testlib as T
+    if not T.have_ref(): pytest.skip("reference .so not built (the emulated product build is made beside it)")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    T.product_emulated()                              # (built once here, not by two workers at the same time)
+    procs = [ctx.Process(target=_worker_product, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    gathered = q.get(timeout=300)
+    for p in procs:
+        p.join(120); assert p.exitcode == 0
+    merged = {}
+    for part, ndev in gathered:
+        assert ndev == 2
+        assert not (set(part) & set(merged)), "shards overlap"
+        merged.update(part)
+    whole, _ = _product_samples(range(1, TOTAL + 1))
+    assert merged == whole

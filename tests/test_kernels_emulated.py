@@ -101,6 +101,25 @@ def test_inv_plane(w, h, descale):
     assert np.array_equal(e[:, :2 * w], o)
 
 
+@pytest.mark.parametrize("w,h", [(8, 4), (45, 17), (64, 16), (130, 18), (66, 33), (129, 34), (40, 5), (3, 3)])
+def test_inv_plane_with_the_reference_group_decoders_last_row(w, h):
+    """k_inv_plane with InvPlaneJob::ll_bottom_row_high = the oracle's restatement of the reference's InvertSpatialQuantOverflowProtected16s (Codec/spatial.c:21114: the
+    routine its group decoder runs for the unprescaled wavelets, whose last coefficient row reads the LL band one row too high) -- last tiles of one, two and more rows,
+    a band of three rows (too short for the shift: the plain filter)."""
+    rng = np.random.default_rng(w * 7 + h)
+    pitch = (w + 7) // 8 * 8
+    b = [np.zeros((h, pitch), np.int16) for _ in range(4)]
+    b[0][:, :w] = rand_plane(rng, w, h, 13)
+    for k in range(1, 4): b[k][:, :w] = rand_plane(rng, w, h, 11, signed=True)
+    o = np.zeros((2 * h, 2 * w), np.int16); e = np.zeros((2 * h, 2 * pitch), np.int16); plain = np.zeros((2 * h, 2 * w), np.int16)
+    bands = (c_i16p * 4)(*[p16(a) for a in b])
+    oracle().orc_inv_spatial_overflow_protected(bands, pitch, w, h, p16(o), 2 * w)
+    oracle().orc_inv_spatial(bands, pitch, w, h, 0, p16(plain), 2 * w)
+    emu().emu_inv_plane_ex(p16(b[0]), p16(b[1]), p16(b[2]), p16(b[3]), pitch, w, h, 0, p16(e), 2 * pitch, 1)
+    assert np.array_equal(e[:, :2 * w], o)
+    assert np.array_equal(o[:-2], plain[:-2]) and (h < 4 or not np.array_equal(o[-2:], plain[-2:]))      # only the last coefficient row differs from the filter as meant
+
+
 @pytest.mark.parametrize("w,rows,b64a", [(8, 2, 0), (160, 3, 1), (960, 2, 0), (2056, 2, 1)])
 def test_half_resolution_output_kernel_16bit(w, rows, b64a):
     """k_half_packed16 = the model of the reference's half-resolution RG48 / b64a output (pinned in tests/test_oracle_vs_ref.py)."""

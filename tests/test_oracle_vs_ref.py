@@ -609,3 +609,55 @@ def test_reference_interlaced_decode_lies_in_oracle_dither_interval(w, h, fmt, k
     assert ok.all(), "%d bytes outside" % (~ok).sum()
     src = np.asarray(frame).reshape(h, pitch)[:, : w * 2]
     assert psnr_yuy2(rimg, src) > 30
+
+
+# ---- the last four decode rows of TestCFHD's table: BGRA / BGRa / RG48 / b64a from 4:2:2 samples (full resolution) --------------------------------------------
+def _yuv422_sample_for_rgb_outputs(w, h, seed, flags=0):
+    """A reference 4:2:2 sample whose picture runs into both clips of the colour conversion: the synthetic frame with a band of saturated colours and ramps."""
+    f, p = synth_yuy2(w, h, seed)
+    v = f.reshape(h, p)
+    v[: h // 6, 0::2] = np.linspace(0, 255, w).astype(np.uint8)[None, :]              # luma ramp over neutral-ish chroma
+    v[h // 6: h // 3, 1::4] = 255; v[h // 6: h // 3, 3::4] = 0                             # saturated chroma pair
+    v[h // 3: h // 2, 1::4] = 0; v[h // 3: h // 2, 3::4] = 255
+    return ref_encode_frames([f], p, w, h, flags=flags)[0]
+
+
+@pytest.mark.parametrize("w,h,name,flags", [(320, 240, "RG48", 0), (336, 252, "b64a", 0), (720, 486, "RG48", 4), (1920, 1080, "b64a", 0), (400, 120, "RG48", 0), (1280, 720, "b64a", 4),
+                                            (144, 90, "RG48", 0), (2048, 858, "RG48", 0)])
+def test_reference_rg48_and_b64a_decode_of_yuv422_equals_oracle(w, h, name, flags):
+    """Pins orc_inv_spatial_to_rgb16_of_yuv422 (the route traced on the instrumented reference: the planes as 16-bit rows, bayer.c:11916 Row16uFull2OutputFormat,
+    RGB2YUV.c:1308 + :1760, bayer.c:478): the reference decodes a 4:2:2 sample to RG48 / b64a deterministically -- word for word, 709 and 601 (flags 4), odd lowpass
+    widths, heights that are not multiples of 8, clips at both ends."""
+    if w % 16:
+        pytest.skip("the oracle restates the vector body of the conversion: widths that are multiples of 16 (what the codec's 4:2:2 widths are)")
+    sample = _yuv422_sample_for_rgb_outputs(w, h, w + h, flags)
+    b64a = name == "b64a"
+    plan = Plan(w, h, pixkind=PIXKIND[name], enc=ENC["422"])
+    mine = oracle_inverse_rgb16_of_yuv422(plan, host_decode_pyramid(sample, plan), b64a, 1 if flags & 4 else 2)[:h]
+    nw = 4 if b64a else 3
+    rows = h if h % 8 == 0 else h - 8
+    for attempt in range(6):
+        dec, dpitch = ref_decode_sample(sample, w, h, fourcc(name))
+        img = np.frombuffer(dec.tobytes(), np.uint16).reshape(h, dpitch // 2)[:, : w * nw]
+        if np.array_equal(mine[:rows], img[:rows]): break
+    bad = np.argwhere(mine[:rows] != img[:rows])
+    assert len(bad) == 0, (len(bad), bad[:6].tolist(), [(int(mine[r, c]), int(img[r, c])) for r, c in bad[:6]])
+
+
+@pytest.mark.parametrize("w,h,name,flags", [(320, 240, "BGRa", 0), (336, 252, "BGRA", 0), (336, 252, "BGRa", 0), (720, 486, "BGRA", 4), (1920, 1080, "BGRA", 0), (400, 120, "BGRa", 0),
+                                            (1280, 720, "BGRa", 4), (144, 90, "BGRA", 0), (720, 480, "BGRA", 0)])
+def test_reference_bgra_decode_of_yuv422_equals_oracle(w, h, name, flags):
+    """Pins orc_inv_spatial_to_rgb32_of_yuv422 (Codec/spatial.c:29577 InvertHorizontalStripYUV16sToPackedRGB32: vector columns and scalar tail columns restated
+    separately): the reference decodes a 4:2:2 sample to BGRA (bottom row first) / BGRa byte for byte -- no dither on this route; odd lowpass widths take different
+    biases for the two formats (decoder.c:12500-12508), 709 and 601, clips at both ends."""
+    sample = _yuv422_sample_for_rgb_outputs(w, h, w + h, flags)
+    plan = Plan(w, h, pixkind=PIXKIND[name], enc=ENC["422"])
+    mine = oracle_inverse_rgb32_of_yuv422(plan, host_decode_pyramid(sample, plan), name == "BGRA", 1 if flags & 4 else 2)[:h]
+    rows = h if h % 8 == 0 else h - 8
+    sl = slice(h - rows, h) if name == "BGRA" else slice(0, rows)       # (the picture's last display rows are not reproducible for such heights; bottom-up: they come first)
+    for attempt in range(6):
+        dec, dpitch = ref_decode_sample(sample, w, h, fourcc(name))
+        img = np.frombuffer(dec.tobytes(), np.uint8).reshape(-1, dpitch)[:h, : w * 4]
+        if np.array_equal(mine[sl], img[sl]): break
+    bad = np.argwhere(mine[sl] != img[sl])
+    assert len(bad) == 0, (len(bad), bad[:6].tolist(), [(int(mine[sl][r, c]), int(img[sl][r, c])) for r, c in bad[:6]])

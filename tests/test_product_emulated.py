@@ -17,9 +17,9 @@ pytestmark = pytest.mark.skipif(not have_ref(), reason="oracle/_ref/libcfhd_ref.
 # per case: frames x pixels up to this run by default (the whole file in about two minutes on one core); CFHD_EMU_MAX_PIXELS=2088960 adds the 1080p cases (seven minutes more)
 MAX_PIXELS = int(os.environ.get("CFHD_EMU_MAX_PIXELS", 720 * 486))
 # not for the emulation: launch sizes made for the hardware (bench-size batches, 8K, forced shapes over dozens of 1080p / 4K frames), the reference's harness
-# binary (links libcfhd_amd.so itself) and the several-device pool (one emulated device)
+# binary (links libcfhd_amd.so itself)
 SKIP = {"test_batched_round_trip_at_bench_sizes_equals_reference", "test_b64a_8k_config_c_round_trip", "test_reference_harness_links_unchanged_and_prints_same_numbers",
-        "test_encoder_pool_and_decoders_over_several_devices_keep_order_and_bytes", "test_yuy2_4k_two_segments"}
+        "test_yuy2_4k_two_segments"}
 # always: the register-strip kernels bench.py times, forced on the smallest batches of the GPU suite (their job tables and launch shapes come from the product)
 ALWAYS = {("test_yuv422_strip_kernels_equal_reference", 1952, 250), ("test_packed16_strip_kernels_equal_reference", 1016, 304), ("test_packed16_strip_kernels_equal_reference", 504, 242),
           ("test_packed16_strip_kernels_equal_reference", 136, 120)}
