@@ -1027,8 +1027,12 @@ CFHD_Error CFHD_PrepareToDecode(CFHD_DecoderRef ref, int, int, CFHD_PixelFormat 
 	const bool rgba8 = (kind == PIX_BGRA || kind == PIX_BGRa) && encf == ENC_RGBA4444;
 	// ... and 4:2:2 samples to RG24: the YU64 rows through the reference's scalar colour conversion with its 15-bit dither (DecodeBatch / k_yu64_to_rgb24)
 	const bool rgb24_of_422 = kind == PIX_RG24 && encf == ENC_YUV422 && d->header.width >= 128;      // (half resolution: frame.c:8504, k_half_rgb24)
+	// ... and 4:2:2 samples to BGRA / BGRa (the reference's fused horizontal pass + 8-bit colour conversion, spatial.c:29577: k_inv_yuv422_rgb32) and to RG48 / b64a (its
+	// 16-bit rows + RGB2YUV.c:1760: k_yu64_to_rgb16) -- the last four rows of TestCFHD's table; full resolution, progressive
+	const bool rgb32_of_422 = (kind == PIX_BGRA || kind == PIX_BGRa) && encf == ENC_YUV422 && !half && d->header.width >= 32;
+	const bool rgb16_of_422 = (kind == PIX_RG48 || kind == PIX_B64A) && encf == ENC_YUV422 && !half && d->header.width >= 128;
 	// (half resolution -- frame.c:7150 ConvertLowpassRGB444ToRGB -- for the outputs of RGB 4:4:4 samples: 8-bit, 10-bit, b64a; k_half_rgb)
-	if (rgb8 && ((encf != ENC_RGB444 && !rgba8 && !rgb24_of_422) || (half && encf != ENC_RGB444 && !rgba8 && !rgb24_of_422) || d->header.width < 32)) return ERR_BADFORMAT;
+	if (rgb8 && ((encf != ENC_RGB444 && !rgba8 && !rgb24_of_422 && !rgb32_of_422) || (half && encf != ENC_RGB444 && !rgba8 && !rgb24_of_422) || d->header.width < 32)) return ERR_BADFORMAT;
 	// ... and to the 10-bit RGB words r210 / DPX0 / AB10 / AR10 ((value before the final >> 1, + 3) >> 3 per component: a model fitted on the reference
 	// decoder and pinned word for word on the CPU, equal to the reference decoder on the GPU)
 	const bool rgb10 = kind >= PIX_R210 && kind <= PIX_AR10;
@@ -1044,7 +1048,9 @@ CFHD_Error CFHD_PrepareToDecode(CFHD_DecoderRef ref, int, int, CFHD_PixelFormat 
 	const bool b64a_of_444 = kind == PIX_B64A && encf == ENC_RGB444;
 	// ... and RGBA 4:4:4:4 samples to RG48 (the RG48 route on planes G, R, B, the alpha plane left behind; full and half resolution)
 	const bool rg48_of_4444 = kind == PIX_RG48 && encf == ENC_RGBA4444;
-	if ((encf == ENC_RGB444) != ((kind == PIX_RG48 && !rg48_of_4444) || (rgb8 && !rgba8 && !rgb24_of_422) || rgb10 || b64a_of_444) || (encf == ENC_RGBA4444) != ((kind == PIX_B64A && !b64a_of_444) || rgba8 || rg48_of_4444)) return ERR_BADFORMAT;
+	if ((kind == PIX_RG48 || kind == PIX_B64A) && encf == ENC_YUV422 && !rgb16_of_422) return ERR_BADFORMAT;
+	if ((encf == ENC_RGB444) != ((kind == PIX_RG48 && !rg48_of_4444 && !rgb16_of_422) || (rgb8 && !rgba8 && !rgb24_of_422 && !rgb32_of_422) || rgb10 || b64a_of_444) ||
+	    (encf == ENC_RGBA4444) != ((kind == PIX_B64A && !b64a_of_444 && !rgb16_of_422) || rgba8 || rg48_of_4444)) return ERR_BADFORMAT;
 	if (kind == PIX_YU64 && d->header.width < 128) return ERR_BADFORMAT;      // (the tail-column rule of the 16-bit rows is restated for chroma bands of 16 columns and more)
 	bool ok;
 	plan_from_sample(d->header, kind, &d->plan, &ok);

@@ -130,6 +130,8 @@ private:
 	void *stream2_ = nullptr, *ev2_[3] = {nullptr, nullptr, nullptr}; bool inv_split_ = false;
 	int lowpass_kind_ = 0;             // the output format as the lowpass bias rule sees it (lowpass_bias(): RG24 of a 4:2:2 sample is not YU64 there)
 	bool byr4_ = false; uint16_t *d_restore_ = nullptr;   // BYR4 output of Bayer samples: the four planes as 16-bit words per quad first, turned into the mosaic by k_bayer_to_byr4 (linear-restore table in HBM)
+	bool rgb16_of_422_ = false, rgb16_b64a_ = false;   // RG48 / b64a output of 4:2:2 samples: YU64 rows first, converted by k_yu64_to_rgb16 (bayer.c:11916 + RGB2YUV.c:1760)
+	bool rgb32_of_422_ = false;        // BGRA / BGRa output of 4:2:2 samples: the last level as k_inv_yuv422_rgb32 (spatial.c:29577)
 	bool rgb24_of_422_ = false;        // RG24 output of 4:2:2 samples: YU64 rows first, converted by k_yu64_to_rgb24 (the reference's route: 16-bit rows, then colour conversion)
 	std::vector<char> direct_;                      // frame i went straight to the caller's (registered) buffer: finish_frame has nothing to copy
 	void *d_jobs_ = nullptr, *h_jobs_ = nullptr; size_t jobs_bytes_ = 0;

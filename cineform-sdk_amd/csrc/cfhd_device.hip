@@ -688,13 +688,20 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 	if (rgb24_of_422_) { if (!own_output) { g_err = "RG24 output of 4:2:2 samples: into the library's own output frames"; return -2; } if (!half) out_kind = PIX_YU64; }
 	const bool rgb24_half = rgb24_of_422_ && half;      // (half resolution: k_half_rgb24 straight from the lowpass planes, no scratch frame)
 	if (rgb24_half) rgb24_of_422_ = false;
+	// RG48 / b64a output of 4:2:2 samples (bayer.c:11916 Row16uFull2OutputFormat: the 16-bit rows through RGB2YUV.c:1308 / :1760): the YU64 route into the scratch frame,
+	// then k_yu64_to_rgb16.  BGRA / BGRa output of 4:2:2 samples: the last level with the reference's fused colour conversion (k_inv_yuv422_rgb32).
+	rgb16_of_422_ = (out_kind == PIX_RG48 || out_kind == PIX_B64A) && plan.encoded_format == ENC_YUV422; rgb16_b64a_ = out_kind == PIX_B64A;
+	const int final_kind = out_kind;
+	if (rgb16_of_422_) { if (!own_output || half) { g_err = "RG48 / b64a output of 4:2:2 samples: full resolution, into the library's own output frames"; return -2; } out_kind = PIX_YU64; }
+	rgb32_of_422_ = (out_kind == PIX_BGRA || out_kind == PIX_BGRa) && plan.encoded_format == ENC_YUV422;
+	if (rgb32_of_422_ && (!own_output || half)) { g_err = "BGRA / BGRa output of 4:2:2 samples: full resolution, into the library's own output frames"; return -2; }
 	// BYR4 output of Bayer samples (decoder.c:14738 + bayer.c:13233 GenerateBYR2): the four component planes as 16-bit rows -- the RG48 route with four planes,
 	// four words per photosite quad -- then k_bayer_to_byr4
 	byr4_ = out_kind == PIX_BYR4;
 	if (byr4_) { if (plan.encoded_format != ENC_BAYER || !own_output || half) { g_err = "BYR4 output: Bayer samples, full resolution"; return -2; } out_kind = PIX_RG48; }
-	const bool repack = v210_ || rgb24_of_422_ || byr4_;
+	const bool repack = v210_ || rgb24_of_422_ || byr4_ || rgb16_of_422_;
 
-	const bool yuv_ok = (out_kind == PIX_YUY2 || out_kind == PIX_2VUY) && plan.encoded_format == ENC_YUV422;
+	const bool yuv_ok = (out_kind == PIX_YUY2 || out_kind == PIX_2VUY || rgb32_of_422_) && plan.encoded_format == ENC_YUV422;
 	// (b64a from an RGB 4:4:4 sample: the three colour planes and a constant alpha word, full resolution)
 	const bool rgb_ok = ((out_kind == PIX_RG48 && plan.encoded_format == ENC_RGB444) || (out_kind == PIX_B64A && plan.encoded_format == ENC_RGBA4444) ||
 	                     (out_kind == PIX_B64A && plan.encoded_format == ENC_RGB444) || (out_kind == PIX_RG48 && plan.encoded_format == ENC_RGBA4444) || byr4_) &&
@@ -723,7 +730,7 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 			build_bayer_linear_restore_curve(curve.data());
 			HIPCHK(hipMalloc((void **)&d_restore_, curve.size() * 2));
 			HIPCHK(hipMemcpy(d_restore_, curve.data(), curve.size() * 2, hipMemcpyHostToDevice));
-		} else out_pitch_ = packed_frame_pitch(v210_ ? PIX_V210 : PIX_RG24, half ? plan.width / 2 : plan.width);
+		} else out_pitch_ = packed_frame_pitch(v210_ ? PIX_V210 : (rgb16_of_422_ ? final_kind : PIX_RG24), half ? plan.width / 2 : plan.width);
 		frame_bytes_ = (size_t)out_pitch_ * out_rows_;
 	}
 	if (own_output) {
@@ -788,7 +795,7 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 			hj.out = own_output ? job_out + job_frame_bytes * i : nullptr; hj.out_pitch = job_pitch;      // (v210 output: the scratch frame k_yu64_to_v210 reads)
 			continue;
 		}
-		if (dec_planes16(out_kind)) {
+		if (dec_planes16(out_kind) && !rgb32_of_422_) {
 			for (int c = 0; c < onch; c++) {
 				dev::InvPlaneJob &p = j.l1[(size_t)i * onch + c];
 				for (int b = 0; b < 4; b++) p.band[b] = base + plan.ch[c].band[0][b].offset;
@@ -816,6 +823,7 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 		y.width = plan.ch[0].band[0][0].width; y.height = plan.ch[0].band[0][0].height; y.display_height = plan.display_height;
 		y.uyvy = out_kind == PIX_2VUY; y.shift = plan.precision - 8; y.dither_seed = 0x9E3779B9u * (uint32_t)(i + 1);
 		y.out = own_output ? d_out_ + frame_bytes_ * i : nullptr; y.out_pitch = out_pitch_;
+		y.bottom_up = out_kind == PIX_BGRA; y.matrix_601 = plan.color_matrix >= 2;       // (k_inv_yuv422_rgb32)
 	}
 	jobs_dirty_ = true;
 	return 0;
@@ -981,6 +989,10 @@ int DecodeBatch::launch_inverse(uint32_t dither_seed)
 		const int nseg = (b.width / 4 + dev::PSTEP - 1) / dev::PSTEP, nstrips = (b.height + dev::QSR - 1) / dev::QSR, waves = act * nseg * nstrips;
 		if (dec_out_channels(out_kind_, plan_) == 4) dev::k_inv_packed16_strip<4><<<(waves + 3) / 4, dev::NTHREADS, 0, st>>>(j.l1, act, nseg, nstrips);
 		else dev::k_inv_packed16_strip<3><<<(waves + 3) / 4, dev::NTHREADS, 0, st>>>(j.l1, act, nseg, nstrips);
+	} else if (rgb32_of_422_) {
+		const BandDesc &b = plan_.ch[0].band[0][0];
+		dim3 grid((b.width + dev::ITW - 1) / dev::ITW, (b.height + dev::ITH - 1) / dev::ITH, act);
+		dev::k_inv_yuv422_rgb32<<<grid, dev::NTHREADS, 0, st>>>(j.yuv);
 	} else if (dec_planes16(out_kind_)) {
 		const BandDesc &b = plan_.ch[0].band[0][0];
 		dim3 grid((b.width + dev::ITW - 1) / dev::ITW, (b.height + dev::ITH - 1) / dev::ITH, act);      // one workgroup per tile, all components
@@ -1003,6 +1015,11 @@ int DecodeBatch::launch_inverse(uint32_t dither_seed)
 		const int pairs = plan_.width / 2;
 		dev::k_yu64_to_rgb24<<<dim3((unsigned)((pairs + dev::NTHREADS - 1) / dev::NTHREADS), (unsigned)out_rows_, (unsigned)act), dev::NTHREADS, 0, st>>>(
 			(const uint16_t *)d_tmp_, tmp_pitch_ / 2, tmp_frame_bytes_ / 2, d_out_, out_pitch_, frame_bytes_, pairs, out_rows_, plan_.color_matrix, dither_seed);
+	}
+	if (rgb16_of_422_) {
+		const int pairs = plan_.width / 2;
+		dev::k_yu64_to_rgb16<<<dim3((unsigned)((pairs + dev::NTHREADS - 1) / dev::NTHREADS), (unsigned)out_rows_, (unsigned)act), dev::NTHREADS, 0, st>>>(
+			(const uint16_t *)d_tmp_, tmp_pitch_ / 2, tmp_frame_bytes_ / 2, (uint16_t *)d_out_, out_pitch_ / 2, frame_bytes_ / 2, pairs, plan_.color_matrix >= 2, rgb16_b64a_ ? 1 : 0);
 	}
 	if (byr4_) {
 		const int quads = plan_.width;

@@ -191,6 +191,10 @@ struct InvYuvJob {
 	int uyvy, shift;
 	uint32_t dither_seed;                   // per frame; the kernel xors in its launch-wide seed
 	uint8_t *out; int out_pitch;            // bytes
+	// k_inv_yuv422_rgb32: BGRA (bottom row first) / BGRa output of a 4:2:2 sample -- the reference's fused horizontal pass + 8-bit colour conversion
+	// (Codec/spatial.c:29577 InvertHorizontalStripYUV16sToPackedRGB32, restated in oracle/cfhd_oracle_inv.c orc_inv_spatial_to_rgb32_of_yuv422): no dither,
+	// matrix 601 or 709 (computer-systems range), bytes B, G, R, 255
+	int bottom_up, matrix_601;
 };
 
 struct HalfYuvJob {                         // k_half_yuv422: the level-1 lowpass planes as a half-resolution packed 8-bit 4:2:2 frame
@@ -947,7 +951,33 @@ __device__ __forceinline__ uint32_t to8(int v, int shift, int dither)
 }
 // pk_to8: the same on two 16-bit lanes (cfhd_gfx950.h)
 
-__global__ void __launch_bounds__(NTHREADS) k_inv_yuv422(const InvYuvJob *jobs, uint32_t launch_seed)
+// One pixel of the RGB32 output from the samples in front of the colour conversion (value before the last >> 1, >> 1, >> shift: ys, and the chroma samples of
+// its pixel pair).  vector: the band column lies in the part of the row the reference's SSE2 loop serves (samples clamped to 8 bits, 16-bit products with six
+// fraction bits); else its scalar tail (no clamp, seven / eight fraction bits).  Returns B | G << 8 | R << 16 | 255 << 24.
+__device__ __forceinline__ uint32_t yuv_to_bgra(int ys, int us, int vs, bool vector, int r_vmult, int g_vmult, int g_umult, int b_umult)
+{
+	const int ymult = 128 * 149, luma_offset = 16;
+	int rr, gg, bb;
+	if (vector) {
+		int yy = ys - luma_offset, uu = us, vv = vs, t;
+		yy = yy < 0 ? 0 : (yy > 255 ? 255 : yy); uu = (uu < 0 ? 0 : (uu > 255 ? 255 : uu)) - 128; vv = (vv < 0 ? 0 : (vv > 255 ? 255 : vv)) - 128;
+		yy = (int)(int16_t)((((int)(int16_t)(yy << 7) * ymult) >> 16) << 1);
+		t = (int)(int16_t)(vv * r_vmult) >> 1; rr = adds16(adds16(yy, t), 32) >> 6;
+		t = (int)(int16_t)(vv * g_vmult) >> 2; gg = subs16(yy, t); t = (int)(int16_t)(uu * g_umult) >> 2; gg = subs16(gg, t); gg = adds16(gg, 32) >> 6;
+		t = (int)(int16_t)(uu * b_umult); bb = adds16(adds16(yy, t), 32) >> 6;
+	} else {
+		const int yy = ((ys - luma_offset) * ymult) >> 7, uu = us - 128, vv = vs - 128;
+		rr = (yy + r_vmult * vv + 64) >> 7;
+		gg = (yy * 2 - g_umult * uu - g_vmult * vv + 128) >> 8;
+		bb = (yy + 2 * b_umult * uu + 64) >> 7;
+	}
+	rr = rr < 0 ? 0 : (rr > 255 ? 255 : rr); gg = gg < 0 ? 0 : (gg > 255 ? 255 : gg); bb = bb < 0 ? 0 : (bb > 255 ? 255 : bb);
+	return (uint32_t)bb | ((uint32_t)gg << 8) | ((uint32_t)rr << 16) | 0xff000000u;
+}
+
+// RGB32: the output stage writes four BGRA pixels per item instead of eight bytes of packed 4:2:2 (k_inv_yuv422_rgb32)
+template <bool RGB32>
+__device__ __forceinline__ void inv_yuv422_tile(const InvYuvJob *jobs, uint32_t launch_seed)
 {
 	const TileId tile = xcd_tile();
 	__shared__ InvYuvJob s_job;
@@ -1031,6 +1061,34 @@ __global__ void __launch_bounds__(NTHREADS) k_inv_yuv422(const InvYuvJob *jobs, 
 			const uint32_t cm = C[-1], cz = C[0], cp = C[1], chh = s_vc[par][1][rl][p + 2];
 			uint32_t ce, co;                              // (V, U): even output, odd output
 			inv_horiz_pk(cm, cz, cp, chh, ce, co);
+			if (RGB32) {
+				// the samples before the colour conversion, in 32 bits: value before the last >> 1 (border columns: the border taps), >> 1, >> shift, no dither
+				int yv[4] = { lo16(ye), lo16(yo), hi16(ye), hi16(yo) };                  // pixels 4 cc .. 4 cc + 3
+				int vv[2] = { lo16(ce), lo16(co) }, uv[2] = { hi16(ce), hi16(co) };        // chroma samples 2 cc, 2 cc + 1
+				const int c = 2 * cc;
+				if (c == 0 || c + 1 == w - 1) {
+					const int l[6] = { lo16(dm), hi16(dm), lo16(d0), hi16(d0), lo16(dp), hi16(dp) };
+					if (c == 0) inv_horiz_border(l, 2, lo16(yhh), 0, yv[0], yv[1]);
+					if (c + 1 == w - 1) inv_horiz_border(l, 3, hi16(yhh), 2, yv[2], yv[3]);
+				}
+				if (cc == 0 || cc == cw - 1) {
+					const int pos = cc == 0 ? 0 : 2;
+					const uint32_t far = pos == 0 ? C[2] : C[-2];
+					if (pos == 0) { inv_horiz(0, lo16(cz), lo16(cp), lo16(far), lo16(chh), 0, vv[0], vv[1]); inv_horiz(0, hi16(cz), hi16(cp), hi16(far), hi16(chh), 0, uv[0], uv[1]); }
+					else { inv_horiz(lo16(cm), lo16(cz), 0, lo16(far), lo16(chh), 2, vv[0], vv[1]); inv_horiz(hi16(cm), hi16(cz), 0, hi16(far), hi16(chh), 2, uv[0], uv[1]); }
+				}
+				int post_column = w - (w % 16);                     // band columns below it: the reference's vector loop (spatial.c:29640-29644)
+				while (post_column > w - 4) post_column -= 16;
+				const int r_vmult = job.matrix_601 ? 204 : 230, g_vmult = job.matrix_601 ? 208 : 137, g_umult = job.matrix_601 ? 100 : 55, b_umult = job.matrix_601 ? 129 : 135;
+				uint4 px;
+				uint32_t *pp = &px.x;
+#pragma unroll
+				for (int k = 0; k < 4; k++)
+					pp[k] = yuv_to_bgra((yv[k] >> 1) >> sh, (uv[k >> 1] >> 1) >> sh, (vv[k >> 1] >> 1) >> sh, c + (k >> 1) < post_column, r_vmult, g_vmult, g_umult, b_umult);
+				const int out_row = job.bottom_up ? job.display_height - 1 - orow : orow;
+				*(uint4 *)(job.out + (size_t)out_row * job.out_pitch + 16 * (size_t)cc) = px;
+				continue;
+			}
 			const uint32_t dz = sh >= 2 ? dither_word(seed, orow, cc >> 2) >> (8 * (cc & 3)) : 0u;    // one hash word per 4 chroma columns, one byte each
 			// 8-bit samples in 16-bit lanes: te = (y0, y2), to = (y1, y3), tce = (v0, u0), tco = (v1, u1)
 			uint32_t te = pk_to8(ye, sh, (dz & 1u) | ((dz << 14) & 0x10000u)), to = pk_to8(yo, sh, ((dz >> 1) & 1u) | ((dz << 13) & 0x10000u));
@@ -1068,6 +1126,8 @@ __global__ void __launch_bounds__(NTHREADS) k_inv_yuv422(const InvYuvJob *jobs, 
 		}
 	}
 }
+__global__ void __launch_bounds__(NTHREADS) k_inv_yuv422(const InvYuvJob *jobs, uint32_t launch_seed) { inv_yuv422_tile<false>(jobs, launch_seed); }
+__global__ void __launch_bounds__(NTHREADS) k_inv_yuv422_rgb32(const InvYuvJob *jobs) { inv_yuv422_tile<true>(jobs, 0u); }
 
 // =============================================================================================
 // k_inv_yuv422_strip: the same last level as k_inv_yuv422, organised around registers instead of LDS tiles.
@@ -2346,6 +2406,39 @@ __global__ void __launch_bounds__(NTHREADS) k_yu64_to_v210(const uint16_t *yu64,
 // scalar conversion (convert.c:11392-11448 ConvertRow16uToDitheredRGB; oracle/cfhd_oracle_inv.c orc_inv_spatial_to_rgb24_of_yuv422): 15-bit dither per pixel,
 // shared by its three components, from the counter-based hash that stands in for rand(); bytes B, G, R, bottom row first.  matrix: 0 computer-systems 709,
 // 1 video 709, 2 computer 601, 3 video 601.  One thread per pixel pair.
+// RG48 / b64a output of 4:2:2 samples: the YU64 rows (k_inv_packed16 into the scratch frame) through the reference's 16-bit colour conversion -- RGB2YUV.c:1308
+// ChannelYUYV16toPlanarYUV16 (every chroma word serves its pixel pair) + :1760 PlanarYUV16toPlanarRGB16 (vector body: 15-bit samples, 13-bit coefficients, mulhi
+// products, saturating sums, the clamp to 14 bits) + bayer.c:478 ConvertLinesToOutput at white point 16 (the words as they are; b64a: 0xffff in front).  Restated in
+// oracle/cfhd_oracle_inv.c orc_yu64_to_rgb16, pinned on the reference decoder.  One thread per pixel pair: 8 bytes in, 12 or 16 out.
+__global__ void __launch_bounds__(NTHREADS) k_yu64_to_rgb16(const uint16_t *yu64, int in_pitch_words, size_t in_frame_words, uint16_t *out, int out_pitch_words, size_t out_frame_words,
+                                                            int pairs, int matrix_601, int b64a)
+{
+	const int p = (int)(blockIdx.x * blockDim.x + threadIdx.x), row = (int)blockIdx.y;
+	if (p >= pairs) return;
+	const cfhd_u2 in = CFHD_LDG64(yu64 + blockIdx.z * in_frame_words + (size_t)row * in_pitch_words + 4 * (size_t)p);      // Y0 C1 | Y1 C2: channel 1 = V, channel 2 = U
+	const int Y[2] = { (int)(in.x & 0xffffu), (int)(in.y & 0xffffu) }, V = (int)(in.x >> 16), U = (int)(in.y >> 16);
+	const int y_offset = 2048 + (matrix_601 ? -28 : -32), ymult = 9535 + (matrix_601 ? 14 : 11);
+	const int r_vmult = (matrix_601 ? 13074 : 14688) + 6, g_vmult = matrix_601 ? 6661 : 4357, g_umult = matrix_601 ? 3210 : 1738, b_umult = matrix_601 ? 16534 : 17326;
+	const int c_offset = (1 << 14) + (matrix_601 ? 23 : 22);
+	const int uu = sat16((U >> 1) - c_offset), vv = sat16((V >> 1) - c_offset);
+	const int rv = (vv * r_vmult) >> 16, gu = (uu * -g_umult) >> 16, gv = (vv * -g_vmult) >> 16, bu = (uu * b_umult) >> 16;
+	uint16_t *o = out + blockIdx.z * out_frame_words + (size_t)row * out_pitch_words + (size_t)p * (b64a ? 8 : 6);
+#pragma unroll
+	for (int k = 0; k < 2; k++) {
+		const int yy = (sat16((Y[k] >> 1) - y_offset) * ymult) >> 16;
+		int comp[3] = { adds16(rv, yy), adds16(adds16(yy, gu), gv), adds16(bu, yy) };
+#pragma unroll
+		for (int c = 0; c < 3; c++) {
+			int v = (int)(int16_t)(comp[c] << 2);
+			v = adds16(v, 0x7fff - 0x3fff);
+			v = (v & 0xffff) - (0x7fff - 0x3fff); v = v < 0 ? 0 : v;
+			comp[c] = (v << 2) & 0xffff;
+		}
+		if (b64a) { o[4 * k] = 0xffff; o[4 * k + 1] = (uint16_t)comp[0]; o[4 * k + 2] = (uint16_t)comp[1]; o[4 * k + 3] = (uint16_t)comp[2]; }
+		else { o[3 * k] = (uint16_t)comp[0]; o[3 * k + 1] = (uint16_t)comp[1]; o[3 * k + 2] = (uint16_t)comp[2]; }
+	}
+}
+
 __global__ void __launch_bounds__(NTHREADS) k_yu64_to_rgb24(const uint16_t *yu64, int in_pitch_words, size_t in_frame_words, uint8_t *out, int out_pitch, size_t out_frame_bytes,
                                                             int pairs, int rows, int matrix, uint32_t seed)
 {

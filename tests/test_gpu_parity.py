@@ -257,7 +257,9 @@ def test_reference_harness_links_unchanged_and_prints_same_numbers():
     if not os.path.exists(ours):
         pytest.fail("harness binary not built: __graft_entry__.build() runs `make -C oracle testcfhd` where /root/reference exists and it travels with the tree")
     want = json.load(open(HARNESS_FIXTURE))["sections"]
-    got = run_harness(ours)
+    # (a frame of the harness costs about two seconds of Qbist drawing on one core: the suite gives it three minutes -- seven or eight sections, among them BGRA from a
+    # 4:2:2 sample, the first of round 4's routes; tools/gpu_r04_d.sh runs it to its end, profiles/r04_testcfhd_amd_D.txt)
+    got = run_harness(ours, limit_s=int(os.environ.get("CFHD_HARNESS_SECONDS", "190")))
     done = [s for s in got if len(s["frames"]) == 10]
     assert len(done) >= HARNESS_MIN_SECTIONS, "our library completed %d sections: %r" % (len(done), [(s["format"], s["encode"], s["decode"], len(s["frames"])) for s in got])
     for k, s in enumerate(done):
@@ -499,6 +501,46 @@ def test_yuv422_decode_to_rg24_lies_in_the_reference_interval(w, h, flags):
         ref_db = db(np.frombuffer(dec.tobytes(), np.uint8).reshape(h, dpitch)[:, : w * 3])
         return abs(mine_db - ref_db) < 0.1 or "PSNR %.2f vs reference %.2f" % (mine_db, ref_db)
     reference_leg(leg, 4, "4:2:2 -> RG24")
+
+
+@pytest.mark.parametrize("w,h,name,flags", [(320, 240, "BGRa", 0), (336, 252, "BGRA", 0), (336, 252, "BGRa", 4), (720, 486, "BGRA", 4), (1920, 1080, "BGRA", 0), (1920, 1080, "BGRa", 0),
+                                            (320, 240, "RG48", 0), (336, 252, "b64a", 4), (720, 486, "RG48", 4), (1920, 1080, "RG48", 0), (1920, 1080, "b64a", 0)])
+def test_yuv422_decode_to_bgra_rg48_b64a_equals_reference_exactly(w, h, name, flags):
+    """The last four decode rows of TestCFHD's table at full resolution: 4:2:2 samples decoded to BGRA (bottom row first) / BGRa -- the reference's fused horizontal
+    pass + 8-bit colour conversion without dither (Codec/spatial.c:29577; k_inv_yuv422_rgb32) -- and to RG48 / b64a -- its 16-bit rows through RGB2YUV.c:1308 / :1760
+    (k_yu64_to_rgb16).  Byte for byte / word for word the oracle's restatement of those routes (pinned on the reference decoder on eight / nine geometries:
+    test_reference_bgra_decode_of_yuv422_equals_oracle, test_reference_rg48_and_b64a_decode_of_yuv422_equals_oracle), 709 and 601, odd lowpass widths, pad rows; the
+    reference decoder runs beside it as a witness.  Half resolution of these pairs is refused."""
+    from test_oracle_vs_ref import _yuv422_sample_for_rgb_outputs
+    sample = _yuv422_sample_for_rgb_outputs(w, h, w + h, flags)
+    plan = Plan(w, h, pixkind=PIXKIND[name], enc=ENC["422"])
+    deq = host_decode_pyramid(sample, plan)
+    cs = 1 if flags & 4 else 2
+    got, gpitch, aw, ah = amd_decode_sample(sample, fourcc(name))
+    assert (aw, ah) == (w, h)
+    if name in ("BGRA", "BGRa"):
+        want = oracle_inverse_rgb32_of_yuv422(plan, deq, name == "BGRA", cs)[:h]
+        mine = np.frombuffer(got.tobytes(), np.uint8).reshape(h, gpitch)[:, : w * 4]
+        view = lambda dec, dpitch: np.frombuffer(dec.tobytes(), np.uint8).reshape(-1, dpitch)[:h, : w * 4]
+    else:
+        nw = 4 if name == "b64a" else 3
+        want = oracle_inverse_rgb16_of_yuv422(plan, deq, name == "b64a", cs)[:h]
+        mine = np.frombuffer(got.tobytes(), np.uint16).reshape(h, gpitch // 2)[:, : w * nw]
+        view = lambda dec, dpitch: np.frombuffer(dec.tobytes(), np.uint16).reshape(h, dpitch // 2)[:, : w * nw]
+    assert np.array_equal(mine, want), "%d values differ from the exact reconstruction" % (mine != want).sum()
+    rows = h if h % 8 == 0 else h - 8
+    sl = slice(h - rows, h) if name == "BGRA" else slice(0, rows)
+    def leg():
+        dec, dpitch = ref_decode_sample(sample, w, h, fourcc(name))
+        img = view(dec, dpitch)
+        return np.array_equal(img[sl], mine[sl]) or "%d values differ" % (img[sl] != mine[sl]).sum()
+    reference_leg(leg, 4, "4:2:2 -> %s" % name)
+    L = product()
+    dec = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
+    a = ctypes.c_int(); b = ctypes.c_int(); c = ctypes.c_uint32()
+    sb = ctypes.create_string_buffer(sample, len(sample))
+    assert L.CFHD_PrepareToDecode(dec, 0, 0, fourcc(name), 2, 0, sb, 512, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)) == 3      # half resolution of these pairs: not built
+    L.CFHD_CloseDecoder(dec)
 
 
 @pytest.mark.parametrize("w,h,encoded", [(320, 240, ENCODED_RGBA4444), (336, 256, ENCODED_RGB444), (320, 240, ENCODED_YUV422), (1920, 1080, ENCODED_RGBA4444), (1920, 1080, ENCODED_YUV422)])
