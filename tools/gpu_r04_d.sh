@@ -16,8 +16,8 @@ for k, s in enumerate(got):
     w = want[k]
     for i, (size, db) in enumerate(s["frames"]):
         f = w["frames"][i]
-        seen = [x for x in (f["psnr_seen"] or [f["psnr"]]) if abs(x - f["psnr"]) <= 1.0]
-        good = size == f["size"] and min(seen) - 0.1001 <= db <= max(seen) + 0.1001
+        seen = f["psnr_seen"] or [f["psnr"]]
+        good = size == f["size"] and (not f.get("stable", True) or min(seen) - 0.1001 <= db <= max(seen) + 0.1001)
         ok += good; bad += not good
         if not good: print("MISMATCH", s["format"], s["encode"], s["decode"], i + 1, (size, db), (f["size"], seen))
 print("harness: %d sections printed (%d complete), %d frames equal to the reference's printout, %d not" % (len(got), sum(len(s["frames"]) == 10 for s in got), ok, bad))
