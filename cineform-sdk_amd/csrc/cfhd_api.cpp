@@ -1029,10 +1029,12 @@ CFHD_Error CFHD_PrepareToDecode(CFHD_DecoderRef ref, int, int, CFHD_PixelFormat 
 	const bool rgb24_of_422 = kind == PIX_RG24 && encf == ENC_YUV422 && d->header.width >= 128;      // (half resolution: frame.c:8504, k_half_rgb24)
 	// ... and 4:2:2 samples to BGRA / BGRa (the reference's fused horizontal pass + 8-bit colour conversion, spatial.c:29577: k_inv_yuv422_rgb32) and to RG48 / b64a (its
 	// 16-bit rows + RGB2YUV.c:1760: k_yu64_to_rgb16) -- the last four rows of TestCFHD's table; full resolution, progressive
-	const bool rgb32_of_422 = (kind == PIX_BGRA || kind == PIX_BGRa) && encf == ENC_YUV422 && !half && d->header.width >= 32;
-	const bool rgb16_of_422 = (kind == PIX_RG48 || kind == PIX_B64A) && encf == ENC_YUV422 && !half && d->header.width >= 128;
+	// (half resolution: the level-1 lowpass planes through frame.c:8504's RGB32 branch -- its SSE2 loop, so half widths that are multiples of 16 -- and frame.c:9567
+	// ConvertLowpass16sYUVtoRGB48: k_half_rgb24's other modes)
+	const bool rgb32_of_422 = (kind == PIX_BGRA || kind == PIX_BGRa) && encf == ENC_YUV422 && d->header.width >= 32 && (!half || (d->header.width / 2) % 16 == 0);
+	const bool rgb16_of_422 = (kind == PIX_RG48 || kind == PIX_B64A) && encf == ENC_YUV422 && d->header.width >= (half ? 32 : 128);
 	// (half resolution -- frame.c:7150 ConvertLowpassRGB444ToRGB -- for the outputs of RGB 4:4:4 samples: 8-bit, 10-bit, b64a; k_half_rgb)
-	if (rgb8 && ((encf != ENC_RGB444 && !rgba8 && !rgb24_of_422 && !rgb32_of_422) || (half && encf != ENC_RGB444 && !rgba8 && !rgb24_of_422) || d->header.width < 32)) return ERR_BADFORMAT;
+	if (rgb8 && ((encf != ENC_RGB444 && !rgba8 && !rgb24_of_422 && !rgb32_of_422) || (half && encf != ENC_RGB444 && !rgba8 && !rgb24_of_422 && !rgb32_of_422) || d->header.width < 32)) return ERR_BADFORMAT;
 	// ... and to the 10-bit RGB words r210 / DPX0 / AB10 / AR10 ((value before the final >> 1, + 3) >> 3 per component: a model fitted on the reference
 	// decoder and pinned word for word on the CPU, equal to the reference decoder on the GPU)
 	const bool rgb10 = kind >= PIX_R210 && kind <= PIX_AR10;

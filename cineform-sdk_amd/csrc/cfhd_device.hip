@@ -692,9 +692,12 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 	// then k_yu64_to_rgb16.  BGRA / BGRa output of 4:2:2 samples: the last level with the reference's fused colour conversion (k_inv_yuv422_rgb32).
 	rgb16_of_422_ = (out_kind == PIX_RG48 || out_kind == PIX_B64A) && plan.encoded_format == ENC_YUV422; rgb16_b64a_ = out_kind == PIX_B64A;
 	const int final_kind = out_kind;
-	if (rgb16_of_422_) { if (!own_output || half) { g_err = "RG48 / b64a output of 4:2:2 samples: full resolution, into the library's own output frames"; return -2; } out_kind = PIX_YU64; }
+	if (rgb16_of_422_) { if (!own_output) { g_err = "RG48 / b64a output of 4:2:2 samples: into the library's own output frames"; return -2; } if (!half) out_kind = PIX_YU64; }
 	rgb32_of_422_ = (out_kind == PIX_BGRA || out_kind == PIX_BGRa) && plan.encoded_format == ENC_YUV422;
-	if (rgb32_of_422_ && (!own_output || half)) { g_err = "BGRA / BGRa output of 4:2:2 samples: full resolution, into the library's own output frames"; return -2; }
+	if (rgb32_of_422_ && (!own_output || (half && (plan.width / 2) % 16))) { g_err = "BGRA / BGRa output of 4:2:2 samples: into the library's own output frames; half widths that are multiples of 16"; return -2; }
+	// (half resolution of the four: k_half_rgb24's other modes straight from the lowpass planes -- frame.c:8504 RGB32 branch, frame.c:9567 -- no scratch frame, no last level)
+	const bool rgb_half_of_422 = half && (rgb16_of_422_ || rgb32_of_422_);
+	if (rgb_half_of_422) { rgb16_of_422_ = false; rgb32_of_422_ = false; }
 	// BYR4 output of Bayer samples (decoder.c:14738 + bayer.c:13233 GenerateBYR2): the four component planes as 16-bit rows -- the RG48 route with four planes,
 	// four words per photosite quad -- then k_bayer_to_byr4
 	byr4_ = out_kind == PIX_BYR4;
@@ -709,7 +712,7 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 	const bool yu64_ok = out_kind == PIX_YU64 && plan.encoded_format == ENC_YUV422 && plan.ch[1].band[0][0].width >= 16;
 	const bool rgb8_ok = dec_rgb8(out_kind) && (plan.encoded_format == ENC_RGB444 || (plan.encoded_format == ENC_RGBA4444 && out_kind != PIX_RG24)) && plan.ch[0].band[0][0].width >= 16 && plan.ch[0].band[0][0].width % 2 == 0;
 	const bool rgb10_ok = dec_rgb10(out_kind) && plan.encoded_format == ENC_RGB444 && plan.ch[0].band[0][0].width >= 16;
-	if (!yuv_ok && !rgb_ok && !yu64_ok && !rgb8_ok && !rgb10_ok && !rgb24_half) { g_err = "output format not supported by the GPU path yet"; return -2; }
+	if (!yuv_ok && !rgb_ok && !yu64_ok && !rgb8_ok && !rgb10_ok && !rgb24_half && !rgb_half_of_422) { g_err = "output format not supported by the GPU path yet"; return -2; }
 	plan_ = plan; n_ = nframes; out_kind_ = out_kind; own_output_ = own_output;
 	HIPCHK(hipStreamCreateWithFlags((hipStream_t *)&stream_, hipStreamNonBlocking));
 	HIPCHK(hipEventCreate((hipEvent_t *)&ev0_));
@@ -763,6 +766,14 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 				p.out = base + plan.ch[c].band[lv - 1][0].offset; p.out_pitch = plan.ch[c].band[lv - 1][0].pitch;
 				p.xstride = 1; p.precision = 0; p.display_height = 2 * p.height;
 			}
+		if (half && plan.encoded_format == ENC_YUV422 && (dec_rgb8(out_kind) || out_kind == PIX_RG48 || out_kind == PIX_B64A)) {      // k_half_rgb24: RG24, BGRA / BGRa, RG48, b64a of a 4:2:2 sample
+			dev::HalfYuvJob &hj = j.half[i];
+			for (int c = 0; c < 3; c++) { hj.ll[c] = base + plan.ch[c].band[0][0].offset; hj.pitch[c] = plan.ch[c].band[0][0].pitch; }
+			hj.width = plan.ch[0].band[0][0].width; hj.rows = out_rows_; hj.uyvy = 0; hj.matrix = plan.color_matrix;
+			hj.mode = out_kind == PIX_RG24 ? 0 : (out_kind == PIX_RG48 ? 2 : (out_kind == PIX_B64A ? 3 : 1)); hj.bottom_up = out_kind == PIX_BGRA;
+			hj.out = own_output ? d_out_ + frame_bytes_ * i : nullptr; hj.out_pitch = out_pitch_;
+			continue;
+		}
 		if (half && plan.encoded_format != ENC_YUV422 && (dec_rgb8(out_kind) || dec_rgb10(out_kind) || (out_kind == PIX_B64A && nch == 3))) {      // k_half_rgb
 			dev::HalfPackedJob &hp = j.halfp[i];
 			for (int c = 0; c < 3; c++) { hp.ll[c] = base + plan.ch[c].band[0][0].offset; hp.word[c] = dec_rgb10(out_kind) ? rgb10_shift(out_kind, c) : 0; }
@@ -969,7 +980,7 @@ int DecodeBatch::launch_inverse(uint32_t dither_seed)
 		HIPCHK(hipEventRecord((hipEvent_t)evl_[1], st));
 	}
 	if (interlaced_ && !half_ && dec_planes16(out_kind_)) return -1;
-	if (half_ && out_kind_ == PIX_RG24 && plan_.encoded_format == ENC_YUV422) {
+	if (half_ && plan_.encoded_format == ENC_YUV422 && (dec_rgb8(out_kind_) || out_kind_ == PIX_RG48 || out_kind_ == PIX_B64A)) {
 		const BandDesc &b = plan_.ch[0].band[0][0];
 		dev::k_half_rgb24<<<dim3((b.width / 2 + dev::NTHREADS - 1) / dev::NTHREADS, out_rows_, act), dev::NTHREADS, 0, st>>>(j.half);
 	} else if (half_ && (dec_rgb8(out_kind_) || dec_rgb10(out_kind_) || (out_kind_ == PIX_B64A && nch == 3))) {

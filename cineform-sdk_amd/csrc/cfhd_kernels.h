@@ -203,6 +203,9 @@ struct HalfYuvJob {                         // k_half_yuv422: the level-1 lowpas
 	int uyvy;
 	uint8_t *out; int out_pitch;            // bytes
 	int matrix;                             // k_half_rgb24: 0 computer-systems 709, 1 video 709, 2 computer 601, 3 video 601 (as k_yu64_to_rgb24)
+	// k_half_rgb24, the other RGB outputs of a 4:2:2 sample at half resolution: 0 RG24 (bottom row first); 1 BGRA / BGRa bytes B, G, R, 255 (the SSE2 loop of
+	// frame.c:8504's RGB32 branch: half widths that are multiples of 16); 2 RG48 words R, G, B; 3 b64a words 0xffff, R, G, B (frame.c:9567 ConvertLowpass16sYUVtoRGB48)
+	int mode, bottom_up;
 };
 
 struct HalfPackedJob {                      // k_half_packed16: level-1 lowpass planes of a 4:4:4(:4) sample as half-resolution 16-bit pixels
@@ -2489,6 +2492,38 @@ __global__ void __launch_bounds__(NTHREADS) k_half_rgb24(const HalfYuvJob *jobs)
 	const int m[4][6] = { { 16, 128 * 149, 230, 137, 55, 135 }, { 0, 128 * 128, 197, 118, 47, 116 }, { 16, 128 * 149, 204, 208, 100, 129 }, { 0, 128 * 128, 175, 179, 86, 111 } };
 	const int *c = m[job.matrix & 3];
 	const int16_t *y = job.ll[0] + (size_t)row * job.pitch[0] + 2 * p;
+	if (job.mode == 1) {
+		// BGRA / BGRa: samples packed to unsigned bytes, 16-bit vector arithmetic with six fraction bits and no rounding term (oracle_half_resolution_rgb32_of_yuv422)
+		int vs = (int)job.ll[1][(size_t)row * job.pitch[1] + p] >> 4, us = (int)job.ll[2][(size_t)row * job.pitch[2] + p] >> 4;
+		vs = (vs < 0 ? 0 : (vs > 255 ? 255 : vs)) - 128; us = (us < 0 ? 0 : (us > 255 ? 255 : us)) - 128;
+		const int tr = (int)(int16_t)(vs * c[2]) >> 1, tgv = (int)(int16_t)(vs * c[3]) >> 2, tgu = (int)(int16_t)(us * c[4]) >> 2, tb = (int)(int16_t)(us * c[5]);
+		uint32_t *o32 = (uint32_t *)(job.out + (size_t)(job.bottom_up ? job.rows - 1 - row : row) * job.out_pitch) + 2 * (size_t)p;
+#pragma unroll
+		for (int k = 0; k < 2; k++) {
+			int ys = (int)y[k] >> 4;
+			ys = (ys < 0 ? 0 : (ys > 255 ? 255 : ys)) - c[0];
+			const int yy = (int)(int16_t)((((int)(int16_t)(ys << 7) * c[1]) >> 16) << 1);
+			int R = adds16(yy, tr) >> 6, G = subs16(subs16(yy, tgv), tgu) >> 6, B = adds16(yy, tb) >> 6;
+			R = R < 0 ? 0 : (R > 255 ? 255 : R); G = G < 0 ? 0 : (G > 255 ? 255 : G); B = B < 0 ? 0 : (B > 255 ? 255 : B);
+			o32[k] = (uint32_t)B | ((uint32_t)G << 8) | ((uint32_t)R << 16) | 0xff000000u;
+		}
+		return;
+	}
+	if (job.mode >= 2) {
+		// RG48 / b64a: the planes read as unsigned words << 4, the scalar arithmetic of frame.c:9567 in 32 bits (oracle_half_resolution_rgb16_of_yuv422)
+		const int V = (int)(((uint32_t)(uint16_t)job.ll[1][(size_t)row * job.pitch[1] + p]) << 4) - 32768, U = (int)(((uint32_t)(uint16_t)job.ll[2][(size_t)row * job.pitch[2] + p]) << 4) - 32768;
+		const int nw = job.mode == 3 ? 4 : 3;
+		uint16_t *o16 = (uint16_t *)(job.out + (size_t)row * job.out_pitch) + (size_t)(2 * p) * nw;
+#pragma unroll
+		for (int k = 0; k < 2; k++) {
+			const int Y = (int)((uint32_t)((int)(((uint32_t)(uint16_t)y[k]) << 4) - (c[0] << 8)) * (uint32_t)c[1]) >> 7;
+			int R = (int)((uint32_t)Y + (uint32_t)(c[2] * V)) >> 7, G = (int)((uint32_t)(2 * Y) - (uint32_t)(c[4] * U) - (uint32_t)(c[3] * V)) >> 8, B = (int)((uint32_t)Y + (uint32_t)(2 * c[5] * U)) >> 7;
+			R = R < 0 ? 0 : (R > 65535 ? 65535 : R); G = G < 0 ? 0 : (G > 65535 ? 65535 : G); B = B < 0 ? 0 : (B > 65535 ? 65535 : B);
+			uint16_t *q = o16 + k * nw;
+			if (nw == 4) { q[0] = 0xffff; q[1] = (uint16_t)R; q[2] = (uint16_t)G; q[3] = (uint16_t)B; } else { q[0] = (uint16_t)R; q[1] = (uint16_t)G; q[2] = (uint16_t)B; }
+		}
+		return;
+	}
 	const int V = ((int)job.ll[1][(size_t)row * job.pitch[1] + p] >> 4) - 128, U = ((int)job.ll[2][(size_t)row * job.pitch[2] + p] >> 4) - 128;
 	uint8_t *o = job.out + (size_t)(job.rows - 1 - row) * job.out_pitch + 6 * (size_t)p;
 #pragma unroll

@@ -708,6 +708,57 @@ def oracle_half_resolution_rgb24_of_yuv422(plan, coeffs, color_space=2):
     return out[::-1].reshape(rows, -1)
 
 
+def _half_lowpass_planes_of_yuv422(plan, coeffs):
+    O = oracle()
+    work = coeffs.copy()
+    for c in range(3):
+        for lv in (2, 1):
+            d = plan.band[(c, lv, 0)]
+            bands = (c_i16p * 4)(*[plan.view(work, c, lv, b).ctypes.data_as(c_i16p) for b in range(4)])
+            dst = plan.view(work, c, lv - 1, 0)
+            O.orc_inv_spatial(bands, d["pitch"], d["width"], d["height"], plan.prescale[lv], dst.ctypes.data_as(c_i16p), plan.band[(c, lv - 1, 0)]["pitch"])
+    rows = plan.height // 2
+    return [plan.view(work, c, 0, 0)[:rows, : plan.band[(c, 0, 0)]["width"]].astype(np.int64) for c in range(3)]
+
+
+def oracle_half_resolution_rgb32_of_yuv422(plan, coeffs, bottom_up, color_space=2):
+    """Half-resolution picture of a 4:2:2 sample as BGRA (bottom row first) / BGRa, restated from the SSE2 loop of the RGB32 branch of frame.c:8504
+    ConvertLowpass16sToRGBNoIPPFast (:9270-9478; half widths that are multiples of 16: the loop serves every column): lowpass planes >> 4 packed to unsigned bytes,
+    (Y - 16) << 7 mulhi 128 * 149 << 1, chroma products in wrapping 16-bit arithmetic shifted to six fraction bits, saturating sums, >> 6 WITHOUT the rounding term of
+    the full-resolution routine, packus; bytes B, G, R, 255.  coeffs: decoded with the lowpass bias of the output format (Plan(..., pixkind=PIXKIND["BGRA"] / ["BGRa"], enc=ENC["422"]))."""
+    Yp, C1, C2 = _half_lowpass_planes_of_yuv422(plan, coeffs)
+    ym, rv, gv, gu, bu = (128 * 149, 204, 208, 100, 129) if color_space == 1 else (128 * 149, 230, 137, 55, 135)
+    s16 = lambda x: ((x + 0x8000) % 0x10000) - 0x8000
+    sat = lambda x: np.clip(x, -32768, 32767)
+    Y = np.clip(Yp >> 4, 0, 255) - 16
+    V = np.repeat(np.clip(C1 >> 4, 0, 255), 2, axis=1) - 128; U = np.repeat(np.clip(C2 >> 4, 0, 255), 2, axis=1) - 128
+    Y = s16(Y << 7); Y = (Y * ym) >> 16; Y = s16(Y << 1)
+    R = sat(Y + (s16(V * rv) >> 1)) >> 6
+    G = sat(sat(Y - (s16(V * gv) >> 2)) - (s16(U * gu) >> 2)) >> 6
+    B = sat(Y + s16(U * bu)) >> 6
+    out = np.zeros((Y.shape[0], Y.shape[1], 4), np.uint8)
+    out[:, :, 0] = np.clip(B, 0, 255); out[:, :, 1] = np.clip(G, 0, 255); out[:, :, 2] = np.clip(R, 0, 255); out[:, :, 3] = 255
+    return (out[::-1] if bottom_up else out).reshape(Y.shape[0], -1)
+
+
+def oracle_half_resolution_rgb16_of_yuv422(plan, coeffs, b64a, color_space=2):
+    """Half-resolution picture of a 4:2:2 sample as RG48 words (R, G, B) / b64a words (0xffff, R, G, B), restated from frame.c:9567 ConvertLowpass16sYUVtoRGB48 (a scalar
+    loop): the lowpass planes read as UNSIGNED 16-bit words << 4, Y = ((Y - 16 * 256) * ymult) >> 7, R = (Y + r_vmult V) >> 7, G = (2 Y - g_umult U - g_vmult V) >> 8,
+    B = (Y + 2 b_umult U) >> 7 with U, V - 32768, saturated to 16 bits.  coeffs: decoded with the bias of the output format (Plan(..., pixkind=PIXKIND["RG48"] / ["b64a"], enc=ENC["422"]))."""
+    Yp, C1, C2 = _half_lowpass_planes_of_yuv422(plan, coeffs)
+    ym, rv, gv, gu, bu = (128 * 149, 204, 208, 100, 129) if color_space == 1 else (128 * 149, 230, 137, 55, 135)
+    u16 = lambda x: x & 0xffff
+    i32 = lambda x: ((x + 2 ** 31) % 2 ** 32) - 2 ** 31              # (the reference computes in int: wraps where a lowpass word is far out of range)
+    Y = i32(i32((u16(Yp) << 4) - (16 << 8)) * ym) >> 7
+    V = np.repeat(u16(C1) << 4, 2, axis=1) - 32768; U = np.repeat(u16(C2) << 4, 2, axis=1) - 32768
+    R = i32(Y + rv * V) >> 7; G = i32(2 * Y - gu * U - gv * V) >> 8; B = i32(Y + 2 * bu * U) >> 7
+    nw = 4 if b64a else 3
+    out = np.zeros((Y.shape[0], Y.shape[1], nw), np.uint16)
+    if b64a: out[:, :, 0] = 0xffff
+    out[:, :, nw - 3] = np.clip(R, 0, 65535); out[:, :, nw - 2] = np.clip(G, 0, 65535); out[:, :, nw - 1] = np.clip(B, 0, 65535)
+    return out.reshape(Y.shape[0], -1)
+
+
 def oracle_half_resolution_rgb(plan, coeffs, name, r=0):
     """Half-resolution picture of an RGB 4:4:4 sample in the 8-bit (RG24 / BGRA / BGRa), 10-bit (r210 / DPX0 / AB10 / AR10) and b64a output formats, restated from
     frame.c:7150 ConvertLowpassRGB444ToRGB: the level-1 lowpass planes G, R, B of a pyramid that carries the lowpass bias of the output format (decoder.c:12290-12312:

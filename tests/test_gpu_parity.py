@@ -510,7 +510,7 @@ def test_yuv422_decode_to_bgra_rg48_b64a_equals_reference_exactly(w, h, name, fl
     pass + 8-bit colour conversion without dither (Codec/spatial.c:29577; k_inv_yuv422_rgb32) -- and to RG48 / b64a -- its 16-bit rows through RGB2YUV.c:1308 / :1760
     (k_yu64_to_rgb16).  Byte for byte / word for word the oracle's restatement of those routes (pinned on the reference decoder on eight / nine geometries:
     test_reference_bgra_decode_of_yuv422_equals_oracle, test_reference_rg48_and_b64a_decode_of_yuv422_equals_oracle), 709 and 601, odd lowpass widths, pad rows; the
-    reference decoder runs beside it as a witness.  Half resolution of these pairs is refused."""
+    reference decoder runs beside it as a witness.  The same four pairs at half resolution."""
     from test_oracle_vs_ref import _yuv422_sample_for_rgb_outputs
     sample = _yuv422_sample_for_rgb_outputs(w, h, w + h, flags)
     plan = Plan(w, h, pixkind=PIXKIND[name], enc=ENC["422"])
@@ -535,12 +535,35 @@ def test_yuv422_decode_to_bgra_rg48_b64a_equals_reference_exactly(w, h, name, fl
         img = view(dec, dpitch)
         return np.array_equal(img[sl], mine[sl]) or "%d values differ" % (img[sl] != mine[sl]).sum()
     reference_leg(leg, 4, "4:2:2 -> %s" % name)
-    L = product()
-    dec = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
-    a = ctypes.c_int(); b = ctypes.c_int(); c = ctypes.c_uint32()
-    sb = ctypes.create_string_buffer(sample, len(sample))
-    assert L.CFHD_PrepareToDecode(dec, 0, 0, fourcc(name), 2, 0, sb, 512, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)) == 3      # half resolution of these pairs: not built
-    L.CFHD_CloseDecoder(dec)
+    # half resolution: the level-1 lowpass planes through frame.c:8504's RGB32 branch (half widths that are multiples of 16) / frame.c:9567 (k_half_rgb24's other modes),
+    # the models pinned on the reference by test_reference_half_resolution_bgra_of_yuv422_equals_model / ..._rg48_and_b64a_of_yuv422_equals_model
+    if name in ("BGRA", "BGRa") and (w // 2) % 16:
+        L = product()
+        dec = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
+        a = ctypes.c_int(); b = ctypes.c_int(); c = ctypes.c_uint32()
+        sb = ctypes.create_string_buffer(sample, len(sample))
+        assert L.CFHD_PrepareToDecode(dec, 0, 0, fourcc(name), 2, 0, sb, 512, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)) == 3      # (the reference's scalar tail of that loop is not restated)
+        L.CFHD_CloseDecoder(dec)
+        return
+    got, gpitch, aw, ah = amd_decode_sample(sample, fourcc(name), resolution=2)
+    assert (aw, ah) == (w // 2, h // 2)
+    if name in ("BGRA", "BGRa"):
+        want = oracle_half_resolution_rgb32_of_yuv422(plan, deq, name == "BGRA", cs)
+        mine = np.frombuffer(got.tobytes(), np.uint8).reshape(h // 2, gpitch)[:, : (w // 2) * 4]
+        want = want[want.shape[0] - h // 2:] if name == "BGRA" else want[: h // 2]
+        hview = lambda dec, dpitch: np.frombuffer(dec.tobytes(), np.uint8).reshape(-1, dpitch)[: h // 2, : (w // 2) * 4]
+    else:
+        want = oracle_half_resolution_rgb16_of_yuv422(plan, deq, name == "b64a", cs)[: h // 2]
+        mine = np.frombuffer(got.tobytes(), np.uint16).reshape(h // 2, gpitch // 2)[:, : (w // 2) * nw]
+        hview = lambda dec, dpitch: np.frombuffer(dec.tobytes(), np.uint16).reshape(-1, dpitch // 2)[: h // 2, : (w // 2) * nw]
+    assert np.array_equal(mine, want), "half resolution: %d values differ from the model" % (mine != want).sum()
+    hh = h // 2 if h % 8 == 0 else h // 2 - 4
+    hsl = slice(h // 2 - hh, h // 2) if name == "BGRA" else slice(0, hh)
+    def half_leg():
+        dec, dpitch = ref_decode_sample(sample, w, h, fourcc(name), resolution=2)
+        img = hview(dec, dpitch)
+        return np.array_equal(img[hsl], mine[hsl]) or "%d values differ" % (img[hsl] != mine[hsl]).sum()
+    reference_leg(half_leg, 4, "4:2:2 -> %s at half resolution" % name)
 
 
 @pytest.mark.parametrize("w,h,encoded", [(320, 240, ENCODED_RGBA4444), (336, 256, ENCODED_RGB444), (320, 240, ENCODED_YUV422), (1920, 1080, ENCODED_RGBA4444), (1920, 1080, ENCODED_YUV422)])

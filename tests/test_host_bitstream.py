@@ -488,7 +488,7 @@ def test_deep_rgb_as_yuv422_and_rgb10_outputs_are_accepted():
 
 def test_decoder_output_format_gates():
     """CFHD_PrepareToDecode (host code: no GPU involved) accepts exactly the (encoded format, output format, resolution) combinations the
-    library decodes and answers CFHD_ERROR_BADFORMAT (3) for the rest: 4:2:2 -> YUY2 / 2vuy (full, half), YU64 (full), BGRA / BGRa / RG48 / b64a (full); RGB 4:4:4 -> RG48
+    library decodes and answers CFHD_ERROR_BADFORMAT (3) for the rest: 4:2:2 -> YUY2 / 2vuy (full, half), YU64 (full), BGRA / BGRa / RG48 / b64a (full, half); RGB 4:4:4 -> RG48
     (full, half), RG24 / BGRA / BGRa / 10-bit RGB / b64a (full, half); RGBA 4:4:4:4 -> b64a and RG48 (full, half), BGRA / BGRa (full)."""
     if not have_ref(): pytest.skip("reference .so not built")
     L = product()
@@ -503,7 +503,8 @@ def test_decoder_output_format_gates():
                 ("444", "RG48", 1), ("444", "RG48", 2), ("444", "RG24", 1), ("444", "BGRA", 1), ("444", "BGRa", 1), ("444", "r210", 1),
                 ("4444", "b64a", 1), ("4444", "b64a", 2), ("4444", "BGRA", 1), ("4444", "BGRa", 1), ("444", "b64a", 1), ("422", "RG24", 1), ("4444", "RG48", 1), ("4444", "RG48", 2),
                 ("444", "RG24", 2), ("444", "BGRA", 2), ("444", "BGRa", 2), ("444", "r210", 2), ("444", "b64a", 2), ("4444", "BGRA", 2), ("4444", "BGRa", 2),
-                ("422", "BGRA", 1), ("422", "BGRa", 1), ("422", "RG48", 1), ("422", "b64a", 1)}       # (round 4: the last four rows of TestCFHD's table, full resolution)
+                ("422", "BGRA", 1), ("422", "BGRa", 1), ("422", "RG48", 1), ("422", "b64a", 1),       # (round 4: the last four rows of TestCFHD's table)
+                ("422", "BGRA", 2), ("422", "BGRa", 2), ("422", "RG48", 2), ("422", "b64a", 2)}
     dec = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
     aw = ctypes.c_int(); ah = ctypes.c_int(); af = ctypes.c_uint32()
     for enc, sample in samples.items():

@@ -661,3 +661,38 @@ def test_reference_bgra_decode_of_yuv422_equals_oracle(w, h, name, flags):
         if np.array_equal(mine[sl], img[sl]): break
     bad = np.argwhere(mine[sl] != img[sl])
     assert len(bad) == 0, (len(bad), bad[:6].tolist(), [(int(mine[sl][r, c]), int(img[sl][r, c])) for r, c in bad[:6]])
+
+
+@pytest.mark.parametrize("w,h,name,flags", [(320, 240, "BGRa", 0), (320, 248, "BGRA", 0), (640, 360, "BGRA", 4), (1920, 1080, "BGRA", 0), (1920, 1080, "BGRa", 0), (1280, 720, "BGRa", 4),
+                                            (704, 480, "BGRA", 0), (352, 288, "BGRa", 0)])
+def test_reference_half_resolution_bgra_of_yuv422_equals_model(w, h, name, flags):
+    """Pins oracle_half_resolution_rgb32_of_yuv422 (the SSE2 loop of frame.c:8504's RGB32 branch) on half widths that are multiples of 16: the reference's half-resolution
+    BGRA / BGRa decode of a 4:2:2 sample, byte for byte."""
+    sample = _yuv422_sample_for_rgb_outputs(w, h, w + h, flags)
+    plan = Plan(w, h, pixkind=PIXKIND[name], enc=ENC["422"])
+    want = oracle_half_resolution_rgb32_of_yuv422(plan, host_decode_pyramid(sample, plan), name == "BGRA", 1 if flags & 4 else 2)
+    hh = h // 2 if h % 8 == 0 else h // 2 - 4
+    for attempt in range(6):
+        dec, dpitch = ref_decode_sample(sample, w, h, fourcc(name), resolution=2)
+        img = np.frombuffer(dec.tobytes(), np.uint8).reshape(-1, dpitch)[: h // 2, : (w // 2) * 4]
+        a, b = (img[h // 2 - hh:], want[want.shape[0] - hh:]) if name == "BGRA" else (img[:hh], want[:hh])
+        if np.array_equal(a, b): break
+    bad = np.argwhere(a != b)
+    assert len(bad) == 0, (len(bad), bad[:6].tolist(), [(int(a[r, c]), int(b[r, c])) for r, c in bad[:6]])
+
+
+@pytest.mark.parametrize("w,h,name,flags", [(320, 240, "RG48", 0), (336, 248, "b64a", 0), (640, 360, "RG48", 4), (1920, 1080, "RG48", 0), (1920, 1080, "b64a", 0), (1280, 720, "b64a", 4),
+                                            (720, 486, "RG48", 0), (400, 120, "b64a", 0)])
+def test_reference_half_resolution_rg48_and_b64a_of_yuv422_equals_model(w, h, name, flags):
+    """Pins oracle_half_resolution_rgb16_of_yuv422 (frame.c:9567 ConvertLowpass16sYUVtoRGB48): the reference's half-resolution RG48 / b64a decode of a 4:2:2 sample, word for word."""
+    sample = _yuv422_sample_for_rgb_outputs(w, h, w + h, flags)
+    plan = Plan(w, h, pixkind=PIXKIND[name], enc=ENC["422"])
+    nw = 4 if name == "b64a" else 3
+    want = oracle_half_resolution_rgb16_of_yuv422(plan, host_decode_pyramid(sample, plan), name == "b64a", 1 if flags & 4 else 2)
+    hh = h // 2 if h % 8 == 0 else h // 2 - 4
+    for attempt in range(6):
+        dec, dpitch = ref_decode_sample(sample, w, h, fourcc(name), resolution=2)
+        img = np.frombuffer(dec.tobytes(), np.uint16).reshape(-1, dpitch // 2)[: h // 2, : (w // 2) * nw]
+        if np.array_equal(img[:hh], want[:hh]): break
+    bad = np.argwhere(img[:hh] != want[:hh])
+    assert len(bad) == 0, (len(bad), bad[:6].tolist(), [(int(img[r, c]), int(want[r, c])) for r, c in bad[:6]])
