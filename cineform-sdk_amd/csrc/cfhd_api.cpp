@@ -98,6 +98,7 @@ struct EncodeParams {
 	FramePlan plan;
 	QuantState qstate = {0, -1, 0};
 	bool gop = false; GopPlan gplan;              // CFHD_ENCODING_FLAGS_YUV_2FRAME_GOP: two frames per sample (cfhd_gop.h)
+	QuantState gstate = {0, -1, 0};               // the quantizer state of the group encoder (rate feedback from the last key sample)
 	bool valid = false;
 };
 
@@ -152,7 +153,8 @@ int make_params(EncodeParams &p, int w, int h, uint32_t fmt, int encoded, uint32
 	p.qstate = {0, -1, 0};
 	derive_quantization(&p.plan, quality, p.progressive, 0.0f, &p.qstate);
 	p.gop = gop;
-	if (gop && (!build_gop_plan(&p.gplan, w, h, kind) || !derive_gop_quantization(&p.gplan, quality))) return ERR_BADFORMAT;
+	p.gstate = {0, -1, 0};
+	if (gop && (!build_gop_plan(&p.gplan, w, h, kind) || !derive_gop_quantization(&p.gplan, quality, &p.gstate))) return ERR_BADFORMAT;
 	p.valid = true;
 	return ERR_OKAY;
 }
@@ -625,7 +627,7 @@ CFHD_Error CFHD_PrepareToEncode(CFHD_EncoderRef ref, int w, int h, CFHD_PixelFor
 		e->params.quality = (int)((0xffff0000u & (uint32_t)e->params.quality) | (0xffffu & (uint32_t)quality));
 		derive_quantization(&e->params.plan, e->params.quality, e->params.progressive, 0.0f, &e->params.qstate);
 		e->batch_ready = false;
-		if (e->params.gop) { if (!derive_gop_quantization(&e->params.gplan, e->params.quality)) return ERR_BADFORMAT; e->gop_ready = false; }
+		// (a group encoder deals its tables on the call that opens the next group, from e->params.quality: nothing to do here)
 		return ERR_OKAY;
 	}
 	int rc = make_params(e->params, w, h, fmt, encoded, flags, quality);
@@ -658,6 +660,16 @@ CFHD_Error CFHD_EncodeSample(CFHD_EncoderRef ref, void *frame, int pitch)
 			e->sample.assign(2 * sample_capacity(e->params), 0);
 		}
 		const uint32_t n = e->gop_calls++;
+		// Rate feedback (encoder.c:2880-2905): every call re-derives the subband tables from the size of the last key sample (the FILMSCAN2/3 limiter moves), the
+		// call that opens a group also runs the bit-rate limiter and deals the divisors to the group's wavelets -- both frames of the group are quantized with them
+		if (!(n & 1u)) {
+			GopPlan next = e->params.gplan;
+			if (!derive_gop_quantization(&next, e->params.quality, &e->params.gstate, 0.0f, true)) return ERR_INTERNAL;
+			bool changed = next.midpoint_prequant != e->params.gplan.midpoint_prequant;
+			for (int c = 0; c < 3 && !changed; c++)
+				for (int k = 0; k < kGopWavelets && !changed; k++) changed = memcmp(next.ch[c].w[k].quant, e->params.gplan.ch[c].w[k].quant, sizeof(next.ch[c].w[k].quant)) != 0;
+			if (changed) { e->params.gplan = next; e->gop_batch.set_plan(next); }
+		} else derive_gop_quantization(&e->params.gplan, e->params.quality, &e->params.gstate, 0.0f, false);
 		if (e->gop_batch.upload_frame((int)(n & 1u), frame, pitch)) return ERR_INTERNAL;
 		size_t bytes;
 		if (!(n & 1u)) {
@@ -674,6 +686,7 @@ CFHD_Error CFHD_EncodeSample(CFHD_EncoderRef ref, void *frame, int pitch)
 		e->meta.local.clear();
 		if (!bytes) return ERR_CODEC_ERROR;
 		e->sample_size = bytes;
+		if (n == 0 || (n & 1u)) e->params.gstate.lastgopbitcount = (int64_t)bytes * 8;      // key samples: the sequence header and the groups (encoder.c:3414)
 		return ERR_OKAY;
 	}
 	if (!e->batch_ready) {

@@ -4,7 +4,7 @@
 
 namespace cfhd {
 
-void derive_subband_tables_for_gop(FramePlan *plan, int quality, QuantState *st, int out[4][17], int *factor, int *new_quality);   // cfhd_tables.cpp
+void derive_gop_subband_divisors(FramePlan *plan, int quality, float framerate, QuantState *st, bool deal, int out[3][17]);   // cfhd_tables.cpp
 
 bool build_gop_plan(GopPlan *plan, int width, int height, int pixel_kind)
 {
@@ -44,32 +44,22 @@ bool build_gop_plan(GopPlan *plan, int width, int height, int pixel_kind)
 		spatial(ch.w[5], ch.w[4].scale[0]);
 	}
 	plan->coeff_elems = at;
+	plan->sample_buffer_bytes = (size_t)width * height * 4 + 65536;      // SampleEncoder.cpp:387 (PixelSize of YUY2 / 2vuy: 4, :1232)
 	return true;
 }
 
-bool derive_gop_quantization(GopPlan *plan, int quality)
+bool derive_gop_quantization(GopPlan *plan, int quality, QuantState *st, float framerate, bool deal)
 {
-	// the subband tables of QuantizationSetQuality, before any sample exists (no rate feedback: see the header)
 	FramePlan fp;
 	if (!build_frame_plan(&fp, plan->width, plan->display_height, plan->pixel_kind, ENC_YUV422)) return false;
-	QuantState st = { 0, -1, 0 };
-	int tabs[4][17], factor, new_quality;
-	derive_subband_tables_for_gop(&fp, quality, &st, tabs, &factor, &new_quality);
-	{
-		// the same question quantizer_is_static() asks of the intra tables: would a (large) previous sample move them?
-		QuantState big = st; big.lastgopbitcount = (int64_t)plan->width * plan->height * 64;
-		int t2[4][17], f2, q2;
-		FramePlan fp2 = fp;
-		derive_subband_tables_for_gop(&fp2, quality, &big, t2, &f2, &q2);
-		if (memcmp(tabs, t2, sizeof(tabs)) != 0) return false;
-		// the bit-rate limiter of LOW .. HIGH at <= 1080p (quantize.c:2994) is rate feedback too
-		if (factor != 0 && !(plan->width > 1920 || plan->height > 1080 || new_quality > 3)) return false;
-	}
+	int tabs[3][17];
+	derive_gop_subband_divisors(&fp, quality, framerate, st, deal, tabs);
+	if (!deal) return true;
 	plan->midpoint_prequant = fp.midpoint_prequant;
 	const int mpq = plan->midpoint_prequant;
 	auto midpoint = [&](int q) { if (mpq) { q *= mpq; q /= (mpq - 1) * 2; } else q /= 2; return q; };
 	for (int c = 0; c < 3; c++) {
-		const int *quant = tabs[c ? 1 : 0];
+		const int *quant = tabs[c];
 		GopChannel &ch = plan->ch[c];
 		int subband = 1;
 		// quantize.c:3480: the two spatial wavelets on the temporal lowpass band, top first (VSCALE(q, qmax, 256) = 256 q; quantScaleFactor 2)
@@ -142,6 +132,7 @@ size_t write_group_sample(const GopPlan &plan, const SampleHeaderInfo &hdr, cons
 {
 	BitWriter w(out, cap);
 	const int nch = plan.num_channels;
+	std::vector<int16_t> zeros;
 	// --- PutVideoGroupHeader (codec.c:835) ---
 	w.put_tag(TAG_SAMPLE, 2);                            // SAMPLE_TYPE_GROUP
 	w.put_tag(TAG_INDEX, nch);
@@ -256,7 +247,14 @@ size_t write_group_sample(const GopPlan &plan, const SampleHeaderInfo &hdr, cons
 			const GopWavelet &wv = ch.w[k];
 			put_wavelet_header(w, wv, k + 1);
 			for (int b = 1; b < 4; b++, subband++) {
+				// "only compress up to 80% of the frame size" (encoder.c:8332): once the sample fills more than that of the caller's sample buffer, the remaining
+				// bands of the frame wavelets are coded as zeros (EncodeZeroBand encoder.c:6220: the same header, one run over the whole band)
+				const bool zero_band = (uint64_t)w.bytes() * 100 > (uint64_t)plan.sample_buffer_bytes * 80;
 				put_band_header(w, b, wv, subband, 3);
+				if (zero_band) {
+					if (zeros.size() < (size_t)wv.pitch * wv.height) zeros.assign((size_t)wv.pitch * wv.height, 0);
+					vlc_encode_band(w, zeros.data(), wv.width, wv.height, wv.pitch, 1, wv.quant[b]);
+				} else
 				vlc_encode_band(w, coeffs + wv.offset[b], wv.width, wv.height, wv.pitch, 1, wv.quant[b]);
 				w.put_tag(TAG_BAND_TRAILER, 0);
 				w.size_pop();

@@ -32,14 +32,17 @@ struct GopPlan {
 	int pixel_kind = PIX_YUY2;
 	GopChannel ch[3];
 	size_t coeff_elems = 0;                  // int16 elements of one group's pyramid
+	size_t sample_buffer_bytes = 0;          // the reference's sample buffer (its BITSTREAM block length): the encoder stops coding the frame wavelets' bands at 80% of it
 	// the level-1 transforms run through the kernels of the intra path: two ordinary frame plans whose level-1 bands alias w[0] / w[1]
 };
 
 // false: geometry the group transform does not serve (the same rule as build_frame_plan: chroma must halve on whole pairs four times here)
 bool build_gop_plan(GopPlan *plan, int width, int height, int pixel_kind);
-// Quantizer tables of the group (QuantizationSetQuality quantize.c:186 + SetTransformQuantization :3480 + SetTransformScale wavelet.c:7142).
-// false: the quality re-derives its tables from the size of the previous group (rate feedback) -- not built for groups.
-bool derive_gop_quantization(GopPlan *plan, int quality);
+// Quantizer tables of the group (QuantizationSetQuality quantize.c:186 + SetTransformQuantization :2865, :3480 + SetTransformScale wavelet.c:7142).
+// The reference runs the first on every CFHD_EncodeSample call and the second only on the call that opens a group (encoder.c:2880-2905), both with the size of
+// the last key sample -- the 40-byte sequence header counts as one (encoder.c:3414) -- in `st`: deal = true for the opening call (the tables are written into the
+// plan), false for the call that completes the group (only the FILMSCAN2/3 limiter in `st` moves).
+bool derive_gop_quantization(GopPlan *plan, int quality, QuantState *st, float framerate = 0.0f, bool deal = true);
 
 // The group sample (codec.c:835 PutVideoGroupHeader + encoder.c:7461 EncodeQuantizedGroup + :8078 EncodeQuantizedFieldPlusTransform) from the
 // group's coefficient pyramid; 0 on overflow.

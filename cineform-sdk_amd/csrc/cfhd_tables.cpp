@@ -331,6 +331,45 @@ const int kChromaQ[4][17] = {
 // out[0] luma, [1] chroma, [2] luma under the bit-rate limiter, [3] chroma under it -- 17 entries each, the numbering of the 2-frame group.
 static void derive_subband_tables(FramePlan *plan, int quality, bool progressive, QuantState *st, int out[4][17], int *factor_out, int *new_quality_out);
 
+// The bit-rate limiter of SetTransformQuantization (quantize.c:2896-2906 the rate of the previous key sample, :2994-3100 the limiter): active only for qualities
+// <= HIGH on <= 1080p 3-channel YUV.  One call per channel; channel 0 moves the state.
+static int bitrate_of_previous_sample(const QuantState *st, float framerate, int gop_length)
+{
+	const float fr = (framerate > 10.0f && framerate < 120.0f) ? framerate : 30.0f;
+	return (int)((float)(int32_t)st->lastgopbitcount * fr / (float)gop_length);
+}
+static bool bitrate_limiter_applies(int fixedQuality, int newQuality, int width, int height, int num_channels, int encoded_format)
+{
+	return fixedQuality != 0 && !(width > 1920 || height > 1080 || num_channels > 3 || newQuality > 3 || encoded_format == ENC_RGB444);
+}
+static void limit_bitrate(int fixedQuality, int currentbitrate, bool progressive, int c, QuantState *st, int quant[17], const int quantMAX[17])
+{
+	const int BR_LIMIT = 130000000, BR_STEPS = 10000000;
+	const int upper = fixedQuality == 1 ? BR_LIMIT - 2 * BR_STEPS : (fixedQuality == 3 ? BR_LIMIT + 2 * BR_STEPS : BR_LIMIT);
+	if (currentbitrate > upper) {
+		memcpy(quant, quantMAX, sizeof(int) * 17);
+		if (c == 0) {
+			if (st->overbitrate == 0) st->overbitrate = 1;
+			if (currentbitrate > upper * 12 / 10) st->overbitrate++;
+			if (st->overbitrate > 16) st->overbitrate = 16;
+		}
+	} else if (st->overbitrate > 0) {
+		if (c == 0) {
+			if (st->overbitrate > 1 && currentbitrate < upper) st->overbitrate--;
+			else if (st->overbitrate == 1 && currentbitrate < upper * 8 / 10) st->overbitrate = 0;
+		}
+		if (st->overbitrate > 0) memcpy(quant, quantMAX, sizeof(int) * 17);
+	}
+	if (st->overbitrate > 1) {
+		const int rc = st->overbitrate - 1;
+		if (progressive) { for (int i = 11; i < 17; i++) quant[i] = (quant[i] * (rc + 4)) >> 2; }
+		else {
+			for (int i : {11, 14}) quant[i] = (quant[i] * (rc + 4)) >> 2;
+			for (int i : {12, 15, 13, 16}) quant[i] = (quant[i] * (rc / 8 + 4)) >> 2;
+		}
+	}
+}
+
 void derive_quantization(FramePlan *plan, int quality, bool progressive, float framerate, QuantState *st)
 {
 	int tabs[4][17], factor, newQuality;
@@ -345,43 +384,14 @@ void derive_quantization(FramePlan *plan, int quality, bool progressive, float f
 
 	plan->prescale[0] = 0; plan->prescale[1] = precision >= 10 ? 2 : 0; plan->prescale[2] = precision == 12 ? 2 : 0;
 
-	// Bit-rate limiter (quantize.c:2994-3100): active only for qualities <= HIGH on <= 1080p 3-channel YUV.
-	int64_t prevbits = st->lastgopbitcount;
-	float fr = (framerate > 10.0f && framerate < 120.0f) ? framerate : 30.0f;
-	int currentbitrate = (int)((float)(int32_t)prevbits * fr);
-	bool limiter_on = fixedQuality != 0 && !(plan->width > 1920 || plan->height > 1080 || plan->num_channels > 3 ||
-	                                          newQuality > 3 || plan->encoded_format == ENC_RGB444);
+	const int currentbitrate = bitrate_of_previous_sample(st, framerate, 1);
+	const bool limiter_on = bitrate_limiter_applies(fixedQuality, newQuality, plan->width, plan->height, plan->num_channels, plan->encoded_format);
 	if (st->overbitrate < 0 || st->overbitrate > 16) st->overbitrate = 0;
 
 	for (int c = 0; c < plan->num_channels; c++) {
 		int quant[17], quantMAX[17];
 		memcpy(quant, c ? qC : qL, sizeof(quant)); memcpy(quantMAX, c ? qCmax : qLmax, sizeof(quantMAX));
-		if (limiter_on) {
-			const int BR_LIMIT = 130000000, BR_STEPS = 10000000;
-			int upper = fixedQuality == 1 ? BR_LIMIT - 2 * BR_STEPS : (fixedQuality == 3 ? BR_LIMIT + 2 * BR_STEPS : BR_LIMIT);
-			if (currentbitrate > upper) {
-				memcpy(quant, quantMAX, sizeof(quant));
-				if (c == 0) {
-					if (st->overbitrate == 0) st->overbitrate = 1;
-					if (currentbitrate > upper * 12 / 10) st->overbitrate++;
-					if (st->overbitrate > 16) st->overbitrate = 16;
-				}
-			} else if (st->overbitrate > 0) {
-				if (c == 0) {
-					if (st->overbitrate > 1 && currentbitrate < upper) st->overbitrate--;
-					else if (st->overbitrate == 1 && currentbitrate < upper * 8 / 10) st->overbitrate = 0;
-				}
-				if (st->overbitrate > 0) memcpy(quant, quantMAX, sizeof(quant));
-			}
-			if (st->overbitrate > 1) {
-				int rc = st->overbitrate - 1;
-				if (progressive) { for (int i = 11; i < 17; i++) quant[i] = (quant[i] * (rc + 4)) >> 2; }
-				else {
-					for (int i : {11, 14}) quant[i] = (quant[i] * (rc + 4)) >> 2;
-					for (int i : {12, 15, 13, 16}) quant[i] = (quant[i] * (rc / 8 + 4)) >> 2;
-				}
-			}
-		}
+		if (limiter_on) limit_bitrate(fixedQuality, currentbitrate, progressive, c, st, quant, quantMAX);
 		ChannelPlan &cp = plan->ch[c];
 		int scale[3][4] = {{4, 2, 2, 1}};
 		for (int k = 1; k < 3; k++) { int s = scale[k - 1][0]; scale[k][0] = 4 * s; scale[k][1] = 2 * s; scale[k][2] = 2 * s; scale[k][3] = s; }
@@ -482,10 +492,21 @@ static void derive_subband_tables(FramePlan *plan, int quality, bool progressive
 	*factor_out = factor; *new_quality_out = newQuality;
 }
 
-// (cfhd_gop.cpp) the tables of a progressive two-frame group: the same derivation, without the intra remap
-void derive_subband_tables_for_gop(FramePlan *plan, int quality, QuantState *st, int out[4][17], int *factor, int *new_quality)
+// (cfhd_gop.cpp) the divisors of a progressive two-frame group, per channel and subband.  Every CFHD_EncodeSample call of a group runs QuantizationSetQuality
+// (encoder.c:2880: the FILMSCAN2/3 limiter moves with the size of the last key sample); only the call that opens a group (deal) also runs SetTransformQuantization
+// (encoder.c:2895-2905, group.count == 0: the bit-rate limiter, its rate = bits * fps / 2) and hands the divisors to the wavelets.
+void derive_gop_subband_divisors(FramePlan *plan, int quality, float framerate, QuantState *st, bool deal, int out[3][17])
 {
-	derive_subband_tables(plan, quality, true, st, out, factor, new_quality);
+	int tabs[4][17], factor, newQuality;
+	derive_subband_tables(plan, quality, true, st, tabs, &factor, &newQuality);
+	if (!deal) return;
+	const int currentbitrate = bitrate_of_previous_sample(st, framerate, 2);
+	const bool limiter_on = bitrate_limiter_applies(factor, newQuality, plan->width, plan->height, plan->num_channels, plan->encoded_format);
+	if (st->overbitrate < 0 || st->overbitrate > 16) st->overbitrate = 0;
+	for (int c = 0; c < 3; c++) {
+		memcpy(out[c], tabs[c ? 1 : 0], sizeof(int) * 17);
+		if (limiter_on) limit_bitrate(factor, currentbitrate, true, c, st, out[c], tabs[c ? 3 : 2]);
+	}
 }
 
 int unit_device(int i, int ndevices, const char *pinned_env, const char *list_env)

@@ -37,8 +37,8 @@ int cfhd_amd_plan_info(int width, int height, int pixel_kind, int encoded_format
 // geometry / quality is not served.
 int cfhd_amd_gop_plan_info(int width, int height, int pixel_kind, int quality, long long *out)
 {
-	GopPlan plan;
-	if (!build_gop_plan(&plan, width, height, pixel_kind) || !derive_gop_quantization(&plan, quality)) return -1;
+	GopPlan plan; QuantState st = {0, -1, 0};
+	if (!build_gop_plan(&plan, width, height, pixel_kind) || !derive_gop_quantization(&plan, quality, &st)) return -1;
 	int n = 0;
 	out[n++] = (long long)plan.coeff_elems; out[n++] = plan.height; out[n++] = plan.midpoint_prequant;
 	for (int c = 0; c < 3; c++)
@@ -53,8 +53,8 @@ int cfhd_amd_gop_plan_info(int width, int height, int pixel_kind, int quality, l
 size_t cfhd_amd_write_gop_host(int kind, int width, int height, int pixel_kind, int quality, unsigned frame_number, const int16_t *coeffs,
                                const uint8_t *meta_global, size_t meta_global_size, uint8_t *out, size_t cap)
 {
-	GopPlan plan;
-	if (!build_gop_plan(&plan, width, height, pixel_kind) || !derive_gop_quantization(&plan, quality)) return 0;
+	GopPlan plan; QuantState st = {0, -1, 0};
+	if (!build_gop_plan(&plan, width, height, pixel_kind) || !derive_gop_quantization(&plan, quality, &st)) return 0;
 	const int input_format = pixel_kind == PIX_2VUY ? 1 : 2;
 	if (kind == 1) return write_sequence_header(plan, input_format, out, cap);
 	if (kind == 2) return write_pframe_sample(plan, frame_number, out, cap);

@@ -30,3 +30,4 @@ print(json.dumps(d["config"].get("kernel_ms_one_step_at_a_time")))
 print(json.dumps({k: (v.get("value"), v.get("roofline", {}).get("frac")) for k, v in d["config"].get("other_workloads", {}).items()}))
 print(json.dumps(d.get("cpu_baseline")))
 PY
+bash tools/profile_round.sh $1_1080p_depth1 512 --depth 1 > gpurun_out/$1_profile_depth1.log 2>&1; tail -3 gpurun_out/$1_profile_depth1.log
