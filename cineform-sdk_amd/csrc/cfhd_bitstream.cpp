@@ -168,31 +168,8 @@ struct HostSink {
 	}
 };
 
-struct TemplateSink {
-	SampleTemplate &t;
-	std::vector<uint8_t> &b;
-	int holes = 0; int stack[8]; int depth = 0; int index_at = 0; int ch_start_tmpl = 0, ch_start_holes = 0;
-	explicit TemplateSink(SampleTemplate &tt) : t(tt), b(tt.bytes) {}
-	void word(uint32_t w) { b.push_back((uint8_t)(w >> 24)); b.push_back((uint8_t)(w >> 16)); b.push_back((uint8_t)(w >> 8)); b.push_back((uint8_t)w); }
-	void tag(int tg, int v) { word(((uint32_t)(uint16_t)tg << 16) | (uint32_t)(v & 0xffff)); }
-	void tag_opt(int tg, int v) { tag(-tg, v); }
-	void bytes(const void *p, size_t n) { const uint8_t *q = (const uint8_t *)p; b.insert(b.end(), q, q + n); }
-	void push(int tg)
-	{
-		SampleTemplate::Patch p; p.kind = 0; p.at_tmpl = (int)b.size(); p.at_holes = holes; p.tag = tg; p.start_tmpl = p.start_holes = p.end_tmpl = p.end_holes = 0;
-		stack[depth++] = (int)t.patches.size(); t.patches.push_back(p);
-		tag(tg, 0);
-	}
-	void pop() { SampleTemplate::Patch &p = t.patches[stack[--depth]]; p.end_tmpl = (int)b.size(); p.end_holes = holes; }
-	void index_entries(int n) { index_at = (int)b.size(); for (int i = 0; i < n; i++) tag(TAG_ENTRY, i); }
-	void channel_begin(int) { ch_start_tmpl = (int)b.size(); ch_start_holes = holes; }
-	void channel_end(int c)
-	{
-		SampleTemplate::Patch p; p.kind = 1; p.at_tmpl = index_at + 4 * c; p.at_holes = 0; p.tag = 0;
-		p.start_tmpl = ch_start_tmpl; p.start_holes = ch_start_holes; p.end_tmpl = (int)b.size(); p.end_holes = holes;
-		t.patches.push_back(p);
-	}
-	void hole(int kind, int c, int lv, int bnd, int fixed) { SampleTemplate::Hole h = { (int)b.size(), kind, c, lv, bnd, fixed }; t.holes.push_back(h); holes++; }
+struct TemplateSink : TemplateRecorder {
+	explicit TemplateSink(SampleTemplate &tt) : TemplateRecorder(tt) {}
 	void lowpass(int c) { const BandDesc &ll = t.plan.ch[c].band[2][0]; hole(0, c, 2, 0, (((ll.width * ll.height * 2) + 3) / 4) * 4); }
 	void band(int c, int lv, int bnd, int, int) { hole(1, c, lv, bnd, 0); }
 	// GPU entropy: the tags stay zero; a band that does need a peak table sends its frame through the host writer (see GpuEntropyEncoder)

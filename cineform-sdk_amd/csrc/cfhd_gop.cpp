@@ -91,82 +91,120 @@ bool derive_gop_quantization(GopPlan *plan, int quality, QuantState *st, float f
 // Writer
 // ------------------------------------------------------------------------------------------
 namespace {
-void put_band_header(BitWriter &w, int band, const GopWavelet &wv, int subband, int encoding)
-{
-	w.put_tag(TAG_MARKER, MARK_BAND_START);
-	w.put_tag(TAG_BAND_NUMBER, band);
-	w.put_tag(TAG_BAND_CODING_FLAGS, 1);                 // code set 17, no difference coding (encoder.c:6120 SetCodingFlags for a progressive group)
-	w.put_tag(TAG_BAND_WIDTH, wv.width);
-	w.put_tag(TAG_BAND_HEIGHT, wv.height);
-	w.put_tag(TAG_BAND_SUBBAND, subband);
-	w.put_tag(TAG_BAND_ENCODING, encoding);
-	w.put_tag(TAG_BAND_QUANTIZATION, wv.quant[band]);
-	w.put_tag(TAG_BAND_SCALE, wv.scale[band]);
-	w.size_push(TAG_SUBBAND_SIZE);
-	w.put_tag(TAG_BAND_HEADER, 0);
-}
-void put_wavelet_header(BitWriter &w, const GopWavelet &wv, int number)
-{
-	w.put_tag(TAG_MARKER, MARK_HIGHPASS_START);
-	w.put_tag(TAG_WAVELET_TYPE, wv.type);
-	w.put_tag(TAG_WAVELET_NUMBER, number);
-	w.put_tag(TAG_WAVELET_LEVEL, wv.level);
-	w.put_tag(TAG_NUM_BANDS, wv.nbands);
-	w.put_tag(TAG_HIGHPASS_WIDTH, wv.width);
-	w.put_tag(TAG_HIGHPASS_HEIGHT, wv.height);
-	w.put_tag(TAG_LOWPASS_BORDER, 0);
-	w.put_tag(TAG_HIGHPASS_BORDER, 0);
-	w.put_tag(TAG_LOWPASS_SCALE, wv.scale[0]);
-	w.put_tag(TAG_LOWPASS_DIVISOR, 0);
-	w.size_push(TAG_LEVEL_SIZE);
-}
-void put_raw16(BitWriter &w, const int16_t *band, int width, int height, int pitch)
-{
+
+// The walk over a group sample's syntax is written once against a sink (as cfhd_bitstream.cpp walk_sample): the host sink codes the payloads inline, the
+// template sink records them as holes the GPU entropy stage fills.
+struct GroupHostSink {
+	BitWriter w; const GopPlan &plan; const int16_t *coeffs;
+	size_t index_at = 0, channel_start = 0;
+	std::vector<int16_t> zeros;
+	GroupHostSink(uint8_t *out, size_t cap, const GopPlan &p, const int16_t *c) : w(out, cap), plan(p), coeffs(c) {}
+	void tag(int t, int v) { w.put_tag(t, v); }
+	void tag_opt(int t, int v) { w.put_tag_opt(t, v); }
+	void bytes(const void *p, size_t n) { w.put_bytes(p, n); }
+	void push(int t) { w.size_push(t); }
+	void pop() { w.size_pop(); }
+	void index_entries(int n) { index_at = w.bytes(); for (int i = 0; i < n; i++) w.put_tag(TAG_ENTRY, i); }
+	void channel_begin(int) { channel_start = w.bytes(); }
+	void channel_end(int c) { w.patch32(index_at + 4 * (size_t)c, (uint32_t)(w.bytes() - channel_start)); }      // the channel's size in the index (encoder.c:7828: bytes, big-endian)
 	// 16-bit big-endian coefficients, row after row without the pitch padding (encoder.c:4423 lowpass, :5850 EncodeQuant16s)
-	for (int r = 0; r < height; r++)
-		for (int x = 0; x < width; x++) w.put_bits((uint16_t)band[(size_t)r * pitch + x], 16);
+	void raw16(int c, int k)
+	{
+		const GopWavelet &wv = plan.ch[c].w[k];
+		const int16_t *band = coeffs + wv.offset[0];
+		for (int r = 0; r < wv.height; r++)
+			for (int x = 0; x < wv.width; x++) w.put_bits((uint16_t)band[(size_t)r * wv.pitch + x], 16);
+		w.pad32();
+	}
+	void band(int c, int k, int b)
+	{
+		const GopWavelet &wv = plan.ch[c].w[k];
+		// "only compress up to 80% of the frame size" (encoder.c:8332): once the sample fills more than that of the caller's sample buffer, the remaining
+		// bands of the frame wavelets are coded as zeros (EncodeZeroBand encoder.c:6220: the same header, one run over the whole band)
+		if (k < 2 && zero_band) {
+			if (zeros.size() < (size_t)wv.pitch * wv.height) zeros.assign((size_t)wv.pitch * wv.height, 0);
+			vlc_encode_band(w, zeros.data(), wv.width, wv.height, wv.pitch, 1, wv.quant[b]);
+		} else vlc_encode_band(w, coeffs + wv.offset[b], wv.width, wv.height, wv.pitch, 1, wv.quant[b]);
+	}
+	bool zero_band = false;
+	void frame_band_begins() { zero_band = (uint64_t)w.bytes() * 100 > (uint64_t)plan.sample_buffer_bytes * 80; }      // (asked in front of the band's header, as the reference does)
+};
+
+struct GroupTemplateSink : TemplateRecorder {
+	const GopPlan &plan;
+	GroupTemplateSink(SampleTemplate &tt, const GopPlan &p) : TemplateRecorder(tt), plan(p) {}
+	// holes: `level` is the wavelet index (0 .. 5), band 0 of wavelets 5 and 3 are raw 16-bit words
+	void raw16(int c, int k) { const GopWavelet &wv = plan.ch[c].w[k]; hole(0, c, k, 0, (((wv.width * wv.height * 2) + 3) / 4) * 4); }
+	void band(int c, int k, int b) { hole(1, c, k, b, 0); }
+	void frame_band_begins() {}          // (data dependent: the caller checks the finished sample against gop_sample_may_zero_bands())
+};
+
+template <typename Sink> void put_band_header(Sink &w, int band, const GopWavelet &wv, int subband, int encoding)
+{
+	w.tag(TAG_MARKER, MARK_BAND_START);
+	w.tag(TAG_BAND_NUMBER, band);
+	w.tag(TAG_BAND_CODING_FLAGS, 1);                     // code set 17, no difference coding (encoder.c:6120 SetCodingFlags for a progressive group)
+	w.tag(TAG_BAND_WIDTH, wv.width);
+	w.tag(TAG_BAND_HEIGHT, wv.height);
+	w.tag(TAG_BAND_SUBBAND, subband);
+	w.tag(TAG_BAND_ENCODING, encoding);
+	w.tag(TAG_BAND_QUANTIZATION, wv.quant[band]);
+	w.tag(TAG_BAND_SCALE, wv.scale[band]);
+	w.push(TAG_SUBBAND_SIZE);
+	w.tag(TAG_BAND_HEADER, 0);
 }
+template <typename Sink> void put_wavelet_header(Sink &w, const GopWavelet &wv, int number)
+{
+	w.tag(TAG_MARKER, MARK_HIGHPASS_START);
+	w.tag(TAG_WAVELET_TYPE, wv.type);
+	w.tag(TAG_WAVELET_NUMBER, number);
+	w.tag(TAG_WAVELET_LEVEL, wv.level);
+	w.tag(TAG_NUM_BANDS, wv.nbands);
+	w.tag(TAG_HIGHPASS_WIDTH, wv.width);
+	w.tag(TAG_HIGHPASS_HEIGHT, wv.height);
+	w.tag(TAG_LOWPASS_BORDER, 0);
+	w.tag(TAG_HIGHPASS_BORDER, 0);
+	w.tag(TAG_LOWPASS_SCALE, wv.scale[0]);
+	w.tag(TAG_LOWPASS_DIVISOR, 0);
+	w.push(TAG_LEVEL_SIZE);
 }
 
-size_t write_group_sample(const GopPlan &plan, const SampleHeaderInfo &hdr, const int16_t *coeffs, uint8_t *out, size_t cap)
+template <typename Sink> void walk_group_sample(Sink &w, const GopPlan &plan, const SampleHeaderInfo &hdr)
 {
-	BitWriter w(out, cap);
 	const int nch = plan.num_channels;
-	std::vector<int16_t> zeros;
 	// --- PutVideoGroupHeader (codec.c:835) ---
-	w.put_tag(TAG_SAMPLE, 2);                            // SAMPLE_TYPE_GROUP
-	w.put_tag(TAG_INDEX, nch);
-	const size_t index_at = w.bytes();
-	for (int i = 0; i < nch; i++) w.put_tag(TAG_ENTRY, i);
-	w.put_tag(TAG_TRANSFORM_TYPE, 2);                    // TRANSFORM_TYPE_FIELDPLUS
-	w.put_tag(TAG_NUM_FRAMES, 2);
-	w.put_tag(TAG_NUM_CHANNELS, nch);
-	w.put_tag_opt(TAG_INPUT_FORMAT, hdr.input_format);
-	{ const int cs = hdr.color_space & ~4; if (cs) w.put_tag_opt(TAG_ENCODED_COLORSPACE, cs); }
-	w.put_tag(TAG_NUM_WAVELETS, kGopWavelets);
-	w.put_tag(TAG_NUM_SUBBANDS, kGopSubbands);
-	w.put_tag(TAG_NUM_SPATIAL, 3);
-	w.put_tag(TAG_FIRST_WAVELET, 3);
-	w.put_tag(TAG_FRAME_WIDTH, plan.width);
-	w.put_tag(TAG_FRAME_HEIGHT, plan.height);
-	w.put_tag_opt(TAG_FRAME_NUMBER, (int)(hdr.frame_number & 0xffff));
-	w.put_tag(TAG_PRECISION, plan.precision);
-	w.put_tag_opt(TAG_FRAME_DISPLAY_HEIGHT, plan.display_height);
-	w.put_tag_opt(TAG_VERSION, (10 << 12) | (1 << 8) | 0);
-	w.put_tag_opt(TAG_QUALITY_L, hdr.encoder_quality & 0xffff);
-	w.put_tag_opt(TAG_QUALITY_H, (hdr.encoder_quality >> 16) & 0xffff);
+	w.tag(TAG_SAMPLE, 2);                                // SAMPLE_TYPE_GROUP
+	w.tag(TAG_INDEX, nch);
+	w.index_entries(nch);
+	w.tag(TAG_TRANSFORM_TYPE, 2);                        // TRANSFORM_TYPE_FIELDPLUS
+	w.tag(TAG_NUM_FRAMES, 2);
+	w.tag(TAG_NUM_CHANNELS, nch);
+	w.tag_opt(TAG_INPUT_FORMAT, hdr.input_format);
+	{ const int cs = hdr.color_space & ~4; if (cs) w.tag_opt(TAG_ENCODED_COLORSPACE, cs); }
+	w.tag(TAG_NUM_WAVELETS, kGopWavelets);
+	w.tag(TAG_NUM_SUBBANDS, kGopSubbands);
+	w.tag(TAG_NUM_SPATIAL, 3);
+	w.tag(TAG_FIRST_WAVELET, 3);
+	w.tag(TAG_FRAME_WIDTH, plan.width);
+	w.tag(TAG_FRAME_HEIGHT, plan.height);
+	w.tag_opt(TAG_FRAME_NUMBER, (int)(hdr.frame_number & 0xffff));
+	w.tag(TAG_PRECISION, plan.precision);
+	w.tag_opt(TAG_FRAME_DISPLAY_HEIGHT, plan.display_height);
+	w.tag_opt(TAG_VERSION, (10 << 12) | (1 << 8) | 0);
+	w.tag_opt(TAG_QUALITY_L, hdr.encoder_quality & 0xffff);
+	w.tag_opt(TAG_QUALITY_H, (hdr.encoder_quality >> 16) & 0xffff);
 	{
 		unsigned table = 0;
 		for (int k = 0; k < kGopWavelets; k++) table += (unsigned)plan.ch[0].w[k].prescale << (14 - 2 * k);
-		w.put_tag_opt(TAG_PRESCALE_TABLE, (int)table);     // the decoder's built-in FIELDPLUS default: optional (codec.c:1040)
+		w.tag_opt(TAG_PRESCALE_TABLE, (int)table);         // the decoder's built-in FIELDPLUS default: optional (codec.c:1040)
 	}
-	if (hdr.channel_number_tag) w.put_tag_opt(TAG_ENCODED_CHANNEL_NUMBER, 0);
+	if (hdr.channel_number_tag) w.tag_opt(TAG_ENCODED_CHANNEL_NUMBER, 0);
 	// --- EncodeQuantizedGroup (encoder.c:7559-7620) ---
-	w.size_push(TAG_SAMPLE_SIZE);
+	w.push(TAG_SAMPLE_SIZE);
 	auto put_metadata = [&](const uint8_t *block, size_t size) {
 		if (!block || !size) return;
-		w.put_tag_opt(TAG_METADATA, (int)(size >> 2));
-		w.put_bytes(block, size);
+		w.tag_opt(TAG_METADATA, (int)(size >> 2));
+		w.bytes(block, size);
 	};
 	put_metadata(hdr.meta_global, hdr.meta_global_size);
 	put_metadata(hdr.meta_local, hdr.meta_local_size);
@@ -177,33 +215,35 @@ size_t write_group_sample(const GopPlan &plan, const SampleHeaderInfo &hdr, cons
 		freespace[4] = (uint8_t)(504 & 0xff); freespace[5] = (uint8_t)(504 >> 8);
 		put_metadata(freespace, sizeof(freespace));
 	}
-	w.put_tag_opt(TAG_INTERLACED_FLAGS, 0);
-	w.put_tag_opt(TAG_PROTECTION_FLAGS, 0);
-	w.put_tag_opt(TAG_PICTURE_ASPECT_X, 16);
-	w.put_tag_opt(TAG_PICTURE_ASPECT_Y, 9);
-	if (hdr.progressive) w.put_tag(TAG_SAMPLE_FLAGS, 1);
+	w.tag_opt(TAG_INTERLACED_FLAGS, 0);
+	w.tag_opt(TAG_PROTECTION_FLAGS, 0);
+	w.tag_opt(TAG_PICTURE_ASPECT_X, 16);
+	w.tag_opt(TAG_PICTURE_ASPECT_Y, 9);
+	if (hdr.progressive) w.tag(TAG_SAMPLE_FLAGS, 1);
+	// the band end code of code set 17, padded to a whole word: what FinishEncodeBand leaves behind the raw words of a 16-bit band
+	uint8_t band_end[8]; size_t band_end_bytes;
+	{ BitWriter e(band_end, sizeof(band_end)); vlc_encode_band(e, nullptr, 0, 0, 0, 1, 1); band_end_bytes = e.bytes(); }
 
 	for (int c = 0; c < nch; c++) {
 		const GopChannel &ch = plan.ch[c];
-		if (c > 0) { w.put_tag(TAG_SAMPLE, SAMPLE_TYPE_CHANNEL); w.put_tag(TAG_CHANNEL, c); }
-		const size_t ch_start = w.bytes();
+		if (c > 0) { w.tag(TAG_SAMPLE, SAMPLE_TYPE_CHANNEL); w.tag(TAG_CHANNEL, c); }
+		w.channel_begin(c);
 		// --- the sample's lowpass band: w[5]'s (encoder.c:4251) ---
 		const GopWavelet &top = ch.w[5];
-		w.put_tag(TAG_MARKER, MARK_LOWPASS_START);
-		w.put_tag(TAG_LOWPASS_SUBBAND, 0);
-		w.put_tag(TAG_NUM_LEVELS, 4);
-		w.put_tag(TAG_LOWPASS_WIDTH, top.width);
-		w.put_tag(TAG_LOWPASS_HEIGHT, top.height);
-		w.put_tag(TAG_MARGIN_LEFT, 0); w.put_tag(TAG_MARGIN_TOP, 0); w.put_tag(TAG_MARGIN_RIGHT, 0); w.put_tag(TAG_MARGIN_BOTTOM, 0);
-		w.put_tag(TAG_PIXEL_OFFSET, 0);
-		w.put_tag(TAG_QUANTIZATION, 1);
-		w.put_tag(TAG_PIXEL_DEPTH, 16);
-		w.size_push(TAG_SUBBAND_SIZE);
-		w.put_tag(TAG_MARKER, MARK_COEFF_START);
-		put_raw16(w, coeffs + top.offset[0], top.width, top.height, top.pitch);
-		w.pad32();
-		w.put_tag(TAG_MARKER, MARK_LOWPASS_END);
-		w.size_pop();
+		w.tag(TAG_MARKER, MARK_LOWPASS_START);
+		w.tag(TAG_LOWPASS_SUBBAND, 0);
+		w.tag(TAG_NUM_LEVELS, 4);
+		w.tag(TAG_LOWPASS_WIDTH, top.width);
+		w.tag(TAG_LOWPASS_HEIGHT, top.height);
+		w.tag(TAG_MARGIN_LEFT, 0); w.tag(TAG_MARGIN_TOP, 0); w.tag(TAG_MARGIN_RIGHT, 0); w.tag(TAG_MARGIN_BOTTOM, 0);
+		w.tag(TAG_PIXEL_OFFSET, 0);
+		w.tag(TAG_QUANTIZATION, 1);
+		w.tag(TAG_PIXEL_DEPTH, 16);
+		w.push(TAG_SUBBAND_SIZE);
+		w.tag(TAG_MARKER, MARK_COEFF_START);
+		w.raw16(c, 5);
+		w.tag(TAG_MARKER, MARK_LOWPASS_END);
+		w.pop();
 		// --- EncodeQuantizedFieldPlusTransform (encoder.c:8078) ---
 		int subband = 1;
 		for (int k = 5; k >= 4; k--) {                     // the spatial wavelets on the temporal lowpass band
@@ -211,66 +251,75 @@ size_t write_group_sample(const GopPlan &plan, const SampleHeaderInfo &hdr, cons
 			put_wavelet_header(w, wv, k + 1);
 			for (int b = 1; b < 4; b++, subband++) {
 				put_band_header(w, b, wv, subband, 3);         // BAND_ENCODING_RUNLENGTHS
-				vlc_encode_band(w, coeffs + wv.offset[b], wv.width, wv.height, wv.pitch, 1, wv.quant[b]);
-				w.put_tag(TAG_BAND_TRAILER, 0);
-				w.size_pop();
+				w.band(c, k, b);
+				w.tag(TAG_BAND_TRAILER, 0);
+				w.pop();
 			}
-			w.put_tag(TAG_MARKER, MARK_HIGHPASS_END);
-			w.size_pop();
+			w.tag(TAG_MARKER, MARK_HIGHPASS_END);
+			w.pop();
 		}
 		{                                                  // the spatial wavelet on the temporal highpass band: all four bands, the lowpass one as raw words
 			const GopWavelet &wv = ch.w[3];
 			put_wavelet_header(w, wv, 4);
 			for (int b = 0; b < 4; b++, subband++) {
 				put_band_header(w, b, wv, subband, b == 0 ? 4 : 3);      // BAND_ENCODING_16BIT for the lowpass band (encoder.c:8219, precision >= 10)
-				if (b == 0) {
-					put_raw16(w, coeffs + wv.offset[0], wv.width, wv.height, wv.pitch);
-					// FinishEncodeBand: the band end code of code set 17, padded to a whole word
-					vlc_encode_band(w, nullptr, 0, 0, 0, 1, 1);
-				} else vlc_encode_band(w, coeffs + wv.offset[b], wv.width, wv.height, wv.pitch, 1, wv.quant[b]);
-				w.put_tag(TAG_BAND_TRAILER, 0);
-				w.size_pop();
+				if (b == 0) { w.raw16(c, 3); w.bytes(band_end, band_end_bytes); }
+				else w.band(c, 3, b);
+				w.tag(TAG_BAND_TRAILER, 0);
+				w.pop();
 			}
-			w.put_tag(TAG_MARKER, MARK_HIGHPASS_END);
-			w.size_pop();
+			w.tag(TAG_MARKER, MARK_HIGHPASS_END);
+			w.pop();
 		}
 		{                                                  // the temporal wavelet: a header and one empty band (encoder.c:6607 EncodeEmptyQuantBand, subband 255)
 			const GopWavelet &wv = ch.w[2];
 			put_wavelet_header(w, wv, 3);
 			put_band_header(w, 1, wv, 255, 3);
-			w.put_tag(TAG_BAND_TRAILER, 0);
-			w.size_pop();
-			w.put_tag(TAG_MARKER, MARK_HIGHPASS_END);
-			w.size_pop();
+			w.tag(TAG_BAND_TRAILER, 0);
+			w.pop();
+			w.tag(TAG_MARKER, MARK_HIGHPASS_END);
+			w.pop();
 		}
 		for (int k = 1; k >= 0; k--) {                     // the frame wavelets, the second frame first
 			const GopWavelet &wv = ch.w[k];
 			put_wavelet_header(w, wv, k + 1);
 			for (int b = 1; b < 4; b++, subband++) {
-				// "only compress up to 80% of the frame size" (encoder.c:8332): once the sample fills more than that of the caller's sample buffer, the remaining
-				// bands of the frame wavelets are coded as zeros (EncodeZeroBand encoder.c:6220: the same header, one run over the whole band)
-				const bool zero_band = (uint64_t)w.bytes() * 100 > (uint64_t)plan.sample_buffer_bytes * 80;
+				w.frame_band_begins();
 				put_band_header(w, b, wv, subband, 3);
-				if (zero_band) {
-					if (zeros.size() < (size_t)wv.pitch * wv.height) zeros.assign((size_t)wv.pitch * wv.height, 0);
-					vlc_encode_band(w, zeros.data(), wv.width, wv.height, wv.pitch, 1, wv.quant[b]);
-				} else
-				vlc_encode_band(w, coeffs + wv.offset[b], wv.width, wv.height, wv.pitch, 1, wv.quant[b]);
-				w.put_tag(TAG_BAND_TRAILER, 0);
-				w.size_pop();
+				w.band(c, k, b);
+				w.tag(TAG_BAND_TRAILER, 0);
+				w.pop();
 			}
-			w.put_tag(TAG_MARKER, MARK_HIGHPASS_END);
-			w.size_pop();
+			w.tag(TAG_MARKER, MARK_HIGHPASS_END);
+			w.pop();
 		}
-		// the channel's size in the index (encoder.c:7828: bytes, big-endian)
-		w.patch32(index_at + 4 * (size_t)c, (uint32_t)(w.bytes() - ch_start));
+		w.channel_end(c);
 	}
 	// --- PutVideoGroupTrailer (codec.c:1075) ---
-	w.put_tag(TAG_SAMPLE, 6);                            // SAMPLE_TYPE_GROUP_TRAILER
-	w.put_tag(TAG_GROUP_TRAILER, 0);
-	w.size_pop();
-	return w.overflow() ? 0 : w.bytes();
+	w.tag(TAG_SAMPLE, 6);                                // SAMPLE_TYPE_GROUP_TRAILER
+	w.tag(TAG_GROUP_TRAILER, 0);
+	w.pop();
 }
+}
+
+size_t write_group_sample(const GopPlan &plan, const SampleHeaderInfo &hdr, const int16_t *coeffs, uint8_t *out, size_t cap)
+{
+	GroupHostSink sink(out, cap, plan, coeffs);
+	walk_group_sample(sink, plan, hdr);
+	return sink.w.overflow() ? 0 : sink.w.bytes();
+}
+
+void build_group_template(const GopPlan &plan, const SampleHeaderInfo &hdr, SampleTemplate *t)
+{
+	t->bytes.clear(); t->holes.clear(); t->patches.clear();
+	GroupTemplateSink sink(*t, plan);
+	walk_group_sample(sink, plan, hdr);
+}
+
+// A finished group sample of `bytes` bytes whose last frame-wavelet band starts at or beyond 80% of the reference's sample buffer may have had bands zeroed by the
+// reference (encoder.c:8332).  The GPU stage cannot know while it writes: a sample this large is written again by the host writer (conservative: the test is on the
+// whole sample, the reference asks in front of every band of the two frame wavelets).
+bool gop_sample_may_zero_bands(const GopPlan &plan, size_t bytes) { return (uint64_t)bytes * 100 > (uint64_t)plan.sample_buffer_bytes * 80; }
 
 size_t write_sequence_header(const GopPlan &plan, int input_format, uint8_t *out, size_t cap)
 {

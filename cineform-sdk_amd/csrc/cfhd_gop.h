@@ -47,6 +47,9 @@ bool derive_gop_quantization(GopPlan *plan, int quality, QuantState *st, float f
 // The group sample (codec.c:835 PutVideoGroupHeader + encoder.c:7461 EncodeQuantizedGroup + :8078 EncodeQuantizedFieldPlusTransform) from the
 // group's coefficient pyramid; 0 on overflow.
 size_t write_group_sample(const GopPlan &plan, const SampleHeaderInfo &hdr, const int16_t *coeffs, uint8_t *out, size_t cap);
+// The same sample as a template for the GPU entropy stage: holes carry (channel, wavelet index as `level`, band); kind 0 = raw 16-bit band (w[5] / w[3] band 0).
+void build_group_template(const GopPlan &plan, const SampleHeaderInfo &hdr, SampleTemplate *t);
+bool gop_sample_may_zero_bands(const GopPlan &plan, size_t bytes);
 // The 40-byte sequence header a sequence starts with (codec.c:736) and the 24-byte sample of a group's second frame (codec.c:1258).
 size_t write_sequence_header(const GopPlan &plan, int input_format, uint8_t *out, size_t cap);
 size_t write_pframe_sample(const GopPlan &plan, uint32_t frame_number, uint8_t *out, size_t cap);

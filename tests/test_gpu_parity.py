@@ -218,7 +218,7 @@ def test_invalid_arguments_and_unsupported_formats():
 
 
 HARNESS_FIXTURE = os.path.join(os.path.dirname(__file__), "golden", "testcfhd_D.json")
-HARNESS_MIN_SECTIONS = 5        # YUY2, 2vuy, YU64, RG24 -> 4:2:2, RG24 -> RGB 4:4:4 at full resolution (what round 3 served; more sections = more checked)
+HARNESS_MIN_SECTIONS = 30       # of the table's 40 (20 rows at full and at half resolution); the hardware run of round 4 (profiles/r04_e_*) printed all 40 in 148 s, the suite gives it 300
 
 
 def run_harness(binary, limit_s=600, stop_after=None):
@@ -259,19 +259,21 @@ def test_reference_harness_links_unchanged_and_prints_same_numbers():
     want = json.load(open(HARNESS_FIXTURE))["sections"]
     # (a frame of the harness costs about two seconds of Qbist drawing on one core: the suite gives it three minutes -- seven or eight sections, among them BGRA from a
     # 4:2:2 sample, the first of round 4's routes; tools/gpu_r04_d.sh runs it to its end, profiles/r04_testcfhd_amd_D.txt)
-    got = run_harness(ours, limit_s=int(os.environ.get("CFHD_HARNESS_SECONDS", "190")))
+    got = run_harness(ours, limit_s=int(os.environ.get("CFHD_HARNESS_SECONDS", "300")))
     done = [s for s in got if len(s["frames"]) == 10]
     assert len(done) >= HARNESS_MIN_SECTIONS, "our library completed %d sections: %r" % (len(done), [(s["format"], s["encode"], s["decode"], len(s["frames"])) for s in got])
     for k, s in enumerate(done):
         w = want[k]
         assert (s["format"], s["encode"], s["decode"]) == (w["format"], w["encode"], w["decode"]), "section %d: %r" % (k, s)
+        # how far the reference's own runs lie apart on a stable frame of this section (rand() dither: 0.1 dB; its alpha race on 4:4:4:4 -> BGRA / BGRa, worst at
+        # half resolution: 0.3 dB between three runs): our number has to lie that close to the values the reference printed, and within 0.1 dB where it repeats itself
+        spread = max([0.1] + [max(f["psnr_seen"]) - min(f["psnr_seen"]) for f in w["frames"] if f.get("stable", True) and f["psnr_seen"]])
         for i, ((size, db), f) in enumerate(zip(s["frames"], w["frames"])):
             where = "%s %s %s frame %d" % (s["format"], s["encode"], s["decode"], i + 1)
             assert size == f["size"], "%s: compressed size %d vs reference %d" % (where, size, f["size"])
-            # the reference's own spread over the fixture's runs (rand() dither; its alpha race on 4:4:4:4 -> BGRA moves a frame by 0.1-0.3 dB)
             if not f.get("stable", True): continue           # (the reference's own runs disagree on this frame by more than a dB: no number to compare with)
             seen = f["psnr_seen"] or [f["psnr"]]
-            assert min(seen) - 0.1 - 1e-6 <= db <= max(seen) + 0.1 + 1e-6, "%s: PSNR %.1f dB vs reference %r" % (where, db, seen)
+            assert min(seen) - spread - 1e-6 <= db <= max(seen) + spread + 1e-6, "%s: PSNR %.1f dB vs reference %r (spread of its runs in this section: %.1f dB)" % (where, db, seen, spread)
     print("harness: %d of %d sections completed and equal to the reference's printout" % (len(done), len(want)))
 
 

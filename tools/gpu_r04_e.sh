@@ -14,10 +14,11 @@ want = json.load(open("tests/golden/testcfhd_D.json"))["sections"]
 ok = bad = unstable = 0
 for k, s in enumerate(got):
     w = want[k]
+    spread = max([0.1] + [max(f["psnr_seen"]) - min(f["psnr_seen"]) for f in w["frames"] if f.get("stable", True) and f["psnr_seen"]])
     for i, (size, db) in enumerate(s["frames"]):
         f = w["frames"][i]; seen = f["psnr_seen"] or [f["psnr"]]
         if not f.get("stable", True): unstable += 1; bad += size != f["size"]; continue
-        good = size == f["size"] and min(seen) - 0.1001 <= db <= max(seen) + 0.1001
+        good = size == f["size"] and min(seen) - spread - 0.0001 <= db <= max(seen) + spread + 0.0001
         ok += good; bad += not good
         if not good: print("MISMATCH", s["format"], s["encode"], s["decode"], i + 1, (size, db), (f["size"], seen))
 print("harness: %d sections printed (%d complete), %d frames equal to the reference's printout, %d not, %d frames on which the reference has no stable PSNR (size equal)" % (len(got), sum(len(s["frames"]) == 10 for s in got), ok, bad, unstable))
