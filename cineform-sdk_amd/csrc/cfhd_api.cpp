@@ -164,6 +164,8 @@ size_t sample_capacity(const EncodeParams &p) { return (size_t)p.width * p.heigh
 // Where the run-length/VLC stage runs: on the GPU by default; CFHD_AMD_ENTROPY=host keeps the reference's arrangement
 // (host threads fed by one D2H copy of the quantized bands).  Both produce the same bytes.
 bool gpu_entropy_enabled() { const char *e = getenv("CFHD_AMD_ENTROPY"); return !(e && strcmp(e, "host") == 0); }
+// CFHD_AMD_ENTROPY=device: (tests) a sample the device stage hands back to the host coder fails the call instead -- proves which stage served a group
+bool gpu_entropy_strict() { const char *e = getenv("CFHD_AMD_ENTROPY"); return e && strcmp(e, "device") == 0; }
 
 int prepare_batch(EncodeBatch &batch, const EncodeParams &p)
 {
@@ -658,6 +660,7 @@ CFHD_Error CFHD_EncodeSample(CFHD_EncoderRef ref, void *frame, int pitch)
 			if (e->gop_batch.prepare(e->params.gplan, false, e->params.pixel_kind)) return ERR_INTERNAL;
 			e->gop_ready = true;
 			e->sample.assign(2 * sample_capacity(e->params), 0);
+			if (gpu_entropy_enabled() && e->gop_batch.prepare_entropy(e->sample.size())) return ERR_INTERNAL;
 		}
 		const uint32_t n = e->gop_calls++;
 		// Rate feedback (encoder.c:2880-2905): every call re-derives the subband tables from the size of the last key sample (the FILMSCAN2/3 limiter moves), the
@@ -677,11 +680,24 @@ CFHD_Error CFHD_EncodeSample(CFHD_EncoderRef ref, void *frame, int pitch)
 			bytes = n == 0 ? write_sequence_header(e->params.gplan, color_format_of(e->params.pixel_kind), e->sample.data(), e->sample.size())
 			               : write_pframe_sample(e->params.gplan, n - 1, e->sample.data(), e->sample.size());
 		} else {
-			if (e->gop_batch.launch_forward() || e->gop_batch.download_coeffs() || e->gop_batch.wait()) return ERR_INTERNAL;
 			MetaBlock global = e->meta.global, local = e->meta.local;
 			meta_remove_hidden(global); meta_remove_hidden(local);
 			SampleHeaderInfo hdr = { n, color_format_of(e->params.pixel_kind), e->params.color_space, e->params.quality, true, global.data(), global.size(), local.data(), local.size() };
-			bytes = write_group_sample(e->params.gplan, hdr, e->gop_batch.host_coeffs(), e->sample.data(), e->sample.size());
+			if (e->gop_batch.launch_forward()) return ERR_INTERNAL;
+			bytes = 0;
+			// GPU entropy stage: the finished group sample comes back, not the pyramid.  The host writer takes over (from the same GPU coefficients) when the header
+			// does not fit the device template block, and for a sample so large that the reference would have zeroed bands of the frame wavelets (encoder.c:8332:
+			// that depends on the bytes written so far, which the device stage only knows when it is done)
+			if (e->gop_batch.has_entropy() && e->gop_batch.entropy().set_frame_header(0, hdr) == 0) {
+				if (e->gop_batch.entropy().launch() || e->gop_batch.entropy().download() || e->gop_batch.wait()) return ERR_INTERNAL;
+				const size_t nb = e->gop_batch.entropy().sample_bytes(0);
+				if (nb && nb <= e->sample.size() && !gop_sample_may_zero_bands(e->params.gplan, nb)) { memcpy(e->sample.data(), e->gop_batch.entropy().host_sample(0), nb); bytes = nb; }
+			}
+			if (!bytes) {
+				if (gpu_entropy_strict()) return ERR_INTERNAL;
+				if (e->gop_batch.download_coeffs() || e->gop_batch.wait()) return ERR_INTERNAL;
+				bytes = write_group_sample(e->params.gplan, hdr, e->gop_batch.host_coeffs(), e->sample.data(), e->sample.size());
+			}
 		}
 		e->meta.local.clear();
 		if (!bytes) return ERR_CODEC_ERROR;
@@ -1153,6 +1169,18 @@ static CFHD_Error decode_group_sample(Decoder *d, const uint8_t *s, size_t size,
 		if (prc) return ERR_INTERNAL;
 		d->gop_ready = true;
 	}
+	const uint32_t dither_seed = 0x2545F491u * ++d->frames_decoded;
+	// GPU entropy stage (the default): the sample goes to HBM, every coded band to one workgroup; a sample the device stage does not serve (launch < 0: geometry
+	// the kernels do not take, a raw band with a divisor) is decoded below by the host coder instead
+	if (gpu_entropy_enabled() && d->gop_batch.launch_entropy_decode(s, size, pg, (size_t)gp.width * gp.display_height * 8 + 131072) == 0) {
+		if (d->gop_batch.launch_inverse(dither_seed, true)) return ERR_INTERNAL;
+		if (d->gop_batch.download_frame(0, nullptr, 0) || d->gop_batch.download_frame(1, nullptr, 0) || d->gop_batch.wait()) return ERR_INTERNAL;
+		if (d->gop_batch.entropy_decode_errors()) return fail_zero(ERR_BADSAMPLE);
+		d->gop_batch.finish_frame(0, out, pitch);
+		d->gop_second = true;
+		return ERR_OKAY;
+	}
+	if (gpu_entropy_strict()) return fail_zero(ERR_INTERNAL);
 	int16_t *coeffs = d->gop_batch.host_coeffs_rw();
 	memset(coeffs, 0, gp.coeff_elems * 2);
 	for (int c = 0; c < 3; c++) {
@@ -1184,7 +1212,7 @@ static CFHD_Error decode_group_sample(Decoder *d, const uint8_t *s, size_t size,
 			}
 		}
 	}
-	if (d->gop_batch.launch_inverse(0x2545F491u * ++d->frames_decoded)) return ERR_INTERNAL;
+	if (d->gop_batch.launch_inverse(dither_seed)) return ERR_INTERNAL;
 	if (d->gop_batch.download_frame(0, nullptr, 0) || d->gop_batch.download_frame(1, nullptr, 0) || d->gop_batch.wait()) return ERR_INTERNAL;
 	d->gop_batch.finish_frame(0, out, pitch);
 	d->gop_second = true;

@@ -155,10 +155,18 @@ public:
 	int upload_frame(int f, const void *frame, int pitch_bytes);      // f = 0, 1: stage one frame of the pair and start its H2D copy
 	int launch_forward();                            // async: level 1 of both frames, temporal step, three spatial transforms per channel
 	int download_coeffs();                           // async: the group pyramid -> pinned host
+	// GPU entropy stage for the group sample (GpuEntropyEncoder::prepare_group): entropy().set_frame_header(0, hdr), launch_forward(), entropy().launch(),
+	// entropy().download(), wait() -> entropy().host_sample(0)
+	int prepare_entropy(size_t sample_cap);
+	bool has_entropy() const { return ent_ready_; }
+	GpuEntropyEncoder &entropy() { return ent_; }
 	const int16_t *host_coeffs() const { return h_coeff_; }
 	// decoder
 	int16_t *host_coeffs_rw() { return h_coeff_; }   // the host entropy decoder writes the dequantized bands here
-	int launch_inverse(uint32_t dither_seed);        // async: pyramid H2D, three inverse spatial transforms, temporal step, last level of both frames
+	// GPU entropy decode of a parsed group sample into the pyramid in HBM (GpuGroupEntropyDecoder); < 0: not served / malformed, decode on the host instead
+	int launch_entropy_decode(const uint8_t *sample, size_t size, const ParsedGroup &pg, size_t sample_cap);
+	int entropy_decode_errors() { return dec_.check(); }                    // after wait()
+	int launch_inverse(uint32_t dither_seed, bool coeffs_on_device = false);      // async: (pyramid H2D,) three inverse spatial transforms, temporal step, last level of both frames
 	int download_frame(int f, void *out, int pitch_bytes);
 	int finish_frame(int f, void *out, int pitch_bytes);
 	int wait();
@@ -170,6 +178,8 @@ private:
 	uint8_t *d_frames_ = nullptr, *h_frames_ = nullptr; size_t frame_bytes_ = 0; int pitch_ = 0, rows_ = 0;
 	int16_t *d_coeff_ = nullptr, *h_coeff_ = nullptr;
 	void *d_jobs_ = nullptr, *h_jobs_ = nullptr; size_t jobs_bytes_ = 0; bool jobs_dirty_ = true;
+	GpuEntropyEncoder ent_; bool ent_ready_ = false;
+	GpuGroupEntropyDecoder dec_; bool dec_ready_ = false;
 };
 
 int packed_frame_pitch(int pixel_kind, int width);     // bytes per row of a tightly packed frame

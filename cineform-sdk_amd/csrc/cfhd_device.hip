@@ -484,7 +484,7 @@ static bool planes_as_strips(const FramePlan &plan, int lv /* wavelet index whos
 	if (forced == 1 || (forced == 0 && frames_1080p_equivalent(plan, frames) < 160.0)) return false;
 	for (int c = 0; c < plan.num_channels; c++) {
 		const BandDesc &b = plan.ch[c].band[lv][0];
-		if (b.width % dev::SBLK || b.width / dev::SBLK > 64 || plan.ch[c].band[lv - 1][0].width != 2 * b.width || plan.ch[c].band[lv - 1][0].height != 2 * b.height ||
+		if (b.width % dev::SBLK || plan.ch[c].band[lv - 1][0].width != 2 * b.width || plan.ch[c].band[lv - 1][0].height != 2 * b.height ||
 		    (plan.ch[c].band[lv - 1][0].pitch & 7) || (b.pitch & 7)) return false;
 	}
 	return true;
@@ -497,7 +497,10 @@ template <typename F> static void for_channel_runs(const FramePlan &plan, int lv
 		       plan.ch[c0 + nc].band[lv][0].height == plan.ch[c0].band[lv][0].height) nc++;
 		const BandDesc &b = plan.ch[c0].band[lv][0];
 		int glog = 0; while ((1 << glog) < b.width / dev::SBLK) glog++;
-		f(c0, nc, glog, b);
+		// more than 64 blocks of 8 columns: one plane per wave in segments of PLSTEP blocks (the lanes at a segment's ends feed their neighbours)
+		const int nblk = b.width / dev::SBLK, nseg = nblk > 64 ? (nblk + dev::PLSTEP - 1) / dev::PLSTEP : 1;
+		if (nseg > 1) glog = 6;
+		f(c0, nc, glog, b, nseg);
 		c0 += nc;
 	}
 }
@@ -604,9 +607,9 @@ int EncodeBatch::launch_forward(bool coeffs_needed)
 		const dev::FwdPlaneJob *jobs = lv == 1 ? j.l2 : j.l3;
 		if (planes_as_strips(plan_, lv, act)) {
 			const int n = act;
-			for_channel_runs(plan_, lv, [&](int c0, int nc, int glog, const BandDesc &b) {
-				const int nstrips = (b.height + dev::SRP - 1) / dev::SRP, per_wave = 64 >> glog, waves = ((n * nc + per_wave - 1) / per_wave) * nstrips;
-				dev::k_fwd_plane_strip<<<(waves + 3) / 4, dev::NTHREADS, 0, st>>>(jobs, n, nch, c0, nc, glog, nstrips, 2 * b.width, 2 * b.height);
+			for_channel_runs(plan_, lv, [&](int c0, int nc, int glog, const BandDesc &b, int nseg) {
+				const int nstrips = (b.height + dev::SRP - 1) / dev::SRP, per_wave = nseg > 1 ? 1 : 64 >> glog, waves = ((n * nc + per_wave - 1) / per_wave) * nstrips * nseg;
+				dev::k_fwd_plane_strip<<<(waves + 3) / 4, dev::NTHREADS, 0, st>>>(jobs, n, nch, c0, nc, glog, nstrips, 2 * b.width, 2 * b.height, nseg);
 			});
 			continue;
 		}
@@ -964,9 +967,9 @@ int DecodeBatch::launch_inverse(uint32_t dither_seed)
 		const dev::InvPlaneJob *jobs = lv == 2 ? j.l3 : j.l2;
 		if (planes_as_strips(plan_, lv, act)) {
 			const int n = act;
-			for_channel_runs(plan_, lv, [&](int c0, int nc, int glog, const BandDesc &cb) {
-				const int nstrips = (cb.height + dev::SRP - 1) / dev::SRP, per_wave = 64 >> glog, waves = ((n * nc + per_wave - 1) / per_wave) * nstrips;
-				dev::k_inv_plane_strip<<<(waves + 3) / 4, dev::NTHREADS, 0, sl>>>(jobs, n, nch, c0, nc, glog, nstrips, cb.width, cb.height);
+			for_channel_runs(plan_, lv, [&](int c0, int nc, int glog, const BandDesc &cb, int nseg) {
+				const int nstrips = (cb.height + dev::SRP - 1) / dev::SRP, per_wave = nseg > 1 ? 1 : 64 >> glog, waves = ((n * nc + per_wave - 1) / per_wave) * nstrips * nseg;
+				dev::k_inv_plane_strip<<<(waves + 3) / 4, dev::NTHREADS, 0, sl>>>(jobs, n, nch, c0, nc, glog, nstrips, cb.width, cb.height, nseg);
 			});
 			HIPCHK(hipEventRecord((hipEvent_t)(inv_split_ ? ev2_[3 - lv] : evl_[2 - lv]), sl));
 			continue;
@@ -1132,6 +1135,8 @@ void GopBatch::release()
 {
 	(void)hipSetDevice(device_);
 	if (stream_) hipStreamSynchronize((hipStream_t)stream_);
+	ent_ready_ = false;                              // (its buffers go with the object or with the next prepare_group(); it is not used before prepare_entropy() ran again)
+	if (dec_ready_) { dec_.release(); dec_ready_ = false; }
 	if (d_frames_) hipFree(d_frames_);
 	if (h_frames_) hipHostFree(h_frames_);
 	if (d_coeff_) hipFree(d_coeff_);
@@ -1170,7 +1175,29 @@ void GopBatch::set_plan(const GopPlan &plan)
 {
 	if (stream_) (void)hipStreamSynchronize((hipStream_t)stream_);
 	plan_ = plan;
+	if (ent_ready_) ent_.set_group_plan(plan);
 	fill_jobs();
+}
+
+int GopBatch::prepare_entropy(size_t sample_cap)
+{
+	(void)hipSetDevice(device_);
+	ent_ready_ = false;
+	if (decode_ || !d_coeff_) return -1;
+	const int rc = ent_.prepare_group(plan_, 1, d_coeff_, plan_.coeff_elems, sample_cap, stream_);
+	ent_ready_ = rc == 0;
+	return rc;
+}
+
+int GopBatch::launch_entropy_decode(const uint8_t *sample, size_t size, const ParsedGroup &pg, size_t sample_cap)
+{
+	(void)hipSetDevice(device_);
+	if (!decode_ || !d_coeff_) return -1;
+	if (!dec_ready_) {
+		if (dec_.prepare(plan_, d_coeff_, sample_cap, out_kind_, stream_, device_)) return -1;
+		dec_ready_ = true;
+	}
+	return dec_.launch(sample, size, pg);
 }
 
 void GopBatch::fill_jobs()
@@ -1263,12 +1290,12 @@ int GopBatch::download_coeffs()
 	return 0;
 }
 
-int GopBatch::launch_inverse(uint32_t dither_seed)
+int GopBatch::launch_inverse(uint32_t dither_seed, bool coeffs_on_device)
 {
 	(void)hipSetDevice(device_);
 	hipStream_t st = (hipStream_t)stream_;
 	if (jobs_dirty_) { HIPCHK(hipMemcpyAsync(d_jobs_, h_jobs_, jobs_bytes_, hipMemcpyHostToDevice, st)); jobs_dirty_ = false; }
-	HIPCHK(hipMemcpyAsync(d_coeff_, h_coeff_, plan_.coeff_elems * 2, hipMemcpyHostToDevice, st));
+	if (!coeffs_on_device) HIPCHK(hipMemcpyAsync(d_coeff_, h_coeff_, plan_.coeff_elems * 2, hipMemcpyHostToDevice, st));
 	GopJobs j = gop_jobs_at(d_jobs_);
 	(void)hipGetLastError();
 	const GopWavelet &top = plan_.ch[0].w[5], &mid = plan_.ch[0].w[4], &t = plan_.ch[0].w[2], &l1 = plan_.ch[0].w[0];

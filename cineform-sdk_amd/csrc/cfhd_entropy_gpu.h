@@ -3,6 +3,7 @@
 #pragma once
 #include "cfhd_core.h"
 #include "cfhd_bitstream.h"
+#include "cfhd_gop.h"
 #include <vector>
 
 namespace cfhd {
@@ -15,6 +16,10 @@ public:
 	int prepare(const FramePlan &plan, int nframes, int16_t *d_coeffs, size_t coeff_stride_elems, size_t sample_cap, void *stream);
 	int set_frame_header(int i, const SampleHeaderInfo &hdr);        // header fields / metadata of frame i's sample
 	void set_plan(const FramePlan &plan) { plan_ = plan; }          // same geometry, new quantizer values: the headers written from now on carry them
+	// Two-frame groups: unit i is a group sample (17 subbands per channel, two raw 16-bit bands), its pyramid laid out by GopPlan; set_frame_header() writes group headers.
+	// A sample beyond gop_sample_may_zero_bands() is not valid (the reference zeroes bands there, encoder.c:8332): the caller writes it on the host.
+	int prepare_group(const GopPlan &plan, int ngroups, int16_t *d_coeffs, size_t coeff_stride_elems, size_t sample_cap, void *stream);
+	void set_group_plan(const GopPlan &plan) { gplan_ = plan; }
 	int launch();                                                    // async: templates H2D + 4 kernels
 	int download();                                                  // sizes + packed offsets -> sync -> one async copy of all sample bytes (wait on the stream afterwards)
 	int fetch_sizes();                                               // sizes only (device-resident consumers); synchronises the stream
@@ -48,6 +53,9 @@ public:
 private:
 	struct Host; Host *host_;           // host mirrors of the job tables (types live in the kernel headers)
 	void release();
+	int prepare_units(int n, int16_t *d_coeffs, size_t coeff_stride_elems, size_t sample_cap, void *stream);
+	void build_template(const SampleHeaderInfo &hdr, SampleTemplate *t) const;
+	bool group_ = false; GopPlan gplan_;
 	FramePlan plan_; int n_ = 0, active_ = 0, device_ = 0 /* the GPU prepare() ran on */; size_t cap_ = 0; void *stream_ = nullptr;
 	int active_frames() const { return active_ > 0 && active_ < n_ ? active_ : n_; }
 	int nbands_ = 0, total_segs_ = 0;
@@ -120,6 +128,26 @@ private:
 	void *ev_l23_ = nullptr, *ev_low_ = nullptr; bool l23_split_ = false;      // ev_low_: in front of k_dec_lowpass when it runs between the two tile passes      // recorded behind the tiles of the level-2 / level-3 bands and the lowpass bands when the tile pass is split
 	void *ev_[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; bool timed_ = false;    // [4]: end of k_dec_parse when the band decoder waits for a second event behind it; [5], [6]: behind k_dec_index / k_dec_chain
 	bool parse_end_ = false;
+};
+
+// Group samples (cfhd_gop.h): parsed on the host (parse_group_sample), every coded band of the 17 subbands per channel decoded by one workgroup of
+// k_dec_bands_par_ll (the flat job list of the round-1 decoder: a single group is a latency problem, not a throughput one), the two raw 16-bit bands of a channel
+// by k_dec_lowpass.  The dequantized pyramid is left in HBM for GopBatch::launch_inverse.
+class GpuGroupEntropyDecoder {
+public:
+	GpuGroupEntropyDecoder() {}
+	~GpuGroupEntropyDecoder() { release(); }
+	int prepare(const GopPlan &plan, int16_t *d_coeffs, size_t sample_cap, int out_pixel_kind, void *stream, int device = -1);
+	// async: sample H2D, job tables, the two kernels.  < 0: the sample does not fit the plan (nothing was launched)
+	int launch(const uint8_t *sample, size_t size, const ParsedGroup &pg);
+	int check();                         // after the stream was synchronised: 0 when every band decoded cleanly
+	void release();
+private:
+	GopPlan plan_; int out_kind_ = 0, device_ = 0; size_t cap_ = 0; void *stream_ = nullptr;
+	int16_t *d_coeffs_ = nullptr;
+	uint8_t *d_sample_ = nullptr, *h_sample_ = nullptr;
+	void *d_tables_ = nullptr, *d_bandjobs_ = nullptr, *d_lowjobs_ = nullptr, *h_bandjobs_ = nullptr, *h_lowjobs_ = nullptr;
+	int *d_errors_ = nullptr, *h_errors_ = nullptr;
 };
 
 } // namespace cfhd

@@ -14,7 +14,7 @@ int device_current();
 namespace { int g_fail(hipError_t e, const char *what) { fprintf(stderr, "[cfhd_amd] %s: %s\n", what, hipGetErrorString(e)); return (int)e ? (int)e : -1; } }
 #define HIPCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return g_fail(_e, #expr); } while (0)
 
-struct GpuEntropyEncoder::Host { EntHostJobs jobs; dev::EntFrameJob *frames = nullptr; /* pinned: async copies must not stall the host */ };
+struct GpuEntropyEncoder::Host { EntHostJobs jobs; std::vector<EntHoleGeom> geom; dev::EntFrameJob *frames = nullptr; /* pinned: async copies must not stall the host */ };
 
 GpuEntropyEncoder::GpuEntropyEncoder() : host_(new Host) {}
 GpuEntropyEncoder::~GpuEntropyEncoder() { release(); delete host_; }
@@ -41,11 +41,30 @@ void GpuEntropyEncoder::release()
 
 int GpuEntropyEncoder::prepare(const FramePlan &plan, int nframes, int16_t *d_coeffs, size_t stride, size_t sample_cap, void *stream)
 {
+	group_ = false; plan_ = plan;
+	return prepare_units(nframes, d_coeffs, stride, sample_cap, stream);
+}
+
+// Two-frame groups (cfhd_gop.h): one group per unit, 17 subbands per channel -- the same kernels over the group's template and band table.
+int GpuEntropyEncoder::prepare_group(const GopPlan &plan, int ngroups, int16_t *d_coeffs, size_t stride, size_t sample_cap, void *stream)
+{
+	group_ = true; gplan_ = plan; plan_ = FramePlan(); plan_.interlaced = false;
+	return prepare_units(ngroups, d_coeffs, stride, sample_cap, stream);
+}
+
+void GpuEntropyEncoder::build_template(const SampleHeaderInfo &hdr, SampleTemplate *t) const
+{
+	if (group_) build_group_template(gplan_, hdr, t); else build_sample_template(plan_, hdr, t);
+}
+
+int GpuEntropyEncoder::prepare_units(int nframes, int16_t *d_coeffs, size_t stride, size_t sample_cap, void *stream)
+{
 	int rc = device_init();
 	if (rc) return rc;
 	release();
 	device_ = device_current(); (void)hipSetDevice(device_);
-	plan_ = plan; n_ = nframes; cap_ = (sample_cap + 255) & ~(size_t)255; stream_ = stream; d_coeffs_ = d_coeffs; coeff_stride_ = stride;
+	const FramePlan &plan = plan_;
+	n_ = nframes; cap_ = (sample_cap + 255) & ~(size_t)255; stream_ = stream; d_coeffs_ = d_coeffs; coeff_stride_ = stride;
 	if (cap_ * (size_t)n_ >= ((size_t)1 << 32)) { fprintf(stderr, "[cfhd_amd] batch of %d frames exceeds the 4 GiB sample arena\n", n_); return -5; }   // packed offsets are 32-bit
 	{
 		std::vector<dev::EntTables> h(2);
@@ -55,9 +74,10 @@ int GpuEntropyEncoder::prepare(const FramePlan &plan, int nframes, int16_t *d_co
 	}
 	SampleHeaderInfo hdr0 = { 1, 2, 2, 4, !plan.interlaced, nullptr, 0, nullptr, 0 };
 	tmpl_.assign(n_, SampleTemplate());
-	build_sample_template(plan, hdr0, &tmpl_[0]);
+	build_template(hdr0, &tmpl_[0]);
 	EntHostJobs &jobs = host_->jobs;
-	if (!ent_build_band_jobs(plan, tmpl_[0], n_, d_coeffs, stride, &jobs)) return -3;
+	host_->geom = group_ ? ent_hole_geometry(gplan_, tmpl_[0]) : ent_hole_geometry(plan, tmpl_[0]);
+	if (!ent_build_band_jobs(host_->geom, tmpl_[0], n_, d_coeffs, stride, &jobs)) return -3;
 	nbands_ = jobs.nbands; total_segs_ = (int)jobs.segjobs.size();
 	HIPCHK(hipMalloc(&d_bands_, jobs.bands.size() * sizeof(dev::EntBandJob)));
 	HIPCHK(hipMemcpy(d_bands_, jobs.bands.data(), jobs.bands.size() * sizeof(dev::EntBandJob), hipMemcpyHostToDevice));
@@ -69,7 +89,7 @@ int GpuEntropyEncoder::prepare(const FramePlan &plan, int nframes, int16_t *d_co
 	// block lists of the level-1 bands, for the geometries k_fwd_yuv422_strip_blocks serves (EncodeBatch::strip_forward): one 16-byte slot per block of the
 	// pyramid (only the slots of listed blocks are ever touched), one mask per chunk
 	static_assert((int)kBlockChunkCols == (int)dev::FWD_CHUNK_COLS_ENT, "one chunk geometry");
-	if (!plan.interlaced && plan.encoded_format == ENC_YUV422 && (plan.pixel_kind == PIX_YUY2 || plan.pixel_kind == PIX_2VUY) && plan.width % 32 == 0) {
+	if (!group_ && !plan.interlaced && plan.encoded_format == ENC_YUV422 && (plan.pixel_kind == PIX_YUY2 || plan.pixel_kind == PIX_2VUY) && plan.width % 32 == 0) {
 		int mask_base[kMaxChannels][kNumBands];
 		masks_per_frame_ = (size_t)block_list_layout(plan, mask_base);
 		HIPCHK(hipMalloc(&d_blocks_, stride * 2 * (size_t)n_));
@@ -100,8 +120,8 @@ int GpuEntropyEncoder::set_frame_header(int f, const SampleHeaderInfo &hdr)
 {
 	if (f < 0 || f >= n_) return -1;
 	SampleTemplate &t = tmpl_[f];
-	build_sample_template(plan_, hdr, &t);
-	if (!ent_fill_frame_block(plan_, t, f, host_->jobs, d_coeffs_ + (size_t)f * coeff_stride_, h_tmpl_ + (size_t)kEntTmplStride * f)) return -4;
+	build_template(hdr, &t);
+	if (!ent_fill_frame_block(host_->geom, t, f, host_->jobs, d_coeffs_ + (size_t)f * coeff_stride_, h_tmpl_ + (size_t)kEntTmplStride * f)) return -4;
 	host_->frames[f] = ent_frame_job(t, d_tmpl_ + (size_t)kEntTmplStride * f, d_samples_ + cap_ * f, (uint32_t)cap_, d_sizes_ + f);
 	dirty_ = true;
 	return 0;
@@ -551,5 +571,90 @@ float GpuEntropyDecoder::kernel_ms(int k)
 	if (!timed_ || k < 0 || k > 2 || hipEventElapsedTime(&ms, (hipEvent_t)ev_[k], (hipEvent_t)end) != hipSuccess) { (void)hipGetLastError(); return 0; }
 	return ms;
 }
+
+// =============================================================================================
+// GpuGroupEntropyDecoder
+// =============================================================================================
+void GpuGroupEntropyDecoder::release()
+{
+	(void)hipSetDevice(device_);
+	void *dev[] = { d_sample_, d_tables_, d_bandjobs_, d_lowjobs_, d_errors_ };
+	for (void *p : dev) if (p) (void)hipFree(p);
+	void *host[] = { h_sample_, h_bandjobs_, h_lowjobs_, h_errors_ };
+	for (void *p : host) if (p) (void)hipHostFree(p);
+	d_sample_ = h_sample_ = nullptr; d_tables_ = d_bandjobs_ = d_lowjobs_ = h_bandjobs_ = h_lowjobs_ = nullptr; d_errors_ = h_errors_ = nullptr;
+}
+
+enum { kGroupBandJobs = 3 * 15, kGroupRawJobs = 3 * 2 };
+
+int GpuGroupEntropyDecoder::prepare(const GopPlan &plan, int16_t *d_coeffs, size_t sample_cap, int out_kind, void *stream, int device)
+{
+	int rc = device_init();
+	if (rc) return rc;
+	release();
+	device_ = device >= 0 ? device : device_current(); (void)hipSetDevice(device_);      // (the GPU the pyramid and the stream live on)
+	plan_ = plan; d_coeffs_ = d_coeffs; cap_ = (sample_cap + 255) & ~(size_t)255; out_kind_ = out_kind; stream_ = stream;
+	std::vector<uint32_t> t = build_dec_tables(1);
+	HIPCHK(hipMalloc(&d_tables_, t.size() * 4));
+	HIPCHK(hipMemcpy(d_tables_, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+	HIPCHK(hipMalloc((void **)&d_sample_, cap_));
+	HIPCHK(hipHostMalloc((void **)&h_sample_, cap_, hipHostMallocPortable));
+	HIPCHK(hipMalloc(&d_bandjobs_, kGroupBandJobs * sizeof(dev::DecBandJob)));
+	HIPCHK(hipMalloc(&d_lowjobs_, kGroupRawJobs * sizeof(dev::DecLowpassJob)));
+	HIPCHK(hipHostMalloc(&h_bandjobs_, kGroupBandJobs * sizeof(dev::DecBandJob), hipHostMallocPortable));
+	HIPCHK(hipHostMalloc(&h_lowjobs_, kGroupRawJobs * sizeof(dev::DecLowpassJob), hipHostMallocPortable));
+	HIPCHK(hipMalloc((void **)&d_errors_, sizeof(int)));
+	HIPCHK(hipHostMalloc((void **)&h_errors_, sizeof(int), hipHostMallocPortable));
+	*h_errors_ = 0;
+	return 0;
+}
+
+int GpuGroupEntropyDecoder::launch(const uint8_t *sample, size_t size, const ParsedGroup &pg)
+{
+	(void)hipSetDevice(device_);
+	hipStream_t st = (hipStream_t)stream_;
+	if (size > cap_) return -1;
+	HIPCHK(hipStreamSynchronize(st));                                       // the pinned sample / tables of the previous launch may still be in flight
+	dev::DecBandJob *bj = (dev::DecBandJob *)h_bandjobs_; dev::DecLowpassJob *lj = (dev::DecLowpassJob *)h_lowjobs_;
+	int nb = 0, nl = 0;
+	for (int c = 0; c < 3; c++) {
+		const GopChannel &ch = plan_.ch[c];
+		const ParsedBand &lp = pg.lowpass[c];
+		const GopWavelet &top = ch.w[5];
+		if (!lp.present || lp.width != top.width || lp.height != top.height || (size_t)lp.offset + (size_t)top.width * top.height * 2 > size) return -2;
+		// the bias the reference adds to the lowpass band while unpacking it: twice the intra frame's for a group (decoder.c:12265 `num_frames == 2 ? 48 : 24`)
+		lj[nl++] = dev::DecLowpassJob{ d_sample_ + lp.offset, d_coeffs_ + top.offset[0], top.width, top.height, top.pitch, 2 * lowpass_bias(10, top.width, out_kind_) };
+		static const int coded[5] = { 5, 4, 3, 1, 0 };
+		for (int k : coded) {
+			const GopWavelet &wv = ch.w[k];
+			for (int b = (k == 3 ? 0 : 1); b < 4; b++) {
+				const ParsedBand &pb = pg.band[c][k][b];
+				if (!pb.present || pb.width != wv.width || pb.height != wv.height || (pb.offset & 3) || (size_t)pb.offset + pb.bytes > size) return -2;
+				if (pb.codebook < 0) {                                       // raw 16-bit words (the lowpass band of the temporal highpass wavelet): signed, no bias
+					if ((size_t)pb.bytes < (size_t)wv.width * wv.height * 2 || pb.quant != 1 || (wv.width & 1)) return -3;
+					lj[nl++] = dev::DecLowpassJob{ d_sample_ + pb.offset, d_coeffs_ + wv.offset[0], wv.width, wv.height, wv.pitch, 0 };
+					continue;
+				}
+				if (pb.codebook != 1 || (wv.offset[b] & 7) || (wv.pitch & 7)) return -3;
+				bj[nb++] = dev::DecBandJob{ d_sample_ + pb.offset, pb.bytes, d_coeffs_ + wv.offset[b], wv.height * wv.pitch, pb.quant, 0u, 0 };
+			}
+		}
+	}
+	if (nb != kGroupBandJobs || nl != kGroupRawJobs) return -2;
+	std::stable_sort(bj, bj + nb, [](const dev::DecBandJob &a, const dev::DecBandJob &b) { return a.bytes > b.bytes; });      // the long bands start first
+	memcpy(h_sample_, sample, size);
+	HIPCHK(hipMemsetAsync(d_errors_, 0, sizeof(int), st));
+	HIPCHK(hipMemcpyAsync(d_sample_, h_sample_, (size + 3) & ~(size_t)3, hipMemcpyHostToDevice, st));
+	HIPCHK(hipMemcpyAsync(d_bandjobs_, bj, nb * sizeof(dev::DecBandJob), hipMemcpyHostToDevice, st));
+	HIPCHK(hipMemcpyAsync(d_lowjobs_, lj, nl * sizeof(dev::DecLowpassJob), hipMemcpyHostToDevice, st));
+	(void)hipGetLastError();
+	dev::k_dec_bands_par_ll<<<nb, dev::DECP_LL_THREADS, 0, st>>>((const dev::DecBandJob *)d_bandjobs_, (const dev::DecTables *)d_tables_, d_errors_);
+	dev::k_dec_lowpass<<<dim3(8, (unsigned)nl), 256, 0, st>>>((const dev::DecLowpassJob *)d_lowjobs_);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipMemcpyAsync(h_errors_, d_errors_, sizeof(int), hipMemcpyDeviceToHost, st));
+	return 0;
+}
+
+int GpuGroupEntropyDecoder::check() { return h_errors_ ? *h_errors_ : -1; }
 
 } // namespace cfhd

@@ -3,6 +3,7 @@
 #pragma once
 #include "cfhd_core.h"
 #include "cfhd_bitstream.h"
+#include "cfhd_gop.h"
 #include "cfhd_entropy_kernels.h"
 #include "cfhd_dec_kernels.h"
 #include <vector>
@@ -11,7 +12,7 @@
 
 namespace cfhd {
 
-enum { kEntTmplBytes = 6144, kEntWordHolesBytes = 1536, kEntHolesBytes = dev::ENT_MAX_HOLES * (int)sizeof(dev::EntHole), kEntMaxPatches = 64,
+enum { kEntTmplBytes = 6144, kEntWordHolesBytes = 1536, kEntHolesBytes = dev::ENT_MAX_HOLES * (int)sizeof(dev::EntHole), kEntMaxPatches = 96,
        kEntPatchBytes = kEntMaxPatches * (int)sizeof(dev::EntPatch), kEntTmplStride = kEntTmplBytes + kEntWordHolesBytes + kEntHolesBytes + kEntPatchBytes };
 
 // Table 0: code set 17 (codebook 1), every band of a progressive intra frame (encoder.c:6120); table 1: code set 18 (codebook 2), the
@@ -220,43 +221,70 @@ struct EntHostJobs {
 	std::vector<std::pair<int, int>> ranges_l1, ranges_rest;
 };
 
-inline bool ent_build_band_jobs(const FramePlan &plan, const SampleTemplate &t0, int nframes, int16_t *coeffs, size_t stride, EntHostJobs *out)
+// Where the holes of a template find their coefficients: the band of the pyramid behind every hole, in template order (the same for every frame of a batch).
+struct EntHoleGeom { size_t offset; int width, height, pitch; int table /* 0: code set 17, 1: code set 18 */; int mask_base /* block lists: first mask, or -1 */; bool level1; };
+inline std::vector<EntHoleGeom> ent_hole_geometry(const FramePlan &plan, const SampleTemplate &t)
 {
-	if ((int)t0.holes.size() > dev::ENT_MAX_HOLES || (int)t0.patches.size() > kEntMaxPatches) return false;
-	out->bands.clear(); out->segjobs.clear(); out->ranges_l1.clear(); out->ranges_rest.clear();
-	out->band_of_hole.assign(t0.holes.size(), -1);
 	int mask_base[kMaxChannels][kNumBands];
 	block_list_layout(plan, mask_base);
+	std::vector<EntHoleGeom> g;
+	for (const SampleTemplate::Hole &hole : t.holes) {
+		const BandDesc &bd = plan.ch[hole.channel].band[hole.level][hole.band];
+		g.push_back(EntHoleGeom{ bd.offset, bd.width, bd.height, bd.pitch,
+		                         plan.interlaced && hole.level == 0 && hole.band == 2 ? 1 : 0,      // subband 8 of the channel (cfhd_bitstream.cpp walk_sample)
+		                         hole.kind == 1 && hole.level == 0 ? mask_base[hole.channel][hole.band] : -1, hole.level == 0 });
+	}
+	return g;
+}
+// a two-frame group (cfhd_gop.cpp walk_group_sample): `level` is the wavelet index; the bands of the two frame wavelets are final once level 1 of both frames has run
+inline std::vector<EntHoleGeom> ent_hole_geometry(const GopPlan &plan, const SampleTemplate &t)
+{
+	std::vector<EntHoleGeom> g;
+	for (const SampleTemplate::Hole &hole : t.holes) {
+		const GopWavelet &wv = plan.ch[hole.channel].w[hole.level];
+		g.push_back(EntHoleGeom{ wv.offset[hole.band], wv.width, wv.height, wv.pitch, 0, -1, hole.level < 2 });
+	}
+	return g;
+}
+
+inline bool ent_build_band_jobs(const std::vector<EntHoleGeom> &geom, const SampleTemplate &t0, int nframes, int16_t *coeffs, size_t stride, EntHostJobs *out)
+{
+	if ((int)t0.holes.size() > dev::ENT_MAX_HOLES || (int)t0.patches.size() > kEntMaxPatches || geom.size() != t0.holes.size()) return false;
+	out->bands.clear(); out->segjobs.clear(); out->ranges_l1.clear(); out->ranges_rest.clear();
+	out->band_of_hole.assign(t0.holes.size(), -1);
 	for (int f = 0; f < nframes; f++) {
 		int16_t *base = coeffs + (size_t)f * stride;
 		for (size_t h = 0; h < t0.holes.size(); h++) {
 			const SampleTemplate::Hole &hole = t0.holes[h];
 			if (hole.kind != 1) continue;
-			const BandDesc &bd = plan.ch[hole.channel].band[hole.level][hole.band];
+			const EntHoleGeom &bd = geom[h];
 			dev::EntBandJob j;
 			j.coeffs = base + bd.offset; j.n = bd.height * bd.pitch;
 			j.nseg = (j.n + dev::ENT_SEG - 1) / dev::ENT_SEG; j.seg_base = (int)out->segjobs.size();
 			j.frame = f; j.hole = (int)h;
-			j.table = plan.interlaced && hole.level == 0 && hole.band == 2;      // subband 8 of the channel (cfhd_bitstream.cpp walk_sample)
+			j.table = bd.table;
 			if (f == 0) {
 				out->band_of_hole[h] = (int)out->bands.size();
-				std::vector<std::pair<int, int>> &r = hole.level == 0 ? out->ranges_l1 : out->ranges_rest;
+				std::vector<std::pair<int, int>> &r = bd.level1 ? out->ranges_l1 : out->ranges_rest;
 				if (!r.empty() && r.back().first + r.back().second == j.seg_base) r.back().second += j.nseg; else r.push_back({ j.seg_base, j.nseg });
 			}
-			for (int s = 0; s < j.nseg; s++) out->segjobs.push_back(dev::EntSegJob{ j.coeffs, j.n, s * dev::ENT_SEG, (int)out->bands.size(), j.table, bd.pitch,
-			                                                                        hole.level == 0 ? mask_base[hole.channel][hole.band] : -1 });
+			for (int s = 0; s < j.nseg; s++) out->segjobs.push_back(dev::EntSegJob{ j.coeffs, j.n, s * dev::ENT_SEG, (int)out->bands.size(), j.table, bd.pitch, bd.mask_base });
 			out->bands.push_back(j);
 		}
 	}
 	out->nbands = (int)out->bands.size() / nframes;
 	return true;
 }
+inline bool ent_build_band_jobs(const FramePlan &plan, const SampleTemplate &t0, int nframes, int16_t *coeffs, size_t stride, EntHostJobs *out)
+{
+	return ent_build_band_jobs(ent_hole_geometry(plan, t0), t0, nframes, coeffs, stride, out);
+}
 
 // Serialises frame f's template into one kEntTmplStride block: bytes | holes-in-front-of-word | EntHole[] | EntPatch[].
-inline bool ent_fill_frame_block(const FramePlan &plan, const SampleTemplate &t, int f, const EntHostJobs &jobs, const int16_t *coeffs_f, uint8_t *block)
+inline bool ent_fill_frame_block(const std::vector<EntHoleGeom> &geom, const SampleTemplate &t, int f, const EntHostJobs &jobs, const int16_t *coeffs_f, uint8_t *block)
 {
 	if (t.bytes.size() > (size_t)kEntTmplBytes || t.bytes.size() / 4 > (size_t)kEntWordHolesBytes || t.holes.size() != jobs.band_of_hole.size() ||
-	    t.patches.size() > (size_t)kEntMaxPatches) return false;
+	    t.patches.size() > (size_t)kEntMaxPatches || geom.size() != t.holes.size()) return false;
 	memcpy(block, t.bytes.data(), t.bytes.size());
 	uint8_t *wh = block + kEntTmplBytes;
 	size_t hole = 0;
@@ -267,7 +295,7 @@ inline bool ent_fill_frame_block(const FramePlan &plan, const SampleTemplate &t,
 	dev::EntHole *eh = (dev::EntHole *)(block + kEntTmplBytes + kEntWordHolesBytes);
 	for (size_t i = 0; i < t.holes.size(); i++) {
 		const SampleTemplate::Hole &src = t.holes[i];
-		const BandDesc &bd = plan.ch[src.channel].band[src.level][src.band];
+		const EntHoleGeom &bd = geom[i];
 		dev::EntHole &d = eh[i];
 		d.tmpl_offset = src.tmpl_offset; d.kind = src.kind; d.fixed_bytes = src.fixed_bytes;
 		d.band_job = src.kind == 1 ? jobs.band_of_hole[i] + f * jobs.nbands : -1;
@@ -281,6 +309,10 @@ inline bool ent_fill_frame_block(const FramePlan &plan, const SampleTemplate &t,
 		ep[i].end_tmpl = p.end_tmpl; ep[i].end_holes = p.end_holes; ep[i].tag = p.tag;
 	}
 	return true;
+}
+inline bool ent_fill_frame_block(const FramePlan &plan, const SampleTemplate &t, int f, const EntHostJobs &jobs, const int16_t *coeffs_f, uint8_t *block)
+{
+	return ent_fill_frame_block(ent_hole_geometry(plan, t), t, f, jobs, coeffs_f, block);
 }
 
 // Frame job whose pointers refer to `block_addr` (the device -- or, under emulation, host -- address of the serialised block).

@@ -32,7 +32,7 @@ namespace dev {
 #endif
 enum { FWD_CHUNK_COLS_ENT = 496 };      // = FWD_CHUNK_COLS of cfhd_kernels.h (static_assert in cfhd_device.hip, which sees both headers)
 enum { ENT_THREADS = 256, ENT_LANES = 64, ENT_WAVES = ENT_THREADS / ENT_LANES, ENT_PER_THREAD = CFHD_ENT_PER_THREAD, ENT_SEG = ENT_LANES * ENT_PER_THREAD,
-       ENT_LDS_WORDS = 256, ENT_TOK_CAP = CFHD_ENT_TOK_CAP, ENT_MAX_HOLES = 40,
+       ENT_LDS_WORDS = 256, ENT_TOK_CAP = CFHD_ENT_TOK_CAP, ENT_MAX_HOLES = 60 /* an intra sample has up to 40, a two-frame group 51; k_ent_layout sums them in one wave */,
        ENT_FILL = CFHD_ENT_FILL /* bytes of a sample one workgroup of k_ent_layout fills at a time */,
        // what k_ent_count leaves per segment for k_ent_emit: one 32-bit word per token -- its finished bit string (run code + value code, left aligned in
        // the upper 26 bits) and its length in the low 6 bits; a token whose run takes several run codes or whose string is longer than 26 bits carries

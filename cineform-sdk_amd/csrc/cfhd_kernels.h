@@ -1533,35 +1533,42 @@ __global__ void __launch_bounds__(NTHREADS) k_fwd_yuv422_strip_blocks_dense(cons
 // (the same strip of consecutive jobs: geometry and row position are wave-uniform), and needs neither LDS nor barriers: the neighbour
 // columns come from the adjacent lanes, and the lanes at the edges of a group sit on the band borders, whose taps do not look outside.
 // One launch per group of equally wide channels (luma | the two chroma planes of 4:2:2 | all planes of 4:4:4).
-// Geometry served: band width a multiple of 8 and at most 512 columns; everything else takes k_inv_plane / k_fwd_plane.
+// Wider planes (more than 64 blocks: level 2 of 4K / 8K frames) take one plane per wave in segments of 62 blocks (strip_who, nseg > 1).
+// Geometry served: band width a multiple of 8; everything else takes k_inv_plane / k_fwd_plane.
 // =============================================================================================
 enum { SRP = 16 };
 
 struct StripWho { int job; int blk; bool stores; int strip; };
 // wave -> (strip of rows, group of 64 >> glog consecutive selected jobs); lane -> (job of the group, block of 8 columns)
-__device__ __forceinline__ StripWho strip_who(int nframes, int nch, int c0, int nc, int glog, int nstrips, int nblk, bool *wave_idle)
+// nseg > 1 (planes of more than 64 blocks: level 2 of 4K and 8K frames): one plane per wave, cut into segments of PLSTEP blocks; lanes 0 and 63 of a wave carry the
+// blocks next to its segment and only feed their neighbours (as in the level-1 strip kernels).
+enum { PLSTEP = 62 };
+__device__ __forceinline__ StripWho strip_who(int nframes, int nch, int c0, int nc, int glog, int nstrips, int nblk, bool *wave_idle, int nseg = 1)
 {
 	const int lane = threadIdx.x & 63, gwave = (int)blockIdx.x * (NTHREADS / 64) + (int)(threadIdx.x >> 6);
-	const int per_wave = 64 >> glog, sub = lane >> glog, b = lane & ((1 << glog) - 1);
-	const int strip = gwave % nstrips, first_sel = (gwave / nstrips) * per_wave, nsel = nframes * nc;
+	const bool segments = nseg > 1;
+	const int per_wave = segments ? 1 : 64 >> glog, sub = segments ? 0 : lane >> glog;
+	const int strip = gwave % nstrips, rest = gwave / nstrips, seg = segments ? rest % nseg : 0;
+	const int b = segments ? seg * PLSTEP - 1 + lane : (lane & ((1 << glog) - 1));
+	const int first_sel = (segments ? rest / nseg : rest) * per_wave, nsel = nframes * nc;
 	*wave_idle = first_sel >= nsel;
 	int sel = first_sel + sub;
 	const bool job_ok = sel < nsel;
 	if (!job_ok) sel = nsel - 1;
 	StripWho w;
 	w.job = (sel / nc) * nch + c0 + sel % nc;
-	w.stores = job_ok && b < nblk;
-	w.blk = b < nblk ? b : nblk - 1;
+	w.stores = job_ok && b >= 0 && b < nblk && (!segments || (lane >= 1 && lane <= PLSTEP));
+	w.blk = b < 0 ? 0 : (b < nblk ? b : nblk - 1);
 	w.strip = strip;
 	return w;
 }
 
-__global__ void __launch_bounds__(NTHREADS) k_inv_plane_strip(const InvPlaneJob *jobs, int nframes, int nch, int c0, int nc, int glog, int nstrips, int w, int h)
+__global__ void __launch_bounds__(NTHREADS) k_inv_plane_strip(const InvPlaneJob *jobs, int nframes, int nch, int c0, int nc, int glog, int nstrips, int w, int h, int nseg)
 {
 	const int lane = threadIdx.x & 63;
 	const int nblk = w / SBLK;
 	bool idle;
-	const StripWho who = strip_who(nframes, nch, c0, nc, glog, nstrips, nblk, &idle);
+	const StripWho who = strip_who(nframes, nch, c0, nc, glog, nstrips, nblk, &idle, nseg);
 	if (idle) return;                                     // whole wave
 	const InvPlaneJob *job = &jobs[who.job];
 	const int blk = who.blk, pitch = job->band_pitch, descale = job->descale;
@@ -1681,12 +1688,12 @@ __device__ __forceinline__ void strip_plane_push(uint32_t (&LW)[6][4], uint32_t 
 	}
 }
 
-__global__ void __launch_bounds__(NTHREADS) k_fwd_plane_strip(const FwdPlaneJob *jobs, int nframes, int nch, int c0, int nc, int glog, int nstrips, int W, int H)
+__global__ void __launch_bounds__(NTHREADS) k_fwd_plane_strip(const FwdPlaneJob *jobs, int nframes, int nch, int c0, int nc, int glog, int nstrips, int W, int H, int nseg)
 {
 	const int lane = threadIdx.x & 63;
 	const int nblk = W / (2 * SBLK), HH = H >> 1;
 	bool idle;
-	const StripWho who = strip_who(nframes, nch, c0, nc, glog, nstrips, nblk, &idle);
+	const StripWho who = strip_who(nframes, nch, c0, nc, glog, nstrips, nblk, &idle, nseg);
 	if (idle) return;                                     // whole wave
 	const FwdPlaneJob *job = &jobs[who.job];
 	const int blk = who.blk, pitch = job->in_pitch, prescale = job->prescale, out_pitch = job->out_pitch;

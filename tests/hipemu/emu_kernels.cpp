@@ -475,7 +475,7 @@ void emu_half_yuv422(int16_t **ll /*[3]: Y, V, U*/, const int *pitch, int width,
 // nplanes planes of the same geometry (plane k: in[k] -> out[4k..4k+3]) through one launch of k_fwd_plane_strip
 int emu_fwd_plane_strip(int16_t **in, int nplanes, int in_pitch, int width, int height, int prescale, const int *quant, int mpq, int16_t **out, int out_pitch)
 {
-	if (width % (2 * SBLK) || width / (2 * SBLK) > 64) return -1;
+	if (width % (2 * SBLK)) return -1;
 	std::vector<FwdPlaneJob> jobs(nplanes);
 	for (int k = 0; k < nplanes; k++) {
 		FwdPlaneJob &job = jobs[k];
@@ -484,8 +484,10 @@ int emu_fwd_plane_strip(int16_t **in, int nplanes, int in_pitch, int width, int 
 		job.out_pitch = out_pitch; job.xstride = 1; job.shift = 0; job.display_height = height; job.compand = 0;
 	}
 	int glog = 0; while ((1 << glog) < width / (2 * SBLK)) glog++;
-	const int nstrips = (height / 2 + SRP - 1) / SRP, per_wave = 64 >> glog, waves = ((nplanes + per_wave - 1) / per_wave) * nstrips;
-	hipemu::launch(dim3((waves + 3) / 4), dim3(NTHREADS), [&] { k_fwd_plane_strip(jobs.data(), nplanes, 1, 0, 1, glog, nstrips, width, height); });
+	const int nblk = width / (2 * SBLK), nseg = nblk > 64 ? (nblk + PLSTEP - 1) / PLSTEP : 1;      // (as cfhd_device.hip for_channel_runs)
+	if (nseg > 1) glog = 6;
+	const int nstrips = (height / 2 + SRP - 1) / SRP, per_wave = nseg > 1 ? 1 : 64 >> glog, waves = ((nplanes + per_wave - 1) / per_wave) * nstrips * nseg;
+	hipemu::launch(dim3((waves + 3) / 4), dim3(NTHREADS), [&] { k_fwd_plane_strip(jobs.data(), nplanes, 1, 0, 1, glog, nstrips, width, height, nseg); });
 	return 0;
 }
 
@@ -493,7 +495,7 @@ int emu_fwd_plane_strip(int16_t **in, int nplanes, int in_pitch, int width, int 
 // product batches the channel planes of many frames: the wave packing (64 >> glog planes per wave) is part of what is tested.
 int emu_inv_plane_strip(int16_t **bands, int nplanes, int band_pitch, int w, int h, int descale, int16_t **out, int out_pitch)
 {
-	if (w % SBLK || w / SBLK > 64) return -1;
+	if (w % SBLK) return -1;
 	std::vector<InvPlaneJob> jobs(nplanes);
 	for (int k = 0; k < nplanes; k++) {
 		InvPlaneJob &job = jobs[k];
@@ -502,8 +504,10 @@ int emu_inv_plane_strip(int16_t **bands, int nplanes, int band_pitch, int w, int
 		job.xstride = 1; job.precision = 0; job.display_height = 2 * h; job.alpha = 0;
 	}
 	int glog = 0; while ((1 << glog) < w / SBLK) glog++;
-	const int nstrips = (h + SRP - 1) / SRP, per_wave = 64 >> glog, waves = ((nplanes + per_wave - 1) / per_wave) * nstrips;
-	hipemu::launch(dim3((waves + 3) / 4), dim3(NTHREADS), [&] { k_inv_plane_strip(jobs.data(), nplanes, 1, 0, 1, glog, nstrips, w, h); });
+	const int nblk = w / SBLK, nseg = nblk > 64 ? (nblk + PLSTEP - 1) / PLSTEP : 1;
+	if (nseg > 1) glog = 6;
+	const int nstrips = (h + SRP - 1) / SRP, per_wave = nseg > 1 ? 1 : 64 >> glog, waves = ((nplanes + per_wave - 1) / per_wave) * nstrips * nseg;
+	hipemu::launch(dim3((waves + 3) / 4), dim3(NTHREADS), [&] { k_inv_plane_strip(jobs.data(), nplanes, 1, 0, 1, glog, nstrips, w, h, nseg); });
 	return 0;
 }
 

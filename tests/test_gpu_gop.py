@@ -135,3 +135,21 @@ def test_interlaced_group_samples_are_refused_not_misdecoded():
     assert L.CFHD_DecodeSample(dec, sb, len(samples[1]), out.ctypes.data_as(ctypes.c_void_p), w * 2) == 3          # CFHD_ERROR_BADFORMAT
     assert not out.reshape(ah.value, w * 2)[:h].any()
     L.CFHD_CloseDecoder(dec)
+
+
+@pytest.mark.parametrize("stage", ["device", "host"])
+def test_group_entropy_stage_on_the_gpu_and_on_the_host(stage):
+    """Groups through the GPU entropy stage (the default: 17 subbands per channel through k_ent_count / scan / layout / emit with the two raw 16-bit bands of a channel as
+    lowpass holes; decode: 45 band jobs of k_dec_bands_par_ll + 6 of k_dec_lowpass) and through the host coder (CFHD_AMD_ENTROPY=host).  CFHD_AMD_ENTROPY=device makes a
+    silent hand-over to the host coder an error, so that leg proves the device stage served every sample.  Both legs: the reference encoder's bytes, pictures inside the
+    dither interval of the exact reconstruction (the checks of the two tests above, odd chroma lowpass width and rate feedback included)."""
+    import os
+    old = os.environ.get("CFHD_AMD_ENTROPY")
+    os.environ["CFHD_AMD_ENTROPY"] = stage
+    try:
+        test_gop_encode_bitstream_identical(320, 240, PIX_YUY2)
+        test_gop_rate_feedback_bitstream_identical(320, 180, 6, 5)
+        test_gop_decode_reference_samples(336, 252, PIX_YUY2)
+    finally:
+        if old is None: del os.environ["CFHD_AMD_ENTROPY"]
+        else: os.environ["CFHD_AMD_ENTROPY"] = old

@@ -1567,17 +1567,18 @@ def test_batched_round_trip_at_bench_sizes_equals_reference(w, h, n, nuniq):
     _batched_yuy2_round_trip_equals_reference(w, h, n, nuniq, expect={0: "k_fwd_yuv422_strip_blocks", 3: "k_inv_yuv422_strip"})
 
 
-@pytest.mark.parametrize("w,h,n", [(1920, 1080, 3), (3840, 2160, 2), (2048, 600, 3), (1952, 250, 2)])
+@pytest.mark.parametrize("w,h,n", [(1920, 1080, 3), (3840, 2160, 2), (2048, 600, 3), (1952, 250, 2), (2304, 72, 2)])
 def test_yuv422_strip_kernels_equal_reference(w, h, n):
     """The kernels bench.py times -- k_fwd_yuv422_strip, k_fwd_plane_strip, k_inv_plane_strip, k_inv_yuv422_strip -- forced on small batches
     (CFHD_AMD_FORWARD / _PLANES / _INVERSE = strip): 1080p; 3840 and 2048 pixels = two segments of 1984 (the second one partial); a height
-    with pad rows and a partial last strip.  Samples equal the reference encoder's, decoded frames lie in the dither interval."""
+    with pad rows and a partial last strip; 3840 and 2304 pixels: level-2 luma planes of 120 and 72 blocks, i.e. the plane strips in segments of 62 blocks.
+    Samples equal the reference encoder's, decoded frames lie in the dither interval."""
     keys = ("CFHD_AMD_FORWARD", "CFHD_AMD_INVERSE", "CFHD_AMD_PLANES")
     old = {k: os.environ.get(k) for k in keys}
     for k in keys: os.environ[k] = "strip"
     try:
         expect = {0: "k_fwd_yuv422_strip_blocks", 3: "k_inv_yuv422_strip"}      # (level-1 bands as block lists for k_ent_count_blocks; CFHD_AMD_BLOCKS=0: dense bands + k_ent_count)
-        if w in (1920, 2048): expect.update({1: "k_fwd_plane_strip", 2: "k_fwd_plane_strip", 4: "k_inv_plane_strip", 5: "k_inv_plane_strip"})
+        if w in (1920, 2048, 3840, 2304): expect.update({1: "k_fwd_plane_strip", 2: "k_fwd_plane_strip", 4: "k_inv_plane_strip", 5: "k_inv_plane_strip"})
         _batched_yuy2_round_trip_equals_reference(w, h, n, n, expect=expect)
     finally:
         for k, v in old.items():
