@@ -50,7 +50,8 @@ public:
 	bool has_entropy() const { return ent_ready_; }
 	bool strip_forward() const;                     // level 1 of 4:2:2 runs as k_fwd_yuv422_strip (else k_fwd_yuv422)
 	bool block_lists_forward() const;               // ... and leaves the quantized level-1 bands as block lists for k_ent_count_blocks (k_fwd_yuv422_strip_blocks)
-	bool strip_forward_packed16() const;            // level 1 of RG48 / b64a runs as k_fwd_packed16_strip (else k_fwd_packed16)
+	bool strip_forward_packed16() const;
+	bool strip_forward_bayer() const;            // level 1 of RG48 / b64a runs as k_fwd_packed16_strip (else k_fwd_packed16)
 	const char *level_kernel(int level) const;      // name of the kernel the next launch_forward() uses for level 0 / 1 / 2 (as a profiler shows it)
 	int download_coeffs();                             // async: final (entropy coded) region of every frame -> pinned host
 	int wait();

@@ -535,10 +535,24 @@ bool EncodeBatch::strip_forward_packed16() const
 	return true;
 }
 
+// k_fwd_bayer_strip serves BYR4 mosaics whose component planes are whole 8-column blocks wide and whose rows are 16-byte aligned, from the launch size on at which
+// the strip kernels pay; BYR5, small launches and CFHD_AMD_FORWARD=tile take k_unpack_byr4 + k_fwd_plane.
+bool EncodeBatch::strip_forward_bayer() const
+{
+	const int forced = shape_override("CFHD_AMD_FORWARD");
+	const int act = active_ > 0 && active_ < n_ ? active_ : n_;
+	if (forced == 1 || (forced == 0 && frames_1080p_equivalent(plan_, act) < 32.0)) return false;
+	if (plan_.pixel_kind != PIX_BYR4 || bayer_fused_ || plan_.width % 8 || plan_.num_channels != 4) return false;
+	EncJobs j = enc_jobs_at(h_jobs_, n_, plan_.num_channels);
+	for (int i = 0; i < n_; i++) if (((uintptr_t)j.bayer[i].in & 15) || ((j.bayer[i].in_pitch * 2) & 15) || j.bayer[i].order != j.bayer[0].order) return false;
+	return true;
+}
+
 const char *EncodeBatch::level_kernel(int level) const
 {
 	const int act = active_ > 0 && active_ < n_ ? active_ : n_;
 	if (level > 0) return planes_as_strips(plan_, level, act) ? "k_fwd_plane_strip" : "k_fwd_plane";
+	if (strip_forward_bayer()) return "k_fwd_bayer_strip";
 	if (plan_.pixel_kind == PIX_BYR4 || plan_.pixel_kind == PIX_BYR5) return bayer_fused_ ? "k_fwd_packed16" : "k_unpack_byr4+k_fwd_plane";
 	if (strip_forward_packed16()) return "k_fwd_packed16_strip";
 	if (enc_packed16(plan_.pixel_kind)) return "k_fwd_packed16";
@@ -574,6 +588,10 @@ int EncodeBatch::launch_forward(bool coeffs_needed)
 		// write -- 8 bytes per quad out, 8 back in -- never exist)
 		dim3 grid(((plan_.width / 2 + dev::TW - 1) / dev::TW) * nch, (plan_.height / 2 + dev::TH - 1) / dev::TH, act);
 		dev::k_fwd_packed16<<<grid, dev::NTHREADS, 0, st>>>(j.l1, nch);
+	} else if (strip_forward_bayer()) {
+		// level 1 straight from the mosaic, every photosite read and curved once, all four component planes from one pass (cfhd_kernels.h k_fwd_bayer_strip)
+		const int nseg = (plan_.width / 8 + dev::PSTEP - 1) / dev::PSTEP, nstrips = (plan_.height / 2 + dev::PSR - 1) / dev::PSR, waves = act * nseg * nstrips;
+		dev::k_fwd_bayer_strip<<<(waves + 3) / 4, dev::NTHREADS, 0, st>>>(j.l1, j.bayer, act, nseg, nstrips);
 	} else if (plan_.pixel_kind == PIX_BYR4 || plan_.pixel_kind == PIX_BYR5) {
 		dev::k_unpack_byr4<<<dim3((plan_.width / 2 + dev::NTHREADS - 1) / dev::NTHREADS, plan_.height, act), dev::NTHREADS, 0, st>>>(j.bayer);      // two quads per thread
 		dim3 grid((plan_.width / 2 + dev::TW - 1) / dev::TW, (plan_.height / 2 + dev::TH - 1) / dev::TH, act * nch);

@@ -1863,6 +1863,130 @@ __global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(C
 }
 
 // =============================================================================================
+// k_fwd_bayer_strip: level 1 of a 16-bit Bayer mosaic (BYR4) in the register-strip organisation -- k_fwd_packed16_strip with the mosaic as the packed source.
+// One lane = 8 photosite quads (16 photosites of two mosaic rows: four 16-byte loads) of every quad row of its strip: every photosite goes through the encode
+// curve once (the 14-bit LUT sits in LDS: 32 KB per workgroup, filled once), every quad gives one sample of each of the four component planes (the arithmetic of
+// k_unpack_byr4, frame.c:5219-5393), and every plane runs the horizontal 2/6 analysis of its 4 sample pairs into its own six-row window; every second quad row the
+// vertical analysis + quantizer emits one row of LL, LH, HL, HH per plane.  The component planes k_unpack_byr4 writes (8 bytes per quad out, 8 back in) never exist.
+// Same arithmetic as k_unpack_byr4 + k_fwd_plane (tested against them), which stay for BYR5, other geometries and small launches.
+// Geometry served: plane width % 8 == 0, mosaic rows 16-byte aligned.
+// =============================================================================================
+struct ByRows { cfhd_u4 v[2][2][2]; };      // [quad row][mosaic row of the pair][half of the lane's 16 photosites]
+__device__ __forceinline__ void by_fetch(ByRows &R, const uint16_t *mosaic, int in_pitch, int y, int display_height)
+{
+#pragma unroll
+	for (int k = 0; k < 2; k++) {
+		const int yy = y + k < display_height ? y + k : display_height - 1;     // quad rows beyond the picture repeat the last one
+		const uint16_t *p = mosaic + (size_t)(2 * yy) * in_pitch;
+		R.v[k][0][0] = CFHD_LDG128(p); R.v[k][0][1] = CFHD_LDG128(p + 8);
+		R.v[k][1][0] = CFHD_LDG128(p + in_pitch); R.v[k][1][1] = CFHD_LDG128(p + in_pitch + 8);
+	}
+}
+template <int SLOT>
+__device__ __forceinline__ void by_push(uint32_t (&LW)[4][6][2], uint32_t (&HW)[4][6][2], const ByRows &R, const uint16_t *s_curve, int order, int mid, int prescale, int lane, bool first, bool last)
+{
+#pragma unroll
+	for (int k = 0; k < 2; k++) {
+		const uint32_t top[8] = { R.v[k][0][0].x, R.v[k][0][0].y, R.v[k][0][0].z, R.v[k][0][0].w, R.v[k][0][1].x, R.v[k][0][1].y, R.v[k][0][1].z, R.v[k][0][1].w };
+		const uint32_t bot[8] = { R.v[k][1][0].x, R.v[k][1][0].y, R.v[k][1][0].z, R.v[k][1][0].w, R.v[k][1][1].x, R.v[k][1][1].y, R.v[k][1][1].z, R.v[k][1][1].w };
+		int o[4][8];
+#pragma unroll
+		for (int q = 0; q < 8; q++) {
+			const int tl = s_curve[(top[q] & 0xffffu) >> 2], tr = s_curve[top[q] >> 18], bl = s_curve[(bot[q] & 0xffffu) >> 2], br = s_curve[bot[q] >> 18];
+			int r, g1, g2, bb;
+			switch (order) {
+			case 0: r = tl; g1 = tr; g2 = bl; bb = br; break;
+			case 1: g1 = tl; r = tr; bb = bl; g2 = br; break;
+			case 3: bb = tl; g1 = tr; g2 = bl; r = br; break;
+			default: g1 = tl; bb = tr; r = bl; g2 = br; break;
+			}
+			const int g = (g1 + g2) >> 1;
+			o[0][q] = g; o[1][q] = ((r - g) >> 1) + mid; o[2][q] = ((bb - g) >> 1) + mid; o[3][q] = (g1 - g2 + 2 * mid) >> 1;
+		}
+#pragma unroll
+		for (int c = 0; c < 4; c++) {
+			uint32_t ext[6];
+#pragma unroll
+			for (int m = 0; m < 4; m++) ext[1 + m] = pack16(o[c][2 * m], o[c][2 * m + 1]);
+			ext[0] = __shfl(ext[4], lane - 1); ext[5] = __shfl(ext[1], lane + 1);
+#pragma unroll
+			for (int m = 0; m < 2; m++) horiz_pair(&ext[2 * m], 0u, prescale, first && m == 0, false, last && m == 1, LW[c][SLOT + k][m], HW[c][SLOT + k][m]);
+		}
+	}
+}
+
+__global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(CFHD_PX_WAVES, CFHD_PX_WAVES))) k_fwd_bayer_strip(const FwdPlaneJob *jobs, const BayerJob *bayer, int nframes, int nseg, int nstrips)
+{
+	__shared__ uint16_t s_curve[1 << 14];
+	{
+		const uint4 *src = (const uint4 *)bayer[0].curve;      // (one curve per batch: every frame's job points at it)
+		uint4 *dst = (uint4 *)s_curve;
+		for (int i = threadIdx.x; i < (1 << 14) * 2 / 16; i += NTHREADS) dst[i] = src[i];
+	}
+	__syncthreads();
+	const int lane = threadIdx.x & 63, gwave = (int)blockIdx.x * (NTHREADS / 64) + wave_uniform((int)(threadIdx.x >> 6));
+	const int seg = gwave % nseg, strip = (gwave / nseg) % nstrips, frame = gwave / (nseg * nstrips);
+	if (frame >= nframes) return;                         // whole wave (behind the only barrier)
+	const FwdPlaneJob *job = jobs + (size_t)frame * 4;
+	const BayerJob *bj = bayer + frame;
+	const int W = job->width, H = job->height, HH = H >> 1, nblk = W / 8;
+	const int b = seg * PSTEP - 1 + lane;
+	const bool stores = b >= 0 && b < nblk && lane >= 1 && lane <= PSTEP;
+	const int blk = b < 0 ? 0 : (b >= nblk ? nblk - 1 : b);
+	const bool first = blk == 0, last = blk == nblk - 1;
+	const int in_pitch = bj->in_pitch, dh = bj->display_height, order = bj->order, mid = 1 << (bj->precision - 1), prescale = job->prescale, out_pitch = job->out_pitch;
+	const uint16_t *px = bj->in + (size_t)blk * 16;
+	const int r0 = strip * PSR, r1 = r0 + PSR < HH ? r0 + PSR : HH;
+	QuantParam q[4][3];
+	int16_t *out[4][4];
+#pragma unroll
+	for (int c = 0; c < 4; c++) {
+#pragma unroll
+		for (int k = 0; k < 3; k++) q[c][k] = job[c].q[1 + k];
+#pragma unroll
+		for (int k = 0; k < 4; k++) out[c][k] = job[c].out[k];
+	}
+	uint32_t LW[4][6][2], HW[4][6][2];
+	int wtop = window_first_row(r0, HH, H);
+	ByRows R;
+	by_fetch(R, px, in_pitch, wtop, dh);
+	by_push<0>(LW, HW, R, s_curve, order, mid, prescale, lane, first, last);
+	by_fetch(R, px, in_pitch, wtop + 2, dh);
+	by_push<2>(LW, HW, R, s_curve, order, mid, prescale, lane, first, last);
+	by_fetch(R, px, in_pitch, wtop + 4, dh);
+	by_push<4>(LW, HW, R, s_curve, order, mid, prescale, lane, first, last);
+	int fetched = -1;
+	for (int r = r0; r < r1; r++) {
+		const int need = window_first_row(r, HH, H);
+		if (need != wtop) {
+			if (fetched != need + 4) by_fetch(R, px, in_pitch, need + 4, dh);
+#pragma unroll
+			for (int c = 0; c < 4; c++) {
+#pragma unroll
+				for (int k = 0; k < 4; k++) { LW[c][k][0] = LW[c][k + 2][0]; LW[c][k][1] = LW[c][k + 2][1]; HW[c][k][0] = HW[c][k + 2][0]; HW[c][k][1] = HW[c][k + 2][1]; }
+			}
+			wtop = need;
+			by_push<4>(LW, HW, R, s_curve, order, mid, prescale, lane, first, last);
+		}
+		if (r + 1 < r1) {
+			const int next_need = window_first_row(r + 1, HH, H);
+			if (next_need != wtop) { by_fetch(R, px, in_pitch, next_need + 4, dh); fetched = next_need + 4; }
+		}
+		const int pos = r == 0 ? 0 : (r == HH - 1 ? 2 : 1);
+		const uint32_t at = ((uint32_t)r * (uint32_t)out_pitch + (uint32_t)blk * 4u) * 2u;     // bytes into the band
+#pragma unroll
+		for (int c = 0; c < 4; c++) {
+			uint32_t o[4][2];
+			strip_fwd_emit<2>(LW[c], HW[c], pos, q[c][0], q[c][1], q[c][2], o);
+			if (stores) {
+#pragma unroll
+				for (int bnd = 0; bnd < 4; bnd++) { uint2 v; v.x = o[bnd][0]; v.y = o[bnd][1]; *(uint2 *)((char *)out[c][bnd] + at) = v; }
+			}
+		}
+	}
+}
+
+// =============================================================================================
 // k_inv_packed16_strip: the last level of RGB 4:4:4 -> RG48 / RGBA 4:4:4:4 -> b64a in the register-strip organisation, the mirror image of
 // k_fwd_packed16_strip.  One lane = 4 band columns of every plane (8-byte loads of LL, LH, HL, HH; a three-row window of the vertical-lowpass
 // bands in registers) -> 8 finished pixels of two output rows, all components, stored as NCH 16-byte words per row.  Segments of 62

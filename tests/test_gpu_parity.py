@@ -1435,6 +1435,37 @@ def test_batched_path_of_the_other_configurations_equals_reference(name, w, h, n
     L.cfhd_amd_batch_destroy(b)
 
 
+@pytest.mark.parametrize("w,h,n", [(192, 96, 2), (1008, 244, 2), (2032, 120, 3), (3840, 2160, 2)])
+def test_bayer_strip_kernel_equals_reference(w, h, n):
+    """k_fwd_bayer_strip (level 1 straight from the BYR4 mosaic: every photosite read and curved once, the four component planes from one pass; the shape large
+    launches take, forced here with CFHD_AMD_FORWARD=strip): one segment, segments of 62 blocks with a partial last one (component planes of 504, 1016 and 1920
+    columns), strips with pad rows below the picture.  Every sample equals the reference encoder's."""
+    L = _batch_api()
+    L.cfhd_amd_batch_kernel_name.restype = ctypes.c_char_p
+    L.cfhd_amd_batch_kernel_name.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    frames = [synth_bayer(w, h, 31 + i).reshape(-1).view(np.uint8).copy() for i in range(n)]
+    refs = ref_encode_frames(frames, w * 2, w, h, PIX_BYR4, encoded=ENCODED_BAYER)
+    old = os.environ.get("CFHD_AMD_FORWARD")
+    os.environ["CFHD_AMD_FORWARD"] = "strip"
+    try:
+        b = L.cfhd_amd_batch_create_ex(w, h, PIX_BYR4, ENCODED_BAYER, 0, QUALITY_FILMSCAN1, n, 4, 1)
+        assert b, amd_last_error()
+        for i, f in enumerate(frames):
+            assert L.cfhd_amd_batch_upload(b, i, f.ctypes.data_as(ctypes.c_void_p), w * 2) == 0
+        assert L.cfhd_amd_batch_kernel_name(b, 0) == b"k_fwd_bayer_strip"
+        assert L.cfhd_amd_batch_roundtrip(b) > 0, amd_last_error()
+        for i in range(n):
+            p = ctypes.c_void_p(); sz = ctypes.c_size_t()
+            assert L.cfhd_amd_batch_get_sample(b, i, ctypes.byref(p), ctypes.byref(sz)) == 0
+            sample = ctypes.string_at(p, sz.value)
+            assert len(sample) == len(refs[i]), "frame %d: %d bytes vs reference %d" % (i, len(sample), len(refs[i]))
+            assert mask_volatile_metadata(sample) == mask_volatile_metadata(refs[i]), "frame %d differs from the reference" % i
+        L.cfhd_amd_batch_destroy(b)
+    finally:
+        if old is None: os.environ.pop("CFHD_AMD_FORWARD", None)
+        else: os.environ["CFHD_AMD_FORWARD"] = old
+
+
 @pytest.mark.parametrize("name,w,h,n,fmt,enc,mode", [
     ("rg48", 1000, 562, 3, PIX_RG48, ENCODED_RGB444, 0), ("rg48-one-block-rows", 504, 242, 2, PIX_RG48, ENCODED_RGB444, 0),
     ("b64a", 1920, 1080, 2, PIX_B64A, ENCODED_RGBA4444, 0), ("b64a-narrow", 136, 120, 2, PIX_B64A, ENCODED_RGBA4444, 0),
