@@ -51,7 +51,8 @@ public:
 	bool strip_forward() const;                     // level 1 of 4:2:2 runs as k_fwd_yuv422_strip (else k_fwd_yuv422)
 	bool block_lists_forward() const;               // ... and leaves the quantized level-1 bands as block lists for k_ent_count_blocks (k_fwd_yuv422_strip_blocks)
 	bool strip_forward_packed16() const;
-	bool strip_forward_bayer() const;            // level 1 of RG48 / b64a runs as k_fwd_packed16_strip (else k_fwd_packed16)
+	bool strip_forward_bayer() const;
+	bool strip_forward_frame() const;            // level 1 of RG48 / b64a runs as k_fwd_packed16_strip (else k_fwd_packed16)
 	const char *level_kernel(int level) const;      // name of the kernel the next launch_forward() uses for level 0 / 1 / 2 (as a profiler shows it)
 	int download_coeffs();                             // async: final (entropy coded) region of every frame -> pinned host
 	int wait();
@@ -106,7 +107,8 @@ public:
 	bool has_entropy() const { return ent_ready_; }
 	bool strip_inverse() const;                     // the last level of 4:2:2 runs as k_inv_yuv422_strip (else k_inv_yuv422)
 	bool strip_inverse_packed16() const;            // the last level of RG48 / b64a output runs as k_inv_packed16_strip (else k_inv_packed16)
-	bool frame_inverse_quads() const;               // interlaced samples: k_inv_frame_yuv422_quad (else k_inv_frame_yuv422)
+	bool frame_inverse_quads() const;
+	bool frame_inverse_strips() const;               // interlaced samples: k_inv_frame_yuv422_quad (else k_inv_frame_yuv422)
 	const char *level_kernel(int level) const;      // name of the kernel the next launch_inverse() uses for level 0 / 1 / 2
 	int set_device_output(int i, void *d_out, int pitch_bytes);
 	int launch_inverse(uint32_t dither_seed);          // async

@@ -481,7 +481,10 @@ static int shape_override(const char *name)           // 0: by size, 1: tile, 2:
 static bool planes_as_strips(const FramePlan &plan, int lv /* wavelet index whose bands are produced / consumed */, int frames)
 {
 	const int forced = shape_override("CFHD_AMD_PLANES");
-	if (forced == 1 || (forced == 0 && frames_1080p_equivalent(plan, frames) < 160.0)) return false;
+	// (the crossover was measured on 4:2:2 frames, whose planes add up to twice the picture; the planes of RGB, RGBA and Bayer frames add up to 3, 4 and 4 times plan.width x plan.height)
+	double samples = 0.0;
+	for (int c = 0; c < plan.num_channels; c++) samples += (double)plan.ch[c].width * plan.ch[c].height;
+	if (forced == 1 || (forced == 0 && frames * samples / (2.0 * 1920.0 * 1080.0) < 160.0)) return false;
 	for (int c = 0; c < plan.num_channels; c++) {
 		const BandDesc &b = plan.ch[c].band[lv][0];
 		if (b.width % dev::SBLK || plan.ch[c].band[lv - 1][0].width != 2 * b.width || plan.ch[c].band[lv - 1][0].height != 2 * b.height ||
@@ -513,6 +516,18 @@ bool EncodeBatch::strip_forward() const
 	const int act = active_ > 0 && active_ < n_ ? active_ : n_;
 	if (forced == 1 || (forced == 0 && frames_1080p_equivalent(plan_, act) < 32.0)) return false;
 	if (plan_.interlaced || plan_.encoded_format != ENC_YUV422 || plan_.width % 32) return false;
+	EncJobs j = enc_jobs_at(h_jobs_, n_, plan_.num_channels);
+	for (int i = 0; i < n_; i++) if (((uintptr_t)j.yuv[i].in & 15) || (j.yuv[i].in_pitch & 15)) return false;
+	return true;
+}
+
+// k_fwd_frame_yuv422_strip: the same geometry rule for interlaced 4:2:2 frames (else the LDS-tiled k_fwd_frame_yuv422)
+bool EncodeBatch::strip_forward_frame() const
+{
+	const int forced = shape_override("CFHD_AMD_FORWARD");
+	const int act = active_ > 0 && active_ < n_ ? active_ : n_;
+	if (forced == 1 || (forced == 0 && frames_1080p_equivalent(plan_, act) < 32.0)) return false;
+	if (!plan_.interlaced || plan_.encoded_format != ENC_YUV422 || plan_.width % 32 || !(plan_.pixel_kind == PIX_YUY2 || plan_.pixel_kind == PIX_2VUY)) return false;
 	EncJobs j = enc_jobs_at(h_jobs_, n_, plan_.num_channels);
 	for (int i = 0; i < n_; i++) if (((uintptr_t)j.yuv[i].in & 15) || (j.yuv[i].in_pitch & 15)) return false;
 	return true;
@@ -556,7 +571,7 @@ const char *EncodeBatch::level_kernel(int level) const
 	if (plan_.pixel_kind == PIX_BYR4 || plan_.pixel_kind == PIX_BYR5) return bayer_fused_ ? "k_fwd_packed16" : "k_unpack_byr4+k_fwd_plane";
 	if (strip_forward_packed16()) return "k_fwd_packed16_strip";
 	if (enc_packed16(plan_.pixel_kind)) return "k_fwd_packed16";
-	if (plan_.interlaced) return "k_fwd_frame_yuv422";
+	if (plan_.interlaced) return strip_forward_frame() ? "k_fwd_frame_yuv422_strip" : "k_fwd_frame_yuv422";
 	return strip_forward() ? (block_lists_forward() ? "k_fwd_yuv422_strip_blocks" : "k_fwd_yuv422_strip") : "k_fwd_yuv422";
 }
 
@@ -605,6 +620,10 @@ int EncodeBatch::launch_forward(bool coeffs_needed)
 	} else if (enc_packed16(plan_.pixel_kind)) {
 		dim3 grid(((plan_.width / 2 + dev::TW - 1) / dev::TW) * nch, (plan_.height / 2 + dev::TH - 1) / dev::TH, act);
 		dev::k_fwd_packed16<<<grid, dev::NTHREADS, 0, st>>>(j.l1, nch);
+	} else if (strip_forward_frame()) {
+		static_assert(sizeof(dev::FwdFrameJob) == sizeof(dev::FwdYuvJob) && offsetof(dev::FwdFrameJob, q) == offsetof(dev::FwdYuvJob, q), "the two level-1 jobs share one table");
+		const int nseg = (plan_.width / 16 + dev::SSEG - 1) / dev::SSEG;      // segments of 124 luma blocks (1984 pixels)
+		dev::k_fwd_frame_yuv422_strip<<<dim3(nseg, (plan_.height / 2 + dev::SRI - 1) / dev::SRI, act), dev::NTHREADS, 0, st>>>((const dev::FwdFrameJob *)j.yuv);
 	} else if (plan_.interlaced) {
 		static_assert(sizeof(dev::FwdFrameJob) == sizeof(dev::FwdYuvJob) && offsetof(dev::FwdFrameJob, q) == offsetof(dev::FwdYuvJob, q), "the two level-1 jobs share one table");
 		dim3 grid((plan_.width / 2 + dev::FTW - 1) / dev::FTW, (plan_.height / 2 + dev::FRW - 1) / dev::FRW, act);
@@ -938,6 +957,14 @@ bool DecodeBatch::strip_inverse_packed16() const
 	return true;
 }
 
+// k_inv_frame_yuv422_strip: the interlaced last level in the shape of k_inv_yuv422_strip, under the same conditions
+bool DecodeBatch::frame_inverse_strips() const
+{
+	if (!interlaced_ || half_) return false;
+	for (int c = 0; c < 3; c++) if (plan_.ch[c].band[0][0].pitch % 8) return false;
+	return strip_inverse();
+}
+
 // k_inv_frame_yuv422_quad: four band columns per thread with 8-byte loads and 16-byte stores (CFHD_AMD_INVERSE=tile: the one-column kernel)
 bool DecodeBatch::frame_inverse_quads() const
 {
@@ -957,7 +984,7 @@ const char *DecodeBatch::level_kernel(int level) const
 	if (half_) return is_packed16(out_kind_) ? "k_half_packed16" : "k_half_yuv422";
 	if (dec_rgb10(out_kind_)) return "k_inv_rgb10";
 	if (dec_planes16(out_kind_)) return strip_inverse_packed16() ? "k_inv_packed16_strip" : "k_inv_packed16";
-	if (interlaced_) return frame_inverse_quads() ? "k_inv_frame_yuv422_quad" : "k_inv_frame_yuv422";
+	if (interlaced_) return frame_inverse_strips() ? "k_inv_frame_yuv422_strip" : (frame_inverse_quads() ? "k_inv_frame_yuv422_quad" : "k_inv_frame_yuv422");
 	return strip_inverse() ? "k_inv_yuv422_strip" : "k_inv_yuv422";
 }
 
@@ -1032,7 +1059,10 @@ int DecodeBatch::launch_inverse(uint32_t dither_seed)
 		else { const int onch = dec_out_channels(out_kind_, plan_); dev::k_inv_packed16<<<grid, dev::NTHREADS, 0, st>>>(j.l1, onch, dec_words_per_position(out_kind_, onch), dither_seed); }
 	} else if (interlaced_) {                           // (half resolution was served above: the level-1 lowpass planes need no inverse frame transform)
 		const BandDesc &b = plan_.ch[0].band[0][0];
-		if (frame_inverse_quads()) dev::k_inv_frame_yuv422_quad<<<dim3((b.width / 4 + dev::NTHREADS - 1) / dev::NTHREADS, b.height, act), dev::NTHREADS, 0, st>>>(j.yuv, dither_seed);
+		if (frame_inverse_strips()) {
+			const int nseg = (b.width / dev::SBLK + dev::SSEG - 1) / dev::SSEG;
+			dev::k_inv_frame_yuv422_strip<<<dim3(nseg, (b.height + dev::SRI - 1) / dev::SRI, act), dev::NTHREADS, 0, st>>>(j.yuv, dither_seed);
+		} else if (frame_inverse_quads()) dev::k_inv_frame_yuv422_quad<<<dim3((b.width / 4 + dev::NTHREADS - 1) / dev::NTHREADS, b.height, act), dev::NTHREADS, 0, st>>>(j.yuv, dither_seed);
 		else dev::k_inv_frame_yuv422<<<dim3((b.width / 2 + dev::NTHREADS - 1) / dev::NTHREADS, b.height, act), dev::NTHREADS, 0, st>>>(j.yuv, dither_seed);
 	} else if (strip_inverse()) {
 		const BandDesc &b = plan_.ch[0].band[0][0];

@@ -2265,6 +2265,235 @@ __global__ void __launch_bounds__(NTHREADS) k_fwd_frame_yuv422(const FwdFrameJob
 }
 
 // =============================================================================================
+// k_inv_frame_yuv422_strip: the interlaced last level in the register-strip organisation -- the workgroup shape, the dither bits and the output stage of
+// k_inv_yuv422_strip (two luma waves of 62 blocks, a V and a U wave, the 8-bit samples interleaved through LDS into 16-byte stores), with the inverse frame
+// transform in place of the vertical synthesis: the horizontal synthesis of (LL, LH) is the temporal lowpass row, that of (HL, HH) the temporal highpass row
+// (spatial.c:19302: the usual 2/6 synthesis, >> 1; packed saturating arithmetic inside the band, the 32-bit border taps at its ends, as k_inv_plane_strip);
+// picture row 2r = low - high, row 2r + 1 = low + high (saturating, temporal.c:5961), then 10 -> 8 bits.  Four 16-byte loads per lane and band row, no window.
+// k_inv_frame_yuv422(_quad) stay for other geometries and small launches.  Geometry served: as k_inv_yuv422_strip (luma band width % 16 == 0).
+// =============================================================================================
+enum { SRI = 16 };                                      // band rows (= picture row pairs) per workgroup of the two interlaced strip kernels
+__device__ __forceinline__ void strip_row_synth16(const uint32_t (&L)[4], const uint32_t (&H)[4], uint32_t prev, uint32_t next, bool first, bool last, uint32_t (&E)[4], uint32_t (&O)[4])
+{
+	const uint32_t ext[6] = { prev, L[0], L[1], L[2], L[3], next };
+#pragma unroll
+	for (int d = 0; d < 4; d++) {
+		const uint32_t dm = ext[d], d0 = ext[d + 1], dp = ext[d + 2];
+		uint32_t e, o;
+		inv_horiz_pk((dm >> 16) | (d0 << 16), d0, (d0 >> 16) | (dp << 16), H[d], e, o);
+		E[d] = pk_sra(e, 1); O[d] = pk_sra(o, 1);
+	}
+	if (first) {
+		const int l[6] = { 0, 0, lo16(L[0]), hi16(L[0]), lo16(L[1]), hi16(L[1]) };
+		int e, o;
+		inv_horiz_border(l, 2, lo16(H[0]), 0, e, o);
+		E[0] = (E[0] & 0xffff0000u) | (uint32_t)(uint16_t)sat16(e >> 1); O[0] = (O[0] & 0xffff0000u) | (uint32_t)(uint16_t)sat16(o >> 1);
+	}
+	if (last) {
+		const int l[6] = { lo16(L[2]), hi16(L[2]), lo16(L[3]), hi16(L[3]), 0, 0 };
+		int e, o;
+		inv_horiz_border(l, 3, hi16(H[3]), 2, e, o);
+		E[3] = (E[3] & 0xffffu) | ((uint32_t)(uint16_t)sat16(e >> 1) << 16); O[3] = (O[3] & 0xffffu) | ((uint32_t)(uint16_t)sat16(o >> 1) << 16);
+	}
+}
+
+__global__ void __launch_bounds__(NTHREADS) k_inv_frame_yuv422_strip(const InvYuvJob *jobs, uint32_t launch_seed)
+{
+	const TileId tile = xcd_tile();
+	__shared__ InvYuvJob s_job;
+	stage_job(&s_job, &jobs[tile.z]);
+	const InvYuvJob &job = s_job;
+	__shared__ uint32_t s_rows[2][2][SROW / 4];           // [buffer][output row parity][bytes: Y samples of the row | V samples | U samples]
+	const uint32_t seed = job.dither_seed ^ launch_seed;
+	const int h = job.height, r0 = tile.y * SRI;
+	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+	const bool luma = wave < 2;
+	const int comp = luma ? 0 : wave - 1;                 // 0 Y, 1 V, 2 U
+	const int w = luma ? job.width : job.width >> 1;
+	const int nblk = w / SBLK;
+	const int seg_first = tile.x * SSEG;
+	const int base = luma ? seg_first + SLUMA_STEP * wave : seg_first >> 1;
+	const int want = base - 1 + lane;
+	const int blk = want < 0 ? 0 : (want < nblk ? want : nblk - 1);
+	const bool stores = lane >= 1 && lane <= SLUMA_STEP && want < nblk;
+	const int v_base = SSEG * 4, u_base = v_base + SSEG * 2;
+	const int lds_at = luma ? 4 * (want - seg_first) : (comp == 1 ? v_base : u_base) + 4 * (want - (seg_first >> 1));
+	const int seg_blocks = job.width / SBLK - seg_first < SSEG ? job.width / SBLK - seg_first : SSEG;
+	const int nquads = 2 * seg_blocks;
+	const bool first = blk == 0, last = blk == nblk - 1;
+	const int pitch = job.band_pitch[comp];
+	const int16_t *const bLL = wave_uniform_ptr(job.band[comp][0]), *const bLH = wave_uniform_ptr(job.band[comp][1]);
+	const int16_t *const bHL = wave_uniform_ptr(job.band[comp][2]), *const bHH = wave_uniform_ptr(job.band[comp][3]);
+	const uint32_t boff = (uint32_t)(SBLK * blk);
+	if (r0 >= h) return;                                  // whole workgroup
+	const int nrows = h - r0 < SRI ? h - r0 : SRI;
+	const int sh = job.shift;
+	for (int s = 0; s < nrows; s++) {
+		const int r = r0 + s;
+		const StripRow ll = strip_load(bLL + boff + (size_t)r * pitch), lh = strip_load(bLH + boff + (size_t)r * pitch);
+		const StripRow hl = strip_load(bHL + boff + (size_t)r * pitch), hh = strip_load(bHH + boff + (size_t)r * pitch);
+		uint32_t El[4], Ol[4], Eh[4], Oh[4];
+		strip_row_synth16(ll.d, lh.d, __shfl(ll.d[3], lane - 1), __shfl(ll.d[0], lane + 1), first, last, El, Ol);
+		strip_row_synth16(hl.d, hh.d, __shfl(hl.d[3], lane - 1), __shfl(hl.d[0], lane + 1), first, last, Eh, Oh);
+		uint32_t (*rowbuf)[SROW / 4] = s_rows[s & 1];
+#pragma unroll
+		for (int par = 0; par < 2; par++) {
+			const int orow = 2 * r + par;
+			// dither bits: as k_inv_yuv422_strip (one hash word per output row and group of 16 luma samples)
+			uint32_t dbits = 0;
+			if (sh >= 2) {
+				if (luma) {
+					const uint32_t z = dither_word(seed, orow, blk);
+					dbits = (z & 0xfu) | ((z >> 4) & 0xf0u) | ((z >> 8) & 0xf00u) | ((z >> 12) & 0xf000u);
+				} else {
+					const uint32_t z0 = dither_word(seed, orow, 2 * blk), z1 = dither_word(seed, orow, 2 * blk + 1);
+					const int b0 = comp == 1 ? 4 : 5;
+#pragma unroll
+					for (int c = 0; c < 8; c++) {
+						const uint32_t byte = ((c < 4 ? z0 : z1) >> (8 * (c & 3))) & 0xffu;
+						dbits |= ((byte >> b0) & 1u) << (2 * c) | ((byte >> (b0 + 2)) & 1u) << (2 * c + 1);
+					}
+				}
+			}
+			if (stores) {
+				uint32_t *dst = &rowbuf[par][lds_at];
+#pragma unroll
+				for (int d = 0; d < 4; d++) {
+					const uint32_t e = par ? pk_adds(El[d], Eh[d]) : pk_subs(El[d], Eh[d]), o = par ? pk_adds(Ol[d], Oh[d]) : pk_subs(Ol[d], Oh[d]);
+					const uint32_t b = dbits >> (4 * d);
+					const uint32_t te = pk_to8(e, sh, (b & 1u) | ((b << 14) & 0x10000u)), to = pk_to8(o, sh, ((b >> 1) & 1u) | ((b << 13) & 0x10000u));
+					dst[d] = te | (to << 8);
+				}
+			}
+		}
+		__syncthreads();
+		if (tid < nquads) {
+#pragma unroll
+			for (int par = 0; par < 2; par++) {
+				const int orow = 2 * r + par;
+				if (orow >= job.display_height) continue;
+				const uint32_t *row = rowbuf[par];
+				const uint32_t y0 = row[2 * tid], y1 = row[2 * tid + 1], vv = row[v_base + tid], uu = row[u_base + tid];
+				const uint32_t uv01 = byte_perm(vv, uu, 0x05010400u), uv23 = byte_perm(vv, uu, 0x07030602u);
+				uint4 q;
+				if (job.uyvy) {
+					q.x = byte_perm(uv01, y0, 0x01050004u); q.y = byte_perm(uv01, y0, 0x03070206u);
+					q.z = byte_perm(uv23, y1, 0x01050004u); q.w = byte_perm(uv23, y1, 0x03070206u);
+				} else {
+					q.x = byte_perm(uv01, y0, 0x05010400u); q.y = byte_perm(uv01, y0, 0x07030602u);
+					q.z = byte_perm(uv23, y1, 0x05010400u); q.w = byte_perm(uv23, y1, 0x07030602u);
+				}
+				*(uint4 *)(job.out + (size_t)orow * job.out_pitch + 32 * (size_t)seg_first + 16 * (size_t)tid) = q;
+			}
+		}
+	}
+}
+
+// =============================================================================================
+// k_fwd_frame_yuv422_strip: the interlaced level 1 in the register-strip organisation -- the workgroup shape and the unpacking of k_fwd_yuv422_strip (two luma
+// waves of 62 blocks each, a V and a U wave fed through LDS; one lane = 8 band columns), with the frame transform in place of the vertical window: the two
+// picture rows of a pair give temporal low = r0 + r1 and high = r1 - r0 of every sample pair, each goes through the horizontal 2/6 analysis, and the band
+// row leaves at once -- LL, LH = quantized highpass of the low, HL = quantized lowpass of the high stored as the difference to its left neighbour (the
+// quantized value of the previous lane's last column comes by lane exchange), HH.  16-byte loads and stores, no window, no halo rows.
+// Same words as k_fwd_frame_yuv422 (tested against it), which stays for other geometries and small launches.  Geometry served: as k_fwd_yuv422_strip.
+// =============================================================================================
+__global__ void __launch_bounds__(NTHREADS) k_fwd_frame_yuv422_strip(const FwdFrameJob *jobs)
+{
+	const TileId tile = xcd_tile();
+	__shared__ FwdFrameJob s_job;
+	stage_job(&s_job, &jobs[tile.z]);
+	const FwdFrameJob &job = s_job;
+	__shared__ uint32_t s_pairs[2][2][2][SFPLANE];        // [buffer][row of the pair][V, U][chroma sample pairs of the row]
+	const int W = job.width, HH = job.height >> 1;
+	const int r0 = tile.y * SRI;
+	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+	const bool luma = wave < 2;
+	const int comp = luma ? 0 : wave - 1;                 // 0 Y, 1 V, 2 U
+	const QuantParam q_lh = job.q[comp][1], q_hl = job.q[comp][2], q_hh = job.q[comp][3];
+	const int nblk = luma ? W / 16 : W / 32;              // blocks of 8 band columns
+	const int seg_first = tile.x * SSEG;
+	const int base = luma ? seg_first + SLUMA_STEP * wave : seg_first >> 1;
+	const int want = base - 1 + lane;
+	const int blk = want < 0 ? 0 : (want < nblk ? want : nblk - 1);
+	const bool stores = lane >= 1 && lane <= SLUMA_STEP && want < nblk;
+	const bool first = blk == 0, last = blk == nblk - 1;
+	const int lds_write_at = (luma && want >= 0 && want < nblk && (wave == 0 ? lane <= SLUMA_STEP : lane >= 1)) ? 4 * (want - seg_first + 1) : -1;
+	const int lds_read_at = 8 * lane - 4;
+	if (r0 >= HH) return;
+	const int r1 = r0 + SRI < HH ? r0 + SRI : HH;
+	const int shift = job.shift;
+	const int ysh0 = job.uyvy ? 8 : 0, ub = job.uyvy ? 0 : 1, vb = job.uyvy ? 2 : 3;
+	const uint32_t usel = (uint32_t)ub | 0x0c00u | ((uint32_t)(4 + ub) << 16) | 0x0c000000u;
+	const uint32_t vsel = (uint32_t)vb | 0x0c00u | ((uint32_t)(4 + vb) << 16) | 0x0c000000u;
+	const uint8_t *in = job.in + 32 * (size_t)blk;
+	const int out_pitch = job.out_pitch[comp];
+	int16_t *const o0 = job.out[comp][0] + SBLK * blk, *const o1 = job.out[comp][1] + SBLK * blk, *const o2 = job.out[comp][2] + SBLK * blk, *const o3 = job.out[comp][3] + SBLK * blk;
+	const int dh = job.display_height, in_pitch = job.in_pitch;
+	for (int r = r0; r < r1; r++) {
+		uint32_t (*buf)[2][SFPLANE] = s_pairs[(r - r0) & 1];
+		uint32_t p[2][8];
+		if (luma) {
+			cfhd_u4 raw[2][2];
+#pragma unroll
+			for (int k = 0; k < 2; k++) {
+				const int y = 2 * r + k;
+				if (y < dh) { const uint8_t *src = in + (size_t)y * in_pitch; raw[k][0] = CFHD_LDG128(src); raw[k][1] = CFHD_LDG128(src + 16); }
+				else { cfhd_u4 g; g.x = g.y = g.z = g.w = 0x80808080u; raw[k][0] = g; raw[k][1] = g; }
+			}
+#pragma unroll
+			for (int k = 0; k < 2; k++) {
+				const uint32_t a[8] = { raw[k][0].x, raw[k][0].y, raw[k][0].z, raw[k][0].w, raw[k][1].x, raw[k][1].y, raw[k][1].z, raw[k][1].w };
+#pragma unroll
+				for (int i = 0; i < 8; i++) p[k][i] = ((a[i] >> ysh0) & 0x00ff00ffu) << shift;
+				if (lds_write_at >= 0) {
+#pragma unroll
+					for (int i = 0; i < 4; i++) {
+						buf[k][0][lds_write_at + i] = byte_perm(a[2 * i + 1], a[2 * i], vsel) << shift;
+						buf[k][1][lds_write_at + i] = byte_perm(a[2 * i + 1], a[2 * i], usel) << shift;
+					}
+				}
+			}
+		}
+		__syncthreads();                                  // (one per row pair: the buffers alternate, so the next pair's writes cannot pass this pair's reads)
+		if (!luma) {
+#pragma unroll
+			for (int k = 0; k < 2; k++) {
+#pragma unroll
+				for (int i = 0; i < 8; i++) p[k][i] = buf[k][comp - 1][lds_read_at + i < 0 ? 0 : lds_read_at + i];
+			}
+		}
+		// temporal pair of every sample (temporal.c:1915), then the horizontal analysis of both
+		uint32_t lo[8], hi[8];
+#pragma unroll
+		for (int i = 0; i < 8; i++) { lo[i] = pk_adds(p[0][i], p[1][i]); hi[i] = pk_subs(p[1][i], p[0][i]); }
+		uint32_t LL[4], LH[4], HLraw[4], HH[4];
+		strip_fwd_row(lo, __shfl(lo[7], lane - 1), __shfl(lo[0], lane + 1), first, last, LL, LH);
+		strip_fwd_row(hi, __shfl(hi[7], lane - 1), __shfl(hi[0], lane + 1), first, last, HLraw, HH);
+		uint32_t hlq[4];
+#pragma unroll
+		for (int d = 0; d < 4; d++) { LH[d] = pk_quantize(LH[d], q_lh); HH[d] = pk_quantize(HH[d], q_hh); hlq[d] = pk_quantize(HLraw[d], q_hl); }
+		// HL: the difference to the quantized value on its left, 0 in front of column 0 (spatial.c:5327 FilterHorizontalRowScaled16sDifferenceFiltered)
+		uint32_t left = __shfl(hlq[3], lane - 1) >> 16;
+		if (first) left = 0u;
+		uint32_t HL[4];
+#pragma unroll
+		for (int d = 0; d < 4; d++) {
+			const uint32_t shifted = (hlq[d] << 16) | (left & 0xffffu);      // (column 2d - 1, column 2d)
+			HL[d] = pk_subs(hlq[d], shifted);
+			left = hlq[d] >> 16;
+		}
+		if (stores) {
+			const size_t at = (size_t)r * out_pitch;
+			uint4 v;
+			v.x = LL[0]; v.y = LL[1]; v.z = LL[2]; v.w = LL[3]; *(uint4 *)(o0 + at) = v;
+			v.x = LH[0]; v.y = LH[1]; v.z = LH[2]; v.w = LH[3]; *(uint4 *)(o1 + at) = v;
+			v.x = HL[0]; v.y = HL[1]; v.z = HL[2]; v.w = HL[3]; *(uint4 *)(o2 + at) = v;
+			v.x = HH[0]; v.y = HH[1]; v.z = HH[2]; v.w = HH[3]; *(uint4 *)(o3 + at) = v;
+		}
+	}
+}
+
+// =============================================================================================
 // Interlaced last level: the inverse of k_fwd_frame_yuv422 (Codec/decoder.c:21493 TransformInverseFrameToYUV, :24304 threaded;
 // Codec/temporal.c:5961 InvertInterlacedRow16s10bitToYUV, :6498 ToUYVY).  Band row r of the level-1 wavelet gives two picture rows: the
 // horizontal synthesis of (LL, LH) is the temporal lowpass row, that of (HL, HH) -- HL un-differenced by k_dec_undiff -- the temporal

@@ -1435,6 +1435,50 @@ def test_batched_path_of_the_other_configurations_equals_reference(name, w, h, n
     L.cfhd_amd_batch_destroy(b)
 
 
+@pytest.mark.parametrize("w,h,n,fmt", [(1920, 1080, 3, PIX_YUY2), (2048, 120, 2, PIX_2VUY), (736, 100, 2, PIX_YUY2), (4000, 64, 2, PIX_YUY2)])
+def test_interlaced_strip_kernels_equal_reference(w, h, n, fmt):
+    """k_fwd_frame_yuv422_strip / k_inv_frame_yuv422_strip (the interlaced level 1 in the register-strip organisation: the shape large launches take, forced here with
+    CFHD_AMD_FORWARD / _INVERSE = strip):
+    one segment, two and three segments of 1984 pixels with a partial last one, pad rows below the picture, both byte orders.  Every sample equals the reference
+    encoder's (the difference-coded band with its lane-crossing left neighbours included); decoded frames lie in the dither interval of the exact reconstruction."""
+    L = _batch_api()
+    L.cfhd_amd_batch_kernel_name.restype = ctypes.c_char_p
+    L.cfhd_amd_batch_kernel_name.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    frames = [synth_yuy2(w, h, 90 + i)[0] for i in range(n)]
+    for f in frames: f.reshape(h, w * 2)[1::2] = np.roll(f.reshape(h, w * 2)[1::2], 6, axis=1)      # the second field a little later: motion between the fields
+    if fmt == PIX_2VUY: frames = [f.reshape(-1, 2)[:, ::-1].reshape(-1).copy() for f in frames]
+    refs = ref_encode_frames(frames, w * 2, w, h, fmt, flags=1)
+    old = {k: os.environ.get(k) for k in ("CFHD_AMD_FORWARD", "CFHD_AMD_INVERSE")}
+    os.environ["CFHD_AMD_FORWARD"] = "strip"; os.environ["CFHD_AMD_INVERSE"] = "strip"
+    try:
+        b = L.cfhd_amd_batch_create_ex(w, h, fmt, ENCODED_YUV422, 1, QUALITY_FILMSCAN1, n, 4, 0)
+        assert b, amd_last_error()
+        for i, f in enumerate(frames):
+            assert L.cfhd_amd_batch_upload(b, i, f.ctypes.data_as(ctypes.c_void_p), w * 2) == 0
+        assert L.cfhd_amd_batch_kernel_name(b, 0) == b"k_fwd_frame_yuv422_strip"
+        assert L.cfhd_amd_batch_kernel_name(b, 3) == (b"k_inv_frame_yuv422_strip" if w % 32 == 0 and (w // 2) % 16 == 0 else b"k_inv_frame_yuv422_quad")
+        assert L.cfhd_amd_batch_roundtrip(b) > 0, amd_last_error()
+        plan = Plan(w, h, pixkind=2 if fmt == PIX_2VUY else 1, progressive=0)
+        for i in range(n):
+            p = ctypes.c_void_p(); sz = ctypes.c_size_t()
+            assert L.cfhd_amd_batch_get_sample(b, i, ctypes.byref(p), ctypes.byref(sz)) == 0
+            sample = ctypes.string_at(p, sz.value)
+            assert len(sample) == len(refs[i]), "frame %d: %d bytes vs reference %d" % (i, len(sample), len(refs[i]))
+            assert mask_volatile_metadata(sample) == mask_volatile_metadata(refs[i]), "frame %d differs from the reference" % i
+            out = np.zeros(h * w * 2, dtype=np.uint8)
+            assert L.cfhd_amd_batch_download_output(b, i, out.ctypes.data_as(ctypes.c_void_p), w * 2) == 0
+            deq = host_decode_pyramid(sample, plan)
+            lo, hi = oracle_inverse_interlaced_yuv422(plan, deq, 0, uyvy=int(fmt == PIX_2VUY))[:h], oracle_inverse_interlaced_yuv422(plan, deq, 1, uyvy=int(fmt == PIX_2VUY))[:h]
+            img = out.reshape(h, w * 2)
+            ok = (img == lo) | (img == hi)
+            assert ok.all(), "frame %d: %d bytes outside the dither interval" % (i, (~ok).sum())
+        L.cfhd_amd_batch_destroy(b)
+    finally:
+        for k, v in old.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+
+
 @pytest.mark.parametrize("w,h,n", [(192, 96, 2), (1008, 244, 2), (2032, 120, 3), (3840, 2160, 2)])
 def test_bayer_strip_kernel_equals_reference(w, h, n):
     """k_fwd_bayer_strip (level 1 straight from the BYR4 mosaic: every photosite read and curved once, the four component planes from one pass; the shape large

@@ -21,7 +21,7 @@ MAX_PIXELS = int(os.environ.get("CFHD_EMU_MAX_PIXELS", 720 * 486))
 SKIP = {"test_batched_round_trip_at_bench_sizes_equals_reference", "test_b64a_8k_config_c_round_trip", "test_reference_harness_links_unchanged_and_prints_same_numbers",
         "test_yuy2_4k_two_segments"}
 # always: the register-strip kernels bench.py times, forced on the smallest batches of the GPU suite (their job tables and launch shapes come from the product)
-ALWAYS = {("test_yuv422_strip_kernels_equal_reference", 1952, 250), ("test_yuv422_strip_kernels_equal_reference", 2304, 72), ("test_bayer_strip_kernel_equals_reference", 1008, 244), ("test_bayer_strip_kernel_equals_reference", 2032, 120), ("test_packed16_strip_kernels_equal_reference", 1016, 304), ("test_packed16_strip_kernels_equal_reference", 504, 242),
+ALWAYS = {("test_yuv422_strip_kernels_equal_reference", 1952, 250), ("test_yuv422_strip_kernels_equal_reference", 2304, 72), ("test_bayer_strip_kernel_equals_reference", 1008, 244), ("test_interlaced_strip_kernels_equal_reference", 2048, 120), ("test_interlaced_strip_kernels_equal_reference", 4000, 64), ("test_bayer_strip_kernel_equals_reference", 2032, 120), ("test_packed16_strip_kernels_equal_reference", 1016, 304), ("test_packed16_strip_kernels_equal_reference", 504, 242),
           ("test_packed16_strip_kernels_equal_reference", 136, 120)}
 
 
