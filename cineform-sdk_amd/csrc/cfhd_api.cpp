@@ -1298,10 +1298,12 @@ static CFHD_Error decode_on_handle(Decoder *d, const ParsedSample &ps, const uin
 		if (d->batch.launch_inverse(0x2545F491u * ++d->frames_decoded)) return ERR_INTERNAL;
 		if (d->batch.download_frame(0, out, pitch)) return ERR_INTERNAL;
 		d->prof.mark(1);
-		if (d->batch.wait()) return ERR_INTERNAL;
+		// the picture is copied out piece by piece behind the DMA of each piece (finish_frame waits on their events); whether the sample decoded cleanly is known
+		// behind it -- a damaged one has its output zeroed as before
+		if (d->batch.finish_frame(0, out, pitch)) return ERR_INTERNAL;
 		d->prof.mark(2);
+		if (d->batch.wait()) return ERR_INTERNAL;
 		if (d->batch.entropy().check()) return fail_zero(ERR_BADSAMPLE);
-		d->batch.finish_frame(0, out, pitch);
 		d->prof.mark(3); d->prof.calls++;
 		return ERR_OKAY;
 	}

@@ -137,6 +137,8 @@ private:
 	bool rgb32_of_422_ = false;        // BGRA / BGRa output of 4:2:2 samples: the last level as k_inv_yuv422_rgb32 (spatial.c:29577)
 	bool rgb24_of_422_ = false;        // RG24 output of 4:2:2 samples: YU64 rows first, converted by k_yu64_to_rgb24 (the reference's route: 16-bit rows, then colour conversion)
 	std::vector<char> direct_;                      // frame i went straight to the caller's (registered) buffer: finish_frame has nothing to copy
+	enum { kMaxOutPieces = 8 };
+	std::vector<void *> piece_ev_; std::vector<int> out_pieces_;     // frames staged in pieces (download_frame / finish_frame): an event behind every piece's DMA
 	void *d_jobs_ = nullptr, *h_jobs_ = nullptr; size_t jobs_bytes_ = 0;
 	float kernel_ms_ = 0;
 	bool timed_ = false;

@@ -417,6 +417,9 @@ int EncodeBatch::sync_jobs()
 	return 0;
 }
 
+// frames from this size on are staged in pieces (below it the extra calls cost more than the overlap gives); CFHD_AMD_STAGE_MIN_BYTES: tests lower it
+static size_t stage_piece_min_bytes() { static const size_t v = [] { const char *e = getenv("CFHD_AMD_STAGE_MIN_BYTES"); return e ? (size_t)atoll(e) : ((size_t)1 << 20); }(); return v; }
+
 int EncodeBatch::upload_frame(int i, const void *frame, int pitch)
 {
 	(void)hipSetDevice(device_);
@@ -436,10 +439,19 @@ int EncodeBatch::upload_frame(int i, const void *frame, int pitch)
 		HIPCHK(hipMemcpy2DAsync(d_in_ + frame_bytes_ * i, (size_t)in_pitch_, src, (size_t)pitch, (size_t)in_pitch_, (size_t)in_rows_, hipMemcpyHostToDevice, (hipStream_t)stream_));
 		return 0;
 	}
+	// a plain buffer: staged through pinned memory, in a few pieces so that the DMA of a piece runs beside the CPU copy of the next (a 1080p frame: 4 MB, 0.2 ms of
+	// memcpy and as much of PCIe -- one after the other they were two thirds of a synchronous CFHD_EncodeSample call).  CFHD_AMD_STAGE_PIECES=1: one piece.
+	static const int pieces_env = [] { const char *e = getenv("CFHD_AMD_STAGE_PIECES"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
+	const int pieces = frame_bytes_ >= stage_piece_min_bytes() ? pieces_env : 1;
 	uint8_t *dst = h_in_ + frame_bytes_ * i;
-	if (pitch == in_pitch_) memcpy(dst, src, frame_bytes_);
-	else for (int r = 0; r < in_rows_; r++) memcpy(dst + (size_t)r * in_pitch_, src + (size_t)r * pitch, (size_t)in_pitch_);
-	HIPCHK(hipMemcpyAsync(d_in_ + frame_bytes_ * i, dst, frame_bytes_, hipMemcpyHostToDevice, (hipStream_t)stream_));
+	for (int k = 0; k < pieces; k++) {
+		const int r0 = (int)((long long)in_rows_ * k / pieces), r1 = (int)((long long)in_rows_ * (k + 1) / pieces);
+		if (r1 <= r0) continue;
+		const size_t off = (size_t)r0 * in_pitch_, bytes = (size_t)(r1 - r0) * in_pitch_;
+		if (pitch == in_pitch_) memcpy(dst + off, src + (size_t)r0 * pitch, bytes);
+		else for (int r = r0; r < r1; r++) memcpy(dst + (size_t)r * in_pitch_, src + (size_t)r * pitch, (size_t)in_pitch_);
+		HIPCHK(hipMemcpyAsync(d_in_ + frame_bytes_ * i + off, dst + off, bytes, hipMemcpyHostToDevice, (hipStream_t)stream_));
+	}
 	return 0;
 }
 
@@ -703,6 +715,8 @@ void DecodeBatch::release()
 	if (ev1_) hipEventDestroy((hipEvent_t)ev1_);
 	for (int k = 0; k < 2; k++) if (evl_[k]) { hipEventDestroy((hipEvent_t)evl_[k]); evl_[k] = nullptr; }
 	if (evdep_) { hipEventDestroy((hipEvent_t)evdep_); evdep_ = nullptr; }
+	for (void *e : piece_ev_) if (e) hipEventDestroy((hipEvent_t)e);
+	piece_ev_.clear(); out_pieces_.clear();
 	for (int k = 0; k < 3; k++) if (ev2_[k]) { hipEventDestroy((hipEvent_t)ev2_[k]); ev2_[k] = nullptr; }
 	if (stream2_) { hipStreamDestroy((hipStream_t)stream2_); stream2_ = nullptr; }
 	if (stream_) hipStreamDestroy((hipStream_t)stream_);
@@ -1109,6 +1123,26 @@ int DecodeBatch::download_frame(int i, void *out, int pitch)
 		direct_[i] = 1;
 		return 0;
 	}
+	// a plain buffer: staged through pinned memory; the few frames of a C ABI call come in pieces with an event behind each, so that finish_frame() can copy a piece
+	// into the caller's buffer while the DMA of the next is still running (as EncodeBatch::upload_frame does on the way in)
+	static const int pieces_env = [] { const char *e = getenv("CFHD_AMD_STAGE_PIECES"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > kMaxOutPieces ? (int)kMaxOutPieces : v); }();
+	const int pieces = (n_ <= 8 && frame_bytes_ >= stage_piece_min_bytes()) ? pieces_env : 1;
+	if (out_pieces_.size() != (size_t)n_) out_pieces_.assign((size_t)n_, 0);
+	out_pieces_[i] = 0;
+	if (pieces > 1) {
+		if (piece_ev_.size() != (size_t)n_ * kMaxOutPieces) {
+			piece_ev_.assign((size_t)n_ * kMaxOutPieces, nullptr);
+			for (void *&e : piece_ev_) { hipEvent_t ev; HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); e = ev; }
+		}
+		for (int k = 0; k < pieces; k++) {
+			const int r0 = (int)((long long)out_rows_ * k / pieces), r1 = (int)((long long)out_rows_ * (k + 1) / pieces);
+			const size_t off = (size_t)r0 * out_pitch_, bytes = (size_t)(r1 - r0) * out_pitch_;
+			if (bytes) HIPCHK(hipMemcpyAsync(h_out_ + frame_bytes_ * i + off, d_out_ + frame_bytes_ * i + off, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream_));
+			HIPCHK(hipEventRecord((hipEvent_t)piece_ev_[(size_t)i * kMaxOutPieces + k], (hipStream_t)stream_));
+		}
+		out_pieces_[i] = pieces;
+		return 0;
+	}
 	HIPCHK(hipMemcpyAsync(h_out_ + frame_bytes_ * i, d_out_ + frame_bytes_ * i, frame_bytes_, hipMemcpyDeviceToHost, (hipStream_t)stream_));
 	return 0;
 }
@@ -1148,6 +1182,19 @@ int DecodeBatch::finish_frame(int i, void *out, int pitch)
 	if (direct_.size() == (size_t)n_ && direct_[i]) return 0;            // already in the caller's buffer
 	const uint8_t *src = h_out_ + frame_bytes_ * i;
 	uint8_t *dst = (uint8_t *)out;
+	const int pieces = out_pieces_.size() == (size_t)n_ ? out_pieces_[i] : 0;
+	if (pieces > 1) {
+		// the frame came down in pieces (download_frame): every piece is copied out as soon as its DMA has finished, beside the DMA of the next one.  (May be
+		// called before wait(): the events order it; after wait() they have all fired.)
+		(void)hipSetDevice(device_);
+		for (int k = 0; k < pieces; k++) {
+			const int r0 = (int)((long long)out_rows_ * k / pieces), r1 = (int)((long long)out_rows_ * (k + 1) / pieces);
+			HIPCHK(hipEventSynchronize((hipEvent_t)piece_ev_[(size_t)i * kMaxOutPieces + k]));
+			if (pitch == out_pitch_) memcpy(dst + (size_t)r0 * out_pitch_, src + (size_t)r0 * out_pitch_, (size_t)(r1 - r0) * out_pitch_);
+			else for (int r = r0; r < r1; r++) memcpy(dst + (ptrdiff_t)r * pitch, src + (size_t)r * out_pitch_, (size_t)out_pitch_);
+		}
+		return 0;
+	}
 	if (pitch == out_pitch_) memcpy(dst, src, frame_bytes_);
 	else for (int r = 0; r < out_rows_; r++) memcpy(dst + (ptrdiff_t)r * pitch, src + (size_t)r * out_pitch_, (size_t)out_pitch_);
 	return 0;

@@ -362,6 +362,7 @@ def product_emulated():
         # of them (cfhd_core.h unit_device), so every pool / handle test of the emulated suite is a several-device run in which a pointer, a stream or an event that
         # crosses devices -- or host code that dereferences device memory -- ends the test loudly.  (Read when the library makes its first HIP call.)
         os.environ.setdefault("HIPEMU_DEVICES", "4")
+        os.environ.setdefault("CFHD_AMD_STAGE_MIN_BYTES", "4096")      # plain host buffers are staged in pieces (cfhd_device.hip upload_frame / download_frame): at every frame size here, not only from 1 MB on
         L = ctypes.CDLL(EMU_PRODUCT_SO)
         declare_cfhd_api(L)
         _emu_product = L
