@@ -167,6 +167,9 @@ bool gpu_entropy_enabled() { const char *e = getenv("CFHD_AMD_ENTROPY"); return 
 // CFHD_AMD_ENTROPY=device: (tests) a sample the device stage hands back to the host coder fails the call instead -- proves which stage served a group
 bool gpu_entropy_strict() { const char *e = getenv("CFHD_AMD_ENTROPY"); return e && strcmp(e, "device") == 0; }
 
+// one caller waiting for one frame: its plain buffers are staged in pieces (cfhd_device.hip upload_frame / download_frame); CFHD_AMD_STAGE_PIECES=1 switches that off
+int sync_stage_pieces() { static const int v = [] { const char *e = getenv("CFHD_AMD_STAGE_PIECES"); const int k = e ? atoi(e) : 4; return k < 1 ? 1 : k; }(); return v; }
+
 int prepare_batch(EncodeBatch &batch, const EncodeParams &p)
 {
 	if (batch.prepare(p.plan, 1, true)) return ERR_INTERNAL;
@@ -706,6 +709,7 @@ CFHD_Error CFHD_EncodeSample(CFHD_EncoderRef ref, void *frame, int pitch)
 		return ERR_OKAY;
 	}
 	if (!e->batch_ready) {
+		e->batch.set_stage_pieces(sync_stage_pieces());
 		if (prepare_batch(e->batch, e->params)) return ERR_INTERNAL;
 		e->batch_ready = true;
 	}
@@ -1283,6 +1287,7 @@ static CFHD_Error decode_on_handle(Decoder *d, const ParsedSample &ps, const uin
 	if (!d->batch_ready) {
 		d->batch.set_interlaced(interlaced);
 		device_select(d->device);                      // the handle's GPU (the batch remembers it: later calls may come from any thread)
+		d->batch.set_stage_pieces(sync_stage_pieces());
 		int prc = d->batch.prepare(d->plan, 1, d->out_kind, true, d->half);
 		if (!prc && gpu_entropy_enabled()) prc = d->batch.prepare_entropy((size_t)d->plan.width * d->plan.height * pixel_bytes_of(d->out_kind) + 65536);
 		device_select(-1);
@@ -1300,10 +1305,17 @@ static CFHD_Error decode_on_handle(Decoder *d, const ParsedSample &ps, const uin
 		d->prof.mark(1);
 		// the picture is copied out piece by piece behind the DMA of each piece (finish_frame waits on their events); whether the sample decoded cleanly is known
 		// behind it -- a damaged one has its output zeroed as before
-		if (d->batch.finish_frame(0, out, pitch)) return ERR_INTERNAL;
-		d->prof.mark(2);
-		if (d->batch.wait()) return ERR_INTERNAL;
-		if (d->batch.entropy().check()) return fail_zero(ERR_BADSAMPLE);
+		if (d->batch.staged_in_pieces()) {
+			if (d->batch.finish_frame(0, out, pitch)) return ERR_INTERNAL;
+			d->prof.mark(2);
+			if (d->batch.wait()) return ERR_INTERNAL;
+			if (d->batch.entropy().check()) return fail_zero(ERR_BADSAMPLE);
+		} else {
+			if (d->batch.wait()) return ERR_INTERNAL;
+			d->prof.mark(2);
+			if (d->batch.entropy().check()) return fail_zero(ERR_BADSAMPLE);
+			d->batch.finish_frame(0, out, pitch);
+		}
 		d->prof.mark(3); d->prof.calls++;
 		return ERR_OKAY;
 	}

@@ -47,6 +47,7 @@ public:
 	// GPU entropy stage (cfhd_entropy_kernels.h): complete samples are produced in HBM after launch_forward().
 	int prepare_entropy(size_t sample_cap);
 	GpuEntropyEncoder &entropy() { return ent_; }
+	void set_stage_pieces(int k) { stage_pieces_ = k < 1 ? 1 : (k > 16 ? 16 : k); }      // plain input frames staged in k pieces (upload_frame)
 	bool has_entropy() const { return ent_ready_; }
 	bool strip_forward() const;                     // level 1 of 4:2:2 runs as k_fwd_yuv422_strip (else k_fwd_yuv422)
 	bool block_lists_forward() const;               // ... and leaves the quantized level-1 bands as block lists for k_ent_count_blocks (k_fwd_yuv422_strip_blocks)
@@ -82,6 +83,7 @@ private:
 	float kernel_ms_ = 0;
 	bool timed_ = false;
 	GpuEntropyEncoder ent_; bool ent_ready_ = false;
+	int stage_pieces_ = 1;
 };
 
 class DecodeBatch {
@@ -138,6 +140,12 @@ private:
 	bool rgb24_of_422_ = false;        // RG24 output of 4:2:2 samples: YU64 rows first, converted by k_yu64_to_rgb24 (the reference's route: 16-bit rows, then colour conversion)
 	std::vector<char> direct_;                      // frame i went straight to the caller's (registered) buffer: finish_frame has nothing to copy
 	enum { kMaxOutPieces = 8 };
+	int stage_pieces_ = 1;
+public:
+	// plain host buffers staged in k pieces (download_frame / finish_frame: the CPU copy of a piece beside the DMA of the next); then finish_frame() may be called before wait()
+	void set_stage_pieces(int k) { stage_pieces_ = k < 1 ? 1 : (k > kMaxOutPieces ? (int)kMaxOutPieces : k); }
+	bool staged_in_pieces() const { return stage_pieces_ > 1; }
+private:
 	std::vector<void *> piece_ev_; std::vector<int> out_pieces_;     // frames staged in pieces (download_frame / finish_frame): an event behind every piece's DMA
 	void *d_jobs_ = nullptr, *h_jobs_ = nullptr; size_t jobs_bytes_ = 0;
 	float kernel_ms_ = 0;

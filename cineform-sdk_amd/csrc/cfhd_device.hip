@@ -440,9 +440,10 @@ int EncodeBatch::upload_frame(int i, const void *frame, int pitch)
 		return 0;
 	}
 	// a plain buffer: staged through pinned memory, in a few pieces so that the DMA of a piece runs beside the CPU copy of the next (a 1080p frame: 4 MB, 0.2 ms of
-	// memcpy and as much of PCIe -- one after the other they were two thirds of a synchronous CFHD_EncodeSample call).  CFHD_AMD_STAGE_PIECES=1: one piece.
-	static const int pieces_env = [] { const char *e = getenv("CFHD_AMD_STAGE_PIECES"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
-	const int pieces = frame_bytes_ >= stage_piece_min_bytes() ? pieces_env : 1;
+	// memcpy and as much of PCIe -- one after the other they were two thirds of a synchronous CFHD_EncodeSample call: 2350 -> 2820 fps).  Only where one caller waits for one
+	// frame (set_stage_pieces: the handles of CFHD_EncodeSample / CFHD_DecodeSample): pool workers and gathered decoders run many such copies side by side already, and
+	// the extra runtime calls cost them 15-20 % (measured, profiles/r04_j_*).
+	const int pieces = frame_bytes_ >= stage_piece_min_bytes() ? stage_pieces_ : 1;
 	uint8_t *dst = h_in_ + frame_bytes_ * i;
 	for (int k = 0; k < pieces; k++) {
 		const int r0 = (int)((long long)in_rows_ * k / pieces), r1 = (int)((long long)in_rows_ * (k + 1) / pieces);
@@ -1125,11 +1126,10 @@ int DecodeBatch::download_frame(int i, void *out, int pitch)
 	}
 	// a plain buffer: staged through pinned memory; the few frames of a C ABI call come in pieces with an event behind each, so that finish_frame() can copy a piece
 	// into the caller's buffer while the DMA of the next is still running (as EncodeBatch::upload_frame does on the way in)
-	static const int pieces_env = [] { const char *e = getenv("CFHD_AMD_STAGE_PIECES"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > kMaxOutPieces ? (int)kMaxOutPieces : v); }();
-	const int pieces = (n_ <= 8 && frame_bytes_ >= stage_piece_min_bytes()) ? pieces_env : 1;
+	const int pieces = (n_ <= 8 && frame_bytes_ >= stage_piece_min_bytes()) ? (stage_pieces_ > kMaxOutPieces ? (int)kMaxOutPieces : stage_pieces_) : 1;
 	if (out_pieces_.size() != (size_t)n_) out_pieces_.assign((size_t)n_, 0);
 	out_pieces_[i] = 0;
-	if (pieces > 1) {
+	if (stage_pieces_ > 1) {                             // (a batch that stages in pieces puts an event behind every frame it stages, also behind one that is too small to cut: finish_frame() may run before wait())
 		if (piece_ev_.size() != (size_t)n_ * kMaxOutPieces) {
 			piece_ev_.assign((size_t)n_ * kMaxOutPieces, nullptr);
 			for (void *&e : piece_ev_) { hipEvent_t ev; HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); e = ev; }
@@ -1183,7 +1183,7 @@ int DecodeBatch::finish_frame(int i, void *out, int pitch)
 	const uint8_t *src = h_out_ + frame_bytes_ * i;
 	uint8_t *dst = (uint8_t *)out;
 	const int pieces = out_pieces_.size() == (size_t)n_ ? out_pieces_[i] : 0;
-	if (pieces > 1) {
+	if (pieces >= 1) {
 		// the frame came down in pieces (download_frame): every piece is copied out as soon as its DMA has finished, beside the DMA of the next one.  (May be
 		// called before wait(): the events order it; after wait() they have all fired.)
 		(void)hipSetDevice(device_);

@@ -9,7 +9,7 @@ with open("/tmp/frames.yuy2", "wb") as f:
     for i in range(8): f.write(synth_yuy2(1920, 1080, 20 + i)[0].tobytes())
 PY
 export CFHD_AMD_DEVICE=0
-for p in 1 4 1 4 2 8; do
+for p in 1 4 1 4; do
   for t in 8 16; do
     echo "pieces $p threads $t: $(CFHD_AMD_STAGE_PIECES=$p tools/_build/cabi_bench 1920 1080 /tmp/frames.yuy2 8 1.5 0 $t $t | tail -1)"
   done
