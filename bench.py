@@ -482,10 +482,11 @@ def main():
             others = {}
             for name in ("2160p", "rg48-2160p", "b64a-4320p", "byr4-2160p", "1080i"):
                 try:
-                    ol, _, _ = measure(name, 5, 2, WORKLOADS[name]["batch"], 0, threads, 0, 1, barrier, reduce_max)
+                    ol, _, _ = measure(name, 2 * max(args.depth, 1) + 1, 2, WORKLOADS[name]["batch"], 0, threads, 0, 1, barrier, reduce_max, depth=args.depth)      # (the same frame queue as the headline)
                     others[name] = {"metric": ol["metric"], "value": ol["value"], "unit": "fps", "ms_per_step": ol["ms_per_step"], "frames_per_step": ol["config"]["frames_per_step_per_gpu"],
                                     "workload": ol["config"]["workload"], "data": ol["data"], "parity": ol["config"]["parity"], "roofline": {k: ol["roofline"][k] for k in ("kernel", "achieved", "peak", "unit", "frac", "launch_ms")},
-                                    "whole_path": ol["config"]["whole_path"], "kernel_ms_per_step": ol["config"]["kernel_ms_per_step"]}
+                                    "whole_path": ol["config"]["whole_path"], "kernel_ms_per_step": ol["config"]["kernel_ms_per_step"], "steps": ol["steps"], "steps_in_flight": ol["config"].get("steps_in_flight"),
+                                    "kernel_ms_one_step_at_a_time": ol["config"].get("kernel_ms_one_step_at_a_time")}
                 except (Exception, SystemExit) as e:      # a failed side run is reported, it does not take the headline line with it
                     others[name] = {"error": str(e)[:300]}
             line["config"]["other_workloads"] = others
