@@ -526,7 +526,7 @@ struct DecodeService : Gatherer<DecodeBatch> {
 		}
 		run_pass = [](Pass &x, int n, uint32_t launch) {
 			x.batch.set_active(n);
-			int rc = x.batch.entropy().launch();
+			int rc = x.batch.launch_entropy();
 			if (!rc) rc = x.batch.launch_inverse(0x2545F491u * launch);
 			for (int i = 0; i < n && !rc; i++) rc = x.batch.download_frame(i, x.ptr[i], x.num[i]);
 			if (!rc) rc = x.batch.wait(); else (void)x.batch.wait();
@@ -1299,7 +1299,7 @@ static CFHD_Error decode_on_handle(Decoder *d, const ParsedSample &ps, const uin
 		d->prof.start();
 		if (d->batch.entropy().set_sample_host(0, s, size)) return fail_zero(ERR_BADSAMPLE);
 		d->prof.mark(0);
-		if (d->batch.entropy().launch()) return ERR_INTERNAL;
+		if (d->batch.launch_entropy()) return ERR_INTERNAL;
 		if (d->batch.launch_inverse(0x2545F491u * ++d->frames_decoded)) return ERR_INTERNAL;
 		if (d->batch.download_frame(0, out, pitch)) return ERR_INTERNAL;
 		d->prof.mark(1);

@@ -158,7 +158,7 @@ long long cfhd_amd_batch_roundtrip(cfhd_amd_batch *b)
 				// the parser only needs the headers and size fields (k_ent_layout): it runs beside k_ent_emit, the band decoder waits for the payloads
 				c->dec.entropy().set_producer_events(c->enc.entropy().headers_event(), c->enc.entropy().samples_event());
 				if (c->dec.entropy().set_samples_device(c->enc.entropy().device_sample(0), c->enc.entropy().sample_cap(), c->enc.entropy().device_sizes())) return fail(-4);
-				if (c->dec.entropy().launch() || c->dec.launch_inverse(seed + (uint32_t)c->first)) return fail(-5);
+				if (c->dec.launch_entropy() || c->dec.launch_inverse(seed + (uint32_t)c->first)) return fail(-5);
 			}
 			t_sub[k] = now();
 			if (c->enc.entropy().download() || c->enc.wait()) return fail(-2);
@@ -197,7 +197,7 @@ long long cfhd_amd_batch_roundtrip(cfhd_amd_batch *b)
 			parallel_for(c->n, b->nthreads < 16 ? b->nthreads : 16, [&, cp](int l) {
 				if (cp->dec.entropy().set_sample_host(l, cp->enc.entropy().host_sample(l), b->sample_size[cp->first + l])) bad++; });
 			if (bad) return -4;
-			if (c->dec.entropy().launch() || c->dec.launch_inverse(seed + (uint32_t)c->first)) return -5;
+			if (c->dec.launch_entropy() || c->dec.launch_inverse(seed + (uint32_t)c->first)) return -5;
 			wait_s += m - a; stage_s += now() - m;
 		}
 		t2 = t1 + wait_s; t3 = t2 + stage_s;

@@ -139,4 +139,20 @@ static inline int block_list_layout(const FramePlan &plan, int mask_base[kMaxCha
 	return at;
 }
 
+// The decode side of the same idea (round 4): the tile pass of the entropy decoder (k_dec_tiles) leaves the dequantized level-1 highpass bands as block lists and the
+// inverse level-1 strip kernel gathers them.  Here a chunk is 64 consecutive blocks of the band's flat raster (512 coefficients, pitch padding included -- what a
+// tile of the decoder is made of), the listed blocks of chunk k sit compacted at the band's own blocks 64 k .. in the pyramid, and there is one 64-bit mask per chunk.
+enum { kDecChunkCoeffs = 512 };
+static inline int dec_block_list_layout(const FramePlan &plan, int mask_base[kMaxChannels][kNumBands])
+{
+	int at = 0;
+	for (int c = 0; c < plan.num_channels; c++)
+		for (int b = 0; b < kNumBands; b++) {
+			const BandDesc &bd = plan.ch[c].band[0][b];
+			mask_base[c][b] = b ? at : -1;
+			if (b) at += (bd.height * bd.pitch + kDecChunkCoeffs - 1) / kDecChunkCoeffs;
+		}
+	return at;
+}
+
 } // namespace cfhd

@@ -794,7 +794,8 @@ __global__ void __launch_bounds__(DX_THREADS) k_dec_reindex(const DxBandJob *job
 // Tiles are numbered position by position: position p holds the tiles of band slot slot_of[p] for every frame (cum[p] tiles lie in front of it, per_band[p] per
 // band).  The positions of the level-2 and level-3 bands come first (tiles 0 .. split - 1), those of the level-1 bands behind them, so that a launch over
 // [first, total) can decode one group while the inverse transforms of the other run (GpuEntropyDecoder::launch_dx).
-struct DxTilePlan { int nslots, nframes; uint32_t cum[40]; uint32_t per_band[40]; uint32_t total, first, split; uint8_t slot_of[40]; };
+struct DxTilePlan { int nslots, nframes; uint32_t cum[40]; uint32_t per_band[40]; uint32_t total, first, split; uint8_t slot_of[40];
+                    int mask_base[40]; /* per position: first chunk mask of the band in a frame's mask array when its tiles leave as block lists (cfhd_core.h dec_block_list_layout), else -1 */ };
 
 enum : uint32_t { DX_TILE_EMPTY = 0xFFFFFFFFu };
 
@@ -839,7 +840,7 @@ __global__ void __launch_bounds__(DX_THREADS) k_dec_tile_index(const DxBandJob *
 
 // What a wave of k_dec_tiles needs to know about a tile, and the first 64 pieces of payload that may reach into it: both are fetched
 // one tile ahead, so that the loads are in flight while the previous tile is decoded.
-struct DxTileMeta { int j; uint32_t ti, first_sub; DxBandJob job; DxBandSum sum; };
+struct DxTileMeta { int j; uint32_t ti, first_sub; DxBandJob job; DxBandSum sum; unsigned long long *masks; /* the band's chunk masks in this frame, or null: dense */ };
 // 0 in every lane, but not to the compiler: an address with it added is per-lane, so the load becomes a vector load (counted by vmcnt) and
 // not a scalar one -- scalar loads share their counter with LDS, and the first LDS read of the decode loop would wait for the prefetch.
 __device__ __forceinline__ uint32_t dx_lane_zero() { return __builtin_amdgcn_mbcnt_lo(0u, 0u); }
@@ -860,12 +861,14 @@ template <typename T> __device__ __forceinline__ T dx_uniform(const T &v)    // 
 	return r;
 }
 struct DxPieces { uint32_t ent, cb, d[4]; };
-__device__ __forceinline__ void dx_tile_meta(const DxTilePlan &plan, uint32_t t, int &slot, const DxBandJob *jobs, const DxBandSum *sums, const uint32_t *tile_start, DxTileMeta &M)
+__device__ __forceinline__ void dx_tile_meta(const DxTilePlan &plan, uint32_t t, int &slot, const DxBandJob *jobs, const DxBandSum *sums, const uint32_t *tile_start, DxTileMeta &M,
+                                             unsigned long long *masks = nullptr, uint32_t masks_per_frame = 0u)
 {
 	while (slot + 1 < plan.nslots && t >= plan.cum[slot + 1]) slot++;       // tiles come in increasing order: the slot only moves forward
 	const uint32_t r = t - plan.cum[slot], per = plan.per_band[slot];
 	const uint32_t f = r / per;
 	M.ti = r - f * per; M.j = (int)plan.slot_of[slot] * plan.nframes + (int)f;
+	M.masks = (masks && plan.mask_base[slot] >= 0) ? masks + (size_t)f * masks_per_frame + (size_t)plan.mask_base[slot] : nullptr;
 	dx_vload(M.first_sub, tile_start + t);
 	dx_vload(M.job, jobs + M.j);
 	dx_vload(M.sum, sums + M.j);
@@ -895,7 +898,7 @@ __device__ __forceinline__ uint32_t dx_tile_last_sub(const DxTileMeta &M) { retu
 enum { DX_TILE_WORDS = DX_TILE / 2 + 32 };
 
 __global__ void __launch_bounds__(DX_TILE_THREADS) k_dec_tiles(const DxBandJob *jobs, DxTilePlan plan, const DecIdxTables *T, const uint32_t *entries, const uint32_t *chunk_base,
-                                                               const DxBandSum *sums, const uint32_t *tile_start)
+                                                               const DxBandSum *sums, const uint32_t *tile_start, unsigned long long *masks, uint32_t masks_per_frame)
 {
 	__shared__ uint2 s_multi[1 << DX_KM];
 	__shared__ uint32_t s_long[DX_LONG11_MAX];
@@ -912,9 +915,9 @@ __global__ void __launch_bounds__(DX_TILE_THREADS) k_dec_tiles(const DxBandJob *
 	// software pipeline: tile t is decoded while the descriptors of tile t + 2 nwaves and the payload pieces of tile t + nwaves are on their way
 	int slot = 0;
 	DxTileMeta M, M1;
-	dx_tile_meta(plan, t, slot, jobs, sums, tile_start, M);
+	dx_tile_meta(plan, t, slot, jobs, sums, tile_start, M, masks, masks_per_frame);
 	M1 = M;
-	if (t + nwaves < plan.total) dx_tile_meta(plan, t + nwaves, slot, jobs, sums, tile_start, M1);
+	if (t + nwaves < plan.total) dx_tile_meta(plan, t + nwaves, slot, jobs, sums, tile_start, M1, masks, masks_per_frame);
 	DxPieces P;
 	dx_tile_pieces(M, dx_tile_has_work(M) ? M.first_sub + (uint32_t)lane : 0xFFFFFFFFu, dx_tile_has_work(M) ? dx_tile_last_sub(M) : 0u, entries, chunk_base, P);
 	int16_t *tile16 = (int16_t *)s_tile;
@@ -923,7 +926,7 @@ __global__ void __launch_bounds__(DX_TILE_THREADS) k_dec_tiles(const DxBandJob *
 	for (; t < plan.total; t += nwaves) {
 		DxTileMeta M2 = M1;
 		DxPieces P1;
-		if (t + 2 * nwaves < plan.total) dx_tile_meta(plan, t + 2 * nwaves, slot, jobs, sums, tile_start, M2);
+		if (t + 2 * nwaves < plan.total) dx_tile_meta(plan, t + 2 * nwaves, slot, jobs, sums, tile_start, M2, masks, masks_per_frame);
 		{
 			const bool w1 = t + nwaves < plan.total && dx_tile_has_work(M1);
 			dx_tile_pieces(M1, w1 ? M1.first_sub + (uint32_t)lane : 0xFFFFFFFFu, w1 ? dx_tile_last_sub(M1) : 0u, entries, chunk_base, P1);
@@ -999,6 +1002,24 @@ __global__ void __launch_bounds__(DX_TILE_THREADS) k_dec_tiles(const DxBandJob *
 			uint4 *dst = (uint4 *)(job.dst + T0);
 			const uint32_t n16 = (T1 - T0) / 8;
 			const uint4 zero = { 0u, 0u, 0u, 0u };
+			unsigned long long *const tmasks = wave_uniform_ptr(M.masks);
+			if (tmasks) {
+				// ... as block lists (cfhd_core.h dec_block_list_layout): of every chunk of 64 blocks only the blocks that hold a nonzero coefficient, compacted to the
+				// chunk's own first places in the band (a lane's rank among the chunk's listed blocks: a ballot + v_mbcnt), and the chunk's occupancy mask.  The inverse
+				// level-1 strip kernel gathers them (k_inv_yuv422_strip_blocks); what lies behind a chunk's listed blocks in the band is stale and never read.
+				static_assert(DX_TILE % 512 == 0, "a tile is a whole number of chunks");
+				const uint32_t chunk0 = T0 / 512u;
+#pragma unroll 1
+				for (uint32_t it = 0; it < (uint32_t)DX_TILE / 512u; it++) {
+					const uint32_t i = it * 64u + (uint32_t)lane;
+					const uint4 v = ((const uint4 *)s_tile)[i];
+					((uint4 *)s_tile)[i] = zero;
+					const bool nz = i < n16 && (v.x | v.y | v.z | v.w) != 0u;
+					const unsigned long long m = __ballot(nz);
+					if (nz) dst[it * 64u + wave_mbcnt(m)] = v;
+					if (lane == 0 && it * 64u < n16) tmasks[chunk0 + it] = m;
+				}
+			} else
 			for (uint32_t i = (uint32_t)lane; i < (uint32_t)DX_TILE / 8; i += 64) {
 				const uint4 v = ((const uint4 *)s_tile)[i];
 				((uint4 *)s_tile)[i] = zero;

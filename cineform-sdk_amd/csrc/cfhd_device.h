@@ -106,11 +106,13 @@ public:
 	// GPU entropy decoder (k_dec_bands): samples in, dequantized pyramid built in HBM (replaces host_coeffs()/upload_coeffs()).
 	int prepare_entropy(size_t sample_cap);
 	GpuEntropyDecoder &entropy() { return ent_; }
+	int launch_entropy();                            // entropy().launch() with the level-1 bands as block lists where the inverse gathers them (block_lists_inverse())
 	bool has_entropy() const { return ent_ready_; }
 	bool strip_inverse() const;                     // the last level of 4:2:2 runs as k_inv_yuv422_strip (else k_inv_yuv422)
 	bool strip_inverse_packed16() const;            // the last level of RG48 / b64a output runs as k_inv_packed16_strip (else k_inv_packed16)
 	bool frame_inverse_quads() const;
-	bool frame_inverse_strips() const;               // interlaced samples: k_inv_frame_yuv422_quad (else k_inv_frame_yuv422)
+	bool frame_inverse_strips() const;
+	bool block_lists_inverse() const;               // interlaced samples: k_inv_frame_yuv422_quad (else k_inv_frame_yuv422)
 	const char *level_kernel(int level) const;      // name of the kernel the next launch_inverse() uses for level 0 / 1 / 2
 	int set_device_output(int i, void *d_out, int pitch_bytes);
 	int launch_inverse(uint32_t dither_seed);          // async

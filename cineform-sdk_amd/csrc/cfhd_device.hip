@@ -890,6 +890,8 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 		y.uyvy = out_kind == PIX_2VUY; y.shift = plan.precision - 8; y.dither_seed = 0x9E3779B9u * (uint32_t)(i + 1);
 		y.out = own_output ? d_out_ + frame_bytes_ * i : nullptr; y.out_pitch = out_pitch_;
 		y.bottom_up = out_kind == PIX_BGRA; y.matrix_601 = plan.color_matrix >= 2;       // (k_inv_yuv422_rgb32)
+		y.masks = nullptr;                               // (block lists: prepare_entropy() knows the mask buffer)
+		{ int mb[kMaxChannels][kNumBands]; dec_block_list_layout(plan, mb); for (int c = 0; c < 3; c++) for (int b = 0; b < 4; b++) y.mask_base[c][b] = mb[c][b]; }
 	}
 	jobs_dirty_ = true;
 	return 0;
@@ -900,7 +902,29 @@ int DecodeBatch::prepare_entropy(size_t sample_cap)
 	ent_.set_skip_level1(half_);                         // half resolution never looks at the level-1 highpass bands
 	int rc = ent_.prepare(plan_, n_, d_coeff_, plan_.coeff_elems, sample_cap, lowpass_kind_, stream_);
 	ent_ready_ = rc == 0;
+	if (ent_ready_ && h_jobs_) {
+		DecJobs j = dec_jobs_at(h_jobs_, n_, plan_.num_channels);
+		for (int i = 0; i < n_; i++) j.yuv[i].masks = ent_.block_masks(i);
+		jobs_dirty_ = true;
+	}
 	return rc;
+}
+
+// The level-1 highpass bands as block lists between the entropy decoder's tile pass and k_inv_yuv422_strip_blocks (cfhd_core.h dec_block_list_layout): wherever the
+// progressive 4:2:2 strip kernel writes 8-bit 4:2:2 pictures behind the GPU entropy stage.  CFHD_AMD_DEC_BLOCKS=0: dense bands (A/B runs).
+bool DecodeBatch::block_lists_inverse() const
+{
+	const int blocks_env = [] { const char *e = getenv("CFHD_AMD_DEC_BLOCKS"); return e ? atoi(e) : 1; }();      // (read at every launch: tests switch within one process)
+	if (!blocks_env || !ent_ready_ || !ent_.block_masks(0) || !ent_.chunk_indexed()) return false;
+	if (interlaced_ || half_ || dec_planes16(out_kind_) || rgb32_of_422_ || rgb16_of_422_ || rgb24_of_422_ || v210_ || byr4_) return false;
+	if (!(out_kind_ == PIX_YUY2 || out_kind_ == PIX_2VUY) || plan_.encoded_format != ENC_YUV422) return false;
+	return strip_inverse();
+}
+
+int DecodeBatch::launch_entropy()
+{
+	ent_.set_block_lists(block_lists_inverse());
+	return ent_.launch();
 }
 
 int DecodeBatch::sync_jobs()
@@ -1000,11 +1024,13 @@ const char *DecodeBatch::level_kernel(int level) const
 	if (dec_rgb10(out_kind_)) return "k_inv_rgb10";
 	if (dec_planes16(out_kind_)) return strip_inverse_packed16() ? "k_inv_packed16_strip" : "k_inv_packed16";
 	if (interlaced_) return frame_inverse_strips() ? "k_inv_frame_yuv422_strip" : (frame_inverse_quads() ? "k_inv_frame_yuv422_quad" : "k_inv_frame_yuv422");
-	return strip_inverse() ? "k_inv_yuv422_strip" : "k_inv_yuv422";
+	return strip_inverse() ? (block_lists_inverse() ? "k_inv_yuv422_strip_blocks" : "k_inv_yuv422_strip") : "k_inv_yuv422";
 }
 
 int DecodeBatch::launch_inverse(uint32_t dither_seed)
 {
+	// (the level-1 bands of the last entropy pass are block lists: only the kernel that gathers them may run behind it)
+	if (ent_ready_ && ent_.level1_as_block_lists() && !block_lists_inverse()) { g_err = "the level-1 bands are block lists but the inverse would read them as dense rows"; return -1; }
 	(void)hipSetDevice(device_);
 	const bool jobs_uploaded_now = jobs_dirty_;          // (the upload is queued on `st`: a second stream must not read the tables before it)
 	int rc = sync_jobs();
@@ -1082,7 +1108,8 @@ int DecodeBatch::launch_inverse(uint32_t dither_seed)
 	} else if (strip_inverse()) {
 		const BandDesc &b = plan_.ch[0].band[0][0];
 		const int nseg = (b.width / dev::SBLK + dev::SSEG - 1) / dev::SSEG;
-		dev::k_inv_yuv422_strip<<<dim3(nseg, (b.height + dev::SR - 1) / dev::SR, act), dev::NTHREADS, 0, st>>>(j.yuv, dither_seed);
+		if (ent_ready_ && ent_.level1_as_block_lists()) dev::k_inv_yuv422_strip_blocks<<<dim3(nseg, (b.height + dev::SR - 1) / dev::SR, act), dev::NTHREADS, 0, st>>>(j.yuv, dither_seed);
+		else dev::k_inv_yuv422_strip<<<dim3(nseg, (b.height + dev::SR - 1) / dev::SR, act), dev::NTHREADS, 0, st>>>(j.yuv, dither_seed);
 	} else {
 		const BandDesc &b = plan_.ch[0].band[0][0];
 		dim3 grid((b.width + dev::ITW - 1) / dev::ITW, (b.height + dev::ITH - 1) / dev::ITH, act);

@@ -102,6 +102,12 @@ public:
 	// Set by launch() when it decoded the bands of levels 2 and 3 (and the lowpass bands) first and recorded this event behind them: the inverse transforms of
 	// those levels may start there, beside the tile pass over the level-1 bands that is still queued on the decoder's stream.  Null otherwise.
 	void *levels23_event() const { return l23_split_ ? ev_l23_ : nullptr; }
+	// Block lists of the level-1 bands (cfhd_core.h dec_block_list_layout): with set_block_lists(true) the next launch() of the chunk-indexed decoder leaves the level-1
+	// highpass bands of a progressive 4:2:2 sample compacted in their own places in the pyramid + one occupancy mask per chunk of 64 blocks, for the inverse level-1 strip
+	// kernel that gathers them; level1_as_block_lists(): what the last launch() did (the inverse has to match it)
+	void set_block_lists(bool on) { use_blocks_ = on && d_masks_; }
+	bool level1_as_block_lists() const { return blocks_written_; }
+	const unsigned long long *block_masks(int frame) const { return d_masks_ ? d_masks_ + (size_t)frame * masks_per_frame_ : nullptr; }
 	int stats(uint32_t out[16]);         // CFHD_AMD_DX_STATS=1: convergence counters of the chunk index (see the .hip)
 private:
 	struct Host; Host *host_;
@@ -128,6 +134,7 @@ private:
 	void *ev_l23_ = nullptr, *ev_low_ = nullptr; bool l23_split_ = false;      // ev_low_: in front of k_dec_lowpass when it runs between the two tile passes      // recorded behind the tiles of the level-2 / level-3 bands and the lowpass bands when the tile pass is split
 	void *ev_[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; bool timed_ = false;    // [4]: end of k_dec_parse when the band decoder waits for a second event behind it; [5], [6]: behind k_dec_index / k_dec_chain
 	bool parse_end_ = false;
+	unsigned long long *d_masks_ = nullptr; size_t masks_per_frame_ = 0; bool use_blocks_ = false, blocks_written_ = false;
 };
 
 // Group samples (cfhd_gop.h): parsed on the host (parse_group_sample), every coded band of the 17 subbands per channel decoded by one workgroup of

@@ -93,7 +93,8 @@ int GpuEntropyEncoder::prepare_units(int nframes, int16_t *d_coeffs, size_t stri
 		int mask_base[kMaxChannels][kNumBands];
 		masks_per_frame_ = (size_t)block_list_layout(plan, mask_base);
 		HIPCHK(hipMalloc(&d_blocks_, stride * 2 * (size_t)n_));
-		HIPCHK(hipMalloc((void **)&d_masks_, masks_per_frame_ * 8 * (size_t)n_));
+		HIPCHK(hipMalloc((void **)&d_masks_, masks_per_frame_ * 8 * (size_t)n_ + 64));      // (+ spare entries: the inverse kernel fetches the masks of two chunks at a time)
+		HIPCHK(hipMemset(d_masks_, 0, masks_per_frame_ * 8 * (size_t)n_ + 64));
 	}
 	HIPCHK(hipMalloc((void **)&d_samples_, cap_ * n_));
 	HIPCHK(hipHostMalloc((void **)&h_samples_, cap_ * n_, hipHostMallocPortable));
@@ -241,7 +242,8 @@ GpuEntropyDecoder::~GpuEntropyDecoder() { release(); delete host_; }
 void GpuEntropyDecoder::release()
 {
 	(void)hipSetDevice(device_);
-	void *dev[] = { d_samples_, d_tables_, d_bandjobs_, d_lowjobs_, d_errors_, d_plan_, d_idx_tables_, d_entries_, d_recs_, d_chunk_base_, d_chunk_job_, d_sums_, d_counters_, d_tile_start_, d_stats_, d_repair_, d_alts_, d_reindex_, d_diffjobs_, d_alt_entries_ };
+	void *dev[] = { d_samples_, d_tables_, d_bandjobs_, d_lowjobs_, d_errors_, d_plan_, d_idx_tables_, d_entries_, d_recs_, d_chunk_base_, d_chunk_job_, d_sums_, d_counters_, d_tile_start_, d_stats_, d_repair_, d_alts_, d_reindex_, d_diffjobs_, d_alt_entries_, d_masks_ };
+	d_masks_ = nullptr; masks_per_frame_ = 0; use_blocks_ = false; blocks_written_ = false;
 	for (void *p : dev) if (p) (void)hipFree(p);
 	d_idx_tables_ = d_entries_ = d_recs_ = d_chunk_base_ = d_chunk_job_ = d_sums_ = d_counters_ = d_tile_start_ = d_stats_ = d_repair_ = d_alts_ = d_reindex_ = d_diffjobs_ = d_alt_entries_ = nullptr;
 	if (h_chunk_job_) (void)hipHostFree(h_chunk_job_);
@@ -325,6 +327,12 @@ int GpuEntropyDecoder::prepare(const FramePlan &plan, int nframes, int16_t *d_co
 		HIPCHK(hipMalloc(&d_plan_, sizeof(dp)));
 		HIPCHK(hipMemcpy(d_plan_, &dp, sizeof(dp), hipMemcpyHostToDevice));
 	}
+	// chunk masks of the level-1 bands as block lists (cfhd_core.h dec_block_list_layout): for 4:2:2 frames, whose last level has a strip kernel that gathers them
+	if (dx_ && plan.encoded_format == ENC_YUV422 && plan.num_channels == 3) {
+		int mask_base[kMaxChannels][kNumBands];
+		masks_per_frame_ = (size_t)dec_block_list_layout(plan, mask_base);
+		HIPCHK(hipMalloc((void **)&d_masks_, masks_per_frame_ * 8 * (size_t)n_));
+	}
 	host_->bands.assign(n_, {}); host_->lows.assign(n_, {}); host_->diffs.assign(n_, {}); host_->host_bytes.assign(n_, 0);
 	for (void *&e : ev_) HIPCHK(hipEventCreate((hipEvent_t *)&e));
 	HIPCHK(hipEventCreate((hipEvent_t *)&ev_l23_));
@@ -377,7 +385,7 @@ int GpuEntropyDecoder::launch()
 {
 	(void)hipSetDevice(device_);
 	hipStream_t st = (hipStream_t)stream_;
-	l23_split_ = false;
+	l23_split_ = false; blocks_written_ = false;
 	if (ext_samples_) {
 		// device-resident samples: parse on the GPU; the job tables have one row per band type (largest first), nframes wide
 		const int nch = plan_.num_channels, nb = n_ * nch * 9;
@@ -484,7 +492,10 @@ int GpuEntropyDecoder::launch_dx(bool device_jobs, int njobs, uint32_t host_chun
 	const dev::DecIdxTables *T = (const dev::DecIdxTables *)d_idx_tables_;
 	dev::DecPlan dp; dec_build_plan(plan_, out_kind_, &dp);
 	const int frames = device_jobs ? n_ : active_frames();
-	const dev::DxTilePlan tp = dx_tile_plan(plan_, dp, frames, skip_level1_);
+	const bool lists = use_blocks_ && d_masks_ && !skip_level1_ && !interlaced_;
+	const dev::DxTilePlan tp = dx_tile_plan(plan_, dp, frames, skip_level1_, lists);
+	unsigned long long *const tmasks = lists ? d_masks_ : nullptr;
+	blocks_written_ = lists;
 	const char *spec_env = getenv("CFHD_AMD_DX_SPECULATE");
 	const bool speculate = !(spec_env && atoi(spec_env) == 0);            // 0: every chunk goes through the repair path (tests)
 	if (device_jobs) HIPCHK(hipMemsetAsync((uint32_t *)d_counters_ + 1, 0, 16, st));     // the repair and re-index lists, the alternate-entry slots and the chunk counter start at zero (the host path uploads zeroed counters)
@@ -524,13 +535,13 @@ int GpuEntropyDecoder::launch_dx(bool device_jobs, int njobs, uint32_t host_chun
 		int ga = g3, gb = g3;
 		if ((uint32_t)ga * dev::DX_TILE_WAVES > ta.total) ga = (int)((ta.total + dev::DX_TILE_WAVES - 1) / dev::DX_TILE_WAVES);
 		if ((uint32_t)gb * dev::DX_TILE_WAVES > tb.total - tb.first) gb = (int)((tb.total - tb.first + dev::DX_TILE_WAVES - 1) / dev::DX_TILE_WAVES);
-		dev::k_dec_tiles<<<ga < 1 ? 1 : ga, dev::DX_TILE_THREADS, 0, st>>>(jobs, ta, T, (const uint32_t *)d_entries_, (const uint32_t *)d_chunk_base_, (const dev::DxBandSum *)d_sums_, (const uint32_t *)d_tile_start_);
+		dev::k_dec_tiles<<<ga < 1 ? 1 : ga, dev::DX_TILE_THREADS, 0, st>>>(jobs, ta, T, (const uint32_t *)d_entries_, (const uint32_t *)d_chunk_base_, (const dev::DxBandSum *)d_sums_, (const uint32_t *)d_tile_start_, tmasks, (uint32_t)masks_per_frame_);
 		HIPCHK(hipEventRecord((hipEvent_t)ev_low_, st));
 		dev::k_dec_lowpass<<<dim3(8, (unsigned)lowpass_jobs), 256, 0, st>>>((const dev::DecLowpassJob *)d_lowjobs_);
 		HIPCHK(hipEventRecord((hipEvent_t)ev_l23_, st));
-		dev::k_dec_tiles<<<gb < 1 ? 1 : gb, dev::DX_TILE_THREADS, 0, st>>>(jobs, tb, T, (const uint32_t *)d_entries_, (const uint32_t *)d_chunk_base_, (const dev::DxBandSum *)d_sums_, (const uint32_t *)d_tile_start_);
+		dev::k_dec_tiles<<<gb < 1 ? 1 : gb, dev::DX_TILE_THREADS, 0, st>>>(jobs, tb, T, (const uint32_t *)d_entries_, (const uint32_t *)d_chunk_base_, (const dev::DxBandSum *)d_sums_, (const uint32_t *)d_tile_start_, tmasks, (uint32_t)masks_per_frame_);
 	} else
-	dev::k_dec_tiles<<<g3, dev::DX_TILE_THREADS, 0, st>>>(jobs, tp, T, (const uint32_t *)d_entries_, (const uint32_t *)d_chunk_base_, (const dev::DxBandSum *)d_sums_, (const uint32_t *)d_tile_start_);
+	dev::k_dec_tiles<<<g3, dev::DX_TILE_THREADS, 0, st>>>(jobs, tp, T, (const uint32_t *)d_entries_, (const uint32_t *)d_chunk_base_, (const dev::DxBandSum *)d_sums_, (const uint32_t *)d_tile_start_, tmasks, (uint32_t)masks_per_frame_);
 	if (interlaced_) dev::k_dec_undiff<<<dim3((unsigned)(frames * plan_.num_channels), dev::DXU_SPLIT), dev::DXU_THREADS, 0, st>>>((const dev::DecDiffJob *)d_diffjobs_, d_errors_);
 	HIPCHK(hipGetLastError());
 	return 0;

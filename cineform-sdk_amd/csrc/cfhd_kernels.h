@@ -195,6 +195,9 @@ struct InvYuvJob {
 	// (Codec/spatial.c:29577 InvertHorizontalStripYUV16sToPackedRGB32, restated in oracle/cfhd_oracle_inv.c orc_inv_spatial_to_rgb32_of_yuv422): no dither,
 	// matrix 601 or 709 (computer-systems range), bytes B, G, R, 255
 	int bottom_up, matrix_601;
+	// k_inv_yuv422_strip_blocks: the level-1 highpass bands arrive as block lists from the entropy decoder's tile pass (cfhd_core.h dec_block_list_layout): of every chunk
+	// of 64 blocks of a band's flat raster the nonzero blocks, compacted at the chunk's first places in the band, and masks[mask_base[c][b] + chunk] says which they are
+	const unsigned long long *masks; int mask_base[3][4];
 };
 
 struct HalfYuvJob {                         // k_half_yuv422: the level-1 lowpass planes as a half-resolution packed 8-bit 4:2:2 frame
@@ -1185,7 +1188,19 @@ __device__ __forceinline__ void strip_row_to8(const uint32_t (&L)[4], const uint
 	}
 }
 
-template <int ROWS_PER_STRIP, bool LATE_LOADS = false>
+// Block `fb` (flat raster, in blocks of 8 coefficients) of a band that is stored as block lists: zero unless its chunk's mask lists it, else the chunk's
+// (rank of the block among the listed ones)-th stored block.  (Measured: fetching the two chunk masks of a wave's row ahead of the arithmetic, through the scalar path,
+// cost 14 registers and a wave per SIMD: 1.45 -> 1.63 ms.  The dependent pair of loads stays.)
+__device__ __forceinline__ StripRow strip_load_listed(const int16_t *band, const unsigned long long *bmasks, uint32_t fb)
+{
+	const unsigned long long m = bmasks[fb >> 6];
+	const uint32_t bit = fb & 63u;
+	StripRow r; r.d[0] = r.d[1] = r.d[2] = r.d[3] = 0u;
+	if ((m >> bit) & 1ull) r = strip_load(band + ((size_t)(fb & ~63u) + (size_t)__popcll(m & ((1ull << bit) - 1ull))) * SBLK);
+	return r;
+}
+
+template <int ROWS_PER_STRIP, bool LATE_LOADS = false, bool BLOCKS = false>
 __device__ __forceinline__ void inv_yuv422_strip(const InvYuvJob *jobs, uint32_t launch_seed)
 {
 	const TileId tile = xcd_tile();
@@ -1226,9 +1241,17 @@ __device__ __forceinline__ void inv_yuv422_strip(const InvYuvJob *jobs, uint32_t
 	if (r0 >= h) return;                                  // whole workgroup
 	const int nrows = h - r0 < ROWS_PER_STRIP ? h - r0 : ROWS_PER_STRIP;
 	int j = inv_window_first_row(r0, h);
+	// the highpass bands: dense rows, or (BLOCKS) block lists -- row `row`'s block of this lane is block row * pitch / 8 + blk of the band's flat raster
+	const unsigned long long *const mLH = BLOCKS ? wave_uniform_ptr(job.masks + job.mask_base[comp][1]) : nullptr;
+	const unsigned long long *const mHL = BLOCKS ? wave_uniform_ptr(job.masks + job.mask_base[comp][2]) : nullptr;
+	const unsigned long long *const mHH = BLOCKS ? wave_uniform_ptr(job.masks + job.mask_base[comp][3]) : nullptr;
+	const uint32_t pitch8 = (uint32_t)pitch / SBLK;
+#define LOAD_LH(row) (BLOCKS ? strip_load_listed(bLH, mLH, (uint32_t)(row) * pitch8 + (uint32_t)blk) : strip_load(pLH + (size_t)(row) * pitch))
+#define LOAD_HL(row) (BLOCKS ? strip_load_listed(bHL, mHL, (uint32_t)(row) * pitch8 + (uint32_t)blk) : strip_load(pHL + (size_t)(row) * pitch))
+#define LOAD_HH(row) (BLOCKS ? strip_load_listed(bHH, mHH, (uint32_t)(row) * pitch8 + (uint32_t)blk) : strip_load(pHH + (size_t)(row) * pitch))
 	StripRow ll0 = strip_load(pLL + (size_t)j * pitch), ll1 = strip_load(pLL + (size_t)(j + 1) * pitch), ll2 = strip_load(pLL + (size_t)(j + 2) * pitch);
-	StripRow lh0 = strip_load(pLH + (size_t)j * pitch), lh1 = strip_load(pLH + (size_t)(j + 1) * pitch), lh2 = strip_load(pLH + (size_t)(j + 2) * pitch);
-	StripRow hl = strip_load(pHL + (size_t)r0 * pitch), hh = strip_load(pHH + (size_t)r0 * pitch);
+	StripRow lh0 = LOAD_LH(j), lh1 = LOAD_LH(j + 1), lh2 = LOAD_LH(j + 2);
+	StripRow hl = LOAD_HL(r0), hh = LOAD_HH(r0);
 	const int sh = job.shift;
 	for (int s = 0; s < nrows; s++) {
 		const int r = r0 + s;
@@ -1238,8 +1261,8 @@ __device__ __forceinline__ void inv_yuv422_strip(const InvYuvJob *jobs, uint32_t
 		const bool advance = jn != j;
 		StripRow nll = ll2, nlh = lh2, nhl = hl, nhh = hh;
 		if (!LATE_LOADS) {
-			if (advance) { nll = strip_load(pLL + (size_t)(jn + 2) * pitch); nlh = strip_load(pLH + (size_t)(jn + 2) * pitch); }
-			if (more) { nhl = strip_load(pHL + (size_t)(r + 1) * pitch); nhh = strip_load(pHH + (size_t)(r + 1) * pitch); }
+			if (advance) { nll = strip_load(pLL + (size_t)(jn + 2) * pitch); nlh = LOAD_LH(jn + 2); }
+			if (more) { nhl = LOAD_HL(r + 1); nhh = LOAD_HH(r + 1); }
 		}
 		// vertical synthesis: rows 2r (even) and 2r + 1 (odd) of the horizontal-low and horizontal-high halves
 		const int pos = r == 0 ? 0 : (r == h - 1 ? 2 : 1);
@@ -1305,8 +1328,8 @@ __device__ __forceinline__ void inv_yuv422_strip(const InvYuvJob *jobs, uint32_t
 			}
 		}
 		if (LATE_LOADS) {
-			if (advance) { nll = strip_load(pLL + (size_t)(jn + 2) * pitch); nlh = strip_load(pLH + (size_t)(jn + 2) * pitch); }
-			if (more) { nhl = strip_load(pHL + (size_t)(r + 1) * pitch); nhh = strip_load(pHH + (size_t)(r + 1) * pitch); }
+			if (advance) { nll = strip_load(pLL + (size_t)(jn + 2) * pitch); nlh = LOAD_LH(jn + 2); }
+			if (more) { nhl = LOAD_HL(r + 1); nhh = LOAD_HH(r + 1); }
 		}
 		if (advance) { ll0 = ll1; ll1 = ll2; ll2 = nll; lh0 = lh1; lh1 = lh2; lh2 = nlh; j = jn; }
 		hl = nhl; hh = nhh;
@@ -1315,8 +1338,12 @@ __device__ __forceinline__ void inv_yuv422_strip(const InvYuvJob *jobs, uint32_t
 #undef pLH
 #undef pHL
 #undef pHH
+#undef LOAD_LH
+#undef LOAD_HL
+#undef LOAD_HH
 }
 __global__ void __launch_bounds__(NTHREADS) k_inv_yuv422_strip(const InvYuvJob *jobs, uint32_t launch_seed) { inv_yuv422_strip<SR, true>(jobs, launch_seed); }
+__global__ void __launch_bounds__(NTHREADS) k_inv_yuv422_strip_blocks(const InvYuvJob *jobs, uint32_t launch_seed) { inv_yuv422_strip<SR, true, true>(jobs, launch_seed); }
 
 // =============================================================================================
 // k_fwd_yuv422_strip: level 1 of the packed 4:2:2 formats with the organisation of k_inv_yuv422_strip (registers and lane exchange instead

@@ -1571,7 +1571,7 @@ def _batched_yuy2_round_trip_equals_reference(w, h, n, nuniq, expect=None):
         assert L.cfhd_amd_batch_kernel_name(b, slot).decode() == name, "slot %d runs %s" % (slot, L.cfhd_amd_batch_kernel_name(b, slot).decode())
     assert L.cfhd_amd_batch_roundtrip(b) > 0, amd_last_error()
     plan = Plan(w, h)
-    interval = {}
+    interval = {}; pictures = []
     for i in range(n):
         p = ctypes.c_void_p(); sz = ctypes.c_size_t()
         assert L.cfhd_amd_batch_get_sample(b, i, ctypes.byref(p), ctypes.byref(sz)) == 0
@@ -1590,7 +1590,9 @@ def _batched_yuy2_round_trip_equals_reference(w, h, n, nuniq, expect=None):
         img = out.reshape(h, w * 2)
         ok = (img == lo) | (img == hi)
         assert ok.all(), "frame %d: %d bytes outside the dither interval" % (i, (~ok).sum())
+        pictures.append(img.copy())
     L.cfhd_amd_batch_destroy(b)
+    return pictures
 
 
 def test_frame_queue_of_batches_equals_synchronous_passes():
@@ -1639,7 +1641,7 @@ def test_frame_queue_of_batches_equals_synchronous_passes():
 def test_batched_round_trip_at_bench_sizes_equals_reference(w, h, n, nuniq):
     """The batch sizes at which the library picks the kernels bench.py times by itself (>= 32 1080p-equivalents per launch: register strips
     at level 1; the plane levels switch at 160)."""
-    _batched_yuy2_round_trip_equals_reference(w, h, n, nuniq, expect={0: "k_fwd_yuv422_strip_blocks", 3: "k_inv_yuv422_strip"})
+    _batched_yuy2_round_trip_equals_reference(w, h, n, nuniq, expect={0: "k_fwd_yuv422_strip_blocks", 3: "k_inv_yuv422_strip_blocks"})
 
 
 @pytest.mark.parametrize("w,h,n", [(1920, 1080, 3), (3840, 2160, 2), (2048, 600, 3), (1952, 250, 2), (2304, 72, 2)])
@@ -1652,9 +1654,16 @@ def test_yuv422_strip_kernels_equal_reference(w, h, n):
     old = {k: os.environ.get(k) for k in keys}
     for k in keys: os.environ[k] = "strip"
     try:
-        expect = {0: "k_fwd_yuv422_strip_blocks", 3: "k_inv_yuv422_strip"}      # (level-1 bands as block lists for k_ent_count_blocks; CFHD_AMD_BLOCKS=0: dense bands + k_ent_count)
+        expect = {0: "k_fwd_yuv422_strip_blocks", 3: "k_inv_yuv422_strip_blocks"}      # (level-1 bands as block lists for k_ent_count_blocks; CFHD_AMD_BLOCKS=0: dense bands + k_ent_count)
         if w in (1920, 2048, 3840, 2304): expect.update({1: "k_fwd_plane_strip", 2: "k_fwd_plane_strip", 4: "k_inv_plane_strip", 5: "k_inv_plane_strip"})
-        _batched_yuy2_round_trip_equals_reference(w, h, n, n, expect=expect)
+        lists = _batched_yuy2_round_trip_equals_reference(w, h, n, n, expect=expect)
+        # the same pass with dense level-1 bands on both sides (round 3's kernels): the same pictures byte for byte -- same coefficients, same dither bits
+        os.environ["CFHD_AMD_DEC_BLOCKS"] = "0"
+        try:
+            dense = _batched_yuy2_round_trip_equals_reference(w, h, n, n, expect={**expect, 3: "k_inv_yuv422_strip"})
+        finally:
+            del os.environ["CFHD_AMD_DEC_BLOCKS"]
+        assert all(np.array_equal(a, b) for a, b in zip(lists, dense))
     finally:
         for k, v in old.items():
             if v is None: os.environ.pop(k, None)
