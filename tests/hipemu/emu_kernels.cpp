@@ -672,7 +672,40 @@ extern "C" int emu_entropy_decode_dx(const uint8_t *sample, size_t size, int pix
 	g_dx_stats[12] = counters[1]; g_dx_stats[13] = counters[2];
 	std::vector<uint32_t> tile_start(tp.total + 1, 0xdeadbeefu);
 	hipemu::launch(dim3((tp.total + dev::DX_THREADS - 1) / dev::DX_THREADS), dim3(dev::DX_THREADS), [&] { dev::k_dec_tile_index(jobs.data(), tp, entries.data(), chunk_base.data(), sums.data(), tile_start.data()); });
-	hipemu::launch(dim3((unsigned)grid), dim3(dev::DX_TILE_THREADS), [&] { dev::k_dec_tiles(jobs.data(), tp, &tables, entries.data(), chunk_base.data(), sums.data(), tile_start.data()); });
+	hipemu::launch(dim3((unsigned)grid), dim3(dev::DX_TILE_THREADS), [&] { dev::k_dec_tiles(jobs.data(), tp, &tables, entries.data(), chunk_base.data(), sums.data(), tile_start.data(), (unsigned long long *)nullptr, 0u); });
+	if (!plan.interlaced && plan.encoded_format == ENC_YUV422) {
+		// the same tile pass with the level-1 highpass bands as block lists (what k_inv_yuv422_strip_blocks gathers): expanded again they must be the dense bands
+		const std::vector<int16_t> dense(pyr);
+		int mask_base[kMaxChannels][kNumBands];
+		const size_t per_frame = (size_t)dec_block_list_layout(plan, mask_base);
+		std::vector<unsigned long long> masks(per_frame * (size_t)nframes + 8, 0x5555555555555555ull);
+		const dev::DxTilePlan tl = dx_tile_plan(plan, dp, nframes, false, true);
+		for (int16_t &v : pyr) v = 0x0bad;             // (stale places must never be read back)
+		hipemu::launch(dim3((unsigned)grid), dim3(dev::DX_TILE_THREADS), [&] { dev::k_dec_tiles(jobs.data(), tl, &tables, entries.data(), chunk_base.data(), sums.data(), tile_start.data(), masks.data(), (uint32_t)per_frame); });
+		for (int f = 0; f < nframes; f++)
+			for (int c = 0; c < plan.num_channels; c++)
+				for (int b = 1; b < 4; b++) {
+					const BandDesc &bd = plan.ch[c].band[0][b];
+					const int n = bd.height * bd.pitch;
+					const int16_t *lists = pyr.data() + (size_t)f * plan.coeff_elems + bd.offset, *want = dense.data() + (size_t)f * plan.coeff_elems + bd.offset;
+					for (int blk = 0; blk < n / 8; blk++) {
+						const unsigned long long m = masks[(size_t)f * per_frame + (size_t)mask_base[c][b] + (size_t)(blk >> 6)];
+						const int bit = blk & 63;
+						int16_t got[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+						if ((m >> bit) & 1ull) memcpy(got, lists + ((size_t)(blk & ~63) + (size_t)__builtin_popcountll(m & ((1ull << bit) - 1ull))) * 8, 16);
+						if (memcmp(got, want + (size_t)blk * 8, 16)) return -50;
+					}
+				}
+		// the bands that stay dense (levels 2 and 3) must be what they were
+		for (int f = 0; f < nframes; f++)
+			for (int c = 0; c < plan.num_channels; c++)
+				for (int lv = 1; lv < kNumLevels; lv++)
+					for (int b = 1; b < 4; b++) {
+						const BandDesc &bd = plan.ch[c].band[lv][b];
+						if (memcmp(pyr.data() + (size_t)f * plan.coeff_elems + bd.offset, dense.data() + (size_t)f * plan.coeff_elems + bd.offset, (size_t)bd.height * bd.pitch * 2)) return -51;
+					}
+		pyr = dense;
+	}
 	hipemu::launch(dim3((unsigned)diffs.size(), 5), dim3(dev::DXU_THREADS), [&] { dev::k_dec_undiff(diffs.data(), &errors); });
 	hipemu::launch(dim3(4, (unsigned)lows.size()), dim3(256), [&] { dev::k_dec_lowpass(lows.data()); });
 	if (errors) return -10 - errors;

@@ -153,3 +153,56 @@ def test_group_entropy_stage_on_the_gpu_and_on_the_host(stage):
     finally:
         if old is None: del os.environ["CFHD_AMD_ENTROPY"]
         else: os.environ["CFHD_AMD_ENTROPY"] = old
+
+
+@pytest.mark.parametrize("stage", ["default", "host"])
+def test_group_decoder_survives_fuzzed_samples(stage):
+    """Damaged group samples through CFHD_DecodeSample (GPU entropy stage: GpuGroupEntropyDecoder's job table + k_dec_bands_par_ll; and the host coder): bursts of garbage,
+    bit flips, oversized size fields, truncation.  Every call returns (OKAY with some picture, BADSAMPLE / BADFORMAT with a zero-filled one), nothing is written behind the
+    output buffer, and the handle decodes the intact group correctly afterwards."""
+    import os
+    assert have_ref(), "oracle/_ref/libcfhd_ref.so is missing"
+    w, h = 320, 240
+    frames = _frames(w, h, 2, PIX_YUY2)
+    samples = ref_encode_frames(frames, w * 2, w, h, pixfmt=PIX_YUY2, flags=ENCODING_FLAGS_2FRAME_GOP)
+    group = np.frombuffer(samples[1], np.uint8).copy()
+    old = os.environ.get("CFHD_AMD_ENTROPY")
+    if stage == "host": os.environ["CFHD_AMD_ENTROPY"] = "host"
+    try:
+        L = product()
+        dec = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
+        aw = ctypes.c_int(); ah = ctypes.c_int(); af = ctypes.c_uint32()
+        sb = ctypes.create_string_buffer(samples[0], len(samples[0]))
+        assert L.CFHD_PrepareToDecode(dec, 0, 0, PIX_YUY2, 1, 0, sb, len(samples[0]), ctypes.byref(aw), ctypes.byref(ah), ctypes.byref(af)) == 0
+        H = ah.value
+        out = np.zeros(H * w * 2 + 4096, np.uint8)
+        rng = np.random.default_rng(77)
+        codes = {}
+        for trial in range(24):
+            t = group.copy()
+            kind = trial % 4
+            if kind == 0:
+                lo = int(rng.integers(700, len(t) - 128)); n = int(rng.integers(1, 128)); t[lo: lo + n] = rng.integers(0, 256, n, dtype=np.uint8)
+            elif kind == 1:
+                for _ in range(int(rng.integers(1, 6))):
+                    i = int(rng.integers(700, len(t))); t[i] ^= np.uint8(1 << int(rng.integers(0, 8)))
+            elif kind == 2:
+                i = int(rng.integers(180, len(t) // 4)) * 4; t[i: i + 4] = [0x20 | int(rng.integers(0, 32)), int(rng.integers(0, 256)), 0xff, 0xff]
+            size = len(t) if kind != 3 else int(rng.integers(1024, len(t))) & ~3
+            out[:] = 7
+            tb = ctypes.create_string_buffer(t.tobytes(), len(t))
+            rc = L.CFHD_DecodeSample(dec, tb, size, out.ctypes.data_as(ctypes.c_void_p), w * 2)
+            codes[rc] = codes.get(rc, 0) + 1
+            assert rc in (0, 3, 5), (trial, rc, amd_last_error())
+            assert np.all(out[H * w * 2:] == 7), "trial %d wrote behind the output buffer" % trial
+            if rc: assert not out[: h * w * 2].any()
+        assert sum(v for k, v in codes.items() if k) >= 3, codes
+        # the intact group afterwards: both frames at intra-like quality
+        tb = ctypes.create_string_buffer(samples[1], len(samples[1])); out[:] = 0
+        assert L.CFHD_DecodeSample(dec, tb, len(samples[1]), out.ctypes.data_as(ctypes.c_void_p), w * 2) == 0
+        assert psnr_yuy2(out[: h * w * 2].reshape(h, w * 2), frames[0].reshape(h, w * 2)) > 38.0
+        L.CFHD_CloseDecoder(dec)
+    finally:
+        if stage == "host":
+            if old is None: del os.environ["CFHD_AMD_ENTROPY"]
+            else: os.environ["CFHD_AMD_ENTROPY"] = old
