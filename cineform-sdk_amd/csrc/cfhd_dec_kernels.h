@@ -1036,11 +1036,12 @@ __global__ void __launch_bounds__(DX_TILE_THREADS) k_dec_tiles(const DxBandJob *
 // (decoder.c:20822).  One workgroup per band walks down the rows: every thread holds a run of consecutive columns, block-wide prefix sums give
 // the number of peaks in front of it and the sum of the columns in front of it.
 enum { DXU_THREADS = 256, DXU_MAX = 16 /* columns per thread: rows of up to 4096 coefficients */, DXU_SPLIT = 32 /* workgroups per band (grid y) */ };
-__global__ void __launch_bounds__(DXU_THREADS) k_dec_undiff(const DecDiffJob *jobs, int *errors)
+__global__ void __launch_bounds__(DXU_THREADS) k_dec_undiff(const DecDiffJob *jobs, int *errors, int only_peak_bands)
 {
 	__shared__ uint32_t s_w[2][DXU_THREADS / 64];
 	const DecDiffJob job = jobs[blockIdx.x];
 	if (!job.band || job.width <= 0) return;
+	if (only_peak_bands && !job.level) return;            // (the bands without a peak table were served by k_dec_undiff_rows)
 	const int t = threadIdx.x, lane = wave_lane(), wave = t >> 6;
 	const int per = (job.width + DXU_THREADS - 1) / DXU_THREADS;
 	if (per > DXU_MAX) { if (t == 0) atomic_or_u32((uint32_t *)errors, (uint32_t)DX_ERR_SPACE); return; }
@@ -1090,6 +1091,47 @@ __global__ void __launch_bounds__(DXU_THREADS) k_dec_undiff(const DecDiffJob *jo
 #pragma unroll
 		for (int i = 0; i < DXU_MAX; i++) if (i < per && c0 + i < c1) line[c0 + i] = (int16_t)((uint32_t)v[i] + before);
 		__syncthreads();                                  // s_w is written again by the next row
+	}
+}
+
+// The same for the bands without a peak table (all but a few torture frames), in the shape the data wants: one wave per band row, a lane holds 16 consecutive
+// columns (two 16-byte loads), running sums inside the lane, one wave scan for the lanes in front of it, rows of more than 1024 columns in pieces with a carry.
+// No LDS, no barrier, no 2-byte access (k_dec_undiff: 256 threads per row, two barriers per row, 0.85 ms per 512 1080i frames; this one: the bands once in, once out).
+// Columns behind the band's width (pitch padding) stay zero.  Bands with a peak table are left to k_dec_undiff(only_peak_bands = 1).
+enum { DXR_WAVES = 4 };
+__global__ void __launch_bounds__(64 * DXR_WAVES) k_dec_undiff_rows(const DecDiffJob *jobs)
+{
+	const DecDiffJob job = jobs[blockIdx.x];
+	if (!job.band || job.width <= 0 || job.level) return;
+	const int lane = wave_lane(), wave = wave_uniform((int)(threadIdx.x >> 6));
+	const int step = (int)gridDim.y * DXR_WAVES;
+	for (int y = (int)blockIdx.y * DXR_WAVES + wave; y < job.height; y += step) {
+		int16_t *line = job.band + (size_t)y * job.pitch;
+		uint32_t carry = 0;                                // wave-uniform: the sum of the columns in front of this piece
+		for (int c0 = 0; c0 < job.width; c0 += 1024) {
+			const int c = c0 + 16 * lane;
+			uint4 a = { 0u, 0u, 0u, 0u }, b = { 0u, 0u, 0u, 0u };
+			if (c < job.width) a = *(const uint4 *)(line + c);
+			if (c + 8 < job.width) b = *(const uint4 *)(line + c + 8);
+			const uint32_t w[8] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w };
+			uint32_t v[16], sum = 0;
+#pragma unroll
+			for (int i = 0; i < 16; i++) {
+				const uint32_t x = (i & 1) ? w[i >> 1] >> 16 : w[i >> 1] & 0xffffu;
+				sum += (c + i < job.width) ? x : 0u;           // (16-bit wrap: only the low halves are ever kept)
+				v[i] = sum;
+			}
+			const uint32_t incl = wave_incl_scan(sum), before = carry + incl - sum;
+			uint32_t o[8];
+#pragma unroll
+			for (int i = 0; i < 8; i++) {
+				const uint32_t lo = (c + 2 * i < job.width) ? (v[2 * i] + before) & 0xffffu : 0u, hi = (c + 2 * i + 1 < job.width) ? (v[2 * i + 1] + before) & 0xffffu : 0u;
+				o[i] = lo | (hi << 16);
+			}
+			if (c < job.width) { uint4 q; q.x = o[0]; q.y = o[1]; q.z = o[2]; q.w = o[3]; *(uint4 *)(line + c) = q; }
+			if (c + 8 < job.width) { uint4 q; q.x = o[4]; q.y = o[5]; q.z = o[6]; q.w = o[7]; *(uint4 *)(line + c + 8) = q; }
+			carry += wave_get(incl, 63);
+		}
 	}
 }
 

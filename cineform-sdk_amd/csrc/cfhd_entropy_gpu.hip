@@ -542,7 +542,13 @@ int GpuEntropyDecoder::launch_dx(bool device_jobs, int njobs, uint32_t host_chun
 		dev::k_dec_tiles<<<gb < 1 ? 1 : gb, dev::DX_TILE_THREADS, 0, st>>>(jobs, tb, T, (const uint32_t *)d_entries_, (const uint32_t *)d_chunk_base_, (const dev::DxBandSum *)d_sums_, (const uint32_t *)d_tile_start_, tmasks, (uint32_t)masks_per_frame_);
 	} else
 	dev::k_dec_tiles<<<g3, dev::DX_TILE_THREADS, 0, st>>>(jobs, tp, T, (const uint32_t *)d_entries_, (const uint32_t *)d_chunk_base_, (const dev::DxBandSum *)d_sums_, (const uint32_t *)d_tile_start_, tmasks, (uint32_t)masks_per_frame_);
-	if (interlaced_) dev::k_dec_undiff<<<dim3((unsigned)(frames * plan_.num_channels), dev::DXU_SPLIT), dev::DXU_THREADS, 0, st>>>((const dev::DecDiffJob *)d_diffjobs_, d_errors_);
+	if (interlaced_) {
+		// the difference-coded band of every channel back to coefficients: a wave per row for the bands without a peak table (CFHD_AMD_UNDIFF=block: the one kernel of
+		// round 3 for all of them, A/B), the workgroup-per-band kernel for the few that have one
+		static const bool rows = [] { const char *e = getenv("CFHD_AMD_UNDIFF"); return !(e && strcmp(e, "block") == 0); }();
+		if (rows) dev::k_dec_undiff_rows<<<dim3((unsigned)(frames * plan_.num_channels), 32), 64 * dev::DXR_WAVES, 0, st>>>((const dev::DecDiffJob *)d_diffjobs_);
+		dev::k_dec_undiff<<<dim3((unsigned)(frames * plan_.num_channels), dev::DXU_SPLIT), dev::DXU_THREADS, 0, st>>>((const dev::DecDiffJob *)d_diffjobs_, d_errors_, rows ? 1 : 0);
+	}
 	HIPCHK(hipGetLastError());
 	return 0;
 }

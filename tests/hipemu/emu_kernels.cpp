@@ -706,7 +706,9 @@ extern "C" int emu_entropy_decode_dx(const uint8_t *sample, size_t size, int pix
 					}
 		pyr = dense;
 	}
-	hipemu::launch(dim3((unsigned)diffs.size(), 5), dim3(dev::DXU_THREADS), [&] { dev::k_dec_undiff(diffs.data(), &errors); });
+	// (both shapes of the un-differencing: mode 1 = the workgroup-per-band kernel for every band, else a wave per row for the bands without a peak table)
+	if (mode != 1) hipemu::launch(dim3((unsigned)diffs.size(), 3), dim3(64 * dev::DXR_WAVES), [&] { dev::k_dec_undiff_rows(diffs.data()); });
+	hipemu::launch(dim3((unsigned)diffs.size(), 5), dim3(dev::DXU_THREADS), [&] { dev::k_dec_undiff(diffs.data(), &errors, mode != 1 ? 1 : 0); });
 	hipemu::launch(dim3(4, (unsigned)lows.size()), dim3(256), [&] { dev::k_dec_lowpass(lows.data()); });
 	if (errors) return -10 - errors;
 	memcpy(coeffs, pyr.data() + (size_t)(nframes - 1) * plan.coeff_elems, (size_t)plan.coeff_elems * 2);
