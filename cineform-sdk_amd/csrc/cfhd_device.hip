@@ -916,9 +916,9 @@ bool DecodeBatch::block_lists_inverse() const
 {
 	const int blocks_env = [] { const char *e = getenv("CFHD_AMD_DEC_BLOCKS"); return e ? atoi(e) : 1; }();      // (read at every launch: tests switch within one process)
 	if (!blocks_env || !ent_ready_ || !ent_.block_masks(0) || !ent_.chunk_indexed()) return false;
-	if (interlaced_ || half_ || dec_planes16(out_kind_) || rgb32_of_422_ || rgb16_of_422_ || rgb24_of_422_ || v210_ || byr4_) return false;
+	if (half_ || dec_planes16(out_kind_) || rgb32_of_422_ || rgb16_of_422_ || rgb24_of_422_ || v210_ || byr4_) return false;
 	if (!(out_kind_ == PIX_YUY2 || out_kind_ == PIX_2VUY) || plan_.encoded_format != ENC_YUV422) return false;
-	return strip_inverse();
+	return interlaced_ ? frame_inverse_strips() : strip_inverse();      // (interlaced: LH and HH as lists, the difference-coded HL dense)
 }
 
 int DecodeBatch::launch_entropy()
@@ -1023,7 +1023,7 @@ const char *DecodeBatch::level_kernel(int level) const
 	if (half_) return is_packed16(out_kind_) ? "k_half_packed16" : "k_half_yuv422";
 	if (dec_rgb10(out_kind_)) return "k_inv_rgb10";
 	if (dec_planes16(out_kind_)) return strip_inverse_packed16() ? "k_inv_packed16_strip" : "k_inv_packed16";
-	if (interlaced_) return frame_inverse_strips() ? "k_inv_frame_yuv422_strip" : (frame_inverse_quads() ? "k_inv_frame_yuv422_quad" : "k_inv_frame_yuv422");
+	if (interlaced_) return frame_inverse_strips() ? (block_lists_inverse() ? "k_inv_frame_yuv422_strip_blocks" : "k_inv_frame_yuv422_strip") : (frame_inverse_quads() ? "k_inv_frame_yuv422_quad" : "k_inv_frame_yuv422");
 	return strip_inverse() ? (block_lists_inverse() ? "k_inv_yuv422_strip_blocks" : "k_inv_yuv422_strip") : "k_inv_yuv422";
 }
 
@@ -1102,7 +1102,8 @@ int DecodeBatch::launch_inverse(uint32_t dither_seed)
 		const BandDesc &b = plan_.ch[0].band[0][0];
 		if (frame_inverse_strips()) {
 			const int nseg = (b.width / dev::SBLK + dev::SSEG - 1) / dev::SSEG;
-			dev::k_inv_frame_yuv422_strip<<<dim3(nseg, (b.height + dev::SRI - 1) / dev::SRI, act), dev::NTHREADS, 0, st>>>(j.yuv, dither_seed);
+			if (ent_ready_ && ent_.level1_as_block_lists()) dev::k_inv_frame_yuv422_strip_blocks<<<dim3(nseg, (b.height + dev::SRI - 1) / dev::SRI, act), dev::NTHREADS, 0, st>>>(j.yuv, dither_seed);
+			else dev::k_inv_frame_yuv422_strip<<<dim3(nseg, (b.height + dev::SRI - 1) / dev::SRI, act), dev::NTHREADS, 0, st>>>(j.yuv, dither_seed);
 		} else if (frame_inverse_quads()) dev::k_inv_frame_yuv422_quad<<<dim3((b.width / 4 + dev::NTHREADS - 1) / dev::NTHREADS, b.height, act), dev::NTHREADS, 0, st>>>(j.yuv, dither_seed);
 		else dev::k_inv_frame_yuv422<<<dim3((b.width / 2 + dev::NTHREADS - 1) / dev::NTHREADS, b.height, act), dev::NTHREADS, 0, st>>>(j.yuv, dither_seed);
 	} else if (strip_inverse()) {

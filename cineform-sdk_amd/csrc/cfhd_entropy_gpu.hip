@@ -492,8 +492,8 @@ int GpuEntropyDecoder::launch_dx(bool device_jobs, int njobs, uint32_t host_chun
 	const dev::DecIdxTables *T = (const dev::DecIdxTables *)d_idx_tables_;
 	dev::DecPlan dp; dec_build_plan(plan_, out_kind_, &dp);
 	const int frames = device_jobs ? n_ : active_frames();
-	const bool lists = use_blocks_ && d_masks_ && !skip_level1_ && !interlaced_;
-	const dev::DxTilePlan tp = dx_tile_plan(plan_, dp, frames, skip_level1_, lists);
+	const bool lists = use_blocks_ && d_masks_ && !skip_level1_;
+	const dev::DxTilePlan tp = dx_tile_plan(plan_, dp, frames, skip_level1_, lists, interlaced_);
 	unsigned long long *const tmasks = lists ? d_masks_ : nullptr;
 	blocks_written_ = lists;
 	const char *spec_env = getenv("CFHD_AMD_DX_SPECULATE");

@@ -410,7 +410,7 @@ inline bool dx_build_jobs(const ParsedSample &ps, const FramePlan &plan, const d
 }
 
 // Tiles of the job table: slot s has ceil(n / DX_TILE) tiles per band, for every frame.
-inline dev::DxTilePlan dx_tile_plan(const FramePlan &plan, const dev::DecPlan &dp, int nframes, bool skip_level1 = false, bool level1_block_lists = false)
+inline dev::DxTilePlan dx_tile_plan(const FramePlan &plan, const dev::DecPlan &dp, int nframes, bool skip_level1 = false, bool level1_block_lists = false, bool interlaced = false)
 {
 	int mask_base[kMaxChannels][kNumBands];
 	dec_block_list_layout(plan, mask_base);
@@ -428,7 +428,9 @@ inline dev::DxTilePlan dx_tile_plan(const FramePlan &plan, const dev::DecPlan &d
 					const uint32_t n = (uint32_t)(bd.height * bd.pitch);
 					const uint32_t per = (skip_level1 && lv == 0) ? 0u : (n + dev::DX_TILE - 1) / dev::DX_TILE;
 					tp.slot_of[pos] = (uint8_t)dp.slot[c][lv][b];
-					tp.mask_base[pos] = (level1_block_lists && lv == 0) ? mask_base[c][b] : -1;      // (the level-1 bands as block lists: k_dec_tiles -> k_inv_yuv422_strip_blocks)
+					// (the level-1 bands as block lists: k_dec_tiles -> k_inv_yuv422_strip_blocks / k_inv_frame_yuv422_strip_blocks; the difference-coded band of an interlaced
+					// frame stays dense: k_dec_undiff walks its rows)
+					tp.mask_base[pos] = (level1_block_lists && lv == 0 && !(interlaced && b == 2)) ? mask_base[c][b] : -1;
 					tp.cum[pos] = cum; cum += per * (uint32_t)nframes;
 					tp.per_band[pos] = per ? per : 1;      // positions without tiles must not be looked at by the kernel's division: one (unreachable) tile per band
 					pos++;

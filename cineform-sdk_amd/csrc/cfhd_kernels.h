@@ -2324,7 +2324,8 @@ __device__ __forceinline__ void strip_row_synth16(const uint32_t (&L)[4], const 
 	}
 }
 
-__global__ void __launch_bounds__(NTHREADS) k_inv_frame_yuv422_strip(const InvYuvJob *jobs, uint32_t launch_seed)
+template <bool BLOCKS>
+__device__ __forceinline__ void inv_frame_yuv422_strip(const InvYuvJob *jobs, uint32_t launch_seed)
 {
 	const TileId tile = xcd_tile();
 	__shared__ InvYuvJob s_job;
@@ -2357,8 +2358,12 @@ __global__ void __launch_bounds__(NTHREADS) k_inv_frame_yuv422_strip(const InvYu
 	const int sh = job.shift;
 	for (int s = 0; s < nrows; s++) {
 		const int r = r0 + s;
-		const StripRow ll = strip_load(bLL + boff + (size_t)r * pitch), lh = strip_load(bLH + boff + (size_t)r * pitch);
-		const StripRow hl = strip_load(bHL + boff + (size_t)r * pitch), hh = strip_load(bHH + boff + (size_t)r * pitch);
+		// (BLOCKS: LH and HH arrive as block lists from the entropy decoder's tile pass, as in k_inv_yuv422_strip_blocks; HL, the difference-coded band, is dense)
+		const uint32_t fb = (uint32_t)r * ((uint32_t)pitch / SBLK) + (uint32_t)blk;
+		const StripRow ll = strip_load(bLL + boff + (size_t)r * pitch);
+		const StripRow lh = BLOCKS ? strip_load_listed(bLH, job.masks + job.mask_base[comp][1], fb) : strip_load(bLH + boff + (size_t)r * pitch);
+		const StripRow hl = strip_load(bHL + boff + (size_t)r * pitch);
+		const StripRow hh = BLOCKS ? strip_load_listed(bHH, job.masks + job.mask_base[comp][3], fb) : strip_load(bHH + boff + (size_t)r * pitch);
 		uint32_t El[4], Ol[4], Eh[4], Oh[4];
 		strip_row_synth16(ll.d, lh.d, __shfl(ll.d[3], lane - 1), __shfl(ll.d[0], lane + 1), first, last, El, Ol);
 		strip_row_synth16(hl.d, hh.d, __shfl(hl.d[3], lane - 1), __shfl(hl.d[0], lane + 1), first, last, Eh, Oh);
@@ -2415,6 +2420,9 @@ __global__ void __launch_bounds__(NTHREADS) k_inv_frame_yuv422_strip(const InvYu
 		}
 	}
 }
+
+__global__ void __launch_bounds__(NTHREADS) k_inv_frame_yuv422_strip(const InvYuvJob *jobs, uint32_t launch_seed) { inv_frame_yuv422_strip<false>(jobs, launch_seed); }
+__global__ void __launch_bounds__(NTHREADS) k_inv_frame_yuv422_strip_blocks(const InvYuvJob *jobs, uint32_t launch_seed) { inv_frame_yuv422_strip<true>(jobs, launch_seed); }
 
 // =============================================================================================
 // k_fwd_frame_yuv422_strip: the interlaced level 1 in the register-strip organisation -- the workgroup shape and the unpacking of k_fwd_yuv422_strip (two luma

@@ -1448,15 +1448,19 @@ def test_interlaced_strip_kernels_equal_reference(w, h, n, fmt):
     for f in frames: f.reshape(h, w * 2)[1::2] = np.roll(f.reshape(h, w * 2)[1::2], 6, axis=1)      # the second field a little later: motion between the fields
     if fmt == PIX_2VUY: frames = [f.reshape(-1, 2)[:, ::-1].reshape(-1).copy() for f in frames]
     refs = ref_encode_frames(frames, w * 2, w, h, fmt, flags=1)
-    old = {k: os.environ.get(k) for k in ("CFHD_AMD_FORWARD", "CFHD_AMD_INVERSE")}
+    old = {k: os.environ.get(k) for k in ("CFHD_AMD_FORWARD", "CFHD_AMD_INVERSE", "CFHD_AMD_DEC_BLOCKS")}
     os.environ["CFHD_AMD_FORWARD"] = "strip"; os.environ["CFHD_AMD_INVERSE"] = "strip"
+    pictures = {}
     try:
+      # twice: the LH / HH bands as block lists between the entropy decoder's tile pass and the inverse (the default), and dense (CFHD_AMD_DEC_BLOCKS=0): same pictures
+      for lists in (1, 0):
+        os.environ["CFHD_AMD_DEC_BLOCKS"] = str(lists)
         b = L.cfhd_amd_batch_create_ex(w, h, fmt, ENCODED_YUV422, 1, QUALITY_FILMSCAN1, n, 4, 0)
         assert b, amd_last_error()
         for i, f in enumerate(frames):
             assert L.cfhd_amd_batch_upload(b, i, f.ctypes.data_as(ctypes.c_void_p), w * 2) == 0
         assert L.cfhd_amd_batch_kernel_name(b, 0) == b"k_fwd_frame_yuv422_strip"
-        assert L.cfhd_amd_batch_kernel_name(b, 3) == (b"k_inv_frame_yuv422_strip" if w % 32 == 0 and (w // 2) % 16 == 0 else b"k_inv_frame_yuv422_quad")
+        assert L.cfhd_amd_batch_kernel_name(b, 3) == (b"k_inv_frame_yuv422_strip_blocks" if lists else b"k_inv_frame_yuv422_strip")
         assert L.cfhd_amd_batch_roundtrip(b) > 0, amd_last_error()
         plan = Plan(w, h, pixkind=2 if fmt == PIX_2VUY else 1, progressive=0)
         for i in range(n):
@@ -1472,7 +1476,9 @@ def test_interlaced_strip_kernels_equal_reference(w, h, n, fmt):
             img = out.reshape(h, w * 2)
             ok = (img == lo) | (img == hi)
             assert ok.all(), "frame %d: %d bytes outside the dither interval" % (i, (~ok).sum())
+            pictures[(lists, i)] = img.copy()
         L.cfhd_amd_batch_destroy(b)
+      assert all(np.array_equal(pictures[(1, i)], pictures[(0, i)]) for i in range(n))
     finally:
         for k, v in old.items():
             if v is None: os.environ.pop(k, None)
