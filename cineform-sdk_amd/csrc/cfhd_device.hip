@@ -941,6 +941,7 @@ void DecodeBatch::clear_host_coeffs(int i) { memset(h_coeff_ + (size_t)i * plan_
 int DecodeBatch::upload_coeffs()
 {
 	(void)hipSetDevice(device_);
+	ent_.dense_pyramid_uploaded();                        // (whatever form the last GPU entropy pass left the level-1 bands in: they are dense rows now)
 	HIPCHK(hipMemcpy2DAsync(d_coeff_, (size_t)plan_.coeff_elems * 2, h_coeff_, (size_t)plan_.final_elems * 2,
 	                        (size_t)plan_.final_elems * 2, n_, hipMemcpyHostToDevice, (hipStream_t)stream_));
 	return 0;

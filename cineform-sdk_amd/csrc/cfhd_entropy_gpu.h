@@ -107,6 +107,7 @@ public:
 	// kernel that gathers them; level1_as_block_lists(): what the last launch() did (the inverse has to match it)
 	void set_block_lists(bool on) { use_blocks_ = on && d_masks_; }
 	bool level1_as_block_lists() const { return blocks_written_; }
+	void dense_pyramid_uploaded() { blocks_written_ = false; }          // the caller replaced the pyramid by dense coefficients from the host (host entropy decode)
 	const unsigned long long *block_masks(int frame) const { return d_masks_ ? d_masks_ + (size_t)frame * masks_per_frame_ : nullptr; }
 	int stats(uint32_t out[16]);         // CFHD_AMD_DX_STATS=1: convergence counters of the chunk index (see the .hip)
 private:
