@@ -456,6 +456,81 @@ int emu_inv_yuv422_strip(int16_t **bands /*[3][4]*/, const int *band_pitch, int 
 	return 0;
 }
 
+// ---- round 4 ----
+// the interlaced last level in the register-strip organisation (luma band width a multiple of 16); lists: LH / HH of every channel given as block lists
+// (masks: the frame's chunk masks, mask_base[c * 4 + b] as cfhd_core.h dec_block_list_layout numbers them), HL dense
+int emu_inv_frame_yuv422_strip(int16_t **bands /*[3][4]*/, const int *band_pitch, int w, int h, int display_height, int uyvy, int shift,
+                               unsigned dither_seed, uint8_t *out, int out_pitch, const unsigned long long *masks, const int *mask_base)
+{
+	if (w % 16) return -1;
+	InvYuvJob job;
+	memset(&job, 0, sizeof(job));
+	for (int c = 0; c < 3; c++) { job.band_pitch[c] = band_pitch[c]; for (int b = 0; b < 4; b++) job.band[c][b] = bands[c * 4 + b]; }
+	job.width = w; job.height = h; job.display_height = display_height; job.uyvy = uyvy; job.shift = shift;
+	job.dither_seed = dither_seed; job.out = out; job.out_pitch = out_pitch;
+	job.masks = masks;
+	if (masks) for (int c = 0; c < 3; c++) for (int b = 0; b < 4; b++) job.mask_base[c][b] = mask_base[c * 4 + b];
+	const dim3 grid((w / SBLK + SSEG - 1) / SSEG, (h + SRI - 1) / SRI, 1);
+	if (masks) hipemu::launch(grid, dim3(NTHREADS), [&] { k_inv_frame_yuv422_strip_blocks(&job, 0u); });
+	else hipemu::launch(grid, dim3(NTHREADS), [&] { k_inv_frame_yuv422_strip(&job, 0u); });
+	return 0;
+}
+
+// the progressive last level from block lists (all three highpass bands of every channel)
+int emu_inv_yuv422_strip_blocks(int16_t **bands /*[3][4]*/, const int *band_pitch, int w, int h, int display_height, int uyvy, int shift,
+                                unsigned dither_seed, uint8_t *out, int out_pitch, const unsigned long long *masks, const int *mask_base)
+{
+	if (w % 16) return -1;
+	InvYuvJob job;
+	memset(&job, 0, sizeof(job));
+	for (int c = 0; c < 3; c++) { job.band_pitch[c] = band_pitch[c]; for (int b = 0; b < 4; b++) job.band[c][b] = bands[c * 4 + b]; }
+	job.width = w; job.height = h; job.display_height = display_height; job.uyvy = uyvy; job.shift = shift;
+	job.dither_seed = dither_seed; job.out = out; job.out_pitch = out_pitch;
+	job.masks = masks;
+	for (int c = 0; c < 3; c++) for (int b = 0; b < 4; b++) job.mask_base[c][b] = mask_base[c * 4 + b];
+	hipemu::launch(dim3((w / SBLK + SSEG - 1) / SSEG, (h + SR - 1) / SR, 1), dim3(NTHREADS), [&] { k_inv_yuv422_strip_blocks(&job, 0u); });
+	return 0;
+}
+
+// the interlaced level 1 in the register-strip organisation (width a multiple of 32)
+int emu_fwd_frame_yuv422_strip(const uint8_t *in, int in_pitch, int width, int height, int display_height, int uyvy, int shift,
+                               const int *quant /*[3][4]*/, int mpq, int16_t **out /*[3][4]*/, const int *out_pitch)
+{
+	if (width % 32) return -1;
+	FwdFrameJob job;
+	memset(&job, 0, sizeof(job));
+	job.in = in; job.in_pitch = in_pitch; job.width = width; job.height = height; job.display_height = display_height;
+	job.uyvy = uyvy; job.shift = shift;
+	for (int c = 0; c < 3; c++) {
+		job.out_pitch[c] = out_pitch[c];
+		for (int b = 0; b < 4; b++) { job.out[c][b] = out[c * 4 + b]; job.q[c][b] = make_q(quant[c * 4 + b], mpq); }
+		if (quant[c * 4 + 2] > 1 && mpq >= 2 && mpq < 9) job.q[c][2].mid = quant[c * 4 + 2] / mpq;
+	}
+	hipemu::launch(dim3((width / 16 + SSEG - 1) / SSEG, (height / 2 + SRI - 1) / SRI, 1), dim3(NTHREADS), [&] { k_fwd_frame_yuv422_strip(&job); });
+	return 0;
+}
+
+// Bayer level 1 straight from the BYR4 mosaic, all four component planes from one pass (k_fwd_bayer_strip); width / height: the component planes (coded height)
+int emu_fwd_bayer_strip(const uint16_t *in, int in_pitch_words, int width, int height, int display_height, const uint16_t *curve, int order,
+                        const int *quant, int mpq, int16_t **out, int out_pitch)
+{
+	if (width % 8) return -1;
+	std::vector<FwdPlaneJob> jobs(4);
+	for (int c = 0; c < 4; c++) {
+		FwdPlaneJob &job = jobs[c];
+		memset(&job, 0, sizeof(job));
+		job.width = width; job.height = height; job.prescale = 0; job.display_height = height;
+		for (int b = 0; b < 4; b++) { job.out[b] = out[c * 4 + b]; job.q[b] = make_q(quant[c * 4 + b], mpq); }
+		job.out_pitch = out_pitch;
+	}
+	BayerJob bj;
+	memset(&bj, 0, sizeof(bj));
+	bj.in = in; bj.in_pitch = in_pitch_words; bj.width = width; bj.height = height; bj.display_height = display_height; bj.curve = curve; bj.order = order; bj.precision = 12;
+	const int nseg = (width / 8 + PSTEP - 1) / PSTEP, nstrips = (height / 2 + PSR - 1) / PSR, waves = nseg * nstrips;
+	hipemu::launch(dim3((waves + 3) / 4), dim3(NTHREADS), [&] { k_fwd_bayer_strip(jobs.data(), &bj, 1, nseg, nstrips); });
+	return 0;
+}
+
 void emu_half_packed16(int16_t **ll, int nch, int pitch, int width, int rows, const int *word, int shift, int alpha, uint16_t *out, int out_pitch_bytes)
 {
 	HalfPackedJob job;
@@ -714,4 +789,11 @@ extern "C" int emu_entropy_decode_dx(const uint8_t *sample, size_t size, int pix
 	memcpy(coeffs, pyr.data() + (size_t)(nframes - 1) * plan.coeff_elems, (size_t)plan.coeff_elems * 2);
 	if (nframes == 2 && memcmp(pyr.data(), pyr.data() + plan.coeff_elems, (size_t)plan.final_elems * 2)) return -30;
 	return 0;
+}
+
+// the running sums of a difference-coded band (no peak table): a wave per row (round 4)
+extern "C" void emu_dec_undiff_rows(int16_t *band, int width, int height, int pitch)
+{
+	cfhd::dev::DecDiffJob job = { band, width, height, pitch, nullptr, 0u, 0 };
+	hipemu::launch(dim3(1, 3), dim3(64 * cfhd::dev::DXR_WAVES), [&] { cfhd::dev::k_dec_undiff_rows(&job); });
 }

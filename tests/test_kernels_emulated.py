@@ -1215,3 +1215,153 @@ def test_fwd_packed16_level1_of_rgb10(w, h, dh, big_endian):
         oracle().orc_fwd_spatial(p16(plane), w, w, h, 0, iarr(quant[:4]), 2, bands, opitch)
         for b in range(4):
             assert np.array_equal(outs[4 * c + b][:, :w // 2], want[b][:, :w // 2]), (c, b)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Round 4: the register-strip kernels of config D, the block lists of the decode side, the row-per-wave running sums
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("w,h,dh", [(64, 16, 16), (736, 24, 21), (1920, 8, 8), (2112, 36, 33), (4000, 8, 8)])
+@pytest.mark.parametrize("uyvy", [0, 1])
+def test_fwd_frame_yuv422_strip_kernel(w, h, dh, uyvy):
+    """k_fwd_frame_yuv422_strip = the oracle's TransformForwardFrameYUV (as test_fwd_frame_yuv422_interlaced_level1 for the tiled kernel): full-range bytes with strong field
+    flicker, one to three segments of 1984 pixels with a partial last one, pad rows below the picture, more than one workgroup of row pairs."""
+    rng = np.random.default_rng(w + h + uyvy)
+    frame = rng.integers(0, 256, size=(dh, w * 2), dtype=np.int64).astype(np.uint8)
+    frame[0::2, : w] = rng.choice([0, 255], size=(len(frame[0::2]), w))
+    quant = [1, 36, 16, 36, 1, 36, 16, 48, 1, 36, 16, 48]
+    outs_o, outs_e, pitches = [], [], []
+    for c in range(3):
+        cw = (w if c == 0 else w // 2) // 2
+        pitch = (cw + 7) // 8 * 8; pitches.append(pitch)
+        outs_o.append([np.zeros((h // 2, pitch), np.int16) for _ in range(4)])
+        outs_e.append([np.full((h // 2, pitch), 77, np.int16) for _ in range(4)])
+    padded = np.full((h, w * 2), 0x80, np.uint8); padded[:dh] = frame
+    O = oracle()
+    for c in range(3):
+        bands = (c_i16p * 4)(*[p16(a) for a in outs_o[c]])
+        O.orc_fwd_frame_yuv422(p8(padded), w * 2, w if c == 0 else w // 2, h, c, 2, uyvy, iarr(quant[4 * c: 4 * c + 4]), 2, bands, pitches[c])
+    ptrs = (c_i16p * 12)(*[p16(a) for c in range(3) for a in outs_e[c]])
+    assert emu().emu_fwd_frame_yuv422_strip(p8(frame), w * 2, w, h, dh, uyvy, 2, iarr(quant), 2, ptrs, iarr(pitches)) == 0
+    for c in range(3):
+        cw = (w if c == 0 else w // 2) // 2
+        for b in range(4):
+            assert np.array_equal(outs_e[c][b][:, :cw], outs_o[c][b][:, :cw]), (c, b)
+
+
+@pytest.mark.parametrize("w,h,dh,order", [(40, 8, 8, 0), (304, 24, 21, 0), (1000, 72, 70, 0), (504, 16, 16, 1), (504, 16, 13, 2), (72, 40, 40, 3)])
+def test_fwd_bayer_strip_kernel(w, h, dh, order):
+    """k_fwd_bayer_strip (level 1 straight from the BYR4 mosaic, curve LUT in LDS, four planes from one pass) = k_unpack_byr4 (pinned on the oracle above) followed by the
+    oracle's plane transform of the four component planes: full-range photosites, all four pixel orders, one to three segments of 62 blocks, pad rows, several strips."""
+    rng = np.random.default_rng(w + h + order)
+    O = oracle()
+    mosaic = rng.integers(0, 65536, size=(2 * dh, 2 * w), dtype=np.int64).astype(np.uint16)
+    curve = np.zeros(1 << 14, np.uint16)
+    O.orc_byr4_log90_curve.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    O.orc_byr4_log90_curve(12, 14, curve.ctypes.data_as(ctypes.c_void_p))
+    E = emu()
+    ppitch = (w + 15) // 16 * 16
+    planes = [np.zeros((h, ppitch), np.int16) for _ in range(4)]
+    E.emu_unpack_byr4.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    E.emu_unpack_byr4(mosaic.ctypes.data_as(ctypes.c_void_p), 2 * w, w, h, dh, curve.ctypes.data_as(ctypes.c_void_p), order, 12, (c_i16p * 4)(*[p16(g) for g in planes]), ppitch)
+    quant = [1, 24, 24, 12, 1, 36, 36, 18, 1, 36, 36, 18, 1, 48, 48, 24]
+    pitch = (w // 2 + 7) // 8 * 8
+    want = []
+    for c in range(4):
+        o = [np.zeros((h // 2, w // 2), np.int16) for _ in range(4)]
+        O.orc_fwd_spatial(p16(planes[c]), ppitch, w, h, 0, iarr(quant[4 * c: 4 * c + 4]), 2, (c_i16p * 4)(*[p16(a) for a in o]), w // 2)
+        want.append(o)
+    outs = [np.full((h // 2, pitch), 77, np.int16) for _ in range(16)]
+    E.emu_fwd_bayer_strip.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    assert E.emu_fwd_bayer_strip(mosaic.ctypes.data_as(ctypes.c_void_p), 2 * w, w, h, dh, curve.ctypes.data_as(ctypes.c_void_p), order, iarr(quant), 2, (c_i16p * 16)(*[p16(o) for o in outs]), pitch) == 0
+    for c in range(4):
+        for b in range(4):
+            assert np.array_equal(outs[4 * c + b][:, : w // 2], want[c][b]), (c, b)
+            assert np.all(outs[4 * c + b][:, w // 2:] == 77)
+
+
+def _as_block_lists(band, pitch, masks, mask_at):
+    """A dense band (rows of `pitch` coefficients) -> the block-list form of cfhd_core.h dec_block_list_layout in place: per chunk of 64 blocks of the flat raster the
+    nonzero blocks compacted at the chunk's first places, junk behind them, the chunk's mask in masks[mask_at + chunk]."""
+    flat = band.reshape(-1).copy()
+    blocks = flat.reshape(-1, 8)
+    out = np.full_like(blocks, 0x0bad)
+    for k in range((len(blocks) + 63) // 64):
+        chunk = blocks[64 * k: 64 * k + 64]
+        nz = np.any(chunk != 0, axis=1)
+        m = 0
+        for i, flag in enumerate(nz):
+            if flag: m |= 1 << i
+        masks[mask_at + k] = m
+        out[64 * k: 64 * k + int(nz.sum())] = chunk[nz]
+    return out.reshape(band.shape)
+
+
+@pytest.mark.parametrize("w,h,dh,interlaced", [(32, 8, 16, 0), (96, 20, 40, 0), (1008, 21, 41, 0), (128, 17, 34, 1), (2000, 6, 12, 1), (1040, 33, 66, 1)])
+@pytest.mark.parametrize("uyvy", [0, 1])
+def test_inverse_strip_kernels_gather_block_lists(w, h, dh, interlaced, uyvy):
+    """k_inv_yuv422_strip_blocks / k_inv_frame_yuv422_strip_blocks: the level-1 highpass bands as block lists (all three for progressive frames, LH and HH for interlaced
+    ones) give byte for byte the picture of the same kernels reading the dense bands -- sparse bands (two thirds of the blocks empty), chunks that straddle rows, a last
+    chunk that is partial, segments of 124 blocks with a partial last one."""
+    rng = np.random.default_rng(w + h + uyvy + interlaced)
+    E = emu()
+    bands, pitches, mask_base, at = [], [], [], 0
+    for ch in range(3):
+        cw = w if ch == 0 else w // 2
+        pitch = (cw + 7) // 8 * 8; pitches.append(pitch)
+        bs = [np.zeros((h, pitch), np.int16) for _ in range(4)]
+        bs[0][:, :cw] = rand_plane(rng, cw, h, 11)
+        for k in range(1, 4):
+            v = rand_plane(rng, cw, h, 9, signed=True)
+            keep = np.repeat(rng.random((h, (cw + 7) // 8)) < 0.35, 8, axis=1)[:, :cw]      # a third of the blocks hold anything
+            bs[k][:, :cw] = np.where(keep, v, 0)
+        bands.append(bs)
+        for b in range(4):
+            mask_base.append(at if b else -1)
+            if b: at += (h * pitch + 511) // 512
+    ptrs = (c_i16p * 12)(*[p16(a) for ch in range(3) for a in bands[ch]])
+    dense = np.full((2 * h, 4 * w + 16), 7, np.uint8)
+    if interlaced:
+        E.emu_inv_frame_yuv422_strip.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_uint, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        assert E.emu_inv_frame_yuv422_strip(ptrs, iarr(pitches), w, h, dh, uyvy, 2, 1234, p8(dense), 4 * w + 16, None, None) == 0
+        # (the dense strip kernel against the oracle: every byte with dither 0 or with dither 1)
+        outs = []
+        for dither in (0, 1):
+            o = np.zeros((2 * h, 4 * w), np.uint8)
+            oracle().orc_inv_frame_to_yuv422(ptrs, iarr(pitches), w, h, 10, uyvy, dither, p8(o), 4 * w)
+            outs.append(o[:dh])
+        e = dense[:dh, :4 * w]
+        assert np.all((e == outs[0]) | (e == outs[1]))
+    else:
+        assert E.emu_inv_yuv422_strip(ptrs, iarr(pitches), w, h, dh, uyvy, 2, 1234, p8(dense), 4 * w + 16) == 0
+    masks = np.full(at + 8, 0x5555555555555555, np.uint64)
+    listed = []
+    for ch in range(3):
+        bs = list(bands[ch])
+        for b in ((1, 3) if interlaced else (1, 2, 3)):
+            bs[b] = _as_block_lists(bands[ch][b], pitches[ch], masks, mask_base[4 * ch + b])
+        listed.append(bs)
+    lptrs = (c_i16p * 12)(*[p16(a) for ch in range(3) for a in listed[ch]])
+    got = np.full((2 * h, 4 * w + 16), 7, np.uint8)
+    fn = E.emu_inv_frame_yuv422_strip if interlaced else E.emu_inv_yuv422_strip_blocks
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_uint, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    assert fn(lptrs, iarr(pitches), w, h, dh, uyvy, 2, 1234, p8(got), 4 * w + 16, masks.ctypes.data_as(ctypes.c_void_p), iarr(mask_base)) == 0
+    assert np.array_equal(got, dense)
+    assert np.all(got[:, 4 * w:] == 7) and np.all(got[dh:] == 7)
+
+
+@pytest.mark.parametrize("w,h", [(5, 3), (100, 7), (960, 13), (1030, 4), (2050, 9), (16, 70)])
+def test_dec_undiff_rows_kernel(w, h):
+    """k_dec_undiff_rows: every row of a difference-coded band becomes its running sum (16-bit wrap), the pitch padding stays zero, rows of more than 1024 columns in
+    pieces with a carry, widths that are no multiple of the lanes' 16 columns."""
+    rng = np.random.default_rng(w * 3 + h)
+    pitch = (w + 7) // 8 * 8
+    band = np.zeros((h, pitch), np.int16)
+    band[:, :w] = rng.integers(-3000, 3000, size=(h, w)).astype(np.int16)
+    band[0, :w] = 32767 if w > 2 else 1                                   # wraps
+    want = np.zeros_like(band)
+    want[:, :w] = np.cumsum(band[:, :w].astype(np.int64), axis=1).astype(np.int16)
+    got = band.copy()
+    E = emu()
+    E.emu_dec_undiff_rows.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    E.emu_dec_undiff_rows(got.ctypes.data_as(ctypes.c_void_p), w, h, pitch)
+    assert np.array_equal(got, want)
