@@ -17,7 +17,7 @@ def build():
     import cfhd_testlib as T
     T.product_emulated()                                  # (leaves the translated sources under tests/_build/hipemu_product)
     csrc = os.path.join(ROOT, "cineform-sdk_amd", "csrc"); hipemu = os.path.join(ROOT, "tests", "hipemu"); gen = os.path.join(ROOT, "tests", "_build", "hipemu_product")
-    srcs = [os.path.join(hipemu, "emu_runtime.cpp")] + [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith(".cpp")] + [os.path.join(gen, f) for f in sorted(os.listdir(gen)) if f.endswith(".cpp")]
+    srcs = [os.path.join(hipemu, "emu_runtime.cpp")] + [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith(".cpp")] + [os.path.join(gen, f) for f in sorted(os.listdir(gen)) if f.endswith(".cpp") and f.count(".") == 1]      # (not the <name>.<pid>.cpp leftovers of an interrupted build)
     deps = srcs + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".h")]
     if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
         subprocess.check_call(["g++", "-O1", "-g", "-w", "-fsanitize=address", "-fno-omit-frame-pointer", "-std=c++17", "-fPIC", "-shared", "-pthread",
