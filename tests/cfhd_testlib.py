@@ -290,16 +290,36 @@ def reference_leg(agree, attempts=6, what=""):
     return False
 
 
+def _metadata_chunks(sample):
+    """(offset, size) of the payload of every metadata chunk in the header of a sample: the tag / value walk of Codec/decoder.c UpdateCodecState as far as the first
+    lowpass marker -- an optional (negated) tag with bit 0x4000 carries a payload of `value` (bit 0x2000: (tag & 0xff) << 16 | value) longwords; 0x4002 = TAG_METADATA."""
+    out = []; pos = 0; n = len(sample)
+    while pos + 4 <= n:
+        tag = (sample[pos] << 8) | sample[pos + 1]; val = (sample[pos + 2] << 8) | sample[pos + 3]
+        pos += 4
+        if tag & 0x8000: tag = (-tag) & 0xffff
+        if tag == 4 and val in (0x1A4A, 0x0D0D): break              # TAG_MARKER lowpass / highpass start: the header is behind us
+        if tag & 0x4000:
+            size = (((tag & 0xff) << 16) | val) * 4 if tag & 0x2000 else val * 4
+            if (tag & 0xff00) == 0x4000 and (tag & 0xff) == 0x02 or tag == 0x4002: out.append((pos, min(size, n - pos)))
+            pos += size
+        elif tag == 2: pos += 4 * val                             # TAG_INDEX: the channel size entries
+    return out
+
+
 def mask_volatile_metadata(sample):
-    """Zero the bytes of a sample that legitimately differ between two encoders:
-    the payloads of the GUID / DATE / TIME / TIMC tuples in the first metadata chunk
-    (EncoderSDK/SampleEncoder.cpp:764,786-787,806-814)."""
+    """Zero the bytes of a sample that legitimately differ between two encoders: the payloads of the GUID / DATE / TIME / TIMC tuples of its metadata chunks
+    (EncoderSDK/SampleEncoder.cpp:764,786-787,806-814) -- wherever in the header they sit: a large user block in front of them pushes them far behind the first
+    kilobyte, and two encoders that run on either side of a full second write different TIME strings (a one-in-twenty flake of the large-metadata test until round 4)."""
     b = bytearray(sample)
-    for tag, n in ((b"GUID", 16), (b"DATE", 10), (b"TIME", 8), (b"TIMC", 11)):
-        i = bytes(b[:1024]).find(tag)
-        if i >= 0:
-            for k in range(n):
-                b[i + 8 + k] = 0
+    regions = _metadata_chunks(bytes(sample)) or [(0, min(len(b), 1024))]
+    for lo, size in regions:
+        chunk = bytes(b[lo: lo + size]); at = 0
+        while at + 8 <= len(chunk):                                  # tuples: FourCC, 24-bit little-endian size + type byte, payload padded to a longword
+            tag = chunk[at: at + 4]; tsize = chunk[at + 4] | (chunk[at + 5] << 8) | (chunk[at + 6] << 16)
+            if tag in (b"GUID", b"DATE", b"TIME", b"TIMC"):
+                for k in range(min(tsize, len(chunk) - at - 8)): b[lo + at + 8 + k] = 0
+            at += 8 + (tsize + 3) // 4 * 4
     return bytes(b)
 
 
