@@ -186,7 +186,7 @@ def normalise_counters(sample):
     return bytes(b)
 
 
-def parity_check(L, b, frames, pitch, W, H, rank, wl, batch, nuniq):
+def parity_check(L, b, frames, pitch, W, H, rank, wl, batch, nuniq, nchk=None, first=0):
     """What was timed is what the reference produces -- checked on frames spread over the batch of the last step (eight of them at 1080p, fewer for the larger
     formats: the checker is scalar C): every checked sample (frame / unique-frame counters set back to the first frame's) against the reference encoder run here on
     the same frame (sample 0 of the 1080p YUY2 workload also against the golden hash in tests/golden), and the decoded frame against the exact integer reconstruction
@@ -194,8 +194,8 @@ def parity_check(L, b, frames, pitch, W, H, rank, wl, batch, nuniq):
     import numpy as np
     import cfhd_testlib as T
     fmt = getattr(T, "PIX_" + wl["fmt"].upper())
-    nchk = 8 if W * H <= 1920 * 1080 else (2 if W * H <= 3840 * 2160 else 1)
-    checked = sorted({(k * batch) // nchk for k in range(nchk)})
+    nchk = nchk or (8 if W * H <= 1920 * 1080 else (2 if W * H <= 3840 * 2160 else 1))
+    checked = sorted({(first + (k * batch) // nchk) % batch for k in range(nchk)})
     out = {"frames_checked": checked}
     bpp = wl["bpp"]
     psnr = []
@@ -267,7 +267,7 @@ def batch_api():
     return L
 
 
-def measure(workload, steps, warmup, batch, unique, threads, rank, world, barrier, reduce_max, depth=1):
+def measure(workload, steps, warmup, batch, unique, threads, rank, world, barrier, reduce_max, depth=1, geometry=None):
     """One workload through the batched device-resident path: frames generated and uploaded, `warmup` untimed steps, `steps` timed ones between
     barriers, parity check of what was timed on rank 0.  Returns (line fields of this workload, frames, pitch).
     depth: batches in flight (the frame queue, cfhd_amd_batch_submit / _wait): step k + 1 is submitted while step k is still on the GPU; every step is still one
@@ -277,6 +277,7 @@ def measure(workload, steps, warmup, batch, unique, threads, rank, world, barrie
     wl = dict(WORKLOADS[workload])
     probing = bool(os.environ.get("CFHD_BENCH_ENCODE_ONLY"))      # timing experiments on the encoder's kernels (tools/gpu_probe.sh): no decode, no parity check
     if probing: wl["mode"] = 1
+    if geometry: wl["w"], wl["h"] = geometry            # tests/test_frame_shards.py: the same pass at a size the emulated product finishes in seconds
     W, H = wl["w"], wl["h"]
     L = batch_api()
     nuniq = min(unique or wl["unique"], batch)
@@ -338,6 +339,16 @@ def measure(workload, steps, warmup, batch, unique, threads, rank, world, barrie
     # With several steps in flight the kernels of concurrent steps share the GPU, and the HIP events around a launch then time that sharing, not the kernel (as-run
     # times: config.kernel_ms_per_step).  The roofline of a kernel is a statement about the kernel: right behind the timed region the same pass runs ALONE_STEPS more
     # times one at a time on the batch of the last step, with the same events -- those launch times feed `roofline` (and agree with a rocprofv3 trace of --depth 1).
+    # What was timed is what gets checked: the parity check reads the samples and pictures the LAST TIMED pass of every batch in flight left behind, before
+    # anything runs again on them (a solo pass afterwards could hide corruption between concurrent passes).
+    parity = None
+    if rank == 0 and not probing:
+        last = (steps - 1) % depth
+        parity = parity_check(L, slots[last], frames, pitch, W, H, rank, wl, batch, nuniq)
+        for k, q in enumerate(slots):
+            if k == last: continue
+            other = parity_check(L, q, frames, pitch, W, H, rank, wl, batch, nuniq, nchk=2 if W * H <= 1920 * 1080 else 1, first=(k + 1) * batch // (depth + 1))
+            parity.setdefault("other_batches_in_flight", []).append(other["frames_checked"])
     kms_alone = None
     if depth > 1:
         ALONE_STEPS = 3
@@ -352,7 +363,6 @@ def measure(workload, steps, warmup, batch, unique, threads, rank, world, barrie
     assert shards.shard_bounds(batch * world, rank, world) == (rank * batch, (rank + 1) * batch)
     fps = shards.whole_job_rate(batch * steps, world, elapsed)
 
-    parity = parity_check(L, b, frames, pitch, W, H, rank, wl, batch, nuniq) if rank == 0 and not probing else None
     dx_stats = None
     if os.environ.get("CFHD_AMD_DX_STATS"):               # convergence counters of the chunk-indexed entropy decoder (diagnostics, slows the kernels a little)
         st = (ctypes.c_uint32 * 16)()
@@ -383,7 +393,7 @@ def measure(workload, steps, warmup, batch, unique, threads, rank, world, barrie
         # events around them time that sharing, and each of the launches is shorter than the longest launch of the step -- profiles/: rocprofv3 averages --; it is reported
         # among other_kernels_gbs with the time it takes as run.)
         dom = max((k for k in algo if k != COUNT1 or len(algo) == 1), key=lambda k: kms[k])
-        ms = kms[dom]
+        ms = kms[dom] or 1e-9                             # (0 only on the emulated build of the CPU tests, whose events carry no time)
         achieved = algo[dom] * batch / (ms * 1e-3) / 1e9
         traffic = None; traffic_source = None
         try:                                             # HBM bytes per launch from the committed PMC passes of this command (profiles/, same batch size), else null
@@ -428,6 +438,16 @@ def measure(workload, steps, warmup, batch, unique, threads, rank, world, barrie
     return line, frames, pitch
 
 
+def launcher_command(gpus, argv):
+    """`python bench.py --gpus N` on its own (no WORLD_SIZE in the environment): the command that starts the N ranks, one process per GPU, exactly as the
+    driver's own command line does; rank 0 of that job prints the line."""
+    import socket
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -443,11 +463,16 @@ def main():
     ap.add_argument("--depth", type=int, default=DEFAULT_DEPTH, help="steps in flight (frame queue of batch objects: cfhd_amd_batch_submit / _wait); 1 = one synchronous pass after the other")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import subprocess
+        raise SystemExit(subprocess.call(launcher_command(args.gpus, sys.argv[1:])))
     wl = WORKLOADS[args.workload]
     W, H = wl["w"], wl["h"]
     batch = args.batch or wl["batch"]
     headline = wl["fmt"] == "YUY2" and not wl["flags"]     # the metric's own pixel format and transform
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(1, args.gpus) and rank == 0:          # the launcher's rank count is what runs (n_gpus in the line says so)
+        print("bench.py: --gpus %d but the launcher started %d ranks (WORLD_SIZE): measuring %d" % (args.gpus, world, world), file=sys.stderr)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("CFHD_AMD_DEVICE", str(local_rank))
     import torch

@@ -194,3 +194,53 @@ def test_two_ranks_gloo_product_batches_on_their_own_devices_equal_the_unsharded
         merged.update(part)
     whole, _ = _product_samples(range(1, TOTAL + 1))
     assert merged == whole
+
+
+def _worker_bench(rank, world, port, q):
+    """bench.py's own measure() -- frame queue, max-over-ranks time, whole-job rate, parity check of what was timed -- as one rank of an N-rank job: the launch
+    bench.py --gpus N gets (RANK / LOCAL_RANK / WORLD_SIZE in the environment), gloo in place of RCCL, the emulated product in place of the GPU."""
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "HIPEMU_DEVICES": str(world), "CFHD_AMD_DEVICE": str(rank),
+                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    import torch, torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    import bench
+    import cfhd_testlib as T
+    def reduce_max(elapsed):
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+    with T.emulated_product():
+        line, frames, pitch = bench.measure("1080p", 3, 1, 3, 2, 1, rank, world, dist.barrier, reduce_max, depth=2, geometry=(192, 96))
+    gathered = [None] * world
+    dist.all_gather_object(gathered, line)
+    if rank == 0: q.put(gathered)
+    dist.destroy_process_group()
+
+
+def test_bench_measure_runs_as_two_ranks_and_reports_the_whole_job():
+    """`python bench.py --gpus 2`: the launcher command starts two ranks of bench.py itself, and measure() run as those two ranks (gloo, two emulated GPUs)
+    prints ONE line on rank 0 with n_gpus = 2, the frames of both ranks in `value`, and the parity check of what rank 0 timed."""
+    import torch.multiprocessing as mp
+    import cfhd_testlib as T
+    if not T.have_ref(): pytest.skip("reference .so not built (Qbist frames, the emulated product build)")
+    sys.path.insert(0, ROOT)
+    import bench
+    cmd = bench.launcher_command(2, ["--gpus", "2", "--steps", "5"])
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "2" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-5] == os.path.join(ROOT, "bench.py") and cmd[-4:] == ["--gpus", "2", "--steps", "5"]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + (os.getpid() % 2000)
+    T.product_emulated()
+    procs = [ctx.Process(target=_worker_bench, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    lines = q.get(timeout=600)
+    for p in procs:
+        p.join(120); assert p.exitcode == 0
+    line = lines[0]
+    assert lines[1] is None                            # one line per job
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["steps"] == 3
+    assert abs(line["value"] - 2 * 3 * 3 / (line["ms_per_step"] * 3e-3)) / line["value"] < 1e-2       # frames of both ranks / the slowest rank's time
+    par = line["config"]["parity"]
+    assert par["samples_equal_reference_encoder"] and par["decoded_frames_in_dither_interval"] and len(par["other_batches_in_flight"]) == 1
