@@ -1245,7 +1245,11 @@ CFHD_Error CFHD_DecodeSample(CFHD_DecoderRef ref, void *sample, size_t size, voi
 	// inverse frame transform, half resolution from the level-1 lowpass planes like any other sample (the reference's output is the same model)
 	const bool interlaced = !ps.progressive;
 	// (YU64 / v210 output of interlaced samples: at half resolution only -- the level-1 lowpass planes, as for progressive samples; RG24 takes another route there: not built)
-	if (interlaced && (ps.encoded_format != ENC_YUV422 || ((d->out_kind == PIX_YU64 || d->out_kind == PIX_V210) && !d->half) || d->out_kind == PIX_RG24)) return fail_zero(ERR_BADFORMAT);
+	// (likewise the 8-bit / 16-bit RGB(A) pictures and the 10-bit RGB words of an interlaced sample: half resolution only -- at full resolution DecodeBatch::launch_inverse has no
+	// inverse frame transform into planes for them, and refusing here keeps the contract of every other unsupported combination: BADFORMAT, zeroed picture, nothing queued)
+	const bool planes_out = d->out_kind == PIX_YU64 || d->out_kind == PIX_V210 || d->out_kind == PIX_BGRA || d->out_kind == PIX_BGRa || d->out_kind == PIX_RG48 || d->out_kind == PIX_B64A ||
+	                        (d->out_kind >= PIX_R210 && d->out_kind <= PIX_AR10);
+	if (interlaced && (ps.encoded_format != ENC_YUV422 || (planes_out && !d->half) || d->out_kind == PIX_RG24)) return fail_zero(ERR_BADFORMAT);
 	if (interlaced && !d->half && ps.width > 8192) return fail_zero(ERR_BADFORMAT);        // k_dec_undiff serves rows of up to 4096 coefficients (cfhd_dec_kernels.h DXU_MAX): an unsupported size, not a bad sample
 	// another call of this geometry in flight right now: decode together with it (see DecodeService)
 	if (decode_gather_slots() > 1 && gpu_entropy_enabled() && size <= (size_t)d->plan.width * d->plan.height * pixel_bytes_of(d->out_kind) + 65536) {

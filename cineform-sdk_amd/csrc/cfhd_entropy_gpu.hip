@@ -242,8 +242,8 @@ GpuEntropyDecoder::~GpuEntropyDecoder() { release(); delete host_; }
 void GpuEntropyDecoder::release()
 {
 	(void)hipSetDevice(device_);
-	void *dev[] = { d_samples_, d_tables_, d_bandjobs_, d_lowjobs_, d_errors_, d_plan_, d_idx_tables_, d_entries_, d_recs_, d_chunk_base_, d_chunk_job_, d_sums_, d_counters_, d_tile_start_, d_stats_, d_repair_, d_alts_, d_reindex_, d_diffjobs_, d_alt_entries_, d_masks_ };
-	d_masks_ = nullptr; masks_per_frame_ = 0; use_blocks_ = false; blocks_written_ = false;
+	void *dev[] = { d_samples_, d_tables_, d_bandjobs_, d_lowjobs_, d_errors_, d_plan_, d_idx_tables_, d_entries_, d_recs_, d_chunk_base_, d_chunk_job_, d_sums_, d_counters_, d_tile_start_, d_stats_, d_repair_, d_alts_, d_reindex_, d_diffjobs_, d_alt_entries_, d_masks_, d_records_, d_nrecs_ };
+	d_masks_ = nullptr; d_records_ = d_nrecs_ = nullptr; masks_per_frame_ = 0; use_blocks_ = false; blocks_written_ = false;
 	for (void *p : dev) if (p) (void)hipFree(p);
 	d_idx_tables_ = d_entries_ = d_recs_ = d_chunk_base_ = d_chunk_job_ = d_sums_ = d_counters_ = d_tile_start_ = d_stats_ = d_repair_ = d_alts_ = d_reindex_ = d_diffjobs_ = d_alt_entries_ = nullptr;
 	if (h_chunk_job_) (void)hipHostFree(h_chunk_job_);
@@ -283,7 +283,8 @@ int GpuEntropyDecoder::prepare(const FramePlan &plan, int nframes, int16_t *d_co
 	HIPCHK(hipMalloc((void **)&d_errors_, sizeof(int)));
 	HIPCHK(hipHostMalloc((void **)&h_errors_, sizeof(int), hipHostMallocPortable));
 	*h_errors_ = 0;
-	{ const char *e = getenv("CFHD_AMD_DEC"); lane_kernel_ = e && strcmp(e, "lane") == 0; dx_ = !(e && (strcmp(e, "lane") == 0 || strcmp(e, "par") == 0)); }   // A/B switches: the round-1 kernels
+	{ const char *e = getenv("CFHD_AMD_DEC"); lane_kernel_ = e && strcmp(e, "lane") == 0; dx_ = !(e && (strcmp(e, "lane") == 0 || strcmp(e, "par") == 0));   // A/B switches: the round-1 kernels,
+	  emit_ = dx_ && e && strcmp(e, "emit") == 0; }                                                                                                              // the single-pass arrangement of round 5
 	if (dx_) {
 		dev::DecIdxTables *it = new dev::DecIdxTables;
 		const bool ok = build_dec_index_tables(1, it);
@@ -305,6 +306,12 @@ int GpuEntropyDecoder::prepare(const FramePlan &plan, int nframes, int16_t *d_co
 		HIPCHK(hipMalloc(&d_reindex_, (size_t)max_chunks_ * sizeof(dev::DxReindex)));
 		alt_slots_ = max_chunks_ / 8 > 64u ? max_chunks_ / 8 : 64u;          // entries of the extra candidates of chunks without a unique alignment (a few per cent of the chunks)
 		HIPCHK(hipMalloc(&d_alt_entries_, (size_t)alt_slots_ * dev::DX_ENTRY_STRIDE * 4));
+		if (emit_) {
+			// one 128-byte record slot per 64-bit piece of the worst-case sample (32 KB per chunk; only the slots of real pieces are ever touched: about a ninth at the
+			// benchmark's quality) + one chunk's worth of scratch, and the record counts (a byte per piece)
+			HIPCHK(hipMalloc(&d_records_, ((size_t)max_chunks_ + 1) * dev::DX_REC_CHUNK * 4));
+			HIPCHK(hipMalloc(&d_nrecs_, (size_t)max_chunks_ * 64 * 4));
+		}
 		{
 			dev::DecPlan dp0; dec_build_plan(plan, out_kind, &dp0);
 			const dev::DxTilePlan tp0 = dx_tile_plan(plan, dp0, n_, false);
@@ -318,6 +325,7 @@ int GpuEntropyDecoder::prepare(const FramePlan &plan, int nframes, int16_t *d_co
 		(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_current());
 		const char *g1 = getenv("CFHD_AMD_DX_GRID_INDEX"), *g3 = getenv("CFHD_AMD_DX_GRID_TILES");
 		grid_index_ = g1 ? atoi(g1) : cus * 5; grid_tiles_ = g3 ? atoi(g3) : cus * (dev::DX_TILE_THREADS >= 1024 ? 1 : 2);      // workgroups that fit a CU at once (LDS: ~30 KB / ~150 KB each)
+		if (emit_ && !g3) grid_tiles_ = cus * (int)((160 * 1024) / (sizeof(uint32_t) * dev::DX_TILE_WORDS * dev::DX_SC_WAVES));      // k_dec_scatter: 8 KB of LDS per wave
 		if (grid_index_ < 1) grid_index_ = 1;
 		if (grid_tiles_ < 1) grid_tiles_ = 1;
 	}
@@ -507,19 +515,29 @@ int GpuEntropyDecoder::launch_dx(bool device_jobs, int njobs, uint32_t host_chun
 	const uint32_t chunk_bound = device_jobs ? max_chunks_ : host_chunks;
 	int g1 = grid_index_, g3 = grid_tiles_;
 	if ((uint32_t)g1 * dev::DX_WAVES > chunk_bound) g1 = (int)((chunk_bound + dev::DX_WAVES - 1) / dev::DX_WAVES);
-	if ((uint32_t)g3 * dev::DX_TILE_WAVES > tp.total) g3 = (int)((tp.total + dev::DX_TILE_WAVES - 1) / dev::DX_TILE_WAVES);
+	const uint32_t tile_waves = emit_ ? (uint32_t)dev::DX_SC_WAVES : (uint32_t)dev::DX_TILE_WAVES;
+	if ((uint32_t)g3 * tile_waves > tp.total) g3 = (int)((tp.total + tile_waves - 1) / tile_waves);
 	if (g1 < 1) g1 = 1;
 	if (g3 < 1) g3 = 1;
-	dev::k_dec_index<<<g1, dev::DX_THREADS, 0, st>>>((const dev::DxChunkDesc *)d_chunk_job_, (const uint32_t *)d_counters_, T, (uint32_t *)d_entries_, (dev::DxChunkRec *)d_recs_, (dev::DxChunkAlt *)d_alts_, speculate ? 1 : 0, (uint32_t *)d_stats_,
+	const dev::DxRecords R = { (uint32_t *)d_records_, (uint32_t *)d_nrecs_, max_chunks_ };
+	if (emit_) dev::k_dec_index_emit<<<g1, dev::DX_THREADS, 0, st>>>((const dev::DxChunkDesc *)d_chunk_job_, (const uint32_t *)d_counters_, T, (uint32_t *)d_entries_, (dev::DxChunkRec *)d_recs_, (dev::DxChunkAlt *)d_alts_,
+	                                                                 speculate ? 1 : 0, (uint32_t *)d_stats_, R, (uint32_t *)d_counters_ + 4);
+	else dev::k_dec_index<<<g1, dev::DX_THREADS, 0, st>>>((const dev::DxChunkDesc *)d_chunk_job_, (const uint32_t *)d_counters_, T, (uint32_t *)d_entries_, (dev::DxChunkRec *)d_recs_, (dev::DxChunkAlt *)d_alts_, speculate ? 1 : 0, (uint32_t *)d_stats_,
 	                                                 (uint32_t *)d_alt_entries_, alt_slots_, (uint32_t *)d_counters_ + 3, (uint32_t *)d_counters_ + 4);
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[5], st));
 	dev::k_dec_chain<<<(njobs + dev::DX_WAVES - 1) / dev::DX_WAVES, dev::DX_THREADS, 0, st>>>(jobs, njobs, (const dev::DxChunkRec *)d_recs_, (const dev::DxChunkAlt *)d_alts_, (uint32_t *)d_chunk_base_,
 	                                                                                            (dev::DxBandSum *)d_sums_, d_errors_, (uint32_t *)d_repair_, (dev::DxReindex *)d_reindex_, (uint32_t *)d_counters_);
 	const int small_grid = njobs < 256 ? (njobs + dev::DX_WAVES - 1) / dev::DX_WAVES : 64;
+	if (emit_) {
+		dev::k_dec_repair_emit<<<small_grid, dev::DX_THREADS, 0, st>>>(jobs, T, (uint32_t *)d_entries_, (dev::DxChunkRec *)d_recs_, (const dev::DxChunkAlt *)d_alts_, (uint32_t *)d_chunk_base_, (dev::DxBandSum *)d_sums_,
+		                                                              d_errors_, (const uint32_t *)d_repair_, (dev::DxReindex *)d_reindex_, (uint32_t *)d_counters_, R, (uint32_t *)d_stats_);
+		dev::k_dec_reindex_emit<<<g1, dev::DX_THREADS, 0, st>>>(jobs, T, (uint32_t *)d_entries_, (const dev::DxReindex *)d_reindex_, (const uint32_t *)d_counters_, R, (uint32_t *)d_stats_);
+	} else {
 	dev::k_dec_repair<<<small_grid, dev::DX_THREADS, 0, st>>>(jobs, T, (uint32_t *)d_entries_, (dev::DxChunkRec *)d_recs_, (const dev::DxChunkAlt *)d_alts_, (uint32_t *)d_chunk_base_, (dev::DxBandSum *)d_sums_,
 	                                                         d_errors_, (const uint32_t *)d_repair_, (dev::DxReindex *)d_reindex_, (uint32_t *)d_counters_, (uint32_t *)d_stats_);
 	dev::k_dec_reindex<<<g1, dev::DX_THREADS, 0, st>>>(jobs, T, (uint32_t *)d_entries_, (const dev::DxReindex *)d_reindex_, (const uint32_t *)d_counters_, (uint32_t *)d_stats_,
 	                                                   (const dev::DxChunkAlt *)d_alts_, (const uint32_t *)d_alt_entries_);
+	}
 	dev::k_dec_tile_index<<<(tp.total + dev::DX_THREADS - 1) / dev::DX_THREADS, dev::DX_THREADS, 0, st>>>(jobs, tp, (const uint32_t *)d_entries_, (const uint32_t *)d_chunk_base_, (const dev::DxBandSum *)d_sums_,
 	                                                                                                  (uint32_t *)d_tile_start_);
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[6], st));
@@ -529,19 +547,22 @@ int GpuEntropyDecoder::launch_dx(bool device_jobs, int njobs, uint32_t host_chun
 	// the plane kernels beside it only stretch it from 1.67 to 2.25 ms.  (The same idea pays on the encoder side, where the kernel that shares the chip waits on memory.)
 	const char *split_env = getenv("CFHD_AMD_TILES_SPLIT");
 	l23_split_ = frames >= 8 && !skip_level1_ && tp.split > 0 && tp.split < tp.total && split_env && split_env[0] == '1';
+	auto tile_pass = [&](const dev::DxTilePlan &p, int g) {
+		if (emit_) dev::k_dec_scatter<<<g < 1 ? 1 : g, dev::DX_SC_THREADS, 0, st>>>(jobs, p, (const uint32_t *)d_entries_, (const uint32_t *)d_chunk_base_, (const dev::DxBandSum *)d_sums_, (const uint32_t *)d_tile_start_, R, tmasks, (uint32_t)masks_per_frame_);
+		else dev::k_dec_tiles<<<g < 1 ? 1 : g, dev::DX_TILE_THREADS, 0, st>>>(jobs, p, T, (const uint32_t *)d_entries_, (const uint32_t *)d_chunk_base_, (const dev::DxBandSum *)d_sums_, (const uint32_t *)d_tile_start_, tmasks, (uint32_t)masks_per_frame_);
+	};
 	if (l23_split_) {
 		dev::DxTilePlan ta = tp, tb = tp;
 		ta.total = tp.split; tb.first = tp.split;
 		int ga = g3, gb = g3;
-		if ((uint32_t)ga * dev::DX_TILE_WAVES > ta.total) ga = (int)((ta.total + dev::DX_TILE_WAVES - 1) / dev::DX_TILE_WAVES);
-		if ((uint32_t)gb * dev::DX_TILE_WAVES > tb.total - tb.first) gb = (int)((tb.total - tb.first + dev::DX_TILE_WAVES - 1) / dev::DX_TILE_WAVES);
-		dev::k_dec_tiles<<<ga < 1 ? 1 : ga, dev::DX_TILE_THREADS, 0, st>>>(jobs, ta, T, (const uint32_t *)d_entries_, (const uint32_t *)d_chunk_base_, (const dev::DxBandSum *)d_sums_, (const uint32_t *)d_tile_start_, tmasks, (uint32_t)masks_per_frame_);
+		if ((uint32_t)ga * tile_waves > ta.total) ga = (int)((ta.total + tile_waves - 1) / tile_waves);
+		if ((uint32_t)gb * tile_waves > tb.total - tb.first) gb = (int)((tb.total - tb.first + tile_waves - 1) / tile_waves);
+		tile_pass(ta, ga);
 		HIPCHK(hipEventRecord((hipEvent_t)ev_low_, st));
 		dev::k_dec_lowpass<<<dim3(8, (unsigned)lowpass_jobs), 256, 0, st>>>((const dev::DecLowpassJob *)d_lowjobs_);
 		HIPCHK(hipEventRecord((hipEvent_t)ev_l23_, st));
-		dev::k_dec_tiles<<<gb < 1 ? 1 : gb, dev::DX_TILE_THREADS, 0, st>>>(jobs, tb, T, (const uint32_t *)d_entries_, (const uint32_t *)d_chunk_base_, (const dev::DxBandSum *)d_sums_, (const uint32_t *)d_tile_start_, tmasks, (uint32_t)masks_per_frame_);
-	} else
-	dev::k_dec_tiles<<<g3, dev::DX_TILE_THREADS, 0, st>>>(jobs, tp, T, (const uint32_t *)d_entries_, (const uint32_t *)d_chunk_base_, (const dev::DxBandSum *)d_sums_, (const uint32_t *)d_tile_start_, tmasks, (uint32_t)masks_per_frame_);
+		tile_pass(tb, gb);
+	} else tile_pass(tp, g3);
 	if (interlaced_) {
 		// the difference-coded band of every channel back to coefficients: a wave per row for the bands without a peak table (CFHD_AMD_UNDIFF=block: the one kernel of
 		// round 3 for all of them, A/B), the workgroup-per-band kernel for the few that have one

@@ -77,5 +77,9 @@ typedef uint32_t cfhd_u2 __attribute__((ext_vector_type(2)));
 #define CFHD_LDG64(p) (*(const __attribute__((address_space(1))) cfhd_u2 *)(p))
 #define CFHD_LDG128(p) (*(const __attribute__((address_space(1))) cfhd_u4 *)(p))
 
+// two consecutive dwords in one store (global_store_dwordx2) at an address that is only dword aligned: gfx950 serves unaligned vector accesses to global memory
+typedef uint32_t cfhd_u2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+__device__ __forceinline__ void store_u32x2_dword_aligned(uint32_t *at, uint32_t a, uint32_t b) { cfhd_u2_a4 v; v.x = a; v.y = b; *(__attribute__((address_space(1))) cfhd_u2_a4 *)at = v; }
+
 } // namespace dev
 } // namespace cfhd

@@ -56,6 +56,7 @@ struct emu_u2 { uint32_t x, y; };
 typedef emu_u2 cfhd_u2;
 #define CFHD_LDG64(p) (*(const cfhd::dev::cfhd_u2 *)(p))
 #define CFHD_LDG128(p) (*(const cfhd::dev::cfhd_u4 *)(p))
+inline void store_u32x2_dword_aligned(uint32_t *at, uint32_t a, uint32_t b) { at[0] = a; at[1] = b; }
 
 } // namespace dev
 } // namespace cfhd

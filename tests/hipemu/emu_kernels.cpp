@@ -694,6 +694,8 @@ extern "C" int emu_entropy_decode_dx(const uint8_t *sample, size_t size, int pix
 {
 	memset(g_dx_stats, 0, sizeof(g_dx_stats));
 	using namespace cfhd;
+	const bool emit = (mode & 16) != 0;                  // + 16: the single-pass arrangement (k_dec_index_emit / k_dec_scatter) in place of k_dec_index / k_dec_tiles
+	mode &= 15;
 	ParsedSample ps;
 	if (parse_sample(sample, size, &ps) != 0) return -1;
 	FramePlan plan;
@@ -740,14 +742,27 @@ extern "C" int emu_entropy_decode_dx(const uint8_t *sample, size_t size, int pix
 	counters[1] = 0; counters[2] = 0; counters[3] = 0; counters[4] = 0;
 	const uint32_t alt_slots = 3;                       // room for the candidates of one or two chunks only: both ways of k_dec_reindex (copy, index again) are exercised
 	std::vector<uint32_t> alt_entries((size_t)alt_slots * dev::DX_ENTRY_STRIDE + 16, 0xdeadbeefu);
-	hipemu::launch(dim3((unsigned)grid), dim3(dev::DX_THREADS), [&] { dev::k_dec_index(chunk_job.data(), counters.data(), &tables, entries.data(), recs.data(), alts.data(), mode != 1, g_dx_stats, alt_entries.data(), alt_slots, &counters[3], &counters[4]); });
+	// the record slots of the single-pass arrangement: one chunk's worth more as scratch, every word poisoned (a record the scatter pass reads must have been written by the walk)
+	std::vector<uint32_t> rec_slots(emit ? ((size_t)nchunks + 1) * dev::DX_REC_CHUNK : 0, 0x7fff7fffu), nrecs(emit ? (size_t)nchunks * 64 + 16 : 0, 0xffffffffu);
+	const dev::DxRecords R = { rec_slots.data(), nrecs.data(), nchunks };
+	if (emit) hipemu::launch(dim3((unsigned)grid), dim3(dev::DX_THREADS), [&] { dev::k_dec_index_emit(chunk_job.data(), counters.data(), &tables, entries.data(), recs.data(), alts.data(), mode != 1, g_dx_stats, R, &counters[4]); });
+	else hipemu::launch(dim3((unsigned)grid), dim3(dev::DX_THREADS), [&] { dev::k_dec_index(chunk_job.data(), counters.data(), &tables, entries.data(), recs.data(), alts.data(), mode != 1, g_dx_stats, alt_entries.data(), alt_slots, &counters[3], &counters[4]); });
 	hipemu::launch(dim3((unsigned)(njobs + dev::DX_WAVES - 1) / dev::DX_WAVES), dim3(dev::DX_THREADS), [&] { dev::k_dec_chain(jobs.data(), njobs, recs.data(), alts.data(), chunk_base.data(), sums.data(), &errors, repair_list.data(), reindex.data(), counters.data()); });
-	hipemu::launch(dim3(2), dim3(dev::DX_THREADS), [&] { dev::k_dec_repair(jobs.data(), &tables, entries.data(), recs.data(), alts.data(), chunk_base.data(), sums.data(), &errors, repair_list.data(), reindex.data(), counters.data(), g_dx_stats); });
-	hipemu::launch(dim3(3), dim3(dev::DX_THREADS), [&] { dev::k_dec_reindex(jobs.data(), &tables, entries.data(), reindex.data(), counters.data(), g_dx_stats, alts.data(), alt_entries.data()); });
+	if (emit) {
+		hipemu::launch(dim3(2), dim3(dev::DX_THREADS), [&] { dev::k_dec_repair_emit(jobs.data(), &tables, entries.data(), recs.data(), alts.data(), chunk_base.data(), sums.data(), &errors, repair_list.data(), reindex.data(), counters.data(), R, g_dx_stats); });
+		hipemu::launch(dim3(3), dim3(dev::DX_THREADS), [&] { dev::k_dec_reindex_emit(jobs.data(), &tables, entries.data(), reindex.data(), counters.data(), R, g_dx_stats); });
+	} else {
+		hipemu::launch(dim3(2), dim3(dev::DX_THREADS), [&] { dev::k_dec_repair(jobs.data(), &tables, entries.data(), recs.data(), alts.data(), chunk_base.data(), sums.data(), &errors, repair_list.data(), reindex.data(), counters.data(), g_dx_stats); });
+		hipemu::launch(dim3(3), dim3(dev::DX_THREADS), [&] { dev::k_dec_reindex(jobs.data(), &tables, entries.data(), reindex.data(), counters.data(), g_dx_stats, alts.data(), alt_entries.data()); });
+	}
 	g_dx_stats[12] = counters[1]; g_dx_stats[13] = counters[2];
 	std::vector<uint32_t> tile_start(tp.total + 1, 0xdeadbeefu);
 	hipemu::launch(dim3((tp.total + dev::DX_THREADS - 1) / dev::DX_THREADS), dim3(dev::DX_THREADS), [&] { dev::k_dec_tile_index(jobs.data(), tp, entries.data(), chunk_base.data(), sums.data(), tile_start.data()); });
-	hipemu::launch(dim3((unsigned)grid), dim3(dev::DX_TILE_THREADS), [&] { dev::k_dec_tiles(jobs.data(), tp, &tables, entries.data(), chunk_base.data(), sums.data(), tile_start.data(), (unsigned long long *)nullptr, 0u); });
+	auto tile_pass = [&](const dev::DxTilePlan &p_, unsigned long long *m_, uint32_t per_) {
+		if (emit) hipemu::launch(dim3((unsigned)grid), dim3(dev::DX_SC_THREADS), [&] { dev::k_dec_scatter(jobs.data(), p_, entries.data(), chunk_base.data(), sums.data(), tile_start.data(), R, m_, per_); });
+		else hipemu::launch(dim3((unsigned)grid), dim3(dev::DX_TILE_THREADS), [&] { dev::k_dec_tiles(jobs.data(), p_, &tables, entries.data(), chunk_base.data(), sums.data(), tile_start.data(), m_, per_); });
+	};
+	tile_pass(tp, nullptr, 0u);
 	if (!plan.interlaced && plan.encoded_format == ENC_YUV422) {
 		// the same tile pass with the level-1 highpass bands as block lists (what k_inv_yuv422_strip_blocks gathers): expanded again they must be the dense bands
 		const std::vector<int16_t> dense(pyr);
@@ -756,7 +771,7 @@ extern "C" int emu_entropy_decode_dx(const uint8_t *sample, size_t size, int pix
 		std::vector<unsigned long long> masks(per_frame * (size_t)nframes + 8, 0x5555555555555555ull);
 		const dev::DxTilePlan tl = dx_tile_plan(plan, dp, nframes, false, true);
 		for (int16_t &v : pyr) v = 0x0bad;             // (stale places must never be read back)
-		hipemu::launch(dim3((unsigned)grid), dim3(dev::DX_TILE_THREADS), [&] { dev::k_dec_tiles(jobs.data(), tl, &tables, entries.data(), chunk_base.data(), sums.data(), tile_start.data(), masks.data(), (uint32_t)per_frame); });
+		tile_pass(tl, masks.data(), (uint32_t)per_frame);
 		for (int f = 0; f < nframes; f++)
 			for (int c = 0; c < plan.num_channels; c++)
 				for (int b = 1; b < 4; b++) {

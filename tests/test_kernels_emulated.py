@@ -818,7 +818,21 @@ def test_fwd_frame_yuv422_interlaced_level1(w, h, dh, uyvy):
 # ---------------------------------------------------------------------------------------------------------------
 # Round-2 decoder (cfhd_dec_kernels.h: k_dec_plan / k_dec_index / k_dec_chain / k_dec_tiles), same kernel source under emulation
 # ---------------------------------------------------------------------------------------------------------------
+DX_ARRANGEMENT = 0      # + 16: the single-pass arrangement (k_dec_index_emit / k_dec_scatter); set per test by the `arrangement` fixture
+
+
+@pytest.fixture(params=[0, 16], ids=["index+tiles", "emit+scatter"])
+def arrangement(request):
+    """Both arrangements of the chunk-indexed decoder run every test of this section: the two-pass one (k_dec_index / k_dec_tiles) and the single-pass one of round 5
+    (k_dec_index_emit leaves the values as records per 64-bit piece, k_dec_scatter turns pieces into tiles)."""
+    global DX_ARRANGEMENT
+    DX_ARRANGEMENT = request.param
+    yield request.param
+    DX_ARRANGEMENT = 0
+
+
 def _dx_decode(sample, plan, mode, grid, size=None, guard=0):
+    mode |= DX_ARRANGEMENT
     E = emu()
     E.emu_entropy_decode_dx.argtypes = [c_u8p, ctypes.c_size_t, ctypes.c_int, c_i16p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int]
     got = np.full(plan.coeff_elems + guard, 99, dtype=np.int16)
@@ -829,7 +843,7 @@ def _dx_decode(sample, plan, mode, grid, size=None, guard=0):
 
 @pytest.mark.parametrize("mode,grid", [(0, 3), (1, 2), (2, 1), (0, 64)])
 @pytest.mark.parametrize("w,h,seed", [(192, 96, 1), (336, 252, 3), (720, 480, 4)])
-def test_dx_decoder_emulated_equals_host_decoder(w, h, seed, mode, grid):
+def test_dx_decoder_emulated_equals_host_decoder(w, h, seed, mode, grid, arrangement):
     """The chunk-indexed decoder reproduces the product's host VLC decoder coefficient for coefficient, every element of every band incl.
     its pitch padding written by the tile kernel itself.  mode 1 switches the run-in speculation off, so every chunk but a band's first
     assumes a wrong start and k_dec_chain has to repair it; mode 2 parses two copies of the sample with k_dec_parse / k_dec_plan."""
@@ -852,7 +866,7 @@ def test_dx_decoder_emulated_equals_host_decoder(w, h, seed, mode, grid):
         assert np.array_equal(plan.view(got, c, lv, b)[:, :cols], plan.view(want, c, lv, b)[:, :cols]), (c, lv, b)
 
 
-def test_dx_decoder_emulated_sparse_and_dense_bands():
+def test_dx_decoder_emulated_sparse_and_dense_bands(arrangement):
     """Extremes of the code: a band that is one single zero run (the tiles behind the first are never touched by a code word), a band with a
     value in every position (three bits per coefficient and more: many pieces per tile), values at the very first and very last position."""
     w, h = 336, 252
@@ -875,7 +889,7 @@ def test_dx_decoder_emulated_sparse_and_dense_bands():
             assert np.array_equal(plan.view(got, c, lv, b), plan.view(want, c, lv, b)), (mode, c, lv, b)
 
 
-def test_dx_decoder_emulated_code_without_unique_alignment():
+def test_dx_decoder_emulated_code_without_unique_alignment(arrangement):
     """A smooth gradient gives a band the same value in every position: the same code word over and over, a bit pattern that parses
     consistently at several alignments, so no lane can find its phase on its own and the true starts travel through a chunk lane by lane
     (and from chunk to chunk through k_dec_chain's repair path).  The result must still be exact."""
@@ -903,7 +917,7 @@ def test_dx_decoder_emulated_code_without_unique_alignment():
 
 
 @pytest.mark.parametrize("mode", [0, 2])
-def test_dx_decoder_emulated_survives_damaged_samples(mode):
+def test_dx_decoder_emulated_survives_damaged_samples(mode, arrangement):
     """Truncated samples are refused; garbage inside the code words never writes outside the pyramid nor hangs (error flag or wrong values, no crash)."""
     w, h = 336, 252
     frame, pitch = synth_yuy2(w, h, 5)
@@ -929,7 +943,7 @@ def test_dx_decoder_emulated_survives_damaged_samples(mode):
 # Interlaced samples: code set 18 + difference coding + peak tables (k_dec_parse / k_dec_tiles / k_dec_undiff), inverse frame transform
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("w,h,seed,peaks", [(192, 96, 1, 0), (336, 252, 3, 1), (720, 480, 4, 1)])
-def test_dx_decoder_emulated_interlaced_samples(w, h, seed, peaks):
+def test_dx_decoder_emulated_interlaced_samples(w, h, seed, peaks, arrangement):
     """The field-difference band of every channel arrives in the second code set, difference coded along the row and -- when a value lies
     beyond the peak threshold -- with its large values in a peak table behind the band.  The emulated kernels must rebuild exactly the
     pyramid of the product's host decoder (pinned against the reference's by test_oracle_vs_ref / test_host_bitstream)."""
@@ -1108,7 +1122,7 @@ def test_fwd_packed16_level1_of_v210(w, h, dh):
 
 
 @pytest.mark.parametrize("interlaced", [0, 1])
-def test_dx_decoder_emulated_fuzzed_samples(interlaced):
+def test_dx_decoder_emulated_fuzzed_samples(interlaced, arrangement):
     """Random damage anywhere in a sample -- headers, size fields, peak table tags, code words, single bit flips, truncation: the kernels
     (device parser included) either flag an error or decode something, never write outside the pyramid and never hang."""
     w, h = 192, 96
