@@ -77,7 +77,9 @@ enum {
 	DX_KE = 11,                       // bits of the window of its table (emit11: 8 bytes per window, 16 KB like the 12-bit table of 4-byte entries it replaces in LDS)
 	DX_REC_SLOT = 32,                 // dwords of a piece's record slot (one 128-byte line): at most 22 code words of a value start in 64 bits (3 bits the shortest), + the step's spare word
 	DX_REC_MAX = 22,
-	DX_REC_CHUNK = DX_ENTRY_STRIDE * DX_REC_SLOT,      // dwords of a chunk's record slots (lane-major like the entries: lane t's four pieces at 4 t .. 4 t + 3)
+	DX_REC_CHUNK = DX_ENTRY_STRIDE * DX_REC_SLOT,      // dwords of a wave's scratch slots (lane-major like the entries: lane t's four pieces at 4 t .. 4 t + 3)
+	DX_DENSE_GROUP = 4,               // records per 16-byte group: a piece's records leave the scratch slots as whole groups, packed piece behind piece
+	DX_DENSE_CHUNK = DX_CHUNK_SUBS * ((DX_REC_MAX + DX_DENSE_GROUP - 1) / DX_DENSE_GROUP) * DX_DENSE_GROUP,      // dwords of a chunk's packed records, worst case (24 KB; the part in use is contiguous from its start)
 };
 enum : uint32_t { DX_END = 0xFFFFFFFFu, DX_BAD = 0xFFFFFFFEu, DX_SPECIAL = 0xFFFFFFFEu };
 enum { DX_FLAG_END = 1, DX_FLAG_BAD = 2, DX_FLAG_UNRESOLVED = 4, DX_ERR_BAD = 1 << 1, DX_ERR_OVERFLOW = 1 << 2, DX_ERR_NOEND = 1 << 3, DX_ERR_SPACE = 1 << 4 };
@@ -118,7 +120,7 @@ struct DxChunkRec { uint32_t start, end, count, flags; };   // start / end: bit 
 // A chunk in front of which the code has no unique alignment (its run-in from every possible offset leaves several candidates for its first
 // code word) is indexed once per candidate: the record holds candidate 0 (the entries are written for it), this the others.
 enum { DX_MAX_ALT = 3 };
-struct DxChunkAlt { uint32_t start[DX_MAX_ALT], end[DX_MAX_ALT], count[DX_MAX_ALT]; uint32_t slot; };      // slot: the candidates' entries sit in alt_entries[slot + q] (DX_BAD: not kept)
+struct DxChunkAlt { uint32_t start[DX_MAX_ALT], end[DX_MAX_ALT], count[DX_MAX_ALT]; uint32_t slot; uint32_t groups[DX_MAX_ALT]; /* k_dec_index_emit: 16-byte groups of the candidate's packed records */ };      // slot: the candidates' entries sit in alt_entries[slot + q] (DX_BAD: not kept)
 struct DxReindex { uint32_t chunk, k, start; int job; };      // a chunk whose entries have to be written again for the start that turned out to be the true one
 struct DxBandSum { uint32_t total; int last_chunk; };        // coefficients the band's code words cover; chunk that holds the band end marker
 
@@ -820,8 +822,12 @@ __global__ void __launch_bounds__(DX_THREADS) k_dec_reindex(const DxBandJob *job
 // code word << 16 | value, expanded, not yet multiplied by the band's divisor) of the values whose code words start in the piece, in raster
 // order.  Positions relative to the PIECE are what makes this fit the speculative walk: when a lane's second walk meets its first at a 64-bit
 // mark, the pieces behind the mark keep their records as they keep their entries -- only the counts in front of them shift, and those live in
-// the entries.  A piece that is walked again has all its records written again (same lane, same addresses, program order).  k_dec_scatter
-// then turns pieces into tiles without a code table: entry + chunk position + records -> LDS image of the tile -> 16-byte stores.
+// the entries.  A piece that is walked again has all its records written again (same lane, same addresses, program order).
+// The slots are scratch memory of the WAVE (32 KB, written again for every chunk the wave indexes, so they live in the caches: the first build
+// gave every chunk its own slots and made the tile pass fetch a 128-byte line for 22 bytes of records -- 3.8 GB per 512 frames, as slow as decoding).
+// When a chunk's walk has settled every lane copies its pieces' records, as whole 16-byte groups, into the chunk's packed record stream, piece
+// behind piece (a wave scan over the group counts gives the places), and leaves per piece where its records start and how many they are.
+// k_dec_scatter then turns pieces into tiles without a code table: entry + chunk position + records -> LDS image of the tile -> 16-byte stores.
 //
 // Two records leave per step in one 8-byte store at the piece's next free place (the table entry of a step holds at most two values): the ones
 // the step does not have are overwritten by the next step's or lie behind the piece's count.  22 values at most start in 64 bits, the store
@@ -989,11 +995,13 @@ __device__ __forceinline__ int dx_runin_candidates_e(const uint32_t bytes, const
 	return n;
 }
 
-// dx_index_staged with the records: rec_chunk = the record slots the walk writes (the chunk's own, or a scratch chunk for a walk whose records nobody reads),
-// nrecs = per lane of the chunk the four record counts (one byte each), written with the entries
+// dx_index_staged with the records: scratch = this wave's record slots, dense / pmeta = where the chunk's packed records and their per-piece places go
+// (entry slot gchunk of their arrays, like the entries; null: the walk is wanted for its outcome only).  *groups_out: 16-byte groups of packed records.
 __device__ __forceinline__ DxChunkRec dx_index_staged_e(const uint32_t bytes, const uint32_t gchunk, const uint32_t k, const uint32_t exact_start, const uint32_t *s_words, const uint2 *s_tab,
-                                                        const uint32_t *s_long, const bool linear, uint32_t *entries, uint32_t *rec_chunk, uint32_t *nrecs, uint32_t *stats = nullptr)
+                                                        const uint32_t *s_long, const bool linear, uint32_t *entries, uint32_t *scratch, uint32_t *dense, uint32_t *pmeta, uint32_t *stats = nullptr,
+                                                        uint32_t *groups_out = nullptr)
 {
+	uint32_t *const rec_chunk = scratch;
 	const int lane = wave_lane();
 	const uint32_t nwords = bytes >> 2;
 	const int64_t first = (int64_t)k * DX_CHUNK_WORDS - (DX_LANE_BITS / 32);
@@ -1074,7 +1082,30 @@ __device__ __forceinline__ DxChunkRec dx_index_staged_e(const uint32_t bytes, co
 		for (int j = 0; j < DX_SUBS; j++) v[j] = (!live || dx_off_get(L.rec_offs, j) == (uint32_t)DX_OFF_INVALID) ? (uint32_t)DX_OFF_INVALID : (dx_off_get(L.rec_offs, j) | ((before + L.rec_cnt[j]) << 5));
 		e.x = v[0]; e.y = v[1]; e.z = v[2]; e.w = v[3];
 		*(uint4 *)(entries + slot) = e;
-		if (nrecs) nrecs[(size_t)gchunk * 64 + (size_t)lane] = L.rec_n;
+	}
+	if (entries && dense) {
+		// the records leave the scratch slots: whole groups of four, piece behind piece in the chunk's packed stream; per piece (16 bits) first group << 5 | records
+		uint32_t nj[DX_SUBS], gj[DX_SUBS], groups = 0;
+#pragma unroll
+		for (int j = 0; j < DX_SUBS; j++) {
+			nj[j] = (lane >= 1 && live && dx_off_get(L.rec_offs, j) != (uint32_t)DX_OFF_INVALID) ? dx_off_get(L.rec_n, j) : 0u;
+			if (nj[j] > (uint32_t)DX_REC_MAX) nj[j] = (uint32_t)DX_REC_MAX;
+			gj[j] = (nj[j] + (uint32_t)DX_DENSE_GROUP - 1u) / (uint32_t)DX_DENSE_GROUP;
+			groups += gj[j];
+		}
+		const uint32_t gincl = wave_incl_scan(groups);
+		uint32_t at = gincl - groups;
+		uint32_t m[DX_SUBS];
+		uint4 *const out = (uint4 *)(dense + (size_t)gchunk * DX_DENSE_CHUNK);
+#pragma unroll
+		for (int j = 0; j < DX_SUBS; j++) {
+			m[j] = (at << 5) | nj[j];
+			const uint4 *src = (const uint4 *)(lane_slots + j * DX_REC_SLOT);
+			for (uint32_t i = 0; i < gj[j]; i++) out[at + i] = src[i];
+			at += gj[j];
+		}
+		if (lane >= 1) { uint2 pm; pm.x = m[0] | (m[1] << 16); pm.y = m[2] | (m[3] << 16); *(uint2 *)(pmeta + ((size_t)gchunk * 64 + (size_t)lane) * 2) = pm; }
+		if (groups_out) *groups_out = wave_get(gincl, 63);
 	}
 	const uint32_t total = wave_get(incl, 63), el = wave_get(L.end, last_live);
 	DxChunkRec r;
@@ -1086,9 +1117,11 @@ __device__ __forceinline__ DxChunkRec dx_index_staged_e(const uint32_t bytes, co
 	return r;
 }
 
-// What the emitting kernels share: the record slots of all chunks (DX_REC_CHUNK words each; one more chunk's worth behind them as scratch for walks whose
-// records nobody reads -- the extra candidates of a chunk without a unique alignment) and the record counts (64 words per chunk).
-struct DxRecords { uint32_t *slots; uint32_t *nrecs; uint32_t scratch_chunk; };
+// What the emitting kernels share: scratch record slots (DX_REC_CHUNK words per wave of the largest grid, indexed by the wave's number in its launch), the packed
+// records of every chunk (DX_DENSE_CHUNK words each) and their per-piece places (128 words per chunk: 16 bits per piece, lane-major like the entries), and the same for
+// the extra candidates of chunks without a unique alignment (alternate slots, as alt_entries).
+struct DxRecords { uint32_t *scratch; uint32_t *dense; uint32_t *pmeta; uint32_t *alt_dense; uint32_t *alt_pmeta; };
+__device__ __forceinline__ uint32_t *dx_wave_scratch(const DxRecords &R) { return R.scratch + (size_t)((uint32_t)blockIdx.x * DX_WAVES + (uint32_t)(threadIdx.x >> 6)) * DX_REC_CHUNK; }
 
 __device__ __attribute__((noinline)) DxChunkRec dx_index_chunk_e(const uint8_t *bits, const uint32_t bytes, const uint32_t gchunk, const uint32_t k, const uint32_t exact_start, uint32_t *s_words,
                                                                  const uint2 *s_tab, const uint32_t *s_long, const bool linear, uint32_t *entries, DxChunkRec *recs, const DxRecords R, uint32_t *stats)
@@ -1096,7 +1129,7 @@ __device__ __attribute__((noinline)) DxChunkRec dx_index_chunk_e(const uint8_t *
 	DxFetch F;
 	dx_fetch_chunk(bits, bytes, k, F);
 	dx_store_stage(F, s_words);
-	const DxChunkRec r = dx_index_staged_e(bytes, gchunk, k, exact_start, s_words, s_tab, s_long, linear, entries, R.slots + (size_t)gchunk * DX_REC_CHUNK, R.nrecs, stats);
+	const DxChunkRec r = dx_index_staged_e(bytes, gchunk, k, exact_start, s_words, s_tab, s_long, linear, entries, dx_wave_scratch(R), R.dense, R.pmeta, stats);
 	if (wave_lane() == 0 && recs) recs[gchunk] = r;
 	return r;
 }
@@ -1113,10 +1146,11 @@ __device__ __forceinline__ void dx_load_tables_wave_e(const DecIdxTables *T, uin
 	for (int i = lane; i < DX_LONG11_MAX; i += 64) s_long[i] = T->long11[i];
 }
 
-// k_dec_index with the records.  The extra candidates of a chunk without a unique alignment are walked for their outcome only (records into the scratch chunk, no
-// entries kept): when k_dec_chain finds one of them to be the true start, k_dec_reindex_emit walks the chunk again from there.
+// k_dec_index with the records.  The extra candidates of a chunk without a unique alignment keep their entries AND their packed records in alternate slots (while there
+// is room): when k_dec_chain finds one of them to be the true start, k_dec_reindex_emit copies both instead of walking the chunk again.
 __global__ void __launch_bounds__(DX_THREADS) CFHD_DX_INDEX_ATTR k_dec_index_emit(const DxChunkDesc *chunk_desc, const uint32_t *counters, const DecIdxTables *T,
-                                                               uint32_t *entries, DxChunkRec *recs, DxChunkAlt *alts, int speculate, uint32_t *stats, const DxRecords R, uint32_t *next_chunk)
+                                                               uint32_t *entries, DxChunkRec *recs, DxChunkAlt *alts, int speculate, uint32_t *stats, const DxRecords R,
+                                                               uint32_t *alt_entries, uint32_t alt_slots, uint32_t *alt_counter, uint32_t *next_chunk)
 {
 	__shared__ uint2 s_tab[1 << DX_KE];
 	__shared__ uint32_t s_long[DX_LONG11_MAX];
@@ -1152,19 +1186,29 @@ __global__ void __launch_bounds__(DX_THREADS) CFHD_DX_INDEX_ATTR k_dec_index_emi
 		} else {
 			const bool unresolved = n > DX_MAX_ALT + 1;
 			if (unresolved) n = 1;
-			DxChunkRec r = dx_index_staged_e(d.bytes, c, d.k, cand[0], s_words, s_tab, s_long, linear, entries, R.slots + (size_t)c * DX_REC_CHUNK, R.nrecs, stats);
+			uint32_t *const scratch = dx_wave_scratch(R);
+			DxChunkRec r = dx_index_staged_e(d.bytes, c, d.k, cand[0], s_words, s_tab, s_long, linear, entries, scratch, R.dense, R.pmeta, stats);
 			r.flags |= ((uint32_t)n << 8) | (unresolved ? (uint32_t)DX_FLAG_UNRESOLVED : 0u);
 			if (wave_lane() == 0) recs[c] = r;
 			if (n > 1) {
 				DxChunkAlt a;
 #pragma unroll
-				for (int i = 0; i < DX_MAX_ALT; i++) { a.start[i] = DX_BAD; a.end[i] = DX_BAD; a.count[i] = 0; }
-				a.slot = DX_BAD;
+				for (int i = 0; i < DX_MAX_ALT; i++) { a.start[i] = DX_BAD; a.end[i] = DX_BAD; a.count[i] = 0; a.groups[i] = 0; }
+				uint32_t slot0 = DX_BAD;
+				if (alt_entries) {
+					if (wave_lane() == 0) slot0 = atomicAdd(alt_counter, (uint32_t)(n - 1));
+					slot0 = wave_get(slot0, 0);
+					if (slot0 + (uint32_t)(n - 1) > alt_slots) slot0 = DX_BAD;
+				}
+				a.slot = slot0;
 #pragma unroll 1
 				for (int i = 1; i < n; i++) {
-					const DxChunkRec ri = dx_index_staged_e(d.bytes, c, d.k, cand[i], s_words, s_tab, s_long, linear, nullptr, R.slots + (size_t)R.scratch_chunk * DX_REC_CHUNK, nullptr, nullptr);
+					const bool keep = slot0 != (uint32_t)DX_BAD;
+					uint32_t groups = 0;
+					const DxChunkRec ri = dx_index_staged_e(d.bytes, keep ? slot0 + (uint32_t)(i - 1) : c, d.k, cand[i], s_words, s_tab, s_long, linear, keep ? alt_entries : nullptr, scratch,
+					                                        keep ? R.alt_dense : nullptr, keep ? R.alt_pmeta : nullptr, nullptr, &groups);
 #pragma unroll
-					for (int q = 0; q < DX_MAX_ALT; q++) if (q == i - 1) { a.start[q] = ri.start; a.end[q] = ri.end; a.count[q] = ri.count; }
+					for (int q = 0; q < DX_MAX_ALT; q++) if (q == i - 1) { a.start[q] = ri.start; a.end[q] = ri.end; a.count[q] = ri.count; a.groups[q] = groups; }
 				}
 				if (wave_lane() == 0) alts[c] = a;
 				if (stats && wave_lane() == 0) atomicAdd(&stats[3], 1u << 16);
@@ -1201,7 +1245,7 @@ __global__ void __launch_bounds__(DX_THREADS) k_dec_repair_emit(const DxBandJob 
 }
 
 __global__ void __launch_bounds__(DX_THREADS) k_dec_reindex_emit(const DxBandJob *jobs, const DecIdxTables *T, uint32_t *entries, const DxReindex *reindex_list, const uint32_t *counters,
-                                                                 const DxRecords R, uint32_t *stats)
+                                                                 const DxRecords R, uint32_t *stats, const DxChunkAlt *alts, const uint32_t *alt_entries)
 {
 	__shared__ uint2 s_tab[1 << DX_KE];
 	__shared__ uint32_t s_long[DX_LONG11_MAX];
@@ -1212,6 +1256,29 @@ __global__ void __launch_bounds__(DX_THREADS) k_dec_reindex_emit(const DxBandJob
 	bool tables = false;
 	for (uint32_t i = (uint32_t)blockIdx.x * DX_WAVES + (uint32_t)wave; i < n; i += (uint32_t)gridDim.x * DX_WAVES) {
 		const DxReindex x = reindex_list[i];
+		// the usual case: k_dec_index_emit kept this candidate's entries and packed records -- copy them into the chunk's place
+		if (alts && alt_entries) {
+			const DxChunkAlt a = alts[x.chunk];
+			int q = -1;
+#pragma unroll
+			for (int k = 0; k < DX_MAX_ALT; k++) if (q < 0 && a.start[k] == x.start) q = k;
+			if (q >= 0 && a.slot != (uint32_t)DX_BAD) {
+				const int lane = wave_lane();
+				const size_t from = (size_t)a.slot + (size_t)q;
+				const uint4 *src = (const uint4 *)(alt_entries + from * DX_ENTRY_STRIDE);
+				uint4 *dst = (uint4 *)(entries + (size_t)x.chunk * DX_ENTRY_STRIDE);
+				if (lane >= 1) dst[lane] = src[lane];
+				const uint2 *pms = (const uint2 *)(R.alt_pmeta + from * 128); uint2 *pmd = (uint2 *)(R.pmeta + (size_t)x.chunk * 128);
+				if (lane >= 1) pmd[lane] = pms[lane];
+				uint32_t groups = 0;
+#pragma unroll
+				for (int k = 0; k < DX_MAX_ALT; k++) if (k == q) groups = a.groups[k];
+				const uint4 *ds = (const uint4 *)(R.alt_dense + from * DX_DENSE_CHUNK); uint4 *dd = (uint4 *)(R.dense + (size_t)x.chunk * DX_DENSE_CHUNK);
+				for (uint32_t g = (uint32_t)lane; g < groups; g += 64) dd[g] = ds[g];
+				if (stats && lane == 0) atomicAdd(&stats[3], 1u << 8);
+				continue;
+			}
+		}
 		if (!tables) { dx_load_tables_wave_e(T, s_tab, s_long); tables = true; CFHD_WAVE_SYNC(); }
 		const DxBandJob job = jobs[x.job];
 		dx_index_chunk_e(job.bits, job.bytes, x.chunk, x.k, x.start, s_words_all[wave], s_tab, s_long, (job.table & 1) != 0, entries, nullptr, R, nullptr);
@@ -1467,16 +1534,17 @@ __global__ void __launch_bounds__(DX_TILE_THREADS) k_dec_tiles(const DxBandJob *
 #define CFHD_DX_SC_THREADS 256
 #endif
 enum { DX_SC_THREADS = CFHD_DX_SC_THREADS, DX_SC_WAVES = DX_SC_THREADS / 64 };
-struct DxScPieces { uint32_t ent, cb, nrec, idx; };
-__device__ __forceinline__ void dx_scatter_pieces(const DxTileMeta &M, uint32_t q, uint32_t last_sub, const uint32_t *entries, const uint32_t *chunk_base, const uint8_t *nrecb, DxScPieces &P)
+struct DxScPieces { uint32_t ent, cb, pm, chunk; };      // pm: the piece's place in its chunk's packed records (first group << 5 | records)
+__device__ __forceinline__ void dx_scatter_pieces(const DxTileMeta &M, uint32_t q, uint32_t last_sub, const uint32_t *entries, const uint32_t *chunk_base, const uint16_t *pmeta16, DxScPieces &P)
 {
-	P.ent = DX_OFF_INVALID; P.cb = 0; P.nrec = 0; P.idx = 0;
+	P.ent = DX_OFF_INVALID; P.cb = 0; P.pm = 0; P.chunk = 0;
 	if (q < last_sub) {
 		const uint32_t kq = q / DX_CHUNK_SUBS, within = q - kq * DX_CHUNK_SUBS;
-		P.idx = (M.job.chunk0 + kq) * DX_ENTRY_STRIDE + DX_SUBS + within;
-		P.ent = entries[P.idx];
-		P.cb = chunk_base[(size_t)M.job.chunk0 + kq];
-		P.nrec = nrecb[P.idx];
+		P.chunk = M.job.chunk0 + kq;
+		const size_t idx = (size_t)P.chunk * DX_ENTRY_STRIDE + DX_SUBS + within;
+		P.ent = entries[idx];
+		P.cb = chunk_base[P.chunk];
+		P.pm = pmeta16[idx];
 	}
 }
 
@@ -1491,7 +1559,7 @@ __global__ void __launch_bounds__(DX_SC_THREADS) k_dec_scatter(const DxBandJob *
 	const uint32_t gwave = (uint32_t)blockIdx.x * DX_SC_WAVES + (uint32_t)wave, nwaves = (uint32_t)gridDim.x * DX_SC_WAVES;
 	uint32_t t = plan.first + gwave;
 	if (t >= plan.total) return;
-	const uint8_t *nrecb = (const uint8_t *)R.nrecs;
+	const uint16_t *nrecb = (const uint16_t *)R.pmeta;
 	// software pipeline as in k_dec_tiles: the descriptors of tile t + 2 nwaves and the piece entries of tile t + nwaves are on their way while tile t is filled
 	int slot = 0;
 	DxTileMeta M, M1;
@@ -1527,9 +1595,9 @@ __global__ void __launch_bounds__(DX_SC_THREADS) k_dec_scatter(const DxBandJob *
 					const uint32_t idx0 = P.cb + (P.ent >> 5);
 					const bool valid = active && off != (uint32_t)DX_OFF_INVALID;
 					const bool inside = valid && idx0 < T1;
-					const uint32_t n = inside ? (P.nrec <= (uint32_t)DX_REC_MAX ? P.nrec : (uint32_t)DX_REC_MAX) : 0u;
+					const uint32_t n = inside ? ((P.pm & 31u) <= (uint32_t)DX_REC_MAX ? P.pm & 31u : (uint32_t)DX_REC_MAX) : 0u;
 					const uint32_t rel = idx0 - T0;                    // "negative" (the piece starts in front of the tile) wraps to a huge number: those places go to the dump slot
-					const uint32_t *recs = R.slots + (size_t)P.idx * DX_REC_SLOT;
+					const uint32_t *recs = R.dense + (size_t)P.chunk * DX_DENSE_CHUNK + (size_t)(P.pm >> 5) * DX_DENSE_GROUP;
 #pragma unroll 1
 					for (uint32_t k = 0; __ballot(k < n) != 0ull; k += 4) {
 						cfhd_u4 r = { 0u, 0u, 0u, 0u };

@@ -242,8 +242,8 @@ GpuEntropyDecoder::~GpuEntropyDecoder() { release(); delete host_; }
 void GpuEntropyDecoder::release()
 {
 	(void)hipSetDevice(device_);
-	void *dev[] = { d_samples_, d_tables_, d_bandjobs_, d_lowjobs_, d_errors_, d_plan_, d_idx_tables_, d_entries_, d_recs_, d_chunk_base_, d_chunk_job_, d_sums_, d_counters_, d_tile_start_, d_stats_, d_repair_, d_alts_, d_reindex_, d_diffjobs_, d_alt_entries_, d_masks_, d_records_, d_nrecs_ };
-	d_masks_ = nullptr; d_records_ = d_nrecs_ = nullptr; masks_per_frame_ = 0; use_blocks_ = false; blocks_written_ = false;
+	void *dev[] = { d_samples_, d_tables_, d_bandjobs_, d_lowjobs_, d_errors_, d_plan_, d_idx_tables_, d_entries_, d_recs_, d_chunk_base_, d_chunk_job_, d_sums_, d_counters_, d_tile_start_, d_stats_, d_repair_, d_alts_, d_reindex_, d_diffjobs_, d_alt_entries_, d_masks_, d_scratch_, d_dense_, d_pmeta_, d_alt_dense_, d_alt_pmeta_ };
+	d_masks_ = nullptr; d_scratch_ = d_dense_ = d_pmeta_ = d_alt_dense_ = d_alt_pmeta_ = nullptr; masks_per_frame_ = 0; use_blocks_ = false; blocks_written_ = false;
 	for (void *p : dev) if (p) (void)hipFree(p);
 	d_idx_tables_ = d_entries_ = d_recs_ = d_chunk_base_ = d_chunk_job_ = d_sums_ = d_counters_ = d_tile_start_ = d_stats_ = d_repair_ = d_alts_ = d_reindex_ = d_diffjobs_ = d_alt_entries_ = nullptr;
 	if (h_chunk_job_) (void)hipHostFree(h_chunk_job_);
@@ -307,10 +307,12 @@ int GpuEntropyDecoder::prepare(const FramePlan &plan, int nframes, int16_t *d_co
 		alt_slots_ = max_chunks_ / 8 > 64u ? max_chunks_ / 8 : 64u;          // entries of the extra candidates of chunks without a unique alignment (a few per cent of the chunks)
 		HIPCHK(hipMalloc(&d_alt_entries_, (size_t)alt_slots_ * dev::DX_ENTRY_STRIDE * 4));
 		if (emit_) {
-			// one 128-byte record slot per 64-bit piece of the worst-case sample (32 KB per chunk; only the slots of real pieces are ever touched: about a ninth at the
-			// benchmark's quality) + one chunk's worth of scratch, and the record counts (a byte per piece)
-			HIPCHK(hipMalloc(&d_records_, ((size_t)max_chunks_ + 1) * dev::DX_REC_CHUNK * 4));
-			HIPCHK(hipMalloc(&d_nrecs_, (size_t)max_chunks_ * 64 * 4));
+			// the packed records of every chunk of the worst-case sample (24 KB per chunk; only the part in use is ever touched: about 7 KB of a full chunk at the
+			// benchmark's quality), 16 bits per piece for their places, the same for the alternate slots; the waves' scratch slots are allocated below with the grid
+			HIPCHK(hipMalloc(&d_dense_, (size_t)max_chunks_ * dev::DX_DENSE_CHUNK * 4));
+			HIPCHK(hipMalloc(&d_pmeta_, (size_t)max_chunks_ * 128 * 4));
+			HIPCHK(hipMalloc(&d_alt_dense_, (size_t)alt_slots_ * dev::DX_DENSE_CHUNK * 4));
+			HIPCHK(hipMalloc(&d_alt_pmeta_, (size_t)alt_slots_ * 128 * 4));
 		}
 		{
 			dev::DecPlan dp0; dec_build_plan(plan, out_kind, &dp0);
@@ -328,6 +330,7 @@ int GpuEntropyDecoder::prepare(const FramePlan &plan, int nframes, int16_t *d_co
 		if (emit_ && !g3) grid_tiles_ = cus * (int)((160 * 1024) / (sizeof(uint32_t) * dev::DX_TILE_WORDS * dev::DX_SC_WAVES));      // k_dec_scatter: 8 KB of LDS per wave
 		if (grid_index_ < 1) grid_index_ = 1;
 		if (grid_tiles_ < 1) grid_tiles_ = 1;
+		if (emit_) HIPCHK(hipMalloc(&d_scratch_, (size_t)(grid_index_ > 64 ? grid_index_ : 64) * dev::DX_WAVES * dev::DX_REC_CHUNK * 4));      // 32 KB per wave of the largest launch that indexes (k_dec_index_emit; k_dec_repair_emit: 64 workgroups)
 	}
 	{
 		dev::DecPlan dp;
@@ -519,9 +522,9 @@ int GpuEntropyDecoder::launch_dx(bool device_jobs, int njobs, uint32_t host_chun
 	if ((uint32_t)g3 * tile_waves > tp.total) g3 = (int)((tp.total + tile_waves - 1) / tile_waves);
 	if (g1 < 1) g1 = 1;
 	if (g3 < 1) g3 = 1;
-	const dev::DxRecords R = { (uint32_t *)d_records_, (uint32_t *)d_nrecs_, max_chunks_ };
+	const dev::DxRecords R = { (uint32_t *)d_scratch_, (uint32_t *)d_dense_, (uint32_t *)d_pmeta_, (uint32_t *)d_alt_dense_, (uint32_t *)d_alt_pmeta_ };
 	if (emit_) dev::k_dec_index_emit<<<g1, dev::DX_THREADS, 0, st>>>((const dev::DxChunkDesc *)d_chunk_job_, (const uint32_t *)d_counters_, T, (uint32_t *)d_entries_, (dev::DxChunkRec *)d_recs_, (dev::DxChunkAlt *)d_alts_,
-	                                                                 speculate ? 1 : 0, (uint32_t *)d_stats_, R, (uint32_t *)d_counters_ + 4);
+	                                                                 speculate ? 1 : 0, (uint32_t *)d_stats_, R, (uint32_t *)d_alt_entries_, alt_slots_, (uint32_t *)d_counters_ + 3, (uint32_t *)d_counters_ + 4);
 	else dev::k_dec_index<<<g1, dev::DX_THREADS, 0, st>>>((const dev::DxChunkDesc *)d_chunk_job_, (const uint32_t *)d_counters_, T, (uint32_t *)d_entries_, (dev::DxChunkRec *)d_recs_, (dev::DxChunkAlt *)d_alts_, speculate ? 1 : 0, (uint32_t *)d_stats_,
 	                                                 (uint32_t *)d_alt_entries_, alt_slots_, (uint32_t *)d_counters_ + 3, (uint32_t *)d_counters_ + 4);
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[5], st));
@@ -531,7 +534,8 @@ int GpuEntropyDecoder::launch_dx(bool device_jobs, int njobs, uint32_t host_chun
 	if (emit_) {
 		dev::k_dec_repair_emit<<<small_grid, dev::DX_THREADS, 0, st>>>(jobs, T, (uint32_t *)d_entries_, (dev::DxChunkRec *)d_recs_, (const dev::DxChunkAlt *)d_alts_, (uint32_t *)d_chunk_base_, (dev::DxBandSum *)d_sums_,
 		                                                              d_errors_, (const uint32_t *)d_repair_, (dev::DxReindex *)d_reindex_, (uint32_t *)d_counters_, R, (uint32_t *)d_stats_);
-		dev::k_dec_reindex_emit<<<g1, dev::DX_THREADS, 0, st>>>(jobs, T, (uint32_t *)d_entries_, (const dev::DxReindex *)d_reindex_, (const uint32_t *)d_counters_, R, (uint32_t *)d_stats_);
+		dev::k_dec_reindex_emit<<<g1, dev::DX_THREADS, 0, st>>>(jobs, T, (uint32_t *)d_entries_, (const dev::DxReindex *)d_reindex_, (const uint32_t *)d_counters_, R, (uint32_t *)d_stats_,
+		                                                        (const dev::DxChunkAlt *)d_alts_, (const uint32_t *)d_alt_entries_);
 	} else {
 	dev::k_dec_repair<<<small_grid, dev::DX_THREADS, 0, st>>>(jobs, T, (uint32_t *)d_entries_, (dev::DxChunkRec *)d_recs_, (const dev::DxChunkAlt *)d_alts_, (uint32_t *)d_chunk_base_, (dev::DxBandSum *)d_sums_,
 	                                                         d_errors_, (const uint32_t *)d_repair_, (dev::DxReindex *)d_reindex_, (uint32_t *)d_counters_, (uint32_t *)d_stats_);

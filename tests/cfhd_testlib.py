@@ -233,12 +233,18 @@ class RefDecoder:
 
 def ref_decode_sample(sample, width, height, pixfmt=PIX_YUY2, resolution=1, cpus=1):
     """Decode through the reference's C ABI (resolution 1 = full, 2 = half) with `cpus` decoder worker threads (RefDecoder)."""
+    if _REF_FRESH_PROCESS and not _IN_FRESH_CHILD:             # reference_leg escalated: this process's reference state is suspect, ask a fresh one
+        return ref_decode_sample_fresh_process(sample, width, height, pixfmt, resolution, cpus)
     d = RefDecoder(sample, pixfmt, resolution, cpus)
     sb = ctypes.create_string_buffer(sample, len(sample))
     out = np.zeros(d.pitch * d.height + 64, dtype=np.uint8)
     assert d.decode(sb, len(sample), out) == 0
     d.close()
     return out[: d.pitch * d.height].copy(), d.pitch
+
+
+_REF_FRESH_PROCESS = False       # set by reference_leg() while it repeats a leg with the reference in a fresh process
+_IN_FRESH_CHILD = bool(os.environ.get("CFHD_TEST_FRESH_CHILD"))
 
 
 def ref_decode_sample_fresh_process(sample, width, height, pixfmt=PIX_YUY2, resolution=1, cpus=1, env_pad=None):
@@ -254,39 +260,68 @@ def ref_decode_sample_fresh_process(sample, width, height, pixfmt=PIX_YUY2, reso
         # env_pad: run the child with a minimal environment + a variable of that many bytes.  (Found in round 4: the answer of that route also depends on the size of the
         # process's environment block -- an extra variable in os.environ flipped it -- i.e. on stack contents the reference never initialised; a caller that pins
         # arithmetic on such a route tries a few sizes.)
-        env = None if env_pad is None else {"PATH": os.environ.get("PATH", "/usr/bin:/bin"), "HOME": os.environ.get("HOME", "/tmp"), "CFHD_TEST_PAD": "x" * env_pad}
+        env = dict(os.environ, CFHD_TEST_FRESH_CHILD="1") if env_pad is None else {"PATH": os.environ.get("PATH", "/usr/bin:/bin"), "HOME": os.environ.get("HOME", "/tmp"), "CFHD_TEST_PAD": "x" * env_pad, "CFHD_TEST_FRESH_CHILD": "1"}
         pitch = int(subprocess.check_output([sys.executable, "-c", code], env=env).split()[-1])
         return np.frombuffer(open(os.path.join(d, "out"), "rb").read(), np.uint8).copy(), pitch
 
 
-REFERENCE_DISAGREEMENTS = []      # (what, detail) of every live-reference leg that never agreed; tests/conftest.py prints them at the end of the run
+REFERENCE_DISAGREEMENTS = []      # (test, route, detail) of every live-reference leg that never agreed, not even with the reference in a fresh process
+REFERENCE_ROUTES = {}             # route ("what") -> [legs that agreed in this process, legs that agreed only with the reference in a fresh process, legs that never agreed]
 
 
 def reference_leg(agree, attempts=6, what=""):
     """The live-reference leg of a GPU test.  The *gate* of such a test is product == oracle (the oracle's model of the route is pinned on the reference by
     tests/test_oracle_vs_ref.py on the CPU, where the reference runs with one worker on a quiet 8-core host); this leg runs the reference decoder once more on
     the GPU box beside it as a witness.  `agree()` runs the reference and returns True (or None) when its output agrees with what the test holds, False or a
-    string (the detail) otherwise.  The reference decoder is a threaded third party with a rand() dither and uninitialised rows on a 256-core host: a leg that
-    never agrees in `attempts` runs is recorded (warning, REFERENCE_DISAGREEMENTS, gpurun_out/reference_disagreements.log) and does NOT fail the suite --
-    two rounds of hardware evidence were lost to hard assertions on it in the middle of a `-x` run."""
-    detail = None
-    for attempt in range(attempts):
+    string (the detail) otherwise; an exception it raises counts as a disagreement with the exception as its detail.
+
+    What is tolerated, and what is not (round 5; the advisor's finding on round 4's version, which swallowed everything):
+      * The reference decoder is a threaded third party with a rand() dither: a leg gets `attempts` runs in this process.
+      * Some of its routes answer differently depending on what the process did before (uninitialised rows: the same sample decodes to the exact words in a
+        fresh process and to other words late in a long pytest process -- reproduced on the build container, the 16-bit routes' "empty detail" entries of round 4).
+        A leg that never agreed here is therefore repeated with the reference in a FRESH process (ref_decode_sample does that while _REF_FRESH_PROCESS is set);
+        agreement there is recorded as "fresh process only" and is not a failure.
+      * A leg that does not agree in a fresh process either is a finding about the product or the oracle: recorded, written to gpurun_out/reference_disagreements.log,
+        and -- CFHD_REFERENCE_LEG=strict -- an assertion on the spot.  Without strict mode the suite goes on (one reference-side flake in the middle of a `-x` run cost
+        two rounds of hardware evidence), but tests/test_gpu_parity.py::test_zz_every_reference_route_agreed fails the run at its end when a ROUTE never agreed on any of
+        its legs, and the last lines of the pytest output carry the counts (tests/conftest.py)."""
+    global _REF_FRESH_PROCESS
+    route = REFERENCE_ROUTES.setdefault(what, [0, 0, 0])
+    def once():
         try:
             r = agree()
-        except Exception as e:                      # (an error code or a crash-free failure of the reference is a finding about the reference too)
-            r = "reference leg raised %s: %s" % (type(e).__name__, e)
-        if r is None or (not isinstance(r, str) and bool(r)): return True            # (numpy booleans are not `True`)
-        detail = r if isinstance(r, str) else ""
-    import warnings
+        except Exception as e:                      # noqa: BLE001 -- an error code or an exception of the reference is a finding too; it is reported, never swallowed
+            return "reference leg raised %s: %s" % (type(e).__name__, e)
+        if r is None or (not isinstance(r, str) and bool(r)): return None            # (numpy booleans are not `True`)
+        return r if isinstance(r, str) else ""
+    detail = None
+    for attempt in range(attempts):
+        detail = once()
+        if detail is None: route[0] += 1; return True
+    here = detail
+    _REF_FRESH_PROCESS = True
+    try:
+        for attempt in range(2):
+            detail = once()
+            if detail is None: break
+    finally:
+        _REF_FRESH_PROCESS = False
     name = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0]
+    import warnings
+    if detail is None:
+        route[1] += 1
+        warnings.warn("live reference agreed only in a fresh process (in this process: %s): %s %s" % (here or "different output", name, what))
+        return True
+    route[2] += 1
     REFERENCE_DISAGREEMENTS.append((name, what, detail))
-    warnings.warn("live reference never agreed in %d attempts: %s %s %s" % (attempts, name, what, detail))
+    warnings.warn("live reference never agreed in %d attempts + 2 in fresh processes: %s %s %s" % (attempts, name, what, detail))
     try:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", "reference_disagreements.log"), "a") as f:
             f.write("%s\t%s\t%s\n" % (name, what, detail))
     except OSError:
         pass
+    assert os.environ.get("CFHD_REFERENCE_LEG") != "strict", "live reference disagrees on %s: %s" % (what, detail)
     return False
 
 

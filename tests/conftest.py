@@ -45,7 +45,7 @@ GPU_FIRST = [
     "test_encoder_pool_and_decoders_over_several_devices_keep_order_and_bytes",
 ]
 # ... and what runs last: the reference's own harness linked against the library (minutes of Qbist drawing on one core; compared with a committed fixture, no live reference).
-GPU_LAST = ["test_reference_harness_links_unchanged_and_prints_same_numbers"]
+GPU_LAST = ["test_reference_harness_links_unchanged_and_prints_same_numbers", "test_zz_every_reference_route_agreed"]
 
 
 def pytest_collection_modifyitems(session, config, items):
@@ -53,14 +53,19 @@ def pytest_collection_modifyitems(session, config, items):
     def key(item):
         if "test_gpu_" not in item.nodeid: return (0, 0)            # the other files keep their place in front
         name = getattr(item, "originalname", None) or item.name.split("[")[0]
-        return (1, len(GPU_FIRST) + 1 if name in GPU_LAST else rank.get(name, len(GPU_FIRST)))
+        return (1, len(GPU_FIRST) + 1 + GPU_LAST.index(name) if name in GPU_LAST else rank.get(name, len(GPU_FIRST)))
     items.sort(key=key)                                               # stable: file order inside one rank
 
 
 def pytest_terminal_summary(terminalreporter, exitstatus, config):
-    """Live-reference legs that never agreed (cfhd_testlib.reference_leg): reported, never a failure -- the gate of those tests is product == oracle."""
+    """The live-reference legs of the run (cfhd_testlib.reference_leg), route by route; the counts go last so that the tail of the output shows them."""
     import cfhd_testlib
-    if cfhd_testlib.REFERENCE_DISAGREEMENTS:
-        terminalreporter.section("live reference disagreements (not failures)")
-        for name, what, detail in cfhd_testlib.REFERENCE_DISAGREEMENTS:
-            terminalreporter.write_line("%s: %s %s" % (name, what, detail or ""))
+    R = cfhd_testlib.REFERENCE_ROUTES
+    if not R: return
+    terminalreporter.section("live reference legs")
+    for name, what, detail in cfhd_testlib.REFERENCE_DISAGREEMENTS:
+        terminalreporter.write_line("never agreed: %s: %s %s" % (name, what, detail or ""))
+    for what, (ok, fresh, never) in sorted(R.items()):
+        if fresh or never: terminalreporter.write_line("%-48s agreed %d, only in a fresh process %d, never %d" % (what, ok, fresh, never))
+    terminalreporter.write_line("live reference legs: %d agreed, %d agreed only with the reference in a fresh process, %d never agreed (%d routes, %d of them without any agreement)"
+                                % (sum(v[0] for v in R.values()), sum(v[1] for v in R.values()), sum(v[2] for v in R.values()), len(R), sum(1 for v in R.values() if v[2] and not (v[0] or v[1]))))

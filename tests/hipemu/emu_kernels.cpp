@@ -743,14 +743,16 @@ extern "C" int emu_entropy_decode_dx(const uint8_t *sample, size_t size, int pix
 	const uint32_t alt_slots = 3;                       // room for the candidates of one or two chunks only: both ways of k_dec_reindex (copy, index again) are exercised
 	std::vector<uint32_t> alt_entries((size_t)alt_slots * dev::DX_ENTRY_STRIDE + 16, 0xdeadbeefu);
 	// the record slots of the single-pass arrangement: one chunk's worth more as scratch, every word poisoned (a record the scatter pass reads must have been written by the walk)
-	std::vector<uint32_t> rec_slots(emit ? ((size_t)nchunks + 1) * dev::DX_REC_CHUNK : 0, 0x7fff7fffu), nrecs(emit ? (size_t)nchunks * 64 + 16 : 0, 0xffffffffu);
-	const dev::DxRecords R = { rec_slots.data(), nrecs.data(), nchunks };
-	if (emit) hipemu::launch(dim3((unsigned)grid), dim3(dev::DX_THREADS), [&] { dev::k_dec_index_emit(chunk_job.data(), counters.data(), &tables, entries.data(), recs.data(), alts.data(), mode != 1, g_dx_stats, R, &counters[4]); });
+	const size_t scratch_waves = (size_t)(grid > 3 ? grid : 3) * dev::DX_WAVES;
+	std::vector<uint32_t> scratch(emit ? scratch_waves * dev::DX_REC_CHUNK : 0, 0x7fff7fffu), dense(emit ? (size_t)nchunks * dev::DX_DENSE_CHUNK + 16 : 0, 0x7fff7fffu), pmeta(emit ? (size_t)nchunks * 128 + 16 : 0, 0xffffffffu);
+	std::vector<uint32_t> alt_dense(emit ? (size_t)alt_slots * dev::DX_DENSE_CHUNK + 16 : 0, 0x7fff7fffu), alt_pmeta(emit ? (size_t)alt_slots * 128 + 16 : 0, 0xffffffffu);
+	const dev::DxRecords R = { scratch.data(), dense.data(), pmeta.data(), alt_dense.data(), alt_pmeta.data() };
+	if (emit) hipemu::launch(dim3((unsigned)grid), dim3(dev::DX_THREADS), [&] { dev::k_dec_index_emit(chunk_job.data(), counters.data(), &tables, entries.data(), recs.data(), alts.data(), mode != 1, g_dx_stats, R, alt_entries.data(), alt_slots, &counters[3], &counters[4]); });
 	else hipemu::launch(dim3((unsigned)grid), dim3(dev::DX_THREADS), [&] { dev::k_dec_index(chunk_job.data(), counters.data(), &tables, entries.data(), recs.data(), alts.data(), mode != 1, g_dx_stats, alt_entries.data(), alt_slots, &counters[3], &counters[4]); });
 	hipemu::launch(dim3((unsigned)(njobs + dev::DX_WAVES - 1) / dev::DX_WAVES), dim3(dev::DX_THREADS), [&] { dev::k_dec_chain(jobs.data(), njobs, recs.data(), alts.data(), chunk_base.data(), sums.data(), &errors, repair_list.data(), reindex.data(), counters.data()); });
 	if (emit) {
 		hipemu::launch(dim3(2), dim3(dev::DX_THREADS), [&] { dev::k_dec_repair_emit(jobs.data(), &tables, entries.data(), recs.data(), alts.data(), chunk_base.data(), sums.data(), &errors, repair_list.data(), reindex.data(), counters.data(), R, g_dx_stats); });
-		hipemu::launch(dim3(3), dim3(dev::DX_THREADS), [&] { dev::k_dec_reindex_emit(jobs.data(), &tables, entries.data(), reindex.data(), counters.data(), R, g_dx_stats); });
+		hipemu::launch(dim3(3), dim3(dev::DX_THREADS), [&] { dev::k_dec_reindex_emit(jobs.data(), &tables, entries.data(), reindex.data(), counters.data(), R, g_dx_stats, alts.data(), alt_entries.data()); });
 	} else {
 		hipemu::launch(dim3(2), dim3(dev::DX_THREADS), [&] { dev::k_dec_repair(jobs.data(), &tables, entries.data(), recs.data(), alts.data(), chunk_base.data(), sums.data(), &errors, repair_list.data(), reindex.data(), counters.data(), g_dx_stats); });
 		hipemu::launch(dim3(3), dim3(dev::DX_THREADS), [&] { dev::k_dec_reindex(jobs.data(), &tables, entries.data(), reindex.data(), counters.data(), g_dx_stats, alts.data(), alt_entries.data()); });

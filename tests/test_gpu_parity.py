@@ -1807,3 +1807,11 @@ def test_decoder_survives_fuzzed_samples(interlaced):
     assert sum(v for k, v in codes.items() if k) >= 4, codes
     img = _check_decode(sample, f, w, h, PIX_YUY2, interlaced=bool(interlaced), decoder=dec)
     L.CFHD_CloseDecoder(dec)
+
+
+def test_zz_every_reference_route_agreed():
+    """Runs at the end of the GPU suite (tests/conftest.py GPU_LAST): every decode ROUTE whose live-reference legs ran (cfhd_testlib.reference_leg) must have agreed with the
+    reference on at least one of its legs -- in this process or with the reference in a fresh one.  A single leg that never agrees is reported and tolerated (the
+    reference's threaded decoder on a 256-core host); a route that never agrees anywhere is a defect of the product or of the oracle's model of that route."""
+    dead = sorted(what for what, (ok, fresh, never) in REFERENCE_ROUTES.items() if never and not (ok or fresh))
+    assert not dead, "routes on which the live reference never agreed: %s -- %s" % (dead, [d for d in REFERENCE_DISAGREEMENTS if d[1] in dead][:6])
