@@ -220,7 +220,7 @@ def parity_check(L, b, frames, pitch, W, H, rank, wl, batch, nuniq, nchk=None, f
         if wl["fmt"] == "YUY2":
             img = img.reshape(H, W * 2)
             plan = T.Plan(W, H, progressive=0 if wl["flags"] & 1 else 1)
-            deq = T.host_decode_pyramid(sample, plan)
+            deq = T.oracle_decode_pyramid(sample, plan)
             inverse = T.oracle_inverse_interlaced_yuv422 if wl["flags"] & 1 else T.oracle_inverse_yuv422
             lo = inverse(plan, deq, 0)[:H]; hi = inverse(plan, deq, 1)[:H]
             assert ((img == lo) | (img == hi)).all(), "decoded frame %d leaves the dither interval of the exact reconstruction" % i
@@ -228,7 +228,7 @@ def parity_check(L, b, frames, pitch, W, H, rank, wl, batch, nuniq, nchk=None, f
         else:
             b64a = wl["fmt"] == "b64a"
             plan = T.Plan(W, H, pixkind=T.PIXKIND[wl["fmt"]], enc=T.ENC["4444" if b64a else "444"])
-            exact = T.oracle_inverse_rgb48(plan, T.host_decode_pyramid(sample, plan), b64a=b64a)[:H]
+            exact = T.oracle_inverse_rgb48(plan, T.oracle_decode_pyramid(sample, plan), b64a=b64a)[:H]
             got = np.frombuffer(img.tobytes(), np.uint16).reshape(H, W * bpp // 2)
             assert np.array_equal(got, exact), "decoded frame %d differs from the exact reconstruction" % i
     out["samples_equal_reference_encoder"] = True

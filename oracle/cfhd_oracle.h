@@ -118,6 +118,13 @@ size_t orc_vlc_encode_band(const PIXEL16 *band, int width, int height, int pitch
 /* Decodes until the band end code; output pre-zeroed by the callee; values are multiplied by quant. */
 int orc_vlc_decode_band(const uint8_t *in, size_t nbytes, int width, int height, int pitch, int quant, PIXEL16 *band);
 
+/* One coded band bit-serially from bit 0 of `in` (code set 17: codebook 1, cubic; 18: codebook 2, linear), optional peak table and difference coding; returns the
+ * payload bits consumed (band end marker included) or < 0. */
+long orc_decode_band_bits(const uint8_t *in, size_t nbytes, int width, int height, int pitch, int quant, int codebook,
+                          const uint8_t *peaks, size_t peak_bytes, int peak_level, int difference, PIXEL16 *band);
+/* The tag-value walk of an intra-frame sample with every band decoded into the caller's rasters (lowpass band: raw words, no bias). */
+int orc_decode_sample(const uint8_t *d, size_t size, PIXEL16 *const dst[4][3][4], const int pitch[4][3][4], const int dims[4][3][4][2], int32_t info[8]);
+
 #ifdef __cplusplus
 }
 #endif

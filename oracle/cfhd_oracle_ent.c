@@ -274,3 +274,154 @@ int orc_vlc_decode_band(const uint8_t *in, size_t nbytes, int width, int height,
 		}
 	}
 }
+
+
+/* =================================== a whole sample's coefficients =================================== */
+
+/* The code words of code sets 17 and 18 are the same (Common/table17.inc / table18.inc: same lengths, same bits); what differs is the
+ * meaning of a magnitude index: cubic expansion for 17 (codebooks.c:1345-1378), the index itself for 18.  A binary trie over the 264
+ * code words (256 magnitudes, 7 zero runs, the band end marker): one step per payload bit, no search. */
+typedef struct { int child[2]; int kind; int value; } trie_t;      /* kind 0: inner node, 1: magnitude index, 2: zero run, 3: band end */
+static trie_t g_trie[8192]; static int g_trie_n = 0;
+static void trie_add(uint32_t bits, int len, int kind, int value)
+{
+	int at = 0, i;
+	for (i = len - 1; i >= 0; i--) {
+		const int b = (int)((bits >> i) & 1u);
+		if (!g_trie[at].child[b]) { g_trie[at].child[b] = g_trie_n; memset(&g_trie[g_trie_n], 0, sizeof(trie_t)); g_trie_n++; }
+		at = g_trie[at].child[b];
+	}
+	g_trie[at].kind = kind; g_trie[at].value = value;
+}
+static void build_trie(void)
+{
+	int i;
+	if (g_trie_n) return;
+	memset(&g_trie[0], 0, sizeof(trie_t)); g_trie_n = 1;
+	for (i = 0; i < 256; i++) trie_add(cfhd_cs17_mag_code[i], cfhd_cs17_mag_len[i], i == 0 ? 2 : 1, i == 0 ? 1 : i);   /* magnitude 0 = a single zero */
+	for (i = 0; i < CFHD_CS17_NUM_RUNS; i++) trie_add(cfhd_cs17_run[i][0], (int)cfhd_cs17_run[i][1], 2, (int)cfhd_cs17_run[i][2]);
+	trie_add(cfhd_cs17_band_end[0], (int)cfhd_cs17_band_end[1], 3, 0);
+}
+
+/* One coded band from bit 0 of `in` (Codec/decoder.c:19534 DecodeBandFSM16sNoGap / :19809 ...WithPeaks, restated bit-serially): code words until the
+ * band end marker; value = sign * expand(index) * quant in 16-bit arithmetic (DeQuantFSM :20597-20608); with a peak table every value whose
+ * magnitude exceeds `peak_level` is replaced by the next 16-bit little-endian word of the table (:19870-19873: the table holds finished
+ * coefficients); with difference coding every row becomes its running sum afterwards (:20822-20836).  The raster is height x pitch and the
+ * zero runs continue through the pitch padding (one long row, :19572).  Returns the number of payload bits consumed (marker included), < 0 on error. */
+long orc_decode_band_bits(const uint8_t *in, size_t nbytes, int width, int height, int pitch, int quant, int codebook,
+                          const uint8_t *peaks, size_t peak_bytes, int peak_level, int difference, PIXEL16 *band)
+{
+	const size_t nbits = nbytes * 8, total = (size_t)height * pitch;
+	size_t pos = 0, idx = 0, peak_at = 0;
+	int r, x;
+	build_trie();
+	for (r = 0; r < height; r++) memset(band + (size_t)r * pitch, 0, (size_t)pitch * sizeof(PIXEL16));
+	for (;;) {
+		int at = 0;
+		while (g_trie[at].kind == 0) {
+			int b;
+			if (pos >= nbits) return -1;
+			b = (in[pos >> 3] >> (7 - (pos & 7))) & 1; pos++;
+			at = g_trie[at].child[b];
+			if (!at) return -2;                               /* not a code word */
+		}
+		if (g_trie[at].kind == 3) break;
+		if (g_trie[at].kind == 2) { idx += (size_t)g_trie[at].value; continue; }
+		{
+			const int i = g_trie[at].value;
+			int sign, mag = codebook == 2 ? i : i + (int)(((int64_t)i * i * i * 768) >> 24);
+			int v;
+			if (pos >= nbits) return -1;
+			sign = (in[pos >> 3] >> (7 - (pos & 7))) & 1; pos++;
+			if (idx >= total) return -3;
+			v = (PIXEL16)((sign ? -mag : mag) * quant);
+			if (peak_level && peaks && (v > peak_level || v < -peak_level)) {
+				if (2 * peak_at + 2 > peak_bytes) return -4;
+				v = (PIXEL16)(uint16_t)(peaks[2 * peak_at] | (peaks[2 * peak_at + 1] << 8)); peak_at++;
+			}
+			band[idx++] = (PIXEL16)v;
+		}
+	}
+	if (difference)
+		for (r = 0; r < height; r++) { PIXEL16 *line = band + (size_t)r * pitch; for (x = 1; x < width; x++) line[x] = (PIXEL16)(line[x] + line[x - 1]); }
+	return (long)pos;
+}
+
+/* The tag-value walk of an intra-frame sample as far as the coefficients (Codec/decoder.c:23300-24000 UpdateCodecState: one case per tag; codec.h:196-404 the tag
+ * numbers; an optional tag is stored negated, :2340-2360; tags with bit 0x4000 carry a payload of `value` -- with bit 0x2000 (tag & 0xff) << 16 | value -- longwords
+ * that the walk skips, tags with bit 0x2000 alone are size fields).  The lowpass band of a channel follows the coefficient marker 0x0F0F as 16-bit big-endian words
+ * (:12230-12545 adds the output-dependent bias: the caller's business); a highpass band's code words follow its BAND_HEADER tag and end with the band end marker, the
+ * walk goes on at the next 32-bit word (bitstream.c AlignBitsTag).  Unlike the product's parser this walk does not look at the size fields at all: where a band ends is
+ * where its code words end, as in the reference.
+ * dst[channel][wavelet 0..2][band 0..3] / pitch likewise: where the band's raster goes (band 0 of wavelet 2 = the lowpass band; NULL: not wanted, the band is walked
+ * over and dropped).  dims[channel][wavelet][band][2] = the width and height the caller's rasters have: a sample that says otherwise is refused.
+ * info[0..7] = width, height, display height, channels, precision, progressive flag, encoded format, bands decoded. */
+int orc_decode_sample(const uint8_t *d, size_t size, PIXEL16 *const dst[4][3][4], const int pitch[4][3][4], const int dims[4][3][4][2], int32_t info[8])
+{
+	size_t pos = 0;
+	int channel = 0, lv = -1, band = 0, bw = 0, bh = 0, bq = 1, bflags = 0, lw = 0, lh = 0, decoded = 0;
+	size_t peak_base = 0; uint32_t peak_offset = 0; int peak_level = 0;
+	memset(info, 0, 8 * sizeof(int32_t));
+	info[5] = 1;
+	while (pos + 4 <= size) {
+		int tag = (int16_t)((d[pos] << 8) | d[pos + 1]);
+		const int value = (d[pos + 2] << 8) | d[pos + 3];
+		pos += 4;
+		if (tag < 0) tag = -tag;
+		if (tag & 0x4000) { pos += (size_t)((tag & 0x2000) ? (((uint32_t)(tag & 0xff) << 16) | (uint32_t)value) : (uint32_t)value) * 4; continue; }
+		if (tag & 0x2000) continue;
+		switch (tag) {
+		case 2: pos += 4 * (size_t)value; break;                            /* CODEC_TAG_INDEX: the channel size table */
+		case 62: channel = value; if (channel < 0 || channel > 3) return -3; break;          /* CODEC_TAG_CHANNEL */
+		case 12: info[3] = value; break;                                    /* NUM_CHANNELS */
+		case 20: info[0] = value; break; case 21: info[1] = value; break;   /* FRAME_WIDTH / FRAME_HEIGHT */
+		case 85: info[2] = value; break;                                    /* FRAME_DISPLAY_HEIGHT */
+		case 70: info[4] = value; break;                                    /* PRECISION */
+		case 68: info[5] = value & 1; break;                                /* SAMPLE_FLAGS: bit 0 progressive */
+		case 84: info[6] = value; break;                                    /* ENCODED_FORMAT */
+		case 27: lw = value; break; case 28: lh = value; break;             /* LOWPASS_WIDTH / LOWPASS_HEIGHT */
+		case 4:                                                             /* CODEC_TAG_MARKER */
+			if (value == 0x0F0F) {                                          /* coefficient start: the raw lowpass band (decoder.c:23446-23470 -> DecodeSampleSubband(0)) */
+				PIXEL16 *out = dst[channel][2][0];
+				const size_t bytes = (size_t)lw * lh * 2;
+				int r, x;
+				if (pos + bytes > size) return -4;
+				if (out) {
+					if (lw != dims[channel][2][0][0] || lh != dims[channel][2][0][1]) return -5;
+					for (r = 0; r < lh; r++) for (x = 0; x < lw; x++) { const uint8_t *p = d + pos + ((size_t)r * lw + x) * 2; out[(size_t)r * pitch[channel][2][0] + x] = (PIXEL16)(uint16_t)((p[0] << 8) | p[1]); }
+				}
+				pos += (bytes + 3) & ~(size_t)3;
+				decoded++;
+			}
+			break;
+		case 38: lv = value - 1; if (lv < 0 || lv > 2) return -6; break;    /* WAVELET_NUMBER */
+		case 48: band = value; if (band < 1 || band > 3) return -7; bflags = 0; break;       /* BAND_NUMBER */
+		case 72: bflags = value; break;                                     /* BAND_CODING_FLAGS: bits 0-3 code book, bit 4 difference coding (decoder.c:23970-23976) */
+		case 75: peak_offset = (peak_offset & ~0xffffu) | (uint32_t)value; peak_base = pos; peak_level = 0; break;      /* PEAK_TABLE_OFFSET_L (:23978): base = the word behind this tuple */
+		case 76: peak_offset = (peak_offset & 0xffffu) | ((uint32_t)value << 16); peak_level = 0; break;
+		case 74: peak_level = value; break;                                 /* PEAK_LEVEL (:23991): base += offset */
+		case 49: bw = value; break; case 50: bh = value; break;             /* BAND_WIDTH / BAND_HEIGHT */
+		case 53: bq = value; break;                                         /* BAND_QUANTIZATION */
+		case 55: {                                                          /* BAND_HEADER: the code words follow (decoder.c:23425) */
+			PIXEL16 *out;
+			long bits;
+			static PIXEL16 *scratch = NULL; static size_t scratch_n = 0;
+			const uint8_t *peaks = NULL; size_t peak_bytes = 0;
+			int p;
+			if (lv < 0) return -8;
+			out = dst[channel][lv][band]; p = out ? pitch[channel][lv][band] : ((bw + 7) & ~7);
+			if (out && (bw != dims[channel][lv][band][0] || bh != dims[channel][lv][band][1])) return -5;
+			if (!out) { if ((size_t)bh * p > scratch_n) { free(scratch); scratch_n = (size_t)bh * p; scratch = (PIXEL16 *)malloc(scratch_n * sizeof(PIXEL16)); } out = scratch; }
+			if (peak_level) { const size_t at = peak_base + peak_offset; if (at + 2 > size) return -9; peaks = d + at; peak_bytes = size - at; }
+			bits = orc_decode_band_bits(d + pos, size - pos, bw, bh, p, bq, bflags & 0xf, peaks, peak_bytes, peak_level, (bflags >> 4) & 1, out);
+			if (bits < 0) return -20 + (int)bits;
+			pos += (((size_t)bits + 31) / 32) * 4;
+			peak_level = 0;
+			decoded++;
+			break; }
+		default: break;
+		}
+	}
+	info[7] = decoded;
+	return 0;
+}

@@ -1006,6 +1006,53 @@ def host_decode_pyramid(sample, plan, lowpass_offset=1):
     return out
 
 
+def oracle_lowpass_bias(precision, lowpass_width, out_pixkind, channel):
+    """What the reference decoder adds to every word of the raw lowpass band before the inverse transform (Codec/decoder.c:12240-12312 even widths, :12468-12545 the
+    bit-serial path of odd widths): 8-bit sources 32; 10-bit sources 24 (odd width: 5) for the 8-bit outputs, 4 (5) for the deep 4:2:2 outputs YU64 / v210, and on the
+    odd-width path 8 (luma) / 4 (chroma) less for the bottom-up 8-bit RGB outputs (:12500-12508); 12-bit sources 8 for the 8-bit RGB outputs, 6 for the 10-bit RGB
+    words, nothing for the 16-bit outputs and Bayer (:12290-12316)."""
+    even = (lowpass_width & 1) == 0
+    K = PIXKIND
+    if precision == 8: return 32
+    if precision == 10:
+        if out_pixkind in (K["YU64"], K["v210"]): return 4 if even else 5
+        if not even and out_pixkind in (K["RG24"], K["BGRA"]): return 5 - 8 if channel == 0 else 5 - 4
+        return 24 if even else 5
+    if precision == 12:
+        if out_pixkind in (K["RG24"], K["BGRA"], K["BGRa"]): return 8
+        if K["r210"] <= out_pixkind <= K["AR10"]: return 6
+    return 0
+
+
+def oracle_decode_pyramid(sample, plan, lowpass_offset=1, out_pixkind=None):
+    """Dequantized coefficient pyramid of an intra-frame sample, in the product's pyramid layout, by the ORACLE alone (oracle/cfhd_oracle_ent.c orc_decode_sample: its own
+    tag-value walk and bit-serial decoder of both code sets, peak tables and difference coding -- nothing of the product's parser or VLC decoder, which the GPU entropy
+    kernels share tables and job builders with).  This is what the decode gates of the GPU tests, bench.py's parity check and smoke() feed the oracle's inverse transform
+    with.  lowpass_offset=1 adds the reference decoder's lowpass bias for the output format (oracle_lowpass_bias; out_pixkind defaults to the plan's pixel kind)."""
+    O = oracle()
+    out = np.zeros(plan.coeff_elems, dtype=np.int16)
+    P16 = ctypes.POINTER(ctypes.c_int16)
+    dst = (P16 * 4 * 3 * 4)(); pitch = (ctypes.c_int * 4 * 3 * 4)(); dims = (ctypes.c_int * 2 * 4 * 3 * 4)()
+    for (c, lv, b), d in plan.band.items():
+        if b == 0 and lv != 2: continue                                  # (the level-1 / level-2 lowpass planes are intermediates of the transform, not coded)
+        v = plan.view(out, c, lv, b)
+        dst[c][lv][b] = v.ctypes.data_as(P16); pitch[c][lv][b] = d["pitch"]; dims[c][lv][b][0] = d["width"]; dims[c][lv][b][1] = d["height"]
+    info = (ctypes.c_int32 * 8)()
+    s = np.frombuffer(sample, dtype=np.uint8).copy()
+    O.orc_decode_sample.argtypes = [c_u8p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    rc = O.orc_decode_sample(p8(s), len(sample), ctypes.byref(dst), ctypes.byref(pitch), ctypes.byref(dims), ctypes.byref(info))
+    assert rc == 0, "oracle sample walk failed: %d" % rc
+    assert info[3] == plan.num_channels and info[7] == 10 * plan.num_channels, "sample has %d channels, %d bands decoded" % (info[3], info[7])
+    if lowpass_offset:
+        kind = plan.pixkind if out_pixkind is None else out_pixkind
+        for c in range(plan.num_channels):
+            d = plan.band[(c, 2, 0)]
+            ll = plan.view(out, c, 2, 0)[:, : d["width"]]
+            bias = oracle_lowpass_bias(info[4] or 8, d["width"], kind, c)
+            ll[:] = np.minimum(ll.astype(np.int32) + bias, 0x7fff).astype(np.int16)
+    return out
+
+
 def oracle_inverse_yuv422(plan, coeffs, dither, uyvy=0):
     """Whole inverse path with the oracle from a dequantized pyramid (product layout) to packed 4:2:2."""
     O = oracle()

@@ -78,7 +78,7 @@ def _check_decode(sample, source, w, h, pixfmt=PIX_YUY2, interlaced=False, decod
     assert (aw, ah) == (w, h)
     img = out.reshape(ah, pitch)[:, : w * 2]
     plan = Plan(w, h, pixkind=2 if pixfmt == PIX_2VUY else 1, progressive=0 if interlaced else 1)
-    coeffs = host_decode_pyramid(sample, plan)
+    coeffs = oracle_decode_pyramid(sample, plan)
     inverse = oracle_inverse_interlaced_yuv422 if interlaced else oracle_inverse_yuv422
     lo = inverse(plan, coeffs, 0, uyvy=int(pixfmt == PIX_2VUY))[:h]
     hi = inverse(plan, coeffs, 1, uyvy=int(pixfmt == PIX_2VUY))[:h]
@@ -154,7 +154,7 @@ def test_encoder_pool_and_decoders_over_several_devices_keep_order_and_bytes():
         os.environ.pop("CFHD_AMD_POOL_DEVICES")
         ref_out = amd_decode_sample(sample)[0]
         plan = Plan(w, h)
-        coeffs = host_decode_pyramid(sample, plan)
+        coeffs = oracle_decode_pyramid(sample, plan)
         lo = oracle_inverse_yuv422(plan, coeffs, 0)[:h]; hi = oracle_inverse_yuv422(plan, coeffs, 1)[:h]
         for o in outs + [ref_out]:
             img = o.reshape(h, -1)[:, : w * 2]
@@ -338,7 +338,7 @@ def _batched_round_trip_body(L, w, h, n, frames):
             out = np.zeros(h * w * 2, dtype=np.uint8)
             assert L.cfhd_amd_batch_download_output(b, i, out.ctypes.data_as(ctypes.c_void_p), w * 2) == 0
             img = out.reshape(h, w * 2)
-            deq = host_decode_pyramid(sample, plan)
+            deq = oracle_decode_pyramid(sample, plan)
             lo = oracle_inverse_yuv422(plan, deq, 0)[:h]; hi = oracle_inverse_yuv422(plan, deq, 1)[:h]
             assert ((img == lo) | (img == hi)).all(), "step %d frame %d" % (step, i)
     L.cfhd_amd_batch_destroy(b)
@@ -366,7 +366,7 @@ def test_rg48_decode_equals_reference_exactly(w, h):
     frames, pitch = qbist_frames(10, 1, w, h, PIX_RG48)
     sample = ref_encode_frames(frames, pitch, w, h, PIX_RG48, encoded=ENCODED_RGB444)[0]
     plan = Plan(w, h, pixkind=PIXKIND["RG48"], enc=3)
-    exact = oracle_inverse_rgb48(plan, host_decode_pyramid(sample, plan))[:h]
+    exact = oracle_inverse_rgb48(plan, oracle_decode_pyramid(sample, plan))[:h]
     got, gpitch, aw, ah = amd_decode_sample(sample, PIX_RG48)
     assert (aw, ah) == (w, h)
     a = np.frombuffer(got.tobytes(), np.uint16).reshape(h, gpitch // 2)[:, : w * 3]
@@ -391,7 +391,7 @@ def test_rg48_round_trip_and_format_gates():
     assert 10 * np.log10(65535.0 ** 2 / mse) > 40.0
     # the CPU twin of the GPU path gives the same words
     plan = Plan(w, h, pixkind=PIXKIND["RG48"], enc=3)
-    assert np.array_equal(oracle_inverse_rgb48(plan, host_decode_pyramid(sample, plan))[:h].reshape(h, w, 3), dec)
+    assert np.array_equal(oracle_inverse_rgb48(plan, oracle_decode_pyramid(sample, plan))[:h].reshape(h, w, 3), dec)
     # gates: RG48 to RGB 4:4:4 or YUV 4:2:2 (not 4:4:4:4 or Bayer), RGB samples only to RGB output formats
     L = product()
     enc = ctypes.c_void_p(); assert L.CFHD_OpenEncoder(ctypes.byref(enc), None) == 0
@@ -488,7 +488,7 @@ def test_yuv422_decode_to_rg24_lies_in_the_reference_interval(w, h, flags):
     img = got.reshape(h, gpitch)[:, : w * 3]
     plan = Plan(w, h, pixkind=PIXKIND["RG24"], enc=1)
     cs = 1 if flags & 4 else 2
-    co = host_decode_pyramid(sample, plan)
+    co = oracle_decode_pyramid(sample, plan)
     lo = oracle_inverse_rgb24_of_yuv422(plan, co, 0, cs); hi = oracle_inverse_rgb24_of_yuv422(plan, co, 32767, cs)
     ok = (img >= lo) & (img <= hi)
     assert ok.all(), "%d bytes outside the interval" % (~ok).sum()
@@ -516,7 +516,7 @@ def test_yuv422_decode_to_bgra_rg48_b64a_equals_reference_exactly(w, h, name, fl
     from test_oracle_vs_ref import _yuv422_sample_for_rgb_outputs
     sample = _yuv422_sample_for_rgb_outputs(w, h, w + h, flags)
     plan = Plan(w, h, pixkind=PIXKIND[name], enc=ENC["422"])
-    deq = host_decode_pyramid(sample, plan)
+    deq = oracle_decode_pyramid(sample, plan)
     cs = 1 if flags & 4 else 2
     got, gpitch, aw, ah = amd_decode_sample(sample, fourcc(name))
     assert (aw, ah) == (w, h)
@@ -607,7 +607,7 @@ def test_half_resolution_decode_of_rgba4444_to_bgra(w, h):
     from test_oracle_vs_ref import rgba4444_sample_with_clips
     sample = rgba4444_sample_with_clips(w, h, w + h)
     plan = Plan(w, h, pixkind=PIXKIND["b64a"], enc=ENC["4444"])
-    want = oracle_half_resolution_rgba8(plan, host_decode_pyramid(sample, plan))[: h // 2]
+    want = oracle_half_resolution_rgba8(plan, oracle_decode_pyramid(sample, plan))[: h // 2]
     hh = h // 2 if h % 8 == 0 else h // 2 - 4
     for name in ("BGRa", "BGRA"):
         got, gpitch, aw, ah = amd_decode_sample(sample, fourcc(name), resolution=2)
@@ -633,7 +633,7 @@ def test_half_resolution_decode_of_yuv422_to_rg24_equals_reference_exactly(w, h,
     assert (aw, ah) == (w // 2, h // 2)
     mine = np.frombuffer(got.tobytes(), np.uint8).reshape(h // 2, gpitch)[:, : (w // 2) * 3]
     plan = Plan(w, h, pixkind=PIXKIND["RG24"])
-    want = oracle_half_resolution_rgb24_of_yuv422(plan, host_decode_pyramid(sample, plan), 1 if flags & 4 else 2)
+    want = oracle_half_resolution_rgb24_of_yuv422(plan, oracle_decode_pyramid(sample, plan), 1 if flags & 4 else 2)
     assert np.array_equal(mine, want[want.shape[0] - h // 2:])
     hh = h // 2 if h % 8 == 0 else h // 2 - 4
     def leg():
@@ -654,7 +654,7 @@ def test_interlaced_samples_at_half_resolution_as_yu64_and_v210(w, h):
         got, gpitch, aw, ah = amd_decode_sample(sample, fourcc(name), resolution=2)
         assert (aw, ah) == (w // 2, h // 2)
         plan = Plan(w, h, pixkind=PIXKIND[name], progressive=0)
-        want = (oracle_half_resolution_yu64 if name == "YU64" else oracle_half_resolution_v210)(plan, host_decode_pyramid(sample, plan))[: h // 2]
+        want = (oracle_half_resolution_yu64 if name == "YU64" else oracle_half_resolution_v210)(plan, oracle_decode_pyramid(sample, plan))[: h // 2]
         mine = np.frombuffer(got.tobytes(), np.uint16 if name == "YU64" else np.uint32).reshape(h // 2, gpitch // (2 if name == "YU64" else 4))[:, : want.shape[1]]
         assert np.array_equal(mine, want), name
     L = product()
@@ -676,7 +676,7 @@ def test_half_resolution_decode_to_v210_equals_reference_exactly(w, h):
     got, gpitch, aw, ah = amd_decode_sample(sample, fourcc("v210"), resolution=2)
     assert (aw, ah) == (w // 2, h // 2)
     plan = Plan(w, h, pixkind=PIXKIND["v210"])
-    want = oracle_half_resolution_v210(plan, host_decode_pyramid(sample, plan))[: h // 2]
+    want = oracle_half_resolution_v210(plan, oracle_decode_pyramid(sample, plan))[: h // 2]
     mine = np.frombuffer(got.tobytes(), np.uint32).reshape(h // 2, gpitch // 4)[:, : want.shape[1]]
     assert np.array_equal(mine, want)
     hh = h // 2 if h % 8 == 0 else h // 2 - 4
@@ -705,7 +705,7 @@ def test_half_resolution_decode_to_yu64_equals_reference_exactly(w, h):
     assert (aw, ah, gpitch) == (w // 2, h // 2, (w // 2) * 4)
     mine = np.frombuffer(got.tobytes(), np.uint16).reshape(h // 2, gpitch // 2)
     plan = Plan(w, h, pixkind=PIXKIND["YU64"])
-    assert np.array_equal(mine, oracle_half_resolution_yu64(plan, host_decode_pyramid(sample, plan))[: h // 2])
+    assert np.array_equal(mine, oracle_half_resolution_yu64(plan, oracle_decode_pyramid(sample, plan))[: h // 2])
     hh = h // 2 if h % 8 == 0 else h // 2 - 4
     def leg():
         dec, dpitch = ref_decode_sample(sample, w, h, fourcc("YU64"), resolution=2)
@@ -722,7 +722,7 @@ def test_half_resolution_decode_of_rgb444_to_the_8bit_10bit_and_b64a_outputs(w, 
     from test_oracle_vs_ref import rgb444_sample_with_clips, half_rgb_view
     sample = rgb444_sample_with_clips(w, h, w + h)
     plan = Plan(w, h, pixkind=PIXKIND["RG48"], enc=ENC["444"])
-    deq = host_decode_pyramid(sample, plan)
+    deq = oracle_decode_pyramid(sample, plan)
     hh = h // 2 if h % 8 == 0 else h // 2 - 4
     for name in ("r210", "DPX0", "AB10", "AR10", "RG30", "b64a"):
         got, gpitch, aw, ah = amd_decode_sample(sample, fourcc(name), resolution=2)
@@ -762,7 +762,7 @@ def test_bayer_decode_to_byr4_equals_reference_exactly(w, h):
     assert (aw, ah, gpitch) == (w, h, w * 2)
     mine = np.frombuffer(got.tobytes(), np.uint16).reshape(h, gpitch // 2)[:, :w]
     plan = Plan(w, h, pixkind=PIXKIND["BYR4"], enc=ENC["bayer"])
-    want = oracle_inverse_byr4(plan, host_decode_pyramid(sample, plan))[:h, :w]
+    want = oracle_inverse_byr4(plan, oracle_decode_pyramid(sample, plan))[:h, :w]
     assert np.array_equal(mine, want), "%d words differ from the exact reconstruction" % (mine != want).sum()
     def leg():
         dec, dpitch = ref_decode_sample(sample, w, h, fourcc("BYR4"))
@@ -789,7 +789,7 @@ def test_rgba4444_decode_to_rg48_equals_reference_exactly(w, h):
         px[:, word: w * 4: 4] = np.where(ramp > 60000, 65535, np.where(ramp < 4000, 0, px[:, word: w * 4: 4]))
     sample = amd_encode_frames([px.reshape(-1).view(np.uint8).copy()], pitch, w, h, PIX_B64A, encoded=ENCODED_RGBA4444)[0]
     plan = Plan(w, h, pixkind=PIXKIND["b64a"], enc=ENC["4444"])
-    deq = host_decode_pyramid(sample, plan)
+    deq = oracle_decode_pyramid(sample, plan)
     got, gpitch, aw, ah = amd_decode_sample(sample, PIX_RG48)
     assert (aw, ah) == (w, h)
     mine = np.frombuffer(got.tobytes(), np.uint16).reshape(h, gpitch // 2)[:, : w * 3]
@@ -822,7 +822,7 @@ def test_rgb444_decode_to_b64a_equals_reference_exactly(w, h):
     assert (aw, ah) == (w, h)
     mine = np.frombuffer(got.tobytes(), np.uint16).reshape(h, gpitch // 2)[:, : w * 4]
     plan = Plan(w, h, pixkind=PIXKIND["b64a"], enc=ENC["444"])
-    want = oracle_inverse_b64a_of_rgb444(plan, host_decode_pyramid(sample, plan))[:h]
+    want = oracle_inverse_b64a_of_rgb444(plan, oracle_decode_pyramid(sample, plan))[:h]
     assert np.array_equal(mine, want)
     rows = h if h % 8 == 0 else h - 8
     def leg():
@@ -865,7 +865,7 @@ def test_yu64_decode_equals_reference_exactly(w, h, src):
     assert (aw, ah) == (w, h) and gpitch == (w * 4 + 15) // 16 * 16
     mine = np.frombuffer(got.tobytes(), np.uint16).reshape(h, gpitch // 2)[:, : w * 2]
     plan = Plan(w, h, pixkind=PIXKIND["YU64"])
-    want = oracle_inverse_yu64(plan, host_decode_pyramid(sample, plan))[:h]       # (pinned on the reference decoder on nine geometries: test_reference_yu64_decode_equals_oracle)
+    want = oracle_inverse_yu64(plan, oracle_decode_pyramid(sample, plan))[:h]       # (pinned on the reference decoder on nine geometries: test_reference_yu64_decode_equals_oracle)
     assert np.array_equal(mine, want), "%d words differ from the exact reconstruction" % (mine != want).sum()
     def leg():
         dec, dpitch = ref_decode_sample(sample, w, h, fourcc("YU64"))
@@ -918,7 +918,7 @@ def test_v210_decode_equals_reference_exactly(w, h, src):
     nwords = (w // 6) * 4
     mine = np.frombuffer(got.tobytes(), np.uint32).reshape(h, gpitch // 4)[:, :nwords]
     plan = Plan(w, h, pixkind=PIXKIND["YU64"])
-    want = oracle_inverse_v210(plan, host_decode_pyramid(sample, plan), w)[:h]    # (pinned on the reference decoder on eight geometries: test_reference_v210_decode_equals_oracle)
+    want = oracle_inverse_v210(plan, oracle_decode_pyramid(sample, plan), w)[:h]    # (pinned on the reference decoder on eight geometries: test_reference_v210_decode_equals_oracle)
     assert np.array_equal(mine, want), "%d words differ from the exact reconstruction" % (mine != want).sum()
     def leg():
         dec, dpitch = ref_decode_sample(sample, w, h, fourcc("v210"))
@@ -950,7 +950,7 @@ def test_rgb8_decode_lies_in_the_reference_interval(w, h, name):
     frames, pitch = qbist_frames(10, 1, w, h, PIX_RG48)
     sample = ref_encode_frames(frames, pitch, w, h, PIX_RG48, encoded=ENCODED_RGB444)[0]
     plan = Plan(w, h, pixkind=PIXKIND["RG48"], enc=3)
-    coeffs = host_decode_pyramid(sample, plan)
+    coeffs = oracle_decode_pyramid(sample, plan)
     bpp = 3 if name == "RG24" else 4
     lo = oracle_inverse_rgb8(plan, coeffs, bpp, name != "BGRa", 0)
     hi = oracle_inverse_rgb8(plan, coeffs, bpp, name != "BGRa", 127)
@@ -996,7 +996,7 @@ def test_rgb10_decode_equals_reference_exactly(w, h, name):
     assert (aw, ah) == (w, h)
     mine = np.frombuffer(got.tobytes(), np.uint32).reshape(h, gpitch // 4)[:, :w]
     plan = Plan(w, h, pixkind=PIXKIND["RG48"], enc=3)
-    want = oracle_inverse_rgb10(plan, host_decode_pyramid(sample, plan), name)[:h, :w]      # (pinned on the reference decoder on eight geometries: test_reference_rgb10_decode_equals_oracle)
+    want = oracle_inverse_rgb10(plan, oracle_decode_pyramid(sample, plan), name)[:h, :w]      # (pinned on the reference decoder on eight geometries: test_reference_rgb10_decode_equals_oracle)
     assert np.array_equal(mine, want), "%d words differ from the exact reconstruction" % (mine != want).sum()
     def leg():
         dec, dpitch = ref_decode_sample(sample, w, h, fourcc(name))
@@ -1052,7 +1052,7 @@ def test_rgba8_encode_to_rgba4444_bitstream_identical(w, h, name):
     own, opitch, aw, ah = amd_decode_sample(mine[0], fmt)
     assert (aw, ah) == (w, h)
     plan = Plan(w, h, pixkind=PIXKIND[name], enc=ENC["4444"])
-    want, alt = oracle_inverse_rgba8(plan, host_decode_pyramid(mine[0], plan), name == "BGRA")
+    want, alt = oracle_inverse_rgba8(plan, oracle_decode_pyramid(mine[0], plan), name == "BGRA")
     assert np.array_equal(own.reshape(h, opitch)[:, : w * 4], want)
     rows = h if h % 8 == 0 else h - 8                   # (the reference's last display rows are not reproducible for such heights: test_oracle_vs_ref)
     sl = slice(0, rows) if name == "BGRa" else slice(h - rows, h)
@@ -1201,7 +1201,7 @@ def test_b64a_decode_equals_reference(w, h):
     frame = px.reshape(-1).view(np.uint8).copy()
     sample = amd_encode_frames([frame], pitch, w, h, PIX_B64A, encoded=ENCODED_RGBA4444)[0]
     plan = Plan(w, h, pixkind=PIXKIND["b64a"], enc=ENC["4444"])
-    pyramid = host_decode_pyramid(sample, plan)
+    pyramid = oracle_decode_pyramid(sample, plan)
     exact = oracle_inverse_rgb48(plan, pyramid, b64a=True)[:h]
     got, gpitch, aw, ah = amd_decode_sample(sample, PIX_B64A)
     assert (aw, ah, gpitch) == (w, h, w * 8)
@@ -1279,7 +1279,7 @@ def test_interlaced_samples_at_half_resolution(w, h, fmt):
     assert (aw, ah) == (w // 2, h // 2)
     img = got.reshape(ah, pitch)[:, : aw * 2]
     plan = Plan(w, h, pixkind=2 if fmt == PIX_2VUY else 1, progressive=0)
-    want = oracle_half_resolution(plan, host_decode_pyramid(sample, plan), int(fmt == PIX_2VUY))
+    want = oracle_half_resolution(plan, oracle_decode_pyramid(sample, plan), int(fmt == PIX_2VUY))
     assert np.array_equal(img, want)
     def leg():
         out, rpitch = ref_decode_sample(sample, w, h, fmt, resolution=2)
@@ -1304,7 +1304,7 @@ def test_b64a_8k_config_c_round_trip():
     assert len(a) == len(b)
     assert mask_volatile_metadata(a) == mask_volatile_metadata(b)
     plan = Plan(w, h, pixkind=PIXKIND["b64a"], enc=ENC["4444"])
-    exact = oracle_inverse_rgb48(plan, host_decode_pyramid(a, plan), b64a=True)[:h]
+    exact = oracle_inverse_rgb48(plan, oracle_decode_pyramid(a, plan), b64a=True)[:h]
     got, gpitch, aw, ah = amd_decode_sample(a, PIX_B64A)
     assert (aw, ah) == (w, h)
     assert np.array_equal(np.frombuffer(got.tobytes(), np.uint16).reshape(h, gpitch // 2), exact)
@@ -1327,7 +1327,7 @@ def test_half_resolution_decode(w, h, fmt):
     sample = amd_encode_frames([f], p, w, h, fmt)[0]
     uyvy = int(fmt == PIX_2VUY)
     plan = Plan(w, h, pixkind=2 if uyvy else 1)
-    want = oracle_half_resolution(plan, host_decode_pyramid(sample, plan), uyvy)
+    want = oracle_half_resolution(plan, oracle_decode_pyramid(sample, plan), uyvy)
     out, pitch, aw, ah = amd_decode_sample(sample, fmt, resolution=2)
     assert (aw, ah, pitch) == (w // 2, h // 2, w)
     assert np.array_equal(out.reshape(ah, pitch), want)
@@ -1351,12 +1351,12 @@ def test_half_resolution_decode_16bit(w, h, b64a):
     frames, pitch = qbist_frames(10, 1, w, h, fmt, alpha=1) if b64a else qbist_frames(10, 1, w, h, fmt)
     sample = amd_encode_frames(frames, pitch, w, h, fmt, encoded=enc)[0]
     plan = Plan(w, h, pixkind=PIXKIND[kind], enc=ENC[encname])
-    want = oracle_half_resolution16(plan, host_decode_pyramid(sample, plan), bool(b64a))
+    want = oracle_half_resolution16(plan, oracle_decode_pyramid(sample, plan), bool(b64a))
     nch = 4 if b64a else 3
     out, opitch, aw, ah = amd_decode_sample(sample, fmt, resolution=2)
     assert (aw, ah) == (w // 2, h // 2)
     assert np.array_equal(np.frombuffer(out.tobytes(), np.uint16).reshape(ah, opitch // 2)[:, : aw * nch], want)
-    raw = oracle_half_resolution16(plan, host_decode_pyramid(sample, plan), bool(b64a), expand_alpha=False)
+    raw = oracle_half_resolution16(plan, oracle_decode_pyramid(sample, plan), bool(b64a), expand_alpha=False)
     # (the reference's half-resolution 16-bit decode depends on what its process did before -- other words in one colour component once `import torch` has run in
     # it, as in the CPU suite where this test runs on the emulated product after the torch tests; a fresh process gives the same words every time: cfhd_testlib)
     calls = [ref_decode_sample, ref_decode_sample, ref_decode_sample, ref_decode_sample_fresh_process]
@@ -1420,7 +1420,7 @@ def test_batched_path_of_the_other_configurations_equals_reference(name, w, h, n
         if fmt == PIX_YUY2:
             if i % nuniq not in exact:
                 plan = Plan(w, h, progressive=0)
-                deq = host_decode_pyramid(sample, plan)
+                deq = oracle_decode_pyramid(sample, plan)
                 exact[i % nuniq] = (oracle_inverse_interlaced_yuv422(plan, deq, 0)[:h], oracle_inverse_interlaced_yuv422(plan, deq, 1)[:h])
             lo, hi = exact[i % nuniq]
             img = out.reshape(h, w * 2)
@@ -1429,7 +1429,7 @@ def test_batched_path_of_the_other_configurations_equals_reference(name, w, h, n
         else:
             if i % nuniq not in exact:
                 plan = Plan(w, h, pixkind=PIXKIND["b64a" if fmt == PIX_B64A else "RG48"], enc=ENC["4444" if fmt == PIX_B64A else "444"])
-                exact[i % nuniq] = oracle_inverse_rgb48(plan, host_decode_pyramid(sample, plan), b64a=fmt == PIX_B64A)[:h]
+                exact[i % nuniq] = oracle_inverse_rgb48(plan, oracle_decode_pyramid(sample, plan), b64a=fmt == PIX_B64A)[:h]
             got = np.frombuffer(out.tobytes(), np.uint16).reshape(h, w * bpp // 2)
             assert np.array_equal(got, exact[i % nuniq]), "frame %d" % i
     L.cfhd_amd_batch_destroy(b)
@@ -1471,7 +1471,7 @@ def test_interlaced_strip_kernels_equal_reference(w, h, n, fmt):
             assert mask_volatile_metadata(sample) == mask_volatile_metadata(refs[i]), "frame %d differs from the reference" % i
             out = np.zeros(h * w * 2, dtype=np.uint8)
             assert L.cfhd_amd_batch_download_output(b, i, out.ctypes.data_as(ctypes.c_void_p), w * 2) == 0
-            deq = host_decode_pyramid(sample, plan)
+            deq = oracle_decode_pyramid(sample, plan)
             lo, hi = oracle_inverse_interlaced_yuv422(plan, deq, 0, uyvy=int(fmt == PIX_2VUY))[:h], oracle_inverse_interlaced_yuv422(plan, deq, 1, uyvy=int(fmt == PIX_2VUY))[:h]
             img = out.reshape(h, w * 2)
             ok = (img == lo) | (img == hi)
@@ -1550,7 +1550,7 @@ def test_packed16_strip_kernels_equal_reference(name, w, h, n, fmt, enc, mode):
             out = np.zeros(h * w * bpp, dtype=np.uint8)
             assert L.cfhd_amd_batch_download_output(b, i, out.ctypes.data_as(ctypes.c_void_p), w * bpp) == 0
             plan = Plan(w, h, pixkind=PIXKIND["b64a" if fmt == PIX_B64A else "RG48"], enc=ENC["4444" if fmt == PIX_B64A else "444"])
-            want = oracle_inverse_rgb48(plan, host_decode_pyramid(sample, plan), b64a=fmt == PIX_B64A)[:h]
+            want = oracle_inverse_rgb48(plan, oracle_decode_pyramid(sample, plan), b64a=fmt == PIX_B64A)[:h]
             assert np.array_equal(np.frombuffer(out.tobytes(), np.uint16).reshape(h, w * bpp // 2), want), "frame %d" % i
         L.cfhd_amd_batch_destroy(b)
     finally:
@@ -1588,7 +1588,7 @@ def _batched_yuy2_round_trip_equals_reference(w, h, n, nuniq, expect=None):
             first = next(k for k in range(len(ma)) if ma[k] != mb[k])
             raise AssertionError("frame %d differs from the reference at byte %d of %d" % (i, first, len(ma)))
         if i % nuniq not in interval:                           # frames repeat: same coefficients, one exact reconstruction per unique frame
-            deq = host_decode_pyramid(sample, plan)
+            deq = oracle_decode_pyramid(sample, plan)
             interval[i % nuniq] = (oracle_inverse_yuv422(plan, deq, 0)[:h], oracle_inverse_yuv422(plan, deq, 1)[:h])
         lo, hi = interval[i % nuniq]
         out = np.zeros(h * w * 2, dtype=np.uint8)
@@ -1634,7 +1634,7 @@ def test_frame_queue_of_batches_equals_synchronous_passes():
                     kk = bytes(buf[:160]).find(struct.pack(">h", -69)); buf[kk + 2:kk + 4] = b"\0\0"
                     u = bytes(buf[:1024]).find(b"UFRM"); buf[u + 8:u + 12] = b"\0\0\0\0"
                 assert bytes(a) == bytes(r), "round %d batch %d frame %d" % (rounds, k, i)
-                deq = host_decode_pyramid(sample, plan)
+                deq = oracle_decode_pyramid(sample, plan)
                 lo, hi = oracle_inverse_yuv422(plan, deq, 0)[:h], oracle_inverse_yuv422(plan, deq, 1)[:h]
                 out = np.zeros(h * w * 2, dtype=np.uint8)
                 assert L.cfhd_amd_batch_download_output(b, i, out.ctypes.data_as(ctypes.c_void_p), w * 2) == 0
@@ -1723,7 +1723,7 @@ def test_concurrent_decoders_share_launches_and_stay_exact():
         plan = Plan(w, h)
         bounds = []
         for smp in samples:
-            deq = host_decode_pyramid(smp, plan)
+            deq = oracle_decode_pyramid(smp, plan)
             bounds.append((oracle_inverse_yuv422(plan, deq, 0)[:h], oracle_inverse_yuv422(plan, deq, 1)[:h]))
         damaged = bytearray(samples[0]); damaged[len(damaged) // 2: len(damaged) // 2 + 64] = bytes(64)
         geoms.append((w, h, samples, bounds, bytes(damaged)))

@@ -82,7 +82,7 @@ def test_reference_decode_lies_in_oracle_dither_interval(w, h, fmt):
     sample = ref_encode_frames([f], p, w, h, fmt)[0]
     uyvy = int(fmt == PIX_2VUY)
     plan = Plan(w, h, pixkind=2 if uyvy else 1)
-    coeffs = host_decode_pyramid(sample, plan)
+    coeffs = oracle_decode_pyramid(sample, plan)
     lo = oracle_inverse_yuv422(plan, coeffs, 0, uyvy)[:h]
     hi = oracle_inverse_yuv422(plan, coeffs, 1, uyvy)[:h]
     for attempt in range(6):                            # the reference's threaded decoder occasionally damages a frame: three attempts
@@ -107,7 +107,7 @@ def test_reference_half_resolution_decode_equals_model(w, h, fmt, interlaced):
     sample = ref_encode_frames([f], p, w, h, fmt, flags=interlaced)[0]
     uyvy = int(fmt == PIX_2VUY)
     plan = Plan(w, h, pixkind=2 if uyvy else 1, progressive=0 if interlaced else 1)
-    want = oracle_half_resolution(plan, host_decode_pyramid(sample, plan), uyvy)
+    want = oracle_half_resolution(plan, oracle_decode_pyramid(sample, plan), uyvy)
     assert want.shape == (h // 2, w)
     for attempt in range(6):                            # the reference's threaded decoder occasionally damages a frame: three attempts
         out, pitch = ref_decode_sample(sample, w, h, fmt, resolution=2)
@@ -123,8 +123,8 @@ def test_reference_half_resolution_16bit_equals_model(w, h, b64a):
     frames, pitch = qbist_frames(10, 1, w, h, fmt, alpha=1) if b64a else qbist_frames(10, 1, w, h, fmt)
     sample = ref_encode_frames(frames, pitch, w, h, fmt, encoded=enc)[0]
     plan = Plan(w, h, pixkind=PIXKIND[kind], enc=ENC[encname])
-    want = oracle_half_resolution16(plan, host_decode_pyramid(sample, plan), bool(b64a))
-    raw = oracle_half_resolution16(plan, host_decode_pyramid(sample, plan), bool(b64a), expand_alpha=False)
+    want = oracle_half_resolution16(plan, oracle_decode_pyramid(sample, plan), bool(b64a))
+    raw = oracle_half_resolution16(plan, oracle_decode_pyramid(sample, plan), bool(b64a), expand_alpha=False)
     nch = 4 if b64a else 3
     for attempt in range(6):
         out, dpitch = ref_decode_sample(sample, w, h, fmt, resolution=2)
@@ -141,7 +141,7 @@ def test_reference_rg48_decode_equals_oracle(w, h):
     frames, pitch = qbist_frames(10, 1, w, h, PIX_RG48)
     sample = ref_encode_frames(frames, pitch, w, h, PIX_RG48, encoded=ENCODED_RGB444)[0]
     plan = Plan(w, h, pixkind=PIXKIND["RG48"], enc=3)
-    mine = oracle_inverse_rgb48(plan, host_decode_pyramid(sample, plan))[:h]
+    mine = oracle_inverse_rgb48(plan, oracle_decode_pyramid(sample, plan))[:h]
     # the reference's threaded decoder now and then returns a frame with damaged stretches (seen on 8 and on 256 cores, also as PSNR
     # outliers in its own harness): it gets three attempts to reproduce the deterministic reconstruction
     for attempt in range(6):
@@ -167,7 +167,7 @@ def test_reference_yu64_decode_equals_oracle(w, h, src):
         f, p = synth_yuy2(w, h, 11)
         sample = ref_encode_frames([f], p, w, h, PIX_YUY2)[0]
     plan = Plan(w, h, pixkind=PIXKIND["YU64"])            # (the output format decides the bias of the lowpass band: 4 instead of 24, decoder.c:12270)
-    mine = oracle_inverse_yu64(plan, host_decode_pyramid(sample, plan))[:h]
+    mine = oracle_inverse_yu64(plan, oracle_decode_pyramid(sample, plan))[:h]
     for attempt in range(6):                            # (the reference's threaded decoder occasionally damages a frame)
         dec, dpitch = ref_decode_sample(sample, w, h, fourcc("YU64"))
         img = np.frombuffer(dec.tobytes(), dtype=np.uint16).reshape(h, dpitch // 2)[:, : w * 2]
@@ -191,7 +191,7 @@ def test_reference_v210_decode_equals_oracle(w, h, src):
         sample = ref_encode_frames([f], p, w, h, PIX_YUY2)[0]
     plan = Plan(w, h, pixkind=PIXKIND["YU64"])
     nwords = (w // 6) * 4
-    mine = oracle_inverse_v210(plan, host_decode_pyramid(sample, plan), w)
+    mine = oracle_inverse_v210(plan, oracle_decode_pyramid(sample, plan), w)
     for attempt in range(6):                            # (the reference's threaded decoder occasionally damages a frame)
         dec, dpitch = ref_decode_sample(sample, w, h, fourcc("v210"))
         img = np.frombuffer(dec.tobytes(), dtype=np.uint32).reshape(h, dpitch // 4)[:, :nwords]
@@ -213,7 +213,7 @@ def test_reference_rgb10_decode_equals_oracle(w, h, name, ramps):
         frames = [np.frombuffer(px.tobytes(), np.uint8).copy()]
     sample = ref_encode_frames(frames, pitch, w, h, PIX_RG48, encoded=ENCODED_RGB444)[0]
     plan = Plan(w, h, pixkind=PIXKIND["RG48"], enc=3)
-    mine = oracle_inverse_rgb10(plan, host_decode_pyramid(sample, plan), name)[:h, :w]
+    mine = oracle_inverse_rgb10(plan, oracle_decode_pyramid(sample, plan), name)[:h, :w]
     for attempt in range(6):                            # (the reference's threaded decoder occasionally damages a frame)
         dec, dpitch = ref_decode_sample(sample, w, h, fourcc(name))
         img = np.frombuffer(dec.tobytes(), dtype=np.uint32).reshape(h, dpitch // 4)[:, :w]
@@ -235,7 +235,7 @@ def test_reference_rgb8_decode_lies_in_oracle_dither_interval(w, h, name):
     frames, pitch = qbist_frames(10, 1, w, h, PIX_RG48)
     sample = ref_encode_frames(frames, pitch, w, h, PIX_RG48, encoded=ENCODED_RGB444)[0]
     plan = Plan(w, h, pixkind=PIXKIND["RG48"], enc=3)
-    coeffs = host_decode_pyramid(sample, plan)
+    coeffs = oracle_decode_pyramid(sample, plan)
     bpp = 3 if name == "RG24" else 4
     lo = oracle_inverse_rgb8(plan, coeffs, bpp, name != "BGRa", 0)
     hi = oracle_inverse_rgb8(plan, coeffs, bpp, name != "BGRa", 127)
@@ -262,7 +262,7 @@ def test_reference_rgba8_decode_of_4444_equals_oracle(w, h, name, seed):
     frames, pitch = qbist_frames(seed, 1, w, h, fmt, alpha=1)
     sample = ref_encode_frames(frames, pitch, w, h, fmt, encoded=ENCODED_RGBA4444)[0]
     plan = Plan(w, h, pixkind=PIXKIND[name], enc=ENC["4444"])
-    want, alt = oracle_inverse_rgba8(plan, host_decode_pyramid(sample, plan), name == "BGRA")
+    want, alt = oracle_inverse_rgba8(plan, oracle_decode_pyramid(sample, plan), name == "BGRA")
     # Heights that are not multiples of 8: the reference's last display rows come out differently from call to call (equal to the oracle in a fresh
     # process, one or two steps off in six rows after other decodes in the same process: something below the picture is not rewritten); they are left
     # out of the comparison here.
@@ -289,7 +289,7 @@ def test_reference_rgb24_decode_of_yuv422_lies_in_oracle_interval(w, h, flags, s
     sample = ref_encode_frames(frames, pitch, w, h, PIX_RG24, encoded=ENCODED_YUV422, flags=flags)[0]
     plan = Plan(w, h, pixkind=PIXKIND["RG24"], enc=1)     # (the output format decides the lowpass bias: odd lowpass widths -- 336 / 16 = 21 for chroma -- take -3 / +1, decoder.c:12500)
     cs = 1 if flags & 4 else 2                           # (the reference decoder ignores the video-range bit of the sample's tag: probed, PSNR drops to 26 dB)
-    co = host_decode_pyramid(sample, plan)
+    co = oracle_decode_pyramid(sample, plan)
     lo = oracle_inverse_rgb24_of_yuv422(plan, co, 0, cs); hi = oracle_inverse_rgb24_of_yuv422(plan, co, 32767, cs)
     rows = h if h % 8 == 0 else h - 8                   # (bottom row first: the picture's last rows are the first rows of the buffer)
     for attempt in range(6):                            # see test_reference_rg48_decode_equals_oracle
@@ -315,7 +315,7 @@ def test_reference_b64a_decode_of_rgb444_equals_model(w, h, seed):
     px[:, 1: w * 4: 4] = np.where(ramp > 60000, 65535, np.where(ramp < 4000, 0, px[:, 1: w * 4: 4]))      # red: stretches at both clips
     sample = ref_encode_frames([px.reshape(-1).view(np.uint8).copy()], pitch, w, h, PIX_B64A, encoded=ENCODED_RGB444)[0]
     plan = Plan(w, h, pixkind=PIXKIND["b64a"], enc=ENC["444"])
-    want = oracle_inverse_b64a_of_rgb444(plan, host_decode_pyramid(sample, plan))[:h]
+    want = oracle_inverse_b64a_of_rgb444(plan, oracle_decode_pyramid(sample, plan))[:h]
     rows = h if h % 8 == 0 else h - 8
     for attempt in range(6):                            # see test_reference_rg48_decode_equals_oracle
         dec, dpitch = ref_decode_sample(sample, w, h, PIX_B64A)
@@ -337,7 +337,7 @@ def test_reference_rg48_decode_of_rgba4444_equals_oracle(w, h, seed):
         px[:, word: w * 4: 4] = np.where(ramp > 60000, 65535, np.where(ramp < 4000, 0, px[:, word: w * 4: 4]))
     sample = ref_encode_frames([px.reshape(-1).view(np.uint8).copy()], pitch, w, h, PIX_B64A, encoded=ENCODED_RGBA4444)[0]
     plan = Plan(w, h, pixkind=PIXKIND["b64a"], enc=ENC["4444"])
-    deq = host_decode_pyramid(sample, plan)
+    deq = oracle_decode_pyramid(sample, plan)
     want = oracle_inverse_rgb48(plan, deq)[:h].reshape(h, w, 4)[:, :, :3].reshape(h, w * 3)
     rows = h if h % 8 == 0 else h - 8                   # (1080: the reference's encoder transforms whatever its heap holds below the picture, its decoder's last rows change from call to call -- test_reference_rgba8_decode_of_4444_equals_oracle; the other heights are multiples of 8)
     for attempt in range(6):
@@ -387,7 +387,7 @@ def test_reference_half_resolution_of_rgb444_equals_model(w, h, seed):
     lies inside [r = 0, r = 31] for RG24 / BGRA / BGRa, reaching both ends."""
     sample = rgb444_sample_with_clips(w, h, seed)
     plan = Plan(w, h, pixkind=PIXKIND["RG48"], enc=ENC["444"])
-    deq = host_decode_pyramid(sample, plan)
+    deq = oracle_decode_pyramid(sample, plan)
     hh = h // 2 if h % 8 == 0 else h // 2 - 4          # (1080: the reference's last rows, see test_reference_rgba8_decode_of_4444_equals_oracle)
     for name in ("r210", "DPX0", "AB10", "AR10", "b64a"):
         want = oracle_half_resolution_rgb(plan, deq, name)[: h // 2]
@@ -420,7 +420,7 @@ def test_reference_half_resolution_bgra_of_rgba4444_equals_model(w, h, seed):
     4:4:4:4 sample, byte for byte (a row of the reference that lost its alpha_Companded race -- bayer.c:13871 / :16034 -- is accepted with the companded alpha, as at full resolution)."""
     sample = rgba4444_sample_with_clips(w, h, seed)
     plan = Plan(w, h, pixkind=PIXKIND["b64a"], enc=ENC["4444"])
-    want = oracle_half_resolution_rgba8(plan, host_decode_pyramid(sample, plan))[: h // 2]
+    want = oracle_half_resolution_rgba8(plan, oracle_decode_pyramid(sample, plan))[: h // 2]
     hh = h // 2 if h % 8 == 0 else h // 2 - 4
     for name in ("BGRa", "BGRA"):
         for attempt in range(6):
@@ -447,7 +447,7 @@ def test_reference_half_resolution_yu64_equals_model(w, h, seed):
     saturated blocks: the reference's half-resolution YU64 decode of a 4:2:2 sample, word for word."""
     sample = ref_encode_frames([yu64_frame_with_ramps(w, h, seed)], w * 4, w, h, fourcc("YU64"))[0]
     plan = Plan(w, h, pixkind=PIXKIND["YU64"])
-    want = oracle_half_resolution_yu64(plan, host_decode_pyramid(sample, plan))[: h // 2]
+    want = oracle_half_resolution_yu64(plan, oracle_decode_pyramid(sample, plan))[: h // 2]
     hh = h // 2 if h % 8 == 0 else h // 2 - 4
     for attempt in range(6):
         dec, dpitch = ref_decode_sample(sample, w, h, fourcc("YU64"), resolution=2)
@@ -463,7 +463,7 @@ def test_reference_half_resolution_v210_equals_model(w, h, seed):
     v210 decode of a 4:2:2 sample, word for word."""
     sample = ref_encode_frames([yu64_frame_with_ramps(w, h, seed)], w * 4, w, h, fourcc("YU64"))[0]
     plan = Plan(w, h, pixkind=PIXKIND["v210"])
-    want = oracle_half_resolution_v210(plan, host_decode_pyramid(sample, plan))[: h // 2]
+    want = oracle_half_resolution_v210(plan, oracle_decode_pyramid(sample, plan))[: h // 2]
     hh = h // 2 if h % 8 == 0 else h // 2 - 4
     for attempt in range(6):
         dec, dpitch = ref_decode_sample(sample, w, h, fourcc("v210"), resolution=2)
@@ -479,7 +479,7 @@ def test_reference_half_resolution_rg24_of_yuv422_equals_model(w, h, seed, flags
     f, p = synth_yuy2(w, h, seed)
     sample = ref_encode_frames([f], p, w, h, PIX_YUY2, flags=flags)[0]
     plan = Plan(w, h, pixkind=PIXKIND["RG24"])
-    want = oracle_half_resolution_rgb24_of_yuv422(plan, host_decode_pyramid(sample, plan), 1 if flags & 4 else 2)
+    want = oracle_half_resolution_rgb24_of_yuv422(plan, oracle_decode_pyramid(sample, plan), 1 if flags & 4 else 2)
     want = want[want.shape[0] - h // 2:]                  # (bottom row first: the picture's rows are the last h / 2 of the padded plane)
     hh = h // 2 if h % 8 == 0 else h // 2 - 4
     for attempt in range(6):
@@ -499,7 +499,7 @@ def test_reference_half_resolution_of_interlaced_samples_as_yu64_and_v210(w, h, 
     for name in ("YU64", "v210"):
         if name == "v210" and (w // 2) % 6: continue
         plan = Plan(w, h, pixkind=PIXKIND[name], progressive=0)
-        deq = host_decode_pyramid(sample, plan)
+        deq = oracle_decode_pyramid(sample, plan)
         want = (oracle_half_resolution_yu64 if name == "YU64" else oracle_half_resolution_v210)(plan, deq)[: h // 2]
         for attempt in range(6):
             dec, dpitch = ref_decode_sample(sample, w, h, fourcc(name), resolution=2)
@@ -528,7 +528,7 @@ def test_reference_byr4_decode_of_bayer_equals_oracle(w, h, seed):
     mosaic = bayer_test_mosaic(w, h, seed)
     sample = ref_encode_frames([np.frombuffer(mosaic.tobytes(), np.uint8).copy()], w * 2, w, h, fourcc("BYR4"), encoded=ENCODED_BAYER)[0]
     plan = Plan(w, h, pixkind=PIXKIND["BYR4"], enc=ENC["bayer"])
-    want = oracle_inverse_byr4(plan, host_decode_pyramid(sample, plan))[:h, :w]
+    want = oracle_inverse_byr4(plan, oracle_decode_pyramid(sample, plan))[:h, :w]
     for attempt in range(6):
         dec, dpitch = ref_decode_sample(sample, w, h, fourcc("BYR4"))
         img = np.frombuffer(dec.tobytes(), dtype=np.uint16).reshape(h, dpitch // 2)[:, :w]
@@ -549,7 +549,7 @@ def test_reference_b64a_decode_equals_oracle(w, h):
     px[:, 0: w * 4: 4] = ((np.arange(h)[:, None] * 523 + np.arange(w)[None, :] * 97) % 65536).astype(np.uint16)
     sample = ref_encode_frames([px.reshape(-1).view(np.uint8).copy()], pitch, w, h, PIX_B64A, encoded=ENCODED_RGBA4444)[0]
     plan = Plan(w, h, pixkind=PIXKIND["b64a"], enc=ENC["4444"])
-    mine = oracle_inverse_rgb48(plan, host_decode_pyramid(sample, plan), b64a=True)[:h]
+    mine = oracle_inverse_rgb48(plan, oracle_decode_pyramid(sample, plan), b64a=True)[:h]
     for attempt in range(6):                            # see test_reference_rg48_decode_equals_oracle
         dec, dpitch = ref_decode_sample(sample, w, h, PIX_B64A)
         img = np.frombuffer(dec.tobytes(), dtype=np.uint16).reshape(h, dpitch // 2)[:, : w * 4]
@@ -557,7 +557,7 @@ def test_reference_b64a_decode_equals_oracle(w, h):
     assert np.array_equal(mine[:, 1::4], img[:, 1::4]) and np.array_equal(mine[:, 2::4], img[:, 2::4]) and np.array_equal(mine[:, 3::4], img[:, 3::4])
     rows_ok = (mine[:, 0::4] == img[:, 0::4]).all(axis=1)          # (no share of rows is required: on a busy host the race is lost on most of them)
     if not rows_ok.all():
-        raw = oracle_inverse_rgb48(plan, host_decode_pyramid(sample, plan), b64a=False)[:h]      # same planes without the alpha expansion
+        raw = oracle_inverse_rgb48(plan, oracle_decode_pyramid(sample, plan), b64a=False)[:h]      # same planes without the alpha expansion
         bad = np.where(~rows_ok)[0]
         assert np.array_equal(img[bad][:, 0::4], raw[bad][:, 3::4])
     # the expansion undoes the encoder's companding to within the quantization error
@@ -584,7 +584,7 @@ def test_interlaced_level1_oracle_equals_reference_coefficients(w, h):
         outs = [plan.view(coeffs, c, 0, b) for b in range(4)]
         bands = (c_i16p * 4)(*[o.ctypes.data_as(c_i16p) for o in outs])
         O.orc_fwd_frame_yuv422(p8(frame), pitch, cw, plan.height, c, plan.precision - 8, 0, iarr(q), plan.mpq, bands, outs[0].shape[1])
-    deq = host_decode_pyramid(sample, plan, lowpass_offset=0)
+    deq = oracle_decode_pyramid(sample, plan, lowpass_offset=0)
     for c in range(3):
         for b in (1, 2, 3):
             bw = plan.band[(c, 0, b)]["width"]
@@ -606,7 +606,7 @@ def test_reference_interlaced_decode_lies_in_oracle_dither_interval(w, h, fmt, k
     sample = ref_encode_frames([frame], pitch, w, h, fmt, flags=1)[0]
     uyvy = int(fmt == PIX_2VUY)
     plan = Plan(w, h, pixkind=2 if uyvy else 1, progressive=0)
-    coeffs = host_decode_pyramid(sample, plan)
+    coeffs = oracle_decode_pyramid(sample, plan)
     lo = oracle_inverse_interlaced_yuv422(plan, coeffs, 0, uyvy)[:h]
     hi = oracle_inverse_interlaced_yuv422(plan, coeffs, 1, uyvy)[:h]
     for attempt in range(6):
@@ -641,7 +641,7 @@ def test_reference_rg48_and_b64a_decode_of_yuv422_equals_oracle(w, h, name, flag
     sample = _yuv422_sample_for_rgb_outputs(w, h, w + h, flags)
     b64a = name == "b64a"
     plan = Plan(w, h, pixkind=PIXKIND[name], enc=ENC["422"])
-    mine = oracle_inverse_rgb16_of_yuv422(plan, host_decode_pyramid(sample, plan), b64a, 1 if flags & 4 else 2)[:h]
+    mine = oracle_inverse_rgb16_of_yuv422(plan, oracle_decode_pyramid(sample, plan), b64a, 1 if flags & 4 else 2)[:h]
     nw = 4 if b64a else 3
     rows = h if h % 8 == 0 else h - 8
     for attempt in range(6):
@@ -660,7 +660,7 @@ def test_reference_bgra_decode_of_yuv422_equals_oracle(w, h, name, flags):
     biases for the two formats (decoder.c:12500-12508), 709 and 601, clips at both ends."""
     sample = _yuv422_sample_for_rgb_outputs(w, h, w + h, flags)
     plan = Plan(w, h, pixkind=PIXKIND[name], enc=ENC["422"])
-    mine = oracle_inverse_rgb32_of_yuv422(plan, host_decode_pyramid(sample, plan), name == "BGRA", 1 if flags & 4 else 2)[:h]
+    mine = oracle_inverse_rgb32_of_yuv422(plan, oracle_decode_pyramid(sample, plan), name == "BGRA", 1 if flags & 4 else 2)[:h]
     rows = h if h % 8 == 0 else h - 8
     sl = slice(h - rows, h) if name == "BGRA" else slice(0, rows)       # (the picture's last display rows are not reproducible for such heights; bottom-up: they come first)
     for attempt in range(6):
@@ -678,7 +678,7 @@ def test_reference_half_resolution_bgra_of_yuv422_equals_model(w, h, name, flags
     BGRA / BGRa decode of a 4:2:2 sample, byte for byte."""
     sample = _yuv422_sample_for_rgb_outputs(w, h, w + h, flags)
     plan = Plan(w, h, pixkind=PIXKIND[name], enc=ENC["422"])
-    want = oracle_half_resolution_rgb32_of_yuv422(plan, host_decode_pyramid(sample, plan), name == "BGRA", 1 if flags & 4 else 2)
+    want = oracle_half_resolution_rgb32_of_yuv422(plan, oracle_decode_pyramid(sample, plan), name == "BGRA", 1 if flags & 4 else 2)
     hh = h // 2 if h % 8 == 0 else h // 2 - 4
     for attempt in range(6):
         dec, dpitch = ref_decode_sample(sample, w, h, fourcc(name), resolution=2)
@@ -696,7 +696,7 @@ def test_reference_half_resolution_rg48_and_b64a_of_yuv422_equals_model(w, h, na
     sample = _yuv422_sample_for_rgb_outputs(w, h, w + h, flags)
     plan = Plan(w, h, pixkind=PIXKIND[name], enc=ENC["422"])
     nw = 4 if name == "b64a" else 3
-    want = oracle_half_resolution_rgb16_of_yuv422(plan, host_decode_pyramid(sample, plan), name == "b64a", 1 if flags & 4 else 2)
+    want = oracle_half_resolution_rgb16_of_yuv422(plan, oracle_decode_pyramid(sample, plan), name == "b64a", 1 if flags & 4 else 2)
     hh = h // 2 if h % 8 == 0 else h // 2 - 4
     for attempt in range(6):
         dec, dpitch = ref_decode_sample(sample, w, h, fourcc(name), resolution=2)
@@ -704,3 +704,31 @@ def test_reference_half_resolution_rg48_and_b64a_of_yuv422_equals_model(w, h, na
         if np.array_equal(img[:hh], want[:hh]): break
     bad = np.argwhere(img[:hh] != want[:hh])
     assert len(bad) == 0, (len(bad), bad[:6].tolist(), [(int(img[r, c]), int(want[r, c])) for r, c in bad[:6]])
+
+
+@pytest.mark.parametrize("w,h,pix,enc,flags", [(320, 240, "YUY2", 1, 0), (336, 252, "YUY2", 1, 0), (1920, 1080, "YUY2", 1, 0), (720, 480, "YUY2", 1, 1), (336, 252, "2vuy", 1, 1),
+                                               (320, 240, "RG48", 3, 0), (328, 248, "b64a", 4, 0), (640, 480, "BYR4", 2, 0)])
+def test_oracle_sample_walk_equals_product_host_decoder(w, h, pix, enc, flags):
+    """Two independent restatements of the sample syntax and the entropy code -- the oracle's tag walk + bit-serial trie decoder (oracle/cfhd_oracle_ent.c
+    orc_decode_sample: no size fields, a band ends where its code words end, as in Codec/decoder.c) and the product's host parser + table decoder (csrc/cfhd_bitstream.cpp,
+    chunk sizes) -- give the same coefficients on reference samples of every encoded format, incl. interlaced frames with peak tables (code set 18, difference coding).
+    The decode gates of the GPU tests use the oracle's; the emulated kernel tests use the product's host decoder as the kernels' twin: this test ties the two."""
+    fmt = fourcc(pix)
+    if flags:
+        f, p = field_flicker_frame(w, h)
+        if pix == "2vuy": f = np.ascontiguousarray(f.reshape(h, p).reshape(h, p // 2, 2)[:, :, ::-1]).reshape(-1)
+    elif pix == "BYR4":
+        f = synth_bayer(w, h, 11).reshape(-1).view(np.uint8).copy(); p = w * 2
+    elif pix == "YUY2":
+        f, p = synth_yuy2(w, h, 7)
+    else:
+        fr, p = qbist_frames(10, 1, w, h, fmt, alpha=1 if pix == "b64a" else 0); f = fr[0]
+    sample = ref_encode_frames([f], p, w, h, fmt, encoded={1: ENCODED_YUV422, 2: ENCODED_BAYER, 3: ENCODED_RGB444, 4: ENCODED_RGBA4444}[enc], flags=flags)[0]
+    if flags:
+        levels = [int.from_bytes(sample[i + 2:i + 4], "big") for i in range(0, len(sample) - 4, 4) if sample[i:i + 2] == b"\xff\xb6"]      # TAG_PEAK_LEVEL (optional)
+        assert any(levels), "the interlaced test frame was expected to carry a peak table"
+    plan = Plan(w, h, pixkind=PIXKIND[pix], enc=enc, progressive=0 if flags else 1)
+    a = oracle_decode_pyramid(sample, plan); b = host_decode_pyramid(sample, plan)
+    for (c, lv, bb), d in plan.band.items():
+        if bb == 0 and lv != 2: continue
+        assert np.array_equal(plan.view(a, c, lv, bb)[:, : d["width"]], plan.view(b, c, lv, bb)[:, : d["width"]]), (c, lv, bb)
