@@ -75,11 +75,18 @@ enum {
 	DX_OFF_INVALID = 31,              // entry: no code word of the true sequence starts in this piece (behind the band end marker / the payload)
 	// the single-pass arrangement (k_dec_index_emit + k_dec_scatter): the index walk leaves, per 64-bit piece, the nonzero coefficients its code words hold
 	DX_KE = 11,                       // bits of the window of its table (emit11: 8 bytes per window, 16 KB like the 12-bit table of 4-byte entries it replaces in LDS)
-	DX_REC_SLOT = 32,                 // dwords of a piece's record slot (one 128-byte line): at most 22 code words of a value start in 64 bits (3 bits the shortest), + the step's spare word
-	DX_REC_MAX = 22,
-	DX_REC_CHUNK = DX_ENTRY_STRIDE * DX_REC_SLOT,      // dwords of a wave's scratch slots (lane-major like the entries: lane t's four pieces at 4 t .. 4 t + 3)
-	DX_DENSE_GROUP = 4,               // records per 16-byte group: a piece's records leave the scratch slots as whole groups, packed piece behind piece
-	DX_DENSE_CHUNK = DX_CHUNK_SUBS * ((DX_REC_MAX + DX_DENSE_GROUP - 1) / DX_DENSE_GROUP) * DX_DENSE_GROUP,      // dwords of a chunk's packed records, worst case (24 KB; the part in use is contiguous from its start)
+	// A piece's step log: 16-bit words, the first 16 in a 32-byte slot, the rest -- a piece can take 22 steps: two group steps in a row consume at least 12 bits, but in
+	// the last 10 bits in front of a mark a group that would pass it is refused and the walk goes one code word (one bit, for a single zero) at a time -- in a second
+	// slot of the same size in the second half of the chunk's log area, which ordinary pieces never touch.
+	DX_REC_SLOT = 8,                  // dwords of a slot
+	DX_REC_MAX = 31,                  // last step a log holds (the walk stops counting there: in-bounds whatever the data)
+	DX_REC_CHUNK = DX_ENTRY_STRIDE * DX_REC_SLOT,      // dwords of one half of a chunk's log area (8 KB, lane-major like the entries: lane t's four pieces at 4 t .. 4 t + 3)
+	DX_LOG_CHUNK = 2 * DX_REC_CHUNK,  // dwords of a chunk's log area
+	// a step of the log: bits 14-15 kind, bits 0-13 payload
+	DX_LOG_FIRST = 0,                 // the first code word of emit11[payload]
+	DX_LOG_GROUP = 1,                 // the whole group of emit11[payload]
+	DX_LOG_VALUE = 2,                 // a value too long for the table: payload = the expanded magnitude with its sign (14 bits, two's complement)
+	DX_LOG_RUN = 3,                   // a zero run too long for the table: payload = its length
 };
 enum : uint32_t { DX_END = 0xFFFFFFFFu, DX_BAD = 0xFFFFFFFEu, DX_SPECIAL = 0xFFFFFFFEu };
 enum { DX_FLAG_END = 1, DX_FLAG_BAD = 2, DX_FLAG_UNRESOLVED = 4, DX_ERR_BAD = 1 << 1, DX_ERR_OVERFLOW = 1 << 2, DX_ERR_NOEND = 1 << 3, DX_ERR_SPACE = 1 << 4 };
@@ -120,7 +127,7 @@ struct DxChunkRec { uint32_t start, end, count, flags; };   // start / end: bit 
 // A chunk in front of which the code has no unique alignment (its run-in from every possible offset leaves several candidates for its first
 // code word) is indexed once per candidate: the record holds candidate 0 (the entries are written for it), this the others.
 enum { DX_MAX_ALT = 3 };
-struct DxChunkAlt { uint32_t start[DX_MAX_ALT], end[DX_MAX_ALT], count[DX_MAX_ALT]; uint32_t slot; uint32_t groups[DX_MAX_ALT]; /* k_dec_index_emit: 16-byte groups of the candidate's packed records */ };      // slot: the candidates' entries sit in alt_entries[slot + q] (DX_BAD: not kept)
+struct DxChunkAlt { uint32_t start[DX_MAX_ALT], end[DX_MAX_ALT], count[DX_MAX_ALT]; uint32_t slot; };      // slot: the candidates' entries sit in alt_entries[slot + q] (DX_BAD: not kept)
 struct DxReindex { uint32_t chunk, k, start; int job; };      // a chunk whose entries have to be written again for the start that turned out to be the true one
 struct DxBandSum { uint32_t total; int last_chunk; };        // coefficients the band's code words cover; chunk that holds the band end marker
 
@@ -814,25 +821,20 @@ __global__ void __launch_bounds__(DX_THREADS) k_dec_reindex(const DxBandJob *job
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------------
-// The single-pass arrangement (round 5): every payload bit is decoded once.
+// The single-pass arrangement (round 5): every payload bit is walked once.
 //
 // k_dec_index walks every bit to find where code words start and what they cover, and k_dec_tiles walked every bit again to learn what the code
-// words say.  The walk below is the same walk over the same pieces with the same hand-over between lanes, rounds and chunks, but a step that
-// passes a value also writes it down: per 64-bit piece a slot of one 128-byte line takes the records (position relative to the piece's first
-// code word << 16 | value, expanded, not yet multiplied by the band's divisor) of the values whose code words start in the piece, in raster
-// order.  Positions relative to the PIECE are what makes this fit the speculative walk: when a lane's second walk meets its first at a 64-bit
-// mark, the pieces behind the mark keep their records as they keep their entries -- only the counts in front of them shift, and those live in
-// the entries.  A piece that is walked again has all its records written again (same lane, same addresses, program order).
-// The slots are scratch memory of the WAVE (32 KB, written again for every chunk the wave indexes, so they live in the caches: the first build
-// gave every chunk its own slots and made the tile pass fetch a 128-byte line for 22 bytes of records -- 3.8 GB per 512 frames, as slow as decoding).
-// When a chunk's walk has settled every lane copies its pieces' records, as whole 16-byte groups, into the chunk's packed record stream, piece
-// behind piece (a wave scan over the group counts gives the places), and leaves per piece where its records start and how many they are.
-// k_dec_scatter then turns pieces into tiles without a code table: entry + chunk position + records -> LDS image of the tile -> 16-byte stores.
-//
-// Two records leave per step in one 8-byte store at the piece's next free place (the table entry of a step holds at most two values): the ones
-// the step does not have are overwritten by the next step's or lie behind the piece's count.  22 values at most start in 64 bits, the store
-// reaches one word further: a slot of 32 words is never left.
-__device__ __forceinline__ void dx_store_rec2(uint32_t *at, uint32_t a, uint32_t b) { store_u32x2_dword_aligned(at, a, b); }
+// words say.  The walk below is the same walk over the same pieces with the same hand-over between lanes, rounds and chunks, but it keeps a LOG:
+// per 64-bit piece one 16-bit word per step -- which table entry the step took and whether it took the entry's first code word or its whole
+// group, or, for a code word beyond the table, the value / the run itself.  The log is all k_dec_scatter needs to put the piece's values into a
+// tile: entry + chunk position + the steps' table entries, looked up again (independent LDS reads, no bit window, no refill, no dependent chain
+// but the running position).  A log is relative to its PIECE, which is what makes this fit the speculative walk: when a lane's second walk
+// meets its first at a 64-bit mark, the pieces behind the mark keep their logs as they keep their entries -- only the counts in front of them
+// shift, and those live in the entries.  A piece that is walked again has its log written again (same lane, same addresses, program order).
+// What the first two builds of the round taught (profiles/r05_a_*, r05_b_*): finished (position, value) records in a 128-byte slot per piece made
+// the tile pass fetch 3.8 GB of mostly empty lines per 512 frames -- as slow as decoding --, and packing the records behind the walk (wave
+// scratch slots + a copy into a dense stream per chunk) cost the index pass a dozen dependent round trips per chunk (+0.9 ms).  Sixteen bits per
+// step in a 32-byte slot need neither: 8 KB of logs per chunk, four pieces to a cache line, consecutive lanes of the tile pass on consecutive slots.
 __device__ __forceinline__ int dx_sext6(uint32_t y, int lsb) { return (int)(y << (26 - lsb)) >> 26; }
 
 // the code word behind a window nothing of which fits the first-level table (le = the table's y: the entry of the code word or an escape into long11[])
@@ -845,24 +847,23 @@ __device__ __forceinline__ uint32_t dx_long11_entry(uint32_t le, const uint32_t 
 	return le;
 }
 
-// The steps of a walk up to a mark (dx_steps with the 11-bit table).  EMIT: count the coefficients and write the values down -- slot: the piece's records,
-// nrec: how many it holds, base: the count at the piece's first code word.
-template <bool EMIT>
+// The steps of a walk up to a mark (dx_steps with the 11-bit table).  LOG: count the coefficients and log the steps -- slot: the piece's log, nsteps: steps in it.
+template <bool LOG>
 __device__ __forceinline__ bool dx_steps_e(DxBitsAhead &B, uint32_t &pos, uint32_t &cnt, const uint32_t lim, uint32_t &endv, const uint32_t *s_words, const uint2 *s_tab, const uint32_t *s_long,
-                                           const bool linear, uint32_t *slot, uint32_t &nrec, const uint32_t base)
+                                           const bool linear, uint16_t *slot, uint32_t &nsteps)
 {
 	bool ok = true;
 	bool go = pos < lim;
 	while (go) {
 		const uint32_t win = B.window();
-		const uint2 t = s_tab[win >> (32 - DX_KE)];
+		const uint32_t wi = win >> (32 - DX_KE);
+		const uint2 t = s_tab[wi];
 		const uint32_t ahead = B.prefetch(s_words);
 		const uint32_t used = (t.x >> 4) & 15u;
 		uint32_t adv = t.x & 15u, add = (t.x >> 8) & 0xfffu;      // the first code word ...
 		const bool all = adv != 0u && pos + used <= lim;
 		adv = all ? used : adv; add = all ? t.x >> 20 : add;      // ... or the group, when it ends in front of the mark
-		uint32_t nv = all ? (t.y >> 28) & 3u : (t.y >> 30) & 1u, o1 = t.y & 0xffu;
-		int v1 = dx_sext6(t.y, 16);
+		uint32_t w = wi | (all ? (uint32_t)DX_LOG_GROUP << 14 : (uint32_t)DX_LOG_FIRST << 14);
 		if (adv == 0u) {
 			const uint32_t le = dx_long11_entry(t.y, s_long, win);
 			const uint32_t ty = (le >> 5) & 7u, ln = le & 31u;
@@ -870,14 +871,11 @@ __device__ __forceinline__ bool dx_steps_e(DxBitsAhead &B, uint32_t &pos, uint32
 			const int m = (int)(linear ? le >> 20 : (le >> 8) & 0xfffu);
 			adv = isrun ? ln : (isval ? ln + 1u : 0u);
 			add = isrun ? (le >> 8) & 0xfffu : (isval ? 1u : 0u);
-			nv = isval ? 1u : 0u; o1 = 0u;
-			v1 = ((win << ln) >> 31) ? -m : m;
+			w = isrun ? ((uint32_t)DX_LOG_RUN << 14) | add : ((uint32_t)DX_LOG_VALUE << 14) | ((uint32_t)(((win << ln) >> 31) ? -m : m) & 0x3fffu);
 			if (!isrun && !isval) { endv = ty == (uint32_t)DX_T_END ? (uint32_t)DX_END : (uint32_t)DX_BAD; ok = false; }
 		}
-		if (EMIT) {
-			const uint32_t rel = cnt - base;
-			dx_store_rec2(slot + nrec, ((rel + o1) << 16) | ((uint32_t)v1 & 0xffffu), ((rel + ((t.y >> 8) & 0xffu)) << 16) | ((uint32_t)dx_sext6(t.y, 22) & 0xffffu));
-			nrec += nv;
+		if (LOG) {
+			if (ok) { slot[nsteps + (nsteps >= 16u ? (uint32_t)(2 * DX_REC_CHUNK - 16) : 0u)] = (uint16_t)w; nsteps = nsteps < (uint32_t)DX_REC_MAX ? nsteps + 1u : nsteps; }
 			cnt += add;
 		}
 		pos += adv;
@@ -887,7 +885,7 @@ __device__ __forceinline__ bool dx_steps_e(DxBitsAhead &B, uint32_t &pos, uint32
 	return ok;
 }
 
-// dx_walk with the records: lane_slots = the four record slots of this lane's pieces
+// dx_walk with the logs: lane_slots = the four step logs of this lane's pieces
 __device__ __forceinline__ void dx_walk_e(DxLane &L, uint32_t pos, const bool merge, const uint32_t lane_base, const uint32_t limit, const uint32_t *s_words, const uint2 *s_tab,
                                           const uint32_t *s_long, const bool linear, uint32_t *lane_slots)
 {
@@ -904,7 +902,7 @@ __device__ __forceinline__ void dx_walk_e(DxLane &L, uint32_t pos, const bool me
 	{
 		const uint32_t lim = lane_base < stop ? lane_base : stop;
 		uint32_t none = 0;
-		if (!dx_steps_e<false>(B, pos, cnt, lim, endv, s_words, s_tab, s_long, linear, lane_slots, none, 0u)) { clear = true; done = true; }
+		if (!dx_steps_e<false>(B, pos, cnt, lim, endv, s_words, s_tab, s_long, linear, (uint16_t *)lane_slots, none)) { clear = true; done = true; }
 	}
 #pragma unroll
 	for (int k = 0; k < DX_SUBS; k++) {
@@ -921,7 +919,7 @@ __device__ __forceinline__ void dx_walk_e(DxLane &L, uint32_t pos, const bool me
 					offs = dx_off_set(offs, k, off); rc[k] = cnt; piece = k;
 					const uint32_t lim = mark < stop ? mark : stop;
 					uint32_t n = 0;
-					if (!dx_steps_e<true>(B, pos, cnt, lim, endv, s_words, s_tab, s_long, linear, lane_slots + k * DX_REC_SLOT, n, rc[k])) { clear = true; done = true; }
+					if (!dx_steps_e<true>(B, pos, cnt, lim, endv, s_words, s_tab, s_long, linear, (uint16_t *)(lane_slots + k * DX_REC_SLOT), n)) { clear = true; done = true; }
 					nrs = dx_off_set(nrs, k, n);
 				}
 			} else { offs = dx_off_set(offs, k, (uint32_t)DX_OFF_INVALID); nrs = dx_off_set(nrs, k, 0u); }
@@ -995,13 +993,11 @@ __device__ __forceinline__ int dx_runin_candidates_e(const uint32_t bytes, const
 	return n;
 }
 
-// dx_index_staged with the records: scratch = this wave's record slots, dense / pmeta = where the chunk's packed records and their per-piece places go
-// (entry slot gchunk of their arrays, like the entries; null: the walk is wanted for its outcome only).  *groups_out: 16-byte groups of packed records.
+// dx_index_staged with the logs: rec_chunk = the step logs the walk writes (DX_REC_CHUNK words: the chunk's own, an alternate slot's, or a spare chunk for a walk that
+// is wanted for its outcome only), nsteps = per lane of the entry slot gchunk the four step counts (one byte each), written with the entries
 __device__ __forceinline__ DxChunkRec dx_index_staged_e(const uint32_t bytes, const uint32_t gchunk, const uint32_t k, const uint32_t exact_start, const uint32_t *s_words, const uint2 *s_tab,
-                                                        const uint32_t *s_long, const bool linear, uint32_t *entries, uint32_t *scratch, uint32_t *dense, uint32_t *pmeta, uint32_t *stats = nullptr,
-                                                        uint32_t *groups_out = nullptr)
+                                                        const uint32_t *s_long, const bool linear, uint32_t *entries, uint32_t *rec_chunk, uint32_t *nsteps, uint32_t *stats = nullptr)
 {
-	uint32_t *const rec_chunk = scratch;
 	const int lane = wave_lane();
 	const uint32_t nwords = bytes >> 2;
 	const int64_t first = (int64_t)k * DX_CHUNK_WORDS - (DX_LANE_BITS / 32);
@@ -1082,30 +1078,7 @@ __device__ __forceinline__ DxChunkRec dx_index_staged_e(const uint32_t bytes, co
 		for (int j = 0; j < DX_SUBS; j++) v[j] = (!live || dx_off_get(L.rec_offs, j) == (uint32_t)DX_OFF_INVALID) ? (uint32_t)DX_OFF_INVALID : (dx_off_get(L.rec_offs, j) | ((before + L.rec_cnt[j]) << 5));
 		e.x = v[0]; e.y = v[1]; e.z = v[2]; e.w = v[3];
 		*(uint4 *)(entries + slot) = e;
-	}
-	if (entries && dense) {
-		// the records leave the scratch slots: whole groups of four, piece behind piece in the chunk's packed stream; per piece (16 bits) first group << 5 | records
-		uint32_t nj[DX_SUBS], gj[DX_SUBS], groups = 0;
-#pragma unroll
-		for (int j = 0; j < DX_SUBS; j++) {
-			nj[j] = (lane >= 1 && live && dx_off_get(L.rec_offs, j) != (uint32_t)DX_OFF_INVALID) ? dx_off_get(L.rec_n, j) : 0u;
-			if (nj[j] > (uint32_t)DX_REC_MAX) nj[j] = (uint32_t)DX_REC_MAX;
-			gj[j] = (nj[j] + (uint32_t)DX_DENSE_GROUP - 1u) / (uint32_t)DX_DENSE_GROUP;
-			groups += gj[j];
-		}
-		const uint32_t gincl = wave_incl_scan(groups);
-		uint32_t at = gincl - groups;
-		uint32_t m[DX_SUBS];
-		uint4 *const out = (uint4 *)(dense + (size_t)gchunk * DX_DENSE_CHUNK);
-#pragma unroll
-		for (int j = 0; j < DX_SUBS; j++) {
-			m[j] = (at << 5) | nj[j];
-			const uint4 *src = (const uint4 *)(lane_slots + j * DX_REC_SLOT);
-			for (uint32_t i = 0; i < gj[j]; i++) out[at + i] = src[i];
-			at += gj[j];
-		}
-		if (lane >= 1) { uint2 pm; pm.x = m[0] | (m[1] << 16); pm.y = m[2] | (m[3] << 16); *(uint2 *)(pmeta + ((size_t)gchunk * 64 + (size_t)lane) * 2) = pm; }
-		if (groups_out) *groups_out = wave_get(gincl, 63);
+		if (nsteps) nsteps[(size_t)gchunk * 64 + (size_t)lane] = L.rec_n;
 	}
 	const uint32_t total = wave_get(incl, 63), el = wave_get(L.end, last_live);
 	DxChunkRec r;
@@ -1117,19 +1090,17 @@ __device__ __forceinline__ DxChunkRec dx_index_staged_e(const uint32_t bytes, co
 	return r;
 }
 
-// What the emitting kernels share: scratch record slots (DX_REC_CHUNK words per wave of the largest grid, indexed by the wave's number in its launch), the packed
-// records of every chunk (DX_DENSE_CHUNK words each) and their per-piece places (128 words per chunk: 16 bits per piece, lane-major like the entries), and the same for
-// the extra candidates of chunks without a unique alignment (alternate slots, as alt_entries).
-struct DxRecords { uint32_t *scratch; uint32_t *dense; uint32_t *pmeta; uint32_t *alt_dense; uint32_t *alt_pmeta; };
-__device__ __forceinline__ uint32_t *dx_wave_scratch(const DxRecords &R) { return R.scratch + (size_t)((uint32_t)blockIdx.x * DX_WAVES + (uint32_t)(threadIdx.x >> 6)) * DX_REC_CHUNK; }
-
+// What the emitting kernels share: the step logs of every chunk (DX_LOG_CHUNK words each) and their step counts (64 words per chunk: a byte per piece, lane-major like
+// the entries), and the same for the extra candidates of chunks without a unique alignment (alternate slots, as alt_entries; one more chunk's worth of logs behind
+// them is the spare for candidates that found no slot).
+struct DxRecords { uint32_t *log; uint32_t *nsteps; uint32_t *alt_log; uint32_t *alt_nsteps; uint32_t alt_spare; };
 __device__ __attribute__((noinline)) DxChunkRec dx_index_chunk_e(const uint8_t *bits, const uint32_t bytes, const uint32_t gchunk, const uint32_t k, const uint32_t exact_start, uint32_t *s_words,
                                                                  const uint2 *s_tab, const uint32_t *s_long, const bool linear, uint32_t *entries, DxChunkRec *recs, const DxRecords R, uint32_t *stats)
 {
 	DxFetch F;
 	dx_fetch_chunk(bits, bytes, k, F);
 	dx_store_stage(F, s_words);
-	const DxChunkRec r = dx_index_staged_e(bytes, gchunk, k, exact_start, s_words, s_tab, s_long, linear, entries, dx_wave_scratch(R), R.dense, R.pmeta, stats);
+	const DxChunkRec r = dx_index_staged_e(bytes, gchunk, k, exact_start, s_words, s_tab, s_long, linear, entries, R.log + (size_t)gchunk * DX_LOG_CHUNK, R.nsteps, stats);
 	if (wave_lane() == 0 && recs) recs[gchunk] = r;
 	return r;
 }
@@ -1146,7 +1117,7 @@ __device__ __forceinline__ void dx_load_tables_wave_e(const DecIdxTables *T, uin
 	for (int i = lane; i < DX_LONG11_MAX; i += 64) s_long[i] = T->long11[i];
 }
 
-// k_dec_index with the records.  The extra candidates of a chunk without a unique alignment keep their entries AND their packed records in alternate slots (while there
+// k_dec_index with the logs.  The extra candidates of a chunk without a unique alignment keep their entries AND their logs in alternate slots (while there
 // is room): when k_dec_chain finds one of them to be the true start, k_dec_reindex_emit copies both instead of walking the chunk again.
 __global__ void __launch_bounds__(DX_THREADS) CFHD_DX_INDEX_ATTR k_dec_index_emit(const DxChunkDesc *chunk_desc, const uint32_t *counters, const DecIdxTables *T,
                                                                uint32_t *entries, DxChunkRec *recs, DxChunkAlt *alts, int speculate, uint32_t *stats, const DxRecords R,
@@ -1186,14 +1157,13 @@ __global__ void __launch_bounds__(DX_THREADS) CFHD_DX_INDEX_ATTR k_dec_index_emi
 		} else {
 			const bool unresolved = n > DX_MAX_ALT + 1;
 			if (unresolved) n = 1;
-			uint32_t *const scratch = dx_wave_scratch(R);
-			DxChunkRec r = dx_index_staged_e(d.bytes, c, d.k, cand[0], s_words, s_tab, s_long, linear, entries, scratch, R.dense, R.pmeta, stats);
+			DxChunkRec r = dx_index_staged_e(d.bytes, c, d.k, cand[0], s_words, s_tab, s_long, linear, entries, R.log + (size_t)c * DX_LOG_CHUNK, R.nsteps, stats);
 			r.flags |= ((uint32_t)n << 8) | (unresolved ? (uint32_t)DX_FLAG_UNRESOLVED : 0u);
 			if (wave_lane() == 0) recs[c] = r;
 			if (n > 1) {
 				DxChunkAlt a;
 #pragma unroll
-				for (int i = 0; i < DX_MAX_ALT; i++) { a.start[i] = DX_BAD; a.end[i] = DX_BAD; a.count[i] = 0; a.groups[i] = 0; }
+				for (int i = 0; i < DX_MAX_ALT; i++) { a.start[i] = DX_BAD; a.end[i] = DX_BAD; a.count[i] = 0; }
 				uint32_t slot0 = DX_BAD;
 				if (alt_entries) {
 					if (wave_lane() == 0) slot0 = atomicAdd(alt_counter, (uint32_t)(n - 1));
@@ -1204,11 +1174,11 @@ __global__ void __launch_bounds__(DX_THREADS) CFHD_DX_INDEX_ATTR k_dec_index_emi
 #pragma unroll 1
 				for (int i = 1; i < n; i++) {
 					const bool keep = slot0 != (uint32_t)DX_BAD;
-					uint32_t groups = 0;
-					const DxChunkRec ri = dx_index_staged_e(d.bytes, keep ? slot0 + (uint32_t)(i - 1) : c, d.k, cand[i], s_words, s_tab, s_long, linear, keep ? alt_entries : nullptr, scratch,
-					                                        keep ? R.alt_dense : nullptr, keep ? R.alt_pmeta : nullptr, nullptr, &groups);
+					const uint32_t at = keep ? slot0 + (uint32_t)(i - 1) : R.alt_spare;
+					const DxChunkRec ri = dx_index_staged_e(d.bytes, at, d.k, cand[i], s_words, s_tab, s_long, linear, keep ? alt_entries : nullptr, R.alt_log + (size_t)at * DX_LOG_CHUNK,
+					                                        keep ? R.alt_nsteps : nullptr, nullptr);
 #pragma unroll
-					for (int q = 0; q < DX_MAX_ALT; q++) if (q == i - 1) { a.start[q] = ri.start; a.end[q] = ri.end; a.count[q] = ri.count; a.groups[q] = groups; }
+					for (int q = 0; q < DX_MAX_ALT; q++) if (q == i - 1) { a.start[q] = ri.start; a.end[q] = ri.end; a.count[q] = ri.count; }
 				}
 				if (wave_lane() == 0) alts[c] = a;
 				if (stats && wave_lane() == 0) atomicAdd(&stats[3], 1u << 16);
@@ -1268,13 +1238,9 @@ __global__ void __launch_bounds__(DX_THREADS) k_dec_reindex_emit(const DxBandJob
 				const uint4 *src = (const uint4 *)(alt_entries + from * DX_ENTRY_STRIDE);
 				uint4 *dst = (uint4 *)(entries + (size_t)x.chunk * DX_ENTRY_STRIDE);
 				if (lane >= 1) dst[lane] = src[lane];
-				const uint2 *pms = (const uint2 *)(R.alt_pmeta + from * 128); uint2 *pmd = (uint2 *)(R.pmeta + (size_t)x.chunk * 128);
-				if (lane >= 1) pmd[lane] = pms[lane];
-				uint32_t groups = 0;
-#pragma unroll
-				for (int k = 0; k < DX_MAX_ALT; k++) if (k == q) groups = a.groups[k];
-				const uint4 *ds = (const uint4 *)(R.alt_dense + from * DX_DENSE_CHUNK); uint4 *dd = (uint4 *)(R.dense + (size_t)x.chunk * DX_DENSE_CHUNK);
-				for (uint32_t g = (uint32_t)lane; g < groups; g += 64) dd[g] = ds[g];
+				if (lane >= 1) R.nsteps[(size_t)x.chunk * 64 + (size_t)lane] = R.alt_nsteps[from * 64 + (size_t)lane];
+				const uint4 *ls = (const uint4 *)(R.alt_log + from * DX_LOG_CHUNK); uint4 *ld = (uint4 *)(R.log + (size_t)x.chunk * DX_LOG_CHUNK);
+				for (int g = lane; g < DX_LOG_CHUNK / 4; g += 64) ld[g] = ls[g];
 				if (stats && lane == 0) atomicAdd(&stats[3], 1u << 8);
 				continue;
 			}
@@ -1528,38 +1494,40 @@ __global__ void __launch_bounds__(DX_TILE_THREADS) k_dec_tiles(const DxBandJob *
 }
 
 // k_dec_scatter: the tile pass of the single-pass arrangement.  Same tiles, same output (dense 16-byte stores or block lists) and the same way of finding a tile's
-// first piece as k_dec_tiles, but nothing is decoded: a lane takes a piece's entry, its chunk's position and its records (k_dec_index_emit) and drops the values --
-// times the band's divisor -- into the LDS image of the tile.  No code tables: 8 KB of LDS per wave, so a CU holds sixteen waves of it beside other kernels.
+// first piece as k_dec_tiles, but no bit is looked at: a lane takes a piece's entry, its chunk's position and its step log (k_dec_index_emit), looks the steps' table
+// entries up again -- independent LDS reads -- and drops the values, times the band's divisor, into the LDS image of the tile.
 #ifndef CFHD_DX_SC_THREADS
 #define CFHD_DX_SC_THREADS 256
 #endif
 enum { DX_SC_THREADS = CFHD_DX_SC_THREADS, DX_SC_WAVES = DX_SC_THREADS / 64 };
-struct DxScPieces { uint32_t ent, cb, pm, chunk; };      // pm: the piece's place in its chunk's packed records (first group << 5 | records)
-__device__ __forceinline__ void dx_scatter_pieces(const DxTileMeta &M, uint32_t q, uint32_t last_sub, const uint32_t *entries, const uint32_t *chunk_base, const uint16_t *pmeta16, DxScPieces &P)
+struct DxScPieces { uint32_t ent, cb, n, chunk, within; };      // n: steps in the piece's log
+__device__ __forceinline__ void dx_scatter_pieces(const DxTileMeta &M, uint32_t q, uint32_t last_sub, const uint32_t *entries, const uint32_t *chunk_base, const uint8_t *nstepb, DxScPieces &P)
 {
-	P.ent = DX_OFF_INVALID; P.cb = 0; P.pm = 0; P.chunk = 0;
+	P.ent = DX_OFF_INVALID; P.cb = 0; P.n = 0; P.chunk = 0; P.within = 0;
 	if (q < last_sub) {
-		const uint32_t kq = q / DX_CHUNK_SUBS, within = q - kq * DX_CHUNK_SUBS;
-		P.chunk = M.job.chunk0 + kq;
-		const size_t idx = (size_t)P.chunk * DX_ENTRY_STRIDE + DX_SUBS + within;
+		const uint32_t kq = q / DX_CHUNK_SUBS;
+		P.within = q - kq * DX_CHUNK_SUBS + DX_SUBS; P.chunk = M.job.chunk0 + kq;
+		const size_t idx = (size_t)P.chunk * DX_ENTRY_STRIDE + P.within;
 		P.ent = entries[idx];
 		P.cb = chunk_base[P.chunk];
-		P.pm = pmeta16[idx];
+		P.n = nstepb[idx];
 	}
 }
 
-__global__ void __launch_bounds__(DX_SC_THREADS) k_dec_scatter(const DxBandJob *jobs, DxTilePlan plan, const uint32_t *entries, const uint32_t *chunk_base, const DxBandSum *sums,
+__global__ void __launch_bounds__(DX_SC_THREADS) k_dec_scatter(const DxBandJob *jobs, DxTilePlan plan, const DecIdxTables *T, const uint32_t *entries, const uint32_t *chunk_base, const DxBandSum *sums,
                                                                const uint32_t *tile_start, const DxRecords R, unsigned long long *masks, uint32_t masks_per_frame)
 {
+	__shared__ uint2 s_tab[1 << DX_KE];
 	__shared__ uint32_t s_tile_all[DX_SC_WAVES][DX_TILE_WORDS];
+	for (int i = threadIdx.x; i < (1 << DX_KE); i += blockDim.x) s_tab[i] = T->emit11[i];
 	const int lane = wave_lane(), wave = wave_uniform((int)(threadIdx.x >> 6));
 	uint32_t *s_tile = s_tile_all[wave];
 	for (int i = lane; i < DX_TILE_WORDS; i += 64) s_tile[i] = 0u;
-	CFHD_WAVE_SYNC();
+	__syncthreads();
 	const uint32_t gwave = (uint32_t)blockIdx.x * DX_SC_WAVES + (uint32_t)wave, nwaves = (uint32_t)gridDim.x * DX_SC_WAVES;
 	uint32_t t = plan.first + gwave;
 	if (t >= plan.total) return;
-	const uint16_t *nrecb = (const uint16_t *)R.pmeta;
+	const uint8_t *nstepb = (const uint8_t *)R.nsteps;
 	// software pipeline as in k_dec_tiles: the descriptors of tile t + 2 nwaves and the piece entries of tile t + nwaves are on their way while tile t is filled
 	int slot = 0;
 	DxTileMeta M, M1;
@@ -1567,7 +1535,7 @@ __global__ void __launch_bounds__(DX_SC_THREADS) k_dec_scatter(const DxBandJob *
 	M1 = M;
 	if (t + nwaves < plan.total) dx_tile_meta(plan, t + nwaves, slot, jobs, sums, tile_start, M1, masks, masks_per_frame);
 	DxScPieces P;
-	dx_scatter_pieces(M, dx_tile_has_work(M) ? M.first_sub + (uint32_t)lane : 0xFFFFFFFFu, dx_tile_has_work(M) ? dx_tile_last_sub(M) : 0u, entries, chunk_base, nrecb, P);
+	dx_scatter_pieces(M, dx_tile_has_work(M) ? M.first_sub + (uint32_t)lane : 0xFFFFFFFFu, dx_tile_has_work(M) ? dx_tile_last_sub(M) : 0u, entries, chunk_base, nstepb, P);
 	int16_t *tile16 = (int16_t *)s_tile;
 	const uint32_t dump = (uint32_t)DX_TILE + (uint32_t)lane;
 #pragma unroll 1
@@ -1577,7 +1545,7 @@ __global__ void __launch_bounds__(DX_SC_THREADS) k_dec_scatter(const DxBandJob *
 		if (t + 2 * nwaves < plan.total) dx_tile_meta(plan, t + 2 * nwaves, slot, jobs, sums, tile_start, M2, masks, masks_per_frame);
 		{
 			const bool w1 = t + nwaves < plan.total && dx_tile_has_work(M1);
-			dx_scatter_pieces(M1, w1 ? M1.first_sub + (uint32_t)lane : 0xFFFFFFFFu, w1 ? dx_tile_last_sub(M1) : 0u, entries, chunk_base, nrecb, P1);
+			dx_scatter_pieces(M1, w1 ? M1.first_sub + (uint32_t)lane : 0xFFFFFFFFu, w1 ? dx_tile_last_sub(M1) : 0u, entries, chunk_base, nstepb, P1);
 		}
 		const DxBandJob job = dx_uniform(M.job);
 		const uint32_t first_sub = (uint32_t)wave_uniform((int)M.first_sub);
@@ -1590,24 +1558,42 @@ __global__ void __launch_bounds__(DX_SC_THREADS) k_dec_scatter(const DxBandJob *
 				for (uint32_t q0 = first_sub; q0 < last_sub; q0 += 64) {
 					const uint32_t q = q0 + (uint32_t)lane;
 					const bool active = q < last_sub;
-					if (q0 != first_sub) dx_scatter_pieces(M, q, last_sub, entries, chunk_base, nrecb, P);
+					if (q0 != first_sub) dx_scatter_pieces(M, q, last_sub, entries, chunk_base, nstepb, P);
 					const uint32_t off = P.ent & 31u;
 					const uint32_t idx0 = P.cb + (P.ent >> 5);
 					const bool valid = active && off != (uint32_t)DX_OFF_INVALID;
 					const bool inside = valid && idx0 < T1;
-					const uint32_t n = inside ? ((P.pm & 31u) <= (uint32_t)DX_REC_MAX ? P.pm & 31u : (uint32_t)DX_REC_MAX) : 0u;
-					const uint32_t rel = idx0 - T0;                    // "negative" (the piece starts in front of the tile) wraps to a huge number: those places go to the dump slot
-					const uint32_t *recs = R.dense + (size_t)P.chunk * DX_DENSE_CHUNK + (size_t)(P.pm >> 5) * DX_DENSE_GROUP;
-#pragma unroll 1
-					for (uint32_t k = 0; __ballot(k < n) != 0ull; k += 4) {
-						cfhd_u4 r = { 0u, 0u, 0u, 0u };
-						if (k < n) r = CFHD_LDG128(recs + k);
-						const uint32_t w[4] = { r.x, r.y, r.z, r.w };
+					const uint32_t n = inside ? (P.n <= (uint32_t)DX_REC_MAX ? P.n : (uint32_t)DX_REC_MAX) : 0u;
+					uint32_t rel = idx0 - T0;                          // "negative" (the piece starts in front of the tile) wraps to a huge number: those places go to the dump slot
+					const uint32_t *log = R.log + (size_t)P.chunk * DX_LOG_CHUNK + (size_t)P.within * DX_REC_SLOT;
+					cfhd_u4 la = { 0u, 0u, 0u, 0u }, lb = { 0u, 0u, 0u, 0u }, lc = { 0u, 0u, 0u, 0u }, ld = { 0u, 0u, 0u, 0u };
+					if (n > 0u) la = CFHD_LDG128(log);
+					if (n > 8u) lb = CFHD_LDG128(log + 4);
+					if (__ballot(n > 16u)) {                               // (rare: a piece of more than sixteen steps)
+						if (n > 16u) lc = CFHD_LDG128(log + DX_REC_CHUNK);
+						if (n > 24u) ld = CFHD_LDG128(log + DX_REC_CHUNK + 4);
+					}
+					const uint32_t lw[16] = { la.x, la.y, la.z, la.w, lb.x, lb.y, lb.z, lb.w, lc.x, lc.y, lc.z, lc.w, ld.x, ld.y, ld.z, ld.w };
 #pragma unroll
-						for (int j = 0; j < 4; j++) {
-							const uint32_t p = rel + (w[j] >> 16);
-							const bool ok = k + (uint32_t)j < n && p < dump;
-							tile16[ok ? p : dump] = (int16_t)mul_u24((uint32_t)(int)(int16_t)(w[j] & 0xffffu), quant);
+					for (int sidx = 0; sidx < 32; sidx++) {
+						if (__ballot((uint32_t)sidx < n) == 0ull) break;          // (wave-uniform: the longest log of the round)
+						{
+							const uint32_t w = (sidx & 1) ? lw[sidx >> 1] >> 16 : lw[sidx >> 1] & 0xffffu;
+							const uint32_t kind = w >> 14;
+							const uint2 e = s_tab[w & ((1u << DX_KE) - 1u)];
+							const bool group = kind == (uint32_t)DX_LOG_GROUP;
+							uint32_t nv = group ? (e.y >> 28) & 3u : (e.y >> 30) & 1u, add = group ? e.x >> 20 : (e.x >> 8) & 0xfffu, o1 = e.y & 0xffu;
+							int v1 = dx_sext6(e.y, 16);
+							if (kind >= (uint32_t)DX_LOG_VALUE) {
+								const bool isval = kind == (uint32_t)DX_LOG_VALUE;
+								nv = isval ? 1u : 0u; add = isval ? 1u : w & 0x3fffu; o1 = 0u;
+								v1 = (int)(w << 18) >> 18;
+							}
+							const bool live = (uint32_t)sidx < n;
+							const uint32_t p1 = rel + o1, p2 = rel + ((e.y >> 8) & 0xffu);
+							tile16[(live && nv >= 1u && p1 < dump) ? p1 : dump] = (int16_t)mul_u24((uint32_t)v1, quant);
+							tile16[(live && nv == 2u && p2 < dump) ? p2 : dump] = (int16_t)mul_u24((uint32_t)dx_sext6(e.y, 22), quant);
+							rel += live ? add : 0u;
 						}
 					}
 					if (__ballot(valid && !inside) || !__ballot(active)) break;

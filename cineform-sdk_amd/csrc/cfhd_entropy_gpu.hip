@@ -242,8 +242,8 @@ GpuEntropyDecoder::~GpuEntropyDecoder() { release(); delete host_; }
 void GpuEntropyDecoder::release()
 {
 	(void)hipSetDevice(device_);
-	void *dev[] = { d_samples_, d_tables_, d_bandjobs_, d_lowjobs_, d_errors_, d_plan_, d_idx_tables_, d_entries_, d_recs_, d_chunk_base_, d_chunk_job_, d_sums_, d_counters_, d_tile_start_, d_stats_, d_repair_, d_alts_, d_reindex_, d_diffjobs_, d_alt_entries_, d_masks_, d_scratch_, d_dense_, d_pmeta_, d_alt_dense_, d_alt_pmeta_ };
-	d_masks_ = nullptr; d_scratch_ = d_dense_ = d_pmeta_ = d_alt_dense_ = d_alt_pmeta_ = nullptr; masks_per_frame_ = 0; use_blocks_ = false; blocks_written_ = false;
+	void *dev[] = { d_samples_, d_tables_, d_bandjobs_, d_lowjobs_, d_errors_, d_plan_, d_idx_tables_, d_entries_, d_recs_, d_chunk_base_, d_chunk_job_, d_sums_, d_counters_, d_tile_start_, d_stats_, d_repair_, d_alts_, d_reindex_, d_diffjobs_, d_alt_entries_, d_masks_, d_log_, d_nsteps_, d_alt_log_, d_alt_nsteps_ };
+	d_masks_ = nullptr; d_log_ = d_nsteps_ = d_alt_log_ = d_alt_nsteps_ = nullptr; masks_per_frame_ = 0; use_blocks_ = false; blocks_written_ = false;
 	for (void *p : dev) if (p) (void)hipFree(p);
 	d_idx_tables_ = d_entries_ = d_recs_ = d_chunk_base_ = d_chunk_job_ = d_sums_ = d_counters_ = d_tile_start_ = d_stats_ = d_repair_ = d_alts_ = d_reindex_ = d_diffjobs_ = d_alt_entries_ = nullptr;
 	if (h_chunk_job_) (void)hipHostFree(h_chunk_job_);
@@ -307,12 +307,12 @@ int GpuEntropyDecoder::prepare(const FramePlan &plan, int nframes, int16_t *d_co
 		alt_slots_ = max_chunks_ / 8 > 64u ? max_chunks_ / 8 : 64u;          // entries of the extra candidates of chunks without a unique alignment (a few per cent of the chunks)
 		HIPCHK(hipMalloc(&d_alt_entries_, (size_t)alt_slots_ * dev::DX_ENTRY_STRIDE * 4));
 		if (emit_) {
-			// the packed records of every chunk of the worst-case sample (24 KB per chunk; only the part in use is ever touched: about 7 KB of a full chunk at the
-			// benchmark's quality), 16 bits per piece for their places, the same for the alternate slots; the waves' scratch slots are allocated below with the grid
-			HIPCHK(hipMalloc(&d_dense_, (size_t)max_chunks_ * dev::DX_DENSE_CHUNK * 4));
-			HIPCHK(hipMalloc(&d_pmeta_, (size_t)max_chunks_ * 128 * 4));
-			HIPCHK(hipMalloc(&d_alt_dense_, (size_t)alt_slots_ * dev::DX_DENSE_CHUNK * 4));
-			HIPCHK(hipMalloc(&d_alt_pmeta_, (size_t)alt_slots_ * 128 * 4));
+			// two 32-byte step-log slots per 64-bit piece of the worst-case sample (16 KB per chunk; only the first slots of real pieces are ever touched, the second
+			// slots by pieces of more than sixteen steps) and a byte per piece for its length; the same for the alternate slots + one spare chunk of logs
+			HIPCHK(hipMalloc(&d_log_, (size_t)max_chunks_ * dev::DX_LOG_CHUNK * 4));
+			HIPCHK(hipMalloc(&d_nsteps_, (size_t)max_chunks_ * 64 * 4));
+			HIPCHK(hipMalloc(&d_alt_log_, ((size_t)alt_slots_ + 1) * dev::DX_LOG_CHUNK * 4));
+			HIPCHK(hipMalloc(&d_alt_nsteps_, (size_t)alt_slots_ * 64 * 4));
 		}
 		{
 			dev::DecPlan dp0; dec_build_plan(plan, out_kind, &dp0);
@@ -327,10 +327,9 @@ int GpuEntropyDecoder::prepare(const FramePlan &plan, int nframes, int16_t *d_co
 		(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_current());
 		const char *g1 = getenv("CFHD_AMD_DX_GRID_INDEX"), *g3 = getenv("CFHD_AMD_DX_GRID_TILES");
 		grid_index_ = g1 ? atoi(g1) : cus * 5; grid_tiles_ = g3 ? atoi(g3) : cus * (dev::DX_TILE_THREADS >= 1024 ? 1 : 2);      // workgroups that fit a CU at once (LDS: ~30 KB / ~150 KB each)
-		if (emit_ && !g3) grid_tiles_ = cus * (int)((160 * 1024) / (sizeof(uint32_t) * dev::DX_TILE_WORDS * dev::DX_SC_WAVES));      // k_dec_scatter: 8 KB of LDS per wave
+		if (emit_ && !g3) grid_tiles_ = cus * (int)((160 * 1024) / (sizeof(uint2) * (1 << dev::DX_KE) + sizeof(uint32_t) * dev::DX_TILE_WORDS * dev::DX_SC_WAVES));      // k_dec_scatter: the table + 8 KB of LDS per wave
 		if (grid_index_ < 1) grid_index_ = 1;
 		if (grid_tiles_ < 1) grid_tiles_ = 1;
-		if (emit_) HIPCHK(hipMalloc(&d_scratch_, (size_t)(grid_index_ > 64 ? grid_index_ : 64) * dev::DX_WAVES * dev::DX_REC_CHUNK * 4));      // 32 KB per wave of the largest launch that indexes (k_dec_index_emit; k_dec_repair_emit: 64 workgroups)
 	}
 	{
 		dev::DecPlan dp;
@@ -522,7 +521,7 @@ int GpuEntropyDecoder::launch_dx(bool device_jobs, int njobs, uint32_t host_chun
 	if ((uint32_t)g3 * tile_waves > tp.total) g3 = (int)((tp.total + tile_waves - 1) / tile_waves);
 	if (g1 < 1) g1 = 1;
 	if (g3 < 1) g3 = 1;
-	const dev::DxRecords R = { (uint32_t *)d_scratch_, (uint32_t *)d_dense_, (uint32_t *)d_pmeta_, (uint32_t *)d_alt_dense_, (uint32_t *)d_alt_pmeta_ };
+	const dev::DxRecords R = { (uint32_t *)d_log_, (uint32_t *)d_nsteps_, (uint32_t *)d_alt_log_, (uint32_t *)d_alt_nsteps_, alt_slots_ };
 	if (emit_) dev::k_dec_index_emit<<<g1, dev::DX_THREADS, 0, st>>>((const dev::DxChunkDesc *)d_chunk_job_, (const uint32_t *)d_counters_, T, (uint32_t *)d_entries_, (dev::DxChunkRec *)d_recs_, (dev::DxChunkAlt *)d_alts_,
 	                                                                 speculate ? 1 : 0, (uint32_t *)d_stats_, R, (uint32_t *)d_alt_entries_, alt_slots_, (uint32_t *)d_counters_ + 3, (uint32_t *)d_counters_ + 4);
 	else dev::k_dec_index<<<g1, dev::DX_THREADS, 0, st>>>((const dev::DxChunkDesc *)d_chunk_job_, (const uint32_t *)d_counters_, T, (uint32_t *)d_entries_, (dev::DxChunkRec *)d_recs_, (dev::DxChunkAlt *)d_alts_, speculate ? 1 : 0, (uint32_t *)d_stats_,
@@ -552,7 +551,7 @@ int GpuEntropyDecoder::launch_dx(bool device_jobs, int njobs, uint32_t host_chun
 	const char *split_env = getenv("CFHD_AMD_TILES_SPLIT");
 	l23_split_ = frames >= 8 && !skip_level1_ && tp.split > 0 && tp.split < tp.total && split_env && split_env[0] == '1';
 	auto tile_pass = [&](const dev::DxTilePlan &p, int g) {
-		if (emit_) dev::k_dec_scatter<<<g < 1 ? 1 : g, dev::DX_SC_THREADS, 0, st>>>(jobs, p, (const uint32_t *)d_entries_, (const uint32_t *)d_chunk_base_, (const dev::DxBandSum *)d_sums_, (const uint32_t *)d_tile_start_, R, tmasks, (uint32_t)masks_per_frame_);
+		if (emit_) dev::k_dec_scatter<<<g < 1 ? 1 : g, dev::DX_SC_THREADS, 0, st>>>(jobs, p, T, (const uint32_t *)d_entries_, (const uint32_t *)d_chunk_base_, (const dev::DxBandSum *)d_sums_, (const uint32_t *)d_tile_start_, R, tmasks, (uint32_t)masks_per_frame_);
 		else dev::k_dec_tiles<<<g < 1 ? 1 : g, dev::DX_TILE_THREADS, 0, st>>>(jobs, p, T, (const uint32_t *)d_entries_, (const uint32_t *)d_chunk_base_, (const dev::DxBandSum *)d_sums_, (const uint32_t *)d_tile_start_, tmasks, (uint32_t)masks_per_frame_);
 	};
 	if (l23_split_) {
