@@ -42,7 +42,11 @@ struct cfhd_amd_batch {
 	bool device_handoff = true;        // the decoder reads the samples where the encoder left them in HBM (k_dec_parse); the host copy arrives beside it
 	double t_fwd = 0, t_entropy_enc = 0, t_entropy_dec = 0, t_inv = 0;   // wall seconds of the last round trip
 	// the frame queue (cfhd_amd_batch_submit / _wait): the pass in flight runs on a thread of its own, on the batch's own HIP streams
-	std::thread worker; bool in_flight = false; long long pending = -1;
+	// (cfhd_amd_batch_submit / _wait).  The default arrangement -- everything on the GPU, one chunk -- needs no thread: submit queues the whole pass on the batch's streams
+	// (the decoder's stream waits for the encoder's events), wait fetches the sizes, queues the copy of the samples and waits for both streams.  The other arrangements
+	// (host hand-off, host entropy, several chunks) have host work in the middle of a pass: those run the blocking pass on a thread of their own.
+	std::thread worker; bool in_flight = false, queued = false; long long pending = -1;
+	double t_launch0 = 0, t_launched = 0;
 	~cfhd_amd_batch() { if (worker.joinable()) worker.join(); }
 };
 
@@ -57,9 +61,58 @@ template <typename F> void parallel_for(int n, int nthreads, F f)
 	for (auto &th : pool) th.join();
 }
 double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// The default pass (all stages on the GPU, samples handed over in HBM, one chunk) in two halves with no host wait inside either.
+// batch_launch: every launch of the pass queued -- forward transform, entropy coder, dense copy of the samples + their sizes on the way to the host on the encoder's
+// stream; parser, entropy decoder and inverse transform on the decoder's stream behind the encoder's events (headers final / payloads final).  Returns 0 or < 0.
+int batch_launch(cfhd_amd_batch *b)
+{
+	cfhd_amd_chunk *c = b->chunks[0].get();
+	b->t_launch0 = now();
+	const uint32_t base_number = b->steps * (uint32_t)b->n;
+	// every frame gets the metadata CFHD_EncodeSample would give it: GUID, encode date / time, a timecode and a unique frame number that advance per frame
+	b->frame_meta.resize(b->n);
+	for (int i = 0; i < b->n; i++) { b->meta.handle(); b->frame_meta[i] = b->meta.global; meta_remove_hidden(b->frame_meta[i]); }
+	const uint32_t seed = 0xA511E9B3u * (b->steps + 1);
+	// the transform kernels start first: the host serialises the sample headers (0.5 ms per 256) while they run
+	if (c->enc.launch_forward(false)) return -2;         // (nothing but the entropy stage reads these coefficients)
+	for (int l = 0; l < c->n; l++) {
+		SampleHeaderInfo h = { base_number + (uint32_t)(c->first + l) + 1, b->color_format, b->color_space, b->quality, b->progressive, b->frame_meta[c->first + l].data(), b->frame_meta[c->first + l].size(), nullptr, 0 };
+		if (c->enc.entropy().set_frame_header(l, h)) return -6;
+	}
+	if (c->enc.entropy().launch()) return -2;
+	if (b->decode) {
+		// the parser only needs the headers and size fields (k_ent_layout): it runs beside k_ent_emit, the band decoder waits for the payloads
+		c->dec.entropy().set_producer_events(c->enc.entropy().headers_event(), c->enc.entropy().samples_event());
+		if (c->dec.entropy().set_samples_device(c->enc.entropy().device_sample(0), c->enc.entropy().sample_cap(), c->enc.entropy().device_sizes())) return -4;
+		if (c->dec.launch_entropy() || c->dec.launch_inverse(seed + (uint32_t)c->first)) return -5;
+	}
+	if (c->enc.entropy().download_queue()) return -2;
+	b->t_launched = now();
+	return 0;
+}
+// batch_finish: the sizes arrive, the copy of the sample bytes is queued, both streams drain.  Returns the total number of sample bytes or < 0.
+long long batch_finish(cfhd_amd_batch *b)
+{
+	cfhd_amd_chunk *c = b->chunks[0].get();
+	if (c->enc.entropy().download_finish() || c->enc.wait()) return -2;
+	for (int l = 0; l < c->n; l++) {
+		size_t n = c->enc.entropy().sample_bytes(l); if (!n) return -3; b->sample_size[c->first + l] = n;
+		if (c->enc.entropy().needs_peak_table(l)) return -8;      // an interlaced frame with field differences beyond +-250 steps: only CFHD_EncodeSample writes those (host writer)
+	}
+	const double t_enc = now();
+	if (b->decode) { if (c->dec.wait()) return -5; if (c->dec.entropy().check()) return -7; }
+	const double t4 = now();
+	b->t_fwd = b->t_launched - b->t_launch0; b->t_entropy_enc = t_enc - b->t_launched; b->t_entropy_dec = 0; b->t_inv = t4 - t_enc;
+	b->steps++;
+	long long total = 0;
+	for (int i = 0; i < b->n; i++) total += (long long)b->sample_size[i];
+	return total;
+}
 }
 
 extern "C" {
+long long cfhd_amd_batch_wait(cfhd_amd_batch *b);
 
 // width x height frames of `pixel_format` encoded as `encoded_format` with `encoding_flags` (the CFHD_PrepareToEncode arguments: YUY2 / 2vuy ->
 // 4:2:2, optionally interlaced; RG48 -> RGB 4:4:4; b64a -> RGBA 4:4:4:4; BYR4 -> Bayer).  mode 0: encode + decode back to the same pixel
@@ -109,13 +162,13 @@ cfhd_amd_batch *cfhd_amd_batch_create(int width, int height, uint32_t pixel_form
 	return cfhd_amd_batch_create_ex(width, height, pixel_format == 0x32767579u /* '2vuy' */ ? pixel_format : 0x59555932u /* 'YUY2' */, 0, 0, quality, nframes, nthreads, 0);
 }
 
-void cfhd_amd_batch_destroy(cfhd_amd_batch *b) { CallerDevice caller_device; delete b; }
+void cfhd_amd_batch_destroy(cfhd_amd_batch *b) { CallerDevice caller_device; if (b && b->in_flight) (void)cfhd_amd_batch_wait(b); delete b; }
 
 // Puts frame i into HBM (outside the timed region of the benchmark).
 int cfhd_amd_batch_upload(cfhd_amd_batch *b, int i, const void *frame, int pitch)
 {
 	CallerDevice caller_device;
-	if (!b || i < 0 || i >= b->n) return -1;
+	if (!b || b->in_flight || i < 0 || i >= b->n) return -1;
 	int l; cfhd_amd_chunk &c = b->chunk_of(i, &l);
 	int rc = c.enc.upload_frame(l, frame, pitch);
 	if (rc) return rc;
@@ -123,10 +176,16 @@ int cfhd_amd_batch_upload(cfhd_amd_batch *b, int i, const void *frame, int pitch
 }
 
 // One step of the hot path over the whole batch.  Returns the total number of sample bytes, or < 0.
+static long long cfhd_amd_batch_roundtrip_locked(cfhd_amd_batch *b);
+// (A batch with a pass in flight -- cfhd_amd_batch_submit without its _wait -- refuses every entry point that would touch its streams, job tables or pinned buffers: -1.)
 long long cfhd_amd_batch_roundtrip(cfhd_amd_batch *b)
 {
+	if (!b || b->in_flight) return -1;
+	return cfhd_amd_batch_roundtrip_locked(b);
+}
+static long long cfhd_amd_batch_roundtrip_locked(cfhd_amd_batch *b)
+{
 	CallerDevice caller_device;
-	if (!b) return -1;
 	const FramePlan &plan = b->plan;
 	double t0 = now(), t1, t2, t3;
 	std::atomic<int> bad(0);
@@ -137,7 +196,11 @@ long long cfhd_amd_batch_roundtrip(cfhd_amd_batch *b)
 	auto prepare_meta = [&] { if (meta_ready) return; meta_ready = true; for (int i = 0; i < b->n; i++) { b->meta.handle(); b->frame_meta[i] = b->meta.global; meta_remove_hidden(b->frame_meta[i]); } };
 	auto header = [&](int i) { SampleHeaderInfo h = { base_number + (uint32_t)i + 1, b->color_format, b->color_space, b->quality, b->progressive, b->frame_meta[i].data(), b->frame_meta[i].size(), nullptr, 0 }; return h; };
 	const uint32_t seed = 0xA511E9B3u * (b->steps + 1);
-	if (b->gpu_entropy && b->device_handoff) {
+	if (b->gpu_entropy && b->device_handoff && b->chunks.size() == 1) {
+		const int rc = batch_launch(b);
+		if (rc) return rc;
+		return batch_finish(b);
+	} else if (b->gpu_entropy && b->device_handoff) {
 		// Samples stay in HBM between the encoder and the decoder: the decoder's stream waits for the encoder's kernels, parses
 		// the samples on the GPU and decodes, while the finished samples travel to the host (the encoder's product) on the
 		// encoder's stream beside it.
@@ -259,17 +322,27 @@ long long cfhd_amd_batch_roundtrip(cfhd_amd_batch *b)
 // (tools/dual_batch.py).  The caller keeps FIFO order by waiting in the order it submitted.
 int cfhd_amd_batch_submit(cfhd_amd_batch *b)
 {
+	CallerDevice caller_device;
 	if (!b || b->in_flight) return -1;
-	b->in_flight = true; b->pending = -1;
-	b->worker = std::thread([b] { b->pending = cfhd_amd_batch_roundtrip(b); });
+	b->pending = -1;
+	if (b->gpu_entropy && b->device_handoff && b->chunks.size() == 1) {
+		const int rc = batch_launch(b);                   // the whole pass is on the batch's streams when this returns; nothing waits
+		if (rc) return rc;
+		b->in_flight = true; b->queued = true;
+		return 0;
+	}
+	b->in_flight = true; b->queued = false;
+	b->worker = std::thread([b] { b->pending = cfhd_amd_batch_roundtrip_locked(b); });
 	return 0;
 }
 
 long long cfhd_amd_batch_wait(cfhd_amd_batch *b)
 {
+	CallerDevice caller_device;
 	if (!b || !b->in_flight) return -1;
-	b->worker.join();
-	b->in_flight = false;
+	if (b->queued) b->pending = batch_finish(b);
+	else b->worker.join();
+	b->in_flight = false; b->queued = false;
 	return b->pending;
 }
 
@@ -279,7 +352,7 @@ long long cfhd_amd_batch_wait(cfhd_amd_batch *b)
 // launch) (ms, HIP events on the launch streams)
 float cfhd_amd_batch_kernel_ms(cfhd_amd_batch *b, int which)
 {
-	if (!b) return 0;
+	if (!b || b->in_flight) return 0;
 	float ms = 0;                                        // summed over the chunks (each chunk times its own launches with HIP events on its stream)
 	for (auto &c : b->chunks) {
 		if (which >= 3 && which != 6 && which != 18 && !(which >= 8 && which < 12) && !b->decode) continue;
@@ -310,7 +383,7 @@ double cfhd_amd_batch_stage_seconds(cfhd_amd_batch *b, int which)
 // CFHD_AMD_DX_STATS=1: convergence counters of the chunk-indexed entropy decoder, summed over the chunks (16 words; GpuEntropyDecoder::stats)
 int cfhd_amd_batch_dx_stats(cfhd_amd_batch *b, uint32_t *out)
 {
-	if (!b || !out) return -1;
+	if (!b || b->in_flight || !out) return -1;
 	for (int k = 0; k < 16; k++) out[k] = 0;
 	int rc = -1;
 	if (b->decode) for (auto &c : b->chunks) { uint32_t s[16]; if (c->dec.entropy().stats(s) == 0) { rc = 0; for (int k = 0; k < 16; k++) out[k] = k == 2 ? (s[k] > out[k] ? s[k] : out[k]) : out[k] + s[k]; } }
@@ -319,7 +392,7 @@ int cfhd_amd_batch_dx_stats(cfhd_amd_batch *b, uint32_t *out)
 
 int cfhd_amd_batch_get_sample(cfhd_amd_batch *b, int i, const void **data, size_t *size)
 {
-	if (!b || i < 0 || i >= b->n) return -1;
+	if (!b || b->in_flight || i < 0 || i >= b->n) return -1;
 	int l; cfhd_amd_chunk &c = b->chunk_of(i, &l);
 	*data = b->gpu_entropy ? (const void *)c.enc.entropy().host_sample(l) : (const void *)b->samples[i].data(); *size = b->sample_size[i];
 	return 0;
@@ -328,7 +401,7 @@ int cfhd_amd_batch_get_sample(cfhd_amd_batch *b, int i, const void **data, size_
 int cfhd_amd_batch_download_output(cfhd_amd_batch *b, int i, void *out, int pitch)
 {
 	CallerDevice caller_device;
-	if (!b || i < 0 || i >= b->n || !b->decode) return -1;
+	if (!b || b->in_flight || i < 0 || i >= b->n || !b->decode) return -1;
 	int l; cfhd_amd_chunk &c = b->chunk_of(i, &l);
 	if (c.dec.download_frame(l, out, pitch) || c.dec.wait()) return -2;
 	return c.dec.finish_frame(l, out, pitch);

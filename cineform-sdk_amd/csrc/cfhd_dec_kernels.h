@@ -75,13 +75,15 @@ enum {
 	DX_OFF_INVALID = 31,              // entry: no code word of the true sequence starts in this piece (behind the band end marker / the payload)
 	// the single-pass arrangement (k_dec_index_emit + k_dec_scatter): the index walk leaves, per 64-bit piece, the nonzero coefficients its code words hold
 	DX_KE = 11,                       // bits of the window of its table (emit11: 8 bytes per window, 16 KB like the 12-bit table of 4-byte entries it replaces in LDS)
-	// A piece's step log: 16-bit words, the first 16 in a 32-byte slot, the rest -- a piece can take 22 steps: two group steps in a row consume at least 12 bits, but in
-	// the last 10 bits in front of a mark a group that would pass it is refused and the walk goes one code word (one bit, for a single zero) at a time -- in a second
-	// slot of the same size in the second half of the chunk's log area, which ordinary pieces never touch.
-	DX_REC_SLOT = 8,                  // dwords of a slot
-	DX_REC_MAX = 31,                  // last step a log holds (the walk stops counting there: in-bounds whatever the data)
-	DX_REC_CHUNK = DX_ENTRY_STRIDE * DX_REC_SLOT,      // dwords of one half of a chunk's log area (8 KB, lane-major like the entries: lane t's four pieces at 4 t .. 4 t + 3)
-	DX_LOG_CHUNK = 2 * DX_REC_CHUNK,  // dwords of a chunk's log area
+	// A chunk's step logs: 16-bit words, [piece of the lane 0..3][step 0..31][lane 0..63] -- the lanes of a wave take their steps of a piece in lock step (dx_steps_e's loop),
+	// so step s of all of them is ONE store of 128 contiguous bytes.  (A slot per piece, the third build, made every step 64 stores to 64 cache lines: the address path of
+	// the CU, 64 cycles per wave and step, was what the index pass waited for: + 0.5 ms.)  A piece can take 22 steps: two group steps in a row consume at least 12 bits, but
+	// in the last 10 bits in front of a mark a group that would pass it is refused and the walk goes one code word (one bit, for a single zero) at a time; rows beyond the
+	// first dozen are rarely touched.
+	DX_LOG_STEPS = 32,                // rows per piece
+	DX_REC_MAX = DX_LOG_STEPS - 1,    // last step a log holds (the walk stops counting there: in-bounds whatever the data)
+	DX_LOG_PIECE = DX_LOG_STEPS * 64, // 16-bit words of one piece row block
+	DX_LOG_CHUNK = DX_SUBS * DX_LOG_PIECE / 2,         // dwords of a chunk's log area (16 KB)
 	// a step of the log: bits 14-15 kind, bits 0-13 payload
 	DX_LOG_FIRST = 0,                 // the first code word of emit11[payload]
 	DX_LOG_GROUP = 1,                 // the whole group of emit11[payload]
@@ -875,7 +877,7 @@ __device__ __forceinline__ bool dx_steps_e(DxBitsAhead &B, uint32_t &pos, uint32
 			if (!isrun && !isval) { endv = ty == (uint32_t)DX_T_END ? (uint32_t)DX_END : (uint32_t)DX_BAD; ok = false; }
 		}
 		if (LOG) {
-			if (ok) { slot[nsteps + (nsteps >= 16u ? (uint32_t)(2 * DX_REC_CHUNK - 16) : 0u)] = (uint16_t)w; nsteps = nsteps < (uint32_t)DX_REC_MAX ? nsteps + 1u : nsteps; }
+			if (ok) { slot[nsteps * 64u] = (uint16_t)w; nsteps = nsteps < (uint32_t)DX_REC_MAX ? nsteps + 1u : nsteps; }
 			cnt += add;
 		}
 		pos += adv;
@@ -885,9 +887,9 @@ __device__ __forceinline__ bool dx_steps_e(DxBitsAhead &B, uint32_t &pos, uint32
 	return ok;
 }
 
-// dx_walk with the logs: lane_slots = the four step logs of this lane's pieces
+// dx_walk with the logs: lane_log = this lane's column of the chunk's log area
 __device__ __forceinline__ void dx_walk_e(DxLane &L, uint32_t pos, const bool merge, const uint32_t lane_base, const uint32_t limit, const uint32_t *s_words, const uint2 *s_tab,
-                                          const uint32_t *s_long, const bool linear, uint32_t *lane_slots)
+                                          const uint32_t *s_long, const bool linear, uint16_t *lane_log)
 {
 	uint32_t cnt = 0, start = pos, endv = pos;
 	uint32_t offs = merge ? L.rec_offs : (uint32_t)DX_OFFS_NONE;
@@ -902,7 +904,7 @@ __device__ __forceinline__ void dx_walk_e(DxLane &L, uint32_t pos, const bool me
 	{
 		const uint32_t lim = lane_base < stop ? lane_base : stop;
 		uint32_t none = 0;
-		if (!dx_steps_e<false>(B, pos, cnt, lim, endv, s_words, s_tab, s_long, linear, (uint16_t *)lane_slots, none)) { clear = true; done = true; }
+		if (!dx_steps_e<false>(B, pos, cnt, lim, endv, s_words, s_tab, s_long, linear, lane_log, none)) { clear = true; done = true; }
 	}
 #pragma unroll
 	for (int k = 0; k < DX_SUBS; k++) {
@@ -919,7 +921,7 @@ __device__ __forceinline__ void dx_walk_e(DxLane &L, uint32_t pos, const bool me
 					offs = dx_off_set(offs, k, off); rc[k] = cnt; piece = k;
 					const uint32_t lim = mark < stop ? mark : stop;
 					uint32_t n = 0;
-					if (!dx_steps_e<true>(B, pos, cnt, lim, endv, s_words, s_tab, s_long, linear, (uint16_t *)(lane_slots + k * DX_REC_SLOT), n)) { clear = true; done = true; }
+					if (!dx_steps_e<true>(B, pos, cnt, lim, endv, s_words, s_tab, s_long, linear, lane_log + k * DX_LOG_PIECE, n)) { clear = true; done = true; }
 					nrs = dx_off_set(nrs, k, n);
 				}
 			} else { offs = dx_off_set(offs, k, (uint32_t)DX_OFF_INVALID); nrs = dx_off_set(nrs, k, 0u); }
@@ -1006,7 +1008,7 @@ __device__ __forceinline__ DxChunkRec dx_index_staged_e(const uint32_t bytes, co
 	const uint32_t lane_base = (uint32_t)lane * DX_LANE_BITS;
 	const bool live = lane_base < limit && lane >= 1;
 	const int last_live = limit == 0u ? 0 : (int)((limit - 1u) / DX_LANE_BITS) < 63 ? (int)((limit - 1u) / DX_LANE_BITS) : 63;
-	uint32_t *lane_slots = rec_chunk + (size_t)lane * (DX_SUBS * DX_REC_SLOT);
+	uint16_t *lane_log = (uint16_t *)rec_chunk + lane;
 	DxLane L;
 	L.start = DX_BAD; L.end = lane_base; L.cnt = 0; L.rec_offs = DX_OFFS_NONE; L.rec_n = 0u;
 #pragma unroll
@@ -1055,7 +1057,7 @@ __device__ __forceinline__ DxChunkRec dx_index_staged_e(const uint32_t bytes, co
 					for (int i = 0; i < DX_MEMO; i++) if (i == hit) { L.end = memo_e[i]; L.cnt = memo_c[i]; }
 				} else {
 					L.end = rec_end; L.cnt = rec_total;
-					dx_walk_e(L, want, !finishing && rec_start != DX_BAD, lane_base, limit, s_words, s_tab, s_long, linear, lane_slots);
+					dx_walk_e(L, want, !finishing && rec_start != DX_BAD, lane_base, limit, s_words, s_tab, s_long, linear, lane_log);
 					const uint32_t walked = lead ? L.start : want;
 					L.start = walked;
 					rec_start = walked; rec_end = L.end; rec_total = L.cnt;
@@ -1513,6 +1515,20 @@ __device__ __forceinline__ void dx_scatter_pieces(const DxTileMeta &M, uint32_t 
 		P.n = nstepb[idx];
 	}
 }
+// The first DX_SC_PRE steps of a piece's log (a column of its chunk's log area: lane within / 4, piece within % 4), fetched a tile ahead; the rest -- rare -- on demand.
+enum { DX_SC_PRE = 12 };
+struct DxScLog { uint32_t g[DX_SC_PRE]; };
+__device__ __forceinline__ const uint16_t *dx_scatter_column(const DxRecords &R, const DxScPieces &P)
+{
+	return (const uint16_t *)R.log + (size_t)P.chunk * (2 * DX_LOG_CHUNK) + (size_t)(P.within & 3u) * DX_LOG_PIECE + (P.within >> 2);
+}
+__device__ __forceinline__ void dx_scatter_log(const DxRecords &R, const DxScPieces &P, DxScLog &G)
+{
+	const uint16_t *col = dx_scatter_column(R, P);
+	const uint32_t n = P.n;
+#pragma unroll
+	for (int sidx = 0; sidx < DX_SC_PRE; sidx++) G.g[sidx] = (uint32_t)sidx < n ? (uint32_t)col[sidx * 64] : 0u;
+}
 
 __global__ void __launch_bounds__(DX_SC_THREADS) k_dec_scatter(const DxBandJob *jobs, DxTilePlan plan, const DecIdxTables *T, const uint32_t *entries, const uint32_t *chunk_base, const DxBandSum *sums,
                                                                const uint32_t *tile_start, const DxRecords R, unsigned long long *masks, uint32_t masks_per_frame)
@@ -1528,25 +1544,34 @@ __global__ void __launch_bounds__(DX_SC_THREADS) k_dec_scatter(const DxBandJob *
 	uint32_t t = plan.first + gwave;
 	if (t >= plan.total) return;
 	const uint8_t *nstepb = (const uint8_t *)R.nsteps;
-	// software pipeline as in k_dec_tiles: the descriptors of tile t + 2 nwaves and the piece entries of tile t + nwaves are on their way while tile t is filled
+	// What a tile waits for is a chain of three dependent fetches -- its descriptor, its pieces' entries, their logs -- and the second build of this kernel waited for the last
+	// of them inside every tile (9.6 us per tile and wave, whatever the work).  Three stages ahead instead: while tile t is filled, the logs of tile t + nwaves, the entries of
+	// tile t + 2 nwaves and the descriptor of tile t + 3 nwaves are on their way, each requested from what arrived during the tile before.
 	int slot = 0;
-	DxTileMeta M, M1;
+	auto pieces_of = [&](const DxTileMeta &m, bool there, DxScPieces &p) {
+		const bool w = there && dx_tile_has_work(m);
+		dx_scatter_pieces(m, w ? m.first_sub + (uint32_t)lane : 0xFFFFFFFFu, w ? dx_tile_last_sub(m) : 0u, entries, chunk_base, nstepb, p);
+	};
+	DxTileMeta M, M1, M2;
 	dx_tile_meta(plan, t, slot, jobs, sums, tile_start, M, masks, masks_per_frame);
-	M1 = M;
+	M1 = M; M2 = M;
 	if (t + nwaves < plan.total) dx_tile_meta(plan, t + nwaves, slot, jobs, sums, tile_start, M1, masks, masks_per_frame);
-	DxScPieces P;
-	dx_scatter_pieces(M, dx_tile_has_work(M) ? M.first_sub + (uint32_t)lane : 0xFFFFFFFFu, dx_tile_has_work(M) ? dx_tile_last_sub(M) : 0u, entries, chunk_base, nstepb, P);
+	if (t + 2 * nwaves < plan.total) dx_tile_meta(plan, t + 2 * nwaves, slot, jobs, sums, tile_start, M2, masks, masks_per_frame);
+	DxScPieces P, P1;
+	pieces_of(M, true, P);
+	pieces_of(M1, t + nwaves < plan.total, P1);
+	DxScLog G;
+	dx_scatter_log(R, P, G);
 	int16_t *tile16 = (int16_t *)s_tile;
 	const uint32_t dump = (uint32_t)DX_TILE + (uint32_t)lane;
 #pragma unroll 1
 	for (; t < plan.total; t += nwaves) {
-		DxTileMeta M2 = M1;
-		DxScPieces P1;
-		if (t + 2 * nwaves < plan.total) dx_tile_meta(plan, t + 2 * nwaves, slot, jobs, sums, tile_start, M2, masks, masks_per_frame);
-		{
-			const bool w1 = t + nwaves < plan.total && dx_tile_has_work(M1);
-			dx_scatter_pieces(M1, w1 ? M1.first_sub + (uint32_t)lane : 0xFFFFFFFFu, w1 ? dx_tile_last_sub(M1) : 0u, entries, chunk_base, nstepb, P1);
-		}
+		DxTileMeta M3 = M2;
+		DxScPieces P2;
+		DxScLog G1;
+		dx_scatter_log(R, P1, G1);
+		pieces_of(M2, t + 2 * nwaves < plan.total, P2);
+		if (t + 3 * nwaves < plan.total) dx_tile_meta(plan, t + 3 * nwaves, slot, jobs, sums, tile_start, M3, masks, masks_per_frame);
 		const DxBandJob job = dx_uniform(M.job);
 		const uint32_t first_sub = (uint32_t)wave_uniform((int)M.first_sub);
 		const uint32_t T0 = M.ti * DX_TILE, T1 = T0 + DX_TILE < (uint32_t)job.n ? T0 + DX_TILE : (uint32_t)job.n;
@@ -1558,43 +1583,34 @@ __global__ void __launch_bounds__(DX_SC_THREADS) k_dec_scatter(const DxBandJob *
 				for (uint32_t q0 = first_sub; q0 < last_sub; q0 += 64) {
 					const uint32_t q = q0 + (uint32_t)lane;
 					const bool active = q < last_sub;
-					if (q0 != first_sub) dx_scatter_pieces(M, q, last_sub, entries, chunk_base, nstepb, P);
+					if (q0 != first_sub) { dx_scatter_pieces(M, q, last_sub, entries, chunk_base, nstepb, P); dx_scatter_log(R, P, G); }      // further rounds: a dense tile (more than 64 pieces)
 					const uint32_t off = P.ent & 31u;
 					const uint32_t idx0 = P.cb + (P.ent >> 5);
 					const bool valid = active && off != (uint32_t)DX_OFF_INVALID;
 					const bool inside = valid && idx0 < T1;
 					const uint32_t n = inside ? (P.n <= (uint32_t)DX_REC_MAX ? P.n : (uint32_t)DX_REC_MAX) : 0u;
 					uint32_t rel = idx0 - T0;                          // "negative" (the piece starts in front of the tile) wraps to a huge number: those places go to the dump slot
-					const uint32_t *log = R.log + (size_t)P.chunk * DX_LOG_CHUNK + (size_t)P.within * DX_REC_SLOT;
-					cfhd_u4 la = { 0u, 0u, 0u, 0u }, lb = { 0u, 0u, 0u, 0u }, lc = { 0u, 0u, 0u, 0u }, ld = { 0u, 0u, 0u, 0u };
-					if (n > 0u) la = CFHD_LDG128(log);
-					if (n > 8u) lb = CFHD_LDG128(log + 4);
-					if (__ballot(n > 16u)) {                               // (rare: a piece of more than sixteen steps)
-						if (n > 16u) lc = CFHD_LDG128(log + DX_REC_CHUNK);
-						if (n > 24u) ld = CFHD_LDG128(log + DX_REC_CHUNK + 4);
-					}
-					const uint32_t lw[16] = { la.x, la.y, la.z, la.w, lb.x, lb.y, lb.z, lb.w, lc.x, lc.y, lc.z, lc.w, ld.x, ld.y, ld.z, ld.w };
+					const uint16_t *col = dx_scatter_column(R, P);
 #pragma unroll
-					for (int sidx = 0; sidx < 32; sidx++) {
+					for (int sidx = 0; sidx < DX_LOG_STEPS; sidx++) {
 						if (__ballot((uint32_t)sidx < n) == 0ull) break;          // (wave-uniform: the longest log of the round)
-						{
-							const uint32_t w = (sidx & 1) ? lw[sidx >> 1] >> 16 : lw[sidx >> 1] & 0xffffu;
-							const uint32_t kind = w >> 14;
-							const uint2 e = s_tab[w & ((1u << DX_KE) - 1u)];
-							const bool group = kind == (uint32_t)DX_LOG_GROUP;
-							uint32_t nv = group ? (e.y >> 28) & 3u : (e.y >> 30) & 1u, add = group ? e.x >> 20 : (e.x >> 8) & 0xfffu, o1 = e.y & 0xffu;
-							int v1 = dx_sext6(e.y, 16);
-							if (kind >= (uint32_t)DX_LOG_VALUE) {
-								const bool isval = kind == (uint32_t)DX_LOG_VALUE;
-								nv = isval ? 1u : 0u; add = isval ? 1u : w & 0x3fffu; o1 = 0u;
-								v1 = (int)(w << 18) >> 18;
-							}
-							const bool live = (uint32_t)sidx < n;
-							const uint32_t p1 = rel + o1, p2 = rel + ((e.y >> 8) & 0xffu);
-							tile16[(live && nv >= 1u && p1 < dump) ? p1 : dump] = (int16_t)mul_u24((uint32_t)v1, quant);
-							tile16[(live && nv == 2u && p2 < dump) ? p2 : dump] = (int16_t)mul_u24((uint32_t)dx_sext6(e.y, 22), quant);
-							rel += live ? add : 0u;
+						uint32_t w;
+						if (sidx < DX_SC_PRE) w = G.g[sidx]; else w = (uint32_t)sidx < n ? (uint32_t)col[sidx * 64] : 0u;
+						const uint32_t kind = w >> 14;
+						const uint2 e = s_tab[w & ((1u << DX_KE) - 1u)];
+						const bool group = kind == (uint32_t)DX_LOG_GROUP;
+						uint32_t nv = group ? (e.y >> 28) & 3u : (e.y >> 30) & 1u, add = group ? e.x >> 20 : (e.x >> 8) & 0xfffu, o1 = e.y & 0xffu;
+						int v1 = dx_sext6(e.y, 16);
+						if (kind >= (uint32_t)DX_LOG_VALUE) {
+							const bool isval = kind == (uint32_t)DX_LOG_VALUE;
+							nv = isval ? 1u : 0u; add = isval ? 1u : w & 0x3fffu; o1 = 0u;
+							v1 = (int)(w << 18) >> 18;
 						}
+						const bool live = (uint32_t)sidx < n;
+						const uint32_t p1 = rel + o1, p2 = rel + ((e.y >> 8) & 0xffu);
+						tile16[(live && nv >= 1u && p1 < dump) ? p1 : dump] = (int16_t)mul_u24((uint32_t)v1, quant);
+						tile16[(live && nv == 2u && p2 < dump) ? p2 : dump] = (int16_t)mul_u24((uint32_t)dx_sext6(e.y, 22), quant);
+						rel += live ? add : 0u;
 					}
 					if (__ballot(valid && !inside) || !__ballot(active)) break;
 				}
@@ -1606,7 +1622,7 @@ __global__ void __launch_bounds__(DX_SC_THREADS) k_dec_scatter(const DxBandJob *
 			unsigned long long *const tmasks = wave_uniform_ptr(M.masks);
 			if (tmasks) {
 				const uint32_t chunk0 = T0 / 512u;
-#pragma unroll 1
+#pragma unroll
 				for (uint32_t it = 0; it < (uint32_t)DX_TILE / 512u; it++) {
 					const uint32_t i = it * 64u + (uint32_t)lane;
 					const uint4 v = ((const uint4 *)s_tile)[i];
@@ -1616,15 +1632,18 @@ __global__ void __launch_bounds__(DX_SC_THREADS) k_dec_scatter(const DxBandJob *
 					if (nz) dst[it * 64u + wave_mbcnt(m)] = v;
 					if (lane == 0 && it * 64u < n16) tmasks[chunk0 + it] = m;
 				}
-			} else
-			for (uint32_t i = (uint32_t)lane; i < (uint32_t)DX_TILE / 8; i += 64) {
-				const uint4 v = ((const uint4 *)s_tile)[i];
-				((uint4 *)s_tile)[i] = zero;
-				if (i < n16) dst[i] = v;
+			} else {
+#pragma unroll
+				for (uint32_t it = 0; it < (uint32_t)DX_TILE / 512u; it++) {
+					const uint32_t i = it * 64u + (uint32_t)lane;
+					const uint4 v = ((const uint4 *)s_tile)[i];
+					((uint4 *)s_tile)[i] = zero;
+					if (i < n16) dst[i] = v;
+				}
 			}
 			CFHD_WAVE_SYNC();
 		}
-		M = M1; M1 = M2; P = P1;
+		M = M1; M1 = M2; M2 = M3; P = P1; P1 = P2; G = G1;
 	}
 }
 

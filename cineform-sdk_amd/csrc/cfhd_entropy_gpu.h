@@ -22,6 +22,8 @@ public:
 	void set_group_plan(const GopPlan &plan) { gplan_ = plan; }
 	int launch();                                                    // async: templates H2D + 4 kernels
 	int download();                                                  // sizes + packed offsets -> sync -> one async copy of all sample bytes (wait on the stream afterwards)
+	int download_queue();                                            // the two halves of download(): what can be queued behind launch() without the host ...
+	int download_finish();                                           // ... and what needs the sizes on the host (synchronises the stream, queues the copy of the sample bytes)
 	int fetch_sizes();                                               // sizes only (device-resident consumers); synchronises the stream
 	const uint32_t *device_sizes() const { return d_sizes_; }
 	const uint8_t *host_sample(int i) const { return h_samples_ + h_offsets_[i]; }   // after download() + stream wait

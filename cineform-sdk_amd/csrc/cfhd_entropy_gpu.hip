@@ -209,7 +209,10 @@ int GpuEntropyEncoder::fetch_sizes()
 	return 0;
 }
 
-int GpuEntropyEncoder::download()
+int GpuEntropyEncoder::download() { const int rc = download_queue(); return rc ? rc : download_finish(); }
+
+// The part of download() that can be queued behind the kernels without the host: the dense copy of the samples in HBM, sizes and offsets on their way to the host.
+int GpuEntropyEncoder::download_queue()
 {
 	(void)hipSetDevice(device_);
 	hipStream_t st = (hipStream_t)stream_;
@@ -223,6 +226,16 @@ int GpuEntropyEncoder::download()
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipMemcpyAsync(h_sizes_, d_sizes_, sizeof(uint32_t) * 2 * n_, hipMemcpyDeviceToHost, st));
 	HIPCHK(hipMemcpyAsync(h_offsets_, d_offsets_, sizeof(uint32_t) * (act + 1), hipMemcpyDeviceToHost, st));
+	return 0;
+}
+
+// ... and the part that needs the sizes: waits for the stream, then queues the one copy of all sample bytes (wait on the stream afterwards).
+int GpuEntropyEncoder::download_finish()
+{
+	(void)hipSetDevice(device_);
+	hipStream_t st = (hipStream_t)stream_;
+	static const bool direct = [] { const char *e = getenv("CFHD_AMD_DOWNLOAD"); return e && strcmp(e, "kernel") == 0; }();
+	const int act = active_frames();
 	HIPCHK(hipStreamSynchronize(st));
 	if (!direct && h_offsets_[act]) HIPCHK(hipMemcpyAsync(h_samples_, d_packed_, h_offsets_[act], hipMemcpyDeviceToHost, st));
 	return 0;

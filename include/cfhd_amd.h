@@ -142,8 +142,10 @@ cfhd_amd_batch *cfhd_amd_batch_create(int width, int height, uint32_t pixel_form
 void cfhd_amd_batch_destroy(cfhd_amd_batch *batch);
 int  cfhd_amd_batch_upload(cfhd_amd_batch *batch, int frame, const void *pixels, int pitch);   /* host frame -> HBM (outside any timed region) */
 long long cfhd_amd_batch_roundtrip(cfhd_amd_batch *batch);                                     /* one pass; total sample bytes, or < 0 */
-/* The same pass as a slot of a frame queue (replaces the reference's EncoderPool job queue, EncoderSDK/EncoderPool.cpp:239-380): submit returns at once, wait
- * returns what cfhd_amd_batch_roundtrip would have; batches in flight at the same time overlap on the GPU.  One pass per batch at a time. */
+/* The same pass as a slot of a frame queue (replaces the reference's EncoderPool job queue, EncoderSDK/EncoderPool.cpp:239-380): submit returns at once -- the whole
+ * pass is queued on the batch's HIP streams, the decoder's stream waiting for the encoder's events; no host thread, no host wait inside the pass --, wait returns what
+ * cfhd_amd_batch_roundtrip would have; batches in flight at the same time overlap on the GPU.  One pass per batch at a time: between submit and wait every other entry
+ * point on that batch (roundtrip, upload, get_sample, download_output, kernel_ms, dx_stats) returns its error value without touching the batch; destroy waits first. */
 int  cfhd_amd_batch_submit(cfhd_amd_batch *batch);
 long long cfhd_amd_batch_wait(cfhd_amd_batch *batch);
 int  cfhd_amd_batch_get_sample(cfhd_amd_batch *batch, int frame, const void **data, size_t *size);
