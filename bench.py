@@ -342,7 +342,7 @@ def measure(workload, steps, warmup, batch, unique, threads, rank, world, barrie
     # What was timed is what gets checked: the parity check reads the samples and pictures the LAST TIMED pass of every batch in flight left behind, before
     # anything runs again on them (a solo pass afterwards could hide corruption between concurrent passes).
     parity = None
-    if rank == 0 and not probing:
+    if rank == 0 and not probing and not os.environ.get("CFHD_BENCH_NO_PARITY"):      # (CFHD_BENCH_NO_PARITY: timing probes of builds that produce no valid output, tools/gpu_r05_f.sh; the line then says parity_checked false)
         last = (steps - 1) % depth
         parity = parity_check(L, slots[last], frames, pitch, W, H, rank, wl, batch, nuniq)
         for k, q in enumerate(slots):

@@ -1480,14 +1480,22 @@ __global__ void __launch_bounds__(DX_TILE_THREADS) k_dec_tiles(const DxBandJob *
 					((uint4 *)s_tile)[i] = zero;
 					const bool nz = i < n16 && (v.x | v.y | v.z | v.w) != 0u;
 					const unsigned long long m = __ballot(nz);
+#ifdef CFHD_DX_PROBE_NOSTORE      /* timing probe (tools/gpu_r05_f.sh): the tile pass without its stores -- what does a wave wait for? */
+					if (nz && v.x == 0x12345u) dst[it * 64u + wave_mbcnt(m)] = v;
+#else
 					if (nz) dst[it * 64u + wave_mbcnt(m)] = v;
 					if (lane == 0 && it * 64u < n16) tmasks[chunk0 + it] = m;
+#endif
 				}
 			} else
 			for (uint32_t i = (uint32_t)lane; i < (uint32_t)DX_TILE / 8; i += 64) {
 				const uint4 v = ((const uint4 *)s_tile)[i];
 				((uint4 *)s_tile)[i] = zero;
+#ifdef CFHD_DX_PROBE_NOSTORE
+				if (i < n16 && v.x == 0x12345u) dst[i] = v;
+#else
 				if (i < n16) dst[i] = v;
+#endif
 			}
 			CFHD_WAVE_SYNC();
 		}

@@ -246,7 +246,7 @@ int EncodeBatch::prepare(const FramePlan &plan, int nframes, bool own_input)
 	const bool bayer = plan.pixel_kind == PIX_BYR4 || plan.pixel_kind == PIX_BYR5;
 	if (plan.pixel_kind != PIX_YUY2 && plan.pixel_kind != PIX_2VUY && !enc_packed16(plan.pixel_kind) && !bayer) { g_err = "pixel format not supported by the GPU path yet"; return -2; }
 	plan_ = plan; n_ = nframes; own_input_ = own_input;
-	{ const char *e = getenv("CFHD_AMD_BAYER"); bayer_fused_ = e && strcmp(e, "fused") == 0; }      // (measured: 5.1 ms against 2.2 for 96 4K frames, see cfhd_device.h)
+	bayer_fused_ = false;      // (level 1 straight from the mosaic through the tiled kernel: measured 5.1 ms against 2.2 for 96 4K frames in round 3; k_fwd_bayer_strip is the fused kernel that pays)
 	HIPCHK(hipStreamCreateWithFlags((hipStream_t *)&stream_, hipStreamNonBlocking));
 	HIPCHK(hipEventCreate((hipEvent_t *)&ev0_));
 	HIPCHK(hipEventCreate((hipEvent_t *)&ev1_));
@@ -385,8 +385,8 @@ int EncodeBatch::prepare_entropy(size_t sample_cap)
 	int rc = ent_.prepare(plan_, n_, d_coeff_, plan_.coeff_elems, sample_cap, stream_);
 	ent_ready_ = rc == 0;
 	if (ent_ready_) fill_block_lists();
-	// the level-1 bands can be counted while levels 2 and 3 are still being transformed (CFHD_AMD_COUNT_SPLIT=0: everything behind level 3, one launch)
-	{ const char *e = getenv("CFHD_AMD_COUNT_SPLIT"); if (ent_ready_ && !(e && e[0] == '0')) ent_.set_level1_event(evl_[0]); }
+	// the level-1 bands can be counted while levels 2 and 3 are still being transformed (measured in round 3 against one launch behind level 3: + 2.8 %)
+	if (ent_ready_) ent_.set_level1_event(evl_[0]);
 	return rc;
 }
 
@@ -418,7 +418,7 @@ int EncodeBatch::sync_jobs()
 }
 
 // frames from this size on are staged in pieces (below it the extra calls cost more than the overlap gives); CFHD_AMD_STAGE_MIN_BYTES: tests lower it
-static size_t stage_piece_min_bytes() { static const size_t v = [] { const char *e = getenv("CFHD_AMD_STAGE_MIN_BYTES"); return e ? (size_t)atoll(e) : ((size_t)1 << 20); }(); return v; }
+static size_t stage_piece_min_bytes() { static const size_t v = [] { const char *e = getenv("CFHD_AMD_STAGE_MIN_BYTES") /* test hook: pieces at the small frames of the CPU suite too */; return e ? (size_t)atoll(e) : ((size_t)1 << 20); }(); return v; }
 
 int EncodeBatch::upload_frame(int i, const void *frame, int pitch)
 {
@@ -599,7 +599,7 @@ bool EncodeBatch::block_lists_forward() const
 int EncodeBatch::launch_forward(bool coeffs_needed)
 {
 	(void)hipSetDevice(device_);
-	static const int dense_env = [] { const char *e = getenv("CFHD_AMD_DENSE_L1"); return e ? atoi(e) : 0; }();      // (1: the dense level-1 bands are always written beside the block lists)
+	const int dense_env = 0;
 	const bool blocks = block_lists_forward();
 	if (ent_ready_) ent_.set_block_lists(blocks);
 	int rc = sync_jobs();

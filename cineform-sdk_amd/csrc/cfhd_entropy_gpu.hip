@@ -142,7 +142,11 @@ int GpuEntropyEncoder::launch()
 	const int act = active_frames(), total_segs = total_segs_ / n_ * act;      // frames 0 .. act-1 (set_active)
 	(void)hipGetLastError();
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[0], st));
+#ifdef CFHD_AMD_PROBES
 	const int count_probe = []{ const char *e = getenv("CFHD_AMD_COUNT_PROBE"); return e ? atoi(e) : 0; }();
+#else
+	const int count_probe = 0;
+#endif
 	const dev::EntBlockLists lists = { (const uint4 *)d_blocks_, d_masks_, d_coeffs_, masks_per_frame_ };
 	auto count_range = [&](hipStream_t s, int lo, int n, bool level1 = false) {
 		const int total = n * act;
@@ -180,7 +184,12 @@ int GpuEntropyEncoder::launch()
 	                                                  (dev::EntBandState *)d_bandstate_, T);
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[3], st));
 	dev::k_ent_emit<<<(total_segs + dev::ENT_WAVES * dev::ENT_EMIT_SEGS - 1) / (dev::ENT_WAVES * dev::ENT_EMIT_SEGS), dev::ENT_THREADS, 0, st>>>(total_segs, (const dev::EntSegState *)d_segs_,
-	                                                          T, (const uint32_t *)d_tokens_, []{ const char *e = getenv("CFHD_AMD_EMIT_PROBE"); return e ? atoi(e) : 0; }());
+	                                                          T, (const uint32_t *)d_tokens_,
+#ifdef CFHD_AMD_PROBES
+	                                                          []{ const char *e = getenv("CFHD_AMD_EMIT_PROBE"); return e ? atoi(e) : 0; }());
+#else
+	                                                          0);
+#endif
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[4], st));
 	timed_ = true;
@@ -216,9 +225,8 @@ int GpuEntropyEncoder::download_queue()
 {
 	(void)hipSetDevice(device_);
 	hipStream_t st = (hipStream_t)stream_;
-	// CFHD_AMD_DOWNLOAD=kernel: k_ent_pack stores the dense samples straight into the pinned host buffer (device-visible), no copy
-	// command at all; default: pack in HBM, then one copy (SDMA engine when the runtime has it enabled).
-	static const bool direct = [] { const char *e = getenv("CFHD_AMD_DOWNLOAD"); return e && strcmp(e, "kernel") == 0; }();
+	// pack in HBM, then one copy (SDMA engine when the runtime has it enabled)
+	const bool direct = false;      // (k_ent_pack storing straight into the pinned host buffer: measured slower than pack + one SDMA copy in round 2)
 	(void)hipGetLastError();
 	const int act = active_frames();
 	dev::k_ent_pack_offsets<<<1, dev::ENT_THREADS, 0, st>>>(d_sizes_, act, d_offsets_);
@@ -234,7 +242,7 @@ int GpuEntropyEncoder::download_finish()
 {
 	(void)hipSetDevice(device_);
 	hipStream_t st = (hipStream_t)stream_;
-	static const bool direct = [] { const char *e = getenv("CFHD_AMD_DOWNLOAD"); return e && strcmp(e, "kernel") == 0; }();
+	const bool direct = false;
 	const int act = active_frames();
 	HIPCHK(hipStreamSynchronize(st));
 	if (!direct && h_offsets_[act]) HIPCHK(hipMemcpyAsync(h_samples_, d_packed_, h_offsets_[act], hipMemcpyDeviceToHost, st));
@@ -338,8 +346,8 @@ int GpuEntropyDecoder::prepare(const FramePlan &plan, int nframes, int16_t *d_co
 		HIPCHK(hipHostMalloc((void **)&h_counters_, 32, hipHostMallocPortable));
 		int cus = 256;
 		(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_current());
-		const char *g1 = getenv("CFHD_AMD_DX_GRID_INDEX"), *g3 = getenv("CFHD_AMD_DX_GRID_TILES");
-		grid_index_ = g1 ? atoi(g1) : cus * 5; grid_tiles_ = g3 ? atoi(g3) : cus * (dev::DX_TILE_THREADS >= 1024 ? 1 : 2);      // workgroups that fit a CU at once (LDS: ~30 KB / ~150 KB each)
+		const char *g3 = nullptr;
+		grid_index_ = cus * 5; grid_tiles_ = cus * (dev::DX_TILE_THREADS >= 1024 ? 1 : 2);      // workgroups that fit a CU at once (LDS: ~30 KB / ~150 KB each)
 		if (emit_ && !g3) grid_tiles_ = cus * (int)((160 * 1024) / (sizeof(uint2) * (1 << dev::DX_KE) + sizeof(uint32_t) * dev::DX_TILE_WORDS * dev::DX_SC_WAVES));      // k_dec_scatter: the table + 8 KB of LDS per wave
 		if (grid_index_ < 1) grid_index_ = 1;
 		if (grid_tiles_ < 1) grid_tiles_ = 1;
@@ -580,9 +588,9 @@ int GpuEntropyDecoder::launch_dx(bool device_jobs, int njobs, uint32_t host_chun
 		tile_pass(tb, gb);
 	} else tile_pass(tp, g3);
 	if (interlaced_) {
-		// the difference-coded band of every channel back to coefficients: a wave per row for the bands without a peak table (CFHD_AMD_UNDIFF=block: the one kernel of
-		// round 3 for all of them, A/B), the workgroup-per-band kernel for the few that have one
-		static const bool rows = [] { const char *e = getenv("CFHD_AMD_UNDIFF"); return !(e && strcmp(e, "block") == 0); }();
+		// the difference-coded band of every channel back to coefficients: a wave per row for the bands without a peak table, the workgroup-per-band
+		// kernel of round 3 for the few that have one (measured against that kernel for all of them: profiles/r04_o_*)
+		const bool rows = true;
 		if (rows) dev::k_dec_undiff_rows<<<dim3((unsigned)(frames * plan_.num_channels), 32), 64 * dev::DXR_WAVES, 0, st>>>((const dev::DecDiffJob *)d_diffjobs_);
 		dev::k_dec_undiff<<<dim3((unsigned)(frames * plan_.num_channels), dev::DXU_SPLIT), dev::DXU_THREADS, 0, st>>>((const dev::DecDiffJob *)d_diffjobs_, d_errors_, rows ? 1 : 0);
 	}

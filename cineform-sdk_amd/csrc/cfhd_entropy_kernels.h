@@ -15,6 +15,14 @@
 #include <stdint.h>
 #include <cfhd_gfx950.h>
 
+// Timing probes of round 3 (kernels that stop early or skip their stores: they write INVALID samples) exist only in builds made with -DCFHD_AMD_PROBES
+// (tools/gpu_probe.sh); the shipped library compiles them out.
+#ifdef CFHD_AMD_PROBES
+#define CFHD_PROBE(p) (p)
+#else
+#define CFHD_PROBE(p) 0
+#endif
+
 namespace cfhd {
 namespace dev {
 
@@ -211,7 +219,7 @@ __device__ __forceinline__ void ent_count_tokens(int seg, const EntSegJob &job, 
 __device__ __forceinline__ void ent_count_segment(int seg, const EntSegJob &job, int frame, const uint32_t *w, int lane, uint32_t *s_tok, EntSegState *segs, const EntTables *tables,
                                                   uint32_t *peak_flags, uint32_t *tokens, int probe)
 {
-	if (probe == 1) { uint32_t o = 0; for (int j = 0; j < ENT_SEG / 128; j++) o |= w[j]; const unsigned long long q = __ballot(o == 0x12345u); if (lane == 0) { EntSegState &z = segs[seg]; z.first_nz = -1; z.last_nz = -1; z.bits = q == 0x123456789ull; z.ntok = 0; z.lead32 = 0; z.lead_valid = 0; } return; }
+	if (CFHD_PROBE(probe) == 1) { uint32_t o = 0; for (int j = 0; j < ENT_SEG / 128; j++) o |= w[j]; const unsigned long long q = __ballot(o == 0x12345u); if (lane == 0) { EntSegState &z = segs[seg]; z.first_nz = -1; z.last_nz = -1; z.bits = q == 0x123456789ull; z.ntok = 0; z.lead32 = 0; z.lead_valid = 0; } return; }
 	int ntok = 0;                                        // wave-uniform
 #pragma unroll
 	for (int j = 0; j < ENT_SEG / 128; j++) {
@@ -234,7 +242,7 @@ __device__ __forceinline__ void ent_count_tokens(int seg, const EntSegJob &job, 
 {
 	const EntTables *T = tables + job.table;
 	uint32_t bits = 0, lead32 = 0, lead_valid = 0;
-	if (probe == 2) { const unsigned long long q = __ballot(s_tok[lane] == 0x12345u); if (lane == 0) { EntSegState &z = segs[seg]; z.first_nz = -1; z.last_nz = -1; z.bits = q == 0x123456789ull && ntok == 0x12345; z.ntok = 0; z.lead32 = 0; z.lead_valid = 0; } return; }
+	if (CFHD_PROBE(probe) == 2) { const unsigned long long q = __ballot(s_tok[lane] == 0x12345u); if (lane == 0) { EntSegState &z = segs[seg]; z.first_nz = -1; z.last_nz = -1; z.bits = q == 0x123456789ull && ntok == 0x12345; z.ntok = 0; z.lead32 = 0; z.lead_valid = 0; } return; }
 	bool peak = false;
 	for (int t0 = 0; t0 < ntok; t0 += ENT_LANES) {       // wave-uniform
 		const int t = t0 + lane;
@@ -260,7 +268,7 @@ __device__ __forceinline__ void ent_count_tokens(int seg, const EntSegJob &job, 
 			const uint32_t str = simple ? (((run ? rp.x : 0u) << vs) | vc) << (32u - rs - vs) : 0u;      // (rs + vs >= 2: a value code has at least its sign)
 			const uint32_t len = simple ? rs + vs : (uint32_t)ENT_CODE_COMPLEX;
 			const uint32_t rec = simple ? str | len : (run << 22) | ((tok & 0xffffu) << 6) | len;
-			if (probe != 4) seg_out[t] = rec;
+			if (CFHD_PROBE(probe) != 4) seg_out[t] = rec;
 			my_top = str; my_len = len;
 		}
 		if (t0 == 0) {
@@ -666,7 +674,7 @@ __device__ __forceinline__ void ent_emit_segment(const EntSegState &st, const En
 	const bool merge_next = has_next && ent_neighbours_merge(st, nx);
 	uint32_t *out = (uint32_t *)st.out;
 	if (!out) return;                                    // the sample overflowed its buffer (k_ent_layout reported size 0)
-	if (probe == 2) { if (first_rec == 0x12345u && lane == 0) out[0] = 1; return; }
+	if (CFHD_PROBE(probe) == 2) { if (first_rec == 0x12345u && lane == 0) out[0] = 1; return; }
 	const int ntok = (int)st.ntok;
 	const uint64_t seg_pos = st.bitoff;                  // bit position of the segment inside the band payload
 	const uint32_t first_word = (uint32_t)(seg_pos >> 5), last_word = (uint32_t)((seg_pos + st.bits - 1) >> 5);
@@ -710,7 +718,7 @@ __device__ __forceinline__ void ent_emit_segment(const EntSegState &st, const En
 		}
 	}
 	CFHD_WAVE_SYNC();
-	if (probe == 3) { if (s_words[lane] == 0x12345u) out[0] = 1; return; }
+	if (CFHD_PROBE(probe) == 3) { if (s_words[lane] == 0x12345u) out[0] = 1; return; }
 	if (use_lds) {
 		// interior words belong to this segment alone: plain coalesced stores; the first and last word may be shared with
 		// the neighbouring segments (or the band's trailer): OR them into the zeroed payload
@@ -721,8 +729,8 @@ __device__ __forceinline__ void ent_emit_segment(const EntSegState &st, const En
 			if (is_first && prev_writes_first) continue;                       // the segment in front stores this word, our bits included
 			if (is_last && merge_next) w |= nx.lead32 >> ((seg_pos + st.bits) & 31u);      // the next segment's first bits: the word is complete
 			w = bswap32(w);
-			if (((is_first && first_shared) || (is_last && last_shared && !merge_next)) && probe != 4) { if (w) atomic_or_u32(&out[first_word + i], w); }
-			else if (probe != 5) out[first_word + i] = w;
+			if (((is_first && first_shared) || (is_last && last_shared && !merge_next)) && CFHD_PROBE(probe) != 4) { if (w) atomic_or_u32(&out[first_word + i], w); }
+			else if (CFHD_PROBE(probe) != 5) out[first_word + i] = w;
 		}
 	}
 }
@@ -736,7 +744,7 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(int total_segs, const 
                                                            int probe = 0 /* timing experiments: 1 leave at once, 2 behind the descriptor loads, 3 without the final stores, 4 plain stores for the shared words, 5 no plain stores */)
 {
 	__shared__ uint32_t s_words_all[ENT_WAVES][ENT_LDS_WORDS + 3];
-	if (probe == 1) return;
+	if (CFHD_PROBE(probe) == 1) return;
 	const int lane = wave_lane();
 	const int wave = wave_uniform((int)(threadIdx.x >> 6));
 	const int seg0 = wave_uniform(((int)blockIdx.x * ENT_WAVES + wave) * ENT_EMIT_SEGS);
