@@ -519,8 +519,16 @@ def main():
                     others[name] = {"error": str(e)[:300]}
             line["config"]["other_workloads"] = others
         if world == 1 and not args.no_c_abi and headline:
+            # the host-fed figures swing with the scheduling of ~ 30 host threads: the plain-buffer configuration runs three times, every run is in the line and
+            # the MINIMUM of each figure beside them (north_star's 4000 fps round trip is judged on that)
+            runs = [c_abi_rates(frames[:8], pitch, W, H, decoders=8, workers=8) for _ in range(3)]
+            good = [r for r in runs if "error" not in r]
+            plain = dict(good[0]) if good else dict(runs[0])
+            if good:
+                plain = {k: min(r[k] for r in good) for k in good[0]}
+                plain["min_of_runs"] = len(good); plain["runs"] = runs
             line["config"]["c_abi_fps"] = {"frame": "%dx%d YUY2, frames and samples in host memory (PCIe inclusive)" % (W, H),
-                                           "plain_buffers": c_abi_rates(frames[:8], pitch, W, H, decoders=8, workers=8),
+                                           "plain_buffers": plain,
                                            "plain_buffers_16_threads": c_abi_rates(frames[:8], pitch, W, H, decoders=16, workers=16),
                                            "buffers_registered_by_the_caller_16_threads": c_abi_rates(frames[:8], pitch, W, H, registered=True, decoders=16, workers=16)}
             ngpu = torch.cuda.device_count()

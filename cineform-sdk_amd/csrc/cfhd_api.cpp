@@ -71,6 +71,12 @@ struct EncMetadata {
 	bool changed = false;
 };
 
+// Settings of the ROCm runtime this library is measured with, for a process that did not choose them itself (set when the library is loaded, i.e. before the first
+// HIP call of an application that links it; an application that set them keeps its values): sample downloads on the SDMA engines instead of blit kernels that
+// compete with the codec's kernels (HSA_ENABLE_SDMA, bench.py: DESIGN.md section 5), kernel arguments written to device memory (HIP_FORCE_DEV_KERNARG: the
+// host-fed round trip of tools/cabi_bench 2.4-2.9 k -> 3.6 k fps, profiles/r05_e_*).
+__attribute__((constructor)) static void cfhd_amd_runtime_defaults() { setenv("HSA_ENABLE_SDMA", "1", 0); setenv("HIP_FORCE_DEV_KERNARG", "1", 0); }
+
 // CFHD_AMD_PROFILE=1: where the wall time of the synchronous calls goes (printed when the handle is closed)
 bool profile_enabled() { static const bool on = [] { const char *e = getenv("CFHD_AMD_PROFILE"); return e && atoi(e) != 0; }(); return on; }
 double wall_now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
@@ -97,6 +103,7 @@ struct EncodeParams {
 	int color_space = 2;
 	FramePlan plan;
 	QuantState qstate = {0, -1, 0};
+	int api_encoded = 0, api_quality = 0;         // the encoded format and quality as the caller passed them (quality gets format marks OR-ed in below)
 	bool gop = false; GopPlan gplan;              // CFHD_ENCODING_FLAGS_YUV_2FRAME_GOP: two frames per sample (cfhd_gop.h)
 	QuantState gstate = {0, -1, 0};               // the quantizer state of the group encoder (rate feedback from the last key sample)
 	bool valid = false;
@@ -105,6 +112,7 @@ struct EncodeParams {
 int make_params(EncodeParams &p, int w, int h, uint32_t fmt, int encoded, uint32_t flags, int quality)
 {
 	p.valid = false;
+	p.api_encoded = encoded; p.api_quality = quality;
 	int kind = pixel_kind_of(fmt);
 	if (kind == PIX_NONE) return ERR_BADFORMAT;
 	// CFHD_ENCODED_FORMAT_YUV_422 (0) from the packed 4:2:2 formats, CFHD_ENCODED_FORMAT_RGB_444 (1) from RG48; the cross
@@ -362,9 +370,17 @@ struct EncodeServices {
 	}
 };
 EncodeServices &encode_services() { static EncodeServices *s = new EncodeServices; return *s; }
-// Off unless asked for: measured on one MI355X at 1080p, pool workers on their own streams reach 8.7-11.8 k fps, gathered into shared passes
-// 5.6-8.2 k (the pass keeps its callers in lock step); only with decoders competing for the GPU did the round trip sometimes gain (3.9 -> 4.6 k).
-int encode_gather_slots() { return gather_slots("CFHD_AMD_ENCODE_BATCH", 0); }        // (read when a pool starts)
+// Pool workers gather their frames into shared passes WHILE DECODERS ARE AT WORK on the GPU, and only then.  Measured on one MI355X at 1080p (profiles/r05_e_*): a pool
+// alone runs faster with every worker on its own stream (7.6 k against 6.8 k fps gathered: a shared pass keeps its callers in lock step), but a pool beside eight decoder
+// threads -- the round trip through the C ABI -- runs at 2.4-2.9 k fps ungathered and 4.1-4.2 k gathered: three dozen launches per frame from sixteen threads queue up in
+// the runtime, a pass of eight frames makes them a dozen.  CFHD_AMD_ENCODE_BATCH=n forces n slots whatever the decoders do (0: never gather).
+std::atomic<int> g_decodes_in_flight(0);
+std::atomic<long long> g_last_decode_ns(0);
+long long mono_ns() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (long long)ts.tv_sec * 1000000000ll + ts.tv_nsec; }
+struct DecodeInFlight { DecodeInFlight() { g_decodes_in_flight.fetch_add(1); } ~DecodeInFlight() { g_last_decode_ns.store(mono_ns()); g_decodes_in_flight.fetch_sub(1); } };
+bool encode_gather_forced() { static const bool f = getenv("CFHD_AMD_ENCODE_BATCH") != nullptr; return f; }
+bool decoders_at_work() { return g_decodes_in_flight.load() > 0 || mono_ns() - g_last_decode_ns.load() < 5000000ll; }       // a decode call running, or one that ended within the last 5 ms
+int encode_gather_slots() { return gather_slots("CFHD_AMD_ENCODE_BATCH", 8); }        // (read when a pool starts)
 // true when the quantizer tables of a sequence never move: FILMSCAN1 (and anything above 1080p for LOW..HIGH) -- decided by asking the
 // derivation itself whether a large previous sample would change them
 bool quantizer_is_static(const EncodeParams &p)
@@ -384,7 +400,7 @@ int encode_one_gathered(EncodeBatch &own, EncodeParams &p, const void *frame, in
 {
 	if (svc) {
 		struct InFlight { std::atomic<int> &n; int before; InFlight(std::atomic<int> &c) : n(c), before(c.fetch_add(1)) {} ~InFlight() { n.fetch_sub(1); } } mark(svc->inflight);
-		if (mark.before > 0) {
+		if (mark.before > 0 && (encode_gather_forced() || decoders_at_work())) {
 			bool usable;
 			{
 				std::lock_guard<std::mutex> lk(svc->m);
@@ -404,7 +420,10 @@ int encode_one_gathered(EncodeBatch &own, EncodeParams &p, const void *frame, in
 	return encode_one(own, p, frame, pitch, frame_number, global, local, out, cap, size_out);
 }
 
+// Handles carry their kind in their first word: the reference's own harness closes an encoder POOL with CFHD_CloseEncoder on its error path (Example/TestCFHD.cpp:1044)
+enum : uint32_t { kEncoderMagic = 0x43464845u /* 'CFHE' */, kPoolMagic = 0x43464850u /* 'CFHP' */ };
 struct Encoder {
+	uint32_t magic = kEncoderMagic;
 	EncodeParams params;
 	MetaState meta;
 	EncodeBatch batch;
@@ -446,6 +465,7 @@ struct PoolWorker {
 };
 
 struct EncoderPool {
+	uint32_t magic = kPoolMagic;
 	int nworkers = 1, queue_len = 1;
 	EncodeParams params;
 	MetaState meta;                           // pool-wide metadata (attached with CFHD_AttachEncoderPoolMetadata)
@@ -729,10 +749,13 @@ CFHD_Error CFHD_GetSampleData(CFHD_EncoderRef ref, void **data, size_t *size)
 	return ERR_OKAY;
 }
 
+CFHD_Error CFHD_ReleaseEncoderPool(CFHD_EncoderPoolRef ref);
 CFHD_Error CFHD_CloseEncoder(CFHD_EncoderRef ref)
 {
 	CallerDevice caller_device;                      // (the caller's current HIP device is put back on the way out)
 	if (!ref) return ERR_INVALID_ARGUMENT;
+	if (*(const uint32_t *)ref == kPoolMagic) return CFHD_ReleaseEncoderPool((CFHD_EncoderPoolRef)ref);      // (what the reference's harness does on its error path)
+	if (*(const uint32_t *)ref != kEncoderMagic) return ERR_INVALID_ARGUMENT;
 	static const char *const names[] = { "encode_one" };
 	((Encoder *)ref)->prof.report("CFHD_EncodeSample", names, 1);
 	delete (Encoder *)ref;
@@ -809,7 +832,26 @@ CFHD_Error CFHD_PrepareEncoderPool(CFHD_EncoderPoolRef ref, uint_least16_t w, ui
 	CallerDevice caller_device;                      // (the caller's current HIP device is put back on the way out)
 	if (!ref) return ERR_INVALID_ARGUMENT;
 	EncoderPool *p = (EncoderPool *)ref;
-	if (p->started) return ERR_UNEXPECTED;
+	if (p->started) {
+		// A pool that is encoding takes the quality of its NEXT frames from this call and nothing else (EncoderSDK/EncoderPool.cpp:129-132 SetNextFrameQuality; the
+		// reference's own harness calls this once per loop turn until its first sample comes back, Example/TestCFHD.cpp:860-897).  Frames already submitted keep the
+		// tables they were submitted under: the call waits for them, then every worker takes the new tables.
+		if ((int)quality == p->params.api_quality) return ERR_OKAY;
+		EncodeParams np;
+		const int rc = make_params(np, p->params.width, p->params.height, p->params.pixel_format, p->params.api_encoded, p->params.flags, quality);
+		if (rc) return rc;
+		std::unique_lock<std::mutex> lk(p->m);
+		p->cv_done.wait(lk, [&] { for (auto &j : p->fifo) if (!j->finished) return false; return true; });
+		p->params = np; p->service = nullptr;           // (shared passes are keyed by quality: the workers go on alone)
+		for (auto &wk : p->workers) {
+			device_select(wk->device);
+			wk->params = np;
+			const int urc = wk->batch.update_quant(np.plan);
+			device_select(-1);
+			if (urc) return ERR_INTERNAL;
+		}
+		return ERR_OKAY;
+	}
 	if ((uint32_t)flags & 2u) return ERR_BADFORMAT;      // two-frame groups are sequential (a frame pair per sample): the synchronous encoder serves them
 	return make_params(p->params, w, h, fmt, encoded, flags, quality);
 }
@@ -833,7 +875,7 @@ CFHD_Error CFHD_StartEncoderPool(CFHD_EncoderPoolRef ref)
 	if (!ref) return ERR_INVALID_ARGUMENT;
 	EncoderPool *p = (EncoderPool *)ref;
 	if (!p->params.valid) return ERR_ENCODING_NOT_STARTED;
-	if (p->started) return ERR_OKAY;
+	if (p->started) return ERR_UNEXPECTED;               // (EncoderSDK/EncoderPool.cpp:187-189; the pool keeps running)
 	p->stopping = false;
 	p->workers.clear();
 	for (int i = 0; i < p->nworkers; i++) {
@@ -1226,6 +1268,7 @@ static CFHD_Error decode_group_sample(Decoder *d, const uint8_t *s, size_t size,
 CFHD_Error CFHD_DecodeSample(CFHD_DecoderRef ref, void *sample, size_t size, void *out, int32_t pitch)
 {
 	CallerDevice caller_device;                      // (the caller's current HIP device is put back on the way out)
+	DecodeInFlight decode_in_flight;                 // (encoder pools of the process gather their frames while decoders are at work: encode_one_gathered)
 	if (!ref || !sample || !out) return ERR_INVALID_ARGUMENT;
 	Decoder *d = (Decoder *)ref;
 	if (!d->prepared) return ERR_UNEXPECTED;

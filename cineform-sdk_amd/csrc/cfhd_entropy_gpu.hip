@@ -183,13 +183,13 @@ int GpuEntropyEncoder::launch()
 	dev::k_ent_layout<<<dim3((unsigned)act, layout_parts), dev::ENT_THREADS, 0, st>>>((const dev::EntFrameJob *)d_frames_, (const dev::EntBandJob *)d_bands_, (dev::EntSegState *)d_segs_,
 	                                                  (dev::EntBandState *)d_bandstate_, T);
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[3], st));
-	dev::k_ent_emit<<<(total_segs + dev::ENT_WAVES * dev::ENT_EMIT_SEGS - 1) / (dev::ENT_WAVES * dev::ENT_EMIT_SEGS), dev::ENT_THREADS, 0, st>>>(total_segs, (const dev::EntSegState *)d_segs_,
-	                                                          T, (const uint32_t *)d_tokens_,
 #ifdef CFHD_AMD_PROBES
-	                                                          []{ const char *e = getenv("CFHD_AMD_EMIT_PROBE"); return e ? atoi(e) : 0; }());
+	const int emit_probe = []{ const char *e = getenv("CFHD_AMD_EMIT_PROBE"); return e ? atoi(e) : 0; }();
 #else
-	                                                          0);
+	const int emit_probe = 0;
 #endif
+	dev::k_ent_emit<<<(total_segs + dev::ENT_WAVES * dev::ENT_EMIT_SEGS - 1) / (dev::ENT_WAVES * dev::ENT_EMIT_SEGS), dev::ENT_THREADS, 0, st>>>(total_segs, (const dev::EntSegState *)d_segs_,
+	                                                          T, (const uint32_t *)d_tokens_, emit_probe);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[4], st));
 	timed_ = true;

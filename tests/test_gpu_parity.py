@@ -203,6 +203,46 @@ def _pool_is_fifo_and_matches_sync():
         assert bytes(a) == bytes(b), "pool sample %d differs from the synchronous encoder" % i
 
 
+def test_encoder_pool_takes_the_calls_of_the_reference_harness():
+    """Example/TestCFHD.cpp:860-897 (-E, EncodeSpeedTest) prepares and starts its pool again on every turn of its loop until the first sample comes back, and closes
+    the POOL with CFHD_CloseEncoder on its error path (:1044).  The reference takes both: a pool that is encoding reads the quality of its next frames from the call
+    and nothing else (EncoderSDK/EncoderPool.cpp:129-132), a second start is refused without harm (:187-189).  Round 4's library answered the second prepare with
+    CFHD_ERROR_UNEXPECTED and then crashed in the close -- found when the harness binary ran -E against it on the GPU box."""
+    import struct
+    L = product()
+    w, h = 320, 240
+    frames = [synth_yuy2(w, h, 60 + i)[0] for i in range(4)]
+    def collect(pool):
+        num = ctypes.c_uint32(); sb = ctypes.c_void_p()
+        assert L.CFHD_WaitForSample(pool, ctypes.byref(num), ctypes.byref(sb)) == 0
+        p = ctypes.c_void_p(); n = ctypes.c_size_t()
+        assert L.CFHD_GetEncodedSample(sb, ctypes.byref(p), ctypes.byref(n)) == 0
+        s = ctypes.string_at(p, n.value)
+        assert L.CFHD_ReleaseSampleBuffer(pool, sb) == 0
+        return s
+    def normalised(s):
+        b = bytearray(mask_volatile_metadata(s))
+        k = bytes(b[:128]).find(struct.pack(">h", -69)); b[k + 2:k + 4] = b"\0\0"
+        u = bytes(b[:1024]).find(b"UFRM"); b[u + 8:u + 12] = b"\0\0\0\0"
+        return bytes(b)
+    pool = ctypes.c_void_p()
+    assert L.CFHD_CreateEncoderPool(ctypes.byref(pool), 1, 4, None) == 0
+    for turn in range(3):                                  # the harness's loop: prepare + start on every turn while frame number 1 is not back yet
+        assert L.CFHD_PrepareEncoderPool(pool, w, h, PIX_YUY2, ENCODED_YUV422, 0, QUALITY_FILMSCAN1) == 0
+        assert L.CFHD_StartEncoderPool(pool) == (0 if turn == 0 else 10)      # CFHD_ERROR_UNEXPECTED: already started, and it keeps running
+        assert L.CFHD_EncodeAsyncSample(pool, turn + 1, frames[turn].ctypes.data_as(ctypes.c_void_p), w * 2, None) == 0
+    first = [collect(pool) for _ in range(3)]
+    want = amd_encode_frames(frames[:3], w * 2, w, h)
+    for a, b in zip(first, want): assert normalised(a) == normalised(b)
+    # a new quality for the frames submitted from now on (CFHD_ENCODING_QUALITY_MEDIUM = 2; width, height and formats of the call are not looked at)
+    assert L.CFHD_PrepareEncoderPool(pool, 64, 64, PIX_YUY2, ENCODED_YUV422, 0, 2) == 0
+    assert L.CFHD_EncodeAsyncSample(pool, 9, frames[3].ctypes.data_as(ctypes.c_void_p), w * 2, None) == 0
+    medium = collect(pool)
+    assert normalised(medium) == normalised(amd_encode_frames([frames[3]], w * 2, w, h, quality=2)[0])
+    assert len(medium) != len(amd_encode_frames([frames[3]], w * 2, w, h)[0])
+    assert L.CFHD_CloseEncoder(pool) == 0                  # the harness's error path: the pool is released, nothing else is touched
+
+
 def test_invalid_arguments_and_unsupported_formats():
     L = product()
     assert L.CFHD_OpenEncoder(None, None) == 1
