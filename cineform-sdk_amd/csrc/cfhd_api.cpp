@@ -139,9 +139,9 @@ int make_params(EncodeParams &p, int w, int h, uint32_t fmt, int encoded, uint32
 	const bool interlaced = (flags & (1u << 0)) != 0;
 	if (interlaced && !(kind == PIX_YUY2 || kind == PIX_2VUY)) return ERR_BADFORMAT;
 	// CFHD_ENCODING_FLAGS_YUV_2FRAME_GOP (CFHDTypes.h:254, "YUV 4:2:2 only"): two frames per sample through the temporal transform (cfhd_gop.h).
-	// Progressive frames, qualities whose tables do not follow the size of the previous group.
+	// With CFHD_ENCODING_FLAGS_YUV_INTERLACED on top, level 1 of both frames is the frame transform (GopPlan::interlaced).
 	const bool gop = (flags & (1u << 1)) != 0;
-	if (gop && (interlaced || !(kind == PIX_YUY2 || kind == PIX_2VUY))) return ERR_BADFORMAT;
+	if (gop && !(kind == PIX_YUY2 || kind == PIX_2VUY)) return ERR_BADFORMAT;
 	const int enc = kind == PIX_BYR4 || kind == PIX_BYR5 ? ENC_BAYER : (((kind == PIX_B64A || rg64) && encoded == 2) || rgba8_as_4444 ? ENC_RGBA4444 : (rgb && !deep_rgb_as_422 ? ENC_RGB444 : ENC_YUV422));
 	// an encoded format other than the default of the input format marks the quality word (SampleEncoder.cpp:216-219; QUALITY_H 0x0800 in the header)
 	if (deep_rgb_as_422 && !rgb8_as_422) quality |= 0x08000000;
@@ -162,7 +162,7 @@ int make_params(EncodeParams &p, int w, int h, uint32_t fmt, int encoded, uint32
 	derive_quantization(&p.plan, quality, p.progressive, 0.0f, &p.qstate);
 	p.gop = gop;
 	p.gstate = {0, -1, 0};
-	if (gop && (!build_gop_plan(&p.gplan, w, h, kind) || !derive_gop_quantization(&p.gplan, quality, &p.gstate))) return ERR_BADFORMAT;
+	if (gop && (!build_gop_plan(&p.gplan, w, h, kind, interlaced) || !derive_gop_quantization(&p.gplan, quality, &p.gstate))) return ERR_BADFORMAT;
 	p.valid = true;
 	return ERR_OKAY;
 }
@@ -705,7 +705,7 @@ CFHD_Error CFHD_EncodeSample(CFHD_EncoderRef ref, void *frame, int pitch)
 		} else {
 			MetaBlock global = e->meta.global, local = e->meta.local;
 			meta_remove_hidden(global); meta_remove_hidden(local);
-			SampleHeaderInfo hdr = { n, color_format_of(e->params.pixel_kind), e->params.color_space, e->params.quality, true, global.data(), global.size(), local.data(), local.size() };
+			SampleHeaderInfo hdr = { n, color_format_of(e->params.pixel_kind), e->params.color_space, e->params.quality, !e->params.gplan.interlaced, global.data(), global.size(), local.data(), local.size() };
 			if (e->gop_batch.launch_forward()) return ERR_INTERNAL;
 			bytes = 0;
 			// GPU entropy stage: the finished group sample comes back, not the pyramid.  The host writer takes over (from the same GPU coefficients) when the header
@@ -714,7 +714,8 @@ CFHD_Error CFHD_EncodeSample(CFHD_EncoderRef ref, void *frame, int pitch)
 			if (e->gop_batch.has_entropy() && e->gop_batch.entropy().set_frame_header(0, hdr) == 0) {
 				if (e->gop_batch.entropy().launch() || e->gop_batch.entropy().download() || e->gop_batch.wait()) return ERR_INTERNAL;
 				const size_t nb = e->gop_batch.entropy().sample_bytes(0);
-				if (nb && nb <= e->sample.size() && !gop_sample_may_zero_bands(e->params.gplan, nb)) { memcpy(e->sample.data(), e->gop_batch.entropy().host_sample(0), nb); bytes = nb; }
+				// (an interlaced group whose difference-coded bands hold values beyond the peak threshold needs peak tables: the host writer's, as for interlaced intra frames)
+				if (nb && nb <= e->sample.size() && !gop_sample_may_zero_bands(e->params.gplan, nb) && !e->gop_batch.entropy().needs_peak_table(0)) { memcpy(e->sample.data(), e->gop_batch.entropy().host_sample(0), nb); bytes = nb; }
 			}
 			if (!bytes) {
 				if (gpu_entropy_strict()) return ERR_INTERNAL;
@@ -1204,10 +1205,13 @@ static CFHD_Error decode_group_sample(Decoder *d, const uint8_t *s, size_t size,
 		return ERR_OKAY;
 	}
 	if (pg.sample_type != 2 || pg.width != gp.width || pg.height != gp.height || pg.precision != 10) return fail_zero(ERR_BADSAMPLE);
-	// Groups of interlaced frames (YUV_INTERLACED | 2FRAME_GOP: no SAMPLE_FLAGS tag, field transform at level 1, difference-coded bands) are not built:
-	// refuse them instead of running the progressive inverse over them (decoder.c:13397 sets `progressive` only from the tag).
-	if (!pg.progressive) return fail_zero(ERR_BADFORMAT);
-	for (int c = 0; c < 3; c++) for (int k = 0; k < kGopWavelets; k++) for (int b = 0; b < 4; b++) if (pg.band[c][k][b].present && pg.band[c][k][b].difference) return fail_zero(ERR_BADFORMAT);
+	// Groups of interlaced frames (YUV_INTERLACED | 2FRAME_GOP) carry no SAMPLE_FLAGS tag (decoder.c:13397 sets `progressive` only from the tag): frame transform at
+	// level 1 of both frames, the band 2 of both frame wavelets difference coded in code set 18 (subbands 12 and 15) -- and nowhere else
+	const bool interlaced = !pg.progressive;
+	for (int c = 0; c < 3; c++) for (int k = 0; k < kGopWavelets; k++) for (int b = 0; b < 4; b++)
+		if (pg.band[c][k][b].present && pg.band[c][k][b].difference != (interlaced && k < 2 && b == 2)) return fail_zero(ERR_BADSAMPLE);
+	if (d->gop_ready && d->gplan.interlaced != interlaced) d->gop_ready = false;
+	d->gplan.interlaced = interlaced;
 	if (!d->gop_ready) {
 		device_select(d->device);
 		const int prc = d->gop_batch.prepare(gp, true, d->out_kind);
@@ -1255,6 +1259,8 @@ static CFHD_Error decode_group_sample(Decoder *d, const uint8_t *s, size_t size,
 						for (int x = 0; x < wv.width; x++) dst[(size_t)r * wv.pitch + x] = (int16_t)(((p[2 * x] << 8) | p[2 * x + 1]) * pb.quant);
 					}
 				} else if (vlc_decode_band(s + pb.offset, pb.bytes, wv.width, wv.height, wv.pitch, pb.quant, pb.codebook, dst)) return fail_zero(ERR_BADSAMPLE);
+				// interlaced groups: peak values, then every row becomes its running sum (decoder.c:19809, :20822)
+				if (pb.difference) finish_difference_band(dst, wv.width, wv.height, wv.pitch, pb.peak_level ? s + pb.peak_offset : nullptr, pb.peak_level ? size - pb.peak_offset : 0, pb.peak_level);
 			}
 		}
 	}

@@ -1340,6 +1340,8 @@ void GopBatch::fill_jobs()
 			const GopWavelet &w = plan.ch[c].w[f];
 			y.out_pitch[c] = w.pitch; iy.band_pitch[c] = w.pitch;
 			for (int b = 0; b < 4; b++) { y.out[c][b] = base + w.offset[b]; y.q[c][b] = make_q(w.quant[b], mpq); iy.band[c][b] = base + w.offset[b]; }
+			// interlaced groups: the difference-coded band is quantized inside the horizontal filter, midpoint = divisor / prequant without the decrement (spatial.c:5360-5363)
+			if (plan.interlaced && w.quant[2] > 1 && mpq >= 2 && mpq < 9) y.q[c][2].mid = w.quant[2] / mpq;
 		}
 		iy.width = plan.ch[0].w[f].width; iy.height = plan.ch[0].w[f].height; iy.display_height = plan.display_height;
 		iy.uyvy = out_kind_ == PIX_2VUY; iy.shift = plan.precision - 8; iy.dither_seed = 0x9E3779B9u * (uint32_t)(f + 1);
@@ -1397,7 +1399,9 @@ int GopBatch::launch_forward()
 	if (jobs_dirty_) { HIPCHK(hipMemcpyAsync(d_jobs_, h_jobs_, jobs_bytes_, hipMemcpyHostToDevice, st)); jobs_dirty_ = false; }
 	GopJobs j = gop_jobs_at(d_jobs_);
 	(void)hipGetLastError();
-	dev::k_fwd_yuv422<<<dim3((plan_.width / 2 + dev::TW - 1) / dev::TW, (plan_.height / 2 + dev::TH - 1) / dev::TH, 2), dev::NTHREADS, 0, st>>>(j.yuv);
+	// level 1 of both frames: the spatial transform, or -- interlaced groups -- the frame transform of interlaced intra frames (the two kernels share the job table)
+	if (plan_.interlaced) dev::k_fwd_frame_yuv422<<<dim3((plan_.width / 2 + dev::FTW - 1) / dev::FTW, (plan_.height / 2 + dev::FRW - 1) / dev::FRW, 2), dev::NTHREADS, 0, st>>>((const dev::FwdFrameJob *)j.yuv);
+	else dev::k_fwd_yuv422<<<dim3((plan_.width / 2 + dev::TW - 1) / dev::TW, (plan_.height / 2 + dev::TH - 1) / dev::TH, 2), dev::NTHREADS, 0, st>>>(j.yuv);
 	const GopWavelet &t = plan_.ch[0].w[2];
 	dev::k_gop_temporal_fwd<<<dim3((unsigned)((t.pitch * t.height / 2 + dev::NTHREADS - 1) / dev::NTHREADS), 3), dev::NTHREADS, 0, st>>>(j.temp);
 	dev::k_fwd_plane<<<dim3((t.width / 2 + dev::TW - 1) / dev::TW, (t.height / 2 + dev::TH - 1) / dev::TH, 6), dev::NTHREADS, 0, st>>>(j.mid);
@@ -1426,7 +1430,8 @@ int GopBatch::launch_inverse(uint32_t dither_seed, bool coeffs_on_device)
 	dev::k_inv_plane<<<dim3((top.width + dev::ITW - 1) / dev::ITW, (top.height + dev::ITH - 1) / dev::ITH, 3), dev::NTHREADS, 0, st>>>(j.itop);
 	dev::k_inv_plane<<<dim3((mid.width + dev::ITW - 1) / dev::ITW, (mid.height + dev::ITH - 1) / dev::ITH, 6), dev::NTHREADS, 0, st>>>(j.imid);
 	dev::k_gop_temporal_inv<<<dim3((unsigned)((t.pitch * t.height / 2 + dev::NTHREADS - 1) / dev::NTHREADS), 3), dev::NTHREADS, 0, st>>>(j.temp);
-	dev::k_inv_yuv422<<<dim3((l1.width + dev::ITW - 1) / dev::ITW, (l1.height + dev::ITH - 1) / dev::ITH, 2), dev::NTHREADS, 0, st>>>(j.iyuv, dither_seed);
+	if (plan_.interlaced) dev::k_inv_frame_yuv422<<<dim3((l1.width / 2 + dev::NTHREADS - 1) / dev::NTHREADS, l1.height, 2), dev::NTHREADS, 0, st>>>(j.iyuv, dither_seed);
+	else dev::k_inv_yuv422<<<dim3((l1.width + dev::ITW - 1) / dev::ITW, (l1.height + dev::ITH - 1) / dev::ITH, 2), dev::NTHREADS, 0, st>>>(j.iyuv, dither_seed);
 	HIPCHK(hipGetLastError());
 	return 0;
 }

@@ -33,7 +33,8 @@ public:
 	// peak table (encoder.c:4802); the GPU sample of such a frame is not valid, the caller writes it on the host from the coefficients.
 	// the next launch() / download() cover frames 0 .. k-1 of the batch (0 = all)
 	void set_active(int k) { active_ = k; }
-	bool needs_peak_table(int i) const { return plan_.interlaced && h_sizes_[n_ + i] != 0; }     // (the flags are only cleared and written for interlaced plans)
+	bool needs_peak_table(int i) const { return peak_flags_in_use() && h_sizes_[n_ + i] != 0; }     // (the flags are only cleared and written for interlaced plans)
+	bool peak_flags_in_use() const { return group_ ? gplan_.interlaced : plan_.interlaced; }
 	size_t sample_cap() const { return cap_; }
 	int total_segments() const { return total_segs_; }
 	// HIP-event time of kernel k of the last launch() (0 k_ent_count -- when the level-1 bands are counted on the second stream: the launches on the main stream

@@ -159,12 +159,12 @@ int GpuEntropyEncoder::launch()
 	};
 	split_ = ev_level1_ && stream2_ && !host_->jobs.ranges_l1.empty() && act >= 8;      // (a single frame gains nothing from six launches instead of one)
 	// the peak flags are raised by the difference-coded band only, a level-1 band: cleared on the stream that counts it
-	if (plan_.interlaced && !split_) HIPCHK(hipMemsetAsync(d_sizes_ + n_, 0, sizeof(uint32_t) * n_, st));
+	if (peak_flags_in_use() && !split_) HIPCHK(hipMemsetAsync(d_sizes_ + n_, 0, sizeof(uint32_t) * n_, st));
 	if (split_) {
 		// the level-1 bands on the second stream as soon as the level-1 transform is done; the bands of levels 2 and 3 here, behind their transforms; the scan waits for both
 		hipStream_t s2 = (hipStream_t)stream2_;
 		HIPCHK(hipStreamWaitEvent(s2, (hipEvent_t)ev_level1_, 0));
-		if (plan_.interlaced) HIPCHK(hipMemsetAsync(d_sizes_ + n_, 0, sizeof(uint32_t) * n_, s2));
+		if (peak_flags_in_use()) HIPCHK(hipMemsetAsync(d_sizes_ + n_, 0, sizeof(uint32_t) * n_, s2));
 		HIPCHK(hipEventRecord((hipEvent_t)ev2_[0], s2));
 		for (const auto &r : host_->jobs.ranges_l1) count_range(s2, r.first, r.second, true);
 		HIPCHK(hipEventRecord((hipEvent_t)ev2_[1], s2));

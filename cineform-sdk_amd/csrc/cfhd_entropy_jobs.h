@@ -259,7 +259,7 @@ inline std::vector<EntHoleGeom> ent_hole_geometry(const GopPlan &plan, const Sam
 	std::vector<EntHoleGeom> g;
 	for (const SampleTemplate::Hole &hole : t.holes) {
 		const GopWavelet &wv = plan.ch[hole.channel].w[hole.level];
-		g.push_back(EntHoleGeom{ wv.offset[hole.band], wv.width, wv.height, wv.pitch, 0, -1, hole.level < 2 });
+		g.push_back(EntHoleGeom{ wv.offset[hole.band], wv.width, wv.height, wv.pitch, gop_band_is_difference_coded(plan, hole.level, hole.band) ? 1 : 0, -1, hole.level < 2 });      // (code set 18: subbands 12 and 15 of an interlaced group)
 	}
 	return g;
 }

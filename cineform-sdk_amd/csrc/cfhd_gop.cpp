@@ -4,10 +4,11 @@
 
 namespace cfhd {
 
-void derive_gop_subband_divisors(FramePlan *plan, int quality, float framerate, QuantState *st, bool deal, int out[3][17]);   // cfhd_tables.cpp
+void derive_gop_subband_divisors(FramePlan *plan, int quality, bool progressive, float framerate, QuantState *st, bool deal, int out[3][17]);   // cfhd_tables.cpp
 
-bool build_gop_plan(GopPlan *plan, int width, int height, int pixel_kind)
+bool build_gop_plan(GopPlan *plan, int width, int height, int pixel_kind, bool interlaced)
 {
+	plan->interlaced = interlaced;
 	if (width <= 0 || height <= 0 || width > kMaxFrameDim || height > kMaxFrameDim) return false;
 	if (pixel_kind != PIX_YUY2 && pixel_kind != PIX_2VUY) return false;              // CFHD_ENCODING_FLAGS_YUV_2FRAME_GOP: "YUV 4:2:2 only" (CFHDTypes.h:254)
 	const int enc_height = (height + 7) & ~7;                                        // encoder.c:1569-1571
@@ -53,7 +54,7 @@ bool derive_gop_quantization(GopPlan *plan, int quality, QuantState *st, float f
 	FramePlan fp;
 	if (!build_frame_plan(&fp, plan->width, plan->display_height, plan->pixel_kind, ENC_YUV422)) return false;
 	int tabs[3][17];
-	derive_gop_subband_divisors(&fp, quality, framerate, st, deal, tabs);
+	derive_gop_subband_divisors(&fp, quality, !plan->interlaced, framerate, st, deal, tabs);
 	if (!deal) return true;
 	plan->midpoint_prequant = fp.midpoint_prequant;
 	const int mpq = plan->midpoint_prequant;
@@ -119,12 +120,29 @@ struct GroupHostSink {
 	void band(int c, int k, int b)
 	{
 		const GopWavelet &wv = plan.ch[c].w[k];
+		const int codebook = gop_band_is_difference_coded(plan, k, b) ? 2 : 1;
 		// "only compress up to 80% of the frame size" (encoder.c:8332): once the sample fills more than that of the caller's sample buffer, the remaining
 		// bands of the frame wavelets are coded as zeros (EncodeZeroBand encoder.c:6220: the same header, one run over the whole band)
 		if (k < 2 && zero_band) {
 			if (zeros.size() < (size_t)wv.pitch * wv.height) zeros.assign((size_t)wv.pitch * wv.height, 0);
-			vlc_encode_band(w, zeros.data(), wv.width, wv.height, wv.pitch, 1, wv.quant[b]);
-		} else vlc_encode_band(w, coeffs + wv.offset[b], wv.width, wv.height, wv.pitch, 1, wv.quant[b]);
+			vlc_encode_band(w, zeros.data(), wv.width, wv.height, wv.pitch, codebook, wv.quant[b]);
+		} else vlc_encode_band(w, coeffs + wv.offset[b], wv.width, wv.height, wv.pitch, codebook, wv.quant[b], collect_peaks ? &peaks : nullptr);
+	}
+	// the three optional tags in front of a peak-coded band's size chunk and the table behind the band (cfhd_bitstream.cpp HostSink: codec.c:1804-1809, encoder.c:6543)
+	std::vector<int16_t> peaks; size_t peak_tags_at = 0; bool collect_peaks = false;
+	void peak_tags() { peak_tags_at = w.bytes(); w.put_tag_opt(TAG_PEAK_TABLE_OFFSET_L, 0); w.put_tag_opt(TAG_PEAK_TABLE_OFFSET_H, 0); w.put_tag_opt(TAG_PEAK_LEVEL, 0); peaks.clear(); collect_peaks = true; }
+	void peak_table(int quant)
+	{
+		collect_peaks = false;
+		if (peaks.empty()) return;
+		const uint32_t offset = (uint32_t)(w.bytes() - peak_tags_at);
+		auto tagword = [](int tag, uint32_t value) { return ((uint32_t)(uint16_t)(int16_t)(-tag) << 16) | (value & 0xffffu); };
+		w.patch32(peak_tags_at, tagword(TAG_PEAK_TABLE_OFFSET_L, offset & 0xffffu));
+		w.patch32(peak_tags_at + 4, tagword(TAG_PEAK_TABLE_OFFSET_H, offset >> 16));
+		w.patch32(peak_tags_at + 8, tagword(TAG_PEAK_LEVEL, (uint32_t)(kPeakThreshold * quant)));
+		if (peaks.size() & 1) peaks.push_back(0);
+		w.put_tag_opt(TAG_PEAK_TABLE, (int)(peaks.size() / 2));
+		w.put_bytes(peaks.data(), peaks.size() * 2);
 	}
 	bool zero_band = false;
 	void frame_band_begins() { zero_band = (uint64_t)w.bytes() * 100 > (uint64_t)plan.sample_buffer_bytes * 80; }      // (asked in front of the band's header, as the reference does)
@@ -137,19 +155,23 @@ struct GroupTemplateSink : TemplateRecorder {
 	void raw16(int c, int k) { const GopWavelet &wv = plan.ch[c].w[k]; hole(0, c, k, 0, (((wv.width * wv.height * 2) + 3) / 4) * 4); }
 	void band(int c, int k, int b) { hole(1, c, k, b, 0); }
 	void frame_band_begins() {}          // (data dependent: the caller checks the finished sample against gop_sample_may_zero_bands())
+	// GPU entropy: the tags stay zero; a band that does need a peak table sends its group through the host writer (GpuEntropyEncoder::needs_peak_table)
+	void peak_tags() { tag_opt(TAG_PEAK_TABLE_OFFSET_L, 0); tag_opt(TAG_PEAK_TABLE_OFFSET_H, 0); tag_opt(TAG_PEAK_LEVEL, 0); }
+	void peak_table(int) {}
 };
 
-template <typename Sink> void put_band_header(Sink &w, int band, const GopWavelet &wv, int subband, int encoding)
+template <typename Sink> void put_band_header(Sink &w, int band, const GopWavelet &wv, int subband, int encoding, bool difference = false)
 {
 	w.tag(TAG_MARKER, MARK_BAND_START);
 	w.tag(TAG_BAND_NUMBER, band);
-	w.tag(TAG_BAND_CODING_FLAGS, 1);                     // code set 17, no difference coding (encoder.c:6120 SetCodingFlags for a progressive group)
+	w.tag(TAG_BAND_CODING_FLAGS, difference ? 2 + 16 : 1);      // code set 17, no difference coding (encoder.c:6120 SetCodingFlags for a progressive group); interlaced: subbands 12 / 15 in code set 18, difference coded
 	w.tag(TAG_BAND_WIDTH, wv.width);
 	w.tag(TAG_BAND_HEIGHT, wv.height);
 	w.tag(TAG_BAND_SUBBAND, subband);
 	w.tag(TAG_BAND_ENCODING, encoding);
 	w.tag(TAG_BAND_QUANTIZATION, wv.quant[band]);
 	w.tag(TAG_BAND_SCALE, wv.scale[band]);
+	if (difference) w.peak_tags();
 	w.push(TAG_SUBBAND_SIZE);
 	w.tag(TAG_BAND_HEADER, 0);
 }
@@ -284,11 +306,13 @@ template <typename Sink> void walk_group_sample(Sink &w, const GopPlan &plan, co
 			const GopWavelet &wv = ch.w[k];
 			put_wavelet_header(w, wv, k + 1);
 			for (int b = 1; b < 4; b++, subband++) {
+				const bool diff = gop_band_is_difference_coded(plan, k, b);
 				w.frame_band_begins();
-				put_band_header(w, b, wv, subband, 3);
+				put_band_header(w, b, wv, subband, 3, diff);
 				w.band(c, k, b);
 				w.tag(TAG_BAND_TRAILER, 0);
 				w.pop();
+				if (diff) w.peak_table(wv.quant[b]);
 			}
 			w.tag(TAG_MARKER, MARK_HIGHPASS_END);
 			w.pop();
@@ -356,6 +380,7 @@ int parse_group_sample(const uint8_t *d, size_t size, ParsedGroup *pg)
 	memset(pg->band, 0, sizeof(pg->band));
 	size_t pos = 0;
 	int channel = 0, wavelet = -1, band = 0, bw = 0, bh = 0, bq = 1, bflags = 0, bsub = 0, benc = 3, lw = 0, lh = 0;
+	size_t peak_base = 0; uint32_t peak_offset = 0; int peak_level = 0;
 	uint32_t pending = 0; size_t pending_at = 0;
 	bool first = true;
 	auto rd = [&](size_t o) { return ((uint32_t)d[o] << 24) | ((uint32_t)d[o + 1] << 16) | ((uint32_t)d[o + 2] << 8) | d[o + 3]; };
@@ -404,6 +429,10 @@ int parse_group_sample(const uint8_t *d, size_t size, ParsedGroup *pg)
 		case TAG_WAVELET_NUMBER: wavelet = value - 1; if (wavelet < 0 || wavelet >= kGopWavelets) return -5; break;
 		case TAG_BAND_NUMBER: band = value; if (band < 0 || band > 3) return -6; bflags = 0; benc = 3; break;
 		case TAG_BAND_CODING_FLAGS: bflags = value; break;
+		// peak table of the band that follows (interlaced groups: subbands 12 and 15): offset in bytes from the word behind the OFFSET_L tuple, level (decoder.c:23978-23993)
+		case TAG_PEAK_TABLE_OFFSET_L: peak_offset = (peak_offset & ~0xffffu) | (uint32_t)value; peak_base = pos; peak_level = 0; break;
+		case TAG_PEAK_TABLE_OFFSET_H: peak_offset = (peak_offset & 0xffffu) | ((uint32_t)value << 16); peak_level = 0; break;
+		case TAG_PEAK_LEVEL: peak_level = value; break;
 		case TAG_BAND_WIDTH: bw = value; break;
 		case TAG_BAND_HEIGHT: bh = value; break;
 		case TAG_BAND_SUBBAND: bsub = value; break;
@@ -417,7 +446,9 @@ int parse_group_sample(const uint8_t *d, size_t size, ParsedGroup *pg)
 			pb.offset = (uint32_t)pos; pb.bytes = (uint32_t)(end - 4 - pos);
 			pb.width = bw; pb.height = bh; pb.quant = bq; pb.subband = bsub; pb.present = true;
 			pb.codebook = benc == 4 ? -1 : (bflags & 0xf);      // -1: raw 16-bit words (BAND_ENCODING_16BIT)
-			pb.difference = (bflags & 0x10) != 0; pb.peak_level = 0; pb.peak_offset = 0;      // (difference-coded bands: interlaced groups, refused by the decoder)
+			pb.difference = (bflags & 0x10) != 0; pb.peak_level = peak_level; pb.peak_offset = peak_level ? (uint32_t)(peak_base + peak_offset) : 0u;      // (difference-coded bands: interlaced groups)
+			if (pb.peak_level && (size_t)pb.peak_offset + 2 > size) return -8;
+			peak_level = 0;
 			pos = end; pending = 0;
 			break; }
 		default: break;

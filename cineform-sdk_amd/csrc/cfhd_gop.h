@@ -30,14 +30,20 @@ struct GopPlan {
 	int width = 0, height = 0, display_height = 0;      // height rounded up to a multiple of 8 (encoder.c:1569)
 	int num_channels = 3, precision = 10, midpoint_prequant = 2;
 	int pixel_kind = PIX_YUY2;
+	// CFHD_ENCODING_FLAGS_YUV_INTERLACED on top of the group flag: level 1 of both frames is the frame transform of interlaced intra frames (Codec/encoder.c:2950-2979
+	// TransformForwardFrameYUV into w[0] / w[1]); everything above it is the same.  The horizontal-lowpass / temporal-highpass band of both frame wavelets (band 2:
+	// subbands 12 and 15) is difference coded in code set 18 with a peak table (encoder.c:6143-6154 SetCodingFlags), as subband 8 of an interlaced intra frame.
+	bool interlaced = false;
 	GopChannel ch[3];
 	size_t coeff_elems = 0;                  // int16 elements of one group's pyramid
 	size_t sample_buffer_bytes = 0;          // the reference's sample buffer (its BITSTREAM block length): the encoder stops coding the frame wavelets' bands at 80% of it
 	// the level-1 transforms run through the kernels of the intra path: two ordinary frame plans whose level-1 bands alias w[0] / w[1]
 };
 
+// the band of a frame wavelet that an interlaced group codes as differences along the row, in code set 18, with a peak table (subbands 12 and 15)
+inline bool gop_band_is_difference_coded(const GopPlan &plan, int wavelet, int band) { return plan.interlaced && wavelet < 2 && band == 2; }
 // false: geometry the group transform does not serve (the same rule as build_frame_plan: chroma must halve on whole pairs four times here)
-bool build_gop_plan(GopPlan *plan, int width, int height, int pixel_kind);
+bool build_gop_plan(GopPlan *plan, int width, int height, int pixel_kind, bool interlaced = false);
 // Quantizer tables of the group (QuantizationSetQuality quantize.c:186 + SetTransformQuantization :2865, :3480 + SetTransformScale wavelet.c:7142).
 // The reference runs the first on every CFHD_EncodeSample call and the second only on the call that opens a group (encoder.c:2880-2905), both with the size of
 // the last key sample -- the 40-byte sequence header counts as one (encoder.c:3414) -- in `st`: deal = true for the opening call (the tables are written into the

@@ -495,17 +495,17 @@ static void derive_subband_tables(FramePlan *plan, int quality, bool progressive
 // (cfhd_gop.cpp) the divisors of a progressive two-frame group, per channel and subband.  Every CFHD_EncodeSample call of a group runs QuantizationSetQuality
 // (encoder.c:2880: the FILMSCAN2/3 limiter moves with the size of the last key sample); only the call that opens a group (deal) also runs SetTransformQuantization
 // (encoder.c:2895-2905, group.count == 0: the bit-rate limiter, its rate = bits * fps / 2) and hands the divisors to the wavelets.
-void derive_gop_subband_divisors(FramePlan *plan, int quality, float framerate, QuantState *st, bool deal, int out[3][17])
+void derive_gop_subband_divisors(FramePlan *plan, int quality, bool progressive, float framerate, QuantState *st, bool deal, int out[3][17])
 {
 	int tabs[4][17], factor, newQuality;
-	derive_subband_tables(plan, quality, true, st, tabs, &factor, &newQuality);
+	derive_subband_tables(plan, quality, progressive, st, tabs, &factor, &newQuality);
 	if (!deal) return;
 	const int currentbitrate = bitrate_of_previous_sample(st, framerate, 2);
 	const bool limiter_on = bitrate_limiter_applies(factor, newQuality, plan->width, plan->height, plan->num_channels, plan->encoded_format);
 	if (st->overbitrate < 0 || st->overbitrate > 16) st->overbitrate = 0;
 	for (int c = 0; c < 3; c++) {
 		memcpy(out[c], tabs[c ? 1 : 0], sizeof(int) * 17);
-		if (limiter_on) limit_bitrate(factor, currentbitrate, true, c, st, out[c], tabs[c ? 3 : 2]);
+		if (limiter_on) limit_bitrate(factor, currentbitrate, progressive, c, st, out[c], tabs[c ? 3 : 2]);
 	}
 }
 

@@ -1208,11 +1208,12 @@ ENCODING_FLAGS_2FRAME_GOP = 2       # Common/CFHDTypes.h:254
 class GopPlan:
     """Python view of cfhd::GopPlan (six wavelets per channel) as the product derives it."""
 
-    def __init__(self, width, height, pixkind=1, quality=QUALITY_FILMSCAN1):
+    def __init__(self, width, height, pixkind=1, quality=QUALITY_FILMSCAN1, interlaced=0):
         L = hooks()
         L.cfhd_amd_gop_plan_info.argtypes = [ctypes.c_int] * 4 + [ctypes.POINTER(ctypes.c_longlong)]
         buf = (ctypes.c_longlong * 512)()
-        n = L.cfhd_amd_gop_plan_info(width, height, pixkind, quality, buf)
+        self.interlaced = int(bool(interlaced))            # CFHD_ENCODING_FLAGS_YUV_INTERLACED on top of the group flag: frame transform at level 1 of both frames
+        n = L.cfhd_amd_gop_plan_info(width, height, pixkind | (self.interlaced << 8), quality, buf)
         assert n > 0, "gop_plan_info failed"
         v = list(buf[:n])
         self.coeff_elems, self.enc_height, self.mpq = v[0:3]
@@ -1247,7 +1248,8 @@ def oracle_forward_gop(gp, frame0, frame1, pitch, uyvy=0):
             outs = [gp.view(coeffs, c, f, b) for b in range(4)]
             bands = (c_i16p * 4)(*[o.ctypes.data_as(c_i16p) for o in outs])
             cw = gp.width if c == 0 else gp.width // 2
-            O.orc_fwd_spatial_yuv422(p8(np.ascontiguousarray(frame)), pitch, cw, H, c, 2, uyvy, iarr(d["quant"]), gp.mpq, bands, d["pitch"])
+            # level 1: the spatial transform, or -- interlaced groups -- the frame transform of interlaced intra frames (Codec/encoder.c:2950-2979)
+            (O.orc_fwd_frame_yuv422 if gp.interlaced else O.orc_fwd_spatial_yuv422)(p8(np.ascontiguousarray(frame)), pitch, cw, H, c, 2, uyvy, iarr(d["quant"]), gp.mpq, bands, d["pitch"])
     def spatial(c, src, dst):
         d = gp.w[(c, dst)]
         outs = [gp.view(coeffs, c, dst, b) for b in range(4)]
@@ -1273,7 +1275,7 @@ def product_write_gop_host(gp, kind, coeffs=None, frame_number=1, meta_global=b"
     out = np.zeros(gp.width * gp.enc_height * 4 + 65536, dtype=np.uint8)
     mg = np.frombuffer(meta_global, dtype=np.uint8).copy() if meta_global else np.zeros(4, np.uint8)
     cf = coeffs if coeffs is not None else np.zeros(8, np.int16)
-    n = L.cfhd_amd_write_gop_host(kind, gp.width, gp.height, gp.pixkind, gp.quality, frame_number, p16(cf), p8(mg), len(meta_global), p8(out), out.size)
+    n = L.cfhd_amd_write_gop_host(kind, gp.width, gp.height, gp.pixkind | (gp.interlaced << 8), gp.quality, frame_number, p16(cf), p8(mg), len(meta_global), p8(out), out.size)
     assert n > 0
     return out[:n].tobytes()
 
@@ -1323,7 +1325,8 @@ def oracle_inverse_gop(gp, coeffs, dither, uyvy=0, reference_defect=True):
         pitches = [gp.w[(c, f)]["pitch"] for c in range(3)]
         w = gp.w[(0, f)]["width"]; h = gp.w[(0, f)]["height"]
         out = np.zeros((2 * h, 4 * w), np.uint8)
-        O.orc_inv_spatial_to_yuv422(ptrs, iarr(pitches), w, h, 10, uyvy, dither, p8(out), 4 * w)
+        # the last level: spatial synthesis, or -- interlaced groups -- the inverse frame transform of interlaced intra frames
+        (O.orc_inv_frame_to_yuv422 if gp.interlaced else O.orc_inv_spatial_to_yuv422)(ptrs, iarr(pitches), w, h, 10, uyvy, dither, p8(out), 4 * w)
         outs.append(out)
     return outs
 

@@ -38,7 +38,8 @@ int cfhd_amd_plan_info(int width, int height, int pixel_kind, int encoded_format
 int cfhd_amd_gop_plan_info(int width, int height, int pixel_kind, int quality, long long *out)
 {
 	GopPlan plan; QuantState st = {0, -1, 0};
-	if (!build_gop_plan(&plan, width, height, pixel_kind) || !derive_gop_quantization(&plan, quality, &st)) return -1;
+	const bool interlaced = (pixel_kind & 0x100) != 0; pixel_kind &= 0xff;      // (bit 8 of the pixel kind: CFHD_ENCODING_FLAGS_YUV_INTERLACED on top of the group flag)
+	if (!build_gop_plan(&plan, width, height, pixel_kind, interlaced) || !derive_gop_quantization(&plan, quality, &st)) return -1;
 	int n = 0;
 	out[n++] = (long long)plan.coeff_elems; out[n++] = plan.height; out[n++] = plan.midpoint_prequant;
 	for (int c = 0; c < 3; c++)
@@ -54,11 +55,12 @@ size_t cfhd_amd_write_gop_host(int kind, int width, int height, int pixel_kind, 
                                const uint8_t *meta_global, size_t meta_global_size, uint8_t *out, size_t cap)
 {
 	GopPlan plan; QuantState st = {0, -1, 0};
-	if (!build_gop_plan(&plan, width, height, pixel_kind) || !derive_gop_quantization(&plan, quality, &st)) return 0;
+	const bool interlaced = (pixel_kind & 0x100) != 0; pixel_kind &= 0xff;
+	if (!build_gop_plan(&plan, width, height, pixel_kind, interlaced) || !derive_gop_quantization(&plan, quality, &st)) return 0;
 	const int input_format = pixel_kind == PIX_2VUY ? 1 : 2;
 	if (kind == 1) return write_sequence_header(plan, input_format, out, cap);
 	if (kind == 2) return write_pframe_sample(plan, frame_number, out, cap);
-	SampleHeaderInfo hdr = { frame_number, input_format, 2, quality, true, meta_global, meta_global_size, nullptr, 0 };
+	SampleHeaderInfo hdr = { frame_number, input_format, 2, quality, !interlaced, meta_global, meta_global_size, nullptr, 0 };
 	return write_group_sample(plan, hdr, coeffs, out, cap);
 }
 
@@ -93,6 +95,8 @@ int cfhd_amd_decode_group_host(const uint8_t *sample, size_t size, int pixel_kin
 					for (int r = 0; r < wv.height; r++)
 						for (int x = 0; x < wv.width; x++) { const uint8_t *p = sample + pb.offset + ((size_t)r * wv.width + x) * 2; dst[(size_t)r * wv.pitch + x] = (int16_t)(((p[0] << 8) | p[1]) * pb.quant); }
 				} else if (vlc_decode_band(sample + pb.offset, pb.bytes, wv.width, wv.height, wv.pitch, pb.quant, pb.codebook, dst)) return -5;
+				// interlaced groups: peak values, then every row becomes its running sum (decoder.c:19809, :20822)
+				if (pb.difference) finish_difference_band(dst, wv.width, wv.height, wv.pitch, pb.peak_level ? sample + pb.peak_offset : nullptr, pb.peak_level ? size - pb.peak_offset : 0, pb.peak_level);
 			}
 		}
 	}

@@ -89,3 +89,69 @@ def test_group_inverse_model_equals_the_reference_group_decoder(w, h, fmt):
             else: lo_f = lo[f][:h]; b_f = better[f][:h]
             assert abs(psnr_yuy2(img, src) - psnr_yuy2(lo_f, src)) < 0.1
             assert psnr_yuy2(b_f, src) > psnr_yuy2(img, src) + 1.0
+
+
+def _interlaced_frames(w, h, n, fmt, flicker=False):
+    """Frames whose two fields disagree (the second field shifted sideways; `flicker`: field flicker strong enough for quantized field differences beyond the peak
+    threshold, i.e. peak tables behind the difference-coded bands)."""
+    out = []
+    for i in range(n):
+        f = (field_flicker_frame(w, h)[0] if flicker else synth_yuy2(w, h, 90 + i)[0]).reshape(h, w * 2).copy()
+        f[1::2] = np.roll(f[1::2], 4 + 2 * (i % 3), axis=1)
+        if flicker: f = np.clip(f.astype(np.int32) + np.random.default_rng(i).integers(-5, 6, f.shape), 0, 255).astype(np.uint8)
+        if fmt == PIX_2VUY: f = f.reshape(h, w, 2)[:, :, ::-1].reshape(h, w * 2)
+        out.append(np.ascontiguousarray(f).reshape(-1))
+    return out
+
+
+@pytest.mark.parametrize("w,h,fmt,flicker", [(320, 240, PIX_YUY2, 0), (720, 486, PIX_2VUY, 0), (336, 252, PIX_YUY2, 1), (400, 120, PIX_YUY2, 0), (1920, 1080, PIX_YUY2, 0), (720, 480, PIX_YUY2, 1)])
+def test_interlaced_group_samples_equal_reference(w, h, fmt, flicker):
+    """CFHD_ENCODING_FLAGS_YUV_INTERLACED | _2FRAME_GOP: level 1 of both frames is the frame transform of interlaced intra frames (Codec/encoder.c:2950-2979), the
+    horizontal-lowpass / temporal-highpass band of both frame wavelets -- subbands 12 and 15 -- is difference coded in code set 18 with a peak table where needed
+    (encoder.c:6143-6154), the quantizer tables are the interlaced ones (quantize.c:492).  Oracle transform + the product's host writer = the reference's samples."""
+    kind = 2 if fmt == PIX_2VUY else 1
+    frames = _interlaced_frames(w, h, 4, fmt, bool(flicker))
+    ref = ref_encode_frames(frames, w * 2, w, h, pixfmt=fmt, flags=ENCODING_FLAGS_2FRAME_GOP | 1)
+    gp = GopPlan(w, h, pixkind=kind, interlaced=1)
+    assert [len(s) for s in ref[0::2]] == [40, 24]
+    assert product_write_gop_host(gp, 1) == ref[0]
+    peaks = 0
+    for g in range(2):
+        s = ref[2 * g + 1]
+        co = oracle_forward_gop(gp, frames[2 * g], frames[2 * g + 1], w * 2, uyvy=int(fmt == PIX_2VUY))
+        off, n = first_metadata_chunk(s)
+        mine = product_write_gop_host(gp, 0, co, 2 * g + 1, meta_global=s[off:off + n])
+        assert len(mine) == len(s), (len(mine), len(s))
+        assert mine == s, "group %d differs at byte %d" % (g, next(i for i in range(len(s)) if mine[i] != s[i]))
+        peaks += sum(int.from_bytes(s[i + 2:i + 4], "big") != 0 for i in range(0, len(s) - 4, 4) if s[i:i + 2] == b"\xff\xb6")      # TAG_PEAK_LEVEL (optional)
+    if flicker: assert peaks, "the flicker frames were expected to carry peak tables"
+
+
+@pytest.mark.parametrize("w,h,fmt,flicker", [(320, 240, PIX_YUY2, 0), (336, 252, PIX_YUY2, 1), (720, 480, PIX_2VUY, 0), (1920, 1080, PIX_YUY2, 0)])
+def test_interlaced_group_inverse_model_equals_the_reference_group_decoder(w, h, fmt, flicker):
+    """The same pin for interlaced groups: reference samples -> host parser / decoder (code set 18, peak tables, running sums along the rows of subbands 12 and 15)
+    -> the group's inverse with the inverse FRAME transform as its last level -- every byte of both frames the reference's group decoder returns lies inside the
+    oracle's dither interval, and the PSNR agrees to 0.1 dB."""
+    kind = 2 if fmt == PIX_2VUY else 1
+    frames = _interlaced_frames(w, h, 4 if w < 1920 else 2, fmt, bool(flicker))
+    samples = ref_encode_frames(frames, w * 2, w, h, pixfmt=fmt, flags=ENCODING_FLAGS_2FRAME_GOP | 1)
+    gp = GopPlan(w, h, pixkind=kind, interlaced=1)
+    ngroups = len(frames) // 2
+    models = []
+    for g in range(ngroups):
+        co = host_decode_group(samples[2 * g + 1], gp)
+        models.append((oracle_inverse_gop(gp, co, 0, uyvy=int(kind == 2)), oracle_inverse_gop(gp, co, 1, uyvy=int(kind == 2))))
+    def outside(got):
+        return [(g, f, int((~((img == models[g][0][f][:h]) | (img == models[g][1][f][:h]))).sum())) for g, pair in enumerate(got) for f, img in enumerate(pair) if img is not None]
+    for attempt in range(3):
+        got = ref_decode_group_frames(samples, w, h, fmt)
+        assert len(got) == ngroups
+        if not any(n for _, _, n in outside(got)): break
+    for g, f, n in outside(got): assert n == 0, "group %d frame %d: %d bytes of the reference decoder's picture lie outside the oracle's dither interval" % (g, f, n)
+    for g, pair in enumerate(got):
+        for f, img in enumerate(pair):
+            if img is None: continue
+            src = frames[2 * g + f].reshape(h, w * 2); lo_f = models[g][0][f][:h]; hi_f = models[g][1][f][:h]
+            if kind == 2: sw = lambda a: a.reshape(-1, 2)[:, ::-1].reshape(h, w * 2); src, img, lo_f, hi_f = sw(src), sw(img), sw(lo_f), sw(hi_f)
+            ends = (psnr_yuy2(lo_f, src), psnr_yuy2(hi_f, src))      # any picture inside the interval lies between its two ends (to the printed 0.1 dB)
+            assert min(ends) - 0.1 < psnr_yuy2(img, src) < max(ends) + 0.1
