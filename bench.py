@@ -428,6 +428,10 @@ def measure(workload, steps, warmup, batch, unique, threads, rank, world, barrie
                        **({"kernel_ms_one_step_at_a_time": {k: round(v, 4) for k, v in kms.items()}} if kms_alone else {})},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source, "launch_ms": round(ms, 4),
+                         # `achieved` is ALGORITHMIC bytes per launch / launch time (what an ideal implementation must move); what the kernel really moved
+                         # through HBM -- less, where the level-1 bands travel as block lists -- is the PMC traffic over the same launch time:
+                         "hbm_gbs_from_pmc_traffic": round(traffic / (ms * 1e-3) / 1e9, 1) if traffic else None,
+                         "hbm_frac_from_pmc_traffic": round(traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                          "launch_ms_measured": ("HIP events around the launch, average over the %d timed steps" % steps) if not kms_alone else
                                                ("HIP events around the launch, average over 3 passes run one at a time right behind the timed region (inside it %d steps are in flight and share the GPU: "
                                                 "this kernel's event time there is %.4f ms)" % (depth, kms_run.get(dom, 0.0))),
