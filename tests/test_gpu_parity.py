@@ -332,7 +332,8 @@ def test_gpu_entropy_and_host_entropy_paths_agree():
         assert mask_volatile_metadata(x) == mask_volatile_metadata(y)
 
 
-@pytest.mark.parametrize("handoff,decoder", [("device", "dx"), ("host", "dx"), ("device", "dx-repair"), ("device", "par"), ("host", "par"), ("host", "lane")])
+@pytest.mark.parametrize("handoff,decoder", [("device", "dx"), ("host", "dx"), ("device", "dx-repair"), ("device", "par"), ("host", "par"), ("host", "lane"),
+                                             ("device", "emit"), ("host", "emit"), ("device", "emit-repair")])      # emit: the single-pass arrangement of round 5 (k_dec_index_emit + k_dec_scatter)
 def test_batched_device_resident_round_trip(handoff, decoder):
     """cfhd_amd_batch_* (what bench.py times): several chunks on their own streams; every sample must equal oracle transform +
     product syntax, every decoded frame must lie in the oracle's dither interval of its own sample.  handoff=device: the decoder
@@ -352,7 +353,7 @@ def test_batched_device_resident_round_trip(handoff, decoder):
     os.environ["CFHD_AMD_CHUNK"] = "2"
     os.environ["CFHD_AMD_HANDOFF"] = handoff
     os.environ["CFHD_AMD_DEC"] = decoder.split("-")[0]
-    if decoder == "dx-repair": os.environ["CFHD_AMD_DX_SPECULATE"] = "0"      # every chunk assumes a wrong start: k_dec_chain repairs them all
+    if decoder.endswith("-repair"): os.environ["CFHD_AMD_DX_SPECULATE"] = "0"      # every chunk assumes a wrong start: k_dec_chain repairs them all
     try:
         _batched_round_trip_body(L, w, h, n, frames)
     finally:

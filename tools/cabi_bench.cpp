@@ -98,16 +98,18 @@ int main(int argc, char **argv)
 			CFHD_ReleaseSampleBuffer(pool, sb);
 			return true;
 		};
-		const double t0 = now();
-		while (now() - t0 < seconds || sent < 4 * workers) {
+		// throughput, not set-up: the clock starts when the first 4 * workers frames are through (pool creation, the workers' first launches and allocations lie in front of it)
+		double t0 = now(); long sent0 = 0; bool warm = false;
+		while (now() - t0 < seconds || !warm) {
 			CHECK(CFHD_EncodeAsyncSample(pool, (uint32_t)sent, frames[sent % nfr].data(), pitch, nullptr));
 			sent++;
 			while (collect(false)) got++;
+			if (!warm && got >= 4 * workers) { warm = true; t0 = now(); sent0 = sent; }
 		}
+		const long sent1 = sent; const double dt = now() - t0;
 		while (got < sent) if (collect(true)) got++;
-		const double dt = now() - t0;
 		CFHD_ReleaseEncoderPool(pool);
-		return sent / dt;
+		return (sent1 - sent0) / dt;
 	};
 	const double pool_enc = pool_run(false);
 	std::atomic<long> decoded(0);
@@ -128,11 +130,20 @@ int main(int argc, char **argv)
 		}
 		CFHD_CloseDecoder(dec); drop_output(out);
 	});
-	const double t0 = now();
+	// (likewise: frames decoded per second from the moment the first 4 * handles frames have come out of the decoders to the moment the pool stops submitting)
+	std::atomic<bool> rt_done(false);
+	double rt_t0 = 0, rt_t1 = 0; long rt_n0 = 0, rt_n1 = 0;
+	std::thread watcher([&] {
+		while (decoded < 4 * handles && !rt_done) std::this_thread::sleep_for(std::chrono::microseconds(200));
+		rt_t0 = now(); rt_n0 = decoded;
+	});
 	pool_run(true);
+	rt_t1 = now(); rt_n1 = decoded;
+	rt_done = true;
 	{ std::lock_guard<std::mutex> lk(Q.m); Q.closed = true; Q.cv.notify_all(); }
 	for (auto &t : th) t.join();
-	const double round_trip = decoded / (now() - t0);
+	watcher.join();
+	const double round_trip = rt_t1 > rt_t0 && rt_n1 > rt_n0 ? (rt_n1 - rt_n0) / (rt_t1 - rt_t0) : 0.0;
 	if (registered) for (auto &fr : frames) cfhd_amd_unregister_host_buffer(fr.data());
 	printf("{\"sync_encode_fps\": %.1f, \"sync_decode_fps\": %.1f, \"decode_fps_%d_handles\": %.1f, \"pool_encode_fps_%d_workers\": %.1f, \"round_trip_fps_pool%d_plus_%d_decoders\": %.1f}\n",
 	       sync_enc, sync_dec, handles, multi_dec, workers, pool_enc, workers, handles, round_trip);
