@@ -172,7 +172,7 @@ size_t sample_capacity(const EncodeParams &p) { return (size_t)p.width * p.heigh
 // Where the run-length/VLC stage runs: on the GPU by default; CFHD_AMD_ENTROPY=host keeps the reference's arrangement
 // (host threads fed by one D2H copy of the quantized bands).  Both produce the same bytes.
 bool gpu_entropy_enabled() { const char *e = getenv("CFHD_AMD_ENTROPY"); return !(e && strcmp(e, "host") == 0); }
-// CFHD_AMD_ENTROPY=device: (tests) a sample the device stage hands back to the host coder fails the call instead -- proves which stage served a group
+// CFHD_AMD_ENTROPY=device: (tests) a sample the device stage hands back to the host coder fails the call instead -- proves which stage served a frame or a group
 bool gpu_entropy_strict() { const char *e = getenv("CFHD_AMD_ENTROPY"); return e && strcmp(e, "device") == 0; }
 
 // one caller waiting for one frame: its plain buffers are staged in pieces (cfhd_device.hip upload_frame / download_frame); CFHD_AMD_STAGE_PIECES=1 switches that off
@@ -242,8 +242,9 @@ int encode_one(EncodeBatch &batch, EncodeParams &p, const void *frame, int pitch
 			p.qstate.lastgopbitcount = (int64_t)n * 8;
 			return ERR_OKAY;
 		}
-		// an interlaced frame whose field-difference band needs a peak table (values beyond +-250, rare): the table sits in front of the
-		// band and changes its coding, so this sample is written by the host writer from the same GPU coefficients
+		// an interlaced frame whose field-difference band has more peak values than the entropy stage's positions hold (two million, GpuEntropyEncoder::needs_peak_table):
+		// this sample is written by the host writer from the same GPU coefficients
+		if (gpu_entropy_strict()) return ERR_INTERNAL;
 		return host_write();
 	}
 	if ((rc = batch.launch_forward())) return ERR_INTERNAL;
@@ -345,7 +346,7 @@ struct EncodeService : Gatherer<EncodeBatch> {
 			if (!rc) rc = x.batch.entropy().launch();
 			if (!rc) rc = x.batch.entropy().download();
 			if (!rc) rc = x.batch.wait(); else (void)x.batch.wait();
-			for (int i = 0; i < n && !rc; i++) if (!x.batch.entropy().sample_bytes(i) || x.batch.entropy().needs_peak_table(i)) rc = 1;   // overflow / peak table: every caller takes its own path
+			for (int i = 0; i < n && !rc; i++) if (!x.batch.entropy().sample_bytes(i) || x.batch.entropy().needs_peak_table(i)) rc = 1;   // overflow / more peak values than the stage places: every caller takes its own path
 			return rc;
 		};
 		start_workers();
@@ -714,7 +715,7 @@ CFHD_Error CFHD_EncodeSample(CFHD_EncoderRef ref, void *frame, int pitch)
 			if (e->gop_batch.has_entropy() && e->gop_batch.entropy().set_frame_header(0, hdr) == 0) {
 				if (e->gop_batch.entropy().launch() || e->gop_batch.entropy().download() || e->gop_batch.wait()) return ERR_INTERNAL;
 				const size_t nb = e->gop_batch.entropy().sample_bytes(0);
-				// (an interlaced group whose difference-coded bands hold values beyond the peak threshold needs peak tables: the host writer's, as for interlaced intra frames)
+				// (an interlaced group with more peak values in a difference-coded band than the entropy stage's positions hold: the host writer's, as for interlaced intra frames)
 				if (nb && nb <= e->sample.size() && !gop_sample_may_zero_bands(e->params.gplan, nb) && !e->gop_batch.entropy().needs_peak_table(0)) { memcpy(e->sample.data(), e->gop_batch.entropy().host_sample(0), nb); bytes = nb; }
 			}
 			if (!bytes) {

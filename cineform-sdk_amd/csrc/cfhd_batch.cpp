@@ -98,7 +98,7 @@ long long batch_finish(cfhd_amd_batch *b)
 	if (c->enc.entropy().download_finish() || c->enc.wait()) return -2;
 	for (int l = 0; l < c->n; l++) {
 		size_t n = c->enc.entropy().sample_bytes(l); if (!n) return -3; b->sample_size[c->first + l] = n;
-		if (c->enc.entropy().needs_peak_table(l)) return -8;      // an interlaced frame with field differences beyond +-250 steps: only CFHD_EncodeSample writes those (host writer)
+		if (c->enc.entropy().needs_peak_table(l)) return -8;      // a band with more peak values than the entropy stage's positions hold (two million): only CFHD_EncodeSample writes such a sample (host writer)
 	}
 	const double t_enc = now();
 	if (b->decode) { if (c->dec.wait()) return -5; if (c->dec.entropy().check()) return -7; }
@@ -227,7 +227,7 @@ static long long cfhd_amd_batch_roundtrip_locked(cfhd_amd_batch *b)
 			if (c->enc.entropy().download() || c->enc.wait()) return fail(-2);
 			for (int l = 0; l < c->n; l++) {
 				size_t n = c->enc.entropy().sample_bytes(l); if (!n) return fail(-3); b->sample_size[c->first + l] = n;
-				if (c->enc.entropy().needs_peak_table(l)) return fail(-8);      // an interlaced frame with field differences beyond +-250 steps: only CFHD_EncodeSample writes those (host writer)
+				if (c->enc.entropy().needs_peak_table(l)) return fail(-8);      // a band with more peak values than the entropy stage's positions hold (two million): only CFHD_EncodeSample writes such a sample (host writer)
 			}
 			t_enc[k] = now();
 			if (b->decode) { if (c->dec.wait()) return fail(-5); if (c->dec.entropy().check()) return fail(-7); }

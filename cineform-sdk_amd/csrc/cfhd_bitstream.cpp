@@ -172,9 +172,6 @@ struct TemplateSink : TemplateRecorder {
 	explicit TemplateSink(SampleTemplate &tt) : TemplateRecorder(tt) {}
 	void lowpass(int c) { const BandDesc &ll = t.plan.ch[c].band[2][0]; hole(0, c, 2, 0, (((ll.width * ll.height * 2) + 3) / 4) * 4); }
 	void band(int c, int lv, int bnd, int, int) { hole(1, c, lv, bnd, 0); }
-	// GPU entropy: the tags stay zero; a band that does need a peak table sends its frame through the host writer (see GpuEntropyEncoder)
-	void peak_tags() { tag_opt(TAG_PEAK_TABLE_OFFSET_L, 0); tag_opt(TAG_PEAK_TABLE_OFFSET_H, 0); tag_opt(TAG_PEAK_LEVEL, 0); }
-	void peak_table(int) {}
 };
 
 template <typename Sink>

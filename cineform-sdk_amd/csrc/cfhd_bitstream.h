@@ -78,9 +78,10 @@ struct BandSource {
 // inserts payloads (holes: raw lowpass words, entropy coded bands) and the size fields that depend on the payload sizes.
 // A template byte at offset x preceded by h holes ends up at x + (sum of the sizes of the first h holes) in the sample.
 struct SampleTemplate {
-	struct Hole { int tmpl_offset; int kind /*0 = lowpass raw, 1 = coded band*/; int channel, level, band; int fixed_bytes; };
+	struct Hole { int tmpl_offset; int kind /*0 = lowpass raw, 1 = coded band, 2 = peak table of the coded band in front of it (empty when the band has no peaks; fixed_bytes: the band's divisor)*/; int channel, level, band; int fixed_bytes; };
 	struct Patch {          // kind 0: 24/16-bit chunk size at (at_tmpl, at_holes), chunk ends at (end_tmpl, end_holes)
 		int kind;           // kind 1: 32-bit big-endian byte count end - start written at at_tmpl (channel index entry)
+		                    // kind 2: the three peak tags at (at_tmpl, at_holes) of the table in hole start_holes, which begins at (end_tmpl, end_holes); tag: the band's divisor.  Left zero when the hole is empty.
 		int at_tmpl, at_holes, start_tmpl, start_holes, end_tmpl, end_holes, tag;
 	};
 	FramePlan plan;
@@ -117,6 +118,17 @@ struct TemplateRecorder {
 		t.patches.push_back(p);
 	}
 	void hole(int kind, int c, int lv, int bnd, int fixed) { SampleTemplate::Hole h = { (int)b.size(), kind, c, lv, bnd, fixed }; t.holes.push_back(h); holes++; }
+	// The peak table of a difference-coded band (codec.c:1804-1809, encoder.c:6543-6585): three optional tags in front of the band's size chunk, zero while the band has
+	// no values beyond the threshold, and behind the band trailer the table chunk -- a hole that stays empty for such a band.  The device fills both (k_ent_layout, k_ent_peaks).
+	int peak_at_tmpl = 0, peak_at_holes = 0;
+	void peak_tags() { peak_at_tmpl = (int)b.size(); peak_at_holes = holes; tag_opt(TAG_PEAK_TABLE_OFFSET_L, 0); tag_opt(TAG_PEAK_TABLE_OFFSET_H, 0); tag_opt(TAG_PEAK_LEVEL, 0); }
+	void peak_table(int quant)
+	{
+		const SampleTemplate::Hole band = t.holes.back();       // (the coded band the table belongs to)
+		SampleTemplate::Patch p; p.kind = 2; p.at_tmpl = peak_at_tmpl; p.at_holes = peak_at_holes; p.start_tmpl = 0; p.start_holes = holes; p.end_tmpl = (int)b.size(); p.end_holes = holes; p.tag = quant;
+		t.patches.push_back(p);
+		hole(2, band.channel, band.level, band.band, quant);
+	}
 };
 
 // Writes a complete intra-frame sample.  Returns the sample size in bytes, or 0 on overflow.

@@ -29,11 +29,12 @@ public:
 	const uint8_t *host_sample(int i) const { return h_samples_ + h_offsets_[i]; }   // after download() + stream wait
 	uint8_t *device_sample(int i) { return d_samples_ + (size_t)i * cap_; }
 	uint32_t sample_bytes(int i) const { return h_sizes_[i]; }
-	// Interlaced frames: true when frame i's difference-coded band holds values beyond the peak threshold, i.e. the reference appends a
-	// peak table (encoder.c:4802); the GPU sample of such a frame is not valid, the caller writes it on the host from the coefficients.
 	// the next launch() / download() cover frames 0 .. k-1 of the batch (0 = all)
 	void set_active(int k) { active_ = k; }
-	bool needs_peak_table(int i) const { return peak_flags_in_use() && h_sizes_[n_ + i] != 0; }     // (the flags are only cleared and written for interlaced plans)
+	// Interlaced frames and groups: the difference-coded bands are coded with peaks (encoder.c:4802) and their tables written on the device (k_ent_peaks).
+	// needs_peak_table(i): a band of sample i has more peaks than the device's positions hold (2 million): that sample is not valid, the caller writes it on the host.
+	bool needs_peak_table(int i) const { return peak_flags_in_use() && (h_sizes_[n_ + i] & 2u) != 0; }     // (the flags are only cleared and written for interlaced plans)
+	bool has_peak_table(int i) const { return peak_flags_in_use() && (h_sizes_[n_ + i] & 1u) != 0; }       // statistics / tests: the sample carries a peak table written on the device
 	bool peak_flags_in_use() const { return group_ ? gplan_.interlaced : plan_.interlaced; }
 	size_t sample_cap() const { return cap_; }
 	int total_segments() const { return total_segs_; }
@@ -145,7 +146,8 @@ private:
 
 // Group samples (cfhd_gop.h): parsed on the host (parse_group_sample), every coded band of the 17 subbands per channel decoded by one workgroup of
 // k_dec_bands_par_ll (the flat job list of the round-1 decoder: a single group is a latency problem, not a throughput one), the two raw 16-bit bands of a channel
-// by k_dec_lowpass.  The dequantized pyramid is left in HBM for GopBatch::launch_inverse.
+// by k_dec_lowpass.  Interlaced groups: the two difference-coded bands of a channel through the same kernel with the tables of code set 18, then k_dec_undiff
+// (peak values, running sums along the rows: decoder.c:19809, :20822).  The dequantized pyramid is left in HBM for GopBatch::launch_inverse.
 class GpuGroupEntropyDecoder {
 public:
 	GpuGroupEntropyDecoder() {}
@@ -160,6 +162,7 @@ private:
 	int16_t *d_coeffs_ = nullptr;
 	uint8_t *d_sample_ = nullptr, *h_sample_ = nullptr;
 	void *d_tables_ = nullptr, *d_bandjobs_ = nullptr, *d_lowjobs_ = nullptr, *h_bandjobs_ = nullptr, *h_lowjobs_ = nullptr;
+	void *d_tables18_ = nullptr, *d_diffjobs_ = nullptr, *h_diffjobs_ = nullptr;      // interlaced groups: code set 18, the difference-coded bands (subbands 12 and 15 of every channel)
 	int *d_errors_ = nullptr, *h_errors_ = nullptr;
 };
 

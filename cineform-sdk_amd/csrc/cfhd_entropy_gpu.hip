@@ -123,7 +123,7 @@ int GpuEntropyEncoder::set_frame_header(int f, const SampleHeaderInfo &hdr)
 	SampleTemplate &t = tmpl_[f];
 	build_template(hdr, &t);
 	if (!ent_fill_frame_block(host_->geom, t, f, host_->jobs, d_coeffs_ + (size_t)f * coeff_stride_, h_tmpl_ + (size_t)kEntTmplStride * f)) return -4;
-	host_->frames[f] = ent_frame_job(t, d_tmpl_ + (size_t)kEntTmplStride * f, d_samples_ + cap_ * f, (uint32_t)cap_, d_sizes_ + f);
+	host_->frames[f] = ent_frame_job(t, d_tmpl_ + (size_t)kEntTmplStride * f, d_samples_ + cap_ * f, (uint32_t)cap_, d_sizes_ + f, d_sizes_ + n_ + f);
 	dirty_ = true;
 	return 0;
 }
@@ -183,6 +183,13 @@ int GpuEntropyEncoder::launch()
 	dev::k_ent_layout<<<dim3((unsigned)act, layout_parts), dev::ENT_THREADS, 0, st>>>((const dev::EntFrameJob *)d_frames_, (const dev::EntBandJob *)d_bands_, (dev::EntSegState *)d_segs_,
 	                                                  (dev::EntBandState *)d_bandstate_, T);
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[3], st));
+	// the values of the peak tables (interlaced plans: the difference-coded bands; a wave looks at a segment's record and leaves unless the segment has peaks)
+	{
+		dev::EntPeakHoles which; which.n = 0;
+		for (size_t h = 0; h < tmpl_[0].holes.size() && which.n < 7; h++) if (tmpl_[0].holes[h].kind == 2) which.hole[which.n++] = (int)h;
+		if (which.n) dev::k_ent_peaks<<<dim3(act >= 64 ? 4u : 32u, (unsigned)which.n, (unsigned)act), dev::ENT_THREADS, 0, st>>>((const dev::EntFrameJob *)d_frames_, which, (const dev::EntBandJob *)d_bands_,
+		                                                  (const dev::EntSegJob *)d_segband_, geom, (const dev::EntSegState *)d_segs_, (const dev::EntBandState *)d_bandstate_);
+	}
 #ifdef CFHD_AMD_PROBES
 	const int emit_probe = []{ const char *e = getenv("CFHD_AMD_EMIT_PROBE"); return e ? atoi(e) : 0; }();
 #else
@@ -640,14 +647,14 @@ float GpuEntropyDecoder::kernel_ms(int k)
 void GpuGroupEntropyDecoder::release()
 {
 	(void)hipSetDevice(device_);
-	void *dev[] = { d_sample_, d_tables_, d_bandjobs_, d_lowjobs_, d_errors_ };
+	void *dev[] = { d_sample_, d_tables_, d_tables18_, d_bandjobs_, d_lowjobs_, d_diffjobs_, d_errors_ };
 	for (void *p : dev) if (p) (void)hipFree(p);
-	void *host[] = { h_sample_, h_bandjobs_, h_lowjobs_, h_errors_ };
+	void *host[] = { h_sample_, h_bandjobs_, h_lowjobs_, h_diffjobs_, h_errors_ };
 	for (void *p : host) if (p) (void)hipHostFree(p);
-	d_sample_ = h_sample_ = nullptr; d_tables_ = d_bandjobs_ = d_lowjobs_ = h_bandjobs_ = h_lowjobs_ = nullptr; d_errors_ = h_errors_ = nullptr;
+	d_sample_ = h_sample_ = nullptr; d_tables_ = d_tables18_ = d_bandjobs_ = d_lowjobs_ = d_diffjobs_ = h_bandjobs_ = h_lowjobs_ = h_diffjobs_ = nullptr; d_errors_ = h_errors_ = nullptr;
 }
 
-enum { kGroupBandJobs = 3 * 15, kGroupRawJobs = 3 * 2 };
+enum { kGroupBandJobs = 3 * 15, kGroupRawJobs = 3 * 2, kGroupDiffJobs = 3 * 2 };
 
 int GpuGroupEntropyDecoder::prepare(const GopPlan &plan, int16_t *d_coeffs, size_t sample_cap, int out_kind, void *stream, int device)
 {
@@ -659,6 +666,11 @@ int GpuGroupEntropyDecoder::prepare(const GopPlan &plan, int16_t *d_coeffs, size
 	std::vector<uint32_t> t = build_dec_tables(1);
 	HIPCHK(hipMalloc(&d_tables_, t.size() * 4));
 	HIPCHK(hipMemcpy(d_tables_, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+	t = build_dec_tables(2);
+	HIPCHK(hipMalloc(&d_tables18_, t.size() * 4));
+	HIPCHK(hipMemcpy(d_tables18_, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+	HIPCHK(hipMalloc(&d_diffjobs_, kGroupDiffJobs * sizeof(dev::DecDiffJob)));
+	HIPCHK(hipHostMalloc(&h_diffjobs_, kGroupDiffJobs * sizeof(dev::DecDiffJob), hipHostMallocPortable));
 	HIPCHK(hipMalloc((void **)&d_sample_, cap_));
 	HIPCHK(hipHostMalloc((void **)&h_sample_, cap_, hipHostMallocPortable));
 	HIPCHK(hipMalloc(&d_bandjobs_, kGroupBandJobs * sizeof(dev::DecBandJob)));
@@ -677,8 +689,8 @@ int GpuGroupEntropyDecoder::launch(const uint8_t *sample, size_t size, const Par
 	hipStream_t st = (hipStream_t)stream_;
 	if (size > cap_) return -1;
 	HIPCHK(hipStreamSynchronize(st));                                       // the pinned sample / tables of the previous launch may still be in flight
-	dev::DecBandJob *bj = (dev::DecBandJob *)h_bandjobs_; dev::DecLowpassJob *lj = (dev::DecLowpassJob *)h_lowjobs_;
-	int nb = 0, nl = 0;
+	dev::DecBandJob *bj = (dev::DecBandJob *)h_bandjobs_; dev::DecLowpassJob *lj = (dev::DecLowpassJob *)h_lowjobs_; dev::DecDiffJob *dj = (dev::DecDiffJob *)h_diffjobs_;
+	int nb = 0, nl = 0, nd = 0;
 	for (int c = 0; c < 3; c++) {
 		const GopChannel &ch = plan_.ch[c];
 		const ParsedBand &lp = pg.lowpass[c];
@@ -697,20 +709,34 @@ int GpuGroupEntropyDecoder::launch(const uint8_t *sample, size_t size, const Par
 					lj[nl++] = dev::DecLowpassJob{ d_sample_ + pb.offset, d_coeffs_ + wv.offset[0], wv.width, wv.height, wv.pitch, 0 };
 					continue;
 				}
-				if (pb.codebook != 1 || (wv.offset[b] & 7) || (wv.pitch & 7)) return -3;
-				bj[nb++] = dev::DecBandJob{ d_sample_ + pb.offset, pb.bytes, d_coeffs_ + wv.offset[b], wv.height * wv.pitch, pb.quant, 0u, 0 };
+				// the difference-coded bands of an interlaced group (band 2 of the two frame wavelets: subbands 12 and 15) come in code set 18, maybe with a peak table
+				const bool diff = gop_band_is_difference_coded(plan_, k, b);
+				if (pb.codebook != (diff ? 2 : 1) || pb.difference != diff || (wv.offset[b] & 7) || (wv.pitch & 7)) return -3;
+				if (diff) {
+					if (nd >= kGroupDiffJobs || wv.width > 16 * 256 || (pb.peak_level && (size_t)pb.peak_offset + 2 > size)) return -3;      // (k_dec_undiff: rows of up to DXU_MAX x DXU_THREADS coefficients)
+					dj[nd++] = dev::DecDiffJob{ d_coeffs_ + wv.offset[b], wv.width, wv.height, wv.pitch, pb.peak_level ? d_sample_ + pb.peak_offset : nullptr,
+					                            pb.peak_level ? (uint32_t)(size - pb.peak_offset) : 0u, pb.peak_level };
+				}
+				bj[nb++] = dev::DecBandJob{ d_sample_ + pb.offset, pb.bytes, d_coeffs_ + wv.offset[b], wv.height * wv.pitch, pb.quant, 0u, diff ? 1 : 0 };
 			}
 		}
 	}
-	if (nb != kGroupBandJobs || nl != kGroupRawJobs) return -2;
-	std::stable_sort(bj, bj + nb, [](const dev::DecBandJob &a, const dev::DecBandJob &b) { return a.bytes > b.bytes; });      // the long bands start first
+	if (nb != kGroupBandJobs || nl != kGroupRawJobs || nd != (plan_.interlaced ? kGroupDiffJobs : 0)) return -2;
+	// the bands of code set 17 in front, those of code set 18 behind them (one launch each: the kernel reads one set of tables); in either part the long bands start first
+	std::stable_sort(bj, bj + nb, [](const dev::DecBandJob &a, const dev::DecBandJob &b) { return a.table != b.table ? a.table < b.table : a.bytes > b.bytes; });
+	const int nb18 = nd, nb17 = nb - nb18;
 	memcpy(h_sample_, sample, size);
 	HIPCHK(hipMemsetAsync(d_errors_, 0, sizeof(int), st));
 	HIPCHK(hipMemcpyAsync(d_sample_, h_sample_, (size + 3) & ~(size_t)3, hipMemcpyHostToDevice, st));
 	HIPCHK(hipMemcpyAsync(d_bandjobs_, bj, nb * sizeof(dev::DecBandJob), hipMemcpyHostToDevice, st));
 	HIPCHK(hipMemcpyAsync(d_lowjobs_, lj, nl * sizeof(dev::DecLowpassJob), hipMemcpyHostToDevice, st));
 	(void)hipGetLastError();
-	dev::k_dec_bands_par_ll<<<nb, dev::DECP_LL_THREADS, 0, st>>>((const dev::DecBandJob *)d_bandjobs_, (const dev::DecTables *)d_tables_, d_errors_);
+	dev::k_dec_bands_par_ll<<<nb17, dev::DECP_LL_THREADS, 0, st>>>((const dev::DecBandJob *)d_bandjobs_, (const dev::DecTables *)d_tables_, d_errors_);
+	if (nb18) {
+		HIPCHK(hipMemcpyAsync(d_diffjobs_, dj, nd * sizeof(dev::DecDiffJob), hipMemcpyHostToDevice, st));
+		dev::k_dec_bands_par_ll<<<nb18, dev::DECP_LL_THREADS, 0, st>>>((const dev::DecBandJob *)d_bandjobs_ + nb17, (const dev::DecTables *)d_tables18_, d_errors_);
+		dev::k_dec_undiff<<<dim3((unsigned)nd, dev::DXU_SPLIT), dev::DXU_THREADS, 0, st>>>((const dev::DecDiffJob *)d_diffjobs_, d_errors_, 0);
+	}
 	dev::k_dec_lowpass<<<dim3(8, (unsigned)nl), 256, 0, st>>>((const dev::DecLowpassJob *)d_lowjobs_);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipMemcpyAsync(h_errors_, d_errors_, sizeof(int), hipMemcpyDeviceToHost, st));

@@ -315,7 +315,9 @@ inline bool ent_fill_frame_block(const std::vector<EntHoleGeom> &geom, const Sam
 		const EntHoleGeom &bd = geom[i];
 		dev::EntHole &d = eh[i];
 		d.tmpl_offset = src.tmpl_offset; d.kind = src.kind; d.fixed_bytes = src.fixed_bytes;
-		d.band_job = src.kind == 1 ? jobs.band_of_hole[i] + f * jobs.nbands : -1;
+		// (a peak table belongs to the coded band in front of it)
+		d.band_job = src.kind == 1 ? jobs.band_of_hole[i] + f * jobs.nbands : (src.kind == 2 && i > 0 && t.holes[i - 1].kind == 1 ? jobs.band_of_hole[i - 1] + f * jobs.nbands : -1);
+		if (src.kind == 2 && d.band_job < 0) return false;
 		d.lowpass = src.kind == 0 ? coeffs_f + bd.offset : nullptr;
 		d.lp_width = bd.width; d.lp_height = bd.height; d.lp_pitch = bd.pitch;
 	}
@@ -333,7 +335,7 @@ inline bool ent_fill_frame_block(const FramePlan &plan, const SampleTemplate &t,
 }
 
 // Frame job whose pointers refer to `block_addr` (the device -- or, under emulation, host -- address of the serialised block).
-inline dev::EntFrameJob ent_frame_job(const SampleTemplate &t, uint8_t *block_addr, uint8_t *out, uint32_t out_cap, uint32_t *size_out)
+inline dev::EntFrameJob ent_frame_job(const SampleTemplate &t, uint8_t *block_addr, uint8_t *out, uint32_t out_cap, uint32_t *size_out, uint32_t *peak_flag)
 {
 	dev::EntFrameJob fj;
 	fj.out = out; fj.out_cap = out_cap;
@@ -341,7 +343,7 @@ inline dev::EntFrameJob ent_frame_job(const SampleTemplate &t, uint8_t *block_ad
 	fj.word_holes = block_addr + kEntTmplBytes;
 	fj.holes = (const dev::EntHole *)(block_addr + kEntTmplBytes + kEntWordHolesBytes); fj.nholes = (int)t.holes.size();
 	fj.patches = (const dev::EntPatch *)(block_addr + kEntTmplBytes + kEntWordHolesBytes + kEntHolesBytes); fj.npatches = (int)t.patches.size();
-	fj.sample_bytes = size_out;
+	fj.sample_bytes = size_out; fj.peak_flag = peak_flag;
 	return fj;
 }
 

@@ -97,11 +97,13 @@ struct EntSegState {               // per segment, written by k_ent_count / k_en
 	// payload lies (k_ent_layout; null while the sample is not placed or overflowed its buffer) and bit 0: a segment of the same band precedes,
 	// bit 1: one follows, bits 8..: the band's entropy table (k_ent_count).  One 64-byte record per segment, three scalar loads per emitting wave.
 	uint8_t *out;
-	uint32_t info, reserved;
+	uint32_t info;
+	uint32_t peaks;                // a band coded with table 1: k_ent_count: values of the segment beyond the peak threshold (up to ENT_SEG); k_ent_scan: that count << ENT_PEAK_OFF_BITS | those of the band's earlier segments
 };
 static_assert(sizeof(EntSegState) == 64, "one segment state per 64 bytes");
 
-struct EntBandState { uint32_t seg_bits, tail_run, payload_bytes, base_byte; uint8_t *out; /* payload address in the sample; null until k_ent_layout placed it */ };
+struct EntBandState { uint32_t seg_bits, tail_run, payload_bytes, base_byte; uint8_t *out; /* payload address in the sample; null until k_ent_layout placed it */
+                      uint32_t npeaks, pad; uint8_t *peak_out; /* a band coded with table 1: values beyond the peak threshold (k_ent_scan), where its table's values go (k_ent_layout; null: no table) */ };
 
 struct EntHole { int tmpl_offset, kind, fixed_bytes, band_job; const int16_t *lowpass; int lp_width, lp_height, lp_pitch; };
 struct EntPatch { int kind, at_tmpl, at_holes, start_tmpl, start_holes, end_tmpl, end_holes, tag; };
@@ -113,6 +115,7 @@ struct EntFrameJob {
 	const EntHole *holes; int nholes;          // holes[] is per frame (band_job / lowpass pointers)
 	const EntPatch *patches; int npatches;
 	uint32_t *sample_bytes;                    // out: size of the finished sample (0 on overflow)
+	uint32_t *peak_flag;                       // the frame's word of peak_flags[] (see ENT_PEAK_THRESHOLD)
 };
 
 __device__ __forceinline__ uint32_t bswap32(uint32_t v) { return (v >> 24) | ((v >> 8) & 0xff00u) | ((v << 8) & 0xff0000u) | (v << 24); }
@@ -183,9 +186,13 @@ __device__ __forceinline__ EntSegJob ent_seg_job(const EntSegJob *seg_jobs, cons
 	return job;
 }
 
-// peak_flags[frame] is raised when a band coded with table 1 holds a coefficient beyond +-ENT_PEAK_THRESHOLD: the reference then appends a
-// peak table (encoder.c:4802, :6543), which this stage does not produce -- the caller sends that frame through the host writer.
-enum { ENT_PEAK_THRESHOLD = 250 };
+// A band coded with table 1 (difference coded) is coded with peaks (EncodeQuantLongRunsPlusPeaks, encoder.c:4802): a coefficient beyond +-ENT_PEAK_THRESHOLD goes
+// into the stream as +-(threshold + 1) and its value x divisor into the peak table behind the band (encoder.c:6543-6585), in raster order.  k_ent_count codes the
+// clamped value and counts the peaks of its segment, k_ent_scan turns the counts into positions, k_ent_layout sizes the table's hole, writes its chunk header and the
+// three tags in front of the band, k_ent_peaks fills the values in.  peak_flags[frame]: bit 0 raised when the frame has a peak at all (statistics), bit 1 when a band
+// has more of them than the positions hold (ENT_PEAK_MAX: the caller writes that sample on the host).
+enum { ENT_PEAK_THRESHOLD = 250, ENT_PEAK_OFF_BITS = 21, ENT_PEAK_MAX = (1 << ENT_PEAK_OFF_BITS) - 1 };
+static_assert(ENT_SEG < (1 << (32 - ENT_PEAK_OFF_BITS)), "a segment's peak count and its position in the band's table share a word");
 // The finished bit string of every token (nonzero coefficient) of every segment is kept in `tokens` (ENT_TOK_STRIDE words per segment, the first
 // 2 * ntok used): k_ent_emit places those -- a third of the bytes -- instead of reading, compacting and coding the coefficients a second time.
 // The coefficients of one segment as lane L of the wave holds them: dwords j * 64 + L (coalesced 4-byte loads), zero beyond the band.
@@ -243,7 +250,7 @@ __device__ __forceinline__ void ent_count_tokens(int seg, const EntSegJob &job, 
 	const EntTables *T = tables + job.table;
 	uint32_t bits = 0, lead32 = 0, lead_valid = 0;
 	if (CFHD_PROBE(probe) == 2) { const unsigned long long q = __ballot(s_tok[lane] == 0x12345u); if (lane == 0) { EntSegState &z = segs[seg]; z.first_nz = -1; z.last_nz = -1; z.bits = q == 0x123456789ull && ntok == 0x12345; z.ntok = 0; z.lead32 = 0; z.lead_valid = 0; } return; }
-	bool peak = false;
+	uint32_t npeaks = 0;                                 // wave-uniform
 	for (int t0 = 0; t0 < ntok; t0 += ENT_LANES) {       // wave-uniform
 		const int t = t0 + lane;
 		const bool have = t < ntok;
@@ -252,8 +259,10 @@ __device__ __forceinline__ void ent_count_tokens(int seg, const EntSegJob &job, 
 		// zero run in front of the token, inside the segment (< 1024); the run in front of the segment's first token reaches into
 		// the earlier segments and is added by k_ent_scan
 		const uint32_t run = (have && t > 0) ? (tok >> 16) - (before >> 16) - 1u : 0u;
-		const int value = (int)(int16_t)(tok & 0xffffu);
-		peak |= value > ENT_PEAK_THRESHOLD || value < -ENT_PEAK_THRESHOLD;
+		int value = (int)(int16_t)(tok & 0xffffu);
+		const bool is_peak = job.table && (value > ENT_PEAK_THRESHOLD || value < -ENT_PEAK_THRESHOLD);
+		if (is_peak) value = value > 0 ? ENT_PEAK_THRESHOLD + 1 : -ENT_PEAK_THRESHOLD - 1;
+		npeaks += (uint32_t)__popcll(__ballot(is_peak));
 		const uint32_t ve = value_entry(T, value);
 		const uint32_t rt = T->run_total[run];
 		const uint2 rp = T->run_pack[run];
@@ -267,7 +276,7 @@ __device__ __forceinline__ void ent_count_tokens(int seg, const EntSegJob &job, 
 			const bool simple = (run == 0u || (rp.y >> 8) == run) && rs + vs <= (uint32_t)ENT_STR_BITS;
 			const uint32_t str = simple ? (((run ? rp.x : 0u) << vs) | vc) << (32u - rs - vs) : 0u;      // (rs + vs >= 2: a value code has at least its sign)
 			const uint32_t len = simple ? rs + vs : (uint32_t)ENT_CODE_COMPLEX;
-			const uint32_t rec = simple ? str | len : (run << 22) | ((tok & 0xffffu) << 6) | len;
+			const uint32_t rec = simple ? str | len : (run << 22) | (((uint32_t)value & 0xffffu) << 6) | len;
 			if (CFHD_PROBE(probe) != 4) seg_out[t] = rec;
 			my_top = str; my_len = len;
 		}
@@ -286,8 +295,7 @@ __device__ __forceinline__ void ent_count_tokens(int seg, const EntSegJob &job, 
 			lead_valid = known < 32u ? known : 32u;
 		}
 	}
-	// raised when a band coded with table 1 holds a coefficient beyond the peak threshold (see above)
-	if (job.table && __ballot(peak) && lane == 0) atomic_or_u32(&peak_flags[frame], 1u);
+	if (npeaks && lane == 0) atomic_or_u32(&peak_flags[frame], 1u);
 	bits = wave_get(wave_incl_scan(bits), ENT_LANES - 1);
 	if (lane == 0) {
 		EntSegState &s = segs[seg];
@@ -298,6 +306,7 @@ __device__ __forceinline__ void ent_count_tokens(int seg, const EntSegJob &job, 
 		s.lead32 = lead32; s.lead_valid = lead_valid;
 		s.out = nullptr;
 		s.info = (job.first != 0 ? 1u : 0u) | (job.first + ENT_SEG < job.n ? 2u : 0u) | ((uint32_t)job.table << 8);
+		s.peaks = npeaks;
 	}
 }
 
@@ -403,13 +412,13 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_scan(const EntBandJob *band
 	__shared__ int s_scan[ENT_THREADS];
 	const EntBandJob &job = bands[blockIdx.x];
 	const EntTables *T = tables + job.table;
-	int carry_prev = -1; uint32_t carry_bits = 0;
+	int carry_prev = -1; uint32_t carry_bits = 0, carry_peaks = 0;
 	for (int c0 = 0; c0 < job.nseg; c0 += ENT_THREADS * ENT_SCAN_PER) {
 		const int i0 = c0 + (int)threadIdx.x * ENT_SCAN_PER;
 		EntSegState s[ENT_SCAN_PER];
 #pragma unroll
 		for (int k = 0; k < ENT_SCAN_PER; k++) {
-			s[k].first_nz = -1; s[k].last_nz = -1; s[k].bits = 0; s[k].lead32 = 0; s[k].lead_valid = 0;
+			s[k].first_nz = -1; s[k].last_nz = -1; s[k].bits = 0; s[k].lead32 = 0; s[k].lead_valid = 0; s[k].peaks = 0;
 			if (i0 + k < job.nseg) s[k] = segs[job.seg_base + i0 + k];
 		}
 		int mine = -1;
@@ -444,14 +453,24 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_scan(const EntBandJob *band
 		}
 		int chunk_bits;
 		uint32_t off = carry_bits + (uint32_t)block_excl_sum((int)total, s_scan, &chunk_bits);
+		// a band coded with peaks (uniform): where each segment's peak values go in the band's table
+		uint32_t pk_off = 0; int chunk_peaks = 0;
+		if (job.table) {
+			uint32_t mine_pk = 0;
+#pragma unroll
+			for (int k = 0; k < ENT_SCAN_PER; k++) mine_pk += s[k].peaks;
+			pk_off = carry_peaks + (uint32_t)block_excl_sum((int)mine_pk, s_scan, &chunk_peaks);
+		}
 #pragma unroll
 		for (int k = 0; k < ENT_SCAN_PER; k++) {
 			if (i0 + k < job.nseg) {
 				EntSegState &o = segs[job.seg_base + i0 + k];
 				o.prev_nz = prevs[k]; o.bits = bits[k]; o.bitoff = off; o.run_code = rcode[k]; o.run_size = rsize[k]; o.run_bits = rbits[k]; o.lead32 = s[k].lead32; o.lead_valid = s[k].lead_valid;
+				if (job.table) o.peaks = (s[k].peaks << ENT_PEAK_OFF_BITS) | (pk_off < (uint32_t)ENT_PEAK_MAX ? pk_off : (uint32_t)ENT_PEAK_MAX);
 			}
-			off += bits[k];
+			off += bits[k]; pk_off += s[k].peaks;
 		}
+		carry_peaks += (uint32_t)chunk_peaks;
 		if (chunk_last > carry_prev) carry_prev = chunk_last;
 		carry_bits += (uint32_t)chunk_bits;
 	}
@@ -462,6 +481,7 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_scan(const EntBandJob *band
 		uint32_t bits = carry_bits + run_bits_any(T, b.tail_run) + (uint32_t)T->band_end_size;
 		b.payload_bytes = ((bits + 31u) >> 5) << 2;
 		b.base_byte = 0; b.out = nullptr;
+		b.npeaks = carry_peaks; b.pad = 0; b.peak_out = nullptr;
 	}
 }
 
@@ -492,7 +512,17 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_layout(const EntFrameJob *f
 	if (tid < 64) {
 		// one wave: every lane fetches the size of one hole (the loads overlap), two prefix sums over the lanes
 		uint32_t bytes = 0;
-		if (tid < f.nholes) { const EntHole &hole = f.holes[tid]; bytes = hole.kind == 0 ? (uint32_t)hole.fixed_bytes : band_state[hole.band_job].payload_bytes; }
+		if (tid < f.nholes) {
+			const EntHole &hole = f.holes[tid];
+			if (hole.kind == 0) bytes = (uint32_t)hole.fixed_bytes;
+			else if (hole.kind == 1) bytes = band_state[hole.band_job].payload_bytes;
+			else {
+				// the peak table of the band in front: chunk header + 16-bit values padded to a whole longword (encoder.c:6543-6585); nothing without peaks
+				const uint32_t np = band_state[hole.band_job].npeaks;
+				bytes = np ? 4u + 4u * ((np + 1u) >> 1) : 0u;
+				if (np > (uint32_t)ENT_PEAK_MAX && part == 0) atomic_or_u32(f.peak_flag, 2u);      // (more peaks than k_ent_scan's positions hold: the host writes this sample)
+			}
+		}
 		const uint32_t pieces = tid < f.nholes ? (bytes / ENT_FILL ? bytes / ENT_FILL : 1u) : 0u;
 		const uint32_t cum = wave_incl_scan(bytes), pc = wave_incl_scan(pieces);
 		if (tid <= f.nholes && tid <= ENT_MAX_HOLES) { s_cum[tid] = cum - bytes; s_piece[tid] = pc - pieces; }
@@ -516,6 +546,14 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_layout(const EntFrameJob *f
 			if (tag & 0x2000) { tag |= (int)((size >> 16) & 0xff); size &= 0xffff; } else size &= 0xffff;
 			tag = -tag;
 			out[at >> 2] = bswap32(((uint32_t)(uint16_t)tag << 16) | size);
+		} else if (p.kind == 2) {
+			// the three optional tags in front of a band coded with peaks: distance to its table, threshold x divisor (encoder.c:6543-6585); they stay zero without a table
+			if (s_cum[p.start_holes + 1] != s_cum[p.start_holes]) {
+				const uint32_t offset = end - at;
+				out[at >> 2] = bswap32(((uint32_t)(uint16_t)(-75) << 16) | (offset & 0xffffu));                  // TAG_PEAK_TABLE_OFFSET_L
+				out[(at >> 2) + 1] = bswap32(((uint32_t)(uint16_t)(-76) << 16) | (offset >> 16));                // TAG_PEAK_TABLE_OFFSET_H
+				out[(at >> 2) + 2] = bswap32(((uint32_t)(uint16_t)(-74) << 16) | ((uint32_t)(ENT_PEAK_THRESHOLD * p.tag) & 0xffffu));      // TAG_PEAK_LEVEL
+			}
 		} else {
 			const uint32_t start = (uint32_t)p.start_tmpl + s_cum[p.start_holes];
 			out[at >> 2] = bswap32(end - start);
@@ -545,6 +583,13 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_layout(const EntFrameJob *f
 				}
 				out[(base >> 2) + i] = bswap32(w);
 			}
+			continue;
+		}
+		if (hole.kind == 2) {
+			// peak table: the chunk header (optional tag 0x4001 with the number of longwords that follow), zeros where k_ent_peaks puts the values
+			const uint32_t np = band_state[hole.band_job].npeaks;
+			for (uint32_t i = w0 + tid; i < w1; i += ENT_THREADS) out[(base >> 2) + i] = i == 0 ? bswap32(((uint32_t)(uint16_t)(-0x4001) << 16) | (((np + 1u) >> 1) & 0xffffu)) : 0u;
+			if (k == 0 && tid == 0) band_state[hole.band_job].peak_out = bytes ? f.out + base + 4 : nullptr;
 			continue;
 		}
 		// coded band: k_ent_emit ORs its code words into zeroed words.  Everything from the word that holds the first bit of the trailer
@@ -770,6 +815,44 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(int total_segs, const 
 		}
 }
 
+
+// =============================================================================================
+// The values of the peak tables (bands coded with table 1 only; launched for interlaced plans).  One workgroup row per band job and frame; a wave per segment that has
+// peaks: the segment's coefficients as k_ent_count holds them (dwords j * 64 + lane: raster order is j, lane, low / high half -- the order of a ballot), each peak's
+// value x divisor as a 16-bit word in host order at the position k_ent_scan gave the segment (encoder.c:4860-4890: the PIXEL product, low 16 bits).
+// grid: (parts, peak tables per sample, frames); which.hole[y]: the y-th table's hole in every frame's template (band job and divisor are the frame's own).
+struct EntPeakHoles { int n; int hole[7]; };
+__global__ void __launch_bounds__(ENT_THREADS) k_ent_peaks(const EntFrameJob *frames, EntPeakHoles which, const EntBandJob *bands, const EntSegJob *seg_jobs, EntBatchGeom geom,
+                                                            const EntSegState *segs, const EntBandState *band_state)
+{
+	const EntHole &hole = frames[blockIdx.z].holes[which.hole[blockIdx.y]];
+	const int bj = hole.band_job, quant = hole.fixed_bytes;
+	const EntBandState bs = band_state[bj];
+	if (!bs.npeaks || !bs.peak_out || bs.npeaks > (uint32_t)ENT_PEAK_MAX) return;       // uniform: the common case leaves here
+	const EntBandJob band = bands[bj];
+	int16_t *table = (int16_t *)bs.peak_out;
+	const int lane = wave_lane();
+	const int wave = wave_uniform((int)(threadIdx.x >> 6));
+	for (int sg = (int)blockIdx.x * ENT_WAVES + wave; sg < band.nseg; sg += (int)gridDim.x * ENT_WAVES) {      // wave-uniform
+		const uint32_t pk = segs[band.seg_base + sg].peaks;
+		if (!(pk >> ENT_PEAK_OFF_BITS)) continue;
+		int frame;
+		const EntSegJob job = ent_seg_job(seg_jobs, geom, band.seg_base + sg, &frame);
+		uint32_t w[ENT_SEG / 128];
+		ent_load_segment(job, lane, w);
+		uint32_t at = pk & (uint32_t)ENT_PEAK_MAX;
+#pragma unroll
+		for (int j = 0; j < ENT_SEG / 128; j++) {
+			const int vl = (int)(int16_t)(w[j] & 0xffffu), vh = (int)(int16_t)(w[j] >> 16);
+			const bool pl = vl > ENT_PEAK_THRESHOLD || vl < -ENT_PEAK_THRESHOLD, ph = vh > ENT_PEAK_THRESHOLD || vh < -ENT_PEAK_THRESHOLD;
+			const unsigned long long ml = __ballot(pl), mh = __ballot(ph);
+			const uint32_t mine = at + wave_mbcnt(ml) + wave_mbcnt(mh);
+			if (pl) table[mine] = (int16_t)(vl * quant);
+			if (ph) table[mine + (pl ? 1u : 0u)] = (int16_t)(vh * quant);
+			at += (uint32_t)(__popcll(ml) + __popcll(mh));
+		}
+	}
+}
 
 // =============================================================================================
 // The finished samples sit in fixed-stride slots (sized for the worst case); the host wants them as bytes.  k_ent_pack_offsets

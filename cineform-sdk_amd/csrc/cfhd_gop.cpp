@@ -155,9 +155,6 @@ struct GroupTemplateSink : TemplateRecorder {
 	void raw16(int c, int k) { const GopWavelet &wv = plan.ch[c].w[k]; hole(0, c, k, 0, (((wv.width * wv.height * 2) + 3) / 4) * 4); }
 	void band(int c, int k, int b) { hole(1, c, k, b, 0); }
 	void frame_band_begins() {}          // (data dependent: the caller checks the finished sample against gop_sample_may_zero_bands())
-	// GPU entropy: the tags stay zero; a band that does need a peak table sends its group through the host writer (GpuEntropyEncoder::needs_peak_table)
-	void peak_tags() { tag_opt(TAG_PEAK_TABLE_OFFSET_L, 0); tag_opt(TAG_PEAK_TABLE_OFFSET_H, 0); tag_opt(TAG_PEAK_LEVEL, 0); }
-	void peak_table(int) {}
 };
 
 template <typename Sink> void put_band_header(Sink &w, int band, const GopWavelet &wv, int subband, int encoding, bool difference = false)

@@ -594,8 +594,8 @@ int emu_inv_plane_strip(int16_t **bands, int nplanes, int band_pitch, int w, int
 // ------------------------------------------------------------------------------------------------------------
 #include "cfhd_entropy_jobs.h"
 
-// interlaced != 0: the plan of a field-coded frame (code set 18 for the difference band); returns -100 when that band needs a peak table,
-// which the GPU stage only detects.
+// interlaced != 0: the plan of a field-coded frame (code set 18 for the difference band, coded with peaks: k_ent_peaks fills the table behind the band); returns -100
+// when a band has more peaks than the stage's positions hold.
 extern "C" long emu_entropy_encode2(int width, int height, int pixel_kind, int quality, unsigned frame_number, int16_t *coeffs /* product pyramid layout */,
                                     const uint8_t *meta, size_t meta_size, uint8_t *out, size_t cap, int interlaced)
 {
@@ -613,10 +613,10 @@ extern "C" long emu_entropy_encode2(int width, int height, int pixel_kind, int q
 	std::vector<uint8_t> block(kEntTmplStride, 0);
 	if (!ent_fill_frame_block(plan, t, 0, jobs, coeffs, block.data())) return -3;
 	uint32_t size = 0;
-	dev::EntFrameJob fj = ent_frame_job(t, block.data(), out, (uint32_t)cap, &size);
+	uint32_t peak_flag = 0;
+	dev::EntFrameJob fj = ent_frame_job(t, block.data(), out, (uint32_t)cap, &size, &peak_flag);
 	static dev::EntTables tables[2]; static bool ready = false;
 	if (!ready) { ent_build_tables(&tables[0], 1); ent_build_tables(&tables[1], 2); ready = true; }
-	uint32_t peak_flag = 0;
 	std::vector<dev::EntSegState> segs(jobs.segjobs.size());
 	std::vector<dev::EntBandState> bstate(jobs.bands.size());
 	const int nseg = (int)jobs.segjobs.size(), nb = (int)jobs.bands.size();
@@ -625,8 +625,13 @@ extern "C" long emu_entropy_encode2(int width, int height, int pixel_kind, int q
 	hipemu::launch(dim3((nseg + dev::ENT_WAVES * dev::ENT_COUNT_SEGS - 1) / (dev::ENT_WAVES * dev::ENT_COUNT_SEGS)), dim3(dev::ENT_THREADS), [&] { dev::k_ent_count(jobs.segjobs.data(), geom, nseg, segs.data(), tables, &peak_flag, tokens.data(), 0, nseg); });
 	hipemu::launch(dim3(nb), dim3(dev::ENT_THREADS), [&] { dev::k_ent_scan(jobs.bands.data(), segs.data(), bstate.data(), tables); });
 	hipemu::launch(dim3(1, 3), dim3(dev::ENT_THREADS), [&] { dev::k_ent_layout(&fj, jobs.bands.data(), segs.data(), bstate.data(), tables); });
+	{
+		dev::EntPeakHoles which; which.n = 0;
+		for (size_t h = 0; h < t.holes.size() && which.n < 7; h++) if (t.holes[h].kind == 2) which.hole[which.n++] = (int)h;
+		if (which.n) hipemu::launch(dim3(2, (unsigned)which.n, 1), dim3(dev::ENT_THREADS), [&] { dev::k_ent_peaks(&fj, which, jobs.bands.data(), jobs.segjobs.data(), geom, segs.data(), bstate.data()); });
+	}
 	hipemu::launch(dim3((nseg + dev::ENT_WAVES * dev::ENT_EMIT_SEGS - 1) / (dev::ENT_WAVES * dev::ENT_EMIT_SEGS)), dim3(dev::ENT_THREADS), [&] { dev::k_ent_emit(nseg, segs.data(), tables, tokens.data()); });
-	return peak_flag ? -100 : (long)size;
+	return (peak_flag & 2u) ? -100 : (long)size;
 }
 
 extern "C" long emu_entropy_encode(int width, int height, int pixel_kind, int quality, unsigned frame_number, int16_t *coeffs, const uint8_t *meta, size_t meta_size,

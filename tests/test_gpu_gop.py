@@ -2,7 +2,7 @@
 the reference encoder's samples byte for byte (sequence header, groups, P-frame headers); CFHD_DecodeSample decodes the reference's group
 samples to pictures inside the dither interval of the exact reconstruction (the oracle's inverse model, which tests/test_gop.py pins on the reference's own group
 decoder)."""
-import ctypes
+import ctypes, os
 import numpy as np
 import pytest
 from cfhd_testlib import *
@@ -127,11 +127,17 @@ def _interlaced_frames(w, h, n, fmt, flicker=False):
 @pytest.mark.parametrize("w,h,fmt,flicker", [(320, 240, PIX_YUY2, 0), (336, 252, PIX_YUY2, 1), (720, 486, PIX_2VUY, 0), (1920, 1080, PIX_YUY2, 0)])
 def test_interlaced_gop_encode_bitstream_identical(w, h, fmt, flicker):
     """CFHD_ENCODING_FLAGS_YUV_INTERLACED | _2FRAME_GOP (round 5): frame transform at level 1 of both frames (k_fwd_frame_yuv422 on the group's job table), subbands 12
-    and 15 difference coded in code set 18 on the GPU entropy stage; a group whose difference bands need peak tables (the flicker frames) comes from the host writer.
-    Byte for byte the reference's samples."""
+    and 15 difference coded in code set 18 with peaks on the GPU entropy stage -- the flicker frames carry peak tables, written on the device as well (k_ent_peaks;
+    CFHD_AMD_ENTROPY=device makes a sample handed to the host writer fail the call).  Byte for byte the reference's samples."""
     assert have_ref(), "oracle/_ref/libcfhd_ref.so is missing"
     frames = _interlaced_frames(w, h, 4, fmt, bool(flicker))
-    mine = amd_encode_frames(frames, w * 2, w, h, fmt, flags=ENCODING_FLAGS_2FRAME_GOP | 1)
+    old = os.environ.get("CFHD_AMD_ENTROPY")
+    os.environ["CFHD_AMD_ENTROPY"] = "device"
+    try:
+        mine = amd_encode_frames(frames, w * 2, w, h, fmt, flags=ENCODING_FLAGS_2FRAME_GOP | 1)
+    finally:
+        if old is None: os.environ.pop("CFHD_AMD_ENTROPY")
+        else: os.environ["CFHD_AMD_ENTROPY"] = old
     refs = ref_encode_frames(frames, w * 2, w, h, pixfmt=fmt, flags=ENCODING_FLAGS_2FRAME_GOP | 1)
     assert [len(s) for s in mine] == [len(s) for s in refs]
     for i, (a, b) in enumerate(zip(mine, refs)):
@@ -141,8 +147,9 @@ def test_interlaced_gop_encode_bitstream_identical(w, h, fmt, flicker):
 @pytest.mark.parametrize("w,h,fmt,flicker", [(320, 240, PIX_YUY2, 0), (336, 252, PIX_YUY2, 1), (720, 480, PIX_2VUY, 0), (1920, 1080, PIX_YUY2, 0)])
 def test_interlaced_gop_decode_reference_samples(w, h, fmt, flicker):
     """A reference-encoded group of interlaced frames carries no SAMPLE_FLAGS tag: `progressive` stays at the reference's default 0 (codec.c:263, decoder.c:13397).
-    Round 4 refused such samples (CFHD_ERROR_BADFORMAT, zero-filled picture); now they decode: difference-coded bands through the host coder (code set 18, peak
-    tables, running sums), the group's inverse on the GPU with the inverse frame transform as its last level.  Gate: the oracle's group inverse, which
+    Round 4 refused such samples (CFHD_ERROR_BADFORMAT, zero-filled picture); now they decode on the device: the difference-coded bands with the tables of code set 18,
+    k_dec_undiff for peak values and running sums (CFHD_AMD_ENTROPY=device: a sample handed to the host coder fails the call), the group's inverse with the inverse
+    frame transform as its last level.  Gate: the oracle's group inverse, which
     tests/test_gop.py pins on the reference's own group decoder byte for byte inside the dither interval; the reference decoder runs beside it as a witness."""
     assert have_ref(), "oracle/_ref/libcfhd_ref.so is missing"
     kind = 2 if fmt == PIX_2VUY else 1
@@ -156,10 +163,16 @@ def test_interlaced_gop_decode_reference_samples(w, h, fmt, flicker):
     assert L.CFHD_PrepareToDecode(dec, 0, 0, fmt, 1, 0, sb, min(512, len(samples[1])), ctypes.byref(aw), ctypes.byref(ah), ctypes.byref(af)) == 0
     H = ah.value
     outs = []
-    for s in samples[1:]:
-        sb = ctypes.create_string_buffer(s, len(s)); out = np.full(w * 2 * H, 7, np.uint8)
-        assert L.CFHD_DecodeSample(dec, sb, len(s), out.ctypes.data_as(ctypes.c_void_p), w * 2) == 0, amd_last_error()
-        outs.append(out.reshape(H, w * 2))
+    old = os.environ.get("CFHD_AMD_ENTROPY")
+    os.environ["CFHD_AMD_ENTROPY"] = "device"
+    try:
+        for s in samples[1:]:
+            sb = ctypes.create_string_buffer(s, len(s)); out = np.full(w * 2 * H, 7, np.uint8)
+            assert L.CFHD_DecodeSample(dec, sb, len(s), out.ctypes.data_as(ctypes.c_void_p), w * 2) == 0, amd_last_error()
+            outs.append(out.reshape(H, w * 2))
+    finally:
+        if old is None: os.environ.pop("CFHD_AMD_ENTROPY")
+        else: os.environ["CFHD_AMD_ENTROPY"] = old
     L.CFHD_CloseDecoder(dec)
     intervals = {}
     for g in range(2):

@@ -203,6 +203,17 @@ def _pool_is_fifo_and_matches_sync():
         assert bytes(a) == bytes(b), "pool sample %d differs from the synchronous encoder" % i
 
 
+def normalise_frame_counters(sample):
+    """The frame number (optional tag 69) and the unique-frame counter of the UFRM metadata tuple count per encoder call: zeroed for comparisons between encoders with different histories."""
+    import struct
+    b = bytearray(sample)
+    k = bytes(b[:160]).find(struct.pack(">h", -69))
+    if k >= 0: b[k + 2:k + 4] = b"\0\0"
+    u = bytes(b[:1024]).find(b"UFRM")
+    if u >= 0: b[u + 8:u + 12] = b"\0\0\0\0"
+    return bytes(b)
+
+
 def test_encoder_pool_takes_the_calls_of_the_reference_harness():
     """Example/TestCFHD.cpp:860-897 (-E, EncodeSpeedTest) prepares and starts its pool again on every turn of its loop until the first sample comes back, and closes
     the POOL with CFHD_CloseEncoder on its error path (:1044).  The reference takes both: a pool that is encoding reads the quality of its next frames from the call
@@ -1217,18 +1228,54 @@ def test_interlaced_encode_bitstream_identical(w, h, pixfmt):
     assert mask_volatile_metadata(prog[0]) != mask_volatile_metadata(mine[0])
 
 
-def test_interlaced_encode_peak_table_frames():
-    """Field-difference steps beyond +-250 make the reference append a peak table to subband 8; the GPU stage flags such a frame and
-    its sample is written by the host writer from the GPU coefficients.  Ordinary frames before and after it stay on the GPU path."""
-    w, h = 320, 64
+@pytest.mark.parametrize("w,h", [(320, 64), (720, 480)])
+def test_interlaced_encode_peak_table_frames(w, h):
+    """Field-difference steps beyond +-250 make the reference code subband 8 with peaks: the value enters the stream as +-251, its product with the divisor goes into
+    a peak table behind the band, three tags in front of the band point at it (encoder.c:4802, :6543).  The GPU entropy stage writes all of that (k_ent_count clamps and
+    counts, k_ent_scan places, k_ent_layout sizes the hole and writes tags and chunk header, k_ent_peaks fills the values in).  Ordinary frames before and after such a frame,
+    through CFHD_EncodeSample and through the batched path -- which has no host writer at all, so equal samples there mean the device wrote the tables -- and the
+    batch's decoder (k_dec_undiff takes the values back out of the table) gives the pictures of the exact reconstruction."""
     calm = synth_yuy2(w, h, 3)[0]
-    frames = [calm, field_flicker_frame(w, h)[0], calm.copy()]
-    mine = amd_encode_frames(frames, w * 2, w, h, PIX_YUY2, flags=1)
+    frames = [calm, field_flicker_frame(w, h)[0], calm.copy(), field_flicker_frame(w, h)[0]]
+    frames[3] = np.roll(frames[3].reshape(h, w * 2), 4, axis=1).reshape(-1).copy()
+    old = os.environ.get("CFHD_AMD_ENTROPY")
+    os.environ["CFHD_AMD_ENTROPY"] = "device"             # (a sample handed to the host writer fails the call)
+    try:
+        mine = amd_encode_frames(frames, w * 2, w, h, PIX_YUY2, flags=1)
+    finally:
+        if old is None: os.environ.pop("CFHD_AMD_ENTROPY")
+        else: os.environ["CFHD_AMD_ENTROPY"] = old
     refs = ref_encode_frames(frames, w * 2, w, h, PIX_YUY2, flags=1)
     for i, (a, b) in enumerate(zip(mine, refs)):
         assert len(a) == len(b), "frame %d: size %d vs reference %d" % (i, len(a), len(b))
         assert mask_volatile_metadata(a) == mask_volatile_metadata(b), "frame %d" % i
     assert len(refs[1]) != len(refs[0])
+    tables = [sum(1 for i in range(0, len(s) - 12, 4) if s[i:i + 2] == b"\xff\xb5" and s[i + 4:i + 6] == b"\xff\xb4" and s[i + 8:i + 10] == b"\xff\xb6" and s[i + 10:i + 12] != b"\0\0") for s in refs]
+    assert tables[0] == 0 and tables[1] > 0 and tables[3] > 0, tables      # (TAG_PEAK_TABLE_OFFSET_L / _H / TAG_PEAK_LEVEL in front of a band that has a table)
+    L = _batch_api()
+    n = len(frames)
+    b = L.cfhd_amd_batch_create_ex(w, h, PIX_YUY2, ENCODED_YUV422, 1, QUALITY_FILMSCAN1, n, 2, 0)
+    assert b, amd_last_error()
+    for turn in range(2):                                 # (twice: the second pass finds the tables, flags and counts of the first)
+        order = list(range(n)) if turn == 0 else [1, 0, 3, 2]
+        for i, k in enumerate(order):
+            assert L.cfhd_amd_batch_upload(b, i, frames[k].ctypes.data_as(ctypes.c_void_p), w * 2) == 0
+        assert L.cfhd_amd_batch_roundtrip(b) > 0, amd_last_error()
+        for i, k in enumerate(order):
+            p = ctypes.c_void_p(); sz = ctypes.c_size_t()
+            assert L.cfhd_amd_batch_get_sample(b, i, ctypes.byref(p), ctypes.byref(sz)) == 0
+            sample = ctypes.string_at(p, sz.value)
+            assert len(sample) == len(refs[k]), "pass %d frame %d: %d bytes vs reference %d" % (turn, k, len(sample), len(refs[k]))
+            assert normalise_frame_counters(mask_volatile_metadata(sample)) == normalise_frame_counters(mask_volatile_metadata(refs[k])), "pass %d frame %d differs from the reference" % (turn, k)
+            out = np.zeros(h * w * 2, dtype=np.uint8)
+            assert L.cfhd_amd_batch_download_output(b, i, out.ctypes.data_as(ctypes.c_void_p), w * 2) == 0
+            plan = Plan(w, h, progressive=0)
+            deq = oracle_decode_pyramid(sample, plan)
+            lo, hi = oracle_inverse_interlaced_yuv422(plan, deq, 0)[:h], oracle_inverse_interlaced_yuv422(plan, deq, 1)[:h]
+            img = out.reshape(h, w * 2)
+            ok = (img == lo) | (img == hi)
+            assert ok.all(), "pass %d frame %d: %d bytes outside the dither interval" % (turn, k, (~ok).sum())
+    L.cfhd_amd_batch_destroy(b)
 
 
 @pytest.mark.parametrize("w,h", [(320, 240), (1920, 1080)])

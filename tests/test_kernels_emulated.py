@@ -345,30 +345,51 @@ def _emu_entropy_interlaced(plan, coeffs, frame_number, meta):
 
 @pytest.mark.parametrize("w,h,seed", [(192, 96, 1), (336, 252, 3), (720, 480, 4)])
 def test_gpu_entropy_stage_emulated_interlaced(w, h, seed):
-    """Interlaced frames: the field-difference band (subband 8 of every channel) goes through the second entropy table (code set 18);
-    the sample equals the host writer's, which test_host_bitstream pins against the reference.  A difference band beyond the peak
-    threshold raises the per-frame flag instead (the API then writes that sample on the host)."""
+    """Interlaced frames: the field-difference band (subband 8 of every channel) goes through the second entropy table (code set 18) and is coded with
+    peaks: values beyond +-250 steps enter the stream as +-251 and their products with the divisor fill the table behind the band (k_ent_count / k_ent_scan /
+    k_ent_layout / k_ent_peaks).  The sample equals the host writer's, which test_host_bitstream pins against the reference: without peaks, with single
+    peaks in odd places (last coefficient of a band, first of a segment, an odd count), and with peaks all over the band."""
     frame, pitch = synth_yuy2(w, h, seed)
     plan = Plan(w, h, progressive=0)
     coeffs = oracle_forward_interlaced_yuv422(plan, frame, pitch)
     for c in range(3): np.clip(plan.view(coeffs, c, 0, 2), -250, 250, out=plan.view(coeffs, c, 0, 2))
     meta = b"GUID\x10\x00\x00G" + bytes(range(16))
-    want = product_write_sample_host(plan, coeffs, 3, meta_global=meta, progressive=0)
-    n, got = _emu_entropy_interlaced(plan, coeffs, 3, meta)
-    assert n > 0, n
-    assert len(got) == len(want)
-    if got != want:
-        first = next(k for k in range(len(got)) if got[k] != want[k])
-        raise AssertionError("first difference at byte %d of %d" % (first, len(got)))
+
+    def check(cf, what):
+        want = product_write_sample_host(plan, cf, 3, meta_global=meta, progressive=0)
+        n, got = _emu_entropy_interlaced(plan, cf, 3, meta)
+        assert n > 0, (what, n)
+        assert len(got) == len(want), (what, len(got), len(want))
+        if got != want:
+            first = next(k for k in range(len(got)) if got[k] != want[k])
+            raise AssertionError("%s: first difference at byte %d of %d" % (what, first, len(got)))
+        return got
+
+    def peak_levels(sample):         # the three optional tags in front of a band coded with peaks: TAG_PEAK_TABLE_OFFSET_L / _H, TAG_PEAK_LEVEL
+        return [int.from_bytes(sample[i + 10:i + 12], "big") for i in range(0, len(sample) - 12, 4) if sample[i:i + 2] == b"\xff\xb5" and sample[i + 4:i + 6] == b"\xff\xb4" and sample[i + 8:i + 10] == b"\xff\xb6"]
+
+    assert not any(peak_levels(check(coeffs, "no peaks")))
     for c, v in ((2, 251), (0, -251)):
         peaky = coeffs.copy()
         d = plan.band[(c, 0, 2)]
         plan.view(peaky, c, 0, 2)[d["height"] - 1, d["width"] - 1] = v
-        assert _emu_entropy_interlaced(plan, peaky, 3, meta)[0] == -100
+        assert sum(1 for l in peak_levels(check(peaky, "one peak in channel %d" % c)) if l) == 1
     ok = coeffs.copy()
-    plan.view(ok, 0, 0, 1)[0, 0] = 900                # other bands may hold anything
+    plan.view(ok, 0, 0, 1)[0, 0] = 900                # other bands may hold anything: no table for them
     plan.view(ok, 0, 0, 2)[0, 0] = 250
-    assert _emu_entropy_interlaced(plan, ok, 3, meta)[0] > 0
+    assert not any(peak_levels(check(ok, "at the threshold")))
+    rng = np.random.default_rng(seed)
+    many = coeffs.copy()
+    for c in range(3):
+        v = plan.view(many, c, 0, 2)[:, :plan.band[(c, 0, 2)]["width"]]      # (the columns beyond the band's width are row padding: zero)
+        n = max(3, v.size // 40) | 1                                        # an odd number of draws (the table is padded to a longword)
+        v[rng.integers(0, v.shape[0], size=n), rng.integers(0, v.shape[1], size=n)] = rng.integers(251, 1024, size=n) * rng.choice([-1, 1], size=n)
+        v[0, 0] = -1023; v[-1, -1] = 777                                    # first and last coefficient of the band
+    assert sum(1 for l in peak_levels(check(many, "peaks all over")) if l) == 3
+    dense = coeffs.copy()
+    v = plan.view(dense, 1, 0, 2)[:, :plan.band[(1, 0, 2)]["width"]]
+    v[:] = np.where(rng.integers(0, 2, size=v.shape) > 0, 300, -4000).astype(np.int16)      # every coefficient of one band a peak
+    check(dense, "a band of peaks only")
 
 
 @pytest.mark.parametrize("parallel", [0, 1, 2, 3])
