@@ -1244,7 +1244,8 @@ static CFHD_Error decode_group_sample(Decoder *d, const uint8_t *s, size_t size,
 		for (int r = 0; r < top.height; r++) {
 			const uint8_t *p = s + lp.offset + (size_t)r * top.width * 2;
 			int16_t *dst = coeffs + top.offset[0] + (size_t)r * top.pitch;
-			for (int x = 0; x < top.width; x++) { int v = (int16_t)((p[2 * x] << 8) | p[2 * x + 1]); v += bias; dst[x] = (int16_t)(v > 0x7fff ? 0x7fff : v); }
+			// (a band of odd width is read 16 unsigned bits at a time, one of even width as pairs of signed words: decoder.c:12240-12290, as k_dec_lowpass does)
+			for (int x = 0; x < top.width; x++) { int v = (int16_t)((p[2 * x] << 8) | p[2 * x + 1]); if (top.width & 1) v = (int)(uint16_t)v; v += bias; dst[x] = (int16_t)(v > 0x7fff ? 0x7fff : v); }
 		}
 		static const int coded[5] = { 5, 4, 3, 1, 0 };
 		for (int k : coded) {
@@ -1389,6 +1390,7 @@ static CFHD_Error decode_on_handle(Decoder *d, const ParsedSample &ps, const uin
 			int16_t *dst = coeffs + ll.offset + (size_t)r * ll.pitch;
 			for (int x = 0; x < ll.width; x++) {
 				int v = (int16_t)((p[2 * x] << 8) | p[2 * x + 1]);
+				if (ll.width & 1) v = (int)(uint16_t)v;           // (odd width: 16 unsigned bits at a time, decoder.c:12240-12290; the same rule as k_dec_lowpass)
 				v += lowpass_offset;
 				dst[x] = (int16_t)(v > 0x7fff ? 0x7fff : v);
 			}

@@ -100,6 +100,47 @@ def test_gop_decode_reference_samples(w, h, fmt):
     reference_leg(leg, 2, "two-frame groups -> 8-bit 4:2:2")
 
 
+def test_group_lowpass_words_beyond_int16_decode_alike_on_both_stages():
+    """The raw lowpass band of a group's top wavelet: a band of odd width is read 16 unsigned bits at a time (decoder.c:12240-12290, GetBits), one of even width as
+    signed words.  720 pixels give 45 chroma lowpass columns: with words of 0x8000 and above in the band (no encoder writes them) the device stage (k_dec_lowpass) and
+    the host coder must still return the same pictures -- the host path read them as signed until round 5 (advisor finding)."""
+    assert have_ref(), "oracle/_ref/libcfhd_ref.so is missing"
+    w, h, fmt = 720, 240, PIX_YUY2
+    frames = _frames(w, h, 2, fmt)
+    samples = ref_encode_frames(frames, w * 2, w, h, pixfmt=fmt, flags=ENCODING_FLAGS_2FRAME_GOP)
+    group = bytearray(samples[1])
+    gp = GopPlan(w, h, pixkind=1)
+    d5 = gp.w[(1, 5)]
+    assert d5["width"] % 2 == 1
+    # where the band lies in the sample: its decoded values are the sample's big-endian words plus a constant (the decoder's lowpass bias)
+    co = host_decode_group(bytes(group), gp)
+    top = gp.view(co, 1, 5, 0)[0, :8].astype(np.int64)
+    words = np.frombuffer(bytes(group[: len(group) // 2 * 2]), dtype=">u2").astype(np.int64)
+    hits = [i for i in range(0, min(len(words), 65536) - 8, 2) if np.array_equal(words[i:i + 8] - words[i], top - top[0]) and words[i] > 256]
+    assert len(hits) == 1, hits
+    at = 2 * hits[0]
+    for k, v in ((0, 0x8000), (3, 0x9abc), (6, 0xffff)): group[at + 2 * k: at + 2 * k + 2] = v.to_bytes(2, "big")
+    L = product()
+    pictures = {}
+    old = os.environ.get("CFHD_AMD_ENTROPY")
+    try:
+        for stage in ("device", "host"):
+            os.environ["CFHD_AMD_ENTROPY"] = stage
+            dec = ctypes.c_void_p(); assert L.CFHD_OpenDecoder(ctypes.byref(dec), None) == 0
+            aw = ctypes.c_int(); ah = ctypes.c_int(); af = ctypes.c_uint32()
+            sb = ctypes.create_string_buffer(samples[0], len(samples[0]))
+            assert L.CFHD_PrepareToDecode(dec, 0, 0, fmt, 1, 0, sb, len(samples[0]), ctypes.byref(aw), ctypes.byref(ah), ctypes.byref(af)) == 0
+            sb = ctypes.create_string_buffer(bytes(group), len(group)); out = np.full(w * 2 * ah.value, 7, np.uint8)
+            assert L.CFHD_DecodeSample(dec, sb, len(group), out.ctypes.data_as(ctypes.c_void_p), w * 2) == 0, amd_last_error()
+            L.CFHD_CloseDecoder(dec)
+            pictures[stage] = out.copy()
+    finally:
+        if old is None: os.environ.pop("CFHD_AMD_ENTROPY", None)
+        else: os.environ["CFHD_AMD_ENTROPY"] = old
+    # (the 8-bit output draws one dither bit per sample from the call counter: both handles decoded their first picture, so the bits agree)
+    assert np.array_equal(pictures["device"], pictures["host"])
+
+
 def test_gop_round_trip_of_the_product_alone():
     """Encode and decode with the product only, entered at a group (no sequence header): every frame comes back at intra-like quality."""
     w, h = 640, 360
