@@ -15,6 +15,7 @@ C ABI from host buffers (`config.c_abi_fps`, PCIe inclusive, never `value`).
 """
 import argparse, ctypes, hashlib, json, os, struct, sys, threading, time
 os.environ.setdefault("HSA_ENABLE_SDMA", "1")   # D2H of the samples on the SDMA engines: blit-kernel copies stall the kernels they overlap with
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # HIP streams share 4 hardware queues by default: the dozen streams of three steps in flight then wait for each other's barriers (profiles/r05_o_*)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -159,6 +160,7 @@ def c_abi_rates(frames, pitch, W, H, seconds=1.5, registered=False, decoders=8, 
             f.write(fr.reshape(H, pitch)[:, : W * 2].tobytes())
         f.flush()
         env = dict(os.environ)
+        env.pop("GPU_MAX_HW_QUEUES", None)                # (this process's setting for its batches in flight; the many-thread C ABI case is faster with the runtime's default: profiles/r05_p_*)
         if all_devices:                                  # no pin: the pool's workers and the decoder handles spread over every GPU the process sees
             env.pop("CFHD_AMD_DEVICE", None); env.pop("LOCAL_RANK", None)
         else:                                            # one GPU, whatever the node has (an unpinned process deals its workers to all of them: INTEGRATION.md section 5)

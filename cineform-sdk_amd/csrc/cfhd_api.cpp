@@ -75,6 +75,9 @@ struct EncMetadata {
 // HIP call of an application that links it; an application that set them keeps its values): sample downloads on the SDMA engines instead of blit kernels that
 // compete with the codec's kernels (HSA_ENABLE_SDMA, bench.py: DESIGN.md section 5), kernel arguments written to device memory (HIP_FORCE_DEV_KERNARG: the
 // host-fed round trip of tools/cabi_bench 2.4-2.9 k -> 3.6 k fps, profiles/r05_e_*).
+// (Not set here: GPU_MAX_HW_QUEUES.  The runtime maps all HIP streams of a process onto 4 hardware queues by default.  For several batches in flight -- a dozen streams -- 16
+// queues are worth +8 % (bench.py sets it for itself); the same setting costs the many-thread C ABI case, pool workers + decoder handles, 10-25 %:
+// profiles/r05_o_*, r05_p_*.)
 __attribute__((constructor)) static void cfhd_amd_runtime_defaults() { setenv("HSA_ENABLE_SDMA", "1", 0); setenv("HIP_FORCE_DEV_KERNARG", "1", 0); }
 
 // CFHD_AMD_PROFILE=1: where the wall time of the synchronous calls goes (printed when the handle is closed)

@@ -74,6 +74,10 @@ int batch_launch(cfhd_amd_batch *b)
 	b->frame_meta.resize(b->n);
 	for (int i = 0; i < b->n; i++) { b->meta.handle(); b->frame_meta[i] = b->meta.global; meta_remove_hidden(b->frame_meta[i]); }
 	const uint32_t seed = 0xA511E9B3u * (b->steps + 1);
+	// passes in flight on one device take turns per stage (cfhd_device.h stage_order_wait): this pass's encode kernels behind those of the pass queued before it, its
+	// decode kernels behind that pass's decode kernels.  CFHD_AMD_QUEUE=unordered: (A/B) every pass as soon as its own dependencies allow
+	static const bool ordered = [] { const char *e = getenv("CFHD_AMD_QUEUE"); return !(e && strcmp(e, "unordered") == 0); }();
+	if (ordered && stage_order_wait(c->enc.device(), 0, c->enc.stream())) return -2;
 	// the transform kernels start first: the host serialises the sample headers (0.5 ms per 256) while they run
 	if (c->enc.launch_forward(false)) return -2;         // (nothing but the entropy stage reads these coefficients)
 	for (int l = 0; l < c->n; l++) {
@@ -81,11 +85,14 @@ int batch_launch(cfhd_amd_batch *b)
 		if (c->enc.entropy().set_frame_header(l, h)) return -6;
 	}
 	if (c->enc.entropy().launch()) return -2;
+	if (ordered && stage_order_done(c->enc.device(), 0, c->enc.stream())) return -2;      // (in front of the copies to the host: the next pass's encode does not wait for PCIe)
 	if (b->decode) {
+		if (ordered && stage_order_wait(c->enc.device(), 1, c->dec.stream())) return -5;
 		// the parser only needs the headers and size fields (k_ent_layout): it runs beside k_ent_emit, the band decoder waits for the payloads
 		c->dec.entropy().set_producer_events(c->enc.entropy().headers_event(), c->enc.entropy().samples_event());
 		if (c->dec.entropy().set_samples_device(c->enc.entropy().device_sample(0), c->enc.entropy().sample_cap(), c->enc.entropy().device_sizes())) return -4;
 		if (c->dec.launch_entropy() || c->dec.launch_inverse(seed + (uint32_t)c->first)) return -5;
+		if (ordered && stage_order_done(c->enc.device(), 1, c->dec.stream())) return -5;
 	}
 	if (c->enc.entropy().download_queue()) return -2;
 	b->t_launched = now();
@@ -325,7 +332,11 @@ int cfhd_amd_batch_submit(cfhd_amd_batch *b)
 	CallerDevice caller_device;
 	if (!b || b->in_flight) return -1;
 	b->pending = -1;
-	if (b->gpu_entropy && b->device_handoff && b->chunks.size() == 1) {
+	// CFHD_AMD_QUEUE=thread: (A/B) the blocking pass on a thread of its own for the default arrangement too, as in round 4.  (Also measured: the launches of a queued
+	// pass -- 2-3 ms of host time with the serialising of 512 sample headers -- on a short-lived thread instead of the caller's: no difference on any line, profiles/r05_q_*.)
+	static const bool threaded = [] { const char *e = getenv("CFHD_AMD_QUEUE"); return e && strcmp(e, "thread") == 0; }();
+	if (b->gpu_entropy && b->device_handoff && b->chunks.size() == 1 && !threaded) {
+		b->chunks[0]->enc.entropy().set_speculative_download(true);
 		const int rc = batch_launch(b);                   // the whole pass is on the batch's streams when this returns; nothing waits
 		if (rc) return rc;
 		b->in_flight = true; b->queued = true;

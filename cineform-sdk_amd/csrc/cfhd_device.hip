@@ -170,6 +170,38 @@ int device_select(int dev)
 	return rc ? -1 : device_current();
 }
 int device_current() { return t_device >= 0 ? t_device : g_device; }
+
+namespace {
+struct StageOrder { std::mutex m; hipEvent_t ev[2] = { nullptr, nullptr }; bool recorded[2] = { false, false }; };
+StageOrder *stage_order_of(int device)
+{
+	static std::mutex m; static std::vector<StageOrder *> all;       // (never freed: events of a device live as long as the process)
+	std::lock_guard<std::mutex> lk(m);
+	if (device < 0) return nullptr;
+	if ((size_t)device >= all.size()) all.resize((size_t)device + 1, nullptr);
+	if (!all[device]) all[device] = new StageOrder;
+	return all[device];
+}
+}
+int stage_order_wait(int device, int stage, void *stream)
+{
+	StageOrder *o = stage_order_of(device);
+	if (!o || stage < 0 || stage > 1) return -1;
+	std::lock_guard<std::mutex> lk(o->m);
+	if (o->recorded[stage]) HIPCHK(hipStreamWaitEvent((hipStream_t)stream, o->ev[stage], 0));
+	return 0;
+}
+int stage_order_done(int device, int stage, void *stream)
+{
+	StageOrder *o = stage_order_of(device);
+	if (!o || stage < 0 || stage > 1) return -1;
+	std::lock_guard<std::mutex> lk(o->m);
+	(void)hipSetDevice(device);
+	if (!o->ev[stage]) HIPCHK(hipEventCreateWithFlags(&o->ev[stage], hipEventDisableTiming));
+	HIPCHK(hipEventRecord(o->ev[stage], (hipStream_t)stream));
+	o->recorded[stage] = true;
+	return 0;
+}
 int device_caller_save() { int d = -1; if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); return -1; } return d; }
 void device_caller_restore(int dev) { if (dev >= 0) { int now = -1; if (hipGetDevice(&now) == hipSuccess && now != dev) (void)hipSetDevice(dev); } }
 

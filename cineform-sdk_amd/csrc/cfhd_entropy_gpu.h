@@ -31,6 +31,8 @@ public:
 	uint32_t sample_bytes(int i) const { return h_sizes_[i]; }
 	// the next launch() / download() cover frames 0 .. k-1 of the batch (0 = all)
 	void set_active(int k) { active_ = k; }
+	// passes queued as a whole (the batch's frame queue): download_queue() sends the sample bytes on their way at once, sized by the previous pass
+	void set_speculative_download(bool on) { speculative_download_ = on; if (!on) expect_bytes_ = 0; }
 	// Interlaced frames and groups: the difference-coded bands are coded with peaks (encoder.c:4802) and their tables written on the device (k_ent_peaks).
 	// needs_peak_table(i): a band of sample i has more peaks than the device's positions hold (2 million): that sample is not valid, the caller writes it on the host.
 	bool needs_peak_table(int i) const { return peak_flags_in_use() && (h_sizes_[n_ + i] & 2u) != 0; }     // (the flags are only cleared and written for interlaced plans)
@@ -67,6 +69,7 @@ private:
 	uint8_t *d_samples_ = nullptr, *h_samples_ = nullptr;
 	uint32_t *d_sizes_ = nullptr, *h_sizes_ = nullptr;
 	uint8_t *d_packed_ = nullptr; uint32_t *d_offsets_ = nullptr, *h_offsets_ = nullptr;   // dense copy of the samples for the D2H transfer
+	size_t expect_bytes_ = 0, copied_ahead_ = 0; int expect_frames_ = 0; bool speculative_download_ = false;      // download_queue(): the copy sized by the last pass (set_speculative_download)
 	void *d_tables_ = nullptr, *d_bands_ = nullptr, *d_segband_ = nullptr, *d_segs_ = nullptr, *d_bandstate_ = nullptr, *d_frames_ = nullptr, *d_tokens_ = nullptr;
 	uint8_t *d_tmpl_ = nullptr, *h_tmpl_ = nullptr;
 	bool dirty_ = true;

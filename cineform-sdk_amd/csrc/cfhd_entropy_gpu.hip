@@ -241,6 +241,14 @@ int GpuEntropyEncoder::download_queue()
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipMemcpyAsync(h_sizes_, d_sizes_, sizeof(uint32_t) * 2 * n_, hipMemcpyDeviceToHost, st));
 	HIPCHK(hipMemcpyAsync(h_offsets_, d_offsets_, sizeof(uint32_t) * (act + 1), hipMemcpyDeviceToHost, st));
+	// The copy of the sample bytes needs their number, which the host learns when the sizes arrive (download_finish()).  A pass that is queued as a whole
+	// (cfhd_amd_batch_submit) would start that copy only when its result is collected, a step or two later; so the copy goes out now, sized by what the last pass of this
+	// many frames produced plus a margin, and download_finish() adds the remainder if this pass turned out larger (consecutive passes of a sequence differ by a few percent).
+	copied_ahead_ = 0;
+	if (!direct && expect_bytes_ && expect_frames_ == act) {
+		copied_ahead_ = expect_bytes_ < cap_ * (size_t)act ? expect_bytes_ : cap_ * (size_t)act;
+		HIPCHK(hipMemcpyAsync(h_samples_, d_packed_, copied_ahead_, hipMemcpyDeviceToHost, st));
+	}
 	return 0;
 }
 
@@ -252,7 +260,9 @@ int GpuEntropyEncoder::download_finish()
 	const bool direct = false;
 	const int act = active_frames();
 	HIPCHK(hipStreamSynchronize(st));
-	if (!direct && h_offsets_[act]) HIPCHK(hipMemcpyAsync(h_samples_, d_packed_, h_offsets_[act], hipMemcpyDeviceToHost, st));
+	const size_t total = h_offsets_[act];
+	if (!direct && total > copied_ahead_) HIPCHK(hipMemcpyAsync(h_samples_ + copied_ahead_, d_packed_ + copied_ahead_, total - copied_ahead_, hipMemcpyDeviceToHost, st));
+	expect_bytes_ = speculative_download_ ? ((total + total / 32 + 4095) & ~(size_t)4095) : 0; expect_frames_ = act;
 	return 0;
 }
 

@@ -1697,16 +1697,29 @@ def test_frame_queue_of_batches_equals_synchronous_passes():
     L.cfhd_amd_batch_submit.argtypes = [ctypes.c_void_p]
     L.cfhd_amd_batch_wait.restype = ctypes.c_longlong; L.cfhd_amd_batch_wait.argtypes = [ctypes.c_void_p]
     w, h, n = 320, 240, 3
-    frames = [synth_yuy2(w, h, 60 + i)[0] for i in range(2 * n)]
-    refs = [ref_encode_frames(frames[k * n:(k + 1) * n], w * 2, w, h) for k in range(2)]
+    base = [synth_yuy2(w, h, 60 + i)[0] for i in range(2 * n)]
+    rng = np.random.default_rng(5)
+    busy = [np.clip(f.astype(np.int32) + rng.integers(-40, 41, f.shape), 16, 235).astype(np.uint8) for f in base]      # samples several times as large
+    flat = [np.full_like(f, 0x80) for f in base]                                                                           # ... and a fraction of the size
+    # what each of the two batches encodes pass after pass: the copy of the sample bytes that a queued pass sends ahead is sized by the batch's previous pass
+    # (GpuEntropyEncoder::download_queue) -- too short for the busy pass behind the plain one, far too long for the flat pass behind the busy one
+    plan_of_rounds = [(base[:n], base[n:]), (busy[:n], flat[n:]), (flat[:n], busy[n:]), (base[:n], base[n:])]
+    refs_of = {}
     slots = []
     for k in range(2):
         b = L.cfhd_amd_batch_create(w, h, PIX_YUY2, QUALITY_FILMSCAN1, n, 2)
         assert b, amd_last_error()
-        for i in range(n): assert L.cfhd_amd_batch_upload(b, i, frames[k * n + i].ctypes.data_as(ctypes.c_void_p), w * 2) == 0
         slots.append(b)
     assert L.cfhd_amd_batch_wait(slots[0]) < 0                       # nothing in flight
-    for rounds in range(2):
+    sizes = []
+    for rounds, contents in enumerate(plan_of_rounds):
+        refs = []
+        for k, b in enumerate(slots):
+            for i in range(n): assert L.cfhd_amd_batch_upload(b, i, contents[k][i].ctypes.data_as(ctypes.c_void_p), w * 2) == 0
+            key = (id(contents[k][0]),)
+            if key not in refs_of: refs_of[key] = ref_encode_frames(contents[k], w * 2, w, h)
+            refs.append(refs_of[key])
+        sizes.append([sum(len(x) for x in r) for r in refs])
         for b in slots: assert L.cfhd_amd_batch_submit(b) == 0
         assert L.cfhd_amd_batch_submit(slots[1]) != 0                # one pass per batch at a time
         for k, b in enumerate(slots):
@@ -1728,6 +1741,7 @@ def test_frame_queue_of_batches_equals_synchronous_passes():
                 assert L.cfhd_amd_batch_download_output(b, i, out.ctypes.data_as(ctypes.c_void_p), w * 2) == 0
                 img = out.reshape(h, w * 2)
                 assert ((img == lo) | (img == hi)).all()
+    assert sizes[1][0] > 1.5 * sizes[0][0] and sizes[1][1] < 0.5 * sizes[0][1], sizes
     for b in slots: L.cfhd_amd_batch_destroy(b)
 
 
