@@ -175,7 +175,7 @@ def c_abi_rates(frames, pitch, W, H, seconds=1.5, registered=False, decoders=8, 
     return json.loads(out.stdout.strip().splitlines()[-1])
 
 
-DEFAULT_DEPTH = 3      # steps in flight in the timed region (measured on the MI355X, gpurun_out/r04c: 47.5 / 50.1 / 52.5 / 52.5 k fps at depth 1 / 2 / 3 / 4)
+DEFAULT_DEPTH = 4      # steps in flight in the timed region (MI355X, 16 hardware queues, free-running passes: 55.4 / 58.2 / 59.1 / 57.0 / 57.3 k fps at depth 2 / 3 / 4 / 5 / 6, profiles/r05_o_*)
 
 
 def normalise_counters(sample):

@@ -74,9 +74,14 @@ int batch_launch(cfhd_amd_batch *b)
 	b->frame_meta.resize(b->n);
 	for (int i = 0; i < b->n; i++) { b->meta.handle(); b->frame_meta[i] = b->meta.global; meta_remove_hidden(b->frame_meta[i]); }
 	const uint32_t seed = 0xA511E9B3u * (b->steps + 1);
-	// passes in flight on one device take turns per stage (cfhd_device.h stage_order_wait): this pass's encode kernels behind those of the pass queued before it, its
-	// decode kernels behind that pass's decode kernels.  CFHD_AMD_QUEUE=unordered: (A/B) every pass as soon as its own dependencies allow
-	static const bool ordered = [] { const char *e = getenv("CFHD_AMD_QUEUE"); return !(e && strcmp(e, "unordered") == 0); }();
+	// Encode-only passes in flight on one device take turns (cfhd_device.h stage_order_wait): this pass's forward transform starts behind the entropy coder of the pass
+	// queued before it.  Passes that start together otherwise run in lock step -- all encode, then all copy their samples to the host, and the copies (the PCIe link) and
+	// the kernels never overlap: byr4-2160p 18.9 k fps with turns, 11.9 k without; rg48-2160p 15.9 / 12.4 k.  Round-trip passes run free: their decode halves fill the
+	// gaps, and turns -- for the encode halves alone or for both -- cost 6 % (54.6 vs 58.1 k fps at 1080p, 16.5 vs 17.9 k at 2160p, 51.4 vs 55.8 k at 1080i; 16 hardware
+	// queues, three steps in flight: profiles/r05_o_*).  CFHD_AMD_QUEUE=ordered: (A/B) turns for both halves of every pass; =free: for none.
+	static const int forced = [] { const char *e = getenv("CFHD_AMD_QUEUE"); return e && strcmp(e, "ordered") == 0 ? 2 : (e && strcmp(e, "free") == 0 ? 0 : -1); }();
+	const int turns = forced >= 0 ? forced : (b->decode ? 0 : 1);
+	const bool ordered = turns >= 1, ordered_decode = turns >= 2;
 	if (ordered && stage_order_wait(c->enc.device(), 0, c->enc.stream())) return -2;
 	// the transform kernels start first: the host serialises the sample headers (0.5 ms per 256) while they run
 	if (c->enc.launch_forward(false)) return -2;         // (nothing but the entropy stage reads these coefficients)
@@ -87,12 +92,12 @@ int batch_launch(cfhd_amd_batch *b)
 	if (c->enc.entropy().launch()) return -2;
 	if (ordered && stage_order_done(c->enc.device(), 0, c->enc.stream())) return -2;      // (in front of the copies to the host: the next pass's encode does not wait for PCIe)
 	if (b->decode) {
-		if (ordered && stage_order_wait(c->enc.device(), 1, c->dec.stream())) return -5;
+		if (ordered_decode && stage_order_wait(c->enc.device(), 1, c->dec.stream())) return -5;
 		// the parser only needs the headers and size fields (k_ent_layout): it runs beside k_ent_emit, the band decoder waits for the payloads
 		c->dec.entropy().set_producer_events(c->enc.entropy().headers_event(), c->enc.entropy().samples_event());
 		if (c->dec.entropy().set_samples_device(c->enc.entropy().device_sample(0), c->enc.entropy().sample_cap(), c->enc.entropy().device_sizes())) return -4;
 		if (c->dec.launch_entropy() || c->dec.launch_inverse(seed + (uint32_t)c->first)) return -5;
-		if (ordered && stage_order_done(c->enc.device(), 1, c->dec.stream())) return -5;
+		if (ordered_decode && stage_order_done(c->enc.device(), 1, c->dec.stream())) return -5;
 	}
 	if (c->enc.entropy().download_queue()) return -2;
 	b->t_launched = now();

@@ -17,9 +17,9 @@ int device_init();                 // picks the device from CFHD_AMD_DEVICE, els
 int device_count();
 int device_select(int dev);        // this thread prepares its batches on device `dev` from now on (-1: the process default again); returns the device in effect, -1 on failure
 int device_current();              // the device device_init() puts this thread on
-// Passes that are queued as a whole (cfhd_amd_batch_submit) take turns per stage on a device: the encode half of a pass starts behind the encode half of the pass queued
-// before it on that device, the decode half behind that pass's decode half, so that at any time one pass's encode kernels run beside another's decode kernels -- and
-// not three passes' worth of the same kernels beside each other (measured: DESIGN.md section 5).  stage 0: encode, 1: decode.  stage_order_wait: work queued on
+// Passes that are queued as a whole (cfhd_amd_batch_submit) can take turns per stage on a device: the encode half of a pass starts behind the encode half of the pass queued
+// before it on that device (the default for encode-only passes: cfhd_batch.cpp batch_launch says why) and, with CFHD_AMD_QUEUE=ordered, the decode half behind that pass's
+// decode half.  stage 0: encode, 1: decode.  stage_order_wait: work queued on
 // `stream` from now on waits for the last stage_order_done of that stage on `device`; stage_order_done: the work `stream` holds now is that stage's latest.
 int stage_order_wait(int device, int stage, void *stream);
 int stage_order_done(int device, int stage, void *stream);

@@ -157,7 +157,9 @@ int GpuEntropyEncoder::launch()
 			dev::k_ent_count<<<(total + dev::ENT_WAVES - 1) / dev::ENT_WAVES, dev::ENT_THREADS, 0, s>>>((const dev::EntSegJob *)d_segband_, geom, total, (dev::EntSegState *)d_segs_, T,
 			                                                                                          d_sizes_ + n_, (uint32_t *)d_tokens_, lo, n, count_probe);
 	};
-	split_ = ev_level1_ && stream2_ && !host_->jobs.ranges_l1.empty() && act >= 8;      // (a single frame gains nothing from six launches instead of one)
+	// CFHD_AMD_COUNT_SPLIT=0: (A/B) the level-1 bands counted on the main stream behind the level-2 / level-3 transforms instead of beside them
+	static const bool split_on = [] { const char *e = getenv("CFHD_AMD_COUNT_SPLIT"); return !(e && atoi(e) == 0); }();
+	split_ = split_on && ev_level1_ && stream2_ && !host_->jobs.ranges_l1.empty() && act >= 8;      // (a single frame gains nothing from six launches instead of one)
 	// the peak flags are raised by the difference-coded band only, a level-1 band: cleared on the stream that counts it
 	if (peak_flags_in_use() && !split_) HIPCHK(hipMemsetAsync(d_sizes_ + n_, 0, sizeof(uint32_t) * n_, st));
 	if (split_) {
@@ -439,6 +441,9 @@ int GpuEntropyDecoder::launch()
 		const int nch = plan_.num_channels, nb = n_ * nch * 9;
 		HIPCHK(hipMemsetAsync(d_errors_, 0, sizeof(int), st));
 		(void)hipGetLastError();
+		// CFHD_AMD_PARSE_EARLY=0: (A/B) the parser behind the finished payloads instead of beside k_ent_emit
+		static const bool parse_early = [] { const char *e = getenv("CFHD_AMD_PARSE_EARLY"); return !(e && atoi(e) == 0); }();
+		if (!parse_early && ev_payloads_) ev_headers_ = ev_payloads_;
 		if (ev_headers_) HIPCHK(hipStreamWaitEvent(st, (hipEvent_t)ev_headers_, 0));
 		HIPCHK(hipEventRecord((hipEvent_t)ev_[0], st));
 		dev::k_dec_parse<<<n_, dev::DEC_PARSE_THREADS, 0, st>>>(ext_samples_, ext_stride_, ext_sizes_, n_,
