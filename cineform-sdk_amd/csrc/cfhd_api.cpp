@@ -178,7 +178,7 @@ bool gpu_entropy_enabled() { const char *e = getenv("CFHD_AMD_ENTROPY"); return 
 // CFHD_AMD_ENTROPY=device: (tests) a sample the device stage hands back to the host coder fails the call instead -- proves which stage served a frame or a group
 bool gpu_entropy_strict() { const char *e = getenv("CFHD_AMD_ENTROPY"); return e && strcmp(e, "device") == 0; }
 
-// one caller waiting for one frame: its plain buffers are staged in pieces (cfhd_device.hip upload_frame / download_frame); CFHD_AMD_STAGE_PIECES=1 switches that off
+// one caller waiting for one frame: its plain buffers are staged in pieces (cfhd_device.hip upload_frame / download_frame)
 int sync_stage_pieces() { return 4; }      // (measured with 1 / 2 / 4 / 8 pieces: profiles/r04_j_*, r04_k_*)
 
 int prepare_batch(EncodeBatch &batch, const EncodeParams &p)

@@ -82,9 +82,9 @@ private:
 	int16_t *d_coeff_ = nullptr, *h_coeff_ = nullptr;
 	void *d_jobs_ = nullptr, *h_jobs_ = nullptr; size_t jobs_bytes_ = 0;
 	int16_t *d_planes_ = nullptr; uint16_t *d_curve_ = nullptr; size_t plane_elems_ = 0;   // Bayer input: component planes + encode curve LUT
-	// Bayer: k_unpack_byr4 writes the component planes and k_fwd_plane transforms them.  CFHD_AMD_BAYER=fused: level 1 computes the planes in its loader
-	// (k_fwd_packed16 layout 10 / 11) and never writes them -- same bytes, but 5.1 ms instead of 2.2 for 96 4K frames (round 3): every plane's loader pays the four
-	// curve gathers of a photosite quad again, and the tile's halo columns on top; the bytes saved (16 per quad) do not pay for 4 x the lookups.  Kept for A/B.
+	// Bayer: k_unpack_byr4 writes the component planes and k_fwd_plane transforms them (small launches; large ones take k_fwd_bayer_strip).  bayer_fused_ (tests only, no
+	// switch since round 5): level 1 computes the planes in its loader (k_fwd_packed16 layout 10 / 11) and never writes them -- same bytes, but 5.1 ms instead of 2.2 for
+	// 96 4K frames (round 3): every plane's loader pays the four curve gathers of a photosite quad again, and the tile's halo columns on top.
 	bool bayer_fused_ = false;
 	float kernel_ms_ = 0;
 	bool timed_ = false;
