@@ -6,9 +6,11 @@ A step = one pass of the hot path over one batch of synthetic frames that are al
 forward kernels -> entropy coding -> samples -> entropy decoding -> inverse kernels -> frames in HBM, and the host copy of every sample.
 `value` is whole-job frames per second (all ranks); `roofline` is the longest kernel of the step against the HBM peak (HIP events around
 every launch, on the stream it runs on); `cpu_baseline` is the unmodified reference (oracle/_ref) timed on this box's host cores on a
-bounded sample.  After the timed region rank 0 checks what it timed: sample 0 of the last step against the reference encoder's golden
-hash, decoded frame 0 against the exact reconstruction (`config.parity_checked`), and measures the same codec through the reference's own
-C ABI from host buffers (`config.c_abi_fps`, PCIe inclusive, never `value`).
+bounded sample.  After the timed region rank 0 checks what it timed -- eight frames spread over the last timed pass of every batch in flight: the
+samples against the reference encoder run on the same frames (sample 0 also against the golden hash), the decoded frames against the oracle's exact
+reconstruction of their own samples (`config.parity`) -- and measures the same codec through the reference's own C ABI from host buffers
+(`config.c_abi_fps`, PCIe inclusive, minimum of three runs, never `value`).  Several steps are in flight in the timed region (`--depth`, a HIP-stream frame
+queue of batch objects: cfhd_amd_batch_submit / _wait); the process runs with 16 hardware queues (GPU_MAX_HW_QUEUES, below).
 
   python bench.py --gpus 1 --steps 20 --warmup 3 [--workload 1080p|2160p]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
