@@ -124,6 +124,8 @@ long orc_decode_band_bits(const uint8_t *in, size_t nbytes, int width, int heigh
                           const uint8_t *peaks, size_t peak_bytes, int peak_level, int difference, PIXEL16 *band);
 /* The tag-value walk of an intra-frame sample with every band decoded into the caller's rasters (lowpass band: raw words, no bias). */
 int orc_decode_sample(const uint8_t *d, size_t size, PIXEL16 *const dst[4][3][4], const int pitch[4][3][4], const int dims[4][3][4][2], int32_t info[8]);
+/* ... of the group sample of a two-frame GOP: six wavelets per channel (decoder.c:11180) */
+int orc_decode_group(const uint8_t *d, size_t size, PIXEL16 *const dst[3][6][4], const int pitch[3][6][4], const int dims[3][6][4][2], int32_t info[8]);
 
 #ifdef __cplusplus
 }

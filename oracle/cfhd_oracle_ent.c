@@ -425,3 +425,96 @@ int orc_decode_sample(const uint8_t *d, size_t size, PIXEL16 *const dst[4][3][4]
 	info[7] = decoded;
 	return 0;
 }
+
+
+/* The same walk over the group sample of a two-frame GOP (Codec/decoder.c:11180 DecodeSampleGroup -> the same UpdateCodecState / DecodeSampleSubband per tag): six
+ * wavelets per channel (WAVELET_NUMBER 1..6 -> 0..5: the two frame wavelets, the temporal wavelet, the spatial wavelet of the temporal highpass, the two of the temporal
+ * lowpass), the lowpass band of the top wavelet (index 5) raw behind the coefficient marker, every other band behind its BAND_HEADER: run-length coded (BAND_ENCODING 3, code
+ * set and difference coding from BAND_CODING_FLAGS, peak tables as for intra samples) or -- band 0 of wavelet 3, the lowpass band of the temporal highpass -- as signed
+ * 16-bit big-endian words times the band's divisor (BAND_ENCODING 4 = BAND_ENCODING_16BIT, decoder.c:12790 DecodeBand16s), the walk going on at the next 32-bit word.
+ * dst / pitch / dims[channel 0..2][wavelet 0..5][band 0..3]; info as orc_decode_sample (info[5]: the progressive flag as the reference defaults it for a group: 0 unless a
+ * SAMPLE_FLAGS tag says otherwise, codec.c:263, decoder.c:13397; info[6]: frames in the group). */
+int orc_decode_group(const uint8_t *d, size_t size, PIXEL16 *const dst[3][6][4], const int pitch[3][6][4], const int dims[3][6][4][2], int32_t info[8])
+{
+	size_t pos = 0;
+	int channel = 0, wv = -1, band = 0, bw = 0, bh = 0, bq = 1, bflags = 0, benc = 3, bsub = 0, lw = 0, lh = 0, decoded = 0;
+	size_t peak_base = 0; uint32_t peak_offset = 0; int peak_level = 0;
+	memset(info, 0, 8 * sizeof(int32_t));
+	while (pos + 4 <= size) {
+		int tag = (int16_t)((d[pos] << 8) | d[pos + 1]);
+		const int value = (d[pos + 2] << 8) | d[pos + 3];
+		pos += 4;
+		if (tag < 0) tag = -tag;
+		if (tag & 0x4000) { pos += (size_t)((tag & 0x2000) ? (((uint32_t)(tag & 0xff) << 16) | (uint32_t)value) : (uint32_t)value) * 4; continue; }
+		if (tag & 0x2000) continue;
+		switch (tag) {
+		case 2: pos += 4 * (size_t)value; break;                            /* CODEC_TAG_INDEX */
+		case 62: channel = value; if (channel < 0 || channel > 2) return -3; break;
+		case 12: info[3] = value; break;
+		case 11: info[6] = value; break;                                    /* NUM_FRAMES */
+		case 20: info[0] = value; break; case 21: info[1] = value; break;
+		case 85: info[2] = value; break;
+		case 70: info[4] = value; break;
+		case 68: info[5] = value & 1; break;
+		case 27: lw = value; break; case 28: lh = value; break;
+		case 4:
+			if (value == 0x0F0F) {
+				PIXEL16 *out = dst[channel][5][0];
+				const size_t bytes = (size_t)lw * lh * 2;
+				int r, x;
+				if (pos + bytes > size) return -4;
+				if (out) {
+					if (lw != dims[channel][5][0][0] || lh != dims[channel][5][0][1]) return -5;
+					for (r = 0; r < lh; r++) for (x = 0; x < lw; x++) { const uint8_t *p = d + pos + ((size_t)r * lw + x) * 2; out[(size_t)r * pitch[channel][5][0] + x] = (PIXEL16)(uint16_t)((p[0] << 8) | p[1]); }
+				}
+				pos += (bytes + 3) & ~(size_t)3;
+				decoded++;
+			}
+			break;
+		case 38: wv = value - 1; if (wv < 0 || wv > 5) return -6; break;
+		case 48: band = value; if (band < 0 || band > 3) return -7; bflags = 0; benc = 3; break;
+		case 72: bflags = value; break;
+		case 75: peak_offset = (peak_offset & ~0xffffu) | (uint32_t)value; peak_base = pos; peak_level = 0; break;
+		case 76: peak_offset = (peak_offset & 0xffffu) | ((uint32_t)value << 16); peak_level = 0; break;
+		case 74: peak_level = value; break;
+		case 49: bw = value; break; case 50: bh = value; break;
+		case 51: bsub = value; break;                                       /* BAND_SUBBAND */
+		case 52: benc = value; break;                                       /* BAND_ENCODING */
+		case 53: bq = value; break;
+		case 55: {
+			PIXEL16 *out;
+			static PIXEL16 *scratch = NULL; static size_t scratch_n = 0;
+			int p;
+			if (wv < 0) return -8;
+			if (bsub == 255) { if (wv != 2 || band != 1) return -10; break; }      /* the empty band of the temporal wavelet: a header and nothing behind it (decoder.c:11954) */
+			out = dst[channel][wv][band]; p = out ? pitch[channel][wv][band] : ((bw + 7) & ~7);
+			if (out && (bw != dims[channel][wv][band][0] || bh != dims[channel][wv][band][1])) return -5;
+			if (!out) { if ((size_t)bh * p > scratch_n) { free(scratch); scratch_n = (size_t)bh * p; scratch = (PIXEL16 *)malloc(scratch_n * sizeof(PIXEL16)); } out = scratch; }
+			if (benc == 4) {
+				const size_t bytes = (size_t)bw * bh * 2;
+				int r, x;
+				if (pos + bytes > size) return -4;
+				for (r = 0; r < bh; r++) for (x = 0; x < bw; x++) { const uint8_t *q = d + pos + ((size_t)r * bw + x) * 2; out[(size_t)r * p + x] = (PIXEL16)((int16_t)(uint16_t)((q[0] << 8) | q[1]) * bq); }
+				pos += (bytes + 3) & ~(size_t)3;
+				{   /* the encoder closes the raw band with the band end code word all the same (encoder.c:8219-8260): walked over as a band of no coefficients */
+					const long e = orc_decode_band_bits(d + pos, size - pos, 0, 0, 0, 1, 1, NULL, 0, 0, 0, out);
+					if (e < 0) return -30 + (int)e;
+					pos += (((size_t)e + 31) / 32) * 4;
+				}
+			} else {
+				const uint8_t *peaks = NULL; size_t peak_bytes = 0;
+				long bits;
+				if (peak_level) { const size_t at = peak_base + peak_offset; if (at + 2 > size) return -9; peaks = d + at; peak_bytes = size - at; }
+				bits = orc_decode_band_bits(d + pos, size - pos, bw, bh, p, bq, bflags & 0xf, peaks, peak_bytes, peak_level, (bflags >> 4) & 1, out);
+				if (bits < 0) return -20 + (int)bits;
+				pos += (((size_t)bits + 31) / 32) * 4;
+			}
+			peak_level = 0;
+			decoded++;
+			break; }
+		default: break;
+		}
+	}
+	info[7] = decoded;
+	return 0;
+}

@@ -1291,6 +1291,38 @@ def host_decode_group(sample, gp):
     return out
 
 
+def oracle_decode_group(sample, gp, lowpass_offset=1):
+    """Dequantized group pyramid of a group sample, in the product's group pyramid layout, by the ORACLE alone (oracle/cfhd_oracle_ent.c orc_decode_group: its own tag-value
+    walk, bit-serial decoder of both code sets with peak tables and difference coding, raw 16-bit bands) -- the group twin of oracle_decode_pyramid, and what the decode
+    gates of the group tests feed the oracle's inverse with.  lowpass_offset=1 adds the reference decoder's lowpass bias of a group for 8-bit output: twice the intra
+    frame's (Codec/decoder.c:12265 `num_frames == 2 ? 48 : 24`; the odd-width path likewise), on words read as unsigned where the band's width is odd (:12468-12545)."""
+    O = oracle()
+    out = np.zeros(gp.coeff_elems, dtype=np.int16)
+    P16 = ctypes.POINTER(ctypes.c_int16)
+    dst = (P16 * 4 * 6 * 3)(); pitch = (ctypes.c_int * 4 * 6 * 3)(); dims = (ctypes.c_int * 2 * 4 * 6 * 3)()
+    for c in range(3):
+        for k in (5, 4, 3, 1, 0):
+            d = gp.w[(c, k)]
+            for b in range(4):
+                if b == 0 and k not in (5, 3): continue                 # (band 0 is coded for the top wavelet -- raw, behind the coefficient marker -- and for the temporal highpass's wavelet)
+                v = gp.view(out, c, k, b)
+                dst[c][k][b] = v.ctypes.data_as(P16); pitch[c][k][b] = d["pitch"]; dims[c][k][b][0] = d["width"]; dims[c][k][b][1] = d["height"]
+    info = (ctypes.c_int32 * 8)()
+    s = np.frombuffer(sample, dtype=np.uint8).copy()
+    O.orc_decode_group.argtypes = [c_u8p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    rc = O.orc_decode_group(p8(s), len(sample), ctypes.byref(dst), ctypes.byref(pitch), ctypes.byref(dims), ctypes.byref(info))
+    assert rc == 0, "oracle group walk failed: %d" % rc
+    assert info[3] == 3 and info[7] == 3 * 17, "group sample has %d channels, %d bands decoded" % (info[3], info[7])
+    if lowpass_offset:
+        for c in range(3):
+            d = gp.w[(c, 5)]
+            ll = gp.view(out, c, 5, 0)[:, : d["width"]]
+            words = ll.view(np.uint16).astype(np.int32) if d["width"] & 1 else ll.astype(np.int32)
+            bias = 2 * oracle_lowpass_bias(10, d["width"], gp.pixkind, c)
+            ll[:] = np.minimum(words + bias, 0x7fff).astype(np.int16)
+    return out
+
+
 def oracle_inverse_gop(gp, coeffs, dither, uyvy=0, reference_defect=True):
     """The inverse group transform with the oracle from a dequantized group pyramid: spatial synthesis of w[5], w[4], w[3] (orc_inv_spatial: the descale variant where
     the encoder prescaled; orc_inv_spatial_overflow_protected -- the routine the reference's group decoder runs, defect of its last row included -- where it did not;

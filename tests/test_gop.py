@@ -70,7 +70,7 @@ def test_group_inverse_model_equals_the_reference_group_decoder(w, h, fmt):
     ngroups = len(frames) // 2
     models = []
     for g in range(ngroups):
-        co = host_decode_group(samples[2 * g + 1], gp)
+        co = oracle_decode_group(samples[2 * g + 1], gp)
         models.append((oracle_inverse_gop(gp, co, 0, uyvy=int(kind == 2)), oracle_inverse_gop(gp, co, 1, uyvy=int(kind == 2)), oracle_inverse_gop(gp, co, 0, uyvy=int(kind == 2), reference_defect=False)))
     def outside(got):
         return [(g, f, int((~((img == models[g][0][f][:h]) | (img == models[g][1][f][:h]))).sum())) for g, pair in enumerate(got) for f, img in enumerate(pair) if img is not None]
@@ -139,7 +139,7 @@ def test_interlaced_group_inverse_model_equals_the_reference_group_decoder(w, h,
     ngroups = len(frames) // 2
     models = []
     for g in range(ngroups):
-        co = host_decode_group(samples[2 * g + 1], gp)
+        co = oracle_decode_group(samples[2 * g + 1], gp)
         models.append((oracle_inverse_gop(gp, co, 0, uyvy=int(kind == 2)), oracle_inverse_gop(gp, co, 1, uyvy=int(kind == 2))))
     def outside(got):
         return [(g, f, int((~((img == models[g][0][f][:h]) | (img == models[g][1][f][:h]))).sum())) for g, pair in enumerate(got) for f, img in enumerate(pair) if img is not None]
@@ -155,3 +155,26 @@ def test_interlaced_group_inverse_model_equals_the_reference_group_decoder(w, h,
             if kind == 2: sw = lambda a: a.reshape(-1, 2)[:, ::-1].reshape(h, w * 2); src, img, lo_f, hi_f = sw(src), sw(img), sw(lo_f), sw(hi_f)
             ends = (psnr_yuy2(lo_f, src), psnr_yuy2(hi_f, src))      # any picture inside the interval lies between its two ends (to the printed 0.1 dB)
             assert min(ends) - 0.1 < psnr_yuy2(img, src) < max(ends) + 0.1
+
+
+@pytest.mark.parametrize("w,h,fmt,interlaced,flicker", [(320, 240, PIX_YUY2, 0, 0), (720, 486, PIX_2VUY, 0, 0), (336, 252, PIX_YUY2, 1, 1), (720, 480, PIX_2VUY, 1, 0),
+                                                         (1920, 1080, PIX_YUY2, 0, 0), (1920, 1080, PIX_YUY2, 1, 0)])
+def test_oracle_group_walk_equals_product_host_decoder(w, h, fmt, interlaced, flicker):
+    """The decode gates of the group tests feed the oracle's inverse with coefficients decoded by the oracle alone (oracle/cfhd_oracle_ent.c orc_decode_group: its own walk over
+    the group sample -- six wavelets, the empty band of the temporal wavelet, the raw 16-bit band of the temporal highpass with the band end code behind it, code sets 17 / 18, peak
+    tables, difference coding; no size field is consulted).  This test ties that decoder to the product's host parser + VLC decoder on reference-encoded groups of every kind
+    the tests use: both must give the same pyramid, coefficient for coefficient -- so a defect shared by the product's host and GPU group decoders cannot hide behind a gate."""
+    assert have_ref(), "oracle/_ref/libcfhd_ref.so is missing"
+    kind = 2 if fmt == PIX_2VUY else 1
+    if interlaced: frames = _interlaced_frames(w, h, 4, fmt, bool(flicker))
+    elif w >= 1920: frames = qbist_frames(10, 4, w, h, fmt)[0]
+    else:
+        frames = [synth_yuy2(w, h, 40 + i)[0] for i in range(4)]
+        if fmt == PIX_2VUY: frames = [f.reshape(-1, 2)[:, ::-1].reshape(-1).copy() for f in frames]
+    samples = ref_encode_frames(frames, w * 2, w, h, pixfmt=fmt, flags=ENCODING_FLAGS_2FRAME_GOP | interlaced)
+    gp = GopPlan(w, h, pixkind=kind, interlaced=interlaced)
+    for g in (1, 3):
+        a = host_decode_group(samples[g], gp); b = oracle_decode_group(samples[g], gp)
+        assert np.array_equal(a, b), "group sample %d: %d coefficients differ" % (g, int((a != b).sum()))
+        if flicker: assert b"\xff\xb5" in samples[g]
+
