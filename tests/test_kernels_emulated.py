@@ -395,14 +395,14 @@ def test_gpu_entropy_stage_emulated_interlaced(w, h, seed):
 @pytest.mark.parametrize("parallel", [0, 1, 2, 3])
 @pytest.mark.parametrize("w,h,seed", [(192, 96, 1), (336, 252, 3), (720, 480, 4)])
 def test_gpu_entropy_decoder_emulated_equals_host_decoder(w, h, seed, parallel):
-    """k_dec_bands (one lane per band), k_dec_bands_par (one workgroup per band; 2: fed by the GPU parser k_dec_parse; 3: the low-latency shape k_dec_bands_par_ll) + k_dec_lowpass under emulation reproduce the product's host VLC decoder (dequantized pyramid incl. lowpass bias)."""
+    """k_dec_bands (one lane per band), k_dec_bands_par (one workgroup per band; 2: fed by the GPU parser k_dec_parse; 3: the low-latency shape k_dec_bands_par_ll) + k_dec_lowpass under emulation reproduce the ORACLE's decoder (oracle_decode_pyramid since round 5; the product's host VLC decoder is tied to it in test_oracle_vs_ref) (dequantized pyramid incl. lowpass bias)."""
     frame, pitch = synth_yuy2(w, h, seed)
     plan = Plan(w, h)
     coeffs = oracle_forward_yuv422(plan, frame, pitch)
     if seed == 3:                                   # long code words: values up to the +-1023 clamp
         v = plan.view(coeffs, 0, 0, 1); v[::7, ::5] = 1023; v[1::9, 2::11] = -1023; v[3::5, 1::13] = 300
     sample = product_write_sample_host(plan, coeffs, 1, meta_global=b"GUID\x10\x00\x00G" + bytes(16))
-    want = host_decode_pyramid(sample, plan)
+    want = oracle_decode_pyramid(sample, plan)
     got = np.full(plan.coeff_elems, 99, dtype=np.int16)
     E = emu()
     E.emu_entropy_decode.argtypes = [c_u8p, ctypes.c_size_t, ctypes.c_int, c_i16p, ctypes.c_size_t, ctypes.c_int]
@@ -865,7 +865,7 @@ def _dx_decode(sample, plan, mode, grid, size=None, guard=0):
 @pytest.mark.parametrize("mode,grid", [(0, 3), (1, 2), (2, 1), (0, 64)])
 @pytest.mark.parametrize("w,h,seed", [(192, 96, 1), (336, 252, 3), (720, 480, 4)])
 def test_dx_decoder_emulated_equals_host_decoder(w, h, seed, mode, grid, arrangement):
-    """The chunk-indexed decoder reproduces the product's host VLC decoder coefficient for coefficient, every element of every band incl.
+    """The chunk-indexed decoder reproduces the oracle's decoder (oracle_decode_pyramid: its own sample walk and bit-serial decoder) coefficient for coefficient, every element of every band incl.
     its pitch padding written by the tile kernel itself.  mode 1 switches the run-in speculation off, so every chunk but a band's first
     assumes a wrong start and k_dec_chain has to repair it; mode 2 parses two copies of the sample with k_dec_parse / k_dec_plan."""
     frame, pitch = synth_yuy2(w, h, seed)
@@ -878,7 +878,7 @@ def test_dx_decoder_emulated_equals_host_decoder(w, h, seed, mode, grid, arrange
     if seed == 3:                                   # long code words: values up to the +-1023 clamp
         v = plan.view(coeffs, 0, 0, 1); v[::7, ::5] = 1023; v[1::9, 2::11] = -1023; v[3::5, 1::13] = 300
     sample = product_write_sample_host(plan, coeffs, 1, meta_global=b"GUID\x10\x00\x00G" + bytes(16))
-    want = host_decode_pyramid(sample, plan)
+    want = oracle_decode_pyramid(sample, plan)
     rc, got = _dx_decode(sample, plan, mode, grid)
     assert rc == 0
     for (c, lv, b) in plan.band:
@@ -901,7 +901,7 @@ def test_dx_decoder_emulated_sparse_and_dense_bands(arrangement):
     dense[:, : d["width"]] = rng.integers(1, 40, (d["height"], d["width"])) * rng.choice([-1, 1], (d["height"], d["width"]))
     e = plan.view(coeffs, 0, 0, 3); e[:] = 0; e[0, 0] = -5; e[-1, plan.band[(0, 0, 3)]["width"] - 1] = 7
     sample = product_write_sample_host(plan, coeffs, 1, meta_global=b"GUID\x10\x00\x00G" + bytes(16))
-    want = host_decode_pyramid(sample, plan)
+    want = oracle_decode_pyramid(sample, plan)
     for mode, grid in ((0, 5), (1, 1)):
         rc, got = _dx_decode(sample, plan, mode, grid)
         assert rc == 0
@@ -922,7 +922,7 @@ def test_dx_decoder_emulated_code_without_unique_alignment(arrangement):
         d = plan.band[(c, lv, b)]
         v = plan.view(coeffs, c, lv, b); v[:] = 0; v[:, : d["width"]] = val
     sample = product_write_sample_host(plan, coeffs, 1, meta_global=b"GUID\x10\x00\x00G" + bytes(16))
-    want = host_decode_pyramid(sample, plan)
+    want = oracle_decode_pyramid(sample, plan)
     for mode, grid in ((0, 4), (1, 3)):
         rc, got = _dx_decode(sample, plan, mode, grid)
         assert rc == 0
@@ -967,7 +967,7 @@ def test_dx_decoder_emulated_survives_damaged_samples(mode, arrangement):
 def test_dx_decoder_emulated_interlaced_samples(w, h, seed, peaks, arrangement):
     """The field-difference band of every channel arrives in the second code set, difference coded along the row and -- when a value lies
     beyond the peak threshold -- with its large values in a peak table behind the band.  The emulated kernels must rebuild exactly the
-    pyramid of the product's host decoder (pinned against the reference's by test_oracle_vs_ref / test_host_bitstream)."""
+    pyramid of the oracle's decoder (code set 18, peak tables, running sums restated in oracle/cfhd_oracle_ent.c; tied to the product's host decoder in test_oracle_vs_ref)."""
     frame, pitch = field_flicker_frame(w, h) if peaks else synth_yuy2(w, h, seed)       # field flicker: quantized steps beyond +-250 in the difference band
     if peaks:
         rng = np.random.default_rng(seed)
@@ -977,7 +977,7 @@ def test_dx_decoder_emulated_interlaced_samples(w, h, seed, peaks, arrangement):
     sample = product_write_sample_host(plan, coeffs, 1, meta_global=b"GUID\x10\x00\x00G" + bytes(16), progressive=0)
     levels = [int.from_bytes(sample[i + 2:i + 4], "big") for i in range(0, len(sample) - 4, 4) if sample[i:i + 2] == b"\xff\xb6"]      # TAG_PEAK_LEVEL (optional)
     assert any(levels) == bool(peaks)
-    want = host_decode_pyramid(sample, plan)
+    want = oracle_decode_pyramid(sample, plan)
     for mode, grid in ((0, 3), (2, 2)):
         rc, got = _dx_decode(sample, plan, mode, grid)
         assert rc == 0, (mode, rc)
