@@ -145,7 +145,10 @@ long long cfhd_amd_batch_roundtrip(cfhd_amd_batch *batch);                      
 /* The same pass as a slot of a frame queue (replaces the reference's EncoderPool job queue, EncoderSDK/EncoderPool.cpp:239-380): submit returns at once -- the whole
  * pass is queued on the batch's HIP streams, the decoder's stream waiting for the encoder's events; no host thread, no host wait inside the pass --, wait returns what
  * cfhd_amd_batch_roundtrip would have; batches in flight at the same time overlap on the GPU.  One pass per batch at a time: between submit and wait every other entry
- * point on that batch (roundtrip, upload, get_sample, download_output, kernel_ms, dx_stats) returns its error value without touching the batch; destroy waits first. */
+ * point on that batch (roundtrip, upload, get_sample, download_output, kernel_ms, dx_stats) returns its error value without touching the batch; destroy waits first.
+ * Encode-only batches in flight on one device take turns (their host copies hide behind the next batch's kernels), round-trip batches run free.  A process that keeps
+ * several batches in flight should run with GPU_MAX_HW_QUEUES=16 in its environment (ROCm runtime, read at start-up: by default all HIP streams of a process share 4
+ * hardware queues and the streams of several passes wait for each other). */
 int  cfhd_amd_batch_submit(cfhd_amd_batch *batch);
 long long cfhd_amd_batch_wait(cfhd_amd_batch *batch);
 int  cfhd_amd_batch_get_sample(cfhd_amd_batch *batch, int frame, const void **data, size_t *size);
