@@ -73,22 +73,6 @@ enum {
 	DX_RUNIN_SHORT = 96, DX_LEAD = 96,    // bits of the quick run-in in front of a chunk / of the lead-in in front of a lane
 	DX_MEMO = CFHD_DX_MEMO,           // outcomes a lane of k_dec_index remembers (start -> end, count)
 	DX_OFF_INVALID = 31,              // entry: no code word of the true sequence starts in this piece (behind the band end marker / the payload)
-	// the single-pass arrangement (k_dec_index_emit + k_dec_scatter): the index walk leaves, per 64-bit piece, the nonzero coefficients its code words hold
-	DX_KE = 11,                       // bits of the window of its table (emit11: 8 bytes per window, 16 KB like the 12-bit table of 4-byte entries it replaces in LDS)
-	// A chunk's step logs: 16-bit words, [piece of the lane 0..3][step 0..31][lane 0..63] -- the lanes of a wave take their steps of a piece in lock step (dx_steps_e's loop),
-	// so step s of all of them is ONE store of 128 contiguous bytes.  (A slot per piece, the third build, made every step 64 stores to 64 cache lines: the address path of
-	// the CU, 64 cycles per wave and step, was what the index pass waited for: + 0.5 ms.)  A piece can take 22 steps: two group steps in a row consume at least 12 bits, but
-	// in the last 10 bits in front of a mark a group that would pass it is refused and the walk goes one code word (one bit, for a single zero) at a time; rows beyond the
-	// first dozen are rarely touched.
-	DX_LOG_STEPS = 32,                // rows per piece
-	DX_REC_MAX = DX_LOG_STEPS - 1,    // last step a log holds (the walk stops counting there: in-bounds whatever the data)
-	DX_LOG_PIECE = DX_LOG_STEPS * 64, // 16-bit words of one piece row block
-	DX_LOG_CHUNK = DX_SUBS * DX_LOG_PIECE / 2,         // dwords of a chunk's log area (16 KB)
-	// a step of the log: bits 14-15 kind, bits 0-13 payload
-	DX_LOG_FIRST = 0,                 // the first code word of emit11[payload]
-	DX_LOG_GROUP = 1,                 // the whole group of emit11[payload]
-	DX_LOG_VALUE = 2,                 // a value too long for the table: payload = the expanded magnitude with its sign (14 bits, two's complement)
-	DX_LOG_RUN = 3,                   // a zero run too long for the table: payload = its length
 };
 enum : uint32_t { DX_END = 0xFFFFFFFFu, DX_BAD = 0xFFFFFFFEu, DX_SPECIAL = 0xFFFFFFFEu };
 enum { DX_FLAG_END = 1, DX_FLAG_BAD = 2, DX_FLAG_UNRESOLVED = 4, DX_ERR_BAD = 1 << 1, DX_ERR_OVERFLOW = 1 << 2, DX_ERR_NOEND = 1 << 3, DX_ERR_SPACE = 1 << 4 };
@@ -113,12 +97,6 @@ struct DecIdxTables {
 	// bits 0-4 length without the sign bit (escape: index bits of the next level), bits 5-7 type (DX_T_*), bits 8-19 zero run | magnitude under code
 	// set 17's companding curve | base of the next level, bits 20-31 magnitude under code set 18's (linear) curve
 	uint32_t long11[DX_LONG11_MAX];
-	// k_dec_index_emit: one entry per 11-bit window with what both kinds of step need -- the first code word alone (a step that would otherwise pass a 64-bit mark) or
-	// the group of multi[] (up to two values and the zero runs around them).  x = bits 0-3 bits of the first code word, sign bit included (0: it does not fit the window --
-	// then y is multi[].y, the entry of the code word / the escape into long11[]), bits 4-7 bits of the group, bits 8-19 coefficients the first code word covers, bits 20-31
-	// coefficients the group covers; y = bits 0-7 / 8-15 position of the group's first / second value relative to the position in front of the step, bits 16-21 / 22-27 the
-	// values (signed; this short they lie below the knee of the companding curve of either code set), bits 28-29 values in the group, bit 30 the first code word is a value.
-	uint2 emit11[1 << DX_KE];
 };
 
 // One coded band of one frame = DecBandJob (cfhd_entropy_kernels.h); the job table is [band slot][frame], a band that is not wanted -- half
@@ -223,7 +201,6 @@ struct DxLane {                       // state of one lane of k_dec_index
 	uint32_t cnt;                     // coefficients covered by the code words that start in the lane's range
 	uint32_t rec_offs;                // per 64-bit piece, one byte each: first code word's offset into the piece (DX_OFF_INVALID: none)
 	uint32_t rec_cnt[DX_SUBS];        // coefficients of the lane in front of that code word
-	uint32_t rec_n;                   // k_dec_index_emit: per piece, one byte each, the records in the piece's slot
 };
 enum : uint32_t { DX_OFFS_NONE = DX_OFF_INVALID * 0x01010101u };
 __device__ __forceinline__ uint32_t dx_off_get(uint32_t offs, int k) { return (offs >> (8 * k)) & 0xffu; }
@@ -672,7 +649,7 @@ __device__ __forceinline__ void dx_load_tables_wave(const DecIdxTables *T, uint3
 // code word.  A chunk indexed for several candidate starts contributes the outcome of the one that is true (and goes on the re-index list when
 // that is not the one its entries were written for).  A chunk none of whose candidates is true -- more candidates than k_dec_index keeps -- is
 // indexed again on the spot when REPAIR is set; otherwise the band is only reported (false) and left to k_dec_repair.
-// How a chunk is indexed again from an exact start (RX): with the tables of k_dec_index, or of k_dec_index_emit (which writes the chunk's records again as well).
+// How a chunk is indexed again from an exact start: RX.
 struct DxNoReindex { __device__ __forceinline__ DxChunkRec operator()(const DxBandJob &, uint32_t, uint32_t, uint32_t) { return DxChunkRec{ 0u, 0u, 0u, 0u }; } };
 struct DxReindexCount {
 	const DecIdxTables *T; uint32_t *s_tab, *s_long, *s_words, *entries; DxChunkRec *recs; bool tables;
@@ -818,438 +795,6 @@ __global__ void __launch_bounds__(DX_THREADS) k_dec_reindex(const DxBandJob *job
 		if (!tables) { dx_load_tables_wave(T, s_tab, s_long); tables = true; CFHD_WAVE_SYNC(); }
 		const DxBandJob job = jobs[x.job];
 		dx_index_chunk(job.bits, job.bytes, x.chunk, x.k, x.start, s_words_all[wave], s_tab, s_long, entries, nullptr, nullptr);
-		if (stats && wave_lane() == 0) atomicAdd(&stats[3], 1u << 8);
-	}
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------------------------
-// The single-pass arrangement (round 5): every payload bit is walked once.
-//
-// k_dec_index walks every bit to find where code words start and what they cover, and k_dec_tiles walked every bit again to learn what the code
-// words say.  The walk below is the same walk over the same pieces with the same hand-over between lanes, rounds and chunks, but it keeps a LOG:
-// per 64-bit piece one 16-bit word per step -- which table entry the step took and whether it took the entry's first code word or its whole
-// group, or, for a code word beyond the table, the value / the run itself.  The log is all k_dec_scatter needs to put the piece's values into a
-// tile: entry + chunk position + the steps' table entries, looked up again (independent LDS reads, no bit window, no refill, no dependent chain
-// but the running position).  A log is relative to its PIECE, which is what makes this fit the speculative walk: when a lane's second walk
-// meets its first at a 64-bit mark, the pieces behind the mark keep their logs as they keep their entries -- only the counts in front of them
-// shift, and those live in the entries.  A piece that is walked again has its log written again (same lane, same addresses, program order).
-// What the first two builds of the round taught (profiles/r05_a_*, r05_b_*): finished (position, value) records in a 128-byte slot per piece made
-// the tile pass fetch 3.8 GB of mostly empty lines per 512 frames -- as slow as decoding --, and packing the records behind the walk (wave
-// scratch slots + a copy into a dense stream per chunk) cost the index pass a dozen dependent round trips per chunk (+0.9 ms).  Sixteen bits per
-// step in a 32-byte slot need neither: 8 KB of logs per chunk, four pieces to a cache line, consecutive lanes of the tile pass on consecutive slots.
-__device__ __forceinline__ int dx_sext6(uint32_t y, int lsb) { return (int)(y << (26 - lsb)) >> 26; }
-
-// the code word behind a window nothing of which fits the first-level table (le = the table's y: the entry of the code word or an escape into long11[])
-__device__ __forceinline__ uint32_t dx_long11_entry(uint32_t le, const uint32_t *s_long, uint32_t win)
-{
-	if (((le >> 5) & 7u) == (uint32_t)DX_T_ESCAPE) {
-		le = s_long[((le >> 8) & 0xfffu) + ((win << DX_KE) >> (32 - DX_L11_BITS))];
-		if (((le >> 5) & 7u) == (uint32_t)DX_T_ESCAPE) le = s_long[((le >> 8) & 0xfffu) + ((win << (DX_KE + DX_L11_BITS)) >> (32 - (le & 31u)))];
-	}
-	return le;
-}
-
-// The steps of a walk up to a mark (dx_steps with the 11-bit table).  LOG: count the coefficients and log the steps -- slot: the piece's log, nsteps: steps in it.
-template <bool LOG>
-__device__ __forceinline__ bool dx_steps_e(DxBitsAhead &B, uint32_t &pos, uint32_t &cnt, const uint32_t lim, uint32_t &endv, const uint32_t *s_words, const uint2 *s_tab, const uint32_t *s_long,
-                                           const bool linear, uint16_t *slot, uint32_t &nsteps)
-{
-	bool ok = true;
-	bool go = pos < lim;
-	while (go) {
-		const uint32_t win = B.window();
-		const uint32_t wi = win >> (32 - DX_KE);
-		const uint2 t = s_tab[wi];
-		const uint32_t ahead = B.prefetch(s_words);
-		const uint32_t used = (t.x >> 4) & 15u;
-		uint32_t adv = t.x & 15u, add = (t.x >> 8) & 0xfffu;      // the first code word ...
-		const bool all = adv != 0u && pos + used <= lim;
-		adv = all ? used : adv; add = all ? t.x >> 20 : add;      // ... or the group, when it ends in front of the mark
-		uint32_t w = wi | (all ? (uint32_t)DX_LOG_GROUP << 14 : (uint32_t)DX_LOG_FIRST << 14);
-		if (adv == 0u) {
-			const uint32_t le = dx_long11_entry(t.y, s_long, win);
-			const uint32_t ty = (le >> 5) & 7u, ln = le & 31u;
-			const bool isrun = ty == (uint32_t)DX_T_RUN, isval = ty == (uint32_t)DX_T_VALUE;
-			const int m = (int)(linear ? le >> 20 : (le >> 8) & 0xfffu);
-			adv = isrun ? ln : (isval ? ln + 1u : 0u);
-			add = isrun ? (le >> 8) & 0xfffu : (isval ? 1u : 0u);
-			w = isrun ? ((uint32_t)DX_LOG_RUN << 14) | add : ((uint32_t)DX_LOG_VALUE << 14) | ((uint32_t)(((win << ln) >> 31) ? -m : m) & 0x3fffu);
-			if (!isrun && !isval) { endv = ty == (uint32_t)DX_T_END ? (uint32_t)DX_END : (uint32_t)DX_BAD; ok = false; }
-		}
-		if (LOG) {
-			if (ok) { slot[nsteps * 64u] = (uint16_t)w; nsteps = nsteps < (uint32_t)DX_REC_MAX ? nsteps + 1u : nsteps; }
-			cnt += add;
-		}
-		pos += adv;
-		B.skip((int)adv, ahead);
-		go = ok && pos < lim;
-	}
-	return ok;
-}
-
-// dx_walk with the logs: lane_log = this lane's column of the chunk's log area
-__device__ __forceinline__ void dx_walk_e(DxLane &L, uint32_t pos, const bool merge, const uint32_t lane_base, const uint32_t limit, const uint32_t *s_words, const uint2 *s_tab,
-                                          const uint32_t *s_long, const bool linear, uint16_t *lane_log)
-{
-	uint32_t cnt = 0, start = pos, endv = pos;
-	uint32_t offs = merge ? L.rec_offs : (uint32_t)DX_OFFS_NONE;
-	uint32_t nrs = merge ? L.rec_n : 0u;
-	uint32_t rc[DX_SUBS] = { L.rec_cnt[0], L.rec_cnt[1], L.rec_cnt[2], L.rec_cnt[3] };
-	const uint32_t lane_end = lane_base + DX_LANE_BITS;
-	const uint32_t stop = lane_end < limit ? lane_end : limit;
-	int piece = -1, merged_at = 0;
-	bool done = false, clear = false, merged = false;
-	DxBitsAhead B;
-	B.seek(s_words, pos);
-	{
-		const uint32_t lim = lane_base < stop ? lane_base : stop;
-		uint32_t none = 0;
-		if (!dx_steps_e<false>(B, pos, cnt, lim, endv, s_words, s_tab, s_long, linear, lane_log, none)) { clear = true; done = true; }
-	}
-#pragma unroll
-	for (int k = 0; k < DX_SUBS; k++) {
-		const uint32_t mark_lo = lane_base + (uint32_t)k * DX_SUB_BITS, mark = mark_lo + DX_SUB_BITS;
-		if (!done) {
-			if (pos >= stop) {
-				endv = pos; clear = pos < lane_end; done = true;
-			} else if (pos < mark) {
-				const uint32_t off = pos - mark_lo;
-				if (piece < 0) { cnt = 0u; start = pos; }
-				if (merge && k > 0 && dx_off_get(offs, k) == off) {
-					merged = true; merged_at = k; done = true;
-				} else {
-					offs = dx_off_set(offs, k, off); rc[k] = cnt; piece = k;
-					const uint32_t lim = mark < stop ? mark : stop;
-					uint32_t n = 0;
-					if (!dx_steps_e<true>(B, pos, cnt, lim, endv, s_words, s_tab, s_long, linear, lane_log + k * DX_LOG_PIECE, n)) { clear = true; done = true; }
-					nrs = dx_off_set(nrs, k, n);
-				}
-			} else { offs = dx_off_set(offs, k, (uint32_t)DX_OFF_INVALID); nrs = dx_off_set(nrs, k, 0u); }
-		}
-	}
-	if (!done) { endv = pos; clear = pos < lane_end; }
-	if (merged) {
-		const int k = merged_at;
-		const uint32_t old = k == 1 ? L.rec_cnt[1] : (k == 2 ? L.rec_cnt[2] : L.rec_cnt[3]);
-		const uint32_t delta = cnt - old;
-		L.rec_cnt[0] = rc[0];
-		L.rec_cnt[1] = k <= 1 ? (dx_off_get(offs, 1) != (uint32_t)DX_OFF_INVALID ? L.rec_cnt[1] + delta : L.rec_cnt[1]) : rc[1];
-		L.rec_cnt[2] = k <= 2 ? (dx_off_get(offs, 2) != (uint32_t)DX_OFF_INVALID ? L.rec_cnt[2] + delta : L.rec_cnt[2]) : rc[2];
-		L.rec_cnt[3] = dx_off_get(offs, 3) != (uint32_t)DX_OFF_INVALID ? L.rec_cnt[3] + delta : L.rec_cnt[3];
-		L.cnt += delta;
-		L.rec_offs = offs; L.rec_n = nrs;
-		L.start = start;
-		return;
-	}
-	if (clear) offs = dx_off_clear_from(offs, piece + 1);
-	L.rec_cnt[0] = rc[0]; L.rec_cnt[1] = rc[1]; L.rec_cnt[2] = rc[2]; L.rec_cnt[3] = rc[3];
-	L.start = start; L.end = endv;
-	L.rec_offs = offs; L.rec_n = nrs;
-	L.cnt = cnt;
-}
-
-// dx_runin_candidates with the 11-bit table
-__device__ __forceinline__ int dx_runin_candidates_e(const uint32_t bytes, const uint32_t k, const uint32_t runin_bits, const uint32_t *s_words, const uint2 *s_tab,
-                                                     const uint32_t *s_long, uint32_t (&cand)[DX_MAX_ALT + 2])
-{
-	const int lane = wave_lane();
-	const uint32_t nwords = bytes >> 2;
-	const int64_t first = (int64_t)k * DX_CHUNK_WORDS - (DX_LANE_BITS / 32);
-	const int64_t left = (int64_t)nwords - first;
-	const uint32_t limit = left <= 0 ? 0u : (left * 32 > (int64_t)(64 * DX_LANE_BITS + 64) ? (uint32_t)(64 * DX_LANE_BITS + 64) : (uint32_t)(left * 32));
-	uint32_t pos = (uint32_t)DX_LANE_BITS - runin_bits + (uint32_t)lane, end = DX_BAD;
-	if (lane < 27) {
-		DxBitsAhead B;
-		B.seek(s_words, pos);
-		bool alive = true;
-		do {
-			if (pos >= (uint32_t)DX_LANE_BITS) { end = pos; alive = false; }
-			else if (pos >= limit) alive = false;
-			else {
-				const uint32_t win = B.window();
-				const uint2 t = s_tab[win >> (32 - DX_KE)];
-				const uint32_t ahead = B.prefetch(s_words);
-				const uint32_t used = (t.x >> 4) & 15u;
-				uint32_t adv = t.x & 15u;
-				adv = (adv != 0u && pos + used <= (uint32_t)DX_LANE_BITS) ? used : adv;
-				if (adv == 0u) {
-					const uint32_t le = dx_long11_entry(t.y, s_long, win);
-					const uint32_t ty = (le >> 5) & 7u;
-					if (ty == (uint32_t)DX_T_RUN) adv = le & 31u;
-					else if (ty == (uint32_t)DX_T_VALUE) adv = (le & 31u) + 1u;
-					else alive = false;
-				}
-				if (alive) { pos += adv; B.skip((int)adv, ahead); }
-			}
-		} while (alive);
-	}
-	unsigned long long mask = __ballot(lane < 27 && end < DX_SPECIAL);
-	int n = 0;
-#pragma unroll 1
-	while (mask && n < DX_MAX_ALT + 2) {
-		const int l = __builtin_ctzll(mask);
-		const uint32_t v = wave_get(end, l);
-		cand[n++] = v - DX_LANE_BITS;
-		mask &= ~__ballot(end == v);
-	}
-	return n;
-}
-
-// dx_index_staged with the logs: rec_chunk = the step logs the walk writes (DX_REC_CHUNK words: the chunk's own, an alternate slot's, or a spare chunk for a walk that
-// is wanted for its outcome only), nsteps = per lane of the entry slot gchunk the four step counts (one byte each), written with the entries
-__device__ __forceinline__ DxChunkRec dx_index_staged_e(const uint32_t bytes, const uint32_t gchunk, const uint32_t k, const uint32_t exact_start, const uint32_t *s_words, const uint2 *s_tab,
-                                                        const uint32_t *s_long, const bool linear, uint32_t *entries, uint32_t *rec_chunk, uint32_t *nsteps, uint32_t *stats = nullptr)
-{
-	const int lane = wave_lane();
-	const uint32_t nwords = bytes >> 2;
-	const int64_t first = (int64_t)k * DX_CHUNK_WORDS - (DX_LANE_BITS / 32);
-	const int64_t left = (int64_t)nwords - first;
-	const uint32_t limit = left <= 0 ? 0u : (left * 32 > (int64_t)(64 * DX_LANE_BITS + 64) ? (uint32_t)(64 * DX_LANE_BITS + 64) : (uint32_t)(left * 32));
-	const uint32_t lane_base = (uint32_t)lane * DX_LANE_BITS;
-	const bool live = lane_base < limit && lane >= 1;
-	const int last_live = limit == 0u ? 0 : (int)((limit - 1u) / DX_LANE_BITS) < 63 ? (int)((limit - 1u) / DX_LANE_BITS) : 63;
-	uint16_t *lane_log = (uint16_t *)rec_chunk + lane;
-	DxLane L;
-	L.start = DX_BAD; L.end = lane_base; L.cnt = 0; L.rec_offs = DX_OFFS_NONE; L.rec_n = 0u;
-#pragma unroll
-	for (int j = 0; j < DX_SUBS; j++) L.rec_cnt[j] = 0;
-	if (lane == 0) { L.start = 0u; L.end = exact_start >= DX_SPECIAL ? exact_start : DX_LANE_BITS + exact_start; }
-	uint32_t memo_s[DX_MEMO], memo_e[DX_MEMO], memo_c[DX_MEMO];
-	int memo_at = 0;
-#pragma unroll
-	for (int i = 0; i < DX_MEMO; i++) { memo_s[i] = DX_BAD; memo_e[i] = 0; memo_c[i] = 0; }
-	uint32_t rec_start = DX_BAD, rec_end = 0, rec_total = 0;
-	bool finishing = false;
-#pragma unroll 1
-	for (int round = 0; round < 70; round++) {
-		uint32_t want; bool need;
-		if (finishing) {
-			const bool special = L.start >= DX_SPECIAL || L.start < lane_base || L.start >= lane_base + DX_LANE_BITS;
-			if (live && special) L.rec_offs = DX_OFFS_NONE;
-			want = L.start; need = live && !special && rec_start != L.start;
-		} else if (round == 0) {
-			const uint32_t first = __shfl_up(L.end, 1u);
-			want = lane == 1 ? first : lane_base - DX_LEAD; need = live;
-		} else {
-			want = __shfl_up(L.end, 1u); need = live && want != L.start;
-		}
-		const unsigned long long moved = __ballot(need);
-		if (!finishing && round > 0) {
-			if (stats && lane == 0 && moved) atomicAdd(&stats[4 + (round - 1 < 11 ? round - 1 : 11)], (uint32_t)__builtin_popcountll(moved));
-			if (!moved) {
-				if (stats && lane == 0) { atomicAdd(&stats[0], (uint32_t)round - 1u); atomicAdd(&stats[1], 1u); atomicMax(&stats[2], (uint32_t)round - 1u); }
-				finishing = true; round--;
-				continue;
-			}
-		}
-		if (finishing && !moved) break;
-		if (need) {
-			L.start = want;
-			const bool lead = !finishing && round == 0 && lane >= 2;
-			if (!lead && (want >= DX_SPECIAL || want < lane_base || want >= lane_base + DX_LANE_BITS)) {
-				L.end = want >= DX_SPECIAL ? want : (uint32_t)DX_BAD; L.cnt = 0;
-			} else {
-				int hit = -1;
-#pragma unroll
-				for (int i = 0; i < DX_MEMO; i++) if (memo_s[i] == want) hit = i;
-				if (hit >= 0 && !finishing && !lead) {
-#pragma unroll
-					for (int i = 0; i < DX_MEMO; i++) if (i == hit) { L.end = memo_e[i]; L.cnt = memo_c[i]; }
-				} else {
-					L.end = rec_end; L.cnt = rec_total;
-					dx_walk_e(L, want, !finishing && rec_start != DX_BAD, lane_base, limit, s_words, s_tab, s_long, linear, lane_log);
-					const uint32_t walked = lead ? L.start : want;
-					L.start = walked;
-					rec_start = walked; rec_end = L.end; rec_total = L.cnt;
-#pragma unroll
-					for (int i = 0; i < DX_MEMO; i++) if (i == memo_at) { memo_s[i] = walked; memo_e[i] = L.end; memo_c[i] = L.cnt; }
-					memo_at = memo_at + 1 < DX_MEMO ? memo_at + 1 : 0;
-				}
-			}
-		}
-		if (finishing) break;
-	}
-	const uint32_t own = live ? L.cnt : 0u;
-	const uint32_t incl = wave_incl_scan(own);
-	const uint32_t before = incl - own;
-	const size_t slot = (size_t)gchunk * DX_ENTRY_STRIDE + (size_t)lane * DX_SUBS;
-	if (lane >= 1 && entries) {
-		uint4 e;
-		uint32_t v[DX_SUBS];
-#pragma unroll
-		for (int j = 0; j < DX_SUBS; j++) v[j] = (!live || dx_off_get(L.rec_offs, j) == (uint32_t)DX_OFF_INVALID) ? (uint32_t)DX_OFF_INVALID : (dx_off_get(L.rec_offs, j) | ((before + L.rec_cnt[j]) << 5));
-		e.x = v[0]; e.y = v[1]; e.z = v[2]; e.w = v[3];
-		*(uint4 *)(entries + slot) = e;
-		if (nsteps) nsteps[(size_t)gchunk * 64 + (size_t)lane] = L.rec_n;
-	}
-	const uint32_t total = wave_get(incl, 63), el = wave_get(L.end, last_live);
-	DxChunkRec r;
-	r.start = exact_start;
-	r.end = el >= DX_SPECIAL ? el : ((last_live < 63 || el < 64u * DX_LANE_BITS) ? (uint32_t)DX_BAD : el - 64u * DX_LANE_BITS);
-	r.count = total;
-	r.flags = (r.end == DX_END ? DX_FLAG_END : 0u) | (r.end == DX_BAD ? DX_FLAG_BAD : 0u);
-	CFHD_WAVE_SYNC();
-	return r;
-}
-
-// What the emitting kernels share: the step logs of every chunk (DX_LOG_CHUNK words each) and their step counts (64 words per chunk: a byte per piece, lane-major like
-// the entries), and the same for the extra candidates of chunks without a unique alignment (alternate slots, as alt_entries; one more chunk's worth of logs behind
-// them is the spare for candidates that found no slot).
-struct DxRecords { uint32_t *log; uint32_t *nsteps; uint32_t *alt_log; uint32_t *alt_nsteps; uint32_t alt_spare; };
-__device__ __attribute__((noinline)) DxChunkRec dx_index_chunk_e(const uint8_t *bits, const uint32_t bytes, const uint32_t gchunk, const uint32_t k, const uint32_t exact_start, uint32_t *s_words,
-                                                                 const uint2 *s_tab, const uint32_t *s_long, const bool linear, uint32_t *entries, DxChunkRec *recs, const DxRecords R, uint32_t *stats)
-{
-	DxFetch F;
-	dx_fetch_chunk(bits, bytes, k, F);
-	dx_store_stage(F, s_words);
-	const DxChunkRec r = dx_index_staged_e(bytes, gchunk, k, exact_start, s_words, s_tab, s_long, linear, entries, R.log + (size_t)gchunk * DX_LOG_CHUNK, R.nsteps, stats);
-	if (wave_lane() == 0 && recs) recs[gchunk] = r;
-	return r;
-}
-
-__device__ __forceinline__ void dx_load_tab_e(const DecIdxTables *T, uint2 *s_tab, uint32_t *s_long)
-{
-	for (int i = threadIdx.x; i < (1 << DX_KE); i += blockDim.x) s_tab[i] = T->emit11[i];
-	for (int i = threadIdx.x; i < DX_LONG11_MAX; i += blockDim.x) s_long[i] = T->long11[i];
-}
-__device__ __forceinline__ void dx_load_tables_wave_e(const DecIdxTables *T, uint2 *s_tab, uint32_t *s_long)
-{
-	const int lane = wave_lane();
-	for (int i = lane; i < (1 << DX_KE); i += 64) s_tab[i] = T->emit11[i];
-	for (int i = lane; i < DX_LONG11_MAX; i += 64) s_long[i] = T->long11[i];
-}
-
-// k_dec_index with the logs.  The extra candidates of a chunk without a unique alignment keep their entries AND their logs in alternate slots (while there
-// is room): when k_dec_chain finds one of them to be the true start, k_dec_reindex_emit copies both instead of walking the chunk again.
-__global__ void __launch_bounds__(DX_THREADS) CFHD_DX_INDEX_ATTR k_dec_index_emit(const DxChunkDesc *chunk_desc, const uint32_t *counters, const DecIdxTables *T,
-                                                               uint32_t *entries, DxChunkRec *recs, DxChunkAlt *alts, int speculate, uint32_t *stats, const DxRecords R,
-                                                               uint32_t *alt_entries, uint32_t alt_slots, uint32_t *alt_counter, uint32_t *next_chunk)
-{
-	__shared__ uint2 s_tab[1 << DX_KE];
-	__shared__ uint32_t s_long[DX_LONG11_MAX];
-	__shared__ uint32_t s_words_all[DX_WAVES][DX_STAGE_PHYS];
-	dx_load_tab_e(T, s_tab, s_long);
-	__syncthreads();
-	const uint32_t total = counters[0];
-	const int wave = wave_uniform((int)(threadIdx.x >> 6));
-	uint32_t *s_words = s_words_all[wave];
-	const uint32_t gwave = (uint32_t)blockIdx.x * DX_WAVES + (uint32_t)wave, nwaves = (uint32_t)gridDim.x * DX_WAVES;
-	uint32_t c = gwave;
-	if (c >= total) return;
-	DxChunkDesc d = chunk_desc[c];
-	DxFetch F;
-	dx_fetch_chunk(d.bits, d.bytes, d.k, F);
-#pragma unroll 1
-	for (; c < total;) {
-		dx_store_stage(F, s_words);
-		uint32_t c1 = 0;
-		if (wave_lane() == 0) c1 = nwaves + atomicAdd(next_chunk, 1u);
-		c1 = wave_get(c1, 0);
-		DxChunkDesc d1 = d;
-		if (c1 < total) { d1 = chunk_desc[c1]; dx_fetch_chunk(d1.bits, d1.bytes, d1.k, F); }
-		uint32_t cand[DX_MAX_ALT + 2] = { 0u, 0u, 0u, 0u, 0u };
-		int n = 1;
-		if (d.k != 0 && speculate) {
-			n = dx_runin_candidates_e(d.bytes, d.k, DX_RUNIN_SHORT, s_words, s_tab, s_long, cand);
-			if (n != 1) n = dx_runin_candidates_e(d.bytes, d.k, DX_LANE_BITS, s_words, s_tab, s_long, cand);
-		}
-		const bool linear = (d.quant_table & 1) != 0;
-		if (n == 0) {
-			if (wave_lane() == 0) recs[c] = DxChunkRec{ (uint32_t)DX_END, (uint32_t)DX_END, 0u, (uint32_t)DX_FLAG_END | (1u << 8) };
-		} else {
-			const bool unresolved = n > DX_MAX_ALT + 1;
-			if (unresolved) n = 1;
-			DxChunkRec r = dx_index_staged_e(d.bytes, c, d.k, cand[0], s_words, s_tab, s_long, linear, entries, R.log + (size_t)c * DX_LOG_CHUNK, R.nsteps, stats);
-			r.flags |= ((uint32_t)n << 8) | (unresolved ? (uint32_t)DX_FLAG_UNRESOLVED : 0u);
-			if (wave_lane() == 0) recs[c] = r;
-			if (n > 1) {
-				DxChunkAlt a;
-#pragma unroll
-				for (int i = 0; i < DX_MAX_ALT; i++) { a.start[i] = DX_BAD; a.end[i] = DX_BAD; a.count[i] = 0; }
-				uint32_t slot0 = DX_BAD;
-				if (alt_entries) {
-					if (wave_lane() == 0) slot0 = atomicAdd(alt_counter, (uint32_t)(n - 1));
-					slot0 = wave_get(slot0, 0);
-					if (slot0 + (uint32_t)(n - 1) > alt_slots) slot0 = DX_BAD;
-				}
-				a.slot = slot0;
-#pragma unroll 1
-				for (int i = 1; i < n; i++) {
-					const bool keep = slot0 != (uint32_t)DX_BAD;
-					const uint32_t at = keep ? slot0 + (uint32_t)(i - 1) : R.alt_spare;
-					const DxChunkRec ri = dx_index_staged_e(d.bytes, at, d.k, cand[i], s_words, s_tab, s_long, linear, keep ? alt_entries : nullptr, R.alt_log + (size_t)at * DX_LOG_CHUNK,
-					                                        keep ? R.alt_nsteps : nullptr, nullptr);
-#pragma unroll
-					for (int q = 0; q < DX_MAX_ALT; q++) if (q == i - 1) { a.start[q] = ri.start; a.end[q] = ri.end; a.count[q] = ri.count; }
-				}
-				if (wave_lane() == 0) alts[c] = a;
-				if (stats && wave_lane() == 0) atomicAdd(&stats[3], 1u << 16);
-			}
-		}
-		d = d1; c = c1;
-	}
-}
-
-// k_dec_repair / k_dec_reindex with the records (a chunk that is indexed again gets its records again)
-struct DxReindexEmit {
-	const DecIdxTables *T; uint2 *s_tab; uint32_t *s_long, *s_words, *entries; DxChunkRec *recs; DxRecords R; bool tables;
-	__device__ __forceinline__ DxChunkRec operator()(const DxBandJob &job, uint32_t gchunk, uint32_t k, uint32_t start)
-	{
-		if (!tables) { dx_load_tables_wave_e(T, s_tab, s_long); tables = true; CFHD_WAVE_SYNC(); }
-		return dx_index_chunk_e(job.bits, job.bytes, gchunk, k, start, s_words, s_tab, s_long, (job.table & 1) != 0, entries, recs, R, nullptr);
-	}
-};
-
-__global__ void __launch_bounds__(DX_THREADS) k_dec_repair_emit(const DxBandJob *jobs, const DecIdxTables *T, uint32_t *entries, DxChunkRec *recs, const DxChunkAlt *alts, uint32_t *chunk_base,
-                                                                DxBandSum *sums, int *errors, const uint32_t *repair_list, DxReindex *reindex_list, uint32_t *counters, const DxRecords R, uint32_t *stats)
-{
-	__shared__ uint2 s_tab[1 << DX_KE];
-	__shared__ uint32_t s_long[DX_LONG11_MAX];
-	__shared__ uint32_t s_words_all[DX_WAVES][DX_STAGE_PHYS];
-	const uint32_t n = counters[1];
-	const int wave = wave_uniform((int)(threadIdx.x >> 6));
-	for (uint32_t i = (uint32_t)blockIdx.x * DX_WAVES + (uint32_t)wave; i < n; i += (uint32_t)gridDim.x * DX_WAVES) {
-		const int j = (int)repair_list[i];
-		const DxBandJob job = jobs[j];
-		DxReindexEmit rx = { T, s_tab, s_long, s_words_all[wave], entries, recs, R, false };
-		(void)dx_chain_band<true>(job, j, rx, recs, alts, chunk_base, sums, errors, reindex_list, counters, stats);
-	}
-}
-
-__global__ void __launch_bounds__(DX_THREADS) k_dec_reindex_emit(const DxBandJob *jobs, const DecIdxTables *T, uint32_t *entries, const DxReindex *reindex_list, const uint32_t *counters,
-                                                                 const DxRecords R, uint32_t *stats, const DxChunkAlt *alts, const uint32_t *alt_entries)
-{
-	__shared__ uint2 s_tab[1 << DX_KE];
-	__shared__ uint32_t s_long[DX_LONG11_MAX];
-	__shared__ uint32_t s_words_all[DX_WAVES][DX_STAGE_PHYS];
-	const uint32_t n = counters[2];
-	if ((uint32_t)blockIdx.x * DX_WAVES >= n) return;
-	const int wave = wave_uniform((int)(threadIdx.x >> 6));
-	bool tables = false;
-	for (uint32_t i = (uint32_t)blockIdx.x * DX_WAVES + (uint32_t)wave; i < n; i += (uint32_t)gridDim.x * DX_WAVES) {
-		const DxReindex x = reindex_list[i];
-		// the usual case: k_dec_index_emit kept this candidate's entries and packed records -- copy them into the chunk's place
-		if (alts && alt_entries) {
-			const DxChunkAlt a = alts[x.chunk];
-			int q = -1;
-#pragma unroll
-			for (int k = 0; k < DX_MAX_ALT; k++) if (q < 0 && a.start[k] == x.start) q = k;
-			if (q >= 0 && a.slot != (uint32_t)DX_BAD) {
-				const int lane = wave_lane();
-				const size_t from = (size_t)a.slot + (size_t)q;
-				const uint4 *src = (const uint4 *)(alt_entries + from * DX_ENTRY_STRIDE);
-				uint4 *dst = (uint4 *)(entries + (size_t)x.chunk * DX_ENTRY_STRIDE);
-				if (lane >= 1) dst[lane] = src[lane];
-				if (lane >= 1) R.nsteps[(size_t)x.chunk * 64 + (size_t)lane] = R.alt_nsteps[from * 64 + (size_t)lane];
-				const uint4 *ls = (const uint4 *)(R.alt_log + from * DX_LOG_CHUNK); uint4 *ld = (uint4 *)(R.log + (size_t)x.chunk * DX_LOG_CHUNK);
-				for (int g = lane; g < DX_LOG_CHUNK / 4; g += 64) ld[g] = ls[g];
-				if (stats && lane == 0) atomicAdd(&stats[3], 1u << 8);
-				continue;
-			}
-		}
-		if (!tables) { dx_load_tables_wave_e(T, s_tab, s_long); tables = true; CFHD_WAVE_SYNC(); }
-		const DxBandJob job = jobs[x.job];
-		dx_index_chunk_e(job.bits, job.bytes, x.chunk, x.k, x.start, s_words_all[wave], s_tab, s_long, (job.table & 1) != 0, entries, nullptr, R, nullptr);
 		if (stats && wave_lane() == 0) atomicAdd(&stats[3], 1u << 8);
 	}
 }
@@ -1500,158 +1045,6 @@ __global__ void __launch_bounds__(DX_TILE_THREADS) k_dec_tiles(const DxBandJob *
 			CFHD_WAVE_SYNC();
 		}
 		M = M1; M1 = M2; P = P1;
-	}
-}
-
-// k_dec_scatter: the tile pass of the single-pass arrangement.  Same tiles, same output (dense 16-byte stores or block lists) and the same way of finding a tile's
-// first piece as k_dec_tiles, but no bit is looked at: a lane takes a piece's entry, its chunk's position and its step log (k_dec_index_emit), looks the steps' table
-// entries up again -- independent LDS reads -- and drops the values, times the band's divisor, into the LDS image of the tile.
-#ifndef CFHD_DX_SC_THREADS
-#define CFHD_DX_SC_THREADS 256
-#endif
-enum { DX_SC_THREADS = CFHD_DX_SC_THREADS, DX_SC_WAVES = DX_SC_THREADS / 64 };
-struct DxScPieces { uint32_t ent, cb, n, chunk, within; };      // n: steps in the piece's log
-__device__ __forceinline__ void dx_scatter_pieces(const DxTileMeta &M, uint32_t q, uint32_t last_sub, const uint32_t *entries, const uint32_t *chunk_base, const uint8_t *nstepb, DxScPieces &P)
-{
-	P.ent = DX_OFF_INVALID; P.cb = 0; P.n = 0; P.chunk = 0; P.within = 0;
-	if (q < last_sub) {
-		const uint32_t kq = q / DX_CHUNK_SUBS;
-		P.within = q - kq * DX_CHUNK_SUBS + DX_SUBS; P.chunk = M.job.chunk0 + kq;
-		const size_t idx = (size_t)P.chunk * DX_ENTRY_STRIDE + P.within;
-		P.ent = entries[idx];
-		P.cb = chunk_base[P.chunk];
-		P.n = nstepb[idx];
-	}
-}
-// The first DX_SC_PRE steps of a piece's log (a column of its chunk's log area: lane within / 4, piece within % 4), fetched a tile ahead; the rest -- rare -- on demand.
-enum { DX_SC_PRE = 12 };
-struct DxScLog { uint32_t g[DX_SC_PRE]; };
-__device__ __forceinline__ const uint16_t *dx_scatter_column(const DxRecords &R, const DxScPieces &P)
-{
-	return (const uint16_t *)R.log + (size_t)P.chunk * (2 * DX_LOG_CHUNK) + (size_t)(P.within & 3u) * DX_LOG_PIECE + (P.within >> 2);
-}
-__device__ __forceinline__ void dx_scatter_log(const DxRecords &R, const DxScPieces &P, DxScLog &G)
-{
-	const uint16_t *col = dx_scatter_column(R, P);
-	const uint32_t n = P.n;
-#pragma unroll
-	for (int sidx = 0; sidx < DX_SC_PRE; sidx++) G.g[sidx] = (uint32_t)sidx < n ? (uint32_t)col[sidx * 64] : 0u;
-}
-
-__global__ void __launch_bounds__(DX_SC_THREADS) k_dec_scatter(const DxBandJob *jobs, DxTilePlan plan, const DecIdxTables *T, const uint32_t *entries, const uint32_t *chunk_base, const DxBandSum *sums,
-                                                               const uint32_t *tile_start, const DxRecords R, unsigned long long *masks, uint32_t masks_per_frame)
-{
-	__shared__ uint2 s_tab[1 << DX_KE];
-	__shared__ uint32_t s_tile_all[DX_SC_WAVES][DX_TILE_WORDS];
-	for (int i = threadIdx.x; i < (1 << DX_KE); i += blockDim.x) s_tab[i] = T->emit11[i];
-	const int lane = wave_lane(), wave = wave_uniform((int)(threadIdx.x >> 6));
-	uint32_t *s_tile = s_tile_all[wave];
-	for (int i = lane; i < DX_TILE_WORDS; i += 64) s_tile[i] = 0u;
-	__syncthreads();
-	const uint32_t gwave = (uint32_t)blockIdx.x * DX_SC_WAVES + (uint32_t)wave, nwaves = (uint32_t)gridDim.x * DX_SC_WAVES;
-	uint32_t t = plan.first + gwave;
-	if (t >= plan.total) return;
-	const uint8_t *nstepb = (const uint8_t *)R.nsteps;
-	// What a tile waits for is a chain of three dependent fetches -- its descriptor, its pieces' entries, their logs -- and the second build of this kernel waited for the last
-	// of them inside every tile (9.6 us per tile and wave, whatever the work).  Three stages ahead instead: while tile t is filled, the logs of tile t + nwaves, the entries of
-	// tile t + 2 nwaves and the descriptor of tile t + 3 nwaves are on their way, each requested from what arrived during the tile before.
-	int slot = 0;
-	auto pieces_of = [&](const DxTileMeta &m, bool there, DxScPieces &p) {
-		const bool w = there && dx_tile_has_work(m);
-		dx_scatter_pieces(m, w ? m.first_sub + (uint32_t)lane : 0xFFFFFFFFu, w ? dx_tile_last_sub(m) : 0u, entries, chunk_base, nstepb, p);
-	};
-	DxTileMeta M, M1, M2;
-	dx_tile_meta(plan, t, slot, jobs, sums, tile_start, M, masks, masks_per_frame);
-	M1 = M; M2 = M;
-	if (t + nwaves < plan.total) dx_tile_meta(plan, t + nwaves, slot, jobs, sums, tile_start, M1, masks, masks_per_frame);
-	if (t + 2 * nwaves < plan.total) dx_tile_meta(plan, t + 2 * nwaves, slot, jobs, sums, tile_start, M2, masks, masks_per_frame);
-	DxScPieces P, P1;
-	pieces_of(M, true, P);
-	pieces_of(M1, t + nwaves < plan.total, P1);
-	DxScLog G;
-	dx_scatter_log(R, P, G);
-	int16_t *tile16 = (int16_t *)s_tile;
-	const uint32_t dump = (uint32_t)DX_TILE + (uint32_t)lane;
-#pragma unroll 1
-	for (; t < plan.total; t += nwaves) {
-		DxTileMeta M3 = M2;
-		DxScPieces P2;
-		DxScLog G1;
-		dx_scatter_log(R, P1, G1);
-		pieces_of(M2, t + 2 * nwaves < plan.total, P2);
-		if (t + 3 * nwaves < plan.total) dx_tile_meta(plan, t + 3 * nwaves, slot, jobs, sums, tile_start, M3, masks, masks_per_frame);
-		const DxBandJob job = dx_uniform(M.job);
-		const uint32_t first_sub = (uint32_t)wave_uniform((int)M.first_sub);
-		const uint32_t T0 = M.ti * DX_TILE, T1 = T0 + DX_TILE < (uint32_t)job.n ? T0 + DX_TILE : (uint32_t)job.n;
-		if (job.bytes != 0u && T0 < (uint32_t)job.n) {
-			if (first_sub != DX_TILE_EMPTY) {
-				const uint32_t last_sub = (uint32_t)wave_uniform((int)dx_tile_last_sub(M));
-				const uint32_t quant = (uint32_t)job.quant;
-#pragma unroll 1
-				for (uint32_t q0 = first_sub; q0 < last_sub; q0 += 64) {
-					const uint32_t q = q0 + (uint32_t)lane;
-					const bool active = q < last_sub;
-					if (q0 != first_sub) { dx_scatter_pieces(M, q, last_sub, entries, chunk_base, nstepb, P); dx_scatter_log(R, P, G); }      // further rounds: a dense tile (more than 64 pieces)
-					const uint32_t off = P.ent & 31u;
-					const uint32_t idx0 = P.cb + (P.ent >> 5);
-					const bool valid = active && off != (uint32_t)DX_OFF_INVALID;
-					const bool inside = valid && idx0 < T1;
-					const uint32_t n = inside ? (P.n <= (uint32_t)DX_REC_MAX ? P.n : (uint32_t)DX_REC_MAX) : 0u;
-					uint32_t rel = idx0 - T0;                          // "negative" (the piece starts in front of the tile) wraps to a huge number: those places go to the dump slot
-					const uint16_t *col = dx_scatter_column(R, P);
-#pragma unroll
-					for (int sidx = 0; sidx < DX_LOG_STEPS; sidx++) {
-						if (__ballot((uint32_t)sidx < n) == 0ull) break;          // (wave-uniform: the longest log of the round)
-						uint32_t w;
-						if (sidx < DX_SC_PRE) w = G.g[sidx]; else w = (uint32_t)sidx < n ? (uint32_t)col[sidx * 64] : 0u;
-						const uint32_t kind = w >> 14;
-						const uint2 e = s_tab[w & ((1u << DX_KE) - 1u)];
-						const bool group = kind == (uint32_t)DX_LOG_GROUP;
-						uint32_t nv = group ? (e.y >> 28) & 3u : (e.y >> 30) & 1u, add = group ? e.x >> 20 : (e.x >> 8) & 0xfffu, o1 = e.y & 0xffu;
-						int v1 = dx_sext6(e.y, 16);
-						if (kind >= (uint32_t)DX_LOG_VALUE) {
-							const bool isval = kind == (uint32_t)DX_LOG_VALUE;
-							nv = isval ? 1u : 0u; add = isval ? 1u : w & 0x3fffu; o1 = 0u;
-							v1 = (int)(w << 18) >> 18;
-						}
-						const bool live = (uint32_t)sidx < n;
-						const uint32_t p1 = rel + o1, p2 = rel + ((e.y >> 8) & 0xffu);
-						tile16[(live && nv >= 1u && p1 < dump) ? p1 : dump] = (int16_t)mul_u24((uint32_t)v1, quant);
-						tile16[(live && nv == 2u && p2 < dump) ? p2 : dump] = (int16_t)mul_u24((uint32_t)dx_sext6(e.y, 22), quant);
-						rel += live ? add : 0u;
-					}
-					if (__ballot(valid && !inside) || !__ballot(active)) break;
-				}
-			}
-			CFHD_WAVE_SYNC();
-			uint4 *dst = (uint4 *)(job.dst + T0);
-			const uint32_t n16 = (T1 - T0) / 8;
-			const uint4 zero = { 0u, 0u, 0u, 0u };
-			unsigned long long *const tmasks = wave_uniform_ptr(M.masks);
-			if (tmasks) {
-				const uint32_t chunk0 = T0 / 512u;
-#pragma unroll
-				for (uint32_t it = 0; it < (uint32_t)DX_TILE / 512u; it++) {
-					const uint32_t i = it * 64u + (uint32_t)lane;
-					const uint4 v = ((const uint4 *)s_tile)[i];
-					((uint4 *)s_tile)[i] = zero;
-					const bool nz = i < n16 && (v.x | v.y | v.z | v.w) != 0u;
-					const unsigned long long m = __ballot(nz);
-					if (nz) dst[it * 64u + wave_mbcnt(m)] = v;
-					if (lane == 0 && it * 64u < n16) tmasks[chunk0 + it] = m;
-				}
-			} else {
-#pragma unroll
-				for (uint32_t it = 0; it < (uint32_t)DX_TILE / 512u; it++) {
-					const uint32_t i = it * 64u + (uint32_t)lane;
-					const uint4 v = ((const uint4 *)s_tile)[i];
-					((uint4 *)s_tile)[i] = zero;
-					if (i < n16) dst[i] = v;
-				}
-			}
-			CFHD_WAVE_SYNC();
-		}
-		M = M1; M1 = M2; M2 = M3; P = P1; P1 = P2; G = G1;
 	}
 }
 

@@ -133,8 +133,6 @@ private:
 	bool lane_kernel_ = false;
 	// cfhd_dec_kernels.h (default): chunk index + tile decode.  CFHD_AMD_DEC=par / lane select the round-1 kernels for A/B runs.
 	bool dx_ = true;
-	// ... and its single-pass arrangement (k_dec_index_emit + k_dec_scatter): record slots per 64-bit piece, record counts
-	bool emit_ = false; void *d_log_ = nullptr, *d_nsteps_ = nullptr, *d_alt_log_ = nullptr, *d_alt_nsteps_ = nullptr;
 	void *d_tile_start_ = nullptr, *d_stats_ = nullptr, *d_repair_ = nullptr, *d_alts_ = nullptr, *d_reindex_ = nullptr, *d_alt_entries_ = nullptr; uint32_t alt_slots_ = 0;
 	void *d_idx_tables_ = nullptr, *d_entries_ = nullptr, *d_recs_ = nullptr, *d_chunk_base_ = nullptr, *d_chunk_job_ = nullptr, *d_sums_ = nullptr, *d_counters_ = nullptr;
 	uint32_t max_chunks_ = 0, *h_counters_ = nullptr; void *h_chunk_job_ = nullptr;

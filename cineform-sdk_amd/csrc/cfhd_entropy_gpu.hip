@@ -282,8 +282,8 @@ GpuEntropyDecoder::~GpuEntropyDecoder() { release(); delete host_; }
 void GpuEntropyDecoder::release()
 {
 	(void)hipSetDevice(device_);
-	void *dev[] = { d_samples_, d_tables_, d_bandjobs_, d_lowjobs_, d_errors_, d_plan_, d_idx_tables_, d_entries_, d_recs_, d_chunk_base_, d_chunk_job_, d_sums_, d_counters_, d_tile_start_, d_stats_, d_repair_, d_alts_, d_reindex_, d_diffjobs_, d_alt_entries_, d_masks_, d_log_, d_nsteps_, d_alt_log_, d_alt_nsteps_ };
-	d_masks_ = nullptr; d_log_ = d_nsteps_ = d_alt_log_ = d_alt_nsteps_ = nullptr; masks_per_frame_ = 0; use_blocks_ = false; blocks_written_ = false;
+	void *dev[] = { d_samples_, d_tables_, d_bandjobs_, d_lowjobs_, d_errors_, d_plan_, d_idx_tables_, d_entries_, d_recs_, d_chunk_base_, d_chunk_job_, d_sums_, d_counters_, d_tile_start_, d_stats_, d_repair_, d_alts_, d_reindex_, d_diffjobs_, d_alt_entries_, d_masks_ };
+	d_masks_ = nullptr; masks_per_frame_ = 0; use_blocks_ = false; blocks_written_ = false;
 	for (void *p : dev) if (p) (void)hipFree(p);
 	d_idx_tables_ = d_entries_ = d_recs_ = d_chunk_base_ = d_chunk_job_ = d_sums_ = d_counters_ = d_tile_start_ = d_stats_ = d_repair_ = d_alts_ = d_reindex_ = d_diffjobs_ = d_alt_entries_ = nullptr;
 	if (h_chunk_job_) (void)hipHostFree(h_chunk_job_);
@@ -323,8 +323,7 @@ int GpuEntropyDecoder::prepare(const FramePlan &plan, int nframes, int16_t *d_co
 	HIPCHK(hipMalloc((void **)&d_errors_, sizeof(int)));
 	HIPCHK(hipHostMalloc((void **)&h_errors_, sizeof(int), hipHostMallocPortable));
 	*h_errors_ = 0;
-	{ const char *e = getenv("CFHD_AMD_DEC"); lane_kernel_ = e && strcmp(e, "lane") == 0; dx_ = !(e && (strcmp(e, "lane") == 0 || strcmp(e, "par") == 0));   // A/B switches: the round-1 kernels,
-	  emit_ = dx_ && e && strcmp(e, "emit") == 0; }                                                                                                              // the single-pass arrangement of round 5
+	{ const char *e = getenv("CFHD_AMD_DEC"); lane_kernel_ = e && strcmp(e, "lane") == 0; dx_ = !(e && (strcmp(e, "lane") == 0 || strcmp(e, "par") == 0)); }   // A/B switch: the round-1 kernels
 	if (dx_) {
 		dev::DecIdxTables *it = new dev::DecIdxTables;
 		const bool ok = build_dec_index_tables(1, it);
@@ -346,14 +345,6 @@ int GpuEntropyDecoder::prepare(const FramePlan &plan, int nframes, int16_t *d_co
 		HIPCHK(hipMalloc(&d_reindex_, (size_t)max_chunks_ * sizeof(dev::DxReindex)));
 		alt_slots_ = max_chunks_ / 8 > 64u ? max_chunks_ / 8 : 64u;          // entries of the extra candidates of chunks without a unique alignment (a few per cent of the chunks)
 		HIPCHK(hipMalloc(&d_alt_entries_, (size_t)alt_slots_ * dev::DX_ENTRY_STRIDE * 4));
-		if (emit_) {
-			// two 32-byte step-log slots per 64-bit piece of the worst-case sample (16 KB per chunk; only the first slots of real pieces are ever touched, the second
-			// slots by pieces of more than sixteen steps) and a byte per piece for its length; the same for the alternate slots + one spare chunk of logs
-			HIPCHK(hipMalloc(&d_log_, (size_t)max_chunks_ * dev::DX_LOG_CHUNK * 4));
-			HIPCHK(hipMalloc(&d_nsteps_, (size_t)max_chunks_ * 64 * 4));
-			HIPCHK(hipMalloc(&d_alt_log_, ((size_t)alt_slots_ + 1) * dev::DX_LOG_CHUNK * 4));
-			HIPCHK(hipMalloc(&d_alt_nsteps_, (size_t)alt_slots_ * 64 * 4));
-		}
 		{
 			dev::DecPlan dp0; dec_build_plan(plan, out_kind, &dp0);
 			const dev::DxTilePlan tp0 = dx_tile_plan(plan, dp0, n_, false);
@@ -365,9 +356,7 @@ int GpuEntropyDecoder::prepare(const FramePlan &plan, int nframes, int16_t *d_co
 		HIPCHK(hipHostMalloc((void **)&h_counters_, 32, hipHostMallocPortable));
 		int cus = 256;
 		(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_current());
-		const char *g3 = nullptr;
 		grid_index_ = cus * 5; grid_tiles_ = cus * (dev::DX_TILE_THREADS >= 1024 ? 1 : 2);      // workgroups that fit a CU at once (LDS: ~30 KB / ~150 KB each)
-		if (emit_ && !g3) grid_tiles_ = cus * (int)((160 * 1024) / (sizeof(uint2) * (1 << dev::DX_KE) + sizeof(uint32_t) * dev::DX_TILE_WORDS * dev::DX_SC_WAVES));      // k_dec_scatter: the table + 8 KB of LDS per wave
 		if (grid_index_ < 1) grid_index_ = 1;
 		if (grid_tiles_ < 1) grid_tiles_ = 1;
 	}
@@ -560,30 +549,20 @@ int GpuEntropyDecoder::launch_dx(bool device_jobs, int njobs, uint32_t host_chun
 	const uint32_t chunk_bound = device_jobs ? max_chunks_ : host_chunks;
 	int g1 = grid_index_, g3 = grid_tiles_;
 	if ((uint32_t)g1 * dev::DX_WAVES > chunk_bound) g1 = (int)((chunk_bound + dev::DX_WAVES - 1) / dev::DX_WAVES);
-	const uint32_t tile_waves = emit_ ? (uint32_t)dev::DX_SC_WAVES : (uint32_t)dev::DX_TILE_WAVES;
+	const uint32_t tile_waves = (uint32_t)dev::DX_TILE_WAVES;
 	if ((uint32_t)g3 * tile_waves > tp.total) g3 = (int)((tp.total + tile_waves - 1) / tile_waves);
 	if (g1 < 1) g1 = 1;
 	if (g3 < 1) g3 = 1;
-	const dev::DxRecords R = { (uint32_t *)d_log_, (uint32_t *)d_nsteps_, (uint32_t *)d_alt_log_, (uint32_t *)d_alt_nsteps_, alt_slots_ };
-	if (emit_) dev::k_dec_index_emit<<<g1, dev::DX_THREADS, 0, st>>>((const dev::DxChunkDesc *)d_chunk_job_, (const uint32_t *)d_counters_, T, (uint32_t *)d_entries_, (dev::DxChunkRec *)d_recs_, (dev::DxChunkAlt *)d_alts_,
-	                                                                 speculate ? 1 : 0, (uint32_t *)d_stats_, R, (uint32_t *)d_alt_entries_, alt_slots_, (uint32_t *)d_counters_ + 3, (uint32_t *)d_counters_ + 4);
-	else dev::k_dec_index<<<g1, dev::DX_THREADS, 0, st>>>((const dev::DxChunkDesc *)d_chunk_job_, (const uint32_t *)d_counters_, T, (uint32_t *)d_entries_, (dev::DxChunkRec *)d_recs_, (dev::DxChunkAlt *)d_alts_, speculate ? 1 : 0, (uint32_t *)d_stats_,
+	dev::k_dec_index<<<g1, dev::DX_THREADS, 0, st>>>((const dev::DxChunkDesc *)d_chunk_job_, (const uint32_t *)d_counters_, T, (uint32_t *)d_entries_, (dev::DxChunkRec *)d_recs_, (dev::DxChunkAlt *)d_alts_, speculate ? 1 : 0, (uint32_t *)d_stats_,
 	                                                 (uint32_t *)d_alt_entries_, alt_slots_, (uint32_t *)d_counters_ + 3, (uint32_t *)d_counters_ + 4);
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[5], st));
 	dev::k_dec_chain<<<(njobs + dev::DX_WAVES - 1) / dev::DX_WAVES, dev::DX_THREADS, 0, st>>>(jobs, njobs, (const dev::DxChunkRec *)d_recs_, (const dev::DxChunkAlt *)d_alts_, (uint32_t *)d_chunk_base_,
 	                                                                                            (dev::DxBandSum *)d_sums_, d_errors_, (uint32_t *)d_repair_, (dev::DxReindex *)d_reindex_, (uint32_t *)d_counters_);
 	const int small_grid = njobs < 256 ? (njobs + dev::DX_WAVES - 1) / dev::DX_WAVES : 64;
-	if (emit_) {
-		dev::k_dec_repair_emit<<<small_grid, dev::DX_THREADS, 0, st>>>(jobs, T, (uint32_t *)d_entries_, (dev::DxChunkRec *)d_recs_, (const dev::DxChunkAlt *)d_alts_, (uint32_t *)d_chunk_base_, (dev::DxBandSum *)d_sums_,
-		                                                              d_errors_, (const uint32_t *)d_repair_, (dev::DxReindex *)d_reindex_, (uint32_t *)d_counters_, R, (uint32_t *)d_stats_);
-		dev::k_dec_reindex_emit<<<g1, dev::DX_THREADS, 0, st>>>(jobs, T, (uint32_t *)d_entries_, (const dev::DxReindex *)d_reindex_, (const uint32_t *)d_counters_, R, (uint32_t *)d_stats_,
-		                                                        (const dev::DxChunkAlt *)d_alts_, (const uint32_t *)d_alt_entries_);
-	} else {
 	dev::k_dec_repair<<<small_grid, dev::DX_THREADS, 0, st>>>(jobs, T, (uint32_t *)d_entries_, (dev::DxChunkRec *)d_recs_, (const dev::DxChunkAlt *)d_alts_, (uint32_t *)d_chunk_base_, (dev::DxBandSum *)d_sums_,
 	                                                         d_errors_, (const uint32_t *)d_repair_, (dev::DxReindex *)d_reindex_, (uint32_t *)d_counters_, (uint32_t *)d_stats_);
 	dev::k_dec_reindex<<<g1, dev::DX_THREADS, 0, st>>>(jobs, T, (uint32_t *)d_entries_, (const dev::DxReindex *)d_reindex_, (const uint32_t *)d_counters_, (uint32_t *)d_stats_,
 	                                                   (const dev::DxChunkAlt *)d_alts_, (const uint32_t *)d_alt_entries_);
-	}
 	dev::k_dec_tile_index<<<(tp.total + dev::DX_THREADS - 1) / dev::DX_THREADS, dev::DX_THREADS, 0, st>>>(jobs, tp, (const uint32_t *)d_entries_, (const uint32_t *)d_chunk_base_, (const dev::DxBandSum *)d_sums_,
 	                                                                                                  (uint32_t *)d_tile_start_);
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[6], st));
@@ -594,8 +573,7 @@ int GpuEntropyDecoder::launch_dx(bool device_jobs, int njobs, uint32_t host_chun
 	const char *split_env = getenv("CFHD_AMD_TILES_SPLIT");
 	l23_split_ = frames >= 8 && !skip_level1_ && tp.split > 0 && tp.split < tp.total && split_env && split_env[0] == '1';
 	auto tile_pass = [&](const dev::DxTilePlan &p, int g) {
-		if (emit_) dev::k_dec_scatter<<<g < 1 ? 1 : g, dev::DX_SC_THREADS, 0, st>>>(jobs, p, T, (const uint32_t *)d_entries_, (const uint32_t *)d_chunk_base_, (const dev::DxBandSum *)d_sums_, (const uint32_t *)d_tile_start_, R, tmasks, (uint32_t)masks_per_frame_);
-		else dev::k_dec_tiles<<<g < 1 ? 1 : g, dev::DX_TILE_THREADS, 0, st>>>(jobs, p, T, (const uint32_t *)d_entries_, (const uint32_t *)d_chunk_base_, (const dev::DxBandSum *)d_sums_, (const uint32_t *)d_tile_start_, tmasks, (uint32_t)masks_per_frame_);
+		dev::k_dec_tiles<<<g < 1 ? 1 : g, dev::DX_TILE_THREADS, 0, st>>>(jobs, p, T, (const uint32_t *)d_entries_, (const uint32_t *)d_chunk_base_, (const dev::DxBandSum *)d_sums_, (const uint32_t *)d_tile_start_, tmasks, (uint32_t)masks_per_frame_);
 	};
 	if (l23_split_) {
 		dev::DxTilePlan ta = tp, tb = tp;

@@ -209,23 +209,6 @@ inline bool build_dec_index_tables(int codebook, dev::DecIdxTables *T)
 		// (windows that are no prefix of any code word keep y = 0: type DX_T_INVALID)
 		for (uint32_t win = 0; win < (1u << DX_KM); win++) if ((T->multi[win].x & 15u) == 0 && (T->multi[win].x & 0xffffu)) return false;   // (a window nothing fits into covers no coefficients)
 	}
-	// k_dec_index_emit: per 11-bit window the first code word and the group of multi[] side by side (one LDS read per step whichever the step takes)
-	for (uint32_t win = 0; win < (1u << DX_KE); win++) {
-		static_assert(DX_KE == DX_KM, "emit11[] is built from multi[]: the same window");
-		const uint2 m = T->multi[win];
-		const uint32_t used = m.x & 15u, total = (m.x >> 4) & 0xfffu, o1 = m.x >> 16, o2 = m.y & 0xffffu;
-		const int v1 = (int)(int8_t)(m.y >> 16), v2 = (int)(int8_t)(m.y >> 24);
-		if (!used) { T->emit11[win].x = 0u; T->emit11[win].y = m.y; continue; }       // nothing fits: the long entry / escape of the first code word, as multi[] holds it
-		const uint16_t e = T->sym12[win << (DX_K - DX_KE)];
-		const uint32_t len = e & 15u, isval = (e >> 4) & 1u, len1 = len + isval, cover1 = isval ? 1u : (uint32_t)(e >> 5);
-		const uint32_t nval = (o1 != (uint32_t)DX_NO_VALUE ? 1u : 0u) + (o2 != (uint32_t)DX_NO_VALUE ? 1u : 0u);
-		if (!len || len1 > (uint32_t)DX_KE || len1 > used || cover1 > 0xfffu || total > 0xfffu) return false;
-		if ((nval >= 1 && o1 > 0xffu) || (nval == 2 && o2 > 0xffu) || v1 < -32 || v1 > 31 || v2 < -32 || v2 > 31) return false;
-		if (isval && (nval < 1 || o1 != 0u)) return false;            // a first code word that is a value is the group's first value, at the position in front of the step
-		if (o2 != (uint32_t)DX_NO_VALUE && o1 == (uint32_t)DX_NO_VALUE) return false;
-		T->emit11[win].x = len1 | (used << 4) | (cover1 << 8) | (total << 20);
-		T->emit11[win].y = (nval >= 1 ? o1 : 0u) | ((nval == 2 ? o2 : 0u) << 8) | (((uint32_t)v1 & 63u) << 16) | (((uint32_t)v2 & 63u) << 22) | (nval << 28) | (isval << 30);
-	}
 	return true;
 }
 

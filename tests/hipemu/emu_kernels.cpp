@@ -699,8 +699,6 @@ extern "C" int emu_entropy_decode_dx(const uint8_t *sample, size_t size, int pix
 {
 	memset(g_dx_stats, 0, sizeof(g_dx_stats));
 	using namespace cfhd;
-	const bool emit = (mode & 16) != 0;                  // + 16: the single-pass arrangement (k_dec_index_emit / k_dec_scatter) in place of k_dec_index / k_dec_tiles
-	mode &= 15;
 	ParsedSample ps;
 	if (parse_sample(sample, size, &ps) != 0) return -1;
 	FramePlan plan;
@@ -747,26 +745,15 @@ extern "C" int emu_entropy_decode_dx(const uint8_t *sample, size_t size, int pix
 	counters[1] = 0; counters[2] = 0; counters[3] = 0; counters[4] = 0;
 	const uint32_t alt_slots = 3;                       // room for the candidates of one or two chunks only: both ways of k_dec_reindex (copy, index again) are exercised
 	std::vector<uint32_t> alt_entries((size_t)alt_slots * dev::DX_ENTRY_STRIDE + 16, 0xdeadbeefu);
-	// the record slots of the single-pass arrangement: one chunk's worth more as scratch, every word poisoned (a record the scatter pass reads must have been written by the walk)
-	std::vector<uint32_t> steplog(emit ? (size_t)nchunks * dev::DX_LOG_CHUNK + 16 : 0, 0xdeaddeadu), nsteps(emit ? (size_t)nchunks * 64 + 16 : 0, 0xffffffffu);
-	std::vector<uint32_t> alt_log(emit ? ((size_t)alt_slots + 1) * dev::DX_LOG_CHUNK + 16 : 0, 0xdeaddeadu), alt_nsteps(emit ? (size_t)alt_slots * 64 + 16 : 0, 0xffffffffu);
-	const dev::DxRecords R = { steplog.data(), nsteps.data(), alt_log.data(), alt_nsteps.data(), alt_slots };
-	if (emit) hipemu::launch(dim3((unsigned)grid), dim3(dev::DX_THREADS), [&] { dev::k_dec_index_emit(chunk_job.data(), counters.data(), &tables, entries.data(), recs.data(), alts.data(), mode != 1, g_dx_stats, R, alt_entries.data(), alt_slots, &counters[3], &counters[4]); });
-	else hipemu::launch(dim3((unsigned)grid), dim3(dev::DX_THREADS), [&] { dev::k_dec_index(chunk_job.data(), counters.data(), &tables, entries.data(), recs.data(), alts.data(), mode != 1, g_dx_stats, alt_entries.data(), alt_slots, &counters[3], &counters[4]); });
+	hipemu::launch(dim3((unsigned)grid), dim3(dev::DX_THREADS), [&] { dev::k_dec_index(chunk_job.data(), counters.data(), &tables, entries.data(), recs.data(), alts.data(), mode != 1, g_dx_stats, alt_entries.data(), alt_slots, &counters[3], &counters[4]); });
 	hipemu::launch(dim3((unsigned)(njobs + dev::DX_WAVES - 1) / dev::DX_WAVES), dim3(dev::DX_THREADS), [&] { dev::k_dec_chain(jobs.data(), njobs, recs.data(), alts.data(), chunk_base.data(), sums.data(), &errors, repair_list.data(), reindex.data(), counters.data()); });
-	if (emit) {
-		hipemu::launch(dim3(2), dim3(dev::DX_THREADS), [&] { dev::k_dec_repair_emit(jobs.data(), &tables, entries.data(), recs.data(), alts.data(), chunk_base.data(), sums.data(), &errors, repair_list.data(), reindex.data(), counters.data(), R, g_dx_stats); });
-		hipemu::launch(dim3(3), dim3(dev::DX_THREADS), [&] { dev::k_dec_reindex_emit(jobs.data(), &tables, entries.data(), reindex.data(), counters.data(), R, g_dx_stats, alts.data(), alt_entries.data()); });
-	} else {
-		hipemu::launch(dim3(2), dim3(dev::DX_THREADS), [&] { dev::k_dec_repair(jobs.data(), &tables, entries.data(), recs.data(), alts.data(), chunk_base.data(), sums.data(), &errors, repair_list.data(), reindex.data(), counters.data(), g_dx_stats); });
-		hipemu::launch(dim3(3), dim3(dev::DX_THREADS), [&] { dev::k_dec_reindex(jobs.data(), &tables, entries.data(), reindex.data(), counters.data(), g_dx_stats, alts.data(), alt_entries.data()); });
-	}
+	hipemu::launch(dim3(2), dim3(dev::DX_THREADS), [&] { dev::k_dec_repair(jobs.data(), &tables, entries.data(), recs.data(), alts.data(), chunk_base.data(), sums.data(), &errors, repair_list.data(), reindex.data(), counters.data(), g_dx_stats); });
+	hipemu::launch(dim3(3), dim3(dev::DX_THREADS), [&] { dev::k_dec_reindex(jobs.data(), &tables, entries.data(), reindex.data(), counters.data(), g_dx_stats, alts.data(), alt_entries.data()); });
 	g_dx_stats[12] = counters[1]; g_dx_stats[13] = counters[2];
 	std::vector<uint32_t> tile_start(tp.total + 1, 0xdeadbeefu);
 	hipemu::launch(dim3((tp.total + dev::DX_THREADS - 1) / dev::DX_THREADS), dim3(dev::DX_THREADS), [&] { dev::k_dec_tile_index(jobs.data(), tp, entries.data(), chunk_base.data(), sums.data(), tile_start.data()); });
 	auto tile_pass = [&](const dev::DxTilePlan &p_, unsigned long long *m_, uint32_t per_) {
-		if (emit) hipemu::launch(dim3((unsigned)grid), dim3(dev::DX_SC_THREADS), [&] { dev::k_dec_scatter(jobs.data(), p_, &tables, entries.data(), chunk_base.data(), sums.data(), tile_start.data(), R, m_, per_); });
-		else hipemu::launch(dim3((unsigned)grid), dim3(dev::DX_TILE_THREADS), [&] { dev::k_dec_tiles(jobs.data(), p_, &tables, entries.data(), chunk_base.data(), sums.data(), tile_start.data(), m_, per_); });
+		hipemu::launch(dim3((unsigned)grid), dim3(dev::DX_TILE_THREADS), [&] { dev::k_dec_tiles(jobs.data(), p_, &tables, entries.data(), chunk_base.data(), sums.data(), tile_start.data(), m_, per_); });
 	};
 	tile_pass(tp, nullptr, 0u);
 	if (!plan.interlaced && plan.encoded_format == ENC_YUV422) {

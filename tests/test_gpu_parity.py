@@ -343,8 +343,7 @@ def test_gpu_entropy_and_host_entropy_paths_agree():
         assert mask_volatile_metadata(x) == mask_volatile_metadata(y)
 
 
-@pytest.mark.parametrize("handoff,decoder", [("device", "dx"), ("host", "dx"), ("device", "dx-repair"), ("device", "par"), ("host", "par"), ("host", "lane"),
-                                             ("device", "emit"), ("host", "emit"), ("device", "emit-repair")])      # emit: the single-pass arrangement of round 5 (k_dec_index_emit + k_dec_scatter)
+@pytest.mark.parametrize("handoff,decoder", [("device", "dx"), ("host", "dx"), ("device", "dx-repair"), ("device", "par"), ("host", "par"), ("host", "lane")])
 def test_batched_device_resident_round_trip(handoff, decoder):
     """cfhd_amd_batch_* (what bench.py times): several chunks on their own streams; every sample must equal oracle transform +
     product syntax, every decoded frame must lie in the oracle's dither interval of its own sample.  handoff=device: the decoder

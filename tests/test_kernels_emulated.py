@@ -839,13 +839,13 @@ def test_fwd_frame_yuv422_interlaced_level1(w, h, dh, uyvy):
 # ---------------------------------------------------------------------------------------------------------------
 # Round-2 decoder (cfhd_dec_kernels.h: k_dec_plan / k_dec_index / k_dec_chain / k_dec_tiles), same kernel source under emulation
 # ---------------------------------------------------------------------------------------------------------------
-DX_ARRANGEMENT = 0      # + 16: the single-pass arrangement (k_dec_index_emit / k_dec_scatter); set per test by the `arrangement` fixture
+DX_ARRANGEMENT = 0      # bits added to the mode of emu_entropy_decode_dx; set per test by the `arrangement` fixture
 
 
-@pytest.fixture(params=[0, 16], ids=["index+tiles", "emit+scatter"])
+@pytest.fixture(params=[0], ids=["index+tiles"])
 def arrangement(request):
-    """Both arrangements of the chunk-indexed decoder run every test of this section: the two-pass one (k_dec_index / k_dec_tiles) and the single-pass one of round 5
-    (k_dec_index_emit leaves the values as records per 64-bit piece, k_dec_scatter turns pieces into tiles)."""
+    """The arrangements of the chunk-indexed decoder that run every test of this section (one since round 6: the single-pass experiment of round 5 -- index walk that
+    logs its steps + a scatter pass -- was measured four times, never adopted and has left the tree; profiles/r05_a..e_*)."""
     global DX_ARRANGEMENT
     DX_ARRANGEMENT = request.param
     yield request.param
