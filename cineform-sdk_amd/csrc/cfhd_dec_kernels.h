@@ -28,14 +28,17 @@
 #include <stdint.h>
 #include "cfhd_entropy_kernels.h"
 
-// k_dec_tiles: a wave owns a tile of 4096 coefficients (8 KB of LDS), sixteen waves -- one workgroup per CU -- share the tables.  Ordinary
-// pictures spend about 0.9 payload bits per coefficient: a tile of 2048 (round 2) met ~29 pieces of 64 bits, so that fewer than half of a wave's
-// lanes had a piece to decode (SQ counters, profiles/r03_a_*: 19.6 active lanes per vector instruction); with 4096 it is ~58.
+// k_dec_tiles (round 6): a WORKGROUP owns a tile -- up to DX_TILE consecutive coefficients of a band, assembled in one LDS image -- and its waves share the
+// pieces that reach into it, 64 consecutive pieces per wave and round.  Rounds 2-5 gave every wave its own tile of 4096 coefficients; measured on the bench's
+// Qbist samples (tools/dx_walk_stats.py) the level-1 bands spend 0.38 payload bits per coefficient, so such a tile met 21 pieces: two thirds of the lanes of
+// three quarters of the tiles had nothing to decode, while the pieces themselves are even (5-9 table lookups each).  What bounds the pieces in flight on a CU is
+// the LDS that holds their output, so the image is now shared: 15360 coefficients (30 KB) meet ~90 level-1 pieces = one full wave and a half, three workgroups
+// fit a CU beside their tables, and the waves without pieces only help to stream the tile out.
 #ifndef CFHD_DX_TILE
-#define CFHD_DX_TILE 4096
+#define CFHD_DX_TILE 15360
 #endif
 #ifndef CFHD_DX_TILE_THREADS
-#define CFHD_DX_TILE_THREADS 1024
+#define CFHD_DX_TILE_THREADS 256
 #endif
 
 namespace cfhd {
@@ -64,11 +67,11 @@ enum {
 	DX_STAGE_WORDS = 64 * (DX_LANE_BITS / 32) + 2, // payload words of a chunk + run-in lane + two words of look-ahead
 	DX_LONG_MAX = 1408,               // entries of the second / third level tables (code words of 13..26 bits)
 	DX_L2_BITS = 7,
-	DX_TILE = CFHD_DX_TILE,           // coefficients per output tile
+	DX_TILE = CFHD_DX_TILE,           // most coefficients of an output tile (a multiple of 512: the chunks of the block lists); DxTilePlan::tile_len says how long the tiles of a band are
 	DX_THREADS = 256, DX_WAVES = DX_THREADS / 64,
-	DX_TILE_THREADS = CFHD_DX_TILE_THREADS, DX_TILE_WAVES = DX_TILE_THREADS / 64,      // k_dec_tiles: its waves share the tables
+	DX_TILE_THREADS = CFHD_DX_TILE_THREADS, DX_TILE_WAVES = DX_TILE_THREADS / 64,      // k_dec_tiles: the waves of a workgroup share the tables and the tile
 	DX_KM = 11,                       // bits of the window of the multi-symbol table of k_dec_tiles
-	DX_NO_VALUE = 0x8000,             // multi[]: offset of a value the lookup does not hold (beyond any tile whatever the position in front of it: a piece starts at most a few thousand coefficients in front of its tile)
+	DX_NO_VALUE = 0xC000,             // multi[]: offset of a value the lookup does not hold (beyond any tile whatever the position in front of it: a piece starts at most a few thousand coefficients in front of its tile)
 	DX_L11_BITS = 7, DX_LONG11_MAX = 1664,   // k_dec_tiles' own tables for the code words that do not fit the 11-bit window: second level 7 bits, third level the rest (up to 26 in all)
 	DX_RUNIN_SHORT = 96, DX_LEAD = 96,    // bits of the quick run-in in front of a chunk / of the lead-in in front of a lane
 	DX_MEMO = CFHD_DX_MEMO,           // outcomes a lane of k_dec_index remembers (start -> end, count)
@@ -94,8 +97,8 @@ struct DecIdxTables {
 	// x & 15 == 0 (the first code word does not fit the window): y is an entry in the format of long11[] -- the code word itself when only its
 	// sign bit lies outside the window, else an escape to long11[] indexed by the next DX_L11_BITS bits (and once more for code words beyond 18 bits).
 	uint2 multi[1 << DX_KM];
-	// bits 0-4 length without the sign bit (escape: index bits of the next level), bits 5-7 type (DX_T_*), bits 8-19 zero run | magnitude under code
-	// set 17's companding curve | base of the next level, bits 20-31 magnitude under code set 18's (linear) curve
+	// bits 0-4 bits of the code word, sign bit included (escape: index bits of the next level), bits 5-7 type (DX_T_*), bits 8-19 payload under code set 17, bits 20-31 under
+	// code set 18: the zero run (in both), the magnitude with the set's companding curve undone (cubic | linear), 0 for the band end marker -- or, escape: base of the next level (bits 8-19)
 	uint32_t long11[DX_LONG11_MAX];
 };
 
@@ -803,12 +806,12 @@ __global__ void __launch_bounds__(DX_THREADS) k_dec_reindex(const DxBandJob *job
 // Tiles are numbered position by position: position p holds the tiles of band slot slot_of[p] for every frame (cum[p] tiles lie in front of it, per_band[p] per
 // band).  The positions of the level-2 and level-3 bands come first (tiles 0 .. split - 1), those of the level-1 bands behind them, so that a launch over
 // [first, total) can decode one group while the inverse transforms of the other run (GpuEntropyDecoder::launch_dx).
-struct DxTilePlan { int nslots, nframes; uint32_t cum[40]; uint32_t per_band[40]; uint32_t total, first, split; uint8_t slot_of[40];
+struct DxTilePlan { int nslots, nframes; uint32_t cum[40]; uint32_t per_band[40]; uint32_t tile_len[40]; /* coefficients per tile of the position (a multiple of 512, at most DX_TILE) */ uint32_t total, first, split; uint8_t slot_of[40];
                     int mask_base[40]; /* per position: first chunk mask of the band in a frame's mask array when its tiles leave as block lists (cfhd_core.h dec_block_list_layout), else -1 */ };
 
 enum : uint32_t { DX_TILE_EMPTY = 0xFFFFFFFFu };
 
-__device__ __forceinline__ void dx_tile_of(const DxTilePlan &plan, uint32_t t, int *job, uint32_t *ti)
+__device__ __forceinline__ void dx_tile_of(const DxTilePlan &plan, uint32_t t, int *job, uint32_t *ti, uint32_t *len)
 {
 	int slot = 0;
 	while (slot + 1 < plan.nslots && t >= plan.cum[slot + 1]) slot++;
@@ -816,6 +819,7 @@ __device__ __forceinline__ void dx_tile_of(const DxTilePlan &plan, uint32_t t, i
 	const uint32_t f = r / per;
 	*ti = r - f * per;
 	*job = (int)plan.slot_of[slot] * plan.nframes + (int)f;
+	*len = plan.tile_len[slot];
 }
 
 // One thread per output tile: the 64-bit piece of payload that holds the code word at (or the last one in front of) the tile's first
@@ -825,11 +829,11 @@ __global__ void __launch_bounds__(DX_THREADS) k_dec_tile_index(const DxBandJob *
 {
 	const uint32_t t = (uint32_t)blockIdx.x * DX_THREADS + (uint32_t)threadIdx.x;
 	if (t >= plan.total) return;
-	int j; uint32_t ti;
-	dx_tile_of(plan, t, &j, &ti);
+	int j; uint32_t ti, len;
+	dx_tile_of(plan, t, &j, &ti, &len);
 	const DxBandJob job = jobs[j];
 	const DxBandSum sum = sums[j];
-	const uint32_t T0 = ti * DX_TILE;
+	const uint32_t T0 = ti * len;
 	uint32_t q0 = DX_TILE_EMPTY;
 	if (job.bytes != 0u && sum.last_chunk >= 0 && T0 < sum.total && T0 < (uint32_t)job.n) {
 		const uint32_t *cb = chunk_base + job.chunk0;
@@ -847,9 +851,9 @@ __global__ void __launch_bounds__(DX_THREADS) k_dec_tile_index(const DxBandJob *
 	tile_start[t] = q0;
 }
 
-// What a wave of k_dec_tiles needs to know about a tile, and the first 64 pieces of payload that may reach into it: both are fetched
+// What a wave of k_dec_tiles needs to know about a tile, and the first 64 pieces of payload it decodes of it: both are fetched
 // one tile ahead, so that the loads are in flight while the previous tile is decoded.
-struct DxTileMeta { int j; uint32_t ti, first_sub; DxBandJob job; DxBandSum sum; unsigned long long *masks; /* the band's chunk masks in this frame, or null: dense */ };
+struct DxTileMeta { int j; uint32_t T0, len, first_sub, next_sub; DxBandJob job; DxBandSum sum; unsigned long long *masks; /* the band's chunk masks in this frame, or null: dense */ };
 // 0 in every lane, but not to the compiler: an address with it added is per-lane, so the load becomes a vector load (counted by vmcnt) and
 // not a scalar one -- scalar loads share their counter with LDS, and the first LDS read of the decode loop would wait for the prefetch.
 __device__ __forceinline__ uint32_t dx_lane_zero() { return __builtin_amdgcn_mbcnt_lo(0u, 0u); }
@@ -869,181 +873,186 @@ template <typename T> __device__ __forceinline__ T dx_uniform(const T &v)    // 
 	for (int i = 0; i < (int)(sizeof(T) / 4); i++) d[i] = (uint32_t)wave_uniform((int)s[i]);
 	return r;
 }
-struct DxPieces { uint32_t ent, cb, d[4]; };
+struct DxPieces { uint32_t ent, cb, d[3]; };
 __device__ __forceinline__ void dx_tile_meta(const DxTilePlan &plan, uint32_t t, int &slot, const DxBandJob *jobs, const DxBandSum *sums, const uint32_t *tile_start, DxTileMeta &M,
                                              unsigned long long *masks = nullptr, uint32_t masks_per_frame = 0u)
 {
 	while (slot + 1 < plan.nslots && t >= plan.cum[slot + 1]) slot++;       // tiles come in increasing order: the slot only moves forward
 	const uint32_t r = t - plan.cum[slot], per = plan.per_band[slot];
-	const uint32_t f = r / per;
-	M.ti = r - f * per; M.j = (int)plan.slot_of[slot] * plan.nframes + (int)f;
+	const uint32_t f = r / per, ti = r - f * per;
+	M.len = plan.tile_len[slot]; M.T0 = ti * M.len; M.j = (int)plan.slot_of[slot] * plan.nframes + (int)f;
 	M.masks = (masks && plan.mask_base[slot] >= 0) ? masks + (size_t)f * masks_per_frame + (size_t)plan.mask_base[slot] : nullptr;
 	dx_vload(M.first_sub, tile_start + t);
+	// the first piece of the band's next tile is the last one that can reach into this tile (the band's last tile: DX_TILE_EMPTY, the pieces run to the band's end)
+	M.next_sub = DX_TILE_EMPTY;
+	if (ti + 1u < per) dx_vload(M.next_sub, tile_start + t + 1);
 	dx_vload(M.job, jobs + M.j);
 	dx_vload(M.sum, sums + M.j);
 }
-__device__ __forceinline__ void dx_tile_pieces(const DxTileMeta &M, uint32_t q, uint32_t last_sub, const uint32_t *entries, const uint32_t *chunk_base, DxPieces &P)
+__device__ __forceinline__ void dx_tile_pieces(const DxTileMeta &M, uint32_t q, uint32_t end_sub, const uint32_t *entries, const uint32_t *chunk_base, DxPieces &P)
 {
 	P.ent = DX_OFF_INVALID; P.cb = 0;
 #pragma unroll
-	for (int i = 0; i < 4; i++) P.d[i] = 0u;
-	if (q < last_sub) {
-		// entry, chunk position and the next 128 bits of the payload from the piece on (the walk needs at most 64 + 26 + 27 of them): independent loads
+	for (int i = 0; i < 3; i++) P.d[i] = 0u;
+	if (q < end_sub) {
+		// entry, chunk position and the next 96 bits of the payload from the piece on (a walk starts inside the piece's 64 bits and looks at 32 bits at a time): independent loads
 		const uint32_t kq = q / DX_CHUNK_SUBS, within = q - kq * DX_CHUNK_SUBS;
 		P.ent = entries[((size_t)M.job.chunk0 + kq) * DX_ENTRY_STRIDE + DX_SUBS + within];
 		P.cb = chunk_base[(size_t)M.job.chunk0 + kq];
 		const uint32_t byte0 = q * (DX_SUB_BITS / 8);
 		const uint32_t *src = (const uint32_t *)(M.job.bits + byte0);
 #pragma unroll
-		for (int i = 0; i < 4; i++) P.d[i] = byte0 + 4u * (uint32_t)i + 4u <= M.job.bytes ? src[i] : 0u;
+		for (int i = 0; i < 3; i++) P.d[i] = byte0 + 4u * (uint32_t)i + 4u <= M.job.bytes ? src[i] : 0u;
 	}
 }
-__device__ __forceinline__ bool dx_tile_has_work(const DxTileMeta &M) { return M.job.bytes != 0u && M.ti * DX_TILE < (uint32_t)M.job.n && M.first_sub != DX_TILE_EMPTY; }
-__device__ __forceinline__ uint32_t dx_tile_last_sub(const DxTileMeta &M) { return ((uint32_t)M.sum.last_chunk + 1u) * DX_CHUNK_SUBS; }
+__device__ __forceinline__ bool dx_tile_has_work(const DxTileMeta &M) { return M.job.bytes != 0u && M.T0 < (uint32_t)M.job.n && M.first_sub != DX_TILE_EMPTY; }
+// one behind the last piece that can reach into the tile
+__device__ __forceinline__ uint32_t dx_tile_end_sub(const DxTileMeta &M)
+{
+	const uint32_t last = ((uint32_t)M.sum.last_chunk + 1u) * DX_CHUNK_SUBS;
+	return (M.next_sub != DX_TILE_EMPTY && M.next_sub + 1u < last) ? M.next_sub + 1u : last;
+}
 
-// The LDS image of a wave's tile: DX_TILE coefficients and, behind them, one dump slot per lane -- a store that has nothing to write (no value
+// The LDS image of a workgroup's tile: DX_TILE coefficients and, behind them, one dump slot per thread -- a store that has nothing to write (no value
 // in this step, or a position outside the tile: a piece reaches in from the tile in front or out into the next one) goes there instead of being
-// masked out, which keeps the decode loop free of execution-mask bookkeeping.
-enum { DX_TILE_WORDS = DX_TILE / 2 + 32 };
+// masked out, which keeps the decode loop free of execution-mask bookkeeping.  The image holds the values as the code words give them (the short
+// ones are below the knee of the companding curve, the long ones carry their expanded magnitude in the table); the band's divisor is applied on the
+// way out, two coefficients per multiply.
+enum { DX_TILE_WORDS = DX_TILE / 2 + DX_TILE_THREADS / 2 };
+static_assert(DX_TILE % 512 == 0, "a tile is a whole number of chunks of 64 blocks");
+static_assert(DX_TILE + DX_TILE_THREADS + 4096 <= DX_NO_VALUE, "a position the table marks as absent must lie behind the dump slots wherever the piece starts (at most 6 x 320 coefficients in front of its tile)");
 
-__global__ void __launch_bounds__(DX_TILE_THREADS) k_dec_tiles(const DxBandJob *jobs, DxTilePlan plan, const DecIdxTables *T, const uint32_t *entries, const uint32_t *chunk_base,
+template <int NT /* threads: DX_TILE_THREADS (the emulated kernel tests also run 64, so that small tiles take several rounds per wave) */>
+__global__ void __launch_bounds__(NT) k_dec_tiles(const DxBandJob *jobs, DxTilePlan plan, const DecIdxTables *T, const uint32_t *entries, const uint32_t *chunk_base,
                                                                const DxBandSum *sums, const uint32_t *tile_start, unsigned long long *masks, uint32_t masks_per_frame)
 {
 	__shared__ uint2 s_multi[1 << DX_KM];
 	__shared__ uint32_t s_long[DX_LONG11_MAX];
-	__shared__ uint32_t s_tile_all[DX_TILE_WAVES][DX_TILE_WORDS];
+	__shared__ uint32_t s_tile[DX_TILE / 2 + NT / 2];
 	for (int i = threadIdx.x; i < DX_LONG11_MAX; i += blockDim.x) s_long[i] = T->long11[i];
 	for (int i = threadIdx.x; i < (1 << DX_KM); i += blockDim.x) s_multi[i] = T->multi[i];
+	for (int i = threadIdx.x; i < DX_TILE / 2 + NT / 2; i += blockDim.x) s_tile[i] = 0u;
 	const int lane = wave_lane(), wave = wave_uniform((int)(threadIdx.x >> 6));
-	uint32_t *s_tile = s_tile_all[wave];
-	for (int i = lane; i < DX_TILE_WORDS; i += 64) s_tile[i] = 0u;
 	__syncthreads();
-	const uint32_t gwave = (uint32_t)blockIdx.x * DX_TILE_WAVES + (uint32_t)wave, nwaves = (uint32_t)gridDim.x * DX_TILE_WAVES;
-	uint32_t t = plan.first + gwave;
-	if (t >= plan.total) return;
-	// software pipeline: tile t is decoded while the descriptors of tile t + 2 nwaves and the payload pieces of tile t + nwaves are on their way
+	const uint32_t stride = (uint32_t)gridDim.x;
+	uint32_t t = plan.first + (uint32_t)blockIdx.x;
+	if (t >= plan.total) return;                           // (the whole workgroup)
+	// software pipeline: tile t is decoded while the descriptors of tile t + 2 stride and this wave's first pieces of tile t + stride are on their way
 	int slot = 0;
 	DxTileMeta M, M1;
 	dx_tile_meta(plan, t, slot, jobs, sums, tile_start, M, masks, masks_per_frame);
 	M1 = M;
-	if (t + nwaves < plan.total) dx_tile_meta(plan, t + nwaves, slot, jobs, sums, tile_start, M1, masks, masks_per_frame);
+	if (t + stride < plan.total) dx_tile_meta(plan, t + stride, slot, jobs, sums, tile_start, M1, masks, masks_per_frame);
+	const uint32_t mine = (uint32_t)wave * 64u + (uint32_t)lane;        // this thread's piece in the first round of a tile
 	DxPieces P;
-	dx_tile_pieces(M, dx_tile_has_work(M) ? M.first_sub + (uint32_t)lane : 0xFFFFFFFFu, dx_tile_has_work(M) ? dx_tile_last_sub(M) : 0u, entries, chunk_base, P);
+	dx_tile_pieces(M, dx_tile_has_work(M) ? M.first_sub + mine : 0xFFFFFFFFu, dx_tile_has_work(M) ? dx_tile_end_sub(M) : 0u, entries, chunk_base, P);
 	int16_t *tile16 = (int16_t *)s_tile;
-	const uint32_t dump = (uint32_t)DX_TILE + (uint32_t)lane;           // this lane's dump slot (16-bit index)
+	const uint32_t dump = (uint32_t)DX_TILE + (uint32_t)threadIdx.x;     // this thread's dump slot (16-bit index)
 #pragma unroll 1
-	for (; t < plan.total; t += nwaves) {
+	for (; t < plan.total; t += stride) {
 		DxTileMeta M2 = M1;
 		DxPieces P1;
-		if (t + 2 * nwaves < plan.total) dx_tile_meta(plan, t + 2 * nwaves, slot, jobs, sums, tile_start, M2, masks, masks_per_frame);
+		if (t + 2 * stride < plan.total) dx_tile_meta(plan, t + 2 * stride, slot, jobs, sums, tile_start, M2, masks, masks_per_frame);
 		{
-			const bool w1 = t + nwaves < plan.total && dx_tile_has_work(M1);
-			dx_tile_pieces(M1, w1 ? M1.first_sub + (uint32_t)lane : 0xFFFFFFFFu, w1 ? dx_tile_last_sub(M1) : 0u, entries, chunk_base, P1);
+			const bool w1 = t + stride < plan.total && dx_tile_has_work(M1);
+			dx_tile_pieces(M1, w1 ? M1.first_sub + mine : 0xFFFFFFFFu, w1 ? dx_tile_end_sub(M1) : 0u, entries, chunk_base, P1);
 		}
 		const DxBandJob job = dx_uniform(M.job);
 		const uint32_t first_sub = (uint32_t)wave_uniform((int)M.first_sub);
-		const uint32_t T0 = M.ti * DX_TILE, T1 = T0 + DX_TILE < (uint32_t)job.n ? T0 + DX_TILE : (uint32_t)job.n;
-		if (job.bytes != 0u && T0 < (uint32_t)job.n) {                         // wave-uniform
-			if (first_sub != DX_TILE_EMPTY) {
-				// piece by piece, one per lane, until the pieces start behind the tile
-				const uint32_t last_sub = (uint32_t)wave_uniform((int)dx_tile_last_sub(M));
-				const uint32_t quant = (uint32_t)job.quant;        // (only the low 16 bits of value x divisor are kept, as in the reference's PIXEL arithmetic)
-				const bool linear = (job.table & 1) != 0;                      // code set 18: the second magnitude of the long entries
-				const int len_tile = (int)(T1 - T0);
+		const uint32_t T0 = (uint32_t)wave_uniform((int)M.T0);
+		const bool any = job.bytes != 0u && T0 < (uint32_t)job.n;           // the same for the whole workgroup
+		const uint32_t tlen = (uint32_t)wave_uniform((int)M.len);
+		const uint32_t T1 = any ? (T0 + tlen < (uint32_t)job.n ? T0 + tlen : (uint32_t)job.n) : T0;
+		if (any && first_sub != DX_TILE_EMPTY) {
+			// 64 consecutive pieces per wave and round, one per lane, until the pieces start behind the tile
+			const uint32_t end_sub = (uint32_t)wave_uniform((int)dx_tile_end_sub(M));
+			const bool linear = (job.table & 1) != 0;                      // code set 18: the second magnitude of the long entries
+			const uint32_t mag_shift = linear ? 20u : 8u;
+			const int len_tile = (int)(T1 - T0);
 #pragma unroll 1
-				for (uint32_t q0 = first_sub; q0 < last_sub; q0 += 64) {
-					const uint32_t q = q0 + (uint32_t)lane;
-					const bool active = q < last_sub;
-					if (q0 != first_sub) dx_tile_pieces(M, q, last_sub, entries, chunk_base, P);     // further rounds: a dense tile (more than 64 pieces)
-					const uint32_t off = P.ent & 31u;
-					const uint32_t idx0 = P.cb + (P.ent >> 5);
-					const bool valid = active && off != (uint32_t)DX_OFF_INVALID;
-					const bool inside = valid && idx0 < T1;
-					if (inside) {
-						// The walk starts at bit `off` (< 31) of the piece and goes on while it is inside the piece's 64 bits; a code word has at most 27
-						// bits, so every 32-bit window the walk looks at lies in the piece's first 96 bits: three words, no refill state -- the window at bit
-						// position pos is cut out of the word pair it starts in.
-						const uint32_t w0 = bswap32(P.d[0]), w1 = bswap32(P.d[1]), w2 = bswap32(P.d[2]);
-						uint32_t pos = off;
-						uint32_t rel = idx0 - T0;                          // position inside the tile; "negative" (the piece starts in front of the tile) wraps to a huge number
-						// one loop with one way out; both kinds of step (a group out of the multi-symbol table | one long code word) feed the same two
-						// unconditional stores
-						bool alive = true;
-						do {
-							const bool second = pos >= 32u;
-							const uint32_t win = (uint32_t)(((((uint64_t)(second ? w1 : w0)) << 32) | (second ? w2 : w1)) << (pos & 31u) >> 32);
-							// up to two values and the zero runs around them per lookup.  A group may reach over the end of the piece: the lane of the
-							// next piece then writes the same values to the same places again.
-							const uint2 e = s_multi[win >> (32 - DX_KM)];
-							uint32_t adv = e.x & 15u, total = (e.x >> 4) & 0xfffu, o1 = e.x >> 16, o2 = e.y & 0xffffu;
-							int v1 = (int)(int8_t)(e.y >> 16), v2 = (int)(int8_t)(e.y >> 24);
-							if (adv == 0u) {
-								// a code word that does not fit the window (a large value, a long run, the band end marker): alone, through its own trie
-								uint32_t le = e.y;
-								if (((le >> 5) & 7u) == (uint32_t)DX_T_ESCAPE) {
-									le = s_long[((le >> 8) & 0xfffu) + ((win << DX_KM) >> (32 - DX_L11_BITS))];
-									if (((le >> 5) & 7u) == (uint32_t)DX_T_ESCAPE) le = s_long[((le >> 8) & 0xfffu) + ((win << (DX_KM + DX_L11_BITS)) >> (32 - (le & 31u)))];
-								}
-								const uint32_t ty = (le >> 5) & 7u, ln = le & 31u;
-								const int m = (int)(linear ? le >> 20 : (le >> 8) & 0xfffu);
-								const bool isval = ty == (uint32_t)DX_T_VALUE, isrun = ty == (uint32_t)DX_T_RUN;
-								total = isrun ? (le >> 8) & 0xfffu : (isval ? 1u : 0u);
-								o1 = isval ? 0u : (uint32_t)DX_NO_VALUE; o2 = (uint32_t)DX_NO_VALUE;
-								v1 = ((win << ln) >> 31) ? -m : m; v2 = 0;
-								adv = isval ? ln + 1u : ln;
-								alive = isval || isrun;                       // else: the band end marker (or a broken code, reported by k_dec_chain)
+			for (uint32_t q0 = first_sub + (uint32_t)wave * 64u; q0 < end_sub; q0 += (uint32_t)NT) {
+				const uint32_t q = q0 + (uint32_t)lane;
+				if (q0 != first_sub + (uint32_t)wave * 64u) dx_tile_pieces(M, q, end_sub, entries, chunk_base, P);     // further rounds: a dense tile (more pieces than the workgroup has threads)
+				const uint32_t off = P.ent & 31u;
+				const uint32_t idx0 = P.cb + (P.ent >> 5);
+				const bool valid = q < end_sub && off != (uint32_t)DX_OFF_INVALID;
+				const bool inside = valid && idx0 < T1;
+				if (inside) {
+					// The walk starts at bit `off` (< 31) of the piece and goes on while it is inside the piece's 64 bits; a code word has at most 27
+					// bits, so every 32-bit window the walk looks at lies in the piece's first 96 bits: three words, no refill state -- the window at bit
+					// position pos is cut out of the word pair it starts in.
+					const uint32_t w0 = bswap32(P.d[0]), w1 = bswap32(P.d[1]), w2 = bswap32(P.d[2]);
+					uint32_t pos = off;
+					uint32_t rel = idx0 - T0;                          // position inside the tile; "negative" (the piece starts in front of the tile) wraps to a huge number
+					// one loop with one way out; both kinds of step (a group out of the multi-symbol table | one long code word) feed the same two
+					// unconditional stores
+					bool alive = true;
+					do {
+						const bool second = pos >= 32u;
+						const uint32_t win = (uint32_t)(((((uint64_t)(second ? w1 : w0)) << 32) | (second ? w2 : w1)) << (pos & 31u) >> 32);
+						// up to two values and the zero runs around them per lookup.  A group may reach over the end of the piece: the lane of the
+						// next piece then writes the same values to the same places again.
+						const uint2 e = s_multi[win >> (32 - DX_KM)];
+						uint32_t adv = e.x & 15u, total = (e.x >> 4) & 0xfffu, o1 = e.x >> 16, o2 = e.y & 0xffffu;
+						int v1 = (int)(int8_t)(e.y >> 16), v2 = (int)(int8_t)(e.y >> 24);
+						if (adv == 0u) {
+							// a code word that does not fit the window (a large value, a long run, the band end marker): alone, through its own trie.  Its entry is made for
+							// this place: bits incl. the sign bit, and one payload field per code set that is the run, the expanded magnitude, or 0 (end marker, no code)
+							uint32_t le = e.y;
+							if (((le >> 5) & 7u) == (uint32_t)DX_T_ESCAPE) {
+								le = s_long[((le >> 8) & 0xfffu) + ((win << DX_KM) >> (32 - DX_L11_BITS))];
+								if (((le >> 5) & 7u) == (uint32_t)DX_T_ESCAPE) le = s_long[((le >> 8) & 0xfffu) + ((win << (DX_KM + DX_L11_BITS)) >> (32 - (le & 31u)))];
 							}
-							// a value whose place lies outside the tile (or that is not there at all) goes to the lane's dump slot: min() does both
-							const uint32_t p1 = rel + o1, p2 = rel + o2;
-							tile16[p1 < dump ? p1 : dump] = (int16_t)mul_u24((uint32_t)v1, quant);
-							tile16[p2 < dump ? p2 : dump] = (int16_t)mul_u24((uint32_t)v2, quant);
-							rel += total;
-							pos += adv;
-							alive = alive && pos < (uint32_t)DX_SUB_BITS && (int)rel < len_tile;
-						} while (alive);
-					}
-					// pieces are in raster order: once a valid one starts behind the tile, all later ones do
-					if (__ballot(valid && !inside) || !__ballot(active)) break;
+							const uint32_t ty = (le >> 5) & 7u, pay = (le >> mag_shift) & 0xfffu;
+							const bool isval = ty == (uint32_t)DX_T_VALUE;
+							adv = le & 31u;
+							total = isval ? 1u : pay;
+							o1 = isval ? 0u : (uint32_t)DX_NO_VALUE; o2 = (uint32_t)DX_NO_VALUE;
+							v1 = (int)(win << ((adv - 1u) & 31u)) < 0 ? -(int)pay : (int)pay;        // (a run's "value" goes to the dump slot)
+							alive = ty - (uint32_t)DX_T_RUN < 2u;                // else: the band end marker (or a broken code, reported by k_dec_chain)
+						}
+						// a value whose place lies outside the tile (or that is not there at all) goes to the thread's dump slot: min() does both
+						const uint32_t p1 = rel + o1, p2 = rel + o2;
+						tile16[p1 < dump ? p1 : dump] = (int16_t)v1;
+						tile16[p2 < dump ? p2 : dump] = (int16_t)v2;
+						rel += total;
+						pos += adv;
+						alive = alive && pos < (uint32_t)DX_SUB_BITS && (int)rel < len_tile;
+					} while (alive);
 				}
+				// pieces are in raster order: once a valid one starts behind the tile, all later ones do
+				if (__ballot(valid && !inside)) break;
 			}
-			CFHD_WAVE_SYNC();
-			// the tile goes out in 16-byte words and is cleared for the next one
+		}
+		__syncthreads();
+		if (any) {
+			// the tile goes out in 16-byte words, times the band's divisor (only the low 16 bits of value x divisor are kept, as in the reference's PIXEL arithmetic),
+			// and the image is cleared for the next one: chunks of 64 blocks, dealt to the waves in turn
 			uint4 *dst = (uint4 *)(job.dst + T0);
 			const uint32_t n16 = (T1 - T0) / 8;
+			const uint32_t quant2 = ((uint32_t)job.quant & 0xffffu) * 0x10001u;
 			const uint4 zero = { 0u, 0u, 0u, 0u };
 			unsigned long long *const tmasks = wave_uniform_ptr(M.masks);
-			if (tmasks) {
-				// ... as block lists (cfhd_core.h dec_block_list_layout): of every chunk of 64 blocks only the blocks that hold a nonzero coefficient, compacted to the
-				// chunk's own first places in the band (a lane's rank among the chunk's listed blocks: a ballot + v_mbcnt), and the chunk's occupancy mask.  The inverse
-				// level-1 strip kernel gathers them (k_inv_yuv422_strip_blocks); what lies behind a chunk's listed blocks in the band is stale and never read.
-				static_assert(DX_TILE % 512 == 0, "a tile is a whole number of chunks");
-				const uint32_t chunk0 = T0 / 512u;
+			const uint32_t chunk0 = T0 / 512u;
 #pragma unroll 1
-				for (uint32_t it = 0; it < (uint32_t)DX_TILE / 512u; it++) {
-					const uint32_t i = it * 64u + (uint32_t)lane;
-					const uint4 v = ((const uint4 *)s_tile)[i];
-					((uint4 *)s_tile)[i] = zero;
-					const bool nz = i < n16 && (v.x | v.y | v.z | v.w) != 0u;
-					const unsigned long long m = __ballot(nz);
-#ifdef CFHD_DX_PROBE_NOSTORE      /* timing probe (tools/gpu_r05_f.sh): the tile pass without its stores -- what does a wave wait for? */
-					if (nz && v.x == 0x12345u) dst[it * 64u + wave_mbcnt(m)] = v;
-#else
-					if (nz) dst[it * 64u + wave_mbcnt(m)] = v;
-					if (lane == 0 && it * 64u < n16) tmasks[chunk0 + it] = m;
-#endif
-				}
-			} else
-			for (uint32_t i = (uint32_t)lane; i < (uint32_t)DX_TILE / 8; i += 64) {
-				const uint4 v = ((const uint4 *)s_tile)[i];
+			for (uint32_t it = (uint32_t)wave; it < (uint32_t)DX_TILE / 512u; it += (uint32_t)(NT / 64)) {
+				const uint32_t i = it * 64u + (uint32_t)lane;
+				uint4 v = ((const uint4 *)s_tile)[i];
 				((uint4 *)s_tile)[i] = zero;
-#ifdef CFHD_DX_PROBE_NOSTORE
-				if (i < n16 && v.x == 0x12345u) dst[i] = v;
-#else
-				if (i < n16) dst[i] = v;
-#endif
+				if (it * 64u >= n16) continue;                // (behind the band's end: cleared, not stored)
+				const bool nz = i < n16 && (v.x | v.y | v.z | v.w) != 0u;
+				v.x = pk_mulw(v.x, quant2); v.y = pk_mulw(v.y, quant2); v.z = pk_mulw(v.z, quant2); v.w = pk_mulw(v.w, quant2);
+				if (tmasks) {
+					// ... as block lists (cfhd_core.h dec_block_list_layout): of every chunk of 64 blocks only the blocks that hold a nonzero coefficient, compacted to the
+					// chunk's own first places in the band (a lane's rank among the chunk's listed blocks: a ballot + v_mbcnt), and the chunk's occupancy mask.  The inverse
+					// level-1 strip kernel gathers them (k_inv_yuv422_strip_blocks); what lies behind a chunk's listed blocks in the band is stale and never read.
+					const unsigned long long m = __ballot(nz);
+					if (nz) dst[it * 64u + wave_mbcnt(m)] = v;
+					if (lane == 0) tmasks[chunk0 + it] = m;
+				} else if (i < n16) dst[i] = v;
 			}
-			CFHD_WAVE_SYNC();
 		}
+		__syncthreads();
 		M = M1; M1 = M2; P = P1;
 	}
 }

@@ -356,7 +356,9 @@ int GpuEntropyDecoder::prepare(const FramePlan &plan, int nframes, int16_t *d_co
 		HIPCHK(hipHostMalloc((void **)&h_counters_, 32, hipHostMallocPortable));
 		int cus = 256;
 		(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_current());
-		grid_index_ = cus * 5; grid_tiles_ = cus * (dev::DX_TILE_THREADS >= 1024 ? 1 : 2);      // workgroups that fit a CU at once (LDS: ~30 KB / ~150 KB each)
+		// workgroups that fit a CU at once: k_dec_index 31 KB of LDS each, k_dec_tiles its tables (22.5 KB) + the image of a tile
+		grid_index_ = cus * 5; grid_tiles_ = cus * (int)((160 * 1024) / (sizeof(uint2) * (1 << dev::DX_KM) + sizeof(uint32_t) * (dev::DX_LONG11_MAX + dev::DX_TILE_WORDS)));
+		if (const char *e = getenv("CFHD_AMD_DX_GRID_TILES")) if (atoi(e) > 0) grid_tiles_ = atoi(e);      // (sweeps: tools/dx_tile_sweep.sh)
 		if (grid_index_ < 1) grid_index_ = 1;
 		if (grid_tiles_ < 1) grid_tiles_ = 1;
 	}
@@ -549,8 +551,8 @@ int GpuEntropyDecoder::launch_dx(bool device_jobs, int njobs, uint32_t host_chun
 	const uint32_t chunk_bound = device_jobs ? max_chunks_ : host_chunks;
 	int g1 = grid_index_, g3 = grid_tiles_;
 	if ((uint32_t)g1 * dev::DX_WAVES > chunk_bound) g1 = (int)((chunk_bound + dev::DX_WAVES - 1) / dev::DX_WAVES);
-	const uint32_t tile_waves = (uint32_t)dev::DX_TILE_WAVES;
-	if ((uint32_t)g3 * tile_waves > tp.total) g3 = (int)((tp.total + tile_waves - 1) / tile_waves);
+	const uint32_t tile_waves = 1u;                       // (a workgroup per tile)
+	if ((uint32_t)g3 > tp.total) g3 = (int)tp.total;
 	if (g1 < 1) g1 = 1;
 	if (g3 < 1) g3 = 1;
 	dev::k_dec_index<<<g1, dev::DX_THREADS, 0, st>>>((const dev::DxChunkDesc *)d_chunk_job_, (const uint32_t *)d_counters_, T, (uint32_t *)d_entries_, (dev::DxChunkRec *)d_recs_, (dev::DxChunkAlt *)d_alts_, speculate ? 1 : 0, (uint32_t *)d_stats_,
@@ -573,7 +575,7 @@ int GpuEntropyDecoder::launch_dx(bool device_jobs, int njobs, uint32_t host_chun
 	const char *split_env = getenv("CFHD_AMD_TILES_SPLIT");
 	l23_split_ = frames >= 8 && !skip_level1_ && tp.split > 0 && tp.split < tp.total && split_env && split_env[0] == '1';
 	auto tile_pass = [&](const dev::DxTilePlan &p, int g) {
-		dev::k_dec_tiles<<<g < 1 ? 1 : g, dev::DX_TILE_THREADS, 0, st>>>(jobs, p, T, (const uint32_t *)d_entries_, (const uint32_t *)d_chunk_base_, (const dev::DxBandSum *)d_sums_, (const uint32_t *)d_tile_start_, tmasks, (uint32_t)masks_per_frame_);
+		dev::k_dec_tiles<dev::DX_TILE_THREADS><<<g < 1 ? 1 : g, dev::DX_TILE_THREADS, 0, st>>>(jobs, p, T, (const uint32_t *)d_entries_, (const uint32_t *)d_chunk_base_, (const dev::DxBandSum *)d_sums_, (const uint32_t *)d_tile_start_, tmasks, (uint32_t)masks_per_frame_);
 	};
 	if (l23_split_) {
 		dev::DxTilePlan ta = tp, tb = tp;

@@ -151,9 +151,11 @@ inline bool build_dec_index_tables(int codebook, dev::DecIdxTables *T)
 	// for code words of 12 to 18 bits, two beyond, none when only the sign bit lies outside the window.
 	{
 		auto entry_of = [&](const RawCode &c, bool *ok) {
-			const uint32_t a = c.kind == 1 ? T->mag_expand[0][c.payload] : (uint32_t)c.payload, b = c.kind == 1 ? T->mag_expand[1][c.payload] : 0u;
-			if (a >= (1u << 12) || b >= (1u << 12) || c.len > 31) *ok = false;
-			return (uint32_t)c.len | ((uint32_t)type_of(c) << 5) | (a << 8) | (b << 20);
+			// bits of the code word with its sign bit; one payload field per code set: the expanded magnitude, the zero run (in both), 0 for the band end marker
+			const uint32_t a = c.kind == 1 ? T->mag_expand[0][c.payload] : (c.kind == 0 ? (uint32_t)c.payload : 0u), b = c.kind == 1 ? T->mag_expand[1][c.payload] : a;
+			const uint32_t bits = (uint32_t)c.len + (c.kind == 1 ? 1u : 0u);
+			if (a >= (1u << 12) || b >= (1u << 12) || bits > 31u) *ok = false;
+			return bits | ((uint32_t)type_of(c) << 5) | (a << 8) | (b << 20);
 		};
 		bool ok = true;
 		uint32_t n11 = 0;
@@ -411,8 +413,9 @@ inline bool dx_build_jobs(const ParsedSample &ps, const FramePlan &plan, const d
 	return true;
 }
 
-// Tiles of the job table: slot s has ceil(n / DX_TILE) tiles per band, for every frame.
-inline dev::DxTilePlan dx_tile_plan(const FramePlan &plan, const dev::DecPlan &dp, int nframes, bool skip_level1 = false, bool level1_block_lists = false, bool interlaced = false)
+// Tiles of the job table: a band of n coefficients is cut into ceil(n / tile_max) tiles of equal length (a multiple of 512: the chunks of the block lists), for every frame.
+// tile_max: dev::DX_TILE (what the kernel's LDS image holds); the emulated kernel tests pass less, so that their small frames meet bands of many tiles.
+inline dev::DxTilePlan dx_tile_plan(const FramePlan &plan, const dev::DecPlan &dp, int nframes, bool skip_level1 = false, bool level1_block_lists = false, bool interlaced = false, uint32_t tile_max = dev::DX_TILE)
 {
 	int mask_base[kMaxChannels][kNumBands];
 	dec_block_list_layout(plan, mask_base);
@@ -428,7 +431,8 @@ inline dev::DxTilePlan dx_tile_plan(const FramePlan &plan, const dev::DecPlan &d
 				for (int b = 1; b < 4; b++) {
 					const BandDesc &bd = plan.ch[c].band[lv][b];
 					const uint32_t n = (uint32_t)(bd.height * bd.pitch);
-					const uint32_t per = (skip_level1 && lv == 0) ? 0u : (n + dev::DX_TILE - 1) / dev::DX_TILE;
+					const uint32_t per = (skip_level1 && lv == 0) ? 0u : (n + tile_max - 1) / tile_max;
+					tp.tile_len[pos] = per ? ((n + per - 1) / per + 511u) / 512u * 512u : tile_max;
 					tp.slot_of[pos] = (uint8_t)dp.slot[c][lv][b];
 					// (the level-1 bands as block lists: k_dec_tiles -> k_inv_yuv422_strip_blocks / k_inv_frame_yuv422_strip_blocks; the difference-coded band of an interlaced
 					// frame stays dense: k_dec_undiff walks its rows)

@@ -51,6 +51,9 @@ __device__ __forceinline__ uint32_t pk_lolo(uint32_t a, uint32_t b) { return __b
 __device__ __forceinline__ uint32_t pk_hihi(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }          // (a.hi, b.hi)
 // wrapping (non-saturating) packed add / negate and signed max: the quantizer's 16-bit arithmetic (quantize.c:1395)
 __device__ __forceinline__ uint32_t pk_addw(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (cfhd_s2)(__builtin_bit_cast(cfhd_s2, a) + __builtin_bit_cast(cfhd_s2, b))); }
+// wrapping packed multiply, low halves of the products (v_pk_mul_lo_u16): value x divisor in the reference's 16-bit PIXEL arithmetic, two coefficients at a time
+typedef unsigned short cfhd_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_mulw(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (cfhd_us2)(__builtin_bit_cast(cfhd_us2, a) * __builtin_bit_cast(cfhd_us2, b))); }
 __device__ __forceinline__ uint32_t pk_negw(uint32_t a) { return __builtin_bit_cast(uint32_t, (cfhd_s2)(-__builtin_bit_cast(cfhd_s2, a))); }
 __device__ __forceinline__ uint32_t pk_maxs(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(cfhd_s2, a), __builtin_bit_cast(cfhd_s2, b))); }
 // 10 -> 8 bits on two lanes: clamp at zero, halve, add the dither bit, >> shift, saturate (v_pk_max_i16 / v_pk_ashrrev_i16 / v_pk_min_i16)

@@ -362,7 +362,7 @@ def mask_volatile_metadata(sample):
 # product library (cineform-sdk_amd/libcfhd_amd.so)
 # ------------------------------------------------------------------------------------------
 PRODUCT_DIR = os.path.join(ROOT, "cineform-sdk_amd")
-PRODUCT_SO = os.path.join(PRODUCT_DIR, "libcfhd_amd.so")
+PRODUCT_SO = os.environ.get("CFHD_AMD_LIB") or os.path.join(PRODUCT_DIR, "libcfhd_amd.so")      # (CFHD_AMD_LIB: A/B runs of another build of the library, tools/gpu_r06_*.sh)
 PIXKIND = {"YUY2": 1, "2vuy": 2, "RG48": 3, "b64a": 4, "BYR4": 5, "YU64": 6, "v210": 7, "RG24": 8, "BGRA": 9, "BGRa": 10, "r210": 11, "DPX0": 12, "AB10": 13, "AR10": 14, "RG64": 15, "BYR5": 16}
 ENC = {"422": 1, "bayer": 2, "444": 3, "4444": 4}
 _product = None

@@ -37,6 +37,7 @@ inline uint32_t pk_sra(uint32_t a, int n) { using namespace emu16; return pack(l
 inline uint32_t pk_lolo(uint32_t a, uint32_t b) { return (a & 0xffffu) | (b << 16); }
 inline uint32_t pk_hihi(uint32_t a, uint32_t b) { return (a >> 16) | (b & 0xffff0000u); }
 inline uint32_t pk_addw(uint32_t a, uint32_t b) { using namespace emu16; return pack(lo(a) + lo(b), hi(a) + hi(b)); }
+inline uint32_t pk_mulw(uint32_t a, uint32_t b) { return ((a & 0xffffu) * (b & 0xffffu) & 0xffffu) | (((a >> 16) * (b >> 16) & 0xffffu) << 16); }
 inline uint32_t pk_negw(uint32_t a) { using namespace emu16; return pack(-lo(a), -hi(a)); }
 inline uint32_t pk_maxs(uint32_t a, uint32_t b) { using namespace emu16; return pack(lo(a) > lo(b) ? lo(a) : lo(b), hi(a) > hi(b) ? hi(a) : hi(b)); }
 inline uint32_t pk_to8(uint32_t v, int shift, uint32_t dither) { using namespace emu16; return to8(lo(v), shift, (int)(dither & 1u)) | (to8(hi(v), shift, (int)((dither >> 16) & 1u)) << 16); }

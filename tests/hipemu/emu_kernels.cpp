@@ -699,6 +699,8 @@ extern "C" int emu_entropy_decode_dx(const uint8_t *sample, size_t size, int pix
 {
 	memset(g_dx_stats, 0, sizeof(g_dx_stats));
 	using namespace cfhd;
+	const bool full_tiles = (mode & 8) != 0, one_wave = (mode & 16) != 0;        // + 16: k_dec_tiles with one wave per workgroup (a tile then takes several rounds of 64 pieces)
+	mode &= 7;
 	ParsedSample ps;
 	if (parse_sample(sample, size, &ps) != 0) return -1;
 	FramePlan plan;
@@ -738,7 +740,9 @@ extern "C" int emu_entropy_decode_dx(const uint8_t *sample, size_t size, int pix
 	std::vector<uint32_t> entries((size_t)nchunks * dev::DX_ENTRY_STRIDE + 16, 0xdeadbeefu), chunk_base(nchunks + 1, 0xdeadbeefu);
 	std::vector<dev::DxChunkRec> recs(nchunks + 1);
 	std::vector<dev::DxBandSum> sums((size_t)njobs);
-	const dev::DxTilePlan tp = dx_tile_plan(plan, dp, nframes);
+	// tiles of at most 1536 coefficients (the small test frames then have bands of many tiles, and tiles met by more pieces than a workgroup has threads), or -- mode + 8 -- of the product's size
+	const uint32_t tile_max = full_tiles ? (uint32_t)dev::DX_TILE : 1536u;
+	const dev::DxTilePlan tp = dx_tile_plan(plan, dp, nframes, false, false, false, tile_max);
 	std::vector<dev::DxChunkAlt> alts(nchunks + 1);
 	std::vector<dev::DxReindex> reindex((size_t)nchunks + 1);
 	std::vector<uint32_t> repair_list((size_t)njobs + 1);
@@ -753,7 +757,8 @@ extern "C" int emu_entropy_decode_dx(const uint8_t *sample, size_t size, int pix
 	std::vector<uint32_t> tile_start(tp.total + 1, 0xdeadbeefu);
 	hipemu::launch(dim3((tp.total + dev::DX_THREADS - 1) / dev::DX_THREADS), dim3(dev::DX_THREADS), [&] { dev::k_dec_tile_index(jobs.data(), tp, entries.data(), chunk_base.data(), sums.data(), tile_start.data()); });
 	auto tile_pass = [&](const dev::DxTilePlan &p_, unsigned long long *m_, uint32_t per_) {
-		hipemu::launch(dim3((unsigned)grid), dim3(dev::DX_TILE_THREADS), [&] { dev::k_dec_tiles(jobs.data(), p_, &tables, entries.data(), chunk_base.data(), sums.data(), tile_start.data(), m_, per_); });
+		if (one_wave) hipemu::launch(dim3((unsigned)grid), dim3(64), [&] { dev::k_dec_tiles<64>(jobs.data(), p_, &tables, entries.data(), chunk_base.data(), sums.data(), tile_start.data(), m_, per_); });
+		else hipemu::launch(dim3((unsigned)grid), dim3(dev::DX_TILE_THREADS), [&] { dev::k_dec_tiles<dev::DX_TILE_THREADS>(jobs.data(), p_, &tables, entries.data(), chunk_base.data(), sums.data(), tile_start.data(), m_, per_); });
 	};
 	tile_pass(tp, nullptr, 0u);
 	if (!plan.interlaced && plan.encoded_format == ENC_YUV422) {
@@ -762,7 +767,7 @@ extern "C" int emu_entropy_decode_dx(const uint8_t *sample, size_t size, int pix
 		int mask_base[kMaxChannels][kNumBands];
 		const size_t per_frame = (size_t)dec_block_list_layout(plan, mask_base);
 		std::vector<unsigned long long> masks(per_frame * (size_t)nframes + 8, 0x5555555555555555ull);
-		const dev::DxTilePlan tl = dx_tile_plan(plan, dp, nframes, false, true);
+		const dev::DxTilePlan tl = dx_tile_plan(plan, dp, nframes, false, true, false, tile_max);
 		for (int16_t &v : pyr) v = 0x0bad;             // (stale places must never be read back)
 		tile_pass(tl, masks.data(), (uint32_t)per_frame);
 		for (int f = 0; f < nframes; f++)

@@ -842,10 +842,11 @@ def test_fwd_frame_yuv422_interlaced_level1(w, h, dh, uyvy):
 DX_ARRANGEMENT = 0      # bits added to the mode of emu_entropy_decode_dx; set per test by the `arrangement` fixture
 
 
-@pytest.fixture(params=[0], ids=["index+tiles"])
+@pytest.fixture(params=[0, 16, 24], ids=["index+tiles", "one-wave-workgroups", "one-wave-workgroups-full-tiles"])
 def arrangement(request):
-    """The arrangements of the chunk-indexed decoder that run every test of this section (one since round 6: the single-pass experiment of round 5 -- index walk that
-    logs its steps + a scatter pass -- was measured four times, never adopted and has left the tree; profiles/r05_a..e_*)."""
+    """The arrangements of the chunk-indexed decoder that run every test of this section: k_dec_tiles with the product's four waves per workgroup and tiles of 1536 coefficients, with
+    one wave per workgroup (a tile then takes several rounds of 64 pieces), and that with tiles of the product's size (hundreds of pieces per tile in the dense bands).  (One decoder since round 6: the single-pass experiment of round 5 -- index walk that
+    logs its steps + a scatter pass -- was measured four times, never adopted and has left the tree; profiles/r05_a..e_*.)"""
     global DX_ARRANGEMENT
     DX_ARRANGEMENT = request.param
     yield request.param
@@ -862,7 +863,7 @@ def _dx_decode(sample, plan, mode, grid, size=None, guard=0):
     return rc, got
 
 
-@pytest.mark.parametrize("mode,grid", [(0, 3), (1, 2), (2, 1), (0, 64)])
+@pytest.mark.parametrize("mode,grid", [(0, 3), (1, 2), (2, 1), (0, 64), (8, 2), (10, 3)])      # + 8: tiles of the product's size (else 1536 coefficients: bands of many tiles)
 @pytest.mark.parametrize("w,h,seed", [(192, 96, 1), (336, 252, 3), (720, 480, 4)])
 def test_dx_decoder_emulated_equals_host_decoder(w, h, seed, mode, grid, arrangement):
     """The chunk-indexed decoder reproduces the oracle's decoder (oracle_decode_pyramid: its own sample walk and bit-serial decoder) coefficient for coefficient, every element of every band incl.

@@ -140,6 +140,19 @@ extern "C" int dx_walk_stats(const uint8_t *sample, size_t size, int tile, uint6
 					int mx = 0; uint64_t lm = 0;
 					for (uint32_t l = 0; l < 64 && q + l < npieces; l++) { if (steps[q + l] > mx) mx = steps[q + l]; lm |= longmask[q + l]; }
 					o[10] += mx; o[11] += __builtin_popcountll(lm); o[15]++;
+					// two phases: short steps in lock step until every lane is done or waits at a long code word, then one long step for those, and again
+					int at[64] = { 0 }; bool any = true;
+					while (any) {
+						int run = 0; any = false; bool lng = false;
+						for (uint32_t l = 0; l < 64 && q + l < npieces; l++) {
+							int n = 0;
+							while (at[l] < steps[q + l] && !((longmask[q + l] >> at[l]) & 1ull)) { at[l]++; n++; }
+							if (n > run) run = n;
+							if (at[l] < steps[q + l]) { lng = true; at[l]++; }
+							if (at[l] < steps[q + l]) any = true;
+						}
+						out[32] += run; out[33] += lng; out[34]++;
+					}
 				}
 			}
 	return 0;

@@ -17,7 +17,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 tile = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 W, H = 1920, 1080
 frames, pitch = T.qbist_frames(10, n, W, H)
-out = (ctypes.c_uint64 * 32)(); hist = (ctypes.c_uint64 * 64)(); lens = (ctypes.c_uint64 * 192)()
+out = (ctypes.c_uint64 * 40)(); hist = (ctypes.c_uint64 * 64)(); lens = (ctypes.c_uint64 * 192)()
 for f in frames:
     s = T.ref_encode_frames([f], pitch, W, H)[0]
     rc = L.dx_walk_stats(s, ctypes.c_size_t(len(s)), tile, out, hist, lens)
@@ -29,6 +29,7 @@ for g, nm in enumerate(("level 1", "levels 2+3")):
     print("   bits/coef %.3f  nonzero %.2f%%  pieces/tile %.1f  lanes/round %.1f  steps/piece %.2f  wave steps/round %.2f (long in %.2f)  lane utilisation %.2f  flat: wave steps/round %.2f  ideal wave steps %.0f vs %.0f vs flat %.0f"
           % (o["bits"] / o["coefs"], 100 * o["nonzero"] / o["coefs"], o["pieces"] / o["tiles"], o["lanes_inside"] / o["rounds"], o["lane_steps"] / o["lanes_inside"], o["wave_steps"] / o["rounds"],
              o["wave_steps_long"] / o["rounds"], o["lane_steps"] / (64 * o["wave_steps"]), o["flat_wave_steps"] / o["flat_rounds"], o["lane_steps"] / 64, o["wave_steps"], o["flat_wave_steps"]))
+print("flat rounds, two phases: short wave steps %.0f, long wave steps %.0f, phases %.0f per frame" % (out[32] / n, out[33] / n, out[34] / n))
 print("steps per piece histogram:", [hist[i] // n for i in range(40)])
 for g, nm in enumerate(("level 1", "levels 2+3")):
     for k, kn in enumerate(("runs", "values")):
