@@ -7,7 +7,7 @@ forward kernels -> entropy coding -> samples -> entropy decoding -> inverse kern
 `value` is whole-job frames per second (all ranks); `roofline` is the longest kernel of the step against the HBM peak (HIP events around
 every launch, on the stream it runs on); `cpu_baseline` is the unmodified reference (oracle/_ref) timed on this box's host cores on a
 bounded sample.  After the timed region rank 0 checks what it timed -- eight frames spread over the last timed pass of every batch in flight: the
-samples against the reference encoder run on the same frames (sample 0 also against the golden hash), the decoded frames against the oracle's exact
+samples -- ALL of them, by hash -- against the reference encoder run on the same frames (sample 0 also against the golden hash), the decoded frames against the oracle's exact
 reconstruction of their own samples (`config.parity`) -- and measures the same codec through the reference's own C ABI from host buffers
 (`config.c_abi_fps`, PCIe inclusive, minimum of three runs, never `value`).  Several steps are in flight in the timed region (`--depth`, a HIP-stream frame
 queue of batch objects: cfhd_amd_batch_submit / _wait); the process runs with 16 hardware queues (GPU_MAX_HW_QUEUES, below).
@@ -190,7 +190,7 @@ def normalise_counters(sample):
     return bytes(b)
 
 
-def parity_check(L, b, frames, pitch, W, H, rank, wl, batch, nuniq, nchk=None, first=0):
+def parity_check(L, b, frames, pitch, W, H, rank, wl, batch, nuniq, nchk=None, first=0, ref_cache=None):
     """What was timed is what the reference produces -- checked on frames spread over the batch of the last step (eight of them at 1080p, fewer for the larger
     formats: the checker is scalar C): every checked sample (frame / unique-frame counters set back to the first frame's) against the reference encoder run here on
     the same frame (sample 0 of the 1080p YUY2 workload also against the golden hash in tests/golden), and the decoded frame against the exact integer reconstruction
@@ -203,6 +203,21 @@ def parity_check(L, b, frames, pitch, W, H, rank, wl, batch, nuniq, nchk=None, f
     out = {"frames_checked": checked}
     bpp = wl["bpp"]
     psnr = []
+    # every sample of the pass against the reference encoder's sample of its frame: the batch cycles through `nuniq` pictures, so the reference encodes each once
+    # (ref_cache, shared by the batches in flight) and the comparison is a hash of the sample with its counters and clock-dependent metadata set aside
+    ref_cache = {} if ref_cache is None else ref_cache
+    def ref_digest(u):
+        if u not in ref_cache:
+            r = T.ref_encode_frames([frames[u]], pitch, W, H, fmt, encoded=wl["enc"], flags=wl["flags"])[0]
+            ref_cache[u] = (len(r), hashlib.sha256(T.mask_volatile_metadata(normalise_counters(r))).digest())
+        return ref_cache[u]
+    for i in range(batch):
+        p = ctypes.c_void_p(); sz = ctypes.c_size_t()
+        assert L.cfhd_amd_batch_get_sample(b, i, ctypes.byref(p), ctypes.byref(sz)) == 0
+        want_len, want = ref_digest(i % nuniq)
+        if sz.value != want_len or hashlib.sha256(T.mask_volatile_metadata(normalise_counters(ctypes.string_at(p, sz.value)))).digest() != want:
+            raise AssertionError("sample %d of the pass differs from the reference encoder's sample of its frame (%d vs %d bytes)" % (i, sz.value, want_len))
+    out["samples_checked"] = batch
     for i in checked:
         frame = frames[i % nuniq]
         p = ctypes.c_void_p(); sz = ctypes.c_size_t()
@@ -348,11 +363,13 @@ def measure(workload, steps, warmup, batch, unique, threads, rank, world, barrie
     parity = None
     if rank == 0 and not probing and not os.environ.get("CFHD_BENCH_NO_PARITY"):      # (CFHD_BENCH_NO_PARITY: timing probes of builds that produce no valid output, tools/gpu_r05_f.sh; the line then says parity_checked false)
         last = (steps - 1) % depth
-        parity = parity_check(L, slots[last], frames, pitch, W, H, rank, wl, batch, nuniq)
+        ref_cache = {}
+        parity = parity_check(L, slots[last], frames, pitch, W, H, rank, wl, batch, nuniq, ref_cache=ref_cache)
         for k, q in enumerate(slots):
             if k == last: continue
-            other = parity_check(L, q, frames, pitch, W, H, rank, wl, batch, nuniq, nchk=2 if W * H <= 1920 * 1080 else 1, first=(k + 1) * batch // (depth + 1))
+            other = parity_check(L, q, frames, pitch, W, H, rank, wl, batch, nuniq, nchk=2 if W * H <= 1920 * 1080 else 1, first=(k + 1) * batch // (depth + 1), ref_cache=ref_cache)
             parity.setdefault("other_batches_in_flight", []).append(other["frames_checked"])
+            parity["samples_checked"] += other["samples_checked"]
     kms_alone = None
     if depth > 1:
         ALONE_STEPS = 3

@@ -811,49 +811,69 @@ struct DxTilePlan { int nslots, nframes; uint32_t cum[40]; uint32_t per_band[40]
 
 enum : uint32_t { DX_TILE_EMPTY = 0xFFFFFFFFu };
 
-__device__ __forceinline__ void dx_tile_of(const DxTilePlan &plan, uint32_t t, int *job, uint32_t *ti, uint32_t *len)
+
+// What k_dec_tiles needs to know about a tile, ready made (k_dec_tile_index, one thread per tile): the decode kernel fetches one record per tile two turns ahead and has no
+// chain of dependent loads (plan -> job -> band sums -> tile start) and no division left in its turn.
+struct DxTileDesc {
+	const uint8_t *bits; int16_t *dst; unsigned long long *masks;     // payload of the band; first coefficient of the tile; the tile's first chunk mask when it leaves as block lists, else null
+	uint32_t bytes, chunk0, first_sub, end_sub;                       // payload bytes, first chunk of the band in the chunk arrays, pieces [first_sub, end_sub) may reach into the tile (first_sub DX_TILE_EMPTY: none)
+	uint32_t T0, ncoef, quant, table;                                 // first coefficient, coefficients of the tile (0: nothing to write: a band that is not wanted), divisor, code set (DecBandJob::table)
+	uint32_t pad[2];
+};
+static_assert(sizeof(DxTileDesc) == 64, "four 16-byte loads");
+
+// The 64-bit piece of payload that holds the code word at (or the last one in front of) coefficient T0 of a band -- where k_dec_tiles starts to decode a tile that begins
+// there.  Two binary searches over what k_dec_index / k_dec_chain left: chunks, then pieces.
+__device__ __forceinline__ uint32_t dx_piece_at(const DxBandJob &job, const DxBandSum &sum, const uint32_t *entries, const uint32_t *chunk_base, const uint32_t T0)
 {
-	int slot = 0;
-	while (slot + 1 < plan.nslots && t >= plan.cum[slot + 1]) slot++;
-	const uint32_t r = t - plan.cum[slot], per = plan.per_band[slot];
-	const uint32_t f = r / per;
-	*ti = r - f * per;
-	*job = (int)plan.slot_of[slot] * plan.nframes + (int)f;
-	*len = plan.tile_len[slot];
+	if (!(job.bytes != 0u && sum.last_chunk >= 0 && T0 < sum.total && T0 < (uint32_t)job.n)) return DX_TILE_EMPTY;
+	const uint32_t *cb = chunk_base + job.chunk0;
+	uint32_t lo = 0, hi = (uint32_t)sum.last_chunk;       // largest chunk k with cb[k] <= T0 (cb[0] = 0)
+	while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (cb[mid] <= T0) lo = mid; else hi = mid - 1; }
+	const uint32_t kc = lo, base = cb[kc];
+	const uint32_t *e = entries + ((size_t)job.chunk0 + kc) * DX_ENTRY_STRIDE + DX_SUBS;      // the chunk's 252 pieces, in order
+	uint32_t a = 0, b = DX_CHUNK_SUBS - 1;                // largest piece whose first code word lies at or in front of T0 (piece 0 does)
+	while (a < b) {
+		const uint32_t mid = (a + b + 1) >> 1, v = e[mid];
+		if ((v & 31u) != (uint32_t)DX_OFF_INVALID && base + (v >> 5) <= T0) a = mid; else b = mid - 1;
+	}
+	return kc * DX_CHUNK_SUBS + a;
 }
 
-// One thread per output tile: the 64-bit piece of payload that holds the code word at (or the last one in front of) the tile's first
-// coefficient -- where k_dec_tiles starts to decode.  Two binary searches over what k_dec_index / k_dec_chain left: chunks, then pieces.
+// One thread per output tile: its record.  The pieces that may reach into the tile run from the one that holds its first coefficient to the one that holds the first
+// coefficient of the band's next tile (the band's last tile: to the chunk with the band end marker).
 __global__ void __launch_bounds__(DX_THREADS) k_dec_tile_index(const DxBandJob *jobs, DxTilePlan plan, const uint32_t *entries, const uint32_t *chunk_base, const DxBandSum *sums,
-                                                               uint32_t *tile_start)
+                                                               DxTileDesc *tiles, unsigned long long *masks, uint32_t masks_per_frame)
 {
 	const uint32_t t = (uint32_t)blockIdx.x * DX_THREADS + (uint32_t)threadIdx.x;
 	if (t >= plan.total) return;
-	int j; uint32_t ti, len;
-	dx_tile_of(plan, t, &j, &ti, &len);
+	int slot = 0;
+	while (slot + 1 < plan.nslots && t >= plan.cum[slot + 1]) slot++;
+	const uint32_t r = t - plan.cum[slot], per = plan.per_band[slot], len = plan.tile_len[slot];
+	const uint32_t f = r / per, ti = r - f * per;
+	const int j = (int)plan.slot_of[slot] * plan.nframes + (int)f;
 	const DxBandJob job = jobs[j];
 	const DxBandSum sum = sums[j];
 	const uint32_t T0 = ti * len;
-	uint32_t q0 = DX_TILE_EMPTY;
-	if (job.bytes != 0u && sum.last_chunk >= 0 && T0 < sum.total && T0 < (uint32_t)job.n) {
-		const uint32_t *cb = chunk_base + job.chunk0;
-		uint32_t lo = 0, hi = (uint32_t)sum.last_chunk;       // largest chunk k with cb[k] <= T0 (cb[0] = 0)
-		while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (cb[mid] <= T0) lo = mid; else hi = mid - 1; }
-		const uint32_t kc = lo, base = cb[kc];
-		const uint32_t *e = entries + ((size_t)job.chunk0 + kc) * DX_ENTRY_STRIDE + DX_SUBS;      // the chunk's 252 pieces, in order
-		uint32_t a = 0, b = DX_CHUNK_SUBS - 1;                // largest piece whose first code word lies at or in front of T0 (piece 0 does)
-		while (a < b) {
-			const uint32_t mid = (a + b + 1) >> 1, v = e[mid];
-			if ((v & 31u) != (uint32_t)DX_OFF_INVALID && base + (v >> 5) <= T0) a = mid; else b = mid - 1;
-		}
-		q0 = kc * DX_CHUNK_SUBS + a;
+	const bool any = job.bytes != 0u && T0 < (uint32_t)job.n;
+	const uint32_t T1 = any ? (T0 + len < (uint32_t)job.n ? T0 + len : (uint32_t)job.n) : T0;
+	DxTileDesc d;
+	d.bits = job.bits; d.bytes = job.bytes; d.chunk0 = job.chunk0; d.quant = (uint32_t)job.quant; d.table = (uint32_t)job.table;
+	d.dst = job.dst + T0; d.T0 = T0; d.ncoef = T1 - T0;
+	d.masks = (any && masks && plan.mask_base[slot] >= 0) ? masks + (size_t)f * masks_per_frame + (size_t)plan.mask_base[slot] + (size_t)(T0 / 512u) : nullptr;
+	d.first_sub = any ? dx_piece_at(job, sum, entries, chunk_base, T0) : (uint32_t)DX_TILE_EMPTY;
+	d.end_sub = 0u;
+	if (d.first_sub != DX_TILE_EMPTY) {
+		const uint32_t last = ((uint32_t)sum.last_chunk + 1u) * DX_CHUNK_SUBS;
+		const uint32_t next = (ti + 1u < per) ? dx_piece_at(job, sum, entries, chunk_base, T0 + len) : (uint32_t)DX_TILE_EMPTY;
+		d.end_sub = (next != DX_TILE_EMPTY && next + 1u < last) ? next + 1u : last;
 	}
-	tile_start[t] = q0;
+	d.pad[0] = 0u; d.pad[1] = 0u;
+	tiles[t] = d;
 }
 
-// What a wave of k_dec_tiles needs to know about a tile, and the first 64 pieces of payload it decodes of it: both are fetched
-// one tile ahead, so that the loads are in flight while the previous tile is decoded.
-struct DxTileMeta { int j; uint32_t T0, len, first_sub, next_sub; DxBandJob job; DxBandSum sum; unsigned long long *masks; /* the band's chunk masks in this frame, or null: dense */ };
+// k_dec_tiles fetches a tile's record and the first 64 pieces of payload every wave decodes of it ahead of time, so that the loads are in flight while the tile
+// in front is decoded.
 // 0 in every lane, but not to the compiler: an address with it added is per-lane, so the load becomes a vector load (counted by vmcnt) and
 // not a scalar one -- scalar loads share their counter with LDS, and the first LDS read of the decode loop would wait for the prefetch.
 __device__ __forceinline__ uint32_t dx_lane_zero() { return __builtin_amdgcn_mbcnt_lo(0u, 0u); }
@@ -874,43 +894,21 @@ template <typename T> __device__ __forceinline__ T dx_uniform(const T &v)    // 
 	return r;
 }
 struct DxPieces { uint32_t ent, cb, d[3]; };
-__device__ __forceinline__ void dx_tile_meta(const DxTilePlan &plan, uint32_t t, int &slot, const DxBandJob *jobs, const DxBandSum *sums, const uint32_t *tile_start, DxTileMeta &M,
-                                             unsigned long long *masks = nullptr, uint32_t masks_per_frame = 0u)
-{
-	while (slot + 1 < plan.nslots && t >= plan.cum[slot + 1]) slot++;       // tiles come in increasing order: the slot only moves forward
-	const uint32_t r = t - plan.cum[slot], per = plan.per_band[slot];
-	const uint32_t f = r / per, ti = r - f * per;
-	M.len = plan.tile_len[slot]; M.T0 = ti * M.len; M.j = (int)plan.slot_of[slot] * plan.nframes + (int)f;
-	M.masks = (masks && plan.mask_base[slot] >= 0) ? masks + (size_t)f * masks_per_frame + (size_t)plan.mask_base[slot] : nullptr;
-	dx_vload(M.first_sub, tile_start + t);
-	// the first piece of the band's next tile is the last one that can reach into this tile (the band's last tile: DX_TILE_EMPTY, the pieces run to the band's end)
-	M.next_sub = DX_TILE_EMPTY;
-	if (ti + 1u < per) dx_vload(M.next_sub, tile_start + t + 1);
-	dx_vload(M.job, jobs + M.j);
-	dx_vload(M.sum, sums + M.j);
-}
-__device__ __forceinline__ void dx_tile_pieces(const DxTileMeta &M, uint32_t q, uint32_t end_sub, const uint32_t *entries, const uint32_t *chunk_base, DxPieces &P)
+__device__ __forceinline__ void dx_tile_pieces(const DxTileDesc &D, uint32_t q, const uint32_t *entries, const uint32_t *chunk_base, DxPieces &P)
 {
 	P.ent = DX_OFF_INVALID; P.cb = 0;
 #pragma unroll
 	for (int i = 0; i < 3; i++) P.d[i] = 0u;
-	if (q < end_sub) {
+	if (D.first_sub != DX_TILE_EMPTY && q < D.end_sub) {
 		// entry, chunk position and the next 96 bits of the payload from the piece on (a walk starts inside the piece's 64 bits and looks at 32 bits at a time): independent loads
 		const uint32_t kq = q / DX_CHUNK_SUBS, within = q - kq * DX_CHUNK_SUBS;
-		P.ent = entries[((size_t)M.job.chunk0 + kq) * DX_ENTRY_STRIDE + DX_SUBS + within];
-		P.cb = chunk_base[(size_t)M.job.chunk0 + kq];
+		P.ent = entries[((size_t)D.chunk0 + kq) * DX_ENTRY_STRIDE + DX_SUBS + within];
+		P.cb = chunk_base[(size_t)D.chunk0 + kq];
 		const uint32_t byte0 = q * (DX_SUB_BITS / 8);
-		const uint32_t *src = (const uint32_t *)(M.job.bits + byte0);
+		const uint32_t *src = (const uint32_t *)(D.bits + byte0);
 #pragma unroll
-		for (int i = 0; i < 3; i++) P.d[i] = byte0 + 4u * (uint32_t)i + 4u <= M.job.bytes ? src[i] : 0u;
+		for (int i = 0; i < 3; i++) P.d[i] = byte0 + 4u * (uint32_t)i + 4u <= D.bytes ? CFHD_LDG32(src + i) : 0u;      // (global_load: a flat load would tick the LDS counter too, and the decode loop's first table lookup would wait for the prefetch)
 	}
-}
-__device__ __forceinline__ bool dx_tile_has_work(const DxTileMeta &M) { return M.job.bytes != 0u && M.T0 < (uint32_t)M.job.n && M.first_sub != DX_TILE_EMPTY; }
-// one behind the last piece that can reach into the tile
-__device__ __forceinline__ uint32_t dx_tile_end_sub(const DxTileMeta &M)
-{
-	const uint32_t last = ((uint32_t)M.sum.last_chunk + 1u) * DX_CHUNK_SUBS;
-	return (M.next_sub != DX_TILE_EMPTY && M.next_sub + 1u < last) ? M.next_sub + 1u : last;
 }
 
 // The LDS image of a workgroup's tile: DX_TILE coefficients and, behind them, one dump slot per thread -- a store that has nothing to write (no value
@@ -919,12 +917,67 @@ __device__ __forceinline__ uint32_t dx_tile_end_sub(const DxTileMeta &M)
 // ones are below the knee of the companding curve, the long ones carry their expanded magnitude in the table); the band's divisor is applied on the
 // way out, two coefficients per multiply.
 enum { DX_TILE_WORDS = DX_TILE / 2 + DX_TILE_THREADS / 2 };
+enum { DX_WAIT_VMCNT0 = 0x0f70 };      // s_waitcnt vmcnt(0) on gfx9: vmcnt = bits 3:0 and 15:14 (0), expcnt = bits 6:4 (7: no wait), lgkmcnt = bits 11:8 (15: no wait)
 static_assert(DX_TILE % 512 == 0, "a tile is a whole number of chunks of 64 blocks");
 static_assert(DX_TILE + DX_TILE_THREADS + 4096 <= DX_NO_VALUE, "a position the table marks as absent must lie behind the dump slots wherever the piece starts (at most 6 x 320 coefficients in front of its tile)");
 
+// One round of k_dec_tiles: this lane's piece q (entry, chunk position and payload words in P) decoded into the LDS image of the tile [T0, T1).  Returns false (to the
+// whole wave) when a piece of the round starts behind the tile: pieces are in raster order, all later ones do too.
+__device__ __forceinline__ bool dx_tile_round(const DxPieces &P, const uint32_t q, const uint32_t end_sub, const uint32_t T0, const uint32_t T1, const int len_tile, const uint32_t mag_shift,
+                                              const uint32_t dump, const uint2 *s_multi, const uint32_t *s_long, int16_t *tile16)
+{
+	const uint32_t off = P.ent & 31u;
+	const uint32_t idx0 = P.cb + (P.ent >> 5);
+	const bool valid = q < end_sub && off != (uint32_t)DX_OFF_INVALID;
+	const bool inside = valid && idx0 < T1;
+	if (inside) {
+		// The walk starts at bit `off` (< 31) of the piece and goes on while it is inside the piece's 64 bits; a code word has at most 27
+		// bits, so every 32-bit window the walk looks at lies in the piece's first 96 bits: three words, no refill state -- the window at bit
+		// position pos is cut out of the word pair it starts in.
+		const uint32_t w0 = bswap32(P.d[0]), w1 = bswap32(P.d[1]), w2 = bswap32(P.d[2]);
+		uint32_t pos = off;
+		uint32_t rel = idx0 - T0;                          // position inside the tile; "negative" (the piece starts in front of the tile) wraps to a huge number
+		// one loop with one way out; both kinds of step (a group out of the multi-symbol table | one long code word) feed the same two
+		// unconditional stores
+		bool alive = true;
+		do {
+			const bool second = pos >= 32u;
+			const uint32_t win = (uint32_t)(((((uint64_t)(second ? w1 : w0)) << 32) | (second ? w2 : w1)) << (pos & 31u) >> 32);
+			// up to two values and the zero runs around them per lookup.  A group may reach over the end of the piece: the lane of the
+			// next piece then writes the same values to the same places again.
+			const uint2 e = s_multi[win >> (32 - DX_KM)];
+			uint32_t adv = e.x & 15u, total = (e.x >> 4) & 0xfffu, o1 = e.x >> 16, o2 = e.y & 0xffffu;
+			int v1 = (int)(int8_t)(e.y >> 16), v2 = (int)(int8_t)(e.y >> 24);
+			if (adv == 0u) {
+				// a code word that does not fit the window (a large value, a long run, the band end marker): alone, through its own trie.  Its entry is made for
+				// this place: bits incl. the sign bit, and one payload field per code set that is the run, the expanded magnitude, or 0 (end marker, no code)
+				uint32_t le = e.y;
+				if (((le >> 5) & 7u) == (uint32_t)DX_T_ESCAPE) {
+					le = s_long[((le >> 8) & 0xfffu) + ((win << DX_KM) >> (32 - DX_L11_BITS))];
+					if (((le >> 5) & 7u) == (uint32_t)DX_T_ESCAPE) le = s_long[((le >> 8) & 0xfffu) + ((win << (DX_KM + DX_L11_BITS)) >> (32 - (le & 31u)))];
+				}
+				const uint32_t ty = (le >> 5) & 7u, pay = (le >> mag_shift) & 0xfffu;
+				const bool isval = ty == (uint32_t)DX_T_VALUE;
+				adv = le & 31u;
+				total = isval ? 1u : pay;
+				o1 = isval ? 0u : (uint32_t)DX_NO_VALUE; o2 = (uint32_t)DX_NO_VALUE;
+				v1 = (int)(win << ((adv - 1u) & 31u)) < 0 ? -(int)pay : (int)pay;        // (a run's "value" goes to the dump slot)
+				alive = ty - (uint32_t)DX_T_RUN < 2u;                // else: the band end marker (or a broken code, reported by k_dec_chain)
+			}
+			// a value whose place lies outside the tile (or that is not there at all) goes to the thread's dump slot: min() does both
+			const uint32_t p1 = rel + o1, p2 = rel + o2;
+			tile16[p1 < dump ? p1 : dump] = (int16_t)v1;
+			tile16[p2 < dump ? p2 : dump] = (int16_t)v2;
+			rel += total;
+			pos += adv;
+			alive = alive && pos < (uint32_t)DX_SUB_BITS && (int)rel < len_tile;
+		} while (alive);
+	}
+	return __ballot(valid && !inside) == 0ull;
+}
+
 template <int NT /* threads: DX_TILE_THREADS (the emulated kernel tests also run 64, so that small tiles take several rounds per wave) */>
-__global__ void __launch_bounds__(NT) k_dec_tiles(const DxBandJob *jobs, DxTilePlan plan, const DecIdxTables *T, const uint32_t *entries, const uint32_t *chunk_base,
-                                                               const DxBandSum *sums, const uint32_t *tile_start, unsigned long long *masks, uint32_t masks_per_frame)
+__global__ void __launch_bounds__(NT) k_dec_tiles(const DxTileDesc *tiles, uint32_t first, uint32_t total, const DecIdxTables *T, const uint32_t *entries, const uint32_t *chunk_base)
 {
 	__shared__ uint2 s_multi[1 << DX_KM];
 	__shared__ uint32_t s_long[DX_LONG11_MAX];
@@ -935,111 +988,61 @@ __global__ void __launch_bounds__(NT) k_dec_tiles(const DxBandJob *jobs, DxTileP
 	const int lane = wave_lane(), wave = wave_uniform((int)(threadIdx.x >> 6));
 	__syncthreads();
 	const uint32_t stride = (uint32_t)gridDim.x;
-	uint32_t t = plan.first + (uint32_t)blockIdx.x;
-	if (t >= plan.total) return;                           // (the whole workgroup)
-	// software pipeline: tile t is decoded while the descriptors of tile t + 2 stride and this wave's first pieces of tile t + stride are on their way
-	int slot = 0;
-	DxTileMeta M, M1;
-	dx_tile_meta(plan, t, slot, jobs, sums, tile_start, M, masks, masks_per_frame);
-	M1 = M;
-	if (t + stride < plan.total) dx_tile_meta(plan, t + stride, slot, jobs, sums, tile_start, M1, masks, masks_per_frame);
+	uint32_t t = first + (uint32_t)blockIdx.x;
+	if (t >= total) return;                                // (the whole workgroup)
+	// software pipeline: tile t is decoded while the record of tile t + 2 stride and this wave's first pieces of tile t + stride are on their way
+	DxTileDesc D, D1;
+	dx_vload(D, tiles + t);
+	D1 = D;
+	if (t + stride < total) dx_vload(D1, tiles + t + stride); else D1.first_sub = DX_TILE_EMPTY;
 	const uint32_t mine = (uint32_t)wave * 64u + (uint32_t)lane;        // this thread's piece in the first round of a tile
 	DxPieces P;
-	dx_tile_pieces(M, dx_tile_has_work(M) ? M.first_sub + mine : 0xFFFFFFFFu, dx_tile_has_work(M) ? dx_tile_end_sub(M) : 0u, entries, chunk_base, P);
+	dx_tile_pieces(D, D.first_sub + mine, entries, chunk_base, P);
 	int16_t *tile16 = (int16_t *)s_tile;
 	const uint32_t dump = (uint32_t)DX_TILE + (uint32_t)threadIdx.x;     // this thread's dump slot (16-bit index)
+	__builtin_amdgcn_s_waitcnt(DX_WAIT_VMCNT0);               // (the first tile's record and pieces: from here on every turn waits for its loads in one place, see below)
 #pragma unroll 1
-	for (; t < plan.total; t += stride) {
-		DxTileMeta M2 = M1;
+	for (; t < total; t += stride) {
+		DxTileDesc D2 = D1;
 		DxPieces P1;
-		if (t + 2 * stride < plan.total) dx_tile_meta(plan, t + 2 * stride, slot, jobs, sums, tile_start, M2, masks, masks_per_frame);
-		{
-			const bool w1 = t + stride < plan.total && dx_tile_has_work(M1);
-			dx_tile_pieces(M1, w1 ? M1.first_sub + mine : 0xFFFFFFFFu, w1 ? dx_tile_end_sub(M1) : 0u, entries, chunk_base, P1);
-		}
-		const DxBandJob job = dx_uniform(M.job);
-		const uint32_t first_sub = (uint32_t)wave_uniform((int)M.first_sub);
-		const uint32_t T0 = (uint32_t)wave_uniform((int)M.T0);
-		const bool any = job.bytes != 0u && T0 < (uint32_t)job.n;           // the same for the whole workgroup
-		const uint32_t tlen = (uint32_t)wave_uniform((int)M.len);
-		const uint32_t T1 = any ? (T0 + tlen < (uint32_t)job.n ? T0 + tlen : (uint32_t)job.n) : T0;
-		if (any && first_sub != DX_TILE_EMPTY) {
+		if (t + 2 * stride < total) dx_vload(D2, tiles + t + 2 * stride); else D2.first_sub = DX_TILE_EMPTY;
+		dx_tile_pieces(D1, D1.first_sub + mine, entries, chunk_base, P1);
+		const DxTileDesc d = dx_uniform(D);
+		const uint32_t T0 = d.T0, T1 = d.T0 + d.ncoef;
+		if (d.first_sub != DX_TILE_EMPTY) {
 			// 64 consecutive pieces per wave and round, one per lane, until the pieces start behind the tile
-			const uint32_t end_sub = (uint32_t)wave_uniform((int)dx_tile_end_sub(M));
-			const bool linear = (job.table & 1) != 0;                      // code set 18: the second magnitude of the long entries
-			const uint32_t mag_shift = linear ? 20u : 8u;
-			const int len_tile = (int)(T1 - T0);
+			const uint32_t mag_shift = (d.table & 1u) ? 20u : 8u;          // code set 18: the second magnitude of the long entries
+			const int len_tile = (int)d.ncoef;
+			// the first round on the pieces fetched a tile ahead -- straight-line code: behind a join with the path that loads further pieces the compiler would wait for
+			// the prefetches just issued --, further rounds (a dense tile: more pieces than the workgroup has threads) load theirs
+			bool more = dx_tile_round(P, d.first_sub + mine, d.end_sub, T0, T1, len_tile, mag_shift, dump, s_multi, s_long, tile16);
 #pragma unroll 1
-			for (uint32_t q0 = first_sub + (uint32_t)wave * 64u; q0 < end_sub; q0 += (uint32_t)NT) {
-				const uint32_t q = q0 + (uint32_t)lane;
-				if (q0 != first_sub + (uint32_t)wave * 64u) dx_tile_pieces(M, q, end_sub, entries, chunk_base, P);     // further rounds: a dense tile (more pieces than the workgroup has threads)
-				const uint32_t off = P.ent & 31u;
-				const uint32_t idx0 = P.cb + (P.ent >> 5);
-				const bool valid = q < end_sub && off != (uint32_t)DX_OFF_INVALID;
-				const bool inside = valid && idx0 < T1;
-				if (inside) {
-					// The walk starts at bit `off` (< 31) of the piece and goes on while it is inside the piece's 64 bits; a code word has at most 27
-					// bits, so every 32-bit window the walk looks at lies in the piece's first 96 bits: three words, no refill state -- the window at bit
-					// position pos is cut out of the word pair it starts in.
-					const uint32_t w0 = bswap32(P.d[0]), w1 = bswap32(P.d[1]), w2 = bswap32(P.d[2]);
-					uint32_t pos = off;
-					uint32_t rel = idx0 - T0;                          // position inside the tile; "negative" (the piece starts in front of the tile) wraps to a huge number
-					// one loop with one way out; both kinds of step (a group out of the multi-symbol table | one long code word) feed the same two
-					// unconditional stores
-					bool alive = true;
-					do {
-						const bool second = pos >= 32u;
-						const uint32_t win = (uint32_t)(((((uint64_t)(second ? w1 : w0)) << 32) | (second ? w2 : w1)) << (pos & 31u) >> 32);
-						// up to two values and the zero runs around them per lookup.  A group may reach over the end of the piece: the lane of the
-						// next piece then writes the same values to the same places again.
-						const uint2 e = s_multi[win >> (32 - DX_KM)];
-						uint32_t adv = e.x & 15u, total = (e.x >> 4) & 0xfffu, o1 = e.x >> 16, o2 = e.y & 0xffffu;
-						int v1 = (int)(int8_t)(e.y >> 16), v2 = (int)(int8_t)(e.y >> 24);
-						if (adv == 0u) {
-							// a code word that does not fit the window (a large value, a long run, the band end marker): alone, through its own trie.  Its entry is made for
-							// this place: bits incl. the sign bit, and one payload field per code set that is the run, the expanded magnitude, or 0 (end marker, no code)
-							uint32_t le = e.y;
-							if (((le >> 5) & 7u) == (uint32_t)DX_T_ESCAPE) {
-								le = s_long[((le >> 8) & 0xfffu) + ((win << DX_KM) >> (32 - DX_L11_BITS))];
-								if (((le >> 5) & 7u) == (uint32_t)DX_T_ESCAPE) le = s_long[((le >> 8) & 0xfffu) + ((win << (DX_KM + DX_L11_BITS)) >> (32 - (le & 31u)))];
-							}
-							const uint32_t ty = (le >> 5) & 7u, pay = (le >> mag_shift) & 0xfffu;
-							const bool isval = ty == (uint32_t)DX_T_VALUE;
-							adv = le & 31u;
-							total = isval ? 1u : pay;
-							o1 = isval ? 0u : (uint32_t)DX_NO_VALUE; o2 = (uint32_t)DX_NO_VALUE;
-							v1 = (int)(win << ((adv - 1u) & 31u)) < 0 ? -(int)pay : (int)pay;        // (a run's "value" goes to the dump slot)
-							alive = ty - (uint32_t)DX_T_RUN < 2u;                // else: the band end marker (or a broken code, reported by k_dec_chain)
-						}
-						// a value whose place lies outside the tile (or that is not there at all) goes to the thread's dump slot: min() does both
-						const uint32_t p1 = rel + o1, p2 = rel + o2;
-						tile16[p1 < dump ? p1 : dump] = (int16_t)v1;
-						tile16[p2 < dump ? p2 : dump] = (int16_t)v2;
-						rel += total;
-						pos += adv;
-						alive = alive && pos < (uint32_t)DX_SUB_BITS && (int)rel < len_tile;
-					} while (alive);
-				}
-				// pieces are in raster order: once a valid one starts behind the tile, all later ones do
-				if (__ballot(valid && !inside)) break;
+			for (uint32_t q0 = d.first_sub + (uint32_t)wave * 64u + (uint32_t)NT; more && q0 < d.end_sub; q0 += (uint32_t)NT) {
+				DxPieces Q;
+				dx_tile_pieces(d, q0 + (uint32_t)lane, entries, chunk_base, Q);
+				more = dx_tile_round(Q, q0 + (uint32_t)lane, d.end_sub, T0, T1, len_tile, mag_shift, dump, s_multi, s_long, tile16);
 			}
 		}
+		// The loads issued at the top of this turn -- the next tile's pieces, the record of the one after -- have had the whole decode to arrive: wait for them HERE, in
+		// front of the stores below.  Left to the compiler the wait sits where the registers are first used, behind the stores, and vmcnt counts in order: every tile then
+		// waited for its own stores to be acknowledged by memory (and, at the top of the decode, for the loads just issued): two exposed memory round trips per tile.
+		__builtin_amdgcn_s_waitcnt(DX_WAIT_VMCNT0);
+		D = D1; D1 = D2; P = P1;
 		__syncthreads();
-		if (any) {
+		if (d.ncoef) {
 			// the tile goes out in 16-byte words, times the band's divisor (only the low 16 bits of value x divisor are kept, as in the reference's PIXEL arithmetic),
 			// and the image is cleared for the next one: chunks of 64 blocks, dealt to the waves in turn
-			uint4 *dst = (uint4 *)(job.dst + T0);
-			const uint32_t n16 = (T1 - T0) / 8;
-			const uint32_t quant2 = ((uint32_t)job.quant & 0xffffu) * 0x10001u;
+			uint4 *dst = (uint4 *)d.dst;
+			const uint32_t n16 = d.ncoef / 8;
+			const uint32_t quant2 = (d.quant & 0xffffu) * 0x10001u;
 			const uint4 zero = { 0u, 0u, 0u, 0u };
-			unsigned long long *const tmasks = wave_uniform_ptr(M.masks);
-			const uint32_t chunk0 = T0 / 512u;
+			unsigned long long *const tmasks = d.masks;
 #pragma unroll 1
 			for (uint32_t it = (uint32_t)wave; it < (uint32_t)DX_TILE / 512u; it += (uint32_t)(NT / 64)) {
 				const uint32_t i = it * 64u + (uint32_t)lane;
 				uint4 v = ((const uint4 *)s_tile)[i];
 				((uint4 *)s_tile)[i] = zero;
-				if (it * 64u >= n16) continue;                // (behind the band's end: cleared, not stored)
+				if (it * 64u >= n16) continue;                // (behind the tile's end: cleared, not stored)
 				const bool nz = i < n16 && (v.x | v.y | v.z | v.w) != 0u;
 				v.x = pk_mulw(v.x, quant2); v.y = pk_mulw(v.y, quant2); v.z = pk_mulw(v.z, quant2); v.w = pk_mulw(v.w, quant2);
 				if (tmasks) {
@@ -1048,12 +1051,11 @@ __global__ void __launch_bounds__(NT) k_dec_tiles(const DxBandJob *jobs, DxTileP
 					// level-1 strip kernel gathers them (k_inv_yuv422_strip_blocks); what lies behind a chunk's listed blocks in the band is stale and never read.
 					const unsigned long long m = __ballot(nz);
 					if (nz) dst[it * 64u + wave_mbcnt(m)] = v;
-					if (lane == 0) tmasks[chunk0 + it] = m;
+					if (lane == 0) tmasks[it] = m;
 				} else if (i < n16) dst[i] = v;
 			}
 		}
 		__syncthreads();
-		M = M1; M1 = M2; P = P1;
 	}
 }
 

@@ -348,7 +348,7 @@ int GpuEntropyDecoder::prepare(const FramePlan &plan, int nframes, int16_t *d_co
 		{
 			dev::DecPlan dp0; dec_build_plan(plan, out_kind, &dp0);
 			const dev::DxTilePlan tp0 = dx_tile_plan(plan, dp0, n_, false);
-			HIPCHK(hipMalloc(&d_tile_start_, ((size_t)tp0.total + 1) * 4));
+			HIPCHK(hipMalloc(&d_tile_start_, ((size_t)tp0.total + 1) * sizeof(dev::DxTileDesc)));      // one record per tile (k_dec_tile_index)
 			const char *se = getenv("CFHD_AMD_DX_STATS");
 			if (se && atoi(se)) { HIPCHK(hipMalloc(&d_stats_, 64)); HIPCHK(hipMemset(d_stats_, 0, 64)); }
 		}
@@ -566,7 +566,7 @@ int GpuEntropyDecoder::launch_dx(bool device_jobs, int njobs, uint32_t host_chun
 	dev::k_dec_reindex<<<g1, dev::DX_THREADS, 0, st>>>(jobs, T, (uint32_t *)d_entries_, (const dev::DxReindex *)d_reindex_, (const uint32_t *)d_counters_, (uint32_t *)d_stats_,
 	                                                   (const dev::DxChunkAlt *)d_alts_, (const uint32_t *)d_alt_entries_);
 	dev::k_dec_tile_index<<<(tp.total + dev::DX_THREADS - 1) / dev::DX_THREADS, dev::DX_THREADS, 0, st>>>(jobs, tp, (const uint32_t *)d_entries_, (const uint32_t *)d_chunk_base_, (const dev::DxBandSum *)d_sums_,
-	                                                                                                  (uint32_t *)d_tile_start_);
+	                                                                                                  (dev::DxTileDesc *)d_tile_start_, tmasks, (uint32_t)masks_per_frame_);
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[6], st));
 	// Many frames: the tiles of the level-2 / level-3 bands (a quarter of them) and the lowpass bands first, an event behind them, then the level-1 tiles -- the caller
 	// may run the inverse transforms of levels 3 and 2 on another stream beside the second launch (DecodeBatch::launch_inverse).  Off unless CFHD_AMD_TILES_SPLIT=1:
@@ -575,7 +575,7 @@ int GpuEntropyDecoder::launch_dx(bool device_jobs, int njobs, uint32_t host_chun
 	const char *split_env = getenv("CFHD_AMD_TILES_SPLIT");
 	l23_split_ = frames >= 8 && !skip_level1_ && tp.split > 0 && tp.split < tp.total && split_env && split_env[0] == '1';
 	auto tile_pass = [&](const dev::DxTilePlan &p, int g) {
-		dev::k_dec_tiles<dev::DX_TILE_THREADS><<<g < 1 ? 1 : g, dev::DX_TILE_THREADS, 0, st>>>(jobs, p, T, (const uint32_t *)d_entries_, (const uint32_t *)d_chunk_base_, (const dev::DxBandSum *)d_sums_, (const uint32_t *)d_tile_start_, tmasks, (uint32_t)masks_per_frame_);
+		dev::k_dec_tiles<dev::DX_TILE_THREADS><<<g < 1 ? 1 : g, dev::DX_TILE_THREADS, 0, st>>>((const dev::DxTileDesc *)d_tile_start_, p.first, p.total, T, (const uint32_t *)d_entries_, (const uint32_t *)d_chunk_base_);
 	};
 	if (l23_split_) {
 		dev::DxTilePlan ta = tp, tb = tp;

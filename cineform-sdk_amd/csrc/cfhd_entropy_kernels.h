@@ -189,9 +189,12 @@ __device__ __forceinline__ EntSegJob ent_seg_job(const EntSegJob *seg_jobs, cons
 // A band coded with table 1 (difference coded) is coded with peaks (EncodeQuantLongRunsPlusPeaks, encoder.c:4802): a coefficient beyond +-ENT_PEAK_THRESHOLD goes
 // into the stream as +-(threshold + 1) and its value x divisor into the peak table behind the band (encoder.c:6543-6585), in raster order.  k_ent_count codes the
 // clamped value and counts the peaks of its segment, k_ent_scan turns the counts into positions, k_ent_layout sizes the table's hole, writes its chunk header and the
-// three tags in front of the band, k_ent_peaks fills the values in.  peak_flags[frame]: bit 0 raised when the frame has a peak at all (statistics), bit 1 when a band
-// has more of them than the positions hold (ENT_PEAK_MAX: the caller writes that sample on the host).
-enum { ENT_PEAK_THRESHOLD = 250, ENT_PEAK_OFF_BITS = 21, ENT_PEAK_MAX = (1 << ENT_PEAK_OFF_BITS) - 1 };
+// three tags in front of the band, k_ent_peaks fills the values in.  peak_flags[frame]: bit 0 raised when the frame has a peak at all (statistics).
+enum { ENT_PEAK_THRESHOLD = 250, ENT_PEAK_OFF_BITS = 21, ENT_PEAK_MAX = (1 << ENT_PEAK_OFF_BITS) - 1,
+       // The table's chunk header counts longwords in 16 bits: the reference writes a table only while (peaks rounded up to even) / 2 <= MAX_CHUNK_SIZE = 0xffff
+       // (encoder.c:6557, codec.h:195) and otherwise nothing at all -- no table, the three tags in front of the band left zero, the clamped values stay in the stream.
+       ENT_PEAK_TABLE_MAX = 2 * 0xffff };
+static_assert(ENT_PEAK_TABLE_MAX <= ENT_PEAK_MAX, "every table that is written has positions for all its peaks");
 static_assert(ENT_SEG < (1 << (32 - ENT_PEAK_OFF_BITS)), "a segment's peak count and its position in the band's table share a word");
 // The finished bit string of every token (nonzero coefficient) of every segment is kept in `tokens` (ENT_TOK_STRIDE words per segment, the first
 // 2 * ntok used): k_ent_emit places those -- a third of the bytes -- instead of reading, compacting and coding the coefficients a second time.
@@ -519,8 +522,7 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_layout(const EntFrameJob *f
 			else {
 				// the peak table of the band in front: chunk header + 16-bit values padded to a whole longword (encoder.c:6543-6585); nothing without peaks
 				const uint32_t np = band_state[hole.band_job].npeaks;
-				bytes = np ? 4u + 4u * ((np + 1u) >> 1) : 0u;
-				if (np > (uint32_t)ENT_PEAK_MAX && part == 0) atomic_or_u32(f.peak_flag, 2u);      // (more peaks than k_ent_scan's positions hold: the host writes this sample)
+				bytes = (np && np <= (uint32_t)ENT_PEAK_TABLE_MAX) ? 4u + 4u * ((np + 1u) >> 1) : 0u;      // (more than the chunk header can count: no table, as the reference)
 			}
 		}
 		const uint32_t pieces = tid < f.nholes ? (bytes / ENT_FILL ? bytes / ENT_FILL : 1u) : 0u;
@@ -587,8 +589,8 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_layout(const EntFrameJob *f
 		}
 		if (hole.kind == 2) {
 			// peak table: the chunk header (optional tag 0x4001 with the number of longwords that follow), zeros where k_ent_peaks puts the values
-			const uint32_t np = band_state[hole.band_job].npeaks;
-			for (uint32_t i = w0 + tid; i < w1; i += ENT_THREADS) out[(base >> 2) + i] = i == 0 ? bswap32(((uint32_t)(uint16_t)(-0x4001) << 16) | (((np + 1u) >> 1) & 0xffffu)) : 0u;
+			const uint32_t np = band_state[hole.band_job].npeaks;      // (<= ENT_PEAK_TABLE_MAX here: the hole of a larger table has no bytes)
+			for (uint32_t i = w0 + tid; i < w1; i += ENT_THREADS) out[(base >> 2) + i] = i == 0 ? bswap32(((uint32_t)(uint16_t)(-0x4001) << 16) | ((np + 1u) >> 1)) : 0u;
 			if (k == 0 && tid == 0) band_state[hole.band_job].peak_out = bytes ? f.out + base + 4 : nullptr;
 			continue;
 		}
@@ -828,7 +830,7 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_peaks(const EntFrameJob *fr
 	const EntHole &hole = frames[blockIdx.z].holes[which.hole[blockIdx.y]];
 	const int bj = hole.band_job, quant = hole.fixed_bytes;
 	const EntBandState bs = band_state[bj];
-	if (!bs.npeaks || !bs.peak_out || bs.npeaks > (uint32_t)ENT_PEAK_MAX) return;       // uniform: the common case leaves here
+	if (!bs.npeaks || !bs.peak_out || bs.npeaks > (uint32_t)ENT_PEAK_TABLE_MAX) return;       // uniform: the common case leaves here
 	const EntBandJob band = bands[bj];
 	int16_t *table = (int16_t *)bs.peak_out;
 	const int lane = wave_lane();

@@ -135,6 +135,7 @@ struct GroupHostSink {
 	{
 		collect_peaks = false;
 		if (peaks.empty()) return;
+		if ((peaks.size() + 1) / 2 > 0xffff) return;        // more longwords than the chunk header can count (MAX_CHUNK_SIZE, codec.h:195): the reference writes no table and leaves the three tags zero (encoder.c:6557)
 		const uint32_t offset = (uint32_t)(w.bytes() - peak_tags_at);
 		auto tagword = [](int tag, uint32_t value) { return ((uint32_t)(uint16_t)(int16_t)(-tag) << 16) | (value & 0xffffu); };
 		w.patch32(peak_tags_at, tagword(TAG_PEAK_TABLE_OFFSET_L, offset & 0xffffu));

@@ -269,7 +269,7 @@ REFERENCE_DISAGREEMENTS = []      # (test, route, detail) of every live-referenc
 REFERENCE_ROUTES = {}             # route ("what") -> [legs that agreed in this process, legs that agreed only with the reference in a fresh process, legs that never agreed]
 
 
-def reference_leg(agree, attempts=6, what=""):
+def reference_leg(agree, attempts=6, what="", racy=False):
     """The live-reference leg of a GPU test.  The *gate* of such a test is product == oracle (the oracle's model of the route is pinned on the reference by
     tests/test_oracle_vs_ref.py on the CPU, where the reference runs with one worker on a quiet 8-core host); this leg runs the reference decoder once more on
     the GPU box beside it as a witness.  `agree()` runs the reference and returns True (or None) when its output agrees with what the test holds, False or a
@@ -282,9 +282,11 @@ def reference_leg(agree, attempts=6, what=""):
         A leg that never agreed here is therefore repeated with the reference in a FRESH process (ref_decode_sample does that while _REF_FRESH_PROCESS is set);
         agreement there is recorded as "fresh process only" and is not a failure.
       * A leg that does not agree in a fresh process either is a finding about the product or the oracle: recorded, written to gpurun_out/reference_disagreements.log,
-        and -- CFHD_REFERENCE_LEG=strict -- an assertion on the spot.  Without strict mode the suite goes on (one reference-side flake in the middle of a `-x` run cost
-        two rounds of hardware evidence), but tests/test_gpu_parity.py::test_zz_every_reference_route_agreed fails the run at its end when a ROUTE never agreed on any of
-        its legs, and the last lines of the pytest output carry the counts (tests/conftest.py)."""
+        and an assertion on the spot -- strict is the default since round 6 (the fresh-process escalation above absorbs the reference's history dependence; rounds 4
+        and 5 ran lenient by default and failed only per route at the end of the run, so a route that agreed at 320x240 and never at 1080p would have passed).
+        CFHD_REFERENCE_LEG=lenient: the suite goes on, tests/test_gpu_parity.py::test_zz_every_reference_route_agreed still fails the run at its end when a ROUTE never
+        agreed on any of its legs.  racy=True: a leg over one of the reference's two documented races (the alpha flag a worker thread sets while others still convert
+        rows, bayer.c:13871 / :16034; rows below a height that is no multiple of 8) never asserts by itself.  The last lines of the pytest output carry the counts (tests/conftest.py)."""
     global _REF_FRESH_PROCESS
     route = REFERENCE_ROUTES.setdefault(what, [0, 0, 0])
     def once():
@@ -321,7 +323,7 @@ def reference_leg(agree, attempts=6, what=""):
             f.write("%s\t%s\t%s\n" % (name, what, detail))
     except OSError:
         pass
-    assert os.environ.get("CFHD_REFERENCE_LEG") != "strict", "live reference disagrees on %s: %s" % (what, detail)
+    assert racy or os.environ.get("CFHD_REFERENCE_LEG", "strict") != "strict", "live reference disagrees on %s: %s" % (what, detail)
     return False
 
 

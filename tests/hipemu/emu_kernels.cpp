@@ -754,11 +754,12 @@ extern "C" int emu_entropy_decode_dx(const uint8_t *sample, size_t size, int pix
 	hipemu::launch(dim3(2), dim3(dev::DX_THREADS), [&] { dev::k_dec_repair(jobs.data(), &tables, entries.data(), recs.data(), alts.data(), chunk_base.data(), sums.data(), &errors, repair_list.data(), reindex.data(), counters.data(), g_dx_stats); });
 	hipemu::launch(dim3(3), dim3(dev::DX_THREADS), [&] { dev::k_dec_reindex(jobs.data(), &tables, entries.data(), reindex.data(), counters.data(), g_dx_stats, alts.data(), alt_entries.data()); });
 	g_dx_stats[12] = counters[1]; g_dx_stats[13] = counters[2];
-	std::vector<uint32_t> tile_start(tp.total + 1, 0xdeadbeefu);
-	hipemu::launch(dim3((tp.total + dev::DX_THREADS - 1) / dev::DX_THREADS), dim3(dev::DX_THREADS), [&] { dev::k_dec_tile_index(jobs.data(), tp, entries.data(), chunk_base.data(), sums.data(), tile_start.data()); });
+	std::vector<dev::DxTileDesc> tile_desc(tp.total + 1);
 	auto tile_pass = [&](const dev::DxTilePlan &p_, unsigned long long *m_, uint32_t per_) {
-		if (one_wave) hipemu::launch(dim3((unsigned)grid), dim3(64), [&] { dev::k_dec_tiles<64>(jobs.data(), p_, &tables, entries.data(), chunk_base.data(), sums.data(), tile_start.data(), m_, per_); });
-		else hipemu::launch(dim3((unsigned)grid), dim3(dev::DX_TILE_THREADS), [&] { dev::k_dec_tiles<dev::DX_TILE_THREADS>(jobs.data(), p_, &tables, entries.data(), chunk_base.data(), sums.data(), tile_start.data(), m_, per_); });
+		memset(tile_desc.data(), 0xdb, tile_desc.size() * sizeof(dev::DxTileDesc));
+		hipemu::launch(dim3((p_.total + dev::DX_THREADS - 1) / dev::DX_THREADS), dim3(dev::DX_THREADS), [&] { dev::k_dec_tile_index(jobs.data(), p_, entries.data(), chunk_base.data(), sums.data(), tile_desc.data(), m_, per_); });
+		if (one_wave) hipemu::launch(dim3((unsigned)grid), dim3(64), [&] { dev::k_dec_tiles<64>(tile_desc.data(), p_.first, p_.total, &tables, entries.data(), chunk_base.data()); });
+		else hipemu::launch(dim3((unsigned)grid), dim3(dev::DX_TILE_THREADS), [&] { dev::k_dec_tiles<dev::DX_TILE_THREADS>(tile_desc.data(), p_.first, p_.total, &tables, entries.data(), chunk_base.data()); });
 	};
 	tile_pass(tp, nullptr, 0u);
 	if (!plan.interlaced && plan.encoded_format == ENC_YUV422) {

@@ -145,6 +145,7 @@ inline unsigned long long __ballot(int pred)
 }
 using std::min; using std::max;
 #define __popcll(x) __builtin_popcountll(x)
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_amdgcn_mbcnt_lo(mask, base) (base)      // lanes below this one within `mask`: the kernels only use it with mask 0
 template <typename T> inline T atomicAdd(T *p, T v) { T o = *p; *p = o + v; return o; }
 template <typename T> inline T atomicMax(T *p, T v) { T o = *p; if (v > o) *p = v; return o; }

@@ -392,6 +392,26 @@ def test_gpu_entropy_stage_emulated_interlaced(w, h, seed):
     check(dense, "a band of peaks only")
 
 
+def test_gpu_entropy_stage_emulated_more_peaks_than_a_table_holds():
+    """A band with more than 131070 peaks (2 x MAX_CHUNK_SIZE, codec.h:195): the reference writes no table and leaves the band's three tags zero (encoder.c:6557; pinned on the
+    reference in test_host_bitstream, "allpeaks") -- k_ent_layout / k_ent_peaks and the host writer do the same; the other channels' bands keep their tables."""
+    w, h = 1024, 528
+    frame, pitch = synth_yuy2(w, h, 5)
+    plan = Plan(w, h, progressive=0)
+    coeffs = oracle_forward_interlaced_yuv422(plan, frame, pitch)
+    rng = np.random.default_rng(9)
+    for c in range(3):
+        v = plan.view(coeffs, c, 0, 2)[:, :plan.band[(c, 0, 2)]["width"]]
+        v[:] = np.where(rng.integers(0, 2, size=v.shape) > 0, 300, -4000).astype(np.int16)
+    assert plan.band[(0, 0, 2)]["width"] * plan.band[(0, 0, 2)]["height"] > 131070 > plan.band[(1, 0, 2)]["width"] * plan.band[(1, 0, 2)]["height"]
+    meta = b"GUID\x10\x00\x00G" + bytes(range(16))
+    want = product_write_sample_host(plan, coeffs, 3, meta_global=meta, progressive=0)
+    n, got = _emu_entropy_interlaced(plan, coeffs, 3, meta)
+    assert n > 0 and got == want
+    levels = [int.from_bytes(got[i + 10:i + 12], "big") for i in range(0, len(got) - 12, 4) if got[i:i + 2] == b"\xff\xb5" and got[i + 4:i + 6] == b"\xff\xb4" and got[i + 8:i + 10] == b"\xff\xb6"]
+    assert len(levels) == 3 and levels[0] == 0 and levels[1] and levels[2]
+
+
 @pytest.mark.parametrize("parallel", [0, 1, 2, 3])
 @pytest.mark.parametrize("w,h,seed", [(192, 96, 1), (336, 252, 3), (720, 480, 4)])
 def test_gpu_entropy_decoder_emulated_equals_host_decoder(w, h, seed, parallel):
