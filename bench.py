@@ -463,6 +463,83 @@ def measure(workload, steps, warmup, batch, unique, threads, rank, world, barrie
     return line, frames, pitch
 
 
+def host_fed(workload, frames, pitch, batch=128, depth=4, steps=24, warmup=4, registered=True):
+    """The frame queue fed from host memory (never `value`): every pass copies its `batch` frames from host memory into HBM, encodes, decodes and copies the decoded pictures
+    back -- cfhd_amd_batch_submit_host / _wait, `depth` batches in flight so that the copies of one pass run beside the kernels of the others; all of it inside the timed
+    region.  The pool semantics of the reference (EncoderSDK/EncoderPool.cpp:239-295, timed by Example/TestCFHD.cpp:1020-1023) for whole batches.  registered: the caller's
+    buffers are page-locked (cfhd_amd_register_host_buffer: DMA straight from / into them); else plain memory, staged by the library.  SURVEY.md 8(d) puts the PCIe bound of
+    this at ~13-14 k fps for 1080p YUY2 (4.1 MB each way per frame)."""
+    import numpy as np
+    import cfhd_testlib as T
+    wl = WORKLOADS[workload]
+    W, H = wl["w"], wl["h"]
+    L = batch_api()
+    L.cfhd_amd_batch_submit_host.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    L.cfhd_amd_register_host_buffer.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    L.cfhd_amd_unregister_host_buffer.argtypes = [ctypes.c_void_p]
+    fmt = getattr(T, "PIX_" + wl["fmt"].upper())
+    fbytes = pitch * H
+    slots = []
+    try:
+        for _ in range(depth):
+            b = L.cfhd_amd_batch_create_ex(W, H, fmt, wl["enc"], wl["flags"], T.QUALITY_FILMSCAN1, batch, 1, wl["mode"])
+            if not b: return {"error": "cfhd_amd_batch_create_ex failed: " + T.amd_last_error()}
+            src = np.empty(batch * fbytes, dtype=np.uint8); dst = np.zeros(batch * fbytes, dtype=np.uint8)
+            for i in range(batch): src[i * fbytes:(i + 1) * fbytes] = frames[i % len(frames)][:fbytes]
+            if registered:
+                assert L.cfhd_amd_register_host_buffer(src.ctypes.data_as(ctypes.c_void_p), src.size) == 0 and L.cfhd_amd_register_host_buffer(dst.ctypes.data_as(ctypes.c_void_p), dst.size) == 0
+            slots.append((b, src, dst))
+        def submit(k):
+            b, src, dst = slots[k]
+            rc = L.cfhd_amd_batch_submit_host(b, src.ctypes.data_as(ctypes.c_void_p), fbytes, pitch, dst.ctypes.data_as(ctypes.c_void_p) if wl["mode"] == 0 else None, fbytes, pitch)
+            assert rc == 0, "cfhd_amd_batch_submit_host: %d %s" % (rc, T.amd_last_error())
+        def collect(k):
+            n = L.cfhd_amd_batch_wait(slots[k][0]); assert n > 0, T.amd_last_error(); return n
+        for _ in range(max(1, warmup // depth)):
+            for k in range(depth): submit(k)
+            for k in range(depth): collect(k)
+        t0 = time.perf_counter(); nbytes = 0
+        for s_ in range(steps):
+            if s_ >= depth: nbytes = collect(s_ % depth)
+            submit(s_ % depth)
+        for s_ in range(steps - depth, steps): nbytes = collect(s_ % depth)
+        el = time.perf_counter() - t0
+        # what came back: every sample of the last pass against the reference encoder's (hash), and a decoded picture from the caller's buffer against its own sample
+        b, src, dst = slots[(steps - 1) % depth]
+        ref = {}
+        for i in range(batch):
+            p = ctypes.c_void_p(); sz = ctypes.c_size_t()
+            assert L.cfhd_amd_batch_get_sample(b, i, ctypes.byref(p), ctypes.byref(sz)) == 0
+            u = i % len(frames)
+            if u not in ref:
+                r = T.ref_encode_frames([frames[u]], pitch, W, H, fmt, encoded=wl["enc"], flags=wl["flags"])[0]
+                ref[u] = hashlib.sha256(T.mask_volatile_metadata(normalise_counters(r))).digest()
+            assert hashlib.sha256(T.mask_volatile_metadata(normalise_counters(ctypes.string_at(p, sz.value)))).digest() == ref[u], "host-fed sample %d differs from the reference encoder's" % i
+        checked = {"samples_checked": batch}
+        if wl["mode"] == 0 and wl["fmt"] == "YUY2":
+            i = batch - 1
+            p = ctypes.c_void_p(); sz = ctypes.c_size_t(); L.cfhd_amd_batch_get_sample(b, i, ctypes.byref(p), ctypes.byref(sz))
+            sample = ctypes.string_at(p, sz.value)
+            plan = T.Plan(W, H, progressive=0 if wl["flags"] & 1 else 1)
+            deq = T.oracle_decode_pyramid(sample, plan)
+            inverse = T.oracle_inverse_interlaced_yuv422 if wl["flags"] & 1 else T.oracle_inverse_yuv422
+            img = dst[i * fbytes:(i + 1) * fbytes].reshape(H, pitch)[:, : W * 2]
+            lo = inverse(plan, deq, 0)[:H]; hi = inverse(plan, deq, 1)[:H]
+            assert ((img == lo) | (img == hi)).all(), "host-fed picture leaves the dither interval of the exact reconstruction"
+            checked["picture_in_dither_interval"] = True
+        per_frame = (fbytes * (2 if wl["mode"] == 0 else 1) + nbytes / batch)
+        return {"fps": round(batch * steps / el, 1), "frames_per_pass": batch, "passes_in_flight": depth, "passes_timed": steps, "ms_per_pass": round(1000 * el / steps, 3),
+                "host_buffers": "registered by the caller (page-locked): DMA straight from / into them" if registered else "plain memory, staged through the library's pinned buffers by the calling thread",
+                "pcie_gbs_both_directions": round(per_frame * batch * steps / el / 1e9, 2), **checked}
+    except (AssertionError, Exception) as e:                 # noqa: BLE001 -- a side figure: reported, never allowed to take the bench line down
+        return {"error": str(e)[:300]}
+    finally:
+        for b, src, dst in slots:
+            L.cfhd_amd_batch_destroy(b)
+            if registered:
+                L.cfhd_amd_unregister_host_buffer(src.ctypes.data_as(ctypes.c_void_p)); L.cfhd_amd_unregister_host_buffer(dst.ctypes.data_as(ctypes.c_void_p))
+
+
 def launcher_command(gpus, argv):
     """`python bench.py --gpus N` on its own (no WORLD_SIZE in the environment): the command that starts the N ranks, one process per GPU, exactly as the
     driver's own command line does; rank 0 of that job prints the line."""
@@ -543,6 +620,11 @@ def main():
                 except (Exception, SystemExit) as e:      # a failed side run is reported, it does not take the headline line with it
                     others[name] = {"error": str(e)[:300]}
             line["config"]["other_workloads"] = others
+        if world == 1 and not args.no_c_abi:
+            # the frame queue fed from host memory: upload -> pass -> picture download inside the timed region (never `value`: frames resident in HBM is what the metric times)
+            line["host_fed"] = {"what": "cfhd_amd_batch_submit_host / _wait: frames from host memory, samples and decoded pictures back to host memory, all inside the timed region",
+                                "registered_buffers": host_fed(args.workload, frames, pitch, registered=True),
+                                "plain_buffers": host_fed(args.workload, frames, pitch, steps=12, registered=False)}
         if world == 1 and not args.no_c_abi and headline:
             # the host-fed figures swing with the scheduling of ~ 30 host threads: the plain-buffer configuration runs three times, every run is in the line and
             # the MINIMUM of each figure beside them (north_star's 4000 fps round trip is judged on that)

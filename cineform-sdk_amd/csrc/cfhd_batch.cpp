@@ -46,6 +46,9 @@ struct cfhd_amd_batch {
 	// (the decoder's stream waits for the encoder's events), wait fetches the sizes, queues the copy of the samples and waits for both streams.  The other arrangements
 	// (host hand-off, host entropy, several chunks) have host work in the middle of a pass: those run the blocking pass on a thread of their own.
 	std::thread worker; bool in_flight = false, queued = false; long long pending = -1;
+	// cfhd_amd_batch_submit_host: the pass in flight takes its frames from / leaves its pictures in the caller's memory
+	const uint8_t *host_in = nullptr; size_t host_in_stride = 0; int host_in_pitch = 0;
+	uint8_t *host_out = nullptr; size_t host_out_stride = 0; int host_out_pitch = 0;
 	double t_launch0 = 0, t_launched = 0;
 	~cfhd_amd_batch() { if (worker.joinable()) worker.join(); }
 };
@@ -83,6 +86,8 @@ int batch_launch(cfhd_amd_batch *b)
 	const int turns = forced >= 0 ? forced : (b->decode ? 0 : 1);
 	const bool ordered = turns >= 1, ordered_decode = turns >= 2;
 	if (ordered && stage_order_wait(c->enc.device(), 0, c->enc.stream())) return -2;
+	// fed from the host: the frames' copies first, on the encoder's stream (passes in flight on other batches run beside them)
+	if (b->host_in && c->enc.upload_frames(b->host_in, b->host_in_stride, b->host_in_pitch)) return -2;
 	// the transform kernels start first: the host serialises the sample headers (0.5 ms per 256) while they run
 	if (c->enc.launch_forward(false)) return -2;         // (nothing but the entropy stage reads these coefficients)
 	for (int l = 0; l < c->n; l++) {
@@ -98,6 +103,7 @@ int batch_launch(cfhd_amd_batch *b)
 		if (c->dec.entropy().set_samples_device(c->enc.entropy().device_sample(0), c->enc.entropy().sample_cap(), c->enc.entropy().device_sizes())) return -4;
 		if (c->dec.launch_entropy() || c->dec.launch_inverse(seed + (uint32_t)c->first)) return -5;
 		if (ordered_decode && stage_order_done(c->enc.device(), 1, c->dec.stream())) return -5;
+		if (b->host_out && c->dec.download_frames(b->host_out, b->host_out_stride, b->host_out_pitch)) return -5;      // the pictures' copies behind the inverse transform, on the decoder's stream
 	}
 	if (c->enc.entropy().download_queue()) return -2;
 	b->t_launched = now();
@@ -114,6 +120,7 @@ long long batch_finish(cfhd_amd_batch *b)
 	}
 	const double t_enc = now();
 	if (b->decode) { if (c->dec.wait()) return -5; if (c->dec.entropy().check()) return -7; }
+	if (b->decode && b->host_out) for (int l = 0; l < c->n; l++) if (c->dec.finish_frame(l, b->host_out + b->host_out_stride * (size_t)l, b->host_out_pitch)) return -5;      // (frames staged through pinned memory: a plain buffer)
 	const double t4 = now();
 	b->t_fwd = b->t_launched - b->t_launch0; b->t_entropy_enc = t_enc - b->t_launched; b->t_entropy_dec = 0; b->t_inv = t4 - t_enc;
 	b->steps++;
@@ -343,7 +350,11 @@ int cfhd_amd_batch_submit(cfhd_amd_batch *b)
 	if (b->gpu_entropy && b->device_handoff && b->chunks.size() == 1 && !threaded) {
 		b->chunks[0]->enc.entropy().set_speculative_download(true);
 		const int rc = batch_launch(b);                   // the whole pass is on the batch's streams when this returns; nothing waits
-		if (rc) return rc;
+		if (rc) {                                         // a launch that failed midway: drain what it queued, leave the batch idle (advisor, round 5)
+			(void)b->chunks[0]->enc.wait(); if (b->decode) (void)b->chunks[0]->dec.wait();
+			b->chunks[0]->enc.entropy().set_speculative_download(false);
+			return rc;
+		}
 		b->in_flight = true; b->queued = true;
 		return 0;
 	}
@@ -352,11 +363,35 @@ int cfhd_amd_batch_submit(cfhd_amd_batch *b)
 	return 0;
 }
 
+// The frame queue fed from host memory (what EncoderSDK/EncoderPool.cpp:239-295 is to the reference: frames in, samples out, nothing resident): the pass copies its n frames
+// from `frames` (frame i at frames + i * frame_stride, rows `pitch` bytes apart) into HBM on its own stream, runs, and copies the n decoded pictures to `pictures` (likewise;
+// null: none) -- all queued behind one another, so that with several batches in flight the copies of one pass run beside the kernels of the others.  Both buffers are
+// borrowed until cfhd_amd_batch_wait returns; buffers registered with cfhd_amd_register_host_buffer are DMA sources / targets as they are (one copy each way when the frames
+// lie back to back at the batch's own pitch), plain buffers are staged through pinned memory by the calling thread.  The samples arrive as for cfhd_amd_batch_submit.
+int cfhd_amd_batch_submit_host(cfhd_amd_batch *b, const void *frames, size_t frame_stride, int pitch, void *pictures, size_t picture_stride, int picture_pitch)
+{
+	CallerDevice caller_device;
+	if (!b || b->in_flight || !frames || pitch <= 0 || (pictures && (!b->decode || picture_pitch <= 0))) return -1;
+	if (!(b->gpu_entropy && b->device_handoff && b->chunks.size() == 1)) return -9;      // (the arrangements with host work in the middle of a pass are not queued: cfhd_amd_batch_upload + _submit)
+	b->pending = -1;
+	b->host_in = (const uint8_t *)frames; b->host_in_stride = frame_stride; b->host_in_pitch = pitch;
+	b->host_out = (uint8_t *)pictures; b->host_out_stride = picture_stride; b->host_out_pitch = picture_pitch;
+	b->chunks[0]->enc.entropy().set_speculative_download(true);
+	const int rc = batch_launch(b);
+	if (rc) { b->host_in = nullptr; b->host_out = nullptr; (void)b->chunks[0]->enc.wait(); if (b->decode) (void)b->chunks[0]->dec.wait(); b->chunks[0]->enc.entropy().set_speculative_download(false); return rc; }
+	b->in_flight = true; b->queued = true;
+	return 0;
+}
+
 long long cfhd_amd_batch_wait(cfhd_amd_batch *b)
 {
 	CallerDevice caller_device;
 	if (!b || !b->in_flight) return -1;
-	if (b->queued) b->pending = batch_finish(b);
+	if (b->queued) {
+		b->pending = batch_finish(b);
+		if (b->pending < 0) { cfhd_amd_chunk *c = b->chunks[0].get(); (void)c->enc.wait(); if (b->decode) (void)c->dec.wait(); }      // an error exit must not leave work on the batch's streams (advisor, round 5)
+		b->host_in = nullptr; b->host_out = nullptr;
+	}
 	else b->worker.join();
 	b->in_flight = false; b->queued = false;
 	return b->pending;

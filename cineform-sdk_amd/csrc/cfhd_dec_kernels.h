@@ -32,13 +32,15 @@
 // pieces that reach into it, 64 consecutive pieces per wave and round.  Rounds 2-5 gave every wave its own tile of 4096 coefficients; measured on the bench's
 // Qbist samples (tools/dx_walk_stats.py) the level-1 bands spend 0.38 payload bits per coefficient, so such a tile met 21 pieces: two thirds of the lanes of
 // three quarters of the tiles had nothing to decode, while the pieces themselves are even (5-9 table lookups each).  What bounds the pieces in flight on a CU is
-// the LDS that holds their output, so the image is now shared: 15360 coefficients (30 KB) meet ~90 level-1 pieces = one full wave and a half, three workgroups
-// fit a CU beside their tables, and the waves without pieces only help to stream the tile out.
+// the LDS that holds their output, so the image is now shared: 14848 coefficients (29 KB) meet ~90 level-1 pieces = one full wave and a half, three workgroups of
+// eight waves fit a CU beside their tables (52.5 KB each), and the waves without pieces only help to stream the tile out.  Measured (profiles/r06_a_*, 512 1080p frames,
+// one step at a time): 1.59 ms (round 5) -> 0.97 ms; 15360 / 256 threads 2.2 ms before the prefetch wait moved in front of the stores (below), 28672 / 512 threads (two
+// workgroups per CU) 1.07, 27648 / 1024 1.42, 8192 / 256 (four per CU) 1.39: the kernel now waits on latency, not on issue slots, and wants waves.
 #ifndef CFHD_DX_TILE
-#define CFHD_DX_TILE 15360
+#define CFHD_DX_TILE 14848
 #endif
 #ifndef CFHD_DX_TILE_THREADS
-#define CFHD_DX_TILE_THREADS 256
+#define CFHD_DX_TILE_THREADS 512
 #endif
 
 namespace cfhd {

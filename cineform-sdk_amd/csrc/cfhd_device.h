@@ -42,6 +42,7 @@ public:
 	const FramePlan &plan() const { return plan_; }
 	// Stage one host frame (any pitch, negative allowed as in Codec/encoder.c:1957) and start its H2D copy.
 	int upload_frame(int i, const void *frame, int pitch_bytes);
+	int upload_frames(const void *frames, size_t frame_stride, int pitch_bytes);      // all n frames, asynchronous on the batch's stream; ONE copy when the frames lie back to back in a registered buffer
 	// Use frames that already live in HBM (bench / device-resident callers).
 	int set_device_frame(int i, const void *d_frame, int pitch_bytes);
 	// the next launches (forward transform, entropy coder, sample download) cover frames 0 .. k-1 only (0 = all)
@@ -123,6 +124,7 @@ public:
 	int set_device_output(int i, void *d_out, int pitch_bytes);
 	int launch_inverse(uint32_t dither_seed);          // async
 	int download_frame(int i, void *out, int pitch_bytes);   // async D2H into pinned staging, then row copy after wait
+	int download_frames(void *out, size_t frame_stride, int pitch_bytes);      // all n frames (finish_frame() for each behind wait()); ONE copy into a registered buffer that takes them back to back
 	int after(void *producer_stream);                  // async: later work on this batch's stream waits for what the producer stream holds now
 	int wait();
 	int finish_frame(int i, void *out, int pitch_bytes);      // after wait(): copy the staged frame to the caller's buffer

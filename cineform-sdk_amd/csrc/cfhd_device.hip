@@ -488,6 +488,19 @@ int EncodeBatch::upload_frame(int i, const void *frame, int pitch)
 	return 0;
 }
 
+// The whole batch from host memory, asynchronous on the batch's stream (the frame queue fed from the host: cfhd_amd_batch_submit_host).
+int EncodeBatch::upload_frames(const void *frames, size_t frame_stride, int pitch)
+{
+	(void)hipSetDevice(device_);
+	if (!own_input_ || !frames) return -1;
+	if (pitch == in_pitch_ && frame_stride == frame_bytes_ && plan_.pixel_kind != PIX_BYR4 && plan_.pixel_kind != PIX_BYR5 && host_buffer_is_registered(frames, frame_bytes_ * (size_t)n_)) {
+		HIPCHK(hipMemcpyAsync(d_in_, frames, frame_bytes_ * (size_t)n_, hipMemcpyHostToDevice, (hipStream_t)stream_));
+		return 0;
+	}
+	for (int i = 0; i < n_; i++) { const int rc = upload_frame(i, (const uint8_t *)frames + frame_stride * (size_t)i, pitch); if (rc) return rc; }
+	return 0;
+}
+
 int EncodeBatch::set_device_frame(int i, const void *d_frame, int pitch)
 {
 	if (i < 0 || i >= n_) return -1;
@@ -1205,6 +1218,21 @@ int DecodeBatch::download_frame(int i, void *out, int pitch)
 		return 0;
 	}
 	HIPCHK(hipMemcpyAsync(h_out_ + frame_bytes_ * i, d_out_ + frame_bytes_ * i, frame_bytes_, hipMemcpyDeviceToHost, (hipStream_t)stream_));
+	return 0;
+}
+
+// The whole batch to host memory, asynchronous on the batch's stream; behind wait() the caller runs finish_frame() for every frame (nothing to do for frames that went
+// straight into a registered buffer).
+int DecodeBatch::download_frames(void *out, size_t frame_stride, int pitch)
+{
+	(void)hipSetDevice(device_);
+	if (!own_output_ || !out) return -1;
+	if (pitch == out_pitch_ && frame_stride == frame_bytes_ && host_buffer_is_registered(out, frame_bytes_ * (size_t)n_)) {
+		HIPCHK(hipMemcpyAsync(out, d_out_, frame_bytes_ * (size_t)n_, hipMemcpyDeviceToHost, (hipStream_t)stream_));
+		direct_.assign((size_t)n_, 1);
+		return 0;
+	}
+	for (int i = 0; i < n_; i++) { const int rc = download_frame(i, (uint8_t *)out + frame_stride * (size_t)i, pitch); if (rc) return rc; }
 	return 0;
 }
 

@@ -150,6 +150,11 @@ long long cfhd_amd_batch_roundtrip(cfhd_amd_batch *batch);                      
  * several batches in flight should run with GPU_MAX_HW_QUEUES=16 in its environment (ROCm runtime, read at start-up: by default all HIP streams of a process share 4
  * hardware queues and the streams of several passes wait for each other). */
 int  cfhd_amd_batch_submit(cfhd_amd_batch *batch);
+/* The same pass fed from host memory: frame i at frames + i * frame_stride (rows `pitch` bytes apart) goes to HBM on the pass's own stream, the decoded pictures come back to
+ * pictures + i * picture_stride (NULL: none) behind it; both buffers are borrowed until cfhd_amd_batch_wait returns.  Buffers registered with
+ * cfhd_amd_register_host_buffer are copied by DMA as they are, plain ones are staged by the calling thread.  This is the pool semantics of the reference
+ * (EncoderSDK/EncoderPool.cpp:239-295: frames in, samples out, nothing resident) for whole batches; bench.py's `host_fed` figure times it. */
+int  cfhd_amd_batch_submit_host(cfhd_amd_batch *batch, const void *frames, size_t frame_stride, int pitch, void *pictures, size_t picture_stride, int picture_pitch);
 long long cfhd_amd_batch_wait(cfhd_amd_batch *batch);
 int  cfhd_amd_batch_get_sample(cfhd_amd_batch *batch, int frame, const void **data, size_t *size);
 int  cfhd_amd_batch_download_output(cfhd_amd_batch *batch, int frame, void *out, int pitch);
