@@ -154,7 +154,7 @@ def c_abi_rates(frames, pitch, W, H, seconds=1.5, registered=False, decoders=8, 
     second through both.  registered: the caller page-locked its frame and output buffers once (cfhd_amd_register_host_buffer, an optional
     extension), so the library DMAs between them and HBM without its staging copy."""
     import subprocess, tempfile
-    tool = os.path.join(ROOT, "tools", "_build", "cabi_bench")
+    tool = os.environ.get("CFHD_CABI_BENCH") or os.path.join(ROOT, "tools", "_build", "cabi_bench")      # (CFHD_CABI_BENCH: the same program linked against the emulated build, tests/test_frame_shards.py)
     if not os.path.exists(tool):
         return {"error": "tools/_build/cabi_bench is not built (run __graft_entry__.build())"}
     with tempfile.NamedTemporaryFile(suffix=".yuy2") as f:
@@ -286,7 +286,7 @@ def batch_api():
     return L
 
 
-def measure(workload, steps, warmup, batch, unique, threads, rank, world, barrier, reduce_max, depth=1, geometry=None):
+def measure(workload, steps, warmup, batch, unique, threads, rank, world, barrier, reduce_max, depth=1, geometry=None, all_gather=None):
     """One workload through the batched device-resident path: frames generated and uploaded, `warmup` untimed steps, `steps` timed ones between
     barriers, parity check of what was timed on rank 0.  Returns (line fields of this workload, frames, pitch).
     depth: batches in flight (the frame queue, cfhd_amd_batch_submit / _wait): step k + 1 is submitted while step k is still on the GPU; every step is still one
@@ -354,7 +354,11 @@ def measure(workload, steps, warmup, batch, unique, threads, rank, world, barrie
         collect(slots[s % depth])
     b = slots[(steps - 1) % depth]                      # the batch that ran the last step: what the parity check looks at
     barrier()
-    elapsed = reduce_max(time.perf_counter() - t0)
+    mine = time.perf_counter() - t0
+    elapsed = reduce_max(mine)
+    # every rank's own time over the collective the job runs on (RCCL on the GPUs): rank 0's line says how many ranks took part and what each of them did --
+    # the slowest sets `value` (all_gather: None for a single rank; a list of one float per rank, in rank order)
+    per_rank = all_gather(mine) if all_gather is not None else [mine]
     # With several steps in flight the kernels of concurrent steps share the GPU, and the HIP events around a launch then time that sharing, not the kernel (as-run
     # times: config.kernel_ms_per_step).  The roofline of a kernel is a statement about the kernel: right behind the timed region the same pass runs ALONE_STEPS more
     # times one at a time on the batch of the last step, with the same events -- those launch times feed `roofline` (and agree with a rocprofv3 trace of --depth 1).
@@ -431,7 +435,7 @@ def measure(workload, steps, warmup, batch, unique, threads, rank, world, barrie
         sum_kernels = sum(v for k, v in kms.items() if k != "k_dec_parse")
         round_trip_bytes = (2 if wl["mode"] == 0 else 1) * (P + 2 * S)     # encode S_in + 2 N_coef, decode 2 N_coef + S_out
         line = {
-            "metric": "%s %s %s fps" % (workload.split("-")[-1], wl["fmt"], "encode+decode" if wl["mode"] == 0 else "encode"), "value": round(fps, 1), "unit": "fps", "n_gpus": world, "steps": steps,
+            "metric": "%s %s %s fps" % (workload.split("-")[-1], wl["fmt"], "encode+decode" if wl["mode"] == 0 else "encode"), "value": round(fps, 1), "unit": "fps", "n_gpus": world, "ranks_seen": len(per_rank), "per_rank_fps": [round(batch * steps / t, 1) for t in per_rank], "steps": steps,
             "warmup": warmup, "ms_per_step": round(1000.0 * elapsed / steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int16", "data": data,
             "config": {"workload": "%dx%d %s FILMSCAN1 %s, frames resident in HBM" % (W, H, wl["label"], "encode+decode round trip" if wl["mode"] == 0 else "encode"), "frames_per_step_per_gpu": batch,
@@ -602,9 +606,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    def all_gather(value):
+        if dist is None:
+            return [value]
+        t = torch.tensor([value], device="cuda", dtype=torch.float64)
+        out = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(out, t)
+        return [float(x.item()) for x in out]
+
     cores = os.cpu_count() or 1
     threads = args.threads or max(1, cores // world)
-    line, frames, pitch = measure(args.workload, args.steps, args.warmup, batch, args.unique, threads, rank, world, barrier, reduce_max, depth=args.depth)
+    line, frames, pitch = measure(args.workload, args.steps, args.warmup, batch, args.unique, threads, rank, world, barrier, reduce_max, depth=args.depth, all_gather=all_gather)
     if rank == 0:
         if world == 1 and args.workload == "1080p" and not args.no_other_workloads:
             # the other BASELINE configs (and north_star's 3840x2160 frames) through the same path, a few steps each, behind the timed region of the

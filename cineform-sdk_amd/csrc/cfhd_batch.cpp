@@ -50,7 +50,8 @@ struct cfhd_amd_batch {
 	const uint8_t *host_in = nullptr; size_t host_in_stride = 0; int host_in_pitch = 0;
 	uint8_t *host_out = nullptr; size_t host_out_stride = 0; int host_out_pitch = 0;
 	double t_launch0 = 0, t_launched = 0;
-	~cfhd_amd_batch() { if (worker.joinable()) worker.join(); }
+	std::vector<void *> shared_streams;      // streams several objects of the batch share (StreamScope): released behind the objects
+	~cfhd_amd_batch() { if (worker.joinable()) worker.join(); chunks.clear(); for (void *s : shared_streams) device_stream_release(s); }
 };
 
 namespace {
@@ -163,13 +164,24 @@ cfhd_amd_batch *cfhd_amd_batch_create_ex(int width, int height, uint32_t pixel_f
 	int chunk = cs ? atoi(cs) : 0;                     // 0 = whole batch in one chunk (measured fastest: launches are already batch-wide)
 	if (chunk <= 0 || !b->gpu_entropy) chunk = nframes;
 	const size_t cap = (size_t)width * height * fp.pixel_bytes + 65536;        // SampleEncoder.cpp:387
+	// Streams of a pass (CFHD_AMD_STREAMS, A/B): 1 = the whole pass on one stream, 2 = one for the encoder and one for the decoder, 3 = one each for the transforms, the
+	// level-1 count and the decoder (default).  The runtime deals its 4 hardware queues (GPU_MAX_HW_QUEUES) to a process's streams in the order of their creation, and
+	// streams on one queue take turns: see cfhd_device.h device_stream_create.
+	const char *sp = getenv("CFHD_AMD_STREAMS");
+	const int streams = sp && atoi(sp) >= 1 && atoi(sp) <= 3 ? atoi(sp) : 3;
 	for (int first = 0; first < nframes; first += chunk) {
 		std::unique_ptr<cfhd_amd_chunk> c(new cfhd_amd_chunk);
 		c->first = first; c->n = nframes - first < chunk ? nframes - first : chunk;
-		if (c->enc.prepare(b->plan, c->n, true)) { delete b; return nullptr; }
-		if (b->decode) { c->dec.set_interlaced(!b->progressive); if (c->dec.prepare(b->plan, c->n, kind, true)) { delete b; return nullptr; } }
-		if (b->gpu_entropy && (c->enc.prepare_entropy(cap) || (b->decode && c->dec.prepare_entropy(cap)))) { delete b; return nullptr; }
-		b->chunks.push_back(std::move(c));
+		bool ok = true;
+		auto encoder = [&] { return !c->enc.prepare(b->plan, c->n, true) && !(b->gpu_entropy && c->enc.prepare_entropy(cap)); };
+		auto decoder = [&] { if (!b->decode) return true; c->dec.set_interlaced(!b->progressive); return !c->dec.prepare(b->plan, c->n, kind, true) && !(b->gpu_entropy && c->dec.prepare_entropy(cap)); };
+		if (streams == 1) { StreamScope scope; ok = encoder() && decoder(); if (scope.stream()) b->shared_streams.push_back(scope.stream()); }
+		else if (streams == 2) {
+			{ StreamScope scope; ok = encoder(); if (scope.stream()) b->shared_streams.push_back(scope.stream()); }
+			if (ok) { StreamScope scope; ok = decoder(); if (scope.stream()) b->shared_streams.push_back(scope.stream()); }
+		} else ok = encoder() && decoder();
+		b->chunks.push_back(std::move(c));                // (also when it failed: the batch's destructor releases what was prepared, then the scopes' streams)
+		if (!ok) { delete b; return nullptr; }
 	}
 	b->samples.resize(nframes); b->sample_size.assign(nframes, 0);
 	if (!b->gpu_entropy) for (auto &s : b->samples) s.resize(cap);

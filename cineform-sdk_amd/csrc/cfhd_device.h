@@ -213,4 +213,5 @@ int host_buffer_register(void *p, size_t bytes);       // 0, or a hipError_t
 int host_buffer_unregister(void *p);
 bool host_buffer_is_registered(const void *p, size_t bytes);
 
+
 } // namespace cfhd

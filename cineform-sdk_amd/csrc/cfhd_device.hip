@@ -153,6 +153,37 @@ bool host_buffer_is_registered(const void *p, size_t bytes)
 	return false;
 }
 
+// ---- streams (cfhd_device.h)
+static thread_local bool t_scope = false;
+static thread_local void *t_scope_stream = nullptr;
+static std::mutex g_shared_mutex;
+static std::vector<void *> g_shared_streams;
+int device_stream_create(void **stream)
+{
+	if (t_scope && t_scope_stream) { *stream = t_scope_stream; return 0; }
+	hipStream_t s;
+	const hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+	if (e != hipSuccess) return (int)e;
+	*stream = (void *)s;
+	if (t_scope) { t_scope_stream = (void *)s; std::lock_guard<std::mutex> lk(g_shared_mutex); g_shared_streams.push_back((void *)s); }
+	return 0;
+}
+void device_stream_destroy(void *stream)
+{
+	if (!stream) return;
+	{ std::lock_guard<std::mutex> lk(g_shared_mutex); for (void *p : g_shared_streams) if (p == stream) return; }      // a scope's stream: its owner releases it
+	(void)hipStreamDestroy((hipStream_t)stream);
+}
+void device_stream_release(void *stream)
+{
+	if (!stream) return;
+	{ std::lock_guard<std::mutex> lk(g_shared_mutex); for (size_t i = 0; i < g_shared_streams.size(); i++) if (g_shared_streams[i] == stream) { g_shared_streams.erase(g_shared_streams.begin() + (long)i); break; } }
+	(void)hipStreamDestroy((hipStream_t)stream);
+}
+StreamScope::StreamScope() { t_scope = true; t_scope_stream = nullptr; }
+StreamScope::~StreamScope() { t_scope = false; t_scope_stream = nullptr; }
+void *StreamScope::stream() const { return t_scope_stream; }
+
 int device_count()
 {
 	int n = 0;
@@ -265,7 +296,7 @@ void EncodeBatch::release()
 	if (ev0_) hipEventDestroy((hipEvent_t)ev0_);
 	if (ev1_) hipEventDestroy((hipEvent_t)ev1_);
 	for (int k = 0; k < 2; k++) if (evl_[k]) { hipEventDestroy((hipEvent_t)evl_[k]); evl_[k] = nullptr; }
-	if (stream_) hipStreamDestroy((hipStream_t)stream_);
+	if (stream_) device_stream_destroy(stream_);
 	d_in_ = h_in_ = nullptr; d_coeff_ = h_coeff_ = nullptr; d_jobs_ = h_jobs_ = nullptr; stream_ = ev0_ = ev1_ = nullptr; n_ = 0;
 }
 
@@ -279,7 +310,7 @@ int EncodeBatch::prepare(const FramePlan &plan, int nframes, bool own_input)
 	if (plan.pixel_kind != PIX_YUY2 && plan.pixel_kind != PIX_2VUY && !enc_packed16(plan.pixel_kind) && !bayer) { g_err = "pixel format not supported by the GPU path yet"; return -2; }
 	plan_ = plan; n_ = nframes; own_input_ = own_input;
 	bayer_fused_ = false;      // (level 1 straight from the mosaic through the tiled kernel: measured 5.1 ms against 2.2 for 96 4K frames in round 3; k_fwd_bayer_strip is the fused kernel that pays)
-	HIPCHK(hipStreamCreateWithFlags((hipStream_t *)&stream_, hipStreamNonBlocking));
+	HIPCHK((hipError_t)device_stream_create(&stream_));
 	HIPCHK(hipEventCreate((hipEvent_t *)&ev0_));
 	HIPCHK(hipEventCreate((hipEvent_t *)&ev1_));
 	for (int k = 0; k < 2; k++) HIPCHK(hipEventCreate((hipEvent_t *)&evl_[k]));
@@ -764,8 +795,8 @@ void DecodeBatch::release()
 	for (void *e : piece_ev_) if (e) hipEventDestroy((hipEvent_t)e);
 	piece_ev_.clear(); out_pieces_.clear();
 	for (int k = 0; k < 3; k++) if (ev2_[k]) { hipEventDestroy((hipEvent_t)ev2_[k]); ev2_[k] = nullptr; }
-	if (stream2_) { hipStreamDestroy((hipStream_t)stream2_); stream2_ = nullptr; }
-	if (stream_) hipStreamDestroy((hipStream_t)stream_);
+	if (stream2_) { device_stream_destroy(stream2_); stream2_ = nullptr; }
+	if (stream_) device_stream_destroy(stream_);
 	d_out_ = h_out_ = nullptr; d_coeff_ = h_coeff_ = nullptr; d_jobs_ = h_jobs_ = nullptr; stream_ = ev0_ = ev1_ = nullptr; n_ = 0;
 }
 
@@ -814,12 +845,14 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 	const bool rgb10_ok = dec_rgb10(out_kind) && plan.encoded_format == ENC_RGB444 && plan.ch[0].band[0][0].width >= 16;
 	if (!yuv_ok && !rgb_ok && !yu64_ok && !rgb8_ok && !rgb10_ok && !rgb24_half && !rgb_half_of_422) { g_err = "output format not supported by the GPU path yet"; return -2; }
 	plan_ = plan; n_ = nframes; out_kind_ = out_kind; own_output_ = own_output;
-	HIPCHK(hipStreamCreateWithFlags((hipStream_t *)&stream_, hipStreamNonBlocking));
+	HIPCHK((hipError_t)device_stream_create(&stream_));
 	HIPCHK(hipEventCreate((hipEvent_t *)&ev0_));
 	HIPCHK(hipEventCreate((hipEvent_t *)&ev1_));
 	for (int k = 0; k < 2; k++) HIPCHK(hipEventCreate((hipEvent_t *)&evl_[k]));
 	for (int k = 0; k < 3; k++) HIPCHK(hipEventCreate((hipEvent_t *)&ev2_[k]));
-	HIPCHK(hipStreamCreateWithFlags((hipStream_t *)&stream2_, hipStreamNonBlocking));
+	// (a second stream only for the arrangement that uses it -- CFHD_AMD_TILES_SPLIT=1, launch_inverse --: a stream that is never used still takes its turn when the
+	// runtime deals its 4 hardware queues to the streams in creation order)
+	{ const char *se = getenv("CFHD_AMD_TILES_SPLIT"); if (se && se[0] == '1') HIPCHK((hipError_t)device_stream_create(&stream2_)); }
 	out_rows_ = half ? plan.display_height / 2 : plan.display_height;
 	out_pitch_ = byr4_ ? plan.width * 8 : packed_frame_pitch(out_kind, half ? plan.width / 2 : plan.width);      // (BYR4: the scratch rows hold four words per quad)
 	frame_bytes_ = (size_t)out_pitch_ * out_rows_;
@@ -1327,7 +1360,7 @@ void GopBatch::release()
 	if (h_coeff_) hipHostFree(h_coeff_);
 	if (d_jobs_) hipFree(d_jobs_);
 	if (h_jobs_) hipHostFree(h_jobs_);
-	if (stream_) hipStreamDestroy((hipStream_t)stream_);
+	if (stream_) device_stream_destroy(stream_);
 	d_frames_ = h_frames_ = nullptr; d_coeff_ = h_coeff_ = nullptr; d_jobs_ = h_jobs_ = nullptr; stream_ = nullptr;
 }
 
@@ -1338,7 +1371,7 @@ int GopBatch::prepare(const GopPlan &plan, bool decode, int out_pixel_kind)
 	release();
 	device_ = device_current(); (void)hipSetDevice(device_);
 	plan_ = plan; decode_ = decode; out_kind_ = out_pixel_kind;
-	HIPCHK(hipStreamCreateWithFlags((hipStream_t *)&stream_, hipStreamNonBlocking));
+	HIPCHK((hipError_t)device_stream_create(&stream_));
 	pitch_ = packed_frame_pitch(decode ? out_pixel_kind : plan.pixel_kind, plan.width); rows_ = plan.display_height;
 	frame_bytes_ = (size_t)pitch_ * rows_;
 	HIPCHK(hipMalloc((void **)&d_frames_, 2 * frame_bytes_));

@@ -8,6 +8,16 @@
 
 namespace cfhd {
 
+// HIP streams of the device-side objects.  Every object creates its stream(s) here; inside a StreamScope (thread-local) all of them get ONE stream, which belongs to the
+// scope's owner: the objects' own device_stream_destroy() leaves it alone, the owner ends its life with device_stream_release() after the objects are gone.  Why: the runtime
+// maps a process's streams onto 4 hardware queues (GPU_MAX_HW_QUEUES) in the order they were created, and streams that share a queue wait for each other -- a batch whose
+// pass lives on one stream takes one queue, so four passes in flight run beside each other without the application setting anything (cfhd_batch.cpp).
+int device_stream_create(void **stream);
+void device_stream_destroy(void *stream);
+void device_stream_release(void *stream);
+struct StreamScope { StreamScope(); ~StreamScope(); void *stream() const; };
+
+
 class GpuEntropyEncoder {
 public:
 	GpuEntropyEncoder();

@@ -32,7 +32,7 @@ void GpuEntropyEncoder::release()
 	if (host_->frames) { (void)hipHostFree(host_->frames); host_->frames = nullptr; }
 	for (void *&e : ev_) if (e) { (void)hipEventDestroy((hipEvent_t)e); e = nullptr; }
 	for (void *&e : ev2_) if (e) { (void)hipEventDestroy((hipEvent_t)e); e = nullptr; }
-	if (stream2_) { (void)hipStreamDestroy((hipStream_t)stream2_); stream2_ = nullptr; }
+	if (stream2_) { device_stream_destroy(stream2_); stream2_ = nullptr; }
 	timed_ = false;
 	d_samples_ = h_samples_ = nullptr; d_sizes_ = h_sizes_ = nullptr; d_tables_ = d_bands_ = d_segband_ = d_segs_ = d_bandstate_ = d_frames_ = d_tokens_ = nullptr;
 	d_tmpl_ = h_tmpl_ = nullptr; n_ = 0;
@@ -113,7 +113,7 @@ int GpuEntropyEncoder::prepare_units(int nframes, int16_t *d_coeffs, size_t stri
 	for (int f = 0; f < n_; f++) { SampleHeaderInfo h = hdr0; h.frame_number = (uint32_t)f + 1; if ((rc = set_frame_header(f, h))) return rc; }
 	for (void *&e : ev_) HIPCHK(hipEventCreate((hipEvent_t *)&e));
 	for (void *&e : ev2_) HIPCHK(hipEventCreate((hipEvent_t *)&e));
-	HIPCHK(hipStreamCreateWithFlags((hipStream_t *)&stream2_, hipStreamNonBlocking));
+	HIPCHK((hipError_t)device_stream_create(&stream2_));
 	return 0;
 }
 

@@ -210,8 +210,14 @@ def _worker_bench(rank, world, port, q):
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
+    def all_gather(value):
+        out = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(out, torch.tensor([value], dtype=torch.float64))
+        return [float(x.item()) for x in out]
+    workload, geometry, batch = os.environ.get("CFHD_TEST_WORKLOAD", "1080p"), (192, 96), 3
+    if workload == "b64a-4320p": geometry, batch = (256, 128), 2
     with T.emulated_product():
-        line, frames, pitch = bench.measure("1080p", 3, 1, 3, 2, 1, rank, world, dist.barrier, reduce_max, depth=2, geometry=(192, 96))
+        line, frames, pitch = bench.measure(workload, 3, 1, batch, 2, 1, rank, world, dist.barrier, reduce_max, depth=2, geometry=geometry, all_gather=all_gather)
     gathered = [None] * world
     dist.all_gather_object(gathered, line)
     if rank == 0: q.put(gathered)
@@ -241,6 +247,60 @@ def test_bench_measure_runs_as_two_ranks_and_reports_the_whole_job():
     line = lines[0]
     assert lines[1] is None                            # one line per job
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["steps"] == 3
+    assert line["ranks_seen"] == 2 and len(line["per_rank_fps"]) == 2 and abs(min(line["per_rank_fps"]) * 2 - line["value"]) <= 0.25      # the slowest rank sets the whole-job figure (rates are rounded to 0.1)
     assert abs(line["value"] - 2 * 3 * 3 / (line["ms_per_step"] * 3e-3)) / line["value"] < 1e-2       # frames of both ranks / the slowest rank's time
     par = line["config"]["parity"]
     assert par["samples_equal_reference_encoder"] and par["decoded_frames_in_dither_interval"] and len(par["other_batches_in_flight"]) == 1
+
+
+def test_bench_measure_runs_config_c_as_eight_ranks():
+    """BASELINE.json configs[3] as the driver's 8-GPU run will start it -- `bench.py --gpus 8 --workload b64a-4320p` -- on eight emulated devices: eight ranks (gloo in place of
+    RCCL), each pinned to its own device, each with its own shard of b64a frames through encode + decode; rank 0's line counts all eight (`ranks_seen`), carries every rank's
+    rate and the parity check of what rank 0 timed."""
+    import torch.multiprocessing as mp
+    import cfhd_testlib as T
+    if not T.have_ref(): pytest.skip("reference .so not built (Qbist frames, the emulated product build)")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 37500 + (os.getpid() % 2000)
+    T.product_emulated()
+    os.environ["CFHD_TEST_WORKLOAD"] = "b64a-4320p"
+    try:
+        procs = [ctx.Process(target=_worker_bench, args=(r, 8, port, q)) for r in range(8)]
+        for p in procs: p.start()
+        lines = q.get(timeout=900)
+        for p in procs:
+            p.join(180); assert p.exitcode == 0
+    finally:
+        del os.environ["CFHD_TEST_WORKLOAD"]
+    line = lines[0]
+    assert all(l is None for l in lines[1:])
+    assert line["n_gpus"] == 8 and line["ranks_seen"] == 8 and len(line["per_rank_fps"]) == 8 and line["scaling"] == "weak"
+    assert "b64a" in line["metric"] and line["config"]["frames_per_step_per_gpu"] == 2
+    assert abs(line["value"] - 8 * 2 * 3 / (line["ms_per_step"] * 3e-3)) / line["value"] < 1e-2
+    par = line["config"]["parity"]
+    assert par["samples_equal_reference_encoder"] and par["decoded_frames_equal_exact_reconstruction"] and par["samples_checked"] == 4      # both batches in flight, two frames each
+
+
+def test_c_abi_leg_of_the_bench_spreads_over_two_devices():
+    """bench.py's `c_abi.one_process_all_N_gpus_plain_buffers` leg (one process, pool workers and decoder handles dealt to every GPU it sees: INTEGRATION.md section 5) on two
+    emulated devices: tools/cabi_bench.cpp linked against the emulated build of the library, unpinned, must come back with all its figures."""
+    import subprocess
+    import cfhd_testlib as T
+    if not T.have_ref(): pytest.skip("reference .so not built (the emulated product build is made beside it)")
+    T.product_emulated()
+    tool = os.path.join(ROOT, "tests", "_build", "cabi_bench_hipemu")
+    src = os.path.join(ROOT, "tools", "cabi_bench.cpp")
+    if not os.path.exists(tool) or os.path.getmtime(tool) < max(os.path.getmtime(src), os.path.getmtime(T.EMU_PRODUCT_SO)):
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"), src, "-o", tool, T.EMU_PRODUCT_SO, "-Wl,-rpath," + os.path.dirname(T.EMU_PRODUCT_SO), "-lpthread"])
+    sys.path.insert(0, ROOT)
+    import bench
+    w, h = 192, 96
+    frames = [T.synth_yuy2(w, h, s)[0] for s in (1, 2, 3, 4)]
+    os.environ["CFHD_CABI_BENCH"] = tool; os.environ["HIPEMU_DEVICES"] = "2"
+    try:
+        r = bench.c_abi_rates(frames, w * 2, w, h, seconds=0.2, decoders=4, workers=4, all_devices=True)
+    finally:
+        del os.environ["CFHD_CABI_BENCH"]; del os.environ["HIPEMU_DEVICES"]
+    assert "error" not in r, r
+    assert r["sync_encode_fps"] > 0 and r["sync_decode_fps"] > 0 and r["decode_fps_4_handles"] > 0 and r["pool_encode_fps_4_workers"] > 0 and r["round_trip_fps_pool4_plus_4_decoders"] > 0, r
