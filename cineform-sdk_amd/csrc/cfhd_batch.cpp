@@ -164,11 +164,13 @@ cfhd_amd_batch *cfhd_amd_batch_create_ex(int width, int height, uint32_t pixel_f
 	int chunk = cs ? atoi(cs) : 0;                     // 0 = whole batch in one chunk (measured fastest: launches are already batch-wide)
 	if (chunk <= 0 || !b->gpu_entropy) chunk = nframes;
 	const size_t cap = (size_t)width * height * fp.pixel_bytes + 65536;        // SampleEncoder.cpp:387
-	// Streams of a pass (CFHD_AMD_STREAMS, A/B): 1 = the whole pass on one stream, 2 = one for the encoder and one for the decoder, 3 = one each for the transforms, the
-	// level-1 count and the decoder (default).  The runtime deals its 4 hardware queues (GPU_MAX_HW_QUEUES) to a process's streams in the order of their creation, and
-	// streams on one queue take turns: see cfhd_device.h device_stream_create.
-	const char *sp = getenv("CFHD_AMD_STREAMS");
-	const int streams = sp && atoi(sp) >= 1 && atoi(sp) <= 3 ? atoi(sp) : 3;
+	// Streams of a pass.  The runtime deals its hardware queues (GPU_MAX_HW_QUEUES, 4 unless the application's environment says otherwise) to a process's streams in the
+	// order of their creation, and streams on one queue take turns (cfhd_entropy_gpu.h device_stream_create).  Measured with four passes in flight (profiles/r06_d_*):
+	//   4 queues:  one stream per pass 55.5 k fps, two (encoder | decoder) 57.9 k, three (transforms | level-1 count | decoder) 56.9 k   [round 5: four, one unused: 50.4-50.8 k]
+	//   16 queues: 45.3 k / 59.8 k / 61.2 k
+	// so a pass takes two streams unless the environment gives the process eight queues or more -- read, never set here.  CFHD_AMD_STREAMS=1|2|3 overrides (A/B).
+	const char *sp = getenv("CFHD_AMD_STREAMS"), *hq = getenv("GPU_MAX_HW_QUEUES");
+	const int streams = sp && atoi(sp) >= 1 && atoi(sp) <= 3 ? atoi(sp) : (hq && atoi(hq) >= 8 ? 3 : 2);
 	for (int first = 0; first < nframes; first += chunk) {
 		std::unique_ptr<cfhd_amd_chunk> c(new cfhd_amd_chunk);
 		c->first = first; c->n = nframes - first < chunk ? nframes - first : chunk;
@@ -177,8 +179,15 @@ cfhd_amd_batch *cfhd_amd_batch_create_ex(int width, int height, uint32_t pixel_f
 		auto decoder = [&] { if (!b->decode) return true; c->dec.set_interlaced(!b->progressive); return !c->dec.prepare(b->plan, c->n, kind, true) && !(b->gpu_entropy && c->dec.prepare_entropy(cap)); };
 		if (streams == 1) { StreamScope scope; ok = encoder() && decoder(); if (scope.stream()) b->shared_streams.push_back(scope.stream()); }
 		else if (streams == 2) {
+			// (CFHD_AMD_STREAM_ORDER=alt, A/B: every second batch of the process creates its decoder's stream first -- with four queues dealt in creation order the encoder of
+			// one pass then shares its queue with the decoder of another instead of with another encoder)
+			static std::atomic<unsigned> created(0);
+			static const bool alternate = [] { const char *e = getenv("CFHD_AMD_STREAM_ORDER"); return e && strcmp(e, "alt") == 0; }();
+			void *dec_stream = nullptr;
+			if (alternate && b->decode && (created.fetch_add(1) & 1u)) { StreamScope scope; void *x = nullptr; if (device_stream_create(&x) == 0) dec_stream = x; }
 			{ StreamScope scope; ok = encoder(); if (scope.stream()) b->shared_streams.push_back(scope.stream()); }
-			if (ok) { StreamScope scope; ok = decoder(); if (scope.stream()) b->shared_streams.push_back(scope.stream()); }
+			if (ok) { StreamScope scope(dec_stream); ok = decoder(); if (scope.stream()) b->shared_streams.push_back(scope.stream()); }
+			else if (dec_stream) b->shared_streams.push_back(dec_stream);
 		} else ok = encoder() && decoder();
 		b->chunks.push_back(std::move(c));                // (also when it failed: the batch's destructor releases what was prepared, then the scopes' streams)
 		if (!ok) { delete b; return nullptr; }

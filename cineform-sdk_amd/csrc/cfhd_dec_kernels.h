@@ -89,7 +89,7 @@ struct DecIdxTables {
 	uint16_t sym12[1 << DX_K];        // first code word: bits 0-3 length without the sign bit (0: longer than 12 bits or invalid), bit 4 value (else zero run) -- with length 0: escape --,
 	                                  // bits 5-15 run length / index of the magnitude / base of the second-level table
 	uint16_t mag_expand[2][256];      // magnitude after undoing the companding curve, by index: [0] code set 17 (cubic), [1] code set 18 (linear)
-	uint32_t long_tab[DX_LONG_MAX];   // bits 0-4 length (escape: index bits of the next level), bits 5-7 type, bits 8-31 run / magnitude index / base of the next level
+	uint32_t long_tab[DX_LONG_MAX];   // bits 0-4 bits of the code word with its sign bit, 0 for the band end marker (escape: index bits of the next level), bits 5-7 type, bits 8-19 coefficients covered (escape: bits 8-31 base of the next level)
 	uint32_t nlong;
 	// k_dec_tiles: everything that fits completely (sign bits included) into the next 11 bits, up to two values with the zero runs around
 	// them: x = bits 0-3 bits used (0: nothing fits -> one code word at a time), bits 4-15 coefficients the lookup covers, bits 16-31 position of
@@ -116,23 +116,6 @@ struct DxChunkAlt { uint32_t start[DX_MAX_ALT], end[DX_MAX_ALT], count[DX_MAX_AL
 struct DxReindex { uint32_t chunk, k, start; int job; };      // a chunk whose entries have to be written again for the start that turned out to be the true one
 struct DxBandSum { uint32_t total; int last_chunk; };        // coefficients the band's code words cover; chunk that holds the band end marker
 
-struct DxSym { int len, type, payload; };                    // len without the sign bit
-
-__device__ __forceinline__ DxSym dx_symbol(const uint16_t *s_sym, const uint32_t *s_long, uint32_t win /* next 32 bits, first bit on top */)
-{
-	const uint32_t e = s_sym[win >> (32 - DX_K)];
-	DxSym s;
-	s.len = (int)(e & 15u);
-	if (s.len) { s.type = (e & 16u) ? DX_T_VALUE : DX_T_RUN; s.payload = (int)(e >> 5); return s; }
-	if (!(e & 16u)) { s.type = DX_T_INVALID; s.payload = 0; return s; }
-	uint32_t x = s_long[(e >> 5) + ((win >> (32 - DX_K - DX_L2_BITS)) & ((1u << DX_L2_BITS) - 1u))];
-	if (((x >> 5) & 7u) == DX_T_ESCAPE) {
-		const int nb = (int)(x & 31u);
-		x = s_long[(x >> 8) + ((win << (DX_K + DX_L2_BITS)) >> (32 - nb))];
-	}
-	s.len = (int)(x & 31u); s.type = (int)((x >> 5) & 7u); s.payload = (int)(x >> 8);
-	return s;
-}
 
 // k_dec_index and its helpers look code words up in ONE 32-bit table (a single LDS read per step, nothing that depends on a second one
 // for code words of up to 12 bits): cnt12 and sym12 of the same window side by side.  Bits 0-3 o1 = bits of the first code word, sign bit
@@ -145,18 +128,17 @@ __device__ __forceinline__ uint32_t dx_tab_entry(const uint32_t c /* cnt12 */, c
 	const uint32_t isval = (e >> 4) & 1u;
 	return (len + isval) | ((c & 15u) << 4) | ((isval ? 1u : (e >> 5)) << 8) | ((c >> 4) << 20);
 }
-// the code word behind a first-level entry without a length (e = its sym12 entry)
-__device__ __forceinline__ DxSym dx_long_symbol(const uint32_t e, const uint32_t *s_long, uint32_t win)
+// the code word behind a first-level entry without a length (e = its sym12 entry): its long_tab entry -- bits 0-4 bits of the code word with its sign bit (0: band end
+// marker / no code word), bits 5-7 type (DX_T_*), bits 8-19 coefficients it covers (the zero run, 1 for a value) -- or 0 (DX_T_INVALID)
+__device__ __forceinline__ uint32_t dx_long_entry(const uint32_t e, const uint32_t *s_long, uint32_t win)
 {
-	DxSym s;
-	if (!(e & 16u)) { s.len = 0; s.type = DX_T_INVALID; s.payload = 0; return s; }
+	if (!(e & 16u)) return 0u;
 	uint32_t x = s_long[(e >> 5) + ((win >> (32 - DX_K - DX_L2_BITS)) & ((1u << DX_L2_BITS) - 1u))];
 	if (((x >> 5) & 7u) == DX_T_ESCAPE) {
 		const int nb = (int)(x & 31u);
 		x = s_long[(x >> 8) + ((win << (DX_K + DX_L2_BITS)) >> (32 - nb))];
 	}
-	s.len = (int)(x & 31u); s.type = (int)((x >> 5) & 7u); s.payload = (int)(x >> 8);
-	return s;
+	return x;
 }
 
 // The payload words of a chunk in LDS: staging word i sits at i + i / 8, so that the 64 lanes of a wave, each walking its own 8 words, hit
@@ -237,11 +219,9 @@ __device__ __forceinline__ bool dx_steps(DxBitsAhead &B, uint32_t &pos, uint32_t
 		const bool all = adv != 0u && used != 0u && pos + used <= lim;
 		adv = all ? used : adv; add = all ? t >> 20 : add;      // ... or several whole ones, none of them beyond the mark
 		if (adv == 0u) {
-			const DxSym sy = dx_long_symbol(t >> 16, s_long, win);
-			const bool isrun = sy.type == DX_T_RUN, isval = sy.type == DX_T_VALUE;
-			adv = isrun ? (uint32_t)sy.len : (isval ? (uint32_t)sy.len + 1u : 0u);
-			add = isrun ? (uint32_t)sy.payload : (isval ? 1u : 0u);
-			if (!isrun && !isval) { endv = sy.type == DX_T_END ? (uint32_t)DX_END : (uint32_t)DX_BAD; ok = false; }
+			const uint32_t x = dx_long_entry(t >> 16, s_long, win), ty = (x >> 5) & 7u;
+			adv = x & 31u; add = (x >> 8) & 0xfffu;             // (made for this place: cfhd_entropy_jobs.h build_dec_index_tables)
+			if (ty - (uint32_t)DX_T_RUN >= 2u) { endv = ty == (uint32_t)DX_T_END ? (uint32_t)DX_END : (uint32_t)DX_BAD; ok = false; }
 		}
 		pos += adv;
 		if (COUNT) cnt += add;
@@ -368,10 +348,9 @@ __device__ __forceinline__ int dx_runin_candidates(const uint32_t bytes, const u
 				uint32_t adv = t & 15u;
 				adv = (adv != 0u && used != 0u && pos + used <= (uint32_t)DX_LANE_BITS) ? used : adv;
 				if (adv == 0u) {
-					const DxSym sy = dx_long_symbol(t >> 16, s_long, win);
-					if (sy.type == DX_T_RUN) adv = (uint32_t)sy.len;
-					else if (sy.type == DX_T_VALUE) adv = (uint32_t)sy.len + 1u;
-					else alive = false;
+					const uint32_t x = dx_long_entry(t >> 16, s_long, win);
+					adv = x & 31u;
+					if (((x >> 5) & 7u) - (uint32_t)DX_T_RUN >= 2u) alive = false;
 				}
 				if (alive) { pos += adv; B.skip((int)adv, ahead); }
 			}

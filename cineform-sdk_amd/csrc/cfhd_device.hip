@@ -181,6 +181,7 @@ void device_stream_release(void *stream)
 	(void)hipStreamDestroy((hipStream_t)stream);
 }
 StreamScope::StreamScope() { t_scope = true; t_scope_stream = nullptr; }
+StreamScope::StreamScope(void *preset) { t_scope = true; t_scope_stream = preset; }
 StreamScope::~StreamScope() { t_scope = false; t_scope_stream = nullptr; }
 void *StreamScope::stream() const { return t_scope_stream; }
 

@@ -15,7 +15,7 @@ namespace cfhd {
 int device_stream_create(void **stream);
 void device_stream_destroy(void *stream);
 void device_stream_release(void *stream);
-struct StreamScope { StreamScope(); ~StreamScope(); void *stream() const; };
+struct StreamScope { StreamScope(); explicit StreamScope(void *preset /* a stream an earlier scope created */); ~StreamScope(); void *stream() const; };
 
 
 class GpuEntropyEncoder {

@@ -86,7 +86,8 @@ inline bool build_dec_index_tables(int codebook, dev::DecIdxTables *T)
 	for (int i = 0; i < ncodes; i++) {
 		const RawCode &c = codes[i];
 		if (c.len <= DX_K) continue;
-		const uint32_t entry = (uint32_t)c.len | ((uint32_t)type_of(c) << 5) | ((uint32_t)c.payload << 8);
+		// what the index walk needs of a long code word: how far it moves the bit position (sign bit included; 0 stops the walk: the band end marker) and the raster position
+		const uint32_t entry = (c.kind == 2 ? 0u : (uint32_t)c.len + (c.kind == 1 ? 1u : 0u)) | ((uint32_t)type_of(c) << 5) | ((c.kind == 0 ? (uint32_t)c.payload : (c.kind == 1 ? 1u : 0u)) << 8);
 		if (c.len <= DX_K + DX_L2_BITS) {
 			const uint32_t p = c.bits >> (c.len - DX_K);
 			const int spare = DX_K + DX_L2_BITS - c.len;
