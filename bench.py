@@ -468,7 +468,7 @@ def measure(workload, steps, warmup, batch, unique, threads, rank, world, barrie
     return line, frames, pitch
 
 
-def host_fed(workload, frames, pitch, batch=128, depth=4, steps=24, warmup=4, registered=True):
+def host_fed(workload, frames, pitch, batch=128, depth=6, steps=36, warmup=6, registered=True):
     """The frame queue fed from host memory (never `value`): every pass copies its `batch` frames from host memory into HBM, encodes, decodes and copies the decoded pictures
     back -- cfhd_amd_batch_submit_host / _wait, `depth` batches in flight so that the copies of one pass run beside the kernels of the others; all of it inside the timed
     region.  The pool semantics of the reference (EncoderSDK/EncoderPool.cpp:239-295, timed by Example/TestCFHD.cpp:1020-1023) for whole batches.  registered: the caller's
@@ -648,7 +648,7 @@ def main():
             # the frame queue fed from host memory: upload -> pass -> picture download inside the timed region (never `value`: frames resident in HBM is what the metric times)
             line["host_fed"] = {"what": "cfhd_amd_batch_submit_host / _wait: frames from host memory, samples and decoded pictures back to host memory, all inside the timed region",
                                 "registered_buffers": host_fed(args.workload, frames, pitch, registered=True),
-                                "plain_buffers": host_fed(args.workload, frames, pitch, steps=12, registered=False)}
+                                "plain_buffers": host_fed(args.workload, frames, pitch, depth=4, steps=12, registered=False)}
         if world == 1 and not args.no_c_abi and headline:
             # the host-fed figures swing with the scheduling of ~ 30 host threads: the plain-buffer configuration runs three times, every run is in the line and
             # the MINIMUM of each figure beside them (north_star's 4000 fps round trip is judged on that)

@@ -1744,6 +1744,61 @@ def test_frame_queue_of_batches_equals_synchronous_passes():
     for b in slots: L.cfhd_amd_batch_destroy(b)
 
 
+@pytest.mark.parametrize("registered", [1, 0])
+def test_frame_queue_fed_from_host_memory(registered):
+    """cfhd_amd_batch_submit_host / _wait (bench.py's host_fed figure): every pass copies its frames out of the caller's memory and its pictures back into it on its own
+    streams, from page-locked or from plain buffers; two batches in flight, contents changing from pass to
+    pass -- the samples equal the reference encoder's, every picture in the caller's buffer lies inside the dither interval of the exact reconstruction of its own sample,
+    and bytes behind the last picture stay untouched."""
+    L = _batch_api()
+    L.cfhd_amd_batch_submit_host.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    L.cfhd_amd_batch_wait.restype = ctypes.c_longlong; L.cfhd_amd_batch_wait.argtypes = [ctypes.c_void_p]
+    L.cfhd_amd_register_host_buffer.argtypes = [ctypes.c_void_p, ctypes.c_size_t]; L.cfhd_amd_unregister_host_buffer.argtypes = [ctypes.c_void_p]
+    w, h, n = 320, 240, 3
+    fb = w * 2 * h
+    pics = [synth_yuy2(w, h, 80 + i)[0] for i in range(4 * n)]
+    slots = []
+    try:
+        for k in range(2):
+            b = L.cfhd_amd_batch_create(w, h, PIX_YUY2, QUALITY_FILMSCAN1, n, 2)
+            assert b, amd_last_error()
+            src = np.zeros(n * fb, np.uint8); dst = np.full(n * fb + 64, 0xA5, np.uint8)
+            if registered:
+                assert L.cfhd_amd_register_host_buffer(src.ctypes.data_as(ctypes.c_void_p), src.size) == 0 and L.cfhd_amd_register_host_buffer(dst.ctypes.data_as(ctypes.c_void_p), n * fb) == 0
+            slots.append((b, src, dst))
+        assert L.cfhd_amd_batch_submit_host(slots[0][0], None, fb, w * 2, None, fb, w * 2) != 0        # no frames
+        plan = Plan(w, h)
+        for rounds in range(2):
+            want = []
+            for k, (b, src, dst) in enumerate(slots):
+                mine = pics[(2 * rounds + k) * n:(2 * rounds + k + 1) * n]
+                for i in range(n): src[i * fb:(i + 1) * fb] = mine[i]
+                want.append(ref_encode_frames(mine, w * 2, w, h))
+                assert L.cfhd_amd_batch_submit_host(b, src.ctypes.data_as(ctypes.c_void_p), fb, w * 2, dst.ctypes.data_as(ctypes.c_void_p), fb, w * 2) == 0, amd_last_error()
+            assert L.cfhd_amd_batch_submit_host(slots[0][0], slots[0][1].ctypes.data_as(ctypes.c_void_p), fb, w * 2, None, fb, w * 2) != 0      # one pass per batch at a time
+            for k, (b, src, dst) in enumerate(slots):
+                assert L.cfhd_amd_batch_wait(b) > 0, amd_last_error()
+                for i in range(n):
+                    p = ctypes.c_void_p(); sz = ctypes.c_size_t()
+                    assert L.cfhd_amd_batch_get_sample(b, i, ctypes.byref(p), ctypes.byref(sz)) == 0
+                    sample = ctypes.string_at(p, sz.value)
+                    a, r = bytearray(mask_volatile_metadata(sample)), bytearray(mask_volatile_metadata(want[k][i]))
+                    for buf in (a, r):
+                        import struct
+                        kk = bytes(buf[:160]).find(struct.pack(">h", -69)); buf[kk + 2:kk + 4] = b"\0\0"
+                        u = bytes(buf[:1024]).find(b"UFRM"); buf[u + 8:u + 12] = b"\0\0\0\0"
+                    assert bytes(a) == bytes(r), "round %d batch %d frame %d" % (rounds, k, i)
+                    deq = oracle_decode_pyramid(sample, plan)
+                    lo, hi = oracle_inverse_yuv422(plan, deq, 0)[:h], oracle_inverse_yuv422(plan, deq, 1)[:h]
+                    img = dst[i * fb:(i + 1) * fb].reshape(h, w * 2)
+                    assert ((img == lo) | (img == hi)).all(), "round %d batch %d picture %d" % (rounds, k, i)
+                assert (dst[n * fb:] == 0xA5).all()
+    finally:
+        for b, src, dst in slots:
+            L.cfhd_amd_batch_destroy(b)
+            if registered: L.cfhd_amd_unregister_host_buffer(src.ctypes.data_as(ctypes.c_void_p)); L.cfhd_amd_unregister_host_buffer(dst.ctypes.data_as(ctypes.c_void_p))
+
+
 @pytest.mark.parametrize("w,h,n,nuniq", [(1920, 1080, 64, 16), (3840, 2160, 40, 4)])
 def test_batched_round_trip_at_bench_sizes_equals_reference(w, h, n, nuniq):
     """The batch sizes at which the library picks the kernels bench.py times by itself (>= 32 1080p-equivalents per launch: register strips
