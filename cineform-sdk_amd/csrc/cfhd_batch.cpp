@@ -121,7 +121,11 @@ long long batch_finish(cfhd_amd_batch *b)
 	}
 	const double t_enc = now();
 	if (b->decode) { if (c->dec.wait()) return -5; if (c->dec.entropy().check()) return -7; }
-	if (b->decode && b->host_out) for (int l = 0; l < c->n; l++) if (c->dec.finish_frame(l, b->host_out + b->host_out_stride * (size_t)l, b->host_out_pitch)) return -5;      // (frames staged through pinned memory: a plain buffer)
+	if (b->decode && b->host_out) {                  // (pictures staged through pinned memory -- a plain buffer -- leave it on a few threads side by side; nothing to do for a registered one)
+		std::atomic<int> bad(0);
+		parallel_for(c->n, c->n > 8 ? 8 : 1, [&](int l) { if (c->dec.finish_frame(l, b->host_out + b->host_out_stride * (size_t)l, b->host_out_pitch)) bad.store(1); });
+		if (bad.load()) return -5;
+	}
 	const double t4 = now();
 	b->t_fwd = b->t_launched - b->t_launch0; b->t_entropy_enc = t_enc - b->t_launched; b->t_entropy_dec = 0; b->t_inv = t4 - t_enc;
 	b->steps++;

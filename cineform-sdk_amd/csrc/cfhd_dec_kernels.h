@@ -1018,12 +1018,21 @@ __global__ void __launch_bounds__(NT) k_dec_tiles(const DxTileDesc *tiles, uint3
 			const uint32_t quant2 = (d.quant & 0xffffu) * 0x10001u;
 			const uint4 zero = { 0u, 0u, 0u, 0u };
 			unsigned long long *const tmasks = d.masks;
-#pragma unroll 1
-			for (uint32_t it = (uint32_t)wave; it < (uint32_t)DX_TILE / 512u; it += (uint32_t)(NT / 64)) {
+			// (all of a wave's chunks are read -- and cleared -- before the first is looked at: one LDS round trip per tile, not one per chunk)
+			enum { NCH = DX_TILE / 512, NW = NT / 64, NIT = (NCH + NW - 1) / NW };
+			uint4 vv[NIT];
+#pragma unroll
+			for (int k = 0; k < NIT; k++) {
+				const uint32_t it = (uint32_t)wave + (uint32_t)(k * NW);
+				vv[k] = zero;
+				if (it < (uint32_t)NCH) { vv[k] = ((const uint4 *)s_tile)[it * 64u + (uint32_t)lane]; ((uint4 *)s_tile)[it * 64u + (uint32_t)lane] = zero; }
+			}
+#pragma unroll
+			for (int k = 0; k < NIT; k++) {
+				const uint32_t it = (uint32_t)wave + (uint32_t)(k * NW);
+				if (it >= (uint32_t)NCH || it * 64u >= n16) continue;      // (behind the tile's end: cleared, not stored)
 				const uint32_t i = it * 64u + (uint32_t)lane;
-				uint4 v = ((const uint4 *)s_tile)[i];
-				((uint4 *)s_tile)[i] = zero;
-				if (it * 64u >= n16) continue;                // (behind the tile's end: cleared, not stored)
+				uint4 v = vv[k];
 				const bool nz = i < n16 && (v.x | v.y | v.z | v.w) != 0u;
 				v.x = pk_mulw(v.x, quant2); v.y = pk_mulw(v.y, quant2); v.z = pk_mulw(v.z, quant2); v.w = pk_mulw(v.w, quant2);
 				if (tmasks) {

@@ -12,6 +12,8 @@
 #include <stdlib.h>
 #include <stdio.h>
 #include <mutex>
+#include <thread>
+#include <atomic>
 #include <string>
 #include <utility>
 
@@ -527,6 +529,25 @@ int EncodeBatch::upload_frames(const void *frames, size_t frame_stride, int pitc
 	if (!own_input_ || !frames) return -1;
 	if (pitch == in_pitch_ && frame_stride == frame_bytes_ && plan_.pixel_kind != PIX_BYR4 && plan_.pixel_kind != PIX_BYR5 && host_buffer_is_registered(frames, frame_bytes_ * (size_t)n_)) {
 		HIPCHK(hipMemcpyAsync(d_in_, frames, frame_bytes_ * (size_t)n_, hipMemcpyHostToDevice, (hipStream_t)stream_));
+		return 0;
+	}
+	if (n_ > 8 && pitch >= in_pitch_ && plan_.pixel_kind != PIX_BYR4 && plan_.pixel_kind != PIX_BYR5 && !host_buffer_is_registered(frames, 1)) {
+		// plain memory, many frames: staged into the batch's pinned memory by a few threads side by side (one thread copies 4 MB in ~0.3 ms: 128 frames one after the
+		// other were 40 ms of a pass), then ONE copy to the device
+		const int nt = n_ < 8 ? n_ : 8;
+		std::atomic<int> next(0);
+		auto work = [&] {
+			for (int i; (i = next.fetch_add(1)) < n_;) {
+				const uint8_t *src = (const uint8_t *)frames + frame_stride * (size_t)i; uint8_t *dst = h_in_ + frame_bytes_ * (size_t)i;
+				if (pitch == in_pitch_) memcpy(dst, src, frame_bytes_);
+				else for (int r = 0; r < in_rows_; r++) memcpy(dst + (size_t)r * in_pitch_, src + (size_t)r * pitch, (size_t)in_pitch_);
+			}
+		};
+		std::vector<std::thread> pool;
+		for (int k = 1; k < nt; k++) pool.emplace_back(work);
+		work();
+		for (auto &t : pool) t.join();
+		HIPCHK(hipMemcpyAsync(d_in_, h_in_, frame_bytes_ * (size_t)n_, hipMemcpyHostToDevice, (hipStream_t)stream_));
 		return 0;
 	}
 	for (int i = 0; i < n_; i++) { const int rc = upload_frame(i, (const uint8_t *)frames + frame_stride * (size_t)i, pitch); if (rc) return rc; }
@@ -1264,6 +1285,13 @@ int DecodeBatch::download_frames(void *out, size_t frame_stride, int pitch)
 	if (pitch == out_pitch_ && frame_stride == frame_bytes_ && host_buffer_is_registered(out, frame_bytes_ * (size_t)n_)) {
 		HIPCHK(hipMemcpyAsync(out, d_out_, frame_bytes_ * (size_t)n_, hipMemcpyDeviceToHost, (hipStream_t)stream_));
 		direct_.assign((size_t)n_, 1);
+		return 0;
+	}
+	if (n_ > 8 && !host_buffer_is_registered(out, 1)) {
+		// plain memory, many frames: ONE copy into the batch's pinned memory; finish_frame() copies every frame out behind wait() (the caller runs them on several threads)
+		HIPCHK(hipMemcpyAsync(h_out_, d_out_, frame_bytes_ * (size_t)n_, hipMemcpyDeviceToHost, (hipStream_t)stream_));
+		direct_.assign((size_t)n_, 0);
+		out_pieces_.assign((size_t)n_, 0);
 		return 0;
 	}
 	for (int i = 0; i < n_; i++) { const int rc = download_frame(i, (uint8_t *)out + frame_stride * (size_t)i, pitch); if (rc) return rc; }

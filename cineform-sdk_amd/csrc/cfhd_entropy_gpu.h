@@ -84,7 +84,7 @@ private:
 	uint8_t *d_tmpl_ = nullptr, *h_tmpl_ = nullptr;
 	bool dirty_ = true;
 	void *ev_[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; bool timed_ = false;
-	bool split_ = false; void *ev_level1_ = nullptr, *stream2_ = nullptr, *ev2_[3] = {nullptr, nullptr, nullptr};      // the level-1 part of k_ent_count on its own stream
+	bool split_ = false, serial_split_ = false; void *ev_level1_ = nullptr, *stream2_ = nullptr, *ev2_[3] = {nullptr, nullptr, nullptr};      // the level-1 part of k_ent_count on its own stream
 	int16_t *d_coeffs_ = nullptr; size_t coeff_stride_ = 0;
 	void *d_blocks_ = nullptr; unsigned long long *d_masks_ = nullptr; size_t masks_per_frame_ = 0; bool use_blocks_ = false;
 };

@@ -113,7 +113,9 @@ int GpuEntropyEncoder::prepare_units(int nframes, int16_t *d_coeffs, size_t stri
 	for (int f = 0; f < n_; f++) { SampleHeaderInfo h = hdr0; h.frame_number = (uint32_t)f + 1; if ((rc = set_frame_header(f, h))) return rc; }
 	for (void *&e : ev_) HIPCHK(hipEventCreate((hipEvent_t *)&e));
 	for (void *&e : ev2_) HIPCHK(hipEventCreate((hipEvent_t *)&e));
-	HIPCHK((hipError_t)device_stream_create(&stream2_));
+	// (the second stream only where it can be used -- the level-1 count beside the level-2 / 3 transforms needs eight frames or more --: a pool worker or a synchronous
+	// encoder would otherwise hold a stream that never runs anything but still takes its turn when the runtime deals its hardware queues)
+	if (n_ >= 8) HIPCHK((hipError_t)device_stream_create(&stream2_));
 	return 0;
 }
 
@@ -162,7 +164,15 @@ int GpuEntropyEncoder::launch()
 	split_ = split_on && ev_level1_ && stream2_ && !host_->jobs.ranges_l1.empty() && act >= 8;      // (a single frame gains nothing from six launches instead of one)
 	// the peak flags are raised by the difference-coded band only, a level-1 band: cleared on the stream that counts it
 	if (peak_flags_in_use() && !split_) HIPCHK(hipMemsetAsync(d_sizes_ + n_, 0, sizeof(uint32_t) * n_, st));
-	if (split_) {
+	serial_split_ = split_ && stream2_ == stream_;      // (a pass whose streams are one, cfhd_batch.cpp StreamScope: the same launches in a row, timed apart)
+	if (serial_split_) {
+		if (peak_flags_in_use()) HIPCHK(hipMemsetAsync(d_sizes_ + n_, 0, sizeof(uint32_t) * n_, st));
+		HIPCHK(hipEventRecord((hipEvent_t)ev2_[0], st));
+		for (const auto &r : host_->jobs.ranges_l1) count_range(st, r.first, r.second, true);
+		HIPCHK(hipEventRecord((hipEvent_t)ev2_[1], st));
+		for (const auto &r : host_->jobs.ranges_rest) count_range(st, r.first, r.second);
+		HIPCHK(hipEventRecord((hipEvent_t)ev2_[2], st));
+	} else if (split_) {
 		// the level-1 bands on the second stream as soon as the level-1 transform is done; the bands of levels 2 and 3 here, behind their transforms; the scan waits for both
 		hipStream_t s2 = (hipStream_t)stream2_;
 		HIPCHK(hipStreamWaitEvent(s2, (hipEvent_t)ev_level1_, 0));
@@ -214,7 +224,8 @@ float GpuEntropyEncoder::kernel_ms(int k)
 		return ms;
 	}
 	void *end = (k == 0 && split_) ? ev2_[2] : ev_[k + 1];      // (the main stream's own launches, not its wait for the second stream)
-	if (hipEventElapsedTime(&ms, (hipEvent_t)ev_[k], (hipEvent_t)end) != hipSuccess) { (void)hipGetLastError(); return 0; }
+	void *begin = (k == 0 && serial_split_) ? ev2_[1] : ev_[k];   // (one stream: the level-1 count ran in front, between ev2_[0] and ev2_[1])
+	if (hipEventElapsedTime(&ms, (hipEvent_t)begin, (hipEvent_t)end) != hipSuccess) { (void)hipGetLastError(); return 0; }
 	return ms;
 }
 

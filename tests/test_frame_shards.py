@@ -303,4 +303,4 @@ def test_c_abi_leg_of_the_bench_spreads_over_two_devices():
     finally:
         del os.environ["CFHD_CABI_BENCH"]; del os.environ["HIPEMU_DEVICES"]
     assert "error" not in r, r
-    assert r["sync_encode_fps"] > 0 and r["sync_decode_fps"] > 0 and r["decode_fps_4_handles"] > 0 and r["pool_encode_fps_4_workers"] > 0 and r["round_trip_fps_pool4_plus_4_decoders"] >= 0, r      # (the round trip's window -- warm decoders to the end of the submissions -- can stay empty at the emulator's pace)
+    assert r["sync_encode_fps"] > 0 and r["sync_decode_fps"] > 0 and r["decode_fps_4_handles"] > 0 and r["pool_encode_fps_4_workers"] > 0 and r["round_trip_fps_pool4_plus_4_decoders"] >= 0, r      # (the round trip's window opens with warm decoders: it can stay empty at the emulator's pace)

@@ -1744,8 +1744,8 @@ def test_frame_queue_of_batches_equals_synchronous_passes():
     for b in slots: L.cfhd_amd_batch_destroy(b)
 
 
-@pytest.mark.parametrize("registered", [1, 0])
-def test_frame_queue_fed_from_host_memory(registered):
+@pytest.mark.parametrize("registered,n", [(1, 3), (0, 3), (0, 10), (1, 10)])      # (more than eight frames from plain memory: staged by several threads, one copy each way)
+def test_frame_queue_fed_from_host_memory(registered, n):
     """cfhd_amd_batch_submit_host / _wait (bench.py's host_fed figure): every pass copies its frames out of the caller's memory and its pictures back into it on its own
     streams, from page-locked or from plain buffers; two batches in flight, contents changing from pass to
     pass -- the samples equal the reference encoder's, every picture in the caller's buffer lies inside the dither interval of the exact reconstruction of its own sample,
@@ -1754,7 +1754,7 @@ def test_frame_queue_fed_from_host_memory(registered):
     L.cfhd_amd_batch_submit_host.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
     L.cfhd_amd_batch_wait.restype = ctypes.c_longlong; L.cfhd_amd_batch_wait.argtypes = [ctypes.c_void_p]
     L.cfhd_amd_register_host_buffer.argtypes = [ctypes.c_void_p, ctypes.c_size_t]; L.cfhd_amd_unregister_host_buffer.argtypes = [ctypes.c_void_p]
-    w, h, n = 320, 240, 3
+    w, h = (320, 240) if n <= 3 else (192, 96)
     fb = w * 2 * h
     pics = [synth_yuy2(w, h, 80 + i)[0] for i in range(4 * n)]
     slots = []

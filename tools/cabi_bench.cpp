@@ -11,7 +11,6 @@
 #include <chrono>
 #include <condition_variable>
 #include <deque>
-#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -80,7 +79,6 @@ int main(int argc, char **argv)
 
 	// --- the asynchronous pool (one submitting thread, as the reference's TestCFHD drives it), optionally feeding decoder threads
 	struct Queue { std::mutex m; std::condition_variable cv; std::deque<std::vector<uint8_t>> q; bool closed = false; size_t cap; } Q; Q.cap = 4 * (size_t)handles;
-	std::function<void()> on_submit_end;                  // (set for the round-trip run: called when the pool's submit loop ends)
 	auto pool_run = [&](bool feed) {
 		CFHD_EncoderPoolRef pool; CHECK(CFHD_CreateEncoderPool(&pool, workers, 2 * workers, nullptr));
 		CHECK(CFHD_PrepareEncoderPool(pool, W, H, YUY2, (CFHD_EncodedFormat)0, 0, (CFHD_EncodingQuality)4));
@@ -109,7 +107,6 @@ int main(int argc, char **argv)
 			if (!warm && got >= 4 * workers) { warm = true; t0 = now(); sent0 = sent; }
 		}
 		const long sent1 = sent; const double dt = now() - t0;
-		if (on_submit_end) on_submit_end();             // (the round trip's window closes here: steady state, not the drain of the queue and the release of the pool)
 		while (got < sent) if (collect(true)) got++;
 		CFHD_ReleaseEncoderPool(pool);
 		return (sent1 - sent0) / dt;
@@ -133,15 +130,16 @@ int main(int argc, char **argv)
 		}
 		CFHD_CloseDecoder(dec); drop_output(out);
 	});
-	// (likewise: frames decoded per second from the moment the first 4 * handles frames have come out of the decoders to the moment the pool stops submitting)
+	// (likewise: frames decoded per second from the moment the first 4 * handles frames have come out of the decoders to the moment pool_run returns -- the pool has stopped
+	// submitting, collected every outstanding sample and been released: the window holds the steady state, the drain of the pool's queue and its teardown; advisor, round 5)
 	std::atomic<bool> rt_done(false);
 	double rt_t0 = 0, rt_t1 = 0; long rt_n0 = 0, rt_n1 = 0;
 	std::thread watcher([&] {
 		while (decoded < 4 * handles && !rt_done) std::this_thread::sleep_for(std::chrono::microseconds(200));
 		rt_t0 = now(); rt_n0 = decoded;
 	});
-	on_submit_end = [&] { rt_t1 = now(); rt_n1 = decoded; };
 	pool_run(true);
+	rt_t1 = now(); rt_n1 = decoded;
 	rt_done = true;
 	{ std::lock_guard<std::mutex> lk(Q.m); Q.closed = true; Q.cv.notify_all(); }
 	for (auto &t : th) t.join();
