@@ -175,6 +175,7 @@ cfhd_amd_batch *cfhd_amd_batch_create_ex(int width, int height, uint32_t pixel_f
 	// so a pass takes two streams unless the environment gives the process eight queues or more -- read, never set here.  CFHD_AMD_STREAMS=1|2|3 overrides (A/B).
 	const char *sp = getenv("CFHD_AMD_STREAMS"), *hq = getenv("GPU_MAX_HW_QUEUES");
 	const int streams = sp && atoi(sp) >= 1 && atoi(sp) <= 3 ? atoi(sp) : (hq && atoi(hq) >= 8 ? 3 : 2);
+	struct Lean { Lean() { device_streams_lean(true); } ~Lean() { device_streams_lean(false); } } lean;      // (a batch creates only the streams it launches on)
 	for (int first = 0; first < nframes; first += chunk) {
 		std::unique_ptr<cfhd_amd_chunk> c(new cfhd_amd_chunk);
 		c->first = first; c->n = nframes - first < chunk ? nframes - first : chunk;

@@ -182,6 +182,9 @@ void device_stream_release(void *stream)
 	{ std::lock_guard<std::mutex> lk(g_shared_mutex); for (size_t i = 0; i < g_shared_streams.size(); i++) if (g_shared_streams[i] == stream) { g_shared_streams.erase(g_shared_streams.begin() + (long)i); break; } }
 	(void)hipStreamDestroy((hipStream_t)stream);
 }
+static thread_local bool t_lean = false;
+void device_streams_lean(bool on) { t_lean = on; }
+bool device_streams_are_lean() { return t_lean; }
 StreamScope::StreamScope() { t_scope = true; t_scope_stream = nullptr; }
 StreamScope::StreamScope(void *preset) { t_scope = true; t_scope_stream = preset; }
 StreamScope::~StreamScope() { t_scope = false; t_scope_stream = nullptr; }
@@ -872,9 +875,9 @@ int DecodeBatch::prepare(const FramePlan &plan, int nframes, int out_kind, bool 
 	HIPCHK(hipEventCreate((hipEvent_t *)&ev1_));
 	for (int k = 0; k < 2; k++) HIPCHK(hipEventCreate((hipEvent_t *)&evl_[k]));
 	for (int k = 0; k < 3; k++) HIPCHK(hipEventCreate((hipEvent_t *)&ev2_[k]));
-	// (a second stream only for the arrangement that uses it -- CFHD_AMD_TILES_SPLIT=1, launch_inverse --: a stream that is never used still takes its turn when the
-	// runtime deals its 4 hardware queues to the streams in creation order)
-	{ const char *se = getenv("CFHD_AMD_TILES_SPLIT"); if (se && se[0] == '1') HIPCHK((hipError_t)device_stream_create(&stream2_)); }
+	// (a batch of the frame queue creates its second stream only for the arrangement that uses it -- CFHD_AMD_TILES_SPLIT=1, launch_inverse --: a stream that is never used
+	// still takes its turn when the runtime deals its 4 hardware queues to the streams in creation order)
+	{ const char *se = getenv("CFHD_AMD_TILES_SPLIT"); if ((se && se[0] == '1') || !device_streams_are_lean()) HIPCHK((hipError_t)device_stream_create(&stream2_)); }      // (not lean: the C ABI's handles, cfhd_entropy_gpu.h device_streams_lean)
 	out_rows_ = half ? plan.display_height / 2 : plan.display_height;
 	out_pitch_ = byr4_ ? plan.width * 8 : packed_frame_pitch(out_kind, half ? plan.width / 2 : plan.width);      // (BYR4: the scratch rows hold four words per quad)
 	frame_bytes_ = (size_t)out_pitch_ * out_rows_;

@@ -15,6 +15,13 @@ namespace cfhd {
 int device_stream_create(void **stream);
 void device_stream_destroy(void *stream);
 void device_stream_release(void *stream);
+// Lean streams (thread-local, set by cfhd_batch.cpp while it prepares a batch of the frame queue): an object creates only the streams it will launch on.  Outside it -- the
+// handles of the C ABI: pool workers, decoders -- every encoder and decoder also creates the second stream of round 5's arrangement although single frames never use it:
+// measured, not explained (profiles/r06_j_*: five runs each on one box) -- with 8 pool workers + 8 decoder threads the round trip through the C ABI runs at 5.0 k fps with
+// those idle streams in place and at 3.8-4.1 k without them; the runtime deals its 4 hardware queues to streams in creation order, and the many-thread case likes its
+// active streams on FEW queues (round 5 found the same from the other side: 16 hardware queues cost that case 10-25 %).
+void device_streams_lean(bool on);
+bool device_streams_are_lean();
 struct StreamScope { StreamScope(); explicit StreamScope(void *preset /* a stream an earlier scope created */); ~StreamScope(); void *stream() const; };
 
 

@@ -113,9 +113,9 @@ int GpuEntropyEncoder::prepare_units(int nframes, int16_t *d_coeffs, size_t stri
 	for (int f = 0; f < n_; f++) { SampleHeaderInfo h = hdr0; h.frame_number = (uint32_t)f + 1; if ((rc = set_frame_header(f, h))) return rc; }
 	for (void *&e : ev_) HIPCHK(hipEventCreate((hipEvent_t *)&e));
 	for (void *&e : ev2_) HIPCHK(hipEventCreate((hipEvent_t *)&e));
-	// (the second stream only where it can be used -- the level-1 count beside the level-2 / 3 transforms needs eight frames or more --: a pool worker or a synchronous
-	// encoder would otherwise hold a stream that never runs anything but still takes its turn when the runtime deals its hardware queues)
-	if (n_ >= 8) HIPCHK((hipError_t)device_stream_create(&stream2_));
+	// (the second stream: used with eight frames or more -- the level-1 count beside the level-2 / 3 transforms --; the C ABI's handles create it nevertheless:
+	// cfhd_entropy_gpu.h device_streams_lean)
+	if (n_ >= 8 || !device_streams_are_lean()) HIPCHK((hipError_t)device_stream_create(&stream2_));
 	return 0;
 }
 
