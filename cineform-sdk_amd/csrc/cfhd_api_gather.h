@@ -131,7 +131,8 @@ enum { kDecodeSignalSlots = 17 };
 std::atomic<int> g_decodes_in_flight[kDecodeSignalSlots];
 std::atomic<long long> g_last_decode_ns[kDecodeSignalSlots];
 long long mono_ns() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (long long)ts.tv_sec * 1000000000ll + ts.tv_nsec; }
-int decode_signal_slot(int device) { return device < 0 || device + 1 >= (int)kDecodeSignalSlots ? 0 : device + 1; }
+// (a handle that was not dealt a device runs on the process default: the slot is that of the real device, so that a decoder's -1 and a pool's device number meet)
+int decode_signal_slot(int device) { if (device < 0) device = device_current(); return device < 0 || device + 1 >= (int)kDecodeSignalSlots ? 0 : device + 1; }
 struct DecodeInFlight {
 	int slot;
 	explicit DecodeInFlight(int device) : slot(decode_signal_slot(device)) { g_decodes_in_flight[slot].fetch_add(1); }

@@ -821,32 +821,48 @@ __device__ __forceinline__ uint32_t dx_piece_at(const DxBandJob &job, const DxBa
 	return kc * DX_CHUNK_SUBS + a;
 }
 
-// One thread per output tile: its record.  The pieces that may reach into the tile run from the one that holds its first coefficient to the one that holds the first
-// coefficient of the band's next tile (the band's last tile: to the chunk with the band end marker).
+// A thread per output tile writes its record.  The pieces that may reach into the tile run from the one that holds its first coefficient to the one that holds the first
+// coefficient of the band's next tile (the band's last tile: to the chunk with the band end marker): a workgroup of DX_THREADS threads serves DX_THREADS - 1 consecutive tiles,
+// every thread searches the first piece of one tile (the last thread: of the tile behind the workgroup's) and hands it to its left neighbour through LDS -- one chain of
+// dependent loads per thread, not two (a synchronous CFHD_DecodeSample waits for this kernel's latency, not for its throughput).
+enum { DX_TILE_INDEX_TILES = DX_THREADS - 1 };
 __global__ void __launch_bounds__(DX_THREADS) k_dec_tile_index(const DxBandJob *jobs, DxTilePlan plan, const uint32_t *entries, const uint32_t *chunk_base, const DxBandSum *sums,
                                                                DxTileDesc *tiles, unsigned long long *masks, uint32_t masks_per_frame)
 {
-	const uint32_t t = (uint32_t)blockIdx.x * DX_THREADS + (uint32_t)threadIdx.x;
-	if (t >= plan.total) return;
-	int slot = 0;
-	while (slot + 1 < plan.nslots && t >= plan.cum[slot + 1]) slot++;
-	const uint32_t r = t - plan.cum[slot], per = plan.per_band[slot], len = plan.tile_len[slot];
-	const uint32_t f = r / per, ti = r - f * per;
-	const int j = (int)plan.slot_of[slot] * plan.nframes + (int)f;
-	const DxBandJob job = jobs[j];
-	const DxBandSum sum = sums[j];
-	const uint32_t T0 = ti * len;
-	const bool any = job.bytes != 0u && T0 < (uint32_t)job.n;
+	__shared__ uint32_t s_first[DX_THREADS];
+	__shared__ int s_job[DX_THREADS];
+	const uint32_t t = (uint32_t)blockIdx.x * DX_TILE_INDEX_TILES + (uint32_t)threadIdx.x;
+	const bool have = t < plan.total;
+	int slot = 0, j = -1;
+	uint32_t per = 1, len = 0, f = 0, ti = 0, T0 = 0, first = DX_TILE_EMPTY;
+	bool any = false;
+	DxBandJob job; DxBandSum sum;
+	memset(&job, 0, sizeof(job)); sum.total = 0; sum.last_chunk = -1;
+	if (have) {
+		while (slot + 1 < plan.nslots && t >= plan.cum[slot + 1]) slot++;
+		const uint32_t r = t - plan.cum[slot];
+		per = plan.per_band[slot]; len = plan.tile_len[slot];
+		f = r / per; ti = r - f * per;
+		j = (int)plan.slot_of[slot] * plan.nframes + (int)f;
+		job = jobs[j]; sum = sums[j];
+		T0 = ti * len;
+		any = job.bytes != 0u && T0 < (uint32_t)job.n;
+		if (any) first = dx_piece_at(job, sum, entries, chunk_base, T0);
+	}
+	s_first[threadIdx.x] = first; s_job[threadIdx.x] = have ? j : -1;
+	__syncthreads();
+	if (!have || threadIdx.x == DX_TILE_INDEX_TILES) return;      // (the last thread only searched for its left neighbour)
 	const uint32_t T1 = any ? (T0 + len < (uint32_t)job.n ? T0 + len : (uint32_t)job.n) : T0;
 	DxTileDesc d;
 	d.bits = job.bits; d.bytes = job.bytes; d.chunk0 = job.chunk0; d.quant = (uint32_t)job.quant; d.table = (uint32_t)job.table;
 	d.dst = job.dst + T0; d.T0 = T0; d.ncoef = T1 - T0;
 	d.masks = (any && masks && plan.mask_base[slot] >= 0) ? masks + (size_t)f * masks_per_frame + (size_t)plan.mask_base[slot] + (size_t)(T0 / 512u) : nullptr;
-	d.first_sub = any ? dx_piece_at(job, sum, entries, chunk_base, T0) : (uint32_t)DX_TILE_EMPTY;
+	d.first_sub = first;
 	d.end_sub = 0u;
-	if (d.first_sub != DX_TILE_EMPTY) {
+	if (first != DX_TILE_EMPTY) {
 		const uint32_t last = ((uint32_t)sum.last_chunk + 1u) * DX_CHUNK_SUBS;
-		const uint32_t next = (ti + 1u < per) ? dx_piece_at(job, sum, entries, chunk_base, T0 + len) : (uint32_t)DX_TILE_EMPTY;
+		// the right neighbour's tile is the band's next tile when it belongs to the same band of the same frame
+		const uint32_t next = (ti + 1u < per && s_job[threadIdx.x + 1] == j) ? s_first[threadIdx.x + 1] : (uint32_t)DX_TILE_EMPTY;
 		d.end_sub = (next != DX_TILE_EMPTY && next + 1u < last) ? next + 1u : last;
 	}
 	d.pad[0] = 0u; d.pad[1] = 0u;

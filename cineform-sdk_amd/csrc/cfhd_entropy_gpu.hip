@@ -576,7 +576,7 @@ int GpuEntropyDecoder::launch_dx(bool device_jobs, int njobs, uint32_t host_chun
 	                                                         d_errors_, (const uint32_t *)d_repair_, (dev::DxReindex *)d_reindex_, (uint32_t *)d_counters_, (uint32_t *)d_stats_);
 	dev::k_dec_reindex<<<g1, dev::DX_THREADS, 0, st>>>(jobs, T, (uint32_t *)d_entries_, (const dev::DxReindex *)d_reindex_, (const uint32_t *)d_counters_, (uint32_t *)d_stats_,
 	                                                   (const dev::DxChunkAlt *)d_alts_, (const uint32_t *)d_alt_entries_);
-	dev::k_dec_tile_index<<<(tp.total + dev::DX_THREADS - 1) / dev::DX_THREADS, dev::DX_THREADS, 0, st>>>(jobs, tp, (const uint32_t *)d_entries_, (const uint32_t *)d_chunk_base_, (const dev::DxBandSum *)d_sums_,
+	dev::k_dec_tile_index<<<(tp.total + dev::DX_TILE_INDEX_TILES - 1) / dev::DX_TILE_INDEX_TILES, dev::DX_THREADS, 0, st>>>(jobs, tp, (const uint32_t *)d_entries_, (const uint32_t *)d_chunk_base_, (const dev::DxBandSum *)d_sums_,
 	                                                                                                  (dev::DxTileDesc *)d_tile_start_, tmasks, (uint32_t)masks_per_frame_);
 	HIPCHK(hipEventRecord((hipEvent_t)ev_[6], st));
 	// Many frames: the tiles of the level-2 / level-3 bands (a quarter of them) and the lowpass bands first, an event behind them, then the level-1 tiles -- the caller

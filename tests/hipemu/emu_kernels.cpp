@@ -757,7 +757,7 @@ extern "C" int emu_entropy_decode_dx(const uint8_t *sample, size_t size, int pix
 	std::vector<dev::DxTileDesc> tile_desc(tp.total + 1);
 	auto tile_pass = [&](const dev::DxTilePlan &p_, unsigned long long *m_, uint32_t per_) {
 		memset(tile_desc.data(), 0xdb, tile_desc.size() * sizeof(dev::DxTileDesc));
-		hipemu::launch(dim3((p_.total + dev::DX_THREADS - 1) / dev::DX_THREADS), dim3(dev::DX_THREADS), [&] { dev::k_dec_tile_index(jobs.data(), p_, entries.data(), chunk_base.data(), sums.data(), tile_desc.data(), m_, per_); });
+		hipemu::launch(dim3((p_.total + dev::DX_TILE_INDEX_TILES - 1) / dev::DX_TILE_INDEX_TILES), dim3(dev::DX_THREADS), [&] { dev::k_dec_tile_index(jobs.data(), p_, entries.data(), chunk_base.data(), sums.data(), tile_desc.data(), m_, per_); });
 		if (one_wave) hipemu::launch(dim3((unsigned)grid), dim3(64), [&] { dev::k_dec_tiles<64>(tile_desc.data(), p_.first, p_.total, &tables, entries.data(), chunk_base.data()); });
 		else hipemu::launch(dim3((unsigned)grid), dim3(dev::DX_TILE_THREADS), [&] { dev::k_dec_tiles<dev::DX_TILE_THREADS>(tile_desc.data(), p_.first, p_.total, &tables, entries.data(), chunk_base.data()); });
 	};
