@@ -375,13 +375,16 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_count_blocks(const EntSegJo
 		const int q = lane + 64 * h, pos = job.first + 8 * q;
 		int row = row0, col = col0 + 8 * q;
 		while (col >= pitch) { col -= pitch; row++; }       // (a segment covers one to three rows of the bands this kernel sees; any number works)
-		const int k = col / FWD_CHUNK_COLS_ENT, i = (col - k * FWD_CHUNK_COLS_ENT) >> 3;
+		// chunk k of the row and block i of the chunk: block c8 of the row / 62 as a multiply and a shift (exact below 1092 blocks = rows of 8736 coefficients), and
+		// every product on the full-rate 24-bit multiplier (the plain forms compile to v_mul_hi / v_mad_u64_u32 at a quarter of the rate: measured 6 % of this kernel)
+		static_assert(FWD_CHUNK_COLS_ENT == 62 * 8, "the division below is by 62 blocks");
+		const uint32_t c8 = (uint32_t)col >> 3, k = mul_u24(c8, 1058u) >> 16, i = c8 - mul_u24(k, 62u);
 		unsigned long long m = 0ull;
-		if (pos < end) m = masks[row * cpr + k];
+		if (pos < end) m = masks[mul_u24((uint32_t)row, (uint32_t)cpr) + k];
 		w[h][0] = w[h][1] = w[h][2] = w[h][3] = 0u;
 		if ((m >> i) & 1ull) {
 			const uint32_t below = (uint32_t)__popcll(m & ((1ull << i) - 1ull));
-			const cfhd_u4 v = CFHD_LDG128(&blocks[(size_t)(row * pitch + k * FWD_CHUNK_COLS_ENT) / 8 + below]);
+			const cfhd_u4 v = CFHD_LDG128(&blocks[mul_u24((uint32_t)row, (uint32_t)pitch >> 3) + mul_u24(k, 62u) + below]);
 			w[h][0] = v.x; w[h][1] = v.y; w[h][2] = v.z; w[h][3] = v.w;
 		}
 	}

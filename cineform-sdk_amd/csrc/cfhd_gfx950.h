@@ -68,6 +68,17 @@ __device__ __forceinline__ uint32_t pk_to8(uint32_t v, int shift, uint32_t dithe
 	return __builtin_bit_cast(uint32_t, x);
 }
 __device__ __forceinline__ uint32_t byte_perm(uint32_t s0, uint32_t s1, uint32_t sel) { return __builtin_amdgcn_perm(s0, s1, sel); }
+// 10 -> 8 bits of four neighbouring samples: e = (s0, s2), o = (s1, s3) as 16-bit lanes before the last >> 1, d2e / d2o = twice the dither bit of each lane (bit 1, bit 17),
+// shift1 = shift + 1 (<= 7).  Equal to pk_to8 on both words, bytes in sample order: ((v >> 1) + d) >> shift = (v + 2 d) >> (shift + 1) for v >= 0, a negative v stays <= 0
+// through the saturating add and the arithmetic shift, and v_sat_pk_u8_i16 clamps each lane to 0 .. 255 while packing -- three instructions a word instead of five, one v_perm
+// instead of a shift and an or.
+__device__ __forceinline__ uint32_t sat_pk_u8(uint32_t v) { uint32_t r; asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(v)); return r; }
+__device__ __forceinline__ uint32_t pk_to8_bytes(uint32_t e, uint32_t o, int shift1, uint32_t d2e, uint32_t d2o)
+{
+	e = pk_sra(pk_adds(e, d2e), shift1); o = pk_sra(pk_adds(o, d2o), shift1);
+	return __builtin_amdgcn_perm(sat_pk_u8(o), sat_pk_u8(e), 0x05010400u);
+}
+__device__ __forceinline__ uint32_t rotr32(uint32_t w, uint32_t n) { return __builtin_amdgcn_alignbit(w, w, n); }   // n < 32
 // product of the low 24 bits (v_mul_u32_u24, full rate; the compiler turns a plain 32-bit multiply whose low half alone is used into the
 // quarter-rate v_mul_lo_u32): the low 16 bits equal those of the full product, which is all the 16-bit coefficient arithmetic keeps
 __device__ __forceinline__ uint32_t mul_u24(uint32_t a, uint32_t b) { uint32_t r; asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
@@ -79,6 +90,8 @@ typedef uint32_t cfhd_u4 __attribute__((ext_vector_type(4)));
 typedef uint32_t cfhd_u2 __attribute__((ext_vector_type(2)));
 #define CFHD_LDG64(p) (*(const __attribute__((address_space(1))) cfhd_u2 *)(p))
 #define CFHD_LDG128(p) (*(const __attribute__((address_space(1))) cfhd_u4 *)(p))
+// ... and 16-byte stores through it (global_store_dwordx4 with a scalar base when the pointer's base is wave-uniform; a generic pointer gives flat_store)
+__device__ __forceinline__ void store_u32x4_global(void *at, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { cfhd_u4 v; v.x = a; v.y = b; v.z = c; v.w = d; *(__attribute__((address_space(1))) cfhd_u4 *)at = v; }
 
 // two consecutive dwords in one store (global_store_dwordx2) at an address that is only dword aligned: gfx950 serves unaligned vector accesses to global memory
 typedef uint32_t cfhd_u2_a4 __attribute__((ext_vector_type(2), aligned(4)));

@@ -271,7 +271,7 @@ __device__ __forceinline__ int quantize(int v, const QuantParam &q)
 	if (q.divisor <= 1) return v;
 	int neg = v < 0;
 	unsigned a = ((unsigned)(neg ? -v : v) + (unsigned)q.mid) & 0xffffu;
-	int r = (int)((a * q.mult) >> 16);
+	int r = (int)((a * (q.mult & 0xffffu)) >> 16);          // (mult < 2^16: cfhd_device.hip quant_param; said here, the product is the full-rate v_mul_u32_u24)
 	return (int)(int16_t)(neg ? -r : r);
 }
 
@@ -283,9 +283,15 @@ __device__ __forceinline__ uint32_t pk_quantize(uint32_t v, const QuantParam &q)
 	const uint32_t s = pk_sra(v, 15);
 	uint32_t a = pk_maxs(v, pk_negw(v));
 	a = pk_addw(a, pk_set(q.mid));
-	const uint32_t r = (((a & 0xffffu) * q.mult) >> 16) | (((a >> 16) * q.mult) & 0xffff0000u);
+	// both factors below 2^16, and said so: the compiler then multiplies with the full-rate v_mul_u32_u24 (halves selected by SDWA) instead of the quarter-rate
+	// v_mul_lo_u32, and one v_perm_b32 collects the two high halves -- three instructions for what took eight issue slots' worth of multiplies and four of masks
+	const uint32_t m = q.mult & 0xffffu;
+	const uint32_t r = pk_hihi((a & 0xffffu) * m, (a >> 16) * m);
 	return pk_addw(r ^ s, pk_negw(s));
 }
+
+// a quantizer every lane of the wave shares, moved to scalar registers: the `divisor <= 1` test becomes a scalar branch, mid and mult scalar operands
+__device__ __forceinline__ QuantParam wave_uniform_quant(const QuantParam &q) { QuantParam u; u.mid = wave_uniform(q.mid); u.mult = (unsigned)wave_uniform((int)q.mult); u.divisor = wave_uniform(q.divisor); return u; }
 
 // 2/6 analysis highpass, interior tap (SIMD association order, spatial.c:326-397 / :10301-10351)
 __device__ __forceinline__ int hp_mid(int a0, int a1, int a2, int a3, int a4, int a5)
@@ -730,6 +736,27 @@ __device__ __forceinline__ uint32_t dither_word(uint32_t seed, int row, int grou
 	return x;
 }
 
+// Dither bits of the 8-bit 4:2:2 outputs (the reference draws rand() & 1 per sample; which sample gets which bit of the hash is this library's choice, and it is made for the
+// strip kernels, where one lane converts the 16 samples of a block of 8 band columns): a group of 32 pixels of an output row = two luma blocks = one V and one U block owns
+// two hash words, word 2g for its luma blocks (the odd block takes the word rotated right by 8) and word 2g + 1 for its chroma blocks (V as it is, U rotated by 8).
+// Sample s = 4 d + k of a block (d = 0..3, k = 0..3) then reads bit 1 + d + 4 (k & 1) + 16 (k >> 1) of the block's word X, so that (X >> d) & 0x20002 is twice the dither
+// of the packed pair (s(4d), s(4d+2)) and (X >> (d + 4)) & 0x20002 that of (s(4d+1), s(4d+3)) -- the form pk_to8_bytes adds (cfhd_gfx950.h).
+__device__ __forceinline__ uint32_t dither422_block(uint32_t seed, int orow, int blk, int comp)      // comp: 0 luma block blk, 1 / 2 V / U block blk
+{
+	const uint32_t w = dither_word(seed, orow, comp == 0 ? (blk & ~1) : 2 * blk + 1);
+	return rotr32(w, (comp == 0 ? (blk & 1) != 0 : comp == 2) ? 8u : 0u);
+}
+__device__ __forceinline__ uint32_t dither422_bit(uint32_t X, int s) { return (X >> (1 + (s >> 2) + 4 * (s & 1) + 16 * ((s >> 1) & 1))) & 1u; }
+// The same bits for the kernels that convert one chroma band column cc (two V, two U samples) and its two luma columns (four samples) per item:
+// bit 0-3 = luma samples 4 cc .. 4 cc + 3, bit 4 / 6 = V samples 2 cc, 2 cc + 1, bit 5 / 7 = U samples 2 cc, 2 cc + 1.
+__device__ __forceinline__ uint32_t dither422_column(uint32_t seed, int orow, int cc)
+{
+	const uint32_t Xl = dither422_block(seed, orow, cc >> 2, 0), Xv = dither422_block(seed, orow, cc >> 3, 1), Xu = dither422_block(seed, orow, cc >> 3, 2);
+	const int sl = 4 * (cc & 3), sc = 2 * (cc & 7);
+	return dither422_bit(Xl, sl) | dither422_bit(Xl, sl + 1) << 1 | dither422_bit(Xl, sl + 2) << 2 | dither422_bit(Xl, sl + 3) << 3
+	     | dither422_bit(Xv, sc) << 4 | dither422_bit(Xu, sc) << 5 | dither422_bit(Xv, sc + 1) << 6 | dither422_bit(Xu, sc + 1) << 7;
+}
+
 // 12-bit component -> 16-bit output word of the 4:4:4(:4) formats; v = lowfilter +/- high before the >>1.  The vector columns of
 // InvertHorizontalStrip16sToRow16u clamp to `precision` bits and shift up (InvertHorizontalStrip16s.c:16596, :16724-16750); the
 // columns its scalar loop handles (band columns >= w - w%8 - 9, :16876-16990) shift first and saturate to 65535.
@@ -1095,7 +1122,7 @@ __device__ __forceinline__ void inv_yuv422_tile(const InvYuvJob *jobs, uint32_t 
 				*(uint4 *)(job.out + (size_t)out_row * job.out_pitch + 16 * (size_t)cc) = px;
 				continue;
 			}
-			const uint32_t dz = sh >= 2 ? dither_word(seed, orow, cc >> 2) >> (8 * (cc & 3)) : 0u;    // one hash word per 4 chroma columns, one byte each
+			const uint32_t dz = sh >= 2 ? dither422_column(seed, orow, cc) : 0u;    // one bit per sample of the item, the assignment of the strip kernels
 			// 8-bit samples in 16-bit lanes: te = (y0, y2), to = (y1, y3), tce = (v0, u0), tco = (v1, u1)
 			uint32_t te = pk_to8(ye, sh, (dz & 1u) | ((dz << 14) & 0x10000u)), to = pk_to8(yo, sh, ((dz >> 1) & 1u) | ((dz << 13) & 0x10000u));
 			uint32_t tce = pk_to8(ce, sh, ((dz >> 4) & 1u) | ((dz << 11) & 0x10000u)), tco = pk_to8(co, sh, ((dz >> 6) & 1u) | ((dz << 9) & 0x10000u));
@@ -1159,10 +1186,10 @@ struct StripRow { uint32_t d[4]; };                   // 8 band columns = 4 colu
 __device__ __forceinline__ StripRow strip_load(const int16_t *p) { const cfhd_u4 v = CFHD_LDG128(p); StripRow r; r.d[0] = v.x; r.d[1] = v.y; r.d[2] = v.z; r.d[3] = v.w; return r; }
 
 // Horizontal synthesis + 10 -> 8 bit of one output row of a block: L, H = the vertically synthesised low / high rows of the block,
-// prev / next = the neighbouring column pairs.  te[d], to[d] = 8-bit samples in 16-bit lanes: (s(4d), s(4d+2)), (s(4d+1), s(4d+3)).
-// dbits = one dither bit per sample, sample s of the block at bit s.
+// prev / next = the neighbouring column pairs.  out[d] = the 8-bit samples 4d .. 4d+3 of the block, bytes in sample order.
+// X = the block's dither word (dither422_block; 0 = no dither), sh1 = shift + 1.
 __device__ __forceinline__ void strip_row_to8(const uint32_t (&L)[4], const uint32_t (&H)[4], uint32_t prev, uint32_t next, bool first, bool last,
-                                              int sh, uint32_t dbits, uint32_t (&te)[4], uint32_t (&to)[4])
+                                              int sh1, uint32_t X, uint32_t (&out)[4])
 {
 	const uint32_t ext[6] = { prev, L[0], L[1], L[2], L[3], next };
 #pragma unroll
@@ -1170,21 +1197,19 @@ __device__ __forceinline__ void strip_row_to8(const uint32_t (&L)[4], const uint
 		const uint32_t dm = ext[d], d0 = ext[d + 1], dp = ext[d + 2];
 		uint32_t e, o;
 		inv_horiz_pk((dm >> 16) | (d0 << 16), d0, (d0 >> 16) | (dp << 16), H[d], e, o);
-		const uint32_t b = dbits >> (4 * d);
-		te[d] = pk_to8(e, sh, (b & 1u) | ((b << 14) & 0x10000u));
-		to[d] = pk_to8(o, sh, ((b >> 1) & 1u) | ((b << 13) & 0x10000u));
+		out[d] = pk_to8_bytes(e, o, sh1, (X >> d) & 0x20002u, (X >> (d + 4)) & 0x20002u);
 	}
 	if (first) {                                          // column 0 of the band: 32-bit border taps
 		const int l[6] = { 0, 0, lo16(L[0]), hi16(L[0]), lo16(L[1]), hi16(L[1]) };
 		int e, o;
 		inv_horiz_border(l, 2, lo16(H[0]), 0, e, o);
-		te[0] = (te[0] & 0xffff0000u) | to8(e, sh, (int)(dbits & 1u)); to[0] = (to[0] & 0xffff0000u) | to8(o, sh, (int)((dbits >> 1) & 1u));
+		out[0] = (out[0] & 0xffff0000u) | to8(e, sh1 - 1, (int)dither422_bit(X, 0)) | (to8(o, sh1 - 1, (int)dither422_bit(X, 1)) << 8);
 	}
 	if (last) {                                           // last column of the band
 		const int l[6] = { lo16(L[2]), hi16(L[2]), lo16(L[3]), hi16(L[3]), 0, 0 };
 		int e, o;
 		inv_horiz_border(l, 3, hi16(H[3]), 2, e, o);
-		te[3] = (te[3] & 0xffffu) | (to8(e, sh, (int)((dbits >> 14) & 1u)) << 16); to[3] = (to[3] & 0xffffu) | (to8(o, sh, (int)((dbits >> 15) & 1u)) << 16);
+		out[3] = (out[3] & 0xffffu) | (to8(e, sh1 - 1, (int)dither422_bit(X, 14)) << 16) | (to8(o, sh1 - 1, (int)dither422_bit(X, 15)) << 24);
 	}
 }
 
@@ -1253,6 +1278,11 @@ __device__ __forceinline__ void inv_yuv422_strip(const InvYuvJob *jobs, uint32_t
 	StripRow lh0 = LOAD_LH(j), lh1 = LOAD_LH(j + 1), lh2 = LOAD_LH(j + 2);
 	StripRow hl = LOAD_HL(r0), hh = LOAD_HH(r0);
 	const int sh = job.shift;
+	// what the interleave stage reads of the job, in scalar registers (the job lies in LDS: every use behind a barrier would be another ds_read)
+	uint8_t *const out_base = wave_uniform_ptr(job.out);
+	const int out_pitch = wave_uniform(job.out_pitch), display_height = wave_uniform(job.display_height), uyvy = wave_uniform(job.uyvy);
+	const int dgroup = luma ? (blk & ~1) : 2 * blk + 1;          // dither422_block: the hash word of the lane's block and its rotation
+	const uint32_t drot = (luma ? (blk & 1) != 0 : comp == 2) ? 8u : 0u;
 	for (int s = 0; s < nrows; s++) {
 		const int r = r0 + s;
 		// loads of the next band row go out before this row's arithmetic
@@ -1267,10 +1297,18 @@ __device__ __forceinline__ void inv_yuv422_strip(const InvYuvJob *jobs, uint32_t
 		// vertical synthesis: rows 2r (even) and 2r + 1 (odd) of the horizontal-low and horizontal-high halves
 		const int pos = r == 0 ? 0 : (r == h - 1 ? 2 : 1);
 		uint32_t Lv[2][4], Hv[2][4];
+		if (pos == 1) {                                       // (one branch for the row, so that the eight packed bodies schedule as one block)
 #pragma unroll
-		for (int d = 0; d < 4; d++) {
-			inv_vert_pk(ll0.d[d], ll1.d[d], ll2.d[d], hl.d[d], pos, Lv[0][d], Lv[1][d]);
-			inv_vert_pk(lh0.d[d], lh1.d[d], lh2.d[d], hh.d[d], pos, Hv[0][d], Hv[1][d]);
+			for (int d = 0; d < 4; d++) {
+				inv_vert_pk(ll0.d[d], ll1.d[d], ll2.d[d], hl.d[d], 1, Lv[0][d], Lv[1][d]);
+				inv_vert_pk(lh0.d[d], lh1.d[d], lh2.d[d], hh.d[d], 1, Hv[0][d], Hv[1][d]);
+			}
+		} else {
+#pragma unroll
+			for (int d = 0; d < 4; d++) {
+				inv_vert_pk(ll0.d[d], ll1.d[d], ll2.d[d], hl.d[d], pos, Lv[0][d], Lv[1][d]);
+				inv_vert_pk(lh0.d[d], lh1.d[d], lh2.d[d], hh.d[d], pos, Hv[0][d], Hv[1][d]);
+			}
 		}
 		// every lane leaves the 16 8-bit samples of its block in LDS (bytes in sample order), luma and chroma alike ...
 		uint32_t (*rowbuf)[SROW / 4] = s_rows[s & 1];
@@ -1278,31 +1316,15 @@ __device__ __forceinline__ void inv_yuv422_strip(const InvYuvJob *jobs, uint32_t
 		for (int par = 0; par < 2; par++) {
 			const int orow = 2 * r + par;
 			const uint32_t prev = __shfl(Lv[par][3], lane - 1), next = __shfl(Lv[par][0], lane + 1);
-			// dither bits: one hash word per (output row, group of 16 luma samples = 4 chroma columns); byte j of it belongs to chroma
-			// column 4g + j: bits 0-3 its four luma samples, 4 / 6 its two V samples, 5 / 7 its two U samples
-			uint32_t dbits = 0;
-			if (sh >= 2) {
-				if (luma) {
-					const uint32_t z = dither_word(seed, orow, blk);
-					dbits = (z & 0xfu) | ((z >> 4) & 0xf0u) | ((z >> 8) & 0xf00u) | ((z >> 12) & 0xf000u);
-				} else {
-					const uint32_t z0 = dither_word(seed, orow, 2 * blk), z1 = dither_word(seed, orow, 2 * blk + 1);
-					const int b0 = comp == 1 ? 4 : 5;             // even sample of a column at bit b0, odd sample at b0 + 2 of the column's byte
-#pragma unroll
-					for (int c = 0; c < 8; c++) {                 // chroma column c of the block -> samples 2c, 2c + 1
-						const uint32_t byte = ((c < 4 ? z0 : z1) >> (8 * (c & 3))) & 0xffu;
-						// strip_row_to8 expects sample s of the block at bit s
-						dbits |= ((byte >> b0) & 1u) << (2 * c) | ((byte >> (b0 + 2)) & 1u) << (2 * c + 1);
-					}
-				}
-			}
-			uint32_t te[4], to[4];
-			strip_row_to8(Lv[par], Hv[par], prev, next, first, last, sh, dbits, te, to);
+			// dither bits: the block's word of the output row (dither422_block)
+			const uint32_t X = sh >= 2 ? rotr32(dither_word(seed, orow, dgroup), drot) : 0u;
+			uint32_t out[4];
+			strip_row_to8(Lv[par], Hv[par], prev, next, first, last, sh + 1, X, out);
 			if (stores) {
-				// bytes in sample order: (s(4d), s(4d+1), s(4d+2), s(4d+3)) = te | to << 8; row layout: Y samples | V samples | U samples
+				// row layout: Y samples | V samples | U samples
 				uint32_t *dst = &rowbuf[par][lds_at];
 #pragma unroll
-				for (int d = 0; d < 4; d++) dst[d] = te[d] | (to[d] << 8);
+				for (int d = 0; d < 4; d++) dst[d] = out[d];
 			}
 		}
 		__syncthreads();
@@ -1311,20 +1333,20 @@ __device__ __forceinline__ void inv_yuv422_strip(const InvYuvJob *jobs, uint32_t
 #pragma unroll
 			for (int par = 0; par < 2; par++) {
 				const int orow = 2 * r + par;
-				if (orow >= job.display_height) continue;
+				if (orow >= display_height) continue;
 				const uint32_t *row = rowbuf[par];
 				const uint32_t y0 = row[2 * tid], y1 = row[2 * tid + 1], vv = row[v_base + tid], uu = row[u_base + tid];
 				// (u0, v0, u1, v1) and (u2, v2, u3, v3), then y(2m), u(m), y(2m+1), v(m) -- or u, y, v, y for UYVY
 				const uint32_t uv01 = byte_perm(vv, uu, 0x05010400u), uv23 = byte_perm(vv, uu, 0x07030602u);
 				uint4 q;
-				if (job.uyvy) {
+				if (uyvy) {
 					q.x = byte_perm(uv01, y0, 0x01050004u); q.y = byte_perm(uv01, y0, 0x03070206u);
 					q.z = byte_perm(uv23, y1, 0x01050004u); q.w = byte_perm(uv23, y1, 0x03070206u);
 				} else {
 					q.x = byte_perm(uv01, y0, 0x05010400u); q.y = byte_perm(uv01, y0, 0x07030602u);
 					q.z = byte_perm(uv23, y1, 0x05010400u); q.w = byte_perm(uv23, y1, 0x07030602u);
 				}
-				*(uint4 *)(job.out + (size_t)orow * job.out_pitch + 32 * (size_t)seg_first + 16 * (size_t)tid) = q;
+				*(uint4 *)(out_base + (size_t)orow * out_pitch + 32 * (size_t)seg_first + 16 * (size_t)tid) = q;
 			}
 		}
 		if (LATE_LOADS) {
@@ -1445,7 +1467,7 @@ __device__ __forceinline__ void fwd_yuv422_strip(const FwdYuvJob *jobs)
 	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 	const bool luma = wave < 2;
 	const int comp = luma ? 0 : wave - 1;                 // 0 Y, 1 V, 2 U
-	const QuantParam q_lh = job.q[comp][1], q_hl = job.q[comp][2], q_hh = job.q[comp][3];
+	const QuantParam q_lh = wave_uniform_quant(job.q[comp][1]), q_hl = wave_uniform_quant(job.q[comp][2]), q_hh = wave_uniform_quant(job.q[comp][3]);      // (a wave = one component)
 	const int nblk = luma ? W / 16 : W / 32;              // blocks of 8 band columns
 	// segments and lanes as in k_inv_yuv422_strip: lane l of a wave holds block base - 1 + l, lanes 1..62 store
 	const int seg_first = tile.x * SSEG;
@@ -1468,11 +1490,14 @@ __device__ __forceinline__ void fwd_yuv422_strip(const FwdYuvJob *jobs)
 	const uint8_t *in = job.in + 32 * (size_t)blk;
 	// block lists: this wave's chunk of every band row = the blocks its lanes 1 .. SLUMA_STEP store (chunk `base / FWD_CHUNK_BLOCKS` of the row)
 	static_assert(SLUMA_STEP == FWD_CHUNK_BLOCKS, "a chunk is what one wave stores of a band row");
-	const int chunks_per_row = BLOCKS ? (nblk + FWD_CHUNK_BLOCKS - 1) / FWD_CHUNK_BLOCKS : 0, chunk = BLOCKS ? base / FWD_CHUNK_BLOCKS : 0;
+	const int chunks_per_row = BLOCKS ? wave_uniform((nblk + FWD_CHUNK_BLOCKS - 1) / FWD_CHUNK_BLOCKS) : 0, chunk = BLOCKS ? wave_uniform(base / FWD_CHUNK_BLOCKS) : 0;
 	// per band, wave-uniform (scalar registers; hoisted: the barrier inside the row loop keeps the compiler from keeping LDS job fields across rows): the slot of the
 	// chunk's first block in band row 0 and the chunk's mask in band row 0
 	uint4 *slot0[3]; unsigned long long *mask0[3];
-	const int pitch8 = wave_uniform(job.out_pitch[comp] >> 3);
+	const int opitch = wave_uniform(job.out_pitch[comp]), pitch8 = opitch >> 3;
+	int16_t *outp[4];                                     // the dense rows: scalar bases, the lane's block as a 32-bit offset
+#pragma unroll
+	for (int b = 0; b < 4; b++) outp[b] = wave_uniform_ptr(job.out[comp][b]);
 	if (BLOCKS) {
 #pragma unroll
 		for (int b = 1; b < 4; b++) {
@@ -1535,7 +1560,7 @@ __device__ __forceinline__ void fwd_yuv422_strip(const FwdYuvJob *jobs)
 				const bool nz = stores && (o[b][0] | o[b][1] | o[b][2] | o[b][3]) != 0u;
 				const unsigned long long m = __ballot(nz);
 				uint4 *rowslots = wave_uniform_ptr(slot0[b - 1] + (size_t)(r * pitch8));      // (scalar base + one 32-bit lane offset)
-				if (nz) { uint4 v; v.x = o[b][0]; v.y = o[b][1]; v.z = o[b][2]; v.w = o[b][3]; rowslots[wave_mbcnt(m)] = v; }      // (lane 0 never stores: the rank among lanes 1 ..)
+				if (nz) store_u32x4_global(rowslots + wave_mbcnt(m), o[b][0], o[b][1], o[b][2], o[b][3]);      // (lane 0 never stores: the rank among lanes 1 ..)
 				if (lane == 0 && chunk < chunks_per_row) mask0[b - 1][r * chunks_per_row] = m >> 1;       // bit i: block i of the chunk (lane i + 1); a wave beyond the last block of the row has no chunk
 			}
 		}
@@ -1543,8 +1568,7 @@ __device__ __forceinline__ void fwd_yuv422_strip(const FwdYuvJob *jobs)
 #pragma unroll
 			for (int b = 0; b < 4; b++) {
 				if (b && BLOCKS && !DENSE) continue;
-				uint4 v; v.x = o[b][0]; v.y = o[b][1]; v.z = o[b][2]; v.w = o[b][3];
-				*(uint4 *)(job.out[comp][b] + (size_t)r * job.out_pitch[comp] + SBLK * blk) = v;
+				store_u32x4_global(outp[b] + (uint32_t)(r * opitch + SBLK * blk), o[b][0], o[b][1], o[b][2], o[b][3]);
 			}
 		}
 	}
@@ -1617,10 +1641,18 @@ __global__ void __launch_bounds__(NTHREADS) k_inv_plane_strip(const InvPlaneJob 
 		StripRow nll = ll2, nlh = lh2, nhl = hl, nhh = hh;
 		const int pos = r == 0 ? 0 : (r == h - 1 ? 2 : 1);
 		uint32_t Lv[2][4], Hv[2][4];
+		if (pos == 1) {                                       // (one branch for the row, as in k_inv_yuv422_strip)
 #pragma unroll
-		for (int d = 0; d < 4; d++) {
-			inv_vert_pk(ll0.d[d], ll1.d[d], ll2.d[d], hl.d[d], pos, Lv[0][d], Lv[1][d]);
-			inv_vert_pk(lh0.d[d], lh1.d[d], lh2.d[d], hh.d[d], pos, Hv[0][d], Hv[1][d]);
+			for (int d = 0; d < 4; d++) {
+				inv_vert_pk(ll0.d[d], ll1.d[d], ll2.d[d], hl.d[d], 1, Lv[0][d], Lv[1][d]);
+				inv_vert_pk(lh0.d[d], lh1.d[d], lh2.d[d], hh.d[d], 1, Hv[0][d], Hv[1][d]);
+			}
+		} else {
+#pragma unroll
+			for (int d = 0; d < 4; d++) {
+				inv_vert_pk(ll0.d[d], ll1.d[d], ll2.d[d], hl.d[d], pos, Lv[0][d], Lv[1][d]);
+				inv_vert_pk(lh0.d[d], lh1.d[d], lh2.d[d], hh.d[d], pos, Hv[0][d], Hv[1][d]);
+			}
 		}
 #pragma unroll
 		for (int par = 0; par < 2; par++) {
@@ -2356,6 +2388,8 @@ __device__ __forceinline__ void inv_frame_yuv422_strip(const InvYuvJob *jobs, ui
 	if (r0 >= h) return;                                  // whole workgroup
 	const int nrows = h - r0 < SRI ? h - r0 : SRI;
 	const int sh = job.shift;
+	const int dgroup = luma ? (blk & ~1) : 2 * blk + 1;          // dither422_block
+	const uint32_t drot = (luma ? (blk & 1) != 0 : comp == 2) ? 8u : 0u;
 	for (int s = 0; s < nrows; s++) {
 		const int r = r0 + s;
 		// (BLOCKS: LH and HH arrive as block lists from the entropy decoder's tile pass, as in k_inv_yuv422_strip_blocks; HL, the difference-coded band, is dense)
@@ -2371,30 +2405,14 @@ __device__ __forceinline__ void inv_frame_yuv422_strip(const InvYuvJob *jobs, ui
 #pragma unroll
 		for (int par = 0; par < 2; par++) {
 			const int orow = 2 * r + par;
-			// dither bits: as k_inv_yuv422_strip (one hash word per output row and group of 16 luma samples)
-			uint32_t dbits = 0;
-			if (sh >= 2) {
-				if (luma) {
-					const uint32_t z = dither_word(seed, orow, blk);
-					dbits = (z & 0xfu) | ((z >> 4) & 0xf0u) | ((z >> 8) & 0xf00u) | ((z >> 12) & 0xf000u);
-				} else {
-					const uint32_t z0 = dither_word(seed, orow, 2 * blk), z1 = dither_word(seed, orow, 2 * blk + 1);
-					const int b0 = comp == 1 ? 4 : 5;
-#pragma unroll
-					for (int c = 0; c < 8; c++) {
-						const uint32_t byte = ((c < 4 ? z0 : z1) >> (8 * (c & 3))) & 0xffu;
-						dbits |= ((byte >> b0) & 1u) << (2 * c) | ((byte >> (b0 + 2)) & 1u) << (2 * c + 1);
-					}
-				}
-			}
+			// dither bits: as k_inv_yuv422_strip (dither422_block)
+			const uint32_t X = sh >= 2 ? rotr32(dither_word(seed, orow, dgroup), drot) : 0u;
 			if (stores) {
 				uint32_t *dst = &rowbuf[par][lds_at];
 #pragma unroll
 				for (int d = 0; d < 4; d++) {
 					const uint32_t e = par ? pk_adds(El[d], Eh[d]) : pk_subs(El[d], Eh[d]), o = par ? pk_adds(Ol[d], Oh[d]) : pk_subs(Ol[d], Oh[d]);
-					const uint32_t b = dbits >> (4 * d);
-					const uint32_t te = pk_to8(e, sh, (b & 1u) | ((b << 14) & 0x10000u)), to = pk_to8(o, sh, ((b >> 1) & 1u) | ((b << 13) & 0x10000u));
-					dst[d] = te | (to << 8);
+					dst[d] = pk_to8_bytes(e, o, sh + 1, (X >> d) & 0x20002u, (X >> (d + 4)) & 0x20002u);
 				}
 			}
 		}
@@ -2444,7 +2462,7 @@ __global__ void __launch_bounds__(NTHREADS) k_fwd_frame_yuv422_strip(const FwdFr
 	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 	const bool luma = wave < 2;
 	const int comp = luma ? 0 : wave - 1;                 // 0 Y, 1 V, 2 U
-	const QuantParam q_lh = job.q[comp][1], q_hl = job.q[comp][2], q_hh = job.q[comp][3];
+	const QuantParam q_lh = wave_uniform_quant(job.q[comp][1]), q_hl = wave_uniform_quant(job.q[comp][2]), q_hh = wave_uniform_quant(job.q[comp][3]);      // (a wave = one component)
 	const int nblk = luma ? W / 16 : W / 32;              // blocks of 8 band columns
 	const int seg_first = tile.x * SSEG;
 	const int base = luma ? seg_first + SLUMA_STEP * wave : seg_first >> 1;
@@ -2573,12 +2591,12 @@ __global__ void __launch_bounds__(NTHREADS) k_inv_frame_yuv422(const InvYuvJob *
 	for (int par = 0; par < 2; par++) {
 		const int orow = 2 * r + par;
 		if (orow >= job.display_height) continue;
-		const uint32_t dz = sh >= 2 ? dither_word(seed, orow, cc >> 2) >> (8 * (cc & 3)) : 0u;      // same bit assignment as the progressive kernels
+		const uint32_t dz = sh >= 2 ? dither422_column(seed, orow, cc) : 0u;      // same bit assignment as the progressive kernels
 		uint32_t b[8];
 #pragma unroll
 		for (int i = 0; i < 8; i++) {
 			const int v = par ? adds16(tl[i], th[i]) : subs16(tl[i], th[i]);
-			b[i] = to8(v, sh, (int)((dz >> i) & 1u));     // the temporal lowpass is the sum of the two rows: clamp at zero, halve, dither, >> shift, saturate (temporal.c:6071-6120)
+			b[i] = to8(v, sh, (int)((dz >> (i == 5 ? 6 : (i == 6 ? 5 : i))) & 1u));     // (b[] holds v0, v1, u0, u1 behind the luma samples, the dither byte v0, u0, v1, u1); the temporal lowpass is the sum of the two rows: clamp at zero, halve, dither, >> shift, saturate (temporal.c:6071-6120)
 		}
 		const uint32_t y0 = b[0], y1 = b[1], y2 = b[2], y3 = b[3], v0 = b[4], v1 = b[5], u0 = b[6], u1 = b[7];
 		uint2 o2;
@@ -2671,14 +2689,14 @@ __global__ void __launch_bounds__(NTHREADS) k_inv_frame_yuv422_quad(const InvYuv
 #pragma unroll
 		for (int half = 0; half < 2; half++) {                 // chroma column cc + half: the bits the one-column kernel uses for it
 			const int ccol = cc + half;
-			const uint32_t dz = sh >= 2 ? dither_word(seed, orow, ccol >> 2) >> (8 * (ccol & 3)) : 0u;
+			const uint32_t dz = sh >= 2 ? dither422_column(seed, orow, ccol) : 0u;
 			uint32_t b[8];
 #pragma unroll
 			for (int i = 0; i < 8; i++) {
 				// sample order of the one-column kernel: four luma (columns 2 ccol, 2 ccol + 1: even, odd each), two V, two U
 				const int idx = i < 4 ? 4 * half + i : (i < 6 ? 8 + 2 * half + (i - 4) : 12 + 2 * half + (i - 6));
 				const int v = par ? adds16(tl[idx], th[idx]) : subs16(tl[idx], th[idx]);
-				b[i] = to8(v, sh, (int)((dz >> i) & 1u));
+				b[i] = to8(v, sh, (int)((dz >> (i == 5 ? 6 : (i == 6 ? 5 : i))) & 1u));
 			}
 			const uint32_t y0 = b[0], y1 = b[1], y2 = b[2], y3 = b[3], v0 = b[4], v1 = b[5], u0 = b[6], u1 = b[7];
 			if (job.uyvy) { words[2 * half] = u0 | (y0 << 8) | (v0 << 16) | (y1 << 24); words[2 * half + 1] = u1 | (y2 << 8) | (v1 << 16) | (y3 << 24); }

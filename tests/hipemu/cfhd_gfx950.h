@@ -41,6 +41,13 @@ inline uint32_t pk_mulw(uint32_t a, uint32_t b) { return ((a & 0xffffu) * (b & 0
 inline uint32_t pk_negw(uint32_t a) { using namespace emu16; return pack(-lo(a), -hi(a)); }
 inline uint32_t pk_maxs(uint32_t a, uint32_t b) { using namespace emu16; return pack(lo(a) > lo(b) ? lo(a) : lo(b), hi(a) > hi(b) ? hi(a) : hi(b)); }
 inline uint32_t pk_to8(uint32_t v, int shift, uint32_t dither) { using namespace emu16; return to8(lo(v), shift, (int)(dither & 1u)) | (to8(hi(v), shift, (int)((dither >> 16) & 1u)) << 16); }
+inline uint32_t pk_to8_bytes(uint32_t e, uint32_t o, int shift1, uint32_t d2e, uint32_t d2o)
+{
+	using namespace emu16;
+	const int s = shift1 - 1;
+	return to8(lo(e), s, (int)((d2e >> 1) & 1u)) | (to8(lo(o), s, (int)((d2o >> 1) & 1u)) << 8) | (to8(hi(e), s, (int)((d2e >> 17) & 1u)) << 16) | (to8(hi(o), s, (int)((d2o >> 17) & 1u)) << 24);
+}
+inline uint32_t rotr32(uint32_t w, uint32_t n) { n &= 31u; return n ? (w >> n) | (w << (32u - n)) : w; }
 inline uint32_t mul_u24(uint32_t a, uint32_t b) { return (a & 0xffffffu) * (b & 0xffffffu); }
 inline uint32_t byte_perm(uint32_t s0, uint32_t s1, uint32_t sel)
 {
@@ -58,6 +65,7 @@ typedef emu_u2 cfhd_u2;
 #define CFHD_LDG64(p) (*(const cfhd::dev::cfhd_u2 *)(p))
 #define CFHD_LDG128(p) (*(const cfhd::dev::cfhd_u4 *)(p))
 inline void store_u32x2_dword_aligned(uint32_t *at, uint32_t a, uint32_t b) { at[0] = a; at[1] = b; }
+inline void store_u32x4_global(void *at, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { uint32_t *p = (uint32_t *)at; p[0] = a; p[1] = b; p[2] = c; p[3] = d; }
 
 } // namespace dev
 } // namespace cfhd
