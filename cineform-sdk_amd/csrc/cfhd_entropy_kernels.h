@@ -789,6 +789,8 @@ __device__ __forceinline__ void ent_emit_segment(const EntSegState &st, const En
 // the first is worked on.  (Round 3's probes: with one segment per wave and the chain segment job -> band state / neighbour states in front of the first
 // useful instruction, that front was 0.58 of this kernel's 1.65 ms; 0.41 with the single round of loads; two segments per wave: front 0.36 but the kernel
 // 1.62 instead of 1.56 -- the second segment waits for the first.  Kept at 1.)
+// (Round 6: resident waves that walk through the segments with the next segment's loads in flight take the same 1.4 ms -- the kernel is bound by the issue of its
+// ~345 mostly scalar instructions per segment, SQ_ACTIVE_INST_ANY = 1.04 per SIMD, not by the latency in front of them: profiles/r06_r_k_ent_emit_as_resident_waves_not_adopted.txt.)
 enum { ENT_EMIT_SEGS = 1 };
 __global__ void __launch_bounds__(ENT_THREADS) k_ent_emit(int total_segs, const EntSegState *segs, const EntTables *tables, const uint32_t *tokens,
                                                            int probe = 0 /* timing experiments: 1 leave at once, 2 behind the descriptor loads, 3 without the final stores, 4 plain stores for the shared words, 5 no plain stores */)

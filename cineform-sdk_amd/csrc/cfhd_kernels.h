@@ -1512,19 +1512,9 @@ __device__ __forceinline__ void fwd_yuv422_strip(const FwdYuvJob *jobs)
 #define CFHD_PUSH(SLOT, Y) strip_fwd_push<SLOT>(st, job, in, s_pairs[t & 1], (Y), (Y) + 2 <= lastrow, luma, comp, lds_write_at, lds_read_at, lane, first, last, shift, ysh0, usel, vsel); t++
 	if (luma && FWD_LATE_LOADS != 2) strip_fwd_fetch(st, job, in, wtop);
 	CFHD_PUSH(0, wtop); CFHD_PUSH(2, wtop + 2); CFHD_PUSH(4, wtop + 4);
-	for (int r = r0; r < r1; r++) {
-		const int need = window_first_row(r, HH, H);
-		if (need != wtop) {                               // the window moves down by two picture rows
-#pragma unroll
-			for (int k = 0; k < 4; k++) {
-#pragma unroll
-				for (int d = 0; d < 4; d++) { st.LW[k][d] = st.LW[k + 2][d]; st.HW[k][d] = st.HW[k + 2][d]; }
-			}
-			wtop = need;
-			CFHD_PUSH(4, wtop + 4);
-		}
+	// One band row: vertical analysis + quantizer of row r from the window, then the stores.
+	auto band_row = [&](const int r, const int pos) {
 		// vertical analysis + quantizer of band row r
-		const int pos = r == 0 ? 0 : (r == HH - 1 ? 2 : 1);
 		uint32_t o[4][4];
 #pragma unroll
 		for (int d = 0; d < 4; d++) {
@@ -1571,7 +1561,30 @@ __device__ __forceinline__ void fwd_yuv422_strip(const FwdYuvJob *jobs)
 				store_u32x4_global(outp[b] + (uint32_t)(r * opitch + SBLK * blk), o[b][0], o[b][1], o[b][2], o[b][3]);
 			}
 		}
-	}
+	};
+	auto window_down = [&]() {                               // the window moves down by two picture rows
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+#pragma unroll
+			for (int d = 0; d < 4; d++) { st.LW[k][d] = st.LW[k + 2][d]; st.HW[k][d] = st.HW[k + 2][d]; }
+		}
+	};
+	auto any_row = [&](const int r) {
+		const int need = window_first_row(r, HH, H);
+		if (need != wtop) { window_down(); wtop = need; CFHD_PUSH(4, wtop + 4); }
+		band_row(r, r == 0 ? 0 : (r == HH - 1 ? 2 : 1));
+	};
+	// Rows 2 .. HH - 2 behind the strip's first: the window moves with every row and the taps are the interior ones.  Unrolled by three, the six window rows come
+	// back to the registers they started in, so the moves of window_down() are names, not instructions (they were 64 v_mov_b32 per band row, an eighth of the kernel).
+	int r = r0;
+	for (; r < r1 && (r == r0 || r < 2); r++) any_row(r);
+	const int mid_end = r1 < HH - 1 ? r1 : HH - 1;
+	// (written out: the compiler does not unroll a loop around a barrier by itself when the trip count is not a known multiple)
+#define CFHD_MID_ROW(R) window_down(); wtop += 2; CFHD_PUSH(4, wtop + 4); band_row((R), 1)
+	for (; r + 3 <= mid_end; r += 3) { CFHD_MID_ROW(r); CFHD_MID_ROW(r + 1); CFHD_MID_ROW(r + 2); }
+	for (; r < mid_end; r++) { CFHD_MID_ROW(r); }
+#undef CFHD_MID_ROW
+	for (; r < r1; r++) any_row(r);
 #undef CFHD_PUSH
 }
 __global__ void __launch_bounds__(NTHREADS) k_fwd_yuv422_strip(const FwdYuvJob *jobs) { fwd_yuv422_strip<SRF>(jobs); }
