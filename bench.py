@@ -328,7 +328,7 @@ def measure(workload, steps, warmup, batch, unique, threads, rank, world, barrie
     INV1, PI2, PI3 = (kname(3), kname(4) + "[L2]", kname(5) + "[L3]") if wl["mode"] == 0 else ("", "", "")
     TILES = "k_dec_tiles+k_dec_undiff" if wl["flags"] & 1 else "k_dec_tiles"
     old_dec = os.environ.get("CFHD_AMD_DEC") in ("par", "lane")
-    DEC = [("k_dec_bands_par", 13)] if old_dec else [("k_dec_plan+k_dec_index", 15), ("k_dec_chain", 16), (TILES, 17)]
+    DEC = [("k_dec_bands_par", 13)] if old_dec else [("k_dec_plan", 19), ("k_dec_index", 15), ("k_dec_chain", 16), (TILES, 17)]
     # the level-1 bands are counted on a second stream while levels 2 and 3 are transformed -- from the block lists the forward strip kernel leaves (k_ent_count_blocks)
     # where it runs, else from the dense bands (k_ent_count)
     COUNT1 = ("k_ent_count_blocks" if FWD1.endswith("_blocks") else "k_ent_count") + "[L1 bands, beside the L2 / L3 transforms]"
@@ -414,7 +414,7 @@ def measure(workload, steps, warmup, batch, unique, threads, rank, world, barrie
         if wl["mode"] == 0:
             algo.update({PI3: S // 4, PI2: S, INV1: 2 * S + P})
             if old_dec: algo["k_dec_bands_par"] = sample_bytes + coded
-            else: algo.update({"k_dec_plan+k_dec_index": sample_bytes, TILES: sample_bytes + coded})
+            else: algo.update({"k_dec_index": sample_bytes, TILES: sample_bytes + coded})
         # the dominant kernel = the longest single launch of the step.  (The level-1 count is up to three launches on a second stream beside the transforms of levels 2 and 3: the
         # events around them time that sharing, and each of the launches is shorter than the longest launch of the step -- profiles/: rocprofv3 averages --; it is reported
         # among other_kernels_gbs with the time it takes as run.)

@@ -425,8 +425,8 @@ long long cfhd_amd_batch_wait(cfhd_amd_batch *b)
 
 // which: 0..2 forward level launches (0 = k_fwd_yuv422), 3..5 inverse level launches (3 = k_inv_yuv422), 6 forward total, 7 inverse total,
 // 8..11 k_ent_count / k_ent_scan / k_ent_layout / k_ent_emit, 12..14 k_dec_parse / band decoder (all its kernels) / k_dec_lowpass,
-// 15..17 k_dec_plan + k_dec_index / k_dec_chain / k_dec_tiles, 18 the level-1 part of k_ent_count on its own stream (then 8 is the rest of it; 0 when the count is one
-// launch) (ms, HIP events on the launch streams)
+// 15..17 k_dec_index / k_dec_chain / k_dec_tiles, 18 the level-1 part of k_ent_count on its own stream (then 8 is the rest of it; 0 when the count is one
+// launch), 19 k_dec_plan (the single workgroup that numbers the chunks in front of k_dec_index) (ms, HIP events on the launch streams)
 float cfhd_amd_batch_kernel_ms(cfhd_amd_batch *b, int which)
 {
 	if (!b || b->in_flight) return 0;
@@ -438,6 +438,7 @@ float cfhd_amd_batch_kernel_ms(cfhd_amd_batch *b, int which)
 		else if (which >= 8 && which < 12) ms += b->gpu_entropy ? c->enc.entropy().kernel_ms(which - 8) : 0.0f;
 		else if (which >= 12 && which < 18) ms += b->gpu_entropy ? c->dec.entropy().kernel_ms(which - 12) : 0.0f;
 		else if (which == 18) ms += b->gpu_entropy ? c->enc.entropy().kernel_ms(4) : 0.0f;
+		else if (which == 19) ms += b->gpu_entropy ? c->dec.entropy().kernel_ms(6) : 0.0f;
 		else ms += which == 6 ? c->enc.last_kernel_ms() : c->dec.last_kernel_ms();
 	}
 	return ms;

@@ -157,7 +157,7 @@ private:
 	int device_ = 0;                       // the GPU prepare() ran on: every launch selects it for the calling thread
 	int launch_dx(bool device_jobs, int njobs, uint32_t host_chunks, int lowpass_jobs);
 	void *ev_l23_ = nullptr, *ev_low_ = nullptr; bool l23_split_ = false;      // ev_low_: in front of k_dec_lowpass when it runs between the two tile passes      // recorded behind the tiles of the level-2 / level-3 bands and the lowpass bands when the tile pass is split
-	void *ev_[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; bool timed_ = false;    // [4]: end of k_dec_parse when the band decoder waits for a second event behind it; [5], [6]: behind k_dec_index / k_dec_chain
+	void *ev_[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; bool timed_ = false;    // [4]: end of k_dec_parse when the band decoder waits for a second event behind it; [5], [6]: behind k_dec_index / k_dec_chain; [7]: behind k_dec_plan (in front of k_dec_index)
 	bool parse_end_ = false;
 	unsigned long long *d_masks_ = nullptr; size_t masks_per_frame_ = 0; bool use_blocks_ = false, blocks_written_ = false;
 };

@@ -558,6 +558,7 @@ int GpuEntropyDecoder::launch_dx(bool device_jobs, int njobs, uint32_t host_chun
 		dev::k_dec_plan<<<1, 1024, 0, st>>>(jobs, njobs, max_chunks_, (uint32_t *)d_counters_, d_errors_);
 		dev::k_dec_plan_fill<<<(njobs + dev::DX_WAVES - 1) / dev::DX_WAVES, dev::DX_THREADS, 0, st>>>(jobs, njobs, (dev::DxChunkDesc *)d_chunk_job_, (const uint32_t *)d_counters_);
 	}
+	HIPCHK(hipEventRecord((hipEvent_t)ev_[7], st));         // (k_dec_index is timed by itself: kernel_ms(3); the plan in front of it: kernel_ms(6))
 	// grid-stride kernels: as many workgroups as the chip holds at once, fewer when there is less work
 	const uint32_t chunk_bound = device_jobs ? max_chunks_ : host_chunks;
 	int g1 = grid_index_, g3 = grid_tiles_;
@@ -629,8 +630,9 @@ float GpuEntropyDecoder::kernel_ms(int k)
 {
 	float ms = 0;
 	if (k >= 3) {                                                // the chunk-indexed decoder's own kernels
-		if (!timed_ || !dx_ || k > 5) return 0;
-		void *a = k == 3 ? ev_[1] : (k == 4 ? ev_[5] : ev_[6]), *b = k == 3 ? ev_[5] : (k == 4 ? ev_[6] : ev_[2]);
+		if (!timed_ || !dx_ || k > 6) return 0;
+		// 3: k_dec_index, 4: k_dec_chain (+ repair, reindex, tile index), 5: k_dec_tiles, 6: k_dec_plan + k_dec_plan_fill (one workgroup that numbers the chunks: latency, not work)
+		void *a = k == 3 ? ev_[7] : (k == 4 ? ev_[5] : (k == 5 ? ev_[6] : ev_[1])), *b = k == 3 ? ev_[5] : (k == 4 ? ev_[6] : (k == 5 ? ev_[2] : ev_[7]));
 		if (hipEventElapsedTime(&ms, (hipEvent_t)a, (hipEvent_t)b) != hipSuccess) { (void)hipGetLastError(); return 0; }
 		if (k == 5 && l23_split_) {                          // k_dec_lowpass ran between the two tile passes: not part of k_dec_tiles
 			float low = 0;
