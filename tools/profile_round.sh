@@ -15,9 +15,9 @@ rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o bench -- python $ROOT/bench.py "$@" 
 T=$(find $OUT/trace -name '*.db' | head -1); F=$(find $OUT/fetch -name '*.db' | head -1); W=$(find $OUT/write -name '*.db' | head -1)
 {
   echo "# python bench.py $* (plain run, then under rocprofv3 --kernel-trace --stats, then --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs)"
-  echo "# note: under rocprofv3 the runtime may copy with blit kernels (__amd_rocclr_copyBuffer.kd in the list below) instead of the SDMA engines; in round 5 the download of the previous step's"
-  echo "#       samples then shared the CUs with k_dec_index and stretched it in the trace (1.4 ms by HIP events, 1.7-4.5 ms traced).  Round 6: the blit copies of this run add up to < 1 ms and"
-  echo "#       k_dec_index's traced average equals its HIP-event time, so the trace's total is the step.  The launch times of the bench line (config.kernel_ms_*) are HIP-event times of the plain run."
+  echo "# note: under rocprofv3 the runtime copies with blit kernels (__amd_rocclr_copyBuffer.kd in the list below) instead of the SDMA engines.  The download of the previous step's"
+  echo "#       samples (4.5 ms as a blit) then shares the CUs with whatever runs beside it and can stretch that kernel in the trace (k_dec_index: its minimum is its HIP-event time of the plain run)."
+  echo "#       The launch times of the bench line (config.kernel_ms_*) are HIP-event times of the plain run."
   echo "# bench line of the plain run:"; cat $OUT/bench_plain.json
   echo "# bench line under the kernel trace:"; cat $OUT/bench_traced.json
   python $ROOT/tools/rocprof_summary.py $T $F $W
