@@ -346,7 +346,8 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_count(const EntSegJob *seg_
 
 // k_ent_count over the block lists k_fwd_yuv422_strip_blocks leaves of the level-1 bands (cfhd_kernels.h FwdBlockLists) instead of the dense bands.  A segment's
 // 1024 raster coefficients are 128 blocks of 8: lane L takes blocks L and L + 64.  For each it works out the chunk the block lies in (band row, position in the
-// row), loads that chunk's occupancy mask, and -- when the block is listed -- the block itself from the slot its rank in the mask gives it.  All lanes do this at
+// row), loads that chunk's occupancy mask and works out the slot its rank in the mask gives a listed block; the listed blocks are then dealt to the lanes in raster
+// order (round 6: a pass of 64 lanes takes 64 *listed* blocks) and fetched.  All lanes do this at
 // once: two dependent memory round trips per segment (masks, blocks), whatever the number of chunks a segment touches (the first version walked the chunks one
 // after the other, five dependent rounds: 1.9 ms per 512 frames where the dense k_ent_count takes 1.6).  The nonzero coefficients then go to the token list in
 // raster order (lanes in block order: a scan of the lanes' counts, first half of the segment, then the second).  What the kernel reads are the listed blocks -- a
@@ -369,7 +370,8 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_count_blocks(const EntSegJo
 	const uint4 *blocks = wave_uniform_ptr(lists.blocks + (size_t)(job.coeffs - lists.coeff0) / 8);      // first block slot of the band (bands start on 128-byte boundaries)
 	const unsigned long long *masks = wave_uniform_ptr(lists.masks + (size_t)frame * lists.masks_per_frame + job.mask_base);
 	const int row0 = job.first / pitch, col0 = job.first - row0 * pitch;      // wave-uniform: where the segment starts
-	uint32_t w[2][4];
+	// 1. which of the segment's 128 blocks are listed, and where each lies: lane L looks at blocks L and L + 64 (two chunk masks per lane, the loads side by side)
+	uint32_t entry[2]; bool listed[2];
 #pragma unroll
 	for (int h = 0; h < 2; h++) {
 		const int q = lane + 64 * h, pos = job.first + 8 * q;
@@ -381,25 +383,35 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_count_blocks(const EntSegJo
 		const uint32_t c8 = (uint32_t)col >> 3, k = mul_u24(c8, 1058u) >> 16, i = c8 - mul_u24(k, 62u);
 		unsigned long long m = 0ull;
 		if (pos < end) m = masks[mul_u24((uint32_t)row, (uint32_t)cpr) + k];
-		w[h][0] = w[h][1] = w[h][2] = w[h][3] = 0u;
-		if ((m >> i) & 1ull) {
-			const uint32_t below = (uint32_t)__popcll(m & ((1ull << i) - 1ull));
-			const cfhd_u4 v = CFHD_LDG128(&blocks[mul_u24((uint32_t)row, (uint32_t)pitch >> 3) + mul_u24(k, 62u) + below]);
-			w[h][0] = v.x; w[h][1] = v.y; w[h][2] = v.z; w[h][3] = v.w;
-		}
+		listed[h] = ((m >> i) & 1ull) != 0ull;
+		// the slot of the block among the band's blocks (below 2^25: a band of 268 M coefficients) and its number in the segment, one word
+		entry[h] = ((mul_u24((uint32_t)row, (uint32_t)pitch >> 3) + mul_u24(k, 62u) + (uint32_t)__popcll(m & ((1ull << i) - 1ull))) << 7) | (uint32_t)q;
 	}
+	// 2. the listed blocks (a third of them on ordinary pictures), in raster order, dealt to the lanes: a listed block's rank among the listed ones (ballot + v_mbcnt) is the
+	//    lane that takes it.  Round 6: before, every lane fetched and compacted its two raster blocks whether listed or not -- two passes of count, scan and eight predicated
+	//    stores per segment where one does (the kernel runs at 89 % of the VALU issue rate).  The ranks travel through the head of the wave's token area.
+	const unsigned long long b0 = __ballot(listed[0]), b1 = __ballot(listed[1]);
+	const int n0 = __popcll(b0), nlisted = n0 + __popcll(b1);             // wave-uniform
+	if (listed[0]) s_tok[wave_mbcnt(b0)] = entry[0];
+	if (listed[1]) s_tok[n0 + (int)wave_mbcnt(b1)] = entry[1];
+	CFHD_WAVE_SYNC();
+	const uint32_t mine[2] = { lane < nlisted ? s_tok[lane] : 0u, lane + 64 < nlisted ? s_tok[lane + 64] : 0u };      // (both read before the first token is written over them)
+	CFHD_WAVE_SYNC();
 	int ntok = 0;                                        // wave-uniform
 #pragma unroll
 	for (int h = 0; h < 2; h++) {
+		if (64 * h >= nlisted) break;                    // wave-uniform: the second pass only for segments with more than 64 listed blocks
+		uint32_t w[4] = { 0u, 0u, 0u, 0u };
+		if (lane + 64 * h < nlisted) { const cfhd_u4 v = CFHD_LDG128(&blocks[mine[h] >> 7]); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
 		uint32_t cnt = 0;
 #pragma unroll
-		for (int d = 0; d < 4; d++) cnt += ((w[h][d] & 0xffffu) != 0u) + ((w[h][d] >> 16) != 0u);
+		for (int d = 0; d < 4; d++) cnt += ((w[d] & 0xffffu) != 0u) + ((w[d] >> 16) != 0u);
 		const uint32_t incl = wave_incl_scan(cnt);
 		uint32_t p = (uint32_t)ntok + incl - cnt;
-		const uint32_t local = (uint32_t)(8 * (lane + 64 * h));      // raster index of the block's first coefficient within the segment
+		const uint32_t local = 8u * (mine[h] & 127u);       // raster index of the block's first coefficient within the segment
 #pragma unroll
 		for (int d = 0; d < 4; d++) {
-			const uint32_t vl = w[h][d] & 0xffffu, vh = w[h][d] >> 16;
+			const uint32_t vl = w[d] & 0xffffu, vh = w[d] >> 16;
 			if (vl) s_tok[p++] = ((local + 2u * d) << 16) | vl;
 			if (vh) s_tok[p++] = ((local + 2u * d + 1u) << 16) | vh;
 		}

@@ -1646,14 +1646,14 @@ def test_packed16_strip_kernels_equal_reference(name, w, h, n, fmt, enc, mode):
             else: os.environ[k] = v
 
 
-def _batched_yuy2_round_trip_equals_reference(w, h, n, nuniq, expect=None):
+def _batched_yuy2_round_trip_equals_reference(w, h, n, nuniq, expect=None, frames_from=None):
     """n frames through cfhd_amd_batch_roundtrip: every sample against the reference encoder's bytes (one reference encoder, n consecutive
     CFHD_EncodeSample calls), every decoded frame inside the dither interval of the exact reconstruction of its sample.
     expect: {kernel slot: name} the library must report for this batch (cfhd_amd_batch_kernel_name)."""
     L = _batch_api()
     L.cfhd_amd_batch_kernel_name.restype = ctypes.c_char_p
     L.cfhd_amd_batch_kernel_name.argtypes = [ctypes.c_void_p, ctypes.c_int]
-    uniq, pitch = qbist_frames(10, nuniq, w, h)
+    uniq, pitch = frames_from(nuniq, w, h) if frames_from else qbist_frames(10, nuniq, w, h)
     frames = [uniq[i % nuniq] for i in range(n)]
     refs = ref_encode_frames(frames, pitch, w, h)               # one reference encoder, n consecutive CFHD_EncodeSample calls
     b = L.cfhd_amd_batch_create(w, h, PIX_YUY2, QUALITY_FILMSCAN1, n, 4)
@@ -1826,6 +1826,27 @@ def test_yuv422_strip_kernels_equal_reference(w, h, n):
         finally:
             del os.environ["CFHD_AMD_DEC_BLOCKS"]
         assert all(np.array_equal(a, b) for a, b in zip(lists, dense))
+    finally:
+        for k, v in old.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+
+
+def test_block_lists_of_dense_and_of_half_flat_frames():
+    """k_ent_count_blocks deals the *listed* blocks of a segment to its lanes, 64 to a pass: a noisy frame lists every block of the level-1 bands (two passes per segment),
+    a frame that is flat on the left and noisy on the right has segments with none, with a few and with all of their blocks listed, and chunks whose masks end in the
+    middle of a segment.  Both through the batched strip path (block lists from k_fwd_yuv422_strip_blocks to k_ent_count_blocks, from k_dec_tiles to
+    k_inv_yuv422_strip_blocks): samples equal the reference encoder's, pictures lie in the dither interval."""
+    def frames_from(nuniq, w, h):
+        rng = np.random.default_rng(3)
+        noisy = np.clip(128 + rng.integers(-24, 25, size=(h, w * 2)), 16, 235).astype(np.uint8)
+        half = np.full((h, w * 2), 128, np.uint8); half[:, w:] = np.clip(128 + rng.integers(-24, 25, size=(h, w)), 16, 235).astype(np.uint8)
+        return [noisy, half][:nuniq], w * 2
+    keys = ("CFHD_AMD_FORWARD", "CFHD_AMD_INVERSE", "CFHD_AMD_PLANES")
+    old = {k: os.environ.get(k) for k in keys}
+    for k in keys: os.environ[k] = "strip"
+    try:
+        _batched_yuy2_round_trip_equals_reference(1952, 64, 2, 2, expect={0: "k_fwd_yuv422_strip_blocks", 3: "k_inv_yuv422_strip_blocks"}, frames_from=frames_from)
     finally:
         for k, v in old.items():
             if v is None: os.environ.pop(k, None)

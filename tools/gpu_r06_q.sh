@@ -13,4 +13,4 @@ for d in (1, 4):
     except Exception as e:
         print("depth", d, "failed", e); print(open("gpurun_out/r06q/bench_d%d.err" % d).read()[-1500:])
 PY
-( time timeout 1500 python -m pytest tests -m gpu -q -x -p no:cacheprovider -k "yuy or YUY or 422 or strip or interlac or 1080 or dither or uyvy or gop or fwd or inv or quant or plane" ) > $O/tests.log 2>&1; tail -6 $O/tests.log
+( time timeout 1500 python -m pytest tests -m gpu -q -x -p no:cacheprovider -k "block or yuy or YUY or 422 or strip or interlac or 1080 or dither or uyvy or gop or fwd or inv or quant or plane" ) > $O/tests.log 2>&1; tail -6 $O/tests.log
