@@ -1760,7 +1760,7 @@ __device__ __forceinline__ void strip_plane_push(uint32_t (&LW)[6][4], uint32_t 
 	}
 }
 
-__global__ void __launch_bounds__(NTHREADS) k_fwd_plane_strip(const FwdPlaneJob *jobs, int nframes, int nch, int c0, int nc, int glog, int nstrips, int W, int H, int nseg)
+__global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) k_fwd_plane_strip(const FwdPlaneJob *jobs, int nframes, int nch, int c0, int nc, int glog, int nstrips, int W, int H, int nseg)
 {
 	const int lane = threadIdx.x & 63;
 	const int nblk = W / (2 * SBLK), HH = H >> 1;
