@@ -1760,7 +1760,9 @@ __device__ __forceinline__ void strip_plane_push(uint32_t (&LW)[6][4], uint32_t 
 	}
 }
 
-__global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) k_fwd_plane_strip(const FwdPlaneJob *jobs, int nframes, int nch, int c0, int nc, int glog, int nstrips, int W, int H, int nseg)
+// (Occupancy attributes measured in round 6, tools/gpu_r06_t.sh: amdgpu_waves_per_eu(4, 4) here 0.51 -> 0.58 ms, (6, 6) on k_inv_plane_strip 0.47 -> 0.62 ms, (5, 5) on
+// k_fwd_yuv422_strip_blocks 1.04 -> 1.06 ms -- the spills cost more than the waves bring; the kernels keep their natural register counts.)
+__global__ void __launch_bounds__(NTHREADS) k_fwd_plane_strip(const FwdPlaneJob *jobs, int nframes, int nch, int c0, int nc, int glog, int nstrips, int W, int H, int nseg)
 {
 	const int lane = threadIdx.x & 63;
 	const int nblk = W / (2 * SBLK), HH = H >> 1;
