@@ -1,6 +1,6 @@
 """Fills the tables of DESIGN.md (the blocks between <!--RESULTS_TABLE--> ... markers, the HOSTFED / CABI / CPU lines) from a bench line and the PMC traffic file:
-   python tools/fill_design_tables.py profiles/r06_s_default_bench_line.json profiles/pmc_traffic.json
-The VALU column is SQ_INSTS_VALU / (8 x SQ_BUSY_CYCLES) of profiles/r06_s_1080p_batch512_sq_counters.txt (tools/profile_sq.sh)."""
+   python tools/fill_design_tables.py profiles/r06_v_default_bench_line.json profiles/pmc_traffic.json
+The VALU column is SQ_INSTS_VALU / (8 x SQ_BUSY_CYCLES) of profiles/r06_u_1080p_batch512_sq_counters.txt (tools/profile_sq.sh)."""
 import json, sys
 bench = sys.argv[1]; pmcf = sys.argv[2]
 d = json.loads(open(bench).read().strip().splitlines()[-1]); c = d["config"]
@@ -8,15 +8,15 @@ k = c["kernel_ms_one_step_at_a_time"]; kr = c["kernel_ms_per_step"]
 pm = json.load(open(pmcf))["kernels"]
 S = 4147200; P = 4147200; sb = c["sample_bytes_per_frame"]; coded = (S - S // 64) * 2
 def name(prefix): return next(n for n in k if n.startswith(prefix))
-rows = [("k_fwd_yuv422_strip_blocks", "P + 2S = 12 441 600", P + 2 * S, "k_fwd_yuv422_strip_blocks", "86 %"),
+rows = [("k_fwd_yuv422_strip_blocks", "P + 2S = 12 441 600", P + 2 * S, "k_fwd_yuv422_strip_blocks", "85 %"),
         ("k_fwd_plane_strip[L2]", "S", S, None, ""), ("k_fwd_plane_strip[L3]", "S ÷ 4", S // 4, None, ""),
-        (name("k_ent_count_blocks"), "level-1 bands as block lists (3S ÷ 4 coefficients)", S * 3 // 4 * 2, "k_ent_count_blocks", "89 %"),
+        (name("k_ent_count_blocks"), "level-1 bands as block lists (3S ÷ 4 coefficients)", S * 3 // 4 * 2, "k_ent_count_blocks", "80 %"),
         ("k_ent_count", "coded bands of levels 2, 3", coded - S * 3 // 4 * 2, "k_ent_count", "75 %"),
-        ("k_ent_emit", "token strings + sample", coded // 2 + sb, "k_ent_emit", "31 % (69 % of wave cycles wait)"),
-        ("k_dec_index", "sample", sb, "k_dec_index", "58 % (70 % of wave cycles wait: LDS lookups)"),
-        ("k_dec_tiles", "sample + coded bands", sb + coded, "k_dec_tiles", "55 % (63 % of wave cycles wait: latency)"),
+        ("k_ent_emit", "token strings + sample", coded // 2 + sb, "k_ent_emit", "31 % (70 % of wave cycles wait)"),
+        ("k_dec_index", "sample", sb, "k_dec_index", "59 % (71 % of wave cycles wait: LDS lookups)"),
+        ("k_dec_tiles", "sample + coded bands", sb + coded, "k_dec_tiles", "54 % (63 % of wave cycles wait: latency)"),
         ("k_inv_plane_strip[L3]", "S ÷ 4", S // 4, None, ""), ("k_inv_plane_strip[L2]", "S", S, None, ""),
-        ("k_inv_yuv422_strip_blocks", "2S + P = 12 441 600", 2 * S + P, "k_inv_yuv422_strip_blocks", "89 %")]
+        ("k_inv_yuv422_strip_blocks", "2S + P = 12 441 600", 2 * S + P, "k_inv_yuv422_strip_blocks", "85 %")]
 out = ["| kernel | algorithmic bytes / frame | ms per 512 frames (one step at a time; as run with four in flight) | GB/s | % of 8 TB/s | PMC traffic / algorithmic | VALU issue |", "|---|---|---|---|---|---|---|"]
 for n, what, b, pk, valu in rows:
     ms = k[n]; gbs = b * 512 / (ms * 1e-3) / 1e9
