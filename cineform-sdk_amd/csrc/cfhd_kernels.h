@@ -1364,6 +1364,8 @@ __device__ __forceinline__ void inv_yuv422_strip(const InvYuvJob *jobs, uint32_t
 #undef LOAD_HL
 #undef LOAD_HH
 }
+// (Round 6, measured and not kept: the band rows three to a round with the window's registers renamed instead of moved, as in k_fwd_yuv422_strip -- 85 registers = five waves per SIMD:
+// 1.07 -> 1.18 ms; held to 80 registers with amdgpu_waves_per_eu(6, 6): 1.07 ms, no gain for a loop body written as a macro.  tools/gpu_r06_t.sh.)
 __global__ void __launch_bounds__(NTHREADS) k_inv_yuv422_strip(const InvYuvJob *jobs, uint32_t launch_seed) { inv_yuv422_strip<SR, true>(jobs, launch_seed); }
 __global__ void __launch_bounds__(NTHREADS) k_inv_yuv422_strip_blocks(const InvYuvJob *jobs, uint32_t launch_seed) { inv_yuv422_strip<SR, true, true>(jobs, launch_seed); }
 
