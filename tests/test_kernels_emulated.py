@@ -1036,6 +1036,14 @@ def test_inv_frame_yuv422(w, h, dh, uyvy):
     q = np.full((2 * h, 4 * w + 16), 7, np.uint8)
     assert emu().emu_inv_frame_yuv422_quad(ptrs, iarr(pitches), w, h, dh, uyvy, 2, 1234, p8(q), 4 * w + 16) == 0
     assert np.array_equal(q, e)
+    # the register-strip kernel (what large launches take; luma band widths that are multiples of 16): the same picture too -- same arithmetic, and since round 6 the same
+    # dither bit for every sample (dither422_block / dither422_column)
+    E = emu()
+    E.emu_inv_frame_yuv422_strip.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_uint, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    st = np.full((2 * h, 4 * w + 16), 7, np.uint8)
+    rc = E.emu_inv_frame_yuv422_strip(ptrs, iarr(pitches), w, h, dh, uyvy, 2, 1234, p8(st), 4 * w + 16, None, None)
+    if w % 16 == 0:
+        assert rc == 0 and np.array_equal(st, e)
     e = e[:dh, :4 * w]
     assert np.all((e == outs[0]) | (e == outs[1]))
     assert np.any(e != outs[0]) and np.any(e != outs[1])
