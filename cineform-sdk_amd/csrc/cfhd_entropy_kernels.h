@@ -377,7 +377,7 @@ __global__ void __launch_bounds__(ENT_THREADS) k_ent_count_blocks(const EntSegJo
 		const int q = lane + 64 * h, pos = job.first + 8 * q;
 		int row = row0, col = col0 + 8 * q;
 		while (col >= pitch) { col -= pitch; row++; }       // (a segment covers one to three rows of the bands this kernel sees; any number works)
-		// chunk k of the row and block i of the chunk: block c8 of the row / 62 as a multiply and a shift (exact below 1092 blocks = rows of 8736 coefficients), and
+		// chunk k of the row and block i of the chunk: block c8 of the row / 62 as a multiply and a shift (exact below 1092 blocks = rows of 8736 coefficients; the widest level-1 row a FramePlan accepts has 8192: kMaxFrameDim), and
 		// every product on the full-rate 24-bit multiplier (the plain forms compile to v_mul_hi / v_mad_u64_u32 at a quarter of the rate: measured 6 % of this kernel)
 		static_assert(FWD_CHUNK_COLS_ENT == 62 * 8, "the division below is by 62 blocks");
 		const uint32_t c8 = (uint32_t)col >> 3, k = mul_u24(c8, 1058u) >> 16, i = c8 - mul_u24(k, 62u);
